@@ -1,0 +1,264 @@
+/*
+ * kb_engine.h — C ABI of the MI355X-native allocate/backfill engine for kube-batch.
+ *
+ * This is the drop-in boundary.  The Go side of kube-batch reaches the
+ * device through these entry points only (cgo -> C ABI -> HIP); nothing here exposes a
+ * torch / HIP / C++ type.  Every function returns 0 (KB_OK) or a negative KB_E_* code;
+ * no exception or abort crosses the boundary; all buffers are caller-allocated and no
+ * caller pointer is retained after a call returns (cgo pointer rules).
+ *
+ * What each entry point stands in for in the reference (paths relative to /root/reference):
+ *
+ *   kb_engine_create / kb_engine_destroy
+ *       framework.OpenSession's plugin construction from conf.Tier / conf.PluginOption
+ *       (pkg/scheduler/framework/framework.go:30-52, pkg/scheduler/conf/scheduler_conf.go:20-56)
+ *       and the action registry lookup (pkg/scheduler/framework/plugins.go:58-72).
+ *   kb_session_load
+ *       cache.Snapshot() -> Session{Jobs,Nodes,Queues} (pkg/scheduler/cache/cache.go:627-683,
+ *       pkg/scheduler/framework/session.go:63-115) plus every plugin's OnSessionOpen state:
+ *       drf totals/shares (plugins/drf/drf.go:60-83), proportion deserved water-fill
+ *       (plugins/proportion/proportion.go:58-154), gang JobValid filter (plugins/gang/gang.go:48-69).
+ *   kb_run_allocate
+ *       allocateAction.Execute (pkg/scheduler/actions/allocate/allocate.go:43-194) with
+ *       util.PredicateNodes / PrioritizeNodes / SelectBestNode
+ *       (pkg/scheduler/util/scheduler_helper.go:63-208) and Session.Allocate / Pipeline
+ *       (pkg/scheduler/framework/session.go:194-288).
+ *   kb_run_backfill
+ *       backfillAction.Execute (pkg/scheduler/actions/backfill/backfill.go:40-71).
+ *   kb_eval_matrix
+ *       the per-(task,node) predicate closure (allocate.go:73-87), the predicates plugin
+ *       (plugins/predicates/predicates.go:123-265) and the nodeorder scorers
+ *       (plugins/nodeorder/nodeorder.go:140-168 -> vendor/k8s.io/kubernetes/pkg/scheduler/
+ *       algorithm/priorities/{least_requested,most_requested,balanced_resource_allocation}.go)
+ *       evaluated for a contiguous range of task rows against the session's live node state.
+ *   kb_argmax_rows
+ *       util.SelectBestNode / findMaxScores (scheduler_helper.go:188-208) with the canonical
+ *       tie-break (first max in ascending node order), for a range of task rows.
+ *   kb_get_binds
+ *       the gang-gated dispatch of Session.Allocate (session.go:277-285 -> cache.Bind):
+ *       which Allocated tasks were handed to the Binder.
+ *   kb_get_shares
+ *       drf jobOpts[*].share / proportion queueOpts[*].share after the run
+ *       (drf.go:157-171, proportion.go:241-253).
+ *
+ * Canonical order: nodes ascending by name, queues ascending by QueueID,
+ * jobs ascending by JobID ("ns/name"), tasks grouped by job and ascending by pod UID inside
+ * a job.  All indices in this ABI are ranks in that order, so "UID string <" in the
+ * reference's fall-back comparators is "index <" here.
+ */
+#ifndef KB_ENGINE_H
+#define KB_ENGINE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define KB_ABI_VERSION 1u
+#define KB_MAX_RES 32u          /* resource dimensions: 0 = cpu (milli), 1 = memory (bytes), 2.. = scalar resources (milli) */
+#define KB_NONE 0xFFFFFFFFu
+
+/* ---- error codes ---------------------------------------------------------------- */
+#define KB_OK              0
+#define KB_E_INVALID      -1    /* bad argument / malformed snapshot */
+#define KB_E_UNSUPPORTED  -2    /* configuration outside the engine's exact envelope: caller falls back to the stock action */
+#define KB_E_DEVICE       -3    /* HIP runtime error (message via kb_last_error) */
+#define KB_E_NOMEM        -4
+#define KB_E_STATE        -5    /* call order violated (e.g. run before load) */
+#define KB_E_CAPACITY     -6    /* caller's output buffer too small; *n_out holds the required count */
+#define KB_E_INTERNAL     -7    /* internal consistency check failed; no decisions emitted */
+
+/* ---- task status (pkg/scheduler/api/types.go:27-61) ------------------------------ */
+enum {
+  KB_TASK_PENDING = 0, KB_TASK_ALLOCATED = 1, KB_TASK_PIPELINED = 2, KB_TASK_BINDING = 3,
+  KB_TASK_BOUND = 4, KB_TASK_RUNNING = 5, KB_TASK_RELEASING = 6, KB_TASK_SUCCEEDED = 7,
+  KB_TASK_FAILED = 8, KB_TASK_UNKNOWN = 9
+};
+
+/* ---- plugins (pkg/scheduler/plugins/factory.go:31-42) ---------------------------- */
+enum {
+  KB_PLUGIN_PRIORITY = 0, KB_PLUGIN_GANG = 1, KB_PLUGIN_CONFORMANCE = 2, KB_PLUGIN_DRF = 3,
+  KB_PLUGIN_PREDICATES = 4, KB_PLUGIN_PROPORTION = 5, KB_PLUGIN_NODEORDER = 6
+};
+
+/* conf.PluginOption.Enabled* (pkg/scheduler/conf/scheduler_conf.go:33-56) */
+#define KB_EN_JOB_ORDER     (1u << 0)
+#define KB_EN_JOB_READY     (1u << 1)
+#define KB_EN_JOB_PIPELINED (1u << 2)
+#define KB_EN_TASK_ORDER    (1u << 3)
+#define KB_EN_PREEMPTABLE   (1u << 4)
+#define KB_EN_RECLAIMABLE   (1u << 5)
+#define KB_EN_QUEUE_ORDER   (1u << 6)
+#define KB_EN_PREDICATE     (1u << 7)
+#define KB_EN_NODE_ORDER    (1u << 8)
+#define KB_EN_ALL           0x1FFu   /* plugins.ApplyPluginConfDefaults (plugins/defaults.go:22-52) */
+
+/* kb_plugin_option.args slots */
+#define KB_ARG_NODEORDER_LEAST    0  /* leastrequested.weight   default 1 (nodeorder.go:111-117) */
+#define KB_ARG_NODEORDER_MOST     1  /* mostrequested.weight    default 0 */
+#define KB_ARG_NODEORDER_NODEAFF  2  /* nodeaffinity.weight     default 1 */
+#define KB_ARG_NODEORDER_PODAFF   3  /* podaffinity.weight      default 1 */
+#define KB_ARG_NODEORDER_BALANCED 4  /* balancedresource.weight default 1 */
+#define KB_ARG_PRED_MEM_PRESSURE  0  /* predicate.MemoryPressureEnable (predicates.go:94-107) */
+#define KB_ARG_PRED_DISK_PRESSURE 1
+#define KB_ARG_PRED_PID_PRESSURE  2
+
+typedef struct kb_plugin_option {
+  uint32_t plugin;     /* KB_PLUGIN_* */
+  uint32_t enabled;    /* KB_EN_* bitmask */
+  int32_t  args[8];    /* plugin-specific, see KB_ARG_* ; unused slots 0 */
+  uint32_t args_set;   /* bit i set <=> args[i] was given in the YAML (otherwise the default applies) */
+} kb_plugin_option;
+
+#define KB_FLAG_SYNC_ROUNDS 1u  /* disable host/device overlap (debug) */
+
+typedef struct kb_config {
+  uint32_t version;                /* KB_ABI_VERSION */
+  uint32_t n_tiers;
+  const uint32_t *tier_begin;      /* [n_tiers+1] offsets into plugins[] */
+  const kb_plugin_option *plugins;
+  int32_t  device;                 /* HIP device ordinal */
+  uint32_t window;                 /* task rows per device round; 0 = engine default */
+  uint32_t topk;                   /* candidates kept per row by the segmented arg-max; 0 = default */
+  uint32_t flags;                  /* KB_FLAG_* */
+} kb_config;
+
+/*
+ * Session snapshot, structure-of-arrays, caller-owned and read-only.
+ * Matrix-shaped fields are dimension-major: x[d * n + i].
+ */
+typedef struct kb_snapshot {
+  uint32_t version;                /* KB_ABI_VERSION */
+  uint32_t n_res;                  /* R, 2..KB_MAX_RES */
+  uint32_t n_nodes, n_tasks, n_jobs, n_queues;
+  uint32_t n_task_classes, n_node_classes;
+
+  /* nodes: api.NodeInfo (pkg/scheduler/api/node_info.go:28-47) */
+  const double   *node_idle;          /* [R][N]  NodeInfo.Idle      */
+  const double   *node_releasing;     /* [R][N]  NodeInfo.Releasing */
+  const double   *node_allocatable;   /* [R][N]  NodeInfo.Allocatable (kube-batch float64 view) */
+  const uint32_t *node_scalar_mask;   /* [N] bit (d-2) set <=> scalar key d exists in Allocatable.ScalarResources */
+  const int64_t  *node_alloc_cpu;     /* [N] k8s nodeinfo.allocatableResource.MilliCPU (vendor/.../nodeinfo/node_info.go:625-628) */
+  const int64_t  *node_alloc_mem;     /* [N] ... .Memory */
+  const int64_t  *node_nz_cpu;        /* [N] nodeinfo.nonzeroRequest.MilliCPU over every pod in ni.Tasks (node_info.go:502-517) */
+  const int64_t  *node_nz_mem;        /* [N] ... .Memory */
+  const int32_t  *node_max_pods;      /* [N] Allocatable.MaxTaskNum (api/resource_info.go:81-82) */
+  const int32_t  *node_pod_cnt;       /* [N] len(ni.Tasks) */
+  const uint32_t *node_class;         /* [N] static-predicate class (labels/taints/conditions flattened by the caller) */
+
+  /* tasks: api.TaskInfo (pkg/scheduler/api/job_info.go:36-54) */
+  const double   *task_resreq;        /* [R][T] TaskInfo.Resreq     */
+  const double   *task_init_resreq;   /* [R][T] TaskInfo.InitResreq */
+  const uint32_t *task_scalar_mask;   /* [T] scalar keys present in Resreq.ScalarResources */
+  const int64_t  *task_nz_cpu;        /* [T] sum over containers of GetNonzeroRequests cpu (vendor/.../priorities/util/non_zero.go:48-61) */
+  const int64_t  *task_nz_mem;        /* [T] */
+  const uint32_t *task_job;           /* [T] job index */
+  const uint32_t *task_class;         /* [T] static-predicate class */
+  const int32_t  *task_priority;      /* [T] TaskInfo.Priority */
+  const int64_t  *task_creation;      /* [T] pod CreationTimestamp (seconds) */
+  const uint8_t  *task_status;        /* [T] KB_TASK_* */
+  const uint32_t *task_node;          /* [T] node index for placed tasks, KB_NONE otherwise */
+
+  /* jobs: api.JobInfo (job_info.go:127-154); tasks of job j are [job_task_begin[j], job_task_begin[j+1]) */
+  const uint32_t *job_task_begin;     /* [J+1] */
+  const uint32_t *job_queue;          /* [J] queue index */
+  const int32_t  *job_min_available;  /* [J] */
+  const int32_t  *job_priority;       /* [J] */
+  const int64_t  *job_creation;       /* [J] PodGroup CreationTimestamp (seconds) */
+
+  /* queues: api.QueueInfo (api/queue_info.go:74-93) */
+  const int32_t  *queue_weight;       /* [Q] */
+  const int64_t  *queue_creation;     /* [Q] */
+
+  /* static predicates p2..p7 folded to a class x class bit table:
+     bit (tc * n_node_classes + nc) of class_compat; NULL => every pair compatible */
+  const uint8_t  *class_compat;
+} kb_snapshot;
+
+/* one placement decision, in the order the reference loop would have made it */
+typedef struct kb_decision {
+  uint32_t task;
+  uint32_t node;
+  uint32_t kind;    /* 0 = ssn.Allocate, 1 = ssn.Pipeline */
+  uint32_t round;   /* device round that produced it (diagnostic) */
+} kb_decision;
+
+typedef struct kb_stats {
+  uint64_t evals;             /* (task,node) evaluations the reference algorithm performs for the work done so far: sum over popped tasks of N */
+  uint64_t tasks_popped;      /* tasks that went through PredicateNodes */
+  uint64_t decisions;         /* Allocate + Pipeline calls */
+  uint64_t binds;             /* tasks dispatched to the Binder */
+  uint64_t rounds;            /* device rounds (matrix -> arg-max -> commit) */
+  uint64_t spec_breaks;       /* rounds cut short because the speculated order diverged */
+  uint64_t row_fallbacks;     /* rows whose top-K candidates were all dirty (full-row rescan) */
+  uint64_t matrix_launches;   /* launches of the mask+score matrix kernel */
+  uint64_t matrix_evals;      /* (task,node) pairs those launches evaluated */
+  double   matrix_ms;         /* HIP-event time of those launches on the engine stream */
+  double   argmax_ms;         /* segmented arg-max kernel */
+  double   commit_ms;         /* sequential commit kernel */
+  double   reduce_ms;         /* gang ballot + share reduction kernel */
+  double   host_order_ms;     /* host time in the order machine (queue/job/task ordering) */
+  double   total_ms;          /* wall time of the run_* calls */
+} kb_stats;
+
+typedef struct kb_engine kb_engine;
+
+int  kb_engine_create(const kb_config *cfg, kb_engine **out);
+void kb_engine_destroy(kb_engine *e);
+const char *kb_last_error(const kb_engine *e);   /* valid until the next call on e; e == NULL -> creation error */
+
+int  kb_session_load(kb_engine *e, const kb_snapshot *snap);
+
+int  kb_run_allocate(kb_engine *e, kb_decision *out, uint64_t cap, uint64_t *n_out);
+int  kb_run_backfill(kb_engine *e, kb_decision *out, uint64_t cap, uint64_t *n_out);
+
+/* rows [t0,t1) of the task x node matrix against the session's current node state.
+   mask_bits: (t1-t0) rows of ceil(N/8) bytes, bit (n & 7) of byte n >> 3; score: (t1-t0) x N uint16.
+   fit_mode: 1 = allocate's predicate (resource fit + plugin predicates), 0 = plugin predicates only (backfill/preempt). */
+int  kb_eval_matrix(kb_engine *e, uint32_t t0, uint32_t t1, uint32_t fit_mode, uint8_t *mask_bits, uint16_t *score);
+
+/* per row of [t0,t1): the k best feasible nodes, descending score then ascending node index;
+   out_node[(t-t0)*k + i] = node index or KB_NONE, out_score likewise (0 where none). */
+int  kb_argmax_rows(kb_engine *e, uint32_t t0, uint32_t t1, uint32_t fit_mode, uint32_t k,
+                    uint32_t *out_node, uint16_t *out_score);
+
+/* device-resident timing of the matrix kernel for the roofline figure: reps launches over rows [t0,t1),
+   nothing copied back; *ms_avg = average launch duration measured with HIP events on the engine stream. */
+int  kb_bench_matrix(kb_engine *e, uint32_t t0, uint32_t t1, uint32_t fit_mode, uint32_t reps, double *ms_avg);
+
+/* task -> node for every task handed to the Binder so far (KB_NONE otherwise); out has n_tasks entries */
+int  kb_get_binds(kb_engine *e, uint32_t *task_node_out);
+/* current task status (KB_TASK_*) and node (or KB_NONE), n_tasks entries each; either pointer may be NULL */
+int  kb_get_task_state(kb_engine *e, uint8_t *status_out, uint32_t *node_out);
+/* live node state: idle/releasing [R][N], nz_cpu/nz_mem [N], pod_cnt [N]; any pointer may be NULL */
+int  kb_get_node_state(kb_engine *e, double *idle, double *releasing, int64_t *nz_cpu, int64_t *nz_mem, int32_t *pod_cnt);
+/* drf job shares [J], proportion queue shares [Q], proportion deserved [R][Q]; any pointer may be NULL */
+int  kb_get_shares(kb_engine *e, double *job_share, double *queue_share, double *queue_deserved);
+int  kb_get_stats(kb_engine *e, kb_stats *out);
+
+/* ---- round-granular entry points for task-row sharding across GPUs ----
+ * One process per GPU holds a full replica of the session.  Per round every rank:
+ *   kb_round_begin      -> the next speculated window of task rows (identical on every rank)
+ *   kb_round_candidates -> mask+score matrix and top-K arg-max for ITS shard of the window rows,
+ *                          written to a caller-provided DEVICE buffer [n_rows_shard][topk] of uint64 keys
+ *   (all-gather of the key buffers across ranks: RCCL, done by the caller)
+ *   kb_round_commit     -> the sequential commit over the full window using the gathered keys; fills the
+ *                          caller-provided DEVICE delta buffer (layout kb_round_delta_doubles) with the
+ *                          committed per-node deltas of the rows this rank owns
+ *   (all-reduce(sum) of the delta buffers: RCCL, done by the caller)
+ *   kb_round_apply      -> install the reduced deltas as the node state for the next round and verify
+ *                          they equal the replica's own commit (KB_E_INTERNAL on divergence)
+ */
+int  kb_round_begin(kb_engine *e, uint32_t action /*0 allocate,1 backfill*/, uint32_t *n_rows);
+int  kb_round_candidates(kb_engine *e, uint32_t row0, uint32_t row1, uint64_t dev_keys_ptr);
+int  kb_round_commit(kb_engine *e, uint64_t dev_all_keys_ptr, uint32_t own_row0, uint32_t own_row1, uint64_t dev_delta_ptr);
+int  kb_round_apply(kb_engine *e, uint64_t dev_delta_ptr, uint32_t *done /*1 when the action finished*/);
+int  kb_round_topk(const kb_engine *e, uint32_t *topk);
+int  kb_round_delta_doubles(const kb_engine *e, uint64_t *n_doubles);   /* N * (2R + 3) float64 per buffer */
+int  kb_round_decisions(kb_engine *e, kb_decision *out, uint64_t cap, uint64_t *n_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KB_ENGINE_H */

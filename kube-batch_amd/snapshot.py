@@ -1,0 +1,608 @@
+"""Session snapshot in structure-of-arrays form, the flattener that produces it from
+Kubernetes-shaped objects, and the deterministic synthetic cluster generator.
+
+The flattener mirrors what the Go shim does inside `Execute(ssn)`:
+  * cache.AddNode/AddPod/AddPodGroup/AddQueue + Snapshot()  (pkg/scheduler/cache/event_handlers.go,
+    cache.go:627-683) -> api.NodeInfo / JobInfo / TaskInfo / QueueInfo
+  * api.NewResource (pkg/scheduler/api/resource_info.go:73-90): cpu & scalars in milli units, memory bytes
+  * api.NewTaskInfo / GetPodResourceRequest (api/job_info.go:69-93, api/pod_info.go:53-73)
+  * k8s nodeinfo non-zero requests (vendor/k8s.io/kubernetes/pkg/scheduler/algorithm/priorities/util/non_zero.go:32-61)
+  * static predicates p2..p7 folded into a task-class x node-class bit table
+and emits everything in the canonical order of SURVEY.md §8c.
+"""
+import ctypes as C
+import math
+from dataclasses import dataclass, field
+from fractions import Fraction
+from typing import Dict, List, Optional, Tuple
+
+import numpy as np
+
+from . import abi
+
+# ------------------------------------------------------------------------------------------------
+# resource.Quantity (vendor/k8s.io/apimachinery/pkg/api/resource/quantity.go)
+# ------------------------------------------------------------------------------------------------
+_SUFFIX = {"n": Fraction(1, 10**9), "u": Fraction(1, 10**6), "m": Fraction(1, 1000), "": Fraction(1),
+           "k": Fraction(10**3), "M": Fraction(10**6), "G": Fraction(10**9), "T": Fraction(10**12),
+           "P": Fraction(10**15), "E": Fraction(10**18),
+           "Ki": Fraction(2**10), "Mi": Fraction(2**20), "Gi": Fraction(2**30), "Ti": Fraction(2**40),
+           "Pi": Fraction(2**50), "Ei": Fraction(2**60)}
+
+
+def parse_quantity(q) -> Fraction:
+    if isinstance(q, (int, Fraction)):
+        return Fraction(q)
+    s = str(q).strip()
+    for suf in sorted(_SUFFIX, key=len, reverse=True):
+        if suf and s.endswith(suf):
+            return Fraction(s[: -len(suf)]) * _SUFFIX[suf]
+    if "e" in s or "E" in s:
+        mant, exp = s.replace("E", "e").split("e")
+        return Fraction(mant) * Fraction(10) ** int(exp)
+    return Fraction(s)
+
+
+def quantity_value(q) -> int:
+    """Quantity.Value(): rounds up (quantity.go:689-696)."""
+    return math.ceil(parse_quantity(q))
+
+
+def quantity_milli_value(q) -> int:
+    """Quantity.MilliValue(): rounds up (quantity.go:699-711)."""
+    return math.ceil(parse_quantity(q) * 1000)
+
+
+def is_scalar_resource_name(name: str) -> bool:
+    """v1helper.IsScalarResourceName (vendor/k8s.io/kubernetes/pkg/apis/core/v1/helper/helpers.go:38-103)."""
+    native = ("/" not in name) or ("kubernetes.io/" in name)
+    extended = (not native) and (not name.startswith("requests."))
+    return (extended or name.startswith("hugepages-") or ("kubernetes.io/" in name)
+            or name.startswith("attachable-volumes-"))
+
+
+DEFAULT_MILLI_CPU_REQUEST = 100                 # non_zero.go:32-37
+DEFAULT_MEMORY_REQUEST = 200 * 1024 * 1024
+
+
+# ------------------------------------------------------------------------------------------------
+# Kubernetes-shaped input objects (only the fields the hot path reads)
+# ------------------------------------------------------------------------------------------------
+@dataclass
+class Node:
+    name: str
+    allocatable: Dict[str, str]
+    labels: Dict[str, str] = field(default_factory=dict)
+    taints: List[Tuple[str, str, str]] = field(default_factory=list)   # (key, value, effect)
+    unschedulable: bool = False
+    ready: bool = True                    # every NodeReady condition True (predicates.go:1675-1700)
+    network_unavailable: bool = False
+
+
+@dataclass
+class Pod:
+    namespace: str
+    name: str
+    containers: List[Dict[str, str]]                       # one requests dict per container
+    group_name: str = ""
+    node_name: str = ""
+    phase: str = "Pending"
+    uid: Optional[str] = None
+    init_containers: List[Dict[str, str]] = field(default_factory=list)
+    priority: Optional[int] = None
+    creation: int = 0
+    deleting: bool = False                                  # DeletionTimestamp != nil
+    node_selector: Dict[str, str] = field(default_factory=dict)
+    tolerations: List[Tuple[str, str, str, str]] = field(default_factory=list)  # (key, operator, value, effect)
+
+
+@dataclass
+class PodGroup:
+    namespace: str
+    name: str
+    min_member: int = 0
+    queue: str = "default"
+    creation: int = 0
+    priority: int = 0          # resolved PriorityClass value (cache.go:661-668)
+
+
+@dataclass
+class Queue:
+    name: str
+    weight: int = 1
+    creation: int = 0
+
+
+def _task_status(p: Pod) -> int:
+    """getTaskStatus (pkg/scheduler/api/helpers.go:35-61)."""
+    if p.phase == "Running":
+        return abi.TASK_RELEASING if p.deleting else abi.TASK_RUNNING
+    if p.phase == "Pending":
+        if p.deleting:
+            return abi.TASK_RELEASING
+        return abi.TASK_PENDING if not p.node_name else abi.TASK_BOUND
+    if p.phase == "Succeeded":
+        return abi.TASK_SUCCEEDED
+    if p.phase == "Failed":
+        return abi.TASK_FAILED
+    return abi.TASK_UNKNOWN
+
+
+def _tolerates(tolerations, taint) -> bool:
+    """v1.Toleration.ToleratesTaint (vendor/k8s.io/api/core/v1/toleration.go:37-56)."""
+    tk, tv, te = taint
+    for key, op, val, eff in tolerations:
+        if eff and eff != te:
+            continue
+        if key and key != tk:
+            continue
+        op = op or "Equal"
+        if op == "Exists":
+            return True
+        if op == "Equal" and val == tv:
+            return True
+    return False
+
+
+def _static_ok(pod_cls, node_cls) -> bool:
+    """p2 CheckNodeCondition, p3 CheckNodeUnschedulable, p4 PodMatchNodeSelector (nodeSelector part),
+    p6 PodToleratesNodeTaints — vendor/.../algorithm/predicates/predicates.go:1675-1700,1576-1593,927-983,1596-1620."""
+    selector, tolerations = pod_cls
+    labels, taints, unsched, ready, netun = node_cls
+    if (not ready) or netun or unsched:
+        return False
+    labels = dict(labels)
+    for k, v in selector:
+        if labels.get(k) != v:
+            return False
+    for t in taints:
+        if t[2] in ("NoSchedule", "NoExecute") and not _tolerates(tolerations, t):
+            return False
+    return True
+
+
+# ------------------------------------------------------------------------------------------------
+# the SoA snapshot
+# ------------------------------------------------------------------------------------------------
+_DTYPES = {C.c_double: np.float64, C.c_uint32: np.uint32, C.c_int64: np.int64, C.c_int32: np.int32, C.c_uint8: np.uint8}
+
+
+class SessionSnapshot:
+    """Numpy-backed kb_snapshot.  Field names equal the C struct's."""
+
+    def __init__(self, **kw):
+        self.names: Dict[str, List[str]] = kw.pop("names", {})
+        for k, v in kw.items():
+            setattr(self, k, v)
+        self._check()
+
+    @property
+    def R(self):
+        return int(self.n_res)
+
+    def _check(self):
+        R, N, T, J, Q = self.n_res, self.n_nodes, self.n_tasks, self.n_jobs, self.n_queues
+        shapes = {"node_idle": (R, N), "node_releasing": (R, N), "node_allocatable": (R, N),
+                  "task_resreq": (R, T), "task_init_resreq": (R, T), "job_task_begin": (J + 1,)}
+        for name, ctype in abi.SNAPSHOT_ARRAYS:
+            a = getattr(self, name, None)
+            if a is None:
+                if name == "class_compat":
+                    continue
+                raise ValueError(f"snapshot field {name} missing")
+            a = np.ascontiguousarray(a, dtype=_DTYPES[ctype])
+            if name in shapes and a.shape != shapes[name]:
+                raise ValueError(f"{name}: shape {a.shape} != {shapes[name]}")
+            setattr(self, name, a)
+        for name in ("node_scalar_mask", "node_alloc_cpu", "node_alloc_mem", "node_nz_cpu", "node_nz_mem",
+                     "node_max_pods", "node_pod_cnt", "node_class"):
+            assert getattr(self, name).shape == (N,), name
+        for name in ("task_scalar_mask", "task_nz_cpu", "task_nz_mem", "task_job", "task_class", "task_priority",
+                     "task_creation", "task_status", "task_node"):
+            assert getattr(self, name).shape == (T,), name
+        for name in ("job_queue", "job_min_available", "job_priority", "job_creation"):
+            assert getattr(self, name).shape == (J,), name
+        for name in ("queue_weight", "queue_creation"):
+            assert getattr(self, name).shape == (Q,), name
+
+    def to_abi(self) -> abi.Snapshot:
+        s = abi.Snapshot()
+        s.version = abi.KB_ABI_VERSION
+        for k in ("n_res", "n_nodes", "n_tasks", "n_jobs", "n_queues", "n_task_classes", "n_node_classes"):
+            setattr(s, k, int(getattr(self, k)))
+        for name, ctype in abi.SNAPSHOT_ARRAYS:
+            a = getattr(self, name, None)
+            if a is None:
+                setattr(s, name, C.POINTER(ctype)())
+            else:
+                setattr(s, name, a.ctypes.data_as(C.POINTER(ctype)))
+        return s
+
+    def task_name(self, t: int) -> str:
+        n = self.names.get("tasks")
+        return n[t] if n else f"t{t}"
+
+    def node_name(self, n: int) -> str:
+        nn = self.names.get("nodes")
+        return nn[n] if nn else f"n{n:06d}"
+
+    def bind_map(self, task_node: np.ndarray) -> Dict[str, str]:
+        """{pod ns/name: node} — the object actions/allocate/allocate_test.go:208 compares."""
+        return {self.task_name(int(t)): self.node_name(int(task_node[t])) for t in np.nonzero(task_node != abi.KB_NONE)[0]}
+
+
+def _resource(rl: Dict[str, str], dims: Dict[str, int], R: int):
+    """api.NewResource (resource_info.go:73-90): returns (vector[R], scalar key mask, MaxTaskNum)."""
+    v = np.zeros(R, dtype=np.float64)
+    mask = 0
+    max_tasks = 0
+    for name, q in rl.items():
+        if name == "cpu":
+            v[0] += float(quantity_milli_value(q))
+        elif name == "memory":
+            v[1] += float(quantity_value(q))
+        elif name == "pods":
+            max_tasks += quantity_value(q)
+        elif is_scalar_resource_name(name):
+            d = dims[name]
+            v[d] += float(quantity_milli_value(q))
+            mask |= 1 << (d - 2)
+    return v, mask, max_tasks
+
+
+def flatten(nodes: List[Node], pods: List[Pod], pod_groups: List[PodGroup], queues: List[Queue],
+            default_queue: str = "default") -> SessionSnapshot:
+    """Kubernetes-shaped objects -> canonical SoA snapshot (what cache.Snapshot() + the Go shim's flatten produce)."""
+    scalar_names = set()
+    for n in nodes:
+        scalar_names.update(k for k in n.allocatable if is_scalar_resource_name(k))
+    for p in pods:
+        for c in list(p.containers) + list(p.init_containers):
+            scalar_names.update(k for k in c if is_scalar_resource_name(k))
+    dims = {name: 2 + i for i, name in enumerate(sorted(scalar_names))}
+    R = 2 + len(dims)
+    if R > abi.KB_MAX_RES:
+        raise ValueError("too many scalar resources")
+
+    nodes = sorted(nodes, key=lambda n: n.name)
+    queues = sorted(queues, key=lambda q: q.name)
+    qidx = {q.name: i for i, q in enumerate(queues)}
+    nidx = {n.name: i for i, n in enumerate(nodes)}
+    N, Q = len(nodes), len(queues)
+
+    # jobs: PodGroup job id "<ns>/<name>" (cache/event_handlers.go:367-369); pods join by the
+    # scheduling.k8s.io/group-name annotation (api/job_info.go:56-66); jobs without a PodGroup or whose
+    # queue does not exist are skipped by Snapshot (cache.go:645-657)
+    pgs = {}
+    for pg in pod_groups:
+        qname = pg.queue or default_queue
+        if qname not in qidx:
+            continue
+        pgs[f"{pg.namespace}/{pg.name}"] = pg
+    job_ids = sorted(pgs)
+    jidx = {j: i for i, j in enumerate(job_ids)}
+    J = len(job_ids)
+
+    job_tasks: List[List[Pod]] = [[] for _ in range(J)]
+    other_pods: List[Pod] = []
+    for p in pods:
+        if p.uid is None:
+            p.uid = f"{p.namespace}-{p.name}"          # util.BuildPod (pkg/scheduler/util/test_utils.go:66-69)
+        jid = f"{p.namespace}/{p.group_name}" if p.group_name else ""
+        if jid in jidx:
+            job_tasks[jidx[jid]].append(p)
+        else:
+            other_pods.append(p)
+    for lst in job_tasks:
+        lst.sort(key=lambda p: p.uid)
+
+    T = sum(len(l) for l in job_tasks)
+    node_idle = np.zeros((R, N)); node_rel = np.zeros((R, N)); node_alloc = np.zeros((R, N))
+    node_mask = np.zeros(N, np.uint32); node_maxp = np.zeros(N, np.int32); node_cnt = np.zeros(N, np.int32)
+    node_acpu = np.zeros(N, np.int64); node_amem = np.zeros(N, np.int64)
+    node_nzc = np.zeros(N, np.int64); node_nzm = np.zeros(N, np.int64)
+    node_cls_keys = []
+    for i, n in enumerate(nodes):
+        v, m, mt = _resource(n.allocatable, dims, R)
+        node_alloc[:, i] = v; node_idle[:, i] = v; node_mask[i] = m; node_maxp[i] = mt
+        node_acpu[i] = quantity_milli_value(n.allocatable.get("cpu", 0))
+        node_amem[i] = quantity_value(n.allocatable.get("memory", 0))
+        node_cls_keys.append((tuple(sorted(n.labels.items())), tuple(n.taints), n.unschedulable, n.ready, n.network_unavailable))
+
+    def pod_vectors(p: Pod):
+        res = np.zeros(R); mask = 0
+        nzc = nzm = 0
+        for c in p.containers:                           # GetPodResourceWithoutInitContainers (pod_info.go:66-73)
+            v, m, _ = _resource(c, dims, R)
+            res += v; mask |= m
+            nzc += quantity_milli_value(c["cpu"]) if "cpu" in c else DEFAULT_MILLI_CPU_REQUEST
+            nzm += quantity_value(c["memory"]) if "memory" in c else DEFAULT_MEMORY_REQUEST
+        init = res.copy()
+        for c in p.init_containers:                      # GetPodResourceRequest: SetMaxResource per init container
+            v, m, _ = _resource(c, dims, R)
+            init = np.maximum(init, v)
+        return res, init, mask, nzc, nzm
+
+    eps = np.array([10.0, 10.0 * 1024 * 1024] + [10.0] * (R - 2))
+
+    def less_equal(l, r):
+        """Resource.LessEqual on dense vectors (resource_info.go:268-302; an absent key reads 0, scalars <= 10 skipped)."""
+        ok = (l < r) | (np.abs(l - r) < eps)
+        ok[2:] |= l[2:] <= 10.0
+        return bool(ok.all())
+
+    def account_on_node(ni, st, res, nzc, nzm):
+        """NodeInfo.AddTask (api/node_info.go:172-212) + k8s nodeinfo.AddPod for a pod already on a node.
+        Returns False where AddTask errors ("Selected node NotReady": the pod does not enter ni.Tasks)."""
+        if st == abi.TASK_PIPELINED:
+            node_rel[:, ni] -= res
+        else:
+            if not less_equal(res, node_idle[:, ni]):
+                return False
+            node_idle[:, ni] -= res
+            if st == abi.TASK_RELEASING:
+                node_rel[:, ni] += res
+        node_cnt[ni] += 1
+        node_nzc[ni] += nzc; node_nzm[ni] += nzm
+        return True
+
+    for p in other_pods:                                 # pods of other schedulers / jobs outside the session
+        if p.node_name in nidx:
+            res, _, _, nzc, nzm = pod_vectors(p)
+            account_on_node(nidx[p.node_name], _task_status(p), res, nzc, nzm)
+
+    t_res = np.zeros((R, T)); t_init = np.zeros((R, T)); t_mask = np.zeros(T, np.uint32)
+    t_nzc = np.zeros(T, np.int64); t_nzm = np.zeros(T, np.int64); t_job = np.zeros(T, np.uint32)
+    t_prio = np.zeros(T, np.int32); t_cre = np.zeros(T, np.int64); t_st = np.zeros(T, np.uint8)
+    t_node = np.full(T, abi.KB_NONE, np.uint32)
+    task_cls_keys = []
+    names_tasks = []
+    begin = np.zeros(J + 1, np.uint32)
+    k = 0
+    for j, lst in enumerate(job_tasks):
+        begin[j] = k
+        for p in lst:
+            res, init, mask, nzc, nzm = pod_vectors(p)
+            st = _task_status(p)
+            t_res[:, k] = res; t_init[:, k] = init; t_mask[k] = mask
+            t_nzc[k] = nzc; t_nzm[k] = nzm; t_job[k] = j
+            t_prio[k] = 1 if p.priority is None else p.priority      # NewTaskInfo default (job_info.go:82)
+            t_cre[k] = p.creation; t_st[k] = st
+            if p.node_name in nidx:
+                if account_on_node(nidx[p.node_name], st, res, nzc, nzm):
+                    t_node[k] = nidx[p.node_name]
+            task_cls_keys.append((tuple(sorted(p.node_selector.items())), tuple(p.tolerations)))
+            names_tasks.append(f"{p.namespace}/{p.name}")
+            k += 1
+    begin[J] = k
+
+    ucls_t = sorted(set(task_cls_keys)) or [((), ())]
+    ucls_n = sorted(set(node_cls_keys)) or [((), (), False, True, False)]
+    tmap = {c: i for i, c in enumerate(ucls_t)}
+    nmap = {c: i for i, c in enumerate(ucls_n)}
+    compat = np.zeros((len(ucls_t) * len(ucls_n) + 7) // 8, np.uint8)
+    for ti, tc in enumerate(ucls_t):
+        for ni, nc in enumerate(ucls_n):
+            if _static_ok(tc, nc):
+                b = ti * len(ucls_n) + ni
+                compat[b >> 3] |= 1 << (b & 7)
+
+    return SessionSnapshot(
+        n_res=R, n_nodes=N, n_tasks=T, n_jobs=J, n_queues=Q,
+        n_task_classes=len(ucls_t), n_node_classes=len(ucls_n),
+        node_idle=node_idle, node_releasing=node_rel, node_allocatable=node_alloc, node_scalar_mask=node_mask,
+        node_alloc_cpu=node_acpu, node_alloc_mem=node_amem, node_nz_cpu=node_nzc, node_nz_mem=node_nzm,
+        node_max_pods=node_maxp, node_pod_cnt=node_cnt,
+        node_class=np.array([nmap[c] for c in node_cls_keys], np.uint32).reshape(N),
+        task_resreq=t_res, task_init_resreq=t_init, task_scalar_mask=t_mask, task_nz_cpu=t_nzc, task_nz_mem=t_nzm,
+        task_job=t_job, task_class=np.array([tmap[c] for c in task_cls_keys], np.uint32).reshape(T),
+        task_priority=t_prio, task_creation=t_cre, task_status=t_st, task_node=t_node,
+        job_task_begin=begin,
+        job_queue=np.array([qidx[pgs[j].queue or default_queue] for j in job_ids], np.uint32).reshape(J),
+        job_min_available=np.array([pgs[j].min_member for j in job_ids], np.int32).reshape(J),
+        job_priority=np.array([pgs[j].priority for j in job_ids], np.int32).reshape(J),
+        job_creation=np.array([pgs[j].creation for j in job_ids], np.int64).reshape(J),
+        queue_weight=np.array([q.weight for q in queues], np.int32).reshape(Q),
+        queue_creation=np.array([q.creation for q in queues], np.int64).reshape(Q),
+        class_compat=compat,
+        names={"nodes": [n.name for n in nodes], "tasks": names_tasks, "jobs": job_ids,
+               "queues": [q.name for q in queues], "dims": ["cpu", "memory"] + sorted(scalar_names)},
+    )
+
+
+# ------------------------------------------------------------------------------------------------
+# deterministic synthetic clusters: counter-based splitmix64, no global RNG state
+# ------------------------------------------------------------------------------------------------
+SEED_BASE = 0x6B756265
+
+
+def _mix(x: np.ndarray) -> np.ndarray:
+    x = x.astype(np.uint64)
+    with np.errstate(over="ignore"):
+        x = (x + np.uint64(0x9E3779B97F4A7C15))
+        x = (x ^ (x >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        x = (x ^ (x >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        x = x ^ (x >> np.uint64(31))
+    return x
+
+
+class _Stream:
+    """u[i] = splitmix64(seed, stream, i): reproducible on any machine, order-independent."""
+
+    def __init__(self, seed: int, stream: int):
+        self.key = _mix(np.array([seed ^ (stream * 0xD1342543DE82EF95 & 0xFFFFFFFFFFFFFFFF)], np.uint64))[0]
+
+    def u64(self, n: int) -> np.ndarray:
+        with np.errstate(over="ignore"):
+            return _mix(np.arange(n, dtype=np.uint64) * np.uint64(0x9E3779B97F4A7C15) + self.key)
+
+    def randint(self, n: int, hi: int) -> np.ndarray:
+        return (self.u64(n) % np.uint64(hi)).astype(np.int64)
+
+    def uniform(self, n: int) -> np.ndarray:
+        return (self.u64(n) >> np.uint64(11)).astype(np.float64) / float(1 << 53)
+
+    def choice(self, n: int, values, probs=None) -> np.ndarray:
+        values = np.asarray(values)
+        if probs is None:
+            return values[self.randint(n, len(values))]
+        cdf = np.cumsum(np.asarray(probs, np.float64))
+        cdf /= cdf[-1]
+        return values[np.searchsorted(cdf, self.uniform(n), side="right").clip(0, len(values) - 1)]
+
+
+@dataclass
+class SynthParams:
+    n_tasks: int
+    n_nodes: int
+    n_queues: int = 1
+    n_res: int = 2
+    seed: int = SEED_BASE
+    gang_sizes: Tuple[int, ...] = (1, 2, 4, 8, 16, 32, 64)
+    gang_probs: Tuple[float, ...] = (0.15, 0.20, 0.20, 0.20, 0.13, 0.08, 0.04)   # mean ~10 tasks per job
+    node_cpu_cores: Tuple[int, ...] = (4, 8, 16, 24, 32)          # sized so total demand ~1.3x capacity
+    node_mem_gib: Tuple[int, ...] = (16, 32, 64, 128)
+    task_cpu_milli: Tuple[int, ...] = (100, 250, 500, 1000, 2000, 4000, 8000)
+    task_mem_mib: Tuple[int, ...] = (128, 256, 512, 1024, 2048, 4096, 8192, 16384, 32768)
+    preload_node_frac: float = 0.10      # nodes carrying 1-8 pods of jobs outside the session
+    running_job_frac: float = 0.05       # session jobs with some tasks already Running
+    best_effort_frac: float = 0.02
+    no_mem_key_frac: float = 0.05
+    scalar_job_frac: float = 0.30        # C4: jobs requesting 1-2 extended resources
+    n_zones: int = 8
+    zone_selector_frac: float = 0.10     # jobs pinned to one zone by nodeSelector (static predicate classes)
+
+
+def synth_config(idx: int, scale: float = 1.0) -> SynthParams:
+    """The BASELINE.json configurations 2..5 (1 is the example/job.yaml fixture)."""
+    def sc(x):
+        return max(1, int(round(x * scale)))
+    if idx == 2:
+        return SynthParams(n_tasks=sc(10_000), n_nodes=sc(1_000), n_queues=1, n_res=2, seed=SEED_BASE + 2)
+    if idx == 3:
+        return SynthParams(n_tasks=sc(100_000), n_nodes=sc(10_000), n_queues=128, n_res=2, seed=SEED_BASE + 3)
+    if idx == 4:
+        return SynthParams(n_tasks=sc(100_000), n_nodes=sc(10_000), n_queues=128, n_res=16, seed=SEED_BASE + 4)
+    if idx == 5:
+        return SynthParams(n_tasks=sc(1_000_000), n_nodes=sc(50_000), n_queues=128, n_res=2,
+                           seed=SEED_BASE + 5, preload_node_frac=0.6)
+    raise ValueError("config index must be 2..5")
+
+
+def synth(p: SynthParams) -> SessionSnapshot:
+    R, N, Q = p.n_res, p.n_nodes, p.n_queues
+    S = lambda k: _Stream(p.seed, k)
+
+    # ---- nodes
+    cpu_m = S(1).choice(N, np.array(p.node_cpu_cores, np.int64)) * 1000
+    mem_b = S(2).choice(N, np.array(p.node_mem_gib, np.int64)) * (1 << 30)
+    node_alloc = np.zeros((R, N)); node_alloc[0] = cpu_m; node_alloc[1] = mem_b
+    node_mask = np.zeros(N, np.uint32)
+    if R > 2:
+        for d in range(2, R):
+            units = S(100 + d).choice(N, np.array([0, 1, 2, 4, 8], np.int64))
+            has = S(200 + d).uniform(N) < 0.6          # the node advertises the extended resource at all
+            node_alloc[d] = np.where(has, units * 1000, 0)
+            node_mask |= (has.astype(np.uint32) << np.uint32(d - 2))
+    node_zone = S(3).randint(N, p.n_zones).astype(np.uint32)
+    node_idle = node_alloc.copy()
+    node_rel = np.zeros((R, N))
+    node_nzc = np.zeros(N, np.int64); node_nzm = np.zeros(N, np.int64); node_cnt = np.zeros(N, np.int32)
+
+    # pods of other tenants already on some nodes (only node aggregates see them)
+    pre = S(4).uniform(N) < p.preload_node_frac
+    npods = np.where(pre, 1 + S(5).randint(N, 8), 0)
+    for k in range(8):
+        on = npods > k
+        c = S(10 + k).choice(N, np.array([100, 250, 500, 1000], np.int64))
+        m = S(20 + k).choice(N, np.array([128, 256, 512, 1024], np.int64)) * (1 << 20)
+        fits = on & (node_idle[0] - c >= 0) & (node_idle[1] - m >= 0)
+        node_idle[0] -= np.where(fits, c, 0); node_idle[1] -= np.where(fits, m, 0)
+        node_nzc += np.where(fits, c, 0); node_nzm += np.where(fits, m, 0); node_cnt += fits.astype(np.int32)
+
+    # ---- jobs: draw gang sizes until the task budget is met
+    est_jobs = int(p.n_tasks / 8) + 64
+    sizes = S(30).choice(est_jobs, np.array(p.gang_sizes, np.int64), p.gang_probs)
+    csum = np.cumsum(sizes)
+    J = int(np.searchsorted(csum, p.n_tasks, side="left")) + 1
+    sizes = sizes[:J].copy()
+    sizes[-1] -= int(csum[J - 1] - p.n_tasks)
+    assert sizes.sum() == p.n_tasks and sizes.min() >= 1
+    T = p.n_tasks
+    begin = np.zeros(J + 1, np.uint32); begin[1:] = np.cumsum(sizes)
+    full = S(31).uniform(J) < 0.7
+    min_avail = np.where(full, sizes, (sizes + 1) // 2).astype(np.int32)
+    job_queue = S(32).randint(J, Q).astype(np.uint32)
+    job_prio = S(33).choice(J, np.array([0, 100, 1000], np.int32)).astype(np.int32)
+    job_creation = (1_600_000_000 + np.arange(J, dtype=np.int64))      # strictly increasing seconds
+    j_cpu = S(34).choice(J, np.array(p.task_cpu_milli, np.int64))
+    j_mem = S(35).choice(J, np.array(p.task_mem_mib, np.int64)) * (1 << 20)
+    j_nomem = S(36).uniform(J) < p.no_mem_key_frac
+    j_be = S(37).uniform(J) < p.best_effort_frac
+    j_zone_sel = S(38).uniform(J) < p.zone_selector_frac
+    j_zone = S(39).randint(J, p.n_zones)
+
+    task_job = np.repeat(np.arange(J, dtype=np.uint32), sizes)
+    t_res = np.zeros((R, T))
+    cpu_t = j_cpu[task_job].astype(np.float64); mem_t = np.where(j_nomem, 0, j_mem)[task_job].astype(np.float64)
+    be_t = j_be[task_job]
+    t_res[0] = np.where(be_t, 0.0, cpu_t); t_res[1] = np.where(be_t, 0.0, mem_t)
+    t_mask = np.zeros(T, np.uint32)
+    if R > 2:
+        j_scalar = S(40).uniform(J) < p.scalar_job_frac
+        d1 = 2 + S(41).randint(J, R - 2); d2 = 2 + S(42).randint(J, R - 2)
+        two = S(43).uniform(J) < 0.5
+        units = S(44).choice(J, np.array([1, 1, 2, 4], np.int64)) * 1000
+        for d in range(2, R):
+            hit = j_scalar & ((d1 == d) | (two & (d2 == d))) & ~j_be
+            t_res[d] = np.where(hit, units, 0)[task_job].astype(np.float64)
+            t_mask |= (hit[task_job].astype(np.uint32) << np.uint32(d - 2))
+    t_init = t_res.copy()
+    # non-zero requests: one container; cpu key always present unless BestEffort, mem key absent in a 5 % slice
+    t_nzc = np.where(be_t, DEFAULT_MILLI_CPU_REQUEST, j_cpu[task_job]).astype(np.int64)
+    t_nzm = np.where(be_t | j_nomem[task_job], DEFAULT_MEMORY_REQUEST, j_mem[task_job]).astype(np.int64)
+    t_prio = np.ones(T, np.int32)
+    t_cre = job_creation[task_job] + 1
+    t_status = np.zeros(T, np.uint8)
+    t_node = np.full(T, abi.KB_NONE, np.uint32)
+
+    # some session jobs already have Running tasks (feeds drf/proportion/gang initial state)
+    run_jobs = np.nonzero((S(45).uniform(J) < p.running_job_frac) & ~j_be)[0]
+    if len(run_jobs):
+        pick = S(46).randint(len(run_jobs), 1 << 30)
+        cursor = 0
+        for jj, j in enumerate(run_jobs):
+            k = 1 + int(pick[jj] % max(1, int(sizes[j])))
+            k = min(k, int(sizes[j]))
+            for t in range(int(begin[j]), int(begin[j]) + k):
+                for _ in range(8):                      # first node (deterministic probe sequence) with room
+                    n = int((int(pick[jj]) + cursor * 7919) % N); cursor += 1
+                    if np.all(node_idle[:, n] - t_res[:, t] >= 0) and node_cnt[n] < 100:
+                        node_idle[:, n] -= t_res[:, t]
+                        node_nzc[n] += t_nzc[t]; node_nzm[n] += t_nzm[t]; node_cnt[n] += 1
+                        t_status[t] = abi.TASK_RUNNING; t_node[t] = n
+                        break
+
+    # static predicate classes: task class 0 = no selector, 1+z = nodeSelector zone=z ; node class = zone
+    t_cls = np.where(j_zone_sel, 1 + j_zone, 0)[task_job].astype(np.uint32)
+    n_tc, n_nc = 1 + p.n_zones, p.n_zones
+    compat = np.zeros((n_tc * n_nc + 7) // 8, np.uint8)
+    for tc in range(n_tc):
+        for nc in range(n_nc):
+            if tc == 0 or tc - 1 == nc:
+                b = tc * n_nc + nc
+                compat[b >> 3] |= 1 << (b & 7)
+
+    queue_weight = S(50).choice(Q, np.array([1, 2, 4, 8], np.int32)).astype(np.int32)
+    return SessionSnapshot(
+        n_res=R, n_nodes=N, n_tasks=T, n_jobs=J, n_queues=Q, n_task_classes=n_tc, n_node_classes=n_nc,
+        node_idle=node_idle, node_releasing=node_rel, node_allocatable=node_alloc, node_scalar_mask=node_mask,
+        node_alloc_cpu=cpu_m.astype(np.int64), node_alloc_mem=mem_b.astype(np.int64),
+        node_nz_cpu=node_nzc, node_nz_mem=node_nzm, node_max_pods=np.full(N, 110, np.int32), node_pod_cnt=node_cnt,
+        node_class=node_zone,
+        task_resreq=t_res, task_init_resreq=t_init, task_scalar_mask=t_mask, task_nz_cpu=t_nzc, task_nz_mem=t_nzm,
+        task_job=task_job, task_class=t_cls, task_priority=t_prio, task_creation=t_cre, task_status=t_status,
+        task_node=t_node, job_task_begin=begin, job_queue=job_queue, job_min_available=min_avail,
+        job_priority=job_prio, job_creation=job_creation, queue_weight=queue_weight,
+        queue_creation=np.zeros(Q, np.int64), class_compat=compat,
+    )

@@ -1,0 +1,1061 @@
+/*
+ * kb_oracle.c — TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+ *
+ * CPU restatement of kube-batch's allocate/backfill hot path (reference @ /root/reference, Go,
+ * RELEASE v0.5).  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load
+ * this library; the product (kube-batch_amd/csrc) never links, imports or calls it.
+ *
+ * The reference is Go and there is no Go toolchain in the build image, so the real binary cannot
+ * be executed here.  Parity of this restatement is pinned by the reference's OWN known-answer
+ * tests, re-stated in tests/test_oracle_kat.py (api/resource_info_test.go, api/node_info_test.go,
+ * actions/allocate/allocate_test.go, util/scheduler_helper_test.go) and by the doc-level worked
+ * example doc/usage/tutorial.md:297-330.  What no in-tree test pins (the vendored k8s scorers'
+ * numeric outputs, container/heap pop order with duplicate queue entries, math/rand tie-break) is
+ * "parity unpinned by tests": it follows the vendored source text line by line and the
+ * canonicalisation of SURVEY.md §8c (first max-score node in ascending node order; maps iterated
+ * in ascending key order).
+ *
+ * Every function cites the reference file:line it follows (paths relative to /root/reference).
+ */
+#include <math.h>
+#include <pthread.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+
+#include "../include/kb_engine.h"
+
+#define KBO_PANIC (-100) /* the Go code would have panicked (Resource.Sub underflow) */
+
+/* ================================================================================================
+ * api.Resource — pkg/scheduler/api/resource_info.go:28-38
+ * Dense vector + presence mask for ScalarResources (bit d-2 <=> key of dimension d exists in the map;
+ * mask == 0 <=> the map is nil: the Go code never creates an empty non-nil map on this path).
+ * ============================================================================================== */
+typedef struct kbo_res {
+  double v[KB_MAX_RES];
+  uint32_t mask;
+  int32_t max_task_num;
+} kbo_res;
+
+static const double minMilliCPU = 10.0;               /* resource_info.go:68 */
+static const double minMilliScalar = 10.0;            /* resource_info.go:69 */
+static const double minMemory = 10.0 * 1024 * 1024;   /* resource_info.go:70 */
+
+static int g_R = 2; /* dimensions in use for the KAT helpers (session code passes R explicitly) */
+
+static void res_zero(kbo_res *r) { memset(r, 0, sizeof(*r)); }
+#define HAS(r, d) (((r)->mask >> ((d)-2)) & 1u)
+#define SETK(r, d) ((r)->mask |= (1u << ((d)-2)))
+
+/* resource_info.go:93-105 */
+static int res_is_empty(const kbo_res *r, int R) {
+  if (!(r->v[0] < minMilliCPU && r->v[1] < minMemory)) return 0;
+  for (int d = 2; d < R; d++)
+    if (HAS(r, d) && r->v[d] >= minMilliScalar) return 0;
+  return 1;
+}
+
+/* resource_info.go:128-140 */
+static void res_add(kbo_res *r, const kbo_res *rr, int R) {
+  r->v[0] += rr->v[0];
+  r->v[1] += rr->v[1];
+  for (int d = 2; d < R; d++)
+    if (HAS(rr, d)) { SETK(r, d); r->v[d] += rr->v[d]; }
+}
+
+/* resource_info.go:268-302 */
+static int le_func(double l, double r, double diff) { return (l < r || fabs(l - r) < diff) ? 1 : 0; }
+static int res_less_equal(const kbo_res *r, const kbo_res *rr, int R) {
+  if (!le_func(r->v[0], rr->v[0], minMilliCPU)) return 0;
+  if (!le_func(r->v[1], rr->v[1], minMemory)) return 0;
+  if (r->mask == 0) return 1;
+  for (int d = 2; d < R; d++) {
+    if (!HAS(r, d)) continue;
+    double q = r->v[d];
+    if (q <= minMilliScalar) continue;
+    if (rr->mask == 0) return 0;
+    double rq = HAS(rr, d) ? rr->v[d] : 0.0;
+    if (!le_func(q, rq, minMilliScalar)) return 0;
+  }
+  return 1;
+}
+
+/* resource_info.go:143-160 — returns KBO_PANIC where Go panics */
+static int res_sub(kbo_res *r, const kbo_res *rr, int R) {
+  if (!res_less_equal(rr, r, R)) return KBO_PANIC;
+  r->v[0] -= rr->v[0];
+  r->v[1] -= rr->v[1];
+  for (int d = 2; d < R; d++) {
+    if (!HAS(rr, d)) continue;
+    if (r->mask == 0) return 0; /* "if r.ScalarResources == nil { return r }" */
+    SETK(r, d);
+    r->v[d] -= rr->v[d];
+  }
+  return 0;
+}
+
+/* resource_info.go:163-188 */
+static void res_set_max(kbo_res *r, const kbo_res *rr, int R) {
+  if (rr->v[0] > r->v[0]) r->v[0] = rr->v[0];
+  if (rr->v[1] > r->v[1]) r->v[1] = rr->v[1];
+  if (rr->mask == 0) return;
+  if (r->mask == 0) { /* copies the whole map on first key and returns */
+    for (int d = 2; d < R; d++)
+      if (HAS(rr, d)) { SETK(r, d); r->v[d] = rr->v[d]; }
+    return;
+  }
+  for (int d = 2; d < R; d++)
+    if (HAS(rr, d)) {
+      double cur = HAS(r, d) ? r->v[d] : 0.0;
+      if (rr->v[d] > cur) { SETK(r, d); r->v[d] = rr->v[d]; }
+    }
+}
+
+/* resource_info.go:194-214 */
+static void res_fit_delta(kbo_res *r, const kbo_res *rr, int R) {
+  if (rr->v[0] > 0) r->v[0] -= rr->v[0] + minMilliCPU;
+  if (rr->v[1] > 0) r->v[1] -= rr->v[1] + minMemory;
+  for (int d = 2; d < R; d++)
+    if (HAS(rr, d) && rr->v[d] > 0) { SETK(r, d); r->v[d] -= rr->v[d] + minMilliScalar; }
+}
+
+/* resource_info.go:217-224 */
+static void res_multi(kbo_res *r, double ratio, int R) {
+  r->v[0] = r->v[0] * ratio;
+  r->v[1] = r->v[1] * ratio;
+  for (int d = 2; d < R; d++)
+    if (HAS(r, d)) r->v[d] = r->v[d] * ratio;
+}
+
+/* resource_info.go:227-265 */
+static int res_less(const kbo_res *r, const kbo_res *rr, int R) {
+  if (!(r->v[0] < rr->v[0])) return 0;
+  if (!(r->v[1] < rr->v[1])) return 0;
+  if (r->mask == 0) {
+    if (rr->mask != 0)
+      for (int d = 2; d < R; d++)
+        if (HAS(rr, d) && rr->v[d] <= minMilliScalar) return 0;
+    return 1;
+  }
+  if (rr->mask == 0) return 0;
+  for (int d = 2; d < R; d++) {
+    if (!HAS(r, d)) continue;
+    double rq = HAS(rr, d) ? rr->v[d] : 0.0;
+    if (!(r->v[d] < rq)) return 0;
+  }
+  return 1;
+}
+
+/* resource_info.go:305-337 */
+static void res_diff(const kbo_res *r, const kbo_res *rr, kbo_res *inc, kbo_res *dec, int R) {
+  res_zero(inc);
+  res_zero(dec);
+  if (r->v[0] > rr->v[0]) inc->v[0] += r->v[0] - rr->v[0]; else dec->v[0] += rr->v[0] - r->v[0];
+  if (r->v[1] > rr->v[1]) inc->v[1] += r->v[1] - rr->v[1]; else dec->v[1] += rr->v[1] - r->v[1];
+  for (int d = 2; d < R; d++) {
+    if (!HAS(r, d)) continue;
+    double rq = HAS(rr, d) ? rr->v[d] : 0.0;
+    if (r->v[d] > rq) { SETK(inc, d); inc->v[d] += r->v[d] - rq; }
+    else { SETK(dec, d); dec->v[d] += rq - r->v[d]; }
+  }
+}
+
+/* resource_info.go:349-361 */
+static double res_get(const kbo_res *r, int d) {
+  if (d < 2) return r->v[d];
+  return HAS(r, d) ? r->v[d] : 0.0;
+}
+
+/* api/helpers/helpers.go:28-44 */
+static void helpers_min(const kbo_res *l, const kbo_res *r, kbo_res *res, int R) {
+  res_zero(res);
+  res->v[0] = fmin(l->v[0], r->v[0]);
+  res->v[1] = fmin(l->v[1], r->v[1]);
+  if (l->mask == 0 || r->mask == 0) return;
+  for (int d = 2; d < R; d++)
+    if (HAS(l, d)) { SETK(res, d); res->v[d] = fmin(l->v[d], HAS(r, d) ? r->v[d] : 0.0); }
+}
+
+/* api/helpers/helpers.go:47-60 */
+static double helpers_share(double l, double r) {
+  if (r == 0) return (l == 0) ? 0.0 : 1.0;
+  return l / r;
+}
+
+/* ---- KAT entry points (tests/test_oracle_kat.py drives resource_info_test.go's tables through these) ---- */
+void kbo_set_dims(int R) { g_R = R; }
+int kbo_res_is_empty(const kbo_res *r) { return res_is_empty(r, g_R); }
+void kbo_res_add(kbo_res *r, const kbo_res *rr) { res_add(r, rr, g_R); }
+int kbo_res_sub(kbo_res *r, const kbo_res *rr) { return res_sub(r, rr, g_R); }
+int kbo_res_less(const kbo_res *r, const kbo_res *rr) { return res_less(r, rr, g_R); }
+int kbo_res_less_equal(const kbo_res *r, const kbo_res *rr) { return res_less_equal(r, rr, g_R); }
+void kbo_res_set_max(kbo_res *r, const kbo_res *rr) { res_set_max(r, rr, g_R); }
+void kbo_res_fit_delta(kbo_res *r, const kbo_res *rr) { res_fit_delta(r, rr, g_R); }
+void kbo_res_multi(kbo_res *r, double ratio) { res_multi(r, ratio, g_R); }
+void kbo_res_diff(const kbo_res *r, const kbo_res *rr, kbo_res *inc, kbo_res *dec) { res_diff(r, rr, inc, dec, g_R); }
+void kbo_res_min(const kbo_res *l, const kbo_res *r, kbo_res *out) { helpers_min(l, r, out, g_R); }
+double kbo_share(double l, double r) { return helpers_share(l, r); }
+/* resource_info.go:108-126 IsZero; returns -1 for the "unknown resource" panic */
+int kbo_res_is_zero(const kbo_res *r, int d) {
+  if (d == 0) return r->v[0] < minMilliCPU;
+  if (d == 1) return r->v[1] < minMemory;
+  if (r->mask == 0) return 1;
+  if (!HAS(r, d)) return -1;
+  return r->v[d] < minMilliScalar;
+}
+
+/* ================================================================================================
+ * container/heap (Go stdlib; not in the tree) as used by util.PriorityQueue —
+ * pkg/scheduler/util/priority_queue.go:26-94.  Published algorithm (go1.13 src/container/heap/heap.go):
+ *   Push: append; up(n-1)         Pop: n=Len-1; Swap(0,n); down(0,n); remove last
+ *   up(j):   for { i=(j-1)/2; if i==j || !less(j,i) break; swap(i,j); j=i }
+ *   down(i0,n): i=i0; for { j1=2i+1; if j1>=n||j1<0 break; j=j1; if j2=j1+1<n && less(j2,j1) j=j2;
+ *                           if !less(j,i) break; swap(i,j); i=j }
+ * less(i,j) = lessFn(items[i], items[j])  (priority_queue.go:71-78).
+ * ============================================================================================== */
+typedef int (*less_fn)(void *ctx, uint32_t a, uint32_t b);
+typedef struct heap_t {
+  uint32_t *items;
+  int n, cap;
+  less_fn less;
+  void *ctx;
+} heap_t;
+
+static void heap_init(heap_t *h, less_fn less, void *ctx) { h->items = NULL; h->n = 0; h->cap = 0; h->less = less; h->ctx = ctx; }
+static void heap_free(heap_t *h) { free(h->items); h->items = NULL; h->n = h->cap = 0; }
+static int heap_less(heap_t *h, int i, int j) { return h->less(h->ctx, h->items[i], h->items[j]); }
+static void heap_swap(heap_t *h, int i, int j) { uint32_t t = h->items[i]; h->items[i] = h->items[j]; h->items[j] = t; }
+static void heap_up(heap_t *h, int j) {
+  for (;;) {
+    int i = (j - 1) / 2; /* parent; Go's (j-1)/2 with j==0 gives 0 (trunc toward zero) */
+    if (i == j || !heap_less(h, j, i)) break;
+    heap_swap(h, i, j);
+    j = i;
+  }
+}
+static void heap_down(heap_t *h, int i0, int n) {
+  int i = i0;
+  for (;;) {
+    int j1 = 2 * i + 1;
+    if (j1 >= n || j1 < 0) break;
+    int j = j1;
+    int j2 = j1 + 1;
+    if (j2 < n && heap_less(h, j2, j1)) j = j2;
+    if (!heap_less(h, j, i)) break;
+    heap_swap(h, i, j);
+    i = j;
+  }
+}
+static void heap_push(heap_t *h, uint32_t x) {
+  if (h->n == h->cap) { h->cap = h->cap ? h->cap * 2 : 16; h->items = (uint32_t *)realloc(h->items, sizeof(uint32_t) * (size_t)h->cap); }
+  h->items[h->n++] = x;
+  heap_up(h, h->n - 1);
+}
+static uint32_t heap_pop(heap_t *h) {
+  int n = h->n - 1;
+  heap_swap(h, 0, n);
+  heap_down(h, 0, n);
+  uint32_t x = h->items[h->n - 1];
+  h->n--;
+  return x;
+}
+
+/* KAT helper: heap over integer keys with "less = key[a] < key[b]" to test the sift mechanics */
+static int key_less(void *ctx, uint32_t a, uint32_t b) { const double *k = (const double *)ctx; return k[a] < k[b]; }
+int kbo_heap_order(const double *keys, const uint32_t *push_ids, int n, uint32_t *pop_out) {
+  heap_t h;
+  heap_init(&h, key_less, (void *)keys);
+  for (int i = 0; i < n; i++) heap_push(&h, push_ids[i]);
+  for (int i = 0; i < n; i++) pop_out[i] = heap_pop(&h);
+  heap_free(&h);
+  return 0;
+}
+
+/* ================================================================================================
+ * util.SelectBestNode / findMaxScores — pkg/scheduler/util/scheduler_helper.go:188-208
+ * Canonical tie-break: rand.Intn(len(maxScores)) replaced by index 0.
+ * Returns the position in the list of the selected entry; fills all max positions for the KAT.
+ * ============================================================================================== */
+int kbo_select_best(const double *scores, int n, int *max_idx_out, int *n_max_out) {
+  int cnt = 0;
+  double maxScore = scores[0];
+  for (int i = 0; i < n; i++) {
+    if (scores[i] > maxScore) { maxScore = scores[i]; cnt = 0; max_idx_out[cnt++] = i; }
+    else if (scores[i] == maxScore) { max_idx_out[cnt++] = i; }
+  }
+  *n_max_out = cnt;
+  return max_idx_out[0];
+}
+
+/* ================================================================================================
+ * k8s scorers (vendored k8s.io/kubernetes v1.16.8)
+ * ============================================================================================== */
+#define MAX_PRIORITY 10 /* vendor/k8s.io/kubernetes/pkg/scheduler/api/types.go:35 */
+
+/* vendor/.../priorities/least_requested.go:50-58 */
+static int64_t least_requested_score(int64_t requested, int64_t capacity) {
+  if (capacity == 0) return 0;
+  if (requested > capacity) return 0;
+  return ((capacity - requested) * (int64_t)MAX_PRIORITY) / capacity;
+}
+/* vendor/.../priorities/most_requested.go:52-61 */
+static int64_t most_requested_score(int64_t requested, int64_t capacity) {
+  if (capacity == 0) return 0;
+  if (requested > capacity) return 0;
+  return (requested * MAX_PRIORITY) / capacity;
+}
+/* vendor/.../priorities/balanced_resource_allocation.go:74-79 */
+static double fraction_of_capacity(int64_t requested, int64_t capacity) {
+  if (capacity == 0) return 1;
+  return (double)requested / (double)capacity;
+}
+/* least_requested.go:36-45 (weights cpu 1, memory 1: resource_allocation.go:46) */
+static int64_t least_scorer(int64_t rc, int64_t ac, int64_t rm, int64_t am) {
+  int64_t nodeScore = 0, weightSum = 0;
+  nodeScore += least_requested_score(rm, am) * 1; weightSum += 1;
+  nodeScore += least_requested_score(rc, ac) * 1; weightSum += 1;
+  return nodeScore / weightSum;
+}
+/* most_requested.go:34-43 */
+static int64_t most_scorer(int64_t rc, int64_t ac, int64_t rm, int64_t am) {
+  int64_t nodeScore = 0, weightSum = 0;
+  nodeScore += most_requested_score(rm, am) * 1; weightSum += 1;
+  nodeScore += most_requested_score(rc, ac) * 1; weightSum += 1;
+  return nodeScore / weightSum;
+}
+/* balanced_resource_allocation.go:42-71 (BalanceAttachedNodeVolumes gate off) */
+static int64_t balanced_scorer(int64_t rc, int64_t ac, int64_t rm, int64_t am) {
+  double cpuFraction = fraction_of_capacity(rc, ac);
+  double memoryFraction = fraction_of_capacity(rm, am);
+  if (cpuFraction >= 1 || memoryFraction >= 1) return 0;
+  double diff = fabs(cpuFraction - memoryFraction);
+  return (int64_t)((1 - diff) * (double)MAX_PRIORITY);
+}
+/* KAT entry: the three scorers for one (pod, node) */
+void kbo_scorers(int64_t rc, int64_t ac, int64_t rm, int64_t am, int64_t *least, int64_t *most, int64_t *bal) {
+  *least = least_scorer(rc, ac, rm, am);
+  *most = most_scorer(rc, ac, rm, am);
+  *bal = balanced_scorer(rc, ac, rm, am);
+}
+
+/* ================================================================================================
+ * Session
+ * ============================================================================================== */
+typedef struct o_node {
+  kbo_res idle, releasing, used, allocatable;
+  int64_t alloc_cpu, alloc_mem, nz_cpu, nz_mem; /* k8s nodeinfo view */
+  int32_t pod_cnt;
+  uint32_t cls;
+} o_node;
+
+typedef struct o_task {
+  kbo_res resreq, init_resreq;
+  int64_t nz_cpu, nz_mem;
+  uint32_t job, cls, node;
+  int32_t priority;
+  int64_t creation;
+  uint8_t status;
+} o_task;
+
+typedef struct o_job {
+  uint32_t queue, t0, t1;
+  int32_t min_available, priority;
+  int64_t creation;
+  int valid;            /* survived the JobValid filter (framework/session.go:89-107) */
+  int32_t cnt[10];      /* len(TaskStatusIndex[status]) */
+  kbo_res drf_allocated;
+  double drf_share;
+  int tasks_init;       /* pendingTasks[job.UID] created (allocate.go:110) */
+  heap_t tasks;
+} o_job;
+
+typedef struct o_queue {
+  int32_t weight;
+  int64_t creation;
+  int has_attr;         /* proportion: queueOpts entry exists (queue has a job in the session) */
+  kbo_res deserved, allocated, request;
+  double share;
+  int has_jobs_heap;
+  heap_t jobs;
+} o_queue;
+
+typedef struct plug_opt { uint32_t plugin, enabled; int32_t args[8]; uint32_t args_set; } plug_opt;
+
+typedef struct kbo_session {
+  int R;
+  uint32_t N, T, J, Q, n_tc, n_nc;
+  o_node *nodes;
+  o_task *tasks;
+  o_job *jobs;
+  o_queue *queues;
+  uint8_t *compat;
+  /* conf */
+  int n_tiers;
+  uint32_t *tier_begin;
+  plug_opt *plugins;
+  int has_plugin[8];
+  int w_least, w_most, w_nodeaff, w_podaff, w_bal;
+  int pred_enabled, nodeorder_enabled;
+  /* drf / proportion */
+  kbo_res drf_total, prop_total;
+  /* outputs */
+  kb_decision *decisions;
+  uint64_t n_dec, cap_dec;
+  uint32_t *bind_node;  /* [T] */
+  uint32_t *bind_order; /* task ids in dispatch order */
+  uint64_t n_binds;
+  uint64_t evals, popped;
+  int panic;
+  int threads;
+} kbo_session;
+
+static int find_plugin_enabled(const kbo_session *s, uint32_t plugin, uint32_t en_bit) {
+  /* is there an option for `plugin` whose Enabled bit is set (session_plugins.go isEnabled) */
+  for (int t = 0; t < s->n_tiers; t++)
+    for (uint32_t p = s->tier_begin[t]; p < s->tier_begin[t + 1]; p++)
+      if (s->plugins[p].plugin == plugin && (s->plugins[p].enabled & en_bit)) return 1;
+  return 0;
+}
+
+/* ---- JobInfo counters: pkg/scheduler/api/job_info.go:383-434, api/helpers.go:64-71 ---- */
+static int allocated_status(int st) { return st == KB_TASK_BOUND || st == KB_TASK_BINDING || st == KB_TASK_RUNNING || st == KB_TASK_ALLOCATED; }
+static int32_t job_ready_num(const o_job *j) {
+  int32_t n = 0;
+  for (int st = 0; st < 10; st++)
+    if (allocated_status(st) || st == KB_TASK_SUCCEEDED) n += j->cnt[st];
+  return n;
+}
+static int32_t job_valid_num(const o_job *j) {
+  int32_t n = 0;
+  for (int st = 0; st < 10; st++)
+    if (allocated_status(st) || st == KB_TASK_SUCCEEDED || st == KB_TASK_PIPELINED || st == KB_TASK_PENDING) n += j->cnt[st];
+  return n;
+}
+static int job_ready(const o_job *j) { return job_ready_num(j) >= j->min_available; }
+
+/* ---- drf: plugins/drf/drf.go:157-171 ---- */
+static double drf_calc_share(const kbo_session *s, const kbo_res *allocated) {
+  double res = 0;
+  for (int d = 0; d < s->R; d++) {
+    if (d >= 2 && !HAS(&s->drf_total, d)) continue; /* totalResource.ResourceNames() */
+    double share = helpers_share(res_get(allocated, d), res_get(&s->drf_total, d));
+    if (share > res) res = share;
+  }
+  return res;
+}
+/* ---- proportion: plugins/proportion/proportion.go:241-253 ---- */
+static void prop_update_share(const kbo_session *s, o_queue *q) {
+  double res = 0;
+  for (int d = 0; d < s->R; d++) {
+    if (d >= 2 && !HAS(&q->deserved, d)) continue; /* attr.deserved.ResourceNames() */
+    double share = helpers_share(res_get(&q->allocated, d), res_get(&q->deserved, d));
+    if (share > res) res = share;
+  }
+  q->share = res;
+}
+
+/* ---- tiered order functions: framework/session_plugins.go:243-331 ---- */
+static int job_order_less(void *ctx, uint32_t l, uint32_t r) {
+  kbo_session *s = (kbo_session *)ctx;
+  const o_job *lv = &s->jobs[l], *rv = &s->jobs[r];
+  for (int t = 0; t < s->n_tiers; t++)
+    for (uint32_t p = s->tier_begin[t]; p < s->tier_begin[t + 1]; p++) {
+      const plug_opt *po = &s->plugins[p];
+      if (!(po->enabled & KB_EN_JOB_ORDER)) continue;
+      int j = 0;
+      if (po->plugin == KB_PLUGIN_PRIORITY) { /* priority.go:61-77 */
+        if (lv->priority > rv->priority) j = -1; else if (lv->priority < rv->priority) j = 1;
+      } else if (po->plugin == KB_PLUGIN_GANG) { /* gang.go:96-119 */
+        int lReady = job_ready(lv), rReady = job_ready(rv);
+        if (lReady && rReady) j = 0; else if (lReady) j = 1; else if (rReady) j = -1; else j = 0;
+      } else if (po->plugin == KB_PLUGIN_DRF) { /* drf.go:114-130 */
+        if (lv->drf_share == rv->drf_share) j = 0; else if (lv->drf_share < rv->drf_share) j = -1; else j = 1;
+      } else continue;
+      if (j != 0) return j < 0;
+    }
+  if (lv->creation == rv->creation) return l < r; /* UID order == canonical index order */
+  return lv->creation < rv->creation;
+}
+static int queue_order_less(void *ctx, uint32_t l, uint32_t r) {
+  kbo_session *s = (kbo_session *)ctx;
+  const o_queue *lv = &s->queues[l], *rv = &s->queues[r];
+  for (int t = 0; t < s->n_tiers; t++)
+    for (uint32_t p = s->tier_begin[t]; p < s->tier_begin[t + 1]; p++) {
+      const plug_opt *po = &s->plugins[p];
+      if (!(po->enabled & KB_EN_QUEUE_ORDER)) continue;
+      if (po->plugin != KB_PLUGIN_PROPORTION) continue;
+      int j; /* proportion.go:156-169 */
+      if (lv->share == rv->share) j = 0; else if (lv->share < rv->share) j = -1; else j = 1;
+      if (j != 0) return j < 0;
+    }
+  if (lv->creation == rv->creation) return l < r;
+  return lv->creation < rv->creation;
+}
+static int task_order_less(void *ctx, uint32_t l, uint32_t r) {
+  kbo_session *s = (kbo_session *)ctx;
+  const o_task *lv = &s->tasks[l], *rv = &s->tasks[r];
+  for (int t = 0; t < s->n_tiers; t++)
+    for (uint32_t p = s->tier_begin[t]; p < s->tier_begin[t + 1]; p++) {
+      const plug_opt *po = &s->plugins[p];
+      if (!(po->enabled & KB_EN_TASK_ORDER)) continue;
+      if (po->plugin != KB_PLUGIN_PRIORITY) continue;
+      int j; /* priority.go:40-56 */
+      if (lv->priority == rv->priority) j = 0; else if (lv->priority > rv->priority) j = -1; else j = 1;
+      if (j != 0) return j < 0;
+    }
+  if (lv->creation == rv->creation) return l < r;
+  return lv->creation < rv->creation;
+}
+
+/* session_plugins.go:165-179 + proportion.go:198-209 (no Enabled* check on Overused) */
+static int ssn_overused(const kbo_session *s, uint32_t q) {
+  if (!s->has_plugin[KB_PLUGIN_PROPORTION]) return 0;
+  const o_queue *attr = &s->queues[q];
+  return res_less_equal(&attr->deserved, &attr->allocated, s->R);
+}
+/* session_plugins.go:182-200 + gang.go:122-125 */
+static int ssn_job_ready(const kbo_session *s, const o_job *j) {
+  if (find_plugin_enabled(s, KB_PLUGIN_GANG, KB_EN_JOB_READY)) return job_ready(j);
+  return 1;
+}
+
+/* ---- per-(task,node) predicate and score ---- */
+static int class_ok(const kbo_session *s, uint32_t tc, uint32_t nc) {
+  if (!s->compat) return 1;
+  uint32_t bit = tc * s->n_nc + nc;
+  return (s->compat[bit >> 3] >> (bit & 7)) & 1;
+}
+/* plugins/predicates/predicates.go:123-265 with the static checks p2..p7 folded into class_ok */
+static int plugin_predicate(const kbo_session *s, const o_task *t, const o_node *n) {
+  if (!s->pred_enabled) return 1; /* session_plugins.go:334-351: no enabled predicate fn => nil */
+  if (n->allocatable.max_task_num <= n->pod_cnt) return 0; /* predicates.go:127 */
+  return class_ok(s, t->cls, n->cls);
+}
+/* actions/allocate/allocate.go:73-87 */
+static int allocate_predicate(const kbo_session *s, const o_task *t, const o_node *n) {
+  if (!res_less_equal(&t->init_resreq, &n->idle, s->R) && !res_less_equal(&t->init_resreq, &n->releasing, s->R)) return 0;
+  return plugin_predicate(s, t, n);
+}
+/* util/scheduler_helper.go:89-171 with nodeorder's five configs (plugins/nodeorder/nodeorder.go:140-168);
+   requested = nodeInfo.NonZeroRequest + pod non-zero request (resource_allocation.go:100-112). */
+static double node_score(const kbo_session *s, const o_task *t, const o_node *n) {
+  if (!s->nodeorder_enabled) return 0.0;
+  int64_t rc = n->nz_cpu + t->nz_cpu, rm = n->nz_mem + t->nz_mem;
+  int least = (int)least_scorer(rc, n->alloc_cpu, rm, n->alloc_mem);
+  int most = (int)most_scorer(rc, n->alloc_cpu, rm, n->alloc_mem);
+  int nodeaff = 0; /* no preferred node-affinity terms in the flattened snapshot: Map gives 0, NormalizeReduce leaves 0 (reduce.go:43-50) */
+  int podaff = 0;  /* no pod (anti)affinity: interpod_affinity.go yields 0 for every node */
+  int bal = (int)balanced_scorer(rc, n->alloc_cpu, rm, n->alloc_mem);
+  double score = 0;
+  score += (double)(least * s->w_least);   /* scheduler_helper.go:162-168: result[i].Score += float64(results[j][i].Score * Weight) */
+  score += (double)(most * s->w_most);
+  score += (double)(nodeaff * s->w_nodeaff);
+  score += (double)(podaff * s->w_podaff);
+  score += (double)(bal * s->w_bal);
+  return score;
+}
+
+/* ---- worker pool mirroring workqueue.ParallelizeUntil(ctx, 16, len(nodes), fn)
+        (vendor/k8s.io/client-go/util/workqueue/parallelizer.go:29-63): a shared piece counter drained by workers ---- */
+typedef struct pool_t {
+  int nthreads;
+  pthread_t *th;
+  pthread_mutex_t mu;
+  pthread_cond_t cv_start, cv_done;
+  int generation, running, stop;
+  kbo_session *s;
+  const o_task *task;
+  int fit_mode;
+  uint8_t *feas;     /* [N] */
+  double *score;     /* [N] */
+  volatile int next;
+} pool_t;
+static pool_t g_pool;
+static int g_pool_threads = 0;
+#define PIECE_CHUNK 64
+
+static void eval_range(kbo_session *s, const o_task *t, int fit_mode, uint8_t *feas, double *score, uint32_t a, uint32_t b) {
+  for (uint32_t i = a; i < b; i++) {
+    const o_node *n = &s->nodes[i];
+    int ok = fit_mode ? allocate_predicate(s, t, n) : plugin_predicate(s, t, n);
+    feas[i] = (uint8_t)ok;
+    score[i] = ok ? node_score(s, t, n) : 0.0;
+  }
+}
+static void *pool_worker(void *arg) {
+  pool_t *p = (pool_t *)arg;
+  int seen = 0;
+  for (;;) {
+    pthread_mutex_lock(&p->mu);
+    while (p->generation == seen && !p->stop) pthread_cond_wait(&p->cv_start, &p->mu);
+    if (p->stop) { pthread_mutex_unlock(&p->mu); return NULL; }
+    seen = p->generation;
+    pthread_mutex_unlock(&p->mu);
+    for (;;) {
+      int piece = __sync_fetch_and_add(&p->next, PIECE_CHUNK);
+      if ((uint32_t)piece >= p->s->N) break;
+      uint32_t b = (uint32_t)piece + PIECE_CHUNK;
+      if (b > p->s->N) b = p->s->N;
+      eval_range(p->s, p->task, p->fit_mode, p->feas, p->score, (uint32_t)piece, b);
+    }
+    pthread_mutex_lock(&p->mu);
+    if (--p->running == 0) pthread_cond_signal(&p->cv_done);
+    pthread_mutex_unlock(&p->mu);
+  }
+}
+static void pool_start(int nthreads) {
+  if (g_pool_threads == nthreads) return;
+  if (g_pool_threads) {
+    pthread_mutex_lock(&g_pool.mu); g_pool.stop = 1; pthread_cond_broadcast(&g_pool.cv_start); pthread_mutex_unlock(&g_pool.mu);
+    for (int i = 0; i < g_pool.nthreads; i++) pthread_join(g_pool.th[i], NULL);
+    free(g_pool.th); g_pool_threads = 0;
+  }
+  if (nthreads <= 1) return;
+  memset(&g_pool, 0, sizeof(g_pool));
+  g_pool.nthreads = nthreads;
+  g_pool.th = (pthread_t *)malloc(sizeof(pthread_t) * (size_t)nthreads);
+  pthread_mutex_init(&g_pool.mu, NULL);
+  pthread_cond_init(&g_pool.cv_start, NULL);
+  pthread_cond_init(&g_pool.cv_done, NULL);
+  for (int i = 0; i < nthreads; i++) pthread_create(&g_pool.th[i], NULL, pool_worker, &g_pool);
+  g_pool_threads = nthreads;
+}
+static void eval_all_nodes(kbo_session *s, const o_task *t, int fit_mode, uint8_t *feas, double *score) {
+  if (s->threads <= 1 || s->N < 256) { eval_range(s, t, fit_mode, feas, score, 0, s->N); return; }
+  pool_start(s->threads);
+  pool_t *p = &g_pool;
+  pthread_mutex_lock(&p->mu);
+  p->s = s; p->task = t; p->fit_mode = fit_mode; p->feas = feas; p->score = score; p->next = 0;
+  p->running = p->nthreads; p->generation++;
+  pthread_cond_broadcast(&p->cv_start);
+  while (p->running) pthread_cond_wait(&p->cv_done, &p->mu);
+  pthread_mutex_unlock(&p->mu);
+}
+
+/* ---- job status bookkeeping: job_info.go:247-264 (UpdateTaskStatus = delete + add) ---- */
+static void job_set_status(kbo_session *s, uint32_t t, int st) {
+  o_task *tk = &s->tasks[t];
+  o_job *j = &s->jobs[tk->job];
+  j->cnt[tk->status]--;
+  tk->status = (uint8_t)st;
+  j->cnt[st]++;
+}
+
+static void push_decision(kbo_session *s, uint32_t task, uint32_t node, uint32_t kind) {
+  if (s->n_dec == s->cap_dec) { s->cap_dec = s->cap_dec ? s->cap_dec * 2 : 1024; s->decisions = (kb_decision *)realloc(s->decisions, sizeof(kb_decision) * s->cap_dec); }
+  kb_decision d = {task, node, kind, 0};
+  s->decisions[s->n_dec++] = d;
+}
+
+/* plugin event handlers: drf.go:135-145, proportion.go:212-223 (fired by both Allocate and Pipeline) */
+static void fire_allocate_event(kbo_session *s, uint32_t t) {
+  o_task *tk = &s->tasks[t];
+  o_job *j = &s->jobs[tk->job];
+  if (s->has_plugin[KB_PLUGIN_DRF]) { res_add(&j->drf_allocated, &tk->resreq, s->R); j->drf_share = drf_calc_share(s, &j->drf_allocated); }
+  if (s->has_plugin[KB_PLUGIN_PROPORTION]) { o_queue *q = &s->queues[j->queue]; res_add(&q->allocated, &tk->resreq, s->R); prop_update_share(s, q); }
+}
+
+/* framework/session.go:290-314 dispatch: cache.Bind + status Binding */
+static void ssn_dispatch(kbo_session *s, uint32_t t) {
+  s->bind_node[t] = s->tasks[t].node;
+  s->bind_order[s->n_binds++] = t;
+  job_set_status(s, t, KB_TASK_BINDING);
+}
+
+/* framework/session.go:235-288 */
+static int ssn_allocate(kbo_session *s, uint32_t t, uint32_t n) {
+  o_task *tk = &s->tasks[t];
+  o_node *nd = &s->nodes[n];
+  o_job *j = &s->jobs[tk->job];
+  job_set_status(s, t, KB_TASK_ALLOCATED);                          /* session.go:243 (before node.AddTask) */
+  /* node.AddTask: api/node_info.go:172-212, status Allocated -> allocateIdleResource (node_info.go:161-167) */
+  if (!res_less_equal(&tk->resreq, &nd->idle, s->R)) return -1;     /* "Selected node NotReady": returns before callbacks */
+  if (res_sub(&nd->idle, &tk->resreq, s->R) == KBO_PANIC) { s->panic = 1; return KBO_PANIC; }
+  res_add(&nd->used, &tk->resreq, s->R);
+  tk->node = n;
+  nd->pod_cnt += 1;                 /* ni.Tasks[key] = ti ; k8s NodeInfo is rebuilt from ni.Pods() per evaluation */
+  nd->nz_cpu += tk->nz_cpu;         /* vendor/.../nodeinfo/node_info.go:502-517 AddPod */
+  nd->nz_mem += tk->nz_mem;
+  push_decision(s, t, n, 0);
+  fire_allocate_event(s, t);
+  if (ssn_job_ready(s, j)) {        /* session.go:277-285: dispatch every Allocated task of the job (canonical: ascending UID) */
+    for (uint32_t i = j->t0; i < j->t1; i++)
+      if (s->tasks[i].status == KB_TASK_ALLOCATED) ssn_dispatch(s, i);
+  }
+  return 0;
+}
+/* framework/session.go:194-232 */
+static int ssn_pipeline(kbo_session *s, uint32_t t, uint32_t n) {
+  o_task *tk = &s->tasks[t];
+  o_node *nd = &s->nodes[n];
+  job_set_status(s, t, KB_TASK_PIPELINED);
+  /* node.AddTask with status Pipelined: node_info.go:196-197 Releasing.Sub(Resreq) */
+  if (res_sub(&nd->releasing, &tk->resreq, s->R) == KBO_PANIC) { s->panic = 1; return KBO_PANIC; }
+  res_add(&nd->used, &tk->resreq, s->R);
+  tk->node = n;
+  nd->pod_cnt += 1;
+  nd->nz_cpu += tk->nz_cpu;
+  nd->nz_mem += tk->nz_mem;
+  push_decision(s, t, n, 1);
+  fire_allocate_event(s, t);
+  return 0;
+}
+
+/* ---- OnSessionOpen of drf / proportion, gang's JobValid filter ---- */
+static int open_plugins(kbo_session *s) {
+  int R = s->R;
+  /* framework/session.go:89-107: openSession() calls ssn.JobValid(job) BEFORE OpenSession assigns ssn.Tiers
+     (framework/framework.go:31-32) and before any plugin has run OnSessionOpen, so JobValid iterates a nil tier list
+     (session_plugins.go:225-240) and returns nil for every job: at this commit the gang JobValid filter
+     (gang.go:48-69) never removes a job.  Faithful restatement: every snapshot job stays in ssn.Jobs. */
+  for (uint32_t j = 0; j < s->J; j++) s->jobs[j].valid = 1;
+  /* drf.go:60-83 */
+  res_zero(&s->drf_total);
+  for (uint32_t n = 0; n < s->N; n++) res_add(&s->drf_total, &s->nodes[n].allocatable, R);
+  for (uint32_t j = 0; j < s->J; j++) {
+    o_job *job = &s->jobs[j];
+    res_zero(&job->drf_allocated);
+    for (uint32_t t = job->t0; t < job->t1; t++)
+      if (allocated_status(s->tasks[t].status)) res_add(&job->drf_allocated, &s->tasks[t].resreq, R);
+    job->drf_share = drf_calc_share(s, &job->drf_allocated);
+  }
+  /* proportion.go:58-154 */
+  res_zero(&s->prop_total);
+  for (uint32_t n = 0; n < s->N; n++) res_add(&s->prop_total, &s->nodes[n].allocatable, R);
+  for (uint32_t q = 0; q < s->Q; q++) { o_queue *a = &s->queues[q]; a->has_attr = 0; res_zero(&a->deserved); res_zero(&a->allocated); res_zero(&a->request); a->share = 0; }
+  for (uint32_t j = 0; j < s->J; j++) {
+    o_job *job = &s->jobs[j];
+    if (!job->valid) continue;
+    o_queue *a = &s->queues[job->queue];
+    a->has_attr = 1;
+    for (uint32_t t = job->t0; t < job->t1; t++) {
+      int st = s->tasks[t].status;
+      if (allocated_status(st)) { res_add(&a->allocated, &s->tasks[t].resreq, R); res_add(&a->request, &s->tasks[t].resreq, R); }
+      else if (st == KB_TASK_PENDING) res_add(&a->request, &s->tasks[t].resreq, R);
+    }
+  }
+  kbo_res remaining = s->prop_total;
+  uint8_t *meet = (uint8_t *)calloc(s->Q ? s->Q : 1, 1);
+  for (;;) {
+    int32_t totalWeight = 0;
+    for (uint32_t q = 0; q < s->Q; q++) {
+      if (!s->queues[q].has_attr || meet[q]) continue;
+      totalWeight += s->queues[q].weight;
+    }
+    if (totalWeight == 0) break;
+    kbo_res increasedDeserved, decreasedDeserved;
+    res_zero(&increasedDeserved);
+    res_zero(&decreasedDeserved);
+    for (uint32_t q = 0; q < s->Q; q++) {
+      o_queue *attr = &s->queues[q];
+      if (!attr->has_attr || meet[q]) continue;
+      kbo_res oldDeserved = attr->deserved;
+      kbo_res inc = remaining;
+      res_multi(&inc, (double)attr->weight / (double)totalWeight, R);
+      res_add(&attr->deserved, &inc, R);
+      if (res_less(&attr->request, &attr->deserved, R)) {
+        kbo_res m;
+        helpers_min(&attr->deserved, &attr->request, &m, R);
+        attr->deserved = m;
+        meet[q] = 1;
+      }
+      prop_update_share(s, attr);
+      kbo_res increased, decreased;
+      res_diff(&attr->deserved, &oldDeserved, &increased, &decreased, R);
+      res_add(&increasedDeserved, &increased, R);
+      res_add(&decreasedDeserved, &decreased, R);
+    }
+    if (res_sub(&remaining, &increasedDeserved, R) == KBO_PANIC) { free(meet); s->panic = 1; return KBO_PANIC; }
+    res_add(&remaining, &decreasedDeserved, R);
+    if (res_is_empty(&remaining, R)) break;
+  }
+  free(meet);
+  return 0;
+}
+
+/* ================================================================================================
+ * public oracle API
+ * ============================================================================================== */
+static void fill_res(kbo_res *r, const double *col, uint32_t stride, uint32_t i, int R, uint32_t mask) {
+  res_zero(r);
+  for (int d = 0; d < R; d++) r->v[d] = col[(size_t)d * stride + i];
+  r->mask = mask;
+  /* a dense value for a key that is absent from the map must read as 0 */
+  for (int d = 2; d < R; d++)
+    if (!HAS(r, d)) r->v[d] = 0.0;
+}
+
+kbo_session *kbo_open(const kb_config *cfg, const kb_snapshot *sn, int threads) {
+  if (!cfg || !sn || sn->n_res < 2 || sn->n_res > KB_MAX_RES) return NULL;
+  kbo_session *s = (kbo_session *)calloc(1, sizeof(*s));
+  int R = s->R = (int)sn->n_res;
+  s->N = sn->n_nodes; s->T = sn->n_tasks; s->J = sn->n_jobs; s->Q = sn->n_queues;
+  s->n_tc = sn->n_task_classes; s->n_nc = sn->n_node_classes;
+  s->threads = threads;
+  s->n_tiers = (int)cfg->n_tiers;
+  s->tier_begin = (uint32_t *)malloc(sizeof(uint32_t) * (cfg->n_tiers + 1));
+  memcpy(s->tier_begin, cfg->tier_begin, sizeof(uint32_t) * (cfg->n_tiers + 1));
+  uint32_t np = cfg->tier_begin[cfg->n_tiers];
+  s->plugins = (plug_opt *)malloc(sizeof(plug_opt) * (np ? np : 1));
+  s->w_least = 1; s->w_most = 0; s->w_nodeaff = 1; s->w_podaff = 1; s->w_bal = 1; /* nodeorder.go:111-117 */
+  for (uint32_t p = 0; p < np; p++) {
+    s->plugins[p].plugin = cfg->plugins[p].plugin;
+    s->plugins[p].enabled = cfg->plugins[p].enabled;
+    memcpy(s->plugins[p].args, cfg->plugins[p].args, sizeof(int32_t) * 8);
+    s->plugins[p].args_set = cfg->plugins[p].args_set;
+    if (cfg->plugins[p].plugin < 8) s->has_plugin[cfg->plugins[p].plugin] = 1;
+    if (cfg->plugins[p].plugin == KB_PLUGIN_NODEORDER) { /* nodeorder.go:119-129 */
+      const kb_plugin_option *o = &cfg->plugins[p];
+      if (o->args_set & 1u) s->w_least = o->args[0];
+      if (o->args_set & 2u) s->w_most = o->args[1];
+      if (o->args_set & 4u) s->w_nodeaff = o->args[2];
+      if (o->args_set & 8u) s->w_podaff = o->args[3];
+      if (o->args_set & 16u) s->w_bal = o->args[4];
+    }
+  }
+  s->pred_enabled = find_plugin_enabled(s, KB_PLUGIN_PREDICATES, KB_EN_PREDICATE);
+  s->nodeorder_enabled = find_plugin_enabled(s, KB_PLUGIN_NODEORDER, KB_EN_NODE_ORDER);
+
+  s->nodes = (o_node *)calloc(s->N ? s->N : 1, sizeof(o_node));
+  for (uint32_t n = 0; n < s->N; n++) {
+    o_node *nd = &s->nodes[n];
+    uint32_t m = sn->node_scalar_mask ? sn->node_scalar_mask[n] : 0;
+    fill_res(&nd->idle, sn->node_idle, s->N, n, R, m);
+    fill_res(&nd->allocatable, sn->node_allocatable, s->N, n, R, m);
+    /* Releasing starts EmptyResource() and only gains keys through Add (node_info.go:65,154): keys with a non-zero value */
+    uint32_t rm = 0;
+    for (int d = 2; d < R; d++) if (sn->node_releasing[(size_t)d * s->N + n] != 0.0) rm |= 1u << (d - 2);
+    fill_res(&nd->releasing, sn->node_releasing, s->N, n, R, rm);
+    nd->allocatable.max_task_num = sn->node_max_pods[n];
+    nd->alloc_cpu = sn->node_alloc_cpu[n]; nd->alloc_mem = sn->node_alloc_mem[n];
+    nd->nz_cpu = sn->node_nz_cpu[n]; nd->nz_mem = sn->node_nz_mem[n];
+    nd->pod_cnt = sn->node_pod_cnt[n];
+    nd->cls = sn->node_class ? sn->node_class[n] : 0;
+  }
+  s->tasks = (o_task *)calloc(s->T ? s->T : 1, sizeof(o_task));
+  for (uint32_t t = 0; t < s->T; t++) {
+    o_task *tk = &s->tasks[t];
+    uint32_t m = sn->task_scalar_mask ? sn->task_scalar_mask[t] : 0;
+    fill_res(&tk->resreq, sn->task_resreq, s->T, t, R, m);
+    /* InitResreq keys: Resreq's keys plus any key an init container raised (SetMaxResource); dense non-zero => present */
+    uint32_t im = m;
+    for (int d = 2; d < R; d++) if (sn->task_init_resreq[(size_t)d * s->T + t] != 0.0) im |= 1u << (d - 2);
+    fill_res(&tk->init_resreq, sn->task_init_resreq, s->T, t, R, im);
+    tk->nz_cpu = sn->task_nz_cpu[t]; tk->nz_mem = sn->task_nz_mem[t];
+    tk->job = sn->task_job[t];
+    tk->cls = sn->task_class ? sn->task_class[t] : 0;
+    tk->priority = sn->task_priority[t];
+    tk->creation = sn->task_creation[t];
+    tk->status = sn->task_status[t];
+    tk->node = sn->task_node ? sn->task_node[t] : KB_NONE;
+  }
+  s->jobs = (o_job *)calloc(s->J ? s->J : 1, sizeof(o_job));
+  for (uint32_t j = 0; j < s->J; j++) {
+    o_job *job = &s->jobs[j];
+    job->t0 = sn->job_task_begin[j]; job->t1 = sn->job_task_begin[j + 1];
+    job->queue = sn->job_queue[j];
+    job->min_available = sn->job_min_available[j];
+    job->priority = sn->job_priority[j];
+    job->creation = sn->job_creation[j];
+    for (uint32_t t = job->t0; t < job->t1; t++) job->cnt[s->tasks[t].status]++;
+    heap_init(&job->tasks, task_order_less, s);
+  }
+  s->queues = (o_queue *)calloc(s->Q ? s->Q : 1, sizeof(o_queue));
+  for (uint32_t q = 0; q < s->Q; q++) {
+    s->queues[q].weight = sn->queue_weight[q];
+    s->queues[q].creation = sn->queue_creation ? sn->queue_creation[q] : 0;
+    heap_init(&s->queues[q].jobs, job_order_less, s);
+  }
+  if (sn->class_compat) {
+    size_t nb = ((size_t)s->n_tc * s->n_nc + 7) / 8;
+    s->compat = (uint8_t *)malloc(nb);
+    memcpy(s->compat, sn->class_compat, nb);
+  }
+  s->bind_node = (uint32_t *)malloc(sizeof(uint32_t) * (s->T ? s->T : 1));
+  s->bind_order = (uint32_t *)malloc(sizeof(uint32_t) * (s->T ? s->T : 1));
+  for (uint32_t t = 0; t < s->T; t++) s->bind_node[t] = KB_NONE;
+  if (open_plugins(s) != 0) { /* keep the session so the caller can read ->panic */ }
+  return s;
+}
+
+void kbo_close(kbo_session *s) {
+  if (!s) return;
+  for (uint32_t j = 0; j < s->J; j++) heap_free(&s->jobs[j].tasks);
+  for (uint32_t q = 0; q < s->Q; q++) heap_free(&s->queues[q].jobs);
+  free(s->nodes); free(s->tasks); free(s->jobs); free(s->queues); free(s->compat);
+  free(s->tier_begin); free(s->plugins); free(s->decisions); free(s->bind_node); free(s->bind_order);
+  free(s);
+}
+
+/* actions/allocate/allocate.go:43-194 */
+int kbo_allocate(kbo_session *s) {
+  if (s->panic) return KBO_PANIC;
+  heap_t queues;
+  heap_init(&queues, queue_order_less, s);
+  for (uint32_t q = 0; q < s->Q; q++) { s->queues[q].has_jobs_heap = 0; s->queues[q].jobs.n = 0; }
+  for (uint32_t j = 0; j < s->J; j++) { s->jobs[j].tasks_init = 0; s->jobs[j].tasks.n = 0; }
+  /* allocate.go:50-65, ssn.Jobs iterated in ascending JobID (canonical) */
+  for (uint32_t j = 0; j < s->J; j++) {
+    o_job *job = &s->jobs[j];
+    if (!job->valid) continue;
+    if (job->queue >= s->Q) continue; /* queue not found */
+    heap_push(&queues, job->queue);
+    s->queues[job->queue].has_jobs_heap = 1;
+    heap_push(&s->queues[job->queue].jobs, j);
+  }
+  uint8_t *feas = (uint8_t *)malloc(s->N ? s->N : 1);
+  double *score = (double *)malloc(sizeof(double) * (s->N ? s->N : 1));
+  int rc = 0;
+  while (queues.n > 0) {
+    uint32_t q = heap_pop(&queues);
+    if (ssn_overused(s, q)) continue;                       /* allocate.go:95-98 */
+    o_queue *queue = &s->queues[q];
+    if (!queue->has_jobs_heap || queue->jobs.n == 0) continue; /* allocate.go:104-107 */
+    uint32_t j = heap_pop(&queue->jobs);
+    o_job *job = &s->jobs[j];
+    if (!job->tasks_init) {                                 /* allocate.go:110-123 */
+      job->tasks_init = 1;
+      for (uint32_t t = job->t0; t < job->t1; t++) {
+        if (s->tasks[t].status != KB_TASK_PENDING) continue;
+        if (res_is_empty(&s->tasks[t].resreq, s->R)) continue; /* BestEffort skipped on Resreq */
+        heap_push(&job->tasks, t);
+      }
+    }
+    while (job->tasks.n > 0) {                              /* allocate.go:129 */
+      uint32_t t = heap_pop(&job->tasks);
+      o_task *tk = &s->tasks[t];
+      eval_all_nodes(s, tk, 1, feas, score);                /* PredicateNodes + PrioritizeNodes */
+      s->evals += s->N;
+      s->popped++;
+      int best = -1;                                        /* SelectBestNode, canonical first max */
+      double maxScore = 0;
+      for (uint32_t n = 0; n < s->N; n++) {
+        if (!feas[n]) continue;
+        if (best < 0 || score[n] > maxScore) { best = (int)n; maxScore = score[n]; }
+      }
+      if (best < 0) break;                                  /* allocate.go:144-148 */
+      o_node *node = &s->nodes[best];
+      if (res_less_equal(&tk->init_resreq, &node->idle, s->R)) {          /* allocate.go:160-166 */
+        int e = ssn_allocate(s, t, (uint32_t)best);
+        if (e == KBO_PANIC) { rc = KBO_PANIC; goto done; }
+      } else {                                              /* allocate.go:167-183 (NodesFitDelta is diagnostic only) */
+        if (res_less_equal(&tk->init_resreq, &node->releasing, s->R)) {
+          int e = ssn_pipeline(s, t, (uint32_t)best);
+          if (e == KBO_PANIC) { rc = KBO_PANIC; goto done; }
+        }
+      }
+      if (ssn_job_ready(s, job) && job->tasks.n > 0) {      /* allocate.go:185-188 */
+        heap_push(&queue->jobs, j);
+        break;
+      }
+    }
+    heap_push(&queues, q);                                  /* allocate.go:192 */
+  }
+done:
+  free(feas); free(score);
+  heap_free(&queues);
+  return rc;
+}
+
+/* actions/backfill/backfill.go:40-71 (jobs ascending JobID, Pending tasks ascending UID, nodes ascending name) */
+int kbo_backfill(kbo_session *s) {
+  if (s->panic) return KBO_PANIC;
+  for (uint32_t j = 0; j < s->J; j++) {
+    o_job *job = &s->jobs[j];
+    if (!job->valid) continue;
+    for (uint32_t t = job->t0; t < job->t1; t++) {
+      o_task *tk = &s->tasks[t];
+      if (tk->status != KB_TASK_PENDING) continue;
+      if (!res_is_empty(&tk->init_resreq, s->R)) continue;
+      s->popped++;
+      for (uint32_t n = 0; n < s->N; n++) {
+        s->evals++;
+        if (!plugin_predicate(s, tk, &s->nodes[n])) continue;
+        int e = ssn_allocate(s, t, n);
+        if (e == KBO_PANIC) return KBO_PANIC;
+        if (e != 0) { /* backfill.go:61-64: Allocate failed -> status was already flipped; try the next node */ continue; }
+        break;
+      }
+    }
+  }
+  return 0;
+}
+
+/* matrix rows [t0,t1) against current node state (parity target of kb_eval_matrix) */
+int kbo_eval_matrix(kbo_session *s, uint32_t t0, uint32_t t1, uint32_t fit_mode, uint8_t *mask_bits, uint16_t *score_out) {
+  size_t rowb = ((size_t)s->N + 7) / 8;
+  uint8_t *feas = (uint8_t *)malloc(s->N ? s->N : 1);
+  double *score = (double *)malloc(sizeof(double) * (s->N ? s->N : 1));
+  for (uint32_t t = t0; t < t1; t++) {
+    eval_all_nodes(s, &s->tasks[t], (int)fit_mode, feas, score);
+    uint8_t *mrow = mask_bits + (size_t)(t - t0) * rowb;
+    memset(mrow, 0, rowb);
+    for (uint32_t n = 0; n < s->N; n++) {
+      if (feas[n]) mrow[n >> 3] |= (uint8_t)(1u << (n & 7));
+      double sc = feas[n] ? score[n] : 0.0;
+      score_out[(size_t)(t - t0) * s->N + n] = (uint16_t)sc;
+    }
+  }
+  free(feas); free(score);
+  return 0;
+}
+
+/* top-k per row: descending score, ascending node index (SelectBestNode generalised; SortNodes' order differs, see preempt) */
+int kbo_argmax_rows(kbo_session *s, uint32_t t0, uint32_t t1, uint32_t fit_mode, uint32_t k, uint32_t *out_node, uint16_t *out_score) {
+  uint8_t *feas = (uint8_t *)malloc(s->N ? s->N : 1);
+  double *score = (double *)malloc(sizeof(double) * (s->N ? s->N : 1));
+  uint8_t *used = (uint8_t *)malloc(s->N ? s->N : 1);
+  for (uint32_t t = t0; t < t1; t++) {
+    eval_all_nodes(s, &s->tasks[t], (int)fit_mode, feas, score);
+    memset(used, 0, s->N);
+    for (uint32_t i = 0; i < k; i++) {
+      int best = -1; double mx = 0;
+      for (uint32_t n = 0; n < s->N; n++) {
+        if (!feas[n] || used[n]) continue;
+        if (best < 0 || score[n] > mx) { best = (int)n; mx = score[n]; }
+      }
+      size_t o = (size_t)(t - t0) * k + i;
+      if (best < 0) { out_node[o] = KB_NONE; out_score[o] = 0; }
+      else { used[best] = 1; out_node[o] = (uint32_t)best; out_score[o] = (uint16_t)mx; }
+    }
+  }
+  free(feas); free(score); free(used);
+  return 0;
+}
+
+/* ---- getters ---- */
+uint64_t kbo_n_decisions(const kbo_session *s) { return s->n_dec; }
+void kbo_get_decisions(const kbo_session *s, kb_decision *out) { memcpy(out, s->decisions, sizeof(kb_decision) * s->n_dec); }
+uint64_t kbo_n_binds(const kbo_session *s) { return s->n_binds; }
+void kbo_get_binds(const kbo_session *s, uint32_t *task_node_out) { memcpy(task_node_out, s->bind_node, sizeof(uint32_t) * s->T); }
+void kbo_get_bind_order(const kbo_session *s, uint32_t *out) { memcpy(out, s->bind_order, sizeof(uint32_t) * s->n_binds); }
+uint64_t kbo_evals(const kbo_session *s) { return s->evals; }
+uint64_t kbo_popped(const kbo_session *s) { return s->popped; }
+int kbo_panicked(const kbo_session *s) { return s->panic; }
+void kbo_get_task_state(const kbo_session *s, uint8_t *status, uint32_t *node) {
+  for (uint32_t t = 0; t < s->T; t++) { if (status) status[t] = s->tasks[t].status; if (node) node[t] = s->tasks[t].node; }
+}
+void kbo_get_node_state(const kbo_session *s, double *idle, double *releasing, int64_t *nz_cpu, int64_t *nz_mem, int32_t *pod_cnt) {
+  for (uint32_t n = 0; n < s->N; n++) {
+    for (int d = 0; d < s->R; d++) {
+      if (idle) idle[(size_t)d * s->N + n] = s->nodes[n].idle.v[d];
+      if (releasing) releasing[(size_t)d * s->N + n] = s->nodes[n].releasing.v[d];
+    }
+    if (nz_cpu) nz_cpu[n] = s->nodes[n].nz_cpu;
+    if (nz_mem) nz_mem[n] = s->nodes[n].nz_mem;
+    if (pod_cnt) pod_cnt[n] = s->nodes[n].pod_cnt;
+  }
+}
+void kbo_get_shares(const kbo_session *s, double *job_share, double *queue_share, double *queue_deserved) {
+  if (job_share) for (uint32_t j = 0; j < s->J; j++) job_share[j] = s->jobs[j].drf_share;
+  if (queue_share) for (uint32_t q = 0; q < s->Q; q++) queue_share[q] = s->queues[q].share;
+  if (queue_deserved)
+    for (uint32_t q = 0; q < s->Q; q++)
+      for (int d = 0; d < s->R; d++) queue_deserved[(size_t)d * s->Q + q] = res_get(&s->queues[q].deserved, d);
+}
+void kbo_get_job_valid(const kbo_session *s, uint8_t *valid) { for (uint32_t j = 0; j < s->J; j++) valid[j] = (uint8_t)s->jobs[j].valid; }
+int32_t kbo_job_valid_num(const kbo_session *s, uint32_t j) { return job_valid_num(&s->jobs[j]); }
+int32_t kbo_job_ready_num(const kbo_session *s, uint32_t j) { return job_ready_num(&s->jobs[j]); }

@@ -1,0 +1,169 @@
+"""ctypes wrapper over oracle/libkboracle.so (kb_oracle.c) — test infrastructure, see kb_oracle.c header."""
+import ctypes as C
+import importlib
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+abi = importlib.import_module("kube-batch_amd.abi")   # the public ABI structs (include/kb_engine.h)
+
+
+def build(force: bool = False) -> str:
+    so = os.path.join(_HERE, "libkboracle.so")
+    src = os.path.join(_HERE, "kb_oracle.c")
+    hdr = os.path.join(_HERE, "..", "include", "kb_engine.h")
+    if force or not os.path.exists(so) or any(os.path.getmtime(f) > os.path.getmtime(so) for f in (src, hdr) if os.path.exists(f)):
+        subprocess.check_call(["make", "-C", _HERE, "-s", "-B" if force else "-s"])
+    return so
+
+
+class OracleRes(C.Structure):
+    """kbo_res: dense api.Resource + ScalarResources key mask."""
+    _fields_ = [("v", C.c_double * abi.KB_MAX_RES), ("mask", C.c_uint32), ("max_task_num", C.c_int32)]
+
+    @staticmethod
+    def make(cpu=0.0, mem=0.0, scalars=None):
+        """scalars: {dim(>=2): value} — a key present in the Go map, even with value 0."""
+        r = OracleRes()
+        r.v[0] = cpu
+        r.v[1] = mem
+        for d, val in (scalars or {}).items():
+            r.v[d] = val
+            r.mask |= 1 << (d - 2)
+        return r
+
+    def as_tuple(self, R):
+        return (self.v[0], self.v[1], {d: self.v[d] for d in range(2, R) if (self.mask >> (d - 2)) & 1})
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        so = build()
+        L = C.CDLL(so)
+        L.kbo_open.restype = C.c_void_p
+        L.kbo_open.argtypes = [C.POINTER(abi.Config), C.POINTER(abi.Snapshot), C.c_int]
+        for name in ("kbo_close", "kbo_allocate", "kbo_backfill"):
+            getattr(L, name).argtypes = [C.c_void_p]
+        L.kbo_allocate.restype = C.c_int
+        L.kbo_backfill.restype = C.c_int
+        for name in ("kbo_n_decisions", "kbo_n_binds", "kbo_evals", "kbo_popped"):
+            getattr(L, name).restype = C.c_uint64
+            getattr(L, name).argtypes = [C.c_void_p]
+        L.kbo_panicked.argtypes = [C.c_void_p]
+        L.kbo_share.restype = C.c_double
+        L.kbo_share.argtypes = [C.c_double, C.c_double]
+        L.kbo_res_multi.argtypes = [C.POINTER(OracleRes), C.c_double]
+        L.kbo_scorers.argtypes = [C.c_int64] * 4 + [C.POINTER(C.c_int64)] * 3
+        L.kbo_job_valid_num.argtypes = [C.c_void_p, C.c_uint32]
+        L.kbo_job_ready_num.argtypes = [C.c_void_p, C.c_uint32]
+        _LIB = L
+    return _LIB
+
+
+def _p(a, t):
+    return a.ctypes.data_as(C.POINTER(t)) if a is not None else C.POINTER(t)()
+
+
+class Oracle:
+    """One open session of the restated reference scheduler."""
+
+    def __init__(self, conf, snap, threads: int = 1):
+        self.L = lib()
+        self.snap = snap
+        cfg, self._keep = conf.to_abi()
+        self._abi_snap = snap.to_abi()
+        self.h = self.L.kbo_open(C.byref(cfg), C.byref(self._abi_snap), int(threads))
+        if not self.h:
+            raise RuntimeError("kbo_open failed")
+        if self.L.kbo_panicked(self.h):
+            raise RuntimeError("reference would panic in OnSessionOpen (Resource.Sub underflow)")
+
+    def close(self):
+        if self.h:
+            self.L.kbo_close(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def allocate(self):
+        rc = self.L.kbo_allocate(self.h)
+        if rc != 0:
+            raise RuntimeError(f"oracle allocate rc={rc} (reference would panic)")
+
+    def backfill(self):
+        rc = self.L.kbo_backfill(self.h)
+        if rc != 0:
+            raise RuntimeError(f"oracle backfill rc={rc}")
+
+    def run(self, actions):
+        for a in actions:
+            {"allocate": self.allocate, "backfill": self.backfill}[a]()
+
+    def decisions(self):
+        n = self.L.kbo_n_decisions(self.h)
+        arr = (abi.Decision * max(n, 1))()
+        self.L.kbo_get_decisions(C.c_void_p(self.h), arr)
+        return np.array([(d.task, d.node, d.kind) for d in arr[:n]], dtype=np.uint32).reshape(n, 3)
+
+    def binds(self):
+        out = np.empty(self.snap.n_tasks, np.uint32)
+        self.L.kbo_get_binds(C.c_void_p(self.h), _p(out, C.c_uint32))
+        return out
+
+    def bind_order(self):
+        n = self.L.kbo_n_binds(self.h)
+        out = np.empty(max(n, 1), np.uint32)
+        self.L.kbo_get_bind_order(C.c_void_p(self.h), _p(out, C.c_uint32))
+        return out[:n]
+
+    @property
+    def evals(self):
+        return int(self.L.kbo_evals(self.h))
+
+    @property
+    def popped(self):
+        return int(self.L.kbo_popped(self.h))
+
+    def task_state(self):
+        st = np.empty(self.snap.n_tasks, np.uint8)
+        nd = np.empty(self.snap.n_tasks, np.uint32)
+        self.L.kbo_get_task_state(C.c_void_p(self.h), _p(st, C.c_uint8), _p(nd, C.c_uint32))
+        return st, nd
+
+    def node_state(self):
+        R, N = self.snap.n_res, self.snap.n_nodes
+        idle = np.empty((R, N)); rel = np.empty((R, N))
+        nzc = np.empty(N, np.int64); nzm = np.empty(N, np.int64); cnt = np.empty(N, np.int32)
+        self.L.kbo_get_node_state(C.c_void_p(self.h), _p(idle, C.c_double), _p(rel, C.c_double),
+                                  _p(nzc, C.c_int64), _p(nzm, C.c_int64), _p(cnt, C.c_int32))
+        return idle, rel, nzc, nzm, cnt
+
+    def shares(self):
+        R, J, Q = self.snap.n_res, self.snap.n_jobs, self.snap.n_queues
+        js = np.empty(J); qs = np.empty(Q); des = np.empty((R, Q))
+        self.L.kbo_get_shares(C.c_void_p(self.h), _p(js, C.c_double), _p(qs, C.c_double), _p(des, C.c_double))
+        return js, qs, des
+
+    def eval_matrix(self, t0, t1, fit_mode=1):
+        N = self.snap.n_nodes
+        rowb = (N + 7) // 8
+        mask = np.zeros((t1 - t0, rowb), np.uint8)
+        score = np.zeros((t1 - t0, N), np.uint16)
+        self.L.kbo_eval_matrix(C.c_void_p(self.h), C.c_uint32(t0), C.c_uint32(t1), C.c_uint32(fit_mode),
+                               _p(mask, C.c_uint8), _p(score, C.c_uint16))
+        return mask, score
+
+    def argmax_rows(self, t0, t1, k, fit_mode=1):
+        nodes = np.empty((t1 - t0, k), np.uint32)
+        score = np.empty((t1 - t0, k), np.uint16)
+        self.L.kbo_argmax_rows(C.c_void_p(self.h), C.c_uint32(t0), C.c_uint32(t1), C.c_uint32(fit_mode), C.c_uint32(k),
+                               _p(nodes, C.c_uint32), _p(score, C.c_uint16))
+        return nodes, score

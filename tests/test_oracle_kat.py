@@ -1,0 +1,274 @@
+"""Pins the CPU oracle against the reference's own known-answer tests.
+
+Each test names the reference test whose table it restates (paths relative to /root/reference).
+Nothing here reads /root/reference at run time.
+"""
+import ctypes as C
+import importlib
+
+import numpy as np
+import pytest
+
+kbm = importlib.import_module("kube-batch_amd")
+abi = kbm.abi
+fixtures = importlib.import_module("kube-batch_amd.fixtures")
+snapmod = kbm.snapshot
+conf = kbm.conf
+
+S1, HP = 2, 3   # dims of "scalar.test/scalar1" and "hugepages-test"
+
+
+@pytest.fixture(scope="module")
+def L(oracle_mod):
+    lib = oracle_mod.lib()
+    lib.kbo_set_dims(4)
+    return lib
+
+
+def R(oracle_mod, cpu=0.0, mem=0.0, **sc):
+    m = {}
+    if "s1" in sc:
+        m[S1] = sc["s1"]
+    if "hp" in sc:
+        m[HP] = sc["hp"]
+    return oracle_mod.OracleRes.make(cpu, mem, m)
+
+
+def tup(r):
+    return r.as_tuple(4)
+
+
+# ---- pkg/scheduler/api/resource_info_test.go:27-58 TestNewResource (through the flattener's NewResource) ----
+def test_new_resource_milli_scaling():
+    v, mask, _ = snapmod._resource({"cpu": "4m", "memory": "2000", "scalar.test/scalar1": "1", "hugepages-test": "2"},
+                                   {"hugepages-test": 2, "scalar.test/scalar1": 3}, 4)
+    assert v.tolist() == [4.0, 2000.0, 2000.0, 1000.0] and mask == 0b11
+    v, mask, mt = snapmod._resource({}, {}, 2)
+    assert v.tolist() == [0.0, 0.0] and mask == 0 and mt == 0
+
+
+# ---- resource_info_test.go:60-100 TestResourceAddScalar is SetScalar on a map: covered by OracleRes.make ----
+
+# ---- resource_info_test.go:102-145 TestSetMaxResource ----
+def test_set_max_resource(L, oracle_mod):
+    r1, r2 = R(oracle_mod), R(oracle_mod, 4000, 2000, s1=1, hp=2)
+    L.kbo_res_set_max(C.byref(r1), C.byref(r2))
+    assert tup(r1) == (4000, 2000, {S1: 1, HP: 2})
+    r1, r2 = R(oracle_mod, 4000, 4000, s1=1, hp=2), R(oracle_mod, 4000, 2000, s1=4, hp=5)
+    L.kbo_res_set_max(C.byref(r1), C.byref(r2))
+    assert tup(r1) == (4000, 4000, {S1: 4, HP: 5})
+
+
+# ---- resource_info_test.go:147-186 TestIsZero ----
+def test_is_zero(L, oracle_mod):
+    assert L.kbo_res_is_zero(C.byref(R(oracle_mod)), 0) == 1
+    full = R(oracle_mod, 4000, 4000, s1=4, hp=5)
+    assert L.kbo_res_is_zero(C.byref(full), 0) == 0
+    assert L.kbo_res_is_zero(C.byref(full), S1) == 1
+
+
+# ---- resource_info_test.go:188-244 TestAddResource ----
+def test_add_resource(L, oracle_mod):
+    r1, r2 = R(oracle_mod), R(oracle_mod, 4000, 2000, s1=1, hp=2)
+    L.kbo_res_add(C.byref(r1), C.byref(r2))
+    assert tup(r1) == (4000, 2000, {S1: 1, HP: 2})
+    r1, r2 = R(oracle_mod, 4000, 4000, s1=1, hp=2), R(oracle_mod, 4000, 2000, s1=4, hp=5)
+    L.kbo_res_add(C.byref(r1), C.byref(r2))
+    assert tup(r1) == (8000, 6000, {S1: 5, HP: 7})
+    r1, r2 = R(oracle_mod, 4000, 4000, s1=1), R(oracle_mod, 4000, 2000, s1=4, hp=5)
+    L.kbo_res_add(C.byref(r1), C.byref(r2))
+    assert tup(r1) == (8000, 6000, {S1: 5, HP: 5})
+
+
+# ---- resource_info_test.go:246-304 TestLessEqual ----
+def test_less_equal(L, oracle_mod):
+    cases = [
+        (R(oracle_mod), R(oracle_mod, 4000, 2000, s1=1000, hp=2000), True),
+        (R(oracle_mod, 4000, 4000, s1=1000, hp=2000), R(oracle_mod, 2000, 2000, s1=4000, hp=5000), False),
+        (R(oracle_mod, 4, 4000, s1=1), R(oracle_mod), True),
+        (R(oracle_mod, 4000, 4000, s1=1000, hp=2000), R(oracle_mod, 8000, 8000, s1=4000, hp=5000), True),
+    ]
+    for a, b, exp in cases:
+        assert bool(L.kbo_res_less_equal(C.byref(a), C.byref(b))) is exp
+
+
+# ---- resource_info_test.go:306-350 TestSubResource ----
+def test_sub_resource(L, oracle_mod):
+    r1, r2 = R(oracle_mod, 4000, 2000, s1=1, hp=2), R(oracle_mod)
+    assert L.kbo_res_sub(C.byref(r1), C.byref(r2)) == 0
+    assert tup(r1) == (4000, 2000, {S1: 1, HP: 2})
+    r1, r2 = R(oracle_mod, 4000, 4000, s1=1000, hp=2000), R(oracle_mod, 3000, 2000, s1=500, hp=1000)
+    assert L.kbo_res_sub(C.byref(r1), C.byref(r2)) == 0
+    assert tup(r1) == (1000, 2000, {S1: 500, HP: 1000})
+    # resource_info.go:158: Sub panics unless rr.LessEqual(r)
+    r1, r2 = R(oracle_mod, 1000, 1000), R(oracle_mod, 3000, 1000)
+    assert L.kbo_res_sub(C.byref(r1), C.byref(r2)) == -100
+
+
+# ---- resource_info_test.go:352-419 TestLess ----
+def test_less(L, oracle_mod):
+    cases = [
+        (R(oracle_mod), R(oracle_mod), False),
+        (R(oracle_mod), R(oracle_mod, 4000, 2000, s1=1000, hp=2000), True),
+        (R(oracle_mod, 4000, 4000, s1=1000, hp=2000), R(oracle_mod, 8000, 8000, s1=4000, hp=5000), True),
+        (R(oracle_mod, 4000, 4000, s1=5000, hp=2000), R(oracle_mod, 8000, 8000, s1=4000, hp=5000), False),
+        (R(oracle_mod, 9000, 4000, s1=1000, hp=2000), R(oracle_mod, 8000, 8000, s1=4000, hp=5000), False),
+    ]
+    for a, b, exp in cases:
+        assert bool(L.kbo_res_less(C.byref(a), C.byref(b))) is exp
+
+
+# ---- pkg/scheduler/api/node_info_test.go:35-105 TestNodeInfo_AddPod (through the flattener's AddTask) ----
+def test_node_info_add_pod():
+    G = 10**9
+    snap = snapmod.flatten(
+        nodes=[snapmod.Node("n1", {"cpu": "8000m", "memory": "10G"})],
+        pods=[snapmod.Pod("c1", "p1", [{"cpu": "1000m", "memory": "1G"}], node_name="n1", phase="Running"),
+              snapmod.Pod("c1", "p2", [{"cpu": "2000m", "memory": "2G"}], node_name="n1", phase="Running")],
+        pod_groups=[], queues=[])
+    assert snap.node_idle[:, 0].tolist() == [5000.0, 7.0 * G]
+    assert snap.node_allocatable[:, 0].tolist() == [8000.0, 10.0 * G]
+    assert snap.node_pod_cnt[0] == 2
+    # "add 1 unknown pod": 1000m/2G on a 2000m/1G node -> AddTask errors, node unchanged
+    snap = snapmod.flatten(
+        nodes=[snapmod.Node("n2", {"cpu": "2000m", "memory": "1G"})],
+        pods=[snapmod.Pod("c2", "p1", [{"cpu": "1000m", "memory": "2G"}], node_name="n2", phase="Unknown")],
+        pod_groups=[], queues=[])
+    assert snap.node_idle[:, 0].tolist() == [2000.0, 1.0 * G] and snap.node_pod_cnt[0] == 0
+
+
+# ---- pkg/scheduler/api/pod_info_test.go:26-100 TestGetPodResourceRequest (init-container max rule) ----
+def test_pod_resource_request_init_containers():
+    G = 10**9
+    snap = snapmod.flatten(
+        nodes=[snapmod.Node("n1", {"cpu": "64", "memory": "64G", "pods": "10"})],
+        pods=[snapmod.Pod("ns", "a", [{"cpu": "1000m", "memory": "1G"}, {"cpu": "2000m", "memory": "1G"}], group_name="g"),
+              snapmod.Pod("ns", "b", [{"cpu": "1000m", "memory": "1G"}, {"cpu": "2000m", "memory": "1G"}], group_name="g",
+                          init_containers=[{"cpu": "2000m", "memory": "5G"}, {"cpu": "2000m", "memory": "1G"}])],
+        pod_groups=[snapmod.PodGroup("ns", "g")], queues=[snapmod.Queue("default")])
+    assert snap.task_init_resreq[:, 0].tolist() == [3000.0, 2.0 * G]
+    assert snap.task_init_resreq[:, 1].tolist() == [3000.0, 5.0 * G]
+    assert snap.task_resreq[:, 1].tolist() == [3000.0, 2.0 * G]        # pod_info_test.go:102-162 (without init containers)
+
+
+# ---- pkg/scheduler/util/scheduler_helper_test.go:24-92 TestSelectBestNode ----
+def test_select_best_node(L):
+    for scores, expected in (([1.0, 1.0, 2.0, 2.0], {2, 3}), ([1.0, 1.0, 3.0, 2.0, 2.0], {2})):
+        arr = (C.c_double * len(scores))(*scores)
+        idx = (C.c_int * len(scores))()
+        n = C.c_int()
+        best = L.kbo_select_best(arr, len(scores), idx, C.byref(n))
+        assert set(idx[: n.value]) == expected and best in expected
+        assert best == min(expected)        # canonical tie-break
+
+
+# ---- pkg/scheduler/actions/allocate/allocate_test.go:38-212 TestAllocate ----
+@pytest.mark.parametrize("case", range(2))
+def test_allocate_reference_cases(oracle_mod, case):
+    name, snap, expected = fixtures.allocate_cases()[case]
+    o = oracle_mod.Oracle(fixtures.allocate_test_tiers(), snap)
+    o.allocate()
+    assert snap.bind_map(o.binds()) == expected, name
+
+
+# ---- doc/usage/tutorial.md:297-330 proportion worked example ----
+def test_proportion_tutorial_example(oracle_mod):
+    Gi = 1 << 30
+    pods = []
+    for i in range(5):
+        pods.append(snapmod.Pod("q1", f"p{i}", [{"cpu": "1", "memory": "2Gi"}], group_name="j1"))
+    for i in range(10):
+        pods.append(snapmod.Pod("q2", f"p{i}", [{"cpu": "1", "memory": "2Gi"}], group_name="j2"))
+    snap = snapmod.flatten(
+        nodes=[snapmod.Node("n1", {"cpu": "6", "memory": "15Gi", "pods": "110"}),
+               snapmod.Node("n2", {"cpu": "3", "memory": "12Gi", "pods": "110"})],
+        pods=pods,
+        pod_groups=[snapmod.PodGroup("q1", "j1", queue="queue1"), snapmod.PodGroup("q2", "j2", queue="queue2")],
+        queues=[snapmod.Queue("queue1", 2), snapmod.Queue("queue2", 4)])
+    o = oracle_mod.Oracle(conf.load_scheduler_conf(), snap)
+    _, _, des = o.shares()
+    assert des[:, 0].tolist() == [3000.0, 9.0 * Gi]
+    assert des[:, 1].tolist() == [6000.0, 18.0 * Gi]
+
+
+# ---- SURVEY.md §8a hand-derived KAT from the vendored formulas (least_requested.go:31-58, most_requested.go:30-61,
+#      balanced_resource_allocation.go:35-79, non_zero.go:32-37) ----
+def test_scorer_hand_kat(L):
+    least, most, bal = C.c_int64(), C.c_int64(), C.c_int64()
+    ac, am = 4000, 8 << 30
+    L.kbo_scorers(1000, ac, 200 << 20, am, C.byref(least), C.byref(most), C.byref(bal))
+    assert (least.value, most.value, bal.value) == (8, 1, 7)
+    L.kbo_scorers(2000, ac, 400 << 20, am, C.byref(least), C.byref(most), C.byref(bal))
+    assert (least.value, bal.value) == (7, 5)
+    # capacity 0 and requested > capacity edges
+    L.kbo_scorers(10, 0, 10, 0, C.byref(least), C.byref(most), C.byref(bal))
+    assert (least.value, most.value, bal.value) == (0, 0, 0)
+    L.kbo_scorers(5000, 4000, 1, am, C.byref(least), C.byref(most), C.byref(bal))
+    assert (least.value, most.value, bal.value) == (4, 0, 0)     # cpu side 0, mem side 9/0; balanced 0 (fraction >= 1)
+
+
+# ---- BASELINE config 1: example/job.yaml on 3 nodes spreads 2/2/2 (SURVEY.md §8a KAT) ----
+def test_example_job_spread(oracle_mod):
+    cfg, snap = fixtures.example_job()
+    o = oracle_mod.Oracle(cfg, snap)
+    o.allocate()
+    binds = o.binds()
+    assert (binds != abi.KB_NONE).sum() == 6
+    assert sorted(np.bincount(binds, minlength=3).tolist()) == [2, 2, 2]
+    dec = o.decisions()
+    # first pod -> first node at score 15, second pod must leave it (12 < 15)
+    assert dec[0, 1] == 0 and dec[1, 1] == 1 and dec[2, 1] == 2
+    assert o.evals == 6 * 3
+
+
+def _go_heap_reference(keys, pushes):
+    """container/heap restated independently in Python (go1.13 src/container/heap/heap.go) for the sift KAT."""
+    items = []
+
+    def less(i, j):
+        return keys[items[i]] < keys[items[j]]
+
+    def up(j):
+        while True:
+            i = (j - 1) // 2 if j > 0 else 0
+            if i == j or not less(j, i):
+                break
+            items[i], items[j] = items[j], items[i]
+            j = i
+
+    def down(i0, n):
+        i = i0
+        while True:
+            j1 = 2 * i + 1
+            if j1 >= n or j1 < 0:
+                break
+            j = j1
+            if j1 + 1 < n and less(j1 + 1, j1):
+                j = j1 + 1
+            if not less(j, i):
+                break
+            items[i], items[j] = items[j], items[i]
+            i = j
+
+    for x in pushes:
+        items.append(x)
+        up(len(items) - 1)
+    out = []
+    while items:
+        n = len(items) - 1
+        items[0], items[n] = items[n], items[0]
+        down(0, n)
+        out.append(items.pop())
+    return out
+
+
+def test_heap_mechanics_with_duplicate_keys(L):
+    rng = np.random.RandomState(7)
+    for n in (1, 2, 3, 7, 64, 257):
+        keys = rng.randint(0, 5, size=n).astype(np.float64)     # many ties: pop order is decided by sift mechanics
+        pushes = rng.permutation(n).astype(np.uint32)
+        out = np.empty(n, np.uint32)
+        L.kbo_heap_order(keys.ctypes.data_as(C.POINTER(C.c_double)), pushes.ctypes.data_as(C.POINTER(C.c_uint32)), n,
+                         out.ctypes.data_as(C.POINTER(C.c_uint32)))
+        assert out.tolist() == _go_heap_reference(keys, pushes.tolist())
+        assert np.all(np.diff(keys[out]) >= 0)
