@@ -1,0 +1,894 @@
+// kb_engine.cpp — the C ABI of include/kb_engine.h over the HIP kernels of kb_kernels.hip.
+//
+// Round structure: the host order machine speculates the reference's task order for a window of W
+// tasks (assuming each gets a node, which only ever fails when a whole feasibility class has died — and that is
+// monotone inside one action), the device evaluates the window's mask+score matrix against the round-start node
+// state (K1), extracts per-row top-K candidates (K3) and commits the window sequentially with dirty-column repair
+// (K5).  A mis-speculation (no feasible node / Pipeline instead of Allocate) stops the commit kernel at that row;
+// the host rolls the order machine back to the round start, replays the confirmed prefix and re-plans.
+#include <hip/hip_runtime.h>
+
+#include <chrono>
+#include <cstdio>
+#include <functional>
+#include <map>
+#include <memory>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/kb_engine.h"
+#include "kb_device.h"
+#include "kb_host.hpp"
+
+using namespace kb;
+
+#define HIP_OK(expr)                                                                                      \
+  do {                                                                                                    \
+    hipError_t _e = (expr);                                                                               \
+    if (_e != hipSuccess) throw EngineError(KB_E_DEVICE, std::string(#expr) + ": " + hipGetErrorString(_e)); \
+  } while (0)
+
+namespace {
+
+double now_ms() {
+  return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+struct DevBuf {
+  void *p = nullptr;
+  size_t bytes = 0;
+  DevBuf() = default;
+  DevBuf(const DevBuf &) = delete;
+  DevBuf &operator=(const DevBuf &) = delete;
+  ~DevBuf() { release(); }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    bytes = 0;
+  }
+  void alloc(size_t n) {
+    release();
+    bytes = n ? n : 16;
+    HIP_OK(hipMalloc(&p, bytes));
+  }
+  template <typename T> T *as() const { return reinterpret_cast<T *>(p); }
+};
+
+template <typename T> void upload(DevBuf &b, const T *src, size_t n, hipStream_t s) {
+  b.alloc(n * sizeof(T));
+  if (n) HIP_OK(hipMemcpyAsync(b.p, src, n * sizeof(T), hipMemcpyHostToDevice, s));
+}
+
+// rows of a [rows][n] host matrix into a zero-padded [rows][np] device matrix
+template <typename T> void upload_padded(DevBuf &b, const T *src, size_t rows, size_t n, size_t np, hipStream_t s) {
+  std::vector<T> tmp(rows * np, T(0));
+  for (size_t r = 0; r < rows; r++) std::memcpy(&tmp[r * np], src + r * n, n * sizeof(T));
+  b.alloc(tmp.size() * sizeof(T));
+  HIP_OK(hipMemcpyAsync(b.p, tmp.data(), tmp.size() * sizeof(T), hipMemcpyHostToDevice, s));
+  HIP_OK(hipStreamSynchronize(s));
+}
+
+struct Timer {   // HIP-event pair on the engine stream
+  hipEvent_t a = nullptr, b = nullptr;
+  void init() {
+    HIP_OK(hipEventCreate(&a));
+    HIP_OK(hipEventCreate(&b));
+  }
+  void destroy() {
+    if (a) (void)hipEventDestroy(a);
+    if (b) (void)hipEventDestroy(b);
+    a = b = nullptr;
+  }
+};
+
+}  // namespace
+
+struct kb_engine {
+  std::string err;
+  int device = 0;
+  uint32_t window = 1024, topk = 16, flags = 0;
+  Policy pol;
+  hipStream_t stream = nullptr;
+  bool loaded = false;
+  HostSession hs;
+  KbDev dev{};
+  kb_stats stats{};
+  uint64_t round_no = 0;
+
+  // session buffers
+  DevBuf b_idle, b_rel, b_nzc, b_nzm, b_podcnt, b_acpu, b_amem, b_maxpods, b_ncls, b_nmask;
+  DevBuf b_tinit, b_tres, b_tnzc, b_tnzm, b_tcls, b_tactive, b_tresmask, b_tjob, b_tstatus, b_tnode, b_tbind, b_tcounted, b_compat;
+  DevBuf b_jbegin, b_jmin, b_jqueue, b_total, b_deserved, b_desmask, b_jalloc, b_jshare, b_qalloc, b_qshare, b_jready;
+  uint32_t total_mask = 0;
+  // round buffers
+  DevBuf b_rows, b_same, b_score, b_maskw, b_keys, b_decnode, b_deckind, b_result, b_dirty;
+  uint32_t round_cap = 0;
+  std::vector<uint32_t> h_rows, h_decnode, h_deckind;
+  std::vector<uint8_t> h_same;
+  uint32_t *h_result = nullptr;   // pinned [8]
+  std::vector<Timer> ev;          // event pool for per-launch timing
+  std::vector<kb_decision> decisions_all;   // decisions of the last multi-GPU round sequence
+
+  // multi-GPU round state
+  struct {
+    bool active = false;
+    uint32_t action = 0;
+    OrderMachine om, ckpt;
+    std::vector<uint8_t> dead;
+    std::vector<uint32_t> seq;
+    std::vector<uint32_t> bf_list;
+    size_t bf_pos = 0;
+    uint64_t spec_pops = 0;
+    bool finished = false;
+    DevBuf scratch_idle, scratch_rel, scratch_nzc, scratch_nzm, scratch_podcnt;
+  } mg;
+
+  ~kb_engine() {
+    for (auto &t : ev) t.destroy();
+    if (h_result) (void)hipHostFree(h_result);
+    if (stream) (void)hipStreamDestroy(stream);
+  }
+};
+
+static thread_local std::string g_create_err;
+
+namespace {
+
+Policy compile_policy(const kb_config *cfg) {
+  Policy p;
+  if (!cfg->tier_begin && cfg->n_tiers) throw EngineError(KB_E_INVALID, "tier_begin is NULL");
+  for (uint32_t t = 0; t < cfg->n_tiers; t++) {
+    for (uint32_t i = cfg->tier_begin[t]; i < cfg->tier_begin[t + 1]; i++) {
+      const kb_plugin_option &o = cfg->plugins[i];
+      switch (o.plugin) {
+        case KB_PLUGIN_PRIORITY:
+          if (o.enabled & KB_EN_JOB_ORDER) p.job_chain.push_back(KB_PLUGIN_PRIORITY);
+          if (o.enabled & KB_EN_TASK_ORDER) p.task_order_priority = true;
+          break;
+        case KB_PLUGIN_GANG:
+          p.has_gang = true;
+          if (o.enabled & KB_EN_JOB_ORDER) p.job_chain.push_back(KB_PLUGIN_GANG);
+          if (o.enabled & KB_EN_JOB_READY) p.gang_job_ready = true;
+          break;
+        case KB_PLUGIN_CONFORMANCE:   // registers evict filters only (conformance.go:41-63)
+          break;
+        case KB_PLUGIN_DRF:
+          p.has_drf = true;
+          if (o.enabled & KB_EN_JOB_ORDER) p.job_chain.push_back(KB_PLUGIN_DRF);
+          break;
+        case KB_PLUGIN_PREDICATES:
+          if (o.enabled & KB_EN_PREDICATE) p.pred_enabled = true;
+          if ((o.args_set & 7u) && (o.args[0] || o.args[1] || o.args[2]))
+            throw EngineError(KB_E_UNSUPPORTED, "predicates pressure checks must be folded into node classes by the caller; flags not supported");
+          break;
+        case KB_PLUGIN_PROPORTION:
+          p.has_proportion = true;
+          if (o.enabled & KB_EN_QUEUE_ORDER) p.queue_order_proportion = true;
+          break;
+        case KB_PLUGIN_NODEORDER:
+          if (o.enabled & KB_EN_NODE_ORDER) p.nodeorder_enabled = true;
+          if (o.args_set & 1u) p.wL = o.args[KB_ARG_NODEORDER_LEAST];       // nodeorder.go:119-129
+          if (o.args_set & 2u) p.wM = o.args[KB_ARG_NODEORDER_MOST];
+          if (o.args_set & 4u) p.wNA = o.args[KB_ARG_NODEORDER_NODEAFF];
+          if (o.args_set & 8u) p.wPA = o.args[KB_ARG_NODEORDER_PODAFF];
+          if (o.args_set & 16u) p.wB = o.args[KB_ARG_NODEORDER_BALANCED];
+          break;
+        default:
+          throw EngineError(KB_E_UNSUPPORTED, "unknown plugin id " + std::to_string(o.plugin));
+      }
+    }
+  }
+  if (p.wL < 0 || p.wM < 0 || p.wB < 0 || 10ll * ((long long)p.wL + p.wM + p.wB) > 65535)
+    throw EngineError(KB_E_UNSUPPORTED, "nodeorder weights must be >= 0 with 10*(least+most+balanced) <= 65535 (u16 score)");
+  return p;
+}
+
+template <typename K> uint32_t intern(std::map<K, uint32_t> &m, const K &k) {
+  auto it = m.find(k);
+  if (it != m.end()) return it->second;
+  uint32_t id = (uint32_t)m.size();
+  m.emplace(k, id);
+  return id;
+}
+
+void ensure_round_buffers(kb_engine *e, uint32_t rows) {
+  if (rows <= e->round_cap) return;
+  const size_t NP = e->dev.NP;
+  e->b_rows.alloc(sizeof(uint32_t) * rows);
+  e->b_same.alloc(rows);
+  e->b_score.alloc(sizeof(uint16_t) * (size_t)rows * NP);
+  e->b_maskw.alloc(sizeof(uint32_t) * (size_t)rows * (NP / 32));
+  e->b_keys.alloc(sizeof(unsigned long long) * (size_t)rows * KB_MAX_TOPK);
+  e->b_decnode.alloc(sizeof(uint32_t) * rows);
+  e->b_deckind.alloc(sizeof(uint32_t) * rows);
+  e->b_dirty.alloc(sizeof(uint32_t) * rows);
+  e->h_rows.resize(rows);
+  e->h_same.resize(rows);
+  e->h_decnode.resize(rows);
+  e->h_deckind.resize(rows);
+  e->round_cap = rows;
+}
+
+Timer &get_timer(kb_engine *e, size_t i) {
+  while (e->ev.size() <= i) {
+    Timer t;
+    t.init();
+    e->ev.push_back(t);
+  }
+  return e->ev[i];
+}
+
+// gang ballot + share reduction on the device, results mirrored to the host session
+void run_finalize(kb_engine *e) {
+  Timer &tm = get_timer(e, 3);
+  HIP_OK(hipEventRecord(tm.a, e->stream));
+  kb_launch_finalize(e->dev, e->b_jbegin.as<uint32_t>(), e->b_jmin.as<int>(), e->b_jqueue.as<uint32_t>(), e->pol.gang_job_ready ? 1 : 0,
+                     e->b_total.as<double>(), e->total_mask, e->b_deserved.as<double>(), e->b_desmask.as<uint32_t>(),
+                     e->b_jalloc.as<double>(), e->b_jshare.as<double>(), e->b_qalloc.as<double>(), e->b_qshare.as<double>(),
+                     e->b_jready.as<int>(), e->stream);
+  HIP_OK(hipEventRecord(tm.b, e->stream));
+  HostSession &hs = e->hs;
+  HIP_OK(hipMemcpyAsync(hs.job_alloc.data(), e->b_jalloc.p, sizeof(double) * hs.job_alloc.size(), hipMemcpyDeviceToHost, e->stream));
+  HIP_OK(hipMemcpyAsync(hs.job_share.data(), e->b_jshare.p, sizeof(double) * hs.job_share.size(), hipMemcpyDeviceToHost, e->stream));
+  HIP_OK(hipMemcpyAsync(hs.queue_alloc.data(), e->b_qalloc.p, sizeof(double) * hs.queue_alloc.size(), hipMemcpyDeviceToHost, e->stream));
+  HIP_OK(hipMemcpyAsync(hs.queue_share.data(), e->b_qshare.p, sizeof(double) * hs.queue_share.size(), hipMemcpyDeviceToHost, e->stream));
+  HIP_OK(hipMemcpyAsync(hs.job_ready.data(), e->b_jready.p, sizeof(int32_t) * hs.job_ready.size(), hipMemcpyDeviceToHost, e->stream));
+  HIP_OK(hipMemcpyAsync(hs.t_status.data(), e->b_tstatus.p, hs.T, hipMemcpyDeviceToHost, e->stream));
+  HIP_OK(hipMemcpyAsync(hs.t_node.data(), e->b_tnode.p, sizeof(uint32_t) * hs.T, hipMemcpyDeviceToHost, e->stream));
+  HIP_OK(hipStreamSynchronize(e->stream));
+  float ms = 0;
+  HIP_OK(hipEventElapsedTime(&ms, tm.a, tm.b));
+  e->stats.reduce_ms += ms;
+  // queues without a job in the session keep share 0 (no queueOpts entry)
+  for (uint32_t q = 0; q < hs.Q; q++)
+    if (!hs.queue_has_attr[q]) hs.queue_share[q] = 0.0;
+}
+
+KbRound make_round(kb_engine *e, uint32_t n_rows, int fit_mode, bool backfill) {
+  KbRound r{};
+  r.rows = e->b_rows.as<uint32_t>();
+  r.row_task0 = 0;
+  r.same_prev = e->b_same.as<uint8_t>();
+  r.n_rows = n_rows;
+  r.fit_mode = fit_mode;
+  r.score = e->b_score.as<uint16_t>();
+  r.maskw = e->b_maskw.as<uint32_t>();
+  r.keys = e->b_keys.as<unsigned long long>();
+  r.topk = e->topk;
+  r.dec_node = e->b_decnode.as<uint32_t>();
+  r.dec_kind = e->b_deckind.as<uint32_t>();
+  r.result = e->b_result.as<uint32_t>();
+  r.dirty_list = e->b_dirty.as<uint32_t>();
+  r.use_rows = 1;
+  r.backfill = backfill ? 1 : 0;
+  r.delta = nullptr;
+  r.own_row0 = r.own_row1 = 0;
+  return r;
+}
+
+// one single-GPU round over e->h_rows[0..n): matrix -> arg-max -> commit; returns n_done / reason
+void run_round(kb_engine *e, uint32_t n, int fit_mode, bool backfill, uint32_t &n_done, uint32_t &reason) {
+  ensure_round_buffers(e, n);
+  HostSession &hs = e->hs;
+  for (uint32_t i = 0; i < n; i++)
+    e->h_same[i] = (i > 0 && hs.t_row_shape[e->h_rows[i]] == hs.t_row_shape[e->h_rows[i - 1]]) ? 1 : 0;
+  HIP_OK(hipMemcpyAsync(e->b_rows.p, e->h_rows.data(), sizeof(uint32_t) * n, hipMemcpyHostToDevice, e->stream));
+  HIP_OK(hipMemcpyAsync(e->b_same.p, e->h_same.data(), n, hipMemcpyHostToDevice, e->stream));
+  KbDev d = e->dev;
+  if (backfill) d.score_enabled = 0;   // backfill.go:50-66 takes the first node that passes the predicates: all scores tie
+  KbRound r = make_round(e, n, fit_mode, backfill);
+  Timer &t1 = get_timer(e, 0), &t3 = get_timer(e, 1), &t5 = get_timer(e, 2);
+  HIP_OK(hipEventRecord(t1.a, e->stream));
+  kb_launch_matrix(d, r, e->stream);
+  HIP_OK(hipEventRecord(t1.b, e->stream));
+  HIP_OK(hipEventRecord(t3.a, e->stream));
+  if (e->topk) kb_launch_argmax(d, r, e->stream);
+  else r.keys = nullptr;
+  HIP_OK(hipEventRecord(t3.b, e->stream));
+  HIP_OK(hipEventRecord(t5.a, e->stream));
+  kb_launch_commit(d, r, e->stream);
+  HIP_OK(hipEventRecord(t5.b, e->stream));
+  HIP_OK(hipMemcpyAsync(e->h_result, e->b_result.p, sizeof(uint32_t) * 8, hipMemcpyDeviceToHost, e->stream));
+  HIP_OK(hipMemcpyAsync(e->h_decnode.data(), e->b_decnode.p, sizeof(uint32_t) * n, hipMemcpyDeviceToHost, e->stream));
+  HIP_OK(hipMemcpyAsync(e->h_deckind.data(), e->b_deckind.p, sizeof(uint32_t) * n, hipMemcpyDeviceToHost, e->stream));
+  HIP_OK(hipStreamSynchronize(e->stream));
+  HIP_OK(hipGetLastError());
+  float ms = 0;
+  HIP_OK(hipEventElapsedTime(&ms, t1.a, t1.b));
+  e->stats.matrix_ms += ms;
+  e->stats.matrix_launches += 1;
+  e->stats.matrix_evals += (uint64_t)n * hs.N;
+  HIP_OK(hipEventElapsedTime(&ms, t3.a, t3.b));
+  e->stats.argmax_ms += ms;
+  HIP_OK(hipEventElapsedTime(&ms, t5.a, t5.b));
+  e->stats.commit_ms += ms;
+  n_done = e->h_result[0];
+  reason = e->h_result[1];
+  e->stats.row_fallbacks += e->h_result[3];
+  e->stats.rounds += 1;
+  e->round_no += 1;
+}
+
+void check_aggregates(kb_engine *e, const OrderMachine &om) {
+  // the host's running drf / proportion / gang aggregates must equal the device reduction bit for bit
+  const HostSession &hs = e->hs;
+  for (size_t i = 0; i < hs.job_ready.size(); i++)
+    if (om.ready[i] != hs.job_ready[i]) throw EngineError(KB_E_INTERNAL, "gang ready count diverged from the device ballot at job " + std::to_string(i));
+  if (e->pol.has_drf)
+    for (size_t i = 0; i < hs.job_share.size(); i++)
+      if (om.jshare[i] != hs.job_share[i]) throw EngineError(KB_E_INTERNAL, "drf share diverged from the device reduction at job " + std::to_string(i));
+  if (e->pol.has_proportion)
+    for (uint32_t q = 0; q < hs.Q; q++)
+      if (hs.queue_has_attr[q] && om.qshare[q] != hs.queue_share[q])
+        throw EngineError(KB_E_INTERNAL, "proportion share diverged from the device reduction at queue " + std::to_string(q));
+}
+
+int guarded(kb_engine *e, const std::function<void()> &fn) {
+  try {
+    if (e) HIP_OK(hipSetDevice(e->device));
+    fn();
+    return KB_OK;
+  } catch (const EngineError &ex) {
+    if (e) e->err = ex.what(); else g_create_err = ex.what();
+    return ex.code;
+  } catch (const std::bad_alloc &) {
+    if (e) e->err = "out of host memory"; else g_create_err = "out of host memory";
+    return KB_E_NOMEM;
+  } catch (const std::exception &ex) {
+    if (e) e->err = ex.what(); else g_create_err = ex.what();
+    return KB_E_INTERNAL;
+  } catch (...) {
+    if (e) e->err = "unknown error"; else g_create_err = "unknown error";
+    return KB_E_INTERNAL;
+  }
+}
+}  // namespace
+
+extern "C" {
+
+const char *kb_last_error(const kb_engine *e) { return e ? e->err.c_str() : g_create_err.c_str(); }
+
+int kb_engine_create(const kb_config *cfg, kb_engine **out) {
+  if (!cfg || !out) { g_create_err = "null argument"; return KB_E_INVALID; }
+  *out = nullptr;
+  kb_engine *e = nullptr;
+  int rc = guarded(nullptr, [&]() {
+    if (cfg->version != KB_ABI_VERSION) throw EngineError(KB_E_INVALID, "ABI version mismatch");
+    std::unique_ptr<kb_engine> eng(new kb_engine());
+    eng->pol = compile_policy(cfg);
+    eng->device = cfg->device;
+    if (cfg->window) eng->window = cfg->window;
+    if (cfg->topk) eng->topk = cfg->topk > KB_MAX_TOPK ? KB_MAX_TOPK : cfg->topk;
+    eng->flags = cfg->flags;
+    int ndev = 0;
+    hipError_t he = hipGetDeviceCount(&ndev);
+    if (he != hipSuccess || ndev <= 0)
+      throw EngineError(KB_E_DEVICE, "no HIP device visible: the engine has no CPU fallback (the stock Go action must handle this cycle)");
+    if (cfg->device < 0 || cfg->device >= ndev) throw EngineError(KB_E_INVALID, "device ordinal out of range");
+    HIP_OK(hipSetDevice(cfg->device));
+    HIP_OK(hipStreamCreateWithFlags(&eng->stream, hipStreamNonBlocking));
+    HIP_OK(hipHostMalloc((void **)&eng->h_result, sizeof(uint32_t) * 8, hipHostMallocDefault));
+    eng->b_result.alloc(sizeof(uint32_t) * 8);
+    e = eng.release();
+  });
+  if (rc == KB_OK) *out = e;
+  return rc;
+}
+
+void kb_engine_destroy(kb_engine *e) {
+  if (!e) return;
+  (void)hipSetDevice(e->device);
+  delete e;
+}
+
+int kb_session_load(kb_engine *e, const kb_snapshot *sn) {
+  if (!e) return KB_E_INVALID;
+  return guarded(e, [&]() {
+    if (!sn) throw EngineError(KB_E_INVALID, "snapshot is NULL");
+    if (sn->version != KB_ABI_VERSION) throw EngineError(KB_E_INVALID, "snapshot ABI version mismatch");
+    if (sn->n_res < 2 || sn->n_res > KB_MAX_RES) throw EngineError(KB_E_INVALID, "n_res out of range");
+    e->loaded = false;
+    e->mg.active = false;
+    HostSession &hs = e->hs;
+    hs = HostSession();
+    const int R = hs.R = (int)sn->n_res;
+    const uint32_t N = hs.N = sn->n_nodes, T = hs.T = sn->n_tasks, J = hs.J = sn->n_jobs, Q = hs.Q = sn->n_queues;
+    const uint32_t NP = ((N + KB_NODE_PAD - 1) / KB_NODE_PAD) * KB_NODE_PAD + (N == 0 ? KB_NODE_PAD : 0);
+    hipStream_t s = e->stream;
+
+    // ---- validation of the exact envelope ----
+    for (uint32_t n = 0; n < N; n++) {
+      if (sn->node_alloc_cpu[n] < 0 || sn->node_alloc_mem[n] < 0 || sn->node_nz_cpu[n] < 0 || sn->node_nz_mem[n] < 0)
+        throw EngineError(KB_E_INVALID, "negative node quantity");
+      if (sn->node_alloc_cpu[n] >= (1ll << 48) || sn->node_alloc_mem[n] >= (1ll << 48) || sn->node_nz_cpu[n] >= (1ll << 48) || sn->node_nz_mem[n] >= (1ll << 48))
+        throw EngineError(KB_E_UNSUPPORTED, "node quantity >= 2^48: exact integer scoring not guaranteed");
+    }
+    hs.t_res.assign(sn->task_resreq, sn->task_resreq + (size_t)R * T);
+    hs.t_init.assign(sn->task_init_resreq, sn->task_init_resreq + (size_t)R * T);
+    hs.t_resmask.assign(T, 0);
+    if (sn->task_scalar_mask) hs.t_resmask.assign(sn->task_scalar_mask, sn->task_scalar_mask + T);
+    // a dense value under an absent key reads 0 (Go map semantics)
+    for (uint32_t t = 0; t < T; t++)
+      for (int d = 2; d < R; d++)
+        if (!((hs.t_resmask[t] >> (d - 2)) & 1u)) hs.t_res[(size_t)d * T + t] = 0.0;
+    hs.t_job.assign(sn->task_job, sn->task_job + T);
+    hs.t_cls.assign(T, 0);
+    if (sn->task_class) hs.t_cls.assign(sn->task_class, sn->task_class + T);
+    hs.t_prio.assign(sn->task_priority, sn->task_priority + T);
+    hs.t_creation.assign(sn->task_creation, sn->task_creation + T);
+    hs.t_status.assign(sn->task_status, sn->task_status + T);
+    hs.t_node.assign(T, KB_NONE);
+    if (sn->task_node) hs.t_node.assign(sn->task_node, sn->task_node + T);
+    hs.job_begin.assign(sn->job_task_begin, sn->job_task_begin + J + 1);
+    hs.job_queue.assign(sn->job_queue, sn->job_queue + J);
+    hs.job_min.assign(sn->job_min_available, sn->job_min_available + J);
+    hs.job_prio.assign(sn->job_priority, sn->job_priority + J);
+    hs.job_creation.assign(sn->job_creation, sn->job_creation + J);
+    hs.queue_weight.assign(sn->queue_weight, sn->queue_weight + Q);
+    hs.queue_creation.assign(Q, 0);
+    if (sn->queue_creation) hs.queue_creation.assign(sn->queue_creation, sn->queue_creation + Q);
+    if (hs.job_begin[0] != 0 || hs.job_begin[J] != T) throw EngineError(KB_E_INVALID, "job_task_begin must cover [0, n_tasks)");
+    for (uint32_t j = 0; j < J; j++) {
+      if (hs.job_begin[j] > hs.job_begin[j + 1]) throw EngineError(KB_E_INVALID, "job_task_begin not monotone");
+      for (uint32_t t = hs.job_begin[j]; t < hs.job_begin[j + 1]; t++)
+        if (hs.t_job[t] != j) throw EngineError(KB_E_INVALID, "tasks must be grouped by job in canonical order");
+    }
+    std::vector<uint32_t> t_active(T, 3u);
+    hs.t_res_empty.assign(T, 0);
+    hs.t_init_empty.assign(T, 0);
+    std::map<std::vector<double>, uint32_t> feas_ids, row_ids;
+    hs.t_feas_shape.assign(T, 0);
+    hs.t_row_shape.assign(T, 0);
+    std::vector<double> key;
+    for (uint32_t t = 0; t < T; t++) {
+      if (hs.t_status[t] > KB_TASK_UNKNOWN) throw EngineError(KB_E_INVALID, "bad task status");
+      if (sn->task_nz_cpu[t] < 0 || sn->task_nz_mem[t] < 0 || sn->task_nz_cpu[t] >= (1ll << 48) || sn->task_nz_mem[t] >= (1ll << 48))
+        throw EngineError(KB_E_UNSUPPORTED, "task non-zero request out of the exact range");
+      Res rq, in;
+      rq.mask = hs.t_resmask[t];
+      for (int d = 0; d < R; d++) {
+        rq.v[d] = hs.t_res[(size_t)d * T + t];
+        in.v[d] = hs.t_init[(size_t)d * T + t];
+        if (rq.v[d] < 0 || in.v[d] < 0) throw EngineError(KB_E_INVALID, "negative request");
+        // api/pod_info.go:53-62: InitResreq = max(sum of containers, every init container) >= Resreq per dimension;
+        // without it ssn.Allocate's AddTask could fail after the status flip (session.go:243 vs :255)
+        if (in.v[d] < rq.v[d]) throw EngineError(KB_E_UNSUPPORTED, "InitResreq < Resreq");
+        if (d >= 2 && in.v[d] != 0.0) in.setk(d);
+        if (d >= 2 && in.v[d] > kMinMilliScalar) t_active[t] |= 1u << d;
+      }
+      in.mask |= rq.mask;
+      hs.t_res_empty[t] = res_is_empty(rq, R);
+      hs.t_init_empty[t] = res_is_empty(in, R);
+      if (hs.t_init_empty[t] && hs.t_status[t] == KB_TASK_PENDING)
+        for (int d = 0; d < R; d++)
+          if (rq.v[d] != 0.0)
+            throw EngineError(KB_E_UNSUPPORTED, "BestEffort task with a non-zero sub-epsilon request (backfill's AddTask retry path)");
+      key.assign(in.v, in.v + R);
+      key.push_back((double)hs.t_cls[t]);
+      hs.t_feas_shape[t] = intern(feas_ids, key);
+      key.push_back((double)sn->task_nz_cpu[t]);
+      key.push_back((double)sn->task_nz_mem[t]);
+      hs.t_row_shape[t] = intern(row_ids, key);
+    }
+    hs.n_feas_shapes = (uint32_t)feas_ids.size();
+
+    // ---- plugin OnSessionOpen state ----
+    // drf.go:60-64 / proportion.go:58-62: total = sum of Allocatable over ssn.Nodes (ascending node name)
+    hs.total = Res();
+    std::vector<uint32_t> nmask(NP, 0);
+    for (uint32_t n = 0; n < N; n++) {
+      Res a;
+      a.mask = sn->node_scalar_mask ? sn->node_scalar_mask[n] : 0;
+      nmask[n] = a.mask;
+      for (int d = 0; d < R; d++) a.v[d] = (d < 2 || a.has(d)) ? sn->node_allocatable[(size_t)d * N + n] : 0.0;
+      res_add(hs.total, a, R);
+    }
+    // proportion.go:65-154 water-filling over the queues that own a job, ascending QueueID
+    hs.deserved.assign(Q, Res());
+    hs.queue_has_attr.assign(Q, 0);
+    std::vector<Res> request(Q), allocated(Q);
+    for (uint32_t j = 0; j < J; j++) {
+      uint32_t q = hs.job_queue[j];
+      if (q >= Q) continue;
+      hs.queue_has_attr[q] = 1;
+      for (uint32_t t = hs.job_begin[j]; t < hs.job_begin[j + 1]; t++) {
+        int st = hs.t_status[t];
+        bool alloc_st = st == KB_TASK_BOUND || st == KB_TASK_BINDING || st == KB_TASK_RUNNING || st == KB_TASK_ALLOCATED;
+        if (!alloc_st && st != KB_TASK_PENDING) continue;
+        Res rq;
+        rq.mask = hs.t_resmask[t];
+        for (int d = 0; d < R; d++) rq.v[d] = hs.t_res[(size_t)d * T + t];
+        res_add(request[q], rq, R);
+        if (alloc_st) res_add(allocated[q], rq, R);
+      }
+    }
+    if (e->pol.has_proportion) {
+      Res remaining = hs.total;
+      std::vector<uint8_t> meet(Q, 0);
+      for (;;) {
+        int32_t totalWeight = 0;
+        for (uint32_t q = 0; q < Q; q++)
+          if (hs.queue_has_attr[q] && !meet[q]) totalWeight += hs.queue_weight[q];
+        if (totalWeight == 0) break;
+        Res increasedDeserved, decreasedDeserved;
+        for (uint32_t q = 0; q < Q; q++) {
+          if (!hs.queue_has_attr[q] || meet[q]) continue;
+          Res oldDeserved = hs.deserved[q];
+          Res part = remaining;
+          res_multi(part, (double)hs.queue_weight[q] / (double)totalWeight, R);
+          res_add(hs.deserved[q], part, R);
+          if (res_less(request[q], hs.deserved[q], R)) {
+            hs.deserved[q] = helpers_min(hs.deserved[q], request[q], R);
+            meet[q] = 1;
+          }
+          Res inc, dec;
+          res_diff(hs.deserved[q], oldDeserved, inc, dec, R);
+          res_add(increasedDeserved, inc, R);
+          res_add(decreasedDeserved, dec, R);
+        }
+        if (!res_sub(remaining, increasedDeserved, R))
+          throw EngineError(KB_E_UNSUPPORTED, "proportion water-filling underflow (the reference would panic in Resource.Sub)");
+        res_add(remaining, decreasedDeserved, R);
+        if (res_is_empty(remaining, R)) break;
+      }
+    }
+
+    // ---- device upload ----
+    KbDev &d = e->dev;
+    d = KbDev{};
+    d.R = R; d.N = N; d.NP = NP; d.T = T; d.J = J; d.Q = Q;
+    upload_padded(e->b_idle, sn->node_idle, R, N, NP, s);
+    upload_padded(e->b_rel, sn->node_releasing, R, N, NP, s);
+    upload_padded(e->b_nzc, sn->node_nz_cpu, 1, N, NP, s);
+    upload_padded(e->b_nzm, sn->node_nz_mem, 1, N, NP, s);
+    upload_padded(e->b_podcnt, sn->node_pod_cnt, 1, N, NP, s);
+    upload_padded(e->b_acpu, sn->node_alloc_cpu, 1, N, NP, s);
+    upload_padded(e->b_amem, sn->node_alloc_mem, 1, N, NP, s);
+    upload_padded(e->b_maxpods, sn->node_max_pods, 1, N, NP, s);
+    std::vector<uint32_t> ncls(NP, 0);
+    if (sn->node_class) std::memcpy(ncls.data(), sn->node_class, sizeof(uint32_t) * N);
+    upload(e->b_ncls, ncls.data(), NP, s);
+    upload(e->b_nmask, nmask.data(), NP, s);
+    upload(e->b_tinit, hs.t_init.data(), (size_t)R * T, s);
+    upload(e->b_tres, hs.t_res.data(), (size_t)R * T, s);
+    upload(e->b_tnzc, sn->task_nz_cpu, T, s);
+    upload(e->b_tnzm, sn->task_nz_mem, T, s);
+    upload(e->b_tcls, hs.t_cls.data(), T, s);
+    upload(e->b_tactive, t_active.data(), T, s);
+    upload(e->b_tresmask, hs.t_resmask.data(), T, s);
+    upload(e->b_tjob, hs.t_job.data(), T, s);
+    upload(e->b_tstatus, hs.t_status.data(), T, s);
+    upload(e->b_tnode, hs.t_node.data(), T, s);
+    std::vector<uint32_t> bind(T, KB_NONE);
+    upload(e->b_tbind, bind.data(), T, s);
+    std::vector<uint8_t> counted(T, 0);
+    for (uint32_t t = 0; t < T; t++) {
+      int st = hs.t_status[t];
+      counted[t] = (st == KB_TASK_BOUND || st == KB_TASK_BINDING || st == KB_TASK_RUNNING || st == KB_TASK_ALLOCATED) ? 1 : 0;   // drf.go:71-77
+    }
+    upload(e->b_tcounted, counted.data(), T, s);
+    d.compat = nullptr;
+    d.n_nc = sn->n_node_classes ? sn->n_node_classes : 1;
+    if (sn->class_compat) {
+      size_t nb = ((size_t)sn->n_task_classes * sn->n_node_classes + 7) / 8;
+      for (uint32_t t = 0; t < T; t++)
+        if (hs.t_cls[t] >= sn->n_task_classes) throw EngineError(KB_E_INVALID, "task class out of range");
+      for (uint32_t n = 0; n < N; n++)
+        if (ncls[n] >= sn->n_node_classes) throw EngineError(KB_E_INVALID, "node class out of range");
+      upload(e->b_compat, sn->class_compat, nb, s);
+      d.compat = e->b_compat.as<uint8_t>();
+    }
+    upload(e->b_jbegin, hs.job_begin.data(), J + 1, s);
+    upload(e->b_jmin, hs.job_min.data(), J, s);
+    upload(e->b_jqueue, hs.job_queue.data(), J, s);
+    upload(e->b_total, hs.total.v, KB_MAX_RES, s);
+    e->total_mask = hs.total.mask;
+    std::vector<double> des((size_t)R * (Q ? Q : 1), 0.0);
+    std::vector<uint32_t> desmask(Q ? Q : 1, 0);
+    for (uint32_t q = 0; q < Q; q++) {
+      desmask[q] = hs.deserved[q].mask;
+      for (int dd = 0; dd < R; dd++) des[(size_t)dd * Q + q] = hs.deserved[q].get(dd);
+    }
+    upload(e->b_deserved, des.data(), des.size(), s);
+    upload(e->b_desmask, desmask.data(), desmask.size(), s);
+    hs.job_alloc.assign((size_t)J * R, 0.0);
+    hs.job_share.assign(J, 0.0);
+    hs.queue_alloc.assign((size_t)Q * R, 0.0);
+    hs.queue_share.assign(Q, 0.0);
+    hs.job_ready.assign(J, 0);
+    e->b_jalloc.alloc(sizeof(double) * (size_t)(J ? J : 1) * R);
+    e->b_jshare.alloc(sizeof(double) * (J ? J : 1));
+    e->b_qalloc.alloc(sizeof(double) * (size_t)(Q ? Q : 1) * R);
+    e->b_qshare.alloc(sizeof(double) * (Q ? Q : 1));
+    e->b_jready.alloc(sizeof(int) * (J ? J : 1));
+    HIP_OK(hipStreamSynchronize(s));
+
+    d.idle = e->b_idle.as<double>(); d.rel = e->b_rel.as<double>();
+    d.nzc = e->b_nzc.as<long long>(); d.nzm = e->b_nzm.as<long long>(); d.podcnt = e->b_podcnt.as<int>();
+    d.acpu = e->b_acpu.as<long long>(); d.amem = e->b_amem.as<long long>();
+    d.maxpods = e->b_maxpods.as<int>(); d.ncls = e->b_ncls.as<uint32_t>(); d.nmask = e->b_nmask.as<uint32_t>();
+    d.t_init = e->b_tinit.as<double>(); d.t_res = e->b_tres.as<double>();
+    d.t_nzc = e->b_tnzc.as<long long>(); d.t_nzm = e->b_tnzm.as<long long>();
+    d.t_cls = e->b_tcls.as<uint32_t>(); d.t_active = e->b_tactive.as<uint32_t>(); d.t_resmask = e->b_tresmask.as<uint32_t>();
+    d.t_job = e->b_tjob.as<uint32_t>(); d.t_status = e->b_tstatus.as<uint8_t>(); d.t_node = e->b_tnode.as<uint32_t>();
+    d.t_bind = e->b_tbind.as<uint32_t>(); d.t_counted = e->b_tcounted.as<uint8_t>();
+    d.wL = e->pol.wL; d.wM = e->pol.wM; d.wB = e->pol.wB;
+    d.pred_enabled = e->pol.pred_enabled ? 1 : 0;
+    d.score_enabled = e->pol.nodeorder_enabled ? 1 : 0;
+    e->round_cap = 0;
+    e->stats = kb_stats{};
+    e->round_no = 0;
+    // initial drf / proportion / gang aggregates come from the device reduction (K2+K4)
+    run_finalize(e);
+    e->stats.reduce_ms = 0;
+    e->loaded = true;
+  });
+}
+
+int kb_run_allocate(kb_engine *e, kb_decision *out, uint64_t cap, uint64_t *n_out) {
+  if (!e) return KB_E_INVALID;
+  return guarded(e, [&]() {
+    if (!e->loaded) throw EngineError(KB_E_STATE, "kb_session_load must precede kb_run_allocate");
+    const double t_start = now_ms();
+    HostSession &hs = e->hs;
+    std::vector<kb_decision> decs;
+    OrderMachine om;
+    double t0 = now_ms();
+    om.init_allocate(&hs, &e->pol);
+    double host_ms = now_ms() - t0;
+    std::vector<uint8_t> dead(hs.n_feas_shapes ? hs.n_feas_shapes : 1, 0);
+    const uint32_t W = e->window;
+    ensure_round_buffers(e, W);
+    uint64_t popped = 0;
+    for (;;) {
+      t0 = now_ms();
+      OrderMachine ckpt = om;   // roll-back point for a mis-speculated round
+      uint32_t n = 0;
+      uint64_t spec_pops = 0;
+      uint32_t t;
+      while (n < W && om.next(t)) {
+        spec_pops++;
+        if (dead[hs.t_feas_shape[t]]) { om.report(Outcome::NoFeasibleNode); continue; }   // known: feasibility only shrinks inside one action
+        e->h_rows[n++] = t;
+        om.report(Outcome::Allocated);
+      }
+      host_ms += now_ms() - t0;
+      if (n == 0) { popped += spec_pops; break; }
+      uint32_t n_done = 0, reason = 0;
+      run_round(e, n, 1, false, n_done, reason);
+      t0 = now_ms();
+      if (reason == KB_REASON_DONE) {
+        popped += spec_pops;
+        for (uint32_t i = 0; i < n; i++) decs.push_back(kb_decision{e->h_rows[i], e->h_decnode[i], e->h_deckind[i], (uint32_t)(e->round_no - 1)});
+      } else {
+        // replay the confirmed prefix on the checkpoint, then feed the true outcome of the row that broke the speculation
+        e->stats.spec_breaks += 1;
+        om = ckpt;
+        uint32_t i = 0;
+        for (;;) {
+          if (!om.next(t)) throw EngineError(KB_E_INTERNAL, "order replay ran out of tasks");
+          popped++;
+          if (dead[hs.t_feas_shape[t]]) { om.report(Outcome::NoFeasibleNode); continue; }
+          if (t != e->h_rows[i]) throw EngineError(KB_E_INTERNAL, "order replay diverged from the speculated sequence");
+          if (reason == KB_REASON_NO_FEASIBLE && i == n_done) {
+            dead[hs.t_feas_shape[t]] = 1;
+            om.report(Outcome::NoFeasibleNode);
+            break;
+          }
+          decs.push_back(kb_decision{t, e->h_decnode[i], e->h_deckind[i], (uint32_t)(e->round_no - 1)});
+          om.report(e->h_deckind[i] ? Outcome::Pipelined : Outcome::Allocated);
+          i++;
+          if (reason == KB_REASON_PIPELINED && i == n_done) break;
+        }
+      }
+      host_ms += now_ms() - t0;
+    }
+    run_finalize(e);
+    check_aggregates(e, om);
+    e->stats.tasks_popped += popped;
+    e->stats.evals += popped * (uint64_t)hs.N;   // PredicateNodes visits every node for every popped task (allocate.go:143)
+    e->stats.decisions += decs.size();
+    e->stats.host_order_ms += host_ms;
+    e->stats.total_ms += now_ms() - t_start;
+    if (n_out) *n_out = decs.size();
+    if (decs.size() > cap) throw EngineError(KB_E_CAPACITY, "decision buffer too small");
+    if (out && !decs.empty()) std::memcpy(out, decs.data(), sizeof(kb_decision) * decs.size());
+  });
+}
+
+int kb_run_backfill(kb_engine *e, kb_decision *out, uint64_t cap, uint64_t *n_out) {
+  if (!e) return KB_E_INVALID;
+  return guarded(e, [&]() {
+    if (!e->loaded) throw EngineError(KB_E_STATE, "kb_session_load must precede kb_run_backfill");
+    const double t_start = now_ms();
+    HostSession &hs = e->hs;
+    // backfill.go:44-47: jobs ascending JobID, Pending tasks ascending UID with an empty InitResreq; the order does not
+    // depend on outcomes, so there is nothing to speculate
+    std::vector<uint32_t> list;
+    for (uint32_t t = 0; t < hs.T; t++)
+      if (hs.t_status[t] == KB_TASK_PENDING && hs.t_init_empty[t] && hs.t_job[t] < hs.J) list.push_back(t);
+    std::vector<kb_decision> decs;
+    const uint32_t W = e->window;
+    ensure_round_buffers(e, W);
+    for (size_t pos = 0; pos < list.size(); pos += W) {
+      uint32_t n = (uint32_t)std::min<size_t>(W, list.size() - pos);
+      std::memcpy(e->h_rows.data(), &list[pos], sizeof(uint32_t) * n);
+      uint32_t n_done = 0, reason = 0;
+      run_round(e, n, 0, true, n_done, reason);
+      if (reason != KB_REASON_DONE || n_done != n) throw EngineError(KB_E_INTERNAL, "backfill round ended early");
+      for (uint32_t i = 0; i < n; i++)
+        if (e->h_decnode[i] != KB_NONE) decs.push_back(kb_decision{e->h_rows[i], e->h_decnode[i], 0u, (uint32_t)(e->round_no - 1)});
+    }
+    run_finalize(e);
+    e->stats.tasks_popped += list.size();
+    // the reference stops at the first node that passes: count the nodes it actually visits
+    uint64_t ev = 0;
+    {
+      std::vector<uint8_t> placed(hs.T, 0);
+      for (auto &dcs : decs) { placed[dcs.task] = 1; ev += (uint64_t)dcs.node + 1; }
+      for (uint32_t t : list) if (!placed[t]) ev += hs.N;
+    }
+    e->stats.evals += ev;
+    e->stats.decisions += decs.size();
+    e->stats.total_ms += now_ms() - t_start;
+    if (n_out) *n_out = decs.size();
+    if (decs.size() > cap) throw EngineError(KB_E_CAPACITY, "decision buffer too small");
+    if (out && !decs.empty()) std::memcpy(out, decs.data(), sizeof(kb_decision) * decs.size());
+  });
+}
+
+static void matrix_chunk(kb_engine *e, uint32_t t0, uint32_t n, uint32_t fit_mode, bool with_argmax, uint32_t k) {
+  ensure_round_buffers(e, n);
+  HostSession &hs = e->hs;
+  for (uint32_t i = 0; i < n; i++) {
+    e->h_rows[i] = t0 + i;
+    e->h_same[i] = (i > 0 && hs.t_row_shape[t0 + i] == hs.t_row_shape[t0 + i - 1]) ? 1 : 0;
+  }
+  HIP_OK(hipMemcpyAsync(e->b_rows.p, e->h_rows.data(), sizeof(uint32_t) * n, hipMemcpyHostToDevice, e->stream));
+  HIP_OK(hipMemcpyAsync(e->b_same.p, e->h_same.data(), n, hipMemcpyHostToDevice, e->stream));
+  KbRound r = make_round(e, n, (int)fit_mode, false);
+  kb_launch_matrix(e->dev, r, e->stream);
+  if (with_argmax) {
+    r.topk = k;
+    kb_launch_argmax(e->dev, r, e->stream);
+  }
+}
+
+int kb_eval_matrix(kb_engine *e, uint32_t t0, uint32_t t1, uint32_t fit_mode, uint8_t *mask_bits, uint16_t *score) {
+  if (!e) return KB_E_INVALID;
+  return guarded(e, [&]() {
+    if (!e->loaded) throw EngineError(KB_E_STATE, "no session loaded");
+    if (t0 > t1 || t1 > e->hs.T) throw EngineError(KB_E_INVALID, "row range out of bounds");
+    const uint32_t N = e->hs.N, NP = e->dev.NP;
+    const size_t rowb = ((size_t)N + 7) / 8;
+    const uint32_t chunk = std::max<uint32_t>(1, std::min<uint32_t>(e->window, 4096));
+    for (uint32_t a = t0; a < t1; a += chunk) {
+      uint32_t n = std::min(chunk, t1 - a);
+      matrix_chunk(e, a, n, fit_mode, false, 0);
+      if (score)
+        HIP_OK(hipMemcpy2DAsync(score + (size_t)(a - t0) * N, sizeof(uint16_t) * N, e->b_score.p, sizeof(uint16_t) * NP, sizeof(uint16_t) * N, n,
+                                hipMemcpyDeviceToHost, e->stream));
+      if (mask_bits)
+        HIP_OK(hipMemcpy2DAsync(mask_bits + (size_t)(a - t0) * rowb, rowb, e->b_maskw.p, NP / 8, rowb, n, hipMemcpyDeviceToHost, e->stream));
+      HIP_OK(hipStreamSynchronize(e->stream));
+    }
+    HIP_OK(hipGetLastError());
+  });
+}
+
+int kb_argmax_rows(kb_engine *e, uint32_t t0, uint32_t t1, uint32_t fit_mode, uint32_t k, uint32_t *out_node, uint16_t *out_score) {
+  if (!e) return KB_E_INVALID;
+  return guarded(e, [&]() {
+    if (!e->loaded) throw EngineError(KB_E_STATE, "no session loaded");
+    if (t0 > t1 || t1 > e->hs.T) throw EngineError(KB_E_INVALID, "row range out of bounds");
+    if (k == 0 || k > KB_MAX_TOPK) throw EngineError(KB_E_INVALID, "k must be in 1..32");
+    const uint32_t chunk = std::max<uint32_t>(1, std::min<uint32_t>(e->window, 4096));
+    std::vector<unsigned long long> keys((size_t)chunk * k);
+    for (uint32_t a = t0; a < t1; a += chunk) {
+      uint32_t n = std::min(chunk, t1 - a);
+      matrix_chunk(e, a, n, fit_mode, true, k);
+      HIP_OK(hipMemcpyAsync(keys.data(), e->b_keys.p, sizeof(unsigned long long) * (size_t)n * k, hipMemcpyDeviceToHost, e->stream));
+      HIP_OK(hipStreamSynchronize(e->stream));
+      for (size_t i = 0; i < (size_t)n * k; i++) {
+        size_t o = (size_t)(a - t0) * k + i;
+        if (keys[i] == 0ull) { out_node[o] = KB_NONE; if (out_score) out_score[o] = 0; }
+        else { out_node[o] = KB_KEY_NODE(keys[i]); if (out_score) out_score[o] = (uint16_t)KB_KEY_SCORE(keys[i]); }
+      }
+    }
+    HIP_OK(hipGetLastError());
+  });
+}
+
+int kb_bench_matrix(kb_engine *e, uint32_t t0, uint32_t t1, uint32_t fit_mode, uint32_t reps, double *ms_avg) {
+  if (!e) return KB_E_INVALID;
+  return guarded(e, [&]() {
+    if (!e->loaded) throw EngineError(KB_E_STATE, "no session loaded");
+    if (t0 >= t1 || t1 > e->hs.T || reps == 0) throw EngineError(KB_E_INVALID, "bad range / reps");
+    uint32_t n = t1 - t0;
+    matrix_chunk(e, t0, n, fit_mode, false, 0);   // warm-up launch, also uploads rows
+    HIP_OK(hipStreamSynchronize(e->stream));
+    KbRound r = make_round(e, n, (int)fit_mode, false);
+    Timer &tm = get_timer(e, 4);
+    HIP_OK(hipEventRecord(tm.a, e->stream));
+    for (uint32_t i = 0; i < reps; i++) kb_launch_matrix(e->dev, r, e->stream);
+    HIP_OK(hipEventRecord(tm.b, e->stream));
+    HIP_OK(hipStreamSynchronize(e->stream));
+    HIP_OK(hipGetLastError());
+    float ms = 0;
+    HIP_OK(hipEventElapsedTime(&ms, tm.a, tm.b));
+    if (ms_avg) *ms_avg = (double)ms / reps;
+  });
+}
+
+int kb_get_binds(kb_engine *e, uint32_t *task_node_out) {
+  if (!e) return KB_E_INVALID;
+  return guarded(e, [&]() {
+    if (!e->loaded) throw EngineError(KB_E_STATE, "no session loaded");
+    HIP_OK(hipMemcpy(task_node_out, e->b_tbind.p, sizeof(uint32_t) * e->hs.T, hipMemcpyDeviceToHost));
+    uint64_t nb = 0;
+    for (uint32_t t = 0; t < e->hs.T; t++) nb += task_node_out[t] != KB_NONE;
+    e->stats.binds = nb;
+  });
+}
+
+int kb_get_task_state(kb_engine *e, uint8_t *status_out, uint32_t *node_out) {
+  if (!e) return KB_E_INVALID;
+  return guarded(e, [&]() {
+    if (!e->loaded) throw EngineError(KB_E_STATE, "no session loaded");
+    if (status_out) HIP_OK(hipMemcpy(status_out, e->b_tstatus.p, e->hs.T, hipMemcpyDeviceToHost));
+    if (node_out) HIP_OK(hipMemcpy(node_out, e->b_tnode.p, sizeof(uint32_t) * e->hs.T, hipMemcpyDeviceToHost));
+  });
+}
+
+int kb_get_node_state(kb_engine *e, double *idle, double *releasing, int64_t *nz_cpu, int64_t *nz_mem, int32_t *pod_cnt) {
+  if (!e) return KB_E_INVALID;
+  return guarded(e, [&]() {
+    if (!e->loaded) throw EngineError(KB_E_STATE, "no session loaded");
+    const uint32_t N = e->hs.N, NP = e->dev.NP;
+    const int R = e->hs.R;
+    if (idle) HIP_OK(hipMemcpy2D(idle, sizeof(double) * N, e->b_idle.p, sizeof(double) * NP, sizeof(double) * N, R, hipMemcpyDeviceToHost));
+    if (releasing) HIP_OK(hipMemcpy2D(releasing, sizeof(double) * N, e->b_rel.p, sizeof(double) * NP, sizeof(double) * N, R, hipMemcpyDeviceToHost));
+    if (nz_cpu) HIP_OK(hipMemcpy(nz_cpu, e->b_nzc.p, sizeof(int64_t) * N, hipMemcpyDeviceToHost));
+    if (nz_mem) HIP_OK(hipMemcpy(nz_mem, e->b_nzm.p, sizeof(int64_t) * N, hipMemcpyDeviceToHost));
+    if (pod_cnt) HIP_OK(hipMemcpy(pod_cnt, e->b_podcnt.p, sizeof(int32_t) * N, hipMemcpyDeviceToHost));
+  });
+}
+
+int kb_get_shares(kb_engine *e, double *job_share, double *queue_share, double *queue_deserved) {
+  if (!e) return KB_E_INVALID;
+  return guarded(e, [&]() {
+    if (!e->loaded) throw EngineError(KB_E_STATE, "no session loaded");
+    const HostSession &hs = e->hs;
+    if (job_share) std::memcpy(job_share, hs.job_share.data(), sizeof(double) * hs.J);
+    if (queue_share) std::memcpy(queue_share, hs.queue_share.data(), sizeof(double) * hs.Q);
+    if (queue_deserved)
+      for (uint32_t q = 0; q < hs.Q; q++)
+        for (int d = 0; d < hs.R; d++) queue_deserved[(size_t)d * hs.Q + q] = hs.deserved[q].get(d);
+  });
+}
+
+int kb_get_stats(kb_engine *e, kb_stats *out) {
+  if (!e || !out) return KB_E_INVALID;
+  *out = e->stats;
+  return KB_OK;
+}
+
+// ---- multi-GPU round API: implemented in a later section of this file ----
+int kb_round_topk(const kb_engine *e, uint32_t *topk) {
+  if (!e || !topk) return KB_E_INVALID;
+  *topk = e->topk;
+  return KB_OK;
+}
+int kb_round_delta_doubles(const kb_engine *e, uint64_t *n_doubles) {
+  if (!e || !n_doubles) return KB_E_INVALID;
+  *n_doubles = (uint64_t)e->dev.NP * (2ull * e->hs.R + 3ull);
+  return KB_OK;
+}
+int kb_round_begin(kb_engine *e, uint32_t, uint32_t *) { if (e) e->err = "multi-GPU rounds not built yet"; return KB_E_UNSUPPORTED; }
+int kb_round_candidates(kb_engine *e, uint32_t, uint32_t, uint64_t) { if (e) e->err = "multi-GPU rounds not built yet"; return KB_E_UNSUPPORTED; }
+int kb_round_commit(kb_engine *e, uint64_t, uint32_t, uint32_t, uint64_t) { if (e) e->err = "multi-GPU rounds not built yet"; return KB_E_UNSUPPORTED; }
+int kb_round_apply(kb_engine *e, uint64_t, uint32_t *) { if (e) e->err = "multi-GPU rounds not built yet"; return KB_E_UNSUPPORTED; }
+int kb_round_decisions(kb_engine *e, kb_decision *, uint64_t, uint64_t *) { if (e) e->err = "multi-GPU rounds not built yet"; return KB_E_UNSUPPORTED; }
+
+}  // extern "C"

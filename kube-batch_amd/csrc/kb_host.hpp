@@ -1,0 +1,200 @@
+// kb_host.hpp — host-side model of the session for the engine: api.Resource algebra with map-presence
+// semantics, plugin OnSessionOpen state (drf totals, proportion deserved), and the order machine that
+// reproduces the control flow of allocate.go:43-194 around the device rounds.
+//
+// This is the engine's own implementation (C++), independent of oracle/kb_oracle.c (test infrastructure).
+#pragma once
+#include <stdint.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/kb_engine.h"
+
+namespace kb {
+
+struct EngineError : std::runtime_error {
+  int code;
+  EngineError(int c, const std::string &m) : std::runtime_error(m), code(c) {}
+};
+
+constexpr double kMinMilliCPU = 10.0;              // pkg/scheduler/api/resource_info.go:68
+constexpr double kMinMilliScalar = 10.0;           // :69
+constexpr double kMinMemory = 10.0 * 1024 * 1024;  // :70
+
+// api.Resource (resource_info.go:28-38): dense vector; `mask` bit (d-2) <=> ScalarResources has key d; mask==0 <=> nil map
+struct Res {
+  double v[KB_MAX_RES];
+  uint32_t mask;
+  Res() : mask(0) { std::memset(v, 0, sizeof(v)); }
+  bool has(int d) const { return (mask >> (d - 2)) & 1u; }
+  void setk(int d) { mask |= 1u << (d - 2); }
+  double get(int d) const { return d < 2 ? v[d] : (has(d) ? v[d] : 0.0); }   // resource_info.go:349-361
+};
+
+inline bool le_func(double l, double r, double diff) { return l < r || std::fabs(l - r) < diff; }
+
+inline void res_add(Res &r, const Res &rr, int R) {   // resource_info.go:128-140
+  r.v[0] += rr.v[0];
+  r.v[1] += rr.v[1];
+  for (int d = 2; d < R; d++)
+    if (rr.has(d)) { r.setk(d); r.v[d] += rr.v[d]; }
+}
+inline bool res_less_equal(const Res &r, const Res &rr, int R) {   // resource_info.go:268-302
+  if (!le_func(r.v[0], rr.v[0], kMinMilliCPU)) return false;
+  if (!le_func(r.v[1], rr.v[1], kMinMemory)) return false;
+  if (r.mask == 0) return true;
+  for (int d = 2; d < R; d++) {
+    if (!r.has(d) || r.v[d] <= kMinMilliScalar) continue;
+    if (rr.mask == 0) return false;
+    if (!le_func(r.v[d], rr.get(d), kMinMilliScalar)) return false;
+  }
+  return true;
+}
+inline bool res_sub(Res &r, const Res &rr, int R) {   // resource_info.go:143-160; false where Go panics
+  if (!res_less_equal(rr, r, R)) return false;
+  r.v[0] -= rr.v[0];
+  r.v[1] -= rr.v[1];
+  for (int d = 2; d < R; d++) {
+    if (!rr.has(d)) continue;
+    if (r.mask == 0) return true;
+    r.setk(d);
+    r.v[d] -= rr.v[d];
+  }
+  return true;
+}
+inline void res_multi(Res &r, double ratio, int R) {   // resource_info.go:217-224
+  r.v[0] = r.v[0] * ratio;
+  r.v[1] = r.v[1] * ratio;
+  for (int d = 2; d < R; d++)
+    if (r.has(d)) r.v[d] = r.v[d] * ratio;
+}
+inline bool res_less(const Res &r, const Res &rr, int R) {   // resource_info.go:227-265
+  if (!(r.v[0] < rr.v[0])) return false;
+  if (!(r.v[1] < rr.v[1])) return false;
+  if (r.mask == 0) {
+    if (rr.mask != 0)
+      for (int d = 2; d < R; d++)
+        if (rr.has(d) && rr.v[d] <= kMinMilliScalar) return false;
+    return true;
+  }
+  if (rr.mask == 0) return false;
+  for (int d = 2; d < R; d++)
+    if (r.has(d) && !(r.v[d] < rr.get(d))) return false;
+  return true;
+}
+inline bool res_is_empty(const Res &r, int R) {   // resource_info.go:93-105
+  if (!(r.v[0] < kMinMilliCPU && r.v[1] < kMinMemory)) return false;
+  for (int d = 2; d < R; d++)
+    if (r.has(d) && r.v[d] >= kMinMilliScalar) return false;
+  return true;
+}
+inline void res_diff(const Res &r, const Res &rr, Res &inc, Res &dec, int R) {   // resource_info.go:305-337
+  inc = Res();
+  dec = Res();
+  if (r.v[0] > rr.v[0]) inc.v[0] += r.v[0] - rr.v[0]; else dec.v[0] += rr.v[0] - r.v[0];
+  if (r.v[1] > rr.v[1]) inc.v[1] += r.v[1] - rr.v[1]; else dec.v[1] += rr.v[1] - r.v[1];
+  for (int d = 2; d < R; d++) {
+    if (!r.has(d)) continue;
+    double rq = rr.get(d);
+    if (r.v[d] > rq) { inc.setk(d); inc.v[d] += r.v[d] - rq; }
+    else { dec.setk(d); dec.v[d] += rq - r.v[d]; }
+  }
+}
+inline Res helpers_min(const Res &l, const Res &r, int R) {   // api/helpers/helpers.go:28-44
+  Res res;
+  res.v[0] = std::fmin(l.v[0], r.v[0]);
+  res.v[1] = std::fmin(l.v[1], r.v[1]);
+  if (l.mask == 0 || r.mask == 0) return res;
+  for (int d = 2; d < R; d++)
+    if (l.has(d)) { res.setk(d); res.v[d] = std::fmin(l.v[d], r.get(d)); }
+  return res;
+}
+inline double helpers_share(double l, double r) {   // api/helpers/helpers.go:47-60
+  if (r == 0) return l == 0 ? 0.0 : 1.0;
+  return l / r;
+}
+
+// ---- policy compiled from conf.Tier lists (framework/session_plugins.go dispatchers) ----
+struct Policy {
+  std::vector<uint8_t> job_chain;   // plugins contributing to JobOrderFn, tier-major order (session_plugins.go:243-267)
+  bool queue_order_proportion = false;   // QueueOrderFn (session_plugins.go:270-295)
+  bool task_order_priority = false;      // TaskOrderFn (session_plugins.go:298-331)
+  bool gang_job_ready = false;           // JobReady (session_plugins.go:182-200 + gang.go:122-125)
+  bool has_gang = false, has_drf = false, has_proportion = false;
+  bool pred_enabled = false, nodeorder_enabled = false;
+  int wL = 1, wM = 0, wNA = 1, wPA = 1, wB = 1;   // nodeorder.go:111-117
+};
+
+// ---- host mirror of the session ----
+struct HostSession {
+  int R = 2;
+  uint32_t N = 0, T = 0, J = 0, Q = 0;
+  std::vector<double> t_res, t_init;      // [R][T]
+  std::vector<uint32_t> t_resmask, t_job, t_cls, t_node;
+  std::vector<int32_t> t_prio;
+  std::vector<int64_t> t_creation;
+  std::vector<uint8_t> t_status;
+  std::vector<uint8_t> t_res_empty;       // Resreq.IsEmpty()   (allocate.go:114)
+  std::vector<uint8_t> t_init_empty;      // InitResreq.IsEmpty() (backfill.go:47)
+  std::vector<uint32_t> t_feas_shape;     // id of (InitResreq, class): tasks sharing it share a feasibility row
+  std::vector<uint32_t> t_row_shape;      // id of (InitResreq, non-zero request, class): identical matrix rows
+  uint32_t n_feas_shapes = 0;
+  std::vector<uint32_t> job_begin, job_queue;
+  std::vector<int32_t> job_min, job_prio;
+  std::vector<int64_t> job_creation;
+  std::vector<int32_t> queue_weight;
+  std::vector<int64_t> queue_creation;
+  // plugin state
+  Res total;                               // drf.totalResource == proportion.totalResource
+  std::vector<Res> deserved;               // [Q] proportion queueOpts[q].deserved
+  std::vector<uint8_t> queue_has_attr;     // queue has a job in the session (proportion.go:69-83)
+  // live aggregates (refreshed from the device share reduction after every action)
+  std::vector<double> job_alloc;           // [J][R]
+  std::vector<double> job_share;           // [J]
+  std::vector<double> queue_alloc;         // [Q][R]
+  std::vector<double> queue_share;         // [Q]
+  std::vector<int32_t> job_ready;          // [J] ReadyTaskNum
+};
+
+enum class Outcome { Allocated, Pipelined, NoFeasibleNode };
+
+// The allocate action's control flow (allocate.go:43-194) as a resumable machine.  next() runs the reference loop up
+// to the point where PredicateNodes would be called for a task and returns that task; report() feeds back what the
+// device decided and runs the rest of the iteration.  Value-copyable so a round can be speculated and rolled back.
+class OrderMachine {
+ public:
+  void init_allocate(const HostSession *hs, const Policy *pol);
+  bool next(uint32_t &task);
+  void report(Outcome o);
+  // running aggregates, compared with the device reduction after the action
+  std::vector<double> jalloc, jshare, qalloc, qshare;
+  std::vector<int32_t> ready;
+  uint64_t steps = 0;
+
+ private:
+  const HostSession *hs_ = nullptr;
+  const Policy *pol_ = nullptr;
+  std::vector<uint32_t> qheap_;
+  std::vector<uint32_t> jheap_items_, jheap_off_, jheap_n_;
+  std::vector<uint32_t> pend_, pend_off_, cursor_;   // per job: Pending non-BestEffort tasks in TaskOrderFn order
+  int cur_q_ = -1, cur_j_ = -1;
+  uint32_t cur_t_ = KB_NONE;
+  bool inner_ = false;
+
+  bool job_ready(uint32_t j) const { return pol_->gang_job_ready ? ready[j] >= hs_->job_min[j] : true; }
+  bool queue_less(uint32_t l, uint32_t r) const;
+  bool job_less(uint32_t l, uint32_t r) const;
+  bool overused(uint32_t q) const;
+  void qpush(uint32_t q);
+  uint32_t qpop();
+  void jpush(uint32_t q, uint32_t j);
+  uint32_t jpop(uint32_t q);
+  void update_shares(uint32_t j, uint32_t t);
+};
+
+}  // namespace kb

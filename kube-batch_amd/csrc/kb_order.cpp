@@ -1,0 +1,235 @@
+// kb_order.cpp — the order machine: queue / job / task ordering of allocate.go around the device rounds.
+//
+// Heaps follow Go's container/heap exactly (util/priority_queue.go:26-94 wraps it): the queue heap holds one entry
+// PER JOB (allocate.go:50-52), so the same queue sits in it many times while its share mutates, and the pop order
+// then depends on the sift mechanics:
+//   Push: append, up(n-1);  Pop: swap(0,n-1), down(0,n-1), remove last
+//   up(j):   i=(j-1)/2; stop if i==j or !less(j,i); swap; j=i
+//   down(i): j1=2i+1; stop if j1>=n; j=j1; if j1+1<n && less(j1+1,j1) j=j1+1; stop if !less(j,i); swap; i=j
+#include "kb_host.hpp"
+
+namespace kb {
+
+// session_plugins.go:270-295 + proportion.go:156-169
+bool OrderMachine::queue_less(uint32_t l, uint32_t r) const {
+  if (pol_->queue_order_proportion) {
+    double ls = qshare[l], rs = qshare[r];
+    if (!(ls == rs)) return ls < rs;
+  }
+  if (hs_->queue_creation[l] == hs_->queue_creation[r]) return l < r;   // UID order == canonical index order
+  return hs_->queue_creation[l] < hs_->queue_creation[r];
+}
+
+// session_plugins.go:243-267 + priority.go:61-77, gang.go:96-119, drf.go:114-130
+bool OrderMachine::job_less(uint32_t l, uint32_t r) const {
+  for (uint8_t p : pol_->job_chain) {
+    int j = 0;
+    if (p == KB_PLUGIN_PRIORITY) {
+      if (hs_->job_prio[l] > hs_->job_prio[r]) j = -1;
+      else if (hs_->job_prio[l] < hs_->job_prio[r]) j = 1;
+    } else if (p == KB_PLUGIN_GANG) {
+      bool lr = ready[l] >= hs_->job_min[l], rr = ready[r] >= hs_->job_min[r];
+      if (lr && rr) j = 0; else if (lr) j = 1; else if (rr) j = -1;
+    } else if (p == KB_PLUGIN_DRF) {
+      if (jshare[l] == jshare[r]) j = 0; else if (jshare[l] < jshare[r]) j = -1; else j = 1;
+    }
+    if (j != 0) return j < 0;
+  }
+  if (hs_->job_creation[l] == hs_->job_creation[r]) return l < r;
+  return hs_->job_creation[l] < hs_->job_creation[r];
+}
+
+// session_plugins.go:165-179 + proportion.go:198-209: deserved.LessEqual(allocated)
+bool OrderMachine::overused(uint32_t q) const {
+  if (!pol_->has_proportion) return false;
+  const int R = hs_->R;
+  const Res &des = hs_->deserved[q];
+  const double *al = &qalloc[(size_t)q * R];
+  if (!le_func(des.v[0], al[0], kMinMilliCPU)) return false;
+  if (!le_func(des.v[1], al[1], kMinMemory)) return false;
+  for (int d = 2; d < R; d++) {
+    if (!des.has(d) || des.v[d] <= kMinMilliScalar) continue;
+    // an absent key on the right reads 0 and a nil map fails exactly when the compare against 0 fails
+    if (!le_func(des.v[d], al[d], kMinMilliScalar)) return false;
+  }
+  return true;
+}
+
+void OrderMachine::qpush(uint32_t q) {
+  qheap_.push_back(q);
+  size_t j = qheap_.size() - 1;
+  for (;;) {
+    size_t i = j == 0 ? 0 : (j - 1) / 2;
+    if (i == j || !queue_less(qheap_[j], qheap_[i])) break;
+    std::swap(qheap_[i], qheap_[j]);
+    j = i;
+  }
+}
+uint32_t OrderMachine::qpop() {
+  size_t n = qheap_.size() - 1;
+  std::swap(qheap_[0], qheap_[n]);
+  size_t i = 0;
+  for (;;) {
+    size_t j1 = 2 * i + 1;
+    if (j1 >= n) break;
+    size_t j = j1;
+    if (j1 + 1 < n && queue_less(qheap_[j1 + 1], qheap_[j1])) j = j1 + 1;
+    if (!queue_less(qheap_[j], qheap_[i])) break;
+    std::swap(qheap_[i], qheap_[j]);
+    i = j;
+  }
+  uint32_t x = qheap_.back();
+  qheap_.pop_back();
+  return x;
+}
+void OrderMachine::jpush(uint32_t q, uint32_t job) {
+  uint32_t *h = &jheap_items_[jheap_off_[q]];
+  uint32_t n = jheap_n_[q]++;
+  h[n] = job;
+  uint32_t j = n;
+  for (;;) {
+    uint32_t i = j == 0 ? 0 : (j - 1) / 2;
+    if (i == j || !job_less(h[j], h[i])) break;
+    std::swap(h[i], h[j]);
+    j = i;
+  }
+}
+uint32_t OrderMachine::jpop(uint32_t q) {
+  uint32_t *h = &jheap_items_[jheap_off_[q]];
+  uint32_t n = jheap_n_[q] - 1;
+  std::swap(h[0], h[n]);
+  uint32_t i = 0;
+  for (;;) {
+    uint32_t j1 = 2 * i + 1;
+    if (j1 >= n) break;
+    uint32_t j = j1;
+    if (j1 + 1 < n && job_less(h[j1 + 1], h[j1])) j = j1 + 1;
+    if (!job_less(h[j], h[i])) break;
+    std::swap(h[i], h[j]);
+    i = j;
+  }
+  jheap_n_[q] = n;
+  return h[n];
+}
+
+void OrderMachine::init_allocate(const HostSession *hs, const Policy *pol) {
+  hs_ = hs;
+  pol_ = pol;
+  const uint32_t J = hs->J, Q = hs->Q;
+  jalloc = hs->job_alloc;
+  jshare = hs->job_share;
+  qalloc = hs->queue_alloc;
+  qshare = hs->queue_share;
+  ready = hs->job_ready;
+  steps = 0;
+  // per-queue job heaps share one flat array; a queue's heap never holds more than its job count
+  jheap_off_.assign(Q + 1, 0);
+  for (uint32_t j = 0; j < J; j++)
+    if (hs->job_queue[j] < Q) jheap_off_[hs->job_queue[j] + 1]++;
+  for (uint32_t q = 0; q < Q; q++) jheap_off_[q + 1] += jheap_off_[q];
+  jheap_items_.assign(J ? J : 1, 0);
+  jheap_n_.assign(Q, 0);
+  qheap_.clear();
+  qheap_.reserve(J);
+  // pendingTasks[job] (allocate.go:110-123): Pending tasks whose Resreq is not empty, in TaskOrderFn order
+  // (session_plugins.go:298-331: priority plugin, then pod creation time, then UID); the comparator is a strict total
+  // order over immutable keys, so the heap's pop order is the sorted order
+  pend_off_.assign(J + 1, 0);
+  pend_.clear();
+  for (uint32_t j = 0; j < J; j++) {
+    pend_off_[j] = (uint32_t)pend_.size();
+    for (uint32_t t = hs->job_begin[j]; t < hs->job_begin[j + 1]; t++)
+      if (hs->t_status[t] == KB_TASK_PENDING && !hs->t_res_empty[t]) pend_.push_back(t);
+    auto b = pend_.begin() + pend_off_[j], e = pend_.end();
+    const bool by_prio = pol->task_order_priority;
+    std::sort(b, e, [hs, by_prio](uint32_t l, uint32_t r) {
+      if (by_prio && hs->t_prio[l] != hs->t_prio[r]) return hs->t_prio[l] > hs->t_prio[r];
+      if (hs->t_creation[l] != hs->t_creation[r]) return hs->t_creation[l] < hs->t_creation[r];
+      return l < r;
+    });
+  }
+  pend_off_[J] = (uint32_t)pend_.size();
+  cursor_.assign(J, 0);
+  for (uint32_t j = 0; j < J; j++) cursor_[j] = pend_off_[j];
+  // allocate.go:50-65: ssn.Jobs in ascending JobID; one queue-heap entry per job
+  for (uint32_t j = 0; j < J; j++) {
+    uint32_t q = hs->job_queue[j];
+    if (q >= Q) continue;   // "queue not found": job skipped
+    qpush(q);
+    jpush(q, j);
+  }
+  inner_ = false;
+  cur_q_ = cur_j_ = -1;
+  cur_t_ = KB_NONE;
+}
+
+bool OrderMachine::next(uint32_t &task) {
+  for (;;) {
+    if (inner_) {
+      uint32_t j = (uint32_t)cur_j_;
+      if (cursor_[j] < pend_off_[j + 1]) {   // allocate.go:129-130
+        task = cur_t_ = pend_[cursor_[j]++];
+        steps++;
+        return true;
+      }
+      inner_ = false;
+      qpush((uint32_t)cur_q_);               // allocate.go:192
+    }
+    if (qheap_.empty()) return false;        // allocate.go:90-92
+    uint32_t q = qpop();
+    if (overused(q)) continue;               // allocate.go:95-98
+    if (jheap_n_[q] == 0) continue;          // allocate.go:104-107
+    uint32_t j = jpop(q);
+    cur_q_ = (int)q;
+    cur_j_ = (int)j;
+    inner_ = true;
+  }
+}
+
+// drf.go:135-145 and proportion.go:212-223 AllocateFunc (fired by ssn.Allocate and ssn.Pipeline alike)
+void OrderMachine::update_shares(uint32_t j, uint32_t t) {
+  const int R = hs_->R;
+  const uint32_t T = hs_->T;
+  if (pol_->has_drf) {
+    double *a = &jalloc[(size_t)j * R];
+    double share = 0;
+    for (int d = 0; d < R; d++) {
+      if (d < 2 || ((hs_->t_resmask[t] >> (d - 2)) & 1u)) a[d] += hs_->t_res[(size_t)d * T + t];
+      if (d >= 2 && !hs_->total.has(d)) continue;
+      double s = helpers_share(a[d], hs_->total.get(d));
+      if (s > share) share = s;
+    }
+    jshare[j] = share;
+  }
+  if (pol_->has_proportion) {
+    uint32_t q = hs_->job_queue[j];
+    double *a = &qalloc[(size_t)q * R];
+    const Res &des = hs_->deserved[q];
+    double share = 0;
+    for (int d = 0; d < R; d++) {
+      if (d < 2 || ((hs_->t_resmask[t] >> (d - 2)) & 1u)) a[d] += hs_->t_res[(size_t)d * T + t];
+      if (d >= 2 && !des.has(d)) continue;
+      double s = helpers_share(a[d], des.get(d));
+      if (s > share) share = s;
+    }
+    qshare[q] = share;
+  }
+}
+
+void OrderMachine::report(Outcome o) {
+  const uint32_t j = (uint32_t)cur_j_, q = (uint32_t)cur_q_;
+  if (o == Outcome::NoFeasibleNode) {        // allocate.go:144-148: break; then queues.Push(queue)
+    inner_ = false;
+    qpush(q);
+    return;
+  }
+  if (o == Outcome::Allocated) ready[j] += 1;   // status Allocated counts towards ReadyTaskNum; Pipelined does not
+  update_shares(j, cur_t_);
+  if (job_ready(j) && cursor_[j] < pend_off_[j + 1]) {   // allocate.go:185-188
+    jpush(q, j);
+    inner_ = false;
+    qpush(q);
+  }
+}
+
+}  // namespace kb

@@ -1,0 +1,178 @@
+"""ctypes binding of the C ABI (include/kb_engine.h -> libkbengine.so).
+
+The library is built in-tree by `build()` (hipcc --offload-arch=gfx950) and loaded from
+kube-batch_amd/libkbengine.so.  There is no CPU fallback: if the library is missing or no HIP device
+is visible the calls raise (the Go side falls back to the stock allocate action in that case).
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from . import abi
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libkbengine.so")
+_LIB = None
+
+EXPORTS = ["kb_engine_create", "kb_engine_destroy", "kb_last_error", "kb_session_load", "kb_run_allocate",
+           "kb_run_backfill", "kb_eval_matrix", "kb_argmax_rows", "kb_bench_matrix", "kb_get_binds",
+           "kb_get_task_state", "kb_get_node_state", "kb_get_shares", "kb_get_stats", "kb_round_begin",
+           "kb_round_candidates", "kb_round_commit", "kb_round_apply", "kb_round_topk", "kb_round_delta_doubles",
+           "kb_round_decisions"]
+
+
+class EngineError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"{abi.ERR_NAMES.get(code, code)}: {msg}")
+        self.code = code
+
+
+def build(force: bool = False) -> str:
+    """Compile the HIP engine for gfx950 in-tree (cross-compiles without a GPU)."""
+    src_dir = os.path.join(_HERE, "csrc")
+    subprocess.check_call(["make", "-C", src_dir, "-s"] + (["-B"] if force else []))
+    return LIB_PATH
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise EngineError(abi.KB_E_DEVICE, f"{LIB_PATH} is missing: run __graft_entry__.build() (hipcc, gfx950). "
+                                               "The engine has no CPU path.")
+        L = C.CDLL(LIB_PATH)
+        vp = C.c_void_p
+        L.kb_engine_create.argtypes = [C.POINTER(abi.Config), C.POINTER(vp)]
+        L.kb_engine_destroy.argtypes = [vp]
+        L.kb_engine_destroy.restype = None
+        L.kb_last_error.argtypes = [vp]
+        L.kb_last_error.restype = C.c_char_p
+        L.kb_session_load.argtypes = [vp, C.POINTER(abi.Snapshot)]
+        for n in ("kb_run_allocate", "kb_run_backfill"):
+            getattr(L, n).argtypes = [vp, C.POINTER(abi.Decision), C.c_uint64, C.POINTER(C.c_uint64)]
+        L.kb_eval_matrix.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint8), C.POINTER(C.c_uint16)]
+        L.kb_argmax_rows.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint16)]
+        L.kb_bench_matrix.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_double)]
+        L.kb_get_binds.argtypes = [vp, C.POINTER(C.c_uint32)]
+        L.kb_get_task_state.argtypes = [vp, C.POINTER(C.c_uint8), C.POINTER(C.c_uint32)]
+        L.kb_get_node_state.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64),
+                                        C.POINTER(C.c_int64), C.POINTER(C.c_int32)]
+        L.kb_get_shares.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]
+        L.kb_get_stats.argtypes = [vp, C.POINTER(abi.Stats)]
+        L.kb_round_begin.argtypes = [vp, C.c_uint32, C.POINTER(C.c_uint32)]
+        L.kb_round_candidates.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint64]
+        L.kb_round_commit.argtypes = [vp, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint64]
+        L.kb_round_apply.argtypes = [vp, C.c_uint64, C.POINTER(C.c_uint32)]
+        L.kb_round_topk.argtypes = [vp, C.POINTER(C.c_uint32)]
+        L.kb_round_delta_doubles.argtypes = [vp, C.POINTER(C.c_uint64)]
+        L.kb_round_decisions.argtypes = [vp, C.POINTER(abi.Decision), C.c_uint64, C.POINTER(C.c_uint64)]
+        _LIB = L
+    return _LIB
+
+
+def _p(a, t):
+    return a.ctypes.data_as(C.POINTER(t)) if a is not None else C.POINTER(t)()
+
+
+class Engine:
+    """One kb_engine handle.  Mirrors the life-cycle the Go action drives: create (once per process),
+    load(snapshot) per scheduling cycle, run_allocate / run_backfill per configured action."""
+
+    def __init__(self, conf, device: int = 0, window: int = 0, topk: int = 0, flags: int = 0):
+        self.L = lib()
+        cfg, self._keep = conf.to_abi(device=device, window=window, topk=topk, flags=flags)
+        h = C.c_void_p()
+        rc = self.L.kb_engine_create(C.byref(cfg), C.byref(h))
+        if rc != abi.KB_OK:
+            raise EngineError(rc, (self.L.kb_last_error(None) or b"").decode())
+        self.h = h
+        self.snap = None
+
+    def _ck(self, rc):
+        if rc != abi.KB_OK:
+            raise EngineError(rc, (self.L.kb_last_error(self.h) or b"").decode())
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.kb_engine_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def load(self, snap):
+        self.snap = snap
+        s = snap.to_abi()
+        self._ck(self.L.kb_session_load(self.h, C.byref(s)))
+
+    def _run(self, fn):
+        cap = max(int(self.snap.n_tasks), 1)
+        arr = (abi.Decision * cap)()
+        n = C.c_uint64()
+        self._ck(fn(self.h, arr, cap, C.byref(n)))
+        a = np.frombuffer(arr, dtype=np.uint32).reshape(cap, 4)[: n.value]
+        return a[:, :3].copy()
+
+    def run_allocate(self):
+        """-> uint32[n,3] (task, node, kind) in the order the reference loop places them."""
+        return self._run(self.L.kb_run_allocate)
+
+    def run_backfill(self):
+        return self._run(self.L.kb_run_backfill)
+
+    def run(self, actions):
+        out = [getattr(self, "run_" + a)() for a in actions]
+        return np.concatenate(out) if out else np.zeros((0, 3), np.uint32)
+
+    def eval_matrix(self, t0, t1, fit_mode=1):
+        N = self.snap.n_nodes
+        mask = np.zeros((t1 - t0, (N + 7) // 8), np.uint8)
+        score = np.zeros((t1 - t0, N), np.uint16)
+        self._ck(self.L.kb_eval_matrix(self.h, t0, t1, fit_mode, _p(mask, C.c_uint8), _p(score, C.c_uint16)))
+        return mask, score
+
+    def argmax_rows(self, t0, t1, k, fit_mode=1):
+        nodes = np.empty((t1 - t0, k), np.uint32)
+        score = np.empty((t1 - t0, k), np.uint16)
+        self._ck(self.L.kb_argmax_rows(self.h, t0, t1, fit_mode, k, _p(nodes, C.c_uint32), _p(score, C.c_uint16)))
+        return nodes, score
+
+    def bench_matrix(self, t0, t1, reps=10, fit_mode=1):
+        ms = C.c_double()
+        self._ck(self.L.kb_bench_matrix(self.h, t0, t1, fit_mode, reps, C.byref(ms)))
+        return ms.value
+
+    def binds(self):
+        out = np.empty(self.snap.n_tasks, np.uint32)
+        self._ck(self.L.kb_get_binds(self.h, _p(out, C.c_uint32)))
+        return out
+
+    def task_state(self):
+        st = np.empty(self.snap.n_tasks, np.uint8)
+        nd = np.empty(self.snap.n_tasks, np.uint32)
+        self._ck(self.L.kb_get_task_state(self.h, _p(st, C.c_uint8), _p(nd, C.c_uint32)))
+        return st, nd
+
+    def node_state(self):
+        R, N = self.snap.n_res, self.snap.n_nodes
+        idle = np.empty((R, N)); rel = np.empty((R, N))
+        nzc = np.empty(N, np.int64); nzm = np.empty(N, np.int64); cnt = np.empty(N, np.int32)
+        self._ck(self.L.kb_get_node_state(self.h, _p(idle, C.c_double), _p(rel, C.c_double), _p(nzc, C.c_int64),
+                                          _p(nzm, C.c_int64), _p(cnt, C.c_int32)))
+        return idle, rel, nzc, nzm, cnt
+
+    def shares(self):
+        R, J, Q = self.snap.n_res, self.snap.n_jobs, self.snap.n_queues
+        js = np.empty(J); qs = np.empty(Q); des = np.empty((R, Q))
+        self._ck(self.L.kb_get_shares(self.h, _p(js, C.c_double), _p(qs, C.c_double), _p(des, C.c_double)))
+        return js, qs, des
+
+    def stats(self):
+        st = abi.Stats()
+        self._ck(self.L.kb_get_stats(self.h, C.byref(st)))
+        return st.as_dict()

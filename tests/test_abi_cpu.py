@@ -1,0 +1,54 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library builds, loads and exports every symbol that
+include/kb_engine.h declares; no compute call is made (there is no GPU here)."""
+import ctypes as C
+import importlib
+import os
+import re
+
+import pytest
+
+kbm = importlib.import_module("kube-batch_amd")
+engine = importlib.import_module("kube-batch_amd.engine")
+abi = kbm.abi
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def L():
+    engine.build()
+    return engine.lib()
+
+
+def test_library_exports_every_header_symbol(L):
+    hdr = open(os.path.join(ROOT, "include", "kb_engine.h")).read()
+    declared = set(re.findall(r"\b(kb_[a-z_]+)\s*\(", hdr))
+    declared -= {"kb_engine"}
+    assert declared == set(engine.EXPORTS), declared ^ set(engine.EXPORTS)
+    for name in declared:
+        assert hasattr(L, name), name
+
+
+def test_struct_sizes_match_header():
+    # include/kb_engine.h layouts (LP64): any drift between the header and the ctypes mirror shows up here
+    assert C.sizeof(abi.PluginOption) == 4 + 4 + 32 + 4
+    assert C.sizeof(abi.Decision) == 16
+    assert C.sizeof(abi.Config) == 8 + 8 + 8 + 16
+    assert C.sizeof(abi.Snapshot) == 32 + 8 * len(abi.SNAPSHOT_ARRAYS)
+    assert C.sizeof(abi.Stats) == 9 * 8 + 6 * 8
+
+
+def test_create_without_gpu_fails_loudly(L):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    conf = kbm.conf.load_scheduler_conf()
+    with pytest.raises(engine.EngineError) as ei:
+        engine.Engine(conf)
+    assert ei.value.code == abi.KB_E_DEVICE
+    assert "no CPU fallback" in str(ei.value)
+
+
+def test_unknown_plugin_rejected():
+    conf = kbm.conf.SchedulerConf(actions=["allocate"], tiers=[[kbm.conf.PluginOption("nosuch")]])
+    with pytest.raises(ValueError):
+        conf.to_abi()

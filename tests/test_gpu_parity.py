@@ -1,0 +1,174 @@
+"""Parity of the HIP path (through the C ABI) against the CPU oracle.  Needs a real MI355X: -m gpu.
+
+Bit-exact bar: mask bits, u16 scores, arg-max candidates, the ordered decision list, the bind set, the
+final float64 node state and the drf / proportion shares must all be identical."""
+import importlib
+
+import numpy as np
+import pytest
+
+kbm = importlib.import_module("kube-batch_amd")
+engine = importlib.import_module("kube-batch_amd.engine")
+fixtures = importlib.import_module("kube-batch_amd.fixtures")
+abi, conf, snapmod = kbm.abi, kbm.conf, kbm.snapshot
+
+pytestmark = pytest.mark.gpu
+
+MOST_CONF = """
+actions: "allocate, backfill"
+tiers:
+- plugins:
+  - name: priority
+  - name: gang
+- plugins:
+  - name: drf
+  - name: predicates
+  - name: proportion
+  - name: nodeorder
+    arguments:
+      leastrequested.weight: 0
+      mostrequested.weight: 5
+      balancedresource.weight: 1
+"""
+
+
+def small(idx, scale, **kw):
+    p = snapmod.synth_config(idx, scale)
+    for k, v in kw.items():
+        setattr(p, k, v)
+    return snapmod.synth(p)
+
+
+def run_both(oracle_mod, cfg, snap, actions, **ekw):
+    o = oracle_mod.Oracle(cfg, snap)
+    o.run(actions)
+    e = engine.Engine(cfg, **ekw)
+    e.load(snap)
+    dec = e.run(actions)
+    return o, e, dec
+
+
+def assert_same_outcome(o, e, dec):
+    od = o.decisions()
+    assert dec.shape == od.shape, (dec.shape, od.shape)
+    assert np.array_equal(dec, od), f"first divergence at decision {int(np.argmax((dec != od).any(axis=1)))}"
+    assert np.array_equal(e.binds(), o.binds())
+    est, end = e.task_state()
+    ost, ond = o.task_state()
+    assert np.array_equal(est, ost) and np.array_equal(end, ond)
+    for a, b in zip(e.node_state(), o.node_state()):
+        assert np.array_equal(a, b)
+    for a, b in zip(e.shares(), o.shares()):
+        assert np.array_equal(a, b)
+    st = e.stats()
+    assert st["evals"] == o.evals and st["tasks_popped"] == o.popped
+
+
+@pytest.mark.parametrize("case", range(2))
+def test_reference_allocate_cases(oracle_mod, case):
+    """actions/allocate/allocate_test.go:51-144 through the HIP path."""
+    name, snap, expected = fixtures.allocate_cases()[case]
+    cfg = fixtures.allocate_test_tiers()
+    o, e, dec = run_both(oracle_mod, cfg, snap, ["allocate"])
+    assert snap.bind_map(e.binds()) == expected, name
+    assert_same_outcome(o, e, dec)
+
+
+def test_example_job_config1(oracle_mod):
+    cfg, snap = fixtures.example_job()
+    o, e, dec = run_both(oracle_mod, cfg, snap, ["allocate"])
+    assert sorted(np.bincount(e.binds(), minlength=3).tolist()) == [2, 2, 2]
+    assert_same_outcome(o, e, dec)
+
+
+def test_matrix_parity_config2(oracle_mod):
+    """K1 over the full 10k x 1k matrix of BASELINE config 2, bit for bit on mask and score."""
+    snap = snapmod.synth(snapmod.synth_config(2))
+    cfg = conf.load_scheduler_conf()
+    o = oracle_mod.Oracle(cfg, snap, threads=8)
+    e = engine.Engine(cfg)
+    e.load(snap)
+    for fit in (1, 0):
+        em, es = e.eval_matrix(0, snap.n_tasks, fit)
+        om, os_ = o.eval_matrix(0, snap.n_tasks, fit)
+        assert np.array_equal(em, om), f"mask differs (fit_mode {fit})"
+        assert np.array_equal(es, os_), f"score differs (fit_mode {fit})"
+    assert em.any() and es.any()
+
+
+def test_matrix_parity_r16_and_after_allocate(oracle_mod):
+    """16-dim resource vectors (config 4 shape, scaled) and a non-trivial live state (after an allocate pass)."""
+    snap = small(4, 0.03)
+    cfg = conf.load_scheduler_conf(MOST_CONF)
+    o, e, dec = run_both(oracle_mod, cfg, snap, ["allocate"])
+    assert_same_outcome(o, e, dec)
+    em, es = e.eval_matrix(0, snap.n_tasks, 1)
+    om, os_ = o.eval_matrix(0, snap.n_tasks, 1)
+    assert np.array_equal(em, om) and np.array_equal(es, os_)
+
+
+def test_argmax_parity(oracle_mod):
+    snap = small(2, 0.5)
+    cfg = conf.load_scheduler_conf()
+    o = oracle_mod.Oracle(cfg, snap, threads=8)
+    e = engine.Engine(cfg)
+    e.load(snap)
+    for k in (1, 8, 32):
+        en, es = e.argmax_rows(0, 600, k)
+        on, os_ = o.argmax_rows(0, 600, k)
+        assert np.array_equal(en, on) and np.array_equal(es, os_), k
+
+
+@pytest.mark.parametrize("window,topk", [(64, 4), (1024, 16), (4096, 0)])
+def test_allocate_backfill_config2(oracle_mod, window, topk):
+    """Full allocate + backfill on BASELINE config 2: ordered decisions, binds, state, shares identical."""
+    snap = snapmod.synth(snapmod.synth_config(2))
+    cfg = conf.load_scheduler_conf()
+    o, e, dec = run_both(oracle_mod, cfg, snap, ["allocate", "backfill"], window=window, topk=topk)
+    assert_same_outcome(o, e, dec)
+    st = e.stats()
+    assert st["decisions"] == len(dec) and st["rounds"] > 0
+
+
+def test_allocate_gang_drf_queues_scaled_config3(oracle_mod):
+    """Config 3 shape (gang minAvailable + DRF + proportion across 128 queues), scaled to oracle-in-seconds size."""
+    snap = small(3, 0.1)
+    cfg = conf.load_scheduler_conf()
+    o, e, dec = run_both(oracle_mod, cfg, snap, ["allocate", "backfill"])
+    assert_same_outcome(o, e, dec)
+    # gang semantics visible in the result: some Allocated tasks of never-ready gangs are not bound
+    st, _ = e.task_state()
+    assert (st == abi.TASK_BINDING).sum() == (e.binds() != abi.KB_NONE).sum()
+
+
+def test_reference_test_tiers_on_synthetic(oracle_mod):
+    """drf+proportion only (allocate_test.go tiers): no predicates, no node order -> pure tie-break path."""
+    snap = small(2, 0.2)
+    o, e, dec = run_both(oracle_mod, fixtures.allocate_test_tiers(), snap, ["allocate"])
+    assert_same_outcome(o, e, dec)
+
+
+def test_edge_cases(oracle_mod):
+    cfg = conf.load_scheduler_conf()
+    # no tasks at all
+    snap = snapmod.flatten([snapmod.Node("n1", {"cpu": "4", "memory": "8Gi", "pods": "10"})], [], [], [snapmod.Queue("default")])
+    o, e, dec = run_both(oracle_mod, cfg, snap, ["allocate", "backfill"])
+    assert len(dec) == 0
+    # pod-count cap: 3 one-cpu pods, node allows 2 pods
+    pods = [snapmod.Pod("ns", f"p{i}", [{"cpu": "1", "memory": "1Gi"}], group_name="g") for i in range(3)]
+    snap = snapmod.flatten([snapmod.Node("n1", {"cpu": "8", "memory": "16Gi", "pods": "2"})], pods,
+                           [snapmod.PodGroup("ns", "g", min_member=1)], [snapmod.Queue("default")])
+    o, e, dec = run_both(oracle_mod, cfg, snap, ["allocate"])
+    assert_same_outcome(o, e, dec)
+    assert len(dec) == 2
+    # taints / selectors / unschedulable nodes through the class table
+    nodes = [snapmod.Node("a", {"cpu": "8", "memory": "16Gi", "pods": "10"}, labels={"zone": "x"}),
+             snapmod.Node("b", {"cpu": "8", "memory": "16Gi", "pods": "10"}, taints=[("k", "v", "NoSchedule")]),
+             snapmod.Node("c", {"cpu": "8", "memory": "16Gi", "pods": "10"}, unschedulable=True)]
+    pods = [snapmod.Pod("ns", "sel", [{"cpu": "1"}], group_name="g", node_selector={"zone": "x"}),
+            snapmod.Pod("ns", "tol", [{"cpu": "1"}], group_name="g", tolerations=[("k", "Equal", "v", "NoSchedule")]),
+            snapmod.Pod("ns", "zzz", [{"cpu": "1"}], group_name="g", node_selector={"zone": "nowhere"})]
+    snap = snapmod.flatten(nodes, pods, [snapmod.PodGroup("ns", "g", min_member=1)], [snapmod.Queue("default")])
+    o, e, dec = run_both(oracle_mod, cfg, snap, ["allocate"])
+    assert_same_outcome(o, e, dec)
+    assert snap.bind_map(e.binds()).get("ns/sel") == "a"
