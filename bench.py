@@ -1,0 +1,168 @@
+#!/usr/bin/env python
+"""bench.py — pod-node scoring evals/s (+ binds/s) of the allocate+backfill cycle on the BASELINE workload.
+
+A "step" is one full scheduling cycle of the hot path over one synthetic session snapshot that is already
+resident in HBM: kb_session_reset (device-to-device restore of the pristine node/task state) ->
+kb_run_allocate -> kb_run_backfill.  The workload is BASELINE.json configs[2] — 100k tasks x 10k nodes, gang
+minAvailable + DRF + proportion across 128 queues, R=2 — the configuration the headline metric is quoted on.
+
+`value` = (task,node) predicate+score evaluations the reference algorithm performs for that cycle (N per popped
+task in allocate, nodes visited until the first fit in backfill: SURVEY.md §8d) x steps / wall time.
+
+One JSON line on rank 0; see DESIGN.md §7 for the roofline accounting (M: 2.125 B per evaluation written by the
+matrix kernel + inputs once) and the cpu_baseline definition.
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--config", type=int, default=3, help="BASELINE config index (2..5)")
+    ap.add_argument("--scale", type=float, default=1.0)
+    ap.add_argument("--window", type=int, default=0)
+    ap.add_argument("--topk", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-tasks", type=int, default=20000)
+    ap.add_argument("--verify", action="store_true", help="compare the bind set with the oracle after the timed region (slow)")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    kbm = importlib.import_module("kube-batch_amd")
+    engine = importlib.import_module("kube-batch_amd.engine")
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if rank == 0:
+            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run", file=sys.stderr)
+        if args.gpus > 1 and world == 1:
+            sys.exit(2)
+    if not torch.cuda.is_available():
+        print("bench.py: no GPU visible; the engine has no CPU path", file=sys.stderr)
+        sys.exit(2)
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl")
+
+    conf = kbm.conf.load_scheduler_conf()          # pkg/scheduler/util.go:31-42 default: allocate, backfill; all six plugins
+    params = kbm.snapshot.synth_config(args.config, args.scale)
+    snap = kbm.snapshot.synth(params)
+    actions = ["allocate", "backfill"]
+
+    if world > 1:
+        distmod = importlib.import_module("kube-batch_amd.dist")
+        runner = distmod.ShardedCycle(conf, snap, device=local_rank, window=args.window, topk=args.topk)
+        step = runner.step
+        eng = runner.engine
+    else:
+        eng = engine.Engine(conf, device=local_rank, window=args.window, topk=args.topk)
+        eng.load(snap)
+
+        def step():
+            eng.reset()
+            for a in actions:
+                getattr(eng, "run_" + a)()
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    s0 = eng.stats()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    t1 = time.perf_counter()
+    s1 = eng.stats()
+    elapsed = t1 - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    binds = eng.binds()
+    n_binds = int((binds != kbm.abi.KB_NONE).sum())
+    d = {k: s1[k] - s0[k] for k in s1}
+    evals = d["evals"]
+    value = evals / elapsed
+
+    # ---- roofline of the dominant-by-bytes kernel (K1 mask+score matrix), measured with HIP events on the engine stream
+    R, N = snap.n_res, snap.n_nodes
+    b_node, b_task = 16 * R + 44, 8 * R + 24                       # SURVEY.md §8d accounting (M)
+    launches = max(1, d["matrix_launches"])
+    rows_per_launch = d["matrix_evals"] / N / launches
+    alg_bytes = rows_per_launch * N * 2.125 + N * b_node + rows_per_launch * b_task
+    avg_ms = d["matrix_ms"] / launches
+    achieved = alg_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+    roofline = {"bound": "hbm", "kernel": "k_matrix", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                "bytes_per_launch": int(alg_bytes), "avg_launch_ms": round(avg_ms, 5), "launches": int(launches),
+                "rows_per_launch": round(rows_per_launch, 1)}
+
+    out = {
+        "metric": "pod-node scoring evals/sec + binds/sec, 100k tasks x 10k nodes snapshot",
+        "value": value, "unit": "evals/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": elapsed * 1e3 / args.steps, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f64+i64", "data": "synthetic",
+        "config": {"workload": f"BASELINE configs[{args.config - 1}]: {snap.n_tasks} tasks x {snap.n_nodes} nodes, "
+                               f"{snap.n_jobs} gang jobs, {snap.n_queues} queues, R={R}, allocate+backfill, "
+                               "plugins priority,gang,drf,predicates,proportion,nodeorder",
+                   "window": int(d["matrix_evals"] / N / launches) if launches else 0, "scale": args.scale},
+        "binds_per_s": n_binds * args.steps / elapsed, "binds": n_binds, "decisions": int(d["decisions"] / args.steps),
+        "evals_per_step": int(evals / args.steps),
+        "kernel_ms_per_step": {k: round(d[k] / args.steps, 3) for k in ("matrix_ms", "argmax_ms", "commit_ms", "reduce_ms", "host_order_ms", "total_ms")},
+        "rounds_per_step": d["rounds"] / args.steps, "spec_breaks_per_step": d["spec_breaks"] / args.steps,
+        "row_fallbacks_per_step": d["row_fallbacks"] / args.steps,
+        "roofline": roofline,
+    }
+
+    if rank == 0 and not args.no_cpu_baseline:
+        import oracle
+        oracle.build()
+        threads = min(16, os.cpu_count() or 1)    # util/scheduler_helper.go:84: 16 workers
+        o = oracle.Oracle(conf, snap, threads=threads)
+        o.set_task_limit(args.cpu_sample_tasks)
+        c0 = time.perf_counter()
+        o.allocate()
+        c1 = time.perf_counter()
+        out["cpu_baseline"] = {"value": o.evals / (c1 - c0), "unit": "evals/s", "cores": threads, "kind": "port",
+                               "sample": f"first {o.popped} popped tasks of the same snapshot's allocate action "
+                                         f"({o.evals} evals, {c1 - c0:.1f} s); C restatement of the Go loop with the "
+                                         "reference's 16-worker per-task fan-out, without its per-pair NodeInfo rebuilds"}
+        o.close()
+    if rank == 0 and args.verify:
+        import oracle
+        o = oracle.Oracle(conf, snap, threads=min(16, os.cpu_count() or 1))
+        o.run(actions)
+        out["verified_bind_set_equals_oracle"] = bool(np.array_equal(binds, o.binds()))
+        out["verified_evals_equal_oracle"] = bool(o.evals == out["evals_per_step"])
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

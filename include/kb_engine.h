@@ -18,6 +18,8 @@
  *       pkg/scheduler/framework/session.go:63-115) plus every plugin's OnSessionOpen state:
  *       drf totals/shares (plugins/drf/drf.go:60-83), proportion deserved water-fill
  *       (plugins/proportion/proportion.go:58-154), gang JobValid filter (plugins/gang/gang.go:48-69).
+ *   kb_session_reset
+ *       a second framework.OpenSession on an unchanged cache (same Snapshot(), same OnSessionOpen results).
  *   kb_run_allocate
  *       allocateAction.Execute (pkg/scheduler/actions/allocate/allocate.go:43-194) with
  *       util.PredicateNodes / PrioritizeNodes / SelectBestNode
@@ -112,6 +114,7 @@ typedef struct kb_plugin_option {
 } kb_plugin_option;
 
 #define KB_FLAG_SYNC_ROUNDS 1u  /* disable host/device overlap (debug) */
+#define KB_FLAG_NO_TOPK     2u  /* skip the segmented arg-max: the commit kernel scans the stored matrix row for every task */
 
 typedef struct kb_config {
   uint32_t version;                /* KB_ABI_VERSION */
@@ -209,6 +212,9 @@ void kb_engine_destroy(kb_engine *e);
 const char *kb_last_error(const kb_engine *e);   /* valid until the next call on e; e == NULL -> creation error */
 
 int  kb_session_load(kb_engine *e, const kb_snapshot *snap);
+/* restore the loaded session to its just-loaded state from the pristine copy kept in HBM (device-to-device);
+   the snapshot is not read again.  Used to run the same cycle repeatedly (bench steps) without a host upload. */
+int  kb_session_reset(kb_engine *e);
 
 int  kb_run_allocate(kb_engine *e, kb_decision *out, uint64_t cap, uint64_t *n_out);
 int  kb_run_backfill(kb_engine *e, kb_decision *out, uint64_t cap, uint64_t *n_out);

@@ -39,6 +39,7 @@ EN_NODE_ORDER = 1 << 8
 EN_ALL = 0x1FF
 
 FLAG_SYNC_ROUNDS = 1
+FLAG_NO_TOPK = 2
 
 
 class PluginOption(C.Structure):

@@ -99,6 +99,7 @@ struct kb_engine {
   // session buffers
   DevBuf b_idle, b_rel, b_nzc, b_nzm, b_podcnt, b_acpu, b_amem, b_maxpods, b_ncls, b_nmask;
   DevBuf b_tinit, b_tres, b_tnzc, b_tnzm, b_tcls, b_tactive, b_tresmask, b_tjob, b_tstatus, b_tnode, b_tbind, b_tcounted, b_compat;
+  DevBuf p_idle, p_rel, p_nzc, p_nzm, p_podcnt, p_tstatus, p_tnode, p_tcounted;   // pristine copies for kb_session_reset
   DevBuf b_jbegin, b_jmin, b_jqueue, b_total, b_deserved, b_desmask, b_jalloc, b_jshare, b_qalloc, b_qshare, b_jready;
   uint32_t total_mask = 0;
   // round buffers
@@ -361,6 +362,7 @@ int kb_engine_create(const kb_config *cfg, kb_engine **out) {
     if (cfg->window) eng->window = cfg->window;
     if (cfg->topk) eng->topk = cfg->topk > KB_MAX_TOPK ? KB_MAX_TOPK : cfg->topk;
     eng->flags = cfg->flags;
+    if (cfg->flags & KB_FLAG_NO_TOPK) eng->topk = 0;
     int ndev = 0;
     hipError_t he = hipGetDeviceCount(&ndev);
     if (he != hipSuccess || ndev <= 0)
@@ -619,10 +621,34 @@ int kb_session_load(kb_engine *e, const kb_snapshot *sn) {
     e->round_cap = 0;
     e->stats = kb_stats{};
     e->round_no = 0;
+    auto snap_copy = [&](DevBuf &dst, const DevBuf &src) {
+      dst.alloc(src.bytes);
+      HIP_OK(hipMemcpyAsync(dst.p, src.p, src.bytes, hipMemcpyDeviceToDevice, s));
+    };
+    snap_copy(e->p_idle, e->b_idle); snap_copy(e->p_rel, e->b_rel); snap_copy(e->p_nzc, e->b_nzc); snap_copy(e->p_nzm, e->b_nzm);
+    snap_copy(e->p_podcnt, e->b_podcnt); snap_copy(e->p_tstatus, e->b_tstatus); snap_copy(e->p_tnode, e->b_tnode);
+    snap_copy(e->p_tcounted, e->b_tcounted);
     // initial drf / proportion / gang aggregates come from the device reduction (K2+K4)
     run_finalize(e);
     e->stats.reduce_ms = 0;
     e->loaded = true;
+  });
+}
+
+int kb_session_reset(kb_engine *e) {
+  if (!e) return KB_E_INVALID;
+  return guarded(e, [&]() {
+    if (!e->loaded) throw EngineError(KB_E_STATE, "no session loaded");
+    hipStream_t s = e->stream;
+    auto restore = [&](DevBuf &dst, const DevBuf &src) { HIP_OK(hipMemcpyAsync(dst.p, src.p, src.bytes, hipMemcpyDeviceToDevice, s)); };
+    restore(e->b_idle, e->p_idle); restore(e->b_rel, e->p_rel); restore(e->b_nzc, e->p_nzc); restore(e->b_nzm, e->p_nzm);
+    restore(e->b_podcnt, e->p_podcnt); restore(e->b_tstatus, e->p_tstatus); restore(e->b_tnode, e->p_tnode);
+    restore(e->b_tcounted, e->p_tcounted);
+    HIP_OK(hipMemsetAsync(e->b_tbind.p, 0xFF, sizeof(uint32_t) * (e->hs.T ? e->hs.T : 1), s));
+    e->mg.active = false;
+    double keep = e->stats.reduce_ms;
+    run_finalize(e);
+    e->stats.reduce_ms = keep;
   });
 }
 

@@ -16,7 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libkbengine.so")
 _LIB = None
 
-EXPORTS = ["kb_engine_create", "kb_engine_destroy", "kb_last_error", "kb_session_load", "kb_run_allocate",
+EXPORTS = ["kb_engine_create", "kb_engine_destroy", "kb_last_error", "kb_session_load", "kb_session_reset", "kb_run_allocate",
            "kb_run_backfill", "kb_eval_matrix", "kb_argmax_rows", "kb_bench_matrix", "kb_get_binds",
            "kb_get_task_state", "kb_get_node_state", "kb_get_shares", "kb_get_stats", "kb_round_begin",
            "kb_round_candidates", "kb_round_commit", "kb_round_apply", "kb_round_topk", "kb_round_delta_doubles",
@@ -50,6 +50,7 @@ def lib():
         L.kb_last_error.argtypes = [vp]
         L.kb_last_error.restype = C.c_char_p
         L.kb_session_load.argtypes = [vp, C.POINTER(abi.Snapshot)]
+        L.kb_session_reset.argtypes = [vp]
         for n in ("kb_run_allocate", "kb_run_backfill"):
             getattr(L, n).argtypes = [vp, C.POINTER(abi.Decision), C.c_uint64, C.POINTER(C.c_uint64)]
         L.kb_eval_matrix.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint8), C.POINTER(C.c_uint16)]
@@ -109,6 +110,10 @@ class Engine:
         self.snap = snap
         s = snap.to_abi()
         self._ck(self.L.kb_session_load(self.h, C.byref(s)))
+
+    def reset(self):
+        """Back to the just-loaded state from the pristine copy resident in HBM (no host upload)."""
+        self._ck(self.L.kb_session_reset(self.h))
 
     def _run(self, fn):
         cap = max(int(self.snap.n_tasks), 1)

@@ -410,6 +410,7 @@ typedef struct kbo_session {
   uint64_t evals, popped;
   int panic;
   int threads;
+  uint64_t task_limit;  /* cpu_baseline sample: stop the allocate loop after this many popped tasks (0 = none) */
 } kbo_session;
 
 static int find_plugin_enabled(const kbo_session *s, uint32_t plugin, uint32_t en_bit) {
@@ -925,6 +926,7 @@ int kbo_allocate(kbo_session *s) {
       }
     }
     while (job->tasks.n > 0) {                              /* allocate.go:129 */
+      if (s->task_limit && s->popped >= s->task_limit) goto done;   /* bounded timing sample, not part of the algorithm */
       uint32_t t = heap_pop(&job->tasks);
       o_task *tk = &s->tasks[t];
       eval_all_nodes(s, tk, 1, feas, score);                /* PredicateNodes + PrioritizeNodes */
@@ -1059,3 +1061,4 @@ void kbo_get_shares(const kbo_session *s, double *job_share, double *queue_share
 void kbo_get_job_valid(const kbo_session *s, uint8_t *valid) { for (uint32_t j = 0; j < s->J; j++) valid[j] = (uint8_t)s->jobs[j].valid; }
 int32_t kbo_job_valid_num(const kbo_session *s, uint32_t j) { return job_valid_num(&s->jobs[j]); }
 int32_t kbo_job_ready_num(const kbo_session *s, uint32_t j) { return job_ready_num(&s->jobs[j]); }
+void kbo_set_task_limit(kbo_session *s, uint64_t limit) { s->task_limit = limit; }

@@ -58,6 +58,7 @@ def lib():
         L.kbo_share.argtypes = [C.c_double, C.c_double]
         L.kbo_res_multi.argtypes = [C.POINTER(OracleRes), C.c_double]
         L.kbo_scorers.argtypes = [C.c_int64] * 4 + [C.POINTER(C.c_int64)] * 3
+        L.kbo_set_task_limit.argtypes = [C.c_void_p, C.c_uint64]
         L.kbo_job_valid_num.argtypes = [C.c_void_p, C.c_uint32]
         L.kbo_job_ready_num.argtypes = [C.c_void_p, C.c_uint32]
         _LIB = L
@@ -92,6 +93,10 @@ class Oracle:
             self.close()
         except Exception:
             pass
+
+    def set_task_limit(self, n):
+        """Bounded cpu_baseline sample: the allocate loop stops after n popped tasks."""
+        self.L.kbo_set_task_limit(self.h, int(n))
 
     def allocate(self):
         rc = self.L.kbo_allocate(self.h)

@@ -119,12 +119,12 @@ def test_argmax_parity(oracle_mod):
         assert np.array_equal(en, on) and np.array_equal(es, os_), k
 
 
-@pytest.mark.parametrize("window,topk", [(64, 4), (1024, 16), (4096, 0)])
-def test_allocate_backfill_config2(oracle_mod, window, topk):
+@pytest.mark.parametrize("window,topk,flags", [(64, 4, 0), (1024, 16, 0), (4096, 0, abi.FLAG_NO_TOPK), (512, 32, 0)])
+def test_allocate_backfill_config2(oracle_mod, window, topk, flags):
     """Full allocate + backfill on BASELINE config 2: ordered decisions, binds, state, shares identical."""
     snap = snapmod.synth(snapmod.synth_config(2))
     cfg = conf.load_scheduler_conf()
-    o, e, dec = run_both(oracle_mod, cfg, snap, ["allocate", "backfill"], window=window, topk=topk)
+    o, e, dec = run_both(oracle_mod, cfg, snap, ["allocate", "backfill"], window=window, topk=topk, flags=flags)
     assert_same_outcome(o, e, dec)
     st = e.stats()
     assert st["decisions"] == len(dec) and st["rounds"] > 0
