@@ -1,21 +1,24 @@
 // kb_device.h — plain-data views shared by the host engine (kb_engine.cpp) and the HIP kernels (kb_kernels.hip).
 //
-// HBM layout of a session: every per-node field is a dense array over NP = N rounded up to 1024
+// HBM layout of a session: every per-node field is a dense array over NP = N rounded up to 2048
 // (so a wave's 16-byte loads never straddle a row end), resource vectors are dimension-major f64[R][NP] /
 // f64[R][T]; the k8s-side scorer inputs are int64[NP]; the per-round mask+score matrix is u16[W][NP] plus
 // bit-packed u32[W][NP/32].
 #pragma once
 #include <stdint.h>
 
-#define KB_NODE_PAD 1024u
-#define KB_K5_THREADS 1024
+#define KB_NODE_PAD 2048u   // NP/8 node chunks split evenly over 256 threads (K3), 16-byte loads never straddle a row
+#define KB_K5_THREADS 512
 #define KB_MAX_TOPK 32
 
-// arg-max key: (score+1) << 32 | (0xFFFFFFFF - node). 0 = no feasible node.  max() over keys = highest score,
-// then lowest node index = util.SelectBestNode with the canonical tie-break (scheduler_helper.go:188-208).
-#define KB_KEY(score, node) ((((unsigned long long)(score) + 1ull) << 32) | (unsigned long long)(0xFFFFFFFFu - (uint32_t)(node)))
+// arg-max key: (0x40000000 + score + 1) << 32 | (0xFFFFFFFF - node).  0 = no feasible node.  max() over keys = highest
+// score, then lowest node index = util.SelectBestNode with the canonical tie-break (scheduler_helper.go:188-208).
+// The 0x40000000 bias makes every key the bit pattern of a positive normal float64, and for such patterns integer
+// order equals floating-point order: wave reductions use v_max_f64 on DPP-moved halves (3 instructions per step).
+#define KB_KEY_BIAS 0x40000000ull
+#define KB_KEY(score, node) (((KB_KEY_BIAS + (unsigned long long)(score) + 1ull) << 32) | (unsigned long long)(0xFFFFFFFFu - (uint32_t)(node)))
 #define KB_KEY_NODE(key) (0xFFFFFFFFu - (uint32_t)((key)&0xFFFFFFFFull))
-#define KB_KEY_SCORE(key) ((uint32_t)((key) >> 32) - 1u)
+#define KB_KEY_SCORE(key) ((uint32_t)(((key) >> 32) - KB_KEY_BIAS) - 1u)
 
 struct KbDev {
   int R;
@@ -31,6 +34,7 @@ struct KbDev {
   const int *maxpods;             // [NP]
   const uint32_t *ncls;           // [NP]
   const uint32_t *nmask;          // [NP] Idle.ScalarResources != nil  (Allocatable had scalar keys)
+  const double *inv_acpu, *inv_amem;  // [NP] 1.0/(double)allocatable, for the exact integer-division estimate
   // tasks
   const double *t_init;           // [R][T]
   const double *t_res;            // [R][T]
@@ -52,31 +56,58 @@ struct KbDev {
   int score_enabled;              // nodeorder plugin registered with EnabledNodeOrder
 };
 
-// one device round (matrix -> arg-max -> commit)
+// one device round (matrix -> sorted candidates -> commit)
+//
+// Rows of the window that share a shape (InitResreq, non-zero request, static class) have identical matrix rows, so
+// the matrix and the candidate lists are built once per distinct shape of the window ("mrows"); row i of the
+// window refers to its shape through shape_slot[i].
+// everything the commit kernel needs to know about one window row, gathered contiguously so that the row i+2 can be
+// fetched with one wave-uniform (scalar) load while row i is being committed
+struct KbRowDesc {          // 56 bytes
+  double init0, init1;     // InitResreq cpu, memory
+  long long nzc, nzm;      // pod non-zero request
+  uint32_t task, active, resmask, cls;
+  uint16_t slot;           // index of the row's shape among the mrows
+  uint16_t flags;          // bit 0: Resreq cpu/memory == InitResreq cpu/memory (no init container raised them)
+  uint32_t pad;
+};
+
 struct KbRound {
-  const uint32_t *rows;       // [n_rows] task ids in speculated order (nullptr: row i is task row_task0 + i)
-  uint32_t row_task0;
-  const uint8_t *same_prev;   // [n_rows] row has the same shape (InitResreq, non-zero request, class) as the previous row
+  // the window, in the reference's task order
+  const uint32_t *rows;        // [n_rows] task ids
+  const uint32_t *shape_slot;  // [n_rows] index of the row's shape among the mrows
   uint32_t n_rows;
-  int fit_mode;               // 1 allocate (resource fit + plugin predicates), 0 plugin predicates only
-  uint16_t *score;            // [n_rows][NP]
-  uint32_t *maskw;            // [n_rows][NP/32]
-  unsigned long long *keys;   // [n_rows][topk]
-  uint32_t topk;
+  KbRowDesc *desc;             // [n_rows] built on the device by kb_launch_gather
+  unsigned long long *trace;   // optional cycle stamps of the commit kernel (debug), nullptr otherwise
+  uint32_t cap;                // slot capacity of the commit kernel's LDS tables (>= n_rows)
+  // matrix rows
+  const uint32_t *mrows;       // [n_mrows] representative task of each shape (nullptr: mrow i is task mrow_task0 + i)
+  uint32_t mrow_task0;
+  const uint8_t *same_prev;    // [n_mrows] mrow has the same shape as mrow-1 (only set by kb_eval_matrix's canonical rows)
+  uint32_t n_mrows;
+  int fit_mode;                // 1 allocate (resource fit + plugin predicates), 0 plugin predicates only
+  uint16_t *score;             // [n_mrows][NP]
+  uint32_t *maskw;             // [n_mrows][NP/32]
+  unsigned long long *keys;    // [n_mrows][L] candidates, best first (descending score, ascending node index), 0-terminated
+  uint32_t L;                  // list length; L >= n_rows + 1 guarantees a clean candidate survives any dirty set of the round
   // commit outputs
-  uint32_t *dec_node;         // [n_rows]
-  uint32_t *dec_kind;         // [n_rows]
-  uint32_t *result;           // [8]: n_done, reason, n_dirty, fallbacks, live_rescans
-  uint32_t *dirty_list;       // [n_rows]
-  int use_rows;               // rows of the matrix are resident locally (single GPU); 0 = candidates only
-  int backfill;               // commit semantics of backfill.go (status Allocated, Resreq accounting, no share feedback)
-  double *delta;              // optional per-node committed deltas of owned rows [NP*(2R+3)] (multi-GPU), may be nullptr
+  uint32_t *dec_node;          // [n_rows]
+  uint32_t *dec_kind;          // [n_rows]
+  uint32_t *result;            // [8]: n_done, reason, n_dirty, list_exhausted (live rescans), window_refills
+  int backfill;                // commit semantics of backfill.go (first node passing the predicates, no score)
+  double *delta;               // optional per-node committed deltas of owned rows [NP*(2R+3)] (multi-GPU), may be nullptr
   uint32_t own_row0, own_row1;
 };
+
+#define KB_K5_MAX_WINDOW 1024u   // dirty-node table + row descriptors of the commit kernel live in LDS: 152 B per row
+
+// dynamic LDS the commit kernel needs for `cap` slots over NP padded nodes (kb_kernels.hip)
+size_t kb_commit_smem_bytes(uint32_t cap, uint32_t NP);
 
 enum { KB_REASON_DONE = 0, KB_REASON_NO_FEASIBLE = 1, KB_REASON_PIPELINED = 2 };
 
 // launch wrappers (kb_kernels.hip); all asynchronous on `stream`
+void kb_launch_gather(const KbDev &d, const KbRound &r, void *stream);
 void kb_launch_matrix(const KbDev &d, const KbRound &r, void *stream);
 void kb_launch_argmax(const KbDev &d, const KbRound &r, void *stream);
 void kb_launch_commit(const KbDev &d, const KbRound &r, void *stream);

@@ -10,6 +10,7 @@
 
 #include <chrono>
 #include <cstdio>
+#include <cstdlib>
 #include <functional>
 #include <map>
 #include <memory>
@@ -97,16 +98,23 @@ struct kb_engine {
   uint64_t round_no = 0;
 
   // session buffers
-  DevBuf b_idle, b_rel, b_nzc, b_nzm, b_podcnt, b_acpu, b_amem, b_maxpods, b_ncls, b_nmask;
+  DevBuf b_idle, b_rel, b_nzc, b_nzm, b_podcnt, b_acpu, b_amem, b_maxpods, b_ncls, b_nmask, b_invac, b_invam;
+  uint32_t eff_window = 0;   // window actually used for this session (bounded by the commit kernel's LDS budget)
   DevBuf b_tinit, b_tres, b_tnzc, b_tnzm, b_tcls, b_tactive, b_tresmask, b_tjob, b_tstatus, b_tnode, b_tbind, b_tcounted, b_compat;
   DevBuf p_idle, p_rel, p_nzc, p_nzm, p_podcnt, p_tstatus, p_tnode, p_tcounted;   // pristine copies for kb_session_reset
   DevBuf b_jbegin, b_jmin, b_jqueue, b_total, b_deserved, b_desmask, b_jalloc, b_jshare, b_qalloc, b_qshare, b_jready;
   uint32_t total_mask = 0;
   // round buffers
-  DevBuf b_rows, b_same, b_score, b_maskw, b_keys, b_decnode, b_deckind, b_result, b_dirty;
-  uint32_t round_cap = 0;
-  std::vector<uint32_t> h_rows, h_decnode, h_deckind;
+  DevBuf b_desc, b_trace;
+  bool trace_on = false;
+  std::vector<double> trace_acc = std::vector<double>(2 * 4 * 12, 0.0);
+  DevBuf b_rows, b_slot, b_mrows, b_same, b_score, b_maskw, b_keys, b_decnode, b_deckind, b_result;
+  uint32_t win_cap = 0, mat_cap = 0;
+  size_t keys_cap = 0;
+  std::vector<uint32_t> h_rows, h_slot, h_mrows, h_decnode, h_deckind;
   std::vector<uint8_t> h_same;
+  std::vector<uint32_t> shape_stamp, shape_slot_of;   // per row-shape id: round stamp and slot inside the current round
+  uint32_t stamp = 0;
   uint32_t *h_result = nullptr;   // pinned [8]
   std::vector<Timer> ev;          // event pool for per-launch timing
   std::vector<kb_decision> decisions_all;   // decisions of the last multi-GPU round sequence
@@ -193,22 +201,37 @@ template <typename K> uint32_t intern(std::map<K, uint32_t> &m, const K &k) {
   return id;
 }
 
-void ensure_round_buffers(kb_engine *e, uint32_t rows) {
-  if (rows <= e->round_cap) return;
-  const size_t NP = e->dev.NP;
+// window buffers: one entry per task row of a round
+void ensure_window_buffers(kb_engine *e, uint32_t rows) {
+  if (rows <= e->win_cap) return;
   e->b_rows.alloc(sizeof(uint32_t) * rows);
-  e->b_same.alloc(rows);
-  e->b_score.alloc(sizeof(uint16_t) * (size_t)rows * NP);
-  e->b_maskw.alloc(sizeof(uint32_t) * (size_t)rows * (NP / 32));
-  e->b_keys.alloc(sizeof(unsigned long long) * (size_t)rows * KB_MAX_TOPK);
+  e->b_slot.alloc(sizeof(uint32_t) * rows);
+  e->b_desc.alloc(sizeof(KbRowDesc) * rows);
   e->b_decnode.alloc(sizeof(uint32_t) * rows);
   e->b_deckind.alloc(sizeof(uint32_t) * rows);
-  e->b_dirty.alloc(sizeof(uint32_t) * rows);
   e->h_rows.resize(rows);
-  e->h_same.resize(rows);
+  e->h_slot.resize(rows);
   e->h_decnode.resize(rows);
   e->h_deckind.resize(rows);
-  e->round_cap = rows;
+  e->win_cap = rows;
+}
+// matrix buffers: one matrix row per distinct shape (or per task row for kb_eval_matrix), L candidate keys per row
+void ensure_matrix_buffers(kb_engine *e, uint32_t mrows, uint32_t L) {
+  const size_t NP = e->dev.NP;
+  if (mrows > e->mat_cap) {
+    e->b_mrows.alloc(sizeof(uint32_t) * mrows);
+    e->b_same.alloc(mrows);
+    e->b_score.alloc(sizeof(uint16_t) * (size_t)mrows * NP);
+    e->b_maskw.alloc(sizeof(uint32_t) * (size_t)mrows * (NP / 32));
+    e->h_mrows.resize(mrows);
+    e->h_same.resize(mrows);
+    e->mat_cap = mrows;
+  }
+  size_t need = (size_t)mrows * L;
+  if (need > e->keys_cap) {
+    e->b_keys.alloc(sizeof(unsigned long long) * need);
+    e->keys_cap = need;
+  }
 }
 
 Timer &get_timer(kb_engine *e, size_t i) {
@@ -246,46 +269,76 @@ void run_finalize(kb_engine *e) {
     if (!hs.queue_has_attr[q]) hs.queue_share[q] = 0.0;
 }
 
-KbRound make_round(kb_engine *e, uint32_t n_rows, int fit_mode, bool backfill) {
+KbRound make_round(kb_engine *e, uint32_t n_rows, uint32_t n_mrows, uint32_t L, int fit_mode, bool backfill) {
   KbRound r{};
   r.rows = e->b_rows.as<uint32_t>();
-  r.row_task0 = 0;
-  r.same_prev = e->b_same.as<uint8_t>();
+  r.shape_slot = e->b_slot.as<uint32_t>();
   r.n_rows = n_rows;
+  r.desc = e->b_desc.as<KbRowDesc>();
+  r.trace = e->trace_on ? e->b_trace.as<unsigned long long>() : nullptr;
+  r.cap = std::max<uint32_t>(64, ((n_rows + 63) / 64) * 64);
+  r.mrows = e->b_mrows.as<uint32_t>();
+  r.mrow_task0 = 0;
+  r.same_prev = nullptr;
+  r.n_mrows = n_mrows;
   r.fit_mode = fit_mode;
   r.score = e->b_score.as<uint16_t>();
   r.maskw = e->b_maskw.as<uint32_t>();
   r.keys = e->b_keys.as<unsigned long long>();
-  r.topk = e->topk;
+  r.L = L;
   r.dec_node = e->b_decnode.as<uint32_t>();
   r.dec_kind = e->b_deckind.as<uint32_t>();
   r.result = e->b_result.as<uint32_t>();
-  r.dirty_list = e->b_dirty.as<uint32_t>();
-  r.use_rows = 1;
   r.backfill = backfill ? 1 : 0;
   r.delta = nullptr;
   r.own_row0 = r.own_row1 = 0;
   return r;
 }
 
-// one single-GPU round over e->h_rows[0..n): matrix -> arg-max -> commit; returns n_done / reason
-void run_round(kb_engine *e, uint32_t n, int fit_mode, bool backfill, uint32_t &n_done, uint32_t &reason) {
-  ensure_round_buffers(e, n);
+// distinct shapes of the window e->h_rows[0..n): fills h_slot (per row) and h_mrows (representative task per shape)
+uint32_t assign_shapes(kb_engine *e, uint32_t n) {
   HostSession &hs = e->hs;
-  for (uint32_t i = 0; i < n; i++)
-    e->h_same[i] = (i > 0 && hs.t_row_shape[e->h_rows[i]] == hs.t_row_shape[e->h_rows[i - 1]]) ? 1 : 0;
+  if (e->shape_stamp.size() != hs.n_row_shapes) {
+    e->shape_stamp.assign(hs.n_row_shapes, 0);
+    e->shape_slot_of.assign(hs.n_row_shapes, 0);
+    e->stamp = 0;
+  }
+  e->stamp++;
+  uint32_t ns = 0;
+  for (uint32_t i = 0; i < n; i++) {
+    uint32_t sh = hs.t_row_shape[e->h_rows[i]];
+    if (e->shape_stamp[sh] != e->stamp) {
+      e->shape_stamp[sh] = e->stamp;
+      e->shape_slot_of[sh] = ns;
+      e->h_mrows[ns] = e->h_rows[i];
+      ns++;
+    }
+    e->h_slot[i] = e->shape_slot_of[sh];
+  }
+  return ns;
+}
+
+// one single-GPU round over e->h_rows[0..n): matrix -> sorted candidates -> commit; returns n_done / reason
+void run_round(kb_engine *e, uint32_t n, int fit_mode, bool backfill, uint32_t &n_done, uint32_t &reason) {
+  ensure_window_buffers(e, n);
+  ensure_matrix_buffers(e, n, n + 1);
+  HostSession &hs = e->hs;
+  const uint32_t ns = assign_shapes(e, n);
+  const uint32_t L = n + 1;   // more candidates than the round can dirty: a clean one always survives
   HIP_OK(hipMemcpyAsync(e->b_rows.p, e->h_rows.data(), sizeof(uint32_t) * n, hipMemcpyHostToDevice, e->stream));
-  HIP_OK(hipMemcpyAsync(e->b_same.p, e->h_same.data(), n, hipMemcpyHostToDevice, e->stream));
+  HIP_OK(hipMemcpyAsync(e->b_slot.p, e->h_slot.data(), sizeof(uint32_t) * n, hipMemcpyHostToDevice, e->stream));
+  HIP_OK(hipMemcpyAsync(e->b_mrows.p, e->h_mrows.data(), sizeof(uint32_t) * ns, hipMemcpyHostToDevice, e->stream));
   KbDev d = e->dev;
   if (backfill) d.score_enabled = 0;   // backfill.go:50-66 takes the first node that passes the predicates: all scores tie
-  KbRound r = make_round(e, n, fit_mode, backfill);
+  KbRound r = make_round(e, n, ns, L, fit_mode, backfill);
   Timer &t1 = get_timer(e, 0), &t3 = get_timer(e, 1), &t5 = get_timer(e, 2);
+  if (e->trace_on) HIP_OK(hipMemsetAsync(e->b_trace.p, 0, e->b_trace.bytes, e->stream));
+  kb_launch_gather(d, r, e->stream);
   HIP_OK(hipEventRecord(t1.a, e->stream));
   kb_launch_matrix(d, r, e->stream);
   HIP_OK(hipEventRecord(t1.b, e->stream));
   HIP_OK(hipEventRecord(t3.a, e->stream));
-  if (e->topk) kb_launch_argmax(d, r, e->stream);
-  else r.keys = nullptr;
+  kb_launch_argmax(d, r, e->stream);
   HIP_OK(hipEventRecord(t3.b, e->stream));
   HIP_OK(hipEventRecord(t5.a, e->stream));
   kb_launch_commit(d, r, e->stream);
@@ -299,13 +352,30 @@ void run_round(kb_engine *e, uint32_t n, int fit_mode, bool backfill, uint32_t &
   HIP_OK(hipEventElapsedTime(&ms, t1.a, t1.b));
   e->stats.matrix_ms += ms;
   e->stats.matrix_launches += 1;
-  e->stats.matrix_evals += (uint64_t)n * hs.N;
+  e->stats.matrix_evals += (uint64_t)ns * hs.N;
   HIP_OK(hipEventElapsedTime(&ms, t3.a, t3.b));
   e->stats.argmax_ms += ms;
   HIP_OK(hipEventElapsedTime(&ms, t5.a, t5.b));
   e->stats.commit_ms += ms;
   n_done = e->h_result[0];
   reason = e->h_result[1];
+  if (e->trace_on) {   // KB_K5_TRACE=1: per-phase shader-clock deltas of the commit kernel, first 512 rows of every round
+    std::vector<unsigned long long> tr(2 * 512 * 10);
+    HIP_OK(hipMemcpy(tr.data(), e->b_trace.p, sizeof(unsigned long long) * tr.size(), hipMemcpyDeviceToHost));
+    uint32_t m = std::min<uint32_t>(n_done, 512);
+    for (int who = 0; who < 2; who++)
+      for (uint32_t i = 0; i + 1 < m; i++) {
+        const unsigned long long *a = &tr[((size_t)who * 512 + i) * 10], *nx = &tr[((size_t)who * 512 + i + 1) * 10];
+        if (!a[8] || !nx[0]) continue;
+        int cls = (int)(a[9] & 3);
+        double *acc = &e->trace_acc[((size_t)who * 4 + cls) * 12];
+        for (int k = 0; k < 8; k++) acc[k] += (double)(a[k + 1] - a[k]);
+        acc[8] += (double)(nx[0] - a[8]);
+        acc[9] += (double)(nx[0] - a[0]);
+        acc[10] += 1.0;
+        acc[11] += (double)(a[9] >> 8);
+      }
+  }
   e->stats.row_fallbacks += e->h_result[3];
   e->stats.rounds += 1;
   e->round_no += 1;
@@ -360,9 +430,8 @@ int kb_engine_create(const kb_config *cfg, kb_engine **out) {
     eng->pol = compile_policy(cfg);
     eng->device = cfg->device;
     if (cfg->window) eng->window = cfg->window;
-    if (cfg->topk) eng->topk = cfg->topk > KB_MAX_TOPK ? KB_MAX_TOPK : cfg->topk;
+    if (eng->window > KB_K5_MAX_WINDOW) eng->window = KB_K5_MAX_WINDOW;   // the commit kernel's dirty-node table lives in LDS
     eng->flags = cfg->flags;
-    if (cfg->flags & KB_FLAG_NO_TOPK) eng->topk = 0;
     int ndev = 0;
     hipError_t he = hipGetDeviceCount(&ndev);
     if (he != hipSuccess || ndev <= 0)
@@ -372,6 +441,9 @@ int kb_engine_create(const kb_config *cfg, kb_engine **out) {
     HIP_OK(hipStreamCreateWithFlags(&eng->stream, hipStreamNonBlocking));
     HIP_OK(hipHostMalloc((void **)&eng->h_result, sizeof(uint32_t) * 8, hipHostMallocDefault));
     eng->b_result.alloc(sizeof(uint32_t) * 8);
+    if (const char *tr = getenv("KB_K5_TRACE")) {
+      if (tr[0] == '1') { eng->trace_on = true; eng->b_trace.alloc(sizeof(unsigned long long) * 2 * 512 * 10); }
+    }
     e = eng.release();
   });
   if (rc == KB_OK) *out = e;
@@ -380,6 +452,19 @@ int kb_engine_create(const kb_config *cfg, kb_engine **out) {
 
 void kb_engine_destroy(kb_engine *e) {
   if (!e) return;
+  if (e->trace_on) {
+    static const char *names[10] = {"top:prefetch-issue", "dirty-eval", "candidate", "wave-reduce", "barrier1", "best", "commit", "barrier2", "tail", "TOTAL"};
+    static const char *cls[4] = {"dirty wins, new shape", "clean wins, new shape", "dirty wins, same shape", "clean wins, same shape"};
+    for (int who = 0; who < 2; who++)
+      for (int c = 0; c < 4; c++) {
+        const double *acc = &e->trace_acc[((size_t)who * 4 + c) * 12];
+        if (acc[10] < 1) continue;
+        fprintf(stderr, "[kb K5 trace] %s | %s | %.0f rows; mean shader clocks:", who ? "cand-wave lane0" : "thread 0", cls[c], acc[10]);
+        for (int k = 0; k < 10; k++) fprintf(stderr, " %s=%.0f", names[k], acc[k] / acc[10]);
+        fprintf(stderr, " [commit: wait-for-node-state+kind=%.0f]", acc[11] / acc[10]);
+        fprintf(stderr, "\n");
+      }
+  }
   (void)hipSetDevice(e->device);
   delete e;
 }
@@ -474,6 +559,7 @@ int kb_session_load(kb_engine *e, const kb_snapshot *sn) {
       hs.t_row_shape[t] = intern(row_ids, key);
     }
     hs.n_feas_shapes = (uint32_t)feas_ids.size();
+    hs.n_row_shapes = (uint32_t)row_ids.size();
 
     // ---- plugin OnSessionOpen state ----
     // drf.go:60-64 / proportion.go:58-62: total = sum of Allocatable over ssn.Nodes (ascending node name)
@@ -548,6 +634,22 @@ int kb_session_load(kb_engine *e, const kb_snapshot *sn) {
     upload_padded(e->b_acpu, sn->node_alloc_cpu, 1, N, NP, s);
     upload_padded(e->b_amem, sn->node_alloc_mem, 1, N, NP, s);
     upload_padded(e->b_maxpods, sn->node_max_pods, 1, N, NP, s);
+    {   // reciprocals of the allocatable quantities for the exact integer-division estimate (IEEE division, same on host and device)
+      std::vector<double> ia(NP, 0.0), im(NP, 0.0);
+      for (uint32_t n = 0; n < N; n++) {
+        ia[n] = 1.0 / (double)sn->node_alloc_cpu[n];
+        im[n] = 1.0 / (double)sn->node_alloc_mem[n];
+      }
+      upload(e->b_invac, ia.data(), NP, s);
+      upload(e->b_invam, im.data(), NP, s);
+      HIP_OK(hipStreamSynchronize(s));
+    }
+    // the commit kernel keeps one slot per window row in LDS (160 KiB per workgroup on gfx950)
+    e->eff_window = std::min<uint32_t>(e->window, KB_K5_MAX_WINDOW);
+    auto cap_of = [](uint32_t w) { return std::max<uint32_t>(64, ((w + 63) / 64) * 64); };
+    while (e->eff_window > 64 && kb_commit_smem_bytes(cap_of(e->eff_window), NP) > 160u * 1024u) e->eff_window -= 64;
+    if (kb_commit_smem_bytes(cap_of(e->eff_window), NP) > 160u * 1024u)
+      throw EngineError(KB_E_UNSUPPORTED, "too many nodes for the commit kernel's LDS dirty bitmap");
     std::vector<uint32_t> ncls(NP, 0);
     if (sn->node_class) std::memcpy(ncls.data(), sn->node_class, sizeof(uint32_t) * N);
     upload(e->b_ncls, ncls.data(), NP, s);
@@ -610,6 +712,7 @@ int kb_session_load(kb_engine *e, const kb_snapshot *sn) {
     d.nzc = e->b_nzc.as<long long>(); d.nzm = e->b_nzm.as<long long>(); d.podcnt = e->b_podcnt.as<int>();
     d.acpu = e->b_acpu.as<long long>(); d.amem = e->b_amem.as<long long>();
     d.maxpods = e->b_maxpods.as<int>(); d.ncls = e->b_ncls.as<uint32_t>(); d.nmask = e->b_nmask.as<uint32_t>();
+    d.inv_acpu = e->b_invac.as<double>(); d.inv_amem = e->b_invam.as<double>();
     d.t_init = e->b_tinit.as<double>(); d.t_res = e->b_tres.as<double>();
     d.t_nzc = e->b_tnzc.as<long long>(); d.t_nzm = e->b_tnzm.as<long long>();
     d.t_cls = e->b_tcls.as<uint32_t>(); d.t_active = e->b_tactive.as<uint32_t>(); d.t_resmask = e->b_tresmask.as<uint32_t>();
@@ -618,7 +721,7 @@ int kb_session_load(kb_engine *e, const kb_snapshot *sn) {
     d.wL = e->pol.wL; d.wM = e->pol.wM; d.wB = e->pol.wB;
     d.pred_enabled = e->pol.pred_enabled ? 1 : 0;
     d.score_enabled = e->pol.nodeorder_enabled ? 1 : 0;
-    e->round_cap = 0;
+    e->win_cap = 0; e->mat_cap = 0; e->keys_cap = 0;
     e->stats = kb_stats{};
     e->round_no = 0;
     auto snap_copy = [&](DevBuf &dst, const DevBuf &src) {
@@ -664,8 +767,8 @@ int kb_run_allocate(kb_engine *e, kb_decision *out, uint64_t cap, uint64_t *n_ou
     om.init_allocate(&hs, &e->pol);
     double host_ms = now_ms() - t0;
     std::vector<uint8_t> dead(hs.n_feas_shapes ? hs.n_feas_shapes : 1, 0);
-    const uint32_t W = e->window;
-    ensure_round_buffers(e, W);
+    const uint32_t W = e->eff_window;
+    ensure_window_buffers(e, W);
     uint64_t popped = 0;
     for (;;) {
       t0 = now_ms();
@@ -735,8 +838,8 @@ int kb_run_backfill(kb_engine *e, kb_decision *out, uint64_t cap, uint64_t *n_ou
     for (uint32_t t = 0; t < hs.T; t++)
       if (hs.t_status[t] == KB_TASK_PENDING && hs.t_init_empty[t] && hs.t_job[t] < hs.J) list.push_back(t);
     std::vector<kb_decision> decs;
-    const uint32_t W = e->window;
-    ensure_round_buffers(e, W);
+    const uint32_t W = e->eff_window;
+    ensure_window_buffers(e, W);
     for (size_t pos = 0; pos < list.size(); pos += W) {
       uint32_t n = (uint32_t)std::min<size_t>(W, list.size() - pos);
       std::memcpy(e->h_rows.data(), &list[pos], sizeof(uint32_t) * n);
@@ -764,21 +867,19 @@ int kb_run_backfill(kb_engine *e, kb_decision *out, uint64_t cap, uint64_t *n_ou
   });
 }
 
-static void matrix_chunk(kb_engine *e, uint32_t t0, uint32_t n, uint32_t fit_mode, bool with_argmax, uint32_t k) {
-  ensure_round_buffers(e, n);
+static KbRound matrix_chunk(kb_engine *e, uint32_t t0, uint32_t n, uint32_t fit_mode, uint32_t k) {
+  ensure_matrix_buffers(e, n, k ? k : 1);
   HostSession &hs = e->hs;
-  for (uint32_t i = 0; i < n; i++) {
-    e->h_rows[i] = t0 + i;
-    e->h_same[i] = (i > 0 && hs.t_row_shape[t0 + i] == hs.t_row_shape[t0 + i - 1]) ? 1 : 0;
-  }
-  HIP_OK(hipMemcpyAsync(e->b_rows.p, e->h_rows.data(), sizeof(uint32_t) * n, hipMemcpyHostToDevice, e->stream));
+  for (uint32_t i = 0; i < n; i++)
+    e->h_same[i] = (i > 0 && hs.t_row_shape[t0 + i] == hs.t_row_shape[t0 + i - 1]) ? 1 : 0;   // identical consecutive rows are computed once
   HIP_OK(hipMemcpyAsync(e->b_same.p, e->h_same.data(), n, hipMemcpyHostToDevice, e->stream));
-  KbRound r = make_round(e, n, (int)fit_mode, false);
+  KbRound r = make_round(e, 0, n, k, (int)fit_mode, false);
+  r.mrows = nullptr;
+  r.mrow_task0 = t0;
+  r.same_prev = e->b_same.as<uint8_t>();
   kb_launch_matrix(e->dev, r, e->stream);
-  if (with_argmax) {
-    r.topk = k;
-    kb_launch_argmax(e->dev, r, e->stream);
-  }
+  if (k) kb_launch_argmax(e->dev, r, e->stream);
+  return r;
 }
 
 int kb_eval_matrix(kb_engine *e, uint32_t t0, uint32_t t1, uint32_t fit_mode, uint8_t *mask_bits, uint16_t *score) {
@@ -788,10 +889,10 @@ int kb_eval_matrix(kb_engine *e, uint32_t t0, uint32_t t1, uint32_t fit_mode, ui
     if (t0 > t1 || t1 > e->hs.T) throw EngineError(KB_E_INVALID, "row range out of bounds");
     const uint32_t N = e->hs.N, NP = e->dev.NP;
     const size_t rowb = ((size_t)N + 7) / 8;
-    const uint32_t chunk = std::max<uint32_t>(1, std::min<uint32_t>(e->window, 4096));
+    const uint32_t chunk = 4096;
     for (uint32_t a = t0; a < t1; a += chunk) {
       uint32_t n = std::min(chunk, t1 - a);
-      matrix_chunk(e, a, n, fit_mode, false, 0);
+      matrix_chunk(e, a, n, fit_mode, 0);
       if (score)
         HIP_OK(hipMemcpy2DAsync(score + (size_t)(a - t0) * N, sizeof(uint16_t) * N, e->b_score.p, sizeof(uint16_t) * NP, sizeof(uint16_t) * N, n,
                                 hipMemcpyDeviceToHost, e->stream));
@@ -809,11 +910,11 @@ int kb_argmax_rows(kb_engine *e, uint32_t t0, uint32_t t1, uint32_t fit_mode, ui
     if (!e->loaded) throw EngineError(KB_E_STATE, "no session loaded");
     if (t0 > t1 || t1 > e->hs.T) throw EngineError(KB_E_INVALID, "row range out of bounds");
     if (k == 0 || k > KB_MAX_TOPK) throw EngineError(KB_E_INVALID, "k must be in 1..32");
-    const uint32_t chunk = std::max<uint32_t>(1, std::min<uint32_t>(e->window, 4096));
+    const uint32_t chunk = 4096;
     std::vector<unsigned long long> keys((size_t)chunk * k);
     for (uint32_t a = t0; a < t1; a += chunk) {
       uint32_t n = std::min(chunk, t1 - a);
-      matrix_chunk(e, a, n, fit_mode, true, k);
+      matrix_chunk(e, a, n, fit_mode, k);
       HIP_OK(hipMemcpyAsync(keys.data(), e->b_keys.p, sizeof(unsigned long long) * (size_t)n * k, hipMemcpyDeviceToHost, e->stream));
       HIP_OK(hipStreamSynchronize(e->stream));
       for (size_t i = 0; i < (size_t)n * k; i++) {
@@ -832,9 +933,8 @@ int kb_bench_matrix(kb_engine *e, uint32_t t0, uint32_t t1, uint32_t fit_mode, u
     if (!e->loaded) throw EngineError(KB_E_STATE, "no session loaded");
     if (t0 >= t1 || t1 > e->hs.T || reps == 0) throw EngineError(KB_E_INVALID, "bad range / reps");
     uint32_t n = t1 - t0;
-    matrix_chunk(e, t0, n, fit_mode, false, 0);   // warm-up launch, also uploads rows
+    KbRound r = matrix_chunk(e, t0, n, fit_mode, 0);   // warm-up launch, also uploads the row flags
     HIP_OK(hipStreamSynchronize(e->stream));
-    KbRound r = make_round(e, n, (int)fit_mode, false);
     Timer &tm = get_timer(e, 4);
     HIP_OK(hipEventRecord(tm.a, e->stream));
     for (uint32_t i = 0; i < reps; i++) kb_launch_matrix(e->dev, r, e->stream);

@@ -74,8 +74,8 @@ __device__ __forceinline__ NodeVals load_node(const KbDev &d, uint32_t n) {
   nv.am = d.amem[m];
   nv.nzc = d.nzc[m];
   nv.nzm = d.nzm[m];
-  nv.inv_ac = 1.0 / (double)nv.ac;
-  nv.inv_am = 1.0 / (double)nv.am;
+  nv.inv_ac = d.inv_acpu[m];
+  nv.inv_am = d.inv_amem[m];
   nv.cls = d.ncls[m];
   nv.slots = d.maxpods[m] > d.podcnt[m];
   return nv;
@@ -141,60 +141,88 @@ __device__ __forceinline__ uint32_t eval_pair(const KbDev &d, const TaskVals &t,
 // registers for all TR rows of the tile; the tile's task vectors are staged once in LDS.
 // Stores: one 8-byte score vector per thread per row (512 B contiguous per wave), one 4-byte mask word per 8 lanes.
 // ------------------------------------------------------------------------------------------------------------
-#define K1_TR 32
-#define K1_NPT 4
+// Two tile shapes: <4 nodes/thread, 32 rows/block> for matrix-sized launches (8-byte score stores, node state amortised
+// over 32 rows) and <1 node/thread, 4 rows/block> for the small per-round launches (a few dozen distinct shapes), where
+// the work has to be spread over all 256 CUs instead of being serialised inside few threads.
+template <int NPT, int TR>
 __global__ void __launch_bounds__(256) k_matrix(KbDev d, KbRound r) {
-  __shared__ TaskVals srow[K1_TR];
-  __shared__ uint8_t ssame[K1_TR];
-  const uint32_t row0 = blockIdx.y * K1_TR;
-  const uint32_t nr = min((uint32_t)K1_TR, r.n_rows - row0);
+  __shared__ TaskVals srow[TR];
+  __shared__ uint8_t ssame[TR];
+  const uint32_t row0 = blockIdx.y * TR;
+  const uint32_t nr = min((uint32_t)TR, r.n_mrows - row0);
   if (threadIdx.x < nr) {
     uint32_t i = row0 + threadIdx.x;
-    uint32_t t = r.rows ? r.rows[i] : r.row_task0 + i;
+    uint32_t t = r.mrows ? r.mrows[i] : r.mrow_task0 + i;
     srow[threadIdx.x] = load_task(d, t);
     ssame[threadIdx.x] = r.same_prev ? r.same_prev[i] : 0;
   }
   __syncthreads();
-  const uint32_t n0 = (blockIdx.x * 256 + threadIdx.x) * K1_NPT;
+  const uint32_t n0 = (blockIdx.x * 256 + threadIdx.x) * NPT;
   const uint32_t lane = threadIdx.x & 63;
-  NodeVals nv[K1_NPT];
+  NodeVals nv[NPT];
 #pragma unroll
-  for (int j = 0; j < K1_NPT; j++) nv[j] = load_node(d, n0 + j);
-  uint32_t res[K1_NPT];
+  for (int j = 0; j < NPT; j++) nv[j] = load_node(d, n0 + j);
+  uint32_t res[NPT];
 #pragma unroll
-  for (int j = 0; j < K1_NPT; j++) res[j] = 0;
+  for (int j = 0; j < NPT; j++) res[j] = 0;
   const size_t mstride = d.NP / 32;
   for (uint32_t rr = 0; rr < nr; rr++) {
     const TaskVals tv = srow[rr];
     if (!(ssame[rr] && rr > 0)) {
 #pragma unroll
-      for (int j = 0; j < K1_NPT; j++) res[j] = eval_pair(d, tv, nv[j], n0 + j, r.fit_mode);
+      for (int j = 0; j < NPT; j++) res[j] = eval_pair(d, tv, nv[j], n0 + j, r.fit_mode);
     }
     const size_t row = row0 + rr;
-    uint2 pk;
-    pk.x = (res[0] & 0xFFFFu) | (res[1] << 16);
-    pk.y = (res[2] & 0xFFFFu) | (res[3] << 16);
-    *reinterpret_cast<uint2 *>(r.score + row * d.NP + n0) = pk;
-    uint32_t nib = ((res[0] >> 16) & 1u) | (((res[1] >> 16) & 1u) << 1) | (((res[2] >> 16) & 1u) << 2) | (((res[3] >> 16) & 1u) << 3);
-    uint32_t w = nib << (4 * (lane & 7));
-    w |= __shfl_xor(w, 1);
-    w |= __shfl_xor(w, 2);
-    w |= __shfl_xor(w, 4);
-    if ((lane & 7) == 0) r.maskw[row * mstride + (n0 >> 5)] = w;
+    if (NPT == 4) {
+      uint2 pk;
+      pk.x = (res[0] & 0xFFFFu) | (res[1 % NPT] << 16);
+      pk.y = (res[2 % NPT] & 0xFFFFu) | (res[3 % NPT] << 16);
+      *reinterpret_cast<uint2 *>(r.score + row * d.NP + n0) = pk;
+      uint32_t nib = ((res[0] >> 16) & 1u) | (((res[1 % NPT] >> 16) & 1u) << 1) | (((res[2 % NPT] >> 16) & 1u) << 2) | (((res[3 % NPT] >> 16) & 1u) << 3);
+      uint32_t w = nib << (4 * (lane & 7));
+      w |= __shfl_xor(w, 1);
+      w |= __shfl_xor(w, 2);
+      w |= __shfl_xor(w, 4);
+      if ((lane & 7) == 0) r.maskw[row * mstride + (n0 >> 5)] = w;
+    } else {
+      r.score[row * d.NP + n0] = (uint16_t)(res[0] & 0xFFFFu);
+      unsigned long long b = __ballot((res[0] >> 16) & 1u);   // one wave = 64 consecutive nodes = two mask words
+      if (lane == 0) *reinterpret_cast<unsigned long long *>(r.maskw + row * mstride + (n0 >> 5)) = b;
+    }
   }
 }
 
 // ------------------------------------------------------------------------------------------------------------
 // wave64 helpers
 // ------------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    unsigned long long u = __shfl_xor(v, o);
-    v = u > v ? u : v;
-  }
-  return v;
+// max over keys (bit patterns of positive normal doubles, or 0) with DPP moves + v_max_f64
+#define KB_DPP_STEP(v, ctrl, row_mask)                                                                    \
+  do {                                                                                                    \
+    int _lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), (ctrl), (row_mask), 0xf, false);          \
+    int _hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), (ctrl), (row_mask), 0xf, false);          \
+    v = fmax(v, __hiloint2double(_hi, _lo));                                                              \
+  } while (0)
+__device__ __forceinline__ unsigned long long wave_max_key(unsigned long long k) {
+  double v = __longlong_as_double((long long)k);
+  KB_DPP_STEP(v, 0xB1, 0xf);    // quad_perm [1,0,3,2]
+  KB_DPP_STEP(v, 0x4E, 0xf);    // quad_perm [2,3,0,1]
+  KB_DPP_STEP(v, 0x141, 0xf);   // row_half_mirror
+  KB_DPP_STEP(v, 0x140, 0xf);   // row_mirror: every lane of a 16-lane row holds the row maximum
+  KB_DPP_STEP(v, 0x142, 0xa);   // row_bcast:15 into rows 1 and 3
+  KB_DPP_STEP(v, 0x143, 0xc);   // row_bcast:31 into rows 2 and 3: lane 63 holds the wave maximum
+  int lo = __builtin_amdgcn_readlane(__double2loint(v), 63);
+  int hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
+  return ((unsigned long long)(uint32_t)hi << 32) | (uint32_t)lo;
 }
+// max over each aligned group of 8 lanes (every lane of the group gets it)
+__device__ __forceinline__ unsigned long long oct_max_key(unsigned long long k) {
+  double v = __longlong_as_double((long long)k);
+  KB_DPP_STEP(v, 0xB1, 0xf);
+  KB_DPP_STEP(v, 0x4E, 0xf);
+  KB_DPP_STEP(v, 0x141, 0xf);
+  return (unsigned long long)__double_as_longlong(v);
+}
+__device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v) { return wave_max_key(v); }
 __device__ __forceinline__ int wave_max_i32(int v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o));
@@ -210,242 +238,541 @@ __device__ __forceinline__ uint32_t lane_prefix_popc(unsigned long long ballot_m
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// K3: segmented arg-max / top-K.  One wave per row; the row (u16 scores + mask bits) is streamed with 16-byte loads.
-// Pass A finds the highest score below the previous level, pass B collects that level's nodes in ascending index
-// order by ballot + prefix popcount, stopping as soon as K candidates exist.
+// K3: segmented arg-max generalised to a sorted candidate list (best first: descending score, ascending node index).
+// One 256-thread workgroup per matrix row.  The row (u16 scores + mask bits) is staged once in LDS with 16-byte loads;
+// each thread owns a contiguous run of NP/256 nodes, so "ascending node index" is thread order.  Per score level:
+// pass A = block max of the scores below the previous level, pass B = count + block exclusive scan + ordered write.
+// The first entry is util.SelectBestNode's choice (scheduler_helper.go:188-208, canonical first-max tie-break).
 // ------------------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_argmax(KbDev d, KbRound r) {
-  const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const uint32_t row = blockIdx.x * 4 + wave;
-  if (row >= r.n_rows) return;
-  const uint4 *srow = reinterpret_cast<const uint4 *>(r.score + (size_t)row * d.NP);
-  const uint8_t *mrow = reinterpret_cast<const uint8_t *>(r.maskw + (size_t)row * (d.NP / 32));
-  const uint32_t K = r.topk;
+  extern __shared__ __align__(16) unsigned char k3_smem[];
+  uint16_t *ls = reinterpret_cast<uint16_t *>(k3_smem);                        // [NP] scores
+  uint8_t *lm = reinterpret_cast<uint8_t *>(k3_smem) + (size_t)d.NP * 2;      // [NP/8] mask bytes
+  __shared__ int s_wmax[4];
+  __shared__ uint32_t s_wcnt[4];
+  const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const uint32_t row = blockIdx.x;
+  {
+    const uint4 *src = reinterpret_cast<const uint4 *>(r.score + (size_t)row * d.NP);
+    uint4 *dst = reinterpret_cast<uint4 *>(ls);
+    for (uint32_t c = tid; c < d.NP / 8; c += 256) dst[c] = src[c];
+    const uint32_t *msrc = r.maskw + (size_t)row * (d.NP / 32);
+    uint32_t *mdst = reinterpret_cast<uint32_t *>(lm);
+    for (uint32_t c = tid; c < d.NP / 32; c += 256) mdst[c] = msrc[c];
+  }
+  __syncthreads();
+  const uint32_t K = r.L;
   unsigned long long *out = r.keys + (size_t)row * K;
-  const uint32_t nchunk = d.NP / 8;
+  const uint32_t per8 = d.NP / (256 * 8);    // 8-node chunks per thread (NP is a multiple of 2048? no: of 1024 -> see below)
+  const uint32_t cbase = tid * per8;         // first chunk of this thread; chunks beyond NP/8 do not exist when NP % 2048 == 0
+  const uint4 *ls4 = reinterpret_cast<const uint4 *>(ls);
   uint32_t found = 0;
   int cur = 0x10000;
   while (found < K) {
     int m = -1;
-    for (uint32_t c = lane; c < nchunk; c += 64) {
-      uint32_t mb = mrow[c];
-      if (mb) {
-        uint4 s = srow[c];
-        uint32_t w[4] = {s.x, s.y, s.z, s.w};
+    for (uint32_t c = 0; c < per8; c++) {
+      uint32_t mb = lm[cbase + c];
+      uint4 sv = ls4[cbase + c];
+      uint32_t w[4] = {sv.x, sv.y, sv.z, sv.w};
 #pragma unroll
-        for (int e = 0; e < 8; e++) {
-          int sc = (int)((w[e >> 1] >> ((e & 1) * 16)) & 0xFFFFu);
-          if (((mb >> e) & 1u) && sc < cur && sc > m) m = sc;
-        }
+      for (int e = 0; e < 8; e++) {
+        int sc = (int)((w[e >> 1] >> ((e & 1) * 16)) & 0xFFFFu);
+        if (((mb >> e) & 1u) && sc < cur && sc > m) m = sc;
       }
     }
     m = wave_max_i32(m);
-    if (m < 0) break;
-    for (uint32_t base = 0; base < nchunk && found < K; base += 64) {
-      uint32_t c = base + lane;
-      uint32_t match = 0;
-      if (c < nchunk) {
-        uint32_t mb = mrow[c];
-        if (mb) {
-          uint4 s = srow[c];
-          uint32_t w[4] = {s.x, s.y, s.z, s.w};
-#pragma unroll
-          for (int e = 0; e < 8; e++) {
-            int sc = (int)((w[e >> 1] >> ((e & 1) * 16)) & 0xFFFFu);
-            if (((mb >> e) & 1u) && sc == m) match |= 1u << e;
-          }
-        }
-      }
-      uint32_t cnt = __popc(match);
-      uint32_t pre = 0, total = 0;
+    if (lane == 0) s_wmax[wave] = m;
+    __syncthreads();
+    m = max(max(s_wmax[0], s_wmax[1]), max(s_wmax[2], s_wmax[3]));
+    if (m < 0) break;                          // uniform
+    uint32_t cnt = 0;
+    for (uint32_t c = 0; c < per8; c++) {
+      uint32_t mb = lm[cbase + c];
+      uint4 sv = ls4[cbase + c];
+      uint32_t w[4] = {sv.x, sv.y, sv.z, sv.w};
 #pragma unroll
       for (int e = 0; e < 8; e++) {
-        unsigned long long b = __ballot((match >> e) & 1u);
-        pre += lane_prefix_popc(b, lane);
-        total += __popcll(b);
+        int sc = (int)((w[e >> 1] >> ((e & 1) * 16)) & 0xFFFFu);
+        cnt += (((mb >> e) & 1u) && sc == m) ? 1u : 0u;
       }
-      (void)cnt;
-      uint32_t pos = found + pre;
-      while (match && pos < K) {
-        int e = __ffs(match) - 1;
-        match &= match - 1;
-        out[pos] = KB_KEY(m, c * 8 + e);
-        pos++;
-      }
-      found += total;
     }
-    if (found > K) found = K;
+    // inclusive scan inside the wave: DPP row shifts, then row broadcasts (the sequence LLVM's buildScan emits)
+    uint32_t pre = cnt;
+    pre += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)pre, 0x111, 0xf, 0xf, false);   // row_shr:1
+    pre += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)pre, 0x112, 0xf, 0xf, false);   // row_shr:2
+    pre += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)pre, 0x114, 0xf, 0xf, false);   // row_shr:4
+    pre += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)pre, 0x118, 0xf, 0xf, false);   // row_shr:8
+    pre += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)pre, 0x142, 0xa, 0xf, false);   // row_bcast:15
+    pre += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)pre, 0x143, 0xc, 0xf, false);   // row_bcast:31
+    if (lane == 63) s_wcnt[wave] = pre;
+    __syncthreads();
+    uint32_t woff = 0, total = 0;
+#pragma unroll
+    for (int w2 = 0; w2 < 4; w2++) {
+      if (w2 < (int)wave) woff += s_wcnt[w2];
+      total += s_wcnt[w2];
+    }
+    uint32_t pos = found + woff + pre - cnt;
+    if (cnt && pos < K) {
+      for (uint32_t c = 0; c < per8 && pos < K; c++) {
+        uint32_t mb = lm[cbase + c];
+        uint4 sv = ls4[cbase + c];
+        uint32_t w[4] = {sv.x, sv.y, sv.z, sv.w};
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+          int sc = (int)((w[e >> 1] >> ((e & 1) * 16)) & 0xFFFFu);
+          if (((mb >> e) & 1u) && sc == m && pos < K) out[pos++] = KB_KEY(m, (cbase + c) * 8 + e);
+        }
+      }
+    }
+    found += total;
     cur = m;
+    __syncthreads();                           // s_wmax / s_wcnt are reused by the next level
   }
-  for (uint32_t i = found + lane; i < K; i += 64) out[i] = 0ull;
+  if (found > K) found = K;
+  for (uint32_t i = found + tid; i < K; i += 256) out[i] = 0ull;
+}
+
+__device__ __forceinline__ bool bit_test(const uint32_t *bm, uint32_t n) { return (bm[n >> 5] >> (n & 31)) & 1u; }
+
+
+// window rows -> contiguous descriptors
+__global__ void __launch_bounds__(256) k_gather(KbDev d, KbRound r) {
+  uint32_t i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= r.n_rows) return;
+  uint32_t t = r.rows[i];
+  KbRowDesc k;
+  k.init0 = d.t_init[t]; k.init1 = d.t_init[(size_t)d.T + t];
+  k.nzc = d.t_nzc[t]; k.nzm = d.t_nzm[t];
+  k.task = t; k.active = d.t_active[t]; k.resmask = d.t_resmask[t]; k.cls = d.t_cls[t];
+  k.slot = (uint16_t)r.shape_slot[i];
+  k.flags = (d.t_res[t] == k.init0 && d.t_res[(size_t)d.T + t] == k.init1) ? 1 : 0;
+  k.pad = 0;
+  r.desc[i] = k;
+}
+
+// LDS layout of the commit kernel for slot capacity `cap`:
+//   8-byte tables [10][cap]: idle0 idle1 rel0 rel1 inv_ac inv_am ac am nzc nzm   (field k of slot s at (k*cap + s)*8)
+//   4-byte tables [4][cap]:  cls node left cursor
+//   KbRowDesc [cap], dirty bitmap [NP/32], header
+#define K5F_IDLE0 0
+#define K5F_IDLE1 1
+#define K5F_REL0 2
+#define K5F_REL1 3
+#define K5F_INVAC 4
+#define K5F_INVAM 5
+#define K5F_AC 6
+#define K5F_AM 7
+#define K5F_NZC 8
+#define K5F_NZM 9
+#define K5_NF8 10
+#define K5_WAVES (KB_K5_THREADS / 64)
+#define K5_SPT (KB_K5_MAX_WINDOW / KB_K5_THREADS)
+
+struct K5Hdr {
+  unsigned long long red[K5_WAVES];
+  unsigned long long cand;
+  uint32_t exhausted, stop, last_slot, refills, rescans, pad;
+};
+
+__host__ __device__ inline size_t k5_smem_bytes(uint32_t cap, uint32_t NP) {
+  return (size_t)cap * (K5_NF8 * 8 + 4 * 4 + sizeof(KbRowDesc)) + (size_t)(NP / 32) * 4 + sizeof(K5Hdr);
+}
+
+__device__ __forceinline__ NodeVals k5_slot_vals(const unsigned long long *tab, const uint32_t *t_cls, const int *t_left, uint32_t cap, uint32_t slot) {
+  NodeVals nv;
+  nv.idle0 = __longlong_as_double((long long)tab[K5F_IDLE0 * cap + slot]);
+  nv.idle1 = __longlong_as_double((long long)tab[K5F_IDLE1 * cap + slot]);
+  nv.rel0 = __longlong_as_double((long long)tab[K5F_REL0 * cap + slot]);
+  nv.rel1 = __longlong_as_double((long long)tab[K5F_REL1 * cap + slot]);
+  nv.inv_ac = __longlong_as_double((long long)tab[K5F_INVAC * cap + slot]);
+  nv.inv_am = __longlong_as_double((long long)tab[K5F_INVAM * cap + slot]);
+  nv.ac = (long long)tab[K5F_AC * cap + slot];
+  nv.am = (long long)tab[K5F_AM * cap + slot];
+  nv.nzc = (long long)tab[K5F_NZC * cap + slot];
+  nv.nzm = (long long)tab[K5F_NZM * cap + slot];
+  nv.cls = t_cls[slot];
+  nv.slots = t_left[slot] > 0;
+  nv.valid = 1;
+  return nv;
+}
+
+// scalar dimensions stay in global memory (rare path): NodeInfo.AddTask's Sub on dims >= 2, task bookkeeping, and the
+// multi-GPU per-node deltas
+__device__ __forceinline__ void k5_commit_globals(const KbDev &d, const KbRound &r, const KbRowDesc &k, double res0, double res1,
+                                                  uint32_t i, uint32_t n, uint32_t kind) {
+  uint32_t km = k.resmask;
+  uint32_t has_map = 0;
+  if (km) {
+    has_map = kind ? 1u : d.nmask[n];   // Sub returns early when the receiver's scalar map is nil (resource_info.go:148-153)
+    if (has_map) {
+      double *vec = kind ? d.rel : d.idle;
+      uint32_t dd = 2, m2 = km;
+      while (m2) {
+        if (m2 & 1u) vec[(size_t)dd * d.NP + n] -= d.t_res[(size_t)dd * d.T + k.task];
+        m2 >>= 1; dd++;
+      }
+      __threadfence_block();
+    }
+  }
+  d.t_status[k.task] = kind ? KB_TASK_PIPELINED : KB_TASK_ALLOCATED;
+  d.t_node[k.task] = n;
+  d.t_counted[k.task] = 1;
+  r.dec_node[i] = n;
+  r.dec_kind[i] = kind;
+  if (r.delta && i >= r.own_row0 && i < r.own_row1) {
+    // per-node committed deltas of the rows this rank owns: [dIdle R][dRel R][dnzc][dnzm][dpodcnt] x NP
+    double *dv = r.delta + (size_t)(kind ? d.R : 0) * d.NP;
+    dv[n] -= res0;
+    dv[(size_t)d.NP + n] -= res1;
+    if (km && has_map) {
+      uint32_t dd = 2, m2 = km;
+      while (m2) {
+        if (m2 & 1u) dv[(size_t)dd * d.NP + n] -= d.t_res[(size_t)dd * d.T + k.task];
+        m2 >>= 1; dd++;
+      }
+    }
+    double *tail = r.delta + (size_t)2 * d.R * d.NP;
+    tail[n] += (double)k.nzc;
+    tail[(size_t)d.NP + n] += (double)k.nzm;
+    tail[(size_t)2 * d.NP + n] += 1.0;
+  }
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// K5: sequential commit.  One 1024-thread workgroup walks the window in reference order.  The dirty set (nodes
-// that received a task in this round) lives in LDS as a bitmap + list; clean columns come from the round's
-// matrix (top-K keys, or the stored row when the candidates are exhausted), dirty columns are re-evaluated live.
+// K5: sequential commit.  One workgroup walks the window in the reference's task order (allocate.go:129-193 /
+// backfill.go:44-67).  Node state changes one node at a time, so for every task
+//     best node = max( best CLEAN node of the task's shape , best DIRTY node re-evaluated against live state )
+//   * clean side: the shape's candidate list from K3, sorted best-first, with a monotone cursor in LDS that skips
+//     entries whose node has become dirty (the dirty set only grows inside a round and the list is longer than the
+//     window, so a clean entry always survives unless the list ran out of feasible nodes);
+//   * dirty side: the live state of every node touched in this round sits in LDS tables (one slot per node); each
+//     thread owns slots {tid, tid+THREADS} and caches their keys, so a task with the same shape as its predecessor
+//     re-evaluates only the slot that just changed (gang members are consecutive and identical).
+// The loop is latency-bound, so it is written for few dependent instructions: row descriptors are staged in LDS once,
+// reductions are DPP + v_max_f64 on biased keys, the candidate's node state is fetched by 13 lanes with ONE load
+// instruction (lane k reads field k from its own array) and a clean winner's slot is initialised by the same lanes with
+// ONE LDS store; two workgroup barriers per task.
 // ------------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ bool bit_test(const uint32_t *bm, uint32_t n) { return (bm[n >> 5] >> (n & 31)) & 1u; }
-
 __global__ void __launch_bounds__(KB_K5_THREADS) k_commit(KbDev d, KbRound r) {
-  extern __shared__ uint32_t dirty_bm[];   // NP/32 words
-  __shared__ unsigned long long red[KB_K5_THREADS / 64];
-  __shared__ unsigned long long s_best, s_cand;
-  __shared__ uint32_t s_ndirty, s_stop, s_exh, s_fallbacks, s_rescans;
+  extern __shared__ __align__(16) unsigned char k5_smem[];
+  const uint32_t cap = r.cap;
+  unsigned long long *tab = reinterpret_cast<unsigned long long *>(k5_smem);
+  uint32_t *t_cls = reinterpret_cast<uint32_t *>(tab + (size_t)K5_NF8 * cap);
+  uint32_t *t_node = t_cls + cap;
+  int *t_left = reinterpret_cast<int *>(t_node + cap);
+  uint32_t *cursor = reinterpret_cast<uint32_t *>(t_left + cap);
+  KbRowDesc *desc = reinterpret_cast<KbRowDesc *>(cursor + cap);
+  uint32_t *bitmap = reinterpret_cast<uint32_t *>(desc + cap);
+  K5Hdr &H = *reinterpret_cast<K5Hdr *>(bitmap + d.NP / 32);
+
   const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  for (uint32_t w = tid; w < d.NP / 32; w += KB_K5_THREADS) dirty_bm[w] = 0;
-  if (tid == 0) { s_ndirty = 0; s_stop = 0; s_fallbacks = 0; s_rescans = 0; s_exh = 0; s_cand = 0; }
-  __syncthreads();
-  const uint32_t K = r.topk;
-  const size_t mstride_b = (size_t)d.NP / 8;
-  for (uint32_t i = 0; i < r.n_rows; i++) {
-    const uint32_t t = r.rows ? r.rows[i] : r.row_task0 + i;
-    const TaskVals tv = load_task(d, t);
-    const uint32_t nd = s_ndirty;
-    unsigned long long key = 0;
-    uint32_t exhausted = 1;
-    if (r.keys) {
-      if (tid < 64) {
-        unsigned long long ck = (tid < K) ? r.keys[(size_t)i * K + tid] : 0ull;
-        bool nz = ck != 0ull;
-        bool dirty = nz && bit_test(dirty_bm, KB_KEY_NODE(ck));
-        unsigned long long clean = (nz && !dirty) ? ck : 0ull;
-        clean = wave_max_u64(clean);
-        uint32_t nnz = __popcll(__ballot(nz));
-        if (tid == 0) { s_cand = clean; s_exh = (clean == 0ull && nnz == K) ? 1u : 0u; }
-      }
-      __syncthreads();
-      exhausted = s_exh;
-      if (tid == 0) key = s_cand;
-    }
-    bool live_all = false;
-    if (exhausted) {
-      if (r.use_rows) {
-        // clean columns from the stored row: 8 nodes (16 B of scores + 1 mask byte + 1 dirty byte) per step
-        const uint4 *srow = reinterpret_cast<const uint4 *>(r.score + (size_t)i * d.NP);
-        const uint8_t *mrow = reinterpret_cast<const uint8_t *>(r.maskw) + (size_t)i * mstride_b;
-        const uint8_t *dbytes = reinterpret_cast<const uint8_t *>(dirty_bm);
-        for (uint32_t c = tid; c < d.NP / 8; c += KB_K5_THREADS) {
-          uint32_t mb = mrow[c] & ~((uint32_t)dbytes[c]);
-          if (mb) {
-            uint4 s = srow[c];
-            uint32_t w[4] = {s.x, s.y, s.z, s.w};
+  const bool cand_wave = wave == K5_WAVES - 1;
+  for (uint32_t w = tid; w < d.NP / 32; w += KB_K5_THREADS) bitmap[w] = 0;
+  for (uint32_t w = tid; w < cap; w += KB_K5_THREADS) cursor[w] = 0;
+  {   // stage the window's row descriptors (coalesced 8-byte copies)
+    const unsigned long long *src = reinterpret_cast<const unsigned long long *>(r.desc);
+    unsigned long long *dst = reinterpret_cast<unsigned long long *>(desc);
+    const uint32_t nq = r.n_rows * (uint32_t)(sizeof(KbRowDesc) / 8);
+    for (uint32_t w = tid; w < nq; w += KB_K5_THREADS) dst[w] = src[w];
+  }
+  if (tid == 0) { H.cand = 0; H.exhausted = 0; H.stop = 0; H.last_slot = 0xFFFFFFFFu; H.refills = 0; H.rescans = 0; }
+  {
+    // The loop below is latency-bound and this workgroup starts on a cold L2 (kernel boundary).  Touch every 128-byte
+    // line it can need later — node state arrays and the candidate lists — once, with all threads, so that the
+    // per-task loads hit the XCD's L2 instead of going out to HBM one at a time.
+    unsigned long long acc = 0;
+    const uint32_t lines = d.NP / 16;   // 16 x 8 bytes per line
+    const unsigned long long *arrs[10] = {
+        reinterpret_cast<const unsigned long long *>(d.idle), reinterpret_cast<const unsigned long long *>(d.idle + d.NP),
+        reinterpret_cast<const unsigned long long *>(d.rel), reinterpret_cast<const unsigned long long *>(d.rel + d.NP),
+        reinterpret_cast<const unsigned long long *>(d.inv_acpu), reinterpret_cast<const unsigned long long *>(d.inv_amem),
+        reinterpret_cast<const unsigned long long *>(d.acpu), reinterpret_cast<const unsigned long long *>(d.amem),
+        reinterpret_cast<const unsigned long long *>(d.nzc), reinterpret_cast<const unsigned long long *>(d.nzm)};
 #pragma unroll
-            for (int e = 0; e < 8; e++) {
-              if ((mb >> e) & 1u) {
-                uint32_t sc = (w[e >> 1] >> ((e & 1) * 16)) & 0xFFFFu;
-                unsigned long long k2 = KB_KEY(sc, c * 8 + e);
-                key = k2 > key ? k2 : key;
-              }
-            }
-          }
-        }
-      } else {
-        // rows live on another rank: re-evaluate every node against the live state
-        live_all = true;
-        for (uint32_t n = tid; n < d.N; n += KB_K5_THREADS) {
-          NodeVals nv = load_node(d, n);
-          uint32_t res = eval_pair(d, tv, nv, n, r.fit_mode);
-          if (res) { unsigned long long k2 = KB_KEY(res & 0xFFFFu, n); key = k2 > key ? k2 : key; }
-        }
-      }
-      if (tid == 0 && r.keys) { s_fallbacks++; if (live_all) s_rescans++; }
+    for (int a = 0; a < 10; a++)
+      for (uint32_t l = tid; l < lines; l += KB_K5_THREADS) acc += arrs[a][(size_t)l * 16];
+    const uint32_t *arr4[3] = {d.ncls, reinterpret_cast<const uint32_t *>(d.maxpods), reinterpret_cast<const uint32_t *>(d.podcnt)};
+#pragma unroll
+    for (int a = 0; a < 3; a++)
+      for (uint32_t l = tid; l < d.NP / 32; l += KB_K5_THREADS) acc += arr4[a][(size_t)l * 32];
+    const size_t klines = ((size_t)r.n_mrows * r.L + 15) / 16;
+    for (size_t l = tid; l < klines; l += KB_K5_THREADS) acc += r.keys[l * 16];
+    if (acc == 0x123456789abcdefull) H.pad = 1;   // keep the loads alive
+  }
+
+  // candidate wave, lanes 0..9: the 8-byte node field this lane fetches / initialises; lanes 10..12: cls, maxpods, podcnt
+  const unsigned long long *g8 = nullptr;
+  const uint32_t *g4 = nullptr;
+  if (cand_wave) {
+    switch (lane) {
+      case K5F_IDLE0: g8 = reinterpret_cast<const unsigned long long *>(d.idle); break;
+      case K5F_IDLE1: g8 = reinterpret_cast<const unsigned long long *>(d.idle + d.NP); break;
+      case K5F_REL0: g8 = reinterpret_cast<const unsigned long long *>(d.rel); break;
+      case K5F_REL1: g8 = reinterpret_cast<const unsigned long long *>(d.rel + d.NP); break;
+      case K5F_INVAC: g8 = reinterpret_cast<const unsigned long long *>(d.inv_acpu); break;
+      case K5F_INVAM: g8 = reinterpret_cast<const unsigned long long *>(d.inv_amem); break;
+      case K5F_AC: g8 = reinterpret_cast<const unsigned long long *>(d.acpu); break;
+      case K5F_AM: g8 = reinterpret_cast<const unsigned long long *>(d.amem); break;
+      case K5F_NZC: g8 = reinterpret_cast<const unsigned long long *>(d.nzc); break;
+      case K5F_NZM: g8 = reinterpret_cast<const unsigned long long *>(d.nzm); break;
+      case 10: g4 = d.ncls; break;
+      case 11: g4 = reinterpret_cast<const uint32_t *>(d.maxpods); break;
+      case 12: g4 = reinterpret_cast<const uint32_t *>(d.podcnt); break;
+      default: break;
     }
-    if (!live_all) {
-      for (uint32_t dd = tid; dd < nd; dd += KB_K5_THREADS) {
-        uint32_t n = r.dirty_list[dd];
+  }
+  __syncthreads();
+
+  unsigned long long ck[K5_SPT];     // cached keys of the dirty slots this thread owns, valid for shape `prev_shape`
+#pragma unroll
+  for (int j = 0; j < K5_SPT; j++) ck[j] = 0ull;
+  uint32_t prev_shape = 0xFFFFFFFFu;
+  uint32_t nd = 0;                   // dirty slots in use (tracked identically by every thread)
+  uint32_t n_done = 0, reason = KB_REASON_DONE;
+
+  // optional cycle trace (KB_K5_TRACE=1): stamps are kept in registers and written once per row by thread 0 and by
+  // lane 0 of the candidate wave
+  const bool tracing = r.trace != nullptr && (tid == 0 || tid == (K5_WAVES - 1) * 64);
+  unsigned long long stamp[10];
+  stamp[9] = 0;
+#define K5_STAMP(k) do { if (tracing) stamp[k] = __builtin_readcyclecounter(); } while (0)
+
+  // candidate window of the current task: 64 consecutive list entries starting at win_base (candidate wave only)
+  unsigned long long win_key = 0ull;
+  uint32_t win_base = 0;
+  if (cand_wave) win_key = (lane < r.L) ? r.keys[(size_t)desc[0].slot * r.L + lane] : 0ull;
+
+  for (uint32_t i = 0; i < r.n_rows; i++) {
+    K5_STAMP(0);
+    const KbRowDesc &cur = desc[i];
+    const uint32_t shape = cur.slot;
+    TaskVals tv;
+    tv.init0 = cur.init0; tv.init1 = cur.init1; tv.nzc = cur.nzc; tv.nzm = cur.nzm;
+    tv.cls = cur.cls; tv.active = cur.active; tv.task = cur.task; tv.pad = 0;
+    const uint32_t last_slot = H.last_slot;
+
+    // ---- candidate wave: issue the prefetch of the next row's candidate window
+    unsigned long long nwin_key = 0ull;
+    uint32_t nwin_base = 0;
+    if (cand_wave && i + 1 < r.n_rows) {
+      const uint32_t nshape = desc[i + 1].slot;
+      nwin_base = cursor[nshape];
+      uint32_t e = nwin_base + lane;
+      nwin_key = (e < r.L) ? r.keys[(size_t)nshape * r.L + e] : 0ull;
+    }
+    K5_STAMP(1);
+
+    // ---- dirty side: live re-evaluation out of the LDS tables, cached per thread while the shape repeats
+    const bool same = shape == prev_shape;
+    unsigned long long key = 0ull;
+#pragma unroll
+    for (int j = 0; j < K5_SPT; j++) {
+      uint32_t slot = tid + j * KB_K5_THREADS;
+      if (slot < nd) {
+        if (!same || slot == last_slot) {
+          NodeVals nv = k5_slot_vals(tab, t_cls, t_left, cap, slot);
+          uint32_t node = t_node[slot];
+          uint32_t res = eval_pair(d, tv, nv, node, r.fit_mode);
+          ck[j] = res ? KB_KEY(res & 0xFFFFu, node) : 0ull;
+        }
+        key = ck[j] > key ? ck[j] : key;
+      }
+    }
+    prev_shape = shape;
+    K5_STAMP(2);
+
+    // ---- clean side: first list entry whose node is not dirty, and (lanes 0..12) that node's state
+    unsigned long long cand = 0ull, st8 = 0ull;
+    uint32_t st4 = 0;
+    if (cand_wave) {
+      uint32_t curs = cursor[shape];
+      bool list_end = false;
+      for (;;) {
+        bool nz = win_key != 0ull;
+        bool clean = nz && (win_base + lane) >= curs && !bit_test(bitmap, KB_KEY_NODE(win_key));
+        unsigned long long b = __ballot(clean);
+        if (b) {
+          int first = __ffsll((unsigned long long)b) - 1;
+          // lists are 0-terminated and sorted best-first, so the first clean entry is the best clean node
+          cand = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(win_key >> 32), first) << 32) |
+                 (uint32_t)__builtin_amdgcn_readlane((int)(win_key & 0xFFFFFFFFull), first);
+          curs = win_base + first;
+          break;
+        }
+        if (__ballot(!nz)) { list_end = true; break; }   // ran past the last feasible node: no clean candidate exists
+        win_base += 64;
+        if (win_base >= r.L) break;                       // list exhausted while still full: live rescan below
+        uint32_t e = win_base + lane;
+        win_key = (e < r.L) ? r.keys[(size_t)shape * r.L + e] : 0ull;
+        if (lane == 0) H.refills++;
+      }
+      if (lane == 0) {
+        cursor[shape] = curs;
+        H.cand = cand;
+        H.exhausted = (!cand && !list_end) ? 1u : 0u;
+      }
+      if (cand) {   // one load instruction per width; consumed only if the candidate wins
+        uint32_t n = KB_KEY_NODE(cand);
+        if (g8) st8 = g8[n];
+        if (g4) st4 = g4[n];
+      }
+      if (lane == 0) key = cand > key ? cand : key;
+    }
+    K5_STAMP(3);
+
+    key = wave_max_key(key);
+    if (lane == 0) H.red[wave] = key;
+    K5_STAMP(4);
+    __syncthreads();
+    K5_STAMP(5);
+    unsigned long long best = oct_max_key(H.red[lane & (K5_WAVES - 1)]);
+    const unsigned long long hcand = H.cand;
+
+    if (H.exhausted) {
+      // cannot happen while L > window size; kept so a shorter (caller-limited) list stays exact: evaluate every CLEAN
+      // node against global state (clean nodes are unchanged since the round started); dirty ones are covered above
+      unsigned long long k2 = 0ull;
+      for (uint32_t n = tid; n < d.N; n += KB_K5_THREADS) {
+        if (bit_test(bitmap, n)) continue;
         NodeVals nv = load_node(d, n);
         uint32_t res = eval_pair(d, tv, nv, n, r.fit_mode);
-        if (res) { unsigned long long k2 = KB_KEY(res & 0xFFFFu, n); key = k2 > key ? k2 : key; }
+        if (res) { unsigned long long k3 = KB_KEY(res & 0xFFFFu, n); k2 = k3 > k2 ? k3 : k2; }
       }
+      k2 = wave_max_key(k2);
+      __syncthreads();
+      if (lane == 0) H.red[wave] = k2;
+      __syncthreads();
+      unsigned long long bclean = oct_max_key(H.red[lane & (K5_WAVES - 1)]);
+      if (tid == 0) { H.rescans++; H.cand = bclean; }
+      if (cand_wave) {
+        cand = bclean;
+        if (cand) {
+          uint32_t n = KB_KEY_NODE(cand);
+          if (g8) st8 = g8[n];
+          if (g4) st4 = g4[n];
+        }
+      }
+      __syncthreads();
+      best = bclean > best ? bclean : best;
     }
-    key = wave_max_u64(key);
-    if (lane == 0) red[wave] = key;
-    __syncthreads();
-    if (tid < 64) {
-      unsigned long long k2 = (tid < KB_K5_THREADS / 64) ? red[tid] : 0ull;
-      k2 = wave_max_u64(k2);
-      if (tid == 0) s_best = k2;
-    }
-    __syncthreads();
-    const unsigned long long best = s_best;
+    const unsigned long long cand_now = H.exhausted ? H.cand : hcand;
+    K5_STAMP(6);
+
     if (best == 0ull) {
       if (r.backfill) {   // backfill.go:50-66: no node passes the predicates -> the task simply stays Pending
         if (tid == 0) { r.dec_node[i] = KB_NONE_U32; r.dec_kind[i] = 0; }
         __syncthreads();
+        n_done = i + 1;
+        win_key = nwin_key; win_base = nwin_base;
         continue;
       }
       // allocate.go:144-148: no feasible node -> the job is abandoned; the host re-plans from here
-      if (tid == 0) { r.result[0] = i; r.result[1] = KB_REASON_NO_FEASIBLE; r.result[2] = nd; r.result[3] = s_fallbacks; r.result[4] = s_rescans; }
-      return;
+      n_done = i;
+      reason = KB_REASON_NO_FEASIBLE;
+      break;
     }
-    if (tid == 0) {
-      const uint32_t n = KB_KEY_NODE(best);
-      uint32_t kind = 0;
-      if (!r.backfill) {   // allocate.go:160: InitResreq.LessEqual(node.Idle) ? Allocate : Pipeline
-        bool fi = le_eps(tv.init0, d.idle[n], EPS_CPU) && le_eps(tv.init1, d.idle[(size_t)d.NP + n], EPS_MEM);
-        uint32_t a = tv.active >> 2, dd = 2;
-        while (a) {
-          if (a & 1u) fi = fi && le_eps(d.t_init[(size_t)dd * d.T + t], d.idle[(size_t)dd * d.NP + n], EPS_SCALAR);
-          a >>= 1; dd++;
-        }
-        kind = fi ? 0u : 1u;
-      }
-      // NodeInfo.AddTask (node_info.go:172-212): Allocated -> Idle.Sub(Resreq); Pipelined -> Releasing.Sub(Resreq)
-      double *vec = kind ? d.rel : d.idle;
-      const double r0 = d.t_res[t], r1 = d.t_res[(size_t)d.T + t];
-      vec[n] -= r0;
-      vec[(size_t)d.NP + n] -= r1;
-      const uint32_t has_map = kind ? 1u : d.nmask[n];   // Sub returns early when the receiver's scalar map is nil (resource_info.go:148-153)
-      uint32_t km = d.t_resmask[t];
-      if (km && has_map) {
-        uint32_t dd = 2;
-        while (km) {
-          if (km & 1u) vec[(size_t)dd * d.NP + n] -= d.t_res[(size_t)dd * d.T + t];
-          km >>= 1; dd++;
-        }
-      }
-      d.nzc[n] += tv.nzc;     // the pod is now in ni.Tasks: k8s NodeInfo rebuilt from it (nodeinfo/node_info.go:502-517)
-      d.nzm[n] += tv.nzm;
-      d.podcnt[n] += 1;
-      d.t_status[t] = kind ? KB_TASK_PIPELINED : KB_TASK_ALLOCATED;
-      d.t_node[t] = n;
-      d.t_counted[t] = 1;
-      r.dec_node[i] = n;
-      r.dec_kind[i] = kind;
-      if (r.delta && i >= r.own_row0 && i < r.own_row1) {
-        // per-node committed deltas of the rows this rank owns: [dIdle R][dRel R][dnzc][dnzm][dpodcnt] x NP
-        double *dv = r.delta + (size_t)(kind ? d.R : 0) * d.NP;
-        dv[n] -= r0;
-        dv[(size_t)d.NP + n] -= r1;
-        uint32_t km2 = d.t_resmask[t];
-        if (km2 && has_map) {
-          uint32_t dd = 2;
-          while (km2) {
-            if (km2 & 1u) dv[(size_t)dd * d.NP + n] -= d.t_res[(size_t)dd * d.T + t];
-            km2 >>= 1; dd++;
+
+    // ---- commit: NodeInfo.AddTask (api/node_info.go:172-212) on the LDS copy of the node
+    const uint32_t n = KB_KEY_NODE(best);
+    const bool clean_wins = best == cand_now;
+    const double res0 = (cur.flags & 1) ? cur.init0 : d.t_res[cur.task];
+    const double res1 = (cur.flags & 1) ? cur.init1 : d.t_res[(size_t)d.T + cur.task];
+    if (clean_wins) {
+      if (cand_wave) {
+        // lanes 0..9 hold field `lane` of the node, lanes 10..12 cls / maxpods / podcnt
+        double v = __longlong_as_double((long long)st8);
+        uint32_t kind = 0;
+        if (!r.backfill) {   // allocate.go:160: InitResreq.LessEqual(node.Idle) ? Allocate : Pipeline
+          bool ok = true;
+          if (lane == K5F_IDLE0) ok = le_eps(tv.init0, v, EPS_CPU);
+          if (lane == K5F_IDLE1) ok = le_eps(tv.init1, v, EPS_MEM);
+          if (lane == 2 && (tv.active >> 2)) {   // scalar dimensions (rare): compared against live global state
+            uint32_t a = tv.active >> 2, dd = 2;
+            while (a) {
+              if (a & 1u) ok = ok && le_eps(d.t_init[(size_t)dd * d.T + tv.task], d.idle[(size_t)dd * d.NP + n], EPS_SCALAR);
+              a >>= 1; dd++;
+            }
           }
+          kind = __ballot(!ok) ? 1u : 0u;
         }
-        double *tail = r.delta + (size_t)2 * d.R * d.NP;
-        tail[n] += (double)tv.nzc;
-        tail[(size_t)d.NP + n] += (double)tv.nzm;
-        tail[(size_t)2 * d.NP + n] += 1.0;
+        K5_STAMP(9);
+        // apply the task: Allocated -> Idle.Sub(Resreq); Pipelined -> Releasing.Sub(Resreq); pod joins ni.Tasks
+        const uint32_t f0 = kind ? K5F_REL0 : K5F_IDLE0;
+        if (lane == f0) v -= res0;
+        if (lane == f0 + 1) v -= res1;
+        unsigned long long out = (unsigned long long)__double_as_longlong(v);
+        if (lane == K5F_NZC) out = st8 + (unsigned long long)tv.nzc;
+        if (lane == K5F_NZM) out = st8 + (unsigned long long)tv.nzm;
+        if (lane >= K5F_INVAC && lane <= K5F_AM) out = st8;
+        if (lane < K5_NF8) tab[(size_t)lane * cap + nd] = out;
+        const int maxp = __builtin_amdgcn_readlane((int)st4, 11), pods = __builtin_amdgcn_readlane((int)st4, 12);
+        if (lane == 10) t_cls[nd] = st4;
+        if (lane == 11) t_left[nd] = maxp - pods - 1;
+        if (lane == 12) t_node[nd] = n;
+        if (lane == 0) {
+          bitmap[n >> 5] |= 1u << (n & 31);
+          H.last_slot = nd;
+          k5_commit_globals(d, r, cur, res0, res1, i, n, kind);
+          if (kind == 1u) H.stop = 1;
+        }
       }
-      if (!bit_test(dirty_bm, n)) {
-        dirty_bm[n >> 5] |= 1u << (n & 31);
-        r.dirty_list[nd] = n;
-        s_ndirty = nd + 1;
-      }
-      if (kind == 1u) {   // the host speculated "Allocated": stop after a Pipeline so it can re-plan
-        r.result[0] = i + 1; r.result[1] = KB_REASON_PIPELINED; r.result[2] = s_ndirty; r.result[3] = s_fallbacks; r.result[4] = s_rescans;
-        s_stop = 1;
+    } else {
+#pragma unroll
+      for (int j = 0; j < K5_SPT; j++) {
+        uint32_t slot = tid + j * KB_K5_THREADS;
+        if (slot < nd && ck[j] == best) {
+          uint32_t kind = 0;
+          if (!r.backfill) {
+            bool fi = le_eps(tv.init0, __longlong_as_double((long long)tab[K5F_IDLE0 * cap + slot]), EPS_CPU) &&
+                      le_eps(tv.init1, __longlong_as_double((long long)tab[K5F_IDLE1 * cap + slot]), EPS_MEM);
+            uint32_t a = tv.active >> 2, dd = 2;
+            while (a) {
+              if (a & 1u) fi = fi && le_eps(d.t_init[(size_t)dd * d.T + tv.task], d.idle[(size_t)dd * d.NP + n], EPS_SCALAR);
+              a >>= 1; dd++;
+            }
+            kind = fi ? 0u : 1u;
+          }
+          const uint32_t f0 = kind ? K5F_REL0 : K5F_IDLE0;
+          tab[(size_t)f0 * cap + slot] = (unsigned long long)__double_as_longlong(__longlong_as_double((long long)tab[(size_t)f0 * cap + slot]) - res0);
+          tab[(size_t)(f0 + 1) * cap + slot] = (unsigned long long)__double_as_longlong(__longlong_as_double((long long)tab[(size_t)(f0 + 1) * cap + slot]) - res1);
+          tab[(size_t)K5F_NZC * cap + slot] += (unsigned long long)tv.nzc;
+          tab[(size_t)K5F_NZM * cap + slot] += (unsigned long long)tv.nzm;
+          t_left[slot] -= 1;
+          H.last_slot = slot;
+          k5_commit_globals(d, r, cur, res0, res1, i, n, kind);
+          if (kind == 1u) H.stop = 1;
+        }
       }
     }
-    __threadfence_block();
+    K5_STAMP(7);
     __syncthreads();
-    if (s_stop) return;
+    K5_STAMP(8);
+    if (tracing && i < 512) {
+      unsigned long long *dst = r.trace + ((tid == 0 ? 0 : 512) + (size_t)i) * 10;
+#pragma unroll
+      for (int k = 0; k < 9; k++) dst[k] = stamp[k];
+      dst[9] = (clean_wins ? 1ull : 0ull) | (same ? 2ull : 0ull) | ((clean_wins && stamp[9] > stamp[6]) ? ((stamp[9] - stamp[6]) << 8) : 0ull);
+    }
+    if (clean_wins) nd++;
+    n_done = i + 1;
+    if (H.stop) { reason = KB_REASON_PIPELINED; break; }   // the host speculated "Allocated": stop after a Pipeline so it can re-plan
+    win_key = nwin_key; win_base = nwin_base;
   }
-  if (tid == 0) { r.result[0] = r.n_rows; r.result[1] = KB_REASON_DONE; r.result[2] = s_ndirty; r.result[3] = s_fallbacks; r.result[4] = s_rescans; }
+
+  // ---- write the dirty nodes' live state back to HBM
+  __syncthreads();
+  for (uint32_t slot = tid; slot < nd; slot += KB_K5_THREADS) {
+    uint32_t n = t_node[slot];
+    d.idle[n] = __longlong_as_double((long long)tab[K5F_IDLE0 * cap + slot]);
+    d.idle[(size_t)d.NP + n] = __longlong_as_double((long long)tab[K5F_IDLE1 * cap + slot]);
+    d.rel[n] = __longlong_as_double((long long)tab[K5F_REL0 * cap + slot]);
+    d.rel[(size_t)d.NP + n] = __longlong_as_double((long long)tab[K5F_REL1 * cap + slot]);
+    d.nzc[n] = (long long)tab[K5F_NZC * cap + slot];
+    d.nzm[n] = (long long)tab[K5F_NZM * cap + slot];
+    d.podcnt[n] = d.maxpods[n] - t_left[slot];
+  }
+  if (tid == 0) { r.result[0] = n_done; r.result[1] = reason; r.result[2] = nd; r.result[3] = H.rescans; r.result[4] = H.refills; }
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -510,18 +837,39 @@ __global__ void k_finalize_queues(KbDev d, const double *deserved, const uint32_
 // ------------------------------------------------------------------------------------------------------------
 // launch wrappers
 // ------------------------------------------------------------------------------------------------------------
-void kb_launch_matrix(const KbDev &d, const KbRound &r, void *stream) {
+size_t kb_commit_smem_bytes(uint32_t cap, uint32_t NP) { return k5_smem_bytes(cap, NP); }
+void kb_launch_gather(const KbDev &d, const KbRound &r, void *stream) {
   if (r.n_rows == 0) return;
-  dim3 grid(d.NP / (256 * K1_NPT), (r.n_rows + K1_TR - 1) / K1_TR);
-  hipLaunchKernelGGL(k_matrix, grid, dim3(256), 0, (hipStream_t)stream, d, r);
+  hipLaunchKernelGGL(k_gather, dim3((r.n_rows + 255) / 256), dim3(256), 0, (hipStream_t)stream, d, r);
+}
+void kb_launch_matrix(const KbDev &d, const KbRound &r, void *stream) {
+  if (r.n_mrows == 0) return;
+  if ((size_t)r.n_mrows * d.NP >= (4u << 20)) {
+    dim3 grid(d.NP / (256 * 4), (r.n_mrows + 31) / 32);
+    hipLaunchKernelGGL((k_matrix<4, 32>), grid, dim3(256), 0, (hipStream_t)stream, d, r);
+  } else {
+    dim3 grid(d.NP / 256, (r.n_mrows + 3) / 4);
+    hipLaunchKernelGGL((k_matrix<1, 4>), grid, dim3(256), 0, (hipStream_t)stream, d, r);
+  }
 }
 void kb_launch_argmax(const KbDev &d, const KbRound &r, void *stream) {
-  if (r.n_rows == 0) return;
-  hipLaunchKernelGGL(k_argmax, dim3((r.n_rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, d, r);
+  if (r.n_mrows == 0) return;
+  size_t sh = (size_t)d.NP * 2 + d.NP / 8;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_argmax), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(k_argmax, dim3(r.n_mrows), dim3(256), sh, (hipStream_t)stream, d, r);
 }
 void kb_launch_commit(const KbDev &d, const KbRound &r, void *stream) {
   if (r.n_rows == 0) return;
-  size_t sh = (size_t)(d.NP / 32) * sizeof(uint32_t);
+  size_t sh = k5_smem_bytes(r.cap, d.NP);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_commit), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set = true;
+  }
   hipLaunchKernelGGL(k_commit, dim3(1), dim3(KB_K5_THREADS), sh, (hipStream_t)stream, d, r);
 }
 void kb_launch_finalize(const KbDev &d, const uint32_t *job_task_begin, const int *job_min_avail, const uint32_t *job_queue,
