@@ -36,7 +36,7 @@ def main():
     ap.add_argument("--window", type=int, default=0)
     ap.add_argument("--topk", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample-tasks", type=int, default=20000)
+    ap.add_argument("--cpu-sample-tasks", type=int, default=0, help="0 = the whole allocate action (a few seconds on 16 threads)")
     ap.add_argument("--verify", action="store_true", help="compare the bind set with the oracle after the timed region (slow)")
     args = ap.parse_args()
 
@@ -108,18 +108,43 @@ def main():
     evals = d["evals"]
     value = evals / elapsed
 
-    # ---- roofline of the dominant-by-bytes kernel (K1 mask+score matrix), measured with HIP events on the engine stream
-    R, N = snap.n_res, snap.n_nodes
-    b_node, b_task = 16 * R + 44, 8 * R + 24                       # SURVEY.md §8d accounting (M)
+    # ---- roofline: the mask+score matrix kernel (K1), HBM-bound by construction (SURVEY.md §8d accounting (M):
+    # 2 B score + 1/8 B mask per evaluation written once, node and task vectors read once).  Two measurements, both with
+    # HIP events on the engine's stream:
+    #   "roofline"        the materialised T x N matrix of this workload in ONE launch (kb_bench_matrix, rows [0,T)):
+    #                     the kernel at the size north_star quotes the roofline target on;
+    #   "roofline_cycle"  the same kernel as the scheduling cycle launches it inside the timed region: one launch per
+    #                     round over the DISTINCT task shapes of the window (a few dozen rows), i.e. latency-sized.
+    R, N, T = snap.n_res, snap.n_nodes, snap.n_tasks
+    b_node, b_task = 16 * R + 44, 8 * R + 24
+
+    def roof(rows, ms, launches, label):
+        alg = rows * N * 2.125 + N * b_node + rows * b_task
+        ach = alg / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+        return {"bound": "hbm", "kernel": "k_matrix", "launch": label, "achieved": round(ach, 2), "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None, "bytes_per_launch": int(alg),
+                "avg_launch_ms": round(ms, 5), "launches": int(launches), "rows_per_launch": round(rows, 1),
+                "evals_per_s": round(rows * N / (ms * 1e-3), 1) if ms > 0 else 0.0}
+
     launches = max(1, d["matrix_launches"])
-    rows_per_launch = d["matrix_evals"] / N / launches
-    alg_bytes = rows_per_launch * N * 2.125 + N * b_node + rows_per_launch * b_task
-    avg_ms = d["matrix_ms"] / launches
-    achieved = alg_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-    roofline = {"bound": "hbm", "kernel": "k_matrix", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
-                "bytes_per_launch": int(alg_bytes), "avg_launch_ms": round(avg_ms, 5), "launches": int(launches),
-                "rows_per_launch": round(rows_per_launch, 1)}
+    roofline_cycle = roof(d["matrix_evals"] / N / launches, d["matrix_ms"] / launches, launches,
+                          "per-round launch inside the timed region (distinct shapes of one window)")
+    full_reps = 5
+    full_ms = eng.bench_matrix(0, T, reps=full_reps) if world == 1 else 0.0
+    roofline = roof(T, full_ms, full_reps, f"kb_bench_matrix rows [0,{T}) x {N} nodes, one launch") if full_ms > 0 else roofline_cycle
+    # HBM bytes per launch from the PMC passes of scripts/profile_round.sh (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate
+    # runs; KB units; FETCH_SIZE doubled per MI355X_MICROARCH.md's gfx950 correction).  Cannot be collected inside this
+    # process, so the committed summary of the same command is read back; null when it is absent or for another config.
+    pmc = os.path.join(ROOT, "profiles", "round1", "rocprofv3_pmc_k_matrix.csv")
+    if full_ms > 0 and args.config == 3 and args.scale == 1.0 and os.path.exists(pmc):
+        import csv
+        vals = {}
+        for row in csv.DictReader(open(pmc)):
+            if "k_matrix<4, 32>" in row["kernel"]:
+                vals[row["counter"]] = float(row["mean_KB_per_dispatch"])
+        if "FETCH_SIZE" in vals and "WRITE_SIZE" in vals:
+            roofline["traffic"] = int((2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024)
+            roofline["traffic_source"] = "profiles/round1/rocprofv3_pmc_k_matrix.csv"
 
     out = {
         "metric": "pod-node scoring evals/sec + binds/sec, 100k tasks x 10k nodes snapshot",
@@ -129,13 +154,13 @@ def main():
         "config": {"workload": f"BASELINE configs[{args.config - 1}]: {snap.n_tasks} tasks x {snap.n_nodes} nodes, "
                                f"{snap.n_jobs} gang jobs, {snap.n_queues} queues, R={R}, allocate+backfill, "
                                "plugins priority,gang,drf,predicates,proportion,nodeorder",
-                   "window": int(d["matrix_evals"] / N / launches) if launches else 0, "scale": args.scale},
+                   "window": args.window or 1024, "scale": args.scale},
         "binds_per_s": n_binds * args.steps / elapsed, "binds": n_binds, "decisions": int(d["decisions"] / args.steps),
         "evals_per_step": int(evals / args.steps),
         "kernel_ms_per_step": {k: round(d[k] / args.steps, 3) for k in ("matrix_ms", "argmax_ms", "commit_ms", "reduce_ms", "host_order_ms", "total_ms")},
         "rounds_per_step": d["rounds"] / args.steps, "spec_breaks_per_step": d["spec_breaks"] / args.steps,
         "row_fallbacks_per_step": d["row_fallbacks"] / args.steps,
-        "roofline": roofline,
+        "roofline": roofline, "roofline_cycle": roofline_cycle,
     }
 
     if rank == 0 and not args.no_cpu_baseline:
@@ -143,12 +168,13 @@ def main():
         oracle.build()
         threads = min(16, os.cpu_count() or 1)    # util/scheduler_helper.go:84: 16 workers
         o = oracle.Oracle(conf, snap, threads=threads)
-        o.set_task_limit(args.cpu_sample_tasks)
+        if args.cpu_sample_tasks:
+            o.set_task_limit(args.cpu_sample_tasks)
         c0 = time.perf_counter()
         o.allocate()
         c1 = time.perf_counter()
         out["cpu_baseline"] = {"value": o.evals / (c1 - c0), "unit": "evals/s", "cores": threads, "kind": "port",
-                               "sample": f"first {o.popped} popped tasks of the same snapshot's allocate action "
+                               "sample": f"{'first ' if args.cpu_sample_tasks else 'all '}{o.popped} popped tasks of the same snapshot's allocate action "
                                          f"({o.evals} evals, {c1 - c0:.1f} s); C restatement of the Go loop with the "
                                          "reference's 16-worker per-task fan-out, without its per-pair NodeInfo rebuilds"}
         o.close()

@@ -91,8 +91,7 @@ struct KbRound {
   unsigned long long *keys;    // [n_mrows][L] candidates, best first (descending score, ascending node index), 0-terminated
   uint32_t L;                  // list length; L >= n_rows + 1 guarantees a clean candidate survives any dirty set of the round
   // commit outputs
-  uint32_t *dec_node;          // [n_rows]
-  uint32_t *dec_kind;          // [n_rows]
+  unsigned long long *dec;     // [n_rows] decision records: low word node (KB_NONE = stayed Pending), high word kind
   uint32_t *result;            // [8]: n_done, reason, n_dirty, list_exhausted (live rescans), window_refills
   int backfill;                // commit semantics of backfill.go (first node passing the predicates, no score)
   double *delta;               // optional per-node committed deltas of owned rows [NP*(2R+3)] (multi-GPU), may be nullptr

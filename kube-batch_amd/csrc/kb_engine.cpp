@@ -108,10 +108,11 @@ struct kb_engine {
   DevBuf b_desc, b_trace;
   bool trace_on = false;
   std::vector<double> trace_acc = std::vector<double>(2 * 4 * 12, 0.0);
-  DevBuf b_rows, b_slot, b_mrows, b_same, b_score, b_maskw, b_keys, b_decnode, b_deckind, b_result;
+  DevBuf b_rows, b_slot, b_mrows, b_same, b_score, b_maskw, b_keys, b_dec, b_result;
   uint32_t win_cap = 0, mat_cap = 0;
   size_t keys_cap = 0;
   std::vector<uint32_t> h_rows, h_slot, h_mrows, h_decnode, h_deckind;
+  std::vector<unsigned long long> h_dec;
   std::vector<uint8_t> h_same;
   std::vector<uint32_t> shape_stamp, shape_slot_of;   // per row-shape id: round stamp and slot inside the current round
   uint32_t stamp = 0;
@@ -207,8 +208,8 @@ void ensure_window_buffers(kb_engine *e, uint32_t rows) {
   e->b_rows.alloc(sizeof(uint32_t) * rows);
   e->b_slot.alloc(sizeof(uint32_t) * rows);
   e->b_desc.alloc(sizeof(KbRowDesc) * rows);
-  e->b_decnode.alloc(sizeof(uint32_t) * rows);
-  e->b_deckind.alloc(sizeof(uint32_t) * rows);
+  e->b_dec.alloc(sizeof(unsigned long long) * rows);
+  e->h_dec.resize(rows);
   e->h_rows.resize(rows);
   e->h_slot.resize(rows);
   e->h_decnode.resize(rows);
@@ -286,8 +287,7 @@ KbRound make_round(kb_engine *e, uint32_t n_rows, uint32_t n_mrows, uint32_t L, 
   r.maskw = e->b_maskw.as<uint32_t>();
   r.keys = e->b_keys.as<unsigned long long>();
   r.L = L;
-  r.dec_node = e->b_decnode.as<uint32_t>();
-  r.dec_kind = e->b_deckind.as<uint32_t>();
+  r.dec = e->b_dec.as<unsigned long long>();
   r.result = e->b_result.as<uint32_t>();
   r.backfill = backfill ? 1 : 0;
   r.delta = nullptr;
@@ -344,10 +344,13 @@ void run_round(kb_engine *e, uint32_t n, int fit_mode, bool backfill, uint32_t &
   kb_launch_commit(d, r, e->stream);
   HIP_OK(hipEventRecord(t5.b, e->stream));
   HIP_OK(hipMemcpyAsync(e->h_result, e->b_result.p, sizeof(uint32_t) * 8, hipMemcpyDeviceToHost, e->stream));
-  HIP_OK(hipMemcpyAsync(e->h_decnode.data(), e->b_decnode.p, sizeof(uint32_t) * n, hipMemcpyDeviceToHost, e->stream));
-  HIP_OK(hipMemcpyAsync(e->h_deckind.data(), e->b_deckind.p, sizeof(uint32_t) * n, hipMemcpyDeviceToHost, e->stream));
+  HIP_OK(hipMemcpyAsync(e->h_dec.data(), e->b_dec.p, sizeof(unsigned long long) * n, hipMemcpyDeviceToHost, e->stream));
   HIP_OK(hipStreamSynchronize(e->stream));
   HIP_OK(hipGetLastError());
+  for (uint32_t i = 0; i < n; i++) {
+    e->h_decnode[i] = (uint32_t)(e->h_dec[i] & 0xFFFFFFFFull);
+    e->h_deckind[i] = (uint32_t)(e->h_dec[i] >> 32);
+  }
   float ms = 0;
   HIP_OK(hipEventElapsedTime(&ms, t1.a, t1.b));
   e->stats.matrix_ms += ms;

@@ -179,10 +179,11 @@ __global__ void __launch_bounds__(256) k_matrix(KbDev d, KbRound r) {
       pk.y = (res[2 % NPT] & 0xFFFFu) | (res[3 % NPT] << 16);
       *reinterpret_cast<uint2 *>(r.score + row * d.NP + n0) = pk;
       uint32_t nib = ((res[0] >> 16) & 1u) | (((res[1 % NPT] >> 16) & 1u) << 1) | (((res[2 % NPT] >> 16) & 1u) << 2) | (((res[3 % NPT] >> 16) & 1u) << 3);
+      // OR the 8 lanes' nibbles into one mask word with DPP moves (no LDS crossbar): xor 1, xor 2, mirror within 8
       uint32_t w = nib << (4 * (lane & 7));
-      w |= __shfl_xor(w, 1);
-      w |= __shfl_xor(w, 2);
-      w |= __shfl_xor(w, 4);
+      w |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)w, 0xB1, 0xf, 0xf, false);    // quad_perm [1,0,3,2]
+      w |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)w, 0x4E, 0xf, 0xf, false);    // quad_perm [2,3,0,1]
+      w |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)w, 0x141, 0xf, 0xf, false);   // row_half_mirror
       if ((lane & 7) == 0) r.maskw[row * mstride + (n0 >> 5)] = w;
     } else {
       r.score[row * d.NP + n0] = (uint16_t)(res[0] & 0xFFFFu);
@@ -367,12 +368,15 @@ __global__ void __launch_bounds__(256) k_gather(KbDev d, KbRound r) {
 #define K5F_NZM 9
 #define K5_NF8 10
 #define K5_WAVES (KB_K5_THREADS / 64)
-#define K5_SPT (KB_K5_MAX_WINDOW / KB_K5_THREADS)
+#define K5_EVAL (KB_K5_THREADS - 64)                                   // threads that own dirty slots (all but the candidate wave)
+#define K5_SPT ((KB_K5_MAX_WINDOW + K5_EVAL - 1) / K5_EVAL)
 
 struct K5Hdr {
   unsigned long long red[K5_WAVES];
-  unsigned long long cand;
-  uint32_t exhausted, stop, last_slot, refills, rescans, pad;
+  unsigned long long cand;          // \  one 16-byte read after barrier 1
+  uint32_t exhausted, pad0;         // /
+  uint32_t last_slot, stop;         //    one 8-byte read after barrier 2
+  uint32_t refills, rescans;
 };
 
 __host__ __device__ inline size_t k5_smem_bytes(uint32_t cap, uint32_t NP) {
@@ -415,11 +419,8 @@ __device__ __forceinline__ void k5_commit_globals(const KbDev &d, const KbRound 
       __threadfence_block();
     }
   }
-  d.t_status[k.task] = kind ? KB_TASK_PIPELINED : KB_TASK_ALLOCATED;
-  d.t_node[k.task] = n;
-  d.t_counted[k.task] = 1;
-  r.dec_node[i] = n;
-  r.dec_kind[i] = kind;
+  // one 8-byte decision record; the task table (status, node, counted) is updated from the records by k_apply
+  *reinterpret_cast<uint2 *>(&r.dec[i]) = make_uint2(n, kind);
   if (r.delta && i >= r.own_row0 && i < r.own_row1) {
     // per-node committed deltas of the rows this rank owns: [dIdle R][dRel R][dnzc][dnzm][dpodcnt] x NP
     double *dv = r.delta + (size_t)(kind ? d.R : 0) * d.NP;
@@ -476,7 +477,7 @@ __global__ void __launch_bounds__(KB_K5_THREADS) k_commit(KbDev d, KbRound r) {
     const uint32_t nq = r.n_rows * (uint32_t)(sizeof(KbRowDesc) / 8);
     for (uint32_t w = tid; w < nq; w += KB_K5_THREADS) dst[w] = src[w];
   }
-  if (tid == 0) { H.cand = 0; H.exhausted = 0; H.stop = 0; H.last_slot = 0xFFFFFFFFu; H.refills = 0; H.rescans = 0; }
+  if (tid == 0) { H.cand = 0; H.exhausted = 0; H.pad0 = 0; H.stop = 0; H.last_slot = 0xFFFFFFFFu; H.refills = 0; H.rescans = 0; }
   {
     // The loop below is latency-bound and this workgroup starts on a cold L2 (kernel boundary).  Touch every 128-byte
     // line it can need later — node state arrays and the candidate lists — once, with all threads, so that the
@@ -498,7 +499,7 @@ __global__ void __launch_bounds__(KB_K5_THREADS) k_commit(KbDev d, KbRound r) {
       for (uint32_t l = tid; l < d.NP / 32; l += KB_K5_THREADS) acc += arr4[a][(size_t)l * 32];
     const size_t klines = ((size_t)r.n_mrows * r.L + 15) / 16;
     for (size_t l = tid; l < klines; l += KB_K5_THREADS) acc += r.keys[l * 16];
-    if (acc == 0x123456789abcdefull) H.pad = 1;   // keep the loads alive
+    if (acc == 0x123456789abcdefull) H.pad0 = 1;   // keep the loads alive
   }
 
   // candidate wave, lanes 0..9: the 8-byte node field this lane fetches / initialises; lanes 10..12: cls, maxpods, podcnt
@@ -529,14 +530,19 @@ __global__ void __launch_bounds__(KB_K5_THREADS) k_commit(KbDev d, KbRound r) {
   for (int j = 0; j < K5_SPT; j++) ck[j] = 0ull;
   uint32_t prev_shape = 0xFFFFFFFFu;
   uint32_t nd = 0;                   // dirty slots in use (tracked identically by every thread)
+  uint32_t last_slot = 0xFFFFFFFFu;  // slot of the previous commit
   uint32_t n_done = 0, reason = KB_REASON_DONE;
 
   // optional cycle trace (KB_K5_TRACE=1): stamps are kept in registers and written once per row by thread 0 and by
   // lane 0 of the candidate wave
+#ifdef KB_K5_TRACE
   const bool tracing = r.trace != nullptr && (tid == 0 || tid == (K5_WAVES - 1) * 64);
   unsigned long long stamp[10];
   stamp[9] = 0;
 #define K5_STAMP(k) do { if (tracing) stamp[k] = __builtin_readcyclecounter(); } while (0)
+#else
+#define K5_STAMP(k) do { } while (0)
+#endif
 
   // candidate window of the current task: 64 consecutive list entries starting at win_base (candidate wave only)
   unsigned long long win_key = 0ull;
@@ -550,7 +556,6 @@ __global__ void __launch_bounds__(KB_K5_THREADS) k_commit(KbDev d, KbRound r) {
     TaskVals tv;
     tv.init0 = cur.init0; tv.init1 = cur.init1; tv.nzc = cur.nzc; tv.nzm = cur.nzm;
     tv.cls = cur.cls; tv.active = cur.active; tv.task = cur.task; tv.pad = 0;
-    const uint32_t last_slot = H.last_slot;
 
     // ---- candidate wave: issue the prefetch of the next row's candidate window
     unsigned long long nwin_key = 0ull;
@@ -568,8 +573,8 @@ __global__ void __launch_bounds__(KB_K5_THREADS) k_commit(KbDev d, KbRound r) {
     unsigned long long key = 0ull;
 #pragma unroll
     for (int j = 0; j < K5_SPT; j++) {
-      uint32_t slot = tid + j * KB_K5_THREADS;
-      if (slot < nd) {
+      uint32_t slot = tid + j * K5_EVAL;
+      if (!cand_wave && slot < nd) {
         if (!same || slot == last_slot) {
           NodeVals nv = k5_slot_vals(tab, t_cls, t_left, cap, slot);
           uint32_t node = t_node[slot];
@@ -627,9 +632,11 @@ __global__ void __launch_bounds__(KB_K5_THREADS) k_commit(KbDev d, KbRound r) {
     __syncthreads();
     K5_STAMP(5);
     unsigned long long best = oct_max_key(H.red[lane & (K5_WAVES - 1)]);
-    const unsigned long long hcand = H.cand;
+    const uint4 hdr1 = *reinterpret_cast<const uint4 *>(&H.cand);
+    const unsigned long long hcand = ((unsigned long long)hdr1.y << 32) | hdr1.x;
+    const uint32_t exhausted = hdr1.z;
 
-    if (H.exhausted) {
+    if (exhausted) {
       // cannot happen while L > window size; kept so a shorter (caller-limited) list stays exact: evaluate every CLEAN
       // node against global state (clean nodes are unchanged since the round started); dirty ones are covered above
       unsigned long long k2 = 0ull;
@@ -656,12 +663,12 @@ __global__ void __launch_bounds__(KB_K5_THREADS) k_commit(KbDev d, KbRound r) {
       __syncthreads();
       best = bclean > best ? bclean : best;
     }
-    const unsigned long long cand_now = H.exhausted ? H.cand : hcand;
+    const unsigned long long cand_now = exhausted ? H.cand : hcand;
     K5_STAMP(6);
 
     if (best == 0ull) {
       if (r.backfill) {   // backfill.go:50-66: no node passes the predicates -> the task simply stays Pending
-        if (tid == 0) { r.dec_node[i] = KB_NONE_U32; r.dec_kind[i] = 0; }
+        if (tid == 0) *reinterpret_cast<uint2 *>(&r.dec[i]) = make_uint2(KB_NONE_U32, 0u);
         __syncthreads();
         n_done = i + 1;
         win_key = nwin_key; win_base = nwin_base;
@@ -720,8 +727,8 @@ __global__ void __launch_bounds__(KB_K5_THREADS) k_commit(KbDev d, KbRound r) {
     } else {
 #pragma unroll
       for (int j = 0; j < K5_SPT; j++) {
-        uint32_t slot = tid + j * KB_K5_THREADS;
-        if (slot < nd && ck[j] == best) {
+        uint32_t slot = tid + j * K5_EVAL;
+        if (!cand_wave && slot < nd && ck[j] == best) {
           uint32_t kind = 0;
           if (!r.backfill) {
             bool fi = le_eps(tv.init0, __longlong_as_double((long long)tab[K5F_IDLE0 * cap + slot]), EPS_CPU) &&
@@ -748,15 +755,19 @@ __global__ void __launch_bounds__(KB_K5_THREADS) k_commit(KbDev d, KbRound r) {
     K5_STAMP(7);
     __syncthreads();
     K5_STAMP(8);
+#ifdef KB_K5_TRACE
     if (tracing && i < 512) {
       unsigned long long *dst = r.trace + ((tid == 0 ? 0 : 512) + (size_t)i) * 10;
 #pragma unroll
       for (int k = 0; k < 9; k++) dst[k] = stamp[k];
       dst[9] = (clean_wins ? 1ull : 0ull) | (same ? 2ull : 0ull) | ((clean_wins && stamp[9] > stamp[6]) ? ((stamp[9] - stamp[6]) << 8) : 0ull);
     }
+#endif
     if (clean_wins) nd++;
     n_done = i + 1;
-    if (H.stop) { reason = KB_REASON_PIPELINED; break; }   // the host speculated "Allocated": stop after a Pipeline so it can re-plan
+    const uint2 hdr2 = *reinterpret_cast<const uint2 *>(&H.last_slot);
+    last_slot = hdr2.x;
+    if (hdr2.y) { reason = KB_REASON_PIPELINED; break; }   // the host speculated "Allocated": stop after a Pipeline so it can re-plan
     win_key = nwin_key; win_base = nwin_base;
   }
 
@@ -773,6 +784,19 @@ __global__ void __launch_bounds__(KB_K5_THREADS) k_commit(KbDev d, KbRound r) {
     d.podcnt[n] = d.maxpods[n] - t_left[slot];
   }
   if (tid == 0) { r.result[0] = n_done; r.result[1] = reason; r.result[2] = nd; r.result[3] = H.rescans; r.result[4] = H.refills; }
+}
+
+// task-table side of ssn.Allocate / ssn.Pipeline for the rows the commit kernel processed (job.UpdateTaskStatus,
+// task.NodeName: framework/session.go:243,205; api/node_info.go:206-209), applied in parallel after the round
+__global__ void __launch_bounds__(256) k_apply(KbDev d, KbRound r) {
+  uint32_t i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= r.result[0]) return;     // n_done
+  uint2 dc = *reinterpret_cast<const uint2 *>(&r.dec[i]);
+  if (dc.x == KB_NONE_U32) return;
+  uint32_t t = r.rows[i];
+  d.t_status[t] = dc.y ? KB_TASK_PIPELINED : KB_TASK_ALLOCATED;
+  d.t_node[t] = dc.x;
+  d.t_counted[t] = 1;
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -871,6 +895,7 @@ void kb_launch_commit(const KbDev &d, const KbRound &r, void *stream) {
     attr_set = true;
   }
   hipLaunchKernelGGL(k_commit, dim3(1), dim3(KB_K5_THREADS), sh, (hipStream_t)stream, d, r);
+  hipLaunchKernelGGL(k_apply, dim3((r.n_rows + 255) / 256), dim3(256), 0, (hipStream_t)stream, d, r);
 }
 void kb_launch_finalize(const KbDev &d, const uint32_t *job_task_begin, const int *job_min_avail, const uint32_t *job_queue,
                         int gang_ready_enabled, const double *total, uint32_t total_mask, const double *deserved,
