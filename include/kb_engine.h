@@ -17,7 +17,7 @@
  *       cache.Snapshot() -> Session{Jobs,Nodes,Queues} (pkg/scheduler/cache/cache.go:627-683,
  *       pkg/scheduler/framework/session.go:63-115) plus every plugin's OnSessionOpen state:
  *       drf totals/shares (plugins/drf/drf.go:60-83), proportion deserved water-fill
- *       (plugins/proportion/proportion.go:58-154), gang JobValid filter (plugins/gang/gang.go:48-69).
+ *       (plugins/proportion/proportion.go:58-154).  (gang's JobValid filter never fires at this commit: DESIGN.md §1.)
  *   kb_session_reset
  *       a second framework.OpenSession on an unchanged cache (same Snapshot(), same OnSessionOpen results).
  *   kb_run_allocate
@@ -114,7 +114,6 @@ typedef struct kb_plugin_option {
 } kb_plugin_option;
 
 #define KB_FLAG_SYNC_ROUNDS 1u  /* disable host/device overlap (debug) */
-#define KB_FLAG_NO_TOPK     2u  /* skip the segmented arg-max: the commit kernel scans the stored matrix row for every task */
 
 typedef struct kb_config {
   uint32_t version;                /* KB_ABI_VERSION */
@@ -123,7 +122,7 @@ typedef struct kb_config {
   const kb_plugin_option *plugins;
   int32_t  device;                 /* HIP device ordinal */
   uint32_t window;                 /* task rows per device round; 0 = engine default */
-  uint32_t topk;                   /* candidates kept per row by the segmented arg-max; 0 = default */
+  uint32_t topk;                   /* reserved (candidate lists are window+1 long by construction) */
   uint32_t flags;                  /* KB_FLAG_* */
 } kb_config;
 
@@ -243,25 +242,27 @@ int  kb_get_node_state(kb_engine *e, double *idle, double *releasing, int64_t *n
 int  kb_get_shares(kb_engine *e, double *job_share, double *queue_share, double *queue_deserved);
 int  kb_get_stats(kb_engine *e, kb_stats *out);
 
-/* ---- round-granular entry points for task-row sharding across GPUs (SURVEY.md §8e) ----
- * One process per GPU holds a full replica of the session.  Per round every rank:
- *   kb_round_begin      -> the next speculated window of task rows (identical on every rank)
- *   kb_round_candidates -> mask+score matrix and top-K arg-max for ITS shard of the window rows,
- *                          written to a caller-provided DEVICE buffer [n_rows_shard][topk] of uint64 keys
+/* ---- round-granular entry points for task-row sharding across GPUs (SURVEY.md §8e, DESIGN.md §8) ----
+ * One process per GPU holds a full replica of the session.  Per round every rank calls, in this order:
+ *   kb_round_begin      -> the next speculated window (identical on every rank): n_rows task rows, n_mrows distinct
+ *                          task shapes (= matrix rows), list_len candidates per matrix row.  n_rows == 0: the action is
+ *                          complete (gang ballot + share reduction done, decisions available).
+ *   kb_round_candidates -> mask+score matrix and sorted candidate lists for matrix rows [mrow0, mrow1) — this rank's
+ *                          shard — written to a caller-provided DEVICE buffer [mrow1-mrow0][list_len] of uint64 keys
  *   (all-gather of the key buffers across ranks: RCCL, done by the caller)
- *   kb_round_commit     -> the sequential commit over the full window using the gathered keys; fills the
- *                          caller-provided DEVICE delta buffer (layout kb_round_delta_doubles) with the
- *                          committed per-node deltas of the rows this rank owns
- *   (all-reduce(sum) of the delta buffers: RCCL, done by the caller)
- *   kb_round_apply      -> install the reduced deltas as the node state for the next round and verify
- *                          they equal the replica's own commit (KB_E_INTERNAL on divergence)
+ *   kb_round_commit     -> the sequential commit over the whole window using the gathered table [n_mrows][list_len];
+ *                          fills the caller-provided DEVICE delta buffer (kb_round_delta_doubles float64: per node
+ *                          dIdle[R], dReleasing[R], d(non-zero cpu), d(non-zero mem), d(pod count)) with the committed
+ *                          deltas of window rows [own_row0, own_row1) only
+ *   (all-reduce(sum) of the delta buffers: RCCL, done by the caller; integer-valued float64 -> exact, order-independent)
+ *   kb_round_apply      -> node state for the next round := round-start state + reduced deltas; KB_E_INTERNAL if that
+ *                          differs from the replica's own commit (replicas diverged)
  */
-int  kb_round_begin(kb_engine *e, uint32_t action /*0 allocate,1 backfill*/, uint32_t *n_rows);
-int  kb_round_candidates(kb_engine *e, uint32_t row0, uint32_t row1, uint64_t dev_keys_ptr);
+int  kb_round_begin(kb_engine *e, uint32_t action /*0 allocate, 1 backfill*/, uint32_t *n_rows, uint32_t *n_mrows, uint32_t *list_len);
+int  kb_round_candidates(kb_engine *e, uint32_t mrow0, uint32_t mrow1, uint64_t dev_keys_ptr);
 int  kb_round_commit(kb_engine *e, uint64_t dev_all_keys_ptr, uint32_t own_row0, uint32_t own_row1, uint64_t dev_delta_ptr);
-int  kb_round_apply(kb_engine *e, uint64_t dev_delta_ptr, uint32_t *done /*1 when the action finished*/);
-int  kb_round_topk(const kb_engine *e, uint32_t *topk);
-int  kb_round_delta_doubles(const kb_engine *e, uint64_t *n_doubles);   /* N * (2R + 3) float64 per buffer */
+int  kb_round_apply(kb_engine *e, uint64_t dev_delta_ptr, uint32_t *done);
+int  kb_round_delta_doubles(const kb_engine *e, uint64_t *n_doubles);   /* NP * (2R + 3) float64 per buffer */
 int  kb_round_decisions(kb_engine *e, kb_decision *out, uint64_t cap, uint64_t *n_out);
 
 #ifdef __cplusplus

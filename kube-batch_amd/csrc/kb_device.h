@@ -110,6 +110,9 @@ void kb_launch_gather(const KbDev &d, const KbRound &r, void *stream);
 void kb_launch_matrix(const KbDev &d, const KbRound &r, void *stream);
 void kb_launch_argmax(const KbDev &d, const KbRound &r, void *stream);
 void kb_launch_commit(const KbDev &d, const KbRound &r, void *stream);
+// node state := round-start state + reduced deltas; returns how many values differ from the live (locally committed) state
+uint32_t kb_apply_deltas(const KbDev &d, const double *s_idle, const double *s_rel, const long long *s_nzc, const long long *s_nzm,
+                         const int *s_podcnt, const double *delta, uint32_t *dev_counter, void *stream);
 // gang ballot + drf/proportion share reduction over the task table
 void kb_launch_finalize(const KbDev &d, const uint32_t *job_task_begin, const int *job_min_avail, const uint32_t *job_queue,
                         int gang_ready_enabled, const double *total /*[R]*/, uint32_t total_mask, const double *deserved /*[R][Q]*/,

@@ -85,6 +85,9 @@ struct Timer {   // HIP-event pair on the engine stream
 
 }  // namespace
 
+struct MgState;
+static void mg_free(MgState *m);
+
 struct kb_engine {
   std::string err;
   int device = 0;
@@ -120,21 +123,11 @@ struct kb_engine {
   std::vector<Timer> ev;          // event pool for per-launch timing
   std::vector<kb_decision> decisions_all;   // decisions of the last multi-GPU round sequence
 
-  // multi-GPU round state
-  struct {
-    bool active = false;
-    uint32_t action = 0;
-    OrderMachine om, ckpt;
-    std::vector<uint8_t> dead;
-    std::vector<uint32_t> seq;
-    std::vector<uint32_t> bf_list;
-    size_t bf_pos = 0;
-    uint64_t spec_pops = 0;
-    bool finished = false;
-    DevBuf scratch_idle, scratch_rel, scratch_nzc, scratch_nzm, scratch_podcnt;
-  } mg;
+  // multi-GPU round state (kb_round_*), defined below
+  struct MgState *mg = nullptr;
 
   ~kb_engine() {
+    mg_free(mg);
     for (auto &t : ev) t.destroy();
     if (h_result) (void)hipHostFree(h_result);
     if (stream) (void)hipStreamDestroy(stream);
@@ -318,51 +311,87 @@ uint32_t assign_shapes(kb_engine *e, uint32_t n) {
   return ns;
 }
 
-// one single-GPU round over e->h_rows[0..n): matrix -> sorted candidates -> commit; returns n_done / reason
-void run_round(kb_engine *e, uint32_t n, int fit_mode, bool backfill, uint32_t &n_done, uint32_t &reason) {
+// ---- one device round, in three host steps so the multi-GPU path can interleave its collectives ----
+struct RoundCtx {
+  KbRound r{};
+  KbDev d{};
+  uint32_t n = 0, ns = 0, L = 0;
+  bool backfill = false;
+};
+
+// upload the window e->h_rows[0..n) (task ids, shape slots, representative rows) and build the row descriptors
+RoundCtx round_prepare(kb_engine *e, uint32_t n, int fit_mode, bool backfill) {
+  RoundCtx c;
   ensure_window_buffers(e, n);
   ensure_matrix_buffers(e, n, n + 1);
-  HostSession &hs = e->hs;
-  const uint32_t ns = assign_shapes(e, n);
-  const uint32_t L = n + 1;   // more candidates than the round can dirty: a clean one always survives
+  c.n = n;
+  c.ns = assign_shapes(e, n);
+  c.L = n + 1;   // more candidates than the round can dirty: a clean one always survives
+  c.backfill = backfill;
   HIP_OK(hipMemcpyAsync(e->b_rows.p, e->h_rows.data(), sizeof(uint32_t) * n, hipMemcpyHostToDevice, e->stream));
   HIP_OK(hipMemcpyAsync(e->b_slot.p, e->h_slot.data(), sizeof(uint32_t) * n, hipMemcpyHostToDevice, e->stream));
-  HIP_OK(hipMemcpyAsync(e->b_mrows.p, e->h_mrows.data(), sizeof(uint32_t) * ns, hipMemcpyHostToDevice, e->stream));
-  KbDev d = e->dev;
-  if (backfill) d.score_enabled = 0;   // backfill.go:50-66 takes the first node that passes the predicates: all scores tie
-  KbRound r = make_round(e, n, ns, L, fit_mode, backfill);
-  Timer &t1 = get_timer(e, 0), &t3 = get_timer(e, 1), &t5 = get_timer(e, 2);
+  HIP_OK(hipMemcpyAsync(e->b_mrows.p, e->h_mrows.data(), sizeof(uint32_t) * c.ns, hipMemcpyHostToDevice, e->stream));
+  c.d = e->dev;
+  if (backfill) c.d.score_enabled = 0;   // backfill.go:50-66 takes the first node that passes the predicates: all scores tie
+  c.r = make_round(e, n, c.ns, c.L, fit_mode, backfill);
   if (e->trace_on) HIP_OK(hipMemsetAsync(e->b_trace.p, 0, e->b_trace.bytes, e->stream));
-  kb_launch_gather(d, r, e->stream);
+  kb_launch_gather(c.d, c.r, e->stream);
+  return c;
+}
+
+// K1 + K3 for matrix rows [m0, m1) of the round; keys go to `keys` (row m0 first)
+void round_candidates(kb_engine *e, const RoundCtx &c, uint32_t m0, uint32_t m1, unsigned long long *keys) {
+  if (m1 <= m0) return;
+  KbRound r = c.r;
+  r.mrows = e->b_mrows.as<uint32_t>() + m0;
+  r.n_mrows = m1 - m0;
+  r.keys = keys;
+  Timer &t1 = get_timer(e, 0), &t3 = get_timer(e, 1);
   HIP_OK(hipEventRecord(t1.a, e->stream));
-  kb_launch_matrix(d, r, e->stream);
+  kb_launch_matrix(c.d, r, e->stream);
   HIP_OK(hipEventRecord(t1.b, e->stream));
   HIP_OK(hipEventRecord(t3.a, e->stream));
-  kb_launch_argmax(d, r, e->stream);
+  kb_launch_argmax(c.d, r, e->stream);
   HIP_OK(hipEventRecord(t3.b, e->stream));
+  e->stats.matrix_launches += 1;
+  e->stats.matrix_evals += (uint64_t)(m1 - m0) * e->hs.N;
+}
+
+// K5 over the whole window with the complete candidate table `keys` [ns][L]
+void round_commit(kb_engine *e, const RoundCtx &c, unsigned long long *keys, double *delta, uint32_t own0, uint32_t own1) {
+  KbRound r = c.r;
+  r.keys = keys;
+  r.delta = delta;
+  r.own_row0 = own0;
+  r.own_row1 = own1;
+  Timer &t5 = get_timer(e, 2);
   HIP_OK(hipEventRecord(t5.a, e->stream));
-  kb_launch_commit(d, r, e->stream);
+  kb_launch_commit(c.d, r, e->stream);
   HIP_OK(hipEventRecord(t5.b, e->stream));
   HIP_OK(hipMemcpyAsync(e->h_result, e->b_result.p, sizeof(uint32_t) * 8, hipMemcpyDeviceToHost, e->stream));
-  HIP_OK(hipMemcpyAsync(e->h_dec.data(), e->b_dec.p, sizeof(unsigned long long) * n, hipMemcpyDeviceToHost, e->stream));
+  HIP_OK(hipMemcpyAsync(e->h_dec.data(), e->b_dec.p, sizeof(unsigned long long) * c.n, hipMemcpyDeviceToHost, e->stream));
+}
+
+// wait for the round, account the kernel times, unpack the decision records
+void round_collect(kb_engine *e, const RoundCtx &c, bool had_candidates, uint32_t &n_done, uint32_t &reason) {
   HIP_OK(hipStreamSynchronize(e->stream));
   HIP_OK(hipGetLastError());
-  for (uint32_t i = 0; i < n; i++) {
+  for (uint32_t i = 0; i < c.n; i++) {
     e->h_decnode[i] = (uint32_t)(e->h_dec[i] & 0xFFFFFFFFull);
     e->h_deckind[i] = (uint32_t)(e->h_dec[i] >> 32);
   }
   float ms = 0;
-  HIP_OK(hipEventElapsedTime(&ms, t1.a, t1.b));
-  e->stats.matrix_ms += ms;
-  e->stats.matrix_launches += 1;
-  e->stats.matrix_evals += (uint64_t)ns * hs.N;
-  HIP_OK(hipEventElapsedTime(&ms, t3.a, t3.b));
-  e->stats.argmax_ms += ms;
-  HIP_OK(hipEventElapsedTime(&ms, t5.a, t5.b));
+  if (had_candidates) {
+    HIP_OK(hipEventElapsedTime(&ms, get_timer(e, 0).a, get_timer(e, 0).b));
+    e->stats.matrix_ms += ms;
+    HIP_OK(hipEventElapsedTime(&ms, get_timer(e, 1).a, get_timer(e, 1).b));
+    e->stats.argmax_ms += ms;
+  }
+  HIP_OK(hipEventElapsedTime(&ms, get_timer(e, 2).a, get_timer(e, 2).b));
   e->stats.commit_ms += ms;
   n_done = e->h_result[0];
   reason = e->h_result[1];
-  if (e->trace_on) {   // KB_K5_TRACE=1: per-phase shader-clock deltas of the commit kernel, first 512 rows of every round
+  if (e->trace_on) {   // KB_K5_TRACE=1 (and make TRACE=1): per-phase shader-clock deltas of the commit kernel, first 512 rows of every round
     std::vector<unsigned long long> tr(2 * 512 * 10);
     HIP_OK(hipMemcpy(tr.data(), e->b_trace.p, sizeof(unsigned long long) * tr.size(), hipMemcpyDeviceToHost));
     uint32_t m = std::min<uint32_t>(n_done, 512);
@@ -384,6 +413,14 @@ void run_round(kb_engine *e, uint32_t n, int fit_mode, bool backfill, uint32_t &
   e->round_no += 1;
 }
 
+// single-GPU round: every matrix row is local
+void run_round(kb_engine *e, uint32_t n, int fit_mode, bool backfill, uint32_t &n_done, uint32_t &reason) {
+  RoundCtx c = round_prepare(e, n, fit_mode, backfill);
+  round_candidates(e, c, 0, c.ns, e->b_keys.as<unsigned long long>());
+  round_commit(e, c, e->b_keys.as<unsigned long long>(), nullptr, 0, 0);
+  round_collect(e, c, true, n_done, reason);
+}
+
 void check_aggregates(kb_engine *e, const OrderMachine &om) {
   // the host's running drf / proportion / gang aggregates must equal the device reduction bit for bit
   const HostSession &hs = e->hs;
@@ -398,6 +435,140 @@ void check_aggregates(kb_engine *e, const OrderMachine &om) {
         throw EngineError(KB_E_INTERNAL, "proportion share diverged from the device reduction at queue " + std::to_string(q));
 }
 
+// Host side of one action as a resumable object: plan() fills e->h_rows with the next window, absorb() digests the
+// device's answer (confirm, or roll back + replay on a mis-speculated round), finish() runs the gang/share reduction.
+struct ActionRun {
+  uint32_t action = 0;   // 0 allocate, 1 backfill
+  OrderMachine om, ckpt;
+  std::vector<uint8_t> dead;
+  std::vector<kb_decision> decs;
+  std::vector<uint32_t> bf_list;
+  size_t bf_pos = 0;
+  uint64_t popped = 0, spec_pops = 0;
+  double host_ms = 0, t_start = 0;
+  bool active = false;
+
+  void begin(kb_engine *e, uint32_t act) {
+    HostSession &hs = e->hs;
+    action = act;
+    decs.clear();
+    popped = spec_pops = 0;
+    host_ms = 0;
+    t_start = now_ms();
+    active = true;
+    ensure_window_buffers(e, e->eff_window);
+    if (action == 0) {
+      double t0 = now_ms();
+      om.init_allocate(&hs, &e->pol);
+      host_ms += now_ms() - t0;
+      dead.assign(hs.n_feas_shapes ? hs.n_feas_shapes : 1, 0);
+    } else {
+      // backfill.go:44-47: jobs ascending JobID, Pending tasks ascending UID with an empty InitResreq; the order does not
+      // depend on outcomes, so there is nothing to speculate
+      bf_list.clear();
+      bf_pos = 0;
+      for (uint32_t t = 0; t < hs.T; t++)
+        if (hs.t_status[t] == KB_TASK_PENDING && hs.t_init_empty[t] && hs.t_job[t] < hs.J) bf_list.push_back(t);
+    }
+  }
+
+  uint32_t plan(kb_engine *e) {
+    HostSession &hs = e->hs;
+    const uint32_t W = e->eff_window;
+    if (action == 1) {
+      uint32_t n = (uint32_t)std::min<size_t>(W, bf_list.size() - bf_pos);
+      if (n) std::memcpy(e->h_rows.data(), &bf_list[bf_pos], sizeof(uint32_t) * n);
+      return n;
+    }
+    double t0 = now_ms();
+    ckpt = om;   // roll-back point for a mis-speculated round
+    uint32_t n = 0, t;
+    spec_pops = 0;
+    while (n < W && om.next(t)) {
+      spec_pops++;
+      if (dead[hs.t_feas_shape[t]]) { om.report(Outcome::NoFeasibleNode); continue; }   // known: feasibility only shrinks inside one action
+      e->h_rows[n++] = t;
+      om.report(Outcome::Allocated);
+    }
+    host_ms += now_ms() - t0;
+    if (n == 0) popped += spec_pops;
+    return n;
+  }
+
+  void absorb(kb_engine *e, uint32_t n, uint32_t n_done, uint32_t reason) {
+    HostSession &hs = e->hs;
+    const uint32_t round = (uint32_t)(e->round_no - 1);
+    if (action == 1) {
+      if (reason != KB_REASON_DONE || n_done != n) throw EngineError(KB_E_INTERNAL, "backfill round ended early");
+      for (uint32_t i = 0; i < n; i++)
+        if (e->h_decnode[i] != KB_NONE) decs.push_back(kb_decision{e->h_rows[i], e->h_decnode[i], 0u, round});
+      bf_pos += n;
+      return;
+    }
+    double t0 = now_ms();
+    if (reason == KB_REASON_DONE) {
+      popped += spec_pops;
+      for (uint32_t i = 0; i < n; i++) decs.push_back(kb_decision{e->h_rows[i], e->h_decnode[i], e->h_deckind[i], round});
+    } else {
+      // replay the confirmed prefix on the checkpoint, then feed the true outcome of the row that broke the speculation
+      e->stats.spec_breaks += 1;
+      om = ckpt;
+      uint32_t i = 0, t;
+      for (;;) {
+        if (!om.next(t)) throw EngineError(KB_E_INTERNAL, "order replay ran out of tasks");
+        popped++;
+        if (dead[hs.t_feas_shape[t]]) { om.report(Outcome::NoFeasibleNode); continue; }
+        if (t != e->h_rows[i]) throw EngineError(KB_E_INTERNAL, "order replay diverged from the speculated sequence");
+        if (reason == KB_REASON_NO_FEASIBLE && i == n_done) {
+          dead[hs.t_feas_shape[t]] = 1;
+          om.report(Outcome::NoFeasibleNode);
+          break;
+        }
+        decs.push_back(kb_decision{t, e->h_decnode[i], e->h_deckind[i], round});
+        om.report(e->h_deckind[i] ? Outcome::Pipelined : Outcome::Allocated);
+        i++;
+        if (reason == KB_REASON_PIPELINED && i == n_done) break;
+      }
+    }
+    host_ms += now_ms() - t0;
+  }
+
+  void finish(kb_engine *e) {
+    HostSession &hs = e->hs;
+    run_finalize(e);
+    if (action == 0) {
+      check_aggregates(e, om);
+      e->stats.tasks_popped += popped;
+      e->stats.evals += popped * (uint64_t)hs.N;   // PredicateNodes visits every node for every popped task (allocate.go:143)
+    } else {
+      e->stats.tasks_popped += bf_list.size();
+      // the reference stops at the first node that passes: count the nodes it actually visits
+      uint64_t ev = 0;
+      std::vector<uint8_t> placed(hs.T, 0);
+      for (auto &dcs : decs) { placed[dcs.task] = 1; ev += (uint64_t)dcs.node + 1; }
+      for (uint32_t t : bf_list) if (!placed[t]) ev += hs.N;
+      e->stats.evals += ev;
+    }
+    e->stats.decisions += decs.size();
+    e->stats.host_order_ms += host_ms;
+    e->stats.total_ms += now_ms() - t_start;
+    active = false;
+  }
+};
+
+}  // namespace
+
+struct MgState {
+  ActionRun run;
+  RoundCtx ctx;
+  bool in_round = false, committed = false, had_candidates = false;
+  uint32_t n_done = 0, reason = 0;
+  std::vector<kb_decision> last_decs;
+  DevBuf s_idle, s_rel, s_nzc, s_nzm, s_podcnt;   // node state at round start
+};
+static void mg_free(MgState *m) { delete m; }
+
+namespace {
 int guarded(kb_engine *e, const std::function<void()> &fn) {
   try {
     if (e) HIP_OK(hipSetDevice(e->device));
@@ -479,7 +650,8 @@ int kb_session_load(kb_engine *e, const kb_snapshot *sn) {
     if (sn->version != KB_ABI_VERSION) throw EngineError(KB_E_INVALID, "snapshot ABI version mismatch");
     if (sn->n_res < 2 || sn->n_res > KB_MAX_RES) throw EngineError(KB_E_INVALID, "n_res out of range");
     e->loaded = false;
-    e->mg.active = false;
+    mg_free(e->mg);
+    e->mg = nullptr;
     HostSession &hs = e->hs;
     hs = HostSession();
     const int R = hs.R = (int)sn->n_res;
@@ -751,124 +923,36 @@ int kb_session_reset(kb_engine *e) {
     restore(e->b_podcnt, e->p_podcnt); restore(e->b_tstatus, e->p_tstatus); restore(e->b_tnode, e->p_tnode);
     restore(e->b_tcounted, e->p_tcounted);
     HIP_OK(hipMemsetAsync(e->b_tbind.p, 0xFF, sizeof(uint32_t) * (e->hs.T ? e->hs.T : 1), s));
-    e->mg.active = false;
+    mg_free(e->mg);
+    e->mg = nullptr;
     double keep = e->stats.reduce_ms;
     run_finalize(e);
     e->stats.reduce_ms = keep;
   });
 }
 
-int kb_run_allocate(kb_engine *e, kb_decision *out, uint64_t cap, uint64_t *n_out) {
+static int run_action(kb_engine *e, uint32_t action, kb_decision *out, uint64_t cap, uint64_t *n_out) {
   if (!e) return KB_E_INVALID;
   return guarded(e, [&]() {
-    if (!e->loaded) throw EngineError(KB_E_STATE, "kb_session_load must precede kb_run_allocate");
-    const double t_start = now_ms();
-    HostSession &hs = e->hs;
-    std::vector<kb_decision> decs;
-    OrderMachine om;
-    double t0 = now_ms();
-    om.init_allocate(&hs, &e->pol);
-    double host_ms = now_ms() - t0;
-    std::vector<uint8_t> dead(hs.n_feas_shapes ? hs.n_feas_shapes : 1, 0);
-    const uint32_t W = e->eff_window;
-    ensure_window_buffers(e, W);
-    uint64_t popped = 0;
+    if (!e->loaded) throw EngineError(KB_E_STATE, "kb_session_load must precede kb_run_*");
+    ActionRun run;
+    run.begin(e, action);
     for (;;) {
-      t0 = now_ms();
-      OrderMachine ckpt = om;   // roll-back point for a mis-speculated round
-      uint32_t n = 0;
-      uint64_t spec_pops = 0;
-      uint32_t t;
-      while (n < W && om.next(t)) {
-        spec_pops++;
-        if (dead[hs.t_feas_shape[t]]) { om.report(Outcome::NoFeasibleNode); continue; }   // known: feasibility only shrinks inside one action
-        e->h_rows[n++] = t;
-        om.report(Outcome::Allocated);
-      }
-      host_ms += now_ms() - t0;
-      if (n == 0) { popped += spec_pops; break; }
+      uint32_t n = run.plan(e);
+      if (n == 0) break;
       uint32_t n_done = 0, reason = 0;
-      run_round(e, n, 1, false, n_done, reason);
-      t0 = now_ms();
-      if (reason == KB_REASON_DONE) {
-        popped += spec_pops;
-        for (uint32_t i = 0; i < n; i++) decs.push_back(kb_decision{e->h_rows[i], e->h_decnode[i], e->h_deckind[i], (uint32_t)(e->round_no - 1)});
-      } else {
-        // replay the confirmed prefix on the checkpoint, then feed the true outcome of the row that broke the speculation
-        e->stats.spec_breaks += 1;
-        om = ckpt;
-        uint32_t i = 0;
-        for (;;) {
-          if (!om.next(t)) throw EngineError(KB_E_INTERNAL, "order replay ran out of tasks");
-          popped++;
-          if (dead[hs.t_feas_shape[t]]) { om.report(Outcome::NoFeasibleNode); continue; }
-          if (t != e->h_rows[i]) throw EngineError(KB_E_INTERNAL, "order replay diverged from the speculated sequence");
-          if (reason == KB_REASON_NO_FEASIBLE && i == n_done) {
-            dead[hs.t_feas_shape[t]] = 1;
-            om.report(Outcome::NoFeasibleNode);
-            break;
-          }
-          decs.push_back(kb_decision{t, e->h_decnode[i], e->h_deckind[i], (uint32_t)(e->round_no - 1)});
-          om.report(e->h_deckind[i] ? Outcome::Pipelined : Outcome::Allocated);
-          i++;
-          if (reason == KB_REASON_PIPELINED && i == n_done) break;
-        }
-      }
-      host_ms += now_ms() - t0;
+      run_round(e, n, action == 0 ? 1 : 0, action == 1, n_done, reason);
+      run.absorb(e, n, n_done, reason);
     }
-    run_finalize(e);
-    check_aggregates(e, om);
-    e->stats.tasks_popped += popped;
-    e->stats.evals += popped * (uint64_t)hs.N;   // PredicateNodes visits every node for every popped task (allocate.go:143)
-    e->stats.decisions += decs.size();
-    e->stats.host_order_ms += host_ms;
-    e->stats.total_ms += now_ms() - t_start;
-    if (n_out) *n_out = decs.size();
-    if (decs.size() > cap) throw EngineError(KB_E_CAPACITY, "decision buffer too small");
-    if (out && !decs.empty()) std::memcpy(out, decs.data(), sizeof(kb_decision) * decs.size());
+    run.finish(e);
+    if (n_out) *n_out = run.decs.size();
+    if (run.decs.size() > cap) throw EngineError(KB_E_CAPACITY, "decision buffer too small");
+    if (out && !run.decs.empty()) std::memcpy(out, run.decs.data(), sizeof(kb_decision) * run.decs.size());
   });
 }
 
-int kb_run_backfill(kb_engine *e, kb_decision *out, uint64_t cap, uint64_t *n_out) {
-  if (!e) return KB_E_INVALID;
-  return guarded(e, [&]() {
-    if (!e->loaded) throw EngineError(KB_E_STATE, "kb_session_load must precede kb_run_backfill");
-    const double t_start = now_ms();
-    HostSession &hs = e->hs;
-    // backfill.go:44-47: jobs ascending JobID, Pending tasks ascending UID with an empty InitResreq; the order does not
-    // depend on outcomes, so there is nothing to speculate
-    std::vector<uint32_t> list;
-    for (uint32_t t = 0; t < hs.T; t++)
-      if (hs.t_status[t] == KB_TASK_PENDING && hs.t_init_empty[t] && hs.t_job[t] < hs.J) list.push_back(t);
-    std::vector<kb_decision> decs;
-    const uint32_t W = e->eff_window;
-    ensure_window_buffers(e, W);
-    for (size_t pos = 0; pos < list.size(); pos += W) {
-      uint32_t n = (uint32_t)std::min<size_t>(W, list.size() - pos);
-      std::memcpy(e->h_rows.data(), &list[pos], sizeof(uint32_t) * n);
-      uint32_t n_done = 0, reason = 0;
-      run_round(e, n, 0, true, n_done, reason);
-      if (reason != KB_REASON_DONE || n_done != n) throw EngineError(KB_E_INTERNAL, "backfill round ended early");
-      for (uint32_t i = 0; i < n; i++)
-        if (e->h_decnode[i] != KB_NONE) decs.push_back(kb_decision{e->h_rows[i], e->h_decnode[i], 0u, (uint32_t)(e->round_no - 1)});
-    }
-    run_finalize(e);
-    e->stats.tasks_popped += list.size();
-    // the reference stops at the first node that passes: count the nodes it actually visits
-    uint64_t ev = 0;
-    {
-      std::vector<uint8_t> placed(hs.T, 0);
-      for (auto &dcs : decs) { placed[dcs.task] = 1; ev += (uint64_t)dcs.node + 1; }
-      for (uint32_t t : list) if (!placed[t]) ev += hs.N;
-    }
-    e->stats.evals += ev;
-    e->stats.decisions += decs.size();
-    e->stats.total_ms += now_ms() - t_start;
-    if (n_out) *n_out = decs.size();
-    if (decs.size() > cap) throw EngineError(KB_E_CAPACITY, "decision buffer too small");
-    if (out && !decs.empty()) std::memcpy(out, decs.data(), sizeof(kb_decision) * decs.size());
-  });
-}
+int kb_run_allocate(kb_engine *e, kb_decision *out, uint64_t cap, uint64_t *n_out) { return run_action(e, 0, out, cap, n_out); }
+int kb_run_backfill(kb_engine *e, kb_decision *out, uint64_t cap, uint64_t *n_out) { return run_action(e, 1, out, cap, n_out); }
 
 static KbRound matrix_chunk(kb_engine *e, uint32_t t0, uint32_t n, uint32_t fit_mode, uint32_t k) {
   ensure_matrix_buffers(e, n, k ? k : 1);
@@ -1003,21 +1087,109 @@ int kb_get_stats(kb_engine *e, kb_stats *out) {
   return KB_OK;
 }
 
-// ---- multi-GPU round API: implemented in a later section of this file ----
-int kb_round_topk(const kb_engine *e, uint32_t *topk) {
-  if (!e || !topk) return KB_E_INVALID;
-  *topk = e->topk;
-  return KB_OK;
+// ---- round-granular API for task-row sharding across GPUs ----
+int kb_round_begin(kb_engine *e, uint32_t action, uint32_t *n_rows, uint32_t *n_mrows, uint32_t *list_len) {
+  if (!e || !n_rows) return KB_E_INVALID;
+  return guarded(e, [&]() {
+    if (!e->loaded) throw EngineError(KB_E_STATE, "no session loaded");
+    if (action > 1) throw EngineError(KB_E_INVALID, "action must be 0 (allocate) or 1 (backfill)");
+    if (!e->mg) e->mg = new MgState();
+    MgState &m = *e->mg;
+    if (!m.run.active) {
+      m.run.begin(e, action);
+      m.in_round = false;
+    } else if (m.run.action != action) {
+      throw EngineError(KB_E_STATE, "another action is still in progress");
+    }
+    if (m.in_round) throw EngineError(KB_E_STATE, "previous round not applied");
+    uint32_t n = m.run.plan(e);
+    *n_rows = n;
+    if (n_mrows) *n_mrows = 0;
+    if (list_len) *list_len = 0;
+    if (n == 0) {   // action complete: gang ballot + share reduction, consistency checks
+      m.last_decs = m.run.decs;
+      m.run.finish(e);
+      return;
+    }
+    m.ctx = round_prepare(e, n, action == 0 ? 1 : 0, action == 1);
+    m.had_candidates = false;
+    m.in_round = true;
+    // round-start copy of the node state: the reduced deltas are applied to it
+    const size_t NP = e->dev.NP;
+    const int R = e->hs.R;
+    auto snap = [&](DevBuf &dst, const DevBuf &src) {
+      if (dst.bytes != src.bytes) dst.alloc(src.bytes);
+      HIP_OK(hipMemcpyAsync(dst.p, src.p, src.bytes, hipMemcpyDeviceToDevice, e->stream));
+    };
+    snap(m.s_idle, e->b_idle); snap(m.s_rel, e->b_rel); snap(m.s_nzc, e->b_nzc); snap(m.s_nzm, e->b_nzm); snap(m.s_podcnt, e->b_podcnt);
+    (void)NP; (void)R;
+    if (n_mrows) *n_mrows = m.ctx.ns;
+    if (list_len) *list_len = m.ctx.L;
+  });
 }
+
+int kb_round_candidates(kb_engine *e, uint32_t mrow0, uint32_t mrow1, uint64_t dev_keys_ptr) {
+  if (!e) return KB_E_INVALID;
+  return guarded(e, [&]() {
+    if (!e->mg || !e->mg->in_round) throw EngineError(KB_E_STATE, "kb_round_begin must precede kb_round_candidates");
+    MgState &m = *e->mg;
+    if (mrow1 > m.ctx.ns) mrow1 = m.ctx.ns;
+    if (mrow0 >= mrow1) return;   // this rank's shard is empty (fewer shapes than ranks)
+    if (!dev_keys_ptr) throw EngineError(KB_E_INVALID, "null key buffer");
+    round_candidates(e, m.ctx, mrow0, mrow1, reinterpret_cast<unsigned long long *>(dev_keys_ptr));
+    m.had_candidates = true;
+    HIP_OK(hipStreamSynchronize(e->stream));   // the caller's collective runs on its own stream
+    HIP_OK(hipGetLastError());
+  });
+}
+
+int kb_round_commit(kb_engine *e, uint64_t dev_all_keys_ptr, uint32_t own_row0, uint32_t own_row1, uint64_t dev_delta_ptr) {
+  if (!e) return KB_E_INVALID;
+  return guarded(e, [&]() {
+    if (!e->mg || !e->mg->in_round) throw EngineError(KB_E_STATE, "kb_round_begin must precede kb_round_commit");
+    MgState &m = *e->mg;
+    if (!dev_all_keys_ptr) throw EngineError(KB_E_INVALID, "null key table");
+    double *delta = reinterpret_cast<double *>(dev_delta_ptr);
+    if (delta) HIP_OK(hipMemsetAsync(delta, 0, sizeof(double) * (size_t)e->dev.NP * (2 * (size_t)e->hs.R + 3), e->stream));
+    round_commit(e, m.ctx, reinterpret_cast<unsigned long long *>(dev_all_keys_ptr), delta, own_row0, own_row1);
+    round_collect(e, m.ctx, m.had_candidates, m.n_done, m.reason);
+    m.committed = true;
+  });
+}
+
+int kb_round_apply(kb_engine *e, uint64_t dev_delta_ptr, uint32_t *done) {
+  if (!e) return KB_E_INVALID;
+  return guarded(e, [&]() {
+    if (!e->mg || !e->mg->in_round || !e->mg->committed) throw EngineError(KB_E_STATE, "kb_round_commit must precede kb_round_apply");
+    MgState &m = *e->mg;
+    if (dev_delta_ptr) {
+      // node state for the next round = round-start state + all-reduced deltas; it must equal this replica's own commit
+      uint32_t mism = kb_apply_deltas(e->dev, m.s_idle.as<double>(), m.s_rel.as<double>(), m.s_nzc.as<long long>(), m.s_nzm.as<long long>(),
+                                      m.s_podcnt.as<int>(), reinterpret_cast<const double *>(dev_delta_ptr), e->b_result.as<uint32_t>() + 6, e->stream);
+      if (mism) throw EngineError(KB_E_INTERNAL, "replicas diverged: reduced per-node deltas differ from the local commit at " + std::to_string(mism) + " values");
+    }
+    m.run.absorb(e, m.ctx.n, m.n_done, m.reason);
+    m.in_round = false;
+    m.committed = false;
+    if (done) *done = 0;
+  });
+}
+
+int kb_round_decisions(kb_engine *e, kb_decision *out, uint64_t cap, uint64_t *n_out) {
+  if (!e) return KB_E_INVALID;
+  return guarded(e, [&]() {
+    if (!e->mg) throw EngineError(KB_E_STATE, "no round-mode action has run");
+    const std::vector<kb_decision> &d = e->mg->run.active ? e->mg->run.decs : e->mg->last_decs;
+    if (n_out) *n_out = d.size();
+    if (d.size() > cap) throw EngineError(KB_E_CAPACITY, "decision buffer too small");
+    if (out && !d.empty()) std::memcpy(out, d.data(), sizeof(kb_decision) * d.size());
+  });
+}
+
 int kb_round_delta_doubles(const kb_engine *e, uint64_t *n_doubles) {
   if (!e || !n_doubles) return KB_E_INVALID;
   *n_doubles = (uint64_t)e->dev.NP * (2ull * e->hs.R + 3ull);
   return KB_OK;
 }
-int kb_round_begin(kb_engine *e, uint32_t, uint32_t *) { if (e) e->err = "multi-GPU rounds not built yet"; return KB_E_UNSUPPORTED; }
-int kb_round_candidates(kb_engine *e, uint32_t, uint32_t, uint64_t) { if (e) e->err = "multi-GPU rounds not built yet"; return KB_E_UNSUPPORTED; }
-int kb_round_commit(kb_engine *e, uint64_t, uint32_t, uint32_t, uint64_t) { if (e) e->err = "multi-GPU rounds not built yet"; return KB_E_UNSUPPORTED; }
-int kb_round_apply(kb_engine *e, uint64_t, uint32_t *) { if (e) e->err = "multi-GPU rounds not built yet"; return KB_E_UNSUPPORTED; }
-int kb_round_decisions(kb_engine *e, kb_decision *, uint64_t, uint64_t *) { if (e) e->err = "multi-GPU rounds not built yet"; return KB_E_UNSUPPORTED; }
 
 }  // extern "C"

@@ -861,6 +861,37 @@ __global__ void k_finalize_queues(KbDev d, const double *deserved, const uint32_
 // ------------------------------------------------------------------------------------------------------------
 // launch wrappers
 // ------------------------------------------------------------------------------------------------------------
+// multi-GPU: install round-start state + all-reduced deltas, counting values that differ from the replica's own commit
+__global__ void __launch_bounds__(256) k_apply_deltas(KbDev d, const double *s_idle, const double *s_rel, const long long *s_nzc,
+                                                      const long long *s_nzm, const int *s_podcnt, const double *delta, uint32_t *counter) {
+  uint32_t n = blockIdx.x * 256 + threadIdx.x;
+  if (n >= d.NP) return;
+  uint32_t bad = 0;
+  for (int dim = 0; dim < d.R; dim++) {
+    size_t o = (size_t)dim * d.NP + n;
+    double vi = s_idle[o] + delta[o];
+    double vr = s_rel[o] + delta[(size_t)d.R * d.NP + o];
+    bad += (vi != d.idle[o]) + (vr != d.rel[o]);
+    d.idle[o] = vi;
+    d.rel[o] = vr;
+  }
+  const double *tail = delta + (size_t)2 * d.R * d.NP;
+  long long c = s_nzc[n] + (long long)tail[n], m = s_nzm[n] + (long long)tail[(size_t)d.NP + n];
+  int p = s_podcnt[n] + (int)tail[(size_t)2 * d.NP + n];
+  bad += (c != d.nzc[n]) + (m != d.nzm[n]) + (p != d.podcnt[n]);
+  d.nzc[n] = c; d.nzm[n] = m; d.podcnt[n] = p;
+  if (bad) atomicAdd(counter, bad);
+}
+uint32_t kb_apply_deltas(const KbDev &d, const double *s_idle, const double *s_rel, const long long *s_nzc, const long long *s_nzm,
+                         const int *s_podcnt, const double *delta, uint32_t *dev_counter, void *stream) {
+  hipStream_t s = (hipStream_t)stream;
+  (void)hipMemsetAsync(dev_counter, 0, sizeof(uint32_t), s);
+  hipLaunchKernelGGL(k_apply_deltas, dim3((d.NP + 255) / 256), dim3(256), 0, s, d, s_idle, s_rel, s_nzc, s_nzm, s_podcnt, delta, dev_counter);
+  uint32_t h = 0;
+  (void)hipMemcpyAsync(&h, dev_counter, sizeof(uint32_t), hipMemcpyDeviceToHost, s);
+  (void)hipStreamSynchronize(s);
+  return h;
+}
 size_t kb_commit_smem_bytes(uint32_t cap, uint32_t NP) { return k5_smem_bytes(cap, NP); }
 void kb_launch_gather(const KbDev &d, const KbRound &r, void *stream) {
   if (r.n_rows == 0) return;

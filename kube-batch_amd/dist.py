@@ -1,0 +1,136 @@
+"""Task-row sharding of the scheduling cycle across the GPUs of one node.
+
+One process per GPU (torch.distributed; backend "nccl" is RCCL over xGMI on ROCm).  Every rank holds a full replica
+of the session.  Per round:
+
+    round_begin        identical speculated window on every rank (deterministic host code)
+    round_candidates   mask+score matrix and sorted candidate lists for THIS RANK'S SHARD of the window's matrix rows
+    all_gather         candidate lists -> full table on every rank              (the path's real exchange step)
+    round_commit       identical sequential commit on every rank; per-node committed deltas of the rows this rank owns
+    all_reduce(sum)    per-node deltas (integer-valued float64: exact, order-independent)
+    round_apply        next round's node state := round start + reduced deltas; must equal the replica's own commit
+
+The transport is pluggable: with the "nccl" backend the collectives run on device buffers; with "gloo" (CPU tests, or
+several ranks sharing one GPU) the same buffers are staged through host memory.
+
+`RoundBackend` is the seam the tests use: the product backend is the engine (C ABI), the CPU tests substitute a small
+deterministic stand-in to exercise the sharding arithmetic and the collectives without a GPU.
+"""
+from typing import List, Optional, Tuple
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+def shard_bounds(n: int, world: int, rank: int) -> Tuple[int, int]:
+    """Contiguous, balanced shard [lo, hi) of n items; every rank computes the same partition."""
+    base, rem = divmod(n, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+class EngineBackend:
+    """The product backend: kb_round_* of the C ABI on this rank's GPU."""
+
+    def __init__(self, engine, device: torch.device):
+        self.e = engine
+        self.device = device
+        self.delta_len = engine.round_delta_doubles()
+
+    def begin(self, action):
+        return self.e.round_begin(action)
+
+    def candidates(self, m0, m1, keys: torch.Tensor):
+        self.e.round_candidates(m0, m1, keys.data_ptr())
+
+    def commit(self, all_keys: torch.Tensor, r0, r1, delta: torch.Tensor):
+        self.e.round_commit(all_keys.data_ptr(), r0, r1, delta.data_ptr())
+
+    def apply(self, delta: torch.Tensor):
+        self.e.round_apply(delta.data_ptr())
+
+    def decisions(self):
+        return self.e.round_decisions()
+
+
+class ShardedCycle:
+    """Runs allocate (+ backfill) with the window's matrix rows sharded across ranks."""
+
+    def __init__(self, conf, snap, device: int = 0, window: int = 0, topk: int = 0, backend=None,
+                 buffer_device: Optional[torch.device] = None, actions=("allocate", "backfill")):
+        self.rank = dist.get_rank() if dist.is_initialized() else 0
+        self.world = dist.get_world_size() if dist.is_initialized() else 1
+        self.actions = list(actions)
+        if backend is None:
+            from .engine import Engine
+            self.engine = Engine(conf, device=device, window=window, topk=topk)
+            self.engine.load(snap)
+            dev = torch.device("cuda", device)
+            backend = EngineBackend(self.engine, dev)
+            buffer_device = dev
+        else:
+            self.engine = getattr(backend, "e", None)
+        self.backend = backend
+        self.buf_dev = buffer_device or torch.device("cpu")
+        # collectives on device buffers only with a device-capable backend (RCCL); otherwise stage through host memory
+        self.stage_host = (not dist.is_initialized()) or dist.get_backend() != "nccl"
+        self.delta = torch.zeros(backend.delta_len, dtype=torch.float64, device=self.buf_dev)
+        self.rounds = 0
+
+    # ---- collectives
+    def _all_gather_keys(self, local: torch.Tensor, chunk: int, L: int) -> torch.Tensor:
+        full = torch.empty((chunk * self.world, L), dtype=torch.int64, device=local.device)
+        if self.world == 1:
+            full.copy_(local)
+            return full
+        if self.stage_host and local.device.type != "cpu":
+            h_local = local.cpu()
+            h_full = torch.empty((chunk * self.world, L), dtype=torch.int64)
+            dist.all_gather_into_tensor(h_full, h_local)
+            full.copy_(h_full)
+        else:
+            dist.all_gather_into_tensor(full, local)
+        return full
+
+    def _all_reduce_delta(self):
+        if self.world == 1:
+            return
+        if self.stage_host and self.delta.device.type != "cpu":
+            h = self.delta.cpu()
+            dist.all_reduce(h, op=dist.ReduceOp.SUM)
+            self.delta.copy_(h)
+        else:
+            dist.all_reduce(self.delta, op=dist.ReduceOp.SUM)
+
+    # ---- one action
+    def run_action(self, action: int) -> np.ndarray:
+        b = self.backend
+        while True:
+            n_rows, n_mrows, L = b.begin(action)
+            if n_rows == 0:
+                break
+            # equal-sized shards of the matrix rows (padded so all_gather_into_tensor applies); the sorted candidate
+            # lists are 0-terminated, padding rows stay 0
+            chunk = (n_mrows + self.world - 1) // self.world
+            m0 = min(self.rank * chunk, n_mrows)
+            m1 = min(m0 + chunk, n_mrows)
+            local = torch.zeros((chunk, L), dtype=torch.int64, device=self.buf_dev)
+            b.candidates(m0, m1, local)
+            table = self._all_gather_keys(local, chunk, L)
+            # the gathered table is [world*chunk][L]; matrix row m lives at row m because shards are contiguous and equal
+            r0, r1 = shard_bounds(n_rows, self.world, self.rank)
+            b.commit(table, r0, r1, self.delta)
+            self._all_reduce_delta()
+            b.apply(self.delta)
+            self.rounds += 1
+        return b.decisions()
+
+    def step(self):
+        """One scheduling cycle from the pristine session state (bench step)."""
+        if self.engine is not None:
+            self.engine.reset()
+        out = []
+        for a in self.actions:
+            out.append(self.run_action({"allocate": 0, "backfill": 1}[a]))
+        return np.concatenate(out) if out else np.zeros((0, 3), np.uint32)

@@ -19,7 +19,7 @@ _LIB = None
 EXPORTS = ["kb_engine_create", "kb_engine_destroy", "kb_last_error", "kb_session_load", "kb_session_reset", "kb_run_allocate",
            "kb_run_backfill", "kb_eval_matrix", "kb_argmax_rows", "kb_bench_matrix", "kb_get_binds",
            "kb_get_task_state", "kb_get_node_state", "kb_get_shares", "kb_get_stats", "kb_round_begin",
-           "kb_round_candidates", "kb_round_commit", "kb_round_apply", "kb_round_topk", "kb_round_delta_doubles",
+           "kb_round_candidates", "kb_round_commit", "kb_round_apply", "kb_round_delta_doubles",
            "kb_round_decisions"]
 
 
@@ -62,11 +62,10 @@ def lib():
                                         C.POINTER(C.c_int64), C.POINTER(C.c_int32)]
         L.kb_get_shares.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]
         L.kb_get_stats.argtypes = [vp, C.POINTER(abi.Stats)]
-        L.kb_round_begin.argtypes = [vp, C.c_uint32, C.POINTER(C.c_uint32)]
+        L.kb_round_begin.argtypes = [vp, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
         L.kb_round_candidates.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint64]
         L.kb_round_commit.argtypes = [vp, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint64]
         L.kb_round_apply.argtypes = [vp, C.c_uint64, C.POINTER(C.c_uint32)]
-        L.kb_round_topk.argtypes = [vp, C.POINTER(C.c_uint32)]
         L.kb_round_delta_doubles.argtypes = [vp, C.POINTER(C.c_uint64)]
         L.kb_round_decisions.argtypes = [vp, C.POINTER(abi.Decision), C.c_uint64, C.POINTER(C.c_uint64)]
         _LIB = L
@@ -181,3 +180,32 @@ class Engine:
         st = abi.Stats()
         self._ck(self.L.kb_get_stats(self.h, C.byref(st)))
         return st.as_dict()
+
+    # ---- round-granular API (task-row sharding across GPUs; see kube-batch_amd/dist.py)
+    def round_begin(self, action: int):
+        n, m, l = C.c_uint32(), C.c_uint32(), C.c_uint32()
+        self._ck(self.L.kb_round_begin(self.h, action, C.byref(n), C.byref(m), C.byref(l)))
+        return n.value, m.value, l.value
+
+    def round_candidates(self, mrow0: int, mrow1: int, dev_keys_ptr: int):
+        self._ck(self.L.kb_round_candidates(self.h, mrow0, mrow1, dev_keys_ptr))
+
+    def round_commit(self, dev_all_keys_ptr: int, own_row0: int, own_row1: int, dev_delta_ptr: int):
+        self._ck(self.L.kb_round_commit(self.h, dev_all_keys_ptr, own_row0, own_row1, dev_delta_ptr))
+
+    def round_apply(self, dev_delta_ptr: int):
+        done = C.c_uint32()
+        self._ck(self.L.kb_round_apply(self.h, dev_delta_ptr, C.byref(done)))
+
+    def round_delta_doubles(self) -> int:
+        n = C.c_uint64()
+        self._ck(self.L.kb_round_delta_doubles(self.h, C.byref(n)))
+        return n.value
+
+    def round_decisions(self):
+        cap = max(int(self.snap.n_tasks), 1)
+        arr = (abi.Decision * cap)()
+        n = C.c_uint64()
+        self._ck(self.L.kb_round_decisions(self.h, arr, cap, C.byref(n)))
+        a = np.frombuffer(arr, dtype=np.uint32).reshape(cap, 4)[: n.value]
+        return a[:, :3].copy()
