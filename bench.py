@@ -149,7 +149,7 @@ def main():
     out = {
         "metric": "pod-node scoring evals/sec + binds/sec, 100k tasks x 10k nodes snapshot",
         "value": value, "unit": "evals/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": elapsed * 1e3 / args.steps, "higher_is_better": True, "scaling": "weak",
+        "ms_per_step": elapsed * 1e3 / args.steps, "higher_is_better": True, "scaling": "strong",
         "vs_baseline": None, "dtype": "f64+i64", "data": "synthetic",
         "config": {"workload": f"BASELINE configs[{args.config - 1}]: {snap.n_tasks} tasks x {snap.n_nodes} nodes, "
                                f"{snap.n_jobs} gang jobs, {snap.n_queues} queues, R={R}, allocate+backfill, "

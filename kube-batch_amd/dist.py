@@ -91,6 +91,8 @@ class ShardedCycle:
             full.copy_(h_full)
         else:
             dist.all_gather_into_tensor(full, local)
+            if full.device.type == "cuda":
+                torch.cuda.current_stream().synchronize()   # the engine's kernels run on their own stream
         return full
 
     def _all_reduce_delta(self):
@@ -102,6 +104,8 @@ class ShardedCycle:
             self.delta.copy_(h)
         else:
             dist.all_reduce(self.delta, op=dist.ReduceOp.SUM)
+            if self.delta.device.type == "cuda":
+                torch.cuda.current_stream().synchronize()
 
     # ---- one action
     def run_action(self, action: int) -> np.ndarray:
