@@ -8,7 +8,9 @@
 #include <stdint.h>
 
 #define KB_NODE_PAD 2048u   // NP/8 node chunks split evenly over 256 threads (K3), 16-byte loads never straddle a row
+#ifndef KB_K5_THREADS
 #define KB_K5_THREADS 512
+#endif
 #define KB_MAX_TOPK 32
 
 // arg-max key: (0x40000000 + score + 1) << 32 | (0xFFFFFFFF - node).  0 = no feasible node.  max() over keys = highest
@@ -49,6 +51,7 @@ struct KbDev {
   uint8_t *t_counted;             // [T] task's Resreq is part of drf/proportion "allocated" (AllocatedStatus at open, or placed in-session)
   // static predicates
   const uint8_t *compat;          // bit (tc*n_nc + nc); nullptr => all compatible
+  const uint32_t *crows;          // the same table as word-aligned rows [n_tc][8] (bit nc of row tc), nullptr if n_nc > 256 or no table
   uint32_t n_nc;
   // policy
   int wL, wM, wB;                 // nodeorder weights (least, most, balanced); node/pod affinity contribute 0
@@ -69,7 +72,7 @@ struct KbRowDesc {          // 56 bytes
   uint32_t task, active, resmask, cls;
   uint16_t slot;           // index of the row's shape among the mrows
   uint16_t flags;          // bit 0: Resreq cpu/memory == InitResreq cpu/memory (no init container raised them)
-  uint32_t pad;
+  uint32_t crow;           // the task class's row of the static-predicate table (bit nc), valid when n_node_classes <= 32
 };
 
 struct KbRound {

@@ -102,15 +102,16 @@ struct kb_engine {
 
   // session buffers
   DevBuf b_idle, b_rel, b_nzc, b_nzm, b_podcnt, b_acpu, b_amem, b_maxpods, b_ncls, b_nmask, b_invac, b_invam;
+  uint64_t stage_hits = 0, stage_misses = 0;   // commit kernel: clean winners whose state was staged by the loader / fetched synchronously
   uint32_t eff_window = 0;   // window actually used for this session (bounded by the commit kernel's LDS budget)
-  DevBuf b_tinit, b_tres, b_tnzc, b_tnzm, b_tcls, b_tactive, b_tresmask, b_tjob, b_tstatus, b_tnode, b_tbind, b_tcounted, b_compat;
+  DevBuf b_tinit, b_tres, b_tnzc, b_tnzm, b_tcls, b_tactive, b_tresmask, b_tjob, b_tstatus, b_tnode, b_tbind, b_tcounted, b_compat, b_crows;
   DevBuf p_idle, p_rel, p_nzc, p_nzm, p_podcnt, p_tstatus, p_tnode, p_tcounted;   // pristine copies for kb_session_reset
   DevBuf b_jbegin, b_jmin, b_jqueue, b_total, b_deserved, b_desmask, b_jalloc, b_jshare, b_qalloc, b_qshare, b_jready;
   uint32_t total_mask = 0;
   // round buffers
   DevBuf b_desc, b_trace;
   bool trace_on = false;
-  std::vector<double> trace_acc = std::vector<double>(2 * 4 * 12, 0.0);
+  std::vector<double> trace_acc = std::vector<double>(3 * 4 * 12, 0.0);
   DevBuf b_rows, b_slot, b_mrows, b_same, b_score, b_maskw, b_keys, b_dec, b_result;
   uint32_t win_cap = 0, mat_cap = 0;
   size_t keys_cap = 0;
@@ -391,24 +392,29 @@ void round_collect(kb_engine *e, const RoundCtx &c, bool had_candidates, uint32_
   e->stats.commit_ms += ms;
   n_done = e->h_result[0];
   reason = e->h_result[1];
-  if (e->trace_on) {   // KB_K5_TRACE=1 (and make TRACE=1): per-phase shader-clock deltas of the commit kernel, first 512 rows of every round
-    std::vector<unsigned long long> tr(2 * 512 * 10);
+  if (e->trace_on) {   // KB_K5_TRACE=1 (and make TRACE=1): per role (eval thread 0, loader, candidate wave), first 512 rows of every round
+    std::vector<unsigned long long> tr(3 * 512 * 8);
     HIP_OK(hipMemcpy(tr.data(), e->b_trace.p, sizeof(unsigned long long) * tr.size(), hipMemcpyDeviceToHost));
     uint32_t m = std::min<uint32_t>(n_done, 512);
-    for (int who = 0; who < 2; who++)
+    for (int role = 0; role < 3; role++)
       for (uint32_t i = 0; i + 1 < m; i++) {
-        const unsigned long long *a = &tr[((size_t)who * 512 + i) * 10], *nx = &tr[((size_t)who * 512 + i + 1) * 10];
-        if (!a[8] || !nx[0]) continue;
-        int cls = (int)(a[9] & 3);
-        double *acc = &e->trace_acc[((size_t)who * 4 + cls) * 12];
-        for (int k = 0; k < 8; k++) acc[k] += (double)(a[k + 1] - a[k]);
-        acc[8] += (double)(nx[0] - a[8]);
-        acc[9] += (double)(nx[0] - a[0]);
+        const unsigned long long *a = &tr[((size_t)role * 512 + i) * 8], *nx = &tr[((size_t)role * 512 + i + 1) * 8];
+        const unsigned long long *c0 = &tr[((size_t)2 * 512 + i) * 8];
+        if (!a[4] || !nx[0] || !c0[4]) continue;
+        int cls = (int)(c0[5] & 3);   // classify rows by the candidate wave's view: bit0 clean wins, bit1 same shape
+        double *acc = &e->trace_acc[((size_t)role * 4 + cls) * 12];
+        acc[0] += (double)(a[1] - a[0]);      // phase-1 work
+        acc[1] += (double)(a[2] - a[1]);      // wait at barrier 1
+        acc[2] += (double)(a[3] - a[2]);      // phase-2 work
+        acc[3] += (double)(a[4] - a[3]);      // wait at barrier 2
+        acc[4] += (double)(nx[0] - a[4]);     // loop tail
+        acc[5] += (double)(nx[0] - a[0]);     // row total
         acc[10] += 1.0;
-        acc[11] += (double)(a[9] >> 8);
       }
   }
   e->stats.row_fallbacks += e->h_result[3];
+  e->stage_hits += e->h_result[5];
+  e->stage_misses += e->h_result[6];
   e->stats.rounds += 1;
   e->round_no += 1;
 }
@@ -616,7 +622,7 @@ int kb_engine_create(const kb_config *cfg, kb_engine **out) {
     HIP_OK(hipHostMalloc((void **)&eng->h_result, sizeof(uint32_t) * 8, hipHostMallocDefault));
     eng->b_result.alloc(sizeof(uint32_t) * 8);
     if (const char *tr = getenv("KB_K5_TRACE")) {
-      if (tr[0] == '1') { eng->trace_on = true; eng->b_trace.alloc(sizeof(unsigned long long) * 2 * 512 * 10); }
+      if (tr[0] == '1') { eng->trace_on = true; eng->b_trace.alloc(sizeof(unsigned long long) * 3 * 512 * 8); }
     }
     e = eng.release();
   });
@@ -626,17 +632,16 @@ int kb_engine_create(const kb_config *cfg, kb_engine **out) {
 
 void kb_engine_destroy(kb_engine *e) {
   if (!e) return;
+  if (getenv("KB_K5_STATS")) fprintf(stderr, "[kb K5] staged-state hits %llu, misses %llu\n", (unsigned long long)e->stage_hits, (unsigned long long)e->stage_misses);
   if (e->trace_on) {
-    static const char *names[10] = {"top:prefetch-issue", "dirty-eval", "candidate", "wave-reduce", "barrier1", "best", "commit", "barrier2", "tail", "TOTAL"};
+    static const char *roles[3] = {"eval thread 0", "loader wave", "candidate wave"};
     static const char *cls[4] = {"dirty wins, new shape", "clean wins, new shape", "dirty wins, same shape", "clean wins, same shape"};
-    for (int who = 0; who < 2; who++)
-      for (int c = 0; c < 4; c++) {
-        const double *acc = &e->trace_acc[((size_t)who * 4 + c) * 12];
+    for (int c = 0; c < 4; c++)
+      for (int role = 0; role < 3; role++) {
+        const double *acc = &e->trace_acc[((size_t)role * 4 + c) * 12];
         if (acc[10] < 1) continue;
-        fprintf(stderr, "[kb K5 trace] %s | %s | %.0f rows; mean shader clocks:", who ? "cand-wave lane0" : "thread 0", cls[c], acc[10]);
-        for (int k = 0; k < 10; k++) fprintf(stderr, " %s=%.0f", names[k], acc[k] / acc[10]);
-        fprintf(stderr, " [commit: wait-for-node-state+kind=%.0f]", acc[11] / acc[10]);
-        fprintf(stderr, "\n");
+        fprintf(stderr, "[kb K5 trace] %-22s | %-14s | %6.0f rows | phase1 %5.0f  wait-b1 %5.0f  phase2 %5.0f  wait-b2 %5.0f  tail %4.0f | row %5.0f clocks\n",
+                cls[c], roles[role], acc[10], acc[0] / acc[10], acc[1] / acc[10], acc[2] / acc[10], acc[3] / acc[10], acc[4] / acc[10], acc[5] / acc[10]);
       }
   }
   (void)hipSetDevice(e->device);
@@ -857,6 +862,18 @@ int kb_session_load(kb_engine *e, const kb_snapshot *sn) {
         if (ncls[n] >= sn->n_node_classes) throw EngineError(KB_E_INVALID, "node class out of range");
       upload(e->b_compat, sn->class_compat, nb, s);
       d.compat = e->b_compat.as<uint8_t>();
+      d.crows = nullptr;
+      if (sn->n_node_classes <= 256) {   // word-aligned rows for the commit kernel (one 32-byte fetch per task class)
+        std::vector<uint32_t> rows((size_t)sn->n_task_classes * 8, 0u);
+        for (uint32_t tc = 0; tc < sn->n_task_classes; tc++)
+          for (uint32_t nc = 0; nc < sn->n_node_classes; nc++) {
+            size_t bit = (size_t)tc * sn->n_node_classes + nc;
+            if ((sn->class_compat[bit >> 3] >> (bit & 7)) & 1) rows[(size_t)tc * 8 + (nc >> 5)] |= 1u << (nc & 31);
+          }
+        upload(e->b_crows, rows.data(), rows.size(), s);
+        HIP_OK(hipStreamSynchronize(s));
+        d.crows = e->b_crows.as<uint32_t>();
+      }
     }
     upload(e->b_jbegin, hs.job_begin.data(), J + 1, s);
     upload(e->b_jmin, hs.job_min.data(), J, s);

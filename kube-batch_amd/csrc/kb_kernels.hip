@@ -93,7 +93,10 @@ __device__ __forceinline__ int div10(long long req, long long cap, double inv_ca
 }
 
 // One (task,node) evaluation.  Returns 0 if infeasible, else 0x10000 | score.
-__device__ __forceinline__ uint32_t eval_pair(const KbDev &d, const TaskVals &t, const NodeVals &n, uint32_t node, int fit_mode) {
+// class_row: nullptr -> look the class pair up in the global bit table; otherwise the task class's row of the table
+// (bit nc), e.g. staged in LDS by the commit kernel so that no global load sits on its critical path.
+__device__ __forceinline__ uint32_t eval_pair(const KbDev &d, const TaskVals &t, const NodeVals &n, uint32_t node, int fit_mode,
+                                              const uint32_t *class_row = nullptr) {
   if (!n.valid) return 0;
   bool ok = true;
   if (fit_mode) {   // allocate.go:81: !InitResreq.LessEqual(Idle) && !InitResreq.LessEqual(Releasing) -> fail
@@ -114,7 +117,9 @@ __device__ __forceinline__ uint32_t eval_pair(const KbDev &d, const TaskVals &t,
   }
   if (d.pred_enabled) {
     ok = ok && n.slots;
-    if (d.compat) {
+    if (class_row) {
+      ok = ok && ((class_row[n.cls >> 5] >> (n.cls & 31)) & 1u);
+    } else if (d.compat) {
       uint32_t bit = t.cls * d.n_nc + n.cls;
       ok = ok && ((d.compat[bit >> 3] >> (bit & 7)) & 1);
     }
@@ -348,7 +353,7 @@ __global__ void __launch_bounds__(256) k_gather(KbDev d, KbRound r) {
   k.task = t; k.active = d.t_active[t]; k.resmask = d.t_resmask[t]; k.cls = d.t_cls[t];
   k.slot = (uint16_t)r.shape_slot[i];
   k.flags = (d.t_res[t] == k.init0 && d.t_res[(size_t)d.T + t] == k.init1) ? 1 : 0;
-  k.pad = 0;
+  k.crow = d.crows ? d.crows[(size_t)k.cls * 8] : 0xFFFFFFFFu;
   r.desc[i] = k;
 }
 
@@ -368,15 +373,21 @@ __global__ void __launch_bounds__(256) k_gather(KbDev d, KbRound r) {
 #define K5F_NZM 9
 #define K5_NF8 10
 #define K5_WAVES (KB_K5_THREADS / 64)
-#define K5_EVAL (KB_K5_THREADS - 64)                                   // threads that own dirty slots (all but the candidate wave)
+#define K5_EVAL (KB_K5_THREADS - 128)                                  // threads that own dirty slots (all but the loader and candidate waves)
 #define K5_SPT ((KB_K5_MAX_WINDOW + K5_EVAL - 1) / K5_EVAL)
 
 struct K5Hdr {
-  unsigned long long red[K5_WAVES];
+  unsigned long long best[2];       // cross-wave max of the row's keys (ds_max_u64), double-buffered by row parity
   unsigned long long cand;          // \  one 16-byte read after barrier 1
   uint32_t exhausted, pad0;         // /
   uint32_t last_slot, stop;         //    one 8-byte read after barrier 2
   uint32_t refills, rescans;
+  uint32_t win_base[2];             // candidate window of the next row (written by the loader wave)
+  uint32_t cs_tag[2];               // staged clean-node states: node ids (0xFFFFFFFF = empty)
+  unsigned long long win[2][64];
+  unsigned long long cs8[2][16];    // staged 8-byte fields (index = field id), written by the loader wave one row ahead
+  uint32_t cs4[2][4];               // cls, maxpods, podcnt
+  unsigned long long red[K5_WAVES]; // live-rescan path only
 };
 
 __host__ __device__ inline size_t k5_smem_bytes(uint32_t cap, uint32_t NP) {
@@ -455,33 +466,477 @@ __device__ __forceinline__ void k5_commit_globals(const KbDev &d, const KbRound 
 // instruction (lane k reads field k from its own array) and a clean winner's slot is initialised by the same lanes with
 // ONE LDS store; two workgroup barriers per task.
 // ------------------------------------------------------------------------------------------------------------
+// per-lane source arrays of the one-instruction node-state fetch: fld < 10 -> 8-byte field fld; 10..12 -> cls, maxpods, podcnt
+__device__ __forceinline__ void k5_field_ptrs(const KbDev &d, uint32_t fld, const unsigned long long *&g8, const uint32_t *&g4) {
+  g8 = nullptr; g4 = nullptr;
+  switch (fld) {
+    case K5F_IDLE0: g8 = reinterpret_cast<const unsigned long long *>(d.idle); break;
+    case K5F_IDLE1: g8 = reinterpret_cast<const unsigned long long *>(d.idle + d.NP); break;
+    case K5F_REL0: g8 = reinterpret_cast<const unsigned long long *>(d.rel); break;
+    case K5F_REL1: g8 = reinterpret_cast<const unsigned long long *>(d.rel + d.NP); break;
+    case K5F_INVAC: g8 = reinterpret_cast<const unsigned long long *>(d.inv_acpu); break;
+    case K5F_INVAM: g8 = reinterpret_cast<const unsigned long long *>(d.inv_amem); break;
+    case K5F_AC: g8 = reinterpret_cast<const unsigned long long *>(d.acpu); break;
+    case K5F_AM: g8 = reinterpret_cast<const unsigned long long *>(d.amem); break;
+    case K5F_NZC: g8 = reinterpret_cast<const unsigned long long *>(d.nzc); break;
+    case K5F_NZM: g8 = reinterpret_cast<const unsigned long long *>(d.nzm); break;
+    case 10: g4 = d.ncls; break;
+    case 11: g4 = reinterpret_cast<const uint32_t *>(d.maxpods); break;
+    case 12: g4 = reinterpret_cast<const uint32_t *>(d.podcnt); break;
+    default: break;
+  }
+}
+
+// Shared view of the commit kernel's LDS (see k5_smem_bytes)
+struct K5Mem {
+  unsigned long long *tab;
+  uint32_t *t_cls, *t_node, *cursor, *bitmap;
+  int *t_left;
+  KbRowDesc *desc;
+  K5Hdr *H;
+  uint32_t cap;
+};
+
+// What every role reads after barrier 1 (identical values in every wave): the row's best key, the clean candidate, and
+// whether the candidate list ran dry while still full (live-rescan protocol, two extra barriers for everybody).
+struct K5Pick {
+  unsigned long long best, cand;
+  uint32_t exhausted;
+};
+__device__ __forceinline__ K5Pick k5_pick(const K5Mem M, uint32_t par) {
+  const uint4 h = *reinterpret_cast<const uint4 *>(&M.H->cand);
+  K5Pick p;
+  p.best = M.H->best[par];
+  p.cand = ((unsigned long long)h.y << 32) | h.x;
+  p.exhausted = h.z;
+  return p;
+}
+
+// Live rescan of every CLEAN node (the candidate list ran out while still full; cannot happen with L > window).  All
+// waves take part: two barriers.  Returns the best clean key; H.cand is replaced by it.
+__device__ __forceinline__ unsigned long long k5_rescan(const KbDev &d, const KbRound &r, const K5Mem M, const KbRowDesc &cur) {
+  const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  TaskVals tv;
+  tv.init0 = cur.init0; tv.init1 = cur.init1; tv.nzc = cur.nzc; tv.nzm = cur.nzm;
+  tv.cls = cur.cls; tv.active = cur.active; tv.task = cur.task; tv.pad = 0;
+  unsigned long long k2 = 0ull;
+  for (uint32_t n = tid; n < d.N; n += KB_K5_THREADS) {
+    if (bit_test(M.bitmap, n)) continue;
+    NodeVals nv = load_node(d, n);
+    uint32_t res = eval_pair(d, tv, nv, n, r.fit_mode);
+    if (res) { unsigned long long k3 = KB_KEY(res & 0xFFFFu, n); k2 = k3 > k2 ? k3 : k2; }
+  }
+  k2 = wave_max_key(k2);
+  if (lane == 0) M.H->red[wave] = k2;
+  __syncthreads();
+  unsigned long long bclean = oct_max_key(M.H->red[lane & (K5_WAVES - 1)]);
+  if (tid == 0) { M.H->rescans++; M.H->cand = bclean; }
+  __syncthreads();
+  return bclean;
+}
+
+#ifdef KB_K5_TRACE
+#define K5R_DECL(role) const bool trc = r.trace != nullptr && (threadIdx.x & 63) == 0 && ((role) != 0 || threadIdx.x == 0); unsigned long long tr0 = 0, tr1 = 0, tr2 = 0, tr3 = 0;
+#define K5R_T0() do { if (trc) tr0 = __builtin_readcyclecounter(); } while (0)
+#define K5R_T1() do { if (trc) tr1 = __builtin_readcyclecounter(); } while (0)
+#define K5R_T2() do { if (trc) tr2 = __builtin_readcyclecounter(); } while (0)
+#define K5R_T3() do { if (trc) tr3 = __builtin_readcyclecounter(); } while (0)
+#define K5R_END(role, i, cw, same) do { if (trc && (i) < 512) { unsigned long long *dst = r.trace + ((size_t)(role) * 512 + (i)) * 8; dst[0] = tr0; dst[1] = tr1; dst[2] = tr2; dst[3] = tr3; dst[4] = __builtin_readcyclecounter(); dst[5] = ((cw) ? 1ull : 0ull) | ((same) ? 2ull : 0ull); } } while (0)
+#else
+#define K5R_DECL(role)
+#define K5R_T0() do { } while (0)
+#define K5R_T1() do { } while (0)
+#define K5R_T2() do { } while (0)
+#define K5R_T3() do { } while (0)
+#define K5R_END(role, i, cw, same) do { } while (0)
+#endif
+
+// ---- role: evaluation waves (own the dirty slots) --------------------------------------------------------------
+__device__ __forceinline__ void k5_eval_role(const KbDev &d, const KbRound &r, const K5Mem M, uint32_t &nd_out, uint32_t &n_done, uint32_t &reason) {
+  const uint32_t tid = threadIdx.x, lane = tid & 63, cap = M.cap;
+  K5Hdr &H = *M.H;
+  const bool use_crow = d.pred_enabled && d.crows != nullptr && d.n_nc <= 32;
+  unsigned long long ck[K5_SPT];     // cached keys of the dirty slots this thread owns, valid for shape `prev_shape`
+#pragma unroll
+  for (int j = 0; j < K5_SPT; j++) ck[j] = 0ull;
+  unsigned long long wmax = 0ull;    // this wave's max over ck[], valid while no lane of the wave re-evaluates
+  uint32_t prev_shape = 0xFFFFFFFFu, nd = 0, last_slot = 0xFFFFFFFFu;
+  K5R_DECL(0)
+  for (uint32_t i = 0; i < r.n_rows; i++) {
+    K5R_T0();
+    const uint32_t par = i & 1;
+    const KbRowDesc &cur = M.desc[i];
+    const uint32_t shape = cur.slot;
+    const bool same = shape == prev_shape;
+    prev_shape = shape;
+    // ---- phase 1: keys of my dirty slots (re-evaluated only when the shape changed or the slot was just committed)
+    bool mine = false;
+#pragma unroll
+    for (int j = 0; j < K5_SPT; j++) {
+      uint32_t slot = tid + j * K5_EVAL;
+      mine = mine || (slot < nd && (!same || slot == last_slot));
+    }
+    if (__ballot(mine)) {
+      if (mine) {
+        TaskVals tv;
+        tv.init0 = cur.init0; tv.init1 = cur.init1; tv.nzc = cur.nzc; tv.nzm = cur.nzm;
+        tv.cls = cur.cls; tv.active = cur.active; tv.task = cur.task; tv.pad = 0;
+        const uint32_t *crow = use_crow ? &cur.crow : nullptr;
+#pragma unroll
+        for (int j = 0; j < K5_SPT; j++) {
+          uint32_t slot = tid + j * K5_EVAL;
+          if (slot < nd && (!same || slot == last_slot)) {
+            NodeVals nv = k5_slot_vals(M.tab, M.t_cls, M.t_left, cap, slot);
+            uint32_t node = M.t_node[slot];
+            uint32_t res = eval_pair(d, tv, nv, node, r.fit_mode, crow);
+            ck[j] = res ? KB_KEY(res & 0xFFFFu, node) : 0ull;
+          }
+        }
+      }
+      unsigned long long key = 0ull;
+#pragma unroll
+      for (int j = 0; j < K5_SPT; j++) key = ck[j] > key ? ck[j] : key;
+      wmax = wave_max_key(key);
+    }
+    if (lane == 0 && wmax) atomicMax(&H.best[par], wmax);
+    K5R_T1();
+    __syncthreads();
+    K5R_T2();
+    // ---- phase 2
+    K5Pick p = k5_pick(M, par);
+    if (tid == 0) H.best[par ^ 1] = 0ull;
+    if (p.exhausted) { unsigned long long bc = k5_rescan(d, r, M, cur); p.cand = bc; p.best = bc > p.best ? bc : p.best; }
+    if (p.best == 0ull) {
+      if (r.backfill) {   // backfill.go:50-66: no node passes the predicates -> the task simply stays Pending
+        if (tid == 0) *reinterpret_cast<uint2 *>(&r.dec[i]) = make_uint2(KB_NONE_U32, 0u);
+        __syncthreads();
+        n_done = i + 1;
+        continue;
+      }
+      n_done = i; reason = KB_REASON_NO_FEASIBLE;   // allocate.go:144-148: the job is abandoned; the host re-plans from here
+      break;
+    }
+    const bool clean_wins = p.best == p.cand;
+    if (!clean_wins) {
+      // a dirty node wins: its owner applies NodeInfo.AddTask (api/node_info.go:172-212) to the LDS copy
+#pragma unroll
+      for (int j = 0; j < K5_SPT; j++) {
+        uint32_t slot = tid + j * K5_EVAL;
+        if (slot < nd && ck[j] == p.best) {
+          const uint32_t n = KB_KEY_NODE(p.best);
+          // Resreq == InitResreq unless an init container raised it (rare): a scalar branch, NOT a select between an LDS
+          // and a global address (the compiler would turn that into flat loads with a full vmcnt+lgkmcnt drain)
+          double res0 = cur.init0, res1 = cur.init1;
+          asm volatile("" : "+v"(res0), "+v"(res1));   // materialise the LDS values here: no pointer phi -> no flat load
+          if (!(__builtin_amdgcn_readfirstlane((int)cur.flags) & 1)) { res0 = d.t_res[cur.task]; res1 = d.t_res[(size_t)d.T + cur.task]; }
+          uint32_t kind = 0;
+          if (!r.backfill) {   // allocate.go:160: InitResreq.LessEqual(node.Idle) ? Allocate : Pipeline
+            bool fi = le_eps(cur.init0, __longlong_as_double((long long)M.tab[K5F_IDLE0 * cap + slot]), EPS_CPU) &&
+                      le_eps(cur.init1, __longlong_as_double((long long)M.tab[K5F_IDLE1 * cap + slot]), EPS_MEM);
+            uint32_t a = cur.active >> 2, dd = 2;
+            while (a) {
+              if (a & 1u) fi = fi && le_eps(d.t_init[(size_t)dd * d.T + cur.task], d.idle[(size_t)dd * d.NP + n], EPS_SCALAR);
+              a >>= 1; dd++;
+            }
+            kind = fi ? 0u : 1u;
+          }
+          const uint32_t f0 = kind ? K5F_REL0 : K5F_IDLE0;
+          M.tab[(size_t)f0 * cap + slot] = (unsigned long long)__double_as_longlong(__longlong_as_double((long long)M.tab[(size_t)f0 * cap + slot]) - res0);
+          M.tab[(size_t)(f0 + 1) * cap + slot] = (unsigned long long)__double_as_longlong(__longlong_as_double((long long)M.tab[(size_t)(f0 + 1) * cap + slot]) - res1);
+          M.tab[(size_t)K5F_NZC * cap + slot] += (unsigned long long)cur.nzc;
+          M.tab[(size_t)K5F_NZM * cap + slot] += (unsigned long long)cur.nzm;
+          M.t_left[slot] -= 1;
+          *reinterpret_cast<uint2 *>(&H.last_slot) = make_uint2(slot, kind);
+          k5_commit_globals(d, r, cur, res0, res1, i, n, kind);
+        }
+      }
+    }
+    K5R_T3();
+    __syncthreads();
+    K5R_END(0, i, clean_wins, same);
+    if (clean_wins) nd++;
+    n_done = i + 1;
+    const uint2 h2 = *reinterpret_cast<const uint2 *>(&H.last_slot);
+    last_slot = h2.x;
+    if (h2.y) { reason = KB_REASON_PIPELINED; break; }
+  }
+  nd_out = nd;
+}
+
+// ---- role: loader wave (every global load of the loop, a full row ahead, landed in LDS staging) -----------------
+__device__ __forceinline__ void k5_load_role(const KbDev &d, const KbRound &r, const K5Mem M, uint32_t &nd_out, uint32_t &n_done, uint32_t &reason) {
+  const uint32_t lane = threadIdx.x & 63;
+  K5Hdr &H = *M.H;
+  // lane (g*16 + k) reads field k of one node with ONE load instruction per width: k < 10: 8-byte field k from its own
+  // array; k = 10..12: cls / maxpods / podcnt.  Two lane groups -> two nodes per instruction.
+  const uint32_t fld = lane & 15, grp = lane >> 4;
+  const unsigned long long *g8 = nullptr;
+  const uint32_t *g4 = nullptr;
+  if (grp < 2) k5_field_ptrs(d, fld, g8, g4);
+  unsigned long long pw_key = 0ull;   // candidate window being fetched, one entry per lane
+  uint32_t pw_base = 0;
+  unsigned long long ps8 = 0ull;      // node states being fetched: lane groups 0/1 -> staging slots 0/1
+  uint32_t ps4 = 0;
+  uint32_t ps_tag0 = 0xFFFFFFFFu, ps_tag1 = 0xFFFFFFFFu;   // nodes in flight for staging slot 0 / 1
+  uint32_t ls_tag0 = 0xFFFFFFFFu, ls_tag1 = 0xFFFFFFFFu;   // what the staging slots hold / will hold
+  uint32_t inv_node = 0xFFFFFFFFu, nd = 0;
+  if (r.n_rows > 1) pw_key = (lane < r.L) ? r.keys[(size_t)M.desc[1].slot * r.L + lane] : 0ull;
+  K5R_DECL(1)
+  for (uint32_t i = 0; i < r.n_rows; i++) {
+    K5R_T0();
+    const uint32_t par = i & 1;
+    // ---- phase 1: drop the copy of the node the previous row committed (it is dirty now), land the states requested in
+    //      the previous row's phase 2 (consumed by this row's commit)
+    if (inv_node != 0xFFFFFFFFu) {
+      if (ls_tag0 == inv_node) { ls_tag0 = 0xFFFFFFFFu; if (ps_tag0 == inv_node) ps_tag0 = 0xFFFFFFFFu; if (lane == 0) H.cs_tag[0] = 0xFFFFFFFFu; }
+      if (ls_tag1 == inv_node) { ls_tag1 = 0xFFFFFFFFu; if (ps_tag1 == inv_node) ps_tag1 = 0xFFFFFFFFu; if (lane == 0) H.cs_tag[1] = 0xFFFFFFFFu; }
+    }
+    if (ps_tag0 != 0xFFFFFFFFu || ps_tag1 != 0xFFFFFFFFu) {
+      const bool on = (grp == 0 && ps_tag0 != 0xFFFFFFFFu) || (grp == 1 && ps_tag1 != 0xFFFFFFFFu);
+      if (on && fld < K5_NF8) H.cs8[grp][fld] = ps8;
+      if (on && fld >= 10 && fld < 13) H.cs4[grp][fld - 10] = ps4;
+      if (lane == 0 && ps_tag0 != 0xFFFFFFFFu) H.cs_tag[0] = ps_tag0;
+      if (lane == 16 && ps_tag1 != 0xFFFFFFFFu) H.cs_tag[1] = ps_tag1;
+      ps_tag0 = 0xFFFFFFFFu; ps_tag1 = 0xFFFFFFFFu;
+    }
+    K5R_T1();
+    __syncthreads();
+    K5R_T2();
+    // ---- phase 2
+    K5Pick p = k5_pick(M, par);
+    // (a) hand the next row's candidate window (requested a row ago) to the candidate wave and stage the states of its
+    //     first two clean nodes: whichever of them survives this row's commit is the next row's clean candidate
+    if (i + 1 < r.n_rows) {
+      const uint32_t nshape = M.desc[i + 1].slot;
+      H.win[par ^ 1][lane] = pw_key;
+      if (lane == 0) H.win_base[par ^ 1] = pw_base;
+      const uint32_t c0 = M.cursor[nshape];
+      const bool nz = pw_key != 0ull;
+      unsigned long long cb = __ballot(nz && (pw_base + lane) >= c0 && !bit_test(M.bitmap, KB_KEY_NODE(pw_key)));
+      uint32_t m1 = 0xFFFFFFFFu, m2 = 0xFFFFFFFFu;
+      if (cb) {
+        int f1 = __ffsll((unsigned long long)cb) - 1;
+        m1 = 0xFFFFFFFFu - (uint32_t)__builtin_amdgcn_readlane((int)(pw_key & 0xFFFFFFFFull), f1);
+        unsigned long long cb2 = cb & (cb - 1);
+        if (cb2) {
+          int f2 = __ffsll((unsigned long long)cb2) - 1;
+          m2 = 0xFFFFFFFFu - (uint32_t)__builtin_amdgcn_readlane((int)(pw_key & 0xFFFFFFFFull), f2);
+        }
+      }
+      const bool have1 = m1 == 0xFFFFFFFFu || ls_tag0 == m1 || ls_tag1 == m1;
+      const bool have2 = m2 == 0xFFFFFFFFu || ls_tag0 == m2 || ls_tag1 == m2;
+      if (!have1) {
+        if (ls_tag0 != m2) { ls_tag0 = m1; ps_tag0 = m1; } else { ls_tag1 = m1; ps_tag1 = m1; }
+      }
+      if (!have2) {
+        if (ls_tag0 != m1) { ls_tag0 = m2; ps_tag0 = m2; } else { ls_tag1 = m2; ps_tag1 = m2; }
+      }
+      const uint32_t want = grp == 0 ? ps_tag0 : (grp == 1 ? ps_tag1 : 0xFFFFFFFFu);
+      if (want != 0xFFFFFFFFu) {
+        if (g8) ps8 = g8[want];
+        if (g4) ps4 = g4[want];
+      }
+    }
+    // (b) request the window of the row after next
+    if (i + 2 < r.n_rows) {
+      const uint32_t n2shape = M.desc[i + 2].slot;
+      pw_base = M.cursor[n2shape];   // may lag: stale entries are filtered by the dirty bitmap when the window is used
+      uint32_t e = pw_base + lane;
+      pw_key = (e < r.L) ? r.keys[(size_t)n2shape * r.L + e] : 0ull;
+    }
+    if (p.exhausted) { unsigned long long bc = k5_rescan(d, r, M, M.desc[i]); p.cand = bc; p.best = bc > p.best ? bc : p.best; }
+    if (p.best == 0ull) {
+      if (r.backfill) { __syncthreads(); n_done = i + 1; inv_node = 0xFFFFFFFFu; continue; }
+      n_done = i; reason = KB_REASON_NO_FEASIBLE;
+      break;
+    }
+    const bool clean_wins = p.best == p.cand;
+    inv_node = clean_wins ? KB_KEY_NODE(p.best) : 0xFFFFFFFFu;
+    K5R_T3();
+    __syncthreads();
+    K5R_END(1, i, clean_wins, false);
+    if (clean_wins) nd++;
+    n_done = i + 1;
+    const uint2 h2 = *reinterpret_cast<const uint2 *>(&H.last_slot);
+    if (h2.y) { reason = KB_REASON_PIPELINED; break; }
+  }
+  nd_out = nd;
+}
+
+// ---- role: candidate wave (walks the candidate lists, commits clean winners) -------------------------------------
+__device__ __forceinline__ void k5_cand_role(const KbDev &d, const KbRound &r, const K5Mem M, uint32_t &nd_out, uint32_t &n_done, uint32_t &reason) {
+  const uint32_t lane = threadIdx.x & 63, cap = M.cap;
+  K5Hdr &H = *M.H;
+  const unsigned long long *g8 = nullptr;   // synchronous miss path: lanes 0..12 fetch the node's fields
+  const uint32_t *g4 = nullptr;
+  if (lane < 16) k5_field_ptrs(d, lane, g8, g4);
+  // the current shape's window (keys per lane), mask of its clean lanes, mask of its empty lanes
+  unsigned long long wkey = 0ull, wb = 0ull, wzero = 0ull;
+  uint32_t wbase = 0, prev_shape = 0xFFFFFFFFu, nd = 0;
+  bool wvalid = false, prev_clean_win = false;
+  K5R_DECL(2)
+  for (uint32_t i = 0; i < r.n_rows; i++) {
+    K5R_T0();
+    const uint32_t par = i & 1;
+    const KbRowDesc &cur = M.desc[i];
+    const uint32_t shape = cur.slot;
+    const bool same_tr = shape == prev_shape;
+    (void)same_tr;
+    // ---- phase 1: first list entry whose node is not dirty.  Inside a run of rows with the same shape the only node
+    // that can have turned dirty since the previous row is the previous row's own clean winner, i.e. the lowest set bit
+    // of the clean mask: clear it instead of re-reading the window and re-testing the bitmap.
+    if (shape == prev_shape && wvalid) {
+      if (prev_clean_win) wb &= wb - 1;
+    } else {
+      wkey = H.win[par][lane];
+      wbase = H.win_base[par];
+      const uint32_t c0 = M.cursor[shape];
+      const bool nz = wkey != 0ull;
+      wb = __ballot(nz && (wbase + lane) >= c0 && !bit_test(M.bitmap, KB_KEY_NODE(wkey)));
+      wzero = __ballot(!nz);
+      wvalid = true;
+    }
+    prev_shape = shape;
+    unsigned long long cand = 0ull;
+    bool list_end = false;
+    uint32_t curs;
+    for (;;) {
+      if (wb) {
+        int first = __ffsll((unsigned long long)wb) - 1;
+        // lists are 0-terminated and sorted best-first, so the first clean entry is the best clean node
+        cand = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(wkey >> 32), first) << 32) |
+               (uint32_t)__builtin_amdgcn_readlane((int)(wkey & 0xFFFFFFFFull), first);
+        curs = wbase + first;
+        break;
+      }
+      curs = wbase;
+      if (wzero) { list_end = true; break; }            // ran past the last feasible node: no clean candidate exists
+      wbase += 64;
+      curs = wbase;
+      if (wbase >= r.L) break;                          // list exhausted while still full: live rescan
+      uint32_t e = wbase + lane;
+      wkey = (e < r.L) ? r.keys[(size_t)shape * r.L + e] : 0ull;
+      const bool nz = wkey != 0ull;
+      wb = __ballot(nz && !bit_test(M.bitmap, KB_KEY_NODE(wkey)));
+      wzero = __ballot(!nz);
+      if (lane == 0) H.refills++;
+    }
+    if (lane == 0) {
+      M.cursor[shape] = curs;
+      *reinterpret_cast<uint4 *>(&H.cand) = make_uint4((uint32_t)(cand & 0xFFFFFFFFull), (uint32_t)(cand >> 32), (!cand && !list_end) ? 1u : 0u, 0u);
+      if (cand) atomicMax(&H.best[par], cand);
+    }
+    K5R_T1();
+    __syncthreads();
+    K5R_T2();
+    // ---- phase 2
+    K5Pick p = k5_pick(M, par);
+    if (p.exhausted) { unsigned long long bc = k5_rescan(d, r, M, cur); p.cand = bc; p.best = bc > p.best ? bc : p.best; wvalid = false; }
+    if (p.best == 0ull) {
+      if (r.backfill) { __syncthreads(); n_done = i + 1; prev_clean_win = false; continue; }
+      n_done = i; reason = KB_REASON_NO_FEASIBLE;
+      break;
+    }
+    const bool clean_wins = p.best == p.cand;
+    if (clean_wins) {
+      // commit: NodeInfo.AddTask (api/node_info.go:172-212) turns the clean node into dirty slot `nd`.  Its pristine state
+      // was staged by the loader a row ahead (normal case) or is fetched synchronously.  Lanes 0..9 get the 8-byte
+      // fields, lanes 10..12 cls / maxpods / podcnt.
+      const uint32_t n = KB_KEY_NODE(p.best);
+      double res0 = cur.init0, res1 = cur.init1;   // scalar branch, not an LDS/global address select (see the eval role)
+      asm volatile("" : "+v"(res0), "+v"(res1));
+      if (!(__builtin_amdgcn_readfirstlane((int)cur.flags) & 1)) { res0 = d.t_res[cur.task]; res1 = d.t_res[(size_t)d.T + cur.task]; }
+      unsigned long long st8 = 0ull;
+      uint32_t st4 = 0;
+      const uint2 tags = *reinterpret_cast<const uint2 *>(&H.cs_tag[0]);
+      const int src = (tags.x == n) ? 0 : ((tags.y == n) ? 1 : 2);
+      if (lane == 0) { if (src < 2) H.refills += 1u << 16; else H.rescans += 1u << 16; }   // staging hits / misses (diagnostic)
+      if (src < 2) {
+        st8 = H.cs8[src][lane & 15];
+        st4 = H.cs4[src][(lane - 10) & 3];
+      } else {
+        if (g8) st8 = g8[n];
+        if (g4) st4 = g4[n];
+      }
+      double v = __longlong_as_double((long long)st8);
+      uint32_t kind = 0;
+      if (!r.backfill) {   // allocate.go:160: InitResreq.LessEqual(node.Idle) ? Allocate : Pipeline
+        bool ok = true;
+        if (lane == K5F_IDLE0) ok = le_eps(cur.init0, v, EPS_CPU);
+        if (lane == K5F_IDLE1) ok = le_eps(cur.init1, v, EPS_MEM);
+        if (lane == 63 && (cur.active >> 2)) {   // scalar dimensions (rare): compared against live global state
+          uint32_t a = cur.active >> 2, dd = 2;
+          while (a) {
+            if (a & 1u) ok = ok && le_eps(d.t_init[(size_t)dd * d.T + cur.task], d.idle[(size_t)dd * d.NP + n], EPS_SCALAR);
+            a >>= 1; dd++;
+          }
+        }
+        kind = __ballot(!ok) ? 1u : 0u;
+      }
+      // apply the task: Allocated -> Idle.Sub(Resreq); Pipelined -> Releasing.Sub(Resreq); pod joins ni.Tasks
+      const uint32_t f0 = kind ? K5F_REL0 : K5F_IDLE0;
+      if (lane == f0) v -= res0;
+      if (lane == f0 + 1) v -= res1;
+      unsigned long long out = (unsigned long long)__double_as_longlong(v);
+      if (lane == K5F_NZC) out = st8 + (unsigned long long)cur.nzc;
+      if (lane == K5F_NZM) out = st8 + (unsigned long long)cur.nzm;
+      if (lane >= K5F_INVAC && lane <= K5F_AM) out = st8;
+      if (lane < K5_NF8) M.tab[(size_t)lane * cap + nd] = out;
+      const int maxp = __builtin_amdgcn_readlane((int)st4, 11), pods = __builtin_amdgcn_readlane((int)st4, 12);
+      // t_cls, t_node, t_left are consecutive [cap] arrays: one store with a per-lane offset (no pointer table)
+      if (lane >= 10 && lane < 13) {
+        const uint32_t which = (lane == 10) ? 0u : ((lane == 12) ? 1u : 2u);
+        const uint32_t val = (lane == 10) ? st4 : ((lane == 12) ? n : (uint32_t)(maxp - pods - 1));
+        M.t_cls[(size_t)which * cap + nd] = val;
+      }
+      if (lane == 0) {
+        atomicOr(&M.bitmap[n >> 5], 1u << (n & 31));
+        *reinterpret_cast<uint2 *>(&H.last_slot) = make_uint2(nd, kind);
+        k5_commit_globals(d, r, cur, res0, res1, i, n, kind);
+      }
+    }
+    K5R_T3();
+    __syncthreads();
+    K5R_END(2, i, clean_wins, same_tr);
+    if (clean_wins) nd++;
+    prev_clean_win = clean_wins;
+    n_done = i + 1;
+    const uint2 h2 = *reinterpret_cast<const uint2 *>(&H.last_slot);
+    if (h2.y) { reason = KB_REASON_PIPELINED; break; }
+  }
+  nd_out = nd;
+}
+
 __global__ void __launch_bounds__(KB_K5_THREADS) k_commit(KbDev d, KbRound r) {
   extern __shared__ __align__(16) unsigned char k5_smem[];
-  const uint32_t cap = r.cap;
-  unsigned long long *tab = reinterpret_cast<unsigned long long *>(k5_smem);
-  uint32_t *t_cls = reinterpret_cast<uint32_t *>(tab + (size_t)K5_NF8 * cap);
-  uint32_t *t_node = t_cls + cap;
-  int *t_left = reinterpret_cast<int *>(t_node + cap);
-  uint32_t *cursor = reinterpret_cast<uint32_t *>(t_left + cap);
-  KbRowDesc *desc = reinterpret_cast<KbRowDesc *>(cursor + cap);
-  uint32_t *bitmap = reinterpret_cast<uint32_t *>(desc + cap);
-  K5Hdr &H = *reinterpret_cast<K5Hdr *>(bitmap + d.NP / 32);
+  K5Mem M;
+  M.cap = r.cap;
+  M.tab = reinterpret_cast<unsigned long long *>(k5_smem);
+  M.t_cls = reinterpret_cast<uint32_t *>(M.tab + (size_t)K5_NF8 * M.cap);
+  M.t_node = M.t_cls + M.cap;
+  M.t_left = reinterpret_cast<int *>(M.t_node + M.cap);
+  M.cursor = reinterpret_cast<uint32_t *>(M.t_left + M.cap);
+  M.desc = reinterpret_cast<KbRowDesc *>(M.cursor + M.cap);
+  M.bitmap = reinterpret_cast<uint32_t *>(M.desc + M.cap);
+  M.H = reinterpret_cast<K5Hdr *>(M.bitmap + d.NP / 32);
+  K5Hdr &H = *M.H;
+  const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, cap = M.cap;
 
-  const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const bool cand_wave = wave == K5_WAVES - 1;
-  for (uint32_t w = tid; w < d.NP / 32; w += KB_K5_THREADS) bitmap[w] = 0;
-  for (uint32_t w = tid; w < cap; w += KB_K5_THREADS) cursor[w] = 0;
+  for (uint32_t w = tid; w < d.NP / 32; w += KB_K5_THREADS) M.bitmap[w] = 0;
+  for (uint32_t w = tid; w < cap; w += KB_K5_THREADS) M.cursor[w] = 0;
   {   // stage the window's row descriptors (coalesced 8-byte copies)
     const unsigned long long *src = reinterpret_cast<const unsigned long long *>(r.desc);
-    unsigned long long *dst = reinterpret_cast<unsigned long long *>(desc);
+    unsigned long long *dst = reinterpret_cast<unsigned long long *>(M.desc);
     const uint32_t nq = r.n_rows * (uint32_t)(sizeof(KbRowDesc) / 8);
     for (uint32_t w = tid; w < nq; w += KB_K5_THREADS) dst[w] = src[w];
   }
-  if (tid == 0) { H.cand = 0; H.exhausted = 0; H.pad0 = 0; H.stop = 0; H.last_slot = 0xFFFFFFFFu; H.refills = 0; H.rescans = 0; }
+  if (tid == 0) {
+    H.best[0] = 0; H.best[1] = 0; H.cand = 0; H.exhausted = 0; H.pad0 = 0; H.stop = 0; H.last_slot = 0xFFFFFFFFu;
+    H.refills = 0; H.rescans = 0; H.win_base[0] = 0; H.win_base[1] = 0; H.cs_tag[0] = 0xFFFFFFFFu; H.cs_tag[1] = 0xFFFFFFFFu;
+  }
   {
-    // The loop below is latency-bound and this workgroup starts on a cold L2 (kernel boundary).  Touch every 128-byte
-    // line it can need later — node state arrays and the candidate lists — once, with all threads, so that the
-    // per-task loads hit the XCD's L2 instead of going out to HBM one at a time.
+    // The loop is latency-bound and this workgroup starts on a cold L2 (kernel boundary).  Touch every 128-byte line it
+    // can need later — node state arrays and the candidate lists — once, with all threads.
     unsigned long long acc = 0;
     const uint32_t lines = d.NP / 16;   // 16 x 8 bytes per line
     const unsigned long long *arrs[10] = {
@@ -501,289 +956,31 @@ __global__ void __launch_bounds__(KB_K5_THREADS) k_commit(KbDev d, KbRound r) {
     for (size_t l = tid; l < klines; l += KB_K5_THREADS) acc += r.keys[l * 16];
     if (acc == 0x123456789abcdefull) H.pad0 = 1;   // keep the loads alive
   }
-
-  // candidate wave, lanes 0..9: the 8-byte node field this lane fetches / initialises; lanes 10..12: cls, maxpods, podcnt
-  const unsigned long long *g8 = nullptr;
-  const uint32_t *g4 = nullptr;
-  if (cand_wave) {
-    switch (lane) {
-      case K5F_IDLE0: g8 = reinterpret_cast<const unsigned long long *>(d.idle); break;
-      case K5F_IDLE1: g8 = reinterpret_cast<const unsigned long long *>(d.idle + d.NP); break;
-      case K5F_REL0: g8 = reinterpret_cast<const unsigned long long *>(d.rel); break;
-      case K5F_REL1: g8 = reinterpret_cast<const unsigned long long *>(d.rel + d.NP); break;
-      case K5F_INVAC: g8 = reinterpret_cast<const unsigned long long *>(d.inv_acpu); break;
-      case K5F_INVAM: g8 = reinterpret_cast<const unsigned long long *>(d.inv_amem); break;
-      case K5F_AC: g8 = reinterpret_cast<const unsigned long long *>(d.acpu); break;
-      case K5F_AM: g8 = reinterpret_cast<const unsigned long long *>(d.amem); break;
-      case K5F_NZC: g8 = reinterpret_cast<const unsigned long long *>(d.nzc); break;
-      case K5F_NZM: g8 = reinterpret_cast<const unsigned long long *>(d.nzm); break;
-      case 10: g4 = d.ncls; break;
-      case 11: g4 = reinterpret_cast<const uint32_t *>(d.maxpods); break;
-      case 12: g4 = reinterpret_cast<const uint32_t *>(d.podcnt); break;
-      default: break;
-    }
-  }
+  __syncthreads();
+  if (wave == K5_WAVES - 2) H.win[0][lane] = (lane < r.L) ? r.keys[(size_t)M.desc[0].slot * r.L + lane] : 0ull;   // row 0's window
   __syncthreads();
 
-  unsigned long long ck[K5_SPT];     // cached keys of the dirty slots this thread owns, valid for shape `prev_shape`
-#pragma unroll
-  for (int j = 0; j < K5_SPT; j++) ck[j] = 0ull;
-  uint32_t prev_shape = 0xFFFFFFFFu;
-  uint32_t nd = 0;                   // dirty slots in use (tracked identically by every thread)
-  uint32_t last_slot = 0xFFFFFFFFu;  // slot of the previous commit
-  uint32_t n_done = 0, reason = KB_REASON_DONE;
-
-  // optional cycle trace (KB_K5_TRACE=1): stamps are kept in registers and written once per row by thread 0 and by
-  // lane 0 of the candidate wave
-#ifdef KB_K5_TRACE
-  const bool tracing = r.trace != nullptr && (tid == 0 || tid == (K5_WAVES - 1) * 64);
-  unsigned long long stamp[10];
-  stamp[9] = 0;
-#define K5_STAMP(k) do { if (tracing) stamp[k] = __builtin_readcyclecounter(); } while (0)
-#else
-#define K5_STAMP(k) do { } while (0)
-#endif
-
-  // candidate window of the current task: 64 consecutive list entries starting at win_base (candidate wave only)
-  unsigned long long win_key = 0ull;
-  uint32_t win_base = 0;
-  if (cand_wave) win_key = (lane < r.L) ? r.keys[(size_t)desc[0].slot * r.L + lane] : 0ull;
-
-  for (uint32_t i = 0; i < r.n_rows; i++) {
-    K5_STAMP(0);
-    const KbRowDesc &cur = desc[i];
-    const uint32_t shape = cur.slot;
-    TaskVals tv;
-    tv.init0 = cur.init0; tv.init1 = cur.init1; tv.nzc = cur.nzc; tv.nzm = cur.nzm;
-    tv.cls = cur.cls; tv.active = cur.active; tv.task = cur.task; tv.pad = 0;
-
-    // ---- candidate wave: issue the prefetch of the next row's candidate window
-    unsigned long long nwin_key = 0ull;
-    uint32_t nwin_base = 0;
-    if (cand_wave && i + 1 < r.n_rows) {
-      const uint32_t nshape = desc[i + 1].slot;
-      nwin_base = cursor[nshape];
-      uint32_t e = nwin_base + lane;
-      nwin_key = (e < r.L) ? r.keys[(size_t)nshape * r.L + e] : 0ull;
-    }
-    K5_STAMP(1);
-
-    // ---- dirty side: live re-evaluation out of the LDS tables, cached per thread while the shape repeats
-    const bool same = shape == prev_shape;
-    unsigned long long key = 0ull;
-#pragma unroll
-    for (int j = 0; j < K5_SPT; j++) {
-      uint32_t slot = tid + j * K5_EVAL;
-      if (!cand_wave && slot < nd) {
-        if (!same || slot == last_slot) {
-          NodeVals nv = k5_slot_vals(tab, t_cls, t_left, cap, slot);
-          uint32_t node = t_node[slot];
-          uint32_t res = eval_pair(d, tv, nv, node, r.fit_mode);
-          ck[j] = res ? KB_KEY(res & 0xFFFFu, node) : 0ull;
-        }
-        key = ck[j] > key ? ck[j] : key;
-      }
-    }
-    prev_shape = shape;
-    K5_STAMP(2);
-
-    // ---- clean side: first list entry whose node is not dirty, and (lanes 0..12) that node's state
-    unsigned long long cand = 0ull, st8 = 0ull;
-    uint32_t st4 = 0;
-    if (cand_wave) {
-      uint32_t curs = cursor[shape];
-      bool list_end = false;
-      for (;;) {
-        bool nz = win_key != 0ull;
-        bool clean = nz && (win_base + lane) >= curs && !bit_test(bitmap, KB_KEY_NODE(win_key));
-        unsigned long long b = __ballot(clean);
-        if (b) {
-          int first = __ffsll((unsigned long long)b) - 1;
-          // lists are 0-terminated and sorted best-first, so the first clean entry is the best clean node
-          cand = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(win_key >> 32), first) << 32) |
-                 (uint32_t)__builtin_amdgcn_readlane((int)(win_key & 0xFFFFFFFFull), first);
-          curs = win_base + first;
-          break;
-        }
-        if (__ballot(!nz)) { list_end = true; break; }   // ran past the last feasible node: no clean candidate exists
-        win_base += 64;
-        if (win_base >= r.L) break;                       // list exhausted while still full: live rescan below
-        uint32_t e = win_base + lane;
-        win_key = (e < r.L) ? r.keys[(size_t)shape * r.L + e] : 0ull;
-        if (lane == 0) H.refills++;
-      }
-      if (lane == 0) {
-        cursor[shape] = curs;
-        H.cand = cand;
-        H.exhausted = (!cand && !list_end) ? 1u : 0u;
-      }
-      if (cand) {   // one load instruction per width; consumed only if the candidate wins
-        uint32_t n = KB_KEY_NODE(cand);
-        if (g8) st8 = g8[n];
-        if (g4) st4 = g4[n];
-      }
-      if (lane == 0) key = cand > key ? cand : key;
-    }
-    K5_STAMP(3);
-
-    key = wave_max_key(key);
-    if (lane == 0) H.red[wave] = key;
-    K5_STAMP(4);
-    __syncthreads();
-    K5_STAMP(5);
-    unsigned long long best = oct_max_key(H.red[lane & (K5_WAVES - 1)]);
-    const uint4 hdr1 = *reinterpret_cast<const uint4 *>(&H.cand);
-    const unsigned long long hcand = ((unsigned long long)hdr1.y << 32) | hdr1.x;
-    const uint32_t exhausted = hdr1.z;
-
-    if (exhausted) {
-      // cannot happen while L > window size; kept so a shorter (caller-limited) list stays exact: evaluate every CLEAN
-      // node against global state (clean nodes are unchanged since the round started); dirty ones are covered above
-      unsigned long long k2 = 0ull;
-      for (uint32_t n = tid; n < d.N; n += KB_K5_THREADS) {
-        if (bit_test(bitmap, n)) continue;
-        NodeVals nv = load_node(d, n);
-        uint32_t res = eval_pair(d, tv, nv, n, r.fit_mode);
-        if (res) { unsigned long long k3 = KB_KEY(res & 0xFFFFu, n); k2 = k3 > k2 ? k3 : k2; }
-      }
-      k2 = wave_max_key(k2);
-      __syncthreads();
-      if (lane == 0) H.red[wave] = k2;
-      __syncthreads();
-      unsigned long long bclean = oct_max_key(H.red[lane & (K5_WAVES - 1)]);
-      if (tid == 0) { H.rescans++; H.cand = bclean; }
-      if (cand_wave) {
-        cand = bclean;
-        if (cand) {
-          uint32_t n = KB_KEY_NODE(cand);
-          if (g8) st8 = g8[n];
-          if (g4) st4 = g4[n];
-        }
-      }
-      __syncthreads();
-      best = bclean > best ? bclean : best;
-    }
-    const unsigned long long cand_now = exhausted ? H.cand : hcand;
-    K5_STAMP(6);
-
-    if (best == 0ull) {
-      if (r.backfill) {   // backfill.go:50-66: no node passes the predicates -> the task simply stays Pending
-        if (tid == 0) *reinterpret_cast<uint2 *>(&r.dec[i]) = make_uint2(KB_NONE_U32, 0u);
-        __syncthreads();
-        n_done = i + 1;
-        win_key = nwin_key; win_base = nwin_base;
-        continue;
-      }
-      // allocate.go:144-148: no feasible node -> the job is abandoned; the host re-plans from here
-      n_done = i;
-      reason = KB_REASON_NO_FEASIBLE;
-      break;
-    }
-
-    // ---- commit: NodeInfo.AddTask (api/node_info.go:172-212) on the LDS copy of the node
-    const uint32_t n = KB_KEY_NODE(best);
-    const bool clean_wins = best == cand_now;
-    const double res0 = (cur.flags & 1) ? cur.init0 : d.t_res[cur.task];
-    const double res1 = (cur.flags & 1) ? cur.init1 : d.t_res[(size_t)d.T + cur.task];
-    if (clean_wins) {
-      if (cand_wave) {
-        // lanes 0..9 hold field `lane` of the node, lanes 10..12 cls / maxpods / podcnt
-        double v = __longlong_as_double((long long)st8);
-        uint32_t kind = 0;
-        if (!r.backfill) {   // allocate.go:160: InitResreq.LessEqual(node.Idle) ? Allocate : Pipeline
-          bool ok = true;
-          if (lane == K5F_IDLE0) ok = le_eps(tv.init0, v, EPS_CPU);
-          if (lane == K5F_IDLE1) ok = le_eps(tv.init1, v, EPS_MEM);
-          if (lane == 2 && (tv.active >> 2)) {   // scalar dimensions (rare): compared against live global state
-            uint32_t a = tv.active >> 2, dd = 2;
-            while (a) {
-              if (a & 1u) ok = ok && le_eps(d.t_init[(size_t)dd * d.T + tv.task], d.idle[(size_t)dd * d.NP + n], EPS_SCALAR);
-              a >>= 1; dd++;
-            }
-          }
-          kind = __ballot(!ok) ? 1u : 0u;
-        }
-        K5_STAMP(9);
-        // apply the task: Allocated -> Idle.Sub(Resreq); Pipelined -> Releasing.Sub(Resreq); pod joins ni.Tasks
-        const uint32_t f0 = kind ? K5F_REL0 : K5F_IDLE0;
-        if (lane == f0) v -= res0;
-        if (lane == f0 + 1) v -= res1;
-        unsigned long long out = (unsigned long long)__double_as_longlong(v);
-        if (lane == K5F_NZC) out = st8 + (unsigned long long)tv.nzc;
-        if (lane == K5F_NZM) out = st8 + (unsigned long long)tv.nzm;
-        if (lane >= K5F_INVAC && lane <= K5F_AM) out = st8;
-        if (lane < K5_NF8) tab[(size_t)lane * cap + nd] = out;
-        const int maxp = __builtin_amdgcn_readlane((int)st4, 11), pods = __builtin_amdgcn_readlane((int)st4, 12);
-        if (lane == 10) t_cls[nd] = st4;
-        if (lane == 11) t_left[nd] = maxp - pods - 1;
-        if (lane == 12) t_node[nd] = n;
-        if (lane == 0) {
-          bitmap[n >> 5] |= 1u << (n & 31);
-          H.last_slot = nd;
-          k5_commit_globals(d, r, cur, res0, res1, i, n, kind);
-          if (kind == 1u) H.stop = 1;
-        }
-      }
-    } else {
-#pragma unroll
-      for (int j = 0; j < K5_SPT; j++) {
-        uint32_t slot = tid + j * K5_EVAL;
-        if (!cand_wave && slot < nd && ck[j] == best) {
-          uint32_t kind = 0;
-          if (!r.backfill) {
-            bool fi = le_eps(tv.init0, __longlong_as_double((long long)tab[K5F_IDLE0 * cap + slot]), EPS_CPU) &&
-                      le_eps(tv.init1, __longlong_as_double((long long)tab[K5F_IDLE1 * cap + slot]), EPS_MEM);
-            uint32_t a = tv.active >> 2, dd = 2;
-            while (a) {
-              if (a & 1u) fi = fi && le_eps(d.t_init[(size_t)dd * d.T + tv.task], d.idle[(size_t)dd * d.NP + n], EPS_SCALAR);
-              a >>= 1; dd++;
-            }
-            kind = fi ? 0u : 1u;
-          }
-          const uint32_t f0 = kind ? K5F_REL0 : K5F_IDLE0;
-          tab[(size_t)f0 * cap + slot] = (unsigned long long)__double_as_longlong(__longlong_as_double((long long)tab[(size_t)f0 * cap + slot]) - res0);
-          tab[(size_t)(f0 + 1) * cap + slot] = (unsigned long long)__double_as_longlong(__longlong_as_double((long long)tab[(size_t)(f0 + 1) * cap + slot]) - res1);
-          tab[(size_t)K5F_NZC * cap + slot] += (unsigned long long)tv.nzc;
-          tab[(size_t)K5F_NZM * cap + slot] += (unsigned long long)tv.nzm;
-          t_left[slot] -= 1;
-          H.last_slot = slot;
-          k5_commit_globals(d, r, cur, res0, res1, i, n, kind);
-          if (kind == 1u) H.stop = 1;
-        }
-      }
-    }
-    K5_STAMP(7);
-    __syncthreads();
-    K5_STAMP(8);
-#ifdef KB_K5_TRACE
-    if (tracing && i < 512) {
-      unsigned long long *dst = r.trace + ((tid == 0 ? 0 : 512) + (size_t)i) * 10;
-#pragma unroll
-      for (int k = 0; k < 9; k++) dst[k] = stamp[k];
-      dst[9] = (clean_wins ? 1ull : 0ull) | (same ? 2ull : 0ull) | ((clean_wins && stamp[9] > stamp[6]) ? ((stamp[9] - stamp[6]) << 8) : 0ull);
-    }
-#endif
-    if (clean_wins) nd++;
-    n_done = i + 1;
-    const uint2 hdr2 = *reinterpret_cast<const uint2 *>(&H.last_slot);
-    last_slot = hdr2.x;
-    if (hdr2.y) { reason = KB_REASON_PIPELINED; break; }   // the host speculated "Allocated": stop after a Pipeline so it can re-plan
-    win_key = nwin_key; win_base = nwin_base;
-  }
+  // Three specialised loops that only meet at the two barriers per row: waves 0..W-3 own the dirty slots, wave W-2 is the
+  // loader, wave W-1 walks the candidate lists and commits clean winners.  Every role derives the same control decisions
+  // (continue / stop / rescan) from the same LDS words, so the barrier counts always match.
+  uint32_t nd = 0, n_done = 0, reason = KB_REASON_DONE;
+  if (wave == K5_WAVES - 1) k5_cand_role(d, r, M, nd, n_done, reason);
+  else if (wave == K5_WAVES - 2) k5_load_role(d, r, M, nd, n_done, reason);
+  else k5_eval_role(d, r, M, nd, n_done, reason);
 
   // ---- write the dirty nodes' live state back to HBM
   __syncthreads();
   for (uint32_t slot = tid; slot < nd; slot += KB_K5_THREADS) {
-    uint32_t n = t_node[slot];
-    d.idle[n] = __longlong_as_double((long long)tab[K5F_IDLE0 * cap + slot]);
-    d.idle[(size_t)d.NP + n] = __longlong_as_double((long long)tab[K5F_IDLE1 * cap + slot]);
-    d.rel[n] = __longlong_as_double((long long)tab[K5F_REL0 * cap + slot]);
-    d.rel[(size_t)d.NP + n] = __longlong_as_double((long long)tab[K5F_REL1 * cap + slot]);
-    d.nzc[n] = (long long)tab[K5F_NZC * cap + slot];
-    d.nzm[n] = (long long)tab[K5F_NZM * cap + slot];
-    d.podcnt[n] = d.maxpods[n] - t_left[slot];
+    uint32_t n = M.t_node[slot];
+    d.idle[n] = __longlong_as_double((long long)M.tab[K5F_IDLE0 * cap + slot]);
+    d.idle[(size_t)d.NP + n] = __longlong_as_double((long long)M.tab[K5F_IDLE1 * cap + slot]);
+    d.rel[n] = __longlong_as_double((long long)M.tab[K5F_REL0 * cap + slot]);
+    d.rel[(size_t)d.NP + n] = __longlong_as_double((long long)M.tab[K5F_REL1 * cap + slot]);
+    d.nzc[n] = (long long)M.tab[K5F_NZC * cap + slot];
+    d.nzm[n] = (long long)M.tab[K5F_NZM * cap + slot];
+    d.podcnt[n] = d.maxpods[n] - M.t_left[slot];
   }
-  if (tid == 0) { r.result[0] = n_done; r.result[1] = reason; r.result[2] = nd; r.result[3] = H.rescans; r.result[4] = H.refills; }
+  if (tid == 0) { r.result[0] = n_done; r.result[1] = reason; r.result[2] = nd; r.result[3] = H.rescans & 0xFFFFu; r.result[4] = H.refills & 0xFFFFu; r.result[5] = H.refills >> 16; r.result[6] = H.rescans >> 16; }
 }
 
 // task-table side of ssn.Allocate / ssn.Pipeline for the rows the commit kernel processed (job.UpdateTaskStatus,
