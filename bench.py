@@ -108,20 +108,21 @@ def main():
     evals = d["evals"]
     value = evals / elapsed
 
-    # ---- roofline: the mask+score matrix kernel (K1), HBM-bound by construction (SURVEY.md §8d accounting (M):
-    # 2 B score + 1/8 B mask per evaluation written once, node and task vectors read once).  Two measurements, both with
-    # HIP events on the engine's stream:
-    #   "roofline"        the materialised T x N matrix of this workload in ONE launch (kb_bench_matrix, rows [0,T)):
-    #                     the kernel at the size north_star quotes the roofline target on;
-    #   "roofline_cycle"  the same kernel as the scheduling cycle launches it inside the timed region: one launch per
-    #                     round over the DISTINCT task shapes of the window (a few dozen rows), i.e. latency-sized.
+    # ---- roofline: the mask+score matrix (K1), HBM-bound by construction (SURVEY.md §8d accounting (M): 2 B score + 1/8 B
+    # mask per evaluation written once, node and task vectors read once).  Two measurements, both with HIP events on the
+    # engine's stream:
+    #   "roofline"        the materialised T x N matrix of this workload (kb_bench_matrix, rows [0,T)): k_matrix over the
+    #                     distinct task shapes + k_expand streaming every task row out — the size north_star quotes the
+    #                     roofline target on; the time is for BOTH launches;
+    #   "roofline_cycle"  k_matrix as the scheduling cycle launches it inside the timed region: one launch per round over the
+    #                     DISTINCT task shapes of the window (a few dozen rows), i.e. latency-sized.
     R, N, T = snap.n_res, snap.n_nodes, snap.n_tasks
     b_node, b_task = 16 * R + 44, 8 * R + 24
 
-    def roof(rows, ms, launches, label):
+    def roof(rows, ms, launches, label, kname="k_matrix"):
         alg = rows * N * 2.125 + N * b_node + rows * b_task
         ach = alg / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
-        return {"bound": "hbm", "kernel": "k_matrix", "launch": label, "achieved": round(ach, 2), "peak": HBM_PEAK_GBS,
+        return {"bound": "hbm", "kernel": kname, "launch": label, "achieved": round(ach, 2), "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None, "bytes_per_launch": int(alg),
                 "avg_launch_ms": round(ms, 5), "launches": int(launches), "rows_per_launch": round(rows, 1),
                 "evals_per_s": round(rows * N / (ms * 1e-3), 1) if ms > 0 else 0.0}
@@ -131,7 +132,8 @@ def main():
                           "per-round launch inside the timed region (distinct shapes of one window)")
     full_reps = 5
     full_ms = eng.bench_matrix(0, T, reps=full_reps) if world == 1 else 0.0
-    roofline = roof(T, full_ms, full_reps, f"kb_bench_matrix rows [0,{T}) x {N} nodes, one launch") if full_ms > 0 else roofline_cycle
+    roofline = (roof(T, full_ms, full_reps, f"kb_bench_matrix rows [0,{T}) x {N} nodes: per-shape evaluation + row expansion",
+                     "k_matrix+k_expand") if full_ms > 0 else roofline_cycle)
     # HBM bytes per launch from the PMC passes of scripts/profile_round.sh (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate
     # runs; KB units; FETCH_SIZE doubled per MI355X_MICROARCH.md's gfx950 correction).  Cannot be collected inside this
     # process, so the committed summary of the same command is read back; null when it is absent or for another config.
@@ -140,8 +142,8 @@ def main():
         import csv
         vals = {}
         for row in csv.DictReader(open(pmc)):
-            if "k_matrix<4, 32>" in row["kernel"]:
-                vals[row["counter"]] = float(row["mean_KB_per_dispatch"])
+            if "k_matrix<4, 32>" in row["kernel"] or "k_expand" in row["kernel"]:
+                vals[row["counter"]] = vals.get(row["counter"], 0.0) + float(row["mean_KB_per_dispatch"])
         if "FETCH_SIZE" in vals and "WRITE_SIZE" in vals:
             roofline["traffic"] = int((2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024)
             roofline["traffic_source"] = "profiles/round1/rocprofv3_pmc_k_matrix.csv"

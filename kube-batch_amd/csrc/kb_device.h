@@ -112,6 +112,9 @@ enum { KB_REASON_DONE = 0, KB_REASON_NO_FEASIBLE = 1, KB_REASON_PIPELINED = 2 };
 void kb_launch_gather(const KbDev &d, const KbRound &r, void *stream);
 void kb_launch_matrix(const KbDev &d, const KbRound &r, void *stream);
 void kb_launch_argmax(const KbDev &d, const KbRound &r, void *stream);
+// per-task rows out of the per-shape rows (kb_eval_matrix / kb_bench_matrix: the materialised T x N matrix)
+void kb_launch_expand(const KbDev &d, const uint16_t *s_score, const uint32_t *s_mask, const uint32_t *row_slot, uint32_t n_rows,
+                      uint16_t *score, uint32_t *maskw, void *stream);
 void kb_launch_commit(const KbDev &d, const KbRound &r, void *stream);
 // node state := round-start state + reduced deltas; returns how many values differ from the live (locally committed) state
 uint32_t kb_apply_deltas(const KbDev &d, const double *s_idle, const double *s_rel, const long long *s_nzc, const long long *s_nzm,

@@ -112,6 +112,8 @@ struct kb_engine {
   DevBuf b_desc, b_trace;
   bool trace_on = false;
   std::vector<double> trace_acc = std::vector<double>(3 * 4 * 12, 0.0);
+  DevBuf b_sscore, b_smask, b_xslot;   // per-shape rows and row->shape map of kb_eval_matrix / kb_bench_matrix
+  size_t xs_cap = 0, xslot_cap = 0;
   DevBuf b_rows, b_slot, b_mrows, b_same, b_score, b_maskw, b_keys, b_dec, b_result;
   uint32_t win_cap = 0, mat_cap = 0;
   size_t keys_cap = 0;
@@ -971,19 +973,47 @@ static int run_action(kb_engine *e, uint32_t action, kb_decision *out, uint64_t 
 int kb_run_allocate(kb_engine *e, kb_decision *out, uint64_t cap, uint64_t *n_out) { return run_action(e, 0, out, cap, n_out); }
 int kb_run_backfill(kb_engine *e, kb_decision *out, uint64_t cap, uint64_t *n_out) { return run_action(e, 1, out, cap, n_out); }
 
-static KbRound matrix_chunk(kb_engine *e, uint32_t t0, uint32_t n, uint32_t fit_mode, uint32_t k) {
-  ensure_matrix_buffers(e, n, k ? k : 1);
+// The materialised matrix for task rows [t0, t0+n): evaluate each distinct shape of the range once (K1), then stream every
+// row out of its shape's row (K1b); optionally the sorted candidate lists of the expanded rows (K3, length k).
+struct ChunkPlan {
+  KbRound r{};        // describes the expanded rows (score / maskw / keys of n rows)
+  KbRound rs{};       // the per-shape launch
+  uint32_t ns = 0;
+};
+static ChunkPlan matrix_plan(kb_engine *e, uint32_t t0, uint32_t n, uint32_t fit_mode, uint32_t k) {
+  ChunkPlan p;
   HostSession &hs = e->hs;
-  for (uint32_t i = 0; i < n; i++)
-    e->h_same[i] = (i > 0 && hs.t_row_shape[t0 + i] == hs.t_row_shape[t0 + i - 1]) ? 1 : 0;   // identical consecutive rows are computed once
-  HIP_OK(hipMemcpyAsync(e->b_same.p, e->h_same.data(), n, hipMemcpyHostToDevice, e->stream));
-  KbRound r = make_round(e, 0, n, k, (int)fit_mode, false);
-  r.mrows = nullptr;
-  r.mrow_task0 = t0;
-  r.same_prev = e->b_same.as<uint8_t>();
-  kb_launch_matrix(e->dev, r, e->stream);
-  if (k) kb_launch_argmax(e->dev, r, e->stream);
-  return r;
+  const size_t NP = e->dev.NP;
+  ensure_window_buffers(e, n);          // h_rows / h_slot staging (host side only matters here)
+  ensure_matrix_buffers(e, n, k ? k : 1);
+  for (uint32_t i = 0; i < n; i++) e->h_rows[i] = t0 + i;
+  if (e->h_mrows.size() < n) e->h_mrows.resize(n);
+  p.ns = assign_shapes(e, n);
+  if (p.ns > e->xs_cap) {
+    e->b_sscore.alloc(sizeof(uint16_t) * (size_t)p.ns * NP);
+    e->b_smask.alloc(sizeof(uint32_t) * (size_t)p.ns * (NP / 32));
+    e->xs_cap = p.ns;
+  }
+  if (n > e->xslot_cap) { e->b_xslot.alloc(sizeof(uint32_t) * n); e->xslot_cap = n; }
+  HIP_OK(hipMemcpyAsync(e->b_xslot.p, e->h_slot.data(), sizeof(uint32_t) * n, hipMemcpyHostToDevice, e->stream));
+  HIP_OK(hipMemcpyAsync(e->b_mrows.p, e->h_mrows.data(), sizeof(uint32_t) * p.ns, hipMemcpyHostToDevice, e->stream));
+  p.rs = make_round(e, 0, p.ns, 1, (int)fit_mode, false);
+  p.rs.score = e->b_sscore.as<uint16_t>();
+  p.rs.maskw = e->b_smask.as<uint32_t>();
+  p.r = make_round(e, 0, n, k ? k : 1, (int)fit_mode, false);
+  p.r.mrows = nullptr;
+  p.r.mrow_task0 = t0;
+  return p;
+}
+static void matrix_launch(kb_engine *e, const ChunkPlan &p, uint32_t n, uint32_t k) {
+  kb_launch_matrix(e->dev, p.rs, e->stream);
+  kb_launch_expand(e->dev, p.rs.score, p.rs.maskw, e->b_xslot.as<uint32_t>(), n, p.r.score, p.r.maskw, e->stream);
+  if (k) kb_launch_argmax(e->dev, p.r, e->stream);
+}
+static KbRound matrix_chunk(kb_engine *e, uint32_t t0, uint32_t n, uint32_t fit_mode, uint32_t k) {
+  ChunkPlan p = matrix_plan(e, t0, n, fit_mode, k);
+  matrix_launch(e, p, n, k);
+  return p.r;
 }
 
 int kb_eval_matrix(kb_engine *e, uint32_t t0, uint32_t t1, uint32_t fit_mode, uint8_t *mask_bits, uint16_t *score) {
@@ -1037,11 +1067,12 @@ int kb_bench_matrix(kb_engine *e, uint32_t t0, uint32_t t1, uint32_t fit_mode, u
     if (!e->loaded) throw EngineError(KB_E_STATE, "no session loaded");
     if (t0 >= t1 || t1 > e->hs.T || reps == 0) throw EngineError(KB_E_INVALID, "bad range / reps");
     uint32_t n = t1 - t0;
-    KbRound r = matrix_chunk(e, t0, n, fit_mode, 0);   // warm-up launch, also uploads the row flags
+    ChunkPlan p = matrix_plan(e, t0, n, fit_mode, 0);
+    matrix_launch(e, p, n, 0);   // warm-up
     HIP_OK(hipStreamSynchronize(e->stream));
     Timer &tm = get_timer(e, 4);
     HIP_OK(hipEventRecord(tm.a, e->stream));
-    for (uint32_t i = 0; i < reps; i++) kb_launch_matrix(e->dev, r, e->stream);
+    for (uint32_t i = 0; i < reps; i++) matrix_launch(e, p, n, 0);   // per-shape evaluation + row expansion: the whole matrix
     HIP_OK(hipEventRecord(tm.b, e->stream));
     HIP_OK(hipStreamSynchronize(e->stream));
     HIP_OK(hipGetLastError());

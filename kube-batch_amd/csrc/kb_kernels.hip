@@ -171,31 +171,76 @@ __global__ void __launch_bounds__(256) k_matrix(KbDev d, KbRound r) {
 #pragma unroll
   for (int j = 0; j < NPT; j++) res[j] = 0;
   const size_t mstride = d.NP / 32;
+  uint2 pk = make_uint2(0u, 0u);   // packed scores / mask word of the last evaluated row (re-stored for identical rows)
+  uint32_t mw = 0;
   for (uint32_t rr = 0; rr < nr; rr++) {
+#ifdef KB_K1_OLDLOOP
+    const bool fresh = true;
+    const bool evalrow = !(ssame[rr] && rr > 0);
     const TaskVals tv = srow[rr];
-    if (!(ssame[rr] && rr > 0)) {
+    if (evalrow) {
+#else
+    const bool fresh = !(ssame[rr] && rr > 0);
+    if (fresh) {
+      const TaskVals tv = srow[rr];
+#endif
+#ifdef KB_K1_NOEVAL   // timing experiment: store path only
+#pragma unroll
+      for (int j = 0; j < NPT; j++) res[j] = 0x10000u | (tv.cls + (uint32_t)nv[j].nzc);
+#else
 #pragma unroll
       for (int j = 0; j < NPT; j++) res[j] = eval_pair(d, tv, nv[j], n0 + j, r.fit_mode);
+#endif
     }
     const size_t row = row0 + rr;
     if (NPT == 4) {
-      uint2 pk;
-      pk.x = (res[0] & 0xFFFFu) | (res[1 % NPT] << 16);
-      pk.y = (res[2 % NPT] & 0xFFFFu) | (res[3 % NPT] << 16);
+      if (fresh) {
+        pk.x = (res[0] & 0xFFFFu) | (res[1 % NPT] << 16);
+        pk.y = (res[2 % NPT] & 0xFFFFu) | (res[3 % NPT] << 16);
+        uint32_t nib = ((res[0] >> 16) & 1u) | (((res[1 % NPT] >> 16) & 1u) << 1) | (((res[2 % NPT] >> 16) & 1u) << 2) | (((res[3 % NPT] >> 16) & 1u) << 3);
+        // OR the 8 lanes' nibbles into one mask word with DPP moves (no LDS crossbar): xor 1, xor 2, mirror within 8
+        uint32_t w = nib << (4 * (lane & 7));
+        w |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)w, 0xB1, 0xf, 0xf, false);    // quad_perm [1,0,3,2]
+        w |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)w, 0x4E, 0xf, 0xf, false);    // quad_perm [2,3,0,1]
+        w |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)w, 0x141, 0xf, 0xf, false);   // row_half_mirror
+        mw = w;
+      }
+      // streaming stores: the matrix is written once and read by another kernel
+#ifdef KB_K1_NT
+      __builtin_nontemporal_store(((unsigned long long)pk.y << 32) | pk.x, reinterpret_cast<unsigned long long *>(r.score + row * d.NP + n0));
+      if ((lane & 7) == 0) __builtin_nontemporal_store(mw, &r.maskw[row * mstride + (n0 >> 5)]);
+#elif defined(KB_K1_NOSTORE)   // timing experiment: evaluation only
+      if (pk.x == 0x12345678u && mw == 0x9abcdefu) *reinterpret_cast<uint2 *>(r.score + row * d.NP + n0) = pk;
+#else
       *reinterpret_cast<uint2 *>(r.score + row * d.NP + n0) = pk;
-      uint32_t nib = ((res[0] >> 16) & 1u) | (((res[1 % NPT] >> 16) & 1u) << 1) | (((res[2 % NPT] >> 16) & 1u) << 2) | (((res[3 % NPT] >> 16) & 1u) << 3);
-      // OR the 8 lanes' nibbles into one mask word with DPP moves (no LDS crossbar): xor 1, xor 2, mirror within 8
-      uint32_t w = nib << (4 * (lane & 7));
-      w |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)w, 0xB1, 0xf, 0xf, false);    // quad_perm [1,0,3,2]
-      w |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)w, 0x4E, 0xf, 0xf, false);    // quad_perm [2,3,0,1]
-      w |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)w, 0x141, 0xf, 0xf, false);   // row_half_mirror
-      if ((lane & 7) == 0) r.maskw[row * mstride + (n0 >> 5)] = w;
+      if ((lane & 7) == 0) r.maskw[row * mstride + (n0 >> 5)] = mw;
+#endif
     } else {
       r.score[row * d.NP + n0] = (uint16_t)(res[0] & 0xFFFFu);
       unsigned long long b = __ballot((res[0] >> 16) & 1u);   // one wave = 64 consecutive nodes = two mask words
       if (lane == 0) *reinterpret_cast<unsigned long long *>(r.maskw + row * mstride + (n0 >> 5)) = b;
     }
   }
+}
+
+// K1b: row expansion.  Tasks with the same shape (InitResreq, non-zero request, class) have identical matrix rows, so the
+// materialised T x N matrix is produced by evaluating each distinct shape once (k_matrix over the representative rows)
+// and streaming every task row out of its shape's row: 16-byte loads that hit L2 / Infinity Cache (S x N is a few MB),
+// 16-byte stores that are the launch's HBM traffic (2 B score + 1 mask bit per evaluation).  One workgroup per task row.
+__global__ void __launch_bounds__(256) k_expand(const uint16_t *__restrict__ s_score, const uint32_t *__restrict__ s_mask,
+                                                const uint32_t *__restrict__ row_slot, uint32_t n_rows, uint32_t NP,
+                                                uint16_t *__restrict__ score, uint32_t *__restrict__ maskw) {
+  const uint32_t row = blockIdx.x;
+  if (row >= n_rows) return;
+  const uint32_t slot = row_slot[row];
+  const uint4 *src = reinterpret_cast<const uint4 *>(s_score + (size_t)slot * NP);
+  uint4 *dst = reinterpret_cast<uint4 *>(score + (size_t)row * NP);
+  const uint32_t n16 = NP / 8;                 // 16-byte chunks per row (NP is a multiple of 2048)
+  for (uint32_t c = threadIdx.x; c < n16; c += 256) dst[c] = src[c];
+  const uint4 *msrc = reinterpret_cast<const uint4 *>(s_mask + (size_t)slot * (NP / 32));
+  uint4 *mdst = reinterpret_cast<uint4 *>(maskw + (size_t)row * (NP / 32));
+  const uint32_t m16 = NP / 128;               // NP/32 words = NP/128 16-byte chunks
+  for (uint32_t c = threadIdx.x; c < m16; c += 256) mdst[c] = msrc[c];
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -1103,6 +1148,11 @@ void kb_launch_matrix(const KbDev &d, const KbRound &r, void *stream) {
     dim3 grid(d.NP / 256, (r.n_mrows + 3) / 4);
     hipLaunchKernelGGL((k_matrix<1, 4>), grid, dim3(256), 0, (hipStream_t)stream, d, r);
   }
+}
+void kb_launch_expand(const KbDev &d, const uint16_t *s_score, const uint32_t *s_mask, const uint32_t *row_slot, uint32_t n_rows,
+                      uint16_t *score, uint32_t *maskw, void *stream) {
+  if (n_rows == 0) return;
+  hipLaunchKernelGGL(k_expand, dim3(n_rows), dim3(256), 0, (hipStream_t)stream, s_score, s_mask, row_slot, n_rows, d.NP, score, maskw);
 }
 void kb_launch_argmax(const KbDev &d, const KbRound &r, void *stream) {
   if (r.n_mrows == 0) return;

@@ -13,7 +13,7 @@ import numpy as np
 from . import abi
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libkbengine.so")
+LIB_PATH = os.environ.get("KB_ENGINE_LIB") or os.path.join(_HERE, "libkbengine.so")   # KB_ENGINE_LIB: A/B builds of the same source
 _LIB = None
 
 EXPORTS = ["kb_engine_create", "kb_engine_destroy", "kb_last_error", "kb_session_load", "kb_session_reset", "kb_run_allocate",
