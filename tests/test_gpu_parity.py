@@ -172,3 +172,72 @@ def test_edge_cases(oracle_mod):
     o, e, dec = run_both(oracle_mod, cfg, snap, ["allocate"])
     assert_same_outcome(o, e, dec)
     assert snap.bind_map(e.binds()).get("ns/sel") == "a"
+
+
+def test_pipeline_init_containers_and_scalars(oracle_mod):
+    """Branches of the commit kernel the synthetic configs do not reach: Pipeline onto Releasing capacity (and the host's
+    re-plan after it), InitResreq > Resreq (init containers), scalar resources consumed in the commit (nvidia.com/gpu)."""
+    cfg = conf.load_scheduler_conf()
+    GPU = "nvidia.com/gpu"
+    nodes = [snapmod.Node("n1", {"cpu": "8", "memory": "16Gi", "pods": "20", GPU: "4"}),
+             snapmod.Node("n2", {"cpu": "8", "memory": "16Gi", "pods": "20", GPU: "2"}),
+             snapmod.Node("n3", {"cpu": "4", "memory": "8Gi", "pods": "20"})]
+    pods = []
+    # a terminating pod on n3 (Releasing 3 cpu / 6Gi) and a running one: n3's Idle is tiny, its Releasing is not
+    pods.append(snapmod.Pod("old", "dying", [{"cpu": "3", "memory": "6Gi"}], node_name="n3", phase="Running", deleting=True, group_name="gold"))
+    pods.append(snapmod.Pod("old", "busy", [{"cpu": "900m", "memory": "1Gi"}], node_name="n3", phase="Running", group_name="gold"))
+    # fill n1/n2 so that later tasks only fit n3's Releasing
+    for i in range(7):
+        pods.append(snapmod.Pod("a", f"fat{i}", [{"cpu": "2", "memory": "4Gi"}], group_name="ga", creation=10 + i))
+    pods.append(snapmod.Pod("b", "pipe1", [{"cpu": "2", "memory": "4Gi"}], group_name="gb", creation=30))
+    pods.append(snapmod.Pod("b", "pipe2", [{"cpu": "1", "memory": "2Gi"}], group_name="gb", creation=31))
+    # init container raises the launch requirement above the running requirement
+    pods.append(snapmod.Pod("c", "init1", [{"cpu": "500m", "memory": "512Mi"}], init_containers=[{"cpu": "1500m", "memory": "1Gi"}], group_name="gc", creation=40))
+    pods.append(snapmod.Pod("c", "init2", [{"cpu": "500m", "memory": "512Mi"}], init_containers=[{"cpu": "1500m", "memory": "1Gi"}], group_name="gc", creation=41))
+    # scalar resource requests: 3 gpus fit n1 only, then 2 on n2, then nothing
+    for i, g in enumerate(["3", "2", "2", "1"]):
+        pods.append(snapmod.Pod("d", f"gpu{i}", [{"cpu": "100m", "memory": "128Mi", GPU: g}], group_name="gd", creation=50 + i))
+    pgs = [snapmod.PodGroup("old", "gold", min_member=1, creation=1), snapmod.PodGroup("a", "ga", min_member=1, creation=2),
+           snapmod.PodGroup("b", "gb", min_member=1, creation=3), snapmod.PodGroup("c", "gc", min_member=2, creation=4),
+           snapmod.PodGroup("d", "gd", min_member=1, creation=5)]
+    snap = snapmod.flatten(nodes, pods, pgs, [snapmod.Queue("default")])
+    assert snap.n_res == 3 and (snap.node_releasing[:, 2] > 0).any()
+    for window in (1024, 64):
+        o, e, dec = run_both(oracle_mod, cfg, snap, ["allocate", "backfill"], window=window)
+        assert_same_outcome(o, e, dec)
+    assert (dec[:, 2] == 1).any(), "the fixture must exercise ssn.Pipeline"
+    st = e.stats()
+    assert st["spec_breaks"] >= 1
+
+
+def test_full_size_properties_config3():
+    """Size-independent properties at BASELINE's full 100k x 10k size (the oracle would take minutes here): node accounting
+    conservation, gang gating of the bind set, idempotence of a second cycle after reset, pod-count caps."""
+    snap = snapmod.synth(snapmod.synth_config(3))
+    cfg = conf.load_scheduler_conf()
+    e = engine.Engine(cfg)
+    e.load(snap)
+    dec = e.run(["allocate", "backfill"])
+    binds = e.binds()
+    st, nd = e.task_state()
+    idle, rel, nzc, nzm, cnt = e.node_state()
+    # every decision placed a Pending task exactly once
+    assert len(np.unique(dec[:, 0])) == len(dec) and (snap.task_status[dec[:, 0]] == abi.TASK_PENDING).all()
+    # Idle + sum of placed Resreq == snapshot Idle, per node and dimension (integer-valued float64: exact)
+    used = np.zeros_like(idle)
+    np.add.at(used.T, dec[:, 1], snap.task_resreq[:, dec[:, 0]].T)
+    assert np.array_equal(idle + used, snap.node_idle)
+    assert np.array_equal(cnt, snap.node_pod_cnt + np.bincount(dec[:, 1], minlength=snap.n_nodes).astype(np.int32))
+    assert (cnt <= snap.node_max_pods).all()
+    # gang gating: a task is bound iff its job reached minAvailable ready tasks
+    ready_status = np.isin(st, (abi.TASK_ALLOCATED, abi.TASK_BINDING, abi.TASK_BOUND, abi.TASK_RUNNING, abi.TASK_SUCCEEDED))
+    ready_per_job = np.add.reduceat(ready_status.astype(np.int64), snap.job_task_begin[:-1].astype(np.int64))
+    job_ready = ready_per_job >= snap.job_min_available
+    placed = np.zeros(snap.n_tasks, bool)
+    placed[dec[:, 0]] = True
+    assert np.array_equal(binds != abi.KB_NONE, placed & job_ready[snap.task_job])
+    assert (st[placed & ~job_ready[snap.task_job]] == abi.TASK_ALLOCATED).all()
+    # a second cycle from the pristine state is identical
+    e.reset()
+    dec2 = e.run(["allocate", "backfill"])
+    assert np.array_equal(dec, dec2) and np.array_equal(e.binds(), binds)
