@@ -110,6 +110,7 @@ struct kb_engine {
   uint32_t total_mask = 0;
   // round buffers
   DevBuf b_desc, b_trace;
+  DevBuf b_views;   // device copies of KbDev + KbRound for the commit kernel's rare paths
   bool trace_on = false;
   std::vector<double> trace_acc = std::vector<double>(3 * 4 * 12, 0.0);
   DevBuf b_sscore, b_smask, b_xslot;   // per-shape rows and row->shape map of kb_eval_matrix / kb_bench_matrix
@@ -369,7 +370,7 @@ void round_commit(kb_engine *e, const RoundCtx &c, unsigned long long *keys, dou
   r.own_row1 = own1;
   Timer &t5 = get_timer(e, 2);
   HIP_OK(hipEventRecord(t5.a, e->stream));
-  kb_launch_commit(c.d, r, e->stream);
+  kb_launch_commit(c.d, r, e->b_views.as<KbDev>(), reinterpret_cast<KbRound *>(e->b_views.as<unsigned char>() + ((sizeof(KbDev) + 15) & ~size_t(15))), e->stream);
   HIP_OK(hipEventRecord(t5.b, e->stream));
   HIP_OK(hipMemcpyAsync(e->h_result, e->b_result.p, sizeof(uint32_t) * 8, hipMemcpyDeviceToHost, e->stream));
   HIP_OK(hipMemcpyAsync(e->h_dec.data(), e->b_dec.p, sizeof(unsigned long long) * c.n, hipMemcpyDeviceToHost, e->stream));
@@ -623,6 +624,7 @@ int kb_engine_create(const kb_config *cfg, kb_engine **out) {
     HIP_OK(hipStreamCreateWithFlags(&eng->stream, hipStreamNonBlocking));
     HIP_OK(hipHostMalloc((void **)&eng->h_result, sizeof(uint32_t) * 8, hipHostMallocDefault));
     eng->b_result.alloc(sizeof(uint32_t) * 8);
+    eng->b_views.alloc(sizeof(KbDev) + sizeof(KbRound) + 64);
     if (const char *tr = getenv("KB_K5_TRACE")) {
       if (tr[0] == '1') { eng->trace_on = true; eng->b_trace.alloc(sizeof(unsigned long long) * 3 * 512 * 8); }
     }

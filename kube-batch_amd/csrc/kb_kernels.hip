@@ -93,6 +93,20 @@ __device__ __forceinline__ int div10(long long req, long long cap, double inv_ca
 }
 
 // One (task,node) evaluation.  Returns 0 if infeasible, else 0x10000 | score.
+// nodeorder's three resource scorers summed with their weights (scheduler_helper.go:162-168); shared by every evaluation path
+__device__ __forceinline__ uint32_t score_core(const TaskVals &t, const NodeVals &n, int wL, int wM, int wB) {
+  long long rc = n.nzc + t.nzc, rm = n.nzm + t.nzm;   // resource_allocation.go:100-112
+  int lc = 0, mc = 0, lm = 0, mm = 0, rem;
+  if (!(n.ac == 0 || rc > n.ac)) { mc = div10(rc, n.ac, n.inv_ac, rem); lc = 10 - mc - rem; }   // most/least_requested.go
+  if (!(n.am == 0 || rm > n.am)) { mm = div10(rm, n.am, n.inv_am, rem); lm = 10 - mm - rem; }
+  int least = (lc + lm) / 2, most = (mc + mm) / 2;
+  double cf = (n.ac == 0) ? 1.0 : (double)rc / (double)n.ac;      // balanced_resource_allocation.go:74-79
+  double mf = (n.am == 0) ? 1.0 : (double)rm / (double)n.am;
+  int bal = 0;
+  if (!(cf >= 1.0 || mf >= 1.0)) bal = (int)(long long)((1.0 - fabs(cf - mf)) * 10.0);
+  return (uint32_t)(least * wL + most * wM + bal * wB);
+}
+
 // class_row: nullptr -> look the class pair up in the global bit table; otherwise the task class's row of the table
 // (bit nc), e.g. staged in LDS by the commit kernel so that no global load sits on its critical path.
 __device__ __forceinline__ uint32_t eval_pair(const KbDev &d, const TaskVals &t, const NodeVals &n, uint32_t node, int fit_mode,
@@ -126,18 +140,7 @@ __device__ __forceinline__ uint32_t eval_pair(const KbDev &d, const TaskVals &t,
   }
   if (!ok) return 0;
   uint32_t score = 0;
-  if (d.score_enabled) {
-    long long rc = n.nzc + t.nzc, rm = n.nzm + t.nzm;   // resource_allocation.go:100-112
-    int lc = 0, mc = 0, lm = 0, mm = 0, rem;
-    if (!(n.ac == 0 || rc > n.ac)) { mc = div10(rc, n.ac, n.inv_ac, rem); lc = 10 - mc - rem; }   // most/least_requested.go
-    if (!(n.am == 0 || rm > n.am)) { mm = div10(rm, n.am, n.inv_am, rem); lm = 10 - mm - rem; }
-    int least = (lc + lm) / 2, most = (mc + mm) / 2;
-    double cf = (n.ac == 0) ? 1.0 : (double)rc / (double)n.ac;      // balanced_resource_allocation.go:74-79
-    double mf = (n.am == 0) ? 1.0 : (double)rm / (double)n.am;
-    int bal = 0;
-    if (!(cf >= 1.0 || mf >= 1.0)) bal = (int)(long long)((1.0 - fabs(cf - mf)) * 10.0);
-    score = (uint32_t)(least * d.wL + most * d.wM + bal * d.wB);
-  }
+  if (d.score_enabled) score = score_core(t, n, d.wL, d.wM, d.wB);
   return 0x10000u | (score & 0xFFFFu);
 }
 
@@ -459,11 +462,12 @@ __device__ __forceinline__ NodeVals k5_slot_vals(const unsigned long long *tab, 
 
 // scalar dimensions stay in global memory (rare path): NodeInfo.AddTask's Sub on dims >= 2, task bookkeeping, and the
 // multi-GPU per-node deltas
-__device__ __forceinline__ void k5_commit_globals(const KbDev &d, const KbRound &r, const KbRowDesc &k, double res0, double res1,
+__device__ __forceinline__ void k5_commit_globals(const KbCommitArgs &a, const KbRowDesc &k, double res0, double res1,
                                                   uint32_t i, uint32_t n, uint32_t kind) {
   uint32_t km = k.resmask;
   uint32_t has_map = 0;
   if (km) {
+    const KbDev &d = *a.dev;
     has_map = kind ? 1u : d.nmask[n];   // Sub returns early when the receiver's scalar map is nil (resource_info.go:148-153)
     if (has_map) {
       double *vec = kind ? d.rel : d.idle;
@@ -476,8 +480,11 @@ __device__ __forceinline__ void k5_commit_globals(const KbDev &d, const KbRound 
     }
   }
   // one 8-byte decision record; the task table (status, node, counted) is updated from the records by k_apply
-  *reinterpret_cast<uint2 *>(&r.dec[i]) = make_uint2(n, kind);
-  if (r.delta && i >= r.own_row0 && i < r.own_row1) {
+  *reinterpret_cast<uint2 *>(&a.dec[i]) = make_uint2(n, kind);
+  if (a.has_delta) {
+    const KbDev &d = *a.dev;
+    const KbRound &r = *a.round;
+    if (i >= r.own_row0 && i < r.own_row1) {
     // per-node committed deltas of the rows this rank owns: [dIdle R][dRel R][dnzc][dnzm][dpodcnt] x NP
     double *dv = r.delta + (size_t)(kind ? d.R : 0) * d.NP;
     dv[n] -= res0;
@@ -493,6 +500,7 @@ __device__ __forceinline__ void k5_commit_globals(const KbDev &d, const KbRound 
     tail[n] += (double)k.nzc;
     tail[(size_t)d.NP + n] += (double)k.nzm;
     tail[(size_t)2 * d.NP + n] += 1.0;
+    }
   }
 }
 
@@ -511,6 +519,47 @@ __device__ __forceinline__ void k5_commit_globals(const KbDev &d, const KbRound 
 // instruction (lane k reads field k from its own array) and a clean winner's slot is initialised by the same lanes with
 // ONE LDS store; two workgroup barriers per task.
 // ------------------------------------------------------------------------------------------------------------
+// eval_pair for the commit kernel: policy scalars from the by-value argument struct, session arrays (scalar resource
+// dimensions, wide class tables) through the device-memory copy of KbDev on the rare paths only
+__device__ __forceinline__ uint32_t eval_pair_k5(const KbCommitArgs &a, const TaskVals &t, const NodeVals &n, uint32_t node, const uint32_t *class_row) {
+  bool ok = true;
+  if (a.fit_mode) {   // allocate.go:81
+    bool fi = le_eps(t.init0, n.idle0, EPS_CPU) && le_eps(t.init1, n.idle1, EPS_MEM);
+    bool fr = le_eps(t.init0, n.rel0, EPS_CPU) && le_eps(t.init1, n.rel1, EPS_MEM);
+    uint32_t act = t.active >> 2;
+    if (act) {
+      const KbDev &d = *a.dev;
+      uint32_t dd = 2;
+      while (act) {
+        if (act & 1u) {
+          double l = d.t_init[(size_t)dd * d.T + t.task];
+          fi = fi && le_eps(l, d.idle[(size_t)dd * d.NP + node], EPS_SCALAR);
+          fr = fr && le_eps(l, d.rel[(size_t)dd * d.NP + node], EPS_SCALAR);
+        }
+        act >>= 1;
+        dd++;
+      }
+    }
+    ok = fi || fr;
+  }
+  if (a.pred_enabled) {
+    ok = ok && n.slots;
+    if (class_row) {
+      ok = ok && ((class_row[n.cls >> 5] >> (n.cls & 31)) & 1u);
+    } else {
+      const KbDev &d = *a.dev;
+      if (d.compat) {
+        uint32_t bit = t.cls * d.n_nc + n.cls;
+        ok = ok && ((d.compat[bit >> 3] >> (bit & 7)) & 1);
+      }
+    }
+  }
+  if (!ok) return 0;
+  uint32_t score = 0;
+  if (a.score_enabled) score = score_core(t, n, a.wL, a.wM, a.wB);
+  return 0x10000u | (score & 0xFFFFu);
+}
+
 // per-lane source arrays of the one-instruction node-state fetch: fld < 10 -> 8-byte field fld; 10..12 -> cls, maxpods, podcnt
 __device__ __forceinline__ void k5_field_ptrs(const KbDev &d, uint32_t fld, const unsigned long long *&g8, const uint32_t *&g4) {
   g8 = nullptr; g4 = nullptr;
@@ -559,7 +608,8 @@ __device__ __forceinline__ K5Pick k5_pick(const K5Mem M, uint32_t par) {
 
 // Live rescan of every CLEAN node (the candidate list ran out while still full; cannot happen with L > window).  All
 // waves take part: two barriers.  Returns the best clean key; H.cand is replaced by it.
-__device__ __forceinline__ unsigned long long k5_rescan(const KbDev &d, const KbRound &r, const K5Mem M, const KbRowDesc &cur) {
+__device__ __forceinline__ unsigned long long k5_rescan(const KbCommitArgs &a, const K5Mem M, const KbRowDesc &cur) {
+  const KbDev &d = *a.dev;
   const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   TaskVals tv;
   tv.init0 = cur.init0; tv.init1 = cur.init1; tv.nzc = cur.nzc; tv.nzm = cur.nzm;
@@ -568,7 +618,7 @@ __device__ __forceinline__ unsigned long long k5_rescan(const KbDev &d, const Kb
   for (uint32_t n = tid; n < d.N; n += KB_K5_THREADS) {
     if (bit_test(M.bitmap, n)) continue;
     NodeVals nv = load_node(d, n);
-    uint32_t res = eval_pair(d, tv, nv, n, r.fit_mode);
+    uint32_t res = eval_pair(d, tv, nv, n, a.fit_mode);
     if (res) { unsigned long long k3 = KB_KEY(res & 0xFFFFu, n); k2 = k3 > k2 ? k3 : k2; }
   }
   k2 = wave_max_key(k2);
@@ -581,12 +631,12 @@ __device__ __forceinline__ unsigned long long k5_rescan(const KbDev &d, const Kb
 }
 
 #ifdef KB_K5_TRACE
-#define K5R_DECL(role) const bool trc = r.trace != nullptr && (threadIdx.x & 63) == 0 && ((role) != 0 || threadIdx.x == 0); unsigned long long tr0 = 0, tr1 = 0, tr2 = 0, tr3 = 0;
+#define K5R_DECL(role) const bool trc = a.trace != nullptr && (threadIdx.x & 63) == 0 && ((role) != 0 || threadIdx.x == 0); unsigned long long tr0 = 0, tr1 = 0, tr2 = 0, tr3 = 0;
 #define K5R_T0() do { if (trc) tr0 = __builtin_readcyclecounter(); } while (0)
 #define K5R_T1() do { if (trc) tr1 = __builtin_readcyclecounter(); } while (0)
 #define K5R_T2() do { if (trc) tr2 = __builtin_readcyclecounter(); } while (0)
 #define K5R_T3() do { if (trc) tr3 = __builtin_readcyclecounter(); } while (0)
-#define K5R_END(role, i, cw, same) do { if (trc && (i) < 512) { unsigned long long *dst = r.trace + ((size_t)(role) * 512 + (i)) * 8; dst[0] = tr0; dst[1] = tr1; dst[2] = tr2; dst[3] = tr3; dst[4] = __builtin_readcyclecounter(); dst[5] = ((cw) ? 1ull : 0ull) | ((same) ? 2ull : 0ull); } } while (0)
+#define K5R_END(role, i, cw, same) do { if (trc && (i) < 512) { unsigned long long *dst = a.trace + ((size_t)(role) * 512 + (i)) * 8; dst[0] = tr0; dst[1] = tr1; dst[2] = tr2; dst[3] = tr3; dst[4] = __builtin_readcyclecounter(); dst[5] = ((cw) ? 1ull : 0ull) | ((same) ? 2ull : 0ull); } } while (0)
 #else
 #define K5R_DECL(role)
 #define K5R_T0() do { } while (0)
@@ -597,18 +647,20 @@ __device__ __forceinline__ unsigned long long k5_rescan(const KbDev &d, const Kb
 #endif
 
 // ---- role: evaluation waves (own the dirty slots) --------------------------------------------------------------
-__device__ __forceinline__ void k5_eval_role(const KbDev &d, const KbRound &r, const K5Mem M, uint32_t &nd_out, uint32_t &n_done, uint32_t &reason) {
+__device__ __forceinline__ void k5_eval_role(const KbCommitArgs a, const K5Mem M, uint32_t &nd_out, uint32_t &n_done, uint32_t &reason) {
   const uint32_t tid = threadIdx.x, lane = tid & 63, cap = M.cap;
   K5Hdr &H = *M.H;
-  const bool use_crow = d.pred_enabled && d.crows != nullptr && d.n_nc <= 32;
   unsigned long long ck[K5_SPT];     // cached keys of the dirty slots this thread owns, valid for shape `prev_shape`
 #pragma unroll
   for (int j = 0; j < K5_SPT; j++) ck[j] = 0ull;
   unsigned long long wmax = 0ull;    // this wave's max over ck[], valid while no lane of the wave re-evaluates
   uint32_t prev_shape = 0xFFFFFFFFu, nd = 0, last_slot = 0xFFFFFFFFu;
   K5R_DECL(0)
-  for (uint32_t i = 0; i < r.n_rows; i++) {
+  const uint32_t tid_id = tid, lane_id = lane;
+  for (uint32_t i = 0; i < a.n_rows; i++) {
     K5R_T0();
+    uint32_t tid = tid_id, lane = lane_id;   // opaque per row: keeps thread/lane masks out of (spilled) SGPR pairs
+    asm volatile("" : "+v"(tid), "+v"(lane));
     const uint32_t par = i & 1;
     const KbRowDesc &cur = M.desc[i];
     const uint32_t shape = cur.slot;
@@ -626,14 +678,14 @@ __device__ __forceinline__ void k5_eval_role(const KbDev &d, const KbRound &r, c
         TaskVals tv;
         tv.init0 = cur.init0; tv.init1 = cur.init1; tv.nzc = cur.nzc; tv.nzm = cur.nzm;
         tv.cls = cur.cls; tv.active = cur.active; tv.task = cur.task; tv.pad = 0;
-        const uint32_t *crow = use_crow ? &cur.crow : nullptr;
+        const uint32_t *crow = a.use_crow ? &cur.crow : nullptr;
 #pragma unroll
         for (int j = 0; j < K5_SPT; j++) {
           uint32_t slot = tid + j * K5_EVAL;
           if (slot < nd && (!same || slot == last_slot)) {
             NodeVals nv = k5_slot_vals(M.tab, M.t_cls, M.t_left, cap, slot);
             uint32_t node = M.t_node[slot];
-            uint32_t res = eval_pair(d, tv, nv, node, r.fit_mode, crow);
+            uint32_t res = eval_pair_k5(a, tv, nv, node, crow);
             ck[j] = res ? KB_KEY(res & 0xFFFFu, node) : 0ull;
           }
         }
@@ -650,10 +702,10 @@ __device__ __forceinline__ void k5_eval_role(const KbDev &d, const KbRound &r, c
     // ---- phase 2
     K5Pick p = k5_pick(M, par);
     if (tid == 0) H.best[par ^ 1] = 0ull;
-    if (p.exhausted) { unsigned long long bc = k5_rescan(d, r, M, cur); p.cand = bc; p.best = bc > p.best ? bc : p.best; }
+    if (p.exhausted) { unsigned long long bc = k5_rescan(a, M, cur); p.cand = bc; p.best = bc > p.best ? bc : p.best; }
     if (p.best == 0ull) {
-      if (r.backfill) {   // backfill.go:50-66: no node passes the predicates -> the task simply stays Pending
-        if (tid == 0) *reinterpret_cast<uint2 *>(&r.dec[i]) = make_uint2(KB_NONE_U32, 0u);
+      if (a.backfill) {   // backfill.go:50-66: no node passes the predicates -> the task simply stays Pending
+        if (tid == 0) *reinterpret_cast<uint2 *>(&a.dec[i]) = make_uint2(KB_NONE_U32, 0u);
         __syncthreads();
         n_done = i + 1;
         continue;
@@ -673,15 +725,18 @@ __device__ __forceinline__ void k5_eval_role(const KbDev &d, const KbRound &r, c
           // and a global address (the compiler would turn that into flat loads with a full vmcnt+lgkmcnt drain)
           double res0 = cur.init0, res1 = cur.init1;
           asm volatile("" : "+v"(res0), "+v"(res1));   // materialise the LDS values here: no pointer phi -> no flat load
-          if (!(__builtin_amdgcn_readfirstlane((int)cur.flags) & 1)) { res0 = d.t_res[cur.task]; res1 = d.t_res[(size_t)d.T + cur.task]; }
+          if (!(__builtin_amdgcn_readfirstlane((int)cur.flags) & 1)) { const KbDev &d = *a.dev; res0 = d.t_res[cur.task]; res1 = d.t_res[(size_t)d.T + cur.task]; }
           uint32_t kind = 0;
-          if (!r.backfill) {   // allocate.go:160: InitResreq.LessEqual(node.Idle) ? Allocate : Pipeline
+          if (!a.backfill) {   // allocate.go:160: InitResreq.LessEqual(node.Idle) ? Allocate : Pipeline
             bool fi = le_eps(cur.init0, __longlong_as_double((long long)M.tab[K5F_IDLE0 * cap + slot]), EPS_CPU) &&
                       le_eps(cur.init1, __longlong_as_double((long long)M.tab[K5F_IDLE1 * cap + slot]), EPS_MEM);
-            uint32_t a = cur.active >> 2, dd = 2;
-            while (a) {
-              if (a & 1u) fi = fi && le_eps(d.t_init[(size_t)dd * d.T + cur.task], d.idle[(size_t)dd * d.NP + n], EPS_SCALAR);
-              a >>= 1; dd++;
+            uint32_t act = cur.active >> 2, dd = 2;
+            if (act) {
+              const KbDev &d = *a.dev;
+              while (act) {
+                if (act & 1u) fi = fi && le_eps(d.t_init[(size_t)dd * d.T + cur.task], d.idle[(size_t)dd * d.NP + n], EPS_SCALAR);
+                act >>= 1; dd++;
+              }
             }
             kind = fi ? 0u : 1u;
           }
@@ -692,7 +747,7 @@ __device__ __forceinline__ void k5_eval_role(const KbDev &d, const KbRound &r, c
           M.tab[(size_t)K5F_NZM * cap + slot] += (unsigned long long)cur.nzm;
           M.t_left[slot] -= 1;
           *reinterpret_cast<uint2 *>(&H.last_slot) = make_uint2(slot, kind);
-          k5_commit_globals(d, r, cur, res0, res1, i, n, kind);
+          k5_commit_globals(a, cur, res0, res1, i, n, kind);
         }
       }
     }
@@ -709,7 +764,7 @@ __device__ __forceinline__ void k5_eval_role(const KbDev &d, const KbRound &r, c
 }
 
 // ---- role: loader wave (every global load of the loop, a full row ahead, landed in LDS staging) -----------------
-__device__ __forceinline__ void k5_load_role(const KbDev &d, const KbRound &r, const K5Mem M, uint32_t &nd_out, uint32_t &n_done, uint32_t &reason) {
+__device__ __forceinline__ void k5_load_role(const KbCommitArgs a, const K5Mem M, uint32_t &nd_out, uint32_t &n_done, uint32_t &reason) {
   const uint32_t lane = threadIdx.x & 63;
   K5Hdr &H = *M.H;
   // lane (g*16 + k) reads field k of one node with ONE load instruction per width: k < 10: 8-byte field k from its own
@@ -717,7 +772,7 @@ __device__ __forceinline__ void k5_load_role(const KbDev &d, const KbRound &r, c
   const uint32_t fld = lane & 15, grp = lane >> 4;
   const unsigned long long *g8 = nullptr;
   const uint32_t *g4 = nullptr;
-  if (grp < 2) k5_field_ptrs(d, fld, g8, g4);
+  if (grp < 2) k5_field_ptrs(*a.dev, fld, g8, g4);
   unsigned long long pw_key = 0ull;   // candidate window being fetched, one entry per lane
   uint32_t pw_base = 0;
   unsigned long long ps8 = 0ull;      // node states being fetched: lane groups 0/1 -> staging slots 0/1
@@ -725,10 +780,13 @@ __device__ __forceinline__ void k5_load_role(const KbDev &d, const KbRound &r, c
   uint32_t ps_tag0 = 0xFFFFFFFFu, ps_tag1 = 0xFFFFFFFFu;   // nodes in flight for staging slot 0 / 1
   uint32_t ls_tag0 = 0xFFFFFFFFu, ls_tag1 = 0xFFFFFFFFu;   // what the staging slots hold / will hold
   uint32_t inv_node = 0xFFFFFFFFu, nd = 0;
-  if (r.n_rows > 1) pw_key = (lane < r.L) ? r.keys[(size_t)M.desc[1].slot * r.L + lane] : 0ull;
+  if (a.n_rows > 1) pw_key = (lane < a.L) ? a.keys[(size_t)M.desc[1].slot * a.L + lane] : 0ull;
   K5R_DECL(1)
-  for (uint32_t i = 0; i < r.n_rows; i++) {
+  const uint32_t lane_id = lane, fld_id = fld, grp_id = grp;
+  for (uint32_t i = 0; i < a.n_rows; i++) {
     K5R_T0();
+    uint32_t lane = lane_id, fld = fld_id, grp = grp_id;   // opaque per row (see the candidate role)
+    asm volatile("" : "+v"(lane), "+v"(fld), "+v"(grp));
     const uint32_t par = i & 1;
     // ---- phase 1: drop the copy of the node the previous row committed (it is dirty now), land the states requested in
     //      the previous row's phase 2 (consumed by this row's commit)
@@ -751,7 +809,7 @@ __device__ __forceinline__ void k5_load_role(const KbDev &d, const KbRound &r, c
     K5Pick p = k5_pick(M, par);
     // (a) hand the next row's candidate window (requested a row ago) to the candidate wave and stage the states of its
     //     first two clean nodes: whichever of them survives this row's commit is the next row's clean candidate
-    if (i + 1 < r.n_rows) {
+    if (i + 1 < a.n_rows) {
       const uint32_t nshape = M.desc[i + 1].slot;
       H.win[par ^ 1][lane] = pw_key;
       if (lane == 0) H.win_base[par ^ 1] = pw_base;
@@ -783,15 +841,15 @@ __device__ __forceinline__ void k5_load_role(const KbDev &d, const KbRound &r, c
       }
     }
     // (b) request the window of the row after next
-    if (i + 2 < r.n_rows) {
+    if (i + 2 < a.n_rows) {
       const uint32_t n2shape = M.desc[i + 2].slot;
       pw_base = M.cursor[n2shape];   // may lag: stale entries are filtered by the dirty bitmap when the window is used
       uint32_t e = pw_base + lane;
-      pw_key = (e < r.L) ? r.keys[(size_t)n2shape * r.L + e] : 0ull;
+      pw_key = (e < a.L) ? a.keys[(size_t)n2shape * a.L + e] : 0ull;
     }
-    if (p.exhausted) { unsigned long long bc = k5_rescan(d, r, M, M.desc[i]); p.cand = bc; p.best = bc > p.best ? bc : p.best; }
+    if (p.exhausted) { unsigned long long bc = k5_rescan(a, M, M.desc[i]); p.cand = bc; p.best = bc > p.best ? bc : p.best; }
     if (p.best == 0ull) {
-      if (r.backfill) { __syncthreads(); n_done = i + 1; inv_node = 0xFFFFFFFFu; continue; }
+      if (a.backfill) { __syncthreads(); n_done = i + 1; inv_node = 0xFFFFFFFFu; continue; }
       n_done = i; reason = KB_REASON_NO_FEASIBLE;
       break;
     }
@@ -809,19 +867,24 @@ __device__ __forceinline__ void k5_load_role(const KbDev &d, const KbRound &r, c
 }
 
 // ---- role: candidate wave (walks the candidate lists, commits clean winners) -------------------------------------
-__device__ __forceinline__ void k5_cand_role(const KbDev &d, const KbRound &r, const K5Mem M, uint32_t &nd_out, uint32_t &n_done, uint32_t &reason) {
-  const uint32_t lane = threadIdx.x & 63, cap = M.cap;
+__device__ __forceinline__ void k5_cand_role(const KbCommitArgs a, const K5Mem M, uint32_t &nd_out, uint32_t &n_done, uint32_t &reason) {
+  const uint32_t lane0 = threadIdx.x & 63, cap = M.cap;
   K5Hdr &H = *M.H;
   const unsigned long long *g8 = nullptr;   // synchronous miss path: lanes 0..12 fetch the node's fields
   const uint32_t *g4 = nullptr;
-  if (lane < 16) k5_field_ptrs(d, lane, g8, g4);
+  if (lane0 < 16) k5_field_ptrs(*a.dev, lane0, g8, g4);
   // the current shape's window (keys per lane), mask of its clean lanes, mask of its empty lanes
   unsigned long long wkey = 0ull, wb = 0ull, wzero = 0ull;
   uint32_t wbase = 0, prev_shape = 0xFFFFFFFFu, nd = 0;
   bool wvalid = false, prev_clean_win = false;
   K5R_DECL(2)
-  for (uint32_t i = 0; i < r.n_rows; i++) {
+  const uint32_t lane_id = lane0;
+  for (uint32_t i = 0; i < a.n_rows; i++) {
     K5R_T0();
+    // re-materialise the lane id every row: otherwise every `lane == k` mask is hoisted out of the loop as an SGPR pair, the
+    // kernel runs out of SGPRs and each mask is spilled to / restored from VGPR lanes (v_readlane pairs) at every use
+    uint32_t lane = lane_id;
+    asm volatile("" : "+v"(lane));
     const uint32_t par = i & 1;
     const KbRowDesc &cur = M.desc[i];
     const uint32_t shape = cur.slot;
@@ -858,9 +921,9 @@ __device__ __forceinline__ void k5_cand_role(const KbDev &d, const KbRound &r, c
       if (wzero) { list_end = true; break; }            // ran past the last feasible node: no clean candidate exists
       wbase += 64;
       curs = wbase;
-      if (wbase >= r.L) break;                          // list exhausted while still full: live rescan
+      if (wbase >= a.L) break;                          // list exhausted while still full: live rescan
       uint32_t e = wbase + lane;
-      wkey = (e < r.L) ? r.keys[(size_t)shape * r.L + e] : 0ull;
+      wkey = (e < a.L) ? a.keys[(size_t)shape * a.L + e] : 0ull;
       const bool nz = wkey != 0ull;
       wb = __ballot(nz && !bit_test(M.bitmap, KB_KEY_NODE(wkey)));
       wzero = __ballot(!nz);
@@ -876,9 +939,9 @@ __device__ __forceinline__ void k5_cand_role(const KbDev &d, const KbRound &r, c
     K5R_T2();
     // ---- phase 2
     K5Pick p = k5_pick(M, par);
-    if (p.exhausted) { unsigned long long bc = k5_rescan(d, r, M, cur); p.cand = bc; p.best = bc > p.best ? bc : p.best; wvalid = false; }
+    if (p.exhausted) { unsigned long long bc = k5_rescan(a, M, cur); p.cand = bc; p.best = bc > p.best ? bc : p.best; wvalid = false; }
     if (p.best == 0ull) {
-      if (r.backfill) { __syncthreads(); n_done = i + 1; prev_clean_win = false; continue; }
+      if (a.backfill) { __syncthreads(); n_done = i + 1; prev_clean_win = false; continue; }
       n_done = i; reason = KB_REASON_NO_FEASIBLE;
       break;
     }
@@ -890,7 +953,7 @@ __device__ __forceinline__ void k5_cand_role(const KbDev &d, const KbRound &r, c
       const uint32_t n = KB_KEY_NODE(p.best);
       double res0 = cur.init0, res1 = cur.init1;   // scalar branch, not an LDS/global address select (see the eval role)
       asm volatile("" : "+v"(res0), "+v"(res1));
-      if (!(__builtin_amdgcn_readfirstlane((int)cur.flags) & 1)) { res0 = d.t_res[cur.task]; res1 = d.t_res[(size_t)d.T + cur.task]; }
+      if (!(__builtin_amdgcn_readfirstlane((int)cur.flags) & 1)) { const KbDev &d = *a.dev; res0 = d.t_res[cur.task]; res1 = d.t_res[(size_t)d.T + cur.task]; }
       unsigned long long st8 = 0ull;
       uint32_t st4 = 0;
       const uint2 tags = *reinterpret_cast<const uint2 *>(&H.cs_tag[0]);
@@ -905,15 +968,17 @@ __device__ __forceinline__ void k5_cand_role(const KbDev &d, const KbRound &r, c
       }
       double v = __longlong_as_double((long long)st8);
       uint32_t kind = 0;
-      if (!r.backfill) {   // allocate.go:160: InitResreq.LessEqual(node.Idle) ? Allocate : Pipeline
-        bool ok = true;
-        if (lane == K5F_IDLE0) ok = le_eps(cur.init0, v, EPS_CPU);
-        if (lane == K5F_IDLE1) ok = le_eps(cur.init1, v, EPS_MEM);
+      if (!a.backfill) {   // allocate.go:160: InitResreq.LessEqual(node.Idle) ? Allocate : Pipeline
+        // lanes 0 / 1 hold Idle cpu / memory: straight-line compare with per-lane operands, other lanes pass
+        const double ini = (lane == K5F_IDLE0) ? cur.init0 : cur.init1;
+        const double eps = (lane == K5F_IDLE0) ? EPS_CPU : EPS_MEM;
+        bool ok = (lane > K5F_IDLE1) || le_eps(ini, v, eps);
         if (lane == 63 && (cur.active >> 2)) {   // scalar dimensions (rare): compared against live global state
-          uint32_t a = cur.active >> 2, dd = 2;
-          while (a) {
-            if (a & 1u) ok = ok && le_eps(d.t_init[(size_t)dd * d.T + cur.task], d.idle[(size_t)dd * d.NP + n], EPS_SCALAR);
-            a >>= 1; dd++;
+          const KbDev &d = *a.dev;
+          uint32_t act = cur.active >> 2, dd = 2;
+          while (act) {
+            if (act & 1u) ok = ok && le_eps(d.t_init[(size_t)dd * d.T + cur.task], d.idle[(size_t)dd * d.NP + n], EPS_SCALAR);
+            act >>= 1; dd++;
           }
         }
         kind = __ballot(!ok) ? 1u : 0u;
@@ -937,7 +1002,7 @@ __device__ __forceinline__ void k5_cand_role(const KbDev &d, const KbRound &r, c
       if (lane == 0) {
         atomicOr(&M.bitmap[n >> 5], 1u << (n & 31));
         *reinterpret_cast<uint2 *>(&H.last_slot) = make_uint2(nd, kind);
-        k5_commit_globals(d, r, cur, res0, res1, i, n, kind);
+        k5_commit_globals(a, cur, res0, res1, i, n, kind);
       }
     }
     K5R_T3();
@@ -952,10 +1017,11 @@ __device__ __forceinline__ void k5_cand_role(const KbDev &d, const KbRound &r, c
   nd_out = nd;
 }
 
-__global__ void __launch_bounds__(KB_K5_THREADS) k_commit(KbDev d, KbRound r) {
+__global__ void __launch_bounds__(KB_K5_THREADS) k_commit(const KbCommitArgs a) {
+  const KbDev &d = *a.dev;
   extern __shared__ __align__(16) unsigned char k5_smem[];
   K5Mem M;
-  M.cap = r.cap;
+  M.cap = a.cap;
   M.tab = reinterpret_cast<unsigned long long *>(k5_smem);
   M.t_cls = reinterpret_cast<uint32_t *>(M.tab + (size_t)K5_NF8 * M.cap);
   M.t_node = M.t_cls + M.cap;
@@ -963,16 +1029,16 @@ __global__ void __launch_bounds__(KB_K5_THREADS) k_commit(KbDev d, KbRound r) {
   M.cursor = reinterpret_cast<uint32_t *>(M.t_left + M.cap);
   M.desc = reinterpret_cast<KbRowDesc *>(M.cursor + M.cap);
   M.bitmap = reinterpret_cast<uint32_t *>(M.desc + M.cap);
-  M.H = reinterpret_cast<K5Hdr *>(M.bitmap + d.NP / 32);
+  M.H = reinterpret_cast<K5Hdr *>(M.bitmap + a.NP / 32);
   K5Hdr &H = *M.H;
   const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, cap = M.cap;
 
   for (uint32_t w = tid; w < d.NP / 32; w += KB_K5_THREADS) M.bitmap[w] = 0;
   for (uint32_t w = tid; w < cap; w += KB_K5_THREADS) M.cursor[w] = 0;
   {   // stage the window's row descriptors (coalesced 8-byte copies)
-    const unsigned long long *src = reinterpret_cast<const unsigned long long *>(r.desc);
+    const unsigned long long *src = reinterpret_cast<const unsigned long long *>(a.desc);
     unsigned long long *dst = reinterpret_cast<unsigned long long *>(M.desc);
-    const uint32_t nq = r.n_rows * (uint32_t)(sizeof(KbRowDesc) / 8);
+    const uint32_t nq = a.n_rows * (uint32_t)(sizeof(KbRowDesc) / 8);
     for (uint32_t w = tid; w < nq; w += KB_K5_THREADS) dst[w] = src[w];
   }
   if (tid == 0) {
@@ -997,21 +1063,21 @@ __global__ void __launch_bounds__(KB_K5_THREADS) k_commit(KbDev d, KbRound r) {
 #pragma unroll
     for (int a = 0; a < 3; a++)
       for (uint32_t l = tid; l < d.NP / 32; l += KB_K5_THREADS) acc += arr4[a][(size_t)l * 32];
-    const size_t klines = ((size_t)r.n_mrows * r.L + 15) / 16;
-    for (size_t l = tid; l < klines; l += KB_K5_THREADS) acc += r.keys[l * 16];
+    const size_t klines = ((size_t)a.n_mrows * a.L + 15) / 16;
+    for (size_t l = tid; l < klines; l += KB_K5_THREADS) acc += a.keys[l * 16];
     if (acc == 0x123456789abcdefull) H.pad0 = 1;   // keep the loads alive
   }
   __syncthreads();
-  if (wave == K5_WAVES - 2) H.win[0][lane] = (lane < r.L) ? r.keys[(size_t)M.desc[0].slot * r.L + lane] : 0ull;   // row 0's window
+  if (wave == K5_WAVES - 2) H.win[0][lane] = (lane < a.L) ? a.keys[(size_t)M.desc[0].slot * a.L + lane] : 0ull;   // row 0's window
   __syncthreads();
 
   // Three specialised loops that only meet at the two barriers per row: waves 0..W-3 own the dirty slots, wave W-2 is the
   // loader, wave W-1 walks the candidate lists and commits clean winners.  Every role derives the same control decisions
   // (continue / stop / rescan) from the same LDS words, so the barrier counts always match.
   uint32_t nd = 0, n_done = 0, reason = KB_REASON_DONE;
-  if (wave == K5_WAVES - 1) k5_cand_role(d, r, M, nd, n_done, reason);
-  else if (wave == K5_WAVES - 2) k5_load_role(d, r, M, nd, n_done, reason);
-  else k5_eval_role(d, r, M, nd, n_done, reason);
+  if (wave == K5_WAVES - 1) k5_cand_role(a, M, nd, n_done, reason);
+  else if (wave == K5_WAVES - 2) k5_load_role(a, M, nd, n_done, reason);
+  else k5_eval_role(a, M, nd, n_done, reason);
 
   // ---- write the dirty nodes' live state back to HBM
   __syncthreads();
@@ -1025,7 +1091,7 @@ __global__ void __launch_bounds__(KB_K5_THREADS) k_commit(KbDev d, KbRound r) {
     d.nzm[n] = (long long)M.tab[K5F_NZM * cap + slot];
     d.podcnt[n] = d.maxpods[n] - M.t_left[slot];
   }
-  if (tid == 0) { r.result[0] = n_done; r.result[1] = reason; r.result[2] = nd; r.result[3] = H.rescans & 0xFFFFu; r.result[4] = H.refills & 0xFFFFu; r.result[5] = H.refills >> 16; r.result[6] = H.rescans >> 16; }
+  if (tid == 0) { a.result[0] = n_done; a.result[1] = reason; a.result[2] = nd; a.result[3] = H.rescans & 0xFFFFu; a.result[4] = H.refills & 0xFFFFu; a.result[5] = H.refills >> 16; a.result[6] = H.rescans >> 16; }
 }
 
 // task-table side of ssn.Allocate / ssn.Pipeline for the rows the commit kernel processed (job.UpdateTaskStatus,
@@ -1164,7 +1230,10 @@ void kb_launch_argmax(const KbDev &d, const KbRound &r, void *stream) {
   }
   hipLaunchKernelGGL(k_argmax, dim3(r.n_mrows), dim3(256), sh, (hipStream_t)stream, d, r);
 }
-void kb_launch_commit(const KbDev &d, const KbRound &r, void *stream) {
+// the session / round views the commit kernel dereferences on its rare paths, written stream-ordered before the launch
+__global__ void k_store_views(KbDev d, KbRound r, KbDev *dd, KbRound *dr) { *dd = d; *dr = r; }
+
+void kb_launch_commit(const KbDev &d, const KbRound &r, KbDev *dev_copy, KbRound *round_copy, void *stream) {
   if (r.n_rows == 0) return;
   size_t sh = k5_smem_bytes(r.cap, d.NP);
   static bool attr_set = false;
@@ -1172,7 +1241,16 @@ void kb_launch_commit(const KbDev &d, const KbRound &r, void *stream) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_commit), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
-  hipLaunchKernelGGL(k_commit, dim3(1), dim3(KB_K5_THREADS), sh, (hipStream_t)stream, d, r);
+  hipLaunchKernelGGL(k_store_views, dim3(1), dim3(1), 0, (hipStream_t)stream, d, r, dev_copy, round_copy);
+  KbCommitArgs a;
+  a.dev = dev_copy; a.round = round_copy;
+  a.keys = r.keys; a.dec = r.dec; a.desc = r.desc; a.result = r.result; a.trace = r.trace;
+  a.n_rows = r.n_rows; a.n_mrows = r.n_mrows; a.L = r.L; a.cap = r.cap; a.N = d.N; a.NP = d.NP;
+  a.fit_mode = r.fit_mode; a.backfill = r.backfill; a.pred_enabled = d.pred_enabled; a.score_enabled = d.score_enabled;
+  a.wL = d.wL; a.wM = d.wM; a.wB = d.wB;
+  a.use_crow = (d.pred_enabled && d.crows != nullptr && d.n_nc <= 32) ? 1u : 0u;
+  a.has_delta = r.delta != nullptr ? 1u : 0u;
+  hipLaunchKernelGGL(k_commit, dim3(1), dim3(KB_K5_THREADS), sh, (hipStream_t)stream, a);
   hipLaunchKernelGGL(k_apply, dim3((r.n_rows + 255) / 256), dim3(256), 0, (hipStream_t)stream, d, r);
 }
 void kb_launch_finalize(const KbDev &d, const uint32_t *job_task_begin, const int *job_min_avail, const uint32_t *job_queue,
