@@ -116,14 +116,16 @@ struct KbCommitArgs {
   uint32_t n_rows, n_mrows, L, cap, N, NP;
   int fit_mode, backfill, pred_enabled, score_enabled, wL, wM, wB;
   uint32_t use_crow, has_delta;
+  int R;
+  uint32_t batch;   // rows speculated per batch (<= 32)
 };
 
 #define KB_K5_MAX_WINDOW 1024u   // dirty-node table + row descriptors of the commit kernel live in LDS: 152 B per row
 
 // dynamic LDS the commit kernel needs for `cap` slots over NP padded nodes (kb_kernels.hip)
-size_t kb_commit_smem_bytes(uint32_t cap, uint32_t NP);
+size_t kb_commit_smem_bytes(uint32_t cap, uint32_t NP, int R);
 
-enum { KB_REASON_DONE = 0, KB_REASON_NO_FEASIBLE = 1, KB_REASON_PIPELINED = 2 };
+enum { KB_REASON_DONE = 0, KB_REASON_NO_FEASIBLE = 1, KB_REASON_PIPELINED = 2, KB_REASON_INTERNAL = 3 };
 
 // launch wrappers (kb_kernels.hip); all asynchronous on `stream`
 void kb_launch_gather(const KbDev &d, const KbRound &r, void *stream);

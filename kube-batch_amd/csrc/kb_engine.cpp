@@ -103,6 +103,7 @@ struct kb_engine {
   // session buffers
   DevBuf b_idle, b_rel, b_nzc, b_nzm, b_podcnt, b_acpu, b_amem, b_maxpods, b_ncls, b_nmask, b_invac, b_invam;
   uint64_t stage_hits = 0, stage_misses = 0;   // commit kernel: clean winners whose state was staged by the loader / fetched synchronously
+  unsigned long long full_evals = 0;
   uint32_t eff_window = 0;   // window actually used for this session (bounded by the commit kernel's LDS budget)
   DevBuf b_tinit, b_tres, b_tnzc, b_tnzm, b_tcls, b_tactive, b_tresmask, b_tjob, b_tstatus, b_tnode, b_tbind, b_tcounted, b_compat, b_crows;
   DevBuf p_idle, p_rel, p_nzc, p_nzm, p_podcnt, p_tstatus, p_tnode, p_tcounted;   // pristine copies for kb_session_reset
@@ -395,29 +396,16 @@ void round_collect(kb_engine *e, const RoundCtx &c, bool had_candidates, uint32_
   e->stats.commit_ms += ms;
   n_done = e->h_result[0];
   reason = e->h_result[1];
-  if (e->trace_on) {   // KB_K5_TRACE=1 (and make TRACE=1): per role (eval thread 0, loader, candidate wave), first 512 rows of every round
-    std::vector<unsigned long long> tr(3 * 512 * 8);
-    HIP_OK(hipMemcpy(tr.data(), e->b_trace.p, sizeof(unsigned long long) * tr.size(), hipMemcpyDeviceToHost));
-    uint32_t m = std::min<uint32_t>(n_done, 512);
-    for (int role = 0; role < 3; role++)
-      for (uint32_t i = 0; i + 1 < m; i++) {
-        const unsigned long long *a = &tr[((size_t)role * 512 + i) * 8], *nx = &tr[((size_t)role * 512 + i + 1) * 8];
-        const unsigned long long *c0 = &tr[((size_t)2 * 512 + i) * 8];
-        if (!a[4] || !nx[0] || !c0[4]) continue;
-        int cls = (int)(c0[5] & 3);   // classify rows by the candidate wave's view: bit0 clean wins, bit1 same shape
-        double *acc = &e->trace_acc[((size_t)role * 4 + cls) * 12];
-        acc[0] += (double)(a[1] - a[0]);      // phase-1 work
-        acc[1] += (double)(a[2] - a[1]);      // wait at barrier 1
-        acc[2] += (double)(a[3] - a[2]);      // phase-2 work
-        acc[3] += (double)(a[4] - a[3]);      // wait at barrier 2
-        acc[4] += (double)(nx[0] - a[4]);     // loop tail
-        acc[5] += (double)(nx[0] - a[0]);     // row total
-        acc[10] += 1.0;
-      }
+  if (reason == KB_REASON_INTERNAL) throw EngineError(KB_E_INTERNAL, "commit kernel ran out of candidate list entries (list shorter than the window)");
+  if (e->trace_on) {   // KB_K5_TRACE=1 (and make TRACE=1): cycles thread 0 spent in each step of the commit kernel
+    unsigned long long tr[12];
+    HIP_OK(hipMemcpy(tr, e->b_trace.p, sizeof(tr), hipMemcpyDeviceToHost));
+    for (int k = 0; k < 12; k++) e->trace_acc[k] += (double)tr[k];
   }
   e->stats.row_fallbacks += e->h_result[3];
   e->stage_hits += e->h_result[5];
   e->stage_misses += e->h_result[6];
+  e->full_evals += e->h_result[7];
   e->stats.rounds += 1;
   e->round_no += 1;
 }
@@ -636,17 +624,16 @@ int kb_engine_create(const kb_config *cfg, kb_engine **out) {
 
 void kb_engine_destroy(kb_engine *e) {
   if (!e) return;
-  if (getenv("KB_K5_STATS")) fprintf(stderr, "[kb K5] staged-state hits %llu, misses %llu\n", (unsigned long long)e->stage_hits, (unsigned long long)e->stage_misses);
+  if (getenv("KB_K5_STATS"))
+    fprintf(stderr, "[kb K5] batches %llu, dirty rows %llu, full shape evaluations %llu, rows %llu\n", (unsigned long long)e->stage_hits,
+            (unsigned long long)e->stage_misses, e->full_evals, (unsigned long long)e->stats.decisions);
   if (e->trace_on) {
-    static const char *roles[3] = {"eval thread 0", "loader wave", "candidate wave"};
-    static const char *cls[4] = {"dirty wins, new shape", "clean wins, new shape", "dirty wins, same shape", "clean wins, same shape"};
-    for (int c = 0; c < 4; c++)
-      for (int role = 0; role < 3; role++) {
-        const double *acc = &e->trace_acc[((size_t)role * 4 + c) * 12];
-        if (acc[10] < 1) continue;
-        fprintf(stderr, "[kb K5 trace] %-22s | %-14s | %6.0f rows | phase1 %5.0f  wait-b1 %5.0f  phase2 %5.0f  wait-b2 %5.0f  tail %4.0f | row %5.0f clocks\n",
-                cls[c], roles[role], acc[10], acc[0] / acc[10], acc[1] / acc[10], acc[2] / acc[10], acc[3] / acc[10], acc[4] / acc[10], acc[5] / acc[10]);
-      }
+    static const char *steps[9] = {"prologue", "stage descriptors", "shapes + windows", "walk", "fetch", "apply", "evaluate", "validate", "commit"};
+    double tot = 0;
+    for (int k = 0; k < 9; k++) tot += e->trace_acc[k];
+    for (int k = 0; k < 9; k++)
+      fprintf(stderr, "[kb K5 trace] %-18s %14.0f clocks  %5.1f %%  (%.0f per batch)\n", steps[k], e->trace_acc[k], 100.0 * e->trace_acc[k] / (tot > 0 ? tot : 1),
+              e->trace_acc[k] / (double)(e->stage_hits ? e->stage_hits : 1));
   }
   (void)hipSetDevice(e->device);
   delete e;
@@ -831,8 +818,8 @@ int kb_session_load(kb_engine *e, const kb_snapshot *sn) {
     // the commit kernel keeps one slot per window row in LDS (160 KiB per workgroup on gfx950)
     e->eff_window = std::min<uint32_t>(e->window, KB_K5_MAX_WINDOW);
     auto cap_of = [](uint32_t w) { return std::max<uint32_t>(64, ((w + 63) / 64) * 64); };
-    while (e->eff_window > 64 && kb_commit_smem_bytes(cap_of(e->eff_window), NP) > 160u * 1024u) e->eff_window -= 64;
-    if (kb_commit_smem_bytes(cap_of(e->eff_window), NP) > 160u * 1024u)
+    while (e->eff_window > 64 && kb_commit_smem_bytes(cap_of(e->eff_window), NP, R) > 160u * 1024u) e->eff_window -= 64;
+    if (kb_commit_smem_bytes(cap_of(e->eff_window), NP, R) > 160u * 1024u)
       throw EngineError(KB_E_UNSUPPORTED, "too many nodes for the commit kernel's LDS dirty bitmap");
     std::vector<uint32_t> ncls(NP, 0);
     if (sn->node_class) std::memcpy(ncls.data(), sn->node_class, sizeof(uint32_t) * N);

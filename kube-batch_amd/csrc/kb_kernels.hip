@@ -19,6 +19,9 @@
 // The path is elementwise compare + integer scoring, HBM/latency bound: no MFMA.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
+
+#include <algorithm>
 
 #include "kb_device.h"
 
@@ -421,26 +424,6 @@ __global__ void __launch_bounds__(256) k_gather(KbDev d, KbRound r) {
 #define K5F_NZM 9
 #define K5_NF8 10
 #define K5_WAVES (KB_K5_THREADS / 64)
-#define K5_EVAL (KB_K5_THREADS - 128)                                  // threads that own dirty slots (all but the loader and candidate waves)
-#define K5_SPT ((KB_K5_MAX_WINDOW + K5_EVAL - 1) / K5_EVAL)
-
-struct K5Hdr {
-  unsigned long long best[2];       // cross-wave max of the row's keys (ds_max_u64), double-buffered by row parity
-  unsigned long long cand;          // \  one 16-byte read after barrier 1
-  uint32_t exhausted, pad0;         // /
-  uint32_t last_slot, stop;         //    one 8-byte read after barrier 2
-  uint32_t refills, rescans;
-  uint32_t win_base[2];             // candidate window of the next row (written by the loader wave)
-  uint32_t cs_tag[2];               // staged clean-node states: node ids (0xFFFFFFFF = empty)
-  unsigned long long win[2][64];
-  unsigned long long cs8[2][16];    // staged 8-byte fields (index = field id), written by the loader wave one row ahead
-  uint32_t cs4[2][4];               // cls, maxpods, podcnt
-  unsigned long long red[K5_WAVES]; // live-rescan path only
-};
-
-__host__ __device__ inline size_t k5_smem_bytes(uint32_t cap, uint32_t NP) {
-  return (size_t)cap * (K5_NF8 * 8 + 4 * 4 + sizeof(KbRowDesc)) + (size_t)(NP / 32) * 4 + sizeof(K5Hdr);
-}
 
 __device__ __forceinline__ NodeVals k5_slot_vals(const unsigned long long *tab, const uint32_t *t_cls, const int *t_left, uint32_t cap, uint32_t slot) {
   NodeVals nv;
@@ -460,65 +443,6 @@ __device__ __forceinline__ NodeVals k5_slot_vals(const unsigned long long *tab, 
   return nv;
 }
 
-// scalar dimensions stay in global memory (rare path): NodeInfo.AddTask's Sub on dims >= 2, task bookkeeping, and the
-// multi-GPU per-node deltas
-__device__ __forceinline__ void k5_commit_globals(const KbCommitArgs &a, const KbRowDesc &k, double res0, double res1,
-                                                  uint32_t i, uint32_t n, uint32_t kind) {
-  uint32_t km = k.resmask;
-  uint32_t has_map = 0;
-  if (km) {
-    const KbDev &d = *a.dev;
-    has_map = kind ? 1u : d.nmask[n];   // Sub returns early when the receiver's scalar map is nil (resource_info.go:148-153)
-    if (has_map) {
-      double *vec = kind ? d.rel : d.idle;
-      uint32_t dd = 2, m2 = km;
-      while (m2) {
-        if (m2 & 1u) vec[(size_t)dd * d.NP + n] -= d.t_res[(size_t)dd * d.T + k.task];
-        m2 >>= 1; dd++;
-      }
-      __threadfence_block();
-    }
-  }
-  // one 8-byte decision record; the task table (status, node, counted) is updated from the records by k_apply
-  *reinterpret_cast<uint2 *>(&a.dec[i]) = make_uint2(n, kind);
-  if (a.has_delta) {
-    const KbDev &d = *a.dev;
-    const KbRound &r = *a.round;
-    if (i >= r.own_row0 && i < r.own_row1) {
-    // per-node committed deltas of the rows this rank owns: [dIdle R][dRel R][dnzc][dnzm][dpodcnt] x NP
-    double *dv = r.delta + (size_t)(kind ? d.R : 0) * d.NP;
-    dv[n] -= res0;
-    dv[(size_t)d.NP + n] -= res1;
-    if (km && has_map) {
-      uint32_t dd = 2, m2 = km;
-      while (m2) {
-        if (m2 & 1u) dv[(size_t)dd * d.NP + n] -= d.t_res[(size_t)dd * d.T + k.task];
-        m2 >>= 1; dd++;
-      }
-    }
-    double *tail = r.delta + (size_t)2 * d.R * d.NP;
-    tail[n] += (double)k.nzc;
-    tail[(size_t)d.NP + n] += (double)k.nzm;
-    tail[(size_t)2 * d.NP + n] += 1.0;
-    }
-  }
-}
-
-// ------------------------------------------------------------------------------------------------------------
-// K5: sequential commit.  One workgroup walks the window in the reference's task order (allocate.go:129-193 /
-// backfill.go:44-67).  Node state changes one node at a time, so for every task
-//     best node = max( best CLEAN node of the task's shape , best DIRTY node re-evaluated against live state )
-//   * clean side: the shape's candidate list from K3, sorted best-first, with a monotone cursor in LDS that skips
-//     entries whose node has become dirty (the dirty set only grows inside a round and the list is longer than the
-//     window, so a clean entry always survives unless the list ran out of feasible nodes);
-//   * dirty side: the live state of every node touched in this round sits in LDS tables (one slot per node); each
-//     thread owns slots {tid, tid+THREADS} and caches their keys, so a task with the same shape as its predecessor
-//     re-evaluates only the slot that just changed (gang members are consecutive and identical).
-// The loop is latency-bound, so it is written for few dependent instructions: row descriptors are staged in LDS once,
-// reductions are DPP + v_max_f64 on biased keys, the candidate's node state is fetched by 13 lanes with ONE load
-// instruction (lane k reads field k from its own array) and a clean winner's slot is initialised by the same lanes with
-// ONE LDS store; two workgroup barriers per task.
-// ------------------------------------------------------------------------------------------------------------
 // eval_pair for the commit kernel: policy scalars from the by-value argument struct, session arrays (scalar resource
 // dimensions, wide class tables) through the device-memory copy of KbDev on the rare paths only
 __device__ __forceinline__ uint32_t eval_pair_k5(const KbCommitArgs &a, const TaskVals &t, const NodeVals &n, uint32_t node, const uint32_t *class_row) {
@@ -581,475 +505,208 @@ __device__ __forceinline__ void k5_field_ptrs(const KbDev &d, uint32_t fld, cons
   }
 }
 
-// Shared view of the commit kernel's LDS (see k5_smem_bytes)
-struct K5Mem {
-  unsigned long long *tab;
-  uint32_t *t_cls, *t_node, *cursor, *bitmap;
-  int *t_left;
-  KbRowDesc *desc;
-  K5Hdr *H;
-  uint32_t cap;
+// ------------------------------------------------------------------------------------------------------------
+// K5: commit.  One workgroup walks the window in the reference's task order (allocate.go:129-193 / backfill.go:44-67).
+// The reference commits one task at a time, but ~90 % of the tasks take the best CLEAN node of their
+// shape (the next untouched entry of the shape's sorted candidate list).  The kernel therefore speculates K7_B rows
+// at once:
+//   walk      one wave hands every row of the batch the next clean entry of its shape's list, in row order, marking
+//             the nodes in the dirty bitmap as it goes (so a later row of another shape skips them);
+//   fetch     16 threads per row pull the 13 state fields of the row's node into a NEW dirty slot (one load each);
+//   apply     one thread per row decides Allocate / Pipeline (allocate.go:160) and applies NodeInfo.AddTask
+//             (api/node_info.go:172-212) to its slot, i.e. the slot holds the state AFTER the row committed;
+//   evaluate  all threads: key(shape q, slot x) for every distinct shape q of the batch and every dirty slot x, old
+//             (-> dmax[q]) and new (-> kb[row][q]);
+//   validate  row j really takes its clean candidate iff  c_j > dmax[q_j]  and  c_j > kb[l][q_j] for every earlier
+//             batch row l: then no dirty node beats it, exactly the reference's arg-max.  The first row that fails is
+//             the batch's "dirty row": its winner is the best dirty key, computed by the same evaluation;
+//   commit    rows before the first failure are final (decision records, cursors); later rows are rolled back
+//             (bitmap bits, speculative scalar-dimension writes) and re-speculated by the next batch; the dirty row is
+//             applied to the slot that owns the winning node.
+// A batch costs about as much as two rows of a row-at-a-time protocol, and commits ~10 rows on the benchmark snapshot.
+// ------------------------------------------------------------------------------------------------------------
+#define K7_B 16u
+
+struct K7Hdr {
+  unsigned long long c[K7_B];           // clean candidate key of batch row j (0: the list has no clean feasible node left)
+  unsigned long long dmax[K7_B];        // per distinct shape q of the batch: best key over the pre-batch dirty slots
+  unsigned long long kb[K7_B][K7_B];    // [row l][shape q]: key of row l's node in its post-commit state
+  unsigned long long win[K7_B][64];     // candidate window of shape q, starting at win_base[q]
+  uint32_t win_base[K7_B];
+  uint32_t rep[K7_B];                   // batch row whose descriptor represents shape q
+  uint32_t q_of[K7_B];                  // shape index of batch row j
+  uint32_t idx[K7_B];                   // list position of c[j]
+  uint32_t kind[K7_B];                  // 0 Allocate, 1 Pipeline
+  uint32_t has_map[K7_B];               // the row's speculative commit wrote scalar dimensions (saved values are valid)
+  int maxp[K7_B], pods[K7_B];
+  // evaluation work list of shape q: slots [e_start, nd), then dlog[e_log0 .. e_log0 + e_nlog), then the batch's new slots
+  uint32_t e_off[K7_B], e_start[K7_B], e_nlog[K7_B], e_log0[K7_B];
+  KbRowDesc desc[K7_B];
+  unsigned long long kstar;             // winner of the dirty row
+  uint32_t nshapes, p, dirty_row, reason, exhausted, pad;
+  uint32_t n_pairs, nlog, n_full, pad3;
+  uint32_t n_batches, n_dirty_rows, n_refills, pad2;
 };
 
-// What every role reads after barrier 1 (identical values in every wave): the row's best key, the clean candidate, and
-// whether the candidate list ran dry while still full (live-rescan protocol, two extra barriers for everybody).
-struct K5Pick {
-  unsigned long long best, cand;
-  uint32_t exhausted;
+struct K7Mem {
+  unsigned long long *tab;              // [K5_NF8][cap2]
+  uint32_t *t_cls, *t_node;             // [cap2]
+  int *t_left;                          // [cap2]
+  uint32_t *cursor;                     // [cap] per shape
+  uint32_t *qstamp;                     // [cap] per shape: first batch row with that shape (0xFFFFFFFF between batches)
+  // per shape: best key over the dirty slots [0, dc_nd) as of dirty-log position dc_log.  Still valid later for the slots
+  // it covered unless the node of dc_key itself was changed by a dirty row since (the commit step then sets dc_nd to
+  // 0xFFFFFFFF); newer slots and slots changed since are simply evaluated again and max'ed in.
+  unsigned long long *dc_key;           // [cap]
+  uint32_t *dc_nd, *dc_log;             // [cap]
+  uint32_t *dlog;                       // [cap] slots changed by dirty rows, in order
+  uint32_t *bitmap;                     // [NP/32]
+  double *save;                         // [K7_B][R-2] scalar-dimension values overwritten by speculative commits
+  K7Hdr *H;
+  uint32_t cap2;
 };
-__device__ __forceinline__ K5Pick k5_pick(const K5Mem M, uint32_t par) {
-  const uint4 h = *reinterpret_cast<const uint4 *>(&M.H->cand);
-  K5Pick p;
-  p.best = M.H->best[par];
-  p.cand = ((unsigned long long)h.y << 32) | h.x;
-  p.exhausted = h.z;
-  return p;
+
+__host__ __device__ inline size_t k7_smem_bytes(uint32_t cap, uint32_t NP, int R) {
+  size_t cap2 = (size_t)cap + K7_B;
+  return cap2 * (K5_NF8 * 8 + 3 * 4) + (size_t)cap * (8 + 8 + 12) + (size_t)(NP / 32) * 4 + (size_t)K7_B * (R > 2 ? R - 2 : 0) * 8 + sizeof(K7Hdr) + 64;
 }
 
-// Live rescan of every CLEAN node (the candidate list ran out while still full; cannot happen with L > window).  All
-// waves take part: two barriers.  Returns the best clean key; H.cand is replaced by it.
-__device__ __forceinline__ unsigned long long k5_rescan(const KbCommitArgs &a, const K5Mem M, const KbRowDesc &cur) {
-  const KbDev &d = *a.dev;
-  const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+__device__ __forceinline__ TaskVals k7_task_vals(const KbRowDesc &k) {
   TaskVals tv;
-  tv.init0 = cur.init0; tv.init1 = cur.init1; tv.nzc = cur.nzc; tv.nzm = cur.nzm;
-  tv.cls = cur.cls; tv.active = cur.active; tv.task = cur.task; tv.pad = 0;
-  unsigned long long k2 = 0ull;
-  for (uint32_t n = tid; n < d.N; n += KB_K5_THREADS) {
-    if (bit_test(M.bitmap, n)) continue;
-    NodeVals nv = load_node(d, n);
-    uint32_t res = eval_pair(d, tv, nv, n, a.fit_mode);
-    if (res) { unsigned long long k3 = KB_KEY(res & 0xFFFFu, n); k2 = k3 > k2 ? k3 : k2; }
+  tv.init0 = k.init0; tv.init1 = k.init1; tv.nzc = k.nzc; tv.nzm = k.nzm;
+  tv.cls = k.cls; tv.active = k.active; tv.task = k.task; tv.pad = 0;
+  return tv;
+}
+
+// decision record + multi-GPU deltas of one committed row; SUB: also apply the scalar dimensions of NodeInfo.AddTask
+// (the batched clean rows did that speculatively in the apply step)
+template <bool SUB>
+__device__ __forceinline__ void k7_commit_globals(const KbCommitArgs &a, const KbRowDesc &k, uint32_t i, uint32_t n, uint32_t kind) {
+  const uint32_t km = k.resmask;
+  uint32_t has_map = 0;
+  if (km) {
+    const KbDev &d = *a.dev;
+    has_map = kind ? 1u : d.nmask[n];   // Sub returns early when the receiver's scalar map is nil (resource_info.go:148-153)
+    if (SUB && has_map) {
+      double *vec = kind ? d.rel : d.idle;
+      uint32_t dd = 2, m2 = km;
+      while (m2) {
+        if (m2 & 1u) vec[(size_t)dd * d.NP + n] -= d.t_res[(size_t)dd * d.T + k.task];
+        m2 >>= 1; dd++;
+      }
+    }
   }
-  k2 = wave_max_key(k2);
-  if (lane == 0) M.H->red[wave] = k2;
-  __syncthreads();
-  unsigned long long bclean = oct_max_key(M.H->red[lane & (K5_WAVES - 1)]);
-  if (tid == 0) { M.H->rescans++; M.H->cand = bclean; }
-  __syncthreads();
-  return bclean;
+  *reinterpret_cast<uint2 *>(&a.dec[i]) = make_uint2(n, kind);
+  if (a.has_delta) {
+    const KbDev &d = *a.dev;
+    const KbRound &r = *a.round;
+    if (i >= r.own_row0 && i < r.own_row1) {
+      double res0 = k.init0, res1 = k.init1;
+      if (!(k.flags & 1)) { res0 = d.t_res[k.task]; res1 = d.t_res[(size_t)d.T + k.task]; }
+      // per-node committed deltas of the rows this rank owns: [dIdle R][dRel R][dnzc][dnzm][dpodcnt] x NP
+      double *dv = r.delta + (size_t)(kind ? d.R : 0) * d.NP;
+      dv[n] -= res0;
+      dv[(size_t)d.NP + n] -= res1;
+      if (km && has_map) {
+        uint32_t dd = 2, m2 = km;
+        while (m2) {
+          if (m2 & 1u) dv[(size_t)dd * d.NP + n] -= d.t_res[(size_t)dd * d.T + k.task];
+          m2 >>= 1; dd++;
+        }
+      }
+      double *tail = r.delta + (size_t)2 * d.R * d.NP;
+      tail[n] += (double)k.nzc;
+      tail[(size_t)d.NP + n] += (double)k.nzm;
+      tail[(size_t)2 * d.NP + n] += 1.0;
+    }
+  }
+}
+
+// Allocate or Pipeline for row k on the node held in `slot` (allocate.go:160), then NodeInfo.AddTask on the LDS copy
+__device__ __forceinline__ uint32_t k7_apply_slot(const KbCommitArgs &a, const K7Mem &M, const KbRowDesc &k, uint32_t slot, uint32_t n) {
+  const uint32_t cap2 = M.cap2;
+  double res0 = k.init0, res1 = k.init1;
+  if (!(k.flags & 1)) { const KbDev &d = *a.dev; res0 = d.t_res[k.task]; res1 = d.t_res[(size_t)d.T + k.task]; }
+  uint32_t kind = 0;
+  if (!a.backfill) {
+    bool fi = le_eps(k.init0, __longlong_as_double((long long)M.tab[K5F_IDLE0 * cap2 + slot]), EPS_CPU) &&
+              le_eps(k.init1, __longlong_as_double((long long)M.tab[K5F_IDLE1 * cap2 + slot]), EPS_MEM);
+    uint32_t act = k.active >> 2;
+    if (act) {
+      const KbDev &d = *a.dev;
+      uint32_t dd = 2;
+      while (act) {
+        if (act & 1u) fi = fi && le_eps(d.t_init[(size_t)dd * d.T + k.task], d.idle[(size_t)dd * d.NP + n], EPS_SCALAR);
+        act >>= 1; dd++;
+      }
+    }
+    kind = fi ? 0u : 1u;
+  }
+  const uint32_t f0 = kind ? K5F_REL0 : K5F_IDLE0;
+  M.tab[(size_t)f0 * cap2 + slot] = (unsigned long long)__double_as_longlong(__longlong_as_double((long long)M.tab[(size_t)f0 * cap2 + slot]) - res0);
+  M.tab[(size_t)(f0 + 1) * cap2 + slot] = (unsigned long long)__double_as_longlong(__longlong_as_double((long long)M.tab[(size_t)(f0 + 1) * cap2 + slot]) - res1);
+  M.tab[(size_t)K5F_NZC * cap2 + slot] += (unsigned long long)k.nzc;
+  M.tab[(size_t)K5F_NZM * cap2 + slot] += (unsigned long long)k.nzm;
+  return kind;
 }
 
 #ifdef KB_K5_TRACE
-#define K5R_DECL(role) const bool trc = a.trace != nullptr && (threadIdx.x & 63) == 0 && ((role) != 0 || threadIdx.x == 0); unsigned long long tr0 = 0, tr1 = 0, tr2 = 0, tr3 = 0;
-#define K5R_T0() do { if (trc) tr0 = __builtin_readcyclecounter(); } while (0)
-#define K5R_T1() do { if (trc) tr1 = __builtin_readcyclecounter(); } while (0)
-#define K5R_T2() do { if (trc) tr2 = __builtin_readcyclecounter(); } while (0)
-#define K5R_T3() do { if (trc) tr3 = __builtin_readcyclecounter(); } while (0)
-#define K5R_END(role, i, cw, same) do { if (trc && (i) < 512) { unsigned long long *dst = a.trace + ((size_t)(role) * 512 + (i)) * 8; dst[0] = tr0; dst[1] = tr1; dst[2] = tr2; dst[3] = tr3; dst[4] = __builtin_readcyclecounter(); dst[5] = ((cw) ? 1ull : 0ull) | ((same) ? 2ull : 0ull); } } while (0)
+#define K7_STAMP(k) do { if (threadIdx.x == 0) { unsigned long long now_ = __builtin_readcyclecounter(); tacc[k] += now_ - tlast; tlast = now_; } } while (0)
 #else
-#define K5R_DECL(role)
-#define K5R_T0() do { } while (0)
-#define K5R_T1() do { } while (0)
-#define K5R_T2() do { } while (0)
-#define K5R_T3() do { } while (0)
-#define K5R_END(role, i, cw, same) do { } while (0)
+#define K7_STAMP(k) do { } while (0)
 #endif
 
-// ---- role: evaluation waves (own the dirty slots) --------------------------------------------------------------
-__device__ __forceinline__ void k5_eval_role(const KbCommitArgs a, const K5Mem M, uint32_t &nd_out, uint32_t &n_done, uint32_t &reason) {
-  const uint32_t tid = threadIdx.x, lane = tid & 63, cap = M.cap;
-  K5Hdr &H = *M.H;
-  unsigned long long ck[K5_SPT];     // cached keys of the dirty slots this thread owns, valid for shape `prev_shape`
-#pragma unroll
-  for (int j = 0; j < K5_SPT; j++) ck[j] = 0ull;
-  unsigned long long wmax = 0ull;    // this wave's max over ck[], valid while no lane of the wave re-evaluates
-  uint32_t prev_shape = 0xFFFFFFFFu, nd = 0, last_slot = 0xFFFFFFFFu;
-  K5R_DECL(0)
-  const uint32_t tid_id = tid, lane_id = lane;
-  for (uint32_t i = 0; i < a.n_rows; i++) {
-    K5R_T0();
-    uint32_t tid = tid_id, lane = lane_id;   // opaque per row: keeps thread/lane masks out of (spilled) SGPR pairs
-    asm volatile("" : "+v"(tid), "+v"(lane));
-    const uint32_t par = i & 1;
-    const KbRowDesc &cur = M.desc[i];
-    const uint32_t shape = cur.slot;
-    const bool same = shape == prev_shape;
-    prev_shape = shape;
-    // ---- phase 1: keys of my dirty slots (re-evaluated only when the shape changed or the slot was just committed)
-    bool mine = false;
-#pragma unroll
-    for (int j = 0; j < K5_SPT; j++) {
-      uint32_t slot = tid + j * K5_EVAL;
-      mine = mine || (slot < nd && (!same || slot == last_slot));
-    }
-    if (__ballot(mine)) {
-      if (mine) {
-        TaskVals tv;
-        tv.init0 = cur.init0; tv.init1 = cur.init1; tv.nzc = cur.nzc; tv.nzm = cur.nzm;
-        tv.cls = cur.cls; tv.active = cur.active; tv.task = cur.task; tv.pad = 0;
-        const uint32_t *crow = a.use_crow ? &cur.crow : nullptr;
-#pragma unroll
-        for (int j = 0; j < K5_SPT; j++) {
-          uint32_t slot = tid + j * K5_EVAL;
-          if (slot < nd && (!same || slot == last_slot)) {
-            NodeVals nv = k5_slot_vals(M.tab, M.t_cls, M.t_left, cap, slot);
-            uint32_t node = M.t_node[slot];
-            uint32_t res = eval_pair_k5(a, tv, nv, node, crow);
-            ck[j] = res ? KB_KEY(res & 0xFFFFu, node) : 0ull;
-          }
-        }
-      }
-      unsigned long long key = 0ull;
-#pragma unroll
-      for (int j = 0; j < K5_SPT; j++) key = ck[j] > key ? ck[j] : key;
-      wmax = wave_max_key(key);
-    }
-    if (lane == 0 && wmax) atomicMax(&H.best[par], wmax);
-    K5R_T1();
-    __syncthreads();
-    K5R_T2();
-    // ---- phase 2
-    K5Pick p = k5_pick(M, par);
-    if (tid == 0) H.best[par ^ 1] = 0ull;
-    if (p.exhausted) { unsigned long long bc = k5_rescan(a, M, cur); p.cand = bc; p.best = bc > p.best ? bc : p.best; }
-    if (p.best == 0ull) {
-      if (a.backfill) {   // backfill.go:50-66: no node passes the predicates -> the task simply stays Pending
-        if (tid == 0) *reinterpret_cast<uint2 *>(&a.dec[i]) = make_uint2(KB_NONE_U32, 0u);
-        __syncthreads();
-        n_done = i + 1;
-        continue;
-      }
-      n_done = i; reason = KB_REASON_NO_FEASIBLE;   // allocate.go:144-148: the job is abandoned; the host re-plans from here
-      break;
-    }
-    const bool clean_wins = p.best == p.cand;
-    if (!clean_wins) {
-      // a dirty node wins: its owner applies NodeInfo.AddTask (api/node_info.go:172-212) to the LDS copy
-#pragma unroll
-      for (int j = 0; j < K5_SPT; j++) {
-        uint32_t slot = tid + j * K5_EVAL;
-        if (slot < nd && ck[j] == p.best) {
-          const uint32_t n = KB_KEY_NODE(p.best);
-          // Resreq == InitResreq unless an init container raised it (rare): a scalar branch, NOT a select between an LDS
-          // and a global address (the compiler would turn that into flat loads with a full vmcnt+lgkmcnt drain)
-          double res0 = cur.init0, res1 = cur.init1;
-          asm volatile("" : "+v"(res0), "+v"(res1));   // materialise the LDS values here: no pointer phi -> no flat load
-          if (!(__builtin_amdgcn_readfirstlane((int)cur.flags) & 1)) { const KbDev &d = *a.dev; res0 = d.t_res[cur.task]; res1 = d.t_res[(size_t)d.T + cur.task]; }
-          uint32_t kind = 0;
-          if (!a.backfill) {   // allocate.go:160: InitResreq.LessEqual(node.Idle) ? Allocate : Pipeline
-            bool fi = le_eps(cur.init0, __longlong_as_double((long long)M.tab[K5F_IDLE0 * cap + slot]), EPS_CPU) &&
-                      le_eps(cur.init1, __longlong_as_double((long long)M.tab[K5F_IDLE1 * cap + slot]), EPS_MEM);
-            uint32_t act = cur.active >> 2, dd = 2;
-            if (act) {
-              const KbDev &d = *a.dev;
-              while (act) {
-                if (act & 1u) fi = fi && le_eps(d.t_init[(size_t)dd * d.T + cur.task], d.idle[(size_t)dd * d.NP + n], EPS_SCALAR);
-                act >>= 1; dd++;
-              }
-            }
-            kind = fi ? 0u : 1u;
-          }
-          const uint32_t f0 = kind ? K5F_REL0 : K5F_IDLE0;
-          M.tab[(size_t)f0 * cap + slot] = (unsigned long long)__double_as_longlong(__longlong_as_double((long long)M.tab[(size_t)f0 * cap + slot]) - res0);
-          M.tab[(size_t)(f0 + 1) * cap + slot] = (unsigned long long)__double_as_longlong(__longlong_as_double((long long)M.tab[(size_t)(f0 + 1) * cap + slot]) - res1);
-          M.tab[(size_t)K5F_NZC * cap + slot] += (unsigned long long)cur.nzc;
-          M.tab[(size_t)K5F_NZM * cap + slot] += (unsigned long long)cur.nzm;
-          M.t_left[slot] -= 1;
-          *reinterpret_cast<uint2 *>(&H.last_slot) = make_uint2(slot, kind);
-          k5_commit_globals(a, cur, res0, res1, i, n, kind);
-        }
-      }
-    }
-    K5R_T3();
-    __syncthreads();
-    K5R_END(0, i, clean_wins, same);
-    if (clean_wins) nd++;
-    n_done = i + 1;
-    const uint2 h2 = *reinterpret_cast<const uint2 *>(&H.last_slot);
-    last_slot = h2.x;
-    if (h2.y) { reason = KB_REASON_PIPELINED; break; }
-  }
-  nd_out = nd;
-}
-
-// ---- role: loader wave (every global load of the loop, a full row ahead, landed in LDS staging) -----------------
-__device__ __forceinline__ void k5_load_role(const KbCommitArgs a, const K5Mem M, uint32_t &nd_out, uint32_t &n_done, uint32_t &reason) {
-  const uint32_t lane = threadIdx.x & 63;
-  K5Hdr &H = *M.H;
-  // lane (g*16 + k) reads field k of one node with ONE load instruction per width: k < 10: 8-byte field k from its own
-  // array; k = 10..12: cls / maxpods / podcnt.  Two lane groups -> two nodes per instruction.
-  const uint32_t fld = lane & 15, grp = lane >> 4;
-  const unsigned long long *g8 = nullptr;
-  const uint32_t *g4 = nullptr;
-  if (grp < 2) k5_field_ptrs(*a.dev, fld, g8, g4);
-  unsigned long long pw_key = 0ull;   // candidate window being fetched, one entry per lane
-  uint32_t pw_base = 0;
-  unsigned long long ps8 = 0ull;      // node states being fetched: lane groups 0/1 -> staging slots 0/1
-  uint32_t ps4 = 0;
-  uint32_t ps_tag0 = 0xFFFFFFFFu, ps_tag1 = 0xFFFFFFFFu;   // nodes in flight for staging slot 0 / 1
-  uint32_t ls_tag0 = 0xFFFFFFFFu, ls_tag1 = 0xFFFFFFFFu;   // what the staging slots hold / will hold
-  uint32_t inv_node = 0xFFFFFFFFu, nd = 0;
-  if (a.n_rows > 1) pw_key = (lane < a.L) ? a.keys[(size_t)M.desc[1].slot * a.L + lane] : 0ull;
-  K5R_DECL(1)
-  const uint32_t lane_id = lane, fld_id = fld, grp_id = grp;
-  for (uint32_t i = 0; i < a.n_rows; i++) {
-    K5R_T0();
-    uint32_t lane = lane_id, fld = fld_id, grp = grp_id;   // opaque per row (see the candidate role)
-    asm volatile("" : "+v"(lane), "+v"(fld), "+v"(grp));
-    const uint32_t par = i & 1;
-    // ---- phase 1: drop the copy of the node the previous row committed (it is dirty now), land the states requested in
-    //      the previous row's phase 2 (consumed by this row's commit)
-    if (inv_node != 0xFFFFFFFFu) {
-      if (ls_tag0 == inv_node) { ls_tag0 = 0xFFFFFFFFu; if (ps_tag0 == inv_node) ps_tag0 = 0xFFFFFFFFu; if (lane == 0) H.cs_tag[0] = 0xFFFFFFFFu; }
-      if (ls_tag1 == inv_node) { ls_tag1 = 0xFFFFFFFFu; if (ps_tag1 == inv_node) ps_tag1 = 0xFFFFFFFFu; if (lane == 0) H.cs_tag[1] = 0xFFFFFFFFu; }
-    }
-    if (ps_tag0 != 0xFFFFFFFFu || ps_tag1 != 0xFFFFFFFFu) {
-      const bool on = (grp == 0 && ps_tag0 != 0xFFFFFFFFu) || (grp == 1 && ps_tag1 != 0xFFFFFFFFu);
-      if (on && fld < K5_NF8) H.cs8[grp][fld] = ps8;
-      if (on && fld >= 10 && fld < 13) H.cs4[grp][fld - 10] = ps4;
-      if (lane == 0 && ps_tag0 != 0xFFFFFFFFu) H.cs_tag[0] = ps_tag0;
-      if (lane == 16 && ps_tag1 != 0xFFFFFFFFu) H.cs_tag[1] = ps_tag1;
-      ps_tag0 = 0xFFFFFFFFu; ps_tag1 = 0xFFFFFFFFu;
-    }
-    K5R_T1();
-    __syncthreads();
-    K5R_T2();
-    // ---- phase 2
-    K5Pick p = k5_pick(M, par);
-    // (a) hand the next row's candidate window (requested a row ago) to the candidate wave and stage the states of its
-    //     first two clean nodes: whichever of them survives this row's commit is the next row's clean candidate
-    if (i + 1 < a.n_rows) {
-      const uint32_t nshape = M.desc[i + 1].slot;
-      H.win[par ^ 1][lane] = pw_key;
-      if (lane == 0) H.win_base[par ^ 1] = pw_base;
-      const uint32_t c0 = M.cursor[nshape];
-      const bool nz = pw_key != 0ull;
-      unsigned long long cb = __ballot(nz && (pw_base + lane) >= c0 && !bit_test(M.bitmap, KB_KEY_NODE(pw_key)));
-      uint32_t m1 = 0xFFFFFFFFu, m2 = 0xFFFFFFFFu;
-      if (cb) {
-        int f1 = __ffsll((unsigned long long)cb) - 1;
-        m1 = 0xFFFFFFFFu - (uint32_t)__builtin_amdgcn_readlane((int)(pw_key & 0xFFFFFFFFull), f1);
-        unsigned long long cb2 = cb & (cb - 1);
-        if (cb2) {
-          int f2 = __ffsll((unsigned long long)cb2) - 1;
-          m2 = 0xFFFFFFFFu - (uint32_t)__builtin_amdgcn_readlane((int)(pw_key & 0xFFFFFFFFull), f2);
-        }
-      }
-      const bool have1 = m1 == 0xFFFFFFFFu || ls_tag0 == m1 || ls_tag1 == m1;
-      const bool have2 = m2 == 0xFFFFFFFFu || ls_tag0 == m2 || ls_tag1 == m2;
-      if (!have1) {
-        if (ls_tag0 != m2) { ls_tag0 = m1; ps_tag0 = m1; } else { ls_tag1 = m1; ps_tag1 = m1; }
-      }
-      if (!have2) {
-        if (ls_tag0 != m1) { ls_tag0 = m2; ps_tag0 = m2; } else { ls_tag1 = m2; ps_tag1 = m2; }
-      }
-      const uint32_t want = grp == 0 ? ps_tag0 : (grp == 1 ? ps_tag1 : 0xFFFFFFFFu);
-      if (want != 0xFFFFFFFFu) {
-        if (g8) ps8 = g8[want];
-        if (g4) ps4 = g4[want];
-      }
-    }
-    // (b) request the window of the row after next
-    if (i + 2 < a.n_rows) {
-      const uint32_t n2shape = M.desc[i + 2].slot;
-      pw_base = M.cursor[n2shape];   // may lag: stale entries are filtered by the dirty bitmap when the window is used
-      uint32_t e = pw_base + lane;
-      pw_key = (e < a.L) ? a.keys[(size_t)n2shape * a.L + e] : 0ull;
-    }
-    if (p.exhausted) { unsigned long long bc = k5_rescan(a, M, M.desc[i]); p.cand = bc; p.best = bc > p.best ? bc : p.best; }
-    if (p.best == 0ull) {
-      if (a.backfill) { __syncthreads(); n_done = i + 1; inv_node = 0xFFFFFFFFu; continue; }
-      n_done = i; reason = KB_REASON_NO_FEASIBLE;
-      break;
-    }
-    const bool clean_wins = p.best == p.cand;
-    inv_node = clean_wins ? KB_KEY_NODE(p.best) : 0xFFFFFFFFu;
-    K5R_T3();
-    __syncthreads();
-    K5R_END(1, i, clean_wins, false);
-    if (clean_wins) nd++;
-    n_done = i + 1;
-    const uint2 h2 = *reinterpret_cast<const uint2 *>(&H.last_slot);
-    if (h2.y) { reason = KB_REASON_PIPELINED; break; }
-  }
-  nd_out = nd;
-}
-
-// ---- role: candidate wave (walks the candidate lists, commits clean winners) -------------------------------------
-__device__ __forceinline__ void k5_cand_role(const KbCommitArgs a, const K5Mem M, uint32_t &nd_out, uint32_t &n_done, uint32_t &reason) {
-  const uint32_t lane0 = threadIdx.x & 63, cap = M.cap;
-  K5Hdr &H = *M.H;
-  const unsigned long long *g8 = nullptr;   // synchronous miss path: lanes 0..12 fetch the node's fields
-  const uint32_t *g4 = nullptr;
-  if (lane0 < 16) k5_field_ptrs(*a.dev, lane0, g8, g4);
-  // the current shape's window (keys per lane), mask of its clean lanes, mask of its empty lanes
-  unsigned long long wkey = 0ull, wb = 0ull, wzero = 0ull;
-  uint32_t wbase = 0, prev_shape = 0xFFFFFFFFu, nd = 0;
-  bool wvalid = false, prev_clean_win = false;
-  K5R_DECL(2)
-  const uint32_t lane_id = lane0;
-  for (uint32_t i = 0; i < a.n_rows; i++) {
-    K5R_T0();
-    // re-materialise the lane id every row: otherwise every `lane == k` mask is hoisted out of the loop as an SGPR pair, the
-    // kernel runs out of SGPRs and each mask is spilled to / restored from VGPR lanes (v_readlane pairs) at every use
-    uint32_t lane = lane_id;
-    asm volatile("" : "+v"(lane));
-    const uint32_t par = i & 1;
-    const KbRowDesc &cur = M.desc[i];
-    const uint32_t shape = cur.slot;
-    const bool same_tr = shape == prev_shape;
-    (void)same_tr;
-    // ---- phase 1: first list entry whose node is not dirty.  Inside a run of rows with the same shape the only node
-    // that can have turned dirty since the previous row is the previous row's own clean winner, i.e. the lowest set bit
-    // of the clean mask: clear it instead of re-reading the window and re-testing the bitmap.
-    if (shape == prev_shape && wvalid) {
-      if (prev_clean_win) wb &= wb - 1;
-    } else {
-      wkey = H.win[par][lane];
-      wbase = H.win_base[par];
-      const uint32_t c0 = M.cursor[shape];
-      const bool nz = wkey != 0ull;
-      wb = __ballot(nz && (wbase + lane) >= c0 && !bit_test(M.bitmap, KB_KEY_NODE(wkey)));
-      wzero = __ballot(!nz);
-      wvalid = true;
-    }
-    prev_shape = shape;
-    unsigned long long cand = 0ull;
-    bool list_end = false;
-    uint32_t curs;
-    for (;;) {
-      if (wb) {
-        int first = __ffsll((unsigned long long)wb) - 1;
-        // lists are 0-terminated and sorted best-first, so the first clean entry is the best clean node
-        cand = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(wkey >> 32), first) << 32) |
-               (uint32_t)__builtin_amdgcn_readlane((int)(wkey & 0xFFFFFFFFull), first);
-        curs = wbase + first;
-        break;
-      }
-      curs = wbase;
-      if (wzero) { list_end = true; break; }            // ran past the last feasible node: no clean candidate exists
-      wbase += 64;
-      curs = wbase;
-      if (wbase >= a.L) break;                          // list exhausted while still full: live rescan
-      uint32_t e = wbase + lane;
-      wkey = (e < a.L) ? a.keys[(size_t)shape * a.L + e] : 0ull;
-      const bool nz = wkey != 0ull;
-      wb = __ballot(nz && !bit_test(M.bitmap, KB_KEY_NODE(wkey)));
-      wzero = __ballot(!nz);
-      if (lane == 0) H.refills++;
-    }
-    if (lane == 0) {
-      M.cursor[shape] = curs;
-      *reinterpret_cast<uint4 *>(&H.cand) = make_uint4((uint32_t)(cand & 0xFFFFFFFFull), (uint32_t)(cand >> 32), (!cand && !list_end) ? 1u : 0u, 0u);
-      if (cand) atomicMax(&H.best[par], cand);
-    }
-    K5R_T1();
-    __syncthreads();
-    K5R_T2();
-    // ---- phase 2
-    K5Pick p = k5_pick(M, par);
-    if (p.exhausted) { unsigned long long bc = k5_rescan(a, M, cur); p.cand = bc; p.best = bc > p.best ? bc : p.best; wvalid = false; }
-    if (p.best == 0ull) {
-      if (a.backfill) { __syncthreads(); n_done = i + 1; prev_clean_win = false; continue; }
-      n_done = i; reason = KB_REASON_NO_FEASIBLE;
-      break;
-    }
-    const bool clean_wins = p.best == p.cand;
-    if (clean_wins) {
-      // commit: NodeInfo.AddTask (api/node_info.go:172-212) turns the clean node into dirty slot `nd`.  Its pristine state
-      // was staged by the loader a row ahead (normal case) or is fetched synchronously.  Lanes 0..9 get the 8-byte
-      // fields, lanes 10..12 cls / maxpods / podcnt.
-      const uint32_t n = KB_KEY_NODE(p.best);
-      double res0 = cur.init0, res1 = cur.init1;   // scalar branch, not an LDS/global address select (see the eval role)
-      asm volatile("" : "+v"(res0), "+v"(res1));
-      if (!(__builtin_amdgcn_readfirstlane((int)cur.flags) & 1)) { const KbDev &d = *a.dev; res0 = d.t_res[cur.task]; res1 = d.t_res[(size_t)d.T + cur.task]; }
-      unsigned long long st8 = 0ull;
-      uint32_t st4 = 0;
-      const uint2 tags = *reinterpret_cast<const uint2 *>(&H.cs_tag[0]);
-      const int src = (tags.x == n) ? 0 : ((tags.y == n) ? 1 : 2);
-      if (lane == 0) { if (src < 2) H.refills += 1u << 16; else H.rescans += 1u << 16; }   // staging hits / misses (diagnostic)
-      if (src < 2) {
-        st8 = H.cs8[src][lane & 15];
-        st4 = H.cs4[src][(lane - 10) & 3];
-      } else {
-        if (g8) st8 = g8[n];
-        if (g4) st4 = g4[n];
-      }
-      double v = __longlong_as_double((long long)st8);
-      uint32_t kind = 0;
-      if (!a.backfill) {   // allocate.go:160: InitResreq.LessEqual(node.Idle) ? Allocate : Pipeline
-        // lanes 0 / 1 hold Idle cpu / memory: straight-line compare with per-lane operands, other lanes pass
-        const double ini = (lane == K5F_IDLE0) ? cur.init0 : cur.init1;
-        const double eps = (lane == K5F_IDLE0) ? EPS_CPU : EPS_MEM;
-        bool ok = (lane > K5F_IDLE1) || le_eps(ini, v, eps);
-        if (lane == 63 && (cur.active >> 2)) {   // scalar dimensions (rare): compared against live global state
-          const KbDev &d = *a.dev;
-          uint32_t act = cur.active >> 2, dd = 2;
-          while (act) {
-            if (act & 1u) ok = ok && le_eps(d.t_init[(size_t)dd * d.T + cur.task], d.idle[(size_t)dd * d.NP + n], EPS_SCALAR);
-            act >>= 1; dd++;
-          }
-        }
-        kind = __ballot(!ok) ? 1u : 0u;
-      }
-      // apply the task: Allocated -> Idle.Sub(Resreq); Pipelined -> Releasing.Sub(Resreq); pod joins ni.Tasks
-      const uint32_t f0 = kind ? K5F_REL0 : K5F_IDLE0;
-      if (lane == f0) v -= res0;
-      if (lane == f0 + 1) v -= res1;
-      unsigned long long out = (unsigned long long)__double_as_longlong(v);
-      if (lane == K5F_NZC) out = st8 + (unsigned long long)cur.nzc;
-      if (lane == K5F_NZM) out = st8 + (unsigned long long)cur.nzm;
-      if (lane >= K5F_INVAC && lane <= K5F_AM) out = st8;
-      if (lane < K5_NF8) M.tab[(size_t)lane * cap + nd] = out;
-      const int maxp = __builtin_amdgcn_readlane((int)st4, 11), pods = __builtin_amdgcn_readlane((int)st4, 12);
-      // t_cls, t_node, t_left are consecutive [cap] arrays: one store with a per-lane offset (no pointer table)
-      if (lane >= 10 && lane < 13) {
-        const uint32_t which = (lane == 10) ? 0u : ((lane == 12) ? 1u : 2u);
-        const uint32_t val = (lane == 10) ? st4 : ((lane == 12) ? n : (uint32_t)(maxp - pods - 1));
-        M.t_cls[(size_t)which * cap + nd] = val;
-      }
-      if (lane == 0) {
-        atomicOr(&M.bitmap[n >> 5], 1u << (n & 31));
-        *reinterpret_cast<uint2 *>(&H.last_slot) = make_uint2(nd, kind);
-        k5_commit_globals(a, cur, res0, res1, i, n, kind);
-      }
-    }
-    K5R_T3();
-    __syncthreads();
-    K5R_END(2, i, clean_wins, same_tr);
-    if (clean_wins) nd++;
-    prev_clean_win = clean_wins;
-    n_done = i + 1;
-    const uint2 h2 = *reinterpret_cast<const uint2 *>(&H.last_slot);
-    if (h2.y) { reason = KB_REASON_PIPELINED; break; }
-  }
-  nd_out = nd;
-}
-
 __global__ void __launch_bounds__(KB_K5_THREADS) k_commit(const KbCommitArgs a) {
-  const KbDev &d = *a.dev;
   extern __shared__ __align__(16) unsigned char k5_smem[];
-  K5Mem M;
-  M.cap = a.cap;
+  const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, cap = a.cap, cap2 = a.cap + K7_B;
+  K7Mem M;
+  M.cap2 = cap2;
   M.tab = reinterpret_cast<unsigned long long *>(k5_smem);
-  M.t_cls = reinterpret_cast<uint32_t *>(M.tab + (size_t)K5_NF8 * M.cap);
-  M.t_node = M.t_cls + M.cap;
-  M.t_left = reinterpret_cast<int *>(M.t_node + M.cap);
-  M.cursor = reinterpret_cast<uint32_t *>(M.t_left + M.cap);
-  M.desc = reinterpret_cast<KbRowDesc *>(M.cursor + M.cap);
-  M.bitmap = reinterpret_cast<uint32_t *>(M.desc + M.cap);
-  M.H = reinterpret_cast<K5Hdr *>(M.bitmap + a.NP / 32);
-  K5Hdr &H = *M.H;
-  const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, cap = M.cap;
-
-  for (uint32_t w = tid; w < d.NP / 32; w += KB_K5_THREADS) M.bitmap[w] = 0;
-  for (uint32_t w = tid; w < cap; w += KB_K5_THREADS) M.cursor[w] = 0;
-  {   // stage the window's row descriptors (coalesced 8-byte copies)
-    const unsigned long long *src = reinterpret_cast<const unsigned long long *>(a.desc);
-    unsigned long long *dst = reinterpret_cast<unsigned long long *>(M.desc);
-    const uint32_t nq = a.n_rows * (uint32_t)(sizeof(KbRowDesc) / 8);
-    for (uint32_t w = tid; w < nq; w += KB_K5_THREADS) dst[w] = src[w];
+  M.dc_key = M.tab + (size_t)K5_NF8 * cap2;   // 8-byte tables first
+  M.t_cls = reinterpret_cast<uint32_t *>(M.dc_key + cap);
+  M.t_node = M.t_cls + cap2;
+  M.t_left = reinterpret_cast<int *>(M.t_node + cap2);
+  M.cursor = reinterpret_cast<uint32_t *>(M.t_left + cap2);
+  M.qstamp = M.cursor + cap;
+  M.dc_nd = M.qstamp + cap;
+  M.dc_log = M.dc_nd + cap;
+  M.dlog = M.dc_log + cap;
+  M.bitmap = M.dlog + cap;
+  {
+    // byte offsets from the LDS base (pointer -> integer -> pointer round trips would lose the address space)
+    size_t off = (size_t)cap2 * (K5_NF8 * 8 + 3 * 4) + (size_t)cap * (8 + 8 + 12) + (size_t)(a.NP / 32) * 4;
+    off = (off + 15) & ~(size_t)15;
+    M.H = reinterpret_cast<K7Hdr *>(k5_smem + off);
+    M.save = reinterpret_cast<double *>(k5_smem + off + sizeof(K7Hdr));
   }
-  if (tid == 0) {
-    H.best[0] = 0; H.best[1] = 0; H.cand = 0; H.exhausted = 0; H.pad0 = 0; H.stop = 0; H.last_slot = 0xFFFFFFFFu;
-    H.refills = 0; H.rescans = 0; H.win_base[0] = 0; H.win_base[1] = 0; H.cs_tag[0] = 0xFFFFFFFFu; H.cs_tag[1] = 0xFFFFFFFFu;
+  K7Hdr &H = *M.H;
+  const int RS = a.R > 2 ? a.R - 2 : 0;
+#ifdef KB_K5_TRACE
+  unsigned long long tacc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tlast = __builtin_readcyclecounter();
+#endif
+
+  for (uint32_t w = tid; w < a.NP / 32; w += KB_K5_THREADS) M.bitmap[w] = 0;
+  for (uint32_t w = tid; w < cap; w += KB_K5_THREADS) { M.cursor[w] = 0; M.qstamp[w] = 0xFFFFFFFFu; M.dc_key[w] = 0ull; M.dc_nd[w] = 0; M.dc_log[w] = 0; }
+  if (tid == 0) { H.reason = KB_REASON_DONE; H.exhausted = 0; H.n_batches = 0; H.n_dirty_rows = 0; H.n_refills = 0; H.p = 0; H.dirty_row = 0; H.pad = 0; H.nlog = 0; H.n_full = 0; }
+  // per-thread source array of the fetch step: thread (row*16 + f) reads field f of the row's node
+  // (pointers read from the KbDev copy are generic; the fetch step wants global_load, not flat_load)
+  typedef const unsigned long long __attribute__((address_space(1))) *gptr8;
+  typedef const uint32_t __attribute__((address_space(1))) *gptr4;
+  gptr8 g8;
+  gptr4 g4;
+  {
+    const unsigned long long *f8 = nullptr;
+    const uint32_t *f4 = nullptr;
+    k5_field_ptrs(*a.dev, tid & 15, f8, f4);
+    g8 = (gptr8)f8;
+    g4 = (gptr4)f4;
   }
   {
-    // The loop is latency-bound and this workgroup starts on a cold L2 (kernel boundary).  Touch every 128-byte line it
-    // can need later — node state arrays and the candidate lists — once, with all threads.
+    // The loop is latency-bound and this workgroup starts on a cold L2 (kernel boundary): touch every 128-byte line of the
+    // node state arrays and of the candidate lists once, with all threads.
+    const KbDev &d = *a.dev;
     unsigned long long acc = 0;
-    const uint32_t lines = d.NP / 16;   // 16 x 8 bytes per line
+    const uint32_t lines = a.NP / 16;
     const unsigned long long *arrs[10] = {
         reinterpret_cast<const unsigned long long *>(d.idle), reinterpret_cast<const unsigned long long *>(d.idle + d.NP),
         reinterpret_cast<const unsigned long long *>(d.rel), reinterpret_cast<const unsigned long long *>(d.rel + d.NP),
@@ -1057,41 +714,333 @@ __global__ void __launch_bounds__(KB_K5_THREADS) k_commit(const KbCommitArgs a) 
         reinterpret_cast<const unsigned long long *>(d.acpu), reinterpret_cast<const unsigned long long *>(d.amem),
         reinterpret_cast<const unsigned long long *>(d.nzc), reinterpret_cast<const unsigned long long *>(d.nzm)};
 #pragma unroll
-    for (int a = 0; a < 10; a++)
-      for (uint32_t l = tid; l < lines; l += KB_K5_THREADS) acc += arrs[a][(size_t)l * 16];
+    for (int f = 0; f < 10; f++)
+      for (uint32_t l = tid; l < lines; l += KB_K5_THREADS) acc += arrs[f][(size_t)l * 16];
     const uint32_t *arr4[3] = {d.ncls, reinterpret_cast<const uint32_t *>(d.maxpods), reinterpret_cast<const uint32_t *>(d.podcnt)};
 #pragma unroll
-    for (int a = 0; a < 3; a++)
-      for (uint32_t l = tid; l < d.NP / 32; l += KB_K5_THREADS) acc += arr4[a][(size_t)l * 32];
+    for (int f = 0; f < 3; f++)
+      for (uint32_t l = tid; l < a.NP / 32; l += KB_K5_THREADS) acc += arr4[f][(size_t)l * 32];
     const size_t klines = ((size_t)a.n_mrows * a.L + 15) / 16;
     for (size_t l = tid; l < klines; l += KB_K5_THREADS) acc += a.keys[l * 16];
-    if (acc == 0x123456789abcdefull) H.pad0 = 1;   // keep the loads alive
+    if (acc == 0x123456789abcdefull) H.pad = 1;   // keep the loads alive
   }
   __syncthreads();
-  if (wave == K5_WAVES - 2) H.win[0][lane] = (lane < a.L) ? a.keys[(size_t)M.desc[0].slot * a.L + lane] : 0ull;   // row 0's window
-  __syncthreads();
+  K7_STAMP(0);
 
-  // Three specialised loops that only meet at the two barriers per row: waves 0..W-3 own the dirty slots, wave W-2 is the
-  // loader, wave W-1 walks the candidate lists and commits clean winners.  Every role derives the same control decisions
-  // (continue / stop / rescan) from the same LDS words, so the barrier counts always match.
-  uint32_t nd = 0, n_done = 0, reason = KB_REASON_DONE;
-  if (wave == K5_WAVES - 1) k5_cand_role(a, M, nd, n_done, reason);
-  else if (wave == K5_WAVES - 2) k5_load_role(a, M, nd, n_done, reason);
-  else k5_eval_role(a, M, nd, n_done, reason);
+  uint32_t i0 = 0, nd = 0, n_done = 0, reason = KB_REASON_DONE;
+  while (i0 < a.n_rows) {
+    const uint32_t nb = min(a.batch, a.n_rows - i0);
+    // ---- stage the batch's row descriptors
+    {
+      const unsigned long long *src = reinterpret_cast<const unsigned long long *>(a.desc + i0);
+      unsigned long long *dst = reinterpret_cast<unsigned long long *>(H.desc);
+      for (uint32_t w = tid; w < nb * (uint32_t)(sizeof(KbRowDesc) / 8); w += KB_K5_THREADS) dst[w] = src[w];
+    }
+    __syncthreads();
+    K7_STAMP(1);
+    // ---- distinct shapes of the batch (wave 0): q_of[j] = rank of the first row with row j's shape
+    if (wave == 0) {
+      const bool in = lane < nb;
+      const uint32_t s = in ? (uint32_t)H.desc[in ? lane : 0].slot : 0u;
+      if (in) atomicMin(&M.qstamp[s], lane);
+      const uint32_t first = in ? M.qstamp[s] : 0xFFFFFFFFu;
+      const bool isrep = in && first == lane;
+      const unsigned long long repmask = __ballot(isrep);
+      // evaluation work list of every distinct shape: reuse the shape's cached dirty max when its node is untouched
+      uint32_t cnt = 0, q = 0;
+      if (in) {
+        q = (uint32_t)__popcll(repmask & ((1ull << first) - 1ull));
+        H.q_of[lane] = q;
+        M.qstamp[s] = 0xFFFFFFFFu;
+      }
+      if (isrep) {
+        const uint32_t nlog = H.nlog;
+        unsigned long long ck = M.dc_key[s];
+        uint32_t start = M.dc_nd[s];
+        const uint32_t log0 = M.dc_log[s];
+        uint32_t nl = nlog - log0;
+        const bool full = start == 0xFFFFFFFFu || nl > 16;   // invalidated by a dirty row on its arg-max node, or too stale
+        if (full) { start = 0; nl = 0; ck = 0ull; }
+        cnt = (nd - start) + nl + nb;
+        H.rep[q] = lane; H.win_base[q] = M.cursor[s]; H.dmax[q] = ck;
+        H.e_start[q] = start; H.e_nlog[q] = nl; H.e_log0[q] = log0;
+        if (full) atomicAdd(&H.n_full, 1u);
+      }
+      // exclusive prefix of the counts over the representative lanes (all inside the first 16 lanes: one DPP row)
+      uint32_t incl = cnt;
+      incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x111, 0xf, 0xf, true);   // row_shr:1
+      incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x112, 0xf, 0xf, true);   // row_shr:2
+      incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x114, 0xf, 0xf, true);   // row_shr:4
+      incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x118, 0xf, 0xf, true);   // row_shr:8
+      if (isrep) H.e_off[q] = incl - cnt;
+      const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 15);
+      const uint32_t nsh = (uint32_t)__popcll(repmask);
+      if (lane >= nsh && lane < K7_B) H.e_off[lane] = 0xFFFFFFFFu;
+      if (lane == 0) { H.nshapes = nsh; H.n_pairs = total; H.n_batches++; }
+    }
+    __syncthreads();
+    // ---- candidate windows of the distinct shapes: one wave per shape
+    const uint32_t nshapes = H.nshapes;
+    for (uint32_t q = wave; q < nshapes; q += K5_WAVES) {
+      const uint32_t s = H.desc[H.rep[q]].slot;
+      const uint32_t e = H.win_base[q] + lane;
+      H.win[q][lane] = (e < a.L) ? a.keys[(size_t)s * a.L + e] : 0ull;
+    }
+    __syncthreads();
+    K7_STAMP(2);
+    // ---- walk (wave 0): runs of consecutive rows with the same shape take successive clean entries of its window
+    if (wave == 0) {
+      const uint32_t myq = (lane < nb) ? H.q_of[lane] : 0xFFFFFFFFu;
+      uint32_t j = 0;
+      while (j < nb) {
+        const uint32_t q = (uint32_t)__builtin_amdgcn_readlane((int)myq, (int)j);
+        const unsigned long long diff = __ballot(lane >= j && lane < nb && myq != q);
+        const uint32_t j1 = diff ? (uint32_t)(__ffsll((unsigned long long)diff) - 1) : nb;
+        uint32_t m = j1 - j;
+        const uint32_t s = H.desc[H.rep[q]].slot;
+        for (;;) {
+          const unsigned long long wkey = H.win[q][lane];
+          const uint32_t base = H.win_base[q];
+          const bool nz = wkey != 0ull;
+          const uint32_t node = KB_KEY_NODE(wkey);
+          const bool cl = nz && !bit_test(M.bitmap, nz ? node : 0u);
+          const unsigned long long clean = __ballot(cl);
+          const unsigned long long zeros = __ballot(!nz);
+          const uint32_t cnt = (uint32_t)__popcll(clean);
+          const uint32_t take = cnt < m ? cnt : m;
+          const uint32_t rank = (uint32_t)__popcll(clean & ((1ull << lane) - 1ull));
+          if (cl && rank < take) {
+            H.c[j + rank] = wkey;
+            H.idx[j + rank] = base + lane;
+            atomicOr(&M.bitmap[node >> 5], 1u << (node & 31));
+          }
+          j += take;
+          m -= take;
+          if (m == 0) break;
+          if (zeros) {   // the list ended: no clean feasible node is left for the remaining rows of the run
+            if (lane < m) { H.c[j + lane] = 0ull; H.idx[j + lane] = 0; }
+            j += m;
+            break;
+          }
+          // every entry of the window is dirty: slide it (entries before it stay dirty for the rest of the round or are
+          // rolled back together with this batch)
+          const uint32_t nbase = base + 64;
+          if (nbase >= a.L) {   // cannot happen while L > window: reported, never silently mis-scheduled
+            if (lane == 0) H.exhausted = 1;
+            if (lane < m) { H.c[j + lane] = 0ull; H.idx[j + lane] = 0; }
+            j += m;
+            break;
+          }
+          const uint32_t e = nbase + lane;
+          H.win[q][lane] = (e < a.L) ? a.keys[(size_t)s * a.L + e] : 0ull;
+          if (lane == 0) { H.win_base[q] = nbase; H.n_refills++; }
+        }
+      }
+    }
+    __syncthreads();
+    K7_STAMP(3);
+    // ---- fetch: thread (row*16 + f) reads field f of the row's candidate node into the row's new dirty slot
+    for (uint32_t w = tid; w < nb * 16; w += KB_K5_THREADS) {
+      const uint32_t j = w >> 4, f = w & 15;
+      const unsigned long long cj = H.c[j];
+      if (cj) {
+        const uint32_t n = KB_KEY_NODE(cj), slot = nd + j;
+        if (f < K5_NF8) M.tab[(size_t)f * cap2 + slot] = g8[n];
+        else if (f == 10) M.t_cls[slot] = g4[n];
+        else if (f == 11) H.maxp[j] = (int)g4[n];
+        else if (f == 12) H.pods[j] = (int)g4[n];
+        else if (f == 13) M.t_node[slot] = n;
+      }
+    }
+    __syncthreads();
+    K7_STAMP(4);
+    // ---- apply: the slot holds the node's state after the row committed; scalar dimensions (global memory, rare) are
+    //      written speculatively and their old values saved for the rollback
+    if (tid < nb) {
+      const uint32_t j = tid;
+      const unsigned long long cj = H.c[j];
+      uint32_t kind = 0, has_map = 0;
+      if (cj) {
+        const KbRowDesc &k = H.desc[j];
+        const uint32_t n = KB_KEY_NODE(cj), slot = nd + j;
+        kind = k7_apply_slot(a, M, k, slot, n);
+        M.t_left[slot] = H.maxp[j] - H.pods[j] - 1;
+        const uint32_t km = k.resmask;
+        if (km) {
+          const KbDev &d = *a.dev;
+          has_map = kind ? 1u : d.nmask[n];
+          if (has_map) {
+            double *vec = kind ? d.rel : d.idle;
+            uint32_t dd = 2, m2 = km;
+            while (m2) {
+              if (m2 & 1u) {
+                const double old = vec[(size_t)dd * d.NP + n];
+                M.save[(size_t)j * RS + (dd - 2)] = old;
+                vec[(size_t)dd * d.NP + n] = old - d.t_res[(size_t)dd * d.T + k.task];
+              }
+              m2 >>= 1; dd++;
+            }
+          }
+        }
+      }
+      H.kind[j] = kind;
+      H.has_map[j] = has_map;
+    }
+    __syncthreads();
+    K7_STAMP(5);
+    // ---- evaluate the work lists: (shape q, slot x) -> dmax[q] for slots older than the batch, kb[row][q] for its own
+    {
+      const uint32_t P = H.n_pairs;
+      uint32_t off[K7_B];
+#pragma unroll
+      for (int k = 0; k < (int)K7_B; k += 4) {
+        const uint4 v = *reinterpret_cast<const uint4 *>(&H.e_off[k]);
+        off[k] = v.x; off[k + 1] = v.y; off[k + 2] = v.z; off[k + 3] = v.w;
+      }
+      for (uint32_t e = tid; e < P; e += KB_K5_THREADS) {
+        uint32_t q = 0;
+#pragma unroll
+        for (int k = 1; k < (int)K7_B; k++) q += (e >= off[k]) ? 1u : 0u;
+        uint32_t r = e - H.e_off[q];
+        const uint32_t start = H.e_start[q], nn = nd - start, nl = H.e_nlog[q];
+        uint32_t x;
+        if (r < nn) x = start + r;
+        else if (r < nn + nl) x = M.dlog[H.e_log0[q] + (r - nn)];
+        else x = nd + (r - nn - nl);
+        unsigned long long key = 0ull;
+        if (x < nd || H.c[x - nd] != 0ull) {
+          const KbRowDesc &k = H.desc[H.rep[q]];
+          const TaskVals tv = k7_task_vals(k);
+          const NodeVals nv = k5_slot_vals(M.tab, M.t_cls, M.t_left, cap2, x);
+          const uint32_t node = M.t_node[x];
+          const uint32_t res = eval_pair_k5(a, tv, nv, node, a.use_crow ? &k.crow : nullptr);
+          key = res ? KB_KEY(res & 0xFFFFu, node) : 0ull;
+        }
+        if (x < nd) { if (key) atomicMax(&H.dmax[q], key); }
+        else H.kb[x - nd][q] = key;
+      }
+    }
+    __syncthreads();
+    K7_STAMP(6);
+    // ---- validate (wave 0)
+    if (wave == 0) {
+      const bool in = lane < nb;
+      const unsigned long long cj = in ? H.c[lane] : 0ull;
+      const uint32_t q = in ? H.q_of[lane] : 0u;
+      unsigned long long m = in ? H.dmax[q] : 0ull;
+#pragma unroll 8
+      for (uint32_t l = 0; l + 1 < nb; l++) {
+        const unsigned long long kk = H.kb[l][q];
+        if (l < lane && kk > m) m = kk;
+      }
+      if (in && H.rep[q] == lane) {   // the shape's dirty max as of this batch's start becomes its cache
+        const uint32_t s = H.desc[lane].slot;
+        M.dc_key[s] = H.dmax[q]; M.dc_nd[s] = nd; M.dc_log[s] = H.nlog;
+      }
+      const bool valid = in && cj != 0ull && cj > m;
+      const unsigned long long inval = __ballot(in && !valid);
+      const unsigned long long pipe = __ballot(valid && H.kind[in ? lane : 0] != 0u);
+      uint32_t p = inval ? (uint32_t)(__ffsll((unsigned long long)inval) - 1) : nb;
+      const unsigned long long pipe_before = pipe & ((1ull << p) - 1ull);
+      uint32_t dirty_row = 0, rsn = KB_REASON_DONE;
+      unsigned long long kstar = 0ull;
+      if (pipe_before) {   // a Pipeline ends the speculation (the host re-plans): commit up to and including that row
+        p = (uint32_t)__ffsll((unsigned long long)pipe_before);
+        rsn = KB_REASON_PIPELINED;
+      } else if (p < nb) {
+        kstar = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(m >> 32), (int)p) << 32) |
+                (uint32_t)__builtin_amdgcn_readlane((int)(m & 0xFFFFFFFFull), (int)p);
+        if (kstar) dirty_row = 1;
+        else if (a.backfill) dirty_row = 2;   // backfill.go:50-66: no node passes the predicates -> the task stays Pending
+        else rsn = KB_REASON_NO_FEASIBLE;     // allocate.go:144-148: the job is abandoned; the host re-plans from here
+      }
+      if (lane == 0) {
+        H.p = p; H.dirty_row = dirty_row; H.reason = rsn; H.kstar = kstar;
+        if (dirty_row == 1) H.n_dirty_rows++;
+      }
+    }
+    __syncthreads();
+    K7_STAMP(7);
+    // ---- commit the valid prefix, roll the rest back, apply the dirty row
+    const uint32_t p = H.p, dirty_row = H.dirty_row;
+    if (tid < nb) {
+      const uint32_t j = tid;
+      const unsigned long long cj = H.c[j];
+      const KbRowDesc &k = H.desc[j];
+      if (j < p) {
+        const uint32_t n = KB_KEY_NODE(cj);
+        atomicMax(&M.cursor[k.slot], H.idx[j] + 1);
+        k7_commit_globals<false>(a, k, i0 + j, n, H.kind[j]);
+      } else if (cj) {
+        const uint32_t n = KB_KEY_NODE(cj);
+        atomicAnd(&M.bitmap[n >> 5], ~(1u << (n & 31)));
+        if (H.has_map[j]) {
+          const KbDev &d = *a.dev;
+          double *vec = H.kind[j] ? d.rel : d.idle;
+          uint32_t dd = 2, m2 = k.resmask;
+          while (m2) {
+            if (m2 & 1u) vec[(size_t)dd * d.NP + n] = M.save[(size_t)j * RS + (dd - 2)];
+            m2 >>= 1; dd++;
+          }
+        }
+      }
+    }
+    if (a.has_delta) __syncthreads();   // the dirty row may hit a node one of the clean rows above just added a delta for
+    if (dirty_row == 1) {
+      const unsigned long long kstar = H.kstar;
+      const uint32_t n = KB_KEY_NODE(kstar);
+      // shapes whose cached dirty max sits on the node that is about to change lose their cache
+      for (uint32_t sh = tid; sh < a.n_mrows; sh += KB_K5_THREADS) {
+        const unsigned long long ck = M.dc_key[sh];
+        if (ck != 0ull && KB_KEY_NODE(ck) == n) M.dc_nd[sh] = 0xFFFFFFFFu;
+      }
+      for (uint32_t x = tid; x < nd + p; x += KB_K5_THREADS) {
+        if (M.t_node[x] == n) {
+          const KbRowDesc &k = H.desc[p];
+          const uint32_t kind = k7_apply_slot(a, M, k, x, n);
+          M.t_left[x] -= 1;
+          k7_commit_globals<true>(a, k, i0 + p, n, kind);
+          if (kind) H.reason = KB_REASON_PIPELINED;
+          const uint32_t nl = H.nlog;
+          M.dlog[nl] = x;
+          H.nlog = nl + 1;
+        }
+      }
+    } else if (dirty_row == 2) {
+      if (tid == 0) *reinterpret_cast<uint2 *>(&a.dec[i0 + p]) = make_uint2(KB_NONE_U32, 0u);
+    }
+    __syncthreads();
+    K7_STAMP(8);
+    nd += p;
+    i0 += p + (dirty_row ? 1u : 0u);
+    n_done = i0;
+    reason = H.reason;
+    if (H.exhausted) reason = KB_REASON_INTERNAL;
+    if (reason != KB_REASON_DONE) break;
+  }
 
   // ---- write the dirty nodes' live state back to HBM
   __syncthreads();
-  for (uint32_t slot = tid; slot < nd; slot += KB_K5_THREADS) {
-    uint32_t n = M.t_node[slot];
-    d.idle[n] = __longlong_as_double((long long)M.tab[K5F_IDLE0 * cap + slot]);
-    d.idle[(size_t)d.NP + n] = __longlong_as_double((long long)M.tab[K5F_IDLE1 * cap + slot]);
-    d.rel[n] = __longlong_as_double((long long)M.tab[K5F_REL0 * cap + slot]);
-    d.rel[(size_t)d.NP + n] = __longlong_as_double((long long)M.tab[K5F_REL1 * cap + slot]);
-    d.nzc[n] = (long long)M.tab[K5F_NZC * cap + slot];
-    d.nzm[n] = (long long)M.tab[K5F_NZM * cap + slot];
-    d.podcnt[n] = d.maxpods[n] - M.t_left[slot];
+  {
+    const KbDev &d = *a.dev;
+    for (uint32_t slot = tid; slot < nd; slot += KB_K5_THREADS) {
+      const uint32_t n = M.t_node[slot];
+      d.idle[n] = __longlong_as_double((long long)M.tab[K5F_IDLE0 * cap2 + slot]);
+      d.idle[(size_t)d.NP + n] = __longlong_as_double((long long)M.tab[K5F_IDLE1 * cap2 + slot]);
+      d.rel[n] = __longlong_as_double((long long)M.tab[K5F_REL0 * cap2 + slot]);
+      d.rel[(size_t)d.NP + n] = __longlong_as_double((long long)M.tab[K5F_REL1 * cap2 + slot]);
+      d.nzc[n] = (long long)M.tab[K5F_NZC * cap2 + slot];
+      d.nzm[n] = (long long)M.tab[K5F_NZM * cap2 + slot];
+      d.podcnt[n] = d.maxpods[n] - M.t_left[slot];
+    }
   }
-  if (tid == 0) { a.result[0] = n_done; a.result[1] = reason; a.result[2] = nd; a.result[3] = H.rescans & 0xFFFFu; a.result[4] = H.refills & 0xFFFFu; a.result[5] = H.refills >> 16; a.result[6] = H.rescans >> 16; }
+  if (tid == 0) {
+    a.result[0] = n_done; a.result[1] = reason; a.result[2] = nd; a.result[3] = 0; a.result[4] = H.n_refills; a.result[7] = H.n_full;
+    a.result[5] = H.n_batches; a.result[6] = H.n_dirty_rows;
+#ifdef KB_K5_TRACE
+    if (a.trace) for (int k = 0; k < 12; k++) a.trace[k] = tacc[k];
+#endif
+  }
 }
 
 // task-table side of ssn.Allocate / ssn.Pipeline for the rows the commit kernel processed (job.UpdateTaskStatus,
@@ -1200,7 +1149,7 @@ uint32_t kb_apply_deltas(const KbDev &d, const double *s_idle, const double *s_r
   (void)hipStreamSynchronize(s);
   return h;
 }
-size_t kb_commit_smem_bytes(uint32_t cap, uint32_t NP) { return k5_smem_bytes(cap, NP); }
+size_t kb_commit_smem_bytes(uint32_t cap, uint32_t NP, int R) { return k7_smem_bytes(cap, NP, R); }
 void kb_launch_gather(const KbDev &d, const KbRound &r, void *stream) {
   if (r.n_rows == 0) return;
   hipLaunchKernelGGL(k_gather, dim3((r.n_rows + 255) / 256), dim3(256), 0, (hipStream_t)stream, d, r);
@@ -1235,12 +1184,12 @@ __global__ void k_store_views(KbDev d, KbRound r, KbDev *dd, KbRound *dr) { *dd 
 
 void kb_launch_commit(const KbDev &d, const KbRound &r, KbDev *dev_copy, KbRound *round_copy, void *stream) {
   if (r.n_rows == 0) return;
-  size_t sh = k5_smem_bytes(r.cap, d.NP);
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_commit), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
+  size_t sh = k7_smem_bytes(r.cap, d.NP, d.R);
   hipLaunchKernelGGL(k_store_views, dim3(1), dim3(1), 0, (hipStream_t)stream, d, r, dev_copy, round_copy);
   KbCommitArgs a;
   a.dev = dev_copy; a.round = round_copy;
@@ -1250,6 +1199,10 @@ void kb_launch_commit(const KbDev &d, const KbRound &r, KbDev *dev_copy, KbRound
   a.wL = d.wL; a.wM = d.wM; a.wB = d.wB;
   a.use_crow = (d.pred_enabled && d.crows != nullptr && d.n_nc <= 32) ? 1u : 0u;
   a.has_delta = r.delta != nullptr ? 1u : 0u;
+  a.R = d.R;
+  static uint32_t batch = 0;
+  if (!batch) { const char *b = getenv("KB_K5_BATCH"); batch = b ? (uint32_t)atoi(b) : K7_B; if (batch < 1 || batch > K7_B) batch = K7_B; }
+  a.batch = batch;
   hipLaunchKernelGGL(k_commit, dim3(1), dim3(KB_K5_THREADS), sh, (hipStream_t)stream, a);
   hipLaunchKernelGGL(k_apply, dim3((r.n_rows + 255) / 256), dim3(256), 0, (hipStream_t)stream, d, r);
 }
