@@ -117,7 +117,8 @@ struct KbCommitArgs {
   int fit_mode, backfill, pred_enabled, score_enabled, wL, wM, wB;
   uint32_t use_crow, has_delta;
   int R;
-  uint32_t batch;   // rows speculated per batch (<= 32)
+  uint32_t batch;        // rows speculated per batch (<= 16)
+  uint32_t batch_small;  // ... in the batch right after a dirty row that came early
 };
 
 #define KB_K5_MAX_WINDOW 1024u   // dirty-node table + row descriptors of the commit kernel live in LDS: 152 B per row

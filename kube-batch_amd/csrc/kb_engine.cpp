@@ -398,9 +398,10 @@ void round_collect(kb_engine *e, const RoundCtx &c, bool had_candidates, uint32_
   reason = e->h_result[1];
   if (reason == KB_REASON_INTERNAL) throw EngineError(KB_E_INTERNAL, "commit kernel ran out of candidate list entries (list shorter than the window)");
   if (e->trace_on) {   // KB_K5_TRACE=1 (and make TRACE=1): cycles thread 0 spent in each step of the commit kernel
-    unsigned long long tr[12];
+    unsigned long long tr[40];
     HIP_OK(hipMemcpy(tr, e->b_trace.p, sizeof(tr), hipMemcpyDeviceToHost));
-    for (int k = 0; k < 12; k++) e->trace_acc[k] += (double)tr[k];
+    for (int k = 0; k < 40; k++) e->trace_acc[k] += (double)tr[k];
+    HIP_OK(hipMemsetAsync(e->b_trace.p, 0, sizeof(tr), e->stream));
   }
   e->stats.row_fallbacks += e->h_result[3];
   e->stage_hits += e->h_result[5];
@@ -614,7 +615,7 @@ int kb_engine_create(const kb_config *cfg, kb_engine **out) {
     eng->b_result.alloc(sizeof(uint32_t) * 8);
     eng->b_views.alloc(sizeof(KbDev) + sizeof(KbRound) + 64);
     if (const char *tr = getenv("KB_K5_TRACE")) {
-      if (tr[0] == '1') { eng->trace_on = true; eng->b_trace.alloc(sizeof(unsigned long long) * 3 * 512 * 8); }
+      if (tr[0] == '1') { eng->trace_on = true; eng->b_trace.alloc(sizeof(unsigned long long) * 64); HIP_OK(hipMemset(eng->b_trace.p, 0, sizeof(unsigned long long) * 64)); }
     }
     e = eng.release();
   });
@@ -628,10 +629,13 @@ void kb_engine_destroy(kb_engine *e) {
     fprintf(stderr, "[kb K5] batches %llu, dirty rows %llu, full shape evaluations %llu, rows %llu\n", (unsigned long long)e->stage_hits,
             (unsigned long long)e->stage_misses, e->full_evals, (unsigned long long)e->stats.decisions);
   if (e->trace_on) {
-    static const char *steps[9] = {"prologue", "stage descriptors", "shapes + windows", "walk", "fetch", "apply", "evaluate", "validate", "commit"};
+    fprintf(stderr, "[kb K5 trace] batches that start with a dirty row: %.0f, of which on the previous dirty row's node: %.0f\n[kb K5 trace] valid-prefix histogram:", e->trace_acc[12], e->trace_acc[13]);
+    for (int k = 0; k <= 16; k++) fprintf(stderr, " %d:%.0f", k, e->trace_acc[16 + k]);
+    fprintf(stderr, "\n");
+    static const char *steps[10] = {"prologue", "stage descriptors", "shapes + windows", "walk", "fetch", "apply", "evaluate", "validate", "commit + row mode", "row-mode evaluate"};
     double tot = 0;
-    for (int k = 0; k < 9; k++) tot += e->trace_acc[k];
-    for (int k = 0; k < 9; k++)
+    for (int k = 0; k < 10; k++) tot += e->trace_acc[k];
+    for (int k = 0; k < 10; k++)
       fprintf(stderr, "[kb K5 trace] %-18s %14.0f clocks  %5.1f %%  (%.0f per batch)\n", steps[k], e->trace_acc[k], 100.0 * e->trace_acc[k] / (tot > 0 ? tot : 1),
               e->trace_acc[k] / (double)(e->stage_hits ? e->stage_hits : 1));
   }

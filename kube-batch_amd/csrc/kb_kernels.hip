@@ -545,6 +545,7 @@ struct K7Hdr {
   unsigned long long kstar;             // winner of the dirty row
   uint32_t nshapes, p, dirty_row, reason, exhausted, pad;
   uint32_t n_pairs, nlog, n_full, pad3;
+  uint32_t seq_rows, seq_pc, n_seq_rows, pad4;
   uint32_t n_batches, n_dirty_rows, n_refills, pad2;
 };
 
@@ -560,6 +561,7 @@ struct K7Mem {
   unsigned long long *dc_key;           // [cap]
   uint32_t *dc_nd, *dc_log;             // [cap]
   uint32_t *dlog;                       // [cap] slots changed by dirty rows, in order
+  unsigned long long *keyq;             // [cap2] keys of one shape against every dirty slot (row-at-a-time mode)
   uint32_t *bitmap;                     // [NP/32]
   double *save;                         // [K7_B][R-2] scalar-dimension values overwritten by speculative commits
   K7Hdr *H;
@@ -568,7 +570,7 @@ struct K7Mem {
 
 __host__ __device__ inline size_t k7_smem_bytes(uint32_t cap, uint32_t NP, int R) {
   size_t cap2 = (size_t)cap + K7_B;
-  return cap2 * (K5_NF8 * 8 + 3 * 4) + (size_t)cap * (8 + 8 + 12) + (size_t)(NP / 32) * 4 + (size_t)K7_B * (R > 2 ? R - 2 : 0) * 8 + sizeof(K7Hdr) + 64;
+  return cap2 * (K5_NF8 * 8 + 8 + 3 * 4) + (size_t)cap * (8 + 8 + 12) + (size_t)(NP / 32) * 4 + (size_t)K7_B * (R > 2 ? R - 2 : 0) * 8 + sizeof(K7Hdr) + 64;
 }
 
 __device__ __forceinline__ TaskVals k7_task_vals(const KbRowDesc &k) {
@@ -662,7 +664,8 @@ __global__ void __launch_bounds__(KB_K5_THREADS) k_commit(const KbCommitArgs a) 
   K7Mem M;
   M.cap2 = cap2;
   M.tab = reinterpret_cast<unsigned long long *>(k5_smem);
-  M.dc_key = M.tab + (size_t)K5_NF8 * cap2;   // 8-byte tables first
+  M.keyq = M.tab + (size_t)K5_NF8 * cap2;   // 8-byte tables first
+  M.dc_key = M.keyq + cap2;
   M.t_cls = reinterpret_cast<uint32_t *>(M.dc_key + cap);
   M.t_node = M.t_cls + cap2;
   M.t_left = reinterpret_cast<int *>(M.t_node + cap2);
@@ -674,7 +677,7 @@ __global__ void __launch_bounds__(KB_K5_THREADS) k_commit(const KbCommitArgs a) 
   M.bitmap = M.dlog + cap;
   {
     // byte offsets from the LDS base (pointer -> integer -> pointer round trips would lose the address space)
-    size_t off = (size_t)cap2 * (K5_NF8 * 8 + 3 * 4) + (size_t)cap * (8 + 8 + 12) + (size_t)(a.NP / 32) * 4;
+    size_t off = (size_t)cap2 * (K5_NF8 * 8 + 8 + 3 * 4) + (size_t)cap * (8 + 8 + 12) + (size_t)(a.NP / 32) * 4;
     off = (off + 15) & ~(size_t)15;
     M.H = reinterpret_cast<K7Hdr *>(k5_smem + off);
     M.save = reinterpret_cast<double *>(k5_smem + off + sizeof(K7Hdr));
@@ -687,7 +690,7 @@ __global__ void __launch_bounds__(KB_K5_THREADS) k_commit(const KbCommitArgs a) 
 
   for (uint32_t w = tid; w < a.NP / 32; w += KB_K5_THREADS) M.bitmap[w] = 0;
   for (uint32_t w = tid; w < cap; w += KB_K5_THREADS) { M.cursor[w] = 0; M.qstamp[w] = 0xFFFFFFFFu; M.dc_key[w] = 0ull; M.dc_nd[w] = 0; M.dc_log[w] = 0; }
-  if (tid == 0) { H.reason = KB_REASON_DONE; H.exhausted = 0; H.n_batches = 0; H.n_dirty_rows = 0; H.n_refills = 0; H.p = 0; H.dirty_row = 0; H.pad = 0; H.nlog = 0; H.n_full = 0; }
+  if (tid == 0) { H.reason = KB_REASON_DONE; H.exhausted = 0; H.n_batches = 0; H.n_dirty_rows = 0; H.n_refills = 0; H.p = 0; H.dirty_row = 0; H.pad = 0; H.nlog = 0; H.n_full = 0; H.pad2 = 0; H.pad3 = 0; H.kstar = 0ull; H.n_seq_rows = 0; }
   // per-thread source array of the fetch step: thread (row*16 + f) reads field f of the row's node
   // (pointers read from the KbDev copy are generic; the fetch step wants global_load, not flat_load)
   typedef const unsigned long long __attribute__((address_space(1))) *gptr8;
@@ -727,9 +730,9 @@ __global__ void __launch_bounds__(KB_K5_THREADS) k_commit(const KbCommitArgs a) 
   __syncthreads();
   K7_STAMP(0);
 
-  uint32_t i0 = 0, nd = 0, n_done = 0, reason = KB_REASON_DONE;
+  uint32_t i0 = 0, nd = 0, n_done = 0, reason = KB_REASON_DONE, nb_next = a.batch;
   while (i0 < a.n_rows) {
-    const uint32_t nb = min(a.batch, a.n_rows - i0);
+    const uint32_t nb = min(nb_next, a.n_rows - i0);
     // ---- stage the batch's row descriptors
     {
       const unsigned long long *src = reinterpret_cast<const unsigned long long *>(a.desc + i0);
@@ -955,23 +958,136 @@ __global__ void __launch_bounds__(KB_K5_THREADS) k_commit(const KbCommitArgs a) 
         else rsn = KB_REASON_NO_FEASIBLE;     // allocate.go:144-148: the job is abandoned; the host re-plans from here
       }
       if (lane == 0) {
+#ifdef KB_K5_TRACE
+        if (dirty_row == 1 && p == 0) { H.pad2++; if (KB_KEY_NODE(kstar) == KB_KEY_NODE(H.kstar)) H.pad3++; }
+        if (a.trace) { a.trace[16 + (p < 16 ? p : 16)] += 1; }
+#endif
         H.p = p; H.dirty_row = dirty_row; H.reason = rsn; H.kstar = kstar;
-        if (dirty_row == 1) H.n_dirty_rows++;
       }
     }
     __syncthreads();
     K7_STAMP(7);
-    // ---- commit the valid prefix, roll the rest back, apply the dirty row
+    // ---- commit the valid prefix
     const uint32_t p = H.p, dirty_row = H.dirty_row;
-    if (tid < nb) {
+    uint32_t pc = p, rows = p + (dirty_row == 2 ? 1u : 0u);   // candidates consumed, rows consumed
+    if (tid < p) {
+      const uint32_t j = tid;
+      const KbRowDesc &k = H.desc[j];
+      atomicMax(&M.cursor[k.slot], H.idx[j] + 1);
+      k7_commit_globals<false>(a, k, i0 + j, KB_KEY_NODE(H.c[j]), H.kind[j]);
+    }
+    if (dirty_row == 2 && tid == 0) *reinterpret_cast<uint2 *>(&a.dec[i0 + p]) = make_uint2(KB_NONE_U32, 0u);
+    if (dirty_row == 1) {
+      // ---- a dirty node beats row p's clean candidate.  Dirty winners come in chains (a big node keeps the best score for
+      // several tasks), so the rest of row p's run of same-shape rows is committed one row at a time by wave 0 alone, with no
+      // workgroup barrier per row: every thread first evaluates the shape against all dirty slots (keyq), then per row
+      //     winner = max( max(keyq) , next unconsumed clean candidate of the run )
+      // a dirty winner's slot is updated in LDS and its key re-evaluated by one lane; a clean winner takes the slot the fetch /
+      // apply steps already prepared for that candidate (same shape => same post-commit state) with the key the evaluate step
+      // already computed (kb).
+      const uint32_t q = H.q_of[p];
+      {
+        const KbRowDesc &k = H.desc[p];
+        const TaskVals tv = k7_task_vals(k);
+        for (uint32_t x = tid; x < nd + p; x += KB_K5_THREADS) {
+          const NodeVals nv = k5_slot_vals(M.tab, M.t_cls, M.t_left, cap2, x);
+          const uint32_t node = M.t_node[x];
+          const uint32_t res = eval_pair_k5(a, tv, nv, node, a.use_crow ? &k.crow : nullptr);
+          M.keyq[x] = res ? KB_KEY(res & 0xFFFFu, node) : 0ull;
+        }
+      }
+      __syncthreads();
+      K7_STAMP(9);
+      if (wave == 0) {
+        const uint32_t myq = (lane < nb) ? H.q_of[lane] : 0xFFFFFFFFu;
+        const unsigned long long diff = __ballot(lane > p && lane < nb && myq != q);
+        const uint32_t run_end = diff ? (uint32_t)(__ffsll((unsigned long long)diff) - 1) : nb;
+        const uint32_t shape = H.desc[p].slot;
+        uint32_t r = p, ndc = nd + p, rsn = KB_REASON_DONE;
+        while (r < run_end) {
+          unsigned long long kmax = 0ull;
+          uint32_t xmax = 0;
+          for (uint32_t x = lane; x < ndc; x += 64) {
+            const unsigned long long kk = M.keyq[x];
+            if (kk > kmax) { kmax = kk; xmax = x; }
+          }
+          const unsigned long long best = wave_max_key(kmax);
+          const unsigned long long cc = H.c[pc];
+          const KbRowDesc &k = H.desc[r];
+          if (best == 0ull && cc == 0ull) {
+            if (a.backfill) {   // backfill.go:50-66: the task stays Pending
+              if (lane == 0) *reinterpret_cast<uint2 *>(&a.dec[i0 + r]) = make_uint2(KB_NONE_U32, 0u);
+              r++;
+              continue;
+            }
+            rsn = KB_REASON_NO_FEASIBLE;   // allocate.go:144-148
+            break;
+          }
+          if (best > cc) {
+            const unsigned long long own = __ballot(kmax == best);
+            const uint32_t xs = (uint32_t)__builtin_amdgcn_readlane((int)xmax, __ffsll((unsigned long long)own) - 1);
+            const uint32_t n = KB_KEY_NODE(best);
+            // shapes whose cached dirty max sits on the node that changes lose their cache
+            for (uint32_t sh = lane; sh < a.n_mrows; sh += 64) {
+              const unsigned long long ck = M.dc_key[sh];
+              if (ck != 0ull && KB_KEY_NODE(ck) == n) M.dc_nd[sh] = 0xFFFFFFFFu;
+            }
+            uint32_t kind = 0;
+            if (lane == 0) {
+              kind = k7_apply_slot(a, M, k, xs, n);
+              M.t_left[xs] -= 1;
+              k7_commit_globals<true>(a, k, i0 + r, n, kind);
+              const uint32_t nl = H.nlog;
+              M.dlog[nl] = xs;
+              H.nlog = nl + 1;
+              H.n_dirty_rows++;
+              const TaskVals tv = k7_task_vals(k);
+              const NodeVals nv = k5_slot_vals(M.tab, M.t_cls, M.t_left, cap2, xs);
+              const uint32_t res = eval_pair_k5(a, tv, nv, n, a.use_crow ? &k.crow : nullptr);
+              M.keyq[xs] = res ? KB_KEY(res & 0xFFFFu, n) : 0ull;
+            }
+            kind = (uint32_t)__builtin_amdgcn_readfirstlane((int)kind);
+            r++;
+            if (kind) { rsn = KB_REASON_PIPELINED; break; }
+          } else {
+            // the prepared slot nd+pc holds candidate pc's node after ROW pc's task; identical for row r's task when both
+            // rows carry plain requests (same shape; no init-container maximum, no scalar resources)
+            const KbRowDesc &kc = H.desc[pc];
+            const uint32_t plain = (uint32_t)(k.flags & kc.flags & 1) && k.resmask == 0 && kc.resmask == 0;
+            if (!plain) break;
+            const uint32_t kind = H.kind[pc];
+            if (lane == 0) {
+              atomicMax(&M.cursor[shape], H.idx[pc] + 1);
+              k7_commit_globals<false>(a, k, i0 + r, KB_KEY_NODE(cc), kind);
+              M.keyq[ndc] = H.kb[pc][q];
+            }
+            ndc++; pc++; r++;
+            if (kind) { rsn = KB_REASON_PIPELINED; break; }
+          }
+          __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+        }
+        // the shape's dirty max as of now becomes its cache
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        unsigned long long kmax = 0ull;
+        for (uint32_t x = lane; x < ndc; x += 64) { const unsigned long long kk = M.keyq[x]; if (kk > kmax) kmax = kk; }
+        kmax = wave_max_key(kmax);
+        if (lane == 0) {
+          M.dc_key[shape] = kmax; M.dc_nd[shape] = ndc; M.dc_log[shape] = H.nlog;
+          H.seq_rows = r; H.seq_pc = pc; H.reason = rsn; H.n_seq_rows += r - p;
+        }
+      }
+      __syncthreads();
+      rows = H.seq_rows;
+      pc = H.seq_pc;
+    }
+    // ---- roll back the candidates nobody consumed: they are re-speculated by the next batch
+    if (tid < nb && tid >= pc) {
       const uint32_t j = tid;
       const unsigned long long cj = H.c[j];
-      const KbRowDesc &k = H.desc[j];
-      if (j < p) {
-        const uint32_t n = KB_KEY_NODE(cj);
-        atomicMax(&M.cursor[k.slot], H.idx[j] + 1);
-        k7_commit_globals<false>(a, k, i0 + j, n, H.kind[j]);
-      } else if (cj) {
+      if (cj) {
+        const KbRowDesc &k = H.desc[j];
         const uint32_t n = KB_KEY_NODE(cj);
         atomicAnd(&M.bitmap[n >> 5], ~(1u << (n & 31)));
         if (H.has_map[j]) {
@@ -985,34 +1101,11 @@ __global__ void __launch_bounds__(KB_K5_THREADS) k_commit(const KbCommitArgs a) 
         }
       }
     }
-    if (a.has_delta) __syncthreads();   // the dirty row may hit a node one of the clean rows above just added a delta for
-    if (dirty_row == 1) {
-      const unsigned long long kstar = H.kstar;
-      const uint32_t n = KB_KEY_NODE(kstar);
-      // shapes whose cached dirty max sits on the node that is about to change lose their cache
-      for (uint32_t sh = tid; sh < a.n_mrows; sh += KB_K5_THREADS) {
-        const unsigned long long ck = M.dc_key[sh];
-        if (ck != 0ull && KB_KEY_NODE(ck) == n) M.dc_nd[sh] = 0xFFFFFFFFu;
-      }
-      for (uint32_t x = tid; x < nd + p; x += KB_K5_THREADS) {
-        if (M.t_node[x] == n) {
-          const KbRowDesc &k = H.desc[p];
-          const uint32_t kind = k7_apply_slot(a, M, k, x, n);
-          M.t_left[x] -= 1;
-          k7_commit_globals<true>(a, k, i0 + p, n, kind);
-          if (kind) H.reason = KB_REASON_PIPELINED;
-          const uint32_t nl = H.nlog;
-          M.dlog[nl] = x;
-          H.nlog = nl + 1;
-        }
-      }
-    } else if (dirty_row == 2) {
-      if (tid == 0) *reinterpret_cast<uint2 *>(&a.dec[i0 + p]) = make_uint2(KB_NONE_U32, 0u);
-    }
     __syncthreads();
     K7_STAMP(8);
-    nd += p;
-    i0 += p + (dirty_row ? 1u : 0u);
+    nd += pc;
+    i0 += rows;
+    nb_next = a.batch;
     n_done = i0;
     reason = H.reason;
     if (H.exhausted) reason = KB_REASON_INTERNAL;
@@ -1035,10 +1128,10 @@ __global__ void __launch_bounds__(KB_K5_THREADS) k_commit(const KbCommitArgs a) 
     }
   }
   if (tid == 0) {
-    a.result[0] = n_done; a.result[1] = reason; a.result[2] = nd; a.result[3] = 0; a.result[4] = H.n_refills; a.result[7] = H.n_full;
+    a.result[0] = n_done; a.result[1] = reason; a.result[2] = nd; a.result[3] = 0; a.result[4] = H.n_refills; a.result[7] = H.n_full; a.result[3] = H.n_seq_rows;
     a.result[5] = H.n_batches; a.result[6] = H.n_dirty_rows;
 #ifdef KB_K5_TRACE
-    if (a.trace) for (int k = 0; k < 12; k++) a.trace[k] = tacc[k];
+    if (a.trace) { for (int k = 0; k < 12; k++) a.trace[k] = tacc[k]; a.trace[12] = H.pad2; a.trace[13] = H.pad3; }
 #endif
   }
 }
@@ -1203,6 +1296,9 @@ void kb_launch_commit(const KbDev &d, const KbRound &r, KbDev *dev_copy, KbRound
   static uint32_t batch = 0;
   if (!batch) { const char *b = getenv("KB_K5_BATCH"); batch = b ? (uint32_t)atoi(b) : K7_B; if (batch < 1 || batch > K7_B) batch = K7_B; }
   a.batch = batch;
+  static uint32_t batch_small = 0;
+  if (!batch_small) { const char *b = getenv("KB_K5_BATCH_SMALL"); batch_small = b ? (uint32_t)atoi(b) : 4; if (batch_small < 1 || batch_small > batch) batch_small = batch; }
+  a.batch_small = batch_small;
   hipLaunchKernelGGL(k_commit, dim3(1), dim3(KB_K5_THREADS), sh, (hipStream_t)stream, a);
   hipLaunchKernelGGL(k_apply, dim3((r.n_rows + 255) / 256), dim3(256), 0, (hipStream_t)stream, d, r);
 }
