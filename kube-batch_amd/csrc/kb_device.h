@@ -101,10 +101,9 @@ struct KbRound {
   uint32_t own_row0, own_row1;
 };
 
-// Arguments of the commit kernel.  Only the ~20 scalars the per-row loops touch are passed by value (they live in SGPRs);
-// the full session / round views stay in device memory and are dereferenced on rare paths only (scalar resource
-// dimensions, live rescan, multi-GPU deltas, prologue / epilogue).  Passing KbDev + KbRound by value (~110 SGPRs of
-// pointers) made the compiler spill SGPRs into VGPR lanes and restore them with v_readlane pairs all over the hot loop.
+// Hot arguments of the commit kernel: the ~25 scalars its loops touch (they live in SGPRs).  The full session / round
+// views are read through `dev` / `round` on rare paths only (scalar resource dimensions, multi-GPU deltas, prologue /
+// epilogue); keeping ~110 SGPRs of pointers live made the compiler spill SGPRs into VGPR lanes all over the loop.
 struct KbCommitArgs {
   const KbDev *dev;
   const KbRound *round;
@@ -117,8 +116,7 @@ struct KbCommitArgs {
   int fit_mode, backfill, pred_enabled, score_enabled, wL, wM, wB;
   uint32_t use_crow, has_delta;
   int R;
-  uint32_t batch;        // rows speculated per batch (<= 16)
-  uint32_t batch_small;  // ... in the batch right after a dirty row that came early
+  uint32_t batch;   // rows speculated per batch (<= 16)
 };
 
 #define KB_K5_MAX_WINDOW 1024u   // dirty-node table + row descriptors of the commit kernel live in LDS: 152 B per row
@@ -135,7 +133,7 @@ void kb_launch_argmax(const KbDev &d, const KbRound &r, void *stream);
 // per-task rows out of the per-shape rows (kb_eval_matrix / kb_bench_matrix: the materialised T x N matrix)
 void kb_launch_expand(const KbDev &d, const uint16_t *s_score, const uint32_t *s_mask, const uint32_t *row_slot, uint32_t n_rows,
                       uint16_t *score, uint32_t *maskw, void *stream);
-void kb_launch_commit(const KbDev &d, const KbRound &r, KbDev *dev_copy, KbRound *round_copy, void *stream);
+void kb_launch_commit(const KbDev &d, const KbRound &r, void *stream);
 // node state := round-start state + reduced deltas; returns how many values differ from the live (locally committed) state
 uint32_t kb_apply_deltas(const KbDev &d, const double *s_idle, const double *s_rel, const long long *s_nzc, const long long *s_nzm,
                          const int *s_podcnt, const double *delta, uint32_t *dev_counter, void *stream);

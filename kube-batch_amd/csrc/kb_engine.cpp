@@ -56,6 +56,30 @@ struct DevBuf {
   template <typename T> T *as() const { return reinterpret_cast<T *>(p); }
 };
 
+// grow-only pinned host array: the per-round staging buffers (window rows in, decision records out) are copied with
+// hipMemcpyAsync every round, which only is asynchronous (and cheap to issue) from page-locked memory
+template <typename T> struct Pinned {
+  T *p = nullptr;
+  size_t n = 0;
+  Pinned() = default;
+  Pinned(const Pinned &) = delete;
+  Pinned &operator=(const Pinned &) = delete;
+  ~Pinned() { if (p) (void)hipHostFree(p); }
+  void resize(size_t m) {
+    if (m <= n) return;
+    T *q = nullptr;
+    HIP_OK(hipHostMalloc((void **)&q, sizeof(T) * m, hipHostMallocDefault));
+    if (p) { std::memcpy(q, p, sizeof(T) * n); (void)hipHostFree(p); }
+    p = q;
+    n = m;
+  }
+  T *data() { return p; }
+  const T *data() const { return p; }
+  size_t size() const { return n; }
+  T &operator[](size_t i) { return p[i]; }
+  const T &operator[](size_t i) const { return p[i]; }
+};
+
 template <typename T> void upload(DevBuf &b, const T *src, size_t n, hipStream_t s) {
   b.alloc(n * sizeof(T));
   if (n) HIP_OK(hipMemcpyAsync(b.p, src, n * sizeof(T), hipMemcpyHostToDevice, s));
@@ -111,7 +135,6 @@ struct kb_engine {
   uint32_t total_mask = 0;
   // round buffers
   DevBuf b_desc, b_trace;
-  DevBuf b_views;   // device copies of KbDev + KbRound for the commit kernel's rare paths
   bool trace_on = false;
   std::vector<double> trace_acc = std::vector<double>(3 * 4 * 12, 0.0);
   DevBuf b_sscore, b_smask, b_xslot;   // per-shape rows and row->shape map of kb_eval_matrix / kb_bench_matrix
@@ -119,8 +142,9 @@ struct kb_engine {
   DevBuf b_rows, b_slot, b_mrows, b_same, b_score, b_maskw, b_keys, b_dec, b_result;
   uint32_t win_cap = 0, mat_cap = 0;
   size_t keys_cap = 0;
-  std::vector<uint32_t> h_rows, h_slot, h_mrows, h_decnode, h_deckind;
-  std::vector<unsigned long long> h_dec;
+  Pinned<uint32_t> h_rows, h_slot, h_mrows;
+  std::vector<uint32_t> h_decnode, h_deckind;
+  Pinned<unsigned long long> h_dec;
   std::vector<uint8_t> h_same;
   std::vector<uint32_t> shape_stamp, shape_slot_of;   // per row-shape id: round stamp and slot inside the current round
   uint32_t stamp = 0;
@@ -371,7 +395,7 @@ void round_commit(kb_engine *e, const RoundCtx &c, unsigned long long *keys, dou
   r.own_row1 = own1;
   Timer &t5 = get_timer(e, 2);
   HIP_OK(hipEventRecord(t5.a, e->stream));
-  kb_launch_commit(c.d, r, e->b_views.as<KbDev>(), reinterpret_cast<KbRound *>(e->b_views.as<unsigned char>() + ((sizeof(KbDev) + 15) & ~size_t(15))), e->stream);
+  kb_launch_commit(c.d, r, e->stream);
   HIP_OK(hipEventRecord(t5.b, e->stream));
   HIP_OK(hipMemcpyAsync(e->h_result, e->b_result.p, sizeof(uint32_t) * 8, hipMemcpyDeviceToHost, e->stream));
   HIP_OK(hipMemcpyAsync(e->h_dec.data(), e->b_dec.p, sizeof(unsigned long long) * c.n, hipMemcpyDeviceToHost, e->stream));
@@ -613,7 +637,6 @@ int kb_engine_create(const kb_config *cfg, kb_engine **out) {
     HIP_OK(hipStreamCreateWithFlags(&eng->stream, hipStreamNonBlocking));
     HIP_OK(hipHostMalloc((void **)&eng->h_result, sizeof(uint32_t) * 8, hipHostMallocDefault));
     eng->b_result.alloc(sizeof(uint32_t) * 8);
-    eng->b_views.alloc(sizeof(KbDev) + sizeof(KbRound) + 64);
     if (const char *tr = getenv("KB_K5_TRACE")) {
       if (tr[0] == '1') { eng->trace_on = true; eng->b_trace.alloc(sizeof(unsigned long long) * 64); HIP_OK(hipMemset(eng->b_trace.p, 0, sizeof(unsigned long long) * 64)); }
     }

@@ -18,6 +18,7 @@
 // int64 truncating division reproduced exactly through a reciprocal estimate + integer remainder fix-up.
 // The path is elementwise compare + integer scoring, HBM/latency bound: no MFMA.
 #include <hip/hip_runtime.h>
+#include <stddef.h>
 #include <stdint.h>
 #include <stdlib.h>
 
@@ -658,7 +659,21 @@ __device__ __forceinline__ uint32_t k7_apply_slot(const KbCommitArgs &a, const K
 #define K7_STAMP(k) do { } while (0)
 #endif
 
-__global__ void __launch_bounds__(KB_K5_THREADS) k_commit(const KbCommitArgs a) {
+// The launch passes {hot scalars, KbDev, KbRound} as ONE by-value block.  Only `hot` is named in the code (-> SGPRs); the two
+// views are reached through the kernel-argument segment pointer, i.e. read from constant memory where a rare path needs them.
+struct K7KernArgs {
+  KbCommitArgs hot;
+  KbDev dev;
+  KbRound round;
+};
+
+__global__ void __launch_bounds__(KB_K5_THREADS) k_commit(const K7KernArgs ka) {
+  KbCommitArgs a = ka.hot;
+  {
+    const unsigned char __attribute__((address_space(4))) *kp = (const unsigned char __attribute__((address_space(4))) *)__builtin_amdgcn_kernarg_segment_ptr();
+    a.dev = (const KbDev *)(kp + offsetof(K7KernArgs, dev));
+    a.round = (const KbRound *)(kp + offsetof(K7KernArgs, round));
+  }
   extern __shared__ __align__(16) unsigned char k5_smem[];
   const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, cap = a.cap, cap2 = a.cap + K7_B;
   K7Mem M;
@@ -730,9 +745,9 @@ __global__ void __launch_bounds__(KB_K5_THREADS) k_commit(const KbCommitArgs a) 
   __syncthreads();
   K7_STAMP(0);
 
-  uint32_t i0 = 0, nd = 0, n_done = 0, reason = KB_REASON_DONE, nb_next = a.batch;
+  uint32_t i0 = 0, nd = 0, n_done = 0, reason = KB_REASON_DONE;
   while (i0 < a.n_rows) {
-    const uint32_t nb = min(nb_next, a.n_rows - i0);
+    const uint32_t nb = min(a.batch, a.n_rows - i0);
     // ---- stage the batch's row descriptors
     {
       const unsigned long long *src = reinterpret_cast<const unsigned long long *>(a.desc + i0);
@@ -1105,7 +1120,6 @@ __global__ void __launch_bounds__(KB_K5_THREADS) k_commit(const KbCommitArgs a) 
     K7_STAMP(8);
     nd += pc;
     i0 += rows;
-    nb_next = a.batch;
     n_done = i0;
     reason = H.reason;
     if (H.exhausted) reason = KB_REASON_INTERNAL;
@@ -1127,6 +1141,19 @@ __global__ void __launch_bounds__(KB_K5_THREADS) k_commit(const KbCommitArgs a) 
       d.podcnt[n] = d.maxpods[n] - M.t_left[slot];
     }
   }
+  // task-table side of ssn.Allocate / ssn.Pipeline for the committed rows (job.UpdateTaskStatus, task.NodeName:
+  // framework/session.go:243,205; api/node_info.go:206-209)
+  {
+    const KbDev &d = *a.dev;
+    for (uint32_t i = tid; i < n_done; i += KB_K5_THREADS) {
+      const uint2 dc = *reinterpret_cast<const uint2 *>(&a.dec[i]);
+      if (dc.x == KB_NONE_U32) continue;
+      const uint32_t t = a.desc[i].task;
+      d.t_status[t] = dc.y ? KB_TASK_PIPELINED : KB_TASK_ALLOCATED;
+      d.t_node[t] = dc.x;
+      d.t_counted[t] = 1;
+    }
+  }
   if (tid == 0) {
     a.result[0] = n_done; a.result[1] = reason; a.result[2] = nd; a.result[3] = 0; a.result[4] = H.n_refills; a.result[7] = H.n_full; a.result[3] = H.n_seq_rows;
     a.result[5] = H.n_batches; a.result[6] = H.n_dirty_rows;
@@ -1134,19 +1161,6 @@ __global__ void __launch_bounds__(KB_K5_THREADS) k_commit(const KbCommitArgs a) 
     if (a.trace) { for (int k = 0; k < 12; k++) a.trace[k] = tacc[k]; a.trace[12] = H.pad2; a.trace[13] = H.pad3; }
 #endif
   }
-}
-
-// task-table side of ssn.Allocate / ssn.Pipeline for the rows the commit kernel processed (job.UpdateTaskStatus,
-// task.NodeName: framework/session.go:243,205; api/node_info.go:206-209), applied in parallel after the round
-__global__ void __launch_bounds__(256) k_apply(KbDev d, KbRound r) {
-  uint32_t i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= r.result[0]) return;     // n_done
-  uint2 dc = *reinterpret_cast<const uint2 *>(&r.dec[i]);
-  if (dc.x == KB_NONE_U32) return;
-  uint32_t t = r.rows[i];
-  d.t_status[t] = dc.y ? KB_TASK_PIPELINED : KB_TASK_ALLOCATED;
-  d.t_node[t] = dc.x;
-  d.t_counted[t] = 1;
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -1272,20 +1286,23 @@ void kb_launch_argmax(const KbDev &d, const KbRound &r, void *stream) {
   }
   hipLaunchKernelGGL(k_argmax, dim3(r.n_mrows), dim3(256), sh, (hipStream_t)stream, d, r);
 }
-// the session / round views the commit kernel dereferences on its rare paths, written stream-ordered before the launch
-__global__ void k_store_views(KbDev d, KbRound r, KbDev *dd, KbRound *dr) { *dd = d; *dr = r; }
-
-void kb_launch_commit(const KbDev &d, const KbRound &r, KbDev *dev_copy, KbRound *round_copy, void *stream) {
+void kb_launch_commit(const KbDev &d, const KbRound &r, void *stream) {
   if (r.n_rows == 0) return;
   static bool attr_set = false;
+  static uint32_t batch = 0;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_commit), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    const char *b = getenv("KB_K5_BATCH");   // rows speculated per batch (tuning knob)
+    batch = b ? (uint32_t)atoi(b) : K7_B;
+    if (batch < 1 || batch > K7_B) batch = K7_B;
     attr_set = true;
   }
-  size_t sh = k7_smem_bytes(r.cap, d.NP, d.R);
-  hipLaunchKernelGGL(k_store_views, dim3(1), dim3(1), 0, (hipStream_t)stream, d, r, dev_copy, round_copy);
-  KbCommitArgs a;
-  a.dev = dev_copy; a.round = round_copy;
+  const size_t sh = k7_smem_bytes(r.cap, d.NP, d.R);
+  K7KernArgs ka;
+  ka.dev = d;
+  ka.round = r;
+  KbCommitArgs &a = ka.hot;
+  a.dev = nullptr; a.round = nullptr;   // set from the kernel-argument segment inside the kernel
   a.keys = r.keys; a.dec = r.dec; a.desc = r.desc; a.result = r.result; a.trace = r.trace;
   a.n_rows = r.n_rows; a.n_mrows = r.n_mrows; a.L = r.L; a.cap = r.cap; a.N = d.N; a.NP = d.NP;
   a.fit_mode = r.fit_mode; a.backfill = r.backfill; a.pred_enabled = d.pred_enabled; a.score_enabled = d.score_enabled;
@@ -1293,14 +1310,8 @@ void kb_launch_commit(const KbDev &d, const KbRound &r, KbDev *dev_copy, KbRound
   a.use_crow = (d.pred_enabled && d.crows != nullptr && d.n_nc <= 32) ? 1u : 0u;
   a.has_delta = r.delta != nullptr ? 1u : 0u;
   a.R = d.R;
-  static uint32_t batch = 0;
-  if (!batch) { const char *b = getenv("KB_K5_BATCH"); batch = b ? (uint32_t)atoi(b) : K7_B; if (batch < 1 || batch > K7_B) batch = K7_B; }
   a.batch = batch;
-  static uint32_t batch_small = 0;
-  if (!batch_small) { const char *b = getenv("KB_K5_BATCH_SMALL"); batch_small = b ? (uint32_t)atoi(b) : 4; if (batch_small < 1 || batch_small > batch) batch_small = batch; }
-  a.batch_small = batch_small;
-  hipLaunchKernelGGL(k_commit, dim3(1), dim3(KB_K5_THREADS), sh, (hipStream_t)stream, a);
-  hipLaunchKernelGGL(k_apply, dim3((r.n_rows + 255) / 256), dim3(256), 0, (hipStream_t)stream, d, r);
+  hipLaunchKernelGGL(k_commit, dim3(1), dim3(KB_K5_THREADS), sh, (hipStream_t)stream, ka);
 }
 void kb_launch_finalize(const KbDev &d, const uint32_t *job_task_begin, const int *job_min_avail, const uint32_t *job_queue,
                         int gang_ready_enabled, const double *total, uint32_t total_mask, const double *deserved,
