@@ -655,7 +655,7 @@ void kb_engine_destroy(kb_engine *e) {
     fprintf(stderr, "[kb K5 trace] batches that start with a dirty row: %.0f, of which on the previous dirty row's node: %.0f\n[kb K5 trace] valid-prefix histogram:", e->trace_acc[12], e->trace_acc[13]);
     for (int k = 0; k <= 16; k++) fprintf(stderr, " %d:%.0f", k, e->trace_acc[16 + k]);
     fprintf(stderr, "\n");
-    static const char *steps[10] = {"prologue", "stage descriptors", "shapes + windows", "walk", "fetch", "apply", "evaluate", "validate", "commit + row mode", "row-mode evaluate"};
+    static const char *steps[10] = {"prologue", "stage descriptors", "shapes + windows", "walk", "(unused)", "fetch + apply", "evaluate", "validate", "commit + row mode", "row-mode evaluate"};
     double tot = 0;
     for (int k = 0; k < 10; k++) tot += e->trace_acc[k];
     for (int k = 0; k < 10; k++)

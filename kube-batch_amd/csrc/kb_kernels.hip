@@ -527,6 +527,7 @@ __device__ __forceinline__ void k5_field_ptrs(const KbDev &d, uint32_t fld, cons
 // A batch costs about as much as two rows of a row-at-a-time protocol, and commits ~10 rows on the benchmark snapshot.
 // ------------------------------------------------------------------------------------------------------------
 #define K7_B 16u
+#define K7_D 96u   // row descriptors staged per refill
 
 struct K7Hdr {
   unsigned long long c[K7_B];           // clean candidate key of batch row j (0: the list has no clean feasible node left)
@@ -539,10 +540,9 @@ struct K7Hdr {
   uint32_t idx[K7_B];                   // list position of c[j]
   uint32_t kind[K7_B];                  // 0 Allocate, 1 Pipeline
   uint32_t has_map[K7_B];               // the row's speculative commit wrote scalar dimensions (saved values are valid)
-  int maxp[K7_B], pods[K7_B];
   // evaluation work list of shape q: slots [e_start, nd), then dlog[e_log0 .. e_log0 + e_nlog), then the batch's new slots
   uint32_t e_off[K7_B], e_start[K7_B], e_nlog[K7_B], e_log0[K7_B];
-  KbRowDesc desc[K7_B];
+  KbRowDesc dbuf[K7_D];                 // row descriptors [dbase, dbase + dcnt) of the window, staged ahead of the batches
   unsigned long long kstar;             // winner of the dirty row
   uint32_t nshapes, p, dirty_row, reason, exhausted, pad;
   uint32_t n_pairs, nlog, n_full, pad3;
@@ -745,21 +745,24 @@ __global__ void __launch_bounds__(KB_K5_THREADS) k_commit(const K7KernArgs ka) {
   __syncthreads();
   K7_STAMP(0);
 
-  uint32_t i0 = 0, nd = 0, n_done = 0, reason = KB_REASON_DONE;
+  uint32_t i0 = 0, nd = 0, n_done = 0, reason = KB_REASON_DONE, dbase = 0, dcnt = 0;
   while (i0 < a.n_rows) {
     const uint32_t nb = min(a.batch, a.n_rows - i0);
-    // ---- stage the batch's row descriptors
-    {
+    // ---- stage row descriptors: three batches' worth per refill, so most batches find theirs already in LDS
+    if (i0 < dbase || i0 + nb > dbase + dcnt) {
+      dbase = i0;
+      dcnt = min(K7_D, a.n_rows - i0);
       const unsigned long long *src = reinterpret_cast<const unsigned long long *>(a.desc + i0);
-      unsigned long long *dst = reinterpret_cast<unsigned long long *>(H.desc);
-      for (uint32_t w = tid; w < nb * (uint32_t)(sizeof(KbRowDesc) / 8); w += KB_K5_THREADS) dst[w] = src[w];
+      unsigned long long *dst = reinterpret_cast<unsigned long long *>(H.dbuf);
+      for (uint32_t w = tid; w < dcnt * (uint32_t)(sizeof(KbRowDesc) / 8); w += KB_K5_THREADS) dst[w] = src[w];
+      __syncthreads();
     }
-    __syncthreads();
+    const KbRowDesc *bd = H.dbuf + (i0 - dbase);
     K7_STAMP(1);
     // ---- distinct shapes of the batch (wave 0): q_of[j] = rank of the first row with row j's shape
     if (wave == 0) {
       const bool in = lane < nb;
-      const uint32_t s = in ? (uint32_t)H.desc[in ? lane : 0].slot : 0u;
+      const uint32_t s = in ? (uint32_t)bd[in ? lane : 0].slot : 0u;
       if (in) atomicMin(&M.qstamp[s], lane);
       const uint32_t first = in ? M.qstamp[s] : 0xFFFFFFFFu;
       const bool isrep = in && first == lane;
@@ -800,7 +803,7 @@ __global__ void __launch_bounds__(KB_K5_THREADS) k_commit(const K7KernArgs ka) {
     // ---- candidate windows of the distinct shapes: one wave per shape
     const uint32_t nshapes = H.nshapes;
     for (uint32_t q = wave; q < nshapes; q += K5_WAVES) {
-      const uint32_t s = H.desc[H.rep[q]].slot;
+      const uint32_t s = bd[H.rep[q]].slot;
       const uint32_t e = H.win_base[q] + lane;
       H.win[q][lane] = (e < a.L) ? a.keys[(size_t)s * a.L + e] : 0ull;
     }
@@ -815,7 +818,6 @@ __global__ void __launch_bounds__(KB_K5_THREADS) k_commit(const K7KernArgs ka) {
         const unsigned long long diff = __ballot(lane >= j && lane < nb && myq != q);
         const uint32_t j1 = diff ? (uint32_t)(__ffsll((unsigned long long)diff) - 1) : nb;
         uint32_t m = j1 - j;
-        const uint32_t s = H.desc[H.rep[q]].slot;
         for (;;) {
           const unsigned long long wkey = H.win[q][lane];
           const uint32_t base = H.win_base[q];
@@ -850,6 +852,7 @@ __global__ void __launch_bounds__(KB_K5_THREADS) k_commit(const K7KernArgs ka) {
             break;
           }
           const uint32_t e = nbase + lane;
+          const uint32_t s = bd[H.rep[q]].slot;
           H.win[q][lane] = (e < a.L) ? a.keys[(size_t)s * a.L + e] : 0ull;
           if (lane == 0) { H.win_base[q] = nbase; H.n_refills++; }
         }
@@ -857,39 +860,57 @@ __global__ void __launch_bounds__(KB_K5_THREADS) k_commit(const K7KernArgs ka) {
     }
     __syncthreads();
     K7_STAMP(3);
-    // ---- fetch: thread (row*16 + f) reads field f of the row's candidate node into the row's new dirty slot
-    for (uint32_t w = tid; w < nb * 16; w += KB_K5_THREADS) {
-      const uint32_t j = w >> 4, f = w & 15;
-      const unsigned long long cj = H.c[j];
-      if (cj) {
-        const uint32_t n = KB_KEY_NODE(cj), slot = nd + j;
-        if (f < K5_NF8) M.tab[(size_t)f * cap2 + slot] = g8[n];
-        else if (f == 10) M.t_cls[slot] = g4[n];
-        else if (f == 11) H.maxp[j] = (int)g4[n];
-        else if (f == 12) H.pods[j] = (int)g4[n];
-        else if (f == 13) M.t_node[slot] = n;
-      }
-    }
-    __syncthreads();
-    K7_STAMP(4);
-    // ---- apply: the slot holds the node's state after the row committed; scalar dimensions (global memory, rare) are
-    //      written speculatively and their old values saved for the rollback
-    if (tid < nb) {
-      const uint32_t j = tid;
+    // ---- fetch + apply: the 16 lanes of one DPP row handle one batch row.  Lane f reads field f of the row's candidate
+    //      node (one load), the group votes Allocate / Pipeline (allocate.go:160) with a ballot, every lane applies
+    //      NodeInfo.AddTask (api/node_info.go:172-212) to its own field and stores it into the row's NEW dirty slot: the slot
+    //      holds the node's state AFTER the row committed.  Scalar dimensions (global memory, rare) are written
+    //      speculatively by lane 15 and their old values saved for the rollback.
+    if (tid < nb * 16) {
+      const uint32_t j = tid >> 4, f = tid & 15;
       const unsigned long long cj = H.c[j];
       uint32_t kind = 0, has_map = 0;
       if (cj) {
-        const KbRowDesc &k = H.desc[j];
+        const KbRowDesc &k = bd[j];
         const uint32_t n = KB_KEY_NODE(cj), slot = nd + j;
-        kind = k7_apply_slot(a, M, k, slot, n);
-        M.t_left[slot] = H.maxp[j] - H.pods[j] - 1;
-        const uint32_t km = k.resmask;
-        if (km) {
+        unsigned long long v8 = 0ull;
+        uint32_t v4 = 0;
+        if (f < K5_NF8) v8 = g8[n];
+        else if (f <= 12) v4 = g4[n];
+        double res0 = k.init0, res1 = k.init1;
+        if (!(k.flags & 1)) { const KbDev &d = *a.dev; res0 = d.t_res[k.task]; res1 = d.t_res[(size_t)d.T + k.task]; }
+        bool ok = true;
+        if (!a.backfill) {
+          const double dv = __longlong_as_double((long long)v8);
+          if (f == K5F_IDLE0) ok = le_eps(k.init0, dv, EPS_CPU);
+          else if (f == K5F_IDLE1) ok = le_eps(k.init1, dv, EPS_MEM);
+          else if (f == 15 && (k.active >> 2)) {
+            const KbDev &d = *a.dev;
+            uint32_t act = k.active >> 2, dd = 2;
+            while (act) {
+              if (act & 1u) ok = ok && le_eps(d.t_init[(size_t)dd * d.T + k.task], d.idle[(size_t)dd * d.NP + n], EPS_SCALAR);
+              act >>= 1; dd++;
+            }
+          }
+        }
+        const unsigned long long bad = __ballot(!ok);
+        kind = ((bad >> (lane & 48u)) & 0xFFFFull) ? 1u : 0u;
+        const uint32_t f0 = kind ? K5F_REL0 : K5F_IDLE0;
+        const double dv = __longlong_as_double((long long)v8);
+        if (f == f0) v8 = (unsigned long long)__double_as_longlong(dv - res0);
+        else if (f == f0 + 1) v8 = (unsigned long long)__double_as_longlong(dv - res1);
+        else if (f == K5F_NZC) v8 += (unsigned long long)k.nzc;
+        else if (f == K5F_NZM) v8 += (unsigned long long)k.nzm;
+        if (f < K5_NF8) M.tab[(size_t)f * cap2 + slot] = v8;
+        const uint32_t nxt = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v4, 0x101, 0xf, 0xf, true);   // row_shl:1: lane 11 <- pods
+        if (f == 10) M.t_cls[slot] = v4;
+        else if (f == 11) M.t_left[slot] = (int)v4 - (int)nxt - 1;
+        else if (f == 13) M.t_node[slot] = n;
+        else if (f == 15 && k.resmask) {
           const KbDev &d = *a.dev;
-          has_map = kind ? 1u : d.nmask[n];
+          has_map = kind ? 1u : d.nmask[n];   // Sub returns early when the receiver's scalar map is nil (resource_info.go:148-153)
           if (has_map) {
             double *vec = kind ? d.rel : d.idle;
-            uint32_t dd = 2, m2 = km;
+            uint32_t dd = 2, m2 = k.resmask;
             while (m2) {
               if (m2 & 1u) {
                 const double old = vec[(size_t)dd * d.NP + n];
@@ -901,8 +922,8 @@ __global__ void __launch_bounds__(KB_K5_THREADS) k_commit(const K7KernArgs ka) {
           }
         }
       }
-      H.kind[j] = kind;
-      H.has_map[j] = has_map;
+      if (f == 14) H.kind[j] = kind;
+      if (f == 15) H.has_map[j] = has_map;
     }
     __syncthreads();
     K7_STAMP(5);
@@ -927,7 +948,7 @@ __global__ void __launch_bounds__(KB_K5_THREADS) k_commit(const K7KernArgs ka) {
         else x = nd + (r - nn - nl);
         unsigned long long key = 0ull;
         if (x < nd || H.c[x - nd] != 0ull) {
-          const KbRowDesc &k = H.desc[H.rep[q]];
+          const KbRowDesc &k = bd[H.rep[q]];
           const TaskVals tv = k7_task_vals(k);
           const NodeVals nv = k5_slot_vals(M.tab, M.t_cls, M.t_left, cap2, x);
           const uint32_t node = M.t_node[x];
@@ -952,7 +973,7 @@ __global__ void __launch_bounds__(KB_K5_THREADS) k_commit(const K7KernArgs ka) {
         if (l < lane && kk > m) m = kk;
       }
       if (in && H.rep[q] == lane) {   // the shape's dirty max as of this batch's start becomes its cache
-        const uint32_t s = H.desc[lane].slot;
+        const uint32_t s = bd[lane].slot;
         M.dc_key[s] = H.dmax[q]; M.dc_nd[s] = nd; M.dc_log[s] = H.nlog;
       }
       const bool valid = in && cj != 0ull && cj > m;
@@ -987,7 +1008,7 @@ __global__ void __launch_bounds__(KB_K5_THREADS) k_commit(const K7KernArgs ka) {
     uint32_t pc = p, rows = p + (dirty_row == 2 ? 1u : 0u);   // candidates consumed, rows consumed
     if (tid < p) {
       const uint32_t j = tid;
-      const KbRowDesc &k = H.desc[j];
+      const KbRowDesc &k = bd[j];
       atomicMax(&M.cursor[k.slot], H.idx[j] + 1);
       k7_commit_globals<false>(a, k, i0 + j, KB_KEY_NODE(H.c[j]), H.kind[j]);
     }
@@ -1002,7 +1023,7 @@ __global__ void __launch_bounds__(KB_K5_THREADS) k_commit(const K7KernArgs ka) {
       // already computed (kb).
       const uint32_t q = H.q_of[p];
       {
-        const KbRowDesc &k = H.desc[p];
+        const KbRowDesc &k = bd[p];
         const TaskVals tv = k7_task_vals(k);
         for (uint32_t x = tid; x < nd + p; x += KB_K5_THREADS) {
           const NodeVals nv = k5_slot_vals(M.tab, M.t_cls, M.t_left, cap2, x);
@@ -1017,8 +1038,8 @@ __global__ void __launch_bounds__(KB_K5_THREADS) k_commit(const K7KernArgs ka) {
         const uint32_t myq = (lane < nb) ? H.q_of[lane] : 0xFFFFFFFFu;
         const unsigned long long diff = __ballot(lane > p && lane < nb && myq != q);
         const uint32_t run_end = diff ? (uint32_t)(__ffsll((unsigned long long)diff) - 1) : nb;
-        const uint32_t shape = H.desc[p].slot;
-        uint32_t r = p, ndc = nd + p, rsn = KB_REASON_DONE;
+        const uint32_t shape = bd[p].slot;
+        uint32_t r = p, ndc = nd + p, rsn = KB_REASON_DONE, last_n = 0xFFFFFFFFu, nlog = H.nlog;
         while (r < run_end) {
           unsigned long long kmax = 0ull;
           uint32_t xmax = 0;
@@ -1028,7 +1049,7 @@ __global__ void __launch_bounds__(KB_K5_THREADS) k_commit(const K7KernArgs ka) {
           }
           const unsigned long long best = wave_max_key(kmax);
           const unsigned long long cc = H.c[pc];
-          const KbRowDesc &k = H.desc[r];
+          const KbRowDesc &k = bd[r];
           if (best == 0ull && cc == 0ull) {
             if (a.backfill) {   // backfill.go:50-66: the task stays Pending
               if (lane == 0) *reinterpret_cast<uint2 *>(&a.dec[i0 + r]) = make_uint2(KB_NONE_U32, 0u);
@@ -1042,32 +1063,33 @@ __global__ void __launch_bounds__(KB_K5_THREADS) k_commit(const K7KernArgs ka) {
             const unsigned long long own = __ballot(kmax == best);
             const uint32_t xs = (uint32_t)__builtin_amdgcn_readlane((int)xmax, __ffsll((unsigned long long)own) - 1);
             const uint32_t n = KB_KEY_NODE(best);
-            // shapes whose cached dirty max sits on the node that changes lose their cache
-            for (uint32_t sh = lane; sh < a.n_mrows; sh += 64) {
-              const unsigned long long ck = M.dc_key[sh];
-              if (ck != 0ull && KB_KEY_NODE(ck) == n) M.dc_nd[sh] = 0xFFFFFFFFu;
+            // shapes whose cached dirty max sits on the node that changes lose their cache (once per node of a chain)
+            if (n != last_n) {
+              for (uint32_t sh = lane; sh < a.n_mrows; sh += 64) {
+                const unsigned long long ck = M.dc_key[sh];
+                if (ck != 0ull && KB_KEY_NODE(ck) == n) M.dc_nd[sh] = 0xFFFFFFFFu;
+              }
+              last_n = n;
             }
             uint32_t kind = 0;
             if (lane == 0) {
               kind = k7_apply_slot(a, M, k, xs, n);
               M.t_left[xs] -= 1;
               k7_commit_globals<true>(a, k, i0 + r, n, kind);
-              const uint32_t nl = H.nlog;
-              M.dlog[nl] = xs;
-              H.nlog = nl + 1;
-              H.n_dirty_rows++;
+              M.dlog[nlog] = xs;
               const TaskVals tv = k7_task_vals(k);
               const NodeVals nv = k5_slot_vals(M.tab, M.t_cls, M.t_left, cap2, xs);
               const uint32_t res = eval_pair_k5(a, tv, nv, n, a.use_crow ? &k.crow : nullptr);
               M.keyq[xs] = res ? KB_KEY(res & 0xFFFFu, n) : 0ull;
             }
             kind = (uint32_t)__builtin_amdgcn_readfirstlane((int)kind);
+            nlog++;
             r++;
             if (kind) { rsn = KB_REASON_PIPELINED; break; }
           } else {
             // the prepared slot nd+pc holds candidate pc's node after ROW pc's task; identical for row r's task when both
             // rows carry plain requests (same shape; no init-container maximum, no scalar resources)
-            const KbRowDesc &kc = H.desc[pc];
+            const KbRowDesc &kc = bd[pc];
             const uint32_t plain = (uint32_t)(k.flags & kc.flags & 1) && k.resmask == 0 && kc.resmask == 0;
             if (!plain) break;
             const uint32_t kind = H.kind[pc];
@@ -1089,7 +1111,9 @@ __global__ void __launch_bounds__(KB_K5_THREADS) k_commit(const K7KernArgs ka) {
         for (uint32_t x = lane; x < ndc; x += 64) { const unsigned long long kk = M.keyq[x]; if (kk > kmax) kmax = kk; }
         kmax = wave_max_key(kmax);
         if (lane == 0) {
-          M.dc_key[shape] = kmax; M.dc_nd[shape] = ndc; M.dc_log[shape] = H.nlog;
+          M.dc_key[shape] = kmax; M.dc_nd[shape] = ndc; M.dc_log[shape] = nlog;
+          H.n_dirty_rows += nlog - H.nlog;
+          H.nlog = nlog;
           H.seq_rows = r; H.seq_pc = pc; H.reason = rsn; H.n_seq_rows += r - p;
         }
       }
@@ -1102,7 +1126,7 @@ __global__ void __launch_bounds__(KB_K5_THREADS) k_commit(const K7KernArgs ka) {
       const uint32_t j = tid;
       const unsigned long long cj = H.c[j];
       if (cj) {
-        const KbRowDesc &k = H.desc[j];
+        const KbRowDesc &k = bd[j];
         const uint32_t n = KB_KEY_NODE(cj);
         atomicAnd(&M.bitmap[n >> 5], ~(1u << (n & 31)));
         if (H.has_map[j]) {
