@@ -156,7 +156,7 @@ def main():
         "config": {"workload": f"BASELINE configs[{args.config - 1}]: {snap.n_tasks} tasks x {snap.n_nodes} nodes, "
                                f"{snap.n_jobs} gang jobs, {snap.n_queues} queues, R={R}, allocate+backfill, "
                                "plugins priority,gang,drf,predicates,proportion,nodeorder",
-                   "window": args.window or 1024, "scale": args.scale},
+                   "window": args.window or 512, "scale": args.scale},
         "binds_per_s": n_binds * args.steps / elapsed, "binds": n_binds, "decisions": int(d["decisions"] / args.steps),
         "evals_per_step": int(evals / args.steps),
         "kernel_ms_per_step": {k: round(d[k] / args.steps, 3) for k in ("matrix_ms", "argmax_ms", "commit_ms", "reduce_ms", "host_order_ms", "total_ms")},

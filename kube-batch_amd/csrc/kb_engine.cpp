@@ -115,7 +115,7 @@ static void mg_free(MgState *m);
 struct kb_engine {
   std::string err;
   int device = 0;
-  uint32_t window = 1024, topk = 16, flags = 0;
+  uint32_t window = 512, topk = 16, flags = 0;   // 512: measured optimum on the 100k x 10k snapshot (dirty set stays small)
   Policy pol;
   hipStream_t stream = nullptr;
   bool loaded = false;
@@ -461,7 +461,7 @@ void check_aggregates(kb_engine *e, const OrderMachine &om) {
 // device's answer (confirm, or roll back + replay on a mis-speculated round), finish() runs the gang/share reduction.
 struct ActionRun {
   uint32_t action = 0;   // 0 allocate, 1 backfill
-  OrderMachine om, ckpt;
+  OrderMachine om;
   std::vector<uint8_t> dead;
   std::vector<kb_decision> decs;
   std::vector<uint32_t> bf_list;
@@ -503,7 +503,7 @@ struct ActionRun {
       return n;
     }
     double t0 = now_ms();
-    ckpt = om;   // roll-back point for a mis-speculated round
+    om.checkpoint();   // roll-back point for a mis-speculated round
     uint32_t n = 0, t;
     spec_pops = 0;
     while (n < W && om.next(t)) {
@@ -534,7 +534,7 @@ struct ActionRun {
     } else {
       // replay the confirmed prefix on the checkpoint, then feed the true outcome of the row that broke the speculation
       e->stats.spec_breaks += 1;
-      om = ckpt;
+      om.rollback();
       uint32_t i = 0, t;
       for (;;) {
         if (!om.next(t)) throw EngineError(KB_E_INTERNAL, "order replay ran out of tasks");
@@ -697,6 +697,11 @@ int kb_session_load(kb_engine *e, const kb_snapshot *sn) {
     for (uint32_t t = 0; t < T; t++)
       for (int d = 2; d < R; d++)
         if (!((hs.t_resmask[t] >> (d - 2)) & 1u)) hs.t_res[(size_t)d * T + t] = 0.0;
+    // task-major copy for the order machine: one task's Resreq is read per scheduling step, and with the dimension-major
+    // device layout that is R cache misses per step
+    hs.t_res_rows.resize((size_t)T * R);
+    for (int d = 0; d < R; d++)
+      for (uint32_t t = 0; t < T; t++) hs.t_res_rows[(size_t)t * R + d] = hs.t_res[(size_t)d * T + t];
     hs.t_job.assign(sn->task_job, sn->task_job + T);
     hs.t_cls.assign(T, 0);
     if (sn->task_class) hs.t_cls.assign(sn->task_class, sn->task_class + T);

@@ -135,6 +135,7 @@ struct HostSession {
   int R = 2;
   uint32_t N = 0, T = 0, J = 0, Q = 0;
   std::vector<double> t_res, t_init;      // [R][T]
+  std::vector<double> t_res_rows;         // [T][R] Resreq again, task-major (host order machine)
   std::vector<uint32_t> t_resmask, t_job, t_cls, t_node;
   std::vector<int32_t> t_prio;
   std::vector<int64_t> t_creation;
@@ -165,12 +166,16 @@ enum class Outcome { Allocated, Pipelined, NoFeasibleNode };
 
 // The allocate action's control flow (allocate.go:43-194) as a resumable machine.  next() runs the reference loop up
 // to the point where PredicateNodes would be called for a task and returns that task; report() feeds back what the
-// device decided and runs the rest of the iteration.  Value-copyable so a round can be speculated and rolled back.
+// device decided and runs the rest of the iteration.  checkpoint() / rollback() bracket a speculated round: the small
+// state (heaps, queue aggregates) is copied, the per-job state (allocated vector, share, ready count, task cursor) is
+// journalled on first touch, so a round costs O(window), not O(jobs x resources).
 class OrderMachine {
  public:
   void init_allocate(const HostSession *hs, const Policy *pol);
   bool next(uint32_t &task);
   void report(Outcome o);
+  void checkpoint();
+  void rollback();
   // running aggregates, compared with the device reduction after the action
   std::vector<double> jalloc, jshare, qalloc, qshare;
   std::vector<int32_t> ready;
@@ -185,6 +190,27 @@ class OrderMachine {
   int cur_q_ = -1, cur_j_ = -1;
   uint32_t cur_t_ = KB_NONE;
   bool inner_ = false;
+  // checkpoint: copies of the small state + first-touch journal of the per-job state
+  std::vector<uint32_t> ck_qheap_, ck_jheap_items_, ck_jheap_n_;
+  std::vector<double> ck_qalloc_, ck_qshare_;
+  int ck_cur_q_ = -1, ck_cur_j_ = -1;
+  uint32_t ck_cur_t_ = KB_NONE;
+  bool ck_inner_ = false;
+  uint64_t ck_steps_ = 0;
+  std::vector<uint32_t> stamp_, jl_jobs_, jl_cursor_;
+  std::vector<int32_t> jl_ready_;
+  std::vector<double> jl_vals_;   // per journalled job: allocated[R], share
+  uint32_t epoch_ = 0;
+  void touch(uint32_t j) {
+    if (stamp_[j] == epoch_) return;
+    stamp_[j] = epoch_;
+    jl_jobs_.push_back(j);
+    jl_cursor_.push_back(cursor_[j]);
+    jl_ready_.push_back(ready[j]);
+    const int R = hs_->R;
+    jl_vals_.insert(jl_vals_.end(), jalloc.begin() + (size_t)j * R, jalloc.begin() + (size_t)(j + 1) * R);
+    jl_vals_.push_back(jshare[j]);
+  }
 
   bool job_ready(uint32_t j) const { return pol_->gang_job_ready ? ready[j] >= hs_->job_min[j] : true; }
   bool queue_less(uint32_t l, uint32_t r) const;

@@ -161,6 +161,39 @@ void OrderMachine::init_allocate(const HostSession *hs, const Policy *pol) {
   inner_ = false;
   cur_q_ = cur_j_ = -1;
   cur_t_ = KB_NONE;
+  stamp_.assign(J ? J : 1, 0);
+  epoch_ = 0;
+  checkpoint();
+}
+
+void OrderMachine::checkpoint() {
+  epoch_++;
+  jl_jobs_.clear(); jl_cursor_.clear(); jl_ready_.clear(); jl_vals_.clear();
+  ck_qheap_ = qheap_;
+  ck_jheap_items_ = jheap_items_;
+  ck_jheap_n_ = jheap_n_;
+  ck_qalloc_ = qalloc;
+  ck_qshare_ = qshare;
+  ck_cur_q_ = cur_q_; ck_cur_j_ = cur_j_; ck_cur_t_ = cur_t_; ck_inner_ = inner_; ck_steps_ = steps;
+}
+
+void OrderMachine::rollback() {
+  const int R = hs_->R;
+  for (size_t k = 0; k < jl_jobs_.size(); k++) {
+    const uint32_t j = jl_jobs_[k];
+    cursor_[j] = jl_cursor_[k];
+    ready[j] = jl_ready_[k];
+    const double *v = &jl_vals_[k * (size_t)(R + 1)];
+    for (int d = 0; d < R; d++) jalloc[(size_t)j * R + d] = v[d];
+    jshare[j] = v[R];
+  }
+  qheap_ = ck_qheap_;
+  jheap_items_ = ck_jheap_items_;
+  jheap_n_ = ck_jheap_n_;
+  qalloc = ck_qalloc_;
+  qshare = ck_qshare_;
+  cur_q_ = ck_cur_q_; cur_j_ = ck_cur_j_; cur_t_ = ck_cur_t_; inner_ = ck_inner_; steps = ck_steps_;
+  checkpoint();   // the restored state is the new roll-back point (fresh journal)
 }
 
 bool OrderMachine::next(uint32_t &task) {
@@ -168,6 +201,7 @@ bool OrderMachine::next(uint32_t &task) {
     if (inner_) {
       uint32_t j = (uint32_t)cur_j_;
       if (cursor_[j] < pend_off_[j + 1]) {   // allocate.go:129-130
+        touch(j);
         task = cur_t_ = pend_[cursor_[j]++];
         steps++;
         return true;
@@ -189,12 +223,13 @@ bool OrderMachine::next(uint32_t &task) {
 // drf.go:135-145 and proportion.go:212-223 AllocateFunc (fired by ssn.Allocate and ssn.Pipeline alike)
 void OrderMachine::update_shares(uint32_t j, uint32_t t) {
   const int R = hs_->R;
-  const uint32_t T = hs_->T;
+  const double *tr = &hs_->t_res_rows[(size_t)t * R];   // absent scalar keys hold 0.0
+  const uint32_t tmask = hs_->t_resmask[t];
   if (pol_->has_drf) {
     double *a = &jalloc[(size_t)j * R];
     double share = 0;
     for (int d = 0; d < R; d++) {
-      if (d < 2 || ((hs_->t_resmask[t] >> (d - 2)) & 1u)) a[d] += hs_->t_res[(size_t)d * T + t];
+      if (d < 2 || ((tmask >> (d - 2)) & 1u)) a[d] += tr[d];
       if (d >= 2 && !hs_->total.has(d)) continue;
       double s = helpers_share(a[d], hs_->total.get(d));
       if (s > share) share = s;
@@ -207,7 +242,7 @@ void OrderMachine::update_shares(uint32_t j, uint32_t t) {
     const Res &des = hs_->deserved[q];
     double share = 0;
     for (int d = 0; d < R; d++) {
-      if (d < 2 || ((hs_->t_resmask[t] >> (d - 2)) & 1u)) a[d] += hs_->t_res[(size_t)d * T + t];
+      if (d < 2 || ((tmask >> (d - 2)) & 1u)) a[d] += tr[d];
       if (d >= 2 && !des.has(d)) continue;
       double s = helpers_share(a[d], des.get(d));
       if (s > share) share = s;
@@ -223,6 +258,7 @@ void OrderMachine::report(Outcome o) {
     qpush(q);
     return;
   }
+  touch(j);
   if (o == Outcome::Allocated) ready[j] += 1;   // status Allocated counts towards ReadyTaskNum; Pipelined does not
   update_shares(j, cur_t_);
   if (job_ready(j) && cursor_[j] < pend_off_[j + 1]) {   // allocate.go:185-188
