@@ -11,7 +11,7 @@
 #ifndef KB_K5_THREADS
 #define KB_K5_THREADS 512
 #endif
-#define KB_MAX_TOPK 32
+#define KB_MAX_TOPK 4096   // longest candidate list kb_argmax_rows hands out
 
 // arg-max key: (0x40000000 + score + 1) << 32 | (0xFFFFFFFF - node).  0 = no feasible node.  max() over keys = highest
 // score, then lowest node index = util.SelectBestNode with the canonical tie-break (scheduler_helper.go:188-208).

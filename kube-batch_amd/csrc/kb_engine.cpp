@@ -139,16 +139,18 @@ struct kb_engine {
   std::vector<double> trace_acc = std::vector<double>(3 * 4 * 12, 0.0);
   DevBuf b_sscore, b_smask, b_xslot;   // per-shape rows and row->shape map of kb_eval_matrix / kb_bench_matrix
   size_t xs_cap = 0, xslot_cap = 0;
-  DevBuf b_rows, b_slot, b_mrows, b_same, b_score, b_maskw, b_keys, b_dec, b_result;
+  DevBuf b_mrows, b_same, b_score, b_maskw, b_keys;
+  DevBuf b_win, b_out;   // per-round upload / download blocks (see h_win / h_out)
   uint32_t win_cap = 0, mat_cap = 0;
   size_t keys_cap = 0;
   Pinned<uint32_t> h_rows, h_slot, h_mrows;
   std::vector<uint32_t> h_decnode, h_deckind;
-  Pinned<unsigned long long> h_dec;
+  Pinned<uint32_t> h_win;             // per-round upload  [rows | slots | mrows] at fixed offsets of KB_K5_MAX_WINDOW
+  Pinned<unsigned long long> h_out;   // per-round download: 64-byte header (result words) + decision records
   std::vector<uint8_t> h_same;
   std::vector<uint32_t> shape_stamp, shape_slot_of;   // per row-shape id: round stamp and slot inside the current round
   uint32_t stamp = 0;
-  uint32_t *h_result = nullptr;   // pinned [8]
+  uint32_t *h_result = nullptr;   // the header words of h_out
   std::vector<Timer> ev;          // event pool for per-launch timing
   std::vector<kb_decision> decisions_all;   // decisions of the last multi-GPU round sequence
 
@@ -158,7 +160,6 @@ struct kb_engine {
   ~kb_engine() {
     mg_free(mg);
     for (auto &t : ev) t.destroy();
-    if (h_result) (void)hipHostFree(h_result);
     if (stream) (void)hipStreamDestroy(stream);
   }
 };
@@ -227,11 +228,7 @@ template <typename K> uint32_t intern(std::map<K, uint32_t> &m, const K &k) {
 // window buffers: one entry per task row of a round
 void ensure_window_buffers(kb_engine *e, uint32_t rows) {
   if (rows <= e->win_cap) return;
-  e->b_rows.alloc(sizeof(uint32_t) * rows);
-  e->b_slot.alloc(sizeof(uint32_t) * rows);
   e->b_desc.alloc(sizeof(KbRowDesc) * rows);
-  e->b_dec.alloc(sizeof(unsigned long long) * rows);
-  e->h_dec.resize(rows);
   e->h_rows.resize(rows);
   e->h_slot.resize(rows);
   e->h_decnode.resize(rows);
@@ -294,13 +291,13 @@ void run_finalize(kb_engine *e) {
 
 KbRound make_round(kb_engine *e, uint32_t n_rows, uint32_t n_mrows, uint32_t L, int fit_mode, bool backfill) {
   KbRound r{};
-  r.rows = e->b_rows.as<uint32_t>();
-  r.shape_slot = e->b_slot.as<uint32_t>();
+  r.rows = e->b_win.as<uint32_t>();
+  r.shape_slot = e->b_win.as<uint32_t>() + KB_K5_MAX_WINDOW;
   r.n_rows = n_rows;
   r.desc = e->b_desc.as<KbRowDesc>();
   r.trace = e->trace_on ? e->b_trace.as<unsigned long long>() : nullptr;
   r.cap = std::max<uint32_t>(64, ((n_rows + 63) / 64) * 64);
-  r.mrows = e->b_mrows.as<uint32_t>();
+  r.mrows = e->b_win.as<uint32_t>() + 2 * KB_K5_MAX_WINDOW;
   r.mrow_task0 = 0;
   r.same_prev = nullptr;
   r.n_mrows = n_mrows;
@@ -309,8 +306,8 @@ KbRound make_round(kb_engine *e, uint32_t n_rows, uint32_t n_mrows, uint32_t L, 
   r.maskw = e->b_maskw.as<uint32_t>();
   r.keys = e->b_keys.as<unsigned long long>();
   r.L = L;
-  r.dec = e->b_dec.as<unsigned long long>();
-  r.result = e->b_result.as<uint32_t>();
+  r.dec = e->b_out.as<unsigned long long>() + 8;   // 64-byte header (result words), then the decision records
+  r.result = e->b_out.as<uint32_t>();
   r.backfill = backfill ? 1 : 0;
   r.delta = nullptr;
   r.own_row0 = r.own_row1 = 0;
@@ -357,9 +354,11 @@ RoundCtx round_prepare(kb_engine *e, uint32_t n, int fit_mode, bool backfill) {
   c.ns = assign_shapes(e, n);
   c.L = n + 1;   // more candidates than the round can dirty: a clean one always survives
   c.backfill = backfill;
-  HIP_OK(hipMemcpyAsync(e->b_rows.p, e->h_rows.data(), sizeof(uint32_t) * n, hipMemcpyHostToDevice, e->stream));
-  HIP_OK(hipMemcpyAsync(e->b_slot.p, e->h_slot.data(), sizeof(uint32_t) * n, hipMemcpyHostToDevice, e->stream));
-  HIP_OK(hipMemcpyAsync(e->b_mrows.p, e->h_mrows.data(), sizeof(uint32_t) * c.ns, hipMemcpyHostToDevice, e->stream));
+  // one staging copy per round: [task rows | shape slots | representative rows], fixed offsets
+  std::memcpy(e->h_win.data(), e->h_rows.data(), sizeof(uint32_t) * n);
+  std::memcpy(e->h_win.data() + KB_K5_MAX_WINDOW, e->h_slot.data(), sizeof(uint32_t) * n);
+  std::memcpy(e->h_win.data() + 2 * KB_K5_MAX_WINDOW, e->h_mrows.data(), sizeof(uint32_t) * c.ns);
+  HIP_OK(hipMemcpyAsync(e->b_win.p, e->h_win.data(), sizeof(uint32_t) * (2 * KB_K5_MAX_WINDOW + c.ns), hipMemcpyHostToDevice, e->stream));
   c.d = e->dev;
   if (backfill) c.d.score_enabled = 0;   // backfill.go:50-66 takes the first node that passes the predicates: all scores tie
   c.r = make_round(e, n, c.ns, c.L, fit_mode, backfill);
@@ -372,7 +371,7 @@ RoundCtx round_prepare(kb_engine *e, uint32_t n, int fit_mode, bool backfill) {
 void round_candidates(kb_engine *e, const RoundCtx &c, uint32_t m0, uint32_t m1, unsigned long long *keys) {
   if (m1 <= m0) return;
   KbRound r = c.r;
-  r.mrows = e->b_mrows.as<uint32_t>() + m0;
+  r.mrows = e->b_win.as<uint32_t>() + 2 * KB_K5_MAX_WINDOW + m0;
   r.n_mrows = m1 - m0;
   r.keys = keys;
   Timer &t1 = get_timer(e, 0), &t3 = get_timer(e, 1);
@@ -397,8 +396,7 @@ void round_commit(kb_engine *e, const RoundCtx &c, unsigned long long *keys, dou
   HIP_OK(hipEventRecord(t5.a, e->stream));
   kb_launch_commit(c.d, r, e->stream);
   HIP_OK(hipEventRecord(t5.b, e->stream));
-  HIP_OK(hipMemcpyAsync(e->h_result, e->b_result.p, sizeof(uint32_t) * 8, hipMemcpyDeviceToHost, e->stream));
-  HIP_OK(hipMemcpyAsync(e->h_dec.data(), e->b_dec.p, sizeof(unsigned long long) * c.n, hipMemcpyDeviceToHost, e->stream));
+  HIP_OK(hipMemcpyAsync(e->h_out.data(), e->b_out.p, 64 + sizeof(unsigned long long) * c.n, hipMemcpyDeviceToHost, e->stream));
 }
 
 // wait for the round, account the kernel times, unpack the decision records
@@ -406,8 +404,8 @@ void round_collect(kb_engine *e, const RoundCtx &c, bool had_candidates, uint32_
   HIP_OK(hipStreamSynchronize(e->stream));
   HIP_OK(hipGetLastError());
   for (uint32_t i = 0; i < c.n; i++) {
-    e->h_decnode[i] = (uint32_t)(e->h_dec[i] & 0xFFFFFFFFull);
-    e->h_deckind[i] = (uint32_t)(e->h_dec[i] >> 32);
+    e->h_decnode[i] = (uint32_t)(e->h_out[8 + i] & 0xFFFFFFFFull);
+    e->h_deckind[i] = (uint32_t)(e->h_out[8 + i] >> 32);
   }
   float ms = 0;
   if (had_candidates) {
@@ -635,8 +633,11 @@ int kb_engine_create(const kb_config *cfg, kb_engine **out) {
     if (cfg->device < 0 || cfg->device >= ndev) throw EngineError(KB_E_INVALID, "device ordinal out of range");
     HIP_OK(hipSetDevice(cfg->device));
     HIP_OK(hipStreamCreateWithFlags(&eng->stream, hipStreamNonBlocking));
-    HIP_OK(hipHostMalloc((void **)&eng->h_result, sizeof(uint32_t) * 8, hipHostMallocDefault));
-    eng->b_result.alloc(sizeof(uint32_t) * 8);
+    eng->b_win.alloc(sizeof(uint32_t) * 3 * KB_K5_MAX_WINDOW);
+    eng->h_win.resize(3 * KB_K5_MAX_WINDOW);
+    eng->b_out.alloc(64 + sizeof(unsigned long long) * KB_K5_MAX_WINDOW);
+    eng->h_out.resize(8 + KB_K5_MAX_WINDOW);
+    eng->h_result = reinterpret_cast<uint32_t *>(eng->h_out.data());
     if (const char *tr = getenv("KB_K5_TRACE")) {
       if (tr[0] == '1') { eng->trace_on = true; eng->b_trace.alloc(sizeof(unsigned long long) * 64); HIP_OK(hipMemset(eng->b_trace.p, 0, sizeof(unsigned long long) * 64)); }
     }
@@ -1019,6 +1020,7 @@ static ChunkPlan matrix_plan(kb_engine *e, uint32_t t0, uint32_t n, uint32_t fit
   HIP_OK(hipMemcpyAsync(e->b_xslot.p, e->h_slot.data(), sizeof(uint32_t) * n, hipMemcpyHostToDevice, e->stream));
   HIP_OK(hipMemcpyAsync(e->b_mrows.p, e->h_mrows.data(), sizeof(uint32_t) * p.ns, hipMemcpyHostToDevice, e->stream));
   p.rs = make_round(e, 0, p.ns, 1, (int)fit_mode, false);
+  p.rs.mrows = e->b_mrows.as<uint32_t>();   // this path stages its representative rows in its own buffer (can exceed a window)
   p.rs.score = e->b_sscore.as<uint16_t>();
   p.rs.maskw = e->b_smask.as<uint32_t>();
   p.r = make_round(e, 0, n, k ? k : 1, (int)fit_mode, false);
@@ -1064,8 +1066,8 @@ int kb_argmax_rows(kb_engine *e, uint32_t t0, uint32_t t1, uint32_t fit_mode, ui
   return guarded(e, [&]() {
     if (!e->loaded) throw EngineError(KB_E_STATE, "no session loaded");
     if (t0 > t1 || t1 > e->hs.T) throw EngineError(KB_E_INVALID, "row range out of bounds");
-    if (k == 0 || k > KB_MAX_TOPK) throw EngineError(KB_E_INVALID, "k must be in 1..32");
-    const uint32_t chunk = 4096;
+    if (k == 0 || k > KB_MAX_TOPK) throw EngineError(KB_E_INVALID, "k must be in 1..4096");
+    const uint32_t chunk = std::max<uint32_t>(1, std::min<uint32_t>(4096, (1u << 20) / k));
     std::vector<unsigned long long> keys((size_t)chunk * k);
     for (uint32_t a = t0; a < t1; a += chunk) {
       uint32_t n = std::min(chunk, t1 - a);
@@ -1234,7 +1236,7 @@ int kb_round_apply(kb_engine *e, uint64_t dev_delta_ptr, uint32_t *done) {
     if (dev_delta_ptr) {
       // node state for the next round = round-start state + all-reduced deltas; it must equal this replica's own commit
       uint32_t mism = kb_apply_deltas(e->dev, m.s_idle.as<double>(), m.s_rel.as<double>(), m.s_nzc.as<long long>(), m.s_nzm.as<long long>(),
-                                      m.s_podcnt.as<int>(), reinterpret_cast<const double *>(dev_delta_ptr), e->b_result.as<uint32_t>() + 6, e->stream);
+                                      m.s_podcnt.as<int>(), reinterpret_cast<const double *>(dev_delta_ptr), e->b_out.as<uint32_t>() + 8, e->stream);
       if (mism) throw EngineError(KB_E_INTERNAL, "replicas diverged: reduced per-node deltas differ from the local commit at " + std::to_string(mism) + " values");
     }
     m.run.absorb(e, m.ctx.n, m.n_done, m.reason);

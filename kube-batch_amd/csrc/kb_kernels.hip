@@ -302,14 +302,49 @@ __device__ __forceinline__ uint32_t lane_prefix_popc(unsigned long long ballot_m
 // pass A = block max of the scores below the previous level, pass B = count + block exclusive scan + ordered write.
 // The first entry is util.SelectBestNode's choice (scheduler_helper.go:188-208, canonical first-max tie-break).
 // ------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int wave_max_i32_dpp(int v) {
+#define KB_DPP_IMAX(ctrl, row_mask) v = max(v, __builtin_amdgcn_update_dpp(v, v, (ctrl), (row_mask), 0xf, false))
+  KB_DPP_IMAX(0xB1, 0xf);
+  KB_DPP_IMAX(0x4E, 0xf);
+  KB_DPP_IMAX(0x141, 0xf);
+  KB_DPP_IMAX(0x140, 0xf);
+  KB_DPP_IMAX(0x142, 0xa);
+  KB_DPP_IMAX(0x143, 0xc);
+#undef KB_DPP_IMAX
+  return __builtin_amdgcn_readlane(v, 63);
+}
+// inclusive scan inside the wave: DPP row shifts, then row broadcasts (the sequence LLVM's buildScan emits)
+__device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v) {
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);   // row_shr:1
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);   // row_shr:2
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);   // row_shr:4
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);   // row_shr:8
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);   // row_bcast:15
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);   // row_bcast:31
+  return v;
+}
+
+// Sorted candidate list of one matrix row: the first K entries of (score descending, node ascending).  Scores are
+// integers, so the list is built FOUR consecutive score values at a time: one pass over the row (staged in LDS) counts
+// each thread's nodes at top, top-1, top-2, top-3 (four 16-bit counters packed in two words) and finds the best score
+// below that band; one packed scan turns the counts into output positions; one more pass scatters.  With the default
+// weights the first band already holds more than a window's worth of nodes.  WIDE (rows of 65536 nodes or more, where a
+// 16-bit counter could overflow): two score values per band, one full word each.
+template <bool WIDE>
 __global__ void __launch_bounds__(256) k_argmax(KbDev d, KbRound r) {
   extern __shared__ __align__(16) unsigned char k3_smem[];
   uint16_t *ls = reinterpret_cast<uint16_t *>(k3_smem);                        // [NP] scores
   uint8_t *lm = reinterpret_cast<uint8_t *>(k3_smem) + (size_t)d.NP * 2;      // [NP/8] mask bytes
   __shared__ int s_wmax[4];
-  __shared__ uint32_t s_wcnt[4];
+  __shared__ uint32_t s_wcnt[4][2];
   const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const uint32_t row = blockIdx.x;
+  const uint32_t K = r.L;
+  unsigned long long *out = r.keys + (size_t)row * K;
+  const uint32_t per8 = d.NP / (256 * 8);    // 8-node chunks per thread (NP is a multiple of 2048)
+  const uint32_t cbase = tid * per8;         // consecutive chunks: thread order == node order
+  const uint4 *ls4 = reinterpret_cast<const uint4 *>(ls);
+  int top = -1;
   {
     const uint4 *src = reinterpret_cast<const uint4 *>(r.score + (size_t)row * d.NP);
     uint4 *dst = reinterpret_cast<uint4 *>(ls);
@@ -319,73 +354,89 @@ __global__ void __launch_bounds__(256) k_argmax(KbDev d, KbRound r) {
     for (uint32_t c = tid; c < d.NP / 32; c += 256) mdst[c] = msrc[c];
   }
   __syncthreads();
-  const uint32_t K = r.L;
-  unsigned long long *out = r.keys + (size_t)row * K;
-  const uint32_t per8 = d.NP / (256 * 8);    // 8-node chunks per thread (NP is a multiple of 2048? no: of 1024 -> see below)
-  const uint32_t cbase = tid * per8;         // first chunk of this thread; chunks beyond NP/8 do not exist when NP % 2048 == 0
-  const uint4 *ls4 = reinterpret_cast<const uint4 *>(ls);
+  for (uint32_t c = 0; c < per8; c++) {   // best score of the row
+    const uint32_t mb = lm[cbase + c];
+    const uint4 sv = ls4[cbase + c];
+    const uint32_t w[4] = {sv.x, sv.y, sv.z, sv.w};
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+      const int sc = (int)((w[e >> 1] >> ((e & 1) * 16)) & 0xFFFFu);
+      if (((mb >> e) & 1u) && sc > top) top = sc;
+    }
+  }
+  top = wave_max_i32_dpp(top);
+  if (lane == 0) s_wmax[wave] = top;
+  __syncthreads();
+  top = max(max(s_wmax[0], s_wmax[1]), max(s_wmax[2], s_wmax[3]));
   uint32_t found = 0;
-  int cur = 0x10000;
-  while (found < K) {
-    int m = -1;
+  while (top >= 0 && found < K) {
+    __syncthreads();   // s_wmax / s_wcnt are reused
+    // counts of this thread's nodes at the four scores of the band; best score below the band
+    uint32_t c01 = 0, c23 = 0;   // 16-bit fields: (top, top-1), (top-2, top-3)
+    int below = -1;
     for (uint32_t c = 0; c < per8; c++) {
-      uint32_t mb = lm[cbase + c];
-      uint4 sv = ls4[cbase + c];
-      uint32_t w[4] = {sv.x, sv.y, sv.z, sv.w};
+      const uint32_t mb = lm[cbase + c];
+      const uint4 sv = ls4[cbase + c];
+      const uint32_t w[4] = {sv.x, sv.y, sv.z, sv.w};
 #pragma unroll
       for (int e = 0; e < 8; e++) {
-        int sc = (int)((w[e >> 1] >> ((e & 1) * 16)) & 0xFFFFu);
-        if (((mb >> e) & 1u) && sc < cur && sc > m) m = sc;
-      }
-    }
-    m = wave_max_i32(m);
-    if (lane == 0) s_wmax[wave] = m;
-    __syncthreads();
-    m = max(max(s_wmax[0], s_wmax[1]), max(s_wmax[2], s_wmax[3]));
-    if (m < 0) break;                          // uniform
-    uint32_t cnt = 0;
-    for (uint32_t c = 0; c < per8; c++) {
-      uint32_t mb = lm[cbase + c];
-      uint4 sv = ls4[cbase + c];
-      uint32_t w[4] = {sv.x, sv.y, sv.z, sv.w};
-#pragma unroll
-      for (int e = 0; e < 8; e++) {
-        int sc = (int)((w[e >> 1] >> ((e & 1) * 16)) & 0xFFFFu);
-        cnt += (((mb >> e) & 1u) && sc == m) ? 1u : 0u;
-      }
-    }
-    // inclusive scan inside the wave: DPP row shifts, then row broadcasts (the sequence LLVM's buildScan emits)
-    uint32_t pre = cnt;
-    pre += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)pre, 0x111, 0xf, 0xf, false);   // row_shr:1
-    pre += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)pre, 0x112, 0xf, 0xf, false);   // row_shr:2
-    pre += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)pre, 0x114, 0xf, 0xf, false);   // row_shr:4
-    pre += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)pre, 0x118, 0xf, 0xf, false);   // row_shr:8
-    pre += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)pre, 0x142, 0xa, 0xf, false);   // row_bcast:15
-    pre += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)pre, 0x143, 0xc, 0xf, false);   // row_bcast:31
-    if (lane == 63) s_wcnt[wave] = pre;
-    __syncthreads();
-    uint32_t woff = 0, total = 0;
-#pragma unroll
-    for (int w2 = 0; w2 < 4; w2++) {
-      if (w2 < (int)wave) woff += s_wcnt[w2];
-      total += s_wcnt[w2];
-    }
-    uint32_t pos = found + woff + pre - cnt;
-    if (cnt && pos < K) {
-      for (uint32_t c = 0; c < per8 && pos < K; c++) {
-        uint32_t mb = lm[cbase + c];
-        uint4 sv = ls4[cbase + c];
-        uint32_t w[4] = {sv.x, sv.y, sv.z, sv.w};
-#pragma unroll
-        for (int e = 0; e < 8; e++) {
-          int sc = (int)((w[e >> 1] >> ((e & 1) * 16)) & 0xFFFFu);
-          if (((mb >> e) & 1u) && sc == m && pos < K) out[pos++] = KB_KEY(m, (cbase + c) * 8 + e);
+        const int sc = (int)((w[e >> 1] >> ((e & 1) * 16)) & 0xFFFFu);
+        if ((mb >> e) & 1u) {
+          const int l = top - sc;   // 0..3 inside the band
+          if (WIDE) {
+            if (l == 0) c01++;
+            else if (l == 1) c23++;
+            else if (l >= 2 && sc > below) below = sc;
+          } else {
+            if (l >= 0 && l < 2) c01 += 1u << (16 * l);
+            else if (l >= 2 && l < 4) c23 += 1u << (16 * (l - 2));
+            else if (l >= 4 && sc > below) below = sc;
+          }
         }
       }
     }
-    found += total;
-    cur = m;
-    __syncthreads();                           // s_wmax / s_wcnt are reused by the next level
+    const uint32_t p01 = wave_incl_scan_u32(c01), p23 = wave_incl_scan_u32(c23);
+    below = wave_max_i32_dpp(below);
+    if (lane == 63) { s_wcnt[wave][0] = p01; s_wcnt[wave][1] = p23; }
+    if (lane == 0) s_wmax[wave] = below;
+    __syncthreads();
+    uint32_t off01 = 0, off23 = 0, tot01 = 0, tot23 = 0;
+#pragma unroll
+    for (int w2 = 0; w2 < 4; w2++) {
+      if (w2 < (int)wave) { off01 += s_wcnt[w2][0]; off23 += s_wcnt[w2][1]; }
+      tot01 += s_wcnt[w2][0];
+      tot23 += s_wcnt[w2][1];
+    }
+    below = max(max(s_wmax[0], s_wmax[1]), max(s_wmax[2], s_wmax[3]));
+    // first output position of this thread's nodes at each score of the band
+    const uint32_t e01 = off01 + p01 - c01, e23 = off23 + p23 - c23;
+    uint32_t t0, t1, t2, t3, pos[4];
+    if (WIDE) {
+      t0 = tot01; t1 = tot23; t2 = 0; t3 = 0;
+      pos[0] = found + e01; pos[1] = found + t0 + e23; pos[2] = 0xFFFFFFFFu; pos[3] = 0xFFFFFFFFu;
+    } else {
+      t0 = tot01 & 0xFFFFu; t1 = tot01 >> 16; t2 = tot23 & 0xFFFFu; t3 = tot23 >> 16;
+      pos[0] = found + (e01 & 0xFFFFu); pos[1] = found + t0 + (e01 >> 16);
+      pos[2] = found + t0 + t1 + (e23 & 0xFFFFu); pos[3] = found + t0 + t1 + t2 + (e23 >> 16);
+    }
+    if ((c01 | c23) && min(min(pos[0], pos[1]), min(pos[2], pos[3])) < K) {
+      for (uint32_t c = 0; c < per8; c++) {
+        const uint32_t mb = lm[cbase + c];
+        const uint4 sv = ls4[cbase + c];
+        const uint32_t w[4] = {sv.x, sv.y, sv.z, sv.w};
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+          const int sc = (int)((w[e >> 1] >> ((e & 1) * 16)) & 0xFFFFu);
+          const int l = top - sc;
+          if (((mb >> e) & 1u) && l >= 0 && l < (WIDE ? 2 : 4)) {
+            const uint32_t at = (l == 0) ? pos[0]++ : (l == 1) ? pos[1]++ : (l == 2) ? pos[2]++ : pos[3]++;
+            if (at < K) out[at] = KB_KEY(sc, (cbase + c) * 8 + e);
+          }
+        }
+      }
+    }
+    found += t0 + t1 + t2 + t3;
+    top = below;
   }
   if (found > K) found = K;
   for (uint32_t i = found + tid; i < K; i += 256) out[i] = 0ull;
@@ -1305,10 +1356,12 @@ void kb_launch_argmax(const KbDev &d, const KbRound &r, void *stream) {
   size_t sh = (size_t)d.NP * 2 + d.NP / 8;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_argmax), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_argmax<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_argmax<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
     attr_set = true;
   }
-  hipLaunchKernelGGL(k_argmax, dim3(r.n_mrows), dim3(256), sh, (hipStream_t)stream, d, r);
+  if (d.NP < 65536u) hipLaunchKernelGGL(k_argmax<false>, dim3(r.n_mrows), dim3(256), sh, (hipStream_t)stream, d, r);
+  else hipLaunchKernelGGL(k_argmax<true>, dim3(r.n_mrows), dim3(256), sh, (hipStream_t)stream, d, r);
 }
 void kb_launch_commit(const KbDev &d, const KbRound &r, void *stream) {
   if (r.n_rows == 0) return;

@@ -117,6 +117,11 @@ def test_argmax_parity(oracle_mod):
         en, es = e.argmax_rows(0, 600, k)
         on, os_ = o.argmax_rows(0, 600, k)
         assert np.array_equal(en, on) and np.array_equal(es, os_), k
+    # long lists: several score bands, and past the last feasible node (KB_NONE padding)
+    for k in (513, snap.n_nodes + 7):
+        en, es = e.argmax_rows(100, 160, k)
+        on, os_ = o.argmax_rows(100, 160, k)
+        assert np.array_equal(en, on) and np.array_equal(es, os_), k
 
 
 @pytest.mark.parametrize("window,topk,flags", [(64, 4, 0), (1024, 16, 0), (4096, 0, abi.FLAG_NO_TOPK), (512, 32, 0)])
