@@ -193,7 +193,7 @@ typedef struct kb_stats {
   uint64_t binds;             /* tasks dispatched to the Binder */
   uint64_t rounds;            /* device rounds (matrix -> arg-max -> commit) */
   uint64_t spec_breaks;       /* rounds cut short because the speculated order diverged */
-  uint64_t row_fallbacks;     /* rows whose top-K candidates were all dirty (full-row rescan) */
+  uint64_t row_fallbacks;     /* rows the commit kernel committed in its row-at-a-time mode (dirty-winner chains) */
   uint64_t matrix_launches;   /* launches of the mask+score matrix kernel */
   uint64_t matrix_evals;      /* (task,node) pairs those launches evaluated */
   double   matrix_ms;         /* HIP-event time of those launches on the engine stream */

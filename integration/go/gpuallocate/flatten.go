@@ -1,0 +1,387 @@
+// flatten.go — framework.Session -> kb_snapshot (SOURCE ONLY, see gpuallocate.go).  The Python twin of this file is
+// kube-batch_amd/snapshot.py:flatten; both produce the same canonical order (SURVEY.md §8c):
+//
+//	nodes  ascending name          (ssn.Nodes is a map: framework/session.go:43)
+//	queues ascending QueueID       (ssn.Queues)
+//	jobs   ascending JobID         (ssn.Jobs), tasks of a job ascending TaskID
+//
+// Every array is C.malloc'ed for the duration of one Execute and freed by free(); the engine copies what it needs in
+// kb_session_load and keeps no caller pointer (cgo pointer rules).
+package gpuallocate
+
+/*
+#include <stdlib.h>
+#include <string.h>
+#include "kb_engine.h"
+*/
+import "C"
+
+import (
+	"fmt"
+	"sort"
+	"unsafe"
+
+	v1 "k8s.io/api/core/v1"
+	"k8s.io/kubernetes/pkg/scheduler/algorithm/predicates"
+	priorityutil "k8s.io/kubernetes/pkg/scheduler/algorithm/priorities/util"
+	"k8s.io/kubernetes/pkg/scheduler/nodeinfo"
+
+	"github.com/kubernetes-sigs/kube-batch/pkg/scheduler/api"
+	"github.com/kubernetes-sigs/kube-batch/pkg/scheduler/framework"
+)
+
+type flat struct {
+	snap  C.kb_snapshot
+	nodes []*api.NodeInfo // index -> object, for the replay
+	tasks []*api.TaskInfo
+	bufs  []unsafe.Pointer
+}
+
+func (f *flat) free() {
+	for _, p := range f.bufs {
+		C.free(p)
+	}
+	f.bufs = nil
+}
+
+// calloc-backed typed views -------------------------------------------------------------------------------
+func (f *flat) f64(n int) []float64 {
+	p := C.calloc(C.size_t(n+1), 8)
+	f.bufs = append(f.bufs, p)
+	return (*[1 << 30]float64)(p)[:n:n]
+}
+func (f *flat) i64(n int) []int64 {
+	p := C.calloc(C.size_t(n+1), 8)
+	f.bufs = append(f.bufs, p)
+	return (*[1 << 30]int64)(p)[:n:n]
+}
+func (f *flat) u32(n int) []uint32 {
+	p := C.calloc(C.size_t(n+1), 4)
+	f.bufs = append(f.bufs, p)
+	return (*[1 << 30]uint32)(p)[:n:n]
+}
+func (f *flat) i32(n int) []int32 {
+	p := C.calloc(C.size_t(n+1), 4)
+	f.bufs = append(f.bufs, p)
+	return (*[1 << 30]int32)(p)[:n:n]
+}
+func (f *flat) u8(n int) []uint8 {
+	p := C.calloc(C.size_t(n+1), 1)
+	f.bufs = append(f.bufs, p)
+	return (*[1 << 30]uint8)(p)[:n:n]
+}
+
+// errUnsupported makes Execute hand the cycle to the stock action (INTEGRATION.md §1)
+type errUnsupported string
+
+func (e errUnsupported) Error() string { return string(e) }
+
+// scalar resource names of the session, sorted: dimension d = 2 + rank
+func scalarDims(ssn *framework.Session) map[v1.ResourceName]int {
+	set := map[v1.ResourceName]bool{}
+	for _, n := range ssn.Nodes {
+		for name := range n.Allocatable.ScalarResources {
+			set[name] = true
+		}
+	}
+	for _, j := range ssn.Jobs {
+		for _, t := range j.Tasks {
+			for name := range t.Resreq.ScalarResources {
+				set[name] = true
+			}
+			for name := range t.InitResreq.ScalarResources {
+				set[name] = true
+			}
+		}
+	}
+	names := make([]string, 0, len(set))
+	for n := range set {
+		names = append(names, string(n))
+	}
+	sort.Strings(names)
+	dims := map[v1.ResourceName]int{}
+	for i, n := range names {
+		dims[v1.ResourceName(n)] = 2 + i
+	}
+	return dims
+}
+
+// put writes an api.Resource into column i of a dimension-major [R][n] matrix and returns its scalar-key mask
+func put(dst []float64, n, i int, r *api.Resource, dims map[v1.ResourceName]int) uint32 {
+	dst[0*n+i] = r.MilliCPU
+	dst[1*n+i] = r.Memory
+	var mask uint32
+	for name, v := range r.ScalarResources {
+		d := dims[name]
+		dst[d*n+i] = v
+		mask |= 1 << uint(d-2)
+	}
+	return mask
+}
+
+// podNonZero = sum over containers of GetNonzeroRequests (vendor/.../priorities/util/non_zero.go:48-61), what
+// nodeinfo.calculateResource accumulates into nonzeroRequest (vendor/.../nodeinfo/node_info.go:502-517)
+func podNonZero(pod *v1.Pod) (cpu, mem int64) {
+	for i := range pod.Spec.Containers {
+		c, m := priorityutil.GetNonzeroRequests(&pod.Spec.Containers[i].Resources.Requests)
+		cpu += c
+		mem += m
+	}
+	return
+}
+
+// static-predicate classes: everything the predicates plugin checks that does not change inside a cycle
+func nodeClassKey(n *api.NodeInfo) string {
+	return fmt.Sprintf("%v|%v|%v|%v", n.Node.Labels, n.Node.Spec.Taints, n.Node.Spec.Unschedulable, n.Node.Status.Conditions)
+}
+func taskClassKey(t *api.TaskInfo) (string, error) {
+	sp := &t.Pod.Spec
+	if sp.Affinity != nil && (sp.Affinity.PodAffinity != nil || sp.Affinity.PodAntiAffinity != nil) {
+		return "", errUnsupported("inter-pod (anti)affinity")
+	}
+	if sp.Affinity != nil && sp.Affinity.NodeAffinity != nil && len(sp.Affinity.NodeAffinity.PreferredDuringSchedulingIgnoredDuringExecution) > 0 {
+		return "", errUnsupported("preferred node affinity (per-row score normalisation)")
+	}
+	for i := range sp.Containers {
+		for _, p := range sp.Containers[i].Ports {
+			if p.HostPort != 0 {
+				return "", errUnsupported("host ports")
+			}
+		}
+	}
+	return fmt.Sprintf("%v|%v|%v", sp.NodeSelector, sp.Affinity, sp.Tolerations), nil
+}
+
+// one (task class, node class) pair through the vendored predicates themselves, the ones
+// plugins/predicates/predicates.go:123-157 and :181-207 call
+func staticOK(t *api.TaskInfo, n *api.NodeInfo) bool {
+	ni := nodeinfo.NewNodeInfo()
+	ni.SetNode(n.Node)
+	if ok, _, _ := predicates.CheckNodeConditionPredicate(t.Pod, nil, ni); !ok {
+		return false
+	}
+	if ok, _, _ := predicates.CheckNodeUnschedulablePredicate(t.Pod, nil, ni); !ok {
+		return false
+	}
+	if ok, _, _ := predicates.PodMatchNodeSelector(t.Pod, nil, ni); !ok {
+		return false
+	}
+	if ok, _, _ := predicates.PodToleratesNodeTaints(t.Pod, nil, ni); !ok {
+		return false
+	}
+	return true
+}
+
+func taskStatus(s api.TaskStatus) uint8 {
+	switch s {
+	case api.Pending:
+		return C.KB_TASK_PENDING
+	case api.Allocated:
+		return C.KB_TASK_ALLOCATED
+	case api.Pipelined:
+		return C.KB_TASK_PIPELINED
+	case api.Binding:
+		return C.KB_TASK_BINDING
+	case api.Bound:
+		return C.KB_TASK_BOUND
+	case api.Running:
+		return C.KB_TASK_RUNNING
+	case api.Releasing:
+		return C.KB_TASK_RELEASING
+	case api.Succeeded:
+		return C.KB_TASK_SUCCEEDED
+	case api.Failed:
+		return C.KB_TASK_FAILED
+	}
+	return C.KB_TASK_UNKNOWN
+}
+
+func flatten(ssn *framework.Session) (*flat, error) {
+	f := &flat{}
+	dims := scalarDims(ssn)
+	R := 2 + len(dims)
+	if R > C.KB_MAX_RES {
+		return nil, errUnsupported("too many scalar resource names")
+	}
+
+	// ---- canonical orders
+	nodeNames := make([]string, 0, len(ssn.Nodes))
+	for name := range ssn.Nodes {
+		nodeNames = append(nodeNames, name)
+	}
+	sort.Strings(nodeNames)
+	nodeIdx := map[string]uint32{}
+	for i, name := range nodeNames {
+		nodeIdx[name] = uint32(i)
+		f.nodes = append(f.nodes, ssn.Nodes[name])
+	}
+	queueIDs := make([]string, 0, len(ssn.Queues))
+	for id := range ssn.Queues {
+		queueIDs = append(queueIDs, string(id))
+	}
+	sort.Strings(queueIDs)
+	queueIdx := map[api.QueueID]uint32{}
+	for i, id := range queueIDs {
+		queueIdx[api.QueueID(id)] = uint32(i)
+	}
+	jobIDs := make([]string, 0, len(ssn.Jobs))
+	for id := range ssn.Jobs {
+		jobIDs = append(jobIDs, string(id))
+	}
+	sort.Strings(jobIDs)
+
+	N, Q, J := len(nodeNames), len(queueIDs), len(jobIDs)
+	T := 0
+	for _, j := range ssn.Jobs {
+		T += len(j.Tasks)
+	}
+
+	// ---- nodes (api/node_info.go:28-47)
+	idle, rel, alloc := f.f64(R*N), f.f64(R*N), f.f64(R*N)
+	nmask := f.u32(N)
+	acpu, amem, nzc, nzm := f.i64(N), f.i64(N), f.i64(N), f.i64(N)
+	maxPods, podCnt := f.i32(N), f.i32(N)
+	nclass := f.u32(N)
+	nodeClasses := map[string]uint32{}
+	var nodeClassRep []*api.NodeInfo
+	for i, n := range f.nodes {
+		put(idle, N, i, n.Idle, dims)
+		put(rel, N, i, n.Releasing, dims)
+		nmask[i] = put(alloc, N, i, n.Allocatable, dims)
+		acpu[i] = n.Node.Status.Allocatable.Cpu().MilliValue() // what nodeinfo.SetNode stores (vendor/.../nodeinfo/node_info.go:625-628)
+		amem[i] = n.Node.Status.Allocatable.Memory().Value()
+		for _, t := range n.Tasks { // every entry of ni.Tasks whatever its status (node_info.go:277-283)
+			c, m := podNonZero(t.Pod)
+			nzc[i] += c
+			nzm[i] += m
+		}
+		maxPods[i] = int32(n.Allocatable.MaxTaskNum)
+		podCnt[i] = int32(len(n.Tasks))
+		key := nodeClassKey(n)
+		id, ok := nodeClasses[key]
+		if !ok {
+			id = uint32(len(nodeClasses))
+			nodeClasses[key] = id
+			nodeClassRep = append(nodeClassRep, n)
+		}
+		nclass[i] = id
+	}
+
+	// ---- jobs and tasks (api/job_info.go:36-54, :127-154)
+	tres, tinit := f.f64(R*T), f.f64(R*T)
+	tmask := f.u32(T)
+	tnzc, tnzm, tcreate := f.i64(T), f.i64(T), f.i64(T)
+	tjob, tclass, tnode := f.u32(T), f.u32(T), f.u32(T)
+	tprio := f.i32(T)
+	tstatus := f.u8(T)
+	jbegin := f.u32(J + 1)
+	jqueue := f.u32(J)
+	jmin, jprio := f.i32(J), f.i32(J)
+	jcreate := f.i64(J)
+	taskClasses := map[string]uint32{}
+	var taskClassRep []*api.TaskInfo
+	t := 0
+	for ji, id := range jobIDs {
+		job := ssn.Jobs[api.JobID(id)]
+		jbegin[ji] = uint32(t)
+		if q, ok := queueIdx[job.Queue]; ok {
+			jqueue[ji] = q
+		} else {
+			jqueue[ji] = C.KB_NONE // "queue not found": allocate.go:56-60 skips the job
+		}
+		jmin[ji] = job.MinAvailable
+		jprio[ji] = job.Priority
+		jcreate[ji] = job.CreationTimestamp.Unix()
+		uids := make([]string, 0, len(job.Tasks))
+		for uid := range job.Tasks {
+			uids = append(uids, string(uid))
+		}
+		sort.Strings(uids)
+		for _, uid := range uids {
+			ti := job.Tasks[api.TaskID(uid)]
+			f.tasks = append(f.tasks, ti)
+			tmask[t] = put(tres, T, t, ti.Resreq, dims)
+			put(tinit, T, t, ti.InitResreq, dims)
+			tnzc[t], tnzm[t] = podNonZero(ti.Pod)
+			tjob[t] = uint32(ji)
+			tprio[t] = ti.Priority
+			tcreate[t] = ti.Pod.CreationTimestamp.Unix()
+			tstatus[t] = taskStatus(ti.Status)
+			tnode[t] = C.KB_NONE
+			if idx, ok := nodeIdx[ti.NodeName]; ok && ti.NodeName != "" {
+				tnode[t] = idx
+			}
+			key, err := taskClassKey(ti)
+			if err != nil {
+				f.free()
+				return nil, err
+			}
+			cid, ok := taskClasses[key]
+			if !ok {
+				cid = uint32(len(taskClasses))
+				taskClasses[key] = cid
+				taskClassRep = append(taskClassRep, ti)
+			}
+			tclass[t] = cid
+			t++
+		}
+	}
+	jbegin[J] = uint32(t)
+
+	// ---- queues (api/queue_info.go:74-93)
+	qweight := f.i32(Q)
+	qcreate := f.i64(Q)
+	for i, id := range queueIDs {
+		q := ssn.Queues[api.QueueID(id)]
+		qweight[i] = q.Weight
+		qcreate[i] = q.Queue.CreationTimestamp.Unix()
+	}
+
+	// ---- static predicates once per (task class, node class)
+	ntc, nnc := len(taskClassRep), len(nodeClassRep)
+	compat := f.u8((ntc*nnc + 7) / 8)
+	for a, tr := range taskClassRep {
+		for b, nr := range nodeClassRep {
+			if staticOK(tr, nr) {
+				bit := a*nnc + b
+				compat[bit>>3] |= 1 << uint(bit&7)
+			}
+		}
+	}
+
+	s := &f.snap
+	s.version = C.KB_ABI_VERSION
+	s.n_res, s.n_nodes, s.n_tasks, s.n_jobs, s.n_queues = C.uint32_t(R), C.uint32_t(N), C.uint32_t(T), C.uint32_t(J), C.uint32_t(Q)
+	s.n_task_classes, s.n_node_classes = C.uint32_t(ntc), C.uint32_t(nnc)
+	s.node_idle = (*C.double)(unsafe.Pointer(&idle[0]))
+	s.node_releasing = (*C.double)(unsafe.Pointer(&rel[0]))
+	s.node_allocatable = (*C.double)(unsafe.Pointer(&alloc[0]))
+	s.node_scalar_mask = (*C.uint32_t)(unsafe.Pointer(&nmask[0]))
+	s.node_alloc_cpu = (*C.int64_t)(unsafe.Pointer(&acpu[0]))
+	s.node_alloc_mem = (*C.int64_t)(unsafe.Pointer(&amem[0]))
+	s.node_nz_cpu = (*C.int64_t)(unsafe.Pointer(&nzc[0]))
+	s.node_nz_mem = (*C.int64_t)(unsafe.Pointer(&nzm[0]))
+	s.node_max_pods = (*C.int32_t)(unsafe.Pointer(&maxPods[0]))
+	s.node_pod_cnt = (*C.int32_t)(unsafe.Pointer(&podCnt[0]))
+	s.node_class = (*C.uint32_t)(unsafe.Pointer(&nclass[0]))
+	s.task_resreq = (*C.double)(unsafe.Pointer(&tres[0]))
+	s.task_init_resreq = (*C.double)(unsafe.Pointer(&tinit[0]))
+	s.task_scalar_mask = (*C.uint32_t)(unsafe.Pointer(&tmask[0]))
+	s.task_nz_cpu = (*C.int64_t)(unsafe.Pointer(&tnzc[0]))
+	s.task_nz_mem = (*C.int64_t)(unsafe.Pointer(&tnzm[0]))
+	s.task_job = (*C.uint32_t)(unsafe.Pointer(&tjob[0]))
+	s.task_class = (*C.uint32_t)(unsafe.Pointer(&tclass[0]))
+	s.task_priority = (*C.int32_t)(unsafe.Pointer(&tprio[0]))
+	s.task_creation = (*C.int64_t)(unsafe.Pointer(&tcreate[0]))
+	s.task_status = (*C.uint8_t)(unsafe.Pointer(&tstatus[0]))
+	s.task_node = (*C.uint32_t)(unsafe.Pointer(&tnode[0]))
+	s.job_task_begin = (*C.uint32_t)(unsafe.Pointer(&jbegin[0]))
+	s.job_queue = (*C.uint32_t)(unsafe.Pointer(&jqueue[0]))
+	s.job_min_available = (*C.int32_t)(unsafe.Pointer(&jmin[0]))
+	s.job_priority = (*C.int32_t)(unsafe.Pointer(&jprio[0]))
+	s.job_creation = (*C.int64_t)(unsafe.Pointer(&jcreate[0]))
+	s.queue_weight = (*C.int32_t)(unsafe.Pointer(&qweight[0]))
+	s.queue_creation = (*C.int64_t)(unsafe.Pointer(&qcreate[0]))
+	s.class_compat = (*C.uint8_t)(unsafe.Pointer(&compat[0]))
+	return f, nil
+}

@@ -1,0 +1,131 @@
+"""Kubernetes manifests -> the objects `snapshot.flatten` consumes (the snapshot loader).
+
+Reads what `kubectl get nodes,pods,podgroups,queues -o yaml` prints (single documents, `---` streams or `kind: List`
+wrappers, YAML or JSON) and keeps exactly the fields the allocate path reads.  Field semantics follow the cache's
+event handlers in the reference:
+
+  * Node      -> api.NewNodeInfo (pkg/scheduler/api/node_info.go:49-84): status.allocatable, labels, spec.taints,
+                 spec.unschedulable, status.conditions (Ready / NetworkUnavailable: predicates CheckNodeCondition)
+  * Pod       -> api.NewTaskInfo (pkg/scheduler/api/job_info.go:68-95, pod_info.go:53-73): container and init-container
+                 requests, spec.nodeName, status.phase, deletionTimestamp, spec.priority, nodeSelector, tolerations,
+                 the group annotation `scheduling.k8s.io/group-name` (job_info.go:56-66); pods of other schedulers keep
+                 their node usage but are not scheduled (cache/event_handlers.go:44-77) -> `scheduler_name` filter
+  * PodGroup  -> JobInfo.SetPodGroup (job_info.go:191-204): minMember, queue ("" -> default queue,
+                 cache/event_handlers.go:386-389)
+  * Queue     -> QueueInfo (queue_info.go:30-46): spec.weight
+  * Job (batch/v1) -> expanded to `parallelism` pending pods named <job>-<i> (what the job controller would create),
+                 for example/job.yaml
+"""
+import calendar
+import time
+from typing import Dict, Iterable, List, Optional, Tuple
+
+import yaml
+
+from .snapshot import Node, Pod, PodGroup, Queue, SessionSnapshot, flatten
+
+GROUP_ANNOTATION = "scheduling.k8s.io/group-name"
+
+
+def _ts(meta) -> int:
+    """metadata.creationTimestamp (RFC 3339, second resolution like metav1.Time) -> Unix seconds; 0 when absent."""
+    v = (meta or {}).get("creationTimestamp")
+    if not v:
+        return 0
+    if isinstance(v, (int, float)):
+        return int(v)
+    if hasattr(v, "timetuple"):            # yaml already parsed it
+        return int(calendar.timegm(v.timetuple()))
+    return int(calendar.timegm(time.strptime(str(v).replace("Z", ""), "%Y-%m-%dT%H:%M:%S")))
+
+
+def _requests(containers) -> List[Dict[str, str]]:
+    out = []
+    for c in containers or []:
+        req = ((c.get("resources") or {}).get("requests") or {})
+        out.append({k: str(v) for k, v in req.items()})
+    return out
+
+
+def _documents(text: str) -> Iterable[dict]:
+    for doc in yaml.safe_load_all(text):
+        if not doc:
+            continue
+        if str(doc.get("kind", "")).endswith("List") and "items" in doc:
+            for it in doc["items"] or []:
+                yield it
+        else:
+            yield doc
+
+
+def _node(doc) -> Node:
+    meta, spec, status = doc.get("metadata", {}), doc.get("spec", {}) or {}, doc.get("status", {}) or {}
+    conds = {c.get("type"): c.get("status") for c in status.get("conditions", []) or []}
+    return Node(
+        name=meta["name"],
+        allocatable={k: str(v) for k, v in (status.get("allocatable") or {}).items()},
+        labels=dict(meta.get("labels") or {}),
+        taints=[(t.get("key", ""), t.get("value", "") or "", t.get("effect", "")) for t in spec.get("taints", []) or []],
+        unschedulable=bool(spec.get("unschedulable", False)),
+        ready=conds.get("Ready", "True") == "True",
+        network_unavailable=conds.get("NetworkUnavailable", "False") == "True",
+    )
+
+
+def _pod(doc, namespace: str) -> Pod:
+    meta, spec, status = doc.get("metadata", {}), doc.get("spec", {}) or {}, doc.get("status", {}) or {}
+    return Pod(
+        namespace=meta.get("namespace", namespace),
+        name=meta["name"],
+        uid=meta.get("uid"),
+        containers=_requests(spec.get("containers")),
+        init_containers=_requests(spec.get("initContainers")),
+        group_name=(meta.get("annotations") or {}).get(GROUP_ANNOTATION, ""),
+        node_name=spec.get("nodeName", "") or "",
+        phase=status.get("phase", "Pending") or "Pending",
+        priority=spec.get("priority"),
+        creation=_ts(meta),
+        deleting=bool(meta.get("deletionTimestamp")),
+        node_selector=dict(spec.get("nodeSelector") or {}),
+        tolerations=[(t.get("key", "") or "", t.get("operator", "Equal") or "Equal", t.get("value", "") or "", t.get("effect", "") or "")
+                     for t in spec.get("tolerations", []) or []],
+    )
+
+
+def load_cluster(text: str, namespace: str = "default", default_queue: str = "default",
+                 scheduler_name: Optional[str] = None) -> Tuple[List[Node], List[Pod], List[PodGroup], List[Queue]]:
+    """Parse a manifest stream into (nodes, pods, pod_groups, queues)."""
+    nodes, pods, pgs, queues = [], [], [], []
+    for doc in _documents(text):
+        kind = doc.get("kind")
+        meta = doc.get("metadata", {}) or {}
+        spec = doc.get("spec", {}) or {}
+        if kind == "Node":
+            nodes.append(_node(doc))
+        elif kind == "Pod":
+            if scheduler_name and (spec.get("schedulerName") or "default-scheduler") != scheduler_name and not spec.get("nodeName"):
+                continue   # pending pod of another scheduler: never enters the cache's jobs (event_handlers.go:44-77)
+            pods.append(_pod(doc, namespace))
+        elif kind == "PodGroup":
+            pgs.append(PodGroup(meta.get("namespace", namespace), meta["name"], min_member=int(spec.get("minMember", 0) or 0),
+                                queue=spec.get("queue", "") or default_queue, creation=_ts(meta)))
+        elif kind == "Queue":
+            queues.append(Queue(meta["name"], weight=int(spec.get("weight", 1) or 1), creation=_ts(meta)))
+        elif kind == "Job":
+            tpl = spec["template"]
+            tmeta, tspec = tpl.get("metadata", {}) or {}, tpl["spec"]
+            for i in range(int(spec.get("parallelism", 1) or 1)):
+                pods.append(_pod({"metadata": {"name": f"{meta['name']}-{i}", "namespace": meta.get("namespace", namespace),
+                                               "annotations": tmeta.get("annotations"), "creationTimestamp": meta.get("creationTimestamp")},
+                                  "spec": tspec, "status": {"phase": "Pending"}}, namespace))
+    return nodes, pods, pgs, queues
+
+
+def load_snapshot(text: str, **kw) -> SessionSnapshot:
+    """Manifest stream -> flattened session snapshot (what kb_session_load takes).  A default queue is added when the
+    stream carries none (config/queue/default.yaml: weight 1)."""
+    default_queue = kw.get("default_queue", "default")
+    nodes, pods, pgs, queues = load_cluster(text, **kw)
+    if not any(q.name == default_queue for q in queues):
+        queues.append(Queue(default_queue, 1))
+    return flatten(nodes, pods, pgs, queues)

@@ -1,0 +1,131 @@
+"""Manifest loader: YAML / JSON cluster dumps flatten to the same snapshot as hand-built objects,
+and the reference's own test cases restated as manifests schedule to the bind sets allocate_test.go expects."""
+import importlib
+import json
+
+import numpy as np
+import yaml
+
+kb = importlib.import_module("kube-batch_amd")
+abi = importlib.import_module("kube-batch_amd.abi")
+fixtures = importlib.import_module("kube-batch_amd.fixtures")
+manifests = importlib.import_module("kube-batch_amd.manifests")
+snapshot = importlib.import_module("kube-batch_amd.snapshot")
+
+# allocate_test.go:86-144 as `kubectl get ... -o yaml` would print it (plus fields the loader must ignore)
+CASE2 = """
+apiVersion: v1
+kind: List
+items:
+- apiVersion: v1
+  kind: Node
+  metadata: {name: n1, labels: {zone: a}}
+  status:
+    allocatable: {cpu: "2", memory: 4G, nvidia.com/gpu: "0"}
+    conditions: [{type: Ready, status: "True"}, {type: MemoryPressure, status: "False"}]
+- apiVersion: scheduling.incubator.k8s.io/v1alpha1
+  kind: Queue
+  metadata: {name: c1}
+  spec: {weight: 1}
+- apiVersion: scheduling.incubator.k8s.io/v1alpha1
+  kind: Queue
+  metadata: {name: c2}
+  spec: {weight: 1}
+- apiVersion: scheduling.incubator.k8s.io/v1alpha1
+  kind: PodGroup
+  metadata: {name: pg1, namespace: c1}
+  spec: {queue: c1}
+- apiVersion: scheduling.incubator.k8s.io/v1alpha1
+  kind: PodGroup
+  metadata: {name: pg2, namespace: c2}
+  spec: {queue: c2}
+""" + "".join(f"""
+- apiVersion: v1
+  kind: Pod
+  metadata:
+    name: {name}
+    namespace: {ns}
+    uid: {ns}-{name}
+    annotations: {{scheduling.k8s.io/group-name: {pg}}}
+  spec:
+    schedulerName: kube-batch
+    containers:
+    - name: c
+      image: busybox
+      resources: {{requests: {{cpu: "1", memory: 1G, nvidia.com/gpu: "0"}}}}
+  status: {{phase: Pending}}
+""" for ns, name, pg in (("c1", "p1", "pg1"), ("c1", "p2", "pg1"), ("c2", "p1", "pg2"), ("c2", "p2", "pg2")))
+
+
+def _same(a, b):
+    for name, _ in abi.SNAPSHOT_ARRAYS:
+        x, y = getattr(a, name, None), getattr(b, name, None)
+        assert (x is None) == (y is None), name
+        if x is not None:
+            assert np.array_equal(x, y), name
+    for k in ("n_res", "n_nodes", "n_tasks", "n_jobs", "n_queues"):
+        assert getattr(a, k) == getattr(b, k), k
+
+
+def test_list_manifest_equals_hand_built_case():
+    _, want, _ = fixtures.allocate_cases()[1]
+    got = manifests.load_snapshot(CASE2, default_queue="c1")
+    _same(got, want)
+    # the same dump as JSON
+    docs = [d for d in yaml.safe_load_all(CASE2)]
+    _same(manifests.load_snapshot(json.dumps(docs[0]), default_queue="c1"), want)
+
+
+def test_reference_case_from_manifest_schedules_like_the_reference(oracle_mod):
+    snap = manifests.load_snapshot(CASE2, default_queue="c1")
+    o = oracle_mod.Oracle(fixtures.allocate_test_tiers(), snap)
+    o.run(["allocate"])
+    assert snap.bind_map(o.binds()) == {"c2/p1": "n1", "c1/p1": "n1"}   # allocate_test.go:139-142
+
+
+def test_example_job_yaml_and_node_fields():
+    text = fixtures.EXAMPLE_JOB_MANIFEST + """
+---
+apiVersion: v1
+kind: Node
+metadata: {name: w1, labels: {disk: ssd}}
+spec:
+  taints: [{key: dedicated, value: batch, effect: NoSchedule}]
+status:
+  allocatable: {cpu: "4", memory: 8Gi, pods: "110"}
+  conditions: [{type: Ready, status: "True"}, {type: NetworkUnavailable, status: "False"}]
+---
+apiVersion: v1
+kind: Node
+metadata: {name: w2}
+spec: {unschedulable: true}
+status:
+  allocatable: {cpu: "4", memory: 8Gi, pods: "110"}
+  conditions: [{type: Ready, status: "False"}]
+---
+apiVersion: v1
+kind: Pod
+metadata: {name: other, namespace: kube-system, creationTimestamp: "2019-05-01T10:00:00Z"}
+spec:
+  nodeName: w1
+  priority: 7
+  nodeSelector: {disk: ssd}
+  tolerations: [{key: dedicated, operator: Exists, effect: NoSchedule}]
+  initContainers: [{name: i, resources: {requests: {cpu: "2"}}}]
+  containers: [{name: c, resources: {requests: {cpu: 500m, memory: 1Gi}}}]
+status: {phase: Running}
+"""
+    nodes, pods, pgs, queues = manifests.load_cluster(text)
+    assert [n.name for n in nodes] == ["w1", "w2"]
+    assert nodes[0].taints == [("dedicated", "batch", "NoSchedule")] and nodes[0].labels == {"disk": "ssd"}
+    assert nodes[1].unschedulable and not nodes[1].ready
+    assert len(pods) == 7 and sum(p.group_name == "qj-1" for p in pods) == 6
+    other = [p for p in pods if p.name == "other"][0]
+    assert other.node_name == "w1" and other.phase == "Running" and other.priority == 7 and other.creation == 1556704800
+    assert other.tolerations == [("dedicated", "Exists", "", "NoSchedule")] and other.node_selector == {"disk": "ssd"}
+    assert other.init_containers == [{"cpu": "2"}] and other.containers == [{"cpu": "500m", "memory": "1Gi"}]
+    assert pgs[0].min_member == 6 and pgs[0].queue == "default" and queues == []
+    snap = manifests.load_snapshot(text)
+    # the running pod occupies w1: Idle = 4000m - max(init 2000m, containers 500m)?  No: Resreq (containers) is what AddTask subtracts
+    w1 = snap.names["nodes"].index("w1")
+    assert snap.node_idle[0, w1] == 3500.0 and snap.node_pod_cnt[w1] == 1
