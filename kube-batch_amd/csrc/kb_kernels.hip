@@ -632,6 +632,16 @@ __device__ __forceinline__ TaskVals k7_task_vals(const KbRowDesc &k) {
   return tv;
 }
 
+// TaskInfo.Resreq cpu / memory of a row: equal to InitResreq unless an init container raised the latter (flags bit 0 clear,
+// rare).  The LDS values are materialised before the branch so that the compiler does not turn "LDS address or global
+// address" into flat loads (which wait on both memory counters).
+__device__ __forceinline__ void k7_resreq(const KbCommitArgs &a, const KbRowDesc &k, double &res0, double &res1) {
+  res0 = k.init0;
+  res1 = k.init1;
+  asm volatile("" : "+v"(res0), "+v"(res1));
+  if (!(k.flags & 1)) { const KbDev &d = *a.dev; res0 = d.t_res[k.task]; res1 = d.t_res[(size_t)d.T + k.task]; }
+}
+
 // decision record + multi-GPU deltas of one committed row; SUB: also apply the scalar dimensions of NodeInfo.AddTask
 // (the batched clean rows did that speculatively in the apply step)
 template <bool SUB>
@@ -655,8 +665,8 @@ __device__ __forceinline__ void k7_commit_globals(const KbCommitArgs &a, const K
     const KbDev &d = *a.dev;
     const KbRound &r = *a.round;
     if (i >= r.own_row0 && i < r.own_row1) {
-      double res0 = k.init0, res1 = k.init1;
-      if (!(k.flags & 1)) { res0 = d.t_res[k.task]; res1 = d.t_res[(size_t)d.T + k.task]; }
+      double res0, res1;
+      k7_resreq(a, k, res0, res1);
       // per-node committed deltas of the rows this rank owns: [dIdle R][dRel R][dnzc][dnzm][dpodcnt] x NP
       double *dv = r.delta + (size_t)(kind ? d.R : 0) * d.NP;
       dv[n] -= res0;
@@ -679,8 +689,8 @@ __device__ __forceinline__ void k7_commit_globals(const KbCommitArgs &a, const K
 // Allocate or Pipeline for row k on the node held in `slot` (allocate.go:160), then NodeInfo.AddTask on the LDS copy
 __device__ __forceinline__ uint32_t k7_apply_slot(const KbCommitArgs &a, const K7Mem &M, const KbRowDesc &k, uint32_t slot, uint32_t n) {
   const uint32_t cap2 = M.cap2;
-  double res0 = k.init0, res1 = k.init1;
-  if (!(k.flags & 1)) { const KbDev &d = *a.dev; res0 = d.t_res[k.task]; res1 = d.t_res[(size_t)d.T + k.task]; }
+  double res0, res1;
+  k7_resreq(a, k, res0, res1);
   uint32_t kind = 0;
   if (!a.backfill) {
     bool fi = le_eps(k.init0, __longlong_as_double((long long)M.tab[K5F_IDLE0 * cap2 + slot]), EPS_CPU) &&
@@ -927,8 +937,8 @@ __global__ void __launch_bounds__(KB_K5_THREADS) k_commit(const K7KernArgs ka) {
         uint32_t v4 = 0;
         if (f < K5_NF8) v8 = g8[n];
         else if (f <= 12) v4 = g4[n];
-        double res0 = k.init0, res1 = k.init1;
-        if (!(k.flags & 1)) { const KbDev &d = *a.dev; res0 = d.t_res[k.task]; res1 = d.t_res[(size_t)d.T + k.task]; }
+        double res0, res1;
+        k7_resreq(a, k, res0, res1);
         bool ok = true;
         if (!a.backfill) {
           const double dv = __longlong_as_double((long long)v8);
