@@ -468,6 +468,23 @@ struct ActionRun {
   double host_ms = 0, t_start = 0;
   bool active = false;
 
+  // A task shape with no feasible node stays infeasible for the rest of the action (idle only shrinks, releasing does not
+  // grow).  The same holds for every shape of the same static class whose compared InitResreq is >= in every dimension:
+  // LessEqual is monotone in its left operand, so that shape's feasible set is a subset of an empty set.  Marking them
+  // now saves the device round each would otherwise end.
+  void mark_dead(const HostSession &hs, uint32_t x) {
+    const int R = hs.R;
+    const double *ex = &hs.feas_eff[(size_t)x * R];
+    for (uint32_t y = 0; y < hs.n_feas_shapes; y++) {
+      if (dead[y] || hs.feas_cls[y] != hs.feas_cls[x]) continue;
+      const double *ey = &hs.feas_eff[(size_t)y * R];
+      bool ge = true;
+      for (int d = 0; d < R && ge; d++) ge = ey[d] >= ex[d];
+      if (ge) dead[y] = 1;
+    }
+    dead[x] = 1;
+  }
+
   void begin(kb_engine *e, uint32_t act) {
     HostSession &hs = e->hs;
     action = act;
@@ -540,7 +557,7 @@ struct ActionRun {
         if (dead[hs.t_feas_shape[t]]) { om.report(Outcome::NoFeasibleNode); continue; }
         if (t != e->h_rows[i]) throw EngineError(KB_E_INTERNAL, "order replay diverged from the speculated sequence");
         if (reason == KB_REASON_NO_FEASIBLE && i == n_done) {
-          dead[hs.t_feas_shape[t]] = 1;
+          mark_dead(hs, hs.t_feas_shape[t]);
           om.report(Outcome::NoFeasibleNode);
           break;
         }
@@ -764,6 +781,16 @@ int kb_session_load(kb_engine *e, const kb_snapshot *sn) {
     }
     hs.n_feas_shapes = (uint32_t)feas_ids.size();
     hs.n_row_shapes = (uint32_t)row_ids.size();
+    // per feasibility shape: the vector LessEqual actually compares (scalar dimensions at or below the epsilon are skipped,
+    // resource_info.go:283-287) and the static class, for the dominance rule of ActionRun::mark_dead
+    hs.feas_eff.assign((size_t)hs.n_feas_shapes * R, 0.0);
+    hs.feas_cls.assign(hs.n_feas_shapes, 0);
+    for (uint32_t t = 0; t < T; t++) {
+      const uint32_t f = hs.t_feas_shape[t];
+      hs.feas_cls[f] = hs.t_cls[t];
+      for (int d = 0; d < R; d++)
+        hs.feas_eff[(size_t)f * R + d] = (d < 2 || ((t_active[t] >> d) & 1u)) ? hs.t_init[(size_t)d * T + t] : 0.0;
+    }
 
     // ---- plugin OnSessionOpen state ----
     // drf.go:60-64 / proportion.go:58-62: total = sum of Allocatable over ssn.Nodes (ascending node name)

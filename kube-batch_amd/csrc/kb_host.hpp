@@ -145,6 +145,8 @@ struct HostSession {
   std::vector<uint32_t> t_feas_shape;     // id of (InitResreq, class): tasks sharing it share a feasibility row
   std::vector<uint32_t> t_row_shape;      // id of (InitResreq, non-zero request, class): identical matrix rows
   uint32_t n_feas_shapes = 0, n_row_shapes = 0;
+  std::vector<double> feas_eff;           // [n_feas_shapes][R] the InitResreq values LessEqual compares (0 where the dimension is skipped)
+  std::vector<uint32_t> feas_cls;         // [n_feas_shapes] static-predicate class
   std::vector<uint32_t> job_begin, job_queue;
   std::vector<int32_t> job_min, job_prio;
   std::vector<int64_t> job_creation;
