@@ -34,7 +34,7 @@ def main():
     ap.add_argument("--config", type=int, default=3, help="BASELINE config index (2..5)")
     ap.add_argument("--scale", type=float, default=1.0)
     ap.add_argument("--window", type=int, default=0)
-    ap.add_argument("--topk", type=int, default=0)
+    ap.add_argument("--commit-batch", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-tasks", type=int, default=0, help="0 = the whole allocate action (a few seconds on 16 threads)")
     ap.add_argument("--verify", action="store_true", help="compare the bind set with the oracle after the timed region (slow)")
@@ -68,11 +68,11 @@ def main():
 
     if world > 1:
         distmod = importlib.import_module("kube-batch_amd.dist")
-        runner = distmod.ShardedCycle(conf, snap, device=local_rank, window=args.window, topk=args.topk)
+        runner = distmod.ShardedCycle(conf, snap, device=local_rank, window=args.window, commit_batch=args.commit_batch)
         step = runner.step
         eng = runner.engine
     else:
-        eng = engine.Engine(conf, device=local_rank, window=args.window, topk=args.topk)
+        eng = engine.Engine(conf, device=local_rank, window=args.window, commit_batch=args.commit_batch)
         eng.load(snap)
 
         def step():

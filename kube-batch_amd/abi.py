@@ -39,7 +39,6 @@ EN_NODE_ORDER = 1 << 8
 EN_ALL = 0x1FF
 
 FLAG_SYNC_ROUNDS = 1
-FLAG_NO_TOPK = 2
 
 
 class PluginOption(C.Structure):
@@ -49,7 +48,7 @@ class PluginOption(C.Structure):
 class Config(C.Structure):
     _fields_ = [("version", C.c_uint32), ("n_tiers", C.c_uint32),
                 ("tier_begin", C.POINTER(C.c_uint32)), ("plugins", C.POINTER(PluginOption)),
-                ("device", C.c_int32), ("window", C.c_uint32), ("topk", C.c_uint32), ("flags", C.c_uint32)]
+                ("device", C.c_int32), ("window", C.c_uint32), ("commit_batch", C.c_uint32), ("flags", C.c_uint32)]
 
 
 _P = C.POINTER

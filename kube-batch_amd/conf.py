@@ -55,7 +55,7 @@ class SchedulerConf:
     actions: List[str]
     tiers: List[List[PluginOption]]
 
-    def to_abi(self, device: int = 0, window: int = 0, topk: int = 0, flags: int = 0):
+    def to_abi(self, device: int = 0, window: int = 0, commit_batch: int = 0, flags: int = 0):
         """Returns (kb_config, keepalive) — keepalive owns the arrays the struct points to."""
         n_p = sum(len(t) for t in self.tiers)
         tier_begin = (C.c_uint32 * (len(self.tiers) + 1))()
@@ -98,7 +98,7 @@ class SchedulerConf:
         cfg.plugins = C.cast(plugins, C.POINTER(abi.PluginOption))
         cfg.device = device
         cfg.window = window
-        cfg.topk = topk
+        cfg.commit_batch = commit_batch
         cfg.flags = flags
         return cfg, (tier_begin, plugins)
 

@@ -97,6 +97,7 @@ struct KbRound {
   unsigned long long *dec;     // [n_rows] decision records: low word node (KB_NONE = stayed Pending), high word kind
   uint32_t *result;            // [8]: n_done, reason, n_dirty, list_exhausted (live rescans), window_refills
   int backfill;                // commit semantics of backfill.go (first node passing the predicates, no score)
+  uint32_t batch;              // rows the commit kernel speculates per batch (0 = default)
   double *delta;               // optional per-node committed deltas of owned rows [NP*(2R+3)] (multi-GPU), may be nullptr
   uint32_t own_row0, own_row1;
 };

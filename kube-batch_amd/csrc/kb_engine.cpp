@@ -115,7 +115,7 @@ static void mg_free(MgState *m);
 struct kb_engine {
   std::string err;
   int device = 0;
-  uint32_t window = 512, topk = 16, flags = 0;   // 512: measured optimum on the 100k x 10k snapshot (dirty set stays small)
+  uint32_t window = 512, commit_batch = 0, flags = 0;   // 512: measured optimum on the 100k x 10k snapshot (dirty set stays small)
   Policy pol;
   hipStream_t stream = nullptr;
   bool loaded = false;
@@ -309,6 +309,7 @@ KbRound make_round(kb_engine *e, uint32_t n_rows, uint32_t n_mrows, uint32_t L, 
   r.dec = e->b_out.as<unsigned long long>() + 8;   // 64-byte header (result words), then the decision records
   r.result = e->b_out.as<uint32_t>();
   r.backfill = backfill ? 1 : 0;
+  r.batch = e->commit_batch;
   r.delta = nullptr;
   r.own_row0 = r.own_row1 = 0;
   return r;
@@ -642,6 +643,7 @@ int kb_engine_create(const kb_config *cfg, kb_engine **out) {
     eng->device = cfg->device;
     if (cfg->window) eng->window = cfg->window;
     if (eng->window > KB_K5_MAX_WINDOW) eng->window = KB_K5_MAX_WINDOW;   // the commit kernel's dirty-node table lives in LDS
+    eng->commit_batch = cfg->commit_batch;
     eng->flags = cfg->flags;
     int ndev = 0;
     hipError_t he = hipGetDeviceCount(&ndev);

@@ -1376,14 +1376,15 @@ void kb_launch_argmax(const KbDev &d, const KbRound &r, void *stream) {
 void kb_launch_commit(const KbDev &d, const KbRound &r, void *stream) {
   if (r.n_rows == 0) return;
   static bool attr_set = false;
-  static uint32_t batch = 0;
+  static uint32_t env_batch = 0;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_commit), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    const char *b = getenv("KB_K5_BATCH");   // rows speculated per batch (tuning knob)
-    batch = b ? (uint32_t)atoi(b) : K7_B;
-    if (batch < 1 || batch > K7_B) batch = K7_B;
+    const char *b = getenv("KB_K5_BATCH");   // tuning override of kb_config.commit_batch
+    env_batch = b ? (uint32_t)atoi(b) : 0;
     attr_set = true;
   }
+  uint32_t batch = env_batch ? env_batch : (r.batch ? r.batch : K7_B);
+  if (batch > K7_B) batch = K7_B;
   const size_t sh = k7_smem_bytes(r.cap, d.NP, d.R);
   K7KernArgs ka;
   ka.dev = d;

@@ -57,14 +57,14 @@ class EngineBackend:
 class ShardedCycle:
     """Runs allocate (+ backfill) with the window's matrix rows sharded across ranks."""
 
-    def __init__(self, conf, snap, device: int = 0, window: int = 0, topk: int = 0, backend=None,
+    def __init__(self, conf, snap, device: int = 0, window: int = 0, commit_batch: int = 0, backend=None,
                  buffer_device: Optional[torch.device] = None, actions=("allocate", "backfill")):
         self.rank = dist.get_rank() if dist.is_initialized() else 0
         self.world = dist.get_world_size() if dist.is_initialized() else 1
         self.actions = list(actions)
         if backend is None:
             from .engine import Engine
-            self.engine = Engine(conf, device=device, window=window, topk=topk)
+            self.engine = Engine(conf, device=device, window=window, commit_batch=commit_batch)
             self.engine.load(snap)
             dev = torch.device("cuda", device)
             backend = EngineBackend(self.engine, dev)

@@ -124,12 +124,12 @@ def test_argmax_parity(oracle_mod):
         assert np.array_equal(en, on) and np.array_equal(es, os_), k
 
 
-@pytest.mark.parametrize("window,topk,flags", [(64, 4, 0), (1024, 16, 0), (4096, 0, abi.FLAG_NO_TOPK), (512, 32, 0)])
-def test_allocate_backfill_config2(oracle_mod, window, topk, flags):
+@pytest.mark.parametrize("window,batch,flags", [(64, 4, 0), (1024, 16, 0), (4096, 1, 0), (512, 7, 0), (200, 2, 0)])
+def test_allocate_backfill_config2(oracle_mod, window, batch, flags):
     """Full allocate + backfill on BASELINE config 2: ordered decisions, binds, state, shares identical."""
     snap = snapmod.synth(snapmod.synth_config(2))
     cfg = conf.load_scheduler_conf()
-    o, e, dec = run_both(oracle_mod, cfg, snap, ["allocate", "backfill"], window=window, topk=topk, flags=flags)
+    o, e, dec = run_both(oracle_mod, cfg, snap, ["allocate", "backfill"], window=window, commit_batch=batch, flags=flags)
     assert_same_outcome(o, e, dec)
     st = e.stats()
     assert st["decisions"] == len(dec) and st["rounds"] > 0
@@ -144,6 +144,20 @@ def test_allocate_gang_drf_queues_scaled_config3(oracle_mod):
     # gang semantics visible in the result: some Allocated tasks of never-ready gangs are not bound
     st, _ = e.task_state()
     assert (st == abi.TASK_BINDING).sum() == (e.binds() != abi.KB_NONE).sum()
+
+
+def test_wide_cluster_more_than_64k_nodes(oracle_mod):
+    """N >= 65536: the two-values-per-band variant of the candidate-list kernel, a 66k-bit dirty bitmap in the commit kernel."""
+    snap = snapmod.synth(snapmod.SynthParams(n_tasks=2500, n_nodes=66_000, n_queues=4, n_res=2, seed=snapmod.SEED_BASE + 77))
+    cfg = conf.load_scheduler_conf()
+    o = oracle_mod.Oracle(cfg, snap, threads=8)
+    e = engine.Engine(cfg)
+    e.load(snap)
+    en, es = e.argmax_rows(10, 40, 300)
+    on, os_ = o.argmax_rows(10, 40, 300)
+    assert np.array_equal(en, on) and np.array_equal(es, os_)
+    o2, e2, dec = run_both(oracle_mod, cfg, snap, ["allocate", "backfill"])
+    assert_same_outcome(o2, e2, dec)
 
 
 def test_reference_test_tiers_on_synthetic(oracle_mod):
