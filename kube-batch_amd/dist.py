@@ -58,7 +58,7 @@ class ShardedCycle:
     """Runs allocate (+ backfill) with the window's matrix rows sharded across ranks."""
 
     def __init__(self, conf, snap, device: int = 0, window: int = 0, commit_batch: int = 0, backend=None,
-                 buffer_device: Optional[torch.device] = None, actions=("allocate", "backfill")):
+                 buffer_device: Optional[torch.device] = None, actions=("allocate", "backfill"), min_rows_per_rank: int = 32):
         self.rank = dist.get_rank() if dist.is_initialized() else 0
         self.world = dist.get_world_size() if dist.is_initialized() else 1
         self.actions = list(actions)
@@ -77,6 +77,9 @@ class ShardedCycle:
         self.stage_host = (not dist.is_initialized()) or dist.get_backend() != "nccl"
         self.delta = torch.zeros(backend.delta_len, dtype=torch.float64, device=self.buf_dev)
         self.rounds = 0
+        self.replicated_rounds = 0
+        # shard a round's matrix rows only when every rank gets at least this many (0 = always shard)
+        self.min_rows_per_rank = min_rows_per_rank
 
     # ---- collectives
     def _all_gather_keys(self, local: torch.Tensor, chunk: int, L: int) -> torch.Tensor:
@@ -116,12 +119,20 @@ class ShardedCycle:
                 break
             # equal-sized shards of the matrix rows (padded so all_gather_into_tensor applies); the sorted candidate
             # lists are 0-terminated, padding rows stay 0
-            chunk = (n_mrows + self.world - 1) // self.world
-            m0 = min(self.rank * chunk, n_mrows)
-            m1 = min(m0 + chunk, n_mrows)
-            local = torch.zeros((chunk, L), dtype=torch.int64, device=self.buf_dev)
-            b.candidates(m0, m1, local)
-            table = self._all_gather_keys(local, chunk, L)
+            if n_mrows < self.min_rows_per_rank * self.world:
+                # too few distinct shapes in this window for the exchange to pay (a matrix row costs ~1 us of kernel time, a
+                # collective + its synchronisation tens of us): every rank evaluates all rows, no all-gather this round.
+                # The decision depends on n_mrows only, which is identical on every rank.
+                table = torch.zeros((n_mrows, L), dtype=torch.int64, device=self.buf_dev)
+                b.candidates(0, n_mrows, table)
+                self.replicated_rounds += 1
+            else:
+                chunk = (n_mrows + self.world - 1) // self.world
+                m0 = min(self.rank * chunk, n_mrows)
+                m1 = min(m0 + chunk, n_mrows)
+                local = torch.zeros((chunk, L), dtype=torch.int64, device=self.buf_dev)
+                b.candidates(m0, m1, local)
+                table = self._all_gather_keys(local, chunk, L)
             # the gathered table is [world*chunk][L]; matrix row m lives at row m because shards are contiguous and equal
             r0, r1 = shard_bounds(n_rows, self.world, self.rank)
             b.commit(table, r0, r1, self.delta)

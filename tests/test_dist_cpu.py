@@ -76,13 +76,14 @@ class FakeBackend:
         return np.array(self.decs, dtype=np.int64)
 
 
-def _worker(rank, world, port, out_dir):
+def _worker(rank, world, port, out_dir, min_rows):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         be = FakeBackend()
-        cyc = distmod.ShardedCycle(None, None, backend=be, buffer_device=torch.device("cpu"), actions=("allocate",))
+        cyc = distmod.ShardedCycle(None, None, backend=be, buffer_device=torch.device("cpu"), actions=("allocate",),
+                                   min_rows_per_rank=min_rows)
         dec = cyc.step()
         # every table a rank saw must be the complete, rank-independent candidate table
         for k, tab in enumerate(be.seen_tables):
@@ -94,15 +95,18 @@ def _worker(rank, world, port, out_dir):
         np.save(os.path.join(out_dir, f"dec{rank}.npy"), dec)
         np.save(os.path.join(out_dir, f"state{rank}.npy"), be.state)
         assert cyc.rounds == 3
+        # min_rows == 0: every round exchanges its rows; a large threshold: every rank evaluates all rows itself
+        assert cyc.replicated_rounds == (0 if min_rows == 0 else 3)
     finally:
         dist.destroy_process_group()
 
 
-def test_sharded_cycle_two_ranks_gloo(tmp_path):
+@pytest.mark.parametrize("min_rows", [0, 1000])
+def test_sharded_cycle_two_ranks_gloo(tmp_path, min_rows):
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
-    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, port, str(tmp_path), min_rows), nprocs=2, join=True)
     d0, d1 = np.load(tmp_path / "dec0.npy"), np.load(tmp_path / "dec1.npy")
     assert d0.shape[0] == 10 + 11 + 12 and np.array_equal(d0, d1)          # replicas take identical decisions
     assert np.array_equal(np.load(tmp_path / "state0.npy"), np.load(tmp_path / "state1.npy"))

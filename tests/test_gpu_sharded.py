@@ -42,7 +42,7 @@ def _worker(rank, world, port, out_dir):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         conf = kbm.conf.load_scheduler_conf()
-        cyc = distmod.ShardedCycle(conf, _snap(), device=0, window=256)
+        cyc = distmod.ShardedCycle(conf, _snap(), device=0, window=256, min_rows_per_rank=0)   # always exchange
         dec = cyc.step()
         np.save(os.path.join(out_dir, f"dec{rank}.npy"), dec)
         np.save(os.path.join(out_dir, f"binds{rank}.npy"), cyc.engine.binds())
