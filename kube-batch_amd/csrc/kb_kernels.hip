@@ -577,7 +577,8 @@ __device__ __forceinline__ void k5_field_ptrs(const KbDev &d, uint32_t fld, cons
 //             applied to the slot that owns the winning node.
 // A batch costs about as much as two rows of a row-at-a-time protocol, and commits ~10 rows on the benchmark snapshot.
 // ------------------------------------------------------------------------------------------------------------
-#define K7_B 16u
+#define K7_B 32u          // most rows one batch can speculate
+#define K7_B_DEFAULT 16u  // batch size after a batch that was cut short; doubled after a fully valid one
 #define K7_D 96u   // row descriptors staged per refill
 
 struct K7Hdr {
@@ -806,9 +807,9 @@ __global__ void __launch_bounds__(KB_K5_THREADS) k_commit(const K7KernArgs ka) {
   __syncthreads();
   K7_STAMP(0);
 
-  uint32_t i0 = 0, nd = 0, n_done = 0, reason = KB_REASON_DONE, dbase = 0, dcnt = 0;
+  uint32_t i0 = 0, nd = 0, n_done = 0, reason = KB_REASON_DONE, dbase = 0, dcnt = 0, nb_cur = a.batch;
   while (i0 < a.n_rows) {
-    const uint32_t nb = min(a.batch, a.n_rows - i0);
+    const uint32_t nb = min(nb_cur, a.n_rows - i0);
     // ---- stage row descriptors: three batches' worth per refill, so most batches find theirs already in LDS
     if (i0 < dbase || i0 + nb > dbase + dcnt) {
       dbase = i0;
@@ -848,14 +849,10 @@ __global__ void __launch_bounds__(KB_K5_THREADS) k_commit(const K7KernArgs ka) {
         H.e_start[q] = start; H.e_nlog[q] = nl; H.e_log0[q] = log0;
         if (full) atomicAdd(&H.n_full, 1u);
       }
-      // exclusive prefix of the counts over the representative lanes (all inside the first 16 lanes: one DPP row)
-      uint32_t incl = cnt;
-      incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x111, 0xf, 0xf, true);   // row_shr:1
-      incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x112, 0xf, 0xf, true);   // row_shr:2
-      incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x114, 0xf, 0xf, true);   // row_shr:4
-      incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x118, 0xf, 0xf, true);   // row_shr:8
+      // exclusive prefix of the counts over the representative lanes
+      const uint32_t incl = wave_incl_scan_u32(cnt);
       if (isrep) H.e_off[q] = incl - cnt;
-      const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 15);
+      const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
       const uint32_t nsh = (uint32_t)__popcll(repmask);
       if (lane >= nsh && lane < K7_B) H.e_off[lane] = 0xFFFFFFFFu;
       if (lane == 0) { H.nshapes = nsh; H.n_pairs = total; H.n_batches++; }
@@ -926,8 +923,8 @@ __global__ void __launch_bounds__(KB_K5_THREADS) k_commit(const K7KernArgs ka) {
     //      NodeInfo.AddTask (api/node_info.go:172-212) to its own field and stores it into the row's NEW dirty slot: the slot
     //      holds the node's state AFTER the row committed.  Scalar dimensions (global memory, rare) are written
     //      speculatively by lane 15 and their old values saved for the rollback.
-    if (tid < nb * 16) {
-      const uint32_t j = tid >> 4, f = tid & 15;
+    for (uint32_t w = tid; w < nb * 16; w += KB_K5_THREADS) {
+      const uint32_t j = w >> 4, f = w & 15;
       const unsigned long long cj = H.c[j];
       uint32_t kind = 0, has_map = 0;
       if (cj) {
@@ -1205,6 +1202,8 @@ __global__ void __launch_bounds__(KB_K5_THREADS) k_commit(const K7KernArgs ka) {
     K7_STAMP(8);
     nd += pc;
     i0 += rows;
+    // clean streaks are long (56 % of the batches commit every row): speculate twice as many rows after a fully valid batch
+    nb_cur = (dirty_row == 0 && p == nb) ? min(2u * a.batch, K7_B) : a.batch;
     n_done = i0;
     reason = H.reason;
     if (H.exhausted) reason = KB_REASON_INTERNAL;
@@ -1383,7 +1382,7 @@ void kb_launch_commit(const KbDev &d, const KbRound &r, void *stream) {
     env_batch = b ? (uint32_t)atoi(b) : 0;
     attr_set = true;
   }
-  uint32_t batch = env_batch ? env_batch : (r.batch ? r.batch : K7_B);
+  uint32_t batch = env_batch ? env_batch : (r.batch ? r.batch : K7_B_DEFAULT);
   if (batch > K7_B) batch = K7_B;
   const size_t sh = k7_smem_bytes(r.cap, d.NP, d.R);
   K7KernArgs ka;
