@@ -98,6 +98,8 @@ struct KbRound {
   uint32_t *result;            // [8]: n_done, reason, n_dirty, list_exhausted (live rescans), window_refills
   int backfill;                // commit semantics of backfill.go (first node passing the predicates, no score)
   uint32_t batch;              // rows the commit kernel speculates per batch (0 = default)
+  unsigned long long *host_out;   // see KbCommitArgs
+  unsigned long long seq;
   double *delta;               // optional per-node committed deltas of owned rows [NP*(2R+3)] (multi-GPU), may be nullptr
   uint32_t own_row0, own_row1;
 };
@@ -118,7 +120,16 @@ struct KbCommitArgs {
   uint32_t use_crow, has_delta;
   int R;
   uint32_t batch;   // rows speculated per batch (<= 16)
+  unsigned long long *host_out;   // pinned host mirror of the output block (fast rounds), or nullptr
+  unsigned long long seq;         // sequence number published last into host_out[KB_OUT_SEQ]
 };
+
+// Output block of a round, 8-byte words: [0..3] eight 32-bit result words, [4] divergence counter of kb_apply_deltas,
+// [8..11] wall-clock stamps (round start, candidate lists start, commit start, commit end), [12] sequence number,
+// [16..] decision records.
+#define KB_OUT_STAMP0 8u
+#define KB_OUT_SEQ 12u
+#define KB_OUT_HDR 16u
 
 #define KB_K5_MAX_WINDOW 1024u   // dirty-node table + row descriptors of the commit kernel live in LDS: 152 B per row
 

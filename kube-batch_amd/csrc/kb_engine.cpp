@@ -61,6 +61,7 @@ struct DevBuf {
 template <typename T> struct Pinned {
   T *p = nullptr;
   size_t n = 0;
+  unsigned flags = hipHostMallocDefault;
   Pinned() = default;
   Pinned(const Pinned &) = delete;
   Pinned &operator=(const Pinned &) = delete;
@@ -68,7 +69,7 @@ template <typename T> struct Pinned {
   void resize(size_t m) {
     if (m <= n) return;
     T *q = nullptr;
-    HIP_OK(hipHostMalloc((void **)&q, sizeof(T) * m, hipHostMallocDefault));
+    HIP_OK(hipHostMalloc((void **)&q, sizeof(T) * m, flags));
     if (p) { std::memcpy(q, p, sizeof(T) * n); (void)hipHostFree(p); }
     p = q;
     n = m;
@@ -146,7 +147,11 @@ struct kb_engine {
   Pinned<uint32_t> h_rows, h_slot, h_mrows;
   std::vector<uint32_t> h_decnode, h_deckind;
   Pinned<uint32_t> h_win;             // per-round upload  [rows | slots | mrows] at fixed offsets of KB_K5_MAX_WINDOW
-  Pinned<unsigned long long> h_out;   // per-round download: 64-byte header (result words) + decision records
+  Pinned<unsigned long long> h_out;   // per-round download: KB_OUT_HDR header words (kb_device.h) + decision records
+  unsigned long long *d_hout = nullptr;   // device view of h_out (fast rounds: the commit kernel writes it directly)
+  bool fast_rounds = true;            // host spins on h_out[KB_OUT_SEQ] instead of synchronising the stream every round
+  unsigned long long seq = 0;
+  double wall_khz = 100000.0;         // rate of the device's constant wall clock
   std::vector<uint8_t> h_same;
   std::vector<uint32_t> shape_stamp, shape_slot_of;   // per row-shape id: round stamp and slot inside the current round
   uint32_t stamp = 0;
@@ -306,8 +311,10 @@ KbRound make_round(kb_engine *e, uint32_t n_rows, uint32_t n_mrows, uint32_t L, 
   r.maskw = e->b_maskw.as<uint32_t>();
   r.keys = e->b_keys.as<unsigned long long>();
   r.L = L;
-  r.dec = e->b_out.as<unsigned long long>() + 8;   // 64-byte header (result words), then the decision records
+  r.dec = e->b_out.as<unsigned long long>() + KB_OUT_HDR;   // header words, then the decision records
   r.result = e->b_out.as<uint32_t>();
+  r.host_out = nullptr;
+  r.seq = 0;
   r.backfill = backfill ? 1 : 0;
   r.batch = e->commit_batch;
   r.delta = nullptr;
@@ -375,13 +382,18 @@ void round_candidates(kb_engine *e, const RoundCtx &c, uint32_t m0, uint32_t m1,
   r.mrows = e->b_win.as<uint32_t>() + 2 * KB_K5_MAX_WINDOW + m0;
   r.n_mrows = m1 - m0;
   r.keys = keys;
-  Timer &t1 = get_timer(e, 0), &t3 = get_timer(e, 1);
-  HIP_OK(hipEventRecord(t1.a, e->stream));
-  kb_launch_matrix(c.d, r, e->stream);
-  HIP_OK(hipEventRecord(t1.b, e->stream));
-  HIP_OK(hipEventRecord(t3.a, e->stream));
-  kb_launch_argmax(c.d, r, e->stream);
-  HIP_OK(hipEventRecord(t3.b, e->stream));
+  if (e->fast_rounds) {   // kernel times come from the wall-clock stamps the kernels leave in the output block
+    kb_launch_matrix(c.d, r, e->stream);
+    kb_launch_argmax(c.d, r, e->stream);
+  } else {
+    Timer &t1 = get_timer(e, 0), &t3 = get_timer(e, 1);
+    HIP_OK(hipEventRecord(t1.a, e->stream));
+    kb_launch_matrix(c.d, r, e->stream);
+    HIP_OK(hipEventRecord(t1.b, e->stream));
+    HIP_OK(hipEventRecord(t3.a, e->stream));
+    kb_launch_argmax(c.d, r, e->stream);
+    HIP_OK(hipEventRecord(t3.b, e->stream));
+  }
   e->stats.matrix_launches += 1;
   e->stats.matrix_evals += (uint64_t)(m1 - m0) * e->hs.N;
 }
@@ -393,30 +405,58 @@ void round_commit(kb_engine *e, const RoundCtx &c, unsigned long long *keys, dou
   r.delta = delta;
   r.own_row0 = own0;
   r.own_row1 = own1;
+  if (e->fast_rounds) {
+    r.host_out = e->d_hout;
+    r.seq = ++e->seq;
+    kb_launch_commit(c.d, r, e->stream);
+    return;
+  }
   Timer &t5 = get_timer(e, 2);
   HIP_OK(hipEventRecord(t5.a, e->stream));
   kb_launch_commit(c.d, r, e->stream);
   HIP_OK(hipEventRecord(t5.b, e->stream));
-  HIP_OK(hipMemcpyAsync(e->h_out.data(), e->b_out.p, 64 + sizeof(unsigned long long) * c.n, hipMemcpyDeviceToHost, e->stream));
+  HIP_OK(hipMemcpyAsync(e->h_out.data(), e->b_out.p, sizeof(unsigned long long) * (KB_OUT_HDR + c.n), hipMemcpyDeviceToHost, e->stream));
 }
 
 // wait for the round, account the kernel times, unpack the decision records
 void round_collect(kb_engine *e, const RoundCtx &c, bool had_candidates, uint32_t &n_done, uint32_t &reason) {
-  HIP_OK(hipStreamSynchronize(e->stream));
-  HIP_OK(hipGetLastError());
+  if (e->fast_rounds) {
+    // the commit kernel publishes the round's sequence number into pinned host memory after everything else
+    volatile unsigned long long *seqw = e->h_out.data() + KB_OUT_SEQ;
+    const double t0 = now_ms();
+    uint32_t spins = 0;
+    while (__atomic_load_n(seqw, __ATOMIC_ACQUIRE) != e->seq) {
+      __builtin_ia32_pause();
+      if ((++spins & 0xFFFFu) == 0 && now_ms() - t0 > 10000.0) {   // a faulted kernel never publishes: surface the HIP error
+        HIP_OK(hipStreamSynchronize(e->stream));
+        HIP_OK(hipGetLastError());
+        if (__atomic_load_n(seqw, __ATOMIC_ACQUIRE) != e->seq) throw EngineError(KB_E_DEVICE, "commit kernel finished without publishing its round");
+      }
+    }
+    const unsigned long long *st = e->h_out.data() + KB_OUT_STAMP0;
+    const double per_ms = 1.0 / e->wall_khz;
+    if (had_candidates) {
+      e->stats.matrix_ms += (double)(st[1] - st[0]) * per_ms;   // includes the descriptor gather
+      e->stats.argmax_ms += (double)(st[2] - st[1]) * per_ms;
+    }
+    e->stats.commit_ms += (double)(st[3] - st[2]) * per_ms;
+  } else {
+    HIP_OK(hipStreamSynchronize(e->stream));
+    HIP_OK(hipGetLastError());
+    float ms = 0;
+    if (had_candidates) {
+      HIP_OK(hipEventElapsedTime(&ms, get_timer(e, 0).a, get_timer(e, 0).b));
+      e->stats.matrix_ms += ms;
+      HIP_OK(hipEventElapsedTime(&ms, get_timer(e, 1).a, get_timer(e, 1).b));
+      e->stats.argmax_ms += ms;
+    }
+    HIP_OK(hipEventElapsedTime(&ms, get_timer(e, 2).a, get_timer(e, 2).b));
+    e->stats.commit_ms += ms;
+  }
   for (uint32_t i = 0; i < c.n; i++) {
-    e->h_decnode[i] = (uint32_t)(e->h_out[8 + i] & 0xFFFFFFFFull);
-    e->h_deckind[i] = (uint32_t)(e->h_out[8 + i] >> 32);
+    e->h_decnode[i] = (uint32_t)(e->h_out[KB_OUT_HDR + i] & 0xFFFFFFFFull);
+    e->h_deckind[i] = (uint32_t)(e->h_out[KB_OUT_HDR + i] >> 32);
   }
-  float ms = 0;
-  if (had_candidates) {
-    HIP_OK(hipEventElapsedTime(&ms, get_timer(e, 0).a, get_timer(e, 0).b));
-    e->stats.matrix_ms += ms;
-    HIP_OK(hipEventElapsedTime(&ms, get_timer(e, 1).a, get_timer(e, 1).b));
-    e->stats.argmax_ms += ms;
-  }
-  HIP_OK(hipEventElapsedTime(&ms, get_timer(e, 2).a, get_timer(e, 2).b));
-  e->stats.commit_ms += ms;
   n_done = e->h_result[0];
   reason = e->h_result[1];
   if (reason == KB_REASON_INTERNAL) throw EngineError(KB_E_INTERNAL, "commit kernel ran out of candidate list entries (list shorter than the window)");
@@ -654,9 +694,19 @@ int kb_engine_create(const kb_config *cfg, kb_engine **out) {
     HIP_OK(hipStreamCreateWithFlags(&eng->stream, hipStreamNonBlocking));
     eng->b_win.alloc(sizeof(uint32_t) * 3 * KB_K5_MAX_WINDOW);
     eng->h_win.resize(3 * KB_K5_MAX_WINDOW);
-    eng->b_out.alloc(64 + sizeof(unsigned long long) * KB_K5_MAX_WINDOW);
-    eng->h_out.resize(8 + KB_K5_MAX_WINDOW);
+    eng->b_out.alloc(sizeof(unsigned long long) * (KB_OUT_HDR + KB_K5_MAX_WINDOW));
+    HIP_OK(hipMemset(eng->b_out.p, 0, eng->b_out.bytes));
+    eng->h_out.flags = hipHostMallocMapped | hipHostMallocCoherent;   // written by the commit kernel while the host polls
+    eng->h_out.resize(KB_OUT_HDR + KB_K5_MAX_WINDOW);
+    std::memset(eng->h_out.data(), 0, sizeof(unsigned long long) * (KB_OUT_HDR + KB_K5_MAX_WINDOW));
     eng->h_result = reinterpret_cast<uint32_t *>(eng->h_out.data());
+    HIP_OK(hipHostGetDevicePointer((void **)&eng->d_hout, eng->h_out.data(), 0));
+    {
+      int khz = 0;
+      if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, eng->device) == hipSuccess && khz > 0) eng->wall_khz = (double)khz;
+      const char *sr = getenv("KB_SYNC_ROUNDS");
+      eng->fast_rounds = !(eng->flags & KB_FLAG_SYNC_ROUNDS) && !(sr && sr[0] == '1');
+    }
     if (const char *tr = getenv("KB_K5_TRACE")) {
       if (tr[0] == '1') { eng->trace_on = true; eng->b_trace.alloc(sizeof(unsigned long long) * 64); HIP_OK(hipMemset(eng->b_trace.p, 0, sizeof(unsigned long long) * 64)); }
     }
@@ -1265,7 +1315,7 @@ int kb_round_apply(kb_engine *e, uint64_t dev_delta_ptr, uint32_t *done) {
     if (dev_delta_ptr) {
       // node state for the next round = round-start state + all-reduced deltas; it must equal this replica's own commit
       uint32_t mism = kb_apply_deltas(e->dev, m.s_idle.as<double>(), m.s_rel.as<double>(), m.s_nzc.as<long long>(), m.s_nzm.as<long long>(),
-                                      m.s_podcnt.as<int>(), reinterpret_cast<const double *>(dev_delta_ptr), e->b_out.as<uint32_t>() + 8, e->stream);
+                                      m.s_podcnt.as<int>(), reinterpret_cast<const double *>(dev_delta_ptr), e->b_out.as<uint32_t>() + 8, e->stream);   // word [4] of the output block
       if (mism) throw EngineError(KB_E_INTERNAL, "replicas diverged: reduced per-node deltas differ from the local commit at " + std::to_string(mism) + " values");
     }
     m.run.absorb(e, m.ctx.n, m.n_done, m.reason);

@@ -339,6 +339,8 @@ __global__ void __launch_bounds__(256) k_argmax(KbDev d, KbRound r) {
   __shared__ uint32_t s_wcnt[4][2];
   const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const uint32_t row = blockIdx.x;
+  if (row == 0 && tid == 0 && r.mrow_task0 == 0 && r.mrows != nullptr)   // round launches only (not kb_eval_matrix's expanded rows)
+    reinterpret_cast<unsigned long long *>(r.result)[KB_OUT_STAMP0 + 1] = wall_clock64();
   const uint32_t K = r.L;
   unsigned long long *out = r.keys + (size_t)row * K;
   const uint32_t per8 = d.NP / (256 * 8);    // 8-node chunks per thread (NP is a multiple of 2048)
@@ -448,6 +450,7 @@ __device__ __forceinline__ bool bit_test(const uint32_t *bm, uint32_t n) { retur
 // window rows -> contiguous descriptors
 __global__ void __launch_bounds__(256) k_gather(KbDev d, KbRound r) {
   uint32_t i = blockIdx.x * 256 + threadIdx.x;
+  if (i == 0) reinterpret_cast<unsigned long long *>(r.result)[KB_OUT_STAMP0] = wall_clock64();   // round start (constant-rate clock)
   if (i >= r.n_rows) return;
   uint32_t t = r.rows[i];
   KbRowDesc k;
@@ -761,6 +764,7 @@ __global__ void __launch_bounds__(KB_K5_THREADS) k_commit(const K7KernArgs ka) {
   }
   K7Hdr &H = *M.H;
   const int RS = a.R > 2 ? a.R - 2 : 0;
+  const unsigned long long t_start = wall_clock64();
 #ifdef KB_K5_TRACE
   unsigned long long tacc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tlast = __builtin_readcyclecounter();
 #endif
@@ -1239,11 +1243,25 @@ __global__ void __launch_bounds__(KB_K5_THREADS) k_commit(const K7KernArgs ka) {
     }
   }
   if (tid == 0) {
-    a.result[0] = n_done; a.result[1] = reason; a.result[2] = nd; a.result[3] = 0; a.result[4] = H.n_refills; a.result[7] = H.n_full; a.result[3] = H.n_seq_rows;
+    a.result[0] = n_done; a.result[1] = reason; a.result[2] = nd; a.result[4] = H.n_refills; a.result[7] = H.n_full; a.result[3] = H.n_seq_rows;
     a.result[5] = H.n_batches; a.result[6] = H.n_dirty_rows;
+    unsigned long long *st = reinterpret_cast<unsigned long long *>(a.result) + KB_OUT_STAMP0;
+    st[2] = t_start;
+    st[3] = wall_clock64();
 #ifdef KB_K5_TRACE
     if (a.trace) { for (int k = 0; k < 12; k++) a.trace[k] = tacc[k]; a.trace[12] = H.pad2; a.trace[13] = H.pad3; }
 #endif
+  }
+  // ---- fast rounds: mirror the header and the decision records into pinned host memory and publish the round's sequence
+  //      number last; the host spins on that word instead of paying a stream synchronisation + D2H copy per round
+  if (a.host_out) {
+    __syncthreads();
+    const unsigned long long *hdr = reinterpret_cast<const unsigned long long *>(a.result);
+    for (uint32_t i = tid; i < KB_OUT_SEQ; i += KB_K5_THREADS) a.host_out[i] = hdr[i];
+    for (uint32_t i = tid; i < n_done; i += KB_K5_THREADS) a.host_out[KB_OUT_HDR + i] = a.dec[i];
+    __threadfence_system();
+    __syncthreads();
+    if (tid == 0) __hip_atomic_store(&a.host_out[KB_OUT_SEQ], a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
   }
 }
 
@@ -1398,6 +1416,8 @@ void kb_launch_commit(const KbDev &d, const KbRound &r, void *stream) {
   a.has_delta = r.delta != nullptr ? 1u : 0u;
   a.R = d.R;
   a.batch = batch;
+  a.host_out = r.host_out;
+  a.seq = r.seq;
   hipLaunchKernelGGL(k_commit, dim3(1), dim3(KB_K5_THREADS), sh, (hipStream_t)stream, ka);
 }
 void kb_launch_finalize(const KbDev &d, const uint32_t *job_task_begin, const int *job_min_avail, const uint32_t *job_queue,
