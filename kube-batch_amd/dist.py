@@ -81,6 +81,12 @@ class ShardedCycle:
         # shard a round's matrix rows only when every rank gets at least this many (0 = always shard)
         self.min_rows_per_rank = min_rows_per_rank
 
+    def _sync_torch(self):
+        """The engine runs on its own non-blocking HIP stream: torch's fill kernels must have finished before the engine
+        writes into a freshly zeroed buffer."""
+        if self.buf_dev.type == "cuda":
+            torch.cuda.current_stream().synchronize()
+
     # ---- collectives
     def _all_gather_keys(self, local: torch.Tensor, chunk: int, L: int) -> torch.Tensor:
         full = torch.empty((chunk * self.world, L), dtype=torch.int64, device=local.device)
@@ -124,6 +130,7 @@ class ShardedCycle:
                 # collective + its synchronisation tens of us): every rank evaluates all rows, no all-gather this round.
                 # The decision depends on n_mrows only, which is identical on every rank.
                 table = torch.zeros((n_mrows, L), dtype=torch.int64, device=self.buf_dev)
+                self._sync_torch()
                 b.candidates(0, n_mrows, table)
                 self.replicated_rounds += 1
             else:
@@ -131,6 +138,7 @@ class ShardedCycle:
                 m0 = min(self.rank * chunk, n_mrows)
                 m1 = min(m0 + chunk, n_mrows)
                 local = torch.zeros((chunk, L), dtype=torch.int64, device=self.buf_dev)
+                self._sync_torch()
                 b.candidates(m0, m1, local)
                 table = self._all_gather_keys(local, chunk, L)
             # the gathered table is [world*chunk][L]; matrix row m lives at row m because shards are contiguous and equal
