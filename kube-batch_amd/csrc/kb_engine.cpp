@@ -3,8 +3,8 @@
 // Round structure: the host order machine speculates the reference's task order for a window of W
 // tasks (assuming each gets a node, which only ever fails when a whole feasibility class has died — and that is
 // monotone inside one action), the device evaluates the window's mask+score matrix against the round-start node
-// state (K1), extracts per-row top-K candidates (K3) and commits the window sequentially with dirty-column repair
-// (K5).  A mis-speculation (no feasible node / Pipeline instead of Allocate) stops the commit kernel at that row;
+// state (K1, once per distinct task shape), builds each shape's sorted candidate list (K3) and commits the window in the
+// reference's order, speculating 16-32 rows at a time against the dirty nodes (K5).  A mis-speculation (no feasible node / Pipeline instead of Allocate) stops the commit kernel at that row;
 // the host rolls the order machine back to the round start, replays the confirmed prefix and re-plans.
 #include <hip/hip_runtime.h>
 
@@ -127,7 +127,7 @@ struct kb_engine {
 
   // session buffers
   DevBuf b_idle, b_rel, b_nzc, b_nzm, b_podcnt, b_acpu, b_amem, b_maxpods, b_ncls, b_nmask, b_invac, b_invam;
-  uint64_t stage_hits = 0, stage_misses = 0;   // commit kernel: clean winners whose state was staged by the loader / fetched synchronously
+  uint64_t stage_hits = 0, stage_misses = 0;   // commit kernel: batches / dirty rows (KB_K5_STATS)
   unsigned long long full_evals = 0;
   uint32_t eff_window = 0;   // window actually used for this session (bounded by the commit kernel's LDS budget)
   DevBuf b_tinit, b_tres, b_tnzc, b_tnzm, b_tcls, b_tactive, b_tresmask, b_tjob, b_tstatus, b_tnode, b_tbind, b_tcounted, b_compat, b_crows;

@@ -5,11 +5,12 @@
 //                    static checks as a class bit table) + nodeorder's LeastRequested / MostRequested /
 //                    BalancedResourceAllocation (vendor/k8s.io/kubernetes/pkg/scheduler/algorithm/priorities/*.go)
 //                    summed as util.PrioritizeNodes does (scheduler_helper.go:162-168).
-//   K3 k_argmax    segmented per-row top-K arg-max = util.SelectBestNode (scheduler_helper.go:188-208), first max in
-//                  ascending node order, generalised to K candidates.
-//   K5 k_commit    the sequential part of allocate.go:129-193 / backfill.go:44-67: for each row in reference order pick the
-//                  best node among the clean columns (from K3 / the stored row) and the re-evaluated dirty columns, then
-//                  apply NodeInfo.AddTask accounting (api/node_info.go:161-212).
+//   K3 k_argmax    per matrix row, the first K entries of (score descending, node ascending) = util.SelectBestNode
+//                  (scheduler_helper.go:188-208, first max in ascending node order) generalised to a sorted candidate list
+//                  (also the order util.SortNodes gives preempt, scheduler_helper.go:174-185).
+//   K5 k_commit    the sequential part of allocate.go:129-193 / backfill.go:44-67: for each row in reference order the best
+//                  node among the clean columns (next untouched entry of the shape's list) and the re-evaluated dirty
+//                  columns, then NodeInfo.AddTask accounting (api/node_info.go:161-212); 16-32 rows speculated per batch.
 //   K2+K4 k_finalize   gang ready count by wavefront ballot (api/job_info.go:383-394, gang.go:122-125), gang-gated bind
 //                  set (framework/session.go:277-285), drf / proportion share reduction (drf.go:157-171,
 //                  proportion.go:241-253, api/helpers/helpers.go:47-60).
