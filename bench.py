@@ -163,13 +163,18 @@ def main():
         "config": {"workload": f"BASELINE configs[{args.config - 1}]: {snap.n_tasks} tasks x {snap.n_nodes} nodes, "
                                f"{snap.n_jobs} gang jobs, {snap.n_queues} queues, R={R}, allocate+backfill, "
                                "plugins priority,gang,drf,predicates,proportion,nodeorder",
-                   "window": args.window or 512, "scale": args.scale},
+                   "window": args.window or 256, "scale": args.scale},
         "binds_per_s": n_binds * args.steps / elapsed, "binds": n_binds, "decisions": int(d["decisions"] / args.steps),
         "evals_per_step": int(evals / args.steps),
         "kernel_ms_per_step": {k: round(d[k] / args.steps, 3) for k in ("matrix_ms", "argmax_ms", "commit_ms", "reduce_ms", "host_order_ms", "total_ms")},
         "rounds_per_step": d["rounds"] / args.steps, "spec_breaks_per_step": d["spec_breaks"] / args.steps,
         "row_fallbacks_per_step": d["row_fallbacks"] / args.steps,
         "roofline": roofline, "roofline_cycle": roofline_cycle,
+        # SURVEY.md §8d accounting (S): the reference's own dataflow streams B_node(R) bytes per evaluation (every popped task
+        # against every node's live state).  The engine never moves those bytes (shape dedup + dirty-node repair); this is the
+        # end-to-end rate expressed in that currency, for comparison with the 8 TB/s a streaming pass would be bound by.
+        "streaming_equivalent": {"bytes_per_eval": b_node, "equivalent_GBps": round(value * b_node / 1e9, 1),
+                                 "frac_of_hbm_peak": round(value * b_node / 1e9 / HBM_PEAK_GBS, 4)},
         # not part of `value`: kb_session_load of the same snapshot (validation, shape interning, proportion water-fill, H2D)
         "session_load_ms": None if load_ms is None else round(load_ms, 2),
         "evals_per_s_including_session_load": None if load_ms is None else evals / args.steps / (elapsed / args.steps + load_ms * 1e-3),

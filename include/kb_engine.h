@@ -121,7 +121,7 @@ typedef struct kb_config {
   const uint32_t *tier_begin;      /* [n_tiers+1] offsets into plugins[] */
   const kb_plugin_option *plugins;
   int32_t  device;                 /* HIP device ordinal */
-  uint32_t window;                 /* task rows per device round (<= 1024); 0 = engine default (512) */
+  uint32_t window;                 /* task rows per device round (<= 1024); 0 = engine default (256) */
   uint32_t commit_batch;           /* rows the commit kernel speculates per batch, 1..16 (doubled after a fully valid batch); 0 = default (16) */
   uint32_t flags;                  /* KB_FLAG_* */
 } kb_config;

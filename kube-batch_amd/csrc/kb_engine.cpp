@@ -116,7 +116,7 @@ static void mg_free(MgState *m);
 struct kb_engine {
   std::string err;
   int device = 0;
-  uint32_t window = 512, commit_batch = 0, flags = 0;   // 512: measured optimum on the 100k x 10k snapshot (dirty set stays small)
+  uint32_t window = 256, commit_batch = 0, flags = 0;   // 256: measured optimum on the 100k x 10k snapshots (small dirty sets vs per-round cost)
   Policy pol;
   hipStream_t stream = nullptr;
   bool loaded = false;

@@ -331,30 +331,33 @@ __device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v) {
 // below that band; one packed scan turns the counts into output positions; one more pass scatters.  With the default
 // weights the first band already holds more than a window's worth of nodes.  WIDE (rows of 65536 nodes or more, where a
 // 16-bit counter could overflow): two score values per band, one full word each.
-template <bool WIDE>
-__global__ void __launch_bounds__(256) k_argmax(KbDev d, KbRound r) {
+template <bool WIDE, int THREADS>
+__global__ void __launch_bounds__(THREADS) k_argmax(KbDev d, KbRound r) {
+  constexpr int WAVES = THREADS / 64;
   extern __shared__ __align__(16) unsigned char k3_smem[];
   uint16_t *ls = reinterpret_cast<uint16_t *>(k3_smem);                        // [NP] scores
   uint8_t *lm = reinterpret_cast<uint8_t *>(k3_smem) + (size_t)d.NP * 2;      // [NP/8] mask bytes
-  __shared__ int s_wmax[4];
-  __shared__ uint32_t s_wcnt[4][2];
+  __shared__ int s_wmax[WAVES];
+  __shared__ uint32_t s_wcnt[WAVES][2];
   const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const uint32_t row = blockIdx.x;
   if (row == 0 && tid == 0 && r.mrow_task0 == 0 && r.mrows != nullptr)   // round launches only (not kb_eval_matrix's expanded rows)
     reinterpret_cast<unsigned long long *>(r.result)[KB_OUT_STAMP0 + 1] = wall_clock64();
   const uint32_t K = r.L;
   unsigned long long *out = r.keys + (size_t)row * K;
-  const uint32_t per8 = d.NP / (256 * 8);    // 8-node chunks per thread (NP is a multiple of 2048)
-  const uint32_t cbase = tid * per8;         // consecutive chunks: thread order == node order
+  // contiguous, balanced ranges of 8-node chunks: thread order == node order (NP/8 need not be a multiple of THREADS)
+  const uint32_t nchunks = d.NP / 8;
+  const uint32_t cbase = (uint32_t)(((unsigned long long)tid * nchunks) / THREADS);
+  const uint32_t per8 = (uint32_t)(((unsigned long long)(tid + 1) * nchunks) / THREADS) - cbase;
   const uint4 *ls4 = reinterpret_cast<const uint4 *>(ls);
   int top = -1;
   {
     const uint4 *src = reinterpret_cast<const uint4 *>(r.score + (size_t)row * d.NP);
     uint4 *dst = reinterpret_cast<uint4 *>(ls);
-    for (uint32_t c = tid; c < d.NP / 8; c += 256) dst[c] = src[c];
+    for (uint32_t c = tid; c < d.NP / 8; c += THREADS) dst[c] = src[c];
     const uint32_t *msrc = r.maskw + (size_t)row * (d.NP / 32);
     uint32_t *mdst = reinterpret_cast<uint32_t *>(lm);
-    for (uint32_t c = tid; c < d.NP / 32; c += 256) mdst[c] = msrc[c];
+    for (uint32_t c = tid; c < d.NP / 32; c += THREADS) mdst[c] = msrc[c];
   }
   __syncthreads();
   for (uint32_t c = 0; c < per8; c++) {   // best score of the row
@@ -370,7 +373,9 @@ __global__ void __launch_bounds__(256) k_argmax(KbDev d, KbRound r) {
   top = wave_max_i32_dpp(top);
   if (lane == 0) s_wmax[wave] = top;
   __syncthreads();
-  top = max(max(s_wmax[0], s_wmax[1]), max(s_wmax[2], s_wmax[3]));
+  top = s_wmax[0];
+#pragma unroll
+  for (int w2 = 1; w2 < WAVES; w2++) top = max(top, s_wmax[w2]);
   uint32_t found = 0;
   while (top >= 0 && found < K) {
     __syncthreads();   // s_wmax / s_wcnt are reused
@@ -405,12 +410,14 @@ __global__ void __launch_bounds__(256) k_argmax(KbDev d, KbRound r) {
     __syncthreads();
     uint32_t off01 = 0, off23 = 0, tot01 = 0, tot23 = 0;
 #pragma unroll
-    for (int w2 = 0; w2 < 4; w2++) {
+    for (int w2 = 0; w2 < WAVES; w2++) {
       if (w2 < (int)wave) { off01 += s_wcnt[w2][0]; off23 += s_wcnt[w2][1]; }
       tot01 += s_wcnt[w2][0];
       tot23 += s_wcnt[w2][1];
     }
-    below = max(max(s_wmax[0], s_wmax[1]), max(s_wmax[2], s_wmax[3]));
+    below = s_wmax[0];
+#pragma unroll
+    for (int w2 = 1; w2 < WAVES; w2++) below = max(below, s_wmax[w2]);
     // first output position of this thread's nodes at each score of the band
     const uint32_t e01 = off01 + p01 - c01, e23 = off23 + p23 - c23;
     uint32_t t0, t1, t2, t3, pos[4];
@@ -442,7 +449,7 @@ __global__ void __launch_bounds__(256) k_argmax(KbDev d, KbRound r) {
     top = below;
   }
   if (found > K) found = K;
-  for (uint32_t i = found + tid; i < K; i += 256) out[i] = 0ull;
+  for (uint32_t i = found + tid; i < K; i += THREADS) out[i] = 0ull;
 }
 
 __device__ __forceinline__ bool bit_test(const uint32_t *bm, uint32_t n) { return (bm[n >> 5] >> (n & 31)) & 1u; }
@@ -1384,12 +1391,17 @@ void kb_launch_argmax(const KbDev &d, const KbRound &r, void *stream) {
   size_t sh = (size_t)d.NP * 2 + d.NP / 8;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_argmax<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_argmax<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_argmax<false, 256>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_argmax<false, 1024>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_argmax<true, 1024>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
     attr_set = true;
   }
-  if (d.NP < 65536u) hipLaunchKernelGGL(k_argmax<false>, dim3(r.n_mrows), dim3(256), sh, (hipStream_t)stream, d, r);
-  else hipLaunchKernelGGL(k_argmax<true>, dim3(r.n_mrows), dim3(256), sh, (hipStream_t)stream, d, r);
+  hipStream_t st = (hipStream_t)stream;
+  // few rows (a round's distinct shapes): the launch is latency-sized, 1024 threads shorten every pass over the row; many rows
+  // (kb_argmax_rows over whole task ranges): 256 threads keep more rows resident per CU
+  if (d.NP >= 65536u) hipLaunchKernelGGL((k_argmax<true, 1024>), dim3(r.n_mrows), dim3(1024), sh, st, d, r);
+  else if (r.n_mrows <= 512) hipLaunchKernelGGL((k_argmax<false, 1024>), dim3(r.n_mrows), dim3(1024), sh, st, d, r);
+  else hipLaunchKernelGGL((k_argmax<false, 256>), dim3(r.n_mrows), dim3(256), sh, st, d, r);
 }
 void kb_launch_commit(const KbDev &d, const KbRound &r, void *stream) {
   if (r.n_rows == 0) return;
