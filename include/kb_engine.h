@@ -57,7 +57,7 @@
 extern "C" {
 #endif
 
-#define KB_ABI_VERSION 1u
+#define KB_ABI_VERSION 2u
 #define KB_MAX_RES 32u          /* resource dimensions: 0 = cpu (milli), 1 = memory (bytes), 2.. = scalar resources (milli) */
 #define KB_NONE 0xFFFFFFFFu
 
@@ -176,6 +176,12 @@ typedef struct kb_snapshot {
   /* static predicates p2..p7 folded to a class x class bit table:
      bit (tc * n_node_classes + nc) of class_compat; NULL => every pair compatible */
   const uint8_t  *class_compat;
+
+  /* preferred node affinity (nodeorder's NodeAffinity priority, vendor/.../priorities/node_affinity.go:34-77): the Map
+     step's count for (task class tc, node class nc) = sum of the weights of the pod's preferred scheduling terms whose
+     match expressions select the node's labels; [n_task_classes][n_node_classes], NULL => no pod has preferred terms.
+     The engine applies NormalizeReduce(10) over the task's feasible nodes (reduce.go:28-63) and the plugin weight. */
+  const int32_t  *class_affinity;
 } kb_snapshot;
 
 /* one placement decision, in the order the reference loop would have made it */

@@ -23,6 +23,7 @@ import (
 
 	v1 "k8s.io/api/core/v1"
 	"k8s.io/kubernetes/pkg/scheduler/algorithm/predicates"
+	"k8s.io/kubernetes/pkg/scheduler/algorithm/priorities"
 	priorityutil "k8s.io/kubernetes/pkg/scheduler/algorithm/priorities/util"
 	"k8s.io/kubernetes/pkg/scheduler/nodeinfo"
 
@@ -139,9 +140,6 @@ func taskClassKey(t *api.TaskInfo) (string, error) {
 	if sp.Affinity != nil && (sp.Affinity.PodAffinity != nil || sp.Affinity.PodAntiAffinity != nil) {
 		return "", errUnsupported("inter-pod (anti)affinity")
 	}
-	if sp.Affinity != nil && sp.Affinity.NodeAffinity != nil && len(sp.Affinity.NodeAffinity.PreferredDuringSchedulingIgnoredDuringExecution) > 0 {
-		return "", errUnsupported("preferred node affinity (per-row score normalisation)")
-	}
 	for i := range sp.Containers {
 		for _, p := range sp.Containers[i].Ports {
 			if p.HostPort != 0 {
@@ -150,6 +148,19 @@ func taskClassKey(t *api.TaskInfo) (string, error) {
 		}
 	}
 	return fmt.Sprintf("%v|%v|%v", sp.NodeSelector, sp.Affinity, sp.Tolerations), nil
+}
+
+// NodeAffinity priority, Map step, for one (task class, node class) pair: the vendored function itself
+// (vendor/k8s.io/kubernetes/pkg/scheduler/algorithm/priorities/node_affinity.go:34-77); the engine applies NormalizeReduce(10)
+// over each task's feasible nodes and the plugin weight
+func affinityCount(t *api.TaskInfo, n *api.NodeInfo) int32 {
+	ni := nodeinfo.NewNodeInfo()
+	ni.SetNode(n.Node)
+	hp, err := priorities.CalculateNodeAffinityPriorityMap(t.Pod, nil, ni)
+	if err != nil {
+		return 0
+	}
+	return int32(hp.Score)
 }
 
 // one (task class, node class) pair through the vendored predicates themselves, the ones
@@ -340,11 +351,17 @@ func flatten(ssn *framework.Session) (*flat, error) {
 	// ---- static predicates once per (task class, node class)
 	ntc, nnc := len(taskClassRep), len(nodeClassRep)
 	compat := f.u8((ntc*nnc + 7) / 8)
+	affinity := f.i32(ntc * nnc)
+	anyAffinity := false
 	for a, tr := range taskClassRep {
 		for b, nr := range nodeClassRep {
 			if staticOK(tr, nr) {
 				bit := a*nnc + b
 				compat[bit>>3] |= 1 << uint(bit&7)
+			}
+			if c := affinityCount(tr, nr); c != 0 {
+				affinity[a*nnc+b] = c
+				anyAffinity = true
 			}
 		}
 	}
@@ -383,5 +400,8 @@ func flatten(ssn *framework.Session) (*flat, error) {
 	s.queue_weight = (*C.int32_t)(unsafe.Pointer(&qweight[0]))
 	s.queue_creation = (*C.int64_t)(unsafe.Pointer(&qcreate[0]))
 	s.class_compat = (*C.uint8_t)(unsafe.Pointer(&compat[0]))
+	if anyAffinity {
+		s.class_affinity = (*C.int32_t)(unsafe.Pointer(&affinity[0]))
+	}
 	return f, nil
 }

@@ -54,7 +54,11 @@ struct KbDev {
   const uint32_t *crows;          // the same table as word-aligned rows [n_tc][8] (bit nc of row tc), nullptr if n_nc > 256 or no table
   uint32_t n_nc;
   // policy
-  int wL, wM, wB;                 // nodeorder weights (least, most, balanced); node/pod affinity contribute 0
+  int wL, wM, wB;                 // nodeorder weights (least, most, balanced); inter-pod affinity contributes 0
+  // preferred node affinity (nodeorder's NodeAffinity config): Map counts per (task class, node class), nullptr if no pod has any
+  const int32_t *aff;             // [n_tc][n_nc]
+  const uint8_t *aff_cls;         // [n_tc] the class's row has a non-zero count
+  int wNA;
   int pred_enabled;               // predicates plugin registered with EnabledPredicate
   int score_enabled;              // nodeorder plugin registered with EnabledNodeOrder
 };
@@ -72,6 +76,7 @@ struct KbRowDesc {          // 56 bytes
   uint32_t task, active, resmask, cls;
   uint16_t slot;           // index of the row's shape among the mrows
   uint16_t flags;          // bit 0: Resreq cpu/memory == InitResreq cpu/memory (no init container raised them)
+                           // bit 1: the task's class has preferred node-affinity terms (score normalised over the feasible set)
   uint32_t crow;           // the task class's row of the static-predicate table (bit nc), valid when n_node_classes <= 32
 };
 
@@ -117,7 +122,7 @@ struct KbCommitArgs {
   unsigned long long *trace;
   uint32_t n_rows, n_mrows, L, cap, N, NP;
   int fit_mode, backfill, pred_enabled, score_enabled, wL, wM, wB;
-  uint32_t use_crow, has_delta;
+  uint32_t use_crow, has_delta, has_aff;
   int R;
   uint32_t batch;   // rows speculated per batch (<= 16)
   unsigned long long *host_out;   // pinned host mirror of the output block (fast rounds), or nullptr
@@ -136,11 +141,15 @@ struct KbCommitArgs {
 // dynamic LDS the commit kernel needs for `cap` slots over NP padded nodes (kb_kernels.hip)
 size_t kb_commit_smem_bytes(uint32_t cap, uint32_t NP, int R);
 
-enum { KB_REASON_DONE = 0, KB_REASON_NO_FEASIBLE = 1, KB_REASON_PIPELINED = 2, KB_REASON_INTERNAL = 3 };
+// KB_REASON_RENORM: the next row's score needs NormalizeReduce over its CURRENT feasible set (preferred node affinity): it is
+// committed as the first row of a fresh round, whose matrix is exact for it
+enum { KB_REASON_DONE = 0, KB_REASON_NO_FEASIBLE = 1, KB_REASON_PIPELINED = 2, KB_REASON_INTERNAL = 3, KB_REASON_RENORM = 4 };
 
 // launch wrappers (kb_kernels.hip); all asynchronous on `stream`
 void kb_launch_gather(const KbDev &d, const KbRound &r, void *stream);
 void kb_launch_matrix(const KbDev &d, const KbRound &r, void *stream);
+// NodeAffinity Map + NormalizeReduce + weight added to the score rows of the matrix (no-op without affinity terms)
+void kb_launch_affinity(const KbDev &d, const KbRound &r, void *stream);
 void kb_launch_argmax(const KbDev &d, const KbRound &r, void *stream);
 // per-task rows out of the per-shape rows (kb_eval_matrix / kb_bench_matrix: the materialised T x N matrix)
 void kb_launch_expand(const KbDev &d, const uint16_t *s_score, const uint32_t *s_mask, const uint32_t *row_slot, uint32_t n_rows,

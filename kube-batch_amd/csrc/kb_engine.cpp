@@ -130,7 +130,7 @@ struct kb_engine {
   uint64_t stage_hits = 0, stage_misses = 0;   // commit kernel: batches / dirty rows (KB_K5_STATS)
   unsigned long long full_evals = 0;
   uint32_t eff_window = 0;   // window actually used for this session (bounded by the commit kernel's LDS budget)
-  DevBuf b_tinit, b_tres, b_tnzc, b_tnzm, b_tcls, b_tactive, b_tresmask, b_tjob, b_tstatus, b_tnode, b_tbind, b_tcounted, b_compat, b_crows;
+  DevBuf b_tinit, b_tres, b_tnzc, b_tnzm, b_tcls, b_tactive, b_tresmask, b_tjob, b_tstatus, b_tnode, b_tbind, b_tcounted, b_compat, b_crows, b_aff, b_affcls;
   DevBuf p_idle, p_rel, p_nzc, p_nzm, p_podcnt, p_tstatus, p_tnode, p_tcounted;   // pristine copies for kb_session_reset
   DevBuf b_jbegin, b_jmin, b_jqueue, b_total, b_deserved, b_desmask, b_jalloc, b_jshare, b_qalloc, b_qshare, b_jready;
   uint32_t total_mask = 0;
@@ -384,11 +384,13 @@ void round_candidates(kb_engine *e, const RoundCtx &c, uint32_t m0, uint32_t m1,
   r.keys = keys;
   if (e->fast_rounds) {   // kernel times come from the wall-clock stamps the kernels leave in the output block
     kb_launch_matrix(c.d, r, e->stream);
+    kb_launch_affinity(c.d, r, e->stream);
     kb_launch_argmax(c.d, r, e->stream);
   } else {
     Timer &t1 = get_timer(e, 0), &t3 = get_timer(e, 1);
     HIP_OK(hipEventRecord(t1.a, e->stream));
     kb_launch_matrix(c.d, r, e->stream);
+    kb_launch_affinity(c.d, r, e->stream);
     HIP_OK(hipEventRecord(t1.b, e->stream));
     HIP_OK(hipEventRecord(t3.a, e->stream));
     kb_launch_argmax(c.d, r, e->stream);
@@ -600,6 +602,13 @@ struct ActionRun {
         if (reason == KB_REASON_NO_FEASIBLE && i == n_done) {
           mark_dead(hs, hs.t_feas_shape[t]);
           om.report(Outcome::NoFeasibleNode);
+          break;
+        }
+        if (reason == KB_REASON_RENORM && i == n_done) {
+          // the device stopped in front of this task (its score must be normalised over a fresh feasible set): nothing was
+          // decided for it; undo the pop so that it heads the next window
+          om.rollback_last_pop();
+          popped--;
           break;
         }
         decs.push_back(kb_decision{t, e->h_decnode[i], e->h_deckind[i], round});
@@ -978,6 +987,32 @@ int kb_session_load(kb_engine *e, const kb_snapshot *sn) {
         d.crows = e->b_crows.as<uint32_t>();
       }
     }
+    d.aff = nullptr;
+    d.aff_cls = nullptr;
+    d.wNA = e->pol.wNA;
+    if (sn->class_affinity && sn->n_task_classes && sn->n_node_classes) {
+      for (uint32_t t = 0; t < T; t++)
+        if (hs.t_cls[t] >= sn->n_task_classes) throw EngineError(KB_E_INVALID, "task class out of range");
+      for (uint32_t n = 0; n < N; n++)
+        if (ncls[n] >= sn->n_node_classes) throw EngineError(KB_E_INVALID, "node class out of range");
+      const size_t na = (size_t)sn->n_task_classes * sn->n_node_classes;
+      std::vector<uint8_t> has(sn->n_task_classes, 0);
+      bool any = false;
+      for (uint32_t tc = 0; tc < sn->n_task_classes; tc++)
+        for (uint32_t nc = 0; nc < sn->n_node_classes; nc++) {
+          const int32_t c = sn->class_affinity[(size_t)tc * sn->n_node_classes + nc];
+          if (c < 0 || c > 100000) throw EngineError(KB_E_UNSUPPORTED, "node-affinity count outside 0..100000");
+          if (c) { has[tc] = 1; any = true; }
+        }
+      if (any && e->pol.wNA != 0) {
+        if (e->pol.wNA < 0 || 10 * (e->pol.wL + e->pol.wM + e->pol.wB + e->pol.wNA) > 65535)
+          throw EngineError(KB_E_UNSUPPORTED, "nodeorder weights exceed the 16-bit score range");
+        upload(e->b_aff, sn->class_affinity, na, s);
+        upload(e->b_affcls, has.data(), has.size(), s);
+        d.aff = e->b_aff.as<int32_t>();
+        d.aff_cls = e->b_affcls.as<uint8_t>();
+      }
+    }
     upload(e->b_jbegin, hs.job_begin.data(), J + 1, s);
     upload(e->b_jmin, hs.job_min.data(), J, s);
     upload(e->b_jqueue, hs.job_queue.data(), J, s);
@@ -1109,6 +1144,7 @@ static ChunkPlan matrix_plan(kb_engine *e, uint32_t t0, uint32_t n, uint32_t fit
 }
 static void matrix_launch(kb_engine *e, const ChunkPlan &p, uint32_t n, uint32_t k) {
   kb_launch_matrix(e->dev, p.rs, e->stream);
+  kb_launch_affinity(e->dev, p.rs, e->stream);
   kb_launch_expand(e->dev, p.rs.score, p.rs.maskw, e->b_xslot.as<uint32_t>(), n, p.r.score, p.r.maskw, e->stream);
   if (k) kb_launch_argmax(e->dev, p.r, e->stream);
 }

@@ -178,6 +178,8 @@ class OrderMachine {
   void report(Outcome o);
   void checkpoint();
   void rollback();
+  // undo the effect of the last next(): the task it returned is handed out again by the following next()
+  void rollback_last_pop() { cursor_[(uint32_t)cur_j_]--; steps--; }
   // running aggregates, compared with the device reduction after the action
   std::vector<double> jalloc, jshare, qalloc, qshare;
   std::vector<int32_t> ready;

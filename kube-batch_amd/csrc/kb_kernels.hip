@@ -467,8 +467,33 @@ __global__ void __launch_bounds__(256) k_gather(KbDev d, KbRound r) {
   k.task = t; k.active = d.t_active[t]; k.resmask = d.t_resmask[t]; k.cls = d.t_cls[t];
   k.slot = (uint16_t)r.shape_slot[i];
   k.flags = (d.t_res[t] == k.init0 && d.t_res[(size_t)d.T + t] == k.init1) ? 1 : 0;
+  if (d.aff_cls && d.aff_cls[k.cls]) k.flags |= 2;
   k.crow = d.crows ? d.crows[(size_t)k.cls * 8] : 0xFFFFFFFFu;
   r.desc[i] = k;
+}
+
+// nodeorder's NodeAffinity priority for the matrix rows whose task class has preferred terms (rare): Map = the class-pair count,
+// Reduce = NormalizeReduce(10) over the row's FEASIBLE nodes (vendor/.../priorities/reduce.go:28-63: max == 0 leaves zeros,
+// else 10 * count / max, integer division), then Score += score * weight (scheduler_helper.go:162-168).  One workgroup per row.
+__global__ void __launch_bounds__(256) k_affinity(KbDev d, KbRound r) {
+  __shared__ int s_max[4];
+  const uint32_t row = blockIdx.x, tid = threadIdx.x;
+  const uint32_t t = r.mrows ? r.mrows[row] : r.mrow_task0 + row;
+  const uint32_t tc = d.t_cls[t];
+  if (!d.aff_cls[tc]) return;   // uniform per block
+  const int32_t *arow = d.aff + (size_t)tc * d.n_nc;
+  const uint32_t *mw = r.maskw + (size_t)row * (d.NP / 32);
+  uint16_t *sc = r.score + (size_t)row * d.NP;
+  int mx = 0;
+  for (uint32_t n = tid; n < d.N; n += 256)
+    if ((mw[n >> 5] >> (n & 31)) & 1u) mx = max(mx, (int)arow[d.ncls[n]]);
+  mx = wave_max_i32(mx);
+  if ((tid & 63) == 0) s_max[tid >> 6] = mx;
+  __syncthreads();
+  mx = max(max(s_max[0], s_max[1]), max(s_max[2], s_max[3]));
+  if (mx == 0) return;
+  for (uint32_t n = tid; n < d.N; n += 256)
+    if ((mw[n >> 5] >> (n & 31)) & 1u) sc[n] = (uint16_t)(sc[n] + (10 * arow[d.ncls[n]] / mx) * d.wNA);
 }
 
 // LDS layout of the commit kernel for slot capacity `cap`:
@@ -821,7 +846,7 @@ __global__ void __launch_bounds__(KB_K5_THREADS) k_commit(const K7KernArgs ka) {
 
   uint32_t i0 = 0, nd = 0, n_done = 0, reason = KB_REASON_DONE, dbase = 0, dcnt = 0, nb_cur = a.batch;
   while (i0 < a.n_rows) {
-    const uint32_t nb = min(nb_cur, a.n_rows - i0);
+    uint32_t nb = min(nb_cur, a.n_rows - i0);
     // ---- stage row descriptors: three batches' worth per refill, so most batches find theirs already in LDS
     if (i0 < dbase || i0 + nb > dbase + dcnt) {
       dbase = i0;
@@ -832,6 +857,15 @@ __global__ void __launch_bounds__(KB_K5_THREADS) k_commit(const K7KernArgs ka) {
       __syncthreads();
     }
     const KbRowDesc *bd = H.dbuf + (i0 - dbase);
+    if (a.has_aff && !a.backfill) {
+      // a row whose score is normalised over its feasible set (preferred node affinity) is exact only against a fresh matrix:
+      // it may be the first row of a round, nothing else; the batch stops in front of it and the round ends there
+      uint32_t ja = nb;
+      for (uint32_t j = (i0 == 0) ? 1u : 0u; j < nb; j++)
+        if (bd[j].flags & 2) { ja = j; break; }
+      if (ja == 0) { reason = KB_REASON_RENORM; n_done = i0; break; }
+      nb = ja;
+    }
     K7_STAMP(1);
     // ---- distinct shapes of the batch (wave 0): q_of[j] = rank of the first row with row j's shape
     if (wave == 0) {
@@ -1381,6 +1415,10 @@ void kb_launch_matrix(const KbDev &d, const KbRound &r, void *stream) {
     hipLaunchKernelGGL((k_matrix<1, 4>), grid, dim3(256), 0, (hipStream_t)stream, d, r);
   }
 }
+void kb_launch_affinity(const KbDev &d, const KbRound &r, void *stream) {
+  if (r.n_mrows == 0 || !d.aff || !d.score_enabled) return;
+  hipLaunchKernelGGL(k_affinity, dim3(r.n_mrows), dim3(256), 0, (hipStream_t)stream, d, r);
+}
 void kb_launch_expand(const KbDev &d, const uint16_t *s_score, const uint32_t *s_mask, const uint32_t *row_slot, uint32_t n_rows,
                       uint16_t *score, uint32_t *maskw, void *stream) {
   if (n_rows == 0) return;
@@ -1427,6 +1465,7 @@ void kb_launch_commit(const KbDev &d, const KbRound &r, void *stream) {
   a.wL = d.wL; a.wM = d.wM; a.wB = d.wB;
   a.use_crow = (d.pred_enabled && d.crows != nullptr && d.n_nc <= 32) ? 1u : 0u;
   a.has_delta = r.delta != nullptr ? 1u : 0u;
+  a.has_aff = (d.aff != nullptr && d.score_enabled) ? 1u : 0u;
   a.R = d.R;
   a.batch = batch;
   a.host_out = r.host_out;

@@ -89,6 +89,11 @@ def _pod(doc, namespace: str) -> Pod:
         node_selector=dict(spec.get("nodeSelector") or {}),
         tolerations=[(t.get("key", "") or "", t.get("operator", "Equal") or "Equal", t.get("value", "") or "", t.get("effect", "") or "")
                      for t in spec.get("tolerations", []) or []],
+        preferred_affinity=[(int(term.get("weight", 0) or 0),
+                             [(ex.get("key", ""), ex.get("operator", ""), tuple(str(v) for v in ex.get("values", []) or []))
+                              for ex in ((term.get("preference") or {}).get("matchExpressions") or [])])
+                            for term in (((spec.get("affinity") or {}).get("nodeAffinity") or {})
+                                         .get("preferredDuringSchedulingIgnoredDuringExecution") or [])],
     )
 
 

@@ -94,6 +94,8 @@ class Pod:
     deleting: bool = False                                  # DeletionTimestamp != nil
     node_selector: Dict[str, str] = field(default_factory=dict)
     tolerations: List[Tuple[str, str, str, str]] = field(default_factory=list)  # (key, operator, value, effect)
+    # nodeAffinity.preferredDuringSchedulingIgnoredDuringExecution: (weight, [(key, operator, (values...))])
+    preferred_affinity: List[Tuple[int, List[Tuple[str, str, Tuple[str, ...]]]]] = field(default_factory=list)
 
 
 @dataclass
@@ -144,10 +146,45 @@ def _tolerates(tolerations, taint) -> bool:
     return False
 
 
+def _requirement_matches(labels: Dict[str, str], key: str, op: str, values) -> bool:
+    """labels.Requirement.Matches (vendor/k8s.io/apimachinery/pkg/labels/selector.go:194-236) for the node-selector operators."""
+    has = key in labels
+    if op == "In":
+        return has and labels[key] in values
+    if op == "NotIn":
+        return (not has) or labels[key] not in values
+    if op == "Exists":
+        return has
+    if op == "DoesNotExist":
+        return not has
+    if op in ("Gt", "Lt"):
+        if not has or len(values) != 1:
+            return False
+        try:
+            lv, rv = int(labels[key]), int(list(values)[0])
+        except ValueError:
+            return False
+        return lv > rv if op == "Gt" else lv < rv
+    raise ValueError(f"{op!r} is not a valid node selector operator")
+
+
+def _affinity_count(preferred, node_labels) -> int:
+    """CalculateNodeAffinityPriorityMap (vendor/.../priorities/node_affinity.go:34-77): sum of the weights of the preferred
+    terms that select the node; a term without match expressions selects nothing (helpers.go:205-208), weight 0 is skipped."""
+    labels = dict(node_labels)
+    count = 0
+    for weight, exprs in preferred:
+        if weight == 0 or not exprs:
+            continue
+        if all(_requirement_matches(labels, k, op, vals) for k, op, vals in exprs):
+            count += int(weight)
+    return count
+
+
 def _static_ok(pod_cls, node_cls) -> bool:
     """p2 CheckNodeCondition, p3 CheckNodeUnschedulable, p4 PodMatchNodeSelector (nodeSelector part),
     p6 PodToleratesNodeTaints — vendor/.../algorithm/predicates/predicates.go:1675-1700,1576-1593,927-983,1596-1620."""
-    selector, tolerations = pod_cls
+    selector, tolerations = pod_cls[0], pod_cls[1]
     labels, taints, unsched, ready, netun = node_cls
     if (not ready) or netun or unsched:
         return False
@@ -187,7 +224,7 @@ class SessionSnapshot:
         for name, ctype in abi.SNAPSHOT_ARRAYS:
             a = getattr(self, name, None)
             if a is None:
-                if name == "class_compat":
+                if name in ("class_compat", "class_affinity"):
                     continue
                 raise ValueError(f"snapshot field {name} missing")
             a = np.ascontiguousarray(a, dtype=_DTYPES[ctype])
@@ -371,12 +408,13 @@ def flatten(nodes: List[Node], pods: List[Pod], pod_groups: List[PodGroup], queu
             if p.node_name in nidx:
                 if account_on_node(nidx[p.node_name], st, res, nzc, nzm):
                     t_node[k] = nidx[p.node_name]
-            task_cls_keys.append((tuple(sorted(p.node_selector.items())), tuple(p.tolerations)))
+            pref = tuple((int(w), tuple((k2, op, tuple(vals)) for k2, op, vals in exprs)) for w, exprs in p.preferred_affinity)
+            task_cls_keys.append((tuple(sorted(p.node_selector.items())), tuple(p.tolerations), pref))
             names_tasks.append(f"{p.namespace}/{p.name}")
             k += 1
     begin[J] = k
 
-    ucls_t = sorted(set(task_cls_keys)) or [((), ())]
+    ucls_t = sorted(set(task_cls_keys)) or [((), (), ())]
     ucls_n = sorted(set(node_cls_keys)) or [((), (), False, True, False)]
     tmap = {c: i for i, c in enumerate(ucls_t)}
     nmap = {c: i for i, c in enumerate(ucls_n)}
@@ -386,6 +424,9 @@ def flatten(nodes: List[Node], pods: List[Pod], pod_groups: List[PodGroup], queu
             if _static_ok(tc, nc):
                 b = ti * len(ucls_n) + ni
                 compat[b >> 3] |= 1 << (b & 7)
+    affinity = None
+    if any(tc[2] for tc in ucls_t):
+        affinity = np.array([[_affinity_count(tc[2], nc[0]) for nc in ucls_n] for tc in ucls_t], np.int32)
 
     return SessionSnapshot(
         n_res=R, n_nodes=N, n_tasks=T, n_jobs=J, n_queues=Q,
@@ -404,7 +445,7 @@ def flatten(nodes: List[Node], pods: List[Pod], pod_groups: List[PodGroup], queu
         job_creation=np.array([pgs[j].creation for j in job_ids], np.int64).reshape(J),
         queue_weight=np.array([q.weight for q in queues], np.int32).reshape(Q),
         queue_creation=np.array([q.creation for q in queues], np.int64).reshape(Q),
-        class_compat=compat,
+        class_compat=compat, class_affinity=affinity,
         names={"nodes": [n.name for n in nodes], "tasks": names_tasks, "jobs": job_ids,
                "queues": [q.name for q in queues], "dims": ["cpu", "memory"] + sorted(scalar_names)},
     )

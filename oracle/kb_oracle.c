@@ -392,6 +392,7 @@ typedef struct kbo_session {
   o_job *jobs;
   o_queue *queues;
   uint8_t *compat;
+  int32_t *affinity;   /* [n_tc][n_nc] NodeAffinity Map counts (node_affinity.go:34-77), NULL: no preferred terms anywhere */
   /* conf */
   int n_tiers;
   uint32_t *tier_begin;
@@ -547,7 +548,7 @@ static double node_score(const kbo_session *s, const o_task *t, const o_node *n)
   int64_t rc = n->nz_cpu + t->nz_cpu, rm = n->nz_mem + t->nz_mem;
   int least = (int)least_scorer(rc, n->alloc_cpu, rm, n->alloc_mem);
   int most = (int)most_scorer(rc, n->alloc_cpu, rm, n->alloc_mem);
-  int nodeaff = 0; /* no preferred node-affinity terms in the flattened snapshot: Map gives 0, NormalizeReduce leaves 0 (reduce.go:43-50) */
+  int nodeaff = 0; /* the NodeAffinity config needs its Reduce over the whole feasible list: added by node_affinity_reduce() below */
   int podaff = 0;  /* no pod (anti)affinity: interpod_affinity.go yields 0 for every node */
   int bal = (int)balanced_scorer(rc, n->alloc_cpu, rm, n->alloc_mem);
   double score = 0;
@@ -624,7 +625,26 @@ static void pool_start(int nthreads) {
   for (int i = 0; i < nthreads; i++) pthread_create(&g_pool.th[i], NULL, pool_worker, &g_pool);
   g_pool_threads = nthreads;
 }
+/* nodeorder's NodeAffinity config: Map = CalculateNodeAffinityPriorityMap (node_affinity.go:34-77, the per-class-pair count
+   of the snapshot), Reduce = NormalizeReduce(MaxPriority=10, reverse=false) over the FEASIBLE nodes (reduce.go:28-63: maxCount == 0
+   leaves the zeros; else score = 10 * count / maxCount, integer division), then Score += float64(score * weight)
+   (scheduler_helper.go:162-168). */
+static void node_affinity_reduce(const kbo_session *s, const o_task *t, const uint8_t *feas, double *score) {
+  if (!s->affinity || !s->nodeorder_enabled) return;
+  const int32_t *row = &s->affinity[(size_t)t->cls * s->n_nc];
+  int max_count = 0;
+  for (uint32_t n = 0; n < s->N; n++)
+    if (feas[n] && row[s->nodes[n].cls] > max_count) max_count = row[s->nodes[n].cls];
+  if (max_count == 0) return;
+  for (uint32_t n = 0; n < s->N; n++)
+    if (feas[n]) score[n] += (double)((10 * row[s->nodes[n].cls] / max_count) * s->w_nodeaff);
+}
+static void eval_all_nodes_raw(kbo_session *s, const o_task *t, int fit_mode, uint8_t *feas, double *score);
 static void eval_all_nodes(kbo_session *s, const o_task *t, int fit_mode, uint8_t *feas, double *score) {
+  eval_all_nodes_raw(s, t, fit_mode, feas, score);
+  node_affinity_reduce(s, t, feas, score);
+}
+static void eval_all_nodes_raw(kbo_session *s, const o_task *t, int fit_mode, uint8_t *feas, double *score) {
   if (s->threads <= 1 || s->N < 256) { eval_range(s, t, fit_mode, feas, score, 0, s->N); return; }
   pool_start(s->threads);
   pool_t *p = &g_pool;
@@ -875,6 +895,11 @@ kbo_session *kbo_open(const kb_config *cfg, const kb_snapshot *sn, int threads) 
     s->compat = (uint8_t *)malloc(nb);
     memcpy(s->compat, sn->class_compat, nb);
   }
+  if (sn->class_affinity) {
+    size_t na = (size_t)s->n_tc * s->n_nc;
+    s->affinity = (int32_t *)malloc(sizeof(int32_t) * (na ? na : 1));
+    memcpy(s->affinity, sn->class_affinity, sizeof(int32_t) * na);
+  }
   s->bind_node = (uint32_t *)malloc(sizeof(uint32_t) * (s->T ? s->T : 1));
   s->bind_order = (uint32_t *)malloc(sizeof(uint32_t) * (s->T ? s->T : 1));
   for (uint32_t t = 0; t < s->T; t++) s->bind_node[t] = KB_NONE;
@@ -886,7 +911,7 @@ void kbo_close(kbo_session *s) {
   if (!s) return;
   for (uint32_t j = 0; j < s->J; j++) heap_free(&s->jobs[j].tasks);
   for (uint32_t q = 0; q < s->Q; q++) heap_free(&s->queues[q].jobs);
-  free(s->nodes); free(s->tasks); free(s->jobs); free(s->queues); free(s->compat);
+  free(s->nodes); free(s->tasks); free(s->jobs); free(s->queues); free(s->compat); free(s->affinity);
   free(s->tier_begin); free(s->plugins); free(s->decisions); free(s->bind_node); free(s->bind_order);
   free(s);
 }

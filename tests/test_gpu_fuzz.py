@@ -57,6 +57,10 @@ def _case(seed):
     s.task_priority[:] = rng.choice([1, 1, 5, 9], size=T).astype(np.int32)
     tight = rng.uniform(size=N) < 0.3
     s.node_max_pods[:] = np.where(tight, s.node_pod_cnt + rng.randint(0, 6, size=N), s.node_max_pods).astype(np.int32)
+    if seed % 3 == 0:     # preferred node affinity on about half of the task classes
+        aff = rng.choice([0, 0, 2, 5, 30], size=(s.n_task_classes, s.n_node_classes)).astype(np.int32)
+        aff[rng.uniform(size=s.n_task_classes) < 0.5] = 0
+        s.class_affinity = aff
     s._check()
     wl, wm, wb = [int(x) for x in rng.choice([0, 1, 1, 2, 5], size=3)]
     cfg = conf.load_scheduler_conf(CONF_TMPL.format(wl=wl, wm=wm, wb=wb))

@@ -160,6 +160,42 @@ def test_wide_cluster_more_than_64k_nodes(oracle_mod):
     assert_same_outcome(o2, e2, dec)
 
 
+def _with_affinity(snap, seed, frac=0.5):
+    """Random NodeAffinity Map counts per (task class, node class); about half of the task classes have no preferred terms."""
+    rng = np.random.RandomState(seed)
+    a = rng.choice([0, 0, 1, 3, 10, 40], size=(snap.n_task_classes, snap.n_node_classes)).astype(np.int32)
+    a[rng.uniform(size=snap.n_task_classes) < frac] = 0
+    snap.class_affinity = a
+    snap._check()
+    return snap
+
+
+def test_preferred_node_affinity(oracle_mod):
+    """NodeAffinity priority (Map counts + NormalizeReduce over the feasible set + weight): matrix, candidate lists and the
+    whole cycle; rows of affinity-bearing classes are committed as first rows of fresh rounds (KB_REASON_RENORM)."""
+    cfg = conf.load_scheduler_conf()
+    snap = _with_affinity(small(3, 0.03, zone_selector_frac=0.5), 7)
+    o = oracle_mod.Oracle(cfg, snap, threads=8)
+    e = engine.Engine(cfg)
+    e.load(snap)
+    em, es = e.eval_matrix(0, snap.n_tasks, 1)
+    om, os_ = o.eval_matrix(0, snap.n_tasks, 1)
+    assert np.array_equal(em, om) and np.array_equal(es, os_)
+    assert int(es.max()) > 20      # the affinity term is really there (least + balanced alone stay <= 20)
+    en, ek = e.argmax_rows(0, 200, 40)
+    on, ok = o.argmax_rows(0, 200, 40)
+    assert np.array_equal(en, on) and np.array_equal(ek, ok)
+    for window, batch in ((0, 0), (64, 3), (1024, 16)):
+        o2, e2, dec = run_both(oracle_mod, cfg, _with_affinity(small(3, 0.03, zone_selector_frac=0.5), 7), ["allocate", "backfill"],
+                               window=window, commit_batch=batch)
+        assert_same_outcome(o2, e2, dec)
+    # a different plugin weight, and weight 0 (the term vanishes)
+    for w in (3, 0):
+        cfgw = conf.load_scheduler_conf(conf.DEFAULT_SCHEDULER_CONF.replace("  - name: nodeorder", f"  - name: nodeorder\n    arguments: {{nodeaffinity.weight: {w}}}"))
+        o3, e3, dec = run_both(oracle_mod, cfgw, _with_affinity(small(2, 0.2, zone_selector_frac=0.5), 9), ["allocate", "backfill"])
+        assert_same_outcome(o3, e3, dec)
+
+
 def test_reference_test_tiers_on_synthetic(oracle_mod):
     """drf+proportion only (allocate_test.go tiers): no predicates, no node order -> pure tie-break path."""
     snap = small(2, 0.2)

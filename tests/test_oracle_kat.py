@@ -272,3 +272,33 @@ def test_heap_mechanics_with_duplicate_keys(L):
                          out.ctypes.data_as(C.POINTER(C.c_uint32)))
         assert out.tolist() == _go_heap_reference(keys, pushes.tolist())
         assert np.all(np.diff(keys[out]) >= 0)
+
+
+def test_node_affinity_priority_map_and_reduce(oracle_mod):
+    """nodeorder's NodeAffinity config (vendor/.../priorities/node_affinity.go:34-77 + reduce.go:28-63), hand-derived from the
+    vendored formulas (no reference test pins it): counts a=8 (5 for zone In [x] + 3 for gen Gt 2), b=2, c=2 (zone NotIn [x];
+    the term without expressions selects nothing, the weight-0 term is skipped); NormalizeReduce(10) over the feasible nodes
+    gives 10, 2, 2; on top of the 15 of the empty 4-cpu / 8-GiB node KAT -> 25, 17, 17.  With node a unschedulable the maximum
+    over the FEASIBLE set drops to 2 -> b and c get the full 10."""
+    S = kbm.snapshot
+
+    def mk(unsched):
+        nodes = [S.Node("a", {"cpu": "4", "memory": "8Gi", "pods": "10"}, labels={"zone": "x", "gen": "3"}, unschedulable=unsched),
+                 S.Node("b", {"cpu": "4", "memory": "8Gi", "pods": "10"}, labels={"zone": "y"}),
+                 S.Node("c", {"cpu": "4", "memory": "8Gi", "pods": "10"})]
+        pods = [S.Pod("ns", "p0", [{"cpu": "1"}], group_name="g",
+                      preferred_affinity=[(5, [("zone", "In", ("x",))]), (3, [("gen", "Gt", ("2",))]), (7, []),
+                                          (0, [("zone", "Exists", ())]), (2, [("zone", "NotIn", ("x",))])])]
+        return S.flatten(nodes, pods, [S.PodGroup("ns", "g")], [S.Queue("default")])
+
+    snap = mk(False)
+    assert snap.class_affinity.tolist() == [[2, 8, 2]]          # node classes sort as (no labels), (zone=x, gen=3), (zone=y)
+    o = oracle_mod.Oracle(kbm.conf.load_scheduler_conf(), snap)
+    mask, score = o.eval_matrix(0, 1, 1)
+    assert score.tolist() == [[25, 17, 17]] and mask.tolist() == [[7]]
+    o.run(["allocate"])
+    assert snap.bind_map(o.binds()) == {"ns/p0": "a"}
+    snap = mk(True)
+    o = oracle_mod.Oracle(kbm.conf.load_scheduler_conf(), snap)
+    mask, score = o.eval_matrix(0, 1, 1)
+    assert score.tolist() == [[0, 25, 25]] and mask.tolist() == [[6]]
