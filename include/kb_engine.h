@@ -57,7 +57,7 @@
 extern "C" {
 #endif
 
-#define KB_ABI_VERSION 2u
+#define KB_ABI_VERSION 3u
 #define KB_MAX_RES 32u          /* resource dimensions: 0 = cpu (milli), 1 = memory (bytes), 2.. = scalar resources (milli) */
 #define KB_NONE 0xFFFFFFFFu
 
@@ -182,6 +182,16 @@ typedef struct kb_snapshot {
      match expressions select the node's labels; [n_task_classes][n_node_classes], NULL => no pod has preferred terms.
      The engine applies NormalizeReduce(10) over the task's feasible nodes (reduce.go:28-63) and the plugin weight. */
   const int32_t  *class_affinity;
+
+  /* host ports (predicates.PodFitsHostPorts, vendor/.../algorithm/predicates/predicates.go:1153-1175 over
+     nodeinfo.HostPortInfo, vendor/.../nodeinfo/host_ports.go:107-135): the caller interns every distinct
+     (hostIP, protocol, hostPort) of the session's pods into a bit 0..63.  node_ports[n] = bits used by the pods in
+     ni.Tasks; task_port_want[t] = bits the pod occupies once placed; task_port_conflict[t] = every bit that conflicts with
+     one of the pod's ports (same protocol and port, and equal IPs or either side 0.0.0.0).  A node fails the predicate
+     iff node_ports & task_port_conflict != 0; placing the pod ORs task_port_want in.  All three NULL => no host ports. */
+  const uint64_t *node_ports;          /* [N] */
+  const uint64_t *task_port_want;      /* [T] */
+  const uint64_t *task_port_conflict;  /* [T] */
 } kb_snapshot;
 
 /* one placement decision, in the order the reference loop would have made it */

@@ -56,6 +56,11 @@ func (f *flat) i64(n int) []int64 {
 	f.bufs = append(f.bufs, p)
 	return (*[1 << 30]int64)(p)[:n:n]
 }
+func (f *flat) u64(n int) []uint64 {
+	p := C.calloc(C.size_t(n+1), 8)
+	f.bufs = append(f.bufs, p)
+	return (*[1 << 30]uint64)(p)[:n:n]
+}
 func (f *flat) u32(n int) []uint32 {
 	p := C.calloc(C.size_t(n+1), 4)
 	f.bufs = append(f.bufs, p)
@@ -140,14 +145,99 @@ func taskClassKey(t *api.TaskInfo) (string, error) {
 	if sp.Affinity != nil && (sp.Affinity.PodAffinity != nil || sp.Affinity.PodAntiAffinity != nil) {
 		return "", errUnsupported("inter-pod (anti)affinity")
 	}
-	for i := range sp.Containers {
-		for _, p := range sp.Containers[i].Ports {
-			if p.HostPort != 0 {
-				return "", errUnsupported("host ports")
+	return fmt.Sprintf("%v|%v|%v", sp.NodeSelector, sp.Affinity, sp.Tolerations), nil
+}
+
+// host ports: every distinct (hostIP, protocol, hostPort > 0) of the session's pods is one bit (nodeinfo/host_ports.go sanitises
+// "" to 0.0.0.0 / TCP); more than 64 of them -> the stock action takes the cycle
+type hostPort struct {
+	ip, proto string
+	port      int32
+}
+
+func podHostPorts(pod *v1.Pod) []hostPort {
+	var out []hostPort
+	for i := range pod.Spec.Containers {
+		for _, cp := range pod.Spec.Containers[i].Ports {
+			if cp.HostPort <= 0 {
+				continue
+			}
+			hp := hostPort{cp.HostIP, string(cp.Protocol), cp.HostPort}
+			if hp.ip == "" {
+				hp.ip = "0.0.0.0"
+			}
+			if hp.proto == "" {
+				hp.proto = string(v1.ProtocolTCP)
+			}
+			out = append(out, hp)
+		}
+	}
+	return out
+}
+
+// HostPortInfo.CheckConflict between a wanted and a used triple (vendor/.../nodeinfo/host_ports.go:107-135)
+func portsConflict(a, b hostPort) bool {
+	return a.proto == b.proto && a.port == b.port && (a.ip == b.ip || a.ip == "0.0.0.0" || b.ip == "0.0.0.0")
+}
+
+type portTable struct {
+	all []hostPort
+	bit map[hostPort]uint
+}
+
+func newPortTable(ssn *framework.Session) (*portTable, error) {
+	pt := &portTable{bit: map[hostPort]uint{}}
+	add := func(pod *v1.Pod) {
+		for _, hp := range podHostPorts(pod) {
+			if _, ok := pt.bit[hp]; !ok {
+				pt.bit[hp] = 0
+				pt.all = append(pt.all, hp)
 			}
 		}
 	}
-	return fmt.Sprintf("%v|%v|%v", sp.NodeSelector, sp.Affinity, sp.Tolerations), nil
+	for _, j := range ssn.Jobs {
+		for _, t := range j.Tasks {
+			add(t.Pod)
+		}
+	}
+	for _, n := range ssn.Nodes {
+		for _, t := range n.Tasks {
+			add(t.Pod)
+		}
+	}
+	if len(pt.all) > 64 {
+		return nil, errUnsupported("more than 64 distinct host ports")
+	}
+	sort.Slice(pt.all, func(i, j int) bool {
+		a, b := pt.all[i], pt.all[j]
+		if a.ip != b.ip {
+			return a.ip < b.ip
+		}
+		if a.proto != b.proto {
+			return a.proto < b.proto
+		}
+		return a.port < b.port
+	})
+	for i, hp := range pt.all {
+		pt.bit[hp] = uint(i)
+	}
+	return pt, nil
+}
+
+func (pt *portTable) masks(pod *v1.Pod) (want, conflict uint64) {
+	mine := podHostPorts(pod)
+	for _, hp := range mine {
+		want |= 1 << pt.bit[hp]
+	}
+	for _, other := range pt.all {
+		for _, hp := range mine {
+			if portsConflict(hp, other) {
+				conflict |= 1 << pt.bit[other]
+				break
+			}
+		}
+	}
+	return
 }
 
 // NodeAffinity priority, Map step, for one (task class, node class) pair: the vendored function itself
@@ -247,12 +337,18 @@ func flatten(ssn *framework.Session) (*flat, error) {
 		T += len(j.Tasks)
 	}
 
+	ports, err := newPortTable(ssn)
+	if err != nil {
+		return nil, err
+	}
+
 	// ---- nodes (api/node_info.go:28-47)
 	idle, rel, alloc := f.f64(R*N), f.f64(R*N), f.f64(R*N)
 	nmask := f.u32(N)
 	acpu, amem, nzc, nzm := f.i64(N), f.i64(N), f.i64(N), f.i64(N)
 	maxPods, podCnt := f.i32(N), f.i32(N)
 	nclass := f.u32(N)
+	nports := f.u64(N)
 	nodeClasses := map[string]uint32{}
 	var nodeClassRep []*api.NodeInfo
 	for i, n := range f.nodes {
@@ -265,6 +361,8 @@ func flatten(ssn *framework.Session) (*flat, error) {
 			c, m := podNonZero(t.Pod)
 			nzc[i] += c
 			nzm[i] += m
+			w, _ := ports.masks(t.Pod) // nodeinfo.UsedPorts(): the ports of every pod in ni.Tasks
+			nports[i] |= w
 		}
 		maxPods[i] = int32(n.Allocatable.MaxTaskNum)
 		podCnt[i] = int32(len(n.Tasks))
@@ -285,6 +383,7 @@ func flatten(ssn *framework.Session) (*flat, error) {
 	tjob, tclass, tnode := f.u32(T), f.u32(T), f.u32(T)
 	tprio := f.i32(T)
 	tstatus := f.u8(T)
+	twant, tconf := f.u64(T), f.u64(T)
 	jbegin := f.u32(J + 1)
 	jqueue := f.u32(J)
 	jmin, jprio := f.i32(J), f.i32(J)
@@ -318,6 +417,7 @@ func flatten(ssn *framework.Session) (*flat, error) {
 			tprio[t] = ti.Priority
 			tcreate[t] = ti.Pod.CreationTimestamp.Unix()
 			tstatus[t] = taskStatus(ti.Status)
+			twant[t], tconf[t] = ports.masks(ti.Pod)
 			tnode[t] = C.KB_NONE
 			if idx, ok := nodeIdx[ti.NodeName]; ok && ti.NodeName != "" {
 				tnode[t] = idx
@@ -402,6 +502,11 @@ func flatten(ssn *framework.Session) (*flat, error) {
 	s.class_compat = (*C.uint8_t)(unsafe.Pointer(&compat[0]))
 	if anyAffinity {
 		s.class_affinity = (*C.int32_t)(unsafe.Pointer(&affinity[0]))
+	}
+	if len(ports.all) > 0 {
+		s.node_ports = (*C.uint64_t)(unsafe.Pointer(&nports[0]))
+		s.task_port_want = (*C.uint64_t)(unsafe.Pointer(&twant[0]))
+		s.task_port_conflict = (*C.uint64_t)(unsafe.Pointer(&tconf[0]))
 	}
 	return f, nil
 }

@@ -31,6 +31,7 @@ struct KbDev {
   long long *nzc;      // [NP] nodeinfo.nonzeroRequest.MilliCPU
   long long *nzm;      // [NP] nodeinfo.nonzeroRequest.Memory
   int *podcnt;         // [NP] len(ni.Tasks)
+  unsigned long long *ports;   // [NP] host-port bits used on the node (nodeinfo.UsedPorts), nullptr: no host ports in the session
   // static node data
   const long long *acpu, *amem;   // [NP] nodeinfo.allocatableResource
   const int *maxpods;             // [NP]
@@ -45,6 +46,7 @@ struct KbDev {
   const uint32_t *t_active;       // [T] dims that LessEqual must compare: bits 0,1 always; bit d iff InitResreq[d] > 10
   const uint32_t *t_resmask;      // [T] scalar keys present in Resreq (bit d-2)
   const uint32_t *t_job;          // [T]
+  const unsigned long long *t_want, *t_conf;   // [T] host-port bits the pod occupies / that conflict with it (nullptr: none)
   uint8_t *t_status;              // [T] KB_TASK_*
   uint32_t *t_node;               // [T]
   uint32_t *t_bind;               // [T] node handed to the Binder, KB_NONE otherwise
@@ -70,7 +72,7 @@ struct KbDev {
 // window refers to its shape through shape_slot[i].
 // everything the commit kernel needs to know about one window row, gathered contiguously so that the row i+2 can be
 // fetched with one wave-uniform (scalar) load while row i is being committed
-struct KbRowDesc {          // 56 bytes
+struct KbRowDesc {          // 72 bytes
   double init0, init1;     // InitResreq cpu, memory
   long long nzc, nzm;      // pod non-zero request
   uint32_t task, active, resmask, cls;
@@ -78,6 +80,7 @@ struct KbRowDesc {          // 56 bytes
   uint16_t flags;          // bit 0: Resreq cpu/memory == InitResreq cpu/memory (no init container raised them)
                            // bit 1: the task's class has preferred node-affinity terms (score normalised over the feasible set)
   uint32_t crow;           // the task class's row of the static-predicate table (bit nc), valid when n_node_classes <= 32
+  unsigned long long want, conf;   // host-port bits the pod occupies / that conflict with it
 };
 
 struct KbRound {
@@ -122,7 +125,7 @@ struct KbCommitArgs {
   unsigned long long *trace;
   uint32_t n_rows, n_mrows, L, cap, N, NP;
   int fit_mode, backfill, pred_enabled, score_enabled, wL, wM, wB;
-  uint32_t use_crow, has_delta, has_aff;
+  uint32_t use_crow, has_delta, has_aff, has_ports;
   int R;
   uint32_t batch;   // rows speculated per batch (<= 16)
   unsigned long long *host_out;   // pinned host mirror of the output block (fast rounds), or nullptr

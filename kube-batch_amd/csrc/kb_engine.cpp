@@ -131,7 +131,8 @@ struct kb_engine {
   unsigned long long full_evals = 0;
   uint32_t eff_window = 0;   // window actually used for this session (bounded by the commit kernel's LDS budget)
   DevBuf b_tinit, b_tres, b_tnzc, b_tnzm, b_tcls, b_tactive, b_tresmask, b_tjob, b_tstatus, b_tnode, b_tbind, b_tcounted, b_compat, b_crows, b_aff, b_affcls;
-  DevBuf p_idle, p_rel, p_nzc, p_nzm, p_podcnt, p_tstatus, p_tnode, p_tcounted;   // pristine copies for kb_session_reset
+  DevBuf p_idle, p_rel, p_nzc, p_nzm, p_podcnt, p_tstatus, p_tnode, p_tcounted, p_ports;   // pristine copies for kb_session_reset
+  DevBuf b_ports, b_twant, b_tconf;   // host ports (only when the snapshot carries any)
   DevBuf b_jbegin, b_jmin, b_jqueue, b_total, b_deserved, b_desmask, b_jalloc, b_jshare, b_qalloc, b_qshare, b_jready;
   uint32_t total_mask = 0;
   // round buffers
@@ -519,7 +520,7 @@ struct ActionRun {
     const int R = hs.R;
     const double *ex = &hs.feas_eff[(size_t)x * R];
     for (uint32_t y = 0; y < hs.n_feas_shapes; y++) {
-      if (dead[y] || hs.feas_cls[y] != hs.feas_cls[x]) continue;
+      if (dead[y] || hs.feas_cls[y] != hs.feas_cls[x] || hs.feas_conf[y] != hs.feas_conf[x]) continue;
       const double *ey = &hs.feas_eff[(size_t)y * R];
       bool ge = true;
       for (int d = 0; d < R && ge; d++) ge = ey[d] >= ex[d];
@@ -835,7 +836,12 @@ int kb_session_load(kb_engine *e, const kb_snapshot *sn) {
             throw EngineError(KB_E_UNSUPPORTED, "BestEffort task with a non-zero sub-epsilon request (backfill's AddTask retry path)");
       key.assign(in.v, in.v + R);
       key.push_back((double)hs.t_cls[t]);
-      hs.t_feas_shape[t] = intern(feas_ids, key);
+      {   // host ports: the conflict mask is part of feasibility, the wanted bits of what a commit changes
+        const uint64_t conf = sn->task_port_conflict ? sn->task_port_conflict[t] : 0, want = sn->task_port_want ? sn->task_port_want[t] : 0;
+        key.push_back((double)(uint32_t)(conf & 0xFFFFFFFFu)); key.push_back((double)(uint32_t)(conf >> 32));
+        hs.t_feas_shape[t] = intern(feas_ids, key);
+        key.push_back((double)(uint32_t)(want & 0xFFFFFFFFu)); key.push_back((double)(uint32_t)(want >> 32));
+      }
       key.push_back((double)sn->task_nz_cpu[t]);
       key.push_back((double)sn->task_nz_mem[t]);
       hs.t_row_shape[t] = intern(row_ids, key);
@@ -846,9 +852,11 @@ int kb_session_load(kb_engine *e, const kb_snapshot *sn) {
     // resource_info.go:283-287) and the static class, for the dominance rule of ActionRun::mark_dead
     hs.feas_eff.assign((size_t)hs.n_feas_shapes * R, 0.0);
     hs.feas_cls.assign(hs.n_feas_shapes, 0);
+    hs.feas_conf.assign(hs.n_feas_shapes, 0);
     for (uint32_t t = 0; t < T; t++) {
       const uint32_t f = hs.t_feas_shape[t];
       hs.feas_cls[f] = hs.t_cls[t];
+      hs.feas_conf[f] = sn->task_port_conflict ? sn->task_port_conflict[t] : 0;
       for (int d = 0; d < R; d++)
         hs.feas_eff[(size_t)f * R + d] = (d < 2 || ((t_active[t] >> d) & 1u)) ? hs.t_init[(size_t)d * T + t] : 0.0;
     }
@@ -987,6 +995,26 @@ int kb_session_load(kb_engine *e, const kb_snapshot *sn) {
         d.crows = e->b_crows.as<uint32_t>();
       }
     }
+    d.ports = nullptr; d.t_want = nullptr; d.t_conf = nullptr;
+    if (sn->node_ports || sn->task_port_want || sn->task_port_conflict) {
+      std::vector<unsigned long long> np_(NP, 0ull), tw(T ? T : 1, 0ull), tc(T ? T : 1, 0ull);
+      bool any = false;
+      for (uint32_t n = 0; n < N && sn->node_ports; n++) { np_[n] = sn->node_ports[n]; any = any || np_[n]; }
+      for (uint32_t t = 0; t < T; t++) {
+        if (sn->task_port_want) tw[t] = sn->task_port_want[t];
+        if (sn->task_port_conflict) tc[t] = sn->task_port_conflict[t];
+        if ((tw[t] & ~tc[t]) != 0) throw EngineError(KB_E_INVALID, "a pod's host ports must conflict with themselves (want is not a subset of conflict)");
+        any = any || tw[t] || tc[t];
+      }
+      if (any) {
+        upload(e->b_ports, np_.data(), NP, s);
+        upload(e->b_twant, tw.data(), tw.size(), s);
+        upload(e->b_tconf, tc.data(), tc.size(), s);
+        d.ports = e->b_ports.as<unsigned long long>();
+        d.t_want = e->b_twant.as<unsigned long long>();
+        d.t_conf = e->b_tconf.as<unsigned long long>();
+      }
+    }
     d.aff = nullptr;
     d.aff_cls = nullptr;
     d.wNA = e->pol.wNA;
@@ -1060,6 +1088,7 @@ int kb_session_load(kb_engine *e, const kb_snapshot *sn) {
     };
     snap_copy(e->p_idle, e->b_idle); snap_copy(e->p_rel, e->b_rel); snap_copy(e->p_nzc, e->b_nzc); snap_copy(e->p_nzm, e->b_nzm);
     snap_copy(e->p_podcnt, e->b_podcnt); snap_copy(e->p_tstatus, e->b_tstatus); snap_copy(e->p_tnode, e->b_tnode);
+    if (d.ports) snap_copy(e->p_ports, e->b_ports);
     snap_copy(e->p_tcounted, e->b_tcounted);
     // initial drf / proportion / gang aggregates come from the device reduction (K2+K4)
     run_finalize(e);
@@ -1076,6 +1105,7 @@ int kb_session_reset(kb_engine *e) {
     auto restore = [&](DevBuf &dst, const DevBuf &src) { HIP_OK(hipMemcpyAsync(dst.p, src.p, src.bytes, hipMemcpyDeviceToDevice, s)); };
     restore(e->b_idle, e->p_idle); restore(e->b_rel, e->p_rel); restore(e->b_nzc, e->p_nzc); restore(e->b_nzm, e->p_nzm);
     restore(e->b_podcnt, e->p_podcnt); restore(e->b_tstatus, e->p_tstatus); restore(e->b_tnode, e->p_tnode);
+    if (e->dev.ports) restore(e->b_ports, e->p_ports);
     restore(e->b_tcounted, e->p_tcounted);
     HIP_OK(hipMemsetAsync(e->b_tbind.p, 0xFF, sizeof(uint32_t) * (e->hs.T ? e->hs.T : 1), s));
     mg_free(e->mg);

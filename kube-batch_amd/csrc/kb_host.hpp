@@ -147,6 +147,7 @@ struct HostSession {
   uint32_t n_feas_shapes = 0, n_row_shapes = 0;
   std::vector<double> feas_eff;           // [n_feas_shapes][R] the InitResreq values LessEqual compares (0 where the dimension is skipped)
   std::vector<uint32_t> feas_cls;         // [n_feas_shapes] static-predicate class
+  std::vector<uint64_t> feas_conf;        // [n_feas_shapes] host-port conflict mask
   std::vector<uint32_t> job_begin, job_queue;
   std::vector<int32_t> job_min, job_prio;
   std::vector<int64_t> job_creation;

@@ -42,6 +42,7 @@ struct TaskVals {
   double init0, init1;
   long long nzc, nzm;
   uint32_t cls, active, task, pad;
+  unsigned long long conf;   // host-port bits that conflict with this pod's ports (0: none)
 };
 struct NodeVals {
   double idle0, idle1, rel0, rel1;
@@ -50,6 +51,7 @@ struct NodeVals {
   uint32_t cls;
   int slots;   // Allocatable.MaxTaskNum > len(pods)  (predicates.go:127 fails on <=)
   int valid;   // node index < N
+  unsigned long long ports;   // host-port bits used by the pods on the node
 };
 
 __device__ __forceinline__ bool le_eps(double l, double r, double eps) { return (l < r) || (fabs(l - r) < eps); }
@@ -64,6 +66,7 @@ __device__ __forceinline__ TaskVals load_task(const KbDev &d, uint32_t t) {
   tv.active = d.t_active[t];
   tv.task = t;
   tv.pad = 0;
+  tv.conf = d.t_conf ? d.t_conf[t] : 0ull;
   return tv;
 }
 
@@ -83,6 +86,7 @@ __device__ __forceinline__ NodeVals load_node(const KbDev &d, uint32_t n) {
   nv.inv_am = d.inv_amem[m];
   nv.cls = d.ncls[m];
   nv.slots = d.maxpods[m] > d.podcnt[m];
+  nv.ports = d.ports ? d.ports[m] : 0ull;
   return nv;
 }
 
@@ -135,7 +139,7 @@ __device__ __forceinline__ uint32_t eval_pair(const KbDev &d, const TaskVals &t,
     ok = fi || fr;
   }
   if (d.pred_enabled) {
-    ok = ok && n.slots;
+    ok = ok && n.slots && ((n.ports & t.conf) == 0ull);   // pod count (predicates.go:127), PodFitsHostPorts (predicates.go:181-190)
     if (class_row) {
       ok = ok && ((class_row[n.cls >> 5] >> (n.cls & 31)) & 1u);
     } else if (d.compat) {
@@ -468,6 +472,8 @@ __global__ void __launch_bounds__(256) k_gather(KbDev d, KbRound r) {
   k.slot = (uint16_t)r.shape_slot[i];
   k.flags = (d.t_res[t] == k.init0 && d.t_res[(size_t)d.T + t] == k.init1) ? 1 : 0;
   if (d.aff_cls && d.aff_cls[k.cls]) k.flags |= 2;
+  k.want = d.t_want ? d.t_want[t] : 0ull;
+  k.conf = d.t_conf ? d.t_conf[t] : 0ull;
   k.crow = d.crows ? d.crows[(size_t)k.cls * 8] : 0xFFFFFFFFu;
   r.desc[i] = k;
 }
@@ -513,7 +519,8 @@ __global__ void __launch_bounds__(256) k_affinity(KbDev d, KbRound r) {
 #define K5_NF8 10
 #define K5_WAVES (KB_K5_THREADS / 64)
 
-__device__ __forceinline__ NodeVals k5_slot_vals(const unsigned long long *tab, const uint32_t *t_cls, const int *t_left, uint32_t cap, uint32_t slot) {
+__device__ __forceinline__ NodeVals k5_slot_vals(const unsigned long long *tab, const uint32_t *t_cls, const int *t_left, uint32_t cap, uint32_t slot,
+                                              const unsigned long long *ptab = nullptr) {
   NodeVals nv;
   nv.idle0 = __longlong_as_double((long long)tab[K5F_IDLE0 * cap + slot]);
   nv.idle1 = __longlong_as_double((long long)tab[K5F_IDLE1 * cap + slot]);
@@ -525,6 +532,7 @@ __device__ __forceinline__ NodeVals k5_slot_vals(const unsigned long long *tab, 
   nv.am = (long long)tab[K5F_AM * cap + slot];
   nv.nzc = (long long)tab[K5F_NZC * cap + slot];
   nv.nzm = (long long)tab[K5F_NZM * cap + slot];
+  nv.ports = ptab ? ptab[slot] : 0ull;
   nv.cls = t_cls[slot];
   nv.slots = t_left[slot] > 0;
   nv.valid = 1;
@@ -555,7 +563,7 @@ __device__ __forceinline__ uint32_t eval_pair_k5(const KbCommitArgs &a, const Ta
     ok = fi || fr;
   }
   if (a.pred_enabled) {
-    ok = ok && n.slots;
+    ok = ok && n.slots && ((n.ports & t.conf) == 0ull);   // pod count (predicates.go:127), PodFitsHostPorts (predicates.go:181-190)
     if (class_row) {
       ok = ok && ((class_row[n.cls >> 5] >> (n.cls & 31)) & 1u);
     } else {
@@ -651,6 +659,7 @@ struct K7Mem {
   uint32_t *dc_nd, *dc_log;             // [cap]
   uint32_t *dlog;                       // [cap] slots changed by dirty rows, in order
   unsigned long long *keyq;             // [cap2] keys of one shape against every dirty slot (row-at-a-time mode)
+  unsigned long long *ptab;             // [cap2] host-port bits of the slot's node (sessions with host ports only)
   uint32_t *bitmap;                     // [NP/32]
   double *save;                         // [K7_B][R-2] scalar-dimension values overwritten by speculative commits
   K7Hdr *H;
@@ -659,13 +668,14 @@ struct K7Mem {
 
 __host__ __device__ inline size_t k7_smem_bytes(uint32_t cap, uint32_t NP, int R) {
   size_t cap2 = (size_t)cap + K7_B;
-  return cap2 * (K5_NF8 * 8 + 8 + 3 * 4) + (size_t)cap * (8 + 8 + 12) + (size_t)(NP / 32) * 4 + (size_t)K7_B * (R > 2 ? R - 2 : 0) * 8 + sizeof(K7Hdr) + 64;
+  return cap2 * (K5_NF8 * 8 + 8 + 8 + 3 * 4) + (size_t)cap * (8 + 8 + 12) + (size_t)(NP / 32) * 4 + (size_t)K7_B * (R > 2 ? R - 2 : 0) * 8 + sizeof(K7Hdr) + 64;
 }
 
 __device__ __forceinline__ TaskVals k7_task_vals(const KbRowDesc &k) {
   TaskVals tv;
   tv.init0 = k.init0; tv.init1 = k.init1; tv.nzc = k.nzc; tv.nzm = k.nzm;
   tv.cls = k.cls; tv.active = k.active; tv.task = k.task; tv.pad = 0;
+  tv.conf = k.conf;
   return tv;
 }
 
@@ -748,6 +758,7 @@ __device__ __forceinline__ uint32_t k7_apply_slot(const KbCommitArgs &a, const K
   M.tab[(size_t)(f0 + 1) * cap2 + slot] = (unsigned long long)__double_as_longlong(__longlong_as_double((long long)M.tab[(size_t)(f0 + 1) * cap2 + slot]) - res1);
   M.tab[(size_t)K5F_NZC * cap2 + slot] += (unsigned long long)k.nzc;
   M.tab[(size_t)K5F_NZM * cap2 + slot] += (unsigned long long)k.nzm;
+  if (a.has_ports) M.ptab[slot] |= k.want;   // the pod's host ports join nodeinfo.UsedPorts()
   return kind;
 }
 
@@ -778,7 +789,8 @@ __global__ void __launch_bounds__(KB_K5_THREADS) k_commit(const K7KernArgs ka) {
   M.cap2 = cap2;
   M.tab = reinterpret_cast<unsigned long long *>(k5_smem);
   M.keyq = M.tab + (size_t)K5_NF8 * cap2;   // 8-byte tables first
-  M.dc_key = M.keyq + cap2;
+  M.ptab = M.keyq + cap2;
+  M.dc_key = M.ptab + cap2;
   M.t_cls = reinterpret_cast<uint32_t *>(M.dc_key + cap);
   M.t_node = M.t_cls + cap2;
   M.t_left = reinterpret_cast<int *>(M.t_node + cap2);
@@ -790,7 +802,7 @@ __global__ void __launch_bounds__(KB_K5_THREADS) k_commit(const K7KernArgs ka) {
   M.bitmap = M.dlog + cap;
   {
     // byte offsets from the LDS base (pointer -> integer -> pointer round trips would lose the address space)
-    size_t off = (size_t)cap2 * (K5_NF8 * 8 + 8 + 3 * 4) + (size_t)cap * (8 + 8 + 12) + (size_t)(a.NP / 32) * 4;
+    size_t off = (size_t)cap2 * (K5_NF8 * 8 + 8 + 8 + 3 * 4) + (size_t)cap * (8 + 8 + 12) + (size_t)(a.NP / 32) * 4;
     off = (off + 15) & ~(size_t)15;
     M.H = reinterpret_cast<K7Hdr *>(k5_smem + off);
     M.save = reinterpret_cast<double *>(k5_smem + off + sizeof(K7Hdr));
@@ -1008,7 +1020,10 @@ __global__ void __launch_bounds__(KB_K5_THREADS) k_commit(const K7KernArgs ka) {
         const uint32_t nxt = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v4, 0x101, 0xf, 0xf, true);   // row_shl:1: lane 11 <- pods
         if (f == 10) M.t_cls[slot] = v4;
         else if (f == 11) M.t_left[slot] = (int)v4 - (int)nxt - 1;
-        else if (f == 13) M.t_node[slot] = n;
+        else if (f == 13) {
+          M.t_node[slot] = n;
+          if (a.has_ports) M.ptab[slot] = a.dev->ports[n] | k.want;
+        }
         else if (f == 15 && k.resmask) {
           const KbDev &d = *a.dev;
           has_map = kind ? 1u : d.nmask[n];   // Sub returns early when the receiver's scalar map is nil (resource_info.go:148-153)
@@ -1054,7 +1069,7 @@ __global__ void __launch_bounds__(KB_K5_THREADS) k_commit(const K7KernArgs ka) {
         if (x < nd || H.c[x - nd] != 0ull) {
           const KbRowDesc &k = bd[H.rep[q]];
           const TaskVals tv = k7_task_vals(k);
-          const NodeVals nv = k5_slot_vals(M.tab, M.t_cls, M.t_left, cap2, x);
+          const NodeVals nv = k5_slot_vals(M.tab, M.t_cls, M.t_left, cap2, x, a.has_ports ? M.ptab : nullptr);
           const uint32_t node = M.t_node[x];
           const uint32_t res = eval_pair_k5(a, tv, nv, node, a.use_crow ? &k.crow : nullptr);
           key = res ? KB_KEY(res & 0xFFFFu, node) : 0ull;
@@ -1130,7 +1145,7 @@ __global__ void __launch_bounds__(KB_K5_THREADS) k_commit(const K7KernArgs ka) {
         const KbRowDesc &k = bd[p];
         const TaskVals tv = k7_task_vals(k);
         for (uint32_t x = tid; x < nd + p; x += KB_K5_THREADS) {
-          const NodeVals nv = k5_slot_vals(M.tab, M.t_cls, M.t_left, cap2, x);
+          const NodeVals nv = k5_slot_vals(M.tab, M.t_cls, M.t_left, cap2, x, a.has_ports ? M.ptab : nullptr);
           const uint32_t node = M.t_node[x];
           const uint32_t res = eval_pair_k5(a, tv, nv, node, a.use_crow ? &k.crow : nullptr);
           M.keyq[x] = res ? KB_KEY(res & 0xFFFFu, node) : 0ull;
@@ -1182,7 +1197,7 @@ __global__ void __launch_bounds__(KB_K5_THREADS) k_commit(const K7KernArgs ka) {
               k7_commit_globals<true>(a, k, i0 + r, n, kind);
               M.dlog[nlog] = xs;
               const TaskVals tv = k7_task_vals(k);
-              const NodeVals nv = k5_slot_vals(M.tab, M.t_cls, M.t_left, cap2, xs);
+              const NodeVals nv = k5_slot_vals(M.tab, M.t_cls, M.t_left, cap2, xs, a.has_ports ? M.ptab : nullptr);
               const uint32_t res = eval_pair_k5(a, tv, nv, n, a.use_crow ? &k.crow : nullptr);
               M.keyq[xs] = res ? KB_KEY(res & 0xFFFFu, n) : 0ull;
             }
@@ -1269,6 +1284,7 @@ __global__ void __launch_bounds__(KB_K5_THREADS) k_commit(const K7KernArgs ka) {
       d.nzc[n] = (long long)M.tab[K5F_NZC * cap2 + slot];
       d.nzm[n] = (long long)M.tab[K5F_NZM * cap2 + slot];
       d.podcnt[n] = d.maxpods[n] - M.t_left[slot];
+      if (a.has_ports) d.ports[n] = M.ptab[slot];
     }
   }
   // task-table side of ssn.Allocate / ssn.Pipeline for the committed rows (job.UpdateTaskStatus, task.NodeName:
@@ -1466,6 +1482,7 @@ void kb_launch_commit(const KbDev &d, const KbRound &r, void *stream) {
   a.use_crow = (d.pred_enabled && d.crows != nullptr && d.n_nc <= 32) ? 1u : 0u;
   a.has_delta = r.delta != nullptr ? 1u : 0u;
   a.has_aff = (d.aff != nullptr && d.score_enabled) ? 1u : 0u;
+  a.has_ports = d.ports != nullptr ? 1u : 0u;
   a.R = d.R;
   a.batch = batch;
   a.host_out = r.host_out;

@@ -96,6 +96,8 @@ class Pod:
     tolerations: List[Tuple[str, str, str, str]] = field(default_factory=list)  # (key, operator, value, effect)
     # nodeAffinity.preferredDuringSchedulingIgnoredDuringExecution: (weight, [(key, operator, (values...))])
     preferred_affinity: List[Tuple[int, List[Tuple[str, str, Tuple[str, ...]]]]] = field(default_factory=list)
+    # container ports with a hostPort: (hostIP, protocol, hostPort); "" -> 0.0.0.0 / TCP (nodeinfo/host_ports.go:137-144)
+    host_ports: List[Tuple[str, str, int]] = field(default_factory=list)
 
 
 @dataclass
@@ -181,6 +183,16 @@ def _affinity_count(preferred, node_labels) -> int:
     return count
 
 
+def _sanitize_port(hp) -> Tuple[str, str, int]:
+    ip, proto, port = hp
+    return (ip or "0.0.0.0", proto or "TCP", int(port))
+
+
+def _ports_conflict(a, b) -> bool:
+    """HostPortInfo.CheckConflict (vendor/.../nodeinfo/host_ports.go:107-135) between a wanted and a used (ip, protocol, port)."""
+    return a[1] == b[1] and a[2] == b[2] and (a[0] == b[0] or a[0] == "0.0.0.0" or b[0] == "0.0.0.0")
+
+
 def _static_ok(pod_cls, node_cls) -> bool:
     """p2 CheckNodeCondition, p3 CheckNodeUnschedulable, p4 PodMatchNodeSelector (nodeSelector part),
     p6 PodToleratesNodeTaints — vendor/.../algorithm/predicates/predicates.go:1675-1700,1576-1593,927-983,1596-1620."""
@@ -201,7 +213,8 @@ def _static_ok(pod_cls, node_cls) -> bool:
 # ------------------------------------------------------------------------------------------------
 # the SoA snapshot
 # ------------------------------------------------------------------------------------------------
-_DTYPES = {C.c_double: np.float64, C.c_uint32: np.uint32, C.c_int64: np.int64, C.c_int32: np.int32, C.c_uint8: np.uint8}
+_DTYPES = {C.c_double: np.float64, C.c_uint32: np.uint32, C.c_int64: np.int64, C.c_int32: np.int32, C.c_uint8: np.uint8,
+           C.c_uint64: np.uint64}
 
 
 class SessionSnapshot:
@@ -224,7 +237,7 @@ class SessionSnapshot:
         for name, ctype in abi.SNAPSHOT_ARRAYS:
             a = getattr(self, name, None)
             if a is None:
-                if name in ("class_compat", "class_affinity"):
+                if name in ("class_compat", "class_affinity", "node_ports", "task_port_want", "task_port_conflict"):
                     continue
                 raise ValueError(f"snapshot field {name} missing")
             a = np.ascontiguousarray(a, dtype=_DTYPES[ctype])
@@ -383,15 +396,35 @@ def flatten(nodes: List[Node], pods: List[Pod], pod_groups: List[PodGroup], queu
         node_nzc[ni] += nzc; node_nzm[ni] += nzm
         return True
 
+    # host ports: every distinct (ip, protocol, port > 0) of the session's pods is one bit
+    universe = sorted({_sanitize_port(hp) for p in pods for hp in p.host_ports if int(hp[2]) > 0})
+    if len(universe) > 64:
+        raise ValueError("more than 64 distinct host ports in one session")
+    port_bit = {hp: i for i, hp in enumerate(universe)}
+    node_ports = np.zeros(N, np.uint64)
+
+    def port_masks(p: Pod):
+        mine = [_sanitize_port(hp) for hp in p.host_ports if int(hp[2]) > 0]
+        want = 0
+        conflict = 0
+        for hp in mine:
+            want |= 1 << port_bit[hp]
+        for other in universe:
+            if any(_ports_conflict(hp, other) for hp in mine):
+                conflict |= 1 << port_bit[other]
+        return want, conflict
+
     for p in other_pods:                                 # pods of other schedulers / jobs outside the session
         if p.node_name in nidx:
             res, _, _, nzc, nzm = pod_vectors(p)
-            account_on_node(nidx[p.node_name], _task_status(p), res, nzc, nzm)
+            if account_on_node(nidx[p.node_name], _task_status(p), res, nzc, nzm):
+                node_ports[nidx[p.node_name]] |= np.uint64(port_masks(p)[0])
 
     t_res = np.zeros((R, T)); t_init = np.zeros((R, T)); t_mask = np.zeros(T, np.uint32)
     t_nzc = np.zeros(T, np.int64); t_nzm = np.zeros(T, np.int64); t_job = np.zeros(T, np.uint32)
     t_prio = np.zeros(T, np.int32); t_cre = np.zeros(T, np.int64); t_st = np.zeros(T, np.uint8)
     t_node = np.full(T, abi.KB_NONE, np.uint32)
+    t_want = np.zeros(T, np.uint64); t_conf = np.zeros(T, np.uint64)
     task_cls_keys = []
     names_tasks = []
     begin = np.zeros(J + 1, np.uint32)
@@ -405,9 +438,12 @@ def flatten(nodes: List[Node], pods: List[Pod], pod_groups: List[PodGroup], queu
             t_nzc[k] = nzc; t_nzm[k] = nzm; t_job[k] = j
             t_prio[k] = 1 if p.priority is None else p.priority      # NewTaskInfo default (job_info.go:82)
             t_cre[k] = p.creation; t_st[k] = st
+            want, conflict = port_masks(p)
+            t_want[k] = want; t_conf[k] = conflict
             if p.node_name in nidx:
                 if account_on_node(nidx[p.node_name], st, res, nzc, nzm):
                     t_node[k] = nidx[p.node_name]
+                    node_ports[nidx[p.node_name]] |= np.uint64(want)
             pref = tuple((int(w), tuple((k2, op, tuple(vals)) for k2, op, vals in exprs)) for w, exprs in p.preferred_affinity)
             task_cls_keys.append((tuple(sorted(p.node_selector.items())), tuple(p.tolerations), pref))
             names_tasks.append(f"{p.namespace}/{p.name}")
@@ -446,6 +482,8 @@ def flatten(nodes: List[Node], pods: List[Pod], pod_groups: List[PodGroup], queu
         queue_weight=np.array([q.weight for q in queues], np.int32).reshape(Q),
         queue_creation=np.array([q.creation for q in queues], np.int64).reshape(Q),
         class_compat=compat, class_affinity=affinity,
+        node_ports=node_ports if universe else None, task_port_want=t_want if universe else None,
+        task_port_conflict=t_conf if universe else None,
         names={"nodes": [n.name for n in nodes], "tasks": names_tasks, "jobs": job_ids,
                "queues": [q.name for q in queues], "dims": ["cpu", "memory"] + sorted(scalar_names)},
     )

@@ -349,12 +349,14 @@ typedef struct o_node {
   int64_t alloc_cpu, alloc_mem, nz_cpu, nz_mem; /* k8s nodeinfo view */
   int32_t pod_cnt;
   uint32_t cls;
+  uint64_t ports;   /* nodeinfo.UsedPorts() as interned bits (vendor/.../nodeinfo/host_ports.go) */
 } o_node;
 
 typedef struct o_task {
   kbo_res resreq, init_resreq;
   int64_t nz_cpu, nz_mem;
   uint32_t job, cls, node;
+  uint64_t port_want, port_conflict;
   int32_t priority;
   int64_t creation;
   uint8_t status;
@@ -534,7 +536,9 @@ static int class_ok(const kbo_session *s, uint32_t tc, uint32_t nc) {
 static int plugin_predicate(const kbo_session *s, const o_task *t, const o_node *n) {
   if (!s->pred_enabled) return 1; /* session_plugins.go:334-351: no enabled predicate fn => nil */
   if (n->allocatable.max_task_num <= n->pod_cnt) return 0; /* predicates.go:127 */
-  return class_ok(s, t->cls, n->cls);
+  if (!class_ok(s, t->cls, n->cls)) return 0;
+  /* PodFitsHostPorts (predicates.go:181-190 -> vendor/.../predicates/predicates.go:1153-1175): any wanted port in conflict with a used one */
+  return (n->ports & t->port_conflict) == 0;
 }
 /* actions/allocate/allocate.go:73-87 */
 static int allocate_predicate(const kbo_session *s, const o_task *t, const o_node *n) {
@@ -698,6 +702,7 @@ static int ssn_allocate(kbo_session *s, uint32_t t, uint32_t n) {
   res_add(&nd->used, &tk->resreq, s->R);
   tk->node = n;
   nd->pod_cnt += 1;                 /* ni.Tasks[key] = ti ; k8s NodeInfo is rebuilt from ni.Pods() per evaluation */
+  nd->ports |= tk->port_want;       /* ... including its UsedPorts (node_info.go:582-607 updateUsedPorts) */
   nd->nz_cpu += tk->nz_cpu;         /* vendor/.../nodeinfo/node_info.go:502-517 AddPod */
   nd->nz_mem += tk->nz_mem;
   push_decision(s, t, n, 0);
@@ -718,6 +723,7 @@ static int ssn_pipeline(kbo_session *s, uint32_t t, uint32_t n) {
   res_add(&nd->used, &tk->resreq, s->R);
   tk->node = n;
   nd->pod_cnt += 1;
+  nd->ports |= tk->port_want;
   nd->nz_cpu += tk->nz_cpu;
   nd->nz_mem += tk->nz_mem;
   push_decision(s, t, n, 1);
@@ -855,6 +861,7 @@ kbo_session *kbo_open(const kb_config *cfg, const kb_snapshot *sn, int threads) 
     nd->nz_cpu = sn->node_nz_cpu[n]; nd->nz_mem = sn->node_nz_mem[n];
     nd->pod_cnt = sn->node_pod_cnt[n];
     nd->cls = sn->node_class ? sn->node_class[n] : 0;
+    nd->ports = sn->node_ports ? sn->node_ports[n] : 0;
   }
   s->tasks = (o_task *)calloc(s->T ? s->T : 1, sizeof(o_task));
   for (uint32_t t = 0; t < s->T; t++) {
@@ -868,6 +875,8 @@ kbo_session *kbo_open(const kb_config *cfg, const kb_snapshot *sn, int threads) 
     tk->nz_cpu = sn->task_nz_cpu[t]; tk->nz_mem = sn->task_nz_mem[t];
     tk->job = sn->task_job[t];
     tk->cls = sn->task_class ? sn->task_class[t] : 0;
+    tk->port_want = sn->task_port_want ? sn->task_port_want[t] : 0;
+    tk->port_conflict = sn->task_port_conflict ? sn->task_port_conflict[t] : 0;
     tk->priority = sn->task_priority[t];
     tk->creation = sn->task_creation[t];
     tk->status = sn->task_status[t];

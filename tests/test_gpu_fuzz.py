@@ -61,6 +61,15 @@ def _case(seed):
         aff = rng.choice([0, 0, 2, 5, 30], size=(s.n_task_classes, s.n_node_classes)).astype(np.int32)
         aff[rng.uniform(size=s.n_task_classes) < 0.5] = 0
         s.class_affinity = aff
+    if seed % 4 == 1:     # host ports
+        want = np.zeros(T, np.uint64)
+        has = rng.uniform(size=T) < 0.3
+        want[has] = (np.uint64(1) << rng.randint(0, 5, size=int(has.sum())).astype(np.uint64))
+        cmask = want | np.where(want != 0, np.uint64(1) << np.uint64(5), np.uint64(0)).astype(np.uint64)   # bit 5: a wildcard sibling
+        want = np.where(rng.uniform(size=T) < 0.05, want | (np.uint64(1) << np.uint64(5)), want).astype(np.uint64)
+        cmask = cmask | want
+        s.task_port_want, s.task_port_conflict = want, cmask
+        s.node_ports = np.where(rng.uniform(size=N) < 0.2, rng.randint(1, 64, size=N), 0).astype(np.uint64)
     s._check()
     wl, wm, wb = [int(x) for x in rng.choice([0, 1, 1, 2, 5], size=3)]
     cfg = conf.load_scheduler_conf(CONF_TMPL.format(wl=wl, wm=wm, wb=wb))

@@ -197,6 +197,47 @@ def test_preferred_node_affinity(oracle_mod):
         assert_same_outcome(o3, e3, dec)
 
 
+def _with_ports(snap, seed):
+    """Random host-port bits: ~25 % of the tasks occupy 1-2 of 6 ports, some ports collide with a wildcard sibling, ~20 % of the
+    nodes already have ports in use."""
+    rng = np.random.RandomState(seed)
+    T, N = snap.n_tasks, snap.n_nodes
+    want = np.zeros(T, np.uint64)
+    has = rng.uniform(size=T) < 0.25
+    want[has] = (np.uint64(1) << rng.randint(0, 6, size=int(has.sum())).astype(np.uint64))
+    two = has & (rng.uniform(size=T) < 0.3)
+    want[two] |= (np.uint64(1) << rng.randint(0, 6, size=int(two.sum())).astype(np.uint64))
+    sibling = np.array([1, 0, 3, 2, 4, 5], np.uint64)                  # bits 0/1 and 2/3 are the same port on 0.0.0.0 / one IP
+    conf = want.copy()
+    for b in range(6):
+        conf |= np.where((want >> np.uint64(b)) & np.uint64(1), np.uint64(1) << sibling[b], np.uint64(0)).astype(np.uint64)
+    snap.task_port_want, snap.task_port_conflict = want, conf
+    used = np.zeros(N, np.uint64)
+    busy = rng.uniform(size=N) < 0.2
+    used[busy] = rng.randint(1, 64, size=int(busy.sum())).astype(np.uint64)
+    snap.node_ports = used
+    snap._check()
+    return snap
+
+
+def test_host_ports(oracle_mod):
+    """PodFitsHostPorts as a dynamic predicate: node port bits live in the dirty slots of the commit kernel."""
+    cfg = conf.load_scheduler_conf()
+    snap = _with_ports(small(3, 0.03), 11)
+    o = oracle_mod.Oracle(cfg, snap, threads=8)
+    e = engine.Engine(cfg)
+    e.load(snap)
+    em, es = e.eval_matrix(0, snap.n_tasks, 1)
+    om, os_ = o.eval_matrix(0, snap.n_tasks, 1)
+    assert np.array_equal(em, om) and np.array_equal(es, os_)
+    for window, batch in ((0, 0), (64, 3), (1024, 16)):
+        o2, e2, dec = run_both(oracle_mod, cfg, _with_ports(small(3, 0.03), 11), ["allocate", "backfill"], window=window, commit_batch=batch)
+        assert_same_outcome(o2, e2, dec)
+    # few nodes, many port-hungry pods: nodes fill up with ports, pods are turned away, jobs get abandoned
+    o3, e3, dec = run_both(oracle_mod, cfg, _with_ports(small(2, 0.1, n_nodes=12), 13), ["allocate", "backfill"])
+    assert_same_outcome(o3, e3, dec)
+
+
 def test_reference_test_tiers_on_synthetic(oracle_mod):
     """drf+proportion only (allocate_test.go tiers): no predicates, no node order -> pure tie-break path."""
     snap = small(2, 0.2)

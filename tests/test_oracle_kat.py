@@ -302,3 +302,32 @@ def test_node_affinity_priority_map_and_reduce(oracle_mod):
     o = oracle_mod.Oracle(kbm.conf.load_scheduler_conf(), snap)
     mask, score = o.eval_matrix(0, 1, 1)
     assert score.tolist() == [[0, 25, 25]] and mask.tolist() == [[6]]
+
+
+def test_host_ports_predicate_and_accounting(oracle_mod):
+    """PodFitsHostPorts over nodeinfo.HostPortInfo (vendor/.../predicates/predicates.go:1153-1175, nodeinfo/host_ports.go:107-135),
+    hand-derived: conflicts need the same protocol and port and equal IPs or a 0.0.0.0 on either side; a placed pod's ports join
+    the node's used set.  Bits (sorted universe): 0 = 0.0.0.0/TCP/80, 1 = 0.0.0.0/UDP/80, 2 = 10.0.0.1/TCP/80, 3 = 10.0.0.2/TCP/80."""
+    S = kbm.snapshot
+    nodes = [S.Node(f"n{i}", {"cpu": "4", "memory": "8Gi", "pods": "10"}) for i in range(3)]
+    pods = [S.Pod("ns", "web0", [{"cpu": "1"}], group_name="g", host_ports=[("", "", 80)]),
+            S.Pod("ns", "web1", [{"cpu": "1"}], group_name="g", host_ports=[("10.0.0.1", "TCP", 80)]),
+            S.Pod("ns", "udp", [{"cpu": "1"}], group_name="g", host_ports=[("", "UDP", 80), ("", "TCP", 0)]),
+            S.Pod("ns", "plain", [{"cpu": "1"}], group_name="g"),
+            S.Pod("kube-system", "run", [{"cpu": "1"}], node_name="n1", phase="Running", host_ports=[("10.0.0.2", "TCP", 80)])]
+    snap = S.flatten(nodes, pods, [S.PodGroup("ns", "g")], [S.Queue("default")])
+    assert snap.names["tasks"] == ["ns/plain", "ns/udp", "ns/web0", "ns/web1"]
+    assert snap.node_ports.tolist() == [0, 8, 0]
+    assert snap.task_port_want.tolist() == [0, 2, 1, 4]
+    assert snap.task_port_conflict.tolist() == [0, 2, 13, 5]          # web0 (0.0.0.0) collides with every TCP/80, web1 not with 10.0.0.2
+    o = oracle_mod.Oracle(kbm.conf.load_scheduler_conf(), snap)
+    mask, _ = o.eval_matrix(0, 4, 1)
+    assert mask[:, 0].tolist() == [7, 7, 5, 7]                        # only web0 is kept off n1 (10.0.0.2/TCP/80 in use there)
+    # three pods that all want 0.0.0.0:80 on two nodes: the third finds no node and its job is abandoned (allocate.go:144-148)
+    nodes = [S.Node(f"n{i}", {"cpu": "4", "memory": "8Gi", "pods": "10"}) for i in range(2)]
+    pods = [S.Pod("ns", f"web{i}", [{"cpu": "1"}], group_name="g", host_ports=[("", "", 80)]) for i in range(3)]
+    pods.append(S.Pod("ns", "plain", [{"cpu": "1"}], group_name="g"))
+    snap = S.flatten(nodes, pods, [S.PodGroup("ns", "g")], [S.Queue("default")])
+    o = oracle_mod.Oracle(kbm.conf.load_scheduler_conf(), snap)
+    o.run(["allocate", "backfill"])
+    assert snap.bind_map(o.binds()) == {"ns/plain": "n0", "ns/web0": "n1", "ns/web1": "n0"}
