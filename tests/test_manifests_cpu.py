@@ -129,3 +129,38 @@ status: {phase: Running}
     # the running pod occupies w1: Idle = 4000m - max(init 2000m, containers 500m)?  No: Resreq (containers) is what AddTask subtracts
     w1 = snap.names["nodes"].index("w1")
     assert snap.node_idle[0, w1] == 3500.0 and snap.node_pod_cnt[w1] == 1
+
+
+def test_host_ports_and_preferred_affinity_from_manifests():
+    text = """
+apiVersion: v1
+kind: Node
+metadata: {name: w1, labels: {disk: ssd}}
+status: {allocatable: {cpu: "4", memory: 8Gi, pods: "10"}}
+---
+apiVersion: v1
+kind: Pod
+metadata: {name: web, namespace: default, annotations: {scheduling.k8s.io/group-name: g}}
+spec:
+  affinity:
+    nodeAffinity:
+      preferredDuringSchedulingIgnoredDuringExecution:
+      - weight: 7
+        preference: {matchExpressions: [{key: disk, operator: In, values: [ssd, nvme]}]}
+  containers:
+  - name: c
+    ports: [{containerPort: 8080, hostPort: 80}, {containerPort: 9090}, {containerPort: 53, hostPort: 53, protocol: UDP, hostIP: 10.0.0.1}]
+    resources: {requests: {cpu: "1"}}
+status: {phase: Pending}
+---
+apiVersion: scheduling.incubator.k8s.io/v1alpha1
+kind: PodGroup
+metadata: {name: g, namespace: default}
+spec: {minMember: 1}
+"""
+    nodes, pods, pgs, queues = manifests.load_cluster(text)
+    assert pods[0].host_ports == [("", "", 80), ("10.0.0.1", "UDP", 53)]
+    assert pods[0].preferred_affinity == [(7, [("disk", "In", ("ssd", "nvme"))])]
+    snap = manifests.load_snapshot(text)
+    assert snap.class_affinity.tolist() == [[7]]
+    assert snap.task_port_want.tolist() == [1 | 2] and snap.task_port_conflict.tolist() == [3] and snap.node_ports.tolist() == [0]
