@@ -72,7 +72,7 @@ struct KbDev {
 // window refers to its shape through shape_slot[i].
 // everything the commit kernel needs to know about one window row, gathered contiguously so that the row i+2 can be
 // fetched with one wave-uniform (scalar) load while row i is being committed
-struct KbRowDesc {          // 72 bytes
+struct KbRowDesc {          // 56 bytes
   double init0, init1;     // InitResreq cpu, memory
   long long nzc, nzm;      // pod non-zero request
   uint32_t task, active, resmask, cls;
@@ -80,7 +80,6 @@ struct KbRowDesc {          // 72 bytes
   uint16_t flags;          // bit 0: Resreq cpu/memory == InitResreq cpu/memory (no init container raised them)
                            // bit 1: the task's class has preferred node-affinity terms (score normalised over the feasible set)
   uint32_t crow;           // the task class's row of the static-predicate table (bit nc), valid when n_node_classes <= 32
-  unsigned long long want, conf;   // host-port bits the pod occupies / that conflict with it
 };
 
 struct KbRound {

@@ -472,8 +472,6 @@ __global__ void __launch_bounds__(256) k_gather(KbDev d, KbRound r) {
   k.slot = (uint16_t)r.shape_slot[i];
   k.flags = (d.t_res[t] == k.init0 && d.t_res[(size_t)d.T + t] == k.init1) ? 1 : 0;
   if (d.aff_cls && d.aff_cls[k.cls]) k.flags |= 2;
-  k.want = d.t_want ? d.t_want[t] : 0ull;
-  k.conf = d.t_conf ? d.t_conf[t] : 0ull;
   k.crow = d.crows ? d.crows[(size_t)k.cls * 8] : 0xFFFFFFFFu;
   r.desc[i] = k;
 }
@@ -671,11 +669,11 @@ __host__ __device__ inline size_t k7_smem_bytes(uint32_t cap, uint32_t NP, int R
   return cap2 * (K5_NF8 * 8 + 8 + 8 + 3 * 4) + (size_t)cap * (8 + 8 + 12) + (size_t)(NP / 32) * 4 + (size_t)K7_B * (R > 2 ? R - 2 : 0) * 8 + sizeof(K7Hdr) + 64;
 }
 
-__device__ __forceinline__ TaskVals k7_task_vals(const KbRowDesc &k) {
+__device__ __forceinline__ TaskVals k7_task_vals(const KbCommitArgs &a, const KbRowDesc &k) {
   TaskVals tv;
   tv.init0 = k.init0; tv.init1 = k.init1; tv.nzc = k.nzc; tv.nzm = k.nzm;
   tv.cls = k.cls; tv.active = k.active; tv.task = k.task; tv.pad = 0;
-  tv.conf = k.conf;
+  tv.conf = a.has_ports ? a.dev->t_conf[k.task] : 0ull;   // host-port sessions only: straight from the task table
   return tv;
 }
 
@@ -758,7 +756,7 @@ __device__ __forceinline__ uint32_t k7_apply_slot(const KbCommitArgs &a, const K
   M.tab[(size_t)(f0 + 1) * cap2 + slot] = (unsigned long long)__double_as_longlong(__longlong_as_double((long long)M.tab[(size_t)(f0 + 1) * cap2 + slot]) - res1);
   M.tab[(size_t)K5F_NZC * cap2 + slot] += (unsigned long long)k.nzc;
   M.tab[(size_t)K5F_NZM * cap2 + slot] += (unsigned long long)k.nzm;
-  if (a.has_ports) M.ptab[slot] |= k.want;   // the pod's host ports join nodeinfo.UsedPorts()
+  if (a.has_ports) M.ptab[slot] |= a.dev->t_want[k.task];   // the pod's host ports join nodeinfo.UsedPorts()
   return kind;
 }
 
@@ -1022,7 +1020,7 @@ __global__ void __launch_bounds__(KB_K5_THREADS) k_commit(const K7KernArgs ka) {
         else if (f == 11) M.t_left[slot] = (int)v4 - (int)nxt - 1;
         else if (f == 13) {
           M.t_node[slot] = n;
-          if (a.has_ports) M.ptab[slot] = a.dev->ports[n] | k.want;
+          if (a.has_ports) M.ptab[slot] = a.dev->ports[n] | a.dev->t_want[k.task];
         }
         else if (f == 15 && k.resmask) {
           const KbDev &d = *a.dev;
@@ -1068,7 +1066,7 @@ __global__ void __launch_bounds__(KB_K5_THREADS) k_commit(const K7KernArgs ka) {
         unsigned long long key = 0ull;
         if (x < nd || H.c[x - nd] != 0ull) {
           const KbRowDesc &k = bd[H.rep[q]];
-          const TaskVals tv = k7_task_vals(k);
+          const TaskVals tv = k7_task_vals(a, k);
           const NodeVals nv = k5_slot_vals(M.tab, M.t_cls, M.t_left, cap2, x, a.has_ports ? M.ptab : nullptr);
           const uint32_t node = M.t_node[x];
           const uint32_t res = eval_pair_k5(a, tv, nv, node, a.use_crow ? &k.crow : nullptr);
@@ -1143,7 +1141,7 @@ __global__ void __launch_bounds__(KB_K5_THREADS) k_commit(const K7KernArgs ka) {
       const uint32_t q = H.q_of[p];
       {
         const KbRowDesc &k = bd[p];
-        const TaskVals tv = k7_task_vals(k);
+        const TaskVals tv = k7_task_vals(a, k);
         for (uint32_t x = tid; x < nd + p; x += KB_K5_THREADS) {
           const NodeVals nv = k5_slot_vals(M.tab, M.t_cls, M.t_left, cap2, x, a.has_ports ? M.ptab : nullptr);
           const uint32_t node = M.t_node[x];
@@ -1196,7 +1194,7 @@ __global__ void __launch_bounds__(KB_K5_THREADS) k_commit(const K7KernArgs ka) {
               M.t_left[xs] -= 1;
               k7_commit_globals<true>(a, k, i0 + r, n, kind);
               M.dlog[nlog] = xs;
-              const TaskVals tv = k7_task_vals(k);
+              const TaskVals tv = k7_task_vals(a, k);
               const NodeVals nv = k5_slot_vals(M.tab, M.t_cls, M.t_left, cap2, xs, a.has_ports ? M.ptab : nullptr);
               const uint32_t res = eval_pair_k5(a, tv, nv, n, a.use_crow ? &k.crow : nullptr);
               M.keyq[xs] = res ? KB_KEY(res & 0xFFFFu, n) : 0ull;
