@@ -105,6 +105,7 @@ struct KbRound {
   uint32_t *result;            // [8]: n_done, reason, n_dirty, list_exhausted (live rescans), window_refills
   int backfill;                // commit semantics of backfill.go (first node passing the predicates, no score)
   uint32_t batch;              // rows the commit kernel speculates per batch (0 = default)
+  uint32_t gather;             // the matrix launch also builds the row descriptors (one extra block row)
   unsigned long long *host_out;   // see KbCommitArgs
   unsigned long long seq;
   double *delta;               // optional per-node committed deltas of owned rows [NP*(2R+3)] (multi-GPU), may be nullptr

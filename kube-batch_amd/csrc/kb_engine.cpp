@@ -318,6 +318,7 @@ KbRound make_round(kb_engine *e, uint32_t n_rows, uint32_t n_mrows, uint32_t L, 
   r.seq = 0;
   r.backfill = backfill ? 1 : 0;
   r.batch = e->commit_batch;
+  r.gather = 0;
   r.delta = nullptr;
   r.own_row0 = r.own_row1 = 0;
   return r;
@@ -355,7 +356,7 @@ struct RoundCtx {
 };
 
 // upload the window e->h_rows[0..n) (task ids, shape slots, representative rows) and build the row descriptors
-RoundCtx round_prepare(kb_engine *e, uint32_t n, int fit_mode, bool backfill) {
+RoundCtx round_prepare(kb_engine *e, uint32_t n, int fit_mode, bool backfill, bool gather_in_matrix = false) {
   RoundCtx c;
   ensure_window_buffers(e, n);
   ensure_matrix_buffers(e, n, n + 1);
@@ -372,7 +373,8 @@ RoundCtx round_prepare(kb_engine *e, uint32_t n, int fit_mode, bool backfill) {
   if (backfill) c.d.score_enabled = 0;   // backfill.go:50-66 takes the first node that passes the predicates: all scores tie
   c.r = make_round(e, n, c.ns, c.L, fit_mode, backfill);
   if (e->trace_on) HIP_OK(hipMemsetAsync(e->b_trace.p, 0, e->b_trace.bytes, e->stream));
-  kb_launch_gather(c.d, c.r, e->stream);
+  c.r.gather = (gather_in_matrix && c.ns > 0) ? 1u : 0u;
+  if (!c.r.gather) kb_launch_gather(c.d, c.r, e->stream);
   return c;
 }
 
@@ -479,7 +481,7 @@ void round_collect(kb_engine *e, const RoundCtx &c, bool had_candidates, uint32_
 
 // single-GPU round: every matrix row is local
 void run_round(kb_engine *e, uint32_t n, int fit_mode, bool backfill, uint32_t &n_done, uint32_t &reason) {
-  RoundCtx c = round_prepare(e, n, fit_mode, backfill);
+  RoundCtx c = round_prepare(e, n, fit_mode, backfill, true);   // single GPU: every matrix row is local, one launch fewer
   round_candidates(e, c, 0, c.ns, e->b_keys.as<unsigned long long>());
   round_commit(e, c, e->b_keys.as<unsigned long long>(), nullptr, 0, 0);
   round_collect(e, c, true, n_done, reason);

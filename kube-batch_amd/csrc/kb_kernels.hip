@@ -161,10 +161,29 @@ __device__ __forceinline__ uint32_t eval_pair(const KbDev &d, const TaskVals &t,
 // Two tile shapes: <4 nodes/thread, 32 rows/block> for matrix-sized launches (8-byte score stores, node state amortised
 // over 32 rows) and <1 node/thread, 4 rows/block> for the small per-round launches (a few dozen distinct shapes), where
 // the work has to be spread over all 256 CUs instead of being serialised inside few threads.
+__device__ __forceinline__ void gather_row(const KbDev &d, const KbRound &r, uint32_t i) {
+  if (i >= r.n_rows) return;
+  const uint32_t t = r.rows[i];
+  KbRowDesc k;
+  k.init0 = d.t_init[t]; k.init1 = d.t_init[(size_t)d.T + t];
+  k.nzc = d.t_nzc[t]; k.nzm = d.t_nzm[t];
+  k.task = t; k.active = d.t_active[t]; k.resmask = d.t_resmask[t]; k.cls = d.t_cls[t];
+  k.slot = (uint16_t)r.shape_slot[i];
+  k.flags = (d.t_res[t] == k.init0 && d.t_res[(size_t)d.T + t] == k.init1) ? 1 : 0;
+  if (d.aff_cls && d.aff_cls[k.cls]) k.flags |= 2;
+  k.crow = d.crows ? d.crows[(size_t)k.cls * 8] : 0xFFFFFFFFu;
+  r.desc[i] = k;
+}
+
 template <int NPT, int TR>
 __global__ void __launch_bounds__(256) k_matrix(KbDev d, KbRound r) {
   __shared__ TaskVals srow[TR];
   __shared__ uint8_t ssame[TR];
+  if (r.gather && blockIdx.y == gridDim.y - 1) {   // the extra block row of a single-GPU round: the window's row descriptors
+    if (blockIdx.x == 0 && threadIdx.x == 0) reinterpret_cast<unsigned long long *>(r.result)[KB_OUT_STAMP0] = wall_clock64();
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < r.n_rows; i += gridDim.x * 256) gather_row(d, r, i);
+    return;
+  }
   const uint32_t row0 = blockIdx.y * TR;
   const uint32_t nr = min((uint32_t)TR, r.n_mrows - row0);
   if (threadIdx.x < nr) {
@@ -459,21 +478,12 @@ __global__ void __launch_bounds__(THREADS) k_argmax(KbDev d, KbRound r) {
 __device__ __forceinline__ bool bit_test(const uint32_t *bm, uint32_t n) { return (bm[n >> 5] >> (n & 31)) & 1u; }
 
 
-// window rows -> contiguous descriptors
+// window rows -> contiguous descriptors (multi-GPU rounds launch it on its own; single-GPU rounds run it as one extra block
+// row of the matrix launch)
 __global__ void __launch_bounds__(256) k_gather(KbDev d, KbRound r) {
-  uint32_t i = blockIdx.x * 256 + threadIdx.x;
+  const uint32_t i = blockIdx.x * 256 + threadIdx.x;
   if (i == 0) reinterpret_cast<unsigned long long *>(r.result)[KB_OUT_STAMP0] = wall_clock64();   // round start (constant-rate clock)
-  if (i >= r.n_rows) return;
-  uint32_t t = r.rows[i];
-  KbRowDesc k;
-  k.init0 = d.t_init[t]; k.init1 = d.t_init[(size_t)d.T + t];
-  k.nzc = d.t_nzc[t]; k.nzm = d.t_nzm[t];
-  k.task = t; k.active = d.t_active[t]; k.resmask = d.t_resmask[t]; k.cls = d.t_cls[t];
-  k.slot = (uint16_t)r.shape_slot[i];
-  k.flags = (d.t_res[t] == k.init0 && d.t_res[(size_t)d.T + t] == k.init1) ? 1 : 0;
-  if (d.aff_cls && d.aff_cls[k.cls]) k.flags |= 2;
-  k.crow = d.crows ? d.crows[(size_t)k.cls * 8] : 0xFFFFFFFFu;
-  r.desc[i] = k;
+  gather_row(d, r, i);
 }
 
 // nodeorder's NodeAffinity priority for the matrix rows whose task class has preferred terms (rare): Map = the class-pair count,
@@ -1422,10 +1432,10 @@ void kb_launch_gather(const KbDev &d, const KbRound &r, void *stream) {
 void kb_launch_matrix(const KbDev &d, const KbRound &r, void *stream) {
   if (r.n_mrows == 0) return;
   if ((size_t)r.n_mrows * d.NP >= (4u << 20)) {
-    dim3 grid(d.NP / (256 * 4), (r.n_mrows + 31) / 32);
+    dim3 grid(d.NP / (256 * 4), (r.n_mrows + 31) / 32 + (r.gather ? 1 : 0));
     hipLaunchKernelGGL((k_matrix<4, 32>), grid, dim3(256), 0, (hipStream_t)stream, d, r);
   } else {
-    dim3 grid(d.NP / 256, (r.n_mrows + 3) / 4);
+    dim3 grid(d.NP / 256, (r.n_mrows + 3) / 4 + (r.gather ? 1 : 0));
     hipLaunchKernelGGL((k_matrix<1, 4>), grid, dim3(256), 0, (hipStream_t)stream, d, r);
   }
 }
