@@ -479,14 +479,6 @@ void round_collect(kb_engine *e, const RoundCtx &c, bool had_candidates, uint32_
   e->round_no += 1;
 }
 
-// single-GPU round: every matrix row is local
-void run_round(kb_engine *e, uint32_t n, int fit_mode, bool backfill, uint32_t &n_done, uint32_t &reason) {
-  RoundCtx c = round_prepare(e, n, fit_mode, backfill, true);   // single GPU: every matrix row is local, one launch fewer
-  round_candidates(e, c, 0, c.ns, e->b_keys.as<unsigned long long>());
-  round_commit(e, c, e->b_keys.as<unsigned long long>(), nullptr, 0, 0);
-  round_collect(e, c, true, n_done, reason);
-}
-
 void check_aggregates(kb_engine *e, const OrderMachine &om) {
   // the host's running drf / proportion / gang aggregates must equal the device reduction bit for bit
   const HostSession &hs = e->hs;
@@ -510,7 +502,8 @@ struct ActionRun {
   std::vector<kb_decision> decs;
   std::vector<uint32_t> bf_list;
   size_t bf_pos = 0;
-  uint64_t popped = 0, spec_pops = 0;
+  uint64_t popped = 0, spec_pops = 0, spec_pops_next = 0;
+  std::vector<uint32_t> rows_next;   // the window speculated behind the one in flight
   double host_ms = 0, t_start = 0;
   bool active = false;
 
@@ -576,6 +569,32 @@ struct ActionRun {
     host_ms += now_ms() - t0;
     if (n == 0) popped += spec_pops;
     return n;
+  }
+
+  // While the device works on the window just launched, speculate the one after it (assuming the one in flight completes,
+  // which ~70 % do) behind a second roll-back point; promote() makes it the current window, a break rolls both back.
+  uint32_t plan_ahead(kb_engine *e) {
+    HostSession &hs = e->hs;
+    const uint32_t W = e->eff_window;
+    double t0 = now_ms();
+    om.push_checkpoint();
+    if (rows_next.size() < W) rows_next.resize(W);
+    uint32_t n = 0, t;
+    spec_pops_next = 0;
+    while (n < W && om.next(t)) {
+      spec_pops_next++;
+      if (dead[hs.t_feas_shape[t]]) { om.report(Outcome::NoFeasibleNode); continue; }
+      rows_next[n++] = t;
+      om.report(Outcome::Allocated);
+    }
+    host_ms += now_ms() - t0;
+    return n;
+  }
+  void promote(kb_engine *e, uint32_t n_next) {
+    om.pop_commit();
+    if (n_next) std::memcpy(e->h_rows.data(), rows_next.data(), sizeof(uint32_t) * n_next);
+    spec_pops = spec_pops_next;
+    if (n_next == 0) popped += spec_pops;
   }
 
   void absorb(kb_engine *e, uint32_t n, uint32_t n_done, uint32_t reason) {
@@ -1124,12 +1143,19 @@ static int run_action(kb_engine *e, uint32_t action, kb_decision *out, uint64_t 
     if (!e->loaded) throw EngineError(KB_E_STATE, "kb_session_load must precede kb_run_*");
     ActionRun run;
     run.begin(e, action);
-    for (;;) {
-      uint32_t n = run.plan(e);
-      if (n == 0) break;
+    uint32_t n = run.plan(e);
+    while (n) {
       uint32_t n_done = 0, reason = 0;
-      run_round(e, n, action == 0 ? 1 : 0, action == 1, n_done, reason);
+      RoundCtx c = round_prepare(e, n, action == 0 ? 1 : 0, action == 1, true);   // single GPU: every matrix row is local
+      round_candidates(e, c, 0, c.ns, e->b_keys.as<unsigned long long>());
+      round_commit(e, c, e->b_keys.as<unsigned long long>(), nullptr, 0, 0);
+      // fast rounds return from the launch immediately: use the wait to speculate the next window
+      const bool ahead = action == 0 && e->fast_rounds;
+      const uint32_t n_next = ahead ? run.plan_ahead(e) : 0;
+      round_collect(e, c, true, n_done, reason);
       run.absorb(e, n, n_done, reason);
+      if (ahead && reason == KB_REASON_DONE) { run.promote(e, n_next); n = n_next; }
+      else n = run.plan(e);
     }
     run.finish(e);
     if (n_out) *n_out = run.decs.size();

@@ -177,8 +177,10 @@ class OrderMachine {
   void init_allocate(const HostSession *hs, const Policy *pol);
   bool next(uint32_t &task);
   void report(Outcome o);
-  void checkpoint();
-  void rollback();
+  void checkpoint();        // roll-back point = now (drops every earlier one)
+  void push_checkpoint();   // a second roll-back point on top (the window after the one in flight is speculated behind it)
+  void pop_commit();        // the older window is confirmed: the newer roll-back point becomes the only one
+  void rollback();          // back to the OLDEST roll-back point, which stays armed
   // undo the effect of the last next(): the task it returned is handed out again by the following next()
   void rollback_last_pop() { cursor_[(uint32_t)cur_j_]--; steps--; }
   // running aggregates, compared with the device reduction after the action
@@ -195,26 +197,35 @@ class OrderMachine {
   int cur_q_ = -1, cur_j_ = -1;
   uint32_t cur_t_ = KB_NONE;
   bool inner_ = false;
-  // checkpoint: copies of the small state + first-touch journal of the per-job state
-  std::vector<uint32_t> ck_qheap_, ck_jheap_items_, ck_jheap_n_;
-  std::vector<double> ck_qalloc_, ck_qshare_;
-  int ck_cur_q_ = -1, ck_cur_j_ = -1;
-  uint32_t ck_cur_t_ = KB_NONE;
-  bool ck_inner_ = false;
-  uint64_t ck_steps_ = 0;
-  std::vector<uint32_t> stamp_, jl_jobs_, jl_cursor_;
-  std::vector<int32_t> jl_ready_;
-  std::vector<double> jl_vals_;   // per journalled job: allocated[R], share
+  // roll-back points: copies of the small state + first-touch journal of the per-job state, at most two deep
+  struct Frame {
+    std::vector<uint32_t> qheap, jheap_items, jheap_n;
+    std::vector<double> qalloc, qshare;
+    int cur_q = -1, cur_j = -1;
+    uint32_t cur_t = KB_NONE;
+    bool inner = false;
+    uint64_t steps = 0;
+    std::vector<uint32_t> jobs, cursor;
+    std::vector<int32_t> ready;
+    std::vector<double> vals;   // per journalled job: allocated[R], share
+    uint32_t epoch = 0;
+  };
+  Frame fr_[2];
+  int depth_ = 0;
+  std::vector<uint32_t> stamp_;
   uint32_t epoch_ = 0;
+  void arm(Frame &f);
+  void undo(Frame &f);
   void touch(uint32_t j) {
-    if (stamp_[j] == epoch_) return;
-    stamp_[j] = epoch_;
-    jl_jobs_.push_back(j);
-    jl_cursor_.push_back(cursor_[j]);
-    jl_ready_.push_back(ready[j]);
+    Frame &f = fr_[depth_ - 1];
+    if (stamp_[j] == f.epoch) return;
+    stamp_[j] = f.epoch;
+    f.jobs.push_back(j);
+    f.cursor.push_back(cursor_[j]);
+    f.ready.push_back(ready[j]);
     const int R = hs_->R;
-    jl_vals_.insert(jl_vals_.end(), jalloc.begin() + (size_t)j * R, jalloc.begin() + (size_t)(j + 1) * R);
-    jl_vals_.push_back(jshare[j]);
+    f.vals.insert(f.vals.end(), jalloc.begin() + (size_t)j * R, jalloc.begin() + (size_t)(j + 1) * R);
+    f.vals.push_back(jshare[j]);
   }
 
   bool job_ready(uint32_t j) const { return pol_->gang_job_ready ? ready[j] >= hs_->job_min[j] : true; }

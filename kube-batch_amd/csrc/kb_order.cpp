@@ -166,33 +166,53 @@ void OrderMachine::init_allocate(const HostSession *hs, const Policy *pol) {
   checkpoint();
 }
 
-void OrderMachine::checkpoint() {
-  epoch_++;
-  jl_jobs_.clear(); jl_cursor_.clear(); jl_ready_.clear(); jl_vals_.clear();
-  ck_qheap_ = qheap_;
-  ck_jheap_items_ = jheap_items_;
-  ck_jheap_n_ = jheap_n_;
-  ck_qalloc_ = qalloc;
-  ck_qshare_ = qshare;
-  ck_cur_q_ = cur_q_; ck_cur_j_ = cur_j_; ck_cur_t_ = cur_t_; ck_inner_ = inner_; ck_steps_ = steps;
+void OrderMachine::arm(Frame &f) {
+  f.epoch = ++epoch_;
+  f.jobs.clear(); f.cursor.clear(); f.ready.clear(); f.vals.clear();
+  f.qheap = qheap_;
+  f.jheap_items = jheap_items_;
+  f.jheap_n = jheap_n_;
+  f.qalloc = qalloc;
+  f.qshare = qshare;
+  f.cur_q = cur_q_; f.cur_j = cur_j_; f.cur_t = cur_t_; f.inner = inner_; f.steps = steps;
 }
 
-void OrderMachine::rollback() {
+void OrderMachine::undo(Frame &f) {
   const int R = hs_->R;
-  for (size_t k = 0; k < jl_jobs_.size(); k++) {
-    const uint32_t j = jl_jobs_[k];
-    cursor_[j] = jl_cursor_[k];
-    ready[j] = jl_ready_[k];
-    const double *v = &jl_vals_[k * (size_t)(R + 1)];
+  for (size_t k = f.jobs.size(); k-- > 0;) {   // newest first: a job logged twice ends with its oldest value
+    const uint32_t j = f.jobs[k];
+    cursor_[j] = f.cursor[k];
+    ready[j] = f.ready[k];
+    const double *v = &f.vals[k * (size_t)(R + 1)];
     for (int d = 0; d < R; d++) jalloc[(size_t)j * R + d] = v[d];
     jshare[j] = v[R];
   }
-  qheap_ = ck_qheap_;
-  jheap_items_ = ck_jheap_items_;
-  jheap_n_ = ck_jheap_n_;
-  qalloc = ck_qalloc_;
-  qshare = ck_qshare_;
-  cur_q_ = ck_cur_q_; cur_j_ = ck_cur_j_; cur_t_ = ck_cur_t_; inner_ = ck_inner_; steps = ck_steps_;
+  qheap_ = f.qheap;
+  jheap_items_ = f.jheap_items;
+  jheap_n_ = f.jheap_n;
+  qalloc = f.qalloc;
+  qshare = f.qshare;
+  cur_q_ = f.cur_q; cur_j_ = f.cur_j; cur_t_ = f.cur_t; inner_ = f.inner; steps = f.steps;
+}
+
+void OrderMachine::checkpoint() {
+  depth_ = 1;
+  arm(fr_[0]);
+}
+
+void OrderMachine::push_checkpoint() {
+  depth_ = 2;
+  arm(fr_[1]);
+}
+
+void OrderMachine::pop_commit() {
+  if (depth_ == 2) std::swap(fr_[0], fr_[1]);
+  depth_ = 1;
+}
+
+void OrderMachine::rollback() {
+  if (depth_ == 2) undo(fr_[1]);
+  undo(fr_[0]);
   checkpoint();   // the restored state is the new roll-back point (fresh journal)
 }
 
