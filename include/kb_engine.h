@@ -57,7 +57,7 @@
 extern "C" {
 #endif
 
-#define KB_ABI_VERSION 3u
+#define KB_ABI_VERSION 4u
 #define KB_MAX_RES 32u          /* resource dimensions: 0 = cpu (milli), 1 = memory (bytes), 2.. = scalar resources (milli) */
 #define KB_NONE 0xFFFFFFFFu
 
@@ -192,6 +192,11 @@ typedef struct kb_snapshot {
   const uint64_t *node_ports;          /* [N] */
   const uint64_t *task_port_want;      /* [T] */
   const uint64_t *task_port_conflict;  /* [T] */
+
+  /* conformance plugin (plugins/conformance/conformance.go:44-58): 1 = the pod may not be evicted (kube-system namespace or a
+     system-cluster-critical / system-node-critical priority class).  Read by preempt only (not an engine action yet: the
+     oracle restates it); NULL => no pod is protected. */
+  const uint8_t  *task_evict_protected; /* [T] */
 } kb_snapshot;
 
 /* one placement decision, in the order the reference loop would have made it */

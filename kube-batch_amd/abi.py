@@ -5,7 +5,7 @@ Only plain C types cross the boundary; the same structs are what the Go shim fil
 """
 import ctypes as C
 
-KB_ABI_VERSION = 3
+KB_ABI_VERSION = 4
 KB_MAX_RES = 32
 KB_NONE = 0xFFFFFFFF
 
@@ -65,6 +65,7 @@ SNAPSHOT_ARRAYS = [
     ("queue_weight", C.c_int32), ("queue_creation", C.c_int64),
     ("class_compat", C.c_uint8), ("class_affinity", C.c_int32),
     ("node_ports", C.c_uint64), ("task_port_want", C.c_uint64), ("task_port_conflict", C.c_uint64),
+    ("task_evict_protected", C.c_uint8),
 ]
 
 

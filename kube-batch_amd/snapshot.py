@@ -237,7 +237,8 @@ class SessionSnapshot:
         for name, ctype in abi.SNAPSHOT_ARRAYS:
             a = getattr(self, name, None)
             if a is None:
-                if name in ("class_compat", "class_affinity", "node_ports", "task_port_want", "task_port_conflict"):
+                if name in ("class_compat", "class_affinity", "node_ports", "task_port_want", "task_port_conflict",
+                            "task_evict_protected"):
                     continue
                 raise ValueError(f"snapshot field {name} missing")
             a = np.ascontiguousarray(a, dtype=_DTYPES[ctype])

@@ -350,6 +350,7 @@ typedef struct o_node {
   int32_t pod_cnt;
   uint32_t cls;
   uint64_t ports;   /* nodeinfo.UsedPorts() as interned bits (vendor/.../nodeinfo/host_ports.go) */
+  uint64_t base_ports;   /* the share of `ports` that belongs to pods outside the session */
 } o_node;
 
 typedef struct o_task {
@@ -357,6 +358,9 @@ typedef struct o_task {
   int64_t nz_cpu, nz_mem;
   uint32_t job, cls, node;
   uint64_t port_want, port_conflict;
+  uint8_t on_node;         /* the task is in some ni.Tasks (preempt bookkeeping) */
+  uint8_t node_status;     /* status of the clone ni.Tasks holds (api/node_info.go:186: the node keeps a copy taken at AddTask) */
+  uint8_t evict_protected; /* conformance: kube-system namespace or a system-critical priority class (conformance.go:44-58) */
   int32_t priority;
   int64_t creation;
   uint8_t status;
@@ -411,6 +415,8 @@ typedef struct kbo_session {
   uint32_t *bind_order; /* task ids in dispatch order */
   uint64_t n_binds;
   uint64_t evals, popped;
+  uint32_t *evictions;  /* task ids in the order stmt.Commit hands them to cache.Evict */
+  uint64_t n_evict, cap_evict;
   int panic;
   int threads;
   uint64_t task_limit;  /* cpu_baseline sample: stop the allocate loop after this many popped tasks (0 = none) */
@@ -705,6 +711,7 @@ static int ssn_allocate(kbo_session *s, uint32_t t, uint32_t n) {
   nd->ports |= tk->port_want;       /* ... including its UsedPorts (node_info.go:582-607 updateUsedPorts) */
   nd->nz_cpu += tk->nz_cpu;         /* vendor/.../nodeinfo/node_info.go:502-517 AddPod */
   nd->nz_mem += tk->nz_mem;
+  tk->node_status = KB_TASK_ALLOCATED;
   push_decision(s, t, n, 0);
   fire_allocate_event(s, t);
   if (ssn_job_ready(s, j)) {        /* session.go:277-285: dispatch every Allocated task of the job (canonical: ascending UID) */
@@ -726,6 +733,7 @@ static int ssn_pipeline(kbo_session *s, uint32_t t, uint32_t n) {
   nd->ports |= tk->port_want;
   nd->nz_cpu += tk->nz_cpu;
   nd->nz_mem += tk->nz_mem;
+  tk->node_status = KB_TASK_PIPELINED;
   push_decision(s, t, n, 1);
   fire_allocate_event(s, t);
   return 0;
@@ -875,11 +883,13 @@ kbo_session *kbo_open(const kb_config *cfg, const kb_snapshot *sn, int threads) 
     tk->nz_cpu = sn->task_nz_cpu[t]; tk->nz_mem = sn->task_nz_mem[t];
     tk->job = sn->task_job[t];
     tk->cls = sn->task_class ? sn->task_class[t] : 0;
+    tk->evict_protected = sn->task_evict_protected ? sn->task_evict_protected[t] : 0;
     tk->port_want = sn->task_port_want ? sn->task_port_want[t] : 0;
     tk->port_conflict = sn->task_port_conflict ? sn->task_port_conflict[t] : 0;
     tk->priority = sn->task_priority[t];
     tk->creation = sn->task_creation[t];
     tk->status = sn->task_status[t];
+    tk->node_status = tk->status;
     tk->node = sn->task_node ? sn->task_node[t] : KB_NONE;
   }
   s->jobs = (o_job *)calloc(s->J ? s->J : 1, sizeof(o_job));
@@ -920,7 +930,7 @@ void kbo_close(kbo_session *s) {
   if (!s) return;
   for (uint32_t j = 0; j < s->J; j++) heap_free(&s->jobs[j].tasks);
   for (uint32_t q = 0; q < s->Q; q++) heap_free(&s->queues[q].jobs);
-  free(s->nodes); free(s->tasks); free(s->jobs); free(s->queues); free(s->compat); free(s->affinity);
+  free(s->nodes); free(s->tasks); free(s->jobs); free(s->queues); free(s->compat); free(s->affinity); free(s->evictions);
   free(s->tier_begin); free(s->plugins); free(s->decisions); free(s->bind_node); free(s->bind_order);
   free(s);
 }
@@ -995,6 +1005,296 @@ done:
   heap_free(&queues);
   return rc;
 }
+
+/* ================================================================================================
+ * preempt (actions/preempt/preempt.go:45-271) with framework.Statement (framework/statement.go:36-220).
+ * Canonical orders where the reference ranges over Go maps: queues ascending QueueID, jobs ascending JobID (underRequest),
+ * a node's tasks ascending task index.  SortNodes needs no canonicalisation: sort.Reverse over Less(score, then host name)
+ * is a strict total order -> descending score, ties by DESCENDING node name (scheduler_helper.go:51-56,174-185).
+ * ============================================================================================== */
+static void fire_deallocate_event(kbo_session *s, uint32_t t) {   /* drf.go:146-156, proportion.go:224-235 */
+  o_task *tk = &s->tasks[t];
+  o_job *j = &s->jobs[tk->job];
+  if (s->has_plugin[KB_PLUGIN_DRF]) { if (res_sub(&j->drf_allocated, &tk->resreq, s->R) == KBO_PANIC) s->panic = 1; j->drf_share = drf_calc_share(s, &j->drf_allocated); }
+  if (s->has_plugin[KB_PLUGIN_PROPORTION]) { o_queue *q = &s->queues[j->queue]; if (res_sub(&q->allocated, &tk->resreq, s->R) == KBO_PANIC) s->panic = 1; prop_update_share(s, q); }
+}
+/* NodeInfo.RemoveTask (api/node_info.go:217-243): accounting by the status of the node's own clone */
+static void node_remove_task(kbo_session *s, uint32_t t) {
+  o_task *tk = &s->tasks[t];
+  o_node *nd = &s->nodes[tk->node];
+  switch (tk->node_status) {
+    case KB_TASK_RELEASING: if (res_sub(&nd->releasing, &tk->resreq, s->R) == KBO_PANIC) s->panic = 1; res_add(&nd->idle, &tk->resreq, s->R); break;
+    case KB_TASK_PIPELINED: res_add(&nd->releasing, &tk->resreq, s->R); break;
+    default: res_add(&nd->idle, &tk->resreq, s->R); break;
+  }
+  /* ni.Used.Sub(task.Resreq): Used is write-only on this path and the snapshot does not carry it (it always covers its own tasks) */
+  nd->pod_cnt -= 1;
+  nd->nz_cpu -= tk->nz_cpu;
+  nd->nz_mem -= tk->nz_mem;
+  /* host ports: UsedPorts is rebuilt from the remaining pods; with interned bits that needs the other pods' masks */
+  uint64_t ports = 0;
+  for (uint32_t i = 0; i < s->T; i++)
+    if (i != t && s->tasks[i].node == tk->node && s->tasks[i].on_node) ports |= s->tasks[i].port_want;
+  nd->ports = (nd->ports & ~tk->port_want) | ports | nd->base_ports;
+  tk->on_node = 0;
+}
+/* NodeInfo.AddTask (api/node_info.go:172-212) for a task whose session status is already `status` */
+static int node_add_task(kbo_session *s, uint32_t t, uint32_t n, int status) {
+  o_task *tk = &s->tasks[t];
+  o_node *nd = &s->nodes[n];
+  switch (status) {
+    case KB_TASK_RELEASING:
+      if (!res_less_equal(&tk->resreq, &nd->idle, s->R)) return -1;
+      if (res_sub(&nd->idle, &tk->resreq, s->R) == KBO_PANIC) { s->panic = 1; return KBO_PANIC; }
+      res_add(&nd->releasing, &tk->resreq, s->R);
+      break;
+    case KB_TASK_PIPELINED:
+      if (res_sub(&nd->releasing, &tk->resreq, s->R) == KBO_PANIC) { s->panic = 1; return KBO_PANIC; }
+      break;
+    default:
+      if (!res_less_equal(&tk->resreq, &nd->idle, s->R)) return -1;
+      if (res_sub(&nd->idle, &tk->resreq, s->R) == KBO_PANIC) { s->panic = 1; return KBO_PANIC; }
+      break;
+  }
+  res_add(&nd->used, &tk->resreq, s->R);
+  tk->node = n;
+  tk->node_status = (uint8_t)status;
+  tk->on_node = 1;
+  nd->pod_cnt += 1;
+  nd->nz_cpu += tk->nz_cpu;
+  nd->nz_mem += tk->nz_mem;
+  nd->ports |= tk->port_want;
+  return 0;
+}
+typedef struct stmt_op { uint8_t kind; uint32_t task; } stmt_op;   /* 0 evict, 1 pipeline */
+typedef struct stmt_t { stmt_op *ops; size_t n, cap; } stmt_t;
+static void stmt_push(stmt_t *st, uint8_t kind, uint32_t task) {
+  if (st->n == st->cap) { st->cap = st->cap ? st->cap * 2 : 16; st->ops = (stmt_op *)realloc(st->ops, sizeof(stmt_op) * st->cap); }
+  st->ops[st->n].kind = kind; st->ops[st->n].task = task; st->n++;
+}
+static void stmt_evict(kbo_session *s, stmt_t *st, uint32_t t) {          /* statement.go:36-69 */
+  job_set_status(s, t, KB_TASK_RELEASING);
+  node_remove_task(s, t);                                                  /* node.UpdateTask = RemoveTask + AddTask */
+  node_add_task(s, t, s->tasks[t].node, KB_TASK_RELEASING);
+  fire_deallocate_event(s, t);
+  stmt_push(st, 0, t);
+}
+static void stmt_unevict(kbo_session *s, uint32_t t) {                     /* statement.go:83-110 */
+  job_set_status(s, t, KB_TASK_RUNNING);
+  node_remove_task(s, t);
+  node_add_task(s, t, s->tasks[t].node, KB_TASK_RUNNING);
+  fire_allocate_event(s, t);
+}
+static void stmt_pipeline(kbo_session *s, stmt_t *st, uint32_t t, uint32_t n) {   /* statement.go:113-150 */
+  job_set_status(s, t, KB_TASK_PIPELINED);
+  node_add_task(s, t, n, KB_TASK_PIPELINED);
+  fire_allocate_event(s, t);
+  stmt_push(st, 1, t);
+}
+static void stmt_unpipeline(kbo_session *s, uint32_t t) {                  /* statement.go:155-190 */
+  job_set_status(s, t, KB_TASK_PENDING);
+  node_remove_task(s, t);
+  s->tasks[t].node = KB_NONE;
+  fire_deallocate_event(s, t);
+}
+static void stmt_discard(kbo_session *s, stmt_t *st) {                     /* statement.go:193-205: newest first */
+  for (size_t i = st->n; i-- > 0;) {
+    if (st->ops[i].kind == 0) stmt_unevict(s, st->ops[i].task);
+    else stmt_unpipeline(s, st->ops[i].task);
+  }
+  st->n = 0;
+}
+static void stmt_commit(kbo_session *s, stmt_t *st) {                      /* statement.go:208-220: evict -> cache.Evict */
+  for (size_t i = 0; i < st->n; i++) {
+    if (st->ops[i].kind != 0) continue;
+    if (s->n_evict == s->cap_evict) { s->cap_evict = s->cap_evict ? s->cap_evict * 2 : 64; s->evictions = (uint32_t *)realloc(s->evictions, sizeof(uint32_t) * s->cap_evict); }
+    s->evictions[s->n_evict++] = st->ops[i].task;
+  }
+  st->n = 0;
+}
+/* session_plugins.go:202-222 + gang.go:126-129 */
+static int ssn_job_pipelined(const kbo_session *s, const o_job *j) {
+  if (find_plugin_enabled(s, KB_PLUGIN_GANG, KB_EN_JOB_PIPELINED)) return j->cnt[KB_TASK_PIPELINED] + job_ready_num(j) >= j->min_available;
+  return 1;
+}
+/* session_plugins.go:121-162: per tier the intersection of the enabled plugins' candidates; the first tier that leaves a
+   non-empty set decides (a nil slice is an empty one).  Returns the number of victims written (input order kept). */
+static size_t ssn_preemptable(kbo_session *s, uint32_t preemptor, const uint32_t *preemptees, size_t n, uint32_t *victims) {
+  int init = 0;
+  size_t nv = 0;
+  uint8_t *keep = (uint8_t *)malloc(n ? n : 1);
+  for (int t = 0; t < s->n_tiers; t++) {
+    for (uint32_t p = s->tier_begin[t]; p < s->tier_begin[t + 1]; p++) {
+      const plug_opt *po = &s->plugins[p];
+      if (!(po->enabled & KB_EN_PREEMPTABLE)) continue;
+      memset(keep, 0, n ? n : 1);
+      if (po->plugin == KB_PLUGIN_CONFORMANCE) {            /* conformance.go:44-58 */
+        for (size_t i = 0; i < n; i++) keep[i] = !s->tasks[preemptees[i]].evict_protected;
+      } else if (po->plugin == KB_PLUGIN_GANG) {            /* gang.go:71-90 */
+        for (size_t i = 0; i < n; i++) {
+          const o_job *job = &s->jobs[s->tasks[preemptees[i]].job];
+          keep[i] = (job->min_available <= job_ready_num(job) - 1) || job->min_available == 1;
+        }
+      } else if (po->plugin == KB_PLUGIN_PRIORITY) {        /* priority.go:81-98 */
+        const o_job *pj = &s->jobs[s->tasks[preemptor].job];
+        for (size_t i = 0; i < n; i++) keep[i] = s->jobs[s->tasks[preemptees[i]].job].priority < pj->priority;
+      } else if (po->plugin == KB_PLUGIN_DRF) {             /* drf.go:84-109: running per-job allocation, in preemptee order */
+        const o_job *pj = &s->jobs[s->tasks[preemptor].job];
+        kbo_res lalloc = pj->drf_allocated;
+        res_add(&lalloc, &s->tasks[preemptor].resreq, s->R);
+        const double ls = drf_calc_share(s, &lalloc);
+        kbo_res *alloc = (kbo_res *)malloc(sizeof(kbo_res) * (n ? n : 1));   /* allocations[job], keyed by first occurrence */
+        uint32_t *ajob = (uint32_t *)malloc(sizeof(uint32_t) * (n ? n : 1));
+        size_t na = 0;
+        for (size_t i = 0; i < n; i++) {
+          const uint32_t jb = s->tasks[preemptees[i]].job;
+          size_t a = 0;
+          while (a < na && ajob[a] != jb) a++;
+          if (a == na) { ajob[na] = jb; alloc[na] = s->jobs[jb].drf_allocated; na++; }
+          if (res_sub(&alloc[a], &s->tasks[preemptees[i]].resreq, s->R) == KBO_PANIC) s->panic = 1;
+          const double rs = drf_calc_share(s, &alloc[a]);
+          keep[i] = (ls < rs) || (fabs(ls - rs) <= 0.000001);   /* shareDelta (drf.go:33) */
+        }
+        free(alloc); free(ajob);
+      } else {
+        continue;   /* predicates / proportion / nodeorder register no preemptable fn */
+      }
+      if (!init) {
+        nv = 0;
+        for (size_t i = 0; i < n; i++) if (keep[i]) victims[nv++] = preemptees[i];
+        init = 1;
+      } else {
+        size_t w = 0;
+        for (size_t v = 0; v < nv; v++) {
+          int in = 0;
+          for (size_t i = 0; i < n && !in; i++) in = keep[i] && preemptees[i] == victims[v];
+          if (in) victims[w++] = victims[v];
+        }
+        nv = w;
+      }
+    }
+    if (nv > 0) break;
+  }
+  free(keep);
+  return nv;
+}
+static int victim_less(void *ctx, uint32_t l, uint32_t r) { return !task_order_less(ctx, l, r); }   /* preempt.go:223-225 */
+/* preempt(): preempt.go:171-254.  mode 0: victims are Running tasks of OTHER jobs in the preemptor job's queue; mode 1: of the same job */
+static int preempt_one(kbo_session *s, stmt_t *st, uint32_t preemptor, int mode, uint8_t *feas, double *score, uint32_t *order) {
+  o_task *pt = &s->tasks[preemptor];
+  const o_job *pj = &s->jobs[pt->job];
+  eval_all_nodes(s, pt, 0, feas, score);       /* PredicateNodes with ssn.PredicateFn only, PrioritizeNodes */
+  s->evals += s->N;
+  uint32_t nf = 0;
+  for (uint32_t n = 0; n < s->N; n++) if (feas[n]) order[nf++] = n;
+  /* SortNodes: descending score, ties by descending host name (= descending canonical index): insertion into a sorted prefix */
+  for (uint32_t i = 1; i < nf; i++) {
+    uint32_t x = order[i];
+    uint32_t k = i;
+    while (k > 0 && (score[order[k - 1]] < score[x] || (score[order[k - 1]] == score[x] && order[k - 1] < x))) { order[k] = order[k - 1]; k--; }
+    order[k] = x;
+  }
+  uint32_t *pre = (uint32_t *)malloc(sizeof(uint32_t) * (s->T ? s->T : 1));
+  uint32_t *vic = (uint32_t *)malloc(sizeof(uint32_t) * (s->T ? s->T : 1));
+  int assigned = 0;
+  for (uint32_t oi = 0; oi < nf && !assigned; oi++) {
+    const uint32_t n = order[oi];
+    size_t np_ = 0;
+    for (uint32_t t = 0; t < s->T; t++) {      /* node.Tasks in canonical order, filtered (preempt.go:112-124 / :150-157) */
+      const o_task *tk = &s->tasks[t];
+      if (!tk->on_node || tk->node != n) continue;
+      if (tk->node_status != KB_TASK_RUNNING) continue;
+      if (mode == 0) { if (!(s->jobs[tk->job].queue == pj->queue && tk->job != pt->job)) continue; }
+      else if (tk->job != pt->job) continue;
+      pre[np_++] = t;
+    }
+    size_t nv = ssn_preemptable(s, preemptor, pre, np_, vic);
+    if (nv == 0) continue;                     /* validateVictims: "no victims" */
+    kbo_res all; res_zero(&all);
+    for (size_t i = 0; i < nv; i++) res_add(&all, &s->tasks[vic[i]].resreq, s->R);
+    if (!res_less_equal(&pt->init_resreq, &all, s->R)) continue;   /* "not enough resources" */
+    heap_t vq; heap_init(&vq, victim_less, s);
+    for (size_t i = 0; i < nv; i++) heap_push(&vq, vic[i]);
+    kbo_res preempted; res_zero(&preempted);
+    while (vq.n > 0) {                          /* lowest priority first (preempt.go:229-241) */
+      uint32_t v = heap_pop(&vq);
+      stmt_evict(s, st, v);
+      res_add(&preempted, &s->tasks[v].resreq, s->R);
+      if (res_less_equal(&pt->init_resreq, &preempted, s->R)) break;
+    }
+    heap_free(&vq);
+    if (res_less_equal(&pt->init_resreq, &preempted, s->R)) {      /* preempt.go:247-256 */
+      stmt_pipeline(s, st, preemptor, n);
+      assigned = 1;
+    }
+  }
+  free(pre); free(vic);
+  return assigned;
+}
+int kbo_preempt(kbo_session *s) {
+  if (s->panic) return KBO_PANIC;
+  for (uint32_t t = 0; t < s->T; t++) s->tasks[t].on_node = s->tasks[t].node != KB_NONE;
+  for (uint32_t n = 0; n < s->N; n++) {        /* ports of pods outside the session stay on the node whatever moves */
+    uint64_t mine = 0;
+    for (uint32_t t = 0; t < s->T; t++) if (s->tasks[t].on_node && s->tasks[t].node == n) mine |= s->tasks[t].port_want;
+    s->nodes[n].base_ports = s->nodes[n].ports & ~mine;
+  }
+  uint8_t *feas = (uint8_t *)malloc(s->N ? s->N : 1);
+  double *score = (double *)malloc(sizeof(double) * (s->N ? s->N : 1));
+  uint32_t *order = (uint32_t *)malloc(sizeof(uint32_t) * (s->N ? s->N : 1));
+  heap_t *qjobs = (heap_t *)calloc(s->Q ? s->Q : 1, sizeof(heap_t));     /* preemptorsMap */
+  heap_t *jtasks = (heap_t *)calloc(s->J ? s->J : 1, sizeof(heap_t));    /* preemptorTasks */
+  uint8_t *qseen = (uint8_t *)calloc(s->Q ? s->Q : 1, 1), *under = (uint8_t *)calloc(s->J ? s->J : 1, 1);
+  for (uint32_t q = 0; q < s->Q; q++) heap_init(&qjobs[q], job_order_less, s);
+  for (uint32_t j = 0; j < s->J; j++) heap_init(&jtasks[j], task_order_less, s);
+  for (uint32_t j = 0; j < s->J; j++) {                                   /* preempt.go:55-76 */
+    o_job *job = &s->jobs[j];
+    if (!job->valid || job->queue >= s->Q) continue;
+    qseen[job->queue] = 1;
+    if (job->cnt[KB_TASK_PENDING] != 0) {
+      heap_push(&qjobs[job->queue], j);
+      under[j] = 1;
+      for (uint32_t t = job->t0; t < job->t1; t++) if (s->tasks[t].status == KB_TASK_PENDING) heap_push(&jtasks[j], t);
+    }
+  }
+  stmt_t st = {0};
+  for (uint32_t q = 0; q < s->Q; q++) {
+    if (!qseen[q]) continue;
+    for (;;) {                                                             /* between jobs within the queue (preempt.go:80-139) */
+      if (qjobs[q].n == 0) break;
+      uint32_t pj = heap_pop(&qjobs[q]);
+      int assigned = 0;
+      st.n = 0;
+      for (;;) {
+        if (jtasks[pj].n == 0) break;
+        uint32_t preemptor = heap_pop(&jtasks[pj]);
+        s->popped++;
+        if (preempt_one(s, &st, preemptor, 0, feas, score, order)) assigned = 1;
+        if (ssn_job_pipelined(s, &s->jobs[pj])) { stmt_commit(s, &st); break; }
+      }
+      if (!ssn_job_pipelined(s, &s->jobs[pj])) { stmt_discard(s, &st); continue; }
+      if (assigned) heap_push(&qjobs[q], pj);
+    }
+    for (uint32_t j = 0; j < s->J; j++) {                                  /* between tasks within a job (preempt.go:142-166) */
+      if (!under[j]) continue;
+      for (;;) {
+        if (jtasks[j].n == 0) break;
+        uint32_t preemptor = heap_pop(&jtasks[j]);
+        s->popped++;
+        st.n = 0;
+        int assigned = preempt_one(s, &st, preemptor, 1, feas, score, order);
+        stmt_commit(s, &st);
+        if (!assigned) break;
+      }
+    }
+  }
+  for (uint32_t q = 0; q < s->Q; q++) heap_free(&qjobs[q]);
+  for (uint32_t j = 0; j < s->J; j++) heap_free(&jtasks[j]);
+  free(qjobs); free(jtasks); free(qseen); free(under); free(st.ops); free(feas); free(score); free(order);
+  return s->panic ? KBO_PANIC : 0;
+}
+uint64_t kbo_n_evictions(const kbo_session *s) { return s->n_evict; }
+void kbo_get_evictions(const kbo_session *s, uint32_t *out) { memcpy(out, s->evictions, sizeof(uint32_t) * s->n_evict); }
 
 /* actions/backfill/backfill.go:40-71 (jobs ascending JobID, Pending tasks ascending UID, nodes ascending name) */
 int kbo_backfill(kbo_session *s) {

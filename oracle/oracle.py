@@ -46,11 +46,12 @@ def lib():
         L = C.CDLL(so)
         L.kbo_open.restype = C.c_void_p
         L.kbo_open.argtypes = [C.POINTER(abi.Config), C.POINTER(abi.Snapshot), C.c_int]
-        for name in ("kbo_close", "kbo_allocate", "kbo_backfill"):
+        for name in ("kbo_close", "kbo_allocate", "kbo_backfill", "kbo_preempt"):
             getattr(L, name).argtypes = [C.c_void_p]
         L.kbo_allocate.restype = C.c_int
         L.kbo_backfill.restype = C.c_int
-        for name in ("kbo_n_decisions", "kbo_n_binds", "kbo_evals", "kbo_popped"):
+        L.kbo_preempt.restype = C.c_int
+        for name in ("kbo_n_decisions", "kbo_n_binds", "kbo_evals", "kbo_popped", "kbo_n_evictions"):
             getattr(L, name).restype = C.c_uint64
             getattr(L, name).argtypes = [C.c_void_p]
         L.kbo_panicked.argtypes = [C.c_void_p]
@@ -108,9 +109,22 @@ class Oracle:
         if rc != 0:
             raise RuntimeError(f"oracle backfill rc={rc}")
 
+    def preempt(self):
+        """actions/preempt/preempt.go (restated for the next engine action; the engine does not run it yet)."""
+        rc = self.L.kbo_preempt(self.h)
+        if rc != 0:
+            raise RuntimeError(f"oracle preempt rc={rc} (reference would panic)")
+
+    def evictions(self):
+        """Task ids in the order stmt.Commit hands them to cache.Evict."""
+        n = self.L.kbo_n_evictions(self.h)
+        out = np.empty(max(n, 1), np.uint32)
+        self.L.kbo_get_evictions(C.c_void_p(self.h), _p(out, C.c_uint32))
+        return out[:n]
+
     def run(self, actions):
         for a in actions:
-            {"allocate": self.allocate, "backfill": self.backfill}[a]()
+            {"allocate": self.allocate, "backfill": self.backfill, "preempt": self.preempt}[a]()
 
     def decisions(self):
         n = self.L.kbo_n_decisions(self.h)

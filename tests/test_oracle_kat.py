@@ -331,3 +331,87 @@ def test_host_ports_predicate_and_accounting(oracle_mod):
     o = oracle_mod.Oracle(kbm.conf.load_scheduler_conf(), snap)
     o.run(["allocate", "backfill"])
     assert snap.bind_map(o.binds()) == {"ns/plain": "n0", "ns/web0": "n1", "ns/web1": "n0"}
+
+
+def _preempt_tiers():
+    """preempt_test.go:162-176: one tier, conformance and gang with EnabledPreemptable only."""
+    return kbm.conf.tiers_literal([kbm.conf.PluginOption("conformance", enabled=abi.EN_PREEMPTABLE),
+                                   kbm.conf.PluginOption("gang", enabled=abi.EN_PREEMPTABLE)])
+
+
+def test_reference_preempt_cases(oracle_mod):
+    """actions/preempt/preempt_test.go:51-131, both cases: the number of evictions the FakeEvictor records (1 and 2).
+    The restatement also says WHO is evicted: victims leave in reverse task order (preempt.go:223-225 negates TaskOrderFn)."""
+    fx = kbm.fixtures
+    S = kbm.snapshot
+    rl = fx.build_resource_list
+    # case 1: one job, two running + two pending pods, node 3 cpu / 3Gi
+    snap = S.flatten(
+        nodes=[S.Node("n1", rl("3", "3Gi"))],
+        pods=[fx.build_pod("c1", "preemptee1", "n1", "Running", rl("1", "1G"), "pg1"),
+              fx.build_pod("c1", "preemptee2", "n1", "Running", rl("1", "1G"), "pg1"),
+              fx.build_pod("c1", "preemptor1", "", "Pending", rl("1", "1G"), "pg1"),
+              fx.build_pod("c1", "preemptor2", "", "Pending", rl("1", "1G"), "pg1")],
+        pod_groups=[S.PodGroup("c1", "pg1", queue="q1")], queues=[S.Queue("q1", 1)])
+    o = oracle_mod.Oracle(_preempt_tiers(), snap)
+    o.run(["preempt"])
+    ev = [snap.task_name(int(t)) for t in o.evictions()]
+    assert len(ev) == 1 and ev == ["c1/preemptee2"]
+    st, nd = o.task_state()
+    names = snap.names["tasks"]
+    # the first preemptor found no victim outside its own job (phase 1) and was consumed; the second one got the slot
+    assert st[names.index("c1/preemptor2")] == abi.TASK_PIPELINED and snap.node_name(int(nd[names.index("c1/preemptor2")])) == "n1"
+    assert st[names.index("c1/preemptor1")] == abi.TASK_PENDING and st[names.index("c1/preemptee2")] == abi.TASK_RELEASING
+    # case 2: the pending pods belong to a second job of the same queue, node 2 cpu / 2G completely used
+    snap = S.flatten(
+        nodes=[S.Node("n1", rl("2", "2G"))],
+        pods=[fx.build_pod("c1", "preemptee1", "n1", "Running", rl("1", "1G"), "pg1"),
+              fx.build_pod("c1", "preemptee2", "n1", "Running", rl("1", "1G"), "pg1"),
+              fx.build_pod("c1", "preemptor1", "", "Pending", rl("1", "1G"), "pg2"),
+              fx.build_pod("c1", "preemptor2", "", "Pending", rl("1", "1G"), "pg2")],
+        pod_groups=[S.PodGroup("c1", "pg1", queue="q1"), S.PodGroup("c1", "pg2", queue="q1")], queues=[S.Queue("q1", 1)])
+    o = oracle_mod.Oracle(_preempt_tiers(), snap)
+    o.run(["preempt"])
+    ev = [snap.task_name(int(t)) for t in o.evictions()]
+    assert ev == ["c1/preemptee2", "c1/preemptee1"]
+    st, _ = o.task_state()
+    names = snap.names["tasks"]
+    assert all(st[names.index(n)] == abi.TASK_PIPELINED for n in ("c1/preemptor1", "c1/preemptor2"))
+    idle, rel, _, _, cnt = o.node_state()
+    assert idle[0, 0] == 0.0 and rel[0, 0] == 0.0 and cnt[0] == 4      # both releasing slots are spoken for
+
+
+def test_preempt_gang_discard_and_priority(oracle_mod):
+    """Hand-derived: a gang of 3 (minAvailable 3) can only displace two running pods -> the job never becomes pipelined and the
+    whole statement is discarded (preempt.go:129-133, statement.go:193-205): no eviction, every status and the node restored.
+    With room for all three the statement commits; the priority plugin only lets lower-priority jobs be victims."""
+    fx = kbm.fixtures
+    S = kbm.snapshot
+    rl = fx.build_resource_list
+    tiers = kbm.conf.tiers_literal([kbm.conf.PluginOption("priority", enabled=abi.EN_PREEMPTABLE | abi.EN_JOB_ORDER),
+                                    kbm.conf.PluginOption("gang", enabled=abi.EN_PREEMPTABLE | abi.EN_JOB_PIPELINED)])
+
+    def cluster(n_victims, victim_prio):
+        pods = [fx.build_pod("c1", f"low{i}", "n1", "Running", rl("1", "1G"), "low") for i in range(n_victims)]
+        pods += [fx.build_pod("c1", f"high{i}", "", "Pending", rl("1", "1G"), "high") for i in range(3)]
+        return S.flatten(nodes=[S.Node("n1", rl(str(n_victims), f"{n_victims}G"))], pods=pods,
+                         pod_groups=[S.PodGroup("c1", "low", queue="q1", priority=victim_prio),
+                                     S.PodGroup("c1", "high", queue="q1", min_member=3, priority=10)], queues=[S.Queue("q1", 1)])
+
+    snap = cluster(2, 1)
+    o = oracle_mod.Oracle(tiers, snap)
+    before = [a.copy() for a in o.node_state()]
+    o.run(["preempt"])
+    assert len(o.evictions()) == 0
+    st, _ = o.task_state()
+    assert sorted(st.tolist()) == [abi.TASK_PENDING] * 3 + [abi.TASK_RUNNING] * 2
+    for a, b in zip(o.node_state(), before):
+        assert np.array_equal(a, b)
+    snap = cluster(3, 1)
+    o = oracle_mod.Oracle(tiers, snap)
+    o.run(["preempt"])
+    assert sorted(snap.task_name(int(t)) for t in o.evictions()) == ["c1/low0", "c1/low1", "c1/low2"]
+    snap = cluster(3, 10)                                              # equal priority: nobody may be preempted (priority.go:86-92)
+    o = oracle_mod.Oracle(tiers, snap)
+    o.run(["preempt"])
+    assert len(o.evictions()) == 0
