@@ -1119,14 +1119,15 @@ static int ssn_job_pipelined(const kbo_session *s, const o_job *j) {
 }
 /* session_plugins.go:121-162: per tier the intersection of the enabled plugins' candidates; the first tier that leaves a
    non-empty set decides (a nil slice is an empty one).  Returns the number of victims written (input order kept). */
-static size_t ssn_preemptable(kbo_session *s, uint32_t preemptor, const uint32_t *preemptees, size_t n, uint32_t *victims) {
+static size_t ssn_evictable(kbo_session *s, uint32_t preemptor, const uint32_t *preemptees, size_t n, uint32_t *victims, int reclaim) {
+  const uint32_t en_bit = reclaim ? KB_EN_RECLAIMABLE : KB_EN_PREEMPTABLE;   /* session_plugins.go:80-118 is the same code with EnabledReclaimable */
   int init = 0;
   size_t nv = 0;
   uint8_t *keep = (uint8_t *)malloc(n ? n : 1);
   for (int t = 0; t < s->n_tiers; t++) {
     for (uint32_t p = s->tier_begin[t]; p < s->tier_begin[t + 1]; p++) {
       const plug_opt *po = &s->plugins[p];
-      if (!(po->enabled & KB_EN_PREEMPTABLE)) continue;
+      if (!(po->enabled & en_bit)) continue;
       memset(keep, 0, n ? n : 1);
       if (po->plugin == KB_PLUGIN_CONFORMANCE) {            /* conformance.go:44-58 */
         for (size_t i = 0; i < n; i++) keep[i] = !s->tasks[preemptees[i]].evict_protected;
@@ -1135,10 +1136,24 @@ static size_t ssn_preemptable(kbo_session *s, uint32_t preemptor, const uint32_t
           const o_job *job = &s->jobs[s->tasks[preemptees[i]].job];
           keep[i] = (job->min_available <= job_ready_num(job) - 1) || job->min_available == 1;
         }
-      } else if (po->plugin == KB_PLUGIN_PRIORITY) {        /* priority.go:81-98 */
+      } else if (po->plugin == KB_PLUGIN_PRIORITY && !reclaim) {        /* priority.go:81-98 (preemptable only) */
         const o_job *pj = &s->jobs[s->tasks[preemptor].job];
         for (size_t i = 0; i < n; i++) keep[i] = s->jobs[s->tasks[preemptees[i]].job].priority < pj->priority;
-      } else if (po->plugin == KB_PLUGIN_DRF) {             /* drf.go:84-109: running per-job allocation, in preemptee order */
+      } else if (po->plugin == KB_PLUGIN_PROPORTION && reclaim) {   /* proportion.go:171-196: running per-queue allocation, in reclaimee order */
+        kbo_res *alloc = (kbo_res *)malloc(sizeof(kbo_res) * (n ? n : 1));
+        uint32_t *aq = (uint32_t *)malloc(sizeof(uint32_t) * (n ? n : 1));
+        size_t na = 0;
+        for (size_t i = 0; i < n; i++) {
+          const uint32_t q = s->jobs[s->tasks[preemptees[i]].job].queue;
+          size_t a = 0;
+          while (a < na && aq[a] != q) a++;
+          if (a == na) { aq[na] = q; alloc[na] = s->queues[q].allocated; na++; }
+          if (res_less(&alloc[a], &s->tasks[preemptees[i]].resreq, s->R)) continue;
+          if (res_sub(&alloc[a], &s->tasks[preemptees[i]].resreq, s->R) == KBO_PANIC) s->panic = 1;
+          keep[i] = res_less_equal(&s->queues[q].deserved, &alloc[a], s->R);
+        }
+        free(alloc); free(aq);
+      } else if (po->plugin == KB_PLUGIN_DRF && !reclaim) {             /* drf.go:84-109: running per-job allocation, in preemptee order */
         const o_job *pj = &s->jobs[s->tasks[preemptor].job];
         kbo_res lalloc = pj->drf_allocated;
         res_add(&lalloc, &s->tasks[preemptor].resreq, s->R);
@@ -1208,7 +1223,7 @@ static int preempt_one(kbo_session *s, stmt_t *st, uint32_t preemptor, int mode,
       else if (tk->job != pt->job) continue;
       pre[np_++] = t;
     }
-    size_t nv = ssn_preemptable(s, preemptor, pre, np_, vic);
+    size_t nv = ssn_evictable(s, preemptor, pre, np_, vic, 0);
     if (nv == 0) continue;                     /* validateVictims: "no victims" */
     kbo_res all; res_zero(&all);
     for (size_t i = 0; i < nv; i++) res_add(&all, &s->tasks[vic[i]].resreq, s->R);
@@ -1291,6 +1306,88 @@ int kbo_preempt(kbo_session *s) {
   for (uint32_t q = 0; q < s->Q; q++) heap_free(&qjobs[q]);
   for (uint32_t j = 0; j < s->J; j++) heap_free(&jtasks[j]);
   free(qjobs); free(jtasks); free(qseen); free(under); free(st.ops); free(feas); free(score); free(order);
+  return s->panic ? KBO_PANIC : 0;
+}
+/* ================================================================================================
+ * reclaim (actions/reclaim/reclaim.go:40-193): across queues, no Statement — ssn.Evict (framework/session.go:317-354) and
+ * ssn.Pipeline act immediately.  Canonical orders: jobs ascending JobID, nodes ascending name, a node's tasks ascending index.
+ * ============================================================================================== */
+static void record_eviction(kbo_session *s, uint32_t t) {
+  if (s->n_evict == s->cap_evict) { s->cap_evict = s->cap_evict ? s->cap_evict * 2 : 64; s->evictions = (uint32_t *)realloc(s->evictions, sizeof(uint32_t) * s->cap_evict); }
+  s->evictions[s->n_evict++] = t;
+}
+int kbo_reclaim(kbo_session *s) {
+  if (s->panic) return KBO_PANIC;
+  for (uint32_t t = 0; t < s->T; t++) s->tasks[t].on_node = s->tasks[t].node != KB_NONE;
+  for (uint32_t n = 0; n < s->N; n++) {
+    uint64_t mine = 0;
+    for (uint32_t t = 0; t < s->T; t++) if (s->tasks[t].on_node && s->tasks[t].node == n) mine |= s->tasks[t].port_want;
+    s->nodes[n].base_ports = s->nodes[n].ports & ~mine;
+  }
+  heap_t queues; heap_init(&queues, queue_order_less, s);
+  heap_t *qjobs = (heap_t *)calloc(s->Q ? s->Q : 1, sizeof(heap_t));
+  heap_t *jtasks = (heap_t *)calloc(s->J ? s->J : 1, sizeof(heap_t));
+  uint8_t *qseen = (uint8_t *)calloc(s->Q ? s->Q : 1, 1);
+  for (uint32_t q = 0; q < s->Q; q++) heap_init(&qjobs[q], job_order_less, s);
+  for (uint32_t j = 0; j < s->J; j++) heap_init(&jtasks[j], task_order_less, s);
+  for (uint32_t j = 0; j < s->J; j++) {                                   /* reclaim.go:54-81 */
+    o_job *job = &s->jobs[j];
+    if (!job->valid || job->queue >= s->Q) continue;
+    if (!qseen[job->queue]) { qseen[job->queue] = 1; heap_push(&queues, job->queue); }
+    if (job->cnt[KB_TASK_PENDING] != 0) {
+      heap_push(&qjobs[job->queue], j);
+      for (uint32_t t = job->t0; t < job->t1; t++) if (s->tasks[t].status == KB_TASK_PENDING) heap_push(&jtasks[j], t);
+    }
+  }
+  uint32_t *pre = (uint32_t *)malloc(sizeof(uint32_t) * (s->T ? s->T : 1));
+  uint32_t *vic = (uint32_t *)malloc(sizeof(uint32_t) * (s->T ? s->T : 1));
+  while (queues.n > 0) {                                                   /* reclaim.go:83-190 */
+    uint32_t q = heap_pop(&queues);
+    if (ssn_overused(s, q)) continue;
+    if (qjobs[q].n == 0) continue;
+    uint32_t j = heap_pop(&qjobs[q]);
+    if (jtasks[j].n == 0) continue;
+    uint32_t task = heap_pop(&jtasks[j]);
+    o_task *pt = &s->tasks[task];
+    s->popped++;
+    int assigned = 0;
+    for (uint32_t n = 0; n < s->N && !assigned; n++) {
+      s->evals++;
+      if (!plugin_predicate(s, pt, &s->nodes[n])) continue;                /* ssn.PredicateFn only */
+      size_t np_ = 0;
+      for (uint32_t t = 0; t < s->T; t++) {
+        const o_task *tk = &s->tasks[t];
+        if (!tk->on_node || tk->node != n || tk->node_status != KB_TASK_RUNNING) continue;
+        if (s->jobs[tk->job].queue != s->jobs[j].queue) pre[np_++] = t;
+      }
+      size_t nv = ssn_evictable(s, task, pre, np_, vic, 1);
+      if (nv == 0) continue;
+      kbo_res all; res_zero(&all);
+      for (size_t i = 0; i < nv; i++) res_add(&all, &s->tasks[vic[i]].resreq, s->R);
+      if (!res_less_equal(&pt->init_resreq, &all, s->R)) continue;
+      kbo_res reclaimed; res_zero(&reclaimed);
+      for (size_t i = 0; i < nv; i++) {                                    /* in victim-list order (reclaim.go:156-169) */
+        const uint32_t v = vic[i];
+        record_eviction(s, v);                                             /* ssn.Evict: cache.Evict first */
+        job_set_status(s, v, KB_TASK_RELEASING);
+        node_remove_task(s, v);
+        node_add_task(s, v, s->tasks[v].node, KB_TASK_RELEASING);
+        fire_deallocate_event(s, v);
+        res_add(&reclaimed, &s->tasks[v].resreq, s->R);
+        if (res_less_equal(&pt->init_resreq, &reclaimed, s->R)) break;
+      }
+      if (res_less_equal(&pt->init_resreq, &reclaimed, s->R)) {            /* reclaim.go:174-183 */
+        if (ssn_pipeline(s, task, n) == KBO_PANIC) break;
+        pt->on_node = 1;
+        assigned = 1;
+      }
+    }
+    if (assigned) heap_push(&queues, q);
+  }
+  heap_free(&queues);
+  for (uint32_t q = 0; q < s->Q; q++) heap_free(&qjobs[q]);
+  for (uint32_t j = 0; j < s->J; j++) heap_free(&jtasks[j]);
+  free(qjobs); free(jtasks); free(qseen); free(pre); free(vic);
   return s->panic ? KBO_PANIC : 0;
 }
 uint64_t kbo_n_evictions(const kbo_session *s) { return s->n_evict; }

@@ -46,11 +46,12 @@ def lib():
         L = C.CDLL(so)
         L.kbo_open.restype = C.c_void_p
         L.kbo_open.argtypes = [C.POINTER(abi.Config), C.POINTER(abi.Snapshot), C.c_int]
-        for name in ("kbo_close", "kbo_allocate", "kbo_backfill", "kbo_preempt"):
+        for name in ("kbo_close", "kbo_allocate", "kbo_backfill", "kbo_preempt", "kbo_reclaim"):
             getattr(L, name).argtypes = [C.c_void_p]
         L.kbo_allocate.restype = C.c_int
         L.kbo_backfill.restype = C.c_int
         L.kbo_preempt.restype = C.c_int
+        L.kbo_reclaim.restype = C.c_int
         for name in ("kbo_n_decisions", "kbo_n_binds", "kbo_evals", "kbo_popped", "kbo_n_evictions"):
             getattr(L, name).restype = C.c_uint64
             getattr(L, name).argtypes = [C.c_void_p]
@@ -115,6 +116,12 @@ class Oracle:
         if rc != 0:
             raise RuntimeError(f"oracle preempt rc={rc} (reference would panic)")
 
+    def reclaim(self):
+        """actions/reclaim/reclaim.go (restated for a later engine action; the engine does not run it yet)."""
+        rc = self.L.kbo_reclaim(self.h)
+        if rc != 0:
+            raise RuntimeError(f"oracle reclaim rc={rc} (reference would panic)")
+
     def evictions(self):
         """Task ids in the order stmt.Commit hands them to cache.Evict."""
         n = self.L.kbo_n_evictions(self.h)
@@ -124,7 +131,7 @@ class Oracle:
 
     def run(self, actions):
         for a in actions:
-            {"allocate": self.allocate, "backfill": self.backfill, "preempt": self.preempt}[a]()
+            {"allocate": self.allocate, "backfill": self.backfill, "preempt": self.preempt, "reclaim": self.reclaim}[a]()
 
     def decisions(self):
         n = self.L.kbo_n_decisions(self.h)

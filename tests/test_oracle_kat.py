@@ -415,3 +415,40 @@ def test_preempt_gang_discard_and_priority(oracle_mod):
     o = oracle_mod.Oracle(tiers, snap)
     o.run(["preempt"])
     assert len(o.evictions()) == 0
+
+
+def test_reference_reclaim_case(oracle_mod):
+    """actions/reclaim/reclaim_test.go:51-99: queue q1 holds the whole node, q2's pending pod reclaims exactly one running pod
+    (tiers: conformance + gang with EnabledReclaimable, reclaim_test.go:140-154).  Victims go in list order (reclaim.go:156-169)."""
+    fx = kbm.fixtures
+    S = kbm.snapshot
+    rl = fx.build_resource_list
+    snap = S.flatten(
+        nodes=[S.Node("n1", rl("3", "3Gi"))],
+        pods=[fx.build_pod("c1", f"preemptee{i}", "n1", "Running", rl("1", "1G"), "pg1") for i in (1, 2, 3)] +
+             [fx.build_pod("c1", "preemptor1", "", "Pending", rl("1", "1G"), "pg2")],
+        pod_groups=[S.PodGroup("c1", "pg1", queue="q1"), S.PodGroup("c1", "pg2", queue="q2")],
+        queues=[S.Queue("q1", 1), S.Queue("q2", 1)])
+    tiers = kbm.conf.tiers_literal([kbm.conf.PluginOption("conformance", enabled=abi.EN_RECLAIMABLE),
+                                    kbm.conf.PluginOption("gang", enabled=abi.EN_RECLAIMABLE)])
+    o = oracle_mod.Oracle(tiers, snap)
+    o.run(["reclaim"])
+    assert [snap.task_name(int(t)) for t in o.evictions()] == ["c1/preemptee1"]
+    st, nd = o.task_state()
+    names = snap.names["tasks"]
+    assert st[names.index("c1/preemptor1")] == abi.TASK_PIPELINED and nd[names.index("c1/preemptor1")] == 0
+    # proportion's reclaimable fn (proportion.go:171-196): a victim must leave its queue at or above its deserved share.
+    # Two equal-weight queues on 4 cpu: q1 runs 3 pods (deserved 2 cpu... but capped by its request) -> exactly one may go.
+    tiers = kbm.conf.tiers_literal([kbm.conf.PluginOption("proportion", enabled=abi.EN_RECLAIMABLE | abi.EN_QUEUE_ORDER),
+                                    kbm.conf.PluginOption("gang", enabled=abi.EN_RECLAIMABLE)])
+    snap = S.flatten(
+        nodes=[S.Node("n1", rl("4", "4G"))],
+        pods=[fx.build_pod("c1", f"run{i}", "n1", "Running", rl("1", "1G"), "pg1") for i in (1, 2, 3, 4)] +
+             [fx.build_pod("c1", f"want{i}", "", "Pending", rl("1", "1G"), "pg2") for i in (1, 2, 3)],
+        pod_groups=[S.PodGroup("c1", "pg1", queue="q1"), S.PodGroup("c1", "pg2", queue="q2")],
+        queues=[S.Queue("q1", 1), S.Queue("q2", 1)])
+    o = oracle_mod.Oracle(tiers, snap)
+    o.run(["reclaim"])
+    # deserved = 2 cpu each (water-fill over equal weights, both queues request >= 2): q1 may shrink from 4 to 2, no further;
+    # but a job gets ONE reclaim attempt per pop of its queue and is not re-pushed (reclaim.go:100-114): one eviction
+    assert len(o.evictions()) == 1
