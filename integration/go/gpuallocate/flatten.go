@@ -384,6 +384,7 @@ func flatten(ssn *framework.Session) (*flat, error) {
 	tprio := f.i32(T)
 	tstatus := f.u8(T)
 	twant, tconf := f.u64(T), f.u64(T)
+	tprot := f.u8(T)
 	jbegin := f.u32(J + 1)
 	jqueue := f.u32(J)
 	jmin, jprio := f.i32(J), f.i32(J)
@@ -418,6 +419,9 @@ func flatten(ssn *framework.Session) (*flat, error) {
 			tcreate[t] = ti.Pod.CreationTimestamp.Unix()
 			tstatus[t] = taskStatus(ti.Status)
 			twant[t], tconf[t] = ports.masks(ti.Pod)
+			if ti.Namespace == "kube-system" || ti.Pod.Spec.PriorityClassName == "system-cluster-critical" || ti.Pod.Spec.PriorityClassName == "system-node-critical" {
+				tprot[t] = 1 // plugins/conformance/conformance.go:44-58 (read by preempt / reclaim)
+			}
 			tnode[t] = C.KB_NONE
 			if idx, ok := nodeIdx[ti.NodeName]; ok && ti.NodeName != "" {
 				tnode[t] = idx
@@ -508,5 +512,6 @@ func flatten(ssn *framework.Session) (*flat, error) {
 		s.task_port_want = (*C.uint64_t)(unsafe.Pointer(&twant[0]))
 		s.task_port_conflict = (*C.uint64_t)(unsafe.Pointer(&tconf[0]))
 	}
+	s.task_evict_protected = (*C.uint8_t)(unsafe.Pointer(&tprot[0]))
 	return f, nil
 }

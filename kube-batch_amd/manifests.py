@@ -89,6 +89,7 @@ def _pod(doc, namespace: str) -> Pod:
         node_selector=dict(spec.get("nodeSelector") or {}),
         tolerations=[(t.get("key", "") or "", t.get("operator", "Equal") or "Equal", t.get("value", "") or "", t.get("effect", "") or "")
                      for t in spec.get("tolerations", []) or []],
+        priority_class_name=spec.get("priorityClassName", "") or "",
         host_ports=[(cp.get("hostIP", "") or "", cp.get("protocol", "") or "", int(cp.get("hostPort", 0) or 0))
                     for c in spec.get("containers", []) or [] for cp in c.get("ports", []) or [] if int(cp.get("hostPort", 0) or 0) > 0],
         preferred_affinity=[(int(term.get("weight", 0) or 0),

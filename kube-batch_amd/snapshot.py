@@ -98,6 +98,7 @@ class Pod:
     preferred_affinity: List[Tuple[int, List[Tuple[str, str, Tuple[str, ...]]]]] = field(default_factory=list)
     # container ports with a hostPort: (hostIP, protocol, hostPort); "" -> 0.0.0.0 / TCP (nodeinfo/host_ports.go:137-144)
     host_ports: List[Tuple[str, str, int]] = field(default_factory=list)
+    priority_class_name: str = ""       # conformance plugin: system-cluster-critical / system-node-critical are never evicted
 
 
 @dataclass
@@ -426,6 +427,7 @@ def flatten(nodes: List[Node], pods: List[Pod], pod_groups: List[PodGroup], queu
     t_prio = np.zeros(T, np.int32); t_cre = np.zeros(T, np.int64); t_st = np.zeros(T, np.uint8)
     t_node = np.full(T, abi.KB_NONE, np.uint32)
     t_want = np.zeros(T, np.uint64); t_conf = np.zeros(T, np.uint64)
+    t_prot = np.zeros(T, np.uint8)
     task_cls_keys = []
     names_tasks = []
     begin = np.zeros(J + 1, np.uint32)
@@ -441,6 +443,8 @@ def flatten(nodes: List[Node], pods: List[Pod], pod_groups: List[PodGroup], queu
             t_cre[k] = p.creation; t_st[k] = st
             want, conflict = port_masks(p)
             t_want[k] = want; t_conf[k] = conflict
+            # plugins/conformance/conformance.go:44-58
+            t_prot[k] = int(p.namespace == "kube-system" or p.priority_class_name in ("system-cluster-critical", "system-node-critical"))
             if p.node_name in nidx:
                 if account_on_node(nidx[p.node_name], st, res, nzc, nzm):
                     t_node[k] = nidx[p.node_name]
@@ -484,7 +488,7 @@ def flatten(nodes: List[Node], pods: List[Pod], pod_groups: List[PodGroup], queu
         queue_creation=np.array([q.creation for q in queues], np.int64).reshape(Q),
         class_compat=compat, class_affinity=affinity,
         node_ports=node_ports if universe else None, task_port_want=t_want if universe else None,
-        task_port_conflict=t_conf if universe else None,
+        task_port_conflict=t_conf if universe else None, task_evict_protected=t_prot if t_prot.any() else None,
         names={"nodes": [n.name for n in nodes], "tasks": names_tasks, "jobs": job_ids,
                "queues": [q.name for q in queues], "dims": ["cpu", "memory"] + sorted(scalar_names)},
     )

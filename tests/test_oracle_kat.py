@@ -452,3 +452,21 @@ def test_reference_reclaim_case(oracle_mod):
     # deserved = 2 cpu each (water-fill over equal weights, both queues request >= 2): q1 may shrink from 4 to 2, no further;
     # but a job gets ONE reclaim attempt per pop of its queue and is not re-pushed (reclaim.go:100-114): one eviction
     assert len(o.evictions()) == 1
+
+
+def test_conformance_protects_system_pods_from_preemption(oracle_mod):
+    """plugins/conformance/conformance.go:44-58: pods in kube-system or with a system-critical priority class are never victims."""
+    fx = kbm.fixtures
+    S = kbm.snapshot
+    rl = fx.build_resource_list
+    pods = [S.Pod("kube-system", "dns", [rl("1", "1G")], group_name="sys", node_name="n1", phase="Running"),
+            S.Pod("c1", "critical", [rl("1", "1G")], group_name="low", node_name="n1", phase="Running", priority_class_name="system-node-critical"),
+            S.Pod("c1", "plain", [rl("1", "1G")], group_name="low", node_name="n1", phase="Running"),
+            S.Pod("c1", "want1", [rl("1", "1G")], group_name="high"), S.Pod("c1", "want2", [rl("1", "1G")], group_name="high")]
+    snap = S.flatten(nodes=[S.Node("n1", rl("3", "3G"))], pods=pods,
+                     pod_groups=[S.PodGroup("kube-system", "sys", queue="q1"), S.PodGroup("c1", "low", queue="q1"), S.PodGroup("c1", "high", queue="q1")],
+                     queues=[S.Queue("q1", 1)])
+    assert snap.task_evict_protected.sum() == 2
+    o = oracle_mod.Oracle(_preempt_tiers(), snap)
+    o.run(["preempt"])
+    assert [snap.task_name(int(t)) for t in o.evictions()] == ["c1/plain"]
