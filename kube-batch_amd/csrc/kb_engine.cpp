@@ -223,13 +223,30 @@ Policy compile_policy(const kb_config *cfg) {
   return p;
 }
 
-template <typename K> uint32_t intern(std::map<K, uint32_t> &m, const K &k) {
-  auto it = m.find(k);
-  if (it != m.end()) return it->second;
-  uint32_t id = (uint32_t)m.size();
-  m.emplace(k, id);
-  return id;
-}
+// shape interning: fixed-length double keys -> dense ids in first-appearance order (hashed: one lookup per task at session load)
+struct Interner {
+  size_t klen = 0;
+  std::vector<double> keys;
+  std::unordered_map<uint64_t, std::vector<uint32_t>> buckets;
+  uint32_t intern(const std::vector<double> &k) {
+    if (!klen) klen = k.size();
+    uint64_t h = 0x9E3779B97F4A7C15ull;   // word-wise multiply-xorshift over the key's bit patterns
+    for (size_t i = 0; i < klen; i++) {
+      uint64_t w;
+      std::memcpy(&w, &k[i], sizeof(w));
+      h = (h ^ w) * 0xFF51AFD7ED558CCDull;
+      h ^= h >> 32;
+    }
+    std::vector<uint32_t> &ids = buckets[h];
+    for (uint32_t id : ids)
+      if (std::memcmp(&keys[(size_t)id * klen], k.data(), klen * sizeof(double)) == 0) return id;
+    const uint32_t id = (uint32_t)(keys.size() / klen);
+    keys.insert(keys.end(), k.begin(), k.end());
+    ids.push_back(id);
+    return id;
+  }
+  size_t size() const { return klen ? keys.size() / klen : 0; }
+};
 
 // window buffers: one entry per task row of a round
 void ensure_window_buffers(kb_engine *e, uint32_t rows) {
@@ -828,7 +845,7 @@ int kb_session_load(kb_engine *e, const kb_snapshot *sn) {
     std::vector<uint32_t> t_active(T, 3u);
     hs.t_res_empty.assign(T, 0);
     hs.t_init_empty.assign(T, 0);
-    std::map<std::vector<double>, uint32_t> feas_ids, row_ids;
+    Interner feas_ids, row_ids;
     hs.t_feas_shape.assign(T, 0);
     hs.t_row_shape.assign(T, 0);
     std::vector<double> key;
@@ -860,12 +877,12 @@ int kb_session_load(kb_engine *e, const kb_snapshot *sn) {
       {   // host ports: the conflict mask is part of feasibility, the wanted bits of what a commit changes
         const uint64_t conf = sn->task_port_conflict ? sn->task_port_conflict[t] : 0, want = sn->task_port_want ? sn->task_port_want[t] : 0;
         key.push_back((double)(uint32_t)(conf & 0xFFFFFFFFu)); key.push_back((double)(uint32_t)(conf >> 32));
-        hs.t_feas_shape[t] = intern(feas_ids, key);
+        hs.t_feas_shape[t] = feas_ids.intern(key);
         key.push_back((double)(uint32_t)(want & 0xFFFFFFFFu)); key.push_back((double)(uint32_t)(want >> 32));
       }
       key.push_back((double)sn->task_nz_cpu[t]);
       key.push_back((double)sn->task_nz_mem[t]);
-      hs.t_row_shape[t] = intern(row_ids, key);
+      hs.t_row_shape[t] = row_ids.intern(key);
     }
     hs.n_feas_shapes = (uint32_t)feas_ids.size();
     hs.n_row_shapes = (uint32_t)row_ids.size();
