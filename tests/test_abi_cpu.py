@@ -52,3 +52,28 @@ def test_unknown_plugin_rejected():
     conf = kbm.conf.SchedulerConf(actions=["allocate"], tiers=[[kbm.conf.PluginOption("nosuch")]])
     with pytest.raises(ValueError):
         conf.to_abi()
+
+
+def test_struct_layouts_match_the_header_as_gcc_sees_it(tmp_path):
+    """Compile include/kb_engine.h with gcc and compare sizeof / offsetof of every field of the boundary structs with the ctypes
+    mirror (kube-batch_amd/abi.py) — the Go side binds the same header through cgo, so the header is the authority."""
+    import subprocess
+    structs = {"kb_snapshot": abi.Snapshot, "kb_config": abi.Config, "kb_plugin_option": abi.PluginOption,
+               "kb_decision": abi.Decision, "kb_stats": abi.Stats}
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "kb_engine.h"', 'int main(void) {',
+             '  printf("KB_ABI_VERSION %u\\n", (unsigned)KB_ABI_VERSION);']
+    for cname, ct in structs.items():
+        lines.append(f'  printf("{cname} %zu\\n", sizeof({cname}));')
+        for fname, _ in ct._fields_:
+            lines.append(f'  printf("{cname}.{fname} %zu\\n", offsetof({cname}, {fname}));')
+    lines += ['  return 0;', '}']
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "layout"
+    subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
+    got = dict(l.split() for l in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.splitlines())
+    assert int(got["KB_ABI_VERSION"]) == abi.KB_ABI_VERSION
+    for cname, ct in structs.items():
+        assert int(got[cname]) == C.sizeof(ct), cname
+        for fname, _ in ct._fields_:
+            assert int(got[f"{cname}.{fname}"]) == getattr(ct, fname).offset, f"{cname}.{fname}"
