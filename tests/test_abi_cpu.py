@@ -77,3 +77,20 @@ def test_struct_layouts_match_the_header_as_gcc_sees_it(tmp_path):
         assert int(got[cname]) == C.sizeof(ct), cname
         for fname, _ in ct._fields_:
             assert int(got[f"{cname}.{fname}"]) == getattr(ct, fname).offset, f"{cname}.{fname}"
+
+
+def test_go_shim_sources_only_use_what_the_header_declares():
+    """The Go action / flattener cannot be compiled here (no Go toolchain): at least every C.<name> they mention and every
+    kb_snapshot field they assign must exist in include/kb_engine.h."""
+    hdr = open(os.path.join(ROOT, "include", "kb_engine.h")).read()
+    godir = os.path.join(ROOT, "integration", "go", "gpuallocate")
+    for fn in sorted(os.listdir(godir)):
+        src = open(os.path.join(godir, fn)).read()
+        for name in set(re.findall(r"\bC\.((?:kb|KB)_[A-Za-z0-9_]+)", src)):
+            assert re.search(r"\b" + re.escape(name) + r"\b", hdr), f"{fn}: C.{name} is not in the header"
+        for field in set(re.findall(r"\bs\.((?:node|task|job|queue|class|n)_[a-z_]+)\b", src)):
+            assert re.search(r"\b" + re.escape(field) + r"\b", hdr), f"{fn}: kb_snapshot.{field} is not in the header"
+    # and the other way round: every snapshot array the header declares is filled by flatten.go (or documented as optional)
+    flat = open(os.path.join(godir, "flatten.go")).read()
+    for name, _ in abi.SNAPSHOT_ARRAYS:
+        assert re.search(r"\bs\." + name + r"\b", flat), f"flatten.go never sets kb_snapshot.{name}"
