@@ -5,6 +5,7 @@ Nothing here reads /root/reference at run time.
 """
 import ctypes as C
 import importlib
+import os
 
 import numpy as np
 import pytest
@@ -470,3 +471,16 @@ def test_conformance_protects_system_pods_from_preemption(oracle_mod):
     o = oracle_mod.Oracle(_preempt_tiers(), snap)
     o.run(["preempt"])
     assert [snap.task_name(int(t)) for t in o.evictions()] == ["c1/plain"]
+
+
+def test_oracle_matches_its_committed_digests(oracle_mod):
+    """tests/golden/oracle_digests.json (made by tests/golden/make_golden.py): the parity checker must not drift silently."""
+    import json
+    import importlib.util
+    here = os.path.dirname(os.path.abspath(__file__))
+    spec = importlib.util.spec_from_file_location("make_golden", os.path.join(here, "golden", "make_golden.py"))
+    mg = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mg)
+    want = json.load(open(os.path.join(here, "golden", "oracle_digests.json")))
+    for name, idx, scale, actions in mg.CASES:
+        assert mg.digest(kbm, oracle_mod, idx, scale, actions) == want[name], name
