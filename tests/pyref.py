@@ -1,0 +1,506 @@
+"""pyref — a SECOND restatement of the reference's allocate + backfill path, pure Python, written from the Go sources (not from
+oracle/kb_oracle.c).  Test infrastructure only (small clusters; it is slow on purpose: plain dicts and loops that read like the
+Go code).  tests/test_oracle_independent.py runs it against the C oracle on random snapshots: two independent restatements
+that agree decision for decision make a transcription slip in either unlikely.  It is still not a reference run.
+
+Canonical orders wherever the Go code ranges over a map: ascending key; SelectBestNode takes the first maximum.
+"""
+import math
+from typing import Dict, List, Optional
+
+MIN_CPU, MIN_SCALAR, MIN_MEM = 10.0, 10.0, 10.0 * 1024 * 1024          # api/resource_info.go:68-70
+PENDING, ALLOCATED, PIPELINED, BINDING, BOUND, RUNNING, RELEASING, SUCCEEDED, FAILED, UNKNOWN = range(10)
+NONE = 0xFFFFFFFF
+EN_JOB_ORDER, EN_JOB_READY, EN_JOB_PIPELINED, EN_TASK_ORDER, EN_PREEMPTABLE, EN_RECLAIMABLE, EN_QUEUE_ORDER, EN_PREDICATE, EN_NODE_ORDER = (1 << i for i in range(9))
+
+
+class Resource:
+    """api.Resource (api/resource_info.go:28-38): scalars is None for a nil map."""
+
+    def __init__(self, cpu=0.0, mem=0.0, scalars: Optional[Dict[int, float]] = None):
+        self.cpu, self.mem, self.scalars = float(cpu), float(mem), scalars
+
+    def clone(self):
+        return Resource(self.cpu, self.mem, None if self.scalars is None else dict(self.scalars))
+
+    def is_empty(self):                                               # :93-105
+        if not (self.cpu < MIN_CPU and self.mem < MIN_MEM):
+            return False
+        return all(q < MIN_SCALAR for q in (self.scalars or {}).values())
+
+    def add(self, rr):                                                # :128-140
+        self.cpu += rr.cpu
+        self.mem += rr.mem
+        for name, q in (rr.scalars or {}).items():
+            if self.scalars is None:
+                self.scalars = {}
+            self.scalars[name] = self.scalars.get(name, 0.0) + q
+        return self
+
+    def sub(self, rr):                                                # :143-160
+        if not rr.less_equal(self):
+            raise ArithmeticError("Resource is not sufficient to do operation")
+        self.cpu -= rr.cpu
+        self.mem -= rr.mem
+        for name, q in (rr.scalars or {}).items():
+            if self.scalars is None:
+                return self
+            self.scalars[name] = self.scalars.get(name, 0.0) - q
+        return self
+
+    def multi(self, ratio):                                           # :217-224
+        self.cpu *= ratio
+        self.mem *= ratio
+        for name in list((self.scalars or {}).keys()):
+            self.scalars[name] *= ratio
+        return self
+
+    def less(self, rr):                                               # :227-265
+        if not self.cpu < rr.cpu or not self.mem < rr.mem:
+            return False
+        if self.scalars is None:
+            if rr.scalars is not None:
+                for q in rr.scalars.values():
+                    if q <= MIN_SCALAR:
+                        return False
+            return True
+        if rr.scalars is None:
+            return False
+        return all(q < rr.scalars.get(name, 0.0) for name, q in self.scalars.items())
+
+    def less_equal(self, rr):                                         # :268-302
+        def le(l, r, diff):
+            return l < r or math.fabs(l - r) < diff
+        if not le(self.cpu, rr.cpu, MIN_CPU) or not le(self.mem, rr.mem, MIN_MEM):
+            return False
+        if self.scalars is None:
+            return True
+        for name, q in self.scalars.items():
+            if q <= MIN_SCALAR:
+                continue
+            if rr.scalars is None:
+                return False
+            if not le(q, rr.scalars.get(name, 0.0), MIN_SCALAR):
+                return False
+        return True
+
+    def diff(self, rr):                                               # :305-337
+        inc, dec = Resource(), Resource()
+        if self.cpu > rr.cpu:
+            inc.cpu += self.cpu - rr.cpu
+        else:
+            dec.cpu += rr.cpu - self.cpu
+        if self.mem > rr.mem:
+            inc.mem += self.mem - rr.mem
+        else:
+            dec.mem += rr.mem - self.mem
+        for name, q in (self.scalars or {}).items():
+            rq = (rr.scalars or {}).get(name, 0.0)
+            tgt = inc if q > rq else dec
+            if tgt.scalars is None:
+                tgt.scalars = {}
+            tgt.scalars[name] = tgt.scalars.get(name, 0.0) + (q - rq if q > rq else rq - q)
+        return inc, dec
+
+    def get(self, name):                                              # :349-361 (0 = cpu, 1 = memory)
+        if name == 0:
+            return self.cpu
+        if name == 1:
+            return self.mem
+        return 0.0 if self.scalars is None else self.scalars.get(name, 0.0)
+
+    def names(self):                                                  # :364-372
+        return [0, 1] + sorted((self.scalars or {}).keys())
+
+
+def helpers_min(l, r):                                                # api/helpers/helpers.go:28-44
+    res = Resource(min(l.cpu, r.cpu), min(l.mem, r.mem))
+    if l.scalars is None or r.scalars is None:
+        return res
+    res.scalars = {name: min(q, r.scalars.get(name, 0.0)) for name, q in l.scalars.items()}
+    return res
+
+
+def helpers_share(l, r):                                              # api/helpers/helpers.go:47-60
+    if r == 0:
+        return 0.0 if l == 0 else 1.0
+    return l / r
+
+
+class GoHeap:
+    """container/heap (go1.13) behind util.PriorityQueue (util/priority_queue.go:26-94)."""
+
+    def __init__(self, less):
+        self.items, self.less = [], less
+
+    def __len__(self):
+        return len(self.items)
+
+    def push(self, x):
+        h = self.items
+        h.append(x)
+        j = len(h) - 1
+        while True:
+            i = (j - 1) // 2 if j > 0 else 0
+            if i == j or not self.less(h[j], h[i]):
+                break
+            h[i], h[j] = h[j], h[i]
+            j = i
+
+    def pop(self):
+        h = self.items
+        n = len(h) - 1
+        h[0], h[n] = h[n], h[0]
+        i = 0
+        while True:
+            j1 = 2 * i + 1
+            if j1 >= n or j1 < 0:
+                break
+            j = j1
+            if j1 + 1 < n and self.less(h[j1 + 1], h[j1]):
+                j = j1 + 1
+            if not self.less(h[j], h[i]):
+                break
+            h[i], h[j] = h[j], h[i]
+            i = j
+        return h.pop()
+
+
+def go_div(a, b):
+    return a // b        # operands are non-negative here: Go's truncation equals floor
+
+
+class Session:
+    def __init__(self, tiers, snap):
+        """tiers: [[(plugin name, enabled bits, {arg: int})]]; snap: kube-batch_amd SessionSnapshot."""
+        s = snap
+        self.tiers = tiers
+        self.R, self.N, self.T, self.J, self.Q = int(s.n_res), int(s.n_nodes), int(s.n_tasks), int(s.n_jobs), int(s.n_queues)
+
+        def res(mat, mask, i):
+            sc = None
+            m = int(mask[i]) if mask is not None else 0
+            if m:
+                sc = {d: float(mat[d, i]) for d in range(2, self.R) if (m >> (d - 2)) & 1}
+            return Resource(mat[0, i], mat[1, i], sc)
+
+        # api.NodeInfo: Idle has Allocatable's scalar key set (NewResource of the same list, node_info.go:49-84); Releasing
+        # starts as EmptyResource() and gains keys only through Add (node_info.go:65,154): the keys with a non-zero value
+        self.idle = [res(s.node_idle, s.node_scalar_mask, n) for n in range(self.N)]
+        self.rel = []
+        for n in range(self.N):
+            sc = {d: float(s.node_releasing[d, n]) for d in range(2, self.R) if s.node_releasing[d, n] != 0.0}
+            self.rel.append(Resource(s.node_releasing[0, n], s.node_releasing[1, n], sc or None))
+        self.alloc = [res(s.node_allocatable, s.node_scalar_mask, n) for n in range(self.N)]
+        self.acpu, self.amem = [int(x) for x in s.node_alloc_cpu], [int(x) for x in s.node_alloc_mem]
+        self.nzc, self.nzm = [int(x) for x in s.node_nz_cpu], [int(x) for x in s.node_nz_mem]
+        self.maxpods, self.podcnt = [int(x) for x in s.node_max_pods], [int(x) for x in s.node_pod_cnt]
+        self.ncls = [int(x) for x in s.node_class]
+        self.nports = [int(x) for x in s.node_ports] if getattr(s, "node_ports", None) is not None else [0] * self.N
+        # TaskInfo: InitResreq carries the keys of Resreq plus those an init container raised (pod_info.go:53-62)
+        self.resreq = [res(s.task_resreq, s.task_scalar_mask, t) for t in range(self.T)]
+        self.init = []
+        for t in range(self.T):
+            m = int(s.task_scalar_mask[t])
+            for d in range(2, self.R):
+                if s.task_init_resreq[d, t] != 0.0:
+                    m |= 1 << (d - 2)
+            self.init.append(Resource(s.task_init_resreq[0, t], s.task_init_resreq[1, t],
+                                      {d: float(s.task_init_resreq[d, t]) for d in range(2, self.R) if (m >> (d - 2)) & 1} if m else None))
+        self.tnzc, self.tnzm = [int(x) for x in s.task_nz_cpu], [int(x) for x in s.task_nz_mem]
+        self.tjob, self.tcls = [int(x) for x in s.task_job], [int(x) for x in s.task_class]
+        self.tprio, self.tcre = [int(x) for x in s.task_priority], [int(x) for x in s.task_creation]
+        self.status = [int(x) for x in s.task_status]
+        self.tnode = [int(x) for x in s.task_node]
+        want, conf = getattr(s, "task_port_want", None), getattr(s, "task_port_conflict", None)
+        self.twant = [int(x) for x in want] if want is not None else [0] * self.T
+        self.tconf = [int(x) for x in conf] if conf is not None else [0] * self.T
+        self.jbegin = [int(x) for x in s.job_task_begin]
+        self.jqueue, self.jmin = [int(x) for x in s.job_queue], [int(x) for x in s.job_min_available]
+        self.jprio, self.jcre = [int(x) for x in s.job_priority], [int(x) for x in s.job_creation]
+        self.qweight, self.qcre = [int(x) for x in s.queue_weight], [int(x) for x in s.queue_creation]
+        self.ntc, self.nnc = int(s.n_task_classes), int(s.n_node_classes)
+        self.compat = s.class_compat
+        self.affinity = getattr(s, "class_affinity", None)
+        self.decisions, self.binds, self.popped = [], {}, 0
+        self._open_plugins()
+
+    # ---- conf helpers (framework/session_plugins.go isEnabled)
+    def _opts(self):
+        for tier in self.tiers:
+            for opt in tier:
+                yield opt
+
+    def _has(self, name):
+        return any(o[0] == name for o in self._opts())
+
+    def _enabled(self, name, bit):
+        return any(o[0] == name and (o[1] & bit) for o in self._opts())
+
+    # ---- JobInfo counters (api/job_info.go:383-434)
+    def _tasks(self, j):
+        return range(self.jbegin[j], self.jbegin[j + 1])
+
+    def ready_num(self, j):
+        return sum(1 for t in self._tasks(j) if self.status[t] in (BOUND, BINDING, RUNNING, ALLOCATED, SUCCEEDED))
+
+    def job_ready(self, j):                                           # gang.go:122-125 behind session_plugins.go:182-200
+        if self._enabled("gang", EN_JOB_READY):
+            return self.ready_num(j) >= self.jmin[j]
+        return True
+
+    # ---- OnSessionOpen of drf and proportion
+    def _open_plugins(self):
+        total = Resource()
+        for n in range(self.N):
+            total.add(self.alloc[n])
+        self.total = total
+        self.jalloc = []
+        for j in range(self.J):                                       # drf.go:60-83
+            a = Resource()
+            for t in self._tasks(j):
+                if self.status[t] in (BOUND, BINDING, RUNNING, ALLOCATED):
+                    a.add(self.resreq[t])
+            self.jalloc.append(a)
+        self.jshare = [self._drf_share(a) for a in self.jalloc]
+        self.qattr = {}                                               # proportion.go:58-154
+        for j in range(self.J):
+            q = self.jqueue[j]
+            if q not in self.qattr:
+                self.qattr[q] = {"deserved": Resource(), "allocated": Resource(), "request": Resource(), "share": 0.0, "weight": self.qweight[q]}
+            a = self.qattr[q]
+            for t in self._tasks(j):
+                if self.status[t] in (BOUND, BINDING, RUNNING, ALLOCATED):
+                    a["allocated"].add(self.resreq[t])
+                    a["request"].add(self.resreq[t])
+                elif self.status[t] == PENDING:
+                    a["request"].add(self.resreq[t])
+        remaining = total.clone()
+        meet = set()
+        while True:
+            tw = sum(a["weight"] for q, a in self.qattr.items() if q not in meet)
+            if tw == 0:
+                break
+            inc_all, dec_all = Resource(), Resource()
+            for q in sorted(self.qattr):
+                a = self.qattr[q]
+                if q in meet:
+                    continue
+                old = a["deserved"].clone()
+                a["deserved"].add(remaining.clone().multi(float(a["weight"]) / float(tw)))
+                if a["request"].less(a["deserved"]):
+                    a["deserved"] = helpers_min(a["deserved"], a["request"])
+                    meet.add(q)
+                self._prop_share(a)
+                inc, dec = a["deserved"].diff(old)
+                inc_all.add(inc)
+                dec_all.add(dec)
+            remaining.sub(inc_all).add(dec_all)
+            if remaining.is_empty():
+                break
+
+    def _drf_share(self, allocated):                                  # drf.go:157-171
+        res = 0.0
+        for rn in self.total.names():
+            res = max(res, helpers_share(allocated.get(rn), self.total.get(rn)))
+        return res
+
+    def _prop_share(self, a):                                         # proportion.go:241-253
+        res = 0.0
+        for rn in a["deserved"].names():
+            res = max(res, helpers_share(a["allocated"].get(rn), a["deserved"].get(rn)))
+        a["share"] = res
+
+    # ---- tiered order functions (framework/session_plugins.go:243-331)
+    def job_less(self, l, r):
+        for name, en, _ in self._opts():
+            if not en & EN_JOB_ORDER:
+                continue
+            j = 0
+            if name == "priority":                                    # priority.go:61-77
+                j = -1 if self.jprio[l] > self.jprio[r] else (1 if self.jprio[l] < self.jprio[r] else 0)
+            elif name == "gang":                                      # gang.go:96-119
+                lr, rr = self.ready_num(l) >= self.jmin[l], self.ready_num(r) >= self.jmin[r]
+                j = 0 if (lr and rr) else (1 if lr else (-1 if rr else 0))
+            elif name == "drf":                                       # drf.go:114-130
+                j = 0 if self.jshare[l] == self.jshare[r] else (-1 if self.jshare[l] < self.jshare[r] else 1)
+            else:
+                continue
+            if j != 0:
+                return j < 0
+        if self.jcre[l] == self.jcre[r]:
+            return l < r
+        return self.jcre[l] < self.jcre[r]
+
+    def queue_less(self, l, r):
+        for name, en, _ in self._opts():
+            if name == "proportion" and en & EN_QUEUE_ORDER:          # proportion.go:156-169
+                ls, rs = self.qattr[l]["share"], self.qattr[r]["share"]
+                if ls != rs:
+                    return ls < rs
+        if self.qcre[l] == self.qcre[r]:
+            return l < r
+        return self.qcre[l] < self.qcre[r]
+
+    def task_less(self, l, r):
+        for name, en, _ in self._opts():
+            if name == "priority" and en & EN_TASK_ORDER:             # priority.go:40-56
+                if self.tprio[l] != self.tprio[r]:
+                    return self.tprio[l] > self.tprio[r]
+        if self.tcre[l] == self.tcre[r]:
+            return l < r
+        return self.tcre[l] < self.tcre[r]
+
+    def overused(self, q):                                            # proportion.go:198-209 (no Enabled* gate, session_plugins.go:165-179)
+        if not self._has("proportion"):
+            return False
+        a = self.qattr[q]
+        return a["deserved"].less_equal(a["allocated"])
+
+    # ---- predicates plugin (plugins/predicates/predicates.go:123-265) with the static checks folded into classes
+    def plugin_predicate(self, t, n):
+        if not self._enabled("predicates", EN_PREDICATE):
+            return True
+        if self.maxpods[n] <= self.podcnt[n]:
+            return False
+        if self.compat is not None:
+            bit = self.tcls[t] * self.nnc + self.ncls[n]
+            if not (int(self.compat[bit >> 3]) >> (bit & 7)) & 1:
+                return False
+        return (self.nports[n] & self.tconf[t]) == 0
+
+    # ---- nodeorder (plugins/nodeorder/nodeorder.go:107-168 over vendor/.../priorities)
+    def _weights(self):
+        w = {"leastrequested.weight": 1, "mostrequested.weight": 0, "nodeaffinity.weight": 1, "podaffinity.weight": 1, "balancedresource.weight": 1}
+        for name, en, args in self._opts():
+            if name == "nodeorder":
+                w.update(args or {})
+        return w
+
+    def prioritize(self, t, feasible):
+        """util.PrioritizeNodes (util/scheduler_helper.go:89-171): map, reduce, weighted sum."""
+        if not self._enabled("nodeorder", EN_NODE_ORDER):
+            return {n: 0.0 for n in feasible}
+        w = self._weights()
+        counts = {}
+        scores = {}
+        for n in feasible:
+            rc, rm = self.nzc[n] + self.tnzc[t], self.nzm[n] + self.tnzm[t]
+            ac, am = self.acpu[n], self.amem[n]
+            lc = 0 if (ac == 0 or rc > ac) else go_div((ac - rc) * 10, ac)
+            lm = 0 if (am == 0 or rm > am) else go_div((am - rm) * 10, am)
+            mc = 0 if (ac == 0 or rc > ac) else go_div(rc * 10, ac)
+            mm = 0 if (am == 0 or rm > am) else go_div(rm * 10, am)
+            cf = 1.0 if ac == 0 else float(rc) / float(ac)
+            mf = 1.0 if am == 0 else float(rm) / float(am)
+            bal = 0 if (cf >= 1 or mf >= 1) else int((1 - math.fabs(cf - mf)) * 10.0)
+            counts[n] = int(self.affinity[self.tcls[t]][self.ncls[n]]) if self.affinity is not None else 0
+            scores[n] = [go_div(lc + lm, 2), go_div(mc + mm, 2), 0, 0, bal]
+        mx = max(counts.values()) if counts else 0                    # NormalizeReduce(10, false) (reduce.go:28-63)
+        for n in feasible:
+            scores[n][2] = go_div(10 * counts[n], mx) if mx > 0 else counts[n]
+        ws = [w["leastrequested.weight"], w["mostrequested.weight"], w["nodeaffinity.weight"], w["podaffinity.weight"], w["balancedresource.weight"]]
+        return {n: float(sum(float(sc * wt) for sc, wt in zip(scores[n], ws))) for n in feasible}
+
+    # ---- Session.Allocate / Pipeline (framework/session.go:194-288)
+    def _fire_allocate(self, t):
+        j = self.tjob[t]
+        if self._has("drf"):
+            self.jalloc[j].add(self.resreq[t])
+            self.jshare[j] = self._drf_share(self.jalloc[j])
+        if self._has("proportion"):
+            a = self.qattr[self.jqueue[j]]
+            a["allocated"].add(self.resreq[t])
+            self._prop_share(a)
+
+    def _join_node(self, t, n):
+        self.tnode[t] = n
+        self.podcnt[n] += 1
+        self.nzc[n] += self.tnzc[t]
+        self.nzm[n] += self.tnzm[t]
+        self.nports[n] |= self.twant[t]
+
+    def ssn_allocate(self, t, n):
+        self.status[t] = ALLOCATED                                    # session.go:243, before node.AddTask
+        if not self.resreq[t].less_equal(self.idle[n]):               # node_info.go:161-167
+            return False
+        self.idle[n].sub(self.resreq[t])
+        self._join_node(t, n)
+        self.decisions.append((t, n, 0))
+        self._fire_allocate(t)
+        j = self.tjob[t]
+        if self.job_ready(j):                                         # session.go:277-285
+            for i in self._tasks(j):
+                if self.status[i] == ALLOCATED:
+                    self.binds[i] = self.tnode[i]
+                    self.status[i] = BINDING
+        return True
+
+    def ssn_pipeline(self, t, n):
+        self.status[t] = PIPELINED
+        self.rel[n].sub(self.resreq[t])                               # node_info.go:196-197
+        self._join_node(t, n)
+        self.decisions.append((t, n, 1))
+        self._fire_allocate(t)
+
+    # ---- actions
+    def allocate(self):                                               # actions/allocate/allocate.go:43-194
+        queues = GoHeap(self.queue_less)
+        jobs_map = {}
+        for j in range(self.J):
+            q = self.jqueue[j]
+            if q >= self.Q:
+                continue
+            queues.push(q)
+            jobs_map.setdefault(q, GoHeap(self.job_less)).push(j)
+        pending = {}
+        while len(queues):
+            q = queues.pop()
+            if self.overused(q):
+                continue
+            jobs = jobs_map.get(q)
+            if jobs is None or not len(jobs):
+                continue
+            j = jobs.pop()
+            if j not in pending:
+                tasks = GoHeap(self.task_less)
+                for t in self._tasks(j):
+                    if self.status[t] == PENDING and not self.resreq[t].is_empty():
+                        tasks.push(t)
+                pending[j] = tasks
+            tasks = pending[j]
+            while len(tasks):
+                t = tasks.pop()
+                self.popped += 1
+                feasible = [n for n in range(self.N)
+                            if (self.init[t].less_equal(self.idle[n]) or self.init[t].less_equal(self.rel[n])) and self.plugin_predicate(t, n)]
+                if not feasible:
+                    break
+                scores = self.prioritize(t, feasible)
+                best = max(scores.values())
+                n = min(k for k, v in scores.items() if v == best)    # canonical first maximum
+                if self.init[t].less_equal(self.idle[n]):
+                    self.ssn_allocate(t, n)
+                elif self.init[t].less_equal(self.rel[n]):
+                    self.ssn_pipeline(t, n)
+                if self.job_ready(j) and len(tasks):
+                    jobs.push(j)
+                    break
+            queues.push(q)
+
+    def backfill(self):                                               # actions/backfill/backfill.go:40-71
+        for j in range(self.J):
+            for t in self._tasks(j):
+                if self.status[t] != PENDING or not self.init[t].is_empty():
+                    continue
+                self.popped += 1
+                for n in range(self.N):
+                    if not self.plugin_predicate(t, n):
+                        continue
+                    if self.ssn_allocate(t, n):
+                        break
+
+    def run(self, actions):
+        for a in actions:
+            getattr(self, a)()
+        return self

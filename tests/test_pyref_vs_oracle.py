@@ -1,0 +1,172 @@
+"""The whole allocate + backfill loop restated twice — oracle/kb_oracle.c (C) and tests/pyref.py (pure Python, written from the
+Go sources independently) — must agree decision for decision, bind for bind and bit for bit in the final node state and shares on
+small random clusters that exercise releasing capacity (Pipeline), init containers, scalar resources with nil-map semantics,
+priorities, pod caps, static classes, preferred node affinity and host ports.  See DESIGN.md §5."""
+import importlib
+
+import numpy as np
+import pytest
+
+import pyref
+
+kbm = importlib.import_module("kube-batch_amd")
+abi, conf, snapmod = kbm.abi, kbm.conf, kbm.snapshot
+
+CONF_TMPL = """
+actions: "allocate, backfill"
+tiers:
+- plugins:
+  - name: priority
+  - name: gang
+- plugins:
+  - name: drf
+  - name: predicates
+  - name: proportion
+  - name: nodeorder
+    arguments:
+      leastrequested.weight: {wl}
+      mostrequested.weight: {wm}
+      nodeaffinity.weight: {wa}
+      balancedresource.weight: {wb}
+"""
+
+CONF_NO_SHARES = """
+actions: "allocate, backfill"
+tiers:
+- plugins:
+  - name: priority
+  - name: gang
+  - name: predicates
+  - name: nodeorder
+"""
+
+
+def _case(seed):
+    rng = np.random.RandomState(7000 + seed)
+    R = int(rng.choice([2, 3, 5]))
+    p = snapmod.SynthParams(
+        n_tasks=int(rng.randint(30, 260 if seed < 60 else 1200)), n_nodes=int(rng.randint(3, 40 if seed < 60 else 120)), n_queues=int(rng.randint(1, 5)), n_res=R,
+        seed=snapmod.SEED_BASE + 900 + seed, preload_node_frac=float(rng.uniform(0, 0.8)), running_job_frac=float(rng.uniform(0, 0.3)),
+        best_effort_frac=float(rng.uniform(0, 0.15)), no_mem_key_frac=float(rng.uniform(0, 0.2)), scalar_job_frac=float(rng.uniform(0, 0.6)),
+        zone_selector_frac=float(rng.uniform(0, 0.4)), n_zones=int(rng.randint(1, 5)))
+    s = snapmod.synth(p)
+    N, T = s.n_nodes, s.n_tasks
+    rel = rng.uniform(size=N) < rng.uniform(0, 0.6)
+    s.node_releasing[0] = np.where(rel, rng.choice([500, 1000, 4000, 16000], size=N), 0).astype(np.float64)
+    s.node_releasing[1] = np.where(rel, rng.choice([1, 4, 16, 64], size=N) * float(1 << 30), 0)
+    for d in range(2, R):
+        s.node_releasing[d] = np.where(rel & (s.node_allocatable[d] > 0), 1000.0 * rng.randint(0, 3, size=N), 0)
+    pending = (s.task_status == abi.TASK_PENDING) & (s.task_resreq[0] > 0)
+    bump = pending & (rng.uniform(size=T) < rng.uniform(0, 0.3))
+    s.task_init_resreq[0] = np.where(bump, s.task_resreq[0] + rng.choice([100, 500, 2000], size=T), s.task_init_resreq[0])
+    s.task_priority[:] = rng.choice([1, 1, 5, 9], size=T).astype(np.int32)
+    tight = rng.uniform(size=N) < 0.3
+    s.node_max_pods[:] = np.where(tight, s.node_pod_cnt + rng.randint(0, 6, size=N), s.node_max_pods).astype(np.int32)
+    if seed % 3 == 0:
+        aff = rng.choice([0, 0, 2, 5, 30], size=(s.n_task_classes, s.n_node_classes)).astype(np.int32)
+        aff[rng.uniform(size=s.n_task_classes) < 0.4] = 0
+        s.class_affinity = aff
+    if seed % 4 == 1:
+        want = np.zeros(T, np.uint64)
+        has = rng.uniform(size=T) < 0.3
+        want[has] = (np.uint64(1) << rng.randint(0, 5, size=int(has.sum())).astype(np.uint64))
+        cmask = want | np.where(want != 0, np.uint64(1) << np.uint64(5), np.uint64(0)).astype(np.uint64)
+        s.task_port_want, s.task_port_conflict = want, cmask
+        s.node_ports = np.where(rng.uniform(size=N) < 0.2, rng.randint(1, 64, size=N), 0).astype(np.uint64)
+    s._check()
+    if seed % 5 == 4:
+        cfg = conf.load_scheduler_conf(CONF_NO_SHARES)
+    else:
+        wl, wm, wa, wb = [int(x) for x in rng.choice([0, 1, 1, 2, 5], size=4)]
+        cfg = conf.load_scheduler_conf(CONF_TMPL.format(wl=wl, wm=wm, wa=wa, wb=wb))
+    return cfg, s
+
+
+def _tiers(cfg):
+    out = []
+    for tier in cfg.tiers:
+        opts = []
+        for po in tier:
+            args = {}
+            for k, v in (po.arguments or {}).items():
+                try:
+                    args[k] = int(str(v), 10)      # framework/arguments.go:29-46: a value Atoi rejects leaves the default
+                except ValueError:
+                    pass
+            opts.append((po.name, po.enabled, args))
+        out.append(opts)
+    return out
+
+
+@pytest.mark.parametrize("seed", range(80))
+def test_python_restatement_equals_c_oracle(oracle_mod, seed):
+    cfg, snap = _case(seed)
+    o = oracle_mod.Oracle(cfg, snap)
+    o.run(["allocate", "backfill"])
+    p = pyref.Session(_tiers(cfg), snap).run(["allocate", "backfill"])
+
+    od = o.decisions()
+    pd = np.array(p.decisions, dtype=np.uint32).reshape(-1, 3)
+    assert pd.shape == od.shape, (seed, pd.shape, od.shape)
+    assert np.array_equal(pd, od), f"seed {seed}: first divergence at decision {int(np.argmax((pd != od).any(axis=1)))}"
+    pb = np.full(snap.n_tasks, abi.KB_NONE, np.uint32)
+    for t, n in p.binds.items():
+        pb[t] = n
+    assert np.array_equal(pb, o.binds())
+    idle, rel, nzc, nzm, cnt = o.node_state()
+    for n in range(snap.n_nodes):
+        for d in range(snap.n_res):
+            assert p.idle[n].get(d) == idle[d, n], (seed, n, d)
+            assert p.rel[n].get(d) == rel[d, n], (seed, n, d)
+    assert np.array_equal(np.array(p.nzc), nzc) and np.array_equal(np.array(p.nzm), nzm) and np.array_equal(np.array(p.podcnt), cnt)
+    if any(po.name == "drf" for t in cfg.tiers for po in t):
+        js, qs, des = o.shares()
+        assert np.array_equal(np.array(p.jshare), js)
+        for q, a in p.qattr.items():
+            assert a["share"] == qs[q], (seed, q)
+            for d in range(snap.n_res):
+                assert a["deserved"].get(d) == des[d, q], (seed, q, d)
+    st, nd = o.task_state()
+    assert np.array_equal(np.array(p.status, np.uint8), st)
+    assert o.popped == p.popped
+    o.close()
+
+
+# ---- the Python restatement against the reference's own known answers (the same ones tests/test_oracle_kat.py pins the C oracle to)
+fixtures = importlib.import_module("kube-batch_amd.fixtures")
+
+
+@pytest.mark.parametrize("case", range(2))
+def test_python_restatement_allocate_reference_cases(case):
+    """pkg/scheduler/actions/allocate/allocate_test.go:38-212 TestAllocate"""
+    name, snap, expected = fixtures.allocate_cases()[case]
+    p = pyref.Session(_tiers(fixtures.allocate_test_tiers()), snap).run(["allocate"])
+    pb = np.full(snap.n_tasks, abi.KB_NONE, np.uint32)
+    for t, n in p.binds.items():
+        pb[t] = n
+    assert snap.bind_map(pb) == expected, name
+
+
+def test_python_restatement_proportion_tutorial_example():
+    """doc/usage/tutorial.md:297-330: deserved = (3 cpu, 9 Gi) and (6 cpu, 18 Gi) for weights 2 and 4"""
+    Gi = 1 << 30
+    pods = [snapmod.Pod("q1", f"p{i}", [{"cpu": "1", "memory": "2Gi"}], group_name="j1") for i in range(5)]
+    pods += [snapmod.Pod("q2", f"p{i}", [{"cpu": "1", "memory": "2Gi"}], group_name="j2") for i in range(10)]
+    snap = snapmod.flatten(
+        nodes=[snapmod.Node("n1", {"cpu": "6", "memory": "15Gi", "pods": "110"}),
+               snapmod.Node("n2", {"cpu": "3", "memory": "12Gi", "pods": "110"})],
+        pods=pods,
+        pod_groups=[snapmod.PodGroup("q1", "j1", queue="queue1"), snapmod.PodGroup("q2", "j2", queue="queue2")],
+        queues=[snapmod.Queue("queue1", 2), snapmod.Queue("queue2", 4)])
+    p = pyref.Session(_tiers(conf.load_scheduler_conf()), snap)
+    assert [p.qattr[0]["deserved"].cpu, p.qattr[0]["deserved"].mem] == [3000.0, 9.0 * Gi]
+    assert [p.qattr[1]["deserved"].cpu, p.qattr[1]["deserved"].mem] == [6000.0, 18.0 * Gi]
+
+
+def test_python_restatement_example_job_spread():
+    """BASELINE config 1: example/job.yaml on 3 nodes spreads 2/2/2"""
+    cfg, snap = fixtures.example_job()
+    p = pyref.Session(_tiers(cfg), snap).run(["allocate"])
+    assert len(p.binds) == 6
+    assert sorted(np.bincount(list(p.binds.values()), minlength=3).tolist()) == [2, 2, 2]
+    assert [d[1] for d in p.decisions[:3]] == [0, 1, 2]
