@@ -702,7 +702,10 @@ static int ssn_allocate(kbo_session *s, uint32_t t, uint32_t n) {
   o_node *nd = &s->nodes[n];
   o_job *j = &s->jobs[tk->job];
   job_set_status(s, t, KB_TASK_ALLOCATED);                          /* session.go:243 (before node.AddTask) */
-  /* node.AddTask: api/node_info.go:172-212, status Allocated -> allocateIdleResource (node_info.go:161-167) */
+  /* node.AddTask: api/node_info.go:172-212.  :173-176 task.NodeName is sticky (RemoveTask never clears it: a task a discarded
+     statement un-pipelined keeps its old NodeName and cannot join another node); :178-182 already in ni.Tasks */
+  if ((tk->node != KB_NONE && tk->node != n) || tk->on_node) return -1;
+  /* status Allocated -> allocateIdleResource (node_info.go:161-167) */
   if (!res_less_equal(&tk->resreq, &nd->idle, s->R)) return -1;     /* "Selected node NotReady": returns before callbacks */
   if (res_sub(&nd->idle, &tk->resreq, s->R) == KBO_PANIC) { s->panic = 1; return KBO_PANIC; }
   res_add(&nd->used, &tk->resreq, s->R);
@@ -712,6 +715,7 @@ static int ssn_allocate(kbo_session *s, uint32_t t, uint32_t n) {
   nd->nz_cpu += tk->nz_cpu;         /* vendor/.../nodeinfo/node_info.go:502-517 AddPod */
   nd->nz_mem += tk->nz_mem;
   tk->node_status = KB_TASK_ALLOCATED;
+  tk->on_node = 1;
   push_decision(s, t, n, 0);
   fire_allocate_event(s, t);
   if (ssn_job_ready(s, j)) {        /* session.go:277-285: dispatch every Allocated task of the job (canonical: ascending UID) */
@@ -725,6 +729,7 @@ static int ssn_pipeline(kbo_session *s, uint32_t t, uint32_t n) {
   o_task *tk = &s->tasks[t];
   o_node *nd = &s->nodes[n];
   job_set_status(s, t, KB_TASK_PIPELINED);
+  if ((tk->node != KB_NONE && tk->node != n) || tk->on_node) return -1;   /* node_info.go:173-182, error returned before the handlers */
   /* node.AddTask with status Pipelined: node_info.go:196-197 Releasing.Sub(Resreq) */
   if (res_sub(&nd->releasing, &tk->resreq, s->R) == KBO_PANIC) { s->panic = 1; return KBO_PANIC; }
   res_add(&nd->used, &tk->resreq, s->R);
@@ -734,6 +739,7 @@ static int ssn_pipeline(kbo_session *s, uint32_t t, uint32_t n) {
   nd->nz_cpu += tk->nz_cpu;
   nd->nz_mem += tk->nz_mem;
   tk->node_status = KB_TASK_PIPELINED;
+  tk->on_node = 1;
   push_decision(s, t, n, 1);
   fire_allocate_event(s, t);
   return 0;
@@ -891,6 +897,7 @@ kbo_session *kbo_open(const kb_config *cfg, const kb_snapshot *sn, int threads) 
     tk->status = sn->task_status[t];
     tk->node_status = tk->status;
     tk->node = sn->task_node ? sn->task_node[t] : KB_NONE;
+    tk->on_node = tk->node != KB_NONE;
   }
   s->jobs = (o_job *)calloc(s->J ? s->J : 1, sizeof(o_job));
   for (uint32_t j = 0; j < s->J; j++) {
@@ -1021,6 +1028,7 @@ static void fire_deallocate_event(kbo_session *s, uint32_t t) {   /* drf.go:146-
 /* NodeInfo.RemoveTask (api/node_info.go:217-243): accounting by the status of the node's own clone */
 static void node_remove_task(kbo_session *s, uint32_t t) {
   o_task *tk = &s->tasks[t];
+  if (!tk->on_node) return;                     /* node_info.go:220-224 "failed to find task on host": logged, nothing changes */
   o_node *nd = &s->nodes[tk->node];
   switch (tk->node_status) {
     case KB_TASK_RELEASING: if (res_sub(&nd->releasing, &tk->resreq, s->R) == KBO_PANIC) s->panic = 1; res_add(&nd->idle, &tk->resreq, s->R); break;
@@ -1042,6 +1050,7 @@ static void node_remove_task(kbo_session *s, uint32_t t) {
 static int node_add_task(kbo_session *s, uint32_t t, uint32_t n, int status) {
   o_task *tk = &s->tasks[t];
   o_node *nd = &s->nodes[n];
+  if ((tk->node != KB_NONE && tk->node != n) || tk->on_node) return -1;   /* node_info.go:173-182: NodeName is sticky */
   switch (status) {
     case KB_TASK_RELEASING:
       if (!res_less_equal(&tk->resreq, &nd->idle, s->R)) return -1;
@@ -1093,8 +1102,7 @@ static void stmt_pipeline(kbo_session *s, stmt_t *st, uint32_t t, uint32_t n) { 
 }
 static void stmt_unpipeline(kbo_session *s, uint32_t t) {                  /* statement.go:155-190 */
   job_set_status(s, t, KB_TASK_PENDING);
-  node_remove_task(s, t);
-  s->tasks[t].node = KB_NONE;
+  node_remove_task(s, t);                        /* task.NodeName keeps the old host (node_info.go:217-243 never clears it) */
   fire_deallocate_event(s, t);
 }
 static void stmt_discard(kbo_session *s, stmt_t *st) {                     /* statement.go:193-205: newest first */
@@ -1248,7 +1256,6 @@ static int preempt_one(kbo_session *s, stmt_t *st, uint32_t preemptor, int mode,
 }
 int kbo_preempt(kbo_session *s) {
   if (s->panic) return KBO_PANIC;
-  for (uint32_t t = 0; t < s->T; t++) s->tasks[t].on_node = s->tasks[t].node != KB_NONE;
   for (uint32_t n = 0; n < s->N; n++) {        /* ports of pods outside the session stay on the node whatever moves */
     uint64_t mine = 0;
     for (uint32_t t = 0; t < s->T; t++) if (s->tasks[t].on_node && s->tasks[t].node == n) mine |= s->tasks[t].port_want;
@@ -1318,7 +1325,6 @@ static void record_eviction(kbo_session *s, uint32_t t) {
 }
 int kbo_reclaim(kbo_session *s) {
   if (s->panic) return KBO_PANIC;
-  for (uint32_t t = 0; t < s->T; t++) s->tasks[t].on_node = s->tasks[t].node != KB_NONE;
   for (uint32_t n = 0; n < s->N; n++) {
     uint64_t mine = 0;
     for (uint32_t t = 0; t < s->T; t++) if (s->tasks[t].on_node && s->tasks[t].node == n) mine |= s->tasks[t].port_want;
@@ -1378,7 +1384,6 @@ int kbo_reclaim(kbo_session *s) {
       }
       if (res_less_equal(&pt->init_resreq, &reclaimed, s->R)) {            /* reclaim.go:174-183 */
         if (ssn_pipeline(s, task, n) == KBO_PANIC) break;
-        pt->on_node = 1;
         assigned = 1;
       }
     }

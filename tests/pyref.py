@@ -222,7 +222,13 @@ class Session:
         self.ntc, self.nnc = int(s.n_task_classes), int(s.n_node_classes)
         self.compat = s.class_compat
         self.affinity = getattr(s, "class_affinity", None)
-        self.decisions, self.binds, self.popped = [], {}, 0
+        prot = getattr(s, "task_evict_protected", None)
+        self.protected = [bool(x) for x in prot] if prot is not None else [False] * self.T
+        self.onnode = [n != NONE for n in self.tnode]
+        self.nstatus = [st if on else None for st, on in zip(self.status, self.onnode)]
+        self.base_ports = list(self.nports)
+        self.session_on = [set() for _ in range(self.N)]
+        self.decisions, self.binds, self.popped, self.evictions = [], {}, 0, []
         self._open_plugins()
 
     # ---- conf helpers (framework/session_plugins.go isEnabled)
@@ -413,35 +419,173 @@ class Session:
             a["allocated"].add(self.resreq[t])
             self._prop_share(a)
 
-    def _join_node(self, t, n):
-        self.tnode[t] = n
-        self.podcnt[n] += 1
+    def _fire_deallocate(self, t):                                    # drf.go:143-151, proportion.go:223-233
+        j = self.tjob[t]
+        if self._has("drf"):
+            self.jalloc[j].sub(self.resreq[t])
+            self.jshare[j] = self._drf_share(self.jalloc[j])
+        if self._has("proportion"):
+            a = self.qattr[self.jqueue[j]]
+            a["allocated"].sub(self.resreq[t])
+            self._prop_share(a)
+
+    # ---- api.NodeInfo.AddTask / RemoveTask / UpdateTask (api/node_info.go:172-256); the node keeps a CLONE of the task, so
+    # the status the node sees (nstatus) is the task's status at the time of the last AddTask
+    def node_add_task(self, t, n):
+        if self.tnode[t] != NONE and self.tnode[t] != n:              # :173-176 "already on different node" (NodeName is sticky)
+            return False
+        if self.onnode[t]:                                            # :178-182 "already on node"
+            return False
+        st = self.status[t]
+        if st == RELEASING:
+            if not self.resreq[t].less_equal(self.idle[n]):
+                return False
+            self.idle[n].sub(self.resreq[t])
+            self.rel[n].add(self.resreq[t])
+        elif st == PIPELINED:
+            self.rel[n].sub(self.resreq[t])
+        else:
+            if not self.resreq[t].less_equal(self.idle[n]):           # allocateIdleResource :161-167
+                return False
+            self.idle[n].sub(self.resreq[t])
+        self.tnode[t], self.onnode[t], self.nstatus[t] = n, True, st
+        self.podcnt[n] += 1                                           # k8s-side sums range over ni.Tasks (nodeinfo rebuilt per call)
         self.nzc[n] += self.tnzc[t]
         self.nzm[n] += self.tnzm[t]
+        self.session_on[n].add(t)
         self.nports[n] |= self.twant[t]
+        return True
 
-    def ssn_allocate(self, t, n):
-        self.status[t] = ALLOCATED                                    # session.go:243, before node.AddTask
-        if not self.resreq[t].less_equal(self.idle[n]):               # node_info.go:161-167
+    def node_remove_task(self, t):
+        if not self.onnode[t]:
             return False
-        self.idle[n].sub(self.resreq[t])
-        self._join_node(t, n)
-        self.decisions.append((t, n, 0))
-        self._fire_allocate(t)
-        j = self.tjob[t]
-        if self.job_ready(j):                                         # session.go:277-285
+        n, st = self.tnode[t], self.nstatus[t]
+        if st == RELEASING:
+            self.rel[n].sub(self.resreq[t])
+            self.idle[n].add(self.resreq[t])
+        elif st == PIPELINED:
+            self.rel[n].add(self.resreq[t])
+        else:
+            self.idle[n].add(self.resreq[t])
+        self.onnode[t] = False
+        self.podcnt[n] -= 1
+        self.nzc[n] -= self.tnzc[t]
+        self.nzm[n] -= self.tnzm[t]
+        self.session_on[n].discard(t)
+        ports = self.base_ports[n]
+        for i in self.session_on[n]:
+            ports |= self.twant[i]
+        self.nports[n] = ports
+        return True
+
+    def node_update_task(self, t):
+        if self.node_remove_task(t):
+            assert self.node_add_task(t, self.tnode[t]), "glog.Fatalf: Failed to add Task during task update"
+
+    def _dispatch_ready(self, j):                                     # session.go:277-285
+        if self.job_ready(j):
             for i in self._tasks(j):
                 if self.status[i] == ALLOCATED:
                     self.binds[i] = self.tnode[i]
                     self.status[i] = BINDING
+
+    def ssn_allocate(self, t, n):
+        self.status[t] = ALLOCATED                                    # session.go:243, before node.AddTask
+        if not self.node_add_task(t, n):
+            return False
+        self.decisions.append((t, n, 0))
+        self._fire_allocate(t)
+        self._dispatch_ready(self.tjob[t])
         return True
 
-    def ssn_pipeline(self, t, n):
+    def ssn_pipeline(self, t, n):                                     # session.go:194-232
         self.status[t] = PIPELINED
-        self.rel[n].sub(self.resreq[t])                               # node_info.go:196-197
-        self._join_node(t, n)
+        if not self.node_add_task(t, n):
+            return False
         self.decisions.append((t, n, 1))
         self._fire_allocate(t)
+        return True
+
+    def ssn_evict(self, t):                                           # session.go:317-354 (reclaim: evicts at once)
+        self.evictions.append(t)
+        self.status[t] = RELEASING
+        self.node_update_task(t)
+        self._fire_deallocate(t)
+
+    def waiting_num(self, j):
+        return sum(1 for t in self._tasks(j) if self.status[t] == PIPELINED)
+
+    def job_pipelined(self, j):                                       # gang.go:126-129 behind session_plugins.go:203-221
+        if self._enabled("gang", EN_JOB_PIPELINED):
+            return self.waiting_num(j) + self.ready_num(j) >= self.jmin[j]
+        return True
+
+    # ---- victims: tier-wise intersection (session_plugins.go:80-162).  A Go nil slice (no append happened) is "no decision".
+    def _victims(self, bit, fns, actor, candidates):
+        victims, init = None, False
+        for tier in self.tiers:
+            for name, en, _ in tier:
+                if not en & bit or name not in fns:
+                    continue
+                cand = fns[name](actor, candidates)
+                if not init:
+                    victims, init = cand, True
+                else:
+                    inter = [v for v in (victims or []) for c in (cand or []) if v == c]
+                    victims = inter or None
+            if victims is not None:
+                return victims
+        return victims
+
+    def _gang_evictable(self, actor, tasks):                          # gang.go:71-90
+        out = []
+        for t in tasks:
+            j = self.tjob[t]
+            if self.jmin[j] <= self.ready_num(j) - 1 or self.jmin[j] == 1:
+                out.append(t)
+        return out or None
+
+    def _conformance_evictable(self, actor, tasks):                   # conformance.go:41-58
+        return [t for t in tasks if not self.protected[t]] or None
+
+    def _priority_preemptable(self, actor, tasks):                    # priority.go:79-97
+        return [t for t in tasks if self.jprio[self.tjob[t]] < self.jprio[self.tjob[actor]]] or None
+
+    def _drf_preemptable(self, actor, tasks):                         # drf.go:85-110
+        ls = self._drf_share(self.jalloc[self.tjob[actor]].clone().add(self.resreq[actor]))
+        allocations, out = {}, []
+        for t in tasks:
+            j = self.tjob[t]
+            if j not in allocations:
+                allocations[j] = self.jalloc[j].clone()
+            rs = self._drf_share(allocations[j].sub(self.resreq[t]))
+            if ls < rs or math.fabs(ls - rs) <= 0.000001:
+                out.append(t)
+        return out or None
+
+    def _proportion_reclaimable(self, actor, tasks):                  # proportion.go:171-196
+        allocations, out = {}, []
+        for t in tasks:
+            q = self.jqueue[self.tjob[t]]
+            a = self.qattr[q]
+            if q not in allocations:
+                allocations[q] = a["allocated"].clone()
+            if allocations[q].less(self.resreq[t]):
+                continue
+            allocations[q].sub(self.resreq[t])
+            if a["deserved"].less_equal(allocations[q]):
+                out.append(t)
+        return out or None
+
+    def preemptable(self, actor, tasks):
+        fns = {"gang": self._gang_evictable, "conformance": self._conformance_evictable, "priority": self._priority_preemptable}
+        if self._has("drf"):
+            fns["drf"] = self._drf_preemptable
+        return self._victims(EN_PREEMPTABLE, {k: v for k, v in fns.items() if self._has(k)}, actor, tasks)
+
+    def reclaimable(self, actor, tasks):
+        fns = {"gang": self._gang_evictable, "conformance": self._conformance_evictable, "proportion": self._proportion_reclaimable}
+        return self._victims(EN_RECLAIMABLE, {k: v for k, v in fns.items() if self._has(k)}, actor, tasks)
 
     # ---- actions
     def allocate(self):                                               # actions/allocate/allocate.go:43-194
@@ -499,6 +643,173 @@ class Session:
                         continue
                     if self.ssn_allocate(t, n):
                         break
+
+    # ---- framework.Statement (framework/statement.go:30-240)
+    def stmt_evict(self, ops, t):
+        self.status[t] = RELEASING
+        self.node_update_task(t)
+        self._fire_deallocate(t)
+        ops.append(("evict", t))
+
+    def stmt_pipeline(self, ops, t, n):
+        self.status[t] = PIPELINED
+        if self.node_add_task(t, n):                                  # an AddTask error is logged; handlers still fire (:128-147)
+            self.decisions.append((t, n, 1))
+        self._fire_allocate(t)
+        ops.append(("pipeline", t))
+
+    def stmt_discard(self, ops):
+        for name, t in reversed(ops):
+            if name == "evict":                                       # unevict :80-107
+                self.status[t] = RUNNING
+                self.node_update_task(t)
+                self._fire_allocate(t)
+            else:                                                     # unpipeline :152-187
+                self.status[t] = PENDING
+                if self.node_remove_task(t):
+                    self.decisions = [d for d in self.decisions if d[0] != t]
+                self._fire_deallocate(t)
+
+    def stmt_commit(self, ops):
+        for name, t in ops:
+            if name == "evict":
+                self.evictions.append(t)                              # cache.Evict
+
+    def _node_tasks(self, n):
+        return [t for t in range(self.T) if self.onnode[t] and self.tnode[t] == n]      # canonical: ascending task index
+
+    def _preempt_one(self, ops, preemptor, flt):                      # actions/preempt/preempt.go:171-254
+        self.popped += 1
+        feasible = [n for n in range(self.N) if self.plugin_predicate(preemptor, n)]
+        scores = self.prioritize(preemptor, feasible)
+        order = sorted(feasible, key=lambda n: (scores[n], n), reverse=True)        # SortNodes: sort.Reverse(score, then host name)
+        for n in order:
+            preemptees = [t for t in self._node_tasks(n) if flt(t)]
+            victims = self.preemptable(preemptor, preemptees)
+            if not victims:                                           # validateVictims :256-270
+                continue
+            all_res = Resource()
+            for v in victims:
+                all_res.add(self.resreq[v])
+            if not self.init[preemptor].less_equal(all_res):
+                continue
+            vq = GoHeap(lambda l, r: not self.task_less(l, r))
+            for v in victims:
+                vq.push(v)
+            preempted = Resource()
+            while len(vq):
+                v = vq.pop()
+                self.stmt_evict(ops, v)
+                preempted.add(self.resreq[v])
+                if self.init[preemptor].less_equal(preempted):
+                    break
+            if self.init[preemptor].less_equal(preempted):
+                self.stmt_pipeline(ops, preemptor, n)
+                return True
+        return False
+
+    def preempt(self):                                                # actions/preempt/preempt.go:44-166
+        preemptors_map, preemptor_tasks, under_request, queues = {}, {}, [], []
+        for j in range(self.J):
+            q = self.jqueue[j]
+            if q >= self.Q:
+                continue
+            if q not in queues:
+                queues.append(q)
+            pend = [t for t in self._tasks(j) if self.status[t] == PENDING]
+            if pend:
+                preemptors_map.setdefault(q, GoHeap(self.job_less)).push(j)
+                under_request.append(j)
+                preemptor_tasks[j] = GoHeap(self.task_less)
+                for t in pend:
+                    preemptor_tasks[j].push(t)
+        for q in sorted(queues):
+            while True:
+                preemptors = preemptors_map.get(q)
+                if preemptors is None or not len(preemptors):
+                    break
+                pj = preemptors.pop()
+                ops, assigned = [], False
+                while True:
+                    if not len(preemptor_tasks[pj]):
+                        break
+                    p = preemptor_tasks[pj].pop()
+                    if self._preempt_one(ops, p, lambda t: self.nstatus[t] == RUNNING and self.jqueue[self.tjob[t]] == self.jqueue[pj]
+                                         and self.tjob[t] != self.tjob[p]):
+                        assigned = True
+                    if self.job_pipelined(pj):
+                        self.stmt_commit(ops)
+                        break
+                if not self.job_pipelined(pj):
+                    self.stmt_discard(ops)
+                    continue
+                if assigned:
+                    preemptors.push(pj)
+            for j in under_request:                                   # preemption between tasks within a job
+                while True:
+                    if j not in preemptor_tasks or not len(preemptor_tasks[j]):
+                        break
+                    p = preemptor_tasks[j].pop()
+                    ops = []
+                    assigned = self._preempt_one(ops, p, lambda t: self.nstatus[t] == RUNNING and self.tjob[t] == self.tjob[p])
+                    self.stmt_commit(ops)
+                    if not assigned:
+                        break
+
+    def reclaim(self):                                                # actions/reclaim/reclaim.go:41-193
+        queues, seen = GoHeap(self.queue_less), set()
+        preemptors_map, preemptor_tasks = {}, {}
+        for j in range(self.J):
+            q = self.jqueue[j]
+            if q >= self.Q:
+                continue
+            if q not in seen:
+                seen.add(q)
+                queues.push(q)
+            pend = [t for t in self._tasks(j) if self.status[t] == PENDING]
+            if pend:
+                preemptors_map.setdefault(q, GoHeap(self.job_less)).push(j)
+                preemptor_tasks[j] = GoHeap(self.task_less)
+                for t in pend:
+                    preemptor_tasks[j].push(t)
+        while len(queues):
+            q = queues.pop()
+            if self.overused(q):
+                continue
+            jobs = preemptors_map.get(q)
+            if jobs is None or not len(jobs):
+                continue
+            j = jobs.pop()
+            tasks = preemptor_tasks.get(j)
+            if tasks is None or not len(tasks):
+                continue
+            task = tasks.pop()
+            self.popped += 1
+            assigned = False
+            for n in range(self.N):
+                if not self.plugin_predicate(task, n):
+                    continue
+                reclaimees = [t for t in self._node_tasks(n) if self.nstatus[t] == RUNNING and self.jqueue[self.tjob[t]] != self.jqueue[j]]
+                victims = self.reclaimable(task, reclaimees)
+                if not victims:
+                    continue
+                all_res = Resource()
+                for v in victims:
+                    all_res.add(self.resreq[v])
+                if not self.init[task].less_equal(all_res):
+                    continue
+                reclaimed = Resource()
+                for v in victims:
+                    self.ssn_evict(v)
+                    reclaimed.add(self.resreq[v])
+                    if self.init[task].less_equal(reclaimed):
+                        break
+                if self.init[task].less_equal(reclaimed):
+                    self.ssn_pipeline(task, n)
+                    assigned = True
+                    break
+            if assigned:
+                queues.push(q)
 
     def run(self, actions):
         for a in actions:

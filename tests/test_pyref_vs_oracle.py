@@ -170,3 +170,136 @@ def test_python_restatement_example_job_spread():
     assert len(p.binds) == 6
     assert sorted(np.bincount(list(p.binds.values()), minlength=3).tolist()) == [2, 2, 2]
     assert [d[1] for d in p.decisions[:3]] == [0, 1, 2]
+
+
+# ---- preempt and reclaim (oracle-only actions so far: groundwork for the engine's next actions)
+CONF_FULL = """
+actions: "{actions}"
+tiers:
+- plugins:
+  - name: priority
+  - name: gang
+  - name: conformance
+- plugins:
+  - name: drf
+  - name: predicates
+  - name: proportion
+  - name: nodeorder
+"""
+
+
+def _evict_case(seed):
+    rng = np.random.RandomState(9000 + seed)
+    R = int(rng.choice([2, 2, 3]))
+    p = snapmod.SynthParams(
+        n_tasks=int(rng.randint(40, 400)), n_nodes=int(rng.randint(2, 24)), n_queues=int(rng.randint(1, 5)), n_res=R,
+        seed=snapmod.SEED_BASE + 1300 + seed, preload_node_frac=float(rng.uniform(0.3, 1.0)), running_job_frac=float(rng.uniform(0.2, 0.7)),
+        best_effort_frac=float(rng.uniform(0, 0.1)), no_mem_key_frac=float(rng.uniform(0, 0.2)), scalar_job_frac=float(rng.uniform(0, 0.5)),
+        zone_selector_frac=float(rng.uniform(0, 0.3)), n_zones=int(rng.randint(1, 4)))
+    s = snapmod.synth(p)
+    s.job_priority[:] = rng.choice([0, 0, 100, 1000], size=s.n_jobs).astype(np.int32)
+    s.task_priority[:] = rng.choice([1, 1, 5, 9], size=s.n_tasks).astype(np.int32)
+    s.job_min_available[:] = np.minimum(s.job_min_available, rng.choice([1, 1, 2, 64], size=s.n_jobs)).astype(np.int32)
+    prot = (rng.uniform(size=s.n_tasks) < 0.05).astype(np.uint8)
+    s.task_evict_protected = prot if prot.any() else None
+    s._check()
+    order = [["preempt"], ["reclaim"], ["reclaim", "allocate", "backfill", "preempt"], ["allocate", "preempt", "reclaim"],
+             ["preempt", "allocate", "backfill"], ["preempt", "reclaim", "allocate", "preempt"]][seed % 6]
+    return conf.load_scheduler_conf(CONF_FULL.format(actions=", ".join(order))), s, order
+
+
+@pytest.mark.parametrize("seed", range(120))
+def test_python_restatement_equals_c_oracle_with_preempt_and_reclaim(oracle_mod, seed):
+    cfg, snap, order = _evict_case(seed)
+    o = oracle_mod.Oracle(cfg, snap)
+    p = pyref.Session(_tiers(cfg), snap)
+    o_panic = p_panic = False
+    try:
+        o.run(order)
+    except RuntimeError:
+        o_panic = True
+    try:
+        p.run(order)
+    except ArithmeticError:
+        p_panic = True
+    assert o_panic == p_panic, (seed, o_panic, p_panic)
+    if o_panic:
+        return
+    assert [int(t) for t in o.evictions()] == p.evictions, seed
+    st, nd = o.task_state()
+    assert np.array_equal(np.array(p.status, np.uint8), st), seed
+    assert np.array_equal(np.array(p.tnode, np.uint32), nd), seed      # NodeName is sticky: un-pipelined tasks keep it
+    idle, rel, nzc, nzm, cnt = o.node_state()
+    for n in range(snap.n_nodes):
+        for d in range(snap.n_res):
+            assert p.idle[n].get(d) == idle[d, n], (seed, n, d)
+            assert p.rel[n].get(d) == rel[d, n], (seed, n, d)
+    assert np.array_equal(np.array(p.nzc), nzc) and np.array_equal(np.array(p.nzm), nzm) and np.array_equal(np.array(p.podcnt), cnt)
+    js, qs, des = o.shares()
+    assert np.array_equal(np.array(p.jshare), js)
+    for q, a in p.qattr.items():
+        assert a["share"] == qs[q], (seed, q)
+    pb = np.full(snap.n_tasks, abi.KB_NONE, np.uint32)
+    for t, n in p.binds.items():
+        pb[t] = n
+    assert np.array_equal(pb, o.binds())
+    o.close()
+
+
+def test_discarded_statement_leaves_a_sticky_node_name(oracle_mod):
+    """Hand-derived from the Go sources; pins a quirk both restatements must share.  NodeInfo.RemoveTask never clears
+    task.NodeName (api/node_info.go:217-243), so a task that a discarded preempt statement un-pipelined (statement.go:152-187)
+    keeps its old host: a later AddTask on another node fails (node_info.go:173-176) AFTER ssn.Allocate flipped its status
+    (session.go:243), it still counts as ready (job_info.go:383-394) and dispatch binds it to the stale NodeName (session.go:290-297).
+
+    n1, n2: 1 cpu, each full with one running low-priority pod; n3: 1 cpu, empty.  Gang `high` (minMember 3, three pending pods).
+    preempt: no plugin scores -> SortNodes = n3, n2, n1.  high0 evicts on n2, high1 on n1, high2 finds nobody -> 2 < 3, statement
+    discarded (no eviction reaches the cache).  allocate: only n3 has room; high0 and high1 fail AddTask there (sticky n2 / n1) but
+    are Allocated; high2 lands on n3; 3 >= minMember -> all three are dispatched to their NodeName."""
+    S = kbm.snapshot
+    rl = fixtures.build_resource_list
+    tiers = conf.tiers_literal([conf.PluginOption("priority", enabled=abi.EN_PREEMPTABLE | abi.EN_JOB_ORDER),
+                                conf.PluginOption("gang", enabled=abi.EN_PREEMPTABLE | abi.EN_JOB_PIPELINED | abi.EN_JOB_READY)])
+    snap = S.flatten(
+        nodes=[S.Node(f"n{i}", rl("1", "1G")) for i in (1, 2, 3)],
+        pods=[fixtures.build_pod("c1", "low1", "n1", "Running", rl("1", "1G"), "low"),
+              fixtures.build_pod("c1", "low2", "n2", "Running", rl("1", "1G"), "low")] +
+             [fixtures.build_pod("c1", f"high{i}", "", "Pending", rl("1", "1G"), "high") for i in range(3)],
+        pod_groups=[S.PodGroup("c1", "low", queue="q1", priority=1), S.PodGroup("c1", "high", queue="q1", min_member=3, priority=10)],
+        queues=[S.Queue("q1", 1)])
+    expected = {"c1/high0": "n2", "c1/high1": "n1", "c1/high2": "n3"}
+    o = oracle_mod.Oracle(tiers, snap)
+    o.run(["preempt", "allocate"])
+    assert len(o.evictions()) == 0
+    assert snap.bind_map(o.binds()) == expected
+    idle, rel, _, _, cnt = o.node_state()
+    assert idle[0].tolist() == [0.0, 0.0, 0.0] and rel[0].tolist() == [0.0, 0.0, 0.0] and cnt.tolist() == [1, 1, 1]
+    p = pyref.Session(_tiers(tiers), snap).run(["preempt", "allocate"])
+    assert p.evictions == [] and {snap.task_name(t): snap.node_name(n) for t, n in p.binds.items()} == expected
+    assert [x.cpu for x in p.idle] == [0.0, 0.0, 0.0] and p.podcnt == [1, 1, 1]
+
+
+def test_python_restatement_reference_preempt_and_reclaim_cases():
+    """actions/preempt/preempt_test.go:51-131 (1 and 2 evictions) and actions/reclaim/reclaim_test.go:51-99 (1 eviction): the
+    counts the reference's FakeEvictor checks, reproduced by the Python restatement on its own."""
+    S = kbm.snapshot
+    rl, pod = fixtures.build_resource_list, fixtures.build_pod
+    tiers = conf.tiers_literal([conf.PluginOption("conformance", enabled=abi.EN_PREEMPTABLE), conf.PluginOption("gang", enabled=abi.EN_PREEMPTABLE)])
+    snap = S.flatten(
+        nodes=[S.Node("n1", rl("3", "3Gi"))],
+        pods=[pod("c1", "preemptee1", "n1", "Running", rl("1", "1G"), "pg1"), pod("c1", "preemptee2", "n1", "Running", rl("1", "1G"), "pg1"),
+              pod("c1", "preemptor1", "", "Pending", rl("1", "1G"), "pg1"), pod("c1", "preemptor2", "", "Pending", rl("1", "1G"), "pg1")],
+        pod_groups=[S.PodGroup("c1", "pg1", queue="q1")], queues=[S.Queue("q1", 1)])
+    assert len(pyref.Session(_tiers(tiers), snap).run(["preempt"]).evictions) == 1
+    snap = S.flatten(
+        nodes=[S.Node("n1", rl("2", "2G"))],
+        pods=[pod("c1", "preemptee1", "n1", "Running", rl("1", "1G"), "pg1"), pod("c1", "preemptee2", "n1", "Running", rl("1", "1G"), "pg1"),
+              pod("c1", "preemptor1", "", "Pending", rl("1", "1G"), "pg2"), pod("c1", "preemptor2", "", "Pending", rl("1", "1G"), "pg2")],
+        pod_groups=[S.PodGroup("c1", "pg1", queue="q1"), S.PodGroup("c1", "pg2", queue="q1")], queues=[S.Queue("q1", 1)])
+    assert len(pyref.Session(_tiers(tiers), snap).run(["preempt"]).evictions) == 2
+    tiers = conf.tiers_literal([conf.PluginOption("conformance", enabled=abi.EN_RECLAIMABLE), conf.PluginOption("gang", enabled=abi.EN_RECLAIMABLE)])
+    snap = S.flatten(
+        nodes=[S.Node("n1", rl("3", "3Gi"))],
+        pods=[pod("c1", f"preemptee{i}", "n1", "Running", rl("1", "1G"), "pg1") for i in (1, 2, 3)] + [pod("c1", "preemptor1", "", "Pending", rl("1", "1G"), "pg2")],
+        pod_groups=[S.PodGroup("c1", "pg1", queue="q1"), S.PodGroup("c1", "pg2", queue="q2")], queues=[S.Queue("q1", 1), S.Queue("q2", 1)])
+    assert len(pyref.Session(_tiers(tiers), snap).run(["reclaim"]).evictions) == 1
