@@ -303,3 +303,62 @@ def test_python_restatement_reference_preempt_and_reclaim_cases():
         pods=[pod("c1", f"preemptee{i}", "n1", "Running", rl("1", "1G"), "pg1") for i in (1, 2, 3)] + [pod("c1", "preemptor1", "", "Pending", rl("1", "1G"), "pg2")],
         pod_groups=[S.PodGroup("c1", "pg1", queue="q1"), S.PodGroup("c1", "pg2", queue="q2")], queues=[S.Queue("q1", 1), S.Queue("q2", 1)])
     assert len(pyref.Session(_tiers(tiers), snap).run(["reclaim"]).evictions) == 1
+
+
+# ---- adversarial raw snapshots (tests/rawgen.py): epsilon edges, zero capacities, nil maps, tie-breaks
+import rawgen  # noqa: E402  (tests/ is on sys.path under pytest rootdir conftest)
+
+
+def _compare_final_state(seed, snap, o, p):
+    st, nd = o.task_state()
+    assert np.array_equal(np.array(p.status, np.uint8), st), seed
+    assert np.array_equal(np.array(p.tnode, np.uint32), nd), seed
+    idle, rel, nzc, nzm, cnt = o.node_state()
+    for n in range(snap.n_nodes):
+        for d in range(snap.n_res):
+            assert p.idle[n].get(d) == idle[d, n], (seed, n, d)
+            assert p.rel[n].get(d) == rel[d, n], (seed, n, d)
+    assert np.array_equal(np.array(p.nzc), nzc) and np.array_equal(np.array(p.nzm), nzm) and np.array_equal(np.array(p.podcnt), cnt)
+    pb = np.full(snap.n_tasks, abi.KB_NONE, np.uint32)
+    for t, n in p.binds.items():
+        pb[t] = n
+    assert np.array_equal(pb, o.binds()), seed
+
+
+@pytest.mark.parametrize("seed", range(600))
+def test_restatements_agree_on_adversarial_snapshots(oracle_mod, seed):
+    snap = rawgen.raw_snapshot(seed)
+    rng = np.random.RandomState(seed)
+    if seed % 3 == 2:
+        order = [["preempt"], ["reclaim", "allocate", "backfill", "preempt"], ["preempt", "allocate"]][(seed // 3) % 3]
+        cfg = conf.load_scheduler_conf(CONF_FULL.format(actions=", ".join(order)))
+    else:
+        order = ["allocate", "backfill"]
+        wl, wm, wa, wb = [int(x) for x in rng.choice([0, 1, 1, 2, 5], size=4)]
+        cfg = conf.load_scheduler_conf(CONF_TMPL.format(wl=wl, wm=wm, wa=wa, wb=wb))
+    o_panic = p_panic = False
+    o = p = None
+    try:
+        o = oracle_mod.Oracle(cfg, snap)
+        o.run(order)
+    except RuntimeError:
+        o_panic = True
+    try:
+        p = pyref.Session(_tiers(cfg), snap)
+        p.run(order)
+    except ArithmeticError:
+        p_panic = True
+    assert o_panic == p_panic, (seed, o_panic, p_panic)
+    if o_panic:
+        return
+    if order == ["allocate", "backfill"]:
+        assert np.array_equal(np.array(p.decisions, dtype=np.uint32).reshape(-1, 3), o.decisions()), seed
+    assert [int(t) for t in o.evictions()] == p.evictions, seed
+    _compare_final_state(seed, snap, o, p)
+    js, qs, des = o.shares()
+    assert np.array_equal(np.array(p.jshare), js), seed
+    for q, a in p.qattr.items():
+        assert a["share"] == qs[q], (seed, q)
+        for d in range(snap.n_res):
+            assert a["deserved"].get(d) == des[d, q], (seed, q, d)
+    o.close()
