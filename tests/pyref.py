@@ -228,7 +228,7 @@ class Session:
         self.nstatus = [st if on else None for st, on in zip(self.status, self.onnode)]
         self.base_ports = list(self.nports)
         self.session_on = [set() for _ in range(self.N)]
-        self.decisions, self.binds, self.popped, self.evictions = [], {}, 0, []
+        self.decisions, self.binds, self.popped, self.evictions, self.pop_order = [], {}, 0, [], []
         self._open_plugins()
 
     # ---- conf helpers (framework/session_plugins.go isEnabled)
@@ -262,7 +262,7 @@ class Session:
             total.add(self.alloc[n])
         self.total = total
         self.jalloc = []
-        for j in range(self.J):                                       # drf.go:60-83
+        for j in range(self.J if self._has("drf") else 0):            # drf.go:60-83
             a = Resource()
             for t in self._tasks(j):
                 if self.status[t] in (BOUND, BINDING, RUNNING, ALLOCATED):
@@ -270,6 +270,8 @@ class Session:
             self.jalloc.append(a)
         self.jshare = [self._drf_share(a) for a in self.jalloc]
         self.qattr = {}                                               # proportion.go:58-154
+        if not self._has("proportion"):
+            return
         for j in range(self.J):
             q = self.jqueue[j]
             if q not in self.qattr:
@@ -588,6 +590,26 @@ class Session:
         return self._victims(EN_RECLAIMABLE, {k: v for k, v in fns.items() if self._has(k)}, actor, tasks)
 
     # ---- actions
+    def place(self, t):
+        """allocate.go:129-183 for one popped task: PredicateNodes, PrioritizeNodes, SelectBestNode, Allocate or Pipeline.
+        Returns "none" (no feasible node), "alloc" or "pipe" ("stay" when neither branch fired)."""
+        self.popped += 1
+        self.pop_order.append(t)
+        feasible = [n for n in range(self.N)
+                    if (self.init[t].less_equal(self.idle[n]) or self.init[t].less_equal(self.rel[n])) and self.plugin_predicate(t, n)]
+        if not feasible:
+            return "none"
+        scores = self.prioritize(t, feasible)
+        best = max(scores.values())
+        n = min(k for k, v in scores.items() if v == best)            # canonical first maximum
+        if self.init[t].less_equal(self.idle[n]):
+            self.ssn_allocate(t, n)
+            return "alloc"
+        if self.init[t].less_equal(self.rel[n]):
+            self.ssn_pipeline(t, n)
+            return "pipe"
+        return "stay"
+
     def allocate(self):                                               # actions/allocate/allocate.go:43-194
         queues = GoHeap(self.queue_less)
         jobs_map = {}
@@ -615,18 +637,8 @@ class Session:
             tasks = pending[j]
             while len(tasks):
                 t = tasks.pop()
-                self.popped += 1
-                feasible = [n for n in range(self.N)
-                            if (self.init[t].less_equal(self.idle[n]) or self.init[t].less_equal(self.rel[n])) and self.plugin_predicate(t, n)]
-                if not feasible:
+                if self.place(t) == "none":
                     break
-                scores = self.prioritize(t, feasible)
-                best = max(scores.values())
-                n = min(k for k, v in scores.items() if v == best)    # canonical first maximum
-                if self.init[t].less_equal(self.idle[n]):
-                    self.ssn_allocate(t, n)
-                elif self.init[t].less_equal(self.rel[n]):
-                    self.ssn_pipeline(t, n)
                 if self.job_ready(j) and len(tasks):
                     jobs.push(j)
                     break
