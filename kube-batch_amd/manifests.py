@@ -27,6 +27,11 @@ from .snapshot import Node, Pod, PodGroup, Queue, SessionSnapshot, flatten
 GROUP_ANNOTATION = "scheduling.k8s.io/group-name"
 
 
+class UnsupportedManifest(ValueError):
+    """The snapshot needs a feature the engine does not evaluate; the Go action hands such a cycle to the stock action
+    (integration/go/gpuallocate/flatten.go errUnsupported)."""
+
+
 def _ts(meta) -> int:
     """metadata.creationTimestamp (RFC 3339, second resolution like metav1.Time) -> Unix seconds; 0 when absent."""
     v = (meta or {}).get("creationTimestamp")
@@ -74,6 +79,11 @@ def _node(doc) -> Node:
 
 def _pod(doc, namespace: str) -> Pod:
     meta, spec, status = doc.get("metadata", {}), doc.get("spec", {}) or {}, doc.get("status", {}) or {}
+    aff = spec.get("affinity") or {}
+    if aff.get("podAffinity") is not None or aff.get("podAntiAffinity") is not None:
+        # predicates p8 / priority a22: not flattened.  The reference's own result there depends on Go map order
+        # (plugins/nodeorder/nodeorder.go:48-62 resolves a session-placed pod's empty NodeName to "the first node holding such a pod")
+        raise UnsupportedManifest(f"pod {meta.get('namespace', namespace)}/{meta.get('name')}: inter-pod (anti)affinity")
     return Pod(
         namespace=meta.get("namespace", namespace),
         name=meta["name"],

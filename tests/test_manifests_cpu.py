@@ -4,6 +4,7 @@ import importlib
 import json
 
 import numpy as np
+import pytest
 import yaml
 
 kb = importlib.import_module("kube-batch_amd")
@@ -164,3 +165,21 @@ spec: {minMember: 1}
     snap = manifests.load_snapshot(text)
     assert snap.class_affinity.tolist() == [[7]]
     assert snap.task_port_want.tolist() == [1 | 2] and snap.task_port_conflict.tolist() == [3] and snap.node_ports.tolist() == [0]
+
+
+def test_inter_pod_affinity_is_reported_unsupported():
+    """Same contract as the Go flattener (integration/go/gpuallocate/flatten.go: errUnsupported -> the stock action runs the cycle)."""
+    text = """
+apiVersion: v1
+kind: Pod
+metadata: {name: p, namespace: ns, annotations: {scheduling.k8s.io/group-name: g}}
+spec:
+  containers: [{name: c, resources: {requests: {cpu: "1"}}}]
+  affinity:
+    podAntiAffinity:
+      requiredDuringSchedulingIgnoredDuringExecution:
+      - topologyKey: kubernetes.io/hostname
+        labelSelector: {matchLabels: {app: web}}
+"""
+    with pytest.raises(manifests.UnsupportedManifest, match="inter-pod"):
+        manifests.load_cluster(text)
