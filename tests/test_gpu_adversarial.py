@@ -1,0 +1,55 @@
+"""Engine vs oracle on the adversarial raw snapshots of tests/rawgen.py (epsilon edges, zero capacities, nil scalar maps,
+tie-breaks, zero queue weights).  Snapshots outside the envelope kb_session_load accepts (KB_E_UNSUPPORTED / KB_E_INVALID: a
+sub-epsilon BestEffort request, a water-fill the reference would panic on) are skipped — the Go action hands those to the stock
+action.
+
+Written after the round's GPU budget was spent: it has NOT run on a GPU yet, so it is opt-in (KB_GPU_ADVERSARIAL=1) until it has
+been seen green once; the two CPU restatements and the host order machine already agree on the same snapshots
+(tests/test_pyref_vs_oracle.py, tests/test_host_order_cpu.py)."""
+import importlib
+import os
+
+import numpy as np
+import pytest
+
+import rawgen
+import test_pyref_vs_oracle as cases
+
+kbm = importlib.import_module("kube-batch_amd")
+engine = importlib.import_module("kube-batch_amd.engine")
+abi, conf = kbm.abi, kbm.conf
+
+pytestmark = [pytest.mark.gpu,
+              pytest.mark.skipif(not os.environ.get("KB_GPU_ADVERSARIAL"), reason="opt-in until verified on a GPU (KB_GPU_ADVERSARIAL=1)")]
+
+
+@pytest.mark.parametrize("seed", range(200))
+def test_engine_equals_oracle_on_adversarial_snapshots(oracle_mod, seed):
+    snap = rawgen.raw_snapshot(seed)
+    rng = np.random.RandomState(seed)
+    wl, wm, wa, wb = [int(x) for x in rng.choice([0, 1, 1, 2, 5], size=4)]
+    cfg = conf.load_scheduler_conf(cases.CONF_TMPL.format(wl=wl, wm=wm, wa=wa, wb=wb))
+    e = engine.Engine(cfg, window=int(rng.choice([0, 1, 3, 64])), commit_batch=int(rng.choice([0, 1, 5, 16])))
+    try:
+        e.load(snap)
+    except engine.EngineError as err:
+        e.close()
+        if err.code in (abi.KB_E_UNSUPPORTED, abi.KB_E_INVALID):
+            pytest.skip(f"outside the engine's envelope: {err}")
+        raise
+    try:
+        o = oracle_mod.Oracle(cfg, snap)
+        o.run(["allocate", "backfill"])
+    except RuntimeError:
+        e.close()
+        pytest.skip("the reference would panic on this snapshot")
+    dec = e.run(["allocate", "backfill"])
+    od = o.decisions()
+    assert dec.shape == od.shape, (seed, dec.shape, od.shape)
+    assert np.array_equal(dec, od), f"seed {seed}: first divergence at decision {int(np.argmax((dec != od).any(axis=1)))}"
+    assert np.array_equal(e.binds(), o.binds())
+    for a, b in zip(e.node_state(), o.node_state()):
+        assert np.array_equal(a, b)
+    for a, b in zip(e.shares(), o.shares()):
+        assert np.array_equal(a, b)
+    e.close()
