@@ -42,7 +42,7 @@ class OracleRes(C.Structure):
 def lib():
     global _LIB
     if _LIB is None:
-        so = build()
+        so = os.environ.get("KB_ORACLE_LIB") or build()   # KB_ORACLE_LIB: an instrumented build (scripts/sanitize_cpu.sh)
         L = C.CDLL(so)
         L.kbo_open.restype = C.c_void_p
         L.kbo_open.argtypes = [C.POINTER(abi.Config), C.POINTER(abi.Snapshot), C.c_int]

@@ -25,6 +25,8 @@ DONE, NO_FEASIBLE, PIPELINED, RENORM = 0, 1, 2, 4           # KB_REASON_* (kube-
 
 @pytest.fixture(scope="module")
 def harness():
+    if os.environ.get("KB_ORDER_HARNESS_LIB"):               # an instrumented build (scripts/sanitize_cpu.sh)
+        return _bind(C.CDLL(os.environ["KB_ORDER_HARNESS_LIB"]))
     out_dir = os.path.join(HERE, "host_harness", "build")
     os.makedirs(out_dir, exist_ok=True)
     so = os.path.join(out_dir, "liborderharness.so")
@@ -32,12 +34,12 @@ def harness():
     deps = srcs + [os.path.join(HERE, "..", "kube-batch_amd", "csrc", "kb_host.hpp")]
     if not os.path.exists(so) or any(os.path.getmtime(d) > os.path.getmtime(so) for d in deps):
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-fno-fast-math", "-o", so] + srcs)
-    L = C.CDLL(so)
+    return _bind(C.CDLL(so))
+
+
+def _bind(L):
     L.hh_create.restype = C.c_void_p
     L.hh_steps.restype = C.c_uint64
-    for f in ("hh_destroy", "hh_next", "hh_report", "hh_checkpoint", "hh_push_checkpoint", "hh_pop_commit", "hh_rollback",
-              "hh_rollback_last_pop", "hh_steps", "hh_state"):
-        getattr(L, f).argtypes = None
     return L
 
 
