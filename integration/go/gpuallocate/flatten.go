@@ -426,6 +426,14 @@ func flatten(ssn *framework.Session) (*flat, error) {
 			if idx, ok := nodeIdx[ti.NodeName]; ok && ti.NodeName != "" {
 				tnode[t] = idx
 			}
+			if ti.Status == api.Pending && ti.NodeName != "" {
+				// Only an earlier action of this cycle can leave this behind: a preempt statement pipelined the task and was
+				// discarded (statement.go:152-187); NodeInfo.RemoveTask keeps task.NodeName (node_info.go:217-243), so AddTask on
+				// any other node now fails after ssn.Allocate flipped the status (node_info.go:173-176, session.go:243).  The
+				// engine's allocate does not model that failure: the stock action takes the cycle.
+				f.free()
+				return nil, errUnsupported("pending task with a stale NodeName (un-pipelined by a discarded statement)")
+			}
 			key, err := taskClassKey(ti)
 			if err != nil {
 				f.free()
