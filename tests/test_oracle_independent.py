@@ -112,3 +112,42 @@ def test_less_equal_agrees_with_the_oracle(oracle_mod, lc, lm, ls, rc, rm, rs):
     # empty-but-non-nil maps are not representable in the snapshot (the flattener never produces them)
     assume(not (ls is not None and not ls) and not (rs is not None and not rs))
     assert bool(L.kbo_res_less_equal(C.byref(mk(lc, lm, ls)), C.byref(mk(rc, rm, rs)))) == less_equal((lc, lm, ls), (rc, rm, rs))
+
+
+# ---- the matrix kernel's integer arithmetic (kube-batch_amd/csrc/kb_kernels.hip div10 / score_core), restated in IEEE doubles:
+#      floor(10*req/cap) from a reciprocal estimate + one remainder correction, and least = 10 - most - (remainder != 0).
+#      Checked against exact integer division over the whole envelope kb_session_load admits (quantities < 2^48).
+def _div10(req: int, cap: int):
+    a = req * 10
+    q = int(float(a) * (1.0 / float(cap)))            # (int)((double)a * inv_cap): truncation, a < 2^52 is exact in a double
+    rem = a - q * cap
+    if rem < 0:
+        q, rem = q - 1, rem + cap
+    elif rem >= cap:
+        q, rem = q + 1, rem - cap
+    return q, rem != 0, rem
+
+
+envelope = st.one_of(st.integers(1, (1 << 48) - 1), st.integers(1, 200_000), st.sampled_from([1, 2, 3, 7, 10, 1000, 64000, (1 << 48) - 1, (1 << 47) + 1]))
+
+
+@settings(max_examples=3000, deadline=None)
+@given(cap=envelope, frac=st.floats(0.0, 1.0), nudge=st.integers(-2, 2))
+def test_reciprocal_div10_is_exact(cap, frac, nudge):
+    req = min(cap, max(0, int(cap * frac) + nudge))
+    q, rem_nz, rem = _div10(req, cap)
+    assert 0 <= rem < cap
+    assert q == (req * 10) // cap and rem_nz == ((req * 10) % cap != 0)
+    assert most_requested_score(req, cap) == q
+    assert least_requested_score(req, cap) == 10 - q - (1 if rem_nz else 0)      # floor(10 - x) = 10 - ceil(x)
+
+
+def test_reciprocal_div10_on_multiples_and_neighbours():
+    """The estimate is worst at exact multiples (q * cap / 10) and one unit either side of them."""
+    for cap in (1, 3, 7, 10, 999, 1000, 4000, 64000, (1 << 30), (1 << 40) + 12345, (1 << 48) - 1):
+        for k in range(11):
+            for d in (-1, 0, 1):
+                req = (k * cap) // 10 + d
+                if 0 <= req <= cap:
+                    q, rem_nz, _ = _div10(req, cap)
+                    assert q == (req * 10) // cap and rem_nz == ((req * 10) % cap != 0), (cap, req)
