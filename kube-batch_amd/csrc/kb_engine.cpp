@@ -218,8 +218,9 @@ Policy compile_policy(const kb_config *cfg) {
       }
     }
   }
-  if (p.wL < 0 || p.wM < 0 || p.wB < 0 || 10ll * ((long long)p.wL + p.wM + p.wB) > 65535)
-    throw EngineError(KB_E_UNSUPPORTED, "nodeorder weights must be >= 0 with 10*(least+most+balanced) <= 65535 (u16 score)");
+  // every scorer yields 0..10 (NodeAffinity after its NormalizeReduce too) and the matrix stores the weighted sum as u16
+  if (p.wL < 0 || p.wM < 0 || p.wB < 0 || p.wNA < 0 || 10ll * ((long long)p.wL + p.wM + p.wB + p.wNA) > 65535)
+    throw EngineError(KB_E_UNSUPPORTED, "nodeorder weights must be >= 0 with 10*(least+most+balanced+nodeaffinity) <= 65535 (u16 score)");
   return p;
 }
 

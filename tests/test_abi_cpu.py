@@ -48,6 +48,32 @@ def test_create_without_gpu_fails_loudly(L):
     assert "no CPU fallback" in str(ei.value)
 
 
+def test_weights_outside_the_u16_score_envelope_are_unsupported(L):
+    """The matrix stores the weighted score as u16; every scorer (NodeAffinity after NormalizeReduce too) yields 0..10.  The policy
+    check runs before any device call, so it answers without a GPU: such a conf must get KB_E_UNSUPPORTED (stock action), not a
+    wrapped score."""
+    tmpl = """
+actions: "allocate"
+tiers:
+- plugins:
+  - name: predicates
+  - name: nodeorder
+    arguments:
+      leastrequested.weight: {wl}
+      mostrequested.weight: {wm}
+      balancedresource.weight: {wb}
+      nodeaffinity.weight: {wa}
+"""
+    for wl, wm, wb, wa in ((3000, 3000, 500, 100), (7000, 0, 0, 1), (1, 0, 1, -1), (-1, 0, 1, 1), (0, 0, 0, 6554)):
+        with pytest.raises(engine.EngineError) as ei:
+            engine.Engine(kbm.conf.load_scheduler_conf(tmpl.format(wl=wl, wm=wm, wb=wb, wa=wa)))
+        assert ei.value.code == abi.KB_E_UNSUPPORTED, (wl, wm, wb, wa)
+    try:        # just inside the envelope: accepted by the policy check (then KB_E_DEVICE here, an engine on a GPU box)
+        engine.Engine(kbm.conf.load_scheduler_conf(tmpl.format(wl=3000, wm=3000, wb=500, wa=53))).close()
+    except engine.EngineError as e:
+        assert e.code == abi.KB_E_DEVICE
+
+
 def test_unknown_plugin_rejected():
     conf = kbm.conf.SchedulerConf(actions=["allocate"], tiers=[[kbm.conf.PluginOption("nosuch")]])
     with pytest.raises(ValueError):
