@@ -77,6 +77,18 @@ def _node(doc) -> Node:
     )
 
 
+def _requirements(lst):
+    return [(ex.get("key", ""), ex.get("operator", ""), tuple(str(v) for v in ex.get("values", []) or [])) for ex in lst or []]
+
+
+def _required_terms(spec):
+    """nodeAffinity.requiredDuringSchedulingIgnoredDuringExecution -> Pod.required_affinity (None when the field is absent)."""
+    req = ((spec.get("affinity") or {}).get("nodeAffinity") or {}).get("requiredDuringSchedulingIgnoredDuringExecution")
+    if req is None:
+        return None
+    return [(_requirements(t.get("matchExpressions")), _requirements(t.get("matchFields"))) for t in req.get("nodeSelectorTerms") or []]
+
+
 def _pod(doc, namespace: str) -> Pod:
     meta, spec, status = doc.get("metadata", {}), doc.get("spec", {}) or {}, doc.get("status", {}) or {}
     aff = spec.get("affinity") or {}
@@ -102,6 +114,7 @@ def _pod(doc, namespace: str) -> Pod:
         priority_class_name=spec.get("priorityClassName", "") or "",
         host_ports=[(cp.get("hostIP", "") or "", cp.get("protocol", "") or "", int(cp.get("hostPort", 0) or 0))
                     for c in spec.get("containers", []) or [] for cp in c.get("ports", []) or [] if int(cp.get("hostPort", 0) or 0) > 0],
+        required_affinity=_required_terms(spec),
         preferred_affinity=[(int(term.get("weight", 0) or 0),
                              [(ex.get("key", ""), ex.get("operator", ""), tuple(str(v) for v in ex.get("values", []) or []))
                               for ex in ((term.get("preference") or {}).get("matchExpressions") or [])])

@@ -96,6 +96,10 @@ class Pod:
     tolerations: List[Tuple[str, str, str, str]] = field(default_factory=list)  # (key, operator, value, effect)
     # nodeAffinity.preferredDuringSchedulingIgnoredDuringExecution: (weight, [(key, operator, (values...))])
     preferred_affinity: List[Tuple[int, List[Tuple[str, str, Tuple[str, ...]]]]] = field(default_factory=list)
+    # nodeAffinity.requiredDuringSchedulingIgnoredDuringExecution.nodeSelectorTerms: None = field absent (selects every node);
+    # a list of terms (matchExpressions, matchFields), each a list of (key, operator, (values...)); terms are ORed, an empty
+    # list or an empty term selects nothing (vendor/.../apis/core/v1/helper/helpers.go:285-314)
+    required_affinity: Optional[List[Tuple[List[Tuple[str, str, Tuple[str, ...]]], List[Tuple[str, str, Tuple[str, ...]]]]]] = None
     # container ports with a hostPort: (hostIP, protocol, hostPort); "" -> 0.0.0.0 / TCP (nodeinfo/host_ports.go:137-144)
     host_ports: List[Tuple[str, str, int]] = field(default_factory=list)
     priority_class_name: str = ""       # conformance plugin: system-cluster-critical / system-node-critical are never evicted
@@ -194,17 +198,61 @@ def _ports_conflict(a, b) -> bool:
     return a[1] == b[1] and a[2] == b[2] and (a[0] == b[0] or a[0] == "0.0.0.0" or b[0] == "0.0.0.0")
 
 
+def _requirement_valid(op: str, values) -> bool:
+    """labels.NewRequirement's validation (vendor/k8s.io/apimachinery/pkg/labels/selector.go:130-176): a requirement it rejects
+    makes NodeSelectorRequirementsAsSelector fail, and MatchNodeSelectorTerms then skips the whole term."""
+    if op in ("In", "NotIn"):
+        return len(values) > 0
+    if op in ("Exists", "DoesNotExist"):
+        return len(values) == 0
+    if op in ("Gt", "Lt"):
+        if len(values) != 1:
+            return False
+        try:
+            int(list(values)[0])
+        except ValueError:
+            return False
+        return True
+    return False
+
+
+def _node_selector_terms_match(terms, labels: Dict[str, str], node_name: str) -> bool:
+    """v1helper.MatchNodeSelectorTerms (vendor/k8s.io/kubernetes/pkg/apis/core/v1/helper/helpers.go:285-314) with the node
+    fields the scheduler offers (metadata.name, predicates.go:915-922); field requirements take In / NotIn with one value
+    (helpers.go:248-273)."""
+    for exprs, fields in terms:
+        if not exprs and not fields:
+            continue
+        if exprs:
+            if not all(_requirement_valid(op, vals) for _, op, vals in exprs):
+                continue
+            if not all(_requirement_matches(labels, k, op, vals) for k, op, vals in exprs):
+                continue
+        if fields:
+            if not all(op in ("In", "NotIn") and len(vals) == 1 for _, op, vals in fields):
+                continue
+            have = {"metadata.name": node_name}
+            if not all((have.get(k, "") == list(vals)[0]) == (op == "In") for k, op, vals in fields):
+                continue
+        return True
+    return False
+
+
 def _static_ok(pod_cls, node_cls) -> bool:
-    """p2 CheckNodeCondition, p3 CheckNodeUnschedulable, p4 PodMatchNodeSelector (nodeSelector part),
+    """p2 CheckNodeCondition, p3 CheckNodeUnschedulable, p4 PodMatchNodeSelector (nodeSelector and required node affinity),
     p6 PodToleratesNodeTaints — vendor/.../algorithm/predicates/predicates.go:1675-1700,1576-1593,927-983,1596-1620."""
     selector, tolerations = pod_cls[0], pod_cls[1]
-    labels, taints, unsched, ready, netun = node_cls
+    required = pod_cls[3] if len(pod_cls) > 3 else (0,)
+    labels, taints, unsched, ready, netun = node_cls[:5]
+    node_name = node_cls[5] if len(node_cls) > 5 else ""
     if (not ready) or netun or unsched:
         return False
     labels = dict(labels)
     for k, v in selector:
         if labels.get(k) != v:
             return False
+    if required[0] and not _node_selector_terms_match(required[1], labels, node_name):
+        return False
     for t in taints:
         if t[2] in ("NoSchedule", "NoExecute") and not _tolerates(tolerations, t):
             return False
@@ -354,12 +402,15 @@ def flatten(nodes: List[Node], pods: List[Pod], pod_groups: List[PodGroup], queu
     node_acpu = np.zeros(N, np.int64); node_amem = np.zeros(N, np.int64)
     node_nzc = np.zeros(N, np.int64); node_nzm = np.zeros(N, np.int64)
     node_cls_keys = []
+    # a pod that selects nodes by field (metadata.name) makes the node name part of the static class
+    by_name = any(fields for p in pods for _, fields in (p.required_affinity or []))
     for i, n in enumerate(nodes):
         v, m, mt = _resource(n.allocatable, dims, R)
         node_alloc[:, i] = v; node_idle[:, i] = v; node_mask[i] = m; node_maxp[i] = mt
         node_acpu[i] = quantity_milli_value(n.allocatable.get("cpu", 0))
         node_amem[i] = quantity_value(n.allocatable.get("memory", 0))
-        node_cls_keys.append((tuple(sorted(n.labels.items())), tuple(n.taints), n.unschedulable, n.ready, n.network_unavailable))
+        node_cls_keys.append((tuple(sorted(n.labels.items())), tuple(n.taints), n.unschedulable, n.ready, n.network_unavailable,
+                              n.name if by_name else ""))
 
     def pod_vectors(p: Pod):
         res = np.zeros(R); mask = 0
@@ -450,13 +501,16 @@ def flatten(nodes: List[Node], pods: List[Pod], pod_groups: List[PodGroup], queu
                     t_node[k] = nidx[p.node_name]
                     node_ports[nidx[p.node_name]] |= np.uint64(want)
             pref = tuple((int(w), tuple((k2, op, tuple(vals)) for k2, op, vals in exprs)) for w, exprs in p.preferred_affinity)
-            task_cls_keys.append((tuple(sorted(p.node_selector.items())), tuple(p.tolerations), pref))
+            req = (0,) if p.required_affinity is None else (1, tuple(
+                (tuple((k2, op, tuple(vals)) for k2, op, vals in exprs), tuple((k2, op, tuple(vals)) for k2, op, vals in fields))
+                for exprs, fields in p.required_affinity))
+            task_cls_keys.append((tuple(sorted(p.node_selector.items())), tuple(p.tolerations), pref, req))
             names_tasks.append(f"{p.namespace}/{p.name}")
             k += 1
     begin[J] = k
 
-    ucls_t = sorted(set(task_cls_keys)) or [((), (), ())]
-    ucls_n = sorted(set(node_cls_keys)) or [((), (), False, True, False)]
+    ucls_t = sorted(set(task_cls_keys)) or [((), (), (), (0,))]
+    ucls_n = sorted(set(node_cls_keys)) or [((), (), False, True, False, "")]
     tmap = {c: i for i, c in enumerate(ucls_t)}
     nmap = {c: i for i, c in enumerate(ucls_n)}
     compat = np.zeros((len(ucls_t) * len(ucls_n) + 7) // 8, np.uint8)

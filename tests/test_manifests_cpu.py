@@ -183,3 +183,73 @@ spec:
 """
     with pytest.raises(manifests.UnsupportedManifest, match="inter-pod"):
         manifests.load_cluster(text)
+
+
+def _feasible(snap):
+    """node names each task's static class admits, decoded from class_compat"""
+    out = {}
+    for t, name in enumerate(snap.names["tasks"]):
+        ok = []
+        for n, nn in enumerate(snap.names["nodes"]):
+            bit = int(snap.task_class[t]) * snap.n_node_classes + int(snap.node_class[n])
+            if (int(snap.class_compat[bit >> 3]) >> (bit & 7)) & 1:
+                ok.append(nn)
+        out[name.split("/")[1]] = ok
+    return out
+
+
+def test_required_node_affinity_terms(oracle_mod):
+    """PodMatchNodeSelector's affinity half (vendor/.../predicates/predicates.go:927-967 over v1helper.MatchNodeSelectorTerms,
+    helpers.go:285-314), hand-derived: terms are ORed, expressions ANDed; an empty term list or an empty term selects nothing; a
+    requirement labels.NewRequirement rejects (no values for In, a non-integer for Gt) drops its term; NotIn matches a node without
+    the label; matchFields sees metadata.name; nodeSelector and affinity must both hold."""
+    S = snapshot
+    nodes = [S.Node("a", {"cpu": "4", "memory": "8Gi", "pods": "10"}, labels={"zone": "x", "gen": "3"}),
+             S.Node("b", {"cpu": "4", "memory": "8Gi", "pods": "10"}, labels={"zone": "y"}),
+             S.Node("c", {"cpu": "4", "memory": "8Gi", "pods": "10"})]
+
+    def pod(name, terms, selector=None):
+        return S.Pod("ns", name, [{"cpu": "1"}], group_name="g", required_affinity=terms, node_selector=selector or {})
+    E = lambda *e: (list(e), [])
+    pods = [pod("p00-nil", None),
+            pod("p01-in-x", [E(("zone", "In", ("x",)))]),
+            pod("p02-or", [E(("zone", "In", ("x",))), E(("zone", "In", ("y",)))]),
+            pod("p03-no-terms", []),
+            pod("p04-empty-term", [([], [])]),
+            pod("p05-gt", [E(("gen", "Gt", ("2",)))]),
+            pod("p06-gt-bad", [E(("gen", "Gt", ("x",)))]),
+            pod("p07-notin", [E(("zone", "NotIn", ("x",)))]),
+            pod("p08-field", [([], [("metadata.name", "In", ("c",))])]),
+            pod("p09-selector-and", [E(("zone", "Exists", ()))], selector={"zone": "y"}),
+            pod("p10-in-empty", [E(("zone", "In", ()))]),
+            pod("p11-expr-and-field", [([("zone", "In", ("x", "y"))], [("metadata.name", "NotIn", ("a",))])]),
+            pod("p12-and", [E(("zone", "In", ("x",)), ("gen", "Lt", ("3",)))]),
+            pod("p13-bad-or-good", [E(("zone", "Exists", ("v",))), E(("zone", "DoesNotExist", ()))])]
+    snap = S.flatten(nodes, pods, [S.PodGroup("ns", "g")], [S.Queue("default")])
+    assert _feasible(snap) == {
+        "p00-nil": ["a", "b", "c"], "p01-in-x": ["a"], "p02-or": ["a", "b"], "p03-no-terms": [], "p04-empty-term": [],
+        "p05-gt": ["a"], "p06-gt-bad": [], "p07-notin": ["b", "c"], "p08-field": ["c"], "p09-selector-and": ["b"],
+        "p10-in-empty": [], "p11-expr-and-field": ["b"], "p12-and": [], "p13-bad-or-good": ["c"]}
+    # the same through the oracle's predicate (mask bits of the matrix rows)
+    o = oracle_mod.Oracle(kb.conf.load_scheduler_conf(), snap)
+    mask, _ = o.eval_matrix(0, snap.n_tasks, 1)
+    want = _feasible(snap)
+    for t, name in enumerate(snap.names["tasks"]):
+        got = [nn for n, nn in enumerate(snap.names["nodes"]) if (int(mask[t, n >> 3]) >> (n & 7)) & 1]
+        assert got == want[name.split("/")[1]], name
+    # and from a manifest
+    text = """
+apiVersion: v1
+kind: Pod
+metadata: {name: p, namespace: ns, annotations: {scheduling.k8s.io/group-name: g}}
+spec:
+  containers: [{name: c, resources: {requests: {cpu: "1"}}}]
+  affinity:
+    nodeAffinity:
+      requiredDuringSchedulingIgnoredDuringExecution:
+        nodeSelectorTerms:
+        - matchExpressions: [{key: zone, operator: In, values: [x, y]}]
+          matchFields: [{key: metadata.name, operator: NotIn, values: [a]}]
+"""
+    _, mpods, _, _ = manifests.load_cluster(text)
+    assert mpods[0].required_affinity == [([("zone", "In", ("x", "y"))], [("metadata.name", "NotIn", ("a",))])]
