@@ -102,6 +102,9 @@ enum {
 #define KB_ARG_NODEORDER_NODEAFF  2  /* nodeaffinity.weight     default 1 */
 #define KB_ARG_NODEORDER_PODAFF   3  /* podaffinity.weight      default 1 */
 #define KB_ARG_NODEORDER_BALANCED 4  /* balancedresource.weight default 1 */
+/* The predicates plugin's optional pressure checks are static per (pod class, node class): the CALLER folds them into
+   class_compat (flatten.go pressureArgs / snapshot.flatten(pressure=...)) and does not pass them; a config that sets one of
+   these slots gets KB_E_UNSUPPORTED (the engine holds no node-condition state). */
 #define KB_ARG_PRED_MEM_PRESSURE  0  /* predicate.MemoryPressureEnable (predicates.go:94-107) */
 #define KB_ARG_PRED_DISK_PRESSURE 1
 #define KB_ARG_PRED_PID_PRESSURE  2

@@ -22,6 +22,7 @@ import (
 	"unsafe"
 
 	v1 "k8s.io/api/core/v1"
+	v1qos "k8s.io/kubernetes/pkg/apis/core/v1/helper/qos"
 	"k8s.io/kubernetes/pkg/scheduler/algorithm/predicates"
 	"k8s.io/kubernetes/pkg/scheduler/algorithm/priorities"
 	priorityutil "k8s.io/kubernetes/pkg/scheduler/algorithm/priorities/util"
@@ -137,15 +138,41 @@ func podNonZero(pod *v1.Pod) (cpu, mem int64) {
 }
 
 // static-predicate classes: everything the predicates plugin checks that does not change inside a cycle
-func nodeClassKey(n *api.NodeInfo) string {
-	return fmt.Sprintf("%v|%v|%v|%v", n.Node.Labels, n.Node.Spec.Taints, n.Node.Spec.Unschedulable, n.Node.Status.Conditions)
+// pressureFlags: the optional checks of the predicates plugin (plugins/predicates/predicates.go:66-110, default off).  The
+// engine does not take them as arguments (kb_engine.h: KB_ARG_PRED_*): they are static per (pod class, node class) and are
+// folded into the class table here, like the other node-condition predicates.
+type pressureFlags struct{ mem, disk, pid bool }
+
+func pressureArgs(ssn *framework.Session) pressureFlags {
+	var pf pressureFlags
+	for _, tier := range ssn.Tiers {
+		for _, p := range tier.Plugins {
+			if p.Name == "predicates" {
+				args := framework.Arguments(p.Arguments) // conf.PluginOption.Arguments is a plain map[string]string
+				args.GetBool(&pf.mem, "predicate.MemoryPressureEnable")
+				args.GetBool(&pf.disk, "predicate.DiskPressureEnable")
+				args.GetBool(&pf.pid, "predicate.PIDPressureEnable")
+			}
+		}
+	}
+	return pf
 }
-func taskClassKey(t *api.TaskInfo) (string, error) {
+
+func nodeClassKey(n *api.NodeInfo) string {
+	// only what the predicates read of a condition: its type and status (heartbeat times would make every node a class)
+	conds := make([]string, 0, len(n.Node.Status.Conditions))
+	for _, c := range n.Node.Status.Conditions {
+		conds = append(conds, string(c.Type)+"="+string(c.Status))
+	}
+	return fmt.Sprintf("%v|%v|%v|%v", n.Node.Labels, n.Node.Spec.Taints, n.Node.Spec.Unschedulable, conds)
+}
+func taskClassKey(t *api.TaskInfo, pf pressureFlags) (string, error) {
 	sp := &t.Pod.Spec
 	if sp.Affinity != nil && (sp.Affinity.PodAffinity != nil || sp.Affinity.PodAntiAffinity != nil) {
 		return "", errUnsupported("inter-pod (anti)affinity")
 	}
-	return fmt.Sprintf("%v|%v|%v", sp.NodeSelector, sp.Affinity, sp.Tolerations), nil
+	bestEffort := pf.mem && v1qos.GetPodQOS(t.Pod) == v1.PodQOSBestEffort // memory pressure only turns BestEffort pods away
+	return fmt.Sprintf("%v|%v|%v|%v", sp.NodeSelector, sp.Affinity, sp.Tolerations, bestEffort), nil
 }
 
 // host ports: every distinct (hostIP, protocol, hostPort > 0) of the session's pods is one bit (nodeinfo/host_ports.go sanitises
@@ -255,7 +282,7 @@ func affinityCount(t *api.TaskInfo, n *api.NodeInfo) int32 {
 
 // one (task class, node class) pair through the vendored predicates themselves, the ones
 // plugins/predicates/predicates.go:123-157 and :181-207 call
-func staticOK(t *api.TaskInfo, n *api.NodeInfo) bool {
+func staticOK(t *api.TaskInfo, n *api.NodeInfo, pf pressureFlags) bool {
 	ni := nodeinfo.NewNodeInfo()
 	ni.SetNode(n.Node)
 	if ok, _, _ := predicates.CheckNodeConditionPredicate(t.Pod, nil, ni); !ok {
@@ -269,6 +296,21 @@ func staticOK(t *api.TaskInfo, n *api.NodeInfo) bool {
 	}
 	if ok, _, _ := predicates.PodToleratesNodeTaints(t.Pod, nil, ni); !ok {
 		return false
+	}
+	if pf.mem { // plugins/predicates/predicates.go:201-215
+		if ok, _, _ := predicates.CheckNodeMemoryPressurePredicate(t.Pod, nil, ni); !ok {
+			return false
+		}
+	}
+	if pf.disk { // :217-231
+		if ok, _, _ := predicates.CheckNodeDiskPressurePredicate(t.Pod, nil, ni); !ok {
+			return false
+		}
+	}
+	if pf.pid { // :233-247
+		if ok, _, _ := predicates.CheckNodePIDPressurePredicate(t.Pod, nil, ni); !ok {
+			return false
+		}
 	}
 	return true
 }
@@ -299,6 +341,7 @@ func taskStatus(s api.TaskStatus) uint8 {
 
 func flatten(ssn *framework.Session) (*flat, error) {
 	f := &flat{}
+	pf := pressureArgs(ssn)
 	dims := scalarDims(ssn)
 	R := 2 + len(dims)
 	if R > C.KB_MAX_RES {
@@ -434,7 +477,7 @@ func flatten(ssn *framework.Session) (*flat, error) {
 				f.free()
 				return nil, errUnsupported("pending task with a stale NodeName (un-pipelined by a discarded statement)")
 			}
-			key, err := taskClassKey(ti)
+			key, err := taskClassKey(ti, pf)
 			if err != nil {
 				f.free()
 				return nil, err
@@ -467,7 +510,7 @@ func flatten(ssn *framework.Session) (*flat, error) {
 	anyAffinity := false
 	for a, tr := range taskClassRep {
 		for b, nr := range nodeClassRep {
-			if staticOK(tr, nr) {
+			if staticOK(tr, nr, pf) {
 				bit := a*nnc + b
 				compat[bit>>3] |= 1 << uint(bit&7)
 			}

@@ -55,8 +55,27 @@ class SchedulerConf:
     actions: List[str]
     tiers: List[List[PluginOption]]
 
-    def to_abi(self, device: int = 0, window: int = 0, commit_batch: int = 0, flags: int = 0):
-        """Returns (kb_config, keepalive) — keepalive owns the arrays the struct points to."""
+    def pressure_flags(self):
+        """(MemoryPressureEnable, DiskPressureEnable, PIDPressureEnable) of the predicates plugin (plugins/predicates/
+        predicates.go:66-110: framework.Arguments.GetBool, default false) — what snapshot.flatten(pressure=...) folds into the
+        static class table."""
+        out = [False, False, False]
+        for tier in self.tiers:
+            for po in tier:
+                if po.name != "predicates":
+                    continue
+                for key, slot in _ARG_SLOTS["predicates"].items():
+                    sval = str((po.arguments or {}).get(key, ""))
+                    if sval in ("1", "t", "T", "TRUE", "true", "True"):
+                        out[slot] = True
+                    elif sval in ("0", "f", "F", "FALSE", "false", "False"):
+                        out[slot] = False
+        return tuple(out)
+
+    def to_abi(self, device: int = 0, window: int = 0, commit_batch: int = 0, flags: int = 0, pressure_folded: bool = False):
+        """Returns (kb_config, keepalive) — keepalive owns the arrays the struct points to.  pressure_folded: the snapshot was
+        flattened with pressure=self.pressure_flags(), so the predicates plugin's pressure arguments are not handed to the
+        engine (which answers KB_E_UNSUPPORTED to them: it has no per-node condition state, kb_engine.h KB_ARG_PRED_*)."""
         n_p = sum(len(t) for t in self.tiers)
         tier_begin = (C.c_uint32 * (len(self.tiers) + 1))()
         plugins = (abi.PluginOption * max(n_p, 1))()
@@ -72,7 +91,7 @@ class SchedulerConf:
                 o.args_set = 0
                 for key, val in (po.arguments or {}).items():
                     slot = _ARG_SLOTS.get(po.name, {}).get(key)
-                    if slot is None or val == "":
+                    if slot is None or val == "" or (pressure_folded and po.name == "predicates"):
                         continue
                     sval = str(val)
                     if po.name == "predicates":          # framework/arguments.go:49-66 strconv.ParseBool

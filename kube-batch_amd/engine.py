@@ -80,9 +80,9 @@ class Engine:
     """One kb_engine handle.  Mirrors the life-cycle the Go action drives: create (once per process),
     load(snapshot) per scheduling cycle, run_allocate / run_backfill per configured action."""
 
-    def __init__(self, conf, device: int = 0, window: int = 0, commit_batch: int = 0, flags: int = 0):
+    def __init__(self, conf, device: int = 0, window: int = 0, commit_batch: int = 0, flags: int = 0, pressure_folded: bool = False):
         self.L = lib()
-        cfg, self._keep = conf.to_abi(device=device, window=window, commit_batch=commit_batch, flags=flags)
+        cfg, self._keep = conf.to_abi(device=device, window=window, commit_batch=commit_batch, flags=flags, pressure_folded=pressure_folded)
         h = C.c_void_p()
         rc = self.L.kb_engine_create(C.byref(cfg), C.byref(h))
         if rc != abi.KB_OK:

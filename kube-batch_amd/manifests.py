@@ -74,6 +74,8 @@ def _node(doc) -> Node:
         unschedulable=bool(spec.get("unschedulable", False)),
         ready=conds.get("Ready", "True") == "True",
         network_unavailable=conds.get("NetworkUnavailable", "False") == "True",
+        memory_pressure=conds.get("MemoryPressure") == "True", disk_pressure=conds.get("DiskPressure") == "True",
+        pid_pressure=conds.get("PIDPressure") == "True",
     )
 
 
@@ -112,6 +114,8 @@ def _pod(doc, namespace: str) -> Pod:
         tolerations=[(t.get("key", "") or "", t.get("operator", "Equal") or "Equal", t.get("value", "") or "", t.get("effect", "") or "")
                      for t in spec.get("tolerations", []) or []],
         priority_class_name=spec.get("priorityClassName", "") or "",
+        limits=[{k: str(v) for k, v in ((c.get("resources") or {}).get("limits") or {}).items()}
+                for c in (spec.get("containers") or []) + (spec.get("initContainers") or [])],
         host_ports=[(cp.get("hostIP", "") or "", cp.get("protocol", "") or "", int(cp.get("hostPort", 0) or 0))
                     for c in spec.get("containers", []) or [] for cp in c.get("ports", []) or [] if int(cp.get("hostPort", 0) or 0) > 0],
         required_affinity=_required_terms(spec),
@@ -156,7 +160,8 @@ def load_snapshot(text: str, **kw) -> SessionSnapshot:
     """Manifest stream -> flattened session snapshot (what kb_session_load takes).  A default queue is added when the
     stream carries none (config/queue/default.yaml: weight 1)."""
     default_queue = kw.get("default_queue", "default")
+    pressure = kw.pop("pressure", (False, False, False))       # SchedulerConf.pressure_flags()
     nodes, pods, pgs, queues = load_cluster(text, **kw)
     if not any(q.name == default_queue for q in queues):
         queues.append(Queue(default_queue, 1))
-    return flatten(nodes, pods, pgs, queues)
+    return flatten(nodes, pods, pgs, queues, pressure=pressure)

@@ -77,6 +77,11 @@ class Node:
     unschedulable: bool = False
     ready: bool = True                    # every NodeReady condition True (predicates.go:1675-1700)
     network_unavailable: bool = False
+    # MemoryPressure / DiskPressure / PIDPressure condition status == "True"; read only when the predicates plugin's optional
+    # checks are enabled (plugins/predicates/predicates.go:94-107,201-247)
+    memory_pressure: bool = False
+    disk_pressure: bool = False
+    pid_pressure: bool = False
 
 
 @dataclass
@@ -103,6 +108,8 @@ class Pod:
     # container ports with a hostPort: (hostIP, protocol, hostPort); "" -> 0.0.0.0 / TCP (nodeinfo/host_ports.go:137-144)
     host_ports: List[Tuple[str, str, int]] = field(default_factory=list)
     priority_class_name: str = ""       # conformance plugin: system-cluster-critical / system-node-critical are never evicted
+    # resources.limits of every container and init container (only read for the pod's QoS class: the memory-pressure check)
+    limits: List[Dict[str, str]] = field(default_factory=list)
 
 
 @dataclass
@@ -238,7 +245,17 @@ def _node_selector_terms_match(terms, labels: Dict[str, str], node_name: str) ->
     return False
 
 
-def _static_ok(pod_cls, node_cls) -> bool:
+def _best_effort_qos(p: "Pod") -> bool:
+    """v1qos.GetPodQOS(pod) == BestEffort (vendor/k8s.io/kubernetes/pkg/apis/core/v1/helper/qos/qos.go:37-82): no container or init
+    container has a cpu or memory request or limit above zero."""
+    for c in list(p.containers) + list(p.init_containers) + list(p.limits):
+        for name in ("cpu", "memory"):
+            if name in c and parse_quantity(c[name]) > 0:
+                return False
+    return True
+
+
+def _static_ok(pod_cls, node_cls, pressure=(False, False, False)) -> bool:
     """p2 CheckNodeCondition, p3 CheckNodeUnschedulable, p4 PodMatchNodeSelector (nodeSelector and required node affinity),
     p6 PodToleratesNodeTaints — vendor/.../algorithm/predicates/predicates.go:1675-1700,1576-1593,927-983,1596-1620."""
     selector, tolerations = pod_cls[0], pod_cls[1]
@@ -256,6 +273,13 @@ def _static_ok(pod_cls, node_cls) -> bool:
     for t in taints:
         if t[2] in ("NoSchedule", "NoExecute") and not _tolerates(tolerations, t):
             return False
+    # optional checks (vendor/.../predicates/predicates.go:1633-1672): memory pressure only turns BestEffort pods away
+    mem_p, disk_p, pid_p = node_cls[6] if len(node_cls) > 6 else (False, False, False)
+    best_effort = pod_cls[4] if len(pod_cls) > 4 else False
+    if pressure[0] and mem_p and best_effort:
+        return False
+    if (pressure[1] and disk_p) or (pressure[2] and pid_p):
+        return False
     return True
 
 
@@ -351,8 +375,12 @@ def _resource(rl: Dict[str, str], dims: Dict[str, int], R: int):
 
 
 def flatten(nodes: List[Node], pods: List[Pod], pod_groups: List[PodGroup], queues: List[Queue],
-            default_queue: str = "default") -> SessionSnapshot:
-    """Kubernetes-shaped objects -> canonical SoA snapshot (what cache.Snapshot() + the Go shim's flatten produce)."""
+            default_queue: str = "default", pressure: Tuple[bool, bool, bool] = (False, False, False)) -> SessionSnapshot:
+    """Kubernetes-shaped objects -> canonical SoA snapshot (what cache.Snapshot() + the Go shim's flatten produce).
+    pressure = the predicates plugin's (MemoryPressureEnable, DiskPressureEnable, PIDPressureEnable) arguments
+    (SchedulerConf.pressure_flags()): static per class pair, so they are folded into class_compat here and the engine never
+    sees them."""
+    pressure = tuple(bool(x) for x in pressure)
     scalar_names = set()
     for n in nodes:
         scalar_names.update(k for k in n.allocatable if is_scalar_resource_name(k))
@@ -410,7 +438,8 @@ def flatten(nodes: List[Node], pods: List[Pod], pod_groups: List[PodGroup], queu
         node_acpu[i] = quantity_milli_value(n.allocatable.get("cpu", 0))
         node_amem[i] = quantity_value(n.allocatable.get("memory", 0))
         node_cls_keys.append((tuple(sorted(n.labels.items())), tuple(n.taints), n.unschedulable, n.ready, n.network_unavailable,
-                              n.name if by_name else ""))
+                              n.name if by_name else "",
+                              (n.memory_pressure and pressure[0], n.disk_pressure and pressure[1], n.pid_pressure and pressure[2])))
 
     def pod_vectors(p: Pod):
         res = np.zeros(R); mask = 0
@@ -504,19 +533,20 @@ def flatten(nodes: List[Node], pods: List[Pod], pod_groups: List[PodGroup], queu
             req = (0,) if p.required_affinity is None else (1, tuple(
                 (tuple((k2, op, tuple(vals)) for k2, op, vals in exprs), tuple((k2, op, tuple(vals)) for k2, op, vals in fields))
                 for exprs, fields in p.required_affinity))
-            task_cls_keys.append((tuple(sorted(p.node_selector.items())), tuple(p.tolerations), pref, req))
+            task_cls_keys.append((tuple(sorted(p.node_selector.items())), tuple(p.tolerations), pref, req,
+                                  pressure[0] and _best_effort_qos(p)))
             names_tasks.append(f"{p.namespace}/{p.name}")
             k += 1
     begin[J] = k
 
-    ucls_t = sorted(set(task_cls_keys)) or [((), (), (), (0,))]
-    ucls_n = sorted(set(node_cls_keys)) or [((), (), False, True, False, "")]
+    ucls_t = sorted(set(task_cls_keys)) or [((), (), (), (0,), False)]
+    ucls_n = sorted(set(node_cls_keys)) or [((), (), False, True, False, "", (False, False, False))]
     tmap = {c: i for i, c in enumerate(ucls_t)}
     nmap = {c: i for i, c in enumerate(ucls_n)}
     compat = np.zeros((len(ucls_t) * len(ucls_n) + 7) // 8, np.uint8)
     for ti, tc in enumerate(ucls_t):
         for ni, nc in enumerate(ucls_n):
-            if _static_ok(tc, nc):
+            if _static_ok(tc, nc, pressure):
                 b = ti * len(ucls_n) + ni
                 compat[b >> 3] |= 1 << (b & 7)
     affinity = None

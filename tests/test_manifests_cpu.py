@@ -253,3 +253,69 @@ spec:
 """
     _, mpods, _, _ = manifests.load_cluster(text)
     assert mpods[0].required_affinity == [([("zone", "In", ("x", "y"))], [("metadata.name", "NotIn", ("a",))])]
+
+
+def test_pressure_predicates_fold_into_the_class_table(oracle_mod):
+    """plugins/predicates/predicates.go:201-247 + vendor/.../predicates/predicates.go:1633-1672, hand-derived: with the plugin's
+    optional arguments on, a node reporting MemoryPressure turns away BestEffort pods only (no cpu/memory request or limit in any
+    container, qos.go:37-82), DiskPressure and PIDPressure turn away every pod; with the arguments off (the default) the
+    conditions are ignored.  The engine never sees the arguments: both flatteners fold them into class_compat."""
+    text = """
+apiVersion: v1
+kind: List
+items:
+- {apiVersion: v1, kind: Node, metadata: {name: n-ok}, status: {allocatable: {cpu: "4", memory: 8Gi, pods: "10"}, conditions: [{type: Ready, status: "True"}]}}
+- {apiVersion: v1, kind: Node, metadata: {name: n-mem}, status: {allocatable: {cpu: "4", memory: 8Gi, pods: "10"}, conditions: [{type: Ready, status: "True"}, {type: MemoryPressure, status: "True"}]}}
+- {apiVersion: v1, kind: Node, metadata: {name: n-disk}, status: {allocatable: {cpu: "4", memory: 8Gi, pods: "10"}, conditions: [{type: Ready, status: "True"}, {type: DiskPressure, status: "True"}]}}
+- {apiVersion: v1, kind: Node, metadata: {name: n-pid}, status: {allocatable: {cpu: "4", memory: 8Gi, pods: "10"}, conditions: [{type: Ready, status: "True"}, {type: PIDPressure, status: "True"}, {type: MemoryPressure, status: "False"}]}}
+- {apiVersion: scheduling.incubator.k8s.io/v1alpha1, kind: PodGroup, metadata: {name: g, namespace: ns}, spec: {minMember: 1}}
+- apiVersion: v1
+  kind: Pod
+  metadata: {name: burstable, namespace: ns, annotations: {scheduling.k8s.io/group-name: g}}
+  spec: {containers: [{name: c, resources: {requests: {cpu: "1"}}}]}
+- apiVersion: v1
+  kind: Pod
+  metadata: {name: besteffort, namespace: ns, annotations: {scheduling.k8s.io/group-name: g}}
+  spec: {containers: [{name: c}]}
+- apiVersion: v1
+  kind: Pod
+  metadata: {name: limit-only, namespace: ns, annotations: {scheduling.k8s.io/group-name: g}}
+  spec: {containers: [{name: c, resources: {limits: {memory: 1Gi}}}]}
+- apiVersion: v1
+  kind: Pod
+  metadata: {name: gpu-only, namespace: ns, annotations: {scheduling.k8s.io/group-name: g}}
+  spec: {containers: [{name: c, resources: {requests: {nvidia.com/gpu: "0"}}}]}
+"""
+    conf_on = kb.conf.load_scheduler_conf("""
+actions: "allocate, backfill"
+tiers:
+- plugins:
+  - name: predicates
+    arguments:
+      predicate.MemoryPressureEnable: true
+      predicate.DiskPressureEnable: true
+      predicate.PIDPressureEnable: "True"
+  - name: nodeorder
+""")
+    assert conf_on.pressure_flags() == (True, True, True)
+    assert kb.conf.load_scheduler_conf().pressure_flags() == (False, False, False)
+    snap = manifests.load_snapshot(text, pressure=conf_on.pressure_flags())
+    assert _feasible(snap) == {"burstable": ["n-mem", "n-ok"], "limit-only": ["n-mem", "n-ok"],
+                               "besteffort": ["n-ok"], "gpu-only": ["n-ok"]}      # node names sort as n-disk, n-mem, n-ok, n-pid
+    # memory pressure alone
+    snap = manifests.load_snapshot(text, pressure=(True, False, False))
+    assert _feasible(snap)["besteffort"] == ["n-disk", "n-ok", "n-pid"] and _feasible(snap)["burstable"] == ["n-disk", "n-mem", "n-ok", "n-pid"]
+    # default: the conditions are not read at all
+    snap = manifests.load_snapshot(text)
+    assert all(v == ["n-disk", "n-mem", "n-ok", "n-pid"] for v in _feasible(snap).values())
+    # the arguments are not handed to the engine once folded (it would answer KB_E_UNSUPPORTED to them)
+    cfg, _keep = conf_on.to_abi(pressure_folded=True)
+    assert all(cfg.plugins[i].args_set == 0 for i in range(2))
+    cfg, _keep = conf_on.to_abi()
+    assert cfg.plugins[0].args_set == 7
+    # end to end through the restated loop: the BestEffort pod is backfilled onto the only node that takes it
+    snap = manifests.load_snapshot(text, pressure=conf_on.pressure_flags())
+    o = oracle_mod.Oracle(conf_on, snap)
+    o.run(["allocate", "backfill"])
+    binds = snap.bind_map(o.binds())
+    assert binds["ns/besteffort"] == "n-ok" and binds["ns/gpu-only"] == "n-ok" and binds["ns/burstable"] in ("n-mem", "n-ok")
