@@ -171,6 +171,15 @@ func taskClassKey(t *api.TaskInfo, pf pressureFlags) (string, error) {
 	if sp.Affinity != nil && (sp.Affinity.PodAffinity != nil || sp.Affinity.PodAntiAffinity != nil) {
 		return "", errUnsupported("inter-pod (anti)affinity")
 	}
+	if t.Status == api.Pending {
+		for i := range sp.Volumes {
+			if sp.Volumes[i].PersistentVolumeClaim != nil {
+				// ssn.Allocate starts with cache.AllocateVolumes (session.go:236-238 -> AssumePodVolumes): an unbound claim can veto
+				// a placement the engine has already accounted for; the stock action takes the cycle
+				return "", errUnsupported("pending pod with a PersistentVolumeClaim (volume binding can veto a placement)")
+			}
+		}
+	}
 	bestEffort := pf.mem && v1qos.GetPodQOS(t.Pod) == v1.PodQOSBestEffort // memory pressure only turns BestEffort pods away
 	return fmt.Sprintf("%v|%v|%v|%v", sp.NodeSelector, sp.Affinity, sp.Tolerations, bestEffort), nil
 }

@@ -98,6 +98,10 @@ def _pod(doc, namespace: str) -> Pod:
         # predicates p8 / priority a22: not flattened.  The reference's own result there depends on Go map order
         # (plugins/nodeorder/nodeorder.go:48-62 resolves a session-placed pod's empty NodeName to "the first node holding such a pod")
         raise UnsupportedManifest(f"pod {meta.get('namespace', namespace)}/{meta.get('name')}: inter-pod (anti)affinity")
+    if (status.get("phase", "Pending") or "Pending") == "Pending" and not spec.get("nodeName") and \
+            any((v or {}).get("persistentVolumeClaim") is not None for v in spec.get("volumes") or []):
+        # ssn.Allocate starts with cache.AllocateVolumes (framework/session.go:236-238): volume binding can veto a placement
+        raise UnsupportedManifest(f"pod {meta.get('namespace', namespace)}/{meta.get('name')}: pending pod with a PersistentVolumeClaim")
     return Pod(
         namespace=meta.get("namespace", namespace),
         name=meta["name"],

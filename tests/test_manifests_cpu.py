@@ -319,3 +319,19 @@ tiers:
     o.run(["allocate", "backfill"])
     binds = snap.bind_map(o.binds())
     assert binds["ns/besteffort"] == "n-ok" and binds["ns/gpu-only"] == "n-ok" and binds["ns/burstable"] in ("n-mem", "n-ok")
+
+
+def test_pending_pod_with_a_volume_claim_is_reported_unsupported():
+    text = """
+apiVersion: v1
+kind: Pod
+metadata: {name: p, namespace: ns, annotations: {scheduling.k8s.io/group-name: g}}
+spec:
+  containers: [{name: c, resources: {requests: {cpu: "1"}}}]
+  volumes: [{name: data, persistentVolumeClaim: {claimName: data-0}}]
+"""
+    with pytest.raises(manifests.UnsupportedManifest, match="PersistentVolumeClaim"):
+        manifests.load_cluster(text)
+    running = text.replace("spec:", "status: {phase: Running}\nspec:\n  nodeName: n1", 1)
+    _, pods, _, _ = manifests.load_cluster(running)                   # a placed pod's claim is already bound
+    assert pods[0].node_name == "n1"
