@@ -164,7 +164,11 @@ func nodeClassKey(n *api.NodeInfo) string {
 	for _, c := range n.Node.Status.Conditions {
 		conds = append(conds, string(c.Type)+"="+string(c.Status))
 	}
-	return fmt.Sprintf("%v|%v|%v|%v", n.Node.Labels, n.Node.Spec.Taints, n.Node.Spec.Unschedulable, conds)
+	taints := make([]string, 0, len(n.Node.Spec.Taints)) // not %v of the structs: TimeAdded is a pointer and would print as an address
+	for _, t := range n.Node.Spec.Taints {
+		taints = append(taints, t.Key+"="+t.Value+":"+string(t.Effect))
+	}
+	return fmt.Sprintf("%v|%v|%v|%v", n.Node.Labels, taints, n.Node.Spec.Unschedulable, conds)
 }
 func taskClassKey(t *api.TaskInfo, pf pressureFlags) (string, error) {
 	sp := &t.Pod.Spec
@@ -181,7 +185,12 @@ func taskClassKey(t *api.TaskInfo, pf pressureFlags) (string, error) {
 		}
 	}
 	bestEffort := pf.mem && v1qos.GetPodQOS(t.Pod) == v1.PodQOSBestEffort // memory pressure only turns BestEffort pods away
-	return fmt.Sprintf("%v|%v|%v|%v", sp.NodeSelector, sp.Affinity, sp.Tolerations, bestEffort), nil
+	tols := make([]string, 0, len(sp.Tolerations)) // TolerationSeconds is a pointer (and irrelevant to ToleratesTaint)
+	for _, x := range sp.Tolerations {
+		tols = append(tols, x.Key+"|"+string(x.Operator)+"|"+x.Value+"|"+string(x.Effect))
+	}
+	// *v1.Affinity is a Stringer (generated.pb.go): %v prints the whole tree, not pointers
+	return fmt.Sprintf("%v|%v|%v|%v", sp.NodeSelector, sp.Affinity, tols, bestEffort), nil
 }
 
 // host ports: every distinct (hostIP, protocol, hostPort > 0) of the session's pods is one bit (nodeinfo/host_ports.go sanitises
