@@ -59,6 +59,7 @@ def main():
     if not torch.cuda.is_available():
         print("bench.py: no GPU visible; the engine has no CPU path", file=sys.stderr)
         sys.exit(2)
+    local_rank %= torch.cuda.device_count()      # a launcher that masks devices per rank leaves ordinal 0 only
     torch.cuda.set_device(local_rank)
     if world > 1:
         import torch.distributed as dist
