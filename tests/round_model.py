@@ -123,6 +123,7 @@ class RoundModel:
         own-row deltas as {node: [dIdle R, dRel R, dnzc, dnzm, dcnt]})."""
         p, R = self.p, self.snap.n_res
         dirty, cursor, out, delta = [], {}, [], {}
+        self._total = {}                      # what the whole window did to the nodes (every row, not only the own ones)
         for i, t in enumerate(self.rows):
             if self.aff_row[t] and i > 0:
                 return i, RENORM, out, delta
@@ -152,8 +153,8 @@ class RoundModel:
             out.append((t, n, kind))
             if n not in dirty:
                 dirty.append(n)
-            if own is None or own[0] <= i < own[1]:
-                d = delta.setdefault(n, [0.0] * (2 * R + 3))
+            for tgt in ([delta] if own is None or own[0] <= i < own[1] else []) + [self._total]:
+                d = tgt.setdefault(n, [0.0] * (2 * R + 3))
                 for k in range(R):
                     d[k] += p.idle[n].get(k) - before[0][k]
                     d[R + k] += p.rel[n].get(k) - before[1][k]
@@ -183,23 +184,20 @@ class RoundModel:
     def commit(self, table, r0, r1, delta):
         lists = [[int(x) for x in table[m].tolist()] for m in range(len(self.mrows))]
         self._last = self.commit_window(lists, own=(r0, r1))
-        # the replica's own total, for apply()'s check
-        self._total = self._sum_all = None
         N, R = self.snap.n_nodes, self.snap.n_res
         delta.zero_()
         for n, d in self._last[3].items():
             for k in range(2 * R + 3):
                 delta[k * N + n] += d[k]
-        self._mine = self._last[3]
 
     def apply(self, delta):
         """the all-reduced deltas must describe exactly what this replica's own commit did to its nodes this round"""
         N, R = self.snap.n_nodes, self.snap.n_res
         n_done, reason, out, _ = self._last
-        touched = sorted({n for _, n, _ in out})
-        got = delta.numpy().reshape(2 * R + 3, N)
-        assert sorted(np.nonzero(np.abs(got).sum(axis=0))[0].tolist()) == [n for n in touched if np.abs(got[:, n]).sum() != 0]
-        self._round_delta = got.copy()
+        want = np.zeros((2 * R + 3, N))
+        for n, d in self._total.items():
+            want[:, n] = d
+        assert np.array_equal(delta.numpy().reshape(2 * R + 3, N), want), "replicas diverged: reduced deltas differ from the local commit"
         self.absorb(n_done, reason, out)
 
     def decisions(self):
