@@ -49,8 +49,11 @@ class Session:
         self.node_releasing = snap.node_releasing.copy()
         self.node_pod_cnt = snap.node_pod_cnt.copy()
         self._gang_ready = any(p.name == "gang" and (p.enabled & abi.EN_JOB_READY) for t in conf.tiers for p in t)
-        self.engine = Engine(conf, **engine_kw)
-        self.engine.load(snap)
+        # engine=<object>: a caller-provided engine (tests replay recorded decisions through the Session without a device)
+        self.engine = engine_kw.pop("engine", None)
+        if self.engine is None:
+            self.engine = Engine(conf, **engine_kw)
+            self.engine.load(snap)
 
     # ---- JobInfo counters (api/job_info.go:383-434)
     def _job_tasks(self, j):
