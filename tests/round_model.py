@@ -51,8 +51,8 @@ class RoundModel:
                 self.dead[y] = True
         self.dead[x] = True
 
-    def plan(self):
-        self.Lh.hh_checkpoint(self.m.h)
+    def plan(self, ahead=False):
+        (self.Lh.hh_push_checkpoint if ahead else self.Lh.hh_checkpoint)(self.m.h)
         rows, pops = [], 0
         while len(rows) < self.W:
             t = self.m.next()
@@ -64,6 +64,12 @@ class RoundModel:
                 continue
             rows.append(t)
             self.m.report("alloc")
+        if ahead:
+            return rows, pops
+        self._set_window(rows, pops)
+        return len(rows)
+
+    def _set_window(self, rows, pops, list_len=None):
         self.rows, self.spec_pops = rows, pops
         if not rows:
             self.popped += pops
@@ -76,8 +82,7 @@ class RoundModel:
                 seen[k] = len(self.mrows)
                 self.mrows.append(t)
             self.mrow_of.append(seen[k])
-        self.L = len(rows) + 1
-        return len(rows)
+        self.L = list_len or len(rows) + 1
 
     def absorb(self, n_done, reason, out):
         rows = self.rows
@@ -118,11 +123,11 @@ class RoundModel:
         keys = sorted((key_of(scores[n], n) for n in feasible), reverse=True)[: self.L]
         return keys + [0] * (self.L - len(keys))
 
-    def commit_window(self, table, own=None):
+    def commit_window(self, table, own=None, pre_dirty=()):
         """K5: the sequential commit over the window against the gathered candidate table.  Returns (n_done, reason, decisions,
         own-row deltas as {node: [dIdle R, dRel R, dnzc, dnzm, dcnt]})."""
         p, R = self.p, self.snap.n_res
-        dirty, cursor, out, delta = [], {}, [], {}
+        dirty, cursor, out, delta = list(pre_dirty), {}, [], {}
         self._total = {}                      # what the whole window did to the nodes (every row, not only the own ones)
         for i, t in enumerate(self.rows):
             if self.aff_row[t] and i > 0:
@@ -170,6 +175,44 @@ class RoundModel:
             table = [self.candidate_list(m) for m in range(len(self.mrows))]
             n_done, reason, out, _ = self.commit_window(table)
             self.absorb(n_done, reason, out)
+        return self
+
+    def run_single_stale(self):
+        """the lists of window k+1 are built while window k commits, i.e. from the state at the START of round k,
+        for the window speculated behind the second checkpoint; its commit starts with the nodes round k changed already dirty
+        (lists of length 2W + 1).  A break re-plans with fresh lists; a next window holding an affinity row (its score is
+        normalised over the feasible set, which the stale state may overstate) gets fresh lists too."""
+        n = self.plan()
+        table = [self.candidate_list(m) for m in range(len(self.mrows))]
+        pre_dirty = []
+        self.stale_rounds = 0
+        while n:
+            rows_next, pops_next = self.plan(ahead=True)
+            cur = (self.rows, self.spec_pops, self.mrow_of, self.mrows, self.L)
+            stale_ok = bool(rows_next) and not any(self.aff_row[t] for t in rows_next)
+            if stale_ok:                                        # K1 + K3 of the NEXT window, before this window's commit
+                popped = self.popped
+                self._set_window(rows_next, pops_next, list_len=2 * self.W + 1)
+                self.popped = popped
+                next_shapes = (self.mrow_of, self.mrows, self.L)
+                table_next = [self.candidate_list(m) for m in range(len(self.mrows))]
+            self.rows, self.spec_pops, self.mrow_of, self.mrows, self.L = cur
+            n_done, reason, out, _ = self.commit_window(table, pre_dirty=pre_dirty)
+            self.absorb(n_done, reason, out)
+            if reason != DONE:                                  # absorb() rolled both speculations back
+                n = self.plan()
+                table, pre_dirty = [self.candidate_list(m) for m in range(len(self.mrows))], []
+                continue
+            self.Lh.hh_pop_commit(self.m.h)                     # ActionRun::promote
+            if stale_ok:
+                self.rows, self.spec_pops = rows_next, pops_next
+                self.mrow_of, self.mrows, self.L = next_shapes
+                table, pre_dirty = table_next, sorted({nd for _, nd, _ in out})   # what round k changed after the lists were built
+                self.stale_rounds += 1
+            else:
+                self._set_window(rows_next, pops_next)
+                table, pre_dirty = [self.candidate_list(m) for m in range(len(self.mrows))], []
+            n = len(rows_next)
         return self
 
     # ---- dist.py backend interface (kb_round_* of the C ABI)

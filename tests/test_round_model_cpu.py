@@ -39,6 +39,12 @@ def _check(L, cfg, snap, seed):
             for d in range(snap.n_res):
                 assert m.p.idle[n].get(d) == ref.idle[n].get(d) and m.p.rel[n].get(d) == ref.rel[n].get(d)
         m.close()
+    # lists one round stale (built while the previous window commits), 2W + 1 entries, previous round's nodes dirty
+    for window in (int(rng.choice([2, 4, 7])), int(rng.choice([16, 48]))):
+        m = round_model.RoundModel(L, cfg, snap, cases._tiers(cfg), window).run_single_stale()
+        assert m.decs == ref.decisions, (seed, window, "stale")
+        assert m.popped == ref.popped, (seed, window, "stale")
+        m.close()
 
 
 @pytest.mark.parametrize("seed", range(30))
