@@ -484,3 +484,21 @@ def test_oracle_matches_its_committed_digests(oracle_mod):
     want = json.load(open(os.path.join(here, "golden", "oracle_digests.json")))
     for name, idx, scale, actions in mg.CASES:
         assert mg.digest(kbm, oracle_mod, idx, scale, actions) == want[name], name
+
+
+def test_threaded_oracle_equals_single_threaded(oracle_mod):
+    """The cpu_baseline leg times the oracle with the reference's 16-worker fan-out per task (util/scheduler_helper.go:63-86; used for
+    N >= 256).  The fan-out must not change a single decision."""
+    cfg = conf.load_scheduler_conf()
+    snap = snapmod.synth(snapmod.synth_config(2, 0.4))
+    assert snap.n_nodes >= 256
+    runs = []
+    for threads in (1, 8, 16):
+        o = oracle_mod.Oracle(cfg, snap, threads=threads)
+        o.run(["allocate", "backfill"])
+        runs.append((o.decisions(), o.binds(), o.evals, [a.copy() for a in o.node_state()]))
+        o.close()
+    for r in runs[1:]:
+        assert np.array_equal(r[0], runs[0][0]) and np.array_equal(r[1], runs[0][1]) and r[2] == runs[0][2]
+        for a, b in zip(r[3], runs[0][3]):
+            assert np.array_equal(a, b)
