@@ -78,3 +78,16 @@ def test_node_info_remove_pod():
     assert p.node_remove_task(snap.names["tasks"].index("c1/p2"))
     assert (p.idle[0].cpu, p.idle[0].mem) == (4000.0, 6 * G) and p.podcnt == [2]
     assert (p.rel[0].cpu, p.rel[0].mem) == (0.0, 0.0)
+
+
+def test_arguments_get_int():
+    """framework/arguments_test.go:29-76 TestArgumentsGetInt through the conf -> kb_config path: an absent key, an unparsable value
+    and an empty value leave the default (args_set bit clear); "15" is taken."""
+    def nodeorder_args(arguments):
+        c = conf.SchedulerConf(actions=["allocate"], tiers=[[conf.PluginOption("nodeorder", arguments=arguments)]])
+        cfg, _keep = c.to_abi()
+        return cfg.plugins[0].args_set, cfg.plugins[0].args[0]   # KB_ARG_NODEORDER_LEAST
+    assert nodeorder_args({"anotherkey": "12"}) == (0, 0)
+    assert nodeorder_args({"leastrequested.weight": "15"}) == (1, 15)
+    assert nodeorder_args({"leastrequested.weight": "errorvalue"}) == (0, 0)
+    assert nodeorder_args({"leastrequested.weight": ""}) == (0, 0)
