@@ -91,3 +91,18 @@ def test_arguments_get_int():
     assert nodeorder_args({"leastrequested.weight": "15"}) == (1, 15)
     assert nodeorder_args({"leastrequested.weight": "errorvalue"}) == (0, 0)
     assert nodeorder_args({"leastrequested.weight": ""}) == (0, 0)
+
+
+def test_add_task_on_a_node_without_room_changes_nothing():
+    """cache/cache_test.go:366-436 (Bind with sufficient / insufficient resources) exercises NodeInfo.AddTask's guarantee
+    (api/node_info.go:169-171: "If error occurs both task and node are guaranteed to be in the original state")."""
+    rl = fx.build_resource_list
+    pods = [fx.build_pod("c1", "small", "", "Pending", rl("1000m", "1G"), "pg"), fx.build_pod("c1", "huge", "", "Pending", rl("5000m", "50G"), "pg")]
+    snap = S.flatten(nodes=[S.Node("n1", rl("2000m", "10G"))], pods=pods, pod_groups=[S.PodGroup("c1", "pg", queue="q")], queues=[S.Queue("q", 1)])
+    p = pyref.Session(_tiers(conf.load_scheduler_conf()), snap)
+    huge, small = snap.names["tasks"].index("c1/huge"), snap.names["tasks"].index("c1/small")
+    before = (p.idle[0].cpu, p.idle[0].mem, p.podcnt[0], p.nzc[0], p.nzm[0])
+    assert not p.node_add_task(huge, 0)
+    assert (p.idle[0].cpu, p.idle[0].mem, p.podcnt[0], p.nzc[0], p.nzm[0]) == before and p.tnode[huge] == pyref.NONE and not p.onnode[huge]
+    assert p.node_add_task(small, 0)
+    assert (p.idle[0].cpu, p.idle[0].mem, p.podcnt[0]) == (1000.0, 9 * G, 1) and p.tnode[small] == 0
