@@ -1194,7 +1194,6 @@ struct ChunkPlan {
 };
 static ChunkPlan matrix_plan(kb_engine *e, uint32_t t0, uint32_t n, uint32_t fit_mode, uint32_t k) {
   ChunkPlan p;
-  HostSession &hs = e->hs;
   const size_t NP = e->dev.NP;
   ensure_window_buffers(e, n);          // h_rows / h_slot staging (host side only matters here)
   ensure_matrix_buffers(e, n, k ? k : 1);
