@@ -148,8 +148,11 @@ def main():
     # HBM bytes per launch from the PMC passes of scripts/profile_round.sh (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate
     # runs; KB units; FETCH_SIZE doubled per MI355X_MICROARCH.md's gfx950 correction).  Cannot be collected inside this
     # process, so the committed summary of the same command is read back; null when it is absent or for another config.
-    pmc = os.path.join(ROOT, "profiles", "round1", "rocprofv3_pmc_k_matrix.csv")
-    if full_ms > 0 and args.config == 3 and args.scale == 1.0 and os.path.exists(pmc):
+    import glob
+    found = sorted(glob.glob(os.path.join(ROOT, "profiles", "round*", "rocprofv3_pmc_k_matrix.csv")),
+                   key=lambda f: int("".join(c for c in os.path.basename(os.path.dirname(f)) if c.isdigit()) or 0))
+    pmc = found[-1] if found else ""                # the newest round's summary
+    if full_ms > 0 and args.config == 3 and args.scale == 1.0 and pmc:
         import csv
         vals = {}
         for row in csv.DictReader(open(pmc)):
@@ -157,7 +160,7 @@ def main():
                 vals[row["counter"]] = vals.get(row["counter"], 0.0) + float(row["mean_KB_per_dispatch"])
         if "FETCH_SIZE" in vals and "WRITE_SIZE" in vals:
             roofline["traffic"] = int((2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024)
-            roofline["traffic_source"] = "profiles/round1/rocprofv3_pmc_k_matrix.csv"
+            roofline["traffic_source"] = os.path.relpath(pmc, ROOT)
 
     out = {
         "metric": "pod-node scoring evals/sec + binds/sec, 100k tasks x 10k nodes snapshot",
