@@ -1075,6 +1075,14 @@ static int node_add_task(kbo_session *s, uint32_t t, uint32_t n, int status) {
   nd->ports |= tk->port_want;
   return 0;
 }
+/* NodeInfo.UpdateTask (node_info.go:245-256) = RemoveTask + AddTask; an AddTask error there is glog.Fatalf — the process dies,
+   which this restatement reports like a panic (reachable only when Idle has drifted below -epsilon, e.g. through sub-epsilon
+   scalar requests that LessEqual skips, resource_info.go:283-287) */
+static void node_update_task(kbo_session *s, uint32_t t, int status) {
+  if (!s->tasks[t].on_node) return;            /* RemoveTask error: UpdateTask returns it, nothing changes */
+  node_remove_task(s, t);
+  if (node_add_task(s, t, s->tasks[t].node, status) != 0) s->panic = 1;
+}
 typedef struct stmt_op { uint8_t kind; uint32_t task; } stmt_op;   /* 0 evict, 1 pipeline */
 typedef struct stmt_t { stmt_op *ops; size_t n, cap; } stmt_t;
 static void stmt_push(stmt_t *st, uint8_t kind, uint32_t task) {
@@ -1083,15 +1091,13 @@ static void stmt_push(stmt_t *st, uint8_t kind, uint32_t task) {
 }
 static void stmt_evict(kbo_session *s, stmt_t *st, uint32_t t) {          /* statement.go:36-69 */
   job_set_status(s, t, KB_TASK_RELEASING);
-  node_remove_task(s, t);                                                  /* node.UpdateTask = RemoveTask + AddTask */
-  node_add_task(s, t, s->tasks[t].node, KB_TASK_RELEASING);
+  node_update_task(s, t, KB_TASK_RELEASING);
   fire_deallocate_event(s, t);
   stmt_push(st, 0, t);
 }
 static void stmt_unevict(kbo_session *s, uint32_t t) {                     /* statement.go:83-110 */
   job_set_status(s, t, KB_TASK_RUNNING);
-  node_remove_task(s, t);
-  node_add_task(s, t, s->tasks[t].node, KB_TASK_RUNNING);
+  node_update_task(s, t, KB_TASK_RUNNING);
   fire_allocate_event(s, t);
 }
 static void stmt_pipeline(kbo_session *s, stmt_t *st, uint32_t t, uint32_t n) {   /* statement.go:113-150 */
@@ -1376,8 +1382,7 @@ int kbo_reclaim(kbo_session *s) {
         const uint32_t v = vic[i];
         record_eviction(s, v);                                             /* ssn.Evict: cache.Evict first */
         job_set_status(s, v, KB_TASK_RELEASING);
-        node_remove_task(s, v);
-        node_add_task(s, v, s->tasks[v].node, KB_TASK_RELEASING);
+        node_update_task(s, v, KB_TASK_RELEASING);
         fire_deallocate_event(s, v);
         res_add(&reclaimed, &s->tasks[v].resreq, s->R);
         if (res_less_equal(&pt->init_resreq, &reclaimed, s->R)) break;

@@ -14,6 +14,10 @@ NONE = 0xFFFFFFFF
 EN_JOB_ORDER, EN_JOB_READY, EN_JOB_PIPELINED, EN_TASK_ORDER, EN_PREEMPTABLE, EN_RECLAIMABLE, EN_QUEUE_ORDER, EN_PREDICATE, EN_NODE_ORDER = (1 << i for i in range(9))
 
 
+class Fatal(ArithmeticError):
+    """glog.Fatalf in the reference: the process dies; reported like the Resource.Sub panic"""
+
+
 class Resource:
     """api.Resource (api/resource_info.go:28-38): scalars is None for a nil map."""
 
@@ -482,7 +486,8 @@ class Session:
 
     def node_update_task(self, t):
         if self.node_remove_task(t):
-            assert self.node_add_task(t, self.tnode[t]), "glog.Fatalf: Failed to add Task during task update"
+            if not self.node_add_task(t, self.tnode[t]):
+                raise Fatal("glog.Fatalf: Failed to add Task during task update (node_info.go:250-254)")
 
     def _dispatch_ready(self, j):                                     # session.go:277-285
         if self.job_ready(j):
