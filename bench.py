@@ -28,6 +28,23 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 
+BINPACK_CONF = """
+actions: "allocate, backfill"
+tiers:
+- plugins:
+  - name: priority
+  - name: gang
+- plugins:
+  - name: drf
+  - name: predicates
+  - name: proportion
+  - name: nodeorder
+    arguments:
+      leastrequested.weight: 0
+      mostrequested.weight: 5
+      balancedresource.weight: 1
+"""
+
 
 def main():
     ap = argparse.ArgumentParser()
@@ -66,6 +83,10 @@ def main():
         dist.init_process_group("nccl")
 
     conf = kbm.conf.load_scheduler_conf()          # pkg/scheduler/util.go:31-42 default: allocate, backfill; all six plugins
+    weights = "least 1, most 0, balanced 1"
+    if args.config == 4:                           # BASELINE configs[3] "binpack weighted scoring" (SURVEY.md §8d synthetic inputs)
+        conf = kbm.conf.load_scheduler_conf(BINPACK_CONF)
+        weights = "least 0, most 5, balanced 1"
     params = kbm.snapshot.synth_config(args.config, args.scale)
     snap = kbm.snapshot.synth(params)
     actions = ["allocate", "backfill"]
@@ -169,7 +190,7 @@ def main():
         "vs_baseline": None, "dtype": "f64+i64", "data": "synthetic",
         "config": {"workload": f"BASELINE configs[{args.config - 1}]: {snap.n_tasks} tasks x {snap.n_nodes} nodes, "
                                f"{snap.n_jobs} gang jobs, {snap.n_queues} queues, R={R}, allocate+backfill, "
-                               "plugins priority,gang,drf,predicates,proportion,nodeorder",
+                               f"plugins priority,gang,drf,predicates,proportion,nodeorder ({weights})",
                    "window": args.window or 256, "scale": args.scale},
         "binds_per_s": n_binds * args.steps / elapsed, "binds": n_binds, "decisions": int(d["decisions"] / args.steps),
         "evals_per_step": int(evals / args.steps),
