@@ -1,12 +1,14 @@
 #!/usr/bin/env python
 """Algorithmic statistics of a scheduling cycle from the ORACLE's decision trace (no GPU): shapes per window, same-shape run lengths,
 how often a row is won by a node its window already changed.  Usage: python scripts/trace_stats.py [config index, default 3]  """
-import sys, time; sys.path.insert(0,'/root/repo'); sys.path.insert(0,'/root/repo/oracle')
+import sys, time; import os; ROOT=os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0,ROOT); sys.path.insert(0,os.path.join(ROOT,'oracle'))
 import importlib, numpy as np
 kbm=importlib.import_module("kube-batch_amd")
 import oracle as om
 cfgi=int(sys.argv[1]) if len(sys.argv)>1 else 3
 conf=kbm.conf.load_scheduler_conf()
+if cfgi==4:
+    import bench; conf=kbm.conf.load_scheduler_conf(bench.BINPACK_CONF)   # configs[3]: binpack weights
 snap=kbm.snapshot.synth(kbm.snapshot.synth_config(cfgi,1.0))
 t0=time.time(); o=om.Oracle(conf,snap,threads=16); o.allocate(); print('oracle allocate s',round(time.time()-t0,1))
 dec=o.decisions(); print('decisions',len(dec),'popped',o.popped)
