@@ -24,6 +24,7 @@ import (
 	"github.com/golang/glog"
 
 	"github.com/kubernetes-sigs/kube-batch/pkg/scheduler/actions/allocate"
+	"github.com/kubernetes-sigs/kube-batch/pkg/scheduler/actions/backfill"
 	"github.com/kubernetes-sigs/kube-batch/pkg/scheduler/api"
 	"github.com/kubernetes-sigs/kube-batch/pkg/scheduler/framework"
 )
@@ -32,14 +33,32 @@ type gpuAllocateAction struct {
 	engine   *C.kb_engine      // one per process, created on first Execute from ssn.Tiers
 	tiersKey string            // re-create the engine when the YAML tiers change
 	fallback framework.Action  // the stock action, used when the engine says KB_E_UNSUPPORTED / KB_E_DEVICE
-	backfill bool              // also run backfill.go's pass on the device
+	backfill bool              // also run backfill.go's pass on the device (then drop "backfill" from the YAML actions list)
+	fallbackBackfill framework.Action
 }
 
-func New() *gpuAllocateAction { return &gpuAllocateAction{fallback: allocate.New(), backfill: false} }
+func New() *gpuAllocateAction {
+	return &gpuAllocateAction{fallback: allocate.New(), backfill: false, fallbackBackfill: backfill.New()}
+}
+
+// NewWithBackfill registers as one action that stands in for "allocate, backfill"
+func NewWithBackfill() *gpuAllocateAction {
+	a := New()
+	a.backfill = true
+	return a
+}
 
 func (a *gpuAllocateAction) Name() string  { return "gpuallocate" } // or "allocate" to override the stock action
 func (a *gpuAllocateAction) Initialize()   {}
 func (a *gpuAllocateAction) UnInitialize() { if a.engine != nil { C.kb_engine_destroy(a.engine); a.engine = nil } }
+
+// stock runs the reference actions this one stands in for
+func (a *gpuAllocateAction) stock(ssn *framework.Session) {
+	a.fallback.Execute(ssn)
+	if a.backfill {
+		a.fallbackBackfill.Execute(ssn)
+	}
+}
 
 func (a *gpuAllocateAction) Execute(ssn *framework.Session) {
 	runtime.LockOSThread() // one HIP context per OS thread is simplest; runOnce is single-threaded anyway (scheduler.go:85-101)
@@ -47,36 +66,67 @@ func (a *gpuAllocateAction) Execute(ssn *framework.Session) {
 
 	if err := a.ensureEngine(ssn); err != nil {          // conf.Tier / conf.PluginOption -> kb_config
 		glog.Warningf("gpuallocate: %v; falling back to the stock allocate action", err)
-		a.fallback.Execute(ssn)
+		a.stock(ssn)
 		return
 	}
 	fl, err := flatten(ssn)                              // canonical order + SoA arrays in C memory (C.calloc), see flatten.go
 	if err != nil {                                      // e.g. host ports / inter-pod affinity: not modelled by the engine
 		glog.V(3).Infof("gpuallocate: %v; stock action takes this cycle", err)
-		a.fallback.Execute(ssn)
+		a.stock(ssn)
 		return
 	}
 	defer fl.free()
 
 	if rc := C.kb_session_load(a.engine, &fl.snap); rc != C.KB_OK {
 		glog.Warningf("gpuallocate: load rc=%d (%s); stock action takes this cycle", rc, C.GoString(C.kb_last_error(a.engine)))
-		a.fallback.Execute(ssn)
+		a.stock(ssn)
 		return
 	}
-	decisions := make([]C.kb_decision, len(fl.tasks))
+	if len(fl.tasks) == 0 { // idle cluster: nothing to place, and &decisions[0] of an empty slice would panic
+		return
+	}
+	// The decision buffer lives in C memory: the engine fills it, Go only reads it (no Go pointer crosses the boundary).
+	capDec := C.size_t(len(fl.tasks))
+	decisions := (*C.kb_decision)(C.calloc(capDec, C.size_t(unsafe.Sizeof(C.kb_decision{}))))
+	if decisions == nil {
+		a.stock(ssn)
+		return
+	}
+	defer C.free(unsafe.Pointer(decisions))
+	dec := (*[1 << 28]C.kb_decision)(unsafe.Pointer(decisions))[:len(fl.tasks):len(fl.tasks)]
+
 	var n C.uint64_t
-	rc := C.kb_run_allocate(a.engine, (*C.kb_decision)(unsafe.Pointer(&decisions[0])), C.uint64_t(len(decisions)), &n)
+	rc := C.kb_run_allocate(a.engine, decisions, C.uint64_t(capDec), &n)
 	if rc != C.KB_OK { // error conventions of SURVEY §8b: never abort; no decisions were applied, so the stock action is still valid
 		glog.Warningf("gpuallocate: run rc=%d (%s); stock action takes this cycle", rc, C.GoString(C.kb_last_error(a.engine)))
-		a.fallback.Execute(ssn)
+		a.stock(ssn)
 		return
 	}
 	// Replay in the engine's order through the Session, exactly what allocate.go:160-183 does per task:
 	// status index, node accounting, plugin event handlers and the gang-gated cache.Bind all run in the reference code.
-	for i := 0; i < int(n); i++ {
-		task, node := fl.tasks[decisions[i].task], fl.nodes[decisions[i].node]
+	a.replay(ssn, fl, dec[:int(n)])
+
+	if a.backfill {
+		// backfill.go:40-71 on the device: BestEffort tasks (empty InitResreq) take the first node, in canonical node order,
+		// that passes the plugin predicates against the state the allocate pass left behind; every decision is an ssn.Allocate
+		// (backfill.go:61).  The engine's session already holds that state, so no second flatten / load is needed.
+		rc = C.kb_run_backfill(a.engine, decisions, C.uint64_t(capDec), &n)
+		if rc != C.KB_OK {
+			// allocate's decisions are already applied to ssn; the stock backfill works from that Session state
+			glog.Warningf("gpuallocate: backfill rc=%d (%s); stock backfill takes over", rc, C.GoString(C.kb_last_error(a.engine)))
+			a.fallbackBackfill.Execute(ssn)
+			return
+		}
+		a.replay(ssn, fl, dec[:int(n)])
+	}
+}
+
+// replay applies the engine's ordered decisions through the Session (framework/session.go:194-288)
+func (a *gpuAllocateAction) replay(ssn *framework.Session, fl *flat, dec []C.kb_decision) {
+	for i := range dec {
+		task, node := fl.tasks[dec[i].task], fl.nodes[dec[i].node]
 		var err error
-		if decisions[i].kind == 0 {
+		if dec[i].kind == 0 {
 			err = ssn.Allocate(task, node.Name) // framework/session.go:235-288
 		} else {
 			err = ssn.Pipeline(task, node.Name) // framework/session.go:194-232
@@ -85,7 +135,6 @@ func (a *gpuAllocateAction) Execute(ssn *framework.Session) {
 			glog.Errorf("gpuallocate: replay of task %s on %s failed: %v", task.UID, node.Name, err)
 		}
 	}
-	// (if a.backfill: C.kb_run_backfill + the same replay with ssn.Allocate, backfill.go:61)
 }
 
 var pluginIDs = map[string]C.uint32_t{
@@ -144,15 +193,37 @@ func (a *gpuAllocateAction) ensureEngine(ssn *framework.Session) error {
 		}
 		begin = append(begin, C.uint32_t(len(opts)))
 	}
-	var cfg C.kb_config
+	// kb_config points at two arrays.  They must live in C memory: passing &cfg with fields that point into Go slices is a
+	// "Go pointer to Go pointer" and panics under the default cgocheck=1.  Same rule flatten.go follows for the snapshot.
+	cBegin := (*C.uint32_t)(C.calloc(C.size_t(len(begin)), 4))
+	if cBegin == nil {
+		return fmt.Errorf("out of memory")
+	}
+	defer C.free(unsafe.Pointer(cBegin))
+	beginView := (*[1 << 20]C.uint32_t)(unsafe.Pointer(cBegin))[:len(begin):len(begin)]
+	copy(beginView, begin)
+	var cOpts *C.kb_plugin_option
+	if len(opts) > 0 {
+		cOpts = (*C.kb_plugin_option)(C.calloc(C.size_t(len(opts)), C.size_t(unsafe.Sizeof(C.kb_plugin_option{}))))
+		if cOpts == nil {
+			return fmt.Errorf("out of memory")
+		}
+		defer C.free(unsafe.Pointer(cOpts))
+		optsView := (*[1 << 20]C.kb_plugin_option)(unsafe.Pointer(cOpts))[:len(opts):len(opts)]
+		copy(optsView, opts)
+	}
+	cfg := (*C.kb_config)(C.calloc(1, C.size_t(unsafe.Sizeof(C.kb_config{}))))
+	if cfg == nil {
+		return fmt.Errorf("out of memory")
+	}
+	defer C.free(unsafe.Pointer(cfg))
 	cfg.version = C.KB_ABI_VERSION
 	cfg.n_tiers = C.uint32_t(len(ssn.Tiers))
-	cfg.tier_begin = (*C.uint32_t)(unsafe.Pointer(&begin[0]))
-	if len(opts) > 0 {
-		cfg.plugins = (*C.kb_plugin_option)(unsafe.Pointer(&opts[0]))
-	}
+	cfg.tier_begin = cBegin
+	cfg.plugins = cOpts
 	cfg.device = 0
-	if rc := C.kb_engine_create(&cfg, &a.engine); rc != C.KB_OK { // cfg is only read during the call
+	if rc := C.kb_engine_create(cfg, &a.engine); rc != C.KB_OK { // cfg and its arrays are only read during the call
+		a.engine = nil
 		return fmt.Errorf("kb_engine_create rc=%d: %s", int(rc), C.GoString(C.kb_last_error(nil)))
 	}
 	a.tiersKey = key

@@ -36,7 +36,9 @@ struct KbDev {
   const long long *acpu, *amem;   // [NP] nodeinfo.allocatableResource
   const int *maxpods;             // [NP]
   const uint32_t *ncls;           // [NP]
-  const uint32_t *nmask;          // [NP] Idle.ScalarResources != nil  (Allocatable had scalar keys)
+  const uint32_t *nmask;          // [NP] bits 0..29: scalar keys of Idle (!= 0 <=> Idle.ScalarResources != nil: Allocatable had scalar keys);
+                                  //      bit 31: Releasing.ScalarResources != nil (it starts EmptyResource() and only gains keys through
+                                  //      Add, node_info.go:65,154; inside allocate / backfill it is only ever Sub'ed, so this is static)
   const double *inv_acpu, *inv_amem;  // [NP] 1.0/(double)allocatable, for the exact integer-division estimate
   // tasks
   const double *t_init;           // [R][T]
@@ -51,6 +53,8 @@ struct KbDev {
   uint32_t *t_node;               // [T]
   uint32_t *t_bind;               // [T] node handed to the Binder, KB_NONE otherwise
   uint8_t *t_counted;             // [T] task's Resreq is part of drf/proportion "allocated" (AllocatedStatus at open, or placed in-session)
+  uint8_t *j_allocated;           // [J] an ssn.Allocate ran for the job in the current action: only then does session.go:277-285
+                                  //     dispatch the job's Allocated tasks (cleared by the gang ballot kernel)
   // static predicates
   const uint8_t *compat;          // bit (tc*n_nc + nc); nullptr => all compatible
   const uint32_t *crows;          // the same table as word-aligned rows [n_tc][8] (bit nc of row tc), nullptr if n_nc > 256 or no table

@@ -130,7 +130,7 @@ struct kb_engine {
   uint64_t stage_hits = 0, stage_misses = 0;   // commit kernel: batches / dirty rows (KB_K5_STATS)
   unsigned long long full_evals = 0;
   uint32_t eff_window = 0;   // window actually used for this session (bounded by the commit kernel's LDS budget)
-  DevBuf b_tinit, b_tres, b_tnzc, b_tnzm, b_tcls, b_tactive, b_tresmask, b_tjob, b_tstatus, b_tnode, b_tbind, b_tcounted, b_compat, b_crows, b_aff, b_affcls;
+  DevBuf b_tinit, b_tres, b_tnzc, b_tnzm, b_tcls, b_tactive, b_tresmask, b_tjob, b_tstatus, b_tnode, b_tbind, b_tcounted, b_jallocated, b_compat, b_crows, b_aff, b_affcls;
   DevBuf p_idle, p_rel, p_nzc, p_nzm, p_podcnt, p_tstatus, p_tnode, p_tcounted, p_ports;   // pristine copies for kb_session_reset
   DevBuf b_ports, b_twant, b_tconf;   // host ports (only when the snapshot carries any)
   DevBuf b_jbegin, b_jmin, b_jqueue, b_total, b_deserved, b_desmask, b_jalloc, b_jshare, b_qalloc, b_qshare, b_jready;
@@ -308,9 +308,10 @@ void run_finalize(kb_engine *e) {
   float ms = 0;
   HIP_OK(hipEventElapsedTime(&ms, tm.a, tm.b));
   e->stats.reduce_ms += ms;
-  // queues without a job in the session keep share 0 (no queueOpts entry)
+  // queues without a job in the session keep share 0 (no queueOpts entry), and so do queues updateShare never ran for
+  // (water-fill loop skipped on total weight 0 and no event yet: HostSession::queue_share_live)
   for (uint32_t q = 0; q < hs.Q; q++)
-    if (!hs.queue_has_attr[q]) hs.queue_share[q] = 0.0;
+    if (!hs.queue_has_attr[q] || !hs.queue_share_live[q]) hs.queue_share[q] = 0.0;
 }
 
 KbRound make_round(kb_engine *e, uint32_t n_rows, uint32_t n_mrows, uint32_t L, int fit_mode, bool backfill) {
@@ -662,6 +663,11 @@ struct ActionRun {
 
   void finish(kb_engine *e) {
     HostSession &hs = e->hs;
+    // every ssn.Allocate / ssn.Pipeline fires proportion's AllocateFunc -> updateShare for the task's queue (proportion.go:212-223)
+    for (const kb_decision &dc : decs) {
+      const uint32_t q = hs.job_queue[hs.t_job[dc.task]];
+      if (q < hs.Q) hs.queue_share_live[q] = 1;
+    }
     run_finalize(e);
     if (action == 0) {
       check_aggregates(e, om);
@@ -907,7 +913,9 @@ int kb_session_load(kb_engine *e, const kb_snapshot *sn) {
     for (uint32_t n = 0; n < N; n++) {
       Res a;
       a.mask = sn->node_scalar_mask ? sn->node_scalar_mask[n] : 0;
-      nmask[n] = a.mask;
+      nmask[n] = a.mask & 0x3FFFFFFFu;
+      for (int d = 2; d < R; d++)   // Releasing gains scalar keys only through Add of a Releasing task's Resreq: dense non-zero <=> key present
+        if (sn->node_releasing[(size_t)d * N + n] != 0.0) nmask[n] |= 0x80000000u;
       for (int d = 0; d < R; d++) a.v[d] = (d < 2 || a.has(d)) ? sn->node_allocatable[(size_t)d * N + n] : 0.0;
       res_add(hs.total, a, R);
     }
@@ -930,14 +938,18 @@ int kb_session_load(kb_engine *e, const kb_snapshot *sn) {
         if (alloc_st) res_add(allocated[q], rq, R);
       }
     }
+    hs.queue_share_at_open = 1;
     if (e->pol.has_proportion) {
       Res remaining = hs.total;
       std::vector<uint8_t> meet(Q, 0);
-      for (;;) {
+      for (bool first = true;; first = false) {
         int32_t totalWeight = 0;
         for (uint32_t q = 0; q < Q; q++)
           if (hs.queue_has_attr[q] && !meet[q]) totalWeight += hs.queue_weight[q];
-        if (totalWeight == 0) break;
+        if (totalWeight == 0) {
+          if (first) hs.queue_share_at_open = 0;   // proportion.go:113-116: no updateShare ran, shares stay 0 until an event
+          break;
+        }
         Res increasedDeserved, decreasedDeserved;
         for (uint32_t q = 0; q < Q; q++) {
           if (!hs.queue_has_attr[q] || meet[q]) continue;
@@ -1011,6 +1023,8 @@ int kb_session_load(kb_engine *e, const kb_snapshot *sn) {
       counted[t] = (st == KB_TASK_BOUND || st == KB_TASK_BINDING || st == KB_TASK_RUNNING || st == KB_TASK_ALLOCATED) ? 1 : 0;   // drf.go:71-77
     }
     upload(e->b_tcounted, counted.data(), T, s);
+    e->b_jallocated.alloc(J ? J : 1);
+    HIP_OK(hipMemsetAsync(e->b_jallocated.p, 0, J ? J : 1, s));
     d.compat = nullptr;
     d.n_nc = sn->n_node_classes ? sn->n_node_classes : 1;
     if (sn->class_compat) {
@@ -1097,6 +1111,7 @@ int kb_session_load(kb_engine *e, const kb_snapshot *sn) {
     hs.job_share.assign(J, 0.0);
     hs.queue_alloc.assign((size_t)Q * R, 0.0);
     hs.queue_share.assign(Q, 0.0);
+    hs.queue_share_live.assign(Q ? Q : 1, hs.queue_share_at_open);
     hs.job_ready.assign(J, 0);
     e->b_jalloc.alloc(sizeof(double) * (size_t)(J ? J : 1) * R);
     e->b_jshare.alloc(sizeof(double) * (J ? J : 1));
@@ -1114,7 +1129,7 @@ int kb_session_load(kb_engine *e, const kb_snapshot *sn) {
     d.t_nzc = e->b_tnzc.as<long long>(); d.t_nzm = e->b_tnzm.as<long long>();
     d.t_cls = e->b_tcls.as<uint32_t>(); d.t_active = e->b_tactive.as<uint32_t>(); d.t_resmask = e->b_tresmask.as<uint32_t>();
     d.t_job = e->b_tjob.as<uint32_t>(); d.t_status = e->b_tstatus.as<uint8_t>(); d.t_node = e->b_tnode.as<uint32_t>();
-    d.t_bind = e->b_tbind.as<uint32_t>(); d.t_counted = e->b_tcounted.as<uint8_t>();
+    d.t_bind = e->b_tbind.as<uint32_t>(); d.t_counted = e->b_tcounted.as<uint8_t>(); d.j_allocated = e->b_jallocated.as<uint8_t>();
     d.wL = e->pol.wL; d.wM = e->pol.wM; d.wB = e->pol.wB;
     d.pred_enabled = e->pol.pred_enabled ? 1 : 0;
     d.score_enabled = e->pol.nodeorder_enabled ? 1 : 0;
@@ -1147,8 +1162,10 @@ int kb_session_reset(kb_engine *e) {
     if (e->dev.ports) restore(e->b_ports, e->p_ports);
     restore(e->b_tcounted, e->p_tcounted);
     HIP_OK(hipMemsetAsync(e->b_tbind.p, 0xFF, sizeof(uint32_t) * (e->hs.T ? e->hs.T : 1), s));
+    HIP_OK(hipMemsetAsync(e->b_jallocated.p, 0, e->b_jallocated.bytes, s));
     mg_free(e->mg);
     e->mg = nullptr;
+    std::fill(e->hs.queue_share_live.begin(), e->hs.queue_share_live.end(), e->hs.queue_share_at_open);
     double keep = e->stats.reduce_ms;
     run_finalize(e);
     e->stats.reduce_ms = keep;

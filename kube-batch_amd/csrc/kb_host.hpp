@@ -157,6 +157,11 @@ struct HostSession {
   Res total;                               // drf.totalResource == proportion.totalResource
   std::vector<Res> deserved;               // [Q] proportion queueOpts[q].deserved
   std::vector<uint8_t> queue_has_attr;     // queue has a job in the session (proportion.go:69-83)
+  // proportion only calls updateShare inside its water-fill loop (proportion.go:101-154) and in its event handlers
+  // (:212-235).  When the loop's first pass finds total weight 0 it breaks before any updateShare, so every queue's share
+  // stays at its zero value — whatever it has allocated — until an Allocate / Pipeline event touches that queue.
+  uint8_t queue_share_at_open = 1;         // the water-fill loop ran at least one pass
+  std::vector<uint8_t> queue_share_live;   // [Q] updateShare has run for the queue (at open or through an event)
   // live aggregates (refreshed from the device share reduction after every action)
   std::vector<double> job_alloc;           // [J][R]
   std::vector<double> job_share;           // [J]

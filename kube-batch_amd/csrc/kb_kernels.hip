@@ -705,7 +705,7 @@ __device__ __forceinline__ void k7_commit_globals(const KbCommitArgs &a, const K
   uint32_t has_map = 0;
   if (km) {
     const KbDev &d = *a.dev;
-    has_map = kind ? 1u : d.nmask[n];   // Sub returns early when the receiver's scalar map is nil (resource_info.go:148-153)
+    has_map = kind ? (d.nmask[n] >> 31) : (d.nmask[n] & 0x7FFFFFFFu);   // Sub returns early when the receiver's scalar map is nil (resource_info.go:148-153)
     if (SUB && has_map) {
       double *vec = kind ? d.rel : d.idle;
       uint32_t dd = 2, m2 = km;
@@ -1034,7 +1034,7 @@ __global__ void __launch_bounds__(KB_K5_THREADS) k_commit(const K7KernArgs ka) {
         }
         else if (f == 15 && k.resmask) {
           const KbDev &d = *a.dev;
-          has_map = kind ? 1u : d.nmask[n];   // Sub returns early when the receiver's scalar map is nil (resource_info.go:148-153)
+          has_map = kind ? (d.nmask[n] >> 31) : (d.nmask[n] & 0x7FFFFFFFu);   // Sub returns early when the receiver's scalar map is nil (resource_info.go:148-153)
           if (has_map) {
             double *vec = kind ? d.rel : d.idle;
             uint32_t dd = 2, m2 = k.resmask;
@@ -1306,6 +1306,7 @@ __global__ void __launch_bounds__(KB_K5_THREADS) k_commit(const K7KernArgs ka) {
       d.t_status[t] = dc.y ? KB_TASK_PIPELINED : KB_TASK_ALLOCATED;
       d.t_node[t] = dc.x;
       d.t_counted[t] = 1;
+      if (!dc.y) d.j_allocated[d.t_job[t]] = 1;   // ssn.Allocate ran for the job: its Allocated tasks are dispatched if it is ready
     }
   }
   if (tid == 0) {
@@ -1354,11 +1355,14 @@ __global__ void __launch_bounds__(256) k_finalize_jobs(KbDev d, const uint32_t *
     ready += __popcll(__ballot(isr));     // JobInfo.ReadyTaskNum (job_info.go:383-394)
   }
   const bool job_ready = gang_ready_enabled ? (ready >= job_min_avail[j]) : true;   // gang.go:122-125 / session_plugins.go:182-200
-  if (job_ready) {                         // session.go:277-285: every Allocated task of a ready job is dispatched
+  // session.go:277-285: the dispatch sits inside ssn.Allocate, so it needs an Allocate on this job in this action; the ready
+  // count only changes through ssn.Allocate here, hence "ready after the job's last Allocate" == "ready now".  Every task in
+  // TaskStatusIndex[Allocated] goes, including ones the snapshot already carried as Allocated.
+  if (job_ready && d.j_allocated[j]) {
     for (uint32_t t = t0 + lane; t < t1; t += 64)
       if (d.t_status[t] == KB_TASK_ALLOCATED) { d.t_status[t] = KB_TASK_BINDING; d.t_bind[t] = d.t_node[t]; }
   }
-  if (lane == 0) job_ready_cnt[j] = ready;
+  if (lane == 0) { job_ready_cnt[j] = ready; d.j_allocated[j] = 0; }
   const uint32_t q = job_queue[j];
   double share = 0.0;
   for (int dim = 0; dim < d.R; dim++) {

@@ -120,3 +120,38 @@ def test_go_shim_sources_only_use_what_the_header_declares():
     flat = open(os.path.join(godir, "flatten.go")).read()
     for name, _ in abi.SNAPSHOT_ARRAYS:
         assert re.search(r"\bs\." + name + r"\b", flat), f"flatten.go never sets kb_snapshot.{name}"
+
+
+def test_go_shim_obeys_the_cgo_pointer_rules_statically():
+    """No Go toolchain here, so the cgo rules the shim must obey are checked on the source text (kb_config used to
+    point into Go slices, a 'Go pointer to Go pointer' panic under cgocheck=1; &decisions[0] panicked on an empty session):
+      * no C struct field is ever assigned the address of a Go slice element or a Go variable;
+      * no C.kb_* call receives &goSlice[0];
+      * every array a C struct points at comes from C.calloc / C.malloc (or one of flatten.go's calloc-backed views);
+      * the backfill pass is really replayed (kb_run_backfill is called, not merely mentioned in a comment)."""
+    godir = os.path.join(ROOT, "integration", "go", "gpuallocate")
+    for fn in sorted(os.listdir(godir)):
+        code = []
+        for line in open(os.path.join(godir, fn)).read().splitlines():
+            code.append(re.sub(r"//.*$", "", line))          # comments may say anything
+        src = "\n".join(code)
+        # 1. struct-field = address-of-Go-slice-element / unsafe.Pointer(&x[...])
+        #    (slices that ARE C memory are fine: flatten.go's calloc-backed views f.f64(n), f.u32(n), ...)
+        cviews = set()
+        for lhs, rhs in re.findall(r"^\s*([\w, ]+?)\s*:?=\s*(f\.(?:f64|i64|u64|u32|i32|u8)\(.*)$", src, flags=re.M):
+            names = [n.strip() for n in lhs.split(",")]
+            if len(names) == len(re.findall(r"\bf\.(?:f64|i64|u64|u32|i32|u8)\(", rhs)):
+                cviews.update(names)
+        taken = re.findall(r"^\s*[A-Za-z_][\w.]*\.[a-z_]+\s*=\s*\(\*C\.[\w]+\)\(unsafe\.Pointer\(&(\w+)\[", src, flags=re.M)
+        bad = [v for v in taken if v not in cviews]
+        assert not bad, f"{fn}: C struct field assigned the address of a Go slice element: {bad}"
+        # 2. C.kb_* call with &slice[i] as an argument
+        for call in re.findall(r"C\.kb_[a-z_]+\(([^\n]*)\)", src):
+            assert not re.search(r"&\w+\[\d*\w*\]", call), f"{fn}: C.kb_* call takes a Go slice element address: {call}"
+        # 3. no make([]C.kb_...) buffers handed to C
+        assert not re.search(r"make\(\[\]C\.kb_", src), f"{fn}: C struct buffers must come from C.calloc"
+    act = open(os.path.join(godir, "gpuallocate.go")).read()
+    act_code = "\n".join(re.sub(r"//.*$", "", l) for l in act.splitlines())
+    assert "C.kb_run_backfill(" in act_code and "fallbackBackfill" in act_code
+    assert "len(fl.tasks) == 0" in act_code
+    assert re.search(r"cfg\s*:=\s*\(\*C\.kb_config\)\(C\.calloc", act_code), "kb_config must be built in C memory"
