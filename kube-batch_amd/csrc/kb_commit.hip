@@ -1,0 +1,630 @@
+// kb_commit.hip — K5, the sequential commit of one window (gfx950 / CDNA4, wave64).
+//
+// The reference places one task after another (allocate.go:129-193 / backfill.go:44-67): task k+1 sees the node state
+// task k left behind.  Per row the answer is
+//     best = max( best CLEAN node of the row's shape  = first entry of the shape's sorted candidate list (K3) whose node
+//                                                       this round has not touched yet,
+//                 best DIRTY node                      = max over the nodes this round already changed of the key
+//                                                       re-evaluated against their LIVE state ).
+// A single wave executes one instruction every ~6 cycles, so a row-at-a-time loop pays ~6 cycles x (every instruction of
+// fit + score + bookkeeping) per row.  Rows, however, arrive in RUNS of one shape (the tasks of a gang), and within a run
+// everything that is expensive is data-parallel:
+//
+//   prepare   wave 0, between two runs: walks the shape's candidate list for the run's first r clean entries (ballot over the
+//             dirty bitmap); lane j then issues every load of candidate j's node state (13 + 2(R-2) loads in flight per lane),
+//             which travel while the workgroup passes the barrier;
+//   evaluate  one evaluation deep, in parallel: waves 1..4: key(shape, dirty slot t), one slot per thread (<= 256 slots);
+//             wave 0, lane j = candidate j: Allocate / Pipeline (allocate.go:160), NodeInfo.AddTask (api/node_info.go:172-212)
+//             on the fetched state, and the key of the node AFTER the placement — the key it competes with once it is dirty;
+//   rows      wave 0, sequential but O(1) per clean row: winner = max(best dirty key, next unconsumed clean candidate); the best
+//             dirty key is a scalar that a clean winner updates with one max (its post-placement key is ready); only a dirty
+//             winner costs an evaluation (AddTask on its slot in LDS, key re-evaluated, wave maximum rebuilt).
+// Two workgroup barriers per run.
+//
+// No speculation, nothing to roll back: a candidate that is not consumed simply stays clean.  Everything the loop touches
+// lives in LDS (slots, lists, row descriptors, dirty bitmap); HBM sees the dirty slots once, in the epilogue.
+//
+// Keys are 32-bit here: (score + 1) << node_bits | (2^node_bits - 1 - node), 0 = infeasible; integer max = highest score,
+// then lowest node index = util.SelectBestNode with the canonical tie-break (scheduler_helper.go:188-208).
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+#include <stdlib.h>
+
+#include "kb_device.h"
+#include "kb_eval.hpp"
+
+#define K9_THREADS 512   // wave 0: the sequential part; waves 1..4: one dirty slot per thread; all: prologue / epilogue
+#define K9_MAXRUN 64
+#define K9_MAXSC 30    // scalar resource dimensions (KB_MAX_RES - 2)
+#define K9_MAXSLOTS 256 // dirty slots (= rows) per round
+#define K9_NF 13   // 8-byte fields per dirty slot
+enum { F_IDLE0 = 0, F_IDLE1, F_REL0, F_REL1, F_INVAC, F_INVAM, F_AC, F_AM, F_NZC, F_NZM, F_PORTS, F_CLS_LEFT, F_NODE_NMASK };
+
+struct K9Shape {   // what an evaluation needs to know about a task shape (64 bytes)
+  double init0, init1, nzc, nzm;           // InitResreq cpu / memory, pod non-zero request (as doubles: exact below 2^53)
+  unsigned long long conf, want;           // host-port conflict mask, host ports the pod occupies
+  uint32_t cls, active, crow, pad;
+};
+
+struct K9Hdr {
+  uint32_t i, nd, reason, stop;            // next row, dirty slots, KB_REASON_*, 1 = leave the run loop
+  uint32_t ncand, n_dirty_rows, n_runs, n_slow;
+  uint32_t cur_s, cur_r, cur_fl, cur_km;   // the run being processed: shape, rows, flags and Resreq key mask of its rows
+};
+
+// dynamic LDS layout for a round of n_rows rows and n_shapes distinct shapes
+struct K9Layout {
+  uint32_t slots, sslots, rowres, sinit, shapes, desc, rinfo, dec, hdr, dk, ckey, cpos, cursor, shp, lists, bitmap, total;   // byte offsets
+  uint32_t Lp, RS;
+};
+__host__ __device__ inline K9Layout k9_layout(uint32_t n_rows, uint32_t n_shapes, uint32_t L, uint32_t NP, int R) {
+  K9Layout o;
+  o.RS = R > 2 ? (uint32_t)(R - 2) : 0u;
+  o.Lp = L;
+  uint32_t off = 0;
+  o.slots = off;  off += (n_rows + K9_MAXRUN) * K9_NF * 8u;   // + a run's worth: P2 writes every candidate's post-placement state
+  o.sslots = off; off += (n_rows + K9_MAXRUN) * o.RS * 16u;
+  o.rowres = off; off += (uint32_t)R * 8u;
+  o.sinit = off;  off += n_shapes * o.RS * 8u;
+  o.shapes = off; off += n_shapes * (uint32_t)sizeof(K9Shape);
+  o.desc = off;   off += n_rows * (uint32_t)sizeof(KbRowDesc);
+  off = (off + 15u) & ~15u;
+  o.rinfo = off;  off += n_rows * 16u;
+  o.dec = off;    off += n_rows * 8u;
+  o.hdr = off;    off += (uint32_t)sizeof(K9Hdr);
+  o.dk = off;     off += K9_MAXSLOTS * 4u;
+  o.ckey = off;   off += K9_MAXRUN * 4u;
+  o.cpos = off;   off += K9_MAXRUN * 4u;
+  o.cursor = off; off += n_shapes * 4u;
+  o.shp = off;    off += n_shapes * 4u;
+  o.lists = off;  off += n_shapes * o.Lp * 4u;
+  o.bitmap = off; off += (NP / 32u) * 4u;
+  o.total = (off + 15u) & ~15u;
+  return o;
+}
+size_t kb_commit_smem_bytes(uint32_t n_rows, uint32_t n_shapes, uint32_t NP, int R) {
+  return k9_layout(n_rows, n_shapes, n_rows + 1, NP, R).total;
+}
+
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
+#define K9_UMAX(ctrl, row_mask) v = max(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, (ctrl), (row_mask), 0xf, false))
+  K9_UMAX(0xB1, 0xf);    // quad_perm [1,0,3,2]
+  K9_UMAX(0x4E, 0xf);    // quad_perm [2,3,0,1]
+  K9_UMAX(0x141, 0xf);   // row_half_mirror
+  K9_UMAX(0x140, 0xf);   // row_mirror
+  K9_UMAX(0x142, 0xa);   // row_bcast:15
+  K9_UMAX(0x143, 0xc);   // row_bcast:31 -> lane 63 holds the wave maximum
+#undef K9_UMAX
+  return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+__device__ __forceinline__ uint32_t rl32(uint32_t v, uint32_t l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)l); }
+__device__ __forceinline__ unsigned long long rl64(unsigned long long v, uint32_t l) {
+  return ((unsigned long long)rl32((uint32_t)(v >> 32), l) << 32) | rl32((uint32_t)v, l);
+}
+__device__ __forceinline__ double u2d(unsigned long long v) { return __longlong_as_double((long long)v); }
+__device__ __forceinline__ unsigned long long d2u(double v) { return (unsigned long long)__double_as_longlong(v); }
+// make EXTRA=-DKB_K9_TRACE: cycles wave 0 spends in each phase of a run, summed per round into words 5..7 and 13..14 of the
+// output block, printed by the host under KB_K5_STATS=1
+#ifdef KB_K9_TRACE
+#define K9_STAMP(k) do { if (wave == 0) { const unsigned long long now_ = __builtin_readcyclecounter(); tacc[k] += (uint32_t)(now_ - tlast); tlast = now_; } } while (0)
+#else
+#define K9_STAMP(k) do { } while (0)
+#endif
+#define K9_WAVE_FENCE() do { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
+
+struct K9KernArgs {
+  KbCommitArgs hot;
+  KbDev dev;
+  KbRound round;
+};
+
+// key of shape sh against the node state in st[0..12] (a dirty slot, or a candidate after its placement); ss: the node's
+// scalar dimensions {Idle, Releasing} x RS, si: the shape's scalar InitResreq
+__device__ __forceinline__ uint32_t k9_eval(const KbCommitArgs &a, const K9Shape &sh, const unsigned long long *st, const unsigned long long *ss,
+                                            const double *si, uint32_t nb, uint32_t nmaskbits) {
+  const double idle0 = u2d(st[F_IDLE0]), idle1 = u2d(st[F_IDLE1]), rel0 = u2d(st[F_REL0]), rel1 = u2d(st[F_REL1]);
+  bool ok = true;
+  if (a.fit_mode) {   // allocate.go:81: !InitResreq.LessEqual(Idle) && !InitResreq.LessEqual(Releasing) -> fail
+    bool fi = le_eps(sh.init0, idle0, EPS_CPU) && le_eps(sh.init1, idle1, EPS_MEM);
+    bool fr = le_eps(sh.init0, rel0, EPS_CPU) && le_eps(sh.init1, rel1, EPS_MEM);
+    uint32_t aa = sh.active >> 2, dd = 0;
+    while (aa) {   // scalar dimensions with InitResreq > 10 (resource_info.go:286-299)
+      if (aa & 1u) {
+        const double l = si[dd];
+        fi = fi && le_eps(l, u2d(ss[dd * 2]), EPS_SCALAR);
+        fr = fr && le_eps(l, u2d(ss[dd * 2 + 1]), EPS_SCALAR);
+      }
+      aa >>= 1; dd++;
+    }
+    ok = fi || fr;
+  }
+  const unsigned long long cl = st[F_CLS_LEFT];
+  const uint32_t ncls = (uint32_t)cl;
+  if (a.pred_enabled) {
+    ok = ok && ((int)(uint32_t)(cl >> 32) > 0) && ((st[F_PORTS] & sh.conf) == 0ull);   // pod count (predicates.go:127), PodFitsHostPorts (predicates.go:181-190)
+    if (a.use_crow) {
+      ok = ok && ((sh.crow >> (ncls & 31)) & 1u);
+    } else {
+      const KbDev &d = *a.dev;
+      if (d.compat) {
+        const uint32_t bit = sh.cls * d.n_nc + ncls;
+        ok = ok && ((d.compat[bit >> 3] >> (bit & 7)) & 1);
+      }
+    }
+  }
+  if (!ok) return 0u;
+  uint32_t score = 0;
+  if (a.score_enabled)
+    score = score_core_f64(sh.nzc, sh.nzm, u2d(st[F_NZC]), u2d(st[F_NZM]), u2d(st[F_AC]), u2d(st[F_AM]), u2d(st[F_INVAC]), u2d(st[F_INVAM]), a.wL, a.wM, a.wB);
+  return ((score + 1u) << nb) | (nmaskbits - (uint32_t)st[F_NODE_NMASK]);
+}
+
+__global__ void __launch_bounds__(K9_THREADS) k_commit(const K9KernArgs ka) {
+  KbCommitArgs a = ka.hot;
+  {   // only `a` is named in the loops (SGPRs); the two views are read through the kernel-argument segment on rare paths
+    const unsigned char __attribute__((address_space(4))) *kp = (const unsigned char __attribute__((address_space(4))) *)__builtin_amdgcn_kernarg_segment_ptr();
+    a.dev = (const KbDev *)(kp + offsetof(K9KernArgs, dev));
+    a.round = (const KbRound *)(kp + offsetof(K9KernArgs, round));
+  }
+  extern __shared__ __align__(16) unsigned char k9_smem[];
+  const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const uint32_t S = a.n_mrows, W = a.n_rows;
+  const K9Layout lo = k9_layout(W, S, a.L, a.NP, a.R);
+  unsigned long long *slots = reinterpret_cast<unsigned long long *>(k9_smem + lo.slots);
+  unsigned long long *sslots = reinterpret_cast<unsigned long long *>(k9_smem + lo.sslots);
+  double *rowres = reinterpret_cast<double *>(k9_smem + lo.rowres);
+  double *sinit = reinterpret_cast<double *>(k9_smem + lo.sinit);
+  K9Shape *shapes = reinterpret_cast<K9Shape *>(k9_smem + lo.shapes);
+  KbRowDesc *desc = reinterpret_cast<KbRowDesc *>(k9_smem + lo.desc);
+  uint4 *rinfo = reinterpret_cast<uint4 *>(k9_smem + lo.rinfo);
+  unsigned long long *ldec = reinterpret_cast<unsigned long long *>(k9_smem + lo.dec);
+  K9Hdr &H = *reinterpret_cast<K9Hdr *>(k9_smem + lo.hdr);
+  uint32_t *dk = reinterpret_cast<uint32_t *>(k9_smem + lo.dk);
+  uint32_t *ckey = reinterpret_cast<uint32_t *>(k9_smem + lo.ckey);
+  uint32_t *cpos = reinterpret_cast<uint32_t *>(k9_smem + lo.cpos);
+  uint32_t *cursor = reinterpret_cast<uint32_t *>(k9_smem + lo.cursor);
+  uint32_t *shp = reinterpret_cast<uint32_t *>(k9_smem + lo.shp);
+  uint32_t *lists = reinterpret_cast<uint32_t *>(k9_smem + lo.lists);
+  uint32_t *bitmap = reinterpret_cast<uint32_t *>(k9_smem + lo.bitmap);
+  const uint32_t RS = lo.RS, Lp = lo.Lp;
+  const uint32_t nb = a.node_bits, nmaskbits = (1u << nb) - 1u;
+  const unsigned long long t_start = wall_clock64();
+
+  // ---------------- prologue (all threads) ----------------
+  for (uint32_t w = tid; w < a.NP / 32; w += K9_THREADS) bitmap[w] = 0;
+  {   // candidate lists: 64-bit keys of K3 -> compact 32-bit keys
+    const uint32_t tot = S * Lp;
+    for (uint32_t idx = tid; idx < tot; idx += K9_THREADS) {
+      const unsigned long long k64 = a.keys[idx];   // [S][L], Lp == L
+      lists[idx] = k64 ? (((KB_KEY_SCORE(k64) + 1u) << nb) | (nmaskbits - KB_KEY_NODE(k64))) : 0u;
+    }
+  }
+  {   // row descriptors
+    const unsigned long long *src = reinterpret_cast<const unsigned long long *>(a.desc);
+    unsigned long long *dst = reinterpret_cast<unsigned long long *>(desc);
+    for (uint32_t w = tid; w < W * (uint32_t)(sizeof(KbRowDesc) / 8); w += K9_THREADS) dst[w] = src[w];
+  }
+  for (uint32_t s = tid; s < S; s += K9_THREADS) cursor[s] = 0;
+  if (tid == 0) { H.i = 0; H.nd = 0; H.reason = KB_REASON_DONE; H.stop = 0; H.ncand = 0; H.n_dirty_rows = 0; H.n_runs = 0; H.n_slow = 0; H.cur_s = 0; H.cur_r = 0; H.cur_fl = 0; H.cur_km = 0; }
+  {
+    // The loop is latency-bound and this workgroup may start on a cold L2 (kernel boundary, another XCD): touch every 128-byte
+    // line of the node state arrays once, with all threads (all loads of a pass in flight together).
+    const KbDev &d = *a.dev;
+    unsigned long long acc = 0;
+    const uint32_t lines = a.NP / 16;
+    const unsigned long long *arrs[10] = {
+        reinterpret_cast<const unsigned long long *>(d.idle), reinterpret_cast<const unsigned long long *>(d.idle + d.NP),
+        reinterpret_cast<const unsigned long long *>(d.rel), reinterpret_cast<const unsigned long long *>(d.rel + d.NP),
+        reinterpret_cast<const unsigned long long *>(d.inv_acpu), reinterpret_cast<const unsigned long long *>(d.inv_amem),
+        reinterpret_cast<const unsigned long long *>(d.acpu), reinterpret_cast<const unsigned long long *>(d.amem),
+        reinterpret_cast<const unsigned long long *>(d.nzc), reinterpret_cast<const unsigned long long *>(d.nzm)};
+    const uint32_t *arr4[4] = {d.ncls, reinterpret_cast<const uint32_t *>(d.maxpods), reinterpret_cast<const uint32_t *>(d.podcnt), d.nmask};
+    for (uint32_t l0 = 0; l0 < lines; l0 += K9_THREADS) {
+      const uint32_t l = l0 + tid;
+      unsigned long long v[10];
+      uint32_t w[4];
+#pragma unroll
+      for (int f = 0; f < 10; f++) v[f] = (l < lines) ? arrs[f][(size_t)l * 16] : 0ull;
+#pragma unroll
+      for (int f = 0; f < 4; f++) w[f] = (l < lines / 2) ? arr4[f][(size_t)l * 32] : 0u;
+#pragma unroll
+      for (int f = 0; f < 10; f++) acc += v[f];
+#pragma unroll
+      for (int f = 0; f < 4; f++) acc += w[f];
+    }
+    if (acc == 0x123456789abcdefull) H.n_slow = 0xFFFFFFFFu;   // keep the loads alive
+  }
+  __syncthreads();
+  // shape -> one of its rows (any: rows of a shape agree on everything the evaluation reads)
+  for (uint32_t i = tid; i < W; i += K9_THREADS) shp[desc[i].slot] = i;
+  __syncthreads();
+  for (uint32_t s = tid; s < S; s += K9_THREADS) {
+    const KbRowDesc &k = desc[shp[s]];
+    K9Shape sh;
+    sh.init0 = k.init0; sh.init1 = k.init1; sh.nzc = (double)k.nzc; sh.nzm = (double)k.nzm;
+    sh.conf = a.has_ports ? a.dev->t_conf[k.task] : 0ull;
+    sh.want = a.has_ports ? a.dev->t_want[k.task] : 0ull;
+    sh.cls = k.cls; sh.active = k.active; sh.crow = k.crow; sh.pad = 0;
+    shapes[s] = sh;
+  }
+  if (RS) {
+    const KbDev &d = *a.dev;
+    for (uint32_t idx = tid; idx < S * RS; idx += K9_THREADS) {
+      const uint32_t s = idx / RS, dd = idx % RS;
+      sinit[idx] = d.t_init[(size_t)(dd + 2) * d.T + desc[shp[s]].task];
+    }
+  }
+  __syncthreads();
+
+  // run table: rows i .. i + r - 1 share a shape and take the shape's own request values (a row whose Resreq differs from its
+  // InitResreq, or whose score needs renormalising, is a run of its own)
+  for (uint32_t i = tid; i < W; i += K9_THREADS) {
+    const KbRowDesc &k = desc[i];
+    const uint32_t sl = k.slot, fl = k.flags, km = k.resmask;
+    const bool plain = (fl & 1u) && (km == 0u || (fl & 4u));
+    uint32_t r = 1;
+    if (plain && !(fl & 2u))
+      while (r < K9_MAXRUN && i + r < W && desc[i + r].slot == sl && desc[i + r].flags == fl && desc[i + r].resmask == km) r++;
+    rinfo[i] = make_uint4(r, sl, fl, km);
+  }
+  __syncthreads();
+
+#ifdef KB_K9_TRACE
+  uint32_t tacc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long tlast = __builtin_readcyclecounter();
+#endif
+  // wave 0's registers: the fetched (raw) node state of candidate `lane` of the run being prepared
+  unsigned long long raw[11] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  uint32_t rcls = 0, rmaxp = 0, rpodc = 0, rnm = 0;
+  unsigned long long rsc[K9_MAXSC][2];
+#pragma unroll
+  for (int q = 0; q < K9_MAXSC; q++) { rsc[q][0] = 0ull; rsc[q][1] = 0ull; }
+
+  // wave 0, between two runs: the next run's parameters, its clean candidates (walk of the shape's list against the dirty
+  // bitmap), and the fetch of the candidates' node state — lane j pulls every field of candidate j, all loads in flight together,
+  // while the workgroup goes through the barrier and the other waves start on the dirty slots
+#define K9_PREPARE_NEXT(i_next, nd_next, reason_in)                                                                    \
+  do {                                                                                                                 \
+    uint32_t rsn_ = (reason_in), stop_ = (rsn_ != KB_REASON_DONE) ? 1u : 0u, nc_ = 0, s_ = 0, r_ = 0, fl_ = 0, km_ = 0; \
+    if (!stop_ && (i_next) < W) {                                                                                      \
+      const uint4 ri_ = rinfo[(i_next)];                                                                               \
+      r_ = (uint32_t)__builtin_amdgcn_readfirstlane((int)ri_.x); s_ = (uint32_t)__builtin_amdgcn_readfirstlane((int)ri_.y); \
+      fl_ = (uint32_t)__builtin_amdgcn_readfirstlane((int)ri_.z); km_ = (uint32_t)__builtin_amdgcn_readfirstlane((int)ri_.w); \
+      if (a.has_aff && !a.backfill && (fl_ & 2u) && (i_next) != 0) {                                                   \
+        /* a row whose score is normalised over its feasible set (preferred node affinity) is exact only against a fresh */ \
+        /* matrix: it may be the first row of a round, nothing else */                                                 \
+        rsn_ = KB_REASON_RENORM; stop_ = 1;                                                                            \
+      } else {                                                                                                         \
+        uint32_t e_ = cursor[s_];                                                                                      \
+        while (nc_ < r_) {                                                                                             \
+          const uint32_t pos_ = e_ + lane;                                                                             \
+          const uint32_t kk_ = (pos_ < Lp) ? lists[s_ * Lp + pos_] : 0u;                                               \
+          const bool nz_ = kk_ != 0u;                                                                                  \
+          const uint32_t nn_ = nmaskbits - (kk_ & nmaskbits);                                                          \
+          const bool cl_ = nz_ && !((bitmap[(nz_ ? nn_ : 0u) >> 5] >> (nn_ & 31)) & 1u);                               \
+          const unsigned long long zeros_ = __ballot(!nz_);                                                            \
+          const uint32_t fz_ = zeros_ ? (uint32_t)__ffsll((unsigned long long)zeros_) - 1u : 64u;                      \
+          const unsigned long long clean_ = __ballot(cl_ && lane < fz_);   /* entries behind the list's end do not count */ \
+          const uint32_t rank_ = (uint32_t)__popcll(clean_ & ((1ull << lane) - 1ull));                                 \
+          if (((clean_ >> lane) & 1ull) && nc_ + rank_ < r_) { ckey[nc_ + rank_] = kk_; cpos[nc_ + rank_] = pos_; }    \
+          nc_ = min(r_, nc_ + (uint32_t)__popcll(clean_));                                                             \
+          if (fz_ < 64u || e_ + 64u >= Lp) break;   /* the list ended (or, never with L = rows + 1, ran out) */         \
+          e_ += 64u;                                                                                                   \
+        }                                                                                                              \
+        K9_WAVE_FENCE();                                                                                               \
+        if (lane < nc_) {                                                                                              \
+          const uint32_t n_ = nmaskbits - (ckey[lane] & nmaskbits);                                                    \
+          _Pragma("unroll") for (int f = 0; f < 10; f++) raw[f] = g8[f][n_];                                           \
+          raw[F_PORTS] = gports ? gports[n_] : 0ull;                                                                   \
+          rcls = gcls[n_]; rmaxp = gmaxp[n_]; rpodc = gpodc[n_]; rnm = gnm[n_];                                        \
+          _Pragma("unroll") for (int q = 0; q < K9_MAXSC; q++)                                                         \
+            if (q < (int)RS) { rsc[q][0] = g8[0][(size_t)(q + 2) * a.NP + n_]; rsc[q][1] = g8[2][(size_t)(q + 2) * a.NP + n_]; } \
+        }                                                                                                              \
+        const bool plain_ = (fl_ & 1u) && (km_ == 0u || (fl_ & 4u));                                                   \
+        if (!plain_ && lane == 63) {   /* an init container raised InitResreq above Resreq (rare): the row's own Resreq */ \
+          const KbDev &d_ = *a.dev;                                                                                    \
+          const uint32_t tk_ = desc[(i_next)].task;                                                                    \
+          for (int dd = 0; dd < a.R; dd++) rowres[dd] = d_.t_res[(size_t)dd * d_.T + tk_];                             \
+        }                                                                                                              \
+      }                                                                                                                \
+    } else {                                                                                                           \
+      stop_ = 1;                                                                                                       \
+    }                                                                                                                  \
+    if (lane == 0) {                                                                                                   \
+      H.i = (i_next); H.nd = (nd_next); H.reason = rsn_; H.stop = stop_; H.ncand = nc_;                                \
+      H.cur_s = s_; H.cur_r = r_; H.cur_fl = fl_; H.cur_km = km_;                                                      \
+    }                                                                                                                  \
+  } while (0)
+
+  typedef const unsigned long long __attribute__((address_space(1))) *gptr8;
+  typedef const uint32_t __attribute__((address_space(1))) *gptr4;
+  gptr8 g8[10];
+  gptr8 gports;
+  gptr4 gcls, gmaxp, gpodc, gnm;
+  {
+    const KbDev &d = *a.dev;
+    g8[0] = (gptr8)reinterpret_cast<const unsigned long long *>(d.idle); g8[1] = (gptr8)reinterpret_cast<const unsigned long long *>(d.idle + d.NP);
+    g8[2] = (gptr8)reinterpret_cast<const unsigned long long *>(d.rel); g8[3] = (gptr8)reinterpret_cast<const unsigned long long *>(d.rel + d.NP);
+    g8[4] = (gptr8)reinterpret_cast<const unsigned long long *>(d.inv_acpu); g8[5] = (gptr8)reinterpret_cast<const unsigned long long *>(d.inv_amem);
+    g8[6] = (gptr8)reinterpret_cast<const unsigned long long *>(d.acpu); g8[7] = (gptr8)reinterpret_cast<const unsigned long long *>(d.amem);
+    g8[8] = (gptr8)reinterpret_cast<const unsigned long long *>(d.nzc); g8[9] = (gptr8)reinterpret_cast<const unsigned long long *>(d.nzm);
+    gports = (gptr8)d.ports;
+    gcls = (gptr4)d.ncls; gmaxp = (gptr4)reinterpret_cast<const uint32_t *>(d.maxpods); gpodc = (gptr4)reinterpret_cast<const uint32_t *>(d.podcnt); gnm = (gptr4)d.nmask;
+  }
+  if (wave == 0) K9_PREPARE_NEXT(0u, 0u, (uint32_t)KB_REASON_DONE);
+
+  // ---------------- run loop (uniform across the workgroup): two barriers per run ----------------
+  for (;;) {
+    K9_STAMP(9);
+    __syncthreads();   // B1: the run's parameters and candidates, and every slot the previous run wrote, are visible
+    K9_STAMP(0);
+    if (H.stop) break;
+    const uint32_t i0 = H.i, nd = H.nd, ncand = H.ncand, s = H.cur_s, r = H.cur_r, fl0 = H.cur_fl, km0 = H.cur_km;
+    const bool plain0 = (fl0 & 1u) && (km0 == 0u || (fl0 & 4u));
+    const K9Shape sh = shapes[s];
+    const double *si = sinit + (size_t)s * RS;
+    // ---- evaluation phase, one evaluation deep: waves 1..4 the shape against "their" dirty slot, wave 0 the candidates
+    if (wave >= 1 && tid - 64u < nd) {
+      const uint32_t t = tid - 64u;
+      dk[t] = k9_eval(a, sh, slots + (size_t)t * K9_NF, sslots + (size_t)t * RS * 2, si, nb, nmaskbits);
+    }
+    uint32_t ck = 0, k1 = 0, ckind = 0;
+    double res0 = sh.init0, res1 = sh.init1;
+    if (wave == 0) {
+      if (!plain0) { res0 = rowres[0]; res1 = rowres[1]; }
+      // P2: lane j = candidate j: Allocate / Pipeline, NodeInfo.AddTask on the fetched state, key of the node after the placement
+      if (lane < ncand) {
+        ck = ckey[lane];
+        const uint32_t n = nmaskbits - (ck & nmaskbits);
+        unsigned long long *st = slots + (size_t)(nd + lane) * K9_NF;
+        unsigned long long *ss = sslots + (size_t)(nd + lane) * RS * 2;
+        double idle0 = u2d(raw[F_IDLE0]), idle1 = u2d(raw[F_IDLE1]), rel0 = u2d(raw[F_REL0]), rel1 = u2d(raw[F_REL1]);
+        uint32_t kind = 0;
+        if (!a.backfill) {   // allocate.go:160: InitResreq.LessEqual(node.Idle) -> Allocate, else Pipeline
+          bool fi = le_eps(sh.init0, idle0, EPS_CPU) && le_eps(sh.init1, idle1, EPS_MEM);
+#pragma unroll
+          for (int q = 0; q < K9_MAXSC; q++)
+            if (q < (int)RS && ((sh.active >> (q + 2)) & 1u)) fi = fi && le_eps(si[q], u2d(rsc[q][0]), EPS_SCALAR);
+          kind = fi ? 0u : 1u;
+        }
+        // NodeInfo.AddTask (api/node_info.go:172-212): Idle (Allocated) or Releasing (Pipelined) -= Resreq, pod joins ni.Tasks
+        if (kind) { rel0 -= res0; rel1 -= res1; } else { idle0 -= res0; idle1 -= res1; }
+        st[F_IDLE0] = d2u(idle0); st[F_IDLE1] = d2u(idle1); st[F_REL0] = d2u(rel0); st[F_REL1] = d2u(rel1);
+        st[F_INVAC] = raw[F_INVAC]; st[F_INVAM] = raw[F_INVAM];
+        st[F_AC] = d2u((double)(long long)raw[F_AC]); st[F_AM] = d2u((double)(long long)raw[F_AM]);
+        st[F_NZC] = d2u((double)(long long)raw[F_NZC] + sh.nzc); st[F_NZM] = d2u((double)(long long)raw[F_NZM] + sh.nzm);
+        st[F_PORTS] = raw[F_PORTS] | sh.want;   // the pod's host ports join nodeinfo.UsedPorts()
+        st[F_CLS_LEFT] = (unsigned long long)rcls | ((unsigned long long)(uint32_t)((int)rmaxp - (int)rpodc - 1) << 32);
+        st[F_NODE_NMASK] = (unsigned long long)n | ((unsigned long long)rnm << 32);
+        const uint32_t has_map = kind ? (rnm >> 31) : (rnm & 0x7FFFFFFFu);   // Sub returns early when the receiver's scalar map is nil (resource_info.go:148-153)
+#pragma unroll
+        for (int q = 0; q < K9_MAXSC; q++)
+          if (q < (int)RS) {
+            double vi = u2d(rsc[q][0]), vr = u2d(rsc[q][1]);
+            if (((km0 >> q) & 1u) && has_map) {
+              const double rq = plain0 ? si[q] : rowres[q + 2];
+              if (kind) vr -= rq; else vi -= rq;
+            }
+            ss[q * 2] = d2u(vi); ss[q * 2 + 1] = d2u(vr);
+          }
+        ckind = kind;
+        k1 = k9_eval(a, sh, st, ss, si, nb, nmaskbits);   // the node's key once it is dirty
+      }
+    }
+    K9_STAMP(1);
+    __syncthreads();   // B2: the dirty keys are in LDS
+    K9_STAMP(2);
+
+    // ---- P3 (wave 0): the rows of the run, in order; then the next run is prepared
+    if (wave == 0) {
+      // dirty keys of the shape: old slot t in lane t & 63, register t >> 6; the run's own new slots: k1 of lanes < pc
+      uint32_t d0 = (lane < nd) ? dk[lane] : 0u, d1 = (lane + 64 < nd) ? dk[lane + 64] : 0u;
+      uint32_t d2 = (lane + 128 < nd) ? dk[lane + 128] : 0u, d3 = (lane + 192 < nd) ? dk[lane + 192] : 0u;
+      uint32_t m = wave_max_u32(max(max(d0, d1), max(d2, d3)));   // best dirty key; clean winners update it in O(1)
+      uint32_t pc = 0, j = 0, reason = KB_REASON_DONE, n_dirty = 0;
+      for (; j < r; j++) {
+        const uint32_t c = (pc < ncand) ? rl32(ck, pc) : 0u;
+        if (m == 0u && c == 0u) {
+          if (a.backfill) {   // backfill.go:50-66: no node passes the predicates -> the task stays Pending
+            if (lane == 0) ldec[i0 + j] = (unsigned long long)KB_NONE_U32;
+            continue;
+          }
+          reason = KB_REASON_NO_FEASIBLE;   // allocate.go:144-148: the job is abandoned; the host re-plans from here
+          break;
+        }
+        uint32_t kind;
+        if (c > m) {   // the clean candidate wins: its slot and its post-placement key are ready
+          const uint32_t n = nmaskbits - (c & nmaskbits);
+          kind = rl32(ckind, pc);
+          m = max(m, rl32(k1, pc));
+          if (lane == 0) {
+            ldec[i0 + j] = (unsigned long long)n | ((unsigned long long)kind << 32);
+            atomicOr(&bitmap[n >> 5], 1u << (n & 31));
+          }
+          pc++;
+        } else {       // a node this round already changed wins: AddTask on its slot, re-evaluate it
+          const uint32_t own = (lane < pc) ? k1 : 0u;
+          const unsigned long long who = __ballot(d0 == m || d1 == m || d2 == m || d3 == m || own == m);
+          const uint32_t L = (uint32_t)__ffsll((unsigned long long)who) - 1u;
+          const bool is_new = L < pc && rl32(k1, L) == m;
+          const uint32_t wsel = (rl32(d0, L) == m) ? 0u : (rl32(d1, L) == m) ? 1u : (rl32(d2, L) == m) ? 2u : 3u;
+          const uint32_t x = is_new ? nd + L : L + 64u * wsel;
+          unsigned long long *st = slots + (size_t)x * K9_NF;
+          unsigned long long *ss = sslots + (size_t)x * RS * 2;
+          // lane f holds field f (lanes 16 + d': the scalar dimension d' + 2)
+          const bool sc_lane = lane >= 16 && lane < 16 + RS;
+          const uint32_t sd = sc_lane ? lane - 16 : 0;
+          unsigned long long cur8 = 0ull, cur8b = 0ull;
+          if (lane < K9_NF) cur8 = st[lane];
+          if (sc_lane) { cur8 = ss[sd * 2]; cur8b = ss[sd * 2 + 1]; }
+          kind = 0;
+          if (!a.backfill) {
+            bool ok = true;
+            if (lane == F_IDLE0) ok = le_eps(sh.init0, u2d(cur8), EPS_CPU);
+            else if (lane == F_IDLE1) ok = le_eps(sh.init1, u2d(cur8), EPS_MEM);
+            else if (sc_lane && ((sh.active >> (2 + sd)) & 1u)) ok = le_eps(si[sd], u2d(cur8), EPS_SCALAR);
+            kind = __ballot(!ok) ? 1u : 0u;
+          }
+          const uint32_t nm = (uint32_t)(rl64(cur8, F_NODE_NMASK) >> 32);
+          const uint32_t n = (uint32_t)rl64(cur8, F_NODE_NMASK);
+          const uint32_t has_map = kind ? (nm >> 31) : (nm & 0x7FFFFFFFu);
+          const uint32_t f0 = kind ? F_REL0 : F_IDLE0;
+          if (lane == f0) cur8 = d2u(u2d(cur8) - res0);
+          else if (lane == f0 + 1) cur8 = d2u(u2d(cur8) - res1);
+          else if (lane == F_NZC) cur8 = d2u(u2d(cur8) + sh.nzc);
+          else if (lane == F_NZM) cur8 = d2u(u2d(cur8) + sh.nzm);
+          else if (lane == F_PORTS) cur8 |= sh.want;
+          else if (lane == F_CLS_LEFT) cur8 -= (1ull << 32);   // one more pod on the node
+          if (sc_lane && ((km0 >> sd) & 1u) && has_map) {
+            const double rq = plain0 ? si[sd] : rowres[sd + 2];
+            if (kind) cur8b = d2u(u2d(cur8b) - rq); else cur8 = d2u(u2d(cur8) - rq);
+          }
+          if (lane < K9_NF) st[lane] = cur8;
+          if (sc_lane) { ss[sd * 2] = cur8; ss[sd * 2 + 1] = cur8b; }
+          if (lane == 0) ldec[i0 + j] = (unsigned long long)n | ((unsigned long long)kind << 32);
+          K9_WAVE_FENCE();
+          const uint32_t nk = k9_eval(a, sh, st, ss, si, nb, nmaskbits);   // uniform: every lane computes the same key
+          if (lane == L) {
+            if (is_new) k1 = nk;
+            else if (wsel == 0) d0 = nk; else if (wsel == 1) d1 = nk; else if (wsel == 2) d2 = nk; else d3 = nk;
+          }
+          m = wave_max_u32(max(max(max(d0, d1), max(d2, d3)), (lane < pc) ? k1 : 0u));
+          n_dirty++;
+        }
+        if (kind) { j++; reason = KB_REASON_PIPELINED; break; }   // a Pipeline ends the speculated order: the host re-plans
+      }
+      K9_STAMP(3);
+      if (lane == 0) {
+        if (pc) cursor[s] = cpos[pc - 1] + 1;
+        H.n_dirty_rows += n_dirty; H.n_runs += 1; H.n_slow += plain0 ? 0u : 1u;
+      }
+      K9_WAVE_FENCE();
+      K9_PREPARE_NEXT(i0 + j, nd + pc, reason);
+      K9_STAMP(4);
+    }
+  }
+#ifdef KB_K9_TRACE
+  if (tid == 0) {
+    unsigned long long *tw = reinterpret_cast<unsigned long long *>(a.result);
+    tw[5] = (unsigned long long)tacc[0] | ((unsigned long long)tacc[1] << 32);
+    tw[6] = (unsigned long long)tacc[2] | ((unsigned long long)tacc[3] << 32);
+    tw[7] = (unsigned long long)tacc[4] | ((unsigned long long)tacc[5] << 32);
+    tw[13] = (unsigned long long)tacc[6] | ((unsigned long long)tacc[7] << 32);
+    tw[14] = (unsigned long long)tacc[8] | ((unsigned long long)tacc[9] << 32);
+  }
+#endif
+
+  // ---------------- epilogue (all threads) ----------------
+  const uint32_t n_done = H.i, nd = H.nd;
+  {   // the dirty nodes' live state back to HBM
+    const KbDev &d = *a.dev;
+    for (uint32_t slot = tid; slot < nd; slot += K9_THREADS) {
+      const unsigned long long *sl = slots + (size_t)slot * K9_NF;
+      const uint32_t n = (uint32_t)sl[F_NODE_NMASK];
+      d.idle[n] = u2d(sl[F_IDLE0]);
+      d.idle[(size_t)d.NP + n] = u2d(sl[F_IDLE1]);
+      d.rel[n] = u2d(sl[F_REL0]);
+      d.rel[(size_t)d.NP + n] = u2d(sl[F_REL1]);
+      d.nzc[n] = (long long)u2d(sl[F_NZC]);
+      d.nzm[n] = (long long)u2d(sl[F_NZM]);
+      d.podcnt[n] = d.maxpods[n] - (int)(uint32_t)(sl[F_CLS_LEFT] >> 32);
+      if (a.has_ports) d.ports[n] = sl[F_PORTS];
+    }
+    for (uint32_t idx = tid; idx < nd * RS; idx += K9_THREADS) {
+      const uint32_t slot = idx / RS, dd = idx % RS;
+      const uint32_t n = (uint32_t)slots[(size_t)slot * K9_NF + F_NODE_NMASK];
+      d.idle[(size_t)(dd + 2) * d.NP + n] = u2d(sslots[(size_t)idx * 2]);
+      d.rel[(size_t)(dd + 2) * d.NP + n] = u2d(sslots[(size_t)idx * 2 + 1]);
+    }
+  }
+  {
+    // decision records; task-table side of ssn.Allocate / ssn.Pipeline for the committed rows (job.UpdateTaskStatus,
+    // task.NodeName: framework/session.go:243,205; api/node_info.go:206-209); multi-GPU: per-node committed deltas of the
+    // rows this rank owns [dIdle R][dRel R][dnzc][dnzm][dpodcnt] x NP (integer-valued: the float64 sums are exact)
+    const KbDev &d = *a.dev;
+    const KbRound &r = *a.round;
+    for (uint32_t i = tid; i < n_done; i += K9_THREADS) {
+      const unsigned long long rec = ldec[i];
+      a.dec[i] = rec;
+      const uint32_t n = (uint32_t)rec, kind = (uint32_t)(rec >> 32);
+      if (n == KB_NONE_U32) continue;
+      const KbRowDesc &k = desc[i];
+      const uint32_t t = k.task;
+      d.t_status[t] = kind ? KB_TASK_PIPELINED : KB_TASK_ALLOCATED;
+      d.t_node[t] = n;
+      d.t_counted[t] = 1;
+      if (!kind) d.j_allocated[d.t_job[t]] = 1;   // ssn.Allocate ran for the job: its Allocated tasks are dispatched if it is ready
+      if (a.has_delta && i >= r.own_row0 && i < r.own_row1) {
+        double res0 = k.init0, res1 = k.init1;
+        if (!(k.flags & 1)) { res0 = d.t_res[t]; res1 = d.t_res[(size_t)d.T + t]; }
+        double *dv = r.delta + (size_t)(kind ? d.R : 0) * d.NP;
+        atomicAdd(&dv[n], -res0);
+        atomicAdd(&dv[(size_t)d.NP + n], -res1);
+        const uint32_t km = k.resmask;
+        if (km) {
+          const uint32_t nm = d.nmask[n];
+          const uint32_t has_map = kind ? (nm >> 31) : (nm & 0x7FFFFFFFu);
+          if (has_map) {
+            uint32_t dd = 2, m2 = km;
+            while (m2) {
+              if (m2 & 1u) atomicAdd(&dv[(size_t)dd * d.NP + n], -d.t_res[(size_t)dd * d.T + t]);
+              m2 >>= 1; dd++;
+            }
+          }
+        }
+        double *tail = r.delta + (size_t)2 * d.R * d.NP;
+        atomicAdd(&tail[n], (double)k.nzc);
+        atomicAdd(&tail[(size_t)d.NP + n], (double)k.nzm);
+        atomicAdd(&tail[(size_t)2 * d.NP + n], 1.0);
+      }
+    }
+  }
+  if (tid == 0) {
+    a.result[0] = n_done; a.result[1] = H.reason; a.result[2] = nd; a.result[3] = H.n_dirty_rows;
+    a.result[4] = H.n_runs; a.result[5] = H.n_slow; a.result[6] = 0; a.result[7] = 0;
+    unsigned long long *st = reinterpret_cast<unsigned long long *>(a.result) + KB_OUT_STAMP0;
+    st[2] = t_start;
+    st[3] = wall_clock64();
+  }
+  // ---- fast rounds: mirror the header and the decision records into pinned host memory and publish the round's sequence
+  //      number last; the host spins on that word instead of paying a stream synchronisation + D2H copy per round
+  if (a.host_out) {
+    __syncthreads();
+    const unsigned long long *hdr = reinterpret_cast<const unsigned long long *>(a.result);
+    for (uint32_t i = tid; i < KB_OUT_HDR; i += K9_THREADS) if (i != KB_OUT_SEQ) a.host_out[i] = hdr[i];
+    for (uint32_t i = tid; i < n_done; i += K9_THREADS) a.host_out[KB_OUT_HDR + i] = ldec[i];
+    __threadfence_system();
+    __syncthreads();
+    if (tid == 0) __hip_atomic_store(&a.host_out[KB_OUT_SEQ], a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+
+void kb_launch_commit(const KbDev &d, const KbRound &r, void *stream) {
+  if (r.n_rows == 0) return;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_commit), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set = true;
+  }
+  const size_t sh = k9_layout(r.n_rows, r.n_mrows, r.L, d.NP, d.R).total;
+  K9KernArgs ka;
+  ka.dev = d;
+  ka.round = r;
+  KbCommitArgs &a = ka.hot;
+  a.dev = nullptr; a.round = nullptr;   // set from the kernel-argument segment inside the kernel
+  a.keys = r.keys; a.dec = r.dec; a.desc = r.desc; a.result = r.result; a.trace = r.trace;
+  a.n_rows = r.n_rows; a.n_mrows = r.n_mrows; a.L = r.L; a.cap = r.cap; a.N = d.N; a.NP = d.NP; a.T = d.T;
+  a.fit_mode = r.fit_mode; a.backfill = r.backfill; a.pred_enabled = d.pred_enabled; a.score_enabled = d.score_enabled;
+  a.wL = d.wL; a.wM = d.wM; a.wB = d.wB;
+  a.use_crow = (d.pred_enabled && d.crows != nullptr && d.n_nc <= 32) ? 1u : 0u;
+  a.has_delta = r.delta != nullptr ? 1u : 0u;
+  a.has_aff = (d.aff != nullptr && d.score_enabled) ? 1u : 0u;
+  a.has_ports = d.ports != nullptr ? 1u : 0u;
+  a.R = d.R;
+  a.batch = 0;
+  a.host_out = r.host_out;
+  a.seq = r.seq;
+  a.node_bits = kb_node_bits(d.NP);
+  hipLaunchKernelGGL(k_commit, dim3(1), dim3(K9_THREADS), sh, (hipStream_t)stream, ka);
+}

@@ -1,0 +1,912 @@
+// kb_commit_batch.hip — K5, batched-speculative variant of the sequential commit (gfx950 / CDNA4, wave64).
+//
+// Best when CLEAN nodes win most rows (spreading scores: the default nodeorder weights): 16-32 rows, across shapes, are
+// speculated at once and validated in parallel; a row won by a node the round already changed cuts the batch short.  When dirty
+// nodes win most rows (bin-packing weights) half of the batches are cut at their first row and the run-at-a-time kernel of
+// kb_commit.hip is about twice as fast; the engine picks per round from the measured share of dirty-won rows
+// (kb_engine.cpp:choose_commit_kernel).  Both kernels compute the same decisions, bit for bit.
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+#include <stdlib.h>
+
+#include <algorithm>
+
+#include "kb_device.h"
+#include "kb_eval.hpp"
+
+#define KB_K5_THREADS 512
+
+// class_row: nullptr -> look the class pair up in the global bit table; otherwise the task class's row of the table (bit nc)
+// ------------------------------------------------------------------------------------------------------------
+// wave64 helpers
+// ------------------------------------------------------------------------------------------------------------
+// max over keys (bit patterns of positive normal doubles, or 0) with DPP moves + v_max_f64
+#define KB_DPP_STEP(v, ctrl, row_mask)                                                                    \
+  do {                                                                                                    \
+    int _lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), (ctrl), (row_mask), 0xf, false);          \
+    int _hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), (ctrl), (row_mask), 0xf, false);          \
+    v = fmax(v, __hiloint2double(_hi, _lo));                                                              \
+  } while (0)
+__device__ __forceinline__ unsigned long long wave_max_key(unsigned long long k) {
+  double v = __longlong_as_double((long long)k);
+  KB_DPP_STEP(v, 0xB1, 0xf);    // quad_perm [1,0,3,2]
+  KB_DPP_STEP(v, 0x4E, 0xf);    // quad_perm [2,3,0,1]
+  KB_DPP_STEP(v, 0x141, 0xf);   // row_half_mirror
+  KB_DPP_STEP(v, 0x140, 0xf);   // row_mirror: every lane of a 16-lane row holds the row maximum
+  KB_DPP_STEP(v, 0x142, 0xa);   // row_bcast:15 into rows 1 and 3
+  KB_DPP_STEP(v, 0x143, 0xc);   // row_bcast:31 into rows 2 and 3: lane 63 holds the wave maximum
+  int lo = __builtin_amdgcn_readlane(__double2loint(v), 63);
+  int hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
+  return ((unsigned long long)(uint32_t)hi << 32) | (uint32_t)lo;
+}
+// max over each aligned group of 8 lanes (every lane of the group gets it)
+__device__ __forceinline__ unsigned long long oct_max_key(unsigned long long k) {
+  double v = __longlong_as_double((long long)k);
+  KB_DPP_STEP(v, 0xB1, 0xf);
+  KB_DPP_STEP(v, 0x4E, 0xf);
+  KB_DPP_STEP(v, 0x141, 0xf);
+  return (unsigned long long)__double_as_longlong(v);
+}
+__device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v) { return wave_max_key(v); }
+__device__ __forceinline__ int wave_max_i32(int v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o));
+  return v;
+}
+__device__ __forceinline__ double wave_sum_f64(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+__device__ __forceinline__ uint32_t lane_prefix_popc(unsigned long long ballot_mask, uint32_t lane) {
+  return __popcll(ballot_mask & ((1ull << lane) - 1ull));
+}
+
+// inclusive scan inside the wave: DPP row shifts, then row broadcasts (the sequence LLVM's buildScan emits)
+__device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v) {
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);   // row_shr:1
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);   // row_shr:2
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);   // row_shr:4
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);   // row_shr:8
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);   // row_bcast:15
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);   // row_bcast:31
+  return v;
+}
+
+
+__device__ __forceinline__ bool bit_test(const uint32_t *bm, uint32_t n) { return (bm[n >> 5] >> (n & 31)) & 1u; }
+
+// LDS layout of the commit kernel for slot capacity `cap`:
+//   8-byte tables [10][cap]: idle0 idle1 rel0 rel1 inv_ac inv_am ac am nzc nzm   (field k of slot s at (k*cap + s)*8)
+//   4-byte tables [4][cap]:  cls node left cursor
+//   KbRowDesc [cap], dirty bitmap [NP/32], header
+#define K5F_IDLE0 0
+#define K5F_IDLE1 1
+#define K5F_REL0 2
+#define K5F_REL1 3
+#define K5F_INVAC 4
+#define K5F_INVAM 5
+#define K5F_AC 6
+#define K5F_AM 7
+#define K5F_NZC 8
+#define K5F_NZM 9
+#define K5_NF8 10
+#define K5_WAVES (KB_K5_THREADS / 64)
+
+__device__ __forceinline__ NodeVals k5_slot_vals(const unsigned long long *tab, const uint32_t *t_cls, const int *t_left, uint32_t cap, uint32_t slot,
+                                              const unsigned long long *ptab = nullptr) {
+  NodeVals nv;
+  nv.idle0 = __longlong_as_double((long long)tab[K5F_IDLE0 * cap + slot]);
+  nv.idle1 = __longlong_as_double((long long)tab[K5F_IDLE1 * cap + slot]);
+  nv.rel0 = __longlong_as_double((long long)tab[K5F_REL0 * cap + slot]);
+  nv.rel1 = __longlong_as_double((long long)tab[K5F_REL1 * cap + slot]);
+  nv.inv_ac = __longlong_as_double((long long)tab[K5F_INVAC * cap + slot]);
+  nv.inv_am = __longlong_as_double((long long)tab[K5F_INVAM * cap + slot]);
+  nv.ac = (long long)tab[K5F_AC * cap + slot];
+  nv.am = (long long)tab[K5F_AM * cap + slot];
+  nv.nzc = (long long)tab[K5F_NZC * cap + slot];
+  nv.nzm = (long long)tab[K5F_NZM * cap + slot];
+  nv.ports = ptab ? ptab[slot] : 0ull;
+  nv.cls = t_cls[slot];
+  nv.slots = t_left[slot] > 0;
+  nv.valid = 1;
+  return nv;
+}
+
+// eval_pair for the commit kernel: policy scalars from the by-value argument struct, session arrays (scalar resource
+// dimensions, wide class tables) through the device-memory copy of KbDev on the rare paths only
+__device__ __forceinline__ uint32_t eval_pair_k5(const KbCommitArgs &a, const TaskVals &t, const NodeVals &n, uint32_t node, const uint32_t *class_row) {
+  bool ok = true;
+  if (a.fit_mode) {   // allocate.go:81
+    bool fi = le_eps(t.init0, n.idle0, EPS_CPU) && le_eps(t.init1, n.idle1, EPS_MEM);
+    bool fr = le_eps(t.init0, n.rel0, EPS_CPU) && le_eps(t.init1, n.rel1, EPS_MEM);
+    uint32_t act = t.active >> 2;
+    if (act) {
+      const KbDev &d = *a.dev;
+      uint32_t dd = 2;
+      while (act) {
+        if (act & 1u) {
+          double l = d.t_init[(size_t)dd * d.T + t.task];
+          fi = fi && le_eps(l, d.idle[(size_t)dd * d.NP + node], EPS_SCALAR);
+          fr = fr && le_eps(l, d.rel[(size_t)dd * d.NP + node], EPS_SCALAR);
+        }
+        act >>= 1;
+        dd++;
+      }
+    }
+    ok = fi || fr;
+  }
+  if (a.pred_enabled) {
+    ok = ok && n.slots && ((n.ports & t.conf) == 0ull);   // pod count (predicates.go:127), PodFitsHostPorts (predicates.go:181-190)
+    if (class_row) {
+      ok = ok && ((class_row[n.cls >> 5] >> (n.cls & 31)) & 1u);
+    } else {
+      const KbDev &d = *a.dev;
+      if (d.compat) {
+        uint32_t bit = t.cls * d.n_nc + n.cls;
+        ok = ok && ((d.compat[bit >> 3] >> (bit & 7)) & 1);
+      }
+    }
+  }
+  if (!ok) return 0;
+  uint32_t score = 0;
+  if (a.score_enabled) score = score_core(t, n, a.wL, a.wM, a.wB);
+  return 0x10000u | (score & 0xFFFFu);
+}
+
+// per-lane source arrays of the one-instruction node-state fetch: fld < 10 -> 8-byte field fld; 10..12 -> cls, maxpods, podcnt
+__device__ __forceinline__ void k5_field_ptrs(const KbDev &d, uint32_t fld, const unsigned long long *&g8, const uint32_t *&g4) {
+  g8 = nullptr; g4 = nullptr;
+  switch (fld) {
+    case K5F_IDLE0: g8 = reinterpret_cast<const unsigned long long *>(d.idle); break;
+    case K5F_IDLE1: g8 = reinterpret_cast<const unsigned long long *>(d.idle + d.NP); break;
+    case K5F_REL0: g8 = reinterpret_cast<const unsigned long long *>(d.rel); break;
+    case K5F_REL1: g8 = reinterpret_cast<const unsigned long long *>(d.rel + d.NP); break;
+    case K5F_INVAC: g8 = reinterpret_cast<const unsigned long long *>(d.inv_acpu); break;
+    case K5F_INVAM: g8 = reinterpret_cast<const unsigned long long *>(d.inv_amem); break;
+    case K5F_AC: g8 = reinterpret_cast<const unsigned long long *>(d.acpu); break;
+    case K5F_AM: g8 = reinterpret_cast<const unsigned long long *>(d.amem); break;
+    case K5F_NZC: g8 = reinterpret_cast<const unsigned long long *>(d.nzc); break;
+    case K5F_NZM: g8 = reinterpret_cast<const unsigned long long *>(d.nzm); break;
+    case 10: g4 = d.ncls; break;
+    case 11: g4 = reinterpret_cast<const uint32_t *>(d.maxpods); break;
+    case 12: g4 = reinterpret_cast<const uint32_t *>(d.podcnt); break;
+    default: break;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// K5: commit.  One workgroup walks the window in the reference's task order (allocate.go:129-193 / backfill.go:44-67).
+// The reference commits one task at a time, but ~90 % of the tasks take the best CLEAN node of their
+// shape (the next untouched entry of the shape's sorted candidate list).  The kernel therefore speculates K7_B rows
+// at once:
+//   walk      one wave hands every row of the batch the next clean entry of its shape's list, in row order, marking
+//             the nodes in the dirty bitmap as it goes (so a later row of another shape skips them);
+//   fetch     16 threads per row pull the 13 state fields of the row's node into a NEW dirty slot (one load each);
+//   apply     one thread per row decides Allocate / Pipeline (allocate.go:160) and applies NodeInfo.AddTask
+//             (api/node_info.go:172-212) to its slot, i.e. the slot holds the state AFTER the row committed;
+//   evaluate  all threads: key(shape q, slot x) for every distinct shape q of the batch and every dirty slot x, old
+//             (-> dmax[q]) and new (-> kb[row][q]);
+//   validate  row j really takes its clean candidate iff  c_j > dmax[q_j]  and  c_j > kb[l][q_j] for every earlier
+//             batch row l: then no dirty node beats it, exactly the reference's arg-max.  The first row that fails is
+//             the batch's "dirty row": its winner is the best dirty key, computed by the same evaluation;
+//   commit    rows before the first failure are final (decision records, cursors); later rows are rolled back
+//             (bitmap bits, speculative scalar-dimension writes) and re-speculated by the next batch; the dirty row is
+//             applied to the slot that owns the winning node.
+// A batch costs about as much as two rows of a row-at-a-time protocol, and commits ~10 rows on the benchmark snapshot.
+// ------------------------------------------------------------------------------------------------------------
+#define K7_B 32u          // most rows one batch can speculate
+#define K7_B_DEFAULT 16u  // batch size after a batch that was cut short; doubled after a fully valid one
+#define K7_D 96u   // row descriptors staged per refill
+
+struct K7Hdr {
+  unsigned long long c[K7_B];           // clean candidate key of batch row j (0: the list has no clean feasible node left)
+  unsigned long long dmax[K7_B];        // per distinct shape q of the batch: best key over the pre-batch dirty slots
+  unsigned long long kb[K7_B][K7_B];    // [row l][shape q]: key of row l's node in its post-commit state
+  unsigned long long win[K7_B][64];     // candidate window of shape q, starting at win_base[q]
+  uint32_t win_base[K7_B];
+  uint32_t rep[K7_B];                   // batch row whose descriptor represents shape q
+  uint32_t q_of[K7_B];                  // shape index of batch row j
+  uint32_t idx[K7_B];                   // list position of c[j]
+  uint32_t kind[K7_B];                  // 0 Allocate, 1 Pipeline
+  uint32_t has_map[K7_B];               // the row's speculative commit wrote scalar dimensions (saved values are valid)
+  // evaluation work list of shape q: slots [e_start, nd), then dlog[e_log0 .. e_log0 + e_nlog), then the batch's new slots
+  uint32_t e_off[K7_B], e_start[K7_B], e_nlog[K7_B], e_log0[K7_B];
+  KbRowDesc dbuf[K7_D];                 // row descriptors [dbase, dbase + dcnt) of the window, staged ahead of the batches
+  unsigned long long kstar;             // winner of the dirty row
+  uint32_t nshapes, p, dirty_row, reason, exhausted, pad;
+  uint32_t n_pairs, nlog, n_full, pad3;
+  uint32_t seq_rows, seq_pc, n_seq_rows, pad4;
+  uint32_t n_batches, n_dirty_rows, n_refills, pad2;
+};
+
+struct K7Mem {
+  unsigned long long *tab;              // [K5_NF8][cap2]
+  uint32_t *t_cls, *t_node;             // [cap2]
+  int *t_left;                          // [cap2]
+  uint32_t *cursor;                     // [cap] per shape
+  uint32_t *qstamp;                     // [cap] per shape: first batch row with that shape (0xFFFFFFFF between batches)
+  // per shape: best key over the dirty slots [0, dc_nd) as of dirty-log position dc_log.  Still valid later for the slots
+  // it covered unless the node of dc_key itself was changed by a dirty row since (the commit step then sets dc_nd to
+  // 0xFFFFFFFF); newer slots and slots changed since are simply evaluated again and max'ed in.
+  unsigned long long *dc_key;           // [cap]
+  uint32_t *dc_nd, *dc_log;             // [cap]
+  uint32_t *dlog;                       // [cap] slots changed by dirty rows, in order
+  unsigned long long *keyq;             // [cap2] keys of one shape against every dirty slot (row-at-a-time mode)
+  unsigned long long *ptab;             // [cap2] host-port bits of the slot's node (sessions with host ports only)
+  uint32_t *bitmap;                     // [NP/32]
+  double *save;                         // [K7_B][R-2] scalar-dimension values overwritten by speculative commits
+  K7Hdr *H;
+  uint32_t cap2;
+};
+
+__host__ __device__ inline size_t k7_smem_bytes(uint32_t cap, uint32_t NP, int R) {
+  size_t cap2 = (size_t)cap + K7_B;
+  return cap2 * (K5_NF8 * 8 + 8 + 8 + 3 * 4) + (size_t)cap * (8 + 8 + 12) + (size_t)(NP / 32) * 4 + (size_t)K7_B * (R > 2 ? R - 2 : 0) * 8 + sizeof(K7Hdr) + 64;
+}
+
+__device__ __forceinline__ TaskVals k7_task_vals(const KbCommitArgs &a, const KbRowDesc &k) {
+  TaskVals tv;
+  tv.init0 = k.init0; tv.init1 = k.init1; tv.nzc = k.nzc; tv.nzm = k.nzm;
+  tv.cls = k.cls; tv.active = k.active; tv.task = k.task; tv.pad = 0;
+  tv.conf = a.has_ports ? a.dev->t_conf[k.task] : 0ull;   // host-port sessions only: straight from the task table
+  return tv;
+}
+
+// TaskInfo.Resreq cpu / memory of a row: equal to InitResreq unless an init container raised the latter (flags bit 0 clear,
+// rare).  The LDS values are materialised before the branch so that the compiler does not turn "LDS address or global
+// address" into flat loads (which wait on both memory counters).
+__device__ __forceinline__ void k7_resreq(const KbCommitArgs &a, const KbRowDesc &k, double &res0, double &res1) {
+  res0 = k.init0;
+  res1 = k.init1;
+  asm volatile("" : "+v"(res0), "+v"(res1));
+  if (!(k.flags & 1)) { const KbDev &d = *a.dev; res0 = d.t_res[k.task]; res1 = d.t_res[(size_t)d.T + k.task]; }
+}
+
+// decision record + multi-GPU deltas of one committed row; SUB: also apply the scalar dimensions of NodeInfo.AddTask
+// (the batched clean rows did that speculatively in the apply step)
+template <bool SUB>
+__device__ __forceinline__ void k7_commit_globals(const KbCommitArgs &a, const KbRowDesc &k, uint32_t i, uint32_t n, uint32_t kind) {
+  const uint32_t km = k.resmask;
+  uint32_t has_map = 0;
+  if (km) {
+    const KbDev &d = *a.dev;
+    has_map = kind ? (d.nmask[n] >> 31) : (d.nmask[n] & 0x7FFFFFFFu);   // Sub returns early when the receiver's scalar map is nil (resource_info.go:148-153)
+    if (SUB && has_map) {
+      double *vec = kind ? d.rel : d.idle;
+      uint32_t dd = 2, m2 = km;
+      while (m2) {
+        if (m2 & 1u) vec[(size_t)dd * d.NP + n] -= d.t_res[(size_t)dd * d.T + k.task];
+        m2 >>= 1; dd++;
+      }
+    }
+  }
+  *reinterpret_cast<uint2 *>(&a.dec[i]) = make_uint2(n, kind);
+  if (a.has_delta) {
+    const KbDev &d = *a.dev;
+    const KbRound &r = *a.round;
+    if (i >= r.own_row0 && i < r.own_row1) {
+      double res0, res1;
+      k7_resreq(a, k, res0, res1);
+      // per-node committed deltas of the rows this rank owns: [dIdle R][dRel R][dnzc][dnzm][dpodcnt] x NP
+      double *dv = r.delta + (size_t)(kind ? d.R : 0) * d.NP;
+      dv[n] -= res0;
+      dv[(size_t)d.NP + n] -= res1;
+      if (km && has_map) {
+        uint32_t dd = 2, m2 = km;
+        while (m2) {
+          if (m2 & 1u) dv[(size_t)dd * d.NP + n] -= d.t_res[(size_t)dd * d.T + k.task];
+          m2 >>= 1; dd++;
+        }
+      }
+      double *tail = r.delta + (size_t)2 * d.R * d.NP;
+      tail[n] += (double)k.nzc;
+      tail[(size_t)d.NP + n] += (double)k.nzm;
+      tail[(size_t)2 * d.NP + n] += 1.0;
+    }
+  }
+}
+
+// Allocate or Pipeline for row k on the node held in `slot` (allocate.go:160), then NodeInfo.AddTask on the LDS copy
+__device__ __forceinline__ uint32_t k7_apply_slot(const KbCommitArgs &a, const K7Mem &M, const KbRowDesc &k, uint32_t slot, uint32_t n) {
+  const uint32_t cap2 = M.cap2;
+  double res0, res1;
+  k7_resreq(a, k, res0, res1);
+  uint32_t kind = 0;
+  if (!a.backfill) {
+    bool fi = le_eps(k.init0, __longlong_as_double((long long)M.tab[K5F_IDLE0 * cap2 + slot]), EPS_CPU) &&
+              le_eps(k.init1, __longlong_as_double((long long)M.tab[K5F_IDLE1 * cap2 + slot]), EPS_MEM);
+    uint32_t act = k.active >> 2;
+    if (act) {
+      const KbDev &d = *a.dev;
+      uint32_t dd = 2;
+      while (act) {
+        if (act & 1u) fi = fi && le_eps(d.t_init[(size_t)dd * d.T + k.task], d.idle[(size_t)dd * d.NP + n], EPS_SCALAR);
+        act >>= 1; dd++;
+      }
+    }
+    kind = fi ? 0u : 1u;
+  }
+  const uint32_t f0 = kind ? K5F_REL0 : K5F_IDLE0;
+  M.tab[(size_t)f0 * cap2 + slot] = (unsigned long long)__double_as_longlong(__longlong_as_double((long long)M.tab[(size_t)f0 * cap2 + slot]) - res0);
+  M.tab[(size_t)(f0 + 1) * cap2 + slot] = (unsigned long long)__double_as_longlong(__longlong_as_double((long long)M.tab[(size_t)(f0 + 1) * cap2 + slot]) - res1);
+  M.tab[(size_t)K5F_NZC * cap2 + slot] += (unsigned long long)k.nzc;
+  M.tab[(size_t)K5F_NZM * cap2 + slot] += (unsigned long long)k.nzm;
+  if (a.has_ports) M.ptab[slot] |= a.dev->t_want[k.task];   // the pod's host ports join nodeinfo.UsedPorts()
+  return kind;
+}
+
+
+// The launch passes {hot scalars, KbDev, KbRound} as ONE by-value block.  Only `hot` is named in the code (-> SGPRs); the two
+// views are reached through the kernel-argument segment pointer, i.e. read from constant memory where a rare path needs them.
+struct K7KernArgs {
+  KbCommitArgs hot;
+  KbDev dev;
+  KbRound round;
+};
+
+__global__ void __launch_bounds__(KB_K5_THREADS) k_commit(const K7KernArgs ka) {
+  KbCommitArgs a = ka.hot;
+  {
+    const unsigned char __attribute__((address_space(4))) *kp = (const unsigned char __attribute__((address_space(4))) *)__builtin_amdgcn_kernarg_segment_ptr();
+    a.dev = (const KbDev *)(kp + offsetof(K7KernArgs, dev));
+    a.round = (const KbRound *)(kp + offsetof(K7KernArgs, round));
+  }
+  extern __shared__ __align__(16) unsigned char k5_smem[];
+  const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, cap = a.cap, cap2 = a.cap + K7_B;
+  K7Mem M;
+  M.cap2 = cap2;
+  M.tab = reinterpret_cast<unsigned long long *>(k5_smem);
+  M.keyq = M.tab + (size_t)K5_NF8 * cap2;   // 8-byte tables first
+  M.ptab = M.keyq + cap2;
+  M.dc_key = M.ptab + cap2;
+  M.t_cls = reinterpret_cast<uint32_t *>(M.dc_key + cap);
+  M.t_node = M.t_cls + cap2;
+  M.t_left = reinterpret_cast<int *>(M.t_node + cap2);
+  M.cursor = reinterpret_cast<uint32_t *>(M.t_left + cap2);
+  M.qstamp = M.cursor + cap;
+  M.dc_nd = M.qstamp + cap;
+  M.dc_log = M.dc_nd + cap;
+  M.dlog = M.dc_log + cap;
+  M.bitmap = M.dlog + cap;
+  {
+    // byte offsets from the LDS base (pointer -> integer -> pointer round trips would lose the address space)
+    size_t off = (size_t)cap2 * (K5_NF8 * 8 + 8 + 8 + 3 * 4) + (size_t)cap * (8 + 8 + 12) + (size_t)(a.NP / 32) * 4;
+    off = (off + 15) & ~(size_t)15;
+    M.H = reinterpret_cast<K7Hdr *>(k5_smem + off);
+    M.save = reinterpret_cast<double *>(k5_smem + off + sizeof(K7Hdr));
+  }
+  K7Hdr &H = *M.H;
+  const int RS = a.R > 2 ? a.R - 2 : 0;
+  const unsigned long long t_start = wall_clock64();
+
+  for (uint32_t w = tid; w < a.NP / 32; w += KB_K5_THREADS) M.bitmap[w] = 0;
+  for (uint32_t w = tid; w < cap; w += KB_K5_THREADS) { M.cursor[w] = 0; M.qstamp[w] = 0xFFFFFFFFu; M.dc_key[w] = 0ull; M.dc_nd[w] = 0; M.dc_log[w] = 0; }
+  if (tid == 0) { H.reason = KB_REASON_DONE; H.exhausted = 0; H.n_batches = 0; H.n_dirty_rows = 0; H.n_refills = 0; H.p = 0; H.dirty_row = 0; H.pad = 0; H.nlog = 0; H.n_full = 0; H.pad2 = 0; H.pad3 = 0; H.kstar = 0ull; H.n_seq_rows = 0; }
+  // per-thread source array of the fetch step: thread (row*16 + f) reads field f of the row's node
+  // (pointers read from the KbDev copy are generic; the fetch step wants global_load, not flat_load)
+  typedef const unsigned long long __attribute__((address_space(1))) *gptr8;
+  typedef const uint32_t __attribute__((address_space(1))) *gptr4;
+  gptr8 g8;
+  gptr4 g4;
+  {
+    const unsigned long long *f8 = nullptr;
+    const uint32_t *f4 = nullptr;
+    k5_field_ptrs(*a.dev, tid & 15, f8, f4);
+    g8 = (gptr8)f8;
+    g4 = (gptr4)f4;
+  }
+  {
+    // The loop is latency-bound and this workgroup starts on a cold L2 (kernel boundary): touch every 128-byte line of the
+    // node state arrays and of the candidate lists once, with all threads.
+    const KbDev &d = *a.dev;
+    unsigned long long acc = 0;
+    const uint32_t lines = a.NP / 16;
+    const unsigned long long *arrs[10] = {
+        reinterpret_cast<const unsigned long long *>(d.idle), reinterpret_cast<const unsigned long long *>(d.idle + d.NP),
+        reinterpret_cast<const unsigned long long *>(d.rel), reinterpret_cast<const unsigned long long *>(d.rel + d.NP),
+        reinterpret_cast<const unsigned long long *>(d.inv_acpu), reinterpret_cast<const unsigned long long *>(d.inv_amem),
+        reinterpret_cast<const unsigned long long *>(d.acpu), reinterpret_cast<const unsigned long long *>(d.amem),
+        reinterpret_cast<const unsigned long long *>(d.nzc), reinterpret_cast<const unsigned long long *>(d.nzm)};
+#pragma unroll
+    for (int f = 0; f < 10; f++)
+      for (uint32_t l = tid; l < lines; l += KB_K5_THREADS) acc += arrs[f][(size_t)l * 16];
+    const uint32_t *arr4[3] = {d.ncls, reinterpret_cast<const uint32_t *>(d.maxpods), reinterpret_cast<const uint32_t *>(d.podcnt)};
+#pragma unroll
+    for (int f = 0; f < 3; f++)
+      for (uint32_t l = tid; l < a.NP / 32; l += KB_K5_THREADS) acc += arr4[f][(size_t)l * 32];
+    const size_t klines = ((size_t)a.n_mrows * a.L + 15) / 16;
+    for (size_t l = tid; l < klines; l += KB_K5_THREADS) acc += a.keys[l * 16];
+    if (acc == 0x123456789abcdefull) H.pad = 1;   // keep the loads alive
+  }
+  __syncthreads();
+
+  uint32_t i0 = 0, nd = 0, n_done = 0, reason = KB_REASON_DONE, dbase = 0, dcnt = 0, nb_cur = a.batch;
+  while (i0 < a.n_rows) {
+    uint32_t nb = min(nb_cur, a.n_rows - i0);
+    // ---- stage row descriptors: three batches' worth per refill, so most batches find theirs already in LDS
+    if (i0 < dbase || i0 + nb > dbase + dcnt) {
+      dbase = i0;
+      dcnt = min(K7_D, a.n_rows - i0);
+      const unsigned long long *src = reinterpret_cast<const unsigned long long *>(a.desc + i0);
+      unsigned long long *dst = reinterpret_cast<unsigned long long *>(H.dbuf);
+      for (uint32_t w = tid; w < dcnt * (uint32_t)(sizeof(KbRowDesc) / 8); w += KB_K5_THREADS) dst[w] = src[w];
+      __syncthreads();
+    }
+    const KbRowDesc *bd = H.dbuf + (i0 - dbase);
+    if (a.has_aff && !a.backfill) {
+      // a row whose score is normalised over its feasible set (preferred node affinity) is exact only against a fresh matrix:
+      // it may be the first row of a round, nothing else; the batch stops in front of it and the round ends there
+      uint32_t ja = nb;
+      for (uint32_t j = (i0 == 0) ? 1u : 0u; j < nb; j++)
+        if (bd[j].flags & 2) { ja = j; break; }
+      if (ja == 0) { reason = KB_REASON_RENORM; n_done = i0; break; }
+      nb = ja;
+    }
+    // ---- distinct shapes of the batch (wave 0): q_of[j] = rank of the first row with row j's shape
+    if (wave == 0) {
+      const bool in = lane < nb;
+      const uint32_t s = in ? (uint32_t)bd[in ? lane : 0].slot : 0u;
+      if (in) atomicMin(&M.qstamp[s], lane);
+      const uint32_t first = in ? M.qstamp[s] : 0xFFFFFFFFu;
+      const bool isrep = in && first == lane;
+      const unsigned long long repmask = __ballot(isrep);
+      // evaluation work list of every distinct shape: reuse the shape's cached dirty max when its node is untouched
+      uint32_t cnt = 0, q = 0;
+      if (in) {
+        q = (uint32_t)__popcll(repmask & ((1ull << first) - 1ull));
+        H.q_of[lane] = q;
+        M.qstamp[s] = 0xFFFFFFFFu;
+      }
+      if (isrep) {
+        const uint32_t nlog = H.nlog;
+        unsigned long long ck = M.dc_key[s];
+        uint32_t start = M.dc_nd[s];
+        const uint32_t log0 = M.dc_log[s];
+        uint32_t nl = nlog - log0;
+        const bool full = start == 0xFFFFFFFFu || nl > 16;   // invalidated by a dirty row on its arg-max node, or too stale
+        if (full) { start = 0; nl = 0; ck = 0ull; }
+        cnt = (nd - start) + nl + nb;
+        H.rep[q] = lane; H.win_base[q] = M.cursor[s]; H.dmax[q] = ck;
+        H.e_start[q] = start; H.e_nlog[q] = nl; H.e_log0[q] = log0;
+        if (full) atomicAdd(&H.n_full, 1u);
+      }
+      // exclusive prefix of the counts over the representative lanes
+      const uint32_t incl = wave_incl_scan_u32(cnt);
+      if (isrep) H.e_off[q] = incl - cnt;
+      const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+      const uint32_t nsh = (uint32_t)__popcll(repmask);
+      if (lane >= nsh && lane < K7_B) H.e_off[lane] = 0xFFFFFFFFu;
+      if (lane == 0) { H.nshapes = nsh; H.n_pairs = total; H.n_batches++; }
+    }
+    __syncthreads();
+    // ---- candidate windows of the distinct shapes: one wave per shape
+    const uint32_t nshapes = H.nshapes;
+    for (uint32_t q = wave; q < nshapes; q += K5_WAVES) {
+      const uint32_t s = bd[H.rep[q]].slot;
+      const uint32_t e = H.win_base[q] + lane;
+      H.win[q][lane] = (e < a.L) ? a.keys[(size_t)s * a.L + e] : 0ull;
+    }
+    __syncthreads();
+    // ---- walk (wave 0): runs of consecutive rows with the same shape take successive clean entries of its window
+    if (wave == 0) {
+      const uint32_t myq = (lane < nb) ? H.q_of[lane] : 0xFFFFFFFFu;
+      uint32_t j = 0;
+      while (j < nb) {
+        const uint32_t q = (uint32_t)__builtin_amdgcn_readlane((int)myq, (int)j);
+        const unsigned long long diff = __ballot(lane >= j && lane < nb && myq != q);
+        const uint32_t j1 = diff ? (uint32_t)(__ffsll((unsigned long long)diff) - 1) : nb;
+        uint32_t m = j1 - j;
+        for (;;) {
+          const unsigned long long wkey = H.win[q][lane];
+          const uint32_t base = H.win_base[q];
+          const bool nz = wkey != 0ull;
+          const uint32_t node = KB_KEY_NODE(wkey);
+          const bool cl = nz && !bit_test(M.bitmap, nz ? node : 0u);
+          const unsigned long long clean = __ballot(cl);
+          const unsigned long long zeros = __ballot(!nz);
+          const uint32_t cnt = (uint32_t)__popcll(clean);
+          const uint32_t take = cnt < m ? cnt : m;
+          const uint32_t rank = (uint32_t)__popcll(clean & ((1ull << lane) - 1ull));
+          if (cl && rank < take) {
+            H.c[j + rank] = wkey;
+            H.idx[j + rank] = base + lane;
+            atomicOr(&M.bitmap[node >> 5], 1u << (node & 31));
+          }
+          j += take;
+          m -= take;
+          if (m == 0) break;
+          if (zeros) {   // the list ended: no clean feasible node is left for the remaining rows of the run
+            if (lane < m) { H.c[j + lane] = 0ull; H.idx[j + lane] = 0; }
+            j += m;
+            break;
+          }
+          // every entry of the window is dirty: slide it (entries before it stay dirty for the rest of the round or are
+          // rolled back together with this batch)
+          const uint32_t nbase = base + 64;
+          if (nbase >= a.L) {   // cannot happen while L > window: reported, never silently mis-scheduled
+            if (lane == 0) H.exhausted = 1;
+            if (lane < m) { H.c[j + lane] = 0ull; H.idx[j + lane] = 0; }
+            j += m;
+            break;
+          }
+          const uint32_t e = nbase + lane;
+          const uint32_t s = bd[H.rep[q]].slot;
+          H.win[q][lane] = (e < a.L) ? a.keys[(size_t)s * a.L + e] : 0ull;
+          if (lane == 0) { H.win_base[q] = nbase; H.n_refills++; }
+        }
+      }
+    }
+    __syncthreads();
+    // ---- fetch + apply: the 16 lanes of one DPP row handle one batch row.  Lane f reads field f of the row's candidate
+    //      node (one load), the group votes Allocate / Pipeline (allocate.go:160) with a ballot, every lane applies
+    //      NodeInfo.AddTask (api/node_info.go:172-212) to its own field and stores it into the row's NEW dirty slot: the slot
+    //      holds the node's state AFTER the row committed.  Scalar dimensions (global memory, rare) are written
+    //      speculatively by lane 15 and their old values saved for the rollback.
+    for (uint32_t w = tid; w < nb * 16; w += KB_K5_THREADS) {
+      const uint32_t j = w >> 4, f = w & 15;
+      const unsigned long long cj = H.c[j];
+      uint32_t kind = 0, has_map = 0;
+      if (cj) {
+        const KbRowDesc &k = bd[j];
+        const uint32_t n = KB_KEY_NODE(cj), slot = nd + j;
+        unsigned long long v8 = 0ull;
+        uint32_t v4 = 0;
+        if (f < K5_NF8) v8 = g8[n];
+        else if (f <= 12) v4 = g4[n];
+        double res0, res1;
+        k7_resreq(a, k, res0, res1);
+        bool ok = true;
+        if (!a.backfill) {
+          const double dv = __longlong_as_double((long long)v8);
+          if (f == K5F_IDLE0) ok = le_eps(k.init0, dv, EPS_CPU);
+          else if (f == K5F_IDLE1) ok = le_eps(k.init1, dv, EPS_MEM);
+          else if (f == 15 && (k.active >> 2)) {
+            const KbDev &d = *a.dev;
+            uint32_t act = k.active >> 2, dd = 2;
+            while (act) {
+              if (act & 1u) ok = ok && le_eps(d.t_init[(size_t)dd * d.T + k.task], d.idle[(size_t)dd * d.NP + n], EPS_SCALAR);
+              act >>= 1; dd++;
+            }
+          }
+        }
+        const unsigned long long bad = __ballot(!ok);
+        kind = ((bad >> (lane & 48u)) & 0xFFFFull) ? 1u : 0u;
+        const uint32_t f0 = kind ? K5F_REL0 : K5F_IDLE0;
+        const double dv = __longlong_as_double((long long)v8);
+        if (f == f0) v8 = (unsigned long long)__double_as_longlong(dv - res0);
+        else if (f == f0 + 1) v8 = (unsigned long long)__double_as_longlong(dv - res1);
+        else if (f == K5F_NZC) v8 += (unsigned long long)k.nzc;
+        else if (f == K5F_NZM) v8 += (unsigned long long)k.nzm;
+        if (f < K5_NF8) M.tab[(size_t)f * cap2 + slot] = v8;
+        const uint32_t nxt = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v4, 0x101, 0xf, 0xf, true);   // row_shl:1: lane 11 <- pods
+        if (f == 10) M.t_cls[slot] = v4;
+        else if (f == 11) M.t_left[slot] = (int)v4 - (int)nxt - 1;
+        else if (f == 13) {
+          M.t_node[slot] = n;
+          if (a.has_ports) M.ptab[slot] = a.dev->ports[n] | a.dev->t_want[k.task];
+        }
+        else if (f == 15 && k.resmask) {
+          const KbDev &d = *a.dev;
+          has_map = kind ? (d.nmask[n] >> 31) : (d.nmask[n] & 0x7FFFFFFFu);   // Sub returns early when the receiver's scalar map is nil (resource_info.go:148-153)
+          if (has_map) {
+            double *vec = kind ? d.rel : d.idle;
+            uint32_t dd = 2, m2 = k.resmask;
+            while (m2) {
+              if (m2 & 1u) {
+                const double old = vec[(size_t)dd * d.NP + n];
+                M.save[(size_t)j * RS + (dd - 2)] = old;
+                vec[(size_t)dd * d.NP + n] = old - d.t_res[(size_t)dd * d.T + k.task];
+              }
+              m2 >>= 1; dd++;
+            }
+          }
+        }
+      }
+      if (f == 14) H.kind[j] = kind;
+      if (f == 15) H.has_map[j] = has_map;
+    }
+    __syncthreads();
+    // ---- evaluate the work lists: (shape q, slot x) -> dmax[q] for slots older than the batch, kb[row][q] for its own
+    {
+      const uint32_t P = H.n_pairs;
+      uint32_t off[K7_B];
+#pragma unroll
+      for (int k = 0; k < (int)K7_B; k += 4) {
+        const uint4 v = *reinterpret_cast<const uint4 *>(&H.e_off[k]);
+        off[k] = v.x; off[k + 1] = v.y; off[k + 2] = v.z; off[k + 3] = v.w;
+      }
+      for (uint32_t e = tid; e < P; e += KB_K5_THREADS) {
+        uint32_t q = 0;
+#pragma unroll
+        for (int k = 1; k < (int)K7_B; k++) q += (e >= off[k]) ? 1u : 0u;
+        uint32_t r = e - H.e_off[q];
+        const uint32_t start = H.e_start[q], nn = nd - start, nl = H.e_nlog[q];
+        uint32_t x;
+        if (r < nn) x = start + r;
+        else if (r < nn + nl) x = M.dlog[H.e_log0[q] + (r - nn)];
+        else x = nd + (r - nn - nl);
+        unsigned long long key = 0ull;
+        if (x < nd || H.c[x - nd] != 0ull) {
+          const KbRowDesc &k = bd[H.rep[q]];
+          const TaskVals tv = k7_task_vals(a, k);
+          const NodeVals nv = k5_slot_vals(M.tab, M.t_cls, M.t_left, cap2, x, a.has_ports ? M.ptab : nullptr);
+          const uint32_t node = M.t_node[x];
+          const uint32_t res = eval_pair_k5(a, tv, nv, node, a.use_crow ? &k.crow : nullptr);
+          key = res ? KB_KEY(res & 0xFFFFu, node) : 0ull;
+        }
+        if (x < nd) { if (key) atomicMax(&H.dmax[q], key); }
+        else H.kb[x - nd][q] = key;
+      }
+    }
+    __syncthreads();
+    // ---- validate (wave 0)
+    if (wave == 0) {
+      const bool in = lane < nb;
+      const unsigned long long cj = in ? H.c[lane] : 0ull;
+      const uint32_t q = in ? H.q_of[lane] : 0u;
+      unsigned long long m = in ? H.dmax[q] : 0ull;
+#pragma unroll 8
+      for (uint32_t l = 0; l + 1 < nb; l++) {
+        const unsigned long long kk = H.kb[l][q];
+        if (l < lane && kk > m) m = kk;
+      }
+      if (in && H.rep[q] == lane) {   // the shape's dirty max as of this batch's start becomes its cache
+        const uint32_t s = bd[lane].slot;
+        M.dc_key[s] = H.dmax[q]; M.dc_nd[s] = nd; M.dc_log[s] = H.nlog;
+      }
+      const bool valid = in && cj != 0ull && cj > m;
+      const unsigned long long inval = __ballot(in && !valid);
+      const unsigned long long pipe = __ballot(valid && H.kind[in ? lane : 0] != 0u);
+      uint32_t p = inval ? (uint32_t)(__ffsll((unsigned long long)inval) - 1) : nb;
+      const unsigned long long pipe_before = pipe & ((1ull << p) - 1ull);
+      uint32_t dirty_row = 0, rsn = KB_REASON_DONE;
+      unsigned long long kstar = 0ull;
+      if (pipe_before) {   // a Pipeline ends the speculation (the host re-plans): commit up to and including that row
+        p = (uint32_t)__ffsll((unsigned long long)pipe_before);
+        rsn = KB_REASON_PIPELINED;
+      } else if (p < nb) {
+        kstar = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(m >> 32), (int)p) << 32) |
+                (uint32_t)__builtin_amdgcn_readlane((int)(m & 0xFFFFFFFFull), (int)p);
+        if (kstar) dirty_row = 1;
+        else if (a.backfill) dirty_row = 2;   // backfill.go:50-66: no node passes the predicates -> the task stays Pending
+        else rsn = KB_REASON_NO_FEASIBLE;     // allocate.go:144-148: the job is abandoned; the host re-plans from here
+      }
+      if (lane == 0) {
+        H.p = p; H.dirty_row = dirty_row; H.reason = rsn; H.kstar = kstar;
+      }
+    }
+    __syncthreads();
+    // ---- commit the valid prefix
+    const uint32_t p = H.p, dirty_row = H.dirty_row;
+    uint32_t pc = p, rows = p + (dirty_row == 2 ? 1u : 0u);   // candidates consumed, rows consumed
+    if (tid < p) {
+      const uint32_t j = tid;
+      const KbRowDesc &k = bd[j];
+      atomicMax(&M.cursor[k.slot], H.idx[j] + 1);
+      k7_commit_globals<false>(a, k, i0 + j, KB_KEY_NODE(H.c[j]), H.kind[j]);
+    }
+    if (dirty_row == 2 && tid == 0) *reinterpret_cast<uint2 *>(&a.dec[i0 + p]) = make_uint2(KB_NONE_U32, 0u);
+    if (dirty_row == 1) {
+      // ---- a dirty node beats row p's clean candidate.  Dirty winners come in chains (a big node keeps the best score for
+      // several tasks), so the rest of row p's run of same-shape rows is committed one row at a time by wave 0 alone, with no
+      // workgroup barrier per row: every thread first evaluates the shape against all dirty slots (keyq), then per row
+      //     winner = max( max(keyq) , next unconsumed clean candidate of the run )
+      // a dirty winner's slot is updated in LDS and its key re-evaluated by one lane; a clean winner takes the slot the fetch /
+      // apply steps already prepared for that candidate (same shape => same post-commit state) with the key the evaluate step
+      // already computed (kb).
+      const uint32_t q = H.q_of[p];
+      {
+        const KbRowDesc &k = bd[p];
+        const TaskVals tv = k7_task_vals(a, k);
+        for (uint32_t x = tid; x < nd + p; x += KB_K5_THREADS) {
+          const NodeVals nv = k5_slot_vals(M.tab, M.t_cls, M.t_left, cap2, x, a.has_ports ? M.ptab : nullptr);
+          const uint32_t node = M.t_node[x];
+          const uint32_t res = eval_pair_k5(a, tv, nv, node, a.use_crow ? &k.crow : nullptr);
+          M.keyq[x] = res ? KB_KEY(res & 0xFFFFu, node) : 0ull;
+        }
+      }
+      __syncthreads();
+      if (wave == 0) {
+        const uint32_t myq = (lane < nb) ? H.q_of[lane] : 0xFFFFFFFFu;
+        const unsigned long long diff = __ballot(lane > p && lane < nb && myq != q);
+        const uint32_t run_end = diff ? (uint32_t)(__ffsll((unsigned long long)diff) - 1) : nb;
+        const uint32_t shape = bd[p].slot;
+        uint32_t r = p, ndc = nd + p, rsn = KB_REASON_DONE, last_n = 0xFFFFFFFFu, nlog = H.nlog;
+        while (r < run_end) {
+          unsigned long long kmax = 0ull;
+          uint32_t xmax = 0;
+          for (uint32_t x = lane; x < ndc; x += 64) {
+            const unsigned long long kk = M.keyq[x];
+            if (kk > kmax) { kmax = kk; xmax = x; }
+          }
+          const unsigned long long best = wave_max_key(kmax);
+          const unsigned long long cc = H.c[pc];
+          const KbRowDesc &k = bd[r];
+          if (best == 0ull && cc == 0ull) {
+            if (a.backfill) {   // backfill.go:50-66: the task stays Pending
+              if (lane == 0) *reinterpret_cast<uint2 *>(&a.dec[i0 + r]) = make_uint2(KB_NONE_U32, 0u);
+              r++;
+              continue;
+            }
+            rsn = KB_REASON_NO_FEASIBLE;   // allocate.go:144-148
+            break;
+          }
+          if (best > cc) {
+            const unsigned long long own = __ballot(kmax == best);
+            const uint32_t xs = (uint32_t)__builtin_amdgcn_readlane((int)xmax, __ffsll((unsigned long long)own) - 1);
+            const uint32_t n = KB_KEY_NODE(best);
+            // shapes whose cached dirty max sits on the node that changes lose their cache (once per node of a chain)
+            if (n != last_n) {
+              for (uint32_t sh = lane; sh < a.n_mrows; sh += 64) {
+                const unsigned long long ck = M.dc_key[sh];
+                if (ck != 0ull && KB_KEY_NODE(ck) == n) M.dc_nd[sh] = 0xFFFFFFFFu;
+              }
+              last_n = n;
+            }
+            uint32_t kind = 0;
+            if (lane == 0) {
+              kind = k7_apply_slot(a, M, k, xs, n);
+              M.t_left[xs] -= 1;
+              k7_commit_globals<true>(a, k, i0 + r, n, kind);
+              M.dlog[nlog] = xs;
+              const TaskVals tv = k7_task_vals(a, k);
+              const NodeVals nv = k5_slot_vals(M.tab, M.t_cls, M.t_left, cap2, xs, a.has_ports ? M.ptab : nullptr);
+              const uint32_t res = eval_pair_k5(a, tv, nv, n, a.use_crow ? &k.crow : nullptr);
+              M.keyq[xs] = res ? KB_KEY(res & 0xFFFFu, n) : 0ull;
+            }
+            kind = (uint32_t)__builtin_amdgcn_readfirstlane((int)kind);
+            nlog++;
+            r++;
+            if (kind) { rsn = KB_REASON_PIPELINED; break; }
+          } else {
+            // the prepared slot nd+pc holds candidate pc's node after ROW pc's task; identical for row r's task when both
+            // rows carry plain requests (same shape; no init-container maximum, no scalar resources)
+            const KbRowDesc &kc = bd[pc];
+            const uint32_t plain = (uint32_t)(k.flags & kc.flags & 1) && k.resmask == 0 && kc.resmask == 0;
+            if (!plain) break;
+            const uint32_t kind = H.kind[pc];
+            if (lane == 0) {
+              atomicMax(&M.cursor[shape], H.idx[pc] + 1);
+              k7_commit_globals<false>(a, k, i0 + r, KB_KEY_NODE(cc), kind);
+              M.keyq[ndc] = H.kb[pc][q];
+            }
+            ndc++; pc++; r++;
+            if (kind) { rsn = KB_REASON_PIPELINED; break; }
+          }
+          __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+        }
+        // the shape's dirty max as of now becomes its cache
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        unsigned long long kmax = 0ull;
+        for (uint32_t x = lane; x < ndc; x += 64) { const unsigned long long kk = M.keyq[x]; if (kk > kmax) kmax = kk; }
+        kmax = wave_max_key(kmax);
+        if (lane == 0) {
+          M.dc_key[shape] = kmax; M.dc_nd[shape] = ndc; M.dc_log[shape] = nlog;
+          H.n_dirty_rows += nlog - H.nlog;
+          H.nlog = nlog;
+          H.seq_rows = r; H.seq_pc = pc; H.reason = rsn; H.n_seq_rows += r - p;
+        }
+      }
+      __syncthreads();
+      rows = H.seq_rows;
+      pc = H.seq_pc;
+    }
+    // ---- roll back the candidates nobody consumed: they are re-speculated by the next batch
+    if (tid < nb && tid >= pc) {
+      const uint32_t j = tid;
+      const unsigned long long cj = H.c[j];
+      if (cj) {
+        const KbRowDesc &k = bd[j];
+        const uint32_t n = KB_KEY_NODE(cj);
+        atomicAnd(&M.bitmap[n >> 5], ~(1u << (n & 31)));
+        if (H.has_map[j]) {
+          const KbDev &d = *a.dev;
+          double *vec = H.kind[j] ? d.rel : d.idle;
+          uint32_t dd = 2, m2 = k.resmask;
+          while (m2) {
+            if (m2 & 1u) vec[(size_t)dd * d.NP + n] = M.save[(size_t)j * RS + (dd - 2)];
+            m2 >>= 1; dd++;
+          }
+        }
+      }
+    }
+    __syncthreads();
+    nd += pc;
+    i0 += rows;
+    // clean streaks are long (56 % of the batches commit every row): speculate twice as many rows after a fully valid batch
+    nb_cur = (dirty_row == 0 && p == nb) ? min(2u * a.batch, K7_B) : a.batch;
+    n_done = i0;
+    reason = H.reason;
+    if (H.exhausted) reason = KB_REASON_INTERNAL;
+    if (reason != KB_REASON_DONE) break;
+  }
+
+  // ---- write the dirty nodes' live state back to HBM
+  __syncthreads();
+  {
+    const KbDev &d = *a.dev;
+    for (uint32_t slot = tid; slot < nd; slot += KB_K5_THREADS) {
+      const uint32_t n = M.t_node[slot];
+      d.idle[n] = __longlong_as_double((long long)M.tab[K5F_IDLE0 * cap2 + slot]);
+      d.idle[(size_t)d.NP + n] = __longlong_as_double((long long)M.tab[K5F_IDLE1 * cap2 + slot]);
+      d.rel[n] = __longlong_as_double((long long)M.tab[K5F_REL0 * cap2 + slot]);
+      d.rel[(size_t)d.NP + n] = __longlong_as_double((long long)M.tab[K5F_REL1 * cap2 + slot]);
+      d.nzc[n] = (long long)M.tab[K5F_NZC * cap2 + slot];
+      d.nzm[n] = (long long)M.tab[K5F_NZM * cap2 + slot];
+      d.podcnt[n] = d.maxpods[n] - M.t_left[slot];
+      if (a.has_ports) d.ports[n] = M.ptab[slot];
+    }
+  }
+  // task-table side of ssn.Allocate / ssn.Pipeline for the committed rows (job.UpdateTaskStatus, task.NodeName:
+  // framework/session.go:243,205; api/node_info.go:206-209)
+  {
+    const KbDev &d = *a.dev;
+    for (uint32_t i = tid; i < n_done; i += KB_K5_THREADS) {
+      const uint2 dc = *reinterpret_cast<const uint2 *>(&a.dec[i]);
+      if (dc.x == KB_NONE_U32) continue;
+      const uint32_t t = a.desc[i].task;
+      d.t_status[t] = dc.y ? KB_TASK_PIPELINED : KB_TASK_ALLOCATED;
+      d.t_node[t] = dc.x;
+      d.t_counted[t] = 1;
+      if (!dc.y) d.j_allocated[d.t_job[t]] = 1;   // ssn.Allocate ran for the job: its Allocated tasks are dispatched if it is ready
+    }
+  }
+  if (tid == 0) {
+    a.result[0] = n_done; a.result[1] = reason; a.result[2] = nd; a.result[4] = H.n_refills; a.result[7] = H.n_full; a.result[3] = H.n_seq_rows;
+    a.result[5] = H.n_batches; a.result[6] = H.n_dirty_rows;
+    unsigned long long *st = reinterpret_cast<unsigned long long *>(a.result) + KB_OUT_STAMP0;
+    st[2] = t_start;
+    st[3] = wall_clock64();
+  }
+  // ---- fast rounds: mirror the header and the decision records into pinned host memory and publish the round's sequence
+  //      number last; the host spins on that word instead of paying a stream synchronisation + D2H copy per round
+  if (a.host_out) {
+    __syncthreads();
+    const unsigned long long *hdr = reinterpret_cast<const unsigned long long *>(a.result);
+    for (uint32_t i = tid; i < KB_OUT_SEQ; i += KB_K5_THREADS) a.host_out[i] = hdr[i];
+    for (uint32_t i = tid; i < n_done; i += KB_K5_THREADS) a.host_out[KB_OUT_HDR + i] = a.dec[i];
+    __threadfence_system();
+    __syncthreads();
+    if (tid == 0) __hip_atomic_store(&a.host_out[KB_OUT_SEQ], a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+
+
+size_t kb_commit_batch_smem_bytes(uint32_t cap, uint32_t NP, int R) { return k7_smem_bytes(cap, NP, R); }
+void kb_launch_commit_batch(const KbDev &d, const KbRound &r, void *stream) {
+  if (r.n_rows == 0) return;
+  static bool attr_set = false;
+  static uint32_t env_batch = 0;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_commit), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    const char *b = getenv("KB_K5_BATCH");   // tuning override of kb_config.commit_batch
+    env_batch = b ? (uint32_t)atoi(b) : 0;
+    attr_set = true;
+  }
+  uint32_t batch = env_batch ? env_batch : (r.batch ? r.batch : K7_B_DEFAULT);
+  if (batch > K7_B) batch = K7_B;
+  const size_t sh = k7_smem_bytes(r.cap, d.NP, d.R);
+  K7KernArgs ka;
+  ka.dev = d;
+  ka.round = r;
+  KbCommitArgs &a = ka.hot;
+  a.dev = nullptr; a.round = nullptr;   // set from the kernel-argument segment inside the kernel
+  a.keys = r.keys; a.dec = r.dec; a.desc = r.desc; a.result = r.result; a.trace = nullptr;
+  a.n_rows = r.n_rows; a.n_mrows = r.n_mrows; a.L = r.L; a.cap = r.cap; a.N = d.N; a.NP = d.NP;
+  a.fit_mode = r.fit_mode; a.backfill = r.backfill; a.pred_enabled = d.pred_enabled; a.score_enabled = d.score_enabled;
+  a.wL = d.wL; a.wM = d.wM; a.wB = d.wB;
+  a.use_crow = (d.pred_enabled && d.crows != nullptr && d.n_nc <= 32) ? 1u : 0u;
+  a.has_delta = r.delta != nullptr ? 1u : 0u;
+  a.has_aff = (d.aff != nullptr && d.score_enabled) ? 1u : 0u;
+  a.has_ports = d.ports != nullptr ? 1u : 0u;
+  a.R = d.R;
+  a.batch = batch;
+  a.T = d.T; a.node_bits = 0;
+  a.host_out = r.host_out;
+  a.seq = r.seq;
+  hipLaunchKernelGGL(k_commit, dim3(1), dim3(KB_K5_THREADS), sh, (hipStream_t)stream, ka);
+}

@@ -8,9 +8,6 @@
 #include <stdint.h>
 
 #define KB_NODE_PAD 2048u   // NP/8 node chunks split evenly over 256 threads (K3), 16-byte loads never straddle a row
-#ifndef KB_K5_THREADS
-#define KB_K5_THREADS 512
-#endif
 #define KB_MAX_TOPK 4096   // longest candidate list kb_argmax_rows hands out
 
 // arg-max key: (0x40000000 + score + 1) << 32 | (0xFFFFFFFF - node).  0 = no feasible node.  max() over keys = highest
@@ -83,6 +80,7 @@ struct KbRowDesc {          // 56 bytes
   uint16_t slot;           // index of the row's shape among the mrows
   uint16_t flags;          // bit 0: Resreq cpu/memory == InitResreq cpu/memory (no init container raised them)
                            // bit 1: the task's class has preferred node-affinity terms (score normalised over the feasible set)
+                           // bit 2: Resreq == InitResreq in every scalar dimension Resreq names
   uint32_t crow;           // the task class's row of the static-predicate table (bit nc), valid when n_node_classes <= 32
 };
 
@@ -127,14 +125,22 @@ struct KbCommitArgs {
   const KbRowDesc *desc;
   uint32_t *result;
   unsigned long long *trace;
-  uint32_t n_rows, n_mrows, L, cap, N, NP;
+  uint32_t n_rows, n_mrows, L, cap, N, NP, T;
   int fit_mode, backfill, pred_enabled, score_enabled, wL, wM, wB;
   uint32_t use_crow, has_delta, has_aff, has_ports;
   int R;
   uint32_t batch;   // rows speculated per batch (<= 16)
   unsigned long long *host_out;   // pinned host mirror of the output block (fast rounds), or nullptr
   unsigned long long seq;         // sequence number published last into host_out[KB_OUT_SEQ]
+  uint32_t node_bits;             // width of the node field of the commit kernel's 32-bit keys (kb_node_bits)
 };
+
+// 32-bit keys of the commit kernel: (score + 1) << node_bits | (2^node_bits - 1 - node); needs (max score + 2) << node_bits <= 2^32
+static inline uint32_t kb_node_bits(uint32_t NP) {
+  uint32_t b = 1;
+  while ((1ull << b) < (unsigned long long)NP) b++;
+  return b;
+}
 
 // Output block of a round, 8-byte words: [0..3] eight 32-bit result words, [4] divergence counter of kb_apply_deltas,
 // [8..11] wall-clock stamps (round start, candidate lists start, commit start, commit end), [12] sequence number,
@@ -143,10 +149,17 @@ struct KbCommitArgs {
 #define KB_OUT_SEQ 12u
 #define KB_OUT_HDR 16u
 
-#define KB_K5_MAX_WINDOW 1024u   // dirty-node table + row descriptors of the commit kernel live in LDS: 152 B per row
+#define KB_K5_MAX_WINDOW 1024u   // staging buffers are sized for it; the commit kernel's LDS budget decides the window actually used
+#define KB_K5_MAX_ROWS 256u      // rows per window: one thread of the commit kernel's workgroup per dirty slot
+#define KB_K5_MAX_SHAPES 256u    // distinct task shapes per window (each keeps its candidate list in LDS: the budget decides)
 
-// dynamic LDS the commit kernel needs for `cap` slots over NP padded nodes (kb_kernels.hip)
-size_t kb_commit_smem_bytes(uint32_t cap, uint32_t NP, int R);
+// Two commit kernels, same decisions bit for bit: KB_COMMIT_BATCH (kb_commit_batch.hip) speculates 16-32 rows across shapes and
+// is the faster one while clean nodes win most rows; KB_COMMIT_RUN (kb_commit.hip) works a same-shape run at a time without
+// speculation and is the faster one when nodes the round already changed win most rows (bin-packing weights).
+enum { KB_COMMIT_BATCH = 0, KB_COMMIT_RUN = 1 };
+// dynamic LDS each needs for a round of n_rows rows (batch: slot capacity `cap`) with n_shapes distinct shapes over NP padded nodes
+size_t kb_commit_smem_bytes(uint32_t n_rows, uint32_t n_shapes, uint32_t NP, int R);
+size_t kb_commit_batch_smem_bytes(uint32_t cap, uint32_t NP, int R);
 
 // KB_REASON_RENORM: the next row's score needs NormalizeReduce over its CURRENT feasible set (preferred node affinity): it is
 // committed as the first row of a fresh round, whose matrix is exact for it
@@ -161,7 +174,8 @@ void kb_launch_argmax(const KbDev &d, const KbRound &r, void *stream);
 // per-task rows out of the per-shape rows (kb_eval_matrix / kb_bench_matrix: the materialised T x N matrix)
 void kb_launch_expand(const KbDev &d, const uint16_t *s_score, const uint32_t *s_mask, const uint32_t *row_slot, uint32_t n_rows,
                       uint16_t *score, uint32_t *maskw, void *stream);
-void kb_launch_commit(const KbDev &d, const KbRound &r, void *stream);
+void kb_launch_commit(const KbDev &d, const KbRound &r, void *stream);         // KB_COMMIT_RUN
+void kb_launch_commit_batch(const KbDev &d, const KbRound &r, void *stream);   // KB_COMMIT_BATCH
 // node state := round-start state + reduced deltas; returns how many values differ from the live (locally committed) state
 uint32_t kb_apply_deltas(const KbDev &d, const double *s_idle, const double *s_rel, const long long *s_nzc, const long long *s_nzm,
                          const int *s_podcnt, const double *delta, uint32_t *dev_counter, void *stream);

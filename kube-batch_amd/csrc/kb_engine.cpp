@@ -127,18 +127,24 @@ struct kb_engine {
 
   // session buffers
   DevBuf b_idle, b_rel, b_nzc, b_nzm, b_podcnt, b_acpu, b_amem, b_maxpods, b_ncls, b_nmask, b_invac, b_invam;
-  uint64_t stage_hits = 0, stage_misses = 0;   // commit kernel: batches / dirty rows (KB_K5_STATS)
-  unsigned long long full_evals = 0;
+  uint64_t k5_walks = 0, k5_rescans = 0, k5_demand = 0, k5_slots = 0;   // commit kernel counters (KB_K5_STATS)
+  double k5_trace[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   uint32_t eff_window = 0;   // window actually used for this session (bounded by the commit kernel's LDS budget)
+  // which commit kernel the next round uses: the share of rows won by a node the round had already changed decides
+  // (exponential average over the rounds so far; KB_COMMIT_KERNEL=batch|run pins it for A/B runs and for the tests)
+  int commit_kernel = KB_COMMIT_BATCH, commit_pin = -1;
+  double dirty_share = 0.0;
+  uint64_t rounds_batch = 0, rounds_run = 0;
+  uint32_t shape_cap = KB_K5_MAX_SHAPES;   // distinct shapes a window may hold (each keeps its candidate list in the commit kernel's LDS)
+  std::vector<uint32_t> plan_stamp;   // per row-shape id: stamp of the window being planned
+  uint32_t plan_epoch = 0;
   DevBuf b_tinit, b_tres, b_tnzc, b_tnzm, b_tcls, b_tactive, b_tresmask, b_tjob, b_tstatus, b_tnode, b_tbind, b_tcounted, b_jallocated, b_compat, b_crows, b_aff, b_affcls;
   DevBuf p_idle, p_rel, p_nzc, p_nzm, p_podcnt, p_tstatus, p_tnode, p_tcounted, p_ports;   // pristine copies for kb_session_reset
   DevBuf b_ports, b_twant, b_tconf;   // host ports (only when the snapshot carries any)
   DevBuf b_jbegin, b_jmin, b_jqueue, b_total, b_deserved, b_desmask, b_jalloc, b_jshare, b_qalloc, b_qshare, b_jready;
   uint32_t total_mask = 0;
   // round buffers
-  DevBuf b_desc, b_trace;
-  bool trace_on = false;
-  std::vector<double> trace_acc = std::vector<double>(3 * 4 * 12, 0.0);
+  DevBuf b_desc;
   DevBuf b_sscore, b_smask, b_xslot;   // per-shape rows and row->shape map of kb_eval_matrix / kb_bench_matrix
   size_t xs_cap = 0, xslot_cap = 0;
   DevBuf b_mrows, b_same, b_score, b_maskw, b_keys;
@@ -320,7 +326,7 @@ KbRound make_round(kb_engine *e, uint32_t n_rows, uint32_t n_mrows, uint32_t L, 
   r.shape_slot = e->b_win.as<uint32_t>() + KB_K5_MAX_WINDOW;
   r.n_rows = n_rows;
   r.desc = e->b_desc.as<KbRowDesc>();
-  r.trace = e->trace_on ? e->b_trace.as<unsigned long long>() : nullptr;
+  r.trace = nullptr;
   r.cap = std::max<uint32_t>(64, ((n_rows + 63) / 64) * 64);
   r.mrows = e->b_win.as<uint32_t>() + 2 * KB_K5_MAX_WINDOW;
   r.mrow_task0 = 0;
@@ -391,7 +397,6 @@ RoundCtx round_prepare(kb_engine *e, uint32_t n, int fit_mode, bool backfill, bo
   c.d = e->dev;
   if (backfill) c.d.score_enabled = 0;   // backfill.go:50-66 takes the first node that passes the predicates: all scores tie
   c.r = make_round(e, n, c.ns, c.L, fit_mode, backfill);
-  if (e->trace_on) HIP_OK(hipMemsetAsync(e->b_trace.p, 0, e->b_trace.bytes, e->stream));
   c.r.gather = (gather_in_matrix && c.ns > 0) ? 1u : 0u;
   if (!c.r.gather) kb_launch_gather(c.d, c.r, e->stream);
   return c;
@@ -429,18 +434,24 @@ void round_commit(kb_engine *e, const RoundCtx &c, unsigned long long *keys, dou
   r.delta = delta;
   r.own_row0 = own0;
   r.own_row1 = own1;
+  auto launch = [&]() {
+    if (e->commit_kernel == KB_COMMIT_RUN) { kb_launch_commit(c.d, r, e->stream); e->rounds_run++; }
+    else { kb_launch_commit_batch(c.d, r, e->stream); e->rounds_batch++; }
+  };
   if (e->fast_rounds) {
     r.host_out = e->d_hout;
     r.seq = ++e->seq;
-    kb_launch_commit(c.d, r, e->stream);
+    launch();
     return;
   }
   Timer &t5 = get_timer(e, 2);
   HIP_OK(hipEventRecord(t5.a, e->stream));
-  kb_launch_commit(c.d, r, e->stream);
+  launch();
   HIP_OK(hipEventRecord(t5.b, e->stream));
   HIP_OK(hipMemcpyAsync(e->h_out.data(), e->b_out.p, sizeof(unsigned long long) * (KB_OUT_HDR + c.n), hipMemcpyDeviceToHost, e->stream));
 }
+
+static inline uint32_t n_done_rows_hint(const kb_engine *e) { return e->h_result[0]; }
 
 // wait for the round, account the kernel times, unpack the decision records
 void round_collect(kb_engine *e, const RoundCtx &c, bool had_candidates, uint32_t &n_done, uint32_t &reason) {
@@ -484,16 +495,24 @@ void round_collect(kb_engine *e, const RoundCtx &c, bool had_candidates, uint32_
   n_done = e->h_result[0];
   reason = e->h_result[1];
   if (reason == KB_REASON_INTERNAL) throw EngineError(KB_E_INTERNAL, "commit kernel ran out of candidate list entries (list shorter than the window)");
-  if (e->trace_on) {   // KB_K5_TRACE=1 (and make TRACE=1): cycles thread 0 spent in each step of the commit kernel
-    unsigned long long tr[40];
-    HIP_OK(hipMemcpy(tr, e->b_trace.p, sizeof(tr), hipMemcpyDeviceToHost));
-    for (int k = 0; k < 40; k++) e->trace_acc[k] += (double)tr[k];
-    HIP_OK(hipMemsetAsync(e->b_trace.p, 0, sizeof(tr), e->stream));
+  // rows won by a node the round had already changed (the batch kernel reports them in word 6, word 3 counts its row-mode rows)
+  const uint32_t dirty_won = e->commit_kernel == KB_COMMIT_RUN ? e->h_result[3] : e->h_result[6];
+  e->stats.row_fallbacks += dirty_won;
+  if (e->commit_kernel == KB_COMMIT_RUN) {
+    e->k5_slots += e->h_result[2];
+    e->k5_walks += e->h_result[4];
+    e->k5_rescans += e->h_result[5];
+    for (int k = 0; k < 10; k++)   // zero unless built with -DKB_K9_TRACE
+      e->k5_trace[k] += (double)(uint32_t)(e->h_out[(k < 6 ? 5 + k / 2 : 13 + (k - 6) / 2)] >> (32 * (k & 1)));
   }
-  e->stats.row_fallbacks += e->h_result[3];
-  e->stage_hits += e->h_result[5];
-  e->stage_misses += e->h_result[6];
-  e->full_evals += e->h_result[7];
+  // next round's kernel: a round in which more than ~a quarter of the rows went to dirty nodes cuts most speculated batches short
+  if (n_done_rows_hint(e)) {
+    const double share = (double)dirty_won / (double)n_done_rows_hint(e);
+    e->dirty_share = e->stats.rounds == 0 ? share : 0.75 * e->dirty_share + 0.25 * share;
+  }
+  if (e->commit_pin >= 0) e->commit_kernel = e->commit_pin;
+  else if (e->commit_kernel == KB_COMMIT_BATCH && e->dirty_share > 0.30) e->commit_kernel = KB_COMMIT_RUN;
+  else if (e->commit_kernel == KB_COMMIT_RUN && e->dirty_share < 0.15) e->commit_kernel = KB_COMMIT_BATCH;
   e->stats.rounds += 1;
   e->round_no += 1;
 }
@@ -567,21 +586,40 @@ struct ActionRun {
     }
   }
 
+  // a window holds at most shape_cap distinct task shapes (one lane of the commit kernel's main wave each)
+  static void new_window(kb_engine *e) {
+    if (e->plan_stamp.size() != e->hs.n_row_shapes) { e->plan_stamp.assign(e->hs.n_row_shapes ? e->hs.n_row_shapes : 1, 0); e->plan_epoch = 0; }
+    e->plan_epoch++;
+  }
+  static bool admit_shape(kb_engine *e, uint32_t shape, uint32_t &nshapes) {
+    if (e->plan_stamp[shape] == e->plan_epoch) return true;
+    if (nshapes >= e->shape_cap) return false;
+    e->plan_stamp[shape] = e->plan_epoch;
+    nshapes++;
+    return true;
+  }
+
   uint32_t plan(kb_engine *e) {
     HostSession &hs = e->hs;
     const uint32_t W = e->eff_window;
     if (action == 1) {
-      uint32_t n = (uint32_t)std::min<size_t>(W, bf_list.size() - bf_pos);
-      if (n) std::memcpy(e->h_rows.data(), &bf_list[bf_pos], sizeof(uint32_t) * n);
+      uint32_t n = 0, nshapes = 0;
+      new_window(e);
+      while (n < W && bf_pos + n < bf_list.size() && admit_shape(e, hs.t_row_shape[bf_list[bf_pos + n]], nshapes)) {
+        e->h_rows[n] = bf_list[bf_pos + n];
+        n++;
+      }
       return n;
     }
     double t0 = now_ms();
     om.checkpoint();   // roll-back point for a mis-speculated round
-    uint32_t n = 0, t;
+    uint32_t n = 0, t, nshapes = 0;
     spec_pops = 0;
+    new_window(e);
     while (n < W && om.next(t)) {
       spec_pops++;
       if (dead[hs.t_feas_shape[t]]) { om.report(Outcome::NoFeasibleNode); continue; }   // known: feasibility only shrinks inside one action
+      if (!admit_shape(e, hs.t_row_shape[t], nshapes)) { om.rollback_last_pop(); spec_pops--; break; }   // the task heads the next window
       e->h_rows[n++] = t;
       om.report(Outcome::Allocated);
     }
@@ -598,11 +636,13 @@ struct ActionRun {
     double t0 = now_ms();
     om.push_checkpoint();
     if (rows_next.size() < W) rows_next.resize(W);
-    uint32_t n = 0, t;
+    uint32_t n = 0, t, nshapes = 0;
     spec_pops_next = 0;
+    new_window(e);
     while (n < W && om.next(t)) {
       spec_pops_next++;
       if (dead[hs.t_feas_shape[t]]) { om.report(Outcome::NoFeasibleNode); continue; }
+      if (!admit_shape(e, hs.t_row_shape[t], nshapes)) { om.rollback_last_pop(); spec_pops_next--; break; }
       rows_next[n++] = t;
       om.report(Outcome::Allocated);
     }
@@ -737,7 +777,7 @@ int kb_engine_create(const kb_config *cfg, kb_engine **out) {
     eng->pol = compile_policy(cfg);
     eng->device = cfg->device;
     if (cfg->window) eng->window = cfg->window;
-    if (eng->window > KB_K5_MAX_WINDOW) eng->window = KB_K5_MAX_WINDOW;   // the commit kernel's dirty-node table lives in LDS
+    if (eng->window > KB_K5_MAX_ROWS) eng->window = KB_K5_MAX_ROWS;   // one thread of the commit kernel per dirty slot
     eng->commit_batch = cfg->commit_batch;
     eng->flags = cfg->flags;
     int ndev = 0;
@@ -759,11 +799,13 @@ int kb_engine_create(const kb_config *cfg, kb_engine **out) {
     {
       int khz = 0;
       if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, eng->device) == hipSuccess && khz > 0) eng->wall_khz = (double)khz;
+      if (const char *ck = getenv("KB_COMMIT_KERNEL")) {
+        if (ck[0] == 'b') eng->commit_pin = KB_COMMIT_BATCH;
+        else if (ck[0] == 'r') eng->commit_pin = KB_COMMIT_RUN;
+        if (eng->commit_pin >= 0) eng->commit_kernel = eng->commit_pin;
+      }
       const char *sr = getenv("KB_SYNC_ROUNDS");
       eng->fast_rounds = !(eng->flags & KB_FLAG_SYNC_ROUNDS) && !(sr && sr[0] == '1');
-    }
-    if (const char *tr = getenv("KB_K5_TRACE")) {
-      if (tr[0] == '1') { eng->trace_on = true; eng->b_trace.alloc(sizeof(unsigned long long) * 64); HIP_OK(hipMemset(eng->b_trace.p, 0, sizeof(unsigned long long) * 64)); }
     }
     e = eng.release();
   });
@@ -774,18 +816,18 @@ int kb_engine_create(const kb_config *cfg, kb_engine **out) {
 void kb_engine_destroy(kb_engine *e) {
   if (!e) return;
   if (getenv("KB_K5_STATS"))
-    fprintf(stderr, "[kb K5] batches %llu, dirty rows %llu, full shape evaluations %llu, rows %llu\n", (unsigned long long)e->stage_hits,
-            (unsigned long long)e->stage_misses, e->full_evals, (unsigned long long)e->stats.decisions);
-  if (e->trace_on) {
-    fprintf(stderr, "[kb K5 trace] batches that start with a dirty row: %.0f, of which on the previous dirty row's node: %.0f\n[kb K5 trace] valid-prefix histogram:", e->trace_acc[12], e->trace_acc[13]);
-    for (int k = 0; k <= 16; k++) fprintf(stderr, " %d:%.0f", k, e->trace_acc[16 + k]);
-    fprintf(stderr, "\n");
-    static const char *steps[10] = {"prologue", "stage descriptors", "shapes + windows", "walk", "(unused)", "fetch + apply", "evaluate", "validate", "commit + row mode", "row-mode evaluate"};
-    double tot = 0;
-    for (int k = 0; k < 10; k++) tot += e->trace_acc[k];
-    for (int k = 0; k < 10; k++)
-      fprintf(stderr, "[kb K5 trace] %-18s %14.0f clocks  %5.1f %%  (%.0f per batch)\n", steps[k], e->trace_acc[k], 100.0 * e->trace_acc[k] / (tot > 0 ? tot : 1),
-              e->trace_acc[k] / (double)(e->stage_hits ? e->stage_hits : 1));
+    fprintf(stderr, "[kb K5] rounds on the batch kernel %llu, on the run kernel %llu, last dirty share %.3f\n", (unsigned long long)e->rounds_batch,
+            (unsigned long long)e->rounds_run, e->dirty_share);
+  if (getenv("KB_K5_STATS"))
+    fprintf(stderr, "[kb K5] rounds %llu, rows %llu, dirty slots %llu, dirty-won rows %llu, runs %llu, runs with a row-specific Resreq %llu (%llu)\n",
+            (unsigned long long)e->stats.rounds, (unsigned long long)e->stats.decisions, (unsigned long long)e->k5_slots,
+            (unsigned long long)e->stats.row_fallbacks, (unsigned long long)e->k5_walks, (unsigned long long)e->k5_rescans,
+            (unsigned long long)e->k5_demand);
+  if (getenv("KB_K5_STATS") && e->k5_trace[0] > 0) {
+    static const char *ph[10] = {"barrier 1 (wave 0's wait)", "evaluate: candidates (wave 0)", "barrier 2", "rows", "prepare the next run",
+                                "-", "-", "-", "-", "loop top"};
+    const double runs = (double)(e->k5_walks ? e->k5_walks : 1);
+    for (int k = 0; k < 10; k++) fprintf(stderr, "[kb K5 trace] %-32s %14.0f clocks  (%.0f per run)\n", ph[k], e->k5_trace[k], e->k5_trace[k] / runs);
   }
   (void)hipSetDevice(e->device);
   delete e;
@@ -995,12 +1037,30 @@ int kb_session_load(kb_engine *e, const kb_snapshot *sn) {
       upload(e->b_invam, im.data(), NP, s);
       HIP_OK(hipStreamSynchronize(s));
     }
-    // the commit kernel keeps one slot per window row in LDS (160 KiB per workgroup on gfx950)
-    e->eff_window = std::min<uint32_t>(e->window, KB_K5_MAX_WINDOW);
-    auto cap_of = [](uint32_t w) { return std::max<uint32_t>(64, ((w + 63) / 64) * 64); };
-    while (e->eff_window > 64 && kb_commit_smem_bytes(cap_of(e->eff_window), NP, R) > 160u * 1024u) e->eff_window -= 64;
-    if (kb_commit_smem_bytes(cap_of(e->eff_window), NP, R) > 160u * 1024u)
-      throw EngineError(KB_E_UNSUPPORTED, "too many nodes for the commit kernel's LDS dirty bitmap");
+    // The commit kernel keeps the window in LDS (160 KiB per workgroup on gfx950): one dirty slot per row (one thread of the
+    // 256-thread workgroup evaluates one slot), the row descriptors, and per distinct shape its candidate list.  Prefer the
+    // largest window that still admits 64 shapes.
+    {
+      const uint32_t budget = 160u * 1024u;
+      const uint32_t W = std::min<uint32_t>(e->window, KB_K5_MAX_ROWS);
+      uint32_t best_w = 0, best_s = 0;
+      for (uint32_t w = W; w >= 1; w = (w > 32 ? ((w - 1) / 32) * 32 : w - 1)) {
+        uint32_t sc = std::min<uint32_t>(KB_K5_MAX_SHAPES, w);
+        if (kb_commit_batch_smem_bytes(std::max<uint32_t>(64, ((w + 63) / 64) * 64), NP, R) > budget) { if (w == 1) break; continue; }
+        while (sc > 0 && kb_commit_smem_bytes(w, sc, NP, R) > budget) sc--;
+        if (sc >= std::min<uint32_t>(64, w)) { best_w = w; best_s = sc; break; }
+        if (sc > best_s) { best_w = w; best_s = sc; }
+        if (w == 1) break;
+      }
+      if (best_w == 0 || best_s == 0) throw EngineError(KB_E_UNSUPPORTED, "too many nodes / resource dimensions for the commit kernel's LDS tables");
+      e->eff_window = best_w;
+      e->shape_cap = best_s;
+    }
+    {   // 32-bit keys: (score + 1) << node_bits | inverted node index
+      const long long max_score = 10ll * ((long long)e->pol.wL + e->pol.wM + e->pol.wB + e->pol.wNA);
+      if (((unsigned long long)(max_score + 2) << kb_node_bits(NP)) > (1ull << 32))
+        throw EngineError(KB_E_UNSUPPORTED, "score range x node count exceeds the commit kernel's 32-bit keys");
+    }
     std::vector<uint32_t> ncls(NP, 0);
     if (sn->node_class) std::memcpy(ncls.data(), sn->node_class, sizeof(uint32_t) * N);
     upload(e->b_ncls, ncls.data(), NP, s);
@@ -1135,6 +1195,8 @@ int kb_session_load(kb_engine *e, const kb_snapshot *sn) {
     d.score_enabled = e->pol.nodeorder_enabled ? 1 : 0;
     e->win_cap = 0; e->mat_cap = 0; e->keys_cap = 0;
     e->stats = kb_stats{};
+    e->dirty_share = 0.0;
+    e->commit_kernel = e->commit_pin >= 0 ? e->commit_pin : KB_COMMIT_BATCH;
     e->round_no = 0;
     auto snap_copy = [&](DevBuf &dst, const DevBuf &src) {
       dst.alloc(src.bytes);

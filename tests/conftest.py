@@ -35,6 +35,27 @@ def pytest_collection_modifyitems(config, items):
             item.add_marker(skip)
 
 
+def pytest_generate_tests(metafunc):
+    """Every gpu-marked test runs once per commit kernel (kb_device.h: KB_COMMIT_BATCH / KB_COMMIT_RUN): the engine picks one
+    per round from the share of dirty-won rows, so both must reproduce the oracle on every input."""
+    if metafunc.definition.get_closest_marker("gpu") is not None and "commit_kernel" in metafunc.fixturenames:
+        metafunc.parametrize("commit_kernel", ["batch", "run"], indirect=True)
+
+
+@pytest.fixture(autouse=True)
+def commit_kernel(request):
+    which = getattr(request, "param", None)
+    old = os.environ.get("KB_COMMIT_KERNEL")
+    if which:
+        os.environ["KB_COMMIT_KERNEL"] = which     # read by kb_engine_create
+    yield which
+    if which:
+        if old is None:
+            os.environ.pop("KB_COMMIT_KERNEL", None)
+        else:
+            os.environ["KB_COMMIT_KERNEL"] = old
+
+
 @pytest.fixture(scope="session")
 def kb():
     return importlib.import_module("kube-batch_amd")
