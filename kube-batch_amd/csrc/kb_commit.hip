@@ -36,7 +36,6 @@
 
 #define K9_THREADS 512   // wave 0: the sequential part; waves 1..4: one dirty slot per thread; all: prologue / epilogue
 #define K9_MAXRUN 64
-#define K9_MAXSC 30    // scalar resource dimensions (KB_MAX_RES - 2)
 #define K9_MAXSLOTS 256 // dirty slots (= rows) per round
 #define K9_NF 13   // 8-byte fields per dirty slot
 enum { F_IDLE0 = 0, F_IDLE1, F_REL0, F_REL1, F_INVAC, F_INVAM, F_AC, F_AM, F_NZC, F_NZM, F_PORTS, F_CLS_LEFT, F_NODE_NMASK };
@@ -55,7 +54,7 @@ struct K9Hdr {
 
 // dynamic LDS layout for a round of n_rows rows and n_shapes distinct shapes
 struct K9Layout {
-  uint32_t slots, sslots, rowres, sinit, shapes, desc, rinfo, dec, hdr, dk, ckey, cpos, cursor, shp, lists, bitmap, total;   // byte offsets
+  uint32_t slots, rowres, sinit, shapes, desc, rinfo, dec, hdr, dk, ckey, cpos, cursor, shp, lists, bitmap, total;   // byte offsets
   uint32_t Lp, RS;
 };
 __host__ __device__ inline K9Layout k9_layout(uint32_t n_rows, uint32_t n_shapes, uint32_t L, uint32_t NP, int R) {
@@ -64,7 +63,6 @@ __host__ __device__ inline K9Layout k9_layout(uint32_t n_rows, uint32_t n_shapes
   o.Lp = L;
   uint32_t off = 0;
   o.slots = off;  off += (n_rows + K9_MAXRUN) * K9_NF * 8u;   // + a run's worth: P2 writes every candidate's post-placement state
-  o.sslots = off; off += (n_rows + K9_MAXRUN) * o.RS * 16u;
   o.rowres = off; off += (uint32_t)R * 8u;
   o.sinit = off;  off += n_shapes * o.RS * 8u;
   o.shapes = off; off += n_shapes * (uint32_t)sizeof(K9Shape);
@@ -119,45 +117,69 @@ struct K9KernArgs {
   KbRound round;
 };
 
-// key of shape sh against the node state in st[0..12] (a dirty slot, or a candidate after its placement); ss: the node's
-// scalar dimensions {Idle, Releasing} x RS, si: the shape's scalar InitResreq
-__device__ __forceinline__ uint32_t k9_eval(const KbCommitArgs &a, const K9Shape &sh, const unsigned long long *st, const unsigned long long *ss,
-                                            const double *si, uint32_t nb, uint32_t nmaskbits) {
-  const double idle0 = u2d(st[F_IDLE0]), idle1 = u2d(st[F_IDLE1]), rel0 = u2d(st[F_REL0]), rel1 = u2d(st[F_REL1]);
+// a node's state as the evaluation reads it
+struct K9St {
+  double idle0, idle1, rel0, rel1, inv_ac, inv_am, ac, am, nzc, nzm;
+  unsigned long long ports;
+  uint32_t cls, node;
+  int left;   // Allocatable.MaxTaskNum - len(pods): predicates.go:127 fails on <= 0
+};
+__device__ __forceinline__ K9St k9_load(const unsigned long long *st) {
+  K9St v;
+  v.idle0 = u2d(st[F_IDLE0]); v.idle1 = u2d(st[F_IDLE1]); v.rel0 = u2d(st[F_REL0]); v.rel1 = u2d(st[F_REL1]);
+  v.inv_ac = u2d(st[F_INVAC]); v.inv_am = u2d(st[F_INVAM]); v.ac = u2d(st[F_AC]); v.am = u2d(st[F_AM]);
+  v.nzc = u2d(st[F_NZC]); v.nzm = u2d(st[F_NZM]); v.ports = st[F_PORTS];
+  v.cls = (uint32_t)st[F_CLS_LEFT]; v.left = (int)(uint32_t)(st[F_CLS_LEFT] >> 32); v.node = (uint32_t)st[F_NODE_NMASK];
+  return v;
+}
+typedef double __attribute__((address_space(1))) *gptrd;
+// Scalar resource dimensions stay in HBM (Idle / Releasing [R][NP]): only shapes that name a scalar read them, only rows whose
+// Resreq names one change them (one float64 atomic add per dimension at L2, exact: a single IEEE addition), and the reads go to
+// L2 as well (agent scope), so what one wave of the workgroup changed is what the others see after the barrier.
+__device__ __forceinline__ double k9_sc(gptrd base, uint32_t NP, uint32_t dd, uint32_t node) {
+  return __hip_atomic_load(base + (size_t)(dd + 2) * NP + node, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void k9_sc_sub(gptrd base, uint32_t NP, uint32_t dd, uint32_t node, double v) {
+  (void)__hip_atomic_fetch_add(base + (size_t)(dd + 2) * NP + node, -v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// key of shape sh against node state v (a dirty slot, or a candidate after its placement); si: the shape's scalar InitResreq.
+// adj_mask / adj_mul / rq: evaluate as if Idle of the scalar dimensions in adj_mask were lower by adj_mul * rq[d] — placements
+// whose scalar part has not reached HBM yet (the caller has already lowered cpu / memory in v); 0 for a plain evaluation.
+__device__ __forceinline__ uint32_t k9_eval_v(const KbCommitArgs &a, const K9Shape &sh, const K9St &v, gptrd gi, gptrd gr, const double *si,
+                                              uint32_t adj_mask, double adj_mul, const double *rq, uint32_t nb, uint32_t nmaskbits) {
   bool ok = true;
   if (a.fit_mode) {   // allocate.go:81: !InitResreq.LessEqual(Idle) && !InitResreq.LessEqual(Releasing) -> fail
-    bool fi = le_eps(sh.init0, idle0, EPS_CPU) && le_eps(sh.init1, idle1, EPS_MEM);
-    bool fr = le_eps(sh.init0, rel0, EPS_CPU) && le_eps(sh.init1, rel1, EPS_MEM);
+    bool fi = le_eps(sh.init0, v.idle0, EPS_CPU) && le_eps(sh.init1, v.idle1, EPS_MEM);
+    bool fr = le_eps(sh.init0, v.rel0, EPS_CPU) && le_eps(sh.init1, v.rel1, EPS_MEM);
     uint32_t aa = sh.active >> 2, dd = 0;
     while (aa) {   // scalar dimensions with InitResreq > 10 (resource_info.go:286-299)
       if (aa & 1u) {
         const double l = si[dd];
-        fi = fi && le_eps(l, u2d(ss[dd * 2]), EPS_SCALAR);
-        fr = fr && le_eps(l, u2d(ss[dd * 2 + 1]), EPS_SCALAR);
+        double id = k9_sc(gi, a.NP, dd, v.node);
+        if ((adj_mask >> dd) & 1u) id -= adj_mul * rq[dd];
+        fi = fi && le_eps(l, id, EPS_SCALAR);
+        fr = fr && le_eps(l, k9_sc(gr, a.NP, dd, v.node), EPS_SCALAR);
       }
       aa >>= 1; dd++;
     }
     ok = fi || fr;
   }
-  const unsigned long long cl = st[F_CLS_LEFT];
-  const uint32_t ncls = (uint32_t)cl;
   if (a.pred_enabled) {
-    ok = ok && ((int)(uint32_t)(cl >> 32) > 0) && ((st[F_PORTS] & sh.conf) == 0ull);   // pod count (predicates.go:127), PodFitsHostPorts (predicates.go:181-190)
+    ok = ok && (v.left > 0) && ((v.ports & sh.conf) == 0ull);   // pod count (predicates.go:127), PodFitsHostPorts (predicates.go:181-190)
     if (a.use_crow) {
-      ok = ok && ((sh.crow >> (ncls & 31)) & 1u);
+      ok = ok && ((sh.crow >> (v.cls & 31)) & 1u);
     } else {
       const KbDev &d = *a.dev;
       if (d.compat) {
-        const uint32_t bit = sh.cls * d.n_nc + ncls;
+        const uint32_t bit = sh.cls * d.n_nc + v.cls;
         ok = ok && ((d.compat[bit >> 3] >> (bit & 7)) & 1);
       }
     }
   }
   if (!ok) return 0u;
   uint32_t score = 0;
-  if (a.score_enabled)
-    score = score_core_f64(sh.nzc, sh.nzm, u2d(st[F_NZC]), u2d(st[F_NZM]), u2d(st[F_AC]), u2d(st[F_AM]), u2d(st[F_INVAC]), u2d(st[F_INVAM]), a.wL, a.wM, a.wB);
-  return ((score + 1u) << nb) | (nmaskbits - (uint32_t)st[F_NODE_NMASK]);
+  if (a.score_enabled) score = score_core_f64(sh.nzc, sh.nzm, v.nzc, v.nzm, v.ac, v.am, v.inv_ac, v.inv_am, a.wL, a.wM, a.wB);
+  return ((score + 1u) << nb) | (nmaskbits - v.node);
 }
 
 __global__ void __launch_bounds__(K9_THREADS) k_commit(const K9KernArgs ka) {
@@ -172,7 +194,6 @@ __global__ void __launch_bounds__(K9_THREADS) k_commit(const K9KernArgs ka) {
   const uint32_t S = a.n_mrows, W = a.n_rows;
   const K9Layout lo = k9_layout(W, S, a.L, a.NP, a.R);
   unsigned long long *slots = reinterpret_cast<unsigned long long *>(k9_smem + lo.slots);
-  unsigned long long *sslots = reinterpret_cast<unsigned long long *>(k9_smem + lo.sslots);
   double *rowres = reinterpret_cast<double *>(k9_smem + lo.rowres);
   double *sinit = reinterpret_cast<double *>(k9_smem + lo.sinit);
   K9Shape *shapes = reinterpret_cast<K9Shape *>(k9_smem + lo.shapes);
@@ -277,9 +298,6 @@ __global__ void __launch_bounds__(K9_THREADS) k_commit(const K9KernArgs ka) {
   // wave 0's registers: the fetched (raw) node state of candidate `lane` of the run being prepared
   unsigned long long raw[11] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   uint32_t rcls = 0, rmaxp = 0, rpodc = 0, rnm = 0;
-  unsigned long long rsc[K9_MAXSC][2];
-#pragma unroll
-  for (int q = 0; q < K9_MAXSC; q++) { rsc[q][0] = 0ull; rsc[q][1] = 0ull; }
 
   // wave 0, between two runs: the next run's parameters, its clean candidates (walk of the shape's list against the dirty
   // bitmap), and the fetch of the candidates' node state — lane j pulls every field of candidate j, all loads in flight together,
@@ -318,8 +336,6 @@ __global__ void __launch_bounds__(K9_THREADS) k_commit(const K9KernArgs ka) {
           _Pragma("unroll") for (int f = 0; f < 10; f++) raw[f] = g8[f][n_];                                           \
           raw[F_PORTS] = gports ? gports[n_] : 0ull;                                                                   \
           rcls = gcls[n_]; rmaxp = gmaxp[n_]; rpodc = gpodc[n_]; rnm = gnm[n_];                                        \
-          _Pragma("unroll") for (int q = 0; q < K9_MAXSC; q++)                                                         \
-            if (q < (int)RS) { rsc[q][0] = g8[0][(size_t)(q + 2) * a.NP + n_]; rsc[q][1] = g8[2][(size_t)(q + 2) * a.NP + n_]; } \
         }                                                                                                              \
         const bool plain_ = (fl_ & 1u) && (km_ == 0u || (fl_ & 4u));                                                   \
         if (!plain_ && lane == 63) {   /* an init container raised InitResreq above Resreq (rare): the row's own Resreq */ \
@@ -342,6 +358,7 @@ __global__ void __launch_bounds__(K9_THREADS) k_commit(const K9KernArgs ka) {
   gptr8 g8[10];
   gptr8 gports;
   gptr4 gcls, gmaxp, gpodc, gnm;
+  gptrd gi, gr;
   {
     const KbDev &d = *a.dev;
     g8[0] = (gptr8)reinterpret_cast<const unsigned long long *>(d.idle); g8[1] = (gptr8)reinterpret_cast<const unsigned long long *>(d.idle + d.NP);
@@ -350,6 +367,7 @@ __global__ void __launch_bounds__(K9_THREADS) k_commit(const K9KernArgs ka) {
     g8[6] = (gptr8)reinterpret_cast<const unsigned long long *>(d.acpu); g8[7] = (gptr8)reinterpret_cast<const unsigned long long *>(d.amem);
     g8[8] = (gptr8)reinterpret_cast<const unsigned long long *>(d.nzc); g8[9] = (gptr8)reinterpret_cast<const unsigned long long *>(d.nzm);
     gports = (gptr8)d.ports;
+    gi = (gptrd)d.idle; gr = (gptrd)d.rel;
     gcls = (gptr4)d.ncls; gmaxp = (gptr4)reinterpret_cast<const uint32_t *>(d.maxpods); gpodc = (gptr4)reinterpret_cast<const uint32_t *>(d.podcnt); gnm = (gptr4)d.nmask;
   }
   if (wave == 0) K9_PREPARE_NEXT(0u, 0u, (uint32_t)KB_REASON_DONE);
@@ -364,10 +382,11 @@ __global__ void __launch_bounds__(K9_THREADS) k_commit(const K9KernArgs ka) {
     const bool plain0 = (fl0 & 1u) && (km0 == 0u || (fl0 & 4u));
     const K9Shape sh = shapes[s];
     const double *si = sinit + (size_t)s * RS;
+    const double *rqv = plain0 ? si : rowres + 2;   // the rows' scalar Resreq
     // ---- evaluation phase, one evaluation deep: waves 1..4 the shape against "their" dirty slot, wave 0 the candidates
     if (wave >= 1 && tid - 64u < nd) {
       const uint32_t t = tid - 64u;
-      dk[t] = k9_eval(a, sh, slots + (size_t)t * K9_NF, sslots + (size_t)t * RS * 2, si, nb, nmaskbits);
+      dk[t] = k9_eval_v(a, sh, k9_load(slots + (size_t)t * K9_NF), gi, gr, si, 0u, 0.0, si, nb, nmaskbits);
     }
     uint32_t ck = 0, k1 = 0, ckind = 0;
     double res0 = sh.init0, res1 = sh.init1;
@@ -378,38 +397,34 @@ __global__ void __launch_bounds__(K9_THREADS) k_commit(const K9KernArgs ka) {
         ck = ckey[lane];
         const uint32_t n = nmaskbits - (ck & nmaskbits);
         unsigned long long *st = slots + (size_t)(nd + lane) * K9_NF;
-        unsigned long long *ss = sslots + (size_t)(nd + lane) * RS * 2;
         double idle0 = u2d(raw[F_IDLE0]), idle1 = u2d(raw[F_IDLE1]), rel0 = u2d(raw[F_REL0]), rel1 = u2d(raw[F_REL1]);
         uint32_t kind = 0;
         if (!a.backfill) {   // allocate.go:160: InitResreq.LessEqual(node.Idle) -> Allocate, else Pipeline
           bool fi = le_eps(sh.init0, idle0, EPS_CPU) && le_eps(sh.init1, idle1, EPS_MEM);
-#pragma unroll
-          for (int q = 0; q < K9_MAXSC; q++)
-            if (q < (int)RS && ((sh.active >> (q + 2)) & 1u)) fi = fi && le_eps(si[q], u2d(rsc[q][0]), EPS_SCALAR);
+          for (uint32_t aa = sh.active >> 2, dd = 0; aa; aa >>= 1, dd++)
+            if (aa & 1u) fi = fi && le_eps(si[dd], k9_sc(gi, a.NP, dd, n), EPS_SCALAR);
           kind = fi ? 0u : 1u;
         }
         // NodeInfo.AddTask (api/node_info.go:172-212): Idle (Allocated) or Releasing (Pipelined) -= Resreq, pod joins ni.Tasks
         if (kind) { rel0 -= res0; rel1 -= res1; } else { idle0 -= res0; idle1 -= res1; }
-        st[F_IDLE0] = d2u(idle0); st[F_IDLE1] = d2u(idle1); st[F_REL0] = d2u(rel0); st[F_REL1] = d2u(rel1);
-        st[F_INVAC] = raw[F_INVAC]; st[F_INVAM] = raw[F_INVAM];
-        st[F_AC] = d2u((double)(long long)raw[F_AC]); st[F_AM] = d2u((double)(long long)raw[F_AM]);
-        st[F_NZC] = d2u((double)(long long)raw[F_NZC] + sh.nzc); st[F_NZM] = d2u((double)(long long)raw[F_NZM] + sh.nzm);
-        st[F_PORTS] = raw[F_PORTS] | sh.want;   // the pod's host ports join nodeinfo.UsedPorts()
-        st[F_CLS_LEFT] = (unsigned long long)rcls | ((unsigned long long)(uint32_t)((int)rmaxp - (int)rpodc - 1) << 32);
+        K9St v;
+        v.idle0 = idle0; v.idle1 = idle1; v.rel0 = rel0; v.rel1 = rel1;
+        v.inv_ac = u2d(raw[F_INVAC]); v.inv_am = u2d(raw[F_INVAM]);
+        v.ac = (double)(long long)raw[F_AC]; v.am = (double)(long long)raw[F_AM];
+        v.nzc = (double)(long long)raw[F_NZC] + sh.nzc; v.nzm = (double)(long long)raw[F_NZM] + sh.nzm;
+        v.ports = raw[F_PORTS] | sh.want;   // the pod's host ports join nodeinfo.UsedPorts()
+        v.cls = rcls; v.node = n; v.left = (int)rmaxp - (int)rpodc - 1;
+        st[F_IDLE0] = d2u(v.idle0); st[F_IDLE1] = d2u(v.idle1); st[F_REL0] = d2u(v.rel0); st[F_REL1] = d2u(v.rel1);
+        st[F_INVAC] = raw[F_INVAC]; st[F_INVAM] = raw[F_INVAM]; st[F_AC] = d2u(v.ac); st[F_AM] = d2u(v.am);
+        st[F_NZC] = d2u(v.nzc); st[F_NZM] = d2u(v.nzm); st[F_PORTS] = v.ports;
+        st[F_CLS_LEFT] = (unsigned long long)rcls | ((unsigned long long)(uint32_t)v.left << 32);
         st[F_NODE_NMASK] = (unsigned long long)n | ((unsigned long long)rnm << 32);
-        const uint32_t has_map = kind ? (rnm >> 31) : (rnm & 0x7FFFFFFFu);   // Sub returns early when the receiver's scalar map is nil (resource_info.go:148-153)
-#pragma unroll
-        for (int q = 0; q < K9_MAXSC; q++)
-          if (q < (int)RS) {
-            double vi = u2d(rsc[q][0]), vr = u2d(rsc[q][1]);
-            if (((km0 >> q) & 1u) && has_map) {
-              const double rq = plain0 ? si[q] : rowres[q + 2];
-              if (kind) vr -= rq; else vi -= rq;
-            }
-            ss[q * 2] = d2u(vi); ss[q * 2 + 1] = d2u(vr);
-          }
+        // the scalar part of the Sub reaches HBM when (and if) the candidate is consumed; the key is evaluated as if it had.
+        // Sub returns early when the receiver's scalar map is nil (resource_info.go:148-153); a Pipeline ends the round, its
+        // Releasing-side key is never read.
+        const uint32_t adjm = (!kind && (rnm & 0x7FFFFFFFu)) ? km0 : 0u;
         ckind = kind;
-        k1 = k9_eval(a, sh, st, ss, si, nb, nmaskbits);   // the node's key once it is dirty
+        k1 = k9_eval_v(a, sh, v, gi, gr, si, adjm, 1.0, rqv, nb, nmaskbits);   // the node's key once it is dirty
       }
     }
     K9_STAMP(1);
@@ -422,7 +437,7 @@ __global__ void __launch_bounds__(K9_THREADS) k_commit(const K9KernArgs ka) {
       uint32_t d0 = (lane < nd) ? dk[lane] : 0u, d1 = (lane + 64 < nd) ? dk[lane + 64] : 0u;
       uint32_t d2 = (lane + 128 < nd) ? dk[lane + 128] : 0u, d3 = (lane + 192 < nd) ? dk[lane + 192] : 0u;
       uint32_t m = wave_max_u32(max(max(d0, d1), max(d2, d3)));   // best dirty key; clean winners update it in O(1)
-      uint32_t pc = 0, j = 0, reason = KB_REASON_DONE, n_dirty = 0;
+      uint32_t pc = 0, j = 0, reason = KB_REASON_DONE, n_dirty = 0, sc_dirty = 0;
       for (; j < r; j++) {
         const uint32_t c = (pc < ncand) ? rl32(ck, pc) : 0u;
         if (m == 0u && c == 0u) {
@@ -442,6 +457,12 @@ __global__ void __launch_bounds__(K9_THREADS) k_commit(const K9KernArgs ka) {
             ldec[i0 + j] = (unsigned long long)n | ((unsigned long long)kind << 32);
             atomicOr(&bitmap[n >> 5], 1u << (n & 31));
           }
+          if (km0) {   // the scalar dimensions Resreq names: Idle / Releasing in HBM (lane 16 + d' takes dimension d' + 2)
+            const uint32_t nmc = rl32(rnm, pc);
+            const bool has_map = kind ? (nmc >> 31) : (nmc & 0x7FFFFFFFu);
+            if (has_map && lane >= 16 && lane < 16 + RS && ((km0 >> (lane - 16)) & 1u)) k9_sc_sub(kind ? gr : gi, a.NP, lane - 16, n, rqv[lane - 16]);
+            sc_dirty = 1;
+          }
           pc++;
         } else {       // a node this round already changed wins: AddTask on its slot, re-evaluate it
           const uint32_t own = (lane < pc) ? k1 : 0u;
@@ -451,23 +472,80 @@ __global__ void __launch_bounds__(K9_THREADS) k_commit(const K9KernArgs ka) {
           const uint32_t wsel = (rl32(d0, L) == m) ? 0u : (rl32(d1, L) == m) ? 1u : (rl32(d2, L) == m) ? 2u : 3u;
           const uint32_t x = is_new ? nd + L : L + 64u * wsel;
           unsigned long long *st = slots + (size_t)x * K9_NF;
-          unsigned long long *ss = sslots + (size_t)x * RS * 2;
-          // lane f holds field f (lanes 16 + d': the scalar dimension d' + 2)
+          // ---- a chain: bin-packing scores keep the same node on top for several rows of the run.  Lane t evaluates the node
+          // after t + 1 placements of this shape (one evaluation pass for the whole chain); the chain runs while the node's key
+          // still beats every other dirty key and the next clean candidate and the placement is an Allocate.  Exact because the
+          // quantities involved are integers (checked): Idle - (t + 1) * Resreq equals t + 1 successive subtractions.
+          const uint32_t rem = r - j;
+          if (rem >= 2u && plain0 && !a.backfill) {
+            const K9St v0 = k9_load(st);
+            const uint32_t nm0 = (uint32_t)(st[F_NODE_NMASK] >> 32);
+            const uint32_t adjm = (nm0 & 0x7FFFFFFFu) ? km0 : 0u;   // Idle has a scalar map: Sub lowers the dimensions Resreq names
+            bool exact = v0.idle0 == trunc(v0.idle0) && v0.idle1 == trunc(v0.idle1) && res0 == trunc(res0) && res1 == trunc(res1) &&
+                         fabs(v0.idle0) < 4.0e15 && fabs(v0.idle1) < 4.0e15 && res0 < 3.0e13 && res1 < 3.0e13;
+            for (uint32_t mm = adjm, dd = 0; mm; mm >>= 1, dd++)
+              if (mm & 1u) { const double id = k9_sc(gi, a.NP, dd, v0.node), rq = si[dd]; exact = exact && id == trunc(id) && rq == trunc(rq) && fabs(id) < 4.0e15 && rq < 3.0e13; }
+            if (exact) {
+              const double tb = (double)lane, ta = (double)(lane + 1);   // placements before / after step `lane`
+              // Allocate at step t needs InitResreq <= Idle after t placements (allocate.go:160)
+              bool fit = le_eps(sh.init0, v0.idle0 - tb * res0, EPS_CPU) && le_eps(sh.init1, v0.idle1 - tb * res1, EPS_MEM);
+              for (uint32_t aa = sh.active >> 2, dd = 0; aa; aa >>= 1, dd++)
+                if (aa & 1u) { double id = k9_sc(gi, a.NP, dd, v0.node); if ((adjm >> dd) & 1u) id -= tb * si[dd]; fit = fit && le_eps(si[dd], id, EPS_SCALAR); }
+              K9St v = v0;
+              v.idle0 = v0.idle0 - ta * res0; v.idle1 = v0.idle1 - ta * res1;
+              v.nzc = v0.nzc + ta * sh.nzc; v.nzm = v0.nzm + ta * sh.nzm;
+              v.ports = v0.ports | sh.want;
+              v.left = v0.left - (int)(lane + 1);
+              const uint32_t kt = k9_eval_v(a, sh, v, gi, gr, si, adjm, ta, si, nb, nmaskbits);   // key after t + 1 placements
+              // the best alternative: every other dirty key, and the next clean candidate
+              const uint32_t others = max(max(max(lane == L && !is_new && wsel == 0 ? 0u : d0, lane == L && !is_new && wsel == 1 ? 0u : d1),
+                                              max(lane == L && !is_new && wsel == 2 ? 0u : d2, lane == L && !is_new && wsel == 3 ? 0u : d3)),
+                                          (lane < pc && !(is_new && lane == L)) ? k1 : 0u);
+              const uint32_t alt = max(wave_max_u32(others), c);
+              const uint32_t kprev = (uint32_t)__shfl_up((int)kt, 1);   // key before step t (t >= 1)
+              const bool okt = lane < rem && fit && (lane == 0 || kprev > alt);
+              const unsigned long long bad = ~__ballot(okt);
+              const uint32_t Lc = bad ? (uint32_t)__ffsll((unsigned long long)bad) - 1u : 64u;
+              if (Lc >= 1u) {
+                const uint32_t n = v0.node;
+                if (lane < Lc) ldec[i0 + j + lane] = (unsigned long long)n;   // kind 0
+                if (lane == Lc - 1u) {   // the node after the chain
+                  st[F_IDLE0] = d2u(v.idle0); st[F_IDLE1] = d2u(v.idle1); st[F_NZC] = d2u(v.nzc); st[F_NZM] = d2u(v.nzm);
+                  st[F_PORTS] = v.ports;
+                  st[F_CLS_LEFT] = (unsigned long long)v.cls | ((unsigned long long)(uint32_t)v.left << 32);
+                  for (uint32_t mm = adjm, dd = 0; mm; mm >>= 1, dd++)
+                    if (mm & 1u) k9_sc_sub(gi, a.NP, dd, v0.node, ta * si[dd]);   // after every evaluation above has read the old value
+                }
+                if (adjm) sc_dirty = 1;
+                const uint32_t nk = rl32(kt, Lc - 1u);
+                if (lane == L) {
+                  if (is_new) k1 = nk;
+                  else if (wsel == 0) d0 = nk; else if (wsel == 1) d1 = nk; else if (wsel == 2) d2 = nk; else d3 = nk;
+                }
+                K9_WAVE_FENCE();
+                m = wave_max_u32(max(max(max(d0, d1), max(d2, d3)), (lane < pc) ? k1 : 0u));
+                n_dirty += Lc;
+                j += Lc - 1u;   // the loop header adds the last one
+                continue;
+              }
+            }
+          }
+          // one row: lane f holds field f of the slot; lanes 16 + d' look at the scalar dimension d' + 2 in HBM when the shape or
+          // the row names one
           const bool sc_lane = lane >= 16 && lane < 16 + RS;
           const uint32_t sd = sc_lane ? lane - 16 : 0;
-          unsigned long long cur8 = 0ull, cur8b = 0ull;
+          unsigned long long cur8 = 0ull;
           if (lane < K9_NF) cur8 = st[lane];
-          if (sc_lane) { cur8 = ss[sd * 2]; cur8b = ss[sd * 2 + 1]; }
+          const uint32_t nm = (uint32_t)(rl64(cur8, F_NODE_NMASK) >> 32);
+          const uint32_t n = (uint32_t)rl64(cur8, F_NODE_NMASK);
           kind = 0;
           if (!a.backfill) {
             bool ok = true;
             if (lane == F_IDLE0) ok = le_eps(sh.init0, u2d(cur8), EPS_CPU);
             else if (lane == F_IDLE1) ok = le_eps(sh.init1, u2d(cur8), EPS_MEM);
-            else if (sc_lane && ((sh.active >> (2 + sd)) & 1u)) ok = le_eps(si[sd], u2d(cur8), EPS_SCALAR);
+            else if (sc_lane && ((sh.active >> (2 + sd)) & 1u)) ok = le_eps(si[sd], k9_sc(gi, a.NP, sd, n), EPS_SCALAR);
             kind = __ballot(!ok) ? 1u : 0u;
           }
-          const uint32_t nm = (uint32_t)(rl64(cur8, F_NODE_NMASK) >> 32);
-          const uint32_t n = (uint32_t)rl64(cur8, F_NODE_NMASK);
           const uint32_t has_map = kind ? (nm >> 31) : (nm & 0x7FFFFFFFu);
           const uint32_t f0 = kind ? F_REL0 : F_IDLE0;
           if (lane == f0) cur8 = d2u(u2d(cur8) - res0);
@@ -476,15 +554,16 @@ __global__ void __launch_bounds__(K9_THREADS) k_commit(const K9KernArgs ka) {
           else if (lane == F_NZM) cur8 = d2u(u2d(cur8) + sh.nzm);
           else if (lane == F_PORTS) cur8 |= sh.want;
           else if (lane == F_CLS_LEFT) cur8 -= (1ull << 32);   // one more pod on the node
-          if (sc_lane && ((km0 >> sd) & 1u) && has_map) {
-            const double rq = plain0 ? si[sd] : rowres[sd + 2];
-            if (kind) cur8b = d2u(u2d(cur8b) - rq); else cur8 = d2u(u2d(cur8) - rq);
-          }
           if (lane < K9_NF) st[lane] = cur8;
-          if (sc_lane) { ss[sd * 2] = cur8; ss[sd * 2 + 1] = cur8b; }
           if (lane == 0) ldec[i0 + j] = (unsigned long long)n | ((unsigned long long)kind << 32);
           K9_WAVE_FENCE();
-          const uint32_t nk = k9_eval(a, sh, st, ss, si, nb, nmaskbits);   // uniform: every lane computes the same key
+          // the new key first (scalar part of the Sub as an adjustment), then the Sub itself goes to HBM
+          const uint32_t adjm1 = (!kind && has_map) ? km0 : 0u;
+          const uint32_t nk = k9_eval_v(a, sh, k9_load(st), gi, gr, si, adjm1, 1.0, rqv, nb, nmaskbits);   // uniform: every lane computes the same key
+          if (km0 && has_map) {
+            if (sc_lane && ((km0 >> sd) & 1u)) k9_sc_sub(kind ? gr : gi, a.NP, sd, n, rqv[sd]);
+            sc_dirty = 1;
+          }
           if (lane == L) {
             if (is_new) k1 = nk;
             else if (wsel == 0) d0 = nk; else if (wsel == 1) d1 = nk; else if (wsel == 2) d2 = nk; else d3 = nk;
@@ -495,6 +574,7 @@ __global__ void __launch_bounds__(K9_THREADS) k_commit(const K9KernArgs ka) {
         if (kind) { j++; reason = KB_REASON_PIPELINED; break; }   // a Pipeline ends the speculated order: the host re-plans
       }
       K9_STAMP(3);
+      if (sc_dirty) __threadfence();   // the scalar atomics have reached L2 before any other wave evaluates against these nodes
       if (lane == 0) {
         if (pc) cursor[s] = cpos[pc - 1] + 1;
         H.n_dirty_rows += n_dirty; H.n_runs += 1; H.n_slow += plain0 ? 0u : 1u;
@@ -530,12 +610,6 @@ __global__ void __launch_bounds__(K9_THREADS) k_commit(const K9KernArgs ka) {
       d.nzm[n] = (long long)u2d(sl[F_NZM]);
       d.podcnt[n] = d.maxpods[n] - (int)(uint32_t)(sl[F_CLS_LEFT] >> 32);
       if (a.has_ports) d.ports[n] = sl[F_PORTS];
-    }
-    for (uint32_t idx = tid; idx < nd * RS; idx += K9_THREADS) {
-      const uint32_t slot = idx / RS, dd = idx % RS;
-      const uint32_t n = (uint32_t)slots[(size_t)slot * K9_NF + F_NODE_NMASK];
-      d.idle[(size_t)(dd + 2) * d.NP + n] = u2d(sslots[(size_t)idx * 2]);
-      d.rel[(size_t)(dd + 2) * d.NP + n] = u2d(sslots[(size_t)idx * 2 + 1]);
     }
   }
   {
