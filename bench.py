@@ -46,6 +46,10 @@ tiers:
 """
 
 
+def _k(n):
+    return f"{n // 1000}k" if n >= 1000 and n % 1000 == 0 else str(n)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -53,11 +57,12 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--config", type=int, default=3, help="BASELINE config index (2..5)")
     ap.add_argument("--scale", type=float, default=1.0)
+    ap.add_argument("--diverse", action="store_true", help="stress variant: every job draws its own request (thousands of distinct task shapes)")
     ap.add_argument("--window", type=int, default=0)
     ap.add_argument("--commit-batch", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-tasks", type=int, default=0, help="0 = the whole allocate action (a few seconds on 16 threads)")
-    ap.add_argument("--verify", action="store_true", help="compare the bind set with the oracle after the timed region (slow)")
+    ap.add_argument("--verify", action="store_true", help="with --no-cpu-baseline: still compare the bind set with the oracle after the timed region")
     args = ap.parse_args()
 
     import numpy as np
@@ -88,6 +93,8 @@ def main():
         conf = kbm.conf.load_scheduler_conf(BINPACK_CONF)
         weights = "least 0, most 5, balanced 1"
     params = kbm.snapshot.synth_config(args.config, args.scale)
+    if args.diverse:
+        params.diverse_requests = True
     snap = kbm.snapshot.synth(params)
     actions = ["allocate", "backfill"]
 
@@ -173,27 +180,41 @@ def main():
     found = sorted(glob.glob(os.path.join(ROOT, "profiles", "round*", "rocprofv3_pmc_k_matrix.csv")),
                    key=lambda f: int("".join(c for c in os.path.basename(os.path.dirname(f)) if c.isdigit()) or 0))
     pmc = found[-1] if found else ""                # the newest round's summary
-    if full_ms > 0 and args.config == 3 and args.scale == 1.0 and pmc:
-        import csv
-        vals = {}
-        for row in csv.DictReader(open(pmc)):
-            if "k_matrix<4, 32>" in row["kernel"] or "k_expand" in row["kernel"]:
-                vals[row["counter"]] = vals.get(row["counter"], 0.0) + float(row["mean_KB_per_dispatch"])
-        if "FETCH_SIZE" in vals and "WRITE_SIZE" in vals:
-            roofline["traffic"] = int((2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024)
-            roofline["traffic_source"] = os.path.relpath(pmc, ROOT)
+    if full_ms > 0 and pmc:
+        # only a profile of THIS launch may speak for it: the bench line committed beside the CSV must carry the same algorithmic
+        # bytes per launch (same configuration, scale and matrix layout); otherwise traffic stays null
+        same = False
+        for js in glob.glob(os.path.join(os.path.dirname(pmc), "*.json")):
+            try:
+                prof_line = json.loads(open(js).read().strip().splitlines()[-1])
+                same = same or int(prof_line["roofline"]["bytes_per_launch"]) == int(roofline["bytes_per_launch"])
+            except Exception:
+                pass
+        if same:
+            import csv
+            vals = {}
+            for row in csv.DictReader(open(pmc)):
+                if "k_matrix<4, 32>" in row["kernel"] or "k_expand" in row["kernel"]:
+                    vals[row["counter"]] = vals.get(row["counter"], 0.0) + float(row["mean_KB_per_dispatch"])
+            if "FETCH_SIZE" in vals and "WRITE_SIZE" in vals:
+                roofline["traffic"] = int((2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024)
+                roofline["traffic_source"] = "committed rocprofv3 PMC passes of the same launch (not re-measured in this run): " + os.path.relpath(pmc, ROOT)
 
     out = {
-        "metric": "pod-node scoring evals/sec + binds/sec, 100k tasks x 10k nodes snapshot",
+        "metric": f"pod-node scoring evals/sec + binds/sec, {_k(snap.n_tasks)} tasks x {_k(snap.n_nodes)} nodes snapshot",
         "value": value, "unit": "evals/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": elapsed * 1e3 / args.steps, "higher_is_better": True, "scaling": "strong",
         "vs_baseline": None, "dtype": "f64+i64", "data": "synthetic",
         "config": {"workload": f"BASELINE configs[{args.config - 1}]: {snap.n_tasks} tasks x {snap.n_nodes} nodes, "
                                f"{snap.n_jobs} gang jobs, {snap.n_queues} queues, R={R}, allocate+backfill, "
                                f"plugins priority,gang,drf,predicates,proportion,nodeorder ({weights})",
-                   "window": args.window or 256, "scale": args.scale},
+                   "window": args.window or 256, "scale": args.scale, "diverse_requests": bool(args.diverse)},
         "binds_per_s": n_binds * args.steps / elapsed, "binds": n_binds, "decisions": int(d["decisions"] / args.steps),
         "evals_per_step": int(evals / args.steps),
+        # `value` counts the evaluations the REFERENCE performs for this cycle (N per popped task).  The engine
+        # itself evaluates far fewer pairs (one matrix row per distinct task shape of a window + the dirty-node repairs):
+        "value_counts": "reference-equivalent (task,node) evaluations",
+        "matrix_evals_per_step": int(d["matrix_evals"] / args.steps),
         "kernel_ms_per_step": {k: round(d[k] / args.steps, 3) for k in ("matrix_ms", "argmax_ms", "commit_ms", "reduce_ms", "host_order_ms", "total_ms")},
         "rounds_per_step": d["rounds"] / args.steps, "spec_breaks_per_step": d["spec_breaks"] / args.steps,
         "row_fallbacks_per_step": d["row_fallbacks"] / args.steps,
@@ -218,12 +239,19 @@ def main():
         c0 = time.perf_counter()
         o.allocate()
         c1 = time.perf_counter()
-        out["cpu_baseline"] = {"value": o.evals / (c1 - c0), "unit": "evals/s", "cores": threads, "kind": "port",
+        out["cpu_baseline"] = {"value": o.evals / (c1 - c0), "unit": "evals/s", "cores": os.cpu_count() or 1, "threads": threads,
+                               "kind": "port",
                                "sample": f"{'first ' if args.cpu_sample_tasks else 'all '}{o.popped} popped tasks of the same snapshot's allocate action "
-                                         f"({o.evals} evals, {c1 - c0:.1f} s); C restatement of the Go loop with the "
-                                         "reference's 16-worker per-task fan-out, without its per-pair NodeInfo rebuilds"}
+                                         f"({o.evals} evals, {c1 - c0:.1f} s) on {threads} threads of the box's {os.cpu_count()} host cores; C restatement "
+                                         "of the Go loop with the reference's 16-worker per-task fan-out, without its per-pair NodeInfo rebuilds"}
+        if not args.cpu_sample_tasks:
+            # the oracle has just run the whole allocate action for the baseline: let it finish the cycle (backfill, untimed) and
+            # check the engine's bind set and evaluation count against it, so every headline line carries its own verification
+            o.backfill()
+            out["verified_bind_set_equals_oracle"] = bool(np.array_equal(binds, o.binds()))
+            out["verified_evals_equal_oracle"] = bool(o.evals == out["evals_per_step"])
         o.close()
-    if rank == 0 and args.verify:
+    elif rank == 0 and args.verify:
         import oracle
         o = oracle.Oracle(conf, snap, threads=min(16, os.cpu_count() or 1))
         o.run(actions)

@@ -1270,6 +1270,7 @@ struct ChunkPlan {
   KbRound r{};        // describes the expanded rows (score / maskw / keys of n rows)
   KbRound rs{};       // the per-shape launch
   uint32_t ns = 0;
+  bool direct = false;   // evaluate every task row itself (no per-shape rows, no expansion)
 };
 static ChunkPlan matrix_plan(kb_engine *e, uint32_t t0, uint32_t n, uint32_t fit_mode, uint32_t k) {
   ChunkPlan p;
@@ -1279,6 +1280,23 @@ static ChunkPlan matrix_plan(kb_engine *e, uint32_t t0, uint32_t n, uint32_t fit
   for (uint32_t i = 0; i < n; i++) e->h_rows[i] = t0 + i;
   if (e->h_mrows.size() < n) e->h_mrows.resize(n);
   p.ns = assign_shapes(e, n);
+  // Expansion streams every task row out of its shape's row: that pays while the shape rows stay cache-resident (a few dozen to
+  // a few hundred shapes).  When (nearly) every job has its own request the shape rows are a second matrix in HBM and the
+  // expansion doubles the traffic: then every row is evaluated directly (KB_K1_DIRECT=1/0 pins the choice for A/B runs).
+  {
+    static const char *pin = getenv("KB_K1_DIRECT");
+    p.direct = pin ? pin[0] == '1' : ((size_t)p.ns * e->dev.NP * 2 > (32u << 20) && (size_t)p.ns * 8 > n);
+  }
+  if (p.direct) {
+    // the tasks of a job are adjacent and share a shape: a row equal to its predecessor re-stores the predecessor's result
+    for (uint32_t i = 0; i < n; i++) e->h_same[i] = (i > 0 && e->h_slot[i] == e->h_slot[i - 1]) ? 1 : 0;
+    HIP_OK(hipMemcpyAsync(e->b_same.p, e->h_same.data(), n, hipMemcpyHostToDevice, e->stream));
+    p.r = make_round(e, 0, n, k ? k : 1, (int)fit_mode, false);
+    p.r.mrows = nullptr;
+    p.r.mrow_task0 = t0;
+    p.r.same_prev = e->b_same.as<uint8_t>();
+    return p;
+  }
   if (p.ns > e->xs_cap) {
     e->b_sscore.alloc(sizeof(uint16_t) * (size_t)p.ns * NP);
     e->b_smask.alloc(sizeof(uint32_t) * (size_t)p.ns * (NP / 32));
@@ -1297,6 +1315,12 @@ static ChunkPlan matrix_plan(kb_engine *e, uint32_t t0, uint32_t n, uint32_t fit
   return p;
 }
 static void matrix_launch(kb_engine *e, const ChunkPlan &p, uint32_t n, uint32_t k) {
+  if (p.direct) {
+    kb_launch_matrix(e->dev, p.r, e->stream);
+    kb_launch_affinity(e->dev, p.r, e->stream);
+    if (k) kb_launch_argmax(e->dev, p.r, e->stream);
+    return;
+  }
   kb_launch_matrix(e->dev, p.rs, e->stream);
   kb_launch_affinity(e->dev, p.rs, e->stream);
   kb_launch_expand(e->dev, p.rs.score, p.rs.maskw, e->b_xslot.as<uint32_t>(), n, p.r.score, p.r.maskw, e->stream);

@@ -26,10 +26,39 @@
 #include "kb_device.h"
 #include "kb_eval.hpp"
 
-// class_row: nullptr -> look the class pair up in the global bit table; otherwise the task class's row of the table
-// (bit nc), e.g. staged in LDS by the commit kernel so that no global load sits on its critical path.
-__device__ __forceinline__ uint32_t eval_pair(const KbDev &d, const TaskVals &t, const NodeVals &n, uint32_t node, int fit_mode,
-                                              const uint32_t *class_row = nullptr) {
+// K1's views of a task row and of a node: the four quantities the scorers divide are carried as doubles (exact below 2^53),
+// converted once per task row / once per node and thread, so that an evaluation is float64 arithmetic only (kb_eval.hpp:
+// score_core_f64 — about a third fewer instructions than the int64 form; this kernel is VALU-bound when task shapes are diverse).
+struct K1Task {
+  double init0, init1, nzc, nzm;
+  uint32_t cls, active, task, pad;
+  unsigned long long conf;   // host-port bits that conflict with this pod's ports (0: none)
+};
+struct K1Node {
+  double idle0, idle1, rel0, rel1, ac, am, nzc, nzm, inv_ac, inv_am;
+  uint32_t cls;
+  int slots;   // Allocatable.MaxTaskNum > len(pods)  (predicates.go:127 fails on <=)
+  int valid;   // node index < N
+  unsigned long long ports;
+};
+__device__ __forceinline__ K1Task k1_task(const KbDev &d, uint32_t t) {
+  const TaskVals v = load_task(d, t);
+  K1Task k;
+  k.init0 = v.init0; k.init1 = v.init1; k.nzc = (double)v.nzc; k.nzm = (double)v.nzm;
+  k.cls = v.cls; k.active = v.active; k.task = v.task; k.pad = 0; k.conf = v.conf;
+  return k;
+}
+__device__ __forceinline__ K1Node k1_node(const KbDev &d, uint32_t n) {
+  const NodeVals v = load_node(d, n);
+  K1Node k;
+  k.idle0 = v.idle0; k.idle1 = v.idle1; k.rel0 = v.rel0; k.rel1 = v.rel1;
+  k.ac = (double)v.ac; k.am = (double)v.am; k.nzc = (double)v.nzc; k.nzm = (double)v.nzm; k.inv_ac = v.inv_ac; k.inv_am = v.inv_am;
+  k.cls = v.cls; k.slots = v.slots; k.valid = v.valid; k.ports = v.ports;
+  return k;
+}
+
+// One (task,node) evaluation.  Returns 0 if infeasible, else 0x10000 | score.
+__device__ __forceinline__ uint32_t eval_pair(const KbDev &d, const K1Task &t, const K1Node &n, uint32_t node, int fit_mode) {
   if (!n.valid) return 0;
   bool ok = true;
   if (fit_mode) {   // allocate.go:81: !InitResreq.LessEqual(Idle) && !InitResreq.LessEqual(Releasing) -> fail
@@ -50,16 +79,14 @@ __device__ __forceinline__ uint32_t eval_pair(const KbDev &d, const TaskVals &t,
   }
   if (d.pred_enabled) {
     ok = ok && n.slots && ((n.ports & t.conf) == 0ull);   // pod count (predicates.go:127), PodFitsHostPorts (predicates.go:181-190)
-    if (class_row) {
-      ok = ok && ((class_row[n.cls >> 5] >> (n.cls & 31)) & 1u);
-    } else if (d.compat) {
+    if (d.compat) {
       uint32_t bit = t.cls * d.n_nc + n.cls;
       ok = ok && ((d.compat[bit >> 3] >> (bit & 7)) & 1);
     }
   }
   if (!ok) return 0;
   uint32_t score = 0;
-  if (d.score_enabled) score = score_core(t, n, d.wL, d.wM, d.wB);
+  if (d.score_enabled) score = score_core_f64(t.nzc, t.nzm, n.nzc, n.nzm, n.ac, n.am, n.inv_ac, n.inv_am, d.wL, d.wM, d.wB);
   return 0x10000u | (score & 0xFFFFu);
 }
 
@@ -94,7 +121,7 @@ __device__ __forceinline__ void gather_row(const KbDev &d, const KbRound &r, uin
 
 template <int NPT, int TR>
 __global__ void __launch_bounds__(256) k_matrix(KbDev d, KbRound r) {
-  __shared__ TaskVals srow[TR];
+  __shared__ K1Task srow[TR];
   __shared__ uint8_t ssame[TR];
   if (r.gather && blockIdx.y == gridDim.y - 1) {   // the extra block row of a single-GPU round: the window's row descriptors
     if (blockIdx.x == 0 && threadIdx.x == 0) reinterpret_cast<unsigned long long *>(r.result)[KB_OUT_STAMP0] = wall_clock64();
@@ -106,15 +133,15 @@ __global__ void __launch_bounds__(256) k_matrix(KbDev d, KbRound r) {
   if (threadIdx.x < nr) {
     uint32_t i = row0 + threadIdx.x;
     uint32_t t = r.mrows ? r.mrows[i] : r.mrow_task0 + i;
-    srow[threadIdx.x] = load_task(d, t);
+    srow[threadIdx.x] = k1_task(d, t);
     ssame[threadIdx.x] = r.same_prev ? r.same_prev[i] : 0;
   }
   __syncthreads();
   const uint32_t n0 = (blockIdx.x * 256 + threadIdx.x) * NPT;
   const uint32_t lane = threadIdx.x & 63;
-  NodeVals nv[NPT];
+  K1Node nv[NPT];
 #pragma unroll
-  for (int j = 0; j < NPT; j++) nv[j] = load_node(d, n0 + j);
+  for (int j = 0; j < NPT; j++) nv[j] = k1_node(d, n0 + j);
   uint32_t res[NPT];
 #pragma unroll
   for (int j = 0; j < NPT; j++) res[j] = 0;
@@ -122,23 +149,11 @@ __global__ void __launch_bounds__(256) k_matrix(KbDev d, KbRound r) {
   uint2 pk = make_uint2(0u, 0u);   // packed scores / mask word of the last evaluated row (re-stored for identical rows)
   uint32_t mw = 0;
   for (uint32_t rr = 0; rr < nr; rr++) {
-#ifdef KB_K1_OLDLOOP
-    const bool fresh = true;
-    const bool evalrow = !(ssame[rr] && rr > 0);
-    const TaskVals tv = srow[rr];
-    if (evalrow) {
-#else
     const bool fresh = !(ssame[rr] && rr > 0);
     if (fresh) {
-      const TaskVals tv = srow[rr];
-#endif
-#ifdef KB_K1_NOEVAL   // timing experiment: store path only
-#pragma unroll
-      for (int j = 0; j < NPT; j++) res[j] = 0x10000u | (tv.cls + (uint32_t)nv[j].nzc);
-#else
+      const K1Task tv = srow[rr];
 #pragma unroll
       for (int j = 0; j < NPT; j++) res[j] = eval_pair(d, tv, nv[j], n0 + j, r.fit_mode);
-#endif
     }
     const size_t row = row0 + rr;
     if (NPT == 4) {
@@ -153,16 +168,9 @@ __global__ void __launch_bounds__(256) k_matrix(KbDev d, KbRound r) {
         w |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)w, 0x141, 0xf, 0xf, false);   // row_half_mirror
         mw = w;
       }
-      // streaming stores: the matrix is written once and read by another kernel
-#ifdef KB_K1_NT
-      __builtin_nontemporal_store(((unsigned long long)pk.y << 32) | pk.x, reinterpret_cast<unsigned long long *>(r.score + row * d.NP + n0));
-      if ((lane & 7) == 0) __builtin_nontemporal_store(mw, &r.maskw[row * mstride + (n0 >> 5)]);
-#elif defined(KB_K1_NOSTORE)   // timing experiment: evaluation only
-      if (pk.x == 0x12345678u && mw == 0x9abcdefu) *reinterpret_cast<uint2 *>(r.score + row * d.NP + n0) = pk;
-#else
+      // the matrix is written once and read by another kernel
       *reinterpret_cast<uint2 *>(r.score + row * d.NP + n0) = pk;
       if ((lane & 7) == 0) r.maskw[row * mstride + (n0 >> 5)] = mw;
-#endif
     } else {
       r.score[row * d.NP + n0] = (uint16_t)(res[0] & 0xFFFFu);
       unsigned long long b = __ballot((res[0] >> 16) & 1u);   // one wave = 64 consecutive nodes = two mask words

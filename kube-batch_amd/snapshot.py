@@ -639,6 +639,8 @@ class SynthParams:
     scalar_job_frac: float = 0.30        # C4: jobs requesting 1-2 extended resources
     n_zones: int = 8
     zone_selector_frac: float = 0.10     # jobs pinned to one zone by nodeSelector (static predicate classes)
+    diverse_requests: bool = False       # stress variant: every job draws its OWN request (1 milli-cpu / 1 MiB steps), so the
+                                         # session holds about as many distinct task shapes as jobs instead of ~70
 
 
 def synth_config(idx: int, scale: float = 1.0) -> SynthParams:
@@ -705,6 +707,9 @@ def synth(p: SynthParams) -> SessionSnapshot:
     job_creation = (1_600_000_000 + np.arange(J, dtype=np.int64))      # strictly increasing seconds
     j_cpu = S(34).choice(J, np.array(p.task_cpu_milli, np.int64))
     j_mem = S(35).choice(J, np.array(p.task_mem_mib, np.int64)) * (1 << 20)
+    if p.diverse_requests:               # same ranges, log-uniform-ish, but practically never two jobs alike
+        j_cpu = (100 * np.exp2(S(34).uniform(J) * np.log2(80.0))).astype(np.int64)               # 100m .. 8000m
+        j_mem = (128 * np.exp2(S(35).uniform(J) * 8.0)).astype(np.int64) * (1 << 20)             # 128Mi .. 32Gi
     j_nomem = S(36).uniform(J) < p.no_mem_key_frac
     j_be = S(37).uniform(J) < p.best_effort_frac
     j_zone_sel = S(38).uniform(J) < p.zone_selector_frac

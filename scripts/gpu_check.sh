@@ -15,14 +15,16 @@ if [ "$WHAT" != "pytest" ]; then
     KB_K5_STATS=1 timeout 300 python bench.py --config $c --steps 3 --warmup 1 --verify --no-cpu-baseline > "$OUT/bench_c$c.json" 2> "$OUT/bench_c$c.err"; echo "bench c$c rc=$?"
     grep "kb K5" "$OUT/bench_c$c.err"
   done
+  KB_K5_STATS=1 timeout 300 python bench.py --config 3 --diverse --steps 3 --warmup 1 --verify --no-cpu-baseline > "$OUT/bench_c3_diverse.json" 2> "$OUT/bench_c3_diverse.err"; echo "bench c3 diverse rc=$?"
   python - "$OUT" <<'PY'
 import json, sys, os
-for f in ("bench_c3.json", "bench_c4.json"):
+for f in ("bench_c3.json", "bench_c4.json", "bench_c3_diverse.json"):
     p = os.path.join(sys.argv[1], f)
     try:
         d = json.loads(open(p).read().strip().splitlines()[-1])
         print(f, "ms/step", round(d["ms_per_step"], 2), "evals/s %.3g" % d["value"], "binds", d["binds"], "rounds", d["rounds_per_step"],
-              "dirty-won rows", d["row_fallbacks_per_step"], "verified", d.get("verified_bind_set_equals_oracle"), d["kernel_ms_per_step"])
+              "dirty-won rows", d["row_fallbacks_per_step"], "verified", d.get("verified_bind_set_equals_oracle"), d["kernel_ms_per_step"],
+              "K1 roofline frac", d["roofline"]["frac"], "avg ms", d["roofline"]["avg_launch_ms"])
     except Exception as e:
         print(f, "unreadable:", e)
 PY

@@ -1,0 +1,75 @@
+#!/usr/bin/env python
+"""Regenerates tests/golden/fullsize_digests.json: what the ORACLE decides on BASELINE configs 3 and 4 at their full size
+(100k tasks x 10k nodes; config 4 = 16 resource dimensions under the bin-packing weights BASELINE names: mostrequested 5,
+leastrequested 0, balancedresource 1).  tests/test_gpu_fullsize.py compares the engine with the live oracle AND with these
+digests, so full-size exactness is part of the driver's -m gpu record and an oracle that drifts between rounds is caught too.
+Not reference outputs (the reference is Go and cannot run here).  Takes about a minute:  python tests/golden/make_fullsize_golden.py
+"""
+import hashlib
+import importlib
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+
+BINPACK_CONF = """
+actions: "allocate, backfill"
+tiers:
+- plugins:
+  - name: priority
+  - name: gang
+- plugins:
+  - name: drf
+  - name: predicates
+  - name: proportion
+  - name: nodeorder
+    arguments:
+      leastrequested.weight: 0
+      mostrequested.weight: 5
+      balancedresource.weight: 1
+"""
+
+CASES = {  # name -> (config index, scheduler conf text or None for the default)
+    "config3_full": (3, None),
+    "config4_binpack_full": (4, BINPACK_CONF),
+}
+
+
+def case_inputs(kbm, name):
+    idx, conf_text = CASES[name]
+    conf = kbm.conf.load_scheduler_conf(conf_text) if conf_text else kbm.conf.load_scheduler_conf()
+    snap = kbm.snapshot.synth(kbm.snapshot.synth_config(idx, 1.0))
+    return conf, snap
+
+
+def digest_of(np, decisions, binds):
+    h = hashlib.sha256()
+    h.update(np.ascontiguousarray(decisions, dtype=np.uint32).tobytes())
+    h.update(np.ascontiguousarray(binds, dtype=np.uint32).tobytes())
+    return h.hexdigest()
+
+
+def main():
+    import numpy as np
+    kbm = importlib.import_module("kube-batch_amd")
+    import oracle
+    oracle.build()
+    out = {}
+    for name in CASES:
+        conf, snap = case_inputs(kbm, name)
+        o = oracle.Oracle(conf, snap, threads=min(16, os.cpu_count() or 1))
+        o.run(["allocate", "backfill"])
+        out[name] = {"tasks": int(snap.n_tasks), "nodes": int(snap.n_nodes), "n_res": int(snap.n_res),
+                     "decisions": int(o.decisions().shape[0]), "binds": int((o.binds() != kbm.abi.KB_NONE).sum()),
+                     "evals": int(o.evals), "sha256": digest_of(np, o.decisions(), o.binds())}
+        print(name, out[name])
+        o.close()
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "fullsize_digests.json"), "w") as f:
+        json.dump(out, f, indent=1, sort_keys=True)
+        f.write("\n")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,48 @@
+"""BASELINE configs 3 and 4 at their FULL size (100k tasks x 10k nodes), engine vs oracle, in the regular -m gpu suite:
+ordered decisions, bind set and evaluation count must equal the live oracle's, and the oracle's must equal the digests committed
+under tests/golden/fullsize_digests.json (tests/golden/make_fullsize_golden.py).  Config 4 runs under the bin-packing weights
+BASELINE names (mostrequested 5, leastrequested 0, balancedresource 1), where the commit kernels' dirty-winner paths carry most
+rows.  The oracle runs once per configuration (about ten seconds on the box's host cores) and is shared by both commit kernels."""
+import importlib
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+import make_fullsize_golden as mfg  # noqa: E402
+
+kbm = importlib.import_module("kube-batch_amd")
+engine = importlib.import_module("kube-batch_amd.engine")
+
+pytestmark = [pytest.mark.gpu]
+_oracle_cache = {}
+
+
+def _oracle_result(oracle_mod, name):
+    if name not in _oracle_cache:
+        conf, snap = mfg.case_inputs(kbm, name)
+        o = oracle_mod.Oracle(conf, snap, threads=min(16, os.cpu_count() or 1))
+        o.run(["allocate", "backfill"])
+        _oracle_cache[name] = (conf, snap, o.decisions().copy(), o.binds().copy(), int(o.evals))
+        o.close()
+    return _oracle_cache[name]
+
+
+@pytest.mark.parametrize("name", sorted(mfg.CASES))
+def test_full_size_cycle_equals_oracle_and_golden_digest(oracle_mod, name):
+    conf, snap, odec, obinds, oevals = _oracle_result(oracle_mod, name)
+    golden = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "fullsize_digests.json")))[name]
+    assert (snap.n_tasks, snap.n_nodes, snap.n_res) == (golden["tasks"], golden["nodes"], golden["n_res"])
+    assert mfg.digest_of(np, odec, obinds) == golden["sha256"], "the oracle no longer reproduces its committed full-size digest"
+    e = engine.Engine(conf)
+    e.load(snap)
+    dec = e.run(["allocate", "backfill"])
+    assert dec.shape == odec.shape
+    assert np.array_equal(dec, odec), f"first divergence at decision {int(np.argmax((dec != odec).any(axis=1)))}"
+    assert np.array_equal(e.binds(), obinds)
+    assert e.stats()["evals"] == oevals == golden["evals"]
+    assert mfg.digest_of(np, dec, e.binds()) == golden["sha256"]
+    e.close()
