@@ -229,6 +229,8 @@ def main():
         "evals_per_s_including_session_load": None if load_ms is None else evals / args.steps / (elapsed / args.steps + load_ms * 1e-3),
     }
 
+    if args.config == 5 and not args.cpu_sample_tasks:
+        args.cpu_sample_tasks = 2000           # 1M x 50k: the faithful loop needs minutes; a bounded sample, as section 4 of the task allows
     if rank == 0 and world == 1 and not args.no_cpu_baseline:      # the CPU baseline is reported at N=1 only
         import oracle
         oracle.build()
@@ -251,9 +253,12 @@ def main():
             out["verified_bind_set_equals_oracle"] = bool(np.array_equal(binds, o.binds()))
             out["verified_evals_equal_oracle"] = bool(o.evals == out["evals_per_step"])
         o.close()
-    elif rank == 0 and args.verify:
+    if rank == 0 and args.verify and "verified_bind_set_equals_oracle" not in out:
         import oracle
         o = oracle.Oracle(conf, snap, threads=min(16, os.cpu_count() or 1))
+        if snap.n_tasks * snap.n_nodes > 4_000_000_000:   # config 5: the oracle's incremental mode (tests/test_oracle_fast_cpu.py)
+            o.set_fast(True)
+            out["verified_with"] = "oracle fast mode"
         o.run(actions)
         out["verified_bind_set_equals_oracle"] = bool(np.array_equal(binds, o.binds()))
         out["verified_evals_equal_oracle"] = bool(o.evals == out["evals_per_step"])

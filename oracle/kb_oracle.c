@@ -420,6 +420,9 @@ typedef struct kbo_session {
   int panic;
   int threads;
   uint64_t task_limit;  /* cpu_baseline sample: stop the allocate loop after this many popped tasks (0 = none) */
+  /* fast mode (kbo_set_fast): per task shape a cached row of keys over all nodes + a max-tree, repaired one node at a time */
+  int fast;
+  struct fast_t *fx;
 } kbo_session;
 
 static int find_plugin_enabled(const kbo_session *s, uint32_t plugin, uint32_t en_bit) {
@@ -933,14 +936,122 @@ kbo_session *kbo_open(const kb_config *cfg, const kb_snapshot *sn, int threads) 
   return s;
 }
 
+static void fast_free(kbo_session *s);
 void kbo_close(kbo_session *s) {
   if (!s) return;
   for (uint32_t j = 0; j < s->J; j++) heap_free(&s->jobs[j].tasks);
   for (uint32_t q = 0; q < s->Q; q++) heap_free(&s->queues[q].jobs);
   free(s->nodes); free(s->tasks); free(s->jobs); free(s->queues); free(s->compat); free(s->affinity); free(s->evictions);
+  fast_free(s);
   free(s->tier_begin); free(s->plugins); free(s->decisions); free(s->bind_node); free(s->bind_order);
   free(s);
 }
+
+/* ================================================================================================
+ * FAST MODE of the allocate loop: the same decisions as the faithful loop above, without
+ * re-evaluating N nodes per popped task.  Test infrastructure like the rest of this file: it exists to produce golden bind
+ * sets for snapshots the faithful mode needs minutes for (config 5: 1M x 50k), and is itself checked against the faithful mode
+ * (tests/test_oracle_fast_cpu.py: identical decisions on synthetic and adversarial snapshots, and on the committed full-size
+ * digests of configs 3 and 4).
+ *   - tasks with equal (InitResreq, non-zero request, static class, host ports) have identical rows: one cached row per SHAPE,
+ *     key[n] = feasible ? score + 1 : 0, built with the faithful per-pair functions the first time the shape is popped;
+ *   - a placement changes ONE node: its entry is re-evaluated in every cached row (again with the faithful functions);
+ *   - SelectBestNode's canonical choice (highest score, lowest index) is the root of a max-tree over the row whose combine
+ *     step prefers the left child on ties.
+ * Shapes whose class carries preferred node-affinity terms are normalised over the current feasible set: they take the
+ * faithful path.  `evals` still counts N per popped task (what the reference does).
+ * ============================================================================================== */
+typedef struct fast_shape {
+  uint32_t rep;       /* a task with this shape */
+  double *key;        /* [N] */
+  uint32_t *tree;     /* [2 * P] best node of each subtree (KB_NONE: none feasible); leaves at P + n */
+} fast_shape;
+typedef struct fast_t {
+  uint32_t P;               /* leaves of the max-tree: N rounded up to a power of two */
+  uint32_t n_shapes, cap;
+  fast_shape *shapes;
+  uint32_t *task_shape;     /* [T] shape id, KB_NONE until the task is first popped */
+  uint32_t *bucket_head;    /* hash -> first shape, chained through next */
+  uint32_t *next;
+  uint32_t n_buckets;
+} fast_t;
+
+static int fast_same_shape(const kbo_session *s, const o_task *a, const o_task *b) {
+  if (a->cls != b->cls || a->nz_cpu != b->nz_cpu || a->nz_mem != b->nz_mem || a->port_want != b->port_want || a->port_conflict != b->port_conflict) return 0;
+  if (a->init_resreq.mask != b->init_resreq.mask) return 0;
+  for (int d = 0; d < s->R; d++) if (a->init_resreq.v[d] != b->init_resreq.v[d]) return 0;
+  return 1;
+}
+static uint64_t fast_hash(const kbo_session *s, const o_task *t) {
+  uint64_t h = 0x9E3779B97F4A7C15ull ^ t->cls;
+  for (int d = 0; d < s->R; d++) { uint64_t w; memcpy(&w, &t->init_resreq.v[d], 8); h = (h ^ w) * 0xFF51AFD7ED558CCDull; h ^= h >> 32; }
+  h = (h ^ (uint64_t)t->nz_cpu) * 0xFF51AFD7ED558CCDull; h ^= h >> 29;
+  h = (h ^ (uint64_t)t->nz_mem ^ t->port_conflict ^ (t->port_want << 1) ^ t->init_resreq.mask) * 0xC4CEB9FE1A85EC53ull; h ^= h >> 32;
+  return h;
+}
+static inline uint32_t fast_better(const double *key, uint32_t l, uint32_t r) {   /* left wins ties: lowest index among equal scores */
+  if (l == KB_NONE) return r;
+  if (r == KB_NONE) return l;
+  return key[r] > key[l] ? r : l;
+}
+static double fast_key(const kbo_session *s, const o_task *t, const o_node *n) {
+  return allocate_predicate(s, t, n) ? node_score(s, t, n) + 1.0 : 0.0;
+}
+static void fast_free(kbo_session *s) {
+  fast_t *f = s->fx;
+  if (!f) return;
+  for (uint32_t i = 0; i < f->n_shapes; i++) { free(f->shapes[i].key); free(f->shapes[i].tree); }
+  free(f->shapes); free(f->task_shape); free(f->bucket_head); free(f->next); free(f);
+  s->fx = NULL;
+}
+static uint32_t fast_shape_of(kbo_session *s, uint32_t t) {
+  fast_t *f = s->fx;
+  if (!f) {
+    f = (fast_t *)calloc(1, sizeof(fast_t));
+    f->P = 1; while (f->P < (s->N ? s->N : 1)) f->P <<= 1;
+    f->task_shape = (uint32_t *)malloc(sizeof(uint32_t) * (s->T ? s->T : 1));
+    for (uint32_t i = 0; i < s->T; i++) f->task_shape[i] = KB_NONE;
+    f->n_buckets = 1u << 16;
+    f->bucket_head = (uint32_t *)malloc(sizeof(uint32_t) * f->n_buckets);
+    for (uint32_t i = 0; i < f->n_buckets; i++) f->bucket_head[i] = KB_NONE;
+    s->fx = f;
+  }
+  if (f->task_shape[t] != KB_NONE) return f->task_shape[t];
+  const o_task *tk = &s->tasks[t];
+  const uint32_t b = (uint32_t)(fast_hash(s, tk) & (f->n_buckets - 1));
+  for (uint32_t i = f->bucket_head[b]; i != KB_NONE; i = f->next[i])
+    if (fast_same_shape(s, tk, &s->tasks[f->shapes[i].rep])) return f->task_shape[t] = i;
+  if (f->n_shapes == f->cap) {
+    f->cap = f->cap ? f->cap * 2 : 64;
+    f->shapes = (fast_shape *)realloc(f->shapes, sizeof(fast_shape) * f->cap);
+    f->next = (uint32_t *)realloc(f->next, sizeof(uint32_t) * f->cap);
+  }
+  const uint32_t id = f->n_shapes++;
+  fast_shape *sh = &f->shapes[id];
+  sh->rep = t;
+  sh->key = (double *)malloc(sizeof(double) * (s->N ? s->N : 1));
+  sh->tree = (uint32_t *)malloc(sizeof(uint32_t) * 2 * f->P);
+  for (uint32_t n = 0; n < s->N; n++) sh->key[n] = fast_key(s, tk, &s->nodes[n]);
+  for (uint32_t n = 0; n < f->P; n++) sh->tree[f->P + n] = (n < s->N && sh->key[n] > 0.0) ? n : KB_NONE;
+  for (uint32_t i = f->P - 1; i >= 1; i--) sh->tree[i] = fast_better(sh->key, sh->tree[2 * i], sh->tree[2 * i + 1]);
+  f->next[id] = f->bucket_head[b];
+  f->bucket_head[b] = id;
+  return f->task_shape[t] = id;
+}
+/* node n changed (AddTask): repair its entry in every cached row */
+static void fast_node_changed(kbo_session *s, uint32_t n) {
+  fast_t *f = s->fx;
+  if (!f) return;
+  for (uint32_t i = 0; i < f->n_shapes; i++) {
+    fast_shape *sh = &f->shapes[i];
+    sh->key[n] = fast_key(s, &s->tasks[sh->rep], &s->nodes[n]);
+    uint32_t p = f->P + n;
+    sh->tree[p] = sh->key[n] > 0.0 ? n : KB_NONE;
+    for (p >>= 1; p >= 1; p >>= 1) sh->tree[p] = fast_better(sh->key, sh->tree[2 * p], sh->tree[2 * p + 1]);
+  }
+}
+void kbo_set_fast(kbo_session *s, int on) { s->fast = on ? 1 : 0; }
+uint32_t kbo_fast_shapes(const kbo_session *s) { return s->fx ? s->fx->n_shapes : 0; }
 
 /* actions/allocate/allocate.go:43-194 */
 int kbo_allocate(kbo_session *s) {
@@ -980,15 +1091,22 @@ int kbo_allocate(kbo_session *s) {
       if (s->task_limit && s->popped >= s->task_limit) goto done;   /* bounded timing sample, not part of the algorithm */
       uint32_t t = heap_pop(&job->tasks);
       o_task *tk = &s->tasks[t];
-      eval_all_nodes(s, tk, 1, feas, score);                /* PredicateNodes + PrioritizeNodes */
+      int best = -1;                                        /* SelectBestNode, canonical first max */
+      const int fast_row = s->fast && !(s->affinity && s->nodeorder_enabled);   /* NormalizeReduce rows stay faithful */
+      if (fast_row) {
+        const uint32_t sh = fast_shape_of(s, t);
+        const uint32_t root = s->N ? s->fx->shapes[sh].tree[1] : KB_NONE;
+        best = root == KB_NONE ? -1 : (int)root;
+      } else {
+        eval_all_nodes(s, tk, 1, feas, score);              /* PredicateNodes + PrioritizeNodes */
+        double maxScore = 0;
+        for (uint32_t n = 0; n < s->N; n++) {
+          if (!feas[n]) continue;
+          if (best < 0 || score[n] > maxScore) { best = (int)n; maxScore = score[n]; }
+        }
+      }
       s->evals += s->N;
       s->popped++;
-      int best = -1;                                        /* SelectBestNode, canonical first max */
-      double maxScore = 0;
-      for (uint32_t n = 0; n < s->N; n++) {
-        if (!feas[n]) continue;
-        if (best < 0 || score[n] > maxScore) { best = (int)n; maxScore = score[n]; }
-      }
       if (best < 0) break;                                  /* allocate.go:144-148 */
       o_node *node = &s->nodes[best];
       if (res_less_equal(&tk->init_resreq, &node->idle, s->R)) {          /* allocate.go:160-166 */
@@ -1000,6 +1118,7 @@ int kbo_allocate(kbo_session *s) {
           if (e == KBO_PANIC) { rc = KBO_PANIC; goto done; }
         }
       }
+      if (s->fast) fast_node_changed(s, (uint32_t)best);
       if (ssn_job_ready(s, job) && job->tasks.n > 0) {      /* allocate.go:185-188 */
         heap_push(&queue->jobs, j);
         break;
@@ -1010,6 +1129,7 @@ int kbo_allocate(kbo_session *s) {
 done:
   free(feas); free(score);
   heap_free(&queues);
+  fast_free(s);   /* the cached rows are valid inside one action only (other actions change nodes behind their back) */
   return rc;
 }
 

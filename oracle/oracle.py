@@ -61,6 +61,7 @@ def lib():
         L.kbo_res_multi.argtypes = [C.POINTER(OracleRes), C.c_double]
         L.kbo_scorers.argtypes = [C.c_int64] * 4 + [C.POINTER(C.c_int64)] * 3
         L.kbo_set_task_limit.argtypes = [C.c_void_p, C.c_uint64]
+        L.kbo_set_fast.argtypes = [C.c_void_p, C.c_int]
         L.kbo_job_valid_num.argtypes = [C.c_void_p, C.c_uint32]
         L.kbo_job_ready_num.argtypes = [C.c_void_p, C.c_uint32]
         _LIB = L
@@ -95,6 +96,11 @@ class Oracle:
             self.close()
         except Exception:
             pass
+
+    def set_fast(self, on=True):
+        """Incremental mode of the allocate loop (per-shape cached rows + one-node repairs): same decisions, for snapshots the
+        faithful mode needs minutes for.  Checked against the faithful mode in tests/test_oracle_fast_cpu.py."""
+        self.L.kbo_set_fast(self.h, 1 if on else 0)
 
     def set_task_limit(self, n):
         """Bounded cpu_baseline sample: the allocate loop stops after n popped tasks."""

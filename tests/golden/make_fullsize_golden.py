@@ -34,7 +34,11 @@ tiers:
 CASES = {  # name -> (config index, scheduler conf text or None for the default)
     "config3_full": (3, None),
     "config4_binpack_full": (4, BINPACK_CONF),
+    "config5_full": (5, None),     # 1M tasks x 50k nodes, allocate + backfill
 }
+# config 5 takes the faithful loop several minutes: its digest comes from the oracle's fast mode (kbo_set_fast), which
+# tests/test_oracle_fast_cpu.py holds to the faithful mode on every smaller snapshot and on the two full-size digests above
+FAST = {"config5_full"}
 
 
 def case_inputs(kbm, name):
@@ -60,10 +64,13 @@ def main():
     for name in CASES:
         conf, snap = case_inputs(kbm, name)
         o = oracle.Oracle(conf, snap, threads=min(16, os.cpu_count() or 1))
+        if name in FAST:
+            o.set_fast(True)
         o.run(["allocate", "backfill"])
         out[name] = {"tasks": int(snap.n_tasks), "nodes": int(snap.n_nodes), "n_res": int(snap.n_res),
                      "decisions": int(o.decisions().shape[0]), "binds": int((o.binds() != kbm.abi.KB_NONE).sum()),
-                     "evals": int(o.evals), "sha256": digest_of(np, o.decisions(), o.binds())}
+                     "evals": int(o.evals), "sha256": digest_of(np, o.decisions(), o.binds()),
+                     "oracle_mode": "fast" if name in FAST else "faithful"}
         print(name, out[name])
         o.close()
     with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "fullsize_digests.json"), "w") as f:

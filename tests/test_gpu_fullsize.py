@@ -1,4 +1,4 @@
-"""BASELINE configs 3 and 4 at their FULL size (100k tasks x 10k nodes), engine vs oracle, in the regular -m gpu suite:
+"""BASELINE configs 3, 4 (100k tasks x 10k nodes) and 5 (1M x 50k, allocate + backfill) at FULL size, engine vs oracle, in the regular -m gpu suite:
 ordered decisions, bind set and evaluation count must equal the live oracle's, and the oracle's must equal the digests committed
 under tests/golden/fullsize_digests.json (tests/golden/make_fullsize_golden.py).  Config 4 runs under the bin-packing weights
 BASELINE names (mostrequested 5, leastrequested 0, balancedresource 1), where the commit kernels' dirty-winner paths carry most
@@ -25,6 +25,8 @@ def _oracle_result(oracle_mod, name):
     if name not in _oracle_cache:
         conf, snap = mfg.case_inputs(kbm, name)
         o = oracle_mod.Oracle(conf, snap, threads=min(16, os.cpu_count() or 1))
+        if name in mfg.FAST:      # 1M x 50k: the oracle's incremental mode (about a minute); see make_fullsize_golden.py
+            o.set_fast(True)
         o.run(["allocate", "backfill"])
         _oracle_cache[name] = (conf, snap, o.decisions().copy(), o.binds().copy(), int(o.evals))
         o.close()
