@@ -27,6 +27,11 @@
  *       (pkg/scheduler/framework/session.go:194-288).
  *   kb_run_backfill
  *       backfillAction.Execute (pkg/scheduler/actions/backfill/backfill.go:40-71).
+ *   kb_run_preempt
+ *       preemptAction.Execute (pkg/scheduler/actions/preempt/preempt.go:45-168) with preempt() (:171-254: PredicateNodes with
+ *       the plugin predicates only, PrioritizeNodes, util.SortNodes scheduler_helper.go:174-185, ssn.Preemptable
+ *       framework/session_plugins.go:122-162, victims lowest TaskOrderFn first) and framework.Statement
+ *       (framework/statement.go:36-220: Evict / Pipeline / Commit / Discard).
  *   kb_eval_matrix
  *       the per-(task,node) predicate closure (allocate.go:73-87), the predicates plugin
  *       (plugins/predicates/predicates.go:123-265) and the nodeorder scorers
@@ -57,7 +62,7 @@
 extern "C" {
 #endif
 
-#define KB_ABI_VERSION 4u
+#define KB_ABI_VERSION 5u
 #define KB_MAX_RES 32u          /* resource dimensions: 0 = cpu (milli), 1 = memory (bytes), 2.. = scalar resources (milli) */
 #define KB_NONE 0xFFFFFFFFu
 
@@ -197,8 +202,7 @@ typedef struct kb_snapshot {
   const uint64_t *task_port_conflict;  /* [T] */
 
   /* conformance plugin (plugins/conformance/conformance.go:44-58): 1 = the pod may not be evicted (kube-system namespace or a
-     system-cluster-critical / system-node-critical priority class).  Read by preempt only (not an engine action yet: the
-     oracle restates it); NULL => no pod is protected. */
+     system-cluster-critical / system-node-critical priority class).  Read by kb_run_preempt; NULL => no pod is protected. */
   const uint8_t  *task_evict_protected; /* [T] */
 } kb_snapshot;
 
@@ -209,6 +213,18 @@ typedef struct kb_decision {
   uint32_t kind;    /* 0 = ssn.Allocate, 1 = ssn.Pipeline */
   uint32_t round;   /* device round that produced it (diagnostic) */
 } kb_decision;
+
+/* one entry of the preempt action's journal: what the reference does through framework.Statement, in order.  The Go action
+   replays it: a new ssn.Statement() whenever `stmt` changes, stmt.Evict(node.Tasks[...].Clone(), "preempt") / stmt.Pipeline(task,
+   node) per entry, stmt.Commit() / stmt.Discard() at the markers (a discarded statement is replayed too: its Pipeline leaves the
+   sticky NodeName behind, framework/statement.go:155-190 + api/node_info.go:217-243). */
+enum { KB_OP_EVICT = 0, KB_OP_PIPELINE = 1, KB_OP_COMMIT = 2, KB_OP_DISCARD = 3 };
+typedef struct kb_stmt_op {
+  uint32_t op;      /* KB_OP_* */
+  uint32_t task;    /* KB_NONE for the markers */
+  uint32_t node;    /* EVICT: the node the victim runs on; PIPELINE: the node the preemptor waits for */
+  uint32_t stmt;    /* statement number inside the action (1-based) */
+} kb_stmt_op;
 
 typedef struct kb_stats {
   uint64_t evals;             /* (task,node) evaluations the reference algorithm performs for the work done so far: sum over popped tasks of N */
@@ -241,6 +257,12 @@ int  kb_session_reset(kb_engine *e);
 
 int  kb_run_allocate(kb_engine *e, kb_decision *out, uint64_t cap, uint64_t *n_out);
 int  kb_run_backfill(kb_engine *e, kb_decision *out, uint64_t cap, uint64_t *n_out);
+/* the preempt action on the session's current state; journal entries in order (KB_E_CAPACITY: *n_out = required count).
+   KB_E_UNSUPPORTED: sessions with preferred node-affinity terms (NormalizeReduce over a feasible set the repairs would change),
+   and states in which the reference itself would panic / abort (Resource.Sub underflow, NodeInfo.UpdateTask). */
+int  kb_run_preempt(kb_engine *e, kb_stmt_op *out, uint64_t cap, uint64_t *n_out);
+/* tasks the committed statements handed to cache.Evict so far, in that order */
+int  kb_get_evictions(kb_engine *e, uint32_t *out, uint64_t cap, uint64_t *n_out);
 
 /* rows [t0,t1) of the task x node matrix against the session's current node state.
    mask_bits: (t1-t0) rows of ceil(N/8) bytes, bit (n & 7) of byte n >> 3; score: (t1-t0) x N uint16.

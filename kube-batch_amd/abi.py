@@ -5,7 +5,7 @@ Only plain C types cross the boundary; the same structs are what the Go shim fil
 """
 import ctypes as C
 
-KB_ABI_VERSION = 4
+KB_ABI_VERSION = 5
 KB_MAX_RES = 32
 KB_NONE = 0xFFFFFFFF
 
@@ -40,9 +40,16 @@ EN_ALL = 0x1FF
 
 FLAG_SYNC_ROUNDS = 1
 
+# kb_stmt_op.op: the preempt action's journal (framework/statement.go)
+OP_EVICT, OP_PIPELINE, OP_COMMIT, OP_DISCARD = range(4)
+
 
 class PluginOption(C.Structure):
     _fields_ = [("plugin", C.c_uint32), ("enabled", C.c_uint32), ("args", C.c_int32 * 8), ("args_set", C.c_uint32)]
+
+
+class StmtOp(C.Structure):
+    _fields_ = [("op", C.c_uint32), ("task", C.c_uint32), ("node", C.c_uint32), ("stmt", C.c_uint32)]
 
 
 class Config(C.Structure):

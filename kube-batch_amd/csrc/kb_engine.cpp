@@ -21,6 +21,7 @@
 #include "../../include/kb_engine.h"
 #include "kb_device.h"
 #include "kb_host.hpp"
+#include "kb_preempt.hpp"
 
 using namespace kb;
 
@@ -165,6 +166,7 @@ struct kb_engine {
   uint32_t *h_result = nullptr;   // the header words of h_out
   std::vector<Timer> ev;          // event pool for per-launch timing
   std::vector<kb_decision> decisions_all;   // decisions of the last multi-GPU round sequence
+  std::vector<uint32_t> evictions;          // committed evictions of the session's preempt actions, in cache.Evict order
 
   // multi-GPU round state (kb_round_*), defined below
   struct MgState *mg = nullptr;
@@ -184,8 +186,12 @@ Policy compile_policy(const kb_config *cfg) {
   Policy p;
   if (!cfg->tier_begin && cfg->n_tiers) throw EngineError(KB_E_INVALID, "tier_begin is NULL");
   for (uint32_t t = 0; t < cfg->n_tiers; t++) {
+    p.preempt_tiers.emplace_back();
     for (uint32_t i = cfg->tier_begin[t]; i < cfg->tier_begin[t + 1]; i++) {
       const kb_plugin_option &o = cfg->plugins[i];
+      // plugins that register a PreemptableFn: conformance.go:60, gang.go:93, priority.go:100, drf.go:111
+      if ((o.enabled & KB_EN_PREEMPTABLE) && (o.plugin == KB_PLUGIN_CONFORMANCE || o.plugin == KB_PLUGIN_GANG || o.plugin == KB_PLUGIN_PRIORITY || o.plugin == KB_PLUGIN_DRF))
+        p.preempt_tiers.back().push_back((uint8_t)o.plugin);
       switch (o.plugin) {
         case KB_PLUGIN_PRIORITY:
           if (o.enabled & KB_EN_JOB_ORDER) p.job_chain.push_back(KB_PLUGIN_PRIORITY);
@@ -195,6 +201,7 @@ Policy compile_policy(const kb_config *cfg) {
           p.has_gang = true;
           if (o.enabled & KB_EN_JOB_ORDER) p.job_chain.push_back(KB_PLUGIN_GANG);
           if (o.enabled & KB_EN_JOB_READY) p.gang_job_ready = true;
+          if (o.enabled & KB_EN_JOB_PIPELINED) p.gang_job_pipelined = true;
           break;
         case KB_PLUGIN_CONFORMANCE:   // registers evict filters only (conformance.go:41-63)
           break;
@@ -891,6 +898,23 @@ int kb_session_load(kb_engine *e, const kb_snapshot *sn) {
       for (uint32_t t = hs.job_begin[j]; t < hs.job_begin[j + 1]; t++)
         if (hs.t_job[t] != j) throw EngineError(KB_E_INVALID, "tasks must be grouped by job in canonical order");
     }
+    hs.t_nzc.assign(sn->task_nz_cpu, sn->task_nz_cpu + T);
+    hs.t_nzm.assign(sn->task_nz_mem, sn->task_nz_mem + T);
+    if (sn->task_port_want || sn->task_port_conflict) {
+      hs.t_want.assign(T, 0); hs.t_conf.assign(T, 0);
+      for (uint32_t t = 0; t < T; t++) { if (sn->task_port_want) hs.t_want[t] = sn->task_port_want[t]; if (sn->task_port_conflict) hs.t_conf[t] = sn->task_port_conflict[t]; }
+    }
+    if (sn->task_evict_protected) hs.t_protected.assign(sn->task_evict_protected, sn->task_evict_protected + T);
+    hs.n_ac.assign(sn->node_alloc_cpu, sn->node_alloc_cpu + N);
+    hs.n_am.assign(sn->node_alloc_mem, sn->node_alloc_mem + N);
+    hs.n_maxpods.assign(sn->node_max_pods, sn->node_max_pods + N);
+    hs.n_cls.assign(N, 0);
+    if (sn->node_class) hs.n_cls.assign(sn->node_class, sn->node_class + N);
+    hs.n_idle_mask.assign(N, 0);
+    if (sn->node_scalar_mask) hs.n_idle_mask.assign(sn->node_scalar_mask, sn->node_scalar_mask + N);
+    hs.n_tc = sn->n_task_classes; hs.n_nc = sn->n_node_classes ? sn->n_node_classes : 1;
+    if (sn->class_compat) hs.compat.assign(sn->class_compat, sn->class_compat + ((size_t)sn->n_task_classes * sn->n_node_classes + 7) / 8);
+    e->evictions.clear();
     std::vector<uint32_t> t_active(T, 3u);
     hs.t_res_empty.assign(T, 0);
     hs.t_init_empty.assign(T, 0);
@@ -1148,6 +1172,7 @@ int kb_session_load(kb_engine *e, const kb_snapshot *sn) {
       if (any && e->pol.wNA != 0) {
         if (e->pol.wNA < 0 || 10 * (e->pol.wL + e->pol.wM + e->pol.wB + e->pol.wNA) > 65535)
           throw EngineError(KB_E_UNSUPPORTED, "nodeorder weights exceed the 16-bit score range");
+        hs.has_affinity = true;
         upload(e->b_aff, sn->class_affinity, na, s);
         upload(e->b_affcls, has.data(), has.size(), s);
         d.aff = e->b_aff.as<int32_t>();
@@ -1228,6 +1253,7 @@ int kb_session_reset(kb_engine *e) {
     mg_free(e->mg);
     e->mg = nullptr;
     std::fill(e->hs.queue_share_live.begin(), e->hs.queue_share_live.end(), e->hs.queue_share_at_open);
+    e->evictions.clear();
     double keep = e->stats.reduce_ms;
     run_finalize(e);
     e->stats.reduce_ms = keep;
@@ -1238,6 +1264,13 @@ static int run_action(kb_engine *e, uint32_t action, kb_decision *out, uint64_t 
   if (!e) return KB_E_INVALID;
   return guarded(e, [&]() {
     if (!e->loaded) throw EngineError(KB_E_STATE, "kb_session_load must precede kb_run_*");
+    // A Pending task that still carries a NodeName was un-pipelined by a discarded preempt statement (NodeInfo.RemoveTask never
+    // clears it, api/node_info.go:217-243): the reference's AddTask then refuses every other node AFTER ssn.Allocate has flipped
+    // the status (session.go:243 vs :255).  Not modelled: the stock action takes such a cycle (it cannot arise under the stock
+    // action order, where preempt runs last).
+    for (uint32_t t = 0; t < e->hs.T; t++)
+      if (e->hs.t_status[t] == KB_TASK_PENDING && e->hs.t_node[t] != KB_NONE)
+        throw EngineError(KB_E_UNSUPPORTED, "a Pending task carries a stale NodeName (un-pipelined by a discarded preempt statement)");
     ActionRun run;
     run.begin(e, action);
     uint32_t n = run.plan(e);
@@ -1263,6 +1296,144 @@ static int run_action(kb_engine *e, uint32_t action, kb_decision *out, uint64_t 
 
 int kb_run_allocate(kb_engine *e, kb_decision *out, uint64_t cap, uint64_t *n_out) { return run_action(e, 0, out, cap, n_out); }
 int kb_run_backfill(kb_engine *e, kb_decision *out, uint64_t cap, uint64_t *n_out) { return run_action(e, 1, out, cap, n_out); }
+
+// ---- preempt (kb_preempt.hpp): statements and victims on the host, PredicateNodes + PrioritizeNodes + SortNodes on the device ----
+namespace {
+// node state of the given nodes: host mirror -> device (after Pipelines / evictions changed it)
+void upload_live_nodes(kb_engine *e, const LiveNodes &ln, const std::vector<uint32_t> &nodes) {
+  const int R = e->hs.R;
+  const uint32_t NP = e->dev.NP;
+  for (uint32_t n : nodes) {
+    for (int d = 0; d < R; d++) {
+      const double vi = ln.idle[n].get(d), vr = ln.rel[n].get(d);
+      HIP_OK(hipMemcpyAsync(e->b_idle.as<double>() + (size_t)d * NP + n, &vi, sizeof(double), hipMemcpyHostToDevice, e->stream));
+      HIP_OK(hipMemcpyAsync(e->b_rel.as<double>() + (size_t)d * NP + n, &vr, sizeof(double), hipMemcpyHostToDevice, e->stream));
+    }
+    const long long c = ln.nzc[n], m = ln.nzm[n];
+    const int pc = ln.podcnt[n];
+    const uint32_t nm = (ln.idle[n].mask & 0x3FFFFFFFu) | (ln.rel[n].mask ? 0x80000000u : 0u);
+    HIP_OK(hipMemcpyAsync(e->b_nzc.as<long long>() + n, &c, sizeof(c), hipMemcpyHostToDevice, e->stream));
+    HIP_OK(hipMemcpyAsync(e->b_nzm.as<long long>() + n, &m, sizeof(m), hipMemcpyHostToDevice, e->stream));
+    HIP_OK(hipMemcpyAsync(e->b_podcnt.as<int>() + n, &pc, sizeof(pc), hipMemcpyHostToDevice, e->stream));
+    HIP_OK(hipMemcpyAsync(e->b_nmask.as<uint32_t>() + n, &nm, sizeof(nm), hipMemcpyHostToDevice, e->stream));
+    if (e->dev.ports) { const unsigned long long p = ln.ports[n]; HIP_OK(hipMemcpyAsync(e->b_ports.as<unsigned long long>() + n, &p, sizeof(p), hipMemcpyHostToDevice, e->stream)); }
+  }
+  HIP_OK(hipStreamSynchronize(e->stream));   // the sources are locals
+}
+}  // namespace
+
+int kb_run_preempt(kb_engine *e, kb_stmt_op *out, uint64_t cap, uint64_t *n_out) {
+  if (!e) return KB_E_INVALID;
+  return guarded(e, [&]() {
+    if (!e->loaded) throw EngineError(KB_E_STATE, "kb_session_load must precede kb_run_preempt");
+    HostSession &hs = e->hs;
+    if (hs.has_affinity && e->pol.nodeorder_enabled)
+      throw EngineError(KB_E_UNSUPPORTED, "preempt with preferred node-affinity terms (NormalizeReduce over the feasible set) is not modelled");
+    const double t_begin = now_ms();
+    const int R = hs.R;
+    const uint32_t N = hs.N, NP = e->dev.NP, T = hs.T, J = hs.J, Q = hs.Q;
+    // ---- live state: device -> host
+    LiveNodes ln;
+    {
+      std::vector<double> idle((size_t)R * NP), rel((size_t)R * NP);
+      std::vector<uint32_t> nmask(NP);
+      ln.nzc.resize(NP); ln.nzm.resize(NP); ln.podcnt.resize(NP); ln.ports.assign(NP, 0);
+      HIP_OK(hipMemcpy(idle.data(), e->b_idle.p, sizeof(double) * idle.size(), hipMemcpyDeviceToHost));
+      HIP_OK(hipMemcpy(rel.data(), e->b_rel.p, sizeof(double) * rel.size(), hipMemcpyDeviceToHost));
+      HIP_OK(hipMemcpy(nmask.data(), e->b_nmask.p, sizeof(uint32_t) * NP, hipMemcpyDeviceToHost));
+      HIP_OK(hipMemcpy(ln.nzc.data(), e->b_nzc.p, sizeof(long long) * NP, hipMemcpyDeviceToHost));
+      HIP_OK(hipMemcpy(ln.nzm.data(), e->b_nzm.p, sizeof(long long) * NP, hipMemcpyDeviceToHost));
+      HIP_OK(hipMemcpy(ln.podcnt.data(), e->b_podcnt.p, sizeof(int) * NP, hipMemcpyDeviceToHost));
+      if (e->dev.ports) HIP_OK(hipMemcpy(ln.ports.data(), e->b_ports.p, sizeof(unsigned long long) * NP, hipMemcpyDeviceToHost));
+      ln.idle.assign(N, Res()); ln.rel.assign(N, Res());
+      for (uint32_t n = 0; n < N; n++) {
+        ln.idle[n].mask = nmask[n] & 0x3FFFFFFFu;
+        for (int d = 0; d < R; d++) {
+          ln.idle[n].v[d] = idle[(size_t)d * NP + n];
+          ln.rel[n].v[d] = rel[(size_t)d * NP + n];
+          // Releasing gains scalar keys only through Add: a dense non-zero value <=> the key is present
+          if (d >= 2 && ln.rel[n].v[d] != 0.0) ln.rel[n].setk(d);
+        }
+      }
+      ln.ac.assign(hs.n_ac.begin(), hs.n_ac.end()); ln.am.assign(hs.n_am.begin(), hs.n_am.end());
+      ln.maxpods = hs.n_maxpods; ln.cls = hs.n_cls;
+    }
+    PreemptMachine pm;
+    pm.counted.resize(T ? T : 1);
+    if (T) HIP_OK(hipMemcpy(pm.counted.data(), e->b_tcounted.p, T, hipMemcpyDeviceToHost));
+    pm.jalloc = hs.job_alloc; pm.jshare = hs.job_share; pm.qalloc = hs.queue_alloc; pm.qshare = hs.queue_share;
+    pm.jmask.assign(J ? J : 1, 0); pm.qmask.assign(Q ? Q : 1, 0);
+    for (uint32_t t = 0; t < T; t++)
+      if (pm.counted[t] && hs.t_job[t] < J) {
+        pm.jmask[hs.t_job[t]] |= hs.t_resmask[t];
+        if (hs.job_queue[hs.t_job[t]] < Q) pm.qmask[hs.job_queue[hs.t_job[t]]] |= hs.t_resmask[t];
+      }
+    // ---- the device side: one complete sorted list per preemptor shape, on demand
+    auto lists = [&](uint32_t task, std::vector<uint64_t> &keys) {
+      ensure_window_buffers(e, 1);
+      ensure_matrix_buffers(e, 1, N + 1);
+      HIP_OK(hipMemcpyAsync(e->b_mrows.p, &task, sizeof(uint32_t), hipMemcpyHostToDevice, e->stream));
+      KbRound r = make_round(e, 0, 1, N + 1, 0 /* plugin predicates only */, false);
+      r.mrows = e->b_mrows.as<uint32_t>();
+      kb_launch_matrix(e->dev, r, e->stream);
+      kb_launch_argmax(e->dev, r, e->stream);
+      std::vector<unsigned long long> raw((size_t)N + 1);
+      HIP_OK(hipMemcpyAsync(raw.data(), e->b_keys.p, sizeof(unsigned long long) * raw.size(), hipMemcpyDeviceToHost, e->stream));
+      HIP_OK(hipStreamSynchronize(e->stream));
+      HIP_OK(hipGetLastError());
+      e->stats.matrix_launches += 1;
+      e->stats.matrix_evals += N;
+      // K3 orders (score descending, node ASCENDING); SortNodes breaks score ties by DESCENDING host name: reverse every run
+      keys.clear();
+      size_t i = 0;
+      while (i < raw.size() && raw[i] != 0ull) {
+        size_t k = i;
+        const uint32_t sc = KB_KEY_SCORE(raw[i]);
+        while (k < raw.size() && raw[k] != 0ull && KB_KEY_SCORE(raw[k]) == sc) k++;
+        for (size_t q = k; q-- > i;) keys.push_back(((uint64_t)sc << 32) | KB_KEY_NODE(raw[q]));
+        i = k;
+      }
+    };
+    auto refresh = [&](const std::vector<uint32_t> &nodes) { upload_live_nodes(e, ln, nodes); };
+    std::vector<uint8_t> status = hs.t_status;
+    std::vector<uint32_t> tnode = hs.t_node;
+    pm.init(&hs, &e->pol, &ln, &status, &tnode, lists, refresh);
+    pm.run();
+    // ---- results: journal out, state back to the device
+    if (n_out) *n_out = pm.ops.size();
+    if (pm.ops.size() > cap) throw EngineError(KB_E_CAPACITY, "journal buffer too small");   // nothing was written to the device yet
+    for (size_t i = 0; i < pm.ops.size(); i++) { out[i].op = pm.ops[i].op; out[i].task = pm.ops[i].task; out[i].node = pm.ops[i].node; out[i].stmt = pm.ops[i].stmt; }
+    upload_live_nodes(e, ln, pm.touched_nodes);
+    hs.t_status = status;
+    hs.t_node = tnode;
+    if (T) {
+      HIP_OK(hipMemcpy(e->b_tstatus.p, status.data(), T, hipMemcpyHostToDevice));
+      HIP_OK(hipMemcpy(e->b_tnode.p, tnode.data(), sizeof(uint32_t) * T, hipMemcpyHostToDevice));
+      HIP_OK(hipMemcpy(e->b_tcounted.p, pm.counted.data(), T, hipMemcpyHostToDevice));
+    }
+    e->evictions.insert(e->evictions.end(), pm.evictions.begin(), pm.evictions.end());
+    for (const StmtOp &op : pm.ops)   // Evict / Pipeline fire proportion's handlers -> updateShare for the task's queue
+      if (op.task != KB_NONE && hs.job_queue[hs.t_job[op.task]] < Q) hs.queue_share_live[hs.job_queue[hs.t_job[op.task]]] = 1;
+    run_finalize(e);
+    // the host's running drf / proportion aggregates must equal the device reduction over the task table
+    if (e->pol.has_drf)
+      for (uint32_t j = 0; j < J; j++)
+        if (pm.jshare[j] != hs.job_share[j]) throw EngineError(KB_E_INTERNAL, "preempt: drf share diverged from the device reduction at job " + std::to_string(j));
+    e->stats.tasks_popped += pm.popped;
+    e->stats.evals += pm.evals;
+    e->stats.total_ms += now_ms() - t_begin;
+  });
+}
+
+int kb_get_evictions(kb_engine *e, uint32_t *out, uint64_t cap, uint64_t *n_out) {
+  if (!e) return KB_E_INVALID;
+  return guarded(e, [&]() {
+    if (!e->loaded) throw EngineError(KB_E_STATE, "no session loaded");
+    if (n_out) *n_out = e->evictions.size();
+    if (e->evictions.size() > cap) throw EngineError(KB_E_CAPACITY, "eviction buffer too small");
+    if (out && !e->evictions.empty()) std::memcpy(out, e->evictions.data(), sizeof(uint32_t) * e->evictions.size());
+  });
+}
 
 // The materialised matrix for task rows [t0, t0+n): evaluate each distinct shape of the range once (K1), then stream every
 // row out of its shape's row (K1b); optionally the sorted candidate lists of the expanded rows (K3, length k).

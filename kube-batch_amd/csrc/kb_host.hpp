@@ -128,6 +128,9 @@ struct Policy {
   bool has_gang = false, has_drf = false, has_proportion = false;
   bool pred_enabled = false, nodeorder_enabled = false;
   int wL = 1, wM = 0, wNA = 1, wPA = 1, wB = 1;   // nodeorder.go:111-117
+  // Preemptable (session_plugins.go:122-162): per tier the plugins registered with EnabledPreemptable that own a victim rule
+  std::vector<std::vector<uint8_t>> preempt_tiers;
+  bool gang_job_pipelined = false;       // JobPipelined (session_plugins.go:202-222 + gang.go:126-129)
 };
 
 // ---- host mirror of the session ----
@@ -153,6 +156,16 @@ struct HostSession {
   std::vector<int64_t> job_creation;
   std::vector<int32_t> queue_weight;
   std::vector<int64_t> queue_creation;
+  // static data the preempt action reads on the host (the allocate / backfill path has it on the device only)
+  std::vector<int64_t> t_nzc, t_nzm;       // pod non-zero request
+  std::vector<uint64_t> t_want, t_conf;    // host ports the pod occupies / that conflict with it (empty: no host ports)
+  std::vector<uint8_t> t_protected;        // conformance: never a victim (empty: none)
+  std::vector<int64_t> n_ac, n_am;         // nodeinfo.allocatableResource
+  std::vector<int32_t> n_maxpods;
+  std::vector<uint32_t> n_cls, n_idle_mask;   // static class; scalar keys of Idle / Allocatable
+  std::vector<uint8_t> compat;             // class x class bit table (empty: every pair compatible)
+  uint32_t n_tc = 0, n_nc = 1;
+  bool has_affinity = false;               // some class carries preferred node-affinity terms (NormalizeReduce)
   // plugin state
   Res total;                               // drf.totalResource == proportion.totalResource
   std::vector<Res> deserved;               // [Q] proportion queueOpts[q].deserved

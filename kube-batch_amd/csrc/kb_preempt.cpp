@@ -1,0 +1,559 @@
+// kb_preempt.cpp — host side of the engine's preempt action; see kb_preempt.hpp.
+#include "kb_preempt.hpp"
+
+#include <climits>
+
+namespace kb {
+
+namespace {
+
+// container/heap with Go's sift mechanics (util/priority_queue.go:26-94 wraps it): the job heap's keys (gang readiness, drf share)
+// move while jobs sit in it, so the pop order depends on them
+template <typename Less> struct GoHeap {
+  std::vector<uint32_t> a;
+  Less less;
+  explicit GoHeap(Less l) : less(l) {}
+  bool empty() const { return a.empty(); }
+  void push(uint32_t x) {
+    a.push_back(x);
+    size_t j = a.size() - 1;
+    for (;;) {
+      size_t i = j == 0 ? 0 : (j - 1) / 2;
+      if (i == j || !less(a[j], a[i])) break;
+      std::swap(a[i], a[j]);
+      j = i;
+    }
+  }
+  uint32_t pop() {
+    size_t n = a.size() - 1;
+    std::swap(a[0], a[n]);
+    size_t i = 0;
+    for (;;) {
+      size_t j1 = 2 * i + 1;
+      if (j1 >= n) break;
+      size_t j = j1;
+      if (j1 + 1 < n && less(a[j1 + 1], a[j1])) j = j1 + 1;
+      if (!less(a[j], a[i])) break;
+      std::swap(a[i], a[j]);
+      i = j;
+    }
+    uint32_t x = a.back();
+    a.pop_back();
+    return x;
+  }
+};
+
+}  // namespace
+
+Res PreemptMachine::task_res(uint32_t t) const {
+  Res r;
+  r.mask = hs_->t_resmask[t];
+  for (int d = 0; d < hs_->R; d++) r.v[d] = hs_->t_res[(size_t)d * hs_->T + t];
+  return r;
+}
+Res PreemptMachine::task_init(uint32_t t) const {   // keys: Resreq's plus every dimension an init container raised (SetMaxResource)
+  Res r;
+  r.mask = hs_->t_resmask[t];
+  for (int d = 0; d < hs_->R; d++) {
+    r.v[d] = hs_->t_init[(size_t)d * hs_->T + t];
+    if (d >= 2 && r.v[d] != 0.0) r.setk(d);
+  }
+  return r;
+}
+int PreemptMachine::ready_num(uint32_t j) const {   // api/job_info.go:383-394
+  const int32_t *c = &cnt[(size_t)j * 10];
+  return c[KB_TASK_BOUND] + c[KB_TASK_BINDING] + c[KB_TASK_RUNNING] + c[KB_TASK_ALLOCATED] + c[KB_TASK_SUCCEEDED];
+}
+bool PreemptMachine::job_pipelined(uint32_t j) const {   // session_plugins.go:202-222 + gang.go:126-129 -> job_info.go Pipelined()
+  if (!pol_->gang_job_pipelined) return true;
+  return cnt[(size_t)j * 10 + KB_TASK_PIPELINED] + ready_num(j) >= hs_->job_min[j];
+}
+bool PreemptMachine::job_less(uint32_t l, uint32_t r) const {   // session_plugins.go:243-267 + priority.go:61-77, gang.go:96-119, drf.go:114-130
+  for (uint8_t p : pol_->job_chain) {
+    int j = 0;
+    if (p == KB_PLUGIN_PRIORITY) {
+      if (hs_->job_prio[l] > hs_->job_prio[r]) j = -1;
+      else if (hs_->job_prio[l] < hs_->job_prio[r]) j = 1;
+    } else if (p == KB_PLUGIN_GANG) {
+      bool lr = ready_num(l) >= hs_->job_min[l], rr = ready_num(r) >= hs_->job_min[r];
+      if (lr && rr) j = 0; else if (lr) j = 1; else if (rr) j = -1;
+    } else if (p == KB_PLUGIN_DRF) {
+      if (jshare[l] == jshare[r]) j = 0; else if (jshare[l] < jshare[r]) j = -1; else j = 1;
+    }
+    if (j != 0) return j < 0;
+  }
+  if (hs_->job_creation[l] == hs_->job_creation[r]) return l < r;
+  return hs_->job_creation[l] < hs_->job_creation[r];
+}
+bool PreemptMachine::task_less(uint32_t l, uint32_t r) const {   // session_plugins.go:298-331 + priority.go:40-56
+  if (pol_->task_order_priority && hs_->t_prio[l] != hs_->t_prio[r]) return hs_->t_prio[l] > hs_->t_prio[r];
+  if (hs_->t_creation[l] != hs_->t_creation[r]) return hs_->t_creation[l] < hs_->t_creation[r];
+  return l < r;
+}
+double PreemptMachine::drf_share(const double *alloc, uint32_t mask) const {   // drf.go:157-171
+  double share = 0;
+  for (int d = 0; d < hs_->R; d++) {
+    if (d >= 2 && !hs_->total.has(d)) continue;
+    const double a = (d < 2 || ((mask >> (d - 2)) & 1u)) ? alloc[d] : 0.0;
+    const double s = helpers_share(a, hs_->total.get(d));
+    if (s > share) share = s;
+  }
+  return share;
+}
+
+// drf.go:135-156, proportion.go:212-235: AllocateFunc / DeallocateFunc (fired by Evict, Pipeline and their undo)
+void PreemptMachine::fire_allocate(uint32_t t) {
+  const int R = hs_->R;
+  const uint32_t j = hs_->t_job[t], tm = hs_->t_resmask[t];
+  if (pol_->has_drf) {
+    double *a = &jalloc[(size_t)j * R];
+    for (int d = 0; d < R; d++)
+      if (d < 2 || ((tm >> (d - 2)) & 1u)) a[d] += hs_->t_res[(size_t)d * hs_->T + t];
+    jmask[j] |= tm;
+    jshare[j] = drf_share(a, jmask[j]);
+  }
+  if (pol_->has_proportion && hs_->job_queue[j] < hs_->Q) {
+    const uint32_t q = hs_->job_queue[j];
+    double *a = &qalloc[(size_t)q * R];
+    for (int d = 0; d < R; d++)
+      if (d < 2 || ((tm >> (d - 2)) & 1u)) a[d] += hs_->t_res[(size_t)d * hs_->T + t];
+    qmask[q] |= tm;
+    const Res &des = hs_->deserved[q];
+    double share = 0;
+    for (int d = 0; d < R; d++) {
+      if (d >= 2 && !des.has(d)) continue;
+      const double s = helpers_share((d < 2 || ((qmask[q] >> (d - 2)) & 1u)) ? a[d] : 0.0, des.get(d));
+      if (s > share) share = s;
+    }
+    qshare[q] = share;
+  }
+  counted[t] = 1;
+}
+void PreemptMachine::fire_deallocate(uint32_t t) {
+  const int R = hs_->R;
+  const uint32_t j = hs_->t_job[t], tm = hs_->t_resmask[t];
+  auto sub = [&](double *a, uint32_t &mask) {   // Resource.Sub (resource_info.go:143-160) on the dense vector + key mask
+    Res r, rr = task_res(t);
+    r.mask = mask;
+    for (int d = 0; d < R; d++) r.v[d] = a[d];
+    if (!res_sub(r, rr, R)) throw EngineError(KB_E_UNSUPPORTED, "preempt: a plugin's allocated vector would underflow (the reference panics in Resource.Sub)");
+    for (int d = 0; d < R; d++) a[d] = r.v[d];
+    mask = r.mask;
+  };
+  (void)tm;
+  if (pol_->has_drf) {
+    double *a = &jalloc[(size_t)j * R];
+    sub(a, jmask[j]);
+    jshare[j] = drf_share(a, jmask[j]);
+  }
+  if (pol_->has_proportion && hs_->job_queue[j] < hs_->Q) {
+    const uint32_t q = hs_->job_queue[j];
+    double *a = &qalloc[(size_t)q * R];
+    sub(a, qmask[q]);
+    const Res &des = hs_->deserved[q];
+    double share = 0;
+    for (int d = 0; d < R; d++) {
+      if (d >= 2 && !des.has(d)) continue;
+      const double s = helpers_share((d < 2 || ((qmask[q] >> (d - 2)) & 1u)) ? a[d] : 0.0, des.get(d));
+      if (s > share) share = s;
+    }
+    qshare[q] = share;
+  }
+  counted[t] = 0;
+}
+
+void PreemptMachine::set_status(uint32_t t, int st) {   // job_info.go:247-264 UpdateTaskStatus = delete + add
+  const uint32_t j = hs_->t_job[t];
+  cnt[(size_t)j * 10 + (*status_)[t]]--;
+  (*status_)[t] = (uint8_t)st;
+  cnt[(size_t)j * 10 + st]++;
+}
+
+void PreemptMachine::touch_node(uint32_t n) {
+  if (!touched_[n]) { touched_[n] = 1; touched_nodes.push_back(n); }
+}
+void PreemptMachine::mark_dirty(uint32_t n) {   // what the plugin predicates / scorers read changed: cached lists are stale for n
+  if (!dirty_[n]) { dirty_[n] = 1; dirty_nodes_.push_back(n); }
+}
+void PreemptMachine::recompute_minprio(uint32_t n) {
+  if (!prio_prunes_) return;
+  const uint32_t N = hs_->N, Q = hs_->Q;
+  for (uint32_t q = 0; q < Q; q++) qn_minprio_[(size_t)q * N + n] = INT_MAX;
+  for (uint32_t t : ntasks_[n]) {
+    if (node_status[t] != KB_TASK_RUNNING) continue;
+    const uint32_t j = hs_->t_job[t], q = hs_->job_queue[j];
+    if (q >= Q) continue;
+    int32_t &m = qn_minprio_[(size_t)q * N + n];
+    if (hs_->job_prio[j] < m) m = hs_->job_prio[j];
+  }
+}
+
+// NodeInfo.RemoveTask (api/node_info.go:217-243): accounting by the status of the node's own clone
+void PreemptMachine::node_remove(uint32_t t) {
+  if (!on_node[t]) return;   // "failed to find task on host": logged, nothing changes
+  const int R = hs_->R;
+  const uint32_t n = (*tnode_)[t];
+  const Res rq = task_res(t);
+  switch (node_status[t]) {
+    case KB_TASK_RELEASING:
+      if (!res_sub(nd_->rel[n], rq, R)) throw EngineError(KB_E_UNSUPPORTED, "preempt: Releasing would underflow (the reference panics in Resource.Sub)");
+      res_add(nd_->idle[n], rq, R);
+      break;
+    case KB_TASK_PIPELINED: res_add(nd_->rel[n], rq, R); break;
+    default: res_add(nd_->idle[n], rq, R); break;
+  }
+  nd_->podcnt[n] -= 1;
+  nd_->nzc[n] -= hs_->t_nzc[t];
+  nd_->nzm[n] -= hs_->t_nzm[t];
+  std::vector<uint32_t> &v = ntasks_[n];
+  v.erase(std::lower_bound(v.begin(), v.end(), t));
+  if (!hs_->t_want.empty()) {   // UsedPorts is rebuilt from the remaining pods
+    uint64_t ports = nd_->base_ports[n];
+    for (uint32_t o : v) ports |= hs_->t_want[o];
+    nd_->ports[n] = ports;
+  }
+  on_node[t] = 0;
+  touch_node(n);
+}
+// NodeInfo.AddTask (api/node_info.go:172-212) for a task whose session status is already `st`
+bool PreemptMachine::node_add(uint32_t t, uint32_t n, int st) {
+  const int R = hs_->R;
+  if (((*tnode_)[t] != KB_NONE && (*tnode_)[t] != n) || on_node[t]) return false;   // NodeName is sticky (node_info.go:173-182)
+  const Res rq = task_res(t);
+  switch (st) {
+    case KB_TASK_RELEASING:
+      if (!res_less_equal(rq, nd_->idle[n], R)) return false;
+      if (!res_sub(nd_->idle[n], rq, R)) throw EngineError(KB_E_UNSUPPORTED, "preempt: Idle would underflow");
+      res_add(nd_->rel[n], rq, R);
+      break;
+    case KB_TASK_PIPELINED:
+      if (!res_sub(nd_->rel[n], rq, R)) throw EngineError(KB_E_UNSUPPORTED, "preempt: Releasing would underflow (the reference panics in Resource.Sub)");
+      break;
+    default:
+      if (!res_less_equal(rq, nd_->idle[n], R)) return false;
+      if (!res_sub(nd_->idle[n], rq, R)) throw EngineError(KB_E_UNSUPPORTED, "preempt: Idle would underflow");
+      break;
+  }
+  (*tnode_)[t] = n;
+  node_status[t] = (uint8_t)st;
+  on_node[t] = 1;
+  nd_->podcnt[n] += 1;
+  nd_->nzc[n] += hs_->t_nzc[t];
+  nd_->nzm[n] += hs_->t_nzm[t];
+  if (!hs_->t_want.empty()) nd_->ports[n] |= hs_->t_want[t];
+  std::vector<uint32_t> &v = ntasks_[n];
+  v.insert(std::lower_bound(v.begin(), v.end(), t), t);
+  touch_node(n);
+  return true;
+}
+// NodeInfo.UpdateTask (node_info.go:245-256) = RemoveTask + AddTask; an AddTask error there is glog.Fatalf
+void PreemptMachine::node_update(uint32_t t, int st) {
+  if (!on_node[t]) return;
+  const uint32_t n = (*tnode_)[t];
+  node_remove(t);
+  if (!node_add(t, n, st)) throw EngineError(KB_E_UNSUPPORTED, "preempt: NodeInfo.UpdateTask could not re-add the task (the reference aborts with glog.Fatalf)");
+  recompute_minprio(n);
+}
+
+void PreemptMachine::evict(uint32_t t) {   // statement.go:36-69
+  set_status(t, KB_TASK_RELEASING);
+  node_update(t, KB_TASK_RELEASING);
+  fire_deallocate(t);
+  ops.push_back(StmtOp{KB_OP_EVICT, t, (*tnode_)[t], stmt_no_});
+}
+void PreemptMachine::unevict(uint32_t t) {   // statement.go:83-110
+  set_status(t, KB_TASK_RUNNING);
+  node_update(t, KB_TASK_RUNNING);
+  fire_allocate(t);
+}
+void PreemptMachine::pipeline(uint32_t t, uint32_t n) {   // statement.go:113-150 (an AddTask error is logged, the handlers still run)
+  set_status(t, KB_TASK_PIPELINED);
+  if (node_add(t, n, KB_TASK_PIPELINED)) mark_dirty(n);
+  fire_allocate(t);
+  ops.push_back(StmtOp{KB_OP_PIPELINE, t, n, stmt_no_});
+}
+void PreemptMachine::unpipeline(uint32_t t) {   // statement.go:155-190; task.NodeName keeps the old host (RemoveTask never clears it)
+  set_status(t, KB_TASK_PENDING);
+  if (on_node[t]) { const uint32_t n = (*tnode_)[t]; node_remove(t); mark_dirty(n); }
+  fire_deallocate(t);
+}
+void PreemptMachine::begin_stmt() {
+  stmt_no_++;
+  stmt_begin_ = ops.size();
+}
+void PreemptMachine::commit() {   // statement.go:208-220: evict -> cache.Evict, pipeline -> no-op
+  const size_t end = ops.size();
+  for (size_t i = stmt_begin_; i < end; i++)
+    if (ops[i].op == KB_OP_EVICT) evictions.push_back(ops[i].task);
+  if (end > stmt_begin_) ops.push_back(StmtOp{KB_OP_COMMIT, KB_NONE, KB_NONE, stmt_no_});   // an empty statement leaves no trace
+  stmt_begin_ = ops.size();
+}
+void PreemptMachine::discard() {   // statement.go:193-205: newest first
+  const size_t end = ops.size();
+  for (size_t i = end; i-- > stmt_begin_;) {
+    if (ops[i].op == KB_OP_EVICT) unevict(ops[i].task);
+    else if (ops[i].op == KB_OP_PIPELINE) unpipeline(ops[i].task);
+  }
+  if (end > stmt_begin_) ops.push_back(StmtOp{KB_OP_DISCARD, KB_NONE, KB_NONE, stmt_no_});
+  stmt_begin_ = ops.size();
+}
+
+// session_plugins.go:122-162: per tier the intersection of the enabled plugins' candidates; once a plugin has spoken an empty
+// set stays empty (Go: a nil slice intersected with anything is nil), and the first tier that leaves a non-empty set decides
+size_t PreemptMachine::evictable(uint32_t preemptor, const std::vector<uint32_t> &pre, std::vector<uint32_t> &victims) {
+  const int R = hs_->R;
+  const size_t n = pre.size();
+  bool init = false;
+  victims.clear();
+  std::vector<uint8_t> keep(n ? n : 1);
+  for (const std::vector<uint8_t> &tier : pol_->preempt_tiers) {
+    for (uint8_t plugin : tier) {
+      std::fill(keep.begin(), keep.end(), 0);
+      if (plugin == KB_PLUGIN_CONFORMANCE) {   // conformance.go:44-58
+        for (size_t i = 0; i < n; i++) keep[i] = hs_->t_protected.empty() || !hs_->t_protected[pre[i]];
+      } else if (plugin == KB_PLUGIN_GANG) {   // gang.go:71-90
+        for (size_t i = 0; i < n; i++) {
+          const uint32_t j = hs_->t_job[pre[i]];
+          keep[i] = (hs_->job_min[j] <= ready_num(j) - 1) || hs_->job_min[j] == 1;
+        }
+      } else if (plugin == KB_PLUGIN_PRIORITY) {   // priority.go:81-98
+        const int32_t pp = hs_->job_prio[hs_->t_job[preemptor]];
+        for (size_t i = 0; i < n; i++) keep[i] = hs_->job_prio[hs_->t_job[pre[i]]] < pp;
+      } else if (plugin == KB_PLUGIN_DRF) {   // drf.go:84-109: running per-job allocation, in preemptee order
+        const uint32_t pj = hs_->t_job[preemptor];
+        Res lalloc;
+        lalloc.mask = jmask[pj];
+        for (int d = 0; d < R; d++) lalloc.v[d] = jalloc[(size_t)pj * R + d];
+        res_add(lalloc, task_res(preemptor), R);
+        const double ls = drf_share(lalloc.v, lalloc.mask);
+        std::vector<uint32_t> ajob;
+        std::vector<Res> alloc;
+        for (size_t i = 0; i < n; i++) {
+          const uint32_t jb = hs_->t_job[pre[i]];
+          size_t a = 0;
+          while (a < ajob.size() && ajob[a] != jb) a++;
+          if (a == ajob.size()) {
+            ajob.push_back(jb);
+            Res r;
+            r.mask = jmask[jb];
+            for (int d = 0; d < R; d++) r.v[d] = jalloc[(size_t)jb * R + d];
+            alloc.push_back(r);
+          }
+          if (!res_sub(alloc[a], task_res(pre[i]), R)) throw EngineError(KB_E_UNSUPPORTED, "preempt: drf allocation would underflow (the reference panics in Resource.Sub)");
+          const double rs = drf_share(alloc[a].v, alloc[a].mask);
+          keep[i] = (ls < rs) || (std::fabs(ls - rs) <= 0.000001);   // shareDelta (drf.go:33)
+        }
+      } else {
+        continue;
+      }
+      if (!init) {
+        for (size_t i = 0; i < n; i++) if (keep[i]) victims.push_back(pre[i]);
+        init = true;
+      } else {
+        size_t w = 0;
+        for (size_t v = 0; v < victims.size(); v++) {
+          bool in = false;
+          for (size_t i = 0; i < n && !in; i++) in = keep[i] && pre[i] == victims[v];
+          if (in) victims[w++] = victims[v];
+        }
+        victims.resize(w);
+      }
+    }
+    if (!victims.empty()) break;
+  }
+  return victims.size();
+}
+
+// plugin predicates (predicates.go:123-265 with the static checks folded into classes) and nodeorder's resource scorers against
+// the LIVE host state of one node — the repair path for nodes a Pipeline changed since the device built the lists
+bool PreemptMachine::host_eval(uint32_t t, uint32_t n, long long &score) const {
+  score = 0;
+  if (pol_->pred_enabled) {
+    if (nd_->maxpods[n] <= nd_->podcnt[n]) return false;   // predicates.go:127
+    if (!hs_->compat.empty()) {
+      const uint32_t bit = hs_->t_cls[t] * hs_->n_nc + nd_->cls[n];
+      if (!((hs_->compat[bit >> 3] >> (bit & 7)) & 1)) return false;
+    }
+    if (!hs_->t_conf.empty() && (nd_->ports[n] & hs_->t_conf[t])) return false;
+  }
+  if (!pol_->nodeorder_enabled) return true;
+  const long long rc = nd_->nzc[n] + hs_->t_nzc[t], rm = nd_->nzm[n] + hs_->t_nzm[t], ac = nd_->ac[n], am = nd_->am[n];
+  auto least = [](long long req, long long cap) -> long long { return (cap == 0 || req > cap) ? 0 : ((cap - req) * 10) / cap; };   // least_requested.go:36-58
+  auto most = [](long long req, long long cap) -> long long { return (cap == 0 || req > cap) ? 0 : (req * 10) / cap; };             // most_requested.go:34-61
+  const long long l = (least(rc, ac) + least(rm, am)) / 2, m = (most(rc, ac) + most(rm, am)) / 2;
+  const double cf = ac == 0 ? 1.0 : (double)rc / (double)ac, mf = am == 0 ? 1.0 : (double)rm / (double)am;   // balanced_resource_allocation.go:42-79
+  long long b = 0;
+  if (!(cf >= 1.0 || mf >= 1.0)) b = (long long)((1.0 - std::fabs(cf - mf)) * 10.0);
+  score = l * pol_->wL + m * pol_->wM + b * pol_->wB;
+  return true;
+}
+
+// one node of preempt()'s walk (preempt.go:195-254); mode 0: victims are Running tasks of OTHER jobs in the preemptor job's queue,
+// mode 1: of the preemptor's own job
+bool PreemptMachine::try_node(uint32_t preemptor, int mode, uint32_t n) {
+  const int R = hs_->R;
+  const uint32_t pj = hs_->t_job[preemptor], pq = hs_->job_queue[pj];
+  if (prio_prunes_ && mode == 0 && pq < hs_->Q && qn_minprio_[(size_t)pq * hs_->N + n] >= hs_->job_prio[pj]) return false;   // no task the priority rule would let go
+  std::vector<uint32_t> pre, victims;
+  for (uint32_t t : ntasks_[n]) {   // node.Tasks in canonical order, filtered (preempt.go:112-124 / :150-157)
+    if (node_status[t] != KB_TASK_RUNNING) continue;
+    const uint32_t j = hs_->t_job[t];
+    if (mode == 0) { if (!(hs_->job_queue[j] == pq && j != pj)) continue; }
+    else if (j != pj) continue;
+    pre.push_back(t);
+  }
+  if (pre.empty()) return false;
+  if (evictable(preemptor, pre, victims) == 0) return false;   // validateVictims: "no victims"
+  const Res init = task_init(preemptor);
+  Res all;
+  for (uint32_t v : victims) res_add(all, task_res(v), R);
+  if (!res_less_equal(init, all, R)) return false;   // "not enough resources"
+  auto vless = [this](uint32_t l, uint32_t r) { return !task_less(l, r); };   // preempt.go:223-225
+  GoHeap<decltype(vless)> vq(vless);
+  for (uint32_t v : victims) vq.push(v);
+  Res preempted;
+  while (!vq.empty()) {   // lowest priority first (preempt.go:229-241)
+    const uint32_t v = vq.pop();
+    evict(v);
+    res_add(preempted, task_res(v), R);
+    if (res_less_equal(init, preempted, R)) break;
+  }
+  if (res_less_equal(init, preempted, R)) {   // preempt.go:247-256
+    pipeline(preemptor, n);
+    return true;
+  }
+  return false;
+}
+
+// preempt(): preempt.go:171-254
+bool PreemptMachine::preempt_one(uint32_t preemptor, int mode) {
+  popped++;
+  evals += hs_->N;
+  // with the priority rule in the deciding tier a task of the preemptor's own job can never be a victim
+  if (prio_prunes_ && mode == 1) return false;
+  if (dirty_nodes_.size() > 256) {   // too many repaired nodes: bring the device up to date and rebuild the lists on demand
+    refresh_(dirty_nodes_);
+    for (uint32_t n : dirty_nodes_) dirty_[n] = 0;
+    dirty_nodes_.clear();
+    std::fill(shape_have_.begin(), shape_have_.end(), 0);
+  }
+  const uint32_t sh = hs_->t_row_shape[preemptor];
+  if (!shape_have_[sh]) {
+    std::vector<uint64_t> keys;
+    lists_(preemptor, keys);
+    shape_list_[sh].assign(keys.begin(), keys.end());
+    shape_have_[sh] = 1;
+  }
+  const std::vector<uint64_t> &L = shape_list_[sh];
+  // the nodes changed since the lists were built, re-evaluated against their live state
+  std::vector<uint64_t> D;
+  for (uint32_t n : dirty_nodes_) {
+    long long sc;
+    if (host_eval(preemptor, n, sc)) D.push_back(((uint64_t)sc << 32) | n);
+  }
+  std::sort(D.begin(), D.end(), [](uint64_t a, uint64_t b) { return a > b; });
+  size_t i = 0, k = 0;
+  for (;;) {
+    while (i < L.size() && dirty_[(uint32_t)L[i]]) i++;
+    uint32_t n;
+    if (i < L.size() && (k >= D.size() || L[i] > D[k])) n = (uint32_t)L[i++];
+    else if (k < D.size()) n = (uint32_t)D[k++];
+    else break;
+    if (try_node(preemptor, mode, n)) return true;
+  }
+  return false;
+}
+
+void PreemptMachine::init(const HostSession *hs, const Policy *pol, LiveNodes *live, std::vector<uint8_t> *status, std::vector<uint32_t> *tnode,
+                          ListFn lists, RefreshFn refresh) {
+  hs_ = hs; pol_ = pol; nd_ = live; status_ = status; tnode_ = tnode;
+  lists_ = std::move(lists); refresh_ = std::move(refresh);
+  const uint32_t N = hs->N, T = hs->T, J = hs->J, Q = hs->Q;
+  ops.clear(); evictions.clear(); touched_nodes.clear();
+  popped = evals = 0;
+  stmt_no_ = 0; stmt_begin_ = 0;
+  cnt.assign((size_t)(J ? J : 1) * 10, 0);
+  for (uint32_t t = 0; t < T; t++) if (hs->t_job[t] < J) cnt[(size_t)hs->t_job[t] * 10 + (*status)[t]]++;
+  node_status.assign(T, 0);
+  on_node.assign(T, 0);
+  ntasks_.assign(N, {});
+  for (uint32_t t = 0; t < T; t++) {
+    node_status[t] = (*status)[t];
+    if ((*tnode)[t] != KB_NONE && (*tnode)[t] < N) { on_node[t] = 1; ntasks_[(*tnode)[t]].push_back(t); }
+  }
+  nd_->base_ports.assign(N, 0);
+  if (!hs->t_want.empty())
+    for (uint32_t n = 0; n < N; n++) {   // ports of pods outside the session stay on the node whatever moves
+      uint64_t mine = 0;
+      for (uint32_t t : ntasks_[n]) mine |= hs->t_want[t];
+      nd_->base_ports[n] = nd_->ports[n] & ~mine;
+    }
+  shape_list_.assign(hs->n_row_shapes ? hs->n_row_shapes : 1, {});
+  shape_have_.assign(hs->n_row_shapes ? hs->n_row_shapes : 1, 0);
+  dirty_.assign(N ? N : 1, 0);
+  dirty_nodes_.clear();
+  touched_.assign(N ? N : 1, 0);
+  // the priority rule prunes when it sits in the first tier that owns any victim rule (every later verdict is a subset of its own)
+  prio_prunes_ = false;
+  for (const std::vector<uint8_t> &tier : pol->preempt_tiers) {
+    if (tier.empty()) continue;
+    prio_prunes_ = std::find(tier.begin(), tier.end(), (uint8_t)KB_PLUGIN_PRIORITY) != tier.end();
+    break;
+  }
+  if (prio_prunes_) {
+    qn_minprio_.assign((size_t)(Q ? Q : 1) * (N ? N : 1), INT_MAX);
+    for (uint32_t n = 0; n < N; n++) recompute_minprio(n);
+  }
+}
+
+// preemptAction.Execute (preempt.go:45-168).  Canonical orders where the reference ranges over Go maps: queues ascending
+// QueueID, jobs ascending JobID (underRequest), a node's tasks ascending task index.
+void PreemptMachine::run() {
+  const uint32_t J = hs_->J, Q = hs_->Q;
+  auto jl = [this](uint32_t l, uint32_t r) { return job_less(l, r); };
+  auto tl = [this](uint32_t l, uint32_t r) { return task_less(l, r); };
+  std::vector<GoHeap<decltype(jl)>> qjobs(Q ? Q : 1, GoHeap<decltype(jl)>(jl));   // preemptorsMap
+  std::vector<GoHeap<decltype(tl)>> jtasks(J ? J : 1, GoHeap<decltype(tl)>(tl));  // preemptorTasks
+  std::vector<uint8_t> qseen(Q ? Q : 1, 0), under(J ? J : 1, 0);
+  for (uint32_t j = 0; j < J; j++) {   // preempt.go:55-76
+    const uint32_t q = hs_->job_queue[j];
+    if (q >= Q) continue;
+    qseen[q] = 1;
+    if (cnt[(size_t)j * 10 + KB_TASK_PENDING] != 0) {
+      qjobs[q].push(j);
+      under[j] = 1;
+      for (uint32_t t = hs_->job_begin[j]; t < hs_->job_begin[j + 1]; t++)
+        if ((*status_)[t] == KB_TASK_PENDING) jtasks[j].push(t);
+    }
+  }
+  for (uint32_t q = 0; q < Q; q++) {
+    if (!qseen[q]) continue;
+    for (;;) {   // between jobs within the queue (preempt.go:80-139)
+      if (qjobs[q].empty()) break;
+      const uint32_t pj = qjobs[q].pop();
+      bool assigned = false;
+      begin_stmt();
+      for (;;) {
+        if (jtasks[pj].empty()) break;
+        const uint32_t preemptor = jtasks[pj].pop();
+        if (preempt_one(preemptor, 0)) assigned = true;
+        if (job_pipelined(pj)) { commit(); break; }
+      }
+      if (!job_pipelined(pj)) { discard(); continue; }
+      if (assigned) qjobs[q].push(pj);
+    }
+    for (uint32_t j = 0; j < J; j++) {   // between tasks within a job (preempt.go:142-166)
+      if (!under[j]) continue;
+      for (;;) {
+        if (jtasks[j].empty()) break;
+        const uint32_t preemptor = jtasks[j].pop();
+        begin_stmt();
+        const bool assigned = preempt_one(preemptor, 1);
+        commit();
+        if (!assigned) break;
+      }
+    }
+  }
+}
+
+}  // namespace kb

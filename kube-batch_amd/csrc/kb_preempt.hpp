@@ -1,0 +1,108 @@
+// kb_preempt.hpp — host side of the preempt action (actions/preempt/preempt.go:45-271) for the engine.
+//
+// The data-parallel part of preempt() — PredicateNodes with the plugin predicates only, PrioritizeNodes, SortNodes
+// (preempt.go:183-193) — runs on the device: one K1 row (fit_mode 0) and one complete K3 list per distinct preemptor shape,
+// valid until a Pipeline changes a node (evictions touch Idle / Releasing only, which neither the plugin predicates nor the
+// scorers read).  Everything else is inherently sequential bookkeeping over small sets — the Statement journal
+// (framework/statement.go:36-220), the tiered Preemptable intersection (framework/session_plugins.go:122-162 with the gang, drf,
+// priority and conformance victim rules), the victim heap of one node — and stays on the host, in this file.
+//
+// This is the engine's own implementation, independent of oracle/kb_oracle.c (test infrastructure).
+#pragma once
+#include <functional>
+#include <vector>
+
+#include "kb_host.hpp"
+
+namespace kb {
+
+// one journal entry handed back through the C ABI (include/kb_engine.h: kb_stmt_op)
+struct StmtOp {
+  uint32_t op;     // KB_OP_*
+  uint32_t task;
+  uint32_t node;
+  uint32_t stmt;   // running statement number inside the action
+};
+
+// live node state on the host while the action runs (Res: dense vector + scalar-key mask, mask == 0 <=> nil map)
+struct LiveNodes {
+  std::vector<Res> idle, rel;
+  std::vector<long long> nzc, nzm, ac, am;
+  std::vector<int32_t> podcnt, maxpods;
+  std::vector<uint32_t> cls;
+  std::vector<uint64_t> ports, base_ports;   // base: the share that belongs to pods outside the session
+};
+
+class PreemptMachine {
+ public:
+  // `lists(shape_task, out)`: nodes passing the plugin predicates for the shape of task `shape_task`, best first in SortNodes'
+  // order (descending score, ties by DESCENDING node name: util/scheduler_helper.go:51-56,174-185), against the node state
+  // the device currently holds.  `refresh(nodes)`: the device's copy of those nodes is brought up to date (cached lists die).
+  using ListFn = std::function<void(uint32_t shape_task, std::vector<uint64_t> &out)>;   // entries: score << 32 | node, descending
+  using RefreshFn = std::function<void(const std::vector<uint32_t> &nodes)>;
+
+  void init(const HostSession *hs, const Policy *pol, LiveNodes *live, std::vector<uint8_t> *status, std::vector<uint32_t> *tnode,
+            ListFn lists, RefreshFn refresh);
+  void run();   // the whole action
+
+  std::vector<StmtOp> ops;             // every Evict / Pipeline / Commit / Discard, in order
+  std::vector<uint32_t> evictions;     // committed evictions in the order stmt.Commit hands them to cache.Evict
+  std::vector<uint8_t> counted;        // [T] task's Resreq is part of drf / proportion "allocated" (in: as of action start)
+  std::vector<double> jalloc, jshare, qalloc, qshare;   // running drf / proportion aggregates (in: as of action start)
+  std::vector<uint32_t> jmask, qmask;  // scalar-key masks of the allocated vectors
+  std::vector<int32_t> cnt;            // [J][10] len(TaskStatusIndex[status])
+  std::vector<uint8_t> node_status, on_node;   // node-side view of every task (api/node_info.go:186: the node keeps its own clone)
+  std::vector<uint32_t> touched_nodes; // nodes whose state changed during the action (for the upload)
+  uint64_t popped = 0, evals = 0;
+
+ private:
+  const HostSession *hs_ = nullptr;
+  const Policy *pol_ = nullptr;
+  LiveNodes *nd_ = nullptr;
+  std::vector<uint8_t> *status_ = nullptr;
+  std::vector<uint32_t> *tnode_ = nullptr;
+  ListFn lists_;
+  RefreshFn refresh_;
+  std::vector<std::vector<uint32_t>> ntasks_;   // node -> tasks in ni.Tasks, ascending task index
+  size_t stmt_begin_ = 0;
+  uint32_t stmt_no_ = 0;
+  // per-shape cached lists + the nodes Pipelines changed since they were built
+  std::vector<std::vector<uint64_t>> shape_list_;
+  std::vector<uint8_t> shape_have_;
+  std::vector<uint8_t> dirty_;
+  std::vector<uint32_t> dirty_nodes_;
+  std::vector<uint8_t> touched_;
+  // pruning index: per (queue, node) the lowest job priority among the node's Running session tasks of that queue
+  std::vector<int32_t> qn_minprio_;
+  bool prio_prunes_ = false;
+
+  Res task_res(uint32_t t) const;
+  Res task_init(uint32_t t) const;
+  int ready_num(uint32_t j) const;
+  bool job_pipelined(uint32_t j) const;
+  bool job_less(uint32_t l, uint32_t r) const;
+  bool task_less(uint32_t l, uint32_t r) const;
+  double drf_share(const double *alloc, uint32_t mask) const;
+  void fire_allocate(uint32_t t);
+  void fire_deallocate(uint32_t t);
+  void set_status(uint32_t t, int st);
+  void node_remove(uint32_t t);
+  bool node_add(uint32_t t, uint32_t n, int st);
+  void node_update(uint32_t t, int st);
+  void touch_node(uint32_t n);
+  void mark_dirty(uint32_t n);
+  void recompute_minprio(uint32_t n);
+  void evict(uint32_t t);
+  void unevict(uint32_t t);
+  void pipeline(uint32_t t, uint32_t n);
+  void unpipeline(uint32_t t);
+  void begin_stmt();
+  void commit();
+  void discard();
+  size_t evictable(uint32_t preemptor, const std::vector<uint32_t> &pre, std::vector<uint32_t> &victims);
+  bool host_eval(uint32_t t, uint32_t n, long long &score) const;
+  bool preempt_one(uint32_t preemptor, int mode);
+  bool try_node(uint32_t preemptor, int mode, uint32_t n);
+};
+
+}  // namespace kb

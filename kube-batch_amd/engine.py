@@ -17,7 +17,7 @@ LIB_PATH = os.environ.get("KB_ENGINE_LIB") or os.path.join(_HERE, "libkbengine.s
 _LIB = None
 
 EXPORTS = ["kb_engine_create", "kb_engine_destroy", "kb_last_error", "kb_session_load", "kb_session_reset", "kb_run_allocate",
-           "kb_run_backfill", "kb_eval_matrix", "kb_argmax_rows", "kb_bench_matrix", "kb_get_binds",
+           "kb_run_backfill", "kb_run_preempt", "kb_get_evictions", "kb_eval_matrix", "kb_argmax_rows", "kb_bench_matrix", "kb_get_binds",
            "kb_get_task_state", "kb_get_node_state", "kb_get_shares", "kb_get_stats", "kb_round_begin",
            "kb_round_candidates", "kb_round_commit", "kb_round_apply", "kb_round_delta_doubles",
            "kb_round_decisions"]
@@ -53,6 +53,8 @@ def lib():
         L.kb_session_reset.argtypes = [vp]
         for n in ("kb_run_allocate", "kb_run_backfill"):
             getattr(L, n).argtypes = [vp, C.POINTER(abi.Decision), C.c_uint64, C.POINTER(C.c_uint64)]
+        L.kb_run_preempt.argtypes = [vp, C.POINTER(abi.StmtOp), C.c_uint64, C.POINTER(C.c_uint64)]
+        L.kb_get_evictions.argtypes = [vp, C.POINTER(C.c_uint32), C.c_uint64, C.POINTER(C.c_uint64)]
         L.kb_eval_matrix.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint8), C.POINTER(C.c_uint16)]
         L.kb_argmax_rows.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint16)]
         L.kb_bench_matrix.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_double)]
@@ -128,6 +130,24 @@ class Engine:
 
     def run_backfill(self):
         return self._run(self.L.kb_run_backfill)
+
+    def run_preempt(self):
+        """The preempt action (actions/preempt/preempt.go) -> uint32[n,4] journal (op, task, node, stmt), abi.OP_*, in order."""
+        cap = 4 * max(int(self.snap.n_tasks), 1) + 16
+        n = C.c_uint64()
+        arr = (abi.StmtOp * cap)()
+        rc = self.L.kb_run_preempt(self.h, arr, cap, C.byref(n))
+        self._ck(rc)
+        self.last_journal = np.frombuffer(arr, dtype=np.uint32).reshape(cap, 4)[: n.value].copy()
+        return np.zeros((0, 3), np.uint32)       # no ssn.Allocate / ssn.Pipeline decisions: the journal carries the Statement ops
+
+    def evictions(self):
+        """Task ids the committed statements handed to cache.Evict, in that order."""
+        cap = max(int(self.snap.n_tasks), 1)
+        out = np.empty(cap, np.uint32)
+        n = C.c_uint64()
+        self._ck(self.L.kb_get_evictions(self.h, _p(out, C.c_uint32), cap, C.byref(n)))
+        return out[: n.value].copy()
 
     def run(self, actions):
         out = [getattr(self, "run_" + a)() for a in actions]
