@@ -443,8 +443,34 @@ bool PreemptMachine::preempt_one(uint32_t preemptor, int mode) {
     lists_(preemptor, keys);
     shape_list_[sh].assign(keys.begin(), keys.end());
     shape_have_[sh] = 1;
+    std::vector<int32_t> &rk = shape_rank_[sh];
+    rk.assign(hs_->N ? hs_->N : 1, -1);
+    for (size_t i = 0; i < keys.size(); i++) rk[(uint32_t)keys[i]] = (int32_t)i;
   }
   const std::vector<uint64_t> &L = shape_list_[sh];
+  const uint32_t pj = hs_->t_job[preemptor], pq = hs_->job_queue[pj];
+  if (prio_prunes_ && mode == 0 && pq < hs_->Q) {
+    // Only nodes that hold a Running task of the preemptor's queue with a lower job priority can yield victims (try_node would
+    // reject every other node at once), and there are few of them: take THEIR keys — the list entry for a clean node, a live
+    // re-evaluation for a node a Pipeline changed — and walk them in SortNodes' order.  Same nodes, same order, same outcome
+    // as walking the whole list.
+    std::vector<uint64_t> C;
+    const int32_t pp = hs_->job_prio[pj];
+    const std::vector<int32_t> &rank = shape_rank_[sh];
+    for (uint32_t n : qnodes_[pq]) {
+      if (qn_minprio_[(size_t)pq * hs_->N + n] >= pp) continue;
+      if (dirty_[n]) {
+        long long sc;
+        if (host_eval(preemptor, n, sc)) C.push_back(((uint64_t)sc << 32) | n);
+      } else if (rank[n] >= 0) {
+        C.push_back(L[(size_t)rank[n]]);
+      }
+    }
+    std::sort(C.begin(), C.end(), [](uint64_t a, uint64_t b) { return a > b; });
+    for (uint64_t key : C)
+      if (try_node(preemptor, mode, (uint32_t)key)) return true;
+    return false;
+  }
   // the nodes changed since the lists were built, re-evaluated against their live state
   std::vector<uint64_t> D;
   for (uint32_t n : dirty_nodes_) {
@@ -490,6 +516,7 @@ void PreemptMachine::init(const HostSession *hs, const Policy *pol, LiveNodes *l
     }
   shape_list_.assign(hs->n_row_shapes ? hs->n_row_shapes : 1, {});
   shape_have_.assign(hs->n_row_shapes ? hs->n_row_shapes : 1, 0);
+  shape_rank_.assign(hs->n_row_shapes ? hs->n_row_shapes : 1, {});
   dirty_.assign(N ? N : 1, 0);
   dirty_nodes_.clear();
   touched_.assign(N ? N : 1, 0);
@@ -503,6 +530,10 @@ void PreemptMachine::init(const HostSession *hs, const Policy *pol, LiveNodes *l
   if (prio_prunes_) {
     qn_minprio_.assign((size_t)(Q ? Q : 1) * (N ? N : 1), INT_MAX);
     for (uint32_t n = 0; n < N; n++) recompute_minprio(n);
+    qnodes_.assign(Q ? Q : 1, {});
+    for (uint32_t q = 0; q < Q; q++)
+      for (uint32_t n = 0; n < N; n++)
+        if (qn_minprio_[(size_t)q * N + n] != INT_MAX) qnodes_[q].push_back(n);
   }
 }
 

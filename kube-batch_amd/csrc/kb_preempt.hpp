@@ -75,6 +75,8 @@ class PreemptMachine {
   // pruning index: per (queue, node) the lowest job priority among the node's Running session tasks of that queue
   std::vector<int32_t> qn_minprio_;
   bool prio_prunes_ = false;
+  std::vector<std::vector<uint32_t>> qnodes_;        // per queue: nodes that hold a Running session task of the queue (superset, fixed)
+  std::vector<std::vector<int32_t>> shape_rank_;     // per shape: position of every node in the shape's list (-1: not in it)
 
   Res task_res(uint32_t t) const;
   Res task_init(uint32_t t) const;

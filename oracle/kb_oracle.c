@@ -423,6 +423,9 @@ typedef struct kbo_session {
   /* fast mode (kbo_set_fast): per task shape a cached row of keys over all nodes + a max-tree, repaired one node at a time */
   int fast;
   struct fast_t *fx;
+  /* node -> tasks in ni.Tasks (bitmap over T per node would be too big: a linked list through next_on_node, head per node;
+     the scans below sort what they collect, so list order does not matter).  Built by node_index_build(). */
+  uint32_t *node_head, *next_on_node, *prev_on_node;
 } kbo_session;
 
 static int find_plugin_enabled(const kbo_session *s, uint32_t plugin, uint32_t en_bit) {
@@ -1146,6 +1149,29 @@ static void fire_deallocate_event(kbo_session *s, uint32_t t) {   /* drf.go:146-
   if (s->has_plugin[KB_PLUGIN_PROPORTION]) { o_queue *q = &s->queues[j->queue]; if (res_sub(&q->allocated, &tk->resreq, s->R) == KBO_PANIC) s->panic = 1; prop_update_share(s, q); }
 }
 /* NodeInfo.RemoveTask (api/node_info.go:217-243): accounting by the status of the node's own clone */
+static void node_index_unlink(kbo_session *s, uint32_t t) {
+  if (!s->node_head) return;
+  const uint32_t n = s->tasks[t].node, nx = s->next_on_node[t], pv = s->prev_on_node[t];
+  if (pv == KB_NONE) s->node_head[n] = nx; else s->next_on_node[pv] = nx;
+  if (nx != KB_NONE) s->prev_on_node[nx] = pv;
+}
+static void node_index_link(kbo_session *s, uint32_t t, uint32_t n) {
+  if (!s->node_head) return;
+  s->prev_on_node[t] = KB_NONE;
+  s->next_on_node[t] = s->node_head[n];
+  if (s->node_head[n] != KB_NONE) s->prev_on_node[s->node_head[n]] = t;
+  s->node_head[n] = t;
+}
+static void node_index_build(kbo_session *s) {
+  free(s->node_head); free(s->next_on_node); free(s->prev_on_node);
+  s->node_head = (uint32_t *)malloc(sizeof(uint32_t) * (s->N ? s->N : 1));
+  s->next_on_node = (uint32_t *)malloc(sizeof(uint32_t) * (s->T ? s->T : 1));
+  s->prev_on_node = (uint32_t *)malloc(sizeof(uint32_t) * (s->T ? s->T : 1));
+  for (uint32_t n = 0; n < s->N; n++) s->node_head[n] = KB_NONE;
+  for (uint32_t t = s->T; t-- > 0;)
+    if (s->tasks[t].on_node && s->tasks[t].node < s->N) node_index_link(s, t, s->tasks[t].node);
+}
+static int cmp_u32(const void *a, const void *b) { const uint32_t x = *(const uint32_t *)a, y = *(const uint32_t *)b; return x < y ? -1 : (x > y ? 1 : 0); }
 static void node_remove_task(kbo_session *s, uint32_t t) {
   o_task *tk = &s->tasks[t];
   if (!tk->on_node) return;                     /* node_info.go:220-224 "failed to find task on host": logged, nothing changes */
@@ -1161,9 +1187,14 @@ static void node_remove_task(kbo_session *s, uint32_t t) {
   nd->nz_mem -= tk->nz_mem;
   /* host ports: UsedPorts is rebuilt from the remaining pods; with interned bits that needs the other pods' masks */
   uint64_t ports = 0;
-  for (uint32_t i = 0; i < s->T; i++)
-    if (i != t && s->tasks[i].node == tk->node && s->tasks[i].on_node) ports |= s->tasks[i].port_want;
+  if (s->node_head) {
+    for (uint32_t i = s->node_head[tk->node]; i != KB_NONE; i = s->next_on_node[i]) if (i != t) ports |= s->tasks[i].port_want;
+  } else {
+    for (uint32_t i = 0; i < s->T; i++)
+      if (i != t && s->tasks[i].node == tk->node && s->tasks[i].on_node) ports |= s->tasks[i].port_want;
+  }
   nd->ports = (nd->ports & ~tk->port_want) | ports | nd->base_ports;
+  node_index_unlink(s, t);
   tk->on_node = 0;
 }
 /* NodeInfo.AddTask (api/node_info.go:172-212) for a task whose session status is already `status` */
@@ -1189,6 +1220,7 @@ static int node_add_task(kbo_session *s, uint32_t t, uint32_t n, int status) {
   tk->node = n;
   tk->node_status = (uint8_t)status;
   tk->on_node = 1;
+  node_index_link(s, t, n);
   nd->pod_cnt += 1;
   nd->nz_cpu += tk->nz_cpu;
   nd->nz_mem += tk->nz_mem;
@@ -1328,6 +1360,12 @@ static size_t ssn_evictable(kbo_session *s, uint32_t preemptor, const uint32_t *
   return nv;
 }
 static int victim_less(void *ctx, uint32_t l, uint32_t r) { return !task_order_less(ctx, l, r); }   /* preempt.go:223-225 */
+static const double *g_sort_score;
+static int sort_nodes_cmp(const void *a, const void *b) {
+  const uint32_t x = *(const uint32_t *)a, y = *(const uint32_t *)b;
+  if (g_sort_score[x] != g_sort_score[y]) return g_sort_score[x] > g_sort_score[y] ? -1 : 1;
+  return x > y ? -1 : (x < y ? 1 : 0);
+}
 /* preempt(): preempt.go:171-254.  mode 0: victims are Running tasks of OTHER jobs in the preemptor job's queue; mode 1: of the same job */
 static int preempt_one(kbo_session *s, stmt_t *st, uint32_t preemptor, int mode, uint8_t *feas, double *score, uint32_t *order) {
   o_task *pt = &s->tasks[preemptor];
@@ -1336,27 +1374,24 @@ static int preempt_one(kbo_session *s, stmt_t *st, uint32_t preemptor, int mode,
   s->evals += s->N;
   uint32_t nf = 0;
   for (uint32_t n = 0; n < s->N; n++) if (feas[n]) order[nf++] = n;
-  /* SortNodes: descending score, ties by descending host name (= descending canonical index): insertion into a sorted prefix */
-  for (uint32_t i = 1; i < nf; i++) {
-    uint32_t x = order[i];
-    uint32_t k = i;
-    while (k > 0 && (score[order[k - 1]] < score[x] || (score[order[k - 1]] == score[x] && order[k - 1] < x))) { order[k] = order[k - 1]; k--; }
-    order[k] = x;
-  }
+  /* SortNodes: descending score, ties by descending host name (= descending canonical index); a strict total order, so any
+     comparison sort yields the one sequence */
+  g_sort_score = score;
+  qsort(order, nf, sizeof(uint32_t), sort_nodes_cmp);
   uint32_t *pre = (uint32_t *)malloc(sizeof(uint32_t) * (s->T ? s->T : 1));
   uint32_t *vic = (uint32_t *)malloc(sizeof(uint32_t) * (s->T ? s->T : 1));
   int assigned = 0;
   for (uint32_t oi = 0; oi < nf && !assigned; oi++) {
     const uint32_t n = order[oi];
     size_t np_ = 0;
-    for (uint32_t t = 0; t < s->T; t++) {      /* node.Tasks in canonical order, filtered (preempt.go:112-124 / :150-157) */
+    for (uint32_t t = s->node_head[n]; t != KB_NONE; t = s->next_on_node[t]) {   /* node.Tasks, filtered (preempt.go:112-124 / :150-157) */
       const o_task *tk = &s->tasks[t];
-      if (!tk->on_node || tk->node != n) continue;
       if (tk->node_status != KB_TASK_RUNNING) continue;
       if (mode == 0) { if (!(s->jobs[tk->job].queue == pj->queue && tk->job != pt->job)) continue; }
       else if (tk->job != pt->job) continue;
       pre[np_++] = t;
     }
+    qsort(pre, np_, sizeof(uint32_t), cmp_u32);   /* canonical order: ascending task index */
     size_t nv = ssn_evictable(s, preemptor, pre, np_, vic, 0);
     if (nv == 0) continue;                     /* validateVictims: "no victims" */
     kbo_res all; res_zero(&all);
@@ -1382,9 +1417,10 @@ static int preempt_one(kbo_session *s, stmt_t *st, uint32_t preemptor, int mode,
 }
 int kbo_preempt(kbo_session *s) {
   if (s->panic) return KBO_PANIC;
+  node_index_build(s);
   for (uint32_t n = 0; n < s->N; n++) {        /* ports of pods outside the session stay on the node whatever moves */
     uint64_t mine = 0;
-    for (uint32_t t = 0; t < s->T; t++) if (s->tasks[t].on_node && s->tasks[t].node == n) mine |= s->tasks[t].port_want;
+    for (uint32_t t = s->node_head[n]; t != KB_NONE; t = s->next_on_node[t]) mine |= s->tasks[t].port_want;
     s->nodes[n].base_ports = s->nodes[n].ports & ~mine;
   }
   uint8_t *feas = (uint8_t *)malloc(s->N ? s->N : 1);
@@ -1439,6 +1475,8 @@ int kbo_preempt(kbo_session *s) {
   for (uint32_t q = 0; q < s->Q; q++) heap_free(&qjobs[q]);
   for (uint32_t j = 0; j < s->J; j++) heap_free(&jtasks[j]);
   free(qjobs); free(jtasks); free(qseen); free(under); free(st.ops); free(feas); free(score); free(order);
+  free(s->node_head); free(s->next_on_node); free(s->prev_on_node);
+  s->node_head = s->next_on_node = s->prev_on_node = NULL;   /* the other actions add tasks without the index */
   return s->panic ? KBO_PANIC : 0;
 }
 /* ================================================================================================

@@ -119,7 +119,7 @@ def test_preempt_on_random_clusters(oracle_mod, seed):
     _run_both(oracle_mod, cfg, snap, order, seed)
 
 
-@pytest.mark.parametrize("scale,idx", [(0.02, 3), (0.05, 3), (0.01, 4), (0.002, 5)])
+@pytest.mark.parametrize("scale,idx", [(0.02, 3), (0.05, 3), (0.01, 4), (0.002, 5), (0.05, 5)])
 def test_preempt_after_allocate_on_scaled_baseline_configs(oracle_mod, scale, idx):
     """BASELINE configs[4] names allocate + backfill + preempt: the three actions in that order on scaled snapshots."""
     snap = kbm.snapshot.synth(kbm.snapshot.synth_config(idx, scale))
