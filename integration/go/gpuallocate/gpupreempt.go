@@ -1,0 +1,110 @@
+// gpupreempt.go — the preempt action on the engine (SOURCE ONLY, like gpuallocate.go: no Go toolchain in the build image; the
+// identical C ABI is exercised through kube-batch_amd/engine.py and tests/test_gpu_preempt.py).
+//
+// Replaces the Execute body of pkg/scheduler/actions/preempt/preempt.go:45-168: flatten the Session as it stands (statuses
+// Allocated / Pipelined / Releasing of this cycle's earlier actions included), run kb_run_preempt, replay the journal through
+// framework.Statement — Evict / Pipeline / Commit / Discard in the engine's order, discarded statements too (their Pipeline
+// leaves the sticky NodeName behind exactly as in the reference: statement.go:155-190, api/node_info.go:217-243).
+package gpuallocate
+
+/*
+#include <stdlib.h>
+#include "kb_engine.h"
+*/
+import "C"
+
+import (
+	"runtime"
+	"unsafe"
+
+	"github.com/golang/glog"
+
+	"github.com/kubernetes-sigs/kube-batch/pkg/scheduler/actions/preempt"
+	"github.com/kubernetes-sigs/kube-batch/pkg/scheduler/api"
+	"github.com/kubernetes-sigs/kube-batch/pkg/scheduler/framework"
+)
+
+type gpuPreemptAction struct {
+	alloc    *gpuAllocateAction // shares the engine (one per process) and ensureEngine
+	fallback framework.Action   // the stock preempt action
+}
+
+// NewPreempt registers next to gpuallocate.New(): framework.RegisterAction(gpuallocate.NewPreempt(a)) with the same *gpuAllocateAction
+func NewPreempt(a *gpuAllocateAction) *gpuPreemptAction {
+	return &gpuPreemptAction{alloc: a, fallback: preempt.New()}
+}
+
+func (p *gpuPreemptAction) Name() string  { return "gpupreempt" } // or "preempt" to override the stock action
+func (p *gpuPreemptAction) Initialize()   {}
+func (p *gpuPreemptAction) UnInitialize() {}
+
+func (p *gpuPreemptAction) Execute(ssn *framework.Session) {
+	runtime.LockOSThread()
+	defer runtime.UnlockOSThread()
+
+	if err := p.alloc.ensureEngine(ssn); err != nil {
+		glog.Warningf("gpupreempt: %v; falling back to the stock preempt action", err)
+		p.fallback.Execute(ssn)
+		return
+	}
+	fl, err := flatten(ssn)
+	if err != nil {
+		glog.V(3).Infof("gpupreempt: %v; stock action takes this cycle", err)
+		p.fallback.Execute(ssn)
+		return
+	}
+	defer fl.free()
+	if len(fl.tasks) == 0 {
+		return
+	}
+	if rc := C.kb_session_load(p.alloc.engine, &fl.snap); rc != C.KB_OK {
+		glog.Warningf("gpupreempt: load rc=%d (%s); stock action takes this cycle", rc, C.GoString(C.kb_last_error(p.alloc.engine)))
+		p.fallback.Execute(ssn)
+		return
+	}
+	// the journal lives in C memory; at most one Evict per running task, one Pipeline per pending task, two markers per statement
+	capOps := C.size_t(4*len(fl.tasks) + 16)
+	ops := (*C.kb_stmt_op)(C.calloc(capOps, C.size_t(unsafe.Sizeof(C.kb_stmt_op{}))))
+	if ops == nil {
+		p.fallback.Execute(ssn)
+		return
+	}
+	defer C.free(unsafe.Pointer(ops))
+	var n C.uint64_t
+	if rc := C.kb_run_preempt(p.alloc.engine, ops, C.uint64_t(capOps), &n); rc != C.KB_OK { // nothing was applied: the stock action is still valid
+		glog.Warningf("gpupreempt: run rc=%d (%s); stock action takes this cycle", rc, C.GoString(C.kb_last_error(p.alloc.engine)))
+		p.fallback.Execute(ssn)
+		return
+	}
+	journal := (*[1 << 28]C.kb_stmt_op)(unsafe.Pointer(ops))[:int(n):int(n)]
+
+	var stmt *framework.Statement
+	cur := C.uint32_t(0)
+	for i := range journal {
+		op := journal[i]
+		if op.stmt != cur { // preempt.go:93 / :153: stmt := ssn.Statement()
+			stmt = ssn.Statement()
+			cur = op.stmt
+		}
+		switch op.op {
+		case C.KB_OP_EVICT: // preempt.go:232: the preemptee is the node's own clone of the task (preempt.go:203-209)
+			node := fl.nodes[op.node]
+			victim, found := node.Tasks[api.PodKey(fl.tasks[op.task].Pod)]
+			if !found {
+				glog.Errorf("gpupreempt: victim %s is not on node %s any more", fl.tasks[op.task].UID, node.Name)
+				continue
+			}
+			if err := stmt.Evict(victim.Clone(), "preempt"); err != nil {
+				glog.Errorf("gpupreempt: evict %s: %v", victim.UID, err)
+			}
+		case C.KB_OP_PIPELINE: // preempt.go:248
+			if err := stmt.Pipeline(fl.tasks[op.task], fl.nodes[op.node].Name); err != nil {
+				glog.Errorf("gpupreempt: pipeline %s on %s: %v", fl.tasks[op.task].UID, fl.nodes[op.node].Name, err)
+			}
+		case C.KB_OP_COMMIT: // preempt.go:124 / :162
+			stmt.Commit()
+		case C.KB_OP_DISCARD: // preempt.go:131
+			stmt.Discard()
+		}
+	}
+}

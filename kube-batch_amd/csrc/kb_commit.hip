@@ -182,7 +182,7 @@ __device__ __forceinline__ uint32_t k9_eval_v(const KbCommitArgs &a, const K9Sha
   return ((score + 1u) << nb) | (nmaskbits - v.node);
 }
 
-__global__ void __launch_bounds__(K9_THREADS) k_commit(const K9KernArgs ka) {
+__global__ void __launch_bounds__(K9_THREADS) k_commit_run(const K9KernArgs ka) {
   KbCommitArgs a = ka.hot;
   {   // only `a` is named in the loops (SGPRs); the two views are read through the kernel-argument segment on rare paths
     const unsigned char __attribute__((address_space(4))) *kp = (const unsigned char __attribute__((address_space(4))) *)__builtin_amdgcn_kernarg_segment_ptr();
@@ -678,7 +678,7 @@ void kb_launch_commit(const KbDev &d, const KbRound &r, void *stream) {
   if (r.n_rows == 0) return;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_commit), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_commit_run), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
   const size_t sh = k9_layout(r.n_rows, r.n_mrows, r.L, d.NP, d.R).total;
@@ -700,5 +700,5 @@ void kb_launch_commit(const KbDev &d, const KbRound &r, void *stream) {
   a.host_out = r.host_out;
   a.seq = r.seq;
   a.node_bits = kb_node_bits(d.NP);
-  hipLaunchKernelGGL(k_commit, dim3(1), dim3(K9_THREADS), sh, (hipStream_t)stream, ka);
+  hipLaunchKernelGGL(k_commit_run, dim3(1), dim3(K9_THREADS), sh, (hipStream_t)stream, ka);
 }

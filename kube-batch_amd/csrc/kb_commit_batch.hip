@@ -346,7 +346,7 @@ struct K7KernArgs {
   KbRound round;
 };
 
-__global__ void __launch_bounds__(KB_K5_THREADS) k_commit(const K7KernArgs ka) {
+__global__ void __launch_bounds__(KB_K5_THREADS) k_commit_batch(const K7KernArgs ka) {
   KbCommitArgs a = ka.hot;
   {
     const unsigned char __attribute__((address_space(4))) *kp = (const unsigned char __attribute__((address_space(4))) *)__builtin_amdgcn_kernarg_segment_ptr();
@@ -882,7 +882,7 @@ void kb_launch_commit_batch(const KbDev &d, const KbRound &r, void *stream) {
   static bool attr_set = false;
   static uint32_t env_batch = 0;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_commit), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_commit_batch), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     const char *b = getenv("KB_K5_BATCH");   // tuning override of kb_config.commit_batch
     env_batch = b ? (uint32_t)atoi(b) : 0;
     attr_set = true;
@@ -908,5 +908,5 @@ void kb_launch_commit_batch(const KbDev &d, const KbRound &r, void *stream) {
   a.T = d.T; a.node_bits = 0;
   a.host_out = r.host_out;
   a.seq = r.seq;
-  hipLaunchKernelGGL(k_commit, dim3(1), dim3(KB_K5_THREADS), sh, (hipStream_t)stream, ka);
+  hipLaunchKernelGGL(k_commit_batch, dim3(1), dim3(KB_K5_THREADS), sh, (hipStream_t)stream, ka);
 }
