@@ -83,7 +83,10 @@ def main():
         sys.exit(2)
     local_rank %= torch.cuda.device_count()      # a launcher that masks devices per rank leaves ordinal 0 only
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    # KB_BENCH_SHARDED=1 (under torch.distributed.run with one process): the multi-GPU code path — round-granular engine calls,
+    # RCCL collectives on the engine's stream — on a one-GPU box, with KB_DIST_ALWAYS_COLLECT=1 the collectives really run
+    force_sharded = world == 1 and os.environ.get("KB_BENCH_SHARDED") == "1" and "MASTER_ADDR" in os.environ
+    if world > 1 or force_sharded:
         import torch.distributed as dist
         dist.init_process_group("nccl")
 
@@ -98,7 +101,7 @@ def main():
     snap = kbm.snapshot.synth(params)
     actions = ["allocate", "backfill"]
 
-    if world > 1:
+    if world > 1 or force_sharded:
         distmod = importlib.import_module("kube-batch_amd.dist")
         runner = distmod.ShardedCycle(conf, snap, device=local_rank, window=args.window, commit_batch=args.commit_batch)
         step = runner.step
@@ -116,7 +119,7 @@ def main():
             for a in actions:
                 getattr(eng, "run_" + a)()
 
-    if world > 1:
+    if world > 1 or force_sharded:
         load_ms = None
 
     def barrier():
@@ -264,7 +267,7 @@ def main():
         out["verified_evals_equal_oracle"] = bool(o.evals == out["evals_per_step"])
     if rank == 0:
         print(json.dumps(out))
-    if world > 1:
+    if world > 1 or force_sharded:
         dist.destroy_process_group()
 
 

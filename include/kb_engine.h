@@ -304,6 +304,10 @@ int  kb_get_stats(kb_engine *e, kb_stats *out);
  *   kb_round_apply      -> node state for the next round := round-start state + reduced deltas; KB_E_INTERNAL if that
  *                          differs from the replica's own commit (replicas diverged)
  */
+/* run the engine's kernels on the caller's HIP stream (e.g. the stream its RCCL collectives are ordered on) instead of the
+   engine's own: launches, collectives and the delta kernel are then ordered by the stream alone, with no host synchronisation
+   between them.  0 restores the engine's own stream.  The caller keeps the stream alive. */
+int  kb_engine_use_stream(kb_engine *e, uint64_t hip_stream);
 int  kb_round_begin(kb_engine *e, uint32_t action /*0 allocate, 1 backfill*/, uint32_t *n_rows, uint32_t *n_mrows, uint32_t *list_len);
 int  kb_round_candidates(kb_engine *e, uint32_t mrow0, uint32_t mrow1, uint64_t dev_keys_ptr);
 int  kb_round_commit(kb_engine *e, uint64_t dev_all_keys_ptr, uint32_t own_row0, uint32_t own_row1, uint64_t dev_delta_ptr);

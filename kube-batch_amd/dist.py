@@ -75,22 +75,30 @@ class ShardedCycle:
         self.buf_dev = buffer_device or torch.device("cpu")
         # collectives on device buffers only with a device-capable backend (RCCL); otherwise stage through host memory
         self.stage_host = (not dist.is_initialized()) or dist.get_backend() != "nccl"
+        # RCCL: the engine launches on torch's current stream, the stream the collectives are ordered on, so a round needs no host
+        # synchronisation between its kernels and its collectives (the commit result still arrives through the pinned mailbox)
+        self.stream_ordered = (not self.stage_host) and self.engine is not None and buffer_device is not None and buffer_device.type == "cuda"
+        if self.stream_ordered:
+            self.engine.use_stream(torch.cuda.current_stream(buffer_device).cuda_stream)
         self.delta = torch.zeros(backend.delta_len, dtype=torch.float64, device=self.buf_dev)
         self.rounds = 0
         self.replicated_rounds = 0
+        # a single-rank group still goes through the collectives when asked to (exercises the RCCL path on a one-GPU box)
+        import os as _os
+        self.always_collect = dist.is_initialized() and _os.environ.get("KB_DIST_ALWAYS_COLLECT") == "1"
         # shard a round's matrix rows only when every rank gets at least this many (0 = always shard)
         self.min_rows_per_rank = min_rows_per_rank
 
     def _sync_torch(self):
         """The engine runs on its own non-blocking HIP stream: torch's fill kernels must have finished before the engine
         writes into a freshly zeroed buffer."""
-        if self.buf_dev.type == "cuda":
+        if self.buf_dev.type == "cuda" and not self.stream_ordered:
             torch.cuda.current_stream().synchronize()
 
     # ---- collectives
     def _all_gather_keys(self, local: torch.Tensor, chunk: int, L: int) -> torch.Tensor:
         full = torch.empty((chunk * self.world, L), dtype=torch.int64, device=local.device)
-        if self.world == 1:
+        if self.world == 1 and not self.always_collect:
             full.copy_(local)
             return full
         if self.stage_host and local.device.type != "cpu":
@@ -100,12 +108,12 @@ class ShardedCycle:
             full.copy_(h_full)
         else:
             dist.all_gather_into_tensor(full, local)
-            if full.device.type == "cuda":
+            if full.device.type == "cuda" and not self.stream_ordered:
                 torch.cuda.current_stream().synchronize()   # the engine's kernels run on their own stream
         return full
 
     def _all_reduce_delta(self):
-        if self.world == 1:
+        if self.world == 1 and not self.always_collect:
             return
         if self.stage_host and self.delta.device.type != "cpu":
             h = self.delta.cpu()
@@ -113,7 +121,7 @@ class ShardedCycle:
             self.delta.copy_(h)
         else:
             dist.all_reduce(self.delta, op=dist.ReduceOp.SUM)
-            if self.delta.device.type == "cuda":
+            if self.delta.device.type == "cuda" and not self.stream_ordered:
                 torch.cuda.current_stream().synchronize()
 
     # ---- one action

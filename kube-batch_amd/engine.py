@@ -17,7 +17,7 @@ LIB_PATH = os.environ.get("KB_ENGINE_LIB") or os.path.join(_HERE, "libkbengine.s
 _LIB = None
 
 EXPORTS = ["kb_engine_create", "kb_engine_destroy", "kb_last_error", "kb_session_load", "kb_session_reset", "kb_run_allocate",
-           "kb_run_backfill", "kb_run_preempt", "kb_get_evictions", "kb_eval_matrix", "kb_argmax_rows", "kb_bench_matrix", "kb_get_binds",
+           "kb_run_backfill", "kb_run_preempt", "kb_get_evictions", "kb_engine_use_stream", "kb_eval_matrix", "kb_argmax_rows", "kb_bench_matrix", "kb_get_binds",
            "kb_get_task_state", "kb_get_node_state", "kb_get_shares", "kb_get_stats", "kb_round_begin",
            "kb_round_candidates", "kb_round_commit", "kb_round_apply", "kb_round_delta_doubles",
            "kb_round_decisions"]
@@ -64,6 +64,7 @@ def lib():
                                         C.POINTER(C.c_int64), C.POINTER(C.c_int32)]
         L.kb_get_shares.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]
         L.kb_get_stats.argtypes = [vp, C.POINTER(abi.Stats)]
+        L.kb_engine_use_stream.argtypes = [vp, C.c_uint64]
         L.kb_round_begin.argtypes = [vp, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
         L.kb_round_candidates.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint64]
         L.kb_round_commit.argtypes = [vp, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint64]
@@ -202,6 +203,10 @@ class Engine:
         return st.as_dict()
 
     # ---- round-granular API (task-row sharding across GPUs; see kube-batch_amd/dist.py)
+    def use_stream(self, hip_stream: int):
+        """Run the engine's kernels on the caller's HIP stream (0: back to the engine's own)."""
+        self._ck(self.L.kb_engine_use_stream(self.h, int(hip_stream)))
+
     def round_begin(self, action: int):
         n, m, l = C.c_uint32(), C.c_uint32(), C.c_uint32()
         self._ck(self.L.kb_round_begin(self.h, action, C.byref(n), C.byref(m), C.byref(l)))
