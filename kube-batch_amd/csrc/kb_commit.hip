@@ -700,6 +700,5 @@ void kb_launch_commit(const KbDev &d, const KbRound &r, void *stream) {
   a.host_out = r.host_out;
   a.seq = r.seq;
   a.node_bits = kb_node_bits(d.NP);
-  a.pre_dirty = nullptr; a.n_pre = 0; a.dirty_out = nullptr;   // the run kernel takes fresh lists only
   hipLaunchKernelGGL(k_commit_run, dim3(1), dim3(K9_THREADS), sh, (hipStream_t)stream, ka);
 }

@@ -421,27 +421,8 @@ __global__ void __launch_bounds__(KB_K5_THREADS) k_commit_batch(const K7KernArgs
     if (acc == 0x123456789abcdefull) H.pad = 1;   // keep the loads alive
   }
   __syncthreads();
-  // ---- one-round-stale lists: the nodes the previous round changed start out as dirty slots holding their live state
-  for (uint32_t w = tid; w < a.n_pre * 16; w += KB_K5_THREADS) {
-    const uint32_t slot = w >> 4, f = w & 15;
-    const uint32_t n = a.pre_dirty[slot];
-    unsigned long long v8 = 0ull;
-    uint32_t v4 = 0;
-    if (f < K5_NF8) v8 = g8[n];
-    else if (f <= 12) v4 = g4[n];
-    if (f < K5_NF8) M.tab[(size_t)f * cap2 + slot] = v8;
-    const uint32_t nxt = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v4, 0x101, 0xf, 0xf, true);   // row_shl:1: lane 11 <- pods
-    if (f == 10) M.t_cls[slot] = v4;
-    else if (f == 11) M.t_left[slot] = (int)v4 - (int)nxt;
-    else if (f == 13) {
-      M.t_node[slot] = n;
-      if (a.has_ports) M.ptab[slot] = a.dev->ports[n];
-      atomicOr(&M.bitmap[n >> 5], 1u << (n & 31));
-    }
-  }
-  __syncthreads();
 
-  uint32_t i0 = 0, nd = a.n_pre, n_done = 0, reason = KB_REASON_DONE, dbase = 0, dcnt = 0, nb_cur = a.batch;
+  uint32_t i0 = 0, nd = 0, n_done = 0, reason = KB_REASON_DONE, dbase = 0, dcnt = 0, nb_cur = a.batch;
   while (i0 < a.n_rows) {
     uint32_t nb = min(nb_cur, a.n_rows - i0);
     // ---- stage row descriptors: three batches' worth per refill, so most batches find theirs already in LDS
@@ -458,7 +439,7 @@ __global__ void __launch_bounds__(KB_K5_THREADS) k_commit_batch(const K7KernArgs
       // a row whose score is normalised over its feasible set (preferred node affinity) is exact only against a fresh matrix:
       // it may be the first row of a round, nothing else; the batch stops in front of it and the round ends there
       uint32_t ja = nb;
-      for (uint32_t j = (i0 == 0 && a.n_pre == 0) ? 1u : 0u; j < nb; j++)
+      for (uint32_t j = (i0 == 0) ? 1u : 0u; j < nb; j++)
         if (bd[j].flags & 2) { ja = j; break; }
       if (ja == 0) { reason = KB_REASON_RENORM; n_done = i0; break; }
       nb = ja;
@@ -874,21 +855,8 @@ __global__ void __launch_bounds__(KB_K5_THREADS) k_commit_batch(const K7KernArgs
       if (!dc.y) d.j_allocated[d.t_job[t]] = 1;   // ssn.Allocate ran for the job: its Allocated tasks are dispatched if it is ready
     }
   }
-  // the nodes this round changed (for a successor running on one-round-stale lists): every new slot, and the pre-seeded slots a
-  // dirty row landed on (the dirty log; a slot may be logged more than once)
-  if (a.dirty_out) {
-    __syncthreads();
-    if (tid == 0) H.pad = 0;
-    for (uint32_t k = tid; k < a.n_pre; k += KB_K5_THREADS) M.qstamp[k] = 0;   // reused as "pre-seeded slot k was changed"
-    __syncthreads();
-    for (uint32_t k = tid; k < H.nlog; k += KB_K5_THREADS) { const uint32_t xs = M.dlog[k]; if (xs < a.n_pre) M.qstamp[xs] = 1; }
-    __syncthreads();
-    for (uint32_t k = tid; k < nd; k += KB_K5_THREADS)
-      if (k >= a.n_pre || M.qstamp[k]) a.dirty_out[atomicAdd(&H.pad, 1u)] = M.t_node[k];
-    __syncthreads();
-  }
   if (tid == 0) {
-    a.result[0] = n_done; a.result[1] = reason; a.result[2] = nd; a.result[4] = H.n_refills; a.result[7] = a.dirty_out ? H.pad : 0u; a.result[3] = H.n_seq_rows;
+    a.result[0] = n_done; a.result[1] = reason; a.result[2] = nd; a.result[4] = H.n_refills; a.result[7] = H.n_full; a.result[3] = H.n_seq_rows;
     a.result[5] = H.n_batches; a.result[6] = H.n_dirty_rows;
     unsigned long long *st = reinterpret_cast<unsigned long long *>(a.result) + KB_OUT_STAMP0;
     st[2] = t_start;
@@ -921,9 +889,7 @@ void kb_launch_commit_batch(const KbDev &d, const KbRound &r, void *stream) {
   }
   uint32_t batch = env_batch ? env_batch : (r.batch ? r.batch : K7_B_DEFAULT);
   if (batch > K7_B) batch = K7_B;
-  // The whole LDS of the CU: no workgroup of another kernel (the successor's K1 / K3 on the second stream) can be co-scheduled
-  // next to this latency-bound one and share its SIMDs
-  const size_t sh = r.dirty_out ? (size_t)160 * 1024 : k7_smem_bytes(r.cap, d.NP, d.R);
+  const size_t sh = k7_smem_bytes(r.cap, d.NP, d.R);
   K7KernArgs ka;
   ka.dev = d;
   ka.round = r;
@@ -940,7 +906,6 @@ void kb_launch_commit_batch(const KbDev &d, const KbRound &r, void *stream) {
   a.R = d.R;
   a.batch = batch;
   a.T = d.T; a.node_bits = 0;
-  a.pre_dirty = r.pre_dirty; a.n_pre = r.n_pre; a.dirty_out = r.dirty_out;
   a.host_out = r.host_out;
   a.seq = r.seq;
   hipLaunchKernelGGL(k_commit_batch, dim3(1), dim3(KB_K5_THREADS), sh, (hipStream_t)stream, ka);

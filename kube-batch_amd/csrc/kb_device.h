@@ -112,11 +112,6 @@ struct KbRound {
   unsigned long long seq;
   double *delta;               // optional per-node committed deltas of owned rows [NP*(2R+3)] (multi-GPU), may be nullptr
   uint32_t own_row0, own_row1;
-  // lists that are ONE ROUND STALE (built from the node state at the start of the previous round, while that round's commit was
-  // still running): the nodes the previous round changed enter this round as dirty slots, with their live state
-  const uint32_t *pre_dirty;   // [n_pre] nodes changed by the previous round
-  uint32_t n_pre;
-  uint32_t *dirty_out;         // [n_rows] out: nodes this round changed (count in result[7])
 };
 
 // Hot arguments of the commit kernel: the ~25 scalars its loops touch (they live in SGPRs).  The full session / round
@@ -138,9 +133,6 @@ struct KbCommitArgs {
   unsigned long long *host_out;   // pinned host mirror of the output block (fast rounds), or nullptr
   unsigned long long seq;         // sequence number published last into host_out[KB_OUT_SEQ]
   uint32_t node_bits;             // width of the node field of the commit kernel's 32-bit keys (kb_node_bits)
-  const uint32_t *pre_dirty;      // see KbRound
-  uint32_t n_pre;
-  uint32_t *dirty_out;
 };
 
 // 32-bit keys of the commit kernel: (score + 1) << node_bits | (2^node_bits - 1 - node); needs (max score + 2) << node_bits <= 2^32
@@ -175,8 +167,6 @@ enum { KB_REASON_DONE = 0, KB_REASON_NO_FEASIBLE = 1, KB_REASON_PIPELINED = 2, K
 
 // launch wrappers (kb_kernels.hip); all asynchronous on `stream`
 void kb_launch_gather(const KbDev &d, const KbRound &r, void *stream);
-void kb_launch_snapshot(const KbDev &d, double *s_idle, double *s_rel, long long *s_nzc, long long *s_nzm, int *s_podcnt,
-                        unsigned long long *s_ports, void *stream);
 void kb_launch_matrix(const KbDev &d, const KbRound &r, void *stream);
 // NodeAffinity Map + NormalizeReduce + weight added to the score rows of the matrix (no-op without affinity terms)
 void kb_launch_affinity(const KbDev &d, const KbRound &r, void *stream);

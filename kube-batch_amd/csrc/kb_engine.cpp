@@ -161,23 +161,6 @@ struct kb_engine {
   unsigned long long seq = 0;
   double wall_khz = 100000.0;         // rate of the device's constant wall clock
   std::vector<uint8_t> h_same;
-  // ---- one-round-stale candidate lists: while the commit of window k runs on one CU, K1 + K3 for window k+1
-  // run on the other 255 from a copy of the node state taken at the start of round k; round k+1's commit then starts with
-  // the nodes round k changed as dirty slots.  A second set of round buffers (swapped in when the window is promoted), a
-  // second stream, and the state copy.
-  struct NextBufs {
-    DevBuf b_win, b_desc, b_score, b_maskw, b_keys, b_out;
-    Pinned<uint32_t> h_win;
-    std::vector<uint32_t> rows, slot, mrows;
-    uint32_t desc_cap = 0, mat_cap = 0, n = 0, ns = 0, L = 0;
-    size_t keys_cap = 0;
-  } nx;
-  DevBuf b_dirty[2];                 // nodes changed by the last / the running round
-  DevBuf s_idle, s_rel, s_nzc, s_nzm, s_podcnt, s_ports;   // node state as of the start of the running round
-  hipStream_t stream2 = nullptr;
-  hipEvent_t ev_snap = nullptr, ev_cand = nullptr, ev_k1a = nullptr, ev_k1b = nullptr, ev_k3b = nullptr;
-  bool stale_ok = false;             // the session qualifies (single GPU fast rounds, no NormalizeReduce rows, LDS room for 2 windows of slots)
-  uint64_t rounds_stale = 0, rounds_stale_wasted = 0;
   std::vector<uint32_t> shape_stamp, shape_slot_of;   // per row-shape id: round stamp and slot inside the current round
   uint32_t stamp = 0;
   uint32_t *h_result = nullptr;   // the header words of h_out
@@ -192,8 +175,6 @@ struct kb_engine {
     mg_free(mg);
     for (auto &t : ev) t.destroy();
     if (own_stream) (void)hipStreamDestroy(own_stream);
-    if (stream2) (void)hipStreamDestroy(stream2);
-    for (hipEvent_t ev : {ev_snap, ev_cand, ev_k1a, ev_k1b, ev_k3b}) if (ev) (void)hipEventDestroy(ev);
   }
 };
 
@@ -372,9 +353,6 @@ KbRound make_round(kb_engine *e, uint32_t n_rows, uint32_t n_mrows, uint32_t L, 
   r.gather = 0;
   r.delta = nullptr;
   r.own_row0 = r.own_row1 = 0;
-  r.pre_dirty = nullptr;
-  r.n_pre = 0;
-  r.dirty_out = nullptr;
   return r;
 }
 
@@ -408,88 +386,6 @@ struct RoundCtx {
   uint32_t n = 0, ns = 0, L = 0;
   bool backfill = false;
 };
-
-// K1 + K3 of the window AFTER the one whose commit is running, on the second stream, from the copy of the node state taken
-// when the running round started; `rows` is the speculated next window
-void prepare_next_window(kb_engine *e, const uint32_t *rows, uint32_t n, uint32_t n_cur) {
-  kb_engine::NextBufs &x = e->nx;
-  HostSession &hs = e->hs;
-  const size_t NP = e->dev.NP;
-  x.rows.assign(rows, rows + n);
-  x.slot.resize(n);
-  x.mrows.resize(n);
-  if (e->shape_stamp.size() != hs.n_row_shapes) { e->shape_stamp.assign(hs.n_row_shapes, 0); e->shape_slot_of.assign(hs.n_row_shapes, 0); e->stamp = 0; }
-  e->stamp++;
-  uint32_t ns = 0;
-  for (uint32_t i = 0; i < n; i++) {
-    const uint32_t sh = hs.t_row_shape[rows[i]];
-    if (e->shape_stamp[sh] != e->stamp) { e->shape_stamp[sh] = e->stamp; e->shape_slot_of[sh] = ns; x.mrows[ns] = rows[i]; ns++; }
-    x.slot[i] = e->shape_slot_of[sh];
-  }
-  const uint32_t L = n + n_cur + 1;   // more candidates than this round and its predecessor can dirty together
-  if (n > x.desc_cap) { x.b_desc.alloc(sizeof(KbRowDesc) * n); x.desc_cap = n; }
-  if (ns > x.mat_cap) {
-    x.b_score.alloc(sizeof(uint16_t) * (size_t)ns * NP);
-    x.b_maskw.alloc(sizeof(uint32_t) * (size_t)ns * (NP / 32));
-    x.mat_cap = ns;
-  }
-  if ((size_t)ns * L > x.keys_cap) { x.b_keys.alloc(sizeof(unsigned long long) * (size_t)ns * L); x.keys_cap = (size_t)ns * L; }
-  std::memcpy(x.h_win.data(), x.rows.data(), sizeof(uint32_t) * n);
-  std::memcpy(x.h_win.data() + KB_K5_MAX_WINDOW, x.slot.data(), sizeof(uint32_t) * n);
-  std::memcpy(x.h_win.data() + 2 * KB_K5_MAX_WINDOW, x.mrows.data(), sizeof(uint32_t) * ns);
-  hipStream_t s2 = e->stream2;
-  HIP_OK(hipStreamWaitEvent(s2, e->ev_snap, 0));
-  HIP_OK(hipMemcpyAsync(x.b_win.p, x.h_win.data(), sizeof(uint32_t) * (2 * KB_K5_MAX_WINDOW + ns), hipMemcpyHostToDevice, s2));
-  KbDev d = e->dev;   // the state the running round started from
-  d.idle = e->s_idle.as<double>(); d.rel = e->s_rel.as<double>(); d.nzc = e->s_nzc.as<long long>(); d.nzm = e->s_nzm.as<long long>();
-  d.podcnt = e->s_podcnt.as<int>();
-  if (d.ports) d.ports = e->s_ports.as<unsigned long long>();
-  KbRound r{};
-  r.rows = x.b_win.as<uint32_t>();
-  r.shape_slot = x.b_win.as<uint32_t>() + KB_K5_MAX_WINDOW;
-  r.n_rows = n;
-  r.desc = x.b_desc.as<KbRowDesc>();
-  r.cap = 0;
-  r.mrows = x.b_win.as<uint32_t>() + 2 * KB_K5_MAX_WINDOW;
-  r.n_mrows = ns;
-  r.fit_mode = 1;
-  r.score = x.b_score.as<uint16_t>();
-  r.maskw = x.b_maskw.as<uint32_t>();
-  r.keys = x.b_keys.as<unsigned long long>();
-  r.L = L;
-  r.result = x.b_out.as<uint32_t>();   // the stamps of these launches must not land in the running round's output block
-  r.gather = 1;
-  HIP_OK(hipEventRecord(e->ev_k1a, s2));
-  kb_launch_matrix(d, r, s2);
-  HIP_OK(hipEventRecord(e->ev_k1b, s2));
-  kb_launch_argmax(d, r, s2);
-  HIP_OK(hipEventRecord(e->ev_k3b, s2));
-  HIP_OK(hipEventRecord(e->ev_cand, s2));
-  x.n = n; x.ns = ns; x.L = L;
-  e->stats.matrix_launches += 1;
-  e->stats.matrix_evals += (uint64_t)ns * hs.N;
-}
-
-// the prepared window becomes the current one: its buffers are swapped in
-RoundCtx adopt_next_window(kb_engine *e) {
-  kb_engine::NextBufs &x = e->nx;
-  auto swap_buf = [](DevBuf &a, DevBuf &b) { std::swap(a.p, b.p); std::swap(a.bytes, b.bytes); };
-  swap_buf(e->b_win, x.b_win); swap_buf(e->b_desc, x.b_desc); swap_buf(e->b_score, x.b_score); swap_buf(e->b_maskw, x.b_maskw); swap_buf(e->b_keys, x.b_keys);
-  std::swap(e->h_win.p, x.h_win.p); std::swap(e->h_win.n, x.h_win.n);
-  {   // capacities travel with the buffers
-    uint32_t wc = e->win_cap, mc = e->mat_cap; size_t kc = e->keys_cap;
-    e->win_cap = std::min<uint32_t>(x.desc_cap, (uint32_t)e->h_rows.size()); e->mat_cap = std::min<uint32_t>(x.mat_cap, (uint32_t)e->h_mrows.size()); e->keys_cap = x.keys_cap;
-    x.desc_cap = wc; x.mat_cap = mc; x.keys_cap = kc;
-  }
-  ensure_window_buffers(e, x.n);
-  std::memcpy(e->h_rows.data(), x.rows.data(), sizeof(uint32_t) * x.n);
-  std::memcpy(e->h_slot.data(), x.slot.data(), sizeof(uint32_t) * x.n);
-  RoundCtx c;
-  c.n = x.n; c.ns = x.ns; c.L = x.L; c.backfill = false;
-  c.d = e->dev;
-  c.r = make_round(e, x.n, x.ns, x.L, 1, false);
-  return c;
-}
 
 // upload the window e->h_rows[0..n) (task ids, shape slots, representative rows) and build the row descriptors
 RoundCtx round_prepare(kb_engine *e, uint32_t n, int fit_mode, bool backfill, bool gather_in_matrix = false) {
@@ -539,17 +435,12 @@ void round_candidates(kb_engine *e, const RoundCtx &c, uint32_t m0, uint32_t m1,
 }
 
 // K5 over the whole window with the complete candidate table `keys` [ns][L]
-void round_commit(kb_engine *e, const RoundCtx &c, unsigned long long *keys, double *delta, uint32_t own0, uint32_t own1,
-                  const uint32_t *pre_dirty = nullptr, uint32_t n_pre = 0, uint32_t *dirty_out = nullptr) {
+void round_commit(kb_engine *e, const RoundCtx &c, unsigned long long *keys, double *delta, uint32_t own0, uint32_t own1) {
   KbRound r = c.r;
   r.keys = keys;
   r.delta = delta;
   r.own_row0 = own0;
   r.own_row1 = own1;
-  r.pre_dirty = pre_dirty;
-  r.n_pre = n_pre;
-  r.dirty_out = dirty_out;
-  if (n_pre) r.cap = std::max<uint32_t>(64, ((c.n + n_pre + 63) / 64) * 64);   // dirty slots of two rounds
   auto launch = [&]() {
     if (e->commit_kernel == KB_COMMIT_RUN) { kb_launch_commit(c.d, r, e->stream); e->rounds_run++; }
     else { kb_launch_commit_batch(c.d, r, e->stream); e->rounds_batch++; }
@@ -904,13 +795,6 @@ int kb_engine_create(const kb_config *cfg, kb_engine **out) {
     HIP_OK(hipSetDevice(cfg->device));
     HIP_OK(hipStreamCreateWithFlags(&eng->own_stream, hipStreamNonBlocking));
     eng->stream = eng->own_stream;
-    HIP_OK(hipStreamCreateWithFlags(&eng->stream2, hipStreamNonBlocking));
-    HIP_OK(hipEventCreateWithFlags(&eng->ev_snap, hipEventDisableTiming));
-    HIP_OK(hipEventCreateWithFlags(&eng->ev_cand, hipEventDisableTiming));
-    HIP_OK(hipEventCreate(&eng->ev_k1a)); HIP_OK(hipEventCreate(&eng->ev_k1b)); HIP_OK(hipEventCreate(&eng->ev_k3b));
-    eng->nx.b_win.alloc(sizeof(uint32_t) * 3 * KB_K5_MAX_WINDOW);
-    eng->nx.h_win.resize(3 * KB_K5_MAX_WINDOW);
-    eng->nx.b_out.alloc(sizeof(unsigned long long) * KB_OUT_HDR);
     eng->b_win.alloc(sizeof(uint32_t) * 3 * KB_K5_MAX_WINDOW);
     eng->h_win.resize(3 * KB_K5_MAX_WINDOW);
     eng->b_out.alloc(sizeof(unsigned long long) * (KB_OUT_HDR + KB_K5_MAX_WINDOW));
@@ -940,9 +824,8 @@ int kb_engine_create(const kb_config *cfg, kb_engine **out) {
 void kb_engine_destroy(kb_engine *e) {
   if (!e) return;
   if (getenv("KB_K5_STATS"))
-    fprintf(stderr, "[kb K5] rounds on the batch kernel %llu, on the run kernel %llu, last dirty share %.3f; rounds on one-round-stale lists %llu, prepared lists wasted %llu\n",
-            (unsigned long long)e->rounds_batch, (unsigned long long)e->rounds_run, e->dirty_share, (unsigned long long)e->rounds_stale,
-            (unsigned long long)e->rounds_stale_wasted);
+    fprintf(stderr, "[kb K5] rounds on the batch kernel %llu, on the run kernel %llu, last dirty share %.3f\n", (unsigned long long)e->rounds_batch,
+            (unsigned long long)e->rounds_run, e->dirty_share);
   if (getenv("KB_K5_STATS"))
     fprintf(stderr, "[kb K5] rounds %llu, rows %llu, dirty slots %llu, dirty-won rows %llu, runs %llu, runs with a row-specific Resreq %llu (%llu)\n",
             (unsigned long long)e->stats.rounds, (unsigned long long)e->stats.decisions, (unsigned long long)e->k5_slots,
@@ -1349,15 +1232,6 @@ int kb_session_load(kb_engine *e, const kb_snapshot *sn) {
     snap_copy(e->p_podcnt, e->b_podcnt); snap_copy(e->p_tstatus, e->b_tstatus); snap_copy(e->p_tnode, e->b_tnode);
     if (d.ports) snap_copy(e->p_ports, e->b_ports);
     snap_copy(e->p_tcounted, e->b_tcounted);
-    {   // one-round-stale lists: state copy, changed-node lists, and the LDS room for two windows' worth of dirty slots
-      snap_copy(e->s_idle, e->b_idle); snap_copy(e->s_rel, e->b_rel); snap_copy(e->s_nzc, e->b_nzc); snap_copy(e->s_nzm, e->b_nzm);
-      snap_copy(e->s_podcnt, e->b_podcnt);
-      if (d.ports) snap_copy(e->s_ports, e->b_ports);
-      for (int k = 0; k < 2; k++) e->b_dirty[k].alloc(sizeof(uint32_t) * 2 * KB_K5_MAX_ROWS);
-      const uint32_t cap2w = std::max<uint32_t>(64, ((2 * e->eff_window + 63) / 64) * 64);
-      static const char *off = getenv("KB_NO_STALE_LISTS");
-      e->stale_ok = e->fast_rounds && !(off && off[0] == '1') && !(d.aff && d.score_enabled) && kb_commit_batch_smem_bytes(cap2w, NP, R) <= 160u * 1024u;
-    }
     // initial drf / proportion / gang aggregates come from the device reduction (K2+K4)
     run_finalize(e);
     e->stats.reduce_ms = 0;
@@ -1401,66 +1275,19 @@ static int run_action(kb_engine *e, uint32_t action, kb_decision *out, uint64_t 
     ActionRun run;
     run.begin(e, action);
     uint32_t n = run.plan(e);
-    // One-round-stale candidate lists (allocate on the batch kernel): while round k commits, the second stream evaluates the
-    // window speculated behind it against the state round k STARTED from; if round k completes, round k+1 starts at once with
-    // those lists and with the nodes round k changed as dirty slots.  A round that breaks the speculation wastes them.
-    const bool stale = action == 0 && e->stale_ok && e->stream == e->own_stream;
-    bool adopted = false;        // the current window's candidates came from the second stream
-    bool pending_b = false;      // stream 2 holds work this stream has not waited for yet
-    uint32_t n_pre = 0, dset = 0;
-    RoundCtx c;
     while (n) {
       uint32_t n_done = 0, reason = 0;
-      if (!adopted) {
-        if (pending_b) { HIP_OK(hipStreamWaitEvent(e->stream, e->ev_cand, 0)); pending_b = false; }   // the state copy is about to be overwritten
-        c = round_prepare(e, n, action == 0 ? 1 : 0, action == 1, true);   // single GPU: every matrix row is local
-        round_candidates(e, c, 0, c.ns, e->b_keys.as<unsigned long long>());
-        n_pre = 0;
-      }
-      const bool may_prepare = stale && e->commit_kernel == KB_COMMIT_BATCH;
-      if (may_prepare) {   // the state this round starts from, for the successor's lists
-        kb_launch_snapshot(e->dev, e->s_idle.as<double>(), e->s_rel.as<double>(), e->s_nzc.as<long long>(), e->s_nzm.as<long long>(),
-                           e->s_podcnt.as<int>(), e->dev.ports ? e->s_ports.as<unsigned long long>() : nullptr, e->stream);
-        HIP_OK(hipEventRecord(e->ev_snap, e->stream));
-      }
-      round_commit(e, c, e->b_keys.as<unsigned long long>(), nullptr, 0, 0, n_pre ? e->b_dirty[dset ^ 1].as<uint32_t>() : nullptr, n_pre,
-                   may_prepare ? e->b_dirty[dset].as<uint32_t>() : nullptr);
-      const bool was_adopted = adopted;
-      if (adopted) e->rounds_stale++;
+      RoundCtx c = round_prepare(e, n, action == 0 ? 1 : 0, action == 1, true);   // single GPU: every matrix row is local
+      round_candidates(e, c, 0, c.ns, e->b_keys.as<unsigned long long>());
+      round_commit(e, c, e->b_keys.as<unsigned long long>(), nullptr, 0, 0);
       // fast rounds return from the launch immediately: use the wait to speculate the next window
       const bool ahead = action == 0 && e->fast_rounds;
       const uint32_t n_next = ahead ? run.plan_ahead(e) : 0;
-      bool prepared = false;
-      if (may_prepare && n_next) {
-        prepare_next_window(e, run.rows_next.data(), n_next, n);
-        prepared = pending_b = true;
-      }
-      round_collect(e, c, !was_adopted, n_done, reason);
-      const uint32_t n_mod = e->h_result[7];
+      round_collect(e, c, true, n_done, reason);
       run.absorb(e, n, n_done, reason);
-      adopted = false;
-      if (ahead && reason == KB_REASON_DONE) {
-        run.promote(e, n_next);
-        n = n_next;
-        if (prepared && n_next && e->commit_kernel == KB_COMMIT_BATCH) {   // (the kernel choice may just have flipped)
-          HIP_OK(hipStreamWaitEvent(e->stream, e->ev_cand, 0));
-          pending_b = false;
-          c = adopt_next_window(e);
-          adopted = true;
-          n_pre = n_mod;
-          dset ^= 1;
-          float ms = 0;   // the overlapped launches are timed with events of their own stream
-          if (hipEventElapsedTime(&ms, e->ev_k1a, e->ev_k1b) == hipSuccess) e->stats.matrix_ms += ms;
-          if (hipEventElapsedTime(&ms, e->ev_k1b, e->ev_k3b) == hipSuccess) e->stats.argmax_ms += ms;
-        } else if (prepared) {
-          e->rounds_stale_wasted++;
-        }
-      } else {
-        if (prepared) e->rounds_stale_wasted++;
-        n = run.plan(e);
-      }
+      if (ahead && reason == KB_REASON_DONE) { run.promote(e, n_next); n = n_next; }
+      else n = run.plan(e);
     }
-    if (pending_b) HIP_OK(hipStreamSynchronize(e->stream2));
     run.finish(e);
     if (n_out) *n_out = run.decs.size();
     if (run.decs.size() > cap) throw EngineError(KB_E_CAPACITY, "decision buffer too small");

@@ -531,23 +531,6 @@ uint32_t kb_apply_deltas(const KbDev &d, const double *s_idle, const double *s_r
   (void)hipStreamSynchronize(s);
   return h;
 }
-// copy of the mutable node state (one launch instead of six copies): the state a round starts from, for the successor's
-// one-round-stale candidate lists
-__global__ void __launch_bounds__(256) k_snapshot(KbDev d, double *s_idle, double *s_rel, long long *s_nzc, long long *s_nzm, int *s_podcnt,
-                                                  unsigned long long *s_ports) {
-  const uint32_t n = blockIdx.x * 256 + threadIdx.x;
-  if (n >= d.NP) return;
-  for (int dim = 0; dim < d.R; dim++) {
-    s_idle[(size_t)dim * d.NP + n] = d.idle[(size_t)dim * d.NP + n];
-    s_rel[(size_t)dim * d.NP + n] = d.rel[(size_t)dim * d.NP + n];
-  }
-  s_nzc[n] = d.nzc[n]; s_nzm[n] = d.nzm[n]; s_podcnt[n] = d.podcnt[n];
-  if (d.ports) s_ports[n] = d.ports[n];
-}
-void kb_launch_snapshot(const KbDev &d, double *s_idle, double *s_rel, long long *s_nzc, long long *s_nzm, int *s_podcnt,
-                        unsigned long long *s_ports, void *stream) {
-  hipLaunchKernelGGL(k_snapshot, dim3((d.NP + 255) / 256), dim3(256), 0, (hipStream_t)stream, d, s_idle, s_rel, s_nzc, s_nzm, s_podcnt, s_ports);
-}
 void kb_launch_gather(const KbDev &d, const KbRound &r, void *stream) {
   if (r.n_rows == 0) return;
   hipLaunchKernelGGL(k_gather, dim3((r.n_rows + 255) / 256), dim3(256), 0, (hipStream_t)stream, d, r);
