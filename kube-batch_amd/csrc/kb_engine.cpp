@@ -1457,7 +1457,7 @@ static ChunkPlan matrix_plan(kb_engine *e, uint32_t t0, uint32_t n, uint32_t fit
   // expansion doubles the traffic: then every row is evaluated directly (KB_K1_DIRECT=1/0 pins the choice for A/B runs).
   {
     static const char *pin = getenv("KB_K1_DIRECT");
-    p.direct = pin ? pin[0] == '1' : ((size_t)p.ns * e->dev.NP * 2 > (32u << 20) && (size_t)p.ns * 8 > n);
+    p.direct = pin ? pin[0] == '1' : ((size_t)p.ns * e->dev.NP * 2 > (32u << 20) && (size_t)p.ns * 16 > n);
   }
   if (p.direct) {
     // the tasks of a job are adjacent and share a shape: a row equal to its predecessor re-stores the predecessor's result

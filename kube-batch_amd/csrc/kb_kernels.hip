@@ -273,20 +273,22 @@ __device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v) {
   return v;
 }
 
-// Sorted candidate list of one matrix row: the first K entries of (score descending, node ascending).  Scores are
-// integers, so the list is built FOUR consecutive score values at a time: one pass over the row (staged in LDS) counts
-// each thread's nodes at top, top-1, top-2, top-3 (four 16-bit counters packed in two words) and finds the best score
-// below that band; one packed scan turns the counts into output positions; one more pass scatters.  With the default
-// weights the first band already holds more than a window's worth of nodes.  WIDE (rows of 65536 nodes or more, where a
-// 16-bit counter could overflow): two score values per band, one full word each.
-template <bool WIDE, int THREADS>
+// Sorted candidate list of one matrix row: the first K entries of (score descending, node ascending).  Scores are integers,
+// so the list is built one BAND of consecutive score values at a time (eight values; WIDE, rows of 65536 nodes or more where a
+// 16-bit counter could overflow: four): one pass over the row (staged in LDS) counts each thread's nodes at every value of
+// the band (16-bit counters packed two per word) and finds the best score below the band; packed wave scans turn the counts
+// into output positions; one more pass scatters.  Spreading scores fill a window from the first band; bin-packing scores,
+// whose best nodes are few per value, need several bands: NW = 4 words (eight values per band) when mostrequested carries weight,
+// NW = 2 otherwise (config 4: 34 -> 26 us per launch; config 3 keeps its 11 us).
+template <bool WIDE, int THREADS, int NW>
 __global__ void __launch_bounds__(THREADS) k_argmax(KbDev d, KbRound r) {
   constexpr int WAVES = THREADS / 64;
   extern __shared__ __align__(16) unsigned char k3_smem[];
   uint16_t *ls = reinterpret_cast<uint16_t *>(k3_smem);                        // [NP] scores
   uint8_t *lm = reinterpret_cast<uint8_t *>(k3_smem) + (size_t)d.NP * 2;      // [NP/8] mask bytes
   __shared__ int s_wmax[WAVES];
-  __shared__ uint32_t s_wcnt[WAVES][2];
+  constexpr int VALS = WIDE ? NW : 2 * NW;   // consecutive score values one band covers
+  __shared__ uint32_t s_wcnt[WAVES][NW];
   const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const uint32_t row = blockIdx.x;
   if (row == 0 && tid == 0 && r.mrow_task0 == 0 && r.mrows != nullptr)   // round launches only (not kb_eval_matrix's expanded rows)
@@ -327,8 +329,11 @@ __global__ void __launch_bounds__(THREADS) k_argmax(KbDev d, KbRound r) {
   uint32_t found = 0;
   while (top >= 0 && found < K) {
     __syncthreads();   // s_wmax / s_wcnt are reused
-    // counts of this thread's nodes at the four scores of the band; best score below the band
-    uint32_t c01 = 0, c23 = 0;   // 16-bit fields: (top, top-1), (top-2, top-3)
+    // counts of this thread's nodes at the VALS scores of the band (16-bit counters, two per word; WIDE: one per word); best
+    // score below the band
+    uint32_t cw[NW];
+#pragma unroll
+    for (int k = 0; k < NW; k++) cw[k] = 0;
     int below = -1;
     for (uint32_t c = 0; c < per8; c++) {
       const uint32_t mb = lm[cbase + c];
@@ -338,46 +343,52 @@ __global__ void __launch_bounds__(THREADS) k_argmax(KbDev d, KbRound r) {
       for (int e = 0; e < 8; e++) {
         const int sc = (int)((w[e >> 1] >> ((e & 1) * 16)) & 0xFFFFu);
         if ((mb >> e) & 1u) {
-          const int l = top - sc;   // 0..3 inside the band
-          if (WIDE) {
-            if (l == 0) c01++;
-            else if (l == 1) c23++;
-            else if (l >= 2 && sc > below) below = sc;
-          } else {
-            if (l >= 0 && l < 2) c01 += 1u << (16 * l);
-            else if (l >= 2 && l < 4) c23 += 1u << (16 * (l - 2));
-            else if (l >= 4 && sc > below) below = sc;
-          }
+          const int l = top - sc;   // 0 .. VALS-1 inside the band
+          if (l < VALS) {
+#pragma unroll
+            for (int k = 0; k < NW; k++)
+              if ((WIDE ? l : (l >> 1)) == k) cw[k] += WIDE ? 1u : (1u << (16 * (l & 1)));
+          } else if (sc > below) below = sc;
         }
       }
     }
-    const uint32_t p01 = wave_incl_scan_u32(c01), p23 = wave_incl_scan_u32(c23);
+    uint32_t pw[NW];
+#pragma unroll
+    for (int k = 0; k < NW; k++) pw[k] = wave_incl_scan_u32(cw[k]);
     below = wave_max_i32_dpp(below);
-    if (lane == 63) { s_wcnt[wave][0] = p01; s_wcnt[wave][1] = p23; }
+    if (lane == 63) {
+#pragma unroll
+      for (int k = 0; k < NW; k++) s_wcnt[wave][k] = pw[k];
+    }
     if (lane == 0) s_wmax[wave] = below;
     __syncthreads();
-    uint32_t off01 = 0, off23 = 0, tot01 = 0, tot23 = 0;
+    uint32_t offw[NW], totw[NW];
+#pragma unroll
+    for (int k = 0; k < NW; k++) { offw[k] = 0; totw[k] = 0; }
 #pragma unroll
     for (int w2 = 0; w2 < WAVES; w2++) {
-      if (w2 < (int)wave) { off01 += s_wcnt[w2][0]; off23 += s_wcnt[w2][1]; }
-      tot01 += s_wcnt[w2][0];
-      tot23 += s_wcnt[w2][1];
+#pragma unroll
+      for (int k = 0; k < NW; k++) {
+        if (w2 < (int)wave) offw[k] += s_wcnt[w2][k];
+        totw[k] += s_wcnt[w2][k];
+      }
     }
     below = s_wmax[0];
 #pragma unroll
     for (int w2 = 1; w2 < WAVES; w2++) below = max(below, s_wmax[w2]);
     // first output position of this thread's nodes at each score of the band
-    const uint32_t e01 = off01 + p01 - c01, e23 = off23 + p23 - c23;
-    uint32_t t0, t1, t2, t3, pos[4];
-    if (WIDE) {
-      t0 = tot01; t1 = tot23; t2 = 0; t3 = 0;
-      pos[0] = found + e01; pos[1] = found + t0 + e23; pos[2] = 0xFFFFFFFFu; pos[3] = 0xFFFFFFFFu;
-    } else {
-      t0 = tot01 & 0xFFFFu; t1 = tot01 >> 16; t2 = tot23 & 0xFFFFu; t3 = tot23 >> 16;
-      pos[0] = found + (e01 & 0xFFFFu); pos[1] = found + t0 + (e01 >> 16);
-      pos[2] = found + t0 + t1 + (e23 & 0xFFFFu); pos[3] = found + t0 + t1 + t2 + (e23 >> 16);
+    uint32_t pos[VALS], run = found, any = 0, first = 0xFFFFFFFFu;
+#pragma unroll
+    for (int v = 0; v < VALS; v++) {
+      const int k = WIDE ? v : (v >> 1), sh = WIDE ? 0 : 16 * (v & 1);
+      const uint32_t mine = WIDE ? cw[k] : ((cw[k] >> sh) & 0xFFFFu);
+      const uint32_t before = WIDE ? (offw[k] + pw[k] - cw[k]) : (((offw[k] + pw[k] - cw[k]) >> sh) & 0xFFFFu);
+      const uint32_t total = WIDE ? totw[k] : ((totw[k] >> sh) & 0xFFFFu);
+      pos[v] = run + before;
+      if (mine) { any = 1; first = min(first, pos[v]); }
+      run += total;
     }
-    if ((c01 | c23) && min(min(pos[0], pos[1]), min(pos[2], pos[3])) < K) {
+    if (any && first < K) {
       for (uint32_t c = 0; c < per8; c++) {
         const uint32_t mb = lm[cbase + c];
         const uint4 sv = ls4[cbase + c];
@@ -386,14 +397,17 @@ __global__ void __launch_bounds__(THREADS) k_argmax(KbDev d, KbRound r) {
         for (int e = 0; e < 8; e++) {
           const int sc = (int)((w[e >> 1] >> ((e & 1) * 16)) & 0xFFFFu);
           const int l = top - sc;
-          if (((mb >> e) & 1u) && l >= 0 && l < (WIDE ? 2 : 4)) {
-            const uint32_t at = (l == 0) ? pos[0]++ : (l == 1) ? pos[1]++ : (l == 2) ? pos[2]++ : pos[3]++;
+          if (((mb >> e) & 1u) && l >= 0 && l < VALS) {
+            uint32_t at = 0;
+#pragma unroll
+            for (int v = 0; v < VALS; v++)
+              if (l == v) at = pos[v]++;
             if (at < K) out[at] = KB_KEY(sc, (cbase + c) * 8 + e);
           }
         }
       }
     }
-    found += t0 + t1 + t2 + t3;
+    found = run;
     top = below;
   }
   if (found > K) found = K;
@@ -554,22 +568,25 @@ void kb_launch_expand(const KbDev &d, const uint16_t *s_score, const uint32_t *s
   if (n_rows == 0) return;
   hipLaunchKernelGGL(k_expand, dim3(n_rows), dim3(256), 0, (hipStream_t)stream, s_score, s_mask, row_slot, n_rows, d.NP, score, maskw);
 }
-void kb_launch_argmax(const KbDev &d, const KbRound &r, void *stream) {
-  if (r.n_mrows == 0) return;
-  size_t sh = (size_t)d.NP * 2 + d.NP / 8;
+template <bool WIDE, int THREADS, int NW> static void k3_launch(const KbDev &d, const KbRound &r, size_t sh, hipStream_t st) {
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_argmax<false, 256>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_argmax<false, 1024>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_argmax<true, 1024>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_argmax<WIDE, THREADS, NW>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
     attr_set = true;
   }
+  hipLaunchKernelGGL((k_argmax<WIDE, THREADS, NW>), dim3(r.n_mrows), dim3(THREADS), sh, st, d, r);
+}
+void kb_launch_argmax(const KbDev &d, const KbRound &r, void *stream) {
+  if (r.n_mrows == 0) return;
+  const size_t sh = (size_t)d.NP * 2 + d.NP / 8;
   hipStream_t st = (hipStream_t)stream;
   // few rows (a round's distinct shapes): the launch is latency-sized, 1024 threads shorten every pass over the row; many rows
-  // (kb_argmax_rows over whole task ranges): 256 threads keep more rows resident per CU
-  if (d.NP >= 65536u) hipLaunchKernelGGL((k_argmax<true, 1024>), dim3(r.n_mrows), dim3(1024), sh, st, d, r);
-  else if (r.n_mrows <= 512) hipLaunchKernelGGL((k_argmax<false, 1024>), dim3(r.n_mrows), dim3(1024), sh, st, d, r);
-  else hipLaunchKernelGGL((k_argmax<false, 256>), dim3(r.n_mrows), dim3(256), sh, st, d, r);
+  // (kb_argmax_rows over whole task ranges): 256 threads keep more rows resident per CU.  Wider bands when the bin-packing
+  // scorer carries weight (its top scores are sparsely populated).
+  const bool wide_bands = d.score_enabled && d.wM > 0;
+  if (d.NP >= 65536u) { if (wide_bands) k3_launch<true, 1024, 4>(d, r, sh, st); else k3_launch<true, 1024, 2>(d, r, sh, st); }
+  else if (r.n_mrows <= 512) { if (wide_bands) k3_launch<false, 1024, 4>(d, r, sh, st); else k3_launch<false, 1024, 2>(d, r, sh, st); }
+  else { if (wide_bands) k3_launch<false, 256, 4>(d, r, sh, st); else k3_launch<false, 256, 2>(d, r, sh, st); }
 }
 void kb_launch_finalize(const KbDev &d, const uint32_t *job_task_begin, const int *job_min_avail, const uint32_t *job_queue,
                         int gang_ready_enabled, const double *total, uint32_t total_mask, const double *deserved,
