@@ -32,6 +32,8 @@
  *       the plugin predicates only, PrioritizeNodes, util.SortNodes scheduler_helper.go:174-185, ssn.Preemptable
  *       framework/session_plugins.go:122-162, victims lowest TaskOrderFn first) and framework.Statement
  *       (framework/statement.go:36-220: Evict / Pipeline / Commit / Discard).
+ *   kb_run_reclaim
+ *       reclaimAction.Execute (pkg/scheduler/actions/reclaim/reclaim.go:41-193).
  *   kb_eval_matrix
  *       the per-(task,node) predicate closure (allocate.go:73-87), the predicates plugin
  *       (plugins/predicates/predicates.go:123-265) and the nodeorder scorers
@@ -261,6 +263,11 @@ int  kb_run_backfill(kb_engine *e, kb_decision *out, uint64_t cap, uint64_t *n_o
    KB_E_UNSUPPORTED: sessions with preferred node-affinity terms (NormalizeReduce over a feasible set the repairs would change),
    and states in which the reference itself would panic / abort (Resource.Sub underflow, NodeInfo.UpdateTask). */
 int  kb_run_preempt(kb_engine *e, kb_stmt_op *out, uint64_t cap, uint64_t *n_out);
+/* the reclaim action (pkg/scheduler/actions/reclaim/reclaim.go:41-193; victims through ssn.Reclaimable, framework/session_plugins.go:
+   80-119, with proportion's rule plugins/proportion/proportion.go:171-196).  There is no Statement: every EVICT entry is an
+   ssn.Evict (framework/session.go:317-354), every PIPELINE an ssn.Pipeline, in order; `stmt` is 0.  The walk is first-fit over
+   nodes in name order with the plugin predicates only: sequential bookkeeping, it runs on the host side of the engine. */
+int  kb_run_reclaim(kb_engine *e, kb_stmt_op *out, uint64_t cap, uint64_t *n_out);
 /* tasks the committed statements handed to cache.Evict so far, in that order */
 int  kb_get_evictions(kb_engine *e, uint32_t *out, uint64_t cap, uint64_t *n_out);
 

@@ -108,3 +108,73 @@ func (p *gpuPreemptAction) Execute(ssn *framework.Session) {
 		}
 	}
 }
+
+// ---- reclaim (pkg/scheduler/actions/reclaim/reclaim.go:41-193) on the engine: same flatten / load, kb_run_reclaim, and a replay
+// through the Session itself — reclaim uses no Statement: ssn.Evict (framework/session.go:317-354) and ssn.Pipeline (:194-232).
+type gpuReclaimAction struct {
+	alloc    *gpuAllocateAction
+	fallback framework.Action
+}
+
+// NewReclaim: framework.RegisterAction(gpuallocate.NewReclaim(a, reclaim.New())) — the stock action is passed in so that this
+// file does not import a second actions package for one constructor.
+func NewReclaim(a *gpuAllocateAction, stock framework.Action) *gpuReclaimAction {
+	return &gpuReclaimAction{alloc: a, fallback: stock}
+}
+
+func (p *gpuReclaimAction) Name() string  { return "gpureclaim" } // or "reclaim" to override the stock action
+func (p *gpuReclaimAction) Initialize()   {}
+func (p *gpuReclaimAction) UnInitialize() {}
+
+func (p *gpuReclaimAction) Execute(ssn *framework.Session) {
+	runtime.LockOSThread()
+	defer runtime.UnlockOSThread()
+
+	if err := p.alloc.ensureEngine(ssn); err != nil {
+		p.fallback.Execute(ssn)
+		return
+	}
+	fl, err := flatten(ssn)
+	if err != nil {
+		p.fallback.Execute(ssn)
+		return
+	}
+	defer fl.free()
+	if len(fl.tasks) == 0 {
+		return
+	}
+	if rc := C.kb_session_load(p.alloc.engine, &fl.snap); rc != C.KB_OK {
+		p.fallback.Execute(ssn)
+		return
+	}
+	capOps := C.size_t(2*len(fl.tasks) + 16)
+	ops := (*C.kb_stmt_op)(C.calloc(capOps, C.size_t(unsafe.Sizeof(C.kb_stmt_op{}))))
+	if ops == nil {
+		p.fallback.Execute(ssn)
+		return
+	}
+	defer C.free(unsafe.Pointer(ops))
+	var n C.uint64_t
+	if rc := C.kb_run_reclaim(p.alloc.engine, ops, C.uint64_t(capOps), &n); rc != C.KB_OK {
+		glog.Warningf("gpureclaim: run rc=%d (%s); stock action takes this cycle", rc, C.GoString(C.kb_last_error(p.alloc.engine)))
+		p.fallback.Execute(ssn)
+		return
+	}
+	journal := (*[1 << 28]C.kb_stmt_op)(unsafe.Pointer(ops))[:int(n):int(n)]
+	for i := range journal {
+		op := journal[i]
+		switch op.op {
+		case C.KB_OP_EVICT: // reclaim.go:163: the reclaimee is the node's own clone of the task (:136-139)
+			node := fl.nodes[op.node]
+			if victim, found := node.Tasks[api.PodKey(fl.tasks[op.task].Pod)]; found {
+				if err := ssn.Evict(victim.Clone(), "reclaim"); err != nil {
+					glog.Errorf("gpureclaim: evict %s: %v", victim.UID, err)
+				}
+			}
+		case C.KB_OP_PIPELINE: // reclaim.go:178
+			if err := ssn.Pipeline(fl.tasks[op.task], fl.nodes[op.node].Name); err != nil {
+				glog.Errorf("gpureclaim: pipeline %s on %s: %v", fl.tasks[op.task].UID, fl.nodes[op.node].Name, err)
+			}
+		}
+	}
+}

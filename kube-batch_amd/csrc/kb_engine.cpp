@@ -187,11 +187,15 @@ Policy compile_policy(const kb_config *cfg) {
   if (!cfg->tier_begin && cfg->n_tiers) throw EngineError(KB_E_INVALID, "tier_begin is NULL");
   for (uint32_t t = 0; t < cfg->n_tiers; t++) {
     p.preempt_tiers.emplace_back();
+    p.reclaim_tiers.emplace_back();
     for (uint32_t i = cfg->tier_begin[t]; i < cfg->tier_begin[t + 1]; i++) {
       const kb_plugin_option &o = cfg->plugins[i];
       // plugins that register a PreemptableFn: conformance.go:60, gang.go:93, priority.go:100, drf.go:111
       if ((o.enabled & KB_EN_PREEMPTABLE) && (o.plugin == KB_PLUGIN_CONFORMANCE || o.plugin == KB_PLUGIN_GANG || o.plugin == KB_PLUGIN_PRIORITY || o.plugin == KB_PLUGIN_DRF))
         p.preempt_tiers.back().push_back((uint8_t)o.plugin);
+      // ... a ReclaimableFn: conformance.go:61, gang.go:92, proportion.go:171
+      if ((o.enabled & KB_EN_RECLAIMABLE) && (o.plugin == KB_PLUGIN_CONFORMANCE || o.plugin == KB_PLUGIN_GANG || o.plugin == KB_PLUGIN_PROPORTION))
+        p.reclaim_tiers.back().push_back((uint8_t)o.plugin);
       switch (o.plugin) {
         case KB_PLUGIN_PRIORITY:
           if (o.enabled & KB_EN_JOB_ORDER) p.job_chain.push_back(KB_PLUGIN_PRIORITY);
@@ -1323,12 +1327,12 @@ void upload_live_nodes(kb_engine *e, const LiveNodes &ln, const std::vector<uint
 }
 }  // namespace
 
-int kb_run_preempt(kb_engine *e, kb_stmt_op *out, uint64_t cap, uint64_t *n_out) {
+static int run_evict_action(kb_engine *e, bool reclaim, kb_stmt_op *out, uint64_t cap, uint64_t *n_out) {
   if (!e) return KB_E_INVALID;
   return guarded(e, [&]() {
-    if (!e->loaded) throw EngineError(KB_E_STATE, "kb_session_load must precede kb_run_preempt");
+    if (!e->loaded) throw EngineError(KB_E_STATE, "kb_session_load must precede kb_run_preempt / kb_run_reclaim");
     HostSession &hs = e->hs;
-    if (hs.has_affinity && e->pol.nodeorder_enabled)
+    if (!reclaim && hs.has_affinity && e->pol.nodeorder_enabled)
       throw EngineError(KB_E_UNSUPPORTED, "preempt with preferred node-affinity terms (NormalizeReduce over the feasible set) is not modelled");
     const double t_begin = now_ms();
     const int R = hs.R;
@@ -1399,7 +1403,7 @@ int kb_run_preempt(kb_engine *e, kb_stmt_op *out, uint64_t cap, uint64_t *n_out)
     std::vector<uint8_t> status = hs.t_status;
     std::vector<uint32_t> tnode = hs.t_node;
     pm.init(&hs, &e->pol, &ln, &status, &tnode, lists, refresh);
-    pm.run();
+    if (reclaim) pm.run_reclaim(); else pm.run();
     // ---- results: journal out, state back to the device
     if (n_out) *n_out = pm.ops.size();
     if (pm.ops.size() > cap) throw EngineError(KB_E_CAPACITY, "journal buffer too small");   // nothing was written to the device yet
@@ -1419,12 +1423,15 @@ int kb_run_preempt(kb_engine *e, kb_stmt_op *out, uint64_t cap, uint64_t *n_out)
     // the host's running drf / proportion aggregates must equal the device reduction over the task table
     if (e->pol.has_drf)
       for (uint32_t j = 0; j < J; j++)
-        if (pm.jshare[j] != hs.job_share[j]) throw EngineError(KB_E_INTERNAL, "preempt: drf share diverged from the device reduction at job " + std::to_string(j));
+        if (pm.jshare[j] != hs.job_share[j]) throw EngineError(KB_E_INTERNAL, "evict action: drf share diverged from the device reduction at job " + std::to_string(j));
     e->stats.tasks_popped += pm.popped;
     e->stats.evals += pm.evals;
     e->stats.total_ms += now_ms() - t_begin;
   });
 }
+
+int kb_run_preempt(kb_engine *e, kb_stmt_op *out, uint64_t cap, uint64_t *n_out) { return run_evict_action(e, false, out, cap, n_out); }
+int kb_run_reclaim(kb_engine *e, kb_stmt_op *out, uint64_t cap, uint64_t *n_out) { return run_evict_action(e, true, out, cap, n_out); }
 
 int kb_get_evictions(kb_engine *e, uint32_t *out, uint64_t cap, uint64_t *n_out) {
   if (!e) return KB_E_INVALID;

@@ -130,6 +130,8 @@ struct Policy {
   int wL = 1, wM = 0, wNA = 1, wPA = 1, wB = 1;   // nodeorder.go:111-117
   // Preemptable (session_plugins.go:122-162): per tier the plugins registered with EnabledPreemptable that own a victim rule
   std::vector<std::vector<uint8_t>> preempt_tiers;
+  // Reclaimable (session_plugins.go:80-119): the same with EnabledReclaimable (conformance, gang, proportion own a rule)
+  std::vector<std::vector<uint8_t>> reclaim_tiers;
   bool gang_job_pipelined = false;       // JobPipelined (session_plugins.go:202-222 + gang.go:126-129)
 };
 

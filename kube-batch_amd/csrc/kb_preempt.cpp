@@ -272,6 +272,15 @@ void PreemptMachine::pipeline(uint32_t t, uint32_t n) {   // statement.go:113-15
   fire_allocate(t);
   ops.push_back(StmtOp{KB_OP_PIPELINE, t, n, stmt_no_});
 }
+// ssn.Pipeline (framework/session.go:194-232), what reclaim calls: unlike Statement.Pipeline an AddTask error (a sticky NodeName
+// left by a discarded preempt statement) returns BEFORE the plugin event handlers — the status is Pipelined, nothing else moved
+void PreemptMachine::pipeline_session(uint32_t t, uint32_t n) {
+  set_status(t, KB_TASK_PIPELINED);
+  ops.push_back(StmtOp{KB_OP_PIPELINE, t, n, stmt_no_});
+  if (!node_add(t, n, KB_TASK_PIPELINED)) return;
+  mark_dirty(n);
+  fire_allocate(t);
+}
 void PreemptMachine::unpipeline(uint32_t t) {   // statement.go:155-190; task.NodeName keeps the old host (RemoveTask never clears it)
   set_status(t, KB_TASK_PENDING);
   if (on_node[t]) { const uint32_t n = (*tnode_)[t]; node_remove(t); mark_dirty(n); }
@@ -300,15 +309,36 @@ void PreemptMachine::discard() {   // statement.go:193-205: newest first
 
 // session_plugins.go:122-162: per tier the intersection of the enabled plugins' candidates; once a plugin has spoken an empty
 // set stays empty (Go: a nil slice intersected with anything is nil), and the first tier that leaves a non-empty set decides
-size_t PreemptMachine::evictable(uint32_t preemptor, const std::vector<uint32_t> &pre, std::vector<uint32_t> &victims) {
+size_t PreemptMachine::evictable(uint32_t preemptor, const std::vector<uint32_t> &pre, std::vector<uint32_t> &victims, bool reclaim) {
   const int R = hs_->R;
   const size_t n = pre.size();
   bool init = false;
   victims.clear();
   std::vector<uint8_t> keep(n ? n : 1);
-  for (const std::vector<uint8_t> &tier : pol_->preempt_tiers) {
+  for (const std::vector<uint8_t> &tier : (reclaim ? pol_->reclaim_tiers : pol_->preempt_tiers)) {
     for (uint8_t plugin : tier) {
       std::fill(keep.begin(), keep.end(), 0);
+      if (plugin == KB_PLUGIN_PROPORTION) {   // proportion.go:171-196: running per-queue allocation, in reclaimee order
+        std::vector<uint32_t> aq;
+        std::vector<Res> alloc;
+        for (size_t i = 0; i < n; i++) {
+          const uint32_t q = hs_->job_queue[hs_->t_job[pre[i]]];
+          if (q >= hs_->Q) continue;
+          size_t a = 0;
+          while (a < aq.size() && aq[a] != q) a++;
+          if (a == aq.size()) {
+            aq.push_back(q);
+            Res r;
+            r.mask = qmask[q];
+            for (int d = 0; d < R; d++) r.v[d] = qalloc[(size_t)q * R + d];
+            alloc.push_back(r);
+          }
+          const Res rq = task_res(pre[i]);
+          if (res_less(alloc[a], rq, R)) continue;
+          if (!res_sub(alloc[a], rq, R)) throw EngineError(KB_E_UNSUPPORTED, "reclaim: queue allocation would underflow (the reference panics in Resource.Sub)");
+          keep[i] = res_less_equal(hs_->deserved[q], alloc[a], R);
+        }
+      } else
       if (plugin == KB_PLUGIN_CONFORMANCE) {   // conformance.go:44-58
         for (size_t i = 0; i < n; i++) keep[i] = hs_->t_protected.empty() || !hs_->t_protected[pre[i]];
       } else if (plugin == KB_PLUGIN_GANG) {   // gang.go:71-90
@@ -584,6 +614,88 @@ void PreemptMachine::run() {
         if (!assigned) break;
       }
     }
+  }
+}
+
+// session_plugins.go:270-295 + proportion.go:156-169
+bool PreemptMachine::queue_less(uint32_t l, uint32_t r) const {
+  if (pol_->queue_order_proportion) {
+    const double ls = qshare[l], rs = qshare[r];
+    if (!(ls == rs)) return ls < rs;
+  }
+  if (hs_->queue_creation[l] == hs_->queue_creation[r]) return l < r;
+  return hs_->queue_creation[l] < hs_->queue_creation[r];
+}
+// session_plugins.go:165-179 + proportion.go:198-209: deserved.LessEqual(allocated)
+bool PreemptMachine::overused(uint32_t q) const {
+  if (!pol_->has_proportion) return false;
+  Res a;
+  a.mask = qmask[q];
+  for (int d = 0; d < hs_->R; d++) a.v[d] = qalloc[(size_t)q * hs_->R + d];
+  return res_less_equal(hs_->deserved[q], a, hs_->R);
+}
+
+// reclaimAction.Execute (reclaim.go:41-193).  Canonical orders where the reference ranges over Go maps: jobs ascending JobID,
+// nodes ascending name, a node's tasks ascending task index.
+void PreemptMachine::run_reclaim() {
+  const int R = hs_->R;
+  const uint32_t J = hs_->J, Q = hs_->Q, N = hs_->N;
+  auto ql = [this](uint32_t l, uint32_t r) { return queue_less(l, r); };
+  auto jl = [this](uint32_t l, uint32_t r) { return job_less(l, r); };
+  auto tl = [this](uint32_t l, uint32_t r) { return task_less(l, r); };
+  GoHeap<decltype(ql)> queues(ql);
+  std::vector<GoHeap<decltype(jl)>> qjobs(Q ? Q : 1, GoHeap<decltype(jl)>(jl));
+  std::vector<GoHeap<decltype(tl)>> jtasks(J ? J : 1, GoHeap<decltype(tl)>(tl));
+  std::vector<uint8_t> qseen(Q ? Q : 1, 0);
+  for (uint32_t j = 0; j < J; j++) {   // reclaim.go:55-83
+    const uint32_t q = hs_->job_queue[j];
+    if (q >= Q) continue;
+    if (!qseen[q]) { qseen[q] = 1; queues.push(q); }
+    if (cnt[(size_t)j * 10 + KB_TASK_PENDING] != 0) {
+      qjobs[q].push(j);
+      for (uint32_t t = hs_->job_begin[j]; t < hs_->job_begin[j + 1]; t++)
+        if ((*status_)[t] == KB_TASK_PENDING) jtasks[j].push(t);
+    }
+  }
+  stmt_no_ = 0;
+  for (;;) {
+    if (queues.empty()) break;
+    const uint32_t q = queues.pop();
+    if (overused(q)) continue;             // reclaim.go:96-99
+    if (qjobs[q].empty()) continue;        // :102-106
+    const uint32_t j = qjobs[q].pop();
+    if (jtasks[j].empty()) continue;       // :109-113
+    const uint32_t task = jtasks[j].pop();
+    popped++;
+    const Res init = task_init(task);
+    bool assigned = false;
+    for (uint32_t n = 0; n < N && !assigned; n++) {
+      long long sc;
+      evals++;
+      if (!host_eval(task, n, sc)) continue;   // ssn.PredicateFn (:118-120): the plugin predicates against the live node
+      std::vector<uint32_t> pre, victims;
+      for (uint32_t t : ntasks_[n]) {          // :128-141: Running tasks of OTHER queues
+        if (node_status[t] != KB_TASK_RUNNING) continue;
+        if (hs_->job_queue[hs_->t_job[t]] != q) pre.push_back(t);
+      }
+      if (pre.empty()) continue;
+      if (evictable(task, pre, victims, true) == 0) continue;   // :142-147
+      Res all;
+      for (uint32_t v : victims) res_add(all, task_res(v), R);
+      if (!res_less_equal(init, all, R)) continue;              // :149-157
+      Res reclaimed;
+      for (uint32_t v : victims) {             // :160-172: ssn.Evict acts at once (framework/session.go:317-354)
+        evict(v);
+        evictions.push_back(v);
+        res_add(reclaimed, task_res(v), R);
+        if (res_less_equal(init, reclaimed, R)) break;
+      }
+      if (res_less_equal(init, reclaimed, R)) {   // :177-186: ssn.Pipeline (framework/session.go:194-232)
+        pipeline_session(task, n);
+        assigned = true;
+      }
+    }
+    if (assigned) queues.push(q);            // :189-191
   }
 }
 

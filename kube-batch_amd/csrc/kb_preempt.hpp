@@ -43,7 +43,8 @@ class PreemptMachine {
 
   void init(const HostSession *hs, const Policy *pol, LiveNodes *live, std::vector<uint8_t> *status, std::vector<uint32_t> *tnode,
             ListFn lists, RefreshFn refresh);
-  void run();   // the whole action
+  void run();           // the preempt action
+  void run_reclaim();   // the reclaim action (actions/reclaim/reclaim.go:41-193): no Statement, ssn.Evict / ssn.Pipeline act at once
 
   std::vector<StmtOp> ops;             // every Evict / Pipeline / Commit / Discard, in order
   std::vector<uint32_t> evictions;     // committed evictions in the order stmt.Commit hands them to cache.Evict
@@ -97,11 +98,14 @@ class PreemptMachine {
   void evict(uint32_t t);
   void unevict(uint32_t t);
   void pipeline(uint32_t t, uint32_t n);
+  void pipeline_session(uint32_t t, uint32_t n);
   void unpipeline(uint32_t t);
   void begin_stmt();
   void commit();
   void discard();
-  size_t evictable(uint32_t preemptor, const std::vector<uint32_t> &pre, std::vector<uint32_t> &victims);
+  size_t evictable(uint32_t preemptor, const std::vector<uint32_t> &pre, std::vector<uint32_t> &victims, bool reclaim = false);
+  bool queue_less(uint32_t l, uint32_t r) const;
+  bool overused(uint32_t q) const;
   bool host_eval(uint32_t t, uint32_t n, long long &score) const;
   bool preempt_one(uint32_t preemptor, int mode);
   bool try_node(uint32_t preemptor, int mode, uint32_t n);

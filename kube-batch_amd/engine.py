@@ -17,7 +17,7 @@ LIB_PATH = os.environ.get("KB_ENGINE_LIB") or os.path.join(_HERE, "libkbengine.s
 _LIB = None
 
 EXPORTS = ["kb_engine_create", "kb_engine_destroy", "kb_last_error", "kb_session_load", "kb_session_reset", "kb_run_allocate",
-           "kb_run_backfill", "kb_run_preempt", "kb_get_evictions", "kb_engine_use_stream", "kb_eval_matrix", "kb_argmax_rows", "kb_bench_matrix", "kb_get_binds",
+           "kb_run_backfill", "kb_run_preempt", "kb_run_reclaim", "kb_get_evictions", "kb_engine_use_stream", "kb_eval_matrix", "kb_argmax_rows", "kb_bench_matrix", "kb_get_binds",
            "kb_get_task_state", "kb_get_node_state", "kb_get_shares", "kb_get_stats", "kb_round_begin",
            "kb_round_candidates", "kb_round_commit", "kb_round_apply", "kb_round_delta_doubles",
            "kb_round_decisions"]
@@ -54,6 +54,7 @@ def lib():
         for n in ("kb_run_allocate", "kb_run_backfill"):
             getattr(L, n).argtypes = [vp, C.POINTER(abi.Decision), C.c_uint64, C.POINTER(C.c_uint64)]
         L.kb_run_preempt.argtypes = [vp, C.POINTER(abi.StmtOp), C.c_uint64, C.POINTER(C.c_uint64)]
+        L.kb_run_reclaim.argtypes = [vp, C.POINTER(abi.StmtOp), C.c_uint64, C.POINTER(C.c_uint64)]
         L.kb_get_evictions.argtypes = [vp, C.POINTER(C.c_uint32), C.c_uint64, C.POINTER(C.c_uint64)]
         L.kb_eval_matrix.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint8), C.POINTER(C.c_uint16)]
         L.kb_argmax_rows.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint16)]
@@ -132,12 +133,16 @@ class Engine:
     def run_backfill(self):
         return self._run(self.L.kb_run_backfill)
 
-    def run_preempt(self):
+    def run_reclaim(self):
+        """The reclaim action (actions/reclaim/reclaim.go): ssn.Evict / ssn.Pipeline entries in last_journal, stmt 0."""
+        return self.run_preempt(fn=self.L.kb_run_reclaim)
+
+    def run_preempt(self, fn=None):
         """The preempt action (actions/preempt/preempt.go) -> uint32[n,4] journal (op, task, node, stmt), abi.OP_*, in order."""
         cap = 4 * max(int(self.snap.n_tasks), 1) + 16
         n = C.c_uint64()
         arr = (abi.StmtOp * cap)()
-        rc = self.L.kb_run_preempt(self.h, arr, cap, C.byref(n))
+        rc = (fn or self.L.kb_run_preempt)(self.h, arr, cap, C.byref(n))
         self._ck(rc)
         self.last_journal = np.frombuffer(arr, dtype=np.uint32).reshape(cap, 4)[: n.value].copy()
         return np.zeros((0, 3), np.uint32)       # no ssn.Allocate / ssn.Pipeline decisions: the journal carries the Statement ops

@@ -18,10 +18,6 @@ abi, conf, fx = kbm.abi, kbm.conf, kbm.fixtures
 pytestmark = [pytest.mark.gpu]
 
 
-def _engine_supported(order):
-    return all(a in ("allocate", "backfill", "preempt") for a in order)
-
-
 def _has(cfg, plugin):
     return any(po.name == plugin for tier in cfg.tiers for po in tier)
 
@@ -113,9 +109,7 @@ def test_reference_preempt_cases(oracle_mod):
 
 @pytest.mark.parametrize("seed", range(60))
 def test_preempt_on_random_clusters(oracle_mod, seed):
-    cfg, snap, order = cases._evict_case(seed)
-    order = [a for a in order if a != "reclaim"] or ["preempt"]
-    cfg = conf.load_scheduler_conf(cases.CONF_FULL.format(actions=", ".join(order)))
+    cfg, snap, order = cases._evict_case(seed)     # orders mix preempt and reclaim with allocate / backfill
     _run_both(oracle_mod, cfg, snap, order, seed)
 
 
@@ -128,9 +122,30 @@ def test_preempt_after_allocate_on_scaled_baseline_configs(oracle_mod, scale, id
     _run_both(oracle_mod, cfg, snap, order, (idx, scale))
 
 
+def test_reference_reclaim_case(oracle_mod):
+    """actions/reclaim/reclaim_test.go:51-99: queue q1 holds the whole node, q2's pending pod reclaims exactly one running pod
+    (tiers: conformance + gang with EnabledReclaimable, reclaim_test.go:140-154)."""
+    S = kbm.snapshot
+    rl = fx.build_resource_list
+    snap = S.flatten(nodes=[S.Node("n1", rl("3", "3Gi"))],
+                     pods=[fx.build_pod("c1", f"preemptee{i}", "n1", "Running", rl("1", "1G"), "pg1") for i in (1, 2, 3)] +
+                          [fx.build_pod("c1", "preemptor1", "", "Pending", rl("1", "1G"), "pg2")],
+                     pod_groups=[S.PodGroup("c1", "pg1", queue="q1"), S.PodGroup("c1", "pg2", queue="q2")], queues=[S.Queue("q1", 1), S.Queue("q2", 1)])
+    cfg = conf.tiers_literal([conf.PluginOption("conformance", enabled=abi.EN_RECLAIMABLE), conf.PluginOption("gang", enabled=abi.EN_RECLAIMABLE)])
+    e = engine.Engine(cfg)
+    e.load(snap)
+    e.run(["reclaim"])
+    o = oracle_mod.Oracle(cfg, snap)
+    o.run(["reclaim"])
+    assert [snap.task_name(int(t)) for t in e.evictions()] == ["c1/preemptee1"]
+    _compare(e, o, snap, "reclaim_test", cfg)
+    e.close()
+    o.close()
+
+
 @pytest.mark.parametrize("seed", range(2, 240, 3))
 def test_preempt_on_adversarial_snapshots(oracle_mod, seed):
     snap = rawgen.raw_snapshot(seed)
-    order = [["preempt"], ["allocate", "backfill", "preempt"], ["preempt", "allocate"]][(seed // 3) % 3]
+    order = [["preempt"], ["reclaim", "allocate", "backfill", "preempt"], ["preempt", "allocate"]][(seed // 3) % 3]
     cfg = conf.load_scheduler_conf(cases.CONF_FULL.format(actions=", ".join(order)))
     _run_both(oracle_mod, cfg, snap, order, seed)
