@@ -162,7 +162,7 @@ __device__ __forceinline__ uint32_t k9_eval_v(const KbCommitArgs &a, const K9Sha
       }
       aa >>= 1; dd++;
     }
-    ok = fi || fr;
+    ok = fi || (a.fit_mode != 2 && fr);   // 2: backfill, AddTask's Resreq.LessEqual(Idle) only (node_info.go:161-167)
   }
   if (a.pred_enabled) {
     ok = ok && (v.left > 0) && ((v.ports & sh.conf) == 0ull);   // pod count (predicates.go:127), PodFitsHostPorts (predicates.go:181-190)

@@ -139,6 +139,9 @@ struct kb_engine {
   uint32_t shape_cap = KB_K5_MAX_SHAPES;   // distinct shapes a window may hold (each keeps its candidate list in the commit kernel's LDS)
   std::vector<uint32_t> plan_stamp;   // per row-shape id: stamp of the window being planned
   uint32_t plan_epoch = 0;
+  const double *t_fit = nullptr;   // backfill's view of t_init (BestEffort rows: Resreq cpu / memory), == b_tinit when they agree
+  bool idle_below_eps = false;
+  DevBuf b_tfit;
   DevBuf b_tinit, b_tres, b_tnzc, b_tnzm, b_tcls, b_tactive, b_tresmask, b_tjob, b_tstatus, b_tnode, b_tbind, b_tcounted, b_jallocated, b_compat, b_crows, b_aff, b_affcls;
   DevBuf p_idle, p_rel, p_nzc, p_nzm, p_podcnt, p_tstatus, p_tnode, p_tcounted, p_ports;   // pristine copies for kb_session_reset
   DevBuf b_ports, b_twant, b_tconf;   // host ports (only when the snapshot carries any)
@@ -406,7 +409,10 @@ RoundCtx round_prepare(kb_engine *e, uint32_t n, int fit_mode, bool backfill, bo
   std::memcpy(e->h_win.data() + 2 * KB_K5_MAX_WINDOW, e->h_mrows.data(), sizeof(uint32_t) * c.ns);
   HIP_OK(hipMemcpyAsync(e->b_win.p, e->h_win.data(), sizeof(uint32_t) * (2 * KB_K5_MAX_WINDOW + c.ns), hipMemcpyHostToDevice, e->stream));
   c.d = e->dev;
-  if (backfill) c.d.score_enabled = 0;   // backfill.go:50-66 takes the first node that passes the predicates: all scores tie
+  if (backfill) {
+    c.d.score_enabled = 0;   // backfill.go:50-66 takes the first node that passes the predicates: all scores tie
+    c.d.t_init = e->t_fit;   // ... and on which ssn.Allocate's AddTask succeeds: Resreq.LessEqual(Idle), fit_mode 2
+  }
   c.r = make_round(e, n, c.ns, c.L, fit_mode, backfill);
   c.r.gather = (gather_in_matrix && c.ns > 0) ? 1u : 0u;
   if (!c.r.gather) kb_launch_gather(c.d, c.r, e->stream);
@@ -546,6 +552,9 @@ void check_aggregates(kb_engine *e, const OrderMachine &om) {
 // device's answer (confirm, or roll back + replay on a mis-speculated round), finish() runs the gang/share reduction.
 struct ActionRun {
   uint32_t action = 0;   // 0 allocate, 1 backfill
+  bool bf_need_pred = false;
+  std::vector<int> bf_podcnt;
+  std::vector<unsigned long long> bf_ports;
   OrderMachine om;
   std::vector<uint8_t> dead;
   std::vector<kb_decision> decs;
@@ -594,6 +603,18 @@ struct ActionRun {
       bf_pos = 0;
       for (uint32_t t = 0; t < hs.T; t++)
         if (hs.t_status[t] == KB_TASK_PENDING && hs.t_init_empty[t] && hs.t_job[t] < hs.J) bf_list.push_back(t);
+      // Only a session with sub-epsilon BestEffort requests (or a node below -epsilon) can see AddTask refuse a node that passed
+      // the predicates; absorb() then needs to tell "no node passes the predicates" (the task stays Pending) from "one did"
+      // (outside the envelope).  Pod counts and used ports only grow during backfill, so the state as of now decides the former.
+      bf_need_pred = e->idle_below_eps;
+      for (uint32_t t : bf_list) bf_need_pred = bf_need_pred || hs.t_res[t] != 0.0 || hs.t_res[(size_t)hs.T + t] != 0.0;
+      if (bf_need_pred) {
+        const uint32_t NP = e->dev.NP;
+        bf_podcnt.resize(NP); bf_ports.assign(NP, 0);
+        HIP_OK(hipMemcpyAsync(bf_podcnt.data(), e->b_podcnt.p, sizeof(int) * NP, hipMemcpyDeviceToHost, e->stream));
+        if (e->dev.ports) HIP_OK(hipMemcpyAsync(bf_ports.data(), e->b_ports.p, sizeof(unsigned long long) * NP, hipMemcpyDeviceToHost, e->stream));
+        HIP_OK(hipStreamSynchronize(e->stream));
+      }
     }
   }
 
@@ -667,13 +688,39 @@ struct ActionRun {
     if (n_next == 0) popped += spec_pops;
   }
 
+  // the plugin predicates of task t (predicates.go:127,181-190 and the static class table) against the pod counts / ports
+  // backfill started from: a superset of the nodes that pass at any later point of the action
+  bool passed_predicates_at_start(kb_engine *e, uint32_t t) const {
+    const HostSession &hs = e->hs;
+    if (!e->pol.pred_enabled) return hs.N > 0;
+    const uint64_t conf = hs.t_conf.empty() ? 0 : hs.t_conf[t];
+    for (uint32_t n = 0; n < hs.N; n++) {
+      if (hs.n_maxpods[n] <= bf_podcnt[n]) continue;
+      if (!hs.compat.empty()) {
+        const uint32_t bit = hs.t_cls[t] * hs.n_nc + hs.n_cls[n];
+        if (!((hs.compat[bit >> 3] >> (bit & 7)) & 1)) continue;
+      }
+      if (bf_ports[n] & conf) continue;
+      return true;
+    }
+    return false;
+  }
+
   void absorb(kb_engine *e, uint32_t n, uint32_t n_done, uint32_t reason) {
     HostSession &hs = e->hs;
     const uint32_t round = (uint32_t)(e->round_no - 1);
     if (action == 1) {
       if (reason != KB_REASON_DONE || n_done != n) throw EngineError(KB_E_INTERNAL, "backfill round ended early");
-      for (uint32_t i = 0; i < n; i++)
-        if (e->h_decnode[i] != KB_NONE) decs.push_back(kb_decision{e->h_rows[i], e->h_decnode[i], 0u, round});
+      for (uint32_t i = 0; i < n; i++) {
+        const uint32_t t = e->h_rows[i];
+        if (e->h_decnode[i] != KB_NONE) { decs.push_back(kb_decision{t, e->h_decnode[i], 0u, round}); continue; }
+        // No node took the task.  With a zero request that means no node passes the predicates and the task stays Pending
+        // (unless a node's Idle sat at or below -epsilon in the snapshot).  With a non-zero sub-epsilon request a node may have passed
+        // the predicates and failed AddTask: ssn.Allocate has then flipped the task to Allocated without a node
+        // (session.go:243 before :255), and what a later dispatch of that job does with it depends on Go's map order.
+        if ((hs.t_res[t] != 0.0 || hs.t_res[(size_t)hs.T + t] != 0.0 || e->idle_below_eps) && passed_predicates_at_start(e, t))
+          throw EngineError(KB_E_UNSUPPORTED, "BestEffort task with a sub-epsilon request found no node (the reference may leave it Allocated without one)");
+      }
       bf_pos += n;
       return;
     }
@@ -946,11 +993,11 @@ int kb_session_load(kb_engine *e, const kb_snapshot *sn) {
       in.mask |= rq.mask;
       hs.t_res_empty[t] = res_is_empty(rq, R);
       hs.t_init_empty[t] = res_is_empty(in, R);
-      if (hs.t_init_empty[t] && hs.t_status[t] == KB_TASK_PENDING)
-        for (int d = 0; d < R; d++)
-          if (rq.v[d] != 0.0)
-            throw EngineError(KB_E_UNSUPPORTED, "BestEffort task with a non-zero sub-epsilon request (backfill's AddTask retry path)");
       key.assign(in.v, in.v + R);
+      // a BestEffort task is placed by backfill, whose only resource test is AddTask's Resreq.LessEqual(Idle)
+      // (api/node_info.go:161-167): its fit vector is Resreq cpu / memory (non-zero below the epsilon at most), see t_fit below
+      key.push_back(hs.t_init_empty[t] ? rq.v[0] : -1.0);
+      key.push_back(hs.t_init_empty[t] ? rq.v[1] : -1.0);
       key.push_back((double)hs.t_cls[t]);
       {   // host ports: the conflict mask is part of feasibility, the wanted bits of what a commit changes
         const uint64_t conf = sn->task_port_conflict ? sn->task_port_conflict[t] : 0, want = sn->task_port_want ? sn->task_port_want[t] : 0;
@@ -1049,6 +1096,9 @@ int kb_session_load(kb_engine *e, const kb_snapshot *sn) {
     d = KbDev{};
     d.R = R; d.N = N; d.NP = NP; d.T = T; d.J = J; d.Q = Q;
     upload_padded(e->b_idle, sn->node_idle, R, N, NP, s);
+    e->idle_below_eps = false;   // NodeInfo keeps Idle above -epsilon (every Sub is guarded by LessEqual); a snapshot may not
+    for (uint32_t n = 0; n < N; n++)
+      if (sn->node_idle[n] <= -kMinMilliCPU || sn->node_idle[(size_t)N + n] <= -kMinMemory) e->idle_below_eps = true;
     upload_padded(e->b_rel, sn->node_releasing, R, N, NP, s);
     upload_padded(e->b_nzc, sn->node_nz_cpu, 1, N, NP, s);
     upload_padded(e->b_nzm, sn->node_nz_mem, 1, N, NP, s);
@@ -1095,6 +1145,21 @@ int kb_session_load(kb_engine *e, const kb_snapshot *sn) {
     upload(e->b_ncls, ncls.data(), NP, s);
     upload(e->b_nmask, nmask.data(), NP, s);
     upload(e->b_tinit, hs.t_init.data(), (size_t)R * T, s);
+    {   // the backfill view of t_init: cpu / memory of a BestEffort task are its Resreq (scalar rows are never compared for
+        // them: every InitResreq scalar is at or below the epsilon, resource_info.go:283-287)
+      bool differs = false;
+      for (uint32_t t = 0; t < T && !differs; t++)
+        differs = hs.t_init_empty[t] && (hs.t_res[t] != hs.t_init[t] || hs.t_res[(size_t)T + t] != hs.t_init[(size_t)T + t]);
+      if (differs) {
+        std::vector<double> fit(hs.t_init);
+        for (uint32_t t = 0; t < T; t++)
+          if (hs.t_init_empty[t]) { fit[t] = hs.t_res[t]; fit[(size_t)T + t] = hs.t_res[(size_t)T + t]; }
+        upload(e->b_tfit, fit.data(), (size_t)R * T, s);
+        e->t_fit = e->b_tfit.as<double>();
+      } else {
+        e->t_fit = e->b_tinit.as<double>();
+      }
+    }
     upload(e->b_tres, hs.t_res.data(), (size_t)R * T, s);
     upload(e->b_tnzc, sn->task_nz_cpu, T, s);
     upload(e->b_tnzm, sn->task_nz_mem, T, s);
@@ -1281,7 +1346,7 @@ static int run_action(kb_engine *e, uint32_t action, kb_decision *out, uint64_t 
     uint32_t n = run.plan(e);
     while (n) {
       uint32_t n_done = 0, reason = 0;
-      RoundCtx c = round_prepare(e, n, action == 0 ? 1 : 0, action == 1, true);   // single GPU: every matrix row is local
+      RoundCtx c = round_prepare(e, n, action == 0 ? 1 : 2, action == 1, true);   // single GPU: every matrix row is local
       round_candidates(e, c, 0, c.ns, e->b_keys.as<unsigned long long>());
       round_commit(e, c, e->b_keys.as<unsigned long long>(), nullptr, 0, 0);
       // fast rounds return from the launch immediately: use the wait to speculate the next window
@@ -1654,7 +1719,7 @@ int kb_round_begin(kb_engine *e, uint32_t action, uint32_t *n_rows, uint32_t *n_
       m.run.finish(e);
       return;
     }
-    m.ctx = round_prepare(e, n, action == 0 ? 1 : 0, action == 1);
+    m.ctx = round_prepare(e, n, action == 0 ? 1 : 2, action == 1);
     m.had_candidates = false;
     m.in_round = true;
     // round-start copy of the node state: the reduced deltas are applied to it

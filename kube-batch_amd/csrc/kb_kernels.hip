@@ -75,7 +75,7 @@ __device__ __forceinline__ uint32_t eval_pair(const KbDev &d, const K1Task &t, c
       a >>= 1;
       dd++;
     }
-    ok = fi || fr;
+    ok = fi || (fit_mode != 2 && fr);   // 2: backfill, AddTask's Resreq.LessEqual(Idle) only (node_info.go:161-167)
   }
   if (d.pred_enabled) {
     ok = ok && n.slots && ((n.ports & t.conf) == 0ull);   // pod count (predicates.go:127), PodFitsHostPorts (predicates.go:181-190)

@@ -1,7 +1,7 @@
 """Engine vs oracle on the adversarial raw snapshots of tests/rawgen.py (epsilon edges, zero capacities, nil scalar maps,
-tie-breaks, zero queue weights).  Snapshots outside the envelope kb_session_load accepts (KB_E_UNSUPPORTED / KB_E_INVALID: a
-sub-epsilon BestEffort request, a water-fill the reference would panic on) are skipped — the Go action hands those to the stock
-action.
+tie-breaks, zero queue weights).  Snapshots outside the engine's envelope (KB_E_UNSUPPORTED / KB_E_INVALID: a water-fill the reference would panic on
+at load; at run time a sub-epsilon BestEffort request that no node's AddTask accepts, after which the reference's result depends on
+Go's map order) are skipped — the Go action hands those to the stock action.
 
 Part of the regular -m gpu suite.  Its first run on a GPU (round 2) found three engine bugs that the synthetic clusters could not
 reach: pre-Allocated snapshot tasks of a ready job were dispatched without any ssn.Allocate on the job (session.go:277-285 sits
@@ -44,7 +44,13 @@ def test_engine_equals_oracle_on_adversarial_snapshots(oracle_mod, seed):
     except RuntimeError:
         e.close()
         pytest.skip("the reference would panic on this snapshot")
-    dec = e.run(["allocate", "backfill"])
+    try:
+        dec = e.run(["allocate", "backfill"])
+    except engine.EngineError as err:
+        e.close()
+        if err.code == abi.KB_E_UNSUPPORTED and "sub-epsilon" in str(err):   # found at run time: a BestEffort task no node's AddTask accepts
+            pytest.skip(f"outside the engine's envelope: {err}")
+        raise
     od = o.decisions()
     assert dec.shape == od.shape, (seed, dec.shape, od.shape)
     assert np.array_equal(dec, od), f"seed {seed}: first divergence at decision {int(np.argmax((dec != od).any(axis=1)))}"
