@@ -189,6 +189,18 @@ __global__ void __launch_bounds__(K9_THREADS) k_commit_run(const K9KernArgs ka) 
     a.dev = (const KbDev *)(kp + offsetof(K9KernArgs, dev));
     a.round = (const KbRound *)(kp + offsetof(K9KernArgs, round));
   }
+  if (a.round->chain_expect != 0u && *a.round->chain != a.round->chain_expect) {   // chained to a round that stopped early: skip
+    if (threadIdx.x == 0) {
+      *a.round->chain = 0u;
+      a.result[0] = 0; a.result[1] = KB_REASON_SKIPPED;
+      if (a.host_out) {
+        a.host_out[0] = (unsigned long long)KB_REASON_SKIPPED << 32;
+        __threadfence_system();
+        __hip_atomic_store(&a.host_out[KB_OUT_SEQ], a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+    }
+    return;
+  }
   extern __shared__ __align__(16) unsigned char k9_smem[];
   const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const uint32_t S = a.n_mrows, W = a.n_rows;
@@ -657,6 +669,7 @@ __global__ void __launch_bounds__(K9_THREADS) k_commit_run(const K9KernArgs ka) 
   if (tid == 0) {
     a.result[0] = n_done; a.result[1] = H.reason; a.result[2] = nd; a.result[3] = H.n_dirty_rows;
     a.result[4] = H.n_runs; a.result[5] = H.n_slow; a.result[6] = 0; a.result[7] = 0;
+    if (a.round->chain) *a.round->chain = H.reason == KB_REASON_DONE ? a.round->chain_tag : 0u;   // the round queued behind this one runs only then
     unsigned long long *st = reinterpret_cast<unsigned long long *>(a.result) + KB_OUT_STAMP0;
     st[2] = t_start;
     st[3] = wall_clock64();

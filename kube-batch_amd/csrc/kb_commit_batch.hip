@@ -353,6 +353,18 @@ __global__ void __launch_bounds__(KB_K5_THREADS) k_commit_batch(const K7KernArgs
     a.dev = (const KbDev *)(kp + offsetof(K7KernArgs, dev));
     a.round = (const KbRound *)(kp + offsetof(K7KernArgs, round));
   }
+  if (a.round->chain_expect != 0u && *a.round->chain != a.round->chain_expect) {   // chained to a round that stopped early: skip
+    if (threadIdx.x == 0) {
+      *a.round->chain = 0u;
+      a.result[0] = 0; a.result[1] = KB_REASON_SKIPPED;
+      if (a.host_out) {
+        a.host_out[0] = (unsigned long long)KB_REASON_SKIPPED << 32;
+        __threadfence_system();
+        __hip_atomic_store(&a.host_out[KB_OUT_SEQ], a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+    }
+    return;
+  }
   extern __shared__ __align__(16) unsigned char k5_smem[];
   const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, cap = a.cap, cap2 = a.cap + K7_B;
   K7Mem M;
@@ -858,6 +870,7 @@ __global__ void __launch_bounds__(KB_K5_THREADS) k_commit_batch(const K7KernArgs
   if (tid == 0) {
     a.result[0] = n_done; a.result[1] = reason; a.result[2] = nd; a.result[4] = H.n_refills; a.result[7] = H.n_full; a.result[3] = H.n_seq_rows;
     a.result[5] = H.n_batches; a.result[6] = H.n_dirty_rows;
+    if (a.round->chain) *a.round->chain = reason == KB_REASON_DONE ? a.round->chain_tag : 0u;   // the round queued behind this one runs only then
     unsigned long long *st = reinterpret_cast<unsigned long long *>(a.result) + KB_OUT_STAMP0;
     st[2] = t_start;
     st[3] = wall_clock64();

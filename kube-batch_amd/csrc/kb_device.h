@@ -112,7 +112,15 @@ struct KbRound {
   unsigned long long seq;
   double *delta;               // optional per-node committed deltas of owned rows [NP*(2R+3)] (multi-GPU), may be nullptr
   uint32_t own_row0, own_row1;
+  // Chained rounds: the host queues round k+1 behind round k before it has seen round k's result.  A commit kernel leaves
+  // chain_tag in *chain when its whole window committed (KB_REASON_DONE), 0 otherwise; a round launched with a non-zero
+  // chain_expect runs only if it finds that value there and is skipped otherwise (its kernels return at once, its commit
+  // kernel reports KB_REASON_SKIPPED).  chain == nullptr: not part of a chain.
+  uint32_t *chain;
+  uint32_t chain_expect, chain_tag;
 };
+// true when the round was queued behind a predecessor that did not complete
+#define KB_CHAIN_BROKEN(r) ((r).chain_expect != 0u && *(r).chain != (r).chain_expect)
 
 // Hot arguments of the commit kernel: the ~25 scalars its loops touch (they live in SGPRs).  The full session / round
 // views are read through `dev` / `round` on rare paths only (scalar resource dimensions, multi-GPU deltas, prologue /
@@ -148,6 +156,7 @@ static inline uint32_t kb_node_bits(uint32_t NP) {
 #define KB_OUT_STAMP0 8u
 #define KB_OUT_SEQ 12u
 #define KB_OUT_HDR 16u
+#define KB_OUT_STRIDE (KB_OUT_HDR + KB_K5_MAX_WINDOW)   // words per half of the pinned host mirror (two halves: chained rounds alternate)
 
 #define KB_K5_MAX_WINDOW 1024u   // staging buffers are sized for it; the commit kernel's LDS budget decides the window actually used
 #define KB_K5_MAX_ROWS 256u      // rows per window: one thread of the commit kernel's workgroup per dirty slot
@@ -163,7 +172,8 @@ size_t kb_commit_batch_smem_bytes(uint32_t cap, uint32_t NP, int R);
 
 // KB_REASON_RENORM: the next row's score needs NormalizeReduce over its CURRENT feasible set (preferred node affinity): it is
 // committed as the first row of a fresh round, whose matrix is exact for it
-enum { KB_REASON_DONE = 0, KB_REASON_NO_FEASIBLE = 1, KB_REASON_PIPELINED = 2, KB_REASON_INTERNAL = 3, KB_REASON_RENORM = 4 };
+// KB_REASON_SKIPPED: the round was chained to a predecessor that stopped early; nothing was evaluated or committed
+enum { KB_REASON_DONE = 0, KB_REASON_NO_FEASIBLE = 1, KB_REASON_PIPELINED = 2, KB_REASON_INTERNAL = 3, KB_REASON_RENORM = 4, KB_REASON_SKIPPED = 5 };
 
 // launch wrappers (kb_kernels.hip); all asynchronous on `stream`
 void kb_launch_gather(const KbDev &d, const KbRound &r, void *stream);

@@ -153,20 +153,24 @@ struct kb_engine {
   size_t xs_cap = 0, xslot_cap = 0;
   DevBuf b_mrows, b_same, b_score, b_maskw, b_keys;
   DevBuf b_win, b_out;   // per-round upload / download blocks (see h_win / h_out)
+  DevBuf b_chain;        // KbRound::chain: tag of the last round that committed its whole window
+  int commit_kernel_of[2] = {0, 0};   // the commit kernel launched for the round in each staging half
   uint32_t win_cap = 0, mat_cap = 0;
   size_t keys_cap = 0;
   Pinned<uint32_t> h_rows, h_slot, h_mrows;
   std::vector<uint32_t> h_decnode, h_deckind;
   Pinned<uint32_t> h_win;             // per-round upload  [rows | slots | mrows] at fixed offsets of KB_K5_MAX_WINDOW
   Pinned<unsigned long long> h_out;   // per-round download: KB_OUT_HDR header words (kb_device.h) + decision records
+  const uint32_t *d_hwin = nullptr;       // device view of h_win
+  bool direct_window = true;              // KB_DIRECT_WINDOW=0: always copy the window into b_win first
   unsigned long long *d_hout = nullptr;   // device view of h_out (fast rounds: the commit kernel writes it directly)
   bool fast_rounds = true;            // host spins on h_out[KB_OUT_SEQ] instead of synchronising the stream every round
+  bool chain_rounds = true;           // queue the next speculated round behind the running one (KbRound::chain); KB_CHAIN_ROUNDS=0 disables
   unsigned long long seq = 0;
   double wall_khz = 100000.0;         // rate of the device's constant wall clock
   std::vector<uint8_t> h_same;
   std::vector<uint32_t> shape_stamp, shape_slot_of;   // per row-shape id: round stamp and slot inside the current round
   uint32_t stamp = 0;
-  uint32_t *h_result = nullptr;   // the header words of h_out
   std::vector<Timer> ev;          // event pool for per-launch timing
   std::vector<kb_decision> decisions_all;   // decisions of the last multi-GPU round sequence
   std::vector<uint32_t> evictions;          // committed evictions of the session's preempt actions, in cache.Evict order
@@ -364,8 +368,9 @@ KbRound make_round(kb_engine *e, uint32_t n_rows, uint32_t n_mrows, uint32_t L, 
 }
 
 // distinct shapes of the window e->h_rows[0..n): fills h_slot (per row) and h_mrows (representative task per shape)
-uint32_t assign_shapes(kb_engine *e, uint32_t n) {
+uint32_t assign_shapes(kb_engine *e, uint32_t n, const uint32_t *rows = nullptr) {
   HostSession &hs = e->hs;
+  if (!rows) rows = e->h_rows.data();
   if (e->shape_stamp.size() != hs.n_row_shapes) {
     e->shape_stamp.assign(hs.n_row_shapes, 0);
     e->shape_slot_of.assign(hs.n_row_shapes, 0);
@@ -374,11 +379,11 @@ uint32_t assign_shapes(kb_engine *e, uint32_t n) {
   e->stamp++;
   uint32_t ns = 0;
   for (uint32_t i = 0; i < n; i++) {
-    uint32_t sh = hs.t_row_shape[e->h_rows[i]];
+    uint32_t sh = hs.t_row_shape[rows[i]];
     if (e->shape_stamp[sh] != e->stamp) {
       e->shape_stamp[sh] = e->stamp;
       e->shape_slot_of[sh] = ns;
-      e->h_mrows[ns] = e->h_rows[i];
+      e->h_mrows[ns] = rows[i];
       ns++;
     }
     e->h_slot[i] = e->shape_slot_of[sh];
@@ -392,28 +397,51 @@ struct RoundCtx {
   KbDev d{};
   uint32_t n = 0, ns = 0, L = 0;
   bool backfill = false;
+  bool direct = false;           // the kernels read the window from the pinned staging block (no copy command)
+  uint32_t buf = 0;              // which half of the pinned upload / download blocks the round uses (chained rounds alternate)
+  unsigned long long seq = 0;    // the sequence number its commit kernel publishes
 };
 
 // upload the window e->h_rows[0..n) (task ids, shape slots, representative rows) and build the row descriptors
-RoundCtx round_prepare(kb_engine *e, uint32_t n, int fit_mode, bool backfill, bool gather_in_matrix = false) {
+// `rows` (default e->h_rows) is the window; `buf` selects the half of the pinned staging blocks; a non-zero `chain_expect` queues
+// the round behind a predecessor whose result the host has not seen yet (KbRound::chain)
+RoundCtx round_prepare(kb_engine *e, uint32_t n, int fit_mode, bool backfill, bool gather_in_matrix = false, const uint32_t *rows = nullptr,
+                       uint32_t buf = 0, uint32_t chain_expect = 0) {
   RoundCtx c;
+  if (!rows) rows = e->h_rows.data();
   ensure_window_buffers(e, n);
   ensure_matrix_buffers(e, n, n + 1);
   c.n = n;
-  c.ns = assign_shapes(e, n);
+  c.ns = assign_shapes(e, n, rows);
   c.L = n + 1;   // more candidates than the round can dirty: a clean one always survives
   c.backfill = backfill;
+  c.buf = buf;
   // one staging copy per round: [task rows | shape slots | representative rows], fixed offsets
-  std::memcpy(e->h_win.data(), e->h_rows.data(), sizeof(uint32_t) * n);
-  std::memcpy(e->h_win.data() + KB_K5_MAX_WINDOW, e->h_slot.data(), sizeof(uint32_t) * n);
-  std::memcpy(e->h_win.data() + 2 * KB_K5_MAX_WINDOW, e->h_mrows.data(), sizeof(uint32_t) * c.ns);
-  HIP_OK(hipMemcpyAsync(e->b_win.p, e->h_win.data(), sizeof(uint32_t) * (2 * KB_K5_MAX_WINDOW + c.ns), hipMemcpyHostToDevice, e->stream));
+  uint32_t *hw = e->h_win.data() + (size_t)buf * 3 * KB_K5_MAX_WINDOW;
+  std::memcpy(hw, rows, sizeof(uint32_t) * n);
+  std::memcpy(hw + KB_K5_MAX_WINDOW, e->h_slot.data(), sizeof(uint32_t) * n);
+  std::memcpy(hw + 2 * KB_K5_MAX_WINDOW, e->h_mrows.data(), sizeof(uint32_t) * c.ns);
+  // single-GPU fast rounds: the descriptor gather and the matrix kernel read the staged window straight from the pinned block
+  // (a few hundred 4-byte reads over PCIe, overlapped with the matrix evaluation) instead of waiting for a 7 us copy command
+  const bool direct = gather_in_matrix && e->fast_rounds && e->direct_window;
+  if (!direct) HIP_OK(hipMemcpyAsync(e->b_win.p, hw, sizeof(uint32_t) * (2 * KB_K5_MAX_WINDOW + c.ns), hipMemcpyHostToDevice, e->stream));
   c.d = e->dev;
   if (backfill) {
     c.d.score_enabled = 0;   // backfill.go:50-66 takes the first node that passes the predicates: all scores tie
     c.d.t_init = e->t_fit;   // ... and on which ssn.Allocate's AddTask succeeds: Resreq.LessEqual(Idle), fit_mode 2
   }
   c.r = make_round(e, n, c.ns, c.L, fit_mode, backfill);
+  if (direct) {
+    const uint32_t *dw = e->d_hwin + (size_t)buf * 3 * KB_K5_MAX_WINDOW;
+    c.r.rows = dw;
+    c.r.shape_slot = dw + KB_K5_MAX_WINDOW;
+    c.r.mrows = dw + 2 * KB_K5_MAX_WINDOW;
+  }
+  c.direct = direct;
+  c.seq = ++e->seq;
+  c.r.chain = e->b_chain.as<uint32_t>();
+  c.r.chain_expect = chain_expect;
+  c.r.chain_tag = (uint32_t)(c.seq & 0x7FFFFFFFull) + 1u;   // never 0
   c.r.gather = (gather_in_matrix && c.ns > 0) ? 1u : 0u;
   if (!c.r.gather) kb_launch_gather(c.d, c.r, e->stream);
   return c;
@@ -423,7 +451,7 @@ RoundCtx round_prepare(kb_engine *e, uint32_t n, int fit_mode, bool backfill, bo
 void round_candidates(kb_engine *e, const RoundCtx &c, uint32_t m0, uint32_t m1, unsigned long long *keys) {
   if (m1 <= m0) return;
   KbRound r = c.r;
-  r.mrows = e->b_win.as<uint32_t>() + 2 * KB_K5_MAX_WINDOW + m0;
+  r.mrows = c.r.mrows + m0;
   r.n_mrows = m1 - m0;
   r.keys = keys;
   if (e->fast_rounds) {   // kernel times come from the wall-clock stamps the kernels leave in the output block
@@ -452,12 +480,13 @@ void round_commit(kb_engine *e, const RoundCtx &c, unsigned long long *keys, dou
   r.own_row0 = own0;
   r.own_row1 = own1;
   auto launch = [&]() {
+    e->commit_kernel_of[c.buf] = e->commit_kernel;
     if (e->commit_kernel == KB_COMMIT_RUN) { kb_launch_commit(c.d, r, e->stream); e->rounds_run++; }
     else { kb_launch_commit_batch(c.d, r, e->stream); e->rounds_batch++; }
   };
   if (e->fast_rounds) {
-    r.host_out = e->d_hout;
-    r.seq = ++e->seq;
+    r.host_out = e->d_hout + (size_t)c.buf * KB_OUT_STRIDE;
+    r.seq = c.seq;
     launch();
     return;
   }
@@ -468,24 +497,28 @@ void round_commit(kb_engine *e, const RoundCtx &c, unsigned long long *keys, dou
   HIP_OK(hipMemcpyAsync(e->h_out.data(), e->b_out.p, sizeof(unsigned long long) * (KB_OUT_HDR + c.n), hipMemcpyDeviceToHost, e->stream));
 }
 
-static inline uint32_t n_done_rows_hint(const kb_engine *e) { return e->h_result[0]; }
 
 // wait for the round, account the kernel times, unpack the decision records
 void round_collect(kb_engine *e, const RoundCtx &c, bool had_candidates, uint32_t &n_done, uint32_t &reason) {
+  const unsigned long long *ho = e->h_out.data() + (e->fast_rounds ? (size_t)c.buf * KB_OUT_STRIDE : 0);
+  const uint32_t *h_result = reinterpret_cast<const uint32_t *>(ho);
   if (e->fast_rounds) {
     // the commit kernel publishes the round's sequence number into pinned host memory after everything else
-    volatile unsigned long long *seqw = e->h_out.data() + KB_OUT_SEQ;
+    volatile const unsigned long long *seqw = ho + KB_OUT_SEQ;
     const double t0 = now_ms();
     uint32_t spins = 0;
-    while (__atomic_load_n(seqw, __ATOMIC_ACQUIRE) != e->seq) {
+    while (__atomic_load_n(seqw, __ATOMIC_ACQUIRE) != c.seq) {
       __builtin_ia32_pause();
       if ((++spins & 0xFFFFu) == 0 && now_ms() - t0 > 10000.0) {   // a faulted kernel never publishes: surface the HIP error
         HIP_OK(hipStreamSynchronize(e->stream));
         HIP_OK(hipGetLastError());
-        if (__atomic_load_n(seqw, __ATOMIC_ACQUIRE) != e->seq) throw EngineError(KB_E_DEVICE, "commit kernel finished without publishing its round");
+        if (__atomic_load_n(seqw, __ATOMIC_ACQUIRE) != c.seq) throw EngineError(KB_E_DEVICE, "commit kernel finished without publishing its round");
       }
     }
-    const unsigned long long *st = e->h_out.data() + KB_OUT_STAMP0;
+    n_done = h_result[0];
+    reason = h_result[1];
+    if (reason == KB_REASON_SKIPPED) return;   // queued behind a round that stopped early: nothing ran
+    const unsigned long long *st = ho + KB_OUT_STAMP0;
     const double per_ms = 1.0 / e->wall_khz;
     if (had_candidates) {
       e->stats.matrix_ms += (double)(st[1] - st[0]) * per_ms;   // includes the descriptor gather
@@ -506,25 +539,25 @@ void round_collect(kb_engine *e, const RoundCtx &c, bool had_candidates, uint32_
     e->stats.commit_ms += ms;
   }
   for (uint32_t i = 0; i < c.n; i++) {
-    e->h_decnode[i] = (uint32_t)(e->h_out[KB_OUT_HDR + i] & 0xFFFFFFFFull);
-    e->h_deckind[i] = (uint32_t)(e->h_out[KB_OUT_HDR + i] >> 32);
+    e->h_decnode[i] = (uint32_t)(ho[KB_OUT_HDR + i] & 0xFFFFFFFFull);
+    e->h_deckind[i] = (uint32_t)(ho[KB_OUT_HDR + i] >> 32);
   }
-  n_done = e->h_result[0];
-  reason = e->h_result[1];
+  n_done = h_result[0];
+  reason = h_result[1];
   if (reason == KB_REASON_INTERNAL) throw EngineError(KB_E_INTERNAL, "commit kernel ran out of candidate list entries (list shorter than the window)");
   // rows won by a node the round had already changed (the batch kernel reports them in word 6, word 3 counts its row-mode rows)
-  const uint32_t dirty_won = e->commit_kernel == KB_COMMIT_RUN ? e->h_result[3] : e->h_result[6];
+  const uint32_t dirty_won = e->commit_kernel_of[c.buf] == KB_COMMIT_RUN ? h_result[3] : h_result[6];
   e->stats.row_fallbacks += dirty_won;
-  if (e->commit_kernel == KB_COMMIT_RUN) {
-    e->k5_slots += e->h_result[2];
-    e->k5_walks += e->h_result[4];
-    e->k5_rescans += e->h_result[5];
+  if (e->commit_kernel_of[c.buf] == KB_COMMIT_RUN) {
+    e->k5_slots += h_result[2];
+    e->k5_walks += h_result[4];
+    e->k5_rescans += h_result[5];
     for (int k = 0; k < 10; k++)   // zero unless built with -DKB_K9_TRACE
-      e->k5_trace[k] += (double)(uint32_t)(e->h_out[(k < 6 ? 5 + k / 2 : 13 + (k - 6) / 2)] >> (32 * (k & 1)));
+      e->k5_trace[k] += (double)(uint32_t)(ho[(k < 6 ? 5 + k / 2 : 13 + (k - 6) / 2)] >> (32 * (k & 1)));
   }
   // next round's kernel: a round in which more than ~a quarter of the rows went to dirty nodes cuts most speculated batches short
-  if (n_done_rows_hint(e)) {
-    const double share = (double)dirty_won / (double)n_done_rows_hint(e);
+  if (n_done) {
+    const double share = (double)dirty_won / (double)n_done;
     e->dirty_share = e->stats.rounds == 0 ? share : 0.75 * e->dirty_share + 0.25 * share;
   }
   if (e->commit_pin >= 0) e->commit_kernel = e->commit_pin;
@@ -847,14 +880,17 @@ int kb_engine_create(const kb_config *cfg, kb_engine **out) {
     HIP_OK(hipStreamCreateWithFlags(&eng->own_stream, hipStreamNonBlocking));
     eng->stream = eng->own_stream;
     eng->b_win.alloc(sizeof(uint32_t) * 3 * KB_K5_MAX_WINDOW);
-    eng->h_win.resize(3 * KB_K5_MAX_WINDOW);
+    eng->h_win.flags = hipHostMallocMapped | hipHostMallocCoherent;   // read by the device directly in single-GPU fast rounds
+    eng->h_win.resize(2 * 3 * KB_K5_MAX_WINDOW);   // two halves: a chained round is staged while its predecessor's copy may still be pending
     eng->b_out.alloc(sizeof(unsigned long long) * (KB_OUT_HDR + KB_K5_MAX_WINDOW));
     HIP_OK(hipMemset(eng->b_out.p, 0, eng->b_out.bytes));
     eng->h_out.flags = hipHostMallocMapped | hipHostMallocCoherent;   // written by the commit kernel while the host polls
-    eng->h_out.resize(KB_OUT_HDR + KB_K5_MAX_WINDOW);
-    std::memset(eng->h_out.data(), 0, sizeof(unsigned long long) * (KB_OUT_HDR + KB_K5_MAX_WINDOW));
-    eng->h_result = reinterpret_cast<uint32_t *>(eng->h_out.data());
+    eng->h_out.resize(2 * KB_OUT_STRIDE);
+    std::memset(eng->h_out.data(), 0, sizeof(unsigned long long) * 2 * KB_OUT_STRIDE);
+    eng->b_chain.alloc(sizeof(uint32_t));
+    HIP_OK(hipMemsetAsync(eng->b_chain.p, 0, sizeof(uint32_t), eng->stream));
     HIP_OK(hipHostGetDevicePointer((void **)&eng->d_hout, eng->h_out.data(), 0));
+    HIP_OK(hipHostGetDevicePointer((void **)&eng->d_hwin, eng->h_win.data(), 0));
     {
       int khz = 0;
       if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, eng->device) == hipSuccess && khz > 0) eng->wall_khz = (double)khz;
@@ -865,6 +901,10 @@ int kb_engine_create(const kb_config *cfg, kb_engine **out) {
       }
       const char *sr = getenv("KB_SYNC_ROUNDS");
       eng->fast_rounds = !(eng->flags & KB_FLAG_SYNC_ROUNDS) && !(sr && sr[0] == '1');
+      const char *cr = getenv("KB_CHAIN_ROUNDS");   // 0: launch every round only after the previous one was collected (A/B, debugging)
+      eng->chain_rounds = !(cr && cr[0] == '0');
+      const char *dw = getenv("KB_DIRECT_WINDOW");
+      eng->direct_window = !(dw && dw[0] == '0');
     }
     e = eng.release();
   });
@@ -1344,18 +1384,47 @@ static int run_action(kb_engine *e, uint32_t action, kb_decision *out, uint64_t 
     ActionRun run;
     run.begin(e, action);
     uint32_t n = run.plan(e);
+    ensure_matrix_buffers(e, e->eff_window, e->eff_window + 1);   // sized once: no reallocation under a round in flight
+    auto launch = [&](uint32_t rows_n, const uint32_t *rows, uint32_t buf, uint32_t chain_expect) {
+      RoundCtx c = round_prepare(e, rows_n, action == 0 ? 1 : 2, action == 1, true, rows, buf, chain_expect);   // single GPU: every matrix row is local
+      unsigned long long *keys = e->b_keys.as<unsigned long long>();
+      round_candidates(e, c, 0, c.ns, keys);
+      round_commit(e, c, keys, nullptr, 0, 0);
+      return c;
+    };
+    // Fast rounds return from the launch immediately.  The host uses the wait to speculate the NEXT window (assuming the one in
+    // flight completes, which ~80 % do) and queues that round behind the running one right away: the device starts it the
+    // moment the commit kernel ends instead of idling through a host round trip (~19 us per round).  A round that stops early
+    // clears the chain word and the queued round skips itself (KbRound::chain).
+    const bool ahead = action == 0 && e->fast_rounds;
+    const bool chained = ahead && e->chain_rounds;
+    uint32_t buf = 0;
+    RoundCtx c{};
+    if (n) c = launch(n, nullptr, buf, 0);
     while (n) {
       uint32_t n_done = 0, reason = 0;
-      RoundCtx c = round_prepare(e, n, action == 0 ? 1 : 2, action == 1, true);   // single GPU: every matrix row is local
-      round_candidates(e, c, 0, c.ns, e->b_keys.as<unsigned long long>());
-      round_commit(e, c, e->b_keys.as<unsigned long long>(), nullptr, 0, 0);
-      // fast rounds return from the launch immediately: use the wait to speculate the next window
-      const bool ahead = action == 0 && e->fast_rounds;
       const uint32_t n_next = ahead ? run.plan_ahead(e) : 0;
+      RoundCtx cn{};
+      const bool queued = chained && n_next > 0;
+      if (queued) cn = launch(n_next, run.rows_next.data(), buf ^ 1u, c.r.chain_tag);
       round_collect(e, c, true, n_done, reason);
       run.absorb(e, n, n_done, reason);
-      if (ahead && reason == KB_REASON_DONE) { run.promote(e, n_next); n = n_next; }
-      else n = run.plan(e);
+      if (ahead && reason == KB_REASON_DONE) {
+        run.promote(e, n_next);
+        n = n_next;
+        if (queued) { c = cn; buf ^= 1u; }
+        else if (n) c = launch(n, nullptr, buf, 0);
+      } else {
+        if (queued) {   // the queued round skipped itself: consume its publication before its staging half is reused
+          uint32_t nd2 = 0, rs2 = 0;
+          round_collect(e, cn, true, nd2, rs2);
+          if (rs2 != KB_REASON_SKIPPED) throw EngineError(KB_E_INTERNAL, "a round queued behind a stopped round ran");
+          e->stats.matrix_launches -= 1;
+          e->stats.matrix_evals -= (uint64_t)cn.ns * e->hs.N;
+        }
+        n = run.plan(e);
+        if (n) c = launch(n, nullptr, buf, 0);
+      }
     }
     run.finish(e);
     if (n_out) *n_out = run.decs.size();

@@ -123,6 +123,7 @@ template <int NPT, int TR>
 __global__ void __launch_bounds__(256) k_matrix(KbDev d, KbRound r) {
   __shared__ K1Task srow[TR];
   __shared__ uint8_t ssame[TR];
+  if (KB_CHAIN_BROKEN(r)) return;
   if (r.gather && blockIdx.y == gridDim.y - 1) {   // the extra block row of a single-GPU round: the window's row descriptors
     if (blockIdx.x == 0 && threadIdx.x == 0) reinterpret_cast<unsigned long long *>(r.result)[KB_OUT_STAMP0] = wall_clock64();
     for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < r.n_rows; i += gridDim.x * 256) gather_row(d, r, i);
@@ -291,6 +292,7 @@ __global__ void __launch_bounds__(THREADS) k_argmax(KbDev d, KbRound r) {
   __shared__ uint32_t s_wcnt[WAVES][NW];
   const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const uint32_t row = blockIdx.x;
+  if (KB_CHAIN_BROKEN(r)) return;
   if (row == 0 && tid == 0 && r.mrow_task0 == 0 && r.mrows != nullptr)   // round launches only (not kb_eval_matrix's expanded rows)
     reinterpret_cast<unsigned long long *>(r.result)[KB_OUT_STAMP0 + 1] = wall_clock64();
   const uint32_t K = r.L;
@@ -421,6 +423,7 @@ __device__ __forceinline__ bool bit_test(const uint32_t *bm, uint32_t n) { retur
 // row of the matrix launch)
 __global__ void __launch_bounds__(256) k_gather(KbDev d, KbRound r) {
   const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+  if (KB_CHAIN_BROKEN(r)) return;
   if (i == 0) reinterpret_cast<unsigned long long *>(r.result)[KB_OUT_STAMP0] = wall_clock64();   // round start (constant-rate clock)
   gather_row(d, r, i);
 }
@@ -431,6 +434,7 @@ __global__ void __launch_bounds__(256) k_gather(KbDev d, KbRound r) {
 __global__ void __launch_bounds__(256) k_affinity(KbDev d, KbRound r) {
   __shared__ int s_max[4];
   const uint32_t row = blockIdx.x, tid = threadIdx.x;
+  if (KB_CHAIN_BROKEN(r)) return;
   const uint32_t t = r.mrows ? r.mrows[row] : r.mrow_task0 + row;
   const uint32_t tc = d.t_cls[t];
   if (!d.aff_cls[tc]) return;   // uniform per block
