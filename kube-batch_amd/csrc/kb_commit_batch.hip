@@ -94,29 +94,46 @@ __device__ __forceinline__ bool bit_test(const uint32_t *bm, uint32_t n) { retur
 #define K5_NF8 10
 #define K5_WAVES (KB_K5_THREADS / 64)
 
-__device__ __forceinline__ NodeVals k5_slot_vals(const unsigned long long *tab, const uint32_t *t_cls, const int *t_left, uint32_t cap, uint32_t slot,
-                                              const unsigned long long *ptab = nullptr) {
-  NodeVals nv;
-  nv.idle0 = __longlong_as_double((long long)tab[K5F_IDLE0 * cap + slot]);
-  nv.idle1 = __longlong_as_double((long long)tab[K5F_IDLE1 * cap + slot]);
-  nv.rel0 = __longlong_as_double((long long)tab[K5F_REL0 * cap + slot]);
-  nv.rel1 = __longlong_as_double((long long)tab[K5F_REL1 * cap + slot]);
-  nv.inv_ac = __longlong_as_double((long long)tab[K5F_INVAC * cap + slot]);
-  nv.inv_am = __longlong_as_double((long long)tab[K5F_INVAM * cap + slot]);
-  nv.ac = (long long)tab[K5F_AC * cap + slot];
-  nv.am = (long long)tab[K5F_AM * cap + slot];
-  nv.nzc = (long long)tab[K5F_NZC * cap + slot];
-  nv.nzm = (long long)tab[K5F_NZM * cap + slot];
+// Float64-only evaluation (kb_eval.hpp: score_core_f64): the k8s scorers' int64 quantities (allocatable, non-zero request sums) are
+// kept as doubles in the LDS slot table and in the staged row descriptors (exact below 2^48, kb_session_load rejects more), so an
+// evaluation has no 64-bit integer multiply and no int64 <-> double conversion.
+static_assert(sizeof(KbRowDesc) == 56 && offsetof(KbRowDesc, nzc) == 16 && offsetof(KbRowDesc, nzm) == 24, "staging converts words 2 and 3 of a descriptor");
+struct TaskValsD {
+  double init0, init1, nzc, nzm;
+  uint32_t cls, active, task, pad;
+  unsigned long long conf;
+};
+struct NodeValsD {
+  double idle0, idle1, rel0, rel1, ac, am, nzc, nzm, inv_ac, inv_am;
+  uint32_t cls;
+  int slots;
+  unsigned long long ports;
+};
+__device__ __forceinline__ double u2d(unsigned long long v) { return __longlong_as_double((long long)v); }
+__device__ __forceinline__ unsigned long long d2u(double v) { return (unsigned long long)__double_as_longlong(v); }
+
+__device__ __forceinline__ NodeValsD k5_slot_vals(const unsigned long long *tab, const uint32_t *t_cls, const int *t_left, uint32_t cap, uint32_t slot,
+                                               const unsigned long long *ptab = nullptr) {
+  NodeValsD nv;
+  nv.idle0 = u2d(tab[K5F_IDLE0 * cap + slot]);
+  nv.idle1 = u2d(tab[K5F_IDLE1 * cap + slot]);
+  nv.rel0 = u2d(tab[K5F_REL0 * cap + slot]);
+  nv.rel1 = u2d(tab[K5F_REL1 * cap + slot]);
+  nv.inv_ac = u2d(tab[K5F_INVAC * cap + slot]);
+  nv.inv_am = u2d(tab[K5F_INVAM * cap + slot]);
+  nv.ac = u2d(tab[K5F_AC * cap + slot]);
+  nv.am = u2d(tab[K5F_AM * cap + slot]);
+  nv.nzc = u2d(tab[K5F_NZC * cap + slot]);
+  nv.nzm = u2d(tab[K5F_NZM * cap + slot]);
   nv.ports = ptab ? ptab[slot] : 0ull;
   nv.cls = t_cls[slot];
   nv.slots = t_left[slot] > 0;
-  nv.valid = 1;
   return nv;
 }
 
 // eval_pair for the commit kernel: policy scalars from the by-value argument struct, session arrays (scalar resource
 // dimensions, wide class tables) through the device-memory copy of KbDev on the rare paths only
-__device__ __forceinline__ uint32_t eval_pair_k5(const KbCommitArgs &a, const TaskVals &t, const NodeVals &n, uint32_t node, const uint32_t *class_row) {
+__device__ __forceinline__ uint32_t eval_pair_k5(const KbCommitArgs &a, const TaskValsD &t, const NodeValsD &n, uint32_t node, const uint32_t *class_row) {
   bool ok = true;
   if (a.fit_mode) {   // allocate.go:81
     bool fi = le_eps(t.init0, n.idle0, EPS_CPU) && le_eps(t.init1, n.idle1, EPS_MEM);
@@ -151,7 +168,7 @@ __device__ __forceinline__ uint32_t eval_pair_k5(const KbCommitArgs &a, const Ta
   }
   if (!ok) return 0;
   uint32_t score = 0;
-  if (a.score_enabled) score = score_core(t, n, a.wL, a.wM, a.wB);
+  if (a.score_enabled) score = score_core_f64(t.nzc, t.nzm, n.nzc, n.nzm, n.ac, n.am, n.inv_ac, n.inv_am, a.wL, a.wM, a.wB);
   return 0x10000u | (score & 0xFFFFu);
 }
 
@@ -199,11 +216,15 @@ __device__ __forceinline__ void k5_field_ptrs(const KbDev &d, uint32_t fld, cons
 #define K7_B 32u          // most rows one batch can speculate
 #define K7_B_DEFAULT 16u  // batch size after a batch that was cut short; doubled after a fully valid one
 #define K7_D 96u   // row descriptors staged per refill
+#define K7_KQ 5    // 64 * K7_KQ >= KB_K5_MAX_ROWS + K7_B dirty slots: the row-at-a-time mode keeps one key per slot in registers
 
+static_assert(64 * K7_KQ >= KB_K5_MAX_ROWS + K7_B, "row mode keeps one key per dirty slot in registers");
 struct K7Hdr {
   unsigned long long c[K7_B];           // clean candidate key of batch row j (0: the list has no clean feasible node left)
   unsigned long long dmax[K7_B];        // per distinct shape q of the batch: best key over the pre-batch dirty slots
   unsigned long long kb[K7_B][K7_B];    // [row l][shape q]: key of row l's node in its post-commit state
+  unsigned long long mrow[K7_B];        // per batch row j: max of kb[l][q_j] over the earlier batch rows l < j (built by the evaluate step)
+  uint32_t rowmask[K7_B];               // per distinct shape q: the batch rows that carry it
   unsigned long long win[K7_B][64];     // candidate window of shape q, starting at win_base[q]
   uint32_t win_base[K7_B];
   uint32_t rep[K7_B];                   // batch row whose descriptor represents shape q
@@ -246,9 +267,10 @@ __host__ __device__ inline size_t k7_smem_bytes(uint32_t cap, uint32_t NP, int R
   return cap2 * (K5_NF8 * 8 + 8 + 8 + 3 * 4) + (size_t)cap * (8 + 8 + 12) + (size_t)(NP / 32) * 4 + (size_t)K7_B * (R > 2 ? R - 2 : 0) * 8 + sizeof(K7Hdr) + 64;
 }
 
-__device__ __forceinline__ TaskVals k7_task_vals(const KbCommitArgs &a, const KbRowDesc &k) {
-  TaskVals tv;
-  tv.init0 = k.init0; tv.init1 = k.init1; tv.nzc = k.nzc; tv.nzm = k.nzm;
+// `k` is a STAGED descriptor (H.dbuf): its nzc / nzm words hold the pod's non-zero request as double bit patterns
+__device__ __forceinline__ TaskValsD k7_task_vals(const KbCommitArgs &a, const KbRowDesc &k) {
+  TaskValsD tv;
+  tv.init0 = k.init0; tv.init1 = k.init1; tv.nzc = __longlong_as_double(k.nzc); tv.nzm = __longlong_as_double(k.nzm);
   tv.cls = k.cls; tv.active = k.active; tv.task = k.task; tv.pad = 0;
   tv.conf = a.has_ports ? a.dev->t_conf[k.task] : 0ull;   // host-port sessions only: straight from the task table
   return tv;
@@ -301,45 +323,23 @@ __device__ __forceinline__ void k7_commit_globals(const KbCommitArgs &a, const K
         }
       }
       double *tail = r.delta + (size_t)2 * d.R * d.NP;
-      tail[n] += (double)k.nzc;
-      tail[(size_t)d.NP + n] += (double)k.nzm;
+      tail[n] += __longlong_as_double(k.nzc);   // staged descriptor: double bits
+      tail[(size_t)d.NP + n] += __longlong_as_double(k.nzm);
       tail[(size_t)2 * d.NP + n] += 1.0;
     }
   }
 }
 
-// Allocate or Pipeline for row k on the node held in `slot` (allocate.go:160), then NodeInfo.AddTask on the LDS copy
-__device__ __forceinline__ uint32_t k7_apply_slot(const KbCommitArgs &a, const K7Mem &M, const KbRowDesc &k, uint32_t slot, uint32_t n) {
-  const uint32_t cap2 = M.cap2;
-  double res0, res1;
-  k7_resreq(a, k, res0, res1);
-  uint32_t kind = 0;
-  if (!a.backfill) {
-    bool fi = le_eps(k.init0, __longlong_as_double((long long)M.tab[K5F_IDLE0 * cap2 + slot]), EPS_CPU) &&
-              le_eps(k.init1, __longlong_as_double((long long)M.tab[K5F_IDLE1 * cap2 + slot]), EPS_MEM);
-    uint32_t act = k.active >> 2;
-    if (act) {
-      const KbDev &d = *a.dev;
-      uint32_t dd = 2;
-      while (act) {
-        if (act & 1u) fi = fi && le_eps(d.t_init[(size_t)dd * d.T + k.task], d.idle[(size_t)dd * d.NP + n], EPS_SCALAR);
-        act >>= 1; dd++;
-      }
-    }
-    kind = fi ? 0u : 1u;
-  }
-  const uint32_t f0 = kind ? K5F_REL0 : K5F_IDLE0;
-  M.tab[(size_t)f0 * cap2 + slot] = (unsigned long long)__double_as_longlong(__longlong_as_double((long long)M.tab[(size_t)f0 * cap2 + slot]) - res0);
-  M.tab[(size_t)(f0 + 1) * cap2 + slot] = (unsigned long long)__double_as_longlong(__longlong_as_double((long long)M.tab[(size_t)(f0 + 1) * cap2 + slot]) - res1);
-  M.tab[(size_t)K5F_NZC * cap2 + slot] += (unsigned long long)k.nzc;
-  M.tab[(size_t)K5F_NZM * cap2 + slot] += (unsigned long long)k.nzm;
-  if (a.has_ports) M.ptab[slot] |= a.dev->t_want[k.task];   // the pod's host ports join nodeinfo.UsedPorts()
-  return kind;
-}
-
-
 // The launch passes {hot scalars, KbDev, KbRound} as ONE by-value block.  Only `hot` is named in the code (-> SGPRs); the two
 // views are reached through the kernel-argument segment pointer, i.e. read from constant memory where a rare path needs them.
+// make EXTRA=-DKB_K7_TRACE OUT=../libkbengine_trace.so: clocks (100 MHz s_memtime) thread 0 spends in each phase of a batch,
+// barrier waits included, summed per round into words 4..7 of the output block; printed by the host under KB_K5_STATS=1
+#ifdef KB_K7_TRACE
+#define K7_STAMP(k) do { if (tid == 0) { const unsigned long long now_ = wall_clock64(); tacc[k] += (uint32_t)(now_ - tlast); tlast = now_; } } while (0)
+#else
+#define K7_STAMP(k) do { } while (0)
+#endif
+
 struct K7KernArgs {
   KbCommitArgs hot;
   KbDev dev;
@@ -435,18 +435,30 @@ __global__ void __launch_bounds__(KB_K5_THREADS) k_commit_batch(const K7KernArgs
   __syncthreads();
 
   uint32_t i0 = 0, nd = 0, n_done = 0, reason = KB_REASON_DONE, dbase = 0, dcnt = 0, nb_cur = a.batch;
+#ifdef KB_K7_TRACE
+  uint32_t tacc[14] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long tlast = wall_clock64();
+  if (tid == 0) tacc[13] = (uint32_t)(tlast - t_start);   // prologue
+#endif
   while (i0 < a.n_rows) {
     uint32_t nb = min(nb_cur, a.n_rows - i0);
     // ---- stage row descriptors: three batches' worth per refill, so most batches find theirs already in LDS
     if (i0 < dbase || i0 + nb > dbase + dcnt) {
+      __syncthreads();   // wave 0 may still be reading the staged descriptors of the previous batch (roll-back)
       dbase = i0;
       dcnt = min(K7_D, a.n_rows - i0);
       const unsigned long long *src = reinterpret_cast<const unsigned long long *>(a.desc + i0);
       unsigned long long *dst = reinterpret_cast<unsigned long long *>(H.dbuf);
-      for (uint32_t w = tid; w < dcnt * (uint32_t)(sizeof(KbRowDesc) / 8); w += KB_K5_THREADS) dst[w] = src[w];
+      for (uint32_t w = tid; w < dcnt * (uint32_t)(sizeof(KbRowDesc) / 8); w += KB_K5_THREADS) {
+        unsigned long long v = src[w];
+        const uint32_t fw = w % (uint32_t)(sizeof(KbRowDesc) / 8);
+        if (fw == 2 || fw == 3) v = d2u((double)(long long)v);   // nzc, nzm: staged as doubles (TaskValsD)
+        dst[w] = v;
+      }
       __syncthreads();
     }
     const KbRowDesc *bd = H.dbuf + (i0 - dbase);
+    K7_STAMP(0);
     if (a.has_aff && !a.backfill) {
       // a row whose score is normalised over its feasible set (preferred node affinity) is exact only against a fresh matrix:
       // it may be the first row of a round, nothing else; the batch stops in front of it and the round ends there
@@ -460,6 +472,7 @@ __global__ void __launch_bounds__(KB_K5_THREADS) k_commit_batch(const K7KernArgs
     if (wave == 0) {
       const bool in = lane < nb;
       const uint32_t s = in ? (uint32_t)bd[in ? lane : 0].slot : 0u;
+      if (lane < K7_B) { H.rowmask[lane] = 0u; H.mrow[lane] = 0ull; }
       if (in) atomicMin(&M.qstamp[s], lane);
       const uint32_t first = in ? M.qstamp[s] : 0xFFFFFFFFu;
       const bool isrep = in && first == lane;
@@ -470,6 +483,7 @@ __global__ void __launch_bounds__(KB_K5_THREADS) k_commit_batch(const K7KernArgs
         q = (uint32_t)__popcll(repmask & ((1ull << first) - 1ull));
         H.q_of[lane] = q;
         M.qstamp[s] = 0xFFFFFFFFu;
+        atomicOr(&H.rowmask[q], 1u << lane);
       }
       if (isrep) {
         const uint32_t nlog = H.nlog;
@@ -493,6 +507,7 @@ __global__ void __launch_bounds__(KB_K5_THREADS) k_commit_batch(const K7KernArgs
       if (lane == 0) { H.nshapes = nsh; H.n_pairs = total; H.n_batches++; }
     }
     __syncthreads();
+    K7_STAMP(1);
     // ---- candidate windows of the distinct shapes: one wave per shape
     const uint32_t nshapes = H.nshapes;
     for (uint32_t q = wave; q < nshapes; q += K5_WAVES) {
@@ -501,6 +516,7 @@ __global__ void __launch_bounds__(KB_K5_THREADS) k_commit_batch(const K7KernArgs
       H.win[q][lane] = (e < a.L) ? a.keys[(size_t)s * a.L + e] : 0ull;
     }
     __syncthreads();
+    K7_STAMP(2);
     // ---- walk (wave 0): runs of consecutive rows with the same shape take successive clean entries of its window
     if (wave == 0) {
       const uint32_t myq = (lane < nb) ? H.q_of[lane] : 0xFFFFFFFFu;
@@ -551,6 +567,7 @@ __global__ void __launch_bounds__(KB_K5_THREADS) k_commit_batch(const K7KernArgs
       }
     }
     __syncthreads();
+    K7_STAMP(3);
     // ---- fetch + apply: the 16 lanes of one DPP row handle one batch row.  Lane f reads field f of the row's candidate
     //      node (one load), the group votes Allocate / Pipeline (allocate.go:160) with a ballot, every lane applies
     //      NodeInfo.AddTask (api/node_info.go:172-212) to its own field and stores it into the row's NEW dirty slot: the slot
@@ -567,6 +584,7 @@ __global__ void __launch_bounds__(KB_K5_THREADS) k_commit_batch(const K7KernArgs
         uint32_t v4 = 0;
         if (f < K5_NF8) v8 = g8[n];
         else if (f <= 12) v4 = g4[n];
+        if (f >= K5F_AC && f <= K5F_NZM) v8 = d2u((double)(long long)v8);   // int64 in HBM, double in the slot table
         double res0, res1;
         k7_resreq(a, k, res0, res1);
         bool ok = true;
@@ -589,8 +607,8 @@ __global__ void __launch_bounds__(KB_K5_THREADS) k_commit_batch(const K7KernArgs
         const double dv = __longlong_as_double((long long)v8);
         if (f == f0) v8 = (unsigned long long)__double_as_longlong(dv - res0);
         else if (f == f0 + 1) v8 = (unsigned long long)__double_as_longlong(dv - res1);
-        else if (f == K5F_NZC) v8 += (unsigned long long)k.nzc;
-        else if (f == K5F_NZM) v8 += (unsigned long long)k.nzm;
+        else if (f == K5F_NZC) v8 = d2u(u2d(v8) + __longlong_as_double(k.nzc));
+        else if (f == K5F_NZM) v8 = d2u(u2d(v8) + __longlong_as_double(k.nzm));
         if (f < K5_NF8) M.tab[(size_t)f * cap2 + slot] = v8;
         const uint32_t nxt = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v4, 0x101, 0xf, 0xf, true);   // row_shl:1: lane 11 <- pods
         if (f == 10) M.t_cls[slot] = v4;
@@ -620,19 +638,18 @@ __global__ void __launch_bounds__(KB_K5_THREADS) k_commit_batch(const K7KernArgs
       if (f == 15) H.has_map[j] = has_map;
     }
     __syncthreads();
+    K7_STAMP(4);
     // ---- evaluate the work lists: (shape q, slot x) -> dmax[q] for slots older than the batch, kb[row][q] for its own
     {
       const uint32_t P = H.n_pairs;
-      uint32_t off[K7_B];
-#pragma unroll
-      for (int k = 0; k < (int)K7_B; k += 4) {
-        const uint4 v = *reinterpret_cast<const uint4 *>(&H.e_off[k]);
-        off[k] = v.x; off[k + 1] = v.y; off[k + 2] = v.z; off[k + 3] = v.w;
-      }
+      // pair e belongs to the shape q with e_off[q] <= e < e_off[q + 1]: lane l of every wave holds e_off[l], the search reads
+      // them back as scalars, one compare per distinct shape of the batch (a handful)
+      uint32_t voff = H.e_off[lane & (K7_B - 1u)];
+      asm volatile("" : "+v"(voff));   // loaded by EVERY lane: the compiler must not sink the load under the `e < P` mask (readlane reads inactive lanes)
+      const uint32_t nsh = (uint32_t)__builtin_amdgcn_readfirstlane((int)H.nshapes);
       for (uint32_t e = tid; e < P; e += KB_K5_THREADS) {
         uint32_t q = 0;
-#pragma unroll
-        for (int k = 1; k < (int)K7_B; k++) q += (e >= off[k]) ? 1u : 0u;
+        for (uint32_t k = 1; k < nsh; k++) q += (e >= (uint32_t)__builtin_amdgcn_readlane((int)voff, (int)k)) ? 1u : 0u;
         uint32_t r = e - H.e_off[q];
         const uint32_t start = H.e_start[q], nn = nd - start, nl = H.e_nlog[q];
         uint32_t x;
@@ -642,28 +659,36 @@ __global__ void __launch_bounds__(KB_K5_THREADS) k_commit_batch(const K7KernArgs
         unsigned long long key = 0ull;
         if (x < nd || H.c[x - nd] != 0ull) {
           const KbRowDesc &k = bd[H.rep[q]];
-          const TaskVals tv = k7_task_vals(a, k);
-          const NodeVals nv = k5_slot_vals(M.tab, M.t_cls, M.t_left, cap2, x, a.has_ports ? M.ptab : nullptr);
+          const TaskValsD tv = k7_task_vals(a, k);
+          const NodeValsD nv = k5_slot_vals(M.tab, M.t_cls, M.t_left, cap2, x, a.has_ports ? M.ptab : nullptr);
           const uint32_t node = M.t_node[x];
           const uint32_t res = eval_pair_k5(a, tv, nv, node, a.use_crow ? &k.crow : nullptr);
           key = res ? KB_KEY(res & 0xFFFFu, node) : 0ull;
         }
         if (x < nd) { if (key) atomicMax(&H.dmax[q], key); }
-        else H.kb[x - nd][q] = key;
+        else {
+          const uint32_t l = x - nd;
+          H.kb[l][q] = key;
+          if (key) {   // a later row of the same shape must beat this node in its post-commit state
+            uint32_t later = H.rowmask[q] & ~((2u << l) - 1u);
+            while (later) {
+              const uint32_t j = (uint32_t)__ffs((int)later) - 1u;
+              atomicMax(&H.mrow[j], key);
+              later &= later - 1u;
+            }
+          }
+        }
       }
     }
     __syncthreads();
+    K7_STAMP(5);
     // ---- validate (wave 0)
     if (wave == 0) {
       const bool in = lane < nb;
       const unsigned long long cj = in ? H.c[lane] : 0ull;
       const uint32_t q = in ? H.q_of[lane] : 0u;
-      unsigned long long m = in ? H.dmax[q] : 0ull;
-#pragma unroll 8
-      for (uint32_t l = 0; l + 1 < nb; l++) {
-        const unsigned long long kk = H.kb[l][q];
-        if (l < lane && kk > m) m = kk;
-      }
+      unsigned long long m = 0ull;
+      if (in) { const unsigned long long m1 = H.dmax[q], m2 = H.mrow[lane]; m = m1 > m2 ? m1 : m2; }
       if (in && H.rep[q] == lane) {   // the shape's dirty max as of this batch's start becomes its cache
         const uint32_t s = bd[lane].slot;
         M.dc_key[s] = H.dmax[q]; M.dc_nd[s] = nd; M.dc_log[s] = H.nlog;
@@ -690,6 +715,7 @@ __global__ void __launch_bounds__(KB_K5_THREADS) k_commit_batch(const K7KernArgs
       }
     }
     __syncthreads();
+    K7_STAMP(6);
     // ---- commit the valid prefix
     const uint32_t p = H.p, dirty_row = H.dirty_row;
     uint32_t pc = p, rows = p + (dirty_row == 2 ? 1u : 0u);   // candidates consumed, rows consumed
@@ -700,7 +726,11 @@ __global__ void __launch_bounds__(KB_K5_THREADS) k_commit_batch(const K7KernArgs
       k7_commit_globals<false>(a, k, i0 + j, KB_KEY_NODE(H.c[j]), H.kind[j]);
     }
     if (dirty_row == 2 && tid == 0) *reinterpret_cast<uint2 *>(&a.dec[i0 + p]) = make_uint2(KB_NONE_U32, 0u);
+    K7_STAMP(7);
     if (dirty_row == 1) {
+#ifdef KB_K7_TRACE
+      tacc[12]++;
+#endif
       // ---- a dirty node beats row p's clean candidate.  Dirty winners come in chains (a big node keeps the best score for
       // several tasks), so the rest of row p's run of same-shape rows is committed one row at a time by wave 0 alone, with no
       // workgroup barrier per row: every thread first evaluates the shape against all dirty slots (keyq), then per row
@@ -711,31 +741,39 @@ __global__ void __launch_bounds__(KB_K5_THREADS) k_commit_batch(const K7KernArgs
       const uint32_t q = H.q_of[p];
       {
         const KbRowDesc &k = bd[p];
-        const TaskVals tv = k7_task_vals(a, k);
+        const TaskValsD tv = k7_task_vals(a, k);
         for (uint32_t x = tid; x < nd + p; x += KB_K5_THREADS) {
-          const NodeVals nv = k5_slot_vals(M.tab, M.t_cls, M.t_left, cap2, x, a.has_ports ? M.ptab : nullptr);
+          const NodeValsD nv = k5_slot_vals(M.tab, M.t_cls, M.t_left, cap2, x, a.has_ports ? M.ptab : nullptr);
           const uint32_t node = M.t_node[x];
           const uint32_t res = eval_pair_k5(a, tv, nv, node, a.use_crow ? &k.crow : nullptr);
           M.keyq[x] = res ? KB_KEY(res & 0xFFFFu, node) : 0ull;
         }
       }
       __syncthreads();
+      K7_STAMP(8);
       if (wave == 0) {
         const uint32_t myq = (lane < nb) ? H.q_of[lane] : 0xFFFFFFFFu;
         const unsigned long long diff = __ballot(lane > p && lane < nb && myq != q);
         const uint32_t run_end = diff ? (uint32_t)(__ffsll((unsigned long long)diff) - 1) : nb;
         const uint32_t shape = bd[p].slot;
         uint32_t r = p, ndc = nd + p, rsn = KB_REASON_DONE, last_n = 0xFFFFFFFFu, nlog = H.nlog;
+        // the keys of the shape against every dirty slot live in registers for the whole run: lane l holds slots l, l + 64, ...
+        // (K7_KQ of them cover cap + K7_B slots); a row then costs a few compares and one wave maximum instead of an LDS scan
+        unsigned long long kq[K7_KQ];
+#pragma unroll
+        for (int u = 0; u < K7_KQ; u++) { const uint32_t x = lane + 64u * (uint32_t)u; kq[u] = (x < ndc) ? M.keyq[x] : 0ull; }
         while (r < run_end) {
-          unsigned long long kmax = 0ull;
-          uint32_t xmax = 0;
-          for (uint32_t x = lane; x < ndc; x += 64) {
-            const unsigned long long kk = M.keyq[x];
-            if (kk > kmax) { kmax = kk; xmax = x; }
-          }
+          unsigned long long kmax = kq[0];
+          uint32_t xmax = lane;
+#pragma unroll
+          for (int u = 1; u < K7_KQ; u++) if (kq[u] > kmax) { kmax = kq[u]; xmax = lane + 64u * (uint32_t)u; }
           const unsigned long long best = wave_max_key(kmax);
           const unsigned long long cc = H.c[pc];
           const KbRowDesc &k = bd[r];
+#ifdef KB_K7_TRACE
+          unsigned long long tr0 = 0;
+          if (tid == 0) tr0 = wall_clock64();
+#endif
           if (best == 0ull && cc == 0ull) {
             if (a.backfill) {   // backfill.go:50-66: the task stays Pending
               if (lane == 0) *reinterpret_cast<uint2 *>(&a.dec[i0 + r]) = make_uint2(KB_NONE_U32, 0u);
@@ -758,19 +796,60 @@ __global__ void __launch_bounds__(KB_K5_THREADS) k_commit_batch(const K7KernArgs
               last_n = n;
             }
             uint32_t kind = 0;
+            unsigned long long nkey = 0ull;
             if (lane == 0) {
-              kind = k7_apply_slot(a, M, k, xs, n);
-              M.t_left[xs] -= 1;
+              // one batch of LDS loads, NodeInfo.AddTask (api/node_info.go:172-212) in registers, the changed fields stored back,
+              // and the node's new key evaluated from the registers (no second trip through LDS)
+              NodeValsD nv = k5_slot_vals(M.tab, M.t_cls, M.t_left, cap2, xs, a.has_ports ? M.ptab : nullptr);
+              const int left = M.t_left[xs] - 1;
+              double res0, res1;
+              k7_resreq(a, k, res0, res1);
+              if (!a.backfill) {
+                bool fi = le_eps(k.init0, nv.idle0, EPS_CPU) && le_eps(k.init1, nv.idle1, EPS_MEM);
+                uint32_t act = k.active >> 2;
+                if (act) {
+                  const KbDev &d = *a.dev;
+                  uint32_t dd = 2;
+                  while (act) {
+                    if (act & 1u) fi = fi && le_eps(d.t_init[(size_t)dd * d.T + k.task], d.idle[(size_t)dd * d.NP + n], EPS_SCALAR);
+                    act >>= 1; dd++;
+                  }
+                }
+                kind = fi ? 0u : 1u;
+              }
+              if (kind) {
+                nv.rel0 -= res0; nv.rel1 -= res1;
+                M.tab[(size_t)K5F_REL0 * cap2 + xs] = (unsigned long long)__double_as_longlong(nv.rel0);
+                M.tab[(size_t)K5F_REL1 * cap2 + xs] = (unsigned long long)__double_as_longlong(nv.rel1);
+              } else {
+                nv.idle0 -= res0; nv.idle1 -= res1;
+                M.tab[(size_t)K5F_IDLE0 * cap2 + xs] = (unsigned long long)__double_as_longlong(nv.idle0);
+                M.tab[(size_t)K5F_IDLE1 * cap2 + xs] = (unsigned long long)__double_as_longlong(nv.idle1);
+              }
+              nv.nzc += __longlong_as_double(k.nzc); nv.nzm += __longlong_as_double(k.nzm);
+              M.tab[(size_t)K5F_NZC * cap2 + xs] = d2u(nv.nzc);
+              M.tab[(size_t)K5F_NZM * cap2 + xs] = d2u(nv.nzm);
+              if (a.has_ports) { nv.ports |= a.dev->t_want[k.task]; M.ptab[xs] = nv.ports; }   // the pod's host ports join nodeinfo.UsedPorts()
+              M.t_left[xs] = left;
+              nv.slots = left > 0;
               k7_commit_globals<true>(a, k, i0 + r, n, kind);
               M.dlog[nlog] = xs;
-              const TaskVals tv = k7_task_vals(a, k);
-              const NodeVals nv = k5_slot_vals(M.tab, M.t_cls, M.t_left, cap2, xs, a.has_ports ? M.ptab : nullptr);
+              const TaskValsD tv = k7_task_vals(a, k);
               const uint32_t res = eval_pair_k5(a, tv, nv, n, a.use_crow ? &k.crow : nullptr);
-              M.keyq[xs] = res ? KB_KEY(res & 0xFFFFu, n) : 0ull;
+              nkey = res ? KB_KEY(res & 0xFFFFu, n) : 0ull;
             }
             kind = (uint32_t)__builtin_amdgcn_readfirstlane((int)kind);
+            nkey = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(nkey >> 32)) << 32) |
+                   (uint32_t)__builtin_amdgcn_readfirstlane((int)(nkey & 0xFFFFFFFFull));
+            if (lane == (xs & 63u)) {
+#pragma unroll
+              for (int u = 0; u < K7_KQ; u++) if ((xs >> 6) == (uint32_t)u) kq[u] = nkey;
+            }
             nlog++;
             r++;
+#ifdef KB_K7_TRACE
+            if (tid == 0) tacc[11] += (uint32_t)(wall_clock64() - tr0);
+#endif
             if (kind) { rsn = KB_REASON_PIPELINED; break; }
           } else {
             // the prepared slot nd+pc holds candidate pc's node after ROW pc's task; identical for row r's task when both
@@ -779,22 +858,23 @@ __global__ void __launch_bounds__(KB_K5_THREADS) k_commit_batch(const K7KernArgs
             const uint32_t plain = (uint32_t)(k.flags & kc.flags & 1) && k.resmask == 0 && kc.resmask == 0;
             if (!plain) break;
             const uint32_t kind = H.kind[pc];
+            const unsigned long long ckey = H.kb[pc][q];
             if (lane == 0) {
               atomicMax(&M.cursor[shape], H.idx[pc] + 1);
               k7_commit_globals<false>(a, k, i0 + r, KB_KEY_NODE(cc), kind);
-              M.keyq[ndc] = H.kb[pc][q];
+            }
+            if (lane == (ndc & 63u)) {
+#pragma unroll
+              for (int u = 0; u < K7_KQ; u++) if ((ndc >> 6) == (uint32_t)u) kq[u] = ckey;
             }
             ndc++; pc++; r++;
             if (kind) { rsn = KB_REASON_PIPELINED; break; }
           }
-          __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-          __builtin_amdgcn_wave_barrier();
         }
         // the shape's dirty max as of now becomes its cache
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        unsigned long long kmax = 0ull;
-        for (uint32_t x = lane; x < ndc; x += 64) { const unsigned long long kk = M.keyq[x]; if (kk > kmax) kmax = kk; }
+        unsigned long long kmax = kq[0];
+#pragma unroll
+        for (int u = 1; u < K7_KQ; u++) if (kq[u] > kmax) kmax = kq[u];
         kmax = wave_max_key(kmax);
         if (lane == 0) {
           M.dc_key[shape] = kmax; M.dc_nd[shape] = ndc; M.dc_log[shape] = nlog;
@@ -804,6 +884,7 @@ __global__ void __launch_bounds__(KB_K5_THREADS) k_commit_batch(const K7KernArgs
         }
       }
       __syncthreads();
+      K7_STAMP(9);
       rows = H.seq_rows;
       pc = H.seq_pc;
     }
@@ -826,7 +907,9 @@ __global__ void __launch_bounds__(KB_K5_THREADS) k_commit_batch(const K7KernArgs
         }
       }
     }
-    __syncthreads();
+    // no barrier here: the commit of the prefix and the roll-back above are wave 0's work (tid < K7_B <= 64) and so are the next
+    // batch's shapes and walk steps; the other waves meet wave 0 again at the barrier in front of the window loads
+    K7_STAMP(10);
     nd += pc;
     i0 += rows;
     // clean streaks are long (56 % of the batches commit every row): speculate twice as many rows after a fully valid batch
@@ -847,8 +930,8 @@ __global__ void __launch_bounds__(KB_K5_THREADS) k_commit_batch(const K7KernArgs
       d.idle[(size_t)d.NP + n] = __longlong_as_double((long long)M.tab[K5F_IDLE1 * cap2 + slot]);
       d.rel[n] = __longlong_as_double((long long)M.tab[K5F_REL0 * cap2 + slot]);
       d.rel[(size_t)d.NP + n] = __longlong_as_double((long long)M.tab[K5F_REL1 * cap2 + slot]);
-      d.nzc[n] = (long long)M.tab[K5F_NZC * cap2 + slot];
-      d.nzm[n] = (long long)M.tab[K5F_NZM * cap2 + slot];
+      d.nzc[n] = (long long)u2d(M.tab[K5F_NZC * cap2 + slot]);
+      d.nzm[n] = (long long)u2d(M.tab[K5F_NZM * cap2 + slot]);
       d.podcnt[n] = d.maxpods[n] - M.t_left[slot];
       if (a.has_ports) d.ports[n] = M.ptab[slot];
     }
@@ -870,6 +953,11 @@ __global__ void __launch_bounds__(KB_K5_THREADS) k_commit_batch(const K7KernArgs
   if (tid == 0) {
     a.result[0] = n_done; a.result[1] = reason; a.result[2] = nd; a.result[4] = H.n_refills; a.result[7] = H.n_full; a.result[3] = H.n_seq_rows;
     a.result[5] = H.n_batches; a.result[6] = H.n_dirty_rows;
+#ifdef KB_K7_TRACE
+    unsigned long long *tw = reinterpret_cast<unsigned long long *>(a.result);
+    for (int k = 0; k < 4; k++) tw[4 + k] = (unsigned long long)tacc[2 * k] | ((unsigned long long)tacc[2 * k + 1] << 32);
+    for (int k = 4; k < 7; k++) tw[9 + k] = (unsigned long long)tacc[2 * k] | ((unsigned long long)tacc[2 * k + 1] << 32);   // words 13..15
+#endif
     if (a.round->chain) *a.round->chain = reason == KB_REASON_DONE ? a.round->chain_tag : 0u;   // the round queued behind this one runs only then
     unsigned long long *st = reinterpret_cast<unsigned long long *>(a.result) + KB_OUT_STAMP0;
     st[2] = t_start;
@@ -880,7 +968,7 @@ __global__ void __launch_bounds__(KB_K5_THREADS) k_commit_batch(const K7KernArgs
   if (a.host_out) {
     __syncthreads();
     const unsigned long long *hdr = reinterpret_cast<const unsigned long long *>(a.result);
-    for (uint32_t i = tid; i < KB_OUT_SEQ; i += KB_K5_THREADS) a.host_out[i] = hdr[i];
+    for (uint32_t i = tid; i < KB_OUT_HDR; i += KB_K5_THREADS) if (i != KB_OUT_SEQ) a.host_out[i] = hdr[i];
     for (uint32_t i = tid; i < n_done; i += KB_K5_THREADS) a.host_out[KB_OUT_HDR + i] = a.dec[i];
     __threadfence_system();
     __syncthreads();

@@ -130,6 +130,8 @@ struct kb_engine {
   DevBuf b_idle, b_rel, b_nzc, b_nzm, b_podcnt, b_acpu, b_amem, b_maxpods, b_ncls, b_nmask, b_invac, b_invam;
   uint64_t k5_walks = 0, k5_rescans = 0, k5_demand = 0, k5_slots = 0;   // commit kernel counters (KB_K5_STATS)
   double k5_trace[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  double k7_trace[14] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long k7_batches = 0;
   uint32_t eff_window = 0;   // window actually used for this session (bounded by the commit kernel's LDS budget)
   // which commit kernel the next round uses: the share of rows won by a node the round had already changed decides
   // (exponential average over the rounds so far; KB_COMMIT_KERNEL=batch|run pins it for A/B runs and for the tests)
@@ -548,6 +550,10 @@ void round_collect(kb_engine *e, const RoundCtx &c, bool had_candidates, uint32_
   // rows won by a node the round had already changed (the batch kernel reports them in word 6, word 3 counts its row-mode rows)
   const uint32_t dirty_won = e->commit_kernel_of[c.buf] == KB_COMMIT_RUN ? h_result[3] : h_result[6];
   e->stats.row_fallbacks += dirty_won;
+  if (e->commit_kernel_of[c.buf] == KB_COMMIT_BATCH) {
+    e->k7_batches += h_result[5];
+    for (int k = 0; k < 14; k++) e->k7_trace[k] += (double)(uint32_t)(ho[(k < 8 ? 4 : 9) + k / 2] >> (32 * (k & 1)));   // zero unless built with -DKB_K7_TRACE
+  }
   if (e->commit_kernel_of[c.buf] == KB_COMMIT_RUN) {
     e->k5_slots += h_result[2];
     e->k5_walks += h_result[4];
@@ -922,6 +928,14 @@ void kb_engine_destroy(kb_engine *e) {
             (unsigned long long)e->stats.rounds, (unsigned long long)e->stats.decisions, (unsigned long long)e->k5_slots,
             (unsigned long long)e->stats.row_fallbacks, (unsigned long long)e->k5_walks, (unsigned long long)e->k5_rescans,
             (unsigned long long)e->k5_demand);
+  if (getenv("KB_K5_STATS")) fprintf(stderr, "[kb K7] batches of the batch kernel %llu\n", e->k7_batches);
+  if (getenv("KB_K5_STATS") && e->k7_trace[1] > 0) {
+    static const char *ph[14] = {"loop top / descriptor refill", "shapes (+ barrier)", "windows (+ barrier)", "walk (+ barrier)", "fetch + apply (+ barrier)",
+                                 "evaluate (+ barrier)", "validate (+ barrier)", "commit the prefix", "row mode: keyq pass (+ barrier)", "row mode: rows (+ barrier)",
+                                 "roll back", "row mode: dirty-winner branch (part of rows)", "row-mode entries (count)", "prologue of the round (per round, not per batch)"};
+    const double nb = (double)(e->k7_batches ? e->k7_batches : 1);
+    for (int k = 0; k < 14; k++) fprintf(stderr, "[kb K7 trace] %-32s %14.0f clocks of 10 ns (%.1f ns per batch)\n", ph[k], e->k7_trace[k], 10.0 * e->k7_trace[k] / nb);
+  }
   if (getenv("KB_K5_STATS") && e->k5_trace[0] > 0) {
     static const char *ph[10] = {"barrier 1 (wave 0's wait)", "evaluate: candidates (wave 0)", "barrier 2", "rows", "prepare the next run",
                                 "-", "-", "-", "-", "loop top"};
