@@ -758,18 +758,29 @@ __global__ void __launch_bounds__(KB_K5_THREADS) k_commit_batch(const K7KernArgs
         const uint32_t shape = bd[p].slot;
         uint32_t r = p, ndc = nd + p, rsn = KB_REASON_DONE, last_n = 0xFFFFFFFFu, nlog = H.nlog;
         // the keys of the shape against every dirty slot live in registers for the whole run: lane l holds slots l, l + 64, ...
-        // (K7_KQ of them cover cap + K7_B slots); a row then costs a few compares and one wave maximum instead of an LDS scan
+        // (K7_KQ of them cover cap + K7_B slots), and `best`, their maximum, is a wave-uniform scalar: a clean winner updates it
+        // with one max (its post-placement key is ready: kb), only a dirty winner costs an evaluation and a new wave maximum
         unsigned long long kq[K7_KQ];
 #pragma unroll
         for (int u = 0; u < K7_KQ; u++) { const uint32_t x = lane + 64u * (uint32_t)u; kq[u] = (x < ndc) ? M.keyq[x] : 0ull; }
-        while (r < run_end) {
+        // what the rows of the run need to know about the batch's prepared candidates, one per lane, read back with readlane
+        const bool inb = lane < nb;
+        unsigned long long myc = inb ? H.c[lane] : 0ull, mykb = inb ? H.kb[lane][q] : 0ull;
+        uint32_t mykind = inb ? H.kind[lane] : 0u, myidx = inb ? H.idx[lane] : 0u;
+        asm volatile("" : "+v"(myc), "+v"(mykb), "+v"(mykind), "+v"(myidx));   // loaded by every lane, here (readlane reads inactive lanes)
+        const unsigned long long plainmask = __ballot(inb && (bd[inb ? lane : 0].flags & 1) && bd[inb ? lane : 0].resmask == 0);
+        uint32_t dec_n = 0, dec_k = 0, dec_f = 0;   // lane j: the decision of row p + j when a clean candidate took it
+        unsigned long long best;
+        {
           unsigned long long kmax = kq[0];
-          uint32_t xmax = lane;
 #pragma unroll
-          for (int u = 1; u < K7_KQ; u++) if (kq[u] > kmax) { kmax = kq[u]; xmax = lane + 64u * (uint32_t)u; }
-          const unsigned long long best = wave_max_key(kmax);
-          const unsigned long long cc = H.c[pc];
-          const KbRowDesc &k = bd[r];
+          for (int u = 1; u < K7_KQ; u++) if (kq[u] > kmax) kmax = kq[u];
+          best = wave_max_key(kmax);
+        }
+        const uint32_t pc0 = pc;
+        while (r < run_end) {
+          const unsigned long long cc = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(myc >> 32), (int)pc) << 32) |
+                                        (uint32_t)__builtin_amdgcn_readlane((int)(myc & 0xFFFFFFFFull), (int)pc);
 #ifdef KB_K7_TRACE
           unsigned long long tr0 = 0;
           if (tid == 0) tr0 = wall_clock64();
@@ -784,6 +795,11 @@ __global__ void __launch_bounds__(KB_K5_THREADS) k_commit_batch(const K7KernArgs
             break;
           }
           if (best > cc) {
+            const KbRowDesc &k = bd[r];
+            unsigned long long kmax = kq[0];
+            uint32_t xmax = lane;
+#pragma unroll
+            for (int u = 1; u < K7_KQ; u++) if (kq[u] > kmax) { kmax = kq[u]; xmax = lane + 64u * (uint32_t)u; }
             const unsigned long long own = __ballot(kmax == best);
             const uint32_t xs = (uint32_t)__builtin_amdgcn_readlane((int)xmax, __ffsll((unsigned long long)own) - 1);
             const uint32_t n = KB_KEY_NODE(best);
@@ -819,12 +835,12 @@ __global__ void __launch_bounds__(KB_K5_THREADS) k_commit_batch(const K7KernArgs
               }
               if (kind) {
                 nv.rel0 -= res0; nv.rel1 -= res1;
-                M.tab[(size_t)K5F_REL0 * cap2 + xs] = (unsigned long long)__double_as_longlong(nv.rel0);
-                M.tab[(size_t)K5F_REL1 * cap2 + xs] = (unsigned long long)__double_as_longlong(nv.rel1);
+                M.tab[(size_t)K5F_REL0 * cap2 + xs] = d2u(nv.rel0);
+                M.tab[(size_t)K5F_REL1 * cap2 + xs] = d2u(nv.rel1);
               } else {
                 nv.idle0 -= res0; nv.idle1 -= res1;
-                M.tab[(size_t)K5F_IDLE0 * cap2 + xs] = (unsigned long long)__double_as_longlong(nv.idle0);
-                M.tab[(size_t)K5F_IDLE1 * cap2 + xs] = (unsigned long long)__double_as_longlong(nv.idle1);
+                M.tab[(size_t)K5F_IDLE0 * cap2 + xs] = d2u(nv.idle0);
+                M.tab[(size_t)K5F_IDLE1 * cap2 + xs] = d2u(nv.idle1);
               }
               nv.nzc += __longlong_as_double(k.nzc); nv.nzm += __longlong_as_double(k.nzm);
               M.tab[(size_t)K5F_NZC * cap2 + xs] = d2u(nv.nzc);
@@ -845,6 +861,12 @@ __global__ void __launch_bounds__(KB_K5_THREADS) k_commit_batch(const K7KernArgs
 #pragma unroll
               for (int u = 0; u < K7_KQ; u++) if ((xs >> 6) == (uint32_t)u) kq[u] = nkey;
             }
+            {   // the changed key may have been the maximum: a new wave maximum
+              unsigned long long km2 = kq[0];
+#pragma unroll
+              for (int u = 1; u < K7_KQ; u++) if (kq[u] > km2) km2 = kq[u];
+              best = wave_max_key(km2);
+            }
             nlog++;
             r++;
 #ifdef KB_K7_TRACE
@@ -854,28 +876,30 @@ __global__ void __launch_bounds__(KB_K5_THREADS) k_commit_batch(const K7KernArgs
           } else {
             // the prepared slot nd+pc holds candidate pc's node after ROW pc's task; identical for row r's task when both
             // rows carry plain requests (same shape; no init-container maximum, no scalar resources)
-            const KbRowDesc &kc = bd[pc];
-            const uint32_t plain = (uint32_t)(k.flags & kc.flags & 1) && k.resmask == 0 && kc.resmask == 0;
-            if (!plain) break;
-            const uint32_t kind = H.kind[pc];
-            const unsigned long long ckey = H.kb[pc][q];
-            if (lane == 0) {
-              atomicMax(&M.cursor[shape], H.idx[pc] + 1);
-              k7_commit_globals<false>(a, k, i0 + r, KB_KEY_NODE(cc), kind);
+            if (!((plainmask >> r) & (plainmask >> pc) & 1ull)) break;
+            const uint32_t kind = (uint32_t)__builtin_amdgcn_readlane((int)mykind, (int)pc);
+            const unsigned long long ckey = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(mykb >> 32), (int)pc) << 32) |
+                                            (uint32_t)__builtin_amdgcn_readlane((int)(mykb & 0xFFFFFFFFull), (int)pc);
+            if (a.has_delta) {   // multi-GPU rounds: the per-node deltas are accumulated row by row
+              if (lane == 0) k7_commit_globals<false>(a, bd[r], i0 + r, KB_KEY_NODE(cc), kind);
+            } else if (lane == r - p) {
+              dec_n = KB_KEY_NODE(cc); dec_k = kind; dec_f = 1u;
             }
             if (lane == (ndc & 63u)) {
 #pragma unroll
               for (int u = 0; u < K7_KQ; u++) if ((ndc >> 6) == (uint32_t)u) kq[u] = ckey;
             }
+            if (ckey > best) best = ckey;
             ndc++; pc++; r++;
             if (kind) { rsn = KB_REASON_PIPELINED; break; }
           }
         }
+        // the clean winners of the run: their cursor and their decision records
+        const uint32_t last_idx = (uint32_t)__builtin_amdgcn_readlane((int)myidx, (int)(pc > pc0 ? pc - 1u : 0u));
+        if (pc > pc0 && lane == 0) atomicMax(&M.cursor[shape], last_idx + 1u);
+        if (dec_f) *reinterpret_cast<uint2 *>(&a.dec[i0 + p + lane]) = make_uint2(dec_n, dec_k);
         // the shape's dirty max as of now becomes its cache
-        unsigned long long kmax = kq[0];
-#pragma unroll
-        for (int u = 1; u < K7_KQ; u++) if (kq[u] > kmax) kmax = kq[u];
-        kmax = wave_max_key(kmax);
+        const unsigned long long kmax = best;
         if (lane == 0) {
           M.dc_key[shape] = kmax; M.dc_nd[shape] = ndc; M.dc_log[shape] = nlog;
           H.n_dirty_rows += nlog - H.nlog;
