@@ -216,6 +216,7 @@ __device__ __forceinline__ void k5_field_ptrs(const KbDev &d, uint32_t fld, cons
 #define K7_B 32u          // most rows one batch can speculate
 #define K7_B_DEFAULT 16u  // batch size after a batch that was cut short; doubled after a fully valid one
 #define K7_D 96u   // row descriptors staged per refill
+#define K7_PWIN_BYTES 32768u   // LDS for the per-shape candidate windows of a round
 #define K7_KQ 5    // 64 * K7_KQ >= KB_K5_MAX_ROWS + K7_B dirty slots: the row-at-a-time mode keeps one key per slot in registers
 
 static_assert(64 * K7_KQ >= KB_K5_MAX_ROWS + K7_B, "row mode keeps one key per dirty slot in registers");
@@ -225,8 +226,6 @@ struct K7Hdr {
   unsigned long long kb[K7_B][K7_B];    // [row l][shape q]: key of row l's node in its post-commit state
   unsigned long long mrow[K7_B];        // per batch row j: max of kb[l][q_j] over the earlier batch rows l < j (built by the evaluate step)
   uint32_t rowmask[K7_B];               // per distinct shape q: the batch rows that carry it
-  unsigned long long win[K7_B][64];     // candidate window of shape q, starting at win_base[q]
-  uint32_t win_base[K7_B];
   uint32_t rep[K7_B];                   // batch row whose descriptor represents shape q
   uint32_t q_of[K7_B];                  // shape index of batch row j
   uint32_t idx[K7_B];                   // list position of c[j]
@@ -258,13 +257,20 @@ struct K7Mem {
   unsigned long long *ptab;             // [cap2] host-port bits of the slot's node (sessions with host ports only)
   uint32_t *bitmap;                     // [NP/32]
   double *save;                         // [K7_B][R-2] scalar-dimension values overwritten by speculative commits
+  // Candidate windows, one per shape of the ROUND and persistent across its batches: pwin[s][0..WL) = entries pbase[s] ..
+  // pbase[s] + WL of the shape's sorted list (K3).  Invariant: every list entry in front of pbase[s] is dirty, so a walk only ever
+  // looks at the window (consumed or foreign-taken entries inside it are dirty bits in the bitmap) and slides it when it holds
+  // no clean entry any more.  WL = 64, 32 or 16 so that all windows of the round fit K7_PWIN_BYTES.
+  unsigned long long *pwin;
+  uint32_t *pbase;                      // [cap]
   K7Hdr *H;
-  uint32_t cap2;
+  uint32_t cap2, WL;
 };
 
 __host__ __device__ inline size_t k7_smem_bytes(uint32_t cap, uint32_t NP, int R) {
   size_t cap2 = (size_t)cap + K7_B;
-  return cap2 * (K5_NF8 * 8 + 8 + 8 + 3 * 4) + (size_t)cap * (8 + 8 + 12) + (size_t)(NP / 32) * 4 + (size_t)K7_B * (R > 2 ? R - 2 : 0) * 8 + sizeof(K7Hdr) + 64;
+  return cap2 * (K5_NF8 * 8 + 8 + 8 + 3 * 4) + (size_t)cap * (8 + 8 + 12) + (size_t)(NP / 32) * 4 + (size_t)K7_B * (R > 2 ? R - 2 : 0) * 8 + sizeof(K7Hdr) + 64 +
+         K7_PWIN_BYTES + (size_t)cap * 4;
 }
 
 // `k` is a STAGED descriptor (H.dbuf): its nzc / nzm words hold the pod's non-zero request as double bit patterns
@@ -388,13 +394,23 @@ __global__ void __launch_bounds__(KB_K5_THREADS) k_commit_batch(const K7KernArgs
     off = (off + 15) & ~(size_t)15;
     M.H = reinterpret_cast<K7Hdr *>(k5_smem + off);
     M.save = reinterpret_cast<double *>(k5_smem + off + sizeof(K7Hdr));
+    size_t off2 = off + sizeof(K7Hdr) + (size_t)K7_B * (a.R > 2 ? a.R - 2 : 0) * 8;
+    off2 = (off2 + 15) & ~(size_t)15;
+    M.pwin = reinterpret_cast<unsigned long long *>(k5_smem + off2);
+    M.pbase = reinterpret_cast<uint32_t *>(k5_smem + off2 + K7_PWIN_BYTES);
   }
+  const uint32_t WL = a.n_mrows <= K7_PWIN_BYTES / (64u * 8u) ? 64u : (a.n_mrows <= K7_PWIN_BYTES / (32u * 8u) ? 32u : 16u);   // n_mrows <= KB_K5_MAX_SHAPES = 256
+  M.WL = WL;
   K7Hdr &H = *M.H;
   const int RS = a.R > 2 ? a.R - 2 : 0;
   const unsigned long long t_start = wall_clock64();
 
   for (uint32_t w = tid; w < a.NP / 32; w += KB_K5_THREADS) M.bitmap[w] = 0;
-  for (uint32_t w = tid; w < cap; w += KB_K5_THREADS) { M.cursor[w] = 0; M.qstamp[w] = 0xFFFFFFFFu; M.dc_key[w] = 0ull; M.dc_nd[w] = 0; M.dc_log[w] = 0; }
+  for (uint32_t w = tid; w < cap; w += KB_K5_THREADS) { M.cursor[w] = 0; M.qstamp[w] = 0xFFFFFFFFu; M.dc_key[w] = 0ull; M.dc_nd[w] = 0; M.dc_log[w] = 0; M.pbase[w] = 0; }
+  for (uint32_t w = tid; w < a.n_mrows * WL; w += KB_K5_THREADS) {   // the first window of every shape's candidate list
+    const uint32_t sh = w / WL, en = w % WL;
+    M.pwin[w] = (en < a.L) ? a.keys[(size_t)sh * a.L + en] : 0ull;
+  }
   if (tid == 0) { H.reason = KB_REASON_DONE; H.exhausted = 0; H.n_batches = 0; H.n_dirty_rows = 0; H.n_refills = 0; H.p = 0; H.dirty_row = 0; H.pad = 0; H.nlog = 0; H.n_full = 0; H.pad2 = 0; H.pad3 = 0; H.kstar = 0ull; H.n_seq_rows = 0; }
   // per-thread source array of the fetch step: thread (row*16 + f) reads field f of the row's node
   // (pointers read from the KbDev copy are generic; the fetch step wants global_load, not flat_load)
@@ -421,15 +437,23 @@ __global__ void __launch_bounds__(KB_K5_THREADS) k_commit_batch(const K7KernArgs
         reinterpret_cast<const unsigned long long *>(d.inv_acpu), reinterpret_cast<const unsigned long long *>(d.inv_amem),
         reinterpret_cast<const unsigned long long *>(d.acpu), reinterpret_cast<const unsigned long long *>(d.amem),
         reinterpret_cast<const unsigned long long *>(d.nzc), reinterpret_cast<const unsigned long long *>(d.nzm)};
-#pragma unroll
-    for (int f = 0; f < 10; f++)
-      for (uint32_t l = tid; l < lines; l += KB_K5_THREADS) acc += arrs[f][(size_t)l * 16];
     const uint32_t *arr4[3] = {d.ncls, reinterpret_cast<const uint32_t *>(d.maxpods), reinterpret_cast<const uint32_t *>(d.podcnt)};
-#pragma unroll
-    for (int f = 0; f < 3; f++)
-      for (uint32_t l = tid; l < a.NP / 32; l += KB_K5_THREADS) acc += arr4[f][(size_t)l * 32];
     const size_t klines = ((size_t)a.n_mrows * a.L + 15) / 16;
-    for (size_t l = tid; l < klines; l += KB_K5_THREADS) acc += a.keys[l * 16];
+    for (uint32_t l0 = 0; l0 < lines; l0 += KB_K5_THREADS) {   // all loads of a pass in flight together
+      const uint32_t l = l0 + tid;
+      unsigned long long v[11];
+      uint32_t w[3];
+#pragma unroll
+      for (int f = 0; f < 10; f++) v[f] = (l < lines) ? arrs[f][(size_t)l * 16] : 0ull;
+      v[10] = (l < klines) ? a.keys[(size_t)l * 16] : 0ull;
+#pragma unroll
+      for (int f = 0; f < 3; f++) w[f] = (l < lines / 2) ? arr4[f][(size_t)l * 32] : 0u;
+#pragma unroll
+      for (int f = 0; f < 11; f++) acc += v[f];
+#pragma unroll
+      for (int f = 0; f < 3; f++) acc += w[f];
+    }
+    for (size_t l = (size_t)((lines + KB_K5_THREADS - 1) / KB_K5_THREADS) * KB_K5_THREADS + tid; l < klines; l += KB_K5_THREADS) acc += a.keys[l * 16];
     if (acc == 0x123456789abcdefull) H.pad = 1;   // keep the loads alive
   }
   __syncthreads();
@@ -469,6 +493,7 @@ __global__ void __launch_bounds__(KB_K5_THREADS) k_commit_batch(const K7KernArgs
       nb = ja;
     }
     // ---- distinct shapes of the batch (wave 0): q_of[j] = rank of the first row with row j's shape
+    unsigned long long slid = 0ull;   // wave 0: shapes (by batch rank) whose window slid during this batch's walk
     if (wave == 0) {
       const bool in = lane < nb;
       const uint32_t s = in ? (uint32_t)bd[in ? lane : 0].slot : 0u;
@@ -494,7 +519,7 @@ __global__ void __launch_bounds__(KB_K5_THREADS) k_commit_batch(const K7KernArgs
         const bool full = start == 0xFFFFFFFFu || nl > 16;   // invalidated by a dirty row on its arg-max node, or too stale
         if (full) { start = 0; nl = 0; ck = 0ull; }
         cnt = (nd - start) + nl + nb;
-        H.rep[q] = lane; H.win_base[q] = M.cursor[s]; H.dmax[q] = ck;
+        H.rep[q] = lane; H.dmax[q] = ck;
         H.e_start[q] = start; H.e_nlog[q] = nl; H.e_log0[q] = log0;
         if (full) atomicAdd(&H.n_full, 1u);
       }
@@ -505,35 +530,27 @@ __global__ void __launch_bounds__(KB_K5_THREADS) k_commit_batch(const K7KernArgs
       const uint32_t nsh = (uint32_t)__popcll(repmask);
       if (lane >= nsh && lane < K7_B) H.e_off[lane] = 0xFFFFFFFFu;
       if (lane == 0) { H.nshapes = nsh; H.n_pairs = total; H.n_batches++; }
-    }
-    __syncthreads();
-    K7_STAMP(1);
-    // ---- candidate windows of the distinct shapes: one wave per shape
-    const uint32_t nshapes = H.nshapes;
-    for (uint32_t q = wave; q < nshapes; q += K5_WAVES) {
-      const uint32_t s = bd[H.rep[q]].slot;
-      const uint32_t e = H.win_base[q] + lane;
-      H.win[q][lane] = (e < a.L) ? a.keys[(size_t)s * a.L + e] : 0ull;
-    }
-    __syncthreads();
-    K7_STAMP(2);
-    // ---- walk (wave 0): runs of consecutive rows with the same shape take successive clean entries of its window
-    if (wave == 0) {
-      const uint32_t myq = (lane < nb) ? H.q_of[lane] : 0xFFFFFFFFu;
+      K7_STAMP(1);
+      // ---- walk (still wave 0, no barrier in between): runs of consecutive rows with the same shape take successive clean
+      //      entries of the shape's persistent window
+      const uint32_t myq = in ? q : 0xFFFFFFFFu;
       uint32_t j = 0;
       while (j < nb) {
-        const uint32_t q = (uint32_t)__builtin_amdgcn_readlane((int)myq, (int)j);
-        const unsigned long long diff = __ballot(lane >= j && lane < nb && myq != q);
+        const uint32_t qr = (uint32_t)__builtin_amdgcn_readlane((int)myq, (int)j);
+        const uint32_t sr = (uint32_t)__builtin_amdgcn_readlane((int)s, (int)j);
+        const unsigned long long diff = __ballot(lane >= j && lane < nb && myq != qr);
         const uint32_t j1 = diff ? (uint32_t)(__ffsll((unsigned long long)diff) - 1) : nb;
         uint32_t m = j1 - j;
+        unsigned long long *wq = M.pwin + (size_t)sr * WL;
+        uint32_t base = M.pbase[sr];
         for (;;) {
-          const unsigned long long wkey = H.win[q][lane];
-          const uint32_t base = H.win_base[q];
-          const bool nz = wkey != 0ull;
+          const bool inw = lane < WL;
+          const unsigned long long wkey = inw ? wq[lane] : 0ull;
+          const bool nz = inw && wkey != 0ull;
           const uint32_t node = KB_KEY_NODE(wkey);
           const bool cl = nz && !bit_test(M.bitmap, nz ? node : 0u);
           const unsigned long long clean = __ballot(cl);
-          const unsigned long long zeros = __ballot(!nz);
+          const unsigned long long zeros = __ballot(inw && wkey == 0ull);
           const uint32_t cnt = (uint32_t)__popcll(clean);
           const uint32_t take = cnt < m ? cnt : m;
           const uint32_t rank = (uint32_t)__popcll(clean & ((1ull << lane) - 1ull));
@@ -550,19 +567,21 @@ __global__ void __launch_bounds__(KB_K5_THREADS) k_commit_batch(const K7KernArgs
             j += m;
             break;
           }
-          // every entry of the window is dirty: slide it (entries before it stay dirty for the rest of the round or are
-          // rolled back together with this batch)
-          const uint32_t nbase = base + 64;
+          // every entry of the window is dirty: slide it.  Entries taken by THIS batch may be rolled back; the roll-back step
+          // re-anchors the windows that slid during the batch (slid) at the shape's cursor
+          const uint32_t nbase = base + WL;
           if (nbase >= a.L) {   // cannot happen while L > window: reported, never silently mis-scheduled
             if (lane == 0) H.exhausted = 1;
             if (lane < m) { H.c[j + lane] = 0ull; H.idx[j + lane] = 0; }
             j += m;
             break;
           }
-          const uint32_t e = nbase + lane;
-          const uint32_t s = bd[H.rep[q]].slot;
-          H.win[q][lane] = (e < a.L) ? a.keys[(size_t)s * a.L + e] : 0ull;
-          if (lane == 0) { H.win_base[q] = nbase; H.n_refills++; }
+          if (inw) wq[lane] = (nbase + lane < a.L) ? a.keys[(size_t)sr * a.L + nbase + lane] : 0ull;
+          if (lane == 0) { M.pbase[sr] = nbase; H.n_refills++; }
+          base = nbase;
+          slid |= 1ull << qr;
+          __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+          __builtin_amdgcn_wave_barrier();
         }
       }
     }
@@ -931,8 +950,21 @@ __global__ void __launch_bounds__(KB_K5_THREADS) k_commit_batch(const K7KernArgs
         }
       }
     }
+    if (wave == 0 && slid != 0ull && pc < nb) {
+      // a window that slid during this batch's walk may have skipped entries whose bits the roll-back has just cleared: re-anchor
+      // it at the shape's cursor (every entry in front of the cursor belongs to a committed row or was dirty when that row passed)
+      unsigned long long sm = slid;
+      while (sm) {
+        const uint32_t qs = (uint32_t)__ffsll((unsigned long long)sm) - 1u;
+        sm &= sm - 1ull;
+        const uint32_t sr = bd[H.rep[qs]].slot;
+        const uint32_t nbase = M.cursor[sr];
+        if (lane < WL) M.pwin[(size_t)sr * WL + lane] = (nbase + lane < a.L) ? a.keys[(size_t)sr * a.L + nbase + lane] : 0ull;
+        if (lane == 0) M.pbase[sr] = nbase;
+      }
+    }
     // no barrier here: the commit of the prefix and the roll-back above are wave 0's work (tid < K7_B <= 64) and so are the next
-    // batch's shapes and walk steps; the other waves meet wave 0 again at the barrier in front of the window loads
+    // batch's shapes and walk steps; the other waves meet wave 0 again at the barrier in front of the fetch step
     K7_STAMP(10);
     nd += pc;
     i0 += rows;

@@ -5,7 +5,7 @@ set -u
 TAG=${1:-q}
 OUT=$PWD/gpurun_out/$TAG
 mkdir -p "$OUT"
-timeout 300 python -m pytest tests/test_gpu_parity.py tests/test_gpu_fuzz.py -x -q -m gpu > "$OUT/pytest.log" 2>&1; echo "pytest rc=$?"
+timeout 300 python -m pytest tests/test_gpu_parity.py tests/test_gpu_fuzz.py tests/test_gpu_adversarial.py -x -q -m gpu > "$OUT/pytest.log" 2>&1; echo "pytest rc=$?"
 tail -n 3 "$OUT/pytest.log"
 for c in 3 4; do
   KB_K5_STATS=1 timeout 200 python bench.py --config $c --steps 5 --warmup 1 --verify --no-cpu-baseline > "$OUT/bench_c${c}.json" 2> "$OUT/bench_c${c}.err"; echo "bench c$c rc=$?"
