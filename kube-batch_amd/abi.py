@@ -5,7 +5,7 @@ Only plain C types cross the boundary; the same structs are what the Go shim fil
 """
 import ctypes as C
 
-KB_ABI_VERSION = 5
+KB_ABI_VERSION = 6
 KB_MAX_RES = 32
 KB_NONE = 0xFFFFFFFF
 
@@ -76,10 +76,24 @@ SNAPSHOT_ARRAYS = [
 ]
 
 
+# kb_interpod: inter-pod (anti)affinity tables (predicate p8 + nodeorder's InterPodAffinityPriority), NULL when no pod has a term
+INTERPOD_ARRAYS = [
+    ("ctr_dom", C.c_uint32), ("ctr_count", C.c_int32), ("ctr_total", C.c_int32),
+    ("task_inc", C.c_uint64), ("task_forbid", C.c_uint64), ("task_require", C.c_uint8), ("task_self", C.c_uint8),
+    ("cls_dom", C.c_uint32), ("cls_bound", C.c_int32), ("cls_unbound", C.c_int32),
+    ("task_cls_inc", C.c_uint64), ("task_sig", C.c_uint32), ("sig_weight", C.c_int32),
+]
+
+
+class Interpod(C.Structure):
+    _fields_ = [("n_counters", C.c_uint32), ("n_domains", C.c_uint32), ("n_classes", C.c_uint32), ("n_sigs", C.c_uint32),
+                ("first_unbound_node", C.c_uint32), ("pad", C.c_uint32)] + [(n, _P(t)) for n, t in INTERPOD_ARRAYS]
+
+
 class Snapshot(C.Structure):
     _fields_ = [("version", C.c_uint32), ("n_res", C.c_uint32), ("n_nodes", C.c_uint32), ("n_tasks", C.c_uint32),
                 ("n_jobs", C.c_uint32), ("n_queues", C.c_uint32), ("n_task_classes", C.c_uint32),
-                ("n_node_classes", C.c_uint32)] + [(n, _P(t)) for n, t in SNAPSHOT_ARRAYS]
+                ("n_node_classes", C.c_uint32)] + [(n, _P(t)) for n, t in SNAPSHOT_ARRAYS] + [("interpod", _P(Interpod))]
 
 
 class Decision(C.Structure):

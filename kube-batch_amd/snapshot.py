@@ -107,6 +107,17 @@ class Pod:
     required_affinity: Optional[List[Tuple[List[Tuple[str, str, Tuple[str, ...]]], List[Tuple[str, str, Tuple[str, ...]]]]]] = None
     # container ports with a hostPort: (hostIP, protocol, hostPort); "" -> 0.0.0.0 / TCP (nodeinfo/host_ports.go:137-144)
     host_ports: List[Tuple[str, str, int]] = field(default_factory=list)
+    # ---- inter-pod (anti)affinity (spec.affinity.podAffinity / podAntiAffinity).  A term is (namespaces, selector, topologyKey):
+    # namespaces () = the pod's own; selector None = nil LabelSelector (matches nothing), else (matchLabels pairs,
+    # matchExpressions [(key, operator, (values...))]) with an empty selector matching everything
+    # (vendor/k8s.io/apimachinery/pkg/apis/meta/v1/helpers.go:34-70).  Preferred terms carry their weight first.
+    labels: Dict[str, str] = field(default_factory=dict)
+    pod_affinity_required: List[tuple] = field(default_factory=list)
+    pod_affinity_preferred: List[tuple] = field(default_factory=list)        # (weight, term)
+    pod_anti_affinity_required: List[tuple] = field(default_factory=list)
+    pod_anti_affinity_preferred: List[tuple] = field(default_factory=list)   # (weight, term)
+    # the cache already holds the pod on node_name (status Binding) while the pod object's Spec.NodeName is still empty
+    spec_node_name_empty: bool = False
     priority_class_name: str = ""       # conformance plugin: system-cluster-critical / system-node-critical are never evicted
     # resources.limits of every container and init container (only read for the pod's QoS class: the memory-pressure check)
     limits: List[Dict[str, str]] = field(default_factory=list)
@@ -245,6 +256,251 @@ def _node_selector_terms_match(terms, labels: Dict[str, str], node_name: str) ->
     return False
 
 
+# ------------------------------------------------------------------------------------------------
+# inter-pod (anti)affinity: predicate p8 and nodeorder's InterPodAffinityPriority
+# ------------------------------------------------------------------------------------------------
+class UnsupportedSnapshot(ValueError):
+    """the session is outside the engine's envelope: the Go action hands the cycle to the stock action"""
+
+
+def _canon_selector(sel):
+    if sel is None:
+        return None
+    ml, exprs = sel
+    ml = tuple(sorted(dict(ml).items())) if not isinstance(ml, tuple) else tuple(sorted(ml))
+    exprs = tuple((k, op, tuple(vals)) for k, op, vals in exprs)
+    for _, op, vals in exprs:   # metav1.LabelSelectorAsSelector / labels.NewRequirement reject these: the reference then errors per pair
+        if op not in ("In", "NotIn", "Exists", "DoesNotExist") or not _requirement_valid(op, vals):
+            raise UnsupportedSnapshot(f"pod selector requirement {op!r} {vals!r} is not valid")
+    return (ml, exprs)
+
+
+def _selector_matches(sel, labels: Dict[str, str]) -> bool:
+    """metav1.LabelSelectorAsSelector(sel).Matches(labels) (helpers.go:34-70; labels/selector.go:194-236)."""
+    if sel is None:
+        return False
+    ml, exprs = sel
+    return all(labels.get(k) == v for k, v in ml) and all(_requirement_matches(labels, k, op, vals) for k, op, vals in exprs)
+
+
+def _term_props(owner: "Pod", term):
+    """(namespaces, selector) of a PodAffinityTerm as its owner resolves them (priorities/util/topologies.go:28-36)."""
+    namespaces, sel, key = term
+    return (tuple(sorted(set(namespaces))) if namespaces else (owner.namespace,), _canon_selector(sel), key)
+
+
+def _pod_matches_props(p: "Pod", ns, sel) -> bool:
+    """PodMatchesTermsNamespaceAndSelector (priorities/util/topologies.go:40-49)."""
+    return p.namespace in ns and _selector_matches(sel, p.labels)
+
+
+def has_interpod_terms(p: "Pod") -> bool:
+    return bool(p.pod_affinity_required or p.pod_affinity_preferred or p.pod_anti_affinity_required or p.pod_anti_affinity_preferred)
+
+
+def build_interpod(nodes, session_pods, other_pods_on_nodes, task_node, task_status):
+    """The inter-pod tables of kb_interpod (include/kb_engine.h) from Kubernetes-shaped objects.
+
+    nodes: sorted by name; session_pods: the session's tasks in canonical task order; task_node[t]: the node whose ni.Tasks holds
+    task t at session open (KB_NONE: none); other_pods_on_nodes: [(pod, node index)] for pods outside the session that sit in some
+    ni.Tasks.  Returns None when no pod of the cluster carries a pod-(anti)affinity term.
+
+    Predicate (vendor/.../algorithm/predicates/predicates.go:1261-1575 without metadata, i.e. the slow path, over
+    plugins/util/util.go:37-90's PodLister = the session's tasks in an allocated status):
+      counter kind 'A' (one per distinct required anti-affinity term of any session pod, as resolved by its owner): counts the
+        OWNERS in an allocated status per value of the term's topology key.  A pod that matches the term's namespaces + selector
+        may not go where that count is positive (satisfiesExistingPodsAntiAffinity, :1400-1441).
+      counter kind 'G' (one per distinct SET of required terms a pod carries as its affinity, or as its anti-affinity): counts
+        the allocated-status pods that match ALL terms' properties, per tuple of the terms' topology values
+        (podMatchesPodAffinityTerms, :1295-1320: the slow path ANDs the terms).  The pod's own affinity needs a positive count in
+        the node's domain unless no pod at all matches and the pod matches its own terms (:1550-1565); its own anti-affinity
+        needs a zero count (:1535-1543).
+    Priority (vendor/.../priorities/interpod_affinity.go:99-235 behind plugins/nodeorder/nodeorder.go:48-62,156-160):
+      class kind 'S' (a preferred term of the pod being scored): counts, per node, the pods in ni.Tasks that match it;
+      class kind 'O' (a term some pod on a node owns: required affinity with hardPodAffinityWeight 1, preferred (anti)affinity
+        with its signed weight): counts its owners per node; the scored pod's weight for it is that weight if it matches.
+      count(node i) = sum over classes c of weight_c x (pods counted by c on the FEASIBLE nodes whose "node" shares c's topology
+      value with i), where the "node" of a pod whose Spec.NodeName is still empty is the first node (ascending name) that holds
+      any such pod (nodeorder.go:48-62)."""
+    N = len(nodes)
+    all_pods = list(session_pods) + [p for p, _ in other_pods_on_nodes]
+    if not any(has_interpod_terms(p) for p in all_pods):
+        return None
+    T = len(session_pods)
+    KB_NONE = abi.KB_NONE
+    allocated = (abi.TASK_ALLOCATED, abi.TASK_BINDING, abi.TASK_BOUND, abi.TASK_RUNNING)   # api.AllocatedStatus (api/helpers.go:63-72)
+
+    # ---- predicate counters
+    counters: Dict[tuple, int] = {}
+
+    def counter(key):
+        if key not in counters:
+            counters[key] = len(counters)
+        return counters[key]
+
+    def group_key(owner, terms):
+        return ("G", tuple(sorted((_term_props(owner, t) for t in terms), key=repr)))
+
+    for p in session_pods:
+        for t in p.pod_anti_affinity_required:
+            ns, sel, key = _term_props(p, t)
+            if not key:
+                raise UnsupportedSnapshot("required pod anti-affinity term with an empty topologyKey")
+            counter(("A", ns, sel, key))
+        for terms in (p.pod_affinity_required, p.pod_anti_affinity_required):
+            if terms:
+                if any(not _term_props(p, t)[2] for t in terms):
+                    raise UnsupportedSnapshot("required pod (anti)affinity term with an empty topologyKey")
+                counter(group_key(p, terms))
+    C = len(counters)
+    if C > 64:
+        raise UnsupportedSnapshot("more than 64 distinct inter-pod predicate counters in one session")
+    ckeys = sorted(counters, key=lambda k: counters[k])
+
+    def domain_table(keys_of):
+        """per counter/class: node -> interned id of the tuple of its topology values (KB_NONE when a label is missing)"""
+        dom = np.full((len(keys_of), N), KB_NONE, np.uint32)
+        width = 1
+        for c, tk in enumerate(keys_of):
+            vals = {}
+            for n, node in enumerate(nodes):
+                if tk and all(k and k in node.labels for k in tk):
+                    vals.setdefault(tuple(node.labels[k] for k in tk), []).append(n)
+            for i, v in enumerate(sorted(vals)):
+                dom[c, vals[v]] = i
+            width = max(width, len(vals))
+        return dom, width
+
+    def counter_topology(k):
+        return (k[3],) if k[0] == "A" else tuple(t[2] for t in k[1])
+
+    ctr_dom, D = domain_table([counter_topology(k) for k in ckeys])
+    t_inc = np.zeros(T, np.uint64); t_forbid = np.zeros(T, np.uint64)
+    t_req = np.full(T, 0xFF, np.uint8); t_self = np.zeros(T, np.uint8)
+    for t, p in enumerate(session_pods):
+        inc = forbid = 0
+        own_a = {("A",) + _term_props(p, term) for term in p.pod_anti_affinity_required}
+        for c, k in enumerate(ckeys):
+            if k[0] == "A":
+                if k in own_a:
+                    inc |= 1 << c
+                if _pod_matches_props(p, k[1], k[2]):
+                    forbid |= 1 << c
+            elif all(_pod_matches_props(p, ns, sel) for ns, sel, _ in k[1]):
+                inc |= 1 << c
+        if p.pod_anti_affinity_required:
+            forbid |= 1 << counters[group_key(p, p.pod_anti_affinity_required)]
+        if p.pod_affinity_required:
+            g = group_key(p, p.pod_affinity_required)
+            t_req[t] = counters[g]
+            t_self[t] = int(all(_pod_matches_props(p, ns, sel) for ns, sel, _ in g[1]))   # targetPodMatchesAffinityOfPod(pod, pod)
+        t_inc[t] = inc; t_forbid[t] = forbid
+    ctr_count = np.zeros((C, D), np.int32); ctr_total = np.zeros(C, np.int32)
+    for t, p in enumerate(session_pods):
+        if int(task_status[t]) not in allocated:
+            continue
+        if int(task_node[t]) == KB_NONE:
+            if int(t_inc[t]):
+                # PodLister lists it under its NodeName although no ni.Tasks holds it: nodeInfo.Filter then hides it from that one
+                # node only (predicates.go:1410-1413) -- not modelled
+                raise UnsupportedSnapshot("an allocated-status task outside every ni.Tasks takes part in inter-pod affinity")
+            continue
+        for c in range(C):
+            if (int(t_inc[t]) >> c) & 1:
+                ctr_total[c] += 1
+                d = ctr_dom[c, int(task_node[t])]
+                if d != KB_NONE:
+                    ctr_count[c, d] += 1
+
+    # ---- priority classes
+    classes: Dict[tuple, int] = {}
+
+    def klass(key):
+        if key not in classes:
+            classes[key] = len(classes)
+        return classes[key]
+
+    def owned_terms(p):
+        """terms of p that score OTHER pods: required affinity with hardPodAffinityWeight 1, preferred affinity +w, preferred
+        anti-affinity -w (interpod_affinity.go:163-196); identical terms of one pod add up"""
+        acc: Dict[tuple, int] = {}
+        for term in p.pod_affinity_required:
+            k = _term_props(p, term); acc[k] = acc.get(k, 0) + 1
+        for w, term in p.pod_affinity_preferred:
+            k = _term_props(p, term); acc[k] = acc.get(k, 0) + int(w)
+        for w, term in p.pod_anti_affinity_preferred:
+            k = _term_props(p, term); acc[k] = acc.get(k, 0) - int(w)
+        return {k: w for k, w in acc.items() if w != 0}
+
+    def subject_terms(p):
+        """preferred terms of p scoring p itself against the pods on the nodes (interpod_affinity.go:137-160)"""
+        acc: Dict[tuple, int] = {}
+        for w, term in p.pod_affinity_preferred:
+            k = _term_props(p, term); acc[k] = acc.get(k, 0) + int(w)
+        for w, term in p.pod_anti_affinity_preferred:
+            k = _term_props(p, term); acc[k] = acc.get(k, 0) - int(w)
+        return {k: w for k, w in acc.items() if w != 0}
+
+    for p in all_pods:
+        for k, w in owned_terms(p).items():
+            klass(("O",) + k + (w,))
+    for p in session_pods:
+        for k in subject_terms(p):
+            klass(("S",) + k)
+    P = len(classes)
+    if P > 64:
+        raise UnsupportedSnapshot("more than 64 distinct inter-pod priority classes in one session")
+    pkeys = sorted(classes, key=lambda k: classes[k])
+    cls_dom, _ = domain_table([(k[3],) for k in pkeys])
+
+    def cls_inc_mask(p):
+        m = 0
+        own = owned_terms(p)
+        for c, k in enumerate(pkeys):
+            if k[0] == "O":
+                if own.get(k[1:4]) == k[4]:
+                    m |= 1 << c
+            elif _pod_matches_props(p, k[1], k[2]):
+                m |= 1 << c
+        return m
+
+    t_cinc = np.zeros(T, np.uint64); t_sig = np.full(T, KB_NONE, np.uint32)
+    sigs: Dict[tuple, int] = {}
+    for t, p in enumerate(session_pods):
+        t_cinc[t] = cls_inc_mask(p)
+        sub = subject_terms(p)
+        w = [0] * P
+        for c, k in enumerate(pkeys):
+            if k[0] == "O":
+                if _pod_matches_props(p, k[1], k[2]):
+                    w[c] = k[4]
+            else:
+                w[c] = sub.get(k[1:4], 0)
+        if any(w):
+            t_sig[t] = sigs.setdefault(tuple(w), len(sigs))
+    S = max(1, len(sigs))
+    sig_w = np.zeros((S, max(1, P)), np.int32)
+    for w, i in sigs.items():
+        sig_w[i, :P] = w
+    cls_bound = np.zeros((max(1, P), N), np.int32); cls_unbound = np.zeros((max(1, P), N), np.int32)
+    first_unbound = KB_NONE
+    on_nodes = [(p, int(task_node[t]), int(t_cinc[t])) for t, p in enumerate(session_pods) if int(task_node[t]) != KB_NONE]
+    on_nodes += [(p, n, cls_inc_mask(p)) for p, n in other_pods_on_nodes]
+    for p, n, m in on_nodes:
+        if p.spec_node_name_empty:
+            first_unbound = min(first_unbound, n)
+        tab = cls_unbound if p.spec_node_name_empty else cls_bound
+        for c in range(P):
+            if (m >> c) & 1:
+                tab[c, n] += 1
+    return dict(n_counters=C, n_domains=int(D), n_classes=P, n_sigs=len(sigs), first_unbound_node=int(first_unbound),
+                ctr_dom=ctr_dom.reshape(C, N) if C else np.zeros((1, N), np.uint32) + KB_NONE,
+                ctr_count=ctr_count if C else np.zeros((1, max(1, D)), np.int32), ctr_total=ctr_total if C else np.zeros(1, np.int32),
+                task_inc=t_inc, task_forbid=t_forbid, task_require=t_req, task_self=t_self,
+                cls_dom=cls_dom if P else np.zeros((1, N), np.uint32) + KB_NONE, cls_bound=cls_bound, cls_unbound=cls_unbound,
+                task_cls_inc=t_cinc, task_sig=t_sig, sig_weight=sig_w)
+
+
 def _best_effort_qos(p: "Pod") -> bool:
     """v1qos.GetPodQOS(pod) == BestEffort (vendor/k8s.io/kubernetes/pkg/apis/core/v1/helper/qos/qos.go:37-82): no container or init
     container has a cpu or memory request or limit above zero."""
@@ -340,6 +596,19 @@ class SessionSnapshot:
                 setattr(s, name, C.POINTER(ctype)())
             else:
                 setattr(s, name, a.ctypes.data_as(C.POINTER(ctype)))
+        ip = getattr(self, "interpod", None)
+        if ip is None:
+            s.interpod = C.POINTER(abi.Interpod)()
+        else:
+            k = abi.Interpod()
+            for name in ("n_counters", "n_domains", "n_classes", "n_sigs", "first_unbound_node"):
+                setattr(k, name, int(ip[name]))
+            for name, ctype in abi.INTERPOD_ARRAYS:
+                a = np.ascontiguousarray(ip[name], dtype=_DTYPES[ctype])
+                ip[name] = a                      # keep the buffer alive as long as the snapshot
+                setattr(k, name, a.ctypes.data_as(C.POINTER(ctype)))
+            self._interpod_abi = k                 # and the struct itself
+            s.interpod = C.pointer(k)
         return s
 
     def task_name(self, t: int) -> str:
@@ -496,11 +765,13 @@ def flatten(nodes: List[Node], pods: List[Pod], pod_groups: List[PodGroup], queu
                 conflict |= 1 << port_bit[other]
         return want, conflict
 
+    others_on_nodes = []
     for p in other_pods:                                 # pods of other schedulers / jobs outside the session
         if p.node_name in nidx:
             res, _, _, nzc, nzm = pod_vectors(p)
             if account_on_node(nidx[p.node_name], _task_status(p), res, nzc, nzm):
                 node_ports[nidx[p.node_name]] |= np.uint64(port_masks(p)[0])
+                others_on_nodes.append((p, nidx[p.node_name]))
 
     t_res = np.zeros((R, T)); t_init = np.zeros((R, T)); t_mask = np.zeros(T, np.uint32)
     t_nzc = np.zeros(T, np.int64); t_nzm = np.zeros(T, np.int64); t_job = np.zeros(T, np.uint32)
@@ -539,6 +810,8 @@ def flatten(nodes: List[Node], pods: List[Pod], pod_groups: List[PodGroup], queu
             k += 1
     begin[J] = k
 
+    interpod = build_interpod(nodes, [p for lst in job_tasks for p in lst], others_on_nodes, t_node, t_st)
+
     ucls_t = sorted(set(task_cls_keys)) or [((), (), (), (0,), False)]
     ucls_n = sorted(set(node_cls_keys)) or [((), (), False, True, False, "", (False, False, False))]
     tmap = {c: i for i, c in enumerate(ucls_t)}
@@ -573,6 +846,7 @@ def flatten(nodes: List[Node], pods: List[Pod], pod_groups: List[PodGroup], queu
         class_compat=compat, class_affinity=affinity,
         node_ports=node_ports if universe else None, task_port_want=t_want if universe else None,
         task_port_conflict=t_conf if universe else None, task_evict_protected=t_prot if t_prot.any() else None,
+        interpod=interpod,
         names={"nodes": [n.name for n in nodes], "tasks": names_tasks, "jobs": job_ids,
                "queues": [q.name for q in queues], "dims": ["cpu", "memory"] + sorted(scalar_names)},
     )

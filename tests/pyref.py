@@ -233,7 +233,79 @@ class Session:
         self.base_ports = list(self.nports)
         self.session_on = [set() for _ in range(self.N)]
         self.decisions, self.binds, self.popped, self.evictions, self.pop_order = [], {}, 0, [], []
+        # inter-pod (anti)affinity tables (include/kb_engine.h: kb_interpod); the per-domain counts are recomputed from the task
+        # statuses on every call here (the PodLister of plugins/util/util.go:37-90), not kept incrementally
+        ip = getattr(s, "interpod", None)
+        self.ip = None
+        if ip is not None:
+            self.ip = {k: (v.tolist() if hasattr(v, "tolist") else v) for k, v in ip.items()}
+            self.ip_at_open = [on for on in self.onnode]
+            self.ip_added = [set() for _ in range(self.N)]      # tasks whose first AddTask happened in this session: Spec.NodeName == ""
         self._open_plugins()
+
+    # ---- inter-pod (anti)affinity on the kb_interpod tables
+    def _ip_count(self, c, dom):
+        """allocated-status session pods counted by predicate counter c in domain dom (None: in any domain or none)"""
+        ip, k = self.ip, 0
+        for t in range(self.T):
+            if self.status[t] in (ALLOCATED, BINDING, BOUND, RUNNING) and (ip["task_inc"][t] >> c) & 1 and self.tnode[t] != NONE:
+                if dom is None or ip["ctr_dom"][c][self.tnode[t]] == dom:
+                    k += 1
+        return k
+
+    def interpod_predicate(self, t, n):
+        """InterPodAffinityMatches (vendor/.../algorithm/predicates/predicates.go:1261-1290) as kb_interpod states it"""
+        ip = self.ip
+        if ip is None:
+            return True
+        for c in range(ip["n_counters"]):
+            if (ip["task_forbid"][t] >> c) & 1:
+                d = ip["ctr_dom"][c][n]
+                if d != NONE and self._ip_count(c, d) > 0:
+                    return False
+        r = ip["task_require"][t]
+        if r != 0xFF:
+            d = ip["ctr_dom"][r][n]
+            if not (d != NONE and self._ip_count(r, d) > 0):
+                if self._ip_count(r, None) > 0 or not ip["task_self"][t]:
+                    return False
+        return True
+
+    def interpod_scores(self, t, feasible):
+        """CalculateInterPodAffinityPriority (vendor/.../priorities/interpod_affinity.go:99-235) as kb_interpod states it"""
+        ip = self.ip
+        if ip is None or ip["task_sig"][t] == NONE:
+            return {n: 0 for n in feasible}
+        w = ip["sig_weight"][ip["task_sig"][t]]
+        z = ip["first_unbound_node"]
+        for n in range(self.N):
+            if self.ip_added[n]:
+                z = min(z, n)
+                break
+        counts = {n: 0 for n in feasible}
+        for p in range(ip["n_classes"]):
+            if w[p] == 0:
+                continue
+            dom = ip["cls_dom"][p]
+            bound, zs = {}, 0
+            for n in feasible:
+                unb = ip["cls_unbound"][p][n] + sum(1 for i in self.ip_added[n] if (ip["task_cls_inc"][i] >> p) & 1)
+                zs += unb
+                if dom[n] != NONE:
+                    bound[dom[n]] = bound.get(dom[n], 0) + ip["cls_bound"][p][n]
+            zdom = dom[z] if z != NONE else NONE
+            for i in feasible:
+                if dom[i] == NONE:
+                    continue
+                counts[i] += w[p] * (bound.get(dom[i], 0) + (zs if dom[i] == zdom else 0))
+        mx, mn = max([0] + list(counts.values())), min([0] + list(counts.values()))
+        out = {}
+        for n in feasible:
+            f = 0.0
+            if mx - mn > 0:
+                f = 10.0 * (float(counts[n] - mn) / float(mx - mn))
+            out[n] = int(f)
+        return out
 
     # ---- conf helpers (framework/session_plugins.go isEnabled)
     def _opts(self):
@@ -379,7 +451,9 @@ class Session:
             bit = self.tcls[t] * self.nnc + self.ncls[n]
             if not (int(self.compat[bit >> 3]) >> (bit & 7)) & 1:
                 return False
-        return (self.nports[n] & self.tconf[t]) == 0
+        if (self.nports[n] & self.tconf[t]) != 0:
+            return False
+        return self.interpod_predicate(t, n)
 
     # ---- nodeorder (plugins/nodeorder/nodeorder.go:107-168 over vendor/.../priorities)
     def _weights(self):
@@ -409,8 +483,10 @@ class Session:
             counts[n] = int(self.affinity[self.tcls[t]][self.ncls[n]]) if self.affinity is not None else 0
             scores[n] = [go_div(lc + lm, 2), go_div(mc + mm, 2), 0, 0, bal]
         mx = max(counts.values()) if counts else 0                    # NormalizeReduce(10, false) (reduce.go:28-63)
+        ips = self.interpod_scores(t, feasible)
         for n in feasible:
             scores[n][2] = go_div(10 * counts[n], mx) if mx > 0 else counts[n]
+            scores[n][3] = ips[n]
         ws = [w["leastrequested.weight"], w["mostrequested.weight"], w["nodeaffinity.weight"], w["podaffinity.weight"], w["balancedresource.weight"]]
         return {n: float(sum(float(sc * wt) for sc, wt in zip(scores[n], ws))) for n in feasible}
 
@@ -460,6 +536,8 @@ class Session:
         self.nzm[n] += self.tnzm[t]
         self.session_on[n].add(t)
         self.nports[n] |= self.twant[t]
+        if self.ip is not None and not self.ip_at_open[t]:
+            self.ip_added[n].add(t)
         return True
 
     def node_remove_task(self, t):
@@ -478,6 +556,8 @@ class Session:
         self.nzc[n] -= self.tnzc[t]
         self.nzm[n] -= self.tnzm[t]
         self.session_on[n].discard(t)
+        if self.ip is not None:
+            self.ip_added[n].discard(t)
         ports = self.base_ports[n]
         for i in self.session_on[n]:
             ports |= self.twant[i]

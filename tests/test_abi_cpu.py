@@ -33,7 +33,8 @@ def test_struct_sizes_match_header():
     assert C.sizeof(abi.PluginOption) == 4 + 4 + 32 + 4
     assert C.sizeof(abi.Decision) == 16
     assert C.sizeof(abi.Config) == 8 + 8 + 8 + 16
-    assert C.sizeof(abi.Snapshot) == 32 + 8 * len(abi.SNAPSHOT_ARRAYS)
+    assert C.sizeof(abi.Snapshot) == 32 + 8 * len(abi.SNAPSHOT_ARRAYS) + 8          # + the kb_interpod pointer
+    assert C.sizeof(abi.Interpod) == 24 + 8 * len(abi.INTERPOD_ARRAYS)
     assert C.sizeof(abi.Stats) == 9 * 8 + 6 * 8
 
 
@@ -85,7 +86,7 @@ def test_struct_layouts_match_the_header_as_gcc_sees_it(tmp_path):
     mirror (kube-batch_amd/abi.py) — the Go side binds the same header through cgo, so the header is the authority."""
     import subprocess
     structs = {"kb_snapshot": abi.Snapshot, "kb_config": abi.Config, "kb_plugin_option": abi.PluginOption,
-               "kb_decision": abi.Decision, "kb_stats": abi.Stats}
+               "kb_decision": abi.Decision, "kb_stats": abi.Stats, "kb_interpod": abi.Interpod}
     lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "kb_engine.h"', 'int main(void) {',
              '  printf("KB_ABI_VERSION %u\\n", (unsigned)KB_ABI_VERSION);']
     for cname, ct in structs.items():
