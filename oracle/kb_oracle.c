@@ -426,6 +426,14 @@ typedef struct kbo_session {
   /* node -> tasks in ni.Tasks (bitmap over T per node would be too big: a linked list through next_on_node, head per node;
      the scans below sort what they collect, so list order does not matter).  Built by node_index_build(). */
   uint32_t *node_head, *next_on_node, *prev_on_node;
+  /* inter-pod (anti)affinity (include/kb_engine.h: kb_interpod), NULL tables: no pod carries a term.  Counts are kept
+     incrementally by ssn_allocate / ssn_pipeline (allocate and backfill only add; preempt / reclaim refuse such sessions). */
+  int ip_on;
+  uint32_t ip_C, ip_D, ip_P, ip_S, ip_Z;
+  uint32_t *ip_ctr_dom, *ip_cls_dom, *ip_task_sig;
+  int32_t *ip_ctr_count, *ip_ctr_total, *ip_cls_bound, *ip_cls_unbound, *ip_sig_weight;
+  uint64_t *ip_task_inc, *ip_task_forbid, *ip_task_cls_inc;
+  uint8_t *ip_task_require, *ip_task_self;
 } kbo_session;
 
 static int find_plugin_enabled(const kbo_session *s, uint32_t plugin, uint32_t en_bit) {
@@ -545,12 +553,34 @@ static int class_ok(const kbo_session *s, uint32_t tc, uint32_t nc) {
   return (s->compat[bit >> 3] >> (bit & 7)) & 1;
 }
 /* plugins/predicates/predicates.go:123-265 with the static checks p2..p7 folded into class_ok */
+/* plugins/predicates/predicates.go:249-262 -> PodAffinityChecker.InterPodAffinityMatches (vendor/.../algorithm/predicates/
+   predicates.go:1261-1290, meta == nil) on the kb_interpod tables: existing pods' anti-affinity and the pod's own anti-affinity
+   forbid a positive count in the node's domain (:1400-1441, :1535-1543); the pod's own affinity needs one, unless no pod at all
+   matches its terms and it matches them itself (:1519-1566). */
+static int interpod_predicate(const kbo_session *s, uint32_t t, uint32_t n) {
+  uint64_t fb = s->ip_task_forbid[t];
+  for (uint32_t c = 0; fb; c++, fb >>= 1) {
+    if (!(fb & 1)) continue;
+    uint32_t d = s->ip_ctr_dom[(size_t)c * s->N + n];
+    if (d != KB_NONE && s->ip_ctr_count[(size_t)c * s->ip_D + d] > 0) return 0;
+  }
+  uint32_t r = s->ip_task_require[t];
+  if (r != 0xFF) {
+    uint32_t d = s->ip_ctr_dom[(size_t)r * s->N + n];
+    if (!(d != KB_NONE && s->ip_ctr_count[(size_t)r * s->ip_D + d] > 0)) {
+      if (s->ip_ctr_total[r] > 0 || !s->ip_task_self[t]) return 0;
+    }
+  }
+  return 1;
+}
 static int plugin_predicate(const kbo_session *s, const o_task *t, const o_node *n) {
   if (!s->pred_enabled) return 1; /* session_plugins.go:334-351: no enabled predicate fn => nil */
   if (n->allocatable.max_task_num <= n->pod_cnt) return 0; /* predicates.go:127 */
   if (!class_ok(s, t->cls, n->cls)) return 0;
   /* PodFitsHostPorts (predicates.go:181-190 -> vendor/.../predicates/predicates.go:1153-1175): any wanted port in conflict with a used one */
-  return (n->ports & t->port_conflict) == 0;
+  if ((n->ports & t->port_conflict) != 0) return 0;
+  if (s->ip_on && !interpod_predicate(s, (uint32_t)(t - s->tasks), (uint32_t)(n - s->nodes))) return 0;
+  return 1;
 }
 /* actions/allocate/allocate.go:73-87 */
 static int allocate_predicate(const kbo_session *s, const o_task *t, const o_node *n) {
@@ -655,10 +685,69 @@ static void node_affinity_reduce(const kbo_session *s, const o_task *t, const ui
   for (uint32_t n = 0; n < s->N; n++)
     if (feas[n]) score[n] += (double)((10 * row[s->nodes[n].cls] / max_count) * s->w_nodeaff);
 }
+/* nodeorder's InterPodAffinityPriority (plugins/nodeorder/nodeorder.go:156-160 -> vendor/.../priorities/interpod_affinity.go:99-235)
+   on the kb_interpod tables.  Only the pods of the FEASIBLE nodes are seen (util/scheduler_helper.go:226-238); a pod whose
+   Spec.NodeName is still empty "lives" on the first node that holds any such pod (nodeorder.go:48-62, canonical: ascending name). */
+static void interpod_priority(const kbo_session *s, const o_task *tk, const uint8_t *feas, double *score) {
+  if (!s->ip_on || !s->nodeorder_enabled) return;
+  const uint32_t t = (uint32_t)(tk - s->tasks);
+  if (s->ip_task_sig[t] == KB_NONE) return;
+  const int32_t *w = &s->ip_sig_weight[(size_t)s->ip_task_sig[t] * s->ip_P];
+  const uint32_t N = s->N;
+  int64_t *counts = (int64_t *)calloc(N ? N : 1, sizeof(int64_t));
+  int64_t *bound = (int64_t *)malloc(sizeof(int64_t) * (N ? N : 1));   /* per domain id (< N) */
+  for (uint32_t p = 0; p < s->ip_P; p++) {
+    if (w[p] == 0) continue;
+    const uint32_t *dom = &s->ip_cls_dom[(size_t)p * N];
+    const int32_t *cb = &s->ip_cls_bound[(size_t)p * N], *cu = &s->ip_cls_unbound[(size_t)p * N];
+    memset(bound, 0, sizeof(int64_t) * (N ? N : 1));
+    int64_t zs = 0;
+    for (uint32_t n = 0; n < N; n++) {
+      if (!feas[n]) continue;
+      zs += cu[n];
+      if (dom[n] != KB_NONE) bound[dom[n]] += cb[n];
+    }
+    const uint32_t zdom = s->ip_Z != KB_NONE ? dom[s->ip_Z] : KB_NONE;
+    for (uint32_t i = 0; i < N; i++) {
+      if (!feas[i] || dom[i] == KB_NONE) continue;
+      counts[i] += (int64_t)w[p] * (bound[dom[i]] + (dom[i] == zdom ? zs : 0));
+    }
+  }
+  int64_t mx = 0, mn = 0;                                      /* interpod_affinity.go:213-220: both start at 0 */
+  for (uint32_t i = 0; i < N; i++) {
+    if (!feas[i]) continue;
+    if (counts[i] > mx) mx = counts[i];
+    if (counts[i] < mn) mn = counts[i];
+  }
+  if (mx - mn > 0)
+    for (uint32_t i = 0; i < N; i++) {
+      if (!feas[i]) continue;
+      double f = 10.0 * ((double)(counts[i] - mn) / (double)(mx - mn));   /* :226-228 */
+      score[i] += (double)((int)f * s->w_podaff);
+    }
+  free(counts); free(bound);
+}
+/* the pod joins ni.Tasks of node n (Allocate or Pipeline: both AddTask) and, for ssn.Allocate, the PodLister's allocated set */
+static void interpod_placed(kbo_session *s, uint32_t t, uint32_t n, int allocated) {
+  if (!s->ip_on) return;
+  uint64_t m = s->ip_task_cls_inc[t];
+  for (uint32_t p = 0; m; p++, m >>= 1)
+    if (m & 1) s->ip_cls_unbound[(size_t)p * s->N + n] += 1;
+  if (n < s->ip_Z) s->ip_Z = n;
+  if (!allocated) return;
+  m = s->ip_task_inc[t];
+  for (uint32_t c = 0; m; c++, m >>= 1) {
+    if (!(m & 1)) continue;
+    s->ip_ctr_total[c] += 1;
+    uint32_t d = s->ip_ctr_dom[(size_t)c * s->N + n];
+    if (d != KB_NONE) s->ip_ctr_count[(size_t)c * s->ip_D + d] += 1;
+  }
+}
 static void eval_all_nodes_raw(kbo_session *s, const o_task *t, int fit_mode, uint8_t *feas, double *score);
 static void eval_all_nodes(kbo_session *s, const o_task *t, int fit_mode, uint8_t *feas, double *score) {
   eval_all_nodes_raw(s, t, fit_mode, feas, score);
   node_affinity_reduce(s, t, feas, score);
+  interpod_priority(s, t, feas, score);
 }
 static void eval_all_nodes_raw(kbo_session *s, const o_task *t, int fit_mode, uint8_t *feas, double *score) {
   if (s->threads <= 1 || s->N < 256) { eval_range(s, t, fit_mode, feas, score, 0, s->N); return; }
@@ -722,6 +811,7 @@ static int ssn_allocate(kbo_session *s, uint32_t t, uint32_t n) {
   nd->nz_mem += tk->nz_mem;
   tk->node_status = KB_TASK_ALLOCATED;
   tk->on_node = 1;
+  interpod_placed(s, t, n, 1);
   push_decision(s, t, n, 0);
   fire_allocate_event(s, t);
   if (ssn_job_ready(s, j)) {        /* session.go:277-285: dispatch every Allocated task of the job (canonical: ascending UID) */
@@ -746,6 +836,7 @@ static int ssn_pipeline(kbo_session *s, uint32_t t, uint32_t n) {
   nd->nz_mem += tk->nz_mem;
   tk->node_status = KB_TASK_PIPELINED;
   tk->on_node = 1;
+  interpod_placed(s, t, n, 0);
   push_decision(s, t, n, 1);
   fire_allocate_event(s, t);
   return 0;
@@ -932,6 +1023,26 @@ kbo_session *kbo_open(const kb_config *cfg, const kb_snapshot *sn, int threads) 
     s->affinity = (int32_t *)malloc(sizeof(int32_t) * (na ? na : 1));
     memcpy(s->affinity, sn->class_affinity, sizeof(int32_t) * na);
   }
+  if (sn->interpod) {
+    const kb_interpod *ip = sn->interpod;
+    s->ip_on = 1;
+    s->ip_C = ip->n_counters; s->ip_D = ip->n_domains ? ip->n_domains : 1; s->ip_P = ip->n_classes; s->ip_S = ip->n_sigs; s->ip_Z = ip->first_unbound_node;
+#define IP_COPY(dst, src, type, count) do { size_t n_ = (size_t)(count); dst = (type *)malloc(sizeof(type) * (n_ ? n_ : 1)); if (n_) memcpy(dst, src, sizeof(type) * n_); } while (0)
+    IP_COPY(s->ip_ctr_dom, ip->ctr_dom, uint32_t, (size_t)s->ip_C * s->N);
+    IP_COPY(s->ip_ctr_count, ip->ctr_count, int32_t, (size_t)s->ip_C * s->ip_D);
+    IP_COPY(s->ip_ctr_total, ip->ctr_total, int32_t, s->ip_C);
+    IP_COPY(s->ip_task_inc, ip->task_inc, uint64_t, s->T);
+    IP_COPY(s->ip_task_forbid, ip->task_forbid, uint64_t, s->T);
+    IP_COPY(s->ip_task_require, ip->task_require, uint8_t, s->T);
+    IP_COPY(s->ip_task_self, ip->task_self, uint8_t, s->T);
+    IP_COPY(s->ip_cls_dom, ip->cls_dom, uint32_t, (size_t)s->ip_P * s->N);
+    IP_COPY(s->ip_cls_bound, ip->cls_bound, int32_t, (size_t)s->ip_P * s->N);
+    IP_COPY(s->ip_cls_unbound, ip->cls_unbound, int32_t, (size_t)s->ip_P * s->N);
+    IP_COPY(s->ip_task_cls_inc, ip->task_cls_inc, uint64_t, s->T);
+    IP_COPY(s->ip_task_sig, ip->task_sig, uint32_t, s->T);
+    IP_COPY(s->ip_sig_weight, ip->sig_weight, int32_t, (size_t)s->ip_S * s->ip_P);
+#undef IP_COPY
+  }
   s->bind_node = (uint32_t *)malloc(sizeof(uint32_t) * (s->T ? s->T : 1));
   s->bind_order = (uint32_t *)malloc(sizeof(uint32_t) * (s->T ? s->T : 1));
   for (uint32_t t = 0; t < s->T; t++) s->bind_node[t] = KB_NONE;
@@ -946,6 +1057,9 @@ void kbo_close(kbo_session *s) {
   for (uint32_t q = 0; q < s->Q; q++) heap_free(&s->queues[q].jobs);
   free(s->nodes); free(s->tasks); free(s->jobs); free(s->queues); free(s->compat); free(s->affinity); free(s->evictions);
   fast_free(s);
+  free(s->ip_ctr_dom); free(s->ip_ctr_count); free(s->ip_ctr_total); free(s->ip_task_inc); free(s->ip_task_forbid); free(s->ip_task_require);
+  free(s->ip_task_self); free(s->ip_cls_dom); free(s->ip_cls_bound); free(s->ip_cls_unbound); free(s->ip_task_cls_inc); free(s->ip_task_sig);
+  free(s->ip_sig_weight);
   free(s->tier_begin); free(s->plugins); free(s->decisions); free(s->bind_node); free(s->bind_order);
   free(s);
 }
@@ -1053,7 +1167,7 @@ static void fast_node_changed(kbo_session *s, uint32_t n) {
     for (p >>= 1; p >= 1; p >>= 1) sh->tree[p] = fast_better(sh->key, sh->tree[2 * p], sh->tree[2 * p + 1]);
   }
 }
-void kbo_set_fast(kbo_session *s, int on) { s->fast = on ? 1 : 0; }
+void kbo_set_fast(kbo_session *s, int on) { s->fast = (on && !s->ip_on) ? 1 : 0; }   /* a placement changes a whole topology domain: the one-node repair does not apply */
 uint32_t kbo_fast_shapes(const kbo_session *s) { return s->fx ? s->fx->n_shapes : 0; }
 
 /* actions/allocate/allocate.go:43-194 */
@@ -1417,6 +1531,7 @@ static int preempt_one(kbo_session *s, stmt_t *st, uint32_t preemptor, int mode,
 }
 int kbo_preempt(kbo_session *s) {
   if (s->panic) return KBO_PANIC;
+  if (s->ip_on) return -3;   /* evictions would take pods OUT of the inter-pod counts: not restated (the engine refuses such sessions too) */
   node_index_build(s);
   for (uint32_t n = 0; n < s->N; n++) {        /* ports of pods outside the session stay on the node whatever moves */
     uint64_t mine = 0;
@@ -1489,6 +1604,7 @@ static void record_eviction(kbo_session *s, uint32_t t) {
 }
 int kbo_reclaim(kbo_session *s) {
   if (s->panic) return KBO_PANIC;
+  if (s->ip_on) return -3;
   for (uint32_t n = 0; n < s->N; n++) {
     uint64_t mine = 0;
     for (uint32_t t = 0; t < s->T; t++) if (s->tasks[t].on_node && s->tasks[t].node == n) mine |= s->tasks[t].port_want;

@@ -21,7 +21,8 @@ def _tiers(cfg):
     return out
 
 
-def random_cluster(seed, n_nodes=7, n_pods=22):
+def random_cluster(seed, n_nodes=7, n_pods=22, n_jobs=5, tight=False):
+    """tight: node capacities and pod requests sized so that resources bind too (Pipelines, gangs that do not fit)"""
     rng = np.random.RandomState(4200 + seed)
     zones = ["z0", "z1", "z2"]
     nodes = []
@@ -31,7 +32,10 @@ def random_cluster(seed, n_nodes=7, n_pods=22):
             labels["zone"] = zones[rng.randint(len(zones))]
         if rng.uniform() < 0.5:
             labels["rack"] = f"r{rng.randint(2)}"
-        nodes.append(snapmod.Node(name=f"n{i:02d}", allocatable={"cpu": "64", "memory": "256Gi", "pods": "110"}, labels=labels))
+        alloc = {"cpu": "64", "memory": "256Gi", "pods": "110"}
+        if tight:
+            alloc = {"cpu": str(int(rng.choice([2, 4, 8]))), "memory": f"{int(rng.choice([8, 16, 32]))}Gi", "pods": str(int(rng.choice([6, 20, 110])))}
+        nodes.append(snapmod.Node(name=f"n{i:02d}", allocatable=alloc, labels=labels))
     apps, tiers_, nss = ["a", "b", "c"], ["fe", "be"], ["ns1", "ns2"]
     keys = ["zone", "kubernetes.io/hostname", "rack"]
 
@@ -50,15 +54,20 @@ def random_cluster(seed, n_nodes=7, n_pods=22):
             ex.append(("app" if vals and vals[0] in apps else "tier", op, vals))
         return (tuple(ml), tuple(ex))
 
-    def term(allow_empty_key=False):
+    def fresh_term(allow_empty_key=False):
         ns = () if rng.uniform() < 0.6 else tuple(sorted(set(rng.choice(nss, size=rng.randint(1, 3)))))
         key = keys[rng.randint(3)] if not (allow_empty_key and rng.uniform() < 0.1) else ""
         return (ns, selector(), key)
 
+    pool = [fresh_term() for _ in range(8)] if tight else None            # workloads share a handful of terms (deployment templates)
+
+    def term(allow_empty_key=False):
+        return pool[rng.randint(len(pool))] if pool else fresh_term(allow_empty_key)
+
     pods, groups = [], []
-    n_jobs = 5
     for j in range(n_jobs):
-        groups.append(snapmod.PodGroup(namespace=nss[j % 2], name=f"pg{j}", min_member=1, queue="default"))
+        groups.append(snapmod.PodGroup(namespace=nss[j % 2], name=f"pg{j}", min_member=int(rng.randint(1, 4)) if tight else 1, queue="default",
+                                       creation=j, priority=int(rng.randint(0, 3)) if tight else 0))
     for i in range(n_pods):
         j = rng.randint(n_jobs + 1)                                       # n_jobs: a pod outside the session
         ns = nss[j % 2] if j < n_jobs else nss[rng.randint(2)]
@@ -67,7 +76,12 @@ def random_cluster(seed, n_nodes=7, n_pods=22):
             labels["app"] = apps[rng.randint(3)]
         if rng.uniform() < 0.5:
             labels["tier"] = tiers_[rng.randint(2)]
-        p = snapmod.Pod(namespace=ns, name=f"p{i:02d}", containers=[{"cpu": "100m", "memory": "128Mi"}],
+        req = {"cpu": "100m", "memory": "128Mi"}
+        if tight:
+            req = {"cpu": f"{int(rng.choice([250, 500, 1000, 2000]))}m", "memory": f"{int(rng.choice([512, 1024, 4096]))}Mi"}
+            if rng.uniform() < 0.08:
+                req = {}                                                   # BestEffort: backfill places it
+        p = snapmod.Pod(namespace=ns, name=f"p{i:03d}", containers=[req],
                         group_name=f"pg{j}" if j < n_jobs else "", labels=labels, creation=i)
         r = rng.uniform()
         if r < 0.30:
@@ -80,6 +94,8 @@ def random_cluster(seed, n_nodes=7, n_pods=22):
             p.pod_anti_affinity_preferred = [(int(rng.choice([1, 10, 100])), term(True)) for _ in range(rng.randint(1, 3))]
         placed = rng.uniform() < (0.35 if j < n_jobs else 1.0)
         if placed:
+            if tight:
+                p.containers = [{"cpu": "50m", "memory": "64Mi"}]           # what already runs must fit (an overfull node is outside the envelope)
             p.node_name = nodes[rng.randint(n_nodes)].name
             p.phase = "Running" if rng.uniform() < 0.7 else "Pending"     # Pending + nodeName = Bound
             if p.phase == "Pending" and rng.uniform() < 0.5:
