@@ -641,6 +641,25 @@ __global__ void __launch_bounds__(K9_THREADS) k_commit_run(const K9KernArgs ka) 
       d.t_node[t] = n;
       d.t_counted[t] = 1;
       if (!kind) d.j_allocated[d.t_job[t]] = 1;   // ssn.Allocate ran for the job: its Allocated tasks are dispatched if it is ready
+      if (d.t_ip_cls_inc) {   // inter-pod affinity: the pod joins ni.Tasks of its node and, when Allocated, the PodLister's allocated set
+        unsigned long long cm = d.t_ip_cls_inc[t];
+        while (cm) {
+          const uint32_t pcl = (uint32_t)__ffsll((unsigned long long)cm) - 1u;
+          cm &= cm - 1ull;
+          atomicAdd(&d.ip_cls_unbound[(size_t)pcl * d.NP + n], 1);
+        }
+        atomicMin(d.ip_z, n);
+        if (!kind) {
+          unsigned long long im = d.t_ip_inc[t];
+          while (im) {
+            const uint32_t c = (uint32_t)__ffsll((unsigned long long)im) - 1u;
+            im &= im - 1ull;
+            atomicAdd(&d.ip_ctr_total[c], 1);
+            const uint32_t dm = d.ip_ctr_dom[(size_t)c * d.NP + n];
+            if (dm != KB_NONE_U32) atomicAdd(&d.ip_ctr_count[(size_t)c * d.ip_D + dm], 1);
+          }
+        }
+      }
       if (a.has_delta && i >= r.own_row0 && i < r.own_row1) {
         double res0 = k.init0, res1 = k.init1;
         if (!(k.flags & 1)) { res0 = d.t_res[t]; res1 = d.t_res[(size_t)d.T + t]; }
@@ -706,7 +725,7 @@ void kb_launch_commit(const KbDev &d, const KbRound &r, void *stream) {
   a.wL = d.wL; a.wM = d.wM; a.wB = d.wB;
   a.use_crow = (d.pred_enabled && d.crows != nullptr && d.n_nc <= 32) ? 1u : 0u;
   a.has_delta = r.delta != nullptr ? 1u : 0u;
-  a.has_aff = (d.aff != nullptr && d.score_enabled) ? 1u : 0u;
+  a.has_aff = ((d.aff != nullptr && d.score_enabled) || d.t_ip_subject != nullptr) ? 1u : 0u;
   a.has_ports = d.ports != nullptr ? 1u : 0u;
   a.R = d.R;
   a.batch = 0;

@@ -1004,6 +1004,25 @@ __global__ void __launch_bounds__(KB_K5_THREADS) k_commit_batch(const K7KernArgs
       d.t_node[t] = dc.x;
       d.t_counted[t] = 1;
       if (!dc.y) d.j_allocated[d.t_job[t]] = 1;   // ssn.Allocate ran for the job: its Allocated tasks are dispatched if it is ready
+      if (d.t_ip_cls_inc) {   // inter-pod affinity: the pod joins ni.Tasks of its node and, when Allocated, the PodLister's allocated set
+        unsigned long long cm = d.t_ip_cls_inc[t];
+        while (cm) {
+          const uint32_t pcl = (uint32_t)__ffsll((unsigned long long)cm) - 1u;
+          cm &= cm - 1ull;
+          atomicAdd(&d.ip_cls_unbound[(size_t)pcl * d.NP + dc.x], 1);
+        }
+        atomicMin(d.ip_z, dc.x);
+        if (!dc.y) {
+          unsigned long long im = d.t_ip_inc[t];
+          while (im) {
+            const uint32_t c = (uint32_t)__ffsll((unsigned long long)im) - 1u;
+            im &= im - 1ull;
+            atomicAdd(&d.ip_ctr_total[c], 1);
+            const uint32_t dm = d.ip_ctr_dom[(size_t)c * d.NP + dc.x];
+            if (dm != KB_NONE_U32) atomicAdd(&d.ip_ctr_count[(size_t)c * d.ip_D + dm], 1);
+          }
+        }
+      }
     }
   }
   if (tid == 0) {
@@ -1058,7 +1077,7 @@ void kb_launch_commit_batch(const KbDev &d, const KbRound &r, void *stream) {
   a.wL = d.wL; a.wM = d.wM; a.wB = d.wB;
   a.use_crow = (d.pred_enabled && d.crows != nullptr && d.n_nc <= 32) ? 1u : 0u;
   a.has_delta = r.delta != nullptr ? 1u : 0u;
-  a.has_aff = (d.aff != nullptr && d.score_enabled) ? 1u : 0u;
+  a.has_aff = ((d.aff != nullptr && d.score_enabled) || d.t_ip_subject != nullptr) ? 1u : 0u;
   a.has_ports = d.ports != nullptr ? 1u : 0u;
   a.R = d.R;
   a.batch = batch;

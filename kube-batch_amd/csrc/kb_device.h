@@ -64,6 +64,27 @@ struct KbDev {
   int wNA;
   int pred_enabled;               // predicates plugin registered with EnabledPredicate
   int score_enabled;              // nodeorder plugin registered with EnabledNodeOrder
+  // inter-pod (anti)affinity (include/kb_engine.h: kb_interpod), all nullptr when no pod carries a term.  A task that is a SUBJECT
+  // (it has predicate checks or non-zero priority weights) is only ever evaluated by the matrix kernel against the live counters:
+  // it is the first row of its round (the host plans it so; t_ip_subject also sets the row's "fresh matrix" flag).  A placement
+  // changes a whole topology domain, which the dirty-node repair of the commit kernels cannot express — and need not: rows that
+  // are not subjects read none of this, and the counters are advanced by the commit kernels' epilogue, once per placed task.
+  const uint32_t *ip_ctr_dom;     // [C][NP] domain of the node for predicate counter c (KB_NONE_U32: label missing)
+  int32_t *ip_ctr_count;          // [C][D] allocated-status pods per domain (live)
+  int32_t *ip_ctr_total;          // [C] (live)
+  const unsigned long long *t_ip_inc, *t_ip_forbid;   // [T]
+  const uint8_t *t_ip_req, *t_ip_self, *t_ip_subject; // [T]
+  const uint32_t *ip_cls_dom;     // [P][NP]
+  const int32_t *ip_cls_bound;    // [P][NP]
+  int32_t *ip_cls_unbound;        // [P][NP] (live)
+  const unsigned long long *t_ip_cls_inc;   // [T]
+  const uint32_t *t_ip_sig;       // [T]
+  const int32_t *ip_sig_w;        // [S][P]
+  uint32_t *ip_z;                 // [1] first node (ascending) holding a pod with an empty Spec.NodeName (live)
+  long long *ip_scratch_cnt;      // [matrix rows][NP] per-node counts of the priority kernel
+  int32_t *ip_scratch_hist;       // [matrix rows][NP] per-domain sums of the priority kernel
+  uint32_t ip_C, ip_D, ip_P;
+  int wPA;
 };
 
 // one device round (matrix -> sorted candidates -> commit)
@@ -180,6 +201,8 @@ void kb_launch_gather(const KbDev &d, const KbRound &r, void *stream);
 void kb_launch_matrix(const KbDev &d, const KbRound &r, void *stream);
 // NodeAffinity Map + NormalizeReduce + weight added to the score rows of the matrix (no-op without affinity terms)
 void kb_launch_affinity(const KbDev &d, const KbRound &r, void *stream);
+// nodeorder's InterPodAffinityPriority added to the score rows of the matrix rows whose task carries weights (no-op otherwise)
+void kb_launch_interpod(const KbDev &d, const KbRound &r, void *stream);
 void kb_launch_argmax(const KbDev &d, const KbRound &r, void *stream);
 // per-task rows out of the per-shape rows (kb_eval_matrix / kb_bench_matrix: the materialised T x N matrix)
 void kb_launch_expand(const KbDev &d, const uint16_t *s_score, const uint32_t *s_mask, const uint32_t *row_slot, uint32_t n_rows,

@@ -146,6 +146,9 @@ struct kb_engine {
   DevBuf b_tfit;
   DevBuf b_tinit, b_tres, b_tnzc, b_tnzm, b_tcls, b_tactive, b_tresmask, b_tjob, b_tstatus, b_tnode, b_tbind, b_tcounted, b_jallocated, b_compat, b_crows, b_aff, b_affcls;
   DevBuf p_idle, p_rel, p_nzc, p_nzm, p_podcnt, p_tstatus, p_tnode, p_tcounted, p_ports;   // pristine copies for kb_session_reset
+  // inter-pod (anti)affinity tables (kb_interpod) and the pristine copies of their live parts
+  DevBuf b_ip_cdom, b_ip_ccnt, b_ip_ctot, b_ip_tinc, b_ip_tforbid, b_ip_treq, b_ip_tself, b_ip_tsubj, b_ip_pdom, b_ip_pbound, b_ip_punb, b_ip_tcinc,
+      b_ip_tsig, b_ip_sigw, b_ip_z, b_ip_scnt, b_ip_shist, p_ip_ccnt, p_ip_ctot, p_ip_punb, p_ip_z;
   DevBuf b_ports, b_twant, b_tconf;   // host ports (only when the snapshot carries any)
   DevBuf b_jbegin, b_jmin, b_jqueue, b_total, b_deserved, b_desmask, b_jalloc, b_jshare, b_qalloc, b_qshare, b_jready;
   uint32_t total_mask = 0;
@@ -296,6 +299,12 @@ void ensure_matrix_buffers(kb_engine *e, uint32_t mrows, uint32_t L) {
     e->h_mrows.resize(mrows);
     e->h_same.resize(mrows);
     e->mat_cap = mrows;
+    if (e->hs.has_interpod) {   // per matrix row: per-node counts and per-domain sums of the inter-pod priority kernel
+      e->b_ip_scnt.alloc(sizeof(long long) * (size_t)mrows * NP);
+      e->b_ip_shist.alloc(sizeof(int32_t) * (size_t)mrows * NP);
+      e->dev.ip_scratch_cnt = e->b_ip_scnt.as<long long>();
+      e->dev.ip_scratch_hist = e->b_ip_shist.as<int32_t>();
+    }
   }
   size_t need = (size_t)mrows * L;
   if (need > e->keys_cap) {
@@ -459,12 +468,14 @@ void round_candidates(kb_engine *e, const RoundCtx &c, uint32_t m0, uint32_t m1,
   if (e->fast_rounds) {   // kernel times come from the wall-clock stamps the kernels leave in the output block
     kb_launch_matrix(c.d, r, e->stream);
     kb_launch_affinity(c.d, r, e->stream);
+    kb_launch_interpod(c.d, r, e->stream);
     kb_launch_argmax(c.d, r, e->stream);
   } else {
     Timer &t1 = get_timer(e, 0), &t3 = get_timer(e, 1);
     HIP_OK(hipEventRecord(t1.a, e->stream));
     kb_launch_matrix(c.d, r, e->stream);
     kb_launch_affinity(c.d, r, e->stream);
+    kb_launch_interpod(c.d, r, e->stream);
     HIP_OK(hipEventRecord(t1.b, e->stream));
     HIP_OK(hipEventRecord(t3.a, e->stream));
     kb_launch_argmax(c.d, r, e->stream);
@@ -610,9 +621,14 @@ struct ActionRun {
   // now saves the device round each would otherwise end.
   void mark_dead(const HostSession &hs, uint32_t x) {
     const int R = hs.R;
+    // inter-pod affinity: a shape that REQUIRES a matching pod in the node's domain gains nodes as pods are placed: never dead.
+    // Forbidding checks only shrink the feasible set (counts only grow inside allocate / backfill): dead stays dead, and a shape
+    // with the same checks and a larger request is dominated as usual.
+    if (!hs.feas_ip_require.empty() && hs.feas_ip_require[x]) return;
     const double *ex = &hs.feas_eff[(size_t)x * R];
     for (uint32_t y = 0; y < hs.n_feas_shapes; y++) {
       if (dead[y] || hs.feas_cls[y] != hs.feas_cls[x] || hs.feas_conf[y] != hs.feas_conf[x]) continue;
+      if (!hs.feas_ip.empty() && hs.feas_ip[y] != hs.feas_ip[x]) continue;
       const double *ey = &hs.feas_eff[(size_t)y * R];
       bool ge = true;
       for (int d = 0; d < R && ge; d++) ge = ey[d] >= ex[d];
@@ -646,6 +662,10 @@ struct ActionRun {
       // the predicates; absorb() then needs to tell "no node passes the predicates" (the task stays Pending) from "one did"
       // (outside the envelope).  Pod counts and used ports only grow during backfill, so the state as of now decides the former.
       bf_need_pred = e->idle_below_eps;
+      if (hs.has_interpod)
+        for (uint32_t t : bf_list)
+          if (hs.t_res[t] != 0.0 || hs.t_res[(size_t)hs.T + t] != 0.0)
+            throw EngineError(KB_E_UNSUPPORTED, "BestEffort task with a sub-epsilon request in a session with inter-pod affinity");
       for (uint32_t t : bf_list) bf_need_pred = bf_need_pred || hs.t_res[t] != 0.0 || hs.t_res[(size_t)hs.T + t] != 0.0;
       if (bf_need_pred) {
         const uint32_t NP = e->dev.NP;
@@ -676,7 +696,8 @@ struct ActionRun {
     if (action == 1) {
       uint32_t n = 0, nshapes = 0;
       new_window(e);
-      while (n < W && bf_pos + n < bf_list.size() && admit_shape(e, hs.t_row_shape[bf_list[bf_pos + n]], nshapes)) {
+      while (n < W && bf_pos + n < bf_list.size() && !(n > 0 && !hs.t_ip_subject.empty() && hs.t_ip_subject[bf_list[bf_pos + n]]) &&
+             admit_shape(e, hs.t_row_shape[bf_list[bf_pos + n]], nshapes)) {   // an inter-pod subject heads its window
         e->h_rows[n] = bf_list[bf_pos + n];
         n++;
       }
@@ -690,7 +711,9 @@ struct ActionRun {
     while (n < W && om.next(t)) {
       spec_pops++;
       if (dead[hs.t_feas_shape[t]]) { om.report(Outcome::NoFeasibleNode); continue; }   // known: feasibility only shrinks inside one action
-      if (!admit_shape(e, hs.t_row_shape[t], nshapes)) { om.rollback_last_pop(); spec_pops--; break; }   // the task heads the next window
+      if (!admit_shape(e, hs.t_row_shape[t], nshapes) || (n > 0 && !hs.t_ip_subject.empty() && hs.t_ip_subject[t])) {
+        om.rollback_last_pop(); spec_pops--; break;   // the task heads the next window (shape budget, or an inter-pod subject: fresh matrix)
+      }
       e->h_rows[n++] = t;
       om.report(Outcome::Allocated);
     }
@@ -713,7 +736,7 @@ struct ActionRun {
     while (n < W && om.next(t)) {
       spec_pops_next++;
       if (dead[hs.t_feas_shape[t]]) { om.report(Outcome::NoFeasibleNode); continue; }
-      if (!admit_shape(e, hs.t_row_shape[t], nshapes)) { om.rollback_last_pop(); spec_pops_next--; break; }
+      if (!admit_shape(e, hs.t_row_shape[t], nshapes) || (n > 0 && !hs.t_ip_subject.empty() && hs.t_ip_subject[t])) { om.rollback_last_pop(); spec_pops_next--; break; }
       rows_next[n++] = t;
       om.report(Outcome::Allocated);
     }
@@ -1025,6 +1048,38 @@ int kb_session_load(kb_engine *e, const kb_snapshot *sn) {
     hs.t_res_empty.assign(T, 0);
     hs.t_init_empty.assign(T, 0);
     Interner feas_ids, row_ids;
+    // inter-pod (anti)affinity tables: validate what indexes device memory
+    const kb_interpod *ip = sn->interpod;
+    if (ip) {
+      if (ip->n_counters > 64 || ip->n_classes > 64) throw EngineError(KB_E_UNSUPPORTED, "more than 64 inter-pod counters / classes");
+      if (ip->n_domains == 0 || ip->n_domains > std::max<uint32_t>(N, 1u)) throw EngineError(KB_E_INVALID, "inter-pod: n_domains outside 1..N");
+      if (!ip->ctr_dom || !ip->ctr_count || !ip->ctr_total || !ip->task_inc || !ip->task_forbid || !ip->task_require || !ip->task_self ||
+          !ip->cls_dom || !ip->cls_bound || !ip->cls_unbound || !ip->task_cls_inc || !ip->task_sig || !ip->sig_weight)
+        throw EngineError(KB_E_INVALID, "inter-pod: missing table");
+      if (ip->first_unbound_node != KB_NONE && ip->first_unbound_node >= N) throw EngineError(KB_E_INVALID, "inter-pod: first_unbound_node out of range");
+      const uint64_t cmask = ip->n_counters == 64 ? ~0ull : ((1ull << ip->n_counters) - 1ull), pmask = ip->n_classes == 64 ? ~0ull : ((1ull << ip->n_classes) - 1ull);
+      for (uint32_t c = 0; c < ip->n_counters; c++)
+        for (uint32_t n = 0; n < N; n++) {
+          const uint32_t dm = ip->ctr_dom[(size_t)c * N + n];
+          if (dm != KB_NONE && dm >= ip->n_domains) throw EngineError(KB_E_INVALID, "inter-pod: counter domain id out of range");
+        }
+      for (uint32_t pc = 0; pc < ip->n_classes; pc++)
+        for (uint32_t n = 0; n < N; n++) {
+          const uint32_t dm = ip->cls_dom[(size_t)pc * N + n];
+          if (dm != KB_NONE && dm >= N) throw EngineError(KB_E_INVALID, "inter-pod: class domain id out of range");
+          if (ip->cls_bound[(size_t)pc * N + n] < 0 || ip->cls_unbound[(size_t)pc * N + n] < 0) throw EngineError(KB_E_INVALID, "inter-pod: negative pod count");
+        }
+      long long wsum = 0;
+      for (uint32_t i = 0; i < ip->n_sigs * ip->n_classes; i++) wsum = std::max<long long>(wsum, std::llabs((long long)ip->sig_weight[i]));
+      if (wsum > 1000000) throw EngineError(KB_E_UNSUPPORTED, "inter-pod: term weight beyond 1e6");
+      for (uint32_t t = 0; t < T; t++) {
+        if ((ip->task_inc[t] & ~cmask) || (ip->task_forbid[t] & ~cmask) || (ip->task_cls_inc[t] & ~pmask)) throw EngineError(KB_E_INVALID, "inter-pod: mask names a missing counter / class");
+        if (ip->task_require[t] != 0xFF && ip->task_require[t] >= ip->n_counters) throw EngineError(KB_E_INVALID, "inter-pod: task_require out of range");
+        if (ip->task_sig[t] != KB_NONE && ip->task_sig[t] >= ip->n_sigs) throw EngineError(KB_E_INVALID, "inter-pod: task_sig out of range");
+      }
+      if (e->pol.nodeorder_enabled && (e->pol.wPA < 0 || 10ll * ((long long)e->pol.wL + e->pol.wM + e->pol.wB + e->pol.wNA + e->pol.wPA) > 65535))
+        throw EngineError(KB_E_UNSUPPORTED, "nodeorder weights (with podaffinity.weight) exceed the 16-bit score range");
+    }
     hs.t_feas_shape.assign(T, 0);
     hs.t_row_shape.assign(T, 0);
     std::vector<double> key;
@@ -1056,11 +1111,17 @@ int kb_session_load(kb_engine *e, const kb_snapshot *sn) {
       {   // host ports: the conflict mask is part of feasibility, the wanted bits of what a commit changes
         const uint64_t conf = sn->task_port_conflict ? sn->task_port_conflict[t] : 0, want = sn->task_port_want ? sn->task_port_want[t] : 0;
         key.push_back((double)(uint32_t)(conf & 0xFFFFFFFFu)); key.push_back((double)(uint32_t)(conf >> 32));
+        if (ip) {   // inter-pod predicate checks are part of feasibility
+          const uint64_t fb = ip->task_forbid[t];
+          key.push_back((double)(uint32_t)(fb & 0xFFFFFFFFu)); key.push_back((double)(uint32_t)(fb >> 32));
+          key.push_back((double)ip->task_require[t]); key.push_back((double)(ip->task_require[t] != 0xFF ? ip->task_self[t] : 0));
+        }
         hs.t_feas_shape[t] = feas_ids.intern(key);
         key.push_back((double)(uint32_t)(want & 0xFFFFFFFFu)); key.push_back((double)(uint32_t)(want >> 32));
       }
       key.push_back((double)sn->task_nz_cpu[t]);
       key.push_back((double)sn->task_nz_mem[t]);
+      if (ip) key.push_back((double)ip->task_sig[t]);   // ... and the priority weights of the score row
       hs.t_row_shape[t] = row_ids.intern(key);
     }
     hs.n_feas_shapes = (uint32_t)feas_ids.size();
@@ -1070,6 +1131,24 @@ int kb_session_load(kb_engine *e, const kb_snapshot *sn) {
     hs.feas_eff.assign((size_t)hs.n_feas_shapes * R, 0.0);
     hs.feas_cls.assign(hs.n_feas_shapes, 0);
     hs.feas_conf.assign(hs.n_feas_shapes, 0);
+    hs.has_interpod = ip != nullptr;
+    hs.t_ip_subject.clear(); hs.feas_ip_require.clear(); hs.feas_ip.clear();
+    if (ip) {
+      hs.t_ip_subject.assign(T, 0);
+      hs.feas_ip_require.assign(hs.n_feas_shapes, 0);
+      hs.feas_ip.assign(hs.n_feas_shapes, 0);
+      Interner ipk;
+      std::vector<double> k3(4);
+      for (uint32_t t = 0; t < T; t++) {
+        const bool checks = ip->task_forbid[t] != 0 || ip->task_require[t] != 0xFF;
+        hs.t_ip_subject[t] = (checks || ip->task_sig[t] != KB_NONE) ? 1 : 0;
+        const uint32_t f = hs.t_feas_shape[t];
+        hs.feas_ip_require[f] = ip->task_require[t] != 0xFF ? 1 : 0;
+        k3[0] = (double)(uint32_t)(ip->task_forbid[t] & 0xFFFFFFFFu); k3[1] = (double)(uint32_t)(ip->task_forbid[t] >> 32);
+        k3[2] = (double)ip->task_require[t]; k3[3] = (double)(ip->task_require[t] != 0xFF ? ip->task_self[t] : 0);
+        hs.feas_ip[f] = ipk.intern(k3);
+      }
+    }
     for (uint32_t t = 0; t < T; t++) {
       const uint32_t f = hs.t_feas_shape[t];
       hs.feas_cls[f] = hs.t_cls[t];
@@ -1303,6 +1382,53 @@ int kb_session_load(kb_engine *e, const kb_snapshot *sn) {
         d.aff_cls = e->b_affcls.as<uint8_t>();
       }
     }
+    d.ip_ctr_dom = nullptr; d.ip_ctr_count = nullptr; d.ip_ctr_total = nullptr; d.t_ip_inc = nullptr; d.t_ip_forbid = nullptr;
+    d.t_ip_req = nullptr; d.t_ip_self = nullptr; d.t_ip_subject = nullptr; d.ip_cls_dom = nullptr; d.ip_cls_bound = nullptr;
+    d.ip_cls_unbound = nullptr; d.t_ip_cls_inc = nullptr; d.t_ip_sig = nullptr; d.ip_sig_w = nullptr; d.ip_z = nullptr;
+    d.ip_scratch_cnt = nullptr; d.ip_scratch_hist = nullptr; d.ip_C = d.ip_D = d.ip_P = 0; d.wPA = e->pol.wPA;
+    if (ip) {
+      const uint32_t C = ip->n_counters, P = ip->n_classes, D = ip->n_domains;
+      auto pad_u32 = [&](DevBuf &b, const uint32_t *src, uint32_t rows) {   // [rows][N] -> [rows][NP], padding KB_NONE
+        std::vector<uint32_t> tmp((size_t)std::max(rows, 1u) * NP, KB_NONE);
+        for (uint32_t r0 = 0; r0 < rows; r0++) std::memcpy(&tmp[(size_t)r0 * NP], src + (size_t)r0 * N, sizeof(uint32_t) * N);
+        upload(b, tmp.data(), tmp.size(), s);
+        HIP_OK(hipStreamSynchronize(s));
+      };
+      auto pad_i32 = [&](DevBuf &b, const int32_t *src, uint32_t rows) {
+        std::vector<int32_t> tmp((size_t)std::max(rows, 1u) * NP, 0);
+        for (uint32_t r0 = 0; r0 < rows; r0++) std::memcpy(&tmp[(size_t)r0 * NP], src + (size_t)r0 * N, sizeof(int32_t) * N);
+        upload(b, tmp.data(), tmp.size(), s);
+        HIP_OK(hipStreamSynchronize(s));
+      };
+      pad_u32(e->b_ip_cdom, ip->ctr_dom, C);
+      pad_u32(e->b_ip_pdom, ip->cls_dom, P);
+      pad_i32(e->b_ip_pbound, ip->cls_bound, P);
+      pad_i32(e->b_ip_punb, ip->cls_unbound, P);
+      std::vector<int32_t> cc((size_t)std::max(C, 1u) * D, 0), ct(std::max(C, 1u), 0);
+      if (C) { std::memcpy(cc.data(), ip->ctr_count, sizeof(int32_t) * (size_t)C * D); std::memcpy(ct.data(), ip->ctr_total, sizeof(int32_t) * C); }
+      upload(e->b_ip_ccnt, cc.data(), cc.size(), s);
+      upload(e->b_ip_ctot, ct.data(), ct.size(), s);
+      upload(e->b_ip_tinc, ip->task_inc, T, s);
+      upload(e->b_ip_tforbid, ip->task_forbid, T, s);
+      upload(e->b_ip_treq, ip->task_require, T, s);
+      upload(e->b_ip_tself, ip->task_self, T, s);
+      upload(e->b_ip_tsubj, hs.t_ip_subject.data(), T, s);
+      upload(e->b_ip_tcinc, ip->task_cls_inc, T, s);
+      upload(e->b_ip_tsig, ip->task_sig, T, s);
+      std::vector<int32_t> sw((size_t)std::max(ip->n_sigs, 1u) * std::max(P, 1u), 0);
+      if (ip->n_sigs && P) std::memcpy(sw.data(), ip->sig_weight, sizeof(int32_t) * (size_t)ip->n_sigs * P);
+      upload(e->b_ip_sigw, sw.data(), sw.size(), s);
+      const uint32_t z0 = ip->first_unbound_node;
+      upload(e->b_ip_z, &z0, 1, s);
+      HIP_OK(hipStreamSynchronize(s));
+      d.ip_ctr_dom = e->b_ip_cdom.as<uint32_t>(); d.ip_ctr_count = e->b_ip_ccnt.as<int32_t>(); d.ip_ctr_total = e->b_ip_ctot.as<int32_t>();
+      d.t_ip_inc = e->b_ip_tinc.as<unsigned long long>(); d.t_ip_forbid = e->b_ip_tforbid.as<unsigned long long>();
+      d.t_ip_req = e->b_ip_treq.as<uint8_t>(); d.t_ip_self = e->b_ip_tself.as<uint8_t>(); d.t_ip_subject = e->b_ip_tsubj.as<uint8_t>();
+      d.ip_cls_dom = e->b_ip_pdom.as<uint32_t>(); d.ip_cls_bound = e->b_ip_pbound.as<int32_t>(); d.ip_cls_unbound = e->b_ip_punb.as<int32_t>();
+      d.t_ip_cls_inc = e->b_ip_tcinc.as<unsigned long long>(); d.t_ip_sig = e->b_ip_tsig.as<uint32_t>(); d.ip_sig_w = e->b_ip_sigw.as<int32_t>();
+      d.ip_z = e->b_ip_z.as<uint32_t>();
+      d.ip_C = C; d.ip_D = D; d.ip_P = P;
+    }
     upload(e->b_jbegin, hs.job_begin.data(), J + 1, s);
     upload(e->b_jmin, hs.job_min.data(), J, s);
     upload(e->b_jqueue, hs.job_queue.data(), J, s);
@@ -1355,6 +1481,7 @@ int kb_session_load(kb_engine *e, const kb_snapshot *sn) {
     snap_copy(e->p_podcnt, e->b_podcnt); snap_copy(e->p_tstatus, e->b_tstatus); snap_copy(e->p_tnode, e->b_tnode);
     if (d.ports) snap_copy(e->p_ports, e->b_ports);
     snap_copy(e->p_tcounted, e->b_tcounted);
+    if (hs.has_interpod) { snap_copy(e->p_ip_ccnt, e->b_ip_ccnt); snap_copy(e->p_ip_ctot, e->b_ip_ctot); snap_copy(e->p_ip_punb, e->b_ip_punb); snap_copy(e->p_ip_z, e->b_ip_z); }
     // initial drf / proportion / gang aggregates come from the device reduction (K2+K4)
     run_finalize(e);
     e->stats.reduce_ms = 0;
@@ -1372,6 +1499,7 @@ int kb_session_reset(kb_engine *e) {
     restore(e->b_podcnt, e->p_podcnt); restore(e->b_tstatus, e->p_tstatus); restore(e->b_tnode, e->p_tnode);
     if (e->dev.ports) restore(e->b_ports, e->p_ports);
     restore(e->b_tcounted, e->p_tcounted);
+    if (e->hs.has_interpod) { restore(e->b_ip_ccnt, e->p_ip_ccnt); restore(e->b_ip_ctot, e->p_ip_ctot); restore(e->b_ip_punb, e->p_ip_punb); restore(e->b_ip_z, e->p_ip_z); }
     HIP_OK(hipMemsetAsync(e->b_tbind.p, 0xFF, sizeof(uint32_t) * (e->hs.T ? e->hs.T : 1), s));
     HIP_OK(hipMemsetAsync(e->b_jallocated.p, 0, e->b_jallocated.bytes, s));
     mg_free(e->mg);
@@ -1480,6 +1608,8 @@ static int run_evict_action(kb_engine *e, bool reclaim, kb_stmt_op *out, uint64_
   return guarded(e, [&]() {
     if (!e->loaded) throw EngineError(KB_E_STATE, "kb_session_load must precede kb_run_preempt / kb_run_reclaim");
     HostSession &hs = e->hs;
+    if (hs.has_interpod)   // an eviction takes a pod OUT of the inter-pod counts (Running -> Releasing leaves api.AllocatedStatus): not modelled
+      throw EngineError(KB_E_UNSUPPORTED, "preempt / reclaim in a session with inter-pod (anti)affinity terms is not modelled");
     if (!reclaim && hs.has_affinity && e->pol.nodeorder_enabled)
       throw EngineError(KB_E_UNSUPPORTED, "preempt with preferred node-affinity terms (NormalizeReduce over the feasible set) is not modelled");
     const double t_begin = now_ms();

@@ -168,6 +168,12 @@ struct HostSession {
   std::vector<uint8_t> compat;             // class x class bit table (empty: every pair compatible)
   uint32_t n_tc = 0, n_nc = 1;
   bool has_affinity = false;               // some class carries preferred node-affinity terms (NormalizeReduce)
+  // inter-pod (anti)affinity (kb_interpod): a SUBJECT task (predicate checks or priority weights) is planned as the first row of its
+  // window; a shape whose affinity REQUIRES a positive count can become feasible again (counts only grow): never marked dead
+  bool has_interpod = false;
+  std::vector<uint8_t> t_ip_subject;       // [T] (empty: no inter-pod affinity in the session)
+  std::vector<uint8_t> feas_ip_require;    // [n_feas_shapes]
+  std::vector<uint32_t> feas_ip;           // [n_feas_shapes] id of the shape's (forbid, require, self) triple: dominance needs equality
   // plugin state
   Res total;                               // drf.totalResource == proportion.totalResource
   std::vector<Res> deserved;               // [Q] proportion queueOpts[q].deserved

@@ -45,8 +45,28 @@ __device__ __forceinline__ K1Task k1_task(const KbDev &d, uint32_t t) {
   const TaskVals v = load_task(d, t);
   K1Task k;
   k.init0 = v.init0; k.init1 = v.init1; k.nzc = (double)v.nzc; k.nzm = (double)v.nzm;
-  k.cls = v.cls; k.active = v.active; k.task = v.task; k.pad = 0; k.conf = v.conf;
+  k.cls = v.cls; k.active = v.active; k.task = v.task; k.conf = v.conf;
+  k.pad = (d.t_ip_forbid && (d.t_ip_forbid[t] != 0ull || d.t_ip_req[t] != 0xFF)) ? 1u : 0u;   // the pod has inter-pod predicate checks
   return k;
+}
+// PodAffinityChecker.InterPodAffinityMatches (vendor/.../algorithm/predicates/predicates.go:1261-1290, meta == nil) on the kb_interpod
+// counters: a positive count in the node's domain forbids (existing pods' anti-affinity :1400-1441, the pod's own :1535-1543) or is
+// required (the pod's own affinity, unless no pod matches at all and the pod matches its own terms: :1519-1566)
+__device__ __forceinline__ bool interpod_ok(const KbDev &d, uint32_t t, uint32_t node) {
+  unsigned long long fb = d.t_ip_forbid[t];
+  while (fb) {
+    const uint32_t c = (uint32_t)__ffsll((unsigned long long)fb) - 1u;
+    fb &= fb - 1ull;
+    const uint32_t dom = d.ip_ctr_dom[(size_t)c * d.NP + node];
+    if (dom != KB_NONE_U32 && d.ip_ctr_count[(size_t)c * d.ip_D + dom] > 0) return false;
+  }
+  const uint32_t r = d.t_ip_req[t];
+  if (r != 0xFFu) {
+    const uint32_t dom = d.ip_ctr_dom[(size_t)r * d.NP + node];
+    if (!(dom != KB_NONE_U32 && d.ip_ctr_count[(size_t)r * d.ip_D + dom] > 0))
+      if (d.ip_ctr_total[r] > 0 || !d.t_ip_self[t]) return false;
+  }
+  return true;
 }
 __device__ __forceinline__ K1Node k1_node(const KbDev &d, uint32_t n) {
   const NodeVals v = load_node(d, n);
@@ -83,6 +103,7 @@ __device__ __forceinline__ uint32_t eval_pair(const KbDev &d, const K1Task &t, c
       uint32_t bit = t.cls * d.n_nc + n.cls;
       ok = ok && ((d.compat[bit >> 3] >> (bit & 7)) & 1);
     }
+    if (t.pad && ok) ok = interpod_ok(d, t.task, node);   // predicates.go:249-262 (rare: subject rows only)
   }
   if (!ok) return 0;
   uint32_t score = 0;
@@ -108,6 +129,7 @@ __device__ __forceinline__ void gather_row(const KbDev &d, const KbRound &r, uin
   k.slot = (uint16_t)r.shape_slot[i];
   k.flags = (d.t_res[t] == k.init0 && d.t_res[(size_t)d.T + t] == k.init1) ? 1 : 0;
   if (d.aff_cls && d.aff_cls[k.cls]) k.flags |= 2;
+  if (d.t_ip_subject && d.t_ip_subject[t]) k.flags |= 2;   // inter-pod subject: exact only against a fresh matrix, like a renormalised row
   {   // bit 2: in every scalar dimension Resreq names, Resreq == InitResreq (the commit kernel then takes the shape's value)
     bool same = true;
     uint32_t m2 = k.resmask;
@@ -562,6 +584,76 @@ void kb_launch_matrix(const KbDev &d, const KbRound &r, void *stream) {
     dim3 grid(d.NP / 256, (r.n_mrows + 3) / 4 + (r.gather ? 1 : 0));
     hipLaunchKernelGGL((k_matrix<1, 4>), grid, dim3(256), 0, (hipStream_t)stream, d, r);
   }
+}
+// nodeorder's InterPodAffinityPriority (plugins/nodeorder/nodeorder.go:156-160 -> vendor/.../priorities/interpod_affinity.go:99-235) on
+// the kb_interpod tables, for the matrix rows whose task carries weights.  One workgroup per row:
+//   count(i) = sum_p w_p * ( sum over FEASIBLE n with dom_p(n) == dom_p(i) of bound_p[n]  +  [dom_p(i) == dom_p(Z)] * sum over feasible n of
+//   unbound_p[n] ),  score(i) += int(10 * (count(i) - min) / (max - min)) * podaffinity.weight  with min / max over the feasible nodes and 0.
+// Only the pods of the feasible nodes count (util/scheduler_helper.go:226-238); a pod whose Spec.NodeName is still empty is looked
+// up through nodeorder's cachedNodeInfo and lands on Z, the first node holding any such pod (nodeorder.go:48-62).
+__global__ void __launch_bounds__(256) k_interpod(KbDev d, KbRound r) {
+  __shared__ long long s_red[2][4];
+  const uint32_t row = blockIdx.x, tid = threadIdx.x;
+  if (KB_CHAIN_BROKEN(r)) return;
+  const uint32_t t = r.mrows ? r.mrows[row] : r.mrow_task0 + row;
+  const uint32_t sig = d.t_ip_sig[t];
+  if (sig == KB_NONE_U32) return;   // uniform per block
+  const int32_t *w = d.ip_sig_w + (size_t)sig * d.ip_P;
+  const uint32_t *mw = r.maskw + (size_t)row * (d.NP / 32);
+  uint16_t *sc = r.score + (size_t)row * d.NP;
+  long long *cnt = d.ip_scratch_cnt + (size_t)row * d.NP;
+  int32_t *hist = d.ip_scratch_hist + (size_t)row * d.NP;
+  const uint32_t Z = *d.ip_z;
+  for (uint32_t n = tid; n < d.N; n += 256) cnt[n] = 0;
+  for (uint32_t p = 0; p < d.ip_P; p++) {
+    const int wp = w[p];
+    if (wp == 0) continue;
+    const uint32_t *dom = d.ip_cls_dom + (size_t)p * d.NP;
+    const int32_t *cb = d.ip_cls_bound + (size_t)p * d.NP, *cu = d.ip_cls_unbound + (size_t)p * d.NP;
+    for (uint32_t n = tid; n < d.N; n += 256) hist[n] = 0;   // domain ids are < N
+    __syncthreads();
+    long long zs = 0;
+    for (uint32_t n = tid; n < d.N; n += 256)
+      if ((mw[n >> 5] >> (n & 31)) & 1u) {
+        zs += cu[n];
+        const uint32_t dm = dom[n];
+        if (dm != KB_NONE_U32 && cb[n] != 0) atomicAdd(&hist[dm], cb[n]);
+      }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) zs += __shfl_xor(zs, o);
+    if ((tid & 63) == 0) s_red[0][tid >> 6] = zs;
+    __threadfence_block();
+    __syncthreads();
+    zs = s_red[0][0] + s_red[0][1] + s_red[0][2] + s_red[0][3];
+    const uint32_t zdom = (Z != KB_NONE_U32) ? dom[Z] : KB_NONE_U32;
+    for (uint32_t n = tid; n < d.N; n += 256)
+      if ((mw[n >> 5] >> (n & 31)) & 1u) {
+        const uint32_t dm = dom[n];
+        if (dm != KB_NONE_U32) cnt[n] += (long long)wp * ((long long)__hip_atomic_load(&hist[dm], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) + (dm == zdom ? zs : 0ll));
+      }
+    __syncthreads();
+  }
+  long long mx = 0, mn = 0;   // interpod_affinity.go:213-220: both start at 0
+  for (uint32_t n = tid; n < d.N; n += 256)
+    if ((mw[n >> 5] >> (n & 31)) & 1u) { mx = max(mx, cnt[n]); mn = min(mn, cnt[n]); }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { mx = max(mx, __shfl_xor(mx, o)); mn = min(mn, __shfl_xor(mn, o)); }
+  __syncthreads();
+  if ((tid & 63) == 0) { s_red[0][tid >> 6] = mx; s_red[1][tid >> 6] = mn; }
+  __syncthreads();
+  mx = max(max(s_red[0][0], s_red[0][1]), max(s_red[0][2], s_red[0][3]));
+  mn = min(min(s_red[1][0], s_red[1][1]), min(s_red[1][2], s_red[1][3]));
+  if (mx - mn <= 0) return;
+  for (uint32_t n = tid; n < d.N; n += 256)
+    if ((mw[n >> 5] >> (n & 31)) & 1u) {
+      const double f = 10.0 * ((double)(cnt[n] - mn) / (double)(mx - mn));   // :226-228, float64 like the reference
+      sc[n] = (uint16_t)(sc[n] + (int)f * d.wPA);
+    }
+}
+
+void kb_launch_interpod(const KbDev &d, const KbRound &r, void *stream) {
+  if (r.n_mrows == 0 || !d.t_ip_sig || !d.score_enabled || d.ip_P == 0) return;
+  hipLaunchKernelGGL(k_interpod, dim3(r.n_mrows), dim3(256), 0, (hipStream_t)stream, d, r);
 }
 void kb_launch_affinity(const KbDev &d, const KbRound &r, void *stream) {
   if (r.n_mrows == 0 || !d.aff || !d.score_enabled) return;

@@ -1,0 +1,88 @@
+"""Inter-pod (anti)affinity on the device — predicate p8 in the matrix kernel, InterPodAffinityPriority in k_interpod, the counters
+advanced by the commit kernels' epilogue — against the C oracle, through the C ABI, on the random clusters of
+tests/test_interpod_oracle_cpu.py (which pin the oracle to a second restatement, itself pinned to the object-level Go semantics by
+tests/test_interpod_cpu.py) and on larger ones.  Needs a real MI355X: -m gpu."""
+import importlib
+
+import numpy as np
+import pytest
+
+from test_gpu_parity import assert_same_outcome
+from test_interpod_cpu import random_cluster
+from test_interpod_oracle_cpu import CONFS, interpod_case
+
+kbm = importlib.import_module("kube-batch_amd")
+engine = importlib.import_module("kube-batch_amd.engine")
+abi, conf, snapmod = kbm.abi, kbm.conf, kbm.snapshot
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(oracle_mod, cfg, snap, **ekw):
+    o = oracle_mod.Oracle(cfg, snap)
+    o.run(["allocate", "backfill"])
+    e = engine.Engine(cfg, **ekw)
+    e.load(snap)
+    dec = e.run(["allocate", "backfill"])
+    assert_same_outcome(o, e, dec)
+    # a second cycle after kb_session_reset restores the live counters too
+    e.reset()
+    dec2 = np.concatenate([e.run_allocate(), e.run_backfill()]) if hasattr(e, "run_allocate") else e.run(["allocate", "backfill"])
+    assert np.array_equal(dec2[:, :3], dec[:, :3])
+    o.close(); e.close()
+    return len(dec)
+
+
+@pytest.mark.parametrize("seed", range(60))
+def test_engine_equals_oracle_with_interpod_affinity(oracle_mod, commit_kernel, seed):
+    try:
+        cfg, snap = interpod_case(seed)
+    except snapmod.UnsupportedSnapshot as e:
+        pytest.skip(str(e))
+    if snap.interpod is None:
+        pytest.skip("no pod-affinity term drawn")
+    _run(oracle_mod, cfg, snap, window=[0, 64, 16][seed % 3])
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_engine_equals_oracle_on_larger_interpod_clusters(oracle_mod, commit_kernel, seed):
+    rng = np.random.RandomState(70 + seed)
+    for attempt in range(8):
+        nodes, pods, groups, queues = random_cluster(5000 + 10 * seed + attempt, n_nodes=int(rng.randint(60, 200)), n_pods=int(rng.randint(400, 1200)),
+                                                     n_jobs=int(rng.randint(20, 80)), tight=True, pool_size=4, weights=(10, 40), templates=True)
+        try:
+            snap = snapmod.flatten(nodes, pods, groups, queues)
+        except snapmod.UnsupportedSnapshot:
+            continue
+        if snap.interpod is not None:
+            break
+    else:
+        pytest.skip("no supported cluster drawn")
+    n = _run(oracle_mod, conf.load_scheduler_conf(CONFS[seed % 2]), snap)
+    assert n > 50
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_engine_equals_oracle_when_few_pods_are_subjects(oracle_mod, commit_kernel, seed):
+    """templates that name one workload each: most pods are not inter-pod subjects and share windows with the few that are"""
+    rng = np.random.RandomState(170 + seed)
+    nodes, pods, groups, queues = random_cluster(7000 + seed, n_nodes=int(rng.randint(60, 200)), n_pods=int(rng.randint(600, 1500)),
+                                                 n_jobs=int(rng.randint(30, 60)), tight=True, pool_size=6, weights=(10, 40), templates=True, narrow=True)
+    snap = snapmod.flatten(nodes, pods, groups, queues)
+    assert snap.interpod is not None
+    ip = snap.interpod
+    subjects = int(((ip["task_forbid"] != 0) | (ip["task_require"] != 255) | (ip["task_sig"] != abi.KB_NONE)).sum())
+    assert 0 < subjects < snap.n_tasks
+    n = _run(oracle_mod, conf.load_scheduler_conf(CONFS[seed % 2]), snap)
+    assert n > 50
+
+
+def test_preempt_is_refused_with_interpod_terms(oracle_mod):
+    cfg, snap = interpod_case(1)
+    assert snap.interpod is not None
+    e = engine.Engine(cfg)
+    e.load(snap)
+    with pytest.raises(engine.EngineError) as ei:
+        e.run_preempt()
+    assert ei.value.code == abi.KB_E_UNSUPPORTED
+    e.close()

@@ -21,7 +21,7 @@ def _tiers(cfg):
     return out
 
 
-def random_cluster(seed, n_nodes=7, n_pods=22, n_jobs=5, tight=False):
+def random_cluster(seed, n_nodes=7, n_pods=22, n_jobs=5, tight=False, pool_size=8, weights=(1, 10, 100), templates=False, narrow=False):
     """tight: node capacities and pod requests sized so that resources bind too (Pipelines, gangs that do not fit)"""
     rng = np.random.RandomState(4200 + seed)
     zones = ["z0", "z1", "z2"]
@@ -40,6 +40,8 @@ def random_cluster(seed, n_nodes=7, n_pods=22, n_jobs=5, tight=False):
     keys = ["zone", "kubernetes.io/hostname", "rack"]
 
     def selector():
+        if narrow:                                                         # terms that name one workload, like real templates do
+            return ((("app", f"a{rng.randint(n_jobs)}"),), ())
         r = rng.uniform()
         if r < 0.08:
             return None                                                  # nil selector: matches nothing
@@ -59,12 +61,13 @@ def random_cluster(seed, n_nodes=7, n_pods=22, n_jobs=5, tight=False):
         key = keys[rng.randint(3)] if not (allow_empty_key and rng.uniform() < 0.1) else ""
         return (ns, selector(), key)
 
-    pool = [fresh_term() for _ in range(8)] if tight else None            # workloads share a handful of terms (deployment templates)
+    pool = [fresh_term() for _ in range(pool_size)] if tight else None            # workloads share a handful of terms (deployment templates)
 
     def term(allow_empty_key=False):
         return pool[rng.randint(len(pool))] if pool else fresh_term(allow_empty_key)
 
     pods, groups = [], []
+    job_spec = {}
     for j in range(n_jobs):
         groups.append(snapmod.PodGroup(namespace=nss[j % 2], name=f"pg{j}", min_member=int(rng.randint(1, 4)) if tight else 1, queue="default",
                                        creation=j, priority=int(rng.randint(0, 3)) if tight else 0))
@@ -72,7 +75,9 @@ def random_cluster(seed, n_nodes=7, n_pods=22, n_jobs=5, tight=False):
         j = rng.randint(n_jobs + 1)                                       # n_jobs: a pod outside the session
         ns = nss[j % 2] if j < n_jobs else nss[rng.randint(2)]
         labels = {}
-        if rng.uniform() < 0.9:
+        if narrow:
+            labels["app"] = f"a{j}"
+        elif rng.uniform() < 0.9:
             labels["app"] = apps[rng.randint(3)]
         if rng.uniform() < 0.5:
             labels["tier"] = tiers_[rng.randint(2)]
@@ -83,15 +88,25 @@ def random_cluster(seed, n_nodes=7, n_pods=22, n_jobs=5, tight=False):
                 req = {}                                                   # BestEffort: backfill places it
         p = snapmod.Pod(namespace=ns, name=f"p{i:03d}", containers=[req],
                         group_name=f"pg{j}" if j < n_jobs else "", labels=labels, creation=i)
-        r = rng.uniform()
-        if r < 0.30:
-            p.pod_anti_affinity_required = [term() for _ in range(rng.randint(1, 3))]
-        if 0.2 < r < 0.45:
-            p.pod_affinity_required = [term() for _ in range(rng.randint(1, 3))]
-        if rng.uniform() < 0.3:
-            p.pod_affinity_preferred = [(int(rng.choice([1, 10, 100])), term()) for _ in range(rng.randint(1, 3))]
-        if rng.uniform() < 0.3:
-            p.pod_anti_affinity_preferred = [(int(rng.choice([1, 10, 100])), term(True)) for _ in range(rng.randint(1, 3))]
+        def draw_spec():
+            r = rng.uniform()
+            spec = [[], [], [], []]
+            if r < 0.30:
+                spec[0] = [term() for _ in range(rng.randint(1, 3))]
+            if 0.2 < r < 0.45:
+                spec[1] = [term() for _ in range(rng.randint(1, 3))]
+            if rng.uniform() < 0.3:
+                spec[2] = [(int(rng.choice(list(weights))), term()) for _ in range(rng.randint(1, 3))]
+            if rng.uniform() < 0.3:
+                spec[3] = [(int(rng.choice(list(weights))), term(True)) for _ in range(rng.randint(1, 3))]
+            return spec
+        if templates:                                                     # the pods of a job share one template, like a Deployment's
+            if j not in job_spec:
+                job_spec[j] = draw_spec() if rng.uniform() < 0.4 else [[], [], [], []]
+            spec = job_spec[j]
+        else:
+            spec = draw_spec()
+        p.pod_anti_affinity_required, p.pod_affinity_required, p.pod_affinity_preferred, p.pod_anti_affinity_preferred = (list(x) for x in spec)
         placed = rng.uniform() < (0.35 if j < n_jobs else 1.0)
         if placed:
             if tight:
