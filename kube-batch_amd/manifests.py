@@ -91,13 +91,30 @@ def _required_terms(spec):
     return [(_requirements(t.get("matchExpressions")), _requirements(t.get("matchFields"))) for t in req.get("nodeSelectorTerms") or []]
 
 
+def _pod_term(t):
+    """v1.PodAffinityTerm -> (namespaces, selector, topologyKey) as kube-batch_amd/snapshot.py:Pod documents it: a missing
+    labelSelector is the nil selector (matches nothing), an empty one matches everything."""
+    sel = t.get("labelSelector")
+    if sel is not None:
+        sel = (tuple(sorted((str(k), str(v)) for k, v in (sel.get("matchLabels") or {}).items())),
+               tuple(_requirements(sel.get("matchExpressions"))))
+    return (tuple(str(n) for n in t.get("namespaces") or []), sel, t.get("topologyKey", "") or "")
+
+
+def _pod_terms(aff, field):
+    block = aff.get(field) or {}
+    required = [_pod_term(t) for t in block.get("requiredDuringSchedulingIgnoredDuringExecution") or []]
+    preferred = [(int(w.get("weight", 0) or 0), _pod_term(w.get("podAffinityTerm") or {}))
+                 for w in block.get("preferredDuringSchedulingIgnoredDuringExecution") or []]
+    return required, preferred
+
+
 def _pod(doc, namespace: str) -> Pod:
     meta, spec, status = doc.get("metadata", {}), doc.get("spec", {}) or {}, doc.get("status", {}) or {}
     aff = spec.get("affinity") or {}
-    if aff.get("podAffinity") is not None or aff.get("podAntiAffinity") is not None:
-        # predicates p8 / priority a22: not flattened.  The reference's own result there depends on Go map order
-        # (plugins/nodeorder/nodeorder.go:48-62 resolves a session-placed pod's empty NodeName to "the first node holding such a pod")
-        raise UnsupportedManifest(f"pod {meta.get('namespace', namespace)}/{meta.get('name')}: inter-pod (anti)affinity")
+    # inter-pod (anti)affinity: predicates p8 / priority a22 (SURVEY.md §8a), flattened into kb_interpod by snapshot.build_interpod
+    pa_req, pa_pref = _pod_terms(aff, "podAffinity")
+    paa_req, paa_pref = _pod_terms(aff, "podAntiAffinity")
     if (status.get("phase", "Pending") or "Pending") == "Pending" and not spec.get("nodeName") and \
             any((v or {}).get("persistentVolumeClaim") is not None for v in spec.get("volumes") or []):
         # ssn.Allocate starts with cache.AllocateVolumes (framework/session.go:236-238): volume binding can veto a placement
@@ -122,6 +139,9 @@ def _pod(doc, namespace: str) -> Pod:
                 for c in (spec.get("containers") or []) + (spec.get("initContainers") or [])],
         host_ports=[(cp.get("hostIP", "") or "", cp.get("protocol", "") or "", int(cp.get("hostPort", 0) or 0))
                     for c in spec.get("containers", []) or [] for cp in c.get("ports", []) or [] if int(cp.get("hostPort", 0) or 0) > 0],
+        labels={str(k): str(v) for k, v in (meta.get("labels") or {}).items()},
+        pod_affinity_required=pa_req, pod_affinity_preferred=pa_pref,
+        pod_anti_affinity_required=paa_req, pod_anti_affinity_preferred=paa_pref,
         required_affinity=_required_terms(spec),
         preferred_affinity=[(int(term.get("weight", 0) or 0),
                              [(ex.get("key", ""), ex.get("operator", ""), tuple(str(v) for v in ex.get("values", []) or []))

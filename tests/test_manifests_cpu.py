@@ -167,22 +167,83 @@ spec: {minMember: 1}
     assert snap.task_port_want.tolist() == [1 | 2] and snap.task_port_conflict.tolist() == [3] and snap.node_ports.tolist() == [0]
 
 
-def test_inter_pod_affinity_is_reported_unsupported():
-    """Same contract as the Go flattener (integration/go/gpuallocate/flatten.go: errUnsupported -> the stock action runs the cycle)."""
+def interpod_kat_text():
+    """three nodes in two zones, a 4-replica `web` job with a required hostname anti-affinity among its pods, a `cache` pod with a required
+    zone affinity and a preferred hostname affinity to them (used by the CPU and the GPU known-answer tests)"""
     text = """
 apiVersion: v1
-kind: Pod
-metadata: {name: p, namespace: ns, annotations: {scheduling.k8s.io/group-name: g}}
-spec:
-  containers: [{name: c, resources: {requests: {cpu: "1"}}}]
-  affinity:
-    podAntiAffinity:
-      requiredDuringSchedulingIgnoredDuringExecution:
-      - topologyKey: kubernetes.io/hostname
-        labelSelector: {matchLabels: {app: web}}
+kind: List
+items:
+- {apiVersion: v1, kind: Node, metadata: {name: n1, labels: {kubernetes.io/hostname: n1, zone: z1}}, status: {allocatable: {cpu: "8", memory: 32Gi, pods: "110"}}}
+- {apiVersion: v1, kind: Node, metadata: {name: n2, labels: {kubernetes.io/hostname: n2, zone: z1}}, status: {allocatable: {cpu: "8", memory: 32Gi, pods: "110"}}}
+- {apiVersion: v1, kind: Node, metadata: {name: n3, labels: {kubernetes.io/hostname: n3, zone: z2}}, status: {allocatable: {cpu: "8", memory: 32Gi, pods: "110"}}}
+- {apiVersion: scheduling.incubator.k8s.io/v1alpha1, kind: Queue, metadata: {name: default}, spec: {weight: 1}}
+- {apiVersion: scheduling.incubator.k8s.io/v1alpha1, kind: PodGroup, metadata: {name: web, namespace: ns, creationTimestamp: "2019-01-01T00:00:00Z"}, spec: {minMember: 1}}
+- {apiVersion: scheduling.incubator.k8s.io/v1alpha1, kind: PodGroup, metadata: {name: cache, namespace: ns, creationTimestamp: "2019-01-01T00:00:01Z"}, spec: {minMember: 1}}
 """
-    with pytest.raises(manifests.UnsupportedManifest, match="inter-pod"):
-        manifests.load_cluster(text)
+    web = """
+- apiVersion: v1
+  kind: Pod
+  metadata: {name: web-%d, namespace: ns, labels: {app: web}, annotations: {scheduling.k8s.io/group-name: web}}
+  spec:
+    containers: [{name: c, resources: {requests: {cpu: "1", memory: 1Gi}}}]
+    affinity:
+      podAntiAffinity:
+        requiredDuringSchedulingIgnoredDuringExecution:
+        - topologyKey: kubernetes.io/hostname
+          labelSelector: {matchLabels: {app: web}}
+  status: {phase: Pending}
+"""
+    cache = """
+- apiVersion: v1
+  kind: Pod
+  metadata: {name: cache-0, namespace: ns, labels: {app: cache}, annotations: {scheduling.k8s.io/group-name: cache}}
+  spec:
+    containers: [{name: c, resources: {requests: {cpu: "1", memory: 1Gi}}}]
+    affinity:
+      podAffinity:
+        requiredDuringSchedulingIgnoredDuringExecution:
+        - topologyKey: zone
+          labelSelector: {matchExpressions: [{key: app, operator: In, values: [web]}]}
+        preferredDuringSchedulingIgnoredDuringExecution:
+        - weight: 50
+          podAffinityTerm: {topologyKey: kubernetes.io/hostname, labelSelector: {matchLabels: {app: web}}}
+  status: {phase: Pending}
+"""
+    text = text + "".join(web % i for i in range(4)) + cache
+    return text
+
+
+def test_inter_pod_affinity_manifest_is_flattened_and_scheduled(oracle_mod):
+    """podAntiAffinity / podAffinity from a cluster dump -> kb_interpod -> the oracle, against an answer derived by hand from the Go code:
+    * web-0 (job `web` is older): no pod is allocated yet, every node passes and ties -> n1; the job is ready (minMember 1) and is
+      pushed back; gang's JobOrderFn now puts the not-yet-ready `cache` job first;
+    * cache-0 requires zone affinity to app=web: web-0 sits in z1, so n1 and n2 pass and n3 (z2) fails.  Resource scores: n1 16
+      (least 8 + balanced 8), n2 17 (8 + 9).  InterPodAffinityPriority: cache-0's preferred term (50, hostname, app=web) matches web-0,
+      whose still empty Spec.NodeName resolves to the first node holding such a pod, n1: counts n1 50, n2 0 -> 10 and 0 -> n1 wins 26 : 17;
+    * web-1: its own hostname anti-affinity (and web-0's, symmetric) forbid n1; cache-0's terms would score it, but cache-0 sits on
+      n1, which is not feasible, and only the pods of the feasible nodes are seen -> n2 and n3 tie -> n2; web-2 -> n3;
+      web-3: every hostname is taken -> no node."""
+    text = interpod_kat_text()
+    nodes, pods, pgs, queues = manifests.load_cluster(text)
+    webp = [p for p in pods if p.name.startswith("web")][0]
+    assert webp.labels == {"app": "web"}
+    assert webp.pod_anti_affinity_required == [((), ((("app", "web"),), ()), "kubernetes.io/hostname")]
+    cp = [p for p in pods if p.name == "cache-0"][0]
+    assert cp.pod_affinity_required == [((), ((), (("app", "In", ("web",)),)), "zone")]
+    assert cp.pod_affinity_preferred == [(50, ((), ((("app", "web"),), ()), "kubernetes.io/hostname"))]
+    snap = manifests.load_snapshot(text)
+    ip = snap.interpod
+    assert ip is not None and ip["n_counters"] == 3 and ip["n_classes"] == 3     # A(hostname), G(anti web), G(aff cache); S(pref), O(required aff, 1), O(pref, 50)
+    cfg = kb.conf.load_scheduler_conf()
+    o = oracle_mod.Oracle(cfg, snap)
+    o.run(["allocate", "backfill"])
+    binds = snap.bind_map(o.binds())
+    # one web replica per node, the fourth finds no node (anti-affinity on all three hostnames); the cache pod joins a web pod
+    assert {binds[f"ns/web-{i}"] for i in range(3)} == {"n1", "n2", "n3"} and "ns/web-3" not in binds
+    assert [binds[f"ns/web-{i}"] for i in range(3)] == ["n1", "n2", "n3"]
+    assert binds["ns/cache-0"] == "n1"
+    o.close()
 
 
 def _feasible(snap):
