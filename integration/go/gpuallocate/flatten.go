@@ -172,9 +172,6 @@ func nodeClassKey(n *api.NodeInfo) string {
 }
 func taskClassKey(t *api.TaskInfo, pf pressureFlags) (string, error) {
 	sp := &t.Pod.Spec
-	if sp.Affinity != nil && (sp.Affinity.PodAffinity != nil || sp.Affinity.PodAntiAffinity != nil) {
-		return "", errUnsupported("inter-pod (anti)affinity")
-	}
 	if t.Status == api.Pending {
 		for i := range sp.Volumes {
 			if sp.Volumes[i].PersistentVolumeClaim != nil {
@@ -190,7 +187,12 @@ func taskClassKey(t *api.TaskInfo, pf pressureFlags) (string, error) {
 		tols = append(tols, x.Key+"|"+string(x.Operator)+"|"+x.Value+"|"+string(x.Effect))
 	}
 	// *v1.Affinity is a Stringer (generated.pb.go): %v prints the whole tree, not pointers
-	return fmt.Sprintf("%v|%v|%v|%v", sp.NodeSelector, sp.Affinity, tols, bestEffort), nil
+	// inter-pod (anti)affinity is dynamic, not part of the static class: interpod.go folds it into kb_interpod
+	var nodeAff *v1.NodeAffinity
+	if sp.Affinity != nil {
+		nodeAff = sp.Affinity.NodeAffinity
+	}
+	return fmt.Sprintf("%v|%v|%v|%v", sp.NodeSelector, nodeAff, tols, bestEffort), nil
 }
 
 // host ports: every distinct (hostIP, protocol, hostPort > 0) of the session's pods is one bit (nodeinfo/host_ports.go sanitises
@@ -582,5 +584,9 @@ func flatten(ssn *framework.Session) (*flat, error) {
 		s.task_port_conflict = (*C.uint64_t)(unsafe.Pointer(&tconf[0]))
 	}
 	s.task_evict_protected = (*C.uint8_t)(unsafe.Pointer(&tprot[0]))
+	if err := f.buildInterpod(tnode, tstatus); err != nil { // predicate p8 / priority a22: kb_interpod (nil when no pod has a term)
+		f.free()
+		return nil, err
+	}
 	return f, nil
 }

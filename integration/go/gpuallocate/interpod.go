@@ -1,0 +1,535 @@
+// interpod.go — inter-pod (anti)affinity -> kb_interpod (SOURCE ONLY, see gpuallocate.go).  The Go twin of
+// kube-batch_amd/snapshot.py:build_interpod, table for table; namespaces, label selectors and topology comparisons go through the
+// vendored helpers the reference itself calls (priorityutil.GetNamespacesFromPodAffinityTerm, metav1.LabelSelectorAsSelector,
+// priorityutil.PodMatchesTermsNamespaceAndSelector), so what a term "matches" is decided by the same code.
+//
+//	predicate: plugins/predicates/predicates.go:249-262 -> vendor/.../algorithm/predicates/predicates.go:1261-1575 (meta == nil)
+//	priority:  plugins/nodeorder/nodeorder.go:48-62,156-160 -> vendor/.../algorithm/priorities/interpod_affinity.go:99-235
+//
+// See include/kb_engine.h (kb_interpod) for what every table means.
+package gpuallocate
+
+/*
+#include <stdlib.h>
+#include "kb_engine.h"
+*/
+import "C"
+
+import (
+	"fmt"
+	"sort"
+	"strings"
+	"unsafe"
+
+	v1 "k8s.io/api/core/v1"
+	metav1 "k8s.io/apimachinery/pkg/apis/meta/v1"
+	"k8s.io/apimachinery/pkg/labels"
+	"k8s.io/apimachinery/pkg/util/sets"
+	priorityutil "k8s.io/kubernetes/pkg/scheduler/algorithm/priorities/util"
+
+	"github.com/kubernetes-sigs/kube-batch/pkg/scheduler/api"
+)
+
+// a PodAffinityTerm as its owner resolves it
+type termProps struct {
+	namespaces sets.String
+	selector   labels.Selector
+	key        string // topologyKey
+	id         string // canonical text of the three: equal ids <=> the same test
+}
+
+func resolveTerm(owner *v1.Pod, term *v1.PodAffinityTerm) (termProps, error) {
+	sel, err := metav1.LabelSelectorAsSelector(term.LabelSelector)
+	if err != nil {
+		// the reference would fail every (pod, node) pair that reaches this term (predicates.go:1299-1302): not modelled
+		return termProps{}, errUnsupported(fmt.Sprintf("pod %s/%s: invalid pod-affinity label selector: %v", owner.Namespace, owner.Name, err))
+	}
+	ns := priorityutil.GetNamespacesFromPodAffinityTerm(owner, term)
+	names := ns.List() // sorted
+	nilSel := "nil"
+	if term.LabelSelector != nil {
+		nilSel = sel.String()
+	}
+	return termProps{namespaces: ns, selector: sel, key: term.TopologyKey,
+		id: strings.Join(names, ",") + "|" + nilSel + "|" + term.TopologyKey}, nil
+}
+
+func (tp termProps) matches(pod *v1.Pod) bool {
+	return priorityutil.PodMatchesTermsNamespaceAndSelector(pod, tp.namespaces, tp.selector)
+}
+
+func podAffinityOf(pod *v1.Pod) (reqAff, reqAnti []v1.PodAffinityTerm, prefAff, prefAnti []v1.WeightedPodAffinityTerm) {
+	a := pod.Spec.Affinity
+	if a == nil {
+		return
+	}
+	if a.PodAffinity != nil {
+		reqAff = a.PodAffinity.RequiredDuringSchedulingIgnoredDuringExecution
+		prefAff = a.PodAffinity.PreferredDuringSchedulingIgnoredDuringExecution
+	}
+	if a.PodAntiAffinity != nil {
+		reqAnti = a.PodAntiAffinity.RequiredDuringSchedulingIgnoredDuringExecution
+		prefAnti = a.PodAntiAffinity.PreferredDuringSchedulingIgnoredDuringExecution
+	}
+	return
+}
+
+func hasInterpodTerms(pod *v1.Pod) bool {
+	ra, rn, pa, pn := podAffinityOf(pod)
+	return len(ra)+len(rn)+len(pa)+len(pn) > 0
+}
+
+// a predicate counter: kind 'A' (owners of one required anti-affinity term) or 'G' (pods matching ALL terms of a set)
+type ipCounter struct {
+	group bool
+	terms []termProps
+}
+
+// a priority class: kind 'O' (owners of a term, signed weight) or 'S' (pods matching a preferred term of the scored pod)
+type ipClass struct {
+	owned  bool
+	term   termProps
+	weight int32
+}
+
+type podOnNode struct {
+	pod  *v1.Pod
+	node uint32
+}
+
+// weights a pod's own terms give OTHER pods (required affinity: hardPodAffinityWeight 1; preferred: signed weight), summed per term id
+func ownedTerms(pod *v1.Pod) (map[string]int32, map[string]termProps, error) {
+	w, tp := map[string]int32{}, map[string]termProps{}
+	ra, _, pa, pn := podAffinityOf(pod)
+	add := func(term *v1.PodAffinityTerm, weight int32) error {
+		p, err := resolveTerm(pod, term)
+		if err != nil {
+			return err
+		}
+		w[p.id] += weight
+		tp[p.id] = p
+		return nil
+	}
+	for i := range ra {
+		if err := add(&ra[i], 1); err != nil {
+			return nil, nil, err
+		}
+	}
+	for i := range pa {
+		if err := add(&pa[i].PodAffinityTerm, pa[i].Weight); err != nil {
+			return nil, nil, err
+		}
+	}
+	for i := range pn {
+		if err := add(&pn[i].PodAffinityTerm, -pn[i].Weight); err != nil {
+			return nil, nil, err
+		}
+	}
+	for id, v := range w {
+		if v == 0 {
+			delete(w, id)
+		}
+	}
+	return w, tp, nil
+}
+
+// weights a pod's preferred terms give the pod itself against the pods on the nodes
+func subjectTerms(pod *v1.Pod) (map[string]int32, map[string]termProps, error) {
+	w, tp := map[string]int32{}, map[string]termProps{}
+	_, _, pa, pn := podAffinityOf(pod)
+	for i := range pa {
+		p, err := resolveTerm(pod, &pa[i].PodAffinityTerm)
+		if err != nil {
+			return nil, nil, err
+		}
+		w[p.id] += pa[i].Weight
+		tp[p.id] = p
+	}
+	for i := range pn {
+		p, err := resolveTerm(pod, &pn[i].PodAffinityTerm)
+		if err != nil {
+			return nil, nil, err
+		}
+		w[p.id] -= pn[i].Weight
+		tp[p.id] = p
+	}
+	for id, v := range w {
+		if v == 0 {
+			delete(w, id)
+		}
+	}
+	return w, tp, nil
+}
+
+func groupOf(pod *v1.Pod, terms []v1.PodAffinityTerm) (string, []termProps, error) {
+	var tps []termProps
+	for i := range terms {
+		p, err := resolveTerm(pod, &terms[i])
+		if err != nil {
+			return "", nil, err
+		}
+		if p.key == "" {
+			return "", nil, errUnsupported("required pod (anti)affinity term with an empty topologyKey")
+		}
+		tps = append(tps, p)
+	}
+	sort.Slice(tps, func(a, b int) bool { return tps[a].id < tps[b].id })
+	ids := make([]string, len(tps))
+	for i := range tps {
+		ids[i] = tps[i].id
+	}
+	return "G:" + strings.Join(ids, ";"), tps, nil
+}
+
+// node -> interned id of the tuple of its values of `keys` (KB_NONE when a label is missing); returns the number of domains
+func domainRow(dst []uint32, nodes []*api.NodeInfo, keys []string) int {
+	vals := map[string][]int{}
+	for n, ni := range nodes {
+		dst[n] = C.KB_NONE
+		lbl := ni.Node.Labels
+		parts := make([]string, 0, len(keys))
+		ok := len(keys) > 0
+		for _, k := range keys {
+			v, has := lbl[k]
+			if k == "" || !has {
+				ok = false
+				break
+			}
+			parts = append(parts, v)
+		}
+		if ok {
+			id := strings.Join(parts, "\x00")
+			vals[id] = append(vals[id], n)
+		}
+	}
+	ids := make([]string, 0, len(vals))
+	for id := range vals {
+		ids = append(ids, id)
+	}
+	sort.Strings(ids)
+	for i, id := range ids {
+		for _, n := range vals[id] {
+			dst[n] = uint32(i)
+		}
+	}
+	return len(ids)
+}
+
+// buildInterpod fills f.snap.interpod (nil when no pod of the cluster carries a pod-(anti)affinity term).
+// tnode[t] / tstatus[t]: as flatten() computed them (the node whose ni.Tasks holds task t at session open, KB_TASK_*).
+func (f *flat) buildInterpod(tnode []uint32, tstatus []uint8) error {
+	N, T := len(f.nodes), len(f.tasks)
+	inSession := map[api.TaskID]bool{}
+	for _, ti := range f.tasks {
+		inSession[ti.UID] = true
+	}
+	// pods outside the session that sit in some ni.Tasks (other schedulers, jobs without a PodGroup)
+	var others []podOnNode
+	for n, ni := range f.nodes {
+		keys := make([]string, 0, len(ni.Tasks))
+		for k := range ni.Tasks {
+			keys = append(keys, string(k))
+		}
+		sort.Strings(keys)
+		for _, k := range keys {
+			ti := ni.Tasks[api.TaskID(k)]
+			if !inSession[ti.UID] {
+				others = append(others, podOnNode{ti.Pod, uint32(n)})
+			}
+		}
+	}
+	any := false
+	for _, ti := range f.tasks {
+		any = any || hasInterpodTerms(ti.Pod)
+	}
+	for _, o := range others {
+		any = any || hasInterpodTerms(o.pod)
+	}
+	if !any {
+		return nil
+	}
+
+	// ---- predicate counters
+	var counters []ipCounter
+	counterIdx := map[string]int{}
+	counter := func(id string, c ipCounter) int {
+		if i, ok := counterIdx[id]; ok {
+			return i
+		}
+		counterIdx[id] = len(counters)
+		counters = append(counters, c)
+		return len(counters) - 1
+	}
+	for _, ti := range f.tasks {
+		ra, rn, _, _ := podAffinityOf(ti.Pod)
+		for i := range rn {
+			p, err := resolveTerm(ti.Pod, &rn[i])
+			if err != nil {
+				return err
+			}
+			if p.key == "" {
+				return errUnsupported("required pod anti-affinity term with an empty topologyKey")
+			}
+			counter("A:"+p.id, ipCounter{group: false, terms: []termProps{p}})
+		}
+		for _, terms := range [][]v1.PodAffinityTerm{ra, rn} {
+			if len(terms) > 0 {
+				id, tps, err := groupOf(ti.Pod, terms)
+				if err != nil {
+					return err
+				}
+				counter(id, ipCounter{group: true, terms: tps})
+			}
+		}
+	}
+	nC := len(counters)
+	if nC > 64 {
+		return errUnsupported("more than 64 distinct inter-pod predicate counters")
+	}
+	ctrDom := f.u32(max1(nC) * N)
+	D := 1
+	for c := range counters {
+		keys := make([]string, len(counters[c].terms))
+		for i, tp := range counters[c].terms {
+			keys[i] = tp.key
+		}
+		if d := domainRow(ctrDom[c*N:(c+1)*N], f.nodes, keys); d > D {
+			D = d
+		}
+	}
+	tInc, tForbid := f.u64(T), f.u64(T)
+	tReq, tSelf := f.u8(T), f.u8(T)
+	for t, ti := range f.tasks {
+		pod := ti.Pod
+		ra, rn, _, _ := podAffinityOf(pod)
+		ownA := map[string]bool{}
+		for i := range rn {
+			p, _ := resolveTerm(pod, &rn[i])
+			ownA["A:"+p.id] = true
+		}
+		for id, c := range counterIdx {
+			ctr := counters[c]
+			if !ctr.group {
+				if ownA[id] {
+					tInc[t] |= 1 << uint(c)
+				}
+				if ctr.terms[0].matches(pod) {
+					tForbid[t] |= 1 << uint(c)
+				}
+				continue
+			}
+			all := true
+			for _, tp := range ctr.terms {
+				all = all && tp.matches(pod)
+			}
+			if all {
+				tInc[t] |= 1 << uint(c)
+			}
+		}
+		tReq[t] = 0xFF
+		if len(rn) > 0 {
+			id, _, _ := groupOf(pod, rn)
+			tForbid[t] |= 1 << uint(counterIdx[id])
+		}
+		if len(ra) > 0 {
+			id, tps, _ := groupOf(pod, ra)
+			tReq[t] = uint8(counterIdx[id])
+			self := true // targetPodMatchesAffinityOfPod(pod, pod) (predicates/metadata.go:767-778)
+			for _, tp := range tps {
+				self = self && tp.matches(pod)
+			}
+			if self {
+				tSelf[t] = 1
+			}
+		}
+	}
+	ctrCount, ctrTotal := f.i32(max1(nC)*D), f.i32(max1(nC))
+	for t := range f.tasks {
+		st := tstatus[t]
+		if !(st == C.KB_TASK_ALLOCATED || st == C.KB_TASK_BINDING || st == C.KB_TASK_BOUND || st == C.KB_TASK_RUNNING) { // api.AllocatedStatus
+			continue
+		}
+		if tnode[t] == C.KB_NONE {
+			if tInc[t] != 0 {
+				// PodLister lists it under its NodeName although no ni.Tasks holds it; nodeInfo.Filter then hides it from that one node only
+				return errUnsupported("an allocated-status task outside every ni.Tasks takes part in inter-pod affinity")
+			}
+			continue
+		}
+		for c := 0; c < nC; c++ {
+			if tInc[t]>>uint(c)&1 == 1 {
+				ctrTotal[c]++
+				if d := ctrDom[c*N+int(tnode[t])]; d != C.KB_NONE {
+					ctrCount[c*D+int(d)]++
+				}
+			}
+		}
+	}
+
+	// ---- priority classes
+	var classes []ipClass
+	classIdx := map[string]int{}
+	class := func(id string, c ipClass) int {
+		if i, ok := classIdx[id]; ok {
+			return i
+		}
+		classIdx[id] = len(classes)
+		classes = append(classes, c)
+		return len(classes) - 1
+	}
+	allPods := make([]*v1.Pod, 0, T+len(others))
+	for _, ti := range f.tasks {
+		allPods = append(allPods, ti.Pod)
+	}
+	for _, o := range others {
+		allPods = append(allPods, o.pod)
+	}
+	for _, pod := range allPods {
+		w, tp, err := ownedTerms(pod)
+		if err != nil {
+			return err
+		}
+		ids := make([]string, 0, len(w))
+		for id := range w {
+			ids = append(ids, id)
+		}
+		sort.Strings(ids)
+		for _, id := range ids {
+			class(fmt.Sprintf("O:%s:%d", id, w[id]), ipClass{owned: true, term: tp[id], weight: w[id]})
+		}
+	}
+	for _, ti := range f.tasks {
+		w, tp, err := subjectTerms(ti.Pod)
+		if err != nil {
+			return err
+		}
+		ids := make([]string, 0, len(w))
+		for id := range w {
+			ids = append(ids, id)
+		}
+		sort.Strings(ids)
+		for _, id := range ids {
+			class("S:"+id, ipClass{owned: false, term: tp[id]})
+		}
+	}
+	nP := len(classes)
+	if nP > 64 {
+		return errUnsupported("more than 64 distinct inter-pod priority classes")
+	}
+	clsDom := f.u32(max1(nP) * N)
+	for p := range classes {
+		domainRow(clsDom[p*N:(p+1)*N], f.nodes, []string{classes[p].term.key})
+	}
+	clsIncMask := func(pod *v1.Pod) (uint64, error) {
+		own, _, err := ownedTerms(pod)
+		if err != nil {
+			return 0, err
+		}
+		var m uint64
+		for p, cl := range classes {
+			if cl.owned {
+				if w, ok := own[cl.term.id]; ok && w == cl.weight {
+					m |= 1 << uint(p)
+				}
+			} else if cl.term.matches(pod) {
+				m |= 1 << uint(p)
+			}
+		}
+		return m, nil
+	}
+	tClsInc, tSig := f.u64(T), f.u32(T)
+	sigIdx := map[string]int{}
+	var sigRows [][]int32
+	for t, ti := range f.tasks {
+		m, err := clsIncMask(ti.Pod)
+		if err != nil {
+			return err
+		}
+		tClsInc[t] = m
+		sub, _, _ := subjectTerms(ti.Pod)
+		row := make([]int32, nP)
+		nonzero := false
+		for p, cl := range classes {
+			if cl.owned {
+				if cl.term.matches(ti.Pod) {
+					row[p] = cl.weight
+				}
+			} else {
+				row[p] = sub[cl.term.id]
+			}
+			nonzero = nonzero || row[p] != 0
+		}
+		tSig[t] = C.KB_NONE
+		if nonzero {
+			key := fmt.Sprint(row)
+			i, ok := sigIdx[key]
+			if !ok {
+				i = len(sigRows)
+				sigIdx[key] = i
+				sigRows = append(sigRows, row)
+			}
+			tSig[t] = uint32(i)
+		}
+	}
+	sigW := f.i32(max1(len(sigRows)) * max1(nP))
+	for i, row := range sigRows {
+		copy(sigW[i*nP:(i+1)*nP], row)
+	}
+	clsBound, clsUnbound := f.i32(max1(nP)*N), f.i32(max1(nP)*N)
+	firstUnbound := uint32(C.KB_NONE)
+	place := func(pod *v1.Pod, n uint32, m uint64) {
+		tab := clsBound
+		if pod.Spec.NodeName == "" { // nodeorder's cachedNodeInfo resolves it to the first node holding any such pod (nodeorder.go:48-62)
+			tab = clsUnbound
+			if n < firstUnbound {
+				firstUnbound = n
+			}
+		}
+		for p := 0; p < nP; p++ {
+			if m>>uint(p)&1 == 1 {
+				tab[p*N+int(n)]++
+			}
+		}
+	}
+	for t, ti := range f.tasks {
+		if tnode[t] != C.KB_NONE {
+			place(ti.Pod, tnode[t], tClsInc[t])
+		}
+	}
+	for _, o := range others {
+		m, err := clsIncMask(o.pod)
+		if err != nil {
+			return err
+		}
+		place(o.pod, o.node, m)
+	}
+
+	// ---- the struct itself lives in C memory too (cgo pointer rules)
+	ipMem := C.calloc(1, C.size_t(unsafe.Sizeof(C.kb_interpod{})))
+	f.bufs = append(f.bufs, ipMem)
+	ip := (*C.kb_interpod)(ipMem)
+	ip.n_counters, ip.n_domains, ip.n_classes, ip.n_sigs = C.uint32_t(nC), C.uint32_t(D), C.uint32_t(nP), C.uint32_t(len(sigRows))
+	ip.first_unbound_node = C.uint32_t(firstUnbound)
+	ip.ctr_dom = (*C.uint32_t)(unsafe.Pointer(&ctrDom[0]))
+	ip.ctr_count = (*C.int32_t)(unsafe.Pointer(&ctrCount[0]))
+	ip.ctr_total = (*C.int32_t)(unsafe.Pointer(&ctrTotal[0]))
+	ip.task_inc = (*C.uint64_t)(unsafe.Pointer(&tInc[0]))
+	ip.task_forbid = (*C.uint64_t)(unsafe.Pointer(&tForbid[0]))
+	ip.task_require = (*C.uint8_t)(unsafe.Pointer(&tReq[0]))
+	ip.task_self = (*C.uint8_t)(unsafe.Pointer(&tSelf[0]))
+	ip.cls_dom = (*C.uint32_t)(unsafe.Pointer(&clsDom[0]))
+	ip.cls_bound = (*C.int32_t)(unsafe.Pointer(&clsBound[0]))
+	ip.cls_unbound = (*C.int32_t)(unsafe.Pointer(&clsUnbound[0]))
+	ip.task_cls_inc = (*C.uint64_t)(unsafe.Pointer(&tClsInc[0]))
+	ip.task_sig = (*C.uint32_t)(unsafe.Pointer(&tSig[0]))
+	ip.sig_weight = (*C.int32_t)(unsafe.Pointer(&sigW[0]))
+	f.snap.interpod = ip
+	return nil
+}
+
+func max1(n int) int {
+	if n < 1 {
+		return 1
+	}
+	return n
+}

@@ -121,6 +121,11 @@ def test_go_shim_sources_only_use_what_the_header_declares():
     flat = open(os.path.join(godir, "flatten.go")).read()
     for name, _ in abi.SNAPSHOT_ARRAYS:
         assert re.search(r"\bs\." + name + r"\b", flat), f"flatten.go never sets kb_snapshot.{name}"
+    ipgo = open(os.path.join(godir, "interpod.go")).read()
+    for name, _ in abi.Interpod._fields_:
+        if name != "pad":
+            assert re.search(r"\bip\." + name + r"\b", ipgo), f"interpod.go never sets kb_interpod.{name}"
+    assert "f.snap.interpod = ip" in ipgo and "buildInterpod(" in flat
 
 
 def test_go_shim_obeys_the_cgo_pointer_rules_statically():
