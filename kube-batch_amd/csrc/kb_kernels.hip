@@ -103,7 +103,8 @@ __device__ __forceinline__ uint32_t eval_pair(const KbDev &d, const K1Task &t, c
       uint32_t bit = t.cls * d.n_nc + n.cls;
       ok = ok && ((d.compat[bit >> 3] >> (bit & 7)) & 1);
     }
-    if (t.pad && ok) ok = interpod_ok(d, t.task, node);   // predicates.go:249-262 (rare: subject rows only)
+    if (d.t_ip_forbid != nullptr)   // uniform: sessions without inter-pod terms pay one scalar branch
+      if (t.pad && ok) ok = interpod_ok(d, t.task, node);   // predicates.go:249-262 (rare: subject rows only)
   }
   if (!ok) return 0;
   uint32_t score = 0;
@@ -578,8 +579,16 @@ void kb_launch_gather(const KbDev &d, const KbRound &r, void *stream) {
 void kb_launch_matrix(const KbDev &d, const KbRound &r, void *stream) {
   if (r.n_mrows == 0) return;
   if ((size_t)r.n_mrows * d.NP >= (4u << 20)) {
-    dim3 grid(d.NP / (256 * 4), (r.n_mrows + 31) / 32 + (r.gather ? 1 : 0));
-    hipLaunchKernelGGL((k_matrix<4, 32>), grid, dim3(256), 0, (hipStream_t)stream, d, r);
+    // <4,32> amortises a thread's node state over 32 rows and stores 8 bytes per row, but a few hundred rows (the distinct shapes of
+    // a whole session) make only ~100 such workgroups: below four per CU the one-node tile with 16 rows fills the chip instead
+    const size_t blocks = (size_t)(d.NP / (256 * 4)) * ((r.n_mrows + 31) / 32);
+    if (blocks >= 1024) {
+      dim3 grid(d.NP / (256 * 4), (r.n_mrows + 31) / 32 + (r.gather ? 1 : 0));
+      hipLaunchKernelGGL((k_matrix<4, 32>), grid, dim3(256), 0, (hipStream_t)stream, d, r);
+    } else {
+      dim3 grid(d.NP / 256, (r.n_mrows + 15) / 16 + (r.gather ? 1 : 0));
+      hipLaunchKernelGGL((k_matrix<1, 16>), grid, dim3(256), 0, (hipStream_t)stream, d, r);
+    }
   } else {
     dim3 grid(d.NP / 256, (r.n_mrows + 3) / 4 + (r.gather ? 1 : 0));
     hipLaunchKernelGGL((k_matrix<1, 4>), grid, dim3(256), 0, (hipStream_t)stream, d, r);
