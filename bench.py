@@ -197,7 +197,8 @@ def main():
             import csv
             vals = {}
             for row in csv.DictReader(open(pmc)):
-                if "k_matrix<4, 32>" in row["kernel"] or "k_expand" in row["kernel"]:
+                # the materialised-matrix launch: k_expand + the matrix kernel over the distinct shapes (any tile but the per-round <1, 4>)
+                if "k_expand" in row["kernel"] or ("k_matrix<" in row["kernel"] and "k_matrix<1, 4>" not in row["kernel"]):
                     vals[row["counter"]] = vals.get(row["counter"], 0.0) + float(row["mean_KB_per_dispatch"])
             if "FETCH_SIZE" in vals and "WRITE_SIZE" in vals:
                 roofline["traffic"] = int((2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024)
