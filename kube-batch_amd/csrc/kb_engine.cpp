@@ -288,6 +288,17 @@ void ensure_window_buffers(kb_engine *e, uint32_t rows) {
   e->h_deckind.resize(rows);
   e->win_cap = rows;
 }
+// scratch rows of the inter-pod priority kernel (per matrix row: per-node counts, per-domain sums)
+void ensure_ip_scratch(kb_engine *e, size_t rows) {
+  if (!e->hs.has_interpod) return;
+  const size_t NP = e->dev.NP;
+  if (e->b_ip_scnt.bytes < sizeof(long long) * rows * NP) {
+    e->b_ip_scnt.alloc(sizeof(long long) * rows * NP);
+    e->b_ip_shist.alloc(sizeof(int32_t) * rows * NP);
+  }
+  e->dev.ip_scratch_cnt = e->b_ip_scnt.as<long long>();
+  e->dev.ip_scratch_hist = e->b_ip_shist.as<int32_t>();
+}
 // matrix buffers: one matrix row per distinct shape (or per task row for kb_eval_matrix), L candidate keys per row
 void ensure_matrix_buffers(kb_engine *e, uint32_t mrows, uint32_t L) {
   const size_t NP = e->dev.NP;
@@ -299,13 +310,8 @@ void ensure_matrix_buffers(kb_engine *e, uint32_t mrows, uint32_t L) {
     e->h_mrows.resize(mrows);
     e->h_same.resize(mrows);
     e->mat_cap = mrows;
-    if (e->hs.has_interpod) {   // per matrix row: per-node counts and per-domain sums of the inter-pod priority kernel
-      e->b_ip_scnt.alloc(sizeof(long long) * (size_t)mrows * NP);
-      e->b_ip_shist.alloc(sizeof(int32_t) * (size_t)mrows * NP);
-      e->dev.ip_scratch_cnt = e->b_ip_scnt.as<long long>();
-      e->dev.ip_scratch_hist = e->b_ip_shist.as<int32_t>();
-    }
   }
+  ensure_ip_scratch(e, std::max<uint32_t>(mrows, e->mat_cap));
   size_t need = (size_t)mrows * L;
   if (need > e->keys_cap) {
     e->b_keys.alloc(sizeof(unsigned long long) * need);
@@ -1772,14 +1778,17 @@ static ChunkPlan matrix_plan(kb_engine *e, uint32_t t0, uint32_t n, uint32_t fit
   return p;
 }
 static void matrix_launch(kb_engine *e, const ChunkPlan &p, uint32_t n, uint32_t k) {
+  ensure_ip_scratch(e, p.direct ? n : p.ns);
   if (p.direct) {
     kb_launch_matrix(e->dev, p.r, e->stream);
     kb_launch_affinity(e->dev, p.r, e->stream);
+    kb_launch_interpod(e->dev, p.r, e->stream);
     if (k) kb_launch_argmax(e->dev, p.r, e->stream);
     return;
   }
   kb_launch_matrix(e->dev, p.rs, e->stream);
   kb_launch_affinity(e->dev, p.rs, e->stream);
+  kb_launch_interpod(e->dev, p.rs, e->stream);
   kb_launch_expand(e->dev, p.rs.score, p.rs.maskw, e->b_xslot.as<uint32_t>(), n, p.r.score, p.r.maskw, e->stream);
   if (k) kb_launch_argmax(e->dev, p.r, e->stream);
 }

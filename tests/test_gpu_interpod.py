@@ -99,3 +99,24 @@ def test_hand_derived_known_answer_on_the_device(oracle_mod, commit_kernel):
     e.run(["allocate", "backfill"])
     assert snap.bind_map(e.binds()) == {"ns/web-0": "n1", "ns/cache-0": "n1", "ns/web-1": "n2", "ns/web-2": "n3"}
     e.close()
+
+
+@pytest.mark.parametrize("seed", [1, 4, 6, 9])
+def test_matrix_with_interpod_predicate_and_priority(oracle_mod, seed):
+    """kb_eval_matrix: mask bits (predicate p8 included) and u16 scores (InterPodAffinityPriority included) of every (task, node) pair
+    against the session-open state, both fit modes; then again after the allocate action has advanced the counters"""
+    cfg, snap = interpod_case(seed)
+    assert snap.interpod is not None
+    o = oracle_mod.Oracle(cfg, snap)
+    e = engine.Engine(cfg)
+    e.load(snap)
+    for stage in range(2):
+        for fit in (1, 0):
+            em, es = e.eval_matrix(0, snap.n_tasks, fit)
+            om, os_ = o.eval_matrix(0, snap.n_tasks, fit)
+            assert np.array_equal(em, om), (seed, stage, fit)
+            assert np.array_equal(es, os_), (seed, stage, fit)
+        if stage == 0:
+            o.run(["allocate"])
+            e.run(["allocate"])
+    o.close(); e.close()
