@@ -64,7 +64,7 @@
 extern "C" {
 #endif
 
-#define KB_ABI_VERSION 6u
+#define KB_ABI_VERSION 7u
 #define KB_MAX_RES 32u          /* resource dimensions: 0 = cpu (milli), 1 = memory (bytes), 2.. = scalar resources (milli) */
 #define KB_NONE 0xFFFFFFFFu
 
@@ -145,16 +145,17 @@ typedef struct kb_config {
    of plugins/util/util.go:37-90) and nodeorder's InterPodAffinityPriority (vendor/.../priorities/interpod_affinity.go:99-235 behind
    plugins/nodeorder/nodeorder.go:48-62,156-160).  The flattener resolves namespaces, label selectors and topology keys into:
 
-   predicate COUNTERS (at most 64).  Counter c maps every node to a domain id (ctr_dom; KB_NONE: the node lacks a topology label of
+   predicate COUNTERS (at most KB_INTERPOD_MAX).  Counter c maps every node to a domain id (ctr_dom; KB_NONE: the node lacks a topology label of
    the counter) and counts, per domain, the session's pods in an allocated status (api.AllocatedStatus) that
      - own a given required anti-affinity term                     ("existing pods' anti-affinity", predicates.go:1400-1441), or
      - match ALL terms of a given set of required terms            (a pod's own affinity / anti-affinity, :1474-1575: the slow path
                                                                     ANDs the terms of one pod).
    ctr_total counts them regardless of the domain.  Per task: task_inc = counters the pod joins when ssn.Allocate places it;
-   task_forbid = counters that must be 0 in the candidate node's domain; task_require = the counter that must be positive there
-   (0xFF: none) unless ctr_total of it is 0 and task_self is set (the first-pod rule, :1550-1565).
+   task_forbid = counters that must be 0 in the candidate node's domain — bit masks of Wc = max(1, ceil(C / 64)) 64-bit words per
+   task (counter c: bit c % 64 of word c / 64); task_require = the counter that must be positive there (0xFFFF: none) unless
+   ctr_total of it is 0 and task_self is set (the first-pod rule, :1550-1565).
 
-   priority CLASSES (at most 64).  Class p maps every node to the id of its value of ONE topology key (cls_dom) and counts, per node,
+   priority CLASSES (at most KB_INTERPOD_MAX; task_cls_inc has Wp = max(1, ceil(P / 64)) words per task).  Class p maps every node to the id of its value of ONE topology key (cls_dom) and counts, per node,
    the pods in ni.Tasks that the class covers (a preferred term of the scored pod: the pods matching it; a term some pod owns -
    required affinity with hardPodAffinityWeight 1, preferred (anti)affinity with its signed weight: its owners): cls_bound for pods
    whose Spec.NodeName is set, cls_unbound for pods whose Spec.NodeName is still empty - those are looked up through nodeorder's
@@ -165,24 +166,25 @@ typedef struct kb_config {
                                    + [cls_dom[p][i] == cls_dom[p][Z]] * sum over feasible n of cls_unbound[p][n] )
      score(i) = int(10 * (count(i) - min) / (max - min)) * podaffinity.weight, min / max over the feasible nodes and 0
    (interpod_affinity.go:213-233; only the pods of the feasible nodes are seen: util/scheduler_helper.go:226-238). */
+#define KB_INTERPOD_MAX 1024u
 typedef struct kb_interpod {
-  uint32_t n_counters;           /* C <= 64 */
+  uint32_t n_counters;           /* C <= KB_INTERPOD_MAX */
   uint32_t n_domains;            /* D: every domain id of every counter is < D */
-  uint32_t n_classes;            /* P <= 64 */
+  uint32_t n_classes;            /* P <= KB_INTERPOD_MAX */
   uint32_t n_sigs;               /* S rows of sig_weight */
   uint32_t first_unbound_node;   /* Z at session open, KB_NONE: no pod with an empty Spec.NodeName sits on a node */
   uint32_t pad;
   const uint32_t *ctr_dom;       /* [C][N] */
   const int32_t  *ctr_count;     /* [C][D] */
   const int32_t  *ctr_total;     /* [C] */
-  const uint64_t *task_inc;      /* [T] */
-  const uint64_t *task_forbid;   /* [T] */
-  const uint8_t  *task_require;  /* [T] */
+  const uint64_t *task_inc;      /* [T][Wc] */
+  const uint64_t *task_forbid;   /* [T][Wc] */
+  const uint16_t *task_require;  /* [T] */
   const uint8_t  *task_self;     /* [T] */
   const uint32_t *cls_dom;       /* [P][N] */
   const int32_t  *cls_bound;     /* [P][N] */
   const int32_t  *cls_unbound;   /* [P][N] */
-  const uint64_t *task_cls_inc;  /* [T] */
+  const uint64_t *task_cls_inc;  /* [T][Wp] */
   const uint32_t *task_sig;      /* [T] */
   const int32_t  *sig_weight;    /* [S][P] */
 } kb_interpod;

@@ -72,6 +72,11 @@ func (f *flat) i32(n int) []int32 {
 	f.bufs = append(f.bufs, p)
 	return (*[1 << 30]int32)(p)[:n:n]
 }
+func (f *flat) u16(n int) []uint16 {
+	p := C.calloc(C.size_t(n+1), 2)
+	f.bufs = append(f.bufs, p)
+	return (*[1 << 30]uint16)(p)[:n:n]
+}
 func (f *flat) u8(n int) []uint8 {
 	p := C.calloc(C.size_t(n+1), 1)
 	f.bufs = append(f.bufs, p)

@@ -283,9 +283,10 @@ func (f *flat) buildInterpod(tnode []uint32, tstatus []uint8) error {
 		}
 	}
 	nC := len(counters)
-	if nC > 64 {
-		return errUnsupported("more than 64 distinct inter-pod predicate counters")
+	if nC > C.KB_INTERPOD_MAX {
+		return errUnsupported("too many distinct inter-pod predicate counters")
 	}
+	Wc := (max1(nC) + 63) / 64 // 64-bit words per task mask: counter c is bit c%64 of word c/64
 	ctrDom := f.u32(max1(nC) * N)
 	D := 1
 	for c := range counters {
@@ -297,8 +298,18 @@ func (f *flat) buildInterpod(tnode []uint32, tstatus []uint8) error {
 			D = d
 		}
 	}
-	tInc, tForbid := f.u64(T), f.u64(T)
-	tReq, tSelf := f.u8(T), f.u8(T)
+	tInc, tForbid := f.u64(T*Wc), f.u64(T*Wc)
+	tReq, tSelf := f.u16(T), f.u8(T)
+	setBit := func(m []uint64, W, t, bit int) { m[t*W+bit/64] |= 1 << uint(bit%64) }
+	hasBit := func(m []uint64, W, t, bit int) bool { return m[t*W+bit/64]>>uint(bit%64)&1 == 1 }
+	anyBit := func(m []uint64, W, t int) bool {
+		for w := 0; w < W; w++ {
+			if m[t*W+w] != 0 {
+				return true
+			}
+		}
+		return false
+	}
 	for t, ti := range f.tasks {
 		pod := ti.Pod
 		ra, rn, _, _ := podAffinityOf(pod)
@@ -311,10 +322,10 @@ func (f *flat) buildInterpod(tnode []uint32, tstatus []uint8) error {
 			ctr := counters[c]
 			if !ctr.group {
 				if ownA[id] {
-					tInc[t] |= 1 << uint(c)
+					setBit(tInc, Wc, t, c)
 				}
 				if ctr.terms[0].matches(pod) {
-					tForbid[t] |= 1 << uint(c)
+					setBit(tForbid, Wc, t, c)
 				}
 				continue
 			}
@@ -323,17 +334,17 @@ func (f *flat) buildInterpod(tnode []uint32, tstatus []uint8) error {
 				all = all && tp.matches(pod)
 			}
 			if all {
-				tInc[t] |= 1 << uint(c)
+				setBit(tInc, Wc, t, c)
 			}
 		}
-		tReq[t] = 0xFF
+		tReq[t] = 0xFFFF
 		if len(rn) > 0 {
 			id, _, _ := groupOf(pod, rn)
-			tForbid[t] |= 1 << uint(counterIdx[id])
+			setBit(tForbid, Wc, t, counterIdx[id])
 		}
 		if len(ra) > 0 {
 			id, tps, _ := groupOf(pod, ra)
-			tReq[t] = uint8(counterIdx[id])
+			tReq[t] = uint16(counterIdx[id])
 			self := true // targetPodMatchesAffinityOfPod(pod, pod) (predicates/metadata.go:767-778)
 			for _, tp := range tps {
 				self = self && tp.matches(pod)
@@ -350,14 +361,14 @@ func (f *flat) buildInterpod(tnode []uint32, tstatus []uint8) error {
 			continue
 		}
 		if tnode[t] == C.KB_NONE {
-			if tInc[t] != 0 {
+			if anyBit(tInc, Wc, t) {
 				// PodLister lists it under its NodeName although no ni.Tasks holds it; nodeInfo.Filter then hides it from that one node only
 				return errUnsupported("an allocated-status task outside every ni.Tasks takes part in inter-pod affinity")
 			}
 			continue
 		}
 		for c := 0; c < nC; c++ {
-			if tInc[t]>>uint(c)&1 == 1 {
+			if hasBit(tInc, Wc, t, c) {
 				ctrTotal[c]++
 				if d := ctrDom[c*N+int(tnode[t])]; d != C.KB_NONE {
 					ctrCount[c*D+int(d)]++
@@ -413,31 +424,32 @@ func (f *flat) buildInterpod(tnode []uint32, tstatus []uint8) error {
 		}
 	}
 	nP := len(classes)
-	if nP > 64 {
-		return errUnsupported("more than 64 distinct inter-pod priority classes")
+	if nP > C.KB_INTERPOD_MAX {
+		return errUnsupported("too many distinct inter-pod priority classes")
 	}
+	Wp := (max1(nP) + 63) / 64
 	clsDom := f.u32(max1(nP) * N)
 	for p := range classes {
 		domainRow(clsDom[p*N:(p+1)*N], f.nodes, []string{classes[p].term.key})
 	}
-	clsIncMask := func(pod *v1.Pod) (uint64, error) {
+	clsIncMask := func(pod *v1.Pod) ([]uint64, error) { // Wp words
 		own, _, err := ownedTerms(pod)
 		if err != nil {
-			return 0, err
+			return nil, err
 		}
-		var m uint64
+		m := make([]uint64, Wp)
 		for p, cl := range classes {
 			if cl.owned {
 				if w, ok := own[cl.term.id]; ok && w == cl.weight {
-					m |= 1 << uint(p)
+					m[p/64] |= 1 << uint(p%64)
 				}
 			} else if cl.term.matches(pod) {
-				m |= 1 << uint(p)
+				m[p/64] |= 1 << uint(p%64)
 			}
 		}
 		return m, nil
 	}
-	tClsInc, tSig := f.u64(T), f.u32(T)
+	tClsInc, tSig := f.u64(T*Wp), f.u32(T)
 	sigIdx := map[string]int{}
 	var sigRows [][]int32
 	for t, ti := range f.tasks {
@@ -445,7 +457,7 @@ func (f *flat) buildInterpod(tnode []uint32, tstatus []uint8) error {
 		if err != nil {
 			return err
 		}
-		tClsInc[t] = m
+		copy(tClsInc[t*Wp:(t+1)*Wp], m)
 		sub, _, _ := subjectTerms(ti.Pod)
 		row := make([]int32, nP)
 		nonzero := false
@@ -477,7 +489,7 @@ func (f *flat) buildInterpod(tnode []uint32, tstatus []uint8) error {
 	}
 	clsBound, clsUnbound := f.i32(max1(nP)*N), f.i32(max1(nP)*N)
 	firstUnbound := uint32(C.KB_NONE)
-	place := func(pod *v1.Pod, n uint32, m uint64) {
+	place := func(pod *v1.Pod, n uint32, m []uint64) {
 		tab := clsBound
 		if pod.Spec.NodeName == "" { // nodeorder's cachedNodeInfo resolves it to the first node holding any such pod (nodeorder.go:48-62)
 			tab = clsUnbound
@@ -486,14 +498,14 @@ func (f *flat) buildInterpod(tnode []uint32, tstatus []uint8) error {
 			}
 		}
 		for p := 0; p < nP; p++ {
-			if m>>uint(p)&1 == 1 {
+			if m[p/64]>>uint(p%64)&1 == 1 {
 				tab[p*N+int(n)]++
 			}
 		}
 	}
 	for t, ti := range f.tasks {
 		if tnode[t] != C.KB_NONE {
-			place(ti.Pod, tnode[t], tClsInc[t])
+			place(ti.Pod, tnode[t], tClsInc[t*Wp:(t+1)*Wp])
 		}
 	}
 	for _, o := range others {
@@ -515,7 +527,7 @@ func (f *flat) buildInterpod(tnode []uint32, tstatus []uint8) error {
 	ip.ctr_total = (*C.int32_t)(unsafe.Pointer(&ctrTotal[0]))
 	ip.task_inc = (*C.uint64_t)(unsafe.Pointer(&tInc[0]))
 	ip.task_forbid = (*C.uint64_t)(unsafe.Pointer(&tForbid[0]))
-	ip.task_require = (*C.uint8_t)(unsafe.Pointer(&tReq[0]))
+	ip.task_require = (*C.uint16_t)(unsafe.Pointer(&tReq[0]))
 	ip.task_self = (*C.uint8_t)(unsafe.Pointer(&tSelf[0]))
 	ip.cls_dom = (*C.uint32_t)(unsafe.Pointer(&clsDom[0]))
 	ip.cls_bound = (*C.int32_t)(unsafe.Pointer(&clsBound[0]))

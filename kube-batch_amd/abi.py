@@ -5,7 +5,7 @@ Only plain C types cross the boundary; the same structs are what the Go shim fil
 """
 import ctypes as C
 
-KB_ABI_VERSION = 6
+KB_ABI_VERSION = 7
 KB_MAX_RES = 32
 KB_NONE = 0xFFFFFFFF
 
@@ -79,7 +79,7 @@ SNAPSHOT_ARRAYS = [
 # kb_interpod: inter-pod (anti)affinity tables (predicate p8 + nodeorder's InterPodAffinityPriority), NULL when no pod has a term
 INTERPOD_ARRAYS = [
     ("ctr_dom", C.c_uint32), ("ctr_count", C.c_int32), ("ctr_total", C.c_int32),
-    ("task_inc", C.c_uint64), ("task_forbid", C.c_uint64), ("task_require", C.c_uint8), ("task_self", C.c_uint8),
+    ("task_inc", C.c_uint64), ("task_forbid", C.c_uint64), ("task_require", C.c_uint16), ("task_self", C.c_uint8),
     ("cls_dom", C.c_uint32), ("cls_bound", C.c_int32), ("cls_unbound", C.c_int32),
     ("task_cls_inc", C.c_uint64), ("task_sig", C.c_uint32), ("sig_weight", C.c_int32),
 ]

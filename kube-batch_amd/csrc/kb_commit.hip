@@ -642,23 +642,26 @@ __global__ void __launch_bounds__(K9_THREADS) k_commit_run(const K9KernArgs ka) 
       d.t_counted[t] = 1;
       if (!kind) d.j_allocated[d.t_job[t]] = 1;   // ssn.Allocate ran for the job: its Allocated tasks are dispatched if it is ready
       if (d.t_ip_cls_inc) {   // inter-pod affinity: the pod joins ni.Tasks of its node and, when Allocated, the PodLister's allocated set
-        unsigned long long cm = d.t_ip_cls_inc[t];
-        while (cm) {
-          const uint32_t pcl = (uint32_t)__ffsll((unsigned long long)cm) - 1u;
-          cm &= cm - 1ull;
-          atomicAdd(&d.ip_cls_unbound[(size_t)pcl * d.NP + n], 1);
-        }
-        atomicMin(d.ip_z, n);
-        if (!kind) {
-          unsigned long long im = d.t_ip_inc[t];
-          while (im) {
-            const uint32_t c = (uint32_t)__ffsll((unsigned long long)im) - 1u;
-            im &= im - 1ull;
-            atomicAdd(&d.ip_ctr_total[c], 1);
-            const uint32_t dm = d.ip_ctr_dom[(size_t)c * d.NP + n];
-            if (dm != KB_NONE_U32) atomicAdd(&d.ip_ctr_count[(size_t)c * d.ip_D + dm], 1);
+        for (uint32_t w = 0; w < d.ip_Wp; w++) {
+          unsigned long long cm = d.t_ip_cls_inc[(size_t)t * d.ip_Wp + w];
+          while (cm) {
+            const uint32_t pcl = 64u * w + (uint32_t)__ffsll((unsigned long long)cm) - 1u;
+            cm &= cm - 1ull;
+            atomicAdd(&d.ip_cls_unbound[(size_t)pcl * d.NP + n], 1);
           }
         }
+        atomicMin(d.ip_z, n);
+        if (!kind)
+          for (uint32_t w = 0; w < d.ip_Wc; w++) {
+            unsigned long long im = d.t_ip_inc[(size_t)t * d.ip_Wc + w];
+            while (im) {
+              const uint32_t c = 64u * w + (uint32_t)__ffsll((unsigned long long)im) - 1u;
+              im &= im - 1ull;
+              atomicAdd(&d.ip_ctr_total[c], 1);
+              const uint32_t dm = d.ip_ctr_dom[(size_t)c * d.NP + n];
+              if (dm != KB_NONE_U32) atomicAdd(&d.ip_ctr_count[(size_t)c * d.ip_D + dm], 1);
+            }
+          }
       }
       if (a.has_delta && i >= r.own_row0 && i < r.own_row1) {
         double res0 = k.init0, res1 = k.init1;

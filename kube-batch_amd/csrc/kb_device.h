@@ -72,18 +72,19 @@ struct KbDev {
   const uint32_t *ip_ctr_dom;     // [C][NP] domain of the node for predicate counter c (KB_NONE_U32: label missing)
   int32_t *ip_ctr_count;          // [C][D] allocated-status pods per domain (live)
   int32_t *ip_ctr_total;          // [C] (live)
-  const unsigned long long *t_ip_inc, *t_ip_forbid;   // [T]
-  const uint8_t *t_ip_req, *t_ip_self, *t_ip_subject; // [T]
+  const unsigned long long *t_ip_inc, *t_ip_forbid;   // [T][ip_Wc] 64-bit words: counter c is bit c % 64 of word c / 64
+  const uint16_t *t_ip_req;                           // [T] counter that must be positive (0xFFFF: none)
+  const uint8_t *t_ip_self, *t_ip_subject, *t_ip_checks;   // [T]; checks: the task has forbid bits or a required counter
   const uint32_t *ip_cls_dom;     // [P][NP]
   const int32_t *ip_cls_bound;    // [P][NP]
   int32_t *ip_cls_unbound;        // [P][NP] (live)
-  const unsigned long long *t_ip_cls_inc;   // [T]
+  const unsigned long long *t_ip_cls_inc;   // [T][ip_Wp]
   const uint32_t *t_ip_sig;       // [T]
   const int32_t *ip_sig_w;        // [S][P]
   uint32_t *ip_z;                 // [1] first node (ascending) holding a pod with an empty Spec.NodeName (live)
   long long *ip_scratch_cnt;      // [matrix rows][NP] per-node counts of the priority kernel
   int32_t *ip_scratch_hist;       // [matrix rows][NP] per-domain sums of the priority kernel
-  uint32_t ip_C, ip_D, ip_P;
+  uint32_t ip_C, ip_D, ip_P, ip_Wc, ip_Wp;
   int wPA;
 };
 

@@ -147,7 +147,7 @@ struct kb_engine {
   DevBuf b_tinit, b_tres, b_tnzc, b_tnzm, b_tcls, b_tactive, b_tresmask, b_tjob, b_tstatus, b_tnode, b_tbind, b_tcounted, b_jallocated, b_compat, b_crows, b_aff, b_affcls;
   DevBuf p_idle, p_rel, p_nzc, p_nzm, p_podcnt, p_tstatus, p_tnode, p_tcounted, p_ports;   // pristine copies for kb_session_reset
   // inter-pod (anti)affinity tables (kb_interpod) and the pristine copies of their live parts
-  DevBuf b_ip_cdom, b_ip_ccnt, b_ip_ctot, b_ip_tinc, b_ip_tforbid, b_ip_treq, b_ip_tself, b_ip_tsubj, b_ip_pdom, b_ip_pbound, b_ip_punb, b_ip_tcinc,
+  DevBuf b_ip_cdom, b_ip_ccnt, b_ip_ctot, b_ip_tinc, b_ip_tforbid, b_ip_treq, b_ip_tself, b_ip_tsubj, b_ip_tchk, b_ip_pdom, b_ip_pbound, b_ip_punb, b_ip_tcinc,
       b_ip_tsig, b_ip_sigw, b_ip_z, b_ip_scnt, b_ip_shist, p_ip_ccnt, p_ip_ctot, p_ip_punb, p_ip_z;
   DevBuf b_ports, b_twant, b_tconf;   // host ports (only when the snapshot carries any)
   DevBuf b_jbegin, b_jmin, b_jqueue, b_total, b_deserved, b_desmask, b_jalloc, b_jshare, b_qalloc, b_qshare, b_jready;
@@ -1057,13 +1057,21 @@ int kb_session_load(kb_engine *e, const kb_snapshot *sn) {
     // inter-pod (anti)affinity tables: validate what indexes device memory
     const kb_interpod *ip = sn->interpod;
     if (ip) {
-      if (ip->n_counters > 64 || ip->n_classes > 64) throw EngineError(KB_E_UNSUPPORTED, "more than 64 inter-pod counters / classes");
+      if (ip->n_counters > KB_INTERPOD_MAX || ip->n_classes > KB_INTERPOD_MAX) throw EngineError(KB_E_UNSUPPORTED, "more than KB_INTERPOD_MAX inter-pod counters / classes");
+      const uint32_t Wc = ip->n_counters ? (ip->n_counters + 63) / 64 : 1, Wp = ip->n_classes ? (ip->n_classes + 63) / 64 : 1;
       if (ip->n_domains == 0 || ip->n_domains > std::max<uint32_t>(N, 1u)) throw EngineError(KB_E_INVALID, "inter-pod: n_domains outside 1..N");
       if (!ip->ctr_dom || !ip->ctr_count || !ip->ctr_total || !ip->task_inc || !ip->task_forbid || !ip->task_require || !ip->task_self ||
           !ip->cls_dom || !ip->cls_bound || !ip->cls_unbound || !ip->task_cls_inc || !ip->task_sig || !ip->sig_weight)
         throw EngineError(KB_E_INVALID, "inter-pod: missing table");
       if (ip->first_unbound_node != KB_NONE && ip->first_unbound_node >= N) throw EngineError(KB_E_INVALID, "inter-pod: first_unbound_node out of range");
-      const uint64_t cmask = ip->n_counters == 64 ? ~0ull : ((1ull << ip->n_counters) - 1ull), pmask = ip->n_classes == 64 ? ~0ull : ((1ull << ip->n_classes) - 1ull);
+      auto beyond = [](const uint64_t *row, uint32_t W, uint32_t nbits) {   // a mask bit at or beyond nbits
+        for (uint32_t w = 0; w < W; w++) {
+          const uint32_t lo = 64 * w;
+          const uint64_t valid = nbits <= lo ? 0ull : (nbits - lo >= 64 ? ~0ull : ((1ull << (nbits - lo)) - 1ull));
+          if (row[w] & ~valid) return true;
+        }
+        return false;
+      };
       for (uint32_t c = 0; c < ip->n_counters; c++)
         for (uint32_t n = 0; n < N; n++) {
           const uint32_t dm = ip->ctr_dom[(size_t)c * N + n];
@@ -1079,8 +1087,10 @@ int kb_session_load(kb_engine *e, const kb_snapshot *sn) {
       for (uint32_t i = 0; i < ip->n_sigs * ip->n_classes; i++) wsum = std::max<long long>(wsum, std::llabs((long long)ip->sig_weight[i]));
       if (wsum > 1000000) throw EngineError(KB_E_UNSUPPORTED, "inter-pod: term weight beyond 1e6");
       for (uint32_t t = 0; t < T; t++) {
-        if ((ip->task_inc[t] & ~cmask) || (ip->task_forbid[t] & ~cmask) || (ip->task_cls_inc[t] & ~pmask)) throw EngineError(KB_E_INVALID, "inter-pod: mask names a missing counter / class");
-        if (ip->task_require[t] != 0xFF && ip->task_require[t] >= ip->n_counters) throw EngineError(KB_E_INVALID, "inter-pod: task_require out of range");
+        if (beyond(ip->task_inc + (size_t)t * Wc, Wc, ip->n_counters) || beyond(ip->task_forbid + (size_t)t * Wc, Wc, ip->n_counters) ||
+            beyond(ip->task_cls_inc + (size_t)t * Wp, Wp, ip->n_classes))
+          throw EngineError(KB_E_INVALID, "inter-pod: mask names a missing counter / class");
+        if (ip->task_require[t] != 0xFFFF && ip->task_require[t] >= ip->n_counters) throw EngineError(KB_E_INVALID, "inter-pod: task_require out of range");
         if (ip->task_sig[t] != KB_NONE && ip->task_sig[t] >= ip->n_sigs) throw EngineError(KB_E_INVALID, "inter-pod: task_sig out of range");
       }
       if (e->pol.nodeorder_enabled && (e->pol.wPA < 0 || 10ll * ((long long)e->pol.wL + e->pol.wM + e->pol.wB + e->pol.wNA + e->pol.wPA) > 65535))
@@ -1118,9 +1128,12 @@ int kb_session_load(kb_engine *e, const kb_snapshot *sn) {
         const uint64_t conf = sn->task_port_conflict ? sn->task_port_conflict[t] : 0, want = sn->task_port_want ? sn->task_port_want[t] : 0;
         key.push_back((double)(uint32_t)(conf & 0xFFFFFFFFu)); key.push_back((double)(uint32_t)(conf >> 32));
         if (ip) {   // inter-pod predicate checks are part of feasibility
-          const uint64_t fb = ip->task_forbid[t];
-          key.push_back((double)(uint32_t)(fb & 0xFFFFFFFFu)); key.push_back((double)(uint32_t)(fb >> 32));
-          key.push_back((double)ip->task_require[t]); key.push_back((double)(ip->task_require[t] != 0xFF ? ip->task_self[t] : 0));
+          const uint32_t Wc = ip->n_counters ? (ip->n_counters + 63) / 64 : 1;
+          for (uint32_t w = 0; w < Wc; w++) {
+            const uint64_t fb = ip->task_forbid[(size_t)t * Wc + w];
+            key.push_back((double)(uint32_t)(fb & 0xFFFFFFFFu)); key.push_back((double)(uint32_t)(fb >> 32));
+          }
+          key.push_back((double)ip->task_require[t]); key.push_back((double)(ip->task_require[t] != 0xFFFF ? ip->task_self[t] : 0));
         }
         hs.t_feas_shape[t] = feas_ids.intern(key);
         key.push_back((double)(uint32_t)(want & 0xFFFFFFFFu)); key.push_back((double)(uint32_t)(want >> 32));
@@ -1144,14 +1157,21 @@ int kb_session_load(kb_engine *e, const kb_snapshot *sn) {
       hs.feas_ip_require.assign(hs.n_feas_shapes, 0);
       hs.feas_ip.assign(hs.n_feas_shapes, 0);
       Interner ipk;
-      std::vector<double> k3(4);
+      const uint32_t Wc = ip->n_counters ? (ip->n_counters + 63) / 64 : 1;
+      std::vector<double> k3(2 * Wc + 2);
+      hs.t_ip_checks.assign(T, 0);
       for (uint32_t t = 0; t < T; t++) {
-        const bool checks = ip->task_forbid[t] != 0 || ip->task_require[t] != 0xFF;
+        bool checks = ip->task_require[t] != 0xFFFF;
+        for (uint32_t w = 0; w < Wc; w++) {
+          const uint64_t fb = ip->task_forbid[(size_t)t * Wc + w];
+          checks = checks || fb != 0;
+          k3[2 * w] = (double)(uint32_t)(fb & 0xFFFFFFFFu); k3[2 * w + 1] = (double)(uint32_t)(fb >> 32);
+        }
+        hs.t_ip_checks[t] = checks ? 1 : 0;
         hs.t_ip_subject[t] = (checks || ip->task_sig[t] != KB_NONE) ? 1 : 0;
         const uint32_t f = hs.t_feas_shape[t];
-        hs.feas_ip_require[f] = ip->task_require[t] != 0xFF ? 1 : 0;
-        k3[0] = (double)(uint32_t)(ip->task_forbid[t] & 0xFFFFFFFFu); k3[1] = (double)(uint32_t)(ip->task_forbid[t] >> 32);
-        k3[2] = (double)ip->task_require[t]; k3[3] = (double)(ip->task_require[t] != 0xFF ? ip->task_self[t] : 0);
+        hs.feas_ip_require[f] = ip->task_require[t] != 0xFFFF ? 1 : 0;
+        k3[2 * Wc] = (double)ip->task_require[t]; k3[2 * Wc + 1] = (double)(ip->task_require[t] != 0xFFFF ? ip->task_self[t] : 0);
         hs.feas_ip[f] = ipk.intern(k3);
       }
     }
@@ -1391,9 +1411,10 @@ int kb_session_load(kb_engine *e, const kb_snapshot *sn) {
     d.ip_ctr_dom = nullptr; d.ip_ctr_count = nullptr; d.ip_ctr_total = nullptr; d.t_ip_inc = nullptr; d.t_ip_forbid = nullptr;
     d.t_ip_req = nullptr; d.t_ip_self = nullptr; d.t_ip_subject = nullptr; d.ip_cls_dom = nullptr; d.ip_cls_bound = nullptr;
     d.ip_cls_unbound = nullptr; d.t_ip_cls_inc = nullptr; d.t_ip_sig = nullptr; d.ip_sig_w = nullptr; d.ip_z = nullptr;
-    d.ip_scratch_cnt = nullptr; d.ip_scratch_hist = nullptr; d.ip_C = d.ip_D = d.ip_P = 0; d.wPA = e->pol.wPA;
+    d.ip_scratch_cnt = nullptr; d.ip_scratch_hist = nullptr; d.ip_C = d.ip_D = d.ip_P = 0; d.ip_Wc = d.ip_Wp = 1; d.wPA = e->pol.wPA; d.t_ip_checks = nullptr;
     if (ip) {
       const uint32_t C = ip->n_counters, P = ip->n_classes, D = ip->n_domains;
+      const uint32_t Wc = C ? (C + 63) / 64 : 1, Wp = P ? (P + 63) / 64 : 1;
       auto pad_u32 = [&](DevBuf &b, const uint32_t *src, uint32_t rows) {   // [rows][N] -> [rows][NP], padding KB_NONE
         std::vector<uint32_t> tmp((size_t)std::max(rows, 1u) * NP, KB_NONE);
         for (uint32_t r0 = 0; r0 < rows; r0++) std::memcpy(&tmp[(size_t)r0 * NP], src + (size_t)r0 * N, sizeof(uint32_t) * N);
@@ -1414,12 +1435,13 @@ int kb_session_load(kb_engine *e, const kb_snapshot *sn) {
       if (C) { std::memcpy(cc.data(), ip->ctr_count, sizeof(int32_t) * (size_t)C * D); std::memcpy(ct.data(), ip->ctr_total, sizeof(int32_t) * C); }
       upload(e->b_ip_ccnt, cc.data(), cc.size(), s);
       upload(e->b_ip_ctot, ct.data(), ct.size(), s);
-      upload(e->b_ip_tinc, ip->task_inc, T, s);
-      upload(e->b_ip_tforbid, ip->task_forbid, T, s);
+      upload(e->b_ip_tinc, ip->task_inc, (size_t)T * Wc, s);
+      upload(e->b_ip_tforbid, ip->task_forbid, (size_t)T * Wc, s);
+      upload(e->b_ip_tchk, hs.t_ip_checks.data(), T, s);
       upload(e->b_ip_treq, ip->task_require, T, s);
       upload(e->b_ip_tself, ip->task_self, T, s);
       upload(e->b_ip_tsubj, hs.t_ip_subject.data(), T, s);
-      upload(e->b_ip_tcinc, ip->task_cls_inc, T, s);
+      upload(e->b_ip_tcinc, ip->task_cls_inc, (size_t)T * Wp, s);
       upload(e->b_ip_tsig, ip->task_sig, T, s);
       std::vector<int32_t> sw((size_t)std::max(ip->n_sigs, 1u) * std::max(P, 1u), 0);
       if (ip->n_sigs && P) std::memcpy(sw.data(), ip->sig_weight, sizeof(int32_t) * (size_t)ip->n_sigs * P);
@@ -1429,11 +1451,12 @@ int kb_session_load(kb_engine *e, const kb_snapshot *sn) {
       HIP_OK(hipStreamSynchronize(s));
       d.ip_ctr_dom = e->b_ip_cdom.as<uint32_t>(); d.ip_ctr_count = e->b_ip_ccnt.as<int32_t>(); d.ip_ctr_total = e->b_ip_ctot.as<int32_t>();
       d.t_ip_inc = e->b_ip_tinc.as<unsigned long long>(); d.t_ip_forbid = e->b_ip_tforbid.as<unsigned long long>();
-      d.t_ip_req = e->b_ip_treq.as<uint8_t>(); d.t_ip_self = e->b_ip_tself.as<uint8_t>(); d.t_ip_subject = e->b_ip_tsubj.as<uint8_t>();
+      d.t_ip_req = e->b_ip_treq.as<uint16_t>(); d.t_ip_self = e->b_ip_tself.as<uint8_t>(); d.t_ip_subject = e->b_ip_tsubj.as<uint8_t>();
+      d.t_ip_checks = e->b_ip_tchk.as<uint8_t>();
       d.ip_cls_dom = e->b_ip_pdom.as<uint32_t>(); d.ip_cls_bound = e->b_ip_pbound.as<int32_t>(); d.ip_cls_unbound = e->b_ip_punb.as<int32_t>();
       d.t_ip_cls_inc = e->b_ip_tcinc.as<unsigned long long>(); d.t_ip_sig = e->b_ip_tsig.as<uint32_t>(); d.ip_sig_w = e->b_ip_sigw.as<int32_t>();
       d.ip_z = e->b_ip_z.as<uint32_t>();
-      d.ip_C = C; d.ip_D = D; d.ip_P = P;
+      d.ip_C = C; d.ip_D = D; d.ip_P = P; d.ip_Wc = Wc; d.ip_Wp = Wp;
     }
     upload(e->b_jbegin, hs.job_begin.data(), J + 1, s);
     upload(e->b_jmin, hs.job_min.data(), J, s);

@@ -172,6 +172,7 @@ struct HostSession {
   // window; a shape whose affinity REQUIRES a positive count can become feasible again (counts only grow): never marked dead
   bool has_interpod = false;
   std::vector<uint8_t> t_ip_subject;       // [T] (empty: no inter-pod affinity in the session)
+  std::vector<uint8_t> t_ip_checks;        // [T] the task has predicate checks (forbid bits or a required counter)
   std::vector<uint8_t> feas_ip_require;    // [n_feas_shapes]
   std::vector<uint32_t> feas_ip;           // [n_feas_shapes] id of the shape's (forbid, require, self) triple: dominance needs equality
   // plugin state

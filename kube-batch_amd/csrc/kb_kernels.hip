@@ -46,22 +46,24 @@ __device__ __forceinline__ K1Task k1_task(const KbDev &d, uint32_t t) {
   K1Task k;
   k.init0 = v.init0; k.init1 = v.init1; k.nzc = (double)v.nzc; k.nzm = (double)v.nzm;
   k.cls = v.cls; k.active = v.active; k.task = v.task; k.conf = v.conf;
-  k.pad = (d.t_ip_forbid && (d.t_ip_forbid[t] != 0ull || d.t_ip_req[t] != 0xFF)) ? 1u : 0u;   // the pod has inter-pod predicate checks
+  k.pad = (d.t_ip_checks && d.t_ip_checks[t]) ? 1u : 0u;   // the pod has inter-pod predicate checks
   return k;
 }
 // PodAffinityChecker.InterPodAffinityMatches (vendor/.../algorithm/predicates/predicates.go:1261-1290, meta == nil) on the kb_interpod
 // counters: a positive count in the node's domain forbids (existing pods' anti-affinity :1400-1441, the pod's own :1535-1543) or is
 // required (the pod's own affinity, unless no pod matches at all and the pod matches its own terms: :1519-1566)
 __device__ __forceinline__ bool interpod_ok(const KbDev &d, uint32_t t, uint32_t node) {
-  unsigned long long fb = d.t_ip_forbid[t];
-  while (fb) {
-    const uint32_t c = (uint32_t)__ffsll((unsigned long long)fb) - 1u;
-    fb &= fb - 1ull;
-    const uint32_t dom = d.ip_ctr_dom[(size_t)c * d.NP + node];
-    if (dom != KB_NONE_U32 && d.ip_ctr_count[(size_t)c * d.ip_D + dom] > 0) return false;
+  for (uint32_t w = 0; w < d.ip_Wc; w++) {
+    unsigned long long fb = d.t_ip_forbid[(size_t)t * d.ip_Wc + w];
+    while (fb) {
+      const uint32_t c = 64u * w + (uint32_t)__ffsll((unsigned long long)fb) - 1u;
+      fb &= fb - 1ull;
+      const uint32_t dom = d.ip_ctr_dom[(size_t)c * d.NP + node];
+      if (dom != KB_NONE_U32 && d.ip_ctr_count[(size_t)c * d.ip_D + dom] > 0) return false;
+    }
   }
   const uint32_t r = d.t_ip_req[t];
-  if (r != 0xFFu) {
+  if (r != 0xFFFFu) {
     const uint32_t dom = d.ip_ctr_dom[(size_t)r * d.NP + node];
     if (!(dom != KB_NONE_U32 && d.ip_ctr_count[(size_t)r * d.ip_D + dom] > 0))
       if (d.ip_ctr_total[r] > 0 || !d.t_ip_self[t]) return false;

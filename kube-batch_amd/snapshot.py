@@ -259,6 +259,9 @@ def _node_selector_terms_match(terms, labels: Dict[str, str], node_name: str) ->
 # ------------------------------------------------------------------------------------------------
 # inter-pod (anti)affinity: predicate p8 and nodeorder's InterPodAffinityPriority
 # ------------------------------------------------------------------------------------------------
+IP_MAX = 1024        # inter-pod predicate counters / priority classes per session (include/kb_engine.h: KB_INTERPOD_MAX)
+
+
 class UnsupportedSnapshot(ValueError):
     """the session is outside the engine's envelope: the Go action hands the cycle to the stock action"""
 
@@ -353,8 +356,8 @@ def build_interpod(nodes, session_pods, other_pods_on_nodes, task_node, task_sta
                     raise UnsupportedSnapshot("required pod (anti)affinity term with an empty topologyKey")
                 counter(group_key(p, terms))
     C = len(counters)
-    if C > 64:
-        raise UnsupportedSnapshot("more than 64 distinct inter-pod predicate counters in one session")
+    if C > IP_MAX:
+        raise UnsupportedSnapshot(f"more than {IP_MAX} distinct inter-pod predicate counters in one session")
     ckeys = sorted(counters, key=lambda k: counters[k])
 
     def domain_table(keys_of):
@@ -375,8 +378,9 @@ def build_interpod(nodes, session_pods, other_pods_on_nodes, task_node, task_sta
         return (k[3],) if k[0] == "A" else tuple(t[2] for t in k[1])
 
     ctr_dom, D = domain_table([counter_topology(k) for k in ckeys])
-    t_inc = np.zeros(T, np.uint64); t_forbid = np.zeros(T, np.uint64)
-    t_req = np.full(T, 0xFF, np.uint8); t_self = np.zeros(T, np.uint8)
+    Wc, = (max(1, (C + 63) // 64),)           # 64-bit words per task mask: counter c is bit c % 64 of word c // 64
+    t_inc = [0] * T; t_forbid = [0] * T        # Python integers here, split into words at the end
+    t_req = np.full(T, 0xFFFF, np.uint16); t_self = np.zeros(T, np.uint8)
     for t, p in enumerate(session_pods):
         inc = forbid = 0
         own_a = {("A",) + _term_props(p, term) for term in p.pod_anti_affinity_required}
@@ -400,13 +404,13 @@ def build_interpod(nodes, session_pods, other_pods_on_nodes, task_node, task_sta
         if int(task_status[t]) not in allocated:
             continue
         if int(task_node[t]) == KB_NONE:
-            if int(t_inc[t]):
+            if t_inc[t]:
                 # PodLister lists it under its NodeName although no ni.Tasks holds it: nodeInfo.Filter then hides it from that one
                 # node only (predicates.go:1410-1413) -- not modelled
                 raise UnsupportedSnapshot("an allocated-status task outside every ni.Tasks takes part in inter-pod affinity")
             continue
         for c in range(C):
-            if (int(t_inc[t]) >> c) & 1:
+            if (t_inc[t] >> c) & 1:
                 ctr_total[c] += 1
                 d = ctr_dom[c, int(task_node[t])]
                 if d != KB_NONE:
@@ -448,8 +452,8 @@ def build_interpod(nodes, session_pods, other_pods_on_nodes, task_node, task_sta
         for k in subject_terms(p):
             klass(("S",) + k)
     P = len(classes)
-    if P > 64:
-        raise UnsupportedSnapshot("more than 64 distinct inter-pod priority classes in one session")
+    if P > IP_MAX:
+        raise UnsupportedSnapshot(f"more than {IP_MAX} distinct inter-pod priority classes in one session")
     pkeys = sorted(classes, key=lambda k: classes[k])
     cls_dom, _ = domain_table([(k[3],) for k in pkeys])
 
@@ -464,7 +468,8 @@ def build_interpod(nodes, session_pods, other_pods_on_nodes, task_node, task_sta
                 m |= 1 << c
         return m
 
-    t_cinc = np.zeros(T, np.uint64); t_sig = np.full(T, KB_NONE, np.uint32)
+    Wp = max(1, (P + 63) // 64)
+    t_cinc = [0] * T; t_sig = np.full(T, KB_NONE, np.uint32)
     sigs: Dict[tuple, int] = {}
     for t, p in enumerate(session_pods):
         t_cinc[t] = cls_inc_mask(p)
@@ -484,7 +489,7 @@ def build_interpod(nodes, session_pods, other_pods_on_nodes, task_node, task_sta
         sig_w[i, :P] = w
     cls_bound = np.zeros((max(1, P), N), np.int32); cls_unbound = np.zeros((max(1, P), N), np.int32)
     first_unbound = KB_NONE
-    on_nodes = [(p, int(task_node[t]), int(t_cinc[t])) for t, p in enumerate(session_pods) if int(task_node[t]) != KB_NONE]
+    on_nodes = [(p, int(task_node[t]), t_cinc[t]) for t, p in enumerate(session_pods) if int(task_node[t]) != KB_NONE]
     on_nodes += [(p, n, cls_inc_mask(p)) for p, n in other_pods_on_nodes]
     for p, n, m in on_nodes:
         if p.spec_node_name_empty:
@@ -493,6 +498,14 @@ def build_interpod(nodes, session_pods, other_pods_on_nodes, task_node, task_sta
         for c in range(P):
             if (m >> c) & 1:
                 tab[c, n] += 1
+    def words(masks, W):
+        out = np.zeros((max(1, len(masks)), W), np.uint64)
+        for i, m in enumerate(masks):
+            for w in range(W):
+                out[i, w] = (m >> (64 * w)) & 0xFFFFFFFFFFFFFFFF
+        return out
+
+    t_inc, t_forbid, t_cinc = words(t_inc, Wc), words(t_forbid, Wc), words(t_cinc, Wp)
     return dict(n_counters=C, n_domains=int(D), n_classes=P, n_sigs=len(sigs), first_unbound_node=int(first_unbound),
                 ctr_dom=ctr_dom.reshape(C, N) if C else np.zeros((1, N), np.uint32) + KB_NONE,
                 ctr_count=ctr_count if C else np.zeros((1, max(1, D)), np.int32), ctr_total=ctr_total if C else np.zeros(1, np.int32),
@@ -543,7 +556,7 @@ def _static_ok(pod_cls, node_cls, pressure=(False, False, False)) -> bool:
 # the SoA snapshot
 # ------------------------------------------------------------------------------------------------
 _DTYPES = {C.c_double: np.float64, C.c_uint32: np.uint32, C.c_int64: np.int64, C.c_int32: np.int32, C.c_uint8: np.uint8,
-           C.c_uint64: np.uint64}
+           C.c_uint64: np.uint64, C.c_uint16: np.uint16}
 
 
 class SessionSnapshot:

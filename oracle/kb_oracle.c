@@ -429,11 +429,12 @@ typedef struct kbo_session {
   /* inter-pod (anti)affinity (include/kb_engine.h: kb_interpod), NULL tables: no pod carries a term.  Counts are kept
      incrementally by ssn_allocate / ssn_pipeline (allocate and backfill only add; preempt / reclaim refuse such sessions). */
   int ip_on;
-  uint32_t ip_C, ip_D, ip_P, ip_S, ip_Z;
+  uint32_t ip_C, ip_D, ip_P, ip_S, ip_Z, ip_Wc, ip_Wp;   /* Wc / Wp: 64-bit words per task mask */
   uint32_t *ip_ctr_dom, *ip_cls_dom, *ip_task_sig;
   int32_t *ip_ctr_count, *ip_ctr_total, *ip_cls_bound, *ip_cls_unbound, *ip_sig_weight;
   uint64_t *ip_task_inc, *ip_task_forbid, *ip_task_cls_inc;
-  uint8_t *ip_task_require, *ip_task_self;
+  uint16_t *ip_task_require;
+  uint8_t *ip_task_self;
 } kbo_session;
 
 static int find_plugin_enabled(const kbo_session *s, uint32_t plugin, uint32_t en_bit) {
@@ -558,14 +559,16 @@ static int class_ok(const kbo_session *s, uint32_t tc, uint32_t nc) {
    forbid a positive count in the node's domain (:1400-1441, :1535-1543); the pod's own affinity needs one, unless no pod at all
    matches its terms and it matches them itself (:1519-1566). */
 static int interpod_predicate(const kbo_session *s, uint32_t t, uint32_t n) {
-  uint64_t fb = s->ip_task_forbid[t];
-  for (uint32_t c = 0; fb; c++, fb >>= 1) {
-    if (!(fb & 1)) continue;
-    uint32_t d = s->ip_ctr_dom[(size_t)c * s->N + n];
-    if (d != KB_NONE && s->ip_ctr_count[(size_t)c * s->ip_D + d] > 0) return 0;
+  for (uint32_t w = 0; w < s->ip_Wc; w++) {
+    uint64_t fb = s->ip_task_forbid[(size_t)t * s->ip_Wc + w];
+    for (uint32_t c = 64 * w; fb; c++, fb >>= 1) {
+      if (!(fb & 1)) continue;
+      uint32_t d = s->ip_ctr_dom[(size_t)c * s->N + n];
+      if (d != KB_NONE && s->ip_ctr_count[(size_t)c * s->ip_D + d] > 0) return 0;
+    }
   }
   uint32_t r = s->ip_task_require[t];
-  if (r != 0xFF) {
+  if (r != 0xFFFF) {
     uint32_t d = s->ip_ctr_dom[(size_t)r * s->N + n];
     if (!(d != KB_NONE && s->ip_ctr_count[(size_t)r * s->ip_D + d] > 0)) {
       if (s->ip_ctr_total[r] > 0 || !s->ip_task_self[t]) return 0;
@@ -730,17 +733,21 @@ static void interpod_priority(const kbo_session *s, const o_task *tk, const uint
 /* the pod joins ni.Tasks of node n (Allocate or Pipeline: both AddTask) and, for ssn.Allocate, the PodLister's allocated set */
 static void interpod_placed(kbo_session *s, uint32_t t, uint32_t n, int allocated) {
   if (!s->ip_on) return;
-  uint64_t m = s->ip_task_cls_inc[t];
-  for (uint32_t p = 0; m; p++, m >>= 1)
-    if (m & 1) s->ip_cls_unbound[(size_t)p * s->N + n] += 1;
+  for (uint32_t w = 0; w < s->ip_Wp; w++) {
+    uint64_t m = s->ip_task_cls_inc[(size_t)t * s->ip_Wp + w];
+    for (uint32_t p = 64 * w; m; p++, m >>= 1)
+      if (m & 1) s->ip_cls_unbound[(size_t)p * s->N + n] += 1;
+  }
   if (n < s->ip_Z) s->ip_Z = n;
   if (!allocated) return;
-  m = s->ip_task_inc[t];
-  for (uint32_t c = 0; m; c++, m >>= 1) {
-    if (!(m & 1)) continue;
-    s->ip_ctr_total[c] += 1;
-    uint32_t d = s->ip_ctr_dom[(size_t)c * s->N + n];
-    if (d != KB_NONE) s->ip_ctr_count[(size_t)c * s->ip_D + d] += 1;
+  for (uint32_t w = 0; w < s->ip_Wc; w++) {
+    uint64_t m = s->ip_task_inc[(size_t)t * s->ip_Wc + w];
+    for (uint32_t c = 64 * w; m; c++, m >>= 1) {
+      if (!(m & 1)) continue;
+      s->ip_ctr_total[c] += 1;
+      uint32_t d = s->ip_ctr_dom[(size_t)c * s->N + n];
+      if (d != KB_NONE) s->ip_ctr_count[(size_t)c * s->ip_D + d] += 1;
+    }
   }
 }
 static void eval_all_nodes_raw(kbo_session *s, const o_task *t, int fit_mode, uint8_t *feas, double *score);
@@ -1027,18 +1034,19 @@ kbo_session *kbo_open(const kb_config *cfg, const kb_snapshot *sn, int threads) 
     const kb_interpod *ip = sn->interpod;
     s->ip_on = 1;
     s->ip_C = ip->n_counters; s->ip_D = ip->n_domains ? ip->n_domains : 1; s->ip_P = ip->n_classes; s->ip_S = ip->n_sigs; s->ip_Z = ip->first_unbound_node;
+    s->ip_Wc = s->ip_C ? (s->ip_C + 63) / 64 : 1; s->ip_Wp = s->ip_P ? (s->ip_P + 63) / 64 : 1;
 #define IP_COPY(dst, src, type, count) do { size_t n_ = (size_t)(count); dst = (type *)malloc(sizeof(type) * (n_ ? n_ : 1)); if (n_) memcpy(dst, src, sizeof(type) * n_); } while (0)
     IP_COPY(s->ip_ctr_dom, ip->ctr_dom, uint32_t, (size_t)s->ip_C * s->N);
     IP_COPY(s->ip_ctr_count, ip->ctr_count, int32_t, (size_t)s->ip_C * s->ip_D);
     IP_COPY(s->ip_ctr_total, ip->ctr_total, int32_t, s->ip_C);
-    IP_COPY(s->ip_task_inc, ip->task_inc, uint64_t, s->T);
-    IP_COPY(s->ip_task_forbid, ip->task_forbid, uint64_t, s->T);
-    IP_COPY(s->ip_task_require, ip->task_require, uint8_t, s->T);
+    IP_COPY(s->ip_task_inc, ip->task_inc, uint64_t, (size_t)s->T * s->ip_Wc);
+    IP_COPY(s->ip_task_forbid, ip->task_forbid, uint64_t, (size_t)s->T * s->ip_Wc);
+    IP_COPY(s->ip_task_require, ip->task_require, uint16_t, s->T);
     IP_COPY(s->ip_task_self, ip->task_self, uint8_t, s->T);
     IP_COPY(s->ip_cls_dom, ip->cls_dom, uint32_t, (size_t)s->ip_P * s->N);
     IP_COPY(s->ip_cls_bound, ip->cls_bound, int32_t, (size_t)s->ip_P * s->N);
     IP_COPY(s->ip_cls_unbound, ip->cls_unbound, int32_t, (size_t)s->ip_P * s->N);
-    IP_COPY(s->ip_task_cls_inc, ip->task_cls_inc, uint64_t, s->T);
+    IP_COPY(s->ip_task_cls_inc, ip->task_cls_inc, uint64_t, (size_t)s->T * s->ip_Wp);
     IP_COPY(s->ip_task_sig, ip->task_sig, uint32_t, s->T);
     IP_COPY(s->ip_sig_weight, ip->sig_weight, int32_t, (size_t)s->ip_S * s->ip_P);
 #undef IP_COPY

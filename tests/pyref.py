@@ -239,6 +239,8 @@ class Session:
         self.ip = None
         if ip is not None:
             self.ip = {k: (v.tolist() if hasattr(v, "tolist") else v) for k, v in ip.items()}
+            for k in ("task_inc", "task_forbid", "task_cls_inc"):      # [T][W] 64-bit words -> one Python integer per task
+                self.ip[k] = [sum(int(w) << (64 * i) for i, w in enumerate(row)) for row in self.ip[k]]
             self.ip_at_open = [on for on in self.onnode]
             self.ip_added = [set() for _ in range(self.N)]      # tasks whose first AddTask happened in this session: Spec.NodeName == ""
         self._open_plugins()
@@ -264,7 +266,7 @@ class Session:
                 if d != NONE and self._ip_count(c, d) > 0:
                     return False
         r = ip["task_require"][t]
-        if r != 0xFF:
+        if r != 0xFFFF:
             d = ip["ctr_dom"][r][n]
             if not (d != NONE and self._ip_count(r, d) > 0):
                 if self._ip_count(r, None) > 0 or not ip["task_self"][t]:

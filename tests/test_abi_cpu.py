@@ -144,9 +144,9 @@ def test_go_shim_obeys_the_cgo_pointer_rules_statically():
         # 1. struct-field = address-of-Go-slice-element / unsafe.Pointer(&x[...])
         #    (slices that ARE C memory are fine: flatten.go's calloc-backed views f.f64(n), f.u32(n), ...)
         cviews = set()
-        for lhs, rhs in re.findall(r"^\s*([\w, ]+?)\s*:?=\s*(f\.(?:f64|i64|u64|u32|i32|u8)\(.*)$", src, flags=re.M):
+        for lhs, rhs in re.findall(r"^\s*([\w, ]+?)\s*:?=\s*(f\.(?:f64|i64|u64|u32|i32|u16|u8)\(.*)$", src, flags=re.M):
             names = [n.strip() for n in lhs.split(",")]
-            if len(names) == len(re.findall(r"\bf\.(?:f64|i64|u64|u32|i32|u8)\(", rhs)):
+            if len(names) == len(re.findall(r"\bf\.(?:f64|i64|u64|u32|i32|u16|u8)\(", rhs)):
                 cviews.update(names)
         taken = re.findall(r"^\s*[A-Za-z_][\w.]*\.[a-z_]+\s*=\s*\(\*C\.[\w]+\)\(unsafe\.Pointer\(&(\w+)\[", src, flags=re.M)
         bad = [v for v in taken if v not in cviews]

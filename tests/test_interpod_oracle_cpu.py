@@ -29,10 +29,15 @@ tiers:
 """]
 
 
-def interpod_case(seed):
+def interpod_case(seed, wide=False):
+    """wide: many distinct terms, so that the per-task masks of kb_interpod span several 64-bit words"""
     rng = np.random.RandomState(900 + seed)
-    nodes, pods, groups, queues = random_cluster(1000 + seed, n_nodes=int(rng.randint(5, 16)), n_pods=int(rng.randint(30, 90)),
-                                                 n_jobs=int(rng.randint(4, 12)), tight=True)
+    if wide:
+        nodes, pods, groups, queues = random_cluster(3000 + seed, n_nodes=int(rng.randint(8, 20)), n_pods=int(rng.randint(150, 260)),
+                                                     n_jobs=int(rng.randint(8, 16)), tight=True, pool_size=70)
+    else:
+        nodes, pods, groups, queues = random_cluster(1000 + seed, n_nodes=int(rng.randint(5, 16)), n_pods=int(rng.randint(30, 90)),
+                                                     n_jobs=int(rng.randint(4, 12)), tight=True)
     snap = snapmod.flatten(nodes, pods, groups, queues)
     if seed % 3 == 0:                                                      # capacity that is being released: Pipeline decisions
         N = snap.n_nodes
@@ -42,10 +47,12 @@ def interpod_case(seed):
     return conf.load_scheduler_conf(CONFS[seed % 2]), snap
 
 
-@pytest.mark.parametrize("seed", range(60))
+@pytest.mark.parametrize("seed", list(range(60)) + [1000 + i for i in range(6)])
 def test_oracle_equals_pyref_with_interpod_affinity(oracle_mod, seed):
     try:
-        cfg, snap = interpod_case(seed)
+        cfg, snap = interpod_case(seed % 1000, wide=seed >= 1000)
+        if seed >= 1000:
+            assert snap.interpod["n_counters"] > 64 and snap.interpod["n_classes"] > 64   # multi-word masks
     except snapmod.UnsupportedSnapshot as e:
         pytest.skip(str(e))
     if snap.interpod is None:
