@@ -58,6 +58,8 @@ def main():
     ap.add_argument("--config", type=int, default=3, help="BASELINE config index (2..5)")
     ap.add_argument("--scale", type=float, default=1.0)
     ap.add_argument("--diverse", action="store_true", help="stress variant: every job draws its own request (thousands of distinct task shapes)")
+    ap.add_argument("--survey-nodes", action="store_true", help="variant: node sizes as SURVEY.md 8d lists them (16..128 cores, 64..512 GiB): capacity ~4x the "
+                    "demand instead of the 1.3x pressure the same paragraph asks for (the default generator keeps the pressure)")
     ap.add_argument("--window", type=int, default=0)
     ap.add_argument("--commit-batch", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -98,6 +100,9 @@ def main():
     params = kbm.snapshot.synth_config(args.config, args.scale)
     if args.diverse:
         params.diverse_requests = True
+    if args.survey_nodes:
+        params.node_cpu_cores = (16, 32, 64, 96, 128)
+        params.node_mem_gib = (64, 128, 256, 512)
     snap = kbm.snapshot.synth(params)
     actions = ["allocate", "backfill"]
 
@@ -212,7 +217,8 @@ def main():
         "config": {"workload": f"BASELINE configs[{args.config - 1}]: {snap.n_tasks} tasks x {snap.n_nodes} nodes, "
                                f"{snap.n_jobs} gang jobs, {snap.n_queues} queues, R={R}, allocate+backfill, "
                                f"plugins priority,gang,drf,predicates,proportion,nodeorder ({weights})",
-                   "window": args.window or 256, "scale": args.scale, "diverse_requests": bool(args.diverse)},
+                   "window": args.window or 256, "scale": args.scale, "diverse_requests": bool(args.diverse),
+                   "node_sizes": "SURVEY 8d list (no capacity pressure)" if args.survey_nodes else "sized for demand ~1.3x capacity"},
         "binds_per_s": n_binds * args.steps / elapsed, "binds": n_binds, "decisions": int(d["decisions"] / args.steps),
         "evals_per_step": int(evals / args.steps),
         # `value` counts the evaluations the REFERENCE performs for this cycle (N per popped task).  The engine

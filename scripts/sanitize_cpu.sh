@@ -11,6 +11,7 @@ g++ -std=c++17 $san -o "$out/liborderharness.so" tests/host_harness/order_harnes
 ASAN_OPTIONS=detect_leaks=0 LD_PRELOAD="$(gcc -print-file-name=libasan.so)" \
 KB_ORACLE_LIB="$out/libkboracle.so" KB_ORDER_HARNESS_LIB="$out/liborderharness.so" \
   python -m pytest tests/test_oracle_kat.py tests/test_oracle_independent.py tests/test_pyref_vs_oracle.py tests/test_host_order_cpu.py \
+    tests/test_interpod_oracle_cpu.py tests/test_manifests_cpu.py \
     -x -q -p no:cacheprovider "$@"
 # ThreadSanitizer over the oracle's worker pool (the cpu_baseline leg's 16-way fan-out)
 gcc -std=c11 -O1 -g -fPIC -shared -ffp-contract=off -fsanitize=thread -o "$out/libkboracle_tsan.so" oracle/kb_oracle.c -lm -lpthread
