@@ -1586,6 +1586,7 @@ static int run_action(kb_engine *e, uint32_t action, kb_decision *out, uint64_t 
         if (queued) { c = cn; buf ^= 1u; }
         else if (n) c = launch(n, nullptr, buf, 0);
       } else {
+        n = run.plan(e);   // re-plan first: the queued round drains (three empty launches) while the host works
         if (queued) {   // the queued round skipped itself: consume its publication before its staging half is reused
           uint32_t nd2 = 0, rs2 = 0;
           round_collect(e, cn, true, nd2, rs2);
@@ -1593,7 +1594,6 @@ static int run_action(kb_engine *e, uint32_t action, kb_decision *out, uint64_t 
           e->stats.matrix_launches -= 1;
           e->stats.matrix_evals -= (uint64_t)cn.ns * e->hs.N;
         }
-        n = run.plan(e);
         if (n) c = launch(n, nullptr, buf, 0);
       }
     }
