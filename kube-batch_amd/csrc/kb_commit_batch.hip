@@ -15,7 +15,7 @@
 #include "kb_device.h"
 #include "kb_eval.hpp"
 
-#define KB_K5_THREADS 512
+#define KB_K5_THREADS 1024
 
 // class_row: nullptr -> look the class pair up in the global bit table; otherwise the task class's row of the table (bit nc)
 // ------------------------------------------------------------------------------------------------------------
@@ -530,6 +530,9 @@ __global__ void __launch_bounds__(KB_K5_THREADS) k_commit_batch(const K7KernArgs
       const uint32_t nsh = (uint32_t)__popcll(repmask);
       if (lane >= nsh && lane < K7_B) H.e_off[lane] = 0xFFFFFFFFu;
       if (lane == 0) { H.nshapes = nsh; H.n_pairs = total; H.n_batches++; }
+#ifdef KB_K7_TRACE
+      if (lane == 0) { tacc[2] += total; if (total > KB_K5_THREADS) tacc[12] += (1u << 16); }   // trace only: pairs per batch (slot 2); batches with more pairs than threads (high half of slot 12)
+#endif
       K7_STAMP(1);
       // ---- walk (still wave 0, no barrier in between): runs of consecutive rows with the same shape take successive clean
       //      entries of the shape's persistent window
