@@ -202,6 +202,9 @@ void kb_launch_gather(const KbDev &d, const KbRound &r, void *stream);
 void kb_launch_matrix(const KbDev &d, const KbRound &r, void *stream);
 // NodeAffinity Map + NormalizeReduce + weight added to the score rows of the matrix (no-op without affinity terms)
 void kb_launch_affinity(const KbDev &d, const KbRound &r, void *stream);
+// feasibility probe: alive[i] |= 1 iff task rows[i] (allocate's predicate: resource fit + plugin predicates) has a feasible node
+// against the current node state; alive must be zero on entry
+void kb_launch_probe(const KbDev &d, const uint32_t *rows, uint32_t n_rows, uint32_t *alive, void *stream);
 // nodeorder's InterPodAffinityPriority added to the score rows of the matrix rows whose task carries weights (no-op otherwise)
 void kb_launch_interpod(const KbDev &d, const KbRound &r, void *stream);
 void kb_launch_argmax(const KbDev &d, const KbRound &r, void *stream);

@@ -159,6 +159,11 @@ struct kb_engine {
   DevBuf b_mrows, b_same, b_score, b_maskw, b_keys;
   DevBuf b_win, b_out;   // per-round upload / download blocks (see h_win / h_out)
   DevBuf b_chain;        // KbRound::chain: tag of the last round that committed its whole window
+  // feasibility probe at speculation breaks (ActionRun::probe_dead_shapes): one representative task per feasibility shape
+  DevBuf b_probe_rows, b_probe_alive;
+  Pinned<uint32_t> h_probe_alive, h_probe_rows;
+  bool probe_enabled = true;          // KB_PROBE=0 disables
+  uint64_t probes = 0, probe_deaths = 0;
   int commit_kernel_of[2] = {0, 0};   // the commit kernel launched for the round in each staging half
   uint32_t win_cap = 0, mat_cap = 0;
   size_t keys_cap = 0;
@@ -618,6 +623,8 @@ struct ActionRun {
   size_t bf_pos = 0;
   uint64_t popped = 0, spec_pops = 0, spec_pops_next = 0;
   std::vector<uint32_t> rows_next;   // the window speculated behind the one in flight
+  std::vector<uint32_t> probe_list;  // feasibility shapes the probe looks at (the ones still alive)
+  uint32_t probe_calls = 0;
   double host_ms = 0, t_start = 0;
   bool active = false;
 
@@ -772,6 +779,34 @@ struct ActionRun {
       return true;
     }
     return false;
+  }
+
+  // At a speculation break the device is idle and the host is about to re-plan anyway: every feasibility shape that is still
+  // alive is evaluated against the current node state (one launch, feasibility only), and whatever has no node left is marked dead
+  // NOW instead of costing a break of its own when its next task comes up.  Exact: inside the allocate action a shape without a
+  // feasible node stays without one (the argument of mark_dead), so the reference's PredicateNodes will find none either when it
+  // pops such a task.  Called only between absorb() and plan(), when no planned window is outstanding.
+  void probe_dead_shapes(kb_engine *e) {
+    HostSession &hs = e->hs;
+    if (!e->probe_enabled || action != 0 || hs.has_interpod || hs.n_feas_shapes == 0 || !e->pol.pred_enabled) return;
+    // only the shapes that are still alive are looked at, and when that is a large matrix (many shapes x many nodes: a launch of
+    // a few hundred microseconds) only every fourth break pays for it; the deaths of the breaks in between are found then
+    probe_calls++;
+    probe_list.clear();
+    for (uint32_t f = 0; f < hs.n_feas_shapes; f++)
+      if (!dead[f]) probe_list.push_back(f);
+    const uint32_t S = (uint32_t)probe_list.size();
+    if (S == 0) return;
+    if ((uint64_t)S * hs.N > (8ull << 20) && (probe_calls & 3u) != 1u) return;
+    for (uint32_t i = 0; i < S; i++) e->h_probe_rows[i] = hs.feas_rep[probe_list[i]];
+    HIP_OK(hipMemcpyAsync(e->b_probe_rows.p, e->h_probe_rows.data(), sizeof(uint32_t) * S, hipMemcpyHostToDevice, e->stream));
+    HIP_OK(hipMemsetAsync(e->b_probe_alive.p, 0, sizeof(uint32_t) * S, e->stream));
+    kb_launch_probe(e->dev, e->b_probe_rows.as<uint32_t>(), S, e->b_probe_alive.as<uint32_t>(), e->stream);
+    HIP_OK(hipMemcpyAsync(e->h_probe_alive.data(), e->b_probe_alive.p, sizeof(uint32_t) * S, hipMemcpyDeviceToHost, e->stream));
+    HIP_OK(hipStreamSynchronize(e->stream));
+    e->probes++;
+    for (uint32_t i = 0; i < S; i++)   // no dominance scan needed: the probe looked at every live shape itself
+      if (e->h_probe_alive[i] == 0) { dead[probe_list[i]] = 1; e->probe_deaths++; }
   }
 
   void absorb(kb_engine *e, uint32_t n, uint32_t n_done, uint32_t reason) {
@@ -938,6 +973,8 @@ int kb_engine_create(const kb_config *cfg, kb_engine **out) {
       eng->fast_rounds = !(eng->flags & KB_FLAG_SYNC_ROUNDS) && !(sr && sr[0] == '1');
       const char *cr = getenv("KB_CHAIN_ROUNDS");   // 0: launch every round only after the previous one was collected (A/B, debugging)
       eng->chain_rounds = !(cr && cr[0] == '0');
+      const char *pb = getenv("KB_PROBE");
+      eng->probe_enabled = !(pb && pb[0] == '0');
       const char *dw = getenv("KB_DIRECT_WINDOW");
       eng->direct_window = !(dw && dw[0] == '0');
     }
@@ -958,6 +995,7 @@ void kb_engine_destroy(kb_engine *e) {
             (unsigned long long)e->stats.row_fallbacks, (unsigned long long)e->k5_walks, (unsigned long long)e->k5_rescans,
             (unsigned long long)e->k5_demand);
   if (getenv("KB_K5_STATS")) fprintf(stderr, "[kb K7] batches of the batch kernel %llu\n", e->k7_batches);
+  if (getenv("KB_K5_STATS")) fprintf(stderr, "[kb probe] %llu probes, %llu shapes marked dead by them\n", (unsigned long long)e->probes, (unsigned long long)e->probe_deaths);
   if (getenv("KB_K5_STATS") && e->k7_trace[1] > 0) {
     static const char *ph[14] = {"loop top / descriptor refill", "shapes (+ barrier)", "windows (+ barrier)", "walk (+ barrier)", "fetch + apply (+ barrier)",
                                  "evaluate (+ barrier)", "validate (+ barrier)", "commit the prefix", "row mode: keyq pass (+ barrier)", "row mode: rows (+ barrier)",
@@ -1150,6 +1188,8 @@ int kb_session_load(kb_engine *e, const kb_snapshot *sn) {
     hs.feas_eff.assign((size_t)hs.n_feas_shapes * R, 0.0);
     hs.feas_cls.assign(hs.n_feas_shapes, 0);
     hs.feas_conf.assign(hs.n_feas_shapes, 0);
+    hs.feas_rep.assign(hs.n_feas_shapes, 0);
+    for (uint32_t t = T; t-- > 0;) hs.feas_rep[hs.t_feas_shape[t]] = t;
     hs.has_interpod = ip != nullptr;
     hs.t_ip_subject.clear(); hs.feas_ip_require.clear(); hs.feas_ip.clear();
     if (ip) {
@@ -1458,6 +1498,10 @@ int kb_session_load(kb_engine *e, const kb_snapshot *sn) {
       d.ip_z = e->b_ip_z.as<uint32_t>();
       d.ip_C = C; d.ip_D = D; d.ip_P = P; d.ip_Wc = Wc; d.ip_Wp = Wp;
     }
+    upload(e->b_probe_rows, hs.feas_rep.data(), hs.n_feas_shapes, s);
+    e->b_probe_alive.alloc(sizeof(uint32_t) * std::max<uint32_t>(hs.n_feas_shapes, 1u));
+    e->h_probe_alive.resize(std::max<uint32_t>(hs.n_feas_shapes, 1u));
+    e->h_probe_rows.resize(std::max<uint32_t>(hs.n_feas_shapes, 1u));
     upload(e->b_jbegin, hs.job_begin.data(), J + 1, s);
     upload(e->b_jmin, hs.job_min.data(), J, s);
     upload(e->b_jqueue, hs.job_queue.data(), J, s);
@@ -1554,6 +1598,7 @@ static int run_action(kb_engine *e, uint32_t action, kb_decision *out, uint64_t 
         throw EngineError(KB_E_UNSUPPORTED, "a Pending task carries a stale NodeName (un-pipelined by a discarded preempt statement)");
     ActionRun run;
     run.begin(e, action);
+    run.probe_dead_shapes(e);   // shapes no node can take from the start (larger than every node, full classes) never cost a break
     uint32_t n = run.plan(e);
     ensure_matrix_buffers(e, e->eff_window, e->eff_window + 1);   // sized once: no reallocation under a round in flight
     auto launch = [&](uint32_t rows_n, const uint32_t *rows, uint32_t buf, uint32_t chain_expect) {
@@ -1586,6 +1631,7 @@ static int run_action(kb_engine *e, uint32_t action, kb_decision *out, uint64_t 
         if (queued) { c = cn; buf ^= 1u; }
         else if (n) c = launch(n, nullptr, buf, 0);
       } else {
+        if (reason != KB_REASON_RENORM) run.probe_dead_shapes(e);
         n = run.plan(e);   // re-plan first: the queued round drains (three empty launches) while the host works
         if (queued) {   // the queued round skipped itself: consume its publication before its staging half is reused
           uint32_t nd2 = 0, rs2 = 0;

@@ -151,6 +151,7 @@ struct HostSession {
   std::vector<uint32_t> t_row_shape;      // id of (InitResreq, non-zero request, class): identical matrix rows
   uint32_t n_feas_shapes = 0, n_row_shapes = 0;
   std::vector<double> feas_eff;           // [n_feas_shapes][R] the InitResreq values LessEqual compares (0 where the dimension is skipped)
+  std::vector<uint32_t> feas_rep;         // [n_feas_shapes] one task of the shape (the feasibility probe evaluates it)
   std::vector<uint32_t> feas_cls;         // [n_feas_shapes] static-predicate class
   std::vector<uint64_t> feas_conf;        // [n_feas_shapes] host-port conflict mask
   std::vector<uint32_t> job_begin, job_queue;

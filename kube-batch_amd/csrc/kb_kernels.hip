@@ -662,6 +662,37 @@ __global__ void __launch_bounds__(256) k_interpod(KbDev d, KbRound r) {
     }
 }
 
+// Feasibility probe (kb_engine.cpp: ActionRun::probe_dead_shapes): thread <-> NPT nodes kept in registers for the TR task rows of the
+// workgroup; a wave that finds a feasible node for a row sets the row's flag.  No scores, nothing stored per pair.
+template <int NPT, int TR>
+__global__ void __launch_bounds__(256) k_probe(KbDev d, const uint32_t *rows, uint32_t n_rows, uint32_t *alive) {
+  __shared__ K1Task srow[TR];
+  const uint32_t row0 = blockIdx.y * TR;
+  const uint32_t nr = min((uint32_t)TR, n_rows - row0);
+  if (threadIdx.x < nr) srow[threadIdx.x] = k1_task(d, rows[row0 + threadIdx.x]);
+  __syncthreads();
+  const uint32_t n0 = (blockIdx.x * 256 + threadIdx.x) * NPT;
+  K1Node nv[NPT];
+#pragma unroll
+  for (int j = 0; j < NPT; j++) nv[j] = k1_node(d, n0 + j);
+  for (uint32_t rr = 0; rr < nr; rr++) {
+    const K1Task tv = srow[rr];
+    uint32_t ok = 0;
+#pragma unroll
+    for (int j = 0; j < NPT; j++) ok |= (eval_pair(d, tv, nv[j], n0 + j, 1) >> 16) & 1u;
+    const unsigned long long any = __ballot(ok);
+    if (any && (threadIdx.x & 63) == 0) atomicOr(&alive[row0 + rr], 1u);
+  }
+}
+void kb_launch_probe(const KbDev &d, const uint32_t *rows, uint32_t n_rows, uint32_t *alive, void *stream) {
+  if (n_rows == 0) return;
+  KbDev dd = d;
+  dd.score_enabled = 0;   // feasibility only
+  if ((size_t)(d.NP / 1024) * ((n_rows + 31) / 32) >= 512)   // enough workgroups of the amortising tile to fill the chip
+    hipLaunchKernelGGL((k_probe<4, 32>), dim3(d.NP / 1024, (n_rows + 31) / 32), dim3(256), 0, (hipStream_t)stream, dd, rows, n_rows, alive);
+  else
+    hipLaunchKernelGGL((k_probe<1, 16>), dim3(d.NP / 256, (n_rows + 15) / 16), dim3(256), 0, (hipStream_t)stream, dd, rows, n_rows, alive);
+}
 void kb_launch_interpod(const KbDev &d, const KbRound &r, void *stream) {
   if (r.n_mrows == 0 || !d.t_ip_sig || !d.score_enabled || d.ip_P == 0) return;
   hipLaunchKernelGGL(k_interpod, dim3(r.n_mrows), dim3(256), 0, (hipStream_t)stream, d, r);
