@@ -170,11 +170,34 @@ class RoundModel:
                 return i + 1, PIPELINED, out, delta
         return len(self.rows), DONE, out, delta
 
-    def run_single(self):
+    def probe_dead_shapes(self):
+        """ActionRun::probe_dead_shapes (DESIGN.md §4): between absorb() and plan(), every feasibility shape that is still alive
+        is checked against the CURRENT node state; a shape without a feasible node is marked dead now.  Returns how many died."""
+        p = self.p
+        rep = {}
+        for t in range(self.snap.n_tasks):
+            rep.setdefault(self.shape[t], t)
+        died = 0
+        for f, t in rep.items():
+            if self.dead[f]:
+                continue
+            if not any((p.init[t].less_equal(p.idle[n]) or p.init[t].less_equal(p.rel[n])) and p.plugin_predicate(t, n) for n in range(p.N)):
+                self.dead[f] = True
+                died += 1
+        return died
+
+    def run_single(self, probe=False):
+        self.probe_deaths = self.breaks = 0
+        if probe:
+            self.probe_deaths += self.probe_dead_shapes()
         while self.plan():
             table = [self.candidate_list(m) for m in range(len(self.mrows))]
             n_done, reason, out, _ = self.commit_window(table)
             self.absorb(n_done, reason, out)
+            if reason != DONE:
+                self.breaks += 1
+                if probe and reason != RENORM:
+                    self.probe_deaths += self.probe_dead_shapes()
         return self
 
     def run_single_stale(self):

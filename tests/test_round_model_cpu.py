@@ -39,6 +39,14 @@ def _check(L, cfg, snap, seed):
             for d in range(snap.n_res):
                 assert m.p.idle[n].get(d) == ref.idle[n].get(d) and m.p.rel[n].get(d) == ref.rel[n].get(d)
         m.close()
+    # the feasibility probe at speculation breaks marks dead shapes early; the decisions must not move, and it may only
+    # ever remove breaks
+    for window in (int(rng.choice([3, 8])), 64):
+        plain = round_model.RoundModel(L, cfg, snap, cases._tiers(cfg), window).run_single()
+        m = round_model.RoundModel(L, cfg, snap, cases._tiers(cfg), window).run_single(probe=True)
+        assert m.decs == ref.decisions and m.popped == ref.popped and m.p.binds == ref.binds, (seed, window, "probe")
+        assert m.breaks <= plain.breaks, (seed, window, m.breaks, plain.breaks)
+        plain.close(); m.close()
     # lists one round stale (built while the previous window commits), 2W + 1 entries, previous round's nodes dirty
     for window in (int(rng.choice([2, 4, 7])), int(rng.choice([16, 48]))):
         m = round_model.RoundModel(L, cfg, snap, cases._tiers(cfg), window).run_single_stale()
