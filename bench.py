@@ -179,8 +179,11 @@ def main():
                           "per-round launch inside the timed region (distinct shapes of one window)")
     full_reps = 5
     full_ms = eng.bench_matrix(0, T, reps=full_reps) if world == 1 else 0.0
-    roofline = (roof(T, full_ms, full_reps, f"kb_bench_matrix rows [0,{T}) x {N} nodes: per-shape evaluation + row expansion",
-                     "k_matrix+k_expand") if full_ms > 0 else roofline_cycle)
+    if args.diverse:     # shapes > rows / 16: the engine evaluates every row directly instead of expanding shape rows (kb_engine.cpp)
+        full_label, full_kernel = f"kb_bench_matrix rows [0,{T}) x {N} nodes: direct per-row evaluation", "k_matrix"
+    else:
+        full_label, full_kernel = f"kb_bench_matrix rows [0,{T}) x {N} nodes: per-shape evaluation + row expansion", "k_matrix+k_expand"
+    roofline = roof(T, full_ms, full_reps, full_label, full_kernel) if full_ms > 0 else roofline_cycle
     # HBM bytes per launch from the PMC passes of scripts/profile_round.sh (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate
     # runs; KB units; FETCH_SIZE doubled per MI355X_MICROARCH.md's gfx950 correction).  Cannot be collected inside this
     # process, so the committed summary of the same command is read back; null when it is absent or for another config.
@@ -188,7 +191,7 @@ def main():
     found = sorted(glob.glob(os.path.join(ROOT, "profiles", "round*", "rocprofv3_pmc_k_matrix.csv")),
                    key=lambda f: int("".join(c for c in os.path.basename(os.path.dirname(f)) if c.isdigit()) or 0))
     pmc = found[-1] if found else ""                # the newest round's summary
-    if full_ms > 0 and pmc:
+    if full_ms > 0 and pmc and not args.diverse:     # the diverse-shape stress evaluates every row directly: another kernel mix
         # only a profile of THIS launch may speak for it: the bench line committed beside the CSV must carry the same algorithmic
         # bytes per launch (same configuration, scale and matrix layout); otherwise traffic stays null
         same = False
