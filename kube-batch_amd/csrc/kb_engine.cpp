@@ -199,89 +199,6 @@ static thread_local std::string g_create_err;
 
 namespace {
 
-Policy compile_policy(const kb_config *cfg) {
-  Policy p;
-  if (!cfg->tier_begin && cfg->n_tiers) throw EngineError(KB_E_INVALID, "tier_begin is NULL");
-  for (uint32_t t = 0; t < cfg->n_tiers; t++) {
-    p.preempt_tiers.emplace_back();
-    p.reclaim_tiers.emplace_back();
-    for (uint32_t i = cfg->tier_begin[t]; i < cfg->tier_begin[t + 1]; i++) {
-      const kb_plugin_option &o = cfg->plugins[i];
-      // plugins that register a PreemptableFn: conformance.go:60, gang.go:93, priority.go:100, drf.go:111
-      if ((o.enabled & KB_EN_PREEMPTABLE) && (o.plugin == KB_PLUGIN_CONFORMANCE || o.plugin == KB_PLUGIN_GANG || o.plugin == KB_PLUGIN_PRIORITY || o.plugin == KB_PLUGIN_DRF))
-        p.preempt_tiers.back().push_back((uint8_t)o.plugin);
-      // ... a ReclaimableFn: conformance.go:61, gang.go:92, proportion.go:171
-      if ((o.enabled & KB_EN_RECLAIMABLE) && (o.plugin == KB_PLUGIN_CONFORMANCE || o.plugin == KB_PLUGIN_GANG || o.plugin == KB_PLUGIN_PROPORTION))
-        p.reclaim_tiers.back().push_back((uint8_t)o.plugin);
-      switch (o.plugin) {
-        case KB_PLUGIN_PRIORITY:
-          if (o.enabled & KB_EN_JOB_ORDER) p.job_chain.push_back(KB_PLUGIN_PRIORITY);
-          if (o.enabled & KB_EN_TASK_ORDER) p.task_order_priority = true;
-          break;
-        case KB_PLUGIN_GANG:
-          p.has_gang = true;
-          if (o.enabled & KB_EN_JOB_ORDER) p.job_chain.push_back(KB_PLUGIN_GANG);
-          if (o.enabled & KB_EN_JOB_READY) p.gang_job_ready = true;
-          if (o.enabled & KB_EN_JOB_PIPELINED) p.gang_job_pipelined = true;
-          break;
-        case KB_PLUGIN_CONFORMANCE:   // registers evict filters only (conformance.go:41-63)
-          break;
-        case KB_PLUGIN_DRF:
-          p.has_drf = true;
-          if (o.enabled & KB_EN_JOB_ORDER) p.job_chain.push_back(KB_PLUGIN_DRF);
-          break;
-        case KB_PLUGIN_PREDICATES:
-          if (o.enabled & KB_EN_PREDICATE) p.pred_enabled = true;
-          if ((o.args_set & 7u) && (o.args[0] || o.args[1] || o.args[2]))
-            throw EngineError(KB_E_UNSUPPORTED, "predicates pressure checks must be folded into node classes by the caller; flags not supported");
-          break;
-        case KB_PLUGIN_PROPORTION:
-          p.has_proportion = true;
-          if (o.enabled & KB_EN_QUEUE_ORDER) p.queue_order_proportion = true;
-          break;
-        case KB_PLUGIN_NODEORDER:
-          if (o.enabled & KB_EN_NODE_ORDER) p.nodeorder_enabled = true;
-          if (o.args_set & 1u) p.wL = o.args[KB_ARG_NODEORDER_LEAST];       // nodeorder.go:119-129
-          if (o.args_set & 2u) p.wM = o.args[KB_ARG_NODEORDER_MOST];
-          if (o.args_set & 4u) p.wNA = o.args[KB_ARG_NODEORDER_NODEAFF];
-          if (o.args_set & 8u) p.wPA = o.args[KB_ARG_NODEORDER_PODAFF];
-          if (o.args_set & 16u) p.wB = o.args[KB_ARG_NODEORDER_BALANCED];
-          break;
-        default:
-          throw EngineError(KB_E_UNSUPPORTED, "unknown plugin id " + std::to_string(o.plugin));
-      }
-    }
-  }
-  // every scorer yields 0..10 (NodeAffinity after its NormalizeReduce too) and the matrix stores the weighted sum as u16
-  if (p.wL < 0 || p.wM < 0 || p.wB < 0 || p.wNA < 0 || 10ll * ((long long)p.wL + p.wM + p.wB + p.wNA) > 65535)
-    throw EngineError(KB_E_UNSUPPORTED, "nodeorder weights must be >= 0 with 10*(least+most+balanced+nodeaffinity) <= 65535 (u16 score)");
-  return p;
-}
-
-// shape interning: fixed-length double keys -> dense ids in first-appearance order (hashed: one lookup per task at session load)
-struct Interner {
-  size_t klen = 0;
-  std::vector<double> keys;
-  std::unordered_map<uint64_t, std::vector<uint32_t>> buckets;
-  uint32_t intern(const std::vector<double> &k) {
-    if (!klen) klen = k.size();
-    uint64_t h = 0x9E3779B97F4A7C15ull;   // word-wise multiply-xorshift over the key's bit patterns
-    for (size_t i = 0; i < klen; i++) {
-      uint64_t w;
-      std::memcpy(&w, &k[i], sizeof(w));
-      h = (h ^ w) * 0xFF51AFD7ED558CCDull;
-      h ^= h >> 32;
-    }
-    std::vector<uint32_t> &ids = buckets[h];
-    for (uint32_t id : ids)
-      if (std::memcmp(&keys[(size_t)id * klen], k.data(), klen * sizeof(double)) == 0) return id;
-    const uint32_t id = (uint32_t)(keys.size() / klen);
-    keys.insert(keys.end(), k.begin(), k.end());
-    ids.push_back(id);
-    return id;
-  }
-  size_t size() const { return klen ? keys.size() / klen : 0; }
-};
 
 // window buffers: one entry per task row of a round
 void ensure_window_buffers(kb_engine *e, uint32_t rows) {
@@ -1023,272 +940,15 @@ int kb_session_load(kb_engine *e, const kb_snapshot *sn) {
     mg_free(e->mg);
     e->mg = nullptr;
     HostSession &hs = e->hs;
-    hs = HostSession();
-    const int R = hs.R = (int)sn->n_res;
-    const uint32_t N = hs.N = sn->n_nodes, T = hs.T = sn->n_tasks, J = hs.J = sn->n_jobs, Q = hs.Q = sn->n_queues;
-    const uint32_t NP = ((N + KB_NODE_PAD - 1) / KB_NODE_PAD) * KB_NODE_PAD + (N == 0 ? KB_NODE_PAD : 0);
-    hipStream_t s = e->stream;
-
-    // ---- validation of the exact envelope ----
-    for (uint32_t n = 0; n < N; n++) {
-      if (sn->node_alloc_cpu[n] < 0 || sn->node_alloc_mem[n] < 0 || sn->node_nz_cpu[n] < 0 || sn->node_nz_mem[n] < 0)
-        throw EngineError(KB_E_INVALID, "negative node quantity");
-      if (sn->node_alloc_cpu[n] >= (1ll << 48) || sn->node_alloc_mem[n] >= (1ll << 48) || sn->node_nz_cpu[n] >= (1ll << 48) || sn->node_nz_mem[n] >= (1ll << 48))
-        throw EngineError(KB_E_UNSUPPORTED, "node quantity >= 2^48: exact integer scoring not guaranteed");
-    }
-    hs.t_res.assign(sn->task_resreq, sn->task_resreq + (size_t)R * T);
-    hs.t_init.assign(sn->task_init_resreq, sn->task_init_resreq + (size_t)R * T);
-    hs.t_resmask.assign(T, 0);
-    if (sn->task_scalar_mask) hs.t_resmask.assign(sn->task_scalar_mask, sn->task_scalar_mask + T);
-    // a dense value under an absent key reads 0 (Go map semantics)
-    for (uint32_t t = 0; t < T; t++)
-      for (int d = 2; d < R; d++)
-        if (!((hs.t_resmask[t] >> (d - 2)) & 1u)) hs.t_res[(size_t)d * T + t] = 0.0;
-    // task-major copy for the order machine: one task's Resreq is read per scheduling step, and with the dimension-major
-    // device layout that is R cache misses per step
-    hs.t_res_rows.resize((size_t)T * R);
-    for (int d = 0; d < R; d++)
-      for (uint32_t t = 0; t < T; t++) hs.t_res_rows[(size_t)t * R + d] = hs.t_res[(size_t)d * T + t];
-    hs.t_job.assign(sn->task_job, sn->task_job + T);
-    hs.t_cls.assign(T, 0);
-    if (sn->task_class) hs.t_cls.assign(sn->task_class, sn->task_class + T);
-    hs.t_prio.assign(sn->task_priority, sn->task_priority + T);
-    hs.t_creation.assign(sn->task_creation, sn->task_creation + T);
-    hs.t_status.assign(sn->task_status, sn->task_status + T);
-    hs.t_node.assign(T, KB_NONE);
-    if (sn->task_node) hs.t_node.assign(sn->task_node, sn->task_node + T);
-    hs.job_begin.assign(sn->job_task_begin, sn->job_task_begin + J + 1);
-    hs.job_queue.assign(sn->job_queue, sn->job_queue + J);
-    hs.job_min.assign(sn->job_min_available, sn->job_min_available + J);
-    hs.job_prio.assign(sn->job_priority, sn->job_priority + J);
-    hs.job_creation.assign(sn->job_creation, sn->job_creation + J);
-    hs.queue_weight.assign(sn->queue_weight, sn->queue_weight + Q);
-    hs.queue_creation.assign(Q, 0);
-    if (sn->queue_creation) hs.queue_creation.assign(sn->queue_creation, sn->queue_creation + Q);
-    if (hs.job_begin[0] != 0 || hs.job_begin[J] != T) throw EngineError(KB_E_INVALID, "job_task_begin must cover [0, n_tasks)");
-    for (uint32_t j = 0; j < J; j++) {
-      if (hs.job_begin[j] > hs.job_begin[j + 1]) throw EngineError(KB_E_INVALID, "job_task_begin not monotone");
-      for (uint32_t t = hs.job_begin[j]; t < hs.job_begin[j + 1]; t++)
-        if (hs.t_job[t] != j) throw EngineError(KB_E_INVALID, "tasks must be grouped by job in canonical order");
-    }
-    hs.t_nzc.assign(sn->task_nz_cpu, sn->task_nz_cpu + T);
-    hs.t_nzm.assign(sn->task_nz_mem, sn->task_nz_mem + T);
-    if (sn->task_port_want || sn->task_port_conflict) {
-      hs.t_want.assign(T, 0); hs.t_conf.assign(T, 0);
-      for (uint32_t t = 0; t < T; t++) { if (sn->task_port_want) hs.t_want[t] = sn->task_port_want[t]; if (sn->task_port_conflict) hs.t_conf[t] = sn->task_port_conflict[t]; }
-    }
-    if (sn->task_evict_protected) hs.t_protected.assign(sn->task_evict_protected, sn->task_evict_protected + T);
-    hs.n_ac.assign(sn->node_alloc_cpu, sn->node_alloc_cpu + N);
-    hs.n_am.assign(sn->node_alloc_mem, sn->node_alloc_mem + N);
-    hs.n_maxpods.assign(sn->node_max_pods, sn->node_max_pods + N);
-    hs.n_cls.assign(N, 0);
-    if (sn->node_class) hs.n_cls.assign(sn->node_class, sn->node_class + N);
-    hs.n_idle_mask.assign(N, 0);
-    if (sn->node_scalar_mask) hs.n_idle_mask.assign(sn->node_scalar_mask, sn->node_scalar_mask + N);
-    hs.n_tc = sn->n_task_classes; hs.n_nc = sn->n_node_classes ? sn->n_node_classes : 1;
-    if (sn->class_compat) hs.compat.assign(sn->class_compat, sn->class_compat + ((size_t)sn->n_task_classes * sn->n_node_classes + 7) / 8);
-    e->evictions.clear();
-    std::vector<uint32_t> t_active(T, 3u);
-    hs.t_res_empty.assign(T, 0);
-    hs.t_init_empty.assign(T, 0);
-    Interner feas_ids, row_ids;
-    // inter-pod (anti)affinity tables: validate what indexes device memory
+    const uint32_t NP = ((sn->n_nodes + KB_NODE_PAD - 1) / KB_NODE_PAD) * KB_NODE_PAD + (sn->n_nodes == 0 ? KB_NODE_PAD : 0);
+    std::vector<uint32_t> t_active, nmask;
+    build_host_session(sn, e->pol, NP, hs, t_active, nmask);   // kb_session.cpp: validation, shapes, plugin OnSessionOpen state
+    const int R = hs.R;
+    const uint32_t N = hs.N, T = hs.T, J = hs.J, Q = hs.Q;
     const kb_interpod *ip = sn->interpod;
-    if (ip) {
-      if (ip->n_counters > KB_INTERPOD_MAX || ip->n_classes > KB_INTERPOD_MAX) throw EngineError(KB_E_UNSUPPORTED, "more than KB_INTERPOD_MAX inter-pod counters / classes");
-      const uint32_t Wc = ip->n_counters ? (ip->n_counters + 63) / 64 : 1, Wp = ip->n_classes ? (ip->n_classes + 63) / 64 : 1;
-      if (ip->n_domains == 0 || ip->n_domains > std::max<uint32_t>(N, 1u)) throw EngineError(KB_E_INVALID, "inter-pod: n_domains outside 1..N");
-      if (!ip->ctr_dom || !ip->ctr_count || !ip->ctr_total || !ip->task_inc || !ip->task_forbid || !ip->task_require || !ip->task_self ||
-          !ip->cls_dom || !ip->cls_bound || !ip->cls_unbound || !ip->task_cls_inc || !ip->task_sig || !ip->sig_weight)
-        throw EngineError(KB_E_INVALID, "inter-pod: missing table");
-      if (ip->first_unbound_node != KB_NONE && ip->first_unbound_node >= N) throw EngineError(KB_E_INVALID, "inter-pod: first_unbound_node out of range");
-      auto beyond = [](const uint64_t *row, uint32_t W, uint32_t nbits) {   // a mask bit at or beyond nbits
-        for (uint32_t w = 0; w < W; w++) {
-          const uint32_t lo = 64 * w;
-          const uint64_t valid = nbits <= lo ? 0ull : (nbits - lo >= 64 ? ~0ull : ((1ull << (nbits - lo)) - 1ull));
-          if (row[w] & ~valid) return true;
-        }
-        return false;
-      };
-      for (uint32_t c = 0; c < ip->n_counters; c++)
-        for (uint32_t n = 0; n < N; n++) {
-          const uint32_t dm = ip->ctr_dom[(size_t)c * N + n];
-          if (dm != KB_NONE && dm >= ip->n_domains) throw EngineError(KB_E_INVALID, "inter-pod: counter domain id out of range");
-        }
-      for (uint32_t pc = 0; pc < ip->n_classes; pc++)
-        for (uint32_t n = 0; n < N; n++) {
-          const uint32_t dm = ip->cls_dom[(size_t)pc * N + n];
-          if (dm != KB_NONE && dm >= N) throw EngineError(KB_E_INVALID, "inter-pod: class domain id out of range");
-          if (ip->cls_bound[(size_t)pc * N + n] < 0 || ip->cls_unbound[(size_t)pc * N + n] < 0) throw EngineError(KB_E_INVALID, "inter-pod: negative pod count");
-        }
-      long long wsum = 0;
-      for (uint32_t i = 0; i < ip->n_sigs * ip->n_classes; i++) wsum = std::max<long long>(wsum, std::llabs((long long)ip->sig_weight[i]));
-      if (wsum > 1000000) throw EngineError(KB_E_UNSUPPORTED, "inter-pod: term weight beyond 1e6");
-      for (uint32_t t = 0; t < T; t++) {
-        if (beyond(ip->task_inc + (size_t)t * Wc, Wc, ip->n_counters) || beyond(ip->task_forbid + (size_t)t * Wc, Wc, ip->n_counters) ||
-            beyond(ip->task_cls_inc + (size_t)t * Wp, Wp, ip->n_classes))
-          throw EngineError(KB_E_INVALID, "inter-pod: mask names a missing counter / class");
-        if (ip->task_require[t] != 0xFFFF && ip->task_require[t] >= ip->n_counters) throw EngineError(KB_E_INVALID, "inter-pod: task_require out of range");
-        if (ip->task_sig[t] != KB_NONE && ip->task_sig[t] >= ip->n_sigs) throw EngineError(KB_E_INVALID, "inter-pod: task_sig out of range");
-      }
-      if (e->pol.nodeorder_enabled && (e->pol.wPA < 0 || 10ll * ((long long)e->pol.wL + e->pol.wM + e->pol.wB + e->pol.wNA + e->pol.wPA) > 65535))
-        throw EngineError(KB_E_UNSUPPORTED, "nodeorder weights (with podaffinity.weight) exceed the 16-bit score range");
-    }
-    hs.t_feas_shape.assign(T, 0);
-    hs.t_row_shape.assign(T, 0);
-    std::vector<double> key;
-    for (uint32_t t = 0; t < T; t++) {
-      if (hs.t_status[t] > KB_TASK_UNKNOWN) throw EngineError(KB_E_INVALID, "bad task status");
-      if (sn->task_nz_cpu[t] < 0 || sn->task_nz_mem[t] < 0 || sn->task_nz_cpu[t] >= (1ll << 48) || sn->task_nz_mem[t] >= (1ll << 48))
-        throw EngineError(KB_E_UNSUPPORTED, "task non-zero request out of the exact range");
-      Res rq, in;
-      rq.mask = hs.t_resmask[t];
-      for (int d = 0; d < R; d++) {
-        rq.v[d] = hs.t_res[(size_t)d * T + t];
-        in.v[d] = hs.t_init[(size_t)d * T + t];
-        if (rq.v[d] < 0 || in.v[d] < 0) throw EngineError(KB_E_INVALID, "negative request");
-        // api/pod_info.go:53-62: InitResreq = max(sum of containers, every init container) >= Resreq per dimension;
-        // without it ssn.Allocate's AddTask could fail after the status flip (session.go:243 vs :255)
-        if (in.v[d] < rq.v[d]) throw EngineError(KB_E_UNSUPPORTED, "InitResreq < Resreq");
-        if (d >= 2 && in.v[d] != 0.0) in.setk(d);
-        if (d >= 2 && in.v[d] > kMinMilliScalar) t_active[t] |= 1u << d;
-      }
-      in.mask |= rq.mask;
-      hs.t_res_empty[t] = res_is_empty(rq, R);
-      hs.t_init_empty[t] = res_is_empty(in, R);
-      key.assign(in.v, in.v + R);
-      // a BestEffort task is placed by backfill, whose only resource test is AddTask's Resreq.LessEqual(Idle)
-      // (api/node_info.go:161-167): its fit vector is Resreq cpu / memory (non-zero below the epsilon at most), see t_fit below
-      key.push_back(hs.t_init_empty[t] ? rq.v[0] : -1.0);
-      key.push_back(hs.t_init_empty[t] ? rq.v[1] : -1.0);
-      key.push_back((double)hs.t_cls[t]);
-      {   // host ports: the conflict mask is part of feasibility, the wanted bits of what a commit changes
-        const uint64_t conf = sn->task_port_conflict ? sn->task_port_conflict[t] : 0, want = sn->task_port_want ? sn->task_port_want[t] : 0;
-        key.push_back((double)(uint32_t)(conf & 0xFFFFFFFFu)); key.push_back((double)(uint32_t)(conf >> 32));
-        if (ip) {   // inter-pod predicate checks are part of feasibility
-          const uint32_t Wc = ip->n_counters ? (ip->n_counters + 63) / 64 : 1;
-          for (uint32_t w = 0; w < Wc; w++) {
-            const uint64_t fb = ip->task_forbid[(size_t)t * Wc + w];
-            key.push_back((double)(uint32_t)(fb & 0xFFFFFFFFu)); key.push_back((double)(uint32_t)(fb >> 32));
-          }
-          key.push_back((double)ip->task_require[t]); key.push_back((double)(ip->task_require[t] != 0xFFFF ? ip->task_self[t] : 0));
-        }
-        hs.t_feas_shape[t] = feas_ids.intern(key);
-        key.push_back((double)(uint32_t)(want & 0xFFFFFFFFu)); key.push_back((double)(uint32_t)(want >> 32));
-      }
-      key.push_back((double)sn->task_nz_cpu[t]);
-      key.push_back((double)sn->task_nz_mem[t]);
-      if (ip) key.push_back((double)ip->task_sig[t]);   // ... and the priority weights of the score row
-      hs.t_row_shape[t] = row_ids.intern(key);
-    }
-    hs.n_feas_shapes = (uint32_t)feas_ids.size();
-    hs.n_row_shapes = (uint32_t)row_ids.size();
-    // per feasibility shape: the vector LessEqual actually compares (scalar dimensions at or below the epsilon are skipped,
-    // resource_info.go:283-287) and the static class, for the dominance rule of ActionRun::mark_dead
-    hs.feas_eff.assign((size_t)hs.n_feas_shapes * R, 0.0);
-    hs.feas_cls.assign(hs.n_feas_shapes, 0);
-    hs.feas_conf.assign(hs.n_feas_shapes, 0);
-    hs.feas_rep.assign(hs.n_feas_shapes, 0);
-    for (uint32_t t = T; t-- > 0;) hs.feas_rep[hs.t_feas_shape[t]] = t;
-    hs.has_interpod = ip != nullptr;
-    hs.t_ip_subject.clear(); hs.feas_ip_require.clear(); hs.feas_ip.clear();
-    if (ip) {
-      hs.t_ip_subject.assign(T, 0);
-      hs.feas_ip_require.assign(hs.n_feas_shapes, 0);
-      hs.feas_ip.assign(hs.n_feas_shapes, 0);
-      Interner ipk;
-      const uint32_t Wc = ip->n_counters ? (ip->n_counters + 63) / 64 : 1;
-      std::vector<double> k3(2 * Wc + 2);
-      hs.t_ip_checks.assign(T, 0);
-      for (uint32_t t = 0; t < T; t++) {
-        bool checks = ip->task_require[t] != 0xFFFF;
-        for (uint32_t w = 0; w < Wc; w++) {
-          const uint64_t fb = ip->task_forbid[(size_t)t * Wc + w];
-          checks = checks || fb != 0;
-          k3[2 * w] = (double)(uint32_t)(fb & 0xFFFFFFFFu); k3[2 * w + 1] = (double)(uint32_t)(fb >> 32);
-        }
-        hs.t_ip_checks[t] = checks ? 1 : 0;
-        hs.t_ip_subject[t] = (checks || ip->task_sig[t] != KB_NONE) ? 1 : 0;
-        const uint32_t f = hs.t_feas_shape[t];
-        hs.feas_ip_require[f] = ip->task_require[t] != 0xFFFF ? 1 : 0;
-        k3[2 * Wc] = (double)ip->task_require[t]; k3[2 * Wc + 1] = (double)(ip->task_require[t] != 0xFFFF ? ip->task_self[t] : 0);
-        hs.feas_ip[f] = ipk.intern(k3);
-      }
-    }
-    for (uint32_t t = 0; t < T; t++) {
-      const uint32_t f = hs.t_feas_shape[t];
-      hs.feas_cls[f] = hs.t_cls[t];
-      hs.feas_conf[f] = sn->task_port_conflict ? sn->task_port_conflict[t] : 0;
-      for (int d = 0; d < R; d++)
-        hs.feas_eff[(size_t)f * R + d] = (d < 2 || ((t_active[t] >> d) & 1u)) ? hs.t_init[(size_t)d * T + t] : 0.0;
-    }
+    hipStream_t s = e->stream;
+    e->evictions.clear();
 
-    // ---- plugin OnSessionOpen state ----
-    // drf.go:60-64 / proportion.go:58-62: total = sum of Allocatable over ssn.Nodes (ascending node name)
-    hs.total = Res();
-    std::vector<uint32_t> nmask(NP, 0);
-    for (uint32_t n = 0; n < N; n++) {
-      Res a;
-      a.mask = sn->node_scalar_mask ? sn->node_scalar_mask[n] : 0;
-      nmask[n] = a.mask & 0x3FFFFFFFu;
-      for (int d = 2; d < R; d++)   // Releasing gains scalar keys only through Add of a Releasing task's Resreq: dense non-zero <=> key present
-        if (sn->node_releasing[(size_t)d * N + n] != 0.0) nmask[n] |= 0x80000000u;
-      for (int d = 0; d < R; d++) a.v[d] = (d < 2 || a.has(d)) ? sn->node_allocatable[(size_t)d * N + n] : 0.0;
-      res_add(hs.total, a, R);
-    }
-    // proportion.go:65-154 water-filling over the queues that own a job, ascending QueueID
-    hs.deserved.assign(Q, Res());
-    hs.queue_has_attr.assign(Q, 0);
-    std::vector<Res> request(Q), allocated(Q);
-    for (uint32_t j = 0; j < J; j++) {
-      uint32_t q = hs.job_queue[j];
-      if (q >= Q) continue;
-      hs.queue_has_attr[q] = 1;
-      for (uint32_t t = hs.job_begin[j]; t < hs.job_begin[j + 1]; t++) {
-        int st = hs.t_status[t];
-        bool alloc_st = st == KB_TASK_BOUND || st == KB_TASK_BINDING || st == KB_TASK_RUNNING || st == KB_TASK_ALLOCATED;
-        if (!alloc_st && st != KB_TASK_PENDING) continue;
-        Res rq;
-        rq.mask = hs.t_resmask[t];
-        for (int d = 0; d < R; d++) rq.v[d] = hs.t_res[(size_t)d * T + t];
-        res_add(request[q], rq, R);
-        if (alloc_st) res_add(allocated[q], rq, R);
-      }
-    }
-    hs.queue_share_at_open = 1;
-    if (e->pol.has_proportion) {
-      Res remaining = hs.total;
-      std::vector<uint8_t> meet(Q, 0);
-      for (bool first = true;; first = false) {
-        int32_t totalWeight = 0;
-        for (uint32_t q = 0; q < Q; q++)
-          if (hs.queue_has_attr[q] && !meet[q]) totalWeight += hs.queue_weight[q];
-        if (totalWeight == 0) {
-          if (first) hs.queue_share_at_open = 0;   // proportion.go:113-116: no updateShare ran, shares stay 0 until an event
-          break;
-        }
-        Res increasedDeserved, decreasedDeserved;
-        for (uint32_t q = 0; q < Q; q++) {
-          if (!hs.queue_has_attr[q] || meet[q]) continue;
-          Res oldDeserved = hs.deserved[q];
-          Res part = remaining;
-          res_multi(part, (double)hs.queue_weight[q] / (double)totalWeight, R);
-          res_add(hs.deserved[q], part, R);
-          if (res_less(request[q], hs.deserved[q], R)) {
-            hs.deserved[q] = helpers_min(hs.deserved[q], request[q], R);
-            meet[q] = 1;
-          }
-          Res inc, dec;
-          res_diff(hs.deserved[q], oldDeserved, inc, dec, R);
-          res_add(increasedDeserved, inc, R);
-          res_add(decreasedDeserved, dec, R);
-        }
-        if (!res_sub(remaining, increasedDeserved, R))
-          throw EngineError(KB_E_UNSUPPORTED, "proportion water-filling underflow (the reference would panic in Resource.Sub)");
-        res_add(remaining, decreasedDeserved, R);
-        if (res_is_empty(remaining, R)) break;
-      }
-    }
 
     // ---- device upload ----
     KbDev &d = e->dev;
@@ -1579,6 +1239,7 @@ int kb_session_reset(kb_engine *e) {
     e->mg = nullptr;
     std::fill(e->hs.queue_share_live.begin(), e->hs.queue_share_live.end(), e->hs.queue_share_at_open);
     e->evictions.clear();
+    e->hs.t_off_node.clear();
     double keep = e->stats.reduce_ms;
     run_finalize(e);
     e->stats.reduce_ms = keep;
@@ -1764,6 +1425,7 @@ static int run_evict_action(kb_engine *e, bool reclaim, kb_stmt_op *out, uint64_
     upload_live_nodes(e, ln, pm.touched_nodes);
     hs.t_status = status;
     hs.t_node = tnode;
+    pm.off_node_tasks(hs.t_off_node);
     if (T) {
       HIP_OK(hipMemcpy(e->b_tstatus.p, status.data(), T, hipMemcpyHostToDevice));
       HIP_OK(hipMemcpy(e->b_tnode.p, tnode.data(), sizeof(uint32_t) * T, hipMemcpyHostToDevice));

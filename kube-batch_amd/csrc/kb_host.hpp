@@ -145,6 +145,10 @@ struct HostSession {
   std::vector<int32_t> t_prio;
   std::vector<int64_t> t_creation;
   std::vector<uint8_t> t_status;
+  // [T] (empty: none) the task carries a NodeName but is NOT in that node's Tasks: un-pipelined by a discarded preempt statement, or
+  // pipelined while the stale name made AddTask fail (api/node_info.go:217-243 never clears NodeName; statement.go:113-150 only logs
+  // the AddTask error).  Status and NodeName alone cannot tell these from tasks that sit on their node, so it is kept between actions.
+  std::vector<uint8_t> t_off_node;
   std::vector<uint8_t> t_res_empty;       // Resreq.IsEmpty()   (allocate.go:114)
   std::vector<uint8_t> t_init_empty;      // InitResreq.IsEmpty() (backfill.go:47)
   std::vector<uint32_t> t_feas_shape;     // id of (InitResreq, class): tasks sharing it share a feasibility row
@@ -192,6 +196,10 @@ struct HostSession {
   std::vector<double> queue_share;         // [Q]
   std::vector<int32_t> job_ready;          // [J] ReadyTaskNum
 };
+
+// kb_session.cpp: the host half of kb_engine_create / kb_session_load (no device code; also built into the CPU test harnesses)
+Policy compile_policy(const kb_config *cfg);
+void build_host_session(const kb_snapshot *sn, const Policy &pol, uint32_t NP, HostSession &hs, std::vector<uint32_t> &t_active, std::vector<uint32_t> &nmask);
 
 enum class Outcome { Allocated, Pipelined, NoFeasibleNode };
 

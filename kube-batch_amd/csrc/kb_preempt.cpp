@@ -535,7 +535,7 @@ void PreemptMachine::init(const HostSession *hs, const Policy *pol, LiveNodes *l
   ntasks_.assign(N, {});
   for (uint32_t t = 0; t < T; t++) {
     node_status[t] = (*status)[t];
-    if ((*tnode)[t] != KB_NONE && (*tnode)[t] < N) { on_node[t] = 1; ntasks_[(*tnode)[t]].push_back(t); }
+    if ((*tnode)[t] != KB_NONE && (*tnode)[t] < N && !(!hs->t_off_node.empty() && hs->t_off_node[t])) { on_node[t] = 1; ntasks_[(*tnode)[t]].push_back(t); }
   }
   nd_->base_ports.assign(N, 0);
   if (!hs->t_want.empty())
@@ -565,6 +565,16 @@ void PreemptMachine::init(const HostSession *hs, const Policy *pol, LiveNodes *l
       for (uint32_t n = 0; n < N; n++)
         if (qn_minprio_[(size_t)q * N + n] != INT_MAX) qnodes_[q].push_back(n);
   }
+}
+
+// tasks that end the action with a NodeName but outside that node's Tasks (HostSession::t_off_node); empty when there are none
+void PreemptMachine::off_node_tasks(std::vector<uint8_t> &off) const {
+  off.clear();
+  for (uint32_t t = 0; t < hs_->T; t++)
+    if ((*tnode_)[t] != KB_NONE && !on_node[t]) {
+      if (off.empty()) off.assign(hs_->T, 0);
+      off[t] = 1;
+    }
 }
 
 // preemptAction.Execute (preempt.go:45-168).  Canonical orders where the reference ranges over Go maps: queues ascending

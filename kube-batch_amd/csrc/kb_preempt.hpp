@@ -44,6 +44,7 @@ class PreemptMachine {
   void init(const HostSession *hs, const Policy *pol, LiveNodes *live, std::vector<uint8_t> *status, std::vector<uint32_t> *tnode,
             ListFn lists, RefreshFn refresh);
   void run();           // the preempt action
+  void off_node_tasks(std::vector<uint8_t> &off) const;   // after run(): what the next action's init() must know (HostSession::t_off_node)
   void run_reclaim();   // the reclaim action (actions/reclaim/reclaim.go:41-193): no Statement, ssn.Evict / ssn.Pipeline act at once
 
   std::vector<StmtOp> ops;             // every Evict / Pipeline / Commit / Discard, in order

@@ -1,16 +1,19 @@
 #!/usr/bin/env bash
-# AddressSanitizer + UndefinedBehaviorSanitizer pass over the CPU-side C/C++ of the test infrastructure and the engine's host
-# order machine: the oracle (oracle/kb_oracle.c) and kube-batch_amd/csrc/kb_order.cpp behind tests/host_harness.  The HIP part of
-# the engine needs a device and is not covered.  Usage: scripts/sanitize_cpu.sh   (prints pytest's summary; any report aborts).
+# AddressSanitizer + UndefinedBehaviorSanitizer pass over the CPU-side C/C++ of the test infrastructure and the engine's host code:
+# the oracle (oracle/kb_oracle.c), kube-batch_amd/csrc/kb_order.cpp (order machine) and kb_session.cpp + kb_preempt.cpp (policy
+# compiler, session build, evict actions) behind tests/host_harness.  The HIP part of the engine needs a device and is not covered.  Usage: scripts/sanitize_cpu.sh   (prints pytest's summary; any report aborts).
 set -euo pipefail
 cd "$(dirname "$0")/.."
 out=$(mktemp -d)
 san="-O1 -g -fPIC -shared -ffp-contract=off -fsanitize=address,undefined -fno-omit-frame-pointer"
 gcc -std=c11 $san -o "$out/libkboracle.so" oracle/kb_oracle.c -lm -lpthread
 g++ -std=c++17 $san -o "$out/liborderharness.so" tests/host_harness/order_harness.cpp kube-batch_amd/csrc/kb_order.cpp
-ASAN_OPTIONS=detect_leaks=0 LD_PRELOAD="$(gcc -print-file-name=libasan.so)" \
-KB_ORACLE_LIB="$out/libkboracle.so" KB_ORDER_HARNESS_LIB="$out/liborderharness.so" \
-  python -m pytest tests/test_oracle_kat.py tests/test_oracle_independent.py tests/test_pyref_vs_oracle.py tests/test_host_order_cpu.py \
+g++ -std=c++17 $san -o "$out/libevictharness.so" tests/host_harness/evict_harness.cpp kube-batch_amd/csrc/kb_session.cpp kube-batch_amd/csrc/kb_preempt.cpp
+# libstdc++ is preloaded too: ASan resolves its __cxa_throw interceptor at start-up, and python itself does not link the C++ runtime
+# (the harnesses throw EngineError where the engine answers KB_E_UNSUPPORTED)
+ASAN_OPTIONS=detect_leaks=0 LD_PRELOAD="$(gcc -print-file-name=libasan.so) $(g++ -print-file-name=libstdc++.so.6)" \
+KB_ORACLE_LIB="$out/libkboracle.so" KB_ORDER_HARNESS_LIB="$out/liborderharness.so" KB_EVICT_HARNESS_LIB="$out/libevictharness.so" \
+  python -m pytest tests/test_oracle_kat.py tests/test_oracle_independent.py tests/test_pyref_vs_oracle.py tests/test_host_order_cpu.py tests/test_host_evict_cpu.py \
     tests/test_interpod_oracle_cpu.py tests/test_manifests_cpu.py \
     -x -q -p no:cacheprovider "$@"
 # ThreadSanitizer over the oracle's worker pool (the cpu_baseline leg's 16-way fan-out)

@@ -113,6 +113,23 @@ def test_preempt_on_random_clusters(oracle_mod, seed):
     _run_both(oracle_mod, cfg, snap, order, seed)
 
 
+@pytest.mark.parametrize("seed", range(36))
+def test_consecutive_evict_actions(oracle_mod, seed):
+    """preempt / reclaim back to back: what a discarded statement leaves behind (a NodeName on a task that is on no node) must survive
+    from one action to the next (HostSession::t_off_node; found by tests/test_host_evict_cpu.py)."""
+    cfg, snap, _ = cases._evict_case(seed)
+    order = cases.EVICT_ORDERS[2 + seed % 4]
+    _run_both(oracle_mod, cfg, snap, order, seed)
+
+
+@pytest.mark.parametrize("seed", range(64))
+def test_evict_actions_under_other_tier_layouts(oracle_mod, seed):
+    """cases.EVICT_CONFS: the victim rules in other tiers (no priority rule: the whole cached list is walked and the dirty nodes are
+    merged into it), bin-packing weights, reclaim decided by proportion."""
+    cfg, snap, order = cases._evict_variant(seed)
+    _run_both(oracle_mod, cfg, snap, order, seed)
+
+
 @pytest.mark.parametrize("scale,idx", [(0.02, 3), (0.05, 3), (0.01, 4), (0.002, 5), (0.05, 5)])
 def test_preempt_after_allocate_on_scaled_baseline_configs(oracle_mod, scale, idx):
     """BASELINE configs[4] names allocate + backfill + preempt: the three actions in that order on scaled snapshots."""
