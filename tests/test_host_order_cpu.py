@@ -33,7 +33,9 @@ def harness():
     srcs = [os.path.join(HERE, "host_harness", "order_harness.cpp"), os.path.join(HERE, "..", "kube-batch_amd", "csrc", "kb_order.cpp")]
     deps = srcs + [os.path.join(HERE, "..", "kube-batch_amd", "csrc", "kb_host.hpp")]
     if not os.path.exists(so) or any(os.path.getmtime(d) > os.path.getmtime(so) for d in deps):
-        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-fno-fast-math", "-o", so] + srcs)
+        tmp = f"{so}.{os.getpid()}"                          # atomic: several pytest workers may build at once
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-fno-fast-math", "-o", tmp] + srcs)
+        os.replace(tmp, so)
     return _bind(C.CDLL(so))
 
 
