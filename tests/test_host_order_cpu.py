@@ -46,7 +46,7 @@ def _bind(L):
 
 
 def _policy(cfg):
-    """compile_policy (kube-batch_amd/csrc/kb_engine.cpp) restated for the harness."""
+    """compile_policy (kube-batch_amd/csrc/kb_session.cpp) restated for this harness (tests/test_host_evict_cpu.py runs the real one)."""
     chain, pol = [], dict(qprop=0, tprio=0, gready=0, gang=0, drf=0, prop=0)
     for tier in cfg.tiers:
         for po in tier:
