@@ -29,6 +29,10 @@ REFRESH_FN = C.CFUNCTYPE(None, C.POINTER(C.c_uint32), C.c_uint32, C.POINTER(C.c_
 
 @pytest.fixture(scope="module")
 def harness():
+    return load_harness()
+
+
+def load_harness():
     if os.environ.get("KB_EVICT_HARNESS_LIB"):               # an instrumented build (scripts/sanitize_cpu.sh)
         return _bind(C.CDLL(os.environ["KB_EVICT_HARNESS_LIB"]))
     out_dir = os.path.join(HERE, "host_harness", "build")
