@@ -219,7 +219,9 @@ typedef struct kb_snapshot {
   const int32_t  *task_priority;      /* [T] TaskInfo.Priority */
   const int64_t  *task_creation;      /* [T] pod CreationTimestamp (seconds) */
   const uint8_t  *task_status;        /* [T] KB_TASK_* */
-  const uint32_t *task_node;          /* [T] node index for placed tasks, KB_NONE otherwise */
+  const uint32_t *task_node;          /* [T] node index for placed tasks, KB_NONE otherwise.  Set <=> the task is in that node's
+                                         ni.Tasks: a task left with a NodeName but on no node (by a discarded or failed Statement
+                                         step of an earlier action) cannot be expressed; the flatteners refuse such a session */
 
   /* jobs: api.JobInfo (job_info.go:127-154); tasks of job j are [job_task_begin[j], job_task_begin[j+1]) */
   const uint32_t *job_task_begin;     /* [J+1] */

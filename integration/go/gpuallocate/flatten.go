@@ -502,6 +502,18 @@ func flatten(ssn *framework.Session) (*flat, error) {
 				f.free()
 				return nil, errUnsupported("pending task with a stale NodeName (un-pipelined by a discarded statement)")
 			}
+			if ti.NodeName != "" {
+				// The snapshot says "task_node set <=> the task is in that node's Tasks".  A statement that pipelined a task carrying a
+				// stale NodeName only logs the failed AddTask (statement.go:113-150): the task is then Pipelined, named after its old
+				// host and on no node at all — a state the arrays cannot express (inside one loaded session the engine tracks it
+				// itself: HostSession::t_off_node).
+				if node, ok := ssn.Nodes[ti.NodeName]; ok {
+					if _, on := node.Tasks[api.PodKey(ti.Pod)]; !on {
+						f.free()
+						return nil, errUnsupported("task carries a NodeName but is not in that node's Tasks (failed AddTask of an earlier statement)")
+					}
+				}
+			}
 			key, err := taskClassKey(ti, pf)
 			if err != nil {
 				f.free()
