@@ -113,14 +113,16 @@ void build_host_session(const kb_snapshot *sn, const Policy &pol, uint32_t NP, H
   hs.t_resmask.assign(T, 0);
   if (sn->task_scalar_mask) hs.t_resmask.assign(sn->task_scalar_mask, sn->task_scalar_mask + T);
   // a dense value under an absent key reads 0 (Go map semantics)
-  for (uint32_t t = 0; t < T; t++)
-    for (int d = 2; d < R; d++)
-      if (!((hs.t_resmask[t] >> (d - 2)) & 1u)) hs.t_res[(size_t)d * T + t] = 0.0;
+  for (int d = 2; d < R; d++) {   // one dimension's row at a time: sequential in the dimension-major layout
+    double *row = &hs.t_res[(size_t)d * T];
+    for (uint32_t t = 0; t < T; t++)
+      if (!((hs.t_resmask[t] >> (d - 2)) & 1u)) row[t] = 0.0;
+  }
   // task-major copy for the order machine: one task's Resreq is read per scheduling step, and with the dimension-major
-  // device layout that is R cache misses per step
+  // device layout that is R cache misses per step (written sequentially here, read from R streams)
   hs.t_res_rows.resize((size_t)T * R);
-  for (int d = 0; d < R; d++)
-    for (uint32_t t = 0; t < T; t++) hs.t_res_rows[(size_t)t * R + d] = hs.t_res[(size_t)d * T + t];
+  for (uint32_t t = 0; t < T; t++)
+    for (int d = 0; d < R; d++) hs.t_res_rows[(size_t)t * R + d] = hs.t_res[(size_t)d * T + t];
   hs.t_job.assign(sn->task_job, sn->task_job + T);
   hs.t_cls.assign(T, 0);
   if (sn->task_class) hs.t_cls.assign(sn->task_class, sn->task_class + T);
@@ -207,9 +209,37 @@ void build_host_session(const kb_snapshot *sn, const Policy &pol, uint32_t NP, H
   }
   hs.t_feas_shape.assign(T, 0);
   hs.t_row_shape.assign(T, 0);
-  std::vector<double> key;
+  // The tasks of a job are adjacent and nearly always identical in everything a shape depends on.  A task whose inputs equal its
+  // predecessor's bit for bit (what the interner compares) takes over the predecessor's derived values; one whose key equals the
+  // predecessor's takes its ids without a hash lookup.  Either way the ids are the ones a lookup would return.
+  std::vector<double> key, prev;
+  size_t prev_feas_len = 0;
+  const uint32_t ipWc = ip ? (ip->n_counters ? (ip->n_counters + 63) / 64 : 1) : 0;
+  auto same_bits = [](double a, double b) { return std::memcmp(&a, &b, sizeof(double)) == 0; };
+  auto same_inputs_as_prev = [&](uint32_t t) {
+    const uint32_t p = t - 1;
+    for (int d = 0; d < R; d++)
+      if (!same_bits(hs.t_res[(size_t)d * T + t], hs.t_res[(size_t)d * T + p]) || !same_bits(hs.t_init[(size_t)d * T + t], hs.t_init[(size_t)d * T + p])) return false;
+    if (hs.t_resmask[t] != hs.t_resmask[p] || hs.t_cls[t] != hs.t_cls[p]) return false;
+    if (sn->task_nz_cpu[t] != sn->task_nz_cpu[p] || sn->task_nz_mem[t] != sn->task_nz_mem[p]) return false;
+    if (sn->task_port_conflict && sn->task_port_conflict[t] != sn->task_port_conflict[p]) return false;
+    if (sn->task_port_want && sn->task_port_want[t] != sn->task_port_want[p]) return false;
+    if (ip) {
+      if (std::memcmp(ip->task_forbid + (size_t)t * ipWc, ip->task_forbid + (size_t)p * ipWc, sizeof(uint64_t) * ipWc) != 0) return false;
+      if (ip->task_require[t] != ip->task_require[p] || ip->task_self[t] != ip->task_self[p] || ip->task_sig[t] != ip->task_sig[p]) return false;
+    }
+    return true;
+  };
   for (uint32_t t = 0; t < T; t++) {
     if (hs.t_status[t] > KB_TASK_UNKNOWN) throw EngineError(KB_E_INVALID, "bad task status");
+    if (t > 0 && same_inputs_as_prev(t)) {   // the predecessor passed every check below with these very values
+      t_active[t] = t_active[t - 1];
+      hs.t_res_empty[t] = hs.t_res_empty[t - 1];
+      hs.t_init_empty[t] = hs.t_init_empty[t - 1];
+      hs.t_feas_shape[t] = hs.t_feas_shape[t - 1];
+      hs.t_row_shape[t] = hs.t_row_shape[t - 1];
+      continue;
+    }
     if (sn->task_nz_cpu[t] < 0 || sn->task_nz_mem[t] < 0 || sn->task_nz_cpu[t] >= (1ll << 48) || sn->task_nz_mem[t] >= (1ll << 48))
       throw EngineError(KB_E_UNSUPPORTED, "task non-zero request out of the exact range");
     Res rq, in;
@@ -233,6 +263,8 @@ void build_host_session(const kb_snapshot *sn, const Policy &pol, uint32_t NP, H
     key.push_back(hs.t_init_empty[t] ? rq.v[0] : -1.0);
     key.push_back(hs.t_init_empty[t] ? rq.v[1] : -1.0);
     key.push_back((double)hs.t_cls[t]);
+    size_t feas_len = 0;
+    bool same_feas = false;
     {   // host ports: the conflict mask is part of feasibility, the wanted bits of what a commit changes
       const uint64_t conf = sn->task_port_conflict ? sn->task_port_conflict[t] : 0, want = sn->task_port_want ? sn->task_port_want[t] : 0;
       key.push_back((double)(uint32_t)(conf & 0xFFFFFFFFu)); key.push_back((double)(uint32_t)(conf >> 32));
@@ -244,13 +276,19 @@ void build_host_session(const kb_snapshot *sn, const Policy &pol, uint32_t NP, H
         }
         key.push_back((double)ip->task_require[t]); key.push_back((double)(ip->task_require[t] != 0xFFFF ? ip->task_self[t] : 0));
       }
-      hs.t_feas_shape[t] = feas_ids.intern(key);
+      feas_len = key.size();
+      same_feas = t > 0 && prev_feas_len == feas_len && std::memcmp(prev.data(), key.data(), feas_len * sizeof(double)) == 0;
+      hs.t_feas_shape[t] = same_feas ? hs.t_feas_shape[t - 1] : feas_ids.intern(key);
       key.push_back((double)(uint32_t)(want & 0xFFFFFFFFu)); key.push_back((double)(uint32_t)(want >> 32));
     }
     key.push_back((double)sn->task_nz_cpu[t]);
     key.push_back((double)sn->task_nz_mem[t]);
     if (ip) key.push_back((double)ip->task_sig[t]);   // ... and the priority weights of the score row
-    hs.t_row_shape[t] = row_ids.intern(key);
+    const bool same_row = same_feas && prev.size() == key.size() &&
+                          std::memcmp(prev.data() + feas_len, key.data() + feas_len, (key.size() - feas_len) * sizeof(double)) == 0;
+    hs.t_row_shape[t] = same_row ? hs.t_row_shape[t - 1] : row_ids.intern(key);
+    prev.swap(key);
+    prev_feas_len = feas_len;
   }
   hs.n_feas_shapes = (uint32_t)feas_ids.size();
   hs.n_row_shapes = (uint32_t)row_ids.size();
@@ -286,8 +324,8 @@ void build_host_session(const kb_snapshot *sn, const Policy &pol, uint32_t NP, H
       hs.feas_ip[f] = ipk.intern(k3);
     }
   }
-  for (uint32_t t = 0; t < T; t++) {
-    const uint32_t f = hs.t_feas_shape[t];
+  for (uint32_t f = 0; f < hs.n_feas_shapes; f++) {   // every task of a shape carries the same values (they are its key)
+    const uint32_t t = hs.feas_rep[f];
     hs.feas_cls[f] = hs.t_cls[t];
     hs.feas_conf[f] = sn->task_port_conflict ? sn->task_port_conflict[t] : 0;
     for (int d = 0; d < R; d++)
@@ -310,7 +348,7 @@ void build_host_session(const kb_snapshot *sn, const Policy &pol, uint32_t NP, H
   // proportion.go:65-154 water-filling over the queues that own a job, ascending QueueID
   hs.deserved.assign(Q, Res());
   hs.queue_has_attr.assign(Q, 0);
-  std::vector<Res> request(Q), allocated(Q);
+  std::vector<Res> request(Q);
   for (uint32_t j = 0; j < J; j++) {
     uint32_t q = hs.job_queue[j];
     if (q >= Q) continue;
@@ -319,11 +357,13 @@ void build_host_session(const kb_snapshot *sn, const Policy &pol, uint32_t NP, H
       int st = hs.t_status[t];
       bool alloc_st = st == KB_TASK_BOUND || st == KB_TASK_BINDING || st == KB_TASK_RUNNING || st == KB_TASK_ALLOCATED;
       if (!alloc_st && st != KB_TASK_PENDING) continue;
-      Res rq;
-      rq.mask = hs.t_resmask[t];
-      for (int d = 0; d < R; d++) rq.v[d] = hs.t_res[(size_t)d * T + t];
-      res_add(request[q], rq, R);
-      if (alloc_st) res_add(allocated[q], rq, R);
+      // Resource.Add (resource_info.go:128-140), task by task in this order: cpu and memory always, a scalar where the task has the key
+      Res &rq = request[q];
+      rq.v[0] += hs.t_res[t];
+      rq.v[1] += hs.t_res[(size_t)T + t];
+      const uint32_t m = hs.t_resmask[t];
+      for (int d = 2; m != 0 && d < R; d++)
+        if ((m >> (d - 2)) & 1u) { rq.setk(d); rq.v[d] += hs.t_res[(size_t)d * T + t]; }
     }
   }
   hs.queue_share_at_open = 1;

@@ -192,4 +192,28 @@ void eh_session(const EH *h, double *deserved, double *total, uint32_t *feas_sha
   n_shapes[1] = h->hs.n_row_shapes;
 }
 
+// FNV-1a over everything the session build leaves in the HostSession (and its two side outputs): two builds of the same snapshot
+// agree on this iff they agree on every derived array (used to compare an optimised build with its predecessor)
+uint64_t eh_digest(const EH *h) {
+  uint64_t x = 1469598103934665603ull;
+  auto mix = [&](const void *p, size_t n) {
+    const unsigned char *b = static_cast<const unsigned char *>(p);
+    for (size_t i = 0; i < n; i++) { x ^= b[i]; x *= 1099511628211ull; }
+    x ^= n; x *= 1099511628211ull;
+  };
+  auto vec = [&](const auto &v) { mix(v.data(), v.size() * sizeof(v[0])); };
+  const HostSession &s = h->hs;
+  vec(s.t_res); vec(s.t_init); vec(s.t_res_rows); vec(s.t_resmask); vec(s.t_job); vec(s.t_cls); vec(s.t_node); vec(s.t_prio); vec(s.t_creation);
+  vec(s.t_status); vec(s.t_res_empty); vec(s.t_init_empty); vec(s.t_feas_shape); vec(s.t_row_shape); vec(s.feas_eff); vec(s.feas_rep);
+  vec(s.feas_cls); vec(s.feas_conf); vec(s.job_begin); vec(s.job_queue); vec(s.job_min); vec(s.job_prio); vec(s.job_creation);
+  vec(s.queue_weight); vec(s.queue_creation); vec(s.t_nzc); vec(s.t_nzm); vec(s.t_want); vec(s.t_conf); vec(s.t_protected); vec(s.n_ac);
+  vec(s.n_am); vec(s.n_maxpods); vec(s.n_cls); vec(s.n_idle_mask); vec(s.compat); vec(s.t_ip_subject); vec(s.t_ip_checks);
+  vec(s.feas_ip_require); vec(s.feas_ip); vec(s.queue_has_attr); vec(h->t_active); vec(h->nmask);
+  mix(s.total.v, sizeof(s.total.v)); mix(&s.total.mask, sizeof(uint32_t)); mix(&s.queue_share_at_open, 1);
+  for (const Res &r : s.deserved) { mix(r.v, sizeof(r.v)); mix(&r.mask, sizeof(uint32_t)); }
+  const uint32_t n[4] = {s.n_feas_shapes, s.n_row_shapes, s.n_tc, s.n_nc};
+  mix(n, sizeof(n));
+  return x;
+}
+
 }  // extern "C"

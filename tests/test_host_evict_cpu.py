@@ -65,6 +65,8 @@ def _bind(L):
     L.eh_node_state.argtypes = [vp, vp, vp, vp, vp, vp]
     L.eh_shares.argtypes = [vp, vp, vp]
     L.eh_session.argtypes = [vp, vp, vp, vp, vp, vp]
+    L.eh_digest.argtypes = [vp]
+    L.eh_digest.restype = C.c_uint64
     return L
 
 
@@ -171,6 +173,9 @@ class HostEngine:
         fs, rs, ns = np.zeros(max(T, 1), np.uint32), np.zeros(max(T, 1), np.uint32), np.zeros(2, np.uint32)
         self.L.eh_session(self.h, _vp(des), _vp(tot), _vp(fs), _vp(rs), _vp(ns))
         return des[:Q], tot, fs[:T], rs[:T], ns
+
+    def digest(self):
+        return int(self.L.eh_digest(self.h))
 
     def close(self):
         if self.h:
@@ -353,3 +358,14 @@ def test_session_build_against_the_python_restatement(harness, seed):
             assert back.setdefault(int(ids[t]), k) == k, (seed, t)       # one id -> equal keys
         assert len(seen) == n
     e.close()
+
+
+def test_session_build_digests_are_pinned(harness):
+    """tests/golden/session_digests.json (made by tests/golden/make_session_digests.py): every array the session build derives, as a
+    digest per snapshot — an optimised kb_session.cpp must reproduce its predecessor bit for bit."""
+    import json
+    import sys
+    sys.path.insert(0, os.path.join(HERE, "golden"))
+    import make_session_digests as gen
+    want = json.load(open(os.path.join(HERE, "golden", "session_digests.json")))
+    assert gen.digests() == want
