@@ -43,6 +43,28 @@ template <typename Less> struct GoHeap {
   }
 };
 
+// The per-job queues of pending tasks (preemptorTasks / reclaim's task queues).  Their keys (priority, creation stamp, index: a strict
+// total order) never change while a task waits, so a priority queue hands them out in sorted order whatever its sift mechanics are:
+// one flat array, each job's segment sorted once, a cursor per job.
+struct TaskQueues {
+  std::vector<uint32_t> items, off, cur;
+  template <typename Less> void build(uint32_t J, const std::vector<uint32_t> &job_begin, const std::vector<uint8_t> &want_job, const std::vector<uint8_t> &status, Less less) {
+    off.assign((size_t)J + 1, 0);
+    items.clear();
+    for (uint32_t j = 0; j < J; j++) {
+      off[j] = (uint32_t)items.size();
+      if (!want_job[j]) continue;
+      for (uint32_t t = job_begin[j]; t < job_begin[j + 1]; t++)
+        if (status[t] == KB_TASK_PENDING) items.push_back(t);
+      std::sort(items.begin() + off[j], items.end(), less);
+    }
+    off[J] = (uint32_t)items.size();
+    cur.assign(off.begin(), off.end() - 1);
+  }
+  bool empty(uint32_t j) const { return cur[j] == off[j + 1]; }
+  uint32_t pop(uint32_t j) { return items[cur[j]++]; }
+};
+
 }  // namespace
 
 Res PreemptMachine::task_res(uint32_t t) const {
@@ -256,17 +278,20 @@ void PreemptMachine::node_update(uint32_t t, int st) {
 }
 
 void PreemptMachine::evict(uint32_t t) {   // statement.go:36-69
+  version_++;
   set_status(t, KB_TASK_RELEASING);
   node_update(t, KB_TASK_RELEASING);
   fire_deallocate(t);
   ops.push_back(StmtOp{KB_OP_EVICT, t, (*tnode_)[t], stmt_no_});
 }
 void PreemptMachine::unevict(uint32_t t) {   // statement.go:83-110
+  version_++;
   set_status(t, KB_TASK_RUNNING);
   node_update(t, KB_TASK_RUNNING);
   fire_allocate(t);
 }
 void PreemptMachine::pipeline(uint32_t t, uint32_t n) {   // statement.go:113-150 (an AddTask error is logged, the handlers still run)
+  version_++;
   set_status(t, KB_TASK_PIPELINED);
   if (node_add(t, n, KB_TASK_PIPELINED)) mark_dirty(n);
   fire_allocate(t);
@@ -275,6 +300,7 @@ void PreemptMachine::pipeline(uint32_t t, uint32_t n) {   // statement.go:113-15
 // ssn.Pipeline (framework/session.go:194-232), what reclaim calls: unlike Statement.Pipeline an AddTask error (a sticky NodeName
 // left by a discarded preempt statement) returns BEFORE the plugin event handlers — the status is Pipelined, nothing else moved
 void PreemptMachine::pipeline_session(uint32_t t, uint32_t n) {
+  version_++;
   set_status(t, KB_TASK_PIPELINED);
   ops.push_back(StmtOp{KB_OP_PIPELINE, t, n, stmt_no_});
   if (!node_add(t, n, KB_TASK_PIPELINED)) return;
@@ -282,6 +308,7 @@ void PreemptMachine::pipeline_session(uint32_t t, uint32_t n) {
   fire_allocate(t);
 }
 void PreemptMachine::unpipeline(uint32_t t) {   // statement.go:155-190; task.NodeName keeps the old host (RemoveTask never clears it)
+  version_++;
   set_status(t, KB_TASK_PENDING);
   if (on_node[t]) { const uint32_t n = (*tnode_)[t]; node_remove(t); mark_dirty(n); }
   fire_deallocate(t);
@@ -461,7 +488,28 @@ bool PreemptMachine::preempt_one(uint32_t preemptor, int mode) {
   evals += hs_->N;
   // with the priority rule in the deciding tier a task of the preemptor's own job can never be a victim
   if (prio_prunes_ && mode == 1) return false;
-  if (dirty_nodes_.size() > 256) {   // too many repaired nodes: bring the device up to date and rebuild the lists on demand
+  // What a preemptor tries depends on its job, its matrix row and its Resreq alone, so when one found nothing AND left everything as it
+  // was (try_node evicts only once the victims are known to cover InitResreq; the version check covers the rounding corner where the
+  // evictions then fall short), the next task of the same job with the same three, met before anything else moved, finds nothing
+  // either.  The tasks of a gang are popped back to back: one walk per job instead of one per task.
+  if (fail_version_ == version_ && fail_mode_ == mode && same_preemptor_class(fail_task_, preemptor)) return false;
+  const uint64_t before = version_;
+  const bool found = preempt_walk(preemptor, mode);
+  if (!found && version_ == before) { fail_version_ = version_; fail_mode_ = mode; fail_task_ = preemptor; }
+  return found;
+}
+
+bool PreemptMachine::same_preemptor_class(uint32_t a, uint32_t b) const {
+  if (a == KB_NONE || hs_->t_job[a] != hs_->t_job[b] || hs_->t_row_shape[a] != hs_->t_row_shape[b] || hs_->t_resmask[a] != hs_->t_resmask[b]) return false;
+  for (int d = 0; d < hs_->R; d++)
+    if (hs_->t_res[(size_t)d * hs_->T + a] != hs_->t_res[(size_t)d * hs_->T + b]) return false;
+  return true;
+}
+
+bool PreemptMachine::preempt_walk(uint32_t preemptor, int mode) {
+  // too many repaired nodes: bring the device up to date and rebuild the lists on demand.  Only the full walk below pays per dirty
+  // node; with the priority rule deciding, a dirty node costs one evaluation when it is a candidate and nothing otherwise.
+  if (dirty_nodes_.size() > 256 && !prio_prunes_) {
     refresh_(dirty_nodes_);
     for (uint32_t n : dirty_nodes_) dirty_[n] = 0;
     dirty_nodes_.clear();
@@ -496,9 +544,12 @@ bool PreemptMachine::preempt_one(uint32_t preemptor, int mode) {
         C.push_back(L[(size_t)rank[n]]);
       }
     }
-    std::sort(C.begin(), C.end(), [](uint64_t a, uint64_t b) { return a > b; });
-    for (uint64_t key : C)
-      if (try_node(preemptor, mode, (uint32_t)key)) return true;
+    // descending key order, lazily: the walk usually ends at one of the first candidates (keys are distinct: the node is part of them)
+    std::make_heap(C.begin(), C.end());
+    for (auto end = C.end(); end != C.begin(); --end) {
+      std::pop_heap(C.begin(), end);
+      if (try_node(preemptor, mode, (uint32_t)*(end - 1))) return true;
+    }
     return false;
   }
   // the nodes changed since the lists were built, re-evaluated against their live state
@@ -528,6 +579,7 @@ void PreemptMachine::init(const HostSession *hs, const Policy *pol, LiveNodes *l
   ops.clear(); evictions.clear(); touched_nodes.clear();
   popped = evals = 0;
   stmt_no_ = 0; stmt_begin_ = 0;
+  version_ = 0; fail_version_ = ~0ull; fail_task_ = KB_NONE; fail_mode_ = -1;
   cnt.assign((size_t)(J ? J : 1) * 10, 0);
   for (uint32_t t = 0; t < T; t++) if (hs->t_job[t] < J) cnt[(size_t)hs->t_job[t] * 10 + (*status)[t]]++;
   node_status.assign(T, 0);
@@ -559,7 +611,14 @@ void PreemptMachine::init(const HostSession *hs, const Policy *pol, LiveNodes *l
   }
   if (prio_prunes_) {
     qn_minprio_.assign((size_t)(Q ? Q : 1) * (N ? N : 1), INT_MAX);
-    for (uint32_t n = 0; n < N; n++) recompute_minprio(n);
+    for (uint32_t n = 0; n < N; n++)   // recompute_minprio(n) without its reset pass (Q strided stores per node: the table is fresh)
+      for (uint32_t t : ntasks_[n]) {
+        if (node_status[t] != KB_TASK_RUNNING) continue;
+        const uint32_t j = hs->t_job[t], q = hs->job_queue[j];
+        if (q >= Q) continue;
+        int32_t &m = qn_minprio_[(size_t)q * N + n];
+        if (hs->job_prio[j] < m) m = hs->job_prio[j];
+      }
     qnodes_.assign(Q ? Q : 1, {});
     for (uint32_t q = 0; q < Q; q++)
       for (uint32_t n = 0; n < N; n++)
@@ -584,7 +643,7 @@ void PreemptMachine::run() {
   auto jl = [this](uint32_t l, uint32_t r) { return job_less(l, r); };
   auto tl = [this](uint32_t l, uint32_t r) { return task_less(l, r); };
   std::vector<GoHeap<decltype(jl)>> qjobs(Q ? Q : 1, GoHeap<decltype(jl)>(jl));   // preemptorsMap
-  std::vector<GoHeap<decltype(tl)>> jtasks(J ? J : 1, GoHeap<decltype(tl)>(tl));  // preemptorTasks
+  TaskQueues jtasks;                                                               // preemptorTasks
   std::vector<uint8_t> qseen(Q ? Q : 1, 0), under(J ? J : 1, 0);
   for (uint32_t j = 0; j < J; j++) {   // preempt.go:55-76
     const uint32_t q = hs_->job_queue[j];
@@ -593,10 +652,9 @@ void PreemptMachine::run() {
     if (cnt[(size_t)j * 10 + KB_TASK_PENDING] != 0) {
       qjobs[q].push(j);
       under[j] = 1;
-      for (uint32_t t = hs_->job_begin[j]; t < hs_->job_begin[j + 1]; t++)
-        if ((*status_)[t] == KB_TASK_PENDING) jtasks[j].push(t);
     }
   }
+  jtasks.build(J, hs_->job_begin, under, *status_, tl);
   for (uint32_t q = 0; q < Q; q++) {
     if (!qseen[q]) continue;
     for (;;) {   // between jobs within the queue (preempt.go:80-139)
@@ -605,8 +663,8 @@ void PreemptMachine::run() {
       bool assigned = false;
       begin_stmt();
       for (;;) {
-        if (jtasks[pj].empty()) break;
-        const uint32_t preemptor = jtasks[pj].pop();
+        if (jtasks.empty(pj)) break;
+        const uint32_t preemptor = jtasks.pop(pj);
         if (preempt_one(preemptor, 0)) assigned = true;
         if (job_pipelined(pj)) { commit(); break; }
       }
@@ -616,8 +674,8 @@ void PreemptMachine::run() {
     for (uint32_t j = 0; j < J; j++) {   // between tasks within a job (preempt.go:142-166)
       if (!under[j]) continue;
       for (;;) {
-        if (jtasks[j].empty()) break;
-        const uint32_t preemptor = jtasks[j].pop();
+        if (jtasks.empty(j)) break;
+        const uint32_t preemptor = jtasks.pop(j);
         begin_stmt();
         const bool assigned = preempt_one(preemptor, 1);
         commit();
@@ -655,7 +713,8 @@ void PreemptMachine::run_reclaim() {
   auto tl = [this](uint32_t l, uint32_t r) { return task_less(l, r); };
   GoHeap<decltype(ql)> queues(ql);
   std::vector<GoHeap<decltype(jl)>> qjobs(Q ? Q : 1, GoHeap<decltype(jl)>(jl));
-  std::vector<GoHeap<decltype(tl)>> jtasks(J ? J : 1, GoHeap<decltype(tl)>(tl));
+  TaskQueues jtasks;
+  std::vector<uint8_t> has_pending(J ? J : 1, 0);
   std::vector<uint8_t> qseen(Q ? Q : 1, 0);
   for (uint32_t j = 0; j < J; j++) {   // reclaim.go:55-83
     const uint32_t q = hs_->job_queue[j];
@@ -663,10 +722,10 @@ void PreemptMachine::run_reclaim() {
     if (!qseen[q]) { qseen[q] = 1; queues.push(q); }
     if (cnt[(size_t)j * 10 + KB_TASK_PENDING] != 0) {
       qjobs[q].push(j);
-      for (uint32_t t = hs_->job_begin[j]; t < hs_->job_begin[j + 1]; t++)
-        if ((*status_)[t] == KB_TASK_PENDING) jtasks[j].push(t);
+      has_pending[j] = 1;
     }
   }
+  jtasks.build(J, hs_->job_begin, has_pending, *status_, tl);
   stmt_no_ = 0;
   for (;;) {
     if (queues.empty()) break;
@@ -674,8 +733,8 @@ void PreemptMachine::run_reclaim() {
     if (overused(q)) continue;             // reclaim.go:96-99
     if (qjobs[q].empty()) continue;        // :102-106
     const uint32_t j = qjobs[q].pop();
-    if (jtasks[j].empty()) continue;       // :109-113
-    const uint32_t task = jtasks[j].pop();
+    if (jtasks.empty(j)) continue;         // :109-113
+    const uint32_t task = jtasks.pop(j);
     popped++;
     const Res init = task_init(task);
     bool assigned = false;

@@ -78,6 +78,10 @@ class PreemptMachine {
   std::vector<int32_t> qn_minprio_;
   bool prio_prunes_ = false;
   std::vector<std::vector<uint32_t>> qnodes_;        // per queue: nodes that hold a Running session task of the queue (superset, fixed)
+  // every Evict / Pipeline and their undo bumps version_; the last preemptor that found nothing, as of which version
+  uint64_t version_ = 0, fail_version_ = ~0ull;
+  uint32_t fail_task_ = KB_NONE;
+  int fail_mode_ = -1;
   std::vector<std::vector<int32_t>> shape_rank_;     // per shape: position of every node in the shape's list (-1: not in it)
 
   Res task_res(uint32_t t) const;
@@ -109,6 +113,8 @@ class PreemptMachine {
   bool overused(uint32_t q) const;
   bool host_eval(uint32_t t, uint32_t n, long long &score) const;
   bool preempt_one(uint32_t preemptor, int mode);
+  bool preempt_walk(uint32_t preemptor, int mode);
+  bool same_preemptor_class(uint32_t a, uint32_t b) const;
   bool try_node(uint32_t preemptor, int mode, uint32_t n);
 };
 
