@@ -20,4 +20,13 @@ KB_ORACLE_LIB="$out/libkboracle.so" KB_ORDER_HARNESS_LIB="$out/liborderharness.s
 gcc -std=c11 -O1 -g -fPIC -shared -ffp-contract=off -fsanitize=thread -o "$out/libkboracle_tsan.so" oracle/kb_oracle.c -lm -lpthread
 TSAN_OPTIONS="report_signal_unsafe=0 exitcode=66" LD_PRELOAD="$(gcc -print-file-name=libtsan.so)" KB_ORACLE_LIB="$out/libkboracle_tsan.so" \
   python -m pytest tests/test_oracle_kat.py -q -k threaded -p no:cacheprovider
+# the same host sources as libkbengine.so gets them: ROCm's clang at -O3 (the harness tests above use g++ -O2)
+CL=/opt/rocm/lib/llvm/bin/clang++
+if [ -x "$CL" ]; then
+  fl="-O3 -std=c++17 -fPIC -shared -ffp-contract=off -fno-fast-math"
+  $CL $fl -o "$out/liborderharness_clang.so" tests/host_harness/order_harness.cpp kube-batch_amd/csrc/kb_order.cpp
+  $CL $fl -o "$out/libevictharness_clang.so" tests/host_harness/evict_harness.cpp kube-batch_amd/csrc/kb_session.cpp kube-batch_amd/csrc/kb_preempt.cpp
+  KB_ORDER_HARNESS_LIB="$out/liborderharness_clang.so" KB_EVICT_HARNESS_LIB="$out/libevictharness_clang.so" \
+    python -m pytest tests/test_host_order_cpu.py tests/test_host_evict_cpu.py -x -q -p no:cacheprovider
+fi
 rm -rf "$out"
