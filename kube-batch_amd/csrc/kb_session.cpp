@@ -131,6 +131,8 @@ void build_host_session(const kb_snapshot *sn, const Policy &pol, uint32_t NP, H
   hs.t_status.assign(sn->task_status, sn->task_status + T);
   hs.t_node.assign(T, KB_NONE);
   if (sn->task_node) hs.t_node.assign(sn->task_node, sn->task_node + T);
+  for (uint32_t t = 0; t < T; t++)
+    if (hs.t_node[t] != KB_NONE && hs.t_node[t] >= N) throw EngineError(KB_E_INVALID, "task_node out of range");
   hs.job_begin.assign(sn->job_task_begin, sn->job_task_begin + J + 1);
   hs.job_queue.assign(sn->job_queue, sn->job_queue + J);
   hs.job_min.assign(sn->job_min_available, sn->job_min_available + J);

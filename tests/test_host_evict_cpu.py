@@ -369,3 +369,39 @@ def test_session_build_digests_are_pinned(harness):
     import make_session_digests as gen
     want = json.load(open(os.path.join(HERE, "golden", "session_digests.json")))
     assert gen.digests() == want
+
+
+def test_malformed_snapshots_are_refused(harness):
+    """kb_session_load's validation (kb_session.cpp) answers KB_E_INVALID / KB_E_UNSUPPORTED before anything indexes with the bad value:
+    one field of a valid snapshot broken at a time."""
+    import copy
+    cfg = conf.load_scheduler_conf(cases.CONF_FULL.format(actions="allocate, backfill"))
+    base = cases._evict_case(3)[1]
+    HostEngine(harness, cfg, base).close()                   # the unbroken snapshot loads
+
+    def broken(mutate):
+        s = copy.copy(base)
+        for name in ("job_task_begin", "task_job", "task_status", "task_resreq", "task_init_resreq", "task_node", "task_nz_cpu", "node_alloc_cpu"):
+            setattr(s, name, getattr(base, name).copy())
+        mutate(s)
+        return s
+
+    def begin_gap(s): s.job_task_begin[0] = 1
+    def begin_short(s): s.job_task_begin[-1] -= 1
+    def begin_backwards(s): s.job_task_begin[1], s.job_task_begin[2] = s.job_task_begin[2] + 1, s.job_task_begin[1]
+    def wrong_job(s): s.task_job[0] = s.n_jobs - 1
+    def bad_status(s): s.task_status[0] = 200
+    def negative_request(s): s.task_resreq[0, 0] = -1.0
+    def init_below_request(s): s.task_init_resreq[0, 0] = s.task_resreq[0, 0] - 1.0
+    def node_out_of_range(s): s.task_node[0] = s.n_nodes
+    def negative_nz(s): s.task_nz_cpu[0] = -5
+    def negative_alloc(s): s.node_alloc_cpu[0] = -1
+    def huge_alloc(s): s.node_alloc_cpu[0] = 1 << 50
+
+    want = {begin_gap: abi.KB_E_INVALID, begin_short: abi.KB_E_INVALID, begin_backwards: abi.KB_E_INVALID, wrong_job: abi.KB_E_INVALID,
+            bad_status: abi.KB_E_INVALID, negative_request: abi.KB_E_INVALID, init_below_request: abi.KB_E_UNSUPPORTED,
+            node_out_of_range: abi.KB_E_INVALID, negative_nz: abi.KB_E_UNSUPPORTED, negative_alloc: abi.KB_E_INVALID, huge_alloc: abi.KB_E_UNSUPPORTED}
+    for mutate, code in want.items():
+        with pytest.raises(HarnessError) as err:
+            HostEngine(harness, cfg, broken(mutate))
+        assert err.value.code == code, (mutate.__name__, str(err.value))
