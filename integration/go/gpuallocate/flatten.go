@@ -405,6 +405,17 @@ func flatten(ssn *framework.Session) (*flat, error) {
 		T += len(j.Tasks)
 	}
 
+	if T == 0 || N == 0 {
+		// No task, or no node to put one on: no action has anything to decide, and the callers return before they touch the
+		// engine (len(fl.tasks) == 0).  Taking &x[0] of the empty arrays below would panic.
+		return f, nil
+	}
+	if Q == 0 {
+		// allocate skips every job ("queue not found", allocate.go:56-60) but backfill.go:40-71 does not look at queues at all:
+		// rather than model a session the reference itself handles inconsistently, the stock actions take the cycle
+		return nil, errUnsupported("session without queues")
+	}
+
 	ports, err := newPortTable(ssn)
 	if err != nil {
 		return nil, err

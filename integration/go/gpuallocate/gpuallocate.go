@@ -25,7 +25,6 @@ import (
 
 	"github.com/kubernetes-sigs/kube-batch/pkg/scheduler/actions/allocate"
 	"github.com/kubernetes-sigs/kube-batch/pkg/scheduler/actions/backfill"
-	"github.com/kubernetes-sigs/kube-batch/pkg/scheduler/api"
 	"github.com/kubernetes-sigs/kube-batch/pkg/scheduler/framework"
 )
 
@@ -77,12 +76,12 @@ func (a *gpuAllocateAction) Execute(ssn *framework.Session) {
 	}
 	defer fl.free()
 
+	if len(fl.tasks) == 0 { // idle cluster (or one without nodes): nothing to place; flatten built no arrays for it
+		return
+	}
 	if rc := C.kb_session_load(a.engine, &fl.snap); rc != C.KB_OK {
 		glog.Warningf("gpuallocate: load rc=%d (%s); stock action takes this cycle", rc, C.GoString(C.kb_last_error(a.engine)))
 		a.stock(ssn)
-		return
-	}
-	if len(fl.tasks) == 0 { // idle cluster: nothing to place, and &decisions[0] of an empty slice would panic
 		return
 	}
 	// The decision buffer lives in C memory: the engine fills it, Go only reads it (no Go pointer crosses the boundary).
@@ -151,14 +150,6 @@ func bit(p *bool, b C.uint32_t) C.uint32_t { // nil -> disabled, exactly isEnabl
 
 // ensureEngine (re)creates the engine when ssn.Tiers changed: conf.Tier / conf.PluginOption (conf/scheduler_conf.go:27-56) -> kb_config
 func (a *gpuAllocateAction) ensureEngine(ssn *framework.Session) error {
-	key := fmt.Sprintf("%+v", ssn.Tiers)
-	if a.engine != nil && key == a.tiersKey {
-		return nil
-	}
-	if a.engine != nil {
-		C.kb_engine_destroy(a.engine)
-		a.engine = nil
-	}
 	var opts []C.kb_plugin_option
 	begin := []C.uint32_t{0}
 	for _, tier := range ssn.Tiers {
@@ -192,6 +183,16 @@ func (a *gpuAllocateAction) ensureEngine(ssn *framework.Session) error {
 			opts = append(opts, o)
 		}
 		begin = append(begin, C.uint32_t(len(opts)))
+	}
+	// The key is the compiled policy itself (plain integers), not a print of ssn.Tiers: PluginOption holds *bool fields, whose
+	// addresses say nothing about their values.
+	key := fmt.Sprint(begin, opts)
+	if a.engine != nil && key == a.tiersKey {
+		return nil
+	}
+	if a.engine != nil {
+		C.kb_engine_destroy(a.engine)
+		a.engine = nil
 	}
 	// kb_config points at two arrays.  They must live in C memory: passing &cfg with fields that point into Go slices is a
 	// "Go pointer to Go pointer" and panics under the default cgocheck=1.  Same rule flatten.go follows for the snapshot.

@@ -161,3 +161,51 @@ def test_go_shim_obeys_the_cgo_pointer_rules_statically():
     assert "C.kb_run_backfill(" in act_code and "fallbackBackfill" in act_code
     assert "len(fl.tasks) == 0" in act_code
     assert re.search(r"cfg\s*:=\s*\(\*C\.kb_config\)\(C\.calloc", act_code), "kb_config must be built in C memory"
+
+
+def _go_code(src):
+    """Go source with comments and string literals blanked (enough for the textual checks below)."""
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    src = re.sub(r"//[^\n]*", "", src)
+    src = re.sub(r'"(\\.|[^"\\\n])*"', '""', src)
+    return re.sub(r"`[^`]*`", '""', src)
+
+
+def test_go_shim_has_no_unused_imports():
+    """`imported and not used` is a hard compile error in Go and nothing here compiles the shim: every import of every file must be
+    referenced (as `name.`) in that file's code."""
+    godir = os.path.join(ROOT, "integration", "go", "gpuallocate")
+    for fn in sorted(os.listdir(godir)):
+        src = open(os.path.join(godir, fn)).read()
+        m = re.search(r"^import \((.*?)^\)", src, flags=re.S | re.M)
+        assert m, fn
+        code = _go_code(src[m.end():])
+        for line in m.group(1).splitlines():
+            mm = re.match(r'\s*(?:(\w+)\s+)?"([^"]+)"', line)
+            if not mm:
+                continue
+            name = mm.group(1) or mm.group(2).rsplit("/", 1)[-1]
+            assert re.search(r"\b" + re.escape(name) + r"\.", code), f"{fn}: import {mm.group(2)!r} is not used"
+
+
+def test_go_shim_handles_empty_sessions_before_taking_slice_addresses():
+    """&x[0] of an empty slice panics: flatten() must leave before its first &view[0] when the session has no task or no node,
+    and every action must test len(fl.tasks) == 0 before it hands &fl.snap to the engine."""
+    godir = os.path.join(ROOT, "integration", "go", "gpuallocate")
+    flat = _go_code(open(os.path.join(godir, "flatten.go")).read())
+    guard = re.search(r"if T == 0 \|\| N == 0 \{\s*return f, nil", flat)
+    first_addr = re.search(r"unsafe\.Pointer\(&\w+\[0\]\)", flat)
+    assert guard and first_addr and guard.start() < first_addr.start()
+    for fn in ("gpuallocate.go", "gpupreempt.go"):
+        code = _go_code(open(os.path.join(godir, fn)).read())
+        for body in re.split(r"\nfunc ", code):
+            if "C.kb_session_load(" in body:
+                assert "len(fl.tasks) == 0" in body and body.index("len(fl.tasks) == 0") < body.index("C.kb_session_load("), fn
+
+
+def test_integration_md_quotes_the_shipped_go_action():
+    """INTEGRATION.md prints gpuallocate.go in full: the copy must be the file."""
+    src = open(os.path.join(ROOT, "integration", "go", "gpuallocate", "gpuallocate.go")).read()
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    body = src[src.index("package gpuallocate"):].strip()
+    assert body in doc, "INTEGRATION.md's listing of gpuallocate.go is out of date"
