@@ -518,7 +518,7 @@ __global__ void __launch_bounds__(256) k_finalize_jobs(KbDev d, const uint32_t *
     s = wave_sum_f64(s);
     if (lane == 0) {
       job_alloc[(size_t)j * d.R + dim] = s;
-      if (s != 0.0) atomicAdd(&queue_alloc[(size_t)q * d.R + dim], s);
+      if (s != 0.0 && q < d.Q) atomicAdd(&queue_alloc[(size_t)q * d.R + dim], s);   // q >= Q: "queue not found" (allocate.go:56-60), no queue row
       if (dim < 2 || ((total_mask >> (dim - 2)) & 1u)) {   // totalResource.ResourceNames() (drf.go:161)
         double sh = share_of(s, total[dim]);
         if (sh > share) share = sh;

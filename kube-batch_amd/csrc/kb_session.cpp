@@ -353,7 +353,12 @@ void build_host_session(const kb_snapshot *sn, const Policy &pol, uint32_t NP, H
   std::vector<Res> request(Q);
   for (uint32_t j = 0; j < J; j++) {
     uint32_t q = hs.job_queue[j];
-    if (q >= Q) continue;
+    if (q >= Q) {
+      // allocate / preempt / reclaim skip such a job ("queue not found", allocate.go:56-60) but proportion's OnSessionOpen reads
+      // ssn.Queues[job.Queue].UID for every job (proportion.go:70-73): with the plugin loaded the reference panics on the nil queue
+      if (pol.has_proportion) throw EngineError(KB_E_UNSUPPORTED, "a job names a queue the session does not hold (the proportion plugin would panic on it)");
+      continue;
+    }
     hs.queue_has_attr[q] = 1;
     for (uint32_t t = hs.job_begin[j]; t < hs.job_begin[j + 1]; t++) {
       int st = hs.t_status[t];

@@ -874,6 +874,10 @@ static int open_plugins(kbo_session *s) {
   for (uint32_t j = 0; j < s->J; j++) {
     o_job *job = &s->jobs[j];
     if (!job->valid) continue;
+    if (job->queue >= s->Q) { /* proportion.go:70-73 reads ssn.Queues[job.Queue].UID: nil pointer when the queue is missing */
+      if (s->has_plugin[KB_PLUGIN_PROPORTION]) { s->panic = 1; return KBO_PANIC; }
+      continue;
+    }
     o_queue *a = &s->queues[job->queue];
     a->has_attr = 1;
     for (uint32_t t = job->t0; t < job->t1; t++) {

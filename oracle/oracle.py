@@ -84,7 +84,7 @@ class Oracle:
         if not self.h:
             raise RuntimeError("kbo_open failed")
         if self.L.kbo_panicked(self.h):
-            raise RuntimeError("reference would panic in OnSessionOpen (Resource.Sub underflow)")
+            raise RuntimeError("reference would panic in OnSessionOpen (Resource.Sub underflow, or a job whose queue is missing)")
 
     def close(self):
         if self.h:

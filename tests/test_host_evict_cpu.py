@@ -405,3 +405,27 @@ def test_malformed_snapshots_are_refused(harness):
         with pytest.raises(HarnessError) as err:
             HostEngine(harness, cfg, broken(mutate))
         assert err.value.code == code, (mutate.__name__, str(err.value))
+
+
+def test_job_with_a_missing_queue(harness, oracle_mod):
+    """job_queue >= n_queues is "queue not found" (allocate.go:56-60).  With proportion loaded the reference panics in OnSessionOpen
+    (proportion.go:70-73: ssn.Queues[job.Queue].UID on a nil queue): the oracle reports the panic, kb_session_load answers
+    KB_E_UNSUPPORTED so that the stock action takes the cycle."""
+    import copy
+    base = cases._evict_case(3)[1]
+    s = copy.copy(base)
+    s.job_queue = base.job_queue.copy()
+    s.job_queue[0] = abi.KB_NONE
+    cfg = conf.load_scheduler_conf(cases.CONF_FULL.format(actions="allocate, backfill"))
+    assert any(po.name == "proportion" for tier in cfg.tiers for po in tier)
+    with pytest.raises(RuntimeError):                        # OnSessionOpen panics: the oracle refuses to open
+        oracle_mod.Oracle(cfg, s)
+    h = C.c_void_p(harness.eh_create())
+    cfg_abi, keep = cfg.to_abi()
+    snap_abi = s.to_abi()
+    R, J, Q = s.n_res, s.n_jobs, s.n_queues
+    z = [np.zeros((max(J, 1), R)), np.zeros(max(J, 1)), np.zeros((max(Q, 1), R)), np.zeros(max(Q, 1))]
+    rc = harness.eh_load(h, C.byref(cfg_abi), C.byref(snap_abi), *[_vp(a) for a in z])
+    assert rc == abi.KB_E_UNSUPPORTED, harness.eh_error(h).decode()
+    assert "queue" in harness.eh_error(h).decode()
+    harness.eh_destroy(h)
