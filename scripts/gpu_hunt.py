@@ -1,7 +1,10 @@
 #!/usr/bin/env python
 """One-off differential hunt on the GPU box, beyond the committed suite: engine vs oracle on many more seeds of the fuzz generator
 (tests/test_gpu_fuzz.py), the adversarial raw snapshots (tests/rawgen.py) and the inter-pod affinity clusters, under both commit
-kernels.  python scripts/gpu_hunt.py [seeds_fuzz] [seeds_raw] [seeds_interpod]   -> prints every divergence, exit code 1 if any."""
+kernels.  python scripts/gpu_hunt.py [seeds_fuzz] [seeds_raw] [seeds_interpod]   -> prints every divergence, exit code 1 if any.
+KB_HUNT_OFFSET=k shifts every seed range by k (fresh cases).  KB_HUNT_EMU=1 runs the same hunt WITHOUT a GPU against the engine's
+host side on the emulated device of tests/host_harness (tests/test_emu_engine_cpu.py): that hunts the host logic (speculation,
+roll-back, dead shapes, probe, chained rounds), not the kernels."""
 import importlib
 import os
 import sys
@@ -20,6 +23,10 @@ import test_gpu_fuzz as fz
 from test_interpod_oracle_cpu import interpod_case
 
 oracle.build()
+OFF = int(os.environ.get("KB_HUNT_OFFSET", "0"))
+if os.environ.get("KB_HUNT_EMU") == "1":
+    import test_emu_engine_cpu as emu
+    engine.LIB_PATH, engine._LIB = emu.build_emulated_library(), None
 n_fuzz, n_raw, n_ip = (int(x) for x in (sys.argv[1:4] + ["200", "600", "400"])[:3])
 bad = 0
 t0 = time.time()
@@ -58,12 +65,12 @@ def compare(tag, cfg, snap, **ekw):
     return "ok"
 
 
-for seed in range(40, 40 + n_fuzz):
+for seed in range(40 + OFF, 40 + OFF + n_fuzz):
     cfg, snap, window, batch = fz._case(seed)
     compare(f"fuzz {seed}", cfg, snap, window=window, commit_batch=batch)
 print("fuzz done", n_fuzz, round(time.time() - t0, 1), "s", flush=True)
 import test_pyref_vs_oracle as cases
-for seed in range(200, 200 + n_raw):
+for seed in range(200 + OFF, 200 + OFF + n_raw):
     snap = rawgen.raw_snapshot(seed)
     rng = np.random.RandomState(seed)
     wl, wm, wa, wb = [int(x) for x in rng.choice([0, 1, 1, 2, 5], size=4)]
@@ -71,7 +78,7 @@ for seed in range(200, 200 + n_raw):
     compare(f"raw {seed}", cfg, snap, window=int(rng.choice([0, 1, 3, 64])), commit_batch=int(rng.choice([0, 1, 5, 16])))
 print("raw done", round(time.time() - t0, 1), "s", flush=True)
 n_sup = 0
-for seed in range(60, 60 + n_ip):
+for seed in range(60 + OFF, 60 + OFF + n_ip):
     try:
         cfg, snap = interpod_case(seed)
     except snapmod.UnsupportedSnapshot:

@@ -91,3 +91,125 @@ def _adopt(module_name, only=None):
 
 for _m in ("test_gpu_parity", "test_gpu_fuzz", "test_gpu_adversarial", "test_gpu_interpod", "test_gpu_preempt", "test_framework_actions"):
     _adopt(_m)
+
+
+# ---- the sharded path's entry points (kb_round_begin / candidates / commit / apply) through dist.py, CPU buffers ----------------
+def _sharded_cycle(so, min_rows_per_rank):
+    import torch
+    distmod = importlib.import_module("kube-batch_amd.dist")
+    engine.LIB_PATH, engine._LIB = so, None
+    conf = kbm.conf.load_scheduler_conf()
+    snap = kbm.snapshot.synth(kbm.snapshot.synth_config(3, 0.05))
+    eng = engine.Engine(conf, device=0, window=256)
+    eng.load(snap)
+    cpu = torch.device("cpu")       # the emulated "device" memory is host memory: torch's CPU tensors are its buffers
+    return conf, snap, distmod.ShardedCycle(conf, snap, backend=distmod.EngineBackend(eng, cpu), buffer_device=cpu, min_rows_per_rank=min_rows_per_rank)
+
+
+def test_sharded_rounds_world1_equal_the_oracle(emulated_engine, oracle_mod):
+    conf, snap, cyc = _sharded_cycle(emulated_engine, 32)
+    dec = cyc.step()
+    o = oracle_mod.Oracle(conf, snap)
+    o.run(["allocate", "backfill"])
+    assert np.array_equal(dec, o.decisions())
+    assert np.array_equal(cyc.engine.binds(), o.binds())
+    for a, b in zip(cyc.engine.node_state(), o.node_state()):
+        assert np.array_equal(a, b)
+    assert np.array_equal(cyc.step(), dec)                 # reset + second cycle: identical
+
+
+def _sharded_worker(rank, world, port, out_dir, so):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        _, _, cyc = _sharded_cycle(so, 0)                  # always exchange: every round all-gathers the lists and all-reduces the deltas
+        dec = cyc.step()
+        np.save(os.path.join(out_dir, f"dec{rank}.npy"), dec)
+        np.save(os.path.join(out_dir, f"binds{rank}.npy"), cyc.engine.binds())
+        st = cyc.engine.stats()
+        np.save(os.path.join(out_dir, f"mevals{rank}.npy"), np.array([st["matrix_evals"], st["rounds"]]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_rounds_two_gloo_ranks_equal_the_oracle(emulated_engine, oracle_mod, tmp_path):
+    import socket
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_sharded_worker, args=(2, port, str(tmp_path), emulated_engine), nprocs=2, join=True)
+    conf = kbm.conf.load_scheduler_conf()
+    o = oracle_mod.Oracle(conf, kbm.snapshot.synth(kbm.snapshot.synth_config(3, 0.05)))
+    o.run(["allocate", "backfill"])
+    for r in (0, 1):
+        assert np.array_equal(np.load(tmp_path / f"dec{r}.npy"), o.decisions()), f"rank {r}"
+        assert np.array_equal(np.load(tmp_path / f"binds{r}.npy"), o.binds()), f"rank {r}"
+    m0, m1 = np.load(tmp_path / "mevals0.npy"), np.load(tmp_path / "mevals1.npy")
+    assert m0[1] == m1[1]                                   # same number of rounds on both ranks
+    assert abs(int(m0[0]) - int(m1[0])) <= m0[1] * 10_000   # each rank evaluated about half of the matrix rows
+
+
+# ---- every launch-path variant of the host protocol gives the same cycle ------------------------------------------------------
+_VARIANTS = [{}, {"KB_CHAIN_ROUNDS": "0"}, {"KB_SYNC_ROUNDS": "1"}, {"KB_PROBE": "0"}, {"KB_DIRECT_WINDOW": "0"},
+             {"KB_COMMIT_KERNEL": "run"}, {"KB_COMMIT_KERNEL": "batch"}, {"KB_CHAIN_ROUNDS": "0", "KB_PROBE": "0", "KB_DIRECT_WINDOW": "0"}]
+
+
+@pytest.mark.parametrize("variant", range(len(_VARIANTS)))
+def test_launch_path_variants_agree_with_the_oracle(oracle_mod, variant, monkeypatch):
+    """Chained rounds, the pinned mailbox, the direct window, the feasibility probe and the commit-kernel pin only change HOW the
+    host drives the device (kb_engine_create reads the switches): decisions, binds, node state and shares stay the oracle's."""
+    import test_gpu_fuzz as fz
+    for k, v in _VARIANTS[variant].items():
+        monkeypatch.setenv(k, v)
+    cases = [fz._case(seed) for seed in (3, 11, 19, 27)]
+    cases.append((kbm.conf.load_scheduler_conf(), kbm.snapshot.synth(kbm.snapshot.synth_config(3, 0.03)), 0, 0))
+    cases.append((kbm.conf.load_scheduler_conf(), kbm.snapshot.synth(kbm.snapshot.synth_config(4, 0.03)), 64, 0))
+    for cfg, snap, window, batch in cases:
+        o = oracle_mod.Oracle(cfg, snap)
+        o.run(["allocate", "backfill"])
+        e = engine.Engine(cfg, window=window, commit_batch=batch)
+        e.load(snap)
+        dec = e.run(["allocate", "backfill"])
+        assert np.array_equal(dec, o.decisions())
+        assert np.array_equal(e.binds(), o.binds())
+        for a, b in zip(e.node_state(), o.node_state()):
+            assert np.array_equal(a, b)
+        assert e.stats()["evals"] == o.evals
+        e.reset()                                            # a second cycle from the pristine copy: identical
+        assert np.array_equal(e.run(["allocate", "backfill"]), dec)
+        e.close()
+        o.close()
+
+
+def test_job_with_a_missing_queue_without_proportion(oracle_mod):
+    """"queue not found" (allocate.go:56-60) is legal when proportion is not loaded: allocate skips the job, drf still counts its
+    running tasks; the share reduction must not look for a queue row (kb_kernels.hip: k_finalize_jobs guards q < Q)."""
+    import copy
+    import test_pyref_vs_oracle as cases
+    conf_text = cases.CONF_FULL.format(actions="allocate, backfill").replace("  - name: proportion\n", "")
+    cfg = kbm.conf.load_scheduler_conf(conf_text)
+    assert not any(po.name == "proportion" for tier in cfg.tiers for po in tier)
+    hit = 0
+    for seed in range(12):
+        base = cases._evict_case(seed)[1]                   # clusters with running tasks
+        s = copy.copy(base)
+        s.job_queue = base.job_queue.copy()
+        s.job_queue[seed % s.n_jobs] = abi.KB_NONE
+        try:
+            o = oracle_mod.Oracle(cfg, s)
+            o.run(["allocate", "backfill"])
+        except RuntimeError:
+            continue
+        e = engine.Engine(cfg)
+        e.load(s)
+        dec = e.run(["allocate", "backfill"])
+        assert np.array_equal(dec, o.decisions()), seed
+        assert np.array_equal(e.binds(), o.binds()), seed
+        ejs, _ = e.shares()[:2]
+        assert np.array_equal(ejs, o.shares()[0]), seed
+        e.close()
+        o.close()
+        hit += 1
+    assert hit >= 6
