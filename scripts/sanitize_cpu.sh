@@ -1,7 +1,9 @@
 #!/usr/bin/env bash
 # AddressSanitizer + UndefinedBehaviorSanitizer pass over the CPU-side C/C++ of the test infrastructure and the engine's host code:
 # the oracle (oracle/kb_oracle.c), kube-batch_amd/csrc/kb_order.cpp (order machine) and kb_session.cpp + kb_preempt.cpp (policy
-# compiler, session build, evict actions) behind tests/host_harness.  The HIP part of the engine needs a device and is not covered.  Usage: scripts/sanitize_cpu.sh   (prints pytest's summary; any report aborts).
+# compiler, session build, evict actions) behind tests/host_harness, and the WHOLE host side of the engine (kb_engine.cpp included) on the
+# emulated device of tests/host_harness/device_emu.cpp.  The HIP kernels need a device and are not covered.
+# Usage: scripts/sanitize_cpu.sh   (prints pytest's summary; any report aborts).
 set -euo pipefail
 cd "$(dirname "$0")/.."
 out=$(mktemp -d)
@@ -16,6 +18,11 @@ KB_ORACLE_LIB="$out/libkboracle.so" KB_ORDER_HARNESS_LIB="$out/liborderharness.s
   python -m pytest tests/test_oracle_kat.py tests/test_oracle_independent.py tests/test_pyref_vs_oracle.py tests/test_host_order_cpu.py tests/test_host_evict_cpu.py \
     tests/test_interpod_oracle_cpu.py tests/test_manifests_cpu.py \
     -x -q -p no:cacheprovider "$@"
+# the complete C ABI on the emulated device: kb_engine.cpp's round protocol, session load / reset, evict actions, kb_round_* (about 3 minutes)
+g++ -std=c++17 $san -Itests/host_harness/hip_mock -o "$out/libkbengine_emu.so" kube-batch_amd/csrc/kb_engine.cpp kube-batch_amd/csrc/kb_session.cpp \
+  kube-batch_amd/csrc/kb_order.cpp kube-batch_amd/csrc/kb_preempt.cpp tests/host_harness/device_emu.cpp
+ASAN_OPTIONS=detect_leaks=0 LD_PRELOAD="$(gcc -print-file-name=libasan.so) $(g++ -print-file-name=libstdc++.so.6)" KB_EMU_LIB="$out/libkbengine_emu.so" \
+  python -m pytest tests/test_emu_engine_cpu.py -x -q -p no:cacheprovider -k "not two_gloo" "$@"
 # ThreadSanitizer over the oracle's worker pool (the cpu_baseline leg's 16-way fan-out)
 gcc -std=c11 -O1 -g -fPIC -shared -ffp-contract=off -fsanitize=thread -o "$out/libkboracle_tsan.so" oracle/kb_oracle.c -lm -lpthread
 TSAN_OPTIONS="report_signal_unsafe=0 exitcode=66" LD_PRELOAD="$(gcc -print-file-name=libtsan.so)" KB_ORACLE_LIB="$out/libkboracle_tsan.so" \
