@@ -20,13 +20,31 @@ KB_ORACLE_LIB="$out/libkboracle.so" KB_ORDER_HARNESS_LIB="$out/liborderharness.s
     -x -q -p no:cacheprovider "$@"
 # the complete C ABI on the emulated device: kb_engine.cpp's round protocol, session load / reset, evict actions, kb_round_* (about 3 minutes)
 g++ -std=c++17 $san -Itests/host_harness/hip_mock -o "$out/libkbengine_emu.so" kube-batch_amd/csrc/kb_engine.cpp kube-batch_amd/csrc/kb_session.cpp \
-  kube-batch_amd/csrc/kb_order.cpp kube-batch_amd/csrc/kb_preempt.cpp tests/host_harness/device_emu.cpp
+  kube-batch_amd/csrc/kb_order.cpp kube-batch_amd/csrc/kb_preempt.cpp tests/host_harness/device_emu.cpp tests/host_harness/hip_mock/hip_mock.cpp
 ASAN_OPTIONS=detect_leaks=0 LD_PRELOAD="$(gcc -print-file-name=libasan.so) $(g++ -print-file-name=libstdc++.so.6)" KB_EMU_LIB="$out/libkbengine_emu.so" \
   python -m pytest tests/test_emu_engine_cpu.py -x -q -p no:cacheprovider -k "not two_gloo" "$@"
 # ThreadSanitizer over the oracle's worker pool (the cpu_baseline leg's 16-way fan-out)
 gcc -std=c11 -O1 -g -fPIC -shared -ffp-contract=off -fsanitize=thread -o "$out/libkboracle_tsan.so" oracle/kb_oracle.c -lm -lpthread
 TSAN_OPTIONS="report_signal_unsafe=0 exitcode=66" LD_PRELOAD="$(gcc -print-file-name=libtsan.so)" KB_ORACLE_LIB="$out/libkboracle_tsan.so" \
   python -m pytest tests/test_oracle_kat.py -q -k threaded -p no:cacheprovider
+# ThreadSanitizer over the host <-> device handshake: the emulated streams run asynchronously (KB_EMU_ASYNC=1: a worker thread per stream with
+# HIP's ordering rules, tests/host_harness/hip_mock), so a staging half, a mailbox word or a result the host touches before the device is done
+# with it is a reported race.  Chained / unchained rounds, pinned mailbox / synchronous rounds, direct window, both commit-kernel pins.
+emu_src="kube-batch_amd/csrc/kb_engine.cpp kube-batch_amd/csrc/kb_session.cpp kube-batch_amd/csrc/kb_order.cpp kube-batch_amd/csrc/kb_preempt.cpp tests/host_harness/hip_mock/hip_mock.cpp"
+tsan="-std=c++17 -O1 -g -fPIC -shared -ffp-contract=off -fsanitize=thread -pthread -Itests/host_harness/hip_mock"
+g++ $tsan -o "$out/libkbengine_emu_tsan.so" $emu_src tests/host_harness/device_emu.cpp
+KB_EMU_ASYNC=1 TSAN_OPTIONS="report_signal_unsafe=0 exitcode=66" LD_PRELOAD="$(gcc -print-file-name=libtsan.so) $(g++ -print-file-name=libstdc++.so.6)" \
+KB_EMU_LIB="$out/libkbengine_emu_tsan.so" python -m pytest tests/test_emu_engine_cpu.py -x -q -p no:cacheprovider -k "variants or fuzz or reference_allocate or config2"
+# negative control: the same build with the commit's mailbox publication weakened from release to relaxed MUST be reported (exit code 66)
+sed 's/r.seq, __ATOMIC_RELEASE)/r.seq, __ATOMIC_RELAXED)/' tests/host_harness/device_emu.cpp > tests/host_harness/_device_emu_relaxed.cpp
+g++ $tsan -o "$out/libkbengine_emu_neg.so" $emu_src tests/host_harness/_device_emu_relaxed.cpp; rm -f tests/host_harness/_device_emu_relaxed.cpp
+set +e
+KB_EMU_ASYNC=1 TSAN_OPTIONS="report_signal_unsafe=0 exitcode=66" LD_PRELOAD="$(gcc -print-file-name=libtsan.so) $(g++ -print-file-name=libstdc++.so.6)" \
+KB_EMU_LIB="$out/libkbengine_emu_neg.so" python -m pytest tests/test_emu_engine_cpu.py -q -p no:cacheprovider -k "variants and 0" > "$out/neg.log" 2>&1
+neg=$?
+set -e
+if [ "$neg" -ne 66 ]; then echo "negative control: ThreadSanitizer did not report the weakened mailbox publication (exit $neg)"; exit 1; fi
+echo "negative control ok: the weakened publication is reported"
 # the same host sources as libkbengine.so gets them: ROCm's clang at -O3 (the harness tests above use g++ -O2)
 CL=/opt/rocm/lib/llvm/bin/clang++
 if [ -x "$CL" ]; then

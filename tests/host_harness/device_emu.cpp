@@ -303,14 +303,17 @@ size_t kb_commit_batch_smem_bytes(uint32_t cap, uint32_t NP, int R) {
 }
 
 // ---- launch wrappers (kb_device.h) ----
-void kb_launch_gather(const KbDev &d, const KbRound &r, void *) {
+void kb_launch_gather(const KbDev &d, const KbRound &r, void *stream) {
+  kbemu_enqueue((hipStream_t)stream, [d, r]() {
   if (r.n_rows == 0) return;
   if (KB_CHAIN_BROKEN(r)) return;
   out64(r)[KB_OUT_STAMP0] = kbemu_wall_clock();
   for (uint32_t i = 0; i < r.n_rows; i++) gather_row(d, r, i);
+  });
 }
 
-void kb_launch_matrix(const KbDev &d, const KbRound &r, void *) {
+void kb_launch_matrix(const KbDev &d, const KbRound &r, void *stream) {
+  kbemu_enqueue((hipStream_t)stream, [d, r]() {
   if (r.n_mrows == 0) return;
   if (KB_CHAIN_BROKEN(r)) return;
   if (r.gather) {
@@ -329,9 +332,11 @@ void kb_launch_matrix(const KbDev &d, const KbRound &r, void *) {
       if (e >> 16) mw[n >> 5] |= 1u << (n & 31);
     }
   }
+  });
 }
 
-void kb_launch_affinity(const KbDev &d, const KbRound &r, void *) {
+void kb_launch_affinity(const KbDev &d, const KbRound &r, void *stream) {
+  kbemu_enqueue((hipStream_t)stream, [d, r]() {
   if (r.n_mrows == 0 || !d.aff || !d.score_enabled) return;
   if (KB_CHAIN_BROKEN(r)) return;
   for (uint32_t m = 0; m < r.n_mrows; m++) {
@@ -347,9 +352,11 @@ void kb_launch_affinity(const KbDev &d, const KbRound &r, void *) {
     for (uint32_t n = 0; n < d.N; n++)
       if (mask_bit(mw, n)) sc[n] = (uint16_t)(sc[n] + (10 * arow[d.ncls[n]] / mx) * d.wNA);
   }
+  });
 }
 
-void kb_launch_interpod(const KbDev &d, const KbRound &r, void *) {
+void kb_launch_interpod(const KbDev &d, const KbRound &r, void *stream) {
+  kbemu_enqueue((hipStream_t)stream, [d, r]() {
   if (r.n_mrows == 0 || !d.t_ip_sig || !d.score_enabled || d.ip_P == 0) return;
   if (KB_CHAIN_BROKEN(r)) return;
   std::vector<long long> cnt(d.N), hist(d.N);
@@ -387,9 +394,11 @@ void kb_launch_interpod(const KbDev &d, const KbRound &r, void *) {
         sc[n] = (uint16_t)(sc[n] + (int)f * d.wPA);
       }
   }
+  });
 }
 
-void kb_launch_probe(const KbDev &d, const uint32_t *rows, uint32_t n_rows, uint32_t *alive, void *) {
+void kb_launch_probe(const KbDev &d, const uint32_t *rows, uint32_t n_rows, uint32_t *alive, void *stream) {
+  kbemu_enqueue((hipStream_t)stream, [d, rows, n_rows, alive]() {
   KbDev dd = d;
   dd.score_enabled = 0;
   for (uint32_t i = 0; i < n_rows; i++) {
@@ -397,9 +406,11 @@ void kb_launch_probe(const KbDev &d, const uint32_t *rows, uint32_t n_rows, uint
     for (uint32_t n = 0; n < d.N; n++)
       if (eval_pair(dd, t, n, 1, true)) { alive[i] |= 1u; break; }
   }
+  });
 }
 
-void kb_launch_argmax(const KbDev &d, const KbRound &r, void *) {
+void kb_launch_argmax(const KbDev &d, const KbRound &r, void *stream) {
+  kbemu_enqueue((hipStream_t)stream, [d, r]() {
   if (r.n_mrows == 0) return;
   if (KB_CHAIN_BROKEN(r)) return;
   if (r.mrow_task0 == 0 && r.mrows != nullptr) out64(r)[KB_OUT_STAMP0 + 1] = kbemu_wall_clock();
@@ -414,22 +425,26 @@ void kb_launch_argmax(const KbDev &d, const KbRound &r, void *) {
     u64 *out = r.keys + (size_t)m * r.L;
     for (uint32_t i = 0; i < r.L; i++) out[i] = i < keys.size() ? keys[i] : 0ull;
   }
+  });
 }
 
 void kb_launch_expand(const KbDev &d, const uint16_t *s_score, const uint32_t *s_mask, const uint32_t *row_slot, uint32_t n_rows,
-                      uint16_t *score, uint32_t *maskw, void *) {
+                      uint16_t *score, uint32_t *maskw, void *stream) {
+  kbemu_enqueue((hipStream_t)stream, [d, s_score, s_mask, row_slot, n_rows, score, maskw]() {
   for (uint32_t row = 0; row < n_rows; row++) {
     const uint32_t slot = row_slot[row];
     std::memcpy(score + (size_t)row * d.NP, s_score + (size_t)slot * d.NP, sizeof(uint16_t) * d.NP);
     std::memcpy(maskw + (size_t)row * (d.NP / 32), s_mask + (size_t)slot * (d.NP / 32), sizeof(uint32_t) * (d.NP / 32));
   }
+  });
 }
 
-void kb_launch_commit(const KbDev &d, const KbRound &r, void *) { emu_commit(d, r, false); }
-void kb_launch_commit_batch(const KbDev &d, const KbRound &r, void *) { emu_commit(d, r, true); }
+void kb_launch_commit(const KbDev &d, const KbRound &r, void *stream) { kbemu_enqueue((hipStream_t)stream, [d, r]() { emu_commit(d, r, false); }); }
+void kb_launch_commit_batch(const KbDev &d, const KbRound &r, void *stream) { kbemu_enqueue((hipStream_t)stream, [d, r]() { emu_commit(d, r, true); }); }
 
 uint32_t kb_apply_deltas(const KbDev &d, const double *s_idle, const double *s_rel, const long long *s_nzc, const long long *s_nzm,
-                         const int *s_podcnt, const double *delta, uint32_t *dev_counter, void *) {
+                         const int *s_podcnt, const double *delta, uint32_t *dev_counter, void *stream) {
+  kbemu_enqueue((hipStream_t)stream, [d, s_idle, s_rel, s_nzc, s_nzm, s_podcnt, delta, dev_counter]() {
   uint32_t bad = 0;
   for (uint32_t n = 0; n < d.NP; n++) {
     for (int dim = 0; dim < d.R; dim++) {
@@ -447,13 +462,16 @@ uint32_t kb_apply_deltas(const KbDev &d, const double *s_idle, const double *s_r
     d.nzc[n] = c; d.nzm[n] = m; d.podcnt[n] = p;
   }
   *dev_counter = bad;
-  return bad;
+  });
+  kbemu_drain((hipStream_t)stream);   // the kernel's counter is copied back and the stream synchronised
+  return *dev_counter;
 }
 
 void kb_launch_finalize(const KbDev &d, const uint32_t *job_task_begin, const int *job_min_avail, const uint32_t *job_queue,
                         int gang_ready_enabled, const double *total, uint32_t total_mask, const double *deserved,
                         const uint32_t *deserved_mask, double *job_alloc, double *job_share, double *queue_alloc,
-                        double *queue_share, int *job_ready_cnt, void *) {
+                        double *queue_share, int *job_ready_cnt, void *stream) {
+  kbemu_enqueue((hipStream_t)stream, [=]() {
   std::memset(queue_alloc, 0, sizeof(double) * (size_t)d.Q * d.R);
   for (uint32_t j = 0; j < d.J; j++) {
     const uint32_t t0 = job_task_begin[j], t1 = job_task_begin[j + 1];
@@ -488,4 +506,5 @@ void kb_launch_finalize(const KbDev &d, const uint32_t *job_task_begin, const in
     }
     queue_share[q] = share;
   }
+  });
 }

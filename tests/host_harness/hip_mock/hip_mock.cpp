@@ -1,0 +1,162 @@
+// hip_mock.cpp — TEST INFRASTRUCTURE: the runtime behind hip/hip_runtime.h (see there).  Host heap for memory, one worker thread per
+// stream in the asynchronous mode (KB_EMU_ASYNC=1), inline execution otherwise.
+#include <hip/hip_runtime.h>
+
+#include <chrono>
+#include <condition_variable>
+#include <deque>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <set>
+#include <thread>
+#include <vector>
+
+namespace {
+
+bool env_flag(const char *name) {
+  const char *v = getenv(name);
+  return v && atoi(v) != 0;
+}
+bool async_mode() {
+  static const bool a = env_flag("KB_EMU_ASYNC");
+  return a;
+}
+
+std::mutex g_mu;                              // registries below
+std::map<const char *, size_t> g_pinned;      // hipHostMalloc'ed ranges
+std::set<kbemu_stream *> g_streams;
+
+bool is_pinned(const void *p) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  auto it = g_pinned.upper_bound((const char *)p);
+  if (it == g_pinned.begin()) return false;
+  --it;
+  return (const char *)p < it->first + it->second;
+}
+
+hipError_t alloc(void **p, size_t bytes) {
+  static const bool poison = env_flag("KB_EMU_POISON");
+  *p = malloc(bytes ? bytes : 1);
+  if (!*p) return hipErrorOutOfMemory;
+  memset(*p, poison ? 0xA5 : 0, bytes);
+  return hipSuccess;
+}
+
+}  // namespace
+
+struct kbemu_stream {
+  std::thread th;
+  std::mutex m;
+  std::condition_variable cv, idle;
+  std::deque<std::function<void()>> q;
+  bool stop = false, busy = false;
+  void run() {
+    std::unique_lock<std::mutex> lk(m);
+    for (;;) {
+      cv.wait(lk, [&] { return stop || !q.empty(); });
+      if (q.empty()) return;
+      std::function<void()> f = std::move(q.front());
+      q.pop_front();
+      busy = true;
+      lk.unlock();
+      f();
+      lk.lock();
+      busy = false;
+      if (q.empty()) idle.notify_all();
+    }
+  }
+};
+
+double kbemu_now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+void kbemu_enqueue(hipStream_t s, std::function<void()> f) {
+  if (!async_mode() || s == nullptr) { f(); return; }   // the null stream: the engine never launches there
+  std::lock_guard<std::mutex> lk(s->m);
+  s->q.push_back(std::move(f));
+  s->cv.notify_one();
+}
+void kbemu_drain(hipStream_t s) {
+  if (!async_mode() || s == nullptr) return;
+  std::unique_lock<std::mutex> lk(s->m);
+  s->idle.wait(lk, [&] { return s->q.empty() && !s->busy; });
+}
+static void drain_all() {
+  if (!async_mode()) return;
+  std::vector<kbemu_stream *> all;
+  { std::lock_guard<std::mutex> lk(g_mu); all.assign(g_streams.begin(), g_streams.end()); }
+  for (kbemu_stream *s : all) kbemu_drain(s);
+}
+
+hipError_t hipMalloc(void **p, size_t bytes) { return alloc(p, bytes); }
+hipError_t hipFree(void *p) { drain_all(); free(p); return hipSuccess; }   // hipFree synchronises the device
+hipError_t kbemu_host_alloc(void **p, size_t bytes) {
+  hipError_t e = alloc(p, bytes);
+  if (e == hipSuccess) { std::lock_guard<std::mutex> lk(g_mu); g_pinned[(const char *)*p] = bytes ? bytes : 1; }
+  return e;
+}
+hipError_t hipHostFree(void *p) {
+  drain_all();
+  { std::lock_guard<std::mutex> lk(g_mu); g_pinned.erase((const char *)p); }
+  free(p);
+  return hipSuccess;
+}
+
+hipError_t hipMemcpy(void *dst, const void *src, size_t n, hipMemcpyKind) { if (n) memmove(dst, src, n); return hipSuccess; }   // does not wait for non-blocking streams
+hipError_t hipMemset(void *dst, int v, size_t n) { if (n) memset(dst, v, n); return hipSuccess; }
+hipError_t hipMemcpy2D(void *dst, size_t dpitch, const void *src, size_t spitch, size_t width, size_t height, hipMemcpyKind) {
+  for (size_t r = 0; r < height; r++) memmove((char *)dst + r * dpitch, (const char *)src + r * spitch, width);
+  return hipSuccess;
+}
+
+hipError_t hipMemcpyAsync(void *dst, const void *src, size_t n, hipMemcpyKind kind, hipStream_t s) {
+  if (!n) return hipSuccess;
+  if (!async_mode() || s == nullptr) { memmove(dst, src, n); return hipSuccess; }
+  if (kind == hipMemcpyHostToDevice && !is_pinned(src)) {          // pageable source: staged before the call returns
+    std::shared_ptr<std::vector<char>> tmp = std::make_shared<std::vector<char>>((const char *)src, (const char *)src + n);
+    kbemu_enqueue(s, [dst, tmp]() { memcpy(dst, tmp->data(), tmp->size()); });
+  } else if (kind == hipMemcpyDeviceToHost && !is_pinned(dst)) {   // pageable destination: complete when the call returns
+    kbemu_drain(s);
+    memmove(dst, src, n);
+  } else {
+    kbemu_enqueue(s, [dst, src, n]() { memmove(dst, src, n); });
+  }
+  return hipSuccess;
+}
+hipError_t hipMemcpy2DAsync(void *dst, size_t dpitch, const void *src, size_t spitch, size_t width, size_t height, hipMemcpyKind kind, hipStream_t s) {
+  if (async_mode() && s != nullptr) {
+    if (kind == hipMemcpyDeviceToHost && !is_pinned(dst)) kbemu_drain(s);
+    else { kbemu_enqueue(s, [=]() { hipMemcpy2D(dst, dpitch, src, spitch, width, height, kind); }); return hipSuccess; }
+  }
+  return hipMemcpy2D(dst, dpitch, src, spitch, width, height, kind);
+}
+hipError_t hipMemsetAsync(void *dst, int v, size_t n, hipStream_t s) {
+  if (n) kbemu_enqueue(s, [dst, v, n]() { memset(dst, v, n); });
+  return hipSuccess;
+}
+
+hipError_t hipStreamCreateWithFlags(hipStream_t *out, unsigned) {
+  kbemu_stream *s = new kbemu_stream();
+  if (async_mode()) s->th = std::thread([s] { s->run(); });
+  { std::lock_guard<std::mutex> lk(g_mu); g_streams.insert(s); }
+  *out = s;
+  return hipSuccess;
+}
+hipError_t hipStreamDestroy(hipStream_t s) {
+  if (!s) return hipSuccess;
+  kbemu_drain(s);
+  { std::lock_guard<std::mutex> lk(g_mu); g_streams.erase(s); }
+  if (s->th.joinable()) {
+    { std::lock_guard<std::mutex> lk(s->m); s->stop = true; }
+    s->cv.notify_one();
+    s->th.join();
+  }
+  delete s;
+  return hipSuccess;
+}
+hipError_t hipStreamSynchronize(hipStream_t s) { kbemu_drain(s); return hipSuccess; }
+
+hipError_t hipEventCreate(hipEvent_t *e) { *e = (hipEvent_t)calloc(1, sizeof(kbemu_event)); return hipSuccess; }
+hipError_t hipEventDestroy(hipEvent_t e) { drain_all(); free(e); return hipSuccess; }
+hipError_t hipEventRecord(hipEvent_t e, hipStream_t s) { kbemu_enqueue(s, [e]() { e->ms = kbemu_now_ms(); }); return hipSuccess; }
+hipError_t hipEventElapsedTime(float *ms, hipEvent_t a, hipEvent_t b) { *ms = (float)(b->ms - a->ms); return hipSuccess; }

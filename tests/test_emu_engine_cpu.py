@@ -36,13 +36,13 @@ def build_emulated_library():
     out_dir = os.path.join(HH, "build")
     os.makedirs(out_dir, exist_ok=True)
     so = os.path.join(out_dir, "libkbengine_emu.so")
-    srcs = [os.path.join(CSRC, f) for f in ("kb_engine.cpp", "kb_session.cpp", "kb_order.cpp", "kb_preempt.cpp")] + [os.path.join(HH, "device_emu.cpp")]
+    srcs = [os.path.join(CSRC, f) for f in ("kb_engine.cpp", "kb_session.cpp", "kb_order.cpp", "kb_preempt.cpp")] + [os.path.join(HH, "device_emu.cpp"), os.path.join(HH, "hip_mock", "hip_mock.cpp")]
     deps = srcs + [os.path.join(CSRC, f) for f in ("kb_device.h", "kb_eval.hpp", "kb_host.hpp", "kb_preempt.hpp")] + \
         [os.path.join(HH, "hip_mock", "hip", "hip_runtime.h"), os.path.join(HERE, "..", "include", "kb_engine.h")]
     if not os.path.exists(so) or any(os.path.getmtime(d) > os.path.getmtime(so) for d in deps):
         tmp = f"{so}.{os.getpid()}"                      # atomic: parallel pytest workers may build at the same time
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-fno-fast-math", "-Wall", "-Wno-unused-result",
-                               "-I" + os.path.join(HH, "hip_mock"), "-o", tmp] + srcs)
+                               "-pthread", "-I" + os.path.join(HH, "hip_mock"), "-o", tmp] + srcs)
         os.replace(tmp, so)
     return so
 
