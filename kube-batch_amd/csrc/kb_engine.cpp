@@ -1083,6 +1083,7 @@ int kb_session_load(kb_engine *e, const kb_snapshot *sn) {
     }
     d.aff = nullptr;
     d.aff_cls = nullptr;
+    hs.cls_has_aff.clear();
     d.wNA = e->pol.wNA;
     if (sn->class_affinity && sn->n_task_classes && sn->n_node_classes) {
       for (uint32_t t = 0; t < T; t++)
@@ -1102,6 +1103,7 @@ int kb_session_load(kb_engine *e, const kb_snapshot *sn) {
         if (e->pol.wNA < 0 || 10 * (e->pol.wL + e->pol.wM + e->pol.wB + e->pol.wNA) > 65535)
           throw EngineError(KB_E_UNSUPPORTED, "nodeorder weights exceed the 16-bit score range");
         hs.has_affinity = true;
+        hs.cls_has_aff = has;
         upload(e->b_aff, sn->class_affinity, na, s);
         upload(e->b_affcls, has.data(), has.size(), s);
         d.aff = e->b_aff.as<int32_t>();
@@ -1346,7 +1348,10 @@ static int run_evict_action(kb_engine *e, bool reclaim, kb_stmt_op *out, uint64_
     HostSession &hs = e->hs;
     if (hs.has_interpod)   // an eviction takes a pod OUT of the inter-pod counts (Running -> Releasing leaves api.AllocatedStatus): not modelled
       throw EngineError(KB_E_UNSUPPORTED, "preempt / reclaim in a session with inter-pod (anti)affinity terms is not modelled");
-    if (!reclaim && hs.has_affinity && e->pol.nodeorder_enabled)
+    // preempt with preferred node-affinity terms: the lists of such preemptors carry the NormalizeReduce'd score and are rebuilt after
+    // every Pipeline instead of repaired (kb_preempt.cpp: preempt_walk).  Checked against the oracle on the CPU (tests/host_harness);
+    // it stays behind a switch until its first run on the device — without it the stock action takes the cycle, as before.
+    if (!reclaim && hs.has_affinity && e->pol.nodeorder_enabled && !preempt_node_affinity_enabled())
       throw EngineError(KB_E_UNSUPPORTED, "preempt with preferred node-affinity terms (NormalizeReduce over the feasible set) is not modelled");
     const double t_begin = now_ms();
     const int R = hs.R;
@@ -1395,6 +1400,7 @@ static int run_evict_action(kb_engine *e, bool reclaim, kb_stmt_op *out, uint64_
       KbRound r = make_round(e, 0, 1, N + 1, 0 /* plugin predicates only */, false);
       r.mrows = e->b_mrows.as<uint32_t>();
       kb_launch_matrix(e->dev, r, e->stream);
+      kb_launch_affinity(e->dev, r, e->stream);   // NodeAffinity priority over the row's feasible set (no-op without such terms)
       kb_launch_argmax(e->dev, r, e->stream);
       std::vector<unsigned long long> raw((size_t)N + 1);
       HIP_OK(hipMemcpyAsync(raw.data(), e->b_keys.p, sizeof(unsigned long long) * raw.size(), hipMemcpyDeviceToHost, e->stream));

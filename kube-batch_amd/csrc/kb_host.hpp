@@ -173,6 +173,7 @@ struct HostSession {
   std::vector<uint8_t> compat;             // class x class bit table (empty: every pair compatible)
   uint32_t n_tc = 0, n_nc = 1;
   bool has_affinity = false;               // some class carries preferred node-affinity terms (NormalizeReduce)
+  std::vector<uint8_t> cls_has_aff;        // [n_tc] the task class has a non-zero preferred node-affinity count (empty: has_affinity is false)
   // inter-pod (anti)affinity (kb_interpod): a SUBJECT task (predicate checks or priority weights) is planned as the first row of its
   // window; a shape whose affinity REQUIRES a positive count can become feasible again (counts only grow): never marked dead
   bool has_interpod = false;

@@ -1,6 +1,8 @@
 // kb_preempt.cpp — host side of the engine's preempt action; see kb_preempt.hpp.
 #include "kb_preempt.hpp"
 
+#include <cstdlib>
+
 #include <climits>
 
 namespace kb {
@@ -506,10 +508,22 @@ bool PreemptMachine::same_preemptor_class(uint32_t a, uint32_t b) const {
   return true;
 }
 
+bool preempt_node_affinity_enabled() {
+  const char *v = std::getenv("KB_PREEMPT_NODE_AFFINITY");
+  return v && v[0] == '1';
+}
+
+// A preemptor whose class has preferred node-affinity terms is scored with NormalizeReduce over ITS feasible set
+// (vendor/.../priorities/reduce.go:28-63 behind util.PrioritizeNodes): one node leaving that set (pod cap reached, a host port
+// taken) can change every other node's score, so a cached list cannot be repaired node by node — it is rebuilt on the device.
+bool PreemptMachine::needs_exact_list(uint32_t preemptor) const {
+  return pol_->nodeorder_enabled && !hs_->cls_has_aff.empty() && hs_->cls_has_aff[hs_->t_cls[preemptor]];
+}
+
 bool PreemptMachine::preempt_walk(uint32_t preemptor, int mode) {
   // too many repaired nodes: bring the device up to date and rebuild the lists on demand.  Only the full walk below pays per dirty
   // node; with the priority rule deciding, a dirty node costs one evaluation when it is a candidate and nothing otherwise.
-  if (dirty_nodes_.size() > 256 && !prio_prunes_) {
+  if ((dirty_nodes_.size() > 256 && !prio_prunes_) || (!dirty_nodes_.empty() && needs_exact_list(preemptor))) {
     refresh_(dirty_nodes_);
     for (uint32_t n : dirty_nodes_) dirty_[n] = 0;
     dirty_nodes_.clear();

@@ -33,6 +33,9 @@ struct LiveNodes {
   std::vector<uint64_t> ports, base_ports;   // base: the share that belongs to pods outside the session
 };
 
+// KB_PREEMPT_NODE_AFFINITY=1: kb_run_preempt accepts sessions with preferred node-affinity terms (read at every call)
+bool preempt_node_affinity_enabled();
+
 class PreemptMachine {
  public:
   // `lists(shape_task, out)`: nodes passing the plugin predicates for the shape of task `shape_task`, best first in SortNodes'
@@ -115,6 +118,7 @@ class PreemptMachine {
   bool preempt_one(uint32_t preemptor, int mode);
   bool preempt_walk(uint32_t preemptor, int mode);
   bool same_preemptor_class(uint32_t a, uint32_t b) const;
+  bool needs_exact_list(uint32_t preemptor) const;
   bool try_node(uint32_t preemptor, int mode, uint32_t n);
 };
 

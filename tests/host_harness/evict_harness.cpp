@@ -72,9 +72,13 @@ int eh_load(EH *h, const kb_config *cfg, const kb_snapshot *sn, const double *jo
     const int R = hs.R;
     const uint32_t N = hs.N, T = hs.T, J = hs.J, Q = hs.Q;
     // kb_session_load sets this while it uploads the preferred node-affinity table (kb_engine.cpp): any non-zero count under a non-zero weight
-    if (sn->class_affinity && h->pol.wNA != 0)
+    hs.cls_has_aff.clear();
+    if (sn->class_affinity && h->pol.wNA != 0) {
+      std::vector<uint8_t> has(sn->n_task_classes ? sn->n_task_classes : 1, 0);
       for (size_t i = 0; i < (size_t)sn->n_task_classes * sn->n_node_classes; i++)
-        if (sn->class_affinity[i]) hs.has_affinity = true;
+        if (sn->class_affinity[i]) { hs.has_affinity = true; has[i / sn->n_node_classes] = 1; }
+      if (hs.has_affinity) hs.cls_has_aff = has;
+    }
     hs.job_alloc.assign(job_alloc, job_alloc + (size_t)J * R);
     hs.job_share.assign(job_share, job_share + J);
     hs.queue_alloc.assign(queue_alloc, queue_alloc + (size_t)Q * R);
@@ -116,7 +120,7 @@ int eh_run(EH *h, int reclaim) {
   return guarded(h, [&]() {
     HostSession &hs = h->hs;
     if (hs.has_interpod) throw EngineError(KB_E_UNSUPPORTED, "preempt / reclaim in a session with inter-pod (anti)affinity terms is not modelled");
-    if (!reclaim && hs.has_affinity && h->pol.nodeorder_enabled)
+    if (!reclaim && hs.has_affinity && h->pol.nodeorder_enabled && !preempt_node_affinity_enabled())
       throw EngineError(KB_E_UNSUPPORTED, "preempt with preferred node-affinity terms (NormalizeReduce over the feasible set) is not modelled");
     const uint32_t N = hs.N, T = hs.T, J = hs.J, Q = hs.Q;
     PreemptMachine pm;

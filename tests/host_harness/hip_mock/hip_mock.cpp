@@ -2,6 +2,8 @@
 // stream in the asynchronous mode (KB_EMU_ASYNC=1), inline execution otherwise.
 #include <hip/hip_runtime.h>
 
+#include <stdio.h>
+
 #include <chrono>
 #include <condition_variable>
 #include <deque>
@@ -22,6 +24,22 @@ bool async_mode() {
   static const bool a = env_flag("KB_EMU_ASYNC");
   return a;
 }
+
+// KB_EMU_STATS=1: a census of the runtime calls (each one costs microseconds of host time on the real runtime), printed at exit
+struct Census {
+  unsigned long long copies[4] = {0, 0, 0, 0}, copy_bytes[4] = {0, 0, 0, 0}, small_copies = 0, memsets = 0, syncs = 0, tasks = 0;
+  bool on = false;
+  Census() { on = env_flag("KB_EMU_STATS"); }
+  ~Census() {
+    if (!on) return;
+    fprintf(stderr, "[kbemu] stream tasks (launches + queued copies) %llu, synchronisations %llu, memsets %llu\n", tasks, syncs, memsets);
+    const char *kn[4] = {"H2H", "H2D", "D2H", "D2D"};
+    for (int k = 0; k < 4; k++)
+      if (copies[k]) fprintf(stderr, "[kbemu] %s copies %llu, %.1f MB\n", kn[k], copies[k], copy_bytes[k] / 1e6);
+    fprintf(stderr, "[kbemu] copies of <= 64 bytes: %llu\n", small_copies);
+  }
+  void copy(hipMemcpyKind k, size_t n) { if (on && (int)k < 4) { copies[k]++; copy_bytes[k] += n; if (n <= 64) small_copies++; } }
+} g_census;
 
 std::mutex g_mu;                              // registries below
 std::map<const char *, size_t> g_pinned;      // hipHostMalloc'ed ranges
@@ -71,6 +89,7 @@ struct kbemu_stream {
 double kbemu_now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 void kbemu_enqueue(hipStream_t s, std::function<void()> f) {
+  if (g_census.on) g_census.tasks++;
   if (!async_mode() || s == nullptr) { f(); return; }   // the null stream: the engine never launches there
   std::lock_guard<std::mutex> lk(s->m);
   s->q.push_back(std::move(f));
@@ -102,7 +121,7 @@ hipError_t hipHostFree(void *p) {
   return hipSuccess;
 }
 
-hipError_t hipMemcpy(void *dst, const void *src, size_t n, hipMemcpyKind) { if (n) memmove(dst, src, n); return hipSuccess; }   // does not wait for non-blocking streams
+hipError_t hipMemcpy(void *dst, const void *src, size_t n, hipMemcpyKind kind) { g_census.copy(kind, n); if (n) memmove(dst, src, n); return hipSuccess; }   // does not wait for non-blocking streams
 hipError_t hipMemset(void *dst, int v, size_t n) { if (n) memset(dst, v, n); return hipSuccess; }
 hipError_t hipMemcpy2D(void *dst, size_t dpitch, const void *src, size_t spitch, size_t width, size_t height, hipMemcpyKind) {
   for (size_t r = 0; r < height; r++) memmove((char *)dst + r * dpitch, (const char *)src + r * spitch, width);
@@ -110,6 +129,7 @@ hipError_t hipMemcpy2D(void *dst, size_t dpitch, const void *src, size_t spitch,
 }
 
 hipError_t hipMemcpyAsync(void *dst, const void *src, size_t n, hipMemcpyKind kind, hipStream_t s) {
+  g_census.copy(kind, n);
   if (!n) return hipSuccess;
   if (!async_mode() || s == nullptr) { memmove(dst, src, n); return hipSuccess; }
   if (kind == hipMemcpyHostToDevice && !is_pinned(src)) {          // pageable source: staged before the call returns
@@ -131,6 +151,7 @@ hipError_t hipMemcpy2DAsync(void *dst, size_t dpitch, const void *src, size_t sp
   return hipMemcpy2D(dst, dpitch, src, spitch, width, height, kind);
 }
 hipError_t hipMemsetAsync(void *dst, int v, size_t n, hipStream_t s) {
+  if (g_census.on) g_census.memsets++;
   if (n) kbemu_enqueue(s, [dst, v, n]() { memset(dst, v, n); });
   return hipSuccess;
 }
@@ -154,7 +175,7 @@ hipError_t hipStreamDestroy(hipStream_t s) {
   delete s;
   return hipSuccess;
 }
-hipError_t hipStreamSynchronize(hipStream_t s) { kbemu_drain(s); return hipSuccess; }
+hipError_t hipStreamSynchronize(hipStream_t s) { if (g_census.on) g_census.syncs++; kbemu_drain(s); return hipSuccess; }
 
 hipError_t hipEventCreate(hipEvent_t *e) { *e = (hipEvent_t)calloc(1, sizeof(kbemu_event)); return hipSuccess; }
 hipError_t hipEventDestroy(hipEvent_t e) { drain_all(); free(e); return hipSuccess; }

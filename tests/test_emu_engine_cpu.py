@@ -213,3 +213,21 @@ def test_job_with_a_missing_queue_without_proportion(oracle_mod):
         o.close()
         hit += 1
     assert hit >= 6
+
+
+@pytest.mark.parametrize("seed", range(60))
+def test_preempt_with_preferred_node_affinity_behind_its_switch(oracle_mod, seed, monkeypatch):
+    """The engine side of tests/test_host_evict_cpu.py's test of the same name: run_evict_action's list path with the NodeAffinity
+    launch between matrix and arg-max, mixed action orders included.  Off by default (KB_E_UNSUPPORTED) until its first device run."""
+    import test_gpu_preempt as gp
+    import test_host_evict_cpu as hev
+    cfg, snap, order = hev.affinity_evict_case(seed)
+    e = engine.Engine(cfg)
+    e.load(snap)
+    if "preempt" in order:
+        with pytest.raises(engine.EngineError) as err:
+            e.run(order)
+        assert err.value.code == abi.KB_E_UNSUPPORTED
+    e.close()
+    monkeypatch.setenv("KB_PREEMPT_NODE_AFFINITY", "1")
+    gp._run_both(oracle_mod, cfg, snap, order, ("affinity", seed))

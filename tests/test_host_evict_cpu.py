@@ -429,3 +429,46 @@ def test_job_with_a_missing_queue(harness, oracle_mod):
     assert rc == abi.KB_E_UNSUPPORTED, harness.eh_error(h).decode()
     assert "queue" in harness.eh_error(h).decode()
     harness.eh_destroy(h)
+
+
+def affinity_evict_case(seed):
+    """_evict_case clusters with preferred node-affinity counts on about half of the task classes and tight pod caps, so that a Pipeline
+    can push a node out of a preemptor's feasible set (NormalizeReduce then changes every other node's score)."""
+    cfg, snap, order = cases._evict_case(seed)
+    rng = np.random.RandomState(31000 + seed)
+    s = copy_snapshot(snap)
+    aff = rng.choice([0, 0, 2, 5, 30], size=(s.n_task_classes, s.n_node_classes)).astype(np.int32)
+    aff[rng.uniform(size=s.n_task_classes) < 0.4] = 0
+    if not aff.any():
+        aff[0, 0] = 7
+    s.class_affinity = aff
+    tight = rng.uniform(size=s.n_nodes) < 0.5
+    s.node_max_pods = np.where(tight, s.node_pod_cnt + rng.randint(0, 3, size=s.n_nodes), s.node_max_pods).astype(np.int32)
+    s._check()
+    order = [["preempt"], ["preempt", "preempt"], ["allocate", "preempt"], ["preempt", "reclaim", "preempt"]][seed % 4]
+    return conf.load_scheduler_conf(cases.CONF_FULL.format(actions=", ".join(order))), s, [a for a in order]
+
+
+def copy_snapshot(snap):
+    import copy
+    s = copy.copy(snap)
+    for name, val in vars(snap).items():
+        if isinstance(val, np.ndarray):
+            setattr(s, name, val.copy())
+    return s
+
+
+@pytest.mark.parametrize("seed", range(60))
+def test_preempt_with_preferred_node_affinity_behind_its_switch(harness, oracle_mod, seed, monkeypatch):
+    """KB_PREEMPT_NODE_AFFINITY=1: preemptors whose class has preferred node-affinity terms get lists with the normalised score, rebuilt
+    (not repaired) after every Pipeline; without the switch the engine keeps answering KB_E_UNSUPPORTED."""
+    cfg, snap, order = affinity_evict_case(seed)
+    evict_only = [a for a in order if a in ("preempt", "reclaim")]
+    if evict_only != order:
+        pytest.skip("the harness runs evict actions only (the emulated engine runs the mixed orders)")
+    with pytest.raises(HarnessError) as err:
+        e = HostEngine(harness, cfg, snap)
+        e.run(order)
+    assert err.value.code == abi.KB_E_UNSUPPORTED
+    monkeypatch.setenv("KB_PREEMPT_NODE_AFFINITY", "1")
+    _run_both(harness, oracle_mod, cfg, snap, order, ("affinity", seed))
