@@ -1377,7 +1377,14 @@ static int run_evict_action(kb_engine *e, bool reclaim, kb_stmt_op *out, uint64_
           ln.rel[n].v[d] = rel[(size_t)d * NP + n];
           // Releasing gains scalar keys only through Add: a dense non-zero value <=> the key is present
           if (d >= 2 && ln.rel[n].v[d] != 0.0) ln.rel[n].setk(d);
+          // Idle: the device's mask holds the keys Allocatable had (plus what an earlier evict action uploaded).  Resource.Sub also
+          // CREATES the keys of its operand in a non-nil map (resource_info.go:143-160: r.ScalarResources[name] -= quant), which is how
+          // allocate / backfill leave a negative value under a key the node never advertised (sub-epsilon requests pass LessEqual
+          // and add up).  Such a key reads non-zero, and a created key that reads 0 is indistinguishable from an absent one.
+          if (d >= 2 && ln.idle[n].mask != 0 && ln.idle[n].v[d] != 0.0) ln.idle[n].setk(d);
         }
+        // a non-nil Releasing map whose keys all read 0 (bit 31): which keys it holds does not matter, that Sub does not return early does
+        if ((nmask[n] >> 31) && ln.rel[n].mask == 0 && R > 2) ln.rel[n].setk(2);
       }
       ln.ac.assign(hs.n_ac.begin(), hs.n_ac.end()); ln.am.assign(hs.n_am.begin(), hs.n_am.end());
       ln.maxpods = hs.n_maxpods; ln.cls = hs.n_cls;

@@ -231,3 +231,36 @@ def test_preempt_with_preferred_node_affinity_behind_its_switch(oracle_mod, seed
     e.close()
     monkeypatch.setenv("KB_PREEMPT_NODE_AFFINITY", "1")
     gp._run_both(oracle_mod, cfg, snap, order, ("affinity", seed))
+
+
+@pytest.mark.parametrize("seed,ci,order", [(2096, 0, "allocate,preempt"), (2161, 3, "allocate,backfill,preempt,allocate"), (2216, 4, "allocate,preempt"),
+                                           (2420, 3, "allocate,preempt"), (2720, 3, "allocate,backfill,preempt,allocate"), (2927, 3, "allocate,preempt"),
+                                           (2983, 4, "allocate,preempt"), (3031, 3, "allocate,preempt")])
+def test_scalar_keys_created_by_allocate_survive_an_evict_action(oracle_mod, seed, ci, order):
+    """Found by scripts/hunt_evict_cpu.py on the emulated device (KB_HUNT_EMU=1), adversarial snapshots under mixed action orders:
+    Resource.Sub creates the keys of its operand in a non-nil map, so sub-epsilon requests for a scalar a node never advertised leave a
+    negative Idle value under a key its Allocatable does not have.  run_evict_action rebuilt the host mirror's key mask from the static
+    mask alone, read that value as 0 and wrote 0 back for every node the action touched."""
+    import rawgen
+    import test_gpu_preempt as gp
+    import test_pyref_vs_oracle as cases
+    confs = [cases.CONF_FULL] + cases.EVICT_CONFS
+    acts = order.split(",")
+    cfg = kbm.conf.load_scheduler_conf(confs[ci].format(actions=", ".join(acts)))
+    gp._run_both(oracle_mod, cfg, rawgen.raw_snapshot(seed), acts, (seed, ci, order))
+
+
+@pytest.mark.parametrize("seed", range(3300, 3380))
+def test_mixed_action_orders_on_adversarial_snapshots(oracle_mod, seed):
+    """allocate / backfill between and around the evict actions, on the raw snapshots and every tier layout: the combination the
+    committed suites did not have (evict-only orders on raw snapshots, mixed orders on synthetic clusters)."""
+    import rawgen
+    import test_gpu_preempt as gp
+    import test_pyref_vs_oracle as cases
+    confs = [cases.CONF_FULL] + cases.EVICT_CONFS
+    orders = [["allocate", "preempt"], ["reclaim", "allocate", "backfill", "preempt"], ["preempt", "allocate", "backfill", "reclaim"],
+              ["allocate", "backfill", "preempt", "allocate"], ["allocate", "reclaim", "preempt"]]
+    ci = seed % len(confs)
+    acts = orders[(seed // len(confs)) % len(orders)]
+    cfg = kbm.conf.load_scheduler_conf(confs[ci].format(actions=", ".join(acts)))
+    gp._run_both(oracle_mod, cfg, rawgen.raw_snapshot(seed), acts, (seed, ci, acts))
