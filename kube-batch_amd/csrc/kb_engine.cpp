@@ -145,7 +145,7 @@ struct kb_engine {
   bool idle_below_eps = false;
   DevBuf b_tfit;
   DevBuf b_tinit, b_tres, b_tnzc, b_tnzm, b_tcls, b_tactive, b_tresmask, b_tjob, b_tstatus, b_tnode, b_tbind, b_tcounted, b_jallocated, b_compat, b_crows, b_aff, b_affcls;
-  DevBuf p_idle, p_rel, p_nzc, p_nzm, p_podcnt, p_tstatus, p_tnode, p_tcounted, p_ports;   // pristine copies for kb_session_reset
+  DevBuf p_idle, p_rel, p_nzc, p_nzm, p_podcnt, p_tstatus, p_tnode, p_tcounted, p_ports, p_nmask;   // pristine copies for kb_session_reset
   // inter-pod (anti)affinity tables (kb_interpod) and the pristine copies of their live parts
   DevBuf b_ip_cdom, b_ip_ccnt, b_ip_ctot, b_ip_tinc, b_ip_tforbid, b_ip_treq, b_ip_tself, b_ip_tsubj, b_ip_tchk, b_ip_pdom, b_ip_pbound, b_ip_punb, b_ip_tcinc,
       b_ip_tsig, b_ip_sigw, b_ip_z, b_ip_scnt, b_ip_shist, p_ip_ccnt, p_ip_ctot, p_ip_punb, p_ip_z;
@@ -1216,6 +1216,7 @@ int kb_session_load(kb_engine *e, const kb_snapshot *sn) {
     snap_copy(e->p_podcnt, e->b_podcnt); snap_copy(e->p_tstatus, e->b_tstatus); snap_copy(e->p_tnode, e->b_tnode);
     if (d.ports) snap_copy(e->p_ports, e->b_ports);
     snap_copy(e->p_tcounted, e->b_tcounted);
+    snap_copy(e->p_nmask, e->b_nmask);   // the evict actions rewrite the key masks of the nodes they touch (upload_live_nodes)
     if (hs.has_interpod) { snap_copy(e->p_ip_ccnt, e->b_ip_ccnt); snap_copy(e->p_ip_ctot, e->b_ip_ctot); snap_copy(e->p_ip_punb, e->b_ip_punb); snap_copy(e->p_ip_z, e->b_ip_z); }
     // initial drf / proportion / gang aggregates come from the device reduction (K2+K4)
     run_finalize(e);
@@ -1234,6 +1235,7 @@ int kb_session_reset(kb_engine *e) {
     restore(e->b_podcnt, e->p_podcnt); restore(e->b_tstatus, e->p_tstatus); restore(e->b_tnode, e->p_tnode);
     if (e->dev.ports) restore(e->b_ports, e->p_ports);
     restore(e->b_tcounted, e->p_tcounted);
+    restore(e->b_nmask, e->p_nmask);
     if (e->hs.has_interpod) { restore(e->b_ip_ccnt, e->p_ip_ccnt); restore(e->b_ip_ctot, e->p_ip_ctot); restore(e->b_ip_punb, e->p_ip_punb); restore(e->b_ip_z, e->p_ip_z); }
     HIP_OK(hipMemsetAsync(e->b_tbind.p, 0xFF, sizeof(uint32_t) * (e->hs.T ? e->hs.T : 1), s));
     HIP_OK(hipMemsetAsync(e->b_jallocated.p, 0, e->b_jallocated.bytes, s));
