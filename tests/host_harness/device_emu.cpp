@@ -287,6 +287,12 @@ double share_of(double l, double r) { return (r == 0.0) ? ((l == 0.0) ? 0.0 : 1.
 // ---- LDS budgets: the window the engine plans depends on what the commit kernels can keep in their 160 KiB.  A model of the same
 // shape (per-row slots and descriptors, per-shape candidate lists, the dirty bitmap) so that windows come out like the GPU build's
 // for the cluster sizes the CPU suite uses; the exact byte counts live with the kernels.
+// KB_EMU_LDS_PENALTY=bytes pretends the kernels need that much more: the engine then plans small windows with few shapes each, a
+// regime the CPU suite's small clusters never reach otherwise (on the GPU it takes tens of thousands of nodes)
+static size_t lds_penalty() {
+  const char *v = getenv("KB_EMU_LDS_PENALTY");
+  return v ? (size_t)atol(v) : 0;
+}
 size_t kb_commit_smem_bytes(uint32_t n_rows, uint32_t n_shapes, uint32_t NP, int R) {
   const size_t RS = R > 2 ? (size_t)(R - 2) : 0;
   size_t off = 0;
@@ -294,12 +300,12 @@ size_t kb_commit_smem_bytes(uint32_t n_rows, uint32_t n_shapes, uint32_t NP, int
   off += (size_t)R * 8 + (size_t)n_shapes * RS * 8 + (size_t)n_shapes * 64 + (size_t)n_rows * sizeof(KbRowDesc);
   off = (off + 15) & ~(size_t)15;
   off += (size_t)n_rows * 16 + (size_t)n_rows * 8 + 48 + 256 * 4 + 64 * 4 + 64 * 4 + (size_t)n_shapes * 4 + (size_t)n_shapes * 4;
-  off += (size_t)n_shapes * ((size_t)n_rows + 1) * 4 + (size_t)(NP / 32) * 4;
+  off += (size_t)n_shapes * ((size_t)n_rows + 1) * 4 + (size_t)(NP / 32) * 4 + lds_penalty();
   return (off + 15) & ~(size_t)15;
 }
 size_t kb_commit_batch_smem_bytes(uint32_t cap, uint32_t NP, int R) {
   const size_t cap2 = (size_t)cap + 32;
-  return cap2 * (13 * 8 + 8 + 8 + 12) + (size_t)cap * 28 + (size_t)(NP / 32) * 4 + (size_t)32 * (R > 2 ? R - 2 : 0) * 8 + 256 + 4096 + (size_t)cap * 4;
+  return cap2 * (13 * 8 + 8 + 8 + 12) + (size_t)cap * 28 + (size_t)(NP / 32) * 4 + (size_t)32 * (R > 2 ? R - 2 : 0) * 8 + 256 + 4096 + (size_t)cap * 4 + lds_penalty();
 }
 
 // ---- launch wrappers (kb_device.h) ----

@@ -47,9 +47,17 @@ def build_emulated_library():
     return so
 
 
+REAL_DEVICE = os.environ.get("KB_EMU_USE_REAL") == "1"   # on the GPU box: the cases that were born here, against the real kernels
+
+
 @pytest.fixture(autouse=True)
 def emulated_engine():
-    """engine.lib() binds whatever engine.LIB_PATH names: point it at the emulated build for the duration of a test of THIS module."""
+    """engine.lib() binds whatever engine.LIB_PATH names: point it at the emulated build for the duration of a test of THIS module.
+    KB_EMU_USE_REAL=1 leaves the product library in place instead (scripts/first_gpu_call_r3.sh): the regression cases the emulated
+    hunts produced then run on the MI355X before they are promoted into the `-m gpu` suite."""
+    if REAL_DEVICE:
+        yield engine.LIB_PATH
+        return
     so = build_emulated_library()
     saved = (engine.LIB_PATH, engine._LIB)
     engine.LIB_PATH, engine._LIB = so, None
@@ -64,6 +72,8 @@ def test_the_emulated_library_exports_the_whole_c_abi(emulated_engine):
 
 
 def test_product_library_path_is_untouched_outside_this_module():
+    if REAL_DEVICE:
+        pytest.skip("running against the product library")
     assert engine.LIB_PATH.endswith("libkbengine_emu.so")          # inside a test of this module
     assert os.path.basename(os.path.dirname(engine.__file__)) == "kube-batch_amd"
     src = open(engine.__file__).read()
