@@ -313,7 +313,8 @@ int  kb_session_reset(kb_engine *e);
 
 int  kb_run_allocate(kb_engine *e, kb_decision *out, uint64_t cap, uint64_t *n_out);
 int  kb_run_backfill(kb_engine *e, kb_decision *out, uint64_t cap, uint64_t *n_out);
-/* the preempt action on the session's current state; journal entries in order (KB_E_CAPACITY: *n_out = required count).
+/* the preempt action on the session's current state; journal entries in order (KB_E_CAPACITY: *n_out = required count; no result was
+   applied, but the device's copy of some nodes may have been refreshed mid-action: kb_session_load again before the next call).
    KB_E_UNSUPPORTED: sessions with preferred node-affinity terms (NormalizeReduce over a feasible set the repairs would change) unless
    KB_PREEMPT_NODE_AFFINITY=1 is set in the environment (lists rebuilt after every Pipeline; CPU-verified, off until its first device run),
    and states in which the reference itself would panic / abort (Resource.Sub underflow, NodeInfo.UpdateTask). */

@@ -62,21 +62,16 @@ func (p *gpuPreemptAction) Execute(ssn *framework.Session) {
 		p.fallback.Execute(ssn)
 		return
 	}
-	// the journal lives in C memory; at most one Evict per running task, one Pipeline per pending task, two markers per statement
-	capOps := C.size_t(4*len(fl.tasks) + 16)
-	ops := (*C.kb_stmt_op)(C.calloc(capOps, C.size_t(unsafe.Sizeof(C.kb_stmt_op{}))))
-	if ops == nil {
+	ops, n, rc := runJournal(p.alloc.engine, &fl.snap, false, len(fl.tasks))
+	if ops != nil {
+		defer C.free(unsafe.Pointer(ops))
+	}
+	if rc != C.KB_OK { // nothing was applied: the stock action is still valid
+		glog.Warningf("gpupreempt: run rc=%d (%s); stock action takes this cycle", int(rc), C.GoString(C.kb_last_error(p.alloc.engine)))
 		p.fallback.Execute(ssn)
 		return
 	}
-	defer C.free(unsafe.Pointer(ops))
-	var n C.uint64_t
-	if rc := C.kb_run_preempt(p.alloc.engine, ops, C.uint64_t(capOps), &n); rc != C.KB_OK { // nothing was applied: the stock action is still valid
-		glog.Warningf("gpupreempt: run rc=%d (%s); stock action takes this cycle", rc, C.GoString(C.kb_last_error(p.alloc.engine)))
-		p.fallback.Execute(ssn)
-		return
-	}
-	journal := (*[1 << 28]C.kb_stmt_op)(unsafe.Pointer(ops))[:int(n):int(n)]
+	journal := (*[1 << 28]C.kb_stmt_op)(unsafe.Pointer(ops))[:n:n]
 
 	var stmt *framework.Statement
 	cur := C.uint32_t(0)
@@ -106,6 +101,37 @@ func (p *gpuPreemptAction) Execute(ssn *framework.Session) {
 		case C.KB_OP_DISCARD: // preempt.go:131
 			stmt.Discard()
 		}
+	}
+}
+
+// runJournal calls kb_run_preempt / kb_run_reclaim with a journal buffer in C memory (the engine fills it, Go only reads it).  There is
+// no useful a-priori bound on the journal: every discarded statement adds its Evict / Pipeline entries again, so a first guess of a few
+// entries per task is used and, on KB_E_CAPACITY (no result was applied; *n_out holds the required count), the session is loaded again
+// — the action may have refreshed the device's copy of some nodes while it ran — and the call repeated once with exactly that size.
+// The caller frees the returned buffer.
+func runJournal(eng *C.kb_engine, snap *C.kb_snapshot, reclaim bool, nTasks int) (*C.kb_stmt_op, int, C.int) {
+	capOps := C.size_t(4*nTasks + 16)
+	for attempt := 0; ; attempt++ {
+		ops := (*C.kb_stmt_op)(C.calloc(capOps, C.size_t(unsafe.Sizeof(C.kb_stmt_op{}))))
+		if ops == nil {
+			return nil, 0, C.KB_E_INTERNAL
+		}
+		var n C.uint64_t
+		var rc C.int
+		if reclaim {
+			rc = C.kb_run_reclaim(eng, ops, C.uint64_t(capOps), &n)
+		} else {
+			rc = C.kb_run_preempt(eng, ops, C.uint64_t(capOps), &n)
+		}
+		if rc == C.KB_E_CAPACITY && attempt == 0 && n > 0 {
+			C.free(unsafe.Pointer(ops))
+			if rl := C.kb_session_load(eng, snap); rl != C.KB_OK {
+				return nil, 0, rl
+			}
+			capOps = C.size_t(n)
+			continue
+		}
+		return ops, int(n), rc
 	}
 }
 
@@ -147,20 +173,16 @@ func (p *gpuReclaimAction) Execute(ssn *framework.Session) {
 		p.fallback.Execute(ssn)
 		return
 	}
-	capOps := C.size_t(2*len(fl.tasks) + 16)
-	ops := (*C.kb_stmt_op)(C.calloc(capOps, C.size_t(unsafe.Sizeof(C.kb_stmt_op{}))))
-	if ops == nil {
+	ops, n, rc := runJournal(p.alloc.engine, &fl.snap, true, len(fl.tasks))
+	if ops != nil {
+		defer C.free(unsafe.Pointer(ops))
+	}
+	if rc != C.KB_OK {
+		glog.Warningf("gpureclaim: run rc=%d (%s); stock action takes this cycle", int(rc), C.GoString(C.kb_last_error(p.alloc.engine)))
 		p.fallback.Execute(ssn)
 		return
 	}
-	defer C.free(unsafe.Pointer(ops))
-	var n C.uint64_t
-	if rc := C.kb_run_reclaim(p.alloc.engine, ops, C.uint64_t(capOps), &n); rc != C.KB_OK {
-		glog.Warningf("gpureclaim: run rc=%d (%s); stock action takes this cycle", rc, C.GoString(C.kb_last_error(p.alloc.engine)))
-		p.fallback.Execute(ssn)
-		return
-	}
-	journal := (*[1 << 28]C.kb_stmt_op)(unsafe.Pointer(ops))[:int(n):int(n)]
+	journal := (*[1 << 28]C.kb_stmt_op)(unsafe.Pointer(ops))[:n:n]
 	for i := range journal {
 		op := journal[i]
 		switch op.op {

@@ -1435,7 +1435,7 @@ static int run_evict_action(kb_engine *e, bool reclaim, kb_stmt_op *out, uint64_
     if (reclaim) pm.run_reclaim(); else pm.run();
     // ---- results: journal out, state back to the device
     if (n_out) *n_out = pm.ops.size();
-    if (pm.ops.size() > cap) throw EngineError(KB_E_CAPACITY, "journal buffer too small");   // nothing was written to the device yet
+    if (pm.ops.size() > cap) throw EngineError(KB_E_CAPACITY, "journal buffer too small");   // no result was written; a refresh may have updated nodes on the device: load the session again before another action
     for (size_t i = 0; i < pm.ops.size(); i++) { out[i].op = pm.ops[i].op; out[i].task = pm.ops[i].task; out[i].node = pm.ops[i].node; out[i].stmt = pm.ops[i].stmt; }
     upload_live_nodes(e, ln, pm.touched_nodes);
     hs.t_status = status;
