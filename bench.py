@@ -45,6 +45,20 @@ tiers:
       balancedresource.weight: 1
 """
 
+PREEMPT_CONF = """
+actions: "allocate, backfill, preempt"
+tiers:
+- plugins:
+  - name: priority
+  - name: gang
+  - name: conformance
+- plugins:
+  - name: drf
+  - name: predicates
+  - name: proportion
+  - name: nodeorder
+"""
+
 
 def _k(n):
     return f"{n // 1000}k" if n >= 1000 and n % 1000 == 0 else str(n)
@@ -65,6 +79,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-tasks", type=int, default=0, help="0 = the whole allocate action (a few seconds on 16 threads)")
     ap.add_argument("--verify", action="store_true", help="with --no-cpu-baseline: still compare the bind set with the oracle after the timed region")
+    ap.add_argument("--preempt", action="store_true", help="BASELINE configs[4] names allocate + backfill + preempt: a step becomes reset -> allocate -> backfill -> "
+                    "preempt under the default tiers plus conformance (scripts/time_preempt.py's configuration); single GPU only")
     args = ap.parse_args()
 
     import numpy as np
@@ -97,6 +113,12 @@ def main():
     if args.config == 4:                           # BASELINE configs[3] "binpack weighted scoring" (SURVEY.md §8d synthetic inputs)
         conf = kbm.conf.load_scheduler_conf(BINPACK_CONF)
         weights = "least 0, most 5, balanced 1"
+    if args.preempt:
+        if world > 1:
+            print("bench.py: --preempt runs on one GPU (the sharded path covers allocate and backfill)", file=sys.stderr)
+            sys.exit(2)
+        nodeorder_args = BINPACK_CONF.split("  - name: nodeorder\n")[1] if args.config == 4 else ""
+        conf = kbm.conf.load_scheduler_conf(PREEMPT_CONF + nodeorder_args)
     params = kbm.snapshot.synth_config(args.config, args.scale)
     if args.diverse:
         params.diverse_requests = True
@@ -104,7 +126,7 @@ def main():
         params.node_cpu_cores = (16, 32, 64, 96, 128)
         params.node_mem_gib = (64, 128, 256, 512)
     snap = kbm.snapshot.synth(params)
-    actions = ["allocate", "backfill"]
+    actions = ["allocate", "backfill"] + (["preempt"] if args.preempt else [])
 
     if world > 1 or force_sharded:
         distmod = importlib.import_module("kube-batch_amd.dist")
@@ -218,7 +240,7 @@ def main():
         "ms_per_step": elapsed * 1e3 / args.steps, "higher_is_better": True, "scaling": "strong",
         "vs_baseline": None, "dtype": "f64+i64", "data": "synthetic",
         "config": {"workload": f"BASELINE configs[{args.config - 1}]: {snap.n_tasks} tasks x {snap.n_nodes} nodes, "
-                               f"{snap.n_jobs} gang jobs, {snap.n_queues} queues, R={R}, allocate+backfill, "
+                               f"{snap.n_jobs} gang jobs, {snap.n_queues} queues, R={R}, {'+'.join(actions)}, "
                                f"plugins priority,gang,drf,predicates,proportion,nodeorder ({weights})",
                    "window": args.window or 256, "scale": args.scale, "diverse_requests": bool(args.diverse),
                    "node_sizes": "SURVEY 8d list (no capacity pressure)" if args.survey_nodes else "sized for demand ~1.3x capacity"},
@@ -263,6 +285,9 @@ def main():
             # the oracle has just run the whole allocate action for the baseline: let it finish the cycle (backfill, untimed) and
             # check the engine's bind set and evaluation count against it, so every headline line carries its own verification
             o.backfill()
+            if args.preempt:
+                o.preempt()
+                out["verified_evictions_equal_oracle"] = bool([int(t) for t in eng.evictions()] == [int(t) for t in o.evictions()])
             out["verified_bind_set_equals_oracle"] = bool(np.array_equal(binds, o.binds()))
             out["verified_evals_equal_oracle"] = bool(o.evals == out["evals_per_step"])
         o.close()
@@ -273,6 +298,8 @@ def main():
             o.set_fast(True)
             out["verified_with"] = "oracle fast mode"
         o.run(actions)
+        if args.preempt:
+            out["verified_evictions_equal_oracle"] = bool([int(t) for t in eng.evictions()] == [int(t) for t in o.evictions()])
         out["verified_bind_set_equals_oracle"] = bool(np.array_equal(binds, o.binds()))
         out["verified_evals_equal_oracle"] = bool(o.evals == out["evals_per_step"])
     if rank == 0:

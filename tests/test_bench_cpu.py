@@ -1,0 +1,69 @@
+"""bench.py's own control flow — argument handling, the timed loop, the roofline / cpu_baseline / verification objects, the one JSON line the
+driver parses — run on the CPU: the engine library is the emulated build of tests/test_emu_engine_cpu.py and torch.cuda is answered by a
+stand-in.  The NUMBERS of such a run mean nothing (an emulated device has no bandwidth); what is checked is that the line has every
+field of the bench contract, that the bind set is verified against the oracle in the same run, and that a flag cannot break the default."""
+import importlib
+import io
+import json
+import os
+import sys
+from contextlib import redirect_stdout
+
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path[:0] = [HERE, os.path.dirname(HERE)]
+import test_emu_engine_cpu as emu  # noqa: E402
+
+engine = importlib.import_module("kube-batch_amd.engine")
+
+
+def _run_bench(monkeypatch, argv):
+    import torch
+    bench = importlib.import_module("bench")
+    monkeypatch.setattr(torch.cuda, "is_available", lambda: True)
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 1)
+    monkeypatch.setattr(torch.cuda, "set_device", lambda d: None)
+    monkeypatch.setattr(torch.cuda, "synchronize", lambda *a, **k: None)
+    monkeypatch.setattr(engine, "LIB_PATH", emu.build_emulated_library())
+    monkeypatch.setattr(engine, "_LIB", None)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        monkeypatch.delenv(k, raising=False)
+    monkeypatch.setattr(sys, "argv", ["bench.py"] + argv)
+    buf = io.StringIO()
+    with redirect_stdout(buf):
+        bench.main()
+    lines = [l for l in buf.getvalue().splitlines() if l.strip()]
+    assert len(lines) == 1, lines                      # ONE JSON line
+    return json.loads(lines[0])
+
+
+CONTRACT = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
+            "config", "roofline", "cpu_baseline")
+
+
+def test_default_line_has_every_field_and_verifies_itself(monkeypatch):
+    out = _run_bench(monkeypatch, ["--scale", "0.02", "--steps", "2", "--warmup", "1"])
+    for k in CONTRACT:
+        assert k in out, k
+    assert out["n_gpus"] == 1 and out["steps"] == 2 and out["warmup"] == 1 and out["unit"] == "evals/s" and out["vs_baseline"] is None
+    assert out["config"]["workload"].startswith("BASELINE configs[2]") and "allocate+backfill" in out["config"]["workload"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in out["roofline"], k
+    assert out["roofline"]["bound"] == "hbm" and out["roofline"]["traffic"] is None      # a scaled run matches no committed PMC profile
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in out["cpu_baseline"], k
+    assert out["verified_bind_set_equals_oracle"] is True and out["verified_evals_equal_oracle"] is True
+    assert out["binds"] > 0 and out["evals_per_step"] > 0
+
+
+@pytest.mark.parametrize("argv", [["--config", "4", "--scale", "0.02", "--steps", "1", "--warmup", "0"],
+                                  ["--config", "3", "--scale", "0.02", "--diverse", "--steps", "1", "--no-cpu-baseline", "--verify"],
+                                  ["--config", "5", "--scale", "0.004", "--steps", "1", "--preempt", "--no-cpu-baseline", "--verify"],
+                                  ["--config", "3", "--scale", "0.02", "--steps", "2", "--preempt"]])
+def test_variants_produce_a_verified_line(monkeypatch, argv):
+    out = _run_bench(monkeypatch, argv)
+    assert out["verified_bind_set_equals_oracle"] is True and out["verified_evals_equal_oracle"] is True, out
+    if "--preempt" in argv:
+        assert out["verified_evictions_equal_oracle"] is True
+        assert "allocate+backfill+preempt" in out["config"]["workload"]
