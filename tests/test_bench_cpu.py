@@ -67,3 +67,12 @@ def test_variants_produce_a_verified_line(monkeypatch, argv):
     if "--preempt" in argv:
         assert out["verified_evictions_equal_oracle"] is True
         assert "allocate+backfill+preempt" in out["config"]["workload"]
+
+
+def test_smoke_entry_point_runs_end_to_end(monkeypatch, capsys):
+    """__graft_entry__.smoke() is what the driver runs on the MI355X before the bench: its own Python must not be what fails there."""
+    monkeypatch.setattr(engine, "LIB_PATH", emu.build_emulated_library())
+    monkeypatch.setattr(engine, "_LIB", None)
+    entry = importlib.import_module("__graft_entry__")
+    entry.smoke()
+    assert "smoke ok" in capsys.readouterr().out
