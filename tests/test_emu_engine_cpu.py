@@ -310,3 +310,39 @@ def test_session_reset_after_evict_actions_reproduces_the_first_run(seed):
         ran += 1
     if not ran:
         pytest.skip("both snapshots are outside the engine's envelope")
+
+
+def test_journal_capacity_contract(oracle_mod):
+    """kb_run_preempt with a journal buffer that is too small answers KB_E_CAPACITY with the required count and applies no result; after
+    kb_session_load the same call with that count gives the journal a roomy first call gives (what the Go shim's runJournal does)."""
+    import test_pyref_vs_oracle as cases
+    done = 0
+    for seed in range(40):
+        cfg, snap, _ = cases._evict_case(seed)
+        ref = engine.Engine(cfg)
+        ref.load(snap)
+        try:
+            ref.run_preempt()
+        except engine.EngineError:
+            ref.close()
+            continue
+        want = ref.last_journal
+        ref.close()
+        if len(want) < 3:
+            continue
+        e = engine.Engine(cfg)
+        e.load(snap)
+        n = C.c_uint64()
+        small = (abi.StmtOp * 2)()
+        assert e.L.kb_run_preempt(e.h, small, 2, C.byref(n)) == abi.KB_E_CAPACITY
+        assert n.value == len(want)
+        assert len(e.evictions()) == 0                                  # no result was applied
+        e.load(snap)
+        exact = (abi.StmtOp * n.value)()
+        n2 = C.c_uint64()
+        assert e.L.kb_run_preempt(e.h, exact, n.value, C.byref(n2)) == abi.KB_OK and n2.value == n.value
+        got = np.frombuffer(exact, dtype=np.uint32).reshape(n.value, 4)
+        assert np.array_equal(got, want)
+        e.close()
+        done += 1
+    assert done >= 10
