@@ -10,7 +10,7 @@ kb_argmax_rows plumbing, kb_round_* (the sharded path's entry points), the evict
 What it does NOT cover: the kernels.  Their parity with the oracle is the `-m gpu` suite on the MI355X; the product has no CPU path
 (tests/test_abi_cpu.py::test_create_without_gpu_fails_loudly) and this library is never loaded outside this file.
 
-Full-size configurations (tests/test_gpu_fullsize.py) are left to the GPU: a sequential matrix over 10k-50k nodes per round is minutes."""
+The full-size configurations 3 and 4 (100k x 10k) run here too, against the golden digests (about fifteen seconds each); 1M x 50k on request."""
 import ctypes as C
 import importlib
 import os
@@ -346,3 +346,14 @@ def test_journal_capacity_contract(oracle_mod):
         e.close()
         done += 1
     assert done >= 10
+
+
+@pytest.mark.parametrize("name", ["config3_full", "config4_binpack_full", "config5_full"])
+def test_full_size_cycles_through_the_host_side(oracle_mod, name):
+    """BASELINE configs[2] and [3] at full size (100k x 10k) through the engine's host side on the emulated device, against the oracle and
+    the committed golden digests (tests/test_gpu_fullsize.py's own test function): about fifteen seconds each.  The 1M x 50k
+    configuration takes two and a half minutes of sequential evaluation: KB_EMU_FULLSIZE_5=1 (passed when this test was written)."""
+    import test_gpu_fullsize as fs
+    if name in fs.mfg.FAST and os.environ.get("KB_EMU_FULLSIZE_5") != "1":
+        pytest.skip("1M x 50k on the emulated device: set KB_EMU_FULLSIZE_5=1 (about 2.5 minutes)")
+    fs.test_full_size_cycle_equals_oracle_and_golden_digest(oracle_mod, name)
