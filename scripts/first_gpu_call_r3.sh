@@ -19,5 +19,6 @@ KB_EMU_USE_REAL=1 python -m pytest tests/test_emu_engine_cpu.py -q -k "preferred
 echo "preempt + node affinity (each case sets KB_PREEMPT_NODE_AFFINITY=1 itself after checking the refusal without it) rc=$?" | tee -a "$out/summary.txt"
 # 4. the three actions of BASELINE configs[4] after the host work on the evict machine (not re-measured since)
 python scripts/time_preempt.py 5 1.0 > "$out/time_preempt_config5.txt" 2>&1; echo "time_preempt rc=$?" | tee -a "$out/summary.txt"
-python bench.py --config 5 --preempt --steps 2 --warmup 1 --verify --no-cpu-baseline > "$out/bench_config5_three_actions.json" 2> "$out/bench_config5_three_actions.err"; echo "bench config 5 with preempt rc=$?" | tee -a "$out/summary.txt"
+python bench.py --config 5 --scale 0.1 --preempt --steps 2 --warmup 1 --verify --no-cpu-baseline > "$out/bench_config5_scale0.1_three_actions_verified.json" 2>> "$out/bench_config5_three_actions.err"
+python bench.py --config 5 --preempt --steps 2 --warmup 1 --no-cpu-baseline > "$out/bench_config5_three_actions.json" 2> "$out/bench_config5_three_actions.err"; echo "bench config 5 with preempt rc=$?" | tee -a "$out/summary.txt"
 python bench.py > "$out/bench_default.json" 2> "$out/bench_default.err"; echo "bench rc=$?" | tee -a "$out/summary.txt"
