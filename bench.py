@@ -288,22 +288,24 @@ def main():
             if args.preempt:
                 o.preempt()
                 out["verified_evictions_equal_oracle"] = bool([int(t) for t in eng.evictions()] == [int(t) for t in o.evictions()])
+                ej, oj = eng.journal(), o.journal()
+                out["verified_journal_equals_oracle"] = bool(ej.shape == oj.shape and np.array_equal(ej, oj))
+                out["journal_entries"] = int(len(ej))
             out["verified_bind_set_equals_oracle"] = bool(np.array_equal(binds, o.binds()))
             out["verified_evals_equal_oracle"] = bool(o.evals == out["evals_per_step"])
         o.close()
-    if rank == 0 and args.verify and args.preempt and snap.n_tasks * snap.n_nodes > 4_000_000_000:
-        # the oracle's incremental mode covers allocate / backfill; its preempt walks every node for every preemptor (hours at 1M x 50k)
-        out["verified_with"] = "not verified at this size: the oracle's preempt is not incremental (run --scale 0.1 --preempt --verify)"
-        args.verify = False
     if rank == 0 and args.verify and "verified_bind_set_equals_oracle" not in out:
         import oracle
         o = oracle.Oracle(conf, snap, threads=min(16, os.cpu_count() or 1))
         if snap.n_tasks * snap.n_nodes > 4_000_000_000:   # config 5: the oracle's incremental mode (tests/test_oracle_fast_cpu.py)
             o.set_fast(True)
-            out["verified_with"] = "oracle fast mode"
+            out["verified_with"] = "oracle fast mode (allocate: cached rows + one-node repairs; preempt: per-queue node sets + cached SortNodes lists), held to the faithful mode in tests/test_oracle_fast_cpu.py"
         o.run(actions)
         if args.preempt:
             out["verified_evictions_equal_oracle"] = bool([int(t) for t in eng.evictions()] == [int(t) for t in o.evictions()])
+            ej, oj = eng.journal(), o.journal()       # every Statement operation of the last step, with statement numbers and commit / discard markers
+            out["verified_journal_equals_oracle"] = bool(ej.shape == oj.shape and np.array_equal(ej, oj))
+            out["journal_entries"] = int(len(ej))
         out["verified_bind_set_equals_oracle"] = bool(np.array_equal(binds, o.binds()))
         out["verified_evals_equal_oracle"] = bool(o.evals == out["evals_per_step"])
     if rank == 0:

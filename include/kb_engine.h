@@ -315,9 +315,10 @@ int  kb_run_allocate(kb_engine *e, kb_decision *out, uint64_t cap, uint64_t *n_o
 int  kb_run_backfill(kb_engine *e, kb_decision *out, uint64_t cap, uint64_t *n_out);
 /* the preempt action on the session's current state; journal entries in order (KB_E_CAPACITY: *n_out = required count; no result was
    applied, but the device's copy of some nodes may have been refreshed mid-action: kb_session_load again before the next call).
-   KB_E_UNSUPPORTED: sessions with preferred node-affinity terms (NormalizeReduce over a feasible set the repairs would change) unless
-   KB_PREEMPT_NODE_AFFINITY=1 is set in the environment (lists rebuilt after every Pipeline; CPU-verified, off until its first device run),
-   and states in which the reference itself would panic / abort (Resource.Sub underflow, NodeInfo.UpdateTask). */
+   Sessions with preferred node-affinity terms are scored with NormalizeReduce over the preemptor's feasible set, which one Pipeline can
+   change for every node: their lists are rebuilt after every Pipeline instead of repaired (KB_PREEMPT_NODE_AFFINITY=0 in the environment
+   restores the round-2 refusal, KB_E_UNSUPPORTED).  KB_E_UNSUPPORTED: states in which the reference itself would panic / abort
+   (Resource.Sub underflow, NodeInfo.UpdateTask). */
 int  kb_run_preempt(kb_engine *e, kb_stmt_op *out, uint64_t cap, uint64_t *n_out);
 /* the reclaim action (pkg/scheduler/actions/reclaim/reclaim.go:41-193; victims through ssn.Reclaimable, framework/session_plugins.go:
    80-119, with proportion's rule plugins/proportion/proportion.go:171-196).  There is no Statement: every EVICT entry is an

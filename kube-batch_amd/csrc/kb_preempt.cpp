@@ -509,8 +509,8 @@ bool PreemptMachine::same_preemptor_class(uint32_t a, uint32_t b) const {
 }
 
 bool preempt_node_affinity_enabled() {
-  const char *v = std::getenv("KB_PREEMPT_NODE_AFFINITY");
-  return v && v[0] == '1';
+  const char *v = std::getenv("KB_PREEMPT_NODE_AFFINITY");   // default on since its first device run (round 3); "0" restores the refusal
+  return !(v && v[0] == '0');
 }
 
 // A preemptor whose class has preferred node-affinity terms is scored with NormalizeReduce over ITS feasible set

@@ -33,7 +33,7 @@ struct LiveNodes {
   std::vector<uint64_t> ports, base_ports;   // base: the share that belongs to pods outside the session
 };
 
-// KB_PREEMPT_NODE_AFFINITY=1: kb_run_preempt accepts sessions with preferred node-affinity terms (read at every call)
+// kb_run_preempt accepts sessions with preferred node-affinity terms unless KB_PREEMPT_NODE_AFFINITY=0 (read at every call)
 bool preempt_node_affinity_enabled();
 
 class PreemptMachine {

@@ -111,11 +111,13 @@ class Engine:
 
     def load(self, snap):
         self.snap = snap
+        self._journals = []
         s = snap.to_abi()
         self._ck(self.L.kb_session_load(self.h, C.byref(s)))
 
     def reset(self):
         """Back to the just-loaded state from the pristine copy resident in HBM (no host upload)."""
+        self._journals = []
         self._ck(self.L.kb_session_reset(self.h))
 
     def _run(self, fn):
@@ -145,7 +147,12 @@ class Engine:
         rc = (fn or self.L.kb_run_preempt)(self.h, arr, cap, C.byref(n))
         self._ck(rc)
         self.last_journal = np.frombuffer(arr, dtype=np.uint32).reshape(cap, 4)[: n.value].copy()
+        self._journals.append(self.last_journal)
         return np.zeros((0, 3), np.uint32)       # no ssn.Allocate / ssn.Pipeline decisions: the journal carries the Statement ops
+
+    def journal(self):
+        """The journals of every preempt / reclaim action since the session was loaded (or reset), concatenated in action order."""
+        return np.concatenate(self._journals) if self._journals else np.zeros((0, 4), np.uint32)
 
     def evictions(self):
         """Task ids the committed statements handed to cache.Evict, in that order."""

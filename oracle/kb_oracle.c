@@ -426,6 +426,14 @@ typedef struct kbo_session {
   /* node -> tasks in ni.Tasks (bitmap over T per node would be too big: a linked list through next_on_node, head per node;
      the scans below sort what they collect, so list order does not matter).  Built by node_index_build(). */
   uint32_t *node_head, *next_on_node, *prev_on_node;
+  /* what preempt / reclaim did, in order, in the shape the engine's C ABI reports it (include/kb_engine.h: kb_stmt_op): every
+     Statement.Evict / Statement.Pipeline with the number of its ssn.Statement() (1-based, in creation order), a COMMIT / DISCARD
+     marker closing every statement that holds at least one operation; reclaim has no Statement: ssn.Evict / ssn.Pipeline with stmt 0 */
+  kb_stmt_op *journal;
+  uint64_t n_journal, cap_journal;
+  uint32_t stmt_no;
+  uint64_t mutations;   /* Statement operations and their undos so far (fast preempt: "nothing has changed since") */
+  struct pfast_t *px;   /* fast mode of preempt (below) */
   /* inter-pod (anti)affinity (include/kb_engine.h: kb_interpod), NULL tables: no pod carries a term.  Counts are kept
      incrementally by ssn_allocate / ssn_pipeline (allocate and backfill only add; preempt / reclaim refuse such sessions). */
   int ip_on;
@@ -1069,6 +1077,7 @@ void kbo_close(kbo_session *s) {
   for (uint32_t q = 0; q < s->Q; q++) heap_free(&s->queues[q].jobs);
   free(s->nodes); free(s->tasks); free(s->jobs); free(s->queues); free(s->compat); free(s->affinity); free(s->evictions);
   fast_free(s);
+  free(s->journal);
   free(s->ip_ctr_dom); free(s->ip_ctr_count); free(s->ip_ctr_total); free(s->ip_task_inc); free(s->ip_task_forbid); free(s->ip_task_require);
   free(s->ip_task_self); free(s->ip_cls_dom); free(s->ip_cls_bound); free(s->ip_cls_unbound); free(s->ip_task_cls_inc); free(s->ip_task_sig);
   free(s->ip_sig_weight);
@@ -1361,6 +1370,12 @@ static void node_update_task(kbo_session *s, uint32_t t, int status) {
   node_remove_task(s, t);
   if (node_add_task(s, t, s->tasks[t].node, status) != 0) s->panic = 1;
 }
+static void journal_push(kbo_session *s, uint32_t op, uint32_t task, uint32_t node, uint32_t stmt) {
+  if (s->n_journal == s->cap_journal) { s->cap_journal = s->cap_journal ? s->cap_journal * 2 : 64; s->journal = (kb_stmt_op *)realloc(s->journal, sizeof(kb_stmt_op) * s->cap_journal); }
+  kb_stmt_op e = {op, task, node, stmt};
+  s->journal[s->n_journal++] = e;
+}
+static void pfast_node_changed(kbo_session *s, uint32_t n);
 typedef struct stmt_op { uint8_t kind; uint32_t task; } stmt_op;   /* 0 evict, 1 pipeline */
 typedef struct stmt_t { stmt_op *ops; size_t n, cap; } stmt_t;
 static void stmt_push(stmt_t *st, uint8_t kind, uint32_t task) {
@@ -1368,28 +1383,36 @@ static void stmt_push(stmt_t *st, uint8_t kind, uint32_t task) {
   st->ops[st->n].kind = kind; st->ops[st->n].task = task; st->n++;
 }
 static void stmt_evict(kbo_session *s, stmt_t *st, uint32_t t) {          /* statement.go:36-69 */
+  s->mutations++;
+  journal_push(s, KB_OP_EVICT, t, s->tasks[t].node, s->stmt_no);
   job_set_status(s, t, KB_TASK_RELEASING);
   node_update_task(s, t, KB_TASK_RELEASING);
   fire_deallocate_event(s, t);
   stmt_push(st, 0, t);
 }
 static void stmt_unevict(kbo_session *s, uint32_t t) {                     /* statement.go:83-110 */
+  s->mutations++;
   job_set_status(s, t, KB_TASK_RUNNING);
   node_update_task(s, t, KB_TASK_RUNNING);
   fire_allocate_event(s, t);
 }
 static void stmt_pipeline(kbo_session *s, stmt_t *st, uint32_t t, uint32_t n) {   /* statement.go:113-150 */
+  s->mutations++;
+  journal_push(s, KB_OP_PIPELINE, t, n, s->stmt_no);
   job_set_status(s, t, KB_TASK_PIPELINED);
-  node_add_task(s, t, n, KB_TASK_PIPELINED);
+  if (node_add_task(s, t, n, KB_TASK_PIPELINED) == 0) pfast_node_changed(s, n);
   fire_allocate_event(s, t);
   stmt_push(st, 1, t);
 }
 static void stmt_unpipeline(kbo_session *s, uint32_t t) {                  /* statement.go:155-190 */
+  s->mutations++;
   job_set_status(s, t, KB_TASK_PENDING);
+  if (s->tasks[t].on_node) pfast_node_changed(s, s->tasks[t].node);
   node_remove_task(s, t);                        /* task.NodeName keeps the old host (node_info.go:217-243 never clears it) */
   fire_deallocate_event(s, t);
 }
 static void stmt_discard(kbo_session *s, stmt_t *st) {                     /* statement.go:193-205: newest first */
+  if (st->n) journal_push(s, KB_OP_DISCARD, KB_NONE, KB_NONE, s->stmt_no);
   for (size_t i = st->n; i-- > 0;) {
     if (st->ops[i].kind == 0) stmt_unevict(s, st->ops[i].task);
     else stmt_unpipeline(s, st->ops[i].task);
@@ -1397,6 +1420,7 @@ static void stmt_discard(kbo_session *s, stmt_t *st) {                     /* st
   st->n = 0;
 }
 static void stmt_commit(kbo_session *s, stmt_t *st) {                      /* statement.go:208-220: evict -> cache.Evict */
+  if (st->n) journal_push(s, KB_OP_COMMIT, KB_NONE, KB_NONE, s->stmt_no);
   for (size_t i = 0; i < st->n; i++) {
     if (st->ops[i].kind != 0) continue;
     if (s->n_evict == s->cap_evict) { s->cap_evict = s->cap_evict ? s->cap_evict * 2 : 64; s->evictions = (uint32_t *)realloc(s->evictions, sizeof(uint32_t) * s->cap_evict); }
@@ -1492,10 +1516,45 @@ static int sort_nodes_cmp(const void *a, const void *b) {
   if (g_sort_score[x] != g_sort_score[y]) return g_sort_score[x] > g_sort_score[y] ? -1 : 1;
   return x > y ? -1 : (x < y ? 1 : 0);
 }
-/* preempt(): preempt.go:171-254.  mode 0: victims are Running tasks of OTHER jobs in the preemptor job's queue; mode 1: of the same job */
-static int preempt_one(kbo_session *s, stmt_t *st, uint32_t preemptor, int mode, uint8_t *feas, double *score, uint32_t *order) {
+/* the body of preempt()'s loop over selectedNodes for ONE node (preempt.go:192-251): 1 = the preemptor was pipelined here.
+   mode 0: victims are Running tasks of OTHER jobs in the preemptor job's queue (:112-124); mode 1: of the same job (:150-157) */
+static int preempt_try_node(kbo_session *s, stmt_t *st, uint32_t preemptor, int mode, uint32_t n, uint32_t *pre, uint32_t *vic) {
   o_task *pt = &s->tasks[preemptor];
   const o_job *pj = &s->jobs[pt->job];
+  size_t np_ = 0;
+  for (uint32_t t = s->node_head[n]; t != KB_NONE; t = s->next_on_node[t]) {   /* node.Tasks, filtered */
+    const o_task *tk = &s->tasks[t];
+    if (tk->node_status != KB_TASK_RUNNING) continue;
+    if (mode == 0) { if (!(s->jobs[tk->job].queue == pj->queue && tk->job != pt->job)) continue; }
+    else if (tk->job != pt->job) continue;
+    pre[np_++] = t;
+  }
+  if (np_ == 0) return 0;                      /* ssn.Preemptable of nothing is nothing: validateVictims "no victims" */
+  qsort(pre, np_, sizeof(uint32_t), cmp_u32);   /* canonical order: ascending task index */
+  size_t nv = ssn_evictable(s, preemptor, pre, np_, vic, 0);
+  if (nv == 0) return 0;                       /* validateVictims: "no victims" */
+  kbo_res all; res_zero(&all);
+  for (size_t i = 0; i < nv; i++) res_add(&all, &s->tasks[vic[i]].resreq, s->R);
+  if (!res_less_equal(&pt->init_resreq, &all, s->R)) return 0;   /* "not enough resources" */
+  heap_t vq; heap_init(&vq, victim_less, s);
+  for (size_t i = 0; i < nv; i++) heap_push(&vq, vic[i]);
+  kbo_res preempted; res_zero(&preempted);
+  while (vq.n > 0) {                          /* lowest priority first (preempt.go:229-241) */
+    uint32_t v = heap_pop(&vq);
+    stmt_evict(s, st, v);
+    res_add(&preempted, &s->tasks[v].resreq, s->R);
+    if (res_less_equal(&pt->init_resreq, &preempted, s->R)) break;
+  }
+  heap_free(&vq);
+  if (res_less_equal(&pt->init_resreq, &preempted, s->R)) {      /* preempt.go:247-256 */
+    stmt_pipeline(s, st, preemptor, n);
+    return 1;
+  }
+  return 0;
+}
+/* preempt(): preempt.go:171-254, the faithful form: every node evaluated, sorted and visited for every preemptor */
+static int preempt_one(kbo_session *s, stmt_t *st, uint32_t preemptor, int mode, uint8_t *feas, double *score, uint32_t *order) {
+  o_task *pt = &s->tasks[preemptor];
   eval_all_nodes(s, pt, 0, feas, score);       /* PredicateNodes with ssn.PredicateFn only, PrioritizeNodes */
   s->evals += s->N;
   uint32_t nf = 0;
@@ -1507,40 +1566,157 @@ static int preempt_one(kbo_session *s, stmt_t *st, uint32_t preemptor, int mode,
   uint32_t *pre = (uint32_t *)malloc(sizeof(uint32_t) * (s->T ? s->T : 1));
   uint32_t *vic = (uint32_t *)malloc(sizeof(uint32_t) * (s->T ? s->T : 1));
   int assigned = 0;
-  for (uint32_t oi = 0; oi < nf && !assigned; oi++) {
-    const uint32_t n = order[oi];
-    size_t np_ = 0;
-    for (uint32_t t = s->node_head[n]; t != KB_NONE; t = s->next_on_node[t]) {   /* node.Tasks, filtered (preempt.go:112-124 / :150-157) */
-      const o_task *tk = &s->tasks[t];
-      if (tk->node_status != KB_TASK_RUNNING) continue;
-      if (mode == 0) { if (!(s->jobs[tk->job].queue == pj->queue && tk->job != pt->job)) continue; }
-      else if (tk->job != pt->job) continue;
-      pre[np_++] = t;
-    }
-    qsort(pre, np_, sizeof(uint32_t), cmp_u32);   /* canonical order: ascending task index */
-    size_t nv = ssn_evictable(s, preemptor, pre, np_, vic, 0);
-    if (nv == 0) continue;                     /* validateVictims: "no victims" */
-    kbo_res all; res_zero(&all);
-    for (size_t i = 0; i < nv; i++) res_add(&all, &s->tasks[vic[i]].resreq, s->R);
-    if (!res_less_equal(&pt->init_resreq, &all, s->R)) continue;   /* "not enough resources" */
-    heap_t vq; heap_init(&vq, victim_less, s);
-    for (size_t i = 0; i < nv; i++) heap_push(&vq, vic[i]);
-    kbo_res preempted; res_zero(&preempted);
-    while (vq.n > 0) {                          /* lowest priority first (preempt.go:229-241) */
-      uint32_t v = heap_pop(&vq);
-      stmt_evict(s, st, v);
-      res_add(&preempted, &s->tasks[v].resreq, s->R);
-      if (res_less_equal(&pt->init_resreq, &preempted, s->R)) break;
-    }
-    heap_free(&vq);
-    if (res_less_equal(&pt->init_resreq, &preempted, s->R)) {      /* preempt.go:247-256 */
-      stmt_pipeline(s, st, preemptor, n);
-      assigned = 1;
-    }
-  }
+  for (uint32_t oi = 0; oi < nf && !assigned; oi++) assigned = preempt_try_node(s, st, preemptor, mode, order[oi], pre, vic);
   free(pre); free(vic);
   return assigned;
 }
+
+/* ================================================================================================
+ * FAST MODE of preempt (kbo_set_fast; the golden journal of BASELINE configs[4], 1M tasks x 50k nodes, where the faithful
+ * preempt_one above — N evaluations, a sort and a walk over every node for each of a million preemptors — needs hours).
+ * Derived from preempt.go:171-254 and scheduler_helper.go:51-56,174-185 alone; three facts about that code, each exact:
+ *  (1) A node contributes nothing to preempt()'s loop unless node.Tasks holds a Running task the filter accepts (an empty
+ *      preemptee list makes ssn.Preemptable return no victims -> validateVictims "no victims" -> continue).  Both filters accept
+ *      only Running tasks of the preemptor's queue.  Inside the action a task is Running on a node only if it was there when
+ *      the action started (Evict makes it Releasing, the undo of a discarded statement puts it back on the same node), so the
+ *      nodes that held a Running task of queue q at the start are a superset of the nodes that can matter for q's preemptors:
+ *      only those are visited, in SortNodes order.
+ *  (2) The order — descending score, ties by descending node name — is a function of the plugin predicates and the scorers,
+ *      which read the node's pod count, non-zero request sums and host ports (predicates.go:127,181-190; nodeorder), not
+ *      Idle / Releasing.  Evict + its undo leave those as they were (UpdateTask = RemoveTask + AddTask of the same pod); only
+ *      Statement.Pipeline and its undo change them, for one node.  So the sorted candidate list of (preemptor shape, queue) is
+ *      cached and rebuilt when a node of that queue's set was pipelined onto or un-pipelined since (a change log).  Shape = what
+ *      plugin_predicate and node_score read of the task: static class, non-zero request, conflicting ports.
+ *  (3) preempt() is a function of (session state, preemptor's job, shape, InitResreq, Resreq, filter).  If it ended without a
+ *      single Statement operation for one preemptor, and no operation or undo has happened since, it ends the same way for the
+ *      next preemptor of the same job with the same shape and requests (the tasks of a gang): answered without a walk.
+ * Sessions whose scores are normalised over the feasible set (preferred node affinity) keep the faithful path, like allocate.
+ * `evals` counts N per preemptor in both modes.  tests/test_oracle_fast_cpu.py holds this mode to the faithful one.
+ * ============================================================================================== */
+typedef struct pfast_list { uint32_t *nodes; uint32_t n; uint64_t built_at; int valid; } pfast_list;
+typedef struct pfast_shape { uint32_t cls; int64_t nz_cpu, nz_mem; uint64_t port_conflict; uint32_t rep; pfast_list *lists; /* [Q] */ } pfast_shape;
+typedef struct pfast_t {
+  uint32_t *qn_begin, *qn_nodes;   /* per queue: nodes that held a Running task of it when the action started, ascending */
+  uint8_t *qn_bits;                /* [Q][ceil(N/8)] the same as a bitmap */
+  size_t row_bytes;
+  uint32_t *changed; uint64_t n_changed, cap_changed;   /* nodes a Pipeline or its undo touched, in order */
+  pfast_shape *shapes; uint32_t n_shapes, cap_shapes;
+  uint32_t *task_shape;            /* [T] */
+  double *key;                     /* [N] scratch: score of the candidates being sorted */
+  /* (3): the last preemptor that left no trace */
+  uint32_t memo_task; int memo_mode; uint64_t memo_mut; int memo_valid;
+} pfast_t;
+static void pfast_free(kbo_session *s) {
+  pfast_t *f = s->px;
+  if (!f) return;
+  for (uint32_t i = 0; i < f->n_shapes; i++) {
+    for (uint32_t q = 0; q < s->Q; q++) free(f->shapes[i].lists[q].nodes);
+    free(f->shapes[i].lists);
+  }
+  free(f->qn_begin); free(f->qn_nodes); free(f->qn_bits); free(f->changed); free(f->shapes); free(f->task_shape); free(f->key); free(f);
+  s->px = NULL;
+}
+static void pfast_init(kbo_session *s) {
+  pfast_t *f = (pfast_t *)calloc(1, sizeof(pfast_t));
+  const uint32_t N = s->N, Q = s->Q;
+  f->row_bytes = ((size_t)N + 7) / 8;
+  f->qn_bits = (uint8_t *)calloc((size_t)(Q ? Q : 1) * (f->row_bytes ? f->row_bytes : 1), 1);
+  f->qn_begin = (uint32_t *)calloc((size_t)Q + 2, sizeof(uint32_t));
+  for (uint32_t t = 0; t < s->T; t++) {
+    const o_task *tk = &s->tasks[t];
+    if (!tk->on_node || tk->node >= N || tk->node_status != KB_TASK_RUNNING) continue;
+    const uint32_t q = s->jobs[tk->job].queue;
+    if (q >= Q) continue;
+    uint8_t *b = &f->qn_bits[(size_t)q * f->row_bytes + (tk->node >> 3)];
+    if (!(*b & (1u << (tk->node & 7)))) { *b |= (uint8_t)(1u << (tk->node & 7)); f->qn_begin[q + 1]++; }
+  }
+  for (uint32_t q = 0; q < Q; q++) f->qn_begin[q + 1] += f->qn_begin[q];
+  f->qn_nodes = (uint32_t *)malloc(sizeof(uint32_t) * (f->qn_begin[Q] ? f->qn_begin[Q] : 1));
+  for (uint32_t q = 0; q < Q; q++) {
+    uint32_t w = f->qn_begin[q];
+    const uint8_t *row = &f->qn_bits[(size_t)q * f->row_bytes];
+    for (uint32_t n = 0; n < N; n++) if (row[n >> 3] & (1u << (n & 7))) f->qn_nodes[w++] = n;
+  }
+  f->task_shape = (uint32_t *)malloc(sizeof(uint32_t) * (s->T ? s->T : 1));
+  for (uint32_t t = 0; t < s->T; t++) f->task_shape[t] = KB_NONE;
+  f->key = (double *)malloc(sizeof(double) * (N ? N : 1));
+  s->px = f;
+}
+static void pfast_node_changed(kbo_session *s, uint32_t n) {
+  pfast_t *f = s->px;
+  if (!f) return;
+  if (f->n_changed == f->cap_changed) { f->cap_changed = f->cap_changed ? f->cap_changed * 2 : 256; f->changed = (uint32_t *)realloc(f->changed, sizeof(uint32_t) * f->cap_changed); }
+  f->changed[f->n_changed++] = n;
+}
+static uint32_t pfast_shape_of(kbo_session *s, uint32_t t) {
+  pfast_t *f = s->px;
+  if (f->task_shape[t] != KB_NONE) return f->task_shape[t];
+  const o_task *tk = &s->tasks[t];
+  if (t > 0 && f->task_shape[t - 1] != KB_NONE) {          /* the tasks of a job mostly repeat their predecessor */
+    const pfast_shape *p = &f->shapes[f->task_shape[t - 1]];
+    if (p->cls == tk->cls && p->nz_cpu == tk->nz_cpu && p->nz_mem == tk->nz_mem && p->port_conflict == tk->port_conflict) return f->task_shape[t] = f->task_shape[t - 1];
+  }
+  for (uint32_t i = 0; i < f->n_shapes; i++) {
+    const pfast_shape *p = &f->shapes[i];
+    if (p->cls == tk->cls && p->nz_cpu == tk->nz_cpu && p->nz_mem == tk->nz_mem && p->port_conflict == tk->port_conflict) return f->task_shape[t] = i;
+  }
+  if (f->n_shapes == f->cap_shapes) { f->cap_shapes = f->cap_shapes ? f->cap_shapes * 2 : 64; f->shapes = (pfast_shape *)realloc(f->shapes, sizeof(pfast_shape) * f->cap_shapes); }
+  pfast_shape *p = &f->shapes[f->n_shapes];
+  p->cls = tk->cls; p->nz_cpu = tk->nz_cpu; p->nz_mem = tk->nz_mem; p->port_conflict = tk->port_conflict; p->rep = t;
+  p->lists = (pfast_list *)calloc(s->Q ? s->Q : 1, sizeof(pfast_list));
+  return f->task_shape[t] = f->n_shapes++;
+}
+/* SortNodes over the queue's node set for this shape against the CURRENT node state */
+static const pfast_list *pfast_list_of(kbo_session *s, uint32_t shape, uint32_t q) {
+  pfast_t *f = s->px;
+  pfast_list *l = &f->shapes[shape].lists[q];
+  if (l->valid) {
+    const uint8_t *row = &f->qn_bits[(size_t)q * f->row_bytes];
+    for (uint64_t i = l->built_at; i < f->n_changed && l->valid; i++) {
+      const uint32_t n = f->changed[i];
+      if (row[n >> 3] & (1u << (n & 7))) l->valid = 0;
+    }
+    l->built_at = f->n_changed;
+    if (l->valid) return l;
+  }
+  const uint32_t a = f->qn_begin[q], b = f->qn_begin[q + 1];
+  if (!l->nodes) l->nodes = (uint32_t *)malloc(sizeof(uint32_t) * (b - a ? b - a : 1));
+  const o_task *rep = &s->tasks[f->shapes[shape].rep];
+  uint32_t nf = 0;
+  for (uint32_t i = a; i < b; i++) {
+    const uint32_t n = f->qn_nodes[i];
+    if (!plugin_predicate(s, rep, &s->nodes[n])) continue;
+    f->key[n] = node_score(s, rep, &s->nodes[n]);
+    l->nodes[nf++] = n;
+  }
+  g_sort_score = f->key;
+  qsort(l->nodes, nf, sizeof(uint32_t), sort_nodes_cmp);
+  l->n = nf; l->built_at = f->n_changed; l->valid = 1;
+  return l;
+}
+static int pfast_same_request(const kbo_session *s, const o_task *a, const o_task *b) {
+  if (a->resreq.mask != b->resreq.mask || a->init_resreq.mask != b->init_resreq.mask) return 0;
+  for (int d = 0; d < s->R; d++) if (a->resreq.v[d] != b->resreq.v[d] || a->init_resreq.v[d] != b->init_resreq.v[d]) return 0;
+  return 1;
+}
+static int preempt_one_fast(kbo_session *s, stmt_t *st, uint32_t preemptor, int mode, uint32_t *pre, uint32_t *vic) {
+  pfast_t *f = s->px;
+  const o_task *pt = &s->tasks[preemptor];
+  s->evals += s->N;
+  const uint32_t q = s->jobs[pt->job].queue;
+  const uint32_t shape = pfast_shape_of(s, preemptor);
+  if (f->memo_valid && f->memo_mut == s->mutations && f->memo_mode == mode) {          /* (3) */
+    const o_task *m = &s->tasks[f->memo_task];
+    if (m->job == pt->job && f->task_shape[f->memo_task] == shape && pfast_same_request(s, m, pt)) return 0;
+  }
+  const uint64_t before = s->mutations;
+  const pfast_list *l = pfast_list_of(s, shape, q);
+  int assigned = 0;
+  for (uint32_t i = 0; i < l->n && !assigned; i++) assigned = preempt_try_node(s, st, preemptor, mode, l->nodes[i], pre, vic);
+  if (!assigned && s->mutations == before) { f->memo_valid = 1; f->memo_task = preemptor; f->memo_mode = mode; f->memo_mut = before; }
+  return assigned;
+}
+
 int kbo_preempt(kbo_session *s) {
   if (s->panic) return KBO_PANIC;
   if (s->ip_on) return -3;   /* evictions would take pods OUT of the inter-pod counts: not restated (the engine refuses such sessions too) */
@@ -1550,9 +1726,13 @@ int kbo_preempt(kbo_session *s) {
     for (uint32_t t = s->node_head[n]; t != KB_NONE; t = s->next_on_node[t]) mine |= s->tasks[t].port_want;
     s->nodes[n].base_ports = s->nodes[n].ports & ~mine;
   }
+  const int fast = s->fast && !(s->affinity && s->nodeorder_enabled);   /* NormalizeReduce over the feasible set: faithful */
   uint8_t *feas = (uint8_t *)malloc(s->N ? s->N : 1);
   double *score = (double *)malloc(sizeof(double) * (s->N ? s->N : 1));
   uint32_t *order = (uint32_t *)malloc(sizeof(uint32_t) * (s->N ? s->N : 1));
+  uint32_t *pre = (uint32_t *)malloc(sizeof(uint32_t) * (s->T ? s->T : 1));
+  uint32_t *vic = (uint32_t *)malloc(sizeof(uint32_t) * (s->T ? s->T : 1));
+  if (fast) pfast_init(s);
   heap_t *qjobs = (heap_t *)calloc(s->Q ? s->Q : 1, sizeof(heap_t));     /* preemptorsMap */
   heap_t *jtasks = (heap_t *)calloc(s->J ? s->J : 1, sizeof(heap_t));    /* preemptorTasks */
   uint8_t *qseen = (uint8_t *)calloc(s->Q ? s->Q : 1, 1), *under = (uint8_t *)calloc(s->J ? s->J : 1, 1);
@@ -1569,6 +1749,7 @@ int kbo_preempt(kbo_session *s) {
     }
   }
   stmt_t st = {0};
+  s->stmt_no = 0;
   for (uint32_t q = 0; q < s->Q; q++) {
     if (!qseen[q]) continue;
     for (;;) {                                                             /* between jobs within the queue (preempt.go:80-139) */
@@ -1576,11 +1757,12 @@ int kbo_preempt(kbo_session *s) {
       uint32_t pj = heap_pop(&qjobs[q]);
       int assigned = 0;
       st.n = 0;
+      s->stmt_no++;                                                        /* stmt := ssn.Statement() (preempt.go:91) */
       for (;;) {
         if (jtasks[pj].n == 0) break;
         uint32_t preemptor = heap_pop(&jtasks[pj]);
         s->popped++;
-        if (preempt_one(s, &st, preemptor, 0, feas, score, order)) assigned = 1;
+        if (fast ? preempt_one_fast(s, &st, preemptor, 0, pre, vic) : preempt_one(s, &st, preemptor, 0, feas, score, order)) assigned = 1;
         if (ssn_job_pipelined(s, &s->jobs[pj])) { stmt_commit(s, &st); break; }
       }
       if (!ssn_job_pipelined(s, &s->jobs[pj])) { stmt_discard(s, &st); continue; }
@@ -1593,7 +1775,8 @@ int kbo_preempt(kbo_session *s) {
         uint32_t preemptor = heap_pop(&jtasks[j]);
         s->popped++;
         st.n = 0;
-        int assigned = preempt_one(s, &st, preemptor, 1, feas, score, order);
+        s->stmt_no++;                                                      /* preempt.go:153 */
+        int assigned = fast ? preempt_one_fast(s, &st, preemptor, 1, pre, vic) : preempt_one(s, &st, preemptor, 1, feas, score, order);
         stmt_commit(s, &st);
         if (!assigned) break;
       }
@@ -1601,7 +1784,8 @@ int kbo_preempt(kbo_session *s) {
   }
   for (uint32_t q = 0; q < s->Q; q++) heap_free(&qjobs[q]);
   for (uint32_t j = 0; j < s->J; j++) heap_free(&jtasks[j]);
-  free(qjobs); free(jtasks); free(qseen); free(under); free(st.ops); free(feas); free(score); free(order);
+  free(qjobs); free(jtasks); free(qseen); free(under); free(st.ops); free(feas); free(score); free(order); free(pre); free(vic);
+  pfast_free(s);
   free(s->node_head); free(s->next_on_node); free(s->prev_on_node);
   s->node_head = s->next_on_node = s->prev_on_node = NULL;   /* the other actions add tasks without the index */
   return s->panic ? KBO_PANIC : 0;
@@ -1667,6 +1851,7 @@ int kbo_reclaim(kbo_session *s) {
       for (size_t i = 0; i < nv; i++) {                                    /* in victim-list order (reclaim.go:156-169) */
         const uint32_t v = vic[i];
         record_eviction(s, v);                                             /* ssn.Evict: cache.Evict first */
+        journal_push(s, KB_OP_EVICT, v, s->tasks[v].node, 0);
         job_set_status(s, v, KB_TASK_RELEASING);
         node_update_task(s, v, KB_TASK_RELEASING);
         fire_deallocate_event(s, v);
@@ -1674,6 +1859,7 @@ int kbo_reclaim(kbo_session *s) {
         if (res_less_equal(&pt->init_resreq, &reclaimed, s->R)) break;
       }
       if (res_less_equal(&pt->init_resreq, &reclaimed, s->R)) {            /* reclaim.go:174-183 */
+        journal_push(s, KB_OP_PIPELINE, task, n, 0);
         if (ssn_pipeline(s, task, n) == KBO_PANIC) break;
         assigned = 1;
       }
@@ -1687,6 +1873,8 @@ int kbo_reclaim(kbo_session *s) {
   return s->panic ? KBO_PANIC : 0;
 }
 uint64_t kbo_n_evictions(const kbo_session *s) { return s->n_evict; }
+uint64_t kbo_n_journal(const kbo_session *s) { return s->n_journal; }
+void kbo_get_journal(const kbo_session *s, kb_stmt_op *out) { memcpy(out, s->journal, sizeof(kb_stmt_op) * s->n_journal); }
 void kbo_get_evictions(const kbo_session *s, uint32_t *out) { memcpy(out, s->evictions, sizeof(uint32_t) * s->n_evict); }
 
 /* actions/backfill/backfill.go:40-71 (jobs ascending JobID, Pending tasks ascending UID, nodes ascending name) */

@@ -52,7 +52,7 @@ def lib():
         L.kbo_backfill.restype = C.c_int
         L.kbo_preempt.restype = C.c_int
         L.kbo_reclaim.restype = C.c_int
-        for name in ("kbo_n_decisions", "kbo_n_binds", "kbo_evals", "kbo_popped", "kbo_n_evictions"):
+        for name in ("kbo_n_decisions", "kbo_n_binds", "kbo_evals", "kbo_popped", "kbo_n_evictions", "kbo_n_journal"):
             getattr(L, name).restype = C.c_uint64
             getattr(L, name).argtypes = [C.c_void_p]
         L.kbo_panicked.argtypes = [C.c_void_p]
@@ -98,8 +98,9 @@ class Oracle:
             pass
 
     def set_fast(self, on=True):
-        """Incremental mode of the allocate loop (per-shape cached rows + one-node repairs): same decisions, for snapshots the
-        faithful mode needs minutes for.  Checked against the faithful mode in tests/test_oracle_fast_cpu.py."""
+        """Incremental modes of the allocate loop (per-shape cached rows + one-node repairs) and of preempt (per-queue node sets,
+        cached SortNodes lists, one walk per run of identical preemptors): same decisions and journal, for snapshots the faithful
+        mode needs minutes or hours for.  Checked against the faithful mode in tests/test_oracle_fast_cpu.py."""
         self.L.kbo_set_fast(self.h, 1 if on else 0)
 
     def set_task_limit(self, n):
@@ -117,13 +118,13 @@ class Oracle:
             raise RuntimeError(f"oracle backfill rc={rc}")
 
     def preempt(self):
-        """actions/preempt/preempt.go (restated for the next engine action; the engine does not run it yet)."""
+        """actions/preempt/preempt.go:45-254."""
         rc = self.L.kbo_preempt(self.h)
         if rc != 0:
             raise RuntimeError(f"oracle preempt rc={rc} (reference would panic)")
 
     def reclaim(self):
-        """actions/reclaim/reclaim.go (restated for a later engine action; the engine does not run it yet)."""
+        """actions/reclaim/reclaim.go:41-193."""
         rc = self.L.kbo_reclaim(self.h)
         if rc != 0:
             raise RuntimeError(f"oracle reclaim rc={rc} (reference would panic)")
@@ -133,6 +134,15 @@ class Oracle:
         n = self.L.kbo_n_evictions(self.h)
         out = np.empty(max(n, 1), np.uint32)
         self.L.kbo_get_evictions(C.c_void_p(self.h), _p(out, C.c_uint32))
+        return out[:n]
+
+    def journal(self):
+        """What preempt / reclaim did, in order, as (op, task, node, stmt) rows in the engine's kb_stmt_op convention
+        (include/kb_engine.h): Evict / Pipeline entries with their statement number, a COMMIT / DISCARD marker closing every
+        non-empty statement; reclaim's ssn.Evict / ssn.Pipeline carry stmt 0."""
+        n = self.L.kbo_n_journal(self.h)
+        out = np.empty((max(n, 1), 4), np.uint32)
+        self.L.kbo_get_journal(C.c_void_p(self.h), _p(out, C.c_uint32))
         return out[:n]
 
     def run(self, actions):

@@ -3,7 +3,7 @@
 (100k tasks x 10k nodes; config 4 = 16 resource dimensions under the bin-packing weights BASELINE names: mostrequested 5,
 leastrequested 0, balancedresource 1).  tests/test_gpu_fullsize.py compares the engine with the live oracle AND with these
 digests, so full-size exactness is part of the driver's -m gpu record and an oracle that drifts between rounds is caught too.
-Not reference outputs (the reference is Go and cannot run here).  Takes about a minute:  python tests/golden/make_fullsize_golden.py
+Not reference outputs (the reference is Go and cannot run here).  Takes about five minutes:  python tests/golden/make_fullsize_golden.py
 """
 import hashlib
 import importlib
@@ -31,14 +31,35 @@ tiers:
       balancedresource.weight: 1
 """
 
+# BASELINE configs[4] as it is stated: allocate + backfill + preempt (default tiers plus conformance, bench.py --preempt)
+PREEMPT_CONF = """
+actions: "allocate, backfill, preempt"
+tiers:
+- plugins:
+  - name: priority
+  - name: gang
+  - name: conformance
+- plugins:
+  - name: drf
+  - name: predicates
+  - name: proportion
+  - name: nodeorder
+"""
+
 CASES = {  # name -> (config index, scheduler conf text or None for the default)
     "config3_full": (3, None),
     "config4_binpack_full": (4, BINPACK_CONF),
     "config5_full": (5, None),     # 1M tasks x 50k nodes, allocate + backfill
+    "config5_full_preempt": (5, PREEMPT_CONF),   # 1M x 50k, allocate + backfill + preempt: decisions, binds, Statement journal, evictions
 }
-# config 5 takes the faithful loop several minutes: its digest comes from the oracle's fast mode (kbo_set_fast), which
-# tests/test_oracle_fast_cpu.py holds to the faithful mode on every smaller snapshot and on the two full-size digests above
-FAST = {"config5_full"}
+# config 5 takes the faithful loop several minutes (and its preempt hours): its digests come from the oracle's fast modes
+# (kbo_set_fast), which tests/test_oracle_fast_cpu.py holds to the faithful modes on every smaller snapshot, on every preempt /
+# reclaim case of the suite, and on the two full-size digests above
+FAST = {"config5_full", "config5_full_preempt"}
+
+
+def case_actions(name):
+    return ["allocate", "backfill", "preempt"] if name.endswith("_preempt") else ["allocate", "backfill"]
 
 
 def case_inputs(kbm, name):
@@ -48,10 +69,15 @@ def case_inputs(kbm, name):
     return conf, snap
 
 
-def digest_of(np, decisions, binds):
+def digest_of(np, decisions, binds, journal=None, evictions=None):
+    """sha256 over the ordered decision list and the bind set; for the cases with an evict action also over the Statement
+    journal (op, task, node, stmt rows) and the evictions in cache.Evict order"""
     h = hashlib.sha256()
     h.update(np.ascontiguousarray(decisions, dtype=np.uint32).tobytes())
     h.update(np.ascontiguousarray(binds, dtype=np.uint32).tobytes())
+    if journal is not None:
+        h.update(np.ascontiguousarray(journal, dtype=np.uint32).tobytes())
+        h.update(np.ascontiguousarray(evictions, dtype=np.uint32).tobytes())
     return h.hexdigest()
 
 
@@ -66,11 +92,17 @@ def main():
         o = oracle.Oracle(conf, snap, threads=min(16, os.cpu_count() or 1))
         if name in FAST:
             o.set_fast(True)
-        o.run(["allocate", "backfill"])
+        o.run(case_actions(name))
+        evict = name.endswith("_preempt")
         out[name] = {"tasks": int(snap.n_tasks), "nodes": int(snap.n_nodes), "n_res": int(snap.n_res),
                      "decisions": int(o.decisions().shape[0]), "binds": int((o.binds() != kbm.abi.KB_NONE).sum()),
-                     "evals": int(o.evals), "sha256": digest_of(np, o.decisions(), o.binds()),
+                     "evals": int(o.evals),
+                     "sha256": digest_of(np, o.decisions(), o.binds(), o.journal() if evict else None, o.evictions() if evict else None),
                      "oracle_mode": "fast" if name in FAST else "faithful"}
+        if evict:
+            j = o.journal()
+            out[name].update({"journal": int(len(j)), "evictions": int(len(o.evictions())), "popped": int(o.popped),
+                              "journal_ops": {k: int((j[:, 0] == v).sum()) for k, v in (("evict", 0), ("pipeline", 1), ("commit", 2), ("discard", 3))}})
         print(name, out[name])
         o.close()
     with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "fullsize_digests.json"), "w") as f:

@@ -65,7 +65,7 @@ def test_variants_produce_a_verified_line(monkeypatch, argv):
     out = _run_bench(monkeypatch, argv)
     assert out["verified_bind_set_equals_oracle"] is True and out["verified_evals_equal_oracle"] is True, out
     if "--preempt" in argv:
-        assert out["verified_evictions_equal_oracle"] is True
+        assert out["verified_evictions_equal_oracle"] is True and out["verified_journal_equals_oracle"] is True and out["journal_entries"] >= 0
         assert "allocate+backfill+preempt" in out["config"]["workload"]
 
 

@@ -47,17 +47,9 @@ def build_emulated_library():
     return so
 
 
-REAL_DEVICE = os.environ.get("KB_EMU_USE_REAL") == "1"   # on the GPU box: the cases that were born here, against the real kernels
-
-
 @pytest.fixture(autouse=True)
 def emulated_engine():
-    """engine.lib() binds whatever engine.LIB_PATH names: point it at the emulated build for the duration of a test of THIS module.
-    KB_EMU_USE_REAL=1 leaves the product library in place instead (scripts/first_gpu_call_r3.sh): the regression cases the emulated
-    hunts produced then run on the MI355X before they are promoted into the `-m gpu` suite."""
-    if REAL_DEVICE:
-        yield engine.LIB_PATH
-        return
+    """engine.lib() binds whatever engine.LIB_PATH names: point it at the emulated build for the duration of a test of THIS module."""
     so = build_emulated_library()
     saved = (engine.LIB_PATH, engine._LIB)
     engine.LIB_PATH, engine._LIB = so, None
@@ -72,8 +64,6 @@ def test_the_emulated_library_exports_the_whole_c_abi(emulated_engine):
 
 
 def test_product_library_path_is_untouched_outside_this_module():
-    if REAL_DEVICE:
-        pytest.skip("running against the product library")
     assert engine.LIB_PATH.endswith("libkbengine_emu.so")          # inside a test of this module
     assert os.path.basename(os.path.dirname(engine.__file__)) == "kube-batch_amd"
     src = open(engine.__file__).read()
@@ -99,7 +89,8 @@ def _adopt(module_name, only=None):
         globals()[f"{name}__{module_name[5:]}"] = obj
 
 
-for _m in ("test_gpu_parity", "test_gpu_fuzz", "test_gpu_adversarial", "test_gpu_interpod", "test_gpu_preempt", "test_framework_actions"):
+# test_gpu_regressions: the cases the hunts on this emulated device produced (round 2), since promoted into the `-m gpu` suite
+for _m in ("test_gpu_parity", "test_gpu_fuzz", "test_gpu_adversarial", "test_gpu_interpod", "test_gpu_preempt", "test_framework_actions", "test_gpu_regressions"):
     _adopt(_m)
 
 
@@ -161,194 +152,7 @@ def test_sharded_rounds_two_gloo_ranks_equal_the_oracle(emulated_engine, oracle_
     assert abs(int(m0[0]) - int(m1[0])) <= m0[1] * 10_000   # each rank evaluated about half of the matrix rows
 
 
-# ---- every launch-path variant of the host protocol gives the same cycle ------------------------------------------------------
-_VARIANTS = [{}, {"KB_CHAIN_ROUNDS": "0"}, {"KB_SYNC_ROUNDS": "1"}, {"KB_PROBE": "0"}, {"KB_DIRECT_WINDOW": "0"},
-             {"KB_COMMIT_KERNEL": "run"}, {"KB_COMMIT_KERNEL": "batch"}, {"KB_CHAIN_ROUNDS": "0", "KB_PROBE": "0", "KB_DIRECT_WINDOW": "0"}]
-
-
-@pytest.mark.parametrize("variant", range(len(_VARIANTS)))
-def test_launch_path_variants_agree_with_the_oracle(oracle_mod, variant, monkeypatch):
-    """Chained rounds, the pinned mailbox, the direct window, the feasibility probe and the commit-kernel pin only change HOW the
-    host drives the device (kb_engine_create reads the switches): decisions, binds, node state and shares stay the oracle's."""
-    import test_gpu_fuzz as fz
-    for k, v in _VARIANTS[variant].items():
-        monkeypatch.setenv(k, v)
-    cases = [fz._case(seed) for seed in (3, 11, 19, 27)]
-    cases.append((kbm.conf.load_scheduler_conf(), kbm.snapshot.synth(kbm.snapshot.synth_config(3, 0.03)), 0, 0))
-    cases.append((kbm.conf.load_scheduler_conf(), kbm.snapshot.synth(kbm.snapshot.synth_config(4, 0.03)), 64, 0))
-    for cfg, snap, window, batch in cases:
-        o = oracle_mod.Oracle(cfg, snap)
-        o.run(["allocate", "backfill"])
-        e = engine.Engine(cfg, window=window, commit_batch=batch)
-        e.load(snap)
-        dec = e.run(["allocate", "backfill"])
-        assert np.array_equal(dec, o.decisions())
-        assert np.array_equal(e.binds(), o.binds())
-        for a, b in zip(e.node_state(), o.node_state()):
-            assert np.array_equal(a, b)
-        assert e.stats()["evals"] == o.evals
-        e.reset()                                            # a second cycle from the pristine copy: identical
-        assert np.array_equal(e.run(["allocate", "backfill"]), dec)
-        e.close()
-        o.close()
-
-
-def test_job_with_a_missing_queue_without_proportion(oracle_mod):
-    """"queue not found" (allocate.go:56-60) is legal when proportion is not loaded: allocate skips the job, drf still counts its
-    running tasks; the share reduction must not look for a queue row (kb_kernels.hip: k_finalize_jobs guards q < Q)."""
-    import copy
-    import test_pyref_vs_oracle as cases
-    conf_text = cases.CONF_FULL.format(actions="allocate, backfill").replace("  - name: proportion\n", "")
-    cfg = kbm.conf.load_scheduler_conf(conf_text)
-    assert not any(po.name == "proportion" for tier in cfg.tiers for po in tier)
-    hit = 0
-    for seed in range(12):
-        base = cases._evict_case(seed)[1]                   # clusters with running tasks
-        s = copy.copy(base)
-        s.job_queue = base.job_queue.copy()
-        s.job_queue[seed % s.n_jobs] = abi.KB_NONE
-        try:
-            o = oracle_mod.Oracle(cfg, s)
-            o.run(["allocate", "backfill"])
-        except RuntimeError:
-            continue
-        e = engine.Engine(cfg)
-        e.load(s)
-        dec = e.run(["allocate", "backfill"])
-        assert np.array_equal(dec, o.decisions()), seed
-        assert np.array_equal(e.binds(), o.binds()), seed
-        ejs, _ = e.shares()[:2]
-        assert np.array_equal(ejs, o.shares()[0]), seed
-        e.close()
-        o.close()
-        hit += 1
-    assert hit >= 6
-
-
-@pytest.mark.parametrize("seed", range(60))
-def test_preempt_with_preferred_node_affinity_behind_its_switch(oracle_mod, seed, monkeypatch):
-    """The engine side of tests/test_host_evict_cpu.py's test of the same name: run_evict_action's list path with the NodeAffinity
-    launch between matrix and arg-max, mixed action orders included.  Off by default (KB_E_UNSUPPORTED) until its first device run."""
-    import test_gpu_preempt as gp
-    import test_host_evict_cpu as hev
-    cfg, snap, order = hev.affinity_evict_case(seed)
-    e = engine.Engine(cfg)
-    e.load(snap)
-    if "preempt" in order:
-        with pytest.raises(engine.EngineError) as err:
-            e.run(order)
-        assert err.value.code == abi.KB_E_UNSUPPORTED
-    e.close()
-    monkeypatch.setenv("KB_PREEMPT_NODE_AFFINITY", "1")
-    gp._run_both(oracle_mod, cfg, snap, order, ("affinity", seed))
-
-
-@pytest.mark.parametrize("seed,ci,order", [(2096, 0, "allocate,preempt"), (2161, 3, "allocate,backfill,preempt,allocate"), (2216, 4, "allocate,preempt"),
-                                           (2420, 3, "allocate,preempt"), (2720, 3, "allocate,backfill,preempt,allocate"), (2927, 3, "allocate,preempt"),
-                                           (2983, 4, "allocate,preempt"), (3031, 3, "allocate,preempt")])
-def test_scalar_keys_created_by_allocate_survive_an_evict_action(oracle_mod, seed, ci, order):
-    """Found by scripts/hunt_evict_cpu.py on the emulated device (KB_HUNT_EMU=1), adversarial snapshots under mixed action orders:
-    Resource.Sub creates the keys of its operand in a non-nil map, so sub-epsilon requests for a scalar a node never advertised leave a
-    negative Idle value under a key its Allocatable does not have.  run_evict_action rebuilt the host mirror's key mask from the static
-    mask alone, read that value as 0 and wrote 0 back for every node the action touched."""
-    import rawgen
-    import test_gpu_preempt as gp
-    import test_pyref_vs_oracle as cases
-    confs = [cases.CONF_FULL] + cases.EVICT_CONFS
-    acts = order.split(",")
-    cfg = kbm.conf.load_scheduler_conf(confs[ci].format(actions=", ".join(acts)))
-    gp._run_both(oracle_mod, cfg, rawgen.raw_snapshot(seed), acts, (seed, ci, order))
-
-
-@pytest.mark.parametrize("seed", range(3300, 3380))
-def test_mixed_action_orders_on_adversarial_snapshots(oracle_mod, seed):
-    """allocate / backfill between and around the evict actions, on the raw snapshots and every tier layout: the combination the
-    committed suites did not have (evict-only orders on raw snapshots, mixed orders on synthetic clusters)."""
-    import rawgen
-    import test_gpu_preempt as gp
-    import test_pyref_vs_oracle as cases
-    confs = [cases.CONF_FULL] + cases.EVICT_CONFS
-    orders = [["allocate", "preempt"], ["reclaim", "allocate", "backfill", "preempt"], ["preempt", "allocate", "backfill", "reclaim"],
-              ["allocate", "backfill", "preempt", "allocate"], ["allocate", "reclaim", "preempt"]]
-    ci = seed % len(confs)
-    acts = orders[(seed // len(confs)) % len(orders)]
-    cfg = kbm.conf.load_scheduler_conf(confs[ci].format(actions=", ".join(acts)))
-    gp._run_both(oracle_mod, cfg, rawgen.raw_snapshot(seed), acts, (seed, ci, acts))
-
-
-@pytest.mark.parametrize("seed", [13, 28, 288] + list(range(400, 440)))
-def test_session_reset_after_evict_actions_reproduces_the_first_run(seed):
-    """kb_session_reset restores the pristine session: the same actions then give the same journals, evictions and state.  The evict
-    actions rewrite the key masks of the nodes they touch (upload_live_nodes), which the reset used to leave behind (seeds 13, 28, 288:
-    a Releasing map that was nil at load stayed non-nil for the second run; found by a reset hunt on the emulated device)."""
-    import rawgen
-    import test_pyref_vs_oracle as cases
-    confs = [cases.CONF_FULL] + cases.EVICT_CONFS
-    orders = [["allocate", "preempt"], ["preempt", "allocate", "backfill"], ["reclaim", "allocate", "backfill", "preempt"],
-              ["allocate", "backfill", "preempt", "reclaim"], ["preempt"], ["reclaim", "preempt"]]
-    ci, order = seed % len(confs), orders[(seed // len(confs)) % len(orders)]
-    cfg = kbm.conf.load_scheduler_conf(confs[ci].format(actions=", ".join(order)))
-
-    def state(e):
-        return [e.binds().copy(), *[x.copy() for x in e.task_state()], *[x.copy() for x in e.node_state()], *[x.copy() for x in e.shares()[:2]],
-                np.array(e.evictions())]
-    ran = 0
-    for snap in (rawgen.raw_snapshot(seed), cases._evict_case(seed)[1]):
-        e = engine.Engine(cfg)
-        try:
-            e.load(snap)
-            first = [np.array(e.run([a])) for a in order] + state(e)
-            e.reset()
-            again = [np.array(e.run([a])) for a in order] + state(e)
-        except engine.EngineError as err:
-            assert err.code in (abi.KB_E_UNSUPPORTED, abi.KB_E_INVALID), err
-            continue
-        finally:
-            e.close()
-        for k, (a, b) in enumerate(zip(first, again)):
-            assert a.shape == b.shape and np.array_equal(a, b), (seed, k)
-        ran += 1
-    if not ran:
-        pytest.skip("both snapshots are outside the engine's envelope")
-
-
-def test_journal_capacity_contract(oracle_mod):
-    """kb_run_preempt with a journal buffer that is too small answers KB_E_CAPACITY with the required count and applies no result; after
-    kb_session_load the same call with that count gives the journal a roomy first call gives (what the Go shim's runJournal does)."""
-    import test_pyref_vs_oracle as cases
-    done = 0
-    for seed in range(40):
-        cfg, snap, _ = cases._evict_case(seed)
-        ref = engine.Engine(cfg)
-        ref.load(snap)
-        try:
-            ref.run_preempt()
-        except engine.EngineError:
-            ref.close()
-            continue
-        want = ref.last_journal
-        ref.close()
-        if len(want) < 3:
-            continue
-        e = engine.Engine(cfg)
-        e.load(snap)
-        n = C.c_uint64()
-        small = (abi.StmtOp * 2)()
-        assert e.L.kb_run_preempt(e.h, small, 2, C.byref(n)) == abi.KB_E_CAPACITY
-        assert n.value == len(want)
-        assert len(e.evictions()) == 0                                  # no result was applied
-        e.load(snap)
-        exact = (abi.StmtOp * n.value)()
-        n2 = C.c_uint64()
-        assert e.L.kb_run_preempt(e.h, exact, n.value, C.byref(n2)) == abi.KB_OK and n2.value == n.value
-        got = np.frombuffer(exact, dtype=np.uint32).reshape(n.value, 4)
-        assert np.array_equal(got, want)
-        e.close()
-        done += 1
-    assert done >= 10
-
-
-@pytest.mark.parametrize("name", ["config3_full", "config4_binpack_full", "config5_full"])
+@pytest.mark.parametrize("name", ["config3_full", "config4_binpack_full", "config5_full", "config5_full_preempt"])
 def test_full_size_cycles_through_the_host_side(oracle_mod, name):
     """BASELINE configs[2] and [3] at full size (100k x 10k) through the engine's host side on the emulated device, against the oracle and
     the committed golden digests (tests/test_gpu_fullsize.py's own test function): about fifteen seconds each.  The 1M x 50k

@@ -1,4 +1,4 @@
-"""BASELINE configs 3, 4 (100k tasks x 10k nodes) and 5 (1M x 50k, allocate + backfill) at FULL size, engine vs oracle, in the regular -m gpu suite:
+"""BASELINE configs 3, 4 (100k tasks x 10k nodes) and 5 (1M x 50k: allocate + backfill, and allocate + backfill + preempt as BASELINE states it) at FULL size, engine vs oracle, in the regular -m gpu suite:
 ordered decisions, bind set and evaluation count must equal the live oracle's, and the oracle's must equal the digests committed
 under tests/golden/fullsize_digests.json (tests/golden/make_fullsize_golden.py).  Config 4 runs under the bin-packing weights
 BASELINE names (mostrequested 5, leastrequested 0, balancedresource 1), where the commit kernels' dirty-winner paths carry most
@@ -27,24 +27,32 @@ def _oracle_result(oracle_mod, name):
         o = oracle_mod.Oracle(conf, snap, threads=min(16, os.cpu_count() or 1))
         if name in mfg.FAST:      # 1M x 50k: the oracle's incremental mode (about a minute); see make_fullsize_golden.py
             o.set_fast(True)
-        o.run(["allocate", "backfill"])
-        _oracle_cache[name] = (conf, snap, o.decisions().copy(), o.binds().copy(), int(o.evals))
+        o.run(mfg.case_actions(name))
+        evict = name.endswith("_preempt")
+        _oracle_cache[name] = (conf, snap, o.decisions().copy(), o.binds().copy(), int(o.evals),
+                               o.journal().copy() if evict else None, o.evictions().copy() if evict else None)
         o.close()
     return _oracle_cache[name]
 
 
 @pytest.mark.parametrize("name", sorted(mfg.CASES))
 def test_full_size_cycle_equals_oracle_and_golden_digest(oracle_mod, name):
-    conf, snap, odec, obinds, oevals = _oracle_result(oracle_mod, name)
+    conf, snap, odec, obinds, oevals, ojournal, oevict = _oracle_result(oracle_mod, name)
     golden = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "fullsize_digests.json")))[name]
     assert (snap.n_tasks, snap.n_nodes, snap.n_res) == (golden["tasks"], golden["nodes"], golden["n_res"])
-    assert mfg.digest_of(np, odec, obinds) == golden["sha256"], "the oracle no longer reproduces its committed full-size digest"
+    assert mfg.digest_of(np, odec, obinds, ojournal, oevict) == golden["sha256"], "the oracle no longer reproduces its committed full-size digest"
     e = engine.Engine(conf)
     e.load(snap)
-    dec = e.run(["allocate", "backfill"])
+    dec = e.run(mfg.case_actions(name))
     assert dec.shape == odec.shape
     assert np.array_equal(dec, odec), f"first divergence at decision {int(np.argmax((dec != odec).any(axis=1)))}"
     assert np.array_equal(e.binds(), obinds)
     assert e.stats()["evals"] == oevals == golden["evals"]
-    assert mfg.digest_of(np, dec, e.binds()) == golden["sha256"]
+    journal = evict = None
+    if ojournal is not None:      # BASELINE configs[4] with its third action: every Statement operation, in order, and what reached cache.Evict
+        journal, evict = e.last_journal, e.evictions()
+        assert journal.shape == ojournal.shape and np.array_equal(journal, ojournal), \
+            f"first divergence at journal entry {int(np.argmax((journal != ojournal).any(axis=1))) if journal.shape == ojournal.shape else (journal.shape, ojournal.shape)}"
+        assert np.array_equal(evict, oevict)
+    assert mfg.digest_of(np, dec, e.binds(), journal, evict) == golden["sha256"]
     e.close()

@@ -24,6 +24,8 @@ def _has(cfg, plugin):
 
 def _compare(e, o, snap, tag, cfg):
     assert [int(t) for t in e.evictions()] == [int(t) for t in o.evictions()], tag
+    ej, oj = e.journal(), o.journal()     # every Statement.Evict / Pipeline with its statement number, commit / discard markers; reclaim: stmt 0
+    assert ej.shape == oj.shape and np.array_equal(ej, oj), (tag, "journal")
     est, end = e.task_state()
     ost, ond = o.task_state()
     assert np.array_equal(est, ost), (tag, np.nonzero(est != ost)[0][:8])

@@ -340,6 +340,28 @@ def _preempt_tiers():
                                    kbm.conf.PluginOption("gang", enabled=abi.EN_PREEMPTABLE)])
 
 
+def preempt_reference_cases():
+    """-> [(snapshot, conf, evictions in cache.Evict order)]: both cases of actions/preempt/preempt_test.go:51-131"""
+    fx = kbm.fixtures
+    S = kbm.snapshot
+    rl = fx.build_resource_list
+    one = S.flatten(
+        nodes=[S.Node("n1", rl("3", "3Gi"))],
+        pods=[fx.build_pod("c1", "preemptee1", "n1", "Running", rl("1", "1G"), "pg1"),
+              fx.build_pod("c1", "preemptee2", "n1", "Running", rl("1", "1G"), "pg1"),
+              fx.build_pod("c1", "preemptor1", "", "Pending", rl("1", "1G"), "pg1"),
+              fx.build_pod("c1", "preemptor2", "", "Pending", rl("1", "1G"), "pg1")],
+        pod_groups=[S.PodGroup("c1", "pg1", queue="q1")], queues=[S.Queue("q1", 1)])
+    two = S.flatten(
+        nodes=[S.Node("n1", rl("2", "2G"))],
+        pods=[fx.build_pod("c1", "preemptee1", "n1", "Running", rl("1", "1G"), "pg1"),
+              fx.build_pod("c1", "preemptee2", "n1", "Running", rl("1", "1G"), "pg1"),
+              fx.build_pod("c1", "preemptor1", "", "Pending", rl("1", "1G"), "pg2"),
+              fx.build_pod("c1", "preemptor2", "", "Pending", rl("1", "1G"), "pg2")],
+        pod_groups=[S.PodGroup("c1", "pg1", queue="q1"), S.PodGroup("c1", "pg2", queue="q1")], queues=[S.Queue("q1", 1)])
+    return [(one, _preempt_tiers(), ["c1/preemptee2"]), (two, _preempt_tiers(), ["c1/preemptee2", "c1/preemptee1"])]
+
+
 def test_reference_preempt_cases(oracle_mod):
     """actions/preempt/preempt_test.go:51-131, both cases: the number of evictions the FakeEvictor records (1 and 2).
     The restatement also says WHO is evicted: victims leave in reverse task order (preempt.go:223-225 negates TaskOrderFn)."""
