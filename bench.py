@@ -206,6 +206,17 @@ def main():
     else:
         full_label, full_kernel = f"kb_bench_matrix rows [0,{T}) x {N} nodes: per-shape evaluation + row expansion", "k_matrix+k_expand"
     roofline = roof(T, full_ms, full_reps, full_label, full_kernel) if full_ms > 0 else roofline_cycle
+    # The launch above leans on the snapshot's shape redundancy (a few hundred distinct task shapes: evaluate once, copy out).  The same
+    # T x N matrix through the matrix kernel's own evaluation, so that the driver's record shows the evaluator and not only the copy:
+    #   roofline_eval           every row evaluated by k_matrix itself, rows equal to their predecessor (the tasks of a job) re-stored
+    #   roofline_eval_all_rows  T x N evaluations, nothing shared (include/kb_engine.h: KB_MATRIX_DIRECT | KB_MATRIX_NO_DEDUP)
+    roofline_eval = roofline_eval_all = None
+    if world == 1 and full_ms > 0:
+        abi = kbm.abi
+        ms_d = eng.bench_matrix(0, T, reps=3, fit_mode=1 | abi.MATRIX_DIRECT)
+        roofline_eval = roof(T, ms_d, 3, f"kb_bench_matrix rows [0,{T}) x {N} nodes: direct per-row evaluation, adjacent equal rows re-stored", "k_matrix")
+        ms_a = eng.bench_matrix(0, T, reps=2, fit_mode=1 | abi.MATRIX_DIRECT | abi.MATRIX_NO_DEDUP)
+        roofline_eval_all = roof(T, ms_a, 2, f"kb_bench_matrix rows [0,{T}) x {N} nodes: {T} x {N} evaluations, nothing shared", "k_matrix")
     # HBM bytes per launch from the PMC passes of scripts/profile_round.sh (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate
     # runs; KB units; FETCH_SIZE doubled per MI355X_MICROARCH.md's gfx950 correction).  Cannot be collected inside this
     # process, so the committed summary of the same command is read back; null when it is absent or for another config.
@@ -253,7 +264,7 @@ def main():
         "kernel_ms_per_step": {k: round(d[k] / args.steps, 3) for k in ("matrix_ms", "argmax_ms", "commit_ms", "reduce_ms", "host_order_ms", "total_ms")},
         "rounds_per_step": d["rounds"] / args.steps, "spec_breaks_per_step": d["spec_breaks"] / args.steps,
         "row_fallbacks_per_step": d["row_fallbacks"] / args.steps,
-        "roofline": roofline, "roofline_cycle": roofline_cycle,
+        "roofline": roofline, "roofline_cycle": roofline_cycle, "roofline_eval": roofline_eval, "roofline_eval_all_rows": roofline_eval_all,
         # SURVEY.md §8d accounting (S): the reference's own dataflow streams B_node(R) bytes per evaluation (every popped task
         # against every node's live state).  The engine never moves those bytes (shape dedup + dirty-node repair); this is the
         # end-to-end rate expressed in that currency, for comparison with the 8 TB/s a streaming pass would be bound by.
@@ -294,6 +305,50 @@ def main():
             out["verified_bind_set_equals_oracle"] = bool(np.array_equal(binds, o.binds()))
             out["verified_evals_equal_oracle"] = bool(o.evals == out["evals_per_step"])
         o.close()
+        if not args.cpu_sample_tasks:
+            # beside the reference-shaped loop on 16 threads: the same action by a smart CPU algorithm (the oracle's incremental mode: one
+            # cached row per task shape, one-node repairs, a max-tree) on ONE thread — the engine's margin over THAT is the honest one
+            o = oracle.Oracle(conf, snap, threads=1)
+            o.set_fast(True)
+            c0 = time.perf_counter()
+            o.allocate()
+            c1 = time.perf_counter()
+            out["cpu_baseline_incremental"] = {"value": o.evals / (c1 - c0), "unit": "evals/s", "cores": os.cpu_count() or 1, "threads": 1, "kind": "port",
+                                               "sample": f"the whole allocate action ({o.evals} reference-equivalent evals, {c1 - c0:.1f} s) by the oracle's "
+                                                         "incremental mode (per-shape cached rows + one-node repairs + max-tree) on one thread"}
+            o.close()
+    default_run = (rank == 0 and world == 1 and args.config == 3 and not (args.diverse or args.survey_nodes or args.preempt) and not args.no_cpu_baseline
+                   and (args.scale == 1.0 or os.environ.get("KB_BENCH_VARIANTS") == "1") and os.environ.get("KB_BENCH_VARIANTS") != "0")
+    if default_run:
+        # the unfriendly inputs, in the driver's own record: SURVEY 8d's literal node sizes (no capacity pressure: dirty nodes win most rows)
+        # and BASELINE configs[3] (R = 16, bin-packing weights), each timed over 3 cycles and verified against the oracle's incremental mode
+        import oracle
+        variants = {}
+        for name, idx, vconf, tweak in (("survey_nodes", 3, kbm.conf.load_scheduler_conf(), True), ("config4_binpack", 4, kbm.conf.load_scheduler_conf(BINPACK_CONF), False)):
+            vp = kbm.snapshot.synth_config(idx, args.scale)
+            if tweak:
+                vp.node_cpu_cores = (16, 32, 64, 96, 128)
+                vp.node_mem_gib = (64, 128, 256, 512)
+            vsnap = kbm.snapshot.synth(vp)
+            ve = engine.Engine(vconf, device=local_rank)
+            ve.load(vsnap)
+            ve.run(["allocate", "backfill"])
+            torch.cuda.synchronize()
+            v0 = time.perf_counter()
+            for _ in range(3):
+                ve.reset()
+                vdec = ve.run(["allocate", "backfill"])
+            torch.cuda.synchronize()
+            vms = (time.perf_counter() - v0) * 1e3 / 3
+            vo = oracle.Oracle(vconf, vsnap, threads=1)
+            vo.set_fast(True)
+            vo.run(["allocate", "backfill"])
+            variants[name] = {"ms_per_step": round(vms, 2), "binds": int((ve.binds() != kbm.abi.KB_NONE).sum()),
+                              "verified": bool(np.array_equal(vdec, vo.decisions()) and np.array_equal(ve.binds(), vo.binds())),
+                              "workload": f"{vsnap.n_tasks} tasks x {vsnap.n_nodes} nodes, R={vsnap.n_res}"}
+            ve.close()
+            vo.close()
+        out["variants"] = variants
     if rank == 0 and args.verify and "verified_bind_set_equals_oracle" not in out:
         import oracle
         o = oracle.Oracle(conf, snap, threads=min(16, os.cpu_count() or 1))

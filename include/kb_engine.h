@@ -330,7 +330,12 @@ int  kb_get_evictions(kb_engine *e, uint32_t *out, uint64_t cap, uint64_t *n_out
 
 /* rows [t0,t1) of the task x node matrix against the session's current node state.
    mask_bits: (t1-t0) rows of ceil(N/8) bytes, bit (n & 7) of byte n >> 3; score: (t1-t0) x N uint16.
-   fit_mode: 1 = allocate's predicate (resource fit + plugin predicates), 0 = plugin predicates only (backfill/preempt). */
+   fit_mode: 1 = allocate's predicate (resource fit + plugin predicates), 0 = plugin predicates only (backfill/preempt),
+   optionally OR'ed with KB_MATRIX_DIRECT / KB_MATRIX_NO_DEDUP (how the launch is organised, never what it computes). */
+#define KB_MATRIX_DIRECT   0x100u   /* every task row is evaluated by the matrix kernel itself (no per-shape rows + row expansion); a row equal
+                                       to its predecessor (the tasks of a job) re-stores the predecessor's result */
+#define KB_MATRIX_NO_DEDUP 0x200u   /* with KB_MATRIX_DIRECT: not even adjacent equal rows share an evaluation: rows x N evaluations,
+                                       the evaluator's own rate (bench.py: roofline_eval_all_rows) */
 int  kb_eval_matrix(kb_engine *e, uint32_t t0, uint32_t t1, uint32_t fit_mode, uint8_t *mask_bits, uint16_t *score);
 
 /* per row of [t0,t1): the k best feasible nodes, descending score then ascending node index;

@@ -42,6 +42,7 @@ FLAG_SYNC_ROUNDS = 1
 
 # kb_stmt_op.op: the preempt action's journal (framework/statement.go)
 OP_EVICT, OP_PIPELINE, OP_COMMIT, OP_DISCARD = range(4)
+MATRIX_DIRECT, MATRIX_NO_DEDUP = 0x100, 0x200   # KB_MATRIX_* (OR'ed into fit_mode of kb_eval_matrix / kb_bench_matrix)
 
 
 class PluginOption(C.Structure):

@@ -1481,8 +1481,10 @@ struct ChunkPlan {
   uint32_t ns = 0;
   bool direct = false;   // evaluate every task row itself (no per-shape rows, no expansion)
 };
-static ChunkPlan matrix_plan(kb_engine *e, uint32_t t0, uint32_t n, uint32_t fit_mode, uint32_t k) {
+static ChunkPlan matrix_plan(kb_engine *e, uint32_t t0, uint32_t n, uint32_t fit_flags, uint32_t k) {
   ChunkPlan p;
+  const uint32_t fit_mode = fit_flags & 0xFFu;
+  if (fit_mode > 2 || (fit_flags & ~(0xFFu | KB_MATRIX_DIRECT | KB_MATRIX_NO_DEDUP))) throw EngineError(KB_E_INVALID, "fit_mode: 0, 1 or 2, optionally with KB_MATRIX_DIRECT / KB_MATRIX_NO_DEDUP");
   const size_t NP = e->dev.NP;
   ensure_window_buffers(e, n);          // h_rows / h_slot staging (host side only matters here)
   ensure_matrix_buffers(e, n, k ? k : 1);
@@ -1495,10 +1497,12 @@ static ChunkPlan matrix_plan(kb_engine *e, uint32_t t0, uint32_t n, uint32_t fit
   {
     static const char *pin = getenv("KB_K1_DIRECT");
     p.direct = pin ? pin[0] == '1' : ((size_t)p.ns * e->dev.NP * 2 > (32u << 20) && (size_t)p.ns * 16 > n);
+    if (fit_flags & KB_MATRIX_DIRECT) p.direct = true;
   }
   if (p.direct) {
     // the tasks of a job are adjacent and share a shape: a row equal to its predecessor re-stores the predecessor's result
-    for (uint32_t i = 0; i < n; i++) e->h_same[i] = (i > 0 && e->h_slot[i] == e->h_slot[i - 1]) ? 1 : 0;
+    const bool dedup = !(fit_flags & KB_MATRIX_NO_DEDUP);
+    for (uint32_t i = 0; i < n; i++) e->h_same[i] = (dedup && i > 0 && e->h_slot[i] == e->h_slot[i - 1]) ? 1 : 0;
     HIP_OK(hipMemcpyAsync(e->b_same.p, e->h_same.data(), n, hipMemcpyHostToDevice, e->stream));
     p.r = make_round(e, 0, n, k ? k : 1, (int)fit_mode, false);
     p.r.mrows = nullptr;

@@ -33,6 +33,7 @@ struct K1Task {
   double init0, init1, nzc, nzm;
   uint32_t cls, active, task, pad;
   unsigned long long conf;   // host-port bits that conflict with this pod's ports (0: none)
+  uint32_t crow, pad2;
 };
 struct K1Node {
   double idle0, idle1, rel0, rel1, ac, am, nzc, nzm, inv_ac, inv_am;
@@ -46,7 +47,10 @@ __device__ __forceinline__ K1Task k1_task(const KbDev &d, uint32_t t) {
   K1Task k;
   k.init0 = v.init0; k.init1 = v.init1; k.nzc = (double)v.nzc; k.nzm = (double)v.nzm;
   k.cls = v.cls; k.active = v.active; k.task = v.task; k.conf = v.conf;
-  k.pad = (d.t_ip_checks && d.t_ip_checks[t]) ? 1u : 0u;   // the pod has inter-pod predicate checks
+  k.pad = (d.t_ip_checks && d.t_ip_checks[t]) ? 1u : 0u;   // bit 0: the pod has inter-pod predicate checks
+  // bits 1..: unused.  crow: the task class's row of the static-predicate table (bit nc) when there are at most 32 node classes — the
+  // class test is then a shift of a scalar, not a dependent load from the global bit table per pair
+  k.crow = (d.crows != nullptr && d.n_nc <= 32) ? d.crows[(size_t)v.cls * 8] : 0u;
   return k;
 }
 // PodAffinityChecker.InterPodAffinityMatches (vendor/.../algorithm/predicates/predicates.go:1261-1290, meta == nil) on the kb_interpod
@@ -79,39 +83,89 @@ __device__ __forceinline__ K1Node k1_node(const KbDev &d, uint32_t n) {
   return k;
 }
 
-// One (task,node) evaluation.  Returns 0 if infeasible, else 0x10000 | score.
-__device__ __forceinline__ uint32_t eval_pair(const KbDev &d, const K1Task &t, const K1Node &n, uint32_t node, int fit_mode) {
-  if (!n.valid) return 0;
-  bool ok = true;
+// A task row is the same for every lane of a workgroup, but it reaches the lanes through LDS, i.e. in VGPRs: every guard on it (active
+// scalar dimensions, inter-pod checks) then compiles to a divergent exec-mask branch and every operand to a vector register.
+// readfirstlane moves the row into SGPRs once per row: the guards become scalar branches, the row's doubles scalar operands.
+__device__ __forceinline__ double k1_uniform(double v) {
+  const int lo = __builtin_amdgcn_readfirstlane(__double2loint(v)), hi = __builtin_amdgcn_readfirstlane(__double2hiint(v));
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ uint32_t k1_uniform(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+__device__ __forceinline__ K1Task k1_uniform(const K1Task &v) {
+  K1Task k;
+  k.init0 = k1_uniform(v.init0); k.init1 = k1_uniform(v.init1); k.nzc = k1_uniform(v.nzc); k.nzm = k1_uniform(v.nzm);
+  k.cls = k1_uniform(v.cls); k.active = k1_uniform(v.active); k.task = k1_uniform(v.task); k.pad = k1_uniform(v.pad);
+  k.conf = ((unsigned long long)k1_uniform((uint32_t)(v.conf >> 32)) << 32) | k1_uniform((uint32_t)(v.conf & 0xFFFFFFFFull));
+  k.crow = k1_uniform(v.crow); k.pad2 = 0;
+  return k;
+}
+
+// One task row against the NPT consecutive nodes of a thread: res[j] = 0 if infeasible, else 0x10000 | score.  `t` is wave-uniform
+// (k1_uniform), so every `if` / `while` below tests a scalar (policy, or a field of the row) and is a scalar branch taken once for
+// all NPT nodes; the per-lane part is straight-line (bitwise & | on the compare results, no short-circuit control flow).
+template <int NPT>
+__device__ __forceinline__ void eval_row(const KbDev &d, const K1Task &t, const K1Node (&n)[NPT], uint32_t n0, int fit_mode, uint32_t (&res)[NPT]) {
+  int ok[NPT];
+#pragma unroll
+  for (int j = 0; j < NPT; j++) ok[j] = n[j].valid;
   if (fit_mode) {   // allocate.go:81: !InitResreq.LessEqual(Idle) && !InitResreq.LessEqual(Releasing) -> fail
-    bool fi = le_eps(t.init0, n.idle0, EPS_CPU) && le_eps(t.init1, n.idle1, EPS_MEM);
-    bool fr = le_eps(t.init0, n.rel0, EPS_CPU) && le_eps(t.init1, n.rel1, EPS_MEM);
-    uint32_t a = t.active >> 2;     // scalar dims with InitResreq > 10 (resource_info.go:286-299)
-    uint32_t dd = 2;
-    while (a) {
-      if (a & 1u) {
-        double l = d.t_init[(size_t)dd * d.T + t.task];
-        fi = fi && le_eps(l, d.idle[(size_t)dd * d.NP + node], EPS_SCALAR);
-        fr = fr && le_eps(l, d.rel[(size_t)dd * d.NP + node], EPS_SCALAR);
-      }
-      a >>= 1;
-      dd++;
+    int fi[NPT], fr[NPT];
+#pragma unroll
+    for (int j = 0; j < NPT; j++) {
+      fi[j] = (int)le_eps(t.init0, n[j].idle0, EPS_CPU) & (int)le_eps(t.init1, n[j].idle1, EPS_MEM);
+      fr[j] = (int)le_eps(t.init0, n[j].rel0, EPS_CPU) & (int)le_eps(t.init1, n[j].rel1, EPS_MEM);
     }
-    ok = fi || (fit_mode != 2 && fr);   // 2: backfill, AddTask's Resreq.LessEqual(Idle) only (node_info.go:161-167)
+    uint32_t a = t.active >> 2;     // scalar dims with InitResreq > 10 (resource_info.go:286-299); the others are skipped by LessEqual
+    while (a) {
+      const uint32_t dd = 2u + (uint32_t)__builtin_ctz(a);
+      a &= a - 1u;
+      const double l = d.t_init[(size_t)dd * d.T + t.task];
+      const double *pi = d.idle + (size_t)dd * d.NP + n0, *pr = d.rel + (size_t)dd * d.NP + n0;   // rows are padded to NP: in bounds for every lane
+      double vi[NPT], vr[NPT];
+      if (NPT == 4) {   // 32 contiguous, 32-byte aligned bytes per thread: two 16-byte loads per vector
+        const double2 i0 = reinterpret_cast<const double2 *>(pi)[0], i1 = reinterpret_cast<const double2 *>(pi)[1];
+        const double2 r0 = reinterpret_cast<const double2 *>(pr)[0], r1 = reinterpret_cast<const double2 *>(pr)[1];
+        vi[0] = i0.x; vi[1 % NPT] = i0.y; vi[2 % NPT] = i1.x; vi[3 % NPT] = i1.y;
+        vr[0] = r0.x; vr[1 % NPT] = r0.y; vr[2 % NPT] = r1.x; vr[3 % NPT] = r1.y;
+      } else {
+#pragma unroll
+        for (int j = 0; j < NPT; j++) { vi[j] = pi[j]; vr[j] = pr[j]; }
+      }
+#pragma unroll
+      for (int j = 0; j < NPT; j++) { fi[j] &= (int)le_eps(l, vi[j], EPS_SCALAR); fr[j] &= (int)le_eps(l, vr[j], EPS_SCALAR); }
+    }
+#pragma unroll
+    for (int j = 0; j < NPT; j++) ok[j] &= fi[j] | ((fit_mode != 2) & fr[j]);   // 2: backfill, AddTask's Resreq.LessEqual(Idle) only (node_info.go:161-167)
   }
   if (d.pred_enabled) {
-    ok = ok && n.slots && ((n.ports & t.conf) == 0ull);   // pod count (predicates.go:127), PodFitsHostPorts (predicates.go:181-190)
-    if (d.compat) {
-      uint32_t bit = t.cls * d.n_nc + n.cls;
-      ok = ok && ((d.compat[bit >> 3] >> (bit & 7)) & 1);
+#pragma unroll
+    for (int j = 0; j < NPT; j++) ok[j] &= n[j].slots & (int)((n[j].ports & t.conf) == 0ull);   // pod count (predicates.go:127), PodFitsHostPorts (:181-190)
+    if (d.crows != nullptr && d.n_nc <= 32) {   // the class row is a scalar word (K1Task::crow)
+#pragma unroll
+      for (int j = 0; j < NPT; j++) ok[j] &= (int)((t.crow >> n[j].cls) & 1u);
+    } else if (d.compat) {
+#pragma unroll
+      for (int j = 0; j < NPT; j++) {
+        const uint32_t bit = t.cls * d.n_nc + n[j].cls;
+        ok[j] &= (d.compat[bit >> 3] >> (bit & 7)) & 1;
+      }
     }
-    if (d.t_ip_forbid != nullptr)   // uniform: sessions without inter-pod terms pay one scalar branch
-      if (t.pad && ok) ok = interpod_ok(d, t.task, node);   // predicates.go:249-262 (rare: subject rows only)
+    if (d.t_ip_forbid != nullptr && t.pad) {   // predicates.go:249-262: subject rows of sessions with inter-pod terms only
+#pragma unroll
+      for (int j = 0; j < NPT; j++)
+        if (ok[j]) ok[j] = interpod_ok(d, t.task, n0 + j);
+    }
   }
-  if (!ok) return 0;
-  uint32_t score = 0;
-  if (d.score_enabled) score = score_core_f64(t.nzc, t.nzm, n.nzc, n.nzm, n.ac, n.am, n.inv_ac, n.inv_am, d.wL, d.wM, d.wB);
-  return 0x10000u | (score & 0xFFFFu);
+  if (d.score_enabled) {
+#pragma unroll
+    for (int j = 0; j < NPT; j++) {
+      const uint32_t sc = score_core_f64(t.nzc, t.nzm, n[j].nzc, n[j].nzm, n[j].ac, n[j].am, n[j].inv_ac, n[j].inv_am, d.wL, d.wM, d.wB);
+      res[j] = ok[j] ? (0x10000u | (sc & 0xFFFFu)) : 0u;
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < NPT; j++) res[j] = ok[j] ? 0x10000u : 0u;
+  }
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -175,11 +229,10 @@ __global__ void __launch_bounds__(256) k_matrix(KbDev d, KbRound r) {
   uint2 pk = make_uint2(0u, 0u);   // packed scores / mask word of the last evaluated row (re-stored for identical rows)
   uint32_t mw = 0;
   for (uint32_t rr = 0; rr < nr; rr++) {
-    const bool fresh = !(ssame[rr] && rr > 0);
+    const bool fresh = !(k1_uniform((uint32_t)ssame[rr]) && rr > 0);
     if (fresh) {
-      const K1Task tv = srow[rr];
-#pragma unroll
-      for (int j = 0; j < NPT; j++) res[j] = eval_pair(d, tv, nv[j], n0 + j, r.fit_mode);
+      const K1Task tv = k1_uniform(srow[rr]);
+      eval_row<NPT>(d, tv, nv, n0, r.fit_mode, res);
     }
     const size_t row = row0 + rr;
     if (NPT == 4) {
@@ -676,10 +729,11 @@ __global__ void __launch_bounds__(256) k_probe(KbDev d, const uint32_t *rows, ui
 #pragma unroll
   for (int j = 0; j < NPT; j++) nv[j] = k1_node(d, n0 + j);
   for (uint32_t rr = 0; rr < nr; rr++) {
-    const K1Task tv = srow[rr];
-    uint32_t ok = 0;
+    const K1Task tv = k1_uniform(srow[rr]);
+    uint32_t pr[NPT], ok = 0;
+    eval_row<NPT>(d, tv, nv, n0, 1, pr);
 #pragma unroll
-    for (int j = 0; j < NPT; j++) ok |= (eval_pair(d, tv, nv[j], n0 + j, 1) >> 16) & 1u;
+    for (int j = 0; j < NPT; j++) ok |= (pr[j] >> 16) & 1u;
     const unsigned long long any = __ballot(ok);
     if (any && (threadIdx.x & 63) == 0) atomicOr(&alive[row0 + rr], 1u);
   }

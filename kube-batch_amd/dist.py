@@ -78,9 +78,19 @@ class ShardedCycle:
         # RCCL: the engine launches on torch's current stream, the stream the collectives are ordered on, so a round needs no host
         # synchronisation between its kernels and its collectives (the commit result still arrives through the pinned mailbox)
         self.stream_ordered = (not self.stage_host) and self.engine is not None and buffer_device is not None and buffer_device.type == "cuda"
+        self._stream = None
         if self.stream_ordered:
-            self.engine.use_stream(torch.cuda.current_stream(buffer_device).cuda_stream)
-        self.delta = torch.zeros(backend.delta_len, dtype=torch.float64, device=self.buf_dev)
+            # a DEDICATED stream: torch's default stream has handle 0, which kb_engine_use_stream reads as "back to the engine's own
+            # non-blocking stream" — the engine would then NOT be ordered with the collectives while every host synchronisation below
+            # is skipped (round-2 review).  Collectives and torch's fills are issued under this stream (see _on_stream); if its
+            # handle were ever 0 the ordering claim is dropped and the synchronising path is used instead.
+            self._stream = torch.cuda.Stream(device=buffer_device)
+            if self._stream.cuda_stream == 0:
+                self.stream_ordered, self._stream = False, None
+            else:
+                self.engine.use_stream(self._stream.cuda_stream)
+        with self._on_stream():
+            self.delta = torch.zeros(backend.delta_len, dtype=torch.float64, device=self.buf_dev)
         self.rounds = 0
         self.replicated_rounds = 0
         # a single-rank group still goes through the collectives when asked to (exercises the RCCL path on a one-GPU box)
@@ -88,6 +98,11 @@ class ShardedCycle:
         self.always_collect = dist.is_initialized() and _os.environ.get("KB_DIST_ALWAYS_COLLECT") == "1"
         # shard a round's matrix rows only when every rank gets at least this many (0 = always shard)
         self.min_rows_per_rank = min_rows_per_rank
+
+    def _on_stream(self):
+        """Context in which torch work (fills, collectives) is enqueued on the stream the engine's kernels run on."""
+        import contextlib
+        return torch.cuda.stream(self._stream) if self._stream is not None else contextlib.nullcontext()
 
     def _sync_torch(self):
         """The engine runs on its own non-blocking HIP stream: torch's fill kernels must have finished before the engine
@@ -126,6 +141,10 @@ class ShardedCycle:
 
     # ---- one action
     def run_action(self, action: int) -> np.ndarray:
+        with self._on_stream():
+            return self._run_action(action)
+
+    def _run_action(self, action: int) -> np.ndarray:
         b = self.backend
         while True:
             n_rows, n_mrows, L = b.begin(action)

@@ -56,6 +56,51 @@ def commit_kernel(request):
             os.environ["KB_COMMIT_KERNEL"] = old
 
 
+# ---- the engine's envelope, pinned ---------------------------------------------------------------------------------------------
+# The differential suites skip a snapshot when the oracle says the reference would panic on it, or when the engine answers
+# KB_E_UNSUPPORTED / KB_E_INVALID (the documented envelope).  A regression that WIDENS the unsupported set would
+# show up as more skips, not as a failure — so the set of skipping cases is committed (tests/golden/expected_skips.json, produced by
+# KB_RECORD_SKIPS=<file> python -m pytest tests/test_emu_engine_cpu.py; the envelope is host logic, identical on the emulated and the
+# real device) and any OTHER skip of a differential case is turned into a failure, on the GPU box and on the emulated device alike.
+_ENVELOPE_MODULES = {"test_gpu_parity", "test_gpu_fuzz", "test_gpu_adversarial", "test_gpu_interpod", "test_gpu_preempt",
+                     "test_framework_actions", "test_gpu_regressions", "test_gpu_fullsize", "test_gpu_sharded"}
+_expected_skips = None
+
+
+def _skip_key(item):
+    fn = getattr(item, "function", None)
+    mod = getattr(fn, "__module__", "") or ""
+    if mod not in _ENVELOPE_MODULES:
+        return None
+    cs = getattr(item, "callspec", None)
+    ident = "-".join(p for p in (cs.id.split("-") if cs is not None else []) if p not in ("batch", "run"))   # the commit-kernel axis skips alike
+    return f"{mod}::{fn.__name__}[{ident}]"
+
+
+@pytest.hookimpl(hookwrapper=True)
+def pytest_runtest_makereport(item, call):
+    global _expected_skips
+    outcome = yield
+    rep = outcome.get_result()
+    if not rep.skipped or call.when != "call":
+        return
+    key = _skip_key(item)
+    if key is None:
+        return
+    reason = rep.longrepr[2] if isinstance(rep.longrepr, tuple) else str(rep.longrepr)
+    rec = os.environ.get("KB_RECORD_SKIPS")
+    if rec:
+        with open(rec, "a") as f:
+            f.write(key + "\t" + reason.replace("\n", " ") + "\n")
+        return
+    if _expected_skips is None:
+        import json
+        _expected_skips = set(json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "expected_skips.json")))["skips"])
+    if key not in _expected_skips:
+        rep.outcome = "failed"
+        rep.longrepr = f"UNEXPECTED SKIP (not in tests/golden/expected_skips.json: did the engine's envelope shrink?): {key}: {reason}"
+
+
 @pytest.fixture(scope="session")
 def kb():
     return importlib.import_module("kube-batch_amd")

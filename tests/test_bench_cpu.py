@@ -57,6 +57,19 @@ def test_default_line_has_every_field_and_verifies_itself(monkeypatch):
     assert out["binds"] > 0 and out["evals_per_step"] > 0
 
 
+def test_default_run_carries_the_unfriendly_inputs(monkeypatch):
+    """the driver's default line also times and verifies SURVEY 8d's literal node sizes and BASELINE configs[3] (variants), reports the
+    oracle's incremental mode beside the 16-thread loop, and the matrix kernel's own evaluation rates (scaled here; full size on the GPU box)"""
+    monkeypatch.setenv("KB_BENCH_VARIANTS", "1")
+    out = _run_bench(monkeypatch, ["--scale", "0.02", "--steps", "1", "--warmup", "0"])
+    assert set(out["variants"]) == {"survey_nodes", "config4_binpack"}
+    for v in out["variants"].values():
+        assert v["verified"] is True and v["ms_per_step"] > 0 and v["binds"] > 0
+    assert out["cpu_baseline_incremental"]["threads"] == 1 and out["cpu_baseline_incremental"]["value"] > 0
+    for k in ("roofline_eval", "roofline_eval_all_rows"):
+        assert out[k]["bound"] == "hbm" and out[k]["kernel"] == "k_matrix" and out[k]["frac"] >= 0
+
+
 @pytest.mark.parametrize("argv", [["--config", "4", "--scale", "0.02", "--steps", "1", "--warmup", "0"],
                                   ["--config", "3", "--scale", "0.02", "--diverse", "--steps", "1", "--no-cpu-baseline", "--verify"],
                                   ["--config", "5", "--scale", "0.004", "--steps", "1", "--preempt", "--no-cpu-baseline", "--verify"],

@@ -94,6 +94,12 @@ def test_matrix_parity_config2(oracle_mod):
         assert np.array_equal(em, om), f"mask differs (fit_mode {fit})"
         assert np.array_equal(es, os_), f"score differs (fit_mode {fit})"
     assert em.any() and es.any()
+    # the same matrix through the other two launch organisations (include/kb_engine.h): every row evaluated by the matrix kernel itself,
+    # with and without sharing an evaluation between adjacent equal rows — the <4 nodes, 32 rows> tile the shape-deduplicated launch never uses
+    om, os_ = o.eval_matrix(0, snap.n_tasks, 1)
+    for flags in (abi.MATRIX_DIRECT, abi.MATRIX_DIRECT | abi.MATRIX_NO_DEDUP):
+        em, es = e.eval_matrix(0, snap.n_tasks, 1 | flags)
+        assert np.array_equal(em, om) and np.array_equal(es, os_), hex(flags)
 
 
 def test_matrix_parity_r16_and_after_allocate(oracle_mod):
@@ -105,6 +111,9 @@ def test_matrix_parity_r16_and_after_allocate(oracle_mod):
     em, es = e.eval_matrix(0, snap.n_tasks, 1)
     om, os_ = o.eval_matrix(0, snap.n_tasks, 1)
     assert np.array_equal(em, om) and np.array_equal(es, os_)
+    for flags in (abi.MATRIX_DIRECT, abi.MATRIX_DIRECT | abi.MATRIX_NO_DEDUP):     # scalar dimensions through the direct tile's 16-byte loads
+        em, es = e.eval_matrix(0, snap.n_tasks, 1 | flags)
+        assert np.array_equal(em, om) and np.array_equal(es, os_), hex(flags)
 
 
 def test_argmax_parity(oracle_mod):

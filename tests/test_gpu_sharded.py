@@ -66,3 +66,47 @@ def test_sharded_two_ranks_one_gpu(oracle_mod, tmp_path):
     m0, m1 = np.load(tmp_path / "mevals0.npy"), np.load(tmp_path / "mevals1.npy")
     assert m0[1] == m1[1]                                   # same number of rounds
     assert abs(int(m0[0]) - int(m1[0])) <= m0[1] * 10_000   # each rank evaluated about half of the matrix rows
+
+
+def _rccl_worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["KB_DIST_ALWAYS_COLLECT"] = "1"           # a one-rank group still goes through the collectives
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=rank, world_size=world)
+    try:
+        class Delayed(distmod.ShardedCycle):
+            """every collective is preceded by ~10 ms of busy-wait ON THE COLLECTIVE STREAM: an engine that is not ordered on that
+            stream reads the gathered keys / the reduced delta before they exist"""
+            def _all_gather_keys(self, local, chunk, L):
+                torch.cuda._sleep(20_000_000)
+                return super()._all_gather_keys(local, chunk, L)
+
+            def _all_reduce_delta(self):
+                torch.cuda._sleep(20_000_000)
+                return super()._all_reduce_delta()
+        conf = kbm.conf.load_scheduler_conf()
+        cyc = Delayed(conf, kbm.snapshot.synth(kbm.snapshot.synth_config(3, 0.01)), device=0, window=256, min_rows_per_rank=0)
+        assert cyc.stream_ordered and cyc._stream is not None and cyc._stream.cuda_stream != 0
+        dec = cyc.step()
+        np.save(os.path.join(out_dir, "dec.npy"), dec)
+        np.save(os.path.join(out_dir, "binds.npy"), cyc.engine.binds())
+    finally:
+        dist.destroy_process_group()
+
+
+def test_rccl_stream_ordering_with_delayed_collectives(oracle_mod, tmp_path):
+    """The RCCL path (backend "nccl", world size 1: the only group a one-GPU box allows) skips every host synchronisation inside a
+    round because the engine's kernels and the collectives share ONE stream.  Round 2 passed torch's default stream (handle 0), which
+    kb_engine_use_stream reads as "the engine's own stream": nothing was ordered, and only launch latency hid it.  Here every
+    collective is delayed by a busy-wait kernel on its stream; the decisions must still be the oracle's."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_rccl_worker, args=(1, port, str(tmp_path)), nprocs=1, join=True)
+    conf = kbm.conf.load_scheduler_conf()
+    o = oracle_mod.Oracle(conf, kbm.snapshot.synth(kbm.snapshot.synth_config(3, 0.01)))
+    o.run(["allocate", "backfill"])
+    assert np.array_equal(np.load(tmp_path / "dec.npy"), o.decisions())
+    assert np.array_equal(np.load(tmp_path / "binds.npy"), o.binds())
