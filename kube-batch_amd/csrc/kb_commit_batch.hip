@@ -215,20 +215,21 @@ __device__ __forceinline__ void k5_field_ptrs(const KbDev &d, uint32_t fld, cons
 // ------------------------------------------------------------------------------------------------------------
 #define K7_B 32u          // most rows one batch can speculate
 #define K7_B_DEFAULT 16u  // batch size after a batch that was cut short; doubled after a fully valid one
-#define K7_D 96u   // row descriptors staged per refill
+#define K7_D 160u   // row descriptors staged per refill (five 32-row batches: four of them find their successor staged and can pre-walk it)
 #define K7_PWIN_BYTES 32768u   // LDS for the per-shape candidate windows of a round
 #define K7_KQ 5    // 64 * K7_KQ >= KB_K5_MAX_ROWS + K7_B dirty slots: the row-at-a-time mode keeps one key per slot in registers
 
 static_assert(64 * K7_KQ >= KB_K5_MAX_ROWS + K7_B, "row mode keeps one key per dirty slot in registers");
 struct K7Hdr {
-  unsigned long long c[K7_B];           // clean candidate key of batch row j (0: the list has no clean feasible node left)
+  unsigned long long c2[2][K7_B];       // clean candidate key of batch row j (0: the list has no clean feasible node left); two buffers:
+                                        // wave 0 walks batch b + 1 into the other one while the workgroup fetches / evaluates batch b
   unsigned long long dmax[K7_B];        // per distinct shape q of the batch: best key over the pre-batch dirty slots
   unsigned long long kb[K7_B][K7_B];    // [row l][shape q]: key of row l's node in its post-commit state
   unsigned long long mrow[K7_B];        // per batch row j: max of kb[l][q_j] over the earlier batch rows l < j (built by the evaluate step)
   uint32_t rowmask[K7_B];               // per distinct shape q: the batch rows that carry it
   uint32_t rep[K7_B];                   // batch row whose descriptor represents shape q
   uint32_t q_of[K7_B];                  // shape index of batch row j
-  uint32_t idx[K7_B];                   // list position of c[j]
+  uint32_t idx2[2][K7_B];               // list position of c[j]
   uint32_t kind[K7_B];                  // 0 Allocate, 1 Pipeline
   uint32_t has_map[K7_B];               // the row's speculative commit wrote scalar dimensions (saved values are valid)
   // evaluation work list of shape q: slots [e_start, nd), then dlog[e_log0 .. e_log0 + e_nlog), then the batch's new slots
@@ -239,6 +240,7 @@ struct K7Hdr {
   uint32_t n_pairs, nlog, n_full, pad3;
   uint32_t seq_rows, seq_pc, n_seq_rows, pad4;
   uint32_t n_batches, n_dirty_rows, n_refills, pad2;
+  uint32_t n_prewalks, n_prewalks_used, pad5, pad6;
 };
 
 struct K7Mem {
@@ -271,6 +273,67 @@ __host__ __device__ inline size_t k7_smem_bytes(uint32_t cap, uint32_t NP, int R
   size_t cap2 = (size_t)cap + K7_B;
   return cap2 * (K5_NF8 * 8 + 8 + 8 + 3 * 4) + (size_t)cap * (8 + 8 + 12) + (size_t)(NP / 32) * 4 + (size_t)K7_B * (R > 2 ? R - 2 : 0) * 8 + sizeof(K7Hdr) + 64 +
          K7_PWIN_BYTES + (size_t)cap * 4;
+}
+
+// The walk: rows [ja, jb) of a batch (descriptors bd) take, in row order, successive clean entries of their shape's persistent candidate
+// window (runs of consecutive rows with the same shape share one scan), marking the nodes in the dirty bitmap so that later rows of other
+// shapes skip them.  Wave 0 only.  c / idx: the batch's candidate buffers; slid: bit j0 set = the window of the run that starts at row j0
+// slid during this walk (the roll-back re-anchors such windows at the shape's cursor); exh / refills: list exhaustion flag and statistics.
+__device__ __forceinline__ void k7_walk(const K7Mem &M, const unsigned long long *keys, uint32_t L, const KbRowDesc *bd, uint32_t ja, uint32_t jb, uint32_t nb,
+                                        uint32_t lane, unsigned long long *c, uint32_t *idx, uint32_t &slid, uint32_t &exh, uint32_t &refills) {
+  const uint32_t WL = M.WL;
+  const uint32_t s = (lane < nb) ? (uint32_t)bd[lane < nb ? lane : 0].slot : 0xFFFFFFFFu;
+  uint32_t j = ja;
+  while (j < jb) {
+    const uint32_t sr = (uint32_t)__builtin_amdgcn_readlane((int)s, (int)j);
+    const unsigned long long diff = __ballot(lane >= j && lane < jb && s != sr);
+    const uint32_t j1 = diff ? (uint32_t)(__ffsll((unsigned long long)diff) - 1) : jb;
+    const uint32_t jrun = j;
+    uint32_t m = j1 - j;
+    unsigned long long *wq = M.pwin + (size_t)sr * WL;
+    uint32_t base = M.pbase[sr];
+    for (;;) {
+      const bool inw = lane < WL;
+      const unsigned long long wkey = inw ? wq[lane] : 0ull;
+      const bool nz = inw && wkey != 0ull;
+      const uint32_t node = KB_KEY_NODE(wkey);
+      const bool cl = nz && !bit_test(M.bitmap, nz ? node : 0u);
+      const unsigned long long clean = __ballot(cl);
+      const unsigned long long zeros = __ballot(inw && wkey == 0ull);
+      const uint32_t cnt = (uint32_t)__popcll(clean);
+      const uint32_t take = cnt < m ? cnt : m;
+      const uint32_t rank = (uint32_t)__popcll(clean & ((1ull << lane) - 1ull));
+      if (cl && rank < take) {
+        c[j + rank] = wkey;
+        idx[j + rank] = base + lane;
+        atomicOr(&M.bitmap[node >> 5], 1u << (node & 31));
+      }
+      j += take;
+      m -= take;
+      if (m == 0) break;
+      if (zeros) {   // the list ended: no clean feasible node is left for the remaining rows of the run
+        if (lane < m) { c[j + lane] = 0ull; idx[j + lane] = 0; }
+        j += m;
+        break;
+      }
+      // every entry of the window is dirty: slide it.  Entries taken by THIS batch may be rolled back; the roll-back step
+      // re-anchors the windows that slid during the batch (slid) at the shape's cursor
+      const uint32_t nbase = base + WL;
+      if (nbase >= L) {   // cannot happen while L > window: reported, never silently mis-scheduled
+        exh = 1;
+        if (lane < m) { c[j + lane] = 0ull; idx[j + lane] = 0; }
+        j += m;
+        break;
+      }
+      if (inw) wq[lane] = (nbase + lane < L) ? keys[(size_t)sr * L + nbase + lane] : 0ull;
+      if (lane == 0) M.pbase[sr] = nbase;
+      refills++;
+      base = nbase;
+      slid |= 1u << jrun;
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
 }
 
 // `k` is a STAGED descriptor (H.dbuf): its nzc / nzm words hold the pod's non-zero request as double bit patterns
@@ -411,7 +474,7 @@ __global__ void __launch_bounds__(KB_K5_THREADS) k_commit_batch(const K7KernArgs
     const uint32_t sh = w / WL, en = w % WL;
     M.pwin[w] = (en < a.L) ? a.keys[(size_t)sh * a.L + en] : 0ull;
   }
-  if (tid == 0) { H.reason = KB_REASON_DONE; H.exhausted = 0; H.n_batches = 0; H.n_dirty_rows = 0; H.n_refills = 0; H.p = 0; H.dirty_row = 0; H.pad = 0; H.nlog = 0; H.n_full = 0; H.pad2 = 0; H.pad3 = 0; H.kstar = 0ull; H.n_seq_rows = 0; }
+  if (tid == 0) { H.reason = KB_REASON_DONE; H.exhausted = 0; H.n_batches = 0; H.n_dirty_rows = 0; H.n_refills = 0; H.p = 0; H.dirty_row = 0; H.pad = 0; H.nlog = 0; H.n_full = 0; H.pad2 = 0; H.pad3 = 0; H.kstar = 0ull; H.n_seq_rows = 0; H.n_prewalks = 0; H.n_prewalks_used = 0; }
   // per-thread source array of the fetch step: thread (row*16 + f) reads field f of the row's node
   // (pointers read from the KbDev copy are generic; the fetch step wants global_load, not flat_load)
   typedef const unsigned long long __attribute__((address_space(1))) *gptr8;
@@ -459,6 +522,13 @@ __global__ void __launch_bounds__(KB_K5_THREADS) k_commit_batch(const K7KernArgs
   __syncthreads();
 
   uint32_t i0 = 0, nd = 0, n_done = 0, reason = KB_REASON_DONE, dbase = 0, dcnt = 0, nb_cur = a.batch;
+  // Pre-walk: while the workgroup fetches and evaluates batch b, wave 0 — whose part in those steps the other fifteen waves take over —
+  // already walks the rows of batch b + 1 (first half during the fetch step, second half during the evaluation) into the other candidate
+  // buffer, assuming batch b turns out fully valid (more than half of the batches do: every candidate consumed, the next batch starts
+  // right behind it with the doubled size).  If it does not, the pre-walk is undone like any unconsumed candidate: bitmap bits cleared,
+  // slid windows re-anchored.  par: candidate buffer of the current batch; pw_*: the pre-walk in flight / carried into the next batch.
+  uint32_t par = 0, pw_slid = 0, pw_exh = 0, pw_ref = 0, pw_use = 0, carried_slid = 0;
+  static_assert(K7_B <= 32, "slid windows are tracked by the batch row that starts their run (32-bit mask)");
 #ifdef KB_K7_TRACE
   uint32_t tacc[14] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   unsigned long long tlast = wall_clock64();
@@ -492,8 +562,11 @@ __global__ void __launch_bounds__(KB_K5_THREADS) k_commit_batch(const K7KernArgs
       if (ja == 0) { reason = KB_REASON_RENORM; n_done = i0; break; }
       nb = ja;
     }
+    unsigned long long *const Hc = H.c2[par];
+    uint32_t *const Hidx = H.idx2[par];
     // ---- distinct shapes of the batch (wave 0): q_of[j] = rank of the first row with row j's shape
-    unsigned long long slid = 0ull;   // wave 0: shapes (by batch rank) whose window slid during this batch's walk
+    uint32_t slid = carried_slid;   // wave 0: windows (by first row of their run) that slid during this batch's walk
+    carried_slid = 0;
     if (wave == 0) {
       const bool in = lane < nb;
       const uint32_t s = in ? (uint32_t)bd[in ? lane : 0].slot : 0u;
@@ -534,60 +607,20 @@ __global__ void __launch_bounds__(KB_K5_THREADS) k_commit_batch(const K7KernArgs
       if (lane == 0) { tacc[2] += total; if (total > KB_K5_THREADS) tacc[12] += (1u << 16); }   // trace only: pairs per batch (slot 2); batches with more pairs than threads (high half of slot 12)
 #endif
       K7_STAMP(1);
-      // ---- walk (still wave 0, no barrier in between): runs of consecutive rows with the same shape take successive clean
-      //      entries of the shape's persistent window
-      const uint32_t myq = in ? q : 0xFFFFFFFFu;
-      uint32_t j = 0;
-      while (j < nb) {
-        const uint32_t qr = (uint32_t)__builtin_amdgcn_readlane((int)myq, (int)j);
-        const uint32_t sr = (uint32_t)__builtin_amdgcn_readlane((int)s, (int)j);
-        const unsigned long long diff = __ballot(lane >= j && lane < nb && myq != qr);
-        const uint32_t j1 = diff ? (uint32_t)(__ffsll((unsigned long long)diff) - 1) : nb;
-        uint32_t m = j1 - j;
-        unsigned long long *wq = M.pwin + (size_t)sr * WL;
-        uint32_t base = M.pbase[sr];
-        for (;;) {
-          const bool inw = lane < WL;
-          const unsigned long long wkey = inw ? wq[lane] : 0ull;
-          const bool nz = inw && wkey != 0ull;
-          const uint32_t node = KB_KEY_NODE(wkey);
-          const bool cl = nz && !bit_test(M.bitmap, nz ? node : 0u);
-          const unsigned long long clean = __ballot(cl);
-          const unsigned long long zeros = __ballot(inw && wkey == 0ull);
-          const uint32_t cnt = (uint32_t)__popcll(clean);
-          const uint32_t take = cnt < m ? cnt : m;
-          const uint32_t rank = (uint32_t)__popcll(clean & ((1ull << lane) - 1ull));
-          if (cl && rank < take) {
-            H.c[j + rank] = wkey;
-            H.idx[j + rank] = base + lane;
-            atomicOr(&M.bitmap[node >> 5], 1u << (node & 31));
-          }
-          j += take;
-          m -= take;
-          if (m == 0) break;
-          if (zeros) {   // the list ended: no clean feasible node is left for the remaining rows of the run
-            if (lane < m) { H.c[j + lane] = 0ull; H.idx[j + lane] = 0; }
-            j += m;
-            break;
-          }
-          // every entry of the window is dirty: slide it.  Entries taken by THIS batch may be rolled back; the roll-back step
-          // re-anchors the windows that slid during the batch (slid) at the shape's cursor
-          const uint32_t nbase = base + WL;
-          if (nbase >= a.L) {   // cannot happen while L > window: reported, never silently mis-scheduled
-            if (lane == 0) H.exhausted = 1;
-            if (lane < m) { H.c[j + lane] = 0ull; H.idx[j + lane] = 0; }
-            j += m;
-            break;
-          }
-          if (inw) wq[lane] = (nbase + lane < a.L) ? a.keys[(size_t)sr * a.L + nbase + lane] : 0ull;
-          if (lane == 0) { M.pbase[sr] = nbase; H.n_refills++; }
-          base = nbase;
-          slid |= 1ull << qr;
-          __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-          __builtin_amdgcn_wave_barrier();
-        }
+      // ---- walk (still wave 0, no barrier in between) — unless the previous batch's pre-walk already did it
+      if (!pw_use) {
+        uint32_t exh = 0, ref = 0;
+        k7_walk(M, a.keys, a.L, bd, 0, nb, nb, lane, Hc, Hidx, slid, exh, ref);
+        if (lane == 0) { if (exh) H.exhausted = 1; H.n_refills += ref; }
       }
     }
+    // can the NEXT batch be pre-walked?  (uniform: every thread computes it)  Its rows must be staged already, and rows whose score is
+    // renormalised over the feasible set stop a batch in front of them (has_aff): those sessions keep the plain protocol
+    const uint32_t nb2 = min(min(2u * a.batch, K7_B), a.n_rows - (i0 + nb));
+    const bool pw = a.prewalk && nb2 > 0 && !a.has_aff && (i0 + nb + nb2 <= dbase + dcnt);
+    const KbRowDesc *bdn = bd + nb;
+    const uint32_t pw_half = nb2 / 2u;
+    pw_slid = 0; pw_exh = 0; pw_ref = 0;
     __syncthreads();
     K7_STAMP(3);
     // ---- fetch + apply: the 16 lanes of one DPP row handle one batch row.  Lane f reads field f of the row's candidate
@@ -595,9 +628,10 @@ __global__ void __launch_bounds__(KB_K5_THREADS) k_commit_batch(const K7KernArgs
     //      NodeInfo.AddTask (api/node_info.go:172-212) to its own field and stores it into the row's NEW dirty slot: the slot
     //      holds the node's state AFTER the row committed.  Scalar dimensions (global memory, rare) are written
     //      speculatively by lane 15 and their old values saved for the rollback.
-    for (uint32_t w = tid; w < nb * 16; w += KB_K5_THREADS) {
+    if (pw && wave == 0) k7_walk(M, a.keys, a.L, bdn, 0, pw_half, nb2, lane, H.c2[par ^ 1u], H.idx2[par ^ 1u], pw_slid, pw_exh, pw_ref);
+    for (uint32_t w = pw ? tid - 64u : tid; w < nb * 16 && !(pw && wave == 0); w += pw ? KB_K5_THREADS - 64u : KB_K5_THREADS) {
       const uint32_t j = w >> 4, f = w & 15;
-      const unsigned long long cj = H.c[j];
+      const unsigned long long cj = Hc[j];
       uint32_t kind = 0, has_map = 0;
       if (cj) {
         const KbRowDesc &k = bd[j];
@@ -669,7 +703,8 @@ __global__ void __launch_bounds__(KB_K5_THREADS) k_commit_batch(const K7KernArgs
       uint32_t voff = H.e_off[lane & (K7_B - 1u)];
       asm volatile("" : "+v"(voff));   // loaded by EVERY lane: the compiler must not sink the load under the `e < P` mask (readlane reads inactive lanes)
       const uint32_t nsh = (uint32_t)__builtin_amdgcn_readfirstlane((int)H.nshapes);
-      for (uint32_t e = tid; e < P; e += KB_K5_THREADS) {
+      if (pw && wave == 0) { k7_walk(M, a.keys, a.L, bdn, pw_half, nb2, nb2, lane, H.c2[par ^ 1u], H.idx2[par ^ 1u], pw_slid, pw_exh, pw_ref); }
+      for (uint32_t e = pw ? tid - 64u : tid; e < P && !(pw && wave == 0); e += pw ? KB_K5_THREADS - 64u : KB_K5_THREADS) {
         uint32_t q = 0;
         for (uint32_t k = 1; k < nsh; k++) q += (e >= (uint32_t)__builtin_amdgcn_readlane((int)voff, (int)k)) ? 1u : 0u;
         uint32_t r = e - H.e_off[q];
@@ -679,7 +714,7 @@ __global__ void __launch_bounds__(KB_K5_THREADS) k_commit_batch(const K7KernArgs
         else if (r < nn + nl) x = M.dlog[H.e_log0[q] + (r - nn)];
         else x = nd + (r - nn - nl);
         unsigned long long key = 0ull;
-        if (x < nd || H.c[x - nd] != 0ull) {
+        if (x < nd || Hc[x - nd] != 0ull) {
           const KbRowDesc &k = bd[H.rep[q]];
           const TaskValsD tv = k7_task_vals(a, k);
           const NodeValsD nv = k5_slot_vals(M.tab, M.t_cls, M.t_left, cap2, x, a.has_ports ? M.ptab : nullptr);
@@ -707,7 +742,7 @@ __global__ void __launch_bounds__(KB_K5_THREADS) k_commit_batch(const K7KernArgs
     // ---- validate (wave 0)
     if (wave == 0) {
       const bool in = lane < nb;
-      const unsigned long long cj = in ? H.c[lane] : 0ull;
+      const unsigned long long cj = in ? Hc[lane] : 0ull;
       const uint32_t q = in ? H.q_of[lane] : 0u;
       unsigned long long m = 0ull;
       if (in) { const unsigned long long m1 = H.dmax[q], m2 = H.mrow[lane]; m = m1 > m2 ? m1 : m2; }
@@ -744,8 +779,8 @@ __global__ void __launch_bounds__(KB_K5_THREADS) k_commit_batch(const K7KernArgs
     if (tid < p) {
       const uint32_t j = tid;
       const KbRowDesc &k = bd[j];
-      atomicMax(&M.cursor[k.slot], H.idx[j] + 1);
-      k7_commit_globals<false>(a, k, i0 + j, KB_KEY_NODE(H.c[j]), H.kind[j]);
+      atomicMax(&M.cursor[k.slot], Hidx[j] + 1);
+      k7_commit_globals<false>(a, k, i0 + j, KB_KEY_NODE(Hc[j]), H.kind[j]);
     }
     if (dirty_row == 2 && tid == 0) *reinterpret_cast<uint2 *>(&a.dec[i0 + p]) = make_uint2(KB_NONE_U32, 0u);
     K7_STAMP(7);
@@ -787,8 +822,8 @@ __global__ void __launch_bounds__(KB_K5_THREADS) k_commit_batch(const K7KernArgs
         for (int u = 0; u < K7_KQ; u++) { const uint32_t x = lane + 64u * (uint32_t)u; kq[u] = (x < ndc) ? M.keyq[x] : 0ull; }
         // what the rows of the run need to know about the batch's prepared candidates, one per lane, read back with readlane
         const bool inb = lane < nb;
-        unsigned long long myc = inb ? H.c[lane] : 0ull, mykb = inb ? H.kb[lane][q] : 0ull;
-        uint32_t mykind = inb ? H.kind[lane] : 0u, myidx = inb ? H.idx[lane] : 0u;
+        unsigned long long myc = inb ? Hc[lane] : 0ull, mykb = inb ? H.kb[lane][q] : 0ull;
+        uint32_t mykind = inb ? H.kind[lane] : 0u, myidx = inb ? Hidx[lane] : 0u;
         asm volatile("" : "+v"(myc), "+v"(mykb), "+v"(mykind), "+v"(myidx));   // loaded by every lane, here (readlane reads inactive lanes)
         const unsigned long long plainmask = __ballot(inb && (bd[inb ? lane : 0].flags & 1) && bd[inb ? lane : 0].resmask == 0);
         uint32_t dec_n = 0, dec_k = 0, dec_f = 0;   // lane j: the decision of row p + j when a clean candidate took it
@@ -937,7 +972,7 @@ __global__ void __launch_bounds__(KB_K5_THREADS) k_commit_batch(const K7KernArgs
     // ---- roll back the candidates nobody consumed: they are re-speculated by the next batch
     if (tid < nb && tid >= pc) {
       const uint32_t j = tid;
-      const unsigned long long cj = H.c[j];
+      const unsigned long long cj = Hc[j];
       if (cj) {
         const KbRowDesc &k = bd[j];
         const uint32_t n = KB_KEY_NODE(cj);
@@ -953,19 +988,39 @@ __global__ void __launch_bounds__(KB_K5_THREADS) k_commit_batch(const K7KernArgs
         }
       }
     }
-    if (wave == 0 && slid != 0ull && pc < nb) {
-      // a window that slid during this batch's walk may have skipped entries whose bits the roll-back has just cleared: re-anchor
-      // it at the shape's cursor (every entry in front of the cursor belongs to a committed row or was dirty when that row passed)
-      unsigned long long sm = slid;
+    // the pre-walk stands iff this batch consumed every candidate and the next one starts right behind it with the size assumed
+    const bool fully = dirty_row == 0 && p == nb && H.reason == KB_REASON_DONE;
+    pw_use = (pw && fully) ? 1u : 0u;
+    if (pw && !fully && tid < nb2) {   // undo it: its candidates are unconsumed (wave 0: nb2 <= 32 threads)
+      const unsigned long long cj = H.c2[par ^ 1u][tid];
+      if (cj) { const uint32_t n = KB_KEY_NODE(cj); atomicAnd(&M.bitmap[n >> 5], ~(1u << (n & 31))); }
+    }
+    if (wave == 0) {
+      // a window that slid during this batch's walk (or during a pre-walk that is being undone) may have skipped entries whose bits the
+      // roll-back has just cleared: re-anchor it at the shape's cursor (every entry in front of the cursor belongs to a committed row or
+      // was dirty when that row passed)
+      uint32_t sm = (pc < nb) ? slid : 0u;
       while (sm) {
-        const uint32_t qs = (uint32_t)__ffsll((unsigned long long)sm) - 1u;
-        sm &= sm - 1ull;
-        const uint32_t sr = bd[H.rep[qs]].slot;
+        const uint32_t j0 = (uint32_t)__ffs((int)sm) - 1u;
+        sm &= sm - 1u;
+        const uint32_t sr = bd[j0].slot;
         const uint32_t nbase = M.cursor[sr];
         if (lane < WL) M.pwin[(size_t)sr * WL + lane] = (nbase + lane < a.L) ? a.keys[(size_t)sr * a.L + nbase + lane] : 0ull;
         if (lane == 0) M.pbase[sr] = nbase;
       }
+      sm = (pw && !fully) ? pw_slid : 0u;
+      while (sm) {
+        const uint32_t j0 = (uint32_t)__ffs((int)sm) - 1u;
+        sm &= sm - 1u;
+        const uint32_t sr = bdn[j0].slot;
+        const uint32_t nbase = M.cursor[sr];
+        if (lane < WL) M.pwin[(size_t)sr * WL + lane] = (nbase + lane < a.L) ? a.keys[(size_t)sr * a.L + nbase + lane] : 0ull;
+        if (lane == 0) M.pbase[sr] = nbase;
+      }
+      if (lane == 0 && pw) { H.n_prewalks++; if (fully) { H.n_prewalks_used++; H.n_refills += pw_ref; if (pw_exh) H.exhausted = 1; } }
     }
+    if (pw_use) carried_slid = pw_slid;
+    par ^= 1u;
     // no barrier here: the commit of the prefix and the roll-back above are wave 0's work (tid < K7_B <= 64) and so are the next
     // batch's shapes and walk steps; the other waves meet wave 0 again at the barrier in front of the fetch step
     K7_STAMP(10);
@@ -1063,10 +1118,13 @@ void kb_launch_commit_batch(const KbDev &d, const KbRound &r, void *stream) {
   if (r.n_rows == 0) return;
   static bool attr_set = false;
   static uint32_t env_batch = 0;
+  static bool env_prewalk = true;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_commit_batch), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     const char *b = getenv("KB_K5_BATCH");   // tuning override of kb_config.commit_batch
     env_batch = b ? (uint32_t)atoi(b) : 0;
+    const char *pwe = getenv("KB_K7_PREWALK");   // A/B switch
+    env_prewalk = !(pwe && pwe[0] == '0');
     attr_set = true;
   }
   uint32_t batch = env_batch ? env_batch : (r.batch ? r.batch : K7_B_DEFAULT);
@@ -1088,6 +1146,7 @@ void kb_launch_commit_batch(const KbDev &d, const KbRound &r, void *stream) {
   a.R = d.R;
   a.batch = batch;
   a.T = d.T; a.node_bits = 0;
+  a.prewalk = env_prewalk ? 1u : 0u;
   a.host_out = r.host_out;
   a.seq = r.seq;
   hipLaunchKernelGGL(k_commit_batch, dim3(1), dim3(KB_K5_THREADS), sh, (hipStream_t)stream, ka);

@@ -163,6 +163,7 @@ struct KbCommitArgs {
   unsigned long long *host_out;   // pinned host mirror of the output block (fast rounds), or nullptr
   unsigned long long seq;         // sequence number published last into host_out[KB_OUT_SEQ]
   uint32_t node_bits;             // width of the node field of the commit kernel's 32-bit keys (kb_node_bits)
+  uint32_t prewalk;               // batch kernel: wave 0 walks batch b + 1 while the workgroup fetches / evaluates batch b (KB_K7_PREWALK=0: off)
 };
 
 // 32-bit keys of the commit kernel: (score + 1) << node_bits | (2^node_bits - 1 - node); needs (max score + 2) << node_bits <= 2^32
@@ -209,7 +210,8 @@ void kb_launch_probe(const KbDev &d, const uint32_t *rows, uint32_t n_rows, uint
 void kb_launch_interpod(const KbDev &d, const KbRound &r, void *stream);
 void kb_launch_argmax(const KbDev &d, const KbRound &r, void *stream);
 // per-task rows out of the per-shape rows (kb_eval_matrix / kb_bench_matrix: the materialised T x N matrix)
-void kb_launch_expand(const KbDev &d, const uint16_t *s_score, const uint32_t *s_mask, const uint32_t *row_slot, uint32_t n_rows,
+// order: the rows sorted by shape slot (nullptr: row order)
+void kb_launch_expand(const KbDev &d, const uint16_t *s_score, const uint32_t *s_mask, const uint32_t *row_slot, const uint32_t *order, uint32_t n_rows,
                       uint16_t *score, uint32_t *maskw, void *stream);
 void kb_launch_commit(const KbDev &d, const KbRound &r, void *stream);         // KB_COMMIT_RUN
 void kb_launch_commit_batch(const KbDev &d, const KbRound &r, void *stream);   // KB_COMMIT_BATCH

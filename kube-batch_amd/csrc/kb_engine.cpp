@@ -154,7 +154,8 @@ struct kb_engine {
   uint32_t total_mask = 0;
   // round buffers
   DevBuf b_desc;
-  DevBuf b_sscore, b_smask, b_xslot;   // per-shape rows and row->shape map of kb_eval_matrix / kb_bench_matrix
+  DevBuf b_sscore, b_smask, b_xslot, b_xorder;   // per-shape rows, row->shape map and rows in shape order of kb_eval_matrix / kb_bench_matrix
+  std::vector<uint32_t> h_xorder;
   size_t xs_cap = 0, xslot_cap = 0;
   DevBuf b_mrows, b_same, b_score, b_maskw, b_keys;
   DevBuf b_win, b_out;   // per-round upload / download blocks (see h_win / h_out)
@@ -1491,9 +1492,13 @@ static ChunkPlan matrix_plan(kb_engine *e, uint32_t t0, uint32_t n, uint32_t fit
   for (uint32_t i = 0; i < n; i++) e->h_rows[i] = t0 + i;
   if (e->h_mrows.size() < n) e->h_mrows.resize(n);
   p.ns = assign_shapes(e, n);
-  // Expansion streams every task row out of its shape's row: that pays while the shape rows stay cache-resident (a few dozen to
-  // a few hundred shapes).  When (nearly) every job has its own request the shape rows are a second matrix in HBM and the
-  // expansion doubles the traffic: then every row is evaluated directly (KB_K1_DIRECT=1/0 pins the choice for A/B runs).
+  // Expansion streams every task row out of its shape's row.  The rows are expanded in SHAPE order (k_expand's `order`), so a shape
+  // row is read from HBM once and copied to all its task rows out of the L2 however many shapes there are; what the per-shape pass
+  // cannot avoid is evaluating and storing the shape rows themselves.  When (nearly) every job has its own request that is a second
+  // matrix: then every row is evaluated by the matrix kernel itself, adjacent equal rows (the tasks of a job) sharing one evaluation
+  // (k_matrix_runs).  Measured on one box (profiles/round3/call5): 9 386 shapes of 100k rows: direct 0.62 ms, expansion 0.89 ms;
+  // 2 989 shapes (BASELINE configs[3]): direct 0.68, expansion 0.66; 1M x 50k with ~500 shapes: direct 28.0, expansion 24.0.
+  // KB_K1_DIRECT=1/0 pins the choice for A/B runs.
   {
     static const char *pin = getenv("KB_K1_DIRECT");
     p.direct = pin ? pin[0] == '1' : ((size_t)p.ns * e->dev.NP * 2 > (32u << 20) && (size_t)p.ns * 16 > n);
@@ -1515,8 +1520,17 @@ static ChunkPlan matrix_plan(kb_engine *e, uint32_t t0, uint32_t n, uint32_t fit
     e->b_smask.alloc(sizeof(uint32_t) * (size_t)p.ns * (NP / 32));
     e->xs_cap = p.ns;
   }
-  if (n > e->xslot_cap) { e->b_xslot.alloc(sizeof(uint32_t) * n); e->xslot_cap = n; }
+  if (n > e->xslot_cap) { e->b_xslot.alloc(sizeof(uint32_t) * n); e->b_xorder.alloc(sizeof(uint32_t) * n); e->xslot_cap = n; }
   HIP_OK(hipMemcpyAsync(e->b_xslot.p, e->h_slot.data(), sizeof(uint32_t) * n, hipMemcpyHostToDevice, e->stream));
+  {   // the rows in shape order (stable counting sort by slot): consecutive workgroups of k_expand then copy out of the same shape row
+    e->h_xorder.resize(n);
+    std::vector<uint32_t> start((size_t)p.ns + 1, 0u);
+    for (uint32_t i = 0; i < n; i++) start[e->h_slot[i] + 1]++;
+    for (uint32_t sidx = 0; sidx < p.ns; sidx++) start[sidx + 1] += start[sidx];
+    for (uint32_t i = 0; i < n; i++) e->h_xorder[start[e->h_slot[i]]++] = i;
+    HIP_OK(hipMemcpyAsync(e->b_xorder.p, e->h_xorder.data(), sizeof(uint32_t) * n, hipMemcpyHostToDevice, e->stream));
+    HIP_OK(hipStreamSynchronize(e->stream));   // h_xorder is pageable and reused by the next plan
+  }
   HIP_OK(hipMemcpyAsync(e->b_mrows.p, e->h_mrows.data(), sizeof(uint32_t) * p.ns, hipMemcpyHostToDevice, e->stream));
   p.rs = make_round(e, 0, p.ns, 1, (int)fit_mode, false);
   p.rs.mrows = e->b_mrows.as<uint32_t>();   // this path stages its representative rows in its own buffer (can exceed a window)
@@ -1539,7 +1553,10 @@ static void matrix_launch(kb_engine *e, const ChunkPlan &p, uint32_t n, uint32_t
   kb_launch_matrix(e->dev, p.rs, e->stream);
   kb_launch_affinity(e->dev, p.rs, e->stream);
   kb_launch_interpod(e->dev, p.rs, e->stream);
-  kb_launch_expand(e->dev, p.rs.score, p.rs.maskw, e->b_xslot.as<uint32_t>(), n, p.r.score, p.r.maskw, e->stream);
+  // shape order pays when the shape rows do not fit the L2s (C5: 23.0 -> 18.8 ms, BASELINE configs[3]: 0.66 -> 0.64 ms); while they do,
+  // task order writes consecutive rows and is the faster one (C3, 509 shapes = 10 MB: 0.41 ms against 0.52; profiles/round3/call6)
+  const bool by_shape = (size_t)p.ns * e->dev.NP * 2 > (16u << 20);
+  kb_launch_expand(e->dev, p.rs.score, p.rs.maskw, e->b_xslot.as<uint32_t>(), by_shape ? e->b_xorder.as<uint32_t>() : nullptr, n, p.r.score, p.r.maskw, e->stream);
   if (k) kb_launch_argmax(e->dev, p.r, e->stream);
 }
 static KbRound matrix_chunk(kb_engine *e, uint32_t t0, uint32_t n, uint32_t fit_mode, uint32_t k) {

@@ -258,14 +258,99 @@ __global__ void __launch_bounds__(256) k_matrix(KbDev d, KbRound r) {
   }
 }
 
+// K1 for the launches that evaluate every task row themselves (kb_eval_matrix / kb_bench_matrix with more distinct shapes than the per-shape
+// rows' cache residency allows): the tasks of a job are adjacent and equal, so the rows of a tile come in RUNS of identical rows.  The
+// <4, 32> tile above stores every row of a run from each thread's own registers (8 bytes per lane per row, one row at a time); rocprofv3's
+// SQ counters (profiles/round3/k1_profile) show what that costs: 141 VGPRs -> three waves per SIMD, each alive for 16 us of which 3 us issue
+// VALU work: the stores of a run are issued one by one between LDS reads and scalar branches, with nothing to overlap them.
+// Here a run is evaluated ONCE into LDS (2 KB of scores + 128 B of mask for the tile's 1 024 nodes) and then streamed out by the whole
+// workgroup with 16-byte stores, every thread holding its 16 bytes in registers and issuing run_len / 2 independent stores back to back:
+// k_expand's store pattern without its load.
+__global__ void __launch_bounds__(256) k_matrix_runs(KbDev d, KbRound r) {
+  constexpr int NPT = 4, TR = 32;
+  __shared__ K1Task srow[TR];
+  __shared__ uint32_t ssame[TR];
+  __shared__ __align__(16) uint2 sres[256];       // 1 024 u16 scores of the current run
+  __shared__ __align__(16) uint32_t smask[32];    // their mask bits
+  const uint32_t row0 = blockIdx.y * TR;
+  const uint32_t nr = min((uint32_t)TR, r.n_mrows - row0);
+  if (threadIdx.x < TR) {
+    uint32_t same = 0;
+    if (threadIdx.x < nr) {
+      const uint32_t i = row0 + threadIdx.x;
+      srow[threadIdx.x] = k1_task(d, r.mrows ? r.mrows[i] : r.mrow_task0 + i);
+      same = (r.same_prev && r.same_prev[i] && threadIdx.x > 0) ? 1u : 0u;
+    }
+    ssame[threadIdx.x] = same;
+  }
+  __syncthreads();
+  const uint32_t lane = threadIdx.x & 63;
+  // bit i: row i of the tile equals row i - 1 (never bit 0; rows past the tile's end read 0 and end the last run)
+  const uint32_t samemask = (uint32_t)__ballot(lane < TR && ssame[lane & (TR - 1)] != 0u);
+  const uint32_t nb = blockIdx.x * 1024u;                       // the tile's first node
+  const uint32_t n0 = nb + threadIdx.x * NPT;
+  K1Node nv[NPT];
+#pragma unroll
+  for (int j = 0; j < NPT; j++) nv[j] = k1_node(d, n0 + j);
+  const size_t mstride = d.NP / 32;
+  uint32_t rr = 0;
+  while (rr < nr) {
+    // rows rr+1 .. of the tile that repeat row rr: the first 0 bit above rr ends the run
+    const uint32_t follow = (rr + 1u < 32u) ? ~(samemask >> (rr + 1u)) : 1u;
+    const uint32_t run_len = min(1u + (uint32_t)__builtin_ctz(follow | 0x80000000u), nr - rr);
+    uint32_t res[NPT];
+    const K1Task tv = k1_uniform(srow[rr]);
+    eval_row<NPT>(d, tv, nv, n0, r.fit_mode, res);
+    uint2 pk;
+    pk.x = (res[0] & 0xFFFFu) | (res[1] << 16);
+    pk.y = (res[2] & 0xFFFFu) | (res[3] << 16);
+    const uint32_t nib = ((res[0] >> 16) & 1u) | (((res[1] >> 16) & 1u) << 1) | (((res[2] >> 16) & 1u) << 2) | (((res[3] >> 16) & 1u) << 3);
+    uint32_t w = nib << (4 * (lane & 7));                        // OR the 8 lanes' nibbles into one mask word (DPP, no LDS crossbar)
+    w |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)w, 0xB1, 0xf, 0xf, false);    // quad_perm [1,0,3,2]
+    w |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)w, 0x4E, 0xf, 0xf, false);    // quad_perm [2,3,0,1]
+    w |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)w, 0x141, 0xf, 0xf, false);   // row_half_mirror
+    const size_t row = row0 + rr;
+    if (run_len == 1u) {   // nothing to share: straight from the registers
+      *reinterpret_cast<uint2 *>(r.score + row * d.NP + n0) = pk;
+      if ((lane & 7) == 0) r.maskw[row * mstride + (n0 >> 5)] = w;
+    } else {
+      sres[threadIdx.x] = pk;
+      if ((lane & 7) == 0) smask[threadIdx.x >> 3] = w;
+      __syncthreads();
+      {
+        const uint32_t c = threadIdx.x & 127u;                   // this thread's 16-byte column of the tile's 2 KB row segment
+        const uint4 v = reinterpret_cast<const uint4 *>(sres)[c];
+        uint16_t *dst = r.score + (row + (threadIdx.x >> 7)) * d.NP + nb + c * 8u;
+        for (uint32_t k = threadIdx.x >> 7; k < run_len; k += 2u, dst += (size_t)2 * d.NP) *reinterpret_cast<uint4 *>(dst) = v;
+      }
+      if (threadIdx.x < 8u * run_len) {                          // 128 B of mask per row: eight 16-byte columns (run_len <= 32 rows)
+        const uint32_t c = threadIdx.x & 7u;
+        const uint4 v = reinterpret_cast<const uint4 *>(smask)[c];
+        *reinterpret_cast<uint4 *>(r.maskw + (row + (threadIdx.x >> 3)) * mstride + (nb >> 5) + c * 4u) = v;
+      }
+      __syncthreads();   // the next run overwrites sres / smask
+    }
+    rr += run_len;
+  }
+}
+
 // K1b: row expansion.  Tasks with the same shape (InitResreq, non-zero request, class) have identical matrix rows, so the
 // materialised T x N matrix is produced by evaluating each distinct shape once (k_matrix over the representative rows)
 // and streaming every task row out of its shape's row: 16-byte loads that hit L2 / Infinity Cache (S x N is a few MB),
 // 16-byte stores that are the launch's HBM traffic (2 B score + 1 mask bit per evaluation).  One workgroup per task row.
+// Rows are taken in SHAPE order (order[]: the host's counting sort by slot), an eighth of that order per XCD (workgroup b runs on XCD
+// b % 8): the workgroups that share an L2 copy out of the same few shape rows, so a shape row is fetched from HBM once per launch
+// however many shapes the session has (with rows in task order, 2 989 shapes = 61 MB of shape rows thrashed the 4 MB L2s and the
+// launch read as much as it wrote: 0.54 ms instead of 0.38, profiles/round3/k1_profile).
 __global__ void __launch_bounds__(256) k_expand(const uint16_t *__restrict__ s_score, const uint32_t *__restrict__ s_mask,
-                                                const uint32_t *__restrict__ row_slot, uint32_t n_rows, uint32_t NP,
+                                                const uint32_t *__restrict__ row_slot, const uint32_t *__restrict__ order, uint32_t n_rows, uint32_t NP,
                                                 uint16_t *__restrict__ score, uint32_t *__restrict__ maskw) {
-  const uint32_t row = blockIdx.x;
+  uint32_t row = blockIdx.x;
+  if (order) {
+    const uint32_t per = (n_rows + 7u) / 8u, at = (blockIdx.x & 7u) * per + (blockIdx.x >> 3);
+    if ((blockIdx.x >> 3) >= per || at >= n_rows) return;
+    row = order[at];
+  }
   if (row >= n_rows) return;
   const uint32_t slot = row_slot[row];
   const uint4 *src = reinterpret_cast<const uint4 *>(s_score + (size_t)slot * NP);
@@ -637,7 +722,10 @@ void kb_launch_matrix(const KbDev &d, const KbRound &r, void *stream) {
     // <4,32> amortises a thread's node state over 32 rows and stores 8 bytes per row, but a few hundred rows (the distinct shapes of
     // a whole session) make only ~100 such workgroups: below four per CU the one-node tile with 16 rows fills the chip instead
     const size_t blocks = (size_t)(d.NP / (256 * 4)) * ((r.n_mrows + 31) / 32);
-    if (blocks >= 1024) {
+    static const bool runs_off = getenv("KB_K1_RUNS") && getenv("KB_K1_RUNS")[0] == '0';   // A/B switch
+    if (blocks >= 1024 && r.same_prev != nullptr && !r.gather && r.chain == nullptr && !runs_off) {
+      hipLaunchKernelGGL(k_matrix_runs, dim3(d.NP / 1024, (r.n_mrows + 31) / 32), dim3(256), 0, (hipStream_t)stream, d, r);
+    } else if (blocks >= 1024) {
       dim3 grid(d.NP / (256 * 4), (r.n_mrows + 31) / 32 + (r.gather ? 1 : 0));
       hipLaunchKernelGGL((k_matrix<4, 32>), grid, dim3(256), 0, (hipStream_t)stream, d, r);
     } else {
@@ -755,10 +843,13 @@ void kb_launch_affinity(const KbDev &d, const KbRound &r, void *stream) {
   if (r.n_mrows == 0 || !d.aff || !d.score_enabled) return;
   hipLaunchKernelGGL(k_affinity, dim3(r.n_mrows), dim3(256), 0, (hipStream_t)stream, d, r);
 }
-void kb_launch_expand(const KbDev &d, const uint16_t *s_score, const uint32_t *s_mask, const uint32_t *row_slot, uint32_t n_rows,
+void kb_launch_expand(const KbDev &d, const uint16_t *s_score, const uint32_t *s_mask, const uint32_t *row_slot, const uint32_t *order, uint32_t n_rows,
                       uint16_t *score, uint32_t *maskw, void *stream) {
   if (n_rows == 0) return;
-  hipLaunchKernelGGL(k_expand, dim3(n_rows), dim3(256), 0, (hipStream_t)stream, s_score, s_mask, row_slot, n_rows, d.NP, score, maskw);
+  static const bool plain = getenv("KB_EXPAND_ORDER") && getenv("KB_EXPAND_ORDER")[0] == '0';   // A/B switch: rows in task order
+  if (plain) order = nullptr;
+  const uint32_t grid = order ? 8u * ((n_rows + 7u) / 8u) : n_rows;
+  hipLaunchKernelGGL(k_expand, dim3(grid), dim3(256), 0, (hipStream_t)stream, s_score, s_mask, row_slot, order, n_rows, d.NP, score, maskw);
 }
 template <bool WIDE, int THREADS, int NW> static void k3_launch(const KbDev &d, const KbRound &r, size_t sh, hipStream_t st) {
   static bool attr_set = false;

@@ -16,4 +16,4 @@ T, N, R = snap.n_tasks, snap.n_nodes, snap.n_res
 for fit in (1,):
     ms = min(e.bench_matrix(0, T, reps=5, fit_mode=fit) for _ in range(3))
     alg = T * N * 2.125 + N * (16 * R + 44) + T * (8 * R + 24)
-    print(f"config {cfg_idx}{' diverse' if params.diverse_requests else ''} KB_K1_DIRECT={os.environ.get('KB_K1_DIRECT', 'auto')} R={R} fit={fit}: {ms:.4f} ms  {alg / ms / 1e6:.1f} GB/s  {alg / ms / 1e6 / 8000:.3f} of peak  {T * N / ms / 1e6:.1f} Gevals/s")
+    print(f"KB_K1_RUNS={os.environ.get('KB_K1_RUNS', '1')} config {cfg_idx}{' diverse' if params.diverse_requests else ''} KB_K1_DIRECT={os.environ.get('KB_K1_DIRECT', 'auto')} R={R} fit={fit}: {ms:.4f} ms  {alg / ms / 1e6:.1f} GB/s  {alg / ms / 1e6 / 8000:.3f} of peak  {T * N / ms / 1e6:.1f} Gevals/s")

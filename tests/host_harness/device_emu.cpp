@@ -434,10 +434,11 @@ void kb_launch_argmax(const KbDev &d, const KbRound &r, void *stream) {
   });
 }
 
-void kb_launch_expand(const KbDev &d, const uint16_t *s_score, const uint32_t *s_mask, const uint32_t *row_slot, uint32_t n_rows,
+void kb_launch_expand(const KbDev &d, const uint16_t *s_score, const uint32_t *s_mask, const uint32_t *row_slot, const uint32_t *order, uint32_t n_rows,
                       uint16_t *score, uint32_t *maskw, void *stream) {
-  kbemu_enqueue((hipStream_t)stream, [d, s_score, s_mask, row_slot, n_rows, score, maskw]() {
-  for (uint32_t row = 0; row < n_rows; row++) {
+  kbemu_enqueue((hipStream_t)stream, [d, s_score, s_mask, row_slot, order, n_rows, score, maskw]() {
+  for (uint32_t at = 0; at < n_rows; at++) {   // the contract: `order` is a permutation of the rows (the kernel takes them in that order)
+    const uint32_t row = order ? order[at] : at;
     const uint32_t slot = row_slot[row];
     std::memcpy(score + (size_t)row * d.NP, s_score + (size_t)slot * d.NP, sizeof(uint16_t) * d.NP);
     std::memcpy(maskw + (size_t)row * (d.NP / 32), s_mask + (size_t)slot * (d.NP / 32), sizeof(uint32_t) * (d.NP / 32));

@@ -116,6 +116,26 @@ def test_matrix_parity_r16_and_after_allocate(oracle_mod):
         assert np.array_equal(em, om) and np.array_equal(es, os_), hex(flags)
 
 
+@pytest.mark.parametrize("n_res,diverse", [(2, False), (2, True), (16, False)])
+def test_matrix_parity_wide_direct_tiles(oracle_mod, n_res, diverse):
+    """A matrix wide and tall enough (4 608 rows x 9 000 nodes) for the tiles the small configurations never launch: k_matrix_runs (runs of
+    adjacent equal rows evaluated once, streamed out with 16-byte stores; rows [0, 4096) and the ragged rest), k_matrix<4, 32>
+    (KB_MATRIX_NO_DEDUP), and the per-shape + expansion path, all bit-equal to the oracle — also in a live state after an allocate pass."""
+    p = snapmod.SynthParams(n_tasks=5000, n_nodes=9000, n_queues=8, n_res=n_res, seed=snapmod.SEED_BASE + 77 + n_res)
+    p.diverse_requests = diverse
+    snap = snapmod.synth(p)
+    cfg = conf.load_scheduler_conf(MOST_CONF) if n_res > 2 else conf.load_scheduler_conf()
+    o, e, dec = run_both(oracle_mod, cfg, snap, ["allocate"])
+    assert_same_outcome(o, e, dec)
+    t1 = 4608
+    om, os_ = o.eval_matrix(0, t1, 1)
+    for flags in (0, abi.MATRIX_DIRECT, abi.MATRIX_DIRECT | abi.MATRIX_NO_DEDUP):
+        em, es = e.eval_matrix(0, t1, 1 | flags)
+        assert np.array_equal(em, om), hex(flags)
+        assert np.array_equal(es, os_), hex(flags)
+    assert om.any() and os_.any()
+
+
 def test_argmax_parity(oracle_mod):
     snap = small(2, 0.5)
     cfg = conf.load_scheduler_conf()
