@@ -106,7 +106,9 @@ def main():
     force_sharded = world == 1 and os.environ.get("KB_BENCH_SHARDED") == "1" and "MASTER_ADDR" in os.environ
     if world > 1 or force_sharded:
         import torch.distributed as dist
-        dist.init_process_group("nccl")
+        # "nccl" = RCCL over xGMI.  KB_DIST_BACKEND=gloo: several ranks on ONE GPU (RCCL refuses two ranks per device), which is how the
+        # N > 1 code path is exercised on a one-GPU box
+        dist.init_process_group(os.environ.get("KB_DIST_BACKEND", "nccl"))
 
     conf = kbm.conf.load_scheduler_conf()          # pkg/scheduler/util.go:31-42 default: allocate, backfill; all six plugins
     weights = "least 1, most 0, balanced 1"
@@ -128,10 +130,21 @@ def main():
     snap = kbm.snapshot.synth(params)
     actions = ["allocate", "backfill"] + (["preempt"] if args.preempt else [])
 
+    dist_mode = None
     if world > 1 or force_sharded:
+        # N > 1.  Default "replicas only": the cycle does not shard profitably (its shardable part, ~19 us of
+        # matrix + candidate lists per round, is shorter than one collective over xGMI; the commit is a sequential dependency), so every
+        # rank runs the whole cycle on its own session replica through the single-GPU fast path, no data-path collective, `value` = what
+        # all ranks processed / time ("scaling": "weak"); after the timed region ONE all-reduce compares a digest of the replicas'
+        # decisions.  KB_DIST_MODE=sharded: north_star's task-row split (matrix rows sharded, lists all-gathered, commit replicated,
+        # deltas all-reduced, per round) — exact, "strong", and slower than one GPU.
         distmod = importlib.import_module("kube-batch_amd.dist")
-        runner = distmod.ShardedCycle(conf, snap, device=local_rank, window=args.window, commit_batch=args.commit_batch)
-        step = runner.step
+        dist_mode = "sharded" if (force_sharded or os.environ.get("KB_DIST_MODE") == "sharded") else "replicas"
+        if dist_mode == "sharded":
+            runner = distmod.ShardedCycle(conf, snap, device=local_rank, window=args.window, commit_batch=args.commit_batch)
+        else:
+            runner = distmod.ReplicatedCycle(conf, snap, device=local_rank, window=args.window, commit_batch=args.commit_batch)
+        step = (lambda: runner.step(verify=False)) if dist_mode == "replicas" else runner.step
         eng = runner.engine
     else:
         eng = engine.Engine(conf, device=local_rank, window=args.window, commit_batch=args.commit_batch)
@@ -167,7 +180,7 @@ def main():
     s1 = eng.stats()
     elapsed = t1 - t0
     if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
@@ -175,7 +188,17 @@ def main():
     n_binds = int((binds != kbm.abi.KB_NONE).sum())
     d = {k: s1[k] - s0[k] for k in s1}
     evals = d["evals"]
-    value = evals / elapsed
+    replicas = world if dist_mode == "replicas" else 1      # independent session replicas: the job processed `world` cycles per step
+    replicas_agree = None
+    if dist_mode == "replicas" and world > 1:
+        dec_last = runner.step(verify=False)                 # outside the timed region: one more cycle, its digest compared across ranks
+        try:
+            runner.check(dec_last)
+            replicas_agree = True
+        except RuntimeError as err:
+            replicas_agree = False
+            print(f"bench.py: {err}", file=sys.stderr)
+    value = replicas * evals / elapsed
 
     # ---- roofline: the mask+score matrix (K1), HBM-bound by construction (SURVEY.md §8d accounting (M): 2 B score + 1/8 B
     # mask per evaluation written once, node and task vectors read once).  Two measurements, both with HIP events on the
@@ -248,14 +271,14 @@ def main():
     out = {
         "metric": f"pod-node scoring evals/sec + binds/sec, {_k(snap.n_tasks)} tasks x {_k(snap.n_nodes)} nodes snapshot",
         "value": value, "unit": "evals/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": elapsed * 1e3 / args.steps, "higher_is_better": True, "scaling": "strong",
+        "ms_per_step": elapsed * 1e3 / args.steps, "higher_is_better": True, "scaling": "weak" if dist_mode == "replicas" else "strong",
         "vs_baseline": None, "dtype": "f64+i64", "data": "synthetic",
         "config": {"workload": f"BASELINE configs[{args.config - 1}]: {snap.n_tasks} tasks x {snap.n_nodes} nodes, "
                                f"{snap.n_jobs} gang jobs, {snap.n_queues} queues, R={R}, {'+'.join(actions)}, "
                                f"plugins priority,gang,drf,predicates,proportion,nodeorder ({weights})",
                    "window": args.window or 256, "scale": args.scale, "diverse_requests": bool(args.diverse),
                    "node_sizes": "SURVEY 8d list (no capacity pressure)" if args.survey_nodes else "sized for demand ~1.3x capacity"},
-        "binds_per_s": n_binds * args.steps / elapsed, "binds": n_binds, "decisions": int(d["decisions"] / args.steps),
+        "binds_per_s": replicas * n_binds * args.steps / elapsed, "binds": n_binds, "decisions": int(d["decisions"] / args.steps),
         "evals_per_step": int(evals / args.steps),
         # `value` counts the evaluations the REFERENCE performs for this cycle (N per popped task).  The engine
         # itself evaluates far fewer pairs (one matrix row per distinct task shape of a window + the dirty-node repairs):
@@ -271,6 +294,8 @@ def main():
         "streaming_equivalent": {"bytes_per_eval": b_node, "equivalent_GBps": round(value * b_node / 1e9, 1),
                                  "frac_of_hbm_peak": round(value * b_node / 1e9 / HBM_PEAK_GBS, 4)},
         # not part of `value`: kb_session_load of the same snapshot (validation, shape interning, proportion water-fill, H2D)
+        "multi_gpu_mode": None if dist_mode is None else ("replicas only: one session replica per GPU, no data-path collective" if dist_mode == "replicas" else "task-row sharded rounds (KB_DIST_MODE=sharded)"),
+        "replicas": replicas, "replicas_agree": replicas_agree,
         "session_load_ms": None if load_ms is None else round(load_ms, 2),
         "evals_per_s_including_session_load": None if load_ms is None else evals / args.steps / (elapsed / args.steps + load_ms * 1e-3),
     }

@@ -184,3 +184,53 @@ class ShardedCycle:
         for a in self.actions:
             out.append(self.run_action({"allocate": 0, "backfill": 1}[a]))
         return np.concatenate(out) if out else np.zeros((0, 3), np.uint32)
+
+
+
+class ReplicatedCycle:
+    """The default multi-GPU mode of bench.py: every rank runs the WHOLE cycle on its own replica through the
+    engine's single-GPU fast path (chained rounds, pinned mailbox, plan-ahead) — the host code and the kernels are deterministic, so
+    the replicas agree without talking — and the ranks compare a digest of what they decided with ONE all-reduce per cycle.
+
+    Why not shard: the part of a round that shards (matrix + candidate lists of ~25 shapes: ~19 us on C3, ~33 us on 1M x 50k) is
+    shorter than one small collective over xGMI, and the commit (80 % of the cycle) is a sequential dependency; ShardedCycle above is
+    the exact task-row split north_star names and costs ~2x a single GPU for that reason.  Replicas cost nothing and buy a
+    cross-check: a replica that diverged (bit flip, driver fault) is detected at the end of the cycle."""
+
+    def __init__(self, conf, snap, device: int = 0, window: int = 0, commit_batch: int = 0, engine=None, actions=("allocate", "backfill")):
+        self.rank = dist.get_rank() if dist.is_initialized() else 0
+        self.world = dist.get_world_size() if dist.is_initialized() else 1
+        self.actions = list(actions)
+        if engine is None:
+            from .engine import Engine
+            engine = Engine(conf, device=device, window=window, commit_batch=commit_batch)
+            engine.load(snap)
+        self.engine = engine
+        self.cycles = 0
+        on_gpu = dist.is_initialized() and dist.get_backend() == "nccl"
+        self._dev = torch.device("cuda", device) if on_gpu else torch.device("cpu")
+
+    @staticmethod
+    def digest(decisions: np.ndarray, binds: np.ndarray) -> int:
+        """63 bits of SHA-256 over the ordered decision list and the bind set"""
+        import hashlib
+        h = hashlib.sha256()
+        h.update(np.ascontiguousarray(decisions, dtype=np.uint32).tobytes())
+        h.update(np.ascontiguousarray(binds, dtype=np.uint32).tobytes())
+        return int.from_bytes(h.digest()[:8], "little") >> 1
+
+    def step(self, verify: bool = True) -> np.ndarray:
+        self.engine.reset()
+        dec = self.engine.run(self.actions)
+        self.cycles += 1
+        if verify and self.world > 1:
+            self.check(dec)
+        return dec
+
+    def check(self, dec: np.ndarray):
+        """one all-reduce (MIN and MAX of the digest in one tensor): every replica took the same decisions"""
+        d = self.digest(dec, self.engine.binds())
+        t = torch.tensor([d, -d], dtype=torch.int64, device=self._dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        if int(t[0].item()) != -int(t[1].item()):
+            raise RuntimeError(f"replicas diverged: rank {self.rank} digest {d:#x}, max {int(t[0].item()):#x}, min {-int(t[1].item()):#x}")

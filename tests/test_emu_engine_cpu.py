@@ -152,6 +152,51 @@ def test_sharded_rounds_two_gloo_ranks_equal_the_oracle(emulated_engine, oracle_
     assert abs(int(m0[0]) - int(m1[0])) <= m0[1] * 10_000   # each rank evaluated about half of the matrix rows
 
 
+# ---- the default multi-GPU mode of bench.py: one session replica per rank, one digest all-reduce (dist.ReplicatedCycle) ---------
+def _replica_worker(rank, world, port, out_dir, so, poison_rank):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        distmod = importlib.import_module("kube-batch_amd.dist")
+        engine.LIB_PATH, engine._LIB = so, None
+        conf = kbm.conf.load_scheduler_conf()
+        snap = kbm.snapshot.synth(kbm.snapshot.synth_config(3, 0.03))
+        cyc = distmod.ReplicatedCycle(conf, snap, device=0)
+        dec = cyc.step(verify=False)
+        if rank == poison_rank:           # a replica that went wrong: the cross-check must say so on EVERY rank
+            dec = dec.copy()
+            dec[len(dec) // 2, 1] ^= 1
+        try:
+            cyc.check(dec)
+            verdict = "agree"
+        except RuntimeError:
+            verdict = "diverged"
+        np.save(os.path.join(out_dir, f"dec{rank}.npy"), dec)
+        open(os.path.join(out_dir, f"verdict{rank}.txt"), "w").write(verdict)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("poison_rank", [-1, 1])
+def test_replicated_cycle_two_gloo_ranks(emulated_engine, oracle_mod, tmp_path, poison_rank):
+    import socket
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_replica_worker, args=(2, port, str(tmp_path), emulated_engine, poison_rank), nprocs=2, join=True)
+    verdicts = [open(tmp_path / f"verdict{r}.txt").read() for r in (0, 1)]
+    if poison_rank < 0:
+        assert verdicts == ["agree", "agree"]
+        o = oracle_mod.Oracle(kbm.conf.load_scheduler_conf(), kbm.snapshot.synth(kbm.snapshot.synth_config(3, 0.03)))
+        o.run(["allocate", "backfill"])
+        for r in (0, 1):
+            assert np.array_equal(np.load(tmp_path / f"dec{r}.npy"), o.decisions()), f"rank {r}"
+    else:
+        assert verdicts == ["diverged", "diverged"]
+
+
 @pytest.mark.parametrize("name", ["config3_full", "config4_binpack_full", "config5_full", "config5_full_preempt"])
 def test_full_size_cycles_through_the_host_side(oracle_mod, name):
     """BASELINE configs[2] and [3] at full size (100k x 10k) through the engine's host side on the emulated device, against the oracle and
