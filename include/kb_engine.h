@@ -313,8 +313,10 @@ int  kb_session_reset(kb_engine *e);
 
 int  kb_run_allocate(kb_engine *e, kb_decision *out, uint64_t cap, uint64_t *n_out);
 int  kb_run_backfill(kb_engine *e, kb_decision *out, uint64_t cap, uint64_t *n_out);
-/* the preempt action on the session's current state; journal entries in order (KB_E_CAPACITY: *n_out = required count; no result was
-   applied, but the device's copy of some nodes may have been refreshed mid-action: kb_session_load again before the next call).
+/* the preempt action on the session's current state; journal entries in order.  ANY non-OK answer of kb_run_preempt / kb_run_reclaim after
+   the action has started (KB_E_CAPACITY: *n_out = required count, no result was applied; KB_E_UNSUPPORTED met mid-action; KB_E_INTERNAL from
+   the closing cross-check) may leave refreshed nodes or committed state behind: the session is then marked and every kb_run_* answers
+   KB_E_STATE until kb_session_load or kb_session_reset; the getters keep working.
    Sessions with preferred node-affinity terms are scored with NormalizeReduce over the preemptor's feasible set, which one Pipeline can
    change for every node: their lists are rebuilt after every Pipeline instead of repaired (KB_PREEMPT_NODE_AFFINITY=0 in the environment
    restores the round-2 refusal, KB_E_UNSUPPORTED).  KB_E_UNSUPPORTED: states in which the reference itself would panic / abort

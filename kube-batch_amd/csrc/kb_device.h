@@ -218,6 +218,9 @@ void kb_launch_commit_batch(const KbDev &d, const KbRound &r, void *stream);   /
 // node state := round-start state + reduced deltas; returns how many values differ from the live (locally committed) state
 uint32_t kb_apply_deltas(const KbDev &d, const double *s_idle, const double *s_rel, const long long *s_nzc, const long long *s_nzm,
                          const int *s_podcnt, const double *delta, uint32_t *dev_counter, void *stream);
+// live state of n nodes from packed records of 5 + 2R 8-byte words {node | nmask << 32, podcnt, nzc, nzm, ports, Idle[R], Releasing[R]}
+// (the evict actions' host mirror -> device); nmask: the writable view of KbDev::nmask
+void kb_launch_scatter_nodes(const KbDev &d, const unsigned long long *rec, uint32_t n, uint32_t *nmask, void *stream);
 // gang ballot + drf/proportion share reduction over the task table
 void kb_launch_finalize(const KbDev &d, const uint32_t *job_task_begin, const int *job_min_avail, const uint32_t *job_queue,
                         int gang_ready_enabled, const double *total /*[R]*/, uint32_t total_mask, const double *deserved /*[R][Q]*/,

@@ -121,6 +121,7 @@ struct kb_engine {
   Policy pol;
   hipStream_t stream = nullptr, own_stream = nullptr;   // stream: the one in use (own_stream unless kb_engine_use_stream gave another)
   bool loaded = false;
+  bool tainted = false;   // an evict action failed after it had touched device / host state: kb_run_* answer KB_E_STATE until kb_session_load / kb_session_reset
   HostSession hs;
   KbDev dev{};
   kb_stats stats{};
@@ -154,6 +155,9 @@ struct kb_engine {
   uint32_t total_mask = 0;
   // round buffers
   DevBuf b_desc;
+  Pinned<unsigned long long> h_listkeys;  // one complete candidate list of an evict action's preemptor shape (D2H target)
+  DevBuf b_scatter;                       // packed node records of upload_live_nodes
+  Pinned<unsigned long long> h_scatter;
   DevBuf b_sscore, b_smask, b_xslot, b_xorder;   // per-shape rows, row->shape map and rows in shape order of kb_eval_matrix / kb_bench_matrix
   std::vector<uint32_t> h_xorder;
   size_t xs_cap = 0, xslot_cap = 0;
@@ -1223,6 +1227,7 @@ int kb_session_load(kb_engine *e, const kb_snapshot *sn) {
     run_finalize(e);
     e->stats.reduce_ms = 0;
     e->loaded = true;
+    e->tainted = false;
   });
 }
 
@@ -1230,6 +1235,7 @@ int kb_session_reset(kb_engine *e) {
   if (!e) return KB_E_INVALID;
   return guarded(e, [&]() {
     if (!e->loaded) throw EngineError(KB_E_STATE, "no session loaded");
+    e->tainted = false;
     hipStream_t s = e->stream;
     auto restore = [&](DevBuf &dst, const DevBuf &src) { HIP_OK(hipMemcpyAsync(dst.p, src.p, src.bytes, hipMemcpyDeviceToDevice, s)); };
     restore(e->b_idle, e->p_idle); restore(e->b_rel, e->p_rel); restore(e->b_nzc, e->p_nzc); restore(e->b_nzm, e->p_nzm);
@@ -1255,6 +1261,7 @@ static int run_action(kb_engine *e, uint32_t action, kb_decision *out, uint64_t 
   if (!e) return KB_E_INVALID;
   return guarded(e, [&]() {
     if (!e->loaded) throw EngineError(KB_E_STATE, "kb_session_load must precede kb_run_*");
+    if (e->tainted) throw EngineError(KB_E_STATE, "a preempt / reclaim call failed after touching the session's state: kb_session_load or kb_session_reset first");
     // A Pending task that still carries a NodeName was un-pipelined by a discarded preempt statement (NodeInfo.RemoveTask never
     // clears it, api/node_info.go:217-243): the reference's AddTask then refuses every other node AFTER ssn.Allocate has flipped
     // the status (session.go:243 vs :255).  Not modelled: the stock action takes such a cycle (it cannot arise under the stock
@@ -1322,25 +1329,33 @@ int kb_run_backfill(kb_engine *e, kb_decision *out, uint64_t cap, uint64_t *n_ou
 // ---- preempt (kb_preempt.hpp): statements and victims on the host, PredicateNodes + PrioritizeNodes + SortNodes on the device ----
 namespace {
 // node state of the given nodes: host mirror -> device (after Pipelines / evictions changed it)
+// One packed record per node in a persistent pinned staging vector, one copy, one scatter kernel (kb_launch_scatter_nodes) — it used
+// to be 2R + 5 tiny asynchronous copies per node out of loop-scoped stack locals (round-2 advisory: correct only because pageable
+// sources are staged at the call, and ten driver calls per dirty node on the preempt refresh path).
 void upload_live_nodes(kb_engine *e, const LiveNodes &ln, const std::vector<uint32_t> &nodes) {
+  if (nodes.empty()) return;
   const int R = e->hs.R;
-  const uint32_t NP = e->dev.NP;
+  const size_t rec = 5 + 2 * (size_t)R, words = rec * nodes.size();
+  e->h_scatter.resize(words);
+  unsigned long long *w = e->h_scatter.data();
   for (uint32_t n : nodes) {
+    const uint32_t nm = (ln.idle[n].mask & 0x3FFFFFFFu) | (ln.rel[n].mask ? 0x80000000u : 0u);
+    w[0] = (unsigned long long)n | ((unsigned long long)nm << 32);
+    w[1] = (unsigned long long)(uint32_t)ln.podcnt[n];
+    w[2] = (unsigned long long)ln.nzc[n];
+    w[3] = (unsigned long long)ln.nzm[n];
+    w[4] = e->dev.ports ? ln.ports[n] : 0ull;
     for (int d = 0; d < R; d++) {
       const double vi = ln.idle[n].get(d), vr = ln.rel[n].get(d);
-      HIP_OK(hipMemcpyAsync(e->b_idle.as<double>() + (size_t)d * NP + n, &vi, sizeof(double), hipMemcpyHostToDevice, e->stream));
-      HIP_OK(hipMemcpyAsync(e->b_rel.as<double>() + (size_t)d * NP + n, &vr, sizeof(double), hipMemcpyHostToDevice, e->stream));
+      std::memcpy(&w[5 + d], &vi, 8);
+      std::memcpy(&w[5 + R + d], &vr, 8);
     }
-    const long long c = ln.nzc[n], m = ln.nzm[n];
-    const int pc = ln.podcnt[n];
-    const uint32_t nm = (ln.idle[n].mask & 0x3FFFFFFFu) | (ln.rel[n].mask ? 0x80000000u : 0u);
-    HIP_OK(hipMemcpyAsync(e->b_nzc.as<long long>() + n, &c, sizeof(c), hipMemcpyHostToDevice, e->stream));
-    HIP_OK(hipMemcpyAsync(e->b_nzm.as<long long>() + n, &m, sizeof(m), hipMemcpyHostToDevice, e->stream));
-    HIP_OK(hipMemcpyAsync(e->b_podcnt.as<int>() + n, &pc, sizeof(pc), hipMemcpyHostToDevice, e->stream));
-    HIP_OK(hipMemcpyAsync(e->b_nmask.as<uint32_t>() + n, &nm, sizeof(nm), hipMemcpyHostToDevice, e->stream));
-    if (e->dev.ports) { const unsigned long long p = ln.ports[n]; HIP_OK(hipMemcpyAsync(e->b_ports.as<unsigned long long>() + n, &p, sizeof(p), hipMemcpyHostToDevice, e->stream)); }
+    w += rec;
   }
-  HIP_OK(hipStreamSynchronize(e->stream));   // the sources are locals
+  e->b_scatter.alloc(sizeof(unsigned long long) * words);
+  HIP_OK(hipMemcpyAsync(e->b_scatter.p, e->h_scatter.data(), sizeof(unsigned long long) * words, hipMemcpyHostToDevice, e->stream));
+  kb_launch_scatter_nodes(e->dev, e->b_scatter.as<unsigned long long>(), (uint32_t)nodes.size(), e->b_nmask.as<uint32_t>(), e->stream);
+  HIP_OK(hipStreamSynchronize(e->stream));   // the staging vector is reused by the next refresh
 }
 }  // namespace
 
@@ -1348,6 +1363,7 @@ static int run_evict_action(kb_engine *e, bool reclaim, kb_stmt_op *out, uint64_
   if (!e) return KB_E_INVALID;
   return guarded(e, [&]() {
     if (!e->loaded) throw EngineError(KB_E_STATE, "kb_session_load must precede kb_run_preempt / kb_run_reclaim");
+    if (e->tainted) throw EngineError(KB_E_STATE, "a preempt / reclaim call failed after touching the session's state: kb_session_load or kb_session_reset first");
     HostSession &hs = e->hs;
     if (hs.has_interpod)   // an eviction takes a pod OUT of the inter-pod counts (Running -> Releasing leaves api.AllocatedStatus): not modelled
       throw EngineError(KB_E_UNSUPPORTED, "preempt / reclaim in a session with inter-pod (anti)affinity terms is not modelled");
@@ -1412,8 +1428,10 @@ static int run_evict_action(kb_engine *e, bool reclaim, kb_stmt_op *out, uint64_
       kb_launch_matrix(e->dev, r, e->stream);
       kb_launch_affinity(e->dev, r, e->stream);   // NodeAffinity priority over the row's feasible set (no-op without such terms)
       kb_launch_argmax(e->dev, r, e->stream);
-      std::vector<unsigned long long> raw((size_t)N + 1);
-      HIP_OK(hipMemcpyAsync(raw.data(), e->b_keys.p, sizeof(unsigned long long) * raw.size(), hipMemcpyDeviceToHost, e->stream));
+      e->h_listkeys.resize((size_t)N + 1);   // pinned, persistent: the copy is a DMA into place instead of a staged pageable copy into a fresh vector
+      const size_t raw_n = (size_t)N + 1;
+      const unsigned long long *raw = e->h_listkeys.data();
+      HIP_OK(hipMemcpyAsync(e->h_listkeys.data(), e->b_keys.p, sizeof(unsigned long long) * raw_n, hipMemcpyDeviceToHost, e->stream));
       HIP_OK(hipStreamSynchronize(e->stream));
       HIP_OK(hipGetLastError());
       e->stats.matrix_launches += 1;
@@ -1421,10 +1439,11 @@ static int run_evict_action(kb_engine *e, bool reclaim, kb_stmt_op *out, uint64_
       // K3 orders (score descending, node ASCENDING); SortNodes breaks score ties by DESCENDING host name: reverse every run
       keys.clear();
       size_t i = 0;
-      while (i < raw.size() && raw[i] != 0ull) {
+      keys.reserve(raw_n);
+      while (i < raw_n && raw[i] != 0ull) {
         size_t k = i;
         const uint32_t sc = KB_KEY_SCORE(raw[i]);
-        while (k < raw.size() && raw[k] != 0ull && KB_KEY_SCORE(raw[k]) == sc) k++;
+        while (k < raw_n && raw[k] != 0ull && KB_KEY_SCORE(raw[k]) == sc) k++;
         for (size_t q = k; q-- > i;) keys.push_back(((uint64_t)sc << 32) | KB_KEY_NODE(raw[q]));
         i = k;
       }
@@ -1433,6 +1452,10 @@ static int run_evict_action(kb_engine *e, bool reclaim, kb_stmt_op *out, uint64_
     std::vector<uint8_t> status = hs.t_status;
     std::vector<uint32_t> tnode = hs.t_node;
     pm.init(&hs, &e->pol, &ln, &status, &tnode, lists, refresh);
+    // from here on a failure leaves state behind (a mid-action refresh may have updated nodes on the device; after the journal is out,
+    // host and device state are committed): whatever throws below, the session is marked tainted and every kb_run_* answers KB_E_STATE
+    // until kb_session_load / kb_session_reset (round-2 advisory: the cross-check at the end used to fail AFTER publishing results)
+    struct Taint { kb_engine *e; bool armed = true; ~Taint() { if (armed) e->tainted = true; } } taint{e};
     if (reclaim) pm.run_reclaim(); else pm.run();
     // ---- results: journal out, state back to the device
     if (n_out) *n_out = pm.ops.size();
@@ -1458,6 +1481,7 @@ static int run_evict_action(kb_engine *e, bool reclaim, kb_stmt_op *out, uint64_
     e->stats.tasks_popped += pm.popped;
     e->stats.evals += pm.evals;
     e->stats.total_ms += now_ms() - t_begin;
+    taint.armed = false;
   });
 }
 

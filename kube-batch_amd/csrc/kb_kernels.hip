@@ -712,6 +712,27 @@ uint32_t kb_apply_deltas(const KbDev &d, const double *s_idle, const double *s_r
   (void)hipStreamSynchronize(s);
   return h;
 }
+__global__ void __launch_bounds__(256) k_scatter_nodes(KbDev d, const unsigned long long *__restrict__ rec, uint32_t n, uint32_t *nmask) {
+  const uint32_t words = 5u + 2u * (uint32_t)d.R;
+  const uint32_t idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= n * words) return;
+  const uint32_t i = idx / words, f = idx % words;
+  const unsigned long long *r = rec + (size_t)i * words;
+  const uint32_t node = (uint32_t)r[0];
+  const unsigned long long v = r[f];
+  if (f == 0) nmask[node] = (uint32_t)(v >> 32);
+  else if (f == 1) d.podcnt[node] = (int)(uint32_t)v;
+  else if (f == 2) d.nzc[node] = (long long)v;
+  else if (f == 3) d.nzm[node] = (long long)v;
+  else if (f == 4) { if (d.ports) d.ports[node] = v; }
+  else if (f < 5u + (uint32_t)d.R) d.idle[(size_t)(f - 5u) * d.NP + node] = __longlong_as_double((long long)v);
+  else d.rel[(size_t)(f - 5u - (uint32_t)d.R) * d.NP + node] = __longlong_as_double((long long)v);
+}
+void kb_launch_scatter_nodes(const KbDev &d, const unsigned long long *rec, uint32_t n, uint32_t *nmask, void *stream) {
+  if (n == 0) return;
+  const uint32_t total = n * (5u + 2u * (uint32_t)d.R);
+  hipLaunchKernelGGL(k_scatter_nodes, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, d, rec, n, nmask);
+}
 void kb_launch_gather(const KbDev &d, const KbRound &r, void *stream) {
   if (r.n_rows == 0) return;
   hipLaunchKernelGGL(k_gather, dim3((r.n_rows + 255) / 256), dim3(256), 0, (hipStream_t)stream, d, r);

@@ -201,15 +201,24 @@ void PreemptMachine::mark_dirty(uint32_t n) {   // what the plugin predicates / 
 }
 void PreemptMachine::recompute_minprio(uint32_t n) {
   if (!prio_prunes_) return;
-  const uint32_t N = hs_->N, Q = hs_->Q;
-  for (uint32_t q = 0; q < Q; q++) qn_minprio_[(size_t)q * N + n] = INT_MAX;
+  const uint32_t Q = hs_->Q;
+  std::vector<std::pair<uint32_t, int32_t>> &v = nq_minprio_[n];
+  v.clear();
   for (uint32_t t : ntasks_[n]) {
     if (node_status[t] != KB_TASK_RUNNING) continue;
     const uint32_t j = hs_->t_job[t], q = hs_->job_queue[j];
     if (q >= Q) continue;
-    int32_t &m = qn_minprio_[(size_t)q * N + n];
-    if (hs_->job_prio[j] < m) m = hs_->job_prio[j];
+    size_t k = 0;
+    while (k < v.size() && v[k].first != q) k++;
+    if (k == v.size()) v.emplace_back(q, hs_->job_prio[j]);
+    else if (hs_->job_prio[j] < v[k].second) v[k].second = hs_->job_prio[j];
   }
+}
+// lowest job priority among node n's Running session tasks of queue q (INT_MAX: none): a node holds tasks of a handful of queues
+int32_t PreemptMachine::minprio(uint32_t q, uint32_t n) const {
+  for (const std::pair<uint32_t, int32_t> &e : nq_minprio_[n])
+    if (e.first == q) return e.second;
+  return INT_MAX;
 }
 
 // NodeInfo.RemoveTask (api/node_info.go:217-243): accounting by the status of the node's own clone
@@ -452,7 +461,7 @@ bool PreemptMachine::host_eval(uint32_t t, uint32_t n, long long &score) const {
 bool PreemptMachine::try_node(uint32_t preemptor, int mode, uint32_t n) {
   const int R = hs_->R;
   const uint32_t pj = hs_->t_job[preemptor], pq = hs_->job_queue[pj];
-  if (prio_prunes_ && mode == 0 && pq < hs_->Q && qn_minprio_[(size_t)pq * hs_->N + n] >= hs_->job_prio[pj]) return false;   // no task the priority rule would let go
+  if (prio_prunes_ && mode == 0 && pq < hs_->Q && minprio(pq, n) >= hs_->job_prio[pj]) return false;   // no task the priority rule would let go
   std::vector<uint32_t> pre, victims;
   for (uint32_t t : ntasks_[n]) {   // node.Tasks in canonical order, filtered (preempt.go:112-124 / :150-157)
     if (node_status[t] != KB_TASK_RUNNING) continue;
@@ -550,7 +559,7 @@ bool PreemptMachine::preempt_walk(uint32_t preemptor, int mode) {
     const int32_t pp = hs_->job_prio[pj];
     const std::vector<int32_t> &rank = shape_rank_[sh];
     for (uint32_t n : qnodes_[pq]) {
-      if (qn_minprio_[(size_t)pq * hs_->N + n] >= pp) continue;
+      if (minprio(pq, n) >= pp) continue;
       if (dirty_[n]) {
         long long sc;
         if (host_eval(preemptor, n, sc)) C.push_back(((uint64_t)sc << 32) | n);
@@ -624,19 +633,14 @@ void PreemptMachine::init(const HostSession *hs, const Policy *pol, LiveNodes *l
     break;
   }
   if (prio_prunes_) {
-    qn_minprio_.assign((size_t)(Q ? Q : 1) * (N ? N : 1), INT_MAX);
-    for (uint32_t n = 0; n < N; n++)   // recompute_minprio(n) without its reset pass (Q strided stores per node: the table is fresh)
-      for (uint32_t t : ntasks_[n]) {
-        if (node_status[t] != KB_TASK_RUNNING) continue;
-        const uint32_t j = hs->t_job[t], q = hs->job_queue[j];
-        if (q >= Q) continue;
-        int32_t &m = qn_minprio_[(size_t)q * N + n];
-        if (hs->job_prio[j] < m) m = hs->job_prio[j];
-      }
+    // sparse: per node the (queue, lowest priority) pairs of its Running session tasks — a dense Q x N table cost tens of MB and an
+    // O(Q N) pass per action at 1M x 50k with hundreds of queues (round-2 advisory)
+    nq_minprio_.assign(N ? N : 1, {});
     qnodes_.assign(Q ? Q : 1, {});
-    for (uint32_t q = 0; q < Q; q++)
-      for (uint32_t n = 0; n < N; n++)
-        if (qn_minprio_[(size_t)q * N + n] != INT_MAX) qnodes_[q].push_back(n);
+    for (uint32_t n = 0; n < N; n++) {
+      recompute_minprio(n);
+      for (const std::pair<uint32_t, int32_t> &e : nq_minprio_[n]) qnodes_[e.first].push_back(n);   // ascending n per queue
+    }
   }
 }
 

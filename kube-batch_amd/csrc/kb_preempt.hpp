@@ -78,7 +78,7 @@ class PreemptMachine {
   std::vector<uint32_t> dirty_nodes_;
   std::vector<uint8_t> touched_;
   // pruning index: per (queue, node) the lowest job priority among the node's Running session tasks of that queue
-  std::vector<int32_t> qn_minprio_;
+  std::vector<std::vector<std::pair<uint32_t, int32_t>>> nq_minprio_;   // [node] -> (queue, lowest priority), sparse
   bool prio_prunes_ = false;
   std::vector<std::vector<uint32_t>> qnodes_;        // per queue: nodes that hold a Running session task of the queue (superset, fixed)
   // every Evict / Pipeline and their undo bumps version_; the last preemptor that found nothing, as of which version
@@ -103,6 +103,7 @@ class PreemptMachine {
   void touch_node(uint32_t n);
   void mark_dirty(uint32_t n);
   void recompute_minprio(uint32_t n);
+  int32_t minprio(uint32_t q, uint32_t n) const;
   void evict(uint32_t t);
   void unevict(uint32_t t);
   void pipeline(uint32_t t, uint32_t n);

@@ -446,6 +446,25 @@ void kb_launch_expand(const KbDev &d, const uint16_t *s_score, const uint32_t *s
   });
 }
 
+void kb_launch_scatter_nodes(const KbDev &d, const unsigned long long *rec, uint32_t n, uint32_t *nmask, void *stream) {
+  kbemu_enqueue((hipStream_t)stream, [d, rec, n, nmask]() {
+  const size_t words = 5 + 2 * (size_t)d.R;
+  for (uint32_t i = 0; i < n; i++) {
+    const unsigned long long *r = rec + (size_t)i * words;
+    const uint32_t node = (uint32_t)r[0];
+    nmask[node] = (uint32_t)(r[0] >> 32);
+    d.podcnt[node] = (int)(uint32_t)r[1];
+    d.nzc[node] = (long long)r[2];
+    d.nzm[node] = (long long)r[3];
+    if (d.ports) d.ports[node] = r[4];
+    for (int dd = 0; dd < d.R; dd++) {
+      std::memcpy(&d.idle[(size_t)dd * d.NP + node], &r[5 + dd], 8);
+      std::memcpy(&d.rel[(size_t)dd * d.NP + node], &r[5 + d.R + dd], 8);
+    }
+  }
+  });
+}
+
 void kb_launch_commit(const KbDev &d, const KbRound &r, void *stream) { kbemu_enqueue((hipStream_t)stream, [d, r]() { emu_commit(d, r, false); }); }
 void kb_launch_commit_batch(const KbDev &d, const KbRound &r, void *stream) { kbemu_enqueue((hipStream_t)stream, [d, r]() { emu_commit(d, r, true); }); }
 

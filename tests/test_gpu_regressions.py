@@ -199,8 +199,15 @@ def test_journal_capacity_contract(oracle_mod):
         small = (abi.StmtOp * 2)()
         assert e.L.kb_run_preempt(e.h, small, 2, C.byref(n)) == abi.KB_E_CAPACITY
         assert n.value == len(want)
-        assert len(e.evictions()) == 0                                  # no result was applied
-        e.load(snap)
+        assert len(e.evictions()) == 0                                  # no result was applied (the getters keep working)
+        # ... but a mid-action refresh may have updated nodes on the device: every kb_run_* refuses until the session is loaded or reset
+        with pytest.raises(engine.EngineError) as err:
+            e.run_allocate()
+        assert err.value.code == abi.KB_E_STATE
+        if done % 2:
+            e.reset()
+        else:
+            e.load(snap)
         exact = (abi.StmtOp * n.value)()
         n2 = C.c_uint64()
         assert e.L.kb_run_preempt(e.h, exact, n.value, C.byref(n2)) == abi.KB_OK and n2.value == n.value
