@@ -218,6 +218,7 @@ __device__ __forceinline__ void k5_field_ptrs(const KbDev &d, uint32_t fld, cons
 #define K7_D 160u   // row descriptors staged per refill (five 32-row batches: four of them find their successor staged and can pre-walk it)
 #define K7_PWIN_BYTES 32768u   // LDS for the per-shape candidate windows of a round
 #define K7_KQ 5    // 64 * K7_KQ >= KB_K5_MAX_ROWS + K7_B dirty slots: the row-at-a-time mode keeps one key per slot in registers
+#define K7_LA_INVALID 0xFFFFFFFFFFFFFFFFull   // look-ahead key: not available (the placement would be a Pipeline, or the slot's state moved on)
 
 static_assert(64 * K7_KQ >= KB_K5_MAX_ROWS + K7_B, "row mode keeps one key per dirty slot in registers");
 struct K7Hdr {
@@ -256,6 +257,10 @@ struct K7Mem {
   uint32_t *dc_nd, *dc_log;             // [cap]
   uint32_t *dlog;                       // [cap] slots changed by dirty rows, in order
   unsigned long long *keyq;             // [cap2] keys of one shape against every dirty slot (row-at-a-time mode)
+  unsigned long long *keyq1, *keyq2;    // [cap2] the same after one / two MORE placements of the run's shape on the slot (K7_LA_INVALID: that
+                                        //        placement would be a Pipeline): a dirty winner's new key without an evaluation in the serial loop
+  uint32_t *wcnt;                       // [cap2] placements deferred on the slot (0, 1 or 2): the look-ahead level its next win reads
+  uint32_t *wlist;                      // [64] slots that carry deferred placements, in the order of their first win
   unsigned long long *ptab;             // [cap2] host-port bits of the slot's node (sessions with host ports only)
   uint32_t *bitmap;                     // [NP/32]
   double *save;                         // [K7_B][R-2] scalar-dimension values overwritten by speculative commits
@@ -272,7 +277,7 @@ struct K7Mem {
 __host__ __device__ inline size_t k7_smem_bytes(uint32_t cap, uint32_t NP, int R) {
   size_t cap2 = (size_t)cap + K7_B;
   return cap2 * (K5_NF8 * 8 + 8 + 8 + 3 * 4) + (size_t)cap * (8 + 8 + 12) + (size_t)(NP / 32) * 4 + (size_t)K7_B * (R > 2 ? R - 2 : 0) * 8 + sizeof(K7Hdr) + 64 +
-         K7_PWIN_BYTES + (size_t)cap * 4;
+         K7_PWIN_BYTES + (size_t)cap * 4 + cap2 * 20 + 64 * 4 + 16;
 }
 
 // The walk: rows [ja, jb) of a batch (descriptors bd) take, in row order, successive clean entries of their shape's persistent candidate
@@ -461,6 +466,12 @@ __global__ void __launch_bounds__(KB_K5_THREADS) k_commit_batch(const K7KernArgs
     off2 = (off2 + 15) & ~(size_t)15;
     M.pwin = reinterpret_cast<unsigned long long *>(k5_smem + off2);
     M.pbase = reinterpret_cast<uint32_t *>(k5_smem + off2 + K7_PWIN_BYTES);
+    size_t off3 = off2 + K7_PWIN_BYTES + (size_t)cap * 4;
+    off3 = (off3 + 15) & ~(size_t)15;
+    M.keyq1 = reinterpret_cast<unsigned long long *>(k5_smem + off3);
+    M.keyq2 = M.keyq1 + cap2;
+    M.wcnt = reinterpret_cast<uint32_t *>(M.keyq2 + cap2);
+    M.wlist = M.wcnt + cap2;
   }
   const uint32_t WL = a.n_mrows <= K7_PWIN_BYTES / (64u * 8u) ? 64u : (a.n_mrows <= K7_PWIN_BYTES / (32u * 8u) ? 32u : 16u);   // n_mrows <= KB_K5_MAX_SHAPES = 256
   M.WL = WL;
@@ -474,7 +485,7 @@ __global__ void __launch_bounds__(KB_K5_THREADS) k_commit_batch(const K7KernArgs
     const uint32_t sh = w / WL, en = w % WL;
     M.pwin[w] = (en < a.L) ? a.keys[(size_t)sh * a.L + en] : 0ull;
   }
-  if (tid == 0) { H.reason = KB_REASON_DONE; H.exhausted = 0; H.n_batches = 0; H.n_dirty_rows = 0; H.n_refills = 0; H.p = 0; H.dirty_row = 0; H.pad = 0; H.nlog = 0; H.n_full = 0; H.pad2 = 0; H.pad3 = 0; H.kstar = 0ull; H.n_seq_rows = 0; H.n_prewalks = 0; H.n_prewalks_used = 0; }
+  if (tid == 0) { H.reason = KB_REASON_DONE; H.exhausted = 0; H.n_batches = 0; H.n_dirty_rows = 0; H.n_refills = 0; H.p = 0; H.dirty_row = 0; H.pad = 0; H.nlog = 0; H.n_full = 0; H.pad2 = 0; H.pad3 = 0; H.kstar = 0ull; H.n_seq_rows = 0; H.n_prewalks = 0; H.n_prewalks_used = 0; H.pad5 = 0; H.pad6 = 0; }
   // per-thread source array of the fetch step: thread (row*16 + f) reads field f of the row's node
   // (pointers read from the KbDev copy are generic; the fetch step wants global_load, not flat_load)
   typedef const unsigned long long __attribute__((address_space(1))) *gptr8;
@@ -617,7 +628,7 @@ __global__ void __launch_bounds__(KB_K5_THREADS) k_commit_batch(const K7KernArgs
     // can the NEXT batch be pre-walked?  (uniform: every thread computes it)  Its rows must be staged already, and rows whose score is
     // renormalised over the feasible set stop a batch in front of them (has_aff): those sessions keep the plain protocol
     const uint32_t nb2 = min(min(2u * a.batch, K7_B), a.n_rows - (i0 + nb));
-    const bool pw = a.prewalk && nb2 > 0 && !a.has_aff && (i0 + nb + nb2 <= dbase + dcnt);
+    const bool pw = (a.prewalk & 1u) && nb2 > 0 && !a.has_aff && (i0 + nb + nb2 <= dbase + dcnt);
     const KbRowDesc *bdn = bd + nb;
     const uint32_t pw_half = nb2 / 2u;
     pw_slid = 0; pw_exh = 0; pw_ref = 0;
@@ -796,14 +807,41 @@ __global__ void __launch_bounds__(KB_K5_THREADS) k_commit_batch(const K7KernArgs
       // apply steps already prepared for that candidate (same shape => same post-commit state) with the key the evaluate step
       // already computed (kb).
       const uint32_t q = H.q_of[p];
+      // Look-ahead (round 3): a dirty winner used to cost wave 0 an AddTask and a whole evaluation on ONE lane (1.14 us, the largest single
+      // item of the cycle: profiles/round3).  The all-thread pass below now also evaluates every slot — the batch's own prepared slots
+      // included — after ONE and after TWO more placements of the run's shape (Allocate each; K7_LA_INVALID where the node would no longer
+      // fit InitResreq, i.e. a Pipeline), so that the serial loop takes a winner's next key from a register and defers the AddTask on
+      // the slot's LDS state to a lane-parallel flush.  Plain rows only (Resreq == InitResreq, no scalar dimensions, allocate, single GPU);
+      // everything else, and a third win in a row on one slot, takes the evaluation on one lane as before (after a flush).
+      const bool la_ok = (a.prewalk & 2u) && !a.backfill && !a.has_delta && (bd[p].flags & 1u) && bd[p].resmask == 0u && (bd[p].active >> 2) == 0u;
       {
         const KbRowDesc &k = bd[p];
         const TaskValsD tv = k7_task_vals(a, k);
-        for (uint32_t x = tid; x < nd + p; x += KB_K5_THREADS) {
-          const NodeValsD nv = k5_slot_vals(M.tab, M.t_cls, M.t_left, cap2, x, a.has_ports ? M.ptab : nullptr);
-          const uint32_t node = M.t_node[x];
-          const uint32_t res = eval_pair_k5(a, tv, nv, node, a.use_crow ? &k.crow : nullptr);
-          M.keyq[x] = res ? KB_KEY(res & 0xFFFFu, node) : 0ull;
+        const unsigned long long want = (a.has_ports && la_ok) ? a.dev->t_want[k.task] : 0ull;
+        const uint32_t x_end = la_ok ? nd + nb : nd + p;
+        for (uint32_t x = tid; x < x_end; x += KB_K5_THREADS) {
+          unsigned long long k0 = 0ull, k1 = K7_LA_INVALID, k2 = K7_LA_INVALID;
+          if (x < nd || Hc[x - nd] != 0ull) {
+            NodeValsD nv = k5_slot_vals(M.tab, M.t_cls, M.t_left, cap2, x, a.has_ports ? M.ptab : nullptr);
+            const uint32_t node = M.t_node[x];
+            const uint32_t res = eval_pair_k5(a, tv, nv, node, a.use_crow ? &k.crow : nullptr);
+            k0 = res ? KB_KEY(res & 0xFFFFu, node) : 0ull;
+            if (la_ok) {
+              int left = M.t_left[x];
+              if (le_eps(k.init0, nv.idle0, EPS_CPU) && le_eps(k.init1, nv.idle1, EPS_MEM)) {   // allocate.go:160: Allocate
+                nv.idle0 -= k.init0; nv.idle1 -= k.init1; nv.nzc += tv.nzc; nv.nzm += tv.nzm; nv.ports |= want; left -= 1; nv.slots = left > 0;
+                const uint32_t r1 = eval_pair_k5(a, tv, nv, node, a.use_crow ? &k.crow : nullptr);
+                k1 = r1 ? KB_KEY(r1 & 0xFFFFu, node) : 0ull;
+                if (le_eps(k.init0, nv.idle0, EPS_CPU) && le_eps(k.init1, nv.idle1, EPS_MEM)) {
+                  nv.idle0 -= k.init0; nv.idle1 -= k.init1; nv.nzc += tv.nzc; nv.nzm += tv.nzm; left -= 1; nv.slots = left > 0;
+                  const uint32_t r2 = eval_pair_k5(a, tv, nv, node, a.use_crow ? &k.crow : nullptr);
+                  k2 = r2 ? KB_KEY(r2 & 0xFFFFu, node) : 0ull;
+                }
+              }
+            }
+          }
+          M.keyq[x] = k0;
+          if (la_ok) { M.keyq1[x] = k1; M.keyq2[x] = k2; M.wcnt[x] = 0u; }
         }
       }
       __syncthreads();
@@ -820,6 +858,38 @@ __global__ void __launch_bounds__(KB_K5_THREADS) k_commit_batch(const K7KernArgs
         unsigned long long kq[K7_KQ];
 #pragma unroll
         for (int u = 0; u < K7_KQ; u++) { const uint32_t x = lane + 64u * (uint32_t)u; kq[u] = (x < ndc) ? M.keyq[x] : 0ull; }
+        // look-ahead: keyq1 / keyq2 / wcnt stay in LDS (keeping them per lane in registers spilled the kernel to scratch); a dirty winner costs
+        // three independent LDS reads on one lane.  npend (uniform): slots in wlist that carry deferred placements
+        uint32_t npend = 0;
+        const TaskValsD tvr = k7_task_vals(a, bd[p]);
+        const unsigned long long wantr = (a.has_ports && la_ok) ? a.dev->t_want[bd[p].task] : 0ull;
+        // apply the deferred placements to the slots' LDS state (one lane per slot, in parallel), drop the look-ahead of those slots, and
+        // invalidate the cached dirty maxima of other shapes that sat on one of those nodes
+        auto flush = [&]() {
+          uint32_t mynode = 0xFFFFFFFFu;
+          if (lane < npend) {
+            const uint32_t x = M.wlist[lane], w = M.wcnt[x];
+            double i0v = u2d(M.tab[(size_t)K5F_IDLE0 * cap2 + x]), i1v = u2d(M.tab[(size_t)K5F_IDLE1 * cap2 + x]);
+            double zc = u2d(M.tab[(size_t)K5F_NZC * cap2 + x]), zm = u2d(M.tab[(size_t)K5F_NZM * cap2 + x]);
+            for (uint32_t i = 0; i < w; i++) { i0v -= tvr.init0; i1v -= tvr.init1; zc += tvr.nzc; zm += tvr.nzm; }   // NodeInfo.AddTask, one task at a time
+            M.tab[(size_t)K5F_IDLE0 * cap2 + x] = d2u(i0v); M.tab[(size_t)K5F_IDLE1 * cap2 + x] = d2u(i1v);
+            M.tab[(size_t)K5F_NZC * cap2 + x] = d2u(zc); M.tab[(size_t)K5F_NZM * cap2 + x] = d2u(zm);
+            M.t_left[x] -= (int)w;
+            if (a.has_ports) M.ptab[x] |= wantr;
+            M.wcnt[x] = 0u; M.keyq1[x] = K7_LA_INVALID; M.keyq2[x] = K7_LA_INVALID;
+            mynode = M.t_node[x];
+          }
+          for (uint32_t sh = lane; sh < a.n_mrows; sh += 64) {
+            const unsigned long long ck = M.dc_key[sh];
+            const uint32_t cn = ck != 0ull ? KB_KEY_NODE(ck) : 0xFFFFFFFEu;
+            bool hit = false;
+            for (uint32_t i = 0; i < npend; i++) hit = hit || ((uint32_t)__builtin_amdgcn_readlane((int)mynode, (int)i) == cn);
+            if (hit) M.dc_nd[sh] = 0xFFFFFFFFu;
+          }
+          __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+          npend = 0;
+        };
         // what the rows of the run need to know about the batch's prepared candidates, one per lane, read back with readlane
         const bool inb = lane < nb;
         unsigned long long myc = inb ? Hc[lane] : 0ull, mykb = inb ? H.kb[lane][q] : 0ull;
@@ -858,8 +928,48 @@ __global__ void __launch_bounds__(KB_K5_THREADS) k_commit_batch(const K7KernArgs
 #pragma unroll
             for (int u = 1; u < K7_KQ; u++) if (kq[u] > kmax) { kmax = kq[u]; xmax = lane + 64u * (uint32_t)u; }
             const unsigned long long own = __ballot(kmax == best);
-            const uint32_t xs = (uint32_t)__builtin_amdgcn_readlane((int)xmax, __ffsll((unsigned long long)own) - 1);
+            const uint32_t ow = (uint32_t)__ffsll((unsigned long long)own) - 1u;
+            const uint32_t xs = (uint32_t)__builtin_amdgcn_readlane((int)xmax, (int)ow);
             const uint32_t n = KB_KEY_NODE(best);
+            if (la_ok && ((plainmask >> r) & 1ull)) {
+              // the winner's key after this placement, from the look-ahead: level = placements already deferred on the slot
+              unsigned long long nk = K7_LA_INVALID;
+              uint32_t lvl = 0;
+              if (lane == 0) {
+                lvl = M.wcnt[xs];
+                const unsigned long long c1 = M.keyq1[xs], c2 = M.keyq2[xs];
+                nk = lvl == 0u ? c1 : (lvl == 1u ? c2 : K7_LA_INVALID);
+              }
+              nk = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(nk >> 32)) << 32) |
+                   (uint32_t)__builtin_amdgcn_readfirstlane((int)(nk & 0xFFFFFFFFull));
+              lvl = (uint32_t)__builtin_amdgcn_readfirstlane((int)lvl);
+              if (nk != K7_LA_INVALID) {
+                if (lane == r - p) { dec_n = n; dec_k = 0u; dec_f = 1u; }
+                if (lane == 0) {
+                  M.wcnt[xs] = lvl + 1u;
+                  if (lvl == 0u) M.wlist[npend] = xs;
+                  M.dlog[nlog] = xs;
+                }
+                if (lvl == 0u) npend++;
+                if (lane == ow) {
+#pragma unroll
+                  for (int u = 0; u < K7_KQ; u++) if ((xs >> 6) == (uint32_t)u) kq[u] = nk;
+                }
+                {
+                  unsigned long long km2 = kq[0];
+#pragma unroll
+                  for (int u = 1; u < K7_KQ; u++) if (kq[u] > km2) km2 = kq[u];
+                  best = wave_max_key(km2);
+                }
+                nlog++;
+                r++;
+#ifdef KB_K7_TRACE
+                if (tid == 0) tacc[11] += (uint32_t)(wall_clock64() - tr0);
+#endif
+                continue;
+              }
+            }
+            if (npend) flush();   // the evaluation below reads the slot's LDS state
             // shapes whose cached dirty max sits on the node that changes lose their cache (once per node of a chain)
             if (n != last_n) {
               for (uint32_t sh = lane; sh < a.n_mrows; sh += 64) {
@@ -911,6 +1021,7 @@ __global__ void __launch_bounds__(KB_K5_THREADS) k_commit_batch(const K7KernArgs
               const uint32_t res = eval_pair_k5(a, tv, nv, n, a.use_crow ? &k.crow : nullptr);
               nkey = res ? KB_KEY(res & 0xFFFFu, n) : 0ull;
             }
+            if (lane == 0 && la_ok) { M.keyq1[xs] = K7_LA_INVALID; M.keyq2[xs] = K7_LA_INVALID; }   // the slot's state moved on: its look-ahead is stale
             kind = (uint32_t)__builtin_amdgcn_readfirstlane((int)kind);
             nkey = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(nkey >> 32)) << 32) |
                    (uint32_t)__builtin_amdgcn_readfirstlane((int)(nkey & 0xFFFFFFFFull));
@@ -951,6 +1062,7 @@ __global__ void __launch_bounds__(KB_K5_THREADS) k_commit_batch(const K7KernArgs
             if (kind) { rsn = KB_REASON_PIPELINED; break; }
           }
         }
+        if (npend) flush();
         // the clean winners of the run: their cursor and their decision records
         const uint32_t last_idx = (uint32_t)__builtin_amdgcn_readlane((int)myidx, (int)(pc > pc0 ? pc - 1u : 0u));
         if (pc > pc0 && lane == 0) atomicMax(&M.cursor[shape], last_idx + 1u);
@@ -1118,13 +1230,13 @@ void kb_launch_commit_batch(const KbDev &d, const KbRound &r, void *stream) {
   if (r.n_rows == 0) return;
   static bool attr_set = false;
   static uint32_t env_batch = 0;
-  static bool env_prewalk = true;
+  static uint32_t env_prewalk = 3u;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_commit_batch), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     const char *b = getenv("KB_K5_BATCH");   // tuning override of kb_config.commit_batch
     env_batch = b ? (uint32_t)atoi(b) : 0;
-    const char *pwe = getenv("KB_K7_PREWALK");   // A/B switch
-    env_prewalk = !(pwe && pwe[0] == '0');
+    const char *pwe = getenv("KB_K7_PREWALK"), *lae = getenv("KB_K7_LOOKAHEAD");   // A/B switches
+    env_prewalk = ((pwe && pwe[0] == '0') ? 0u : 1u) | ((lae && lae[0] == '0') ? 0u : 2u);
     attr_set = true;
   }
   uint32_t batch = env_batch ? env_batch : (r.batch ? r.batch : K7_B_DEFAULT);
@@ -1146,7 +1258,7 @@ void kb_launch_commit_batch(const KbDev &d, const KbRound &r, void *stream) {
   a.R = d.R;
   a.batch = batch;
   a.T = d.T; a.node_bits = 0;
-  a.prewalk = env_prewalk ? 1u : 0u;
+  a.prewalk = env_prewalk;
   a.host_out = r.host_out;
   a.seq = r.seq;
   hipLaunchKernelGGL(k_commit_batch, dim3(1), dim3(KB_K5_THREADS), sh, (hipStream_t)stream, ka);

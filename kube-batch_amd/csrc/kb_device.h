@@ -163,7 +163,8 @@ struct KbCommitArgs {
   unsigned long long *host_out;   // pinned host mirror of the output block (fast rounds), or nullptr
   unsigned long long seq;         // sequence number published last into host_out[KB_OUT_SEQ]
   uint32_t node_bits;             // width of the node field of the commit kernel's 32-bit keys (kb_node_bits)
-  uint32_t prewalk;               // batch kernel: wave 0 walks batch b + 1 while the workgroup fetches / evaluates batch b (KB_K7_PREWALK=0: off)
+  uint32_t prewalk;               // batch kernel: bit 0: wave 0 walks batch b + 1 while the workgroup fetches / evaluates batch b (KB_K7_PREWALK=0: off);
+                                  //               bit 1: look-ahead keys for dirty winners in row mode (KB_K7_LOOKAHEAD=0: off)
 };
 
 // 32-bit keys of the commit kernel: (score + 1) << node_bits | (2^node_bits - 1 - node); needs (max score + 2) << node_bits <= 2^32
