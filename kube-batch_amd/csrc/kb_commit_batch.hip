@@ -218,6 +218,7 @@ __device__ __forceinline__ void k5_field_ptrs(const KbDev &d, uint32_t fld, cons
 #define K7_D 160u   // row descriptors staged per refill (five 32-row batches: four of them find their successor staged and can pre-walk it)
 #define K7_PWIN_BYTES 32768u   // LDS for the per-shape candidate windows of a round
 #define K7_KQ 5    // 64 * K7_KQ >= KB_K5_MAX_ROWS + K7_B dirty slots: the row-at-a-time mode keeps one key per slot in registers
+#define K7_CH 16u   // depth of the on-demand chain table
 #define K7_LA_INVALID 0xFFFFFFFFFFFFFFFFull   // look-ahead key: not available (the placement would be a Pipeline, or the slot's state moved on)
 
 static_assert(64 * K7_KQ >= KB_K5_MAX_ROWS + K7_B, "row mode keeps one key per dirty slot in registers");
@@ -261,6 +262,7 @@ struct K7Mem {
                                         //        placement would be a Pipeline): a dirty winner's new key without an evaluation in the serial loop
   uint32_t *wcnt;                       // [cap2] placements deferred on the slot (0, 1 or 2): the look-ahead level its next win reads
   uint32_t *wlist;                      // [64] slots that carry deferred placements, in the order of their first win
+  unsigned long long *chain;            // [K7_CH] one slot's keys after 1 .. K7_CH more placements, built on demand when its look-ahead runs out
   unsigned long long *ptab;             // [cap2] host-port bits of the slot's node (sessions with host ports only)
   uint32_t *bitmap;                     // [NP/32]
   double *save;                         // [K7_B][R-2] scalar-dimension values overwritten by speculative commits
@@ -277,7 +279,7 @@ struct K7Mem {
 __host__ __device__ inline size_t k7_smem_bytes(uint32_t cap, uint32_t NP, int R) {
   size_t cap2 = (size_t)cap + K7_B;
   return cap2 * (K5_NF8 * 8 + 8 + 8 + 3 * 4) + (size_t)cap * (8 + 8 + 12) + (size_t)(NP / 32) * 4 + (size_t)K7_B * (R > 2 ? R - 2 : 0) * 8 + sizeof(K7Hdr) + 64 +
-         K7_PWIN_BYTES + (size_t)cap * 4 + cap2 * 20 + 64 * 4 + 16;
+         K7_PWIN_BYTES + (size_t)cap * 4 + cap2 * 20 + 64 * 4 + 16 + K7_CH * 8;
 }
 
 // The walk: rows [ja, jb) of a batch (descriptors bd) take, in row order, successive clean entries of their shape's persistent candidate
@@ -472,6 +474,7 @@ __global__ void __launch_bounds__(KB_K5_THREADS) k_commit_batch(const K7KernArgs
     M.keyq2 = M.keyq1 + cap2;
     M.wcnt = reinterpret_cast<uint32_t *>(M.keyq2 + cap2);
     M.wlist = M.wcnt + cap2;
+    M.chain = reinterpret_cast<unsigned long long *>(k5_smem + ((off3 + (size_t)cap2 * 20 + 64 * 4 + 15) & ~(size_t)15));
   }
   const uint32_t WL = a.n_mrows <= K7_PWIN_BYTES / (64u * 8u) ? 64u : (a.n_mrows <= K7_PWIN_BYTES / (32u * 8u) ? 32u : 16u);   // n_mrows <= KB_K5_MAX_SHAPES = 256
   M.WL = WL;
@@ -860,14 +863,16 @@ __global__ void __launch_bounds__(KB_K5_THREADS) k_commit_batch(const K7KernArgs
         for (int u = 0; u < K7_KQ; u++) { const uint32_t x = lane + 64u * (uint32_t)u; kq[u] = (x < ndc) ? M.keyq[x] : 0ull; }
         // look-ahead: keyq1 / keyq2 / wcnt stay in LDS (keeping them per lane in registers spilled the kernel to scratch); a dirty winner costs
         // three independent LDS reads on one lane.  npend (uniform): slots in wlist that carry deferred placements
-        uint32_t npend = 0;
-        const TaskValsD tvr = k7_task_vals(a, bd[p]);
-        const unsigned long long wantr = (a.has_ports && la_ok) ? a.dev->t_want[bd[p].task] : 0ull;
+        uint32_t npend = 0, chain_slot = 0xFFFFFFFFu;
+        // (the run's task values are re-read from the staged descriptor inside the two helpers: held across the serial loop they pushed
+        // the kernel over its 128-VGPR budget and into scratch)
         // apply the deferred placements to the slots' LDS state (one lane per slot, in parallel), drop the look-ahead of those slots, and
         // invalidate the cached dirty maxima of other shapes that sat on one of those nodes
         auto flush = [&]() {
           uint32_t mynode = 0xFFFFFFFFu;
           if (lane < npend) {
+            const TaskValsD tvr = k7_task_vals(a, bd[p]);
+            const unsigned long long wantr = a.has_ports ? a.dev->t_want[bd[p].task] : 0ull;
             const uint32_t x = M.wlist[lane], w = M.wcnt[x];
             double i0v = u2d(M.tab[(size_t)K5F_IDLE0 * cap2 + x]), i1v = u2d(M.tab[(size_t)K5F_IDLE1 * cap2 + x]);
             double zc = u2d(M.tab[(size_t)K5F_NZC * cap2 + x]), zm = u2d(M.tab[(size_t)K5F_NZM * cap2 + x]);
@@ -889,6 +894,29 @@ __global__ void __launch_bounds__(KB_K5_THREADS) k_commit_batch(const K7KernArgs
           __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
           __builtin_amdgcn_wave_barrier();
           npend = 0;
+          chain_slot = 0xFFFFFFFFu;
+        };
+        // a slot whose look-ahead has run out (a big node that keeps winning): lane t evaluates it after t + 1 more placements of the
+        // run's shape, one at a time (NodeInfo.AddTask's own subtractions, Allocate only), in ONE pass — the next K7_CH wins on that
+        // slot read their key from this table.  Called right after a flush: the slot's LDS state is current.
+        auto chain_build = [&](uint32_t xs) {
+          const TaskValsD tvr = k7_task_vals(a, bd[p]);
+          const unsigned long long wantr = a.has_ports ? a.dev->t_want[bd[p].task] : 0ull;
+          NodeValsD nv = k5_slot_vals(M.tab, M.t_cls, M.t_left, cap2, xs, a.has_ports ? M.ptab : nullptr);
+          int left = M.t_left[xs];
+          bool valid = true;
+          const uint32_t steps = min(lane, K7_CH - 1u) + 1u;
+          for (uint32_t st = 0; st < steps; st++) {
+            valid = valid && le_eps(tvr.init0, nv.idle0, EPS_CPU) && le_eps(tvr.init1, nv.idle1, EPS_MEM);   // allocate.go:160
+            nv.idle0 -= tvr.init0; nv.idle1 -= tvr.init1; nv.nzc += tvr.nzc; nv.nzm += tvr.nzm; left -= 1;
+          }
+          nv.ports |= wantr; nv.slots = left > 0;
+          const uint32_t node = M.t_node[xs];
+          const uint32_t res = eval_pair_k5(a, tvr, nv, node, a.use_crow ? &bd[p].crow : nullptr);
+          if (lane < K7_CH) M.chain[lane] = valid ? (res ? KB_KEY(res & 0xFFFFu, node) : 0ull) : K7_LA_INVALID;
+          __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+          chain_slot = xs;
         };
         // what the rows of the run need to know about the batch's prepared candidates, one per lane, read back with readlane
         const bool inb = lane < nb;
@@ -937,12 +965,20 @@ __global__ void __launch_bounds__(KB_K5_THREADS) k_commit_batch(const K7KernArgs
               uint32_t lvl = 0;
               if (lane == 0) {
                 lvl = M.wcnt[xs];
-                const unsigned long long c1 = M.keyq1[xs], c2 = M.keyq2[xs];
-                nk = lvl == 0u ? c1 : (lvl == 1u ? c2 : K7_LA_INVALID);
+                const unsigned long long c1 = M.keyq1[xs], c2 = M.keyq2[xs], cc2 = M.chain[lvl < K7_CH ? lvl : 0u];
+                nk = (xs == chain_slot) ? (lvl < K7_CH ? cc2 : K7_LA_INVALID) : (lvl == 0u ? c1 : (lvl == 1u ? c2 : K7_LA_INVALID));
               }
               nk = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(nk >> 32)) << 32) |
                    (uint32_t)__builtin_amdgcn_readfirstlane((int)(nk & 0xFFFFFFFFull));
               lvl = (uint32_t)__builtin_amdgcn_readfirstlane((int)lvl);
+              if (nk == K7_LA_INVALID && (a.prewalk & 4u)) {   // no look-ahead left for this slot (it keeps winning, or its state moved on): apply what is deferred, build its chain
+                if (npend) flush();
+                chain_build(xs);
+                lvl = 0u;
+                nk = M.chain[0];
+                nk = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(nk >> 32)) << 32) |
+                     (uint32_t)__builtin_amdgcn_readfirstlane((int)(nk & 0xFFFFFFFFull));
+              }
               if (nk != K7_LA_INVALID) {
                 if (lane == r - p) { dec_n = n; dec_k = 0u; dec_f = 1u; }
                 if (lane == 0) {
@@ -1230,13 +1266,14 @@ void kb_launch_commit_batch(const KbDev &d, const KbRound &r, void *stream) {
   if (r.n_rows == 0) return;
   static bool attr_set = false;
   static uint32_t env_batch = 0;
-  static uint32_t env_prewalk = 3u;
+  static uint32_t env_prewalk = 7u;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_commit_batch), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     const char *b = getenv("KB_K5_BATCH");   // tuning override of kb_config.commit_batch
     env_batch = b ? (uint32_t)atoi(b) : 0;
     const char *pwe = getenv("KB_K7_PREWALK"), *lae = getenv("KB_K7_LOOKAHEAD");   // A/B switches
-    env_prewalk = ((pwe && pwe[0] == '0') ? 0u : 1u) | ((lae && lae[0] == '0') ? 0u : 2u);
+    const char *che = getenv("KB_K7_CHAIN");
+    env_prewalk = ((pwe && pwe[0] == '0') ? 0u : 1u) | ((lae && lae[0] == '0') ? 0u : 2u) | ((che && che[0] == '0') ? 0u : 4u);
     attr_set = true;
   }
   uint32_t batch = env_batch ? env_batch : (r.batch ? r.batch : K7_B_DEFAULT);

@@ -164,7 +164,7 @@ struct KbCommitArgs {
   unsigned long long seq;         // sequence number published last into host_out[KB_OUT_SEQ]
   uint32_t node_bits;             // width of the node field of the commit kernel's 32-bit keys (kb_node_bits)
   uint32_t prewalk;               // batch kernel: bit 0: wave 0 walks batch b + 1 while the workgroup fetches / evaluates batch b (KB_K7_PREWALK=0: off);
-                                  //               bit 1: look-ahead keys for dirty winners in row mode (KB_K7_LOOKAHEAD=0: off)
+                                  //               bit 1: look-ahead keys for dirty winners in row mode (KB_K7_LOOKAHEAD=0: off); bit 2: on-demand chain tables (KB_K7_CHAIN=0: off)
 };
 
 // 32-bit keys of the commit kernel: (score + 1) << node_bits | (2^node_bits - 1 - node); needs (max score + 2) << node_bits <= 2^32
