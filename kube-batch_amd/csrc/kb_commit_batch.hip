@@ -14,6 +14,7 @@
 
 #include "kb_device.h"
 #include "kb_eval.hpp"
+#include "kb_warm.hpp"
 
 #define KB_K5_THREADS 1024
 
@@ -430,7 +431,7 @@ __global__ void __launch_bounds__(KB_K5_THREADS) k_commit_batch(const K7KernArgs
     a.round = (const KbRound *)(kp + offsetof(K7KernArgs, round));
   }
   if (a.round->chain_expect != 0u && *a.round->chain != a.round->chain_expect) {   // chained to a round that stopped early: skip
-    if (threadIdx.x == 0) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
       *a.round->chain = 0u;
       a.result[0] = 0; a.result[1] = KB_REASON_SKIPPED;
       if (a.host_out) {
@@ -439,6 +440,15 @@ __global__ void __launch_bounds__(KB_K5_THREADS) k_commit_batch(const K7KernArgs
         __hip_atomic_store(&a.host_out[KB_OUT_SEQ], a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
       }
     }
+    return;
+  }
+  if (blockIdx.x != 0) {   // helper workgroups (kb_warm.hpp): warm a slice of the node state into the XCD's L2 and leave
+    if ((blockIdx.x & 7u) != 0u) return;
+    const uint32_t h = blockIdx.x / 8u - 1u, lines = a.NP / 16;
+    const size_t klines = ((size_t)a.n_mrows * a.L + 15) / 16;
+    const uint32_t l0 = (uint32_t)(((unsigned long long)h * lines) / KB_WARM_HELPERS), l1 = (uint32_t)(((unsigned long long)(h + 1) * lines) / KB_WARM_HELPERS);
+    const unsigned long long acc = kb_warm_lines(*a.dev, a.keys, klines, l0, l1, threadIdx.x, KB_K5_THREADS);
+    if (acc == 0x123456789abcdefull) a.result[15] = 1;   // keep the loads alive (never true)
     return;
   }
   extern __shared__ __align__(16) unsigned char k5_smem[];
@@ -502,35 +512,11 @@ __global__ void __launch_bounds__(KB_K5_THREADS) k_commit_batch(const K7KernArgs
     g8 = (gptr8)f8;
     g4 = (gptr4)f4;
   }
-  {
-    // The loop is latency-bound and this workgroup starts on a cold L2 (kernel boundary): touch every 128-byte line of the
-    // node state arrays and of the candidate lists once, with all threads.
-    const KbDev &d = *a.dev;
-    unsigned long long acc = 0;
-    const uint32_t lines = a.NP / 16;
-    const unsigned long long *arrs[10] = {
-        reinterpret_cast<const unsigned long long *>(d.idle), reinterpret_cast<const unsigned long long *>(d.idle + d.NP),
-        reinterpret_cast<const unsigned long long *>(d.rel), reinterpret_cast<const unsigned long long *>(d.rel + d.NP),
-        reinterpret_cast<const unsigned long long *>(d.inv_acpu), reinterpret_cast<const unsigned long long *>(d.inv_amem),
-        reinterpret_cast<const unsigned long long *>(d.acpu), reinterpret_cast<const unsigned long long *>(d.amem),
-        reinterpret_cast<const unsigned long long *>(d.nzc), reinterpret_cast<const unsigned long long *>(d.nzm)};
-    const uint32_t *arr4[3] = {d.ncls, reinterpret_cast<const uint32_t *>(d.maxpods), reinterpret_cast<const uint32_t *>(d.podcnt)};
+  if (gridDim.x == 1) {
+    // no helper workgroups (KB_WARM_HELPERS_OFF=1): this workgroup warms the XCD's L2 itself, all threads, before the loop starts
     const size_t klines = ((size_t)a.n_mrows * a.L + 15) / 16;
-    for (uint32_t l0 = 0; l0 < lines; l0 += KB_K5_THREADS) {   // all loads of a pass in flight together
-      const uint32_t l = l0 + tid;
-      unsigned long long v[11];
-      uint32_t w[3];
-#pragma unroll
-      for (int f = 0; f < 10; f++) v[f] = (l < lines) ? arrs[f][(size_t)l * 16] : 0ull;
-      v[10] = (l < klines) ? a.keys[(size_t)l * 16] : 0ull;
-#pragma unroll
-      for (int f = 0; f < 3; f++) w[f] = (l < lines / 2) ? arr4[f][(size_t)l * 32] : 0u;
-#pragma unroll
-      for (int f = 0; f < 11; f++) acc += v[f];
-#pragma unroll
-      for (int f = 0; f < 3; f++) acc += w[f];
-    }
-    for (size_t l = (size_t)((lines + KB_K5_THREADS - 1) / KB_K5_THREADS) * KB_K5_THREADS + tid; l < klines; l += KB_K5_THREADS) acc += a.keys[l * 16];
+    const unsigned long long acc = kb_warm_lines(*a.dev, a.keys, klines, 0, a.NP / 16, tid, KB_K5_THREADS);
+    for (size_t l = (size_t)(a.NP / 16) + tid; l < klines; l += KB_K5_THREADS) if (a.keys[l * 16] == 0x123456789abcdefull) H.pad = 1;
     if (acc == 0x123456789abcdefull) H.pad = 1;   // keep the loads alive
   }
   __syncthreads();
@@ -1298,5 +1284,6 @@ void kb_launch_commit_batch(const KbDev &d, const KbRound &r, void *stream) {
   a.prewalk = env_prewalk;
   a.host_out = r.host_out;
   a.seq = r.seq;
-  hipLaunchKernelGGL(k_commit_batch, dim3(1), dim3(KB_K5_THREADS), sh, (hipStream_t)stream, ka);
+  static const bool helpers_off = getenv("KB_WARM_HELPERS_OFF") && getenv("KB_WARM_HELPERS_OFF")[0] == '1';   // A/B switch
+  hipLaunchKernelGGL(k_commit_batch, dim3(helpers_off ? 1u : KB_WARM_GRID), dim3(KB_K5_THREADS), sh, (hipStream_t)stream, ka);
 }
