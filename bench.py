@@ -225,7 +225,7 @@ def main():
     full_reps = 5
     full_ms = eng.bench_matrix(0, T, reps=full_reps) if world == 1 else 0.0
     if args.diverse:     # shapes > rows / 16: the engine evaluates every row directly instead of expanding shape rows (kb_engine.cpp)
-        full_label, full_kernel = f"kb_bench_matrix rows [0,{T}) x {N} nodes: direct per-row evaluation", "k_matrix"
+        full_label, full_kernel = f"kb_bench_matrix rows [0,{T}) x {N} nodes: direct per-row evaluation, runs of adjacent equal rows evaluated once", "k_matrix_runs"
     else:
         full_label, full_kernel = f"kb_bench_matrix rows [0,{T}) x {N} nodes: per-shape evaluation + row expansion", "k_matrix+k_expand"
     roofline = roof(T, full_ms, full_reps, full_label, full_kernel) if full_ms > 0 else roofline_cycle
@@ -237,9 +237,9 @@ def main():
     if world == 1 and full_ms > 0:
         abi = kbm.abi
         ms_d = eng.bench_matrix(0, T, reps=3, fit_mode=1 | abi.MATRIX_DIRECT)
-        roofline_eval = roof(T, ms_d, 3, f"kb_bench_matrix rows [0,{T}) x {N} nodes: direct per-row evaluation, adjacent equal rows re-stored", "k_matrix")
+        roofline_eval = roof(T, ms_d, 3, f"kb_bench_matrix rows [0,{T}) x {N} nodes: direct per-row evaluation, runs of adjacent equal rows evaluated once", "k_matrix_runs")
         ms_a = eng.bench_matrix(0, T, reps=2, fit_mode=1 | abi.MATRIX_DIRECT | abi.MATRIX_NO_DEDUP)
-        roofline_eval_all = roof(T, ms_a, 2, f"kb_bench_matrix rows [0,{T}) x {N} nodes: {T} x {N} evaluations, nothing shared", "k_matrix")
+        roofline_eval_all = roof(T, ms_a, 2, f"kb_bench_matrix rows [0,{T}) x {N} nodes: {T} x {N} evaluations, nothing shared", "k_matrix<4,32>")
     # HBM bytes per launch from the PMC passes of scripts/profile_round.sh (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate
     # runs; KB units; FETCH_SIZE doubled per MI355X_MICROARCH.md's gfx950 correction).  Cannot be collected inside this
     # process, so the committed summary of the same command is read back; null when it is absent or for another config.

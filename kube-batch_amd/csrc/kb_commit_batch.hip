@@ -215,7 +215,8 @@ __device__ __forceinline__ void k5_field_ptrs(const KbDev &d, uint32_t fld, cons
 // A batch costs about as much as two rows of a row-at-a-time protocol, and commits ~10 rows on the benchmark snapshot.
 // ------------------------------------------------------------------------------------------------------------
 #define K7_B 32u          // most rows one batch can speculate
-#define K7_B_DEFAULT 16u  // batch size after a batch that was cut short; doubled after a fully valid one
+#define K7_B_DEFAULT 32u  // rows speculated per batch (kb_config.commit_batch / KB_K5_BATCH override; doubled after a fully valid batch, capped at K7_B).  16 until
+                          // round 3: with the cheaper evaluation, the pre-walk and the look-ahead the sweep 8 / 12 / 16 / 24 / 32 gives C3 62.7 / 57.3 / 55.1 / 54.1 / 53.6 ms
 #define K7_D 160u   // row descriptors staged per refill (five 32-row batches: four of them find their successor staged and can pre-walk it)
 #define K7_PWIN_BYTES 32768u   // LDS for the per-shape candidate windows of a round
 #define K7_KQ 5    // 64 * K7_KQ >= KB_K5_MAX_ROWS + K7_B dirty slots: the row-at-a-time mode keeps one key per slot in registers
@@ -808,6 +809,11 @@ __global__ void __launch_bounds__(KB_K5_THREADS) k_commit_batch(const K7KernArgs
         const TaskValsD tv = k7_task_vals(a, k);
         const unsigned long long want = (a.has_ports && la_ok) ? a.dev->t_want[k.task] : 0ull;
         const uint32_t x_end = la_ok ? nd + nb : nd + p;
+        // only a slot that can still win needs a look-ahead: it wins at its current key k0 only against a clean candidate below k0, and the
+        // run's clean candidates are successive entries of one sorted list — none of them is below the candidate of the LAST batch row
+        // with the run's shape.  Most dirty slots lost long ago: their waves skip the two extra evaluations.
+        const uint32_t rm_ = H.rowmask[q];
+        const unsigned long long cmin = Hc[31u - (uint32_t)__clz((int)(rm_ | 1u))];
         for (uint32_t x = tid; x < x_end; x += KB_K5_THREADS) {
           unsigned long long k0 = 0ull, k1 = K7_LA_INVALID, k2 = K7_LA_INVALID;
           if (x < nd || Hc[x - nd] != 0ull) {
@@ -815,7 +821,7 @@ __global__ void __launch_bounds__(KB_K5_THREADS) k_commit_batch(const K7KernArgs
             const uint32_t node = M.t_node[x];
             const uint32_t res = eval_pair_k5(a, tv, nv, node, a.use_crow ? &k.crow : nullptr);
             k0 = res ? KB_KEY(res & 0xFFFFu, node) : 0ull;
-            if (la_ok) {
+            if (la_ok && k0 != 0ull && k0 >= cmin) {
               int left = M.t_left[x];
               if (le_eps(k.init0, nv.idle0, EPS_CPU) && le_eps(k.init1, nv.idle1, EPS_MEM)) {   // allocate.go:160: Allocate
                 nv.idle0 -= k.init0; nv.idle1 -= k.init1; nv.nzc += tv.nzc; nv.nzm += tv.nzm; nv.ports |= want; left -= 1; nv.slots = left > 0;
