@@ -187,6 +187,15 @@ struct kb_engine {
   std::vector<uint32_t> shape_stamp, shape_slot_of;   // per row-shape id: round stamp and slot inside the current round
   uint32_t stamp = 0;
   std::vector<Timer> ev;          // event pool for per-launch timing
+  Pinned<unsigned char> h_fin;    // pinned D2H target of run_finalize (seven results in one block, copied out after ONE synchronisation)
+  // the host mirrors of the device reduction as of kb_session_load: kb_session_reset restores them instead of reducing the restored
+  // (identical) state again
+  struct FinalMirror { std::vector<double> job_alloc, job_share, queue_alloc, queue_share; std::vector<int32_t> job_ready; std::vector<uint8_t> t_status; std::vector<uint32_t> t_node; bool valid = false; } fin0;
+  // where the host's wall time of a cycle goes outside the device rounds (KB_K5_STATS=1 prints it): reset, the action's start up to its
+  // first launch, the speculation breaks (from a stopped round's answer to the re-planned launch), the closing reduction, round waits
+  bool async_pending = false;   // kb_session_reset queued device-to-device copies on `stream` and returned without waiting: whoever touches the
+                                // buffers outside that stream (null-stream copies of the getters and of the evict actions, a stream switch) waits first
+  double tl_reset = 0, tl_begin = 0, tl_break = 0, tl_finish = 0, tl_wait = 0, tl_backfill = 0;
   std::vector<kb_decision> decisions_all;   // decisions of the last multi-GPU round sequence
   std::vector<uint32_t> evictions;          // committed evictions of the session's preempt actions, in cache.Evict order
 
@@ -255,6 +264,13 @@ Timer &get_timer(kb_engine *e, size_t i) {
   return e->ev[i];
 }
 
+// the engine's own stream is non-blocking: a null-stream hipMemcpy does not wait for what kb_session_reset left queued on it
+void quiesce(kb_engine *e) {
+  if (!e->async_pending) return;
+  HIP_OK(hipStreamSynchronize(e->stream));
+  e->async_pending = false;
+}
+
 // gang ballot + share reduction on the device, results mirrored to the host session
 void run_finalize(kb_engine *e) {
   Timer &tm = get_timer(e, 3);
@@ -265,14 +281,22 @@ void run_finalize(kb_engine *e) {
                      e->b_jready.as<int>(), e->stream);
   HIP_OK(hipEventRecord(tm.b, e->stream));
   HostSession &hs = e->hs;
-  HIP_OK(hipMemcpyAsync(hs.job_alloc.data(), e->b_jalloc.p, sizeof(double) * hs.job_alloc.size(), hipMemcpyDeviceToHost, e->stream));
-  HIP_OK(hipMemcpyAsync(hs.job_share.data(), e->b_jshare.p, sizeof(double) * hs.job_share.size(), hipMemcpyDeviceToHost, e->stream));
-  HIP_OK(hipMemcpyAsync(hs.queue_alloc.data(), e->b_qalloc.p, sizeof(double) * hs.queue_alloc.size(), hipMemcpyDeviceToHost, e->stream));
-  HIP_OK(hipMemcpyAsync(hs.queue_share.data(), e->b_qshare.p, sizeof(double) * hs.queue_share.size(), hipMemcpyDeviceToHost, e->stream));
-  HIP_OK(hipMemcpyAsync(hs.job_ready.data(), e->b_jready.p, sizeof(int32_t) * hs.job_ready.size(), hipMemcpyDeviceToHost, e->stream));
-  HIP_OK(hipMemcpyAsync(hs.t_status.data(), e->b_tstatus.p, hs.T, hipMemcpyDeviceToHost, e->stream));
-  HIP_OK(hipMemcpyAsync(hs.t_node.data(), e->b_tnode.p, sizeof(uint32_t) * hs.T, hipMemcpyDeviceToHost, e->stream));
+  // seven results, one pinned block: the copies queue behind the kernels as DMA commands (a pageable target makes every one of them a
+  // staged, blocking copy), ONE synchronisation, then plain memcpys into the host session's vectors
+  struct Part { void *dst; const void *src; size_t bytes, off; };
+  Part parts[7] = {{hs.job_alloc.data(), e->b_jalloc.p, sizeof(double) * hs.job_alloc.size(), 0}, {hs.job_share.data(), e->b_jshare.p, sizeof(double) * hs.job_share.size(), 0},
+                   {hs.queue_alloc.data(), e->b_qalloc.p, sizeof(double) * hs.queue_alloc.size(), 0}, {hs.queue_share.data(), e->b_qshare.p, sizeof(double) * hs.queue_share.size(), 0},
+                   {hs.job_ready.data(), e->b_jready.p, sizeof(int32_t) * hs.job_ready.size(), 0}, {hs.t_status.data(), e->b_tstatus.p, hs.T, 0},
+                   {hs.t_node.data(), e->b_tnode.p, sizeof(uint32_t) * hs.T, 0}};
+  size_t total = 0;
+  for (Part &pt : parts) { pt.off = total; total += (pt.bytes + 63) & ~(size_t)63; }
+  e->h_fin.resize(total ? total : 64);
+  for (const Part &pt : parts)
+    if (pt.bytes) HIP_OK(hipMemcpyAsync(e->h_fin.data() + pt.off, pt.src, pt.bytes, hipMemcpyDeviceToHost, e->stream));
   HIP_OK(hipStreamSynchronize(e->stream));
+  e->async_pending = false;
+  for (const Part &pt : parts)
+    if (pt.bytes) std::memcpy(pt.dst, e->h_fin.data() + pt.off, pt.bytes);
   float ms = 0;
   HIP_OK(hipEventElapsedTime(&ms, tm.a, tm.b));
   e->stats.reduce_ms += ms;
@@ -791,7 +815,11 @@ struct ActionRun {
       const uint32_t q = hs.job_queue[hs.t_job[dc.task]];
       if (q < hs.Q) hs.queue_share_live[q] = 1;
     }
-    run_finalize(e);
+    // an action that decided nothing left the task table as the last reduction saw it (every call that changes it ends with one):
+    // the host mirrors are current, nothing to recount (a cycle's backfill usually finds no BestEffort task at all)
+    const double t_fin0 = now_ms();
+    if (!decs.empty() || getenv("KB_ALWAYS_REDUCE")) run_finalize(e);
+    e->tl_finish += now_ms() - t_fin0;
     if (action == 0) {
       check_aggregates(e, om);
       e->stats.tasks_popped += popped;
@@ -917,6 +945,9 @@ void kb_engine_destroy(kb_engine *e) {
             (unsigned long long)e->stats.row_fallbacks, (unsigned long long)e->k5_walks, (unsigned long long)e->k5_rescans,
             (unsigned long long)e->k5_demand);
   if (getenv("KB_K5_STATS")) fprintf(stderr, "[kb K7] batches of the batch kernel %llu\n", e->k7_batches);
+  if (getenv("KB_K5_STATS"))
+    fprintf(stderr, "[kb host] ms over the engine's life: reset %.2f, allocate up to its first launch %.2f, speculation breaks (answer -> re-planned launch) %.2f, "
+            "closing reductions %.2f, waiting for rounds %.2f, backfill up to its first launch %.2f\n", e->tl_reset, e->tl_begin, e->tl_break, e->tl_finish, e->tl_wait, e->tl_backfill);
   if (getenv("KB_K5_STATS")) fprintf(stderr, "[kb probe] %llu probes, %llu shapes marked dead by them\n", (unsigned long long)e->probes, (unsigned long long)e->probe_deaths);
   if (getenv("KB_K5_STATS") && e->k7_trace[1] > 0) {
     static const char *ph[14] = {"loop top / descriptor refill", "shapes (+ barrier)", "windows (+ barrier)", "walk (+ barrier)", "fetch + apply (+ barrier)",
@@ -941,7 +972,9 @@ int kb_session_load(kb_engine *e, const kb_snapshot *sn) {
     if (!sn) throw EngineError(KB_E_INVALID, "snapshot is NULL");
     if (sn->version != KB_ABI_VERSION) throw EngineError(KB_E_INVALID, "snapshot ABI version mismatch");
     if (sn->n_res < 2 || sn->n_res > KB_MAX_RES) throw EngineError(KB_E_INVALID, "n_res out of range");
+    quiesce(e);
     e->loaded = false;
+    e->fin0.valid = false;
     mg_free(e->mg);
     e->mg = nullptr;
     HostSession &hs = e->hs;
@@ -1225,6 +1258,8 @@ int kb_session_load(kb_engine *e, const kb_snapshot *sn) {
     if (hs.has_interpod) { snap_copy(e->p_ip_ccnt, e->b_ip_ccnt); snap_copy(e->p_ip_ctot, e->b_ip_ctot); snap_copy(e->p_ip_punb, e->b_ip_punb); snap_copy(e->p_ip_z, e->b_ip_z); }
     // initial drf / proportion / gang aggregates come from the device reduction (K2+K4)
     run_finalize(e);
+    e->fin0.job_alloc = hs.job_alloc; e->fin0.job_share = hs.job_share; e->fin0.queue_alloc = hs.queue_alloc; e->fin0.queue_share = hs.queue_share;
+    e->fin0.job_ready = hs.job_ready; e->fin0.t_status = hs.t_status; e->fin0.t_node = hs.t_node; e->fin0.valid = true;
     e->stats.reduce_ms = 0;
     e->loaded = true;
     e->tainted = false;
@@ -1235,6 +1270,7 @@ int kb_session_reset(kb_engine *e) {
   if (!e) return KB_E_INVALID;
   return guarded(e, [&]() {
     if (!e->loaded) throw EngineError(KB_E_STATE, "no session loaded");
+    const double t_reset0 = now_ms();
     e->tainted = false;
     hipStream_t s = e->stream;
     auto restore = [&](DevBuf &dst, const DevBuf &src) { HIP_OK(hipMemcpyAsync(dst.p, src.p, src.bytes, hipMemcpyDeviceToDevice, s)); };
@@ -1251,9 +1287,20 @@ int kb_session_reset(kb_engine *e) {
     std::fill(e->hs.queue_share_live.begin(), e->hs.queue_share_live.end(), e->hs.queue_share_at_open);
     e->evictions.clear();
     e->hs.t_off_node.clear();
-    double keep = e->stats.reduce_ms;
-    run_finalize(e);
-    e->stats.reduce_ms = keep;
+    // The restored state is bit for bit the one kb_session_load reduced (the pristine copies were taken in front of that reduction,
+    // which flips no status: no job has an Allocate yet): its results come back from the host copies made then.  The device-side result
+    // buffers keep the previous reduction's values; nothing reads them before the next reduction rewrites them.
+    if (e->fin0.valid && !getenv("KB_RESET_REDUCE")) {
+      e->async_pending = true;   // stream-ordered with everything run_allocate / run_backfill launch; quiesce() for the rest
+      HostSession &hs = e->hs;
+      hs.job_alloc = e->fin0.job_alloc; hs.job_share = e->fin0.job_share; hs.queue_alloc = e->fin0.queue_alloc; hs.queue_share = e->fin0.queue_share;
+      hs.job_ready = e->fin0.job_ready; hs.t_status = e->fin0.t_status; hs.t_node = e->fin0.t_node;
+    } else {
+      double keep = e->stats.reduce_ms;
+      run_finalize(e);
+      e->stats.reduce_ms = keep;
+    }
+    e->tl_reset += now_ms() - t_reset0;
   });
 }
 
@@ -1269,6 +1316,7 @@ static int run_action(kb_engine *e, uint32_t action, kb_decision *out, uint64_t 
     for (uint32_t t = 0; t < e->hs.T; t++)
       if (e->hs.t_status[t] == KB_TASK_PENDING && e->hs.t_node[t] != KB_NONE)
         throw EngineError(KB_E_UNSUPPORTED, "a Pending task carries a stale NodeName (un-pipelined by a discarded preempt statement)");
+    const double t_act0 = now_ms();
     ActionRun run;
     run.begin(e, action);
     run.probe_dead_shapes(e);   // shapes no node can take from the start (larger than every node, full classes) never cost a break
@@ -1290,13 +1338,17 @@ static int run_action(kb_engine *e, uint32_t action, kb_decision *out, uint64_t 
     uint32_t buf = 0;
     RoundCtx c{};
     if (n) c = launch(n, nullptr, buf, 0);
+    (action == 0 ? e->tl_begin : e->tl_backfill) += now_ms() - t_act0;
     while (n) {
       uint32_t n_done = 0, reason = 0;
       const uint32_t n_next = ahead ? run.plan_ahead(e) : 0;
       RoundCtx cn{};
       const bool queued = chained && n_next > 0;
       if (queued) cn = launch(n_next, run.rows_next.data(), buf ^ 1u, c.r.chain_tag);
+      const double t_w0 = now_ms();
       round_collect(e, c, true, n_done, reason);
+      const double t_b0 = now_ms();
+      e->tl_wait += t_b0 - t_w0;
       run.absorb(e, n, n_done, reason);
       if (ahead && reason == KB_REASON_DONE) {
         run.promote(e, n_next);
@@ -1314,6 +1366,7 @@ static int run_action(kb_engine *e, uint32_t action, kb_decision *out, uint64_t 
           e->stats.matrix_evals -= (uint64_t)cn.ns * e->hs.N;
         }
         if (n) c = launch(n, nullptr, buf, 0);
+        if (action == 0) e->tl_break += now_ms() - t_b0;
       }
     }
     run.finish(e);
@@ -1364,6 +1417,7 @@ static int run_evict_action(kb_engine *e, bool reclaim, kb_stmt_op *out, uint64_
   return guarded(e, [&]() {
     if (!e->loaded) throw EngineError(KB_E_STATE, "kb_session_load must precede kb_run_preempt / kb_run_reclaim");
     if (e->tainted) throw EngineError(KB_E_STATE, "a preempt / reclaim call failed after touching the session's state: kb_session_load or kb_session_reset first");
+    quiesce(e);
     HostSession &hs = e->hs;
     if (hs.has_interpod)   // an eviction takes a pod OUT of the inter-pod counts (Running -> Releasing leaves api.AllocatedStatus): not modelled
       throw EngineError(KB_E_UNSUPPORTED, "preempt / reclaim in a session with inter-pod (anti)affinity terms is not modelled");
@@ -1659,6 +1713,7 @@ int kb_get_binds(kb_engine *e, uint32_t *task_node_out) {
   if (!e) return KB_E_INVALID;
   return guarded(e, [&]() {
     if (!e->loaded) throw EngineError(KB_E_STATE, "no session loaded");
+    quiesce(e);
     HIP_OK(hipMemcpy(task_node_out, e->b_tbind.p, sizeof(uint32_t) * e->hs.T, hipMemcpyDeviceToHost));
     uint64_t nb = 0;
     for (uint32_t t = 0; t < e->hs.T; t++) nb += task_node_out[t] != KB_NONE;
@@ -1670,6 +1725,7 @@ int kb_get_task_state(kb_engine *e, uint8_t *status_out, uint32_t *node_out) {
   if (!e) return KB_E_INVALID;
   return guarded(e, [&]() {
     if (!e->loaded) throw EngineError(KB_E_STATE, "no session loaded");
+    quiesce(e);
     if (status_out) HIP_OK(hipMemcpy(status_out, e->b_tstatus.p, e->hs.T, hipMemcpyDeviceToHost));
     if (node_out) HIP_OK(hipMemcpy(node_out, e->b_tnode.p, sizeof(uint32_t) * e->hs.T, hipMemcpyDeviceToHost));
   });
@@ -1679,6 +1735,7 @@ int kb_get_node_state(kb_engine *e, double *idle, double *releasing, int64_t *nz
   if (!e) return KB_E_INVALID;
   return guarded(e, [&]() {
     if (!e->loaded) throw EngineError(KB_E_STATE, "no session loaded");
+    quiesce(e);
     const uint32_t N = e->hs.N, NP = e->dev.NP;
     const int R = e->hs.R;
     if (idle) HIP_OK(hipMemcpy2D(idle, sizeof(double) * N, e->b_idle.p, sizeof(double) * NP, sizeof(double) * N, R, hipMemcpyDeviceToHost));
@@ -1813,6 +1870,7 @@ int kb_engine_use_stream(kb_engine *e, uint64_t hip_stream) {
   if (!e) return KB_E_INVALID;
   return guarded(e, [&]() {
     HIP_OK(hipStreamSynchronize(e->stream));
+    e->async_pending = false;
     e->stream = hip_stream ? reinterpret_cast<hipStream_t>(hip_stream) : e->own_stream;
   });
 }
