@@ -175,17 +175,28 @@ func nodeClassKey(n *api.NodeInfo) string {
 	}
 	return fmt.Sprintf("%v|%v|%v|%v", n.Node.Labels, taints, n.Node.Spec.Unschedulable, conds)
 }
-func taskClassKey(t *api.TaskInfo, pf pressureFlags) (string, error) {
-	sp := &t.Pod.Spec
-	if t.Status == api.Pending {
-		for i := range sp.Volumes {
-			if sp.Volumes[i].PersistentVolumeClaim != nil {
-				// ssn.Allocate starts with cache.AllocateVolumes (session.go:236-238 -> AssumePodVolumes): an unbound claim can veto
-				// a placement the engine has already accounted for; the stock action takes the cycle
-				return "", errUnsupported("pending pod with a PersistentVolumeClaim (volume binding can veto a placement)")
-			}
+// pendingWithClaim: a Pending pod whose spec names a PersistentVolumeClaim.  ssn.Allocate opens with cache.AllocateVolumes
+// (framework/session.go:236-238 -> cache/cache.go:206-211 -> volumeBinder.AssumePodVolumes, vendor/.../controller/volume/scheduling/
+// scheduler_binder.go:253-322).  Nothing in pkg/scheduler calls FindPodVolumes at this commit, so podBindingCache holds no decision for
+// the pod: GetBindings / GetProvisionedPVCs return nil (scheduler_binder_cache.go:124-154), both loops are empty and the call returns
+// (false, nil), or (true, nil) when every claim is bound.  A claim can therefore never veto an Allocate, and the replay goes through the
+// real ssn.Allocate anyway (VolumeReady, BindVolumes at dispatch).  The one trace inside the session is `assumedPod.Spec.NodeName =
+// nodeName` (:269) for a pod whose claims are not all bound; its only reader is nodeorder's cachedNodeInfo (plugins/nodeorder/
+// nodeorder.go:55).  So the claim matters only together with inter-pod terms: buildInterpod refuses that combination, nothing else.
+func pendingWithClaim(t *api.TaskInfo) bool {
+	if t.Status != api.Pending {
+		return false
+	}
+	for i := range t.Pod.Spec.Volumes {
+		if t.Pod.Spec.Volumes[i].PersistentVolumeClaim != nil {
+			return true
 		}
 	}
+	return false
+}
+
+func taskClassKey(t *api.TaskInfo, pf pressureFlags) (string, error) {
+	sp := &t.Pod.Spec
 	bestEffort := pf.mem && v1qos.GetPodQOS(t.Pod) == v1.PodQOSBestEffort // memory pressure only turns BestEffort pods away
 	tols := make([]string, 0, len(sp.Tolerations)) // TolerationSeconds is a pointer (and irrelevant to ToleratesTaint)
 	for _, x := range sp.Tolerations {

@@ -248,6 +248,11 @@ func (f *flat) buildInterpod(tnode []uint32, tstatus []uint8) error {
 	if !any {
 		return nil
 	}
+	for _, ti := range f.tasks {
+		if pendingWithClaim(ti) { // flatten.go: AssumePodVolumes would set its Spec.NodeName, which nodeorder's inter-pod priority reads
+			return errUnsupported("pending pod with a PersistentVolumeClaim in a session with inter-pod (anti)affinity terms")
+		}
+	}
 
 	// ---- predicate counters
 	var counters []ipCounter

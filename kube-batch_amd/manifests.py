@@ -115,11 +115,11 @@ def _pod(doc, namespace: str) -> Pod:
     # inter-pod (anti)affinity: predicates p8 / priority a22, flattened into kb_interpod by snapshot.build_interpod
     pa_req, pa_pref = _pod_terms(aff, "podAffinity")
     paa_req, paa_pref = _pod_terms(aff, "podAntiAffinity")
-    if (status.get("phase", "Pending") or "Pending") == "Pending" and not spec.get("nodeName") and \
-            any((v or {}).get("persistentVolumeClaim") is not None for v in spec.get("volumes") or []):
-        # ssn.Allocate starts with cache.AllocateVolumes (framework/session.go:236-238): volume binding can veto a placement
-        raise UnsupportedManifest(f"pod {meta.get('namespace', namespace)}/{meta.get('name')}: pending pod with a PersistentVolumeClaim")
+    # a claim never vetoes a placement at this commit (snapshot.build_interpod: AssumePodVolumes finds no cached binding decision); it
+    # only matters in a session with inter-pod terms, where flatten() reports the combination unsupported
+    has_claim = any((v or {}).get("persistentVolumeClaim") is not None for v in spec.get("volumes") or [])
     return Pod(
+        has_volume_claim=has_claim,
         namespace=meta.get("namespace", namespace),
         name=meta["name"],
         uid=meta.get("uid"),

@@ -121,6 +121,9 @@ class Pod:
     priority_class_name: str = ""       # conformance plugin: system-cluster-critical / system-node-critical are never evicted
     # resources.limits of every container and init container (only read for the pod's QoS class: the memory-pressure check)
     limits: List[Dict[str, str]] = field(default_factory=list)
+    # spec.volumes names a PersistentVolumeClaim.  Inside the session a claim cannot veto a placement (build_interpod's docstring has
+    # the walk through AssumePodVolumes); it only matters together with inter-pod terms
+    has_volume_claim: bool = False
 
 
 @dataclass
@@ -329,6 +332,18 @@ def build_interpod(nodes, session_pods, other_pods_on_nodes, task_node, task_sta
     all_pods = list(session_pods) + [p for p, _ in other_pods_on_nodes]
     if not any(has_interpod_terms(p) for p in all_pods):
         return None
+    # Volume claims.  ssn.Allocate opens with cache.AllocateVolumes (framework/session.go:236-238 -> cache/cache.go:206-211 ->
+    # volumeBinder.AssumePodVolumes, vendor/.../controller/volume/scheduling/scheduler_binder.go:253-322).  At this commit nothing in
+    # pkg/scheduler calls FindPodVolumes, so podBindingCache holds no decision for the pod: GetBindings / GetProvisionedPVCs return nil
+    # (scheduler_binder_cache.go:124-154), both loops are empty and the call returns (false, nil) — or (true, nil) when every claim is
+    # bound.  A claim can therefore never veto an Allocate; the one trace it leaves inside the session is `assumedPod.Spec.NodeName =
+    # nodeName` (:269) on a pod whose claims are not all bound, and the only reader of that field is nodeorder's cachedNodeInfo
+    # (plugins/nodeorder/nodeorder.go:55): with inter-pod terms in the session such a pod would stop counting for node Z.  Whether a
+    # claim is bound is not in the snapshot, so that combination — and only it — stays with the stock action.
+    for p, st in zip(session_pods, task_status):
+        if p.has_volume_claim and st == abi.TASK_PENDING:
+            raise UnsupportedSnapshot("pending pod with a PersistentVolumeClaim in a session with inter-pod (anti)affinity terms "
+                                      "(AssumePodVolumes sets its Spec.NodeName, which nodeorder's inter-pod priority reads)")
     T = len(session_pods)
     KB_NONE = abi.KB_NONE
     allocated = (abi.TASK_ALLOCATED, abi.TASK_BINDING, abi.TASK_BOUND, abi.TASK_RUNNING)   # api.AllocatedStatus (api/helpers.go:63-72)

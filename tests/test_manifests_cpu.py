@@ -382,17 +382,39 @@ tiers:
     assert binds["ns/besteffort"] == "n-ok" and binds["ns/gpu-only"] == "n-ok" and binds["ns/burstable"] in ("n-mem", "n-ok")
 
 
-def test_pending_pod_with_a_volume_claim_is_reported_unsupported():
+def test_pending_pod_with_a_volume_claim_only_matters_with_inter_pod_terms():
+    """A claim cannot veto ssn.Allocate at this commit (nothing calls FindPodVolumes, so AssumePodVolumes finds no binding decision
+    and returns nil: snapshot.build_interpod has the walk); it sets the pod's Spec.NodeName, which only nodeorder's inter-pod
+    priority reads.  So a pending pod with a claim is an ordinary task, except in a session with inter-pod terms."""
     text = """
 apiVersion: v1
+kind: Node
+metadata: {name: n1}
+status: {allocatable: {cpu: "4", memory: 8Gi, pods: "10"}}
+---
+apiVersion: scheduling.incubator.k8s.io/v1alpha1
+kind: PodGroup
+metadata: {name: g, namespace: ns}
+spec: {minMember: 1}
+---
+apiVersion: v1
 kind: Pod
-metadata: {name: p, namespace: ns, annotations: {scheduling.k8s.io/group-name: g}}
+metadata: {name: p, namespace: ns, labels: {app: a}, annotations: {scheduling.k8s.io/group-name: g}}
 spec:
   containers: [{name: c, resources: {requests: {cpu: "1"}}}]
   volumes: [{name: data, persistentVolumeClaim: {claimName: data-0}}]
 """
-    with pytest.raises(manifests.UnsupportedManifest, match="PersistentVolumeClaim"):
-        manifests.load_cluster(text)
-    running = text.replace("spec:", "status: {phase: Running}\nspec:\n  nodeName: n1", 1)
-    _, pods, _, _ = manifests.load_cluster(running)                   # a placed pod's claim is already bound
-    assert pods[0].node_name == "n1"
+    _, pods, _, _ = manifests.load_cluster(text)
+    assert pods[0].has_volume_claim and pods[0].phase == "Pending"
+    snap = manifests.load_snapshot(text)                              # flattens like any other pending pod
+    assert snap.n_tasks == 1 and snap.interpod is None
+    with_terms = text.replace("  volumes:", """  affinity:
+    podAntiAffinity:
+      requiredDuringSchedulingIgnoredDuringExecution:
+      - labelSelector: {matchLabels: {app: a}}
+        topologyKey: kubernetes.io/hostname
+  volumes:""", 1)
+    with pytest.raises(snapshot.UnsupportedSnapshot, match="PersistentVolumeClaim"):
+        manifests.load_snapshot(with_terms)
+    running = with_terms.replace("spec:\n  containers", "status: {phase: Running}\nspec:\n  nodeName: n1\n  containers", 1)
+    assert manifests.load_snapshot(running).interpod is not None      # a placed pod's claim is already bound: nothing to assume
