@@ -246,7 +246,8 @@ typedef struct kb_snapshot {
 
   /* host ports (predicates.PodFitsHostPorts, vendor/.../algorithm/predicates/predicates.go:1153-1175 over
      nodeinfo.HostPortInfo, vendor/.../nodeinfo/host_ports.go:107-135): the caller interns every distinct
-     (hostIP, protocol, hostPort) of the session's pods into a bit 0..63.  node_ports[n] = bits used by the pods in
+     (hostIP, protocol, hostPort) of the session's pods that can conflict with a port of a Pending pod (the only pods the
+     predicate is asked for; the others' ports can never decide anything) into a bit 0..63.  node_ports[n] = bits used by the pods in
      ni.Tasks; task_port_want[t] = bits the pod occupies once placed; task_port_conflict[t] = every bit that conflicts with
      one of the pod's ports (same protocol and port, and equal IPs or either side 0.0.0.0).  A node fails the predicate
      iff node_ports & task_port_conflict != 0; placing the pod ORs task_port_want in.  All three NULL => no host ports. */

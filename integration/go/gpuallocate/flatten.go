@@ -211,8 +211,11 @@ func taskClassKey(t *api.TaskInfo, pf pressureFlags) (string, error) {
 	return fmt.Sprintf("%v|%v|%v|%v", sp.NodeSelector, nodeAff, tols, bestEffort), nil
 }
 
-// host ports: every distinct (hostIP, protocol, hostPort > 0) of the session's pods is one bit (nodeinfo/host_ports.go sanitises
-// "" to 0.0.0.0 / TCP); more than 64 of them -> the stock action takes the cycle
+// host ports: a distinct (hostIP, protocol, hostPort > 0) of the session's pods is one bit (nodeinfo/host_ports.go sanitises "" to
+// 0.0.0.0 / TCP) if it can ever take part in a conflict test.  PodFitsHostPorts is only asked for a Pending task (allocate, backfill, the
+// preemptors of preempt / reclaim) and a placement adds a Pending task's own ports: a triple that conflicts with no Pending task's port
+// (what the daemons already on the nodes listen on, usually) can never decide anything and gets no bit.  More than 64 of the rest ->
+// the stock action takes the cycle
 type hostPort struct {
 	ip, proto string
 	port      int32
@@ -258,9 +261,13 @@ func newPortTable(ssn *framework.Session) (*portTable, error) {
 			}
 		}
 	}
+	var asked []hostPort // the ports of the Pending tasks
 	for _, j := range ssn.Jobs {
 		for _, t := range j.Tasks {
 			add(t.Pod)
+			if t.Status == api.Pending {
+				asked = append(asked, podHostPorts(t.Pod)...)
+			}
 		}
 	}
 	for _, n := range ssn.Nodes {
@@ -268,8 +275,24 @@ func newPortTable(ssn *framework.Session) (*portTable, error) {
 			add(t.Pod)
 		}
 	}
+	kept := pt.all[:0]
+	for _, hp := range pt.all {
+		live := false
+		for _, a := range asked {
+			if portsConflict(a, hp) {
+				live = true
+				break
+			}
+		}
+		if live {
+			kept = append(kept, hp)
+		} else {
+			delete(pt.bit, hp)
+		}
+	}
+	pt.all = kept
 	if len(pt.all) > 64 {
-		return nil, errUnsupported("more than 64 distinct host ports")
+		return nil, errUnsupported("more than 64 distinct host ports that a pending pod's ports can conflict with")
 	}
 	sort.Slice(pt.all, func(i, j int) bool {
 		a, b := pt.all[i], pt.all[j]
@@ -290,7 +313,9 @@ func newPortTable(ssn *framework.Session) (*portTable, error) {
 func (pt *portTable) masks(pod *v1.Pod) (want, conflict uint64) {
 	mine := podHostPorts(pod)
 	for _, hp := range mine {
-		want |= 1 << pt.bit[hp]
+		if b, ok := pt.bit[hp]; ok { // no bit: the triple conflicts with no pending pod's port
+			want |= 1 << b
+		}
 	}
 	for _, other := range pt.all {
 		for _, hp := range mine {

@@ -672,8 +672,10 @@ def _resource(rl: Dict[str, str], dims: Dict[str, int], R: int):
 
 
 def flatten(nodes: List[Node], pods: List[Pod], pod_groups: List[PodGroup], queues: List[Queue],
-            default_queue: str = "default", pressure: Tuple[bool, bool, bool] = (False, False, False)) -> SessionSnapshot:
+            default_queue: str = "default", pressure: Tuple[bool, bool, bool] = (False, False, False),
+            prune_ports: bool = True) -> SessionSnapshot:
     """Kubernetes-shaped objects -> canonical SoA snapshot (what cache.Snapshot() + the Go shim's flatten produce).
+    prune_ports=False interns every host port of the cluster (tests: the pruned and the unpruned table must decide alike).
     pressure = the predicates plugin's (MemoryPressureEnable, DiskPressureEnable, PIDPressureEnable) arguments
     (SchedulerConf.pressure_flags()): static per class pair, so they are folded into class_compat here and the engine never
     sees them."""
@@ -775,10 +777,15 @@ def flatten(nodes: List[Node], pods: List[Pod], pod_groups: List[PodGroup], queu
         node_nzc[ni] += nzc; node_nzm[ni] += nzm
         return True
 
-    # host ports: every distinct (ip, protocol, port > 0) of the session's pods is one bit
-    universe = sorted({_sanitize_port(hp) for p in pods for hp in p.host_ports if int(hp[2]) > 0})
+    # host ports: a distinct (ip, protocol, port > 0) of the cluster's pods is one bit — if it can ever take part in a conflict test.
+    # PodFitsHostPorts is only ever asked for a Pending task (allocate, backfill, the preemptors of preempt / reclaim), and a placement
+    # adds a Pending task's own ports: a triple that conflicts with no Pending task's port (what the daemons already running on the nodes
+    # listen on, usually) can never decide anything and gets no bit.  More than 64 of the rest -> the stock action takes the cycle.
+    every = sorted({_sanitize_port(hp) for p in pods for hp in p.host_ports if int(hp[2]) > 0})
+    asked = sorted({_sanitize_port(hp) for p in pods if _task_status(p) == abi.TASK_PENDING for hp in p.host_ports if int(hp[2]) > 0})
+    universe = [u for u in every if any(_ports_conflict(hp, u) for hp in asked)] if prune_ports else every
     if len(universe) > 64:
-        raise ValueError("more than 64 distinct host ports in one session")
+        raise ValueError("more than 64 distinct host ports that a pending pod's ports can conflict with in one session")
     port_bit = {hp: i for i, hp in enumerate(universe)}
     node_ports = np.zeros(N, np.uint64)
 
@@ -787,7 +794,8 @@ def flatten(nodes: List[Node], pods: List[Pod], pod_groups: List[PodGroup], queu
         want = 0
         conflict = 0
         for hp in mine:
-            want |= 1 << port_bit[hp]
+            if hp in port_bit:
+                want |= 1 << port_bit[hp]
         for other in universe:
             if any(_ports_conflict(hp, other) for hp in mine):
                 conflict |= 1 << port_bit[other]
