@@ -107,8 +107,13 @@ __device__ __forceinline__ unsigned long long d2u(double v) { return (unsigned l
 // output block, printed by the host under KB_K5_STATS=1
 #ifdef KB_K9_TRACE
 #define K9_STAMP(k) do { if (wave == 0) { const unsigned long long now_ = __builtin_readcyclecounter(); tacc[k] += (uint32_t)(now_ - tlast); tlast = now_; } } while (0)
+// the same interval also into slot k2 when `cond` holds (runs that touch scalar dimensions, accounted apart)
+#define K9_STAMP2(k, k2, cond) do { if (wave == 0) { const unsigned long long now_ = __builtin_readcyclecounter(); tacc[k] += (uint32_t)(now_ - tlast); if (cond) tacc[k2] += (uint32_t)(now_ - tlast); tlast = now_; } } while (0)
+#define K9_COUNT(k, v) do { tacc[k] += (v); } while (0)
 #else
 #define K9_STAMP(k) do { } while (0)
+#define K9_STAMP2(k, k2, cond) do { } while (0)
+#define K9_COUNT(k, v) do { } while (0)
 #endif
 #define K9_WAVE_FENCE() do { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
 
@@ -143,10 +148,39 @@ __device__ __forceinline__ double k9_sc(gptrd base, uint32_t NP, uint32_t dd, ui
 __device__ __forceinline__ void k9_sc_sub(gptrd base, uint32_t NP, uint32_t dd, uint32_t node, double v) {
   (void)__hip_atomic_fetch_add(base + (size_t)(dd + 2) * NP + node, -v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-// key of shape sh against node state v (a dirty slot, or a candidate after its placement); si: the shape's scalar InitResreq.
+// The scalar dimensions one evaluation reads: Idle and Releasing of up to two of them are loaded up front, the four loads in flight together.
+// Read where they are used (a dependent L2 round trip per value, one after the other behind the `&&` of the fit test) they made an
+// evaluation of a shape with scalar requests cost three times a plain one (profiles/round3/call18: config 4, runs with scalar dimensions
+// are 29 % of the runs and 44 % of the rows phase).  Dimensions beyond two go to L2 where they are used, as before.
+#define K9_NOD 0xFFFFFFFFu
+struct K9Sc {
+  uint32_t dA, dB;         // dimension indices (0 = the first one after cpu / memory); K9_NOD: none
+  double iA, rA, iB, rB;   // Idle / Releasing of the node in dA / dB
+};
+__device__ __forceinline__ K9Sc k9_sc_preload(uint32_t mask, gptrd gi, gptrd gr, uint32_t NP, uint32_t node) {
+  K9Sc c;
+  c.dA = K9_NOD; c.dB = K9_NOD; c.iA = 0.0; c.rA = 0.0; c.iB = 0.0; c.rB = 0.0;
+  if (mask) {
+    const uint32_t m2 = mask & (mask - 1u);
+    c.dA = (uint32_t)__ffs((int)mask) - 1u;
+    if (m2) c.dB = (uint32_t)__ffs((int)m2) - 1u;
+    const uint32_t b = m2 ? c.dB : c.dA;   // one dimension only: the second pair repeats the first (no branch around loads)
+    c.iA = k9_sc(gi, NP, c.dA, node); c.rA = k9_sc(gr, NP, c.dA, node);
+    c.iB = k9_sc(gi, NP, b, node); c.rB = k9_sc(gr, NP, b, node);
+  }
+  return c;
+}
+__device__ __forceinline__ double k9_sci(const K9Sc &c, gptrd gi, uint32_t NP, uint32_t dd, uint32_t node) {
+  return dd == c.dA ? c.iA : (dd == c.dB ? c.iB : k9_sc(gi, NP, dd, node));
+}
+__device__ __forceinline__ double k9_scr(const K9Sc &c, gptrd gr, uint32_t NP, uint32_t dd, uint32_t node) {
+  return dd == c.dA ? c.rA : (dd == c.dB ? c.rB : k9_sc(gr, NP, dd, node));
+}
+// key of shape sh against node state v (a dirty slot, or a candidate after its placement); si: the shape's scalar InitResreq;
+// sc: the node's scalar dimensions as k9_sc_preload(sh.active >> 2, ...) returned them (nothing may have lowered them in between).
 // adj_mask / adj_mul / rq: evaluate as if Idle of the scalar dimensions in adj_mask were lower by adj_mul * rq[d] — placements
 // whose scalar part has not reached HBM yet (the caller has already lowered cpu / memory in v); 0 for a plain evaluation.
-__device__ __forceinline__ uint32_t k9_eval_v(const KbCommitArgs &a, const K9Shape &sh, const K9St &v, gptrd gi, gptrd gr, const double *si,
+__device__ __forceinline__ uint32_t k9_eval_v(const KbCommitArgs &a, const K9Shape &sh, const K9St &v, const K9Sc &sc, gptrd gi, gptrd gr, const double *si,
                                               uint32_t adj_mask, double adj_mul, const double *rq, uint32_t nb, uint32_t nmaskbits) {
   bool ok = true;
   if (a.fit_mode) {   // allocate.go:81: !InitResreq.LessEqual(Idle) && !InitResreq.LessEqual(Releasing) -> fail
@@ -156,10 +190,10 @@ __device__ __forceinline__ uint32_t k9_eval_v(const KbCommitArgs &a, const K9Sha
     while (aa) {   // scalar dimensions with InitResreq > 10 (resource_info.go:286-299)
       if (aa & 1u) {
         const double l = si[dd];
-        double id = k9_sc(gi, a.NP, dd, v.node);
+        double id = k9_sci(sc, gi, a.NP, dd, v.node);
         if ((adj_mask >> dd) & 1u) id -= adj_mul * rq[dd];
         fi = fi && le_eps(l, id, EPS_SCALAR);
-        fr = fr && le_eps(l, k9_sc(gr, a.NP, dd, v.node), EPS_SCALAR);
+        fr = fr && le_eps(l, k9_scr(sc, gr, a.NP, dd, v.node), EPS_SCALAR);
       }
       aa >>= 1; dd++;
     }
@@ -383,7 +417,8 @@ __global__ void __launch_bounds__(K9_THREADS) k_commit_run(const K9KernArgs ka) 
     // ---- evaluation phase, one evaluation deep: waves 1..4 the shape against "their" dirty slot, wave 0 the candidates
     if (wave >= 1 && tid - 64u < nd) {
       const uint32_t t = tid - 64u;
-      dk[t] = k9_eval_v(a, sh, k9_load(slots + (size_t)t * K9_NF), gi, gr, si, 0u, 0.0, si, nb, nmaskbits);
+      const K9St vs = k9_load(slots + (size_t)t * K9_NF);
+      dk[t] = k9_eval_v(a, sh, vs, k9_sc_preload(sh.active >> 2, gi, gr, a.NP, vs.node), gi, gr, si, 0u, 0.0, si, nb, nmaskbits);
     }
     uint32_t ck = 0, k1 = 0, ckind = 0;
     double res0 = sh.init0, res1 = sh.init1;
@@ -396,10 +431,11 @@ __global__ void __launch_bounds__(K9_THREADS) k_commit_run(const K9KernArgs ka) 
         unsigned long long *st = slots + (size_t)(nd + lane) * K9_NF;
         double idle0 = u2d(raw[F_IDLE0]), idle1 = u2d(raw[F_IDLE1]), rel0 = u2d(raw[F_REL0]), rel1 = u2d(raw[F_REL1]);
         uint32_t kind = 0;
+        const K9Sc scn = k9_sc_preload(sh.active >> 2, gi, gr, a.NP, n);   // the candidate's scalar dimensions: for the test below and the key
         if (!a.backfill) {   // allocate.go:160: InitResreq.LessEqual(node.Idle) -> Allocate, else Pipeline
           bool fi = le_eps(sh.init0, idle0, EPS_CPU) && le_eps(sh.init1, idle1, EPS_MEM);
           for (uint32_t aa = sh.active >> 2, dd = 0; aa; aa >>= 1, dd++)
-            if (aa & 1u) fi = fi && le_eps(si[dd], k9_sc(gi, a.NP, dd, n), EPS_SCALAR);
+            if (aa & 1u) fi = fi && le_eps(si[dd], k9_sci(scn, gi, a.NP, dd, n), EPS_SCALAR);
           kind = fi ? 0u : 1u;
         }
         // NodeInfo.AddTask (api/node_info.go:172-212): Idle (Allocated) or Releasing (Pipelined) -= Resreq, pod joins ni.Tasks
@@ -421,10 +457,10 @@ __global__ void __launch_bounds__(K9_THREADS) k_commit_run(const K9KernArgs ka) 
         // Releasing-side key is never read.
         const uint32_t adjm = (!kind && (rnm & 0x7FFFFFFFu)) ? km0 : 0u;
         ckind = kind;
-        k1 = k9_eval_v(a, sh, v, gi, gr, si, adjm, 1.0, rqv, nb, nmaskbits);   // the node's key once it is dirty
+        k1 = k9_eval_v(a, sh, v, scn, gi, gr, si, adjm, 1.0, rqv, nb, nmaskbits);   // the node's key once it is dirty
       }
     }
-    K9_STAMP(1);
+    K9_STAMP2(1, 7, (sh.active >> 2) != 0u || km0 != 0u);
     __syncthreads();   // B2: the dirty keys are in LDS
     K9_STAMP(2);
 
@@ -462,6 +498,7 @@ __global__ void __launch_bounds__(K9_THREADS) k_commit_run(const K9KernArgs ka) 
           }
           pc++;
         } else {       // a node this round already changed wins: AddTask on its slot, re-evaluate it
+          K9_COUNT(8, 1u);
           const uint32_t own = (lane < pc) ? k1 : 0u;
           const unsigned long long who = __ballot(d0 == m || d1 == m || d2 == m || d3 == m || own == m);
           const uint32_t L = (uint32_t)__ffsll((unsigned long long)who) - 1u;
@@ -480,20 +517,22 @@ __global__ void __launch_bounds__(K9_THREADS) k_commit_run(const K9KernArgs ka) 
             const uint32_t adjm = (nm0 & 0x7FFFFFFFu) ? km0 : 0u;   // Idle has a scalar map: Sub lowers the dimensions Resreq names
             bool exact = v0.idle0 == trunc(v0.idle0) && v0.idle1 == trunc(v0.idle1) && res0 == trunc(res0) && res1 == trunc(res1) &&
                          fabs(v0.idle0) < 4.0e15 && fabs(v0.idle1) < 4.0e15 && res0 < 3.0e13 && res1 < 3.0e13;
+            // the node's scalar dimensions the chain reads: the ones the shape tests, the ones its Resreq lowers (loaded once, together)
+            const K9Sc scc = k9_sc_preload((sh.active >> 2) | adjm, gi, gr, a.NP, v0.node);
             for (uint32_t mm = adjm, dd = 0; mm; mm >>= 1, dd++)
-              if (mm & 1u) { const double id = k9_sc(gi, a.NP, dd, v0.node), rq = si[dd]; exact = exact && id == trunc(id) && rq == trunc(rq) && fabs(id) < 4.0e15 && rq < 3.0e13; }
+              if (mm & 1u) { const double id = k9_sci(scc, gi, a.NP, dd, v0.node), rq = si[dd]; exact = exact && id == trunc(id) && rq == trunc(rq) && fabs(id) < 4.0e15 && rq < 3.0e13; }
             if (exact) {
               const double tb = (double)lane, ta = (double)(lane + 1);   // placements before / after step `lane`
               // Allocate at step t needs InitResreq <= Idle after t placements (allocate.go:160)
               bool fit = le_eps(sh.init0, v0.idle0 - tb * res0, EPS_CPU) && le_eps(sh.init1, v0.idle1 - tb * res1, EPS_MEM);
               for (uint32_t aa = sh.active >> 2, dd = 0; aa; aa >>= 1, dd++)
-                if (aa & 1u) { double id = k9_sc(gi, a.NP, dd, v0.node); if ((adjm >> dd) & 1u) id -= tb * si[dd]; fit = fit && le_eps(si[dd], id, EPS_SCALAR); }
+                if (aa & 1u) { double id = k9_sci(scc, gi, a.NP, dd, v0.node); if ((adjm >> dd) & 1u) id -= tb * si[dd]; fit = fit && le_eps(si[dd], id, EPS_SCALAR); }
               K9St v = v0;
               v.idle0 = v0.idle0 - ta * res0; v.idle1 = v0.idle1 - ta * res1;
               v.nzc = v0.nzc + ta * sh.nzc; v.nzm = v0.nzm + ta * sh.nzm;
               v.ports = v0.ports | sh.want;
               v.left = v0.left - (int)(lane + 1);
-              const uint32_t kt = k9_eval_v(a, sh, v, gi, gr, si, adjm, ta, si, nb, nmaskbits);   // key after t + 1 placements
+              const uint32_t kt = k9_eval_v(a, sh, v, scc, gi, gr, si, adjm, ta, si, nb, nmaskbits);   // key after t + 1 placements
               // the best alternative: every other dirty key, and the next clean candidate
               const uint32_t others = max(max(max(lane == L && !is_new && wsel == 0 ? 0u : d0, lane == L && !is_new && wsel == 1 ? 0u : d1),
                                               max(lane == L && !is_new && wsel == 2 ? 0u : d2, lane == L && !is_new && wsel == 3 ? 0u : d3)),
@@ -535,6 +574,8 @@ __global__ void __launch_bounds__(K9_THREADS) k_commit_run(const K9KernArgs ka) 
           if (lane < K9_NF) cur8 = st[lane];
           const uint32_t nm = (uint32_t)(rl64(cur8, F_NODE_NMASK) >> 32);
           const uint32_t n = (uint32_t)rl64(cur8, F_NODE_NMASK);
+          // the scalar dimensions the new key will read (only when a key is needed: not on the run's last row), in flight with the vote's loads
+          const K9Sc scs = k9_sc_preload((j + 1u < r) ? (sh.active >> 2) : 0u, gi, gr, a.NP, n);
           kind = 0;
           if (!a.backfill) {
             bool ok = true;
@@ -554,23 +595,29 @@ __global__ void __launch_bounds__(K9_THREADS) k_commit_run(const K9KernArgs ka) 
           if (lane < K9_NF) st[lane] = cur8;
           if (lane == 0) ldec[i0 + j] = (unsigned long long)n | ((unsigned long long)kind << 32);
           K9_WAVE_FENCE();
-          // the new key first (scalar part of the Sub as an adjustment), then the Sub itself goes to HBM
+          // the new key first (scalar part of the Sub as an adjustment), then the Sub itself goes to HBM.  The last row of a run (and a
+          // Pipeline, which ends the round) needs no new key: the next run evaluates every slot against ITS shape anyway
+          const bool more = j + 1u < r && !kind;
           const uint32_t adjm1 = (!kind && has_map) ? km0 : 0u;
-          const uint32_t nk = k9_eval_v(a, sh, k9_load(st), gi, gr, si, adjm1, 1.0, rqv, nb, nmaskbits);   // uniform: every lane computes the same key
+          uint32_t nk = 0u;
+          if (more) nk = k9_eval_v(a, sh, k9_load(st), scs, gi, gr, si, adjm1, 1.0, rqv, nb, nmaskbits);   // uniform: every lane computes the same key
           if (km0 && has_map) {
             if (sc_lane && ((km0 >> sd) & 1u)) k9_sc_sub(kind ? gr : gi, a.NP, sd, n, rqv[sd]);
             sc_dirty = 1;
           }
-          if (lane == L) {
-            if (is_new) k1 = nk;
-            else if (wsel == 0) d0 = nk; else if (wsel == 1) d1 = nk; else if (wsel == 2) d2 = nk; else d3 = nk;
+          if (more) {
+            if (lane == L) {
+              if (is_new) k1 = nk;
+              else if (wsel == 0) d0 = nk; else if (wsel == 1) d1 = nk; else if (wsel == 2) d2 = nk; else d3 = nk;
+            }
+            m = wave_max_u32(max(max(max(d0, d1), max(d2, d3)), (lane < pc) ? k1 : 0u));
           }
-          m = wave_max_u32(max(max(max(d0, d1), max(d2, d3)), (lane < pc) ? k1 : 0u));
           n_dirty++;
         }
         if (kind) { j++; reason = KB_REASON_PIPELINED; break; }   // a Pipeline ends the speculated order: the host re-plans
       }
-      K9_STAMP(3);
+      K9_STAMP2(3, 5, (sh.active >> 2) != 0u || km0 != 0u);
+      K9_COUNT(6, ((sh.active >> 2) != 0u || km0 != 0u) ? 1u : 0u);
       if (sc_dirty) __threadfence();   // the scalar atomics have reached L2 before any other wave evaluates against these nodes
       if (lane == 0) {
         if (pc) cursor[s] = cpos[pc - 1] + 1;

@@ -958,7 +958,8 @@ void kb_engine_destroy(kb_engine *e) {
   }
   if (getenv("KB_K5_STATS") && e->k5_trace[0] > 0) {
     static const char *ph[10] = {"barrier 1 (wave 0's wait)", "evaluate: candidates (wave 0)", "barrier 2", "rows", "prepare the next run",
-                                "-", "-", "-", "-", "loop top"};
+                                "rows, of runs with scalar dimensions", "runs with scalar dimensions (count)", "evaluate, of runs with scalar dimensions",
+                                "dirty-winner entries (count)", "loop top"};
     const double runs = (double)(e->k5_walks ? e->k5_walks : 1);
     for (int k = 0; k < 10; k++) fprintf(stderr, "[kb K5 trace] %-32s %14.0f clocks  (%.0f per run)\n", ph[k], e->k5_trace[k], e->k5_trace[k] / runs);
   }
