@@ -140,6 +140,17 @@ struct KbRound {
   // kernel reports KB_REASON_SKIPPED).  chain == nullptr: not part of a chain.
   uint32_t *chain;
   uint32_t chain_expect, chain_tag;
+  // Overlapped candidate lists (round 3): for a chained round the matrix and arg-max launches run on a SECOND stream beside the
+  // predecessor's commit kernel, against whatever node state they find: exact for every node the predecessor leaves alone, arbitrary for
+  // the (at most n_prev) nodes it changes.  The arg-max kernel leaves ready_tag in ready[row] behind each finished list; kb_launch_repair
+  // (first stream, behind the predecessor's commit) waits for it, re-evaluates the predecessor's nodes against the state it left and
+  // merges: `stale` [n_mrows][stale_L] -> keys [n_mrows][L].  ready == nullptr: not an overlapped round.
+  uint32_t *ready;
+  uint32_t ready_tag;
+  const unsigned long long *stale;   // kb_launch_repair: the lists of the overlapped arg-max launch
+  uint32_t stale_L;                  // >= n_prev + L: what is left of a stale list without the predecessor's nodes still holds the true top L
+  const unsigned long long *prev_dec;   // decision records of the predecessor round (low word: node), n_prev of them
+  uint32_t n_prev;
 };
 // true when the round was queued behind a predecessor that did not complete
 #define KB_CHAIN_BROKEN(r) ((r).chain_expect != 0u && *(r).chain != (r).chain_expect)
@@ -210,6 +221,8 @@ void kb_launch_probe(const KbDev &d, const uint32_t *rows, uint32_t n_rows, uint
 // nodeorder's InterPodAffinityPriority added to the score rows of the matrix rows whose task carries weights (no-op otherwise)
 void kb_launch_interpod(const KbDev &d, const KbRound &r, void *stream);
 void kb_launch_argmax(const KbDev &d, const KbRound &r, void *stream);
+// overlapped rounds (KbRound::ready): stale lists + the predecessor's nodes re-evaluated -> the round's candidate lists
+void kb_launch_repair(const KbDev &d, const KbRound &r, void *stream);
 // per-task rows out of the per-shape rows (kb_eval_matrix / kb_bench_matrix: the materialised T x N matrix)
 // order: the rows sorted by shape slot (nullptr: row order)
 void kb_launch_expand(const KbDev &d, const uint16_t *s_score, const uint32_t *s_mask, const uint32_t *row_slot, const uint32_t *order, uint32_t n_rows,

@@ -162,6 +162,15 @@ struct kb_engine {
   std::vector<uint32_t> h_xorder;
   size_t xs_cap = 0, xslot_cap = 0;
   DevBuf b_mrows, b_same, b_score, b_maskw, b_keys;
+  // Overlapped candidate lists: the matrix and arg-max launches of a chained round run on a second stream
+  // beside its predecessor's commit kernel, into buffers of their own (matrix rows, stale lists per staging half, one `ready` word per
+  // list, a scratch block for their time stamps); kb_launch_repair on the first stream turns the stale lists into the round's lists
+  hipStream_t stream_b = nullptr;
+  DevBuf b_score2, b_maskw2, b_stale, b_ready, b_scratch_out;
+  uint32_t mat2_cap = 0;
+  size_t stale_cap = 0;
+  bool overlap = true;             // KB_OVERLAP=0: every round on the plain path (matrix -> arg-max -> commit on one stream)
+  uint64_t overlapped_rounds = 0, overlap_faults = 0;
   DevBuf b_win, b_out;   // per-round upload / download blocks (see h_win / h_out)
   DevBuf b_chain;        // KbRound::chain: tag of the last round that committed its whole window
   // feasibility probe at speculation breaks (ActionRun::probe_dead_shapes): one representative task per feasibility shape
@@ -206,6 +215,7 @@ struct kb_engine {
     mg_free(mg);
     for (auto &t : ev) t.destroy();
     if (own_stream) (void)hipStreamDestroy(own_stream);
+    if (stream_b) (void)hipStreamDestroy(stream_b);
   }
 };
 
@@ -217,7 +227,7 @@ namespace {
 // window buffers: one entry per task row of a round
 void ensure_window_buffers(kb_engine *e, uint32_t rows) {
   if (rows <= e->win_cap) return;
-  e->b_desc.alloc(sizeof(KbRowDesc) * rows);
+  if (!e->b_desc.p) e->b_desc.alloc(sizeof(KbRowDesc) * 2 * KB_K5_MAX_WINDOW);   // two fixed halves (chained rounds alternate): a round in flight must not see them move
   e->h_rows.resize(rows);
   e->h_slot.resize(rows);
   e->h_decnode.resize(rows);
@@ -306,12 +316,12 @@ void run_finalize(kb_engine *e) {
     if (!hs.queue_has_attr[q] || !hs.queue_share_live[q]) hs.queue_share[q] = 0.0;
 }
 
-KbRound make_round(kb_engine *e, uint32_t n_rows, uint32_t n_mrows, uint32_t L, int fit_mode, bool backfill) {
+KbRound make_round(kb_engine *e, uint32_t n_rows, uint32_t n_mrows, uint32_t L, int fit_mode, bool backfill, uint32_t buf = 0) {
   KbRound r{};
   r.rows = e->b_win.as<uint32_t>();
   r.shape_slot = e->b_win.as<uint32_t>() + KB_K5_MAX_WINDOW;
   r.n_rows = n_rows;
-  r.desc = e->b_desc.as<KbRowDesc>();
+  r.desc = e->b_desc.as<KbRowDesc>() + (size_t)buf * KB_K5_MAX_WINDOW;
   r.trace = nullptr;
   r.cap = std::max<uint32_t>(64, ((n_rows + 63) / 64) * 64);
   r.mrows = e->b_win.as<uint32_t>() + 2 * KB_K5_MAX_WINDOW;
@@ -398,7 +408,7 @@ RoundCtx round_prepare(kb_engine *e, uint32_t n, int fit_mode, bool backfill, bo
     c.d.score_enabled = 0;   // backfill.go:50-66 takes the first node that passes the predicates: all scores tie
     c.d.t_init = e->t_fit;   // ... and on which ssn.Allocate's AddTask succeeds: Resreq.LessEqual(Idle), fit_mode 2
   }
-  c.r = make_round(e, n, c.ns, c.L, fit_mode, backfill);
+  c.r = make_round(e, n, c.ns, c.L, fit_mode, backfill, buf);
   if (direct) {
     const uint32_t *dw = e->d_hwin + (size_t)buf * 3 * KB_K5_MAX_WINDOW;
     c.r.rows = dw;
@@ -440,6 +450,64 @@ void round_candidates(kb_engine *e, const RoundCtx &c, uint32_t m0, uint32_t m1,
   }
   e->stats.matrix_launches += 1;
   e->stats.matrix_evals += (uint64_t)(m1 - m0) * e->hs.N;
+}
+
+// The same for a chained round, overlapped with its predecessor (n_prev rows, running or queued on the first stream): matrix + arg-max on
+// the second stream with lists of n_prev + L entries, then — first stream, i.e. behind the predecessor's commit kernel — the repair launch
+// that waits for the lists, re-evaluates the predecessor's nodes and merges (kb_kernels.hip: k_repair).  The host's order guarantees that
+// every round before the predecessor has been COLLECTED when this is called (run_action plans a window only after it has the answer of the
+// round two in front of it), so the only nodes that can change under the second stream's launches are the predecessor's.
+void ensure_overlap_buffers(kb_engine *e, uint32_t mrows, uint32_t stale_L) {
+  const size_t NP = e->dev.NP;
+  if (!e->stream_b) HIP_OK(hipStreamCreateWithFlags(&e->stream_b, hipStreamNonBlocking));
+  if (mrows > e->mat2_cap) {
+    HIP_OK(hipStreamSynchronize(e->stream_b));
+    e->b_score2.alloc(sizeof(uint16_t) * (size_t)mrows * NP);
+    e->b_maskw2.alloc(sizeof(uint32_t) * (size_t)mrows * (NP / 32));
+    e->mat2_cap = mrows;
+  }
+  const size_t need = (size_t)mrows * stale_L;
+  if (need > e->stale_cap) {
+    HIP_OK(hipStreamSynchronize(e->stream_b));
+    HIP_OK(hipStreamSynchronize(e->stream));
+    e->b_stale.alloc(sizeof(unsigned long long) * 2 * need);
+    e->stale_cap = need;
+  }
+  if (!e->b_ready.p) {
+    e->b_ready.alloc(sizeof(uint32_t) * 2 * KB_K5_MAX_WINDOW);
+    HIP_OK(hipMemset(e->b_ready.p, 0, e->b_ready.bytes));
+    e->b_scratch_out.alloc(sizeof(unsigned long long) * KB_OUT_HDR);
+    HIP_OK(hipMemset(e->b_scratch_out.p, 0, e->b_scratch_out.bytes));
+  }
+}
+void round_candidates_overlapped(kb_engine *e, const RoundCtx &c, uint32_t n_prev, unsigned long long *keys) {
+  if (c.ns == 0) return;
+  const uint32_t stale_L = n_prev + c.L;
+  unsigned long long *stale = e->b_stale.as<unsigned long long>() + (size_t)c.buf * e->stale_cap;
+  uint32_t *ready = e->b_ready.as<uint32_t>() + (size_t)c.buf * KB_K5_MAX_WINDOW;
+  KbRound rb = c.r;   // the second stream's view: runs whatever the chain word says (the predecessor has not written it yet)
+  rb.chain_expect = 0;
+  rb.score = e->b_score2.as<uint16_t>();
+  rb.maskw = e->b_maskw2.as<uint32_t>();
+  rb.keys = stale;
+  rb.L = stale_L;
+  rb.result = e->b_scratch_out.as<uint32_t>();   // their time stamps do not belong to the round's timeline
+  rb.ready = ready;
+  rb.ready_tag = (uint32_t)c.seq;
+  kb_launch_matrix(c.d, rb, e->stream_b);        // also gathers the row descriptors into this round's half (gather == 1)
+  kb_launch_argmax(c.d, rb, e->stream_b);
+  KbRound ra = c.r;   // first stream: behind the predecessor's commit kernel
+  ra.keys = keys;
+  ra.ready = ready;
+  ra.ready_tag = (uint32_t)c.seq;
+  ra.stale = stale;
+  ra.stale_L = stale_L;
+  ra.prev_dec = e->b_out.as<unsigned long long>() + KB_OUT_HDR;   // the predecessor's decision records (it completed, or the chain is broken)
+  ra.n_prev = n_prev;
+  kb_launch_repair(c.d, ra, e->stream);
+  e->stats.matrix_launches += 1;
+  e->stats.matrix_evals += (uint64_t)c.ns * e->hs.N;
+  e->overlapped_rounds += 1;
 }
 
 // K5 over the whole window with the complete candidate table `keys` [ns][L]
@@ -792,6 +860,14 @@ struct ActionRun {
           om.report(Outcome::NoFeasibleNode);
           break;
         }
+        if (reason == KB_REASON_SKIPPED && i == n_done) {
+          // only an overlapped round whose candidate lists never arrived skips itself behind a predecessor that completed (k_repair's
+          // bounded wait): nothing was decided; the task heads the next window, which goes the plain way (and so does the rest of the action)
+          e->overlap_faults += 1;
+          om.rollback_last_pop();
+          popped--;
+          break;
+        }
         if (reason == KB_REASON_RENORM && i == n_done) {
           // the device stopped in front of this task (its score must be normalised over a fresh feasible set): nothing was
           // decided for it; undo the pop so that it heads the next window
@@ -925,6 +1001,8 @@ int kb_engine_create(const kb_config *cfg, kb_engine **out) {
       eng->chain_rounds = !(cr && cr[0] == '0');
       const char *pb = getenv("KB_PROBE");
       eng->probe_enabled = !(pb && pb[0] == '0');
+      const char *ov = getenv("KB_OVERLAP");
+      eng->overlap = !(ov && ov[0] == '0');
       const char *dw = getenv("KB_DIRECT_WINDOW");
       eng->direct_window = !(dw && dw[0] == '0');
     }
@@ -944,6 +1022,8 @@ void kb_engine_destroy(kb_engine *e) {
             (unsigned long long)e->stats.rounds, (unsigned long long)e->stats.decisions, (unsigned long long)e->k5_slots,
             (unsigned long long)e->stats.row_fallbacks, (unsigned long long)e->k5_walks, (unsigned long long)e->k5_rescans,
             (unsigned long long)e->k5_demand);
+  if (getenv("KB_K5_STATS")) fprintf(stderr, "[kb overlap] rounds with candidate lists built beside the predecessor's commit %llu, lists that never arrived %llu\n",
+                                     (unsigned long long)e->overlapped_rounds, (unsigned long long)e->overlap_faults);
   if (getenv("KB_K5_STATS")) fprintf(stderr, "[kb K7] batches of the batch kernel %llu\n", e->k7_batches);
   if (getenv("KB_K5_STATS"))
     fprintf(stderr, "[kb host] ms over the engine's life: reset %.2f, allocate up to its first launch %.2f, speculation breaks (answer -> re-planned launch) %.2f, "
@@ -1323,13 +1403,19 @@ static int run_action(kb_engine *e, uint32_t action, kb_decision *out, uint64_t 
     run.probe_dead_shapes(e);   // shapes no node can take from the start (larger than every node, full classes) never cost a break
     uint32_t n = run.plan(e);
     ensure_matrix_buffers(e, e->eff_window, e->eff_window + 1);   // sized once: no reallocation under a round in flight
-    auto launch = [&](uint32_t rows_n, const uint32_t *rows, uint32_t buf, uint32_t chain_expect) {
+    // chained rounds of plain sessions (cpu and memory only: the batch kernel writes scalar dimensions speculatively; no score that is
+    // normalised over the feasible set, no inter-pod counters) build their candidate lists beside the predecessor's commit kernel
+    const bool overlap_ok = e->overlap && action == 0 && e->fast_rounds && e->hs.R == 2 && !e->hs.has_affinity && !e->hs.has_interpod &&
+                            2 * e->eff_window + 1 <= 1024u;
+    auto launch = [&](uint32_t rows_n, const uint32_t *rows, uint32_t buf, uint32_t chain_expect, uint32_t n_prev) {
       RoundCtx c = round_prepare(e, rows_n, action == 0 ? 1 : 2, action == 1, true, rows, buf, chain_expect);   // single GPU: every matrix row is local
       unsigned long long *keys = e->b_keys.as<unsigned long long>();
-      round_candidates(e, c, 0, c.ns, keys);
+      if (overlap_ok && c.direct && chain_expect != 0 && !e->overlap_faults) round_candidates_overlapped(e, c, n_prev, keys);
+      else round_candidates(e, c, 0, c.ns, keys);
       round_commit(e, c, keys, nullptr, 0, 0);
       return c;
     };
+    if (overlap_ok) ensure_overlap_buffers(e, e->eff_window, 2 * e->eff_window + 1);
     // Fast rounds return from the launch immediately.  The host uses the wait to speculate the NEXT window (assuming the one in
     // flight completes, which ~80 % do) and queues that round behind the running one right away: the device starts it the
     // moment the commit kernel ends instead of idling through a host round trip (~19 us per round).  A round that stops early
@@ -1338,14 +1424,14 @@ static int run_action(kb_engine *e, uint32_t action, kb_decision *out, uint64_t 
     const bool chained = ahead && e->chain_rounds;
     uint32_t buf = 0;
     RoundCtx c{};
-    if (n) c = launch(n, nullptr, buf, 0);
+    if (n) c = launch(n, nullptr, buf, 0, 0);
     (action == 0 ? e->tl_begin : e->tl_backfill) += now_ms() - t_act0;
     while (n) {
       uint32_t n_done = 0, reason = 0;
       const uint32_t n_next = ahead ? run.plan_ahead(e) : 0;
       RoundCtx cn{};
       const bool queued = chained && n_next > 0;
-      if (queued) cn = launch(n_next, run.rows_next.data(), buf ^ 1u, c.r.chain_tag);
+      if (queued) cn = launch(n_next, run.rows_next.data(), buf ^ 1u, c.r.chain_tag, n);
       const double t_w0 = now_ms();
       round_collect(e, c, true, n_done, reason);
       const double t_b0 = now_ms();
@@ -1355,7 +1441,7 @@ static int run_action(kb_engine *e, uint32_t action, kb_decision *out, uint64_t 
         run.promote(e, n_next);
         n = n_next;
         if (queued) { c = cn; buf ^= 1u; }
-        else if (n) c = launch(n, nullptr, buf, 0);
+        else if (n) c = launch(n, nullptr, buf, 0, 0);
       } else {
         if (reason != KB_REASON_RENORM) run.probe_dead_shapes(e);
         n = run.plan(e);   // re-plan first: the queued round drains (three empty launches) while the host works
@@ -1366,10 +1452,11 @@ static int run_action(kb_engine *e, uint32_t action, kb_decision *out, uint64_t 
           e->stats.matrix_launches -= 1;
           e->stats.matrix_evals -= (uint64_t)cn.ns * e->hs.N;
         }
-        if (n) c = launch(n, nullptr, buf, 0);
+        if (n) c = launch(n, nullptr, buf, 0, 0);
         if (action == 0) e->tl_break += now_ms() - t_b0;
       }
     }
+    if (e->stream_b) HIP_OK(hipStreamSynchronize(e->stream_b));   // a candidate launch of a round that was skipped may still be running
     run.finish(e);
     if (n_out) *n_out = run.decs.size();
     if (run.decs.size() > cap) throw EngineError(KB_E_CAPACITY, "decision buffer too small");

@@ -577,6 +577,128 @@ __global__ void __launch_bounds__(THREADS) k_argmax(KbDev d, KbRound r) {
   }
   if (found > K) found = K;
   for (uint32_t i = found + tid; i < K; i += THREADS) out[i] = 0ull;
+  if (r.ready != nullptr) {   // overlapped round: the list is complete and visible before its tag is
+    __threadfence();
+    __syncthreads();
+    if (tid == 0) __hip_atomic_store(&r.ready[row], r.ready_tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// k_repair: the candidate lists of an OVERLAPPED round (KbRound::ready).  Its matrix and arg-max launches ran on the second stream while
+// the predecessor round's commit kernel was still changing nodes: their lists are exact for every node the predecessor left alone and
+// arbitrary for the nodes it changed.  One workgroup per matrix row, behind the predecessor's commit on the first stream:
+//   1. the predecessor's nodes (its decision records; a node may have taken several rows) -> a bitmap in LDS, each node owned by one thread;
+//   2. the owner evaluates the row's shape against the node's state as the predecessor LEFT it (eval_row<1>, K1's own arithmetic);
+//   3. the stale list without the predecessor's nodes, merged with the new keys by rank: survivors keep their order (block scan of the
+//      survivor flags) and count the new keys above them; a new key counts the survivors above it (binary search + the scan) and the new
+//      keys above it.  Keys are distinct (the node index is part of them), so the ranks are a permutation.
+// A clean node of the true top L has at most L - 1 clean and n_prev changed nodes above it in the stale order: stale_L >= n_prev + L entries
+// hold every one of them.
+// ------------------------------------------------------------------------------------------------------------
+#define KB_REPAIR_THREADS 1024
+__global__ void __launch_bounds__(KB_REPAIR_THREADS) k_repair(KbDev d, KbRound r) {
+  extern __shared__ __align__(16) unsigned char kr_smem[];
+  unsigned long long *stale = reinterpret_cast<unsigned long long *>(kr_smem);                 // [KB_REPAIR_THREADS]
+  unsigned long long *fresh = stale + KB_REPAIR_THREADS;                                       // [n_prev] keys of the predecessor's nodes (0: infeasible / not owned)
+  uint32_t *alive_before = reinterpret_cast<uint32_t *>(fresh + KB_K5_MAX_WINDOW);             // [KB_REPAIR_THREADS + 1] survivors in front of entry i
+  uint32_t *bitmap = alive_before + KB_REPAIR_THREADS + 1;                                     // [NP / 32]
+  __shared__ uint32_t s_wtot[KB_REPAIR_THREADS / 64];
+  __shared__ K1Task s_task;
+  const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, row = blockIdx.x;
+  if (KB_CHAIN_BROKEN(r)) return;
+  if (row == 0 && tid == 0) {   // the round's matrix / arg-max stamps: the candidate launches ran beside the predecessor, this is what the round waits for
+    unsigned long long *st = reinterpret_cast<unsigned long long *>(r.result);
+    const unsigned long long now = wall_clock64();
+    st[KB_OUT_STAMP0] = now; st[KB_OUT_STAMP0 + 1] = now;
+  }
+  for (uint32_t w = tid; w < d.NP / 32; w += KB_REPAIR_THREADS) bitmap[w] = 0u;
+  __shared__ uint32_t s_late;
+  if (tid == 0) {
+    s_task = k1_task(d, r.mrows ? r.mrows[row] : r.mrow_task0 + row);
+    // the list was launched (second stream) before this kernel (first stream) and had a whole commit kernel's time to finish: the wait is
+    // normally over before it starts.  Bounded all the same: a list that never arrives breaks the chain — the commit kernel behind this one
+    // then skips the round and the host launches it again on the plain path — instead of hanging the device.
+    uint32_t spins = 0, late = 0;
+    while (__hip_atomic_load(&r.ready[row], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != r.ready_tag) {
+      __builtin_amdgcn_s_sleep(8);
+      if (++spins > (1u << 21)) { late = 1; break; }
+    }
+    s_late = late;
+    if (late && r.chain != nullptr) *r.chain = 0u;
+  }
+  __syncthreads();
+  if (s_late) return;
+  // 1 + 2: the predecessor's nodes
+  const uint32_t np = r.n_prev;
+  unsigned long long fk = 0ull;
+  if (tid < np) {
+    const uint32_t node = (uint32_t)(r.prev_dec[tid] & 0xFFFFFFFFull);
+    if (node != KB_NONE_U32) {
+      const uint32_t old = atomicOr(&bitmap[node >> 5], 1u << (node & 31));
+      if (!((old >> (node & 31)) & 1u)) {   // this thread owns the node
+        const K1Task tv = k1_uniform(s_task);
+        K1Node nv[1];
+        nv[0] = k1_node(d, node);
+        uint32_t res[1];
+        eval_row<1>(d, tv, nv, node, r.fit_mode, res);
+        if (res[0] >> 16) fk = KB_KEY(res[0] & 0xFFFFu, node);
+      }
+    }
+  }
+  if (tid < KB_K5_MAX_WINDOW) fresh[tid] = fk;
+  // the stale list (0-terminated, best first)
+  const uint32_t Ls = r.stale_L;
+  const unsigned long long sk = (tid < Ls) ? r.stale[(size_t)row * Ls + tid] : 0ull;
+  stale[tid] = sk;
+  __syncthreads();
+  // 3: survivors and their prefix counts
+  const bool alive = sk != 0ull && !((bitmap[KB_KEY_NODE(sk) >> 5] >> (KB_KEY_NODE(sk) & 31)) & 1u);
+  const unsigned long long bal = __ballot(alive);
+  const uint32_t in_wave = (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
+  if (lane == 0) s_wtot[wave] = (uint32_t)__popcll(bal);
+  __syncthreads();
+  uint32_t before = in_wave;
+  for (uint32_t w = 0; w < wave; w++) before += s_wtot[w];
+  alive_before[tid] = before;
+  if (tid == KB_REPAIR_THREADS - 1) alive_before[KB_REPAIR_THREADS] = before + (alive ? 1u : 0u);
+  __syncthreads();
+  const uint32_t K = r.L;
+  unsigned long long *out = r.keys + (size_t)row * K;
+  uint32_t n_fresh = 0;   // feasible new keys (uniform after the loop below only for thread-local use)
+  if (alive) {
+    uint32_t rank = before;
+    for (uint32_t i = 0; i < np; i++) rank += (fresh[i] > sk) ? 1u : 0u;
+    if (rank < K) out[rank] = sk;
+  }
+  if (fk != 0ull) {
+    // stale entries above fk: the list is descending; entries equal to 0 (behind its end) are never above
+    uint32_t lo = 0, hi = KB_REPAIR_THREADS;
+    while (lo < hi) {
+      const uint32_t mid = (lo + hi) >> 1;
+      if (stale[mid] > fk) lo = mid + 1; else hi = mid;
+    }
+    uint32_t rank = alive_before[lo];
+    for (uint32_t i = 0; i < np; i++) rank += (fresh[i] > fk) ? 1u : 0u;
+    if (rank < K) out[rank] = fk;
+  }
+  // the tail: entries behind the merged list read 0
+  (void)n_fresh;
+  uint32_t cnt_fresh = 0;
+  for (uint32_t i = lane; i < np; i += 64) cnt_fresh += fresh[i] != 0ull ? 1u : 0u;   // every wave counts for itself (no further barrier)
+  for (int off = 32; off > 0; off >>= 1) cnt_fresh += (uint32_t)__shfl_xor((int)cnt_fresh, off);
+  const uint32_t total = alive_before[KB_REPAIR_THREADS] + cnt_fresh;
+  for (uint32_t i = total + tid; i < K; i += KB_REPAIR_THREADS) out[i] = 0ull;
+}
+void kb_launch_repair(const KbDev &d, const KbRound &r, void *stream) {
+  if (r.n_mrows == 0) return;
+  static bool attr_set = false;
+  const size_t sh = sizeof(unsigned long long) * (KB_REPAIR_THREADS + KB_K5_MAX_WINDOW) + sizeof(uint32_t) * (KB_REPAIR_THREADS + 1) + sizeof(uint32_t) * (d.NP / 32);
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_repair), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(k_repair, dim3(r.n_mrows), dim3(KB_REPAIR_THREADS), sh, (hipStream_t)stream, d, r);
 }
 
 __device__ __forceinline__ bool bit_test(const uint32_t *bm, uint32_t n) { return (bm[n >> 5] >> (n & 31)) & 1u; }

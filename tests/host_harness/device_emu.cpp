@@ -15,6 +15,8 @@
 
 #include <algorithm>
 #include <cstring>
+#include <mutex>
+#include <thread>
 #include <vector>
 
 #include "../../kube-batch_amd/csrc/kb_device.h"
@@ -128,6 +130,7 @@ void gather_row(const KbDev &d, const KbRound &r, uint32_t i) {
 uint32_t mrow_task(const KbRound &r, uint32_t m) { return r.mrows ? r.mrows[m] : r.mrow_task0 + m; }
 
 // ---- the sequential commit of one window (kb_commit.hip / kb_commit_batch.hip: same decisions, different statistics words) ----
+void remember_commit_nodes(const std::vector<uint32_t> &nodes);
 void emu_commit(const KbDev &d, const KbRound &r, bool batch_kernel) {
   if (r.n_rows == 0) return;
   u64 *o64 = out64(r);
@@ -271,6 +274,7 @@ void emu_commit(const KbDev &d, const KbRound &r, bool batch_kernel) {
   if (batch_kernel) { r.result[3] = 0; r.result[4] = 0; r.result[5] = (n_done + 15u) / 16u; r.result[6] = dirty_won; r.result[7] = 0; }
   else              { r.result[3] = dirty_won; r.result[4] = n_done; r.result[5] = 0; r.result[6] = 0; r.result[7] = 0; }
   if (r.chain) *r.chain = reason == KB_REASON_DONE ? r.chain_tag : 0u;
+  remember_commit_nodes(dirty_nodes);   // what an overlapped matrix launch may have seen half-changed (kb_launch_matrix poisons it)
   o64[KB_OUT_STAMP0 + 2] = t_start;
   o64[KB_OUT_STAMP0 + 3] = kbemu_wall_clock();
   if (r.host_out) {   // fast rounds: header and decision records into the pinned mirror, the sequence number last
@@ -318,6 +322,19 @@ void kb_launch_gather(const KbDev &d, const KbRound &r, void *stream) {
   });
 }
 
+// Overlapped rounds (KbRound::ready): on the device the matrix launch of such a round runs on a second stream while the predecessor's commit
+// kernel is still changing nodes, so what it sees of THOSE nodes is arbitrary.  The emulated streams execute a launch where it is enqueued
+// (or on one worker per stream), which would hide that: the emulated matrix launch therefore POISONS its result for every node the last
+// commit changed (feasible with the top score, or infeasible, by a hash) — the repair launch must override exactly these, whatever they hold.
+static std::vector<uint32_t> g_last_commit_nodes;
+static std::mutex g_last_commit_mu;
+namespace {
+void remember_commit_nodes(const std::vector<uint32_t> &nodes) {
+  std::lock_guard<std::mutex> lk(g_last_commit_mu);
+  g_last_commit_nodes = nodes;
+}
+}
+
 void kb_launch_matrix(const KbDev &d, const KbRound &r, void *stream) {
   kbemu_enqueue((hipStream_t)stream, [d, r]() {
   if (r.n_mrows == 0) return;
@@ -336,6 +353,15 @@ void kb_launch_matrix(const KbDev &d, const KbRound &r, void *stream) {
       const uint32_t e = eval_pair(d, t, n, r.fit_mode, true);
       sc[n] = (uint16_t)(e & 0xFFFFu);
       if (e >> 16) mw[n >> 5] |= 1u << (n & 31);
+    }
+    if (r.ready != nullptr) {
+      std::lock_guard<std::mutex> lk(g_last_commit_mu);
+      for (uint32_t n : g_last_commit_nodes) {
+        if (n >= d.N) continue;
+        const uint32_t h = (n * 2654435761u) ^ (m * 40503u) ^ (uint32_t)r.ready_tag;
+        if (h & 4u) { sc[n] = (uint16_t)(0xFFFFu - (h >> 20)); mw[n >> 5] |= 1u << (n & 31); }
+        else { sc[n] = 0; mw[n >> 5] &= ~(1u << (n & 31)); }
+      }
     }
   }
   });
@@ -428,6 +454,50 @@ void kb_launch_argmax(const KbDev &d, const KbRound &r, void *stream) {
     for (uint32_t n = 0; n < d.NP; n++)
       if (mask_bit(mw, n)) keys.push_back(KB_KEY(sc[n], n));
     std::sort(keys.begin(), keys.end(), [](u64 a, u64 b) { return a > b; });   // score descending, node ascending
+    u64 *out = r.keys + (size_t)m * r.L;
+    for (uint32_t i = 0; i < r.L; i++) out[i] = i < keys.size() ? keys[i] : 0ull;
+    if (r.ready != nullptr) __atomic_store_n(&r.ready[m], r.ready_tag, __ATOMIC_RELEASE);
+  }
+  });
+}
+
+// k_repair's contract: per matrix row, the stale list (r.stale, r.stale_L entries) without the predecessor's nodes (r.prev_dec, r.n_prev
+// records), plus those nodes evaluated against the state the predecessor left, best first, r.L entries, 0-padded
+void kb_launch_repair(const KbDev &d, const KbRound &r, void *stream) {
+  kbemu_enqueue((hipStream_t)stream, [d, r]() {
+  if (r.n_mrows == 0) return;
+  if (KB_CHAIN_BROKEN(r)) return;
+  out64(r)[KB_OUT_STAMP0] = kbemu_wall_clock();
+  out64(r)[KB_OUT_STAMP0 + 1] = out64(r)[KB_OUT_STAMP0];
+  std::vector<uint32_t> prev;
+  for (uint32_t i = 0; i < r.n_prev; i++) {
+    const uint32_t n = (uint32_t)(r.prev_dec[i] & 0xFFFFFFFFull);
+    if (n != KB_NONE_U32) prev.push_back(n);
+  }
+  std::sort(prev.begin(), prev.end());
+  prev.erase(std::unique(prev.begin(), prev.end()), prev.end());
+  std::vector<u64> keys;
+  for (uint32_t m = 0; m < r.n_mrows; m++) {
+    const double t0 = (double)kbemu_wall_clock();
+    while (__atomic_load_n(&r.ready[m], __ATOMIC_ACQUIRE) != r.ready_tag) {   // asynchronous emulated streams: the other worker is still on it
+      std::this_thread::yield();
+      if ((double)kbemu_wall_clock() - t0 > 3.0e9) { if (r.chain) *r.chain = 0u; return; }   // the bounded wait of the kernel
+    }
+    const Row t = row_of_task(d, mrow_task(r, m));
+    keys.clear();
+    const u64 *st = r.stale + (size_t)m * r.stale_L;
+    if (getenv("KB_EMU_REPAIR_OFF")) {   // negative control: the stale list as it is (tests/test_emu_engine_cpu.py expects wrong decisions)
+      u64 *o = r.keys + (size_t)m * r.L;
+      for (uint32_t i = 0; i < r.L; i++) o[i] = st[i];
+      continue;
+    }
+    for (uint32_t i = 0; i < r.stale_L && st[i] != 0ull; i++)
+      if (!std::binary_search(prev.begin(), prev.end(), KB_KEY_NODE(st[i]))) keys.push_back(st[i]);
+    for (uint32_t n : prev) {
+      const uint32_t e = eval_pair(d, t, n, r.fit_mode, true);
+      if (e >> 16) keys.push_back(KB_KEY(e & 0xFFFFu, n));
+    }
+    std::sort(keys.begin(), keys.end(), [](u64 a, u64 b) { return a > b; });
     u64 *out = r.keys + (size_t)m * r.L;
     for (uint32_t i = 0; i < r.L; i++) out[i] = i < keys.size() ? keys[i] : 0ull;
   }

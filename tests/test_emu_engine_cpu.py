@@ -206,3 +206,35 @@ def test_full_size_cycles_through_the_host_side(oracle_mod, name):
     if name in fs.mfg.FAST and os.environ.get("KB_EMU_FULLSIZE_5") != "1":
         pytest.skip("1M x 50k on the emulated device: set KB_EMU_FULLSIZE_5=1 (about 2.5 minutes)")
     fs.test_full_size_cycle_equals_oracle_and_golden_digest(oracle_mod, name)
+
+
+def test_overlapped_candidate_lists_are_repaired(emulated_engine, monkeypatch):
+    """Chained rounds of plain sessions build their candidate lists on a second stream beside the predecessor's commit kernel and repair them
+    behind it (kb_kernels.hip: k_repair).  The emulated matrix launch of such a round POISONS what it reports for the nodes
+    the last commit changed, so the decisions only come out right if the repair launch overrides exactly those: equal to the oracle with it,
+    different without it (KB_EMU_REPAIR_OFF=1 hands the stale lists on as they are — the negative control), and equal again on the plain
+    path (KB_OVERLAP=0)."""
+    oracle_mod = importlib.import_module("oracle")
+    snap = kbm.snapshot.synth(kbm.snapshot.synth_config(3, 0.05))
+    conf = kbm.conf.load_scheduler_conf()
+    o = oracle_mod.Oracle(conf, snap)
+    o.run(["allocate", "backfill"])
+
+    def cycle():
+        eng = engine.Engine(conf)
+        eng.load(snap)
+        dec = eng.run_allocate()
+        eng.run_backfill()
+        out = (np.array_equal(eng.binds(), o.binds()), eng.stats()["rounds"], len(dec))
+        eng.close()
+        return out
+
+    ok, rounds, _ = cycle()
+    assert ok and rounds > 10
+    monkeypatch.setenv("KB_EMU_REPAIR_OFF", "1")
+    broken, _, _ = cycle()
+    assert not broken                                   # the overlapped path was taken, and its stale lists alone are wrong
+    monkeypatch.delenv("KB_EMU_REPAIR_OFF")
+    monkeypatch.setenv("KB_OVERLAP", "0")
+    ok_plain, rounds_plain, _ = cycle()
+    assert ok_plain and rounds_plain == rounds
