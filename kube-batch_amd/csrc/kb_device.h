@@ -147,6 +147,8 @@ struct KbRound {
   // merges: `stale` [n_mrows][stale_L] -> keys [n_mrows][L].  ready == nullptr: not an overlapped round.
   uint32_t *ready;
   uint32_t ready_tag;
+  void *task_rows;                   // [n_mrows] 64-byte records: each row's task as the matrix kernel evaluates it, written by the arg-max launch in
+                                     // front of the tag (the repair launch then needs one load for it instead of a walk through the task arrays)
   const unsigned long long *stale;   // kb_launch_repair: the lists of the overlapped arg-max launch
   uint32_t stale_L;                  // >= n_prev + L: what is left of a stale list without the predecessor's nodes still holds the true top L
   const unsigned long long *prev_dec;   // decision records of the predecessor round (low word: node), n_prev of them

@@ -166,7 +166,7 @@ struct kb_engine {
   // beside its predecessor's commit kernel, into buffers of their own (matrix rows, stale lists per staging half, one `ready` word per
   // list, a scratch block for their time stamps); kb_launch_repair on the first stream turns the stale lists into the round's lists
   hipStream_t stream_b = nullptr;
-  DevBuf b_score2, b_maskw2, b_stale, b_ready, b_scratch_out;
+  DevBuf b_score2, b_maskw2, b_stale, b_ready, b_scratch_out, b_task_rows;
   uint32_t mat2_cap = 0;
   size_t stale_cap = 0;
   bool overlap = true;             // KB_OVERLAP=0: every round on the plain path (matrix -> arg-max -> commit on one stream)
@@ -476,6 +476,7 @@ void ensure_overlap_buffers(kb_engine *e, uint32_t mrows, uint32_t stale_L) {
   if (!e->b_ready.p) {
     e->b_ready.alloc(sizeof(uint32_t) * 2 * KB_K5_MAX_WINDOW);
     HIP_OK(hipMemset(e->b_ready.p, 0, e->b_ready.bytes));
+    e->b_task_rows.alloc((size_t)64 * 2 * KB_K5_MAX_WINDOW);
     e->b_scratch_out.alloc(sizeof(unsigned long long) * KB_OUT_HDR);
     HIP_OK(hipMemset(e->b_scratch_out.p, 0, e->b_scratch_out.bytes));
   }
@@ -494,12 +495,14 @@ void round_candidates_overlapped(kb_engine *e, const RoundCtx &c, uint32_t n_pre
   rb.result = e->b_scratch_out.as<uint32_t>();   // their time stamps do not belong to the round's timeline
   rb.ready = ready;
   rb.ready_tag = (uint32_t)c.seq;
+  rb.task_rows = reinterpret_cast<unsigned char *>(e->b_task_rows.p) + (size_t)c.buf * 64 * KB_K5_MAX_WINDOW;
   kb_launch_matrix(c.d, rb, e->stream_b);        // also gathers the row descriptors into this round's half (gather == 1)
   kb_launch_argmax(c.d, rb, e->stream_b);
   KbRound ra = c.r;   // first stream: behind the predecessor's commit kernel
   ra.keys = keys;
   ra.ready = ready;
   ra.ready_tag = (uint32_t)c.seq;
+  ra.task_rows = rb.task_rows;
   ra.stale = stale;
   ra.stale_L = stale_L;
   ra.prev_dec = e->b_out.as<unsigned long long>() + KB_OUT_HDR;   // the predecessor's decision records (it completed, or the chain is broken)
@@ -1403,14 +1406,15 @@ static int run_action(kb_engine *e, uint32_t action, kb_decision *out, uint64_t 
     run.probe_dead_shapes(e);   // shapes no node can take from the start (larger than every node, full classes) never cost a break
     uint32_t n = run.plan(e);
     ensure_matrix_buffers(e, e->eff_window, e->eff_window + 1);   // sized once: no reallocation under a round in flight
-    // chained rounds of plain sessions (cpu and memory only: the batch kernel writes scalar dimensions speculatively; no score that is
-    // normalised over the feasible set, no inter-pod counters) build their candidate lists beside the predecessor's commit kernel
-    const bool overlap_ok = e->overlap && action == 0 && e->fast_rounds && e->hs.R == 2 && !e->hs.has_affinity && !e->hs.has_interpod &&
-                            2 * e->eff_window + 1 <= 1024u;
+    // chained rounds of plain sessions (no score that is normalised over the feasible set, no inter-pod counters) build their candidate
+    // lists beside the predecessor's commit kernel.  With scalar dimensions only behind a predecessor on the run kernel: the batch kernel
+    // writes them speculatively for candidates it may hand back, i.e. on nodes that stay CLEAN, which no repair would look at again
+    const bool overlap_ok = e->overlap && action == 0 && e->fast_rounds && !e->hs.has_affinity && !e->hs.has_interpod && 2 * e->eff_window + 1 <= 1024u;
     auto launch = [&](uint32_t rows_n, const uint32_t *rows, uint32_t buf, uint32_t chain_expect, uint32_t n_prev) {
       RoundCtx c = round_prepare(e, rows_n, action == 0 ? 1 : 2, action == 1, true, rows, buf, chain_expect);   // single GPU: every matrix row is local
       unsigned long long *keys = e->b_keys.as<unsigned long long>();
-      if (overlap_ok && c.direct && chain_expect != 0 && !e->overlap_faults) round_candidates_overlapped(e, c, n_prev, keys);
+      if (overlap_ok && c.direct && chain_expect != 0 && !e->overlap_faults && (e->hs.R == 2 || e->commit_kernel_of[buf ^ 1u] == KB_COMMIT_RUN))
+        round_candidates_overlapped(e, c, n_prev, keys);
       else round_candidates(e, c, 0, c.ns, keys);
       round_commit(e, c, keys, nullptr, 0, 0);
       return c;

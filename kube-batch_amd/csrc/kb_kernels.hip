@@ -577,7 +577,9 @@ __global__ void __launch_bounds__(THREADS) k_argmax(KbDev d, KbRound r) {
   }
   if (found > K) found = K;
   for (uint32_t i = found + tid; i < K; i += THREADS) out[i] = 0ull;
-  if (r.ready != nullptr) {   // overlapped round: the list is complete and visible before its tag is
+  if (r.ready != nullptr) {   // overlapped round: the list (and the row's task record) is complete and visible before its tag is
+    static_assert(sizeof(K1Task) == 64, "KbRound::task_rows holds 64-byte records");
+    if (tid == 0 && r.task_rows != nullptr) reinterpret_cast<K1Task *>(r.task_rows)[row] = k1_task(d, r.mrows ? r.mrows[row] : r.mrow_task0 + row);
     __threadfence();
     __syncthreads();
     if (tid == 0) __hip_atomic_store(&r.ready[row], r.ready_tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
@@ -604,18 +606,20 @@ __global__ void __launch_bounds__(KB_REPAIR_THREADS) k_repair(KbDev d, KbRound r
   uint32_t *alive_before = reinterpret_cast<uint32_t *>(fresh + KB_K5_MAX_WINDOW);             // [KB_REPAIR_THREADS + 1] survivors in front of entry i
   uint32_t *bitmap = alive_before + KB_REPAIR_THREADS + 1;                                     // [NP / 32]
   __shared__ uint32_t s_wtot[KB_REPAIR_THREADS / 64];
-  __shared__ K1Task s_task;
   const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, row = blockIdx.x;
   if (KB_CHAIN_BROKEN(r)) return;
   if (row == 0 && tid == 0) {   // the round's matrix / arg-max stamps: the candidate launches ran beside the predecessor, this is what the round waits for
     unsigned long long *st = reinterpret_cast<unsigned long long *>(r.result);
-    const unsigned long long now = wall_clock64();
-    st[KB_OUT_STAMP0] = now; st[KB_OUT_STAMP0 + 1] = now;
+    st[KB_OUT_STAMP0] = wall_clock64();   // [+1] follows when row 0's tag has been seen: "matrix" time of such a round = what it waited for its lists
   }
+  // Latency is what this launch costs (it sits between two commit kernels): every load that does not depend on another is issued before the
+  // first wait.  The predecessor's decision records are final (kernel boundary), so its nodes are fetched while thread 0 still looks for the tag.
+  const uint32_t np = r.n_prev;
+  uint32_t node = KB_NONE_U32;
+  if (tid < np) node = (uint32_t)(r.prev_dec[tid] & 0xFFFFFFFFull);
   for (uint32_t w = tid; w < d.NP / 32; w += KB_REPAIR_THREADS) bitmap[w] = 0u;
   __shared__ uint32_t s_late;
-  if (tid == 0) {
-    s_task = k1_task(d, r.mrows ? r.mrows[row] : r.mrow_task0 + row);
+  if (tid == KB_REPAIR_THREADS - 1) {   // a thread without a decision record to fetch (n_prev <= the window < the workgroup): the tag's round trip runs beside that fetch
     // the list was launched (second stream) before this kernel (first stream) and had a whole commit kernel's time to finish: the wait is
     // normally over before it starts.  Bounded all the same: a list that never arrives breaks the chain — the commit kernel behind this one
     // then skips the round and the host launches it again on the plain path — instead of hanging the device.
@@ -626,31 +630,31 @@ __global__ void __launch_bounds__(KB_REPAIR_THREADS) k_repair(KbDev d, KbRound r
     }
     s_late = late;
     if (late && r.chain != nullptr) *r.chain = 0u;
+    if (row == 0) reinterpret_cast<unsigned long long *>(r.result)[KB_OUT_STAMP0 + 1] = wall_clock64();
   }
   __syncthreads();
   if (s_late) return;
-  // 1 + 2: the predecessor's nodes
-  const uint32_t np = r.n_prev;
-  unsigned long long fk = 0ull;
-  if (tid < np) {
-    const uint32_t node = (uint32_t)(r.prev_dec[tid] & 0xFFFFFFFFull);
-    if (node != KB_NONE_U32) {
-      const uint32_t old = atomicOr(&bitmap[node >> 5], 1u << (node & 31));
-      if (!((old >> (node & 31)) & 1u)) {   // this thread owns the node
-        const K1Task tv = k1_uniform(s_task);
-        K1Node nv[1];
-        nv[0] = k1_node(d, node);
-        uint32_t res[1];
-        eval_row<1>(d, tv, nv, node, r.fit_mode, res);
-        if (res[0] >> 16) fk = KB_KEY(res[0] & 0xFFFFu, node);
-      }
-    }
+  // 1 + 2, one round trip for all of it: the predecessor's nodes (a node may have taken several rows: one owner each) and their state; behind
+  // the tag, the row's task record and the stale list; then the owners evaluate (K1's own arithmetic)
+  bool owner = false;
+  K1Node nv[1];
+  nv[0].valid = 0;
+  if (node != KB_NONE_U32) {
+    const uint32_t old = atomicOr(&bitmap[node >> 5], 1u << (node & 31));
+    owner = !((old >> (node & 31)) & 1u);
+    if (owner) nv[0] = k1_node(d, node);
   }
-  if (tid < KB_K5_MAX_WINDOW) fresh[tid] = fk;
-  // the stale list (0-terminated, best first)
   const uint32_t Ls = r.stale_L;
   const unsigned long long sk = (tid < Ls) ? r.stale[(size_t)row * Ls + tid] : 0ull;
-  stale[tid] = sk;
+  unsigned long long fk = 0ull;
+  if (owner) {
+    const K1Task tv = k1_uniform(reinterpret_cast<const K1Task *>(r.task_rows)[row]);
+    uint32_t res[1];
+    eval_row<1>(d, tv, nv, node, r.fit_mode, res);
+    if (res[0] >> 16) fk = KB_KEY(res[0] & 0xFFFFu, node);
+  }
+  if (tid < KB_K5_MAX_WINDOW) fresh[tid] = fk;
+  stale[tid] = sk;   // 0-terminated, best first
   __syncthreads();
   // 3: survivors and their prefix counts
   const bool alive = sk != 0ull && !((bitmap[KB_KEY_NODE(sk) >> 5] >> (KB_KEY_NODE(sk) & 31)) & 1u);
@@ -665,10 +669,21 @@ __global__ void __launch_bounds__(KB_REPAIR_THREADS) k_repair(KbDev d, KbRound r
   __syncthreads();
   const uint32_t K = r.L;
   unsigned long long *out = r.keys + (size_t)row * K;
-  uint32_t n_fresh = 0;   // feasible new keys (uniform after the loop below only for thread-local use)
+  // new keys above a key: eight per step as four 16-byte LDS reads in flight together (one 8-byte read per step, each waited for, made this
+  // launch take 15 us; fresh[] reads 0 behind n_prev: every thread stored its key or 0)
+  const uint32_t np8 = (np + 7u) & ~7u;
+  auto fresh_above = [&](unsigned long long key) {
+    uint32_t c = 0;
+    for (uint32_t i = 0; i < np8; i += 8) {
+      const ulonglong2 a = *reinterpret_cast<const ulonglong2 *>(&fresh[i]), b = *reinterpret_cast<const ulonglong2 *>(&fresh[i + 2]);
+      const ulonglong2 e = *reinterpret_cast<const ulonglong2 *>(&fresh[i + 4]), f = *reinterpret_cast<const ulonglong2 *>(&fresh[i + 6]);
+      c += (a.x > key ? 1u : 0u) + (a.y > key ? 1u : 0u) + (b.x > key ? 1u : 0u) + (b.y > key ? 1u : 0u) +
+           (e.x > key ? 1u : 0u) + (e.y > key ? 1u : 0u) + (f.x > key ? 1u : 0u) + (f.y > key ? 1u : 0u);
+    }
+    return c;
+  };
   if (alive) {
-    uint32_t rank = before;
-    for (uint32_t i = 0; i < np; i++) rank += (fresh[i] > sk) ? 1u : 0u;
+    const uint32_t rank = before + fresh_above(sk);
     if (rank < K) out[rank] = sk;
   }
   if (fk != 0ull) {
@@ -678,12 +693,10 @@ __global__ void __launch_bounds__(KB_REPAIR_THREADS) k_repair(KbDev d, KbRound r
       const uint32_t mid = (lo + hi) >> 1;
       if (stale[mid] > fk) lo = mid + 1; else hi = mid;
     }
-    uint32_t rank = alive_before[lo];
-    for (uint32_t i = 0; i < np; i++) rank += (fresh[i] > fk) ? 1u : 0u;
+    const uint32_t rank = alive_before[lo] + fresh_above(fk);
     if (rank < K) out[rank] = fk;
   }
   // the tail: entries behind the merged list read 0
-  (void)n_fresh;
   uint32_t cnt_fresh = 0;
   for (uint32_t i = lane; i < np; i += 64) cnt_fresh += fresh[i] != 0ull ? 1u : 0u;   // every wave counts for itself (no further barrier)
   for (int off = 32; off > 0; off >>= 1) cnt_fresh += (uint32_t)__shfl_xor((int)cnt_fresh, off);
