@@ -271,7 +271,7 @@ def main():
     out = {
         "metric": f"pod-node scoring evals/sec + binds/sec, {_k(snap.n_tasks)} tasks x {_k(snap.n_nodes)} nodes snapshot",
         "value": value, "unit": "evals/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": elapsed * 1e3 / args.steps, "higher_is_better": True, "scaling": "weak" if dist_mode == "replicas" else "strong",
+        "ms_per_step": elapsed * 1e3 / args.steps, "higher_is_better": True, "scaling": "strong" if dist_mode == "sharded" else "weak",   # --gpus N runs N session replicas (per-GPU work fixed); only KB_DIST_MODE=sharded splits one session
         "vs_baseline": None, "dtype": "f64+i64", "data": "synthetic",
         "config": {"workload": f"BASELINE configs[{args.config - 1}]: {snap.n_tasks} tasks x {snap.n_nodes} nodes, "
                                f"{snap.n_jobs} gang jobs, {snap.n_queues} queues, R={R}, {'+'.join(actions)}, "

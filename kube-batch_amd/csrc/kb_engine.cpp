@@ -166,7 +166,9 @@ struct kb_engine {
   // beside its predecessor's commit kernel, into buffers of their own (matrix rows, stale lists per staging half, one `ready` word per
   // list, a scratch block for their time stamps); kb_launch_repair on the first stream turns the stale lists into the round's lists
   hipStream_t stream_b = nullptr;
-  DevBuf b_score2, b_maskw2, b_stale, b_ready, b_scratch_out, b_task_rows;
+  DevBuf b_score2, b_maskw2, b_stale, b_ready, b_task_rows;
+  Pinned<unsigned long long> h_cand_out;   // per staging half: the output-block words the second stream's launches stamp (start of the matrix launch, start of the arg-max launch)
+  unsigned long long *d_cand_out = nullptr;
   uint32_t mat2_cap = 0;
   size_t stale_cap = 0;
   bool overlap = true;             // KB_OVERLAP=0: every round on the plain path (matrix -> arg-max -> commit on one stream)
@@ -378,6 +380,7 @@ struct RoundCtx {
   bool direct = false;           // the kernels read the window from the pinned staging block (no copy command)
   uint32_t buf = 0;              // which half of the pinned upload / download blocks the round uses (chained rounds alternate)
   unsigned long long seq = 0;    // the sequence number its commit kernel publishes
+  bool overlapped = false;       // its candidate lists were built on the second stream and repaired (round_candidates_overlapped)
 };
 
 // upload the window e->h_rows[0..n) (task ids, shape slots, representative rows) and build the row descriptors
@@ -477,8 +480,10 @@ void ensure_overlap_buffers(kb_engine *e, uint32_t mrows, uint32_t stale_L) {
     e->b_ready.alloc(sizeof(uint32_t) * 2 * KB_K5_MAX_WINDOW);
     HIP_OK(hipMemset(e->b_ready.p, 0, e->b_ready.bytes));
     e->b_task_rows.alloc((size_t)64 * 2 * KB_K5_MAX_WINDOW);
-    e->b_scratch_out.alloc(sizeof(unsigned long long) * KB_OUT_HDR);
-    HIP_OK(hipMemset(e->b_scratch_out.p, 0, e->b_scratch_out.bytes));
+    e->h_cand_out.flags = hipHostMallocMapped | hipHostMallocCoherent;
+    e->h_cand_out.resize(2 * KB_OUT_HDR);
+    std::memset(e->h_cand_out.data(), 0, sizeof(unsigned long long) * 2 * KB_OUT_HDR);
+    HIP_OK(hipHostGetDevicePointer((void **)&e->d_cand_out, e->h_cand_out.data(), 0));
   }
 }
 void round_candidates_overlapped(kb_engine *e, const RoundCtx &c, uint32_t n_prev, unsigned long long *keys) {
@@ -492,7 +497,7 @@ void round_candidates_overlapped(kb_engine *e, const RoundCtx &c, uint32_t n_pre
   rb.maskw = e->b_maskw2.as<uint32_t>();
   rb.keys = stale;
   rb.L = stale_L;
-  rb.result = e->b_scratch_out.as<uint32_t>();   // their time stamps do not belong to the round's timeline
+  rb.result = reinterpret_cast<uint32_t *>(e->d_cand_out + (size_t)c.buf * KB_OUT_HDR);   // their time stamps, apart from the round's timeline (round_collect reads them)
   rb.ready = ready;
   rb.ready_tag = (uint32_t)c.seq;
   rb.task_rows = reinterpret_cast<unsigned char *>(e->b_task_rows.p) + (size_t)c.buf * 64 * KB_K5_MAX_WINDOW;
@@ -561,7 +566,14 @@ void round_collect(kb_engine *e, const RoundCtx &c, bool had_candidates, uint32_
     if (reason == KB_REASON_SKIPPED) return;   // queued behind a round that stopped early: nothing ran
     const unsigned long long *st = ho + KB_OUT_STAMP0;
     const double per_ms = 1.0 / e->wall_khz;
-    if (had_candidates) {
+    if (had_candidates && c.overlapped) {
+      // matrix: the launch itself, timed on the second stream (start of the matrix launch -> start of the arg-max launch behind it); it ran
+      // beside the predecessor's commit kernel, i.e. NOT on the cycle's timeline.  arg-max: what the round waits for on the first stream
+      // instead — the repair launch, from its start (its wait for the lists included) to the start of the commit kernel
+      const unsigned long long *cs = e->h_cand_out.data() + (size_t)c.buf * KB_OUT_HDR + KB_OUT_STAMP0;
+      if (cs[1] > cs[0]) e->stats.matrix_ms += (double)(cs[1] - cs[0]) * per_ms;
+      e->stats.argmax_ms += (double)(st[2] - st[0]) * per_ms;
+    } else if (had_candidates) {
       e->stats.matrix_ms += (double)(st[1] - st[0]) * per_ms;   // includes the descriptor gather
       e->stats.argmax_ms += (double)(st[2] - st[1]) * per_ms;
     }
@@ -1413,8 +1425,10 @@ static int run_action(kb_engine *e, uint32_t action, kb_decision *out, uint64_t 
     auto launch = [&](uint32_t rows_n, const uint32_t *rows, uint32_t buf, uint32_t chain_expect, uint32_t n_prev) {
       RoundCtx c = round_prepare(e, rows_n, action == 0 ? 1 : 2, action == 1, true, rows, buf, chain_expect);   // single GPU: every matrix row is local
       unsigned long long *keys = e->b_keys.as<unsigned long long>();
-      if (overlap_ok && c.direct && chain_expect != 0 && !e->overlap_faults && (e->hs.R == 2 || e->commit_kernel_of[buf ^ 1u] == KB_COMMIT_RUN))
+      if (overlap_ok && c.direct && chain_expect != 0 && !e->overlap_faults && (e->hs.R == 2 || e->commit_kernel_of[buf ^ 1u] == KB_COMMIT_RUN)) {
         round_candidates_overlapped(e, c, n_prev, keys);
+        c.overlapped = true;
+      }
       else round_candidates(e, c, 0, c.ns, keys);
       round_commit(e, c, keys, nullptr, 0, 0);
       return c;
