@@ -1,0 +1,63 @@
+"""The exactness claim behind the overlapped candidate lists (kb_kernels.hip: k_repair), stated on plain integers:
+
+  a round's candidate list = the first L entries of its nodes in descending key order (key 0 = infeasible; keys are distinct, the node index is
+  part of them).  The overlapped launches see the TRUE key of every node the predecessor round leaves alone and an ARBITRARY key (old, new,
+  torn: anything, feasible or not) for the at most n_prev nodes it changes, and keep the first n_prev + L entries of that stale order.
+  Dropping the predecessor's nodes from the stale list and merging their true keys in gives the true list.
+
+The bound is tight: one entry less and a counterexample exists (the second test builds it).  This is the model; the kernel's own merge (block
+scan + binary search + counts) is checked against the oracle on the device (`-m gpu`) and, as a contract, on the emulated device."""
+import random
+
+import pytest
+
+
+def top(keys, n):
+    """descending, feasible only, at most n"""
+    return sorted((k for k in keys if k), reverse=True)[:n]
+
+
+def repaired(stale_keys, true_keys, changed, L, stale_len):
+    node_of = {k: i for i, k in enumerate(stale_keys) if k}
+    stale_list = top(stale_keys, stale_len)
+    survivors = [k for k in stale_list if node_of[k] not in changed]
+    fresh = [true_keys[i] for i in changed if true_keys[i]]
+    return sorted(survivors + fresh, reverse=True)[:L]
+
+
+def make_case(rng, n_nodes, n_prev, p_infeasible):
+    # distinct keys: (score << 20) | (2^20 - 1 - node), like KB_KEY's order (score descending, node ascending)
+    def key(score, node):
+        return (score + 1) << 20 | (0xFFFFF - node)
+    true_keys = [0 if rng.random() < p_infeasible else key(rng.randrange(0, 40), i) for i in range(n_nodes)]
+    changed = set(rng.sample(range(n_nodes), min(n_prev, n_nodes)))
+    stale_keys = list(true_keys)
+    for i in changed:   # whatever the overlapped launch happened to see: infeasible, the old key, a wildly better or worse one
+        stale_keys[i] = rng.choice([0, true_keys[i], key(rng.randrange(0, 40), i), key(10_000, i), key(0, i)])
+    return true_keys, stale_keys, changed
+
+
+@pytest.mark.parametrize("seed", range(200))
+def test_repaired_list_is_the_true_list(seed):
+    rng = random.Random(seed)
+    n_nodes = rng.choice([1, 2, 5, 40, 300, 2000])
+    n_prev = rng.choice([0, 1, 3, 17, 64, 256])
+    L = rng.choice([1, 2, 9, 65, 257])
+    true_keys, stale_keys, changed = make_case(rng, n_nodes, n_prev, rng.choice([0.0, 0.3, 0.95]))
+    assert repaired(stale_keys, true_keys, changed, L, len(changed) + L) == top(true_keys, L)
+    assert repaired(stale_keys, true_keys, changed, L, n_prev + L) == top(true_keys, L)      # what the engine asks for (n_prev rows >= nodes changed)
+
+
+def test_the_bound_is_tight():
+    """n_prev changed nodes whose stale keys all sit on top push a needed clean node out of a stale list that is one entry short."""
+    n_prev, L, n_nodes = 4, 3, 20
+    key = lambda score, node: (score + 1) << 20 | (0xFFFFF - node)
+    true_keys = [key(5, i) for i in range(n_nodes)]
+    changed = set(range(10, 10 + n_prev))
+    stale_keys = list(true_keys)
+    for i in changed:
+        stale_keys[i] = key(1000, i)            # looked great to the overlapped launch ...
+        true_keys[i] = 0                        # ... and is full now
+    want = top(true_keys, L)
+    assert repaired(stale_keys, true_keys, changed, L, n_prev + L) == want
+    assert repaired(stale_keys, true_keys, changed, L, n_prev + L - 1) != want
