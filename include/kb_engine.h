@@ -309,7 +309,11 @@ const char *kb_last_error(const kb_engine *e);   /* valid until the next call on
 
 int  kb_session_load(kb_engine *e, const kb_snapshot *snap);
 /* restore the loaded session to its just-loaded state from the pristine copy kept in HBM (device-to-device);
-   the snapshot is not read again.  Used to run the same cycle repeatedly (bench steps) without a host upload. */
+   the snapshot is not read again.  Used to run the same cycle repeatedly (bench steps) without a host upload.
+   The copies are queued on the engine's stream and the call returns without waiting for them: the actions that follow are
+   ordered behind them on that stream, and every other entry point that looks at the state (the getters, the evict actions,
+   kb_engine_use_stream, kb_session_load) waits first.  The drf / proportion / gang aggregates come back from the host copies
+   made when the session was loaded (the restored state is bit for bit the one that reduction saw). */
 int  kb_session_reset(kb_engine *e);
 
 int  kb_run_allocate(kb_engine *e, kb_decision *out, uint64_t cap, uint64_t *n_out);
