@@ -24,12 +24,15 @@ pytestmark = [pytest.mark.gpu]
 
 # ---- every launch-path variant of the host protocol gives the same cycle ------------------------------------------------------
 _VARIANTS = [{}, {"KB_CHAIN_ROUNDS": "0"}, {"KB_SYNC_ROUNDS": "1"}, {"KB_PROBE": "0"}, {"KB_DIRECT_WINDOW": "0"},
-             {"KB_COMMIT_KERNEL": "run"}, {"KB_COMMIT_KERNEL": "batch"}, {"KB_CHAIN_ROUNDS": "0", "KB_PROBE": "0", "KB_DIRECT_WINDOW": "0"}]
+             {"KB_COMMIT_KERNEL": "run"}, {"KB_COMMIT_KERNEL": "batch"}, {"KB_CHAIN_ROUNDS": "0", "KB_PROBE": "0", "KB_DIRECT_WINDOW": "0"},
+             # round 3: chained rounds build their candidate lists on a second stream beside the predecessor's commit and repair them
+             # (the default, variant 0); KB_OVERLAP=0 keeps every round on one stream
+             {"KB_OVERLAP": "0"}, {"KB_OVERLAP": "0", "KB_COMMIT_KERNEL": "run"}]
 
 
 @pytest.mark.parametrize("variant", range(len(_VARIANTS)))
 def test_launch_path_variants_agree_with_the_oracle(oracle_mod, variant, monkeypatch):
-    """Chained rounds, the pinned mailbox, the direct window, the feasibility probe and the commit-kernel pin only change HOW the
+    """Chained rounds, the pinned mailbox, the direct window, the feasibility probe, the commit-kernel pin and the overlapped candidate lists only change HOW the
     host drives the device (kb_engine_create reads the switches): decisions, binds, node state and shares stay the oracle's."""
     import test_gpu_fuzz as fz
     for k, v in _VARIANTS[variant].items():
