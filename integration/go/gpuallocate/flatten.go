@@ -538,7 +538,11 @@ func flatten(ssn *framework.Session) (*flat, error) {
 				tprot[t] = 1 // plugins/conformance/conformance.go:44-58 (read by preempt / reclaim)
 			}
 			tnode[t] = C.KB_NONE
-			if idx, ok := nodeIdx[ti.NodeName]; ok && ti.NodeName != "" {
+			// a terminated pod keeps its Spec.NodeName but was never added to that node's Tasks (cache/event_handlers.go:72-92 addTask:
+			// !isTerminated): for the snapshot it is on no node.  (Round 3: such a task used to trip the "not in that node's Tasks" check
+			// below, i.e. every session with a finished pod went to the stock action.)
+			terminated := ti.Status == api.Succeeded || ti.Status == api.Failed
+			if idx, ok := nodeIdx[ti.NodeName]; ok && ti.NodeName != "" && !terminated {
 				tnode[t] = idx
 			}
 			if ti.Status == api.Pending && ti.NodeName != "" {
@@ -549,7 +553,7 @@ func flatten(ssn *framework.Session) (*flat, error) {
 				f.free()
 				return nil, errUnsupported("pending task with a stale NodeName (un-pipelined by a discarded statement)")
 			}
-			if ti.NodeName != "" {
+			if ti.NodeName != "" && !terminated {
 				// The snapshot says "task_node set <=> the task is in that node's Tasks".  A statement that pipelined a task carrying a
 				// stale NodeName only logs the failed AddTask (statement.go:113-150): the task is then Pipelined, named after its old
 				// host and on no node at all — a state the arrays cannot express (inside one loaded session the engine tracks it

@@ -802,8 +802,12 @@ def flatten(nodes: List[Node], pods: List[Pod], pod_groups: List[PodGroup], queu
         return want, conflict
 
     others_on_nodes = []
+    # cache/event_handlers.go:72-92 addTask: a pod with a NodeName enters that node's Tasks unless it is terminated (Succeeded / Failed):
+    # a finished pod keeps its Spec.NodeName but holds nothing on the node — no Idle, no pod slot, no port (found by tests/objref_fit.py,
+    # round 3: every terminated pod used to be accounted on its old node)
+    terminated = (abi.TASK_SUCCEEDED, abi.TASK_FAILED)
     for p in other_pods:                                 # pods of other schedulers / jobs outside the session
-        if p.node_name in nidx:
+        if p.node_name in nidx and _task_status(p) not in terminated:
             res, _, _, nzc, nzm = pod_vectors(p)
             if account_on_node(nidx[p.node_name], _task_status(p), res, nzc, nzm):
                 node_ports[nidx[p.node_name]] |= np.uint64(port_masks(p)[0])
@@ -832,7 +836,7 @@ def flatten(nodes: List[Node], pods: List[Pod], pod_groups: List[PodGroup], queu
             t_want[k] = want; t_conf[k] = conflict
             # plugins/conformance/conformance.go:44-58
             t_prot[k] = int(p.namespace == "kube-system" or p.priority_class_name in ("system-cluster-critical", "system-node-critical"))
-            if p.node_name in nidx:
+            if p.node_name in nidx and st not in terminated:
                 if account_on_node(nidx[p.node_name], st, res, nzc, nzm):
                     t_node[k] = nidx[p.node_name]
                     node_ports[nidx[p.node_name]] |= np.uint64(want)

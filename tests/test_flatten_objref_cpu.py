@@ -1,0 +1,177 @@
+"""The flattener against an object-level restatement (tests/objref_fit.py).
+
+Engine and oracle both start from snapshot.flatten's arrays, so every other differential test would miss a flattening mistake that both sides
+then agree on.  Here random Kubernetes-shaped clusters (labels, taints, conditions, selectors, required node affinity incl. Gt / Lt and
+matchFields, tolerations, host ports with wildcard addresses, init containers, extended resources, pods in every phase, pods of other
+schedulers) are flattened and the oracle's feasibility mask for every Pending task — its resource fit and plugin predicates over the flattened
+arrays — is compared, pair by pair, with what objref_fit.py derives from the objects themselves."""
+import importlib
+import random
+
+import numpy as np
+import pytest
+
+import objref_fit as ref
+
+kbm = importlib.import_module("kube-batch_amd")
+S = kbm.snapshot
+
+ZONES = ["a", "b", "c"]
+TAINT_KEYS = ["dedicated", "gpu", "spot"]
+
+
+def cluster(seed):
+    rng = random.Random(seed)
+    n_nodes = rng.choice([1, 3, 8, 20])
+    nodes, cap = [], {}
+    for i in range(n_nodes):
+        cpu, mem_gi, pods = rng.choice([2, 4, 8, 16]), rng.choice([4, 8, 32]), rng.choice([2, 5, 110])
+        alloc = {"cpu": str(cpu), "memory": f"{mem_gi}Gi", "pods": str(pods)}
+        if rng.random() < 0.4:
+            alloc["nvidia.com/gpu"] = str(rng.choice([1, 4, 8]))
+        labels = {}
+        if rng.random() < 0.8:
+            labels["zone"] = rng.choice(ZONES)
+        if rng.random() < 0.5:
+            labels["gen"] = str(rng.choice([1, 2, 3, 10]))
+        if rng.random() < 0.2:
+            labels["gen"] = "x"                                   # not an integer: Gt / Lt fail on it
+        taints = [(rng.choice(TAINT_KEYS), rng.choice(["", "yes"]), rng.choice(["NoSchedule", "NoExecute", "PreferNoSchedule"]))
+                  for _ in range(rng.choice([0, 0, 0, 1, 2]))]
+        nodes.append(S.Node(f"n{i:02d}", alloc, labels=labels, taints=taints, unschedulable=rng.random() < 0.08, ready=rng.random() > 0.08,
+                            network_unavailable=rng.random() < 0.05, memory_pressure=rng.random() < 0.2, disk_pressure=rng.random() < 0.1,
+                            pid_pressure=rng.random() < 0.1))
+        cap[nodes[-1].name] = {"cpu": cpu * 1000, "memory": mem_gi * 1024, "pods": pods, "gpu": int(alloc.get("nvidia.com/gpu", 0))}
+
+    def requests():
+        r = {}
+        if rng.random() < 0.9:
+            r["cpu"] = rng.choice(["100m", "250m", "1", "1500m", "3"])
+        if rng.random() < 0.9:
+            r["memory"] = rng.choice(["64Mi", "512Mi", "1Gi", "3Gi", "5M"])
+        if rng.random() < 0.15:
+            r["nvidia.com/gpu"] = str(rng.choice([1, 2]))
+        return r
+
+    def tolerations():
+        out = []
+        for _ in range(rng.choice([0, 0, 1, 2])):
+            op = rng.choice(["Exists", "Equal", ""])
+            out.append((rng.choice(TAINT_KEYS + [""]) if op == "Exists" else rng.choice(TAINT_KEYS), op, "" if op == "Exists" else rng.choice(["", "yes"]),
+                        rng.choice(["", "NoSchedule", "NoExecute"])))
+        return out
+
+    def required():
+        if rng.random() < 0.7:
+            return None
+        terms = []
+        for _ in range(rng.choice([0, 1, 1, 2])):
+            exprs, fields = [], []
+            for _ in range(rng.choice([0, 1, 2])):
+                op = rng.choice(["In", "NotIn", "Exists", "DoesNotExist", "Gt", "Lt"])
+                if op in ("In", "NotIn"):
+                    exprs.append(("zone", op, tuple(rng.sample(ZONES, rng.choice([1, 2])))))
+                elif op in ("Gt", "Lt"):
+                    exprs.append(("gen", op, (str(rng.choice([1, 2, 5])),)))
+                else:
+                    exprs.append((rng.choice(["zone", "gen", "nope"]), op, ()))
+            if rng.random() < 0.3:
+                fields.append(("metadata.name", rng.choice(["In", "NotIn"]), (rng.choice(nodes).name,)))
+            terms.append((exprs, fields))
+        return terms
+
+    def ports():
+        return [(rng.choice(["", "0.0.0.0", "10.0.0.1", "10.0.0.2"]), rng.choice(["", "TCP", "UDP"]), rng.choice([0, 80, 80, 443, 8080]))
+                for _ in range(rng.choice([0, 0, 0, 1, 2]))]
+
+    pods, groups = [], []
+    n_groups = rng.choice([1, 2, 4])
+    for g in range(n_groups):
+        groups.append(S.PodGroup("ns", f"g{g}", min_member=rng.choice([1, 2]), queue="default"))
+    uid = 0
+
+    def place(p):
+        """put a pod on a random node that still has room for it (plain arithmetic on the generator's own capacity table)"""
+        res, _ = ref.pod_requests(p)
+        need = {"cpu": res.get("cpu", 0.0), "memory": res.get("memory", 0.0) / (1024 * 1024), "gpu": res.get("nvidia.com/gpu", 0.0) / 1000}
+        for name in rng.sample(list(cap), len(cap)):
+            c = cap[name]
+            if c["cpu"] - need["cpu"] >= 20 and c["memory"] - need["memory"] >= 20 and c["gpu"] >= need["gpu"]:
+                c["cpu"] -= need["cpu"]; c["memory"] -= need["memory"]; c["gpu"] -= need["gpu"]
+                return name
+        return ""
+
+    for _ in range(rng.choice([5, 15, 40])):
+        uid += 1
+        in_session = rng.random() < 0.8
+        kind = rng.choice(["pending", "pending", "pending", "running", "running", "bound", "releasing", "done"])
+        p = S.Pod("ns", f"p{uid:03d}", [requests() for _ in range(rng.choice([1, 1, 2]))], group_name=(f"g{rng.randrange(n_groups)}" if in_session else ""),
+                  init_containers=[requests() for _ in range(rng.choice([0, 0, 1]))], node_selector=({"zone": rng.choice(ZONES)} if rng.random() < 0.25 else {}),
+                  tolerations=tolerations(), required_affinity=required(), host_ports=ports(), limits=([requests()] if rng.random() < 0.2 else []))
+        if kind == "pending":
+            p.phase = "Pending"
+        else:
+            p.node_name = place(p)
+            if not p.node_name:
+                continue
+            p.phase = {"running": "Running", "bound": "Pending", "releasing": "Running", "done": rng.choice(["Succeeded", "Failed"])}[kind]
+            p.deleting = kind == "releasing"
+        pods.append(p)
+    return nodes, pods, groups
+
+
+@pytest.mark.parametrize("seed", range(120))
+def test_flattened_mask_equals_the_object_level_answer(oracle_mod, seed):
+    nodes, pods, groups = cluster(seed)
+    pressure = (seed % 3 == 0, seed % 4 == 0, seed % 5 == 0)
+    snap = S.flatten(nodes, pods, groups, [S.Queue("default")], pressure=pressure)
+    want = ref.feasibility(nodes, pods, pressure)
+    tasks, node_names = snap.names["tasks"], snap.names["nodes"]
+    assert node_names == sorted(n.name for n in nodes)
+    # the node arrays themselves: Idle / Releasing of cpu and memory, pod count, the k8s scorers' non-zero request sums (non_zero.go:
+    # 100 milli-cpu / 200 MiB where a container names none)
+    by_name = {n.name: n for n in nodes}
+    for i, nn in enumerate(node_names):
+        on = [p for p in pods if p.node_name == nn and ref.task_status(p) not in ("Succeeded", "Failed")]
+        nv = ref.NodeView(by_name[nn], on)
+        assert snap.node_idle[0, i] == nv.idle.get("cpu", 0.0) and snap.node_idle[1, i] == nv.idle.get("memory", 0.0), (seed, nn)
+        assert snap.node_releasing[0, i] == nv.releasing.get("cpu", 0.0) and snap.node_releasing[1, i] == nv.releasing.get("memory", 0.0), (seed, nn)
+        assert snap.node_pod_cnt[i] == len(nv.pods) and snap.node_max_pods[i] == nv.max_pods, (seed, nn)
+        nzc = sum(S.quantity_milli_value(c["cpu"]) if "cpu" in c else 100 for p in on for c in p.containers)
+        nzm = sum(S.quantity_value(c["memory"]) if "memory" in c else 200 * 1024 * 1024 for p in on for c in p.containers)
+        assert snap.node_nz_cpu[i] == nzc and snap.node_nz_mem[i] == nzm, (seed, nn)
+    if snap.n_tasks == 0:
+        pytest.skip("no session task in this cluster")
+    o = oracle_mod.Oracle(kbm.conf.load_scheduler_conf(), snap)
+    mask, _ = o.eval_matrix(0, snap.n_tasks, 1)
+    o.close()
+    checked = 0
+    for t, name in enumerate(tasks):
+        if snap.task_status[t] != kbm.abi.TASK_PENDING:
+            continue
+        for n, nn in enumerate(node_names):
+            got = bool((mask[t, n >> 3] >> (n & 7)) & 1)
+            assert got == want[(name, nn)], (seed, name, nn, got)
+            checked += 1
+    assert checked > 0 or not any(ref.task_status(p) == "Pending" and p.group_name for p in pods)
+
+
+def test_the_object_level_reference_sees_what_it_should():
+    """a hand-made cluster with one answer per rule, so that a reference that says yes to everything cannot pass the test above"""
+    n = S.Node("n1", {"cpu": "2", "memory": "4Gi", "pods": "2"}, labels={"zone": "a", "gen": "3"}, taints=[("dedicated", "yes", "NoSchedule")])
+    tol = [("dedicated", "Equal", "yes", "")]
+    mk = lambda **kw: S.Pod("ns", "p", [{"cpu": "1", "memory": "1Gi"}], tolerations=tol, **kw)
+    nv = ref.NodeView(n, [])
+    assert ref.may_place(mk(), nv)
+    assert not ref.may_place(S.Pod("ns", "p", [{"cpu": "1"}]), nv)                                        # taint not tolerated
+    assert not ref.may_place(mk(node_selector={"zone": "b"}), nv)
+    assert ref.may_place(mk(required_affinity=[([("gen", "Gt", ("2",))], [])]), nv)
+    assert not ref.may_place(mk(required_affinity=[([("gen", "Lt", ("2",))], [])]), nv)
+    assert not ref.may_place(mk(required_affinity=[]), nv)                                                # no term selects nothing
+    assert not ref.may_place(S.Pod("ns", "p", [{"cpu": "1"}], init_containers=[{"cpu": "3"}], tolerations=tol), nv)   # an init container decides
+    busy = ref.NodeView(n, [S.Pod("ns", "r", [{"cpu": "500m"}], node_name="n1", phase="Running", host_ports=[("", "", 80)])])
+    assert not ref.may_place(mk(host_ports=[("10.0.0.1", "TCP", 80)]), busy) and ref.may_place(mk(host_ports=[("10.0.0.1", "UDP", 80)]), busy)
+    full = ref.NodeView(n, [S.Pod("ns", f"r{i}", [{"cpu": "100m"}], node_name="n1", phase="Running") for i in range(2)])
+    assert not ref.may_place(mk(), full)                                                                  # pod cap
+    rel = ref.NodeView(n, [S.Pod("ns", "r", [{"cpu": "1500m", "memory": "1Gi"}], node_name="n1", phase="Running", deleting=True)])
+    assert ref.may_place(mk(), rel)                                                                       # fits Releasing, not Idle
