@@ -140,6 +140,25 @@ def test_flattened_mask_equals_the_object_level_answer(oracle_mod, seed):
         nzc = sum(S.quantity_milli_value(c["cpu"]) if "cpu" in c else 100 for p in on for c in p.containers)
         nzm = sum(S.quantity_value(c["memory"]) if "memory" in c else 200 * 1024 * 1024 for p in on for c in p.containers)
         assert snap.node_nz_cpu[i] == nzc and snap.node_nz_mem[i] == nzm, (seed, nn)
+    dims = snap.names["dims"]
+    for i, nn in enumerate(node_names):                      # Allocatable, every dimension (scalars in milli-units)
+        alloc = ref.resource_of(by_name[nn].allocatable)
+        for d, dn in enumerate(dims):
+            assert snap.node_allocatable[d, i] == alloc.get(dn, 0.0), (seed, nn, dn)
+        assert snap.node_alloc_cpu[i] == alloc.get("cpu", 0.0) and snap.node_alloc_mem[i] == alloc.get("memory", 0.0)
+    by_pod = {f"{p.namespace}/{p.name}": p for p in pods}
+    for t, name in enumerate(tasks):                          # Resreq / InitResreq of every task, every dimension; its non-zero request; its status
+        res, init = ref.pod_requests(by_pod[name])
+        for d, dn in enumerate(dims):
+            assert snap.task_resreq[d, t] == res.get(dn, 0.0) and snap.task_init_resreq[d, t] == init.get(dn, 0.0), (seed, name, dn)
+        p = by_pod[name]
+        assert snap.task_nz_cpu[t] == sum(S.quantity_milli_value(c["cpu"]) if "cpu" in c else 100 for c in p.containers)
+        assert snap.task_nz_mem[t] == sum(S.quantity_value(c["memory"]) if "memory" in c else 200 * 1024 * 1024 for c in p.containers)
+        st = {"Pending": kbm.abi.TASK_PENDING, "Bound": kbm.abi.TASK_BOUND, "Running": kbm.abi.TASK_RUNNING, "Releasing": kbm.abi.TASK_RELEASING,
+              "Succeeded": kbm.abi.TASK_SUCCEEDED, "Failed": kbm.abi.TASK_FAILED}[ref.task_status(p)]
+        assert snap.task_status[t] == st, (seed, name)
+        on_node = p.node_name and ref.task_status(p) not in ("Succeeded", "Failed")
+        assert snap.task_node[t] == (node_names.index(p.node_name) if on_node else kbm.abi.KB_NONE), (seed, name)
     if snap.n_tasks == 0:
         pytest.skip("no session task in this cluster")
     o = oracle_mod.Oracle(kbm.conf.load_scheduler_conf(), snap)
