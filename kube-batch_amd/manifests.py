@@ -73,7 +73,8 @@ def _node(doc) -> Node:
         taints=[(t.get("key", ""), t.get("value", "") or "", t.get("effect", "")) for t in spec.get("taints", []) or []],
         unschedulable=bool(spec.get("unschedulable", False)),
         ready=conds.get("Ready", "True") == "True",
-        network_unavailable=conds.get("NetworkUnavailable", "False") == "True",
+        # CheckNodeCondition (vendor/.../predicates/predicates.go:1688): the node is out unless the condition's status is False — Unknown too
+        network_unavailable=conds.get("NetworkUnavailable", "False") != "False",
         memory_pressure=conds.get("MemoryPressure") == "True", disk_pressure=conds.get("DiskPressure") == "True",
         pid_pressure=conds.get("PIDPressure") == "True",
     )

@@ -194,3 +194,92 @@ def test_the_object_level_reference_sees_what_it_should():
     assert not ref.may_place(mk(), full)                                                                  # pod cap
     rel = ref.NodeView(n, [S.Pod("ns", "r", [{"cpu": "1500m", "memory": "1Gi"}], node_name="n1", phase="Running", deleting=True)])
     assert ref.may_place(mk(), rel)                                                                       # fits Releasing, not Idle
+
+
+def _manifests(nodes, pods, groups):
+    """the same cluster as `kubectl get ... -o yaml` would print it (only what the loader reads)"""
+    docs = []
+    for i, n in enumerate(nodes):
+        conds = [{"type": "Ready", "status": "True" if n.ready else ("False" if i % 2 else "Unknown")}]
+        if n.network_unavailable:
+            conds.append({"type": "NetworkUnavailable", "status": "True" if i % 2 else "Unknown"})   # anything but False takes the node out
+        elif i % 3 == 0:
+            conds.append({"type": "NetworkUnavailable", "status": "False"})
+        for flag, typ in ((n.memory_pressure, "MemoryPressure"), (n.disk_pressure, "DiskPressure"), (n.pid_pressure, "PIDPressure")):
+            if flag:
+                conds.append({"type": typ, "status": "True"})
+        docs.append({"apiVersion": "v1", "kind": "Node", "metadata": {"name": n.name, "labels": dict(n.labels)},
+                     "spec": {"unschedulable": n.unschedulable, "taints": [{"key": k, "value": v, "effect": e} for k, v, e in n.taints]},
+                     "status": {"allocatable": dict(n.allocatable), "conditions": conds}})
+    for g in groups:
+        docs.append({"apiVersion": "scheduling.incubator.k8s.io/v1alpha1", "kind": "PodGroup", "metadata": {"name": g.name, "namespace": g.namespace},
+                     "spec": {"minMember": g.min_member, "queue": g.queue}})
+    docs.append({"apiVersion": "scheduling.incubator.k8s.io/v1alpha1", "kind": "Queue", "metadata": {"name": "default"}, "spec": {"weight": 1}})
+    for p in pods:
+        def container(req, j, with_ports):
+            c = {"name": f"c{j}", "resources": {"requests": dict(req)}}
+            if with_ports and p.host_ports:
+                c["ports"] = [dict({"containerPort": 1, "hostPort": port}, **({"hostIP": ip} if ip else {}), **({"protocol": pr} if pr else {}))
+                              for ip, pr, port in p.host_ports]
+            return c
+        spec = {"containers": [container(r, j, j == 0) for j, r in enumerate(p.containers)]}
+        if p.limits:
+            spec["containers"][0]["resources"]["limits"] = dict(p.limits[0])
+        if p.init_containers:
+            spec["initContainers"] = [container(r, j, False) for j, r in enumerate(p.init_containers)]
+        if p.node_name:
+            spec["nodeName"] = p.node_name
+        if p.node_selector:
+            spec["nodeSelector"] = dict(p.node_selector)
+        if p.tolerations:
+            spec["tolerations"] = [dict({"key": k, "effect": e}, **({"operator": op} if op else {}), **({"value": v} if v else {})) for k, op, v, e in p.tolerations]
+        if p.required_affinity is not None:
+            spec["affinity"] = {"nodeAffinity": {"requiredDuringSchedulingIgnoredDuringExecution": {"nodeSelectorTerms": [
+                dict(({"matchExpressions": [{"key": k, "operator": op, "values": list(v)} for k, op, v in ex]} if ex else {}),
+                     **({"matchFields": [{"key": k, "operator": op, "values": list(v)} for k, op, v in fl]} if fl else {})) for ex, fl in p.required_affinity]}}}
+        meta = {"name": p.name, "namespace": p.namespace}
+        if p.group_name:
+            meta["annotations"] = {"scheduling.k8s.io/group-name": p.group_name}
+        if p.deleting:
+            meta["deletionTimestamp"] = "2019-01-01T00:00:00Z"
+        docs.append({"apiVersion": "v1", "kind": "Pod", "metadata": meta, "spec": spec, "status": {"phase": p.phase}})
+    import yaml
+    return yaml.safe_dump_all(docs)
+
+
+@pytest.mark.parametrize("seed", range(0, 120, 3))
+def test_manifest_loader_round_trip(seed):
+    """the same cluster through kube-batch_amd/manifests.py (YAML as kubectl prints it -> objects -> flatten) gives the same arrays, and the object-level
+    reference gives the same answers on the loaded objects"""
+    manifests = importlib.import_module("kube-batch_amd.manifests")
+    nodes, pods, groups = cluster(seed)
+    a = S.flatten(nodes, pods, groups, [S.Queue("default")])
+    n2, p2, g2, q2 = manifests.load_cluster(_manifests(nodes, pods, groups), namespace="ns")
+    b = S.flatten(n2, p2, g2, q2)
+    assert a.names == b.names
+    for f in ("node_idle", "node_releasing", "node_allocatable", "node_pod_cnt", "node_max_pods", "node_nz_cpu", "node_nz_mem", "task_resreq",
+              "task_init_resreq", "task_status", "task_node", "task_job", "job_min_available", "node_ports", "task_port_want", "task_port_conflict"):
+        x, y = getattr(a, f), getattr(b, f)
+        assert (x is None and y is None) or np.array_equal(x, y), (seed, f)
+
+    def static_pairs(sn):   # class ids are labels (an absent toleration operator and "Equal" intern differently): compare what they MEAN per (task, node)
+        bit = lambda tc, nc: (sn.class_compat[(tc * sn.n_node_classes + nc) >> 3] >> ((tc * sn.n_node_classes + nc) & 7)) & 1
+        return [[bit(int(tc), int(nc)) for nc in sn.node_class] for tc in sn.task_class]
+    assert static_pairs(a) == static_pairs(b), seed
+    assert ref.feasibility(nodes, pods) == ref.feasibility(n2, p2)
+
+
+def test_network_unavailable_unknown_takes_the_node_out():
+    """CheckNodeCondition fails unless NetworkUnavailable's status is False (predicates.go:1688): "Unknown" is not False"""
+    manifests = importlib.import_module("kube-batch_amd.manifests")
+    text = """
+apiVersion: v1
+kind: Node
+metadata: {name: n1}
+status:
+  allocatable: {cpu: "4", memory: 8Gi, pods: "10"}
+  conditions: [{type: Ready, status: "True"}, {type: NetworkUnavailable, status: Unknown}]
+"""
+    nodes, _, _, _ = manifests.load_cluster(text)
+    assert nodes[0].network_unavailable and nodes[0].ready
+    assert not ref.may_place(S.Pod("ns", "p", [{"cpu": "1"}]), ref.NodeView(nodes[0], []))
