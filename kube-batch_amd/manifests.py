@@ -110,7 +110,7 @@ def _pod_terms(aff, field):
     return required, preferred
 
 
-def _pod(doc, namespace: str) -> Pod:
+def _pod(doc, namespace: str, scheduler_name: Optional[str] = None) -> Pod:
     meta, spec, status = doc.get("metadata", {}), doc.get("spec", {}) or {}, doc.get("status", {}) or {}
     aff = spec.get("affinity") or {}
     # inter-pod (anti)affinity: predicates p8 / priority a22, flattened into kb_interpod by snapshot.build_interpod
@@ -119,7 +119,19 @@ def _pod(doc, namespace: str) -> Pod:
     # a claim never vetoes a placement at this commit (snapshot.build_interpod: AssumePodVolumes finds no cached binding decision); it
     # only matters in a session with inter-pod terms, where flatten() reports the combination unsupported
     has_claim = any((v or {}).get("persistentVolumeClaim") is not None for v in spec.get("volumes") or [])
+    # without the group-name annotation the cache gives a pod kube-batch schedules a shadow PodGroup (cache/util.go:47-92): job id = its
+    # controller's UID or its own, minMember from the group-min-member annotation (1 when absent or not an integer)
+    ann = meta.get("annotations") or {}
+    shadow, shadow_min = "", 1
+    if not ann.get(GROUP_ANNOTATION) and scheduler_name and (spec.get("schedulerName") or "default-scheduler") == scheduler_name:
+        ctrl = [o for o in meta.get("ownerReferences") or [] if o.get("controller")]
+        shadow = str((ctrl[0].get("uid") if ctrl else None) or meta.get("uid") or f"{meta.get('namespace', namespace)}-{meta.get('name')}")
+        try:
+            shadow_min = int(ann.get("scheduling.k8s.io/group-min-member", 1))
+        except (TypeError, ValueError):
+            shadow_min = 1
     return Pod(
+        shadow_job=shadow, shadow_min_member=shadow_min,
         has_volume_claim=has_claim,
         namespace=meta.get("namespace", namespace),
         name=meta["name"],
@@ -165,7 +177,7 @@ def load_cluster(text: str, namespace: str = "default", default_queue: str = "de
         elif kind == "Pod":
             if scheduler_name and (spec.get("schedulerName") or "default-scheduler") != scheduler_name and not spec.get("nodeName"):
                 continue   # pending pod of another scheduler: never enters the cache's jobs (event_handlers.go:44-77)
-            pods.append(_pod(doc, namespace))
+            pods.append(_pod(doc, namespace, scheduler_name))
         elif kind == "PodGroup":
             pgs.append(PodGroup(meta.get("namespace", namespace), meta["name"], min_member=int(spec.get("minMember", 0) or 0),
                                 queue=spec.get("queue", "") or default_queue, creation=_ts(meta)))
@@ -176,8 +188,10 @@ def load_cluster(text: str, namespace: str = "default", default_queue: str = "de
             tmeta, tspec = tpl.get("metadata", {}) or {}, tpl["spec"]
             for i in range(int(spec.get("parallelism", 1) or 1)):
                 pods.append(_pod({"metadata": {"name": f"{meta['name']}-{i}", "namespace": meta.get("namespace", namespace),
-                                               "annotations": tmeta.get("annotations"), "creationTimestamp": meta.get("creationTimestamp")},
-                                  "spec": tspec, "status": {"phase": "Pending"}}, namespace))
+                                               "annotations": tmeta.get("annotations"), "creationTimestamp": meta.get("creationTimestamp"),
+                                               # the Job controller owns its pods: without a group annotation they share ONE shadow job
+                                               "ownerReferences": [{"controller": True, "uid": meta.get("uid") or f"{meta.get('namespace', namespace)}-{meta['name']}"}]},
+                                  "spec": tspec, "status": {"phase": "Pending"}}, namespace, scheduler_name))
     return nodes, pods, pgs, queues
 
 

@@ -121,6 +121,11 @@ class Pod:
     priority_class_name: str = ""       # conformance plugin: system-cluster-critical / system-node-critical are never evicted
     # resources.limits of every container and init container (only read for the pod's QoS class: the memory-pressure check)
     limits: List[Dict[str, str]] = field(default_factory=list)
+    # A pod WITHOUT the group-name annotation that kube-batch itself schedules gets a shadow PodGroup from the cache (cache/event_handlers.go:
+    # 45-68 getOrCreateJob, cache/util.go:47-92 createShadowPodGroup): job id = the UID of its controller, or its own; minMember = the
+    # group-min-member annotation or 1; the default queue.  shadow_job: that job id ("" = none: the pod is outside the session)
+    shadow_job: str = ""
+    shadow_min_member: int = 1
     # spec.volumes names a PersistentVolumeClaim.  Inside the session a claim cannot veto a placement (build_interpod's docstring has
     # the walk through AssumePodVolumes); it only matters together with inter-pod terms
     has_volume_claim: bool = False
@@ -706,6 +711,11 @@ def flatten(nodes: List[Node], pods: List[Pod], pod_groups: List[PodGroup], queu
         if qname not in qidx:
             continue
         pgs[f"{pg.namespace}/{pg.name}"] = pg
+    # shadow PodGroups (Pod.shadow_job): the job id is the bare UID, the group carries the first such pod's creation stamp, the default queue
+    for p in pods:
+        if not p.group_name and p.shadow_job and p.shadow_job not in pgs and default_queue in qidx:
+            pgs[p.shadow_job] = PodGroup(p.namespace, p.shadow_job, min_member=p.shadow_min_member, queue=default_queue, creation=p.creation,
+                                         priority=p.priority or 0)   # Spec.PriorityClassName = the pod's (cache/util.go:89): its resolved value
     job_ids = sorted(pgs)
     jidx = {j: i for i, j in enumerate(job_ids)}
     J = len(job_ids)
@@ -715,7 +725,7 @@ def flatten(nodes: List[Node], pods: List[Pod], pod_groups: List[PodGroup], queu
     for p in pods:
         if p.uid is None:
             p.uid = f"{p.namespace}-{p.name}"          # util.BuildPod (pkg/scheduler/util/test_utils.go:66-69)
-        jid = f"{p.namespace}/{p.group_name}" if p.group_name else ""
+        jid = f"{p.namespace}/{p.group_name}" if p.group_name else p.shadow_job
         if jid in jidx:
             job_tasks[jidx[jid]].append(p)
         else:

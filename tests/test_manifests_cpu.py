@@ -418,3 +418,44 @@ spec:
         manifests.load_snapshot(with_terms)
     running = with_terms.replace("spec:\n  containers", "status: {phase: Running}\nspec:\n  nodeName: n1\n  containers", 1)
     assert manifests.load_snapshot(running).interpod is not None      # a placed pod's claim is already bound: nothing to assume
+
+
+def test_pods_without_a_group_get_a_shadow_pod_group(oracle_mod):
+    """cache/event_handlers.go:45-68 + cache/util.go:47-92: a pod kube-batch schedules that carries no group-name annotation becomes a job of its own
+    (job id = its controller's UID, or its own UID; minMember from the group-min-member annotation, default 1; default queue); pods of one controller
+    share the job; a pod of another scheduler stays outside the session."""
+    text = """
+apiVersion: v1
+kind: Node
+metadata: {name: n1}
+status: {allocatable: {cpu: "8", memory: 16Gi, pods: "10"}}
+---
+apiVersion: v1
+kind: Pod
+metadata: {name: solo, namespace: ns, uid: zz-solo}
+spec: {schedulerName: kube-batch, containers: [{name: c, resources: {requests: {cpu: "1"}}}]}
+---
+apiVersion: v1
+kind: Pod
+metadata: {name: rs-a, namespace: ns, uid: u-a, ownerReferences: [{controller: true, uid: aa-rs}], annotations: {scheduling.k8s.io/group-min-member: "2"}}
+spec: {schedulerName: kube-batch, containers: [{name: c, resources: {requests: {cpu: "1"}}}]}
+---
+apiVersion: v1
+kind: Pod
+metadata: {name: rs-b, namespace: ns, uid: u-b, ownerReferences: [{controller: true, uid: aa-rs}], annotations: {scheduling.k8s.io/group-min-member: "2"}}
+spec: {schedulerName: kube-batch, containers: [{name: c, resources: {requests: {cpu: "1"}}}]}
+---
+apiVersion: v1
+kind: Pod
+metadata: {name: other, namespace: ns, uid: u-o}
+spec: {schedulerName: default-scheduler, containers: [{name: c, resources: {requests: {cpu: "1"}}}]}
+"""
+    snap = manifests.load_snapshot(text, scheduler_name="kube-batch")
+    assert snap.names["jobs"] == ["aa-rs", "zz-solo"]                    # bare UIDs, ascending
+    assert snap.names["tasks"] == ["ns/rs-a", "ns/rs-b", "ns/solo"]
+    assert snap.job_min_available.tolist() == [2, 1] and snap.job_task_begin.tolist() == [0, 2, 3]
+    o = oracle_mod.Oracle(kb.conf.load_scheduler_conf(), snap)
+    o.run(["allocate", "backfill"])
+    assert snap.bind_map(o.binds()) == {"ns/rs-a": "n1", "ns/rs-b": "n1", "ns/solo": "n1"}
+    # without naming the scheduler the loader cannot tell whose pods these are: they stay outside the session, as before
+    assert manifests.load_snapshot(text).n_tasks == 0
