@@ -438,6 +438,8 @@ typedef struct kbo_session {
      incrementally by ssn_allocate / ssn_pipeline (allocate and backfill only add; preempt / reclaim refuse such sessions). */
   int ip_on;
   uint32_t ip_C, ip_D, ip_P, ip_S, ip_Z, ip_Wc, ip_Wp;   /* Wc / Wp: 64-bit words per task mask */
+  uint32_t ip_Z0;        /* Z as the snapshot gave it: the pods it stands for never leave their ni.Tasks inside a session */
+  int32_t *ip_unb_n;     /* [N] pods with an empty Spec.NodeName that THIS session added to ni.Tasks of node n and that are still there */
   uint32_t *ip_ctr_dom, *ip_cls_dom, *ip_task_sig;
   int32_t *ip_ctr_count, *ip_ctr_total, *ip_cls_bound, *ip_cls_unbound, *ip_sig_weight;
   uint64_t *ip_task_inc, *ip_task_forbid, *ip_task_cls_inc;
@@ -746,6 +748,7 @@ static void interpod_placed(kbo_session *s, uint32_t t, uint32_t n, int allocate
     for (uint32_t p = 64 * w; m; p++, m >>= 1)
       if (m & 1) s->ip_cls_unbound[(size_t)p * s->N + n] += 1;
   }
+  s->ip_unb_n[n] += 1;
   if (n < s->ip_Z) s->ip_Z = n;
   if (!allocated) return;
   for (uint32_t w = 0; w < s->ip_Wc; w++) {
@@ -756,6 +759,43 @@ static void interpod_placed(kbo_session *s, uint32_t t, uint32_t n, int allocate
       uint32_t d = s->ip_ctr_dom[(size_t)c * s->N + n];
       if (d != KB_NONE) s->ip_ctr_count[(size_t)c * s->ip_D + d] += 1;
     }
+  }
+}
+/* The evict actions move pods the other way.  What each table counts decides what moves:
+     predicate counters (ip_ctr_*): the PodLister's pods = session tasks in an ALLOCATED status (plugins/util/util.go:37-60).  Evict makes its
+       victim Releasing (statement.go:36-69, session.go:317-354 -> job.UpdateTaskStatus): it leaves the list although it stays in ni.Tasks;
+       the undo of a discarded statement brings it back (statement.go:83-110);
+     priority classes (ip_cls_*): the pods in ni.Tasks (nodeorder builds its nodeInfo from node.Pods()): an eviction changes nothing there, a
+       Pipeline adds the preemptor (Spec.NodeName still empty: the "unbound" count, and Z), its undo takes it out again. */
+static void interpod_allocated_status(kbo_session *s, uint32_t t, int joins) {   /* task t (on its node) enters (+1) / leaves (-1) the allocated statuses */
+#ifdef KBO_NEGATIVE_CONTROL_NO_IP_EVICT   /* tests/test_interpod_oracle_cpu.py builds this variant to show that its cases notice */
+  return;
+#endif
+  if (!s->ip_on || !s->tasks[t].on_node) return;
+  const uint32_t n = s->tasks[t].node;
+  for (uint32_t w = 0; w < s->ip_Wc; w++) {
+    uint64_t m = s->ip_task_inc[(size_t)t * s->ip_Wc + w];
+    for (uint32_t c = 64 * w; m; c++, m >>= 1) {
+      if (!(m & 1)) continue;
+      s->ip_ctr_total[c] += joins;
+      uint32_t d = s->ip_ctr_dom[(size_t)c * s->N + n];
+      if (d != KB_NONE) s->ip_ctr_count[(size_t)c * s->ip_D + d] += joins;
+    }
+  }
+}
+static void interpod_unpipelined(kbo_session *s, uint32_t t, uint32_t n) {   /* a task this session pipelined leaves ni.Tasks of node n again */
+  if (!s->ip_on) return;
+  for (uint32_t w = 0; w < s->ip_Wp; w++) {
+    uint64_t m = s->ip_task_cls_inc[(size_t)t * s->ip_Wp + w];
+    for (uint32_t p = 64 * w; m; p++, m >>= 1)
+      if (m & 1) s->ip_cls_unbound[(size_t)p * s->N + n] -= 1;
+  }
+  s->ip_unb_n[n] -= 1;
+  if (n == s->ip_Z && s->ip_unb_n[n] == 0 && n != s->ip_Z0) {   /* Z = the first node (ascending) that holds any pod with an empty Spec.NodeName */
+    uint32_t z = s->ip_Z0;
+    for (uint32_t i = n + 1; i < s->N && i < s->ip_Z0; i++)
+      if (s->ip_unb_n[i] > 0) { z = i; break; }
+    s->ip_Z = z;
   }
 }
 static void eval_all_nodes_raw(kbo_session *s, const o_task *t, int fit_mode, uint8_t *feas, double *score);
@@ -1046,6 +1086,8 @@ kbo_session *kbo_open(const kb_config *cfg, const kb_snapshot *sn, int threads) 
     const kb_interpod *ip = sn->interpod;
     s->ip_on = 1;
     s->ip_C = ip->n_counters; s->ip_D = ip->n_domains ? ip->n_domains : 1; s->ip_P = ip->n_classes; s->ip_S = ip->n_sigs; s->ip_Z = ip->first_unbound_node;
+    s->ip_Z0 = s->ip_Z;
+    s->ip_unb_n = (int32_t *)calloc(s->N ? s->N : 1, sizeof(int32_t));
     s->ip_Wc = s->ip_C ? (s->ip_C + 63) / 64 : 1; s->ip_Wp = s->ip_P ? (s->ip_P + 63) / 64 : 1;
 #define IP_COPY(dst, src, type, count) do { size_t n_ = (size_t)(count); dst = (type *)malloc(sizeof(type) * (n_ ? n_ : 1)); if (n_) memcpy(dst, src, sizeof(type) * n_); } while (0)
     IP_COPY(s->ip_ctr_dom, ip->ctr_dom, uint32_t, (size_t)s->ip_C * s->N);
@@ -1080,7 +1122,7 @@ void kbo_close(kbo_session *s) {
   free(s->journal);
   free(s->ip_ctr_dom); free(s->ip_ctr_count); free(s->ip_ctr_total); free(s->ip_task_inc); free(s->ip_task_forbid); free(s->ip_task_require);
   free(s->ip_task_self); free(s->ip_cls_dom); free(s->ip_cls_bound); free(s->ip_cls_unbound); free(s->ip_task_cls_inc); free(s->ip_task_sig);
-  free(s->ip_sig_weight);
+  free(s->ip_sig_weight); free(s->ip_unb_n);
   free(s->tier_begin); free(s->plugins); free(s->decisions); free(s->bind_node); free(s->bind_order);
   free(s);
 }
@@ -1385,6 +1427,7 @@ static void stmt_push(stmt_t *st, uint8_t kind, uint32_t task) {
 static void stmt_evict(kbo_session *s, stmt_t *st, uint32_t t) {          /* statement.go:36-69 */
   s->mutations++;
   journal_push(s, KB_OP_EVICT, t, s->tasks[t].node, s->stmt_no);
+  interpod_allocated_status(s, t, -1);
   job_set_status(s, t, KB_TASK_RELEASING);
   node_update_task(s, t, KB_TASK_RELEASING);
   fire_deallocate_event(s, t);
@@ -1394,20 +1437,21 @@ static void stmt_unevict(kbo_session *s, uint32_t t) {                     /* st
   s->mutations++;
   job_set_status(s, t, KB_TASK_RUNNING);
   node_update_task(s, t, KB_TASK_RUNNING);
+  interpod_allocated_status(s, t, +1);
   fire_allocate_event(s, t);
 }
 static void stmt_pipeline(kbo_session *s, stmt_t *st, uint32_t t, uint32_t n) {   /* statement.go:113-150 */
   s->mutations++;
   journal_push(s, KB_OP_PIPELINE, t, n, s->stmt_no);
   job_set_status(s, t, KB_TASK_PIPELINED);
-  if (node_add_task(s, t, n, KB_TASK_PIPELINED) == 0) pfast_node_changed(s, n);
+  if (node_add_task(s, t, n, KB_TASK_PIPELINED) == 0) { pfast_node_changed(s, n); interpod_placed(s, t, n, 0); }
   fire_allocate_event(s, t);
   stmt_push(st, 1, t);
 }
 static void stmt_unpipeline(kbo_session *s, uint32_t t) {                  /* statement.go:155-190 */
   s->mutations++;
   job_set_status(s, t, KB_TASK_PENDING);
-  if (s->tasks[t].on_node) pfast_node_changed(s, s->tasks[t].node);
+  if (s->tasks[t].on_node) { pfast_node_changed(s, s->tasks[t].node); interpod_unpipelined(s, t, s->tasks[t].node); }
   node_remove_task(s, t);                        /* task.NodeName keeps the old host (node_info.go:217-243 never clears it) */
   fire_deallocate_event(s, t);
 }
@@ -1719,14 +1763,13 @@ static int preempt_one_fast(kbo_session *s, stmt_t *st, uint32_t preemptor, int 
 
 int kbo_preempt(kbo_session *s) {
   if (s->panic) return KBO_PANIC;
-  if (s->ip_on) return -3;   /* evictions would take pods OUT of the inter-pod counts: not restated (the engine refuses such sessions too) */
   node_index_build(s);
   for (uint32_t n = 0; n < s->N; n++) {        /* ports of pods outside the session stay on the node whatever moves */
     uint64_t mine = 0;
     for (uint32_t t = s->node_head[n]; t != KB_NONE; t = s->next_on_node[t]) mine |= s->tasks[t].port_want;
     s->nodes[n].base_ports = s->nodes[n].ports & ~mine;
   }
-  const int fast = s->fast && !(s->affinity && s->nodeorder_enabled);   /* NormalizeReduce over the feasible set: faithful */
+  const int fast = s->fast && !(s->affinity && s->nodeorder_enabled) && !s->ip_on;   /* NormalizeReduce over the feasible set / inter-pod counters that evictions change: faithful */
   uint8_t *feas = (uint8_t *)malloc(s->N ? s->N : 1);
   double *score = (double *)malloc(sizeof(double) * (s->N ? s->N : 1));
   uint32_t *order = (uint32_t *)malloc(sizeof(uint32_t) * (s->N ? s->N : 1));
@@ -1800,7 +1843,6 @@ static void record_eviction(kbo_session *s, uint32_t t) {
 }
 int kbo_reclaim(kbo_session *s) {
   if (s->panic) return KBO_PANIC;
-  if (s->ip_on) return -3;
   for (uint32_t n = 0; n < s->N; n++) {
     uint64_t mine = 0;
     for (uint32_t t = 0; t < s->T; t++) if (s->tasks[t].on_node && s->tasks[t].node == n) mine |= s->tasks[t].port_want;
@@ -1852,6 +1894,7 @@ int kbo_reclaim(kbo_session *s) {
         const uint32_t v = vic[i];
         record_eviction(s, v);                                             /* ssn.Evict: cache.Evict first */
         journal_push(s, KB_OP_EVICT, v, s->tasks[v].node, 0);
+        interpod_allocated_status(s, v, -1);
         job_set_status(s, v, KB_TASK_RELEASING);
         node_update_task(s, v, KB_TASK_RELEASING);
         fire_deallocate_event(s, v);

@@ -21,7 +21,7 @@ def _tiers(cfg):
     return out
 
 
-def random_cluster(seed, n_nodes=7, n_pods=22, n_jobs=5, tight=False, pool_size=8, weights=(1, 10, 100), templates=False, narrow=False):
+def random_cluster(seed, n_nodes=7, n_pods=22, n_jobs=5, tight=False, pool_size=8, weights=(1, 10, 100), templates=False, narrow=False, n_queues=1):
     """tight: node capacities and pod requests sized so that resources bind too (Pipelines, gangs that do not fit)"""
     rng = np.random.RandomState(4200 + seed)
     zones = ["z0", "z1", "z2"]
@@ -69,7 +69,8 @@ def random_cluster(seed, n_nodes=7, n_pods=22, n_jobs=5, tight=False, pool_size=
     pods, groups = [], []
     job_spec = {}
     for j in range(n_jobs):
-        groups.append(snapmod.PodGroup(namespace=nss[j % 2], name=f"pg{j}", min_member=int(rng.randint(1, 4)) if tight else 1, queue="default",
+        groups.append(snapmod.PodGroup(namespace=nss[j % 2], name=f"pg{j}", min_member=int(rng.randint(1, 4)) if tight else 1,
+                                       queue="default" if n_queues == 1 else f"q{j % n_queues}",
                                        creation=j, priority=int(rng.randint(0, 3)) if tight else 0))
     for i in range(n_pods):
         j = rng.randint(n_jobs + 1)                                       # n_jobs: a pod outside the session
@@ -116,6 +117,8 @@ def random_cluster(seed, n_nodes=7, n_pods=22, n_jobs=5, tight=False, pool_size=
             if p.phase == "Pending" and rng.uniform() < 0.5:
                 p.spec_node_name_empty = True                              # the cache's Binding: Spec.NodeName not written yet
         pods.append(p)
+    if n_queues > 1:                                                       # several queues with different weights: reclaim has something to take
+        return nodes, pods, groups, [snapmod.Queue(name=f"q{i}", weight=1 + 2 * i) for i in range(n_queues)]
     return nodes, pods, groups, [snapmod.Queue(name="default")]
 
 

@@ -95,3 +95,44 @@ def test_interpod_cases_place_pods_and_refuse_nodes(oracle_mod):
         refused += sum(1 for t in range(snap.n_tasks) for n in range(snap.n_nodes) if not S.interpod_predicate(t, n))
         o.close()
     assert placed > 200 and refused > 500, (placed, refused)
+
+
+# ---- preempt / reclaim in sessions with inter-pod terms (round 3) -------------------------------------------------------------------
+# An eviction takes its victim OUT of the predicate's pod list (Releasing is not an allocated status) while it stays in ni.Tasks, a Pipeline
+# adds the preemptor to ni.Tasks with an empty Spec.NodeName, a discarded statement undoes both.  The C oracle keeps the kb_interpod counts
+# incrementally through all of it; tests/pyref.py recounts them from the task statuses at every predicate / priority call (the PodLister's own
+# way): two independent routes to the same journal.
+EVICT_ORDERS_IP = [["preempt"], ["reclaim"], ["allocate", "preempt"], ["reclaim", "allocate", "backfill", "preempt"], ["preempt", "reclaim"], ["preempt", "preempt"]]
+
+
+def interpod_evict_case(seed):
+    rng = np.random.RandomState(7700 + seed)
+    nodes, pods, groups, queues = random_cluster(5000 + seed, n_nodes=int(rng.randint(3, 10)), n_pods=int(rng.randint(30, 110)), n_jobs=int(rng.randint(4, 10)),
+                                                 tight=True, n_queues=int(rng.choice([1, 2, 3])))
+    room = {n.name: [snapmod.quantity_milli_value(n.allocatable["cpu"]), snapmod.quantity_value(n.allocatable["memory"]) // (1 << 20), int(n.allocatable["pods"])] for n in nodes}
+    for p in pods:                                                         # what already runs (50m / 64Mi each) ...
+        if p.node_name:
+            r = room[p.node_name]; r[0] -= 50; r[1] -= 64; r[2] -= 1
+    for p in pods:                                                         # ... made worth taking where the node has the room: victims hold real capacity
+        if p.node_name and p.group_name and rng.uniform() < 0.8:
+            c, m = int(rng.choice([500, 1000, 2000])), int(rng.choice([512, 1024]))
+            r = room[p.node_name]
+            if r[0] - c >= 100 and r[1] - m >= 100 and r[2] >= 0:
+                r[0] -= c - 50; r[1] -= m - 64
+                p.containers = [{"cpu": f"{c}m", "memory": f"{m}Mi"}]
+    snap = snapmod.flatten(nodes, pods, groups, queues)
+    order = EVICT_ORDERS_IP[seed % len(EVICT_ORDERS_IP)]
+    text = (CONFS[seed % 2] or conf.DEFAULT_SCHEDULER_CONF).replace('actions: "allocate, backfill"', 'actions: "%s"' % ", ".join(order))
+    return conf.load_scheduler_conf(text), snap, order
+
+
+@pytest.mark.parametrize("seed", range(150))
+def test_oracle_equals_pyref_with_interpod_affinity_under_preempt_and_reclaim(oracle_mod, seed):
+    from test_pyref_vs_oracle import _pyref_vs_oracle_evict
+    try:
+        cfg, snap, order = interpod_evict_case(seed)
+    except (snapmod.UnsupportedSnapshot, ValueError) as e:
+        pytest.skip(str(e))
+    if snap.interpod is None:
+        pytest.skip("no pod-affinity term drawn")
+    _pyref_vs_oracle_evict(oracle_mod, cfg, snap, order, seed)   # evictions in order, task statuses and (sticky) node names, node state, shares, binds
