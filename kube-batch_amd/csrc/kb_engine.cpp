@@ -1525,7 +1525,10 @@ static int run_evict_action(kb_engine *e, bool reclaim, kb_stmt_op *out, uint64_
     if (e->tainted) throw EngineError(KB_E_STATE, "a preempt / reclaim call failed after touching the session's state: kb_session_load or kb_session_reset first");
     quiesce(e);
     HostSession &hs = e->hs;
-    if (hs.has_interpod)   // an eviction takes a pod OUT of the inter-pod counts (Running -> Releasing leaves api.AllocatedStatus): not modelled
+    // an eviction takes a pod OUT of the inter-pod predicate's pod list (Running -> Releasing leaves api.AllocatedStatus): modelled on the
+    // host side of the evict machine (kb_preempt.cpp: ip_*), the lists rebuilt on the device after every change; written and checked
+    // against the oracle on the emulated device in round 3 and off until its first run on the MI355X (KB_EVICT_INTERPOD=1)
+    if (hs.has_interpod && !evict_interpod_enabled())
       throw EngineError(KB_E_UNSUPPORTED, "preempt / reclaim in a session with inter-pod (anti)affinity terms is not modelled");
     // preempt with preferred node-affinity terms: the lists of such preemptors carry the NormalizeReduce'd score and are rebuilt after
     // every Pipeline instead of repaired (kb_preempt.cpp: preempt_walk).  Checked against the oracle on the CPU (tests/host_harness);
@@ -1587,6 +1590,7 @@ static int run_evict_action(kb_engine *e, bool reclaim, kb_stmt_op *out, uint64_
       r.mrows = e->b_mrows.as<uint32_t>();
       kb_launch_matrix(e->dev, r, e->stream);
       kb_launch_affinity(e->dev, r, e->stream);   // NodeAffinity priority over the row's feasible set (no-op without such terms)
+      kb_launch_interpod(e->dev, r, e->stream);   // InterPodAffinityPriority over the same set, against the counts uploaded last (no-op without such terms)
       kb_launch_argmax(e->dev, r, e->stream);
       e->h_listkeys.resize((size_t)N + 1);   // pinned, persistent: the copy is a DMA into place instead of a staged pageable copy into a fresh vector
       const size_t raw_n = (size_t)N + 1;
@@ -1612,6 +1616,25 @@ static int run_evict_action(kb_engine *e, bool reclaim, kb_stmt_op *out, uint64_
     std::vector<uint8_t> status = hs.t_status;
     std::vector<uint32_t> tnode = hs.t_node;
     pm.init(&hs, &e->pol, &ln, &status, &tnode, lists, refresh);
+    // inter-pod terms: the live counts (allocate / backfill of this session may have advanced them) come to the host; the machine keeps them
+    // current and puts them back on the device in front of every list it asks for, and once more when the action is over
+    IpLive ipl;
+    auto ip_upload = [&]() {
+      if (!ipl.ccnt.empty()) HIP_OK(hipMemcpyAsync(e->b_ip_ccnt.p, ipl.ccnt.data(), sizeof(int32_t) * ipl.ccnt.size(), hipMemcpyHostToDevice, e->stream));
+      if (!ipl.ctot.empty()) HIP_OK(hipMemcpyAsync(e->b_ip_ctot.p, ipl.ctot.data(), sizeof(int32_t) * ipl.ctot.size(), hipMemcpyHostToDevice, e->stream));
+      if (!ipl.punb.empty()) HIP_OK(hipMemcpyAsync(e->b_ip_punb.p, ipl.punb.data(), sizeof(int32_t) * ipl.punb.size(), hipMemcpyHostToDevice, e->stream));
+      HIP_OK(hipMemcpyAsync(e->b_ip_z.p, &ipl.z, sizeof(uint32_t), hipMemcpyHostToDevice, e->stream));
+      HIP_OK(hipStreamSynchronize(e->stream));   // the sources are this frame's vectors, and they change again before the next call
+    };
+    if (hs.has_interpod) {
+      ipl.NP = NP;
+      ipl.ccnt.resize((size_t)std::max(hs.ip_C, 1u) * hs.ip_D); ipl.ctot.resize(std::max(hs.ip_C, 1u)); ipl.punb.resize((size_t)std::max(hs.ip_P, 1u) * NP);
+      HIP_OK(hipMemcpy(ipl.ccnt.data(), e->b_ip_ccnt.p, sizeof(int32_t) * ipl.ccnt.size(), hipMemcpyDeviceToHost));
+      HIP_OK(hipMemcpy(ipl.ctot.data(), e->b_ip_ctot.p, sizeof(int32_t) * ipl.ctot.size(), hipMemcpyDeviceToHost));
+      HIP_OK(hipMemcpy(ipl.punb.data(), e->b_ip_punb.p, sizeof(int32_t) * ipl.punb.size(), hipMemcpyDeviceToHost));
+      HIP_OK(hipMemcpy(&ipl.z, e->b_ip_z.p, sizeof(uint32_t), hipMemcpyDeviceToHost));
+      pm.set_interpod(&ipl, ip_upload);
+    }
     // from here on a failure leaves state behind (a mid-action refresh may have updated nodes on the device; after the journal is out,
     // host and device state are committed): whatever throws below, the session is marked tainted and every kb_run_* answers KB_E_STATE
     // until kb_session_load / kb_session_reset (round-2 advisory: the cross-check at the end used to fail AFTER publishing results)
@@ -1622,6 +1645,7 @@ static int run_evict_action(kb_engine *e, bool reclaim, kb_stmt_op *out, uint64_
     if (pm.ops.size() > cap) throw EngineError(KB_E_CAPACITY, "journal buffer too small");   // no result was written; a refresh may have updated nodes on the device: load the session again before another action
     for (size_t i = 0; i < pm.ops.size(); i++) { out[i].op = pm.ops[i].op; out[i].task = pm.ops[i].task; out[i].node = pm.ops[i].node; out[i].stmt = pm.ops[i].stmt; }
     upload_live_nodes(e, ln, pm.touched_nodes);
+    if (hs.has_interpod) ip_upload();   // what the next action's kernels read
     hs.t_status = status;
     hs.t_node = tnode;
     pm.off_node_tasks(hs.t_off_node);

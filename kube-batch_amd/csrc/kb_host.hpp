@@ -179,6 +179,14 @@ struct HostSession {
   bool has_interpod = false;
   std::vector<uint8_t> t_ip_subject;       // [T] (empty: no inter-pod affinity in the session)
   std::vector<uint8_t> t_ip_checks;        // [T] the task has predicate checks (forbid bits or a required counter)
+  // the kb_interpod tables the evict actions need on the host (what a task joins and checks, the counters' node -> domain maps): the
+  // live counts themselves come back from the device when such an action starts (kb_engine.cpp: run_evict_action)
+  uint32_t ip_C = 0, ip_D = 1, ip_P = 0, ip_Wc = 1, ip_Wp = 1;
+  std::vector<uint64_t> ip_task_inc, ip_task_forbid;   // [T][ip_Wc]
+  std::vector<uint64_t> ip_task_cls_inc;               // [T][ip_Wp]
+  std::vector<uint16_t> ip_task_require;               // [T]
+  std::vector<uint8_t> ip_task_self;                   // [T]
+  std::vector<uint32_t> ip_ctr_dom;                    // [ip_C][N]
   std::vector<uint8_t> feas_ip_require;    // [n_feas_shapes]
   std::vector<uint32_t> feas_ip;           // [n_feas_shapes] id of the shape's (forbid, require, self) triple: dominance needs equality
   // plugin state

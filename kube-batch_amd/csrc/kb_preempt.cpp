@@ -288,8 +288,86 @@ void PreemptMachine::node_update(uint32_t t, int st) {
   recompute_minprio(n);
 }
 
+// ---- inter-pod (anti)affinity under the evict actions (behind KB_EVICT_INTERPOD=1) ----
+bool evict_interpod_enabled() {
+  const char *v = std::getenv("KB_EVICT_INTERPOD");
+  return v && v[0] == '1';
+}
+void PreemptMachine::set_interpod(IpLive *ip, std::function<void()> upload) {
+  ip_ = ip; ip_upload_ = std::move(upload);
+  ip_changed_ = false;
+  ip_z0_ = ip ? ip->z : KB_NONE;   // the pods Z stands for when the action starts stay where they are: only this action's Pipelines come and go
+  ip_unb_n_.assign(hs_->N ? hs_->N : 1, 0);
+}
+void PreemptMachine::ip_allocated_status(uint32_t t, int joins) {   // task t, in its node's Tasks, enters (+1) / leaves (-1) the allocated statuses
+#ifdef KB_NEGATIVE_CONTROL_NO_IP_EVICT   // a test build (tests/README.md): the differential cases must notice an eviction that leaves the counts alone
+  return;
+#endif
+  if (!ip_ || !on_node[t]) return;
+  const uint32_t n = (*tnode_)[t], Wc = hs_->ip_Wc;
+  for (uint32_t w = 0; w < Wc; w++) {
+    uint64_t m = hs_->ip_task_inc[(size_t)t * Wc + w];
+    for (uint32_t c = 64 * w; m; c++, m >>= 1) {
+      if (!(m & 1)) continue;
+      ip_->ctot[c] += joins;
+      const uint32_t d = hs_->ip_ctr_dom[(size_t)c * hs_->N + n];
+      if (d != KB_NONE) ip_->ccnt[(size_t)c * hs_->ip_D + d] += joins;
+    }
+  }
+  ip_changed_ = true;
+}
+void PreemptMachine::ip_placed(uint32_t t, uint32_t n) {   // a Pipeline put task t into ni.Tasks of node n (Spec.NodeName still empty)
+  if (!ip_) return;
+  const uint32_t Wp = hs_->ip_Wp;
+  for (uint32_t w = 0; w < Wp; w++) {
+    uint64_t m = hs_->ip_task_cls_inc[(size_t)t * Wp + w];
+    for (uint32_t p = 64 * w; m; p++, m >>= 1)
+      if (m & 1) ip_->punb[(size_t)p * ip_->NP + n] += 1;
+  }
+  ip_unb_n_[n] += 1;
+  if (n < ip_->z) ip_->z = n;
+  ip_changed_ = true;
+}
+void PreemptMachine::ip_unplaced(uint32_t t, uint32_t n) {   // ... and its undo takes it out again
+  if (!ip_) return;
+  const uint32_t Wp = hs_->ip_Wp;
+  for (uint32_t w = 0; w < Wp; w++) {
+    uint64_t m = hs_->ip_task_cls_inc[(size_t)t * Wp + w];
+    for (uint32_t p = 64 * w; m; p++, m >>= 1)
+      if (m & 1) ip_->punb[(size_t)p * ip_->NP + n] -= 1;
+  }
+  ip_unb_n_[n] -= 1;
+  if (n == ip_->z && ip_unb_n_[n] == 0 && n != ip_z0_) {   // Z = the first node (ascending) that holds any pod with an empty Spec.NodeName
+    uint32_t z = ip_z0_;
+    for (uint32_t i = n + 1; i < hs_->N && i < ip_z0_; i++)
+      if (ip_unb_n_[i] > 0) { z = i; break; }
+    ip_->z = z;
+  }
+  ip_changed_ = true;
+}
+// PodAffinityChecker.InterPodAffinityMatches on the kb_interpod counters (the arithmetic of kb_kernels.hip: interpod_ok, on the host's live counts)
+bool PreemptMachine::ip_predicate(uint32_t t, uint32_t n) const {
+  const uint32_t Wc = hs_->ip_Wc;
+  for (uint32_t w = 0; w < Wc; w++) {
+    uint64_t fb = hs_->ip_task_forbid[(size_t)t * Wc + w];
+    for (uint32_t c = 64 * w; fb; c++, fb >>= 1) {
+      if (!(fb & 1)) continue;
+      const uint32_t d = hs_->ip_ctr_dom[(size_t)c * hs_->N + n];
+      if (d != KB_NONE && ip_->ccnt[(size_t)c * hs_->ip_D + d] > 0) return false;
+    }
+  }
+  const uint32_t r = hs_->ip_task_require[t];
+  if (r != 0xFFFFu) {
+    const uint32_t d = hs_->ip_ctr_dom[(size_t)r * hs_->N + n];
+    if (!(d != KB_NONE && ip_->ccnt[(size_t)r * hs_->ip_D + d] > 0))
+      if (ip_->ctot[r] > 0 || !hs_->ip_task_self[t]) return false;
+  }
+  return true;
+}
+
 void PreemptMachine::evict(uint32_t t) {   // statement.go:36-69
   version_++;
+  ip_allocated_status(t, -1);
   set_status(t, KB_TASK_RELEASING);
   node_update(t, KB_TASK_RELEASING);
   fire_deallocate(t);
@@ -299,12 +377,13 @@ void PreemptMachine::unevict(uint32_t t) {   // statement.go:83-110
   version_++;
   set_status(t, KB_TASK_RUNNING);
   node_update(t, KB_TASK_RUNNING);
+  ip_allocated_status(t, +1);
   fire_allocate(t);
 }
 void PreemptMachine::pipeline(uint32_t t, uint32_t n) {   // statement.go:113-150 (an AddTask error is logged, the handlers still run)
   version_++;
   set_status(t, KB_TASK_PIPELINED);
-  if (node_add(t, n, KB_TASK_PIPELINED)) mark_dirty(n);
+  if (node_add(t, n, KB_TASK_PIPELINED)) { mark_dirty(n); ip_placed(t, n); }
   fire_allocate(t);
   ops.push_back(StmtOp{KB_OP_PIPELINE, t, n, stmt_no_});
 }
@@ -316,12 +395,13 @@ void PreemptMachine::pipeline_session(uint32_t t, uint32_t n) {
   ops.push_back(StmtOp{KB_OP_PIPELINE, t, n, stmt_no_});
   if (!node_add(t, n, KB_TASK_PIPELINED)) return;
   mark_dirty(n);
+  ip_placed(t, n);
   fire_allocate(t);
 }
 void PreemptMachine::unpipeline(uint32_t t) {   // statement.go:155-190; task.NodeName keeps the old host (RemoveTask never clears it)
   version_++;
   set_status(t, KB_TASK_PENDING);
-  if (on_node[t]) { const uint32_t n = (*tnode_)[t]; node_remove(t); mark_dirty(n); }
+  if (on_node[t]) { const uint32_t n = (*tnode_)[t]; ip_unplaced(t, n); node_remove(t); mark_dirty(n); }
   fire_deallocate(t);
 }
 void PreemptMachine::begin_stmt() {
@@ -443,6 +523,7 @@ bool PreemptMachine::host_eval(uint32_t t, uint32_t n, long long &score) const {
       if (!((hs_->compat[bit >> 3] >> (bit & 7)) & 1)) return false;
     }
     if (!hs_->t_conf.empty() && (nd_->ports[n] & hs_->t_conf[t])) return false;
+    if (ip_ && hs_->t_ip_checks[t] && !ip_predicate(t, n)) return false;   // predicates.go:249-262 (the score below is only read where lists are repaired: never with inter-pod terms)
   }
   if (!pol_->nodeorder_enabled) return true;
   const long long rc = nd_->nzc[n] + hs_->t_nzc[t], rm = nd_->nzm[n] + hs_->t_nzm[t], ac = nd_->ac[n], am = nd_->am[n];
@@ -532,11 +613,15 @@ bool PreemptMachine::needs_exact_list(uint32_t preemptor) const {
 bool PreemptMachine::preempt_walk(uint32_t preemptor, int mode) {
   // too many repaired nodes: bring the device up to date and rebuild the lists on demand.  Only the full walk below pays per dirty
   // node; with the priority rule deciding, a dirty node costs one evaluation when it is a candidate and nothing otherwise.
-  if ((dirty_nodes_.size() > 256 && !prio_prunes_) || (!dirty_nodes_.empty() && needs_exact_list(preemptor))) {
+  if ((dirty_nodes_.size() > 256 && !prio_prunes_) || (!dirty_nodes_.empty() && needs_exact_list(preemptor)) || (ip_ && (ip_changed_ || !dirty_nodes_.empty()))) {
     refresh_(dirty_nodes_);
     for (uint32_t n : dirty_nodes_) dirty_[n] = 0;
     dirty_nodes_.clear();
     std::fill(shape_have_.begin(), shape_have_.end(), 0);
+    if (ip_) {   // inter-pod terms: a placement or an eviction moves a whole topology domain, and the priority is normalised over the feasible
+      ip_upload_();   // set: no list survives a change; the device evaluates against the counts as they stand now
+      ip_changed_ = false;
+    }
   }
   const uint32_t sh = hs_->t_row_shape[preemptor];
   if (!shape_have_[sh]) {

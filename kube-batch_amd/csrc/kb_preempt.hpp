@@ -35,6 +35,18 @@ struct LiveNodes {
 
 // kb_run_preempt accepts sessions with preferred node-affinity terms unless KB_PREEMPT_NODE_AFFINITY=0 (read at every call)
 bool preempt_node_affinity_enabled();
+// kb_run_preempt / kb_run_reclaim accept sessions with inter-pod (anti)affinity terms only with KB_EVICT_INTERPOD=1 (round 3: written and
+// checked against the oracle on the emulated device; off until its first run on the MI355X — without it they answer KB_E_UNSUPPORTED)
+bool evict_interpod_enabled();
+
+// the live kb_interpod counts while an evict action runs (device -> host when it starts, host -> device before every list and when it ends)
+struct IpLive {
+  std::vector<int32_t> ccnt;   // [C][D] allocated-status pods per counter and domain
+  std::vector<int32_t> ctot;   // [C]
+  std::vector<int32_t> punb;   // [P][NP] pods with an empty Spec.NodeName per priority class and node
+  uint32_t z = KB_NONE;        // first node (ascending) holding a pod with an empty Spec.NodeName
+  uint32_t NP = 0;
+};
 
 class PreemptMachine {
  public:
@@ -46,6 +58,8 @@ class PreemptMachine {
 
   void init(const HostSession *hs, const Policy *pol, LiveNodes *live, std::vector<uint8_t> *status, std::vector<uint32_t> *tnode,
             ListFn lists, RefreshFn refresh);
+  // sessions with inter-pod terms: the live counts and how to put them on the device (call after init)
+  void set_interpod(IpLive *ip, std::function<void()> upload);
   void run();           // the preempt action
   void off_node_tasks(std::vector<uint8_t> &off) const;   // after run(): what the next action's init() must know (HostSession::t_off_node)
   void run_reclaim();   // the reclaim action (actions/reclaim/reclaim.go:41-193): no Statement, ssn.Evict / ssn.Pipeline act at once
@@ -86,6 +100,19 @@ class PreemptMachine {
   uint32_t fail_task_ = KB_NONE;
   int fail_mode_ = -1;
   std::vector<std::vector<int32_t>> shape_rank_;     // per shape: position of every node in the shape's list (-1: not in it)
+
+  // inter-pod (anti)affinity: an eviction takes its victim out of the predicate's pod list (Releasing is no allocated status: plugins/util/
+  // util.go:37-60) while it stays in ni.Tasks; a Pipeline adds the preemptor to ni.Tasks with an empty Spec.NodeName (the priority's
+  // "unbound" count, and Z); a discarded statement undoes both.  Lists are rebuilt from the device after every such change.
+  IpLive *ip_ = nullptr;
+  std::function<void()> ip_upload_;
+  bool ip_changed_ = false;
+  uint32_t ip_z0_ = KB_NONE;
+  std::vector<int32_t> ip_unb_n_;   // [N] pods this action pipelined onto the node and that are still there
+  void ip_allocated_status(uint32_t t, int joins);
+  void ip_placed(uint32_t t, uint32_t n);
+  void ip_unplaced(uint32_t t, uint32_t n);
+  bool ip_predicate(uint32_t t, uint32_t n) const;
 
   Res task_res(uint32_t t) const;
   Res task_init(uint32_t t) const;

@@ -303,7 +303,17 @@ void build_host_session(const kb_snapshot *sn, const Policy &pol, uint32_t NP, H
   for (uint32_t t = T; t-- > 0;) hs.feas_rep[hs.t_feas_shape[t]] = t;
   hs.has_interpod = ip != nullptr;
   hs.t_ip_subject.clear(); hs.feas_ip_require.clear(); hs.feas_ip.clear();
+  hs.ip_task_inc.clear(); hs.ip_task_forbid.clear(); hs.ip_task_cls_inc.clear(); hs.ip_task_require.clear(); hs.ip_task_self.clear(); hs.ip_ctr_dom.clear();
+  hs.ip_C = 0; hs.ip_D = 1; hs.ip_P = 0; hs.ip_Wc = 1; hs.ip_Wp = 1;
   if (ip) {
+    hs.ip_C = ip->n_counters; hs.ip_D = ip->n_domains ? ip->n_domains : 1; hs.ip_P = ip->n_classes;
+    hs.ip_Wc = hs.ip_C ? (hs.ip_C + 63) / 64 : 1; hs.ip_Wp = hs.ip_P ? (hs.ip_P + 63) / 64 : 1;
+    hs.ip_task_inc.assign(ip->task_inc, ip->task_inc + (size_t)T * hs.ip_Wc);
+    hs.ip_task_forbid.assign(ip->task_forbid, ip->task_forbid + (size_t)T * hs.ip_Wc);
+    hs.ip_task_cls_inc.assign(ip->task_cls_inc, ip->task_cls_inc + (size_t)T * hs.ip_Wp);
+    hs.ip_task_require.assign(ip->task_require, ip->task_require + T);
+    hs.ip_task_self.assign(ip->task_self, ip->task_self + T);
+    hs.ip_ctr_dom.assign(ip->ctr_dom, ip->ctr_dom + (size_t)hs.ip_C * N);
     hs.t_ip_subject.assign(T, 0);
     hs.feas_ip_require.assign(hs.n_feas_shapes, 0);
     hs.feas_ip.assign(hs.n_feas_shapes, 0);

@@ -238,3 +238,30 @@ def test_overlapped_candidate_lists_are_repaired(emulated_engine, monkeypatch):
     monkeypatch.setenv("KB_OVERLAP", "0")
     ok_plain, rounds_plain, _ = cycle()
     assert ok_plain and rounds_plain == rounds
+
+
+# ---- preempt / reclaim in sessions with inter-pod (anti)affinity terms (round 3, behind KB_EVICT_INTERPOD=1 until its first device run) ----
+@pytest.mark.parametrize("seed", range(150))
+def test_evict_actions_with_interpod_terms_equal_the_oracle(emulated_engine, monkeypatch, seed):
+    """The evict machine keeps the kb_interpod counts on the host (an eviction takes its victim out of the predicate's pod list, a Pipeline adds the
+    preemptor with an empty Spec.NodeName, a discarded statement undoes both), puts them on the device in front of every list it asks for, and
+    rebuilds every list after a change: journal, evictions, statuses, node state and shares equal the oracle's (which is itself held to
+    tests/pyref.py's recount-from-statuses on the same clusters: tests/test_interpod_oracle_cpu.py).  Without the switch: KB_E_UNSUPPORTED."""
+    import test_interpod_oracle_cpu as ipo
+    import test_gpu_preempt as gp
+    oracle_mod = importlib.import_module("oracle")
+    try:
+        cfg, snap, order = ipo.interpod_evict_case(seed)
+    except (kbm.snapshot.UnsupportedSnapshot, ValueError) as e:
+        pytest.skip(str(e))
+    if snap.interpod is None:
+        pytest.skip("no pod-affinity term drawn")
+    if seed % 25 == 0 and any(a in ("preempt", "reclaim") for a in order):        # the refusal stays the default
+        e = engine.Engine(cfg)
+        e.load(snap)
+        with pytest.raises(engine.EngineError) as err:
+            e.run(order)
+        assert err.value.code == abi.KB_E_UNSUPPORTED
+        e.close()
+    monkeypatch.setenv("KB_EVICT_INTERPOD", "1")
+    gp._run_both(oracle_mod, cfg, snap, order, seed)
