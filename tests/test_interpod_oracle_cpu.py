@@ -120,6 +120,9 @@ def interpod_evict_case(seed):
             if r[0] - c >= 100 and r[1] - m >= 100 and r[2] >= 0:
                 r[0] -= c - 50; r[1] -= m - 64
                 p.containers = [{"cpu": f"{c}m", "memory": f"{m}Mi"}]
+    for p in pods:                                                         # victims that keep others away: while such a pod is in an allocated status no pod
+        if p.node_name and p.group_name and p.phase == "Running" and rng.uniform() < 0.35:   # with the label may join its node (or zone); evicted, it no longer counts
+            p.pod_anti_affinity_required = [((), ((("app", ["a", "b", "c"][rng.randint(3)]),), ()), ["kubernetes.io/hostname", "zone"][rng.randint(2)])]
     snap = snapmod.flatten(nodes, pods, groups, queues)
     order = EVICT_ORDERS_IP[seed % len(EVICT_ORDERS_IP)]
     text = (CONFS[seed % 2] or conf.DEFAULT_SCHEDULER_CONF).replace('actions: "allocate, backfill"', 'actions: "%s"' % ", ".join(order))
