@@ -87,7 +87,7 @@ def cluster(seed):
     pods, groups = [], []
     n_groups = rng.choice([1, 2, 4])
     for g in range(n_groups):
-        groups.append(S.PodGroup("ns", f"g{g}", min_member=rng.choice([1, 2]), queue="default"))
+        groups.append(S.PodGroup("ns", f"g{g}", min_member=rng.choice([1, 2]), queue="default", creation=rng.randrange(1000), priority=rng.choice([0, 0, 5, 100])))
     uid = 0
 
     def place(p):
@@ -107,7 +107,8 @@ def cluster(seed):
         kind = rng.choice(["pending", "pending", "pending", "running", "running", "bound", "releasing", "done"])
         p = S.Pod("ns", f"p{uid:03d}", [requests() for _ in range(rng.choice([1, 1, 2]))], group_name=(f"g{rng.randrange(n_groups)}" if in_session else ""),
                   init_containers=[requests() for _ in range(rng.choice([0, 0, 1]))], node_selector=({"zone": rng.choice(ZONES)} if rng.random() < 0.25 else {}),
-                  tolerations=tolerations(), required_affinity=required(), host_ports=ports(), limits=([requests()] if rng.random() < 0.2 else []))
+                  tolerations=tolerations(), required_affinity=required(), host_ports=ports(), limits=([requests()] if rng.random() < 0.2 else []),
+                  priority=rng.choice([None, None, 0, 7, 1000]), creation=rng.randrange(1000))
         if kind == "pending":
             p.phase = "Pending"
         else:
@@ -159,6 +160,15 @@ def test_flattened_mask_equals_the_object_level_answer(oracle_mod, seed):
         assert snap.task_status[t] == st, (seed, name)
         on_node = p.node_name and ref.task_status(p) not in ("Succeeded", "Failed")
         assert snap.task_node[t] == (node_names.index(p.node_name) if on_node else kbm.abi.KB_NONE), (seed, name)
+        # what the order functions read: NewTaskInfo's priority (1 unless Spec.Priority is set, job_info.go:82-99), the creation stamp, the task's job
+        assert snap.task_priority[t] == (1 if p.priority is None else p.priority) and snap.task_creation[t] == p.creation, (seed, name)
+        assert snap.names["jobs"][snap.task_job[t]] == f"{p.namespace}/{p.group_name}", (seed, name)
+    for j, jid in enumerate(snap.names["jobs"]):              # jobs ascending JobID, with their PodGroup's minMember / priority / creation stamp, tasks ascending UID
+        g = [x for x in groups if f"{x.namespace}/{x.name}" == jid][0]
+        assert (snap.job_min_available[j], snap.job_priority[j], snap.job_creation[j]) == (g.min_member, g.priority, g.creation), (seed, jid)
+        mine = [tasks[t] for t in range(snap.job_task_begin[j], snap.job_task_begin[j + 1])]
+        assert mine == sorted(mine) and all(by_pod[nm].group_name == g.name for nm in mine), (seed, jid)
+    assert snap.names["jobs"] == sorted(snap.names["jobs"]) and sum(1 for p in pods if p.group_name) == snap.n_tasks
     if snap.n_tasks == 0:
         pytest.skip("no session task in this cluster")
     o = oracle_mod.Oracle(kbm.conf.load_scheduler_conf(), snap)
