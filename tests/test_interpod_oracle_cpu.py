@@ -105,7 +105,7 @@ def test_interpod_cases_place_pods_and_refuse_nodes(oracle_mod):
 EVICT_ORDERS_IP = [["preempt"], ["reclaim"], ["allocate", "preempt"], ["reclaim", "allocate", "backfill", "preempt"], ["preempt", "reclaim"], ["preempt", "preempt"]]
 
 
-def interpod_evict_case(seed):
+def interpod_evict_case(seed, objects=False):
     rng = np.random.RandomState(7700 + seed)
     nodes, pods, groups, queues = random_cluster(5000 + seed, n_nodes=int(rng.randint(3, 10)), n_pods=int(rng.randint(30, 110)), n_jobs=int(rng.randint(4, 10)),
                                                  tight=True, n_queues=int(rng.choice([1, 2, 3])))
@@ -126,6 +126,8 @@ def interpod_evict_case(seed):
     snap = snapmod.flatten(nodes, pods, groups, queues)
     order = EVICT_ORDERS_IP[seed % len(EVICT_ORDERS_IP)]
     text = (CONFS[seed % 2] or conf.DEFAULT_SCHEDULER_CONF).replace('actions: "allocate, backfill"', 'actions: "%s"' % ", ".join(order))
+    if objects:
+        return conf.load_scheduler_conf(text), snap, order, nodes, pods
     return conf.load_scheduler_conf(text), snap, order
 
 
@@ -139,3 +141,56 @@ def test_oracle_equals_pyref_with_interpod_affinity_under_preempt_and_reclaim(or
     if snap.interpod is None:
         pytest.skip("no pod-affinity term drawn")
     _pyref_vs_oracle_evict(oracle_mod, cfg, snap, order, seed)   # evictions in order, task statuses and (sticky) node names, node state, shares, binds
+
+
+@pytest.mark.parametrize("seed", range(150))
+def test_predicate_after_evict_actions_equals_the_object_level_answer(oracle_mod, seed):
+    """Oracle, pyref and engine agree with each other above — but all three read the kb_interpod TABLES.  Here the session the oracle leaves behind
+    after its evict actions (who is Releasing, who was pipelined where, who went back to Pending) is rebuilt as Kubernetes-shaped objects, and the
+    inter-pod predicate of every still-Pending task on every node is asked of tests/interpod_objref.py (labels, selectors, namespaces, topology
+    keys: no table) and compared with what the oracle's live counts answer: an eviction that left the counts alone, a Pipeline booked as allocated,
+    a discard that did not put a victim back would show here."""
+    import interpod_objref as objref
+    cfg, snap, order, nodes, pods = interpod_evict_case(seed, objects=True)
+    if snap.interpod is None:
+        pytest.skip("no pod-affinity term drawn")
+    nbits = snap.n_task_classes * snap.n_node_classes
+    all_compatible = all((snap.class_compat[b >> 3] >> (b & 7)) & 1 for b in range(nbits))
+    if snap.node_ports is not None or not all_compatible:
+        pytest.skip("other plugin predicates in play")           # random_cluster draws none: the mask below is pod cap + inter-pod only
+    o = oracle_mod.Oracle(cfg, snap)
+    try:
+        o.run(order)
+    except RuntimeError:
+        pytest.skip("the reference panics on this snapshot")
+    st, nd = o.task_state()
+    _, _, _, _, cnt = o.node_state()
+    nodes_sorted = sorted(nodes, key=lambda n: n.name)
+    by_name = {f"{p.namespace}/{p.name}": p for p in pods}
+    status_name = {abi.TASK_PENDING: "Pending", abi.TASK_ALLOCATED: "Allocated", abi.TASK_PIPELINED: "Pipelined", abi.TASK_BINDING: "Binding",
+                   abi.TASK_BOUND: "Bound", abi.TASK_RUNNING: "Running", abi.TASK_RELEASING: "Releasing"}
+    states = []
+    for t, name in enumerate(snap.names["tasks"]):
+        p = by_name[name]
+        on = int(st[t]) != abi.TASK_PENDING and int(nd[t]) != abi.KB_NONE        # an un-pipelined task keeps its NodeName but is in no ni.Tasks
+        opened_on_node = int(snap.task_node[t]) != abi.KB_NONE
+        spec = (p.node_name if not p.spec_node_name_empty else "") if opened_on_node else ""   # placed by this session: Spec.NodeName still empty
+        states.append(objref.PodState(p, nodes_sorted[int(nd[t])].name if on else None, status_name[int(st[t])], spec))
+    session = set(snap.names["tasks"])
+    for p in pods:
+        if f"{p.namespace}/{p.name}" not in session and p.node_name:
+            s_ = objref.PodState(p, p.node_name, "Running", "" if p.spec_node_name_empty else p.node_name)
+            s_.in_session = False
+            states.append(s_)
+    W = objref.World(nodes, states)
+    pending = [t for t in range(snap.n_tasks) if int(st[t]) == abi.TASK_PENDING]
+    if not pending:
+        pytest.skip("nothing left pending")
+    mask, _ = o.eval_matrix(0, snap.n_tasks, 0)                                  # plugin predicates only, against the session as it stands
+    for t in pending:
+        pod = by_name[snap.names["tasks"][t]]
+        for n, node in enumerate(nodes_sorted):
+            want = bool(snap.node_max_pods[n] > cnt[n]) and objref.predicate(W, pod, node)
+            got = bool((mask[t, n >> 3] >> (n & 7)) & 1)
+            assert got == want, (seed, order, snap.names["tasks"][t], node.name, got, want)
+    o.close()
