@@ -877,7 +877,8 @@ struct ActionRun {
         }
         if (reason == KB_REASON_SKIPPED && i == n_done) {
           // only an overlapped round whose candidate lists never arrived skips itself behind a predecessor that completed (k_repair's
-          // bounded wait): nothing was decided; the task heads the next window, which goes the plain way (and so does the rest of the action)
+          // bounded wait): nothing was decided; the task heads the next window, which goes the plain way — and so does every round of this
+          // engine from now on (overlap_faults is never cleared: a launch that got lost on the second stream is not expected to heal)
           e->overlap_faults += 1;
           om.rollback_last_pop();
           popped--;

@@ -456,7 +456,11 @@ void kb_launch_argmax(const KbDev &d, const KbRound &r, void *stream) {
     std::sort(keys.begin(), keys.end(), [](u64 a, u64 b) { return a > b; });   // score descending, node ascending
     u64 *out = r.keys + (size_t)m * r.L;
     for (uint32_t i = 0; i < r.L; i++) out[i] = i < keys.size() ? keys[i] : 0ull;
-    if (r.ready != nullptr) __atomic_store_n(&r.ready[m], r.ready_tag, __ATOMIC_RELEASE);
+    // KB_EMU_DROP_TAG=k: every k-th overlapped round never publishes its lists (what a launch that failed on the second stream would look like):
+    // the repair launch must give up after its bounded wait and break the chain, the engine must run that round again on the plain path
+    const int drop = getenv("KB_EMU_DROP_TAG") ? atoi(getenv("KB_EMU_DROP_TAG")) : 0;   // read per launch: tests switch it on and off inside one process
+    const bool dropped = r.ready != nullptr && drop > 0 && (r.ready_tag % (uint32_t)drop) == 0;
+    if (r.ready != nullptr && !dropped) __atomic_store_n(&r.ready[m], r.ready_tag, __ATOMIC_RELEASE);
   }
   });
 }
@@ -481,7 +485,8 @@ void kb_launch_repair(const KbDev &d, const KbRound &r, void *stream) {
     const double t0 = (double)kbemu_wall_clock();
     while (__atomic_load_n(&r.ready[m], __ATOMIC_ACQUIRE) != r.ready_tag) {   // asynchronous emulated streams: the other worker is still on it
       std::this_thread::yield();
-      if ((double)kbemu_wall_clock() - t0 > 3.0e9) { if (r.chain) *r.chain = 0u; return; }   // the bounded wait of the kernel
+      const double bound = getenv("KB_EMU_REPAIR_WAIT_NS") ? atof(getenv("KB_EMU_REPAIR_WAIT_NS")) : 3.0e9;
+      if ((double)kbemu_wall_clock() - t0 > bound) { if (r.chain) *r.chain = 0u; return; }   // the bounded wait of the kernel
     }
     const Row t = row_of_task(d, mrow_task(r, m));
     keys.clear();

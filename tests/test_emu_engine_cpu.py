@@ -265,3 +265,27 @@ def test_evict_actions_with_interpod_terms_equal_the_oracle(emulated_engine, mon
         e.close()
     monkeypatch.setenv("KB_EVICT_INTERPOD", "1")
     gp._run_both(oracle_mod, cfg, snap, order, seed)
+
+
+def test_a_candidate_list_that_never_arrives_breaks_the_chain_and_the_round_runs_again(emulated_engine, monkeypatch):
+    """k_repair's wait for its lists is bounded: a list that never arrives (here: the emulated arg-max launch of every third overlapped round
+    drops its tag) makes it break the chain, the commit kernel behind it skips the round, the host takes the skipped round back, counts the fault
+    and keeps every later round of that engine on the plain path — same decisions as the oracle, no hang, no wrong bind."""
+    oracle_mod = importlib.import_module("oracle")
+    snap = kbm.snapshot.synth(kbm.snapshot.synth_config(3, 0.05))
+    conf = kbm.conf.load_scheduler_conf()
+    o = oracle_mod.Oracle(conf, snap)
+    o.run(["allocate", "backfill"])
+    monkeypatch.setenv("KB_EMU_DROP_TAG", "3")
+    monkeypatch.setenv("KB_EMU_REPAIR_WAIT_NS", "2e6")
+    for _ in range(2):                                   # twice: the fault must not outlive the action that met it
+        eng = engine.Engine(conf)
+        eng.load(snap)
+        dec = eng.run_allocate()
+        eng.run_backfill()
+        assert np.array_equal(dec, o.decisions()[: len(dec)]) and np.array_equal(eng.binds(), o.binds())
+        eng.reset()
+        dec2 = eng.run_allocate()
+        eng.run_backfill()
+        assert np.array_equal(dec2, dec) and np.array_equal(eng.binds(), o.binds())
+        eng.close()
