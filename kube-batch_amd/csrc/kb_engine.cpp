@@ -1339,6 +1339,7 @@ int kb_session_load(kb_engine *e, const kb_snapshot *sn) {
     d.pred_enabled = e->pol.pred_enabled ? 1 : 0;
     d.score_enabled = e->pol.nodeorder_enabled ? 1 : 0;
     e->win_cap = 0; e->mat_cap = 0; e->keys_cap = 0;
+    e->mat2_cap = 0; e->stale_cap = 0;   // the second stream's matrix rows are [rows][NP] too: a session with more nodes needs them again
     e->stats = kb_stats{};
     e->dirty_share = 0.0;
     e->commit_kernel = e->commit_pin >= 0 ? e->commit_pin : KB_COMMIT_BATCH;

@@ -289,3 +289,23 @@ def test_a_candidate_list_that_never_arrives_breaks_the_chain_and_the_round_runs
         eng.run_backfill()
         assert np.array_equal(dec2, dec) and np.array_equal(eng.binds(), o.binds())
         eng.close()
+
+
+def test_one_engine_through_sessions_of_growing_size(emulated_engine):
+    """The Go action keeps ONE engine and loads a new session every cycle; clusters grow.  Every buffer sized by the node count must follow
+    (round 3: the second stream's matrix rows of the overlapped rounds kept the first session's size — found by review; with a small window and a
+    cluster that grows from 8 to 20 000 nodes two matrix rows no longer fit, which scripts/sanitize_cpu.sh's AddressSanitizer pass reports)."""
+    oracle_mod = importlib.import_module("oracle")
+    conf = kbm.conf.load_scheduler_conf()
+    S = kbm.snapshot
+    eng = engine.Engine(conf, window=16)
+    for n_tasks, n_nodes in ((64, 8), (200, 20000), (400, 300), (300, 45000)):
+        snap = S.synth(S.SynthParams(n_tasks=n_tasks, n_nodes=n_nodes, n_queues=4, n_res=2, seed=S.SEED_BASE + 77 + n_nodes))
+        o = oracle_mod.Oracle(conf, snap)
+        o.run(["allocate", "backfill"])
+        eng.load(snap)
+        eng.run_allocate()
+        eng.run_backfill()
+        assert np.array_equal(eng.binds(), o.binds()), (n_tasks, n_nodes)
+        o.close()
+    eng.close()
