@@ -499,14 +499,14 @@ void round_candidates_overlapped(kb_engine *e, const RoundCtx &c, uint32_t n_pre
   rb.L = stale_L;
   rb.result = reinterpret_cast<uint32_t *>(e->d_cand_out + (size_t)c.buf * KB_OUT_HDR);   // their time stamps, apart from the round's timeline (round_collect reads them)
   rb.ready = ready;
-  rb.ready_tag = (uint32_t)c.seq;
+  rb.ready_tag = c.r.chain_tag;   // the round's own tag (sequence number folded to 31 bits, + 1): unique among the rounds in flight, never the 0 the words start from
   rb.task_rows = reinterpret_cast<unsigned char *>(e->b_task_rows.p) + (size_t)c.buf * 64 * KB_K5_MAX_WINDOW;
   kb_launch_matrix(c.d, rb, e->stream_b);        // also gathers the row descriptors into this round's half (gather == 1)
   kb_launch_argmax(c.d, rb, e->stream_b);
   KbRound ra = c.r;   // first stream: behind the predecessor's commit kernel
   ra.keys = keys;
   ra.ready = ready;
-  ra.ready_tag = (uint32_t)c.seq;
+  ra.ready_tag = c.r.chain_tag;
   ra.task_rows = rb.task_rows;
   ra.stale = stale;
   ra.stale_L = stale_L;
