@@ -354,7 +354,10 @@ void kb_launch_matrix(const KbDev &d, const KbRound &r, void *stream) {
       sc[n] = (uint16_t)(e & 0xFFFFu);
       if (e >> 16) mw[n >> 5] |= 1u << (n & 31);
     }
-    if (r.ready != nullptr) {
+    // (with asynchronous emulated streams, KB_EMU_ASYNC=1, the launch really runs beside the predecessor and "the last commit" may be an
+    // older round whose nodes are final and are NOT repaired: no poison then, the staleness is real)
+    static const bool async_streams = getenv("KB_EMU_ASYNC") && getenv("KB_EMU_ASYNC")[0] == '1';
+    if (r.ready != nullptr && !async_streams) {
       std::lock_guard<std::mutex> lk(g_last_commit_mu);
       for (uint32_t n : g_last_commit_nodes) {
         if (n >= d.N) continue;
