@@ -1,0 +1,55 @@
+#!/usr/bin/env bash
+# First GPU call of round 4: what round 3 wrote or fixed WITHOUT a device after its GPU budget was spent, against the real kernels, before anything
+# else is built on it.  Usage on the GPU box:  bash scripts/first_gpu_call_r4.sh      (about 12 minutes; writes gpurun_out/r4_first/*)
+#   1. the -m gpu suite (last device run: profiles/round3/call31; since then only host-side changes: kb_session_load resets the second stream's
+#      buffer sizes, the overlapped rounds' list tag is the chain tag)
+#   2. the emulator-born cases of late round 3 with the PRODUCT library (KB_EMU_LIB names the library tests/test_emu_engine_cpu.py loads):
+#      one engine through sessions of growing size (the reload fix), overlapped candidate lists, the launch-path variants
+#   3. preempt / reclaim with inter-pod (anti)affinity terms behind KB_EVICT_INTERPOD=1: FIRST device run (every case sets the switch itself after
+#      checking the refusal without it).  Green here => make it the default (kb_preempt.cpp: evict_interpod_enabled), move the cases into
+#      tests/test_gpu_interpod.py, drop the line from DESIGN section 2
+#   4. the default bench line and the two variants, for the record of what the round starts from
+set -uo pipefail
+cd "$(dirname "$0")/.."
+out=gpurun_out/r4_first
+mkdir -p "$out"
+lib="$PWD/kube-batch_amd/libkbengine.so"
+timeout 1500 python -m pytest tests -x -q -m gpu -p no:cacheprovider > "$out/pytest_gpu.txt" 2>&1; echo "gpu suite rc=$?" | tee -a "$out/summary.txt"
+KB_EMU_LIB="$lib" timeout 600 python -m pytest tests/test_emu_engine_cpu.py -q -p no:cacheprovider \
+  -k "growing_size or overlapped_candidate_lists or launch_path_variants" > "$out/pytest_emu_cases_on_device.txt" 2>&1
+echo "emulator-born cases on the device rc=$?" | tee -a "$out/summary.txt"
+KB_EMU_LIB="$lib" timeout 900 python -m pytest tests/test_emu_engine_cpu.py -q -p no:cacheprovider \
+  -k "evict_actions_with_interpod_terms" > "$out/pytest_evict_interpod_on_device.txt" 2>&1
+echo "evict actions with inter-pod terms on the device rc=$?" | tee -a "$out/summary.txt"
+KB_EVICT_INTERPOD=1 KB_EMU_LIB="$lib" timeout 600 python - > "$out/hunt_evict_interpod_on_device.txt" 2>&1 <<'EOF'
+# the hunt's engine-against-oracle leg on fresh seeds, product library
+import importlib, os, sys
+sys.path[:0] = [os.getcwd(), os.path.join(os.getcwd(), "tests")]
+import pytest
+engine = importlib.import_module("kube-batch_amd.engine")
+import oracle, test_gpu_preempt as gp, test_interpod_oracle_cpu as ipo
+oracle.build()
+bad = ran = 0
+for seed in range(3000, 3150):
+    try:
+        cfg, snap, order = ipo.interpod_evict_case(seed)
+    except Exception:
+        continue
+    if snap.interpod is None:
+        continue
+    try:
+        gp._run_both(oracle, cfg, snap, order, seed)
+        ran += 1
+    except pytest.skip.Exception:
+        pass
+    except BaseException as err:
+        bad += 1
+        print(f"seed {seed} {order}: {type(err).__name__}: {str(err)[:300]}", flush=True)
+print(f"{ran} comparisons, {bad} divergences")
+sys.exit(1 if bad else 0)
+EOF
+echo "inter-pod evict hunt on the device rc=$?" | tee -a "$out/summary.txt"
+python bench.py > "$out/bench_default.json" 2> "$out/bench_default.err"; echo "bench rc=$?" | tee -a "$out/summary.txt"
+python bench.py --config 4 --steps 3 --warmup 1 --no-cpu-baseline > "$out/bench_config4.json" 2> "$out/bench_config4.err"; echo "bench config 4 rc=$?" | tee -a "$out/summary.txt"
+python bench.py --config 5 --preempt --steps 2 --warmup 1 --no-cpu-baseline > "$out/bench_config5_three_actions.json" 2> "$out/bench_config5.err"; echo "bench config 5 three actions rc=$?" | tee -a "$out/summary.txt"
+cat "$out/summary.txt"
