@@ -206,6 +206,10 @@ struct kb_engine {
   // first launch, the speculation breaks (from a stopped round's answer to the re-planned launch), the closing reduction, round waits
   bool async_pending = false;   // kb_session_reset queued device-to-device copies on `stream` and returned without waiting: whoever touches the
                                 // buffers outside that stream (null-stream copies of the getters and of the evict actions, a stream switch) waits first
+  // "a Pending task carries a NodeName" is looked for in front of an allocate / backfill only when it can have appeared: once per loaded
+  // session (load_clean remembers that the load-time state passed; kb_session_reset returns to that state) and after every evict action
+  // (a discarded statement is the one thing inside a session that creates such a task)
+  bool stale_checked = false, pristine = true, load_clean = false;
   double tl_reset = 0, tl_begin = 0, tl_break = 0, tl_finish = 0, tl_wait = 0, tl_backfill = 0;
   std::vector<kb_decision> decisions_all;   // decisions of the last multi-GPU round sequence
   std::vector<uint32_t> evictions;          // committed evictions of the session's preempt actions, in cache.Evict order
@@ -698,8 +702,8 @@ struct ActionRun {
       // depend on outcomes, so there is nothing to speculate
       bf_list.clear();
       bf_pos = 0;
-      for (uint32_t t = 0; t < hs.T; t++)
-        if (hs.t_status[t] == KB_TASK_PENDING && hs.t_init_empty[t] && hs.t_job[t] < hs.J) bf_list.push_back(t);
+      for (uint32_t t : hs.init_empty_tasks)
+        if (hs.t_status[t] == KB_TASK_PENDING && hs.t_job[t] < hs.J) bf_list.push_back(t);
       // Only a session with sub-epsilon BestEffort requests (or a node below -epsilon) can see AddTask refuse a node that passed
       // the predicates; absorb() then needs to tell "no node passes the predicates" (the task stays Pending) from "one did"
       // (outside the envelope).  Pod counts and used ports only grow during backfill, so the state as of now decides the former.
@@ -1072,6 +1076,7 @@ int kb_session_load(kb_engine *e, const kb_snapshot *sn) {
     quiesce(e);
     e->loaded = false;
     e->fin0.valid = false;
+    e->stale_checked = false; e->pristine = true; e->load_clean = false;
     mg_free(e->mg);
     e->mg = nullptr;
     HostSession &hs = e->hs;
@@ -1370,6 +1375,8 @@ int kb_session_reset(kb_engine *e) {
     if (!e->loaded) throw EngineError(KB_E_STATE, "no session loaded");
     const double t_reset0 = now_ms();
     e->tainted = false;
+    e->pristine = true;
+    e->stale_checked = e->load_clean;
     hipStream_t s = e->stream;
     auto restore = [&](DevBuf &dst, const DevBuf &src) { HIP_OK(hipMemcpyAsync(dst.p, src.p, src.bytes, hipMemcpyDeviceToDevice, s)); };
     restore(e->b_idle, e->p_idle); restore(e->b_rel, e->p_rel); restore(e->b_nzc, e->p_nzc); restore(e->b_nzm, e->p_nzm);
@@ -1411,9 +1418,13 @@ static int run_action(kb_engine *e, uint32_t action, kb_decision *out, uint64_t 
     // clears it, api/node_info.go:217-243): the reference's AddTask then refuses every other node AFTER ssn.Allocate has flipped
     // the status (session.go:243 vs :255).  Not modelled: the stock action takes such a cycle (it cannot arise under the stock
     // action order, where preempt runs last).
-    for (uint32_t t = 0; t < e->hs.T; t++)
-      if (e->hs.t_status[t] == KB_TASK_PENDING && e->hs.t_node[t] != KB_NONE)
-        throw EngineError(KB_E_UNSUPPORTED, "a Pending task carries a stale NodeName (un-pipelined by a discarded preempt statement)");
+    if (!e->stale_checked) {
+      for (uint32_t t = 0; t < e->hs.T; t++)
+        if (e->hs.t_status[t] == KB_TASK_PENDING && e->hs.t_node[t] != KB_NONE)
+          throw EngineError(KB_E_UNSUPPORTED, "a Pending task carries a stale NodeName (un-pipelined by a discarded preempt statement)");
+      e->stale_checked = true;   // allocate and backfill never create one
+      if (e->pristine) e->load_clean = true;
+    }
     const double t_act0 = now_ms();
     ActionRun run;
     run.begin(e, action);
@@ -1526,6 +1537,8 @@ static int run_evict_action(kb_engine *e, bool reclaim, kb_stmt_op *out, uint64_
     if (!e->loaded) throw EngineError(KB_E_STATE, "kb_session_load must precede kb_run_preempt / kb_run_reclaim");
     if (e->tainted) throw EngineError(KB_E_STATE, "a preempt / reclaim call failed after touching the session's state: kb_session_load or kb_session_reset first");
     quiesce(e);
+    e->pristine = false;
+    e->stale_checked = false;
     HostSession &hs = e->hs;
     // an eviction takes a pod OUT of the inter-pod predicate's pod list (Running -> Releasing leaves api.AllocatedStatus): modelled on the
     // host side of the evict machine (kb_preempt.cpp: ip_*), the lists rebuilt on the device after every change; written and checked

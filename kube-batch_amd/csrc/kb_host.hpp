@@ -151,6 +151,7 @@ struct HostSession {
   std::vector<uint8_t> t_off_node;
   std::vector<uint8_t> t_res_empty;       // Resreq.IsEmpty()   (allocate.go:114)
   std::vector<uint8_t> t_init_empty;      // InitResreq.IsEmpty() (backfill.go:47)
+  std::vector<uint32_t> init_empty_tasks; // the tasks with t_init_empty set, ascending (a request never changes inside a session)
   std::vector<uint32_t> t_feas_shape;     // id of (InitResreq, class): tasks sharing it share a feasibility row
   std::vector<uint32_t> t_row_shape;      // id of (InitResreq, non-zero request, class): identical matrix rows
   uint32_t n_feas_shapes = 0, n_row_shapes = 0;
@@ -237,8 +238,13 @@ class OrderMachine {
   const HostSession *hs_ = nullptr;
   const Policy *pol_ = nullptr;
   std::vector<uint32_t> qheap_;
-  std::vector<uint32_t> jheap_items_, jheap_off_, jheap_n_;
-  std::vector<uint32_t> pend_, pend_off_, cursor_;   // per job: Pending non-BestEffort tasks in TaskOrderFn order
+  static constexpr uint32_t kNotBuilt = 0xFFFFFFFFu;   // jheap_n_: the queue has not been popped yet, its job heap is still to be built
+  std::vector<uint32_t> jheap_items_, jheap_off_, jheap_n_, qjobs_;
+  void build_jobs(uint32_t q);
+  // per job: Pending non-BestEffort tasks in TaskOrderFn order, built on the job's first pop into the job's own task range of pend_
+  std::vector<uint32_t> pend_, pend_end_, cursor_;
+  std::vector<uint8_t> pend_built_;
+  void build_pending(uint32_t j);
   int cur_q_ = -1, cur_j_ = -1;
   uint32_t cur_t_ = KB_NONE;
   bool inner_ = false;

@@ -128,35 +128,32 @@ void OrderMachine::init_allocate(const HostSession *hs, const Policy *pol) {
     if (hs->job_queue[j] < Q) jheap_off_[hs->job_queue[j] + 1]++;
   for (uint32_t q = 0; q < Q; q++) jheap_off_[q + 1] += jheap_off_[q];
   jheap_items_.assign(J ? J : 1, 0);
-  jheap_n_.assign(Q, 0);
+  // A queue's job heap is built the first time the queue is popped (build_jobs; kNotBuilt stands in its size until then, and travels with
+  // the sizes through the roll-back points).  What job_less reads of a job (ReadyTaskNum, drf share) moves only when one of the job's
+  // tasks is handled, i.e. after the job was popped from that very heap: the pushes find the values they would have found here.
+  jheap_n_.assign(Q, kNotBuilt);
+  qjobs_.assign(J ? J : 1, 0);   // the jobs of every queue, ascending (counting sort over the offsets above)
+  {
+    std::vector<uint32_t> fill(jheap_off_.begin(), jheap_off_.end() - 1);
+    for (uint32_t j = 0; j < J; j++)
+      if (hs->job_queue[j] < Q) qjobs_[fill[hs->job_queue[j]]++] = j;
+  }
   qheap_.clear();
   qheap_.reserve(J);
-  // pendingTasks[job] (allocate.go:110-123): Pending tasks whose Resreq is not empty, in TaskOrderFn order
-  // (session_plugins.go:298-331: priority plugin, then pod creation time, then UID); the comparator is a strict total
-  // order over immutable keys, so the heap's pop order is the sorted order
-  pend_off_.assign(J + 1, 0);
-  pend_.clear();
-  for (uint32_t j = 0; j < J; j++) {
-    pend_off_[j] = (uint32_t)pend_.size();
-    for (uint32_t t = hs->job_begin[j]; t < hs->job_begin[j + 1]; t++)
-      if (hs->t_status[t] == KB_TASK_PENDING && !hs->t_res_empty[t]) pend_.push_back(t);
-    auto b = pend_.begin() + pend_off_[j], e = pend_.end();
-    const bool by_prio = pol->task_order_priority;
-    std::sort(b, e, [hs, by_prio](uint32_t l, uint32_t r) {
-      if (by_prio && hs->t_prio[l] != hs->t_prio[r]) return hs->t_prio[l] > hs->t_prio[r];
-      if (hs->t_creation[l] != hs->t_creation[r]) return hs->t_creation[l] < hs->t_creation[r];
-      return l < r;
-    });
-  }
-  pend_off_[J] = (uint32_t)pend_.size();
+  // pendingTasks[job] (allocate.go:110-123): Pending tasks whose Resreq is not empty, in TaskOrderFn order.  A job's list is built the
+  // first time the job is popped (build_pending): a job's tasks are adjacent in the snapshot, so its list lives in pend_ at the job's own
+  // task range, and nothing about it depends on what the action has done so far (statuses only change when the action closes).  The host
+  // builds them while the device works on the window in front; a cycle that ends on exhausted capacity never builds most of them.
+  if (pend_.size() < hs->T) pend_.resize(hs->T);
+  pend_end_.assign(J ? J : 1, 0);
+  pend_built_.assign(J ? J : 1, 0);
   cursor_.assign(J, 0);
-  for (uint32_t j = 0; j < J; j++) cursor_[j] = pend_off_[j];
+  for (uint32_t j = 0; j < J; j++) cursor_[j] = hs->job_begin[j];
   // allocate.go:50-65: ssn.Jobs in ascending JobID; one queue-heap entry per job
   for (uint32_t j = 0; j < J; j++) {
     uint32_t q = hs->job_queue[j];
     if (q >= Q) continue;   // "queue not found": job skipped
     qpush(q);
-    jpush(q, j);
   }
   inner_ = false;
   cur_q_ = cur_j_ = -1;
@@ -164,6 +161,30 @@ void OrderMachine::init_allocate(const HostSession *hs, const Policy *pol) {
   stamp_.assign(J ? J : 1, 0);
   epoch_ = 0;
   checkpoint();
+}
+
+// allocate.go:50-65 walks ssn.Jobs in ascending JobID and pushes each job into its queue's heap: per queue, its jobs in ascending order
+void OrderMachine::build_jobs(uint32_t q) {
+  jheap_n_[q] = 0;
+  for (uint32_t k = jheap_off_[q]; k < jheap_off_[q + 1]; k++) jpush(q, qjobs_[k]);
+}
+
+// session_plugins.go:298-331 TaskOrderFn: priority plugin, then pod creation time, then UID; the comparator is a strict total order over
+// immutable keys, so the heap's pop order (allocate.go:110-123 pushes into a PriorityQueue) is the sorted order
+void OrderMachine::build_pending(uint32_t j) {
+  const HostSession *hs = hs_;
+  const uint32_t b = hs->job_begin[j];
+  uint32_t n = b;
+  for (uint32_t t = b; t < hs->job_begin[j + 1]; t++)
+    if (hs->t_status[t] == KB_TASK_PENDING && !hs->t_res_empty[t]) pend_[n++] = t;
+  const bool by_prio = pol_->task_order_priority;
+  std::sort(pend_.begin() + b, pend_.begin() + n, [hs, by_prio](uint32_t l, uint32_t r) {
+    if (by_prio && hs->t_prio[l] != hs->t_prio[r]) return hs->t_prio[l] > hs->t_prio[r];
+    if (hs->t_creation[l] != hs->t_creation[r]) return hs->t_creation[l] < hs->t_creation[r];
+    return l < r;
+  });
+  pend_end_[j] = n;
+  pend_built_[j] = 1;
 }
 
 void OrderMachine::arm(Frame &f) {
@@ -220,7 +241,8 @@ bool OrderMachine::next(uint32_t &task) {
   for (;;) {
     if (inner_) {
       uint32_t j = (uint32_t)cur_j_;
-      if (cursor_[j] < pend_off_[j + 1]) {   // allocate.go:129-130
+      if (!pend_built_[j]) build_pending(j);
+      if (cursor_[j] < pend_end_[j]) {       // allocate.go:129-130
         touch(j);
         task = cur_t_ = pend_[cursor_[j]++];
         steps++;
@@ -232,6 +254,7 @@ bool OrderMachine::next(uint32_t &task) {
     if (qheap_.empty()) return false;        // allocate.go:90-92
     uint32_t q = qpop();
     if (overused(q)) continue;               // allocate.go:95-98
+    if (jheap_n_[q] == kNotBuilt) build_jobs(q);
     if (jheap_n_[q] == 0) continue;          // allocate.go:104-107
     uint32_t j = jpop(q);
     cur_q_ = (int)q;
@@ -281,7 +304,7 @@ void OrderMachine::report(Outcome o) {
   touch(j);
   if (o == Outcome::Allocated) ready[j] += 1;   // status Allocated counts towards ReadyTaskNum; Pipelined does not
   update_shares(j, cur_t_);
-  if (job_ready(j) && cursor_[j] < pend_off_[j + 1]) {   // allocate.go:185-188
+  if (job_ready(j) && cursor_[j] < pend_end_[j]) {   // allocate.go:185-188 (the current job: its list is built)
     jpush(q, j);
     inner_ = false;
     qpush(q);

@@ -294,6 +294,9 @@ void build_host_session(const kb_snapshot *sn, const Policy &pol, uint32_t NP, H
   }
   hs.n_feas_shapes = (uint32_t)feas_ids.size();
   hs.n_row_shapes = (uint32_t)row_ids.size();
+  hs.init_empty_tasks.clear();   // backfill's candidates by request (backfill.go:47), ascending: the action filters them by status
+  for (uint32_t t = 0; t < T; t++)
+    if (hs.t_init_empty[t]) hs.init_empty_tasks.push_back(t);
   // per feasibility shape: the vector LessEqual actually compares (scalar dimensions at or below the epsilon are skipped,
   // resource_info.go:283-287) and the static class, for the dominance rule of ActionRun::mark_dead
   hs.feas_eff.assign((size_t)hs.n_feas_shapes * R, 0.0);

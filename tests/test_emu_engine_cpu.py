@@ -309,3 +309,32 @@ def test_one_engine_through_sessions_of_growing_size(emulated_engine):
         assert np.array_equal(eng.binds(), o.binds()), (n_tasks, n_nodes)
         o.close()
     eng.close()
+
+
+@pytest.mark.parametrize("seed", [1, 5, 8, 11, 15])
+def test_the_stale_node_name_check_runs_whenever_one_can_have_appeared(emulated_engine, seed):
+    """allocate / backfill refuse a session in which a Pending task carries a NodeName (a discarded preempt statement leaves one behind).  The
+    engine looks for one only when it can have appeared — once per loaded session, and after every evict action (round 3: it was a scan of all
+    tasks in front of every action) — so: refused after the preempt that creates it, again on a second try, fine after kb_session_reset (the
+    load-time state was checked by the first allocate), refused again when the preempt is repeated."""
+    import test_pyref_vs_oracle as cases
+    oracle_mod = importlib.import_module("oracle")
+    cfg, snap, _ = cases._evict_case(seed)
+    o = oracle_mod.Oracle(cfg, snap)
+    o.run(["allocate"])
+    e = engine.Engine(cfg)
+    e.load(snap)
+    for _ in range(2):
+        first = e.run_allocate()
+        assert np.array_equal(first, o.decisions()[: len(first)]) and np.array_equal(e.binds(), o.binds())
+        e.reset()
+        e.run(["preempt"])
+        for _ in range(2):
+            with pytest.raises(engine.EngineError) as err:
+                e.run_allocate()
+            assert err.value.code == abi.KB_E_UNSUPPORTED and "stale NodeName" in str(err.value)
+        with pytest.raises(engine.EngineError):
+            e.run_backfill()
+        e.reset()
+    e.close()
+    o.close()
