@@ -153,6 +153,11 @@ struct KbRound {
   uint32_t stale_L;                  // >= n_prev + L: what is left of a stale list without the predecessor's nodes still holds the true top L
   const unsigned long long *prev_dec;   // decision records of the predecessor round (low word: node), n_prev of them
   uint32_t n_prev;
+  // Folded repair (KB_FOLD_REPAIR=1; off by default until it has run on a device): no repair launch — the batch commit launch carries the
+  // fields above itself and repairs row i in its own workgroup 8 * (i / 7) + 1 + i % 7 (the workgroups that otherwise exit at once), which
+  // leaves ready_tag in fold_done[i]; the commit workgroup waits for the n_mrows words before it reads the first candidate
+  uint32_t fold;
+  uint32_t *fold_done;
 };
 // true when the round was queued behind a predecessor that did not complete
 #define KB_CHAIN_BROKEN(r) ((r).chain_expect != 0u && *(r).chain != (r).chain_expect)

@@ -166,13 +166,15 @@ struct kb_engine {
   // beside its predecessor's commit kernel, into buffers of their own (matrix rows, stale lists per staging half, one `ready` word per
   // list, a scratch block for their time stamps); kb_launch_repair on the first stream turns the stale lists into the round's lists
   hipStream_t stream_b = nullptr;
-  DevBuf b_score2, b_maskw2, b_stale, b_ready, b_task_rows;
+  DevBuf b_score2, b_maskw2, b_stale, b_ready, b_task_rows, b_fold_done;
   Pinned<unsigned long long> h_cand_out;   // per staging half: the output-block words the second stream's launches stamp (start of the matrix launch, start of the arg-max launch)
   unsigned long long *d_cand_out = nullptr;
   uint32_t mat2_cap = 0;
   size_t stale_cap = 0;
   bool overlap = true;             // KB_OVERLAP=0: every round on the plain path (matrix -> arg-max -> commit on one stream)
-  uint64_t overlapped_rounds = 0, overlap_faults = 0;
+  uint64_t overlapped_rounds = 0, overlap_faults = 0, folded_rounds = 0;
+  bool fold_repair = false;        // KB_FOLD_REPAIR=1: an overlapped round on the batch commit kernel repairs its lists inside the commit launch (KbRound::fold);
+                                   // off until it has run on a device
   DevBuf b_win, b_out;   // per-round upload / download blocks (see h_win / h_out)
   DevBuf b_chain;        // KbRound::chain: tag of the last round that committed its whole window
   // feasibility probe at speculation breaks (ActionRun::probe_dead_shapes): one representative task per feasibility shape
@@ -484,13 +486,15 @@ void ensure_overlap_buffers(kb_engine *e, uint32_t mrows, uint32_t stale_L) {
     e->b_ready.alloc(sizeof(uint32_t) * 2 * KB_K5_MAX_WINDOW);
     HIP_OK(hipMemset(e->b_ready.p, 0, e->b_ready.bytes));
     e->b_task_rows.alloc((size_t)64 * 2 * KB_K5_MAX_WINDOW);
+    e->b_fold_done.alloc(sizeof(uint32_t) * 2 * KB_K5_MAX_WINDOW);
+    HIP_OK(hipMemset(e->b_fold_done.p, 0, e->b_fold_done.bytes));
     e->h_cand_out.flags = hipHostMallocMapped | hipHostMallocCoherent;
     e->h_cand_out.resize(2 * KB_OUT_HDR);
     std::memset(e->h_cand_out.data(), 0, sizeof(unsigned long long) * 2 * KB_OUT_HDR);
     HIP_OK(hipHostGetDevicePointer((void **)&e->d_cand_out, e->h_cand_out.data(), 0));
   }
 }
-void round_candidates_overlapped(kb_engine *e, const RoundCtx &c, uint32_t n_prev, unsigned long long *keys) {
+void round_candidates_overlapped(kb_engine *e, RoundCtx &c, uint32_t n_prev, unsigned long long *keys) {
   if (c.ns == 0) return;
   const uint32_t stale_L = n_prev + c.L;
   unsigned long long *stale = e->b_stale.as<unsigned long long>() + (size_t)c.buf * e->stale_cap;
@@ -516,7 +520,14 @@ void round_candidates_overlapped(kb_engine *e, const RoundCtx &c, uint32_t n_pre
   ra.stale_L = stale_L;
   ra.prev_dec = e->b_out.as<unsigned long long>() + KB_OUT_HDR;   // the predecessor's decision records (it completed, or the chain is broken)
   ra.n_prev = n_prev;
-  kb_launch_repair(c.d, ra, e->stream);
+  if (e->fold_repair && e->commit_kernel == KB_COMMIT_BATCH) {   // no launch of its own: round_commit's launch carries the repair (KbRound::fold)
+    ra.fold = 1;
+    ra.fold_done = e->b_fold_done.as<uint32_t>() + (size_t)c.buf * KB_K5_MAX_WINDOW;
+    c.r = ra;
+    e->folded_rounds += 1;
+  } else {
+    kb_launch_repair(c.d, ra, e->stream);
+  }
   e->stats.matrix_launches += 1;
   e->stats.matrix_evals += (uint64_t)c.ns * e->hs.N;
   e->overlapped_rounds += 1;
@@ -1023,6 +1034,8 @@ int kb_engine_create(const kb_config *cfg, kb_engine **out) {
       eng->probe_enabled = !(pb && pb[0] == '0');
       const char *ov = getenv("KB_OVERLAP");
       eng->overlap = !(ov && ov[0] == '0');
+      const char *fr = getenv("KB_FOLD_REPAIR");
+      eng->fold_repair = fr && fr[0] == '1';
       const char *dw = getenv("KB_DIRECT_WINDOW");
       eng->direct_window = !(dw && dw[0] == '0');
     }
@@ -1044,6 +1057,7 @@ void kb_engine_destroy(kb_engine *e) {
             (unsigned long long)e->k5_demand);
   if (getenv("KB_K5_STATS")) fprintf(stderr, "[kb overlap] rounds with candidate lists built beside the predecessor's commit %llu, lists that never arrived %llu\n",
                                      (unsigned long long)e->overlapped_rounds, (unsigned long long)e->overlap_faults);
+  if (getenv("KB_K5_STATS") && e->fold_repair) fprintf(stderr, "[kb overlap] of them repaired inside the commit launch %llu\n", (unsigned long long)e->folded_rounds);
   if (getenv("KB_K5_STATS")) fprintf(stderr, "[kb K7] batches of the batch kernel %llu\n", e->k7_batches);
   if (getenv("KB_K5_STATS"))
     fprintf(stderr, "[kb host] ms over the engine's life: reset %.2f, allocate up to its first launch %.2f, speculation breaks (answer -> re-planned launch) %.2f, "
@@ -1435,6 +1449,10 @@ static int run_action(kb_engine *e, uint32_t action, kb_decision *out, uint64_t 
     // lists beside the predecessor's commit kernel.  With scalar dimensions only behind a predecessor on the run kernel: the batch kernel
     // writes them speculatively for candidates it may hand back, i.e. on nodes that stay CLEAN, which no repair would look at again
     const bool overlap_ok = e->overlap && action == 0 && e->fast_rounds && !e->hs.has_affinity && !e->hs.has_interpod && 2 * e->eff_window + 1 <= 1024u;
+    // The second stream is ordered behind nothing the first one holds: the copies kb_session_reset left queued there must have landed before
+    // an overlapped launch reads the node state (the feasibility probe's read-back waits for them when it runs — it does not without the
+    // predicates plugin, with KB_PROBE=0, or when every shape is dead; found on the emulated device with asynchronous streams)
+    if (overlap_ok) quiesce(e);
     auto launch = [&](uint32_t rows_n, const uint32_t *rows, uint32_t buf, uint32_t chain_expect, uint32_t n_prev) {
       RoundCtx c = round_prepare(e, rows_n, action == 0 ? 1 : 2, action == 1, true, rows, buf, chain_expect);   // single GPU: every matrix row is local
       unsigned long long *keys = e->b_keys.as<unsigned long long>();

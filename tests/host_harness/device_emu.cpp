@@ -470,8 +470,7 @@ void kb_launch_argmax(const KbDev &d, const KbRound &r, void *stream) {
 
 // k_repair's contract: per matrix row, the stale list (r.stale, r.stale_L entries) without the predecessor's nodes (r.prev_dec, r.n_prev
 // records), plus those nodes evaluated against the state the predecessor left, best first, r.L entries, 0-padded
-void kb_launch_repair(const KbDev &d, const KbRound &r, void *stream) {
-  kbemu_enqueue((hipStream_t)stream, [d, r]() {
+static void emu_repair(const KbDev &d, const KbRound &r) {
   if (r.n_mrows == 0) return;
   if (KB_CHAIN_BROKEN(r)) return;
   out64(r)[KB_OUT_STAMP0] = kbemu_wall_clock();
@@ -508,8 +507,12 @@ void kb_launch_repair(const KbDev &d, const KbRound &r, void *stream) {
     std::sort(keys.begin(), keys.end(), [](u64 a, u64 b) { return a > b; });
     u64 *out = r.keys + (size_t)m * r.L;
     for (uint32_t i = 0; i < r.L; i++) out[i] = i < keys.size() ? keys[i] : 0ull;
+    if (r.fold) __atomic_store_n(&r.fold_done[m], r.ready_tag, __ATOMIC_RELEASE);
   }
-  });
+}
+void kb_launch_repair(const KbDev &d, const KbRound &r, void *stream) {
+  if (r.fold) { fprintf(stderr, "emulated device: a repair launch for a round that folds its repair into the commit launch\n"); abort(); }
+  kbemu_enqueue((hipStream_t)stream, [d, r]() { emu_repair(d, r); });
 }
 
 void kb_launch_expand(const KbDev &d, const uint16_t *s_score, const uint32_t *s_mask, const uint32_t *row_slot, const uint32_t *order, uint32_t n_rows,
@@ -544,7 +547,20 @@ void kb_launch_scatter_nodes(const KbDev &d, const unsigned long long *rec, uint
 }
 
 void kb_launch_commit(const KbDev &d, const KbRound &r, void *stream) { kbemu_enqueue((hipStream_t)stream, [d, r]() { emu_commit(d, r, false); }); }
-void kb_launch_commit_batch(const KbDev &d, const KbRound &r, void *stream) { kbemu_enqueue((hipStream_t)stream, [d, r]() { emu_commit(d, r, true); }); }
+static unsigned long long g_folded_launches = 0;
+extern "C" unsigned long long kbemu_folded_launches() { return __atomic_load_n(&g_folded_launches, __ATOMIC_RELAXED); }   // tests: the folded path was taken
+// KbRound::fold: the launch repairs the round's overlapped candidate lists itself before its commit workgroup reads them; a list that never
+// arrives clears the chain word, which the commit then finds broken (KB_REASON_SKIPPED), as on the device
+void kb_launch_commit_batch(const KbDev &d, const KbRound &r, void *stream) {
+  kbemu_enqueue((hipStream_t)stream, [d, r]() {
+    if (r.fold) {
+      __atomic_fetch_add(&g_folded_launches, 1ull, __ATOMIC_RELAXED);
+      if (r.ready == nullptr || r.stale == nullptr || r.fold_done == nullptr || r.task_rows == nullptr) { fprintf(stderr, "emulated device: folded round without its repair fields\n"); abort(); }
+      emu_repair(d, r);
+    }
+    emu_commit(d, r, true);
+  });
+}
 
 uint32_t kb_apply_deltas(const KbDev &d, const double *s_idle, const double *s_rel, const long long *s_nzc, const long long *s_nzm,
                          const int *s_podcnt, const double *delta, uint32_t *dev_counter, void *stream) {

@@ -139,7 +139,13 @@ hipError_t hipMemcpyAsync(void *dst, const void *src, size_t n, hipMemcpyKind ki
     kbemu_drain(s);
     memmove(dst, src, n);
   } else {
-    kbemu_enqueue(s, [dst, src, n]() { memmove(dst, src, n); });
+    // KB_EMU_D2D_DELAY_US: a device-to-device copy takes that long on its stream (tests: work on another stream that needs the copy's result
+    // must be ordered behind it by the engine, not by luck)
+    const long delay_us = getenv("KB_EMU_D2D_DELAY_US") ? atol(getenv("KB_EMU_D2D_DELAY_US")) : 0;
+    if (delay_us > 0 && kind == hipMemcpyDeviceToDevice)
+      kbemu_enqueue(s, [dst, src, n, delay_us]() { std::this_thread::sleep_for(std::chrono::microseconds(delay_us)); memmove(dst, src, n); });
+    else
+      kbemu_enqueue(s, [dst, src, n]() { memmove(dst, src, n); });
   }
   return hipSuccess;
 }

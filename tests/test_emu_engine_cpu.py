@@ -208,8 +208,10 @@ def test_full_size_cycles_through_the_host_side(oracle_mod, name):
     fs.test_full_size_cycle_equals_oracle_and_golden_digest(oracle_mod, name)
 
 
-def test_overlapped_candidate_lists_are_repaired(emulated_engine, monkeypatch):
-    """Chained rounds of plain sessions build their candidate lists on a second stream beside the predecessor's commit kernel and repair them
+@pytest.mark.parametrize("fold", [False, True])
+def test_overlapped_candidate_lists_are_repaired(emulated_engine, monkeypatch, fold):
+    """fold: KB_FOLD_REPAIR=1, the batch commit launch repairs the lists itself (KbRound::fold; no repair launch for those rounds).
+    Chained rounds of plain sessions build their candidate lists on a second stream beside the predecessor's commit kernel and repair them
     behind it (kb_kernels.hip: k_repair).  The emulated matrix launch of such a round POISONS what it reports for the nodes
     the last commit changed, so the decisions only come out right if the repair launch overrides exactly those: equal to the oracle with it,
     different without it (KB_EMU_REPAIR_OFF=1 hands the stale lists on as they are — the negative control), and equal again on the plain
@@ -229,8 +231,16 @@ def test_overlapped_candidate_lists_are_repaired(emulated_engine, monkeypatch):
         eng.close()
         return out
 
+    monkeypatch.delenv("KB_FOLD_REPAIR", raising=False)
+    if fold:
+        monkeypatch.setenv("KB_FOLD_REPAIR", "1")
+        monkeypatch.setenv("KB_COMMIT_KERNEL", "batch")   # this small cluster would move to the run kernel, whose rounds keep the repair launch
+    folded = C.CDLL(emulated_engine).kbemu_folded_launches
+    folded.restype = C.c_ulonglong
+    f0 = folded()
     ok, rounds, _ = cycle()
     assert ok and rounds > 10
+    assert (folded() - f0 > 10) if fold else (folded() == f0)
     monkeypatch.setenv("KB_EMU_REPAIR_OFF", "1")
     broken, _, _ = cycle()
     assert not broken                                   # the overlapped path was taken, and its stale lists alone are wrong
@@ -267,8 +277,11 @@ def test_evict_actions_with_interpod_terms_equal_the_oracle(emulated_engine, mon
     gp._run_both(oracle_mod, cfg, snap, order, seed)
 
 
-def test_a_candidate_list_that_never_arrives_breaks_the_chain_and_the_round_runs_again(emulated_engine, monkeypatch):
-    """k_repair's wait for its lists is bounded: a list that never arrives (here: the emulated arg-max launch of every third overlapped round
+@pytest.mark.parametrize("fold", [False, True])
+def test_a_candidate_list_that_never_arrives_breaks_the_chain_and_the_round_runs_again(emulated_engine, monkeypatch, fold):
+    """fold: the same with the repair inside the commit launch (KB_FOLD_REPAIR=1): the row that waited clears the chain word, the commit workgroup
+    of the same launch finds it so and reports the round skipped.
+    k_repair's wait for its lists is bounded: a list that never arrives (here: the emulated arg-max launch of every third overlapped round
     drops its tag) makes it break the chain, the commit kernel behind it skips the round, the host takes the skipped round back, counts the fault
     and keeps every later round of that engine on the plain path — same decisions as the oracle, no hang, no wrong bind."""
     oracle_mod = importlib.import_module("oracle")
@@ -278,6 +291,9 @@ def test_a_candidate_list_that_never_arrives_breaks_the_chain_and_the_round_runs
     o.run(["allocate", "backfill"])
     monkeypatch.setenv("KB_EMU_DROP_TAG", "3")
     monkeypatch.setenv("KB_EMU_REPAIR_WAIT_NS", "2e6")
+    if fold:
+        monkeypatch.setenv("KB_FOLD_REPAIR", "1")
+        monkeypatch.setenv("KB_COMMIT_KERNEL", "batch")
     for _ in range(2):                                   # twice: the fault must not outlive the action that met it
         eng = engine.Engine(conf)
         eng.load(snap)
@@ -338,3 +354,40 @@ def test_the_stale_node_name_check_runs_whenever_one_can_have_appeared(emulated_
         e.reset()
     e.close()
     o.close()
+
+
+_RESET_RACE_SCRIPT = r"""
+import importlib, os, sys
+import numpy as np
+sys.path.insert(0, {root!r}); sys.path.insert(0, {tests!r})
+kbm = importlib.import_module("kube-batch_amd")
+engine = importlib.import_module("kube-batch_amd.engine")
+oracle_mod = importlib.import_module("oracle")
+engine.LIB_PATH, engine._LIB = {so!r}, None
+snap = kbm.snapshot.synth(kbm.snapshot.synth_config(3, 0.03))
+conf = kbm.conf.load_scheduler_conf()
+o = oracle_mod.Oracle(conf, snap)
+o.run(["allocate", "backfill"])
+e = engine.Engine(conf)
+e.load(snap)
+dec = e.run(["allocate", "backfill"])
+assert np.array_equal(dec, o.decisions())
+for _ in range(3):
+    e.reset()
+    again = e.run(["allocate", "backfill"])
+    assert np.array_equal(again, dec), "the cycle after kb_session_reset differs"
+    assert np.array_equal(e.binds(), o.binds())
+e.close()
+print("ok")
+"""
+
+
+def test_overlapped_launches_wait_for_the_copies_kb_session_reset_left_queued(emulated_engine):
+    """kb_session_reset restores the node state with device-to-device copies on the engine's stream and returns without waiting.  The first
+    overlapped round of the next allocate evaluates on the SECOND stream, which nothing orders behind those copies unless the engine does
+    (with the feasibility probe on, the probe's own read-back happened to; KB_PROBE=0 showed it — found on the emulated device with asynchronous
+    streams, one run in twenty).  Here the copies are slow (20 ms each): without the wait the second cycle sees the first one's node state."""
+    env = dict(os.environ, KB_EMU_ASYNC="1", KB_EMU_D2D_DELAY_US="20000", KB_PROBE="0")
+    code = _RESET_RACE_SCRIPT.format(root=os.path.join(HERE, ".."), tests=HERE, so=emulated_engine)
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr
