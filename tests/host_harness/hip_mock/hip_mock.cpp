@@ -4,6 +4,7 @@
 
 #include <stdio.h>
 
+#include <atomic>
 #include <chrono>
 #include <condition_variable>
 #include <deque>
@@ -69,6 +70,8 @@ struct kbemu_stream {
   std::condition_variable cv, idle;
   std::deque<std::function<void()>> q;
   bool stop = false, busy = false;
+  long jitter_us = 0;   // set at creation (hipStreamCreateWithFlags)
+  unsigned long long rng = (unsigned long long)(uintptr_t)this * 0x9E3779B97F4A7C15ull + (getenv("KB_EMU_JITTER_SEED") ? strtoull(getenv("KB_EMU_JITTER_SEED"), nullptr, 10) : 1ull);
   void run() {
     std::unique_lock<std::mutex> lk(m);
     for (;;) {
@@ -78,6 +81,13 @@ struct kbemu_stream {
       q.pop_front();
       busy = true;
       lk.unlock();
+      // KB_EMU_JITTER_US=n: every task starts up to n microseconds late, each stream on a pseudo-random sequence of its own (KB_EMU_JITTER_SEED):
+      // the relative timing of the engine's two streams — which the device decides anew on every run — is swept instead of being whatever
+      // two idle host threads make it
+      if (jitter_us > 0) {
+        rng = rng * 6364136223846793005ull + 1442695040888963407ull;
+        std::this_thread::sleep_for(std::chrono::microseconds((long)((rng >> 33) % (unsigned long long)(jitter_us + 1))));
+      }
       f();
       lk.lock();
       busy = false;
@@ -164,6 +174,13 @@ hipError_t hipMemsetAsync(void *dst, int v, size_t n, hipStream_t s) {
 
 hipError_t hipStreamCreateWithFlags(hipStream_t *out, unsigned) {
   kbemu_stream *s = new kbemu_stream();
+  {   // KB_EMU_JITTER_STREAMS: bit i set = the i-th stream an engine creates is jittered (the engine's own stream is its first, the overlapped
+      // rounds' second stream its second; default: all); counted modulo 2 so that every engine of a process gets the same treatment
+    static std::atomic<unsigned> created{0};
+    const unsigned idx = created.fetch_add(1) & 1u;
+    const unsigned long mask = getenv("KB_EMU_JITTER_STREAMS") ? strtoul(getenv("KB_EMU_JITTER_STREAMS"), nullptr, 0) : ~0ul;
+    if ((mask >> idx) & 1ul) s->jitter_us = getenv("KB_EMU_JITTER_US") ? atol(getenv("KB_EMU_JITTER_US")) : 0;
+  }
   if (async_mode()) s->th = std::thread([s] { s->run(); });
   { std::lock_guard<std::mutex> lk(g_mu); g_streams.insert(s); }
   *out = s;
