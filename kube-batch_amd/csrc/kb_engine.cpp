@@ -468,7 +468,22 @@ void round_candidates(kb_engine *e, const RoundCtx &c, uint32_t m0, uint32_t m1,
 // round two in front of it), so the only nodes that can change under the second stream's launches are the predecessor's.
 void ensure_overlap_buffers(kb_engine *e, uint32_t mrows, uint32_t stale_L) {
   const size_t NP = e->dev.NP;
-  if (!e->stream_b) HIP_OK(hipStreamCreateWithFlags(&e->stream_b, hipStreamNonBlocking));
+  if (!e->stream_b) {
+    // KB_STREAM_B_CUMASK=w0,w1,... (hex words, bit i of word i / 32 = CU i as hipExtStreamCreateWithCUMask counts them): the second stream's
+    // launches stay off the masked-out CUs — the commit workgroup's CU and XCD, which they otherwise share (A/B switch; unset: every CU)
+    std::vector<uint32_t> mask;
+    if (const char *cm = getenv("KB_STREAM_B_CUMASK")) {
+      for (const char *p = cm; *p;) {
+        char *end = nullptr;
+        const unsigned long w = strtoul(p, &end, 16);
+        if (end == p) break;
+        mask.push_back((uint32_t)w);
+        p = (*end == ',') ? end + 1 : end;
+      }
+    }
+    if (!mask.empty()) HIP_OK(hipExtStreamCreateWithCUMask(&e->stream_b, (uint32_t)mask.size(), mask.data()));
+    else HIP_OK(hipStreamCreateWithFlags(&e->stream_b, hipStreamNonBlocking));
+  }
   if (mrows > e->mat2_cap) {
     HIP_OK(hipStreamSynchronize(e->stream_b));
     e->b_score2.alloc(sizeof(uint16_t) * (size_t)mrows * NP);

@@ -58,6 +58,7 @@ hipError_t hipMemcpy2DAsync(void *dst, size_t dpitch, const void *src, size_t sp
 hipError_t hipMemset(void *dst, int v, size_t n);
 hipError_t hipMemsetAsync(void *dst, int v, size_t n, hipStream_t s = nullptr);
 hipError_t hipStreamCreateWithFlags(hipStream_t *s, unsigned flags);
+hipError_t hipExtStreamCreateWithCUMask(hipStream_t *s, uint32_t words, const uint32_t *mask);
 hipError_t hipStreamDestroy(hipStream_t s);
 hipError_t hipStreamSynchronize(hipStream_t s);
 hipError_t hipEventCreate(hipEvent_t *e);

@@ -186,6 +186,7 @@ hipError_t hipStreamCreateWithFlags(hipStream_t *out, unsigned) {
   *out = s;
   return hipSuccess;
 }
+hipError_t hipExtStreamCreateWithCUMask(hipStream_t *out, uint32_t, const uint32_t *) { return hipStreamCreateWithFlags(out, 0); }
 hipError_t hipStreamDestroy(hipStream_t s) {
   if (!s) return hipSuccess;
   kbemu_drain(s);
