@@ -21,6 +21,7 @@
 #include "../../include/kb_engine.h"
 #include "kb_device.h"
 #include "kb_host.hpp"
+#include "kb_waterfill.hpp"
 #include "kb_preempt.hpp"
 
 using namespace kb;
@@ -173,6 +174,8 @@ struct kb_engine {
   size_t stale_cap = 0;
   bool overlap = true;             // KB_OVERLAP=0: every round on the plain path (matrix -> arg-max -> commit on one stream)
   uint64_t overlapped_rounds = 0, overlap_faults = 0, folded_rounds = 0;
+  bool device_waterfill = false;   // KB_DEVICE_WATERFILL=1: proportion's water-fill runs as a launch at kb_session_load (kb_waterfill.hip); off until it has run on a device
+  uint32_t waterfill_passes = 0;
   bool fold_repair = false;        // KB_FOLD_REPAIR=1: an overlapped round on the batch commit kernel repairs its lists inside the commit launch (KbRound::fold);
                                    // off until it has run on a device
   DevBuf b_win, b_out;   // per-round upload / download blocks (see h_win / h_out)
@@ -1049,6 +1052,8 @@ int kb_engine_create(const kb_config *cfg, kb_engine **out) {
       eng->probe_enabled = !(pb && pb[0] == '0');
       const char *ov = getenv("KB_OVERLAP");
       eng->overlap = !(ov && ov[0] == '0');
+      const char *wf = getenv("KB_DEVICE_WATERFILL");
+      eng->device_waterfill = wf && wf[0] == '1';
       const char *fr = getenv("KB_FOLD_REPAIR");
       eng->fold_repair = fr && fr[0] == '1';
       const char *dw = getenv("KB_DIRECT_WINDOW");
@@ -1096,6 +1101,39 @@ void kb_engine_destroy(kb_engine *e) {
   delete e;
 }
 
+// proportion's OnSessionOpen water-fill as a launch (kb_waterfill.hip; KB_DEVICE_WATERFILL=1): the queues' requests, weights and the
+// session's total go up, `deserved` comes back for the host's order machine (Overused, the queue order) and stays on the device for
+// k_finalize_queues.  build_host_session left hs.deserved at zero.
+static void device_waterfill(kb_engine *e) {
+  HostSession &hs = e->hs;
+  const uint32_t Q = hs.Q;
+  std::vector<WfQueue> qs(Q ? Q : 1);
+  for (uint32_t q = 0; q < Q; q++) {
+    qs[q].request = hs.queue_request[q];
+    qs[q].weight = hs.queue_weight[q];
+    qs[q].has_attr = hs.queue_has_attr[q];
+    qs[q].meet = 0;
+    qs[q].active = 0;
+  }
+  WfState st;
+  st.remaining = hs.total;
+  st.total_weight = 0; st.stop = 0; st.share_at_open = 1; st.underflow = 0; st.passes = 0;
+  DevBuf b_q, b_st;
+  b_q.alloc(sizeof(WfQueue) * qs.size());
+  b_st.alloc(sizeof(WfState));
+  HIP_OK(hipMemcpy(b_q.p, qs.data(), sizeof(WfQueue) * qs.size(), hipMemcpyHostToDevice));
+  HIP_OK(hipMemcpy(b_st.p, &st, sizeof(WfState), hipMemcpyHostToDevice));
+  kb_launch_waterfill(b_q.as<WfQueue>(), Q, b_st.as<WfState>(), hs.R, e->stream);
+  HIP_OK(hipStreamSynchronize(e->stream));
+  HIP_OK(hipGetLastError());
+  HIP_OK(hipMemcpy(qs.data(), b_q.p, sizeof(WfQueue) * qs.size(), hipMemcpyDeviceToHost));
+  HIP_OK(hipMemcpy(&st, b_st.p, sizeof(WfState), hipMemcpyDeviceToHost));
+  if (st.underflow) throw EngineError(KB_E_UNSUPPORTED, "proportion water-filling underflow (the reference would panic in Resource.Sub)");
+  for (uint32_t q = 0; q < Q; q++) hs.deserved[q] = qs[q].deserved;
+  hs.queue_share_at_open = st.share_at_open ? 1 : 0;
+  e->waterfill_passes = st.passes;
+}
+
 int kb_session_load(kb_engine *e, const kb_snapshot *sn) {
   if (!e) return KB_E_INVALID;
   return guarded(e, [&]() {
@@ -1111,6 +1149,7 @@ int kb_session_load(kb_engine *e, const kb_snapshot *sn) {
     HostSession &hs = e->hs;
     const uint32_t NP = ((sn->n_nodes + KB_NODE_PAD - 1) / KB_NODE_PAD) * KB_NODE_PAD + (sn->n_nodes == 0 ? KB_NODE_PAD : 0);
     std::vector<uint32_t> t_active, nmask;
+    hs.waterfill_on_device = e->device_waterfill && e->pol.has_proportion;
     build_host_session(sn, e->pol, NP, hs, t_active, nmask);   // kb_session.cpp: validation, shapes, plugin OnSessionOpen state
     const int R = hs.R;
     const uint32_t N = hs.N, T = hs.T, J = hs.J, Q = hs.Q;
@@ -1338,6 +1377,7 @@ int kb_session_load(kb_engine *e, const kb_snapshot *sn) {
     upload(e->b_jqueue, hs.job_queue.data(), J, s);
     upload(e->b_total, hs.total.v, KB_MAX_RES, s);
     e->total_mask = hs.total.mask;
+    if (hs.waterfill_on_device) device_waterfill(e);
     std::vector<double> des((size_t)R * (Q ? Q : 1), 0.0);
     std::vector<uint32_t> desmask(Q ? Q : 1, 0);
     for (uint32_t q = 0; q < Q; q++) {

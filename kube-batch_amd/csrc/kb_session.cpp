@@ -98,7 +98,9 @@ struct Interner {
 // kb_session_load, host part.  t_active: per task the dimensions LessEqual compares (bits 0, 1 always; a scalar bit when InitResreq
 // exceeds the epsilon); nmask: per node (padded to NP) the scalar keys of Idle, bit 31 <=> Releasing carries scalar keys.
 void build_host_session(const kb_snapshot *sn, const Policy &pol, uint32_t NP, HostSession &hs, std::vector<uint32_t> &t_active, std::vector<uint32_t> &nmask) {
+  const bool waterfill_on_device = hs.waterfill_on_device;   // the caller's choice, made before this call
   hs = HostSession();
+  hs.waterfill_on_device = waterfill_on_device;
   const int R = hs.R = (int)sn->n_res;
   const uint32_t N = hs.N = sn->n_nodes, T = hs.T = sn->n_tasks, J = hs.J = sn->n_jobs, Q = hs.Q = sn->n_queues;
   // ---- validation of the exact envelope ----
@@ -387,7 +389,8 @@ void build_host_session(const kb_snapshot *sn, const Policy &pol, uint32_t NP, H
     }
   }
   hs.queue_share_at_open = 1;
-  if (pol.has_proportion) {
+  hs.queue_request = request;
+  if (pol.has_proportion && !hs.waterfill_on_device) {   // on the device: kb_session_load runs kb_launch_waterfill over hs.queue_request (KB_DEVICE_WATERFILL=1)
     Res remaining = hs.total;
     std::vector<uint8_t> meet(Q, 0);
     for (bool first = true;; first = false) {

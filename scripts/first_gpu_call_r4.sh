@@ -13,7 +13,11 @@
 #      candidate lists in its own idle workgroups, kb_repair.hpp): the launch-path variants, the overlapped-list cases, the fuzz and full-size
 #      suites with the switch on, then the same-box A/B on configs 3, 4, 5.  Green and not slower => default on, k_repair becomes a wrapper
 #      around kb_repair_row (one copy of the text), DESIGN section 9 item 2
-#   5. the default bench line and the two variants, for the record of what the round starts from
+#   5. proportion's water-fill as a launch behind KB_DEVICE_WATERFILL=1: FIRST device run of k_waterfill (kb_waterfill.hip): the adversarial,
+#      fuzz, regression and preempt suites with the switch on (they compare `deserved` and the shares with the oracle bit for bit), the
+#      host-against-device cases of tests/test_emu_engine_cpu.py on the product library.  Green => default on, the host loop in
+#      kb_session.cpp goes (kb_waterfill.hpp stays the one text), DESIGN section 9 item 4
+#   6. the default bench line and the two variants, for the record of what the round starts from
 set -uo pipefail
 cd "$(dirname "$0")/.."
 out=gpurun_out/r4_first
@@ -65,6 +69,10 @@ for cfg in 3 4 5; do
     echo "config $cfg fold $fold rc=$? $(python -c "import json,sys; d=json.loads(open('$out/bench_config${cfg}_fold${fold}.json').read().strip().splitlines()[-1]); print(d.get('ms_per_step'), d.get('verified_bind_set_equals_oracle'))" 2>/dev/null)" | tee -a "$out/summary.txt"
   done
 done
+KB_DEVICE_WATERFILL=1 timeout 900 python -m pytest tests/test_gpu_adversarial.py tests/test_gpu_fuzz.py tests/test_gpu_regressions.py tests/test_gpu_preempt.py -x -q -m gpu -p no:cacheprovider \
+  > "$out/pytest_gpu_waterfill.txt" 2>&1; echo "device water-fill: gpu suites rc=$?" | tee -a "$out/summary.txt"
+KB_EMU_LIB="$lib" timeout 600 python -m pytest tests/test_emu_engine_cpu.py -q -p no:cacheprovider -k "device_waterfill" \
+  > "$out/pytest_waterfill_cases_on_device.txt" 2>&1; echo "device water-fill: host-against-device cases on the device rc=$?" | tee -a "$out/summary.txt"
 python bench.py > "$out/bench_default.json" 2> "$out/bench_default.err"; echo "bench rc=$?" | tee -a "$out/summary.txt"
 python bench.py --config 4 --steps 3 --warmup 1 --no-cpu-baseline > "$out/bench_config4.json" 2> "$out/bench_config4.err"; echo "bench config 4 rc=$?" | tee -a "$out/summary.txt"
 python bench.py --config 5 --preempt --steps 2 --warmup 1 --no-cpu-baseline > "$out/bench_config5_three_actions.json" 2> "$out/bench_config5.err"; echo "bench config 5 three actions rc=$?" | tee -a "$out/summary.txt"

@@ -27,6 +27,15 @@ ASAN_OPTIONS=detect_leaks=0 LD_PRELOAD="$(gcc -print-file-name=libasan.so) $(g++
 gcc -std=c11 -O1 -g -fPIC -shared -ffp-contract=off -fsanitize=thread -o "$out/libkboracle_tsan.so" oracle/kb_oracle.c -lm -lpthread
 TSAN_OPTIONS="report_signal_unsafe=0 exitcode=66" LD_PRELOAD="$(gcc -print-file-name=libtsan.so)" KB_ORACLE_LIB="$out/libkboracle_tsan.so" \
   python -m pytest tests/test_oracle_kat.py -q -k threaded -p no:cacheprovider
+# ThreadSanitizer over kb_waterfill.hip's kernel text run by 256 host threads with a real barrier (tests/host_harness/waterfill_kernel_harness.cpp):
+# an access pair the kernel's barriers do not order is a reported race (the first run reported one: lane 0's read of the stop word beside the
+# other lanes' — a speculated load; lane 0 now keeps its own copy)
+g++ -std=c++17 -O1 -g -fPIC -shared -ffp-contract=off -fsanitize=thread -pthread -Itests/host_harness/hip_mock -o "$out/libwaterfillkernel_tsan.so" \
+  tests/host_harness/waterfill_kernel_harness.cpp
+TSAN_OPTIONS="report_signal_unsafe=0 exitcode=66" LD_PRELOAD="$(gcc -print-file-name=libtsan.so) $(g++ -print-file-name=libstdc++.so.6)" \
+KB_WATERFILL_HARNESS_LIB="$out/libwaterfillkernel_tsan.so" python -m pytest tests/test_waterfill_kernel_cpu.py -x -q -p no:cacheprovider
+# the whole emulated suite with proportion's water-fill taken from the (emulated) launch
+KB_DEVICE_WATERFILL=1 python -m pytest tests/test_emu_engine_cpu.py -x -q -p no:cacheprovider -n 8 -k "not two_gloo and not fullsize"
 # ThreadSanitizer over the host <-> device handshake: the emulated streams run asynchronously (KB_EMU_ASYNC=1: a worker thread per stream with
 # HIP's ordering rules, tests/host_harness/hip_mock), so a staging half, a mailbox word or a result the host touches before the device is done
 # with it is a reported race.  Chained / unchained rounds, pinned mailbox / synchronous rounds, direct window, both commit-kernel pins.

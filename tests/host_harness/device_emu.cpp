@@ -19,6 +19,7 @@
 #include <thread>
 #include <vector>
 
+#include "../../kube-batch_amd/csrc/kb_waterfill.hpp"   // before kb_eval.hpp: it brings include/kb_engine.h, whose task-status enum kb_eval.hpp names as macros
 #include "../../kube-batch_amd/csrc/kb_device.h"
 #include "../../kube-batch_amd/csrc/kb_eval.hpp"
 
@@ -626,5 +627,16 @@ void kb_launch_finalize(const KbDev &d, const uint32_t *job_task_begin, const in
     }
     queue_share[q] = share;
   }
+  });
+}
+
+// k_waterfill's contract: proportion's OnSessionOpen loop over the queue records, in the steps the kernel's lanes run (kb_waterfill.hpp — the
+// step functions are shared text; what the kernel adds, the placement of its barriers, is not emulated)
+static unsigned long long g_waterfill_launches = 0;
+extern "C" unsigned long long kbemu_waterfill_launches() { return __atomic_load_n(&g_waterfill_launches, __ATOMIC_RELAXED); }
+void kb_launch_waterfill(kb::WfQueue *qs, uint32_t Q, kb::WfState *st, int R, void *stream) {
+  kbemu_enqueue((hipStream_t)stream, [qs, Q, st, R]() {
+    __atomic_fetch_add(&g_waterfill_launches, 1ull, __ATOMIC_RELAXED);
+    kb::wf_run_sequential(qs, Q, *st, R);
   });
 }

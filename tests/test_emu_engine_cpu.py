@@ -37,7 +37,7 @@ def build_emulated_library():
     os.makedirs(out_dir, exist_ok=True)
     so = os.path.join(out_dir, "libkbengine_emu.so")
     srcs = [os.path.join(CSRC, f) for f in ("kb_engine.cpp", "kb_session.cpp", "kb_order.cpp", "kb_preempt.cpp")] + [os.path.join(HH, "device_emu.cpp"), os.path.join(HH, "hip_mock", "hip_mock.cpp")]
-    deps = srcs + [os.path.join(CSRC, f) for f in ("kb_device.h", "kb_eval.hpp", "kb_host.hpp", "kb_preempt.hpp")] + \
+    deps = srcs + [os.path.join(CSRC, f) for f in ("kb_device.h", "kb_eval.hpp", "kb_host.hpp", "kb_res.hpp", "kb_waterfill.hpp", "kb_preempt.hpp")] + \
         [os.path.join(HH, "hip_mock", "hip", "hip_runtime.h"), os.path.join(HERE, "..", "include", "kb_engine.h")]
     if not os.path.exists(so) or any(os.path.getmtime(d) > os.path.getmtime(so) for d in deps):
         tmp = f"{so}.{os.getpid()}"                      # atomic: parallel pytest workers may build at the same time
@@ -391,3 +391,110 @@ def test_overlapped_launches_wait_for_the_copies_kb_session_reset_left_queued(em
     code = _RESET_RACE_SCRIPT.format(root=os.path.join(HERE, ".."), tests=HERE, so=emulated_engine)
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr
+
+
+# ---- proportion's water-fill as a launch (round 3, behind KB_DEVICE_WATERFILL=1 until its first device run) -------------------------------
+def _waterfill_counter(so):
+    """launches of the emulated k_waterfill so far; the product library (scripts/first_gpu_call_r4.sh: KB_EMU_LIB) has no such counter: None"""
+    L = C.CDLL(so)
+    if not hasattr(L, "kbemu_waterfill_launches"):
+        return lambda: None
+    f = L.kbemu_waterfill_launches
+    f.restype = C.c_ulonglong
+    return f
+
+
+def _load_and_run(cfg, snap):
+    """(error code, None) where kb_session_load refuses, else (None, (decisions, binds, node state, shares))"""
+    e = engine.Engine(cfg)
+    try:
+        e.load(snap)
+    except engine.EngineError as err:
+        e.close()
+        return err.code, None
+    try:
+        dec = e.run(["allocate", "backfill"])
+    except engine.EngineError as err:
+        e.close()
+        return None, ("run", err.code)
+    out = (dec, e.binds(), e.node_state(), e.shares())
+    e.close()
+    return None, out
+
+
+def _same(a, b):
+    if isinstance(a, tuple):
+        return isinstance(b, tuple) and len(a) == len(b) and all(_same(x, y) for x, y in zip(a, b))
+    if isinstance(a, np.ndarray):
+        return np.array_equal(a, b)
+    return a == b
+
+
+@pytest.mark.parametrize("block", range(8))
+def test_the_device_waterfill_equals_the_host_loop_on_adversarial_snapshots(emulated_engine, monkeypatch, block):
+    """kb_waterfill.hpp's steps (the text kb_waterfill.hip's lanes run, here run one after the other by the emulated launch) against
+    kb_session.cpp's loop — which tests/test_host_evict_cpu.py holds to tests/pyref.py and the adversarial `-m gpu` cases to the oracle — on
+    tests/rawgen.py's snapshots (zero and huge queue weights, queues without jobs, nil scalar maps, requests above and below the cluster's total):
+    the same `deserved` bit for bit, the same shares, the same decisions, and KB_E_UNSUPPORTED on exactly the snapshots whose water-fill
+    underflows (the reference panics in Resource.Sub there)."""
+    import rawgen
+    import test_pyref_vs_oracle as cases
+    launches = _waterfill_counter(emulated_engine)
+    refused = 0
+    for seed in range(block * 50, block * 50 + 50):
+        snap = rawgen.raw_snapshot(seed)
+        rng = np.random.RandomState(seed)
+        wl, wm, wa, wb = [int(x) for x in rng.choice([0, 1, 1, 2, 5], size=4)]
+        cfg = kbm.conf.load_scheduler_conf(cases.CONF_TMPL.format(wl=wl, wm=wm, wa=wa, wb=wb))
+        monkeypatch.delenv("KB_DEVICE_WATERFILL", raising=False)
+        n0 = launches()
+        host = _load_and_run(cfg, snap)
+        assert launches() == n0                            # off by default
+        monkeypatch.setenv("KB_DEVICE_WATERFILL", "1")
+        dev = _load_and_run(cfg, snap)
+        has_proportion = any(po.name == "proportion" for t in cfg.tiers for po in t)
+        assert host[0] == dev[0], (seed, host[0], dev[0])
+        if host[0] is None:
+            assert n0 is None or launches() == n0 + (1 if has_proportion else 0), seed
+            assert _same(host[1], dev[1]), seed
+        else:
+            refused += 1
+    assert refused < 50                                    # the block compared something
+
+
+def test_the_device_waterfill_on_the_tutorial_example_and_on_128_queues(emulated_engine, monkeypatch):
+    """doc/usage/tutorial.md:297-330 (deserved = (3 cpu, 9 Gi) and (6 cpu, 18 Gi) for weights 2 and 4: the reference's own known answer for the
+    loop) and BASELINE configs[2]'s 128 queues scaled down (several passes: queues meet their request one after the other), through the launch;
+    the session then survives a reset and a second cycle."""
+    snapmod = kbm.snapshot
+    oracle_mod = importlib.import_module("oracle")
+    monkeypatch.setenv("KB_DEVICE_WATERFILL", "1")
+    launches = _waterfill_counter(emulated_engine)
+    Gi = 1 << 30
+    pods = [snapmod.Pod("q1", f"p{i}", [{"cpu": "1", "memory": "2Gi"}], group_name="j1") for i in range(5)]
+    pods += [snapmod.Pod("q2", f"p{i}", [{"cpu": "1", "memory": "2Gi"}], group_name="j2") for i in range(10)]
+    snap = snapmod.flatten(
+        nodes=[snapmod.Node("n1", {"cpu": "6", "memory": "15Gi", "pods": "110"}), snapmod.Node("n2", {"cpu": "3", "memory": "12Gi", "pods": "110"})],
+        pods=pods, pod_groups=[snapmod.PodGroup("q1", "j1", queue="queue1"), snapmod.PodGroup("q2", "j2", queue="queue2")],
+        queues=[snapmod.Queue("queue1", 2), snapmod.Queue("queue2", 4)])
+    cfg = kbm.conf.load_scheduler_conf()
+    n0 = launches()
+    e = engine.Engine(cfg)
+    e.load(snap)
+    assert n0 is None or launches() == n0 + 1
+    des = e.shares()[2]
+    assert [des[0, 0], des[1, 0]] == [3000.0, 9.0 * Gi] and [des[0, 1], des[1, 1]] == [6000.0, 18.0 * Gi]
+    e.close()
+
+    snap = snapmod.synth(snapmod.synth_config(3, 0.05))
+    o = oracle_mod.Oracle(cfg, snap)
+    o.run(["allocate", "backfill"])
+    e = engine.Engine(cfg)
+    e.load(snap)
+    for _ in range(2):
+        dec = e.run(["allocate", "backfill"])
+        assert np.array_equal(dec, o.decisions()) and np.array_equal(e.binds(), o.binds())
+        for a, b in zip(e.shares(), o.shares()):
+            assert np.array_equal(a, b)
+        e.reset()
+    e.close()

@@ -39,7 +39,7 @@ def load_harness():
     os.makedirs(out_dir, exist_ok=True)
     so = os.path.join(out_dir, "libevictharness.so")
     srcs = [os.path.join(HERE, "host_harness", "evict_harness.cpp"), os.path.join(CSRC, "kb_session.cpp"), os.path.join(CSRC, "kb_preempt.cpp")]
-    deps = srcs + [os.path.join(CSRC, "kb_host.hpp"), os.path.join(CSRC, "kb_preempt.hpp"), os.path.join(HERE, "..", "include", "kb_engine.h")]
+    deps = srcs + [os.path.join(CSRC, "kb_host.hpp"), os.path.join(CSRC, "kb_res.hpp"), os.path.join(CSRC, "kb_preempt.hpp"), os.path.join(HERE, "..", "include", "kb_engine.h")]
     if not os.path.exists(so) or any(os.path.getmtime(d) > os.path.getmtime(so) for d in deps):
         tmp = f"{so}.{os.getpid()}"
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-fno-fast-math", "-o", tmp] + srcs)

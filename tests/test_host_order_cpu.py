@@ -31,7 +31,7 @@ def harness():
     os.makedirs(out_dir, exist_ok=True)
     so = os.path.join(out_dir, "liborderharness.so")
     srcs = [os.path.join(HERE, "host_harness", "order_harness.cpp"), os.path.join(HERE, "..", "kube-batch_amd", "csrc", "kb_order.cpp")]
-    deps = srcs + [os.path.join(HERE, "..", "kube-batch_amd", "csrc", "kb_host.hpp")]
+    deps = srcs + [os.path.join(HERE, "..", "kube-batch_amd", "csrc", f) for f in ("kb_host.hpp", "kb_res.hpp")]
     if not os.path.exists(so) or any(os.path.getmtime(d) > os.path.getmtime(so) for d in deps):
         tmp = f"{so}.{os.getpid()}"                          # atomic: several pytest workers may build at once
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-fno-fast-math", "-o", tmp] + srcs)
