@@ -120,8 +120,11 @@ func (a *gpuAllocateAction) Execute(ssn *framework.Session) {
 	}
 }
 
-// replay applies the engine's ordered decisions through the Session (framework/session.go:194-288)
-func (a *gpuAllocateAction) replay(ssn *framework.Session, fl *flat, dec []C.kb_decision) {
+// replay applies the engine's ordered decisions through the Session (framework/session.go:194-288); it returns how many of them the
+// Session refused (0: the Session now stands where the engine's own session stands — what cycle.go needs to know before it lets the next
+// action run on the loaded session)
+func (a *gpuAllocateAction) replay(ssn *framework.Session, fl *flat, dec []C.kb_decision) int {
+	failed := 0
 	for i := range dec {
 		task, node := fl.tasks[dec[i].task], fl.nodes[dec[i].node]
 		var err error
@@ -132,8 +135,10 @@ func (a *gpuAllocateAction) replay(ssn *framework.Session, fl *flat, dec []C.kb_
 		}
 		if err != nil {
 			glog.Errorf("gpuallocate: replay of task %s on %s failed: %v", task.UID, node.Name, err)
+			failed++
 		}
 	}
+	return failed
 }
 
 var pluginIDs = map[string]C.uint32_t{

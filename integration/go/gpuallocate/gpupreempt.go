@@ -71,8 +71,13 @@ func (p *gpuPreemptAction) Execute(ssn *framework.Session) {
 		p.fallback.Execute(ssn)
 		return
 	}
-	journal := (*[1 << 28]C.kb_stmt_op)(unsafe.Pointer(ops))[:n:n]
+	replayPreemptJournal(ssn, fl, (*[1 << 28]C.kb_stmt_op)(unsafe.Pointer(ops))[:n:n])
+}
 
+// replayPreemptJournal applies kb_run_preempt's journal through framework.Statement in the engine's order; it returns how many entries the
+// Session refused (0: the Session stands where the engine's session stands, cycle.go)
+func replayPreemptJournal(ssn *framework.Session, fl *flat, journal []C.kb_stmt_op) int {
+	failed := 0
 	var stmt *framework.Statement
 	cur := C.uint32_t(0)
 	for i := range journal {
@@ -87,14 +92,17 @@ func (p *gpuPreemptAction) Execute(ssn *framework.Session) {
 			victim, found := node.Tasks[api.PodKey(fl.tasks[op.task].Pod)]
 			if !found {
 				glog.Errorf("gpupreempt: victim %s is not on node %s any more", fl.tasks[op.task].UID, node.Name)
+				failed++
 				continue
 			}
 			if err := stmt.Evict(victim.Clone(), "preempt"); err != nil {
 				glog.Errorf("gpupreempt: evict %s: %v", victim.UID, err)
+				failed++
 			}
 		case C.KB_OP_PIPELINE: // preempt.go:248
 			if err := stmt.Pipeline(fl.tasks[op.task], fl.nodes[op.node].Name); err != nil {
 				glog.Errorf("gpupreempt: pipeline %s on %s: %v", fl.tasks[op.task].UID, fl.nodes[op.node].Name, err)
+				failed++
 			}
 		case C.KB_OP_COMMIT: // preempt.go:124 / :162
 			stmt.Commit()
@@ -102,6 +110,7 @@ func (p *gpuPreemptAction) Execute(ssn *framework.Session) {
 			stmt.Discard()
 		}
 	}
+	return failed
 }
 
 // runJournal calls kb_run_preempt / kb_run_reclaim with a journal buffer in C memory (the engine fills it, Go only reads it).  There is
@@ -182,21 +191,34 @@ func (p *gpuReclaimAction) Execute(ssn *framework.Session) {
 		p.fallback.Execute(ssn)
 		return
 	}
-	journal := (*[1 << 28]C.kb_stmt_op)(unsafe.Pointer(ops))[:n:n]
+	replayReclaimJournal(ssn, fl, (*[1 << 28]C.kb_stmt_op)(unsafe.Pointer(ops))[:n:n])
+}
+
+// replayReclaimJournal applies kb_run_reclaim's journal through the Session itself (reclaim uses no Statement); it returns how many entries
+// the Session refused
+func replayReclaimJournal(ssn *framework.Session, fl *flat, journal []C.kb_stmt_op) int {
+	failed := 0
 	for i := range journal {
 		op := journal[i]
 		switch op.op {
 		case C.KB_OP_EVICT: // reclaim.go:163: the reclaimee is the node's own clone of the task (:136-139)
 			node := fl.nodes[op.node]
-			if victim, found := node.Tasks[api.PodKey(fl.tasks[op.task].Pod)]; found {
-				if err := ssn.Evict(victim.Clone(), "reclaim"); err != nil {
-					glog.Errorf("gpureclaim: evict %s: %v", victim.UID, err)
-				}
+			victim, found := node.Tasks[api.PodKey(fl.tasks[op.task].Pod)]
+			if !found {
+				glog.Errorf("gpureclaim: victim %s is not on node %s any more", fl.tasks[op.task].UID, node.Name)
+				failed++
+				continue
+			}
+			if err := ssn.Evict(victim.Clone(), "reclaim"); err != nil {
+				glog.Errorf("gpureclaim: evict %s: %v", victim.UID, err)
+				failed++
 			}
 		case C.KB_OP_PIPELINE: // reclaim.go:178
 			if err := ssn.Pipeline(fl.tasks[op.task], fl.nodes[op.node].Name); err != nil {
 				glog.Errorf("gpureclaim: pipeline %s on %s: %v", fl.tasks[op.task].UID, fl.nodes[op.node].Name, err)
+				failed++
 			}
 		}
 	}
+	return failed
 }

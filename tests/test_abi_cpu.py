@@ -196,12 +196,35 @@ def test_go_shim_handles_empty_sessions_before_taking_slice_addresses():
     guard = re.search(r"if T == 0 \|\| N == 0 \{\s*return f, nil", flat)
     first_addr = re.search(r"unsafe\.Pointer\(&\w+\[0\]\)", flat)
     assert guard and first_addr and guard.start() < first_addr.start()
-    for fn in ("gpuallocate.go", "gpupreempt.go"):
+    for fn in ("gpuallocate.go", "gpupreempt.go", "cycle.go"):
         code = _go_code(open(os.path.join(godir, fn)).read())
         for body in re.split(r"\nfunc ", code):
             # the actions themselves; a helper that RE-loads an already loaded session (runJournal) is behind an action's check
             if "C.kb_session_load(" in body and re.match(r"\([^)]*\) Execute\(", body):
                 assert "len(fl.tasks) == 0" in body and body.index("len(fl.tasks) == 0") < body.index("C.kb_session_load("), fn
+
+
+def test_go_cycle_action_keeps_the_loaded_session_only_while_the_replay_was_clean():
+    """cycle.go runs the engine actions of a cycle on ONE flatten + load (round-2 advisory: the single actions re-flatten per action).  Textual
+    checks of what makes that safe: every replay helper reports refused entries, the cycle drops the loaded session after a refusal, after an
+    engine error (the stock action then runs the step) and on KB_E_CAPACITY (same step again on a fresh load), and it calls all four actions."""
+    godir = os.path.join(ROOT, "integration", "go", "gpuallocate")
+    cyc = _go_code(open(os.path.join(godir, "cycle.go")).read())
+    for call in ("C.kb_run_allocate(", "C.kb_run_backfill(", "C.kb_run_preempt(", "C.kb_run_reclaim(", "C.kb_session_load(", "flatten(ssn)"):
+        assert call in cyc, call
+    assert cyc.count("C.kb_session_load(") == 1                              # one place loads: the top of the step loop, behind `!loaded`
+    body = cyc[cyc.index("func (c *gpuCycleAction) Execute("):cyc.index("func (c *gpuCycleAction) runStock(")]
+    assert re.search(r"if !loaded \{.*?flatten\(ssn\).*?C\.kb_session_load\(.*?loaded = true", body, flags=re.S)
+    assert re.search(r"res\.rc == C\.KB_E_CAPACITY.*?loaded = false\s*continue", body, flags=re.S)
+    assert re.search(r"res\.rc != C\.KB_OK \{.*?c\.stock\[step\]\.Execute\(ssn\)\s*loaded = false", body, flags=re.S)
+    assert re.search(r"res\.failed > 0 \{\s*loaded = false", body)
+    act = _go_code(open(os.path.join(godir, "gpuallocate.go")).read())
+    pre = _go_code(open(os.path.join(godir, "gpupreempt.go")).read())
+    assert re.search(r"func \(a \*gpuAllocateAction\) replay\([^)]*\) int \{", act) and "failed++" in act
+    for fn in ("replayPreemptJournal", "replayReclaimJournal"):
+        assert re.search(r"func " + fn + r"\([^)]*\) int \{", pre), fn
+        assert fn + "(" in cyc
+    assert pre.count("failed++") >= 5
 
 
 def test_integration_md_quotes_the_shipped_go_action():
