@@ -1150,7 +1150,17 @@ int kb_session_load(kb_engine *e, const kb_snapshot *sn) {
     const uint32_t NP = ((sn->n_nodes + KB_NODE_PAD - 1) / KB_NODE_PAD) * KB_NODE_PAD + (sn->n_nodes == 0 ? KB_NODE_PAD : 0);
     std::vector<uint32_t> t_active, nmask;
     hs.waterfill_on_device = e->device_waterfill && e->pol.has_proportion;
+    // KB_LOAD_TRACE=1: where a load's time goes, phase by phase, on stderr (the Go action loads a session every cycle)
+    static const bool load_trace = [] { const char *v = getenv("KB_LOAD_TRACE"); return v && v[0] == '1'; }();
+    double t_mark = now_ms();
+    auto mark = [&](const char *what) {
+      if (!load_trace) return;
+      const double t = now_ms();
+      fprintf(stderr, "kb_session_load: %-28s %8.3f ms\n", what, t - t_mark);
+      t_mark = t;
+    };
     build_host_session(sn, e->pol, NP, hs, t_active, nmask);   // kb_session.cpp: validation, shapes, plugin OnSessionOpen state
+    mark("build_host_session");
     const int R = hs.R;
     const uint32_t N = hs.N, T = hs.T, J = hs.J, Q = hs.Q;
     const kb_interpod *ip = sn->interpod;
@@ -1207,6 +1217,7 @@ int kb_session_load(kb_engine *e, const kb_snapshot *sn) {
       if (((unsigned long long)(max_score + 2) << kb_node_bits(NP)) > (1ull << 32))
         throw EngineError(KB_E_UNSUPPORTED, "score range x node count exceeds the commit kernel's 32-bit keys");
     }
+    mark("node arrays, window");
     std::vector<uint32_t> ncls(NP, 0);
     if (sn->node_class) std::memcpy(ncls.data(), sn->node_class, sizeof(uint32_t) * N);
     upload(e->b_ncls, ncls.data(), NP, s);
@@ -1246,6 +1257,7 @@ int kb_session_load(kb_engine *e, const kb_snapshot *sn) {
     upload(e->b_tcounted, counted.data(), T, s);
     e->b_jallocated.alloc(J ? J : 1);
     HIP_OK(hipMemsetAsync(e->b_jallocated.p, 0, J ? J : 1, s));
+    mark("task arrays");
     d.compat = nullptr;
     d.n_nc = sn->n_node_classes ? sn->n_node_classes : 1;
     if (sn->class_compat) {
@@ -1368,6 +1380,7 @@ int kb_session_load(kb_engine *e, const kb_snapshot *sn) {
       d.ip_z = e->b_ip_z.as<uint32_t>();
       d.ip_C = C; d.ip_D = D; d.ip_P = P; d.ip_Wc = Wc; d.ip_Wp = Wp;
     }
+    mark("classes, ports, inter-pod");
     upload(e->b_probe_rows, hs.feas_rep.data(), hs.n_feas_shapes, s);
     e->b_probe_alive.alloc(sizeof(uint32_t) * std::max<uint32_t>(hs.n_feas_shapes, 1u));
     e->h_probe_alive.resize(std::max<uint32_t>(hs.n_feas_shapes, 1u));
@@ -1418,6 +1431,7 @@ int kb_session_load(kb_engine *e, const kb_snapshot *sn) {
     e->dirty_share = 0.0;
     e->commit_kernel = e->commit_pin >= 0 ? e->commit_pin : KB_COMMIT_BATCH;
     e->round_no = 0;
+    mark("jobs, queues, deserved");
     auto snap_copy = [&](DevBuf &dst, const DevBuf &src) {
       dst.alloc(src.bytes);
       HIP_OK(hipMemcpyAsync(dst.p, src.p, src.bytes, hipMemcpyDeviceToDevice, s));
@@ -1429,7 +1443,9 @@ int kb_session_load(kb_engine *e, const kb_snapshot *sn) {
     snap_copy(e->p_nmask, e->b_nmask);   // the evict actions rewrite the key masks of the nodes they touch (upload_live_nodes)
     if (hs.has_interpod) { snap_copy(e->p_ip_ccnt, e->b_ip_ccnt); snap_copy(e->p_ip_ctot, e->b_ip_ctot); snap_copy(e->p_ip_punb, e->b_ip_punb); snap_copy(e->p_ip_z, e->b_ip_z); }
     // initial drf / proportion / gang aggregates come from the device reduction (K2+K4)
+    mark("pristine copies (queued)");
     run_finalize(e);
+    mark("aggregates (device reduction)");
     e->fin0.job_alloc = hs.job_alloc; e->fin0.job_share = hs.job_share; e->fin0.queue_alloc = hs.queue_alloc; e->fin0.queue_share = hs.queue_share;
     e->fin0.job_ready = hs.job_ready; e->fin0.t_status = hs.t_status; e->fin0.t_node = hs.t_node; e->fin0.valid = true;
     e->stats.reduce_ms = 0;
