@@ -89,3 +89,32 @@ def test_smoke_entry_point_runs_end_to_end(monkeypatch, capsys):
     entry = importlib.import_module("__graft_entry__")
     entry.smoke()
     assert "smoke ok" in capsys.readouterr().out
+
+
+def test_two_ranks_under_torch_distributed_run_print_one_line(tmp_path):
+    """The driver's N > 1 launch — `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py
+    --gpus N ...` — with two ranks here: gloo stands in for RCCL (KB_DIST_BACKEND), the emulated library for the engine
+    (tests/host_harness/bench_emu_launcher.py).  Rank 0 prints ONE line, it counts both replicas' work ("weak"), the MAX over the ranks' times is
+    taken, and the replicas' decision digests were compared after the timed region."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, KB_EMU_LIB=emu.build_emulated_library(), KB_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "KB_DIST_MODE"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(HERE, "host_harness", "bench_emu_launcher.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--scale", "0.02"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=os.path.dirname(HERE))
+    assert r.returncode == 0, r.stdout + r.stderr
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["warmup"] == 1 and d["scaling"] == "weak"
+    assert d["replicas"] == 2 and d["replicas_agree"] is True and d["multi_gpu_mode"].startswith("replicas only")
+    assert "cpu_baseline" not in d or d["cpu_baseline"] is None        # reported at N = 1 only
+    assert d["roofline"]["bound"] == "hbm"
+    # both replicas' evaluations over the slowest rank's time
+    assert abs(d["value"] - 2 * d["evals_per_step"] / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"]
