@@ -78,5 +78,10 @@ if [ -x "$CL" ]; then
   $CL $fl -o "$out/libevictharness_clang.so" tests/host_harness/evict_harness.cpp kube-batch_amd/csrc/kb_session.cpp kube-batch_amd/csrc/kb_preempt.cpp
   KB_ORDER_HARNESS_LIB="$out/liborderharness_clang.so" KB_EVICT_HARNESS_LIB="$out/libevictharness_clang.so" \
     python -m pytest tests/test_host_order_cpu.py tests/test_host_evict_cpu.py -x -q -p no:cacheprovider
+  # ... and the whole host side of the engine on the emulated device (the library's name is part of one test)
+  mkdir -p "$out/clang"
+  $CL $fl -pthread -Itests/host_harness/hip_mock -o "$out/clang/libkbengine_emu.so" kube-batch_amd/csrc/kb_engine.cpp kube-batch_amd/csrc/kb_session.cpp \
+    kube-batch_amd/csrc/kb_order.cpp kube-batch_amd/csrc/kb_preempt.cpp tests/host_harness/device_emu.cpp tests/host_harness/hip_mock/hip_mock.cpp
+  KB_EMU_LIB="$out/clang/libkbengine_emu.so" python -m pytest tests/test_emu_engine_cpu.py -x -q -p no:cacheprovider -n 8 -k "not two_gloo"
 fi
 rm -rf "$out"
