@@ -5,7 +5,8 @@ is NON-INCREASING in k, the loop's winners are the global top-r of all (node, k)
 This script measures on the synthetic clusters how often that premise holds, per shape, from the snapshot's initial node state:
     python scripts/study_run_monotone.py [--config 3] [--scale 0.1] [--survey-nodes] [--depth 16]
 It prints, per nodeorder weight set, the share of (shape, node) sequences that are non-increasing over the feasible prefix, and the share of shapes for
-which EVERY node's sequence is."""
+which EVERY node's sequence is.  (Result, round 3: the premise fails for most shapes once Balanced is in the score — and is not needed: with the PREFIX MINIMUM of
+every node's sequence in its place the selection equals the loop always; tests/run_selection_model.py has the argument and the executable model.)"""
 import argparse
 import importlib
 import os
