@@ -34,6 +34,8 @@ g++ -std=c++17 -O1 -g -fPIC -shared -ffp-contract=off -fsanitize=thread -pthread
   tests/host_harness/waterfill_kernel_harness.cpp
 TSAN_OPTIONS="report_signal_unsafe=0 exitcode=66" LD_PRELOAD="$(gcc -print-file-name=libtsan.so) $(g++ -print-file-name=libstdc++.so.6)" \
 KB_WATERFILL_HARNESS_LIB="$out/libwaterfillkernel_tsan.so" python -m pytest tests/test_waterfill_kernel_cpu.py -x -q -p no:cacheprovider
+# the whole emulated suite with every run of identical rows committed by one selection (the emulated commit launch only)
+KB_EMU_RUN_SELECT=1 python -m pytest tests/test_emu_engine_cpu.py -x -q -p no:cacheprovider -n 8 -k "not two_gloo and not fullsize"
 # the whole emulated suite with proportion's water-fill taken from the (emulated) launch
 KB_DEVICE_WATERFILL=1 python -m pytest tests/test_emu_engine_cpu.py -x -q -p no:cacheprovider -n 8 -k "not two_gloo and not fullsize"
 # ThreadSanitizer over the host <-> device handshake: the emulated streams run asynchronously (KB_EMU_ASYNC=1: a worker thread per stream with

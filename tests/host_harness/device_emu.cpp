@@ -132,6 +132,7 @@ uint32_t mrow_task(const KbRound &r, uint32_t m) { return r.mrows ? r.mrows[m] :
 
 // ---- the sequential commit of one window (kb_commit.hip / kb_commit_batch.hip: same decisions, different statistics words) ----
 void remember_commit_nodes(const std::vector<uint32_t> &nodes);
+unsigned long long g_selected_rows = 0;   // rows committed by the run selection (KB_EMU_RUN_SELECT)
 void emu_commit(const KbDev &d, const KbRound &r, bool batch_kernel) {
   if (r.n_rows == 0) return;
   u64 *o64 = out64(r);
@@ -154,50 +155,37 @@ void emu_commit(const KbDev &d, const KbRound &r, bool batch_kernel) {
   uint32_t n_done = 0, reason = KB_REASON_DONE, dirty_won = 0;
   KbDev dl = d;   // the commit kernels carry their own copies of the policy switches (KbCommitArgs); same values
   uint32_t i = 0;
-  for (; i < r.n_rows; i++) {
-    const KbRowDesc &k = r.desc[i];
-    if (has_aff && !r.backfill && (k.flags & 2u) && i != 0) { reason = KB_REASON_RENORM; break; }
+  // KB_EMU_RUN_SELECT=1 (tests/run_selection_model.py): a run of consecutive rows that are the same in everything a decision
+  // depends on is committed by ONE selection instead of row by row — every candidate node's own key sequence (its score after j placements of the
+  // shape, while it fits), the prefix minimum of it, the first r of all (node, step) entries by (prefix minimum desc, node asc, step asc).  The
+  // contract of the launch does not change: the whole emulated suite must still equal the oracle with the switch on.
+  // KB_EMU_RUN_SELECT=2 is the negative control: the real key in the place of the prefix minimum (the premise "a node's keys only fall").
+  static const int run_select_mode = [] { const char *v = getenv("KB_EMU_RUN_SELECT"); return v ? atoi(v) : 0; }();
+  const bool run_select = run_select_mode != 0;
+  auto make_row = [&](const KbRowDesc &k) {
     Row row;
     row.init0 = k.init0; row.init1 = k.init1; row.nzc = (double)k.nzc; row.nzm = (double)k.nzm;
     row.cls = k.cls; row.active = k.active; row.task = k.task;
     row.conf = has_ports ? d.t_conf[k.task] : 0ull;
     row.ip_checks = false;
     row.use_crow = use_crow; row.crow = k.crow;
-    // best node the round already changed: exact re-evaluation against its live state
-    u64 best_dirty = 0;
-    for (uint32_t n : dirty_nodes) {
-      const uint32_t e = eval_pair(dl, row, n, r.fit_mode, false);
-      if (e) best_dirty = std::max(best_dirty, ((u64)((e & 0xFFFFu) + 1u) << 32) | (u64)(0xFFFFFFFFu - n));
+    return row;
+  };
+  auto kind_of = [&](const KbRowDesc &k, uint32_t n) -> uint32_t {   // allocate.go:160: InitResreq.LessEqual(node.Idle) -> Allocate, else Pipeline
+    if (r.backfill) return 0u;
+    bool fi = le_eps(k.init0, d.idle[n], EPS_CPU) && le_eps(k.init1, d.idle[(size_t)d.NP + n], EPS_MEM);
+    uint32_t a = k.active >> 2, dd = 2;
+    while (a) {
+      if (a & 1u) fi = fi && le_eps(d.t_init[(size_t)dd * d.T + k.task], d.idle[(size_t)dd * d.NP + n], EPS_SCALAR);
+      a >>= 1;
+      dd++;
     }
-    // best clean node: the first entry of the shape's sorted list (round-start state) whose node is still untouched
-    u64 best_clean = 0;
-    const u64 *list = r.keys + (size_t)k.slot * r.L;
-    for (uint32_t e = 0; e < r.L && list[e] != 0ull; e++) {
-      const uint32_t n = KB_KEY_NODE(list[e]);
-      if (!dirty[n]) { best_clean = ((u64)(KB_KEY_SCORE(list[e]) + 1u) << 32) | (u64)(0xFFFFFFFFu - n); break; }
-    }
-    if (best_dirty == 0 && best_clean == 0) {
-      if (r.backfill) { dec[i] = (u64)KB_NONE_U32; continue; }   // backfill.go:50-66: the task stays Pending
-      reason = KB_REASON_NO_FEASIBLE;                            // allocate.go:144-148: the host re-plans from here
-      break;
-    }
-    const u64 win = std::max(best_dirty, best_clean);
-    const uint32_t n = 0xFFFFFFFFu - (uint32_t)(win & 0xFFFFFFFFull);
-    if (best_dirty >= best_clean) dirty_won++;
+    return fi ? 0u : 1u;
+  };
+  // NodeInfo.AddTask (api/node_info.go:172-212): Idle (Allocated) or Releasing (Pipelined) -= Resreq, the pod joins ni.Tasks.
+  // Resource.Sub leaves the scalars alone when the receiver's map is nil (resource_info.go:148-153).
+  auto add_task = [&](const KbRowDesc &k, uint32_t n, uint32_t kind) {
     const uint32_t t = k.task;
-    uint32_t kind = 0;
-    if (!r.backfill) {   // allocate.go:160: InitResreq.LessEqual(node.Idle) -> Allocate, else Pipeline
-      bool fi = le_eps(k.init0, d.idle[n], EPS_CPU) && le_eps(k.init1, d.idle[(size_t)d.NP + n], EPS_MEM);
-      uint32_t a = k.active >> 2, dd = 2;
-      while (a) {
-        if (a & 1u) fi = fi && le_eps(d.t_init[(size_t)dd * d.T + t], d.idle[(size_t)dd * d.NP + n], EPS_SCALAR);
-        a >>= 1;
-        dd++;
-      }
-      kind = fi ? 0u : 1u;
-    }
-    // NodeInfo.AddTask (api/node_info.go:172-212): Idle (Allocated) or Releasing (Pipelined) -= Resreq, the pod joins ni.Tasks.
-    // Resource.Sub leaves the scalars alone when the receiver's map is nil (resource_info.go:148-153).
     double *side = kind ? d.rel : d.idle;
     side[n] -= d.t_res[t];
     side[(size_t)d.NP + n] -= d.t_res[(size_t)d.T + t];
@@ -212,9 +200,106 @@ void emu_commit(const KbDev &d, const KbRound &r, bool batch_kernel) {
     d.nzm[n] += k.nzm;
     d.podcnt[n] += 1;
     if (has_ports) d.ports[n] |= d.t_want[t];
+  };
+  auto same_decision_inputs = [&](uint32_t a, uint32_t b) {   // rows a and b differ in the task id only
+    const KbRowDesc &x = r.desc[a], &y = r.desc[b];
+    if (x.slot != y.slot || x.flags != y.flags || (x.flags & 2u) || x.init0 != y.init0 || x.init1 != y.init1 || x.nzc != y.nzc || x.nzm != y.nzm ||
+        x.active != y.active || x.resmask != y.resmask || x.cls != y.cls || x.crow != y.crow) return false;
+    for (int dd = 0; dd < d.R; dd++)
+      if (d.t_res[(size_t)dd * d.T + x.task] != d.t_res[(size_t)dd * d.T + y.task] || d.t_init[(size_t)dd * d.T + x.task] != d.t_init[(size_t)dd * d.T + y.task]) return false;
+    if (has_ports && (d.t_conf[x.task] != d.t_conf[y.task] || d.t_want[x.task] != d.t_want[y.task])) return false;
+    return true;
+  };
+  struct Entry { uint32_t eff, node, step, kind; };
+  while (i < r.n_rows) {
+    const KbRowDesc &k = r.desc[i];
+    if (has_aff && !r.backfill && (k.flags & 2u) && i != 0) { reason = KB_REASON_RENORM; break; }
+    uint32_t i1 = i + 1;
+    if (run_select) while (i1 < r.n_rows && same_decision_inputs(i, i1)) i1++;
+    if (i1 - i >= 2) {
+      const uint32_t rlen = i1 - i;
+      const Row row = make_row(k);
+      std::vector<uint32_t> cand(dirty_nodes);
+      const u64 *list = r.keys + (size_t)k.slot * r.L;
+      for (uint32_t e = 0, got = 0; e < r.L && list[e] != 0ull && got < rlen; e++) {   // winners are among the rlen best initial keys
+        const uint32_t n = KB_KEY_NODE(list[e]);
+        if (!dirty[n]) { cand.push_back(n); got++; }
+      }
+      std::vector<Entry> ent;
+      std::vector<double> sv_idle(d.R), sv_rel(d.R);
+      for (uint32_t n : cand) {   // one lane per node: its own sequence, from its own state
+        for (int dd = 0; dd < d.R; dd++) { sv_idle[dd] = d.idle[(size_t)dd * d.NP + n]; sv_rel[dd] = d.rel[(size_t)dd * d.NP + n]; }
+        const long long sv_nzc = d.nzc[n], sv_nzm = d.nzm[n];
+        const int sv_pods = d.podcnt[n];
+        const u64 sv_ports = has_ports ? d.ports[n] : 0ull;
+        uint32_t eff = 0xFFFFFFFFu;
+        for (uint32_t j = 0; j < rlen; j++) {
+          const uint32_t e = eval_pair(dl, row, n, r.fit_mode, false);
+          if (!e) break;                                  // feasibility only shrinks inside a run: the sequence ends here
+          eff = run_select_mode == 2 ? (e & 0xFFFFu) : std::min(eff, e & 0xFFFFu);
+          const uint32_t kind = kind_of(k, n);
+          ent.push_back(Entry{eff, n, j, kind});
+          if (kind) break;                                // a Pipeline ends the round when it is picked: nothing behind it is ever reached
+          add_task(k, n, 0u);
+        }
+        for (int dd = 0; dd < d.R; dd++) { d.idle[(size_t)dd * d.NP + n] = sv_idle[dd]; d.rel[(size_t)dd * d.NP + n] = sv_rel[dd]; }
+        d.nzc[n] = sv_nzc; d.nzm[n] = sv_nzm; d.podcnt[n] = sv_pods;
+        if (has_ports) d.ports[n] = sv_ports;
+      }
+      std::sort(ent.begin(), ent.end(), [](const Entry &a, const Entry &b) {
+        if (a.eff != b.eff) return a.eff > b.eff;
+        if (a.node != b.node) return a.node < b.node;
+        return a.step < b.step;
+      });
+      bool stop = false;
+      uint32_t q = 0;
+      for (; q < rlen && q < ent.size(); q++) {
+        const KbRowDesc &kq = r.desc[i + q];
+        const uint32_t n = ent[q].node, kind = ent[q].kind;
+        if (dirty[n]) dirty_won++;
+        add_task(kq, n, kind);
+        if (!dirty[n]) { dirty[n] = 1; dirty_nodes.push_back(n); }
+        dec[i + q] = (u64)n | ((u64)kind << 32);
+        if (kind) { q++; reason = KB_REASON_PIPELINED; stop = true; break; }
+      }
+      i += q;
+      __atomic_fetch_add(&g_selected_rows, (unsigned long long)q, __ATOMIC_RELAXED);
+      if (stop) break;
+      if (q < rlen) {   // the run's shape has no feasible node left
+        if (r.backfill) { for (; i < i1; i++) dec[i] = (u64)KB_NONE_U32; continue; }
+        reason = KB_REASON_NO_FEASIBLE;
+        break;
+      }
+      continue;
+    }
+    const Row row = make_row(k);
+    // best node the round already changed: exact re-evaluation against its live state
+    u64 best_dirty = 0;
+    for (uint32_t n : dirty_nodes) {
+      const uint32_t e = eval_pair(dl, row, n, r.fit_mode, false);
+      if (e) best_dirty = std::max(best_dirty, ((u64)((e & 0xFFFFu) + 1u) << 32) | (u64)(0xFFFFFFFFu - n));
+    }
+    // best clean node: the first entry of the shape's sorted list (round-start state) whose node is still untouched
+    u64 best_clean = 0;
+    const u64 *list = r.keys + (size_t)k.slot * r.L;
+    for (uint32_t e = 0; e < r.L && list[e] != 0ull; e++) {
+      const uint32_t n = KB_KEY_NODE(list[e]);
+      if (!dirty[n]) { best_clean = ((u64)(KB_KEY_SCORE(list[e]) + 1u) << 32) | (u64)(0xFFFFFFFFu - n); break; }
+    }
+    if (best_dirty == 0 && best_clean == 0) {
+      if (r.backfill) { dec[i] = (u64)KB_NONE_U32; i++; continue; }   // backfill.go:50-66: the task stays Pending
+      reason = KB_REASON_NO_FEASIBLE;                                 // allocate.go:144-148: the host re-plans from here
+      break;
+    }
+    const u64 win = std::max(best_dirty, best_clean);
+    const uint32_t n = 0xFFFFFFFFu - (uint32_t)(win & 0xFFFFFFFFull);
+    if (best_dirty >= best_clean) dirty_won++;
+    const uint32_t kind = kind_of(k, n);
+    add_task(k, n, kind);
     if (!dirty[n]) { dirty[n] = 1; dirty_nodes.push_back(n); }
     dec[i] = (u64)n | ((u64)kind << 32);
-    if (kind) { i++; reason = KB_REASON_PIPELINED; break; }   // a Pipeline ends the speculated order: the host re-plans
+    i++;
+    if (kind) { reason = KB_REASON_PIPELINED; break; }   // a Pipeline ends the speculated order: the host re-plans
   }
   n_done = i;
   // ---- epilogue: decision records, the task-table side of ssn.Allocate / ssn.Pipeline, inter-pod counters, multi-GPU deltas
@@ -632,6 +717,7 @@ void kb_launch_finalize(const KbDev &d, const uint32_t *job_task_begin, const in
 
 // k_waterfill's contract: proportion's OnSessionOpen loop over the queue records, in the steps the kernel's lanes run (kb_waterfill.hpp — the
 // step functions are shared text; what the kernel adds, the placement of its barriers, is not emulated)
+extern "C" unsigned long long kbemu_selected_rows() { return __atomic_load_n(&g_selected_rows, __ATOMIC_RELAXED); }
 static unsigned long long g_waterfill_launches = 0;
 extern "C" unsigned long long kbemu_waterfill_launches() { return __atomic_load_n(&g_waterfill_launches, __ATOMIC_RELAXED); }
 void kb_launch_waterfill(kb::WfQueue *qs, uint32_t Q, kb::WfState *st, int R, void *stream) {

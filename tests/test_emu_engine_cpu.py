@@ -498,3 +498,64 @@ def test_the_device_waterfill_on_the_tutorial_example_and_on_128_queues(emulated
             assert np.array_equal(a, b)
         e.reset()
     e.close()
+
+
+# ---- a run of identical rows committed by ONE selection (the emulated commit launch, KB_EMU_RUN_SELECT=1) ------------------
+_RUN_SELECT_SCRIPT = r"""
+import importlib, os, sys
+sys.path[:0] = [{root!r}, {tests!r}]
+import ctypes as C
+import numpy as np
+engine = importlib.import_module("kube-batch_amd.engine")
+kbm = importlib.import_module("kube-batch_amd")
+import oracle
+import bench
+engine.LIB_PATH, engine._LIB = {so!r}, None
+sel = C.CDLL({so!r}).kbemu_selected_rows
+sel.restype = C.c_ulonglong
+wrong = total = 0
+for idx, survey, scale in ((3, False, 0.05), (3, True, 0.05), (4, False, 0.03), (2, False, 1.0)):
+    conf = kbm.conf.load_scheduler_conf(bench.BINPACK_CONF) if idx == 4 else kbm.conf.load_scheduler_conf()
+    p = kbm.snapshot.synth_config(idx, scale)
+    if survey:
+        p.node_cpu_cores = (16, 32, 64, 96, 128)
+        p.node_mem_gib = (64, 128, 256, 512)
+    snap = kbm.snapshot.synth(p)
+    o = oracle.Oracle(conf, snap)
+    o.run(["allocate", "backfill"])
+    e = engine.Engine(conf)
+    e.load(snap)
+    s0 = sel()
+    dec = e.run(["allocate", "backfill"])
+    same = dec.shape == o.decisions().shape and np.array_equal(dec, o.decisions()) and np.array_equal(e.binds(), o.binds())
+    if same:
+        same = all(np.array_equal(a, b) for a, b in zip(e.node_state(), o.node_state()))
+    wrong += 0 if same else 1
+    total += 1
+    print("case", idx, survey, "decisions", len(dec), "rows by selection", sel() - s0, "equal" if same else "DIFFERENT")
+    e.close()
+print("wrong", wrong, "of", total)
+"""
+
+
+@pytest.mark.parametrize("mode", ["1", "2"])
+def test_runs_of_identical_rows_committed_by_one_selection(emulated_engine, mode):
+    """tests/run_selection_model.py's claim inside the engine's own launch contract: the emulated commit launch takes every run of rows that differ in
+    the task id only through ONE selection — each candidate node's own key sequence against its own state (the product's per-pair arithmetic, epsilon
+    compares, scalar dimensions, ports, pod caps), prefix minima, the first r of all (node, step) entries — and the cycle still equals the oracle
+    (decisions in order, binds, final node state) on the bench configurations, where most rows are committed that way.  (The whole emulated suite
+    also passes with the switch on: scripts/sanitize_cpu.sh.)  Mode 2 is the negative control — the real key in the place of the prefix minimum,
+    i.e. the premise 'a node's keys only fall', which Balanced breaks: at least one configuration must come out different."""
+    env = dict(os.environ, KB_EMU_RUN_SELECT=mode)
+    code = _RUN_SELECT_SCRIPT.format(root=os.path.join(HERE, ".."), tests=HERE, so=emulated_engine)
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout + r.stderr
+    lines = [l for l in r.stdout.splitlines() if l.startswith("case")]
+    assert len(lines) == 4, r.stdout
+    for l in lines:
+        f = l.split()
+        assert int(f[8]) * 2 > int(f[4]), l                     # most rows of the cycle went through the selection
+    if mode == "1":
+        assert "wrong 0 of 4" in r.stdout, r.stdout
+    else:
+        assert "wrong 0 of 4" not in r.stdout, r.stdout
