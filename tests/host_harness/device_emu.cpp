@@ -133,6 +133,7 @@ uint32_t mrow_task(const KbRound &r, uint32_t m) { return r.mrows ? r.mrows[m] :
 // ---- the sequential commit of one window (kb_commit.hip / kb_commit_batch.hip: same decisions, different statistics words) ----
 void remember_commit_nodes(const std::vector<uint32_t> &nodes);
 unsigned long long g_selected_rows = 0;   // rows committed by the run selection (KB_EMU_RUN_SELECT)
+unsigned long long g_select_lanes = 0, g_select_steps = 0;   // ... the node sequences walked for them, and the evaluations those walks cost
 void emu_commit(const KbDev &d, const KbRound &r, bool batch_kernel) {
   if (r.n_rows == 0) return;
   u64 *o64 = out64(r);
@@ -227,16 +228,33 @@ void emu_commit(const KbDev &d, const KbRound &r, bool batch_kernel) {
       }
       std::vector<Entry> ent;
       std::vector<double> sv_idle(d.R), sv_rel(d.R);
+      // A lane may stop where its prefix minimum falls below the rlen-th best INITIAL key of the candidates: rlen entries (the first steps of the
+      // rlen best) are at or above that key, so nothing below it is among the first rlen.  (Mode 2, the negative control, walks everything.)
+      uint32_t floor_key = 0;
+      if (run_select_mode == 1 && cand.size() >= rlen) {
+        std::vector<uint32_t> k0;
+        for (uint32_t n : cand) {
+          const uint32_t e = eval_pair(dl, row, n, r.fit_mode, false);
+          if (e) k0.push_back(e & 0xFFFFu);
+        }
+        if (k0.size() >= rlen) {
+          std::nth_element(k0.begin(), k0.begin() + (rlen - 1), k0.end(), [](uint32_t a, uint32_t b) { return a > b; });
+          floor_key = k0[rlen - 1];
+        }
+      }
       for (uint32_t n : cand) {   // one lane per node: its own sequence, from its own state
         for (int dd = 0; dd < d.R; dd++) { sv_idle[dd] = d.idle[(size_t)dd * d.NP + n]; sv_rel[dd] = d.rel[(size_t)dd * d.NP + n]; }
         const long long sv_nzc = d.nzc[n], sv_nzm = d.nzm[n];
         const int sv_pods = d.podcnt[n];
         const u64 sv_ports = has_ports ? d.ports[n] : 0ull;
         uint32_t eff = 0xFFFFFFFFu;
+        __atomic_fetch_add(&g_select_lanes, 1ull, __ATOMIC_RELAXED);
         for (uint32_t j = 0; j < rlen; j++) {
           const uint32_t e = eval_pair(dl, row, n, r.fit_mode, false);
+          __atomic_fetch_add(&g_select_steps, 1ull, __ATOMIC_RELAXED);
           if (!e) break;                                  // feasibility only shrinks inside a run: the sequence ends here
           eff = run_select_mode == 2 ? (e & 0xFFFFu) : std::min(eff, e & 0xFFFFu);
+          if (eff < floor_key) break;                     // below the floor: neither this entry nor anything behind it can be picked
           const uint32_t kind = kind_of(k, n);
           ent.push_back(Entry{eff, n, j, kind});
           if (kind) break;                                // a Pipeline ends the round when it is picked: nothing behind it is ever reached
@@ -718,6 +736,8 @@ void kb_launch_finalize(const KbDev &d, const uint32_t *job_task_begin, const in
 // k_waterfill's contract: proportion's OnSessionOpen loop over the queue records, in the steps the kernel's lanes run (kb_waterfill.hpp — the
 // step functions are shared text; what the kernel adds, the placement of its barriers, is not emulated)
 extern "C" unsigned long long kbemu_selected_rows() { return __atomic_load_n(&g_selected_rows, __ATOMIC_RELAXED); }
+extern "C" unsigned long long kbemu_select_lanes() { return __atomic_load_n(&g_select_lanes, __ATOMIC_RELAXED); }
+extern "C" unsigned long long kbemu_select_steps() { return __atomic_load_n(&g_select_steps, __ATOMIC_RELAXED); }
 static unsigned long long g_waterfill_launches = 0;
 extern "C" unsigned long long kbemu_waterfill_launches() { return __atomic_load_n(&g_waterfill_launches, __ATOMIC_RELAXED); }
 void kb_launch_waterfill(kb::WfQueue *qs, uint32_t Q, kb::WfState *st, int R, void *stream) {

@@ -511,8 +511,9 @@ kbm = importlib.import_module("kube-batch_amd")
 import oracle
 import bench
 engine.LIB_PATH, engine._LIB = {so!r}, None
-sel = C.CDLL({so!r}).kbemu_selected_rows
-sel.restype = C.c_ulonglong
+L = C.CDLL({so!r})
+sel, lanes, steps = L.kbemu_selected_rows, L.kbemu_select_lanes, L.kbemu_select_steps
+sel.restype = lanes.restype = steps.restype = C.c_ulonglong
 wrong = total = 0
 for idx, survey, scale in ((3, False, 0.05), (3, True, 0.05), (4, False, 0.03), (2, False, 1.0)):
     conf = kbm.conf.load_scheduler_conf(bench.BINPACK_CONF) if idx == 4 else kbm.conf.load_scheduler_conf()
@@ -525,14 +526,15 @@ for idx, survey, scale in ((3, False, 0.05), (3, True, 0.05), (4, False, 0.03), 
     o.run(["allocate", "backfill"])
     e = engine.Engine(conf)
     e.load(snap)
-    s0 = sel()
+    s0, l0, t0 = sel(), lanes(), steps()
     dec = e.run(["allocate", "backfill"])
     same = dec.shape == o.decisions().shape and np.array_equal(dec, o.decisions()) and np.array_equal(e.binds(), o.binds())
     if same:
         same = all(np.array_equal(a, b) for a, b in zip(e.node_state(), o.node_state()))
     wrong += 0 if same else 1
     total += 1
-    print("case", idx, survey, "decisions", len(dec), "rows by selection", sel() - s0, "equal" if same else "DIFFERENT")
+    print("case", idx, survey, "decisions", len(dec), "rows by selection", sel() - s0, "equal" if same else "DIFFERENT",
+          "| node sequences walked", lanes() - l0, "evaluations", steps() - t0)
     e.close()
 print("wrong", wrong, "of", total)
 """
