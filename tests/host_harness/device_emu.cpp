@@ -133,6 +133,7 @@ uint32_t mrow_task(const KbRound &r, uint32_t m) { return r.mrows ? r.mrows[m] :
 // ---- the sequential commit of one window (kb_commit.hip / kb_commit_batch.hip: same decisions, different statistics words) ----
 void remember_commit_nodes(const std::vector<uint32_t> &nodes);
 unsigned long long g_selected_rows = 0;   // rows committed by the run selection (KB_EMU_RUN_SELECT)
+unsigned long long g_select_runs = 0;     // ... the runs they came in
 unsigned long long g_select_lanes = 0, g_select_steps = 0;   // ... the node sequences walked for them, and the evaluations those walks cost
 void emu_commit(const KbDev &d, const KbRound &r, bool batch_kernel) {
   if (r.n_rows == 0) return;
@@ -282,6 +283,7 @@ void emu_commit(const KbDev &d, const KbRound &r, bool batch_kernel) {
       }
       i += q;
       __atomic_fetch_add(&g_selected_rows, (unsigned long long)q, __ATOMIC_RELAXED);
+      __atomic_fetch_add(&g_select_runs, 1ull, __ATOMIC_RELAXED);
       if (stop) break;
       if (q < rlen) {   // the run's shape has no feasible node left
         if (r.backfill) { for (; i < i1; i++) dec[i] = (u64)KB_NONE_U32; continue; }
@@ -736,6 +738,7 @@ void kb_launch_finalize(const KbDev &d, const uint32_t *job_task_begin, const in
 // k_waterfill's contract: proportion's OnSessionOpen loop over the queue records, in the steps the kernel's lanes run (kb_waterfill.hpp — the
 // step functions are shared text; what the kernel adds, the placement of its barriers, is not emulated)
 extern "C" unsigned long long kbemu_selected_rows() { return __atomic_load_n(&g_selected_rows, __ATOMIC_RELAXED); }
+extern "C" unsigned long long kbemu_select_runs() { return __atomic_load_n(&g_select_runs, __ATOMIC_RELAXED); }
 extern "C" unsigned long long kbemu_select_lanes() { return __atomic_load_n(&g_select_lanes, __ATOMIC_RELAXED); }
 extern "C" unsigned long long kbemu_select_steps() { return __atomic_load_n(&g_select_steps, __ATOMIC_RELAXED); }
 static unsigned long long g_waterfill_launches = 0;
