@@ -176,6 +176,7 @@ struct kb_engine {
   uint64_t overlapped_rounds = 0, overlap_faults = 0, folded_rounds = 0;
   bool device_waterfill = false;   // KB_DEVICE_WATERFILL=1: proportion's water-fill runs as a launch at kb_session_load (kb_waterfill.hip); off until it has run on a device
   uint32_t waterfill_passes = 0;
+  DevBuf b_wf_queues, b_wf_state;
   bool fold_repair = false;        // KB_FOLD_REPAIR=1: an overlapped round on the batch commit kernel repairs its lists inside the commit launch (KbRound::fold);
                                    // off until it has run on a device
   DevBuf b_win, b_out;   // per-round upload / download blocks (see h_win / h_out)
@@ -1118,9 +1119,9 @@ static void device_waterfill(kb_engine *e) {
   WfState st;
   st.remaining = hs.total;
   st.total_weight = 0; st.stop = 0; st.share_at_open = 1; st.underflow = 0; st.passes = 0;
-  DevBuf b_q, b_st;
-  b_q.alloc(sizeof(WfQueue) * qs.size());
-  b_st.alloc(sizeof(WfState));
+  DevBuf &b_q = e->b_wf_queues, &b_st = e->b_wf_state;   // kept between loads (the Go action loads a session every cycle): grown, never shrunk
+  if (b_q.bytes < sizeof(WfQueue) * qs.size()) b_q.alloc(sizeof(WfQueue) * qs.size());
+  if (b_st.bytes < sizeof(WfState)) b_st.alloc(sizeof(WfState));
   HIP_OK(hipMemcpy(b_q.p, qs.data(), sizeof(WfQueue) * qs.size(), hipMemcpyHostToDevice));
   HIP_OK(hipMemcpy(b_st.p, &st, sizeof(WfState), hipMemcpyHostToDevice));
   kb_launch_waterfill(b_q.as<WfQueue>(), Q, b_st.as<WfState>(), hs.R, e->stream);
