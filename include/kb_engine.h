@@ -324,9 +324,8 @@ int  kb_run_backfill(kb_engine *e, kb_decision *out, uint64_t cap, uint64_t *n_o
    KB_E_STATE until kb_session_load or kb_session_reset; the getters keep working.
    Sessions with preferred node-affinity terms are scored with NormalizeReduce over the preemptor's feasible set, which one Pipeline can
    change for every node: their lists are rebuilt after every Pipeline instead of repaired (KB_PREEMPT_NODE_AFFINITY=0 in the environment
-   restores the round-2 refusal, KB_E_UNSUPPORTED).  Sessions with inter-pod (anti)affinity terms: KB_E_UNSUPPORTED unless KB_EVICT_INTERPOD=1
-   (the evict machine then keeps the kb_interpod counts current on the host and rebuilds every list after a change; checked against the oracle
-   on the emulated device, not yet on the MI355X).  KB_E_UNSUPPORTED: states in which the reference itself would panic / abort
+   restores the round-2 refusal, KB_E_UNSUPPORTED).  Sessions with inter-pod (anti)affinity terms: the evict machine keeps the kb_interpod
+   counts current on the host and rebuilds every list after a change (tests/test_gpu_interpod.py).  KB_E_UNSUPPORTED: states in which the reference itself would panic / abort
    (Resource.Sub underflow, NodeInfo.UpdateTask). */
 int  kb_run_preempt(kb_engine *e, kb_stmt_op *out, uint64_t cap, uint64_t *n_out);
 /* the reclaim action (pkg/scheduler/actions/reclaim/reclaim.go:41-193; victims through ssn.Reclaimable, framework/session_plugins.go:

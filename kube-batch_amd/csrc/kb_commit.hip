@@ -56,9 +56,20 @@ struct K9Hdr {
 // dynamic LDS layout for a round of n_rows rows and n_shapes distinct shapes
 struct K9Layout {
   uint32_t slots, rowres, sinit, shapes, desc, rinfo, dec, hdr, dk, ckey, cpos, cursor, shp, lists, bitmap, total;   // byte offsets
+  uint32_t sel;   // the selection kernel's scratch (K9Sel), 0 in the run kernel's layout
   uint32_t Lp, RS;
 };
-__host__ __device__ inline K9Layout k9_layout(uint32_t n_rows, uint32_t n_shapes, uint32_t L, uint32_t NP, int R) {
+// Scratch of the run selection (k_commit_run<true>): what the evaluation phase leaves about every dirty slot one placement deep, and wave 0's
+// entry / contender tables.
+struct K9Sel {
+  uint32_t dk1[K9_MAXSLOTS];          // key of dirty slot t after ONE more placement of the run's shape (0: infeasible; only where dk[t] is above the floor)
+  uint32_t dkk[K9_MAXSLOTS];          // bit 0: that placement would be a Pipeline; bit 1: the one after it would be
+  unsigned long long e_comp[64];      // entries: prefix-minimum key << 8 | 255 - step  (greater = picked earlier)
+  uint32_t e_info[64];                // contender | kind << 8 | step << 16
+  uint32_t c_slot[64], c_next[64], c_eff[64], c_flag[64], c_take[64];   // contenders: state slot, next unknown step, prefix minimum so far, bit 0 ended / bit 1 clean / bit 2 its last taken entry is a Pipeline
+  uint32_t al[64], kt[64], kk[64];    // a deep pass: the contenders it walks, the keys and kinds its lanes found
+};
+__host__ __device__ inline K9Layout k9_layout(uint32_t n_rows, uint32_t n_shapes, uint32_t L, uint32_t NP, int R, bool sel = false) {
   K9Layout o;
   o.RS = R > 2 ? (uint32_t)(R - 2) : 0u;
   o.Lp = L;
@@ -79,11 +90,14 @@ __host__ __device__ inline K9Layout k9_layout(uint32_t n_rows, uint32_t n_shapes
   o.shp = off;    off += n_shapes * 4u;
   o.lists = off;  off += n_shapes * o.Lp * 4u;
   o.bitmap = off; off += (NP / 32u) * 4u;
+  off = (off + 15u) & ~15u;
+  o.sel = 0;
+  if (sel) { o.sel = off; off += (uint32_t)sizeof(K9Sel); }
   o.total = (off + 15u) & ~15u;
   return o;
 }
-size_t kb_commit_smem_bytes(uint32_t n_rows, uint32_t n_shapes, uint32_t NP, int R) {
-  return k9_layout(n_rows, n_shapes, n_rows + 1, NP, R).total;
+size_t kb_commit_smem_bytes(uint32_t n_rows, uint32_t n_shapes, uint32_t NP, int R) {   // the window is planned for either of the two (the selection kernel's scratch included)
+  return k9_layout(n_rows, n_shapes, n_rows + 1, NP, R, true).total;
 }
 
 __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
@@ -217,6 +231,30 @@ __device__ __forceinline__ uint32_t k9_eval_v(const KbCommitArgs &a, const K9Sha
   return ((score + 1u) << nb) | (nmaskbits - v.node);
 }
 
+// allocate.go:160: InitResreq.LessEqual(node.Idle) -> Allocate, else Pipeline; idle0 / idle1: the node's Idle cpu / memory as the caller has it,
+// the scalar dimensions as k9_eval_v reads them (adj_*: placements whose scalar part has not reached HBM)
+__device__ __forceinline__ bool k9_fits_idle(const KbCommitArgs &a, const K9Shape &sh, double idle0, double idle1, const K9Sc &sc, gptrd gi, const double *si, uint32_t node,
+                                             uint32_t adj_mask, double adj_mul, const double *rq) {
+  bool fi = le_eps(sh.init0, idle0, EPS_CPU) && le_eps(sh.init1, idle1, EPS_MEM);
+  for (uint32_t aa = sh.active >> 2, dd = 0; aa; aa >>= 1, dd++)
+    if (aa & 1u) {
+      double id = k9_sci(sc, gi, a.NP, dd, node);
+      if ((adj_mask >> dd) & 1u) id -= adj_mul * rq[dd];
+      fi = fi && le_eps(si[dd], id, EPS_SCALAR);
+    }
+  return fi;
+}
+
+// SEL (KB_COMMIT_SELECT, DESIGN.md section 4 "run selection"): the rows phase of a run of r >= 2 plain rows is ONE selection instead of a loop
+// over the rows.  Every candidate node — the run's r best clean entries and the dirty slots whose key is above the r-th of them — has its own
+// key sequence key(n, j) (its key for the shape after j placements of the shape, while the placement still fits), which depends on that
+// node's state only; with eff(n, j) = min key(n, 0..j), the serial loop's picks are the first r of all (n, j) entries in (eff descending,
+// j ascending) order (keys carry the node, so entries of different nodes never tie): a node picked at key s was the maximum; while its next
+// keys stay >= s it wins again at once, and when its key falls below s the prefix minimum is the real key again.  A Pipeline entry ends
+// its node's sequence (picked, it ends the round).  Steps 0 and 1 of every candidate come out of the parallel evaluation phase; deeper
+// steps are walked by the lanes of wave 0, several steps per candidate in one pass; the order is a rank by count.  Nothing is written
+// before the picks are known, so any limit of the tables (64 entries, 64 candidates) simply hands the run to the serial loop.
+template <bool SEL>
 __global__ void __launch_bounds__(K9_THREADS) k_commit_run(const K9KernArgs ka) {
   KbCommitArgs a = ka.hot;
   {   // only `a` is named in the loops (SGPRs); the two views are read through the kernel-argument segment on rare paths
@@ -247,7 +285,8 @@ __global__ void __launch_bounds__(K9_THREADS) k_commit_run(const K9KernArgs ka) 
   extern __shared__ __align__(16) unsigned char k9_smem[];
   const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const uint32_t S = a.n_mrows, W = a.n_rows;
-  const K9Layout lo = k9_layout(W, S, a.L, a.NP, a.R);
+  const K9Layout lo = k9_layout(W, S, a.L, a.NP, a.R, SEL);
+  K9Sel &X = *reinterpret_cast<K9Sel *>(k9_smem + lo.sel);   // SEL only
   unsigned long long *slots = reinterpret_cast<unsigned long long *>(k9_smem + lo.slots);
   double *rowres = reinterpret_cast<double *>(k9_smem + lo.rowres);
   double *sinit = reinterpret_cast<double *>(k9_smem + lo.sinit);
@@ -317,7 +356,7 @@ __global__ void __launch_bounds__(K9_THREADS) k_commit_run(const K9KernArgs ka) 
     const bool plain = (fl & 1u) && (km == 0u || (fl & 4u));
     uint32_t r = 1;
     if (plain && !(fl & 2u))
-      while (r < K9_MAXRUN && i + r < W && desc[i + r].slot == sl && desc[i + r].flags == fl && desc[i + r].resmask == km) r++;
+      while (r < (SEL ? 32u : K9_MAXRUN) && i + r < W && desc[i + r].slot == sl && desc[i + r].flags == fl && desc[i + r].resmask == km) r++;
     rinfo[i] = make_uint4(r, sl, fl, km);
   }
   __syncthreads();
@@ -414,13 +453,37 @@ __global__ void __launch_bounds__(K9_THREADS) k_commit_run(const K9KernArgs ka) 
     const K9Shape sh = shapes[s];
     const double *si = sinit + (size_t)s * RS;
     const double *rqv = plain0 ? si : rowres + 2;   // the rows' scalar Resreq
+    // SEL: the run goes through the selection (plain rows of the allocate action, at least two of them); cmin: the r-th best clean candidate's
+    // key — r entries are at or above it, so no entry below it is among the picks (0: the list holds fewer than r clean nodes)
+    const bool sel_run = SEL && !a.backfill && plain0 && r >= 2u;
+    const uint32_t cmin = (sel_run && ncand == r) ? ckey[r - 1u] : 0u;
     // ---- evaluation phase, one evaluation deep: waves 1..4 the shape against "their" dirty slot, wave 0 the candidates
     if (wave >= 1 && tid - 64u < nd) {
       const uint32_t t = tid - 64u;
       const K9St vs = k9_load(slots + (size_t)t * K9_NF);
-      dk[t] = k9_eval_v(a, sh, vs, k9_sc_preload(sh.active >> 2, gi, gr, a.NP, vs.node), gi, gr, si, 0u, 0.0, si, nb, nmaskbits);
+      const K9Sc scp = k9_sc_preload(sh.active >> 2, gi, gr, a.NP, vs.node);
+      const uint32_t key0 = k9_eval_v(a, sh, vs, scp, gi, gr, si, 0u, 0.0, si, nb, nmaskbits);
+      dk[t] = key0;
+      if (SEL) {
+        // a slot that can be picked (its key is above the floor): what its first placement would be, and its key and kind one placement on
+        uint32_t key1 = 0u, kk = 0u;
+        if (sel_run && key0 > cmin) {
+          const uint32_t nm0 = (uint32_t)(slots[(size_t)t * K9_NF + F_NODE_NMASK] >> 32);
+          const uint32_t adjm = (nm0 & 0x7FFFFFFFu) ? km0 : 0u;   // Idle has a scalar map: Sub lowers the dimensions Resreq names
+          if (k9_fits_idle(a, sh, vs.idle0, vs.idle1, scp, gi, si, vs.node, 0u, 0.0, si)) {
+            K9St v1 = vs;
+            v1.idle0 -= sh.init0; v1.idle1 -= sh.init1; v1.nzc += sh.nzc; v1.nzm += sh.nzm;
+            v1.ports |= sh.want; v1.left -= 1;
+            key1 = k9_eval_v(a, sh, v1, scp, gi, gr, si, adjm, 1.0, si, nb, nmaskbits);
+            if (!k9_fits_idle(a, sh, v1.idle0, v1.idle1, scp, gi, si, vs.node, adjm, 1.0, si)) kk |= 2u;
+          } else {
+            kk = 1u;   // the first placement would be a Pipeline: it ends the slot's sequence
+          }
+        }
+        X.dk1[t] = key1; X.dkk[t] = kk;
+      }
     }
-    uint32_t ck = 0, k1 = 0, ckind = 0;
+    uint32_t ck = 0, k1 = 0, ckind = 0, ckind1 = 0;
     double res0 = sh.init0, res1 = sh.init1;
     if (wave == 0) {
       if (!plain0) { res0 = rowres[0]; res1 = rowres[1]; }
@@ -458,6 +521,7 @@ __global__ void __launch_bounds__(K9_THREADS) k_commit_run(const K9KernArgs ka) 
         const uint32_t adjm = (!kind && (rnm & 0x7FFFFFFFu)) ? km0 : 0u;
         ckind = kind;
         k1 = k9_eval_v(a, sh, v, scn, gi, gr, si, adjm, 1.0, rqv, nb, nmaskbits);   // the node's key once it is dirty
+        if (SEL && sel_run && !kind) ckind1 = k9_fits_idle(a, sh, v.idle0, v.idle1, scn, gi, si, n, adjm, 1.0, rqv) ? 0u : 1u;   // a second placement on it: Allocate / Pipeline
       }
     }
     K9_STAMP2(1, 7, (sh.active >> 2) != 0u || km0 != 0u);
@@ -471,6 +535,235 @@ __global__ void __launch_bounds__(K9_THREADS) k_commit_run(const K9KernArgs ka) 
       uint32_t d2 = (lane + 128 < nd) ? dk[lane + 128] : 0u, d3 = (lane + 192 < nd) ? dk[lane + 192] : 0u;
       uint32_t m = wave_max_u32(max(max(d0, d1), max(d2, d3)));   // best dirty key; clean winners update it in O(1)
       uint32_t pc = 0, j = 0, reason = KB_REASON_DONE, n_dirty = 0, sc_dirty = 0;
+      bool sel_done = false;
+      if constexpr (SEL) if (sel_run) {
+        const unsigned long long lt = (1ull << lane) - 1ull;
+        // ---- every pick a clean candidate's first placement?  No dirty key above the r-th clean candidate, no clean candidate whose key
+        //      after its placement is: row j takes candidate j (a Pipeline among them ends the round behind its row)
+        const unsigned long long deeper = __ballot(lane + 1u < r && lane < ncand && ckind == 0u && k1 > cmin);
+        if (ncand == r && m < cmin && !deeper) {
+          const unsigned long long pipes = __ballot(lane < r && ckind != 0u);
+          const uint32_t n_take = pipes ? (uint32_t)__ffsll((unsigned long long)pipes) : r;
+          if (pipes) reason = KB_REASON_PIPELINED;
+          if (lane < n_take) {
+            const uint32_t n = nmaskbits - (ck & nmaskbits);
+            ldec[i0 + lane] = (unsigned long long)n | ((unsigned long long)ckind << 32);
+            atomicOr(&bitmap[n >> 5], 1u << (n & 31));
+            if (km0) {   // the scalar dimensions Resreq names: Idle / Releasing in HBM
+              const bool has_map = ckind ? (rnm >> 31) : (rnm & 0x7FFFFFFFu);
+              if (has_map)
+                for (uint32_t mm = km0, dd = 0; mm; mm >>= 1, dd++)
+                  if (mm & 1u) k9_sc_sub(ckind ? gr : gi, a.NP, dd, n, rqv[dd]);
+            }
+          }
+          if (km0) sc_dirty = 1;
+          pc = n_take; j = n_take;
+          sel_done = true;
+        } else {
+          // ---- the general case.  Contenders: the clean candidates (lane = candidate) and the dirty slots whose key is above the floor;
+          //      entries: steps 0 and 1 of each, as far as they exist and are above the floor
+          const bool a0v = lane < ncand;
+          const uint32_t ce1 = min(ck, k1);
+          const bool a1v = a0v && ckind == 0u && k1 != 0u && ce1 > cmin;
+          uint32_t dq[4], dkk4[4], dd4[4] = {d0, d1, d2, d3}, de1[4], myc[4] = {0, 0, 0, 0};
+          bool b0v[4], b1v[4];
+          unsigned long long bb0[4], bb1[4];
+          uint32_t nD = 0, nB1 = 0;
+#pragma unroll
+          for (int u = 0; u < 4; u++) {
+            const uint32_t t = lane + 64u * (uint32_t)u;
+            dq[u] = (t < nd) ? X.dk1[t] : 0u;
+            dkk4[u] = (t < nd) ? X.dkk[t] : 0u;
+            b0v[u] = dd4[u] > cmin;
+            de1[u] = min(dd4[u], dq[u]);
+            b1v[u] = b0v[u] && !(dkk4[u] & 1u) && dq[u] != 0u && de1[u] > cmin;
+            bb0[u] = __ballot(b0v[u]);
+            bb1[u] = __ballot(b1v[u]);
+            nD += (uint32_t)__popcll(bb0[u]);
+            nB1 += (uint32_t)__popcll(bb1[u]);
+          }
+          const unsigned long long ba1 = __ballot(a1v);
+          const uint32_t nA1 = (uint32_t)__popcll(ba1);
+          const uint32_t nC = ncand + nD;
+          uint32_t n = ncand + nA1 + nD + nB1;
+          bool bail = nC > 64u || n > 64u;
+          if (!bail) {
+            if (a0v) {
+              X.e_comp[lane] = ((unsigned long long)ck << 8) | 255ull;
+              X.e_info[lane] = lane | (ckind << 8);
+              X.c_slot[lane] = nd + lane; X.c_next[lane] = a1v ? 2u : 1u; X.c_eff[lane] = a1v ? ce1 : ck;
+              X.c_flag[lane] = 2u | ((!a1v || ckind1) ? 1u : 0u);   // ended: a Pipeline, no second placement, or one below the floor
+              X.c_take[lane] = 0u;
+            }
+            uint32_t base = ncand;
+            if (a1v) {
+              const uint32_t pos = base + (uint32_t)__popcll(ba1 & lt);
+              X.e_comp[pos] = ((unsigned long long)ce1 << 8) | 254ull;
+              X.e_info[pos] = lane | (ckind1 << 8) | (1u << 16);
+            }
+            base += nA1;
+            uint32_t cbase = ncand;
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+              if (b0v[u]) {
+                const uint32_t c = cbase + (uint32_t)__popcll(bb0[u] & lt);
+                const uint32_t pos = base + (c - ncand);
+                myc[u] = c;
+                X.e_comp[pos] = ((unsigned long long)dd4[u] << 8) | 255ull;
+                X.e_info[pos] = c | ((dkk4[u] & 1u) << 8);
+                X.c_slot[c] = lane + 64u * (uint32_t)u; X.c_next[c] = b1v[u] ? 2u : 1u; X.c_eff[c] = b1v[u] ? de1[u] : dd4[u];
+                X.c_flag[c] = (!b1v[u] || (dkk4[u] & 2u)) ? 1u : 0u;
+                X.c_take[c] = 0u;
+              }
+              cbase += (uint32_t)__popcll(bb0[u]);
+            }
+            base += nD;
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+              if (b1v[u]) {
+                const uint32_t pos = base + (uint32_t)__popcll(bb1[u] & lt);
+                X.e_comp[pos] = ((unsigned long long)de1[u] << 8) | 254ull;
+                X.e_info[pos] = myc[u] | (((dkk4[u] >> 1) & 1u) << 8) | (1u << 16);
+              }
+              base += (uint32_t)__popcll(bb1[u]);
+            }
+            K9_WAVE_FENCE();
+          }
+          unsigned long long comp = 0ull;
+          uint32_t info = 0u, rank = 0u;
+          while (!bail) {
+            // rank by count: entry e is picked as row #(entries in front of it)
+            comp = lane < n ? X.e_comp[lane] : 0ull;
+            info = lane < n ? X.e_info[lane] : 0u;
+            rank = 0u;
+            for (uint32_t i = 0; i < n; i++) { const unsigned long long si_ = rl64(comp, i); rank += (si_ > comp) ? 1u : 0u; }
+            // a contender whose last known step would be picked in front of the last row may be picked again: walk it on
+            const uint32_t c = info & 0xFFu, ej = info >> 16;
+            const bool alive = lane < n && ej + 1u == X.c_next[c] && !(X.c_flag[c] & 1u) && rank + 1u < r;
+            const unsigned long long ab = __ballot(alive);
+            if (!ab) break;
+            const uint32_t na = (uint32_t)__popcll(ab);
+            uint32_t D = (64u - n) / na;
+            if (D == 0u) { bail = true; break; }
+            D = min(D, r - 1u);
+            if (alive) X.al[(uint32_t)__popcll(ab & lt)] = c;
+            K9_WAVE_FENCE();
+            // lane -> (contender ai, step u of this pass): the contender's state after that many more placements, one subtraction at a time
+            const bool act = lane < na * D;
+            const uint32_t ai = lane / D, u = lane - ai * D;
+            uint32_t cc = 0u, jj = 0u, kind = 0u;
+            bool inexact = false;
+            if (act) {
+              cc = X.al[ai];
+              const uint32_t slot = X.c_slot[cc], b = (X.c_flag[cc] >> 1) & 1u;
+              jj = X.c_next[cc] + u;
+              const uint32_t mpl = jj - b;   // placements on top of the slot's state (a clean candidate's slot holds it after the first)
+              const unsigned long long *st = slots + (size_t)slot * K9_NF;
+              K9St v = k9_load(st);
+              const uint32_t nm0 = (uint32_t)(st[F_NODE_NMASK] >> 32);
+              const uint32_t adjm = (nm0 & 0x7FFFFFFFu) ? km0 : 0u;
+              const K9Sc scx = k9_sc_preload(sh.active >> 2, gi, gr, a.NP, v.node);
+              // scalar dimensions are evaluated as Idle - jj * Resreq: equal to jj subtractions when both are integers (checked)
+              if (jj >= 2u)
+                for (uint32_t mm = (sh.active >> 2) & adjm, dd = 0; mm; mm >>= 1, dd++)
+                  if (mm & 1u) {
+                    const double id = k9_sci(scx, gi, a.NP, dd, v.node), rq = si[dd];
+                    if (!(id == trunc(id) && rq == trunc(rq) && fabs(id) < 4.0e15 && rq < 3.0e13)) inexact = true;
+                  }
+              for (uint32_t t = 0; t < mpl; t++) { v.idle0 -= sh.init0; v.idle1 -= sh.init1; v.nzc += sh.nzc; v.nzm += sh.nzm; }
+              if (mpl) v.ports |= sh.want;
+              v.left -= (int)mpl;
+              const uint32_t key = k9_eval_v(a, sh, v, scx, gi, gr, si, adjm, (double)jj, si, nb, nmaskbits);
+              kind = k9_fits_idle(a, sh, v.idle0, v.idle1, scx, gi, si, v.node, adjm, (double)jj, si) ? 0u : 1u;
+              X.kt[lane] = key; X.kk[lane] = kind;
+            }
+            if (__ballot(inexact)) { bail = true; break; }
+            K9_WAVE_FENCE();
+            // step jj exists iff every step of the pass before it exists and is an Allocate, and its own key is not 0
+            bool valid = act;
+            uint32_t run = 0u;
+            if (act) {
+              run = X.c_eff[cc];
+              for (uint32_t t = 0; t <= u; t++) {
+                const uint32_t kt = X.kt[ai * D + t];
+                valid = valid && kt != 0u && (t == u || X.kk[ai * D + t] == 0u);
+                run = min(run, kt);
+              }
+            }
+            const unsigned long long vb = __ballot(valid);
+            if (valid) {
+              const uint32_t pos = n + (uint32_t)__popcll(vb & lt);
+              X.e_comp[pos] = ((unsigned long long)run << 8) | (unsigned long long)(255u - jj);
+              X.e_info[pos] = cc | (kind << 8) | (jj << 16);
+            }
+            K9_WAVE_FENCE();
+            if (act && u == 0u) {
+              const unsigned long long gm = (vb >> (ai * D)) & (D >= 64u ? ~0ull : ((1ull << D) - 1ull));
+              const uint32_t g = (uint32_t)__popcll(gm);
+              uint32_t run2 = X.c_eff[cc];
+              for (uint32_t t = 0; t < g; t++) run2 = min(run2, X.kt[ai * D + t]);
+              const bool ended = g < D || X.kk[ai * D + g - 1u] != 0u;
+              X.c_next[cc] += g; X.c_eff[cc] = run2;
+              if (ended) X.c_flag[cc] |= 1u;
+            }
+            n += (uint32_t)__popcll(vb);
+            K9_WAVE_FENCE();
+          }
+          if (!bail) {
+            // ---- the picks: rows in rank order; a Pipeline ends the round behind its row; fewer entries than rows: no feasible node is left
+            const bool have = lane < n;
+            const uint32_t ekind = (info >> 8) & 1u, ec = info & 0xFFu;
+            const uint32_t cnt = min(n, r);
+            const uint32_t pr = (have && rank < r && ekind) ? rank : 0xFFFFFFFFu;
+            const uint32_t minpipe = ~wave_max_u32(~pr);
+            uint32_t n_take = cnt;
+            if (minpipe < cnt) { n_take = minpipe + 1u; reason = KB_REASON_PIPELINED; }
+            else if (cnt < r) reason = KB_REASON_NO_FEASIBLE;   // allocate.go:144-148
+            if (have && rank < n_take) {
+              const uint32_t node = (uint32_t)slots[(size_t)X.c_slot[ec] * K9_NF + F_NODE_NMASK];
+              ldec[i0 + rank] = (unsigned long long)node | ((unsigned long long)ekind << 32);
+              atomicAdd(&X.c_take[ec], 1u);
+              if (ekind) atomicOr(&X.c_flag[ec], 4u);
+            }
+            K9_WAVE_FENCE();
+            // ---- NodeInfo.AddTask (api/node_info.go:172-212), once per placement, on every contender that was picked: lane = contender
+            const uint32_t T = (lane < nC) ? X.c_take[lane] : 0u;
+            if (T) {
+              const uint32_t fl = X.c_flag[lane], b = (fl >> 1) & 1u, pipe_last = (fl >> 2) & 1u;
+              unsigned long long *st = slots + (size_t)X.c_slot[lane] * K9_NF;
+              const uint32_t node = (uint32_t)st[F_NODE_NMASK], nm = (uint32_t)(st[F_NODE_NMASK] >> 32);
+              const uint32_t extra = T - b;   // a clean candidate's slot already holds its first placement
+              if (extra) {
+                double idle0 = u2d(st[F_IDLE0]), idle1 = u2d(st[F_IDLE1]), rel0 = u2d(st[F_REL0]), rel1 = u2d(st[F_REL1]);
+                double zc = u2d(st[F_NZC]), zm = u2d(st[F_NZM]);
+                for (uint32_t t = 0; t < extra; t++) {
+                  if (pipe_last && t + 1u == extra) { rel0 -= sh.init0; rel1 -= sh.init1; } else { idle0 -= sh.init0; idle1 -= sh.init1; }
+                  zc += sh.nzc; zm += sh.nzm;
+                }
+                st[F_IDLE0] = d2u(idle0); st[F_IDLE1] = d2u(idle1); st[F_REL0] = d2u(rel0); st[F_REL1] = d2u(rel1);
+                st[F_NZC] = d2u(zc); st[F_NZM] = d2u(zm);
+                st[F_PORTS] |= sh.want;
+                st[F_CLS_LEFT] -= ((unsigned long long)extra << 32);   // that many more pods on the node
+              }
+              if (km0)   // the scalar dimensions Resreq names, in HBM, one Sub per placement (Sub returns early when the receiver's map is nil)
+                for (uint32_t t = 0; t < T; t++) {
+                  const bool pp = pipe_last && t + 1u == T;
+                  const bool has_map = pp ? (nm >> 31) : (nm & 0x7FFFFFFFu);
+                  if (has_map)
+                    for (uint32_t mm = km0, dd = 0; mm; mm >>= 1, dd++)
+                      if (mm & 1u) k9_sc_sub(pp ? gr : gi, a.NP, dd, node, si[dd]);
+                }
+              if (b) atomicOr(&bitmap[node >> 5], 1u << (node & 31));
+            }
+            if (km0) sc_dirty = 1;
+            pc = (uint32_t)__popcll(__ballot(lane < ncand && T != 0u));
+            n_dirty = n_take - pc;
+            j = n_take;
+            sel_done = true;
+          }
+        }
+      }
+      if (!sel_done)
       for (; j < r; j++) {
         const uint32_t c = (pc < ncand) ? rl32(ck, pc) : 0u;
         if (m == 0u && c == 0u) {
@@ -741,14 +1034,15 @@ __global__ void __launch_bounds__(K9_THREADS) k_commit_run(const K9KernArgs ka) 
   }
 }
 
-void kb_launch_commit(const KbDev &d, const KbRound &r, void *stream) {
+template <bool SEL>
+static void k9_launch(const KbDev &d, const KbRound &r, void *stream) {
   if (r.n_rows == 0) return;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_commit_run), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_commit_run<SEL>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
-  const size_t sh = k9_layout(r.n_rows, r.n_mrows, r.L, d.NP, d.R).total;
+  const size_t sh = k9_layout(r.n_rows, r.n_mrows, r.L, d.NP, d.R, SEL).total;
   K9KernArgs ka;
   ka.dev = d;
   ka.round = r;
@@ -767,6 +1061,9 @@ void kb_launch_commit(const KbDev &d, const KbRound &r, void *stream) {
   a.host_out = r.host_out;
   a.seq = r.seq;
   a.node_bits = kb_node_bits(d.NP);
+  a.prewalk = 0;
   static const bool helpers_off = getenv("KB_WARM_HELPERS_OFF") && getenv("KB_WARM_HELPERS_OFF")[0] == '1';   // A/B switch
-  hipLaunchKernelGGL(k_commit_run, dim3(helpers_off ? 1u : KB_WARM_GRID), dim3(K9_THREADS), sh, (hipStream_t)stream, ka);
+  hipLaunchKernelGGL(k_commit_run<SEL>, dim3(helpers_off ? 1u : KB_WARM_GRID), dim3(K9_THREADS), sh, (hipStream_t)stream, ka);
 }
+void kb_launch_commit(const KbDev &d, const KbRound &r, void *stream) { k9_launch<false>(d, r, stream); }       // KB_COMMIT_RUN
+void kb_launch_commit_sel(const KbDev &d, const KbRound &r, void *stream) { k9_launch<true>(d, r, stream); }    // KB_COMMIT_SELECT

@@ -10,12 +10,9 @@
 #include <stdint.h>
 #include <stdlib.h>
 
-#include <algorithm>
-
 #include "kb_device.h"
 #include "kb_eval.hpp"
 #include "kb_warm.hpp"
-#include "kb_repair.hpp"
 
 #define KB_K5_THREADS 1024
 
@@ -436,11 +433,6 @@ __device__ __forceinline__ void k7_report_skipped(const KbCommitArgs &a) {
   }
 }
 
-// FOLD (KbRound::fold, KB_FOLD_REPAIR=1): the launch also repairs the round's overlapped candidate lists (kb_repair.hpp) — row i in workgroup
-// 8 * (i / 7) + 1 + i % 7, i.e. in the workgroups that otherwise exit at once — while the commit workgroup clears its tables and the helper
-// workgroups warm the node state; the commit workgroup then waits for the rows' fold_done words instead of for a kernel boundary.
-static_assert(KB_K5_THREADS == KB_REPAIR_THREADS, "a repair row is one workgroup of the commit launch");
-template <bool FOLD>
 __global__ void __launch_bounds__(KB_K5_THREADS) k_commit_batch(const K7KernArgs ka) {
   KbCommitArgs a = ka.hot;
   {
@@ -454,21 +446,9 @@ __global__ void __launch_bounds__(KB_K5_THREADS) k_commit_batch(const K7KernArgs
   }
   extern __shared__ __align__(16) unsigned char k5_smem[];
   if (blockIdx.x != 0) {   // helper workgroups (kb_warm.hpp): warm a slice of the node state into the XCD's L2 and leave
-    if ((blockIdx.x & 7u) != 0u) {
-      if (FOLD) {
-        const uint32_t row = (blockIdx.x >> 3) * 7u + (blockIdx.x & 7u) - 1u;
-        if (row < a.n_mrows) {
-          kb_repair_row(*a.dev, *a.round, row, k5_smem);   // a list that never arrived: the chain word is cleared, the commit workgroup finds it so
-          __threadfence();
-          __syncthreads();
-          if (threadIdx.x == 0) __hip_atomic_store(&a.round->fold_done[row], a.round->ready_tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-        }
-      }
-      return;
-    }
+    if ((blockIdx.x & 7u) != 0u) return;
     const uint32_t h = blockIdx.x / 8u - 1u, lines = a.NP / 16;
-    if (FOLD && h >= KB_WARM_HELPERS) return;   // the folded launch's grid grows with the matrix rows
-    const size_t klines = FOLD ? 0 : ((size_t)a.n_mrows * a.L + 15) / 16;   // folded: the lists are being written
+    const size_t klines = ((size_t)a.n_mrows * a.L + 15) / 16;
     const uint32_t l0 = (uint32_t)(((unsigned long long)h * lines) / KB_WARM_HELPERS), l1 = (uint32_t)(((unsigned long long)(h + 1) * lines) / KB_WARM_HELPERS);
     const unsigned long long acc = kb_warm_lines(*a.dev, a.keys, klines, l0, l1, threadIdx.x, KB_K5_THREADS);
     if (acc == 0x123456789abcdefull) a.result[15] = 1;   // keep the loads alive (never true)
@@ -516,25 +496,6 @@ __global__ void __launch_bounds__(KB_K5_THREADS) k_commit_batch(const K7KernArgs
 
   for (uint32_t w = tid; w < a.NP / 32; w += KB_K5_THREADS) M.bitmap[w] = 0;
   for (uint32_t w = tid; w < cap; w += KB_K5_THREADS) { M.cursor[w] = 0; M.qstamp[w] = 0xFFFFFFFFu; M.dc_key[w] = 0ull; M.dc_nd[w] = 0; M.dc_log[w] = 0; M.pbase[w] = 0; }
-  unsigned long long t_lists = t_start;
-  if (FOLD) {
-    // the rows' repairs run in this launch's other workgroups: wait for every row's word (n_mrows <= KB_K5_MAX_SHAPES < the workgroup).
-    // Bounded like the repair's own wait for its list (longer than that one, so a late list is reported by the row that waited for it).
-    if (tid < a.n_mrows) {
-      uint32_t spins = 0;
-      const uint32_t tag = a.round->ready_tag;
-      while (__hip_atomic_load(&a.round->fold_done[tid], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != tag) {
-        __builtin_amdgcn_s_sleep(2);
-        if (++spins > (1u << 22)) { __hip_atomic_store(a.round->chain, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
-      }
-    }
-    __syncthreads();
-    if (__hip_atomic_load(a.round->chain, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != a.round->chain_expect) {   // a list never arrived: the round runs again on the plain path
-      if (tid == 0) k7_report_skipped(a);
-      return;
-    }
-    t_lists = wall_clock64();
-  }
   for (uint32_t w = tid; w < a.n_mrows * WL; w += KB_K5_THREADS) {   // the first window of every shape's candidate list
     const uint32_t sh = w / WL, en = w % WL;
     M.pwin[w] = (en < a.L) ? a.keys[(size_t)sh * a.L + en] : 0ull;
@@ -553,7 +514,7 @@ __global__ void __launch_bounds__(KB_K5_THREADS) k_commit_batch(const K7KernArgs
     g8 = (gptr8)f8;
     g4 = (gptr4)f4;
   }
-  if (!FOLD && gridDim.x == 1) {
+  if (gridDim.x == 1) {
     // no helper workgroups (KB_WARM_HELPERS_OFF=1): this workgroup warms the XCD's L2 itself, all threads, before the loop starts
     const size_t klines = ((size_t)a.n_mrows * a.L + 15) / 16;
     const unsigned long long acc = kb_warm_lines(*a.dev, a.keys, klines, 0, a.NP / 16, tid, KB_K5_THREADS);
@@ -1278,7 +1239,6 @@ __global__ void __launch_bounds__(KB_K5_THREADS) k_commit_batch(const K7KernArgs
     unsigned long long *st = reinterpret_cast<unsigned long long *>(a.result) + KB_OUT_STAMP0;
     st[2] = t_start;
     st[3] = wall_clock64();
-    if (FOLD) { st[0] = t_start; st[1] = t_start; st[2] = t_lists; }   // [0] .. [2]: what the round waited for its lists; [2] .. [3]: the commit proper
   }
   // ---- fast rounds: mirror the header and the decision records into pinned host memory and publish the round's sequence
   //      number last; the host spins on that word instead of paying a stream synchronisation + D2H copy per round
@@ -1301,8 +1261,7 @@ void kb_launch_commit_batch(const KbDev &d, const KbRound &r, void *stream) {
   static uint32_t env_batch = 0;
   static uint32_t env_prewalk = 7u;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_commit_batch<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_commit_batch<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_commit_batch), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     const char *b = getenv("KB_K5_BATCH");   // tuning override of kb_config.commit_batch
     env_batch = b ? (uint32_t)atoi(b) : 0;
     const char *pwe = getenv("KB_K7_PREWALK"), *lae = getenv("KB_K7_LOOKAHEAD");   // A/B switches
@@ -1333,11 +1292,5 @@ void kb_launch_commit_batch(const KbDev &d, const KbRound &r, void *stream) {
   a.host_out = r.host_out;
   a.seq = r.seq;
   static const bool helpers_off = getenv("KB_WARM_HELPERS_OFF") && getenv("KB_WARM_HELPERS_OFF")[0] == '1';   // A/B switch
-  if (r.fold) {   // the grid reaches the workgroup of the last matrix row; the helpers stay (KB_WARM_HELPERS_OFF does not apply)
-    const uint32_t last = r.n_mrows ? 8u * ((r.n_mrows - 1u) / 7u) + 1u + (r.n_mrows - 1u) % 7u : 0u;
-    const size_t shf = std::max(sh, kb_repair_smem_bytes(d.NP));
-    hipLaunchKernelGGL(k_commit_batch<true>, dim3(std::max(KB_WARM_GRID, last + 1u)), dim3(KB_K5_THREADS), shf, (hipStream_t)stream, ka);
-    return;
-  }
-  hipLaunchKernelGGL(k_commit_batch<false>, dim3(helpers_off ? 1u : KB_WARM_GRID), dim3(KB_K5_THREADS), sh, (hipStream_t)stream, ka);
+  hipLaunchKernelGGL(k_commit_batch, dim3(helpers_off ? 1u : KB_WARM_GRID), dim3(KB_K5_THREADS), sh, (hipStream_t)stream, ka);
 }

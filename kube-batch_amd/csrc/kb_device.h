@@ -153,11 +153,6 @@ struct KbRound {
   uint32_t stale_L;                  // >= n_prev + L: what is left of a stale list without the predecessor's nodes still holds the true top L
   const unsigned long long *prev_dec;   // decision records of the predecessor round (low word: node), n_prev of them
   uint32_t n_prev;
-  // Folded repair (KB_FOLD_REPAIR=1; off by default until it has run on a device): no repair launch — the batch commit launch carries the
-  // fields above itself and repairs row i in its own workgroup 8 * (i / 7) + 1 + i % 7 (the workgroups that otherwise exit at once), which
-  // leaves ready_tag in fold_done[i]; the commit workgroup waits for the n_mrows words before it reads the first candidate
-  uint32_t fold;
-  uint32_t *fold_done;
 };
 // true when the round was queued behind a predecessor that did not complete
 #define KB_CHAIN_BROKEN(r) ((r).chain_expect != 0u && *(r).chain != (r).chain_expect)
@@ -204,10 +199,11 @@ static inline uint32_t kb_node_bits(uint32_t NP) {
 #define KB_K5_MAX_ROWS 256u      // rows per window: one thread of the commit kernel's workgroup per dirty slot
 #define KB_K5_MAX_SHAPES 256u    // distinct task shapes per window (each keeps its candidate list in LDS: the budget decides)
 
-// Two commit kernels, same decisions bit for bit: KB_COMMIT_BATCH (kb_commit_batch.hip) speculates 16-32 rows across shapes and
+// Three commit kernels, same decisions bit for bit: KB_COMMIT_BATCH (kb_commit_batch.hip) speculates 16-32 rows across shapes and
 // is the faster one while clean nodes win most rows; KB_COMMIT_RUN (kb_commit.hip) works a same-shape run at a time without
-// speculation and is the faster one when nodes the round already changed win most rows (bin-packing weights).
-enum { KB_COMMIT_BATCH = 0, KB_COMMIT_RUN = 1 };
+// speculation and was the faster one when nodes the round already changed win most rows (bin-packing weights); KB_COMMIT_SELECT
+// (kb_commit.hip, k_commit_run<true>) is the run kernel with the rows of a run committed by ONE selection instead of a loop.
+enum { KB_COMMIT_BATCH = 0, KB_COMMIT_RUN = 1, KB_COMMIT_SELECT = 2 };
 // dynamic LDS each needs for a round of n_rows rows (batch: slot capacity `cap`) with n_shapes distinct shapes over NP padded nodes
 size_t kb_commit_smem_bytes(uint32_t n_rows, uint32_t n_shapes, uint32_t NP, int R);
 size_t kb_commit_batch_smem_bytes(uint32_t cap, uint32_t NP, int R);
@@ -235,6 +231,7 @@ void kb_launch_repair(const KbDev &d, const KbRound &r, void *stream);
 void kb_launch_expand(const KbDev &d, const uint16_t *s_score, const uint32_t *s_mask, const uint32_t *row_slot, const uint32_t *order, uint32_t n_rows,
                       uint16_t *score, uint32_t *maskw, void *stream);
 void kb_launch_commit(const KbDev &d, const KbRound &r, void *stream);         // KB_COMMIT_RUN
+void kb_launch_commit_sel(const KbDev &d, const KbRound &r, void *stream);     // KB_COMMIT_SELECT
 void kb_launch_commit_batch(const KbDev &d, const KbRound &r, void *stream);   // KB_COMMIT_BATCH
 // node state := round-start state + reduced deltas; returns how many values differ from the live (locally committed) state
 uint32_t kb_apply_deltas(const KbDev &d, const double *s_idle, const double *s_rel, const long long *s_nzc, const long long *s_nzm,

@@ -136,10 +136,11 @@ struct kb_engine {
   unsigned long long k7_batches = 0;
   uint32_t eff_window = 0;   // window actually used for this session (bounded by the commit kernel's LDS budget)
   // which commit kernel the next round uses: the share of rows won by a node the round had already changed decides
-  // (exponential average over the rounds so far; KB_COMMIT_KERNEL=batch|run pins it for A/B runs and for the tests)
-  int commit_kernel = KB_COMMIT_BATCH, commit_pin = -1;
+  // (exponential average over the rounds so far; KB_COMMIT_KERNEL=batch|run|select pins it for A/B runs and for the tests).
+  // dirty_kernel: the kernel for rounds whose rows mostly go to nodes the round already changed (KB_DIRTY_KERNEL=run: the round-3 choice)
+  int commit_kernel = KB_COMMIT_BATCH, commit_pin = -1, dirty_kernel = KB_COMMIT_RUN;
   double dirty_share = 0.0;
-  uint64_t rounds_batch = 0, rounds_run = 0;
+  uint64_t rounds_batch = 0, rounds_run = 0, rounds_sel = 0;
   uint32_t shape_cap = KB_K5_MAX_SHAPES;   // distinct shapes a window may hold (each keeps its candidate list in the commit kernel's LDS)
   std::vector<uint32_t> plan_stamp;   // per row-shape id: stamp of the window being planned
   uint32_t plan_epoch = 0;
@@ -167,18 +168,16 @@ struct kb_engine {
   // beside its predecessor's commit kernel, into buffers of their own (matrix rows, stale lists per staging half, one `ready` word per
   // list, a scratch block for their time stamps); kb_launch_repair on the first stream turns the stale lists into the round's lists
   hipStream_t stream_b = nullptr;
-  DevBuf b_score2, b_maskw2, b_stale, b_ready, b_task_rows, b_fold_done;
+  DevBuf b_score2, b_maskw2, b_stale, b_ready, b_task_rows;
   Pinned<unsigned long long> h_cand_out;   // per staging half: the output-block words the second stream's launches stamp (start of the matrix launch, start of the arg-max launch)
   unsigned long long *d_cand_out = nullptr;
   uint32_t mat2_cap = 0;
   size_t stale_cap = 0;
   bool overlap = true;             // KB_OVERLAP=0: every round on the plain path (matrix -> arg-max -> commit on one stream)
-  uint64_t overlapped_rounds = 0, overlap_faults = 0, folded_rounds = 0;
-  bool device_waterfill = false;   // KB_DEVICE_WATERFILL=1: proportion's water-fill runs as a launch at kb_session_load (kb_waterfill.hip); off until it has run on a device
+  uint64_t overlapped_rounds = 0, overlap_faults = 0;
+  bool device_waterfill = true;    // proportion's water-fill runs as a launch at kb_session_load (kb_waterfill.hip); KB_DEVICE_WATERFILL=0: the host loop of kb_session.cpp (A/B)
   uint32_t waterfill_passes = 0;
   DevBuf b_wf_queues, b_wf_state;
-  bool fold_repair = false;        // KB_FOLD_REPAIR=1: an overlapped round on the batch commit kernel repairs its lists inside the commit launch (KbRound::fold);
-                                   // off until it has run on a device
   DevBuf b_win, b_out;   // per-round upload / download blocks (see h_win / h_out)
   DevBuf b_chain;        // KbRound::chain: tag of the last round that committed its whole window
   // feasibility probe at speculation breaks (ActionRun::probe_dead_shapes): one representative task per feasibility shape
@@ -473,20 +472,7 @@ void round_candidates(kb_engine *e, const RoundCtx &c, uint32_t m0, uint32_t m1,
 void ensure_overlap_buffers(kb_engine *e, uint32_t mrows, uint32_t stale_L) {
   const size_t NP = e->dev.NP;
   if (!e->stream_b) {
-    // KB_STREAM_B_CUMASK=w0,w1,... (hex words, bit i of word i / 32 = CU i as hipExtStreamCreateWithCUMask counts them): the second stream's
-    // launches stay off the masked-out CUs — the commit workgroup's CU and XCD, which they otherwise share (A/B switch; unset: every CU)
-    std::vector<uint32_t> mask;
-    if (const char *cm = getenv("KB_STREAM_B_CUMASK")) {
-      for (const char *p = cm; *p;) {
-        char *end = nullptr;
-        const unsigned long w = strtoul(p, &end, 16);
-        if (end == p) break;
-        mask.push_back((uint32_t)w);
-        p = (*end == ',') ? end + 1 : end;
-      }
-    }
-    if (!mask.empty()) HIP_OK(hipExtStreamCreateWithCUMask(&e->stream_b, (uint32_t)mask.size(), mask.data()));
-    else HIP_OK(hipStreamCreateWithFlags(&e->stream_b, hipStreamNonBlocking));
+    HIP_OK(hipStreamCreateWithFlags(&e->stream_b, hipStreamNonBlocking));
   }
   if (mrows > e->mat2_cap) {
     HIP_OK(hipStreamSynchronize(e->stream_b));
@@ -505,8 +491,6 @@ void ensure_overlap_buffers(kb_engine *e, uint32_t mrows, uint32_t stale_L) {
     e->b_ready.alloc(sizeof(uint32_t) * 2 * KB_K5_MAX_WINDOW);
     HIP_OK(hipMemset(e->b_ready.p, 0, e->b_ready.bytes));
     e->b_task_rows.alloc((size_t)64 * 2 * KB_K5_MAX_WINDOW);
-    e->b_fold_done.alloc(sizeof(uint32_t) * 2 * KB_K5_MAX_WINDOW);
-    HIP_OK(hipMemset(e->b_fold_done.p, 0, e->b_fold_done.bytes));
     e->h_cand_out.flags = hipHostMallocMapped | hipHostMallocCoherent;
     e->h_cand_out.resize(2 * KB_OUT_HDR);
     std::memset(e->h_cand_out.data(), 0, sizeof(unsigned long long) * 2 * KB_OUT_HDR);
@@ -539,14 +523,7 @@ void round_candidates_overlapped(kb_engine *e, RoundCtx &c, uint32_t n_prev, uns
   ra.stale_L = stale_L;
   ra.prev_dec = e->b_out.as<unsigned long long>() + KB_OUT_HDR;   // the predecessor's decision records (it completed, or the chain is broken)
   ra.n_prev = n_prev;
-  if (e->fold_repair && e->commit_kernel == KB_COMMIT_BATCH) {   // no launch of its own: round_commit's launch carries the repair (KbRound::fold)
-    ra.fold = 1;
-    ra.fold_done = e->b_fold_done.as<uint32_t>() + (size_t)c.buf * KB_K5_MAX_WINDOW;
-    c.r = ra;
-    e->folded_rounds += 1;
-  } else {
-    kb_launch_repair(c.d, ra, e->stream);
-  }
+  kb_launch_repair(c.d, ra, e->stream);
   e->stats.matrix_launches += 1;
   e->stats.matrix_evals += (uint64_t)c.ns * e->hs.N;
   e->overlapped_rounds += 1;
@@ -562,6 +539,7 @@ void round_commit(kb_engine *e, const RoundCtx &c, unsigned long long *keys, dou
   auto launch = [&]() {
     e->commit_kernel_of[c.buf] = e->commit_kernel;
     if (e->commit_kernel == KB_COMMIT_RUN) { kb_launch_commit(c.d, r, e->stream); e->rounds_run++; }
+    else if (e->commit_kernel == KB_COMMIT_SELECT) { kb_launch_commit_sel(c.d, r, e->stream); e->rounds_sel++; }
     else { kb_launch_commit_batch(c.d, r, e->stream); e->rounds_batch++; }
   };
   if (e->fast_rounds) {
@@ -633,13 +611,14 @@ void round_collect(kb_engine *e, const RoundCtx &c, bool had_candidates, uint32_
   reason = h_result[1];
   if (reason == KB_REASON_INTERNAL) throw EngineError(KB_E_INTERNAL, "commit kernel ran out of candidate list entries (list shorter than the window)");
   // rows won by a node the round had already changed (the batch kernel reports them in word 6, word 3 counts its row-mode rows)
-  const uint32_t dirty_won = e->commit_kernel_of[c.buf] == KB_COMMIT_RUN ? h_result[3] : h_result[6];
+  const bool run_like = e->commit_kernel_of[c.buf] != KB_COMMIT_BATCH;   // the run kernel and the selection kernel report alike
+  const uint32_t dirty_won = run_like ? h_result[3] : h_result[6];
   e->stats.row_fallbacks += dirty_won;
   if (e->commit_kernel_of[c.buf] == KB_COMMIT_BATCH) {
     e->k7_batches += h_result[5];
     for (int k = 0; k < 14; k++) e->k7_trace[k] += (double)(uint32_t)(ho[(k < 8 ? 4 : 9) + k / 2] >> (32 * (k & 1)));   // zero unless built with -DKB_K7_TRACE
   }
-  if (e->commit_kernel_of[c.buf] == KB_COMMIT_RUN) {
+  if (run_like) {
     e->k5_slots += h_result[2];
     e->k5_walks += h_result[4];
     e->k5_rescans += h_result[5];
@@ -652,8 +631,8 @@ void round_collect(kb_engine *e, const RoundCtx &c, bool had_candidates, uint32_
     e->dirty_share = e->stats.rounds == 0 ? share : 0.75 * e->dirty_share + 0.25 * share;
   }
   if (e->commit_pin >= 0) e->commit_kernel = e->commit_pin;
-  else if (e->commit_kernel == KB_COMMIT_BATCH && e->dirty_share > 0.30) e->commit_kernel = KB_COMMIT_RUN;
-  else if (e->commit_kernel == KB_COMMIT_RUN && e->dirty_share < 0.15) e->commit_kernel = KB_COMMIT_BATCH;
+  else if (e->commit_kernel == KB_COMMIT_BATCH && e->dirty_share > 0.30) e->commit_kernel = e->dirty_kernel;
+  else if (e->commit_kernel != KB_COMMIT_BATCH && e->dirty_share < 0.15) e->commit_kernel = KB_COMMIT_BATCH;
   e->stats.rounds += 1;
   e->round_no += 1;
 }
@@ -1043,7 +1022,12 @@ int kb_engine_create(const kb_config *cfg, kb_engine **out) {
       if (const char *ck = getenv("KB_COMMIT_KERNEL")) {
         if (ck[0] == 'b') eng->commit_pin = KB_COMMIT_BATCH;
         else if (ck[0] == 'r') eng->commit_pin = KB_COMMIT_RUN;
+        else if (ck[0] == 's') eng->commit_pin = KB_COMMIT_SELECT;
         if (eng->commit_pin >= 0) eng->commit_kernel = eng->commit_pin;
+      }
+      if (const char *dk = getenv("KB_DIRTY_KERNEL")) {
+        if (dk[0] == 'r') eng->dirty_kernel = KB_COMMIT_RUN;
+        else if (dk[0] == 's') eng->dirty_kernel = KB_COMMIT_SELECT;
       }
       const char *sr = getenv("KB_SYNC_ROUNDS");
       eng->fast_rounds = !(eng->flags & KB_FLAG_SYNC_ROUNDS) && !(sr && sr[0] == '1');
@@ -1054,9 +1038,7 @@ int kb_engine_create(const kb_config *cfg, kb_engine **out) {
       const char *ov = getenv("KB_OVERLAP");
       eng->overlap = !(ov && ov[0] == '0');
       const char *wf = getenv("KB_DEVICE_WATERFILL");
-      eng->device_waterfill = wf && wf[0] == '1';
-      const char *fr = getenv("KB_FOLD_REPAIR");
-      eng->fold_repair = fr && fr[0] == '1';
+      eng->device_waterfill = !(wf && wf[0] == '0');
       const char *dw = getenv("KB_DIRECT_WINDOW");
       eng->direct_window = !(dw && dw[0] == '0');
     }
@@ -1069,8 +1051,8 @@ int kb_engine_create(const kb_config *cfg, kb_engine **out) {
 void kb_engine_destroy(kb_engine *e) {
   if (!e) return;
   if (getenv("KB_K5_STATS"))
-    fprintf(stderr, "[kb K5] rounds on the batch kernel %llu, on the run kernel %llu, last dirty share %.3f\n", (unsigned long long)e->rounds_batch,
-            (unsigned long long)e->rounds_run, e->dirty_share);
+    fprintf(stderr, "[kb K5] rounds on the batch kernel %llu, on the run kernel %llu, on the selection kernel %llu, last dirty share %.3f\n", (unsigned long long)e->rounds_batch,
+            (unsigned long long)e->rounds_run, (unsigned long long)e->rounds_sel, e->dirty_share);
   if (getenv("KB_K5_STATS"))
     fprintf(stderr, "[kb K5] rounds %llu, rows %llu, dirty slots %llu, dirty-won rows %llu, runs %llu, runs with a row-specific Resreq %llu (%llu)\n",
             (unsigned long long)e->stats.rounds, (unsigned long long)e->stats.decisions, (unsigned long long)e->k5_slots,
@@ -1078,7 +1060,6 @@ void kb_engine_destroy(kb_engine *e) {
             (unsigned long long)e->k5_demand);
   if (getenv("KB_K5_STATS")) fprintf(stderr, "[kb overlap] rounds with candidate lists built beside the predecessor's commit %llu, lists that never arrived %llu\n",
                                      (unsigned long long)e->overlapped_rounds, (unsigned long long)e->overlap_faults);
-  if (getenv("KB_K5_STATS") && e->fold_repair) fprintf(stderr, "[kb overlap] of them repaired inside the commit launch %llu\n", (unsigned long long)e->folded_rounds);
   if (getenv("KB_K5_STATS")) fprintf(stderr, "[kb K7] batches of the batch kernel %llu\n", e->k7_batches);
   if (getenv("KB_K5_STATS"))
     fprintf(stderr, "[kb host] ms over the engine's life: reset %.2f, allocate up to its first launch %.2f, speculation breaks (answer -> re-planned launch) %.2f, "
@@ -1102,7 +1083,7 @@ void kb_engine_destroy(kb_engine *e) {
   delete e;
 }
 
-// proportion's OnSessionOpen water-fill as a launch (kb_waterfill.hip; KB_DEVICE_WATERFILL=1): the queues' requests, weights and the
+// proportion's OnSessionOpen water-fill as a launch (kb_waterfill.hip; default since its first device run, round 4; KB_DEVICE_WATERFILL=0: the host loop): the queues' requests, weights and the
 // session's total go up, `deserved` comes back for the host's order machine (Overused, the queue order) and stays on the device for
 // k_finalize_queues.  build_host_session left hs.deserved at zero.
 static void device_waterfill(kb_engine *e) {
@@ -1122,13 +1103,15 @@ static void device_waterfill(kb_engine *e) {
   DevBuf &b_q = e->b_wf_queues, &b_st = e->b_wf_state;   // kept between loads (the Go action loads a session every cycle): grown, never shrunk
   if (b_q.bytes < sizeof(WfQueue) * qs.size()) b_q.alloc(sizeof(WfQueue) * qs.size());
   if (b_st.bytes < sizeof(WfState)) b_st.alloc(sizeof(WfState));
-  HIP_OK(hipMemcpy(b_q.p, qs.data(), sizeof(WfQueue) * qs.size(), hipMemcpyHostToDevice));
-  HIP_OK(hipMemcpy(b_st.p, &st, sizeof(WfState), hipMemcpyHostToDevice));
+  // everything on the engine's (non-blocking) stream, so that the copies and the launch are ordered by the API and not by what the
+  // null stream happens to do with a pageable buffer; qs / st live until the synchronisation below
+  HIP_OK(hipMemcpyAsync(b_q.p, qs.data(), sizeof(WfQueue) * qs.size(), hipMemcpyHostToDevice, e->stream));
+  HIP_OK(hipMemcpyAsync(b_st.p, &st, sizeof(WfState), hipMemcpyHostToDevice, e->stream));
   kb_launch_waterfill(b_q.as<WfQueue>(), Q, b_st.as<WfState>(), hs.R, e->stream);
+  HIP_OK(hipMemcpyAsync(qs.data(), b_q.p, sizeof(WfQueue) * qs.size(), hipMemcpyDeviceToHost, e->stream));
+  HIP_OK(hipMemcpyAsync(&st, b_st.p, sizeof(WfState), hipMemcpyDeviceToHost, e->stream));
   HIP_OK(hipStreamSynchronize(e->stream));
   HIP_OK(hipGetLastError());
-  HIP_OK(hipMemcpy(qs.data(), b_q.p, sizeof(WfQueue) * qs.size(), hipMemcpyDeviceToHost));
-  HIP_OK(hipMemcpy(&st, b_st.p, sizeof(WfState), hipMemcpyDeviceToHost));
   if (st.underflow) throw EngineError(KB_E_UNSUPPORTED, "proportion water-filling underflow (the reference would panic in Resource.Sub)");
   for (uint32_t q = 0; q < Q; q++) hs.deserved[q] = qs[q].deserved;
   hs.queue_share_at_open = st.share_at_open ? 1 : 0;
@@ -1528,7 +1511,7 @@ static int run_action(kb_engine *e, uint32_t action, kb_decision *out, uint64_t 
     auto launch = [&](uint32_t rows_n, const uint32_t *rows, uint32_t buf, uint32_t chain_expect, uint32_t n_prev) {
       RoundCtx c = round_prepare(e, rows_n, action == 0 ? 1 : 2, action == 1, true, rows, buf, chain_expect);   // single GPU: every matrix row is local
       unsigned long long *keys = e->b_keys.as<unsigned long long>();
-      if (overlap_ok && c.direct && chain_expect != 0 && !e->overlap_faults && (e->hs.R == 2 || e->commit_kernel_of[buf ^ 1u] == KB_COMMIT_RUN)) {
+      if (overlap_ok && c.direct && chain_expect != 0 && !e->overlap_faults && (e->hs.R == 2 || e->commit_kernel_of[buf ^ 1u] != KB_COMMIT_BATCH)) {
         round_candidates_overlapped(e, c, n_prev, keys);
         c.overlapped = true;
       }
@@ -1631,10 +1614,8 @@ static int run_evict_action(kb_engine *e, bool reclaim, kb_stmt_op *out, uint64_
     e->stale_checked = false;
     HostSession &hs = e->hs;
     // an eviction takes a pod OUT of the inter-pod predicate's pod list (Running -> Releasing leaves api.AllocatedStatus): modelled on the
-    // host side of the evict machine (kb_preempt.cpp: ip_*), the lists rebuilt on the device after every change; written and checked
-    // against the oracle on the emulated device in round 3 and off until its first run on the MI355X (KB_EVICT_INTERPOD=1)
-    if (hs.has_interpod && !evict_interpod_enabled())
-      throw EngineError(KB_E_UNSUPPORTED, "preempt / reclaim in a session with inter-pod (anti)affinity terms is not modelled");
+    // host side of the evict machine (kb_preempt.cpp: ip_*), the lists rebuilt on the device after every change (round 3; on by default
+    // since its first device run, round 4: profiles/round4/first_call)
     // preempt with preferred node-affinity terms: the lists of such preemptors carry the NormalizeReduce'd score and are rebuilt after
     // every Pipeline instead of repaired (kb_preempt.cpp: preempt_walk).  Checked against the oracle on the CPU (tests/host_harness);
     // it stays behind a switch until its first run on the device — without it the stock action takes the cycle, as before.

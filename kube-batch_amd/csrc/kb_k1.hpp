@@ -1,6 +1,5 @@
 // kb_k1.hpp — the matrix kernel's per-pair evaluation (K1): a task row against a node, as kb_kernels.hip's k_matrix / k_matrix_runs / k_probe
-// run it and as the repair of overlapped candidate lists re-runs it for the predecessor's nodes (kb_repair.hpp), from whichever launch that
-// repair is part of.  Moved out of kb_kernels.hip unchanged.
+// run it and as the repair of overlapped candidate lists (k_repair) re-runs it for the predecessor's nodes.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stddef.h>

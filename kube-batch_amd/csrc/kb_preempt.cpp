@@ -288,11 +288,7 @@ void PreemptMachine::node_update(uint32_t t, int st) {
   recompute_minprio(n);
 }
 
-// ---- inter-pod (anti)affinity under the evict actions (behind KB_EVICT_INTERPOD=1) ----
-bool evict_interpod_enabled() {
-  const char *v = std::getenv("KB_EVICT_INTERPOD");
-  return v && v[0] == '1';
-}
+// ---- inter-pod (anti)affinity under the evict actions ----
 void PreemptMachine::set_interpod(IpLive *ip, std::function<void()> upload) {
   ip_ = ip; ip_upload_ = std::move(upload);
   ip_changed_ = false;

@@ -35,9 +35,6 @@ struct LiveNodes {
 
 // kb_run_preempt accepts sessions with preferred node-affinity terms unless KB_PREEMPT_NODE_AFFINITY=0 (read at every call)
 bool preempt_node_affinity_enabled();
-// kb_run_preempt / kb_run_reclaim accept sessions with inter-pod (anti)affinity terms only with KB_EVICT_INTERPOD=1 (round 3: written and
-// checked against the oracle on the emulated device; off until its first run on the MI355X — without it they answer KB_E_UNSUPPORTED)
-bool evict_interpod_enabled();
 
 // the live kb_interpod counts while an evict action runs (device -> host when it starts, host -> device before every list and when it ends)
 struct IpLive {

@@ -76,4 +76,12 @@ KB_EMU_LIB="$lib" timeout 600 python -m pytest tests/test_emu_engine_cpu.py -q -
 python bench.py > "$out/bench_default.json" 2> "$out/bench_default.err"; echo "bench rc=$?" | tee -a "$out/summary.txt"
 python bench.py --config 4 --steps 3 --warmup 1 --no-cpu-baseline > "$out/bench_config4.json" 2> "$out/bench_config4.err"; echo "bench config 4 rc=$?" | tee -a "$out/summary.txt"
 python bench.py --config 5 --preempt --steps 2 --warmup 1 --no-cpu-baseline > "$out/bench_config5_three_actions.json" 2> "$out/bench_config5.err"; echo "bench config 5 three actions rc=$?" | tee -a "$out/summary.txt"
+# 7. the CU-masked second stream (KB_STREAM_B_CUMASK): same-box A/B on config 3 — which bit is which CU of which XCD is unknown, so two readings:
+#    "the first 32 bits are XCD 0" and "bit i is CU i/8 of XCD i%8"
+for m in none 00000000,ffffffff,ffffffff,ffffffff,ffffffff,ffffffff,ffffffff,ffffffff fefefefe,fefefefe,fefefefe,fefefefe,fefefefe,fefefefe,fefefefe,fefefefe; do
+  if [ "$m" = none ]; then unset KB_STREAM_B_CUMASK; else export KB_STREAM_B_CUMASK=$m; fi
+  python bench.py --steps 10 --warmup 3 --no-cpu-baseline > "$out/bench_cumask_${m:0:8}.json" 2> "$out/bench_cumask_${m:0:8}.err"
+  echo "cumask $m rc=$? $(python -c "import json,sys; d=json.loads(open('$out/bench_cumask_${m:0:8}.json').read().strip().splitlines()[-1]); print(d.get('ms_per_step'), d.get('verified_bind_set_equals_oracle'))" 2>/dev/null)" | tee -a "$out/summary.txt"
+done
+unset KB_STREAM_B_CUMASK
 cat "$out/summary.txt"

@@ -410,7 +410,7 @@ size_t kb_commit_smem_bytes(uint32_t n_rows, uint32_t n_shapes, uint32_t NP, int
   off += (size_t)R * 8 + (size_t)n_shapes * RS * 8 + (size_t)n_shapes * 64 + (size_t)n_rows * sizeof(KbRowDesc);
   off = (off + 15) & ~(size_t)15;
   off += (size_t)n_rows * 16 + (size_t)n_rows * 8 + 48 + 256 * 4 + 64 * 4 + 64 * 4 + (size_t)n_shapes * 4 + (size_t)n_shapes * 4;
-  off += (size_t)n_shapes * ((size_t)n_rows + 1) * 4 + (size_t)(NP / 32) * 4 + lds_penalty();
+  off += (size_t)n_shapes * ((size_t)n_rows + 1) * 4 + (size_t)(NP / 32) * 4 + 4864 /* the selection kernel's scratch */ + lds_penalty();
   return (off + 15) & ~(size_t)15;
 }
 size_t kb_commit_batch_smem_bytes(uint32_t cap, uint32_t NP, int R) {
@@ -613,11 +613,9 @@ static void emu_repair(const KbDev &d, const KbRound &r) {
     std::sort(keys.begin(), keys.end(), [](u64 a, u64 b) { return a > b; });
     u64 *out = r.keys + (size_t)m * r.L;
     for (uint32_t i = 0; i < r.L; i++) out[i] = i < keys.size() ? keys[i] : 0ull;
-    if (r.fold) __atomic_store_n(&r.fold_done[m], r.ready_tag, __ATOMIC_RELEASE);
   }
 }
 void kb_launch_repair(const KbDev &d, const KbRound &r, void *stream) {
-  if (r.fold) { fprintf(stderr, "emulated device: a repair launch for a round that folds its repair into the commit launch\n"); abort(); }
   kbemu_enqueue((hipStream_t)stream, [d, r]() { emu_repair(d, r); });
 }
 
@@ -653,20 +651,9 @@ void kb_launch_scatter_nodes(const KbDev &d, const unsigned long long *rec, uint
 }
 
 void kb_launch_commit(const KbDev &d, const KbRound &r, void *stream) { kbemu_enqueue((hipStream_t)stream, [d, r]() { emu_commit(d, r, false); }); }
-static unsigned long long g_folded_launches = 0;
-extern "C" unsigned long long kbemu_folded_launches() { return __atomic_load_n(&g_folded_launches, __ATOMIC_RELAXED); }   // tests: the folded path was taken
-// KbRound::fold: the launch repairs the round's overlapped candidate lists itself before its commit workgroup reads them; a list that never
-// arrives clears the chain word, which the commit then finds broken (KB_REASON_SKIPPED), as on the device
-void kb_launch_commit_batch(const KbDev &d, const KbRound &r, void *stream) {
-  kbemu_enqueue((hipStream_t)stream, [d, r]() {
-    if (r.fold) {
-      __atomic_fetch_add(&g_folded_launches, 1ull, __ATOMIC_RELAXED);
-      if (r.ready == nullptr || r.stale == nullptr || r.fold_done == nullptr || r.task_rows == nullptr) { fprintf(stderr, "emulated device: folded round without its repair fields\n"); abort(); }
-      emu_repair(d, r);
-    }
-    emu_commit(d, r, true);
-  });
-}
+void kb_launch_commit_batch(const KbDev &d, const KbRound &r, void *stream) { kbemu_enqueue((hipStream_t)stream, [d, r]() { emu_commit(d, r, true); }); }
+// the selection kernel (k_commit_run<true>): the run kernel's contract and statistics words
+void kb_launch_commit_sel(const KbDev &d, const KbRound &r, void *stream) { kbemu_enqueue((hipStream_t)stream, [d, r]() { emu_commit(d, r, false); }); }
 
 uint32_t kb_apply_deltas(const KbDev &d, const double *s_idle, const double *s_rel, const long long *s_nzc, const long long *s_nzm,
                          const int *s_podcnt, const double *delta, uint32_t *dev_counter, void *stream) {

@@ -208,10 +208,8 @@ def test_full_size_cycles_through_the_host_side(oracle_mod, name):
     fs.test_full_size_cycle_equals_oracle_and_golden_digest(oracle_mod, name)
 
 
-@pytest.mark.parametrize("fold", [False, True])
-def test_overlapped_candidate_lists_are_repaired(emulated_engine, monkeypatch, fold):
-    """fold: KB_FOLD_REPAIR=1, the batch commit launch repairs the lists itself (KbRound::fold; no repair launch for those rounds).
-    Chained rounds of plain sessions build their candidate lists on a second stream beside the predecessor's commit kernel and repair them
+def test_overlapped_candidate_lists_are_repaired(emulated_engine, monkeypatch):
+    """Chained rounds of plain sessions build their candidate lists on a second stream beside the predecessor's commit kernel and repair them
     behind it (kb_kernels.hip: k_repair).  The emulated matrix launch of such a round POISONS what it reports for the nodes
     the last commit changed, so the decisions only come out right if the repair launch overrides exactly those: equal to the oracle with it,
     different without it (KB_EMU_REPAIR_OFF=1 hands the stale lists on as they are — the negative control), and equal again on the plain
@@ -231,16 +229,8 @@ def test_overlapped_candidate_lists_are_repaired(emulated_engine, monkeypatch, f
         eng.close()
         return out
 
-    monkeypatch.delenv("KB_FOLD_REPAIR", raising=False)
-    if fold:
-        monkeypatch.setenv("KB_FOLD_REPAIR", "1")
-        monkeypatch.setenv("KB_COMMIT_KERNEL", "batch")   # this small cluster would move to the run kernel, whose rounds keep the repair launch
-    folded = C.CDLL(emulated_engine).kbemu_folded_launches
-    folded.restype = C.c_ulonglong
-    f0 = folded()
     ok, rounds, _ = cycle()
     assert ok and rounds > 10
-    assert (folded() - f0 > 10) if fold else (folded() == f0)
     monkeypatch.setenv("KB_EMU_REPAIR_OFF", "1")
     broken, _, _ = cycle()
     assert not broken                                   # the overlapped path was taken, and its stale lists alone are wrong
@@ -250,38 +240,8 @@ def test_overlapped_candidate_lists_are_repaired(emulated_engine, monkeypatch, f
     assert ok_plain and rounds_plain == rounds
 
 
-# ---- preempt / reclaim in sessions with inter-pod (anti)affinity terms (round 3, behind KB_EVICT_INTERPOD=1 until its first device run) ----
-@pytest.mark.parametrize("seed", range(150))
-def test_evict_actions_with_interpod_terms_equal_the_oracle(emulated_engine, monkeypatch, seed):
-    """The evict machine keeps the kb_interpod counts on the host (an eviction takes its victim out of the predicate's pod list, a Pipeline adds the
-    preemptor with an empty Spec.NodeName, a discarded statement undoes both), puts them on the device in front of every list it asks for, and
-    rebuilds every list after a change: journal, evictions, statuses, node state and shares equal the oracle's (which is itself held to
-    tests/pyref.py's recount-from-statuses on the same clusters: tests/test_interpod_oracle_cpu.py).  Without the switch: KB_E_UNSUPPORTED."""
-    import test_interpod_oracle_cpu as ipo
-    import test_gpu_preempt as gp
-    oracle_mod = importlib.import_module("oracle")
-    try:
-        cfg, snap, order = ipo.interpod_evict_case(seed)
-    except (kbm.snapshot.UnsupportedSnapshot, ValueError) as e:
-        pytest.skip(str(e))
-    if snap.interpod is None:
-        pytest.skip("no pod-affinity term drawn")
-    if seed % 25 == 0 and any(a in ("preempt", "reclaim") for a in order):        # the refusal stays the default
-        e = engine.Engine(cfg)
-        e.load(snap)
-        with pytest.raises(engine.EngineError) as err:
-            e.run(order)
-        assert err.value.code == abi.KB_E_UNSUPPORTED
-        e.close()
-    monkeypatch.setenv("KB_EVICT_INTERPOD", "1")
-    gp._run_both(oracle_mod, cfg, snap, order, seed)
-
-
-@pytest.mark.parametrize("fold", [False, True])
-def test_a_candidate_list_that_never_arrives_breaks_the_chain_and_the_round_runs_again(emulated_engine, monkeypatch, fold):
-    """fold: the same with the repair inside the commit launch (KB_FOLD_REPAIR=1): the row that waited clears the chain word, the commit workgroup
-    of the same launch finds it so and reports the round skipped.
-    k_repair's wait for its lists is bounded: a list that never arrives (here: the emulated arg-max launch of every third overlapped round
+def test_a_candidate_list_that_never_arrives_breaks_the_chain_and_the_round_runs_again(emulated_engine, monkeypatch):
+    """k_repair's wait for its lists is bounded: a list that never arrives (here: the emulated arg-max launch of every third overlapped round
     drops its tag) makes it break the chain, the commit kernel behind it skips the round, the host takes the skipped round back, counts the fault
     and keeps every later round of that engine on the plain path — same decisions as the oracle, no hang, no wrong bind."""
     oracle_mod = importlib.import_module("oracle")
@@ -291,9 +251,6 @@ def test_a_candidate_list_that_never_arrives_breaks_the_chain_and_the_round_runs
     o.run(["allocate", "backfill"])
     monkeypatch.setenv("KB_EMU_DROP_TAG", "3")
     monkeypatch.setenv("KB_EMU_REPAIR_WAIT_NS", "2e6")
-    if fold:
-        monkeypatch.setenv("KB_FOLD_REPAIR", "1")
-        monkeypatch.setenv("KB_COMMIT_KERNEL", "batch")
     for _ in range(2):                                   # twice: the fault must not outlive the action that met it
         eng = engine.Engine(conf)
         eng.load(snap)
@@ -393,7 +350,7 @@ def test_overlapped_launches_wait_for_the_copies_kb_session_reset_left_queued(em
     assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr
 
 
-# ---- proportion's water-fill as a launch (round 3, behind KB_DEVICE_WATERFILL=1 until its first device run) -------------------------------
+# ---- proportion's water-fill as a launch (round 3; the default since its first device run: tests/test_gpu_waterfill.py) ----
 def _waterfill_counter(so):
     """launches of the emulated k_waterfill so far; the product library (scripts/first_gpu_call_r4.sh: KB_EMU_LIB) has no such counter: None"""
     L = C.CDLL(so)
@@ -446,11 +403,11 @@ def test_the_device_waterfill_equals_the_host_loop_on_adversarial_snapshots(emul
         rng = np.random.RandomState(seed)
         wl, wm, wa, wb = [int(x) for x in rng.choice([0, 1, 1, 2, 5], size=4)]
         cfg = kbm.conf.load_scheduler_conf(cases.CONF_TMPL.format(wl=wl, wm=wm, wa=wa, wb=wb))
-        monkeypatch.delenv("KB_DEVICE_WATERFILL", raising=False)
+        monkeypatch.setenv("KB_DEVICE_WATERFILL", "0")     # the host loop (the A/B switch)
         n0 = launches()
         host = _load_and_run(cfg, snap)
-        assert launches() == n0                            # off by default
-        monkeypatch.setenv("KB_DEVICE_WATERFILL", "1")
+        assert launches() == n0
+        monkeypatch.delenv("KB_DEVICE_WATERFILL")          # the launch: the default since its first device run (round 4)
         dev = _load_and_run(cfg, snap)
         has_proportion = any(po.name == "proportion" for t in cfg.tiers for po in t)
         assert host[0] == dev[0], (seed, host[0], dev[0])
@@ -468,7 +425,7 @@ def test_the_device_waterfill_on_the_tutorial_example_and_on_128_queues(emulated
     the session then survives a reset and a second cycle."""
     snapmod = kbm.snapshot
     oracle_mod = importlib.import_module("oracle")
-    monkeypatch.setenv("KB_DEVICE_WATERFILL", "1")
+    monkeypatch.delenv("KB_DEVICE_WATERFILL", raising=False)
     launches = _waterfill_counter(emulated_engine)
     Gi = 1 << 30
     pods = [snapmod.Pod("q1", f"p{i}", [{"cpu": "1", "memory": "2Gi"}], group_name="j1") for i in range(5)]
