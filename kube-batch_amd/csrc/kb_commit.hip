@@ -68,6 +68,7 @@ struct K9Sel {
   uint32_t e_info[64];                // contender | kind << 8 | step << 16
   uint32_t c_slot[64], c_next[64], c_eff[64], c_flag[64], c_take[64];   // contenders: state slot, next unknown step, prefix minimum so far, bit 0 ended / bit 1 clean / bit 2 its last taken entry is a Pipeline
   uint32_t al[64], kt[64], kk[64];    // a deep pass: the contenders it walks, the keys and kinds its lanes found
+  uint32_t stat[4];                   // runs committed with every pick a clean first placement / by the general selection / handed to the serial loop; deep passes
 };
 __host__ __device__ inline K9Layout k9_layout(uint32_t n_rows, uint32_t n_shapes, uint32_t L, uint32_t NP, int R, bool sel = false) {
   K9Layout o;
@@ -321,6 +322,7 @@ __global__ void __launch_bounds__(K9_THREADS) k_commit_run(const K9KernArgs ka) 
     for (uint32_t w = tid; w < W * (uint32_t)(sizeof(KbRowDesc) / 8); w += K9_THREADS) dst[w] = src[w];
   }
   for (uint32_t s = tid; s < S; s += K9_THREADS) cursor[s] = 0;
+  if constexpr (SEL) { if (tid < 4) X.stat[tid] = 0u; }
   if (tid == 0) { H.i = 0; H.nd = 0; H.reason = KB_REASON_DONE; H.stop = 0; H.ncand = 0; H.n_dirty_rows = 0; H.n_runs = 0; H.n_slow = 0; H.cur_s = 0; H.cur_r = 0; H.cur_fl = 0; H.cur_km = 0; }
   if (gridDim.x == 1) {   // no helper workgroups (KB_WARM_HELPERS_OFF=1): warm the XCD's L2 here, all threads
     const unsigned long long acc = kb_warm_lines(*a.dev, a.keys, 0, 0, a.NP / 16, tid, K9_THREADS);
@@ -464,7 +466,7 @@ __global__ void __launch_bounds__(K9_THREADS) k_commit_run(const K9KernArgs ka) 
       const K9Sc scp = k9_sc_preload(sh.active >> 2, gi, gr, a.NP, vs.node);
       const uint32_t key0 = k9_eval_v(a, sh, vs, scp, gi, gr, si, 0u, 0.0, si, nb, nmaskbits);
       dk[t] = key0;
-      if (SEL) {
+      if constexpr (SEL) {
         // a slot that can be picked (its key is above the floor): what its first placement would be, and its key and kind one placement on
         uint32_t key1 = 0u, kk = 0u;
         if (sel_run && key0 > cmin) {
@@ -559,6 +561,7 @@ __global__ void __launch_bounds__(K9_THREADS) k_commit_run(const K9KernArgs ka) 
           if (km0) sc_dirty = 1;
           pc = n_take; j = n_take;
           sel_done = true;
+          if (lane == 0) X.stat[0]++;
         } else {
           // ---- the general case.  Contenders: the clean candidates (lane = candidate) and the dirty slots whose key is above the floor;
           //      entries: steps 0 and 1 of each, as far as they exist and are above the floor
@@ -707,6 +710,7 @@ __global__ void __launch_bounds__(K9_THREADS) k_commit_run(const K9KernArgs ka) 
               if (ended) X.c_flag[cc] |= 1u;
             }
             n += (uint32_t)__popcll(vb);
+            if (lane == 0) X.stat[3]++;
             K9_WAVE_FENCE();
           }
           if (!bail) {
@@ -760,6 +764,9 @@ __global__ void __launch_bounds__(K9_THREADS) k_commit_run(const K9KernArgs ka) 
             n_dirty = n_take - pc;
             j = n_take;
             sel_done = true;
+            if (lane == 0) X.stat[1]++;
+          } else if (lane == 0) {
+            X.stat[2]++;
           }
         }
       }
@@ -1016,6 +1023,7 @@ __global__ void __launch_bounds__(K9_THREADS) k_commit_run(const K9KernArgs ka) 
   if (tid == 0) {
     a.result[0] = n_done; a.result[1] = H.reason; a.result[2] = nd; a.result[3] = H.n_dirty_rows;
     a.result[4] = H.n_runs; a.result[5] = H.n_slow; a.result[6] = 0; a.result[7] = 0;
+    if constexpr (SEL) { a.result[6] = X.stat[0] | (X.stat[1] << 16); a.result[7] = X.stat[2] | (X.stat[3] << 16); }
     if (a.round->chain) *a.round->chain = H.reason == KB_REASON_DONE ? a.round->chain_tag : 0u;   // the round queued behind this one runs only then
     unsigned long long *st = reinterpret_cast<unsigned long long *>(a.result) + KB_OUT_STAMP0;
     st[2] = t_start;

@@ -141,6 +141,7 @@ struct kb_engine {
   int commit_kernel = KB_COMMIT_BATCH, commit_pin = -1, dirty_kernel = KB_COMMIT_RUN;
   double dirty_share = 0.0;
   uint64_t rounds_batch = 0, rounds_run = 0, rounds_sel = 0;
+  uint64_t sel_stat[4] = {0, 0, 0, 0};   // selection kernel: runs with every pick a clean first placement / through the general selection / handed to the serial loop; deep passes
   uint32_t shape_cap = KB_K5_MAX_SHAPES;   // distinct shapes a window may hold (each keeps its candidate list in the commit kernel's LDS)
   std::vector<uint32_t> plan_stamp;   // per row-shape id: stamp of the window being planned
   uint32_t plan_epoch = 0;
@@ -618,6 +619,9 @@ void round_collect(kb_engine *e, const RoundCtx &c, bool had_candidates, uint32_
     e->k7_batches += h_result[5];
     for (int k = 0; k < 14; k++) e->k7_trace[k] += (double)(uint32_t)(ho[(k < 8 ? 4 : 9) + k / 2] >> (32 * (k & 1)));   // zero unless built with -DKB_K7_TRACE
   }
+  if (e->commit_kernel_of[c.buf] == KB_COMMIT_SELECT) {
+    e->sel_stat[0] += h_result[6] & 0xFFFFu; e->sel_stat[1] += h_result[6] >> 16; e->sel_stat[2] += h_result[7] & 0xFFFFu; e->sel_stat[3] += h_result[7] >> 16;
+  }
   if (run_like) {
     e->k5_slots += h_result[2];
     e->k5_walks += h_result[4];
@@ -1053,6 +1057,9 @@ void kb_engine_destroy(kb_engine *e) {
   if (getenv("KB_K5_STATS"))
     fprintf(stderr, "[kb K5] rounds on the batch kernel %llu, on the run kernel %llu, on the selection kernel %llu, last dirty share %.3f\n", (unsigned long long)e->rounds_batch,
             (unsigned long long)e->rounds_run, (unsigned long long)e->rounds_sel, e->dirty_share);
+  if (getenv("KB_K5_STATS") && e->rounds_sel)
+    fprintf(stderr, "[kb select] runs of >= 2 rows: all picks clean first placements %llu, general selection %llu, handed to the serial loop %llu; deep passes %llu\n",
+            (unsigned long long)e->sel_stat[0], (unsigned long long)e->sel_stat[1], (unsigned long long)e->sel_stat[2], (unsigned long long)e->sel_stat[3]);
   if (getenv("KB_K5_STATS"))
     fprintf(stderr, "[kb K5] rounds %llu, rows %llu, dirty slots %llu, dirty-won rows %llu, runs %llu, runs with a row-specific Resreq %llu (%llu)\n",
             (unsigned long long)e->stats.rounds, (unsigned long long)e->stats.decisions, (unsigned long long)e->k5_slots,

@@ -1,0 +1,42 @@
+#!/usr/bin/env bash
+# Round 4's GPU calls, one parameterised script:   gpurun -- 'bash scripts/gpu_r4.sh <step> [args]'   (writes gpurun_out/r4_<step>/*)
+#   sel      the selection commit kernel (k_commit_run<true>): the differential suites pinned to it, then same-box A/B against the round-3 kernels
+#   suite    the whole -m gpu suite
+#   bench    the default bench line and the variants
+set -uo pipefail
+cd "$(dirname "$0")/.."
+step="${1:-suite}"; shift || true
+out="gpurun_out/r4_${step}"
+mkdir -p "$out"
+ms() { python -c "import json,sys; d=json.loads(open('$1').read().strip().splitlines()[-1]); print(d.get('ms_per_step'), d.get('verified_bind_set_equals_oracle'), d.get('kernel_ms_per_step'))" 2>/dev/null; }
+bench_ab() {   # name, env assignments..., -- bench args
+  local name="$1"; shift
+  local envs=(); while [ "$1" != "--" ]; do envs+=("$1"); shift; done; shift
+  env "${envs[@]}" KB_K5_STATS=1 python bench.py --no-cpu-baseline "$@" > "$out/bench_${name}.json" 2> "$out/bench_${name}.err"
+  echo "bench $name rc=$? $(ms "$out/bench_${name}.json")" | tee -a "$out/summary.txt"
+  grep -h "kb select\|kb K5\] rounds on" "$out/bench_${name}.err" | tee -a "$out/summary.txt"
+}
+case "$step" in
+sel)
+  timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_fuzz.py tests/test_gpu_adversarial.py tests/test_gpu_regressions.py tests/test_gpu_preempt.py tests/test_gpu_interpod.py \
+    -q -m gpu -p no:cacheprovider -k "select" > "$out/pytest_select.txt" 2>&1; echo "differential suites on the selection kernel rc=$? $(tail -1 "$out/pytest_select.txt")" | tee -a "$out/summary.txt"
+  for cfg in "3" "4" "3 --survey-nodes"; do
+    tag="c${cfg// --survey-nodes/survey}"; tag="${tag// /}"
+    bench_ab "${tag}_r3" KB_DIRTY_KERNEL=run -- --config ${cfg} --steps 5 --warmup 2 --verify
+    bench_ab "${tag}_auto" KB_DIRTY_KERNEL=select -- --config ${cfg} --steps 5 --warmup 2 --verify
+    bench_ab "${tag}_pinsel" KB_COMMIT_KERNEL=select -- --config ${cfg} --steps 5 --warmup 2 --verify
+    bench_ab "${tag}_pinrun" KB_COMMIT_KERNEL=run -- --config ${cfg} --steps 5 --warmup 2 --verify
+  done
+  ;;
+suite)
+  timeout 1500 python -m pytest tests -q -m gpu -p no:cacheprovider "$@" > "$out/pytest_gpu.txt" 2>&1; echo "gpu suite rc=$? $(tail -1 "$out/pytest_gpu.txt")" | tee -a "$out/summary.txt"
+  ;;
+bench)
+  python bench.py > "$out/bench_default.json" 2> "$out/bench_default.err"; echo "bench rc=$? $(ms "$out/bench_default.json")" | tee -a "$out/summary.txt"
+  bench_ab config4 -- --config 4 --steps 5 --warmup 2 --verify
+  bench_ab config5 -- --config 5 --steps 3 --warmup 1 --verify
+  bench_ab config5_preempt -- --config 5 --preempt --steps 2 --warmup 1 --verify
+  ;;
+*) echo "unknown step $step"; exit 2 ;;
+esac
+cat "$out/summary.txt"
