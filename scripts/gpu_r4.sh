@@ -23,9 +23,12 @@ sel)
   for cfg in "3" "4" "3 --survey-nodes"; do
     tag="c${cfg// --survey-nodes/survey}"; tag="${tag// /}"
     bench_ab "${tag}_r3" KB_DIRTY_KERNEL=run -- --config ${cfg} --steps 5 --warmup 2 --verify
-    bench_ab "${tag}_auto" KB_DIRTY_KERNEL=select -- --config ${cfg} --steps 5 --warmup 2 --verify
     bench_ab "${tag}_pinsel" KB_COMMIT_KERNEL=select -- --config ${cfg} --steps 5 --warmup 2 --verify
-    bench_ab "${tag}_pinrun" KB_COMMIT_KERNEL=run -- --config ${cfg} --steps 5 --warmup 2 --verify
+    if [ -f kube-batch_amd/libkbengine_trace.so ]; then   # make EXTRA=-DKB_K9_TRACE OUT=../libkbengine_trace.so: wave 0's cycles per phase
+      KB_ENGINE_LIB=$PWD/kube-batch_amd/libkbengine_trace.so KB_COMMIT_KERNEL=select KB_K5_STATS=1 python bench.py --no-cpu-baseline --config ${cfg} --steps 2 --warmup 1 \
+        > "$out/trace_${tag}.json" 2> "$out/trace_${tag}.err"
+      echo "== trace ${tag}" | tee -a "$out/summary.txt"; grep -h "kb K5 trace\|kb K5\] rounds [0-9]" "$out/trace_${tag}.err" | tee -a "$out/summary.txt"
+    fi
   done
   ;;
 suite)
