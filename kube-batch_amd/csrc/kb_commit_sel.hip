@@ -11,9 +11,9 @@
 //    a node picked at key s was the maximum with the lowest index among equals (util.SelectBestNode, scheduler_helper.go:188-208, with
 //    the canonical tie-break); while its next keys stay >= s it wins again at once (nobody else changed) — the steps on which eff stays s —
 //    and when its key falls below s the prefix minimum is the real key again.  A Pipeline entry (allocate.go:160: InitResreq no longer
-//    fits Idle) ends its node's sequence; picked, it ends the round behind its row.  Steps 0 and 1 of every candidate come out of the
-//    parallel evaluation phase; deeper steps are walked by the lanes of wave 0, several steps per candidate in one pass; the order is
-//    a rank by count over at most 64 entries.  Nothing is written before the picks are known, so any limit of the tables simply hands
+//    fits Idle) ends its node's sequence; picked, it ends the round behind its row.  Step 0 of every candidate (and step 1 of the clean
+//    ones) comes out of the parallel evaluation phase; deeper steps are walked by the lanes of wave 0, several steps per candidate in
+//    one pass (most runs need none: every pick is a clean candidate's first placement); the order is a rank by count over at most 64 entries.  Nothing is written before the picks are known, so any limit of the tables simply hands
 //    the run to the serial loop of kb_commit.hip, kept here verbatim.  (tests/run_selection_model.py and the emulated launch of
 //    tests/host_harness/device_emu.cpp hold the claim to the serial loop on the CPU.)
 //
@@ -23,7 +23,7 @@
 //    applies NodeInfo.AddTask to the first r survivors and evaluates their keys after the placement.  Wave 0 only selects.  What is
 //    left on the critical path of a run: one evaluation (dirty slots and candidates side by side), two barriers, the selection.
 //
-//   waves 1..4   key(shape, dirty slot t) and, for slots above the floor, the key and the kinds one placement on
+//   waves 1..4   key(shape, dirty slot t) and the kind of the slot's next placement
 //   wave 5 / 6   alternating: candidates of the CURRENT run (filter, AddTask, key)  |  walk + fetch for the NEXT run
 //   wave 0       selection (or the serial loop), decision records, cursors, the next run's header
 #include "kb_k9.hpp"
@@ -50,7 +50,7 @@ __global__ void __launch_bounds__(K9_THREADS) k_commit_select(const K9KernArgs k
   K9Sel &X = *reinterpret_cast<K9Sel *>(k9_smem + lo.sel);
   const unsigned long long t_start = wall_clock64();
   k9_prologue(a, lo, k9_smem, tid, K9_SEL_MAXRUN);
-  if (tid < 4) X.stat[tid] = 0u;   // first touched by wave 0 behind the loop's first barrier
+  if (tid < 4) { X.stat[tid] = 0u; X.tr[tid] = 0u; }   // first touched behind the loop's first barrier
 
 #ifdef KB_K9_TRACE
   uint32_t tacc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -123,10 +123,9 @@ __global__ void __launch_bounds__(K9_THREADS) k_commit_select(const K9KernArgs k
         for (int dd = 0; dd < a.R; dd++) rowres[(par) * (uint32_t)a.R + (uint32_t)dd] = d_.t_res[(size_t)dd * d_.T + tk_]; \
       }                                                                                                                \
     }                                                                                                                  \
-    if (lane == 0) {                                                                                                   \
-      P_.i = (i_next); P_.s = s_; P_.r = r_; P_.fl = fl_; P_.km = km_; P_.nf = nc_;                                    \
-      P_.cmin_est = (nc_ == want_ && want_ != 0u) ? P_.ckey[want_ - 1u] : 0u;   /* the r-th survivor is among the first r + r_prev */ \
-    }                                                                                                                  \
+    if (lane == 0) { P_.i = (i_next); P_.s = s_; P_.r = r_; P_.fl = fl_; P_.km = km_; P_.nf = nc_; }                   \
+    if (lane < (uint32_t)(sizeof(K9Shape) / 8) && (i_next) < W)                                                        \
+      reinterpret_cast<unsigned long long *>(&P_.sh)[lane] = reinterpret_cast<const unsigned long long *>(&shapes[s_])[lane]; \
   } while (0)
 
   if (wave == K9S_PREP0) K9S_PREP(0u, 0u, 0u);
@@ -139,14 +138,20 @@ __global__ void __launch_bounds__(K9_THREADS) k_commit_select(const K9KernArgs k
     if (H.stop) break;
     const uint32_t par = k & 1u;
     const K9Prep &P = X.prep[par];
-    const uint32_t i0 = H.i, nd = H.nd, s = P.s, r = P.r, fl0 = P.fl, km0 = P.km, nf = P.nf, cmin_est = P.cmin_est;
+    const uint32_t i0 = H.i, nd = H.nd, s = P.s, r = P.r, fl0 = P.fl, km0 = P.km, nf = P.nf;
     const bool plain0 = (fl0 & 1u) && (km0 == 0u || (fl0 & 4u));
-    const K9Shape sh = shapes[s];
+    const K9Shape sh = P.sh;   // == shapes[s]
     const double *si = sinit + (size_t)s * RS;
     const double *rres = rowres + par * (uint32_t)a.R;   // the row's own Resreq (rows that are not plain)
     const double *rqv = plain0 ? si : rres + 2;          // the rows' scalar Resreq
     // the run goes through the selection: plain rows of the allocate action, at least two of them
     const bool sel_run = !a.backfill && plain0 && r >= 2u;
+#ifdef KB_K9_TRACE
+    const unsigned long long tr0 = __builtin_readcyclecounter();
+#define K9S_ROLE_END(k) do { if (lane == 0) atomicAdd(&X.tr[k], (uint32_t)(__builtin_readcyclecounter() - tr0)); } while (0)
+#else
+#define K9S_ROLE_END(k) do { } while (0)
+#endif
     // ---- evaluation phase, one evaluation deep
     if (wave >= 1u && wave <= 4u) {
       if (tid - 64u < nd) {   // the shape against "their" dirty slot
@@ -155,24 +160,10 @@ __global__ void __launch_bounds__(K9_THREADS) k_commit_select(const K9KernArgs k
         const K9Sc scp = k9_sc_preload(sh.active >> 2, gi, gr, a.NP, vs.node);
         const uint32_t key0 = k9_eval_v(a, sh, vs, scp, gi, gr, si, 0u, 0.0, si, nb, nmaskbits);
         dk[t] = key0;
-        // a slot that can be picked (its key is above the floor — cmin_est: a lower bound of the r-th surviving candidate's key): what its
-        // first placement would be, and its key and kind one placement on
-        uint32_t key1 = 0u, kk = 0u;
-        if (sel_run && key0 > cmin_est) {
-          const uint32_t nm0 = (uint32_t)(slots[(size_t)t * K9_NF + F_NODE_NMASK] >> 32);
-          const uint32_t adjm = (nm0 & 0x7FFFFFFFu) ? km0 : 0u;   // Idle has a scalar map: Sub lowers the dimensions Resreq names
-          if (k9_fits_idle(a, sh, vs.idle0, vs.idle1, scp, gi, si, vs.node, 0u, 0.0, si)) {
-            K9St v1 = vs;
-            v1.idle0 -= sh.init0; v1.idle1 -= sh.init1; v1.nzc += sh.nzc; v1.nzm += sh.nzm;
-            v1.ports |= sh.want; v1.left -= 1;
-            key1 = k9_eval_v(a, sh, v1, scp, gi, gr, si, adjm, 1.0, si, nb, nmaskbits);
-            if (!k9_fits_idle(a, sh, v1.idle0, v1.idle1, scp, gi, si, vs.node, adjm, 1.0, si)) kk |= 2u;
-          } else {
-            kk = 1u;   // the first placement would be a Pipeline: it ends the slot's sequence
-          }
-        }
-        X.dk1[t] = key1; X.dkk[t] = kk;
+        // what the slot's next placement of the shape would be (allocate.go:160) — the selection reads it for the slots it considers
+        if (sel_run) X.dkk[t] = k9_fits_idle(a, sh, vs.idle0, vs.idle1, scp, gi, si, vs.node, 0u, 0.0, si) ? 0u : 1u;
       }
+      if (wave == 1u) K9S_ROLE_END(2);
     } else if (wave == K9S_PREP0 + par) {
       // ---- this run's candidates: of the entries fetched one iteration ago, the first r whose node the predecessor left alone; lane j holds
       //      entry j's node state.  P2: Allocate / Pipeline, NodeInfo.AddTask on the fetched state, key of the node after the placement
@@ -220,9 +211,11 @@ __global__ void __launch_bounds__(K9_THREADS) k_commit_select(const K9KernArgs k
         X.ckind[rho] = kind; X.ck1[rho] = k1; X.ckind1[rho] = kind1; X.crnm[rho] = rnm;
       }
       if (lane == 0) H.ncand = ncand;
+      K9S_ROLE_END(0);
     } else if (wave == K9S_PREP0 + (par ^ 1u)) {
       // ---- the next run (it starts behind this one's last row if this one completes; if it does not, the round ends here)
       K9S_PREP(i0 + r, r, par ^ 1u);
+      K9S_ROLE_END(1);
     }
     K9_STAMP(1);
     __syncthreads();   // B2: the dirty keys, the candidates and their slots are in LDS
@@ -275,27 +268,22 @@ __global__ void __launch_bounds__(K9_THREADS) k_commit_select(const K9KernArgs k
           const bool a0v = lane < ncand;
           const uint32_t ce1 = min(ck, k1);
           const bool a1v = a0v && ckind == 0u && k1 != 0u && ce1 > cmin;
-          uint32_t dq[4], dkk4[4], dd4[4] = {d0, d1, d2, d3}, de1[4], myc[4] = {0, 0, 0, 0};
-          bool b0v[4], b1v[4];
-          unsigned long long bb0[4], bb1[4];
-          uint32_t nD = 0, nB1 = 0;
+          uint32_t dkk4[4], dd4[4] = {d0, d1, d2, d3};
+          bool b0v[4];
+          unsigned long long bb0[4];
+          uint32_t nD = 0;
 #pragma unroll
           for (int u = 0; u < 4; u++) {
             const uint32_t t = lane + 64u * (uint32_t)u;
-            dq[u] = (t < nd) ? X.dk1[t] : 0u;
             dkk4[u] = (t < nd) ? X.dkk[t] : 0u;
             b0v[u] = dd4[u] > cmin;
-            de1[u] = min(dd4[u], dq[u]);
-            b1v[u] = b0v[u] && !(dkk4[u] & 1u) && dq[u] != 0u && de1[u] > cmin;
             bb0[u] = __ballot(b0v[u]);
-            bb1[u] = __ballot(b1v[u]);
             nD += (uint32_t)__popcll(bb0[u]);
-            nB1 += (uint32_t)__popcll(bb1[u]);
           }
           const unsigned long long ba1 = __ballot(a1v);
           const uint32_t nA1 = (uint32_t)__popcll(ba1);
           const uint32_t nC = ncand + nD;
-          uint32_t n = ncand + nA1 + nD + nB1;
+          uint32_t n = ncand + nA1 + nD;
           bool bail = nC > 64u || n > 64u;
           if (!bail) {
             if (a0v) {
@@ -312,30 +300,17 @@ __global__ void __launch_bounds__(K9_THREADS) k_commit_select(const K9KernArgs k
               X.e_info[pos] = lane | (ckind1 << 8) | (1u << 16);
             }
             base += nA1;
-            uint32_t cbase = ncand;
 #pragma unroll
-            for (int u = 0; u < 4; u++) {
+            for (int u = 0; u < 4; u++) {   // the dirty contenders: step 0 (their key as the evaluation phase found it); the passes below walk them on
               if (b0v[u]) {
-                const uint32_t c = cbase + (uint32_t)__popcll(bb0[u] & lt);
-                const uint32_t pos = base + (c - ncand);
-                myc[u] = c;
+                const uint32_t pos = base + (uint32_t)__popcll(bb0[u] & lt), c = pos - nA1;
                 X.e_comp[pos] = ((unsigned long long)dd4[u] << 8) | 255ull;
                 X.e_info[pos] = c | ((dkk4[u] & 1u) << 8);
-                X.c_slot[c] = lane + 64u * (uint32_t)u; X.c_next[c] = b1v[u] ? 2u : 1u; X.c_eff[c] = b1v[u] ? de1[u] : dd4[u];
-                X.c_flag[c] = (!b1v[u] || (dkk4[u] & 2u)) ? 1u : 0u;
+                X.c_slot[c] = lane + 64u * (uint32_t)u; X.c_next[c] = 1u; X.c_eff[c] = dd4[u];
+                X.c_flag[c] = dkk4[u] & 1u;   // ended: its first placement is a Pipeline
                 X.c_take[c] = 0u;
               }
-              cbase += (uint32_t)__popcll(bb0[u]);
-            }
-            base += nD;
-#pragma unroll
-            for (int u = 0; u < 4; u++) {
-              if (b1v[u]) {
-                const uint32_t pos = base + (uint32_t)__popcll(bb1[u] & lt);
-                X.e_comp[pos] = ((unsigned long long)de1[u] << 8) | 254ull;
-                X.e_info[pos] = myc[u] | (((dkk4[u] >> 1) & 1u) << 8) | (1u << 16);
-              }
-              base += (uint32_t)__popcll(bb1[u]);
+              base += (uint32_t)__popcll(bb0[u]);
             }
             K9_WAVE_FENCE();
           }
@@ -363,12 +338,13 @@ __global__ void __launch_bounds__(K9_THREADS) k_commit_select(const K9KernArgs k
             // lane -> (contender ai, step u of this pass): the contender's state after that many more placements, one subtraction at a time
             const bool act = lane < na * D;
             const uint32_t ai = lane / D, u = lane - ai * D;
-            uint32_t cc = 0u, jj = 0u, kind = 0u;
+            uint32_t cc = 0u, jj = 0u, kind = 0u, key = 0u, run = 0xFFFFFFFFu;
             bool inexact = false;
             if (act) {
               cc = X.al[ai];
               const uint32_t slot = X.c_slot[cc], b = (X.c_flag[cc] >> 1) & 1u;
               jj = X.c_next[cc] + u;
+              run = X.c_eff[cc];
               const uint32_t mpl = jj - b;   // placements on top of the slot's state (a clean candidate's slot holds it after the first)
               const unsigned long long *st = slots + (size_t)slot * K9_NF;
               K9St v = k9_load(st);
@@ -385,22 +361,19 @@ __global__ void __launch_bounds__(K9_THREADS) k_commit_select(const K9KernArgs k
               for (uint32_t t = 0; t < mpl; t++) { v.idle0 -= sh.init0; v.idle1 -= sh.init1; v.nzc += sh.nzc; v.nzm += sh.nzm; }
               if (mpl) v.ports |= sh.want;
               v.left -= (int)mpl;
-              const uint32_t key = k9_eval_v(a, sh, v, scx, gi, gr, si, adjm, (double)jj, si, nb, nmaskbits);
+              key = k9_eval_v(a, sh, v, scx, gi, gr, si, adjm, (double)jj, si, nb, nmaskbits);
               kind = k9_fits_idle(a, sh, v.idle0, v.idle1, scx, gi, si, v.node, adjm, (double)jj, si) ? 0u : 1u;
-              X.kt[lane] = key; X.kk[lane] = kind;
             }
             if (__ballot(inexact)) { bail = true; break; }
-            K9_WAVE_FENCE();
-            // step jj exists iff every step of the pass before it exists and is an Allocate, and its own key is not 0
-            bool valid = act;
-            uint32_t run = 0u;
-            if (act) {
-              run = X.c_eff[cc];
-              for (uint32_t t = 0; t <= u; t++) {
-                const uint32_t kt = X.kt[ai * D + t];
-                valid = valid && kt != 0u && (t == u || X.kk[ai * D + t] == 0u);
-                run = min(run, kt);
-              }
+            // step jj exists iff every step of the pass before it exists and is an Allocate, and its own key is not 0.  The lanes of a
+            // contender are neighbours [g0, g0 + D): ballots for the existence, a shuffle per step for the prefix minimum
+            const uint32_t g0 = ai * D;
+            const unsigned long long ends = __ballot(act && (key == 0u || kind != 0u));   // nothing exists behind such a step
+            const unsigned long long mine = lt & ~((1ull << (g0 & 63u)) - 1ull);          // my contender's lanes in front of me
+            const bool valid = act && key != 0u && (ends & mine) == 0ull;
+            for (uint32_t t = 0; t < D; t++) {
+              const uint32_t kt = (uint32_t)__shfl((int)key, (int)(g0 + t));
+              if (t <= u) run = min(run, kt);
             }
             const unsigned long long vb = __ballot(valid);
             if (valid) {
@@ -408,15 +381,15 @@ __global__ void __launch_bounds__(K9_THREADS) k_commit_select(const K9KernArgs k
               X.e_comp[pos] = ((unsigned long long)run << 8) | (unsigned long long)(255u - jj);
               X.e_info[pos] = cc | (kind << 8) | (jj << 16);
             }
-            K9_WAVE_FENCE();
-            if (act && u == 0u) {
-              const unsigned long long gm = (vb >> (ai * D)) & ((1ull << D) - 1ull);   // D <= K9_SEL_MAXRUN - 1
-              const uint32_t g = (uint32_t)__popcll(gm);
-              uint32_t run2 = X.c_eff[cc];
-              for (uint32_t t = 0; t < g; t++) run2 = min(run2, X.kt[ai * D + t]);
-              const bool ended = g < D || X.kk[ai * D + g - 1u] != 0u;
-              X.c_next[cc] += g; X.c_eff[cc] = run2;
-              if (ended) X.c_flag[cc] |= 1u;
+            {   // the contender's record, by its first lane: g steps were found
+              const uint32_t g = act ? (uint32_t)__popcll((vb >> (g0 & 63u)) & ((1ull << D) - 1ull)) : 0u;   // D <= K9_SEL_MAXRUN - 1
+              const uint32_t lastl = g0 + (g ? g - 1u : 0u);
+              const uint32_t run_last = (uint32_t)__shfl((int)run, (int)lastl), kind_last = (uint32_t)__shfl((int)kind, (int)lastl);
+              if (act && u == 0u) {
+                X.c_next[cc] += g;
+                if (g) X.c_eff[cc] = run_last;
+                if (g < D || kind_last != 0u) X.c_flag[cc] |= 1u;   // the sequence ended inside the pass, or its last step is a Pipeline
+              }
             }
             n += (uint32_t)__popcll(vb);
             if (lane == 0) X.stat[3]++;
@@ -581,6 +554,9 @@ __global__ void __launch_bounds__(K9_THREADS) k_commit_select(const K9KernArgs k
         H.n_dirty_rows += n_dirty; H.n_runs += 1; H.n_slow += plain0 ? 0u : 1u;
         H.i = i_next; H.nd = nd + pc; H.reason = reason; H.stop = stop;
       }
+#ifdef KB_K9_TRACE
+      if (r == 1u && lane == 0) X.tr[3] += (uint32_t)(__builtin_readcyclecounter() - tlast);
+#endif
       K9_STAMP(3);
     }
   }
@@ -592,6 +568,8 @@ __global__ void __launch_bounds__(K9_THREADS) k_commit_select(const K9KernArgs k
     tw[7] = (unsigned long long)tacc[4] | ((unsigned long long)tacc[5] << 32);
     tw[13] = (unsigned long long)tacc[6] | ((unsigned long long)tacc[7] << 32);
     tw[14] = (unsigned long long)tacc[8] | ((unsigned long long)tacc[9] << 32);
+    tw[4] = (unsigned long long)X.tr[0] | ((unsigned long long)X.tr[1] << 32);
+    tw[15] = (unsigned long long)X.tr[2] | ((unsigned long long)X.tr[3] << 32);
   }
 #endif
   __syncthreads();   // the statistics words (wave 0) before the epilogue reads them

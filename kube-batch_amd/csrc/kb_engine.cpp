@@ -131,7 +131,7 @@ struct kb_engine {
   // session buffers
   DevBuf b_idle, b_rel, b_nzc, b_nzm, b_podcnt, b_acpu, b_amem, b_maxpods, b_ncls, b_nmask, b_invac, b_invam;
   uint64_t k5_walks = 0, k5_rescans = 0, k5_demand = 0, k5_slots = 0;   // commit kernel counters (KB_K5_STATS)
-  double k5_trace[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  double k5_trace[14] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   double k7_trace[14] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   unsigned long long k7_batches = 0;
   uint32_t eff_window = 0;   // window actually used for this session (bounded by the commit kernel's LDS budget)
@@ -628,6 +628,8 @@ void round_collect(kb_engine *e, const RoundCtx &c, bool had_candidates, uint32_
     e->k5_rescans += h_result[5];
     for (int k = 0; k < 10; k++)   // zero unless built with -DKB_K9_TRACE
       e->k5_trace[k] += (double)(uint32_t)(ho[(k < 6 ? 5 + k / 2 : 13 + (k - 6) / 2)] >> (32 * (k & 1)));
+    if (e->commit_kernel_of[c.buf] == KB_COMMIT_SELECT && e->k5_trace[0] > 0)   // the selection kernel's trace build: its other waves' evaluation phase
+      for (int k = 10; k < 14; k++) e->k5_trace[k] += (double)(uint32_t)(ho[k < 12 ? 4 : 15] >> (32 * (k & 1)));
   }
   // next round's kernel: a round in which more than ~a quarter of the rows went to dirty nodes cuts most speculated batches short
   if (n_done) {
@@ -1087,6 +1089,8 @@ void kb_engine_destroy(kb_engine *e) {
                                     "selection: entries + first rank", "selection: deep passes", "selection: picks + AddTask", "selection: all picks clean", "loop top"};
     const double runs = (double)(e->k5_walks ? e->k5_walks : 1);
     for (int k = 0; k < 10; k++) fprintf(stderr, "[kb K5 trace] %-32s %14.0f clocks  (%.0f per run)\n", e->rounds_sel > e->rounds_run ? ph_sel[k] : ph[k], e->k5_trace[k], e->k5_trace[k] / runs);
+    static const char *ph_role[4] = {"evaluation phase: the candidates' wave", "evaluation phase: the walking wave", "evaluation phase: wave 1 (dirty slots)", "rows step of single rows (part of rows)"};
+    if (e->rounds_sel > e->rounds_run) for (int k = 10; k < 14; k++) fprintf(stderr, "[kb K5 trace] %-32s %14.0f clocks  (%.0f per run)\n", ph_role[k - 10], e->k5_trace[k], e->k5_trace[k] / runs);
   }
   (void)hipSetDevice(e->device);
   delete e;

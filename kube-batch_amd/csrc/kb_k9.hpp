@@ -34,18 +34,19 @@ struct K9Hdr {
 // A run prepared one iteration ahead by a "prep" wave: its parameters and the clean entries of its shape's list as of the walk — r + r_prev of
 // them, because the run in front of it (r_prev rows) may still take some (filtered against the dirty bitmap when the run's turn comes).
 struct K9Prep {
-  uint32_t i, s, r, fl, km, nf, cmin_est, pad;   // first row, shape, rows, flags, Resreq key mask; entries fetched; lower bound of the r-th surviving key
+  uint32_t i, s, r, fl, km, nf, pad0, pad1;      // first row, shape, rows, flags, Resreq key mask; entries fetched
+  K9Shape sh;                                    // shapes[s]: the run's header comes out of ONE block (a single LDS round trip behind the barrier)
   uint32_t ckey[64], cpos[64];                   // the fetched entries: key and list position, best first
 };
 struct K9Sel {
   K9Prep prep[2];                     // by parity of the run's number
   uint32_t ckind[64], ck1[64], ckind1[64], crnm[64];   // per surviving candidate (P2's results, written by the prep wave, read by wave 0)
-  uint32_t dk1[K9_MAXSLOTS];          // key of dirty slot t after ONE more placement of the run's shape (0: infeasible; only where dk[t] is above the floor)
-  uint32_t dkk[K9_MAXSLOTS];          // bit 0: that placement would be a Pipeline; bit 1: the one after it would be
+  uint32_t dkk[K9_MAXSLOTS];          // dirty slot t: its next placement of the run's shape would be a Pipeline (allocate.go:160)
   unsigned long long e_comp[64];      // entries: prefix-minimum key << 8 | 255 - step  (greater = picked earlier)
   uint32_t e_info[64];                // contender | kind << 8 | step << 16
   uint32_t c_slot[64], c_next[64], c_eff[64], c_flag[64], c_take[64];   // contenders: state slot, next unknown step, prefix minimum so far, bit 0 ended / bit 1 clean / bit 2 its last taken entry is a Pipeline
-  uint32_t al[64], kt[64], kk[64];    // a deep pass: the contenders it walks, the keys and kinds its lanes found
+  uint32_t al[64];                    // a deep pass: the contenders it walks
+  uint32_t tr[4];                     // KB_K9_TRACE: cycles of the candidates' wave, of the walking wave, of wave 1 in the evaluation phase; of wave 0's rows step for single rows
   uint32_t stat[4];                   // runs committed with every pick a clean first placement / by the general selection / handed to the serial loop; deep passes
 };
 

@@ -1,6 +1,7 @@
 #!/usr/bin/env bash
 # Round 4's GPU calls, one parameterised script:   gpurun -- 'bash scripts/gpu_r4.sh <step> [args]'   (writes gpurun_out/r4_<step>/*)
 #   sel      the selection commit kernel (k_commit_run<true>): the differential suites pinned to it, then same-box A/B against the round-3 kernels
+#   trace    the selection kernel's per-phase cycle trace (configs 3 and 4)
 #   suite    the whole -m gpu suite
 #   bench    the default bench line and the variants
 set -uo pipefail
@@ -29,6 +30,13 @@ sel)
         > "$out/trace_${tag}.json" 2> "$out/trace_${tag}.err"
       echo "== trace ${tag}" | tee -a "$out/summary.txt"; grep -h "kb K5 trace\|kb K5\] rounds [0-9]" "$out/trace_${tag}.err" | tee -a "$out/summary.txt"
     fi
+  done
+  ;;
+trace)   # the selection kernel's per-phase trace only (make EXTRA=-DKB_K9_TRACE OUT=../libkbengine_trace.so)
+  for cfg in "3" "4"; do
+    KB_ENGINE_LIB=$PWD/kube-batch_amd/libkbengine_trace.so KB_COMMIT_KERNEL=select KB_K5_STATS=1 python bench.py --no-cpu-baseline --config ${cfg} --steps 2 --warmup 1 \
+      > "$out/trace_c${cfg}.json" 2> "$out/trace_c${cfg}.err"
+    echo "== trace c${cfg} $(ms "$out/trace_c${cfg}.json")" | tee -a "$out/summary.txt"; grep -h "kb K5 trace\|kb K5\] rounds [0-9]\|kb select" "$out/trace_c${cfg}.err" | tee -a "$out/summary.txt"
   done
   ;;
 suite)
