@@ -12,26 +12,44 @@
 //    the canonical tie-break); while its next keys stay >= s it wins again at once (nobody else changed) — the steps on which eff stays s —
 //    and when its key falls below s the prefix minimum is the real key again.  A Pipeline entry (allocate.go:160: InitResreq no longer
 //    fits Idle) ends its node's sequence; picked, it ends the round behind its row.  Step 0 of every candidate (and step 1 of the clean
-//    ones) comes out of the parallel evaluation phase; deeper steps are walked by the lanes of wave 0, several steps per candidate in
-//    one pass (most runs need none: every pick is a clean candidate's first placement); the order is a rank by count over at most 64 entries.  Nothing is written before the picks are known, so any limit of the tables simply hands
-//    the run to the serial loop of kb_commit.hip, kept here verbatim.  (tests/run_selection_model.py and the emulated launch of
-//    tests/host_harness/device_emu.cpp hold the claim to the serial loop on the CPU.)
+//    ones) is evaluated in parallel before the selection; deeper steps are walked by the lanes of wave 0, several steps per candidate in
+//    one pass (most runs need none: every pick is a clean candidate's first placement); the order is a rank by count over at most 64
+//    entries.  Nothing is written before the picks are known, so any limit of the tables simply hands the run to the serial loop of
+//    kb_commit.hip, kept here.  (tests/run_selection_model.py and the emulated launch of tests/host_harness/device_emu.cpp hold the
+//    claim to the serial loop on the CPU.)
 //
-// 2. A run is PREPARED while its predecessor is committed.  Two "prep" waves alternate: during the evaluation phase of run k one of them
-//    walks run k + 1's candidate list and issues the fetch of its candidates' node state (r' + r of them: run k may still take up to r
-//    of them), the other one — which did the same for run k one iteration earlier — drops the entries run k - 1 took (dirty bitmap),
-//    applies NodeInfo.AddTask to the first r survivors and evaluates their keys after the placement.  Wave 0 only selects.  What is
-//    left on the critical path of a run: one evaluation (dirty slots and candidates side by side), two barriers, the selection.
-//
-//   waves 1..4   key(shape, dirty slot t) and the kind of the slot's next placement
-//   wave 5 / 6   alternating: candidates of the CURRENT run (filter, AddTask, key)  |  walk + fetch for the NEXT run
-//   wave 0       selection (or the serial loop), decision records, cursors, the next run's header
+// 2. The workgroup is a PIPELINE of waves that hand runs to each other through sequence words in LDS — no workgroup barrier inside the
+//    loop, so that a wave with a long step does not hold up the others:
+//      waves 5..7   prep, run m on wave 5 + m % 3: walk the shape's candidate list two runs ahead (r + r' + r'' clean entries: the two runs in
+//                   front may still take theirs), fetch the entries' node state, NodeInfo.AddTask and the key after the placement for each
+//                   (registers); when run m - 1 is committed: drop the entries it and its predecessor took (dirty bitmap), store the first r
+//                   survivors as the run's candidates (their dirty slots included), publish seq_cand = m + 1;
+//      waves 1..4   when run k - 1 is committed: key(shape k, dirty slot t) for every dirty slot, publish seq_dk = k + 1;
+//      wave 0       when both are there: the selection (or the serial loop), decision records, cursors, dirty slots; publish seq_done = k + 1.
+//    A run's critical path is one evaluation (dirty slots) and its selection.  The words only grow; every wait is bounded (a wave that
+//    waits too long raises `err`, everybody leaves, the round reports KB_REASON_INTERNAL instead of hanging).
 #include "kb_k9.hpp"
 
-#define K9S_PREP0 5u   // waves K9S_PREP0 and K9S_PREP0 + 1 prepare the runs of even / odd number
+#define K9S_PREP0 5u          // waves 5, 6, 7 prepare runs m % 3 == 0, 1, 2
+#define K9S_PREPS 3u
+#define K9S_SPIN_LIMIT (1u << 21)   // polls of ~100+ cycles each: a few hundred milliseconds
 
-// make EXTRA=-DKB_K9_TRACE: cycles wave 0 spends per phase — 0: barrier 1, 1: the evaluation phase (wave 0 waits at barrier 2), 3: rows (serial
-// loop, tail), 4: -, 5: entries + first rank, 6: deep passes (with their ranks), 7: picks + AddTask, 8: runs through the all-clean path, 9: loop top
+// the sequence words (K9Sync, in LDS): acquire loads / release stores at workgroup scope
+__device__ __forceinline__ uint32_t k9s_ld(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ void k9s_st(uint32_t *p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP); }
+// wait until *p >= need; false when the round stopped (or somebody timed out) before that
+__device__ __forceinline__ bool k9s_wait(K9Sync &Y, const uint32_t *p, uint32_t need) {
+  uint32_t spins = 0;
+  for (;;) {
+    if (k9s_ld(p) >= need) return true;
+    if ((++spins & 31u) == 0u) {   // the words a waiter is woken by move with seq_done; stop / err are looked at now and then
+      if (k9s_ld(&Y.stop) | k9s_ld(&Y.err)) return k9s_ld(p) >= need;
+      if (spins > K9S_SPIN_LIMIT) { k9s_st(&Y.err, 1u); return false; }
+    }
+    __builtin_amdgcn_s_sleep(1);
+  }
+}
+
 __global__ void __launch_bounds__(K9_THREADS) k_commit_select(const K9KernArgs ka) {
   KbCommitArgs a = ka.hot;
   {   // only `a` is named in the loops (SGPRs); the two views are read through the kernel-argument segment on rare paths
@@ -48,184 +66,71 @@ __global__ void __launch_bounds__(K9_THREADS) k_commit_select(const K9KernArgs k
   K9_LDS_VIEWS(lo)
   (void)shp; (void)S;
   K9Sel &X = *reinterpret_cast<K9Sel *>(k9_smem + lo.sel);
+  K9Sync &Y = X.sync;
   const unsigned long long t_start = wall_clock64();
   k9_prologue(a, lo, k9_smem, tid, K9_SEL_MAXRUN);
-  if (tid < 4) { X.stat[tid] = 0u; X.tr[tid] = 0u; }   // first touched behind the loop's first barrier
 
-#ifdef KB_K9_TRACE
-  uint32_t tacc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-  unsigned long long tlast = __builtin_readcyclecounter();
-#endif
-  // a prep wave's registers: the fetched (raw) node state of entry `lane` of the run it prepared
-  unsigned long long raw[11] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-  uint32_t rcls = 0, rmaxp = 0, rpodc = 0, rnm = 0;
-  const unsigned long long lt = (1ull << lane) - 1ull;
-
-  typedef const unsigned long long __attribute__((address_space(1))) *gptr8;
-  typedef const uint32_t __attribute__((address_space(1))) *gptr4;
-  gptr8 g8[10];
-  gptr8 gports;
-  gptr4 gcls, gmaxp, gpodc, gnm;
-  gptrd gi, gr;
-  {
-    const KbDev &d = *a.dev;
-    g8[0] = (gptr8)reinterpret_cast<const unsigned long long *>(d.idle); g8[1] = (gptr8)reinterpret_cast<const unsigned long long *>(d.idle + d.NP);
-    g8[2] = (gptr8)reinterpret_cast<const unsigned long long *>(d.rel); g8[3] = (gptr8)reinterpret_cast<const unsigned long long *>(d.rel + d.NP);
-    g8[4] = (gptr8)reinterpret_cast<const unsigned long long *>(d.inv_acpu); g8[5] = (gptr8)reinterpret_cast<const unsigned long long *>(d.inv_amem);
-    g8[6] = (gptr8)reinterpret_cast<const unsigned long long *>(d.acpu); g8[7] = (gptr8)reinterpret_cast<const unsigned long long *>(d.amem);
-    g8[8] = (gptr8)reinterpret_cast<const unsigned long long *>(d.nzc); g8[9] = (gptr8)reinterpret_cast<const unsigned long long *>(d.nzm);
-    gports = (gptr8)d.ports;
-    gi = (gptrd)d.idle; gr = (gptrd)d.rel;
-    gcls = (gptr4)d.ncls; gmaxp = (gptr4)reinterpret_cast<const uint32_t *>(d.maxpods); gpodc = (gptr4)reinterpret_cast<const uint32_t *>(d.podcnt); gnm = (gptr4)d.nmask;
-  }
-
-  // A prep wave, one run ahead: the parameters of the run that starts at row i_next, the first r + r_prev clean entries of its shape's list
-  // (walk against the dirty bitmap AS IT IS: the run in front of it, r_prev rows, is being committed and may take up to r_prev of them), and
-  // the fetch of those entries' node state — lane j pulls every field of entry j, all loads in flight together; they land while the
-  // predecessor is committed.  With at most i_prev dirty nodes and a list of W + 1 entries the walk finds r + r_prev clean entries unless
-  // the list ends (its 0 terminator): nf < r + r_prev means every clean feasible node of the shape is among the nf.
-#define K9S_PREP(i_next, r_prev, par)                                                                                  \
-  do {                                                                                                                 \
-    K9Prep &P_ = X.prep[(par)];                                                                                        \
-    uint32_t nc_ = 0, s_ = 0, r_ = 0, fl_ = 0, km_ = 0, want_ = 0;                                                     \
-    if ((i_next) < W) {                                                                                                \
-      const uint4 ri_ = rinfo[(i_next)];                                                                               \
-      r_ = (uint32_t)__builtin_amdgcn_readfirstlane((int)ri_.x); s_ = (uint32_t)__builtin_amdgcn_readfirstlane((int)ri_.y); \
-      fl_ = (uint32_t)__builtin_amdgcn_readfirstlane((int)ri_.z); km_ = (uint32_t)__builtin_amdgcn_readfirstlane((int)ri_.w); \
-      want_ = r_ + (r_prev);   /* <= 2 * K9_SEL_MAXRUN = 64: one entry per lane */                                     \
-      uint32_t e_ = cursor[s_];                                                                                        \
-      while (nc_ < want_) {                                                                                            \
-        const uint32_t pos_ = e_ + lane;                                                                               \
-        const uint32_t kk_ = (pos_ < Lp) ? lists[s_ * Lp + pos_] : 0u;                                                 \
-        const bool nz_ = kk_ != 0u;                                                                                    \
-        const uint32_t nn_ = nmaskbits - (kk_ & nmaskbits);                                                            \
-        const bool cl_ = nz_ && !((bitmap[(nz_ ? nn_ : 0u) >> 5] >> (nn_ & 31)) & 1u);                                 \
-        const unsigned long long zeros_ = __ballot(!nz_);                                                              \
-        const uint32_t fz_ = zeros_ ? (uint32_t)__ffsll((unsigned long long)zeros_) - 1u : 64u;                        \
-        const unsigned long long clean_ = __ballot(cl_ && lane < fz_);   /* entries behind the list's end do not count */ \
-        const uint32_t rank_ = (uint32_t)__popcll(clean_ & lt);                                                        \
-        if (((clean_ >> lane) & 1ull) && nc_ + rank_ < want_) { P_.ckey[nc_ + rank_] = kk_; P_.cpos[nc_ + rank_] = pos_; } \
-        nc_ = min(want_, nc_ + (uint32_t)__popcll(clean_));                                                            \
-        if (fz_ < 64u || e_ + 64u >= Lp) break;   /* the list ended */                                                 \
-        e_ += 64u;                                                                                                     \
-      }                                                                                                                \
-      K9_WAVE_FENCE();                                                                                                 \
-      if (lane < nc_) {                                                                                                \
-        const uint32_t n_ = nmaskbits - (P_.ckey[lane] & nmaskbits);                                                   \
-        _Pragma("unroll") for (int f = 0; f < 10; f++) raw[f] = g8[f][n_];                                             \
-        raw[F_PORTS] = gports ? gports[n_] : 0ull;                                                                     \
-        rcls = gcls[n_]; rmaxp = gmaxp[n_]; rpodc = gpodc[n_]; rnm = gnm[n_];                                          \
-      }                                                                                                                \
-      const bool plain_ = (fl_ & 1u) && (km_ == 0u || (fl_ & 4u));                                                     \
-      if (!plain_ && lane == 63) {   /* an init container raised InitResreq above Resreq (rare): the row's own Resreq */ \
-        const KbDev &d_ = *a.dev;                                                                                      \
-        const uint32_t tk_ = desc[(i_next)].task;                                                                      \
-        for (int dd = 0; dd < a.R; dd++) rowres[(par) * (uint32_t)a.R + (uint32_t)dd] = d_.t_res[(size_t)dd * d_.T + tk_]; \
-      }                                                                                                                \
-    }                                                                                                                  \
-    if (lane == 0) { P_.i = (i_next); P_.s = s_; P_.r = r_; P_.fl = fl_; P_.km = km_; P_.nf = nc_; }                   \
-    if (lane < (uint32_t)(sizeof(K9Shape) / 8) && (i_next) < W)                                                        \
-      reinterpret_cast<unsigned long long *>(&P_.sh)[lane] = reinterpret_cast<const unsigned long long *>(&shapes[s_])[lane]; \
-  } while (0)
-
-  if (wave == K9S_PREP0) K9S_PREP(0u, 0u, 0u);
-
-  // ---------------- run loop (uniform across the workgroup): two barriers per run ----------------
-  for (uint32_t k = 0;; k++) {
-    K9_STAMP(9);
-    __syncthreads();   // B1: the run's header, its prepared entries, and every slot / bitmap bit the previous run wrote, are visible
-    K9_STAMP(0);
-    if (H.stop) break;
-    const uint32_t par = k & 1u;
-    const K9Prep &P = X.prep[par];
-    const uint32_t i0 = H.i, nd = H.nd, s = P.s, r = P.r, fl0 = P.fl, km0 = P.km, nf = P.nf;
-    const bool plain0 = (fl0 & 1u) && (km0 == 0u || (fl0 & 4u));
-    const K9Shape sh = P.sh;   // == shapes[s]
-    const double *si = sinit + (size_t)s * RS;
-    const double *rres = rowres + par * (uint32_t)a.R;   // the row's own Resreq (rows that are not plain)
-    const double *rqv = plain0 ? si : rres + 2;          // the rows' scalar Resreq
-    // the run goes through the selection: plain rows of the allocate action, at least two of them
-    const bool sel_run = !a.backfill && plain0 && r >= 2u;
-#ifdef KB_K9_TRACE
-    const unsigned long long tr0 = __builtin_readcyclecounter();
-#define K9S_ROLE_END(k) do { if (lane == 0) atomicAdd(&X.tr[k], (uint32_t)(__builtin_readcyclecounter() - tr0)); } while (0)
-#else
-#define K9S_ROLE_END(k) do { } while (0)
-#endif
-    // ---- evaluation phase, one evaluation deep
-    if (wave >= 1u && wave <= 4u) {
-      if (tid - 64u < nd) {   // the shape against "their" dirty slot
-        const uint32_t t = tid - 64u;
-        const K9St vs = k9_load(slots + (size_t)t * K9_NF);
-        const K9Sc scp = k9_sc_preload(sh.active >> 2, gi, gr, a.NP, vs.node);
-        const uint32_t key0 = k9_eval_v(a, sh, vs, scp, gi, gr, si, 0u, 0.0, si, nb, nmaskbits);
-        dk[t] = key0;
-        // what the slot's next placement of the shape would be (allocate.go:160) — the selection reads it for the slots it considers
-        if (sel_run) X.dkk[t] = k9_fits_idle(a, sh, vs.idle0, vs.idle1, scp, gi, si, vs.node, 0u, 0.0, si) ? 0u : 1u;
-      }
-      if (wave == 1u) K9S_ROLE_END(2);
-    } else if (wave == K9S_PREP0 + par) {
-      // ---- this run's candidates: of the entries fetched one iteration ago, the first r whose node the predecessor left alone; lane j holds
-      //      entry j's node state.  P2: Allocate / Pipeline, NodeInfo.AddTask on the fetched state, key of the node after the placement
-      const uint32_t key = (lane < nf) ? P.ckey[lane] : 0u;
-      const uint32_t n = nmaskbits - (key & nmaskbits);
-      const bool keep = lane < nf && !((bitmap[n >> 5] >> (n & 31)) & 1u);
-      const unsigned long long kb = __ballot(keep);
-      const uint32_t rho = (uint32_t)__popcll(kb & lt);
-      const uint32_t ncand = min((uint32_t)__popcll(kb), r);
-      if (keep && rho < r) {
-        double res0 = sh.init0, res1 = sh.init1;
-        if (!plain0) { res0 = rres[0]; res1 = rres[1]; }
-        unsigned long long *st = slots + (size_t)(nd + rho) * K9_NF;
-        double idle0 = u2d(raw[F_IDLE0]), idle1 = u2d(raw[F_IDLE1]), rel0 = u2d(raw[F_REL0]), rel1 = u2d(raw[F_REL1]);
-        uint32_t kind = 0;
-        const K9Sc scn = k9_sc_preload(sh.active >> 2, gi, gr, a.NP, n);   // the candidate's scalar dimensions: for the test below and the key
-        if (!a.backfill) {   // allocate.go:160: InitResreq.LessEqual(node.Idle) -> Allocate, else Pipeline
-          bool fi = le_eps(sh.init0, idle0, EPS_CPU) && le_eps(sh.init1, idle1, EPS_MEM);
-          for (uint32_t aa = sh.active >> 2, dd = 0; aa; aa >>= 1, dd++)
-            if (aa & 1u) fi = fi && le_eps(si[dd], k9_sci(scn, gi, a.NP, dd, n), EPS_SCALAR);
-          kind = fi ? 0u : 1u;
-        }
-        // NodeInfo.AddTask (api/node_info.go:172-212): Idle (Allocated) or Releasing (Pipelined) -= Resreq, pod joins ni.Tasks
-        if (kind) { rel0 -= res0; rel1 -= res1; } else { idle0 -= res0; idle1 -= res1; }
-        K9St v;
-        v.idle0 = idle0; v.idle1 = idle1; v.rel0 = rel0; v.rel1 = rel1;
-        v.inv_ac = u2d(raw[F_INVAC]); v.inv_am = u2d(raw[F_INVAM]);
-        v.ac = (double)(long long)raw[F_AC]; v.am = (double)(long long)raw[F_AM];
-        v.nzc = (double)(long long)raw[F_NZC] + sh.nzc; v.nzm = (double)(long long)raw[F_NZM] + sh.nzm;
-        v.ports = raw[F_PORTS] | sh.want;   // the pod's host ports join nodeinfo.UsedPorts()
-        v.cls = rcls; v.node = n; v.left = (int)rmaxp - (int)rpodc - 1;
-        st[F_IDLE0] = d2u(v.idle0); st[F_IDLE1] = d2u(v.idle1); st[F_REL0] = d2u(v.rel0); st[F_REL1] = d2u(v.rel1);
-        st[F_INVAC] = raw[F_INVAC]; st[F_INVAM] = raw[F_INVAM]; st[F_AC] = d2u(v.ac); st[F_AM] = d2u(v.am);
-        st[F_NZC] = d2u(v.nzc); st[F_NZM] = d2u(v.nzm); st[F_PORTS] = v.ports;
-        st[F_CLS_LEFT] = (unsigned long long)rcls | ((unsigned long long)(uint32_t)v.left << 32);
-        st[F_NODE_NMASK] = (unsigned long long)n | ((unsigned long long)rnm << 32);
-        // the scalar part of the Sub reaches HBM when (and if) the candidate is consumed; the key is evaluated as if it had.
-        // Sub returns early when the receiver's scalar map is nil (resource_info.go:148-153); a Pipeline ends the round, its
-        // Releasing-side key is never read.
-        const uint32_t adjm = (!kind && (rnm & 0x7FFFFFFFu)) ? km0 : 0u;
-        const uint32_t k1 = k9_eval_v(a, sh, v, scn, gi, gr, si, adjm, 1.0, rqv, nb, nmaskbits);   // the node's key once it is dirty
-        uint32_t kind1 = 0u;
-        if (sel_run && !kind) kind1 = k9_fits_idle(a, sh, v.idle0, v.idle1, scn, gi, si, n, adjm, 1.0, rqv) ? 0u : 1u;   // a second placement on it
-        ckey[rho] = key; cpos[rho] = P.cpos[lane];
-        X.ckind[rho] = kind; X.ck1[rho] = k1; X.ckind1[rho] = kind1; X.crnm[rho] = rnm;
-      }
-      if (lane == 0) H.ncand = ncand;
-      K9S_ROLE_END(0);
-    } else if (wave == K9S_PREP0 + (par ^ 1u)) {
-      // ---- the next run (it starts behind this one's last row if this one completes; if it does not, the round ends here)
-      K9S_PREP(i0 + r, r, par ^ 1u);
-      K9S_ROLE_END(1);
+  // ---- the runs of the window, by number: run k starts at row X.runs[k] (rinfo there holds its length, shape, flags, Resreq key mask).  A
+  //      row starts a run iff it cannot join its predecessor (k9_prologue's rule) or its stretch of joinable rows has reached a multiple of
+  //      the longest run.  W <= KB_K5_MAX_ROWS = 256: eight mask words.
+  if (tid < 8) { X.brk[tid] = 0u; X.stm[tid] = 0u; }
+  if (tid < 4) X.stat[tid] = 0u;
+  if (tid == 0) { Y.seq_done = 0u; Y.seq_cand = 0u; Y.nd_pub = 0u; Y.ncand_pub = 0u; Y.stop = 0u; Y.err = 0u; Y.seq_dk[0] = 0u; Y.seq_dk[1] = 0u; Y.seq_dk[2] = 0u; Y.seq_dk[3] = 0u; }
+  __syncthreads();
+  if (tid < W) {
+    bool brk = tid == 0;
+    if (tid) {
+      const KbRowDesc &p = desc[tid - 1], &q = desc[tid];
+      const bool plain = (p.flags & 1u) && (p.resmask == 0u || (p.flags & 4u));
+      brk = !(plain && !(p.flags & 2u) && q.slot == p.slot && q.flags == p.flags && q.resmask == p.resmask);
     }
-    K9_STAMP(1);
-    __syncthreads();   // B2: the dirty keys, the candidates and their slots are in LDS
-    K9_STAMP(2);
+    if (brk) atomicOr(&X.brk[tid >> 5], 1u << (tid & 31));
+  }
+  __syncthreads();
+  if (tid < W) {
+    uint32_t w = tid >> 5, mword = X.brk[w] & (0xFFFFFFFFu >> (31u - (tid & 31u)));   // break bits at or below my row
+    while (mword == 0u) { w--; mword = X.brk[w]; }                                      // row 0 always breaks
+    const uint32_t p = 32u * w + (31u - (uint32_t)__clz((int)mword));                   // first row of my stretch
+    if ((tid - p) % K9_SEL_MAXRUN == 0u) atomicOr(&X.stm[tid >> 5], 1u << (tid & 31));
+  }
+  __syncthreads();
+  if (tid < W && ((X.stm[tid >> 5] >> (tid & 31)) & 1u)) {
+    uint32_t kidx = (uint32_t)__popc(X.stm[tid >> 5] & ((1u << (tid & 31)) - 1u));
+    for (uint32_t w = 0; w < (tid >> 5); w++) kidx += (uint32_t)__popc(X.stm[w]);
+    X.runs[kidx] = (uint16_t)tid;
+  }
+  __syncthreads();
+  uint32_t K = 0;
+  for (uint32_t w = 0; w < 8; w++) K += (uint32_t)__popc(X.stm[w]);
 
-    // ---- P3 (wave 0): the rows of the run; then the next run's header
-    if (wave == 0) {
-      const uint32_t ncand = H.ncand;
+  const unsigned long long lt = (1ull << lane) - 1ull;
+  gptrd gi, gr;
+  { const KbDev &d = *a.dev; gi = (gptrd)d.idle; gr = (gptrd)d.rel; }
+  // a run's header, from the tables the prologue built (nothing in them changes inside the loop)
+#define K9S_RUN_HEADER(kk)                                                                                             \
+  const uint32_t i0 = X.runs[(kk)];                                                                                    \
+  const uint4 ri_ = rinfo[i0];                                                                                         \
+  const uint32_t r = (uint32_t)__builtin_amdgcn_readfirstlane((int)ri_.x), s = (uint32_t)__builtin_amdgcn_readfirstlane((int)ri_.y); \
+  const uint32_t fl0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)ri_.z), km0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)ri_.w); \
+  const bool plain0 = (fl0 & 1u) && (km0 == 0u || (fl0 & 4u));                                                         \
+  const K9Shape sh = shapes[s];                                                                                        \
+  const double *si = sinit + (size_t)s * RS;                                                                           \
+  const double *rres = rowres + ((kk) % K9S_PREPS) * (uint32_t)a.R;   /* the row's own Resreq (rows that are not plain) */ \
+  const double *rqv = plain0 ? si : rres + 2;                         /* the rows' scalar Resreq */                    \
+  const bool sel_run = !a.backfill && plain0 && r >= 2u;              /* the run goes through the selection */          \
+  (void)rqv; (void)sel_run; (void)rres; (void)i0;
+
+  if (wave == 0) {
+    // =================================================== wave 0: the selection ===================================================
+    uint32_t nd = 0, n_dirty_rows = 0, n_runs = 0, n_slow = 0, i_end = 0, reason_end = KB_REASON_DONE;
+    for (uint32_t k = 0; k < K; k++) {
+      K9S_RUN_HEADER(k)
+      bool ok = k9s_wait(Y, &Y.seq_cand, k + 1u);
+      for (uint32_t w = 0; w < 4 && ok; w++) ok = k9s_wait(Y, &Y.seq_dk[w], k + 1u);
+      if (!ok) { reason_end = KB_REASON_INTERNAL; i_end = i0; break; }
+      const uint32_t ncand = Y.ncand_pub;
       uint32_t ck = 0, k1 = 0, ckind = 0, ckind1 = 0;
-      rnm = 0;
+      uint32_t rnm = 0;
       if (lane < ncand) { ck = ckey[lane]; k1 = X.ck1[lane]; ckind = X.ckind[lane]; ckind1 = X.ckind1[lane]; rnm = X.crnm[lane]; }
       double res0 = sh.init0, res1 = sh.init1;
       if (!plain0) { res0 = rres[0]; res1 = rres[1]; }
@@ -261,7 +166,6 @@ __global__ void __launch_bounds__(K9_THREADS) k_commit_select(const K9KernArgs k
           pc = n_take; j = n_take;
           sel_done = true;
           if (lane == 0) X.stat[0]++;
-          K9_STAMP(8);
         } else {
           // ---- the general case.  Contenders: the clean candidates (lane = candidate) and the dirty slots whose key is above the floor;
           //      entries: steps 0 and 1 of each, as far as they exist and are above the floor
@@ -316,14 +220,13 @@ __global__ void __launch_bounds__(K9_THREADS) k_commit_select(const K9KernArgs k
           }
           unsigned long long comp = 0ull;
           uint32_t info = 0u, rank = 0u;
-          bool first = true;
           while (!bail) {
             // rank by count: entry e is picked as row #(entries in front of it)
             comp = lane < n ? X.e_comp[lane] : 0ull;
             info = lane < n ? X.e_info[lane] : 0u;
             rank = 0u;
             for (uint32_t i = 0; i < n; i++) { const unsigned long long si_ = rl64(comp, i); rank += (si_ > comp) ? 1u : 0u; }
-            if (first) { K9_STAMP(5); first = false; }
+            
             // a contender whose last known step would be picked in front of the last row may be picked again: walk it on
             const uint32_t c = info & 0xFFu, ej = info >> 16;
             const bool alive = lane < n && ej + 1u == X.c_next[c] && !(X.c_flag[c] & 1u) && rank + 1u < r;
@@ -395,7 +298,6 @@ __global__ void __launch_bounds__(K9_THREADS) k_commit_select(const K9KernArgs k
             if (lane == 0) X.stat[3]++;
             K9_WAVE_FENCE();
           }
-          K9_STAMP(6);
           if (!bail) {
             // ---- the picks: rows in rank order; a Pipeline ends the round behind its row; fewer entries than rows: no feasible node is left
             const bool have = lane < n;
@@ -451,7 +353,6 @@ __global__ void __launch_bounds__(K9_THREADS) k_commit_select(const K9KernArgs k
           } else if (lane == 0) {
             X.stat[2]++;
           }
-          K9_STAMP(7);
         }
       }
       if (!sel_done)
@@ -540,7 +441,6 @@ __global__ void __launch_bounds__(K9_THREADS) k_commit_select(const K9KernArgs k
         if (kind) { j++; reason = KB_REASON_PIPELINED; break; }   // a Pipeline ends the speculated order: the host re-plans
       }
       if (sc_dirty) __threadfence();   // the scalar atomics have reached L2 before any other wave evaluates against these nodes
-      // the next run's header (its candidates were walked while this one was evaluated)
       const uint32_t i_next = i0 + j;
       uint32_t stop = (reason != KB_REASON_DONE || i_next >= W) ? 1u : 0u;
       if (!stop && a.has_aff && !a.backfill && i_next != 0u) {
@@ -549,30 +449,155 @@ __global__ void __launch_bounds__(K9_THREADS) k_commit_select(const K9KernArgs k
         const uint32_t fln = (uint32_t)__builtin_amdgcn_readfirstlane((int)rinfo[i_next].z);
         if (fln & 2u) { reason = KB_REASON_RENORM; stop = 1u; }
       }
+      if (lane == 0 && pc) cursor[s] = cpos[pc - 1] + 1;
+      nd += pc; n_dirty_rows += n_dirty; n_runs += 1u; n_slow += plain0 ? 0u : 1u;
+      i_end = i_next; reason_end = reason;
+      // publish: everything this run wrote (slots, bitmap, cursor, decision records) is in LDS before the word moves
       if (lane == 0) {
-        if (pc) cursor[s] = cpos[pc - 1] + 1;
-        H.n_dirty_rows += n_dirty; H.n_runs += 1; H.n_slow += plain0 ? 0u : 1u;
-        H.i = i_next; H.nd = nd + pc; H.reason = reason; H.stop = stop;
+        Y.nd_pub = nd;
+        if (stop) k9s_st(&Y.stop, 1u);
+        k9s_st(&Y.seq_done, k + 1u);
       }
-#ifdef KB_K9_TRACE
-      if (r == 1u && lane == 0) X.tr[3] += (uint32_t)(__builtin_readcyclecounter() - tlast);
-#endif
-      K9_STAMP(3);
+      if (stop) break;
+    }
+    if (lane == 0) {
+      if (k9s_ld(&Y.err)) reason_end = KB_REASON_INTERNAL;
+      k9s_st(&Y.stop, 1u);
+      H.i = i_end; H.nd = nd; H.reason = reason_end; H.n_dirty_rows = n_dirty_rows; H.n_runs = n_runs; H.n_slow = n_slow;
+    }
+  } else if (wave <= 4u) {
+    // =================================================== waves 1..4: the dirty slots ===================================================
+    const uint32_t t = tid - 64u;
+    for (uint32_t k = 0; k < K; k++) {
+      K9S_RUN_HEADER(k)
+      if (!k9s_wait(Y, &Y.seq_done, k) || k9s_ld(&Y.stop)) break;   // run k - 1 is committed: the slots are final
+      const uint32_t nd = Y.nd_pub;
+      if (t < nd) {   // the shape against "their" dirty slot
+        const K9St vs = k9_load(slots + (size_t)t * K9_NF);
+        const K9Sc scp = k9_sc_preload(sh.active >> 2, gi, gr, a.NP, vs.node);
+        dk[t] = k9_eval_v(a, sh, vs, scp, gi, gr, si, 0u, 0.0, si, nb, nmaskbits);
+        // what the slot's next placement of the shape would be (allocate.go:160) — the selection reads it for the slots it considers
+        if (sel_run) X.dkk[t] = k9_fits_idle(a, sh, vs.idle0, vs.idle1, scp, gi, si, vs.node, 0u, 0.0, si) ? 0u : 1u;
+      }
+      if (lane == 0) k9s_st(&Y.seq_dk[wave - 1u], k + 1u);
+    }
+  } else if (wave < K9S_PREP0 + K9S_PREPS) {
+    // =================================================== waves 5..7: the candidates ===================================================
+    typedef const unsigned long long __attribute__((address_space(1))) *gptr8;
+    typedef const uint32_t __attribute__((address_space(1))) *gptr4;
+    gptr8 g8[10];
+    gptr8 gports;
+    gptr4 gcls, gmaxp, gpodc, gnm;
+    {
+      const KbDev &d = *a.dev;
+      g8[0] = (gptr8)reinterpret_cast<const unsigned long long *>(d.idle); g8[1] = (gptr8)reinterpret_cast<const unsigned long long *>(d.idle + d.NP);
+      g8[2] = (gptr8)reinterpret_cast<const unsigned long long *>(d.rel); g8[3] = (gptr8)reinterpret_cast<const unsigned long long *>(d.rel + d.NP);
+      g8[4] = (gptr8)reinterpret_cast<const unsigned long long *>(d.inv_acpu); g8[5] = (gptr8)reinterpret_cast<const unsigned long long *>(d.inv_amem);
+      g8[6] = (gptr8)reinterpret_cast<const unsigned long long *>(d.acpu); g8[7] = (gptr8)reinterpret_cast<const unsigned long long *>(d.amem);
+      g8[8] = (gptr8)reinterpret_cast<const unsigned long long *>(d.nzc); g8[9] = (gptr8)reinterpret_cast<const unsigned long long *>(d.nzm);
+      gports = (gptr8)d.ports;
+      gcls = (gptr4)d.ncls; gmaxp = (gptr4)reinterpret_cast<const uint32_t *>(d.maxpods); gpodc = (gptr4)reinterpret_cast<const uint32_t *>(d.podcnt); gnm = (gptr4)d.nmask;
+    }
+    K9Prep &P = X.prep[wave - K9S_PREP0];
+    for (uint32_t m = wave - K9S_PREP0; m < K; m += K9S_PREPS) {
+      K9S_RUN_HEADER(m)
+      // ---- walk + fetch, two runs ahead: the runs in front that are not committed yet (m - 2 when the walk may start, and m - 1) can still
+      //      take up to their own length of this shape's clean entries, so that many more are fetched: lane j = entry j (64 lanes).  With at
+      //      most (rows committed so far) dirty nodes and a list of W + 1 entries the walk finds them unless the list ends (its 0 terminator):
+      //      nf < want means every clean feasible node of the shape is among the nf.
+      const uint32_t r1 = m >= 1u ? (uint32_t)X.runs[m] - (uint32_t)X.runs[m - 1u] : 0u, r2 = m >= 2u ? (uint32_t)X.runs[m - 1u] - (uint32_t)X.runs[m - 2u] : 0u;
+      uint32_t want = r + r1 + r2, need = m >= 2u ? m - 2u : 0u;
+      if (want > 64u) { want = r + r1; need = m >= 1u ? m - 1u : 0u; }   // r <= K9_SEL_MAXRUN = 32
+      if (!k9s_wait(Y, &Y.seq_done, need) || k9s_ld(&Y.stop)) break;
+      uint32_t nf = 0;
+      {
+        uint32_t e_ = cursor[s];
+        while (nf < want) {
+          const uint32_t pos_ = e_ + lane;
+          const uint32_t kk_ = (pos_ < Lp) ? lists[s * Lp + pos_] : 0u;
+          const bool nz_ = kk_ != 0u;
+          const uint32_t nn_ = nmaskbits - (kk_ & nmaskbits);
+          const bool cl_ = nz_ && !((bitmap[(nz_ ? nn_ : 0u) >> 5] >> (nn_ & 31)) & 1u);
+          const unsigned long long zeros_ = __ballot(!nz_);
+          const uint32_t fz_ = zeros_ ? (uint32_t)__ffsll((unsigned long long)zeros_) - 1u : 64u;
+          const unsigned long long clean_ = __ballot(cl_ && lane < fz_);   // entries behind the list's end do not count
+          const uint32_t rank_ = (uint32_t)__popcll(clean_ & lt);
+          if (((clean_ >> lane) & 1ull) && nf + rank_ < want) { P.ckey[nf + rank_] = kk_; P.cpos[nf + rank_] = pos_; }
+          nf = min(want, nf + (uint32_t)__popcll(clean_));
+          if (fz_ < 64u || e_ + 64u >= Lp) break;   // the list ended
+          e_ += 64u;
+        }
+        K9_WAVE_FENCE();
+      }
+      const uint32_t key = (lane < nf) ? P.ckey[lane] : 0u, mypos = (lane < nf) ? P.cpos[lane] : 0u;
+      const uint32_t n = nmaskbits - (key & nmaskbits);
+      unsigned long long raw[11] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+      uint32_t rcls = 0, rmaxp = 0, rpodc = 0, rnm = 0;
+      if (lane < nf) {   // every field of entry `lane`, all loads in flight together
+#pragma unroll
+        for (int f = 0; f < 10; f++) raw[f] = g8[f][n];
+        raw[F_PORTS] = gports ? gports[n] : 0ull;
+        rcls = gcls[n]; rmaxp = gmaxp[n]; rpodc = gpodc[n]; rnm = gnm[n];
+      }
+      if (!plain0 && lane == 63) {   // an init container raised InitResreq above Resreq (rare): the row's own Resreq
+        const KbDev &d_ = *a.dev;
+        const uint32_t tk_ = desc[i0].task;
+        for (int dd = 0; dd < a.R; dd++) rowres[(m % K9S_PREPS) * (uint32_t)a.R + (uint32_t)dd] = d_.t_res[(size_t)dd * d_.T + tk_];
+      }
+      K9_WAVE_FENCE();
+      // ---- P2, for every fetched entry (which of them are the run's candidates is decided below): Allocate / Pipeline, NodeInfo.AddTask on
+      //      the fetched state, key of the node after the placement
+      K9St v;
+      uint32_t kind = 0u, k1 = 0u, kind1 = 0u;
+      {
+        double res0 = sh.init0, res1 = sh.init1;
+        if (!plain0) { res0 = rres[0]; res1 = rres[1]; }
+        double idle0 = u2d(raw[F_IDLE0]), idle1 = u2d(raw[F_IDLE1]), rel0 = u2d(raw[F_REL0]), rel1 = u2d(raw[F_REL1]);
+        const K9Sc scn = k9_sc_preload(sh.active >> 2, gi, gr, a.NP, lane < nf ? n : 0u);   // the candidate's scalar dimensions: for the test below and the key
+        if (!a.backfill) {   // allocate.go:160: InitResreq.LessEqual(node.Idle) -> Allocate, else Pipeline
+          bool fi = le_eps(sh.init0, idle0, EPS_CPU) && le_eps(sh.init1, idle1, EPS_MEM);
+          for (uint32_t aa = sh.active >> 2, dd = 0; aa; aa >>= 1, dd++)
+            if (aa & 1u) fi = fi && le_eps(si[dd], k9_sci(scn, gi, a.NP, dd, lane < nf ? n : 0u), EPS_SCALAR);
+          kind = fi ? 0u : 1u;
+        }
+        // NodeInfo.AddTask (api/node_info.go:172-212): Idle (Allocated) or Releasing (Pipelined) -= Resreq, pod joins ni.Tasks
+        if (kind) { rel0 -= res0; rel1 -= res1; } else { idle0 -= res0; idle1 -= res1; }
+        v.idle0 = idle0; v.idle1 = idle1; v.rel0 = rel0; v.rel1 = rel1;
+        v.inv_ac = u2d(raw[F_INVAC]); v.inv_am = u2d(raw[F_INVAM]);
+        v.ac = (double)(long long)raw[F_AC]; v.am = (double)(long long)raw[F_AM];
+        v.nzc = (double)(long long)raw[F_NZC] + sh.nzc; v.nzm = (double)(long long)raw[F_NZM] + sh.nzm;
+        v.ports = raw[F_PORTS] | sh.want;   // the pod's host ports join nodeinfo.UsedPorts()
+        v.cls = rcls; v.node = lane < nf ? n : 0u; v.left = (int)rmaxp - (int)rpodc - 1;
+        // the scalar part of the Sub reaches HBM when (and if) the candidate is consumed; the key is evaluated as if it had.
+        // Sub returns early when the receiver's scalar map is nil (resource_info.go:148-153); a Pipeline ends the round, its
+        // Releasing-side key is never read.
+        const uint32_t adjm = (!kind && (rnm & 0x7FFFFFFFu)) ? km0 : 0u;
+        if (lane < nf) {
+          k1 = k9_eval_v(a, sh, v, scn, gi, gr, si, adjm, 1.0, rqv, nb, nmaskbits);   // the node's key once it is dirty
+          if (sel_run && !kind) kind1 = k9_fits_idle(a, sh, v.idle0, v.idle1, scn, gi, si, n, adjm, 1.0, rqv) ? 0u : 1u;   // a second placement on it
+        }
+      }
+      // ---- when run m - 1 is committed: the first r entries whose node the runs in front left alone are the run's candidates
+      if (!k9s_wait(Y, &Y.seq_done, m) || k9s_ld(&Y.stop)) break;
+      const uint32_t nd = Y.nd_pub;
+      const bool keep = lane < nf && !((bitmap[n >> 5] >> (n & 31)) & 1u);
+      const unsigned long long kb = __ballot(keep);
+      const uint32_t rho = (uint32_t)__popcll(kb & lt);
+      const uint32_t ncand = min((uint32_t)__popcll(kb), r);
+      if (keep && rho < r) {
+        unsigned long long *st = slots + (size_t)(nd + rho) * K9_NF;
+        st[F_IDLE0] = d2u(v.idle0); st[F_IDLE1] = d2u(v.idle1); st[F_REL0] = d2u(v.rel0); st[F_REL1] = d2u(v.rel1);
+        st[F_INVAC] = raw[F_INVAC]; st[F_INVAM] = raw[F_INVAM]; st[F_AC] = d2u(v.ac); st[F_AM] = d2u(v.am);
+        st[F_NZC] = d2u(v.nzc); st[F_NZM] = d2u(v.nzm); st[F_PORTS] = v.ports;
+        st[F_CLS_LEFT] = (unsigned long long)rcls | ((unsigned long long)(uint32_t)v.left << 32);
+        st[F_NODE_NMASK] = (unsigned long long)n | ((unsigned long long)rnm << 32);
+        ckey[rho] = key; cpos[rho] = mypos;
+        X.ckind[rho] = kind; X.ck1[rho] = k1; X.ckind1[rho] = kind1; X.crnm[rho] = rnm;
+      }
+      if (lane == 0) { Y.ncand_pub = ncand; k9s_st(&Y.seq_cand, m + 1u); }
     }
   }
-#ifdef KB_K9_TRACE
-  if (tid == 0) {
-    unsigned long long *tw = reinterpret_cast<unsigned long long *>(a.result);
-    tw[5] = (unsigned long long)tacc[0] | ((unsigned long long)tacc[1] << 32);
-    tw[6] = (unsigned long long)tacc[2] | ((unsigned long long)tacc[3] << 32);
-    tw[7] = (unsigned long long)tacc[4] | ((unsigned long long)tacc[5] << 32);
-    tw[13] = (unsigned long long)tacc[6] | ((unsigned long long)tacc[7] << 32);
-    tw[14] = (unsigned long long)tacc[8] | ((unsigned long long)tacc[9] << 32);
-    tw[4] = (unsigned long long)X.tr[0] | ((unsigned long long)X.tr[1] << 32);
-    tw[15] = (unsigned long long)X.tr[2] | ((unsigned long long)X.tr[3] << 32);
-  }
-#endif
-  __syncthreads();   // the statistics words (wave 0) before the epilogue reads them
+  __syncthreads();   // wave 0 has left the loop: the header and the statistics words are final
   k9_epilogue(a, lo, k9_smem, tid, t_start, X.stat[0] | (X.stat[1] << 16), X.stat[2] | (X.stat[3] << 16));
 }
 

@@ -31,22 +31,30 @@ struct K9Hdr {
 };
 
 // ---- the selection kernel's extra LDS (kb_commit_sel.hip) ----
-// A run prepared one iteration ahead by a "prep" wave: its parameters and the clean entries of its shape's list as of the walk — r + r_prev of
-// them, because the run in front of it (r_prev rows) may still take some (filtered against the dirty bitmap when the run's turn comes).
+// A prep wave's scratch: the clean entries of the shape's list as of its walk (more than the run's rows: the runs in front of it may still
+// take some; filtered against the dirty bitmap when the run's turn comes).
 struct K9Prep {
-  uint32_t i, s, r, fl, km, nf, pad0, pad1;      // first row, shape, rows, flags, Resreq key mask; entries fetched
-  K9Shape sh;                                    // shapes[s]: the run's header comes out of ONE block (a single LDS round trip behind the barrier)
   uint32_t ckey[64], cpos[64];                   // the fetched entries: key and list position, best first
 };
+// The sequence words the waves hand runs over with (they only grow; acquire / release at workgroup scope)
+struct K9Sync {
+  uint32_t seq_done;                  // runs committed (wave 0)
+  uint32_t seq_cand;                  // runs whose candidates are in LDS (the run's prep wave)
+  uint32_t seq_dk[4];                 // runs whose dirty keys are in LDS, per evaluating wave
+  uint32_t nd_pub, ncand_pub;         // dirty slots after the last committed run; candidates of the run seq_cand announces
+  uint32_t stop, err;                 // the round is over (wave 0); a wait ran out of patience
+};
 struct K9Sel {
-  K9Prep prep[2];                     // by parity of the run's number
+  K9Sync sync;
+  K9Prep prep[3];                     // one per prep wave
+  uint16_t runs[KB_K5_MAX_ROWS];      // first row of run k
+  uint32_t brk[8], stm[8];            // row masks: the row cannot join its predecessor / the row starts a run
   uint32_t ckind[64], ck1[64], ckind1[64], crnm[64];   // per surviving candidate (P2's results, written by the prep wave, read by wave 0)
   uint32_t dkk[K9_MAXSLOTS];          // dirty slot t: its next placement of the run's shape would be a Pipeline (allocate.go:160)
   unsigned long long e_comp[64];      // entries: prefix-minimum key << 8 | 255 - step  (greater = picked earlier)
   uint32_t e_info[64];                // contender | kind << 8 | step << 16
   uint32_t c_slot[64], c_next[64], c_eff[64], c_flag[64], c_take[64];   // contenders: state slot, next unknown step, prefix minimum so far, bit 0 ended / bit 1 clean / bit 2 its last taken entry is a Pipeline
   uint32_t al[64];                    // a deep pass: the contenders it walks
-  uint32_t tr[4];                     // KB_K9_TRACE: cycles of the candidates' wave, of the walking wave, of wave 1 in the evaluation phase; of wave 0's rows step for single rows
   uint32_t stat[4];                   // runs committed with every pick a clean first placement / by the general selection / handed to the serial loop; deep passes
 };
 
@@ -61,7 +69,7 @@ __host__ __device__ inline K9Layout k9_layout(uint32_t n_rows, uint32_t n_shapes
   o.Lp = L;
   uint32_t off = 0;
   o.slots = off;  off += (n_rows + K9_MAXRUN) * K9_NF * 8u;   // + a run's worth: P2 writes every candidate's post-placement state
-  o.rowres = off; off += 2u * (uint32_t)R * 8u;               // two halves: the selection kernel prepares a run while its predecessor is committed
+  o.rowres = off; off += 3u * (uint32_t)R * 8u;               // three thirds: the selection kernel prepares runs ahead of the one being committed
   o.sinit = off;  off += n_shapes * o.RS * 8u;
   o.shapes = off; off += n_shapes * (uint32_t)sizeof(K9Shape);
   o.desc = off;   off += n_rows * (uint32_t)sizeof(KbRowDesc);

@@ -13,14 +13,14 @@ ms() { python -c "import json,sys; d=json.loads(open('$1').read().strip().splitl
 bench_ab() {   # name, env assignments..., -- bench args
   local name="$1"; shift
   local envs=(); while [ "$1" != "--" ]; do envs+=("$1"); shift; done; shift
-  env "${envs[@]}" KB_K5_STATS=1 python bench.py --no-cpu-baseline "$@" > "$out/bench_${name}.json" 2> "$out/bench_${name}.err"
+  timeout 300 env "${envs[@]}" KB_K5_STATS=1 python bench.py --no-cpu-baseline "$@" > "$out/bench_${name}.json" 2> "$out/bench_${name}.err"
   echo "bench $name rc=$? $(ms "$out/bench_${name}.json")" | tee -a "$out/summary.txt"
   grep -h "kb select\|kb K5\] rounds on" "$out/bench_${name}.err" | tee -a "$out/summary.txt"
 }
 case "$step" in
 sel)
   timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_fuzz.py tests/test_gpu_adversarial.py tests/test_gpu_regressions.py tests/test_gpu_preempt.py tests/test_gpu_interpod.py \
-    -q -m gpu -p no:cacheprovider -k "select" > "$out/pytest_select.txt" 2>&1; echo "differential suites on the selection kernel rc=$? $(tail -1 "$out/pytest_select.txt")" | tee -a "$out/summary.txt"
+    -q -m gpu -p no:cacheprovider -k "select" --maxfail=10 > "$out/pytest_select.txt" 2>&1; echo "differential suites on the selection kernel rc=$? $(tail -1 "$out/pytest_select.txt")" | tee -a "$out/summary.txt"
   for cfg in "3" "4" "3 --survey-nodes"; do
     tag="c${cfg// --survey-nodes/survey}"; tag="${tag// /}"
     bench_ab "${tag}_r3" KB_DIRTY_KERNEL=run -- --config ${cfg} --steps 5 --warmup 2 --verify
