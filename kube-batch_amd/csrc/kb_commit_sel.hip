@@ -64,7 +64,7 @@ __global__ void __launch_bounds__(K9_THREADS) k_commit_select(const K9KernArgs k
   const K9Layout lo = k9_layout(W, S, a.L, a.NP, a.R, true);
   unsigned char *k9_base_ = k9_smem;
   K9_LDS_VIEWS(lo)
-  (void)shp; (void)S;
+  (void)shp; (void)S; (void)dk;
   K9Sel &X = *reinterpret_cast<K9Sel *>(k9_smem + lo.sel);
   K9Sync &Y = X.sync;
   const unsigned long long t_start = wall_clock64();
@@ -74,8 +74,8 @@ __global__ void __launch_bounds__(K9_THREADS) k_commit_select(const K9KernArgs k
   //      row starts a run iff it cannot join its predecessor (k9_prologue's rule) or its stretch of joinable rows has reached a multiple of
   //      the longest run.  W <= KB_K5_MAX_ROWS = 256: eight mask words.
   if (tid < 8) { X.brk[tid] = 0u; X.stm[tid] = 0u; }
-  if (tid < 4) X.stat[tid] = 0u;
-  if (tid == 0) { Y.seq_done = 0u; Y.seq_cand = 0u; Y.nd_pub = 0u; Y.ncand_pub = 0u; Y.stop = 0u; Y.err = 0u; Y.seq_dk[0] = 0u; Y.seq_dk[1] = 0u; Y.seq_dk[2] = 0u; Y.seq_dk[3] = 0u; }
+  if (tid < 4) { X.stat[tid] = 0u; X.tr[tid] = 0u; }
+  if (tid < sizeof(K9Sync) / 4) reinterpret_cast<uint32_t *>(&Y)[tid] = 0u;   // every sequence word starts at 0; nd_at[0] = 0: run 0 finds no dirty slot
   __syncthreads();
   if (tid < W) {
     bool brk = tid == 0;
@@ -103,6 +103,18 @@ __global__ void __launch_bounds__(K9_THREADS) k_commit_select(const K9KernArgs k
   uint32_t K = 0;
   for (uint32_t w = 0; w < 8; w++) K += (uint32_t)__popc(X.stm[w]);
 
+#ifdef KB_K9_TRACE
+  // make EXTRA=-DKB_K9_TRACE: wave 0's cycles — 0: waiting for a run's candidates and dirty keys, 3: rows (serial loop, tail, publish), 5: entries + first
+  // rank, 6: deep passes, 7: picks + AddTask, 8: the all-clean path; X.tr: the prep waves' wait for their run's turn / for the walk's turn,
+  // wave 1's wait for the previous run / its evaluation
+  uint32_t tacc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long tlast = __builtin_readcyclecounter();
+#define K9S_TR(k, t0) do { if (lane == 0) atomicAdd(&X.tr[k], (uint32_t)(__builtin_readcyclecounter() - (t0))); } while (0)
+#define K9S_NOW() __builtin_readcyclecounter()
+#else
+#define K9S_TR(k, t0) do { (void)(t0); } while (0)
+#define K9S_NOW() 0ull
+#endif
   const unsigned long long lt = (1ull << lane) - 1ull;
   gptrd gi, gr;
   { const KbDev &d = *a.dev; gi = (gptrd)d.idle; gr = (gptrd)d.rel; }
@@ -125,22 +137,38 @@ __global__ void __launch_bounds__(K9_THREADS) k_commit_select(const K9KernArgs k
     uint32_t nd = 0, n_dirty_rows = 0, n_runs = 0, n_slow = 0, i_end = 0, reason_end = KB_REASON_DONE;
     for (uint32_t k = 0; k < K; k++) {
       K9S_RUN_HEADER(k)
-      bool ok = k9s_wait(Y, &Y.seq_cand, k + 1u);
-      for (uint32_t w = 0; w < 4 && ok; w++) ok = k9s_wait(Y, &Y.seq_dk[w], k + 1u);
-      if (!ok) { reason_end = KB_REASON_INTERNAL; i_end = i0; break; }
-      const uint32_t ncand = Y.ncand_pub;
+      K9_STAMP(3);
+      {   // the run's candidates (seq_cand) and its dirty keys (seq_dk[0..3]): five neighbouring words, one load per poll
+        uint32_t spins = 0;
+        bool ok = true;
+        for (;;) {
+          const uint32_t v = (lane < 5u) ? k9s_ld(&Y.seq_cand + lane) : 0xFFFFFFFFu;
+          if (__ballot(v < k + 1u) == 0ull) break;
+          if ((++spins & 31u) == 0u && (k9s_ld(&Y.err) || spins > K9S_SPIN_LIMIT)) { k9s_st(&Y.err, 1u); ok = false; break; }
+          __builtin_amdgcn_s_sleep(1);
+        }
+        if (!ok) { reason_end = KB_REASON_INTERNAL; i_end = i0; break; }
+      }
+      const uint32_t ncand = Y.ncand_at[k & 3u];
+      const uint32_t *dk = X.dkb[k & 1u];
+      uint32_t *chg = Y.chg[k & 1u];
+      if (lane < 10u) chg[lane] = 0u;
+      K9_STAMP(0);
       uint32_t ck = 0, k1 = 0, ckind = 0, ckind1 = 0;
       uint32_t rnm = 0;
       if (lane < ncand) { ck = ckey[lane]; k1 = X.ck1[lane]; ckind = X.ckind[lane]; ckind1 = X.ckind1[lane]; rnm = X.crnm[lane]; }
+      uint32_t m = (lane < 4u) ? Y.mdk[k & 1u][lane] : 0u;   // best dirty key: the evaluating waves' maxima; clean winners update it in O(1)
+      m = max(max(rl32(m, 0), rl32(m, 1)), max(rl32(m, 2), rl32(m, 3)));
       double res0 = sh.init0, res1 = sh.init1;
       if (!plain0) { res0 = rres[0]; res1 = rres[1]; }
       // cmin: the r-th best clean candidate's key — r entries are at or above it, so no entry below it is among the picks (0: the list
       // holds fewer than r clean nodes)
       const uint32_t cmin = (sel_run && ncand == r) ? ckey[r - 1u] : 0u;
-      // dirty keys of the shape: old slot t in lane t & 63, register t >> 6; the run's own new slots: k1 of lanes < pc
-      uint32_t d0 = (lane < nd) ? dk[lane] : 0u, d1 = (lane + 64 < nd) ? dk[lane + 64] : 0u;
-      uint32_t d2 = (lane + 128 < nd) ? dk[lane + 128] : 0u, d3 = (lane + 192 < nd) ? dk[lane + 192] : 0u;
-      uint32_t m = wave_max_u32(max(max(d0, d1), max(d2, d3)));   // best dirty key; clean winners update it in O(1)
+      // dirty keys of the shape: old slot t in lane t & 63, register t >> 6 — fetched only where a dirty slot can be picked
+      uint32_t d0 = 0u, d1 = 0u, d2 = 0u, d3 = 0u;
+      bool have_d = false;
+#define K9S_LOAD_D() do { if (!have_d) { d0 = (lane < nd) ? dk[lane] : 0u; d1 = (lane + 64 < nd) ? dk[lane + 64] : 0u; d2 = (lane + 128 < nd) ? dk[lane + 128] : 0u; \
+                                        d3 = (lane + 192 < nd) ? dk[lane + 192] : 0u; have_d = true; } } while (0)
       uint32_t pc = 0, j = 0, reason = KB_REASON_DONE, n_dirty = 0, sc_dirty = 0;
       bool sel_done = false;
       if (sel_run) {
@@ -156,6 +184,7 @@ __global__ void __launch_bounds__(K9_THREADS) k_commit_select(const K9KernArgs k
             ldec[i0 + lane] = (unsigned long long)n | ((unsigned long long)ckind << 32);
             atomicOr(&bitmap[n >> 5], 1u << (n & 31));
             if (km0) {   // the scalar dimensions Resreq names: Idle / Releasing in HBM
+              atomicOr(&chg[(nd + lane) >> 5], 1u << ((nd + lane) & 31));   // an early evaluation for the next run read them before this Sub
               const bool has_map = ckind ? (rnm >> 31) : (rnm & 0x7FFFFFFFu);
               if (has_map)
                 for (uint32_t mm = km0, dd = 0; mm; mm >>= 1, dd++)
@@ -166,9 +195,11 @@ __global__ void __launch_bounds__(K9_THREADS) k_commit_select(const K9KernArgs k
           pc = n_take; j = n_take;
           sel_done = true;
           if (lane == 0) X.stat[0]++;
+          K9_STAMP(8);
         } else {
           // ---- the general case.  Contenders: the clean candidates (lane = candidate) and the dirty slots whose key is above the floor;
           //      entries: steps 0 and 1 of each, as far as they exist and are above the floor
+          K9S_LOAD_D();
           const bool a0v = lane < ncand;
           const uint32_t ce1 = min(ck, k1);
           const bool a1v = a0v && ckind == 0u && k1 != 0u && ce1 > cmin;
@@ -179,7 +210,7 @@ __global__ void __launch_bounds__(K9_THREADS) k_commit_select(const K9KernArgs k
 #pragma unroll
           for (int u = 0; u < 4; u++) {
             const uint32_t t = lane + 64u * (uint32_t)u;
-            dkk4[u] = (t < nd) ? X.dkk[t] : 0u;
+            dkk4[u] = (t < nd) ? X.dkk[k & 1u][t] : 0u;
             b0v[u] = dd4[u] > cmin;
             bb0[u] = __ballot(b0v[u]);
             nD += (uint32_t)__popcll(bb0[u]);
@@ -220,12 +251,14 @@ __global__ void __launch_bounds__(K9_THREADS) k_commit_select(const K9KernArgs k
           }
           unsigned long long comp = 0ull;
           uint32_t info = 0u, rank = 0u;
+          bool first = true;
           while (!bail) {
             // rank by count: entry e is picked as row #(entries in front of it)
             comp = lane < n ? X.e_comp[lane] : 0ull;
             info = lane < n ? X.e_info[lane] : 0u;
             rank = 0u;
             for (uint32_t i = 0; i < n; i++) { const unsigned long long si_ = rl64(comp, i); rank += (si_ > comp) ? 1u : 0u; }
+            if (first) { K9_STAMP(5); first = false; }
             
             // a contender whose last known step would be picked in front of the last row may be picked again: walk it on
             const uint32_t c = info & 0xFFu, ej = info >> 16;
@@ -298,6 +331,7 @@ __global__ void __launch_bounds__(K9_THREADS) k_commit_select(const K9KernArgs k
             if (lane == 0) X.stat[3]++;
             K9_WAVE_FENCE();
           }
+          K9_STAMP(6);
           if (!bail) {
             // ---- the picks: rows in rank order; a Pipeline ends the round behind its row; fewer entries than rows: no feasible node is left
             const bool have = lane < n;
@@ -322,6 +356,7 @@ __global__ void __launch_bounds__(K9_THREADS) k_commit_select(const K9KernArgs k
               unsigned long long *st = slots + (size_t)X.c_slot[lane] * K9_NF;
               const uint32_t node = (uint32_t)st[F_NODE_NMASK], nm = (uint32_t)(st[F_NODE_NMASK] >> 32);
               const uint32_t extra = T - b;   // a clean candidate's slot already holds its first placement
+              if (extra || km0) { const uint32_t x = X.c_slot[lane]; atomicOr(&chg[x >> 5], 1u << (x & 31)); }   // not what an early evaluation for the next run saw (its scalar dimensions: in HBM only now)
               if (extra) {
                 double idle0 = u2d(st[F_IDLE0]), idle1 = u2d(st[F_IDLE1]), rel0 = u2d(st[F_REL0]), rel1 = u2d(st[F_REL1]);
                 double zc = u2d(st[F_NZC]), zm = u2d(st[F_NZM]);
@@ -353,6 +388,7 @@ __global__ void __launch_bounds__(K9_THREADS) k_commit_select(const K9KernArgs k
           } else if (lane == 0) {
             X.stat[2]++;
           }
+          K9_STAMP(7);
         }
       }
       if (!sel_done)
@@ -376,6 +412,7 @@ __global__ void __launch_bounds__(K9_THREADS) k_commit_select(const K9KernArgs k
             atomicOr(&bitmap[n >> 5], 1u << (n & 31));
           }
           if (km0) {   // the scalar dimensions Resreq names: Idle / Releasing in HBM (lane 16 + d' takes dimension d' + 2)
+            if (lane == 0) atomicOr(&chg[(nd + pc) >> 5], 1u << ((nd + pc) & 31));   // an early evaluation for the next run read them before this Sub
             const uint32_t nmc = rl32(rnm, pc);
             const bool has_map = kind ? (nmc >> 31) : (nmc & 0x7FFFFFFFu);
             if (has_map && lane >= 16 && lane < 16 + RS && ((km0 >> (lane - 16)) & 1u)) k9_sc_sub(kind ? gr : gi, a.NP, lane - 16, n, rqv[lane - 16]);
@@ -383,12 +420,14 @@ __global__ void __launch_bounds__(K9_THREADS) k_commit_select(const K9KernArgs k
           }
           pc++;
         } else {       // a node this round already changed wins: AddTask on its slot, re-evaluate it
+          K9S_LOAD_D();
           const uint32_t own = (lane < pc) ? k1 : 0u;
           const unsigned long long who = __ballot(d0 == m || d1 == m || d2 == m || d3 == m || own == m);
           const uint32_t L = (uint32_t)__ffsll((unsigned long long)who) - 1u;
           const bool is_new = L < pc && rl32(k1, L) == m;
           const uint32_t wsel = (rl32(d0, L) == m) ? 0u : (rl32(d1, L) == m) ? 1u : (rl32(d2, L) == m) ? 2u : 3u;
           const uint32_t x = is_new ? nd + L : L + 64u * wsel;
+          if (lane == 0) atomicOr(&chg[x >> 5], 1u << (x & 31));   // the slot is not what an early evaluation for the next run saw
           unsigned long long *st = slots + (size_t)x * K9_NF;
           // one row: lane f holds field f of the slot; lanes 16 + d' look at the scalar dimension d' + 2 in HBM when the shape or
           // the row names one
@@ -454,7 +493,7 @@ __global__ void __launch_bounds__(K9_THREADS) k_commit_select(const K9KernArgs k
       i_end = i_next; reason_end = reason;
       // publish: everything this run wrote (slots, bitmap, cursor, decision records) is in LDS before the word moves
       if (lane == 0) {
-        Y.nd_pub = nd;
+        Y.nd_at[(k + 1u) & 3u] = nd;
         if (stop) k9s_st(&Y.stop, 1u);
         k9s_st(&Y.seq_done, k + 1u);
       }
@@ -467,19 +506,41 @@ __global__ void __launch_bounds__(K9_THREADS) k_commit_select(const K9KernArgs k
     }
   } else if (wave <= 4u) {
     // =================================================== waves 1..4: the dirty slots ===================================================
+    // Run q's dirty keys are evaluated EARLY, while run q - 1 is still being selected: against the slots as run q - 2 left them plus run
+    // q - 1's candidates in their prepared state (one placement).  Most runs only consume clean candidates, once each: then the early
+    // keys are the keys.  What run q - 1 changed otherwise (wave 0 lists those slots in chg) is evaluated again when it is committed.
     const uint32_t t = tid - 64u;
-    for (uint32_t k = 0; k < K; k++) {
-      K9S_RUN_HEADER(k)
-      if (!k9s_wait(Y, &Y.seq_done, k) || k9s_ld(&Y.stop)) break;   // run k - 1 is committed: the slots are final
-      const uint32_t nd = Y.nd_pub;
-      if (t < nd) {   // the shape against "their" dirty slot
+    for (uint32_t q = 0; q < K; q++) {
+      K9S_RUN_HEADER(q)
+      uint32_t *dko = X.dkb[q & 1u], *dkko = X.dkk[q & 1u];
+      uint32_t key = 0u, nd_early = 0u;
+      const unsigned long long tw0 = K9S_NOW();
+      if (q >= 1u) {
+        if (!k9s_wait(Y, &Y.seq_done, q - 1u) || !k9s_wait(Y, &Y.seq_cand, q) || k9s_ld(&Y.stop)) break;
+        nd_early = Y.nd_at[(q - 1u) & 3u] + Y.ncand_at[(q - 1u) & 3u];
+        if (t < nd_early) {   // the shape against "their" dirty slot
+          const K9St vs = k9_load(slots + (size_t)t * K9_NF);
+          const K9Sc scp = k9_sc_preload(sh.active >> 2, gi, gr, a.NP, vs.node);
+          key = k9_eval_v(a, sh, vs, scp, gi, gr, si, 0u, 0.0, si, nb, nmaskbits);
+          // what the slot's next placement of the shape would be (allocate.go:160) — the selection reads it for the slots it considers
+          if (sel_run) dkko[t] = k9_fits_idle(a, sh, vs.idle0, vs.idle1, scp, gi, si, vs.node, 0u, 0.0, si) ? 0u : 1u;
+        }
+      }
+      if (wave == 1u) K9S_TR(3, tw0);
+      const unsigned long long tw1 = K9S_NOW();
+      if (!k9s_wait(Y, &Y.seq_done, q) || k9s_ld(&Y.stop)) break;   // run q - 1 is committed: the slots are final
+      if (wave == 1u) K9S_TR(2, tw1);
+      const uint32_t nd = Y.nd_at[q & 3u];
+      if (t < nd && (t >= nd_early || ((Y.chg[(q - 1u) & 1u][t >> 5] >> (t & 31)) & 1u))) {   // (q == 0: nd == 0)
         const K9St vs = k9_load(slots + (size_t)t * K9_NF);
         const K9Sc scp = k9_sc_preload(sh.active >> 2, gi, gr, a.NP, vs.node);
-        dk[t] = k9_eval_v(a, sh, vs, scp, gi, gr, si, 0u, 0.0, si, nb, nmaskbits);
-        // what the slot's next placement of the shape would be (allocate.go:160) — the selection reads it for the slots it considers
-        if (sel_run) X.dkk[t] = k9_fits_idle(a, sh, vs.idle0, vs.idle1, scp, gi, si, vs.node, 0u, 0.0, si) ? 0u : 1u;
+        key = k9_eval_v(a, sh, vs, scp, gi, gr, si, 0u, 0.0, si, nb, nmaskbits);
+        if (sel_run) dkko[t] = k9_fits_idle(a, sh, vs.idle0, vs.idle1, scp, gi, si, vs.node, 0u, 0.0, si) ? 0u : 1u;
       }
-      if (lane == 0) k9s_st(&Y.seq_dk[wave - 1u], k + 1u);
+      if (t >= nd) key = 0u;
+      if (t < K9_MAXSLOTS) dko[t] = key;
+      const uint32_t wm = wave_max_u32(key);
+      if (lane == 0) { Y.mdk[q & 1u][wave - 1u] = wm; k9s_st(&Y.seq_dk[wave - 1u], q + 1u); }
     }
   } else if (wave < K9S_PREP0 + K9S_PREPS) {
     // =================================================== waves 5..7: the candidates ===================================================
@@ -508,7 +569,9 @@ __global__ void __launch_bounds__(K9_THREADS) k_commit_select(const K9KernArgs k
       const uint32_t r1 = m >= 1u ? (uint32_t)X.runs[m] - (uint32_t)X.runs[m - 1u] : 0u, r2 = m >= 2u ? (uint32_t)X.runs[m - 1u] - (uint32_t)X.runs[m - 2u] : 0u;
       uint32_t want = r + r1 + r2, need = m >= 2u ? m - 2u : 0u;
       if (want > 64u) { want = r + r1; need = m >= 1u ? m - 1u : 0u; }   // r <= K9_SEL_MAXRUN = 32
+      const unsigned long long tp0 = K9S_NOW();
       if (!k9s_wait(Y, &Y.seq_done, need) || k9s_ld(&Y.stop)) break;
+      K9S_TR(1, tp0);
       uint32_t nf = 0;
       {
         uint32_t e_ = cursor[s];
@@ -578,8 +641,10 @@ __global__ void __launch_bounds__(K9_THREADS) k_commit_select(const K9KernArgs k
         }
       }
       // ---- when run m - 1 is committed: the first r entries whose node the runs in front left alone are the run's candidates
+      const unsigned long long tp1 = K9S_NOW();
       if (!k9s_wait(Y, &Y.seq_done, m) || k9s_ld(&Y.stop)) break;
-      const uint32_t nd = Y.nd_pub;
+      K9S_TR(0, tp1);
+      const uint32_t nd = Y.nd_at[m & 3u];
       const bool keep = lane < nf && !((bitmap[n >> 5] >> (n & 31)) & 1u);
       const unsigned long long kb = __ballot(keep);
       const uint32_t rho = (uint32_t)__popcll(kb & lt);
@@ -594,10 +659,27 @@ __global__ void __launch_bounds__(K9_THREADS) k_commit_select(const K9KernArgs k
         ckey[rho] = key; cpos[rho] = mypos;
         X.ckind[rho] = kind; X.ck1[rho] = k1; X.ckind1[rho] = kind1; X.crnm[rho] = rnm;
       }
-      if (lane == 0) { Y.ncand_pub = ncand; k9s_st(&Y.seq_cand, m + 1u); }
+      if (lane == 0) { Y.ncand_at[m & 3u] = ncand; k9s_st(&Y.seq_cand, m + 1u); }
     }
   }
+#ifdef KB_K9_TRACE
+  if (tid == 0) {
+    unsigned long long *tw = reinterpret_cast<unsigned long long *>(a.result);
+    tw[5] = (unsigned long long)tacc[0] | ((unsigned long long)tacc[1] << 32);
+    tw[6] = (unsigned long long)tacc[2] | ((unsigned long long)tacc[3] << 32);
+    tw[7] = (unsigned long long)tacc[4] | ((unsigned long long)tacc[5] << 32);
+    tw[13] = (unsigned long long)tacc[6] | ((unsigned long long)tacc[7] << 32);
+    tw[14] = (unsigned long long)tacc[8] | ((unsigned long long)tacc[9] << 32);
+  }
+#endif
   __syncthreads();   // wave 0 has left the loop: the header and the statistics words are final
+#ifdef KB_K9_TRACE
+  if (tid == 0) {
+    unsigned long long *tw = reinterpret_cast<unsigned long long *>(a.result);
+    tw[4] = (unsigned long long)X.tr[0] | ((unsigned long long)X.tr[1] << 32);
+    tw[15] = (unsigned long long)X.tr[2] | ((unsigned long long)X.tr[3] << 32);
+  }
+#endif
   k9_epilogue(a, lo, k9_smem, tid, t_start, X.stat[0] | (X.stat[1] << 16), X.stat[2] | (X.stat[3] << 16));
 }
 

@@ -1085,11 +1085,11 @@ void kb_engine_destroy(kb_engine *e) {
     static const char *ph[10] = {"barrier 1 (wave 0's wait)", "evaluate: candidates (wave 0)", "barrier 2", "rows", "prepare the next run",
                                 "rows, of runs with scalar dimensions", "runs with scalar dimensions (count)", "evaluate, of runs with scalar dimensions",
                                 "dirty-winner entries (count)", "loop top"};
-    static const char *ph_sel[10] = {"barrier 1 (wave 0's wait)", "-", "evaluation phase (wave 0 waits at barrier 2)", "rows: serial loop, tail", "-",
+    static const char *ph_sel[10] = {"wave 0 waits for candidates + dirty keys", "-", "-", "rows: serial loop, tail, publish", "-",
                                     "selection: entries + first rank", "selection: deep passes", "selection: picks + AddTask", "selection: all picks clean", "loop top"};
     const double runs = (double)(e->k5_walks ? e->k5_walks : 1);
     for (int k = 0; k < 10; k++) fprintf(stderr, "[kb K5 trace] %-32s %14.0f clocks  (%.0f per run)\n", e->rounds_sel > e->rounds_run ? ph_sel[k] : ph[k], e->k5_trace[k], e->k5_trace[k] / runs);
-    static const char *ph_role[4] = {"evaluation phase: the candidates' wave", "evaluation phase: the walking wave", "evaluation phase: wave 1 (dirty slots)", "rows step of single rows (part of rows)"};
+    static const char *ph_role[4] = {"prep waves wait for their run's turn (sum of 3)", "prep waves wait for the walk's turn (sum of 3)", "wave 1 waits for the previous run", "wave 1 evaluates + publishes"};
     if (e->rounds_sel > e->rounds_run) for (int k = 10; k < 14; k++) fprintf(stderr, "[kb K5 trace] %-32s %14.0f clocks  (%.0f per run)\n", ph_role[k - 10], e->k5_trace[k], e->k5_trace[k] / runs);
   }
   (void)hipSetDevice(e->device);

@@ -41,8 +41,11 @@ struct K9Sync {
   uint32_t seq_done;                  // runs committed (wave 0)
   uint32_t seq_cand;                  // runs whose candidates are in LDS (the run's prep wave)
   uint32_t seq_dk[4];                 // runs whose dirty keys are in LDS, per evaluating wave
-  uint32_t nd_pub, ncand_pub;         // dirty slots after the last committed run; candidates of the run seq_cand announces
   uint32_t stop, err;                 // the round is over (wave 0); a wait ran out of patience
+  uint32_t nd_at[4];                  // [k & 3]: dirty slots when run k starts (wave 0, in front of seq_done = k)
+  uint32_t ncand_at[4];               // [k & 3]: candidates of run k (its prep wave, in front of seq_cand = k + 1)
+  uint32_t mdk[2][4];                 // [k & 1][w]: best dirty key of run k's shape among evaluating wave w's slots
+  uint32_t chg[2][10];                // [k & 1]: slots run k changed other than by consuming a clean candidate once (what an early evaluation for run k + 1 got wrong)
 };
 struct K9Sel {
   K9Sync sync;
@@ -50,11 +53,13 @@ struct K9Sel {
   uint16_t runs[KB_K5_MAX_ROWS];      // first row of run k
   uint32_t brk[8], stm[8];            // row masks: the row cannot join its predecessor / the row starts a run
   uint32_t ckind[64], ck1[64], ckind1[64], crnm[64];   // per surviving candidate (P2's results, written by the prep wave, read by wave 0)
-  uint32_t dkk[K9_MAXSLOTS];          // dirty slot t: its next placement of the run's shape would be a Pipeline (allocate.go:160)
+  uint32_t dkb[2][K9_MAXSLOTS];       // [k & 1][t]: key(shape of run k, dirty slot t)
+  uint32_t dkk[2][K9_MAXSLOTS];       // [k & 1][t]: slot t's next placement of the run's shape would be a Pipeline (allocate.go:160)
   unsigned long long e_comp[64];      // entries: prefix-minimum key << 8 | 255 - step  (greater = picked earlier)
   uint32_t e_info[64];                // contender | kind << 8 | step << 16
   uint32_t c_slot[64], c_next[64], c_eff[64], c_flag[64], c_take[64];   // contenders: state slot, next unknown step, prefix minimum so far, bit 0 ended / bit 1 clean / bit 2 its last taken entry is a Pipeline
   uint32_t al[64];                    // a deep pass: the contenders it walks
+  uint32_t tr[4];                     // KB_K9_TRACE: cycles the other waves wait / work (kb_commit_sel.hip)
   uint32_t stat[4];                   // runs committed with every pick a clean first placement / by the general selection / handed to the serial loop; deep passes
 };
 
