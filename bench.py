@@ -27,6 +27,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+RANK_SEED_STRIDE = 7919   # --gpus N: rank k schedules the snapshot of seed + RANK_SEED_STRIDE * k (tests/golden/make_bench_rank_digests.py)
 
 BINPACK_CONF = """
 actions: "allocate, backfill"
@@ -131,20 +132,35 @@ def main():
     actions = ["allocate", "backfill"] + (["preempt"] if args.preempt else [])
 
     dist_mode = None
+    rank_digest_expected = None
     if world > 1 or force_sharded:
-        # N > 1.  Default "replicas only": the cycle does not shard profitably (its shardable part, ~19 us of
-        # matrix + candidate lists per round, is shorter than one collective over xGMI; the commit is a sequential dependency), so every
-        # rank runs the whole cycle on its own session replica through the single-GPU fast path, no data-path collective, `value` = what
-        # all ranks processed / time ("scaling": "weak"); after the timed region ONE all-reduce compares a digest of the replicas'
-        # decisions.  KB_DIST_MODE=sharded: north_star's task-row split (matrix rows sharded, lists all-gathered, commit replicated,
-        # deltas all-reduced, per round) — exact, "strong", and slower than one GPU.
+        # N > 1.  north_star's task-row split is NOT the default: the cycle does not shard profitably (its shardable
+        # part, ~19 us of matrix + candidate lists per round, is shorter than one collective over xGMI; the commit is a sequential
+        # dependency).  Default "sessions": rank k schedules its OWN snapshot (the generator's seed + k; rank 0's is the N = 1 workload)
+        # through the single-GPU fast path, no data-path collective; every rank's decisions are held to a committed golden digest
+        # (tests/golden/bench_rank_digests.json, from the oracle).  `value` is the per-session rate of the SLOWEST rank — what one 100k x 10k
+        # snapshot is scheduled at — so that it stays comparable with the N = 1 line; the aggregate is printed beside it
+        # (`aggregate_evals_per_s`, `sessions_per_s`).  KB_DIST_MODE=sharded: north_star's task-row split (matrix rows sharded, lists
+        # all-gathered, commit replicated, deltas all-reduced, per round) — exact, "strong", and slower than one GPU.
+        # KB_DIST_MODE=replicas: round 3's mode, every rank the SAME session, digests compared across ranks.
         distmod = importlib.import_module("kube-batch_amd.dist")
-        dist_mode = "sharded" if (force_sharded or os.environ.get("KB_DIST_MODE") == "sharded") else "replicas"
+        mode_env = os.environ.get("KB_DIST_MODE", "sessions")
+        dist_mode = "sharded" if (force_sharded or mode_env == "sharded") else ("replicas" if mode_env == "replicas" else "sessions")
+        if dist_mode == "sessions" and rank > 0:
+            params.seed = params.seed + RANK_SEED_STRIDE * rank
+            snap = kbm.snapshot.synth(params)
+        if dist_mode == "sessions":
+            try:
+                golden = json.load(open(os.path.join(ROOT, "tests", "golden", "bench_rank_digests.json")))
+                key = f"config{args.config}_scale{args.scale:g}{'_survey' if args.survey_nodes else ''}{'_diverse' if args.diverse else ''}"
+                rank_digest_expected = golden.get(key, {}).get(str(rank))
+            except OSError:
+                rank_digest_expected = None
         if dist_mode == "sharded":
             runner = distmod.ShardedCycle(conf, snap, device=local_rank, window=args.window, commit_batch=args.commit_batch)
         else:
             runner = distmod.ReplicatedCycle(conf, snap, device=local_rank, window=args.window, commit_batch=args.commit_batch)
-        step = (lambda: runner.step(verify=False)) if dist_mode == "replicas" else runner.step
+        step = (lambda: runner.step(verify=False)) if dist_mode != "sharded" else runner.step
         eng = runner.engine
     else:
         eng = engine.Engine(conf, device=local_rank, window=args.window, commit_batch=args.commit_batch)
@@ -179,6 +195,7 @@ def main():
     t1 = time.perf_counter()
     s1 = eng.stats()
     elapsed = t1 - t0
+    elapsed_local = elapsed
     if world > 1:
         tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -188,8 +205,10 @@ def main():
     n_binds = int((binds != kbm.abi.KB_NONE).sum())
     d = {k: s1[k] - s0[k] for k in s1}
     evals = d["evals"]
-    replicas = world if dist_mode == "replicas" else 1      # independent session replicas: the job processed `world` cycles per step
     replicas_agree = None
+    sessions_verified = None
+    aggregate = None
+    value = evals / elapsed                                   # one session's rate (N = 1, sharded: the job's)
     if dist_mode == "replicas" and world > 1:
         dec_last = runner.step(verify=False)                 # outside the timed region: one more cycle, its digest compared across ranks
         try:
@@ -198,7 +217,27 @@ def main():
         except RuntimeError as err:
             replicas_agree = False
             print(f"bench.py: {err}", file=sys.stderr)
-    value = replicas * evals / elapsed
+    if dist_mode == "sessions":
+        # outside the timed region: one more cycle per rank, its digest against the committed golden digest of THIS rank's snapshot;
+        # the per-session rate of the slowest rank is the line's value, the sum over the ranks is the aggregate
+        dec_last = runner.step(verify=False)
+        mine = distmod.ReplicatedCycle.digest(dec_last, eng.binds())
+        ok_here = 1 if (rank_digest_expected is not None and int(rank_digest_expected) == mine) else (0 if rank_digest_expected is not None else -1)
+        dev = "cuda" if (world > 1 and dist.get_backend() == "nccl") else "cpu"
+        stat = torch.tensor([evals / elapsed_local, -float(ok_here), float(evals), float(n_binds)], dtype=torch.float64, device=dev)
+        if world > 1:
+            mn = stat.clone(); dist.all_reduce(mn, op=dist.ReduceOp.MIN)
+            sm = stat.clone(); dist.all_reduce(sm, op=dist.ReduceOp.SUM)
+            mx = stat.clone(); dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+        else:
+            mn = sm = mx = stat
+        value = float(mn[0].item())                           # slowest rank's evals/s on its own snapshot
+        worst = -int(mx[1].item())                            # min over ranks of ok_here
+        sessions_verified = None if worst < 0 else bool(worst == 1)
+        aggregate = {"aggregate_evals_per_s": float(sm[2].item()) / elapsed, "sessions_per_s": world * args.steps / elapsed,
+                     "aggregate_binds_per_s": float(sm[3].item()) * args.steps / elapsed}
+        if ok_here == 0:
+            print(f"bench.py: rank {rank}: decisions digest {mine} differs from the golden digest {rank_digest_expected}", file=sys.stderr)
 
     # ---- roofline: the mask+score matrix (K1), HBM-bound by construction (SURVEY.md §8d accounting (M): 2 B score + 1/8 B
     # mask per evaluation written once, node and task vectors read once).  Two measurements, both with HIP events on the
@@ -271,14 +310,14 @@ def main():
     out = {
         "metric": f"pod-node scoring evals/sec + binds/sec, {_k(snap.n_tasks)} tasks x {_k(snap.n_nodes)} nodes snapshot",
         "value": value, "unit": "evals/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": elapsed * 1e3 / args.steps, "higher_is_better": True, "scaling": "strong" if dist_mode == "sharded" else "weak",   # --gpus N runs N session replicas (per-GPU work fixed); only KB_DIST_MODE=sharded splits one session
+        "ms_per_step": elapsed * 1e3 / args.steps, "higher_is_better": True, "scaling": "strong" if dist_mode == "sharded" else "weak",   # --gpus N: one session per GPU (per-GPU work fixed); only KB_DIST_MODE=sharded splits one session
         "vs_baseline": None, "dtype": "f64+i64", "data": "synthetic",
         "config": {"workload": f"BASELINE configs[{args.config - 1}]: {snap.n_tasks} tasks x {snap.n_nodes} nodes, "
                                f"{snap.n_jobs} gang jobs, {snap.n_queues} queues, R={R}, {'+'.join(actions)}, "
                                f"plugins priority,gang,drf,predicates,proportion,nodeorder ({weights})",
                    "window": args.window or 256, "scale": args.scale, "diverse_requests": bool(args.diverse),
                    "node_sizes": "SURVEY 8d list (no capacity pressure)" if args.survey_nodes else "sized for demand ~1.3x capacity"},
-        "binds_per_s": replicas * n_binds * args.steps / elapsed, "binds": n_binds, "decisions": int(d["decisions"] / args.steps),
+        "binds_per_s": n_binds * args.steps / elapsed, "binds": n_binds, "decisions": int(d["decisions"] / args.steps),
         "evals_per_step": int(evals / args.steps),
         # `value` counts the evaluations the REFERENCE performs for this cycle (N per popped task).  The engine
         # itself evaluates far fewer pairs (one matrix row per distinct task shape of a window + the dirty-node repairs):
@@ -294,8 +333,11 @@ def main():
         "streaming_equivalent": {"bytes_per_eval": b_node, "equivalent_GBps": round(value * b_node / 1e9, 1),
                                  "frac_of_hbm_peak": round(value * b_node / 1e9 / HBM_PEAK_GBS, 4)},
         # not part of `value`: kb_session_load of the same snapshot (validation, shape interning, proportion water-fill, H2D)
-        "multi_gpu_mode": None if dist_mode is None else ("replicas only: one session replica per GPU, no data-path collective" if dist_mode == "replicas" else "task-row sharded rounds (KB_DIST_MODE=sharded)"),
-        "replicas": replicas, "replicas_agree": replicas_agree,
+        "multi_gpu_mode": None if dist_mode is None else {"sessions": "one independent session per GPU (rank k: seed + k), no data-path collective; value = the slowest rank's per-session rate",
+                                                          "replicas": "the same session on every GPU (KB_DIST_MODE=replicas), digests compared; value = one session's rate",
+                                                          "sharded": "task-row sharded rounds (KB_DIST_MODE=sharded)"}[dist_mode],
+        "replicas_agree": replicas_agree, "sessions_verified_against_golden_digests": sessions_verified,
+        **(aggregate or {}),
         "session_load_ms": None if load_ms is None else round(load_ms, 2),
         "evals_per_s_including_session_load": None if load_ms is None else evals / args.steps / (elapsed / args.steps + load_ms * 1e-3),
     }

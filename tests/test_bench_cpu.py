@@ -94,8 +94,9 @@ def test_smoke_entry_point_runs_end_to_end(monkeypatch, capsys):
 def test_two_ranks_under_torch_distributed_run_print_one_line(tmp_path):
     """The driver's N > 1 launch — `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py
     --gpus N ...` — with two ranks here: gloo stands in for RCCL (KB_DIST_BACKEND), the emulated library for the engine
-    (tests/host_harness/bench_emu_launcher.py).  Rank 0 prints ONE line, it counts both replicas' work ("weak"), the MAX over the ranks' times is
-    taken, and the replicas' decision digests were compared after the timed region."""
+    (tests/host_harness/bench_emu_launcher.py).  Rank 0 prints ONE line.  Default mode: every rank schedules its OWN snapshot (seed + rank),
+    each one's decisions are held to tests/golden/bench_rank_digests.json (the oracle's), `value` is the per-session rate of the slowest rank —
+    comparable with the N = 1 line, not N times it — and the aggregate stands beside it."""
     import socket
     import subprocess
     s = socket.socket()
@@ -113,8 +114,29 @@ def test_two_ranks_under_torch_distributed_run_print_one_line(tmp_path):
     assert len(lines) == 1, r.stdout
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 2 and d["warmup"] == 1 and d["scaling"] == "weak"
-    assert d["replicas"] == 2 and d["replicas_agree"] is True and d["multi_gpu_mode"].startswith("replicas only")
+    assert d["multi_gpu_mode"].startswith("one independent session per GPU") and d["sessions_verified_against_golden_digests"] is True
     assert "cpu_baseline" not in d or d["cpu_baseline"] is None        # reported at N = 1 only
     assert d["roofline"]["bound"] == "hbm"
-    # both replicas' evaluations over the slowest rank's time
-    assert abs(d["value"] - 2 * d["evals_per_step"] / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"]
+    # `value`: one session's rate (the slowest rank's), never the ranks' sum; the sum is the aggregate
+    assert d["value"] <= 1.05 * d["evals_per_step"] / (d["ms_per_step"] * 1e-3) * 1.5
+    assert d["aggregate_evals_per_s"] >= 1.5 * d["value"] and abs(d["sessions_per_s"] - 2 * 2 / (d["ms_per_step"] * 2e-3)) <= 1e-6 * d["sessions_per_s"]
+
+
+def test_two_identical_replicas_still_agree(tmp_path):
+    """KB_DIST_MODE=replicas (round 3's default): the same session on both ranks, digests compared across them; `value` is ONE session's rate."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, KB_EMU_LIB=emu.build_emulated_library(), KB_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1", KB_DIST_MODE="replicas")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(HERE, "host_harness", "bench_emu_launcher.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--scale", "0.02"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=os.path.dirname(HERE))
+    assert r.returncode == 0, r.stdout + r.stderr
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    assert d["replicas_agree"] is True and d["multi_gpu_mode"].startswith("the same session on every GPU")
+    assert abs(d["value"] - d["evals_per_step"] / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"]
