@@ -307,6 +307,39 @@ def main():
                 roofline["traffic"] = int((2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024)
                 roofline["traffic_source"] = "committed rocprofv3 PMC passes of the same launch (not re-measured in this run): " + os.path.relpath(pmc, ROOT)
 
+    # ---- the commit kernels: where the timed region actually goes (one workgroup on one of the 256 CUs; the HBM roofline above does not
+    # bound it).  Live: the kernels' own wall-clock stamps over the timed region -> ns and shader cycles per committed row.  From the committed
+    # rocprofv3 PMC passes of the same command (profiles/round*/rocprofv3_pmc_k_commit.csv, scripts/gpu_r4.sh profile; not re-measured here):
+    # per kernel, the instruction mix per dispatch, the share of wave cycles spent issuing / parked, instructions per busy cycle of the CU.
+    commit_ms_step = d["commit_ms"] / args.steps
+    rows_step = max(1.0, d["decisions"] / args.steps)
+    roofline_commit = {"bound": "issue of one CU (latency-bound serial dependency; not an HBM or MFMA roofline)",
+                       "commit_ms_per_step": round(commit_ms_step, 3), "share_of_step": round(commit_ms_step / (elapsed * 1e3 / args.steps), 4),
+                       "ns_per_committed_row": round(commit_ms_step * 1e6 / rows_step, 1),
+                       "cycles_per_committed_row_at_2.4GHz": round(commit_ms_step * 1e6 / rows_step * 2.4, 0),
+                       "rounds_per_step": d["rounds"] / args.steps, "us_per_round": round(commit_ms_step * 1e3 / max(1.0, d["rounds"] / args.steps), 1),
+                       "streaming_equivalent_frac_of_hbm_peak": round(value * b_node / 1e9 / HBM_PEAK_GBS, 4),   # SURVEY 8d accounting (S), see streaming_equivalent
+                       "counters": None}
+    found_c = sorted(glob.glob(os.path.join(ROOT, "profiles", "round*", "rocprofv3_pmc_k_commit.csv")),
+                     key=lambda f: int("".join(c for c in os.path.basename(os.path.dirname(f)) if c.isdigit()) or 0))
+    if found_c:
+        import csv
+        per = {}
+        for row in csv.DictReader(open(found_c[-1])):
+            per.setdefault(row["kernel"], {})[row["counter"]] = float(row["mean_per_dispatch"])
+        cnt = {}
+        for kname, c in per.items():
+            insts = sum(c.get(k, 0.0) for k in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_SMEM", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR"))
+            wc = c.get("SQ_WAVE_CYCLES", 0.0)
+            cnt[kname] = {"wave_insts_per_dispatch": {k[3:].lower(): int(c[k]) for k in c if k.startswith("SQ_INSTS_")},
+                          "wave_cycle_shares": None if not wc else {"issuing": round(c.get("SQ_ACTIVE_INST_ANY", 0.0) / wc, 3), "parked_waitcnt_or_sleep": round(c.get("SQ_WAIT_ANY", 0.0) / wc, 3),
+                                                                    "issue_stalled": round(c.get("SQ_WAIT_INST_ANY", 0.0) / wc, 3), "of_it_lds": round(c.get("SQ_WAIT_INST_LDS", 0.0) / wc, 4)},
+                          "wave_insts_per_cu_busy_cycle": None if not c.get("SQ_BUSY_CYCLES") else round(insts / c["SQ_BUSY_CYCLES"], 3),
+                          "lds_bank_conflict_share": None if not c.get("SQ_LDS_IDX_ACTIVE") else round(c.get("SQ_LDS_BANK_CONFLICT", 0.0) / c["SQ_LDS_IDX_ACTIVE"], 3),
+                          "waves_per_dispatch": int(c.get("SQ_WAVES", 0))}
+        roofline_commit["counters"] = cnt
+        roofline_commit["counters_source"] = "committed rocprofv3 PMC passes of the default command (not re-measured in this run): " + os.path.relpath(found_c[-1], ROOT)
+
     out = {
         "metric": f"pod-node scoring evals/sec + binds/sec, {_k(snap.n_tasks)} tasks x {_k(snap.n_nodes)} nodes snapshot",
         "value": value, "unit": "evals/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -327,6 +360,7 @@ def main():
         "rounds_per_step": d["rounds"] / args.steps, "spec_breaks_per_step": d["spec_breaks"] / args.steps,
         "row_fallbacks_per_step": d["row_fallbacks"] / args.steps,
         "roofline": roofline, "roofline_cycle": roofline_cycle, "roofline_eval": roofline_eval, "roofline_eval_all_rows": roofline_eval_all,
+        "roofline_commit": roofline_commit,
         # SURVEY.md §8d accounting (S): the reference's own dataflow streams B_node(R) bytes per evaluation (every popped task
         # against every node's live state).  The engine never moves those bytes (shape dedup + dirty-node repair); this is the
         # end-to-end rate expressed in that currency, for comparison with the 8 TB/s a streaming pass would be bound by.

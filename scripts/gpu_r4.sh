@@ -2,6 +2,7 @@
 # Round 4's GPU calls, one parameterised script:   gpurun -- 'bash scripts/gpu_r4.sh <step> [args]'   (writes gpurun_out/r4_<step>/*)
 #   sel      the selection commit kernel (k_commit_run<true>): the differential suites pinned to it, then same-box A/B against the round-3 kernels
 #   trace    the selection kernel's per-phase cycle trace (configs 3 and 4)
+#   profile  rocprofv3: kernel stats, HBM bytes of the matrix launches, SQ counters of the commit kernels (scripts/summarize_profile.py r4_profile profiles/round4)
 #   suite    the whole -m gpu suite
 #   bench    the default bench line and the variants
 set -uo pipefail
@@ -38,6 +39,23 @@ trace)   # the selection kernel's per-phase trace only (make EXTRA=-DKB_K9_TRACE
       > "$out/trace_c${cfg}.json" 2> "$out/trace_c${cfg}.err"
     echo "== trace c${cfg} $(ms "$out/trace_c${cfg}.json")" | tee -a "$out/summary.txt"; grep -h "kb K5 trace\|kb K5\] rounds [0-9]\|kb select" "$out/trace_c${cfg}.err" | tee -a "$out/summary.txt"
   done
+  ;;
+profile)   # rocprofv3 evidence of the default bench command: kernel stats, HBM bytes of the matrix launches, SQ counters of the commit kernels
+  export TMPDIR=/tmp
+  CMD="python $PWD/bench.py --steps 2 --warmup 1 --no-cpu-baseline"
+  P="$PWD/$out"
+  ( cd /tmp
+    rocprofv3 --kernel-trace --stats -f csv -d "$P/trace" -o bench -- $CMD > "$P/bench_trace.log" 2>&1
+    rocprofv3 --pmc FETCH_SIZE -f csv --kernel-include-regex "k_matrix|k_expand" -d "$P/pmc_fetch" -o bench -- $CMD > "$P/bench_pmc_fetch.log" 2>&1
+    rocprofv3 --pmc WRITE_SIZE -f csv --kernel-include-regex "k_matrix|k_expand" -d "$P/pmc_write" -o bench -- $CMD > "$P/bench_pmc_write.log" 2>&1
+    # the commit kernels (one workgroup on one CU): waves, busy / wave cycles and how they split, instruction mix, LDS
+    rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE -f csv --kernel-include-regex "k_commit" \
+      -d "$P/pmc_commit_a" -o bench -- $CMD > "$P/bench_pmc_commit_a.log" 2>&1
+    rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR -f csv --kernel-include-regex "k_commit" \
+      -d "$P/pmc_commit_b" -o bench -- $CMD > "$P/bench_pmc_commit_b.log" 2>&1
+  )
+  find "$out" -name "*.csv" | head -20 | tee -a "$out/summary.txt"
+  for f in trace pmc_fetch pmc_write pmc_commit_a pmc_commit_b; do echo "$f: $(tail -1 "$out/bench_${f/trace/trace}.log" 2>/dev/null | cut -c1-160)" >> "$out/summary.txt"; done
   ;;
 suite)
   timeout 1500 python -m pytest tests -q -m gpu -p no:cacheprovider "$@" > "$out/pytest_gpu.txt" 2>&1; echo "gpu suite rc=$? $(tail -1 "$out/pytest_gpu.txt")" | tee -a "$out/summary.txt"

@@ -55,6 +55,10 @@ def test_default_line_has_every_field_and_verifies_itself(monkeypatch):
         assert k in out["cpu_baseline"], k
     assert out["verified_bind_set_equals_oracle"] is True and out["verified_evals_equal_oracle"] is True
     assert out["binds"] > 0 and out["evals_per_step"] > 0
+    rc = out["roofline_commit"]      # the commit kernels' own figure: live time per committed row + the committed PMC counters of the same command
+    for k in ("commit_ms_per_step", "ns_per_committed_row", "cycles_per_committed_row_at_2.4GHz", "us_per_round", "streaming_equivalent_frac_of_hbm_peak", "counters"):
+        assert k in rc, k
+    assert rc["ns_per_committed_row"] > 0 and (rc["counters"] is None or any("k_commit" in k for k in rc["counters"]))
 
 
 def test_default_run_carries_the_unfriendly_inputs(monkeypatch):
