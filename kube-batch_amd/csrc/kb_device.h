@@ -226,6 +226,7 @@ void kb_launch_interpod(const KbDev &d, const KbRound &r, void *stream);
 void kb_launch_argmax(const KbDev &d, const KbRound &r, void *stream);
 // overlapped rounds (KbRound::ready): stale lists + the predecessor's nodes re-evaluated -> the round's candidate lists
 void kb_launch_repair(const KbDev &d, const KbRound &r, void *stream);
+size_t kb_repair_smem_bytes(uint32_t NP);   // its dynamic LDS (<= 150 KiB or the engine does not overlap rounds)
 // per-task rows out of the per-shape rows (kb_eval_matrix / kb_bench_matrix: the materialised T x N matrix)
 // order: the rows sorted by shape slot (nullptr: row order)
 void kb_launch_expand(const KbDev &d, const uint16_t *s_score, const uint32_t *s_mask, const uint32_t *row_slot, const uint32_t *order, uint32_t n_rows,

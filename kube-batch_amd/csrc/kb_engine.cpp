@@ -1548,7 +1548,8 @@ static int run_action(kb_engine *e, uint32_t action, kb_decision *out, uint64_t 
     // chained rounds of plain sessions (no score that is normalised over the feasible set, no inter-pod counters) build their candidate
     // lists beside the predecessor's commit kernel.  With scalar dimensions only behind a predecessor on the run kernel: the batch kernel
     // writes them speculatively for candidates it may hand back, i.e. on nodes that stay CLEAN, which no repair would look at again
-    const bool overlap_ok = e->overlap && action == 0 && e->fast_rounds && !e->hs.has_affinity && !e->hs.has_interpod && 2 * e->eff_window + 1 <= 1024u;
+    const bool overlap_ok = e->overlap && action == 0 && e->fast_rounds && !e->hs.has_affinity && !e->hs.has_interpod && 2 * e->eff_window + 1 <= 1024u &&
+                            kb_repair_smem_bytes(e->dev.NP) <= 150u * 1024u;   // the repair launch's LDS (its node bitmap grows with the cluster)
     // The second stream is ordered behind nothing the first one holds: the copies kb_session_reset left queued there must have landed before
     // an overlapped launch reads the node state (the feasibility probe's read-back waits for them when it runs — it does not without the
     // predicates plugin, with KB_PROBE=0, or when every shape is dead; found on the emulated device with asynchronous streams)
@@ -1600,6 +1601,9 @@ static int run_action(kb_engine *e, uint32_t action, kb_decision *out, uint64_t 
           if (rs2 != KB_REASON_SKIPPED) throw EngineError(KB_E_INTERNAL, "a round queued behind a stopped round ran");
           e->stats.matrix_launches -= 1;
           e->stats.matrix_evals -= (uint64_t)cn.ns * e->hs.N;
+          // its matrix / arg-max launches on the second stream (they run whatever the chain word says) read the descriptor and window
+          // halves the re-planned rounds are about to rewrite from the first stream: nothing else orders the two
+          if (cn.overlapped && e->stream_b) HIP_OK(hipStreamSynchronize(e->stream_b));
         }
         if (n) c = launch(n, nullptr, buf, 0, 0);
         if (action == 0) e->tl_break += now_ms() - t_b0;
@@ -1642,7 +1646,7 @@ void upload_live_nodes(kb_engine *e, const LiveNodes &ln, const std::vector<uint
     }
     w += rec;
   }
-  e->b_scatter.alloc(sizeof(unsigned long long) * words);
+  if (e->b_scatter.bytes < sizeof(unsigned long long) * words) e->b_scatter.alloc(sizeof(unsigned long long) * words);   // grown, never shrunk: hipFree synchronises the device
   HIP_OK(hipMemcpyAsync(e->b_scatter.p, e->h_scatter.data(), sizeof(unsigned long long) * words, hipMemcpyHostToDevice, e->stream));
   kb_launch_scatter_nodes(e->dev, e->b_scatter.as<unsigned long long>(), (uint32_t)nodes.size(), e->b_nmask.as<uint32_t>(), e->stream);
   HIP_OK(hipStreamSynchronize(e->stream));   // the staging vector is reused by the next refresh

@@ -562,10 +562,13 @@ __global__ void __launch_bounds__(KB_REPAIR_THREADS) k_repair(KbDev d, KbRound r
   const uint32_t total = alive_before[KB_REPAIR_THREADS] + cnt_fresh;
   for (uint32_t i = total + tid; i < K; i += KB_REPAIR_THREADS) out[i] = 0ull;
 }
+size_t kb_repair_smem_bytes(uint32_t NP) {
+  return sizeof(unsigned long long) * (KB_REPAIR_THREADS + KB_K5_MAX_WINDOW) + sizeof(uint32_t) * (KB_REPAIR_THREADS + 1) + sizeof(uint32_t) * (NP / 32);
+}
 void kb_launch_repair(const KbDev &d, const KbRound &r, void *stream) {
   if (r.n_mrows == 0) return;
   static bool attr_set = false;
-  const size_t sh = sizeof(unsigned long long) * (KB_REPAIR_THREADS + KB_K5_MAX_WINDOW) + sizeof(uint32_t) * (KB_REPAIR_THREADS + 1) + sizeof(uint32_t) * (d.NP / 32);
+  const size_t sh = kb_repair_smem_bytes(d.NP);   // the engine overlaps rounds only while this fits the attribute below (kb_engine.cpp: overlap_ok)
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_repair), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
     attr_set = true;

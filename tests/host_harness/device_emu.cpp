@@ -615,6 +615,7 @@ static void emu_repair(const KbDev &d, const KbRound &r) {
     for (uint32_t i = 0; i < r.L; i++) out[i] = i < keys.size() ? keys[i] : 0ull;
   }
 }
+size_t kb_repair_smem_bytes(uint32_t NP) { return 8 * (1024 + 1024) + 4 * 1025 + 4 * (size_t)(NP / 32); }
 void kb_launch_repair(const KbDev &d, const KbRound &r, void *stream) {
   kbemu_enqueue((hipStream_t)stream, [d, r]() { emu_repair(d, r); });
 }
