@@ -163,6 +163,7 @@ struct kb_engine {
   // round buffers
   DevBuf b_desc;
   Pinned<unsigned long long> h_listkeys;  // one complete candidate list of an evict action's preemptor shape (D2H target)
+  Pinned<unsigned char> h_evict;          // an evict action's entry / exit staging: node state and task table through ONE pinned block, one synchronisation each way
   DevBuf b_scatter;                       // packed node records of upload_live_nodes
   Pinned<unsigned long long> h_scatter;
   DevBuf b_sscore, b_smask, b_xslot, b_xorder;   // per-shape rows, row->shape map and rows in shape order of kb_eval_matrix / kb_bench_matrix
@@ -1675,17 +1676,32 @@ static int run_evict_action(kb_engine *e, bool reclaim, kb_stmt_op *out, uint64_
     const uint32_t N = hs.N, NP = e->dev.NP, T = hs.T, J = hs.J, Q = hs.Q;
     // ---- live state: device -> host
     LiveNodes ln;
+    std::vector<uint8_t> counted_in;
+    const double t_e0 = now_ms();
     {
-      std::vector<double> idle((size_t)R * NP), rel((size_t)R * NP);
-      std::vector<uint32_t> nmask(NP);
-      ln.nzc.resize(NP); ln.nzm.resize(NP); ln.podcnt.resize(NP); ln.ports.assign(NP, 0);
-      HIP_OK(hipMemcpy(idle.data(), e->b_idle.p, sizeof(double) * idle.size(), hipMemcpyDeviceToHost));
-      HIP_OK(hipMemcpy(rel.data(), e->b_rel.p, sizeof(double) * rel.size(), hipMemcpyDeviceToHost));
-      HIP_OK(hipMemcpy(nmask.data(), e->b_nmask.p, sizeof(uint32_t) * NP, hipMemcpyDeviceToHost));
-      HIP_OK(hipMemcpy(ln.nzc.data(), e->b_nzc.p, sizeof(long long) * NP, hipMemcpyDeviceToHost));
-      HIP_OK(hipMemcpy(ln.nzm.data(), e->b_nzm.p, sizeof(long long) * NP, hipMemcpyDeviceToHost));
-      HIP_OK(hipMemcpy(ln.podcnt.data(), e->b_podcnt.p, sizeof(int) * NP, hipMemcpyDeviceToHost));
-      if (e->dev.ports) HIP_OK(hipMemcpy(ln.ports.data(), e->b_ports.p, sizeof(unsigned long long) * NP, hipMemcpyDeviceToHost));
+      // one pinned block, every copy asynchronous on the engine's stream, ONE synchronisation (round 3: seven blocking pageable copies)
+      const size_t o_idle = 0, o_rel = o_idle + sizeof(double) * (size_t)R * NP, o_nzc = o_rel + sizeof(double) * (size_t)R * NP, o_nzm = o_nzc + sizeof(long long) * NP,
+                   o_ports = o_nzm + sizeof(long long) * NP, o_nmask = o_ports + sizeof(unsigned long long) * NP, o_pod = o_nmask + sizeof(uint32_t) * NP,
+                   o_cnt = o_pod + sizeof(int) * NP, o_end = o_cnt + (((size_t)T + 7) & ~(size_t)7);
+      e->h_evict.resize(o_end + 16);
+      unsigned char *hb = e->h_evict.data();
+      HIP_OK(hipMemcpyAsync(hb + o_idle, e->b_idle.p, sizeof(double) * (size_t)R * NP, hipMemcpyDeviceToHost, e->stream));
+      HIP_OK(hipMemcpyAsync(hb + o_rel, e->b_rel.p, sizeof(double) * (size_t)R * NP, hipMemcpyDeviceToHost, e->stream));
+      HIP_OK(hipMemcpyAsync(hb + o_nzc, e->b_nzc.p, sizeof(long long) * NP, hipMemcpyDeviceToHost, e->stream));
+      HIP_OK(hipMemcpyAsync(hb + o_nzm, e->b_nzm.p, sizeof(long long) * NP, hipMemcpyDeviceToHost, e->stream));
+      if (e->dev.ports) HIP_OK(hipMemcpyAsync(hb + o_ports, e->b_ports.p, sizeof(unsigned long long) * NP, hipMemcpyDeviceToHost, e->stream));
+      HIP_OK(hipMemcpyAsync(hb + o_nmask, e->b_nmask.p, sizeof(uint32_t) * NP, hipMemcpyDeviceToHost, e->stream));
+      HIP_OK(hipMemcpyAsync(hb + o_pod, e->b_podcnt.p, sizeof(int) * NP, hipMemcpyDeviceToHost, e->stream));
+      if (T) HIP_OK(hipMemcpyAsync(hb + o_cnt, e->b_tcounted.p, T, hipMemcpyDeviceToHost, e->stream));
+      HIP_OK(hipStreamSynchronize(e->stream));
+      const double *idle = reinterpret_cast<const double *>(hb + o_idle), *rel = reinterpret_cast<const double *>(hb + o_rel);
+      const uint32_t *nmask = reinterpret_cast<const uint32_t *>(hb + o_nmask);
+      ln.nzc.assign(reinterpret_cast<const long long *>(hb + o_nzc), reinterpret_cast<const long long *>(hb + o_nzc) + NP);
+      ln.nzm.assign(reinterpret_cast<const long long *>(hb + o_nzm), reinterpret_cast<const long long *>(hb + o_nzm) + NP);
+      ln.podcnt.assign(reinterpret_cast<const int *>(hb + o_pod), reinterpret_cast<const int *>(hb + o_pod) + NP);
+      if (e->dev.ports) ln.ports.assign(reinterpret_cast<const unsigned long long *>(hb + o_ports), reinterpret_cast<const unsigned long long *>(hb + o_ports) + NP);
+      else ln.ports.assign(NP, 0);
+      counted_in.assign(hb + o_cnt, hb + o_cnt + T);
       ln.idle.assign(N, Res()); ln.rel.assign(N, Res());
       for (uint32_t n = 0; n < N; n++) {
         ln.idle[n].mask = nmask[n] & 0x3FFFFFFFu;
@@ -1707,8 +1723,8 @@ static int run_evict_action(kb_engine *e, bool reclaim, kb_stmt_op *out, uint64_
       ln.maxpods = hs.n_maxpods; ln.cls = hs.n_cls;
     }
     PreemptMachine pm;
-    pm.counted.resize(T ? T : 1);
-    if (T) HIP_OK(hipMemcpy(pm.counted.data(), e->b_tcounted.p, T, hipMemcpyDeviceToHost));
+    pm.counted.assign(counted_in.begin(), counted_in.end());
+    if (pm.counted.empty()) pm.counted.resize(1);
     pm.jalloc = hs.job_alloc; pm.jshare = hs.job_share; pm.qalloc = hs.queue_alloc; pm.qshare = hs.queue_share;
     pm.jmask.assign(J ? J : 1, 0); pm.qmask.assign(Q ? Q : 1, 0);
     for (uint32_t t = 0; t < T; t++)
@@ -1717,7 +1733,10 @@ static int run_evict_action(kb_engine *e, bool reclaim, kb_stmt_op *out, uint64_
         if (hs.job_queue[hs.t_job[t]] < Q) pm.qmask[hs.job_queue[hs.t_job[t]]] |= hs.t_resmask[t];
       }
     // ---- the device side: one complete sorted list per preemptor shape, on demand
+    double tl_lists = 0.0, tl_lists_host = 0.0, tl_refresh = 0.0;
+    uint64_t n_lists = 0, n_refresh = 0;
     auto lists = [&](uint32_t task, std::vector<uint64_t> &keys) {
+      const double tl0 = now_ms();
       ensure_window_buffers(e, 1);
       ensure_matrix_buffers(e, 1, N + 1);
       HIP_OK(hipMemcpyAsync(e->b_mrows.p, &task, sizeof(uint32_t), hipMemcpyHostToDevice, e->stream));
@@ -1733,6 +1752,8 @@ static int run_evict_action(kb_engine *e, bool reclaim, kb_stmt_op *out, uint64_
       HIP_OK(hipMemcpyAsync(e->h_listkeys.data(), e->b_keys.p, sizeof(unsigned long long) * raw_n, hipMemcpyDeviceToHost, e->stream));
       HIP_OK(hipStreamSynchronize(e->stream));
       HIP_OK(hipGetLastError());
+      const double tl1 = now_ms();
+      tl_lists += tl1 - tl0; n_lists++;
       e->stats.matrix_launches += 1;
       e->stats.matrix_evals += N;
       // K3 orders (score descending, node ASCENDING); SortNodes breaks score ties by DESCENDING host name: reverse every run
@@ -1746,8 +1767,9 @@ static int run_evict_action(kb_engine *e, bool reclaim, kb_stmt_op *out, uint64_
         for (size_t q = k; q-- > i;) keys.push_back(((uint64_t)sc << 32) | KB_KEY_NODE(raw[q]));
         i = k;
       }
+      tl_lists_host += now_ms() - tl1;
     };
-    auto refresh = [&](const std::vector<uint32_t> &nodes) { upload_live_nodes(e, ln, nodes); };
+    auto refresh = [&](const std::vector<uint32_t> &nodes) { const double t0 = now_ms(); upload_live_nodes(e, ln, nodes); tl_refresh += now_ms() - t0; n_refresh++; };
     std::vector<uint8_t> status = hs.t_status;
     std::vector<uint32_t> tnode = hs.t_node;
     pm.init(&hs, &e->pol, &ln, &status, &tnode, lists, refresh);
@@ -1774,7 +1796,9 @@ static int run_evict_action(kb_engine *e, bool reclaim, kb_stmt_op *out, uint64_
     // host and device state are committed): whatever throws below, the session is marked tainted and every kb_run_* answers KB_E_STATE
     // until kb_session_load / kb_session_reset (round-2 advisory: the cross-check at the end used to fail AFTER publishing results)
     struct Taint { kb_engine *e; bool armed = true; ~Taint() { if (armed) e->tainted = true; } } taint{e};
+    const double t_e1 = now_ms();
     if (reclaim) pm.run_reclaim(); else pm.run();
+    const double t_e2 = now_ms();
     // ---- results: journal out, state back to the device
     if (n_out) *n_out = pm.ops.size();
     if (pm.ops.size() > cap) throw EngineError(KB_E_CAPACITY, "journal buffer too small");   // no result was written; a refresh may have updated nodes on the device: load the session again before another action
@@ -1784,10 +1808,16 @@ static int run_evict_action(kb_engine *e, bool reclaim, kb_stmt_op *out, uint64_
     hs.t_status = status;
     hs.t_node = tnode;
     pm.off_node_tasks(hs.t_off_node);
-    if (T) {
-      HIP_OK(hipMemcpy(e->b_tstatus.p, status.data(), T, hipMemcpyHostToDevice));
-      HIP_OK(hipMemcpy(e->b_tnode.p, tnode.data(), sizeof(uint32_t) * T, hipMemcpyHostToDevice));
-      HIP_OK(hipMemcpy(e->b_tcounted.p, pm.counted.data(), T, hipMemcpyHostToDevice));
+    if (T) {   // the task table back: through the pinned block, asynchronous, ordered in front of the finalize launches on the same stream
+      const size_t t8 = ((size_t)T + 7) & ~(size_t)7;
+      e->h_evict.resize(2 * t8 + sizeof(uint32_t) * (size_t)T + 16);
+      unsigned char *hb = e->h_evict.data();
+      std::memcpy(hb, status.data(), T);
+      std::memcpy(hb + t8, pm.counted.data(), T);
+      std::memcpy(hb + 2 * t8, tnode.data(), sizeof(uint32_t) * (size_t)T);
+      HIP_OK(hipMemcpyAsync(e->b_tstatus.p, hb, T, hipMemcpyHostToDevice, e->stream));
+      HIP_OK(hipMemcpyAsync(e->b_tcounted.p, hb + t8, T, hipMemcpyHostToDevice, e->stream));
+      HIP_OK(hipMemcpyAsync(e->b_tnode.p, hb + 2 * t8, sizeof(uint32_t) * (size_t)T, hipMemcpyHostToDevice, e->stream));
     }
     e->evictions.insert(e->evictions.end(), pm.evictions.begin(), pm.evictions.end());
     for (const StmtOp &op : pm.ops)   // Evict / Pipeline fire proportion's handlers -> updateShare for the task's queue
@@ -1800,6 +1830,11 @@ static int run_evict_action(kb_engine *e, bool reclaim, kb_stmt_op *out, uint64_
     e->stats.tasks_popped += pm.popped;
     e->stats.evals += pm.evals;
     e->stats.total_ms += now_ms() - t_begin;
+    static const bool ev_trace = [] { const char *v = getenv("KB_EVICT_TRACE"); return v && v[0] == '1'; }();
+    if (ev_trace)   // host timeline of the action (profiles/round4)
+      fprintf(stderr, "[kb evict] %s: entry (state to the host, machine set-up) %.2f ms; machine %.2f ms of which %llu lists %.2f ms on the device + %.2f ms host reorder, %llu node refreshes %.2f ms; exit (journal, state back, finalize, checks) %.2f ms; popped %llu, journal %zu\n",
+              reclaim ? "reclaim" : "preempt", t_e1 - t_e0, t_e2 - t_e1, (unsigned long long)n_lists, tl_lists, tl_lists_host, (unsigned long long)n_refresh, tl_refresh, now_ms() - t_e2,
+              (unsigned long long)pm.popped, pm.ops.size());
     taint.armed = false;
   });
 }

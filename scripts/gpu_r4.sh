@@ -3,6 +3,7 @@
 #   sel      the selection commit kernel (k_commit_run<true>): the differential suites pinned to it, then same-box A/B against the round-3 kernels
 #   trace    the selection kernel's per-phase cycle trace (configs 3 and 4)
 #   profile  rocprofv3: kernel stats, HBM bytes of the matrix launches, SQ counters of the commit kernels (scripts/summarize_profile.py r4_profile profiles/round4)
+#   evict    1M x 50k allocate + backfill + preempt: host timeline of the evict action, session-load phases, kernel stats
 #   suite    the whole -m gpu suite
 #   bench    the default bench line and the variants
 set -uo pipefail
@@ -56,6 +57,14 @@ profile)   # rocprofv3 evidence of the default bench command: kernel stats, HBM 
   )
   find "$out" -name "*.csv" | head -20 | tee -a "$out/summary.txt"
   for f in trace pmc_fetch pmc_write pmc_commit_a pmc_commit_b; do echo "$f: $(tail -1 "$out/bench_${f/trace/trace}.log" 2>/dev/null | cut -c1-160)" >> "$out/summary.txt"; done
+  ;;
+evict)   # 1M x 50k with its third action: host timeline of the evict action (KB_EVICT_TRACE), kb_session_load's phases (KB_LOAD_TRACE), kernel stats
+  KB_EVICT_TRACE=1 KB_LOAD_TRACE=1 timeout 600 python bench.py --config 5 --preempt --steps 2 --warmup 1 --no-cpu-baseline --verify > "$out/bench_config5_preempt.json" 2> "$out/bench_config5_preempt.err"
+  echo "config 5 three actions rc=$? $(ms "$out/bench_config5_preempt.json")" | tee -a "$out/summary.txt"
+  grep -h "kb evict\|kb load" "$out/bench_config5_preempt.err" | tail -24 | tee -a "$out/summary.txt"
+  export TMPDIR=/tmp; P="$PWD/$out"
+  ( cd /tmp; rocprofv3 --kernel-trace --stats -f csv -d "$P/trace" -o bench -- python $OLDPWD/bench.py --config 5 --preempt --steps 1 --warmup 1 --no-cpu-baseline > "$P/bench_trace.log" 2>&1 )
+  head -14 "$out/trace/bench_kernel_stats.csv" | cut -c1-150 | tee -a "$out/summary.txt"
   ;;
 suite)
   timeout 1500 python -m pytest tests -q -m gpu -p no:cacheprovider "$@" > "$out/pytest_gpu.txt" 2>&1; echo "gpu suite rc=$? $(tail -1 "$out/pytest_gpu.txt")" | tee -a "$out/summary.txt"
