@@ -40,7 +40,9 @@ double now_ms() {
 
 struct DevBuf {
   void *p = nullptr;
-  size_t bytes = 0;
+  size_t bytes = 0;   // the size asked for last
+  size_t cap = 0;     // what is allocated: a session of the same size (the Go action loads one every cycle) or a smaller one reuses it —
+                      // hipFree synchronises the device and hipMalloc is not cheap either
   DevBuf() = default;
   DevBuf(const DevBuf &) = delete;
   DevBuf &operator=(const DevBuf &) = delete;
@@ -49,11 +51,14 @@ struct DevBuf {
     if (p) (void)hipFree(p);
     p = nullptr;
     bytes = 0;
+    cap = 0;
   }
   void alloc(size_t n) {
+    n = n ? n : 16;
+    if (p && n <= cap) { bytes = n; return; }
     release();
-    bytes = n ? n : 16;
-    HIP_OK(hipMalloc(&p, bytes));
+    bytes = cap = n;
+    HIP_OK(hipMalloc(&p, cap));
   }
   template <typename T> T *as() const { return reinterpret_cast<T *>(p); }
 };

@@ -3,6 +3,11 @@
 // also builds with g++ into the CPU test harnesses (tests/host_harness), which drive the engine's own host logic without a GPU.
 //
 // This is the engine's own implementation, independent of oracle/kb_oracle.c (test infrastructure).
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <atomic>
+#include <thread>
 #include <unordered_map>
 
 #include "kb_host.hpp"
@@ -97,9 +102,39 @@ struct Interner {
 
 // kb_session_load, host part.  t_active: per task the dimensions LessEqual compares (bits 0, 1 always; a scalar bit when InitResreq
 // exceeds the epsilon); nmask: per node (padded to NP) the scalar keys of Idle, bit 31 <=> Releasing carries scalar keys.
+// The Go action loads a session every scheduling cycle: at 1M tasks the O(T) passes below (copies, the task-major transpose, the
+// "same as its predecessor" test that lets nearly every task skip shape interning) are memory traffic worth splitting over a few host
+// threads.  fn(t0, t1) over disjoint ranges; small sessions stay on the calling thread.
+template <typename F> static void par_for(uint32_t T, F fn) {
+  const unsigned hw = std::thread::hardware_concurrency();
+  const uint32_t nt = T < (1u << 16) ? 1u : std::min<uint32_t>(8u, hw ? hw : 1u);
+  if (nt <= 1) { fn(0u, T); return; }
+  std::vector<std::thread> th;
+  const uint32_t step = (T + nt - 1) / nt;
+  for (uint32_t i = 1; i < nt; i++) th.emplace_back([&, i] { fn(std::min(T, i * step), std::min(T, (i + 1) * step)); });
+  fn(0u, std::min(T, step));
+  for (auto &t : th) t.join();
+}
+template <typename V, typename S> static void par_copy(V &dst, const S *src, size_t n) {   // dst := src[0..n), the destination's storage reused
+  dst.resize(n);
+  par_for((uint32_t)n, [&](uint32_t a, uint32_t b) { std::copy(src + a, src + b, dst.begin() + a); });
+}
+
 void build_host_session(const kb_snapshot *sn, const Policy &pol, uint32_t NP, HostSession &hs, std::vector<uint32_t> &t_active, std::vector<uint32_t> &nmask) {
   const bool waterfill_on_device = hs.waterfill_on_device;   // the caller's choice, made before this call
-  hs = HostSession();
+  static const bool trace = [] { const char *v = getenv("KB_LOAD_TRACE"); return v && v[0] == '1'; }();
+  auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  double t_mark = now();
+  auto mark = [&](const char *what) { if (trace) { const double t = now(); fprintf(stderr, "  build_host_session: %-40s %8.3f ms\n", what, t - t_mark); t_mark = t; } };
+  {   // a fresh session, but the T-sized arrays keep their storage from the last load (same cluster, next cycle: no allocation, no page faults)
+    HostSession old = std::move(hs);
+    hs = HostSession();
+    hs.t_res = std::move(old.t_res); hs.t_init = std::move(old.t_init); hs.t_res_rows = std::move(old.t_res_rows); hs.t_resmask = std::move(old.t_resmask);
+    hs.t_job = std::move(old.t_job); hs.t_cls = std::move(old.t_cls); hs.t_prio = std::move(old.t_prio); hs.t_creation = std::move(old.t_creation);
+    hs.t_status = std::move(old.t_status); hs.t_node = std::move(old.t_node); hs.t_nzc = std::move(old.t_nzc); hs.t_nzm = std::move(old.t_nzm);
+    hs.t_res_empty = std::move(old.t_res_empty); hs.t_init_empty = std::move(old.t_init_empty);
+    hs.t_feas_shape = std::move(old.t_feas_shape); hs.t_row_shape = std::move(old.t_row_shape);
+  }
   hs.waterfill_on_device = waterfill_on_device;
   const int R = hs.R = (int)sn->n_res;
   const uint32_t N = hs.N = sn->n_nodes, T = hs.T = sn->n_tasks, J = hs.J = sn->n_jobs, Q = hs.Q = sn->n_queues;
@@ -110,31 +145,41 @@ void build_host_session(const kb_snapshot *sn, const Policy &pol, uint32_t NP, H
     if (sn->node_alloc_cpu[n] >= (1ll << 48) || sn->node_alloc_mem[n] >= (1ll << 48) || sn->node_nz_cpu[n] >= (1ll << 48) || sn->node_nz_mem[n] >= (1ll << 48))
       throw EngineError(KB_E_UNSUPPORTED, "node quantity >= 2^48: exact integer scoring not guaranteed");
   }
-  hs.t_res.assign(sn->task_resreq, sn->task_resreq + (size_t)R * T);
-  hs.t_init.assign(sn->task_init_resreq, sn->task_init_resreq + (size_t)R * T);
-  hs.t_resmask.assign(T, 0);
-  if (sn->task_scalar_mask) hs.t_resmask.assign(sn->task_scalar_mask, sn->task_scalar_mask + T);
-  // a dense value under an absent key reads 0 (Go map semantics)
-  for (int d = 2; d < R; d++) {   // one dimension's row at a time: sequential in the dimension-major layout
-    double *row = &hs.t_res[(size_t)d * T];
-    for (uint32_t t = 0; t < T; t++)
-      if (!((hs.t_resmask[t] >> (d - 2)) & 1u)) row[t] = 0.0;
+  hs.t_res.resize((size_t)R * T); hs.t_init.resize((size_t)R * T); hs.t_resmask.resize(T); hs.t_res_rows.resize((size_t)T * R);
+  par_for(T, [&](uint32_t t0, uint32_t t1) {
+    for (uint32_t t = t0; t < t1; t++) hs.t_resmask[t] = sn->task_scalar_mask ? sn->task_scalar_mask[t] : 0u;
+    for (int d = 0; d < R; d++) {   // one dimension's row at a time: sequential in the dimension-major layout
+      std::copy(sn->task_resreq + (size_t)d * T + t0, sn->task_resreq + (size_t)d * T + t1, hs.t_res.begin() + (size_t)d * T + t0);
+      std::copy(sn->task_init_resreq + (size_t)d * T + t0, sn->task_init_resreq + (size_t)d * T + t1, hs.t_init.begin() + (size_t)d * T + t0);
+      if (d >= 2) {   // a dense value under an absent key reads 0 (Go map semantics)
+        double *row = &hs.t_res[(size_t)d * T];
+        for (uint32_t t = t0; t < t1; t++)
+          if (!((hs.t_resmask[t] >> (d - 2)) & 1u)) row[t] = 0.0;
+      }
+    }
+    // task-major copy for the order machine: one task's Resreq is read per scheduling step, and with the dimension-major
+    // device layout that is R cache misses per step (written sequentially here, read from R streams)
+    for (uint32_t t = t0; t < t1; t++)
+      for (int d = 0; d < R; d++) hs.t_res_rows[(size_t)t * R + d] = hs.t_res[(size_t)d * T + t];
+  });
+  mark("request vectors (copy, absent keys, task-major copy)");
+  hs.t_job.resize(T); hs.t_cls.resize(T); hs.t_prio.resize(T); hs.t_creation.resize(T); hs.t_status.resize(T); hs.t_node.resize(T); hs.t_nzc.resize(T); hs.t_nzm.resize(T);
+  {
+    std::atomic<int> bad_node{0};
+    par_for(T, [&](uint32_t t0, uint32_t t1) {
+      std::copy(sn->task_job + t0, sn->task_job + t1, hs.t_job.begin() + t0);
+      if (sn->task_class) std::copy(sn->task_class + t0, sn->task_class + t1, hs.t_cls.begin() + t0); else std::fill(hs.t_cls.begin() + t0, hs.t_cls.begin() + t1, 0);
+      std::copy(sn->task_priority + t0, sn->task_priority + t1, hs.t_prio.begin() + t0);
+      std::copy(sn->task_creation + t0, sn->task_creation + t1, hs.t_creation.begin() + t0);
+      std::copy(sn->task_status + t0, sn->task_status + t1, hs.t_status.begin() + t0);
+      if (sn->task_node) std::copy(sn->task_node + t0, sn->task_node + t1, hs.t_node.begin() + t0); else std::fill(hs.t_node.begin() + t0, hs.t_node.begin() + t1, KB_NONE);
+      std::copy(sn->task_nz_cpu + t0, sn->task_nz_cpu + t1, hs.t_nzc.begin() + t0);
+      std::copy(sn->task_nz_mem + t0, sn->task_nz_mem + t1, hs.t_nzm.begin() + t0);
+      for (uint32_t t = t0; t < t1; t++)
+        if (hs.t_node[t] != KB_NONE && hs.t_node[t] >= N) bad_node.store(1, std::memory_order_relaxed);
+    });
+    if (bad_node.load()) throw EngineError(KB_E_INVALID, "task_node out of range");
   }
-  // task-major copy for the order machine: one task's Resreq is read per scheduling step, and with the dimension-major
-  // device layout that is R cache misses per step (written sequentially here, read from R streams)
-  hs.t_res_rows.resize((size_t)T * R);
-  for (uint32_t t = 0; t < T; t++)
-    for (int d = 0; d < R; d++) hs.t_res_rows[(size_t)t * R + d] = hs.t_res[(size_t)d * T + t];
-  hs.t_job.assign(sn->task_job, sn->task_job + T);
-  hs.t_cls.assign(T, 0);
-  if (sn->task_class) hs.t_cls.assign(sn->task_class, sn->task_class + T);
-  hs.t_prio.assign(sn->task_priority, sn->task_priority + T);
-  hs.t_creation.assign(sn->task_creation, sn->task_creation + T);
-  hs.t_status.assign(sn->task_status, sn->task_status + T);
-  hs.t_node.assign(T, KB_NONE);
-  if (sn->task_node) hs.t_node.assign(sn->task_node, sn->task_node + T);
-  for (uint32_t t = 0; t < T; t++)
-    if (hs.t_node[t] != KB_NONE && hs.t_node[t] >= N) throw EngineError(KB_E_INVALID, "task_node out of range");
   hs.job_begin.assign(sn->job_task_begin, sn->job_task_begin + J + 1);
   hs.job_queue.assign(sn->job_queue, sn->job_queue + J);
   hs.job_min.assign(sn->job_min_available, sn->job_min_available + J);
@@ -149,8 +194,6 @@ void build_host_session(const kb_snapshot *sn, const Policy &pol, uint32_t NP, H
     for (uint32_t t = hs.job_begin[j]; t < hs.job_begin[j + 1]; t++)
       if (hs.t_job[t] != j) throw EngineError(KB_E_INVALID, "tasks must be grouped by job in canonical order");
   }
-  hs.t_nzc.assign(sn->task_nz_cpu, sn->task_nz_cpu + T);
-  hs.t_nzm.assign(sn->task_nz_mem, sn->task_nz_mem + T);
   if (sn->task_port_want || sn->task_port_conflict) {
     hs.t_want.assign(T, 0); hs.t_conf.assign(T, 0);
     for (uint32_t t = 0; t < T; t++) { if (sn->task_port_want) hs.t_want[t] = sn->task_port_want[t]; if (sn->task_port_conflict) hs.t_conf[t] = sn->task_port_conflict[t]; }
@@ -165,9 +208,10 @@ void build_host_session(const kb_snapshot *sn, const Policy &pol, uint32_t NP, H
   if (sn->node_scalar_mask) hs.n_idle_mask.assign(sn->node_scalar_mask, sn->node_scalar_mask + N);
   hs.n_tc = sn->n_task_classes; hs.n_nc = sn->n_node_classes ? sn->n_node_classes : 1;
   if (sn->class_compat) hs.compat.assign(sn->class_compat, sn->class_compat + ((size_t)sn->n_task_classes * sn->n_node_classes + 7) / 8);
+  mark("task / job / node arrays, validation");
   t_active.assign(T, 3u);
-  hs.t_res_empty.assign(T, 0);
-  hs.t_init_empty.assign(T, 0);
+  hs.t_res_empty.resize(T);
+  hs.t_init_empty.resize(T);
   Interner feas_ids, row_ids;
   // inter-pod (anti)affinity tables: validate what indexes device memory
   const kb_interpod *ip = sn->interpod;
@@ -211,8 +255,8 @@ void build_host_session(const kb_snapshot *sn, const Policy &pol, uint32_t NP, H
     if (pol.nodeorder_enabled && (pol.wPA < 0 || 10ll * ((long long)pol.wL + pol.wM + pol.wB + pol.wNA + pol.wPA) > 65535))
       throw EngineError(KB_E_UNSUPPORTED, "nodeorder weights (with podaffinity.weight) exceed the 16-bit score range");
   }
-  hs.t_feas_shape.assign(T, 0);
-  hs.t_row_shape.assign(T, 0);
+  hs.t_feas_shape.resize(T);
+  hs.t_row_shape.resize(T);
   // The tasks of a job are adjacent and nearly always identical in everything a shape depends on.  A task whose inputs equal its
   // predecessor's bit for bit (what the interner compares) takes over the predecessor's derived values; one whose key equals the
   // predecessor's takes its ids without a hash lookup.  Either way the ids are the ones a lookup would return.
@@ -234,16 +278,24 @@ void build_host_session(const kb_snapshot *sn, const Policy &pol, uint32_t NP, H
     }
     return true;
   };
+  // which tasks equal their predecessor: independent per task, so split over the host threads (the sequential pass below then only
+  // computes the others — a few per job — and copies forward)
+  std::vector<uint8_t> same_prev(T, 0);
+  {
+    std::atomic<int> bad_status{0};
+    par_for(T, [&](uint32_t t0, uint32_t t1) {
+      for (uint32_t t = t0; t < t1; t++) {
+        if (hs.t_status[t] > KB_TASK_UNKNOWN) bad_status.store(1, std::memory_order_relaxed);
+        same_prev[t] = (t > 0 && same_inputs_as_prev(t)) ? 1 : 0;
+      }
+    });
+    if (bad_status.load()) throw EngineError(KB_E_INVALID, "bad task status");
+  }
+  mark("shapes: equal-to-predecessor flags");
+  uint32_t prev_feas_id = 0, prev_row_id = 0;
+  bool prev_valid = false;   // `prev` holds the key of the last task that was computed (the tasks in between equal it)
   for (uint32_t t = 0; t < T; t++) {
-    if (hs.t_status[t] > KB_TASK_UNKNOWN) throw EngineError(KB_E_INVALID, "bad task status");
-    if (t > 0 && same_inputs_as_prev(t)) {   // the predecessor passed every check below with these very values
-      t_active[t] = t_active[t - 1];
-      hs.t_res_empty[t] = hs.t_res_empty[t - 1];
-      hs.t_init_empty[t] = hs.t_init_empty[t - 1];
-      hs.t_feas_shape[t] = hs.t_feas_shape[t - 1];
-      hs.t_row_shape[t] = hs.t_row_shape[t - 1];
-      continue;
-    }
+    if (same_prev[t]) continue;   // the predecessor passed every check below with these very values: filled in behind this loop
     if (sn->task_nz_cpu[t] < 0 || sn->task_nz_mem[t] < 0 || sn->task_nz_cpu[t] >= (1ll << 48) || sn->task_nz_mem[t] >= (1ll << 48))
       throw EngineError(KB_E_UNSUPPORTED, "task non-zero request out of the exact range");
     Res rq, in;
@@ -281,8 +333,8 @@ void build_host_session(const kb_snapshot *sn, const Policy &pol, uint32_t NP, H
         key.push_back((double)ip->task_require[t]); key.push_back((double)(ip->task_require[t] != 0xFFFF ? ip->task_self[t] : 0));
       }
       feas_len = key.size();
-      same_feas = t > 0 && prev_feas_len == feas_len && std::memcmp(prev.data(), key.data(), feas_len * sizeof(double)) == 0;
-      hs.t_feas_shape[t] = same_feas ? hs.t_feas_shape[t - 1] : feas_ids.intern(key);
+      same_feas = prev_valid && prev_feas_len == feas_len && std::memcmp(prev.data(), key.data(), feas_len * sizeof(double)) == 0;
+      hs.t_feas_shape[t] = same_feas ? prev_feas_id : feas_ids.intern(key);
       key.push_back((double)(uint32_t)(want & 0xFFFFFFFFu)); key.push_back((double)(uint32_t)(want >> 32));
     }
     key.push_back((double)sn->task_nz_cpu[t]);
@@ -290,10 +342,26 @@ void build_host_session(const kb_snapshot *sn, const Policy &pol, uint32_t NP, H
     if (ip) key.push_back((double)ip->task_sig[t]);   // ... and the priority weights of the score row
     const bool same_row = same_feas && prev.size() == key.size() &&
                           std::memcmp(prev.data() + feas_len, key.data() + feas_len, (key.size() - feas_len) * sizeof(double)) == 0;
-    hs.t_row_shape[t] = same_row ? hs.t_row_shape[t - 1] : row_ids.intern(key);
+    hs.t_row_shape[t] = same_row ? prev_row_id : row_ids.intern(key);
     prev.swap(key);
     prev_feas_len = feas_len;
+    prev_valid = true; prev_feas_id = hs.t_feas_shape[t]; prev_row_id = hs.t_row_shape[t];
   }
+  mark("shapes: stretch heads (validation, interning)");
+  // the tasks that equal their predecessor take the values of the head of their stretch (every head is final now): ranges over the threads
+  par_for(T, [&](uint32_t t0, uint32_t t1) {
+    uint32_t h = t0;
+    while (h > 0 && same_prev[h]) h--;   // the head my first tasks belong to
+    for (uint32_t t = t0; t < t1; t++) {
+      if (!same_prev[t]) { h = t; continue; }
+      t_active[t] = t_active[h];
+      hs.t_res_empty[t] = hs.t_res_empty[h];
+      hs.t_init_empty[t] = hs.t_init_empty[h];
+      hs.t_feas_shape[t] = hs.t_feas_shape[h];
+      hs.t_row_shape[t] = hs.t_row_shape[h];
+    }
+  });
+  mark("shapes: stretches filled in");
   hs.n_feas_shapes = (uint32_t)feas_ids.size();
   hs.n_row_shapes = (uint32_t)row_ids.size();
   hs.init_empty_tasks.clear();   // backfill's candidates by request (backfill.go:47), ascending: the action filters them by status
@@ -349,6 +417,7 @@ void build_host_session(const kb_snapshot *sn, const Policy &pol, uint32_t NP, H
       hs.feas_eff[(size_t)f * R + d] = (d < 2 || ((t_active[t] >> d) & 1u)) ? hs.t_init[(size_t)d * T + t] : 0.0;
   }
 
+  mark("shape tables, inter-pod");
   // ---- plugin OnSessionOpen state ----
   // drf.go:60-64 / proportion.go:58-62: total = sum of Allocatable over ssn.Nodes (ascending node name)
   hs.total = Res();
@@ -388,6 +457,7 @@ void build_host_session(const kb_snapshot *sn, const Policy &pol, uint32_t NP, H
         if ((m >> (d - 2)) & 1u) { rq.setk(d); rq.v[d] += hs.t_res[(size_t)d * T + t]; }
     }
   }
+  mark("total, per-queue request");
   hs.queue_share_at_open = 1;
   hs.queue_request = request;
   if (pol.has_proportion && !hs.waterfill_on_device) {   // on the device: kb_session_load runs kb_launch_waterfill over hs.queue_request (KB_DEVICE_WATERFILL=1)
