@@ -166,7 +166,7 @@ typedef struct kb_config {
                                    + [cls_dom[p][i] == cls_dom[p][Z]] * sum over feasible n of cls_unbound[p][n] )
      score(i) = int(10 * (count(i) - min) / (max - min)) * podaffinity.weight, min / max over the feasible nodes and 0
    (interpod_affinity.go:213-233; only the pods of the feasible nodes are seen: util/scheduler_helper.go:226-238). */
-#define KB_INTERPOD_MAX 1024u
+#define KB_INTERPOD_MAX 65534u   /* the width of task_require (uint16, 0xFFFF = none); the tables themselves are multi-word / dense: no other limit */
 typedef struct kb_interpod {
   uint32_t n_counters;           /* C <= KB_INTERPOD_MAX */
   uint32_t n_domains;            /* D: every domain id of every counter is < D */

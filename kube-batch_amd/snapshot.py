@@ -267,7 +267,7 @@ def _node_selector_terms_match(terms, labels: Dict[str, str], node_name: str) ->
 # ------------------------------------------------------------------------------------------------
 # inter-pod (anti)affinity: predicate p8 and nodeorder's InterPodAffinityPriority
 # ------------------------------------------------------------------------------------------------
-IP_MAX = 1024        # inter-pod predicate counters / priority classes per session (include/kb_engine.h: KB_INTERPOD_MAX)
+IP_MAX = 65534       # inter-pod predicate counters / priority classes per session (include/kb_engine.h: KB_INTERPOD_MAX: the width of task_require)
 
 
 class UnsupportedSnapshot(ValueError):

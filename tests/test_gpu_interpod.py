@@ -95,6 +95,15 @@ def test_evict_actions_with_interpod_terms_equal_the_oracle(oracle_mod, seed):
     gp._run_both(oracle_mod, cfg, snap, order, seed)
 
 
+def test_more_than_1024_counters_and_classes(oracle_mod):
+    """round 3's envelope stopped at 1024 inter-pod predicate counters / priority classes per session; the tables were multi-word already
+    (vendor/k8s.io/kubernetes/pkg/scheduler/algorithm/predicates/predicates.go:1153-1175,1261-1290 know no such limit).  More than 2 x 1024
+    of each: the engine equals the oracle (which tests/test_interpod_oracle_cpu.py holds to the second restatement at this width)."""
+    from test_interpod_oracle_cpu import very_wide_interpod_case
+    cfg, snap = very_wide_interpod_case()
+    assert _run(oracle_mod, cfg, snap) > 500
+
+
 def test_hand_derived_known_answer_on_the_device(oracle_mod, commit_kernel):
     """tests/test_manifests_cpu.py derives the outcome of this cluster by hand from the Go code (first-node ties, the empty
     Spec.NodeName quirk of nodeorder's cachedNodeInfo, only the feasible nodes' pods being seen): the HIP path must produce it too."""

@@ -47,6 +47,39 @@ def interpod_case(seed, wide=False):
     return conf.load_scheduler_conf(CONFS[seed % 2]), snap
 
 
+def very_wide_interpod_case(n_pods=1100):
+    """more than 2 x 1024 distinct predicate counters AND priority classes (round 3's envelope stopped at 1024 of each): every pod repels the
+    pods of one label value of its own and prefers those of another, by host name; a third of the pods already run"""
+    rng = np.random.RandomState(77)
+    nodes = [snapmod.Node(name=f"n{i:02d}", allocatable={"cpu": "64", "memory": "256Gi", "pods": "110"},
+                          labels={"kubernetes.io/hostname": f"n{i:02d}", "zone": f"z{i % 3}"}) for i in range(48)]
+    groups = [snapmod.PodGroup(namespace="ns1", name=f"pg{j}", min_member=1, queue="default", creation=j) for j in range(40)]
+    pods = []
+    for i in range(n_pods):
+        p = snapmod.Pod(namespace="ns1", name=f"p{i:04d}", containers=[{"cpu": "100m", "memory": "128Mi"}], group_name=f"pg{i % 40}",
+                        labels={"app": f"u{(i * 7 + 3) % n_pods}", "tier": f"t{i % 5}"}, creation=i)
+        p.pod_anti_affinity_required = [((), ((("app", f"u{i}"),), ()), "kubernetes.io/hostname")]
+        p.pod_affinity_preferred = [(int(rng.choice([1, 10, 100])), ((), ((("app", f"u{(i + 1) % n_pods}"),), ()), "zone" if i % 2 else "kubernetes.io/hostname"))]
+        if i % 3 == 0:
+            p.node_name = nodes[int(rng.randint(len(nodes)))].name
+            p.phase = "Running"
+        pods.append(p)
+    snap = snapmod.flatten(nodes, pods, groups, [snapmod.Queue(name="default")])
+    assert snap.interpod["n_counters"] > 2048 and snap.interpod["n_classes"] > 2048
+    return conf.load_scheduler_conf(CONFS[1]), snap
+
+
+def test_oracle_equals_pyref_beyond_1024_counters_and_classes(oracle_mod):
+    """the oracle at that width, held to the second restatement (tests/test_gpu_interpod.py holds the engine to the oracle)"""
+    cfg, snap = very_wide_interpod_case()
+    o = oracle_mod.Oracle(cfg, snap)
+    o.run(["allocate", "backfill"])
+    p = pyref.Session(_tiers(cfg), snap).run(["allocate", "backfill"])
+    pd = np.array(p.decisions, dtype=np.uint32).reshape(-1, 3)
+    assert pd.shape == o.decisions().shape and np.array_equal(pd, o.decisions())
+    assert len(pd) > 500
+
+
 @pytest.mark.parametrize("seed", list(range(60)) + [1000 + i for i in range(6)])
 def test_oracle_equals_pyref_with_interpod_affinity(oracle_mod, seed):
     try:
