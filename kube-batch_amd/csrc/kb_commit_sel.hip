@@ -135,8 +135,6 @@ __global__ void __launch_bounds__(K9_THREADS) k_commit_select(const K9KernArgs k
   if (wave == 0) {
     // =================================================== wave 0: the selection ===================================================
     uint32_t nd = 0, n_dirty_rows = 0, n_runs = 0, n_slow = 0, i_end = 0, reason_end = KB_REASON_DONE;
-    uint32_t prev_nd0 = 0, prev_pc = 0;   // the run in front: dirty slots when it started, clean candidates it consumed
-    bool prev_chg = true;                 // ... and whether it changed slots in any other way (then the early dirty keys of this run are not final)
     for (uint32_t k = 0; k < K; k++) {
       K9S_RUN_HEADER(k)
       K9_STAMP(3);
@@ -144,9 +142,7 @@ __global__ void __launch_bounds__(K9_THREADS) k_commit_select(const K9KernArgs k
         uint32_t spins = 0;
         bool ok = true;
         for (;;) {
-          // lane 0: seq_cand; lanes 1..4: seq_dk — or seq_early when the run in front only consumed clean candidates, once each
-          const uint32_t *wp = (lane == 0u) ? &Y.seq_cand : (prev_chg ? &Y.seq_dk[(lane - 1u) & 3u] : &Y.seq_early[(lane - 1u) & 3u]);
-          const uint32_t v = (lane < 5u) ? k9s_ld(wp) : 0xFFFFFFFFu;
+          const uint32_t v = (lane < 5u) ? k9s_ld(&Y.seq_cand + lane) : 0xFFFFFFFFu;
           if (__ballot(v < k + 1u) == 0ull) break;
           if ((++spins & 31u) == 0u && (k9s_ld(&Y.err) || spins > K9S_SPIN_LIMIT)) { k9s_st(&Y.err, 1u); ok = false; break; }
           __builtin_amdgcn_s_sleep(1);
@@ -161,11 +157,8 @@ __global__ void __launch_bounds__(K9_THREADS) k_commit_select(const K9KernArgs k
       uint32_t ck = 0, k1 = 0, ckind = 0, ckind1 = 0;
       uint32_t rnm = 0;
       if (lane < ncand) { ck = ckey[lane]; k1 = X.ck1[lane]; ckind = X.ckind[lane]; ckind1 = X.ckind1[lane]; rnm = X.crnm[lane]; }
-      // best dirty key: the evaluating waves' maxima (clean winners update it in O(1)).  From the early evaluation: the maxima over the slots
-      // that were dirty before the run in front, and the keys of the candidates it consumed
-      uint32_t m = (lane < 4u) ? (prev_chg ? Y.mdk[k & 1u][lane] : Y.mdko[k & 1u][lane]) : 0u;
-      if (!prev_chg && lane >= 4u && lane - 4u < prev_pc) m = dk[prev_nd0 + lane - 4u];   // prev_pc <= K9_SEL_MAXRUN
-      m = wave_max_u32(m);
+      uint32_t m = (lane < 4u) ? Y.mdk[k & 1u][lane] : 0u;   // best dirty key: the evaluating waves' maxima; clean winners update it in O(1)
+      m = max(max(rl32(m, 0), rl32(m, 1)), max(rl32(m, 2), rl32(m, 3)));
       double res0 = sh.init0, res1 = sh.init1;
       if (!plain0) { res0 = rres[0]; res1 = rres[1]; }
       // cmin: the r-th best clean candidate's key — r entries are at or above it, so no entry below it is among the picks (0: the list
@@ -178,10 +171,6 @@ __global__ void __launch_bounds__(K9_THREADS) k_commit_select(const K9KernArgs k
                                         d3 = (lane + 192 < nd) ? dk[lane + 192] : 0u; have_d = true; } } while (0)
       uint32_t pc = 0, j = 0, reason = KB_REASON_DONE, n_dirty = 0, sc_dirty = 0;
       bool sel_done = false;
-      // As soon as a run's picks are known — which clean candidates it consumes (dirty bitmap, cursor) and how many (the next run's first
-      // slot) — the next run's prep wave may settle ITS candidates, beside what is left of this run (AddTask on the picked slots, scalar
-      // dimensions, the tail); the dirty keys of the next run still wait for seq_done.
-#define K9S_PUBLISH_PICKS(pc_) do { if (lane == 0) { if (pc_) cursor[s] = cpos[(pc_) - 1u] + 1u; Y.nd_at[(k + 1u) & 3u] = nd + (pc_); k9s_st(&Y.seq_picks, k + 1u); } } while (0)
       if (sel_run) {
         // ---- every pick a clean candidate's first placement?  No dirty key above the r-th clean candidate, no clean candidate whose key
         //      after its placement is: row j takes candidate j (a Pipeline among them ends the round behind its row)
@@ -204,7 +193,6 @@ __global__ void __launch_bounds__(K9_THREADS) k_commit_select(const K9KernArgs k
           }
           if (km0) sc_dirty = 1;
           pc = n_take; j = n_take;
-          K9S_PUBLISH_PICKS(pc);
           sel_done = true;
           if (lane == 0) X.stat[0]++;
           K9_STAMP(8);
@@ -363,12 +351,6 @@ __global__ void __launch_bounds__(K9_THREADS) k_commit_select(const K9KernArgs k
             K9_WAVE_FENCE();
             // ---- NodeInfo.AddTask (api/node_info.go:172-212), once per placement, on every contender that was picked: lane = contender
             const uint32_t T = (lane < nC) ? X.c_take[lane] : 0u;
-            if (T && lane < ncand) {   // a consumed clean candidate: its node is dirty from here on
-              const uint32_t nodec = nmaskbits - (ck & nmaskbits);
-              atomicOr(&bitmap[nodec >> 5], 1u << (nodec & 31));
-            }
-            pc = (uint32_t)__popcll(__ballot(lane < ncand && T != 0u));
-            K9S_PUBLISH_PICKS(pc);
             if (T) {
               const uint32_t fl = X.c_flag[lane], b = (fl >> 1) & 1u, pipe_last = (fl >> 2) & 1u;
               unsigned long long *st = slots + (size_t)X.c_slot[lane] * K9_NF;
@@ -395,8 +377,10 @@ __global__ void __launch_bounds__(K9_THREADS) k_commit_select(const K9KernArgs k
                     for (uint32_t mm = km0, dd = 0; mm; mm >>= 1, dd++)
                       if (mm & 1u) k9_sc_sub(pp ? gr : gi, a.NP, dd, node, si[dd]);
                 }
+              if (b) atomicOr(&bitmap[node >> 5], 1u << (node & 31));
             }
             if (km0) sc_dirty = 1;
+            pc = (uint32_t)__popcll(__ballot(lane < ncand && T != 0u));
             n_dirty = n_take - pc;
             j = n_take;
             sel_done = true;
@@ -495,7 +479,6 @@ __global__ void __launch_bounds__(K9_THREADS) k_commit_select(const K9KernArgs k
         }
         if (kind) { j++; reason = KB_REASON_PIPELINED; break; }   // a Pipeline ends the speculated order: the host re-plans
       }
-      if (!sel_done) K9S_PUBLISH_PICKS(pc);
       if (sc_dirty) __threadfence();   // the scalar atomics have reached L2 before any other wave evaluates against these nodes
       const uint32_t i_next = i0 + j;
       uint32_t stop = (reason != KB_REASON_DONE || i_next >= W) ? 1u : 0u;
@@ -505,9 +488,7 @@ __global__ void __launch_bounds__(K9_THREADS) k_commit_select(const K9KernArgs k
         const uint32_t fln = (uint32_t)__builtin_amdgcn_readfirstlane((int)rinfo[i_next].z);
         if (fln & 2u) { reason = KB_REASON_RENORM; stop = 1u; }
       }
-      prev_nd0 = nd; prev_pc = pc;
-      K9_WAVE_FENCE();
-      prev_chg = __ballot(lane < 10u && chg[lane < 10u ? lane : 0u] != 0u) != 0ull;
+      if (lane == 0 && pc) cursor[s] = cpos[pc - 1] + 1;
       nd += pc; n_dirty_rows += n_dirty; n_runs += 1u; n_slow += plain0 ? 0u : 1u;
       i_end = i_next; reason_end = reason;
       // publish: everything this run wrote (slots, bitmap, cursor, decision records) is in LDS before the word moves
@@ -543,12 +524,8 @@ __global__ void __launch_bounds__(K9_THREADS) k_commit_select(const K9KernArgs k
           key = k9_eval_v(a, sh, vs, scp, gi, gr, si, 0u, 0.0, si, nb, nmaskbits);
           // what the slot's next placement of the shape would be (allocate.go:160) — the selection reads it for the slots it considers
           if (sel_run) dkko[t] = k9_fits_idle(a, sh, vs.idle0, vs.idle1, scp, gi, si, vs.node, 0u, 0.0, si) ? 0u : 1u;
-          dko[t] = key;
         }
-        const uint32_t wmo = wave_max_u32(t < Y.nd_at[(q - 1u) & 3u] ? key : 0u);
-        if (lane == 0) Y.mdko[q & 1u][wave - 1u] = wmo;
       }
-      if (lane == 0) k9s_st(&Y.seq_early[wave - 1u], q + 1u);
       if (wave == 1u) K9S_TR(3, tw0);
       const unsigned long long tw1 = K9S_NOW();
       if (!k9s_wait(Y, &Y.seq_done, q) || k9s_ld(&Y.stop)) break;   // run q - 1 is committed: the slots are final
@@ -665,7 +642,7 @@ __global__ void __launch_bounds__(K9_THREADS) k_commit_select(const K9KernArgs k
       }
       // ---- when run m - 1 is committed: the first r entries whose node the runs in front left alone are the run's candidates
       const unsigned long long tp1 = K9S_NOW();
-      if (!k9s_wait(Y, &Y.seq_picks, m) || k9s_ld(&Y.stop)) break;   // run m - 1's picks are known (it may still be applying them: other slots)
+      if (!k9s_wait(Y, &Y.seq_done, m) || k9s_ld(&Y.stop)) break;
       K9S_TR(0, tp1);
       const uint32_t nd = Y.nd_at[m & 3u];
       const bool keep = lane < nf && !((bitmap[n >> 5] >> (n & 31)) & 1u);

@@ -41,13 +41,10 @@ struct K9Sync {
   uint32_t seq_done;                  // runs committed (wave 0)
   uint32_t seq_cand;                  // runs whose candidates are in LDS (the run's prep wave)
   uint32_t seq_dk[4];                 // runs whose dirty keys are in LDS, per evaluating wave
-  uint32_t seq_early[4];              // runs whose EARLY dirty keys are in LDS (final unless the run in front lists changed slots)
-  uint32_t seq_picks;                 // runs whose picks are known: the dirty bitmap, the cursor and nd_at hold them (wave 0, ahead of seq_done)
   uint32_t stop, err;                 // the round is over (wave 0); a wait ran out of patience
   uint32_t nd_at[4];                  // [k & 3]: dirty slots when run k starts (wave 0, in front of seq_done = k)
   uint32_t ncand_at[4];               // [k & 3]: candidates of run k (its prep wave, in front of seq_cand = k + 1)
   uint32_t mdk[2][4];                 // [k & 1][w]: best dirty key of run k's shape among evaluating wave w's slots
-  uint32_t mdko[2][4];                // ... among the slots that were dirty before run k - 1 (the early evaluation; run k - 1's consumed candidates: dkb)
   uint32_t chg[2][10];                // [k & 1]: slots run k changed other than by consuming a clean candidate once (what an early evaluation for run k + 1 got wrong)
 };
 struct K9Sel {
