@@ -36,8 +36,8 @@ TSAN_OPTIONS="report_signal_unsafe=0 exitcode=66" LD_PRELOAD="$(gcc -print-file-
 KB_WATERFILL_HARNESS_LIB="$out/libwaterfillkernel_tsan.so" python -m pytest tests/test_waterfill_kernel_cpu.py -x -q -p no:cacheprovider
 # the whole emulated suite with every run of identical rows committed by one selection (the emulated commit launch only)
 KB_EMU_RUN_SELECT=1 python -m pytest tests/test_emu_engine_cpu.py -x -q -p no:cacheprovider -n 8 -k "not two_gloo and not fullsize"
-# the whole emulated suite with proportion's water-fill taken from the (emulated) launch
-KB_DEVICE_WATERFILL=1 python -m pytest tests/test_emu_engine_cpu.py -x -q -p no:cacheprovider -n 8 -k "not two_gloo and not fullsize"
+# the whole emulated suite with proportion's water-fill on the host loop (the launch is the default)
+KB_DEVICE_WATERFILL=0 python -m pytest tests/test_emu_engine_cpu.py -x -q -p no:cacheprovider -n 8 -k "not two_gloo and not fullsize"
 # ThreadSanitizer over the host <-> device handshake: the emulated streams run asynchronously (KB_EMU_ASYNC=1: a worker thread per stream with
 # HIP's ordering rules, tests/host_harness/hip_mock), so a staging half, a mailbox word or a result the host touches before the device is done
 # with it is a reported race.  Chained / unchained rounds, pinned mailbox / synchronous rounds, direct window, both commit-kernel pins.
@@ -56,12 +56,10 @@ unset KB_OVERLAP
 # for its lists, the tags, the second stream's buffers; the whole emulated-engine suite must still equal the oracle
 KB_EMU_ASYNC=1 python -m pytest tests/test_emu_engine_cpu.py -x -q -p no:cacheprovider -k "not two_gloo"
 # the same with the relative timing of the two streams swept: every task of the first / the second / both streams starts up to 2 ms late
-# (hip_mock: KB_EMU_JITTER_US, KB_EMU_JITTER_STREAMS) — two idle host threads otherwise always meet in the same order; and with the repair
-# folded into the batch commit launch (KB_FOLD_REPAIR=1, off by default)
+# (hip_mock: KB_EMU_JITTER_US, KB_EMU_JITTER_STREAMS) — two idle host threads otherwise always meet in the same order
 for streams in 1 2 3; do
   KB_EMU_ASYNC=1 KB_EMU_JITTER_US=2000 KB_EMU_JITTER_STREAMS=$streams python -m pytest tests/test_emu_engine_cpu.py -x -q -p no:cacheprovider -n 8 -k "not two_gloo and not fullsize"
 done
-KB_FOLD_REPAIR=1 KB_COMMIT_KERNEL=batch KB_EMU_ASYNC=1 KB_EMU_JITTER_US=300 python -m pytest tests/test_emu_engine_cpu.py -x -q -p no:cacheprovider -n 8 -k "not two_gloo"
 # negative control: the same build with the commit's mailbox publication weakened from release to relaxed MUST be reported (exit code 66)
 sed 's/r.seq, __ATOMIC_RELEASE)/r.seq, __ATOMIC_RELAXED)/' tests/host_harness/device_emu.cpp > tests/host_harness/_device_emu_relaxed.cpp
 g++ $tsan -o "$out/libkbengine_emu_neg.so" $emu_src tests/host_harness/_device_emu_relaxed.cpp; rm -f tests/host_harness/_device_emu_relaxed.cpp
