@@ -28,6 +28,8 @@
 //      wave 0       when both are there: the selection (or the serial loop), decision records, cursors, dirty slots; publish seq_done = k + 1.
 //    A run's critical path is one evaluation (dirty slots) and its selection.  The words only grow; every wait is bounded (a wave that
 //    waits too long raises `err`, everybody leaves, the round reports KB_REASON_INTERNAL instead of hanging).
+#include <string.h>
+
 #include "kb_k9.hpp"
 
 #define K9S_PREP0 5u          // waves 5, 6, 7 prepare runs m % 3 == 0, 1, 2
@@ -38,7 +40,7 @@
 __device__ __forceinline__ uint32_t k9s_ld(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP); }
 __device__ __forceinline__ void k9s_st(uint32_t *p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP); }
 // wait until *p >= need; false when the round stopped (or somebody timed out) before that
-__device__ __forceinline__ bool k9s_wait(K9Sync &Y, const uint32_t *p, uint32_t need) {
+__device__ __forceinline__ bool k9s_wait(K9Sync &Y, const uint32_t *p, uint32_t need, uint32_t nap = 1u) {
   uint32_t spins = 0;
   for (;;) {
     if (k9s_ld(p) >= need) return true;
@@ -46,7 +48,7 @@ __device__ __forceinline__ bool k9s_wait(K9Sync &Y, const uint32_t *p, uint32_t 
       if (k9s_ld(&Y.stop) | k9s_ld(&Y.err)) return k9s_ld(p) >= need;
       if (spins > K9S_SPIN_LIMIT) { k9s_st(&Y.err, 1u); return false; }
     }
-    __builtin_amdgcn_s_sleep(1);
+    if (nap == 0u) { } else if (nap == 1u) __builtin_amdgcn_s_sleep(1); else if (nap <= 4u) __builtin_amdgcn_s_sleep(4); else __builtin_amdgcn_s_sleep(16);   // (s_sleep takes an immediate)
   }
 }
 
@@ -115,6 +117,7 @@ __global__ void __launch_bounds__(K9_THREADS) k_commit_select(const K9KernArgs k
 #define K9S_TR(k, t0) do { (void)(t0); } while (0)
 #define K9S_NOW() 0ull
 #endif
+  const uint32_t nap_prep = a.prewalk & 0xFFu, nap_dk = (a.prewalk >> 8) & 0xFFu;   // how long a waiting wave sleeps between two polls (KB_SEL_SLEEP=prep,dk)
   const unsigned long long lt = (1ull << lane) - 1ull;
   gptrd gi, gr;
   { const KbDev &d = *a.dev; gi = (gptrd)d.idle; gr = (gptrd)d.rel; }
@@ -479,7 +482,7 @@ __global__ void __launch_bounds__(K9_THREADS) k_commit_select(const K9KernArgs k
         }
         if (kind) { j++; reason = KB_REASON_PIPELINED; break; }   // a Pipeline ends the speculated order: the host re-plans
       }
-      if (sc_dirty) __threadfence();   // the scalar atomics have reached L2 before any other wave evaluates against these nodes
+      if (sc_dirty) __threadfence();   // the scalar atomics have reached L2 before any other wave evaluates against these nodes (dropping it measured no gain: profiles/round4/call20)
       const uint32_t i_next = i0 + j;
       uint32_t stop = (reason != KB_REASON_DONE || i_next >= W) ? 1u : 0u;
       if (!stop && a.has_aff && !a.backfill && i_next != 0u) {
@@ -516,7 +519,7 @@ __global__ void __launch_bounds__(K9_THREADS) k_commit_select(const K9KernArgs k
       uint32_t key = 0u, nd_early = 0u;
       const unsigned long long tw0 = K9S_NOW();
       if (q >= 1u) {
-        if (!k9s_wait(Y, &Y.seq_done, q - 1u) || !k9s_wait(Y, &Y.seq_cand, q) || k9s_ld(&Y.stop)) break;
+        if (!k9s_wait(Y, &Y.seq_done, q - 1u, nap_dk) || !k9s_wait(Y, &Y.seq_cand, q, nap_dk) || k9s_ld(&Y.stop)) break;
         nd_early = Y.nd_at[(q - 1u) & 3u] + Y.ncand_at[(q - 1u) & 3u];
         if (t < nd_early) {   // the shape against "their" dirty slot
           const K9St vs = k9_load(slots + (size_t)t * K9_NF);
@@ -528,7 +531,7 @@ __global__ void __launch_bounds__(K9_THREADS) k_commit_select(const K9KernArgs k
       }
       if (wave == 1u) K9S_TR(3, tw0);
       const unsigned long long tw1 = K9S_NOW();
-      if (!k9s_wait(Y, &Y.seq_done, q) || k9s_ld(&Y.stop)) break;   // run q - 1 is committed: the slots are final
+      if (!k9s_wait(Y, &Y.seq_done, q, nap_dk) || k9s_ld(&Y.stop)) break;   // run q - 1 is committed: the slots are final
       if (wave == 1u) K9S_TR(2, tw1);
       const uint32_t nd = Y.nd_at[q & 3u];
       if (t < nd && (t >= nd_early || ((Y.chg[(q - 1u) & 1u][t >> 5] >> (t & 31)) & 1u))) {   // (q == 0: nd == 0)
@@ -570,7 +573,7 @@ __global__ void __launch_bounds__(K9_THREADS) k_commit_select(const K9KernArgs k
       uint32_t want = r + r1 + r2, need = m >= 2u ? m - 2u : 0u;
       if (want > 64u) { want = r + r1; need = m >= 1u ? m - 1u : 0u; }   // r <= K9_SEL_MAXRUN = 32
       const unsigned long long tp0 = K9S_NOW();
-      if (!k9s_wait(Y, &Y.seq_done, need) || k9s_ld(&Y.stop)) break;
+      if (!k9s_wait(Y, &Y.seq_done, need, nap_prep) || k9s_ld(&Y.stop)) break;
       K9S_TR(1, tp0);
       uint32_t nf = 0;
       {
@@ -642,7 +645,7 @@ __global__ void __launch_bounds__(K9_THREADS) k_commit_select(const K9KernArgs k
       }
       // ---- when run m - 1 is committed: the first r entries whose node the runs in front left alone are the run's candidates
       const unsigned long long tp1 = K9S_NOW();
-      if (!k9s_wait(Y, &Y.seq_done, m) || k9s_ld(&Y.stop)) break;
+      if (!k9s_wait(Y, &Y.seq_done, m, nap_prep) || k9s_ld(&Y.stop)) break;
       K9S_TR(0, tp1);
       const uint32_t nd = Y.nd_at[m & 3u];
       const bool keep = lane < nf && !((bitmap[n >> 5] >> (n & 31)) & 1u);
@@ -693,6 +696,12 @@ void kb_launch_commit_sel(const KbDev &d, const KbRound &r, void *stream) {
   const size_t sh = k9_layout(r.n_rows, r.n_mrows, r.L, d.NP, d.R, true).total;
   K9KernArgs ka;
   k9_fill_args(ka, d, r);
+  static const uint32_t naps = [] {   // KB_SEL_SLEEP=prep,dk: s_sleep units (64 clocks) between two polls of a waiting prep / evaluating wave
+    uint32_t pn = 1, dn = 1;
+    if (const char *v = getenv("KB_SEL_SLEEP")) { pn = (uint32_t)atoi(v); if (const char *c = strchr(v, ',')) dn = (uint32_t)atoi(c + 1); }
+    return (pn & 0xFFu) | ((dn & 0xFFu) << 8);
+  }();
+  ka.hot.prewalk = naps;
   static const bool helpers_off = getenv("KB_WARM_HELPERS_OFF") && getenv("KB_WARM_HELPERS_OFF")[0] == '1';   // A/B switch
   hipLaunchKernelGGL(k_commit_select, dim3(helpers_off ? 1u : KB_WARM_GRID), dim3(K9_THREADS), sh, (hipStream_t)stream, ka);
 }

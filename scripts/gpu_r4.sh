@@ -66,6 +66,20 @@ evict)   # 1M x 50k with its third action: host timeline of the evict action (KB
   ( cd /tmp; rocprofv3 --kernel-trace --stats -f csv -d "$P/trace" -o bench -- python $OLDPWD/bench.py --config 5 --preempt --steps 1 --warmup 1 --no-cpu-baseline > "$P/bench_trace.log" 2>&1 )
   head -14 "$out/trace/bench_kernel_stats.csv" | cut -c1-150 | tee -a "$out/summary.txt"
   ;;
+sleep)   # the selection kernel's polls: how long a waiting wave sleeps (KB_SEL_SLEEP=prep,dk), same box, config 3 pinned to the kernel
+  for sl in ${SLEEPS:-1,1 0,0 0,1 1,0}; do
+    bench_ab "c3_sleep_${sl/,/_}" KB_COMMIT_KERNEL=select KB_SEL_SLEEP=$sl -- --config 3 --steps 5 --warmup 2 --verify
+  done
+  bench_ab "survey_sleep_1_1" KB_COMMIT_KERNEL=select KB_SEL_SLEEP=1,1 -- --config 3 --survey-nodes --steps 5 --warmup 2 --verify
+  bench_ab "survey_sleep_16_1" KB_COMMIT_KERNEL=select KB_SEL_SLEEP=16,1 -- --config 3 --survey-nodes --steps 5 --warmup 2 --verify
+  ;;
+c4)   # config 4 (R = 16: scalar dimensions) pinned to the selection kernel, with the R = 16 parity cases
+  timeout 600 python -m pytest tests/test_gpu_parity.py tests/test_gpu_fuzz.py tests/test_gpu_regressions.py -q -m gpu -p no:cacheprovider -k "select" --maxfail=10 > "$out/pytest_select.txt" 2>&1
+  echo "parity / fuzz / regressions on the selection kernel rc=$? $(tail -1 "$out/pytest_select.txt")" | tee -a "$out/summary.txt"
+  bench_ab c4_pinsel KB_COMMIT_KERNEL=select -- --config 4 --steps 5 --warmup 2 --verify
+  bench_ab c4_default -- --config 4 --steps 5 --warmup 2 --verify
+  bench_ab c3_pinsel KB_COMMIT_KERNEL=select -- --config 3 --steps 5 --warmup 2 --verify
+  ;;
 suite)
   timeout 1500 python -m pytest tests -q -m gpu -p no:cacheprovider "$@" > "$out/pytest_gpu.txt" 2>&1; echo "gpu suite rc=$? $(tail -1 "$out/pytest_gpu.txt")" | tee -a "$out/summary.txt"
   ;;
