@@ -299,6 +299,10 @@ typedef struct kb_stats {
   double   reduce_ms;         /* gang ballot + share reduction kernel */
   double   host_order_ms;     /* host time in the order machine (queue/job/task ordering) */
   double   total_ms;          /* wall time of the run_* calls */
+  uint64_t rounds_select;     /* of `rounds`: committed by the selection kernel (k_commit_select); the others by the batch or the run kernel */
+  uint64_t select_runs_clean;   /* selection kernel, runs of >= 2 plain rows: every pick a clean candidate's first placement */
+  uint64_t select_runs_general; /* ... committed by the general selection (entries ranked, contenders walked on) */
+  uint64_t select_runs_serial;  /* ... handed to the serial loop (a table limit, non-integer scalar dimensions) */
 } kb_stats;
 
 typedef struct kb_engine kb_engine;

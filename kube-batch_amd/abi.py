@@ -106,7 +106,8 @@ class Stats(C.Structure):
                 ("rounds", C.c_uint64), ("spec_breaks", C.c_uint64), ("row_fallbacks", C.c_uint64),
                 ("matrix_launches", C.c_uint64), ("matrix_evals", C.c_uint64),
                 ("matrix_ms", C.c_double), ("argmax_ms", C.c_double), ("commit_ms", C.c_double),
-                ("reduce_ms", C.c_double), ("host_order_ms", C.c_double), ("total_ms", C.c_double)]
+                ("reduce_ms", C.c_double), ("host_order_ms", C.c_double), ("total_ms", C.c_double),
+                ("rounds_select", C.c_uint64), ("select_runs_clean", C.c_uint64), ("select_runs_general", C.c_uint64), ("select_runs_serial", C.c_uint64)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}

@@ -635,6 +635,8 @@ void round_collect(kb_engine *e, const RoundCtx &c, bool had_candidates, uint32_
   }
   if (e->commit_kernel_of[c.buf] == KB_COMMIT_SELECT) {
     e->sel_stat[0] += h_result[6] & 0xFFFFu; e->sel_stat[1] += h_result[6] >> 16; e->sel_stat[2] += h_result[7] & 0xFFFFu; e->sel_stat[3] += h_result[7] >> 16;
+    e->stats.rounds_select += 1;
+    e->stats.select_runs_clean += h_result[6] & 0xFFFFu; e->stats.select_runs_general += h_result[6] >> 16; e->stats.select_runs_serial += h_result[7] & 0xFFFFu;
   }
   if (run_like) {
     e->k5_slots += h_result[2];

@@ -367,3 +367,24 @@ def test_full_size_properties_config3():
     e.reset()
     dec2 = e.run(["allocate", "backfill"])
     assert np.array_equal(dec, dec2) and np.array_equal(e.binds(), binds)
+
+
+def test_the_pinned_commit_kernel_is_the_one_that_runs(oracle_mod, commit_kernel):
+    """KB_COMMIT_KERNEL pins the kernel for every round (the suite's three-way axis would mean nothing otherwise), and under `select` the runs
+    of two or more plain rows really go through the selection — not through the serial loop it keeps as a fall-back: kb_stats counts them."""
+    snap = kbm.snapshot.synth(kbm.snapshot.synth_config(2, 1.0))
+    cfg = kbm.conf.load_scheduler_conf()
+    e = engine.Engine(cfg)
+    e.load(snap)
+    dec = e.run(["allocate", "backfill"])
+    st = e.stats()
+    o = oracle_mod.Oracle(cfg, snap)
+    o.run(["allocate", "backfill"])
+    assert np.array_equal(dec, o.decisions())
+    if commit_kernel == "select":
+        assert st["rounds_select"] == st["rounds"] > 10
+        by_selection = st["select_runs_clean"] + st["select_runs_general"]
+        assert by_selection > 200 and st["select_runs_serial"] < 0.2 * by_selection, st
+    elif commit_kernel in ("batch", "run"):   # (unpinned — the emulated-device re-collection — the engine chooses per round)
+        assert st["rounds_select"] == 0 and st["select_runs_clean"] == 0 and st["select_runs_general"] == 0
+    e.close(); o.close()
