@@ -1839,9 +1839,9 @@ static int run_evict_action(kb_engine *e, bool reclaim, kb_stmt_op *out, uint64_
     e->stats.total_ms += now_ms() - t_begin;
     static const bool ev_trace = [] { const char *v = getenv("KB_EVICT_TRACE"); return v && v[0] == '1'; }();
     if (ev_trace)   // host timeline of the action (profiles/round4)
-      fprintf(stderr, "[kb evict] %s: entry (state to the host, machine set-up) %.2f ms; machine %.2f ms of which %llu lists %.2f ms on the device + %.2f ms host reorder, %llu node refreshes %.2f ms; exit (journal, state back, finalize, checks) %.2f ms; popped %llu, journal %zu\n",
+      fprintf(stderr, "[kb evict] %s: entry (state to the host, machine set-up) %.2f ms; machine %.2f ms of which %llu lists %.2f ms on the device + %.2f ms host reorder, %llu node refreshes %.2f ms; exit (journal, state back, finalize, checks) %.2f ms; popped %llu (walked %llu: %.2f ms, %llu nodes tried; skipped with their job %llu, turned away one by one %llu, own-job preemptors the priority rule excludes %llu), journal %zu\n",
               reclaim ? "reclaim" : "preempt", t_e1 - t_e0, t_e2 - t_e1, (unsigned long long)n_lists, tl_lists, tl_lists_host, (unsigned long long)n_refresh, tl_refresh, now_ms() - t_e2,
-              (unsigned long long)pm.popped, pm.ops.size());
+              (unsigned long long)pm.popped, (unsigned long long)pm.tr_walks, pm.tr_walk_ms, (unsigned long long)pm.tr_tries, (unsigned long long)pm.tr_skipped, (unsigned long long)pm.tr_shortcut, (unsigned long long)pm.tr_pruned, pm.ops.size());
     taint.armed = false;
   });
 }

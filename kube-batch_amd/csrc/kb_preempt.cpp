@@ -1,6 +1,7 @@
 // kb_preempt.cpp — host side of the engine's preempt action; see kb_preempt.hpp.
 #include "kb_preempt.hpp"
 
+#include <chrono>
 #include <cstdlib>
 
 #include <climits>
@@ -65,6 +66,9 @@ struct TaskQueues {
   }
   bool empty(uint32_t j) const { return cur[j] == off[j + 1]; }
   uint32_t pop(uint32_t j) { return items[cur[j]++]; }
+  const uint32_t *rest(uint32_t j) const { return items.data() + cur[j]; }   // what is left of job j's queue, in pop order
+  uint32_t left(uint32_t j) const { return off[j + 1] - cur[j]; }
+  void drain(uint32_t j) { cur[j] = off[j + 1]; }
 };
 
 }  // namespace
@@ -428,13 +432,15 @@ size_t PreemptMachine::evictable(uint32_t preemptor, const std::vector<uint32_t>
   const size_t n = pre.size();
   bool init = false;
   victims.clear();
-  std::vector<uint8_t> keep(n ? n : 1);
+  std::vector<uint8_t> &keep = scratch_keep_;   // (members: a node tried costs no allocation)
+  keep.assign(n ? n : 1, 0);
   for (const std::vector<uint8_t> &tier : (reclaim ? pol_->reclaim_tiers : pol_->preempt_tiers)) {
     for (uint8_t plugin : tier) {
       std::fill(keep.begin(), keep.end(), 0);
       if (plugin == KB_PLUGIN_PROPORTION) {   // proportion.go:171-196: running per-queue allocation, in reclaimee order
-        std::vector<uint32_t> aq;
-        std::vector<Res> alloc;
+        std::vector<uint32_t> &aq = scratch_ids_;
+        std::vector<Res> &alloc = scratch_alloc_;
+        aq.clear(); alloc.clear();
         for (size_t i = 0; i < n; i++) {
           const uint32_t q = hs_->job_queue[hs_->t_job[pre[i]]];
           if (q >= hs_->Q) continue;
@@ -470,8 +476,9 @@ size_t PreemptMachine::evictable(uint32_t preemptor, const std::vector<uint32_t>
         for (int d = 0; d < R; d++) lalloc.v[d] = jalloc[(size_t)pj * R + d];
         res_add(lalloc, task_res(preemptor), R);
         const double ls = drf_share(lalloc.v, lalloc.mask);
-        std::vector<uint32_t> ajob;
-        std::vector<Res> alloc;
+        std::vector<uint32_t> &ajob = scratch_ids_;
+        std::vector<Res> &alloc = scratch_alloc_;
+        ajob.clear(); alloc.clear();
         for (size_t i = 0; i < n; i++) {
           const uint32_t jb = hs_->t_job[pre[i]];
           size_t a = 0;
@@ -536,10 +543,12 @@ bool PreemptMachine::host_eval(uint32_t t, uint32_t n, long long &score) const {
 // one node of preempt()'s walk (preempt.go:195-254); mode 0: victims are Running tasks of OTHER jobs in the preemptor job's queue,
 // mode 1: of the preemptor's own job
 bool PreemptMachine::try_node(uint32_t preemptor, int mode, uint32_t n) {
+  tr_tries++;
   const int R = hs_->R;
   const uint32_t pj = hs_->t_job[preemptor], pq = hs_->job_queue[pj];
   if (prio_prunes_ && mode == 0 && pq < hs_->Q && minprio(pq, n) >= hs_->job_prio[pj]) return false;   // no task the priority rule would let go
-  std::vector<uint32_t> pre, victims;
+  std::vector<uint32_t> &pre = scratch_pre_, &victims = scratch_victims_;   // (members: no allocation per node tried)
+  pre.clear(); victims.clear();
   for (uint32_t t : ntasks_[n]) {   // node.Tasks in canonical order, filtered (preempt.go:112-124 / :150-157)
     if (node_status[t] != KB_TASK_RUNNING) continue;
     const uint32_t j = hs_->t_job[t];
@@ -575,14 +584,16 @@ bool PreemptMachine::preempt_one(uint32_t preemptor, int mode) {
   popped++;
   evals += hs_->N;
   // with the priority rule in the deciding tier a task of the preemptor's own job can never be a victim
-  if (prio_prunes_ && mode == 1) return false;
+  if (prio_prunes_ && mode == 1) { tr_pruned++; return false; }
   // What a preemptor tries depends on its job, its matrix row and its Resreq alone, so when one found nothing AND left everything as it
   // was (try_node evicts only once the victims are known to cover InitResreq; the version check covers the rounding corner where the
   // evictions then fall short), the next task of the same job with the same three, met before anything else moved, finds nothing
   // either.  The tasks of a gang are popped back to back: one walk per job instead of one per task.
-  if (fail_version_ == version_ && fail_mode_ == mode && same_preemptor_class(fail_task_, preemptor)) return false;
+  if (fail_version_ == version_ && fail_mode_ == mode && same_preemptor_class(fail_task_, preemptor)) { tr_shortcut++; return false; }
   const uint64_t before = version_;
+  const auto tw0 = std::chrono::steady_clock::now();
   const bool found = preempt_walk(preemptor, mode);
+  tr_walks++; tr_walk_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tw0).count();
   if (!found && version_ == before) { fail_version_ = version_; fail_mode_ = mode; fail_task_ = preemptor; }
   return found;
 }
@@ -754,6 +765,9 @@ void PreemptMachine::run() {
     }
   }
   jtasks.build(J, hs_->job_begin, under, *status_, tl);
+  std::vector<uint32_t> active;   // under-request jobs whose task queue is not empty, ascending
+  for (uint32_t j = 0; j < J; j++)
+    if (under[j] && !jtasks.empty(j)) active.push_back(j);
   for (uint32_t q = 0; q < Q; q++) {
     if (!qseen[q]) continue;
     for (;;) {   // between jobs within the queue (preempt.go:80-139)
@@ -764,14 +778,32 @@ void PreemptMachine::run() {
       for (;;) {
         if (jtasks.empty(pj)) break;
         const uint32_t preemptor = jtasks.pop(pj);
-        if (preempt_one(preemptor, 0)) assigned = true;
+        const bool got = preempt_one(preemptor, 0);
+        if (got) assigned = true;
         if (job_pipelined(pj)) { commit(); break; }
+        // The tasks of a gang are popped back to back and are the same preemptor (job, matrix row, Resreq): when this one found nothing and
+        // left everything as it was, each of the others would be popped, counted and turned away by preempt_one's first lines, one by one,
+        // with nothing moving in between (the job is not pipelined and stays so).  Count them all at once.
+        if (!got && fail_version_ == version_ && fail_mode_ == 0 && fail_task_ != KB_NONE && same_preemptor_class(fail_task_, preemptor)) {
+          const uint32_t nrest = jtasks.left(pj);
+          const uint32_t *rest = jtasks.rest(pj);
+          bool all_same = true;
+          for (uint32_t i = 0; i < nrest && all_same; i++) all_same = same_preemptor_class(preemptor, rest[i]);
+          if (all_same && nrest) {
+            popped += nrest; evals += (uint64_t)nrest * hs_->N; tr_skipped += nrest;
+            jtasks.drain(pj);
+          }
+        }
       }
       if (!job_pipelined(pj)) { discard(); continue; }
       if (assigned) qjobs[q].push(pj);
     }
-    for (uint32_t j = 0; j < J; j++) {   // between tasks within a job (preempt.go:142-166)
-      if (!under[j]) continue;
+    // between tasks within a job (preempt.go:142-166): EVERY under-request job, once per queue of the outer loop, in ascending job order.
+    // Only the jobs that still have a pending task in their queue do anything: they are kept as a list (1M x 50k: 100k jobs x 128
+    // queues of empty visits otherwise)
+    size_t keep = 0;
+    for (size_t ai = 0; ai < active.size(); ai++) {
+      const uint32_t j = active[ai];
       for (;;) {
         if (jtasks.empty(j)) break;
         const uint32_t preemptor = jtasks.pop(j);
@@ -780,7 +812,9 @@ void PreemptMachine::run() {
         commit();
         if (!assigned) break;
       }
+      if (!jtasks.empty(j)) active[keep++] = j;
     }
+    active.resize(keep);
   }
 }
 
