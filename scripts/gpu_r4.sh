@@ -4,6 +4,7 @@
 #   trace    the selection kernel's per-phase cycle trace (configs 3 and 4)
 #   profile  rocprofv3: kernel stats, HBM bytes of the matrix launches, SQ counters of the commit kernels (scripts/summarize_profile.py r4_profile profiles/round4)
 #   evict    1M x 50k allocate + backfill + preempt: host timeline of the evict action, session-load phases, kernel stats
+#   hunt     fresh-seed differential hunt under the three commit kernels
 #   suite    the whole -m gpu suite
 #   bench    the default bench line and the variants
 set -uo pipefail
@@ -79,6 +80,9 @@ c4)   # config 4 (R = 16: scalar dimensions) pinned to the selection kernel, wit
   bench_ab c4_pinsel KB_COMMIT_KERNEL=select -- --config 4 --steps 5 --warmup 2 --verify
   bench_ab c4_default -- --config 4 --steps 5 --warmup 2 --verify
   bench_ab c3_pinsel KB_COMMIT_KERNEL=select -- --config 3 --steps 5 --warmup 2 --verify
+  ;;
+hunt)   # fresh seeds beyond the committed suite, engine vs oracle under the three commit kernels (scripts/gpu_hunt.py; KB_HUNT_OFFSET shifts the seeds)
+  KB_HUNT_OFFSET=${KB_HUNT_OFFSET:-40000} timeout 1200 python scripts/gpu_hunt.py ${1:-300} ${2:-900} ${3:-400} > "$out/hunt.txt" 2>&1; echo "hunt rc=$? $(tail -2 "$out/hunt.txt" | tr '\n' ' ')" | tee -a "$out/summary.txt"
   ;;
 suite)
   timeout 1500 python -m pytest tests -q -m gpu -p no:cacheprovider "$@" > "$out/pytest_gpu.txt" 2>&1; echo "gpu suite rc=$? $(tail -1 "$out/pytest_gpu.txt")" | tee -a "$out/summary.txt"
