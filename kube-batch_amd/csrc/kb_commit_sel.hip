@@ -66,7 +66,7 @@ __global__ void __launch_bounds__(K9_THREADS) k_commit_select(const K9KernArgs k
   const K9Layout lo = k9_layout(W, S, a.L, a.NP, a.R, true);
   unsigned char *k9_base_ = k9_smem;
   K9_LDS_VIEWS(lo)
-  (void)shp; (void)S; (void)dk;
+  (void)shp; (void)S; (void)dk; (void)ckey; (void)cpos;
   K9Sel &X = *reinterpret_cast<K9Sel *>(k9_smem + lo.sel);
   K9Sync &Y = X.sync;
   const unsigned long long t_start = wall_clock64();
@@ -138,6 +138,9 @@ __global__ void __launch_bounds__(K9_THREADS) k_commit_select(const K9KernArgs k
   if (wave == 0) {
     // =================================================== wave 0: the selection ===================================================
     uint32_t nd = 0, n_dirty_rows = 0, n_runs = 0, n_slow = 0, i_end = 0, reason_end = KB_REASON_DONE;
+    uint32_t prev_nd0 = 0, prev_pc = 0;   // the run in front: dirty slots when it started, clean candidates it consumed
+    bool prev_chg = true;                 // ... whether it changed slots in any other way (then the early dirty keys of this run are not final)
+    bool prev_all = false;                // ... and whether it took every candidate of its own (then this run's candidates, settled ahead on that assumption, stand)
     for (uint32_t k = 0; k < K; k++) {
       K9S_RUN_HEADER(k)
       K9_STAMP(3);
@@ -145,28 +148,36 @@ __global__ void __launch_bounds__(K9_THREADS) k_commit_select(const K9KernArgs k
         uint32_t spins = 0;
         bool ok = true;
         for (;;) {
-          const uint32_t v = (lane < 5u) ? k9s_ld(&Y.seq_cand + lane) : 0xFFFFFFFFu;
+          // lane 0: the candidates — settled ahead (seq_spec) when the run in front took all of its own, else settled behind it (seq_cand);
+          // lanes 1..4: the dirty keys — the early ones (seq_early) when the run in front changed nothing else, else the final ones (seq_dk)
+          const uint32_t *wp = (lane == 0u) ? (prev_all ? &Y.seq_spec : &Y.seq_cand) : (prev_chg ? &Y.seq_dk[(lane - 1u) & 3u] : &Y.seq_early[(lane - 1u) & 3u]);
+          const uint32_t v = (lane < 5u) ? k9s_ld(wp) : 0xFFFFFFFFu;
           if (__ballot(v < k + 1u) == 0ull) break;
           if ((++spins & 31u) == 0u && (k9s_ld(&Y.err) || spins > K9S_SPIN_LIMIT)) { k9s_st(&Y.err, 1u); ok = false; break; }
           __builtin_amdgcn_s_sleep(1);
         }
         if (!ok) { reason_end = KB_REASON_INTERNAL; i_end = i0; break; }
       }
+      if (prev_all && lane == 0) k9s_st(&Y.seq_cand, k + 1u);   // the candidates settled ahead are the candidates: the evaluating waves may build on them
       const uint32_t ncand = Y.ncand_at[k & 3u];
+      const K9Sel::Cand &CD = X.cand[k & 1u];
       const uint32_t *dk = X.dkb[k & 1u];
       uint32_t *chg = Y.chg[k & 1u];
       if (lane < 10u) chg[lane] = 0u;
       K9_STAMP(0);
       uint32_t ck = 0, k1 = 0, ckind = 0, ckind1 = 0;
       uint32_t rnm = 0;
-      if (lane < ncand) { ck = ckey[lane]; k1 = X.ck1[lane]; ckind = X.ckind[lane]; ckind1 = X.ckind1[lane]; rnm = X.crnm[lane]; }
-      uint32_t m = (lane < 4u) ? Y.mdk[k & 1u][lane] : 0u;   // best dirty key: the evaluating waves' maxima; clean winners update it in O(1)
-      m = max(max(rl32(m, 0), rl32(m, 1)), max(rl32(m, 2), rl32(m, 3)));
+      if (lane < ncand) { ck = CD.ckey[lane]; k1 = CD.ck1[lane]; ckind = CD.ckind[lane]; ckind1 = CD.ckind1[lane]; rnm = CD.crnm[lane]; }
+      // best dirty key: the evaluating waves' maxima (clean winners update it in O(1)).  From the early evaluation: the maxima over the slots
+      // that were dirty before the run in front, and the keys of the candidates it consumed
+      uint32_t m = (lane < 4u) ? (prev_chg ? Y.mdk[k & 1u][lane] : Y.mdko[k & 1u][lane]) : 0u;
+      if (!prev_chg && lane >= 4u && lane - 4u < prev_pc) m = dk[prev_nd0 + lane - 4u];   // prev_pc <= K9_SEL_MAXRUN
+      m = wave_max_u32(m);
       double res0 = sh.init0, res1 = sh.init1;
       if (!plain0) { res0 = rres[0]; res1 = rres[1]; }
       // cmin: the r-th best clean candidate's key — r entries are at or above it, so no entry below it is among the picks (0: the list
       // holds fewer than r clean nodes)
-      const uint32_t cmin = (sel_run && ncand == r) ? ckey[r - 1u] : 0u;
+      const uint32_t cmin = (sel_run && ncand == r) ? CD.ckey[r - 1u] : 0u;
       // dirty keys of the shape: old slot t in lane t & 63, register t >> 6 — fetched only where a dirty slot can be picked
       uint32_t d0 = 0u, d1 = 0u, d2 = 0u, d3 = 0u;
       bool have_d = false;
@@ -491,12 +502,16 @@ __global__ void __launch_bounds__(K9_THREADS) k_commit_select(const K9KernArgs k
         const uint32_t fln = (uint32_t)__builtin_amdgcn_readfirstlane((int)rinfo[i_next].z);
         if (fln & 2u) { reason = KB_REASON_RENORM; stop = 1u; }
       }
-      if (lane == 0 && pc) cursor[s] = cpos[pc - 1] + 1;
+      if (lane == 0 && pc) cursor[s] = CD.cpos[pc - 1] + 1;
+      prev_nd0 = nd; prev_pc = pc; prev_all = pc == ncand;
+      K9_WAVE_FENCE();
+      prev_chg = __ballot(lane < 10u && chg[lane < 10u ? lane : 0u] != 0u) != 0ull;
       nd += pc; n_dirty_rows += n_dirty; n_runs += 1u; n_slow += plain0 ? 0u : 1u;
       i_end = i_next; reason_end = reason;
       // publish: everything this run wrote (slots, bitmap, cursor, decision records) is in LDS before the word moves
       if (lane == 0) {
         Y.nd_at[(k + 1u) & 3u] = nd;
+        Y.spec_ok[(k + 1u) & 3u] = prev_all ? 1u : 0u;
         if (stop) k9s_st(&Y.stop, 1u);
         k9s_st(&Y.seq_done, k + 1u);
       }
@@ -527,8 +542,12 @@ __global__ void __launch_bounds__(K9_THREADS) k_commit_select(const K9KernArgs k
           key = k9_eval_v(a, sh, vs, scp, gi, gr, si, 0u, 0.0, si, nb, nmaskbits);
           // what the slot's next placement of the shape would be (allocate.go:160) — the selection reads it for the slots it considers
           if (sel_run) dkko[t] = k9_fits_idle(a, sh, vs.idle0, vs.idle1, scp, gi, si, vs.node, 0u, 0.0, si) ? 0u : 1u;
+          dko[t] = key;
         }
+        const uint32_t wmo = wave_max_u32(t < Y.nd_at[(q - 1u) & 3u] ? key : 0u);
+        if (lane == 0) Y.mdko[q & 1u][wave - 1u] = wmo;
       }
+      if (lane == 0) k9s_st(&Y.seq_early[wave - 1u], q + 1u);
       if (wave == 1u) K9S_TR(3, tw0);
       const unsigned long long tw1 = K9S_NOW();
       if (!k9s_wait(Y, &Y.seq_done, q, nap_dk) || k9s_ld(&Y.stop)) break;   // run q - 1 is committed: the slots are final
@@ -643,26 +662,47 @@ __global__ void __launch_bounds__(K9_THREADS) k_commit_select(const K9KernArgs k
           if (sel_run && !kind) kind1 = k9_fits_idle(a, sh, v.idle0, v.idle1, scn, gi, si, n, adjm, 1.0, rqv) ? 0u : 1u;   // a second placement on it
         }
       }
-      // ---- when run m - 1 is committed: the first r entries whose node the runs in front left alone are the run's candidates
+      // ---- the run's candidates: the first r entries whose node the runs in front leave alone, stored as its future dirty slots.  Settled
+      //      AHEAD, while run m - 1 is being selected, on the assumption that it takes every candidate of its own (most runs do: then their nodes
+      //      are exactly what gets dirty and the next slot is known); wave 0 says whether that held (spec_ok), and if not the same step runs
+      //      again behind run m - 1 against the bitmap as it then is.
+      K9Sel::Cand &CD = X.cand[m & 1u];
+      auto settle = [&](bool ahead) {
+        uint32_t nd0 = Y.nd_at[m & 3u];
+        bool keep = lane < nf && !((bitmap[n >> 5] >> (n & 31)) & 1u);
+        if (ahead) {   // m >= 1: run m - 1's candidates are final (seq_cand >= m); its nodes count as taken, its slots as used
+          const K9Sel::Cand &CP = X.cand[(m - 1u) & 1u];
+          const uint32_t ncp = Y.ncand_at[(m - 1u) & 3u];
+          nd0 = Y.nd_at[(m - 1u) & 3u] + ncp;
+          for (uint32_t i = 0; i < ncp; i++) keep = keep && (nmaskbits - (CP.ckey[i] & nmaskbits)) != n;
+        }
+        const unsigned long long kb = __ballot(keep);
+        const uint32_t rho = (uint32_t)__popcll(kb & lt);
+        const uint32_t ncand = min((uint32_t)__popcll(kb), r);
+        if (keep && rho < r) {
+          unsigned long long *st = slots + (size_t)(nd0 + rho) * K9_NF;
+          st[F_IDLE0] = d2u(v.idle0); st[F_IDLE1] = d2u(v.idle1); st[F_REL0] = d2u(v.rel0); st[F_REL1] = d2u(v.rel1);
+          st[F_INVAC] = raw[F_INVAC]; st[F_INVAM] = raw[F_INVAM]; st[F_AC] = d2u(v.ac); st[F_AM] = d2u(v.am);
+          st[F_NZC] = d2u(v.nzc); st[F_NZM] = d2u(v.nzm); st[F_PORTS] = v.ports;
+          st[F_CLS_LEFT] = (unsigned long long)rcls | ((unsigned long long)(uint32_t)v.left << 32);
+          st[F_NODE_NMASK] = (unsigned long long)n | ((unsigned long long)rnm << 32);
+          CD.ckey[rho] = key; CD.cpos[rho] = mypos;
+          CD.ckind[rho] = kind; CD.ck1[rho] = k1; CD.ckind1[rho] = kind1; CD.crnm[rho] = rnm;
+        }
+        if (lane == 0) Y.ncand_at[m & 3u] = ncand;
+      };
+      if (m >= 1u) {
+        if (!k9s_wait(Y, &Y.seq_cand, m, nap_prep) || k9s_ld(&Y.stop)) break;   // run m - 1's candidates stand (and run m - 2 is committed)
+        settle(true);
+        if (lane == 0) k9s_st(&Y.seq_spec, m + 1u);
+      }
       const unsigned long long tp1 = K9S_NOW();
       if (!k9s_wait(Y, &Y.seq_done, m, nap_prep) || k9s_ld(&Y.stop)) break;
       K9S_TR(0, tp1);
-      const uint32_t nd = Y.nd_at[m & 3u];
-      const bool keep = lane < nf && !((bitmap[n >> 5] >> (n & 31)) & 1u);
-      const unsigned long long kb = __ballot(keep);
-      const uint32_t rho = (uint32_t)__popcll(kb & lt);
-      const uint32_t ncand = min((uint32_t)__popcll(kb), r);
-      if (keep && rho < r) {
-        unsigned long long *st = slots + (size_t)(nd + rho) * K9_NF;
-        st[F_IDLE0] = d2u(v.idle0); st[F_IDLE1] = d2u(v.idle1); st[F_REL0] = d2u(v.rel0); st[F_REL1] = d2u(v.rel1);
-        st[F_INVAC] = raw[F_INVAC]; st[F_INVAM] = raw[F_INVAM]; st[F_AC] = d2u(v.ac); st[F_AM] = d2u(v.am);
-        st[F_NZC] = d2u(v.nzc); st[F_NZM] = d2u(v.nzm); st[F_PORTS] = v.ports;
-        st[F_CLS_LEFT] = (unsigned long long)rcls | ((unsigned long long)(uint32_t)v.left << 32);
-        st[F_NODE_NMASK] = (unsigned long long)n | ((unsigned long long)rnm << 32);
-        ckey[rho] = key; cpos[rho] = mypos;
-        X.ckind[rho] = kind; X.ck1[rho] = k1; X.ckind1[rho] = kind1; X.crnm[rho] = rnm;
+      if (m == 0u || !Y.spec_ok[m & 3u]) {   // (otherwise wave 0 takes the candidates settled ahead and announces them itself)
+        settle(false);
+        if (lane == 0) k9s_st(&Y.seq_cand, m + 1u);
       }
-      if (lane == 0) { Y.ncand_at[m & 3u] = ncand; k9s_st(&Y.seq_cand, m + 1u); }
     }
   }
 #ifdef KB_K9_TRACE

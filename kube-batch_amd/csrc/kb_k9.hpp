@@ -41,10 +41,14 @@ struct K9Sync {
   uint32_t seq_done;                  // runs committed (wave 0)
   uint32_t seq_cand;                  // runs whose candidates are in LDS (the run's prep wave)
   uint32_t seq_dk[4];                 // runs whose dirty keys are in LDS, per evaluating wave
+  uint32_t seq_early[4];              // runs whose EARLY dirty keys are in LDS (final unless the run in front lists changed slots)
+  uint32_t seq_spec;                  // runs whose candidates are in LDS ON THE ASSUMPTION that the run in front takes every candidate of its own
+  uint32_t spec_ok[4];                // [m & 3]: that assumption held for run m (wave 0, in front of seq_done = m; four deep: a prep wave may read its run's word late)
   uint32_t stop, err;                 // the round is over (wave 0); a wait ran out of patience
   uint32_t nd_at[4];                  // [k & 3]: dirty slots when run k starts (wave 0, in front of seq_done = k)
   uint32_t ncand_at[4];               // [k & 3]: candidates of run k (its prep wave, in front of seq_cand = k + 1)
   uint32_t mdk[2][4];                 // [k & 1][w]: best dirty key of run k's shape among evaluating wave w's slots
+  uint32_t mdko[2][4];                // ... among the slots that were dirty before run k - 1 (the early evaluation; run k - 1's consumed candidates: dkb)
   uint32_t chg[2][10];                // [k & 1]: slots run k changed other than by consuming a clean candidate once (what an early evaluation for run k + 1 got wrong)
 };
 struct K9Sel {
@@ -52,7 +56,7 @@ struct K9Sel {
   K9Prep prep[3];                     // one per prep wave
   uint16_t runs[KB_K5_MAX_ROWS];      // first row of run k
   uint32_t brk[8], stm[8];            // row masks: the row cannot join its predecessor / the row starts a run
-  uint32_t ckind[64], ck1[64], ckind1[64], crnm[64];   // per surviving candidate (P2's results, written by the prep wave, read by wave 0)
+  struct Cand { uint32_t ckey[64], cpos[64], ckind[64], ck1[64], ckind1[64], crnm[64]; } cand[2];   // [m & 1]: run m's candidates (its prep wave writes them — possibly ahead, see seq_spec —, wave 0 reads them)
   uint32_t dkb[2][K9_MAXSLOTS];       // [k & 1][t]: key(shape of run k, dirty slot t)
   uint32_t dkk[2][K9_MAXSLOTS];       // [k & 1][t]: slot t's next placement of the run's shape would be a Pipeline (allocate.go:160)
   unsigned long long e_comp[64];      // entries: prefix-minimum key << 8 | 255 - step  (greater = picked earlier)

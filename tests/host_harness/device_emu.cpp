@@ -410,7 +410,7 @@ size_t kb_commit_smem_bytes(uint32_t n_rows, uint32_t n_shapes, uint32_t NP, int
   off += 3 * (size_t)R * 8 + (size_t)n_shapes * RS * 8 + (size_t)n_shapes * 64 + (size_t)n_rows * sizeof(KbRowDesc);
   off = (off + 15) & ~(size_t)15;
   off += (size_t)n_rows * 16 + (size_t)n_rows * 8 + 48 + 256 * 4 + 64 * 4 + 64 * 4 + (size_t)n_shapes * 4 + (size_t)n_shapes * 4;
-  off += (size_t)n_shapes * ((size_t)n_rows + 1) * 4 + (size_t)(NP / 32) * 4 + 8900 /* the selection kernel's block */ + lds_penalty();
+  off += (size_t)n_shapes * ((size_t)n_rows + 1) * 4 + (size_t)(NP / 32) * 4 + 10500 /* the selection kernel's block */ + lds_penalty();
   return (off + 15) & ~(size_t)15;
 }
 size_t kb_commit_batch_smem_bytes(uint32_t cap, uint32_t NP, int R) {
