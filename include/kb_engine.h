@@ -64,7 +64,7 @@
 extern "C" {
 #endif
 
-#define KB_ABI_VERSION 7u
+#define KB_ABI_VERSION 8u
 #define KB_MAX_RES 32u          /* resource dimensions: 0 = cpu (milli), 1 = memory (bytes), 2.. = scalar resources (milli) */
 #define KB_NONE 0xFFFFFFFFu
 
@@ -247,13 +247,17 @@ typedef struct kb_snapshot {
   /* host ports (predicates.PodFitsHostPorts, vendor/.../algorithm/predicates/predicates.go:1153-1175 over
      nodeinfo.HostPortInfo, vendor/.../nodeinfo/host_ports.go:107-135): the caller interns every distinct
      (hostIP, protocol, hostPort) of the session's pods that can conflict with a port of a Pending pod (the only pods the
-     predicate is asked for; the others' ports can never decide anything) into a bit 0..63.  node_ports[n] = bits used by the pods in
-     ni.Tasks; task_port_want[t] = bits the pod occupies once placed; task_port_conflict[t] = every bit that conflicts with
-     one of the pod's ports (same protocol and port, and equal IPs or either side 0.0.0.0).  A node fails the predicate
-     iff node_ports & task_port_conflict != 0; placing the pod ORs task_port_want in.  All three NULL => no host ports. */
-  const uint64_t *node_ports;          /* [N] */
-  const uint64_t *task_port_want;      /* [T] */
-  const uint64_t *task_port_conflict;  /* [T] */
+     predicate is asked for; the others' ports can never decide anything) into a bit: triple i is bit i % 64 of word i / 64 of a
+     mask of Wh = max(1, port_words) 64-bit words (port_words, at the end of this struct; any number of triples).
+     node_ports[n] = bits used by the pods in ni.Tasks; task_port_want[t] = bits the pod occupies once placed;
+     task_port_conflict[t] = every bit that conflicts with one of the pod's ports (same protocol and port, and equal IPs or
+     either side 0.0.0.0).  A node fails the predicate iff node_ports & task_port_conflict != 0 in any word; placing the pod ORs
+     task_port_want in.  All three NULL => no host ports.  Word 0 is the fast one: a Pending pod whose masks reach into the
+     words behind it is decided in a device round of its own, so the flattener hands the low bits to the
+     triples the Pending pods name most often (kube-batch_amd/snapshot.py, integration/go/gpuallocate/flatten.go). */
+  const uint64_t *node_ports;          /* [N][Wh] */
+  const uint64_t *task_port_want;      /* [T][Wh] */
+  const uint64_t *task_port_conflict;  /* [T][Wh] */
 
   /* conformance plugin (plugins/conformance/conformance.go:44-58): 1 = the pod may not be evicted (kube-system namespace or a
      system-cluster-critical / system-node-critical priority class).  Read by kb_run_preempt; NULL => no pod is protected. */
@@ -261,6 +265,9 @@ typedef struct kb_snapshot {
 
   /* inter-pod (anti)affinity tables; NULL => no pod of the cluster carries a podAffinity / podAntiAffinity term */
   const kb_interpod *interpod;
+
+  uint32_t port_words;             /* Wh: 64-bit words per host-port mask; 0 reads as 1 */
+  uint32_t pad;
 } kb_snapshot;
 
 /* one placement decision, in the order the reference loop would have made it */

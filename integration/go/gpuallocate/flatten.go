@@ -214,8 +214,8 @@ func taskClassKey(t *api.TaskInfo, pf pressureFlags) (string, error) {
 // host ports: a distinct (hostIP, protocol, hostPort > 0) of the session's pods is one bit (nodeinfo/host_ports.go sanitises "" to
 // 0.0.0.0 / TCP) if it can ever take part in a conflict test.  PodFitsHostPorts is only asked for a Pending task (allocate, backfill, the
 // preemptors of preempt / reclaim) and a placement adds a Pending task's own ports: a triple that conflicts with no Pending task's port
-// (what the daemons already on the nodes listen on, usually) can never decide anything and gets no bit.  More than 64 of the rest ->
-// the stock action takes the cycle
+// (what the daemons already on the nodes listen on, usually) can never decide anything and gets no bit.  Any number of the rest: masks of
+// portTable.words() 64-bit words (kb_snapshot.port_words)
 type hostPort struct {
 	ip, proto string
 	port      int32
@@ -291,11 +291,33 @@ func newPortTable(ssn *framework.Session) (*portTable, error) {
 		}
 	}
 	pt.all = kept
+	// Any number of triples: masks of words() 64-bit words (kb_snapshot.port_words).  The engine decides a Pending pod whose masks reach
+	// beyond word 0 in a device round of its own, so with more than 64 triples the ones the Pending pods' ports conflict with most often
+	// take the low bits (the same rule as kube-batch_amd/snapshot.py; ties and the <= 64 case: ascending ip, protocol, port).
+	weight := map[hostPort]int{}
 	if len(pt.all) > 64 {
-		return nil, errUnsupported("more than 64 distinct host ports that a pending pod's ports can conflict with")
+		for _, j := range ssn.Jobs {
+			for _, t := range j.Tasks {
+				if t.Status != api.Pending {
+					continue
+				}
+				mine := podHostPorts(t.Pod)
+				for _, hp := range pt.all {
+					for _, a := range mine {
+						if portsConflict(a, hp) {
+							weight[hp]++
+							break
+						}
+					}
+				}
+			}
+		}
 	}
 	sort.Slice(pt.all, func(i, j int) bool {
 		a, b := pt.all[i], pt.all[j]
+		if weight[a] != weight[b] {
+			return weight[a] > weight[b]
+		}
 		if a.ip != b.ip {
 			return a.ip < b.ip
 		}
@@ -310,22 +332,34 @@ func newPortTable(ssn *framework.Session) (*portTable, error) {
 	return pt, nil
 }
 
-func (pt *portTable) masks(pod *v1.Pod) (want, conflict uint64) {
+// 64-bit words per mask (kb_snapshot.port_words)
+func (pt *portTable) words() int {
+	if len(pt.all) <= 64 {
+		return 1
+	}
+	return (len(pt.all) + 63) / 64
+}
+
+// masks ORs the pod's bits into want / conflict, two rows of words() words (triple i: bit i % 64 of word i / 64)
+func (pt *portTable) masks(pod *v1.Pod, want, conflict []uint64) {
 	mine := podHostPorts(pod)
 	for _, hp := range mine {
 		if b, ok := pt.bit[hp]; ok { // no bit: the triple conflicts with no pending pod's port
-			want |= 1 << b
+			want[b/64] |= 1 << (b % 64)
 		}
+	}
+	if conflict == nil {
+		return
 	}
 	for _, other := range pt.all {
 		for _, hp := range mine {
 			if portsConflict(hp, other) {
-				conflict |= 1 << pt.bit[other]
+				b := pt.bit[other]
+				conflict[b/64] |= 1 << (b % 64)
 				break
 			}
 		}
 	}
-	return
 }
 
 // NodeAffinity priority, Map step, for one (task class, node class) pair: the vendored function itself
@@ -463,7 +497,8 @@ func flatten(ssn *framework.Session) (*flat, error) {
 	acpu, amem, nzc, nzm := f.i64(N), f.i64(N), f.i64(N), f.i64(N)
 	maxPods, podCnt := f.i32(N), f.i32(N)
 	nclass := f.u32(N)
-	nports := f.u64(N)
+	Wh := ports.words()
+	nports := f.u64(N * Wh) // [N][Wh]
 	nodeClasses := map[string]uint32{}
 	var nodeClassRep []*api.NodeInfo
 	for i, n := range f.nodes {
@@ -476,8 +511,7 @@ func flatten(ssn *framework.Session) (*flat, error) {
 			c, m := podNonZero(t.Pod)
 			nzc[i] += c
 			nzm[i] += m
-			w, _ := ports.masks(t.Pod) // nodeinfo.UsedPorts(): the ports of every pod in ni.Tasks
-			nports[i] |= w
+			ports.masks(t.Pod, nports[i*Wh:(i+1)*Wh], nil) // nodeinfo.UsedPorts(): the ports of every pod in ni.Tasks
 		}
 		maxPods[i] = int32(n.Allocatable.MaxTaskNum)
 		podCnt[i] = int32(len(n.Tasks))
@@ -498,7 +532,7 @@ func flatten(ssn *framework.Session) (*flat, error) {
 	tjob, tclass, tnode := f.u32(T), f.u32(T), f.u32(T)
 	tprio := f.i32(T)
 	tstatus := f.u8(T)
-	twant, tconf := f.u64(T), f.u64(T)
+	twant, tconf := f.u64(T*Wh), f.u64(T*Wh) // [T][Wh]
 	tprot := f.u8(T)
 	jbegin := f.u32(J + 1)
 	jqueue := f.u32(J)
@@ -533,7 +567,7 @@ func flatten(ssn *framework.Session) (*flat, error) {
 			tprio[t] = ti.Priority
 			tcreate[t] = ti.Pod.CreationTimestamp.Unix()
 			tstatus[t] = taskStatus(ti.Status)
-			twant[t], tconf[t] = ports.masks(ti.Pod)
+			ports.masks(ti.Pod, twant[t*Wh:(t+1)*Wh], tconf[t*Wh:(t+1)*Wh])
 			if ti.Namespace == "kube-system" || ti.Pod.Spec.PriorityClassName == "system-cluster-critical" || ti.Pod.Spec.PriorityClassName == "system-node-critical" {
 				tprot[t] = 1 // plugins/conformance/conformance.go:44-58 (read by preempt / reclaim)
 			}
@@ -650,6 +684,7 @@ func flatten(ssn *framework.Session) (*flat, error) {
 		s.node_ports = (*C.uint64_t)(unsafe.Pointer(&nports[0]))
 		s.task_port_want = (*C.uint64_t)(unsafe.Pointer(&twant[0]))
 		s.task_port_conflict = (*C.uint64_t)(unsafe.Pointer(&tconf[0]))
+		s.port_words = C.uint32_t(Wh)
 	}
 	s.task_evict_protected = (*C.uint8_t)(unsafe.Pointer(&tprot[0]))
 	if err := f.buildInterpod(tnode, tstatus); err != nil { // predicate p8 / priority a22: kb_interpod (nil when no pod has a term)

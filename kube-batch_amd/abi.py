@@ -5,7 +5,7 @@ Only plain C types cross the boundary; the same structs are what the Go shim fil
 """
 import ctypes as C
 
-KB_ABI_VERSION = 7
+KB_ABI_VERSION = 8
 KB_MAX_RES = 32
 KB_NONE = 0xFFFFFFFF
 
@@ -94,7 +94,8 @@ class Interpod(C.Structure):
 class Snapshot(C.Structure):
     _fields_ = [("version", C.c_uint32), ("n_res", C.c_uint32), ("n_nodes", C.c_uint32), ("n_tasks", C.c_uint32),
                 ("n_jobs", C.c_uint32), ("n_queues", C.c_uint32), ("n_task_classes", C.c_uint32),
-                ("n_node_classes", C.c_uint32)] + [(n, _P(t)) for n, t in SNAPSHOT_ARRAYS] + [("interpod", _P(Interpod))]
+                ("n_node_classes", C.c_uint32)] + [(n, _P(t)) for n, t in SNAPSHOT_ARRAYS] + [("interpod", _P(Interpod)),
+                                                                                        ("port_words", C.c_uint32), ("pad", C.c_uint32)]
 
 
 class Decision(C.Structure):

@@ -28,7 +28,13 @@ struct KbDev {
   long long *nzc;      // [NP] nodeinfo.nonzeroRequest.MilliCPU
   long long *nzm;      // [NP] nodeinfo.nonzeroRequest.Memory
   int *podcnt;         // [NP] len(ni.Tasks)
-  unsigned long long *ports;   // [NP] host-port bits used on the node (nodeinfo.UsedPorts), nullptr: no host ports in the session
+  unsigned long long *ports;   // [NP] host-port bits (word 0 of the masks) used on the node (nodeinfo.UsedPorts), nullptr: no host ports in the session
+  // host-port masks of several words (kb_snapshot.port_words > 1): the port_xw words behind the first.  Only K1's evaluation reads them
+  // (kb_k1.hpp: eval_row) and only the host changes them, between rounds (kb_launch_or_ports_x): a pod with a bit in them is decided in
+  // a round of its own, and every other pod carries zeros there — the commit kernels never need them
+  unsigned long long *ports_x;               // [port_xw][NP]
+  const unsigned long long *t_want_x, *t_conf_x;   // [T][port_xw]
+  uint32_t port_xw;                          // 0: one word
   // static node data
   const long long *acpu, *amem;   // [NP] nodeinfo.allocatableResource
   const int *maxpods;             // [NP]
@@ -221,6 +227,8 @@ void kb_launch_affinity(const KbDev &d, const KbRound &r, void *stream);
 // feasibility probe: alive[i] |= 1 iff task rows[i] (allocate's predicate: resource fit + plugin predicates) has a feasible node
 // against the current node state; alive must be zero on entry
 void kb_launch_probe(const KbDev &d, const uint32_t *rows, uint32_t n_rows, uint32_t *alive, void *stream);
+// the pod's host-port words behind the first join the node's (sessions with kb_snapshot.port_words > 1, after the round that placed the pod)
+void kb_launch_or_ports_x(const KbDev &d, uint32_t task, uint32_t node, void *stream);
 // nodeorder's InterPodAffinityPriority added to the score rows of the matrix rows whose task carries weights (no-op otherwise)
 void kb_launch_interpod(const KbDev &d, const KbRound &r, void *stream);
 void kb_launch_argmax(const KbDev &d, const KbRound &r, void *stream);

@@ -163,6 +163,7 @@ struct kb_engine {
   DevBuf b_ip_cdom, b_ip_ccnt, b_ip_ctot, b_ip_tinc, b_ip_tforbid, b_ip_treq, b_ip_tself, b_ip_tsubj, b_ip_tchk, b_ip_pdom, b_ip_pbound, b_ip_punb, b_ip_tcinc,
       b_ip_tsig, b_ip_sigw, b_ip_z, b_ip_scnt, b_ip_shist, p_ip_ccnt, p_ip_ctot, p_ip_punb, p_ip_z;
   DevBuf b_ports, b_twant, b_tconf;   // host ports (only when the snapshot carries any)
+  DevBuf b_ports_x, b_twant_x, b_tconf_x, p_ports_x;   // their words behind the first (kb_snapshot.port_words > 1 and some pod reaches there), pristine copy
   DevBuf b_jbegin, b_jmin, b_jqueue, b_total, b_deserved, b_desmask, b_jalloc, b_jshare, b_qalloc, b_qshare, b_jready;
   uint32_t total_mask = 0;
   // round buffers
@@ -700,7 +701,7 @@ struct ActionRun {
   uint32_t action = 0;   // 0 allocate, 1 backfill
   bool bf_need_pred = false;
   std::vector<int> bf_podcnt;
-  std::vector<unsigned long long> bf_ports;
+  std::vector<unsigned long long> bf_ports, bf_ports_x;   // word 0 [NP]; the words behind it [port_xw][NP]
   OrderMachine om;
   std::vector<uint8_t> dead;
   std::vector<kb_decision> decs;
@@ -726,6 +727,7 @@ struct ActionRun {
     const double *ex = &hs.feas_eff[(size_t)x * R];
     for (uint32_t y = 0; y < hs.n_feas_shapes; y++) {
       if (dead[y] || hs.feas_cls[y] != hs.feas_cls[x] || hs.feas_conf[y] != hs.feas_conf[x]) continue;
+      if (hs.port_xw && std::memcmp(&hs.t_conf_x[(size_t)hs.feas_rep[y] * hs.port_xw], &hs.t_conf_x[(size_t)hs.feas_rep[x] * hs.port_xw], sizeof(uint64_t) * hs.port_xw) != 0) continue;
       if (!hs.feas_ip.empty() && hs.feas_ip[y] != hs.feas_ip[x]) continue;
       const double *ey = &hs.feas_eff[(size_t)y * R];
       bool ge = true;
@@ -770,6 +772,8 @@ struct ActionRun {
         bf_podcnt.resize(NP); bf_ports.assign(NP, 0);
         HIP_OK(hipMemcpyAsync(bf_podcnt.data(), e->b_podcnt.p, sizeof(int) * NP, hipMemcpyDeviceToHost, e->stream));
         if (e->dev.ports) HIP_OK(hipMemcpyAsync(bf_ports.data(), e->b_ports.p, sizeof(unsigned long long) * NP, hipMemcpyDeviceToHost, e->stream));
+        bf_ports_x.assign((size_t)e->dev.port_xw * NP, 0);
+        if (e->dev.port_xw) HIP_OK(hipMemcpyAsync(bf_ports_x.data(), e->b_ports_x.p, sizeof(unsigned long long) * bf_ports_x.size(), hipMemcpyDeviceToHost, e->stream));
         HIP_OK(hipStreamSynchronize(e->stream));
       }
     }
@@ -795,9 +799,10 @@ struct ActionRun {
       uint32_t n = 0, nshapes = 0;
       new_window(e);
       while (n < W && bf_pos + n < bf_list.size() && !(n > 0 && !hs.t_ip_subject.empty() && hs.t_ip_subject[bf_list[bf_pos + n]]) &&
-             admit_shape(e, hs.t_row_shape[bf_list[bf_pos + n]], nshapes)) {   // an inter-pod subject heads its window
+             !(n > 0 && hs.wide(bf_list[bf_pos + n])) && admit_shape(e, hs.t_row_shape[bf_list[bf_pos + n]], nshapes)) {   // an inter-pod subject heads its window
         e->h_rows[n] = bf_list[bf_pos + n];
         n++;
+        if (hs.wide(e->h_rows[n - 1])) break;   // a pod whose host-port masks reach beyond word 0: a round of its own (kb_host.hpp)
       }
       return n;
     }
@@ -809,11 +814,12 @@ struct ActionRun {
     while (n < W && om.next(t)) {
       spec_pops++;
       if (dead[hs.t_feas_shape[t]]) { om.report(Outcome::NoFeasibleNode); continue; }   // known: feasibility only shrinks inside one action
-      if (!admit_shape(e, hs.t_row_shape[t], nshapes) || (n > 0 && !hs.t_ip_subject.empty() && hs.t_ip_subject[t])) {
-        om.rollback_last_pop(); spec_pops--; break;   // the task heads the next window (shape budget, or an inter-pod subject: fresh matrix)
+      if (!admit_shape(e, hs.t_row_shape[t], nshapes) || (n > 0 && !hs.t_ip_subject.empty() && hs.t_ip_subject[t]) || (n > 0 && hs.wide(t))) {
+        om.rollback_last_pop(); spec_pops--; break;   // the task heads the next window (shape budget, an inter-pod subject: fresh matrix, or host-port masks beyond word 0)
       }
       e->h_rows[n++] = t;
       om.report(Outcome::Allocated);
+      if (hs.wide(t)) break;   // ... and is that window's only row: the commit kernels keep to word 0 of the masks (kb_host.hpp: t_wide)
     }
     host_ms += now_ms() - t0;
     if (n == 0) popped += spec_pops;
@@ -834,9 +840,10 @@ struct ActionRun {
     while (n < W && om.next(t)) {
       spec_pops_next++;
       if (dead[hs.t_feas_shape[t]]) { om.report(Outcome::NoFeasibleNode); continue; }
-      if (!admit_shape(e, hs.t_row_shape[t], nshapes) || (n > 0 && !hs.t_ip_subject.empty() && hs.t_ip_subject[t])) { om.rollback_last_pop(); spec_pops_next--; break; }
+      if (!admit_shape(e, hs.t_row_shape[t], nshapes) || (n > 0 && !hs.t_ip_subject.empty() && hs.t_ip_subject[t]) || (n > 0 && hs.wide(t))) { om.rollback_last_pop(); spec_pops_next--; break; }
       rows_next[n++] = t;
       om.report(Outcome::Allocated);
+      if (hs.wide(t)) break;
     }
     host_ms += now_ms() - t0;
     return n;
@@ -861,6 +868,9 @@ struct ActionRun {
         if (!((hs.compat[bit >> 3] >> (bit & 7)) & 1)) continue;
       }
       if (bf_ports[n] & conf) continue;
+      bool clash = false;
+      for (uint32_t w = 0; w < hs.port_xw && !clash; w++) clash = (bf_ports_x[(size_t)w * e->dev.NP + n] & hs.t_conf_x[(size_t)t * hs.port_xw + w]) != 0;
+      if (clash) continue;
       return true;
     }
     return false;
@@ -894,7 +904,16 @@ struct ActionRun {
       if (e->h_probe_alive[i] == 0) { dead[probe_list[i]] = 1; e->probe_deaths++; }
   }
 
+  // host-port masks of several words: the placed pod's words behind the first join the node's (both ssn.Allocate and ssn.Pipeline end in
+  // NodeInfo.AddTask; the kernels advanced word 0).  On the action's stream, in front of whatever the next round launches.
   void absorb(kb_engine *e, uint32_t n, uint32_t n_done, uint32_t reason) {
+    const size_t first = decs.size();
+    absorb_round(e, n, n_done, reason);
+    if (e->dev.port_xw)
+      for (size_t i = first; i < decs.size(); i++)
+        if (e->hs.wide(decs[i].task) && decs[i].node != KB_NONE) kb_launch_or_ports_x(e->dev, decs[i].task, decs[i].node, e->stream);
+  }
+  void absorb_round(kb_engine *e, uint32_t n, uint32_t n_done, uint32_t reason) {
     HostSession &hs = e->hs;
     const uint32_t round = (uint32_t)(e->round_no - 1);
     if (action == 1) {
@@ -1317,13 +1336,15 @@ int kb_session_load(kb_engine *e, const kb_snapshot *sn) {
       }
     }
     d.ports = nullptr; d.t_want = nullptr; d.t_conf = nullptr;
+    d.ports_x = nullptr; d.t_want_x = nullptr; d.t_conf_x = nullptr; d.port_xw = 0;
     if (sn->node_ports || sn->task_port_want || sn->task_port_conflict) {
+      const size_t Wh = sn->port_words ? sn->port_words : 1;   // 64-bit words per mask; word 0 here, the others below
       std::vector<unsigned long long> np_(NP, 0ull), tw(T ? T : 1, 0ull), tc(T ? T : 1, 0ull);
       bool any = false;
-      for (uint32_t n = 0; n < N && sn->node_ports; n++) { np_[n] = sn->node_ports[n]; any = any || np_[n]; }
+      for (uint32_t n = 0; n < N && sn->node_ports; n++) { np_[n] = sn->node_ports[(size_t)n * Wh]; any = any || np_[n]; }
       for (uint32_t t = 0; t < T; t++) {
-        if (sn->task_port_want) tw[t] = sn->task_port_want[t];
-        if (sn->task_port_conflict) tc[t] = sn->task_port_conflict[t];
+        if (sn->task_port_want) tw[t] = sn->task_port_want[(size_t)t * Wh];
+        if (sn->task_port_conflict) tc[t] = sn->task_port_conflict[(size_t)t * Wh];
         if ((tw[t] & ~tc[t]) != 0) throw EngineError(KB_E_INVALID, "a pod's host ports must conflict with themselves (want is not a subset of conflict)");
         any = any || tw[t] || tc[t];
       }
@@ -1334,6 +1355,28 @@ int kb_session_load(kb_engine *e, const kb_snapshot *sn) {
         d.ports = e->b_ports.as<unsigned long long>();
         d.t_want = e->b_twant.as<unsigned long long>();
         d.t_conf = e->b_tconf.as<unsigned long long>();
+      }
+      if (hs.port_xw) {   // some pod reaches beyond word 0 (kb_host.hpp: t_wide): the words behind it, nodes word-major ([port_xw][NP]: K1 reads runs of nodes)
+        const uint32_t X = hs.port_xw;
+        std::vector<unsigned long long> nx((size_t)X * NP, 0ull);
+        for (uint32_t n = 0; n < N && sn->node_ports; n++)
+          for (uint32_t w = 0; w < X; w++) nx[(size_t)w * NP + n] = sn->node_ports[(size_t)n * Wh + 1 + w];
+        static_assert(sizeof(unsigned long long) == sizeof(uint64_t), "host-port words");
+        upload(e->b_ports_x, nx.data(), nx.size(), s);
+        upload(e->b_twant_x, reinterpret_cast<const unsigned long long *>(hs.t_want_x.data()), hs.t_want_x.size(), s);
+        upload(e->b_tconf_x, reinterpret_cast<const unsigned long long *>(hs.t_conf_x.data()), hs.t_conf_x.size(), s);
+        d.ports_x = e->b_ports_x.as<unsigned long long>();
+        d.t_want_x = e->b_twant_x.as<unsigned long long>();
+        d.t_conf_x = e->b_tconf_x.as<unsigned long long>();
+        d.port_xw = X;
+        if (!d.ports) {   // word 0 empty everywhere: the kernels still take the host-port path by d.ports
+          upload(e->b_ports, np_.data(), NP, s);
+          upload(e->b_twant, tw.data(), tw.size(), s);
+          upload(e->b_tconf, tc.data(), tc.size(), s);
+          d.ports = e->b_ports.as<unsigned long long>();
+          d.t_want = e->b_twant.as<unsigned long long>();
+          d.t_conf = e->b_tconf.as<unsigned long long>();
+        }
       }
     }
     d.aff = nullptr;
@@ -1476,6 +1519,7 @@ int kb_session_load(kb_engine *e, const kb_snapshot *sn) {
     snap_copy(e->p_idle, e->b_idle); snap_copy(e->p_rel, e->b_rel); snap_copy(e->p_nzc, e->b_nzc); snap_copy(e->p_nzm, e->b_nzm);
     snap_copy(e->p_podcnt, e->b_podcnt); snap_copy(e->p_tstatus, e->b_tstatus); snap_copy(e->p_tnode, e->b_tnode);
     if (d.ports) snap_copy(e->p_ports, e->b_ports);
+    if (d.ports_x) snap_copy(e->p_ports_x, e->b_ports_x);
     snap_copy(e->p_tcounted, e->b_tcounted);
     snap_copy(e->p_nmask, e->b_nmask);   // the evict actions rewrite the key masks of the nodes they touch (upload_live_nodes)
     if (hs.has_interpod) { snap_copy(e->p_ip_ccnt, e->b_ip_ccnt); snap_copy(e->p_ip_ctot, e->b_ip_ctot); snap_copy(e->p_ip_punb, e->b_ip_punb); snap_copy(e->p_ip_z, e->b_ip_z); }
@@ -1504,6 +1548,7 @@ int kb_session_reset(kb_engine *e) {
     restore(e->b_idle, e->p_idle); restore(e->b_rel, e->p_rel); restore(e->b_nzc, e->p_nzc); restore(e->b_nzm, e->p_nzm);
     restore(e->b_podcnt, e->p_podcnt); restore(e->b_tstatus, e->p_tstatus); restore(e->b_tnode, e->p_tnode);
     if (e->dev.ports) restore(e->b_ports, e->p_ports);
+    if (e->dev.ports_x) restore(e->b_ports_x, e->p_ports_x);
     restore(e->b_tcounted, e->p_tcounted);
     restore(e->b_nmask, e->p_nmask);
     if (e->hs.has_interpod) { restore(e->b_ip_ccnt, e->p_ip_ccnt); restore(e->b_ip_ctot, e->p_ip_ctot); restore(e->b_ip_punb, e->p_ip_punb); restore(e->b_ip_z, e->p_ip_z); }
@@ -1578,7 +1623,9 @@ static int run_action(kb_engine *e, uint32_t action, kb_decision *out, uint64_t 
     // flight completes, which ~80 % do) and queues that round behind the running one right away: the device starts it the
     // moment the commit kernel ends instead of idling through a host round trip (~19 us per round).  A round that stops early
     // clears the chain word and the queued round skips itself (KbRound::chain).
-    const bool ahead = action == 0 && e->fast_rounds;
+    // (sessions with host-port masks of several words: one round at a time — a pod that reaches beyond word 0 changes node state from the host
+    //  after its round, which a round already queued or overlapped would not see)
+    const bool ahead = action == 0 && e->fast_rounds && !e->dev.port_xw;
     const bool chained = ahead && e->chain_rounds;
     uint32_t buf = 0;
     RoundCtx c{};
@@ -1657,6 +1704,11 @@ void upload_live_nodes(kb_engine *e, const LiveNodes &ln, const std::vector<uint
   if (e->b_scatter.bytes < sizeof(unsigned long long) * words) e->b_scatter.alloc(sizeof(unsigned long long) * words);   // grown, never shrunk: hipFree synchronises the device
   HIP_OK(hipMemcpyAsync(e->b_scatter.p, e->h_scatter.data(), sizeof(unsigned long long) * words, hipMemcpyHostToDevice, e->stream));
   kb_launch_scatter_nodes(e->dev, e->b_scatter.as<unsigned long long>(), (uint32_t)nodes.size(), e->b_nmask.as<uint32_t>(), e->stream);
+  // host-port masks of several words: the words behind the first, one 8-byte copy each (a rare session; [port_xw][NP] on the device, [N][port_xw] here)
+  for (uint32_t X = e->dev.port_xw, i = 0; X && i < nodes.size(); i++)
+    for (uint32_t w = 0; w < X; w++)
+      HIP_OK(hipMemcpyAsync(e->b_ports_x.as<unsigned long long>() + (size_t)w * e->dev.NP + nodes[i], &ln.ports_x[(size_t)nodes[i] * X + w], sizeof(unsigned long long),
+                            hipMemcpyHostToDevice, e->stream));
   HIP_OK(hipStreamSynchronize(e->stream));   // the staging vector is reused by the next refresh
 }
 }  // namespace
@@ -1708,6 +1760,14 @@ static int run_evict_action(kb_engine *e, bool reclaim, kb_stmt_op *out, uint64_
       ln.podcnt.assign(reinterpret_cast<const int *>(hb + o_pod), reinterpret_cast<const int *>(hb + o_pod) + NP);
       if (e->dev.ports) ln.ports.assign(reinterpret_cast<const unsigned long long *>(hb + o_ports), reinterpret_cast<const unsigned long long *>(hb + o_ports) + NP);
       else ln.ports.assign(NP, 0);
+      ln.ports_x.assign((size_t)N * hs.port_xw, 0);
+      if (e->dev.port_xw) {   // the masks' words behind the first: [port_xw][NP] on the device, [N][port_xw] in the machine
+        std::vector<unsigned long long> px((size_t)e->dev.port_xw * NP);
+        HIP_OK(hipMemcpyAsync(px.data(), e->b_ports_x.p, sizeof(unsigned long long) * px.size(), hipMemcpyDeviceToHost, e->stream));
+        HIP_OK(hipStreamSynchronize(e->stream));
+        for (uint32_t n = 0; n < N; n++)
+          for (uint32_t w = 0; w < hs.port_xw; w++) ln.ports_x[(size_t)n * hs.port_xw + w] = px[(size_t)w * NP + n];
+      }
       counted_in.assign(hb + o_cnt, hb + o_cnt + T);
       ln.idle.assign(N, Res()); ln.rel.assign(N, Res());
       for (uint32_t n = 0; n < N; n++) {

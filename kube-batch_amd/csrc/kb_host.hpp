@@ -70,7 +70,14 @@ struct HostSession {
   std::vector<int64_t> queue_creation;
   // static data the preempt action reads on the host (the allocate / backfill path has it on the device only)
   std::vector<int64_t> t_nzc, t_nzm;       // pod non-zero request
-  std::vector<uint64_t> t_want, t_conf;    // host ports the pod occupies / that conflict with it (empty: no host ports)
+  std::vector<uint64_t> t_want, t_conf;    // host ports the pod occupies / that conflict with it — word 0 of the masks (empty: no host ports)
+  // kb_snapshot.port_words > 1: the words behind the first, [T][port_xw].  A task with a bit in any of them (t_wide) is decided in a
+  // round of its own on the plain path: K1 evaluates the full mask (kb_k1.hpp), the commit kernels keep to word 0, and the host ORs the
+  // pod's high words into the node's after the round (ActionRun::absorb).  Pods that stay inside word 0 never read or change the others.
+  uint32_t port_xw = 0;
+  std::vector<uint64_t> t_want_x, t_conf_x;
+  std::vector<uint8_t> t_wide;             // [T] (empty: port_xw == 0)
+  bool wide(uint32_t t) const { return !t_wide.empty() && t_wide[t]; }
   std::vector<uint8_t> t_protected;        // conformance: never a victim (empty: none)
   std::vector<int64_t> n_ac, n_am;         // nodeinfo.allocatableResource
   std::vector<int32_t> n_maxpods;

@@ -122,6 +122,16 @@ __device__ __forceinline__ void eval_row(const KbDev &d, const K1Task &t, const 
   if (d.pred_enabled) {
 #pragma unroll
     for (int j = 0; j < NPT; j++) ok[j] &= n[j].slots & (int)((n[j].ports & t.conf) == 0ull);   // pod count (predicates.go:127), PodFitsHostPorts (:181-190)
+    if (d.port_xw) {   // host-port masks of several words: the words behind the first, straight from HBM ([port_xw][NP], rows padded to NP).  A row
+                       // that stays inside word 0 carries zeros here (one scalar load per word, no node traffic)
+      for (uint32_t w = 0; w < d.port_xw; w++) {
+        const unsigned long long cx = d.t_conf_x[(size_t)t.task * d.port_xw + w];
+        if (cx == 0ull) continue;
+        const unsigned long long *px = d.ports_x + (size_t)w * d.NP + n0;
+#pragma unroll
+        for (int j = 0; j < NPT; j++) ok[j] &= (int)((px[j] & cx) == 0ull);
+      }
+    }
     if (d.crows != nullptr && d.n_nc <= 32) {   // the class row is a scalar word (K1Task::crow)
 #pragma unroll
       for (int j = 0; j < NPT; j++) ok[j] &= (int)((t.crow >> n[j].cls) & 1u);

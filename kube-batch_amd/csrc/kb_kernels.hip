@@ -844,6 +844,18 @@ __global__ void __launch_bounds__(256) k_probe(KbDev d, const uint32_t *rows, ui
     if (any && (threadIdx.x & 63) == 0) atomicOr(&alive[row0 + rr], 1u);
   }
 }
+__global__ void k_or_ports_x(KbDev d, uint32_t task, uint32_t node) {
+  const uint32_t w = threadIdx.x;
+  if (w < d.port_xw) d.ports_x[(size_t)w * d.NP + node] |= d.t_want_x[(size_t)task * d.port_xw + w];
+}
+void kb_launch_or_ports_x(const KbDev &d, uint32_t task, uint32_t node, void *stream) {
+  for (uint32_t w0 = 0; w0 < d.port_xw; w0 += 1024u) {   // one thread per word
+    KbDev dd = d;
+    dd.ports_x += (size_t)w0 * d.NP; dd.t_want_x += w0; dd.port_xw = d.port_xw;   // t_want_x keeps its row stride (port_xw)
+    const uint32_t n = d.port_xw - w0 < 1024u ? d.port_xw - w0 : 1024u;
+    hipLaunchKernelGGL(k_or_ports_x, dim3(1), dim3(n), 0, (hipStream_t)stream, dd, task, node);
+  }
+}
 void kb_launch_probe(const KbDev &d, const uint32_t *rows, uint32_t n_rows, uint32_t *alive, void *stream) {
   if (n_rows == 0) return;
   KbDev dd = d;

@@ -248,6 +248,12 @@ void PreemptMachine::node_remove(uint32_t t) {
     uint64_t ports = nd_->base_ports[n];
     for (uint32_t o : v) ports |= hs_->t_want[o];
     nd_->ports[n] = ports;
+    const uint32_t X = hs_->port_xw;
+    for (uint32_t w = 0; w < X; w++) {
+      uint64_t px = nd_->base_ports_x[(size_t)n * X + w];
+      for (uint32_t o : v) px |= hs_->t_want_x[(size_t)o * X + w];
+      nd_->ports_x[(size_t)n * X + w] = px;
+    }
   }
   on_node[t] = 0;
   touch_node(n);
@@ -278,6 +284,7 @@ bool PreemptMachine::node_add(uint32_t t, uint32_t n, int st) {
   nd_->nzc[n] += hs_->t_nzc[t];
   nd_->nzm[n] += hs_->t_nzm[t];
   if (!hs_->t_want.empty()) nd_->ports[n] |= hs_->t_want[t];
+  for (uint32_t w = 0, X = hs_->port_xw; w < X; w++) nd_->ports_x[(size_t)n * X + w] |= hs_->t_want_x[(size_t)t * X + w];
   std::vector<uint32_t> &v = ntasks_[n];
   v.insert(std::lower_bound(v.begin(), v.end(), t), t);
   touch_node(n);
@@ -526,6 +533,8 @@ bool PreemptMachine::host_eval(uint32_t t, uint32_t n, long long &score) const {
       if (!((hs_->compat[bit >> 3] >> (bit & 7)) & 1)) return false;
     }
     if (!hs_->t_conf.empty() && (nd_->ports[n] & hs_->t_conf[t])) return false;
+    for (uint32_t w = 0, X = hs_->port_xw; w < X; w++)
+      if (nd_->ports_x[(size_t)n * X + w] & hs_->t_conf_x[(size_t)t * X + w]) return false;
     if (ip_ && hs_->t_ip_checks[t] && !ip_predicate(t, n)) return false;   // predicates.go:249-262 (the score below is only read where lists are repaired: never with inter-pod terms)
   }
   if (!pol_->nodeorder_enabled) return true;
@@ -710,6 +719,13 @@ void PreemptMachine::init(const HostSession *hs, const Policy *pol, LiveNodes *l
       uint64_t mine = 0;
       for (uint32_t t : ntasks_[n]) mine |= hs->t_want[t];
       nd_->base_ports[n] = nd_->ports[n] & ~mine;
+    }
+  nd_->base_ports_x.assign((size_t)N * hs->port_xw, 0);
+  for (uint32_t n = 0, X = hs->port_xw; n < N && X; n++)
+    for (uint32_t w = 0; w < X; w++) {
+      uint64_t mine = 0;
+      for (uint32_t t : ntasks_[n]) mine |= hs->t_want_x[(size_t)t * X + w];
+      nd_->base_ports_x[(size_t)n * X + w] = nd_->ports_x[(size_t)n * X + w] & ~mine;
     }
   shape_list_.assign(hs->n_row_shapes ? hs->n_row_shapes : 1, {});
   shape_have_.assign(hs->n_row_shapes ? hs->n_row_shapes : 1, 0);

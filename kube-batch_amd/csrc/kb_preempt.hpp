@@ -31,6 +31,7 @@ struct LiveNodes {
   std::vector<int32_t> podcnt, maxpods;
   std::vector<uint32_t> cls;
   std::vector<uint64_t> ports, base_ports;   // base: the share that belongs to pods outside the session
+  std::vector<uint64_t> ports_x, base_ports_x;   // [N][HostSession::port_xw] the masks' words behind the first (empty: one word)
 };
 
 // kb_run_preempt accepts sessions with preferred node-affinity terms unless KB_PREEMPT_NODE_AFFINITY=0 (read at every call)

@@ -194,9 +194,26 @@ void build_host_session(const kb_snapshot *sn, const Policy &pol, uint32_t NP, H
     for (uint32_t t = hs.job_begin[j]; t < hs.job_begin[j + 1]; t++)
       if (hs.t_job[t] != j) throw EngineError(KB_E_INVALID, "tasks must be grouped by job in canonical order");
   }
+  const uint32_t Wh = sn->port_words ? sn->port_words : 1;   // 64-bit words per host-port mask
+  hs.port_xw = 0; hs.t_want_x.clear(); hs.t_conf_x.clear(); hs.t_wide.clear();
   if (sn->task_port_want || sn->task_port_conflict) {
     hs.t_want.assign(T, 0); hs.t_conf.assign(T, 0);
-    for (uint32_t t = 0; t < T; t++) { if (sn->task_port_want) hs.t_want[t] = sn->task_port_want[t]; if (sn->task_port_conflict) hs.t_conf[t] = sn->task_port_conflict[t]; }
+    for (uint32_t t = 0; t < T; t++) { if (sn->task_port_want) hs.t_want[t] = sn->task_port_want[(size_t)t * Wh]; if (sn->task_port_conflict) hs.t_conf[t] = sn->task_port_conflict[(size_t)t * Wh]; }
+    if (Wh > 1) {
+      const uint32_t X = Wh - 1;
+      hs.port_xw = X;
+      hs.t_want_x.assign((size_t)T * X, 0); hs.t_conf_x.assign((size_t)T * X, 0); hs.t_wide.assign(T, 0);
+      for (uint32_t t = 0; t < T; t++)
+        for (uint32_t w = 0; w < X; w++) {
+          const uint64_t wt = sn->task_port_want ? sn->task_port_want[(size_t)t * Wh + 1 + w] : 0, cf = sn->task_port_conflict ? sn->task_port_conflict[(size_t)t * Wh + 1 + w] : 0;
+          hs.t_want_x[(size_t)t * X + w] = wt; hs.t_conf_x[(size_t)t * X + w] = cf;
+          if (wt & ~cf) throw EngineError(KB_E_INVALID, "a pod's host ports must conflict with themselves (want is not a subset of conflict)");
+          if (wt | cf) hs.t_wide[t] = 1;
+        }
+      bool any_wide = false;
+      for (uint32_t t = 0; t < T && !any_wide; t++) any_wide = hs.t_wide[t] != 0;
+      if (!any_wide) { hs.port_xw = 0; hs.t_want_x.clear(); hs.t_conf_x.clear(); hs.t_wide.clear(); }   // what only nodes carry there never meets a pod's mask
+    }
   }
   if (sn->task_evict_protected) hs.t_protected.assign(sn->task_evict_protected, sn->task_evict_protected + T);
   hs.n_ac.assign(sn->node_alloc_cpu, sn->node_alloc_cpu + N);
@@ -270,8 +287,8 @@ void build_host_session(const kb_snapshot *sn, const Policy &pol, uint32_t NP, H
       if (!same_bits(hs.t_res[(size_t)d * T + t], hs.t_res[(size_t)d * T + p]) || !same_bits(hs.t_init[(size_t)d * T + t], hs.t_init[(size_t)d * T + p])) return false;
     if (hs.t_resmask[t] != hs.t_resmask[p] || hs.t_cls[t] != hs.t_cls[p]) return false;
     if (sn->task_nz_cpu[t] != sn->task_nz_cpu[p] || sn->task_nz_mem[t] != sn->task_nz_mem[p]) return false;
-    if (sn->task_port_conflict && sn->task_port_conflict[t] != sn->task_port_conflict[p]) return false;
-    if (sn->task_port_want && sn->task_port_want[t] != sn->task_port_want[p]) return false;
+    if (sn->task_port_conflict && std::memcmp(sn->task_port_conflict + (size_t)t * Wh, sn->task_port_conflict + (size_t)p * Wh, sizeof(uint64_t) * Wh) != 0) return false;
+    if (sn->task_port_want && std::memcmp(sn->task_port_want + (size_t)t * Wh, sn->task_port_want + (size_t)p * Wh, sizeof(uint64_t) * Wh) != 0) return false;
     if (ip) {
       if (std::memcmp(ip->task_forbid + (size_t)t * ipWc, ip->task_forbid + (size_t)p * ipWc, sizeof(uint64_t) * ipWc) != 0) return false;
       if (ip->task_require[t] != ip->task_require[p] || ip->task_self[t] != ip->task_self[p] || ip->task_sig[t] != ip->task_sig[p]) return false;
@@ -322,8 +339,12 @@ void build_host_session(const kb_snapshot *sn, const Policy &pol, uint32_t NP, H
     size_t feas_len = 0;
     bool same_feas = false;
     {   // host ports: the conflict mask is part of feasibility, the wanted bits of what a commit changes
-      const uint64_t conf = sn->task_port_conflict ? sn->task_port_conflict[t] : 0, want = sn->task_port_want ? sn->task_port_want[t] : 0;
+      const uint64_t conf = sn->task_port_conflict ? sn->task_port_conflict[(size_t)t * Wh] : 0, want = sn->task_port_want ? sn->task_port_want[(size_t)t * Wh] : 0;
       key.push_back((double)(uint32_t)(conf & 0xFFFFFFFFu)); key.push_back((double)(uint32_t)(conf >> 32));
+      for (uint32_t w = 0; w < hs.port_xw; w++) {   // the words behind the first
+        const uint64_t cx = hs.t_conf_x[(size_t)t * hs.port_xw + w];
+        key.push_back((double)(uint32_t)(cx & 0xFFFFFFFFu)); key.push_back((double)(uint32_t)(cx >> 32));
+      }
       if (ip) {   // inter-pod predicate checks are part of feasibility
         const uint32_t Wc = ip->n_counters ? (ip->n_counters + 63) / 64 : 1;
         for (uint32_t w = 0; w < Wc; w++) {
@@ -336,6 +357,10 @@ void build_host_session(const kb_snapshot *sn, const Policy &pol, uint32_t NP, H
       same_feas = prev_valid && prev_feas_len == feas_len && std::memcmp(prev.data(), key.data(), feas_len * sizeof(double)) == 0;
       hs.t_feas_shape[t] = same_feas ? prev_feas_id : feas_ids.intern(key);
       key.push_back((double)(uint32_t)(want & 0xFFFFFFFFu)); key.push_back((double)(uint32_t)(want >> 32));
+      for (uint32_t w = 0; w < hs.port_xw; w++) {
+        const uint64_t wx = hs.t_want_x[(size_t)t * hs.port_xw + w];
+        key.push_back((double)(uint32_t)(wx & 0xFFFFFFFFu)); key.push_back((double)(uint32_t)(wx >> 32));
+      }
     }
     key.push_back((double)sn->task_nz_cpu[t]);
     key.push_back((double)sn->task_nz_mem[t]);
@@ -412,7 +437,7 @@ void build_host_session(const kb_snapshot *sn, const Policy &pol, uint32_t NP, H
   for (uint32_t f = 0; f < hs.n_feas_shapes; f++) {   // every task of a shape carries the same values (they are its key)
     const uint32_t t = hs.feas_rep[f];
     hs.feas_cls[f] = hs.t_cls[t];
-    hs.feas_conf[f] = sn->task_port_conflict ? sn->task_port_conflict[t] : 0;
+    hs.feas_conf[f] = hs.t_conf.empty() ? 0 : hs.t_conf[t];   // word 0; the words behind it are compared through the shape's task (ActionRun::mark_dead)
     for (int d = 0; d < R; d++)
       hs.feas_eff[(size_t)f * R + d] = (d < 2 || ((t_active[t] >> d) & 1u)) ? hs.t_init[(size_t)d * T + t] : 0.0;
   }

@@ -617,6 +617,20 @@ class SessionSnapshot:
             assert getattr(self, name).shape == (J,), name
         for name in ("queue_weight", "queue_creation"):
             assert getattr(self, name).shape == (Q,), name
+        # host-port masks: [n] (one 64-bit word) or [n][Wh]; all three of one width
+        widths = set()
+        for name, n in (("node_ports", N), ("task_port_want", T), ("task_port_conflict", T)):
+            a = getattr(self, name, None)
+            if a is None:
+                continue
+            if a.ndim == 1:
+                a = a.reshape(n, 1) if getattr(self, "port_words", 1) in (0, 1) else a.reshape(n, int(self.port_words))
+            assert a.ndim == 2 and a.shape[0] == n, name
+            widths.add(int(a.shape[1]))
+            setattr(self, name, np.ascontiguousarray(a) if a.shape[1] > 1 else np.ascontiguousarray(a.reshape(n)))
+        if len(widths) > 1:
+            raise ValueError(f"host-port masks of different widths: {sorted(widths)}")
+        self.port_words = widths.pop() if widths else 1
 
     def to_abi(self) -> abi.Snapshot:
         s = abi.Snapshot()
@@ -629,6 +643,7 @@ class SessionSnapshot:
                 setattr(s, name, C.POINTER(ctype)())
             else:
                 setattr(s, name, a.ctypes.data_as(C.POINTER(ctype)))
+        s.port_words = int(getattr(self, "port_words", 1))
         ip = getattr(self, "interpod", None)
         if ip is None:
             s.interpod = C.POINTER(abi.Interpod)()
@@ -790,14 +805,23 @@ def flatten(nodes: List[Node], pods: List[Pod], pod_groups: List[PodGroup], queu
     # host ports: a distinct (ip, protocol, port > 0) of the cluster's pods is one bit — if it can ever take part in a conflict test.
     # PodFitsHostPorts is only ever asked for a Pending task (allocate, backfill, the preemptors of preempt / reclaim), and a placement
     # adds a Pending task's own ports: a triple that conflicts with no Pending task's port (what the daemons already running on the nodes
-    # listen on, usually) can never decide anything and gets no bit.  More than 64 of the rest -> the stock action takes the cycle.
+    # listen on, usually) can never decide anything and gets no bit.  Any number of them: masks of Wh = ceil(n / 64) words.  The engine
+    # decides a Pending pod whose masks reach beyond word 0 in a device round of its own (include/kb_engine.h), so the triples the Pending
+    # pods' ports conflict with most often take the low bits.
     every = sorted({_sanitize_port(hp) for p in pods for hp in p.host_ports if int(hp[2]) > 0})
     asked = sorted({_sanitize_port(hp) for p in pods if _task_status(p) == abi.TASK_PENDING for hp in p.host_ports if int(hp[2]) > 0})
     universe = [u for u in every if any(_ports_conflict(hp, u) for hp in asked)] if prune_ports else every
     if len(universe) > 64:
-        raise ValueError("more than 64 distinct host ports that a pending pod's ports can conflict with in one session")
+        pending = [[_sanitize_port(hp) for hp in p.host_ports if int(hp[2]) > 0] for p in pods if _task_status(p) == abi.TASK_PENDING]
+        pending = [m for m in pending if m]
+        weight = {u: sum(1 for m in pending if any(_ports_conflict(hp, u) for hp in m)) for u in universe}
+        universe = sorted(universe, key=lambda u: (-weight[u], u))
     port_bit = {hp: i for i, hp in enumerate(universe)}
-    node_ports = np.zeros(N, np.uint64)
+    Wh = max(1, (len(universe) + 63) // 64)
+    node_ports = np.zeros((N, Wh), np.uint64)
+
+    def mask_words(m: int):
+        return np.array([(m >> (64 * w)) & 0xFFFFFFFFFFFFFFFF for w in range(Wh)], np.uint64)
 
     def port_masks(p: Pod):
         mine = [_sanitize_port(hp) for hp in p.host_ports if int(hp[2]) > 0]
@@ -820,14 +844,14 @@ def flatten(nodes: List[Node], pods: List[Pod], pod_groups: List[PodGroup], queu
         if p.node_name in nidx and _task_status(p) not in terminated:
             res, _, _, nzc, nzm = pod_vectors(p)
             if account_on_node(nidx[p.node_name], _task_status(p), res, nzc, nzm):
-                node_ports[nidx[p.node_name]] |= np.uint64(port_masks(p)[0])
+                node_ports[nidx[p.node_name]] |= mask_words(port_masks(p)[0])
                 others_on_nodes.append((p, nidx[p.node_name]))
 
     t_res = np.zeros((R, T)); t_init = np.zeros((R, T)); t_mask = np.zeros(T, np.uint32)
     t_nzc = np.zeros(T, np.int64); t_nzm = np.zeros(T, np.int64); t_job = np.zeros(T, np.uint32)
     t_prio = np.zeros(T, np.int32); t_cre = np.zeros(T, np.int64); t_st = np.zeros(T, np.uint8)
     t_node = np.full(T, abi.KB_NONE, np.uint32)
-    t_want = np.zeros(T, np.uint64); t_conf = np.zeros(T, np.uint64)
+    t_want = np.zeros((T, Wh), np.uint64); t_conf = np.zeros((T, Wh), np.uint64)
     t_prot = np.zeros(T, np.uint8)
     task_cls_keys = []
     names_tasks = []
@@ -843,13 +867,13 @@ def flatten(nodes: List[Node], pods: List[Pod], pod_groups: List[PodGroup], queu
             t_prio[k] = 1 if p.priority is None else p.priority      # NewTaskInfo default (job_info.go:82)
             t_cre[k] = p.creation; t_st[k] = st
             want, conflict = port_masks(p)
-            t_want[k] = want; t_conf[k] = conflict
+            t_want[k] = mask_words(want); t_conf[k] = mask_words(conflict)
             # plugins/conformance/conformance.go:44-58
             t_prot[k] = int(p.namespace == "kube-system" or p.priority_class_name in ("system-cluster-critical", "system-node-critical"))
             if p.node_name in nidx and st not in terminated:
                 if account_on_node(nidx[p.node_name], st, res, nzc, nzm):
                     t_node[k] = nidx[p.node_name]
-                    node_ports[nidx[p.node_name]] |= np.uint64(want)
+                    node_ports[nidx[p.node_name]] |= mask_words(want)
             pref = tuple((int(w), tuple((k2, op, tuple(vals)) for k2, op, vals in exprs)) for w, exprs in p.preferred_affinity)
             req = (0,) if p.required_affinity is None else (1, tuple(
                 (tuple((k2, op, tuple(vals)) for k2, op, vals in exprs), tuple((k2, op, tuple(vals)) for k2, op, vals in fields))

@@ -349,15 +349,20 @@ typedef struct o_node {
   int64_t alloc_cpu, alloc_mem, nz_cpu, nz_mem; /* k8s nodeinfo view */
   int32_t pod_cnt;
   uint32_t cls;
-  uint64_t ports;   /* nodeinfo.UsedPorts() as interned bits (vendor/.../nodeinfo/host_ports.go) */
-  uint64_t base_ports;   /* the share of `ports` that belongs to pods outside the session */
+  uint64_t *ports;   /* [Wh] nodeinfo.UsedPorts() as interned bits (vendor/.../nodeinfo/host_ports.go); Wh = kbo_session.Wh words per mask */
+  uint64_t *base_ports;   /* [Wh] the share of `ports` that belongs to pods outside the session */
 } o_node;
+
+/* host-port masks of Wh words (kb_snapshot.port_words): the reference keeps sets of (ip, protocol, port) without a width */
+static inline int pm_meet(const uint64_t *a, const uint64_t *b, uint32_t W) { for (uint32_t w = 0; w < W; w++) if (a[w] & b[w]) return 1; return 0; }
+static inline void pm_or(uint64_t *a, const uint64_t *b, uint32_t W) { for (uint32_t w = 0; w < W; w++) a[w] |= b[w]; }
+static inline int pm_eq(const uint64_t *a, const uint64_t *b, uint32_t W) { for (uint32_t w = 0; w < W; w++) if (a[w] != b[w]) return 0; return 1; }
 
 typedef struct o_task {
   kbo_res resreq, init_resreq;
   int64_t nz_cpu, nz_mem;
   uint32_t job, cls, node;
-  uint64_t port_want, port_conflict;
+  const uint64_t *port_want, *port_conflict;   /* [Wh] */
   uint8_t on_node;         /* the task is in some ni.Tasks (preempt bookkeeping) */
   uint8_t node_status;     /* status of the clone ni.Tasks holds (api/node_info.go:186: the node keeps a copy taken at AddTask) */
   uint8_t evict_protected; /* conformance: kube-system namespace or a system-critical priority class (conformance.go:44-58) */
@@ -394,6 +399,8 @@ typedef struct kbo_session {
   int R;
   uint32_t N, T, J, Q, n_tc, n_nc;
   o_node *nodes;
+  uint32_t Wh;            /* 64-bit words per host-port mask (kb_snapshot.port_words, 0 reads as 1) */
+  uint64_t *pm_nodes, *pm_base, *pm_want, *pm_conf, *pm_scratch;   /* [N][Wh], [N][Wh], [T][Wh], [T][Wh], [Wh] */
   o_task *tasks;
   o_job *jobs;
   o_queue *queues;
@@ -591,7 +598,7 @@ static int plugin_predicate(const kbo_session *s, const o_task *t, const o_node 
   if (n->allocatable.max_task_num <= n->pod_cnt) return 0; /* predicates.go:127 */
   if (!class_ok(s, t->cls, n->cls)) return 0;
   /* PodFitsHostPorts (predicates.go:181-190 -> vendor/.../predicates/predicates.go:1153-1175): any wanted port in conflict with a used one */
-  if ((n->ports & t->port_conflict) != 0) return 0;
+  if (pm_meet(n->ports, t->port_conflict, s->Wh)) return 0;
   if (s->ip_on && !interpod_predicate(s, (uint32_t)(t - s->tasks), (uint32_t)(n - s->nodes))) return 0;
   return 1;
 }
@@ -861,7 +868,7 @@ static int ssn_allocate(kbo_session *s, uint32_t t, uint32_t n) {
   res_add(&nd->used, &tk->resreq, s->R);
   tk->node = n;
   nd->pod_cnt += 1;                 /* ni.Tasks[key] = ti ; k8s NodeInfo is rebuilt from ni.Pods() per evaluation */
-  nd->ports |= tk->port_want;       /* ... including its UsedPorts (node_info.go:582-607 updateUsedPorts) */
+  pm_or(nd->ports, tk->port_want, s->Wh);       /* ... including its UsedPorts (node_info.go:582-607 updateUsedPorts) */
   nd->nz_cpu += tk->nz_cpu;         /* vendor/.../nodeinfo/node_info.go:502-517 AddPod */
   nd->nz_mem += tk->nz_mem;
   tk->node_status = KB_TASK_ALLOCATED;
@@ -886,7 +893,7 @@ static int ssn_pipeline(kbo_session *s, uint32_t t, uint32_t n) {
   res_add(&nd->used, &tk->resreq, s->R);
   tk->node = n;
   nd->pod_cnt += 1;
-  nd->ports |= tk->port_want;
+  pm_or(nd->ports, tk->port_want, s->Wh);
   nd->nz_cpu += tk->nz_cpu;
   nd->nz_mem += tk->nz_mem;
   tk->node_status = KB_TASK_PIPELINED;
@@ -1017,6 +1024,12 @@ kbo_session *kbo_open(const kb_config *cfg, const kb_snapshot *sn, int threads) 
   s->nodeorder_enabled = find_plugin_enabled(s, KB_PLUGIN_NODEORDER, KB_EN_NODE_ORDER);
 
   s->nodes = (o_node *)calloc(s->N ? s->N : 1, sizeof(o_node));
+  s->Wh = sn->port_words ? sn->port_words : 1;
+  s->pm_nodes = (uint64_t *)calloc((size_t)(s->N ? s->N : 1) * s->Wh, sizeof(uint64_t));
+  s->pm_base = (uint64_t *)calloc((size_t)(s->N ? s->N : 1) * s->Wh, sizeof(uint64_t));
+  s->pm_want = (uint64_t *)calloc((size_t)(s->T ? s->T : 1) * s->Wh, sizeof(uint64_t));
+  s->pm_conf = (uint64_t *)calloc((size_t)(s->T ? s->T : 1) * s->Wh, sizeof(uint64_t));
+  s->pm_scratch = (uint64_t *)calloc(s->Wh, sizeof(uint64_t));
   for (uint32_t n = 0; n < s->N; n++) {
     o_node *nd = &s->nodes[n];
     uint32_t m = sn->node_scalar_mask ? sn->node_scalar_mask[n] : 0;
@@ -1031,7 +1044,8 @@ kbo_session *kbo_open(const kb_config *cfg, const kb_snapshot *sn, int threads) 
     nd->nz_cpu = sn->node_nz_cpu[n]; nd->nz_mem = sn->node_nz_mem[n];
     nd->pod_cnt = sn->node_pod_cnt[n];
     nd->cls = sn->node_class ? sn->node_class[n] : 0;
-    nd->ports = sn->node_ports ? sn->node_ports[n] : 0;
+    nd->ports = s->pm_nodes + (size_t)n * s->Wh; nd->base_ports = s->pm_base + (size_t)n * s->Wh;
+    if (sn->node_ports) memcpy(nd->ports, sn->node_ports + (size_t)n * s->Wh, sizeof(uint64_t) * s->Wh);
   }
   s->tasks = (o_task *)calloc(s->T ? s->T : 1, sizeof(o_task));
   for (uint32_t t = 0; t < s->T; t++) {
@@ -1046,8 +1060,9 @@ kbo_session *kbo_open(const kb_config *cfg, const kb_snapshot *sn, int threads) 
     tk->job = sn->task_job[t];
     tk->cls = sn->task_class ? sn->task_class[t] : 0;
     tk->evict_protected = sn->task_evict_protected ? sn->task_evict_protected[t] : 0;
-    tk->port_want = sn->task_port_want ? sn->task_port_want[t] : 0;
-    tk->port_conflict = sn->task_port_conflict ? sn->task_port_conflict[t] : 0;
+    tk->port_want = s->pm_want + (size_t)t * s->Wh; tk->port_conflict = s->pm_conf + (size_t)t * s->Wh;
+    if (sn->task_port_want) memcpy(s->pm_want + (size_t)t * s->Wh, sn->task_port_want + (size_t)t * s->Wh, sizeof(uint64_t) * s->Wh);
+    if (sn->task_port_conflict) memcpy(s->pm_conf + (size_t)t * s->Wh, sn->task_port_conflict + (size_t)t * s->Wh, sizeof(uint64_t) * s->Wh);
     tk->priority = sn->task_priority[t];
     tk->creation = sn->task_creation[t];
     tk->status = sn->task_status[t];
@@ -1117,6 +1132,7 @@ void kbo_close(kbo_session *s) {
   if (!s) return;
   for (uint32_t j = 0; j < s->J; j++) heap_free(&s->jobs[j].tasks);
   for (uint32_t q = 0; q < s->Q; q++) heap_free(&s->queues[q].jobs);
+  free(s->pm_nodes); free(s->pm_base); free(s->pm_want); free(s->pm_conf); free(s->pm_scratch);
   free(s->nodes); free(s->tasks); free(s->jobs); free(s->queues); free(s->compat); free(s->affinity); free(s->evictions);
   fast_free(s);
   free(s->journal);
@@ -1157,7 +1173,7 @@ typedef struct fast_t {
 } fast_t;
 
 static int fast_same_shape(const kbo_session *s, const o_task *a, const o_task *b) {
-  if (a->cls != b->cls || a->nz_cpu != b->nz_cpu || a->nz_mem != b->nz_mem || a->port_want != b->port_want || a->port_conflict != b->port_conflict) return 0;
+  if (a->cls != b->cls || a->nz_cpu != b->nz_cpu || a->nz_mem != b->nz_mem || !pm_eq(a->port_want, b->port_want, s->Wh) || !pm_eq(a->port_conflict, b->port_conflict, s->Wh)) return 0;
   if (a->init_resreq.mask != b->init_resreq.mask) return 0;
   for (int d = 0; d < s->R; d++) if (a->init_resreq.v[d] != b->init_resreq.v[d]) return 0;
   return 1;
@@ -1166,7 +1182,9 @@ static uint64_t fast_hash(const kbo_session *s, const o_task *t) {
   uint64_t h = 0x9E3779B97F4A7C15ull ^ t->cls;
   for (int d = 0; d < s->R; d++) { uint64_t w; memcpy(&w, &t->init_resreq.v[d], 8); h = (h ^ w) * 0xFF51AFD7ED558CCDull; h ^= h >> 32; }
   h = (h ^ (uint64_t)t->nz_cpu) * 0xFF51AFD7ED558CCDull; h ^= h >> 29;
-  h = (h ^ (uint64_t)t->nz_mem ^ t->port_conflict ^ (t->port_want << 1) ^ t->init_resreq.mask) * 0xC4CEB9FE1A85EC53ull; h ^= h >> 32;
+  uint64_t pc = 0, pw = 0;
+  for (uint32_t w = 0; w < s->Wh; w++) { pc = (pc * 0x9E3779B97F4A7C15ull) ^ t->port_conflict[w]; pw = (pw * 0xC2B2AE3D27D4EB4Full) ^ t->port_want[w]; }
+  h = (h ^ (uint64_t)t->nz_mem ^ pc ^ (pw << 1) ^ t->init_resreq.mask) * 0xC4CEB9FE1A85EC53ull; h ^= h >> 32;
   return h;
 }
 static inline uint32_t fast_better(const double *key, uint32_t l, uint32_t r) {   /* left wins ties: lowest index among equal scores */
@@ -1363,14 +1381,13 @@ static void node_remove_task(kbo_session *s, uint32_t t) {
   nd->nz_cpu -= tk->nz_cpu;
   nd->nz_mem -= tk->nz_mem;
   /* host ports: UsedPorts is rebuilt from the remaining pods; with interned bits that needs the other pods' masks */
-  uint64_t ports = 0;
+  memcpy(nd->ports, nd->base_ports, sizeof(uint64_t) * s->Wh);
   if (s->node_head) {
-    for (uint32_t i = s->node_head[tk->node]; i != KB_NONE; i = s->next_on_node[i]) if (i != t) ports |= s->tasks[i].port_want;
+    for (uint32_t i = s->node_head[tk->node]; i != KB_NONE; i = s->next_on_node[i]) if (i != t) pm_or(nd->ports, s->tasks[i].port_want, s->Wh);
   } else {
     for (uint32_t i = 0; i < s->T; i++)
-      if (i != t && s->tasks[i].node == tk->node && s->tasks[i].on_node) ports |= s->tasks[i].port_want;
+      if (i != t && s->tasks[i].node == tk->node && s->tasks[i].on_node) pm_or(nd->ports, s->tasks[i].port_want, s->Wh);
   }
-  nd->ports = (nd->ports & ~tk->port_want) | ports | nd->base_ports;
   node_index_unlink(s, t);
   tk->on_node = 0;
 }
@@ -1401,7 +1418,7 @@ static int node_add_task(kbo_session *s, uint32_t t, uint32_t n, int status) {
   nd->pod_cnt += 1;
   nd->nz_cpu += tk->nz_cpu;
   nd->nz_mem += tk->nz_mem;
-  nd->ports |= tk->port_want;
+  pm_or(nd->ports, tk->port_want, s->Wh);
   return 0;
 }
 /* NodeInfo.UpdateTask (node_info.go:245-256) = RemoveTask + AddTask; an AddTask error there is glog.Fatalf — the process dies,
@@ -1638,7 +1655,7 @@ static int preempt_one(kbo_session *s, stmt_t *st, uint32_t preemptor, int mode,
  * `evals` counts N per preemptor in both modes.  tests/test_oracle_fast_cpu.py holds this mode to the faithful one.
  * ============================================================================================== */
 typedef struct pfast_list { uint32_t *nodes; uint32_t n; uint64_t built_at; int valid; } pfast_list;
-typedef struct pfast_shape { uint32_t cls; int64_t nz_cpu, nz_mem; uint64_t port_conflict; uint32_t rep; pfast_list *lists; /* [Q] */ } pfast_shape;
+typedef struct pfast_shape { uint32_t cls; int64_t nz_cpu, nz_mem; const uint64_t *port_conflict; /* [Wh], the representative's */ uint32_t rep; pfast_list *lists; /* [Q] */ } pfast_shape;
 typedef struct pfast_t {
   uint32_t *qn_begin, *qn_nodes;   /* per queue: nodes that held a Running task of it when the action started, ascending */
   uint8_t *qn_bits;                /* [Q][ceil(N/8)] the same as a bitmap */
@@ -1698,11 +1715,11 @@ static uint32_t pfast_shape_of(kbo_session *s, uint32_t t) {
   const o_task *tk = &s->tasks[t];
   if (t > 0 && f->task_shape[t - 1] != KB_NONE) {          /* the tasks of a job mostly repeat their predecessor */
     const pfast_shape *p = &f->shapes[f->task_shape[t - 1]];
-    if (p->cls == tk->cls && p->nz_cpu == tk->nz_cpu && p->nz_mem == tk->nz_mem && p->port_conflict == tk->port_conflict) return f->task_shape[t] = f->task_shape[t - 1];
+    if (p->cls == tk->cls && p->nz_cpu == tk->nz_cpu && p->nz_mem == tk->nz_mem && pm_eq(p->port_conflict, tk->port_conflict, s->Wh)) return f->task_shape[t] = f->task_shape[t - 1];
   }
   for (uint32_t i = 0; i < f->n_shapes; i++) {
     const pfast_shape *p = &f->shapes[i];
-    if (p->cls == tk->cls && p->nz_cpu == tk->nz_cpu && p->nz_mem == tk->nz_mem && p->port_conflict == tk->port_conflict) return f->task_shape[t] = i;
+    if (p->cls == tk->cls && p->nz_cpu == tk->nz_cpu && p->nz_mem == tk->nz_mem && pm_eq(p->port_conflict, tk->port_conflict, s->Wh)) return f->task_shape[t] = i;
   }
   if (f->n_shapes == f->cap_shapes) { f->cap_shapes = f->cap_shapes ? f->cap_shapes * 2 : 64; f->shapes = (pfast_shape *)realloc(f->shapes, sizeof(pfast_shape) * f->cap_shapes); }
   pfast_shape *p = &f->shapes[f->n_shapes];
@@ -1765,9 +1782,10 @@ int kbo_preempt(kbo_session *s) {
   if (s->panic) return KBO_PANIC;
   node_index_build(s);
   for (uint32_t n = 0; n < s->N; n++) {        /* ports of pods outside the session stay on the node whatever moves */
-    uint64_t mine = 0;
-    for (uint32_t t = s->node_head[n]; t != KB_NONE; t = s->next_on_node[t]) mine |= s->tasks[t].port_want;
-    s->nodes[n].base_ports = s->nodes[n].ports & ~mine;
+    uint64_t *mine = s->pm_scratch;
+    memset(mine, 0, sizeof(uint64_t) * s->Wh);
+    for (uint32_t t = s->node_head[n]; t != KB_NONE; t = s->next_on_node[t]) pm_or(mine, s->tasks[t].port_want, s->Wh);
+    for (uint32_t w = 0; w < s->Wh; w++) s->nodes[n].base_ports[w] = s->nodes[n].ports[w] & ~mine[w];
   }
   const int fast = s->fast && !(s->affinity && s->nodeorder_enabled) && !s->ip_on;   /* NormalizeReduce over the feasible set / inter-pod counters that evictions change: faithful */
   uint8_t *feas = (uint8_t *)malloc(s->N ? s->N : 1);
@@ -1844,9 +1862,10 @@ static void record_eviction(kbo_session *s, uint32_t t) {
 int kbo_reclaim(kbo_session *s) {
   if (s->panic) return KBO_PANIC;
   for (uint32_t n = 0; n < s->N; n++) {
-    uint64_t mine = 0;
-    for (uint32_t t = 0; t < s->T; t++) if (s->tasks[t].on_node && s->tasks[t].node == n) mine |= s->tasks[t].port_want;
-    s->nodes[n].base_ports = s->nodes[n].ports & ~mine;
+    uint64_t *mine = s->pm_scratch;
+    memset(mine, 0, sizeof(uint64_t) * s->Wh);
+    for (uint32_t t = 0; t < s->T; t++) if (s->tasks[t].on_node && s->tasks[t].node == n) pm_or(mine, s->tasks[t].port_want, s->Wh);
+    for (uint32_t w = 0; w < s->Wh; w++) s->nodes[n].base_ports[w] = s->nodes[n].ports[w] & ~mine[w];
   }
   heap_t queues; heap_init(&queues, queue_order_less, s);
   heap_t *qjobs = (heap_t *)calloc(s->Q ? s->Q : 1, sizeof(heap_t));

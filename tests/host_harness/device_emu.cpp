@@ -99,6 +99,10 @@ uint32_t eval_pair(const KbDev &d, const Row &t, uint32_t node, int fit_mode, bo
       ok = ok && ((d.compat[bit >> 3] >> (bit & 7)) & 1);
     }
     if (with_interpod && d.t_ip_forbid != nullptr && t.ip_checks && ok) ok = interpod_ok(d, t.task, node);
+    // host-port masks of several words: only the matrix side (K1: kb_k1.hpp eval_row) reads the words behind the first; the commit kernels keep to word 0
+    if (with_interpod)
+      for (uint32_t w = 0; w < d.port_xw; w++)
+        if (d.ports_x[(size_t)w * d.NP + node] & d.t_conf_x[(size_t)t.task * d.port_xw + w]) ok = false;
   }
   if (!ok) return 0;
   uint32_t score = 0;
@@ -538,6 +542,11 @@ void kb_launch_interpod(const KbDev &d, const KbRound &r, void *stream) {
   });
 }
 
+void kb_launch_or_ports_x(const KbDev &d, uint32_t task, uint32_t node, void *stream) {
+  kbemu_enqueue((hipStream_t)stream, [d, task, node]() {
+    for (uint32_t w = 0; w < d.port_xw; w++) d.ports_x[(size_t)w * d.NP + node] |= d.t_want_x[(size_t)task * d.port_xw + w];
+  });
+}
 void kb_launch_probe(const KbDev &d, const uint32_t *rows, uint32_t n_rows, uint32_t *alive, void *stream) {
   kbemu_enqueue((hipStream_t)stream, [d, rows, n_rows, alive]() {
   KbDev dd = d;

@@ -90,7 +90,11 @@ int eh_load(EH *h, const kb_config *cfg, const kb_snapshot *sn, const double *jo
     ln.nzc.assign(sn->node_nz_cpu, sn->node_nz_cpu + N); ln.nzm.assign(sn->node_nz_mem, sn->node_nz_mem + N);
     ln.podcnt.assign(sn->node_pod_cnt, sn->node_pod_cnt + N);
     ln.ports.assign(N, 0);
-    if (sn->node_ports) ln.ports.assign(sn->node_ports, sn->node_ports + N);
+    const size_t Wh = sn->port_words ? sn->port_words : 1;   // host-port masks: word 0 and, behind it, what HostSession::port_xw kept
+    for (uint32_t n = 0; n < N && sn->node_ports; n++) ln.ports[n] = sn->node_ports[(size_t)n * Wh];
+    ln.ports_x.assign((size_t)N * h->hs.port_xw, 0);
+    for (uint32_t n = 0; n < N && sn->node_ports; n++)
+      for (uint32_t w = 0; w < h->hs.port_xw; w++) ln.ports_x[(size_t)n * h->hs.port_xw + w] = sn->node_ports[(size_t)n * Wh + 1 + w];
     for (uint32_t n = 0; n < N; n++) {
       ln.idle[n].mask = h->nmask[n] & 0x3FFFFFFFu;
       for (int d = 0; d < R; d++) {
@@ -217,6 +221,7 @@ uint64_t eh_digest(const EH *h) {
   for (const Res &r : s.deserved) { mix(r.v, sizeof(r.v)); mix(&r.mask, sizeof(uint32_t)); }
   const uint32_t n[4] = {s.n_feas_shapes, s.n_row_shapes, s.n_tc, s.n_nc};
   mix(n, sizeof(n));
+  if (s.port_xw) { vec(s.t_want_x); vec(s.t_conf_x); vec(s.t_wide); }   // host-port masks of several words (the pinned digests predate them: one-word sessions hash as before)
   return x;
 }
 

@@ -8,6 +8,8 @@ Canonical orders wherever the Go code ranges over a map: ascend
 import math
 from typing import Dict, List, Optional
 
+import numpy as np
+
 MIN_CPU, MIN_SCALAR, MIN_MEM = 10.0, 10.0, 10.0 * 1024 * 1024          # api/resource_info.go:68-70
 PENDING, ALLOCATED, PIPELINED, BINDING, BOUND, RUNNING, RELEASING, SUCCEEDED, FAILED, UNKNOWN = range(10)
 NONE = 0xFFFFFFFF
@@ -200,7 +202,12 @@ class Session:
         self.nzc, self.nzm = [int(x) for x in s.node_nz_cpu], [int(x) for x in s.node_nz_mem]
         self.maxpods, self.podcnt = [int(x) for x in s.node_max_pods], [int(x) for x in s.node_pod_cnt]
         self.ncls = [int(x) for x in s.node_class]
-        self.nports = [int(x) for x in s.node_ports] if getattr(s, "node_ports", None) is not None else [0] * self.N
+        def masks(a, n):   # [n] or [n][Wh] 64-bit words -> one Python int per row (the reference keeps sets: no width)
+            if a is None:
+                return [0] * n
+            a = np.asarray(a, dtype=np.uint64).reshape(n, -1)
+            return [sum(int(a[i, w]) << (64 * w) for w in range(a.shape[1])) for i in range(n)]
+        self.nports = masks(getattr(s, "node_ports", None), self.N)
         # TaskInfo: InitResreq carries the keys of Resreq plus those an init container raised (pod_info.go:53-62)
         self.resreq = [res(s.task_resreq, s.task_scalar_mask, t) for t in range(self.T)]
         self.init = []
@@ -217,8 +224,7 @@ class Session:
         self.status = [int(x) for x in s.task_status]
         self.tnode = [int(x) for x in s.task_node]
         want, conf = getattr(s, "task_port_want", None), getattr(s, "task_port_conflict", None)
-        self.twant = [int(x) for x in want] if want is not None else [0] * self.T
-        self.tconf = [int(x) for x in conf] if conf is not None else [0] * self.T
+        self.twant, self.tconf = masks(want, self.T), masks(conf, self.T)
         self.jbegin = [int(x) for x in s.job_task_begin]
         self.jqueue, self.jmin = [int(x) for x in s.job_queue], [int(x) for x in s.job_min_available]
         self.jprio, self.jcre = [int(x) for x in s.job_priority], [int(x) for x in s.job_creation]

@@ -109,3 +109,37 @@ def raw_snapshot(seed: int):
                 s.node_ports[tnode[t]] |= s.task_port_want[t]
     s._check()
     return s
+
+
+def widen_ports(s, seed, words=3, p_task=0.5, p_node=0.4, low_share=0.5):
+    """Host-port masks of `words` 64-bit words on a raw snapshot (its own random stream: the snapshot's other fields and every fixture
+    drawn from raw_snapshot stay as they are).  A share of the pods keeps to word 0 (the engine's fast path), the others name triples
+    anywhere; a pod conflicts with what it wants plus, sometimes, a few neighbours (a wildcard IP)."""
+    rng = np.random.RandomState(seed)
+    N, T = int(s.n_nodes), int(s.n_tasks)
+    bits = 64 * words
+    want = np.zeros((T, words), np.uint64); conf = np.zeros((T, words), np.uint64); nodes = np.zeros((N, words), np.uint64)
+
+    def setbit(a, i, b):
+        a[i, b // 64] |= np.uint64(1) << np.uint64(b % 64)
+    pool = sorted(set(int(x) for x in rng.randint(0, bits, size=max(4, T // 6))) | {0, 1, 63, 64, bits - 1})
+    for t in range(T):
+        if rng.uniform() >= p_task:
+            continue
+        for _ in range(int(rng.randint(1, 3))):
+            b = int(rng.randint(0, 64)) if rng.uniform() < low_share else int(pool[rng.randint(0, len(pool))])
+            setbit(want, t, b); setbit(conf, t, b)
+            if rng.uniform() < 0.3:
+                for nb in (b ^ 1, (b + 64) % bits):
+                    setbit(conf, t, nb)
+    for n in range(N):
+        if rng.uniform() < p_node:
+            for _ in range(int(rng.randint(1, 4))):
+                setbit(nodes, n, int(pool[rng.randint(0, len(pool))]))
+    for t in range(T):
+        if s.task_node[t] != abi.KB_NONE:
+            nodes[s.task_node[t]] |= want[t]
+    s.node_ports, s.task_port_want, s.task_port_conflict = nodes, want, conf
+    s.port_words = words
+    s._check()
+    return s

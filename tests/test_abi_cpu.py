@@ -33,7 +33,7 @@ def test_struct_sizes_match_header():
     assert C.sizeof(abi.PluginOption) == 4 + 4 + 32 + 4
     assert C.sizeof(abi.Decision) == 16
     assert C.sizeof(abi.Config) == 8 + 8 + 8 + 16
-    assert C.sizeof(abi.Snapshot) == 32 + 8 * len(abi.SNAPSHOT_ARRAYS) + 8          # + the kb_interpod pointer
+    assert C.sizeof(abi.Snapshot) == 32 + 8 * len(abi.SNAPSHOT_ARRAYS) + 8 + 8      # + the kb_interpod pointer + port_words, pad (ABI 8)
     assert C.sizeof(abi.Interpod) == 24 + 8 * len(abi.INTERPOD_ARRAYS)
     assert C.sizeof(abi.Stats) == 9 * 8 + 6 * 8 + 4 * 8          # + the selection kernel's four counters (round 4)
 

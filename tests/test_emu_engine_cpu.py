@@ -90,17 +90,21 @@ def _adopt(module_name, only=None):
 
 
 # test_gpu_regressions: the cases the hunts on this emulated device produced (round 2), since promoted into the `-m gpu` suite
-for _m in ("test_gpu_parity", "test_gpu_fuzz", "test_gpu_adversarial", "test_gpu_interpod", "test_gpu_preempt", "test_framework_actions", "test_gpu_regressions"):
+for _m in ("test_gpu_parity", "test_gpu_fuzz", "test_gpu_adversarial", "test_gpu_interpod", "test_gpu_preempt", "test_framework_actions", "test_gpu_regressions",
+           "test_gpu_wideports"):
     _adopt(_m)
 
 
 # ---- the sharded path's entry points (kb_round_begin / candidates / commit / apply) through dist.py, CPU buffers ----------------
-def _sharded_cycle(so, min_rows_per_rank):
+def _sharded_cycle(so, min_rows_per_rank, wide_ports=False):
     import torch
     distmod = importlib.import_module("kube-batch_amd.dist")
     engine.LIB_PATH, engine._LIB = so, None
     conf = kbm.conf.load_scheduler_conf()
     snap = kbm.snapshot.synth(kbm.snapshot.synth_config(3, 0.05))
+    if wide_ports:                         # host-port masks of three words: pods that reach beyond word 0 get rounds of their own on this path too
+        import rawgen
+        rawgen.widen_ports(snap, 77, words=3, p_task=0.3)
     eng = engine.Engine(conf, device=0, window=256)
     eng.load(snap)
     cpu = torch.device("cpu")       # the emulated "device" memory is host memory: torch's CPU tensors are its buffers
@@ -117,6 +121,16 @@ def test_sharded_rounds_world1_equal_the_oracle(emulated_engine, oracle_mod):
     for a, b in zip(cyc.engine.node_state(), o.node_state()):
         assert np.array_equal(a, b)
     assert np.array_equal(cyc.step(), dec)                 # reset + second cycle: identical
+
+
+def test_sharded_rounds_with_host_port_masks_of_several_words(emulated_engine, oracle_mod):
+    conf, snap, cyc = _sharded_cycle(emulated_engine, 32, wide_ports=True)
+    dec = cyc.step()
+    o = oracle_mod.Oracle(conf, snap)
+    o.run(["allocate", "backfill"])
+    assert np.array_equal(dec, o.decisions())
+    assert np.array_equal(cyc.engine.binds(), o.binds())
+    assert np.array_equal(cyc.step(), dec)
 
 
 def _sharded_worker(rank, world, port, out_dir, so):

@@ -335,8 +335,8 @@ def test_host_ports_predicate_and_accounting(oracle_mod):
 
 
 def test_host_ports_that_no_pending_pod_can_conflict_with_get_no_bit(oracle_mod):
-    """The 64-bit host-port table only interns triples a Pending pod's port can conflict with: what running daemons listen on does not
-    count against the limit, and the pruned table decides like the complete one."""
+    """The host-port table only interns triples a Pending pod's port can conflict with: what running daemons listen on does not widen the
+    masks, and the pruned table decides like the complete one."""
     S = kbm.snapshot
     nodes = [S.Node(f"n{i}", {"cpu": "8", "memory": "16Gi", "pods": "110"}) for i in range(4)]
     daemons = [S.Pod("kube-system", f"d{i:03d}", [{"cpu": "10m"}], node_name=f"n{i % 4}", phase="Running", host_ports=[("", "TCP", 9000 + i)])
@@ -344,25 +344,29 @@ def test_host_ports_that_no_pending_pod_can_conflict_with_get_no_bit(oracle_mod)
     daemons.append(S.Pod("kube-system", "web-n2", [{"cpu": "10m"}], node_name="n2", phase="Running", host_ports=[("10.0.0.7", "TCP", 80)]))
     pending = [S.Pod("ns", f"web{i}", [{"cpu": "1"}], group_name="g", host_ports=[("", "", 80)]) for i in range(4)] + \
               [S.Pod("ns", "plain", [{"cpu": "1"}], group_name="g")]
-    with pytest.raises(ValueError, match="64 distinct host ports"):
-        S.flatten(nodes, daemons + pending, [S.PodGroup("ns", "g")], [S.Queue("default")], prune_ports=False)
     snap = S.flatten(nodes, daemons + pending, [S.PodGroup("ns", "g")], [S.Queue("default")])
+    assert snap.port_words == 1
     assert snap.node_ports.tolist() == [0, 0, 2, 0]                    # bits: 0 = 0.0.0.0/TCP/80 (asked), 1 = 10.0.0.7/TCP/80 (conflicts with it)
     assert sorted(set(snap.task_port_want.tolist())) == [0, 1] and sorted(set(snap.task_port_conflict.tolist())) == [0, 3]
     o = oracle_mod.Oracle(kbm.conf.load_scheduler_conf(), snap)
     o.run(["allocate", "backfill"])
     binds = snap.bind_map(o.binds())
     assert sorted(binds[f"ns/web{i}"] for i in range(4) if f"ns/web{i}" in binds) == ["n0", "n1", "n3"]   # n2 is taken, the fourth finds none
-    # with few enough ports for both tables: same decisions
+    # the complete tables — one word with few daemons, two words with all of them (kb_snapshot.port_words; the triples the Pending pods'
+    # ports conflict with take the low bits) — decide like the pruned one
     few = daemons[:40] + daemons[-1:] + pending
     a = S.flatten(nodes, few, [S.PodGroup("ns", "g")], [S.Queue("default")])
     b = S.flatten(nodes, few, [S.PodGroup("ns", "g")], [S.Queue("default")], prune_ports=False)
+    c = S.flatten(nodes, daemons + pending, [S.PodGroup("ns", "g")], [S.Queue("default")], prune_ports=False)
+    assert (a.port_words, b.port_words, c.port_words) == (1, 1, 2) and c.node_ports.shape == (4, 2)
+    assert c.node_ports[:, 0].tolist()[2] & 3 == 2 and sorted(set(c.task_port_conflict[:, 0].tolist())) == [0, 3]   # the same two low bits
     res = []
-    for sn in (a, b):
+    for sn in (a, b, c):
         o = oracle_mod.Oracle(kbm.conf.load_scheduler_conf(), sn)
         o.run(["allocate", "backfill"])
         res.append(sn.bind_map(o.binds()))
     assert res[0] == res[1] and len(res[0]) == 4
+    assert res[2] == binds                                             # all daemons: two words against the pruned single word
 
 
 def _preempt_tiers():

@@ -101,6 +101,21 @@ def _tiers(cfg):
 @pytest.mark.parametrize("seed", range(80))
 def test_python_restatement_equals_c_oracle(oracle_mod, seed):
     cfg, snap = _case(seed)
+    _compare(oracle_mod, cfg, snap, seed)
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_host_port_masks_of_several_words(oracle_mod, seed):
+    """kb_snapshot.port_words > 1: more than 64 interned (ip, protocol, port) triples.  The Python side keeps one unbounded integer per
+    mask (the reference keeps sets), the C side words: the two must still agree on every decision."""
+    import rawgen
+    cfg, snap = _case(seed)
+    rawgen.widen_ports(snap, 4400 + seed, words=2 + seed % 3)
+    assert snap.port_words == 2 + seed % 3 and snap.task_port_conflict.shape == (snap.n_tasks, snap.port_words)
+    _compare(oracle_mod, cfg, snap, seed)
+
+
+def _compare(oracle_mod, cfg, snap, seed):
     o = oracle_mod.Oracle(cfg, snap)
     o.run(["allocate", "backfill"])
     p = pyref.Session(_tiers(cfg), snap).run(["allocate", "backfill"])
