@@ -1737,6 +1737,7 @@ static int run_evict_action(kb_engine *e, bool reclaim, kb_stmt_op *out, uint64_
     LiveNodes ln;
     std::vector<uint8_t> counted_in;
     const double t_e0 = now_ms();
+    double t_e_copy = t_e0, t_e_nodes = t_e0, t_e_tasks = t_e0;   // entry, in parts (KB_EVICT_TRACE)
     {
       // one pinned block, every copy asynchronous on the engine's stream, ONE synchronisation (round 3: seven blocking pageable copies)
       const size_t o_idle = 0, o_rel = o_idle + sizeof(double) * (size_t)R * NP, o_nzc = o_rel + sizeof(double) * (size_t)R * NP, o_nzm = o_nzc + sizeof(long long) * NP,
@@ -1753,6 +1754,7 @@ static int run_evict_action(kb_engine *e, bool reclaim, kb_stmt_op *out, uint64_
       HIP_OK(hipMemcpyAsync(hb + o_pod, e->b_podcnt.p, sizeof(int) * NP, hipMemcpyDeviceToHost, e->stream));
       if (T) HIP_OK(hipMemcpyAsync(hb + o_cnt, e->b_tcounted.p, T, hipMemcpyDeviceToHost, e->stream));
       HIP_OK(hipStreamSynchronize(e->stream));
+      t_e_copy = now_ms();
       const double *idle = reinterpret_cast<const double *>(hb + o_idle), *rel = reinterpret_cast<const double *>(hb + o_rel);
       const uint32_t *nmask = reinterpret_cast<const uint32_t *>(hb + o_nmask);
       ln.nzc.assign(reinterpret_cast<const long long *>(hb + o_nzc), reinterpret_cast<const long long *>(hb + o_nzc) + NP);
@@ -1789,6 +1791,7 @@ static int run_evict_action(kb_engine *e, bool reclaim, kb_stmt_op *out, uint64_
       ln.ac.assign(hs.n_ac.begin(), hs.n_ac.end()); ln.am.assign(hs.n_am.begin(), hs.n_am.end());
       ln.maxpods = hs.n_maxpods; ln.cls = hs.n_cls;
     }
+    t_e_nodes = now_ms();
     PreemptMachine pm;
     pm.counted.assign(counted_in.begin(), counted_in.end());
     if (pm.counted.empty()) pm.counted.resize(1);
@@ -1839,6 +1842,7 @@ static int run_evict_action(kb_engine *e, bool reclaim, kb_stmt_op *out, uint64_
     auto refresh = [&](const std::vector<uint32_t> &nodes) { const double t0 = now_ms(); upload_live_nodes(e, ln, nodes); tl_refresh += now_ms() - t0; n_refresh++; };
     std::vector<uint8_t> status = hs.t_status;
     std::vector<uint32_t> tnode = hs.t_node;
+    t_e_tasks = now_ms();
     pm.init(&hs, &e->pol, &ln, &status, &tnode, lists, refresh);
     // inter-pod terms: the live counts (allocate / backfill of this session may have advanced them) come to the host; the machine keeps them
     // current and puts them back on the device in front of every list it asks for, and once more when the action is over
@@ -1889,6 +1893,7 @@ static int run_evict_action(kb_engine *e, bool reclaim, kb_stmt_op *out, uint64_
     e->evictions.insert(e->evictions.end(), pm.evictions.begin(), pm.evictions.end());
     for (const StmtOp &op : pm.ops)   // Evict / Pipeline fire proportion's handlers -> updateShare for the task's queue
       if (op.task != KB_NONE && hs.job_queue[hs.t_job[op.task]] < Q) hs.queue_share_live[hs.job_queue[hs.t_job[op.task]]] = 1;
+    const double t_x_fin = now_ms();
     run_finalize(e);
     // the host's running drf / proportion aggregates must equal the device reduction over the task table
     if (e->pol.has_drf)
@@ -1899,6 +1904,9 @@ static int run_evict_action(kb_engine *e, bool reclaim, kb_stmt_op *out, uint64_
     e->stats.total_ms += now_ms() - t_begin;
     static const bool ev_trace = [] { const char *v = getenv("KB_EVICT_TRACE"); return v && v[0] == '1'; }();
     if (ev_trace)   // host timeline of the action (profiles/round4)
+      fprintf(stderr, "[kb evict] %s: entry %.2f ms = copies %.2f + node mirror %.2f + task tables %.2f + machine tables %.2f; machine set-up %.2f ms (job / task queues) + run; exit: journal + state back %.2f, finalize + checks %.2f\n",
+              reclaim ? "reclaim" : "preempt", t_e1 - t_e0, t_e_copy - t_e0, t_e_nodes - t_e_copy, t_e_tasks - t_e_nodes, t_e1 - t_e_tasks, pm.tr_setup_ms, t_x_fin - t_e2, now_ms() - t_x_fin);
+    if (ev_trace)
       fprintf(stderr, "[kb evict] %s: entry (state to the host, machine set-up) %.2f ms; machine %.2f ms of which %llu lists %.2f ms on the device + %.2f ms host reorder, %llu node refreshes %.2f ms; exit (journal, state back, finalize, checks) %.2f ms; popped %llu (walked %llu: %.2f ms, %llu nodes tried; skipped with their job %llu, turned away one by one %llu, own-job preemptors the priority rule excludes %llu), journal %zu\n",
               reclaim ? "reclaim" : "preempt", t_e1 - t_e0, t_e2 - t_e1, (unsigned long long)n_lists, tl_lists, tl_lists_host, (unsigned long long)n_refresh, tl_refresh, now_ms() - t_e2,
               (unsigned long long)pm.popped, (unsigned long long)pm.tr_walks, pm.tr_walk_ms, (unsigned long long)pm.tr_tries, (unsigned long long)pm.tr_skipped, (unsigned long long)pm.tr_shortcut, (unsigned long long)pm.tr_pruned, pm.ops.size());

@@ -640,7 +640,15 @@ bool PreemptMachine::preempt_walk(uint32_t preemptor, int mode) {
     }
   }
   const uint32_t sh = hs_->t_row_shape[preemptor];
-  if (!shape_have_[sh]) {
+  const uint32_t pj = hs_->t_job[preemptor], pq = hs_->job_queue[pj];
+  // With the priority rule deciding, only the few nodes that hold a lower-priority Running task of the preemptor's queue are ever tried
+  // (below): their keys are a handful of evaluations, which the host makes itself (host_eval: the scorer the lists are repaired with,
+  // bit for bit the device's) — no list of all N nodes is fetched, sorted and ranked for the shape.  Round 4: 319 lists = 26 ms on the
+  // device + 4 ms of host reordering + a 50k-entry rank table each, at 1M x 50k.  Scores that are normalised over the feasible set
+  // (preferred node affinity, inter-pod terms) still need the device's list.
+  const bool queue_candidates = prio_prunes_ && mode == 0 && pq < hs_->Q;
+  const bool host_keys = queue_candidates && !needs_exact_list(preemptor) && !ip_;
+  if (!host_keys && !shape_have_[sh]) {
     std::vector<uint64_t> keys;
     lists_(preemptor, keys);
     shape_list_[sh].assign(keys.begin(), keys.end());
@@ -650,8 +658,7 @@ bool PreemptMachine::preempt_walk(uint32_t preemptor, int mode) {
     for (size_t i = 0; i < keys.size(); i++) rk[(uint32_t)keys[i]] = (int32_t)i;
   }
   const std::vector<uint64_t> &L = shape_list_[sh];
-  const uint32_t pj = hs_->t_job[preemptor], pq = hs_->job_queue[pj];
-  if (prio_prunes_ && mode == 0 && pq < hs_->Q) {
+  if (queue_candidates) {
     // Only nodes that hold a Running task of the preemptor's queue with a lower job priority can yield victims (try_node would
     // reject every other node at once), and there are few of them: take THEIR keys — the list entry for a clean node, a live
     // re-evaluation for a node a Pipeline changed — and walk them in SortNodes' order.  Same nodes, same order, same outcome
@@ -661,7 +668,7 @@ bool PreemptMachine::preempt_walk(uint32_t preemptor, int mode) {
     const std::vector<int32_t> &rank = shape_rank_[sh];
     for (uint32_t n : qnodes_[pq]) {
       if (minprio(pq, n) >= pp) continue;
-      if (dirty_[n]) {
+      if (host_keys || dirty_[n]) {
         long long sc;
         if (host_eval(preemptor, n, sc)) C.push_back(((uint64_t)sc << 32) | n);
       } else if (rank[n] >= 0) {
@@ -708,10 +715,17 @@ void PreemptMachine::init(const HostSession *hs, const Policy *pol, LiveNodes *l
   for (uint32_t t = 0; t < T; t++) if (hs->t_job[t] < J) cnt[(size_t)hs->t_job[t] * 10 + (*status)[t]]++;
   node_status.assign(T, 0);
   on_node.assign(T, 0);
-  ntasks_.assign(N, {});
-  for (uint32_t t = 0; t < T; t++) {
-    node_status[t] = (*status)[t];
-    if ((*tnode)[t] != KB_NONE && (*tnode)[t] < N && !(!hs->t_off_node.empty() && hs->t_off_node[t])) { on_node[t] = 1; ntasks_[(*tnode)[t]].push_back(t); }
+  ntasks_.resize(N);
+  {   // a node's tasks, ascending: counted first, so that every list is allocated once (1M tasks on 50k nodes: no regrowth), and the lists
+      // keep their storage from one action to the next
+    std::vector<uint32_t> per(N ? N : 1, 0);
+    for (uint32_t t = 0; t < T; t++) {
+      node_status[t] = (*status)[t];
+      if ((*tnode)[t] != KB_NONE && (*tnode)[t] < N && !(!hs->t_off_node.empty() && hs->t_off_node[t])) { on_node[t] = 1; per[(*tnode)[t]]++; }
+    }
+    for (uint32_t n = 0; n < N; n++) { ntasks_[n].clear(); ntasks_[n].reserve(per[n] + 4u); }
+    for (uint32_t t = 0; t < T; t++)
+      if (on_node[t]) ntasks_[(*tnode)[t]].push_back(t);
   }
   nd_->base_ports.assign(N, 0);
   if (!hs->t_want.empty())
@@ -766,6 +780,7 @@ void PreemptMachine::off_node_tasks(std::vector<uint8_t> &off) const {
 // QueueID, jobs ascending JobID (underRequest), a node's tasks ascending task index.
 void PreemptMachine::run() {
   const uint32_t J = hs_->J, Q = hs_->Q;
+  const auto t_run0 = std::chrono::steady_clock::now();
   auto jl = [this](uint32_t l, uint32_t r) { return job_less(l, r); };
   auto tl = [this](uint32_t l, uint32_t r) { return task_less(l, r); };
   std::vector<GoHeap<decltype(jl)>> qjobs(Q ? Q : 1, GoHeap<decltype(jl)>(jl));   // preemptorsMap
@@ -784,6 +799,7 @@ void PreemptMachine::run() {
   std::vector<uint32_t> active;   // under-request jobs whose task queue is not empty, ascending
   for (uint32_t j = 0; j < J; j++)
     if (under[j] && !jtasks.empty(j)) active.push_back(j);
+  tr_setup_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_run0).count();
   for (uint32_t q = 0; q < Q; q++) {
     if (!qseen[q]) continue;
     for (;;) {   // between jobs within the queue (preempt.go:80-139)

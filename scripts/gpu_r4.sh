@@ -5,6 +5,7 @@
 #   profile  rocprofv3: kernel stats, HBM bytes of the matrix launches, SQ counters of the commit kernels (scripts/summarize_profile.py r4_profile profiles/round4)
 #   evict    1M x 50k allocate + backfill + preempt: host timeline of the evict action, session-load phases, kernel stats
 #   hunt     fresh-seed differential hunt under the three commit kernels
+#   wide     host-port masks of several words: their differential cases on the device, then the default bench (K1 gained a branch)
 #   suite    the whole -m gpu suite
 #   bench    the default bench line and the variants
 set -uo pipefail
@@ -34,6 +35,13 @@ sel)
       echo "== trace ${tag}" | tee -a "$out/summary.txt"; grep -h "kb K5 trace\|kb K5\] rounds [0-9]" "$out/trace_${tag}.err" | tee -a "$out/summary.txt"
     fi
   done
+  ;;
+wide)
+  timeout 900 python -m pytest tests/test_gpu_wideports.py -q -m gpu -p no:cacheprovider --maxfail=10 > "$out/pytest_wide.txt" 2>&1
+  echo "host-port masks of several words rc=$? $(tail -1 "$out/pytest_wide.txt")" | tee -a "$out/summary.txt"
+  timeout 900 python -m pytest tests/test_gpu_fuzz.py tests/test_gpu_preempt.py -q -m gpu -p no:cacheprovider --maxfail=10 -k "not select and not run" > "$out/pytest_ports.txt" 2>&1
+  echo "fuzz + preempt suites (one-word host ports among them) rc=$? $(tail -1 "$out/pytest_ports.txt")" | tee -a "$out/summary.txt"
+  bench_ab "c3" -- --config 3 --steps 5 --warmup 2 --verify
   ;;
 trace)   # the selection kernel's per-phase trace only (make EXTRA=-DKB_K9_TRACE OUT=../libkbengine_trace.so)
   for cfg in "3" "4"; do
