@@ -63,7 +63,7 @@ def commit_kernel(request):
 # KB_RECORD_SKIPS=<file> python -m pytest tests/test_emu_engine_cpu.py; the envelope is host logic, identical on the emulated and the
 # real device) and any OTHER skip of a differential case is turned into a failure, on the GPU box and on the emulated device alike.
 _ENVELOPE_MODULES = {"test_gpu_parity", "test_gpu_fuzz", "test_gpu_adversarial", "test_gpu_interpod", "test_gpu_preempt",
-                     "test_framework_actions", "test_gpu_regressions", "test_gpu_fullsize", "test_gpu_sharded"}
+                     "test_framework_actions", "test_gpu_regressions", "test_gpu_fullsize", "test_gpu_sharded", "test_gpu_wideports"}
 _expected_skips = None
 
 
