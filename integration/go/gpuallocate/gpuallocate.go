@@ -69,7 +69,7 @@ func (a *gpuAllocateAction) Execute(ssn *framework.Session) {
 		return
 	}
 	fl, err := flatten(ssn)                              // canonical order + SoA arrays in C memory (C.calloc), see flatten.go
-	if err != nil {                                      // e.g. host ports / inter-pod affinity: not modelled by the engine
+	if err != nil {                                      // e.g. a PVC pod in a session with inter-pod terms: outside the engine's envelope
 		glog.V(3).Infof("gpuallocate: %v; stock action takes this cycle", err)
 		a.stock(ssn)
 		return
