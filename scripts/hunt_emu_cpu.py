@@ -4,6 +4,7 @@ suite; they look for host-side bugs (kb_engine.cpp), not kernel bugs.  python sc
   reset    run a mixed action order, kb_session_reset, run it again: journals, evictions and all state identical
   reload   ONE engine per tier layout, hundreds of different sessions through it (kb_session_load every cycle, as the Go action does): == oracle
   sharded  the round-granular entry points (kb_round_*) through dist.ShardedCycle at world size 1, exchanging always / never: == oracle
+  wideports  host-port masks of 2..5 words on raw / fuzz / evict snapshots under mixed action orders, reset + second run on some: == oracle
 Exit code 1 on any difference.  (allocate + backfill and the evict orders against the oracle: scripts/gpu_hunt.py and
 scripts/hunt_evict_cpu.py with KB_HUNT_EMU=1.)"""
 import importlib
@@ -131,6 +132,48 @@ def hunt_sharded(lo, hi):
     return bad
 
 
+def hunt_wideports(lo, hi):
+    import test_gpu_fuzz as fuzz
+    import test_gpu_preempt as pre
+    orders = [["allocate", "backfill"], ["allocate", "backfill", "preempt"], ["reclaim", "allocate", "backfill", "preempt"], ["preempt", "allocate", "backfill"], ["preempt"], ["reclaim", "preempt"]]
+    bad = ok = skip = 0
+    for seed in range(lo, hi):
+        for kind in ("raw", "fuzz", "evict"):
+            if kind == "raw":
+                snap = rawgen.raw_snapshot(seed)
+            elif kind == "fuzz":
+                snap = fuzz._case(seed % 40)[1]
+            else:
+                snap = cases._evict_case(seed)[1]
+            rawgen.widen_ports(snap, 70000 + seed, words=2 + seed % 4, p_task=[0.3, 0.6, 0.9][seed % 3], low_share=[0.0, 0.5, 0.9][(seed // 3) % 3])
+            order = orders[(seed // 2) % len(orders)] if kind != "fuzz" else orders[0]
+            cfg = conf.load_scheduler_conf(CONFS[seed % len(CONFS)].format(actions=", ".join(order)))
+            o = oracle.Oracle(cfg, snap)
+            try:
+                o.run(order)
+            except RuntimeError:
+                skip += 1; o.close(); continue
+            e = engine.Engine(cfg, window=[0, 64, 100, 256][seed % 4])
+            try:
+                e.load(snap); e.run(order)
+                pre._compare(e, o, snap, (kind, seed), cfg)
+                if seed % 5 == 0:
+                    first = [e.binds().copy(), np.array(e.evictions())]
+                    e.reset(); e.run(order)
+                    assert np.array_equal(first[0], e.binds()) and np.array_equal(first[1], np.array(e.evictions())), "reset"
+                ok += 1
+            except engine.EngineError as err:
+                if err.code in (abi.KB_E_UNSUPPORTED, abi.KB_E_INVALID):
+                    skip += 1
+                else:
+                    bad += 1; print("ENGINE ERROR", kind, seed, order, err, flush=True)
+            except AssertionError as err:
+                bad += 1; print("WIDE PORTS DIVERGE", kind, seed, order, str(err)[:200], flush=True)
+            e.close(); o.close()
+    print(f"[{lo},{hi}): {ok} equal, {skip} skipped, {bad} differ")
+    return bad
+
+
 if __name__ == "__main__":
     mode, lo, hi = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
-    sys.exit(1 if {"reset": hunt_reset, "reload": hunt_reload, "sharded": hunt_sharded}[mode](lo, hi) else 0)
+    sys.exit(1 if {"reset": hunt_reset, "reload": hunt_reload, "sharded": hunt_sharded, "wideports": hunt_wideports}[mode](lo, hi) else 0)
