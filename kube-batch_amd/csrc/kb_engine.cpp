@@ -146,7 +146,13 @@ struct kb_engine {
   int commit_kernel = KB_COMMIT_BATCH, commit_pin = -1, dirty_kernel = KB_COMMIT_RUN;
   double dirty_share = 0.0;
   uint64_t rounds_batch = 0, rounds_run = 0, rounds_sel = 0;
-  int kernel_policy = 1;           // 1: by measured commit time per row (default); 0: by the share of dirty-won rows (KB_KERNEL_POLICY=share)
+  // which commit kernel an allocate round runs on (all three compute the same decisions; backfill rounds: the batch kernel):
+  //   2 (default): the selection kernel.  Same-box runs of the five configurations, per-round choice by measurement / selection pinned / batch
+  //      pinned: C2 7.07 / 6.90 / 9.65 ms, C3 50.8 / 49.1, survey 69.4 / 68.4, C4 79.1 / 78.4, C5 323.2 / 310.6 / 328.3 — the measured choice put
+  //      18 % (C3) to 40 % (C5) of the rounds on the batch kernel and lost to plain selection every time (profiles/round4/call30_pinned_kernels)
+  //   1 KB_KERNEL_POLICY=measured: by measured commit time per committed row (round 4's first rule)
+  //   0 KB_KERNEL_POLICY=share: by the share of dirty-won rows (round 3's rule)
+  int kernel_policy = 2;
   double kernel_cost[2] = {0.0, 0.0};   // ms per committed row: batch kernel, selection kernel (exponential averages)
   double last_commit_ms = 0.0;
   uint64_t last_probe_round = 0;
@@ -550,7 +556,7 @@ void round_commit(kb_engine *e, const RoundCtx &c, unsigned long long *keys, dou
   r.own_row1 = own1;
   auto launch = [&]() {
     // backfill rounds (no scores, no runs to select from: every row takes the first node that passes) stay on the batch kernel unless pinned
-    const int kern = (e->commit_pin < 0 && e->kernel_policy == 1 && r.backfill) ? (int)KB_COMMIT_BATCH : e->commit_kernel;
+    const int kern = (e->commit_pin < 0 && e->kernel_policy >= 1 && r.backfill) ? (int)KB_COMMIT_BATCH : e->commit_kernel;
     e->commit_kernel_of[c.buf] = kern;
     if (kern == KB_COMMIT_RUN) { kb_launch_commit(c.d, r, e->stream); e->rounds_run++; }
     else if (kern == KB_COMMIT_SELECT) { kb_launch_commit_sel(c.d, r, e->stream); e->rounds_sel++; }
@@ -655,6 +661,8 @@ void round_collect(kb_engine *e, const RoundCtx &c, bool had_candidates, uint32_
   }
   if (e->commit_pin >= 0) {
     e->commit_kernel = e->commit_pin;
+  } else if (e->kernel_policy == 2) {
+    e->commit_kernel = KB_COMMIT_SELECT;
   } else if (e->kernel_policy == 0) {   // KB_KERNEL_POLICY=share, the round-3 rule: by the share of dirty-won rows
     if (e->commit_kernel == KB_COMMIT_BATCH && e->dirty_share > 0.30) e->commit_kernel = e->dirty_kernel;
     else if (e->commit_kernel != KB_COMMIT_BATCH && e->dirty_share < 0.15) e->commit_kernel = KB_COMMIT_BATCH;
@@ -1087,7 +1095,7 @@ int kb_engine_create(const kb_config *cfg, kb_engine **out) {
         else if (ck[0] == 's') eng->commit_pin = KB_COMMIT_SELECT;
         if (eng->commit_pin >= 0) eng->commit_kernel = eng->commit_pin;
       }
-      if (const char *kp = getenv("KB_KERNEL_POLICY")) eng->kernel_policy = kp[0] == 's' ? 0 : 1;
+      if (const char *kp = getenv("KB_KERNEL_POLICY")) eng->kernel_policy = kp[0] == 's' && kp[1] == 'h' ? 0 : (kp[0] == 'm' ? 1 : 2);   // share | measured | select
       if (const char *dk = getenv("KB_DIRTY_KERNEL")) {
         if (dk[0] == 'r') eng->dirty_kernel = KB_COMMIT_RUN;
         else if (dk[0] == 's') eng->dirty_kernel = KB_COMMIT_SELECT;
@@ -1509,7 +1517,7 @@ int kb_session_load(kb_engine *e, const kb_snapshot *sn) {
     e->dirty_share = 0.0;
     e->kernel_cost[0] = e->kernel_cost[1] = 0.0;
     e->last_probe_round = 0;
-    e->commit_kernel = e->commit_pin >= 0 ? e->commit_pin : KB_COMMIT_BATCH;
+    e->commit_kernel = e->commit_pin >= 0 ? e->commit_pin : (e->kernel_policy == 2 ? (int)KB_COMMIT_SELECT : (int)KB_COMMIT_BATCH);
     e->round_no = 0;
     mark("jobs, queues, deserved");
     auto snap_copy = [&](DevBuf &dst, const DevBuf &src) {

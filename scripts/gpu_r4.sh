@@ -6,6 +6,7 @@
 #   evict    1M x 50k allocate + backfill + preempt: host timeline of the evict action, session-load phases, kernel stats
 #   hunt     fresh-seed differential hunt under the three commit kernels
 #   wide     host-port masks of several words: their differential cases on the device, then the default bench (K1 gained a branch)
+#   pin      configs 5 and 2 pinned to the selection / the batch kernel beside the per-round choice (what the policy costs or gains)
 #   suite    the whole -m gpu suite
 #   bench    the default bench line and the variants
 set -uo pipefail
@@ -91,6 +92,14 @@ c4)   # config 4 (R = 16: scalar dimensions) pinned to the selection kernel, wit
   ;;
 hunt)   # fresh seeds beyond the committed suite, engine vs oracle under the three commit kernels (scripts/gpu_hunt.py; KB_HUNT_OFFSET shifts the seeds)
   KB_HUNT_OFFSET=${KB_HUNT_OFFSET:-40000} timeout 1200 python scripts/gpu_hunt.py ${1:-300} ${2:-900} ${3:-400} > "$out/hunt.txt" 2>&1; echo "hunt rc=$? $(tail -2 "$out/hunt.txt" | tr '\n' ' ')" | tee -a "$out/summary.txt"
+  ;;
+pin)
+  for cfg in 5 2; do
+    st=3; [ "$cfg" = 2 ] && st=10
+    bench_ab "c${cfg}_auto" -- --config $cfg --steps $st --warmup 1 --verify
+    bench_ab "c${cfg}_pinsel" KB_COMMIT_KERNEL=select -- --config $cfg --steps $st --warmup 1 --verify
+    bench_ab "c${cfg}_pinbatch" KB_COMMIT_KERNEL=batch -- --config $cfg --steps $st --warmup 1 --verify
+  done
   ;;
 suite)
   timeout 1500 python -m pytest tests -q -m gpu -p no:cacheprovider "$@" > "$out/pytest_gpu.txt" 2>&1; echo "gpu suite rc=$? $(tail -1 "$out/pytest_gpu.txt")" | tee -a "$out/summary.txt"
