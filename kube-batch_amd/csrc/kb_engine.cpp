@@ -146,8 +146,9 @@ struct kb_engine {
   int commit_kernel = KB_COMMIT_BATCH, commit_pin = -1, dirty_kernel = KB_COMMIT_RUN;
   double dirty_share = 0.0;
   uint64_t rounds_batch = 0, rounds_run = 0, rounds_sel = 0;
-  // which commit kernel an allocate round runs on (all three compute the same decisions; backfill rounds: the batch kernel):
-  //   2 (default): the selection kernel.  Same-box runs of the five configurations, per-round choice by measurement / selection pinned / batch
+  // which commit kernel a round runs on (all three compute the same decisions):
+  //   2 (default): the selection kernel, backfill rounds included (its row loop; 1M x 50k: ~80 backfill rounds whose rows all go for the same
+  //      first node — the batch kernel's slowest case: 323.8 ms with them on the batch kernel, 310.6 on this one).  Same-box runs of the five configurations, per-round choice by measurement / selection pinned / batch
   //      pinned: C2 7.07 / 6.90 / 9.65 ms, C3 50.8 / 49.1, survey 69.4 / 68.4, C4 79.1 / 78.4, C5 323.2 / 310.6 / 328.3 — the measured choice put
   //      18 % (C3) to 40 % (C5) of the rounds on the batch kernel and lost to plain selection every time (profiles/round4/call30_pinned_kernels)
   //   1 KB_KERNEL_POLICY=measured: by measured commit time per committed row (round 4's first rule)
@@ -556,7 +557,7 @@ void round_commit(kb_engine *e, const RoundCtx &c, unsigned long long *keys, dou
   r.own_row1 = own1;
   auto launch = [&]() {
     // backfill rounds (no scores, no runs to select from: every row takes the first node that passes) stay on the batch kernel unless pinned
-    const int kern = (e->commit_pin < 0 && e->kernel_policy >= 1 && r.backfill) ? (int)KB_COMMIT_BATCH : e->commit_kernel;
+    const int kern = (e->commit_pin < 0 && e->kernel_policy == 1 && r.backfill) ? (int)KB_COMMIT_BATCH : e->commit_kernel;   // (the measured rule kept backfill apart)
     e->commit_kernel_of[c.buf] = kern;
     if (kern == KB_COMMIT_RUN) { kb_launch_commit(c.d, r, e->stream); e->rounds_run++; }
     else if (kern == KB_COMMIT_SELECT) { kb_launch_commit_sel(c.d, r, e->stream); e->rounds_sel++; }
