@@ -405,6 +405,12 @@ __global__ void __launch_bounds__(K9_THREADS) k_commit_select(const K9KernArgs k
           K9_STAMP(7);
         }
       }
+      // backfill.go:50-66 takes the FIRST node that passes the predicates (all scores tie: the round runs with scores off), and nothing in the
+      // placement of a plain BestEffort row — an empty request — changes what the predicates read of the node except its pod count (and its ports,
+      // if the pod had any: then it conflicts with itself).  So the node that wins a row of such a run wins the following rows too until it is
+      // full: they are committed at once.  (1M x 50k: 80 backfill rounds of 256 rows that all go for the same few nodes, ~20 ms row by row.)
+      const bool bf_bulk = a.backfill && plain0 && km0 == 0u && !(fl0 & 2u) && !a.score_enabled && sh.init0 == 0.0 && sh.init1 == 0.0 && (sh.active >> 2) == 0u &&
+                           res0 == 0.0 && res1 == 0.0 && (sh.want & sh.conf) == 0ull;
       if (!sel_done)
       for (; j < r; j++) {   // ---- the serial loop of kb_commit.hip (single rows, backfill, rows with their own Resreq, whatever the selection handed back)
         const uint32_t c = (pc < ncand) ? rl32(ck, pc) : 0u;
@@ -469,8 +475,20 @@ __global__ void __launch_bounds__(K9_THREADS) k_commit_select(const K9KernArgs k
           else if (lane == F_NZM) cur8 = d2u(u2d(cur8) + sh.nzm);
           else if (lane == F_PORTS) cur8 |= sh.want;
           else if (lane == F_CLS_LEFT) cur8 -= (1ull << 32);   // one more pod on the node
+          uint32_t bulk = 1u;   // rows this node takes now
+          if (bf_bulk) {
+            const uint32_t left1 = (uint32_t)(rl64(cur8, F_CLS_LEFT) >> 32);   // pod slots left behind row j's placement: each takes one more row of the run
+            bulk = 1u + min(r - j - 1u, left1);
+            if (bulk > 1u) {
+              if (lane == F_NZC) { double z = u2d(cur8); for (uint32_t t = 1; t < bulk; t++) z += sh.nzc; cur8 = d2u(z); }   // one addition per placement, as AddTask does them
+              else if (lane == F_NZM) { double z = u2d(cur8); for (uint32_t t = 1; t < bulk; t++) z += sh.nzm; cur8 = d2u(z); }
+              else if (lane == F_CLS_LEFT) cur8 -= ((unsigned long long)(bulk - 1u) << 32);
+            }
+          }
           if (lane < K9_NF) st[lane] = cur8;
-          if (lane == 0) ldec[i0 + j] = (unsigned long long)n | ((unsigned long long)kind << 32);
+          if (lane < bulk) ldec[i0 + j + lane] = (unsigned long long)n | ((unsigned long long)kind << 32);   // bulk > 1: backfill, kind == 0
+          j += bulk - 1u;
+          n_dirty += bulk - 1u;
           K9_WAVE_FENCE();
           // the new key first (scalar part of the Sub as an adjustment), then the Sub itself goes to HBM.  The last row of a run (and a
           // Pipeline, which ends the round) needs no new key: the next run evaluates every slot against ITS shape anyway

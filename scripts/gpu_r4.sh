@@ -6,6 +6,7 @@
 #   evict    1M x 50k allocate + backfill + preempt: host timeline of the evict action, session-load phases, kernel stats
 #   hunt     fresh-seed differential hunt under the three commit kernels
 #   wide     host-port masks of several words: their differential cases on the device, then the default bench (K1 gained a branch)
+#   bf       backfill rows in bulk (selection kernel): every -m gpu case under the selection kernel, then configs 3, 5 and survey nodes
 #   pin      configs 5 and 2 pinned to the selection / the batch kernel beside the per-round choice (what the policy costs or gains)
 #   suite    the whole -m gpu suite
 #   bench    the default bench line and the variants
@@ -92,6 +93,12 @@ c4)   # config 4 (R = 16: scalar dimensions) pinned to the selection kernel, wit
   ;;
 hunt)   # fresh seeds beyond the committed suite, engine vs oracle under the three commit kernels (scripts/gpu_hunt.py; KB_HUNT_OFFSET shifts the seeds)
   KB_HUNT_OFFSET=${KB_HUNT_OFFSET:-40000} timeout 1200 python scripts/gpu_hunt.py ${1:-300} ${2:-900} ${3:-400} > "$out/hunt.txt" 2>&1; echo "hunt rc=$? $(tail -2 "$out/hunt.txt" | tr '\n' ' ')" | tee -a "$out/summary.txt"
+  ;;
+bf)
+  timeout 900 python -m pytest tests -q -m gpu -p no:cacheprovider -k "select" --maxfail=10 > "$out/pytest_select.txt" 2>&1; echo "every case on the selection kernel rc=$? $(tail -1 "$out/pytest_select.txt")" | tee -a "$out/summary.txt"
+  bench_ab c3 -- --config 3 --steps 5 --warmup 2 --verify
+  bench_ab c5 -- --config 5 --steps 3 --warmup 1 --verify
+  bench_ab survey -- --config 3 --survey-nodes --steps 5 --warmup 2 --verify
   ;;
 pin)
   for cfg in 5 2; do
