@@ -100,6 +100,12 @@ bf)
   bench_ab c5 -- --config 5 --steps 3 --warmup 1 --verify
   bench_ab survey -- --config 3 --survey-nodes --steps 5 --warmup 2 --verify
   ;;
+last)   # the lines the bf step did not measure
+  python bench.py > "$out/bench_default.json" 2> "$out/bench_default.err"; echo "bench rc=$? $(ms "$out/bench_default.json")" | tee -a "$out/summary.txt"
+  bench_ab config4 -- --config 4 --steps 5 --warmup 2 --verify
+  bench_ab config2 -- --config 2 --steps 10 --warmup 3 --verify
+  bench_ab config5_preempt -- --config 5 --preempt --steps 2 --warmup 1 --verify
+  ;;
 pin)
   for cfg in 5 2; do
     st=3; [ "$cfg" = 2 ] && st=10
