@@ -140,23 +140,15 @@ struct kb_engine {
   double k7_trace[14] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   unsigned long long k7_batches = 0;
   uint32_t eff_window = 0;   // window actually used for this session (bounded by the commit kernel's LDS budget)
-  // which commit kernel the next round uses: the share of rows won by a node the round had already changed decides
-  // (exponential average over the rounds so far; KB_COMMIT_KERNEL=batch|run|select pins it for A/B runs and for the tests).
-  // dirty_kernel: the kernel for rounds whose rows mostly go to nodes the round already changed (KB_DIRTY_KERNEL=run: the round-3 choice)
-  int commit_kernel = KB_COMMIT_BATCH, commit_pin = -1, dirty_kernel = KB_COMMIT_RUN;
-  double dirty_share = 0.0;
+  // Which commit kernel a round runs on: the selection kernel (kb_commit_sel.hip), backfill rounds included; KB_COMMIT_KERNEL=batch|run|select
+  // pins one of the three — they compute the same decisions, and every -m gpu case runs under each.  Two per-round rules came and went:
+  // round 3's (by the share of rows won by a node the round had already changed) and round 4's first (by measured commit time per committed
+  // row, the other kernel probed now and then).  Same-box runs of the five configurations, measured rule / selection pinned / batch pinned:
+  // C2 7.07 / 6.90 / 9.65 ms, C3 50.8 / 49.1, survey 69.4 / 68.4, C4 79.1 / 78.4, C5 323.2 / 310.6 / 328.3 — the rule left 18 % (C3) to 40 %
+  // (C5) of the rounds on the batch kernel and lost to plain selection every time (profiles/round4/call30_pinned_kernels); removed.
+  int commit_kernel = KB_COMMIT_SELECT, commit_pin = -1;
+  double dirty_share = 0.0;   // share of rows won by a node the round had already changed (exponential average; a statistic)
   uint64_t rounds_batch = 0, rounds_run = 0, rounds_sel = 0;
-  // which commit kernel a round runs on (all three compute the same decisions):
-  //   2 (default): the selection kernel, backfill rounds included (its row loop; 1M x 50k: ~80 backfill rounds whose rows all go for the same
-  //      first node — the batch kernel's slowest case: 323.8 ms with them on the batch kernel, 310.6 on this one).  Same-box runs of the five configurations, per-round choice by measurement / selection pinned / batch
-  //      pinned: C2 7.07 / 6.90 / 9.65 ms, C3 50.8 / 49.1, survey 69.4 / 68.4, C4 79.1 / 78.4, C5 323.2 / 310.6 / 328.3 — the measured choice put
-  //      18 % (C3) to 40 % (C5) of the rounds on the batch kernel and lost to plain selection every time (profiles/round4/call30_pinned_kernels)
-  //   1 KB_KERNEL_POLICY=measured: by measured commit time per committed row (round 4's first rule)
-  //   0 KB_KERNEL_POLICY=share: by the share of dirty-won rows (round 3's rule)
-  int kernel_policy = 2;
-  double kernel_cost[2] = {0.0, 0.0};   // ms per committed row: batch kernel, selection kernel (exponential averages)
-  double last_commit_ms = 0.0;
-  uint64_t last_probe_round = 0;
   uint64_t sel_stat[4] = {0, 0, 0, 0};   // selection kernel: runs with every pick a clean first placement / through the general selection / handed to the serial loop; deep passes
   uint32_t shape_cap = KB_K5_MAX_SHAPES;   // distinct shapes a window may hold (each keeps its candidate list in the commit kernel's LDS)
   std::vector<uint32_t> plan_stamp;   // per row-shape id: stamp of the window being planned
@@ -556,8 +548,7 @@ void round_commit(kb_engine *e, const RoundCtx &c, unsigned long long *keys, dou
   r.own_row0 = own0;
   r.own_row1 = own1;
   auto launch = [&]() {
-    // backfill rounds (no scores, no runs to select from: every row takes the first node that passes) stay on the batch kernel unless pinned
-    const int kern = (e->commit_pin < 0 && e->kernel_policy == 1 && r.backfill) ? (int)KB_COMMIT_BATCH : e->commit_kernel;   // (the measured rule kept backfill apart)
+    const int kern = e->commit_kernel;
     e->commit_kernel_of[c.buf] = kern;
     if (kern == KB_COMMIT_RUN) { kb_launch_commit(c.d, r, e->stream); e->rounds_run++; }
     else if (kern == KB_COMMIT_SELECT) { kb_launch_commit_sel(c.d, r, e->stream); e->rounds_sel++; }
@@ -611,7 +602,6 @@ void round_collect(kb_engine *e, const RoundCtx &c, bool had_candidates, uint32_
       e->stats.argmax_ms += (double)(st[2] - st[1]) * per_ms;
     }
     e->stats.commit_ms += (double)(st[3] - st[2]) * per_ms;
-    e->last_commit_ms = (double)(st[3] - st[2]) * per_ms;
   } else {
     HIP_OK(hipStreamSynchronize(e->stream));
     HIP_OK(hipGetLastError());
@@ -624,7 +614,6 @@ void round_collect(kb_engine *e, const RoundCtx &c, bool had_candidates, uint32_
     }
     HIP_OK(hipEventElapsedTime(&ms, get_timer(e, 2).a, get_timer(e, 2).b));
     e->stats.commit_ms += ms;
-    e->last_commit_ms = ms;
   }
   for (uint32_t i = 0; i < c.n; i++) {
     e->h_decnode[i] = (uint32_t)(ho[KB_OUT_HDR + i] & 0xFFFFFFFFull);
@@ -655,36 +644,9 @@ void round_collect(kb_engine *e, const RoundCtx &c, bool had_candidates, uint32_
     if (e->commit_kernel_of[c.buf] == KB_COMMIT_SELECT && e->k5_trace[0] > 0)   // the selection kernel's trace build: its other waves' evaluation phase
       for (int k = 10; k < 14; k++) e->k5_trace[k] += (double)(uint32_t)(ho[k < 12 ? 4 : 15] >> (32 * (k & 1)));
   }
-  // next round's kernel: a round in which more than ~a quarter of the rows went to dirty nodes cuts most speculated batches short
   if (n_done) {
     const double share = (double)dirty_won / (double)n_done;
     e->dirty_share = e->stats.rounds == 0 ? share : 0.75 * e->dirty_share + 0.25 * share;
-  }
-  if (e->commit_pin >= 0) {
-    e->commit_kernel = e->commit_pin;
-  } else if (e->kernel_policy == 2) {
-    e->commit_kernel = KB_COMMIT_SELECT;
-  } else if (e->kernel_policy == 0) {   // KB_KERNEL_POLICY=share, the round-3 rule: by the share of dirty-won rows
-    if (e->commit_kernel == KB_COMMIT_BATCH && e->dirty_share > 0.30) e->commit_kernel = e->dirty_kernel;
-    else if (e->commit_kernel != KB_COMMIT_BATCH && e->dirty_share < 0.15) e->commit_kernel = KB_COMMIT_BATCH;
-  } else {
-    // measured: the kernels leave their own wall-clock stamps; an exponential average of the commit time per committed row is kept for the
-    // batch kernel and for the selection kernel, the cheaper one runs, the other one is tried again every 32nd round (all kernels compute
-    // the same decisions, so the choice — which depends on timing — never shows in the result)
-    const int kk = e->commit_kernel_of[c.buf] == KB_COMMIT_BATCH ? 0 : 1;
-    if (n_done >= 16 && e->last_commit_ms > 0.0 && !c.r.backfill) {
-      const double per_row = e->last_commit_ms / (double)n_done;
-      e->kernel_cost[kk] = e->kernel_cost[kk] == 0.0 ? per_row : 0.8 * e->kernel_cost[kk] + 0.2 * per_row;
-    }
-    int want = e->kernel_cost[1] == 0.0 ? 1 : (e->kernel_cost[0] == 0.0 ? 0 : (e->kernel_cost[1] < e->kernel_cost[0] ? 1 : 0));
-    if (e->kernel_cost[0] != 0.0 && e->kernel_cost[1] != 0.0) {
-      // refresh the other kernel's figure now and then — the rarer, the further behind it is (a round on a kernel 2.5 x slower costs 1.5 rounds:
-      // every 32nd round when the two are close, every 32 * ratio^2-th otherwise, at most every 1024th)
-      const double ratio = e->kernel_cost[want ^ 1] / e->kernel_cost[want];
-      const uint64_t every = (uint64_t)std::min(1024.0, 32.0 * ratio * ratio);
-      if (e->stats.rounds - e->last_probe_round >= every) { want ^= 1; e->last_probe_round = e->stats.rounds; }
-    }
-    e->commit_kernel = want ? KB_COMMIT_SELECT : KB_COMMIT_BATCH;
   }
   e->stats.rounds += 1;
   e->round_no += 1;
@@ -1095,11 +1057,6 @@ int kb_engine_create(const kb_config *cfg, kb_engine **out) {
         else if (ck[0] == 'r') eng->commit_pin = KB_COMMIT_RUN;
         else if (ck[0] == 's') eng->commit_pin = KB_COMMIT_SELECT;
         if (eng->commit_pin >= 0) eng->commit_kernel = eng->commit_pin;
-      }
-      if (const char *kp = getenv("KB_KERNEL_POLICY")) eng->kernel_policy = kp[0] == 's' && kp[1] == 'h' ? 0 : (kp[0] == 'm' ? 1 : 2);   // share | measured | select
-      if (const char *dk = getenv("KB_DIRTY_KERNEL")) {
-        if (dk[0] == 'r') eng->dirty_kernel = KB_COMMIT_RUN;
-        else if (dk[0] == 's') eng->dirty_kernel = KB_COMMIT_SELECT;
       }
       const char *sr = getenv("KB_SYNC_ROUNDS");
       eng->fast_rounds = !(eng->flags & KB_FLAG_SYNC_ROUNDS) && !(sr && sr[0] == '1');
@@ -1516,9 +1473,7 @@ int kb_session_load(kb_engine *e, const kb_snapshot *sn) {
     e->mat2_cap = 0; e->stale_cap = 0;   // the second stream's matrix rows are [rows][NP] too: a session with more nodes needs them again
     e->stats = kb_stats{};
     e->dirty_share = 0.0;
-    e->kernel_cost[0] = e->kernel_cost[1] = 0.0;
-    e->last_probe_round = 0;
-    e->commit_kernel = e->commit_pin >= 0 ? e->commit_pin : (e->kernel_policy == 2 ? (int)KB_COMMIT_SELECT : (int)KB_COMMIT_BATCH);
+    e->commit_kernel = e->commit_pin >= 0 ? e->commit_pin : (int)KB_COMMIT_SELECT;
     e->round_no = 0;
     mark("jobs, queues, deserved");
     auto snap_copy = [&](DevBuf &dst, const DevBuf &src) {

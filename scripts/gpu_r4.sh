@@ -1,6 +1,6 @@
 #!/usr/bin/env bash
 # Round 4's GPU calls, one parameterised script:   gpurun -- 'bash scripts/gpu_r4.sh <step> [args]'   (writes gpurun_out/r4_<step>/*)
-#   sel      the selection commit kernel (k_commit_run<true>): the differential suites pinned to it, then same-box A/B against the round-3 kernels
+#   sel      the selection commit kernel (k_commit_run<true>): the differential suites pinned to it, then same-box A/B against the batch kernel
 #   trace    the selection kernel's per-phase cycle trace (configs 3 and 4)
 #   profile  rocprofv3: kernel stats, HBM bytes of the matrix launches, SQ counters of the commit kernels (scripts/summarize_profile.py r4_profile profiles/round4)
 #   evict    1M x 50k allocate + backfill + preempt: host timeline of the evict action, session-load phases, kernel stats
@@ -29,7 +29,7 @@ sel)
     -q -m gpu -p no:cacheprovider -k "select" --maxfail=10 > "$out/pytest_select.txt" 2>&1; echo "differential suites on the selection kernel rc=$? $(tail -1 "$out/pytest_select.txt")" | tee -a "$out/summary.txt"
   for cfg in "3" "4" "3 --survey-nodes"; do
     tag="c${cfg// --survey-nodes/survey}"; tag="${tag// /}"
-    bench_ab "${tag}_r3" KB_DIRTY_KERNEL=run -- --config ${cfg} --steps 5 --warmup 2 --verify
+    bench_ab "${tag}_pinbatch" KB_COMMIT_KERNEL=batch -- --config ${cfg} --steps 5 --warmup 2 --verify
     bench_ab "${tag}_pinsel" KB_COMMIT_KERNEL=select -- --config ${cfg} --steps 5 --warmup 2 --verify
     if [ -f kube-batch_amd/libkbengine_trace.so ]; then   # make EXTRA=-DKB_K9_TRACE OUT=../libkbengine_trace.so: wave 0's cycles per phase
       KB_ENGINE_LIB=$PWD/kube-batch_amd/libkbengine_trace.so KB_COMMIT_KERNEL=select KB_K5_STATS=1 python bench.py --no-cpu-baseline --config ${cfg} --steps 2 --warmup 1 \
