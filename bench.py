@@ -279,7 +279,7 @@ def main():
         roofline_eval = roof(T, ms_d, 3, f"kb_bench_matrix rows [0,{T}) x {N} nodes: direct per-row evaluation, runs of adjacent equal rows evaluated once", "k_matrix_runs")
         ms_a = eng.bench_matrix(0, T, reps=2, fit_mode=1 | abi.MATRIX_DIRECT | abi.MATRIX_NO_DEDUP)
         roofline_eval_all = roof(T, ms_a, 2, f"kb_bench_matrix rows [0,{T}) x {N} nodes: {T} x {N} evaluations, nothing shared", "k_matrix<4,32>")
-    # HBM bytes per launch from the PMC passes of scripts/profile_round.sh (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate
+    # HBM bytes per launch from the PMC passes of scripts/gpu_r4.sh profile (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate
     # runs; KB units; FETCH_SIZE doubled per MI355X_MICROARCH.md's gfx950 correction).  Cannot be collected inside this
     # process, so the committed summary of the same command is read back; null when it is absent or for another config.
     import glob

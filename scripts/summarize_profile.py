@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""gpurun_out/prof_<tag>/ (written by scripts/profile_round.sh on the GPU box) -> the summaries committed under profiles/.
+"""gpurun_out/prof_<tag>/ (written by `scripts/gpu_r4.sh profile` on the GPU box) -> the summaries committed under profiles/.
 
   rocprofv3_kernel_stats.csv   the --kernel-trace --stats table as rocprofv3 wrote it
   rocprofv3_pmc_k_matrix.csv   per kernel: dispatches, mean / max KB per dispatch of FETCH_SIZE and WRITE_SIZE (separate passes)

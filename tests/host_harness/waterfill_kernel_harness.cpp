@@ -3,7 +3,7 @@
 // barriers stand between them — is executed (and, under ThreadSanitizer, checked for unordered accesses) without a device.  The device
 // vocabulary the kernel uses is mapped one to one: threadIdx.x = a thread-local index, __shared__ = one static object for the workgroup,
 // __syncthreads() = pthread_barrier_wait over the 256 threads, atomicOr = an atomic OR.  What this cannot show is the compiler's device
-// code; the first device run of KB_DEVICE_WATERFILL=1 (scripts/first_gpu_call_r4.sh) does.
+// code; the first device run of the launch (round 4's first GPU call, profiles/round4/first_call/) did.
 #include <pthread.h>
 #include <stdint.h>
 

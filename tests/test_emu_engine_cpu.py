@@ -366,7 +366,7 @@ def test_overlapped_launches_wait_for_the_copies_kb_session_reset_left_queued(em
 
 # ---- proportion's water-fill as a launch (round 3; the default since its first device run: tests/test_gpu_waterfill.py) ----
 def _waterfill_counter(so):
-    """launches of the emulated k_waterfill so far; the product library (scripts/first_gpu_call_r4.sh: KB_EMU_LIB) has no such counter: None"""
+    """launches of the emulated k_waterfill so far; the product library (KB_EMU_LIB pointing at it, as round 4's first device call did) has no such counter: None"""
     L = C.CDLL(so)
     if not hasattr(L, "kbemu_waterfill_launches"):
         return lambda: None
