@@ -1868,8 +1868,9 @@ static int run_evict_action(kb_engine *e, bool reclaim, kb_stmt_op *out, uint64_
     e->stats.total_ms += now_ms() - t_begin;
     static const bool ev_trace = [] { const char *v = getenv("KB_EVICT_TRACE"); return v && v[0] == '1'; }();
     if (ev_trace)   // host timeline of the action (profiles/round4)
-      fprintf(stderr, "[kb evict] %s: entry %.2f ms = copies %.2f + node mirror %.2f + task tables %.2f + machine tables %.2f; machine set-up %.2f ms (job / task queues) + run; exit: journal + state back %.2f, finalize + checks %.2f\n",
-              reclaim ? "reclaim" : "preempt", t_e1 - t_e0, t_e_copy - t_e0, t_e_nodes - t_e_copy, t_e_tasks - t_e_nodes, t_e1 - t_e_tasks, pm.tr_setup_ms, t_x_fin - t_e2, now_ms() - t_x_fin);
+      fprintf(stderr, "[kb evict] %s: entry %.2f ms = copies %.2f + node mirror %.2f + task tables %.2f + machine tables %.2f; machine set-up %.2f ms (job / task queues) + run, of it %.2f ms collecting candidates (%llu queue nodes looked at); exit: journal + state back %.2f, finalize + checks %.2f\n",
+              reclaim ? "reclaim" : "preempt", t_e1 - t_e0, t_e_copy - t_e0, t_e_nodes - t_e_copy, t_e_tasks - t_e_nodes, t_e1 - t_e_tasks, pm.tr_setup_ms, pm.tr_scan_ms,
+              (unsigned long long)pm.tr_scan_nodes, t_x_fin - t_e2, now_ms() - t_x_fin);
     if (ev_trace)
       fprintf(stderr, "[kb evict] %s: entry (state to the host, machine set-up) %.2f ms; machine %.2f ms of which %llu lists %.2f ms on the device + %.2f ms host reorder, %llu node refreshes %.2f ms; exit (journal, state back, finalize, checks) %.2f ms; popped %llu (walked %llu: %.2f ms, %llu nodes tried; skipped with their job %llu, turned away one by one %llu, own-job preemptors the priority rule excludes %llu), journal %zu\n",
               reclaim ? "reclaim" : "preempt", t_e1 - t_e0, t_e2 - t_e1, (unsigned long long)n_lists, tl_lists, tl_lists_host, (unsigned long long)n_refresh, tl_refresh, now_ms() - t_e2,

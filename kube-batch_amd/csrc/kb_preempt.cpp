@@ -666,6 +666,8 @@ bool PreemptMachine::preempt_walk(uint32_t preemptor, int mode) {
     std::vector<uint64_t> C;
     const int32_t pp = hs_->job_prio[pj];
     const std::vector<int32_t> &rank = shape_rank_[sh];
+    const auto tsc0 = std::chrono::steady_clock::now();
+    tr_scan_nodes += qnodes_[pq].size();
     for (uint32_t n : qnodes_[pq]) {
       if (minprio(pq, n) >= pp) continue;
       if (host_keys || dirty_[n]) {
@@ -675,6 +677,7 @@ bool PreemptMachine::preempt_walk(uint32_t preemptor, int mode) {
         C.push_back(L[(size_t)rank[n]]);
       }
     }
+    tr_scan_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tsc0).count();
     // descending key order, lazily: the walk usually ends at one of the first candidates (keys are distinct: the node is part of them)
     std::make_heap(C.begin(), C.end());
     for (auto end = C.end(); end != C.begin(); --end) {

@@ -73,7 +73,8 @@ class PreemptMachine {
   uint64_t popped = 0, evals = 0;
   // where an action's time goes (KB_EVICT_TRACE): preemptors that walked nodes, nodes tried, the walks' time, preemptors skipped with their job
   uint64_t tr_walks = 0, tr_tries = 0, tr_skipped = 0, tr_pruned = 0, tr_shortcut = 0;
-  double tr_walk_ms = 0.0, tr_setup_ms = 0.0;
+  double tr_walk_ms = 0.0, tr_setup_ms = 0.0, tr_scan_ms = 0.0;
+  uint64_t tr_scan_nodes = 0;
   std::vector<uint32_t> scratch_pre_, scratch_victims_, scratch_ids_;
   std::vector<uint8_t> scratch_keep_;
   std::vector<Res> scratch_alloc_;
