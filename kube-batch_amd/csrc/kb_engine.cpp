@@ -1471,6 +1471,7 @@ int kb_session_load(kb_engine *e, const kb_snapshot *sn) {
     d.score_enabled = e->pol.nodeorder_enabled ? 1 : 0;
     e->win_cap = 0; e->mat_cap = 0; e->keys_cap = 0;
     e->mat2_cap = 0; e->stale_cap = 0;   // the second stream's matrix rows are [rows][NP] too: a session with more nodes needs them again
+    e->xs_cap = 0;   // kb_eval_matrix's per-shape rows are [shapes][NP] as well (found by tests/test_gpu_reload.py: fewer shapes over more nodes overran them)
     e->stats = kb_stats{};
     e->dirty_share = 0.0;
     e->commit_kernel = e->commit_pin >= 0 ? e->commit_pin : (int)KB_COMMIT_SELECT;

@@ -76,6 +76,7 @@ def test_product_library_path_is_untouched_outside_this_module():
 _SKIP = {
     # sizes that only make sense on the device
     "test_gpu_parity": {"test_wide_cluster_more_than_64k_nodes", "test_full_size_properties_config3"},
+    "test_gpu_reload": {"test_soak_1000_cycles_no_device_memory_growth"},      # device memory accounting
 }
 
 
@@ -91,7 +92,7 @@ def _adopt(module_name, only=None):
 
 # test_gpu_regressions: the cases the hunts on this emulated device produced (round 2), since promoted into the `-m gpu` suite
 for _m in ("test_gpu_parity", "test_gpu_fuzz", "test_gpu_adversarial", "test_gpu_interpod", "test_gpu_preempt", "test_framework_actions", "test_gpu_regressions",
-           "test_gpu_wideports"):
+           "test_gpu_wideports", "test_gpu_reload"):
     _adopt(_m)
 
 
