@@ -374,14 +374,10 @@ size_t kb_commit_smem_bytes(uint32_t n_rows, uint32_t n_shapes, uint32_t NP, int
 
 void kb_launch_commit(const KbDev &d, const KbRound &r, void *stream) {
   if (r.n_rows == 0) return;
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_commit_run), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_set = true;
-  }
+  static bool lds_set[64] = {};
+  k9_allow_full_lds(reinterpret_cast<const void *>(k_commit_run), lds_set);
   const size_t sh = k9_layout(r.n_rows, r.n_mrows, r.L, d.NP, d.R).total;
   K9KernArgs ka;
   k9_fill_args(ka, d, r);
-  static const bool helpers_off = getenv("KB_WARM_HELPERS_OFF") && getenv("KB_WARM_HELPERS_OFF")[0] == '1';   // A/B switch
-  hipLaunchKernelGGL(k_commit_run, dim3(helpers_off ? 1u : KB_WARM_GRID), dim3(K9_THREADS), sh, (hipStream_t)stream, ka);
+  hipLaunchKernelGGL(k_commit_run, dim3(KB_WARM_GRID), dim3(K9_THREADS), sh, (hipStream_t)stream, ka);
 }

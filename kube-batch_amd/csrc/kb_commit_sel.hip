@@ -117,7 +117,9 @@ __global__ void __launch_bounds__(K9_THREADS) k_commit_select(const K9KernArgs k
 #define K9S_TR(k, t0) do { (void)(t0); } while (0)
 #define K9S_NOW() 0ull
 #endif
-  const uint32_t nap_prep = a.prewalk & 0xFFu, nap_dk = (a.prewalk >> 8) & 0xFFu;   // how long a waiting wave sleeps between two polls (KB_SEL_SLEEP=prep,dk)
+  // how long a waiting prep / evaluating wave sleeps between two polls: s_sleep 1 (64 clocks).  Measured 0 .. 1 alike, longer slower
+  // (profiles/round4/call18_19_20_polls_and_fence); the KB_SEL_SLEEP switch that swept it is gone
+  constexpr uint32_t nap_prep = 1u, nap_dk = 1u;
   const unsigned long long lt = (1ull << lane) - 1ull;
   gptrd gi, gr;
   { const KbDev &d = *a.dev; gi = (gptrd)d.idle; gr = (gptrd)d.rel; }
@@ -746,20 +748,10 @@ __global__ void __launch_bounds__(K9_THREADS) k_commit_select(const K9KernArgs k
 
 void kb_launch_commit_sel(const KbDev &d, const KbRound &r, void *stream) {
   if (r.n_rows == 0) return;
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_commit_select), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_set = true;
-  }
+  static bool lds_set[64] = {};
+  k9_allow_full_lds(reinterpret_cast<const void *>(k_commit_select), lds_set);
   const size_t sh = k9_layout(r.n_rows, r.n_mrows, r.L, d.NP, d.R, true).total;
   K9KernArgs ka;
   k9_fill_args(ka, d, r);
-  static const uint32_t naps = [] {   // KB_SEL_SLEEP=prep,dk: s_sleep units (64 clocks) between two polls of a waiting prep / evaluating wave
-    uint32_t pn = 1, dn = 1;
-    if (const char *v = getenv("KB_SEL_SLEEP")) { pn = (uint32_t)atoi(v); if (const char *c = strchr(v, ',')) dn = (uint32_t)atoi(c + 1); }
-    return (pn & 0xFFu) | ((dn & 0xFFu) << 8);
-  }();
-  ka.hot.prewalk = naps;
-  static const bool helpers_off = getenv("KB_WARM_HELPERS_OFF") && getenv("KB_WARM_HELPERS_OFF")[0] == '1';   // A/B switch
-  hipLaunchKernelGGL(k_commit_select, dim3(helpers_off ? 1u : KB_WARM_GRID), dim3(K9_THREADS), sh, (hipStream_t)stream, ka);
+  hipLaunchKernelGGL(k_commit_select, dim3(KB_WARM_GRID), dim3(K9_THREADS), sh, (hipStream_t)stream, ka);
 }

@@ -134,7 +134,7 @@ struct KbRound {
   unsigned long long *dec;     // [n_rows] decision records: low word node (KB_NONE = stayed Pending), high word kind
   uint32_t *result;            // [8]: n_done, reason, n_dirty, list_exhausted (live rescans), window_refills
   int backfill;                // commit semantics of backfill.go (first node passing the predicates, no score)
-  uint32_t batch;              // rows the commit kernel speculates per batch (0 = default)
+  uint32_t batch;              // unused
   uint32_t gather;             // the matrix launch also builds the row descriptors (one extra block row)
   unsigned long long *host_out;   // see KbCommitArgs
   unsigned long long seq;
@@ -178,12 +178,11 @@ struct KbCommitArgs {
   int fit_mode, backfill, pred_enabled, score_enabled, wL, wM, wB;
   uint32_t use_crow, has_delta, has_aff, has_ports;
   int R;
-  uint32_t batch;   // rows speculated per batch (<= 16)
+  uint32_t batch;   // unused (the batch kernel's rows per batch)
   unsigned long long *host_out;   // pinned host mirror of the output block (fast rounds), or nullptr
   unsigned long long seq;         // sequence number published last into host_out[KB_OUT_SEQ]
   uint32_t node_bits;             // width of the node field of the commit kernel's 32-bit keys (kb_node_bits)
-  uint32_t prewalk;               // batch kernel: bit 0: wave 0 walks batch b + 1 while the workgroup fetches / evaluates batch b (KB_K7_PREWALK=0: off);
-                                  //               bit 1: look-ahead keys for dirty winners in row mode (KB_K7_LOOKAHEAD=0: off); bit 2: on-demand chain tables (KB_K7_CHAIN=0: off)
+  uint32_t prewalk;               // unused
 };
 
 // 32-bit keys of the commit kernel: (score + 1) << node_bits | (2^node_bits - 1 - node); needs (max score + 2) << node_bits <= 2^32
@@ -205,14 +204,13 @@ static inline uint32_t kb_node_bits(uint32_t NP) {
 #define KB_K5_MAX_ROWS 256u      // rows per window: one thread of the commit kernel's workgroup per dirty slot
 #define KB_K5_MAX_SHAPES 256u    // distinct task shapes per window (each keeps its candidate list in LDS: the budget decides)
 
-// Three commit kernels, same decisions bit for bit: KB_COMMIT_BATCH (kb_commit_batch.hip) speculates 16-32 rows across shapes and
-// is the faster one while clean nodes win most rows; KB_COMMIT_RUN (kb_commit.hip) works a same-shape run at a time without
-// speculation and was the faster one when nodes the round already changed win most rows (bin-packing weights); KB_COMMIT_SELECT
-// (kb_commit.hip, k_commit_run<true>) is the run kernel with the rows of a run committed by ONE selection instead of a loop.
-enum { KB_COMMIT_BATCH = 0, KB_COMMIT_RUN = 1, KB_COMMIT_SELECT = 2 };
-// dynamic LDS each needs for a round of n_rows rows (batch: slot capacity `cap`) with n_shapes distinct shapes over NP padded nodes
+// Two commit kernels, same decisions bit for bit: KB_COMMIT_SELECT (kb_commit_sel.hip, k_commit_select: a run of same-shape rows committed by
+// ONE selection, the workgroup a pipeline of waves) runs every round; KB_COMMIT_RUN (kb_commit.hip, k_commit_run: the same runs, row by row,
+// no speculation) is the plain restatement it is held to (KB_COMMIT_KERNEL=run, one axis of the -m gpu suite).  Round 3's batch kernel
+// (value 0: speculation across shapes) was retired in round 5.
+enum { KB_COMMIT_RUN = 1, KB_COMMIT_SELECT = 2 };
+// dynamic LDS a round of n_rows rows with n_shapes distinct shapes over NP padded nodes needs (either kernel)
 size_t kb_commit_smem_bytes(uint32_t n_rows, uint32_t n_shapes, uint32_t NP, int R);
-size_t kb_commit_batch_smem_bytes(uint32_t cap, uint32_t NP, int R);
 
 // KB_REASON_RENORM: the next row's score needs NormalizeReduce over its CURRENT feasible set (preferred node affinity): it is
 // committed as the first row of a fresh round, whose matrix is exact for it
@@ -241,7 +239,6 @@ void kb_launch_expand(const KbDev &d, const uint16_t *s_score, const uint32_t *s
                       uint16_t *score, uint32_t *maskw, void *stream);
 void kb_launch_commit(const KbDev &d, const KbRound &r, void *stream);         // KB_COMMIT_RUN
 void kb_launch_commit_sel(const KbDev &d, const KbRound &r, void *stream);     // KB_COMMIT_SELECT
-void kb_launch_commit_batch(const KbDev &d, const KbRound &r, void *stream);   // KB_COMMIT_BATCH
 // node state := round-start state + reduced deltas; returns how many values differ from the live (locally committed) state
 uint32_t kb_apply_deltas(const KbDev &d, const double *s_idle, const double *s_rel, const long long *s_nzc, const long long *s_nzm,
                          const int *s_podcnt, const double *delta, uint32_t *dev_counter, void *stream);

@@ -4,7 +4,7 @@
 // tasks (assuming each gets a node, which only ever fails when a whole feasibility class has died — and that is
 // monotone inside one action), the device evaluates the window's mask+score matrix against the round-start node
 // state (K1, once per distinct task shape), builds each shape's sorted candidate list (K3) and commits the window in the
-// reference's order, speculating 16-32 rows at a time against the dirty nodes (K5).  A mis-speculation (no feasible node / Pipeline instead of Allocate) stops the commit kernel at that row;
+// reference's order, a run of same-shape rows at a time (K5).  A mis-speculation (no feasible node / Pipeline instead of Allocate) stops the commit kernel at that row;
 // the host rolls the order machine back to the round start, replays the confirmed prefix and re-plans.
 #include <hip/hip_runtime.h>
 
@@ -88,19 +88,77 @@ template <typename T> struct Pinned {
   const T &operator[](size_t i) const { return p[i]; }
 };
 
-template <typename T> void upload(DevBuf &b, const T *src, size_t n, hipStream_t s) {
-  b.alloc(n * sizeof(T));
-  if (n) HIP_OK(hipMemcpyAsync(b.p, src, n * sizeof(T), hipMemcpyHostToDevice, s));
-}
+// kb_session_load's staging: ONE pinned area, grow-only like the device buffers, in which every host-to-device source of a load is
+// assembled (padding included) and from which it is copied asynchronously.  Round 4 copied from pageable memory — the caller's snapshot,
+// std::vectors of this file —: the runtime pins such a source on the fly (or stages it, blocking) at every call, a per-call cost of
+// tens to hundreds of microseconds with a long tail, about thirty times per load, and upload_padded synchronised the stream behind each
+// of its eight temporaries.  A block stays valid until the next load resets the area, and a load ends behind a stream synchronisation.
+// Sources of 8 MiB and more (the task request vectors of a million-task session) skip the area: one pin per call is cheaper than the
+// extra pass over them, and HIP has consumed a pageable source when the call returns.
+struct PinnedArena {
+  struct Block { unsigned char *p; size_t cap; };
+  std::vector<Block> blocks;
+  size_t cur = 0, off = 0;
+  PinnedArena() = default;
+  PinnedArena(const PinnedArena &) = delete;
+  PinnedArena &operator=(const PinnedArena &) = delete;
+  ~PinnedArena() { for (Block &b : blocks) (void)hipHostFree(b.p); }
+  void reset() { cur = 0; off = 0; }
+  void *take(size_t bytes) {
+    bytes = (bytes + 255) & ~(size_t)255;
+    while (cur < blocks.size() && off + bytes > blocks[cur].cap) { cur++; off = 0; }
+    if (cur == blocks.size()) {
+      Block b{nullptr, std::max<size_t>(bytes, (size_t)8 << 20)};
+      HIP_OK(hipHostMalloc((void **)&b.p, b.cap, hipHostMallocDefault));
+      blocks.push_back(b);
+      off = 0;
+    }
+    void *p = blocks[cur].p + off;
+    off += bytes;
+    return p;
+  }
+  size_t bytes_held() const { size_t t = 0; for (const Block &b : blocks) t += b.cap; return t; }
+};
+constexpr size_t kStageMaxBytes = (size_t)8 << 20;
 
-// rows of a [rows][n] host matrix into a zero-padded [rows][np] device matrix
-template <typename T> void upload_padded(DevBuf &b, const T *src, size_t rows, size_t n, size_t np, hipStream_t s) {
-  std::vector<T> tmp(rows * np, T(0));
-  for (size_t r = 0; r < rows; r++) std::memcpy(&tmp[r * np], src + r * n, n * sizeof(T));
-  b.alloc(tmp.size() * sizeof(T));
-  HIP_OK(hipMemcpyAsync(b.p, tmp.data(), tmp.size() * sizeof(T), hipMemcpyHostToDevice, s));
-  HIP_OK(hipStreamSynchronize(s));
-}
+struct Uploader {
+  PinnedArena &arena;
+  hipStream_t s;
+  Uploader(PinnedArena &a, hipStream_t st) : arena(a), s(st) {}
+  // b := n elements the caller writes through the returned pointer BEFORE the next take / copy (the copy is queued by commit())
+  template <typename T> T *stage(DevBuf &b, size_t n) {
+    b.alloc(n * sizeof(T));
+    pending_dst = b.p; pending_bytes = n * sizeof(T);
+    pending_src = arena.take(pending_bytes ? pending_bytes : 16);
+    return reinterpret_cast<T *>(pending_src);
+  }
+  void commit() {
+    if (pending_bytes) HIP_OK(hipMemcpyAsync(pending_dst, pending_src, pending_bytes, hipMemcpyHostToDevice, s));
+    pending_bytes = 0;
+  }
+  template <typename T> void copy(DevBuf &b, const T *src, size_t n) {
+    if (n * sizeof(T) >= kStageMaxBytes) {
+      b.alloc(n * sizeof(T));
+      HIP_OK(hipMemcpyAsync(b.p, src, n * sizeof(T), hipMemcpyHostToDevice, s));
+      return;
+    }
+    T *p = stage<T>(b, n);
+    if (n) std::memcpy(p, src, n * sizeof(T));
+    commit();
+  }
+  // rows of a [rows][n] host matrix into a padded [rows][np] device matrix (pad value `fill`)
+  template <typename T> void padded(DevBuf &b, const T *src, size_t rows, size_t n, size_t np, T fill = T(0)) {
+    T *p = stage<T>(b, rows * np);
+    for (size_t r = 0; r < rows; r++) {
+      if (n) std::memcpy(p + r * np, src + r * n, n * sizeof(T));
+      std::fill(p + r * np + n, p + (r + 1) * np, fill);
+    }
+    commit();
+  }
+ private:
+  void *pending_dst = nullptr, *pending_src = nullptr;
+  size_t pending_bytes = 0;
+};
 
 struct Timer {   // HIP-event pair on the engine stream
   hipEvent_t a = nullptr, b = nullptr;
@@ -137,18 +195,14 @@ struct kb_engine {
   DevBuf b_idle, b_rel, b_nzc, b_nzm, b_podcnt, b_acpu, b_amem, b_maxpods, b_ncls, b_nmask, b_invac, b_invam;
   uint64_t k5_walks = 0, k5_rescans = 0, k5_demand = 0, k5_slots = 0;   // commit kernel counters (KB_K5_STATS)
   double k5_trace[14] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-  double k7_trace[14] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-  unsigned long long k7_batches = 0;
   uint32_t eff_window = 0;   // window actually used for this session (bounded by the commit kernel's LDS budget)
-  // Which commit kernel a round runs on: the selection kernel (kb_commit_sel.hip), backfill rounds included; KB_COMMIT_KERNEL=batch|run|select
-  // pins one of the three — they compute the same decisions, and every -m gpu case runs under each.  Two per-round rules came and went:
-  // round 3's (by the share of rows won by a node the round had already changed) and round 4's first (by measured commit time per committed
-  // row, the other kernel probed now and then).  Same-box runs of the five configurations, measured rule / selection pinned / batch pinned:
-  // C2 7.07 / 6.90 / 9.65 ms, C3 50.8 / 49.1, survey 69.4 / 68.4, C4 79.1 / 78.4, C5 323.2 / 310.6 / 328.3 — the rule left 18 % (C3) to 40 %
-  // (C5) of the rounds on the batch kernel and lost to plain selection every time (profiles/round4/call30_pinned_kernels); removed.
+  // Which commit kernel a round runs on: the selection kernel (kb_commit_sel.hip), backfill rounds included; KB_COMMIT_KERNEL=run|select pins
+  // one of the two — they compute the same decisions, and every -m gpu case runs under each (the run kernel, kb_commit.hip, is the plain
+  // serial restatement the selection is held to).  Round 3's batch kernel (speculation across shapes) and the per-round rules that chose
+  // between kernels lost to plain selection on every configuration (profiles/round4/call30_pinned_kernels) and are gone: HISTORY.md.
   int commit_kernel = KB_COMMIT_SELECT, commit_pin = -1;
   double dirty_share = 0.0;   // share of rows won by a node the round had already changed (exponential average; a statistic)
-  uint64_t rounds_batch = 0, rounds_run = 0, rounds_sel = 0;
+  uint64_t rounds_run = 0, rounds_sel = 0;
   uint64_t sel_stat[4] = {0, 0, 0, 0};   // selection kernel: runs with every pick a clean first placement / through the general selection / handed to the serial loop; deep passes
   uint32_t shape_cap = KB_K5_MAX_SHAPES;   // distinct shapes a window may hold (each keeps its candidate list in the commit kernel's LDS)
   std::vector<uint32_t> plan_stamp;   // per row-shape id: stamp of the window being planned
@@ -214,6 +268,7 @@ struct kb_engine {
   std::vector<uint32_t> shape_stamp, shape_slot_of;   // per row-shape id: round stamp and slot inside the current round
   uint32_t stamp = 0;
   std::vector<Timer> ev;          // event pool for per-launch timing
+  PinnedArena load_arena;         // kb_session_load's staging area (above)
   Pinned<unsigned char> h_fin;    // pinned D2H target of run_finalize (seven results in one block, copied out after ONE synchronisation)
   // the host mirrors of the device reduction as of kb_session_load: kb_session_reset restores them instead of reducing the restored
   // (identical) state again
@@ -304,7 +359,7 @@ void quiesce(kb_engine *e) {
 }
 
 // gang ballot + share reduction on the device, results mirrored to the host session
-void run_finalize(kb_engine *e) {
+void run_finalize(kb_engine *e, const std::function<void()> &after_sync = nullptr) {
   Timer &tm = get_timer(e, 3);
   HIP_OK(hipEventRecord(tm.a, e->stream));
   kb_launch_finalize(e->dev, e->b_jbegin.as<uint32_t>(), e->b_jmin.as<int>(), e->b_jqueue.as<uint32_t>(), e->pol.gang_job_ready ? 1 : 0,
@@ -327,6 +382,7 @@ void run_finalize(kb_engine *e) {
     if (pt.bytes) HIP_OK(hipMemcpyAsync(e->h_fin.data() + pt.off, pt.src, pt.bytes, hipMemcpyDeviceToHost, e->stream));
   HIP_OK(hipStreamSynchronize(e->stream));
   e->async_pending = false;
+  if (after_sync) after_sync();   // kb_session_load: what else came back behind this synchronisation (the water-fill's results)
   for (const Part &pt : parts)
     if (pt.bytes) std::memcpy(pt.dst, e->h_fin.data() + pt.off, pt.bytes);
   float ms = 0;
@@ -360,7 +416,7 @@ KbRound make_round(kb_engine *e, uint32_t n_rows, uint32_t n_mrows, uint32_t L, 
   r.host_out = nullptr;
   r.seq = 0;
   r.backfill = backfill ? 1 : 0;
-  r.batch = e->commit_batch;
+  r.batch = 0;
   r.gather = 0;
   r.delta = nullptr;
   r.own_row0 = r.own_row1 = 0;
@@ -551,8 +607,7 @@ void round_commit(kb_engine *e, const RoundCtx &c, unsigned long long *keys, dou
     const int kern = e->commit_kernel;
     e->commit_kernel_of[c.buf] = kern;
     if (kern == KB_COMMIT_RUN) { kb_launch_commit(c.d, r, e->stream); e->rounds_run++; }
-    else if (kern == KB_COMMIT_SELECT) { kb_launch_commit_sel(c.d, r, e->stream); e->rounds_sel++; }
-    else { kb_launch_commit_batch(c.d, r, e->stream); e->rounds_batch++; }
+    else { kb_launch_commit_sel(c.d, r, e->stream); e->rounds_sel++; }
   };
   if (e->fast_rounds) {
     r.host_out = e->d_hout + (size_t)c.buf * KB_OUT_STRIDE;
@@ -621,21 +676,17 @@ void round_collect(kb_engine *e, const RoundCtx &c, bool had_candidates, uint32_
   }
   n_done = h_result[0];
   reason = h_result[1];
-  if (reason == KB_REASON_INTERNAL) throw EngineError(KB_E_INTERNAL, "commit kernel ran out of candidate list entries (list shorter than the window)");
-  // rows won by a node the round had already changed (the batch kernel reports them in word 6, word 3 counts its row-mode rows)
-  const bool run_like = e->commit_kernel_of[c.buf] != KB_COMMIT_BATCH;   // the run kernel and the selection kernel report alike
-  const uint32_t dirty_won = run_like ? h_result[3] : h_result[6];
+  if (reason == KB_REASON_INTERNAL)   // only the selection kernel's bounded waits raise it (kb_commit_sel.hip: K9Sync::err): a hand-over between its waves never arrived
+    throw EngineError(KB_E_INTERNAL, "selection commit kernel: a wave's bounded wait ran out (round " + std::to_string(e->round_no) + ", " + std::to_string(h_result[4]) +
+                                     " runs and " + std::to_string(n_done) + " of " + std::to_string(c.n) + " rows committed before it)");
+  const uint32_t dirty_won = h_result[3];   // rows won by a node the round had already changed
   e->stats.row_fallbacks += dirty_won;
-  if (e->commit_kernel_of[c.buf] == KB_COMMIT_BATCH) {
-    e->k7_batches += h_result[5];
-    for (int k = 0; k < 14; k++) e->k7_trace[k] += (double)(uint32_t)(ho[(k < 8 ? 4 : 9) + k / 2] >> (32 * (k & 1)));   // zero unless built with -DKB_K7_TRACE
-  }
   if (e->commit_kernel_of[c.buf] == KB_COMMIT_SELECT) {
     e->sel_stat[0] += h_result[6] & 0xFFFFu; e->sel_stat[1] += h_result[6] >> 16; e->sel_stat[2] += h_result[7] & 0xFFFFu; e->sel_stat[3] += h_result[7] >> 16;
     e->stats.rounds_select += 1;
     e->stats.select_runs_clean += h_result[6] & 0xFFFFu; e->stats.select_runs_general += h_result[6] >> 16; e->stats.select_runs_serial += h_result[7] & 0xFFFFu;
   }
-  if (run_like) {
+  {
     e->k5_slots += h_result[2];
     e->k5_walks += h_result[4];
     e->k5_rescans += h_result[5];
@@ -956,7 +1007,7 @@ struct ActionRun {
     // an action that decided nothing left the task table as the last reduction saw it (every call that changes it ends with one):
     // the host mirrors are current, nothing to recount (a cycle's backfill usually finds no BestEffort task at all)
     const double t_fin0 = now_ms();
-    if (!decs.empty() || getenv("KB_ALWAYS_REDUCE")) run_finalize(e);
+    if (!decs.empty()) run_finalize(e);
     e->tl_finish += now_ms() - t_fin0;
     if (action == 0) {
       check_aggregates(e, om);
@@ -1053,8 +1104,7 @@ int kb_engine_create(const kb_config *cfg, kb_engine **out) {
       int khz = 0;
       if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, eng->device) == hipSuccess && khz > 0) eng->wall_khz = (double)khz;
       if (const char *ck = getenv("KB_COMMIT_KERNEL")) {
-        if (ck[0] == 'b') eng->commit_pin = KB_COMMIT_BATCH;
-        else if (ck[0] == 'r') eng->commit_pin = KB_COMMIT_RUN;
+        if (ck[0] == 'r') eng->commit_pin = KB_COMMIT_RUN;
         else if (ck[0] == 's') eng->commit_pin = KB_COMMIT_SELECT;
         if (eng->commit_pin >= 0) eng->commit_kernel = eng->commit_pin;
       }
@@ -1080,7 +1130,7 @@ int kb_engine_create(const kb_config *cfg, kb_engine **out) {
 void kb_engine_destroy(kb_engine *e) {
   if (!e) return;
   if (getenv("KB_K5_STATS"))
-    fprintf(stderr, "[kb K5] rounds on the batch kernel %llu, on the run kernel %llu, on the selection kernel %llu, last dirty share %.3f\n", (unsigned long long)e->rounds_batch,
+    fprintf(stderr, "[kb K5] rounds on the run kernel %llu, on the selection kernel %llu, last dirty share %.3f\n",
             (unsigned long long)e->rounds_run, (unsigned long long)e->rounds_sel, e->dirty_share);
   if (getenv("KB_K5_STATS") && e->rounds_sel)
     fprintf(stderr, "[kb select] runs of >= 2 rows: all picks clean first placements %llu, general selection %llu, handed to the serial loop %llu; deep passes %llu\n",
@@ -1092,18 +1142,10 @@ void kb_engine_destroy(kb_engine *e) {
             (unsigned long long)e->k5_demand);
   if (getenv("KB_K5_STATS")) fprintf(stderr, "[kb overlap] rounds with candidate lists built beside the predecessor's commit %llu, lists that never arrived %llu\n",
                                      (unsigned long long)e->overlapped_rounds, (unsigned long long)e->overlap_faults);
-  if (getenv("KB_K5_STATS")) fprintf(stderr, "[kb K7] batches of the batch kernel %llu\n", e->k7_batches);
   if (getenv("KB_K5_STATS"))
     fprintf(stderr, "[kb host] ms over the engine's life: reset %.2f, allocate up to its first launch %.2f, speculation breaks (answer -> re-planned launch) %.2f, "
             "closing reductions %.2f, waiting for rounds %.2f, backfill up to its first launch %.2f\n", e->tl_reset, e->tl_begin, e->tl_break, e->tl_finish, e->tl_wait, e->tl_backfill);
   if (getenv("KB_K5_STATS")) fprintf(stderr, "[kb probe] %llu probes, %llu shapes marked dead by them\n", (unsigned long long)e->probes, (unsigned long long)e->probe_deaths);
-  if (getenv("KB_K5_STATS") && e->k7_trace[1] > 0) {
-    static const char *ph[14] = {"loop top / descriptor refill", "shapes (+ barrier)", "windows (+ barrier)", "walk (+ barrier)", "fetch + apply (+ barrier)",
-                                 "evaluate (+ barrier)", "validate (+ barrier)", "commit the prefix", "row mode: keyq pass (+ barrier)", "row mode: rows (+ barrier)",
-                                 "roll back", "row mode: dirty-winner branch (part of rows)", "row-mode entries (count)", "prologue of the round (per round, not per batch)"};
-    const double nb = (double)(e->k7_batches ? e->k7_batches : 1);
-    for (int k = 0; k < 14; k++) fprintf(stderr, "[kb K7 trace] %-32s %14.0f clocks of 10 ns (%.1f ns per batch)\n", ph[k], e->k7_trace[k], 10.0 * e->k7_trace[k] / nb);
-  }
   if (getenv("KB_K5_STATS") && e->k5_trace[0] > 0) {
     static const char *ph[10] = {"barrier 1 (wave 0's wait)", "evaluate: candidates (wave 0)", "barrier 2", "rows", "prepare the next run",
                                 "rows, of runs with scalar dimensions", "runs with scalar dimensions (count)", "evaluate, of runs with scalar dimensions",
@@ -1122,36 +1164,48 @@ void kb_engine_destroy(kb_engine *e) {
 // proportion's OnSessionOpen water-fill as a launch (kb_waterfill.hip; default since its first device run, round 4; KB_DEVICE_WATERFILL=0: the host loop): the queues' requests, weights and the
 // session's total go up, `deserved` comes back for the host's order machine (Overused, the queue order) and stays on the device for
 // k_finalize_queues.  build_host_session left hs.deserved at zero.
-static void device_waterfill(kb_engine *e) {
+// Queued on the engine's stream, nothing waited for: the launch leaves `deserved` where k_finalize_queues reads it (b_deserved / b_desmask,
+// in their [R][Q] layout) and the queue records and flags travel back into the load's pinned area; waterfill_collect reads them behind
+// the synchronisation that ends the load (run_finalize's).
+struct WaterfillInFlight { WfQueue *qs = nullptr; WfState *st = nullptr; };
+static WaterfillInFlight device_waterfill_queue(kb_engine *e) {
   HostSession &hs = e->hs;
   const uint32_t Q = hs.Q;
-  std::vector<WfQueue> qs(Q ? Q : 1);
+  const size_t nq = Q ? Q : 1;
+  WaterfillInFlight w;
+  w.qs = reinterpret_cast<WfQueue *>(e->load_arena.take(sizeof(WfQueue) * nq));
+  w.st = reinterpret_cast<WfState *>(e->load_arena.take(sizeof(WfState)));
+  for (size_t q = 0; q < nq; q++) new (&w.qs[q]) WfQueue();
+  new (w.st) WfState();
   for (uint32_t q = 0; q < Q; q++) {
-    qs[q].request = hs.queue_request[q];
-    qs[q].weight = hs.queue_weight[q];
-    qs[q].has_attr = hs.queue_has_attr[q];
-    qs[q].meet = 0;
-    qs[q].active = 0;
+    w.qs[q].request = hs.queue_request[q];
+    w.qs[q].weight = hs.queue_weight[q];
+    w.qs[q].has_attr = hs.queue_has_attr[q];
+    w.qs[q].meet = 0;
+    w.qs[q].active = 0;
   }
-  WfState st;
+  WfState &st = *w.st;
   st.remaining = hs.total;
   st.total_weight = 0; st.stop = 0; st.share_at_open = 1; st.underflow = 0; st.passes = 0;
   DevBuf &b_q = e->b_wf_queues, &b_st = e->b_wf_state;   // kept between loads (the Go action loads a session every cycle): grown, never shrunk
-  if (b_q.bytes < sizeof(WfQueue) * qs.size()) b_q.alloc(sizeof(WfQueue) * qs.size());
-  if (b_st.bytes < sizeof(WfState)) b_st.alloc(sizeof(WfState));
-  // everything on the engine's (non-blocking) stream, so that the copies and the launch are ordered by the API and not by what the
-  // null stream happens to do with a pageable buffer; qs / st live until the synchronisation below
-  HIP_OK(hipMemcpyAsync(b_q.p, qs.data(), sizeof(WfQueue) * qs.size(), hipMemcpyHostToDevice, e->stream));
-  HIP_OK(hipMemcpyAsync(b_st.p, &st, sizeof(WfState), hipMemcpyHostToDevice, e->stream));
-  kb_launch_waterfill(b_q.as<WfQueue>(), Q, b_st.as<WfState>(), hs.R, e->stream);
-  HIP_OK(hipMemcpyAsync(qs.data(), b_q.p, sizeof(WfQueue) * qs.size(), hipMemcpyDeviceToHost, e->stream));
-  HIP_OK(hipMemcpyAsync(&st, b_st.p, sizeof(WfState), hipMemcpyDeviceToHost, e->stream));
-  HIP_OK(hipStreamSynchronize(e->stream));
+  b_q.alloc(sizeof(WfQueue) * nq);
+  b_st.alloc(sizeof(WfState));
+  e->b_deserved.alloc(sizeof(double) * (size_t)hs.R * nq);
+  e->b_desmask.alloc(sizeof(uint32_t) * nq);
+  HIP_OK(hipMemcpyAsync(b_q.p, w.qs, sizeof(WfQueue) * nq, hipMemcpyHostToDevice, e->stream));
+  HIP_OK(hipMemcpyAsync(b_st.p, w.st, sizeof(WfState), hipMemcpyHostToDevice, e->stream));
+  kb_launch_waterfill(b_q.as<WfQueue>(), Q, b_st.as<WfState>(), hs.R, e->b_deserved.as<double>(), e->b_desmask.as<uint32_t>(), e->stream);
+  HIP_OK(hipMemcpyAsync(w.qs, b_q.p, sizeof(WfQueue) * nq, hipMemcpyDeviceToHost, e->stream));
+  HIP_OK(hipMemcpyAsync(w.st, b_st.p, sizeof(WfState), hipMemcpyDeviceToHost, e->stream));
+  return w;
+}
+static void waterfill_collect(kb_engine *e, const WaterfillInFlight &w) {
+  HostSession &hs = e->hs;
   HIP_OK(hipGetLastError());
-  if (st.underflow) throw EngineError(KB_E_UNSUPPORTED, "proportion water-filling underflow (the reference would panic in Resource.Sub)");
-  for (uint32_t q = 0; q < Q; q++) hs.deserved[q] = qs[q].deserved;
-  hs.queue_share_at_open = st.share_at_open ? 1 : 0;
-  e->waterfill_passes = st.passes;
+  if (w.st->underflow) throw EngineError(KB_E_UNSUPPORTED, "proportion water-filling underflow (the reference would panic in Resource.Sub)");
+  for (uint32_t q = 0; q < hs.Q; q++) hs.deserved[q] = w.qs[q].deserved;
+  hs.queue_share_at_open = w.st->share_at_open ? 1 : 0;
+  e->waterfill_passes = w.st->passes;
 }
 
 int kb_session_load(kb_engine *e, const kb_snapshot *sn) {
@@ -1187,31 +1241,36 @@ int kb_session_load(kb_engine *e, const kb_snapshot *sn) {
     hipStream_t s = e->stream;
     e->evictions.clear();
 
-
-    // ---- device upload ----
+    // ---- device upload: every source goes through the load's pinned area (PinnedArena above), every copy is asynchronous on the engine's
+    //      stream, and the ONE synchronisation of a load is the one that ends it (run_finalize's, below)
+    e->load_arena.reset();
+    Uploader up(e->load_arena, s);
+    WaterfillInFlight wf_flight;
+    // proportion's water-fill first: it needs the host session only, and its (tiny, serial) launch runs while the host assembles the rest
+    if (hs.waterfill_on_device) wf_flight = device_waterfill_queue(e);
     KbDev &d = e->dev;
     d = KbDev{};
     d.R = R; d.N = N; d.NP = NP; d.T = T; d.J = J; d.Q = Q;
-    upload_padded(e->b_idle, sn->node_idle, R, N, NP, s);
+    up.padded(e->b_idle, sn->node_idle, R, N, NP);
     e->idle_below_eps = false;   // NodeInfo keeps Idle above -epsilon (every Sub is guarded by LessEqual); a snapshot may not
     for (uint32_t n = 0; n < N; n++)
       if (sn->node_idle[n] <= -kMinMilliCPU || sn->node_idle[(size_t)N + n] <= -kMinMemory) e->idle_below_eps = true;
-    upload_padded(e->b_rel, sn->node_releasing, R, N, NP, s);
-    upload_padded(e->b_nzc, sn->node_nz_cpu, 1, N, NP, s);
-    upload_padded(e->b_nzm, sn->node_nz_mem, 1, N, NP, s);
-    upload_padded(e->b_podcnt, sn->node_pod_cnt, 1, N, NP, s);
-    upload_padded(e->b_acpu, sn->node_alloc_cpu, 1, N, NP, s);
-    upload_padded(e->b_amem, sn->node_alloc_mem, 1, N, NP, s);
-    upload_padded(e->b_maxpods, sn->node_max_pods, 1, N, NP, s);
+    up.padded(e->b_rel, sn->node_releasing, R, N, NP);
+    up.padded(e->b_nzc, sn->node_nz_cpu, 1, N, NP);
+    up.padded(e->b_nzm, sn->node_nz_mem, 1, N, NP);
+    up.padded(e->b_podcnt, sn->node_pod_cnt, 1, N, NP);
+    up.padded(e->b_acpu, sn->node_alloc_cpu, 1, N, NP);
+    up.padded(e->b_amem, sn->node_alloc_mem, 1, N, NP);
+    up.padded(e->b_maxpods, sn->node_max_pods, 1, N, NP);
     {   // reciprocals of the allocatable quantities for the exact integer-division estimate (IEEE division, same on host and device)
-      std::vector<double> ia(NP, 0.0), im(NP, 0.0);
-      for (uint32_t n = 0; n < N; n++) {
-        ia[n] = 1.0 / (double)sn->node_alloc_cpu[n];
-        im[n] = 1.0 / (double)sn->node_alloc_mem[n];
-      }
-      upload(e->b_invac, ia.data(), NP, s);
-      upload(e->b_invam, im.data(), NP, s);
-      HIP_OK(hipStreamSynchronize(s));
+      double *ia = up.stage<double>(e->b_invac, NP);
+      for (uint32_t n = 0; n < N; n++) ia[n] = 1.0 / (double)sn->node_alloc_cpu[n];
+      std::fill(ia + N, ia + NP, 0.0);
+      up.commit();
+      double *im = up.stage<double>(e->b_invam, NP);
+      for (uint32_t n = 0; n < N; n++) im[n] = 1.0 / (double)sn->node_alloc_mem[n];
+      std::fill(im + N, im + NP, 0.0);
+      up.commit();
     }
     // The commit kernel keeps the window in LDS (160 KiB per workgroup on gfx950): one dirty slot per row (one thread of the
     // 256-thread workgroup evaluates one slot), the row descriptors, and per distinct shape its candidate list.  Prefer the
@@ -1222,7 +1281,6 @@ int kb_session_load(kb_engine *e, const kb_snapshot *sn) {
       uint32_t best_w = 0, best_s = 0;
       for (uint32_t w = W; w >= 1; w = (w > 32 ? ((w - 1) / 32) * 32 : w - 1)) {
         uint32_t sc = std::min<uint32_t>(KB_K5_MAX_SHAPES, w);
-        if (kb_commit_batch_smem_bytes(std::max<uint32_t>(64, ((w + 63) / 64) * 64), NP, R) > budget) { if (w == 1) break; continue; }
         while (sc > 0 && kb_commit_smem_bytes(w, sc, NP, R) > budget) sc--;
         if (sc >= std::min<uint32_t>(64, w)) { best_w = w; best_s = sc; break; }
         if (sc > best_s) { best_w = w; best_s = sc; }
@@ -1238,11 +1296,16 @@ int kb_session_load(kb_engine *e, const kb_snapshot *sn) {
         throw EngineError(KB_E_UNSUPPORTED, "score range x node count exceeds the commit kernel's 32-bit keys");
     }
     mark("node arrays, window");
-    std::vector<uint32_t> ncls(NP, 0);
-    if (sn->node_class) std::memcpy(ncls.data(), sn->node_class, sizeof(uint32_t) * N);
-    upload(e->b_ncls, ncls.data(), NP, s);
-    upload(e->b_nmask, nmask.data(), NP, s);
-    upload(e->b_tinit, hs.t_init.data(), (size_t)R * T, s);
+    const uint32_t *ncls;   // the staged copy stays readable for the range checks below (the area is only reset by the next load)
+    {
+      uint32_t *p = up.stage<uint32_t>(e->b_ncls, NP);
+      std::fill(p, p + NP, 0u);
+      if (sn->node_class) std::memcpy(p, sn->node_class, sizeof(uint32_t) * N);
+      up.commit();
+      ncls = p;
+    }
+    up.copy(e->b_nmask, nmask.data(), NP);
+    up.copy(e->b_tinit, hs.t_init.data(), (size_t)R * T);
     {   // the backfill view of t_init: cpu / memory of a BestEffort task are its Resreq (scalar rows are never compared for
         // them: every InitResreq scalar is at or below the epsilon, resource_info.go:283-287)
       bool differs = false;
@@ -1252,29 +1315,32 @@ int kb_session_load(kb_engine *e, const kb_snapshot *sn) {
         std::vector<double> fit(hs.t_init);
         for (uint32_t t = 0; t < T; t++)
           if (hs.t_init_empty[t]) { fit[t] = hs.t_res[t]; fit[(size_t)T + t] = hs.t_res[(size_t)T + t]; }
-        upload(e->b_tfit, fit.data(), (size_t)R * T, s);
+        up.copy(e->b_tfit, fit.data(), (size_t)R * T);
         e->t_fit = e->b_tfit.as<double>();
       } else {
         e->t_fit = e->b_tinit.as<double>();
       }
     }
-    upload(e->b_tres, hs.t_res.data(), (size_t)R * T, s);
-    upload(e->b_tnzc, sn->task_nz_cpu, T, s);
-    upload(e->b_tnzm, sn->task_nz_mem, T, s);
-    upload(e->b_tcls, hs.t_cls.data(), T, s);
-    upload(e->b_tactive, t_active.data(), T, s);
-    upload(e->b_tresmask, hs.t_resmask.data(), T, s);
-    upload(e->b_tjob, hs.t_job.data(), T, s);
-    upload(e->b_tstatus, hs.t_status.data(), T, s);
-    upload(e->b_tnode, hs.t_node.data(), T, s);
-    std::vector<uint32_t> bind(T, KB_NONE);
-    upload(e->b_tbind, bind.data(), T, s);
-    std::vector<uint8_t> counted(T, 0);
-    for (uint32_t t = 0; t < T; t++) {
-      int st = hs.t_status[t];
-      counted[t] = (st == KB_TASK_BOUND || st == KB_TASK_BINDING || st == KB_TASK_RUNNING || st == KB_TASK_ALLOCATED) ? 1 : 0;   // drf.go:71-77
+    up.copy(e->b_tres, hs.t_res.data(), (size_t)R * T);
+    up.copy(e->b_tnzc, sn->task_nz_cpu, T);
+    up.copy(e->b_tnzm, sn->task_nz_mem, T);
+    up.copy(e->b_tcls, hs.t_cls.data(), T);
+    up.copy(e->b_tactive, t_active.data(), T);
+    up.copy(e->b_tresmask, hs.t_resmask.data(), T);
+    up.copy(e->b_tjob, hs.t_job.data(), T);
+    up.copy(e->b_tstatus, hs.t_status.data(), T);
+    up.copy(e->b_tnode, hs.t_node.data(), T);
+    e->b_tbind.alloc(sizeof(uint32_t) * (T ? T : 1));   // nothing is bound yet: KB_NONE everywhere, set on the device
+    HIP_OK(hipMemsetAsync(e->b_tbind.p, 0xFF, sizeof(uint32_t) * (T ? T : 1), s));
+    static_assert(KB_NONE == 0xFFFFFFFFu, "t_bind is cleared with a byte pattern");
+    {
+      uint8_t *counted = up.stage<uint8_t>(e->b_tcounted, T);
+      for (uint32_t t = 0; t < T; t++) {
+        const int st = hs.t_status[t];
+        counted[t] = (st == KB_TASK_BOUND || st == KB_TASK_BINDING || st == KB_TASK_RUNNING || st == KB_TASK_ALLOCATED) ? 1 : 0;   // drf.go:71-77
+      }
+      up.commit();
     }
-    upload(e->b_tcounted, counted.data(), T, s);
     e->b_jallocated.alloc(J ? J : 1);
     HIP_OK(hipMemsetAsync(e->b_jallocated.p, 0, J ? J : 1, s));
     mark("task arrays");
@@ -1286,7 +1352,7 @@ int kb_session_load(kb_engine *e, const kb_snapshot *sn) {
         if (hs.t_cls[t] >= sn->n_task_classes) throw EngineError(KB_E_INVALID, "task class out of range");
       for (uint32_t n = 0; n < N; n++)
         if (ncls[n] >= sn->n_node_classes) throw EngineError(KB_E_INVALID, "node class out of range");
-      upload(e->b_compat, sn->class_compat, nb, s);
+      up.copy(e->b_compat, sn->class_compat, nb);
       d.compat = e->b_compat.as<uint8_t>();
       d.crows = nullptr;
       if (sn->n_node_classes <= 256) {   // word-aligned rows for the commit kernel (one 32-byte fetch per task class)
@@ -1296,8 +1362,7 @@ int kb_session_load(kb_engine *e, const kb_snapshot *sn) {
             size_t bit = (size_t)tc * sn->n_node_classes + nc;
             if ((sn->class_compat[bit >> 3] >> (bit & 7)) & 1) rows[(size_t)tc * 8 + (nc >> 5)] |= 1u << (nc & 31);
           }
-        upload(e->b_crows, rows.data(), rows.size(), s);
-        HIP_OK(hipStreamSynchronize(s));
+        up.copy(e->b_crows, rows.data(), rows.size());
         d.crows = e->b_crows.as<uint32_t>();
       }
     }
@@ -1315,9 +1380,9 @@ int kb_session_load(kb_engine *e, const kb_snapshot *sn) {
         any = any || tw[t] || tc[t];
       }
       if (any) {
-        upload(e->b_ports, np_.data(), NP, s);
-        upload(e->b_twant, tw.data(), tw.size(), s);
-        upload(e->b_tconf, tc.data(), tc.size(), s);
+        up.copy(e->b_ports, np_.data(), NP);
+        up.copy(e->b_twant, tw.data(), tw.size());
+        up.copy(e->b_tconf, tc.data(), tc.size());
         d.ports = e->b_ports.as<unsigned long long>();
         d.t_want = e->b_twant.as<unsigned long long>();
         d.t_conf = e->b_tconf.as<unsigned long long>();
@@ -1328,17 +1393,17 @@ int kb_session_load(kb_engine *e, const kb_snapshot *sn) {
         for (uint32_t n = 0; n < N && sn->node_ports; n++)
           for (uint32_t w = 0; w < X; w++) nx[(size_t)w * NP + n] = sn->node_ports[(size_t)n * Wh + 1 + w];
         static_assert(sizeof(unsigned long long) == sizeof(uint64_t), "host-port words");
-        upload(e->b_ports_x, nx.data(), nx.size(), s);
-        upload(e->b_twant_x, reinterpret_cast<const unsigned long long *>(hs.t_want_x.data()), hs.t_want_x.size(), s);
-        upload(e->b_tconf_x, reinterpret_cast<const unsigned long long *>(hs.t_conf_x.data()), hs.t_conf_x.size(), s);
+        up.copy(e->b_ports_x, nx.data(), nx.size());
+        up.copy(e->b_twant_x, reinterpret_cast<const unsigned long long *>(hs.t_want_x.data()), hs.t_want_x.size());
+        up.copy(e->b_tconf_x, reinterpret_cast<const unsigned long long *>(hs.t_conf_x.data()), hs.t_conf_x.size());
         d.ports_x = e->b_ports_x.as<unsigned long long>();
         d.t_want_x = e->b_twant_x.as<unsigned long long>();
         d.t_conf_x = e->b_tconf_x.as<unsigned long long>();
         d.port_xw = X;
         if (!d.ports) {   // word 0 empty everywhere: the kernels still take the host-port path by d.ports
-          upload(e->b_ports, np_.data(), NP, s);
-          upload(e->b_twant, tw.data(), tw.size(), s);
-          upload(e->b_tconf, tc.data(), tc.size(), s);
+          up.copy(e->b_ports, np_.data(), NP);
+          up.copy(e->b_twant, tw.data(), tw.size());
+          up.copy(e->b_tconf, tc.data(), tc.size());
           d.ports = e->b_ports.as<unsigned long long>();
           d.t_want = e->b_twant.as<unsigned long long>();
           d.t_conf = e->b_tconf.as<unsigned long long>();
@@ -1368,8 +1433,8 @@ int kb_session_load(kb_engine *e, const kb_snapshot *sn) {
           throw EngineError(KB_E_UNSUPPORTED, "nodeorder weights exceed the 16-bit score range");
         hs.has_affinity = true;
         hs.cls_has_aff = has;
-        upload(e->b_aff, sn->class_affinity, na, s);
-        upload(e->b_affcls, has.data(), has.size(), s);
+        up.copy(e->b_aff, sn->class_affinity, na);
+        up.copy(e->b_affcls, has.data(), has.size());
         d.aff = e->b_aff.as<int32_t>();
         d.aff_cls = e->b_affcls.as<uint8_t>();
       }
@@ -1381,17 +1446,18 @@ int kb_session_load(kb_engine *e, const kb_snapshot *sn) {
     if (ip) {
       const uint32_t C = ip->n_counters, P = ip->n_classes, D = ip->n_domains;
       const uint32_t Wc = C ? (C + 63) / 64 : 1, Wp = P ? (P + 63) / 64 : 1;
-      auto pad_u32 = [&](DevBuf &b, const uint32_t *src, uint32_t rows) {   // [rows][N] -> [rows][NP], padding KB_NONE
-        std::vector<uint32_t> tmp((size_t)std::max(rows, 1u) * NP, KB_NONE);
-        for (uint32_t r0 = 0; r0 < rows; r0++) std::memcpy(&tmp[(size_t)r0 * NP], src + (size_t)r0 * N, sizeof(uint32_t) * N);
-        upload(b, tmp.data(), tmp.size(), s);
-        HIP_OK(hipStreamSynchronize(s));
+      // [rows][N] -> [max(rows, 1)][NP], the pad (and the row of a table without rows) KB_NONE / 0
+      auto pad_u32 = [&](DevBuf &b, const uint32_t *src, uint32_t rows) {
+        if (rows) { up.padded<uint32_t>(b, src, rows, N, NP, KB_NONE); return; }
+        uint32_t *p0 = up.stage<uint32_t>(b, NP);
+        std::fill(p0, p0 + NP, KB_NONE);
+        up.commit();
       };
       auto pad_i32 = [&](DevBuf &b, const int32_t *src, uint32_t rows) {
-        std::vector<int32_t> tmp((size_t)std::max(rows, 1u) * NP, 0);
-        for (uint32_t r0 = 0; r0 < rows; r0++) std::memcpy(&tmp[(size_t)r0 * NP], src + (size_t)r0 * N, sizeof(int32_t) * N);
-        upload(b, tmp.data(), tmp.size(), s);
-        HIP_OK(hipStreamSynchronize(s));
+        if (rows) { up.padded<int32_t>(b, src, rows, N, NP, 0); return; }
+        int32_t *p0 = up.stage<int32_t>(b, NP);
+        std::fill(p0, p0 + NP, 0);
+        up.commit();
       };
       pad_u32(e->b_ip_cdom, ip->ctr_dom, C);
       pad_u32(e->b_ip_pdom, ip->cls_dom, P);
@@ -1399,22 +1465,21 @@ int kb_session_load(kb_engine *e, const kb_snapshot *sn) {
       pad_i32(e->b_ip_punb, ip->cls_unbound, P);
       std::vector<int32_t> cc((size_t)std::max(C, 1u) * D, 0), ct(std::max(C, 1u), 0);
       if (C) { std::memcpy(cc.data(), ip->ctr_count, sizeof(int32_t) * (size_t)C * D); std::memcpy(ct.data(), ip->ctr_total, sizeof(int32_t) * C); }
-      upload(e->b_ip_ccnt, cc.data(), cc.size(), s);
-      upload(e->b_ip_ctot, ct.data(), ct.size(), s);
-      upload(e->b_ip_tinc, ip->task_inc, (size_t)T * Wc, s);
-      upload(e->b_ip_tforbid, ip->task_forbid, (size_t)T * Wc, s);
-      upload(e->b_ip_tchk, hs.t_ip_checks.data(), T, s);
-      upload(e->b_ip_treq, ip->task_require, T, s);
-      upload(e->b_ip_tself, ip->task_self, T, s);
-      upload(e->b_ip_tsubj, hs.t_ip_subject.data(), T, s);
-      upload(e->b_ip_tcinc, ip->task_cls_inc, (size_t)T * Wp, s);
-      upload(e->b_ip_tsig, ip->task_sig, T, s);
+      up.copy(e->b_ip_ccnt, cc.data(), cc.size());
+      up.copy(e->b_ip_ctot, ct.data(), ct.size());
+      up.copy(e->b_ip_tinc, ip->task_inc, (size_t)T * Wc);
+      up.copy(e->b_ip_tforbid, ip->task_forbid, (size_t)T * Wc);
+      up.copy(e->b_ip_tchk, hs.t_ip_checks.data(), T);
+      up.copy(e->b_ip_treq, ip->task_require, T);
+      up.copy(e->b_ip_tself, ip->task_self, T);
+      up.copy(e->b_ip_tsubj, hs.t_ip_subject.data(), T);
+      up.copy(e->b_ip_tcinc, ip->task_cls_inc, (size_t)T * Wp);
+      up.copy(e->b_ip_tsig, ip->task_sig, T);
       std::vector<int32_t> sw((size_t)std::max(ip->n_sigs, 1u) * std::max(P, 1u), 0);
       if (ip->n_sigs && P) std::memcpy(sw.data(), ip->sig_weight, sizeof(int32_t) * (size_t)ip->n_sigs * P);
-      upload(e->b_ip_sigw, sw.data(), sw.size(), s);
+      up.copy(e->b_ip_sigw, sw.data(), sw.size());
       const uint32_t z0 = ip->first_unbound_node;
-      upload(e->b_ip_z, &z0, 1, s);
-      HIP_OK(hipStreamSynchronize(s));
+      up.copy(e->b_ip_z, &z0, 1);
       d.ip_ctr_dom = e->b_ip_cdom.as<uint32_t>(); d.ip_ctr_count = e->b_ip_ccnt.as<int32_t>(); d.ip_ctr_total = e->b_ip_ctot.as<int32_t>();
       d.t_ip_inc = e->b_ip_tinc.as<unsigned long long>(); d.t_ip_forbid = e->b_ip_tforbid.as<unsigned long long>();
       d.t_ip_req = e->b_ip_treq.as<uint16_t>(); d.t_ip_self = e->b_ip_tself.as<uint8_t>(); d.t_ip_subject = e->b_ip_tsubj.as<uint8_t>();
@@ -1425,36 +1490,36 @@ int kb_session_load(kb_engine *e, const kb_snapshot *sn) {
       d.ip_C = C; d.ip_D = D; d.ip_P = P; d.ip_Wc = Wc; d.ip_Wp = Wp;
     }
     mark("classes, ports, inter-pod");
-    upload(e->b_probe_rows, hs.feas_rep.data(), hs.n_feas_shapes, s);
+    up.copy(e->b_probe_rows, hs.feas_rep.data(), hs.n_feas_shapes);
     e->b_probe_alive.alloc(sizeof(uint32_t) * std::max<uint32_t>(hs.n_feas_shapes, 1u));
     e->h_probe_alive.resize(std::max<uint32_t>(hs.n_feas_shapes, 1u));
     e->h_probe_rows.resize(std::max<uint32_t>(hs.n_feas_shapes, 1u));
-    upload(e->b_jbegin, hs.job_begin.data(), J + 1, s);
-    upload(e->b_jmin, hs.job_min.data(), J, s);
-    upload(e->b_jqueue, hs.job_queue.data(), J, s);
-    upload(e->b_total, hs.total.v, KB_MAX_RES, s);
+    up.copy(e->b_jbegin, hs.job_begin.data(), J + 1);
+    up.copy(e->b_jmin, hs.job_min.data(), J);
+    up.copy(e->b_jqueue, hs.job_queue.data(), J);
+    up.copy(e->b_total, hs.total.v, KB_MAX_RES);
     e->total_mask = hs.total.mask;
-    if (hs.waterfill_on_device) device_waterfill(e);
-    std::vector<double> des((size_t)R * (Q ? Q : 1), 0.0);
-    std::vector<uint32_t> desmask(Q ? Q : 1, 0);
-    for (uint32_t q = 0; q < Q; q++) {
-      desmask[q] = hs.deserved[q].mask;
-      for (int dd = 0; dd < R; dd++) des[(size_t)dd * Q + q] = hs.deserved[q].get(dd);
+    if (!hs.waterfill_on_device) {   // the host loop of kb_session.cpp filled hs.deserved (the launch writes b_deserved / b_desmask itself)
+      double *des = up.stage<double>(e->b_deserved, (size_t)R * (Q ? Q : 1));
+      std::fill(des, des + (size_t)R * (Q ? Q : 1), 0.0);
+      for (uint32_t q = 0; q < Q; q++)
+        for (int dd = 0; dd < R; dd++) des[(size_t)dd * Q + q] = hs.deserved[q].get(dd);
+      up.commit();
+      uint32_t *desmask = up.stage<uint32_t>(e->b_desmask, Q ? Q : 1);
+      desmask[0] = 0;
+      for (uint32_t q = 0; q < Q; q++) desmask[q] = hs.deserved[q].mask;
+      up.commit();
     }
-    upload(e->b_deserved, des.data(), des.size(), s);
-    upload(e->b_desmask, desmask.data(), desmask.size(), s);
     hs.job_alloc.assign((size_t)J * R, 0.0);
     hs.job_share.assign(J, 0.0);
     hs.queue_alloc.assign((size_t)Q * R, 0.0);
     hs.queue_share.assign(Q, 0.0);
-    hs.queue_share_live.assign(Q ? Q : 1, hs.queue_share_at_open);
     hs.job_ready.assign(J, 0);
     e->b_jalloc.alloc(sizeof(double) * (size_t)(J ? J : 1) * R);
     e->b_jshare.alloc(sizeof(double) * (J ? J : 1));
     e->b_qalloc.alloc(sizeof(double) * (size_t)(Q ? Q : 1) * R);
     e->b_qshare.alloc(sizeof(double) * (Q ? Q : 1));
     e->b_jready.alloc(sizeof(int) * (J ? J : 1));
-    HIP_OK(hipStreamSynchronize(s));
 
     d.idle = e->b_idle.as<double>(); d.rel = e->b_rel.as<double>();
     d.nzc = e->b_nzc.as<long long>(); d.nzm = e->b_nzm.as<long long>(); d.podcnt = e->b_podcnt.as<int>();
@@ -1490,8 +1555,13 @@ int kb_session_load(kb_engine *e, const kb_snapshot *sn) {
     if (hs.has_interpod) { snap_copy(e->p_ip_ccnt, e->b_ip_ccnt); snap_copy(e->p_ip_ctot, e->b_ip_ctot); snap_copy(e->p_ip_punb, e->b_ip_punb); snap_copy(e->p_ip_z, e->b_ip_z); }
     // initial drf / proportion / gang aggregates come from the device reduction (K2+K4)
     mark("pristine copies (queued)");
-    run_finalize(e);
-    mark("aggregates (device reduction)");
+    // the load's synchronisation; the water-fill's answer (deserved, "did a pass run") is read behind it, in front of the host-side
+    // post-processing of the shares, which wants to know whether updateShare ran at open
+    run_finalize(e, [&]() {
+      if (hs.waterfill_on_device) waterfill_collect(e, wf_flight);
+      hs.queue_share_live.assign(Q ? Q : 1, hs.queue_share_at_open);
+    });
+    mark("aggregates (device reduction, the load's one synchronisation)");
     e->fin0.job_alloc = hs.job_alloc; e->fin0.job_share = hs.job_share; e->fin0.queue_alloc = hs.queue_alloc; e->fin0.queue_share = hs.queue_share;
     e->fin0.job_ready = hs.job_ready; e->fin0.t_status = hs.t_status; e->fin0.t_node = hs.t_node; e->fin0.valid = true;
     e->stats.reduce_ms = 0;
@@ -1527,7 +1597,7 @@ int kb_session_reset(kb_engine *e) {
     // The restored state is bit for bit the one kb_session_load reduced (the pristine copies were taken in front of that reduction,
     // which flips no status: no job has an Allocate yet): its results come back from the host copies made then.  The device-side result
     // buffers keep the previous reduction's values; nothing reads them before the next reduction rewrites them.
-    if (e->fin0.valid && !getenv("KB_RESET_REDUCE")) {
+    if (e->fin0.valid) {
       e->async_pending = true;   // stream-ordered with everything run_allocate / run_backfill launch; quiesce() for the rest
       HostSession &hs = e->hs;
       hs.job_alloc = e->fin0.job_alloc; hs.job_share = e->fin0.job_share; hs.queue_alloc = e->fin0.queue_alloc; hs.queue_share = e->fin0.queue_share;
@@ -1564,8 +1634,7 @@ static int run_action(kb_engine *e, uint32_t action, kb_decision *out, uint64_t 
     uint32_t n = run.plan(e);
     ensure_matrix_buffers(e, e->eff_window, e->eff_window + 1);   // sized once: no reallocation under a round in flight
     // chained rounds of plain sessions (no score that is normalised over the feasible set, no inter-pod counters) build their candidate
-    // lists beside the predecessor's commit kernel.  With scalar dimensions only behind a predecessor on the run kernel: the batch kernel
-    // writes them speculatively for candidates it may hand back, i.e. on nodes that stay CLEAN, which no repair would look at again
+    // lists beside the predecessor's commit kernel
     const bool overlap_ok = e->overlap && action == 0 && e->fast_rounds && !e->hs.has_affinity && !e->hs.has_interpod && 2 * e->eff_window + 1 <= 1024u &&
                             kb_repair_smem_bytes(e->dev.NP) <= 150u * 1024u;   // the repair launch's LDS (its node bitmap grows with the cluster)
     // The second stream is ordered behind nothing the first one holds: the copies kb_session_reset left queued there must have landed before
@@ -1575,7 +1644,7 @@ static int run_action(kb_engine *e, uint32_t action, kb_decision *out, uint64_t 
     auto launch = [&](uint32_t rows_n, const uint32_t *rows, uint32_t buf, uint32_t chain_expect, uint32_t n_prev) {
       RoundCtx c = round_prepare(e, rows_n, action == 0 ? 1 : 2, action == 1, true, rows, buf, chain_expect);   // single GPU: every matrix row is local
       unsigned long long *keys = e->b_keys.as<unsigned long long>();
-      if (overlap_ok && c.direct && chain_expect != 0 && !e->overlap_faults && (e->hs.R == 2 || e->commit_kernel_of[buf ^ 1u] != KB_COMMIT_BATCH)) {
+      if (overlap_ok && c.direct && chain_expect != 0 && !e->overlap_faults) {
         round_candidates_overlapped(e, c, n_prev, keys);
         c.overlapped = true;
       }
@@ -1691,10 +1760,7 @@ static int run_evict_action(kb_engine *e, bool reclaim, kb_stmt_op *out, uint64_
     // host side of the evict machine (kb_preempt.cpp: ip_*), the lists rebuilt on the device after every change (round 3; on by default
     // since its first device run, round 4: profiles/round4/first_call)
     // preempt with preferred node-affinity terms: the lists of such preemptors carry the NormalizeReduce'd score and are rebuilt after
-    // every Pipeline instead of repaired (kb_preempt.cpp: preempt_walk).  Checked against the oracle on the CPU (tests/host_harness);
-    // it stays behind a switch until its first run on the device — without it the stock action takes the cycle, as before.
-    if (!reclaim && hs.has_affinity && e->pol.nodeorder_enabled && !preempt_node_affinity_enabled())
-      throw EngineError(KB_E_UNSUPPORTED, "preempt with preferred node-affinity terms (NormalizeReduce over the feasible set) is not modelled");
+    // every Pipeline instead of repaired (kb_preempt.cpp: preempt_walk; tests/test_gpu_regressions.py: test_preempt_with_preferred_node_affinity).
     const double t_begin = now_ms();
     const int R = hs.R;
     const uint32_t N = hs.N, NP = e->dev.NP, T = hs.T, J = hs.J, Q = hs.Q;
@@ -1917,12 +1983,8 @@ static ChunkPlan matrix_plan(kb_engine *e, uint32_t t0, uint32_t n, uint32_t fit
   // matrix: then every row is evaluated by the matrix kernel itself, adjacent equal rows (the tasks of a job) sharing one evaluation
   // (k_matrix_runs).  Measured on one box (profiles/round3/call5): 9 386 shapes of 100k rows: direct 0.62 ms, expansion 0.89 ms;
   // 2 989 shapes (BASELINE configs[3]): direct 0.68, expansion 0.66; 1M x 50k with ~500 shapes: direct 28.0, expansion 24.0.
-  // KB_K1_DIRECT=1/0 pins the choice for A/B runs.
-  {
-    static const char *pin = getenv("KB_K1_DIRECT");
-    p.direct = pin ? pin[0] == '1' : ((size_t)p.ns * e->dev.NP * 2 > (32u << 20) && (size_t)p.ns * 16 > n);
-    if (fit_flags & KB_MATRIX_DIRECT) p.direct = true;
-  }
+  // KB_MATRIX_DIRECT in fit_flags pins the direct path (bench.py's evaluator-only variants).
+  p.direct = ((size_t)p.ns * e->dev.NP * 2 > (32u << 20) && (size_t)p.ns * 16 > n) || (fit_flags & KB_MATRIX_DIRECT);
   if (p.direct) {
     // the tasks of a job are adjacent and share a shape: a row equal to its predecessor re-stores the predecessor's result
     const bool dedup = !(fit_flags & KB_MATRIX_NO_DEDUP);

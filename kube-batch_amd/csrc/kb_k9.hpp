@@ -312,10 +312,6 @@ __device__ __forceinline__ void k9_prologue(const KbCommitArgs &a, const K9Layou
   }
   for (uint32_t s = tid; s < S; s += K9_THREADS) cursor[s] = 0;
   if (tid == 0) { H.i = 0; H.nd = 0; H.reason = KB_REASON_DONE; H.stop = 0; H.ncand = 0; H.n_dirty_rows = 0; H.n_runs = 0; H.n_slow = 0; H.cur_s = 0; H.cur_r = 0; H.cur_fl = 0; H.cur_km = 0; }
-  if (gridDim.x == 1) {   // no helper workgroups (KB_WARM_HELPERS_OFF=1): warm the XCD's L2 here, all threads
-    const unsigned long long acc = kb_warm_lines(*a.dev, a.keys, 0, 0, a.NP / 16, tid, K9_THREADS);
-    if (acc == 0x123456789abcdefull) H.n_slow = 0xFFFFFFFFu;   // keep the loads alive
-  }
   __syncthreads();
   // shape -> one of its rows (any: rows of a shape agree on everything the evaluation reads)
   for (uint32_t i = tid; i < W; i += K9_THREADS) shp[desc[i].slot] = i;
@@ -458,6 +454,9 @@ __device__ __forceinline__ void k9_epilogue(const KbCommitArgs &a, const K9Layou
     if (tid == 0) __hip_atomic_store(&a.host_out[KB_OUT_SEQ], a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
   }
 }
+
+// host side: 160 KiB of dynamic LDS for a commit kernel (kb_warm.hpp: kb_allow_lds)
+static inline void k9_allow_full_lds(const void *fn, bool (&set_on)[64]) { kb_allow_lds(fn, 160 * 1024, set_on); }
 
 // host side: the kernel-argument block of a commit launch
 static inline void k9_fill_args(K9KernArgs &ka, const KbDev &d, const KbRound &r) {

@@ -26,6 +26,7 @@
 #include "kb_device.h"
 #include "kb_eval.hpp"
 #include "kb_k1.hpp"
+#include "kb_warm.hpp"
 
 // ------------------------------------------------------------------------------------------------------------
 // K1: mask + score matrix.  grid (NP / (256*NPT), ceil(n_rows/TR)); thread <-> NPT consecutive nodes kept in
@@ -567,12 +568,9 @@ size_t kb_repair_smem_bytes(uint32_t NP) {
 }
 void kb_launch_repair(const KbDev &d, const KbRound &r, void *stream) {
   if (r.n_mrows == 0) return;
-  static bool attr_set = false;
   const size_t sh = kb_repair_smem_bytes(d.NP);   // the engine overlaps rounds only while this fits the attribute below (kb_engine.cpp: overlap_ok)
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_repair), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-    attr_set = true;
-  }
+  static bool lds_set[64] = {};
+  kb_allow_lds(reinterpret_cast<const void *>(k_repair), 150 * 1024, lds_set);
   hipLaunchKernelGGL(k_repair, dim3(r.n_mrows), dim3(KB_REPAIR_THREADS), sh, (hipStream_t)stream, d, r);
 }
 
@@ -740,8 +738,7 @@ void kb_launch_matrix(const KbDev &d, const KbRound &r, void *stream) {
     // <4,32> amortises a thread's node state over 32 rows and stores 8 bytes per row, but a few hundred rows (the distinct shapes of
     // a whole session) make only ~100 such workgroups: below four per CU the one-node tile with 16 rows fills the chip instead
     const size_t blocks = (size_t)(d.NP / (256 * 4)) * ((r.n_mrows + 31) / 32);
-    static const bool runs_off = getenv("KB_K1_RUNS") && getenv("KB_K1_RUNS")[0] == '0';   // A/B switch
-    if (blocks >= 1024 && r.same_prev != nullptr && !r.gather && r.chain == nullptr && !runs_off) {
+    if (blocks >= 1024 && r.same_prev != nullptr && !r.gather && r.chain == nullptr) {
       hipLaunchKernelGGL(k_matrix_runs, dim3(d.NP / 1024, (r.n_mrows + 31) / 32), dim3(256), 0, (hipStream_t)stream, d, r);
     } else if (blocks >= 1024) {
       dim3 grid(d.NP / (256 * 4), (r.n_mrows + 31) / 32 + (r.gather ? 1 : 0));
@@ -876,17 +873,12 @@ void kb_launch_affinity(const KbDev &d, const KbRound &r, void *stream) {
 void kb_launch_expand(const KbDev &d, const uint16_t *s_score, const uint32_t *s_mask, const uint32_t *row_slot, const uint32_t *order, uint32_t n_rows,
                       uint16_t *score, uint32_t *maskw, void *stream) {
   if (n_rows == 0) return;
-  static const bool plain = getenv("KB_EXPAND_ORDER") && getenv("KB_EXPAND_ORDER")[0] == '0';   // A/B switch: rows in task order
-  if (plain) order = nullptr;
   const uint32_t grid = order ? 8u * ((n_rows + 7u) / 8u) : n_rows;
   hipLaunchKernelGGL(k_expand, dim3(grid), dim3(256), 0, (hipStream_t)stream, s_score, s_mask, row_slot, order, n_rows, d.NP, score, maskw);
 }
 template <bool WIDE, int THREADS, int NW> static void k3_launch(const KbDev &d, const KbRound &r, size_t sh, hipStream_t st) {
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_argmax<WIDE, THREADS, NW>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-    attr_set = true;
-  }
+  static bool lds_set[64] = {};   // one per instantiation
+  kb_allow_lds(reinterpret_cast<const void *>(k_argmax<WIDE, THREADS, NW>), 150 * 1024, lds_set);
   hipLaunchKernelGGL((k_argmax<WIDE, THREADS, NW>), dim3(r.n_mrows), dim3(THREADS), sh, st, d, r);
 }
 void kb_launch_argmax(const KbDev &d, const KbRound &r, void *stream) {

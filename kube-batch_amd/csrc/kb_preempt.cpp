@@ -614,11 +614,6 @@ bool PreemptMachine::same_preemptor_class(uint32_t a, uint32_t b) const {
   return true;
 }
 
-bool preempt_node_affinity_enabled() {
-  const char *v = std::getenv("KB_PREEMPT_NODE_AFFINITY");   // default on since its first device run (round 3); "0" restores the refusal
-  return !(v && v[0] == '0');
-}
-
 // A preemptor whose class has preferred node-affinity terms is scored with NormalizeReduce over ITS feasible set
 // (vendor/.../priorities/reduce.go:28-63 behind util.PrioritizeNodes): one node leaving that set (pod cap reached, a host port
 // taken) can change every other node's score, so a cached list cannot be repaired node by node — it is rebuilt on the device.

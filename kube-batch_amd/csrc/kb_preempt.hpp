@@ -34,9 +34,6 @@ struct LiveNodes {
   std::vector<uint64_t> ports_x, base_ports_x;   // [N][HostSession::port_xw] the masks' words behind the first (empty: one word)
 };
 
-// kb_run_preempt accepts sessions with preferred node-affinity terms unless KB_PREEMPT_NODE_AFFINITY=0 (read at every call)
-bool preempt_node_affinity_enabled();
-
 // the live kb_interpod counts while an evict action runs (device -> host when it starts, host -> device before every list and when it ends)
 struct IpLive {
   std::vector<int32_t> ccnt;   // [C][D] allocated-status pods per counter and domain

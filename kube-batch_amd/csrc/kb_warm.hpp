@@ -1,4 +1,4 @@
-// kb_warm.hpp — L2 warm-up of the commit kernels (kb_commit_batch.hip, kb_commit.hip).
+// kb_warm.hpp — L2 warm-up of the commit kernels (kb_commit.hip, kb_commit_sel.hip), and the launchers' dynamic-LDS attribute.
 //
 // The commit loop is latency-bound and its workgroup starts on a cold L2 at every kernel boundary, so the prologue touches every
 // 128-byte line of the node state once.  One CU pulls that at ~200 GB/s: 5.9 us per round at 10k nodes and
@@ -43,4 +43,14 @@ __device__ __forceinline__ unsigned long long kb_warm_lines(const KbDev &d, cons
     for (int f = 0; f < 4; f++) acc += w[f];
   }
   return acc;
+}
+
+// host side: let `fn` use up to `bytes` of dynamic LDS.  The attribute belongs to the (function, device) pair: each launcher remembers it per
+// device ordinal (`set_on`, a static of its own), not per process — a second engine on another GPU of the same process needs it too
+static inline void kb_allow_lds(const void *fn, int bytes, bool (&set_on)[64]) {
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (dev >= 0 && dev < 64 && set_on[dev]) return;
+  (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (dev >= 0 && dev < 64) set_on[dev] = true;
 }

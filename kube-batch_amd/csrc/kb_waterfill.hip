@@ -14,7 +14,8 @@ using namespace kb;
 
 #define KB_WF_THREADS 256
 
-__global__ void __launch_bounds__(KB_WF_THREADS) k_waterfill(WfQueue *qs, uint32_t Q, WfState *gst, int R) {
+// des / desmask (optional): `deserved` once more, in the layout k_finalize_queues reads ([R][Q] values, absent scalar keys as 0; [Q] key masks)
+__global__ void __launch_bounds__(KB_WF_THREADS) k_waterfill(WfQueue *qs, uint32_t Q, WfState *gst, int R, double *des, uint32_t *desmask) {
   __shared__ __align__(8) unsigned char s_raw[sizeof(WfState)];   // a Res has a constructor: no __shared__ object of it
   WfState &S = *reinterpret_cast<WfState *>(s_raw);
   const uint32_t tid = threadIdx.x;
@@ -54,6 +55,11 @@ __global__ void __launch_bounds__(KB_WF_THREADS) k_waterfill(WfQueue *qs, uint32
     }
     __syncthreads();
   }
+  if (des)   // behind the loop's last barrier: every queue record is final
+    for (uint32_t q = tid; q < Q; q += KB_WF_THREADS) {
+      desmask[q] = qs[q].deserved.mask;
+      for (int d = 0; d < R; d++) des[(size_t)d * Q + q] = qs[q].deserved.get(d);
+    }
   if (tid == 0) {
     gst->remaining = S.remaining;
     gst->total_weight = S.total_weight;
@@ -61,6 +67,6 @@ __global__ void __launch_bounds__(KB_WF_THREADS) k_waterfill(WfQueue *qs, uint32
   }
 }
 
-void kb_launch_waterfill(WfQueue *qs, uint32_t Q, WfState *st, int R, void *stream) {
-  hipLaunchKernelGGL(k_waterfill, dim3(1), dim3(KB_WF_THREADS), 0, (hipStream_t)stream, qs, Q, st, R);
+void kb_launch_waterfill(WfQueue *qs, uint32_t Q, WfState *st, int R, double *des, uint32_t *desmask, void *stream) {
+  hipLaunchKernelGGL(k_waterfill, dim3(1), dim3(KB_WF_THREADS), 0, (hipStream_t)stream, qs, Q, st, R, des, desmask);
 }

@@ -92,5 +92,6 @@ inline void wf_run_sequential(WfQueue *qs, uint32_t Q, WfState &st, int R) {
 }  // namespace kb
 
 // kb_waterfill.hip (the emulated device: tests/host_harness/device_emu.cpp): the loop over `Q` queue records and one state record, both in
-// device memory; st->remaining holds the session's total on entry; on return the records hold deserved / meet and st the flags above
-void kb_launch_waterfill(kb::WfQueue *qs, uint32_t Q, kb::WfState *st, int R, void *stream);
+// device memory; st->remaining holds the session's total on entry; on return the records hold deserved / meet and st the flags above, and
+// des [R][Q] / desmask [Q] (device memory, may be null) `deserved` in the layout k_finalize_queues reads
+void kb_launch_waterfill(kb::WfQueue *qs, uint32_t Q, kb::WfState *st, int R, double *des, uint32_t *desmask, void *stream);

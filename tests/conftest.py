@@ -36,10 +36,10 @@ def pytest_collection_modifyitems(config, items):
 
 
 def pytest_generate_tests(metafunc):
-    """Every gpu-marked test runs once per commit kernel (kb_device.h: KB_COMMIT_BATCH / KB_COMMIT_RUN / KB_COMMIT_SELECT): the engine picks
-    one per round from the share of dirty-won rows, so each must reproduce the oracle on every input."""
+    """Every gpu-marked test that asks for the `commit_kernel` fixture runs once per commit kernel (kb_device.h: KB_COMMIT_RUN, the plain
+    row-by-row restatement, and KB_COMMIT_SELECT, the one the engine runs): each must reproduce the oracle on every input."""
     if metafunc.definition.get_closest_marker("gpu") is not None and "commit_kernel" in metafunc.fixturenames:
-        metafunc.parametrize("commit_kernel", ["batch", "run", "select"], indirect=True)
+        metafunc.parametrize("commit_kernel", ["run", "select"], indirect=True)
 
 
 @pytest.fixture(autouse=True)
@@ -73,7 +73,7 @@ def _skip_key(item):
     if mod not in _ENVELOPE_MODULES:
         return None
     cs = getattr(item, "callspec", None)
-    ident = "-".join(p for p in (cs.id.split("-") if cs is not None else []) if p not in ("batch", "run", "select"))   # the commit-kernel axis skips alike
+    ident = "-".join(p for p in (cs.id.split("-") if cs is not None else []) if p not in ("run", "select"))   # the commit-kernel axis skips alike
     return f"{mod}::{fn.__name__}[{ident}]"
 
 

@@ -134,12 +134,12 @@ void gather_row(const KbDev &d, const KbRound &r, uint32_t i) {
 
 uint32_t mrow_task(const KbRound &r, uint32_t m) { return r.mrows ? r.mrows[m] : r.mrow_task0 + m; }
 
-// ---- the sequential commit of one window (kb_commit.hip / kb_commit_batch.hip: same decisions, different statistics words) ----
+// ---- the sequential commit of one window (kb_commit.hip / kb_commit_sel.hip: same decisions) ----
 void remember_commit_nodes(const std::vector<uint32_t> &nodes);
 unsigned long long g_selected_rows = 0;   // rows committed by the run selection (KB_EMU_RUN_SELECT)
 unsigned long long g_select_runs = 0;     // ... the runs they came in
 unsigned long long g_select_lanes = 0, g_select_steps = 0;   // ... the node sequences walked for them, and the evaluations those walks cost
-void emu_commit(const KbDev &d, const KbRound &r, bool batch_kernel) {
+void emu_commit(const KbDev &d, const KbRound &r) {
   if (r.n_rows == 0) return;
   u64 *o64 = out64(r);
   if (r.chain_expect != 0u && *r.chain != r.chain_expect) {   // chained to a round that stopped early: skip
@@ -381,8 +381,7 @@ void emu_commit(const KbDev &d, const KbRound &r, bool batch_kernel) {
   for (uint32_t w = 13; w < KB_OUT_HDR; w++) o64[w] = 0;
   const uint32_t nd = (uint32_t)dirty_nodes.size();
   r.result[0] = n_done; r.result[1] = reason; r.result[2] = nd;
-  if (batch_kernel) { r.result[3] = 0; r.result[4] = 0; r.result[5] = (n_done + 15u) / 16u; r.result[6] = dirty_won; r.result[7] = 0; }
-  else              { r.result[3] = dirty_won; r.result[4] = n_done; r.result[5] = 0; r.result[6] = 0; r.result[7] = 0; }
+  r.result[3] = dirty_won; r.result[4] = n_done; r.result[5] = 0; r.result[6] = 0; r.result[7] = 0;
   if (r.chain) *r.chain = reason == KB_REASON_DONE ? r.chain_tag : 0u;
   remember_commit_nodes(dirty_nodes);   // what an overlapped matrix launch may have seen half-changed (kb_launch_matrix poisons it)
   o64[KB_OUT_STAMP0 + 2] = t_start;
@@ -416,10 +415,6 @@ size_t kb_commit_smem_bytes(uint32_t n_rows, uint32_t n_shapes, uint32_t NP, int
   off += (size_t)n_rows * 16 + (size_t)n_rows * 8 + 48 + 256 * 4 + 64 * 4 + 64 * 4 + (size_t)n_shapes * 4 + (size_t)n_shapes * 4;
   off += (size_t)n_shapes * ((size_t)n_rows + 1) * 4 + (size_t)(NP / 32) * 4 + 10500 /* the selection kernel's block */ + lds_penalty();
   return (off + 15) & ~(size_t)15;
-}
-size_t kb_commit_batch_smem_bytes(uint32_t cap, uint32_t NP, int R) {
-  const size_t cap2 = (size_t)cap + 32;
-  return cap2 * (13 * 8 + 8 + 8 + 12) + (size_t)cap * 28 + (size_t)(NP / 32) * 4 + (size_t)32 * (R > 2 ? R - 2 : 0) * 8 + 256 + 4096 + (size_t)cap * 4 + lds_penalty();
 }
 
 // ---- launch wrappers (kb_device.h) ----
@@ -660,10 +655,9 @@ void kb_launch_scatter_nodes(const KbDev &d, const unsigned long long *rec, uint
   });
 }
 
-void kb_launch_commit(const KbDev &d, const KbRound &r, void *stream) { kbemu_enqueue((hipStream_t)stream, [d, r]() { emu_commit(d, r, false); }); }
-void kb_launch_commit_batch(const KbDev &d, const KbRound &r, void *stream) { kbemu_enqueue((hipStream_t)stream, [d, r]() { emu_commit(d, r, true); }); }
+void kb_launch_commit(const KbDev &d, const KbRound &r, void *stream) { kbemu_enqueue((hipStream_t)stream, [d, r]() { emu_commit(d, r); }); }
 // the selection kernel (k_commit_run<true>): the run kernel's contract and statistics words
-void kb_launch_commit_sel(const KbDev &d, const KbRound &r, void *stream) { kbemu_enqueue((hipStream_t)stream, [d, r]() { emu_commit(d, r, false); }); }
+void kb_launch_commit_sel(const KbDev &d, const KbRound &r, void *stream) { kbemu_enqueue((hipStream_t)stream, [d, r]() { emu_commit(d, r); }); }
 
 uint32_t kb_apply_deltas(const KbDev &d, const double *s_idle, const double *s_rel, const long long *s_nzc, const long long *s_nzm,
                          const int *s_podcnt, const double *delta, uint32_t *dev_counter, void *stream) {
@@ -740,9 +734,14 @@ extern "C" unsigned long long kbemu_select_lanes() { return __atomic_load_n(&g_s
 extern "C" unsigned long long kbemu_select_steps() { return __atomic_load_n(&g_select_steps, __ATOMIC_RELAXED); }
 static unsigned long long g_waterfill_launches = 0;
 extern "C" unsigned long long kbemu_waterfill_launches() { return __atomic_load_n(&g_waterfill_launches, __ATOMIC_RELAXED); }
-void kb_launch_waterfill(kb::WfQueue *qs, uint32_t Q, kb::WfState *st, int R, void *stream) {
-  kbemu_enqueue((hipStream_t)stream, [qs, Q, st, R]() {
+void kb_launch_waterfill(kb::WfQueue *qs, uint32_t Q, kb::WfState *st, int R, double *des, uint32_t *desmask, void *stream) {
+  kbemu_enqueue((hipStream_t)stream, [qs, Q, st, R, des, desmask]() {
     __atomic_fetch_add(&g_waterfill_launches, 1ull, __ATOMIC_RELAXED);
     kb::wf_run_sequential(qs, Q, *st, R);
+    if (des)
+      for (uint32_t q = 0; q < Q; q++) {
+        desmask[q] = qs[q].deserved.mask;
+        for (int d = 0; d < R; d++) des[(size_t)d * Q + q] = qs[q].deserved.get(d);
+      }
   });
 }

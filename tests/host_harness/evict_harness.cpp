@@ -124,8 +124,6 @@ int eh_run(EH *h, int reclaim) {
   return guarded(h, [&]() {
     HostSession &hs = h->hs;
     if (hs.has_interpod) throw EngineError(KB_E_UNSUPPORTED, "preempt / reclaim in a session with inter-pod (anti)affinity terms is not modelled");
-    if (!reclaim && hs.has_affinity && h->pol.nodeorder_enabled && !preempt_node_affinity_enabled())
-      throw EngineError(KB_E_UNSUPPORTED, "preempt with preferred node-affinity terms (NormalizeReduce over the feasible set) is not modelled");
     const uint32_t N = hs.N, T = hs.T, J = hs.J, Q = hs.Q;
     PreemptMachine pm;
     pm.counted = h->counted;

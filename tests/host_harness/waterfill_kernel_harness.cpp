@@ -43,7 +43,7 @@ void kbwf_run_kernel(kb::WfQueue *qs, uint32_t Q, kb::WfState *st, int R) {
   for (uint32_t t = 0; t < KB_WF_THREADS; t++)
     th.emplace_back([=]() {
       threadIdx.x = t;
-      k_waterfill(qs, Q, st, R);
+      k_waterfill(qs, Q, st, R, nullptr, nullptr);
     });
   for (auto &x : th) x.join();
   pthread_barrier_destroy(&g_bar);

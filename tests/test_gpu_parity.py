@@ -385,6 +385,6 @@ def test_the_pinned_commit_kernel_is_the_one_that_runs(oracle_mod, commit_kernel
         assert st["rounds_select"] == st["rounds"] > 10
         by_selection = st["select_runs_clean"] + st["select_runs_general"]
         assert by_selection > 200 and st["select_runs_serial"] < 0.2 * by_selection, st
-    elif commit_kernel in ("batch", "run"):   # (unpinned — the emulated-device re-collection — the engine chooses per round)
+    elif commit_kernel == "run":   # (None: the emulated-device re-collection, which does not pin a kernel)
         assert st["rounds_select"] == 0 and st["select_runs_clean"] == 0 and st["select_runs_general"] == 0
     e.close(); o.close()

@@ -24,7 +24,7 @@ pytestmark = [pytest.mark.gpu]
 
 # ---- every launch-path variant of the host protocol gives the same cycle ------------------------------------------------------
 _VARIANTS = [{}, {"KB_CHAIN_ROUNDS": "0"}, {"KB_SYNC_ROUNDS": "1"}, {"KB_PROBE": "0"}, {"KB_DIRECT_WINDOW": "0"},
-             {"KB_COMMIT_KERNEL": "run"}, {"KB_COMMIT_KERNEL": "batch"}, {"KB_CHAIN_ROUNDS": "0", "KB_PROBE": "0", "KB_DIRECT_WINDOW": "0"},
+             {"KB_COMMIT_KERNEL": "run"}, {"KB_COMMIT_KERNEL": "select"}, {"KB_CHAIN_ROUNDS": "0", "KB_PROBE": "0", "KB_DIRECT_WINDOW": "0"},
              # round 3: chained rounds build their candidate lists on a second stream beside the predecessor's commit and repair them
              # (the default, variant 0); KB_OVERLAP=0 keeps every round on one stream
              {"KB_OVERLAP": "0"}, {"KB_OVERLAP": "0", "KB_COMMIT_KERNEL": "run"}]
@@ -92,20 +92,10 @@ def test_job_with_a_missing_queue_without_proportion(oracle_mod):
 @pytest.mark.parametrize("seed", range(60))
 def test_preempt_with_preferred_node_affinity(oracle_mod, seed, monkeypatch):
     """The engine side of tests/test_host_evict_cpu.py's test of the same name: run_evict_action's list path with the NodeAffinity
-    launch between matrix and arg-max, mixed action orders included.  KB_PREEMPT_NODE_AFFINITY=0 restores the refusal the path had
-    until its first device run (KB_E_UNSUPPORTED)."""
+    launch between matrix and arg-max, mixed action orders included."""
     import test_gpu_preempt as gp
     import test_host_evict_cpu as hev
     cfg, snap, order = hev.affinity_evict_case(seed)
-    if "preempt" in order and seed % 6 == 0:
-        monkeypatch.setenv("KB_PREEMPT_NODE_AFFINITY", "0")
-        e = engine.Engine(cfg)
-        e.load(snap)
-        with pytest.raises(engine.EngineError) as err:
-            e.run(order)
-        assert err.value.code == abi.KB_E_UNSUPPORTED
-        e.close()
-        monkeypatch.delenv("KB_PREEMPT_NODE_AFFINITY")
     gp._run_both(oracle_mod, cfg, snap, order, ("affinity", seed))
 
 

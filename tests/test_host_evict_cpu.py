@@ -461,15 +461,9 @@ def copy_snapshot(snap):
 @pytest.mark.parametrize("seed", range(60))
 def test_preempt_with_preferred_node_affinity(harness, oracle_mod, seed, monkeypatch):
     """Preemptors whose class has preferred node-affinity terms get lists with the normalised score, rebuilt (not repaired) after every
-    Pipeline; KB_PREEMPT_NODE_AFFINITY=0 restores the refusal (KB_E_UNSUPPORTED) the path had until its first device run."""
+    Pipeline."""
     cfg, snap, order = affinity_evict_case(seed)
     evict_only = [a for a in order if a in ("preempt", "reclaim")]
     if evict_only != order:
         pytest.skip("the harness runs evict actions only (the emulated engine runs the mixed orders)")
-    monkeypatch.setenv("KB_PREEMPT_NODE_AFFINITY", "0")
-    with pytest.raises(HarnessError) as err:
-        e = HostEngine(harness, cfg, snap)
-        e.run(order)
-    assert err.value.code == abi.KB_E_UNSUPPORTED
-    monkeypatch.delenv("KB_PREEMPT_NODE_AFFINITY")
     _run_both(harness, oracle_mod, cfg, snap, order, ("affinity", seed))
