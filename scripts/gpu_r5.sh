@@ -1,0 +1,102 @@
+#!/usr/bin/env bash
+# Round 5's GPU calls, one parameterised script:   gpurun -- 'bash scripts/gpu_r5.sh <step> [args]'   (writes gpurun_out/r5_<step>/*)
+#   first    the reload module (one engine, many sessions; soak), the whole -m gpu suite, the default bench, kb_session_load traces of configs 3, 4, 5
+#   ab       same-box A/B of engine builds: every kube-batch_amd/libkbengine_<tag>.so beside the default one (configs 3, survey, 4, 5), each
+#            verified; optionally the differential suites on one of them:   ab [tag-to-test]
+#   trace    the selection kernel's per-phase cycle trace (make EXTRA=-DKB_K9_TRACE OUT=../libkbengine_trace.so), configs 3 and 4
+#   profile  rocprofv3 of the default command: kernel stats, HBM bytes of the matrix launches, SQ counters of the commit kernel
+#            (scripts/summarize_profile.py r5_profile profiles/round5)
+#   suite    the whole -m gpu suite          bench   the default bench line and the single-configuration lines
+#   loads    kb_session_load: KB_LOAD_TRACE of configs 3, 4, 5 and the bench's load statistics
+#   scale    N in {1, 2} x {sessions, sharded} on whatever GPUs the box has (scripts/scale_curve.sh)
+set -uo pipefail
+cd "$(dirname "$0")/.."
+step="${1:-suite}"; shift || true
+out="gpurun_out/r5_${step}"
+mkdir -p "$out"
+python scripts/kernel_sources_sha.py > "$out/kernel_sources.sha256"
+ms() { python -c "import json,sys; d=json.loads(open('$1').read().strip().splitlines()[-1]); print(d.get('ms_per_step'), d.get('verified_bind_set_equals_oracle'), d.get('kernel_ms_per_step'), 'load', d.get('session_load_ms'), d.get('session_load_ms_max'))" 2>/dev/null; }
+bench_ab() {   # name, env assignments..., -- bench args
+  local name="$1"; shift
+  local envs=(); while [ "$1" != "--" ]; do envs+=("$1"); shift; done; shift
+  timeout 400 env "${envs[@]}" KB_K5_STATS=1 python bench.py --no-cpu-baseline "$@" > "$out/bench_${name}.json" 2> "$out/bench_${name}.err"
+  echo "bench $name rc=$? $(ms "$out/bench_${name}.json")" | tee -a "$out/summary.txt"
+  grep -h "kb select" "$out/bench_${name}.err" | tee -a "$out/summary.txt"
+}
+case "$step" in
+first)
+  timeout 900 python -m pytest tests/test_gpu_reload.py -q -m gpu -p no:cacheprovider -x -s > "$out/pytest_reload.txt" 2>&1; echo "reload module rc=$? $(tail -1 "$out/pytest_reload.txt")" | tee -a "$out/summary.txt"
+  grep -h "^soak" "$out/pytest_reload.txt" | tee -a "$out/summary.txt"
+  timeout 1200 python -m pytest tests -q -m gpu -p no:cacheprovider --deselect tests/test_gpu_reload.py > "$out/pytest_gpu.txt" 2>&1; echo "gpu suite (without the reload module) rc=$? $(tail -1 "$out/pytest_gpu.txt")" | tee -a "$out/summary.txt"
+  timeout 600 python bench.py > "$out/bench_default.json" 2> "$out/bench_default.err"; echo "bench rc=$? $(ms "$out/bench_default.json")" | tee -a "$out/summary.txt"
+  python -c "import json; d=json.loads(open('$out/bench_default.json').read().strip().splitlines()[-1]); print(json.dumps(d.get('variants'), indent=1)); print('loads', d.get('session_load_ms_samples'))" | tee -a "$out/summary.txt"
+  for cfg in 3 4 5; do
+    KB_LOAD_TRACE=1 timeout 300 python bench.py --config $cfg --steps 1 --warmup 0 --no-cpu-baseline > "$out/load_c${cfg}.json" 2> "$out/session_load_trace_config${cfg}.txt"
+    echo "config $cfg load: $(ms "$out/load_c${cfg}.json")" | tee -a "$out/summary.txt"
+  done
+  ;;
+loads)
+  for cfg in 3 4 5; do
+    KB_LOAD_TRACE=1 timeout 300 python bench.py --config $cfg --steps 1 --warmup 0 --no-cpu-baseline > "$out/load_c${cfg}.json" 2> "$out/session_load_trace_config${cfg}.txt"
+    echo "config $cfg load: $(ms "$out/load_c${cfg}.json")" | tee -a "$out/summary.txt"
+  done
+  ;;
+ab)   # every libkbengine_<tag>.so in the package directory beside the default build, same box, same process order
+  test_tag="${1:-}"
+  libs=("default"); for f in kube-batch_amd/libkbengine_*.so; do [ -f "$f" ] && libs+=("$(basename "$f" .so | sed 's/libkbengine_//')"); done
+  for rep in 1 2; do
+    for tag in "${libs[@]}"; do
+      lib="$PWD/kube-batch_amd/libkbengine.so"; [ "$tag" != default ] && lib="$PWD/kube-batch_amd/libkbengine_${tag}.so"
+      bench_ab "c3_${tag}_r${rep}" KB_ENGINE_LIB=$lib -- --config 3 --steps 5 --warmup 2 --verify
+    done
+  done
+  for tag in "${libs[@]}"; do
+    lib="$PWD/kube-batch_amd/libkbengine.so"; [ "$tag" != default ] && lib="$PWD/kube-batch_amd/libkbengine_${tag}.so"
+    bench_ab "survey_${tag}" KB_ENGINE_LIB=$lib -- --config 3 --survey-nodes --steps 5 --warmup 2 --verify
+    bench_ab "c4_${tag}" KB_ENGINE_LIB=$lib -- --config 4 --steps 5 --warmup 2 --verify
+    bench_ab "c5_${tag}" KB_ENGINE_LIB=$lib -- --config 5 --steps 2 --warmup 1 --verify
+  done
+  if [ -n "$test_tag" ]; then
+    KB_ENGINE_LIB=$PWD/kube-batch_amd/libkbengine_${test_tag}.so timeout 900 python -m pytest tests -q -m gpu -p no:cacheprovider -k "select or reload" --maxfail=10 > "$out/pytest_${test_tag}.txt" 2>&1
+    echo "differential suites on libkbengine_${test_tag}.so (selection kernel) rc=$? $(tail -1 "$out/pytest_${test_tag}.txt")" | tee -a "$out/summary.txt"
+  fi
+  ;;
+trace)
+  for cfg in "3" "4"; do
+    KB_ENGINE_LIB=$PWD/kube-batch_amd/libkbengine_trace.so KB_K5_STATS=1 python bench.py --no-cpu-baseline --config ${cfg} --steps 2 --warmup 1 \
+      > "$out/trace_c${cfg}.json" 2> "$out/trace_c${cfg}.err"
+    echo "== trace c${cfg} $(ms "$out/trace_c${cfg}.json")" | tee -a "$out/summary.txt"; grep -h "kb K5 trace\|kb K5\] rounds [0-9]\|kb select" "$out/trace_c${cfg}.err" | tee -a "$out/summary.txt"
+  done
+  ;;
+profile)   # rocprofv3 evidence of the default bench command: kernel stats, HBM bytes of the matrix launches, SQ counters of the commit kernel
+  export TMPDIR=/tmp
+  CMD="python $PWD/bench.py --steps 2 --warmup 1 --no-cpu-baseline"
+  P="$PWD/$out"
+  ( cd /tmp
+    rocprofv3 --kernel-trace --stats -f csv -d "$P/trace" -o bench -- $CMD > "$P/bench_trace.log" 2>&1
+    rocprofv3 --pmc FETCH_SIZE -f csv --kernel-include-regex "k_matrix|k_expand" -d "$P/pmc_fetch" -o bench -- $CMD > "$P/bench_pmc_fetch.log" 2>&1
+    rocprofv3 --pmc WRITE_SIZE -f csv --kernel-include-regex "k_matrix|k_expand" -d "$P/pmc_write" -o bench -- $CMD > "$P/bench_pmc_write.log" 2>&1
+    rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE -f csv --kernel-include-regex "k_commit" \
+      -d "$P/pmc_commit_a" -o bench -- $CMD > "$P/bench_pmc_commit_a.log" 2>&1
+    rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR -f csv --kernel-include-regex "k_commit" \
+      -d "$P/pmc_commit_b" -o bench -- $CMD > "$P/bench_pmc_commit_b.log" 2>&1
+  )
+  find "$out" -name "*.csv" | head -20 | tee -a "$out/summary.txt"
+  ;;
+suite)
+  timeout 1500 python -m pytest tests -q -m gpu -p no:cacheprovider "$@" > "$out/pytest_gpu.txt" 2>&1; echo "gpu suite rc=$? $(tail -1 "$out/pytest_gpu.txt")" | tee -a "$out/summary.txt"
+  ;;
+bench)
+  timeout 600 python bench.py > "$out/bench_default.json" 2> "$out/bench_default.err"; echo "bench rc=$? $(ms "$out/bench_default.json")" | tee -a "$out/summary.txt"
+  bench_ab survey_nodes -- --config 3 --survey-nodes --steps 5 --warmup 2 --verify
+  bench_ab config4 -- --config 4 --steps 5 --warmup 2 --verify
+  bench_ab config2 -- --config 2 --steps 10 --warmup 3 --verify
+  bench_ab config5 -- --config 5 --steps 3 --warmup 1 --verify
+  bench_ab config5_preempt -- --config 5 --preempt --steps 2 --warmup 1 --verify
+  ;;
+scale)
+  bash scripts/scale_curve.sh "$out" 2>&1 | tee -a "$out/summary.txt"
+  ;;
+*) echo "unknown step $step"; exit 2 ;;
+esac
+cat "$out/summary.txt"

@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""gpurun_out/prof_<tag>/ (written by `scripts/gpu_r4.sh profile` on the GPU box) -> the summaries committed under profiles/.
+"""gpurun_out/prof_<tag>/ (written by `scripts/gpu_r5.sh profile` on the GPU box) -> the summaries committed under profiles/.
 
   rocprofv3_kernel_stats.csv   the --kernel-trace --stats table as rocprofv3 wrote it
   rocprofv3_pmc_k_matrix.csv   per kernel: dispatches, mean / max KB per dispatch of FETCH_SIZE and WRITE_SIZE (separate passes)
@@ -14,7 +14,7 @@ tag = sys.argv[1] if len(sys.argv) > 1 else "r1"
 dst = Path(sys.argv[2] if len(sys.argv) > 2 else "profiles/round1")
 src = Path("gpurun_out") / f"prof_{tag}"
 if not src.exists():
-    src = Path("gpurun_out") / tag            # scripts/gpu_r4.sh profile writes gpurun_out/r4_profile
+    src = Path("gpurun_out") / tag            # scripts/gpu_r5.sh profile writes gpurun_out/r5_profile
 dst.mkdir(parents=True, exist_ok=True)
 shutil.copy(src / "trace" / "bench_kernel_stats.csv", dst / "rocprofv3_kernel_stats.csv")
 rows = []
@@ -31,7 +31,7 @@ with open(dst / "rocprofv3_pmc_k_matrix.csv", "w", newline="") as f:
     w.writerow(["counter", "kernel", "dispatches", "mean_KB_per_dispatch", "max_KB_per_dispatch"])
     for r in rows:
         w.writerow([r[0], r[1], r[2], f"{r[3]:.3f}", f"{r[4]:.3f}"])
-# the commit kernels' SQ / GRBM counters (scripts/gpu_r4.sh profile: two passes), per kernel: dispatches and the mean per dispatch
+# the commit kernels' SQ / GRBM counters (scripts/gpu_r5.sh profile: two passes), per kernel: dispatches and the mean per dispatch
 crow = []
 for sub in ("pmc_commit_a", "pmc_commit_b"):
     fn = src / sub / "bench_counter_collection.csv"
@@ -49,6 +49,9 @@ if crow:
         w.writerow(["kernel", "counter", "dispatches", "mean_per_dispatch", "max_per_dispatch"])
         for r in crow:
             w.writerow([r[0], r[1], r[2], f"{r[3]:.1f}", f"{r[4]:.1f}"])
+# the device sources the numbers were measured on (written on the GPU box by scripts/gpu_r5.sh): bench.py quotes the CSVs only for these
+if (src / "kernel_sources.sha256").exists():
+    shutil.copy(src / "kernel_sources.sha256", dst / "kernel_sources.sha256")
 # the bench line printed under the kernel trace
 log = src / "bench_trace.log"
 for line in log.read_text().splitlines():

@@ -1,6 +1,6 @@
 #!/usr/bin/env python
-"""What sits between two commit kernels: from a rocprofv3 --kernel-trace CSV (gpurun_out/r4_profile/trace/bench_kernel_trace.csv, written by
-`scripts/gpu_r4.sh profile` / `evict`), the commit kernels' busy time, the gaps between consecutive ones and which kernels ran inside them.
+"""What sits between two commit kernels: from a rocprofv3 --kernel-trace CSV (gpurun_out/r5_profile/trace/bench_kernel_trace.csv, written by
+`scripts/gpu_r5.sh profile` / `evict`), the commit kernels' busy time, the gaps between consecutive ones and which kernels ran inside them.
 python scripts/trace_gaps.py <bench_kernel_trace.csv> [sessions]      (sessions: bench steps + warm-up in the traced command, to print per-session figures)"""
 import collections
 import csv
