@@ -59,6 +59,7 @@ __global__ void __launch_bounds__(K9_THREADS) k_commit_select(const K9KernArgs k
     a.dev = (const KbDev *)(kp + offsetof(K9KernArgs, dev));
     a.round = (const KbRound *)(kp + offsetof(K9KernArgs, round));
   }
+  //@@ top
   if (k9_preamble(a)) return;
   extern __shared__ __align__(16) unsigned char k9_smem[];
   const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -104,6 +105,15 @@ __global__ void __launch_bounds__(K9_THREADS) k_commit_select(const K9KernArgs k
   __syncthreads();
   uint32_t K = 0;
   for (uint32_t w = 0; w < 8; w++) K += (uint32_t)__popc(X.stm[w]);
+  {   // rinfo, compacted in place: entry k = run k's header {first row | rows << 16, shape, flags, Resreq key mask} — one load per run instead
+      // of runs[k] -> rinfo[row] (k <= its first row, every read is done before the first write)
+    uint4 rr = make_uint4(0u, 0u, 0u, 0u);
+    uint32_t i0c = 0u;
+    if (tid < K) { i0c = X.runs[tid]; rr = rinfo[i0c]; }
+    __syncthreads();
+    if (tid < K) rinfo[tid] = make_uint4(i0c | (rr.x << 16), rr.y, rr.z, rr.w);
+    __syncthreads();
+  }
 
 #ifdef KB_K9_TRACE
   // make EXTRA=-DKB_K9_TRACE: wave 0's cycles — 0: waiting for a run's candidates and dirty keys, 3: rows (serial loop, tail, publish), 5: entries + first
@@ -123,100 +133,131 @@ __global__ void __launch_bounds__(K9_THREADS) k_commit_select(const K9KernArgs k
   const unsigned long long lt = (1ull << lane) - 1ull;
   gptrd gi, gr;
   { const KbDev &d = *a.dev; gi = (gptrd)d.idle; gr = (gptrd)d.rel; }
-  // a run's header, from the tables the prologue built (nothing in them changes inside the loop)
-#define K9S_RUN_HEADER(kk)                                                                                             \
-  const uint32_t i0 = X.runs[(kk)];                                                                                    \
-  const uint4 ri_ = rinfo[i0];                                                                                         \
-  const uint32_t r = (uint32_t)__builtin_amdgcn_readfirstlane((int)ri_.x), s = (uint32_t)__builtin_amdgcn_readfirstlane((int)ri_.y); \
-  const uint32_t fl0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)ri_.z), km0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)ri_.w); \
+  // a run's header, from the tables built above (nothing in them changes inside the loop)
+#define K9S_RUN_HEADER_OF(ri_)                                                                                         \
+  const uint32_t hx_ = (uint32_t)__builtin_amdgcn_readfirstlane((int)(ri_).x);                                          \
+  const uint32_t i0 = hx_ & 0xFFFFu, r = hx_ >> 16, s = (uint32_t)__builtin_amdgcn_readfirstlane((int)(ri_).y);          \
+  const uint32_t fl0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(ri_).z), km0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(ri_).w); \
   const bool plain0 = (fl0 & 1u) && (km0 == 0u || (fl0 & 4u));                                                         \
+  const bool sel_run = !a.backfill && plain0 && r >= 2u;              /* the run goes through the selection */          \
+  (void)sel_run; (void)i0;
+#define K9S_RUN_SHAPE(kk)                                                                                              \
   const K9Shape sh = shapes[s];                                                                                        \
   const double *si = sinit + (size_t)s * RS;                                                                           \
   const double *rres = rowres + ((kk) % K9S_PREPS) * (uint32_t)a.R;   /* the row's own Resreq (rows that are not plain) */ \
   const double *rqv = plain0 ? si : rres + 2;                         /* the rows' scalar Resreq */                    \
-  const bool sel_run = !a.backfill && plain0 && r >= 2u;              /* the run goes through the selection */          \
-  (void)rqv; (void)sel_run; (void)rres; (void)i0;
+  (void)rqv; (void)rres;
+#define K9S_RUN_HEADER(kk)                                                                                             \
+  const uint4 ri_ = rinfo[(kk)];                                                                                       \
+  K9S_RUN_HEADER_OF(ri_)                                                                                               \
+  K9S_RUN_SHAPE(kk)
 
+  //@@ w0_setup
   if (wave == 0) {
     // =================================================== wave 0: the selection ===================================================
     uint32_t nd = 0, n_dirty_rows = 0, n_runs = 0, n_slow = 0, i_end = 0, reason_end = KB_REASON_DONE;
     uint32_t prev_nd0 = 0, prev_pc = 0;   // the run in front: dirty slots when it started, clean candidates it consumed
     bool prev_chg = true;                 // ... whether it changed slots in any other way (then the early dirty keys of this run are not final)
     bool prev_all = false;                // ... and whether it took every candidate of its own (then this run's candidates, settled ahead on that assumption, stand)
+  //@@ w0_header_wait
+    uint4 hd_next = rinfo[0];   // (K >= 1: a launch has rows)
     for (uint32_t k = 0; k < K; k++) {
-      K9S_RUN_HEADER(k)
+      uint32_t lane_i = tid;   // wave 0: tid == lane.  Opaque per iteration: otherwise every `lane < c` of the loop is hoisted in front of it as an
+      asm volatile("" : "+v"(lane_i));   // SGPR-pair mask, the pairs are spilled to VGPR lanes and read back here — dearer than the compare
+      const uint4 hd = hd_next;
+      if (k + 1u < K) hd_next = rinfo[k + 1u];   // the next run's header: in flight behind this run's work
+      K9S_RUN_HEADER_OF(hd)
       K9_STAMP(3);
       {   // the run's candidates (seq_cand) and its dirty keys (seq_dk[0..3]): five neighbouring words, one load per poll
         uint32_t spins = 0;
         bool ok = true;
         for (;;) {
-          // lane 0: the candidates — settled ahead (seq_spec) when the run in front took all of its own, else settled behind it (seq_cand);
+          // lane_i 0: the candidates — settled ahead (seq_spec) when the run in front took all of its own, else settled behind it (seq_cand);
           // lanes 1..4: the dirty keys — the early ones (seq_early) when the run in front changed nothing else, else the final ones (seq_dk)
-          const uint32_t *wp = (lane == 0u) ? (prev_all ? &Y.seq_spec : &Y.seq_cand) : (prev_chg ? &Y.seq_dk[(lane - 1u) & 3u] : &Y.seq_early[(lane - 1u) & 3u]);
-          const uint32_t v = (lane < 5u) ? k9s_ld(wp) : 0xFFFFFFFFu;
+          const uint32_t *wp = (lane_i == 0u) ? (prev_all ? &Y.seq_spec : &Y.seq_cand) : (prev_chg ? &Y.seq_dk[(lane_i - 1u) & 3u] : &Y.seq_early[(lane_i - 1u) & 3u]);
+          const uint32_t v = (lane_i < 5u) ? k9s_ld(wp) : 0xFFFFFFFFu;
           if (__ballot(v < k + 1u) == 0ull) break;
           if ((++spins & 31u) == 0u && (k9s_ld(&Y.err) || spins > K9S_SPIN_LIMIT)) { k9s_st(&Y.err, 1u); ok = false; break; }
           __builtin_amdgcn_s_sleep(1);
         }
         if (!ok) { reason_end = KB_REASON_INTERNAL; i_end = i0; break; }
       }
-      if (prev_all && lane == 0) k9s_st(&Y.seq_cand, k + 1u);   // the candidates settled ahead are the candidates: the evaluating waves may build on them
+  //@@ w0_loads
+      if (prev_all && lane_i == 0) k9s_st(&Y.seq_cand, k + 1u);   // the candidates settled ahead are the candidates: the evaluating waves may build on them
+      // ONE batch of LDS reads behind the wait: the number of candidates, their fields (a lane_i beyond the last candidate reads a stale word and
+      // zeroes it below), the evaluating waves' maxima
       const uint32_t ncand = Y.ncand_at[k & 3u];
       const K9Sel::Cand &CD = X.cand[k & 1u];
       const uint32_t *dk = X.dkb[k & 1u];
       uint32_t *chg = Y.chg[k & 1u];
-      if (lane < 10u) chg[lane] = 0u;
-      K9_STAMP(0);
-      uint32_t ck = 0, k1 = 0, ckind = 0, ckind1 = 0;
-      uint32_t rnm = 0;
-      if (lane < ncand) { ck = CD.ckey[lane]; k1 = CD.ck1[lane]; ckind = CD.ckind[lane]; ckind1 = CD.ckind1[lane]; rnm = CD.crnm[lane]; }
+      uint32_t ck = CD.ckey[lane_i], k1 = CD.ck1[lane_i], ckind = CD.ckind[lane_i];
+      const uint32_t cpos = CD.cpos[lane_i];
       // best dirty key: the evaluating waves' maxima (clean winners update it in O(1)).  From the early evaluation: the maxima over the slots
       // that were dirty before the run in front, and the keys of the candidates it consumed
-      uint32_t m = (lane < 4u) ? (prev_chg ? Y.mdk[k & 1u][lane] : Y.mdko[k & 1u][lane]) : 0u;
-      if (!prev_chg && lane >= 4u && lane - 4u < prev_pc) m = dk[prev_nd0 + lane - 4u];   // prev_pc <= K9_SEL_MAXRUN
+      uint32_t m = (lane_i < 4u) ? (prev_chg ? Y.mdk[k & 1u][lane_i] : Y.mdko[k & 1u][lane_i]) : 0u;
+      if (!prev_chg && lane_i >= 4u && lane_i - 4u < prev_pc) m = dk[prev_nd0 + lane_i - 4u];   // prev_pc <= K9_SEL_MAXRUN
+      if (lane_i < 10u) chg[lane_i] = 0u;
+      K9_STAMP(0);
+      if (lane_i >= ncand) { ck = 0u; k1 = 0u; ckind = 0u; }
       m = wave_max_u32(m);
-      double res0 = sh.init0, res1 = sh.init1;
-      if (!plain0) { res0 = rres[0]; res1 = rres[1]; }
-      // cmin: the r-th best clean candidate's key — r entries are at or above it, so no entry below it is among the picks (0: the list
-      // holds fewer than r clean nodes)
-      const uint32_t cmin = (sel_run && ncand == r) ? CD.ckey[r - 1u] : 0u;
-      // dirty keys of the shape: old slot t in lane t & 63, register t >> 6 — fetched only where a dirty slot can be picked
-      uint32_t d0 = 0u, d1 = 0u, d2 = 0u, d3 = 0u;
-      bool have_d = false;
-#define K9S_LOAD_D() do { if (!have_d) { d0 = (lane < nd) ? dk[lane] : 0u; d1 = (lane + 64 < nd) ? dk[lane + 64] : 0u; d2 = (lane + 128 < nd) ? dk[lane + 128] : 0u; \
-                                        d3 = (lane + 192 < nd) ? dk[lane + 192] : 0u; have_d = true; } } while (0)
       uint32_t pc = 0, j = 0, reason = KB_REASON_DONE, n_dirty = 0, sc_dirty = 0;
-      bool sel_done = false;
-      if (sel_run) {
-        // ---- every pick a clean candidate's first placement?  No dirty key above the r-th clean candidate, no clean candidate whose key
-        //      after its placement is: row j takes candidate j (a Pipeline among them ends the round behind its row)
-        const unsigned long long deeper = __ballot(lane + 1u < r && lane < ncand && ckind == 0u && k1 > cmin);
+      bool chg_any = false;   // this run changed slots other than by consuming a clean candidate once (chg carries which; the next run's early keys are then not final)
+      bool run_done = false;
+  //@@ w0_clean
+      if (!a.backfill && plain0) {
+        // ---- every pick a clean candidate's first placement?  r candidates, no dirty key above the r-th of them, no candidate whose key
+        //      after its placement is: row j takes candidate j (a Pipeline among them ends the round behind its row).  Single rows too:
+        //      the serial loop below would do exactly this for a row whose best clean candidate beats every dirty key.
+        // cmin: the r-th best clean candidate's key — r entries are at or above it, so no entry below it is among the picks (0: the list
+        // holds fewer than r clean nodes)
+        const uint32_t cmin = (ncand == r) ? rl32(ck, r - 1u) : 0u;
+        const unsigned long long deeper = __ballot(lane_i + 1u < r && ckind == 0u && k1 > cmin);   // (lanes beyond the candidates hold zeros)
         if (ncand == r && m < cmin && !deeper) {
-          const unsigned long long pipes = __ballot(lane < r && ckind != 0u);
+          const unsigned long long pipes = __ballot(lane_i < r && ckind != 0u);
           const uint32_t n_take = pipes ? (uint32_t)__ffsll((unsigned long long)pipes) : r;
           if (pipes) reason = KB_REASON_PIPELINED;
-          if (lane < n_take) {
+          if (lane_i < n_take) {
             const uint32_t n = nmaskbits - (ck & nmaskbits);
-            ldec[i0 + lane] = (unsigned long long)n | ((unsigned long long)ckind << 32);
+            ldec[i0 + lane_i] = (unsigned long long)n | ((unsigned long long)ckind << 32);
             atomicOr(&bitmap[n >> 5], 1u << (n & 31));
             if (km0) {   // the scalar dimensions Resreq names: Idle / Releasing in HBM
-              atomicOr(&chg[(nd + lane) >> 5], 1u << ((nd + lane) & 31));   // an early evaluation for the next run read them before this Sub
+              const double *rqv = sinit + (size_t)s * RS;   // (plain rows: the shape's own request)
+              const uint32_t rnm = CD.crnm[lane_i];
+              atomicOr(&chg[(nd + lane_i) >> 5], 1u << ((nd + lane_i) & 31));   // an early evaluation for the next run read them before this Sub
               const bool has_map = ckind ? (rnm >> 31) : (rnm & 0x7FFFFFFFu);
               if (has_map)
                 for (uint32_t mm = km0, dd = 0; mm; mm >>= 1, dd++)
                   if (mm & 1u) k9_sc_sub(ckind ? gr : gi, a.NP, dd, n, rqv[dd]);
             }
           }
-          if (km0) sc_dirty = 1;
+          if (km0) { sc_dirty = 1; chg_any = true; }
           pc = n_take; j = n_take;
-          sel_done = true;
-          if (lane == 0) X.stat[0]++;
+          run_done = true;
+          if (lane_i == 0 && r >= 2u) atomicAdd(&X.stat[0], 1u);
           K9_STAMP(8);
-        } else {
-          // ---- the general case.  Contenders: the clean candidates (lane = candidate) and the dirty slots whose key is above the floor;
+        }
+      }
+  //@@ w0_slow_general
+      if (!run_done) {
+      // ================= everything else: the general selection, the serial loop (they need the shape and the candidates' other fields)
+      K9S_RUN_SHAPE(k)
+      uint32_t ckind1 = 0, rnm = 0;
+      if (lane_i < ncand) { ckind1 = CD.ckind1[lane_i]; rnm = CD.crnm[lane_i]; }
+      double res0 = sh.init0, res1 = sh.init1;
+      if (!plain0) { res0 = rres[0]; res1 = rres[1]; }
+      const uint32_t cmin = (sel_run && ncand == r) ? rl32(ck, r - 1u) : 0u;
+      // dirty keys of the shape: old slot t in lane_i t & 63, register t >> 6 — fetched only where a dirty slot can be picked
+      uint32_t d0 = 0u, d1 = 0u, d2 = 0u, d3 = 0u;
+      bool have_d = false;
+#define K9S_LOAD_D() do { if (!have_d) { d0 = (lane_i < nd) ? dk[lane_i] : 0u; d1 = (lane_i + 64 < nd) ? dk[lane_i + 64] : 0u; d2 = (lane_i + 128 < nd) ? dk[lane_i + 128] : 0u; \
+                                        d3 = (lane_i + 192 < nd) ? dk[lane_i + 192] : 0u; have_d = true; } } while (0)
+      bool sel_done = false;
+      if (sel_run) {
+        {
+          // ---- the general case.  Contenders: the clean candidates (lane_i = candidate) and the dirty slots whose key is above the floor;
           //      entries: steps 0 and 1 of each, as far as they exist and are above the floor
           K9S_LOAD_D();
-          const bool a0v = lane < ncand;
+          const bool a0v = lane_i < ncand;
           const uint32_t ce1 = min(ck, k1);
           const bool a1v = a0v && ckind == 0u && k1 != 0u && ce1 > cmin;
           uint32_t dkk4[4], dd4[4] = {d0, d1, d2, d3};
@@ -225,7 +266,7 @@ __global__ void __launch_bounds__(K9_THREADS) k_commit_select(const K9KernArgs k
           uint32_t nD = 0;
 #pragma unroll
           for (int u = 0; u < 4; u++) {
-            const uint32_t t = lane + 64u * (uint32_t)u;
+            const uint32_t t = lane_i + 64u * (uint32_t)u;
             dkk4[u] = (t < nd) ? X.dkk[k & 1u][t] : 0u;
             b0v[u] = dd4[u] > cmin;
             bb0[u] = __ballot(b0v[u]);
@@ -238,17 +279,17 @@ __global__ void __launch_bounds__(K9_THREADS) k_commit_select(const K9KernArgs k
           bool bail = nC > 64u || n > 64u;
           if (!bail) {
             if (a0v) {
-              X.e_comp[lane] = ((unsigned long long)ck << 8) | 255ull;
-              X.e_info[lane] = lane | (ckind << 8);
-              X.c_slot[lane] = nd + lane; X.c_next[lane] = a1v ? 2u : 1u; X.c_eff[lane] = a1v ? ce1 : ck;
-              X.c_flag[lane] = 2u | ((!a1v || ckind1) ? 1u : 0u);   // ended: a Pipeline, no second placement, or one below the floor
-              X.c_take[lane] = 0u;
+              X.e_comp[lane_i] = ((unsigned long long)ck << 8) | 255ull;
+              X.e_info[lane_i] = lane_i | (ckind << 8);
+              X.c_slot[lane_i] = nd + lane_i; X.c_next[lane_i] = a1v ? 2u : 1u; X.c_eff[lane_i] = a1v ? ce1 : ck;
+              X.c_flag[lane_i] = 2u | ((!a1v || ckind1) ? 1u : 0u);   // ended: a Pipeline, no second placement, or one below the floor
+              X.c_take[lane_i] = 0u;
             }
             uint32_t base = ncand;
             if (a1v) {
               const uint32_t pos = base + (uint32_t)__popcll(ba1 & lt);
               X.e_comp[pos] = ((unsigned long long)ce1 << 8) | 254ull;
-              X.e_info[pos] = lane | (ckind1 << 8) | (1u << 16);
+              X.e_info[pos] = lane_i | (ckind1 << 8) | (1u << 16);
             }
             base += nA1;
 #pragma unroll
@@ -257,7 +298,7 @@ __global__ void __launch_bounds__(K9_THREADS) k_commit_select(const K9KernArgs k
                 const uint32_t pos = base + (uint32_t)__popcll(bb0[u] & lt), c = pos - nA1;
                 X.e_comp[pos] = ((unsigned long long)dd4[u] << 8) | 255ull;
                 X.e_info[pos] = c | ((dkk4[u] & 1u) << 8);
-                X.c_slot[c] = lane + 64u * (uint32_t)u; X.c_next[c] = 1u; X.c_eff[c] = dd4[u];
+                X.c_slot[c] = lane_i + 64u * (uint32_t)u; X.c_next[c] = 1u; X.c_eff[c] = dd4[u];
                 X.c_flag[c] = dkk4[u] & 1u;   // ended: its first placement is a Pipeline
                 X.c_take[c] = 0u;
               }
@@ -270,15 +311,15 @@ __global__ void __launch_bounds__(K9_THREADS) k_commit_select(const K9KernArgs k
           bool first = true;
           while (!bail) {
             // rank by count: entry e is picked as row #(entries in front of it)
-            comp = lane < n ? X.e_comp[lane] : 0ull;
-            info = lane < n ? X.e_info[lane] : 0u;
+            comp = lane_i < n ? X.e_comp[lane_i] : 0ull;
+            info = lane_i < n ? X.e_info[lane_i] : 0u;
             rank = 0u;
             for (uint32_t i = 0; i < n; i++) { const unsigned long long si_ = rl64(comp, i); rank += (si_ > comp) ? 1u : 0u; }
             if (first) { K9_STAMP(5); first = false; }
             
             // a contender whose last known step would be picked in front of the last row may be picked again: walk it on
             const uint32_t c = info & 0xFFu, ej = info >> 16;
-            const bool alive = lane < n && ej + 1u == X.c_next[c] && !(X.c_flag[c] & 1u) && rank + 1u < r;
+            const bool alive = lane_i < n && ej + 1u == X.c_next[c] && !(X.c_flag[c] & 1u) && rank + 1u < r;
             const unsigned long long ab = __ballot(alive);
             if (!ab) break;
             const uint32_t na = (uint32_t)__popcll(ab);
@@ -287,9 +328,9 @@ __global__ void __launch_bounds__(K9_THREADS) k_commit_select(const K9KernArgs k
             D = min(D, r - 1u);
             if (alive) X.al[(uint32_t)__popcll(ab & lt)] = c;
             K9_WAVE_FENCE();
-            // lane -> (contender ai, step u of this pass): the contender's state after that many more placements, one subtraction at a time
-            const bool act = lane < na * D;
-            const uint32_t ai = lane / D, u = lane - ai * D;
+            // lane_i -> (contender ai, step u of this pass): the contender's state after that many more placements, one subtraction at a time
+            const bool act = lane_i < na * D;
+            const uint32_t ai = lane_i / D, u = lane_i - ai * D;
             uint32_t cc = 0u, jj = 0u, kind = 0u, key = 0u, run = 0xFFFFFFFFu;
             bool inexact = false;
             if (act) {
@@ -333,7 +374,7 @@ __global__ void __launch_bounds__(K9_THREADS) k_commit_select(const K9KernArgs k
               X.e_comp[pos] = ((unsigned long long)run << 8) | (unsigned long long)(255u - jj);
               X.e_info[pos] = cc | (kind << 8) | (jj << 16);
             }
-            {   // the contender's record, by its first lane: g steps were found
+            {   // the contender's record, by its first lane_i: g steps were found
               const uint32_t g = act ? (uint32_t)__popcll((vb >> (g0 & 63u)) & ((1ull << D) - 1ull)) : 0u;   // D <= K9_SEL_MAXRUN - 1
               const uint32_t lastl = g0 + (g ? g - 1u : 0u);
               const uint32_t run_last = (uint32_t)__shfl((int)run, (int)lastl), kind_last = (uint32_t)__shfl((int)kind, (int)lastl);
@@ -344,13 +385,13 @@ __global__ void __launch_bounds__(K9_THREADS) k_commit_select(const K9KernArgs k
               }
             }
             n += (uint32_t)__popcll(vb);
-            if (lane == 0) X.stat[3]++;
+            if (lane_i == 0) atomicAdd(&X.stat[3], 1u);
             K9_WAVE_FENCE();
           }
           K9_STAMP(6);
           if (!bail) {
             // ---- the picks: rows in rank order; a Pipeline ends the round behind its row; fewer entries than rows: no feasible node is left
-            const bool have = lane < n;
+            const bool have = lane_i < n;
             const uint32_t ekind = (info >> 8) & 1u, ec = info & 0xFFu;
             const uint32_t cnt = min(n, r);
             const uint32_t pr = (have && rank < r && ekind) ? rank : 0xFFFFFFFFu;
@@ -365,14 +406,14 @@ __global__ void __launch_bounds__(K9_THREADS) k_commit_select(const K9KernArgs k
               if (ekind) atomicOr(&X.c_flag[ec], 4u);
             }
             K9_WAVE_FENCE();
-            // ---- NodeInfo.AddTask (api/node_info.go:172-212), once per placement, on every contender that was picked: lane = contender
-            const uint32_t T = (lane < nC) ? X.c_take[lane] : 0u;
+            // ---- NodeInfo.AddTask (api/node_info.go:172-212), once per placement, on every contender that was picked: lane_i = contender
+            const uint32_t T = (lane_i < nC) ? X.c_take[lane_i] : 0u;
             if (T) {
-              const uint32_t fl = X.c_flag[lane], b = (fl >> 1) & 1u, pipe_last = (fl >> 2) & 1u;
-              unsigned long long *st = slots + (size_t)X.c_slot[lane] * K9_NF;
+              const uint32_t fl = X.c_flag[lane_i], b = (fl >> 1) & 1u, pipe_last = (fl >> 2) & 1u;
+              unsigned long long *st = slots + (size_t)X.c_slot[lane_i] * K9_NF;
               const uint32_t node = (uint32_t)st[F_NODE_NMASK], nm = (uint32_t)(st[F_NODE_NMASK] >> 32);
               const uint32_t extra = T - b;   // a clean candidate's slot already holds its first placement
-              if (extra || km0) { const uint32_t x = X.c_slot[lane]; atomicOr(&chg[x >> 5], 1u << (x & 31)); }   // not what an early evaluation for the next run saw (its scalar dimensions: in HBM only now)
+              if (extra || km0) { const uint32_t x = X.c_slot[lane_i]; atomicOr(&chg[x >> 5], 1u << (x & 31)); }   // not what an early evaluation for the next run saw (its scalar dimensions: in HBM only now)
               if (extra) {
                 double idle0 = u2d(st[F_IDLE0]), idle1 = u2d(st[F_IDLE1]), rel0 = u2d(st[F_REL0]), rel1 = u2d(st[F_REL1]);
                 double zc = u2d(st[F_NZC]), zm = u2d(st[F_NZM]);
@@ -396,13 +437,14 @@ __global__ void __launch_bounds__(K9_THREADS) k_commit_select(const K9KernArgs k
               if (b) atomicOr(&bitmap[node >> 5], 1u << (node & 31));
             }
             if (km0) sc_dirty = 1;
-            pc = (uint32_t)__popcll(__ballot(lane < ncand && T != 0u));
+            if (__ballot(T != 0u && (T - ((X.c_flag[lane_i < nC ? lane_i : 0u] >> 1) & 1u) != 0u || km0 != 0u)) != 0ull) chg_any = true;   // some lane_i listed its slot in chg above
+            pc = (uint32_t)__popcll(__ballot(lane_i < ncand && T != 0u));
             n_dirty = n_take - pc;
             j = n_take;
             sel_done = true;
-            if (lane == 0) X.stat[1]++;
-          } else if (lane == 0) {
-            X.stat[2]++;
+            if (lane_i == 0) atomicAdd(&X.stat[1], 1u);
+          } else if (lane_i == 0) {
+            atomicAdd(&X.stat[2], 1u);
           }
           K9_STAMP(7);
         }
@@ -411,6 +453,7 @@ __global__ void __launch_bounds__(K9_THREADS) k_commit_select(const K9KernArgs k
       // placement of a plain BestEffort row — an empty request — changes what the predicates read of the node except its pod count (and its ports,
       // if the pod had any: then it conflicts with itself).  So the node that wins a row of such a run wins the following rows too until it is
       // full: they are committed at once.  (1M x 50k: 80 backfill rounds of 256 rows that all go for the same few nodes, ~20 ms row by row.)
+  //@@ w0_slow_serial
       const bool bf_bulk = a.backfill && plain0 && km0 == 0u && !(fl0 & 2u) && !a.score_enabled && sh.init0 == 0.0 && sh.init1 == 0.0 && (sh.active >> 2) == 0u &&
                            res0 == 0.0 && res1 == 0.0 && (sh.want & sh.conf) == 0ull;
       if (!sel_done)
@@ -418,7 +461,7 @@ __global__ void __launch_bounds__(K9_THREADS) k_commit_select(const K9KernArgs k
         const uint32_t c = (pc < ncand) ? rl32(ck, pc) : 0u;
         if (m == 0u && c == 0u) {
           if (a.backfill) {   // backfill.go:50-66: no node passes the predicates -> the task stays Pending
-            if (lane == 0) ldec[i0 + j] = (unsigned long long)KB_NONE_U32;
+            if (lane_i == 0) ldec[i0 + j] = (unsigned long long)KB_NONE_U32;
             continue;
           }
           reason = KB_REASON_NO_FEASIBLE;   // allocate.go:144-148: the job is abandoned; the host re-plans from here
@@ -429,34 +472,36 @@ __global__ void __launch_bounds__(K9_THREADS) k_commit_select(const K9KernArgs k
           const uint32_t n = nmaskbits - (c & nmaskbits);
           kind = rl32(ckind, pc);
           m = max(m, rl32(k1, pc));
-          if (lane == 0) {
+          if (lane_i == 0) {
             ldec[i0 + j] = (unsigned long long)n | ((unsigned long long)kind << 32);
             atomicOr(&bitmap[n >> 5], 1u << (n & 31));
           }
-          if (km0) {   // the scalar dimensions Resreq names: Idle / Releasing in HBM (lane 16 + d' takes dimension d' + 2)
-            if (lane == 0) atomicOr(&chg[(nd + pc) >> 5], 1u << ((nd + pc) & 31));   // an early evaluation for the next run read them before this Sub
+          if (km0) {   // the scalar dimensions Resreq names: Idle / Releasing in HBM (lane_i 16 + d' takes dimension d' + 2)
+            if (lane_i == 0) atomicOr(&chg[(nd + pc) >> 5], 1u << ((nd + pc) & 31));   // an early evaluation for the next run read them before this Sub
+            chg_any = true;
             const uint32_t nmc = rl32(rnm, pc);
             const bool has_map = kind ? (nmc >> 31) : (nmc & 0x7FFFFFFFu);
-            if (has_map && lane >= 16 && lane < 16 + RS && ((km0 >> (lane - 16)) & 1u)) k9_sc_sub(kind ? gr : gi, a.NP, lane - 16, n, rqv[lane - 16]);
+            if (has_map && lane_i >= 16 && lane_i < 16 + RS && ((km0 >> (lane_i - 16)) & 1u)) k9_sc_sub(kind ? gr : gi, a.NP, lane_i - 16, n, rqv[lane_i - 16]);
             sc_dirty = 1;
           }
           pc++;
         } else {       // a node this round already changed wins: AddTask on its slot, re-evaluate it
           K9S_LOAD_D();
-          const uint32_t own = (lane < pc) ? k1 : 0u;
+          const uint32_t own = (lane_i < pc) ? k1 : 0u;
           const unsigned long long who = __ballot(d0 == m || d1 == m || d2 == m || d3 == m || own == m);
           const uint32_t L = (uint32_t)__ffsll((unsigned long long)who) - 1u;
           const bool is_new = L < pc && rl32(k1, L) == m;
           const uint32_t wsel = (rl32(d0, L) == m) ? 0u : (rl32(d1, L) == m) ? 1u : (rl32(d2, L) == m) ? 2u : 3u;
           const uint32_t x = is_new ? nd + L : L + 64u * wsel;
-          if (lane == 0) atomicOr(&chg[x >> 5], 1u << (x & 31));   // the slot is not what an early evaluation for the next run saw
+          if (lane_i == 0) atomicOr(&chg[x >> 5], 1u << (x & 31));   // the slot is not what an early evaluation for the next run saw
+          chg_any = true;
           unsigned long long *st = slots + (size_t)x * K9_NF;
-          // one row: lane f holds field f of the slot; lanes 16 + d' look at the scalar dimension d' + 2 in HBM when the shape or
+          // one row: lane_i f holds field f of the slot; lanes 16 + d' look at the scalar dimension d' + 2 in HBM when the shape or
           // the row names one
-          const bool sc_lane = lane >= 16 && lane < 16 + RS;
-          const uint32_t sd = sc_lane ? lane - 16 : 0;
+          const bool sc_lane = lane_i >= 16 && lane_i < 16 + RS;
+          const uint32_t sd = sc_lane ? lane_i - 16 : 0;
           unsigned long long cur8 = 0ull;
-          if (lane < K9_NF) cur8 = st[lane];
+          if (lane_i < K9_NF) cur8 = st[lane_i];
           const uint32_t nm = (uint32_t)(rl64(cur8, F_NODE_NMASK) >> 32);
           const uint32_t n = (uint32_t)rl64(cur8, F_NODE_NMASK);
           // the scalar dimensions the new key will read (only when a key is needed: not on the run's last row), in flight with the vote's loads
@@ -464,31 +509,31 @@ __global__ void __launch_bounds__(K9_THREADS) k_commit_select(const K9KernArgs k
           kind = 0;
           if (!a.backfill) {
             bool ok = true;
-            if (lane == F_IDLE0) ok = le_eps(sh.init0, u2d(cur8), EPS_CPU);
-            else if (lane == F_IDLE1) ok = le_eps(sh.init1, u2d(cur8), EPS_MEM);
+            if (lane_i == F_IDLE0) ok = le_eps(sh.init0, u2d(cur8), EPS_CPU);
+            else if (lane_i == F_IDLE1) ok = le_eps(sh.init1, u2d(cur8), EPS_MEM);
             else if (sc_lane && ((sh.active >> (2 + sd)) & 1u)) ok = le_eps(si[sd], k9_sc(gi, a.NP, sd, n), EPS_SCALAR);
             kind = __ballot(!ok) ? 1u : 0u;
           }
           const uint32_t has_map = kind ? (nm >> 31) : (nm & 0x7FFFFFFFu);
           const uint32_t f0 = kind ? F_REL0 : F_IDLE0;
-          if (lane == f0) cur8 = d2u(u2d(cur8) - res0);
-          else if (lane == f0 + 1) cur8 = d2u(u2d(cur8) - res1);
-          else if (lane == F_NZC) cur8 = d2u(u2d(cur8) + sh.nzc);
-          else if (lane == F_NZM) cur8 = d2u(u2d(cur8) + sh.nzm);
-          else if (lane == F_PORTS) cur8 |= sh.want;
-          else if (lane == F_CLS_LEFT) cur8 -= (1ull << 32);   // one more pod on the node
+          if (lane_i == f0) cur8 = d2u(u2d(cur8) - res0);
+          else if (lane_i == f0 + 1) cur8 = d2u(u2d(cur8) - res1);
+          else if (lane_i == F_NZC) cur8 = d2u(u2d(cur8) + sh.nzc);
+          else if (lane_i == F_NZM) cur8 = d2u(u2d(cur8) + sh.nzm);
+          else if (lane_i == F_PORTS) cur8 |= sh.want;
+          else if (lane_i == F_CLS_LEFT) cur8 -= (1ull << 32);   // one more pod on the node
           uint32_t bulk = 1u;   // rows this node takes now
           if (bf_bulk) {
             const uint32_t left1 = (uint32_t)(rl64(cur8, F_CLS_LEFT) >> 32);   // pod slots left behind row j's placement: each takes one more row of the run
             bulk = 1u + min(r - j - 1u, left1);
             if (bulk > 1u) {
-              if (lane == F_NZC) { double z = u2d(cur8); for (uint32_t t = 1; t < bulk; t++) z += sh.nzc; cur8 = d2u(z); }   // one addition per placement, as AddTask does them
-              else if (lane == F_NZM) { double z = u2d(cur8); for (uint32_t t = 1; t < bulk; t++) z += sh.nzm; cur8 = d2u(z); }
-              else if (lane == F_CLS_LEFT) cur8 -= ((unsigned long long)(bulk - 1u) << 32);
+              if (lane_i == F_NZC) { double z = u2d(cur8); for (uint32_t t = 1; t < bulk; t++) z += sh.nzc; cur8 = d2u(z); }   // one addition per placement, as AddTask does them
+              else if (lane_i == F_NZM) { double z = u2d(cur8); for (uint32_t t = 1; t < bulk; t++) z += sh.nzm; cur8 = d2u(z); }
+              else if (lane_i == F_CLS_LEFT) cur8 -= ((unsigned long long)(bulk - 1u) << 32);
             }
           }
-          if (lane < K9_NF) st[lane] = cur8;
-          if (lane < bulk) ldec[i0 + j + lane] = (unsigned long long)n | ((unsigned long long)kind << 32);   // bulk > 1: backfill, kind == 0
+          if (lane_i < K9_NF) st[lane_i] = cur8;
+          if (lane_i < bulk) ldec[i0 + j + lane_i] = (unsigned long long)n | ((unsigned long long)kind << 32);   // bulk > 1: backfill, kind == 0
           j += bulk - 1u;
           n_dirty += bulk - 1u;
           K9_WAVE_FENCE();
@@ -497,39 +542,42 @@ __global__ void __launch_bounds__(K9_THREADS) k_commit_select(const K9KernArgs k
           const bool more = j + 1u < r && !kind;
           const uint32_t adjm1 = (!kind && has_map) ? km0 : 0u;
           uint32_t nk = 0u;
-          if (more) nk = k9_eval_v(a, sh, k9_load(st), scs, gi, gr, si, adjm1, 1.0, rqv, nb, nmaskbits);   // uniform: every lane computes the same key
+          if (more) nk = k9_eval_v(a, sh, k9_load(st), scs, gi, gr, si, adjm1, 1.0, rqv, nb, nmaskbits);   // uniform: every lane_i computes the same key
           if (km0 && has_map) {
             if (sc_lane && ((km0 >> sd) & 1u)) k9_sc_sub(kind ? gr : gi, a.NP, sd, n, rqv[sd]);
             sc_dirty = 1;
           }
           if (more) {
-            if (lane == L) {
+            if (lane_i == L) {
               if (is_new) k1 = nk;
               else if (wsel == 0) d0 = nk; else if (wsel == 1) d1 = nk; else if (wsel == 2) d2 = nk; else d3 = nk;
             }
-            m = wave_max_u32(max(max(max(d0, d1), max(d2, d3)), (lane < pc) ? k1 : 0u));
+            m = wave_max_u32(max(max(max(d0, d1), max(d2, d3)), (lane_i < pc) ? k1 : 0u));
           }
           n_dirty++;
         }
         if (kind) { j++; reason = KB_REASON_PIPELINED; break; }   // a Pipeline ends the speculated order: the host re-plans
       }
+      }   // (!run_done)
+  //@@ w0_tail
       if (sc_dirty) __threadfence();   // the scalar atomics have reached L2 before any other wave evaluates against these nodes (dropping it measured no gain: profiles/round4/call20)
       const uint32_t i_next = i0 + j;
-      uint32_t stop = (reason != KB_REASON_DONE || i_next >= W) ? 1u : 0u;
+      uint32_t stop = (reason != KB_REASON_DONE || k + 1u >= K) ? 1u : 0u;   // (a complete run ends the window iff it is the last one: i_next == W)
       if (!stop && a.has_aff && !a.backfill && i_next != 0u) {
         // a row whose score is normalised over its feasible set (preferred node affinity) is exact only against a fresh matrix: it may be
         // the first row of a round, nothing else
-        const uint32_t fln = (uint32_t)__builtin_amdgcn_readfirstlane((int)rinfo[i_next].z);
+        // (the window goes on and this run is complete: row i_next heads run k + 1, whose header is already here)
+        const uint32_t fln = (uint32_t)__builtin_amdgcn_readfirstlane((int)hd_next.z);
         if (fln & 2u) { reason = KB_REASON_RENORM; stop = 1u; }
       }
-      if (lane == 0 && pc) cursor[s] = CD.cpos[pc - 1] + 1;
+      if (pc) { const uint32_t cp = rl32(cpos, pc - 1u); if (lane_i == 0) cursor[s] = cp + 1u; }
       prev_nd0 = nd; prev_pc = pc; prev_all = pc == ncand;
       K9_WAVE_FENCE();
-      prev_chg = __ballot(lane < 10u && chg[lane < 10u ? lane : 0u] != 0u) != 0ull;
+      prev_chg = chg_any;   // (chg itself is for the evaluating waves: which slots)
       nd += pc; n_dirty_rows += n_dirty; n_runs += 1u; n_slow += plain0 ? 0u : 1u;
       i_end = i_next; reason_end = reason;
       // publish: everything this run wrote (slots, bitmap, cursor, decision records) is in LDS before the word moves
-      if (lane == 0) {
+      if (lane_i == 0) {
         Y.nd_at[(k + 1u) & 3u] = nd;
         Y.spec_ok[(k + 1u) & 3u] = prev_all ? 1u : 0u;
         if (stop) k9s_st(&Y.stop, 1u);
@@ -542,6 +590,7 @@ __global__ void __launch_bounds__(K9_THREADS) k_commit_select(const K9KernArgs k
       k9s_st(&Y.stop, 1u);
       H.i = i_end; H.nd = nd; H.reason = reason_end; H.n_dirty_rows = n_dirty_rows; H.n_runs = n_runs; H.n_slow = n_slow;
     }
+  //@@ dk_waves
   } else if (wave <= 4u) {
     // =================================================== waves 1..4: the dirty slots ===================================================
     // Run q's dirty keys are evaluated EARLY, while run q - 1 is still being selected: against the slots as run q - 2 left them plus run
@@ -584,6 +633,7 @@ __global__ void __launch_bounds__(K9_THREADS) k_commit_select(const K9KernArgs k
       const uint32_t wm = wave_max_u32(key);
       if (lane == 0) { Y.mdk[q & 1u][wave - 1u] = wm; k9s_st(&Y.seq_dk[wave - 1u], q + 1u); }
     }
+  //@@ prep_waves
   } else if (wave < K9S_PREP0 + K9S_PREPS) {
     // =================================================== waves 5..7: the candidates ===================================================
     typedef const unsigned long long __attribute__((address_space(1))) *gptr8;
@@ -725,6 +775,7 @@ __global__ void __launch_bounds__(K9_THREADS) k_commit_select(const K9KernArgs k
       }
     }
   }
+  //@@ epilogue
 #ifdef KB_K9_TRACE
   if (tid == 0) {
     unsigned long long *tw = reinterpret_cast<unsigned long long *>(a.result);

@@ -105,9 +105,12 @@ struct Interner {
 // The Go action loads a session every scheduling cycle: at 1M tasks the O(T) passes below (copies, the task-major transpose, the
 // "same as its predecessor" test that lets nearly every task skip shape interning) are memory traffic worth splitting over a few host
 // threads.  fn(t0, t1) over disjoint ranges; small sessions stay on the calling thread.
-template <typename F> static void par_for(uint32_t T, F fn) {
+// `weight`: 8-byte words a pass touches per task (a pass over 16 resource dimensions of 100k tasks is as much memory as one over 2 dimensions of 800k)
+template <typename F> static void par_for(uint32_t T, uint32_t weight, F fn) {
   const unsigned hw = std::thread::hardware_concurrency();
-  const uint32_t nt = T < (1u << 19) ? 1u : std::min<uint32_t>(8u, hw ? hw : 1u);   // below ~500k tasks thread start-up and the remote cache lines it leaves behind cost more than the split saves (100k tasks: 3.7 -> 10 ms on the GPU box)
+  // below ~2M words thread start-up and the remote cache lines it leaves behind cost more than the split saves (100k tasks x 2 dimensions on eight
+  // threads: 3.7 -> 10 ms on the GPU box, round 4; 100k x 16 dimensions on one: 1.7 + 1.8 ms of the 11 ms load, round 5's first call)
+  const uint32_t nt = (uint64_t)T * weight < (1ull << 21) ? 1u : std::min<uint32_t>(8u, hw ? hw : 1u);
   if (nt <= 1) { fn(0u, T); return; }
   std::vector<std::thread> th;
   const uint32_t step = (T + nt - 1) / nt;
@@ -117,7 +120,7 @@ template <typename F> static void par_for(uint32_t T, F fn) {
 }
 template <typename V, typename S> static void par_copy(V &dst, const S *src, size_t n) {   // dst := src[0..n), the destination's storage reused
   dst.resize(n);
-  par_for((uint32_t)n, [&](uint32_t a, uint32_t b) { std::copy(src + a, src + b, dst.begin() + a); });
+  par_for((uint32_t)n, 8u, [&](uint32_t a, uint32_t b) { std::copy(src + a, src + b, dst.begin() + a); });
 }
 
 void build_host_session(const kb_snapshot *sn, const Policy &pol, uint32_t NP, HostSession &hs, std::vector<uint32_t> &t_active, std::vector<uint32_t> &nmask) {
@@ -146,7 +149,7 @@ void build_host_session(const kb_snapshot *sn, const Policy &pol, uint32_t NP, H
       throw EngineError(KB_E_UNSUPPORTED, "node quantity >= 2^48: exact integer scoring not guaranteed");
   }
   hs.t_res.resize((size_t)R * T); hs.t_init.resize((size_t)R * T); hs.t_resmask.resize(T); hs.t_res_rows.resize((size_t)T * R);
-  par_for(T, [&](uint32_t t0, uint32_t t1) {
+  par_for(T, 4u * (uint32_t)R, [&](uint32_t t0, uint32_t t1) {
     for (uint32_t t = t0; t < t1; t++) hs.t_resmask[t] = sn->task_scalar_mask ? sn->task_scalar_mask[t] : 0u;
     for (int d = 0; d < R; d++) {   // one dimension's row at a time: sequential in the dimension-major layout
       std::copy(sn->task_resreq + (size_t)d * T + t0, sn->task_resreq + (size_t)d * T + t1, hs.t_res.begin() + (size_t)d * T + t0);
@@ -166,7 +169,7 @@ void build_host_session(const kb_snapshot *sn, const Policy &pol, uint32_t NP, H
   hs.t_job.resize(T); hs.t_cls.resize(T); hs.t_prio.resize(T); hs.t_creation.resize(T); hs.t_status.resize(T); hs.t_node.resize(T); hs.t_nzc.resize(T); hs.t_nzm.resize(T);
   {
     std::atomic<int> bad_node{0};
-    par_for(T, [&](uint32_t t0, uint32_t t1) {
+    par_for(T, 8u, [&](uint32_t t0, uint32_t t1) {
       std::copy(sn->task_job + t0, sn->task_job + t1, hs.t_job.begin() + t0);
       if (sn->task_class) std::copy(sn->task_class + t0, sn->task_class + t1, hs.t_cls.begin() + t0); else std::fill(hs.t_cls.begin() + t0, hs.t_cls.begin() + t1, 0);
       std::copy(sn->task_priority + t0, sn->task_priority + t1, hs.t_prio.begin() + t0);
@@ -300,7 +303,7 @@ void build_host_session(const kb_snapshot *sn, const Policy &pol, uint32_t NP, H
   std::vector<uint8_t> same_prev(T, 0);
   {
     std::atomic<int> bad_status{0};
-    par_for(T, [&](uint32_t t0, uint32_t t1) {
+    par_for(T, 2u * (uint32_t)R + 4u, [&](uint32_t t0, uint32_t t1) {
       for (uint32_t t = t0; t < t1; t++) {
         if (hs.t_status[t] > KB_TASK_UNKNOWN) bad_status.store(1, std::memory_order_relaxed);
         same_prev[t] = (t > 0 && same_inputs_as_prev(t)) ? 1 : 0;
@@ -374,7 +377,7 @@ void build_host_session(const kb_snapshot *sn, const Policy &pol, uint32_t NP, H
   }
   mark("shapes: stretch heads (validation, interning)");
   // the tasks that equal their predecessor take the values of the head of their stretch (every head is final now): ranges over the threads
-  par_for(T, [&](uint32_t t0, uint32_t t1) {
+  par_for(T, 4u, [&](uint32_t t0, uint32_t t1) {
     uint32_t h = t0;
     while (h > 0 && same_prev[h]) h--;   // the head my first tasks belong to
     for (uint32_t t = t0; t < t1; t++) {

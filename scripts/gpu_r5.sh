@@ -41,24 +41,23 @@ loads)
     echo "config $cfg load: $(ms "$out/load_c${cfg}.json")" | tee -a "$out/summary.txt"
   done
   ;;
-ab)   # every libkbengine_<tag>.so in the package directory beside the default build, same box, same process order
-  test_tag="${1:-}"
-  libs=("default"); for f in kube-batch_amd/libkbengine_*.so; do [ -f "$f" ] && libs+=("$(basename "$f" .so | sed 's/libkbengine_//')"); done
+ab)   # ab <tag,tag,...> [test]: kube-batch_amd/libkbengine_<tag>.so beside the default build, same box, alternating; `test`: the differential
+      # suites (selection kernel, reload module) on the DEFAULT build afterwards
+  IFS=',' read -r -a tags <<< "${1:-base}"
+  libs=("default" "${tags[@]}")
+  libpath() { if [ "$1" = default ]; then echo "$PWD/kube-batch_amd/libkbengine.so"; else echo "$PWD/kube-batch_amd/libkbengine_$1.so"; fi; }
   for rep in 1 2; do
-    for tag in "${libs[@]}"; do
-      lib="$PWD/kube-batch_amd/libkbengine.so"; [ "$tag" != default ] && lib="$PWD/kube-batch_amd/libkbengine_${tag}.so"
-      bench_ab "c3_${tag}_r${rep}" KB_ENGINE_LIB=$lib -- --config 3 --steps 5 --warmup 2 --verify
-    done
+    for tag in "${libs[@]}"; do bench_ab "c3_${tag}_r${rep}" KB_ENGINE_LIB=$(libpath $tag) -- --config 3 --steps 5 --warmup 2 --verify; done
   done
   for tag in "${libs[@]}"; do
-    lib="$PWD/kube-batch_amd/libkbengine.so"; [ "$tag" != default ] && lib="$PWD/kube-batch_amd/libkbengine_${tag}.so"
-    bench_ab "survey_${tag}" KB_ENGINE_LIB=$lib -- --config 3 --survey-nodes --steps 5 --warmup 2 --verify
-    bench_ab "c4_${tag}" KB_ENGINE_LIB=$lib -- --config 4 --steps 5 --warmup 2 --verify
-    bench_ab "c5_${tag}" KB_ENGINE_LIB=$lib -- --config 5 --steps 2 --warmup 1 --verify
+    bench_ab "survey_${tag}" KB_ENGINE_LIB=$(libpath $tag) -- --config 3 --survey-nodes --steps 5 --warmup 2 --verify
+    bench_ab "c4_${tag}" KB_ENGINE_LIB=$(libpath $tag) -- --config 4 --steps 5 --warmup 2 --verify
+    bench_ab "c5_${tag}" KB_ENGINE_LIB=$(libpath $tag) -- --config 5 --steps 2 --warmup 1
+    bench_ab "c2_${tag}" KB_ENGINE_LIB=$(libpath $tag) -- --config 2 --steps 10 --warmup 3 --verify
   done
-  if [ -n "$test_tag" ]; then
-    KB_ENGINE_LIB=$PWD/kube-batch_amd/libkbengine_${test_tag}.so timeout 900 python -m pytest tests -q -m gpu -p no:cacheprovider -k "select or reload" --maxfail=10 > "$out/pytest_${test_tag}.txt" 2>&1
-    echo "differential suites on libkbengine_${test_tag}.so (selection kernel) rc=$? $(tail -1 "$out/pytest_${test_tag}.txt")" | tee -a "$out/summary.txt"
+  if [ "${2:-}" = test ]; then
+    timeout 900 python -m pytest tests -q -m gpu -p no:cacheprovider -k "select or reload or fullsize" --maxfail=10 > "$out/pytest_default.txt" 2>&1
+    echo "differential suites on the default build (selection kernel, reload, full size) rc=$? $(tail -1 "$out/pytest_default.txt")" | tee -a "$out/summary.txt"
   fi
   ;;
 trace)
