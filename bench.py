@@ -81,7 +81,7 @@ def main():
     ap.add_argument("--cpu-sample-tasks", type=int, default=0, help="0 = the whole allocate action (a few seconds on 16 threads)")
     ap.add_argument("--verify", action="store_true", help="with --no-cpu-baseline: still compare the bind set with the oracle after the timed region")
     ap.add_argument("--preempt", action="store_true", help="BASELINE configs[4] names allocate + backfill + preempt: a step becomes reset -> allocate -> backfill -> "
-                    "preempt under the default tiers plus conformance (scripts/time_preempt.py's configuration); single GPU only")
+                    "preempt under the default tiers plus conformance (scripts/time_preempt.py's configuration); with --gpus N every replica runs the evict action and the journals are compared (kube-batch_amd/dist.py)")
     args = ap.parse_args()
 
     import numpy as np
@@ -117,9 +117,6 @@ def main():
         conf = kbm.conf.load_scheduler_conf(BINPACK_CONF)
         weights = "least 0, most 5, balanced 1"
     if args.preempt:
-        if world > 1:
-            print("bench.py: --preempt runs on one GPU (the sharded path covers allocate and backfill)", file=sys.stderr)
-            sys.exit(2)
         nodeorder_args = BINPACK_CONF.split("  - name: nodeorder\n")[1] if args.config == 4 else ""
         conf = kbm.conf.load_scheduler_conf(PREEMPT_CONF + nodeorder_args)
     params = kbm.snapshot.synth_config(args.config, args.scale)
@@ -152,14 +149,16 @@ def main():
         if dist_mode == "sessions":
             try:
                 golden = json.load(open(os.path.join(ROOT, "tests", "golden", "bench_rank_digests.json")))
-                key = f"config{args.config}_scale{args.scale:g}{'_survey' if args.survey_nodes else ''}{'_diverse' if args.diverse else ''}"
+                # the committed digests are the oracle's for the stock configuration of each config index under allocate + backfill: anything else
+                # (another action list) has no entry and reports sessions_verified_against_golden_digests = null
+                key = f"config{args.config}_scale{args.scale:g}{'_survey' if args.survey_nodes else ''}{'_diverse' if args.diverse else ''}{'_preempt' if args.preempt else ''}"
                 rank_digest_expected = golden.get(key, {}).get(str(rank))
             except OSError:
                 rank_digest_expected = None
         if dist_mode == "sharded":
-            runner = distmod.ShardedCycle(conf, snap, device=local_rank, window=args.window, commit_batch=args.commit_batch)
+            runner = distmod.ShardedCycle(conf, snap, device=local_rank, window=args.window, commit_batch=args.commit_batch, actions=actions)
         else:
-            runner = distmod.ReplicatedCycle(conf, snap, device=local_rank, window=args.window, commit_batch=args.commit_batch)
+            runner = distmod.ReplicatedCycle(conf, snap, device=local_rank, window=args.window, commit_batch=args.commit_batch, actions=actions)
         step = (lambda: runner.step(verify=False)) if dist_mode != "sharded" else runner.step
         eng = runner.engine
     else:
@@ -225,7 +224,7 @@ def main():
         # outside the timed region: one more cycle per rank, its digest against the committed golden digest of THIS rank's snapshot;
         # the per-session rate of the slowest rank is the line's value, the sum over the ranks is the aggregate
         dec_last = runner.step(verify=False)
-        mine = distmod.ReplicatedCycle.digest(dec_last, eng.binds())
+        mine = distmod.ReplicatedCycle.digest(dec_last, eng.binds(), eng.journal() if args.preempt else None, eng.evictions() if args.preempt else None)
         ok_here = 1 if (rank_digest_expected is not None and int(rank_digest_expected) == mine) else (0 if rank_digest_expected is not None else -1)
         dev = "cuda" if (world > 1 and dist.get_backend() == "nccl") else "cpu"
         stat = torch.tensor([evals / elapsed_local, -float(ok_here), float(evals), float(n_binds)], dtype=torch.float64, device=dev)
@@ -392,6 +391,7 @@ def main():
         "multi_gpu_mode": None if dist_mode is None else {"sessions": "one independent session per GPU (rank k: seed + k), no data-path collective; value = the slowest rank's per-session rate",
                                                           "replicas": "the same session on every GPU (KB_DIST_MODE=replicas), digests compared; value = one session's rate",
                                                           "sharded": "task-row sharded rounds (KB_DIST_MODE=sharded)"}[dist_mode],
+        "dist_backend": None if dist_mode is None else dist.get_backend(),   # "nccl" = RCCL: what carried the N ranks (scripts/scale_curve.sh asserts it)
         "replicas_agree": replicas_agree, "sessions_verified_against_golden_digests": sessions_verified,
         **(aggregate or {}),
         "session_load_ms": None if load_ms is None else round(load_ms, 2),

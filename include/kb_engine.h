@@ -391,6 +391,14 @@ int  kb_get_stats(kb_engine *e, kb_stats *out);
  *   (all-reduce(sum) of the delta buffers: RCCL, done by the caller; integer-valued float64 -> exact, order-independent)
  *   kb_round_apply      -> node state for the next round := round-start state + reduced deltas; KB_E_INTERNAL if that
  *                          differs from the replica's own commit (replicas diverged)
+ * The reduced deltas are a CROSS-CHECK (every replica commits the whole window itself): they need not sit between two rounds.  The
+ * deferred form takes the all-reduce off the critical path: kb_round_apply with a NULL buffer only absorbs the round's result; the
+ * caller reduces round k's buffer on a side stream while round k + 1 is planned and evaluated, and hands it to
+ *   kb_round_check      -> queued, nothing waited for: (state at the start of round k) + reduced deltas == (state at the start of
+ *                          round k + 1), called after kb_round_begin of round k + 1 has returned rows; with against_live != 0
+ *                          after the kb_round_begin that returned n_rows == 0: == the live state (the action's last round)
+ *   kb_round_check_result -> the number of values that differed in any check since the action began (one synchronisation);
+ *                          non-zero: the replicas diverged
  */
 /* run the engine's kernels on the caller's HIP stream (e.g. the stream its RCCL collectives are ordered on) instead of the
    engine's own: launches, collectives and the delta kernel are then ordered by the stream alone, with no host synchronisation
@@ -400,6 +408,8 @@ int  kb_round_begin(kb_engine *e, uint32_t action /*0 allocate, 1 backfill*/, ui
 int  kb_round_candidates(kb_engine *e, uint32_t mrow0, uint32_t mrow1, uint64_t dev_keys_ptr);
 int  kb_round_commit(kb_engine *e, uint64_t dev_all_keys_ptr, uint32_t own_row0, uint32_t own_row1, uint64_t dev_delta_ptr);
 int  kb_round_apply(kb_engine *e, uint64_t dev_delta_ptr, uint32_t *done);
+int  kb_round_check(kb_engine *e, uint64_t dev_delta_ptr, uint32_t against_live);
+int  kb_round_check_result(kb_engine *e, uint32_t *mismatches);
 int  kb_round_delta_doubles(const kb_engine *e, uint64_t *n_doubles);   /* NP * (2R + 3) float64 per buffer */
 int  kb_round_decisions(kb_engine *e, kb_decision *out, uint64_t cap, uint64_t *n_out);
 

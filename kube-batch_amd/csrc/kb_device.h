@@ -242,6 +242,10 @@ void kb_launch_commit_sel(const KbDev &d, const KbRound &r, void *stream);     /
 // node state := round-start state + reduced deltas; returns how many values differ from the live (locally committed) state
 uint32_t kb_apply_deltas(const KbDev &d, const double *s_idle, const double *s_rel, const long long *s_nzc, const long long *s_nzm,
                          const int *s_podcnt, const double *delta, uint32_t *dev_counter, void *stream);
+// (s0 + delta) == s1 for every node value, s0 / s1: two copies of the node state {Idle [R][NP], Releasing [R][NP], nz cpu, nz mem, pod count};
+// differences are ADDED to *dev_counter; queued on `stream`, nothing waited for (the deferred cross-check of the sharded path)
+struct KbNodeCopy { const double *idle, *rel; const long long *nzc, *nzm; const int *podcnt; };
+void kb_check_deltas(const KbDev &d, const KbNodeCopy &s0, const KbNodeCopy &s1, const double *delta, uint32_t *dev_counter, void *stream);
 // live state of n nodes from packed records of 5 + 2R 8-byte words {node | nmask << 32, podcnt, nzc, nzm, ports, Idle[R], Releasing[R]}
 // (the evict actions' host mirror -> device); nmask: the writable view of KbDev::nmask
 void kb_launch_scatter_nodes(const KbDev &d, const unsigned long long *rec, uint32_t n, uint32_t *nmask, void *stream);

@@ -53,6 +53,7 @@ struct DevBuf {
     bytes = 0;
     cap = 0;
   }
+  void swap(DevBuf &o) { std::swap(p, o.p); std::swap(bytes, o.bytes); std::swap(cap, o.cap); }
   void alloc(size_t n) {
     n = n ? n : 16;
     if (p && n <= cap) { bytes = n; return; }
@@ -1038,6 +1039,12 @@ struct MgState {
   uint32_t n_done = 0, reason = 0;
   std::vector<kb_decision> last_decs;
   DevBuf s_idle, s_rel, s_nzc, s_nzm, s_podcnt;   // node state at round start
+  // the deferred cross-check (kb_round_check): the state at the start of the round BEFORE the current one, a device counter of differing
+  // values that lives for the action, the rounds begun in it
+  DevBuf q_idle, q_rel, q_nzc, q_nzm, q_podcnt, chk_counter;
+  uint32_t rounds_begun = 0;
+  KbNodeCopy cur() const { return KbNodeCopy{s_idle.as<double>(), s_rel.as<double>(), s_nzc.as<long long>(), s_nzm.as<long long>(), s_podcnt.as<int>()}; }
+  KbNodeCopy prev() const { return KbNodeCopy{q_idle.as<double>(), q_rel.as<double>(), q_nzc.as<long long>(), q_nzm.as<long long>(), q_podcnt.as<int>()}; }
 };
 static void mg_free(MgState *m) { delete m; }
 
@@ -2179,6 +2186,9 @@ int kb_round_begin(kb_engine *e, uint32_t action, uint32_t *n_rows, uint32_t *n_
     if (!m.run.active) {
       m.run.begin(e, action);
       m.in_round = false;
+      m.rounds_begun = 0;
+      m.chk_counter.alloc(sizeof(uint32_t));
+      HIP_OK(hipMemsetAsync(m.chk_counter.p, 0, sizeof(uint32_t), e->stream));
     } else if (m.run.action != action) {
       throw EngineError(KB_E_STATE, "another action is still in progress");
     }
@@ -2195,9 +2205,12 @@ int kb_round_begin(kb_engine *e, uint32_t action, uint32_t *n_rows, uint32_t *n_
     m.ctx = round_prepare(e, n, action == 0 ? 1 : 2, action == 1);
     m.had_candidates = false;
     m.in_round = true;
-    // round-start copy of the node state: the reduced deltas are applied to it
+    // round-start copy of the node state: the reduced deltas are applied to it.  The copy of the round before stays (kb_round_check compares
+    // that round's reduced deltas against the two of them, one round late)
     const size_t NP = e->dev.NP;
     const int R = e->hs.R;
+    m.q_idle.swap(m.s_idle); m.q_rel.swap(m.s_rel); m.q_nzc.swap(m.s_nzc); m.q_nzm.swap(m.s_nzm); m.q_podcnt.swap(m.s_podcnt);
+    m.rounds_begun += 1;
     auto snap = [&](DevBuf &dst, const DevBuf &src) {
       if (dst.bytes != src.bytes) dst.alloc(src.bytes);
       HIP_OK(hipMemcpyAsync(dst.p, src.p, src.bytes, hipMemcpyDeviceToDevice, e->stream));
@@ -2255,6 +2268,34 @@ int kb_round_apply(kb_engine *e, uint64_t dev_delta_ptr, uint32_t *done) {
     m.in_round = false;
     m.committed = false;
     if (done) *done = 0;
+  });
+}
+
+int kb_round_check(kb_engine *e, uint64_t dev_delta_ptr, uint32_t against_live) {
+  if (!e) return KB_E_INVALID;
+  return guarded(e, [&]() {
+    if (!e->mg || !dev_delta_ptr) throw EngineError(KB_E_STATE, "kb_round_check: no round-mode action / null delta buffer");
+    MgState &m = *e->mg;
+    const double *delta = reinterpret_cast<const double *>(dev_delta_ptr);
+    const KbDev &d = e->dev;
+    if (against_live) {   // the action's last round: its start copy + deltas == the live state (the kb_round_begin that ended the action took no copy)
+      if (m.in_round || m.rounds_begun < 1) throw EngineError(KB_E_STATE, "kb_round_check(against_live): behind the kb_round_begin that ended the action");
+      kb_check_deltas(d, m.cur(), KbNodeCopy{d.idle, d.rel, d.nzc, d.nzm, d.podcnt}, delta, m.chk_counter.as<uint32_t>(), e->stream);
+    } else {              // round k's deltas, round k + 1 begun: the two start copies
+      if (!m.in_round || m.rounds_begun < 2) throw EngineError(KB_E_STATE, "kb_round_check: behind the kb_round_begin of the NEXT round");
+      kb_check_deltas(d, m.prev(), m.cur(), delta, m.chk_counter.as<uint32_t>(), e->stream);
+    }
+  });
+}
+
+int kb_round_check_result(kb_engine *e, uint32_t *mismatches) {
+  if (!e || !mismatches) return KB_E_INVALID;
+  return guarded(e, [&]() {
+    if (!e->mg || !e->mg->chk_counter.p) throw EngineError(KB_E_STATE, "kb_round_check_result: no round-mode action has run");
+    uint32_t h = 0;
+    HIP_OK(hipMemcpyAsync(&h, e->mg->chk_counter.p, sizeof(uint32_t), hipMemcpyDeviceToHost, e->stream));
+    HIP_OK(hipStreamSynchronize(e->stream));
+    *mismatches = h;
   });
 }
 

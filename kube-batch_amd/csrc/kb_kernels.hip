@@ -707,6 +707,22 @@ uint32_t kb_apply_deltas(const KbDev &d, const double *s_idle, const double *s_r
   (void)hipStreamSynchronize(s);
   return h;
 }
+__global__ void __launch_bounds__(256) k_check_deltas(uint32_t NP, int R, KbNodeCopy s0, KbNodeCopy s1, const double *delta, uint32_t *counter) {
+  const uint32_t n = blockIdx.x * 256 + threadIdx.x;
+  if (n >= NP) return;
+  uint32_t bad = 0;
+  for (int dim = 0; dim < R; dim++) {
+    const size_t o = (size_t)dim * NP + n;
+    bad += (s0.idle[o] + delta[o] != s1.idle[o]) + (s0.rel[o] + delta[(size_t)R * NP + o] != s1.rel[o]);
+  }
+  const double *tail = delta + (size_t)2 * R * NP;
+  bad += (s0.nzc[n] + (long long)tail[n] != s1.nzc[n]) + (s0.nzm[n] + (long long)tail[(size_t)NP + n] != s1.nzm[n]) +
+         (s0.podcnt[n] + (int)tail[(size_t)2 * NP + n] != s1.podcnt[n]);
+  if (bad) atomicAdd(counter, bad);
+}
+void kb_check_deltas(const KbDev &d, const KbNodeCopy &s0, const KbNodeCopy &s1, const double *delta, uint32_t *dev_counter, void *stream) {
+  hipLaunchKernelGGL(k_check_deltas, dim3((d.NP + 255) / 256), dim3(256), 0, (hipStream_t)stream, d.NP, d.R, s0, s1, delta, dev_counter);
+}
 __global__ void __launch_bounds__(256) k_scatter_nodes(KbDev d, const unsigned long long *__restrict__ rec, uint32_t n, uint32_t *nmask) {
   const uint32_t words = 5u + 2u * (uint32_t)d.R;
   const uint32_t idx = blockIdx.x * 256 + threadIdx.x;

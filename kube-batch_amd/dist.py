@@ -10,6 +10,18 @@ of the session.  Per round:
     all_reduce(sum)    per-node deltas (integer-valued float64: exact, order-independent)
     round_apply        next round's node state := round start + reduced deltas; must equal the replica's own commit
 
+Every replica commits the whole window itself, so the reduced deltas are a CROSS-CHECK, not data the next round waits for.  The default
+(`defer_check=True`) therefore takes that all-reduce off the critical path: round k's buffer (two alternate) is reduced asynchronously — on a
+side stream with RCCL — while round k + 1 is planned and evaluated, and compared one round late on the device (kb_round_check: start of round
+k + deltas == start of round k + 1; a counter read once per action).  `defer_check=False` is the lock-step form above.
+
+preempt / reclaim (BASELINE configs[4] names allocate + backfill + preempt) in this mode: the evict actions are host machines around a few
+device lists (kb_preempt.cpp; 49 ms of host time at 1M x 50k, nothing in them shards), and every replica needs their result — the
+Statement journal applied to its node and task state — before the next action.  So every rank runs the action on its own replica
+(deterministic, like the host side of a round) and ONE all-reduce per action compares a digest of journal and evictions: a replica that
+diverged is reported on every rank.  (Rank 0 running it alone and broadcasting the journal would leave the other replicas the same
+host work — replaying the journal through the same machine — plus the broadcast.)
+
 The transport is pluggable: with the "nccl" backend the collectives run on device buffers; with "gloo" (CPU tests, or
 several ranks sharing one GPU) the same buffers are staged through host memory.
 
@@ -47,8 +59,14 @@ class EngineBackend:
     def commit(self, all_keys: torch.Tensor, r0, r1, delta: torch.Tensor):
         self.e.round_commit(all_keys.data_ptr(), r0, r1, delta.data_ptr())
 
-    def apply(self, delta: torch.Tensor):
-        self.e.round_apply(delta.data_ptr())
+    def apply(self, delta: Optional[torch.Tensor]):
+        self.e.round_apply(delta.data_ptr() if delta is not None else 0)
+
+    def check(self, delta: torch.Tensor, against_live: bool):
+        self.e.round_check(delta.data_ptr(), against_live)
+
+    def check_result(self) -> int:
+        return self.e.round_check_result()
 
     def decisions(self):
         return self.e.round_decisions()
@@ -58,7 +76,7 @@ class ShardedCycle:
     """Runs allocate (+ backfill) with the window's matrix rows sharded across ranks."""
 
     def __init__(self, conf, snap, device: int = 0, window: int = 0, commit_batch: int = 0, backend=None,
-                 buffer_device: Optional[torch.device] = None, actions=("allocate", "backfill"), min_rows_per_rank: int = 32):
+                 buffer_device: Optional[torch.device] = None, actions=("allocate", "backfill"), min_rows_per_rank: int = 32, defer_check: bool = True):
         self.rank = dist.get_rank() if dist.is_initialized() else 0
         self.world = dist.get_world_size() if dist.is_initialized() else 1
         self.actions = list(actions)
@@ -91,8 +109,14 @@ class ShardedCycle:
                 self.engine.use_stream(self._stream.cuda_stream)
         with self._on_stream():
             self.delta = torch.zeros(backend.delta_len, dtype=torch.float64, device=self.buf_dev)
+            self.delta2 = torch.zeros(backend.delta_len, dtype=torch.float64, device=self.buf_dev)
+        # the reduced deltas as a deferred cross-check (module docstring); backends without the check entry points (the CPU stand-ins) run lock-step
+        self.defer_check = bool(defer_check) and hasattr(backend, "check")
+        self._side = torch.cuda.Stream(device=buffer_device) if (self.stream_ordered and self.defer_check) else None
+        self.deferred_checks = 0
         self.rounds = 0
         self.replicated_rounds = 0
+        self.evict_actions = 0
         # a single-rank group still goes through the collectives when asked to (exercises the RCCL path on a one-GPU box)
         import os as _os
         self.always_collect = dist.is_initialized() and _os.environ.get("KB_DIST_ALWAYS_COLLECT") == "1"
@@ -139,6 +163,39 @@ class ShardedCycle:
             if self.delta.device.type == "cuda" and not self.stream_ordered:
                 torch.cuda.current_stream().synchronize()
 
+    def _all_reduce_delta_async(self, buf: torch.Tensor):
+        """-> a callable that completes the reduction of `buf` (the commit that filled it has been collected: its kernel is over).  RCCL: issued on
+        a side stream, the returned wait makes the engine's stream wait for it (no host wait); gloo: staged through host memory, asynchronous
+        on the process group's own thread."""
+        if self.world == 1 and not self.always_collect:
+            return lambda: None
+        if self._side is not None:
+            self._side.wait_stream(self._stream)
+            with torch.cuda.stream(self._side):
+                work = dist.all_reduce(buf, op=dist.ReduceOp.SUM, async_op=True)
+
+            def done():
+                work.wait()                              # orders the current (the engine's) stream behind the collective
+                self._stream.wait_stream(self._side)
+            return done
+        if self.stage_host and buf.device.type != "cpu":
+            h = buf.cpu()
+            work = dist.all_reduce(h, op=dist.ReduceOp.SUM, async_op=True)
+
+            def done():
+                work.wait()
+                buf.copy_(h)
+                if buf.device.type == "cuda":
+                    torch.cuda.current_stream().synchronize()
+            return done
+        work = dist.all_reduce(buf, op=dist.ReduceOp.SUM, async_op=True)
+
+        def done():
+            work.wait()
+            if buf.device.type == "cuda" and not self.stream_ordered:
+                torch.cuda.current_stream().synchronize()
+        return done
+
     # ---- one action
     def run_action(self, action: int) -> np.ndarray:
         with self._on_stream():
@@ -146,8 +203,15 @@ class ShardedCycle:
 
     def _run_action(self, action: int) -> np.ndarray:
         b = self.backend
+        pending = None      # (completion of the all-reduce of the round before, its buffer)
+        k = 0
         while True:
             n_rows, n_mrows, L = b.begin(action)
+            if pending is not None:     # round k - 1's reduced deltas: start of k - 1 + deltas == start of k (or, behind the last round, == the live state)
+                pending[0]()
+                b.check(pending[1], n_rows == 0)
+                self.deferred_checks += 1
+                pending = None
             if n_rows == 0:
                 break
             # equal-sized shards of the matrix rows (padded so all_gather_into_tensor applies); the sorted candidate
@@ -170,11 +234,41 @@ class ShardedCycle:
                 table = self._all_gather_keys(local, chunk, L)
             # the gathered table is [world*chunk][L]; matrix row m lives at row m because shards are contiguous and equal
             r0, r1 = shard_bounds(n_rows, self.world, self.rank)
-            b.commit(table, r0, r1, self.delta)
-            self._all_reduce_delta()
-            b.apply(self.delta)
+            if self.defer_check:
+                buf = self.delta if (k & 1) == 0 else self.delta2
+                b.commit(table, r0, r1, buf)
+                pending = (self._all_reduce_delta_async(buf), buf)
+                b.apply(None)                   # absorb the round's result; the cross-check follows one round late
+            else:
+                b.commit(table, r0, r1, self.delta)
+                self._all_reduce_delta()
+                b.apply(self.delta)
             self.rounds += 1
+            k += 1
+        if self.defer_check and k:
+            bad = b.check_result()
+            if bad:
+                raise RuntimeError(f"replicas diverged: the reduced per-node deltas differ from the local commits at {bad} values (rank {self.rank})")
         return b.decisions()
+
+    def run_evict(self, name: str) -> np.ndarray:
+        """preempt / reclaim on every replica (module docstring), journals cross-checked with one all-reduce; -> the journal"""
+        if self.engine is None:
+            raise RuntimeError("the evict actions need the engine backend")
+        with self._on_stream():
+            getattr(self.engine, "run_" + name)()
+        journal = self.engine.last_journal
+        if self.world > 1 or self.always_collect:
+            d = ReplicatedCycle.digest(journal, self.engine.evictions())
+            dev = self.buf_dev if not self.stage_host else torch.device("cpu")
+            with self._on_stream():
+                t = torch.tensor([d, -d], dtype=torch.int64, device=dev)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                agree = int(t[0].item()) == -int(t[1].item())
+            if not agree:
+                raise RuntimeError(f"replicas diverged in {name}: rank {self.rank} journal digest {d:#x}")
+        self.evict_actions += 1
+        return journal
 
     def step(self):
         """One scheduling cycle from the pristine session state (bench step)."""
@@ -182,7 +276,10 @@ class ShardedCycle:
             self.engine.reset()
         out = []
         for a in self.actions:
-            out.append(self.run_action({"allocate": 0, "backfill": 1}[a]))
+            if a in ("preempt", "reclaim"):
+                self.run_evict(a)      # no ssn.Allocate / ssn.Pipeline decisions: the journal carries the Statement operations (engine.journal())
+            else:
+                out.append(self.run_action({"allocate": 0, "backfill": 1}[a]))
         return np.concatenate(out) if out else np.zeros((0, 3), np.uint32)
 
 
@@ -211,12 +308,16 @@ class ReplicatedCycle:
         self._dev = torch.device("cuda", device) if on_gpu else torch.device("cpu")
 
     @staticmethod
-    def digest(decisions: np.ndarray, binds: np.ndarray) -> int:
-        """63 bits of SHA-256 over the ordered decision list and the bind set"""
+    def digest(decisions: np.ndarray, binds: np.ndarray, journal: Optional[np.ndarray] = None, evictions: Optional[np.ndarray] = None) -> int:
+        """63 bits of SHA-256 over the ordered decision list and the bind set (and, for cycles with an evict action, the Statement journal and
+        the evictions in cache.Evict order)"""
         import hashlib
         h = hashlib.sha256()
         h.update(np.ascontiguousarray(decisions, dtype=np.uint32).tobytes())
         h.update(np.ascontiguousarray(binds, dtype=np.uint32).tobytes())
+        if journal is not None:
+            h.update(np.ascontiguousarray(journal, dtype=np.uint32).tobytes())
+            h.update(np.ascontiguousarray(evictions if evictions is not None else np.zeros(0, np.uint32), dtype=np.uint32).tobytes())
         return int.from_bytes(h.digest()[:8], "little") >> 1
 
     def step(self, verify: bool = True) -> np.ndarray:
@@ -229,7 +330,8 @@ class ReplicatedCycle:
 
     def check(self, dec: np.ndarray):
         """one all-reduce (MIN and MAX of the digest in one tensor): every replica took the same decisions"""
-        d = self.digest(dec, self.engine.binds())
+        evict = any(a in ("preempt", "reclaim") for a in self.actions)
+        d = self.digest(dec, self.engine.binds(), self.engine.journal() if evict else None, self.engine.evictions() if evict else None)
         t = torch.tensor([d, -d], dtype=torch.int64, device=self._dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         if int(t[0].item()) != -int(t[1].item()):

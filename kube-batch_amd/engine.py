@@ -19,7 +19,7 @@ _LIB = None
 EXPORTS = ["kb_engine_create", "kb_engine_destroy", "kb_last_error", "kb_session_load", "kb_session_reset", "kb_run_allocate",
            "kb_run_backfill", "kb_run_preempt", "kb_run_reclaim", "kb_get_evictions", "kb_engine_use_stream", "kb_eval_matrix", "kb_argmax_rows", "kb_bench_matrix", "kb_get_binds",
            "kb_get_task_state", "kb_get_node_state", "kb_get_shares", "kb_get_stats", "kb_round_begin",
-           "kb_round_candidates", "kb_round_commit", "kb_round_apply", "kb_round_delta_doubles",
+           "kb_round_candidates", "kb_round_commit", "kb_round_apply", "kb_round_check", "kb_round_check_result", "kb_round_delta_doubles",
            "kb_round_decisions"]
 
 
@@ -70,6 +70,8 @@ def lib():
         L.kb_round_candidates.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint64]
         L.kb_round_commit.argtypes = [vp, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint64]
         L.kb_round_apply.argtypes = [vp, C.c_uint64, C.POINTER(C.c_uint32)]
+        L.kb_round_check.argtypes = [vp, C.c_uint64, C.c_uint32]
+        L.kb_round_check_result.argtypes = [vp, C.POINTER(C.c_uint32)]
         L.kb_round_delta_doubles.argtypes = [vp, C.POINTER(C.c_uint64)]
         L.kb_round_decisions.argtypes = [vp, C.POINTER(abi.Decision), C.c_uint64, C.POINTER(C.c_uint64)]
         _LIB = L
@@ -233,6 +235,15 @@ class Engine:
     def round_apply(self, dev_delta_ptr: int):
         done = C.c_uint32()
         self._ck(self.L.kb_round_apply(self.h, dev_delta_ptr, C.byref(done)))
+
+    def round_check(self, dev_delta_ptr: int, against_live: bool = False):
+        """deferred cross-check of a round's reduced deltas (include/kb_engine.h); queued, nothing waited for"""
+        self._ck(self.L.kb_round_check(self.h, dev_delta_ptr, 1 if against_live else 0))
+
+    def round_check_result(self) -> int:
+        n = C.c_uint32()
+        self._ck(self.L.kb_round_check_result(self.h, C.byref(n)))
+        return n.value
 
     def round_delta_doubles(self) -> int:
         n = C.c_uint64()

@@ -684,6 +684,24 @@ uint32_t kb_apply_deltas(const KbDev &d, const double *s_idle, const double *s_r
   return *dev_counter;
 }
 
+void kb_check_deltas(const KbDev &d, const KbNodeCopy &s0, const KbNodeCopy &s1, const double *delta, uint32_t *dev_counter, void *stream) {
+  const uint32_t NP = d.NP;
+  const int R = d.R;
+  kbemu_enqueue((hipStream_t)stream, [NP, R, s0, s1, delta, dev_counter]() {
+    uint32_t bad = 0;
+    for (uint32_t n = 0; n < NP; n++) {
+      for (int dim = 0; dim < R; dim++) {
+        const size_t o = (size_t)dim * NP + n;
+        bad += (s0.idle[o] + delta[o] != s1.idle[o]) + (s0.rel[o] + delta[(size_t)R * NP + o] != s1.rel[o]);
+      }
+      const double *tail = delta + (size_t)2 * R * NP;
+      bad += (s0.nzc[n] + (long long)tail[n] != s1.nzc[n]) + (s0.nzm[n] + (long long)tail[(size_t)NP + n] != s1.nzm[n]) +
+             (s0.podcnt[n] + (int)tail[(size_t)2 * NP + n] != s1.podcnt[n]);
+    }
+    __atomic_fetch_add(dev_counter, bad, __ATOMIC_RELAXED);
+  });
+}
+
 void kb_launch_finalize(const KbDev &d, const uint32_t *job_task_begin, const int *job_min_avail, const uint32_t *job_queue,
                         int gang_ready_enabled, const double *total, uint32_t total_mask, const double *deserved,
                         const uint32_t *deserved_mask, double *job_alloc, double *job_share, double *queue_alloc,

@@ -124,6 +124,35 @@ def test_sharded_rounds_world1_equal_the_oracle(emulated_engine, oracle_mod):
     assert np.array_equal(cyc.step(), dec)                 # reset + second cycle: identical
 
 
+def test_sharded_rounds_cross_check_their_deltas_one_round_late(emulated_engine, oracle_mod):
+    """defer_check (the default): every round's reduced deltas are compared on the device one round late (kb_round_check), the counter is read
+    once per action; a reduced buffer that is off by one value fails the action on that read.  Lock-step (defer_check=False) gives the same cycle."""
+    import torch
+    distmod = importlib.import_module("kube-batch_amd.dist")
+    conf, snap, cyc = _sharded_cycle(emulated_engine, 0)
+    dec = cyc.step()
+    assert cyc.defer_check and cyc.deferred_checks == cyc.rounds > 5
+    eng = engine.Engine(conf, device=0, window=256)
+    eng.load(snap)
+    cpu = torch.device("cpu")
+    lock = distmod.ShardedCycle(conf, snap, backend=distmod.EngineBackend(eng, cpu), buffer_device=cpu, min_rows_per_rank=0, defer_check=False)
+    assert np.array_equal(lock.step(), dec) and lock.deferred_checks == 0
+
+    class Poisoned(distmod.ShardedCycle):
+        def _all_reduce_delta_async(self, buf):
+            done = super()._all_reduce_delta_async(buf)
+
+            def bad():
+                done()
+                if self.rounds == 3:
+                    buf[5] += 1.0          # what a replica that committed something else would contribute
+            return bad
+    eng2 = engine.Engine(conf, device=0, window=256)
+    eng2.load(snap)
+    with pytest.raises(RuntimeError, match="replicas diverged"):
+        Poisoned(conf, snap, backend=distmod.EngineBackend(eng2, cpu), buffer_device=cpu, min_rows_per_rank=0).step()
+
+
 def test_sharded_rounds_with_host_port_masks_of_several_words(emulated_engine, oracle_mod):
     conf, snap, cyc = _sharded_cycle(emulated_engine, 32, wide_ports=True)
     dec = cyc.step()
@@ -165,6 +194,47 @@ def test_sharded_rounds_two_gloo_ranks_equal_the_oracle(emulated_engine, oracle_
     m0, m1 = np.load(tmp_path / "mevals0.npy"), np.load(tmp_path / "mevals1.npy")
     assert m0[1] == m1[1]                                   # same number of rounds on both ranks
     assert abs(int(m0[0]) - int(m1[0])) <= m0[1] * 10_000   # each rank evaluated about half of the matrix rows
+
+
+# ---- BASELINE configs[4] names a third action: preempt (and reclaim) in the sharded mode — every replica runs the evict action, one all-reduce
+#      compares the journals (kube-batch_amd/dist.py) — on the reference's own preempt cases and on a scaled 1M x 50k cycle
+from test_gpu_sharded import sharded_evict_inputs as _sharded_evict_inputs, check_sharded_evict_outputs as _check_sharded_evict_outputs  # noqa: E402
+
+
+def _sharded_evict_worker(rank, world, port, out_dir, so, case):
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        distmod = importlib.import_module("kube-batch_amd.dist")
+        engine.LIB_PATH, engine._LIB = so, None
+        cfg, snap, order = _sharded_evict_inputs(case)
+        eng = engine.Engine(cfg, device=0, window=256)
+        eng.load(snap)
+        cpu = torch.device("cpu")
+        cyc = distmod.ShardedCycle(cfg, snap, backend=distmod.EngineBackend(eng, cpu), buffer_device=cpu, min_rows_per_rank=0, actions=order)
+        dec = cyc.step()
+        assert cyc.evict_actions == sum(a in ("preempt", "reclaim") for a in order)
+        np.save(os.path.join(out_dir, f"dec{rank}.npy"), dec)
+        np.save(os.path.join(out_dir, f"binds{rank}.npy"), eng.binds())
+        np.save(os.path.join(out_dir, f"journal{rank}.npy"), eng.journal())
+        np.save(os.path.join(out_dir, f"evict{rank}.npy"), np.array(eng.evictions(), np.uint32))
+        for i, a in enumerate(eng.node_state()):
+            np.save(os.path.join(out_dir, f"node{i}_{rank}.npy"), a)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("case", range(4))
+def test_sharded_cycle_with_evict_actions_two_gloo_ranks(emulated_engine, oracle_mod, tmp_path, case):
+    import socket
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_sharded_evict_worker, args=(2, port, str(tmp_path), emulated_engine, case), nprocs=2, join=True)
+    _check_sharded_evict_outputs(oracle_mod, tmp_path, case)
 
 
 # ---- the default multi-GPU mode of bench.py: one session replica per rank, one digest all-reduce (dist.ReplicatedCycle) ---------
