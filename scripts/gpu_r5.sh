@@ -56,7 +56,7 @@ ab)   # ab <tag,tag,...> [test]: kube-batch_amd/libkbengine_<tag>.so beside the 
     bench_ab "c2_${tag}" KB_ENGINE_LIB=$(libpath $tag) -- --config 2 --steps 10 --warmup 3 --verify
   done
   if [ "${2:-}" = test ]; then
-    timeout 900 python -m pytest tests -q -m gpu -p no:cacheprovider -k "select or reload or fullsize" --maxfail=10 > "$out/pytest_default.txt" 2>&1
+    timeout 900 python -m pytest tests -q -m gpu -p no:cacheprovider -k "select or reload or fullsize or sharded or waterfill or framework" --maxfail=10 > "$out/pytest_default.txt" 2>&1
     echo "differential suites on the default build (selection kernel, reload, full size) rc=$? $(tail -1 "$out/pytest_default.txt")" | tee -a "$out/summary.txt"
   fi
   ;;
