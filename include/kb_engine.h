@@ -124,6 +124,12 @@ typedef struct kb_plugin_option {
 } kb_plugin_option;
 
 #define KB_FLAG_SYNC_ROUNDS 1u  /* disable host/device overlap (debug) */
+/* While a round runs the calling thread POLLS the round's sequence word in pinned memory (no stream synchronisation per round: ~20 us of a
+ * ~115 us round).  By default it spins (`pause`): one core is busy for the length of the action — 40 ms of a one-second scheduling period at
+ * 100k x 10k — which is the right trade inside cmd/kube-batch, whose runOnce is single-threaded (pkg/scheduler/scheduler.go:85-101).  With
+ * KB_FLAG_YIELD_WAIT the thread gives the core up between two polls (sched_yield): other runnable threads of the process get it, a round's
+ * answer is noticed a few microseconds later. */
+#define KB_FLAG_YIELD_WAIT 2u
 
 typedef struct kb_config {
   uint32_t version;                /* KB_ABI_VERSION */

@@ -39,6 +39,7 @@ EN_NODE_ORDER = 1 << 8
 EN_ALL = 0x1FF
 
 FLAG_SYNC_ROUNDS = 1
+FLAG_YIELD_WAIT = 2     # the host gives its core up between two polls of a round's sequence word (include/kb_engine.h)
 
 # kb_stmt_op.op: the preempt action's journal (framework/statement.go)
 OP_EVICT, OP_PIPELINE, OP_COMMIT, OP_DISCARD = range(4)

@@ -8,6 +8,8 @@
 // the host rolls the order machine back to the round start, replays the confirmed prefix and re-plans.
 #include <hip/hip_runtime.h>
 
+#include <sched.h>
+
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -631,6 +633,8 @@ void round_commit(kb_engine *e, const RoundCtx &c, unsigned long long *keys, dou
     r.host_out = e->d_hout + (size_t)c.buf * KB_OUT_STRIDE;
     r.seq = c.seq;
     launch();
+    // a launch the runtime refuses (too much LDS, a bad attribute) never publishes its round: say so now instead of after the watchdog's ten seconds
+    HIP_OK(hipGetLastError());
     return;
   }
   Timer &t5 = get_timer(e, 2);
@@ -650,8 +654,9 @@ void round_collect(kb_engine *e, const RoundCtx &c, bool had_candidates, uint32_
     volatile const unsigned long long *seqw = ho + KB_OUT_SEQ;
     const double t0 = now_ms();
     uint32_t spins = 0;
+    const bool yield_wait = (e->flags & KB_FLAG_YIELD_WAIT) != 0;   // include/kb_engine.h: spin (default) or give the core up between polls
     while (__atomic_load_n(seqw, __ATOMIC_ACQUIRE) != c.seq) {
-      __builtin_ia32_pause();
+      if (yield_wait) sched_yield(); else __builtin_ia32_pause();
       if ((++spins & 0xFFFFu) == 0 && now_ms() - t0 > 10000.0) {   // a faulted kernel never publishes: surface the HIP error
         HIP_OK(hipStreamSynchronize(e->stream));
         HIP_OK(hipGetLastError());

@@ -357,7 +357,11 @@ __device__ __forceinline__ bool k9_prologue(const KbCommitArgs &a, const K9Layou
         }
       }
     }
-    if (__syncthreads_or(gone ? 1 : 0)) return false;   // (also the barrier behind which every thread may read the lists)
+    // (no __syncthreads_or: the device library's reduction brings 256 bytes of STATIC LDS, and static + the 160 KiB of dynamic LDS these kernels
+    //  ask for is more than a workgroup may have — every launch then fails with "invalid argument"; round 5's third GPU call)
+    if (gone) H.stop = 1u;                                // H was initialised in front of the prologue's first barrier
+    __syncthreads();                                     // also the barrier behind which every thread may read the lists
+    if (H.stop) return false;
     t_lists = wall_clock64();
   }
   {   // candidate lists: 64-bit keys of K3 -> compact 32-bit keys

@@ -154,7 +154,7 @@ def test_argmax_parity(oracle_mod):
 
 
 @pytest.mark.parametrize("window,batch,flags", [(64, 4, 0), (1024, 16, 0), (4096, 1, 0), (512, 7, 0), (200, 2, 0),
-                                                (0, 0, abi.FLAG_SYNC_ROUNDS), (96, 5, abi.FLAG_SYNC_ROUNDS)])
+                                                (0, 0, abi.FLAG_SYNC_ROUNDS), (96, 5, abi.FLAG_SYNC_ROUNDS), (0, 0, abi.FLAG_YIELD_WAIT)])
 def test_allocate_backfill_config2(oracle_mod, window, batch, flags):
     """Full allocate + backfill on BASELINE config 2: ordered decisions, binds, state, shares identical."""
     snap = snapmod.synth(snapmod.synth_config(2))
