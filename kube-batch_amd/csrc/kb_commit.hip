@@ -44,8 +44,7 @@ __global__ void __launch_bounds__(K9_THREADS) k_commit_run(const K9KernArgs ka) 
   K9_LDS_VIEWS(lo)
   (void)shp;
   const unsigned long long t_start = wall_clock64();
-  unsigned long long t_lists = 0ull;
-  if (!k9_prologue(a, lo, k9_smem, tid, K9_MAXRUN, t_lists)) { if (tid == 0) k9_publish_skipped(a); return; }
+  k9_prologue(a, lo, k9_smem, tid, K9_MAXRUN);
 
 
 #ifdef KB_K9_TRACE
@@ -366,7 +365,7 @@ __global__ void __launch_bounds__(K9_THREADS) k_commit_run(const K9KernArgs ka) 
 #endif
 
 
-  k9_epilogue(a, lo, k9_smem, tid, t_start, 0u, 0u, t_lists);
+  k9_epilogue(a, lo, k9_smem, tid, t_start, 0u, 0u);
 }
 
 size_t kb_commit_smem_bytes(uint32_t n_rows, uint32_t n_shapes, uint32_t NP, int R) {   // the window is planned for either of the two run-at-a-time kernels (the selection kernel's block included)

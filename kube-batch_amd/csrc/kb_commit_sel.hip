@@ -71,8 +71,7 @@ __global__ void __launch_bounds__(K9_THREADS) k_commit_select(const K9KernArgs k
   K9Sel &X = *reinterpret_cast<K9Sel *>(k9_smem + lo.sel);
   K9Sync &Y = X.sync;
   const unsigned long long t_start = wall_clock64();
-  unsigned long long t_lists = 0ull;
-  if (!k9_prologue(a, lo, k9_smem, tid, K9_SEL_MAXRUN, t_lists)) { if (tid == 0) k9_publish_skipped(a); return; }
+  k9_prologue(a, lo, k9_smem, tid, K9_SEL_MAXRUN);
 
   // ---- the runs of the window, by number: run k starts at row X.runs[k] (rinfo there holds its length, shape, flags, Resreq key mask).  A
   //      row starts a run iff it cannot join its predecessor (k9_prologue's rule) or its stretch of joinable rows has reached a multiple of
@@ -795,7 +794,7 @@ __global__ void __launch_bounds__(K9_THREADS) k_commit_select(const K9KernArgs k
     tw[15] = (unsigned long long)X.tr[2] | ((unsigned long long)X.tr[3] << 32);
   }
 #endif
-  k9_epilogue(a, lo, k9_smem, tid, t_start, X.stat[0] | (X.stat[1] << 16), X.stat[2] | (X.stat[3] << 16), t_lists);
+  k9_epilogue(a, lo, k9_smem, tid, t_start, X.stat[0] | (X.stat[1] << 16), X.stat[2] | (X.stat[3] << 16));
 }
 
 void kb_launch_commit_sel(const KbDev &d, const KbRound &r, void *stream) {

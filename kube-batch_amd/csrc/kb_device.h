@@ -159,12 +159,6 @@ struct KbRound {
   uint32_t stale_L;                  // >= n_prev + L: what is left of a stale list without the predecessor's nodes still holds the true top L
   const unsigned long long *prev_dec;   // decision records of the predecessor round (low word: node), n_prev of them
   uint32_t n_prev;
-  // Round 5: the repair launch no longer sits between two commit kernels.  It runs on the SECOND stream behind an event of the predecessor's
-  // commit, i.e. beside this round's commit launch, and leaves lists_tag in lists_ready[row] behind each repaired list; the commit kernel's
-  // prologue does everything that does not need the lists first and then waits for the tags (bounded; a chain broken meanwhile — the repair
-  // launch gave up on its stale lists — makes it report KB_REASON_SKIPPED like a round queued behind a stopped one).  nullptr: lists are final at launch.
-  uint32_t *lists_ready;
-  uint32_t lists_tag;
 };
 // true when the round was queued behind a predecessor that did not complete
 #define KB_CHAIN_BROKEN(r) ((r).chain_expect != 0u && *(r).chain != (r).chain_expect)
@@ -189,8 +183,6 @@ struct KbCommitArgs {
   unsigned long long seq;         // sequence number published last into host_out[KB_OUT_SEQ]
   uint32_t node_bits;             // width of the node field of the commit kernel's 32-bit keys (kb_node_bits)
   uint32_t prewalk;               // unused
-  const uint32_t *lists_ready;    // KbRound::lists_ready / lists_tag
-  uint32_t lists_tag;
 };
 
 // 32-bit keys of the commit kernel: (score + 1) << node_bits | (2^node_bits - 1 - node); needs (max score + 2) << node_bits <= 2^32

@@ -236,8 +236,7 @@ struct kb_engine {
   // beside its predecessor's commit kernel, into buffers of their own (matrix rows, stale lists per staging half, one `ready` word per
   // list, a scratch block for their time stamps); kb_launch_repair on the first stream turns the stale lists into the round's lists
   hipStream_t stream_b = nullptr;
-  DevBuf b_score2, b_maskw2, b_stale, b_ready, b_task_rows, b_lready;   // b_lready: one word per repaired list and staging half (KbRound::lists_ready)
-  hipEvent_t ev_commit[2] = {nullptr, nullptr};   // per staging half: "the predecessor's commit kernel is over" (the repair launch on the second stream waits for it)
+  DevBuf b_score2, b_maskw2, b_stale, b_ready, b_task_rows;
   Pinned<unsigned long long> h_cand_out;   // per staging half: the output-block words the second stream's launches stamp (start of the matrix launch, start of the arg-max launch)
   unsigned long long *d_cand_out = nullptr;
   uint32_t mat2_cap = 0;
@@ -297,7 +296,6 @@ struct kb_engine {
     for (auto &t : ev) t.destroy();
     if (own_stream) (void)hipStreamDestroy(own_stream);
     if (stream_b) (void)hipStreamDestroy(stream_b);
-    for (hipEvent_t ev : ev_commit) if (ev) (void)hipEventDestroy(ev);
   }
 };
 
@@ -563,9 +561,6 @@ void ensure_overlap_buffers(kb_engine *e, uint32_t mrows, uint32_t stale_L) {
     e->b_ready.alloc(sizeof(uint32_t) * 2 * KB_K5_MAX_WINDOW);
     HIP_OK(hipMemset(e->b_ready.p, 0, e->b_ready.bytes));
     e->b_task_rows.alloc((size_t)64 * 2 * KB_K5_MAX_WINDOW);
-    e->b_lready.alloc(sizeof(uint32_t) * 2 * KB_K5_MAX_WINDOW);
-    HIP_OK(hipMemset(e->b_lready.p, 0, e->b_lready.bytes));
-    for (hipEvent_t &ev : e->ev_commit) HIP_OK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
     e->h_cand_out.flags = hipHostMallocMapped | hipHostMallocCoherent;
     e->h_cand_out.resize(2 * KB_OUT_HDR);
     std::memset(e->h_cand_out.data(), 0, sizeof(unsigned long long) * 2 * KB_OUT_HDR);
@@ -589,28 +584,16 @@ void round_candidates_overlapped(kb_engine *e, RoundCtx &c, uint32_t n_prev, uns
   rb.task_rows = reinterpret_cast<unsigned char *>(e->b_task_rows.p) + (size_t)c.buf * 64 * KB_K5_MAX_WINDOW;
   kb_launch_matrix(c.d, rb, e->stream_b);        // also gathers the row descriptors into this round's half (gather == 1)
   kb_launch_argmax(c.d, rb, e->stream_b);
-  // The repair: behind the predecessor's commit kernel — an event on the first stream, where that kernel is the last thing queued — but on the
-  // SECOND stream, so that it runs beside this round's commit launch instead of in front of it.  The commit kernel's prologue waits for the tag
-  // each repaired list leaves (kb_k9.hpp: k9_prologue) after it has done everything that does not need the lists.  Round 4 had the launch on
-  // the first stream, between the two commit kernels: 13.9 us per round on the dependent chain (4.5 ms of the 100k x 10k cycle, 25 of 1M x 50k).
-  KbRound ra = c.r;
+  KbRound ra = c.r;   // first stream: behind the predecessor's commit kernel
   ra.keys = keys;
   ra.ready = ready;
   ra.ready_tag = c.r.chain_tag;
   ra.task_rows = rb.task_rows;
   ra.stale = stale;
   ra.stale_L = stale_L;
-  ra.prev_dec = e->b_out.as<unsigned long long>() + KB_OUT_HDR;   // the predecessor's decision records (it completed, or the chain is broken); this
-                                                                  // round's commit kernel overwrites them in its epilogue, i.e. behind its wait for the tags
+  ra.prev_dec = e->b_out.as<unsigned long long>() + KB_OUT_HDR;   // the predecessor's decision records (it completed, or the chain is broken)
   ra.n_prev = n_prev;
-  ra.result = rb.result;                                          // its stamps: the second stream's block
-  ra.lists_ready = e->b_lready.as<uint32_t>() + (size_t)c.buf * KB_K5_MAX_WINDOW;
-  ra.lists_tag = c.r.chain_tag;
-  HIP_OK(hipEventRecord(e->ev_commit[c.buf], e->stream));
-  HIP_OK(hipStreamWaitEvent(e->stream_b, e->ev_commit[c.buf], 0));
-  kb_launch_repair(c.d, ra, e->stream_b);
-  c.r.lists_ready = ra.lists_ready;   // round_commit launches with it
-  c.r.lists_tag = ra.lists_tag;
+  kb_launch_repair(c.d, ra, e->stream);
   e->stats.matrix_launches += 1;
   e->stats.matrix_evals += (uint64_t)c.ns * e->hs.N;
   e->overlapped_rounds += 1;

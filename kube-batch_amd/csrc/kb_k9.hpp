@@ -248,19 +248,17 @@ __device__ __forceinline__ bool k9_fits_idle(const KbCommitArgs &a, const K9Shap
 // What every workgroup of a commit launch does first.  Returns true when this workgroup has nothing (more) to do: the round was chained to a
 // predecessor that stopped early (workgroup 0 reports KB_REASON_SKIPPED), or this is a helper workgroup (kb_warm.hpp), which warms its slice
 // of the node state into the XCD's L2 and leaves.
-// the round does not run (queued behind a round that stopped early, or its candidate lists never arrived): nothing was evaluated or committed
-__device__ __forceinline__ void k9_publish_skipped(const KbCommitArgs &a) {
-  *a.round->chain = 0u;
-  a.result[0] = 0; a.result[1] = KB_REASON_SKIPPED;
-  if (a.host_out) {
-    a.host_out[0] = (unsigned long long)KB_REASON_SKIPPED << 32;
-    __threadfence_system();
-    __hip_atomic_store(&a.host_out[KB_OUT_SEQ], a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-  }
-}
 __device__ __forceinline__ bool k9_preamble(const KbCommitArgs &a) {
   if (a.round->chain_expect != 0u && *a.round->chain != a.round->chain_expect) {   // chained to a round that stopped early: skip
-    if (threadIdx.x == 0 && blockIdx.x == 0) k9_publish_skipped(a);
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+      *a.round->chain = 0u;
+      a.result[0] = 0; a.result[1] = KB_REASON_SKIPPED;
+      if (a.host_out) {
+        a.host_out[0] = (unsigned long long)KB_REASON_SKIPPED << 32;
+        __threadfence_system();
+        __hip_atomic_store(&a.host_out[KB_OUT_SEQ], a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+    }
     return true;
   }
   if (blockIdx.x != 0) {
@@ -295,15 +293,19 @@ __device__ __forceinline__ bool k9_preamble(const KbCommitArgs &a) {
 
 // ---------------- prologue (all threads): the round staged into LDS ----------------
 // maxrun: longest run of rows that share one evaluation (K9_MAXRUN; the selection kernel: K9_SEL_MAXRUN)
-// t_lists: when the candidate lists were there (an overlapped round's lists are repaired BESIDE this launch: KbRound::lists_ready)
-// returns false when the round must be skipped (the lists never came: the caller publishes KB_REASON_SKIPPED and leaves)
-__device__ __forceinline__ bool k9_prologue(const KbCommitArgs &a, const K9Layout &lo, unsigned char *k9_base_, const uint32_t tid, const uint32_t maxrun,
-                                            unsigned long long &t_lists) {
+__device__ __forceinline__ void k9_prologue(const KbCommitArgs &a, const K9Layout &lo, unsigned char *k9_base_, const uint32_t tid, const uint32_t maxrun) {
   const uint32_t S = a.n_mrows, W = a.n_rows;
   K9_LDS_VIEWS(lo)
   (void)slots; (void)rowres; (void)ldec; (void)dk; (void)ckey; (void)cpos; (void)RS;
   for (uint32_t w = tid; w < a.NP / 32; w += K9_THREADS) bitmap[w] = 0;
-  {   // row descriptors (nothing here needs the lists: it runs beside the repair launch)
+  {   // candidate lists: 64-bit keys of K3 -> compact 32-bit keys
+    const uint32_t tot = S * Lp;
+    for (uint32_t idx = tid; idx < tot; idx += K9_THREADS) {
+      const unsigned long long k64 = a.keys[idx];   // [S][L], Lp == L
+      lists[idx] = k64 ? (((KB_KEY_SCORE(k64) + 1u) << nb) | (nmaskbits - KB_KEY_NODE(k64))) : 0u;
+    }
+  }
+  {   // row descriptors
     const unsigned long long *src = reinterpret_cast<const unsigned long long *>(a.desc);
     unsigned long long *dst = reinterpret_cast<unsigned long long *>(desc);
     for (uint32_t w = tid; w < W * (uint32_t)(sizeof(KbRowDesc) / 8); w += K9_THREADS) dst[w] = src[w];
@@ -343,42 +345,13 @@ __device__ __forceinline__ bool k9_prologue(const KbCommitArgs &a, const K9Layou
       while (r < maxrun && i + r < W && desc[i + r].slot == sl && desc[i + r].flags == fl && desc[i + r].resmask == km) r++;
     rinfo[i] = make_uint4(r, sl, fl, km);
   }
-  // the candidate lists last: everything above ran beside the launch that repairs them (overlapped rounds)
-  t_lists = 0ull;
-  if (a.lists_ready != nullptr) {   // one thread per list waits for its tag; S <= KB_K5_MAX_SHAPES < the workgroup
-    bool gone = false;
-    if (tid < S) {
-      uint32_t spins = 0;
-      while (__hip_atomic_load(&a.lists_ready[tid], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != a.lists_tag) {
-        __builtin_amdgcn_s_sleep(2);
-        if ((++spins & 15u) == 0u) {   // the repair launch gave up (it cleared the chain word), or something is very wrong: leave instead of hanging the device
-          if (a.round->chain_expect != 0u && __hip_atomic_load(a.round->chain, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != a.round->chain_expect) { gone = true; break; }
-          if (spins > (1u << 22)) { gone = true; break; }
-        }
-      }
-    }
-    // (no __syncthreads_or: the device library's reduction brings 256 bytes of STATIC LDS, and static + the 160 KiB of dynamic LDS these kernels
-    //  ask for is more than a workgroup may have — every launch then fails with "invalid argument"; round 5's third GPU call)
-    if (gone) H.stop = 1u;                                // H was initialised in front of the prologue's first barrier
-    __syncthreads();                                     // also the barrier behind which every thread may read the lists
-    if (H.stop) return false;
-    t_lists = wall_clock64();
-  }
-  {   // candidate lists: 64-bit keys of K3 -> compact 32-bit keys
-    const uint32_t tot = S * Lp;
-    for (uint32_t idx = tid; idx < tot; idx += K9_THREADS) {
-      const unsigned long long k64 = a.keys[idx];   // [S][L], Lp == L
-      lists[idx] = k64 ? (((KB_KEY_SCORE(k64) + 1u) << nb) | (nmaskbits - KB_KEY_NODE(k64))) : 0u;
-    }
-  }
   __syncthreads();
-  return true;
 }
 
 // ---------------- epilogue (all threads): dirty slots, decision records, task table, result words, host mirror ----------------
 // w6 / w7: result words 6 and 7 (0 in the run kernel; the selection kernel's statistics)
 __device__ __forceinline__ void k9_epilogue(const KbCommitArgs &a, const K9Layout &lo, unsigned char *k9_base_, const uint32_t tid, const unsigned long long t_start,
-                                            const uint32_t w6, const uint32_t w7, const unsigned long long t_lists = 0ull) {
+                                            const uint32_t w6, const uint32_t w7) {
   K9_LDS_VIEWS(lo)
   (void)rowres; (void)sinit; (void)shapes; (void)rinfo; (void)dk; (void)ckey; (void)cpos; (void)cursor; (void)shp; (void)lists; (void)bitmap; (void)RS; (void)Lp; (void)nb; (void)nmaskbits;
   const uint32_t n_done = H.i, nd = H.nd;
@@ -468,8 +441,6 @@ __device__ __forceinline__ void k9_epilogue(const KbCommitArgs &a, const K9Layou
     unsigned long long *st = reinterpret_cast<unsigned long long *>(a.result) + KB_OUT_STAMP0;
     st[2] = t_start;
     st[3] = wall_clock64();
-    // a round whose lists were repaired beside this launch: [0] .. [2] is what the round waited for them (the host books it as the lists' time)
-    if (t_lists != 0ull) { st[0] = t_start; st[2] = t_lists; }
   }
   // ---- fast rounds: mirror the header and the decision records into pinned host memory and publish the round's sequence
   //      number last; the host spins on that word instead of paying a stream synchronisation + D2H copy per round
@@ -507,6 +478,4 @@ static inline void k9_fill_args(K9KernArgs &ka, const KbDev &d, const KbRound &r
   a.seq = r.seq;
   a.node_bits = kb_node_bits(d.NP);
   a.prewalk = 0;
-  a.lists_ready = r.lists_ready;
-  a.lists_tag = r.lists_tag;
 }

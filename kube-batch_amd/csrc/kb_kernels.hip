@@ -468,9 +468,9 @@ __global__ void __launch_bounds__(KB_REPAIR_THREADS) k_repair(KbDev d, KbRound r
   __shared__ uint32_t s_wtot[KB_REPAIR_THREADS / 64];
   const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, row = blockIdx.x;
   if (KB_CHAIN_BROKEN(r)) return;
-  if (row == 0 && tid == 0) {   // this launch's own stamps (r.result: the second stream's stamp block; what the ROUND waits for its lists is the commit kernel's to say)
+  if (row == 0 && tid == 0) {   // the round's matrix / arg-max stamps: the candidate launches ran beside the predecessor, this is what the round waits for
     unsigned long long *st = reinterpret_cast<unsigned long long *>(r.result);
-    st[KB_OUT_STAMP0 + 2] = wall_clock64();
+    st[KB_OUT_STAMP0] = wall_clock64();   // [+1] follows when row 0's tag has been seen: "matrix" time of such a round = what it waited for its lists
   }
   // Latency is what this launch costs (it sits between two commit kernels): every load that does not depend on another is issued before the
   // first wait.  The predecessor's decision records are final (kernel boundary), so its nodes are fetched while thread 0 still looks for the tag.
@@ -490,6 +490,7 @@ __global__ void __launch_bounds__(KB_REPAIR_THREADS) k_repair(KbDev d, KbRound r
     }
     s_late = late;
     if (late && r.chain != nullptr) *r.chain = 0u;
+    if (row == 0) reinterpret_cast<unsigned long long *>(r.result)[KB_OUT_STAMP0 + 1] = wall_clock64();
   }
   __syncthreads();
   if (s_late) return;
@@ -561,14 +562,6 @@ __global__ void __launch_bounds__(KB_REPAIR_THREADS) k_repair(KbDev d, KbRound r
   for (int off = 32; off > 0; off >>= 1) cnt_fresh += (uint32_t)__shfl_xor((int)cnt_fresh, off);
   const uint32_t total = alive_before[KB_REPAIR_THREADS] + cnt_fresh;
   for (uint32_t i = total + tid; i < K; i += KB_REPAIR_THREADS) out[i] = 0ull;
-  if (r.lists_ready != nullptr) {   // the commit launch of this round runs beside this one and waits for the tag (kb_k9.hpp: k9_prologue)
-    __threadfence();
-    __syncthreads();
-    if (tid == 0) {
-      __hip_atomic_store(&r.lists_ready[row], r.lists_tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-      if (row == 0) reinterpret_cast<unsigned long long *>(r.result)[KB_OUT_STAMP0 + 3] = wall_clock64();
-    }
-  }
 }
 size_t kb_repair_smem_bytes(uint32_t NP) {
   return sizeof(unsigned long long) * (KB_REPAIR_THREADS + KB_K5_MAX_WINDOW) + sizeof(uint32_t) * (KB_REPAIR_THREADS + 1) + sizeof(uint32_t) * (NP / 32);

@@ -152,28 +152,6 @@ void emu_commit(const KbDev &d, const KbRound &r) {
     return;
   }
   const u64 t_start = kbemu_wall_clock();
-  u64 t_lists = 0;
-  if (r.lists_ready != nullptr) {   // the round's lists are repaired beside this launch (second stream): k9_prologue's bounded wait for the tags
-    bool gone = false;
-    for (uint32_t m = 0; m < r.n_mrows && !gone; m++) {
-      const double t0 = (double)kbemu_wall_clock();
-      while (__atomic_load_n(&r.lists_ready[m], __ATOMIC_ACQUIRE) != r.lists_tag) {
-        std::this_thread::yield();
-        if (r.chain_expect != 0u && __atomic_load_n(r.chain, __ATOMIC_RELAXED) != r.chain_expect) { gone = true; break; }   // the repair launch gave up on its stale lists
-        if ((double)kbemu_wall_clock() - t0 > 6.0e9) { gone = true; break; }
-      }
-    }
-    if (gone) {
-      *r.chain = 0u;
-      r.result[0] = 0; r.result[1] = KB_REASON_SKIPPED;
-      if (r.host_out) {
-        r.host_out[0] = (u64)KB_REASON_SKIPPED << 32;
-        __atomic_store_n(&r.host_out[KB_OUT_SEQ], r.seq, __ATOMIC_RELEASE);
-      }
-      return;
-    }
-    t_lists = kbemu_wall_clock();
-  }
   const bool has_aff = (d.aff != nullptr && d.score_enabled) || d.t_ip_subject != nullptr;
   const bool has_ports = d.ports != nullptr;
   const bool use_crow = d.pred_enabled && d.crows != nullptr && d.n_nc <= 32;
@@ -407,7 +385,6 @@ void emu_commit(const KbDev &d, const KbRound &r) {
   if (r.chain) *r.chain = reason == KB_REASON_DONE ? r.chain_tag : 0u;
   remember_commit_nodes(dirty_nodes);   // what an overlapped matrix launch may have seen half-changed (kb_launch_matrix poisons it)
   o64[KB_OUT_STAMP0 + 2] = t_start;
-  if (t_lists) { o64[KB_OUT_STAMP0] = t_start; o64[KB_OUT_STAMP0 + 2] = t_lists; }   // [0] .. [2]: what the round waited for its lists
   o64[KB_OUT_STAMP0 + 3] = kbemu_wall_clock();
   if (r.host_out) {   // fast rounds: header and decision records into the pinned mirror, the sequence number last
     for (uint32_t w = 0; w < KB_OUT_HDR; w++) if (w != KB_OUT_SEQ) r.host_out[w] = o64[w];
@@ -606,7 +583,8 @@ void kb_launch_argmax(const KbDev &d, const KbRound &r, void *stream) {
 static void emu_repair(const KbDev &d, const KbRound &r) {
   if (r.n_mrows == 0) return;
   if (KB_CHAIN_BROKEN(r)) return;
-  out64(r)[KB_OUT_STAMP0 + 2] = kbemu_wall_clock();   // (r.result: the second stream's stamp block)
+  out64(r)[KB_OUT_STAMP0] = kbemu_wall_clock();
+  out64(r)[KB_OUT_STAMP0 + 1] = out64(r)[KB_OUT_STAMP0];
   std::vector<uint32_t> prev;
   for (uint32_t i = 0; i < r.n_prev; i++) {
     const uint32_t n = (uint32_t)(r.prev_dec[i] & 0xFFFFFFFFull);
@@ -628,7 +606,6 @@ static void emu_repair(const KbDev &d, const KbRound &r) {
     if (getenv("KB_EMU_REPAIR_OFF")) {   // negative control: the stale list as it is (tests/test_emu_engine_cpu.py expects wrong decisions)
       u64 *o = r.keys + (size_t)m * r.L;
       for (uint32_t i = 0; i < r.L; i++) o[i] = st[i];
-      if (r.lists_ready) __atomic_store_n(&r.lists_ready[m], r.lists_tag, __ATOMIC_RELEASE);
       continue;
     }
     for (uint32_t i = 0; i < r.stale_L && st[i] != 0ull; i++)
@@ -640,9 +617,7 @@ static void emu_repair(const KbDev &d, const KbRound &r) {
     std::sort(keys.begin(), keys.end(), [](u64 a, u64 b) { return a > b; });
     u64 *out = r.keys + (size_t)m * r.L;
     for (uint32_t i = 0; i < r.L; i++) out[i] = i < keys.size() ? keys[i] : 0ull;
-    if (r.lists_ready) __atomic_store_n(&r.lists_ready[m], r.lists_tag, __ATOMIC_RELEASE);   // the commit launch of the round (first stream) waits for it
   }
-  out64(r)[KB_OUT_STAMP0 + 3] = kbemu_wall_clock();
 }
 size_t kb_repair_smem_bytes(uint32_t NP) { return 8 * (1024 + 1024) + 4 * 1025 + 4 * (size_t)(NP / 32); }
 void kb_launch_repair(const KbDev &d, const KbRound &r, void *stream) {

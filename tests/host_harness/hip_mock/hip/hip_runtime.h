@@ -31,7 +31,7 @@
 typedef int hipError_t;
 enum { hipSuccess = 0, hipErrorInvalidValue = 1, hipErrorOutOfMemory = 2 };
 typedef struct kbemu_stream *hipStream_t;
-typedef struct kbemu_event { double ms; unsigned long long recorded, done; } *hipEvent_t;   // recorded: records issued (host side); done: records executed (stream side)
+typedef struct kbemu_event { double ms; } *hipEvent_t;
 enum hipMemcpyKind { hipMemcpyHostToHost = 0, hipMemcpyHostToDevice = 1, hipMemcpyDeviceToHost = 2, hipMemcpyDeviceToDevice = 3, hipMemcpyDefault = 4 };
 enum { hipStreamNonBlocking = 1 };
 enum { hipHostMallocDefault = 0, hipHostMallocMapped = 2, hipHostMallocCoherent = 0x40000000 };
@@ -62,11 +62,8 @@ hipError_t hipExtStreamCreateWithCUMask(hipStream_t *s, uint32_t words, const ui
 hipError_t hipStreamDestroy(hipStream_t s);
 hipError_t hipStreamSynchronize(hipStream_t s);
 hipError_t hipEventCreate(hipEvent_t *e);
-enum { hipEventDisableTiming = 2 };
-static inline hipError_t hipEventCreateWithFlags(hipEvent_t *e, unsigned) { return hipEventCreate(e); }
 hipError_t hipEventDestroy(hipEvent_t e);
 hipError_t hipEventRecord(hipEvent_t e, hipStream_t s = nullptr);
-hipError_t hipStreamWaitEvent(hipStream_t s, hipEvent_t e, unsigned flags = 0);
 hipError_t hipEventElapsedTime(float *ms, hipEvent_t a, hipEvent_t b);
 
 // for device_emu.cpp: run `f` as the next piece of work of stream `s` (at once in the synchronous mode), wait for a stream

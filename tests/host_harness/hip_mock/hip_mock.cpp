@@ -203,17 +203,5 @@ hipError_t hipStreamSynchronize(hipStream_t s) { if (g_census.on) g_census.syncs
 
 hipError_t hipEventCreate(hipEvent_t *e) { *e = (hipEvent_t)calloc(1, sizeof(kbemu_event)); return hipSuccess; }
 hipError_t hipEventDestroy(hipEvent_t e) { drain_all(); free(e); return hipSuccess; }
-hipError_t hipEventRecord(hipEvent_t e, hipStream_t s) {
-  const unsigned long long ticket = __atomic_add_fetch(&e->recorded, 1ull, __ATOMIC_RELAXED);
-  kbemu_enqueue(s, [e, ticket]() { e->ms = kbemu_now_ms(); __atomic_store_n(&e->done, ticket, __ATOMIC_RELEASE); });
-  return hipSuccess;
-}
-// work queued on `s` behind this call starts only when the LAST record of `e` issued before it has executed on its stream
-hipError_t hipStreamWaitEvent(hipStream_t s, hipEvent_t e, unsigned) {
-  const unsigned long long ticket = __atomic_load_n(&e->recorded, __ATOMIC_RELAXED);
-  kbemu_enqueue(s, [e, ticket]() {
-    while (__atomic_load_n(&e->done, __ATOMIC_ACQUIRE) < ticket) std::this_thread::sleep_for(std::chrono::microseconds(20));
-  });
-  return hipSuccess;
-}
+hipError_t hipEventRecord(hipEvent_t e, hipStream_t s) { kbemu_enqueue(s, [e]() { e->ms = kbemu_now_ms(); }); return hipSuccess; }
 hipError_t hipEventElapsedTime(float *ms, hipEvent_t a, hipEvent_t b) { *ms = (float)(b->ms - a->ms); return hipSuccess; }
