@@ -78,7 +78,7 @@ def test_engine_equals_oracle_when_few_pods_are_subjects(oracle_mod, commit_kern
 
 
 @pytest.mark.parametrize("seed", range(150))
-def test_evict_actions_with_interpod_terms_equal_the_oracle(oracle_mod, seed):
+def test_evict_actions_with_interpod_terms_equal_the_oracle(oracle_mod, commit_kernel, seed):
     """preempt / reclaim in sessions with inter-pod (anti)affinity terms (actions/preempt/preempt.go:182 calls the same ssn.PredicateFn, i.e.
     plugins/predicates/predicates.go:249-262): the evict machine keeps the kb_interpod counts on the host (an eviction takes its victim out
     of the predicate's pod list, a Pipeline adds the preemptor with an empty Spec.NodeName, a discarded statement undoes both), puts them
@@ -86,12 +86,8 @@ def test_evict_actions_with_interpod_terms_equal_the_oracle(oracle_mod, seed):
     shares equal the oracle's.  Round 3 wrote it behind a switch; since its first device run (round 4) there is no switch and no refusal."""
     import test_gpu_preempt as gp
     from test_interpod_oracle_cpu import interpod_evict_case
-    try:
-        cfg, snap, order = interpod_evict_case(seed)
-    except (snapmod.UnsupportedSnapshot, ValueError):
-        return   # the generator drew a cluster the flattener refuses: nothing to compare (not an envelope skip: those are pinned)
-    if snap.interpod is None:
-        return   # no pod-affinity term drawn
+    cfg, snap, order = interpod_evict_case(seed)     # every one of the 150 seeds draws a cluster the flattener takes, with pod-affinity terms:
+    assert snap.interpod is not None                 # a seed that stops doing so fails here instead of passing with nothing compared
     gp._run_both(oracle_mod, cfg, snap, order, seed)
 
 
