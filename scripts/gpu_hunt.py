@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """One-off differential hunt on the GPU box, beyond the committed suite: engine vs oracle on many more seeds of the fuzz generator
-(tests/test_gpu_fuzz.py), the adversarial raw snapshots (tests/rawgen.py) and the inter-pod affinity clusters, under the three commit
+(tests/test_gpu_fuzz.py), the adversarial raw snapshots (tests/rawgen.py) and the inter-pod affinity clusters, under both commit
 kernels.  python scripts/gpu_hunt.py [seeds_fuzz] [seeds_raw] [seeds_interpod]   -> prints every divergence, exit code 1 if any.
 KB_HUNT_OFFSET=k shifts every seed range by k (fresh cases).  KB_HUNT_EMU=1 runs the same hunt WITHOUT a GPU against the engine's
 host side on the emulated device of tests/host_harness (tests/test_emu_engine_cpu.py): that hunts the host logic (speculation,
@@ -39,7 +39,7 @@ def compare(tag, cfg, snap, **ekw):
         o.run(["allocate", "backfill"])
     except RuntimeError:
         return "oracle-panic"
-    for k in ("batch", "run", "select"):
+    for k in ("run", "select"):
         os.environ["KB_COMMIT_KERNEL"] = k
         try:
             e = engine.Engine(cfg, **ekw)

@@ -8,7 +8,8 @@
 #            (scripts/summarize_profile.py r5_profile profiles/round5)
 #   suite    the whole -m gpu suite          bench   the default bench line and the single-configuration lines
 #   loads    kb_session_load: KB_LOAD_TRACE of configs 3, 4, 5 and the bench's load statistics
-#   scale    N in {1, 2} x {sessions, sharded} on whatever GPUs the box has (scripts/scale_curve.sh)
+#   scale    N in {1, 2, 4, 8} x {sessions, sharded} on whatever GPUs the box has (scripts/scale_curve.sh)
+#   final    the closing evidence: suite, profile (summarised on the box), bench lines, smoke, N = 2 plumbing over gloo
 set -uo pipefail
 cd "$(dirname "$0")/.."
 step="${1:-suite}"; shift || true
@@ -95,6 +96,23 @@ bench)
   ;;
 scale)
   bash scripts/scale_curve.sh "$out" 2>&1 | tee -a "$out/summary.txt"
+  ;;
+final)   # the round's closing evidence on the final tree: whole suite, rocprofv3 passes summarised ON THE BOX into profiles/round5 (so that the bench
+         # line below quotes them), the default bench and the single-configuration lines, smoke, the N = 2 plumbing of scripts/scale_curve.sh
+  timeout 1500 python -m pytest tests -q -m gpu -p no:cacheprovider > "$out/pytest_gpu.txt" 2>&1; echo "gpu suite rc=$? $(tail -1 "$out/pytest_gpu.txt")" | tee -a "$out/summary.txt"
+  bash scripts/gpu_r5.sh profile > "$out/profile_step.txt" 2>&1
+  python scripts/summarize_profile.py r5_profile profiles/round5 >> "$out/profile_step.txt" 2>&1
+  python scripts/trace_gaps.py gpurun_out/r5_profile/trace/bench_kernel_trace.csv 3 > "$out/gaps_config3.txt" 2>&1; head -12 "$out/gaps_config3.txt" | tee -a "$out/summary.txt"
+  timeout 600 python bench.py > "$out/bench_default.json" 2> "$out/bench_default.err"; echo "bench rc=$? $(ms "$out/bench_default.json")" | tee -a "$out/summary.txt"
+  python -c "import json; d=json.loads(open('$out/bench_default.json').read().strip().splitlines()[-1]); print(json.dumps({k: (v['ms_per_step'], v['verified']) for k, v in d['variants'].items()})); print('roofline', d['roofline']['frac'], d['roofline']['traffic'], d['roofline'].get('traffic_refused')); print('loads', d['session_load_ms_samples'])" | tee -a "$out/summary.txt"
+  bench_ab survey_nodes -- --config 3 --survey-nodes --steps 5 --warmup 2 --verify
+  bench_ab config4 -- --config 4 --steps 5 --warmup 2 --verify
+  bench_ab config2 -- --config 2 --steps 10 --warmup 3 --verify
+  bench_ab config5 -- --config 5 --steps 3 --warmup 1 --verify
+  bench_ab config5_preempt -- --config 5 --preempt --steps 2 --warmup 1 --verify
+  timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -1 | tee -a "$out/summary.txt"
+  KB_HUNT_OFFSET=${KB_HUNT_OFFSET:-50000} timeout 600 python scripts/gpu_hunt.py 200 600 300 > "$out/hunt.txt" 2>&1; echo "fresh-seed hunt (both kernels) rc=$? $(tail -1 "$out/hunt.txt")" | tee -a "$out/summary.txt"
+  KB_SCALE_GLOO=1 timeout 900 bash scripts/scale_curve.sh "$out/scale" 3 > "$out/scale_curve_log.txt" 2>&1; cat "$out/scale/scale_curve.txt" | tee -a "$out/summary.txt"
   ;;
 *) echo "unknown step $step"; exit 2 ;;
 esac
