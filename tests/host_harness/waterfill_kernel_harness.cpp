@@ -17,6 +17,7 @@ struct Idx { uint32_t x; };
 thread_local Idx threadIdx;
 pthread_barrier_t g_bar;
 inline unsigned atomicOr(unsigned *p, unsigned v) { return __atomic_fetch_or(p, v, __ATOMIC_RELAXED); }
+inline unsigned atomicAdd(unsigned *p, unsigned v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
 }  // namespace
 #define __shared__ static
 #define __align__(n) __attribute__((aligned(n)))
