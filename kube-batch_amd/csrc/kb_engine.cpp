@@ -96,8 +96,8 @@ template <typename T> struct Pinned {
 // std::vectors of this file —: the runtime pins such a source on the fly (or stages it, blocking) at every call, a per-call cost of
 // tens to hundreds of microseconds with a long tail, about thirty times per load, and upload_padded synchronised the stream behind each
 // of its eight temporaries.  A block stays valid until the next load resets the area, and a load ends behind a stream synchronisation.
-// Sources of 8 MiB and more (the task request vectors of a million-task session) skip the area: one pin per call is cheaper than the
-// extra pass over them, and HIP has consumed a pageable source when the call returns.
+// Sources of 8 MiB and more that outlive the load (the task vectors of a million-task session: Uploader::copy_persistent) skip the area: one pin
+// per call is cheaper than the extra pass over them.
 struct PinnedArena {
   struct Block { unsigned char *p; size_t cap; };
   std::vector<Block> blocks;
@@ -139,15 +139,21 @@ struct Uploader {
     if (pending_bytes) HIP_OK(hipMemcpyAsync(pending_dst, pending_src, pending_bytes, hipMemcpyHostToDevice, s));
     pending_bytes = 0;
   }
+  // any source: copied into the area first (the source may die before the load's synchronisation: block-scoped temporaries)
   template <typename T> void copy(DevBuf &b, const T *src, size_t n) {
+    T *p = stage<T>(b, n);
+    if (n) std::memcpy(p, src, n * sizeof(T));
+    commit();
+  }
+  // a source that outlives the load's synchronisation (the caller's snapshot, the host session's vectors): from 8 MiB on straight from where it
+  // lies — the runtime pins it for the transfer; one pin per call is cheaper than an extra pass over a million-task vector
+  template <typename T> void copy_persistent(DevBuf &b, const T *src, size_t n) {
     if (n * sizeof(T) >= kStageMaxBytes) {
       b.alloc(n * sizeof(T));
       HIP_OK(hipMemcpyAsync(b.p, src, n * sizeof(T), hipMemcpyHostToDevice, s));
       return;
     }
-    T *p = stage<T>(b, n);
-    if (n) std::memcpy(p, src, n * sizeof(T));
-    commit();
+    copy(b, src, n);
   }
   // rows of a [rows][n] host matrix into a padded [rows][np] device matrix (pad value `fill`)
   template <typename T> void padded(DevBuf &b, const T *src, size_t rows, size_t n, size_t np, T fill = T(0)) {
@@ -1317,7 +1323,7 @@ int kb_session_load(kb_engine *e, const kb_snapshot *sn) {
       ncls = p;
     }
     up.copy(e->b_nmask, nmask.data(), NP);
-    up.copy(e->b_tinit, hs.t_init.data(), (size_t)R * T);
+    up.copy_persistent(e->b_tinit, hs.t_init.data(), (size_t)R * T);
     {   // the backfill view of t_init: cpu / memory of a BestEffort task are its Resreq (scalar rows are never compared for
         // them: every InitResreq scalar is at or below the epsilon, resource_info.go:283-287)
       bool differs = false;
@@ -1333,15 +1339,15 @@ int kb_session_load(kb_engine *e, const kb_snapshot *sn) {
         e->t_fit = e->b_tinit.as<double>();
       }
     }
-    up.copy(e->b_tres, hs.t_res.data(), (size_t)R * T);
-    up.copy(e->b_tnzc, sn->task_nz_cpu, T);
-    up.copy(e->b_tnzm, sn->task_nz_mem, T);
-    up.copy(e->b_tcls, hs.t_cls.data(), T);
-    up.copy(e->b_tactive, t_active.data(), T);
-    up.copy(e->b_tresmask, hs.t_resmask.data(), T);
-    up.copy(e->b_tjob, hs.t_job.data(), T);
-    up.copy(e->b_tstatus, hs.t_status.data(), T);
-    up.copy(e->b_tnode, hs.t_node.data(), T);
+    up.copy_persistent(e->b_tres, hs.t_res.data(), (size_t)R * T);
+    up.copy_persistent(e->b_tnzc, sn->task_nz_cpu, T);
+    up.copy_persistent(e->b_tnzm, sn->task_nz_mem, T);
+    up.copy_persistent(e->b_tcls, hs.t_cls.data(), T);
+    up.copy_persistent(e->b_tactive, t_active.data(), T);
+    up.copy_persistent(e->b_tresmask, hs.t_resmask.data(), T);
+    up.copy_persistent(e->b_tjob, hs.t_job.data(), T);
+    up.copy_persistent(e->b_tstatus, hs.t_status.data(), T);
+    up.copy_persistent(e->b_tnode, hs.t_node.data(), T);
     e->b_tbind.alloc(sizeof(uint32_t) * (T ? T : 1));   // nothing is bound yet: KB_NONE everywhere, set on the device
     HIP_OK(hipMemsetAsync(e->b_tbind.p, 0xFF, sizeof(uint32_t) * (T ? T : 1), s));
     static_assert(KB_NONE == 0xFFFFFFFFu, "t_bind is cleared with a byte pattern");
@@ -1406,8 +1412,8 @@ int kb_session_load(kb_engine *e, const kb_snapshot *sn) {
           for (uint32_t w = 0; w < X; w++) nx[(size_t)w * NP + n] = sn->node_ports[(size_t)n * Wh + 1 + w];
         static_assert(sizeof(unsigned long long) == sizeof(uint64_t), "host-port words");
         up.copy(e->b_ports_x, nx.data(), nx.size());
-        up.copy(e->b_twant_x, reinterpret_cast<const unsigned long long *>(hs.t_want_x.data()), hs.t_want_x.size());
-        up.copy(e->b_tconf_x, reinterpret_cast<const unsigned long long *>(hs.t_conf_x.data()), hs.t_conf_x.size());
+        up.copy_persistent(e->b_twant_x, reinterpret_cast<const unsigned long long *>(hs.t_want_x.data()), hs.t_want_x.size());
+        up.copy_persistent(e->b_tconf_x, reinterpret_cast<const unsigned long long *>(hs.t_conf_x.data()), hs.t_conf_x.size());
         d.ports_x = e->b_ports_x.as<unsigned long long>();
         d.t_want_x = e->b_twant_x.as<unsigned long long>();
         d.t_conf_x = e->b_tconf_x.as<unsigned long long>();
@@ -1479,13 +1485,13 @@ int kb_session_load(kb_engine *e, const kb_snapshot *sn) {
       if (C) { std::memcpy(cc.data(), ip->ctr_count, sizeof(int32_t) * (size_t)C * D); std::memcpy(ct.data(), ip->ctr_total, sizeof(int32_t) * C); }
       up.copy(e->b_ip_ccnt, cc.data(), cc.size());
       up.copy(e->b_ip_ctot, ct.data(), ct.size());
-      up.copy(e->b_ip_tinc, ip->task_inc, (size_t)T * Wc);
-      up.copy(e->b_ip_tforbid, ip->task_forbid, (size_t)T * Wc);
+      up.copy_persistent(e->b_ip_tinc, ip->task_inc, (size_t)T * Wc);
+      up.copy_persistent(e->b_ip_tforbid, ip->task_forbid, (size_t)T * Wc);
       up.copy(e->b_ip_tchk, hs.t_ip_checks.data(), T);
       up.copy(e->b_ip_treq, ip->task_require, T);
       up.copy(e->b_ip_tself, ip->task_self, T);
       up.copy(e->b_ip_tsubj, hs.t_ip_subject.data(), T);
-      up.copy(e->b_ip_tcinc, ip->task_cls_inc, (size_t)T * Wp);
+      up.copy_persistent(e->b_ip_tcinc, ip->task_cls_inc, (size_t)T * Wp);
       up.copy(e->b_ip_tsig, ip->task_sig, T);
       std::vector<int32_t> sw((size_t)std::max(ip->n_sigs, 1u) * std::max(P, 1u), 0);
       if (ip->n_sigs && P) std::memcpy(sw.data(), ip->sig_weight, sizeof(int32_t) * (size_t)ip->n_sigs * P);
