@@ -79,8 +79,9 @@ struct Interner {
   size_t klen = 0;
   std::vector<double> keys;
   std::unordered_map<uint64_t, std::vector<uint32_t>> buckets;
-  uint32_t intern(const std::vector<double> &k) {
-    if (!klen) klen = k.size();
+  Interner() = default;
+  explicit Interner(size_t len) : klen(len) {}
+  uint32_t intern(const double *k) {
     uint64_t h = 0x9E3779B97F4A7C15ull;   // word-wise multiply-xorshift over the key's bit patterns
     for (size_t i = 0; i < klen; i++) {
       uint64_t w;
@@ -90,12 +91,17 @@ struct Interner {
     }
     std::vector<uint32_t> &ids = buckets[h];
     for (uint32_t id : ids)
-      if (std::memcmp(&keys[(size_t)id * klen], k.data(), klen * sizeof(double)) == 0) return id;
+      if (std::memcmp(&keys[(size_t)id * klen], k, klen * sizeof(double)) == 0) return id;
     const uint32_t id = (uint32_t)(keys.size() / klen);
-    keys.insert(keys.end(), k.begin(), k.end());
+    keys.insert(keys.end(), k, k + klen);
     ids.push_back(id);
     return id;
   }
+  uint32_t intern(const std::vector<double> &k) {
+    if (!klen) klen = k.size();
+    return intern(k.data());
+  }
+  const double *key(uint32_t id) const { return &keys[(size_t)id * klen]; }
   size_t size() const { return klen ? keys.size() / klen : 0; }
 };
 }  // namespace
@@ -106,17 +112,26 @@ struct Interner {
 // "same as its predecessor" test that lets nearly every task skip shape interning) are memory traffic worth splitting over a few host
 // threads.  fn(t0, t1) over disjoint ranges; small sessions stay on the calling thread.
 // `weight`: 8-byte words a pass touches per task (a pass over 16 resource dimensions of 100k tasks is as much memory as one over 2 dimensions of 800k)
-template <typename F> static void par_for(uint32_t T, uint32_t weight, F fn) {
+static uint32_t par_threads(uint32_t T, uint32_t weight) {
   const unsigned hw = std::thread::hardware_concurrency();
   // below ~2M words thread start-up and the remote cache lines it leaves behind cost more than the split saves (100k tasks x 2 dimensions on eight
   // threads: 3.7 -> 10 ms on the GPU box, round 4; 100k x 16 dimensions on one: 1.7 + 1.8 ms of the 11 ms load, round 5's first call)
-  const uint32_t nt = (uint64_t)T * weight < (1ull << 21) ? 1u : std::min<uint32_t>(8u, hw ? hw : 1u);
-  if (nt <= 1) { fn(0u, T); return; }
+  // KB_HOST_SPLIT_WORDS: the threshold, for the tests that hold the split passes to the one-thread passes on small sessions
+  uint64_t min_words = 1ull << 21;
+  if (const char *v = getenv("KB_HOST_SPLIT_WORDS")) min_words = strtoull(v, nullptr, 10);
+  return (uint64_t)T * weight < min_words ? 1u : std::min<uint32_t>(8u, hw ? hw : 1u);
+}
+// fn(i, t0, t1): part i of nt, the same ranges for the same (T, nt)
+template <typename F> static void par_parts(uint32_t T, uint32_t nt, F fn) {
+  if (nt <= 1) { fn(0u, 0u, T); return; }
   std::vector<std::thread> th;
   const uint32_t step = (T + nt - 1) / nt;
-  for (uint32_t i = 1; i < nt; i++) th.emplace_back([&, i] { fn(std::min(T, i * step), std::min(T, (i + 1) * step)); });
-  fn(0u, std::min(T, step));
+  for (uint32_t i = 1; i < nt; i++) th.emplace_back([&, i] { fn(i, std::min(T, i * step), std::min(T, (i + 1) * step)); });
+  fn(0u, 0u, std::min(T, step));
   for (auto &t : th) t.join();
+}
+template <typename F> static void par_for(uint32_t T, uint32_t weight, F fn) {
+  par_parts(T, par_threads(T, weight), [&](uint32_t, uint32_t a, uint32_t b) { fn(a, b); });
 }
 template <typename V, typename S> static void par_copy(V &dst, const S *src, size_t n) {   // dst := src[0..n), the destination's storage reused
   dst.resize(n);
@@ -232,7 +247,6 @@ void build_host_session(const kb_snapshot *sn, const Policy &pol, uint32_t NP, H
   t_active.assign(T, 3u);
   hs.t_res_empty.resize(T);
   hs.t_init_empty.resize(T);
-  Interner feas_ids, row_ids;
   // inter-pod (anti)affinity tables: validate what indexes device memory
   const kb_interpod *ip = sn->interpod;
   if (ip) {
@@ -280,8 +294,6 @@ void build_host_session(const kb_snapshot *sn, const Policy &pol, uint32_t NP, H
   // The tasks of a job are adjacent and nearly always identical in everything a shape depends on.  A task whose inputs equal its
   // predecessor's bit for bit (what the interner compares) takes over the predecessor's derived values; one whose key equals the
   // predecessor's takes its ids without a hash lookup.  Either way the ids are the ones a lookup would return.
-  std::vector<double> key, prev;
-  size_t prev_feas_len = 0;
   const uint32_t ipWc = ip ? (ip->n_counters ? (ip->n_counters + 63) / 64 : 1) : 0;
   auto same_bits = [](double a, double b) { return std::memcmp(&a, &b, sizeof(double)) == 0; };
   auto same_inputs_as_prev = [&](uint32_t t) {
@@ -298,95 +310,118 @@ void build_host_session(const kb_snapshot *sn, const Policy &pol, uint32_t NP, H
     }
     return true;
   };
-  // which tasks equal their predecessor: independent per task, so split over the host threads (the sequential pass below then only
-  // computes the others — a few per job — and copies forward)
+  // One pass over the tasks, split over the host threads: which tasks equal their predecessor bit for bit in everything a shape depends on (nearly
+  // all: the tasks of a job are adjacent and alike), and for the others — the stretch heads, a few per job — validation, the derived flags and the
+  // shape keys while their lines are in the cache.  ids are handed out in first-appearance order over the whole session, which reads sequential —
+  // but only the ORDER of distinct keys is: every part of the task range interns its own heads (part-local ids in part-local first-appearance
+  // order), the parts' distinct keys are then interned in part order (a key new to part i and absent from the parts before it meets the session's
+  // table exactly when one pass over all tasks would have met it), and the fill pass below maps local ids to session ids.
+  // One million tasks in 100k jobs: 8.5 ms of interning on one thread behind 2 ms of flags were the largest piece of a 21 ms load.
   std::vector<uint8_t> same_prev(T, 0);
-  {
-    std::atomic<int> bad_status{0};
-    par_for(T, 2u * (uint32_t)R + 4u, [&](uint32_t t0, uint32_t t1) {
-      for (uint32_t t = t0; t < t1; t++) {
-        if (hs.t_status[t] > KB_TASK_UNKNOWN) bad_status.store(1, std::memory_order_relaxed);
-        same_prev[t] = (t > 0 && same_inputs_as_prev(t)) ? 1 : 0;
-      }
-    });
-    if (bad_status.load()) throw EngineError(KB_E_INVALID, "bad task status");
-  }
-  mark("shapes: equal-to-predecessor flags");
-  uint32_t prev_feas_id = 0, prev_row_id = 0;
-  bool prev_valid = false;   // `prev` holds the key of the last task that was computed (the tasks in between equal it)
-  for (uint32_t t = 0; t < T; t++) {
-    if (same_prev[t]) continue;   // the predecessor passed every check below with these very values: filled in behind this loop
-    if (sn->task_nz_cpu[t] < 0 || sn->task_nz_mem[t] < 0 || sn->task_nz_cpu[t] >= (1ll << 48) || sn->task_nz_mem[t] >= (1ll << 48))
-      throw EngineError(KB_E_UNSUPPORTED, "task non-zero request out of the exact range");
-    Res rq, in;
-    rq.mask = hs.t_resmask[t];
-    for (int d = 0; d < R; d++) {
-      rq.v[d] = hs.t_res[(size_t)d * T + t];
-      in.v[d] = hs.t_init[(size_t)d * T + t];
-      if (rq.v[d] < 0 || in.v[d] < 0) throw EngineError(KB_E_INVALID, "negative request");
-      // api/pod_info.go:53-62: InitResreq = max(sum of containers, every init container) >= Resreq per dimension;
-      // without it ssn.Allocate's AddTask could fail after the status flip (session.go:243 vs :255)
-      if (in.v[d] < rq.v[d]) throw EngineError(KB_E_UNSUPPORTED, "InitResreq < Resreq");
-      if (d >= 2 && in.v[d] != 0.0) in.setk(d);
-      if (d >= 2 && in.v[d] > kMinMilliScalar) t_active[t] |= 1u << d;
-    }
-    in.mask |= rq.mask;
-    hs.t_res_empty[t] = res_is_empty(rq, R);
-    hs.t_init_empty[t] = res_is_empty(in, R);
-    key.assign(in.v, in.v + R);
-    // a BestEffort task is placed by backfill, whose only resource test is AddTask's Resreq.LessEqual(Idle)
-    // (api/node_info.go:161-167): its fit vector is Resreq cpu / memory (non-zero below the epsilon at most), see t_fit below
-    key.push_back(hs.t_init_empty[t] ? rq.v[0] : -1.0);
-    key.push_back(hs.t_init_empty[t] ? rq.v[1] : -1.0);
-    key.push_back((double)hs.t_cls[t]);
-    size_t feas_len = 0;
-    bool same_feas = false;
-    {   // host ports: the conflict mask is part of feasibility, the wanted bits of what a commit changes
-      const uint64_t conf = sn->task_port_conflict ? sn->task_port_conflict[(size_t)t * Wh] : 0, want = sn->task_port_want ? sn->task_port_want[(size_t)t * Wh] : 0;
-      key.push_back((double)(uint32_t)(conf & 0xFFFFFFFFu)); key.push_back((double)(uint32_t)(conf >> 32));
-      for (uint32_t w = 0; w < hs.port_xw; w++) {   // the words behind the first
-        const uint64_t cx = hs.t_conf_x[(size_t)t * hs.port_xw + w];
-        key.push_back((double)(uint32_t)(cx & 0xFFFFFFFFu)); key.push_back((double)(uint32_t)(cx >> 32));
-      }
-      if (ip) {   // inter-pod predicate checks are part of feasibility
-        const uint32_t Wc = ip->n_counters ? (ip->n_counters + 63) / 64 : 1;
-        for (uint32_t w = 0; w < Wc; w++) {
-          const uint64_t fb = ip->task_forbid[(size_t)t * Wc + w];
-          key.push_back((double)(uint32_t)(fb & 0xFFFFFFFFu)); key.push_back((double)(uint32_t)(fb >> 32));
-        }
-        key.push_back((double)ip->task_require[t]); key.push_back((double)(ip->task_require[t] != 0xFFFF ? ip->task_self[t] : 0));
-      }
-      feas_len = key.size();
-      same_feas = prev_valid && prev_feas_len == feas_len && std::memcmp(prev.data(), key.data(), feas_len * sizeof(double)) == 0;
-      hs.t_feas_shape[t] = same_feas ? prev_feas_id : feas_ids.intern(key);
-      key.push_back((double)(uint32_t)(want & 0xFFFFFFFFu)); key.push_back((double)(uint32_t)(want >> 32));
-      for (uint32_t w = 0; w < hs.port_xw; w++) {
-        const uint64_t wx = hs.t_want_x[(size_t)t * hs.port_xw + w];
-        key.push_back((double)(uint32_t)(wx & 0xFFFFFFFFu)); key.push_back((double)(uint32_t)(wx >> 32));
-      }
-    }
-    key.push_back((double)sn->task_nz_cpu[t]);
-    key.push_back((double)sn->task_nz_mem[t]);
-    if (ip) key.push_back((double)ip->task_sig[t]);   // ... and the priority weights of the score row
-    const bool same_row = same_feas && prev.size() == key.size() &&
-                          std::memcmp(prev.data() + feas_len, key.data() + feas_len, (key.size() - feas_len) * sizeof(double)) == 0;
-    hs.t_row_shape[t] = same_row ? prev_row_id : row_ids.intern(key);
-    prev.swap(key);
-    prev_feas_len = feas_len;
-    prev_valid = true; prev_feas_id = hs.t_feas_shape[t]; prev_row_id = hs.t_row_shape[t];
-  }
-  mark("shapes: stretch heads (validation, interning)");
-  // the tasks that equal their predecessor take the values of the head of their stretch (every head is final now): ranges over the threads
-  par_for(T, 4u, [&](uint32_t t0, uint32_t t1) {
-    uint32_t h = t0;
-    while (h > 0 && same_prev[h]) h--;   // the head my first tasks belong to
+  std::atomic<int> bad_status{0};
+  const size_t feas_len = (size_t)R + 3 + 2 + 2 * (size_t)hs.port_xw + (ip ? 2 * (size_t)ipWc + 2 : 0);
+  const size_t klen = feas_len + 2 + 2 * (size_t)hs.port_xw + 2 + (ip ? 1 : 0);
+  struct HeadPart {
+    std::vector<uint32_t> heads, lf, lr;   // the part's heads and their part-local feasibility / row shape ids
+    Interner feas, row;
+    std::vector<uint32_t> gf, gr;          // part-local id -> session id
+    int err = 0;                           // the part's first refusal (its lowest task)
+    const char *msg = nullptr;
+  };
+  const uint32_t nt_heads = par_threads(T, 2u * (uint32_t)R + 4u);
+  std::vector<HeadPart> parts(nt_heads);
+  par_parts(T, nt_heads, [&](uint32_t pi, uint32_t t0, uint32_t t1) {
+    HeadPart &P = parts[pi];
+    P.feas = Interner(feas_len); P.row = Interner(klen);
+    std::vector<double> kbuf(klen), pbuf(klen);
+    double *key = kbuf.data(), *prev = pbuf.data();
+    bool prev_valid = false;   // `prev` holds the key of the part's last head
+    uint32_t prev_f = 0, prev_r = 0;
     for (uint32_t t = t0; t < t1; t++) {
-      if (!same_prev[t]) { h = t; continue; }
+      if (hs.t_status[t] > KB_TASK_UNKNOWN) bad_status.store(1, std::memory_order_relaxed);
+      same_prev[t] = (t > 0 && same_inputs_as_prev(t)) ? 1 : 0;
+      if (same_prev[t] || P.err) continue;   // its head passed every check below with these very values (filled in behind this pass); a part reports its first refusal
+      if (sn->task_nz_cpu[t] < 0 || sn->task_nz_mem[t] < 0 || sn->task_nz_cpu[t] >= (1ll << 48) || sn->task_nz_mem[t] >= (1ll << 48)) {
+        P.err = KB_E_UNSUPPORTED; P.msg = "task non-zero request out of the exact range"; continue;
+      }
+      Res rq, in;
+      rq.mask = hs.t_resmask[t];
+      uint32_t active = 3u;
+      for (int d = 0; d < R; d++) {
+        rq.v[d] = hs.t_res[(size_t)d * T + t];
+        in.v[d] = hs.t_init[(size_t)d * T + t];
+        if (rq.v[d] < 0 || in.v[d] < 0) { P.err = KB_E_INVALID; P.msg = "negative request"; break; }
+        // api/pod_info.go:53-62: InitResreq = max(sum of containers, every init container) >= Resreq per dimension;
+        // without it ssn.Allocate's AddTask could fail after the status flip (session.go:243 vs :255)
+        if (in.v[d] < rq.v[d]) { P.err = KB_E_UNSUPPORTED; P.msg = "InitResreq < Resreq"; break; }
+        if (d >= 2 && in.v[d] != 0.0) in.setk(d);
+        if (d >= 2 && in.v[d] > kMinMilliScalar) active |= 1u << d;
+      }
+      if (P.err) continue;
+      t_active[t] = active;
+      in.mask |= rq.mask;
+      hs.t_res_empty[t] = res_is_empty(rq, R);
+      hs.t_init_empty[t] = res_is_empty(in, R);
+      double *k = key;
+      auto put64 = [&k](uint64_t w) { *k++ = (double)(uint32_t)(w & 0xFFFFFFFFu); *k++ = (double)(uint32_t)(w >> 32); };
+      for (int d = 0; d < R; d++) *k++ = in.v[d];
+      // a BestEffort task is placed by backfill, whose only resource test is AddTask's Resreq.LessEqual(Idle)
+      // (api/node_info.go:161-167): its fit vector is Resreq cpu / memory (non-zero below the epsilon at most), see t_fit below
+      *k++ = hs.t_init_empty[t] ? rq.v[0] : -1.0;
+      *k++ = hs.t_init_empty[t] ? rq.v[1] : -1.0;
+      *k++ = (double)hs.t_cls[t];
+      // host ports: the conflict mask is part of feasibility, the wanted bits of what a commit changes
+      put64(sn->task_port_conflict ? sn->task_port_conflict[(size_t)t * Wh] : 0);
+      for (uint32_t w = 0; w < hs.port_xw; w++) put64(hs.t_conf_x[(size_t)t * hs.port_xw + w]);   // the words behind the first
+      if (ip) {   // inter-pod predicate checks are part of feasibility
+        for (uint32_t w = 0; w < ipWc; w++) put64(ip->task_forbid[(size_t)t * ipWc + w]);
+        *k++ = (double)ip->task_require[t];
+        *k++ = (double)(ip->task_require[t] != 0xFFFF ? ip->task_self[t] : 0);
+      }
+      put64(sn->task_port_want ? sn->task_port_want[(size_t)t * Wh] : 0);
+      for (uint32_t w = 0; w < hs.port_xw; w++) put64(hs.t_want_x[(size_t)t * hs.port_xw + w]);
+      *k++ = (double)sn->task_nz_cpu[t];
+      *k++ = (double)sn->task_nz_mem[t];
+      if (ip) *k++ = (double)ip->task_sig[t];   // ... and the priority weights of the score row
+      // a head whose key equals the last head's takes its ids without a hash lookup
+      const bool same_feas = prev_valid && std::memcmp(prev, key, feas_len * sizeof(double)) == 0;
+      const uint32_t f = same_feas ? prev_f : P.feas.intern(key);
+      const bool same_row = same_feas && std::memcmp(prev + feas_len, key + feas_len, (klen - feas_len) * sizeof(double)) == 0;
+      const uint32_t r = same_row ? prev_r : P.row.intern(key);
+      P.heads.push_back(t); P.lf.push_back(f); P.lr.push_back(r);
+      std::swap(key, prev);
+      prev_valid = true; prev_f = f; prev_r = r;
+    }
+  });
+  if (bad_status.load()) throw EngineError(KB_E_INVALID, "bad task status");
+  for (const HeadPart &P : parts)   // parts in task order, each stopped at its first refusal: the lowest task's, as one pass over all tasks reports it
+    if (P.err) throw EngineError(P.err, P.msg);
+  Interner feas_ids(feas_len), row_ids(klen);
+  for (HeadPart &P : parts) {
+    P.gf.resize(P.feas.size()); P.gr.resize(P.row.size());
+    for (uint32_t i = 0; i < P.gf.size(); i++) P.gf[i] = feas_ids.intern(P.feas.key(i));
+    for (uint32_t i = 0; i < P.gr.size(); i++) P.gr[i] = row_ids.intern(P.row.key(i));
+  }
+  mark("shapes: equal-to-predecessor flags, stretch heads (validation, interning)");
+  // session ids for the heads, and the tasks that equal their predecessor take the values of the head of their stretch: the same parts
+  par_parts(T, nt_heads, [&](uint32_t pi, uint32_t t0, uint32_t t1) {
+    const HeadPart &P = parts[pi];
+    for (size_t i = 0; i < P.heads.size(); i++) { hs.t_feas_shape[P.heads[i]] = P.gf[P.lf[i]]; hs.t_row_shape[P.heads[i]] = P.gr[P.lr[i]]; }
+    if (t0 >= t1) return;
+    uint32_t h = t0, hf = 0, hr = 0;
+    if (same_prev[t0]) {   // my first tasks continue a stretch whose head lies in a part before mine: its ids through that part's maps (its owner may not have stored them yet)
+      uint32_t q = pi;
+      while (q > 0 && parts[q - 1].heads.empty()) q--;
+      const HeadPart &B = parts[q - 1];   // task 0 is a head: some part before mine holds one
+      h = B.heads.back(); hf = B.gf[B.lf.back()]; hr = B.gr[B.lr.back()];
+    }
+    for (uint32_t t = t0; t < t1; t++) {
+      if (!same_prev[t]) { h = t; hf = hs.t_feas_shape[t]; hr = hs.t_row_shape[t]; continue; }
       t_active[t] = t_active[h];
       hs.t_res_empty[t] = hs.t_res_empty[h];
       hs.t_init_empty[t] = hs.t_init_empty[h];
-      hs.t_feas_shape[t] = hs.t_feas_shape[h];
-      hs.t_row_shape[t] = hs.t_row_shape[h];
+      hs.t_feas_shape[t] = hf;
+      hs.t_row_shape[t] = hr;
     }
   });
   mark("shapes: stretches filled in");
@@ -464,7 +499,7 @@ void build_host_session(const kb_snapshot *sn, const Policy &pol, uint32_t NP, H
   hs.queue_has_attr.assign(Q, 0);
   std::vector<Res> request(Q);
   for (uint32_t j = 0; j < J; j++) {
-    uint32_t q = hs.job_queue[j];
+    const uint32_t q = hs.job_queue[j];
     if (q >= Q) {
       // allocate / preempt / reclaim skip such a job ("queue not found", allocate.go:56-60) but proportion's OnSessionOpen reads
       // ssn.Queues[job.Queue].UID for every job (proportion.go:70-73): with the plugin loaded the reference panics on the nil queue
@@ -472,19 +507,55 @@ void build_host_session(const kb_snapshot *sn, const Policy &pol, uint32_t NP, H
       continue;
     }
     hs.queue_has_attr[q] = 1;
-    for (uint32_t t = hs.job_begin[j]; t < hs.job_begin[j + 1]; t++) {
-      int st = hs.t_status[t];
-      bool alloc_st = st == KB_TASK_BOUND || st == KB_TASK_BINDING || st == KB_TASK_RUNNING || st == KB_TASK_ALLOCATED;
-      if (!alloc_st && st != KB_TASK_PENDING) continue;
-      // Resource.Add (resource_info.go:128-140), task by task in this order: cpu and memory always, a scalar where the task has the key
-      Res &rq = request[q];
-      rq.v[0] += hs.t_res[t];
-      rq.v[1] += hs.t_res[(size_t)T + t];
-      const uint32_t m = hs.t_resmask[t];
-      for (int d = 2; m != 0 && d < R; d++)
-        if ((m >> (d - 2)) & 1u) { rq.setk(d); rq.v[d] += hs.t_res[(size_t)d * T + t]; }
-    }
   }
+  // Resource.Add (resource_info.go:128-140) of every allocated-status or Pending task's Resreq onto its queue's request, job by job, task by
+  // task: cpu and memory always, a scalar where the task has the key.  `whole`: every addend a whole number below 2^53
+  auto add_jobs = [&](uint32_t j0, uint32_t j1, std::vector<Res> &req, bool *whole) {
+    auto is_whole = [](double v) { return v < 9007199254740992.0 && (double)(long long)v == v; };   // requests are >= 0 here (validated above); NaN fails the first test
+    bool w = true;
+    for (uint32_t j = j0; j < j1; j++) {
+      const uint32_t q = hs.job_queue[j];
+      if (q >= Q) continue;
+      Res &rq = req[q];
+      for (uint32_t t = hs.job_begin[j]; t < hs.job_begin[j + 1]; t++) {
+        const int st = hs.t_status[t];
+        const bool alloc_st = st == KB_TASK_BOUND || st == KB_TASK_BINDING || st == KB_TASK_RUNNING || st == KB_TASK_ALLOCATED;
+        if (!alloc_st && st != KB_TASK_PENDING) continue;
+        const double c = hs.t_res[t], mm = hs.t_res[(size_t)T + t];
+        rq.v[0] += c;
+        rq.v[1] += mm;
+        w = w && is_whole(c) && is_whole(mm);
+        const uint32_t m = hs.t_resmask[t];
+        for (int d = 2; m != 0 && d < R; d++)
+          if ((m >> (d - 2)) & 1u) { const double x = hs.t_res[(size_t)d * T + t]; rq.setk(d); rq.v[d] += x; w = w && is_whole(x); }
+      }
+    }
+    if (whole) *whole = w;
+  };
+  // The sums are floating point and their order is the reference's — except when it cannot matter: whole numbers whose total stays below
+  // 2^53 (milli-cpu, bytes, milli-units of extended resources) add without rounding in ANY order, so ranges of jobs are summed on the host
+  // threads and combined; anything else (a fractional quantity, a total at or beyond 2^53) takes the one pass in order.
+  const uint32_t nt_req = par_threads(T, 2u * (uint32_t)R + 2u);
+  bool summed = false;
+  if (nt_req > 1) {
+    std::vector<std::vector<Res>> part(nt_req, std::vector<Res>(Q));
+    std::vector<uint8_t> whole(nt_req, 0);
+    par_parts(J, nt_req, [&](uint32_t i, uint32_t j0, uint32_t j1) { bool w = false; add_jobs(j0, j1, part[i], &w); whole[i] = w ? 1 : 0; });
+    bool exact = true;
+    for (uint32_t i = 0; i < nt_req; i++) exact = exact && whole[i];
+    std::vector<Res> sum(Q);
+    for (uint32_t q = 0; q < Q && exact; q++)
+      for (uint32_t i = 0; i < nt_req && exact; i++) {
+        sum[q].mask |= part[i][q].mask;
+        for (int d = 0; d < R; d++) {
+          exact = exact && part[i][q].v[d] < 9007199254740992.0;   // a part's total below 2^53: none of its partial sums was rounded
+          sum[q].v[d] += part[i][q].v[d];
+          exact = exact && sum[q].v[d] < 9007199254740992.0;
+        }
+      }
+    if (exact) { request.swap(sum); summed = true; }
+  }
+  if (!summed) add_jobs(0, J, request, nullptr);
   mark("total, per-queue request");
   hs.queue_share_at_open = 1;
   hs.queue_request = request;

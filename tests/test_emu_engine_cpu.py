@@ -542,6 +542,98 @@ def test_the_device_waterfill_on_the_tutorial_example_and_on_128_queues(emulated
     e.close()
 
 
+# ---- kb_session_load's host passes split over threads (kb_session.cpp par_parts) against the same passes on one thread ------------------------
+def _session_tables(cfg, snap):
+    """(error code, None) or (None, everything a cycle shows of the session: decisions, bind set, node state, shares, counters — the counters
+    carry the number of distinct shapes, the matrix rows evaluated per shape id)"""
+    e = engine.Engine(cfg)
+    try:
+        e.load(snap)
+    except engine.EngineError as err:
+        e.close()
+        return (err.code, str(err)), None
+    try:
+        dec = e.run(["allocate", "backfill"])
+    except engine.EngineError as err:                    # outside the exact envelope at run time: the same refusal either way
+        e.close()
+        return None, ("run", err.code, str(err))
+    st = e.stats()
+    out = (dec, e.binds(), e.node_state(), e.shares(), tuple(sorted((k, v) for k, v in st.items() if isinstance(v, int))))
+    e.close()
+    return None, out
+
+
+@pytest.mark.parametrize("block", range(4))
+def test_session_build_split_over_host_threads_is_the_one_thread_build(emulated_engine, monkeypatch, block):
+    """The stretch heads are interned per part of the task range and the parts' distinct keys merged in part order; the per-queue request is summed
+    per range of jobs when every addend is a whole number.  KB_HOST_SPLIT_WORDS=1 forces eight parts on sessions of a few dozen tasks (parts
+    without a head, stretches across part borders, parts of one task): the same refusal (code AND text: the lowest task's) or the same cycle
+    bit for bit, counters included, as the one-thread passes — on tests/rawgen.py's snapshots (fractional quantities, nil scalar maps, zero
+    weights, invalid inputs)."""
+    import rawgen
+    import test_pyref_vs_oracle as cases
+    cfg = kbm.conf.load_scheduler_conf(cases.CONF_TMPL.format(wl=1, wm=0, wa=1, wb=1))
+    compared = refused = 0
+    for seed in range(block * 40, block * 40 + 40):
+        snap = rawgen.raw_snapshot(seed)
+        monkeypatch.setenv("KB_HOST_SPLIT_WORDS", str(1 << 40))
+        one = _session_tables(cfg, snap)
+        monkeypatch.setenv("KB_HOST_SPLIT_WORDS", "1")
+        split = _session_tables(cfg, snap)
+        monkeypatch.delenv("KB_HOST_SPLIT_WORDS")
+        assert one[0] == split[0], (seed, one[0], split[0])
+        if one[0] is None:
+            assert _same(one[1], split[1]), seed
+            compared += 0 if isinstance(one[1][0], str) else 1
+        else:
+            refused += 1
+    assert compared >= 10, (compared, refused)
+
+
+def test_split_session_build_on_scaled_configurations_and_the_lowest_refusal(emulated_engine, monkeypatch, oracle_mod):
+    """Scaled BASELINE configurations (R = 2 and R = 16, inter-pod terms, host-port masks of several words) through the split build against the
+    ORACLE; a fractional request and a total at 2^53 (both take the in-order sum); two invalid tasks in different parts (the lower one's
+    refusal, as one pass over all tasks reports it)."""
+    import test_gpu_interpod as gi
+    import test_gpu_wideports as gw
+    snapmod = kbm.snapshot
+    monkeypatch.setenv("KB_HOST_SPLIT_WORDS", "1")
+    cfg = kbm.conf.load_scheduler_conf()
+    snaps = [snapmod.synth(snapmod.synth_config(3, 0.03)), snapmod.synth(snapmod.synth_config(4, 0.02))]
+    frac = snapmod.synth(snapmod.synth_config(3, 0.02))
+    frac.task_resreq[0, 5::7] += 0.5; frac.task_init_resreq[0, 5::7] += 0.5          # half a milli-cpu: not a whole number
+    huge = snapmod.synth(snapmod.synth_config(3, 0.02))
+    pend = np.nonzero(huge.task_status == 0)[0][:64]
+    huge.task_resreq[1, pend] = float(1 << 47); huge.task_init_resreq[1, pend] = float(1 << 47)   # 64 x 2^47 = 2^53 bytes on the queues' requests
+    snaps += [frac, huge]
+    for snap in snaps:
+        o = oracle_mod.Oracle(cfg, snap)
+        o.run(["allocate", "backfill"])
+        e = engine.Engine(cfg)
+        e.load(snap)
+        dec = e.run(["allocate", "backfill"])
+        assert np.array_equal(dec, o.decisions()) and np.array_equal(e.binds(), o.binds())
+        for a, b in zip(e.shares(), o.shares()):
+            assert np.array_equal(a, b)
+        for a, b in zip(e.node_state(), o.node_state()):
+            assert np.array_equal(a, b)
+        e.close()
+    bad = snapmod.synth(snapmod.synth_config(3, 0.02))
+    T = bad.task_resreq.shape[1]
+    heads = np.nonzero(np.diff(bad.task_job.astype(np.int64), prepend=-1))[0]
+    lo, hi = int(heads[1]), int(heads[-2])
+    assert lo < T // 8 and hi > 7 * T // 8
+    bad.task_init_resreq[0, lo] = bad.task_resreq[0, lo] - 1.0       # "InitResreq < Resreq" in the first part
+    bad.task_resreq[1, hi] = -5.0                                    # "negative request" in the last
+    for words in ("1", str(1 << 40)):
+        monkeypatch.setenv("KB_HOST_SPLIT_WORDS", words)
+        e = engine.Engine(cfg)
+        with pytest.raises(engine.EngineError) as ei:
+            e.load(bad)
+        assert "InitResreq < Resreq" in str(ei.value), (words, str(ei.value))
+        e.close()
+
+
 # ---- DESIGN section 9.2: a run of identical rows committed by ONE selection (the emulated commit launch, KB_EMU_RUN_SELECT=1) ------------------
 _RUN_SELECT_SCRIPT = r"""
 import importlib, os, sys
