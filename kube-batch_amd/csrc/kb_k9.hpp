@@ -298,17 +298,33 @@ __device__ __forceinline__ void k9_prologue(const KbCommitArgs &a, const K9Layou
   K9_LDS_VIEWS(lo)
   (void)slots; (void)rowres; (void)ldec; (void)dk; (void)ckey; (void)cpos; (void)RS;
   for (uint32_t w = tid; w < a.NP / 32; w += K9_THREADS) bitmap[w] = 0;
-  {   // candidate lists: 64-bit keys of K3 -> compact 32-bit keys
-    const uint32_t tot = S * Lp;
-    for (uint32_t idx = tid; idx < tot; idx += K9_THREADS) {
-      const unsigned long long k64 = a.keys[idx];   // [S][L], Lp == L
-      lists[idx] = k64 ? (((KB_KEY_SCORE(k64) + 1u) << nb) | (nmaskbits - KB_KEY_NODE(k64))) : 0u;
+  {   // candidate lists (64-bit keys of K3 -> compact 32-bit keys) and row descriptors.  Every load of a thread is issued before the first one is
+      // waited for: with one load per loop iteration, each waited for, a thread made 13 + 4 round trips to L2 / HBM one after the other at
+      // 25 shapes x 257 entries and 256 rows — in front of every round, with nothing else on the CU to hide them
+    constexpr uint32_t UD = 4, UL = 16;
+    const unsigned long long *dsrc = reinterpret_cast<const unsigned long long *>(a.desc);
+    unsigned long long *ddst = reinterpret_cast<unsigned long long *>(desc);
+    const uint32_t dwords = W * (uint32_t)(sizeof(KbRowDesc) / 8), tot = S * Lp;   // [S][L], Lp == L
+    for (uint32_t dbase = 0, lbase = 0; dbase < dwords || lbase < tot; dbase += K9_THREADS * UD, lbase += K9_THREADS * UL) {
+      unsigned long long dv[UD] = {}, lv[UL] = {};
+      const bool more_d = dbase < dwords, more_l = lbase < tot;   // (uniform; the loads inside are clamped, not predicated)
+      if (more_d) {
+#pragma unroll
+        for (uint32_t u = 0; u < UD; u++) dv[u] = dsrc[min(dbase + u * K9_THREADS + tid, dwords - 1u)];
+      }
+      if (more_l) {
+#pragma unroll
+        for (uint32_t u = 0; u < UL; u++) lv[u] = a.keys[min(lbase + u * K9_THREADS + tid, tot - 1u)];
+      }
+#pragma unroll
+      for (uint32_t u = 0; u < UD; u++) { const uint32_t w = dbase + u * K9_THREADS + tid; if (w < dwords) ddst[w] = dv[u]; }
+#pragma unroll
+      for (uint32_t u = 0; u < UL; u++) {
+        const uint32_t idx = lbase + u * K9_THREADS + tid;
+        const unsigned long long k64 = lv[u];
+        if (idx < tot) lists[idx] = k64 ? (((KB_KEY_SCORE(k64) + 1u) << nb) | (nmaskbits - KB_KEY_NODE(k64))) : 0u;
+      }
     }
-  }
-  {   // row descriptors
-    const unsigned long long *src = reinterpret_cast<const unsigned long long *>(a.desc);
-    unsigned long long *dst = reinterpret_cast<unsigned long long *>(desc);
-    for (uint32_t w = tid; w < W * (uint32_t)(sizeof(KbRowDesc) / 8); w += K9_THREADS) dst[w] = src[w];
   }
   for (uint32_t s = tid; s < S; s += K9_THREADS) cursor[s] = 0;
   if (tid == 0) { H.i = 0; H.nd = 0; H.reason = KB_REASON_DONE; H.stop = 0; H.ncand = 0; H.n_dirty_rows = 0; H.n_runs = 0; H.n_slow = 0; H.cur_s = 0; H.cur_r = 0; H.cur_fl = 0; H.cur_km = 0; }
@@ -355,6 +371,17 @@ __device__ __forceinline__ void k9_epilogue(const KbCommitArgs &a, const K9Layou
   K9_LDS_VIEWS(lo)
   (void)rowres; (void)sinit; (void)shapes; (void)rinfo; (void)dk; (void)ckey; (void)cpos; (void)cursor; (void)shp; (void)lists; (void)bitmap; (void)RS; (void)Lp; (void)nb; (void)nmaskbits;
   const uint32_t n_done = H.i, nd = H.nd;
+  // Loads whose result is wanted further down, issued in front of the write-back so that their round trips run beside it: the header words
+  // earlier launches of the round left in the result block (its matrix / arg-max stamps; the mirror below copies the block), and the job of
+  // "my" committed row (n_done <= the window < the workgroup: one row per thread).  The words this kernel writes itself reach the mirror through LDS
+  // (mh: the last two slots, beyond every dirty slot) instead of a read-back from global memory behind the barrier.
+  const unsigned long long *hdr = reinterpret_cast<const unsigned long long *>(a.result);
+  unsigned long long *mh = slots + (size_t)(a.n_rows + K9_MAXRUN - 2u) * K9_NF;   // (2 * K9_NF >= KB_OUT_HDR words)
+  static_assert(2u * K9_NF >= KB_OUT_HDR, "the header's LDS copy lives in two slots");
+  unsigned long long hpre = 0ull;
+  if (a.host_out && tid < KB_OUT_HDR) hpre = hdr[tid];
+  uint32_t my_job = 0u;
+  if (tid < n_done) my_job = a.dev->t_job[desc[tid].task];
   {   // the dirty nodes' live state back to HBM
     const KbDev &d = *a.dev;
     for (uint32_t slot = tid; slot < nd; slot += K9_THREADS) {
@@ -386,7 +413,7 @@ __device__ __forceinline__ void k9_epilogue(const KbCommitArgs &a, const K9Layou
       d.t_status[t] = kind ? KB_TASK_PIPELINED : KB_TASK_ALLOCATED;
       d.t_node[t] = n;
       d.t_counted[t] = 1;
-      if (!kind) d.j_allocated[d.t_job[t]] = 1;   // ssn.Allocate ran for the job: its Allocated tasks are dispatched if it is ready
+      if (!kind) d.j_allocated[i == tid ? my_job : d.t_job[t]] = 1;   // ssn.Allocate ran for the job: its Allocated tasks are dispatched if it is ready
       if (d.t_ip_cls_inc) {   // inter-pod affinity: the pod joins ni.Tasks of its node and, when Allocated, the PodLister's allocated set
         for (uint32_t w = 0; w < d.ip_Wp; w++) {
           unsigned long long cm = d.t_ip_cls_inc[(size_t)t * d.ip_Wp + w];
@@ -439,15 +466,22 @@ __device__ __forceinline__ void k9_epilogue(const KbCommitArgs &a, const K9Layou
     a.result[4] = H.n_runs; a.result[5] = H.n_slow; a.result[6] = w6; a.result[7] = w7;
     if (a.round->chain) *a.round->chain = H.reason == KB_REASON_DONE ? a.round->chain_tag : 0u;   // the round queued behind this one runs only then
     unsigned long long *st = reinterpret_cast<unsigned long long *>(a.result) + KB_OUT_STAMP0;
+    const unsigned long long t_end = wall_clock64();
     st[2] = t_start;
-    st[3] = wall_clock64();
+    st[3] = t_end;
+    mh[0] = (unsigned long long)n_done | ((unsigned long long)H.reason << 32); mh[1] = (unsigned long long)nd | ((unsigned long long)H.n_dirty_rows << 32);
+    mh[2] = (unsigned long long)H.n_runs | ((unsigned long long)H.n_slow << 32); mh[3] = (unsigned long long)w6 | ((unsigned long long)w7 << 32);
+    mh[KB_OUT_STAMP0 + 2] = t_start; mh[KB_OUT_STAMP0 + 3] = t_end;
   }
   // ---- fast rounds: mirror the header and the decision records into pinned host memory and publish the round's sequence
   //      number last; the host spins on that word instead of paying a stream synchronisation + D2H copy per round
   if (a.host_out) {
     __syncthreads();
-    const unsigned long long *hdr = reinterpret_cast<const unsigned long long *>(a.result);
-    for (uint32_t i = tid; i < KB_OUT_HDR; i += K9_THREADS) if (i != KB_OUT_SEQ) a.host_out[i] = hdr[i];
+#ifdef KB_K9_TRACE
+    for (uint32_t i = tid; i < KB_OUT_HDR; i += K9_THREADS) if (i != KB_OUT_SEQ) a.host_out[i] = hdr[i];   // (the trace words were written by thread 0 a moment ago)
+#else
+    if (tid < KB_OUT_HDR && tid != KB_OUT_SEQ) a.host_out[tid] = (tid < 4u || tid == KB_OUT_STAMP0 + 2u || tid == KB_OUT_STAMP0 + 3u) ? mh[tid] : hpre;
+#endif
     for (uint32_t i = tid; i < n_done; i += K9_THREADS) a.host_out[KB_OUT_HDR + i] = ldec[i];
     __threadfence_system();
     __syncthreads();

@@ -452,9 +452,13 @@ __global__ void __launch_bounds__(THREADS) k_argmax(KbDev d, KbRound r) {
 // arbitrary for the nodes it changed.  One workgroup per matrix row, behind the predecessor's commit on the first stream:
 //   1. the predecessor's nodes (its decision records; a node may have taken several rows) -> a bitmap in LDS, each node owned by one thread;
 //   2. the owner evaluates the row's shape against the node's state as the predecessor LEFT it (eval_row<1>, K1's own arithmetic);
-//   3. the stale list without the predecessor's nodes, merged with the new keys by rank: survivors keep their order (block scan of the
-//      survivor flags) and count the new keys above them; a new key counts the survivors above it (binary search + the scan) and the new
-//      keys above it.  Keys are distinct (the node index is part of them), so the ranks are a permutation.
+//   3. the stale list without the predecessor's nodes, merged with the new keys by rank.  A new key f finds its place lo(f) in the stale list (the
+//      number of stale entries above it: binary search) and leaves a mark there; a survivor at index i then has exactly the new keys with
+//      lo(f) <= i above it — a prefix sum of the marks, in the same block scan that counts the survivors in front of it; a new key has the
+//      survivors in front of index lo(f) and the new keys above it (counted directly: at most n_prev of them, the work split over the whole
+//      workgroup).  Keys are distinct (the node index is part of them; a stale entry equal to a new key is that node's own, and dropped), so the
+//      ranks are a permutation.  (Every survivor counting the new keys above it by comparison — n_prev 64-bit compares in each of ~500
+//      threads — was 3 of this launch's 14 us, on the dependent chain of every round.)
 // A clean node of the true top L has at most L - 1 clean and n_prev changed nodes above it in the stale order: stale_L >= n_prev + L entries
 // hold every one of them.
 // ------------------------------------------------------------------------------------------------------------
@@ -464,8 +468,11 @@ __global__ void __launch_bounds__(KB_REPAIR_THREADS) k_repair(KbDev d, KbRound r
   unsigned long long *stale = reinterpret_cast<unsigned long long *>(kr_smem);                 // [KB_REPAIR_THREADS]
   unsigned long long *fresh = stale + KB_REPAIR_THREADS;                                       // [n_prev] keys of the predecessor's nodes (0: infeasible / not owned)
   uint32_t *alive_before = reinterpret_cast<uint32_t *>(fresh + KB_K5_MAX_WINDOW);             // [KB_REPAIR_THREADS + 1] survivors in front of entry i
-  uint32_t *bitmap = alive_before + KB_REPAIR_THREADS + 1;                                     // [NP / 32]
-  __shared__ uint32_t s_wtot[KB_REPAIR_THREADS / 64];
+  uint32_t *marks = alive_before + KB_REPAIR_THREADS + 1;                                      // [KB_REPAIR_THREADS + 1] new keys whose place in the stale list is index i
+  uint32_t *fresh_above = marks + KB_REPAIR_THREADS + 1;                                       // [KB_K5_MAX_WINDOW] new keys above new key j
+  uint32_t *bitmap = fresh_above + KB_K5_MAX_WINDOW;                                           // [NP / 32]
+  __shared__ uint32_t s_wtot[KB_REPAIR_THREADS / 64], s_mtot[KB_REPAIR_THREADS / 64];
+  static_assert(KB_K5_MAX_WINDOW <= KB_REPAIR_THREADS && KB_K5_MAX_WINDOW % 8 == 0, "a thread per decision record of the predecessor; fresh[] is read eight entries at a time");
   const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, row = blockIdx.x;
   if (KB_CHAIN_BROKEN(r)) return;
   if (row == 0 && tid == 0) {   // the round's matrix / arg-max stamps: the candidate launches ran beside the predecessor, this is what the round waits for
@@ -478,6 +485,9 @@ __global__ void __launch_bounds__(KB_REPAIR_THREADS) k_repair(KbDev d, KbRound r
   uint32_t node = KB_NONE_U32;
   if (tid < np) node = (uint32_t)(r.prev_dec[tid] & 0xFFFFFFFFull);
   for (uint32_t w = tid; w < d.NP / 32; w += KB_REPAIR_THREADS) bitmap[w] = 0u;
+  marks[tid] = 0u;
+  if (tid == 0) marks[KB_REPAIR_THREADS] = 0u;
+  if (tid < KB_K5_MAX_WINDOW) fresh_above[tid] = 0u;
   __shared__ uint32_t s_late;
   if (tid == KB_REPAIR_THREADS - 1) {   // a thread without a decision record to fetch (n_prev <= the window < the workgroup): the tag's round trip runs beside that fetch
     // the list was launched (second stream) before this kernel (first stream) and had a whole commit kernel's time to finish: the wait is
@@ -516,44 +526,63 @@ __global__ void __launch_bounds__(KB_REPAIR_THREADS) k_repair(KbDev d, KbRound r
   if (tid < KB_K5_MAX_WINDOW) fresh[tid] = fk;
   stale[tid] = sk;   // 0-terminated, best first
   __syncthreads();
-  // 3: survivors and their prefix counts
+  // 3: survivors and their prefix counts; the new keys' places
   const bool alive = sk != 0ull && !((bitmap[KB_KEY_NODE(sk) >> 5] >> (KB_KEY_NODE(sk) & 31)) & 1u);
   const unsigned long long bal = __ballot(alive);
   const uint32_t in_wave = (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
   if (lane == 0) s_wtot[wave] = (uint32_t)__popcll(bal);
+  uint32_t lo = 0;
+  if (fk != 0ull) {
+    // stale entries above fk: the list is descending; entries equal to 0 (behind its end) are never above
+    uint32_t hi = KB_REPAIR_THREADS;
+    while (lo < hi) {
+      const uint32_t mid = (lo + hi) >> 1;
+      if (stale[mid] > fk) lo = mid + 1; else hi = mid;
+    }
+    atomicAdd(&marks[lo], 1u);
+  }
+  {   // new keys above a new key, eight per step as four 16-byte LDS reads in flight together (fresh[] reads 0 behind n_prev: every thread stored
+      // its key or 0).  A window of at most 256 rows (the commit kernel's KB_K5_MAX_ROWS): thread (part, j) compares key j with a quarter of them
+    auto count_above = [&](unsigned long long key, uint32_t i0, uint32_t i1) {
+      uint32_t c = 0;
+      for (uint32_t i = i0; i < i1; i += 8) {
+        const ulonglong2 a = *reinterpret_cast<const ulonglong2 *>(&fresh[i]), b = *reinterpret_cast<const ulonglong2 *>(&fresh[i + 2]);
+        const ulonglong2 e = *reinterpret_cast<const ulonglong2 *>(&fresh[i + 4]), f = *reinterpret_cast<const ulonglong2 *>(&fresh[i + 6]);
+        c += (a.x > key ? 1u : 0u) + (a.y > key ? 1u : 0u) + (b.x > key ? 1u : 0u) + (b.y > key ? 1u : 0u) +
+             (e.x > key ? 1u : 0u) + (e.y > key ? 1u : 0u) + (f.x > key ? 1u : 0u) + (f.y > key ? 1u : 0u);
+      }
+      return c;
+    };
+    const uint32_t np8 = (np + 7u) & ~7u;
+    if (np <= KB_REPAIR_THREADS / 4u) {
+      const uint32_t j = tid % (KB_REPAIR_THREADS / 4u), part = tid / (KB_REPAIR_THREADS / 4u);
+      const uint32_t per = (((np8 + 3u) >> 2) + 7u) & ~7u, i0 = part * per, i1 = min(np8, i0 + per);
+      const unsigned long long key = fresh[j];
+      if (key != 0ull && i0 < i1) {
+        const uint32_t c = count_above(key, i0, i1);
+        if (c) atomicAdd(&fresh_above[j], c);
+      }
+    } else if (fk != 0ull) {
+      fresh_above[tid] = count_above(fk, 0u, np8);
+    }
+  }
   __syncthreads();
-  uint32_t before = in_wave;
-  for (uint32_t w = 0; w < wave; w++) before += s_wtot[w];
+  const uint32_t mscan = wave_incl_scan_u32(marks[tid]);   // new keys whose place is at or in front of my entry, inside the wave
+  if (lane == 63) s_mtot[wave] = mscan;
+  __syncthreads();
+  uint32_t before = in_wave, above = mscan;
+  for (uint32_t w = 0; w < wave; w++) { before += s_wtot[w]; above += s_mtot[w]; }
   alive_before[tid] = before;
   if (tid == KB_REPAIR_THREADS - 1) alive_before[KB_REPAIR_THREADS] = before + (alive ? 1u : 0u);
   __syncthreads();
   const uint32_t K = r.L;
   unsigned long long *out = r.keys + (size_t)row * K;
-  // new keys above a key: eight per step as four 16-byte LDS reads in flight together (one 8-byte read per step, each waited for, made this
-  // launch take 15 us; fresh[] reads 0 behind n_prev: every thread stored its key or 0)
-  const uint32_t np8 = (np + 7u) & ~7u;
-  auto fresh_above = [&](unsigned long long key) {
-    uint32_t c = 0;
-    for (uint32_t i = 0; i < np8; i += 8) {
-      const ulonglong2 a = *reinterpret_cast<const ulonglong2 *>(&fresh[i]), b = *reinterpret_cast<const ulonglong2 *>(&fresh[i + 2]);
-      const ulonglong2 e = *reinterpret_cast<const ulonglong2 *>(&fresh[i + 4]), f = *reinterpret_cast<const ulonglong2 *>(&fresh[i + 6]);
-      c += (a.x > key ? 1u : 0u) + (a.y > key ? 1u : 0u) + (b.x > key ? 1u : 0u) + (b.y > key ? 1u : 0u) +
-           (e.x > key ? 1u : 0u) + (e.y > key ? 1u : 0u) + (f.x > key ? 1u : 0u) + (f.y > key ? 1u : 0u);
-    }
-    return c;
-  };
   if (alive) {
-    const uint32_t rank = before + fresh_above(sk);
+    const uint32_t rank = before + above;
     if (rank < K) out[rank] = sk;
   }
   if (fk != 0ull) {
-    // stale entries above fk: the list is descending; entries equal to 0 (behind its end) are never above
-    uint32_t lo = 0, hi = KB_REPAIR_THREADS;
-    while (lo < hi) {
-      const uint32_t mid = (lo + hi) >> 1;
-      if (stale[mid] > fk) lo = mid + 1; else hi = mid;
-    }
-    const uint32_t rank = alive_before[lo] + fresh_above(fk);
+    const uint32_t rank = alive_before[lo] + fresh_above[tid];
     if (rank < K) out[rank] = fk;
   }
   // the tail: entries behind the merged list read 0
@@ -564,7 +593,7 @@ __global__ void __launch_bounds__(KB_REPAIR_THREADS) k_repair(KbDev d, KbRound r
   for (uint32_t i = total + tid; i < K; i += KB_REPAIR_THREADS) out[i] = 0ull;
 }
 size_t kb_repair_smem_bytes(uint32_t NP) {
-  return sizeof(unsigned long long) * (KB_REPAIR_THREADS + KB_K5_MAX_WINDOW) + sizeof(uint32_t) * (KB_REPAIR_THREADS + 1) + sizeof(uint32_t) * (NP / 32);
+  return sizeof(unsigned long long) * (KB_REPAIR_THREADS + KB_K5_MAX_WINDOW) + sizeof(uint32_t) * (2 * (KB_REPAIR_THREADS + 1) + KB_K5_MAX_WINDOW) + sizeof(uint32_t) * (NP / 32);
 }
 void kb_launch_repair(const KbDev &d, const KbRound &r, void *stream) {
   if (r.n_mrows == 0) return;

@@ -54,7 +54,7 @@ ab)   # ab <tag,tag,...> [test]: kube-batch_amd/libkbengine_<tag>.so beside the 
     bench_ab "survey_${tag}" KB_ENGINE_LIB=$(libpath $tag) -- --config 3 --survey-nodes --steps 5 --warmup 2 --verify
     bench_ab "c4_${tag}" KB_ENGINE_LIB=$(libpath $tag) -- --config 4 --steps 5 --warmup 2 --verify
     bench_ab "c5_${tag}" KB_ENGINE_LIB=$(libpath $tag) -- --config 5 --steps 2 --warmup 1
-    bench_ab "c2_${tag}" KB_ENGINE_LIB=$(libpath $tag) -- --config 2 --steps 10 --warmup 3 --verify
+    [ -n "${AB_SKIP_C2:-}" ] || bench_ab "c2_${tag}" KB_ENGINE_LIB=$(libpath $tag) -- --config 2 --steps 10 --warmup 3 --verify
   done
   if [ "${2:-}" = test ]; then
     timeout 900 python -m pytest tests -q -m gpu -p no:cacheprovider -k "select or reload or fullsize or sharded or waterfill or framework" --maxfail=10 > "$out/pytest_default.txt" 2>&1

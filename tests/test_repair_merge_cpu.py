@@ -61,3 +61,87 @@ def test_the_bound_is_tight():
     want = top(true_keys, L)
     assert repaired(stale_keys, true_keys, changed, L, n_prev + L) == want
     assert repaired(stale_keys, true_keys, changed, L, n_prev + L - 1) != want
+
+
+def ranks_by_place_marks(stale_list, dead, fresh, threads=1024):
+    """k_repair's merge as the kernel computes it (kb_kernels.hip): `stale_list` descending and padded with zeros to `threads` entries, `dead[i]` = entry i
+    is one of the predecessor's nodes, `fresh` = its new keys (0: infeasible).  Returns {rank: key}."""
+    assert len(stale_list) == threads and len(dead) == threads
+    alive = [k != 0 and not dd for k, dd in zip(stale_list, dead)]
+    alive_before = [0] * (threads + 1)
+    for i in range(threads):
+        alive_before[i + 1] = alive_before[i] + (1 if alive[i] else 0)
+    marks = [0] * (threads + 1)
+    place = {}
+    for j, f in enumerate(fresh):
+        if not f:
+            continue
+        lo, hi = 0, threads                       # stale entries above f: binary search on the descending list (zeros are never above)
+        while lo < hi:
+            mid = (lo + hi) >> 1
+            if stale_list[mid] > f:
+                lo = mid + 1
+            else:
+                hi = mid
+        place[j] = lo
+        marks[lo] += 1
+    out = {}
+    run = 0
+    for i in range(threads):
+        run += marks[i]                           # inclusive prefix sum: new keys whose place is at or in front of entry i
+        if alive[i]:
+            rank = alive_before[i] + run
+            assert rank not in out
+            out[rank] = stale_list[i]
+    n_parts = 4
+    np8 = (len(fresh) + 7) & ~7
+    padded = list(fresh) + [0] * (np8 - len(fresh))
+    per = (((np8 + 3) >> 2) + 7) & ~7
+    for j, f in enumerate(fresh):
+        if not f:
+            continue
+        above = 0
+        for part in range(n_parts):               # thread (part, j): one quarter of the new keys, eight at a time
+            i0, i1 = part * per, min(np8, part * per + per)
+            for i in range(i0, i1, 8):
+                above += sum(1 for g in padded[i:i + 8] if g > f)
+        rank = alive_before[place[j]] + above
+        assert rank not in out
+        out[rank] = f
+    return out
+
+
+@pytest.mark.parametrize("seed", range(300))
+def test_ranks_from_place_marks_are_the_merged_order(seed):
+    """The rank arithmetic of k_repair (place of a new key in the stale list by binary search, a mark there, prefix sums of marks and of survivor
+    flags) gives every survivor and every new key its position in the merged descending order — including new keys equal to their node's own
+    stale entry, lists that end early, infeasible new keys, and n_prev from 0 to 256."""
+    rng = random.Random(1000 + seed)
+    n_nodes = rng.choice([1, 2, 5, 40, 300, 2000])
+    n_prev = rng.choice([0, 1, 3, 7, 8, 9, 17, 64, 255, 256])
+    L = rng.choice([1, 2, 9, 65, 257])
+    true_keys, stale_keys, changed = make_case(rng, n_nodes, n_prev, rng.choice([0.0, 0.3, 0.95]))
+    node_of = {}
+    for i, k in enumerate(stale_keys):
+        if k:
+            node_of[k] = i
+    stale_len = n_prev + L
+    stale_list = top(stale_keys, stale_len)
+    dead = [node_of[k] in changed for k in stale_list]
+    threads = 1024
+    stale_list = stale_list + [0] * (threads - len(stale_list))
+    dead = dead + [False] * (threads - len(dead))
+    # decision records: a node may have taken several rows (one owner each: the other records carry key 0), and the records are in row order
+    records = list(changed)
+    if records:
+        records += [rng.choice(records) for _ in range(rng.randrange(0, 256 - len(records) + 1))]
+    rng.shuffle(records)
+    seen, fresh = set(), []
+    for n in records:
+        fresh.append(true_keys[n] if n not in seen else 0)
+        seen.add(n)
+    got = ranks_by_place_marks(stale_list, dead, fresh, threads)
+    merged = sorted([k for k, dd in zip(stale_list, dead) if k and not dd] + [f for f in fresh if f], reverse=True)
+    assert sorted(got) == list(range(len(merged)))
+    assert [got[r] for r in range(len(merged))] == merged
+    assert merged[:L] == top(true_keys, L)
