@@ -71,7 +71,13 @@ __global__ void __launch_bounds__(K9_THREADS) k_commit_select(const K9KernArgs k
   K9Sel &X = *reinterpret_cast<K9Sel *>(k9_smem + lo.sel);
   K9Sync &Y = X.sync;
   const unsigned long long t_start = wall_clock64();
-  k9_prologue(a, lo, k9_smem, tid, K9_SEL_MAXRUN);
+  // (run lengths: from the run-start bitmap below — k9_prologue's own rule walks forward row by row)
+#ifdef KB_K9_TRACE
+  unsigned long long t_stage[2] = {0ull, 0ull};   // (trace build: the fixed parts of a round in units of the 100 MHz clock — staging, shape tables, run tables, loop)
+  k9_prologue(a, lo, k9_smem, tid, 0u, t_stage);
+#else
+  k9_prologue(a, lo, k9_smem, tid, 0u);
+#endif
 
   // ---- the runs of the window, by number: run k starts at row X.runs[k] (rinfo there holds its length, shape, flags, Resreq key mask).  A
   //      row starts a run iff it cannot join its predecessor (k9_prologue's rule) or its stretch of joinable rows has reached a multiple of
@@ -109,9 +115,10 @@ __global__ void __launch_bounds__(K9_THREADS) k_commit_select(const K9KernArgs k
       // of runs[k] -> rinfo[row] (k <= its first row, every read is done before the first write)
     uint4 rr = make_uint4(0u, 0u, 0u, 0u);
     uint32_t i0c = 0u;
-    if (tid < K) { i0c = X.runs[tid]; rr = rinfo[i0c]; }
+    uint32_t rlen = 0u;
+    if (tid < K) { i0c = X.runs[tid]; rr = rinfo[i0c]; rlen = ((tid + 1u < K) ? (uint32_t)X.runs[tid + 1u] : W) - i0c; }   // the run ends where the next one starts
     __syncthreads();
-    if (tid < K) rinfo[tid] = make_uint4(i0c | (rr.x << 16), rr.y, rr.z, rr.w);
+    if (tid < K) rinfo[tid] = make_uint4(i0c | (rlen << 16), rr.y, rr.z, rr.w);
     __syncthreads();
   }
 
@@ -120,6 +127,8 @@ __global__ void __launch_bounds__(K9_THREADS) k_commit_select(const K9KernArgs k
   // rank, 6: deep passes, 7: picks + AddTask, 8: the all-clean path; X.tr: the prep waves' wait for their run's turn / for the walk's turn,
   // wave 1's wait for the previous run / its evaluation
   uint32_t tacc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  const unsigned long long t_tab = wall_clock64();
+  tacc[1] = (uint32_t)(t_stage[0] - t_start); tacc[9] = (uint32_t)(t_stage[1] - t_stage[0]); tacc[2] = (uint32_t)(t_tab - t_stage[1]);
   unsigned long long tlast = __builtin_readcyclecounter();
 #define K9S_TR(k, t0) do { if (lane == 0) atomicAdd(&X.tr[k], (uint32_t)(__builtin_readcyclecounter() - (t0))); } while (0)
 #define K9S_NOW() __builtin_readcyclecounter()
@@ -585,6 +594,9 @@ __global__ void __launch_bounds__(K9_THREADS) k_commit_select(const K9KernArgs k
       }
       if (stop) break;
     }
+#ifdef KB_K9_TRACE
+    tacc[4] = (uint32_t)(wall_clock64() - t_tab);
+#endif
     if (lane == 0) {
       if (k9s_ld(&Y.err)) reason_end = KB_REASON_INTERNAL;
       k9s_st(&Y.stop, 1u);

@@ -204,6 +204,7 @@ struct kb_engine {
   DevBuf b_idle, b_rel, b_nzc, b_nzm, b_podcnt, b_acpu, b_amem, b_maxpods, b_ncls, b_nmask, b_invac, b_invam;
   uint64_t k5_walks = 0, k5_rescans = 0, k5_demand = 0, k5_slots = 0;   // commit kernel counters (KB_K5_STATS)
   double k5_trace[14] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  double tl_repair_tag = 0;   // KB_K5_STATS: ms between the start of a repair launch and the moment its first workgroup had seen its list's tag
   uint32_t eff_window = 0;   // window actually used for this session (bounded by the commit kernel's LDS budget)
   // Which commit kernel a round runs on: the selection kernel (kb_commit_sel.hip), backfill rounds included; KB_COMMIT_KERNEL=run|select pins
   // one of the two — they compute the same decisions, and every -m gpu case runs under each (the run kernel, kb_commit.hip, is the plain
@@ -664,6 +665,7 @@ void round_collect(kb_engine *e, const RoundCtx &c, bool had_candidates, uint32_
       const unsigned long long *cs = e->h_cand_out.data() + (size_t)c.buf * KB_OUT_HDR + KB_OUT_STAMP0;
       if (cs[1] > cs[0]) e->stats.matrix_ms += (double)(cs[1] - cs[0]) * per_ms;
       e->stats.argmax_ms += (double)(st[2] - st[0]) * per_ms;
+      if (st[1] > st[0]) e->tl_repair_tag += (double)(st[1] - st[0]) * per_ms;   // ... of which: until workgroup 0 had seen its list's tag
     } else if (had_candidates) {
       e->stats.matrix_ms += (double)(st[1] - st[0]) * per_ms;   // includes the descriptor gather
       e->stats.argmax_ms += (double)(st[2] - st[1]) * per_ms;
@@ -1158,8 +1160,8 @@ void kb_engine_destroy(kb_engine *e) {
             (unsigned long long)e->stats.rounds, (unsigned long long)e->stats.decisions, (unsigned long long)e->k5_slots,
             (unsigned long long)e->stats.row_fallbacks, (unsigned long long)e->k5_walks, (unsigned long long)e->k5_rescans,
             (unsigned long long)e->k5_demand);
-  if (getenv("KB_K5_STATS")) fprintf(stderr, "[kb overlap] rounds with candidate lists built beside the predecessor's commit %llu, lists that never arrived %llu\n",
-                                     (unsigned long long)e->overlapped_rounds, (unsigned long long)e->overlap_faults);
+  if (getenv("KB_K5_STATS")) fprintf(stderr, "[kb overlap] rounds with candidate lists built beside the predecessor's commit %llu, lists that never arrived %llu; repair launches: %.3f ms from their start to the tag seen\n",
+                                     (unsigned long long)e->overlapped_rounds, (unsigned long long)e->overlap_faults, e->tl_repair_tag);
   if (getenv("KB_K5_STATS"))
     fprintf(stderr, "[kb host] ms over the engine's life: reset %.2f, allocate up to its first launch %.2f, speculation breaks (answer -> re-planned launch) %.2f, "
             "closing reductions %.2f, waiting for rounds %.2f, backfill up to its first launch %.2f\n", e->tl_reset, e->tl_begin, e->tl_break, e->tl_finish, e->tl_wait, e->tl_backfill);
@@ -1168,8 +1170,8 @@ void kb_engine_destroy(kb_engine *e) {
     static const char *ph[10] = {"barrier 1 (wave 0's wait)", "evaluate: candidates (wave 0)", "barrier 2", "rows", "prepare the next run",
                                 "rows, of runs with scalar dimensions", "runs with scalar dimensions (count)", "evaluate, of runs with scalar dimensions",
                                 "dirty-winner entries (count)", "loop top"};
-    static const char *ph_sel[10] = {"wave 0 waits for candidates + dirty keys", "-", "-", "rows: serial loop, tail, publish", "-",
-                                    "selection: entries + first rank", "selection: deep passes", "selection: picks + AddTask", "selection: all picks clean", "loop top"};
+    static const char *ph_sel[10] = {"wave 0 waits for candidates + dirty keys", "staging: lists, descriptors (10 ns units, not clocks)", "run tables (10 ns units)", "rows: serial loop, tail, publish", "wave 0's loop (10 ns units)",
+                                    "selection: entries + first rank", "selection: deep passes", "selection: picks + AddTask", "selection: all picks clean", "shape tables (10 ns units)"};
     const double runs = (double)(e->k5_walks ? e->k5_walks : 1);
     for (int k = 0; k < 10; k++) fprintf(stderr, "[kb K5 trace] %-32s %14.0f clocks  (%.0f per run)\n", e->rounds_sel > e->rounds_run ? ph_sel[k] : ph[k], e->k5_trace[k], e->k5_trace[k] / runs);
     static const char *ph_role[4] = {"prep waves wait for their run's turn (sum of 3)", "prep waves wait for the walk's turn (sum of 3)", "wave 1 waits for the previous run", "wave 1 evaluates + publishes"};

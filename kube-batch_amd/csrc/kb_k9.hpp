@@ -293,7 +293,10 @@ __device__ __forceinline__ bool k9_preamble(const KbCommitArgs &a) {
 
 // ---------------- prologue (all threads): the round staged into LDS ----------------
 // maxrun: longest run of rows that share one evaluation (K9_MAXRUN; the selection kernel: K9_SEL_MAXRUN)
-__device__ __forceinline__ void k9_prologue(const KbCommitArgs &a, const K9Layout &lo, unsigned char *k9_base_, const uint32_t tid, const uint32_t maxrun) {
+// maxrun == 0: the caller derives the run lengths itself (the selection kernel: from its run-start bitmap); `stamps` (trace builds): the 100 MHz clock
+// behind the staging barrier and behind the shape tables
+__device__ __forceinline__ void k9_prologue(const KbCommitArgs &a, const K9Layout &lo, unsigned char *k9_base_, const uint32_t tid, const uint32_t maxrun,
+                                            unsigned long long *stamps = nullptr) {
   const uint32_t S = a.n_mrows, W = a.n_rows;
   K9_LDS_VIEWS(lo)
   (void)slots; (void)rowres; (void)ldec; (void)dk; (void)ckey; (void)cpos; (void)RS;
@@ -329,6 +332,7 @@ __device__ __forceinline__ void k9_prologue(const KbCommitArgs &a, const K9Layou
   for (uint32_t s = tid; s < S; s += K9_THREADS) cursor[s] = 0;
   if (tid == 0) { H.i = 0; H.nd = 0; H.reason = KB_REASON_DONE; H.stop = 0; H.ncand = 0; H.n_dirty_rows = 0; H.n_runs = 0; H.n_slow = 0; H.cur_s = 0; H.cur_r = 0; H.cur_fl = 0; H.cur_km = 0; }
   __syncthreads();
+  if (stamps) stamps[0] = wall_clock64();
   // shape -> one of its rows (any: rows of a shape agree on everything the evaluation reads)
   for (uint32_t i = tid; i < W; i += K9_THREADS) shp[desc[i].slot] = i;
   __syncthreads();
@@ -349,6 +353,7 @@ __device__ __forceinline__ void k9_prologue(const KbCommitArgs &a, const K9Layou
     }
   }
   __syncthreads();
+  if (stamps) stamps[1] = wall_clock64();
 
   // run table: rows i .. i + r - 1 share a shape and take the shape's own request values (a row whose Resreq differs from its
   // InitResreq, or whose score needs renormalising, is a run of its own)
@@ -357,7 +362,7 @@ __device__ __forceinline__ void k9_prologue(const KbCommitArgs &a, const K9Layou
     const uint32_t sl = k.slot, fl = k.flags, km = k.resmask;
     const bool plain = (fl & 1u) && (km == 0u || (fl & 4u));
     uint32_t r = 1;
-    if (plain && !(fl & 2u))
+    if (plain && !(fl & 2u))   // (one LDS round trip per step, and the rows at the head of a stretch take maxrun - 1 of them: 3 us of every round at 32)
       while (r < maxrun && i + r < W && desc[i + r].slot == sl && desc[i + r].flags == fl && desc[i + r].resmask == km) r++;
     rinfo[i] = make_uint4(r, sl, fl, km);
   }
@@ -478,6 +483,7 @@ __device__ __forceinline__ void k9_epilogue(const KbCommitArgs &a, const K9Layou
   if (a.host_out) {
     __syncthreads();
 #ifdef KB_K9_TRACE
+    (void)hpre;
     for (uint32_t i = tid; i < KB_OUT_HDR; i += K9_THREADS) if (i != KB_OUT_SEQ) a.host_out[i] = hdr[i];   // (the trace words were written by thread 0 a moment ago)
 #else
     if (tid < KB_OUT_HDR && tid != KB_OUT_SEQ) a.host_out[tid] = (tid < 4u || tid == KB_OUT_STAMP0 + 2u || tid == KB_OUT_STAMP0 + 3u) ? mh[tid] : hpre;
