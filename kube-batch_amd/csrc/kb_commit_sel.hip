@@ -79,6 +79,9 @@ __global__ void __launch_bounds__(K9_THREADS) k_commit_select(const K9KernArgs k
   k9_prologue(a, lo, k9_smem, tid, 0u);
 #endif
 
+  // the job of "my" row (the epilogue marks it as allocated): fetched now, wanted then
+  uint32_t job_of_my_row = 0u;
+  if (tid < W) job_of_my_row = a.dev->t_job[desc[tid].task];
   // ---- the runs of the window, by number: run k starts at row X.runs[k] (rinfo there holds its length, shape, flags, Resreq key mask).  A
   //      row starts a run iff it cannot join its predecessor (k9_prologue's rule) or its stretch of joinable rows has reached a multiple of
   //      the longest run.  W <= KB_K5_MAX_ROWS = 256: eight mask words.
@@ -806,7 +809,7 @@ __global__ void __launch_bounds__(K9_THREADS) k_commit_select(const K9KernArgs k
     tw[15] = (unsigned long long)X.tr[2] | ((unsigned long long)X.tr[3] << 32);
   }
 #endif
-  k9_epilogue(a, lo, k9_smem, tid, t_start, X.stat[0] | (X.stat[1] << 16), X.stat[2] | (X.stat[3] << 16));
+  k9_epilogue(a, lo, k9_smem, tid, t_start, X.stat[0] | (X.stat[1] << 16), X.stat[2] | (X.stat[3] << 16), true, job_of_my_row);
 }
 
 void kb_launch_commit_sel(const KbDev &d, const KbRound &r, void *stream) {

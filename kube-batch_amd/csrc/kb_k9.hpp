@@ -371,8 +371,9 @@ __device__ __forceinline__ void k9_prologue(const KbCommitArgs &a, const K9Layou
 
 // ---------------- epilogue (all threads): dirty slots, decision records, task table, result words, host mirror ----------------
 // w6 / w7: result words 6 and 7 (0 in the run kernel; the selection kernel's statistics)
+// job_known / job_of_my_row: the caller fetched t_job of row `tid`'s task long ago (the selection kernel: behind its prologue)
 __device__ __forceinline__ void k9_epilogue(const KbCommitArgs &a, const K9Layout &lo, unsigned char *k9_base_, const uint32_t tid, const unsigned long long t_start,
-                                            const uint32_t w6, const uint32_t w7) {
+                                            const uint32_t w6, const uint32_t w7, const bool job_known = false, const uint32_t job_of_my_row = 0u) {
   K9_LDS_VIEWS(lo)
   (void)rowres; (void)sinit; (void)shapes; (void)rinfo; (void)dk; (void)ckey; (void)cpos; (void)cursor; (void)shp; (void)lists; (void)bitmap; (void)RS; (void)Lp; (void)nb; (void)nmaskbits;
   const uint32_t n_done = H.i, nd = H.nd;
@@ -383,10 +384,13 @@ __device__ __forceinline__ void k9_epilogue(const KbCommitArgs &a, const K9Layou
   const unsigned long long *hdr = reinterpret_cast<const unsigned long long *>(a.result);
   unsigned long long *mh = slots + (size_t)(a.n_rows + K9_MAXRUN - 2u) * K9_NF;   // (2 * K9_NF >= KB_OUT_HDR words)
   static_assert(2u * K9_NF >= KB_OUT_HDR, "the header's LDS copy lives in two slots");
+  // the decision records' copies in pinned host memory first: the stores with the longest way to go, and the fence below waits for them
+  if (a.host_out)
+    for (uint32_t i = tid; i < n_done; i += K9_THREADS) a.host_out[KB_OUT_HDR + i] = ldec[i];
   unsigned long long hpre = 0ull;
   if (a.host_out && tid < KB_OUT_HDR) hpre = hdr[tid];
-  uint32_t my_job = 0u;
-  if (tid < n_done) my_job = a.dev->t_job[desc[tid].task];
+  uint32_t my_job = job_of_my_row;
+  if (!job_known && tid < n_done) my_job = a.dev->t_job[desc[tid].task];
   {   // the dirty nodes' live state back to HBM
     const KbDev &d = *a.dev;
     for (uint32_t slot = tid; slot < nd; slot += K9_THREADS) {
@@ -488,7 +492,6 @@ __device__ __forceinline__ void k9_epilogue(const KbCommitArgs &a, const K9Layou
 #else
     if (tid < KB_OUT_HDR && tid != KB_OUT_SEQ) a.host_out[tid] = (tid < 4u || tid == KB_OUT_STAMP0 + 2u || tid == KB_OUT_STAMP0 + 3u) ? mh[tid] : hpre;
 #endif
-    for (uint32_t i = tid; i < n_done; i += K9_THREADS) a.host_out[KB_OUT_HDR + i] = ldec[i];
     __threadfence_system();
     __syncthreads();
     if (tid == 0) __hip_atomic_store(&a.host_out[KB_OUT_SEQ], a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
