@@ -44,7 +44,10 @@ __global__ void __launch_bounds__(K9_THREADS) k_commit_run(const K9KernArgs ka) 
   K9_LDS_VIEWS(lo)
   (void)shp;
   const unsigned long long t_start = wall_clock64();
-  k9_prologue(a, lo, k9_smem, tid, K9_MAXRUN);
+  if (!k9_prologue(a, lo, k9_smem, tid, K9_MAXRUN)) {   // (only a launch that carries its own repair workgroups can fail here: the selection kernel's)
+    if (tid == 0) k9_publish_skipped(a);
+    return;
+  }
 
 
 #ifdef KB_K9_TRACE

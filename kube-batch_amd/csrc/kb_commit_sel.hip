@@ -30,7 +30,10 @@
 //    waits too long raises `err`, everybody leaves, the round reports KB_REASON_INTERNAL instead of hanging).
 #include <string.h>
 
+#include <algorithm>
+
 #include "kb_k9.hpp"
+#include "kb_repair.hpp"
 
 #define K9S_PREP0 5u          // waves 5, 6, 7 prepare runs m % 3 == 0, 1, 2
 #define K9S_PREPS 3u
@@ -60,8 +63,19 @@ __global__ void __launch_bounds__(K9_THREADS) k_commit_select(const K9KernArgs k
     a.round = (const KbRound *)(kp + offsetof(K9KernArgs, round));
   }
   //@@ top
-  if (k9_preamble(a)) return;
   extern __shared__ __align__(16) unsigned char k9_smem[];
+  // A launch that carries its round's repair workgroups (KbRound::lists_ready): row j is workgroup number j among those whose index is not a
+  // multiple of 8 (1 .. 7, 9 .. 15, ...; the multiples are the commit workgroup and its L2 helpers) — the FIRST workgroups behind workgroup 0, because
+  // a launch's workgroups start in index order at ~0.13 us apiece (8 waves and a 160 KB LDS block each): behind the 64 others a row started
+  // 8 us late and the commit workgroup waited 13 us for its lists (call 13)
+  if ((blockIdx.x & 7u) != 0u && a.round->lists_ready != nullptr) {
+    const uint32_t row = blockIdx.x - 1u - blockIdx.x / 8u;
+    // (inlined, the views through the kernel-argument segment: as a function of its own the views arrive as VGPR pointers, every field becomes a
+    // vector load repeated behind each store and a row takes 15 us instead of 7 — calls 13, 14; the segment pointer is not a callee's to ask for — call 15)
+    if (row < a.n_mrows && !KB_CHAIN_BROKEN(*a.round)) kb_repair_row<K9_THREADS>(*a.dev, *a.round, k9_smem, row, threadIdx.x);
+    return;
+  }
+  if (k9_preamble(a)) return;
   const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const uint32_t S = a.n_mrows, W = a.n_rows;
   const K9Layout lo = k9_layout(W, S, a.L, a.NP, a.R, true);
@@ -74,10 +88,14 @@ __global__ void __launch_bounds__(K9_THREADS) k_commit_select(const K9KernArgs k
   // (run lengths: from the run-start bitmap below — k9_prologue's own rule walks forward row by row)
 #ifdef KB_K9_TRACE
   unsigned long long t_stage[2] = {0ull, 0ull};   // (trace build: the fixed parts of a round in units of the 100 MHz clock — staging, shape tables, run tables, loop)
-  k9_prologue(a, lo, k9_smem, tid, 0u, t_stage);
+  const bool staged = k9_prologue(a, lo, k9_smem, tid, 0u, t_stage);
 #else
-  k9_prologue(a, lo, k9_smem, tid, 0u);
+  const bool staged = k9_prologue(a, lo, k9_smem, tid, 0u);
 #endif
+  if (!staged) {   // a candidate list never came: nothing was evaluated or committed
+    if (tid == 0) k9_publish_skipped(a);
+    return;
+  }
 
   // the job of "my" row (the epilogue marks it as allocated): fetched now, wanted then
   uint32_t job_of_my_row = 0u;
@@ -816,8 +834,13 @@ void kb_launch_commit_sel(const KbDev &d, const KbRound &r, void *stream) {
   if (r.n_rows == 0) return;
   static bool lds_set[64] = {};
   k9_allow_full_lds(reinterpret_cast<const void *>(k_commit_select), lds_set);
-  const size_t sh = k9_layout(r.n_rows, r.n_mrows, r.L, d.NP, d.R, true).total;
+  size_t sh = k9_layout(r.n_rows, r.n_mrows, r.L, d.NP, d.R, true).total;
+  if (r.lists_ready != nullptr) sh = std::max(sh, kb_repair_lds_bytes(d.NP, K9_THREADS));   // the repair workgroups' own tables: more than a window of a few rows needs (call 20)
   K9KernArgs ka;
   k9_fill_args(ka, d, r);
-  hipLaunchKernelGGL(k_commit_select, dim3(KB_WARM_GRID), dim3(K9_THREADS), sh, (hipStream_t)stream, ka);
+  static_assert(KB_REPAIR_THREADS == K9_THREADS, "the repair workgroups of a fused launch are workgroups of this kernel");
+  // a round whose lists are repaired beside its commit: one more workgroup per matrix row (they only need kb_repair_lds_bytes of the block)
+  uint32_t grid = KB_WARM_GRID;
+  if (r.lists_ready != nullptr) grid = std::max<uint32_t>(grid, r.n_mrows + (r.n_mrows - 1u) / 7u + 1u);   // row j: workgroup j + j / 7 + 1
+  hipLaunchKernelGGL(k_commit_select, dim3(grid), dim3(K9_THREADS), sh, (hipStream_t)stream, ka);
 }

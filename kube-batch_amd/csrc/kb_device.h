@@ -159,6 +159,13 @@ struct KbRound {
   uint32_t stale_L;                  // >= n_prev + L: what is left of a stale list without the predecessor's nodes still holds the true top L
   const unsigned long long *prev_dec;   // decision records of the predecessor round (low word: node), n_prev of them
   uint32_t n_prev;
+  // Round 5: the selection kernel's launch carries the repair workgroups itself (one per matrix row behind its KB_WARM_GRID workgroups; kb_repair.hpp)
+  // instead of a launch of its own in front of it: they leave lists_tag in lists_ready[row] behind each repaired list, and the commit
+  // workgroup — which has staged everything else meanwhile — waits for the tags before it stages the lists (bounded; a chain word cleared
+  // meanwhile, i.e. a stale list that never arrived, makes it report KB_REASON_SKIPPED like a round queued behind a stopped one).
+  // nullptr: the lists are final when the commit launch starts.
+  uint32_t *lists_ready;
+  uint32_t lists_tag;
 };
 // true when the round was queued behind a predecessor that did not complete
 #define KB_CHAIN_BROKEN(r) ((r).chain_expect != 0u && *(r).chain != (r).chain_expect)

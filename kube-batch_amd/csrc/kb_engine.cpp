@@ -243,7 +243,8 @@ struct kb_engine {
   // beside its predecessor's commit kernel, into buffers of their own (matrix rows, stale lists per staging half, one `ready` word per
   // list, a scratch block for their time stamps); kb_launch_repair on the first stream turns the stale lists into the round's lists
   hipStream_t stream_b = nullptr;
-  DevBuf b_score2, b_maskw2, b_stale, b_ready, b_task_rows;
+  DevBuf b_score2, b_maskw2, b_stale, b_ready, b_task_rows, b_lready;   // b_lready: one word per repaired list and staging half (KbRound::lists_ready)
+  bool fuse_repair = true;   // the selection kernel's launch carries its round's repair workgroups (KB_FUSE_REPAIR=0: the launch of its own in front of it)
   Pinned<unsigned long long> h_cand_out;   // per staging half: the output-block words the second stream's launches stamp (start of the matrix launch, start of the arg-max launch)
   unsigned long long *d_cand_out = nullptr;
   uint32_t mat2_cap = 0;
@@ -568,6 +569,8 @@ void ensure_overlap_buffers(kb_engine *e, uint32_t mrows, uint32_t stale_L) {
     e->b_ready.alloc(sizeof(uint32_t) * 2 * KB_K5_MAX_WINDOW);
     HIP_OK(hipMemset(e->b_ready.p, 0, e->b_ready.bytes));
     e->b_task_rows.alloc((size_t)64 * 2 * KB_K5_MAX_WINDOW);
+    e->b_lready.alloc(sizeof(uint32_t) * 2 * KB_K5_MAX_WINDOW);
+    HIP_OK(hipMemset(e->b_lready.p, 0, e->b_lready.bytes));
     e->h_cand_out.flags = hipHostMallocMapped | hipHostMallocCoherent;
     e->h_cand_out.resize(2 * KB_OUT_HDR);
     std::memset(e->h_cand_out.data(), 0, sizeof(unsigned long long) * 2 * KB_OUT_HDR);
@@ -600,7 +603,18 @@ void round_candidates_overlapped(kb_engine *e, RoundCtx &c, uint32_t n_prev, uns
   ra.stale_L = stale_L;
   ra.prev_dec = e->b_out.as<unsigned long long>() + KB_OUT_HDR;   // the predecessor's decision records (it completed, or the chain is broken)
   ra.n_prev = n_prev;
-  kb_launch_repair(c.d, ra, e->stream);
+  if (e->fuse_repair && e->commit_kernel == KB_COMMIT_SELECT) {
+    // The selection kernel's launch carries the repair workgroups itself (kb_commit_sel.hip, kb_repair.hpp): they start with the commit
+    // workgroup instead of a launch earlier — a kernel boundary, a launch latency and the commit prologue's staging off the dependent chain
+    // of every round.  round_commit launches with these fields; this round's commit kernel overwrites prev_dec (the result block) in its
+    // epilogue, i.e. behind its wait for the repaired lists.
+    c.r.ready = ra.ready; c.r.ready_tag = ra.ready_tag; c.r.task_rows = ra.task_rows; c.r.stale = ra.stale; c.r.stale_L = ra.stale_L;
+    c.r.prev_dec = ra.prev_dec; c.r.n_prev = ra.n_prev;
+    c.r.lists_ready = e->b_lready.as<uint32_t>() + (size_t)c.buf * KB_K5_MAX_WINDOW;
+    c.r.lists_tag = c.r.chain_tag;
+  } else {
+    kb_launch_repair(c.d, ra, e->stream);
+  }
   e->stats.matrix_launches += 1;
   e->stats.matrix_evals += (uint64_t)c.ns * e->hs.N;
   e->overlapped_rounds += 1;
@@ -664,7 +678,7 @@ void round_collect(kb_engine *e, const RoundCtx &c, bool had_candidates, uint32_
       // instead — the repair launch, from its start (its wait for the lists included) to the start of the commit kernel
       const unsigned long long *cs = e->h_cand_out.data() + (size_t)c.buf * KB_OUT_HDR + KB_OUT_STAMP0;
       if (cs[1] > cs[0]) e->stats.matrix_ms += (double)(cs[1] - cs[0]) * per_ms;
-      e->stats.argmax_ms += (double)(st[2] - st[0]) * per_ms;
+      if (st[2] > st[0]) e->stats.argmax_ms += (double)(st[2] - st[0]) * per_ms;   // (a launch that carries its own repair workgroups: they start WITH the commit workgroup, the wait is inside commit_ms)
       if (st[1] > st[0]) e->tl_repair_tag += (double)(st[1] - st[0]) * per_ms;   // ... of which: until workgroup 0 had seen its list's tag
     } else if (had_candidates) {
       e->stats.matrix_ms += (double)(st[1] - st[0]) * per_ms;   // includes the descriptor gather
@@ -1136,6 +1150,8 @@ int kb_engine_create(const kb_config *cfg, kb_engine **out) {
       eng->probe_enabled = !(pb && pb[0] == '0');
       const char *ov = getenv("KB_OVERLAP");
       eng->overlap = !(ov && ov[0] == '0');
+      const char *fr = getenv("KB_FUSE_REPAIR");   // 0: the repair launch of its own between two commit kernels (A/B; the run kernel's rounds always take it)
+      eng->fuse_repair = !(fr && fr[0] == '0');
       const char *wf = getenv("KB_DEVICE_WATERFILL");
       eng->device_waterfill = !(wf && wf[0] == '0');
       const char *dw = getenv("KB_DIRECT_WINDOW");

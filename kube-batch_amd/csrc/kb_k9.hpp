@@ -248,22 +248,25 @@ __device__ __forceinline__ bool k9_fits_idle(const KbCommitArgs &a, const K9Shap
 // What every workgroup of a commit launch does first.  Returns true when this workgroup has nothing (more) to do: the round was chained to a
 // predecessor that stopped early (workgroup 0 reports KB_REASON_SKIPPED), or this is a helper workgroup (kb_warm.hpp), which warms its slice
 // of the node state into the XCD's L2 and leaves.
+// the round does not run (queued behind a round that stopped early, or its candidate lists never arrived): nothing was evaluated or committed
+__device__ __forceinline__ void k9_publish_skipped(const KbCommitArgs &a) {
+  *a.round->chain = 0u;
+  a.result[0] = 0; a.result[1] = KB_REASON_SKIPPED;
+  if (a.host_out) {
+    a.host_out[0] = (unsigned long long)KB_REASON_SKIPPED << 32;
+    __threadfence_system();
+    __hip_atomic_store(&a.host_out[KB_OUT_SEQ], a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
 __device__ __forceinline__ bool k9_preamble(const KbCommitArgs &a) {
   if (a.round->chain_expect != 0u && *a.round->chain != a.round->chain_expect) {   // chained to a round that stopped early: skip
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
-      *a.round->chain = 0u;
-      a.result[0] = 0; a.result[1] = KB_REASON_SKIPPED;
-      if (a.host_out) {
-        a.host_out[0] = (unsigned long long)KB_REASON_SKIPPED << 32;
-        __threadfence_system();
-        __hip_atomic_store(&a.host_out[KB_OUT_SEQ], a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-      }
-    }
+    if (threadIdx.x == 0 && blockIdx.x == 0) k9_publish_skipped(a);
     return true;
   }
   if (blockIdx.x != 0) {
     if ((blockIdx.x & 7u) != 0u) return true;
     const uint32_t h = blockIdx.x / 8u - 1u, lines = a.NP / 16;
+    if (h >= KB_WARM_HELPERS) return true;   // (a launch that carries repair workgroups may be longer than KB_WARM_GRID)
     const uint32_t l0 = (uint32_t)(((unsigned long long)h * lines) / KB_WARM_HELPERS), l1 = (uint32_t)(((unsigned long long)(h + 1) * lines) / KB_WARM_HELPERS);
     const unsigned long long acc = kb_warm_lines(*a.dev, a.keys, 0, l0, l1, threadIdx.x, K9_THREADS);   // the lists are copied to LDS by the prologue itself
     if (acc == 0x123456789abcdefull) a.result[15] = 1;   // keep the loads alive (never true)
@@ -292,35 +295,59 @@ __device__ __forceinline__ bool k9_preamble(const KbCommitArgs &a) {
   const uint32_t nb = a.node_bits, nmaskbits = (1u << nb) - 1u;
 
 // ---------------- prologue (all threads): the round staged into LDS ----------------
-// maxrun: longest run of rows that share one evaluation (K9_MAXRUN; the selection kernel: K9_SEL_MAXRUN)
-// maxrun == 0: the caller derives the run lengths itself (the selection kernel: from its run-start bitmap); `stamps` (trace builds): the 100 MHz clock
-// behind the staging barrier and behind the shape tables
-__device__ __forceinline__ void k9_prologue(const KbCommitArgs &a, const K9Layout &lo, unsigned char *k9_base_, const uint32_t tid, const uint32_t maxrun,
+// One thread per tag waits until tags[i] == tag (i < n <= the workgroup); false when that never happens: the chain word was cleared meanwhile (a
+// repair workgroup gave up on its stale list) or the bound ran out.  H.stop must read 0 in LDS when the first thread arrives; ends in a barrier
+// behind which every thread of the workgroup may read what the tags cover (the waiting threads' acquire loads invalidate the CU's caches).
+// ACQ: the tags cover plain stores of another launch (the arg-max launch's: an acquire per look); otherwise what they cover was stored through to
+// memory and is read with agent-scope loads (the repair workgroups' lists), and the look is a relaxed one
+template <bool ACQ>
+__device__ __forceinline__ bool k9_wait_tags(const KbCommitArgs &a, K9Hdr &H, const uint32_t *tags, const uint32_t tag, const uint32_t n, const uint32_t tid) {
+  if (tid < n) {
+    bool gone = false;
+    uint32_t spins = 0;
+    while ((ACQ ? __hip_atomic_load(&tags[tid], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) : __hip_atomic_load(&tags[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) != tag) {
+      __builtin_amdgcn_s_sleep(2);
+      if ((++spins & 15u) == 0u) {
+        if (a.round->chain_expect != 0u && __hip_atomic_load(a.round->chain, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != a.round->chain_expect) { gone = true; break; }
+        if (spins > (1u << 22)) { gone = true; break; }
+      }
+    }
+    if (gone) H.stop = 1u;
+  }
+  __syncthreads();
+  return H.stop == 0u;
+}
+
+// maxrun: longest run of rows that share one evaluation (K9_MAXRUN); 0: the caller derives the run lengths itself (the selection kernel: from its
+// run-start bitmap).  `stamps` (trace builds): the 100 MHz clock behind the staging barrier and behind the shape tables.
+// A launch that carries its own repair workgroups (KbRound::lists_ready): nothing the second stream wrote is read before the arg-max launch's
+// tags are seen (the row descriptors come from its matrix launch), everything that does not need the lists is staged next, and the lists last,
+// behind the repair workgroups' tags.  Returns false when a tag never came: the caller publishes KB_REASON_SKIPPED and leaves.
+__device__ __forceinline__ bool k9_prologue(const KbCommitArgs &a, const K9Layout &lo, unsigned char *k9_base_, const uint32_t tid, const uint32_t maxrun,
                                             unsigned long long *stamps = nullptr) {
   const uint32_t S = a.n_mrows, W = a.n_rows;
   K9_LDS_VIEWS(lo)
   (void)slots; (void)rowres; (void)ldec; (void)dk; (void)ckey; (void)cpos; (void)RS;
+  const bool fused = a.round->lists_ready != nullptr;
   for (uint32_t w = tid; w < a.NP / 32; w += K9_THREADS) bitmap[w] = 0;
-  {   // candidate lists (64-bit keys of K3 -> compact 32-bit keys) and row descriptors.  Every load of a thread is issued before the first one is
-      // waited for: with one load per loop iteration, each waited for, a thread made 13 + 4 round trips to L2 / HBM one after the other at
-      // 25 shapes x 257 entries and 256 rows — in front of every round, with nothing else on the CU to hide them
-    constexpr uint32_t UD = 4, UL = 16;
-    const unsigned long long *dsrc = reinterpret_cast<const unsigned long long *>(a.desc);
-    unsigned long long *ddst = reinterpret_cast<unsigned long long *>(desc);
-    const uint32_t dwords = W * (uint32_t)(sizeof(KbRowDesc) / 8), tot = S * Lp;   // [S][L], Lp == L
-    for (uint32_t dbase = 0, lbase = 0; dbase < dwords || lbase < tot; dbase += K9_THREADS * UD, lbase += K9_THREADS * UL) {
-      unsigned long long dv[UD] = {}, lv[UL] = {};
-      const bool more_d = dbase < dwords, more_l = lbase < tot;   // (uniform; the loads inside are clamped, not predicated)
-      if (more_d) {
+  if (tid == 0) { H.i = 0; H.nd = 0; H.reason = KB_REASON_DONE; H.stop = 0; H.ncand = 0; H.n_dirty_rows = 0; H.n_runs = 0; H.n_slow = 0; H.cur_s = 0; H.cur_r = 0; H.cur_fl = 0; H.cur_km = 0; }
+  if (fused) {
+    __syncthreads();
+    if (!k9_wait_tags<true>(a, H, a.round->ready, a.round->ready_tag, S, tid)) return false;
+  }
+  // Candidate lists (64-bit keys of K3 -> compact 32-bit keys) and row descriptors.  Every load of a thread is issued before the first one is
+  // waited for: with one load per loop iteration, each waited for, a thread made 13 + 4 round trips to L2 / HBM one after the other at
+  // 25 shapes x 257 entries and 256 rows — in front of every round, with nothing else on the CU to hide them
+  constexpr uint32_t UD = 4, UL = 16;
+  const uint32_t tot = S * Lp;   // [S][L], Lp == L
+  auto stage_lists = [&](uint32_t lbase0) {
+    for (uint32_t lbase = lbase0; lbase < tot; lbase += K9_THREADS * UL) {
+      unsigned long long lv[UL];
 #pragma unroll
-        for (uint32_t u = 0; u < UD; u++) dv[u] = dsrc[min(dbase + u * K9_THREADS + tid, dwords - 1u)];
+      for (uint32_t u = 0; u < UL; u++) {   // (clamped, not predicated: S >= 1 with W >= 1)
+        const unsigned long long *kp = &a.keys[min(lbase + u * K9_THREADS + tid, tot - 1u)];
+        lv[u] = fused ? __hip_atomic_load(kp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *kp;   // (fused: stored through by the repair workgroups of this launch)
       }
-      if (more_l) {
-#pragma unroll
-        for (uint32_t u = 0; u < UL; u++) lv[u] = a.keys[min(lbase + u * K9_THREADS + tid, tot - 1u)];
-      }
-#pragma unroll
-      for (uint32_t u = 0; u < UD; u++) { const uint32_t w = dbase + u * K9_THREADS + tid; if (w < dwords) ddst[w] = dv[u]; }
 #pragma unroll
       for (uint32_t u = 0; u < UL; u++) {
         const uint32_t idx = lbase + u * K9_THREADS + tid;
@@ -328,9 +355,32 @@ __device__ __forceinline__ void k9_prologue(const KbCommitArgs &a, const K9Layou
         if (idx < tot) lists[idx] = k64 ? (((KB_KEY_SCORE(k64) + 1u) << nb) | (nmaskbits - KB_KEY_NODE(k64))) : 0u;
       }
     }
+  };
+  {
+    const unsigned long long *dsrc = reinterpret_cast<const unsigned long long *>(a.desc);
+    unsigned long long *ddst = reinterpret_cast<unsigned long long *>(desc);
+    const uint32_t dwords = W * (uint32_t)(sizeof(KbRowDesc) / 8);
+    static_assert(KB_K5_MAX_ROWS * (sizeof(KbRowDesc) / 8) <= K9_THREADS * UD, "the descriptors are staged in one batch");
+    unsigned long long dv[UD], lv[UL] = {};
+#pragma unroll
+    for (uint32_t u = 0; u < UD; u++) dv[u] = dsrc[min(u * K9_THREADS + tid, dwords - 1u)];
+    if (!fused && tot) {   // the first batch of the lists in the same round trip
+#pragma unroll
+      for (uint32_t u = 0; u < UL; u++) lv[u] = a.keys[min(u * K9_THREADS + tid, tot - 1u)];
+    }
+#pragma unroll
+    for (uint32_t u = 0; u < UD; u++) { const uint32_t w = u * K9_THREADS + tid; if (w < dwords) ddst[w] = dv[u]; }
+    if (!fused) {
+#pragma unroll
+      for (uint32_t u = 0; u < UL; u++) {
+        const uint32_t idx = u * K9_THREADS + tid;
+        const unsigned long long k64 = lv[u];
+        if (idx < tot) lists[idx] = k64 ? (((KB_KEY_SCORE(k64) + 1u) << nb) | (nmaskbits - KB_KEY_NODE(k64))) : 0u;
+      }
+      stage_lists(K9_THREADS * UL);
+    }
   }
   for (uint32_t s = tid; s < S; s += K9_THREADS) cursor[s] = 0;
-  if (tid == 0) { H.i = 0; H.nd = 0; H.reason = KB_REASON_DONE; H.stop = 0; H.ncand = 0; H.n_dirty_rows = 0; H.n_runs = 0; H.n_slow = 0; H.cur_s = 0; H.cur_r = 0; H.cur_fl = 0; H.cur_km = 0; }
   __syncthreads();
   if (stamps) stamps[0] = wall_clock64();
   // shape -> one of its rows (any: rows of a shape agree on everything the evaluation reads)
@@ -366,7 +416,12 @@ __device__ __forceinline__ void k9_prologue(const KbCommitArgs &a, const K9Layou
       while (r < maxrun && i + r < W && desc[i + r].slot == sl && desc[i + r].flags == fl && desc[i + r].resmask == km) r++;
     rinfo[i] = make_uint4(r, sl, fl, km);
   }
+  if (fused) {   // the candidate lists last: everything above ran beside the workgroups that repair them
+    if (!k9_wait_tags<false>(a, H, a.round->lists_ready, a.round->lists_tag, S, tid)) return false;
+    stage_lists(0u);
+  }
   __syncthreads();
+  return true;
 }
 
 // ---------------- epilogue (all threads): dirty slots, decision records, task table, result words, host mirror ----------------

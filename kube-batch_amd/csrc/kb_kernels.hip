@@ -26,6 +26,7 @@
 #include "kb_device.h"
 #include "kb_eval.hpp"
 #include "kb_k1.hpp"
+#include "kb_repair.hpp"
 #include "kb_warm.hpp"
 
 // ------------------------------------------------------------------------------------------------------------
@@ -286,17 +287,6 @@ __device__ __forceinline__ int wave_max_i32_dpp(int v) {
 #undef KB_DPP_IMAX
   return __builtin_amdgcn_readlane(v, 63);
 }
-// inclusive scan inside the wave: DPP row shifts, then row broadcasts (the sequence LLVM's buildScan emits)
-__device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v) {
-  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);   // row_shr:1
-  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);   // row_shr:2
-  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);   // row_shr:4
-  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);   // row_shr:8
-  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);   // row_bcast:15
-  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);   // row_bcast:31
-  return v;
-}
-
 // Sorted candidate list of one matrix row: the first K entries of (score descending, node ascending).  Scores are integers,
 // so the list is built one BAND of consecutive score values at a time (eight values; WIDE, rows of 65536 nodes or more where a
 // 16-bit counter could overflow: four): one pass over the row (staged in LDS) counts each thread's nodes at every value of
@@ -447,154 +437,15 @@ __global__ void __launch_bounds__(THREADS) k_argmax(KbDev d, KbRound r) {
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// k_repair: the candidate lists of an OVERLAPPED round (KbRound::ready).  Its matrix and arg-max launches ran on the second stream while
-// the predecessor round's commit kernel was still changing nodes: their lists are exact for every node the predecessor left alone and
-// arbitrary for the nodes it changed.  One workgroup per matrix row, behind the predecessor's commit on the first stream:
-//   1. the predecessor's nodes (its decision records; a node may have taken several rows) -> a bitmap in LDS, each node owned by one thread;
-//   2. the owner evaluates the row's shape against the node's state as the predecessor LEFT it (eval_row<1>, K1's own arithmetic);
-//   3. the stale list without the predecessor's nodes, merged with the new keys by rank.  A new key f finds its place lo(f) in the stale list (the
-//      number of stale entries above it: binary search) and leaves a mark there; a survivor at index i then has exactly the new keys with
-//      lo(f) <= i above it — a prefix sum of the marks, in the same block scan that counts the survivors in front of it; a new key has the
-//      survivors in front of index lo(f) and the new keys above it (counted directly: at most n_prev of them, the work split over the whole
-//      workgroup).  Keys are distinct (the node index is part of them; a stale entry equal to a new key is that node's own, and dropped), so the
-//      ranks are a permutation.  (Every survivor counting the new keys above it by comparison — n_prev 64-bit compares in each of ~500
-//      threads — was 3 of this launch's 14 us, on the dependent chain of every round.)
-// A clean node of the true top L has at most L - 1 clean and n_prev changed nodes above it in the stale order: stale_L >= n_prev + L entries
-// hold every one of them.
+// k_repair: the candidate lists of an OVERLAPPED round as a launch of its own (kb_repair.hpp has the work; the selection kernel's launch
+// carries the same workgroups itself: kb_commit_sel.hip).  One workgroup per matrix row, behind the predecessor's commit on the first stream.
 // ------------------------------------------------------------------------------------------------------------
-#define KB_REPAIR_THREADS 1024
 __global__ void __launch_bounds__(KB_REPAIR_THREADS) k_repair(KbDev d, KbRound r) {
   extern __shared__ __align__(16) unsigned char kr_smem[];
-  unsigned long long *stale = reinterpret_cast<unsigned long long *>(kr_smem);                 // [KB_REPAIR_THREADS]
-  unsigned long long *fresh = stale + KB_REPAIR_THREADS;                                       // [n_prev] keys of the predecessor's nodes (0: infeasible / not owned)
-  uint32_t *alive_before = reinterpret_cast<uint32_t *>(fresh + KB_K5_MAX_WINDOW);             // [KB_REPAIR_THREADS + 1] survivors in front of entry i
-  uint32_t *marks = alive_before + KB_REPAIR_THREADS + 1;                                      // [KB_REPAIR_THREADS + 1] new keys whose place in the stale list is index i
-  uint32_t *fresh_above = marks + KB_REPAIR_THREADS + 1;                                       // [KB_K5_MAX_WINDOW] new keys above new key j
-  uint32_t *bitmap = fresh_above + KB_K5_MAX_WINDOW;                                           // [NP / 32]
-  __shared__ uint32_t s_wtot[KB_REPAIR_THREADS / 64], s_mtot[KB_REPAIR_THREADS / 64];
-  static_assert(KB_K5_MAX_WINDOW <= KB_REPAIR_THREADS && KB_K5_MAX_WINDOW % 8 == 0, "a thread per decision record of the predecessor; fresh[] is read eight entries at a time");
-  const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, row = blockIdx.x;
   if (KB_CHAIN_BROKEN(r)) return;
-  if (row == 0 && tid == 0) {   // the round's matrix / arg-max stamps: the candidate launches ran beside the predecessor, this is what the round waits for
-    unsigned long long *st = reinterpret_cast<unsigned long long *>(r.result);
-    st[KB_OUT_STAMP0] = wall_clock64();   // [+1] follows when row 0's tag has been seen: "matrix" time of such a round = what it waited for its lists
-  }
-  // Latency is what this launch costs (it sits between two commit kernels): every load that does not depend on another is issued before the
-  // first wait.  The predecessor's decision records are final (kernel boundary), so its nodes are fetched while thread 0 still looks for the tag.
-  const uint32_t np = r.n_prev;
-  uint32_t node = KB_NONE_U32;
-  if (tid < np) node = (uint32_t)(r.prev_dec[tid] & 0xFFFFFFFFull);
-  for (uint32_t w = tid; w < d.NP / 32; w += KB_REPAIR_THREADS) bitmap[w] = 0u;
-  marks[tid] = 0u;
-  if (tid == 0) marks[KB_REPAIR_THREADS] = 0u;
-  if (tid < KB_K5_MAX_WINDOW) fresh_above[tid] = 0u;
-  __shared__ uint32_t s_late;
-  if (tid == KB_REPAIR_THREADS - 1) {   // a thread without a decision record to fetch (n_prev <= the window < the workgroup): the tag's round trip runs beside that fetch
-    // the list was launched (second stream) before this kernel (first stream) and had a whole commit kernel's time to finish: the wait is
-    // normally over before it starts.  Bounded all the same: a list that never arrives breaks the chain — the commit kernel behind this one
-    // then skips the round and the host launches it again on the plain path — instead of hanging the device.
-    uint32_t spins = 0, late = 0;
-    while (__hip_atomic_load(&r.ready[row], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != r.ready_tag) {
-      __builtin_amdgcn_s_sleep(8);
-      if (++spins > (1u << 21)) { late = 1; break; }
-    }
-    s_late = late;
-    if (late && r.chain != nullptr) *r.chain = 0u;
-    if (row == 0) reinterpret_cast<unsigned long long *>(r.result)[KB_OUT_STAMP0 + 1] = wall_clock64();
-  }
-  __syncthreads();
-  if (s_late) return;
-  // 1 + 2, one round trip for all of it: the predecessor's nodes (a node may have taken several rows: one owner each) and their state; behind
-  // the tag, the row's task record and the stale list; then the owners evaluate (K1's own arithmetic)
-  bool owner = false;
-  K1Node nv[1];
-  nv[0].valid = 0;
-  if (node != KB_NONE_U32) {
-    const uint32_t old = atomicOr(&bitmap[node >> 5], 1u << (node & 31));
-    owner = !((old >> (node & 31)) & 1u);
-    if (owner) nv[0] = k1_node(d, node);
-  }
-  const uint32_t Ls = r.stale_L;
-  const unsigned long long sk = (tid < Ls) ? r.stale[(size_t)row * Ls + tid] : 0ull;
-  unsigned long long fk = 0ull;
-  if (owner) {
-    const K1Task tv = k1_uniform(reinterpret_cast<const K1Task *>(r.task_rows)[row]);
-    uint32_t res[1];
-    eval_row<1>(d, tv, nv, node, r.fit_mode, res);
-    if (res[0] >> 16) fk = KB_KEY(res[0] & 0xFFFFu, node);
-  }
-  if (tid < KB_K5_MAX_WINDOW) fresh[tid] = fk;
-  stale[tid] = sk;   // 0-terminated, best first
-  __syncthreads();
-  // 3: survivors and their prefix counts; the new keys' places
-  const bool alive = sk != 0ull && !((bitmap[KB_KEY_NODE(sk) >> 5] >> (KB_KEY_NODE(sk) & 31)) & 1u);
-  const unsigned long long bal = __ballot(alive);
-  const uint32_t in_wave = (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
-  if (lane == 0) s_wtot[wave] = (uint32_t)__popcll(bal);
-  uint32_t lo = 0;
-  if (fk != 0ull) {
-    // stale entries above fk: the list is descending; entries equal to 0 (behind its end) are never above
-    uint32_t hi = KB_REPAIR_THREADS;
-    while (lo < hi) {
-      const uint32_t mid = (lo + hi) >> 1;
-      if (stale[mid] > fk) lo = mid + 1; else hi = mid;
-    }
-    atomicAdd(&marks[lo], 1u);
-  }
-  {   // new keys above a new key, eight per step as four 16-byte LDS reads in flight together (fresh[] reads 0 behind n_prev: every thread stored
-      // its key or 0).  A window of at most 256 rows (the commit kernel's KB_K5_MAX_ROWS): thread (part, j) compares key j with a quarter of them
-    auto count_above = [&](unsigned long long key, uint32_t i0, uint32_t i1) {
-      uint32_t c = 0;
-      for (uint32_t i = i0; i < i1; i += 8) {
-        const ulonglong2 a = *reinterpret_cast<const ulonglong2 *>(&fresh[i]), b = *reinterpret_cast<const ulonglong2 *>(&fresh[i + 2]);
-        const ulonglong2 e = *reinterpret_cast<const ulonglong2 *>(&fresh[i + 4]), f = *reinterpret_cast<const ulonglong2 *>(&fresh[i + 6]);
-        c += (a.x > key ? 1u : 0u) + (a.y > key ? 1u : 0u) + (b.x > key ? 1u : 0u) + (b.y > key ? 1u : 0u) +
-             (e.x > key ? 1u : 0u) + (e.y > key ? 1u : 0u) + (f.x > key ? 1u : 0u) + (f.y > key ? 1u : 0u);
-      }
-      return c;
-    };
-    const uint32_t np8 = (np + 7u) & ~7u;
-    if (np <= KB_REPAIR_THREADS / 4u) {
-      const uint32_t j = tid % (KB_REPAIR_THREADS / 4u), part = tid / (KB_REPAIR_THREADS / 4u);
-      const uint32_t per = (((np8 + 3u) >> 2) + 7u) & ~7u, i0 = part * per, i1 = min(np8, i0 + per);
-      const unsigned long long key = fresh[j];
-      if (key != 0ull && i0 < i1) {
-        const uint32_t c = count_above(key, i0, i1);
-        if (c) atomicAdd(&fresh_above[j], c);
-      }
-    } else if (fk != 0ull) {
-      fresh_above[tid] = count_above(fk, 0u, np8);
-    }
-  }
-  __syncthreads();
-  const uint32_t mscan = wave_incl_scan_u32(marks[tid]);   // new keys whose place is at or in front of my entry, inside the wave
-  if (lane == 63) s_mtot[wave] = mscan;
-  __syncthreads();
-  uint32_t before = in_wave, above = mscan;
-  for (uint32_t w = 0; w < wave; w++) { before += s_wtot[w]; above += s_mtot[w]; }
-  alive_before[tid] = before;
-  if (tid == KB_REPAIR_THREADS - 1) alive_before[KB_REPAIR_THREADS] = before + (alive ? 1u : 0u);
-  __syncthreads();
-  const uint32_t K = r.L;
-  unsigned long long *out = r.keys + (size_t)row * K;
-  if (alive) {
-    const uint32_t rank = before + above;
-    if (rank < K) out[rank] = sk;
-  }
-  if (fk != 0ull) {
-    const uint32_t rank = alive_before[lo] + fresh_above[tid];
-    if (rank < K) out[rank] = fk;
-  }
-  // the tail: entries behind the merged list read 0
-  uint32_t cnt_fresh = 0;
-  for (uint32_t i = lane; i < np; i += 64) cnt_fresh += fresh[i] != 0ull ? 1u : 0u;   // every wave counts for itself (no further barrier)
-  for (int off = 32; off > 0; off >>= 1) cnt_fresh += (uint32_t)__shfl_xor((int)cnt_fresh, off);
-  const uint32_t total = alive_before[KB_REPAIR_THREADS] + cnt_fresh;
-  for (uint32_t i = total + tid; i < K; i += KB_REPAIR_THREADS) out[i] = 0ull;
+  kb_repair_row<KB_REPAIR_THREADS>(d, r, kr_smem, blockIdx.x, threadIdx.x);
 }
-size_t kb_repair_smem_bytes(uint32_t NP) {
-  return sizeof(unsigned long long) * (KB_REPAIR_THREADS + KB_K5_MAX_WINDOW) + sizeof(uint32_t) * (2 * (KB_REPAIR_THREADS + 1) + KB_K5_MAX_WINDOW) + sizeof(uint32_t) * (NP / 32);
-}
+size_t kb_repair_smem_bytes(uint32_t NP) { return kb_repair_lds_bytes(NP, KB_REPAIR_THREADS); }
 void kb_launch_repair(const KbDev &d, const KbRound &r, void *stream) {
   if (r.n_mrows == 0) return;
   const size_t sh = kb_repair_smem_bytes(d.NP);   // the engine overlaps rounds only while this fits the attribute below (kb_engine.cpp: overlap_ok)

@@ -3,6 +3,7 @@
 #   first    the reload module (one engine, many sessions; soak), the whole -m gpu suite, the default bench, kb_session_load traces of configs 3, 4, 5
 #   ab       same-box A/B of engine builds: every kube-batch_amd/libkbengine_<tag>.so beside the default one (configs 3, survey, 4, 5), each
 #            verified; optionally the differential suites on one of them:   ab [tag-to-test]
+#   fuse     A/B of KB_FUSE_REPAIR (repair workgroups inside the selection kernel's launch, or a launch of their own) + the differential suites on both
 #   trace    the selection kernel's per-phase cycle trace (make EXTRA=-DKB_K9_TRACE OUT=../libkbengine_trace.so), configs 3 and 4
 #   profile  rocprofv3 of the default command: kernel stats, HBM bytes of the matrix launches, SQ counters of the commit kernel
 #            (scripts/summarize_profile.py r5_profile profiles/round5)
@@ -61,6 +62,24 @@ ab)   # ab <tag,tag,...> [test]: kube-batch_amd/libkbengine_<tag>.so beside the 
     echo "differential suites on the default build (selection kernel, reload, full size) rc=$? $(tail -1 "$out/pytest_default.txt")" | tee -a "$out/summary.txt"
   fi
   ;;
+fuse)   # the repair workgroups inside the selection kernel's launch (default) against the launch of their own (KB_FUSE_REPAIR=0), same box, same
+        # library, alternating; then the differential suites on the default and the selection / full-size ones on the other path
+  for rep in $(seq 1 ${AB_REPS:-2}); do
+    bench_ab "c3_fused_r${rep}" -- --config 3 --steps 5 --warmup 2 --verify
+    bench_ab "c3_unfused_r${rep}" KB_FUSE_REPAIR=0 -- --config 3 --steps 5 --warmup 2 --verify
+  done
+  for v in fused unfused; do
+    envs=(); [ "$v" = unfused ] && envs=(KB_FUSE_REPAIR=0)
+    bench_ab "survey_${v}" "${envs[@]}" -- --config 3 --survey-nodes --steps 5 --warmup 2 --verify
+    bench_ab "c4_${v}" "${envs[@]}" -- --config 4 --steps 5 --warmup 2 --verify
+    bench_ab "c5_${v}" "${envs[@]}" -- --config 5 --steps 2 --warmup 1 --verify
+    [ -n "${AB_SKIP_C2:-}" ] || bench_ab "c2_${v}" "${envs[@]}" -- --config 2 --steps 10 --warmup 3 --verify
+  done
+  timeout 900 python -m pytest tests -q -m gpu -p no:cacheprovider -k "select or reload or fullsize or sharded or waterfill or framework" --maxfail=10 > "$out/pytest_default.txt" 2>&1
+  echo "differential suites, repair inside the launch rc=$? $(tail -1 "$out/pytest_default.txt")" | tee -a "$out/summary.txt"
+  KB_FUSE_REPAIR=0 timeout 600 python -m pytest tests -q -m gpu -p no:cacheprovider -k "fullsize or (select and (fuzz or parity or adversarial))" --maxfail=10 > "$out/pytest_unfused.txt" 2>&1
+  echo "selection + full-size suites, repair as a launch of its own rc=$? $(tail -1 "$out/pytest_unfused.txt")" | tee -a "$out/summary.txt"
+  ;;
 trace)
   for cfg in "3" "4"; do
     KB_ENGINE_LIB=$PWD/kube-batch_amd/libkbengine_trace.so KB_K5_STATS=1 python bench.py --no-cpu-baseline --config ${cfg} --steps 2 --warmup 1 \
@@ -111,7 +130,7 @@ final)   # the round's closing evidence on the final tree: whole suite, rocprofv
   bench_ab config5 -- --config 5 --steps 3 --warmup 1 --verify
   bench_ab config5_preempt -- --config 5 --preempt --steps 2 --warmup 1 --verify
   timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -1 | tee -a "$out/summary.txt"
-  KB_HUNT_OFFSET=${KB_HUNT_OFFSET:-50000} timeout 600 python scripts/gpu_hunt.py 200 600 300 > "$out/hunt.txt" 2>&1; echo "fresh-seed hunt (both kernels) rc=$? $(tail -1 "$out/hunt.txt")" | tee -a "$out/summary.txt"
+  KB_HUNT_OFFSET=${KB_HUNT_OFFSET:-50000} timeout 600 python scripts/gpu_hunt.py ${HUNT_ARGS:-200 600 300} > "$out/hunt.txt" 2>&1; echo "fresh-seed hunt (both kernels) rc=$? $(tail -1 "$out/hunt.txt")" | tee -a "$out/summary.txt"
   KB_SCALE_GLOO=1 timeout 900 bash scripts/scale_curve.sh "$out/scale" 3 > "$out/scale_curve_log.txt" 2>&1; cat "$out/scale/scale_curve.txt" | tee -a "$out/summary.txt"
   ;;
 *) echo "unknown step $step"; exit 2 ;;

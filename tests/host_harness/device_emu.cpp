@@ -617,9 +617,10 @@ static void emu_repair(const KbDev &d, const KbRound &r) {
     std::sort(keys.begin(), keys.end(), [](u64 a, u64 b) { return a > b; });
     u64 *out = r.keys + (size_t)m * r.L;
     for (uint32_t i = 0; i < r.L; i++) out[i] = i < keys.size() ? keys[i] : 0ull;
+    if (r.lists_ready != nullptr) __atomic_store_n(&r.lists_ready[m], r.lists_tag, __ATOMIC_RELEASE);   // the tag the commit workgroup of a fused launch waits for
   }
 }
-size_t kb_repair_smem_bytes(uint32_t NP) { return 8 * (1024 + 1024) + 4 * 1025 + 4 * (size_t)(NP / 32); }
+size_t kb_repair_smem_bytes(uint32_t NP) { return 8 * (1024 + 512) + 4 * (2 * 1025 + 512) + 4 * 36 + 4 * (size_t)(NP / 32); }   // kb_repair.hpp: kb_repair_lds_bytes
 void kb_launch_repair(const KbDev &d, const KbRound &r, void *stream) {
   kbemu_enqueue((hipStream_t)stream, [d, r]() { emu_repair(d, r); });
 }
@@ -657,7 +658,14 @@ void kb_launch_scatter_nodes(const KbDev &d, const unsigned long long *rec, uint
 
 void kb_launch_commit(const KbDev &d, const KbRound &r, void *stream) { kbemu_enqueue((hipStream_t)stream, [d, r]() { emu_commit(d, r); }); }
 // the selection kernel (k_commit_run<true>): the run kernel's contract and statistics words
-void kb_launch_commit_sel(const KbDev &d, const KbRound &r, void *stream) { kbemu_enqueue((hipStream_t)stream, [d, r]() { emu_commit(d, r); }); }
+// A round whose launch carries its own repair workgroups (KbRound::lists_ready): the lists are repaired inside the launch, in front of everything
+// the commit reads of them; a stale list that never arrives clears the chain word and the commit reports KB_REASON_SKIPPED
+void kb_launch_commit_sel(const KbDev &d, const KbRound &r, void *stream) {
+  kbemu_enqueue((hipStream_t)stream, [d, r]() {
+    if (r.lists_ready != nullptr) emu_repair(d, r);
+    emu_commit(d, r);
+  });
+}
 
 uint32_t kb_apply_deltas(const KbDev &d, const double *s_idle, const double *s_rel, const long long *s_nzc, const long long *s_nzm,
                          const int *s_podcnt, const double *delta, uint32_t *dev_counter, void *stream) {

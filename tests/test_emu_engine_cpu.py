@@ -293,12 +293,15 @@ def test_full_size_cycles_through_the_host_side(oracle_mod, name):
     fs.test_full_size_cycle_equals_oracle_and_golden_digest(oracle_mod, name)
 
 
-def test_overlapped_candidate_lists_are_repaired(emulated_engine, monkeypatch):
-    """Chained rounds of plain sessions build their candidate lists on a second stream beside the predecessor's commit kernel and repair them
+@pytest.mark.parametrize("fuse", ["1", "0"])
+def test_overlapped_candidate_lists_are_repaired(emulated_engine, monkeypatch, fuse):
+    """(fuse: the repair inside the selection kernel's launch — the default — or as a launch of its own in front of it, KB_FUSE_REPAIR=0.)
+    Chained rounds of plain sessions build their candidate lists on a second stream beside the predecessor's commit kernel and repair them
     behind it (kb_kernels.hip: k_repair).  The emulated matrix launch of such a round POISONS what it reports for the nodes
     the last commit changed, so the decisions only come out right if the repair launch overrides exactly those: equal to the oracle with it,
     different without it (KB_EMU_REPAIR_OFF=1 hands the stale lists on as they are — the negative control), and equal again on the plain
     path (KB_OVERLAP=0)."""
+    monkeypatch.setenv("KB_FUSE_REPAIR", fuse)
     oracle_mod = importlib.import_module("oracle")
     snap = kbm.snapshot.synth(kbm.snapshot.synth_config(3, 0.05))
     conf = kbm.conf.load_scheduler_conf()
@@ -325,8 +328,9 @@ def test_overlapped_candidate_lists_are_repaired(emulated_engine, monkeypatch):
     assert ok_plain and rounds_plain == rounds
 
 
-def test_a_candidate_list_that_never_arrives_breaks_the_chain_and_the_round_runs_again(emulated_engine, monkeypatch):
-    """k_repair's wait for its lists is bounded: a list that never arrives (here: the emulated arg-max launch of every third overlapped round
+@pytest.mark.parametrize("fuse", ["1", "0"])
+def test_a_candidate_list_that_never_arrives_breaks_the_chain_and_the_round_runs_again(emulated_engine, monkeypatch, fuse):
+    """(fuse: as above.)  k_repair's wait for its lists is bounded: a list that never arrives (here: the emulated arg-max launch of every third overlapped round
     drops its tag) makes it break the chain, the commit kernel behind it skips the round, the host takes the skipped round back, counts the fault
     and keeps every later round of that engine on the plain path — same decisions as the oracle, no hang, no wrong bind."""
     oracle_mod = importlib.import_module("oracle")
@@ -334,6 +338,7 @@ def test_a_candidate_list_that_never_arrives_breaks_the_chain_and_the_round_runs
     conf = kbm.conf.load_scheduler_conf()
     o = oracle_mod.Oracle(conf, snap)
     o.run(["allocate", "backfill"])
+    monkeypatch.setenv("KB_FUSE_REPAIR", fuse)
     monkeypatch.setenv("KB_EMU_DROP_TAG", "3")
     monkeypatch.setenv("KB_EMU_REPAIR_WAIT_NS", "2e6")
     for _ in range(2):                                   # twice: the fault must not outlive the action that met it
