@@ -27,7 +27,10 @@ _VARIANTS = [{}, {"KB_CHAIN_ROUNDS": "0"}, {"KB_SYNC_ROUNDS": "1"}, {"KB_PROBE":
              {"KB_COMMIT_KERNEL": "run"}, {"KB_COMMIT_KERNEL": "select"}, {"KB_CHAIN_ROUNDS": "0", "KB_PROBE": "0", "KB_DIRECT_WINDOW": "0"},
              # round 3: chained rounds build their candidate lists on a second stream beside the predecessor's commit and repair them
              # (the default, variant 0); KB_OVERLAP=0 keeps every round on one stream
-             {"KB_OVERLAP": "0"}, {"KB_OVERLAP": "0", "KB_COMMIT_KERNEL": "run"}]
+             {"KB_OVERLAP": "0"}, {"KB_OVERLAP": "0", "KB_COMMIT_KERNEL": "run"},
+             # round 5: the selection kernel's launch carries the repair workgroups of its round (the default, variant 0); KB_FUSE_REPAIR=0
+             # keeps them a launch of their own in front of it (what the run kernel's rounds always do: variant 5)
+             {"KB_FUSE_REPAIR": "0"}]
 
 
 @pytest.mark.parametrize("variant", range(len(_VARIANTS)))
@@ -40,6 +43,9 @@ def test_launch_path_variants_agree_with_the_oracle(oracle_mod, variant, monkeyp
     cases = [fz._case(seed) for seed in (3, 11, 19, 27)]
     cases.append((kbm.conf.load_scheduler_conf(), kbm.snapshot.synth(kbm.snapshot.synth_config(3, 0.03)), 0, 0))
     cases.append((kbm.conf.load_scheduler_conf(), kbm.snapshot.synth(kbm.snapshot.synth_config(4, 0.03)), 64, 0))
+    # windows of one and three rows: the commit workgroup's LDS layout is then smaller than a repair workgroup's tables (round 5, call 20)
+    cases.append((kbm.conf.load_scheduler_conf(), kbm.snapshot.synth(kbm.snapshot.synth_config(3, 0.01)), 3, 0))
+    cases.append((kbm.conf.load_scheduler_conf(), kbm.snapshot.synth(kbm.snapshot.synth_config(2, 0.05)), 1, 0))
     for cfg, snap, window, batch in cases:
         o = oracle_mod.Oracle(cfg, snap)
         o.run(["allocate", "backfill"])
