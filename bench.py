@@ -378,6 +378,10 @@ def main():
         "value_counts": "reference-equivalent (task,node) evaluations",
         "matrix_evals_per_step": int(d["matrix_evals"] / args.steps),
         "kernel_ms_per_step": {k: round(d[k] / args.steps, 3) for k in ("matrix_ms", "argmax_ms", "commit_ms", "reduce_ms", "host_order_ms", "total_ms")},
+        # (round 5: a chained round's repair workgroups ride in its commit launch — commit_ms contains the commit workgroup's wait for them,
+        #  argmax_ms only what a round waited for its lists OUTSIDE that launch: first rounds, re-planned rounds, KB_FUSE_REPAIR=0; matrix_ms of
+        #  chained rounds ran on the second stream beside the predecessor's commit and is not on the cycle's timeline)
+        "kernel_ms_note": "commit_ms includes the wait for the repair workgroups of the same launch; matrix_ms of chained rounds is off the timeline",
         "rounds_per_step": d["rounds"] / args.steps, "spec_breaks_per_step": d["spec_breaks"] / args.steps,
         "row_fallbacks_per_step": d["row_fallbacks"] / args.steps,
         "roofline": roofline, "roofline_cycle": roofline_cycle, "roofline_eval": roofline_eval, "roofline_eval_all_rows": roofline_eval_all,
