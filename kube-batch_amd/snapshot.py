@@ -1039,7 +1039,7 @@ def synth(p: SynthParams) -> SessionSnapshot:
         node_nzc += np.where(fits, c, 0); node_nzm += np.where(fits, m, 0); node_cnt += fits.astype(np.int32)
 
     # ---- jobs: draw gang sizes until the task budget is met
-    est_jobs = int(p.n_tasks / 8) + 64
+    est_jobs = max(int(p.n_tasks / 8) + 64, -(-p.n_tasks // min(p.gang_sizes)) + 1)   # (draws are indexed: asking for more leaves the first ones as they were)
     sizes = S(30).choice(est_jobs, np.array(p.gang_sizes, np.int64), p.gang_probs)
     csum = np.cumsum(sizes)
     J = int(np.searchsorted(csum, p.n_tasks, side="left")) + 1

@@ -63,6 +63,31 @@ def test_launch_path_variants_agree_with_the_oracle(oracle_mod, variant, monkeyp
         o.close()
 
 
+@pytest.mark.parametrize("fuse", ["1", "0"])
+def test_windows_of_as_many_shapes_as_a_window_admits(oracle_mod, monkeypatch, fuse):
+    """Single-task jobs that each draw their own request: every window is cut at the shape capacity (64 rows, 64 shapes), so a chained round
+    repairs 64 lists — in the selection kernel's launch the repair workgroups then reach beyond its KB_WARM_GRID workgroups (rows 56 and up;
+    round 5).  Equal to the oracle with the repair inside the launch and as a launch of its own."""
+    monkeypatch.setenv("KB_FUSE_REPAIR", fuse)
+    p = kbm.snapshot.synth_config(3, 0.03)
+    p.gang_sizes, p.gang_probs, p.diverse_requests = (1,), (1.0,), True
+    snap = kbm.snapshot.synth(p)
+    cfg = kbm.conf.load_scheduler_conf()
+    o = oracle_mod.Oracle(cfg, snap)
+    o.run(["allocate", "backfill"])
+    e = engine.Engine(cfg)
+    e.load(snap)
+    dec = e.run(["allocate", "backfill"])
+    assert np.array_equal(dec, o.decisions()) and np.array_equal(e.binds(), o.binds())
+    for a, b in zip(e.node_state(), o.node_state()):
+        assert np.array_equal(a, b)
+    st = e.stats()
+    assert st["evals"] == o.evals
+    assert st["matrix_evals"] / (snap.node_idle.shape[1] * st["matrix_launches"]) > 56.0, st      # shapes per round, on average
+    e.close()
+    o.close()
+
+
 def test_job_with_a_missing_queue_without_proportion(oracle_mod):
     """"queue not found" (allocate.go:56-60) is legal when proportion is not loaded: allocate skips the job, drf still counts its
     running tasks; the share reduction must not look for a queue row (kb_kernels.hip: k_finalize_jobs guards q < Q)."""
