@@ -293,6 +293,8 @@ struct kb_engine {
   // (a discarded statement is the one thing inside a session that creates such a task)
   bool stale_checked = false, pristine = true, load_clean = false;
   double tl_reset = 0, tl_begin = 0, tl_break = 0, tl_finish = 0, tl_wait = 0, tl_backfill = 0;
+  double tl_begin_parts[3] = {0, 0, 0};   // of tl_begin: the order machine's set-up, the first feasibility probe, the first plan (the rest: buffers, the first launch)
+  double tl_break_parts[3] = {0, 0, 0};   // of tl_break: absorbing the answer (roll-back + replay), the probe, the re-plan (the rest: the skipped round, the launch)
   std::vector<kb_decision> decisions_all;   // decisions of the last multi-GPU round sequence
   std::vector<uint32_t> evictions;          // committed evictions of the session's preempt actions, in cache.Evict order
 
@@ -1181,6 +1183,9 @@ void kb_engine_destroy(kb_engine *e) {
   if (getenv("KB_K5_STATS"))
     fprintf(stderr, "[kb host] ms over the engine's life: reset %.2f, allocate up to its first launch %.2f, speculation breaks (answer -> re-planned launch) %.2f, "
             "closing reductions %.2f, waiting for rounds %.2f, backfill up to its first launch %.2f\n", e->tl_reset, e->tl_begin, e->tl_break, e->tl_finish, e->tl_wait, e->tl_backfill);
+  if (getenv("KB_K5_STATS"))
+    fprintf(stderr, "[kb host] of the start: order machine %.2f, first probe %.2f, first plan %.2f; of the breaks: absorb %.2f, probe %.2f, re-plan %.2f\n",
+            e->tl_begin_parts[0], e->tl_begin_parts[1], e->tl_begin_parts[2], e->tl_break_parts[0], e->tl_break_parts[1], e->tl_break_parts[2]);
   if (getenv("KB_K5_STATS")) fprintf(stderr, "[kb probe] %llu probes, %llu shapes marked dead by them\n", (unsigned long long)e->probes, (unsigned long long)e->probe_deaths);
   if (getenv("KB_K5_STATS") && e->k5_trace[0] > 0) {
     static const char *ph[10] = {"barrier 1 (wave 0's wait)", "evaluate: candidates (wave 0)", "barrier 2", "rows", "prepare the next run",
@@ -1666,8 +1671,12 @@ static int run_action(kb_engine *e, uint32_t action, kb_decision *out, uint64_t 
     const double t_act0 = now_ms();
     ActionRun run;
     run.begin(e, action);
+    const double t_act1 = now_ms();
     run.probe_dead_shapes(e);   // shapes no node can take from the start (larger than every node, full classes) never cost a break
+    const double t_act2 = now_ms();
     uint32_t n = run.plan(e);
+    const double t_act3 = now_ms();
+    if (action == 0) { e->tl_begin_parts[0] += t_act1 - t_act0; e->tl_begin_parts[1] += t_act2 - t_act1; e->tl_begin_parts[2] += t_act3 - t_act2; }
     ensure_matrix_buffers(e, e->eff_window, e->eff_window + 1);   // sized once: no reallocation under a round in flight
     // chained rounds of plain sessions (no score that is normalised over the feasible set, no inter-pod counters) build their candidate
     // lists beside the predecessor's commit kernel
@@ -1712,6 +1721,7 @@ static int run_action(kb_engine *e, uint32_t action, kb_decision *out, uint64_t 
       const double t_b0 = now_ms();
       e->tl_wait += t_b0 - t_w0;
       run.absorb(e, n, n_done, reason);
+      const double t_b1 = now_ms();
       if (ahead && reason == KB_REASON_DONE) {
         run.promote(e, n_next);
         n = n_next;
@@ -1719,7 +1729,9 @@ static int run_action(kb_engine *e, uint32_t action, kb_decision *out, uint64_t 
         else if (n) c = launch(n, nullptr, buf, 0, 0);
       } else {
         if (reason != KB_REASON_RENORM) run.probe_dead_shapes(e);
+        const double t_b2 = now_ms();
         n = run.plan(e);   // re-plan first: the queued round drains (three empty launches) while the host works
+        if (action == 0) { e->tl_break_parts[0] += t_b1 - t_b0; e->tl_break_parts[1] += t_b2 - t_b1; e->tl_break_parts[2] += now_ms() - t_b2; }
         if (queued) {   // the queued round skipped itself: consume its publication before its staging half is reused
           uint32_t nd2 = 0, rs2 = 0;
           round_collect(e, cn, true, nd2, rs2);
