@@ -545,8 +545,9 @@ void round_candidates(kb_engine *e, const RoundCtx &c, uint32_t m0, uint32_t m1,
 }
 
 // The same for a chained round, overlapped with its predecessor (n_prev rows, running or queued on the first stream): matrix + arg-max on
-// the second stream with lists of n_prev + L entries, then — first stream, i.e. behind the predecessor's commit kernel — the repair launch
-// that waits for the lists, re-evaluates the predecessor's nodes and merges (kb_kernels.hip: k_repair).  The host's order guarantees that
+// the second stream with lists of n_prev + L entries, then — first stream, i.e. behind the predecessor's commit kernel — the repair that
+// waits for the lists, re-evaluates the predecessor's nodes and merges (kb_repair.hpp): workgroups of the selection kernel's own launch, or
+// (the run kernel's rounds, KB_FUSE_REPAIR=0) a launch in front of it (kb_kernels.hip: k_repair).  The host's order guarantees that
 // every round before the predecessor has been COLLECTED when this is called (run_action plans a window only after it has the answer of the
 // round two in front of it), so the only nodes that can change under the second stream's launches are the predecessor's.
 void ensure_overlap_buffers(kb_engine *e, uint32_t mrows, uint32_t stale_L) {
@@ -677,7 +678,8 @@ void round_collect(kb_engine *e, const RoundCtx &c, bool had_candidates, uint32_
     if (had_candidates && c.overlapped) {
       // matrix: the launch itself, timed on the second stream (start of the matrix launch -> start of the arg-max launch behind it); it ran
       // beside the predecessor's commit kernel, i.e. NOT on the cycle's timeline.  arg-max: what the round waits for on the first stream
-      // instead — the repair launch, from its start (its wait for the lists included) to the start of the commit kernel
+      // instead — the repair launch, from its start (its wait for the lists included) to the start of the commit kernel; a commit launch that
+      // carries its own repair workgroups has that wait inside commit_ms
       const unsigned long long *cs = e->h_cand_out.data() + (size_t)c.buf * KB_OUT_HDR + KB_OUT_STAMP0;
       if (cs[1] > cs[0]) e->stats.matrix_ms += (double)(cs[1] - cs[0]) * per_ms;
       if (st[2] > st[0]) e->stats.argmax_ms += (double)(st[2] - st[0]) * per_ms;   // (a launch that carries its own repair workgroups: they start WITH the commit workgroup, the wait is inside commit_ms)
