@@ -289,13 +289,21 @@ def main():
     # process, so the committed summary of the same command is read back; null when it is absent or for another config.
     import glob
     sys.path.insert(0, os.path.join(ROOT, "scripts"))
-    from kernel_sources_sha import kernel_sources_sha
+    from kernel_sources_sha import kernel_sources_sha, kernel_tu_sha, read_tu_stamp
     live_sha = kernel_sources_sha(ROOT)
 
-    def stale(csv_path):
-        """None when the committed summary was measured on THESE device sources (profiles/roundN/kernel_sources.sha256, written on the GPU box
-        beside the CSVs), else the reason it may not be quoted"""
-        stamp = os.path.join(os.path.dirname(csv_path), "kernel_sources.sha256")
+    def stale(csv_path, tu):
+        """None when the committed summary was measured on kernels compiled from THESE sources, else the reason it may not be quoted.  The stamps
+        are written on the GPU box beside the CSVs: kernel_tu.sha256 (one value per translation unit — `tu` is the .hip file that defines the
+        kernels the CSV speaks of; scripts/kernel_sources_sha.py) or, for summaries older than that, kernel_sources.sha256 (the whole tree)"""
+        here = os.path.dirname(csv_path)
+        per_tu = os.path.join(here, "kernel_tu.sha256")
+        if os.path.exists(per_tu):
+            rec, live = read_tu_stamp(per_tu).get(tu), kernel_tu_sha(ROOT, tu)
+            if rec is None:
+                return f"{os.path.relpath(per_tu, ROOT)} has no entry for {tu}: {os.path.basename(csv_path)} cannot be tied to the kernels of this tree"
+            return None if rec == live else f"{os.path.relpath(csv_path, ROOT)} was measured on another {tu} (sha256 of the translation unit {rec[:12]}, this tree {live[:12]})"
+        stamp = os.path.join(here, "kernel_sources.sha256")
         if not os.path.exists(stamp):
             return f"{os.path.relpath(csv_path, ROOT)} carries no kernel_sources.sha256: it cannot be tied to the kernels of this tree"
         rec = open(stamp).read().split()[0]
@@ -313,8 +321,8 @@ def main():
                 same = same or int(prof_line["roofline"]["bytes_per_launch"]) == int(roofline["bytes_per_launch"])
             except Exception:
                 pass
-        if same and stale(pmc):
-            roofline["traffic_refused"] = stale(pmc)
+        if same and stale(pmc, "kb_kernels.hip"):
+            roofline["traffic_refused"] = stale(pmc, "kb_kernels.hip")
         elif same:
             import csv
             vals = {}
@@ -341,8 +349,8 @@ def main():
                        "counters": None}
     found_c = sorted(glob.glob(os.path.join(ROOT, "profiles", "round*", "rocprofv3_pmc_k_commit.csv")),
                      key=lambda f: int("".join(c for c in os.path.basename(os.path.dirname(f)) if c.isdigit()) or 0))
-    if found_c and stale(found_c[-1]):
-        roofline_commit["counters_refused"] = stale(found_c[-1])
+    if found_c and stale(found_c[-1], "kb_commit_sel.hip"):
+        roofline_commit["counters_refused"] = stale(found_c[-1], "kb_commit_sel.hip")
     elif found_c:
         import csv
         per = {}

@@ -727,15 +727,24 @@ __global__ void __launch_bounds__(256) k_probe(KbDev d, const uint32_t *rows, ui
   K1Node nv[NPT];
 #pragma unroll
   for (int j = 0; j < NPT; j++) nv[j] = k1_node(d, n0 + j);
+  // A row's flag is one word that every workgroup of the row's grid line may set: as an atomicOr per wave and row that was
+  // (NP / 64) * n_rows agent-scope atomics on n_rows / 16 cache lines (100k x 10k: 160 per word, 82k per launch, most of the launch's 46 us).
+  // Every writer stores the same 1 behind the launch's memset, so plain stores do — and the workgroup's waves merge theirs first
+  // (bit rr of a wave-uniform word; TR <= 32).
+  static_assert(TR <= 32, "one bit per row of the workgroup");
+  __shared__ uint32_t s_any[4];
+  uint32_t wave_any = 0;
   for (uint32_t rr = 0; rr < nr; rr++) {
     const K1Task tv = k1_uniform(srow[rr]);
     uint32_t pr[NPT], ok = 0;
     eval_row<NPT>(d, tv, nv, n0, 1, pr);
 #pragma unroll
     for (int j = 0; j < NPT; j++) ok |= (pr[j] >> 16) & 1u;
-    const unsigned long long any = __ballot(ok);
-    if (any && (threadIdx.x & 63) == 0) atomicOr(&alive[row0 + rr], 1u);
+    if (__ballot(ok)) wave_any |= 1u << rr;
   }
+  if ((threadIdx.x & 63) == 0) s_any[threadIdx.x >> 6] = wave_any;
+  __syncthreads();
+  if (threadIdx.x < nr && (((s_any[0] | s_any[1] | s_any[2] | s_any[3]) >> threadIdx.x) & 1u)) alive[row0 + threadIdx.x] = 1u;
 }
 __global__ void k_or_ports_x(KbDev d, uint32_t task, uint32_t node) {
   const uint32_t w = threadIdx.x;

@@ -4,9 +4,11 @@
 #   ab       same-box A/B of engine builds: every kube-batch_amd/libkbengine_<tag>.so beside the default one (configs 3, survey, 4, 5), each
 #            verified; optionally the differential suites on one of them:   ab [tag-to-test]
 #   fuse     A/B of KB_FUSE_REPAIR (repair workgroups inside the selection kernel's launch, or a launch of their own) + the differential suites on both
+#   abq      the default build against libkbengine_base.so on configs 3, 5, 4 and the survey's nodes, shortest useful order first (a call of a few minutes)
 #   trace    the selection kernel's per-phase cycle trace (make EXTRA=-DKB_K9_TRACE OUT=../libkbengine_trace.so), configs 3 and 4
 #   profile  rocprofv3 of the default command: kernel stats, HBM bytes of the matrix launches, SQ counters of the commit kernel
 #            (scripts/summarize_profile.py r5_profile profiles/round5)
+#   pmc_matrix  FETCH_SIZE / WRITE_SIZE passes of the matrix launches + the kernel trace only (a change to kb_kernels.hip alone)
 #   suite    the whole -m gpu suite          bench   the default bench line and the single-configuration lines
 #   loads    kb_session_load: KB_LOAD_TRACE of configs 3, 4, 5 and the bench's load statistics
 #   scale    N in {1, 2, 4, 8} x {sessions, sharded} on whatever GPUs the box has (scripts/scale_curve.sh)
@@ -17,13 +19,14 @@ step="${1:-suite}"; shift || true
 out="gpurun_out/r5_${step}"
 mkdir -p "$out"
 python scripts/kernel_sources_sha.py > "$out/kernel_sources.sha256"
+python scripts/kernel_sources_sha.py --tu > "$out/kernel_tu.sha256"
 ms() { python -c "import json,sys; d=json.loads(open('$1').read().strip().splitlines()[-1]); print(d.get('ms_per_step'), d.get('verified_bind_set_equals_oracle'), d.get('kernel_ms_per_step'), 'load', d.get('session_load_ms'), d.get('session_load_ms_max'))" 2>/dev/null; }
 bench_ab() {   # name, env assignments..., -- bench args
   local name="$1"; shift
   local envs=(); while [ "$1" != "--" ]; do envs+=("$1"); shift; done; shift
   timeout 400 env "${envs[@]}" KB_K5_STATS=1 python bench.py --no-cpu-baseline "$@" > "$out/bench_${name}.json" 2> "$out/bench_${name}.err"
   echo "bench $name rc=$? $(ms "$out/bench_${name}.json")" | tee -a "$out/summary.txt"
-  grep -h "kb select" "$out/bench_${name}.err" | tee -a "$out/summary.txt"
+  grep -h "kb select\|kb host\|kb probe" "$out/bench_${name}.err" | tee -a "$out/summary.txt"
 }
 case "$step" in
 first)
@@ -62,6 +65,21 @@ ab)   # ab <tag,tag,...> [test]: kube-batch_amd/libkbengine_<tag>.so beside the 
     echo "differential suites on the default build (selection kernel, reload, full size) rc=$? $(tail -1 "$out/pytest_default.txt")" | tee -a "$out/summary.txt"
   fi
   ;;
+abq)   # the round's last GPU minutes: the default build against kube-batch_amd/libkbengine_base.so (the tree of call 26), alternating, most
+       # important line first — the call may be cut anywhere: every line is written (and verified) on its own
+  base="KB_ENGINE_LIB=$PWD/kube-batch_amd/libkbengine_base.so"
+  bench_ab c3_new_r1 -- --config 3 --steps 5 --warmup 2 --verify
+  bench_ab c3_base_r1 $base -- --config 3 --steps 5 --warmup 2 --verify
+  bench_ab c3_new_r2 -- --config 3 --steps 5 --warmup 2 --verify
+  bench_ab c3_base_r2 $base -- --config 3 --steps 5 --warmup 2 --verify
+  bench_ab c5_new -- --config 5 --steps 2 --warmup 1 --verify
+  bench_ab c5_base $base -- --config 5 --steps 2 --warmup 1
+  bench_ab c4_new -- --config 4 --steps 3 --warmup 1 --verify
+  bench_ab c4_base $base -- --config 4 --steps 3 --warmup 1
+  bench_ab survey_new -- --config 3 --survey-nodes --steps 3 --warmup 1 --verify
+  bench_ab survey_base $base -- --config 3 --survey-nodes --steps 3 --warmup 1
+  timeout 300 python -m pytest tests/test_gpu_fullsize.py tests/test_gpu_parity.py -q -m gpu -p no:cacheprovider -x > "$out/pytest_subset.txt" 2>&1; echo "full-size + parity modules rc=$? $(tail -1 "$out/pytest_subset.txt")" | tee -a "$out/summary.txt"
+  ;;
 fuse)   # the repair workgroups inside the selection kernel's launch (default) against the launch of their own (KB_FUSE_REPAIR=0), same box, same
         # library, alternating; then the differential suites on the default and the selection / full-size ones on the other path
   for rep in $(seq 1 ${AB_REPS:-2}); do
@@ -99,6 +117,18 @@ profile)   # rocprofv3 evidence of the default bench command: kernel stats, HBM 
       -d "$P/pmc_commit_a" -o bench -- $CMD > "$P/bench_pmc_commit_a.log" 2>&1
     rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR -f csv --kernel-include-regex "k_commit" \
       -d "$P/pmc_commit_b" -o bench -- $CMD > "$P/bench_pmc_commit_b.log" 2>&1
+  )
+  find "$out" -name "*.csv" | head -20 | tee -a "$out/summary.txt"
+  ;;
+pmc_matrix)   # the matrix launches' HBM bytes and the kernel stats again, after a change to kb_kernels.hip that left the commit kernels' translation
+              # unit alone (scripts/kernel_sources_sha.py --tu): FETCH_SIZE, WRITE_SIZE, then the kernel trace — in that order, the call may be cut
+  export TMPDIR=/tmp
+  CMD="python $PWD/bench.py --steps 2 --warmup 1 --no-cpu-baseline"
+  P="$PWD/$out"
+  ( cd /tmp
+    rocprofv3 --pmc FETCH_SIZE -f csv --kernel-include-regex "k_matrix|k_expand" -d "$P/pmc_fetch" -o bench -- $CMD > "$P/bench_pmc_fetch.log" 2>&1
+    rocprofv3 --pmc WRITE_SIZE -f csv --kernel-include-regex "k_matrix|k_expand" -d "$P/pmc_write" -o bench -- $CMD > "$P/bench_pmc_write.log" 2>&1
+    rocprofv3 --kernel-trace --stats -f csv -d "$P/trace" -o bench -- $CMD > "$P/bench_trace.log" 2>&1
   )
   find "$out" -name "*.csv" | head -20 | tee -a "$out/summary.txt"
   ;;

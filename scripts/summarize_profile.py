@@ -52,6 +52,21 @@ if crow:
 # the device sources the numbers were measured on (written on the GPU box by scripts/gpu_r5.sh): bench.py quotes the CSVs only for these
 if (src / "kernel_sources.sha256").exists():
     shutil.copy(src / "kernel_sources.sha256", dst / "kernel_sources.sha256")
+# ... and per translation unit (scripts/kernel_sources_sha.py --tu): a call that measured the matrix launches only (scripts/gpu_r5.sh pmc_matrix)
+# replaces kb_kernels.hip's line and leaves the commit kernels' as the call that measured THEM wrote it
+if (src / "kernel_tu.sha256").exists():
+    sys.path.insert(0, str(Path(__file__).resolve().parent))
+    from kernel_sources_sha import read_tu_stamp
+    fresh = read_tu_stamp(src / "kernel_tu.sha256")
+    kept = read_tu_stamp(dst / "kernel_tu.sha256") if (dst / "kernel_tu.sha256").exists() else {}
+    merged = dict(kept)
+    merged.update(fresh if crow else {k: v for k, v in fresh.items() if k == "kb_kernels.hip"})
+    with open(dst / "kernel_tu.sha256", "w") as f:
+        f.write("# sha256 per translation unit (scripts/kernel_sources_sha.py --tu) of the sources the summaries of this directory were measured on:\n"
+                "# rocprofv3_pmc_k_matrix.csv <-> kb_kernels.hip, rocprofv3_pmc_k_commit.csv <-> kb_commit_sel.hip (bench.py: stale()).\n"
+                f"# last written from gpurun_out/{src.name} ({'all passes' if crow else 'matrix passes + kernel trace only: the other lines kept'})\n")
+        for k in sorted(merged):
+            f.write(f"{merged[k]}  {k}\n")
 # the bench line printed under the kernel trace
 log = src / "bench_trace.log"
 for line in log.read_text().splitlines():
