@@ -256,9 +256,11 @@ struct kb_engine {
   DevBuf b_wf_queues, b_wf_state;
   DevBuf b_win, b_out;   // per-round upload / download blocks (see h_win / h_out)
   DevBuf b_chain;        // KbRound::chain: tag of the last round that committed its whole window
-  // feasibility probe at speculation breaks (ActionRun::probe_dead_shapes): one representative task per feasibility shape
-  DevBuf b_probe_rows, b_probe_alive;
+  // feasibility probe at speculation breaks (ActionRun::probe_launch / probe_collect): one representative task per feasibility shape still alive.
+  // Rows in and flags out live in mapped pinned memory the kernel reads and writes directly (like h_win / h_out): the probe is ONE stream
+  // operation — it was copy -> memset -> kernel -> copy, ~4.5 us each with a gap behind each, around a kernel of 8.6 us
   Pinned<uint32_t> h_probe_alive, h_probe_rows;
+  uint32_t *d_probe_alive = nullptr, *d_probe_rows = nullptr;   // their device addresses (re-read when kb_session_load grew them)
   bool probe_enabled = true;          // KB_PROBE=0 disables
   uint64_t probes = 0, probe_deaths = 0;
   int commit_kernel_of[2] = {0, 0};   // the commit kernel launched for the round in each staging half
@@ -751,6 +753,10 @@ void check_aggregates(kb_engine *e, const OrderMachine &om) {
 
 // Host side of one action as a resumable object: plan() fills e->h_rows with the next window, absorb() digests the
 // device's answer (confirm, or roll back + replay on a mis-speculated round), finish() runs the gang/share reduction.
+// probes of more (shape, node) pairs than this run at every fourth break only (ActionRun::probe_launch); -DKB_PROBE_SPARSE_ABOVE=... for an A/B build
+#ifndef KB_PROBE_SPARSE_ABOVE
+#define KB_PROBE_SPARSE_ABOVE (8ull << 20)
+#endif
 struct ActionRun {
   uint32_t action = 0;   // 0 allocate, 1 backfill
   bool bf_need_pred = false;
@@ -934,9 +940,16 @@ struct ActionRun {
   // alive is evaluated against the current node state (one launch, feasibility only), and whatever has no node left is marked dead
   // NOW instead of costing a break of its own when its next task comes up.  Exact: inside the allocate action a shape without a
   // feasible node stays without one (the argument of mark_dead), so the reference's PredicateNodes will find none either when it
-  // pops such a task.  Called only between absorb() and plan(), when no planned window is outstanding.
-  void probe_dead_shapes(kb_engine *e) {
+  // pops such a task.  In two halves: probe_launch() right behind the answer of the round that broke (same stream: behind that round's
+  // commit kernel and the skipped round queued behind it; the node state it reads is final), probe_collect() in front of the re-plan —
+  // the host absorbs the answer (roll-back + replay, ~12 us) while the kernel runs.  The list is built from `dead` as the broken round was
+  // planned with; what absorb() marks meanwhile (the row that broke, the shapes it dominates) the probe finds dead again: not counted twice.
+  // No planned window is outstanding between the two halves, and absorb() of the allocate action launches nothing (sessions with host-port
+  // masks of several words, whose absorb() updates node words on the stream, probe behind it: run_action).
+  uint32_t probe_S = 0;   // rows of the probe in flight (0: none)
+  void probe_launch(kb_engine *e) {
     HostSession &hs = e->hs;
+    probe_S = 0;
     if (!e->probe_enabled || action != 0 || hs.has_interpod || hs.n_feas_shapes == 0 || !e->pol.pred_enabled) return;
     // only the shapes that are still alive are looked at, and when that is a large matrix (many shapes x many nodes: a launch of
     // a few hundred microseconds) only every fourth break pays for it; the deaths of the breaks in between are found then
@@ -946,17 +959,24 @@ struct ActionRun {
       if (!dead[f]) probe_list.push_back(f);
     const uint32_t S = (uint32_t)probe_list.size();
     if (S == 0) return;
-    if ((uint64_t)S * hs.N > (8ull << 20) && (probe_calls & 3u) != 1u) return;
-    for (uint32_t i = 0; i < S; i++) e->h_probe_rows[i] = hs.feas_rep[probe_list[i]];
-    HIP_OK(hipMemcpyAsync(e->b_probe_rows.p, e->h_probe_rows.data(), sizeof(uint32_t) * S, hipMemcpyHostToDevice, e->stream));
-    HIP_OK(hipMemsetAsync(e->b_probe_alive.p, 0, sizeof(uint32_t) * S, e->stream));
-    kb_launch_probe(e->dev, e->b_probe_rows.as<uint32_t>(), S, e->b_probe_alive.as<uint32_t>(), e->stream);
-    HIP_OK(hipMemcpyAsync(e->h_probe_alive.data(), e->b_probe_alive.p, sizeof(uint32_t) * S, hipMemcpyDeviceToHost, e->stream));
+    if ((uint64_t)S * hs.N > KB_PROBE_SPARSE_ABOVE && (probe_calls & 3u) != 1u) return;
+    for (uint32_t i = 0; i < S; i++) { e->h_probe_rows[i] = hs.feas_rep[probe_list[i]]; e->h_probe_alive[i] = 0u; }
+    kb_launch_probe(e->dev, e->d_probe_rows, S, e->d_probe_alive, e->stream);
+    probe_S = S;
+  }
+  void probe_collect(kb_engine *e) {
+    if (probe_S == 0) return;
+    const uint32_t S = probe_S;
+    probe_S = 0;
     HIP_OK(hipStreamSynchronize(e->stream));
     e->probes++;
     for (uint32_t i = 0; i < S; i++)   // no dominance scan needed: the probe looked at every live shape itself
-      if (e->h_probe_alive[i] == 0) { dead[probe_list[i]] = 1; e->probe_deaths++; }
+      if (e->h_probe_alive[i] == 0 && !dead[probe_list[i]]) { dead[probe_list[i]] = 1; e->probe_deaths++; }
   }
+  void probe_abandon(kb_engine *e) {   // an exception between the halves: the kernel must not outlive the call (it writes into h_probe_alive)
+    if (probe_S) { (void)hipStreamSynchronize(e->stream); probe_S = 0; }
+  }
+  void probe_dead_shapes(kb_engine *e) { probe_launch(e); probe_collect(e); }
 
   // host-port masks of several words: the placed pod's words behind the first join the node's (both ssn.Allocate and ssn.Pipeline end in
   // NodeInfo.AddTask; the kernels advanced word 0).  On the action's stream, in front of whatever the next round launches.
@@ -1132,6 +1152,7 @@ int kb_engine_create(const kb_config *cfg, kb_engine **out) {
     eng->b_out.alloc(sizeof(unsigned long long) * (KB_OUT_HDR + KB_K5_MAX_WINDOW));
     HIP_OK(hipMemset(eng->b_out.p, 0, eng->b_out.bytes));
     eng->h_out.flags = hipHostMallocMapped | hipHostMallocCoherent;   // written by the commit kernel while the host polls
+    eng->h_probe_rows.flags = eng->h_probe_alive.flags = hipHostMallocMapped | hipHostMallocCoherent;   // the probe kernel's rows in / flags out
     eng->h_out.resize(2 * KB_OUT_STRIDE);
     std::memset(eng->h_out.data(), 0, sizeof(unsigned long long) * 2 * KB_OUT_STRIDE);
     eng->b_chain.alloc(sizeof(uint32_t));
@@ -1533,10 +1554,10 @@ int kb_session_load(kb_engine *e, const kb_snapshot *sn) {
       d.ip_C = C; d.ip_D = D; d.ip_P = P; d.ip_Wc = Wc; d.ip_Wp = Wp;
     }
     mark("classes, ports, inter-pod");
-    up.copy(e->b_probe_rows, hs.feas_rep.data(), hs.n_feas_shapes);
-    e->b_probe_alive.alloc(sizeof(uint32_t) * std::max<uint32_t>(hs.n_feas_shapes, 1u));
     e->h_probe_alive.resize(std::max<uint32_t>(hs.n_feas_shapes, 1u));
     e->h_probe_rows.resize(std::max<uint32_t>(hs.n_feas_shapes, 1u));
+    HIP_OK(hipHostGetDevicePointer((void **)&e->d_probe_alive, e->h_probe_alive.data(), 0));
+    HIP_OK(hipHostGetDevicePointer((void **)&e->d_probe_rows, e->h_probe_rows.data(), 0));
     up.copy(e->b_jbegin, hs.job_begin.data(), J + 1);
     up.copy(e->b_jmin, hs.job_min.data(), J);
     up.copy(e->b_jqueue, hs.job_queue.data(), J);
@@ -1722,7 +1743,10 @@ static int run_action(kb_engine *e, uint32_t action, kb_decision *out, uint64_t 
       round_collect(e, c, true, n_done, reason);
       const double t_b0 = now_ms();
       e->tl_wait += t_b0 - t_w0;
-      run.absorb(e, n, n_done, reason);
+      // a break: the feasibility probe goes out before the host starts on the answer (ActionRun::probe_launch)
+      const bool probe_early = ahead && reason != KB_REASON_DONE && reason != KB_REASON_RENORM;
+      if (probe_early) run.probe_launch(e);
+      try { run.absorb(e, n, n_done, reason); } catch (...) { run.probe_abandon(e); throw; }
       const double t_b1 = now_ms();
       if (ahead && reason == KB_REASON_DONE) {
         run.promote(e, n_next);
@@ -1730,7 +1754,8 @@ static int run_action(kb_engine *e, uint32_t action, kb_decision *out, uint64_t 
         if (queued) { c = cn; buf ^= 1u; }
         else if (n) c = launch(n, nullptr, buf, 0, 0);
       } else {
-        if (reason != KB_REASON_RENORM) run.probe_dead_shapes(e);
+        if (probe_early) run.probe_collect(e);
+        else if (reason != KB_REASON_RENORM) run.probe_dead_shapes(e);
         const double t_b2 = now_ms();
         n = run.plan(e);   // re-plan first: the queued round drains (three empty launches) while the host works
         if (action == 0) { e->tl_break_parts[0] += t_b1 - t_b0; e->tl_break_parts[1] += t_b2 - t_b1; e->tl_break_parts[2] += now_ms() - t_b2; }

@@ -80,6 +80,21 @@ abq)   # the round's last GPU minutes: the default build against kube-batch_amd/
   bench_ab survey_base $base -- --config 3 --survey-nodes --steps 3 --warmup 1
   timeout 300 python -m pytest tests/test_gpu_fullsize.py tests/test_gpu_parity.py -q -m gpu -p no:cacheprovider -x > "$out/pytest_subset.txt" 2>&1; echo "full-size + parity modules rc=$? $(tail -1 "$out/pytest_subset.txt")" | tee -a "$out/summary.txt"
   ;;
+last)   # the round's last call, shortest useful order first (it may be cut anywhere): the host side of the probe (one stream operation, launched
+        # before the answer is absorbed) against the build before it, the rocprofv3 passes on the final device sources, then probes at every break
+        # for the large configurations (libkbengine_p64.so: -DKB_PROBE_SPARSE_ABOVE='(64ull<<20)')
+  base="KB_ENGINE_LIB=$PWD/kube-batch_amd/libkbengine_base.so"; p64="KB_ENGINE_LIB=$PWD/kube-batch_amd/libkbengine_p64.so"
+  bench_ab c3_new_r1 -- --config 3 --steps 5 --warmup 2 --verify
+  bench_ab c3_base_r1 $base -- --config 3 --steps 5 --warmup 2 --verify
+  bench_ab c3_new_r2 -- --config 3 --steps 5 --warmup 2 --verify
+  bench_ab c3_base_r2 $base -- --config 3 --steps 5 --warmup 2 --verify
+  bash scripts/gpu_r5.sh profile > "$out/profile_step.txt" 2>&1; tail -3 "$out/profile_step.txt" | tee -a "$out/summary.txt"
+  bench_ab c5_new -- --config 5 --steps 2 --warmup 1 --verify
+  bench_ab c5_p64 $p64 -- --config 5 --steps 2 --warmup 1
+  bench_ab c4_new -- --config 4 --steps 3 --warmup 1 --verify
+  bench_ab c4_p64 $p64 -- --config 4 --steps 3 --warmup 1 --verify
+  bench_ab c5_p64v $p64 -- --config 5 --steps 2 --warmup 1 --verify
+  ;;
 fuse)   # the repair workgroups inside the selection kernel's launch (default) against the launch of their own (KB_FUSE_REPAIR=0), same box, same
         # library, alternating; then the differential suites on the default and the selection / full-size ones on the other path
   for rep in $(seq 1 ${AB_REPS:-2}); do
