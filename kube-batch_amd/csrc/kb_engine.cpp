@@ -296,7 +296,7 @@ struct kb_engine {
   bool stale_checked = false, pristine = true, load_clean = false;
   double tl_reset = 0, tl_begin = 0, tl_break = 0, tl_finish = 0, tl_wait = 0, tl_backfill = 0;
   double tl_begin_parts[3] = {0, 0, 0};   // of tl_begin: the order machine's set-up, the first feasibility probe, the first plan (the rest: buffers, the first launch)
-  double tl_break_parts[3] = {0, 0, 0};   // of tl_break: absorbing the answer (roll-back + replay), the probe, the re-plan (the rest: the skipped round, the launch)
+  double tl_break_parts[3] = {0, 0, 0};   // of tl_break: the probe's launch + absorbing the answer (roll-back + replay) beside it, waiting for the probe, the re-plan (the rest: the skipped round, the launch)
   std::vector<kb_decision> decisions_all;   // decisions of the last multi-GPU round sequence
   std::vector<uint32_t> evictions;          // committed evictions of the session's preempt actions, in cache.Evict order
 
@@ -1207,7 +1207,7 @@ void kb_engine_destroy(kb_engine *e) {
     fprintf(stderr, "[kb host] ms over the engine's life: reset %.2f, allocate up to its first launch %.2f, speculation breaks (answer -> re-planned launch) %.2f, "
             "closing reductions %.2f, waiting for rounds %.2f, backfill up to its first launch %.2f\n", e->tl_reset, e->tl_begin, e->tl_break, e->tl_finish, e->tl_wait, e->tl_backfill);
   if (getenv("KB_K5_STATS"))
-    fprintf(stderr, "[kb host] of the start: order machine %.2f, first probe %.2f, first plan %.2f; of the breaks: absorb %.2f, probe %.2f, re-plan %.2f\n",
+    fprintf(stderr, "[kb host] of the start: order machine %.2f, first probe %.2f, first plan %.2f; of the breaks: probe launch + absorb %.2f, waiting for the probe %.2f, re-plan %.2f\n",
             e->tl_begin_parts[0], e->tl_begin_parts[1], e->tl_begin_parts[2], e->tl_break_parts[0], e->tl_break_parts[1], e->tl_break_parts[2]);
   if (getenv("KB_K5_STATS")) fprintf(stderr, "[kb probe] %llu probes, %llu shapes marked dead by them\n", (unsigned long long)e->probes, (unsigned long long)e->probe_deaths);
   if (getenv("KB_K5_STATS") && e->k5_trace[0] > 0) {
