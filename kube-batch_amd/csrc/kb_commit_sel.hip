@@ -169,7 +169,7 @@ __global__ void __launch_bounds__(K9_THREADS) k_commit_select(const K9KernArgs k
   const uint32_t i0 = hx_ & 0xFFFFu, r = hx_ >> 16, s = (uint32_t)__builtin_amdgcn_readfirstlane((int)(ri_).y);          \
   const uint32_t fl0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(ri_).z), km0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(ri_).w); \
   const bool plain0 = (fl0 & 1u) && (km0 == 0u || (fl0 & 4u));                                                         \
-  const bool sel_run = !a.backfill && plain0 && r >= 2u;              /* the run goes through the selection */          \
+  const bool sel_run = !a.backfill && plain0 && r >= 2u && a.whole;   /* the run goes through the selection */          \
   (void)sel_run; (void)i0;
 #define K9S_RUN_SHAPE(kk)                                                                                              \
   const K9Shape sh = shapes[s];                                                                                        \
@@ -271,11 +271,10 @@ __global__ void __launch_bounds__(K9_THREADS) k_commit_select(const K9KernArgs k
       if (!run_done) {
       // ================= everything else: the general selection, the serial loop (they need the shape and the candidates' other fields)
       K9S_RUN_SHAPE(k)
-      uint32_t ckind1 = 0, rnm = 0;
-      if (lane_i < ncand) { ckind1 = CD.ckind1[lane_i]; rnm = CD.crnm[lane_i]; }
+      uint32_t rnm = 0;
+      if (lane_i < ncand) rnm = CD.crnm[lane_i];
       double res0 = sh.init0, res1 = sh.init1;
       if (!plain0) { res0 = rres[0]; res1 = rres[1]; }
-      const uint32_t cmin = (sel_run && ncand == r) ? rl32(ck, r - 1u) : 0u;
       // dirty keys of the shape: old slot t in lane_i t & 63, register t >> 6 — fetched only where a dirty slot can be picked
       uint32_t d0 = 0u, d1 = 0u, d2 = 0u, d3 = 0u;
       bool have_d = false;
@@ -283,201 +282,186 @@ __global__ void __launch_bounds__(K9_THREADS) k_commit_select(const K9KernArgs k
                                         d3 = (lane_i + 192 < nd) ? dk[lane_i + 192] : 0u; have_d = true; } } while (0)
       bool sel_done = false;
       if (sel_run) {
-        {
-          // ---- the general case.  Contenders: the clean candidates (lane_i = candidate) and the dirty slots whose key is above the floor;
-          //      entries: steps 0 and 1 of each, as far as they exist and are above the floor
-          K9S_LOAD_D();
-          const bool a0v = lane_i < ncand;
-          const uint32_t ce1 = min(ck, k1);
-          const bool a1v = a0v && ckind == 0u && k1 != 0u && ce1 > cmin;
-          uint32_t dkk4[4], dd4[4] = {d0, d1, d2, d3};
-          bool b0v[4];
-          unsigned long long bb0[4];
-          uint32_t nD = 0;
-#pragma unroll
-          for (int u = 0; u < 4; u++) {
-            const uint32_t t = lane_i + 64u * (uint32_t)u;
-            dkk4[u] = (t < nd) ? X.dkk[k & 1u][t] : 0u;
-            b0v[u] = dd4[u] > cmin;
-            bb0[u] = __ballot(b0v[u]);
-            nD += (uint32_t)__popcll(bb0[u]);
+        // ---- the SHOTS (round 6; tests/run_selection_model.py: table_run).  The contenders of the rows still open: everybody whose key is at or
+        //      above the rem-th clean candidate in front (the distinct winners of rem rows are the rem best by current key) — clean candidates,
+        //      candidates this run has consumed, dirty slots.  Lane g * D + u evaluates contender g after u further placements of the shape
+        //      (D = the lanes' budget / contenders: two entries each for 32 contenders, 32 for two; api/node_info.go:172-212 applied u times as
+        //      Idle - u * Resreq, exact for whole numbers below 2^47: KbDev::whole, the host's scan at kb_session_load — a session with anything
+        //      else commits its runs row by row); prefix minima per contender; ONE rank
+        //      of all entries by (eff desc, step asc): the serial loop's picks in order (the argument at the top of this file).  Of that order a
+        //      shot commits what is FINAL: entries above the floor (nobody outside the table comes first) in front of the first table that ends
+        //      while its sequence may go on — what lies behind a table's end ranks behind its last entry, nowhere else — ; that entry itself waits
+        //      for the next shot, so a contender's key after its placements is always an entry of its table.  The best contender's first entry is
+        //      always final: every shot commits a row.  A Pipeline (allocate.go:175-182) ends the round behind its row.
+        K9S_LOAD_D();
+        bool pooled = false;   // the pool's keys live in X.pool as well (from the second shot on)
+        while (j < r) {
+          const uint32_t rem = r - j;
+          const uint32_t fidx = pc + rem - 1u;
+          uint32_t thr = max(fidx < ncand ? rl32(ck, fidx) : 0u, 1u);   // the floor: the rem-th clean candidate in front (clean keys fall along the list); 1: fewer are left, everybody feasible contends
+          // -- contenders: the pool's entries at or above the floor, numbered clean candidates first (list order), then this run's consumed ones, then the dirty slots
+          bool isc, isk, is0, is1, is2, is3;
+          unsigned long long bc, bk, b0, b1, b2, b3;
+          uint32_t nc_, nk_, n0_, n1_, n2_, n3_, nC;
+          for (uint32_t again = 0;; again++) {
+            isc = lane_i >= pc && lane_i < ncand && ck >= thr; isk = lane_i < pc && k1 >= thr;
+            is0 = d0 >= thr; is1 = d1 >= thr; is2 = d2 >= thr; is3 = d3 >= thr;
+            bc = __ballot(isc); bk = __ballot(isk); b0 = __ballot(is0); b1 = __ballot(is1); b2 = __ballot(is2); b3 = __ballot(is3);
+            nc_ = (uint32_t)__popcll(bc); nk_ = (uint32_t)__popcll(bk); n0_ = (uint32_t)__popcll(b0); n1_ = (uint32_t)__popcll(b1); n2_ = (uint32_t)__popcll(b2); n3_ = (uint32_t)__popcll(b3);
+            nC = nc_ + nk_ + n0_ + n1_ + n2_ + n3_;
+            if (nC <= 32u || again) break;
+            // more contenders than the lanes hold two entries of (the clean list has run short: every feasible dirty slot contends): a higher floor —
+            // the fifth best of the lanes' own maxima, i.e. the entries of five lanes at most (30); whoever stays outside has a key below it
+            uint32_t lm = max(max(max(is0 ? d0 : 0u, is1 ? d1 : 0u), max(is2 ? d2 : 0u, is3 ? d3 : 0u)), max(isk ? k1 : 0u, isc ? ck : 0u));
+            for (uint32_t t = 0; t < 5u; t++) {
+              const uint32_t mx = wave_max_u32(lm);
+              if (mx == 0u) break;
+              thr = mx;
+              if (lm == mx) lm = 0u;
+            }
           }
-          const unsigned long long ba1 = __ballot(a1v);
-          const uint32_t nA1 = (uint32_t)__popcll(ba1);
-          const uint32_t nC = ncand + nD;
-          uint32_t n = ncand + nA1 + nD;
-          bool bail = nC > 64u || n > 64u;
-          if (!bail) {
-            if (a0v) {
-              X.e_comp[lane_i] = ((unsigned long long)ck << 8) | 255ull;
-              X.e_info[lane_i] = lane_i | (ckind << 8);
-              X.c_slot[lane_i] = nd + lane_i; X.c_next[lane_i] = a1v ? 2u : 1u; X.c_eff[lane_i] = a1v ? ce1 : ck;
-              X.c_flag[lane_i] = 2u | ((!a1v || ckind1) ? 1u : 0u);   // ended: a Pipeline, no second placement, or one below the floor
-              X.c_take[lane_i] = 0u;
-            }
-            uint32_t base = ncand;
-            if (a1v) {
-              const uint32_t pos = base + (uint32_t)__popcll(ba1 & lt);
-              X.e_comp[pos] = ((unsigned long long)ce1 << 8) | 254ull;
-              X.e_info[pos] = lane_i | (ckind1 << 8) | (1u << 16);
-            }
-            base += nA1;
-#pragma unroll
-            for (int u = 0; u < 4; u++) {   // the dirty contenders: step 0 (their key as the evaluation phase found it); the passes below walk them on
-              if (b0v[u]) {
-                const uint32_t pos = base + (uint32_t)__popcll(bb0[u] & lt), c = pos - nA1;
-                X.e_comp[pos] = ((unsigned long long)dd4[u] << 8) | 255ull;
-                X.e_info[pos] = c | ((dkk4[u] & 1u) << 8);
-                X.c_slot[c] = lane_i + 64u * (uint32_t)u; X.c_next[c] = 1u; X.c_eff[c] = dd4[u];
-                X.c_flag[c] = dkk4[u] & 1u;   // ended: its first placement is a Pipeline
-                X.c_take[c] = 0u;
-              }
-              base += (uint32_t)__popcll(bb0[u]);
-            }
-            K9_WAVE_FENCE();
+          if (nC == 0u) { reason = KB_REASON_NO_FEASIBLE; break; }   // allocate.go:144-148
+          const uint32_t lgD = nC <= 2u ? 5u : (nC <= 4u ? 4u : (nC <= 8u ? 3u : (nC <= 16u ? 2u : 1u))), D = 1u << lgD;
+          {
+            uint32_t base = 0u;
+            if (isc) { const uint32_t p_ = base + (uint32_t)__popcll(bc & lt); X.c_slot[p_] = (nd + lane_i) | 0x80000000u; }   // bit 31: the slot is one placement ahead (a clean candidate)
+            base += nc_;
+            if (isk) { const uint32_t p_ = base + (uint32_t)__popcll(bk & lt); X.c_slot[p_] = nd + lane_i; }
+            base += nk_;
+            if (is0) { const uint32_t p_ = base + (uint32_t)__popcll(b0 & lt); X.c_slot[p_] = lane_i; }
+            base += n0_;
+            if (is1) { const uint32_t p_ = base + (uint32_t)__popcll(b1 & lt); X.c_slot[p_] = lane_i + 64u; }
+            base += n1_;
+            if (is2) { const uint32_t p_ = base + (uint32_t)__popcll(b2 & lt); X.c_slot[p_] = lane_i + 128u; }
+            base += n2_;
+            if (is3) { const uint32_t p_ = base + (uint32_t)__popcll(b3 & lt); X.c_slot[p_] = lane_i + 192u; }
           }
-          unsigned long long comp = 0ull;
-          uint32_t info = 0u, rank = 0u;
-          bool first = true;
-          while (!bail) {
-            // rank by count: entry e is picked as row #(entries in front of it)
-            comp = lane_i < n ? X.e_comp[lane_i] : 0ull;
-            info = lane_i < n ? X.e_info[lane_i] : 0u;
-            rank = 0u;
-            for (uint32_t i = 0; i < n; i++) { const unsigned long long si_ = rl64(comp, i); rank += (si_ > comp) ? 1u : 0u; }
-            if (first) { K9_STAMP(5); first = false; }
-            
-            // a contender whose last known step would be picked in front of the last row may be picked again: walk it on
-            const uint32_t c = info & 0xFFu, ej = info >> 16;
-            const bool alive = lane_i < n && ej + 1u == X.c_next[c] && !(X.c_flag[c] & 1u) && rank + 1u < r;
-            const unsigned long long ab = __ballot(alive);
-            if (!ab) break;
-            const uint32_t na = (uint32_t)__popcll(ab);
-            uint32_t D = (64u - n) / na;
-            if (D == 0u) { bail = true; break; }
-            D = min(D, r - 1u);
-            if (alive) X.al[(uint32_t)__popcll(ab & lt)] = c;
-            K9_WAVE_FENCE();
-            // lane_i -> (contender ai, step u of this pass): the contender's state after that many more placements, one subtraction at a time
-            const bool act = lane_i < na * D;
-            const uint32_t ai = lane_i / D, u = lane_i - ai * D;
-            uint32_t cc = 0u, jj = 0u, kind = 0u, key = 0u, run = 0xFFFFFFFFu;
-            bool inexact = false;
-            if (act) {
-              cc = X.al[ai];
-              const uint32_t slot = X.c_slot[cc], b = (X.c_flag[cc] >> 1) & 1u;
-              jj = X.c_next[cc] + u;
-              run = X.c_eff[cc];
-              const uint32_t mpl = jj - b;   // placements on top of the slot's state (a clean candidate's slot holds it after the first)
-              const unsigned long long *st = slots + (size_t)slot * K9_NF;
-              K9St v = k9_load(st);
-              const uint32_t nm0 = (uint32_t)(st[F_NODE_NMASK] >> 32);
-              const uint32_t adjm = (nm0 & 0x7FFFFFFFu) ? km0 : 0u;
-              const K9Sc scx = k9_sc_preload(sh.active >> 2, gi, gr, a.NP, v.node);
-              // scalar dimensions are evaluated as Idle - jj * Resreq: equal to jj subtractions when both are integers (checked)
-              if (jj >= 2u)
-                for (uint32_t mm = (sh.active >> 2) & adjm, dd = 0; mm; mm >>= 1, dd++)
-                  if (mm & 1u) {
-                    const double id = k9_sci(scx, gi, a.NP, dd, v.node), rq = si[dd];
-                    if (!(id == trunc(id) && rq == trunc(rq) && fabs(id) < 4.0e15 && rq < 3.0e13)) inexact = true;
-                  }
-              for (uint32_t t = 0; t < mpl; t++) { v.idle0 -= sh.init0; v.idle1 -= sh.init1; v.nzc += sh.nzc; v.nzm += sh.nzm; }
-              if (mpl) v.ports |= sh.want;
-              v.left -= (int)mpl;
-              key = k9_eval_v(a, sh, v, scx, gi, gr, si, adjm, (double)jj, si, nb, nmaskbits);
-              kind = k9_fits_idle(a, sh, v.idle0, v.idle1, scx, gi, si, v.node, adjm, (double)jj, si) ? 0u : 1u;
+          K9_WAVE_FENCE();
+          K9_STAMP(5);
+          // -- the table: lane g * D + u
+          const uint32_t tg = lane_i >> lgD, tu = lane_i & (D - 1u);
+          const bool act = tg < nC;
+          uint32_t key = 0u, kind = 0u, tnode = 0u;
+          if (act) {
+            const uint32_t cs = X.c_slot[tg], slot = cs & 0x7FFFFFFFu, b = cs >> 31;
+            const unsigned long long *st = slots + (size_t)slot * K9_NF;
+            K9St v = k9_load(st);
+            tnode = v.node;
+            const uint32_t nm0 = (uint32_t)(st[F_NODE_NMASK] >> 32);
+            const uint32_t adjm = (nm0 & 0x7FFFFFFFu) ? km0 : 0u;
+            const K9Sc scx = k9_sc_preload(sh.active >> 2, gi, gr, a.NP, v.node);
+            const uint32_t mpl = tu >= b ? tu - b : 0u;   // placements on top of the slot's state
+            const double fm = (double)mpl;   // (whole numbers below 2^47: Idle - u * Resreq is what u subtractions give — resource_info.go:143-156, one Sub per placement)
+            v.idle0 -= fm * sh.init0; v.idle1 -= fm * sh.init1; v.nzc += fm * sh.nzc; v.nzm += fm * sh.nzm;
+            if (mpl) v.ports |= sh.want;
+            v.left -= (int)mpl;
+            bool fi = true;   // (sel_run: allocate, fit_mode 1)
+            key = k9_eval_v(a, sh, v, scx, gi, gr, si, adjm, (double)tu, si, nb, nmaskbits, &fi);
+            kind = fi ? 0u : 1u;   // allocate.go:160: InitResreq.LessEqual(node.Idle) -> Allocate, else Pipeline
+            if (b && tu == 0u) {   // a clean candidate's own first placement: as its prep wave found it (key against the clean node, Allocate / Pipeline)
+              const uint32_t ci = slot - nd;
+              key = CD.ckey[ci]; kind = CD.ckind[ci];
             }
-            if (__ballot(inexact)) { bail = true; break; }
-            // step jj exists iff every step of the pass before it exists and is an Allocate, and its own key is not 0.  The lanes of a
-            // contender are neighbours [g0, g0 + D): ballots for the existence, a shuffle per step for the prefix minimum
-            const uint32_t g0 = ai * D;
-            const unsigned long long ends = __ballot(act && (key == 0u || kind != 0u));   // nothing exists behind such a step
-            const unsigned long long mine = lt & ~((1ull << (g0 & 63u)) - 1ull);          // my contender's lanes in front of me
-            const bool valid = act && key != 0u && (ends & mine) == 0ull;
-            for (uint32_t t = 0; t < D; t++) {
-              const uint32_t kt = (uint32_t)__shfl((int)key, (int)(g0 + t));
-              if (t <= u) run = min(run, kt);
-            }
-            const unsigned long long vb = __ballot(valid);
-            if (valid) {
-              const uint32_t pos = n + (uint32_t)__popcll(vb & lt);
-              X.e_comp[pos] = ((unsigned long long)run << 8) | (unsigned long long)(255u - jj);
-              X.e_info[pos] = cc | (kind << 8) | (jj << 16);
-            }
-            {   // the contender's record, by its first lane_i: g steps were found
-              const uint32_t g = act ? (uint32_t)__popcll((vb >> (g0 & 63u)) & ((1ull << D) - 1ull)) : 0u;   // D <= K9_SEL_MAXRUN - 1
-              const uint32_t lastl = g0 + (g ? g - 1u : 0u);
-              const uint32_t run_last = (uint32_t)__shfl((int)run, (int)lastl), kind_last = (uint32_t)__shfl((int)kind, (int)lastl);
-              if (act && u == 0u) {
-                X.c_next[cc] += g;
-                if (g) X.c_eff[cc] = run_last;
-                if (g < D || kind_last != 0u) X.c_flag[cc] |= 1u;   // the sequence ended inside the pass, or its last step is a Pipeline
-              }
-            }
-            n += (uint32_t)__popcll(vb);
-            if (lane_i == 0) atomicAdd(&X.stat[3], 1u);
-            K9_WAVE_FENCE();
           }
+          // an entry exists iff its key is not 0 and every entry of its contender in front of it exists and is an Allocate
+          const unsigned long long ends = __ballot(act && (key == 0u || kind != 0u));
+          const unsigned long long front = lt & ~((1ull << ((tg << lgD) & 63u)) - 1ull);   // my contender's lanes in front of me
+          const bool valid = act && key != 0u && (ends & front) == 0ull;
+          X.e_key[lane_i] = key;
+          // prefix minimum per contender (its lanes are neighbours; D <= 16: inside one DPP row)
+          uint32_t eff = valid ? key : 0xFFFFFFFFu;
+#define K9S_SHR(sft) do { const uint32_t t_ = (uint32_t)__builtin_amdgcn_update_dpp((int)0xFFFFFFFFu, (int)eff, 0x110 + (sft), 0xf, 0xf, false); if (tu >= (sft)) eff = min(eff, t_); } while (0)
+          K9S_SHR(1); K9S_SHR(2); K9S_SHR(4); K9S_SHR(8);
+#undef K9S_SHR
+          if (lgD == 5u) { const uint32_t t_ = (uint32_t)__shfl((int)eff, (int)((lane_i & 0x30u) | 15u) - 16); if (tu >= 16u) eff = min(eff, t_); }   // the contender's first row
+          if (!valid) eff = 0u;
+          X.e_eff[lane_i] = eff;
+          K9_WAVE_FENCE();
           K9_STAMP(6);
-          if (!bail) {
-            // ---- the picks: rows in rank order; a Pipeline ends the round behind its row; fewer entries than rows: no feasible node is left
-            const bool have = lane_i < n;
-            const uint32_t ekind = (info >> 8) & 1u, ec = info & 0xFFu;
-            const uint32_t cnt = min(n, r);
-            const uint32_t pr = (have && rank < r && ekind) ? rank : 0xFFFFFFFFu;
-            const uint32_t minpipe = ~wave_max_u32(~pr);
-            uint32_t n_take = cnt;
-            if (minpipe < cnt) { n_take = minpipe + 1u; reason = KB_REASON_PIPELINED; }
-            else if (cnt < r) reason = KB_REASON_NO_FEASIBLE;   // allocate.go:144-148
-            if (have && rank < n_take) {
-              const uint32_t node = (uint32_t)slots[(size_t)X.c_slot[ec] * K9_NF + F_NODE_NMASK];
-              ldec[i0 + rank] = (unsigned long long)node | ((unsigned long long)ekind << 32);
-              atomicAdd(&X.c_take[ec], 1u);
-              if (ekind) atomicOr(&X.c_flag[ec], 4u);
+          // -- the rank: entries with a greater eff, and the same contender's earlier entries with the same eff (they are neighbours)
+          uint32_t rank = 0u;
+          {
+            const uint32_t n_e = nC << lgD;
+            const uint4 *ev = reinterpret_cast<const uint4 *>(X.e_eff);
+            for (uint32_t i = 0; i < n_e; i += 4u) {
+              const uint4 q_ = ev[i >> 2];
+              rank += (q_.x > eff ? 1u : 0u) + (q_.y > eff ? 1u : 0u) + (q_.z > eff ? 1u : 0u) + (q_.w > eff ? 1u : 0u);
             }
-            K9_WAVE_FENCE();
-            // ---- NodeInfo.AddTask (api/node_info.go:172-212), once per placement, on every contender that was picked: lane_i = contender
-            const uint32_t T = (lane_i < nC) ? X.c_take[lane_i] : 0u;
-            if (T) {
-              const uint32_t fl = X.c_flag[lane_i], b = (fl >> 1) & 1u, pipe_last = (fl >> 2) & 1u;
-              unsigned long long *st = slots + (size_t)X.c_slot[lane_i] * K9_NF;
-              const uint32_t node = (uint32_t)st[F_NODE_NMASK], nm = (uint32_t)(st[F_NODE_NMASK] >> 32);
-              const uint32_t extra = T - b;   // a clean candidate's slot already holds its first placement
-              if (extra || km0) { const uint32_t x = X.c_slot[lane_i]; atomicOr(&chg[x >> 5], 1u << (x & 31)); }   // not what an early evaluation for the next run saw (its scalar dimensions: in HBM only now)
-              if (extra) {
-                double idle0 = u2d(st[F_IDLE0]), idle1 = u2d(st[F_IDLE1]), rel0 = u2d(st[F_REL0]), rel1 = u2d(st[F_REL1]);
-                double zc = u2d(st[F_NZC]), zm = u2d(st[F_NZM]);
-                for (uint32_t t = 0; t < extra; t++) {
-                  if (pipe_last && t + 1u == extra) { rel0 -= sh.init0; rel1 -= sh.init1; } else { idle0 -= sh.init0; idle1 -= sh.init1; }
-                  zc += sh.nzc; zm += sh.nzm;
-                }
-                st[F_IDLE0] = d2u(idle0); st[F_IDLE1] = d2u(idle1); st[F_REL0] = d2u(rel0); st[F_REL1] = d2u(rel1);
-                st[F_NZC] = d2u(zc); st[F_NZM] = d2u(zm);
-                st[F_PORTS] |= sh.want;
-                st[F_CLS_LEFT] -= ((unsigned long long)extra << 32);   // that many more pods on the node
+            const uint32_t prev = (uint32_t)__shfl_up((int)eff, 1);
+            const unsigned long long starts = __ballot(!(tu > 0u && prev == eff));
+            const unsigned long long upto = starts & (lt | (1ull << lane_i));
+            rank += lane_i - (63u - (uint32_t)__clzll((long long)upto));
+          }
+          // -- how many of them are final
+          const uint32_t nvalid = (uint32_t)__popcll(__ballot(valid));
+          uint32_t cutv = 0xFFFFu;
+          if (valid) {
+            if (eff < thr) cutv = rank;                          // somebody outside the table may come first
+            else if (tu == D - 1u && kind == 0u) cutv = rank;     // the table ends here, the sequence may not: the next shot
+            else if (kind != 0u) cutv = rank + 1u;                // a Pipeline ends the round behind its row
+          }
+          const uint32_t n_take = min(min(rem, nvalid), 0xFFFFu - wave_max_u32(0xFFFFu - cutv));
+          if (n_take == 0u) { reason = KB_REASON_INTERNAL; k9s_st(&Y.err, 1u); break; }   // (never: the best contender's first entry is final)
+          const bool picked = valid && rank < n_take;
+          if (picked) ldec[i0 + j + rank] = (unsigned long long)tnode | ((unsigned long long)kind << 32);
+          const unsigned long long pb = __ballot(picked), ppipe = __ballot(picked && kind != 0u);
+          const bool pipe = ppipe != 0ull;
+          const uint32_t gp = pipe ? (((uint32_t)__ffsll((unsigned long long)ppipe) - 1u) >> lgD) : 0xFFFFFFFFu;   // the contender whose last row is the Pipeline
+          // -- NodeInfo.AddTask (api/node_info.go:172-212) on every contender that took rows: lane g = contender g
+          uint32_t T = 0u, c_x = 0u, c_b = 0u;
+          if (lane_i < nC) {
+            T = (uint32_t)__popcll((pb >> (lane_i << lgD)) & ((1ull << D) - 1ull));
+            const uint32_t cs = X.c_slot[lane_i];
+            c_x = cs & 0x7FFFFFFFu; c_b = cs >> 31;
+          }
+          if (T) {
+            unsigned long long *st = slots + (size_t)c_x * K9_NF;
+            const uint32_t node = (uint32_t)st[F_NODE_NMASK], nm = (uint32_t)(st[F_NODE_NMASK] >> 32);
+            const bool plast = lane_i == gp;
+            const uint32_t extra = T - c_b;   // a clean candidate's slot already holds its first placement
+            if (extra || km0 || c_x < nd) atomicOr(&chg[c_x >> 5], 1u << (c_x & 31));   // not what an early evaluation for the next run saw (scalar dimensions: in HBM only)
+            if (extra) {
+              const double fa = (double)(extra - (plast ? 1u : 0u));
+              double idle0 = u2d(st[F_IDLE0]), idle1 = u2d(st[F_IDLE1]), rel0 = u2d(st[F_REL0]), rel1 = u2d(st[F_REL1]);
+              idle0 -= fa * sh.init0; idle1 -= fa * sh.init1;
+              if (plast) { rel0 -= sh.init0; rel1 -= sh.init1; }
+              st[F_IDLE0] = d2u(idle0); st[F_IDLE1] = d2u(idle1); st[F_REL0] = d2u(rel0); st[F_REL1] = d2u(rel1);
+              st[F_NZC] = d2u(u2d(st[F_NZC]) + (double)extra * sh.nzc); st[F_NZM] = d2u(u2d(st[F_NZM]) + (double)extra * sh.nzm);
+              st[F_PORTS] |= sh.want;
+              st[F_CLS_LEFT] -= ((unsigned long long)extra << 32);   // that many more pods on the node
+            }
+            if (km0)   // the scalar dimensions Resreq names, in HBM, one Sub per placement (Sub returns early when the receiver's map is nil)
+              for (uint32_t t = 0; t < T; t++) {
+                const bool pp = plast && t + 1u == T;
+                const bool has_map = pp ? (nm >> 31) : (nm & 0x7FFFFFFFu);
+                if (has_map)
+                  for (uint32_t mm = km0, dd = 0; mm; mm >>= 1, dd++)
+                    if (mm & 1u) k9_sc_sub(pp ? gr : gi, a.NP, dd, node, si[dd]);
               }
-              if (km0)   // the scalar dimensions Resreq names, in HBM, one Sub per placement (Sub returns early when the receiver's map is nil)
-                for (uint32_t t = 0; t < T; t++) {
-                  const bool pp = pipe_last && t + 1u == T;
-                  const bool has_map = pp ? (nm >> 31) : (nm & 0x7FFFFFFFu);
-                  if (has_map)
-                    for (uint32_t mm = km0, dd = 0; mm; mm >>= 1, dd++)
-                      if (mm & 1u) k9_sc_sub(pp ? gr : gi, a.NP, dd, node, si[dd]);
-                }
-              if (b) atomicOr(&bitmap[node >> 5], 1u << (node & 31));
+            if (c_b) atomicOr(&bitmap[node >> 5], 1u << (node & 31));
+          }
+          if (__ballot(T != 0u && (T - c_b != 0u || km0 != 0u || c_x < nd)) != 0ull) chg_any = true;
+          if (km0) sc_dirty = 1;
+          pc += (uint32_t)__popcll(__ballot(T != 0u && c_b != 0u));   // clean candidates leave the list in list order (their keys fall along it)
+          j += n_take;
+          if (lane_i == 0) atomicAdd(&X.stat[3], 1u);
+          if (pipe) { reason = KB_REASON_PIPELINED; K9_STAMP(7); break; }
+          if (j < r) {
+            // -- another shot: the contenders' keys after their placements (entry T of their table: the last entry is never taken) go back into the pool
+            if (!pooled) {
+              X.pool[lane_i] = d0; X.pool[lane_i + 64u] = d1; X.pool[lane_i + 128u] = d2; X.pool[lane_i + 192u] = d3; X.pool[lane_i + 256u] = k1;
+              pooled = true;
+              K9_WAVE_FENCE();
             }
-            if (km0) sc_dirty = 1;
-            if (__ballot(T != 0u && (T - ((X.c_flag[lane_i < nC ? lane_i : 0u] >> 1) & 1u) != 0u || km0 != 0u)) != 0ull) chg_any = true;   // some lane_i listed its slot in chg above
-            pc = (uint32_t)__popcll(__ballot(lane_i < ncand && T != 0u));
-            n_dirty = n_take - pc;
-            j = n_take;
-            sel_done = true;
-            if (lane_i == 0) atomicAdd(&X.stat[1], 1u);
-          } else if (lane_i == 0) {
-            atomicAdd(&X.stat[2], 1u);
+            if (T) X.pool[c_x < nd ? c_x : 256u + (c_x - nd)] = X.e_key[(lane_i << lgD) + T];
+            K9_WAVE_FENCE();
+            d0 = X.pool[lane_i]; d1 = X.pool[lane_i + 64u]; d2 = X.pool[lane_i + 128u]; d3 = X.pool[lane_i + 192u]; k1 = X.pool[lane_i + 256u];
           }
           K9_STAMP(7);
         }
+        n_dirty = j - pc;
+        sel_done = true;
+        if (lane_i == 0) atomicAdd(&X.stat[1], 1u);
       }
       // backfill.go:50-66 takes the FIRST node that passes the predicates (all scores tie: the round runs with scores off), and nothing in the
       // placement of a plain BestEffort row — an empty request — changes what the predicates read of the node except its pod count (and its ports,
@@ -632,7 +616,7 @@ __global__ void __launch_bounds__(K9_THREADS) k_commit_select(const K9KernArgs k
     const uint32_t t = tid - 64u;
     for (uint32_t q = 0; q < K; q++) {
       K9S_RUN_HEADER(q)
-      uint32_t *dko = X.dkb[q & 1u], *dkko = X.dkk[q & 1u];
+      uint32_t *dko = X.dkb[q & 1u];
       uint32_t key = 0u, nd_early = 0u;
       const unsigned long long tw0 = K9S_NOW();
       if (q >= 1u) {
@@ -642,8 +626,6 @@ __global__ void __launch_bounds__(K9_THREADS) k_commit_select(const K9KernArgs k
           const K9St vs = k9_load(slots + (size_t)t * K9_NF);
           const K9Sc scp = k9_sc_preload(sh.active >> 2, gi, gr, a.NP, vs.node);
           key = k9_eval_v(a, sh, vs, scp, gi, gr, si, 0u, 0.0, si, nb, nmaskbits);
-          // what the slot's next placement of the shape would be (allocate.go:160) — the selection reads it for the slots it considers
-          if (sel_run) dkko[t] = k9_fits_idle(a, sh, vs.idle0, vs.idle1, scp, gi, si, vs.node, 0u, 0.0, si) ? 0u : 1u;
           dko[t] = key;
         }
         const uint32_t wmo = wave_max_u32(t < Y.nd_at[(q - 1u) & 3u] ? key : 0u);
@@ -659,7 +641,6 @@ __global__ void __launch_bounds__(K9_THREADS) k_commit_select(const K9KernArgs k
         const K9St vs = k9_load(slots + (size_t)t * K9_NF);
         const K9Sc scp = k9_sc_preload(sh.active >> 2, gi, gr, a.NP, vs.node);
         key = k9_eval_v(a, sh, vs, scp, gi, gr, si, 0u, 0.0, si, nb, nmaskbits);
-        if (sel_run) dkko[t] = k9_fits_idle(a, sh, vs.idle0, vs.idle1, scp, gi, si, vs.node, 0u, 0.0, si) ? 0u : 1u;
       }
       if (t >= nd) key = 0u;
       if (t < K9_MAXSLOTS) dko[t] = key;
@@ -736,7 +717,7 @@ __global__ void __launch_bounds__(K9_THREADS) k_commit_select(const K9KernArgs k
       // ---- P2, for every fetched entry (which of them are the run's candidates is decided below): Allocate / Pipeline, NodeInfo.AddTask on
       //      the fetched state, key of the node after the placement
       K9St v;
-      uint32_t kind = 0u, k1 = 0u, kind1 = 0u;
+      uint32_t kind = 0u, k1 = 0u;
       {
         double res0 = sh.init0, res1 = sh.init1;
         if (!plain0) { res0 = rres[0]; res1 = rres[1]; }
@@ -762,7 +743,6 @@ __global__ void __launch_bounds__(K9_THREADS) k_commit_select(const K9KernArgs k
         const uint32_t adjm = (!kind && (rnm & 0x7FFFFFFFu)) ? km0 : 0u;
         if (lane < nf) {
           k1 = k9_eval_v(a, sh, v, scn, gi, gr, si, adjm, 1.0, rqv, nb, nmaskbits);   // the node's key once it is dirty
-          if (sel_run && !kind) kind1 = k9_fits_idle(a, sh, v.idle0, v.idle1, scn, gi, si, n, adjm, 1.0, rqv) ? 0u : 1u;   // a second placement on it
         }
       }
       // ---- the run's candidates: the first r entries whose node the runs in front leave alone, stored as its future dirty slots.  Settled
@@ -790,7 +770,7 @@ __global__ void __launch_bounds__(K9_THREADS) k_commit_select(const K9KernArgs k
           st[F_CLS_LEFT] = (unsigned long long)rcls | ((unsigned long long)(uint32_t)v.left << 32);
           st[F_NODE_NMASK] = (unsigned long long)n | ((unsigned long long)rnm << 32);
           CD.ckey[rho] = key; CD.cpos[rho] = mypos;
-          CD.ckind[rho] = kind; CD.ck1[rho] = k1; CD.ckind1[rho] = kind1; CD.crnm[rho] = rnm;
+          CD.ckind[rho] = kind; CD.ck1[rho] = k1; CD.crnm[rho] = rnm;
         }
         if (lane == 0) Y.ncand_at[m & 3u] = ncand;
       };

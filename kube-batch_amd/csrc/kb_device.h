@@ -70,6 +70,8 @@ struct KbDev {
   int wNA;
   int pred_enabled;               // predicates plugin registered with EnabledPredicate
   int score_enabled;              // nodeorder plugin registered with EnabledNodeOrder
+  uint32_t whole;                 // every request, Idle and Releasing value of the session is a whole number below 2^47 (k8s quantities in milli-units /
+                                  // bytes always are): u placements are then Idle - u * Resreq exactly, which the selection kernel's shots rely on
   // inter-pod (anti)affinity (include/kb_engine.h: kb_interpod), all nullptr when no pod carries a term.  A task that is a SUBJECT
   // (it has predicate checks or non-zero priority weights) is only ever evaluated by the matrix kernel against the live counters:
   // it is the first row of its round (the host plans it so; t_ip_subject also sets the row's "fresh matrix" flag).  A placement
@@ -190,6 +192,7 @@ struct KbCommitArgs {
   unsigned long long seq;         // sequence number published last into host_out[KB_OUT_SEQ]
   uint32_t node_bits;             // width of the node field of the commit kernel's 32-bit keys (kb_node_bits)
   uint32_t prewalk;               // unused
+  uint32_t whole;                 // KbDev::whole
 };
 
 // 32-bit keys of the commit kernel: (score + 1) << node_bits | (2^node_bits - 1 - node); needs (max score + 2) << node_bits <= 2^32

@@ -186,6 +186,7 @@ struct Timer {   // HIP-event pair on the engine stream
 
 struct MgState;
 static void mg_free(MgState *m);
+static void mg_reset(MgState *m);
 
 struct kb_engine {
   std::string err;
@@ -1094,10 +1095,20 @@ struct MgState {
   // values that lives for the action, the rounds begun in it
   DevBuf q_idle, q_rel, q_nzc, q_nzm, q_podcnt, chk_counter;
   uint32_t rounds_begun = 0;
+  bool chk_valid = false;   // chk_counter belongs to an action begun since the last load / reset
   KbNodeCopy cur() const { return KbNodeCopy{s_idle.as<double>(), s_rel.as<double>(), s_nzc.as<long long>(), s_nzm.as<long long>(), s_podcnt.as<int>()}; }
   KbNodeCopy prev() const { return KbNodeCopy{q_idle.as<double>(), q_rel.as<double>(), q_nzc.as<long long>(), q_nzm.as<long long>(), q_podcnt.as<int>()}; }
 };
 static void mg_free(MgState *m) { delete m; }
+// kb_session_reset: the round-mode action state goes, its device buffers stay (ten node-state copies + the counter: a sharded cycle resets every
+// step, and hipFree synchronises the device — inside the timed step, on the first rounds' critical path)
+static void mg_reset(MgState *m) {
+  if (!m) return;
+  m->run = ActionRun();
+  m->in_round = false; m->committed = false; m->had_candidates = false;
+  m->n_done = 0; m->reason = 0; m->rounds_begun = 0; m->chk_valid = false;
+  m->last_decs.clear();
+}
 
 namespace {
 int guarded(kb_engine *e, const std::function<void()> &fn) {
@@ -1282,8 +1293,7 @@ int kb_session_load(kb_engine *e, const kb_snapshot *sn) {
     e->loaded = false;
     e->fin0.valid = false;
     e->stale_checked = false; e->pristine = true; e->load_clean = false;
-    mg_free(e->mg);
-    e->mg = nullptr;
+    mg_reset(e->mg);   // (its device buffers are grow-only like every other one: no hipFree / hipMalloc per cycle)
     HostSession &hs = e->hs;
     const uint32_t NP = ((sn->n_nodes + KB_NODE_PAD - 1) / KB_NODE_PAD) * KB_NODE_PAD + (sn->n_nodes == 0 ? KB_NODE_PAD : 0);
     std::vector<uint32_t> t_active, nmask;
@@ -1308,6 +1318,8 @@ int kb_session_load(kb_engine *e, const kb_snapshot *sn) {
     // ---- device upload: every source goes through the load's pinned area (PinnedArena above), every copy is asynchronous on the engine's
     //      stream, and the ONE synchronisation of a load is the one that ends it (run_finalize's, below)
     e->load_arena.reset();
+    e->async_pending = true;   // from here on copies out of (and the water-fill's answers into) the pinned area are queued: a validation that throws below
+                               // leaves them in flight, and the next load's quiesce() must wait for them before the area is handed out again
     Uploader up(e->load_arena, s);
     WaterfillInFlight wf_flight;
     // proportion's water-fill first: it needs the host session only, and its (tiny, serial) launch runs while the host assembles the rest
@@ -1598,6 +1610,7 @@ int kb_session_load(kb_engine *e, const kb_snapshot *sn) {
     d.wL = e->pol.wL; d.wM = e->pol.wM; d.wB = e->pol.wB;
     d.pred_enabled = e->pol.pred_enabled ? 1 : 0;
     d.score_enabled = e->pol.nodeorder_enabled ? 1 : 0;
+    d.whole = hs.whole ? 1u : 0u;
     e->win_cap = 0; e->mat_cap = 0; e->keys_cap = 0;
     e->mat2_cap = 0; e->stale_cap = 0;   // the second stream's matrix rows are [rows][NP] too: a session with more nodes needs them again
     e->xs_cap = 0;   // kb_eval_matrix's per-shape rows are [shapes][NP] as well (found by tests/test_gpu_reload.py: fewer shapes over more nodes overran them)
@@ -1653,8 +1666,7 @@ int kb_session_reset(kb_engine *e) {
     if (e->hs.has_interpod) { restore(e->b_ip_ccnt, e->p_ip_ccnt); restore(e->b_ip_ctot, e->p_ip_ctot); restore(e->b_ip_punb, e->p_ip_punb); restore(e->b_ip_z, e->p_ip_z); }
     HIP_OK(hipMemsetAsync(e->b_tbind.p, 0xFF, sizeof(uint32_t) * (e->hs.T ? e->hs.T : 1), s));
     HIP_OK(hipMemsetAsync(e->b_jallocated.p, 0, e->b_jallocated.bytes, s));
-    mg_free(e->mg);
-    e->mg = nullptr;
+    mg_reset(e->mg);   // (its device buffers are grow-only like every other one: no hipFree / hipMalloc per cycle)
     std::fill(e->hs.queue_share_live.begin(), e->hs.queue_share_live.end(), e->hs.queue_share_at_open);
     e->evictions.clear();
     e->hs.t_off_node.clear();
@@ -1675,22 +1687,29 @@ int kb_session_reset(kb_engine *e) {
   });
 }
 
+// What allocate / backfill refuse before they touch anything — whichever way the action is entered (kb_run_allocate / kb_run_backfill, or the first
+// kb_round_begin of an action on the task-row split: every rank would diverge alike there, so neither the delta cross-check nor the journal digest
+// would notice).
+static void action_entry_guards(kb_engine *e) {
+  if (!e->loaded) throw EngineError(KB_E_STATE, "kb_session_load must precede kb_run_* / kb_round_begin");
+  if (e->tainted) throw EngineError(KB_E_STATE, "a preempt / reclaim call failed after touching the session's state: kb_session_load or kb_session_reset first");
+  // A Pending task that still carries a NodeName was un-pipelined by a discarded preempt statement (NodeInfo.RemoveTask never
+  // clears it, api/node_info.go:217-243): the reference's AddTask then refuses every other node AFTER ssn.Allocate has flipped
+  // the status (session.go:243 vs :255).  Not modelled: the stock action takes such a cycle (it cannot arise under the stock
+  // action order, where preempt runs last).
+  if (!e->stale_checked) {
+    for (uint32_t t = 0; t < e->hs.T; t++)
+      if (e->hs.t_status[t] == KB_TASK_PENDING && e->hs.t_node[t] != KB_NONE)
+        throw EngineError(KB_E_UNSUPPORTED, "a Pending task carries a stale NodeName (un-pipelined by a discarded preempt statement)");
+    e->stale_checked = true;   // allocate and backfill never create one
+    if (e->pristine) e->load_clean = true;
+  }
+}
+
 static int run_action(kb_engine *e, uint32_t action, kb_decision *out, uint64_t cap, uint64_t *n_out) {
   if (!e) return KB_E_INVALID;
   return guarded(e, [&]() {
-    if (!e->loaded) throw EngineError(KB_E_STATE, "kb_session_load must precede kb_run_*");
-    if (e->tainted) throw EngineError(KB_E_STATE, "a preempt / reclaim call failed after touching the session's state: kb_session_load or kb_session_reset first");
-    // A Pending task that still carries a NodeName was un-pipelined by a discarded preempt statement (NodeInfo.RemoveTask never
-    // clears it, api/node_info.go:217-243): the reference's AddTask then refuses every other node AFTER ssn.Allocate has flipped
-    // the status (session.go:243 vs :255).  Not modelled: the stock action takes such a cycle (it cannot arise under the stock
-    // action order, where preempt runs last).
-    if (!e->stale_checked) {
-      for (uint32_t t = 0; t < e->hs.T; t++)
-        if (e->hs.t_status[t] == KB_TASK_PENDING && e->hs.t_node[t] != KB_NONE)
-          throw EngineError(KB_E_UNSUPPORTED, "a Pending task carries a stale NodeName (un-pipelined by a discarded preempt statement)");
-      e->stale_checked = true;   // allocate and backfill never create one
-      if (e->pristine) e->load_clean = true;
-    }
+    action_entry_guards(e);
     const double t_act0 = now_ms();
     ActionRun run;
     run.begin(e, action);
@@ -2252,11 +2271,14 @@ int kb_round_begin(kb_engine *e, uint32_t action, uint32_t *n_rows, uint32_t *n_
     if (!e->mg) e->mg = new MgState();
     MgState &m = *e->mg;
     if (!m.run.active) {
+      action_entry_guards(e);   // (the same refusals as kb_run_allocate / kb_run_backfill: a tainted session, a stale NodeName behind a discarded statement)
       m.run.begin(e, action);
+      m.run.probe_dead_shapes(e);   // as run_action does: shapes no node can take from the start never cost a round (every replica reads the same state: the same answer)
       m.in_round = false;
       m.rounds_begun = 0;
       m.chk_counter.alloc(sizeof(uint32_t));
       HIP_OK(hipMemsetAsync(m.chk_counter.p, 0, sizeof(uint32_t), e->stream));
+      m.chk_valid = true;
     } else if (m.run.action != action) {
       throw EngineError(KB_E_STATE, "another action is still in progress");
     }
@@ -2333,6 +2355,9 @@ int kb_round_apply(kb_engine *e, uint64_t dev_delta_ptr, uint32_t *done) {
       if (mism) throw EngineError(KB_E_INTERNAL, "replicas diverged: reduced per-node deltas differ from the local commit at " + std::to_string(mism) + " values");
     }
     m.run.absorb(e, m.ctx.n, m.n_done, m.reason);
+    // a speculation break: the feasibility probe marks every shape that died with the one that broke the round (run_action's rule; without it the
+    // split paid one round per dead shape — 61 breaks per 100k x 10k cycle against the single-GPU path's 14, round 5)
+    if (m.reason != KB_REASON_DONE && m.reason != KB_REASON_RENORM) m.run.probe_dead_shapes(e);
     m.in_round = false;
     m.committed = false;
     if (done) *done = 0;
@@ -2359,7 +2384,7 @@ int kb_round_check(kb_engine *e, uint64_t dev_delta_ptr, uint32_t against_live) 
 int kb_round_check_result(kb_engine *e, uint32_t *mismatches) {
   if (!e || !mismatches) return KB_E_INVALID;
   return guarded(e, [&]() {
-    if (!e->mg || !e->mg->chk_counter.p) throw EngineError(KB_E_STATE, "kb_round_check_result: no round-mode action has run");
+    if (!e->mg || !e->mg->chk_valid) throw EngineError(KB_E_STATE, "kb_round_check_result: no round-mode action has run");
     uint32_t h = 0;
     HIP_OK(hipMemcpyAsync(&h, e->mg->chk_counter.p, sizeof(uint32_t), hipMemcpyDeviceToHost, e->stream));
     HIP_OK(hipStreamSynchronize(e->stream));

@@ -84,6 +84,7 @@ struct HostSession {
   std::vector<uint32_t> n_cls, n_idle_mask;   // static class; scalar keys of Idle / Allocatable
   std::vector<uint8_t> compat;             // class x class bit table (empty: every pair compatible)
   uint32_t n_tc = 0, n_nc = 1;
+  bool whole = true;                       // every request / Idle / Releasing value is a whole number below 2^47 (KbDev::whole)
   bool has_affinity = false;               // some class carries preferred node-affinity terms (NormalizeReduce)
   std::vector<uint8_t> cls_has_aff;        // [n_tc] the task class has a non-zero preferred node-affinity count (empty: has_affinity is false)
   // inter-pod (anti)affinity (kb_interpod): a SUBJECT task (predicate checks or priority weights) is planned as the first row of its

@@ -56,15 +56,16 @@ struct K9Sel {
   K9Prep prep[3];                     // one per prep wave
   uint16_t runs[KB_K5_MAX_ROWS];      // first row of run k
   uint32_t brk[8], stm[8];            // row masks: the row cannot join its predecessor / the row starts a run
-  struct Cand { uint32_t ckey[64], cpos[64], ckind[64], ck1[64], ckind1[64], crnm[64]; } cand[2];   // [m & 1]: run m's candidates (its prep wave writes them — possibly ahead, see seq_spec —, wave 0 reads them)
+  struct Cand { uint32_t ckey[64], cpos[64], ckind[64], ck1[64], crnm[64]; } cand[2];   // [m & 1]: run m's candidates (its prep wave writes them — possibly ahead, see seq_spec —, wave 0 reads them)
   uint32_t dkb[2][K9_MAXSLOTS];       // [k & 1][t]: key(shape of run k, dirty slot t)
-  uint32_t dkk[2][K9_MAXSLOTS];       // [k & 1][t]: slot t's next placement of the run's shape would be a Pipeline (allocate.go:160)
-  unsigned long long e_comp[64];      // entries: prefix-minimum key << 8 | 255 - step  (greater = picked earlier)
-  uint32_t e_info[64];                // contender | kind << 8 | step << 16
-  uint32_t c_slot[64], c_next[64], c_eff[64], c_flag[64], c_take[64];   // contenders: state slot, next unknown step, prefix minimum so far, bit 0 ended / bit 1 clean / bit 2 its last taken entry is a Pipeline
-  uint32_t al[64];                    // a deep pass: the contenders it walks
+  // a shot of the selection (wave 0's own scratch): the contenders' slots (bit 31: a clean candidate, its slot one placement ahead), the table's
+  // keys and prefix minima (lane g * D + u), the pool's keys between two shots ([t]: dirty slot t, [256 + i]: this run's candidate i once consumed)
+  uint32_t c_slot[64];
+  alignas(16) uint32_t e_eff[64];
+  uint32_t e_key[64];
+  uint32_t pool[K9_MAXSLOTS + 64];
   uint32_t tr[4];                     // KB_K9_TRACE: cycles the other waves wait / work (kb_commit_sel.hip)
-  uint32_t stat[4];                   // runs committed with every pick a clean first placement / by the general selection / handed to the serial loop; deep passes
+  uint32_t stat[4];                   // runs committed with every pick a clean first placement / by look-ahead passes / handed to the serial loop; look-ahead passes
 };
 
 // dynamic LDS layout for a round of n_rows rows and n_shapes distinct shapes (sel: with the selection kernel's extra block)
@@ -194,8 +195,9 @@ __device__ __forceinline__ double k9_scr(const K9Sc &c, gptrd gr, uint32_t NP, u
 // sc: the node's scalar dimensions as k9_sc_preload(sh.active >> 2, ...) returned them (nothing may have lowered them in between).
 // adj_mask / adj_mul / rq: evaluate as if Idle of the scalar dimensions in adj_mask were lower by adj_mul * rq[d] — placements
 // whose scalar part has not reached HBM yet (the caller has already lowered cpu / memory in v); 0 for a plain evaluation.
+// fits_idle (when asked for; allocate's fit_mode only): InitResreq.LessEqual(Idle) of the same evaluation — allocate.go:160's Allocate / Pipeline test
 __device__ __forceinline__ uint32_t k9_eval_v(const KbCommitArgs &a, const K9Shape &sh, const K9St &v, const K9Sc &sc, gptrd gi, gptrd gr, const double *si,
-                                              uint32_t adj_mask, double adj_mul, const double *rq, uint32_t nb, uint32_t nmaskbits) {
+                                              uint32_t adj_mask, double adj_mul, const double *rq, uint32_t nb, uint32_t nmaskbits, bool *fits_idle = nullptr) {
   bool ok = true;
   if (a.fit_mode) {   // allocate.go:81: !InitResreq.LessEqual(Idle) && !InitResreq.LessEqual(Releasing) -> fail
     bool fi = le_eps(sh.init0, v.idle0, EPS_CPU) && le_eps(sh.init1, v.idle1, EPS_MEM);
@@ -212,6 +214,7 @@ __device__ __forceinline__ uint32_t k9_eval_v(const KbCommitArgs &a, const K9Sha
       aa >>= 1; dd++;
     }
     ok = fi || (a.fit_mode != 2 && fr);   // 2: backfill, AddTask's Resreq.LessEqual(Idle) only (node_info.go:161-167)
+    if (fits_idle) *fits_idle = fi;
   }
   if (a.pred_enabled) {
     ok = ok && (v.left > 0) && ((v.ports & sh.conf) == 0ull);   // pod count (predicates.go:127), PodFitsHostPorts (predicates.go:181-190)
@@ -576,4 +579,5 @@ static inline void k9_fill_args(K9KernArgs &ka, const KbDev &d, const KbRound &r
   a.seq = r.seq;
   a.node_bits = kb_node_bits(d.NP);
   a.prewalk = 0;
+  a.whole = d.whole;
 }

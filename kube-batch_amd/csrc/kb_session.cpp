@@ -164,11 +164,22 @@ void build_host_session(const kb_snapshot *sn, const Policy &pol, uint32_t NP, H
       throw EngineError(KB_E_UNSUPPORTED, "node quantity >= 2^48: exact integer scoring not guaranteed");
   }
   hs.t_res.resize((size_t)R * T); hs.t_init.resize((size_t)R * T); hs.t_resmask.resize(T); hs.t_res_rows.resize((size_t)T * R);
+  // whole numbers below 2^47 (KbDev::whole): k8s quantities in milli-units / bytes always are; anything else only costs the selection kernel its
+  // shots (the rows of a run then go one by one: one Sub per placement, in order, whatever the values)
+  std::atomic<int> fractional{0};
+  auto whole_run = [](const double *p, size_t n) {
+    bool ok = true;
+    for (size_t i = 0; i < n; i++) ok = ok && p[i] == std::floor(p[i]) && std::fabs(p[i]) < 140737488355328.0;
+    return ok;
+  };
+  for (int d = 0; d < R; d++)
+    if (!whole_run(sn->node_idle + (size_t)d * N, N) || !whole_run(sn->node_releasing + (size_t)d * N, N)) fractional.store(1, std::memory_order_relaxed);
   par_for(T, 4u * (uint32_t)R, [&](uint32_t t0, uint32_t t1) {
     for (uint32_t t = t0; t < t1; t++) hs.t_resmask[t] = sn->task_scalar_mask ? sn->task_scalar_mask[t] : 0u;
     for (int d = 0; d < R; d++) {   // one dimension's row at a time: sequential in the dimension-major layout
       std::copy(sn->task_resreq + (size_t)d * T + t0, sn->task_resreq + (size_t)d * T + t1, hs.t_res.begin() + (size_t)d * T + t0);
       std::copy(sn->task_init_resreq + (size_t)d * T + t0, sn->task_init_resreq + (size_t)d * T + t1, hs.t_init.begin() + (size_t)d * T + t0);
+      if (!whole_run(sn->task_resreq + (size_t)d * T + t0, t1 - t0) || !whole_run(sn->task_init_resreq + (size_t)d * T + t0, t1 - t0)) fractional.store(1, std::memory_order_relaxed);
       if (d >= 2) {   // a dense value under an absent key reads 0 (Go map semantics)
         double *row = &hs.t_res[(size_t)d * T];
         for (uint32_t t = t0; t < t1; t++)
@@ -180,6 +191,7 @@ void build_host_session(const kb_snapshot *sn, const Policy &pol, uint32_t NP, H
     for (uint32_t t = t0; t < t1; t++)
       for (int d = 0; d < R; d++) hs.t_res_rows[(size_t)t * R + d] = hs.t_res[(size_t)d * T + t];
   });
+  hs.whole = fractional.load() == 0;
   mark("request vectors (copy, absent keys, task-major copy)");
   hs.t_job.resize(T); hs.t_cls.resize(T); hs.t_prio.resize(T); hs.t_creation.resize(T); hs.t_status.resize(T); hs.t_node.resize(T); hs.t_nzc.resize(T); hs.t_nzm.resize(T);
   {

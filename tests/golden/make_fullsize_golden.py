@@ -51,11 +51,15 @@ CASES = {  # name -> (config index, scheduler conf text or None for the default)
     "config4_binpack_full": (4, BINPACK_CONF),
     "config5_full": (5, None),     # 1M tasks x 50k nodes, allocate + backfill
     "config5_full_preempt": (5, PREEMPT_CONF),   # 1M x 50k, allocate + backfill + preempt: decisions, binds, Statement journal, evictions
+    "config3_diverse_full": (3, None),           # round 6: configs[2] with every job drawing its OWN request (bench.py --diverse: ~9 600 distinct task shapes)
 }
 # config 5 takes the faithful loop several minutes (and its preempt hours): its digests come from the oracle's fast modes
 # (kbo_set_fast), which tests/test_oracle_fast_cpu.py holds to the faithful modes on every smaller snapshot, on every preempt /
 # reclaim case of the suite, and on the two full-size digests above
-FAST = {"config5_full", "config5_full_preempt"}
+FAST = {"config5_full", "config5_full_preempt", "config3_diverse_full"}
+# held to the committed digest only on the GPU box (bench.py's `variants.diverse`, tests/test_gpu_fullsize.py): the oracle's incremental mode gains little from
+# its per-shape cache when every job is a shape of its own and needs minutes for this one; the scaled-down diverse sessions of the suite are live-oracle cases
+DIGEST_ONLY = {"config3_diverse_full"}
 
 
 def case_actions(name):
@@ -65,7 +69,10 @@ def case_actions(name):
 def case_inputs(kbm, name):
     idx, conf_text = CASES[name]
     conf = kbm.conf.load_scheduler_conf(conf_text) if conf_text else kbm.conf.load_scheduler_conf()
-    snap = kbm.snapshot.synth(kbm.snapshot.synth_config(idx, 1.0))
+    params = kbm.snapshot.synth_config(idx, 1.0)
+    if "_diverse" in name:
+        params.diverse_requests = True
+    snap = kbm.snapshot.synth(params)
     return conf, snap
 
 
@@ -86,8 +93,10 @@ def main():
     kbm = importlib.import_module("kube-batch_amd")
     import oracle
     oracle.build()
-    out = {}
-    for name in CASES:
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "fullsize_digests.json")
+    only = sys.argv[1:]          # python tests/golden/make_fullsize_golden.py [case ...]: these cases only, merged into the committed file
+    out = json.load(open(path)) if only else {}
+    for name in (only or CASES):
         conf, snap = case_inputs(kbm, name)
         o = oracle.Oracle(conf, snap, threads=min(16, os.cpu_count() or 1))
         if name in FAST:
@@ -105,7 +114,7 @@ def main():
                               "journal_ops": {k: int((j[:, 0] == v).sum()) for k, v in (("evict", 0), ("pipeline", 1), ("commit", 2), ("discard", 3))}})
         print(name, out[name])
         o.close()
-    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "fullsize_digests.json"), "w") as f:
+    with open(path, "w") as f:
         json.dump(out, f, indent=1, sort_keys=True)
         f.write("\n")
 

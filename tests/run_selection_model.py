@@ -117,3 +117,69 @@ def selected_run(c, shape, r, w, lanes=None):
             entries.append((-eff, n, j, kind))
     entries.sort()
     return [(n, kind) for _, n, _, kind in entries[:r]]
+
+
+
+def table_run(c, shape, r, w, cap=32, lanes=64):
+    """Round 6: what the selection kernel's SHOTS do (kb_commit_sel.hip) — the selection above with bounded tables, committing per shot exactly the
+    picks that are final.  One shot: the nC best contenders by current key (nC <= cap), F = the best key of everybody else, and per contender its next
+    D = 2^floor(log2(lanes / nC)) entries (key after 0 .. D - 1 further placements: one parallel evaluation), prefix minima per contender, ONE rank
+    of all entries by (eff desc, step asc).  In rank order an entry is FINAL — the serial loop's next pick — as long as (a) its eff is above F (no
+    outsider comes first) and (b) no entry in front of it is the LAST entry of a table whose sequence may go on (what lies behind a table's end is
+    unknown, but its eff is at most the last entry's: it ranks behind that entry, nowhere else).  The final picks are committed (at least one per
+    shot: the best contender's first entry), the node states move on, the next shot sees the rest of the run.  A Pipeline ends the round behind its
+    row."""
+    c = c.copy()
+    tc, tm, req = shape[0], shape[1], (float(shape[2]), float(shape[3]))
+    N = len(c.ac)
+    out = []
+    while len(out) < r:
+        rem = r - len(out)
+        pool = []
+        for n in range(N):
+            s0 = node_sequence(c, n, shape, 1, w)
+            if s0:
+                pool.append(((s0[0][0], -n), n))
+        pool.sort(reverse=True)
+        if not pool:
+            break
+        nC = min(len(pool), cap, max(rem, 1) + 3)      # (the kernel: everybody at or above the rem-th clean candidate's key; any superset of the top rem works)
+        chosen = [n for _, n in pool[:nC]]
+        F = pool[nC][0] if len(pool) > nC else None
+        D = 1
+        while D * 2 * nC <= lanes:
+            D *= 2
+        entries = []
+        for n in chosen:
+            seq = node_sequence(c, n, shape, D, w)
+            eff = None
+            for u, (k, kind) in enumerate(seq):
+                kk = (k, -n)
+                eff = kk if eff is None else min(eff, kk)
+                open_end = (u == D - 1 and kind == ALLOCATE)       # the table ends here, the sequence may not
+                entries.append((eff, -u, n, kind, open_end))
+                if kind == PIPELINE:
+                    break
+        entries.sort(key=lambda e: (e[0], e[1]), reverse=True)
+        take = []
+        for eff, mu, n, kind, open_end in entries:
+            if len(take) == rem or (F is not None and eff < F):
+                break
+            take.append((n, kind))
+            if open_end or kind == PIPELINE:
+                break
+        assert take, "a shot always commits the best contender's first entry"
+        stop = False
+        for n, kind in take:
+            if kind == ALLOCATE:
+                c.idle[n] -= req
+            else:
+                c.rel[n] -= req
+                stop = True
+            c.nzc[n] += tc
+            c.nzm[n] += tm
+            c.podcnt[n] += 1
+            out.append((n, kind))
+        if stop:
+            break
+    return out

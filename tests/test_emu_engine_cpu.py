@@ -163,13 +163,36 @@ def test_sharded_rounds_with_host_port_masks_of_several_words(emulated_engine, o
     assert np.array_equal(cyc.step(), dec)
 
 
+def _recording(cyc):
+    """hooks on a ShardedCycle's two collectives: the all-gathered candidate table and the reduced per-node deltas of every round, as the cycle used them"""
+    cyc.tables, cyc.deltas = [], []
+    gather, reduce_async = cyc._all_gather_keys, cyc._all_reduce_delta_async
+
+    def rec_gather(local, chunk, L):
+        full = gather(local, chunk, L)
+        cyc.tables.append(full.clone().numpy())
+        return full
+
+    def rec_reduce(buf):
+        done = reduce_async(buf)
+
+        def rec_done():
+            done()
+            cyc.deltas.append(buf.clone().numpy())
+        return rec_done
+    cyc._all_gather_keys, cyc._all_reduce_delta_async = rec_gather, rec_reduce
+    return cyc
+
+
 def _sharded_worker(rank, world, port, out_dir, so):
     import torch.distributed as dist
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         _, _, cyc = _sharded_cycle(so, 0)                  # always exchange: every round all-gathers the lists and all-reduces the deltas
+        _recording(cyc)
         dec = cyc.step()
+        np.savez(os.path.join(out_dir, f"coll{rank}.npz"), **{f"t{i}": t for i, t in enumerate(cyc.tables)}, **{f"d{i}": d for i, d in enumerate(cyc.deltas)})
         np.save(os.path.join(out_dir, f"dec{rank}.npy"), dec)
         np.save(os.path.join(out_dir, f"binds{rank}.npy"), cyc.engine.binds())
         st = cyc.engine.stats()
@@ -194,6 +217,30 @@ def test_sharded_rounds_two_gloo_ranks_equal_the_oracle(emulated_engine, oracle_
     m0, m1 = np.load(tmp_path / "mevals0.npy"), np.load(tmp_path / "mevals1.npy")
     assert m0[1] == m1[1]                                   # same number of rounds on both ranks
     assert abs(int(m0[0]) - int(m1[0])) <= m0[1] * 10_000   # each rank evaluated about half of the matrix rows
+    # the collectives against REAL lists (round 5's review: tests/test_dist_cpu.py checks them on a stand-in backend only): every round's
+    # all-gathered table and reduced deltas are the same on both ranks, and equal what ONE rank that evaluates every matrix row and owns every
+    # window row gets without any exchange — rows of the table beyond the window's shapes are padding and stay 0
+    _, _, ref = _sharded_cycle(emulated_engine, 0)
+    _recording(ref)
+    ref.step()
+    c0, c1 = np.load(tmp_path / "coll0.npz"), np.load(tmp_path / "coll1.npz")
+    n_t, n_d = len(ref.tables), int(m0[1])
+    assert n_t > 5 and sorted(c0.files) == sorted(c1.files) == sorted([f"t{i}" for i in range(n_t)] + [f"d{i}" for i in range(n_d)])
+    for i in range(n_t):
+        t0, t1, tr = c0[f"t{i}"], c1[f"t{i}"], ref.tables[i]
+        assert np.array_equal(t0, t1), f"round {i}: the ranks gathered different tables"
+        assert np.array_equal(t0[: len(tr)], tr) and not t0[len(tr):].any(), f"round {i}: the gathered table differs from the lists of an unsharded round"
+    ref_d = ref.engine.round_delta_doubles()
+    for i in range(n_d):
+        assert np.array_equal(c0[f"d{i}"], c1[f"d{i}"]), f"round {i}: the ranks hold different reduced deltas"
+        assert c0[f"d{i}"].shape == (ref_d,) and c0[f"d{i}"].any()
+    # the reduced deltas of all rounds sum to the cycle's whole effect on the node state (the device-side check compares them round by round)
+    idle0 = np.asarray(kbm.snapshot.synth(kbm.snapshot.synth_config(3, 0.05)).node_idle, np.float64)
+    total = sum(c0[f"d{i}"] for i in range(n_d))
+    eidle = ref.engine.node_state()[0]
+    N, R, NP = eidle.shape[1], eidle.shape[0], ref_d // (2 * eidle.shape[0] + 3)
+    for dim in range(R):
+        assert np.array_equal(idle0.reshape(R, N)[dim] + total[dim * NP: dim * NP + N], eidle[dim]), f"dimension {dim}"
 
 
 # ---- BASELINE configs[4] names a third action: preempt (and reclaim) in the sharded mode — every replica runs the evict action, one all-reduce
@@ -403,6 +450,37 @@ def test_the_stale_node_name_check_runs_whenever_one_can_have_appeared(emulated_
     o.close()
 
 
+@pytest.mark.parametrize("seed", [1, 5, 8])
+def test_the_round_api_refuses_what_the_actions_refuse(emulated_engine, seed):
+    """round 5's advisor: kb_round_begin entered allocate / backfill without the guards of kb_run_allocate — a tainted session, a Pending task
+    with a stale NodeName behind a discarded preempt statement.  On the task-row split (ShardedCycle with preempt AHEAD of allocate) every rank
+    would have diverged from the reference alike, which neither the delta cross-check nor the journal digest can see.  Now the first
+    kb_round_begin of the action answers KB_E_UNSUPPORTED like kb_run_allocate does, and goes on refusing until the session is reset."""
+    import torch
+    import test_pyref_vs_oracle as cases
+    distmod = importlib.import_module("kube-batch_amd.dist")
+    cfg, snap, _ = cases._evict_case(seed)
+    e = engine.Engine(cfg)
+    e.load(snap)
+    cpu = torch.device("cpu")
+    cyc = distmod.ShardedCycle(cfg, snap, backend=distmod.EngineBackend(e, cpu), buffer_device=cpu, min_rows_per_rank=0, actions=["preempt", "allocate", "backfill"])
+    for _ in range(2):
+        with pytest.raises(engine.EngineError) as err:
+            cyc.step()
+        assert err.value.code == abi.KB_E_UNSUPPORTED and "stale NodeName" in str(err.value)
+        with pytest.raises(engine.EngineError) as err:     # ... and a second kb_round_begin on the same state says the same
+            e.round_begin(0)
+        assert err.value.code == abi.KB_E_UNSUPPORTED
+    e.reset()
+    plain = distmod.ShardedCycle(cfg, snap, backend=distmod.EngineBackend(e, cpu), buffer_device=cpu, min_rows_per_rank=0, actions=["allocate"])
+    oracle_mod = importlib.import_module("oracle")
+    o = oracle_mod.Oracle(cfg, snap)
+    o.run(["allocate"])
+    assert np.array_equal(plain.step(), o.decisions())      # the same engine, reset: the split runs and equals the oracle
+    e.close()
+    o.close()
+
+
 _RESET_RACE_SCRIPT = r"""
 import importlib, os, sys
 import numpy as np
@@ -486,8 +564,9 @@ def test_the_device_waterfill_equals_the_host_loop_on_adversarial_snapshots(emul
     underflows (the reference panics in Resource.Sub there)."""
     import rawgen
     import test_pyref_vs_oracle as cases
+    oracle_mod = importlib.import_module("oracle")
     launches = _waterfill_counter(emulated_engine)
-    refused = 0
+    refused = vs_oracle = 0
     for seed in range(block * 50, block * 50 + 50):
         snap = rawgen.raw_snapshot(seed)
         rng = np.random.RandomState(seed)
@@ -504,9 +583,25 @@ def test_the_device_waterfill_equals_the_host_loop_on_adversarial_snapshots(emul
         if host[0] is None:
             assert n0 is None or launches() == n0 + (1 if has_proportion else 0), seed
             assert _same(host[1], dev[1]), seed
+            # ... and the launch against the ORACLE directly (round 5's review: against the host loop alone the launch was compared with the
+            # engine itself): `deserved` and both share vectors bit for bit, the decisions, the bind set, the node state
+            if not (isinstance(dev[1][0], str) and dev[1][0] == "run"):     # ("run", code): refused at run time, by both alike
+                try:
+                    o = oracle_mod.Oracle(cfg, snap)
+                    o.run(["allocate", "backfill"])
+                except RuntimeError:
+                    continue                               # the reference panics on this snapshot later in the cycle
+                dec, binds, nodes, shares = dev[1]
+                for got, want in zip(shares, o.shares()):
+                    assert np.array_equal(got, want), seed
+                assert np.array_equal(dec, o.decisions()) and np.array_equal(binds, o.binds()), seed
+                for got, want in zip(nodes, o.node_state()):
+                    assert np.array_equal(got, want), seed
+                o.close()
+                vs_oracle += 1
         else:
             refused += 1
-    assert refused < 50                                    # the block compared something
+    assert refused < 50 and vs_oracle >= 10                # the block compared something, with the host loop and with the oracle
 
 
 def test_the_device_waterfill_on_the_tutorial_example_and_on_128_queues(emulated_engine, monkeypatch):

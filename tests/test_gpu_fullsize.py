@@ -22,6 +22,9 @@ _oracle_cache = {}
 
 
 def _oracle_result(oracle_mod, name):
+    if name not in _oracle_cache and name in mfg.DIGEST_ONLY:     # the committed digest speaks for the oracle (make_fullsize_golden.py: DIGEST_ONLY)
+        conf, snap = mfg.case_inputs(kbm, name)
+        _oracle_cache[name] = (conf, snap, None, None, None, None, None)
     if name not in _oracle_cache:
         conf, snap = mfg.case_inputs(kbm, name)
         o = oracle_mod.Oracle(conf, snap, threads=min(16, os.cpu_count() or 1))
@@ -40,14 +43,17 @@ def test_full_size_cycle_equals_oracle_and_golden_digest(oracle_mod, name):
     conf, snap, odec, obinds, oevals, ojournal, oevict = _oracle_result(oracle_mod, name)
     golden = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "fullsize_digests.json")))[name]
     assert (snap.n_tasks, snap.n_nodes, snap.n_res) == (golden["tasks"], golden["nodes"], golden["n_res"])
-    assert mfg.digest_of(np, odec, obinds, ojournal, oevict) == golden["sha256"], "the oracle no longer reproduces its committed full-size digest"
+    if odec is not None:
+        assert mfg.digest_of(np, odec, obinds, ojournal, oevict) == golden["sha256"], "the oracle no longer reproduces its committed full-size digest"
     e = engine.Engine(conf)
     e.load(snap)
     dec = e.run(mfg.case_actions(name))
-    assert dec.shape == odec.shape
-    assert np.array_equal(dec, odec), f"first divergence at decision {int(np.argmax((dec != odec).any(axis=1)))}"
-    assert np.array_equal(e.binds(), obinds)
-    assert e.stats()["evals"] == oevals == golden["evals"]
+    if odec is not None:
+        assert dec.shape == odec.shape
+        assert np.array_equal(dec, odec), f"first divergence at decision {int(np.argmax((dec != odec).any(axis=1)))}"
+        assert np.array_equal(e.binds(), obinds)
+        assert e.stats()["evals"] == oevals
+    assert dec.shape[0] == golden["decisions"] and e.stats()["evals"] == golden["evals"]
     journal = evict = None
     if ojournal is not None:      # BASELINE configs[4] with its third action: every Statement operation, in order, and what reached cache.Evict
         journal, evict = e.last_journal, e.evictions()

@@ -240,3 +240,44 @@ def test_journal_capacity_contract(oracle_mod):
         e.close()
         done += 1
     assert done >= 10
+
+
+# ---- round 6: the selection kernel's shots evaluate u placements as Idle - u * Resreq, which is u subtractions only for whole numbers -----------
+@pytest.mark.parametrize("case", ["fractional", "bin_packing", "short_clean_lists"])
+def test_runs_on_sessions_the_shots_cannot_take_and_on_the_ones_they_are_for(oracle_mod, commit_kernel, case):
+    """kb_session_load scans requests, Idle and Releasing for whole numbers below 2^47 (KbDev::whole; k8s quantities in milli-units and bytes always
+    are).  `fractional`: quarter-milli requests and Idle values — a run's rows then go one by one (one Sub per placement, in the reference's order of
+    floating-point operations: api/node_info.go:172-212), and the cycle still equals the oracle bit for bit, node state included.
+    `bin_packing`: most_requested.go:34-61 with weight 5 on few large nodes — one node takes many rows of a run (deep tables, two contenders).
+    `short_clean_lists`: a handful of nodes and runs longer than that — every feasible dirty slot contends (the raised floor of the shots)."""
+    S = kbm.snapshot
+    binpack = kbm.conf.load_scheduler_conf('actions: "allocate, backfill"\ntiers:\n- plugins:\n  - name: priority\n  - name: gang\n- plugins:\n  - name: drf\n  - name: predicates\n'
+                                           '  - name: proportion\n  - name: nodeorder\n    arguments:\n      leastrequested.weight: 0\n      mostrequested.weight: 5\n      balancedresource.weight: 1\n')
+    if case == "fractional":
+        cfg, snap = kbm.conf.load_scheduler_conf(), S.synth(S.synth_config(3, 0.03))
+        T, N, R = snap.n_tasks, snap.n_nodes, snap.n_res
+        res, init = np.asarray(snap.task_resreq).reshape(R, T), np.asarray(snap.task_init_resreq).reshape(R, T)
+        jobs = np.asarray(snap.task_job)
+        bump = np.where((jobs % 3 == 0) & (res[0] > 0), 0.25, 0.0)          # every task of a job alike: runs stay runs
+        res[0] += bump
+        init[0] += bump
+        np.asarray(snap.node_idle).reshape(R, N)[0, ::4] += 0.5
+    elif case == "bin_packing":
+        cfg = binpack
+        snap = S.synth(S.SynthParams(n_tasks=1500, n_nodes=12, n_queues=3, n_res=2, seed=S.SEED_BASE + 601, node_cpu_cores=(96, 128), node_mem_gib=(512,)))
+    else:
+        cfg = kbm.conf.load_scheduler_conf()
+        snap = S.synth(S.SynthParams(n_tasks=1200, n_nodes=40, n_queues=2, n_res=2, seed=S.SEED_BASE + 602))
+    o = oracle_mod.Oracle(cfg, snap)
+    o.run(["allocate", "backfill"])
+    e = engine.Engine(cfg)
+    e.load(snap)
+    dec = e.run(["allocate", "backfill"])
+    assert len(dec) > 100 and np.array_equal(dec, o.decisions())
+    assert np.array_equal(e.binds(), o.binds())
+    for a, b in zip(e.node_state(), o.node_state()):
+        assert np.array_equal(a, b)
+    for a, b in zip(e.shares(), o.shares()):
+        assert np.array_equal(a, b)
+    e.close()
+    o.close()

@@ -51,3 +51,23 @@ def test_identical_nodes_and_a_key_that_rises():
     for w in WEIGHTS:
         for r in (1, 5, 40, 100):
             assert m.selected_run(c, shape, r, w) == m.serial_run(c, shape, r, w)      # ... and the selection is still the loop
+
+
+
+@pytest.mark.parametrize("seed", range(80))
+def test_shots_equal_the_serial_loop(seed):
+    """round 6: bounded tables, one rank per shot, only the FINAL picks committed (table_run) against the serial loop — every lane budget from one
+    contender with a deep table to 32 contenders with two entries each.  A Pipeline ends the serial loop's round too: the comparison stops behind
+    the first one."""
+    rng = np.random.RandomState(2000 + seed)
+    N = int(rng.choice([1, 2, 5, 20, 60]))
+    c = _cluster(rng, N)
+    for _ in range(4):
+        shape, r, w = _shape(rng), int(rng.choice([1, 2, 7, 32])), WEIGHTS[rng.randint(len(WEIGHTS))]
+        want = m.serial_run(c, shape, r, w)
+        for i, (_, kind) in enumerate(want):
+            if kind == m.PIPELINE:
+                want = want[:i + 1]
+                break
+        for cap, lanes in ((32, 64), (8, 64), (2, 64), (1, 64), (32, 32), (3, 8), (1, 2), (5, 5)):
+            assert m.table_run(c, shape, r, w, cap, lanes) == want, (seed, N, shape, r, w, cap, lanes)
