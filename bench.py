@@ -80,6 +80,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-tasks", type=int, default=0, help="0 = the whole allocate action (a few seconds on 16 threads)")
     ap.add_argument("--verify", action="store_true", help="with --no-cpu-baseline: still compare the bind set with the oracle after the timed region")
+    ap.add_argument("--spin-wait", action="store_true", help="KB_FLAG_SPIN_WAIT: the calling thread spins for the whole wait for a round (round 5's default) instead of "
+                    "giving the core up between polls after a short spin (N = 1 only)")
     ap.add_argument("--preempt", action="store_true", help="BASELINE configs[4] names allocate + backfill + preempt: a step becomes reset -> allocate -> backfill -> "
                     "preempt under the default tiers plus conformance (scripts/time_preempt.py's configuration); with --gpus N every replica runs the evict action and the journals are compared (kube-batch_amd/dist.py)")
     args = ap.parse_args()
@@ -130,31 +132,86 @@ def main():
 
     dist_mode = None
     rank_digest_expected = None
+    sessions_block = None       # N > 1, both answers in one invocation: the sessions mode's figures beside the task-row split's
     if world > 1 or force_sharded:
-        # N > 1.  north_star's task-row split is NOT the default: the cycle does not shard profitably (its shardable
-        # part, ~19 us of matrix + candidate lists per round, is shorter than one collective over xGMI; the commit is a sequential
-        # dependency).  Default "sessions": rank k schedules its OWN snapshot (the generator's seed + k; rank 0's is the N = 1 workload)
-        # through the single-GPU fast path, no data-path collective; every rank's decisions are held to a committed golden digest
-        # (tests/golden/bench_rank_digests.json, from the oracle).  `value` is the per-session rate of the SLOWEST rank — what one 100k x 10k
-        # snapshot is scheduled at — so that it stays comparable with the N = 1 line; the aggregate is printed beside it
-        # (`aggregate_evals_per_s`, `sessions_per_s`).  KB_DIST_MODE=sharded: north_star's task-row split (matrix rows sharded, lists
-        # all-gathered, commit replicated, deltas all-reduced, per round) — exact, "strong", and slower than one GPU.
-        # KB_DIST_MODE=replicas: round 3's mode, every rank the SAME session, digests compared across ranks.
+        # N > 1, ONE command, BOTH answers (round 6; KB_DIST_MODE unset or "both"):
+        #   sharded   north_star's task-row split of ONE session — every rank the same snapshot, the window's matrix rows sharded, candidate lists
+        #             all-gathered, the commit replicated, per-node deltas all-reduced over RCCL per round.  Exact, "strong", and — because the commit
+        #             (80 % of a round) is a sequential dependency every rank repeats — at best as fast as one GPU.  This is what north_star defines
+        #             the multi-GPU metric on: it is the line's `value`, `ms_per_step` and `scaling`.
+        #   sessions  rank k schedules its OWN snapshot (the generator's seed + k; rank 0's is the N = 1 workload) through the single-GPU fast path, no
+        #             data-path collective; every rank's decisions are held to a committed golden digest (tests/golden/bench_rank_digests.json, the
+        #             oracle's).  Reported beside it under `sessions`: the slowest rank's per-session rate and the aggregate over the ranks.
+        # KB_DIST_MODE=sessions / sharded: that mode alone (round 5's lines); KB_DIST_MODE=replicas: round 3's mode, every rank the SAME session
+        # through the fast path, digests compared across ranks.
         distmod = importlib.import_module("kube-batch_amd.dist")
-        mode_env = os.environ.get("KB_DIST_MODE", "sessions")
-        dist_mode = "sharded" if (force_sharded or mode_env == "sharded") else ("replicas" if mode_env == "replicas" else "sessions")
+        mode_env = os.environ.get("KB_DIST_MODE", "both")
+        dist_mode = "sharded" if (force_sharded or mode_env in ("sharded", "both")) else ("replicas" if mode_env == "replicas" else "sessions")
+        golden_key = f"config{args.config}_scale{args.scale:g}{'_survey' if args.survey_nodes else ''}{'_diverse' if args.diverse else ''}{'_preempt' if args.preempt else ''}"
+        try:
+            # the committed digests are the oracle's for the stock configuration of each config index under allocate + backfill: anything else
+            # (another action list) has no entry and reports `verified` = null
+            golden_ranks = json.load(open(os.path.join(ROOT, "tests", "golden", "bench_rank_digests.json"))).get(golden_key, {})
+        except OSError:
+            golden_ranks = {}
+
+        def sessions_phase(snap_mine):
+            """W warm-up + K timed cycles of this rank's OWN session (barrier + synchronize on both sides, MAX over the ranks), one more cycle held to
+            the golden digest -> (the `sessions` object, the runner)"""
+            r_ = distmod.ReplicatedCycle(conf, snap_mine, device=local_rank, window=args.window, commit_batch=args.commit_batch, actions=actions)
+            for _ in range(args.warmup):
+                r_.step(verify=False)
+            st0 = r_.engine.stats()
+            torch.cuda.synchronize()
+            if world > 1:
+                dist.barrier()
+            torch.cuda.synchronize()
+            q0 = time.perf_counter()
+            for _ in range(args.steps):
+                r_.step(verify=False)
+            torch.cuda.synchronize()
+            if world > 1:
+                dist.barrier()
+            torch.cuda.synchronize()
+            el_local = time.perf_counter() - q0
+            st1 = r_.engine.stats()
+            ev = st1["evals"] - st0["evals"]
+            dec_last = r_.step(verify=False)                 # outside the timed region: its digest against the committed one of THIS rank's snapshot
+            nb = int((r_.engine.binds() != kbm.abi.KB_NONE).sum())
+            mine = distmod.ReplicatedCycle.digest(dec_last, r_.engine.binds(), r_.engine.journal() if args.preempt else None, r_.engine.evictions() if args.preempt else None)
+            want = golden_ranks.get(str(rank))
+            ok_here = 1 if (want is not None and int(want) == mine) else (0 if want is not None else -1)
+            if ok_here == 0:
+                print(f"bench.py: rank {rank}: decisions digest {mine} differs from the golden digest {want}", file=sys.stderr)
+            dev = "cuda" if (world > 1 and dist.get_backend() == "nccl") else "cpu"
+            stat = torch.tensor([ev / el_local, -float(ok_here), float(ev), float(nb), -el_local], dtype=torch.float64, device=dev)
+            if world > 1:
+                mn = stat.clone(); dist.all_reduce(mn, op=dist.ReduceOp.MIN)
+                sm = stat.clone(); dist.all_reduce(sm, op=dist.ReduceOp.SUM)
+                mx = stat.clone(); dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+            else:
+                mn = sm = mx = stat
+            el = -float(mn[4].item())                        # MAX over the ranks of the timed region
+            worst = -int(mx[1].item())                       # MIN over the ranks of ok_here
+            verified = None if worst < 0 else bool(worst == 1)
+            blk = {"mode": "one independent session per GPU (rank k: seed + k), no data-path collective", "ms_per_step": el * 1e3 / args.steps,
+                   "value": None if verified is False else float(mn[0].item()), "value_is": "the slowest rank's per-session evals/s (comparable with the N = 1 line)",
+                   "aggregate_evals_per_s": float(sm[2].item()) / el, "sessions_per_s": world * args.steps / el,
+                   "aggregate_binds_per_s": float(sm[3].item()) * args.steps / el, "scaling": "weak", "verified": verified,
+                   "verified_with": "tests/golden/bench_rank_digests.json (the oracle's digest of every rank's own snapshot)"}
+            return blk, r_
+
+        if mode_env == "both" and not force_sharded:
+            import dataclasses
+            mine_params = dataclasses.replace(params, seed=params.seed + RANK_SEED_STRIDE * rank)
+            sessions_block, sess_runner = sessions_phase(kbm.snapshot.synth(mine_params) if rank > 0 else snap)
+            sess_runner.engine.close()
+            del sess_runner
         if dist_mode == "sessions" and rank > 0:
             params.seed = params.seed + RANK_SEED_STRIDE * rank
             snap = kbm.snapshot.synth(params)
         if dist_mode == "sessions":
-            try:
-                golden = json.load(open(os.path.join(ROOT, "tests", "golden", "bench_rank_digests.json")))
-                # the committed digests are the oracle's for the stock configuration of each config index under allocate + backfill: anything else
-                # (another action list) has no entry and reports sessions_verified_against_golden_digests = null
-                key = f"config{args.config}_scale{args.scale:g}{'_survey' if args.survey_nodes else ''}{'_diverse' if args.diverse else ''}{'_preempt' if args.preempt else ''}"
-                rank_digest_expected = golden.get(key, {}).get(str(rank))
-            except OSError:
-                rank_digest_expected = None
+            rank_digest_expected = golden_ranks.get(str(rank))
         if dist_mode == "sharded":
             runner = distmod.ShardedCycle(conf, snap, device=local_rank, window=args.window, commit_batch=args.commit_batch, actions=actions)
         else:
@@ -162,7 +219,7 @@ def main():
         step = (lambda: runner.step(verify=False)) if dist_mode != "sharded" else runner.step
         eng = runner.engine
     else:
-        eng = engine.Engine(conf, device=local_rank, window=args.window, commit_batch=args.commit_batch)
+        eng = engine.Engine(conf, device=local_rank, window=args.window, commit_batch=args.commit_batch, flags=kbm.abi.FLAG_SPIN_WAIT if args.spin_wait else 0)
         eng.load(snap)
         # what the Go shim pays every cycle (host pre-processing + H2D into a live engine, warm buffers): kb_session_load returns behind its
         # own synchronisation, so the call is the cost.  Seven loads: the median is reported, the maximum beside it.
@@ -212,6 +269,34 @@ def main():
     sessions_verified = None
     aggregate = None
     value = evals / elapsed                                   # one session's rate (N = 1, sharded: the job's)
+    sharded_block = None
+    if dist_mode == "sharded":
+        # outside the timed region: one more cycle; every rank decided the SAME session, whose decisions + bind set are held to the committed digest of
+        # rank 0's snapshot (the oracle's); the ranks' verdicts are reduced so that the line says what ALL of them found
+        coll = runner.collective_times()
+        dec_last = runner.step()
+        mine = distmod.ReplicatedCycle.digest(dec_last, eng.binds(), eng.journal() if args.preempt else None, eng.evictions() if args.preempt else None)
+        want = golden_ranks.get("0")
+        ok_here = 1 if (want is not None and int(want) == mine) else (0 if want is not None else -1)
+        if ok_here == 0:
+            print(f"bench.py: rank {rank}: the task-row split's decisions digest {mine} differs from the golden digest {want}", file=sys.stderr)
+        if world > 1:
+            tv = torch.tensor([float(ok_here)], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
+            dist.all_reduce(tv, op=dist.ReduceOp.MIN)
+            ok_here = int(tv.item())
+        sharded_verified = None if ok_here < 0 else bool(ok_here == 1)
+        rounds_t = max(1.0, d["rounds"])
+        sharded_block = {"mode": "north_star's task-row split of ONE session: matrix rows sharded, lists all-gathered, commit replicated, per-node deltas all-reduced per round",
+                         "ms_per_step": elapsed * 1e3 / args.steps, "value": None if sharded_verified is False else value, "scaling": "strong",
+                         "dist_backend": dist.get_backend(), "ranks_seen_by_rccl": dist.get_world_size() if dist.get_backend() == "nccl" else 0,
+                         "ranks": dist.get_world_size(), "rounds_per_step": d["rounds"] / args.steps, "spec_breaks_per_step": d["spec_breaks"] / args.steps,
+                         "rounds_that_exchanged_lists": coll["gathers"], "rounds_every_rank_evaluated_alone": runner.replicated_rounds,
+                         "allgather_us_per_round": None if not coll["gathers"] else round(coll["gather_s"] * 1e6 / coll["gathers"], 1),
+                         "allreduce_us_per_round": None if not coll["reduces"] else round(coll["reduce_s"] * 1e6 / coll["reduces"], 1),
+                         "collective_times_are": coll["clock"], "deferred_delta_checks": runner.deferred_checks,
+                         "verified": sharded_verified, "verified_with": "tests/golden/bench_rank_digests.json, rank 0's snapshot (the oracle's digest of decisions + bind set)"}
+        if sharded_verified is False:
+            value = None
     if dist_mode == "replicas" and world > 1:
         dec_last = runner.step(verify=False)                 # outside the timed region: one more cycle, its digest compared across ranks
         try:
@@ -255,7 +340,7 @@ def main():
     R, N, T = snap.n_res, snap.n_nodes, snap.n_tasks
     b_node, b_task = 16 * R + 44, 8 * R + 24
 
-    def roof(rows, ms, launches, label, kname="k_matrix"):
+    def roof(rows, ms, launches, label, kname="k_matrix", N=N, b_node=b_node, b_task=b_task):
         alg = rows * N * 2.125 + N * b_node + rows * b_task
         ach = alg / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
         return {"bound": "hbm", "kernel": kname, "launch": label, "achieved": round(ach, 2), "peak": HBM_PEAK_GBS,
@@ -372,12 +457,12 @@ def main():
     out = {
         "metric": f"pod-node scoring evals/sec + binds/sec, {_k(snap.n_tasks)} tasks x {_k(snap.n_nodes)} nodes snapshot",
         "value": value, "unit": "evals/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": elapsed * 1e3 / args.steps, "higher_is_better": True, "scaling": "strong" if dist_mode == "sharded" else "weak",   # --gpus N: one session per GPU (per-GPU work fixed); only KB_DIST_MODE=sharded splits one session
+        "ms_per_step": elapsed * 1e3 / args.steps, "higher_is_better": True, "scaling": "strong" if dist_mode == "sharded" else "weak",   # the task-row split divides ONE session (total work fixed); sessions mode: one session per GPU
         "vs_baseline": None, "dtype": "f64+i64", "data": "synthetic",
         "config": {"workload": f"BASELINE configs[{args.config - 1}]: {snap.n_tasks} tasks x {snap.n_nodes} nodes, "
                                f"{snap.n_jobs} gang jobs, {snap.n_queues} queues, R={R}, {'+'.join(actions)}, "
                                f"plugins priority,gang,drf,predicates,proportion,nodeorder ({weights})",
-                   "window": args.window or 256, "scale": args.scale, "diverse_requests": bool(args.diverse),
+                   "window": args.window or 256, "scale": args.scale, "diverse_requests": bool(args.diverse), "host_wait": "spin" if args.spin_wait else "short spin, then sched_yield between polls",
                    "node_sizes": "SURVEY 8d list (no capacity pressure)" if args.survey_nodes else "sized for demand ~1.3x capacity"},
         "binds_per_s": n_binds * args.steps / elapsed, "binds": n_binds, "decisions": int(d["decisions"] / args.steps),
         "evals_per_step": int(evals / args.steps),
@@ -402,7 +487,9 @@ def main():
         # not part of `value`: kb_session_load of the same snapshot (validation, shape interning, proportion water-fill, H2D)
         "multi_gpu_mode": None if dist_mode is None else {"sessions": "one independent session per GPU (rank k: seed + k), no data-path collective; value = the slowest rank's per-session rate",
                                                           "replicas": "the same session on every GPU (KB_DIST_MODE=replicas), digests compared; value = one session's rate",
-                                                          "sharded": "task-row sharded rounds (KB_DIST_MODE=sharded)"}[dist_mode],
+                                                          "sharded": "north_star's task-row split of ONE session (value, ms_per_step, scaling are its figures)"
+                                                                     + ("; the sessions mode of the same invocation under `sessions`" if sessions_block else "")}[dist_mode],
+        "sharded": sharded_block, "sessions": sessions_block,
         "dist_backend": None if dist_mode is None else dist.get_backend(),   # "nccl" = RCCL: what carried the N ranks (scripts/scale_curve.sh asserts it)
         "replicas_agree": replicas_agree, "sessions_verified_against_golden_digests": sessions_verified,
         **(aggregate or {}),
@@ -460,8 +547,19 @@ def main():
         # the unfriendly inputs, in the driver's own record: SURVEY 8d's literal node sizes (no capacity pressure: dirty nodes win most rows)
         # and BASELINE configs[3] (R = 16, bin-packing weights), each timed over 3 cycles and verified against the oracle's incremental mode
         import oracle
+
+        def variant_roofline(ve, vsnap, direct=False):
+            """the variant's OWN materialised T x N matrix through kb_bench_matrix (the launch `roofline` above times for the headline workload): every
+            configuration's roofline fraction in the driver's record — R = 16's sits below R = 2's, and was invisible in round 5's line"""
+            vR, vN, vT = vsnap.n_res, vsnap.n_nodes, vsnap.n_tasks
+            vms = ve.bench_matrix(0, vT, reps=3)
+            kn = "k_matrix_runs" if direct else "k_matrix+k_expand"
+            rf = roof(vT, vms, 3, f"kb_bench_matrix rows [0,{vT}) x {vN} nodes, R={vR}", kn, N=vN, b_node=16 * vR + 44, b_task=8 * vR + 24)
+            return {k: rf[k] for k in ("kernel", "achieved", "peak", "unit", "frac", "bytes_per_launch", "avg_launch_ms")}
+
         variants = {}
-        for name, idx, vconf, tweak in (("survey_nodes", 3, kbm.conf.load_scheduler_conf(), True), ("config4_binpack", 4, kbm.conf.load_scheduler_conf(BINPACK_CONF), False)):
+        for name, idx, vconf, tweak in (("survey_nodes", 3, kbm.conf.load_scheduler_conf(), True), ("config4_binpack", 4, kbm.conf.load_scheduler_conf(BINPACK_CONF), False),
+                                        ("config2", 2, kbm.conf.load_scheduler_conf(), False)):
             vp = kbm.snapshot.synth_config(idx, args.scale)
             if tweak:
                 vp.node_cpu_cores = (16, 32, 64, 96, 128)
@@ -482,6 +580,7 @@ def main():
             vo.run(["allocate", "backfill"])
             variants[name] = {"ms_per_step": round(vms, 2), "binds": int((ve.binds() != kbm.abi.KB_NONE).sum()),
                               "verified": bool(np.array_equal(vdec, vo.decisions()) and np.array_equal(ve.binds(), vo.binds())),
+                              "evals_per_s": round(vo.evals / (vms * 1e-3), 1), "roofline": variant_roofline(ve, vsnap),
                               "workload": f"{vsnap.n_tasks} tasks x {vsnap.n_nodes} nodes, R={vsnap.n_res}"}
             ve.close()
             vo.close()
@@ -490,7 +589,9 @@ def main():
         sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
         import make_fullsize_golden as mfg
         golden = json.load(open(os.path.join(ROOT, "tests", "golden", "fullsize_digests.json")))
-        for name, case in (("config5", "config5_full"), ("config5_preempt", "config5_full_preempt")) if args.scale == 1.0 else ():   # the digests are the full size's
+        # ... and configs[2] with every job drawing its OWN request (--diverse: ~9 600 distinct task shapes, the input that leans least on shape redundancy),
+        # held to its committed digest likewise (the oracle's incremental mode needs minutes for it: make_fullsize_golden.py)
+        for name, case in (("diverse", "config3_diverse_full"), ("config5", "config5_full"), ("config5_preempt", "config5_full_preempt")) if args.scale == 1.0 else ():   # the digests are the full size's
             vconf, vsnap = mfg.case_inputs(kbm, case)
             vact = mfg.case_actions(case)
             ve = engine.Engine(vconf, device=local_rank)
@@ -514,7 +615,10 @@ def main():
             variants[name] = {"ms_per_step": round(vms, 2), "binds": int((ve.binds() != kbm.abi.KB_NONE).sum()),
                               "verified": bool(digest == golden[case]["sha256"]), "verified_with": "tests/golden/fullsize_digests.json (the oracle's digest of decisions, binds"
                               + (", Statement journal, evictions)" if evict else ")"), "session_load_ms": round(sorted(vloads)[1], 2),
-                              "workload": f"{vsnap.n_tasks} tasks x {vsnap.n_nodes} nodes, R={vsnap.n_res}, {'+'.join(vact)}"}
+                              "evals_per_s": None if evict else round(golden[case]["evals"] / (vms * 1e-3), 1),
+                              # (1M x 50k: its materialised matrix is 109 GB — not allocated for a side figure; the 100k x 10k variants carry theirs)
+                              "roofline": variant_roofline(ve, vsnap, direct=True) if name == "diverse" else None,
+                              "workload": f"{vsnap.n_tasks} tasks x {vsnap.n_nodes} nodes, R={vsnap.n_res}, {'+'.join(vact)}" + (", one request per job" if name == "diverse" else "")}
             ve.close()
         out["variants"] = variants
     if rank == 0 and args.verify and "verified_bind_set_equals_oracle" not in out:
@@ -535,7 +639,7 @@ def main():
         print(json.dumps(out))
     if world > 1 or force_sharded:
         dist.destroy_process_group()
-    if sessions_verified is False or replicas_agree is False:
+    if sessions_verified is False or replicas_agree is False or (sharded_block and sharded_block["verified"] is False) or (sessions_block and sessions_block["verified"] is False):
         sys.exit(1)
 
 

@@ -125,11 +125,14 @@ typedef struct kb_plugin_option {
 
 #define KB_FLAG_SYNC_ROUNDS 1u  /* disable host/device overlap (debug) */
 /* While a round runs the calling thread POLLS the round's sequence word in pinned memory (no stream synchronisation per round: ~20 us of a
- * ~115 us round).  By default it spins (`pause`): one core is busy for the length of the action — 40 ms of a one-second scheduling period at
- * 100k x 10k — which is the right trade inside cmd/kube-batch, whose runOnce is single-threaded (pkg/scheduler/scheduler.go:85-101).  With
- * KB_FLAG_YIELD_WAIT the thread gives the core up between two polls (sched_yield): other runnable threads of the process get it, a round's
- * answer is noticed a few microseconds later. */
+ * ~110 us round).  Default since round 6: a short spin (`pause`, KB_WAIT_SPIN_US microseconds — most answers arrive inside it, the host reaches
+ * the wait with the round half over), then the thread gives the core up between two polls (sched_yield): inside cmd/kube-batch the informer
+ * goroutines' threads (pkg/scheduler/cache) get the core while a round runs, the answer is noticed a few microseconds late at worst.
+ * KB_FLAG_SPIN_WAIT: spin for the whole wait (round 5's default; one core busy for the length of the action).  KB_FLAG_YIELD_WAIT (round 5's
+ * opt-in) is accepted and means the default. */
 #define KB_FLAG_YIELD_WAIT 2u
+#define KB_FLAG_SPIN_WAIT 4u
+#define KB_WAIT_SPIN_US 20.0
 
 typedef struct kb_config {
   uint32_t version;                /* KB_ABI_VERSION */
@@ -314,8 +317,8 @@ typedef struct kb_stats {
   double   total_ms;          /* wall time of the run_* calls */
   uint64_t rounds_select;     /* of `rounds`: committed by the selection kernel (k_commit_select); the others by the batch or the run kernel */
   uint64_t select_runs_clean;   /* selection kernel, runs of >= 2 plain rows: every pick a clean candidate's first placement */
-  uint64_t select_runs_general; /* ... committed by the general selection (entries ranked, contenders walked on) */
-  uint64_t select_runs_serial;  /* ... handed to the serial loop (a table limit, non-integer scalar dimensions) */
+  uint64_t select_runs_shots;   /* ... committed by shots: bounded tables of the contenders' next keys, one rank, the final picks (kb_commit_sel.hip) */
+  uint64_t select_shots;        /* ... the shots those runs took (a table that ends while its sequence may go on costs another one) */
 } kb_stats;
 
 typedef struct kb_engine kb_engine;

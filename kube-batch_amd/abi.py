@@ -39,7 +39,8 @@ EN_NODE_ORDER = 1 << 8
 EN_ALL = 0x1FF
 
 FLAG_SYNC_ROUNDS = 1
-FLAG_YIELD_WAIT = 2     # the host gives its core up between two polls of a round's sequence word (include/kb_engine.h)
+FLAG_YIELD_WAIT = 2     # round 5's opt-in, the default since round 6: a short spin, then the host gives its core up between two polls (include/kb_engine.h)
+FLAG_SPIN_WAIT = 4      # spin for the whole wait (round 5's default)
 
 # kb_stmt_op.op: the preempt action's journal (framework/statement.go)
 OP_EVICT, OP_PIPELINE, OP_COMMIT, OP_DISCARD = range(4)
@@ -109,7 +110,7 @@ class Stats(C.Structure):
                 ("matrix_launches", C.c_uint64), ("matrix_evals", C.c_uint64),
                 ("matrix_ms", C.c_double), ("argmax_ms", C.c_double), ("commit_ms", C.c_double),
                 ("reduce_ms", C.c_double), ("host_order_ms", C.c_double), ("total_ms", C.c_double),
-                ("rounds_select", C.c_uint64), ("select_runs_clean", C.c_uint64), ("select_runs_general", C.c_uint64), ("select_runs_serial", C.c_uint64)]
+                ("rounds_select", C.c_uint64), ("select_runs_clean", C.c_uint64), ("select_runs_shots", C.c_uint64), ("select_shots", C.c_uint64)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}

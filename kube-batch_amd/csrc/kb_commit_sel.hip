@@ -299,20 +299,24 @@ __global__ void __launch_bounds__(K9_THREADS) k_commit_select(const K9KernArgs k
           const uint32_t rem = r - j;
           const uint32_t fidx = pc + rem - 1u;
           uint32_t thr = max(fidx < ncand ? rl32(ck, fidx) : 0u, 1u);   // the floor: the rem-th clean candidate in front (clean keys fall along the list); 1: fewer are left, everybody feasible contends
-          // -- contenders: the pool's entries at or above the floor, numbered clean candidates first (list order), then this run's consumed ones, then the dirty slots
-          bool isc, isk, is0, is1, is2, is3;
-          unsigned long long bc, bk, b0, b1, b2, b3;
-          uint32_t nc_, nk_, n0_, n1_, n2_, n3_, nC;
+          // -- contenders: the pool's entries at or above the floor.  Lane i holds candidate i of this run (consumed: its key after the placements it took, slot
+          //    nd + i; still clean: its list key, same slot, one placement ahead) and the dirty slots i, i + 64, i + 128, i + 192 (registers beyond nd: zeros)
+          const uint32_t kc = lane_i < pc ? k1 : (lane_i < ncand ? ck : 0u);
+          bool isc, is0, is1, is2, is3;
+          unsigned long long bc, b0, b1, b2, b3;
+          uint32_t nc_, n0_, n1_, n2_, n3_, nC;
           for (uint32_t again = 0;; again++) {
-            isc = lane_i >= pc && lane_i < ncand && ck >= thr; isk = lane_i < pc && k1 >= thr;
-            is0 = d0 >= thr; is1 = d1 >= thr; is2 = d2 >= thr; is3 = d3 >= thr;
-            bc = __ballot(isc); bk = __ballot(isk); b0 = __ballot(is0); b1 = __ballot(is1); b2 = __ballot(is2); b3 = __ballot(is3);
-            nc_ = (uint32_t)__popcll(bc); nk_ = (uint32_t)__popcll(bk); n0_ = (uint32_t)__popcll(b0); n1_ = (uint32_t)__popcll(b1); n2_ = (uint32_t)__popcll(b2); n3_ = (uint32_t)__popcll(b3);
-            nC = nc_ + nk_ + n0_ + n1_ + n2_ + n3_;
+            isc = kc >= thr; is0 = d0 >= thr; is1 = d1 >= thr; is2 = d2 >= thr; is3 = d3 >= thr;
+            bc = __ballot(isc); b0 = __ballot(is0);
+            nc_ = (uint32_t)__popcll(bc); n0_ = (uint32_t)__popcll(b0);
+            b1 = 0ull; b2 = 0ull; b3 = 0ull; n1_ = 0u; n2_ = 0u; n3_ = 0u;
+            if (nd > 64u) { b1 = __ballot(is1); n1_ = (uint32_t)__popcll(b1); }
+            if (nd > 128u) { b2 = __ballot(is2); b3 = __ballot(is3); n2_ = (uint32_t)__popcll(b2); n3_ = (uint32_t)__popcll(b3); }
+            nC = nc_ + n0_ + n1_ + n2_ + n3_;
             if (nC <= 32u || again) break;
             // more contenders than the lanes hold two entries of (the clean list has run short: every feasible dirty slot contends): a higher floor —
-            // the fifth best of the lanes' own maxima, i.e. the entries of five lanes at most (30); whoever stays outside has a key below it
-            uint32_t lm = max(max(max(is0 ? d0 : 0u, is1 ? d1 : 0u), max(is2 ? d2 : 0u, is3 ? d3 : 0u)), max(isk ? k1 : 0u, isc ? ck : 0u));
+            // the fifth best of the lanes' own maxima, i.e. the entries of five lanes at most (25); whoever stays outside has a key below it
+            uint32_t lm = max(max(max(d0, d1), max(d2, d3)), kc);
             for (uint32_t t = 0; t < 5u; t++) {
               const uint32_t mx = wave_max_u32(lm);
               if (mx == 0u) break;
@@ -321,29 +325,56 @@ __global__ void __launch_bounds__(K9_THREADS) k_commit_select(const K9KernArgs k
             }
           }
           if (nC == 0u) { reason = KB_REASON_NO_FEASIBLE; break; }   // allocate.go:144-148
-          const uint32_t lgD = nC <= 2u ? 5u : (nC <= 4u ? 4u : (nC <= 8u ? 3u : (nC <= 16u ? 2u : 1u))), D = 1u << lgD;
+          // -- the rem best of them, best first: the distinct winners of rem rows are the rem best by current key, and every contender less is a deeper
+          //    table for the others.  Records and keys go to LDS in pool order, contender lane p ranks its key among the nC (they are distinct: they carry
+          //    the node), rank = its number; the ones behind the rem-th are dropped and the floor moves up to the rem-th key
           {
-            uint32_t base = 0u;
-            if (isc) { const uint32_t p_ = base + (uint32_t)__popcll(bc & lt); X.c_slot[p_] = (nd + lane_i) | 0x80000000u; }   // bit 31: the slot is one placement ahead (a clean candidate)
-            base += nc_;
-            if (isk) { const uint32_t p_ = base + (uint32_t)__popcll(bk & lt); X.c_slot[p_] = nd + lane_i; }
-            base += nk_;
-            if (is0) { const uint32_t p_ = base + (uint32_t)__popcll(b0 & lt); X.c_slot[p_] = lane_i; }
-            base += n0_;
-            if (is1) { const uint32_t p_ = base + (uint32_t)__popcll(b1 & lt); X.c_slot[p_] = lane_i + 64u; }
-            base += n1_;
-            if (is2) { const uint32_t p_ = base + (uint32_t)__popcll(b2 & lt); X.c_slot[p_] = lane_i + 128u; }
-            base += n2_;
-            if (is3) { const uint32_t p_ = base + (uint32_t)__popcll(b3 & lt); X.c_slot[p_] = lane_i + 192u; }
+            const uint32_t p_c = (uint32_t)__popcll(bc & lt), p_0 = nc_ + (uint32_t)__popcll(b0 & lt);
+            if (isc) { X.c_slot[p_c] = (nd + lane_i) | (lane_i >= pc ? 0x80000000u : 0u); X.c_key[p_c] = kc; }   // bit 31: the slot is one placement ahead (a clean candidate)
+            if (is0) { X.c_slot[p_0] = lane_i; X.c_key[p_0] = d0; }
+            if (nd > 64u && is1) { const uint32_t p_1 = nc_ + n0_ + (uint32_t)__popcll(b1 & lt); X.c_slot[p_1] = lane_i + 64u; X.c_key[p_1] = d1; }
+            if (nd > 128u) {
+              if (is2) { const uint32_t p_2 = nc_ + n0_ + n1_ + (uint32_t)__popcll(b2 & lt); X.c_slot[p_2] = lane_i + 128u; X.c_key[p_2] = d2; }
+              if (is3) { const uint32_t p_3 = nc_ + n0_ + n1_ + n2_ + (uint32_t)__popcll(b3 & lt); X.c_slot[p_3] = lane_i + 192u; X.c_key[p_3] = d3; }
+            }
+            if (lane_i >= nC && lane_i < nC + 8u) X.c_key[lane_i] = 0u;   // (nC <= 32; the rank reads eight keys at a time)
+            K9_WAVE_FENCE();
+            const uint32_t myk = lane_i < nC ? X.c_key[lane_i] : 0u;
+            uint32_t rk = 0u;
+            const uint4 *kv = reinterpret_cast<const uint4 *>(X.c_key);
+            for (uint32_t i = 0; i < nC; i += 8u) {
+              const uint4 q0_ = kv[i >> 2], q1_ = kv[(i >> 2) + 1u];
+              rk += (q0_.x > myk ? 1u : 0u) + (q0_.y > myk ? 1u : 0u) + (q0_.z > myk ? 1u : 0u) + (q0_.w > myk ? 1u : 0u);
+              rk += (q1_.x > myk ? 1u : 0u) + (q1_.y > myk ? 1u : 0u) + (q1_.z > myk ? 1u : 0u) + (q1_.w > myk ? 1u : 0u);
+            }
+            if (lane_i < nC && rk < rem) X.c_sorted[rk] = X.c_slot[lane_i];
+            if (nC > rem) {
+              thr = rl32(myk, (uint32_t)__ffsll((unsigned long long)__ballot(lane_i < nC && rk == rem - 1u)) - 1u);
+              nC = rem;
+            }
+            K9_WAVE_FENCE();
           }
-          K9_WAVE_FENCE();
+          // -- the lanes' layout.  Uniform: contender g's D entries in lanes g * D ...  With a DEEP table: the best contender (number 0) in lanes 0 .. 15 (sixteen
+          //    entries: under MostRequested the node just used wins until it is full, most_requested.go:34-61), the others share lanes 16 .. 63 — wherever
+          //    that costs them nothing (their D is what the uniform layout gives them) or the session packs (a.wM > a.wL)
+          uint32_t lgD = nC <= 2u ? 5u : (nC <= 4u ? 4u : (nC <= 8u ? 3u : (nC <= 16u ? 2u : 1u)));
+          bool deep = false;
+          if (nC >= 5u && nC <= 25u) {
+            const uint32_t o_ = nC - 1u, lgO = o_ <= 6u ? 3u : (o_ <= 12u ? 2u : 1u);   // 48 lanes for the others
+            if (lgO == lgD || a.wM > a.wL) { deep = true; lgD = lgO; }
+          }
+          const uint32_t D = 1u << lgD;
           K9_STAMP(5);
-          // -- the table: lane g * D + u
-          const uint32_t tg = lane_i >> lgD, tu = lane_i & (D - 1u);
+          // -- the table: contender tg's entry tu (its key after tu further placements); gst: the first lane of my contender, Dg: its entries
+          uint32_t tg, tu, gst, Dg;
+          if (deep && lane_i < 16u) { tg = 0u; tu = lane_i; gst = 0u; Dg = 16u; }
+          else if (deep) { const uint32_t l_ = lane_i - 16u; tg = 1u + (l_ >> lgD); tu = l_ & (D - 1u); gst = lane_i - tu; Dg = D; }
+          else { tg = lane_i >> lgD; tu = lane_i & (D - 1u); gst = lane_i - tu; Dg = D; }
           const bool act = tg < nC;
+          const uint32_t n_e = deep ? 16u + ((nC - 1u) << lgD) : (nC << lgD);   // lanes in use
           uint32_t key = 0u, kind = 0u, tnode = 0u;
           if (act) {
-            const uint32_t cs = X.c_slot[tg], slot = cs & 0x7FFFFFFFu, b = cs >> 31;
+            const uint32_t cs = X.c_sorted[tg], slot = cs & 0x7FFFFFFFu, b = cs >> 31;
             const unsigned long long *st = slots + (size_t)slot * K9_NF;
             K9St v = k9_load(st);
             tnode = v.node;
@@ -365,15 +396,15 @@ __global__ void __launch_bounds__(K9_THREADS) k_commit_select(const K9KernArgs k
           }
           // an entry exists iff its key is not 0 and every entry of its contender in front of it exists and is an Allocate
           const unsigned long long ends = __ballot(act && (key == 0u || kind != 0u));
-          const unsigned long long front = lt & ~((1ull << ((tg << lgD) & 63u)) - 1ull);   // my contender's lanes in front of me
+          const unsigned long long front = lt & ~((1ull << gst) - 1ull);   // my contender's lanes in front of me
           const bool valid = act && key != 0u && (ends & front) == 0ull;
           X.e_key[lane_i] = key;
-          // prefix minimum per contender (its lanes are neighbours; D <= 16: inside one DPP row)
+          // prefix minimum per contender (its lanes are neighbours; up to 16 entries: inside one DPP row)
           uint32_t eff = valid ? key : 0xFFFFFFFFu;
 #define K9S_SHR(sft) do { const uint32_t t_ = (uint32_t)__builtin_amdgcn_update_dpp((int)0xFFFFFFFFu, (int)eff, 0x110 + (sft), 0xf, 0xf, false); if (tu >= (sft)) eff = min(eff, t_); } while (0)
           K9S_SHR(1); K9S_SHR(2); K9S_SHR(4); K9S_SHR(8);
 #undef K9S_SHR
-          if (lgD == 5u) { const uint32_t t_ = (uint32_t)__shfl((int)eff, (int)((lane_i & 0x30u) | 15u) - 16); if (tu >= 16u) eff = min(eff, t_); }   // the contender's first row
+          if (Dg == 32u) { const uint32_t t_ = (uint32_t)__shfl((int)eff, (int)((lane_i & 0x30u) | 15u) - 16); if (tu >= 16u) eff = min(eff, t_); }   // the contender's first row
           if (!valid) eff = 0u;
           X.e_eff[lane_i] = eff;
           K9_WAVE_FENCE();
@@ -381,11 +412,13 @@ __global__ void __launch_bounds__(K9_THREADS) k_commit_select(const K9KernArgs k
           // -- the rank: entries with a greater eff, and the same contender's earlier entries with the same eff (they are neighbours)
           uint32_t rank = 0u;
           {
-            const uint32_t n_e = nC << lgD;
-            const uint4 *ev = reinterpret_cast<const uint4 *>(X.e_eff);
-            for (uint32_t i = 0; i < n_e; i += 4u) {
-              const uint4 q_ = ev[i >> 2];
-              rank += (q_.x > eff ? 1u : 0u) + (q_.y > eff ? 1u : 0u) + (q_.z > eff ? 1u : 0u) + (q_.w > eff ? 1u : 0u);
+            const uint4 *ev = reinterpret_cast<const uint4 *>(X.e_eff);   // (every lane stored its word: zeros behind the lanes in use)
+            for (uint32_t i = 0; i < n_e; i += 16u) {   // four reads in flight
+              const uint4 q0_ = ev[(i >> 2)], q1_ = ev[(i >> 2) + 1u], q2_ = ev[(i >> 2) + 2u], q3_ = ev[(i >> 2) + 3u];
+              rank += (q0_.x > eff ? 1u : 0u) + (q0_.y > eff ? 1u : 0u) + (q0_.z > eff ? 1u : 0u) + (q0_.w > eff ? 1u : 0u);
+              rank += (q1_.x > eff ? 1u : 0u) + (q1_.y > eff ? 1u : 0u) + (q1_.z > eff ? 1u : 0u) + (q1_.w > eff ? 1u : 0u);
+              rank += (q2_.x > eff ? 1u : 0u) + (q2_.y > eff ? 1u : 0u) + (q2_.z > eff ? 1u : 0u) + (q2_.w > eff ? 1u : 0u);
+              rank += (q3_.x > eff ? 1u : 0u) + (q3_.y > eff ? 1u : 0u) + (q3_.z > eff ? 1u : 0u) + (q3_.w > eff ? 1u : 0u);
             }
             const uint32_t prev = (uint32_t)__shfl_up((int)eff, 1);
             const unsigned long long starts = __ballot(!(tu > 0u && prev == eff));
@@ -397,21 +430,25 @@ __global__ void __launch_bounds__(K9_THREADS) k_commit_select(const K9KernArgs k
           uint32_t cutv = 0xFFFFu;
           if (valid) {
             if (eff < thr) cutv = rank;                          // somebody outside the table may come first
-            else if (tu == D - 1u && kind == 0u) cutv = rank;     // the table ends here, the sequence may not: the next shot
+            else if (tu == Dg - 1u && kind == 0u) cutv = rank;    // the table ends here, the sequence may not: the next shot
             else if (kind != 0u) cutv = rank + 1u;                // a Pipeline ends the round behind its row
           }
-          const uint32_t n_take = min(min(rem, nvalid), 0xFFFFu - wave_max_u32(0xFFFFu - cutv));
+          const uint32_t cut_at = 0xFFFFu - wave_max_u32(0xFFFFu - cutv);
+          const uint32_t n_take = min(min(rem, nvalid), cut_at);
+          if (cut_at < min(rem, nvalid) && __ballot(valid && rank == cut_at && eff >= thr && kind == 0u) != 0ull && lane_i == 0) atomicAdd(&X.stat[2], 1u);   // (statistics: a shot cut short by a table's end)
           if (n_take == 0u) { reason = KB_REASON_INTERNAL; k9s_st(&Y.err, 1u); break; }   // (never: the best contender's first entry is final)
           const bool picked = valid && rank < n_take;
           if (picked) ldec[i0 + j + rank] = (unsigned long long)tnode | ((unsigned long long)kind << 32);
           const unsigned long long pb = __ballot(picked), ppipe = __ballot(picked && kind != 0u);
           const bool pipe = ppipe != 0ull;
-          const uint32_t gp = pipe ? (((uint32_t)__ffsll((unsigned long long)ppipe) - 1u) >> lgD) : 0xFFFFFFFFu;   // the contender whose last row is the Pipeline
+          uint32_t gp = 0xFFFFFFFFu;   // the contender whose last row is the Pipeline
+          if (pipe) { const uint32_t lp_ = (uint32_t)__ffsll((unsigned long long)ppipe) - 1u; gp = deep ? (lp_ < 16u ? 0u : 1u + ((lp_ - 16u) >> lgD)) : (lp_ >> lgD); }
           // -- NodeInfo.AddTask (api/node_info.go:172-212) on every contender that took rows: lane g = contender g
           uint32_t T = 0u, c_x = 0u, c_b = 0u;
+          const uint32_t cst = deep ? (lane_i == 0u ? 0u : 16u + ((lane_i - 1u) << lgD)) : (lane_i << lgD);   // lane g: the first lane of contender g's table
           if (lane_i < nC) {
-            T = (uint32_t)__popcll((pb >> (lane_i << lgD)) & ((1ull << D) - 1ull));
-            const uint32_t cs = X.c_slot[lane_i];
+            T = (uint32_t)__popcll((pb >> cst) & ((1ull << ((deep && lane_i == 0u) ? 16u : D)) - 1ull));
+            const uint32_t cs = X.c_sorted[lane_i];
             c_x = cs & 0x7FFFFFFFu; c_b = cs >> 31;
           }
           if (T) {
@@ -453,7 +490,7 @@ __global__ void __launch_bounds__(K9_THREADS) k_commit_select(const K9KernArgs k
               pooled = true;
               K9_WAVE_FENCE();
             }
-            if (T) X.pool[c_x < nd ? c_x : 256u + (c_x - nd)] = X.e_key[(lane_i << lgD) + T];
+            if (T) X.pool[c_x < nd ? c_x : 256u + (c_x - nd)] = X.e_key[cst + T];
             K9_WAVE_FENCE();
             d0 = X.pool[lane_i]; d1 = X.pool[lane_i + 64u]; d2 = X.pool[lane_i + 128u]; d3 = X.pool[lane_i + 192u]; k1 = X.pool[lane_i + 256u];
           }

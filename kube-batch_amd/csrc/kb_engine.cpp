@@ -214,7 +214,7 @@ struct kb_engine {
   int commit_kernel = KB_COMMIT_SELECT, commit_pin = -1;
   double dirty_share = 0.0;   // share of rows won by a node the round had already changed (exponential average; a statistic)
   uint64_t rounds_run = 0, rounds_sel = 0;
-  uint64_t sel_stat[4] = {0, 0, 0, 0};   // selection kernel: runs with every pick a clean first placement / through the general selection / handed to the serial loop; deep passes
+  uint64_t sel_stat[4] = {0, 0, 0, 0};   // selection kernel: runs with every pick a clean first placement / committed by shots; shots cut short by a table's end; shots
   uint32_t shape_cap = KB_K5_MAX_SHAPES;   // distinct shapes a window may hold (each keeps its candidate list in the commit kernel's LDS)
   std::vector<uint32_t> plan_stamp;   // per row-shape id: stamp of the window being planned
   uint32_t plan_epoch = 0;
@@ -236,8 +236,9 @@ struct kb_engine {
   Pinned<unsigned char> h_evict;          // an evict action's entry / exit staging: node state and task table through ONE pinned block, one synchronisation each way
   DevBuf b_scatter;                       // packed node records of upload_live_nodes
   Pinned<unsigned long long> h_scatter;
-  DevBuf b_sscore, b_smask, b_xslot, b_xorder;   // per-shape rows, row->shape map and rows in shape order of kb_eval_matrix / kb_bench_matrix
+  DevBuf b_sscore, b_smask, b_xslot, b_xorder, b_xchunks;   // per-shape rows, row->shape map, rows in shape order and its chunk table (kb_eval_matrix / kb_bench_matrix)
   std::vector<uint32_t> h_xorder;
+  std::vector<KbXChunk> h_xchunks;
   size_t xs_cap = 0, xslot_cap = 0;
   DevBuf b_mrows, b_same, b_score, b_maskw, b_keys;
   // Overlapped candidate lists: the matrix and arg-max launches of a chained round run on a second stream
@@ -664,10 +665,13 @@ void round_collect(kb_engine *e, const RoundCtx &c, bool had_candidates, uint32_
     volatile const unsigned long long *seqw = ho + KB_OUT_SEQ;
     const double t0 = now_ms();
     uint32_t spins = 0;
-    const bool yield_wait = (e->flags & KB_FLAG_YIELD_WAIT) != 0;   // include/kb_engine.h: spin (default) or give the core up between polls
+    const bool spin_only = (e->flags & KB_FLAG_SPIN_WAIT) != 0;   // include/kb_engine.h: a short spin, then the core is given up between polls (default); or spin throughout
+    bool yielding = false;
     while (__atomic_load_n(seqw, __ATOMIC_ACQUIRE) != c.seq) {
-      if (yield_wait) sched_yield(); else __builtin_ia32_pause();
-      if ((++spins & 0xFFFFu) == 0 && now_ms() - t0 > 10000.0) {   // a faulted kernel never publishes: surface the HIP error
+      if (yielding) sched_yield(); else __builtin_ia32_pause();
+      ++spins;
+      if (!spin_only && !yielding && (spins & 0x3Fu) == 0 && now_ms() - t0 > KB_WAIT_SPIN_US * 1e-3) yielding = true;
+      if ((spins & 0xFFFFu) == 0 && now_ms() - t0 > 10000.0) {   // a faulted kernel never publishes: surface the HIP error
         HIP_OK(hipStreamSynchronize(e->stream));
         HIP_OK(hipGetLastError());
         if (__atomic_load_n(seqw, __ATOMIC_ACQUIRE) != c.seq) throw EngineError(KB_E_DEVICE, "commit kernel finished without publishing its round");
@@ -719,7 +723,7 @@ void round_collect(kb_engine *e, const RoundCtx &c, bool had_candidates, uint32_
   if (e->commit_kernel_of[c.buf] == KB_COMMIT_SELECT) {
     e->sel_stat[0] += h_result[6] & 0xFFFFu; e->sel_stat[1] += h_result[6] >> 16; e->sel_stat[2] += h_result[7] & 0xFFFFu; e->sel_stat[3] += h_result[7] >> 16;
     e->stats.rounds_select += 1;
-    e->stats.select_runs_clean += h_result[6] & 0xFFFFu; e->stats.select_runs_general += h_result[6] >> 16; e->stats.select_runs_serial += h_result[7] & 0xFFFFu;
+    e->stats.select_runs_clean += h_result[6] & 0xFFFFu; e->stats.select_runs_shots += h_result[6] >> 16; e->stats.select_shots += h_result[7] >> 16;
   }
   {
     e->k5_slots += h_result[2];
@@ -1205,7 +1209,7 @@ void kb_engine_destroy(kb_engine *e) {
     fprintf(stderr, "[kb K5] rounds on the run kernel %llu, on the selection kernel %llu, last dirty share %.3f\n",
             (unsigned long long)e->rounds_run, (unsigned long long)e->rounds_sel, e->dirty_share);
   if (getenv("KB_K5_STATS") && e->rounds_sel)
-    fprintf(stderr, "[kb select] runs of >= 2 rows: all picks clean first placements %llu, general selection %llu, handed to the serial loop %llu; deep passes %llu\n",
+    fprintf(stderr, "[kb select] runs of >= 2 rows: all picks clean first placements %llu, committed by shots %llu (shots cut short by a table's end %llu; shots %llu)\n",
             (unsigned long long)e->sel_stat[0], (unsigned long long)e->sel_stat[1], (unsigned long long)e->sel_stat[2], (unsigned long long)e->sel_stat[3]);
   if (getenv("KB_K5_STATS"))
     fprintf(stderr, "[kb K5] rounds %llu, rows %llu, dirty slots %llu, dirty-won rows %llu, runs %llu, runs with a row-specific Resreq %llu (%llu)\n",
@@ -2059,6 +2063,7 @@ struct ChunkPlan {
   KbRound r{};        // describes the expanded rows (score / maskw / keys of n rows)
   KbRound rs{};       // the per-shape launch
   uint32_t ns = 0;
+  uint32_t n_xchunks = 0;   // chunks of the tiled expansion (kb_device.h: KbXChunk)
   bool direct = false;   // evaluate every task row itself (no per-shape rows, no expansion)
 };
 static ChunkPlan matrix_plan(kb_engine *e, uint32_t t0, uint32_t n, uint32_t fit_flags, uint32_t k) {
@@ -2104,6 +2109,13 @@ static ChunkPlan matrix_plan(kb_engine *e, uint32_t t0, uint32_t n, uint32_t fit
     for (uint32_t sidx = 0; sidx < p.ns; sidx++) start[sidx + 1] += start[sidx];
     for (uint32_t i = 0; i < n; i++) e->h_xorder[start[e->h_slot[i]]++] = i;
     HIP_OK(hipMemcpyAsync(e->b_xorder.p, e->h_xorder.data(), sizeof(uint32_t) * n, hipMemcpyHostToDevice, e->stream));
+    // ... and the chunk table of the tiled expansion: stretches of one shape, KB_XCHUNK_ROWS rows at most (start[s] is now the END of shape s's stretch)
+    e->h_xchunks.clear();
+    for (uint32_t sidx = 0, at = 0; sidx < p.ns; sidx++)
+      while (at < start[sidx]) { const uint32_t cnt = std::min<uint32_t>(KB_XCHUNK_ROWS, start[sidx] - at); e->h_xchunks.push_back(KbXChunk{sidx, at, cnt, 0u}); at += cnt; }
+    e->b_xchunks.alloc(sizeof(KbXChunk) * std::max<size_t>(e->h_xchunks.size(), 1));
+    HIP_OK(hipMemcpyAsync(e->b_xchunks.p, e->h_xchunks.data(), sizeof(KbXChunk) * e->h_xchunks.size(), hipMemcpyHostToDevice, e->stream));
+    p.n_xchunks = (uint32_t)e->h_xchunks.size();
     HIP_OK(hipStreamSynchronize(e->stream));   // h_xorder is pageable and reused by the next plan
   }
   HIP_OK(hipMemcpyAsync(e->b_mrows.p, e->h_mrows.data(), sizeof(uint32_t) * p.ns, hipMemcpyHostToDevice, e->stream));
@@ -2130,8 +2142,12 @@ static void matrix_launch(kb_engine *e, const ChunkPlan &p, uint32_t n, uint32_t
   kb_launch_interpod(e->dev, p.rs, e->stream);
   // shape order pays when the shape rows do not fit the L2s (C5: 23.0 -> 18.8 ms, BASELINE configs[3]: 0.66 -> 0.64 ms); while they do,
   // task order writes consecutive rows and is the faster one (C3, 509 shapes = 10 MB: 0.41 ms against 0.52; profiles/round3/call6)
+  // round 6: the TILED expansion (a workgroup loads its tile of the shape row once for 64 task rows) takes the rows in shape order always; KB_EXPAND_TILES=0:
+  // round 5's row-per-workgroup copy (the A/B switch of the traffic measurement)
+  static const bool tiles = [] { const char *v = getenv("KB_EXPAND_TILES"); return !(v && v[0] == '0'); }();
   const bool by_shape = (size_t)p.ns * e->dev.NP * 2 > (16u << 20);
-  kb_launch_expand(e->dev, p.rs.score, p.rs.maskw, e->b_xslot.as<uint32_t>(), by_shape ? e->b_xorder.as<uint32_t>() : nullptr, n, p.r.score, p.r.maskw, e->stream);
+  if (tiles) kb_launch_expand(e->dev, p.rs.score, p.rs.maskw, e->b_xslot.as<uint32_t>(), e->b_xorder.as<uint32_t>(), n, p.r.score, p.r.maskw, e->stream, e->b_xchunks.as<KbXChunk>(), p.n_xchunks);
+  else kb_launch_expand(e->dev, p.rs.score, p.rs.maskw, e->b_xslot.as<uint32_t>(), by_shape ? e->b_xorder.as<uint32_t>() : nullptr, n, p.r.score, p.r.maskw, e->stream);
   if (k) kb_launch_argmax(e->dev, p.r, e->stream);
 }
 static KbRound matrix_chunk(kb_engine *e, uint32_t t0, uint32_t n, uint32_t fit_mode, uint32_t k) {

@@ -60,7 +60,8 @@ struct K9Sel {
   uint32_t dkb[2][K9_MAXSLOTS];       // [k & 1][t]: key(shape of run k, dirty slot t)
   // a shot of the selection (wave 0's own scratch): the contenders' slots (bit 31: a clean candidate, its slot one placement ahead), the table's
   // keys and prefix minima (lane g * D + u), the pool's keys between two shots ([t]: dirty slot t, [256 + i]: this run's candidate i once consumed)
-  uint32_t c_slot[64];
+  uint32_t c_slot[64], c_sorted[64];   // ... in pool order; the rem best by key, best first (what the table and the AddTask step read)
+  alignas(16) uint32_t c_key[64];      // their keys (pool order)
   alignas(16) uint32_t e_eff[64];
   uint32_t e_key[64];
   uint32_t pool[K9_MAXSLOTS + 64];

@@ -775,9 +775,30 @@ void kb_launch_affinity(const KbDev &d, const KbRound &r, void *stream) {
   if (r.n_mrows == 0 || !d.aff || !d.score_enabled) return;
   hipLaunchKernelGGL(k_affinity, dim3(r.n_mrows), dim3(256), 0, (hipStream_t)stream, d, r);
 }
+// K1b, tiled: workgroup (tile, chunk) holds 4 KB of the chunk's shape row (2048 u16 scores: 16 bytes per thread) and 256 B of its mask in registers and
+// streams them to every task row of the chunk — the launch's HBM traffic is its stores (2.125 B per pair) plus one read of a shape tile per 64 rows
+__global__ void __launch_bounds__(256) k_expand_tiles(const uint16_t *__restrict__ s_score, const uint32_t *__restrict__ s_mask, const uint32_t *__restrict__ order,
+                                                      const KbXChunk *__restrict__ chunks, uint32_t NP, uint16_t *__restrict__ score, uint32_t *__restrict__ maskw) {
+  const KbXChunk c = chunks[blockIdx.y];
+  const size_t col = (size_t)blockIdx.x * 2048u, mcol = (size_t)blockIdx.x * 64u, mstride = NP / 32;
+  const uint4 v = reinterpret_cast<const uint4 *>(s_score + (size_t)c.slot * NP + col)[threadIdx.x];
+  const bool ml = threadIdx.x < 16u;
+  uint4 mv = make_uint4(0u, 0u, 0u, 0u);
+  if (ml) mv = reinterpret_cast<const uint4 *>(s_mask + (size_t)c.slot * mstride + mcol)[threadIdx.x];
+  for (uint32_t i = 0; i < c.count; i++) {
+    const uint32_t row = order[c.first + i];   // (uniform: a scalar load)
+    reinterpret_cast<uint4 *>(score + (size_t)row * NP + col)[threadIdx.x] = v;
+    if (ml) reinterpret_cast<uint4 *>(maskw + (size_t)row * mstride + mcol)[threadIdx.x] = mv;
+  }
+}
+
 void kb_launch_expand(const KbDev &d, const uint16_t *s_score, const uint32_t *s_mask, const uint32_t *row_slot, const uint32_t *order, uint32_t n_rows,
-                      uint16_t *score, uint32_t *maskw, void *stream) {
+                      uint16_t *score, uint32_t *maskw, void *stream, const KbXChunk *chunks, uint32_t n_chunks) {
   if (n_rows == 0) return;
+  if (chunks && order && n_chunks) {   // NP is a multiple of KB_NODE_PAD = 2048
+    hipLaunchKernelGGL(k_expand_tiles, dim3(d.NP / 2048u, n_chunks), dim3(256), 0, (hipStream_t)stream, s_score, s_mask, order, chunks, d.NP, score, maskw);
+    return;
+  }
   const uint32_t grid = order ? 8u * ((n_rows + 7u) / 8u) : n_rows;
   hipLaunchKernelGGL(k_expand, dim3(grid), dim3(256), 0, (hipStream_t)stream, s_score, s_mask, row_slot, order, n_rows, d.NP, score, maskw);
 }

@@ -117,6 +117,11 @@ class ShardedCycle:
         self.rounds = 0
         self.replicated_rounds = 0
         self.evict_actions = 0
+        # what the two collectives of a round cost (bench.py's `sharded` object): device time between two events on the stream the collective runs on
+        # when it is stream-ordered (RCCL), else the host's wall clock around the call and its completion (gloo: staging through host memory included)
+        self._gather_s = self._reduce_s = 0.0
+        self._gathers = self._reduces = 0
+        self._events = []          # (kind, start event, end event): summed by collective_times()
         # a single-rank group still goes through the collectives when asked to (exercises the RCCL path on a one-GPU box)
         import os as _os
         self.always_collect = dist.is_initialized() and _os.environ.get("KB_DIST_ALWAYS_COLLECT") == "1"
@@ -135,11 +140,54 @@ class ShardedCycle:
             torch.cuda.current_stream().synchronize()
 
     # ---- collectives
+    def collective_times(self) -> dict:
+        """seconds spent in the rounds' all-gathers / all-reduces since construction and how many there were (see __init__ for the clock)"""
+        if self._events:
+            torch.cuda.synchronize()
+            for kind, a, b in self._events:
+                dt = a.elapsed_time(b) * 1e-3
+                if kind == 0:
+                    self._gather_s += dt
+                else:
+                    self._reduce_s += dt
+            self._events = []
+        return {"gather_s": self._gather_s, "gathers": self._gathers, "reduce_s": self._reduce_s, "reduces": self._reduces,
+                "clock": "device time between events on the collective's stream (RCCL)" if self.stream_ordered else "host wall clock around the call and its completion (staged through host memory)"}
+
+    def _timed(self, kind: int, stream=None):
+        """context manager: one collective of kind 0 (all-gather) / 1 (all-reduce)"""
+        import contextlib
+        import time as _time
+
+        @contextlib.contextmanager
+        def cm():
+            if self.stream_ordered:
+                st = stream if stream is not None else self._stream
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record(st)
+                yield
+                b.record(st)
+                self._events.append((kind, a, b))
+            else:
+                t0 = _time.perf_counter()
+                yield
+                if kind == 0:
+                    self._gather_s += _time.perf_counter() - t0
+                else:
+                    self._reduce_s += _time.perf_counter() - t0
+        return cm()
+
     def _all_gather_keys(self, local: torch.Tensor, chunk: int, L: int) -> torch.Tensor:
-        full = torch.empty((chunk * self.world, L), dtype=torch.int64, device=local.device)
         if self.world == 1 and not self.always_collect:
+            full = torch.empty((chunk * self.world, L), dtype=torch.int64, device=local.device)
             full.copy_(local)
             return full
+        self._gathers += 1
+        with self._timed(0):
+            return self._all_gather_keys_impl(local, chunk, L)
+
+    def _all_gather_keys_impl(self, local: torch.Tensor, chunk: int, L: int) -> torch.Tensor:
+        full = torch.empty((chunk * self.world, L), dtype=torch.int64, device=local.device)
         if self.stage_host and local.device.type != "cpu":
             h_local = local.cpu()
             h_full = torch.empty((chunk * self.world, L), dtype=torch.int64)
@@ -154,6 +202,11 @@ class ShardedCycle:
     def _all_reduce_delta(self):
         if self.world == 1 and not self.always_collect:
             return
+        self._reduces += 1
+        with self._timed(1):
+            self._all_reduce_delta_impl()
+
+    def _all_reduce_delta_impl(self):
         if self.stage_host and self.delta.device.type != "cpu":
             h = self.delta.cpu()
             dist.all_reduce(h, op=dist.ReduceOp.SUM)
@@ -169,31 +222,41 @@ class ShardedCycle:
         on the process group's own thread."""
         if self.world == 1 and not self.always_collect:
             return lambda: None
+        self._reduces += 1
+        import time as _time
         if self._side is not None:
             self._side.wait_stream(self._stream)
             with torch.cuda.stream(self._side):
-                work = dist.all_reduce(buf, op=dist.ReduceOp.SUM, async_op=True)
+                with self._timed(1, self._side):
+                    work = dist.all_reduce(buf, op=dist.ReduceOp.SUM, async_op=True)
 
             def done():
                 work.wait()                              # orders the current (the engine's) stream behind the collective
                 self._stream.wait_stream(self._side)
             return done
+        t0 = _time.perf_counter()
         if self.stage_host and buf.device.type != "cpu":
             h = buf.cpu()
             work = dist.all_reduce(h, op=dist.ReduceOp.SUM, async_op=True)
+            self._reduce_s += _time.perf_counter() - t0
 
             def done():
+                t1 = _time.perf_counter()
                 work.wait()
                 buf.copy_(h)
                 if buf.device.type == "cuda":
                     torch.cuda.current_stream().synchronize()
+                self._reduce_s += _time.perf_counter() - t1
             return done
         work = dist.all_reduce(buf, op=dist.ReduceOp.SUM, async_op=True)
+        self._reduce_s += _time.perf_counter() - t0
 
         def done():
+            t1 = _time.perf_counter()
             work.wait()
             if buf.device.type == "cuda" and not self.stream_ordered:
                 torch.cuda.current_stream().synchronize()
+            self._reduce_s += _time.perf_counter() - t1
         return done
 
     # ---- one action

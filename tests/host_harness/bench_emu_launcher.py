@@ -20,6 +20,21 @@ torch.cuda.synchronize = lambda *a, **k: None
 engine = importlib.import_module("kube-batch_amd.engine")
 engine.LIB_PATH, engine._LIB = os.environ["KB_EMU_LIB"], None
 
+# the task-row split keeps its round buffers where the engine's "device" memory is: on the emulated device that is host memory
+distmod = importlib.import_module("kube-batch_amd.dist")
+_ShardedCycle = distmod.ShardedCycle
+
+
+class _EmulatedShardedCycle(_ShardedCycle):
+    def __init__(self, conf, snap, device=0, window=0, commit_batch=0, actions=("allocate", "backfill"), **kw):
+        eng = engine.Engine(conf, device=device, window=window, commit_batch=commit_batch)
+        eng.load(snap)
+        cpu = torch.device("cpu")
+        super().__init__(conf, snap, backend=distmod.EngineBackend(eng, cpu), buffer_device=cpu, actions=actions, **kw)
+
+
+distmod.ShardedCycle = _EmulatedShardedCycle
+
 import bench  # noqa: E402
 
 sys.argv = ["bench.py"] + sys.argv[1:]

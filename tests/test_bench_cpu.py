@@ -66,9 +66,10 @@ def test_default_run_carries_the_unfriendly_inputs(monkeypatch):
     oracle's incremental mode beside the 16-thread loop, and the matrix kernel's own evaluation rates (scaled here; full size on the GPU box)"""
     monkeypatch.setenv("KB_BENCH_VARIANTS", "1")
     out = _run_bench(monkeypatch, ["--scale", "0.02", "--steps", "1", "--warmup", "0"])
-    assert set(out["variants"]) == {"survey_nodes", "config4_binpack"}
+    assert set(out["variants"]) == {"survey_nodes", "config4_binpack", "config2"}      # (+ diverse, config5, config5_preempt at full size: their digests are the full size's)
     for v in out["variants"].values():
-        assert v["verified"] is True and v["ms_per_step"] > 0 and v["binds"] > 0
+        assert v["verified"] is True and v["ms_per_step"] > 0 and v["binds"] > 0 and v["evals_per_s"] > 0
+        assert v["roofline"]["frac"] >= 0 and v["roofline"]["bytes_per_launch"] > 0      # every variant carries its own roofline fraction (round 5's review)
     assert out["cpu_baseline_incremental"]["threads"] == 1 and out["cpu_baseline_incremental"]["value"] > 0
     for k in ("roofline_eval", "roofline_eval_all_rows"):
         assert out[k]["bound"] == "hbm" and out[k]["kernel"].startswith("k_matrix") and out[k]["frac"] >= 0
@@ -98,9 +99,10 @@ def test_smoke_entry_point_runs_end_to_end(monkeypatch, capsys):
 def test_two_ranks_under_torch_distributed_run_print_one_line(tmp_path):
     """The driver's N > 1 launch — `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py
     --gpus N ...` — with two ranks here: gloo stands in for RCCL (KB_DIST_BACKEND), the emulated library for the engine
-    (tests/host_harness/bench_emu_launcher.py).  Rank 0 prints ONE line.  Default mode: every rank schedules its OWN snapshot (seed + rank),
-    each one's decisions are held to tests/golden/bench_rank_digests.json (the oracle's), `value` is the per-session rate of the slowest rank —
-    comparable with the N = 1 line, not N times it — and the aggregate stands beside it."""
+    (tests/host_harness/bench_emu_launcher.py).  Rank 0 prints ONE line with BOTH multi-GPU answers (round 6): north_star's task-row split of one
+    session — the line's value, ms_per_step and scaling ("strong"), its decisions held to the golden digest of rank 0's snapshot, the collectives'
+    own times — and, under `sessions`, one independent session per rank (each held to tests/golden/bench_rank_digests.json, the slowest rank's
+    per-session rate and the aggregate)."""
     import socket
     import subprocess
     s = socket.socket()
@@ -117,11 +119,40 @@ def test_two_ranks_under_torch_distributed_run_print_one_line(tmp_path):
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, r.stdout
     d = json.loads(lines[0])
-    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["warmup"] == 1 and d["scaling"] == "weak"
-    assert d["multi_gpu_mode"].startswith("one independent session per GPU") and d["sessions_verified_against_golden_digests"] is True
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["warmup"] == 1 and d["scaling"] == "strong"
+    assert d["multi_gpu_mode"].startswith("north_star's task-row split")
     assert "cpu_baseline" not in d or d["cpu_baseline"] is None        # reported at N = 1 only
     assert d["roofline"]["bound"] == "hbm"
-    # `value`: one session's rate (the slowest rank's), never the ranks' sum; the sum is the aggregate
+    sh, se = d["sharded"], d["sessions"]
+    assert sh["verified"] is True and sh["scaling"] == "strong" and sh["dist_backend"] == "gloo" and sh["ranks"] == 2 and sh["ranks_seen_by_rccl"] == 0
+    assert sh["value"] == d["value"] and abs(sh["ms_per_step"] - d["ms_per_step"]) < 1e-9 and sh["rounds_per_step"] > 0
+    assert abs(d["value"] - d["evals_per_step"] / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"]       # the split's rate: ONE session's evaluations over the job's time
+    assert sh["allreduce_us_per_round"] > 0 and sh["deferred_delta_checks"] > 0
+    assert sh["rounds_that_exchanged_lists"] + sh["rounds_every_rank_evaluated_alone"] >= sh["rounds_per_step"]
+    assert (sh["allgather_us_per_round"] is None) == (sh["rounds_that_exchanged_lists"] == 0)
+    assert se["verified"] is True and se["scaling"] == "weak" and se["value"] > 0
+    # sessions: one session's rate (the slowest rank's), never the ranks' sum; the sum is the aggregate
+    assert se["aggregate_evals_per_s"] >= 1.5 * se["value"] and abs(se["sessions_per_s"] - 2 * 2 / (se["ms_per_step"] * 2e-3)) <= 1e-6 * se["sessions_per_s"]
+
+
+def test_two_ranks_sessions_mode_alone(tmp_path):
+    """KB_DIST_MODE=sessions: round 5's default line (every rank its own snapshot, value = the slowest rank's per-session rate, "weak")"""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, KB_EMU_LIB=emu.build_emulated_library(), KB_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1", KB_DIST_MODE="sessions")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(HERE, "host_harness", "bench_emu_launcher.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--scale", "0.02"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=os.path.dirname(HERE))
+    assert r.returncode == 0, r.stdout + r.stderr
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["sharded"] is None and d["sessions"] is None
+    assert d["multi_gpu_mode"].startswith("one independent session per GPU") and d["sessions_verified_against_golden_digests"] is True
     assert d["value"] <= 1.05 * d["evals_per_step"] / (d["ms_per_step"] * 1e-3) * 1.5
     assert d["aggregate_evals_per_s"] >= 1.5 * d["value"] and abs(d["sessions_per_s"] - 2 * 2 / (d["ms_per_step"] * 2e-3)) <= 1e-6 * d["sessions_per_s"]
 

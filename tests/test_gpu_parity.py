@@ -154,7 +154,7 @@ def test_argmax_parity(oracle_mod):
 
 
 @pytest.mark.parametrize("window,batch,flags", [(64, 4, 0), (1024, 16, 0), (4096, 1, 0), (512, 7, 0), (200, 2, 0),
-                                                (0, 0, abi.FLAG_SYNC_ROUNDS), (96, 5, abi.FLAG_SYNC_ROUNDS), (0, 0, abi.FLAG_YIELD_WAIT)])
+                                                (0, 0, abi.FLAG_SYNC_ROUNDS), (96, 5, abi.FLAG_SYNC_ROUNDS), (0, 0, abi.FLAG_YIELD_WAIT), (0, 0, abi.FLAG_SPIN_WAIT)])
 def test_allocate_backfill_config2(oracle_mod, window, batch, flags):
     """Full allocate + backfill on BASELINE config 2: ordered decisions, binds, state, shares identical."""
     snap = snapmod.synth(snapmod.synth_config(2))
@@ -383,8 +383,8 @@ def test_the_pinned_commit_kernel_is_the_one_that_runs(oracle_mod, commit_kernel
     assert np.array_equal(dec, o.decisions())
     if commit_kernel == "select":
         assert st["rounds_select"] == st["rounds"] > 10
-        by_selection = st["select_runs_clean"] + st["select_runs_general"]
-        assert by_selection > 200 and st["select_runs_serial"] < 0.2 * by_selection, st
+        by_selection = st["select_runs_clean"] + st["select_runs_shots"]
+        assert by_selection > 200 and st["select_runs_shots"] <= st["select_shots"] < 4 * st["select_runs_shots"] + 1, st      # every such run takes a shot, few take many
     elif commit_kernel == "run":   # (None: the emulated-device re-collection, which does not pin a kernel)
-        assert st["rounds_select"] == 0 and st["select_runs_clean"] == 0 and st["select_runs_general"] == 0
+        assert st["rounds_select"] == 0 and st["select_runs_clean"] == 0 and st["select_runs_shots"] == 0 and st["select_shots"] == 0
     e.close(); o.close()
