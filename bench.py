@@ -452,6 +452,9 @@ def main():
                           "lds_bank_conflict_share": None if not c.get("SQ_LDS_IDX_ACTIVE") else round(c.get("SQ_LDS_BANK_CONFLICT", 0.0) / c["SQ_LDS_IDX_ACTIVE"], 3),
                           "waves_per_dispatch": int(c.get("SQ_WAVES", 0))}
         roofline_commit["counters"] = cnt
+        shape_note = os.path.join(os.path.dirname(found_c[-1]), "rocprofv3_pmc_k_commit.launch_shape.txt")
+        roofline_commit["counters_launch_shape"] = (open(shape_note).read().strip() if os.path.exists(shape_note)
+                                                    else "the default launch: commit workgroup + L2 helpers + one repair workgroup per shape (sums over ~30 mostly idle workgroups)")
         roofline_commit["counters_source"] = "committed rocprofv3 PMC passes of the default command (not re-measured in this run): " + os.path.relpath(found_c[-1], ROOT)
 
     out = {

@@ -3,20 +3,22 @@
 // Same contract and same decisions as kb_commit.hip (the reference's sequential placement, allocate.go:129-193 / backfill.go:44-67, a
 // run of same-shape rows at a time), two differences in how a run is worked:
 //
-// 1. The rows of a run are ONE selection instead of a loop over the rows.  Every candidate node of a run of r plain rows — the r best clean
-//    entries of the shape's list and the dirty slots whose key is above the r-th of them — has its own key sequence key(n, j): its key
-//    for the shape after j placements of the shape, while the next placement still passes the predicates (api/node_info.go:172-212
-//    applied j times).  It depends on that node's state only.  With eff(n, j) = min key(n, 0..j), the serial loop's picks are the first
-//    r of all (n, j) entries in (eff descending, j ascending) order — keys carry the node index, so entries of different nodes never tie:
-//    a node picked at key s was the maximum with the lowest index among equals (util.SelectBestNode, scheduler_helper.go:188-208, with
-//    the canonical tie-break); while its next keys stay >= s it wins again at once (nobody else changed) — the steps on which eff stays s —
+// 1. The rows of a run are ONE selection instead of a loop over the rows.  Every node has its own key sequence key(n, j): its key for the
+//    shape after j placements of the shape, while the next placement still passes the predicates (api/node_info.go:172-212 applied j
+//    times).  It depends on that node's state only.  With eff(n, j) = min key(n, 0..j), the serial loop's picks are the first r of all
+//    (n, j) entries in (eff descending, j ascending) order — keys carry the node index, so entries of different nodes never tie: a node
+//    picked at key s was the maximum with the lowest index among equals (util.SelectBestNode, scheduler_helper.go:188-208, with the
+//    canonical tie-break); while its next keys stay >= s it wins again at once (nobody else changed) — the steps on which eff stays s —
 //    and when its key falls below s the prefix minimum is the real key again.  A Pipeline entry (allocate.go:160: InitResreq no longer
-//    fits Idle) ends its node's sequence; picked, it ends the round behind its row.  Step 0 of every candidate (and step 1 of the clean
-//    ones) is evaluated in parallel before the selection; deeper steps are walked by the lanes of wave 0, several steps per candidate in
-//    one pass (most runs need none: every pick is a clean candidate's first placement); the order is a rank by count over at most 64
-//    entries.  Nothing is written before the picks are known, so any limit of the tables simply hands the run to the serial loop of
-//    kb_commit.hip, kept here.  (tests/run_selection_model.py and the emulated launch of tests/host_harness/device_emu.cpp hold the
-//    claim to the serial loop on the CPU.)
+//    fits Idle) ends its node's sequence; picked, it ends the round behind its row.  Most runs need no table at all: every pick is a clean
+//    candidate's first placement (the all-clean test in wave 0's loop).  The others are committed by SHOTS (round 6): the rem best
+//    contenders by current key — the distinct winners of rem rows are among them —, for each its next D keys evaluated in parallel by the
+//    64 lanes (D = lanes / contenders; the best one gets sixteen), prefix minima by DPP, one rank through LDS, and of that order the
+//    picks that are FINAL: above the floor (the best key outside the table) and in front of the first table that ends while its sequence
+//    may go on.  What is not final yet is the next shot's, against the node states the committed picks left.  Placements are evaluated as
+//    Idle - u * Resreq, which is u subtractions for whole numbers below 2^47 (KbDev::whole: kb_session_load looks at every request, Idle
+//    and Releasing value; a session with anything else commits its runs row by row, like single rows, backfill and rows with their own
+//    Resreq always do).  (tests/run_selection_model.py — selected_run, table_run — holds both claims to the serial loop on the CPU.)
 //
 // 2. The workgroup is a PIPELINE of waves that hand runs to each other through sequence words in LDS — no workgroup barrier inside the
 //    loop, so that a wave with a long step does not hold up the others:
@@ -859,5 +861,10 @@ void kb_launch_commit_sel(const KbDev &d, const KbRound &r, void *stream) {
   // a round whose lists are repaired beside its commit: one more workgroup per matrix row (they only need kb_repair_lds_bytes of the block)
   uint32_t grid = KB_WARM_GRID;
   if (r.lists_ready != nullptr) grid = std::max<uint32_t>(grid, r.n_mrows + (r.n_mrows - 1u) / 7u + 1u);   // row j: workgroup j + j / 7 + 1
+  // a PROFILING aid (scripts/gpu_r6.sh profile; never set in operation): the commit workgroup alone in its launch, so that a rocprofv3 PMC pass
+  // counts ITS waves' instructions and cycles — with the L2 helpers and the repair rows in the launch the per-dispatch sums are of ~30 workgroups
+  // that mostly idle (round 5: "parked 0.992").  Needs the repair as a launch of its own (KB_FUSE_REPAIR=0); costs the warm L2.
+  static const bool solo = [] { const char *v = getenv("KB_PROFILE_SOLO_COMMIT"); return v && v[0] == '1'; }();
+  if (solo && r.lists_ready == nullptr) grid = 1u;
   hipLaunchKernelGGL(k_commit_select, dim3(grid), dim3(K9_THREADS), sh, (hipStream_t)stream, ka);
 }

@@ -775,20 +775,41 @@ void kb_launch_affinity(const KbDev &d, const KbRound &r, void *stream) {
   if (r.n_mrows == 0 || !d.aff || !d.score_enabled) return;
   hipLaunchKernelGGL(k_affinity, dim3(r.n_mrows), dim3(256), 0, (hipStream_t)stream, d, r);
 }
-// K1b, tiled: workgroup (tile, chunk) holds 4 KB of the chunk's shape row (2048 u16 scores: 16 bytes per thread) and 256 B of its mask in registers and
-// streams them to every task row of the chunk — the launch's HBM traffic is its stores (2.125 B per pair) plus one read of a shape tile per 64 rows
+// K1b, tiled: workgroup (tile, chunk) holds its tile of the chunk's shape row in registers — up to 16 384 u16 scores (eight 16-byte pieces per thread: a
+// whole row at 10k nodes, so a row leaves as ONE contiguous 20 KB stream like k_expand's) and the tile's mask words — and streams them to every task row of
+// the chunk: the launch's HBM traffic is its stores (2.125 B per pair) plus one read of a shape tile per 64 rows
+#define KB_XTILE_NODES 16384u
+// the rows are written once and read by nobody in this launch: -DKB_XTILE_NT=1 stores them non-temporally (A/B build)
+typedef unsigned int kb_u32x4 __attribute__((ext_vector_type(4)));
+#if defined(KB_XTILE_NT) && KB_XTILE_NT
+#define KB_XSTORE(p, val) __builtin_nontemporal_store(kb_u32x4{(val).x, (val).y, (val).z, (val).w}, reinterpret_cast<kb_u32x4 *>(p))
+#else
+#define KB_XSTORE(p, val) (*(p) = (val))
+#endif
 __global__ void __launch_bounds__(256) k_expand_tiles(const uint16_t *__restrict__ s_score, const uint32_t *__restrict__ s_mask, const uint32_t *__restrict__ order,
                                                       const KbXChunk *__restrict__ chunks, uint32_t NP, uint16_t *__restrict__ score, uint32_t *__restrict__ maskw) {
   const KbXChunk c = chunks[blockIdx.y];
-  const size_t col = (size_t)blockIdx.x * 2048u, mcol = (size_t)blockIdx.x * 64u, mstride = NP / 32;
-  const uint4 v = reinterpret_cast<const uint4 *>(s_score + (size_t)c.slot * NP + col)[threadIdx.x];
-  const bool ml = threadIdx.x < 16u;
+  const uint32_t node0 = blockIdx.x * KB_XTILE_NODES, tn = min(KB_XTILE_NODES, NP - node0);   // NP is a multiple of 2048
+  const uint32_t n16 = tn / 8u, m16 = tn / 128u;   // 16-byte pieces of the tile's scores / mask words
+  const size_t mstride = NP / 32;
+  const uint4 *src = reinterpret_cast<const uint4 *>(s_score + (size_t)c.slot * NP + node0);
+  uint4 v[8];
+#pragma unroll
+  for (uint32_t k = 0; k < 8u; k++) { const uint32_t p = threadIdx.x + 256u * k; v[k] = p < n16 ? src[p] : make_uint4(0u, 0u, 0u, 0u); }
+  const bool ml = threadIdx.x < m16;   // (m16 <= 128)
   uint4 mv = make_uint4(0u, 0u, 0u, 0u);
-  if (ml) mv = reinterpret_cast<const uint4 *>(s_mask + (size_t)c.slot * mstride + mcol)[threadIdx.x];
+  if (ml) mv = reinterpret_cast<const uint4 *>(s_mask + (size_t)c.slot * mstride + node0 / 32u)[threadIdx.x];
+  // the chunk's rows: lane i of every wave holds row i (KB_XCHUNK_ROWS = 64 = a wave) — one vector load in front of the loop instead of a scalar
+  // load, and the wait for it, in every iteration; the stores then leave back to back
+  static_assert(KB_XCHUNK_ROWS == 64u, "one lane per row of a chunk");
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t myrow = lane < c.count ? order[c.first + lane] : 0u;
   for (uint32_t i = 0; i < c.count; i++) {
-    const uint32_t row = order[c.first + i];   // (uniform: a scalar load)
-    reinterpret_cast<uint4 *>(score + (size_t)row * NP + col)[threadIdx.x] = v;
-    if (ml) reinterpret_cast<uint4 *>(maskw + (size_t)row * mstride + mcol)[threadIdx.x] = mv;
+    const size_t row = (size_t)(uint32_t)__builtin_amdgcn_readlane((int)myrow, (int)i);
+    uint4 *dst = reinterpret_cast<uint4 *>(score + row * NP + node0);
+#pragma unroll
+    for (uint32_t k = 0; k < 8u; k++) { const uint32_t p = threadIdx.x + 256u * k; if (p < n16) KB_XSTORE(&dst[p], v[k]); }
+    if (ml) KB_XSTORE(&reinterpret_cast<uint4 *>(maskw + row * mstride + node0 / 32u)[threadIdx.x], mv);
   }
 }
 
@@ -796,7 +817,7 @@ void kb_launch_expand(const KbDev &d, const uint16_t *s_score, const uint32_t *s
                       uint16_t *score, uint32_t *maskw, void *stream, const KbXChunk *chunks, uint32_t n_chunks) {
   if (n_rows == 0) return;
   if (chunks && order && n_chunks) {   // NP is a multiple of KB_NODE_PAD = 2048
-    hipLaunchKernelGGL(k_expand_tiles, dim3(d.NP / 2048u, n_chunks), dim3(256), 0, (hipStream_t)stream, s_score, s_mask, order, chunks, d.NP, score, maskw);
+    hipLaunchKernelGGL(k_expand_tiles, dim3((d.NP + KB_XTILE_NODES - 1u) / KB_XTILE_NODES, n_chunks), dim3(256), 0, (hipStream_t)stream, s_score, s_mask, order, chunks, d.NP, score, maskw);
     return;
   }
   const uint32_t grid = order ? 8u * ((n_rows + 7u) / 8u) : n_rows;

@@ -709,6 +709,10 @@ void PreemptMachine::init(const HostSession *hs, const Policy *pol, LiveNodes *l
   popped = evals = 0;
   stmt_no_ = 0; stmt_begin_ = 0;
   version_ = 0; fail_version_ = ~0ull; fail_task_ = KB_NONE; fail_mode_ = -1;
+  // (the engine keeps ONE machine for its life — its per-node lists, pruning index and scratch vectors keep their storage from one action and one
+  //  cycle to the next —, so everything an earlier action may have left is put back here)
+  tr_walks = tr_tries = tr_skipped = tr_pruned = tr_shortcut = 0; tr_walk_ms = tr_setup_ms = tr_scan_ms = 0.0; tr_scan_nodes = 0;
+  ip_ = nullptr; ip_upload_ = nullptr; ip_changed_ = false; ip_z0_ = KB_NONE; ip_unb_n_.clear();
   cnt.assign((size_t)(J ? J : 1) * 10, 0);
   for (uint32_t t = 0; t < T; t++) if (hs->t_job[t] < J) cnt[(size_t)hs->t_job[t] * 10 + (*status)[t]]++;
   node_status.assign(T, 0);

@@ -55,6 +55,87 @@ trace)
   if [ $# -eq 0 ]; then set -- 4 3; fi
   trace_cfgs "$@"
   ;;
+mix)   # one call: the differential modules under both commit kernels, the default bench line (variants, driver-style), then two A/Bs on the same box:
+       # the tiled row expansion against round 5's copy (roofline of configs 3 and 4), the yielding wait against the pure spin
+  timeout 1200 python -m pytest tests/test_gpu_parity.py tests/test_gpu_adversarial.py tests/test_gpu_regressions.py tests/test_gpu_fuzz.py tests/test_gpu_fullsize.py tests/test_gpu_interpod.py tests/test_gpu_waterfill.py \
+    -q -m gpu -p no:cacheprovider --maxfail=10 > "$out/pytest_subset.txt" 2>&1; echo "differential modules, both commit kernels rc=$? $(tail -1 "$out/pytest_subset.txt")" | tee -a "$out/summary.txt"
+  grep -h "^FAILED\|^ERROR" "$out/pytest_subset.txt" | head -20 | tee -a "$out/summary.txt"
+  timeout 900 python bench.py > "$out/bench_default.json" 2> "$out/bench_default.err"; echo "bench default rc=$? $(ms "$out/bench_default.json")" | tee -a "$out/summary.txt"
+  python - "$out/bench_default.json" <<'PY' | tee -a "$out/summary.txt"
+import json, sys
+d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+print("value", d["value"], "verified", d.get("verified_bind_set_equals_oracle"), d.get("verified_evals_equal_oracle"), "roofline", d["roofline"]["frac"], d["roofline"].get("traffic"), d["roofline"].get("traffic_refused"))
+for k, v in d.get("variants", {}).items():
+    print(" variant", k, v["ms_per_step"], v["verified"], (v.get("roofline") or {}).get("frac"), v.get("evals_per_s"))
+PY
+  for cfg in 3 4; do
+    for t in 1 0; do
+      KB_EXPAND_TILES=$t timeout 300 python bench.py --config $cfg --steps 2 --warmup 1 --no-cpu-baseline > "$out/expand_c${cfg}_tiles${t}.json" 2> "$out/expand_c${cfg}_tiles${t}.err"
+      python -c "import json; d=json.loads(open('$out/expand_c${cfg}_tiles${t}.json').read().strip().splitlines()[-1]); r=d['roofline']; print('expand config $cfg tiles=$t', r['kernel'], 'frac', r['frac'], 'ms', r['avg_launch_ms'], 'eval-only', d['roofline_eval']['frac'], d['roofline_eval_all_rows']['frac'])" | tee -a "$out/summary.txt"
+    done
+  done
+  for rep in 1 2; do
+    bench_ab "c3_yield_r${rep}" -- --config 3 --steps 8 --warmup 2
+    bench_ab "c3_spin_r${rep}" -- --config 3 --steps 8 --warmup 2 --spin-wait
+  done
+  ;;
+profile)   # rocprofv3 evidence of the default bench command on THIS tree: kernel stats, HBM bytes of the matrix launches (FETCH / WRITE in separate passes),
+           # SQ counters of the commit kernel with the commit workgroup ALONE in its launch (KB_PROFILE_SOLO_COMMIT=1 KB_FUSE_REPAIR=0: attributable to
+           # its eight waves; the default launch carries ~30 mostly idle workgroups) — then   python scripts/summarize_profile.py r6_profile profiles/round6
+  export TMPDIR=/tmp
+  CMD="python $PWD/bench.py --steps 2 --warmup 1 --no-cpu-baseline"
+  P="$PWD/$out"
+  ( cd /tmp
+    rocprofv3 --kernel-trace --stats -f csv -d "$P/trace" -o bench -- $CMD > "$P/bench_trace.log" 2>&1
+    rocprofv3 --pmc FETCH_SIZE -f csv --kernel-include-regex "k_matrix|k_expand" -d "$P/pmc_fetch" -o bench -- $CMD > "$P/bench_pmc_fetch.log" 2>&1
+    rocprofv3 --pmc WRITE_SIZE -f csv --kernel-include-regex "k_matrix|k_expand" -d "$P/pmc_write" -o bench -- $CMD > "$P/bench_pmc_write.log" 2>&1
+    KB_PROFILE_SOLO_COMMIT=1 KB_FUSE_REPAIR=0 rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE -f csv --kernel-include-regex "k_commit" \
+      -d "$P/pmc_commit_a" -o bench -- $CMD > "$P/bench_pmc_commit_a.log" 2>&1
+    KB_PROFILE_SOLO_COMMIT=1 KB_FUSE_REPAIR=0 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR -f csv --kernel-include-regex "k_commit" \
+      -d "$P/pmc_commit_b" -o bench -- $CMD > "$P/bench_pmc_commit_b.log" 2>&1
+  )
+  echo "the commit workgroup alone in its launch (KB_PROFILE_SOLO_COMMIT=1 KB_FUSE_REPAIR=0: no L2 helpers, the repair rows a launch of their own): the sums per dispatch are of its eight waves" > "$out/pmc_commit_launch_shape.txt"
+  find "$out" -name "*.csv" | head -20 | tee -a "$out/summary.txt"
+  python scripts/summarize_profile.py r6_profile profiles/round6 2>&1 | tail -2 | tee -a "$out/summary.txt"
+  mkdir -p "$out/profiles_round6" && cp -r profiles/round6/. "$out/profiles_round6/"
+  python scripts/trace_gaps.py "$out/trace/bench_kernel_trace.csv" 3 > "$out/gaps_config3.txt" 2>&1; head -12 "$out/gaps_config3.txt" | tee -a "$out/summary.txt"
+  ;;
+mix2)  # the tiled expansion again (rows preloaded), the evict action's host timeline at 1M x 50k, the profile passes, two gloo ranks on the one GPU
+  for cfg in 3 4; do
+    for t in 1 0; do
+      KB_EXPAND_TILES=$t timeout 300 python bench.py --config $cfg --steps 2 --warmup 1 --no-cpu-baseline > "$out/expand_c${cfg}_tiles${t}.json" 2> "$out/expand_c${cfg}_tiles${t}.err"
+      python -c "import json; d=json.loads(open('$out/expand_c${cfg}_tiles${t}.json').read().strip().splitlines()[-1]); r=d['roofline']; print('expand config $cfg tiles=$t', r['kernel'], 'frac', r['frac'], 'ms', r['avg_launch_ms'], 'eval-only', d['roofline_eval']['frac'], d['roofline_eval_all_rows']['frac'])" | tee -a "$out/summary.txt"
+    done
+  done
+  KB_EVICT_TRACE=1 timeout 600 python bench.py --config 5 --preempt --steps 2 --warmup 1 --no-cpu-baseline --verify > "$out/bench_c5_preempt.json" 2> "$out/bench_c5_preempt.err"
+  echo "config 5 + preempt rc=$? $(ms "$out/bench_c5_preempt.json")" | tee -a "$out/summary.txt"; grep -h "kb evict" "$out/bench_c5_preempt.err" | tail -2 | tee -a "$out/summary.txt"
+  bash scripts/gpu_r6.sh profile > "$out/profile_step.txt" 2>&1; tail -16 "$out/profile_step.txt" | tee -a "$out/summary.txt"
+  KB_SCALE_GLOO=1 timeout 900 bash scripts/scale_curve.sh "$out/scale" 3 > "$out/scale_curve_log.txt" 2>&1; cat "$out/scale/scale_curve.txt" | tee -a "$out/summary.txt"
+  ;;
+expand)  # the tiled expansion: bench's own event timing (normal run) for the default build, the non-temporal build (libkbengine_nt.so), round 5's copy
+         # (KB_EXPAND_TILES=0), each twice; then the same under rocprofv3 --kernel-trace (the profiler's durations beside the bench's own)
+  one() { # name, env..., -- args
+    local name="$1"; shift; local envs=(); while [ "$1" != "--" ]; do envs+=("$1"); shift; done; shift
+    timeout 300 env "${envs[@]}" python bench.py --steps 2 --warmup 1 --no-cpu-baseline "$@" > "$out/x_${name}.json" 2> "$out/x_${name}.err"
+    python -c "import json; d=json.loads(open('$out/x_${name}.json').read().strip().splitlines()[-1]); r=d['roofline']; print('$name', r['kernel'], 'frac', r['frac'], 'ms', r['avg_launch_ms'])" | tee -a "$out/summary.txt"
+  }
+  nt="KB_ENGINE_LIB=$PWD/kube-batch_amd/libkbengine_nt.so"
+  for rep in 1 2; do
+    for cfg in 3 4; do
+      one "c${cfg}_tiles_r${rep}" -- --config $cfg
+      one "c${cfg}_nt_r${rep}" $nt -- --config $cfg
+      one "c${cfg}_rowcopy_r${rep}" KB_EXPAND_TILES=0 -- --config $cfg
+    done
+  done
+  export TMPDIR=/tmp
+  P="$PWD/$out"
+  for v in tiles nt; do
+    envs=(); [ "$v" = nt ] && envs=($nt)
+    ( cd /tmp; env "${envs[@]}" rocprofv3 --kernel-trace --stats -f csv -d "$P/trace_$v" -o bench -- python /root/repo/bench.py --steps 2 --warmup 1 --no-cpu-baseline > "$P/trace_$v.log" 2>&1 ) || true
+    grep -h "k_expand\|k_matrix<1, 16>" "$P/trace_$v/bench_kernel_stats.csv" 2>/dev/null | cut -c1-140 | tee -a "$out/summary.txt"
+    grep -h '"metric"' "$P/trace_$v.log" | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('under rocprofv3 ($v):', d['roofline']['avg_launch_ms'], d['roofline']['frac'])" | tee -a "$out/summary.txt"
+  done
+  ;;
 subset)
   timeout 1200 python -m pytest tests/test_gpu_parity.py tests/test_gpu_adversarial.py tests/test_gpu_regressions.py tests/test_gpu_fuzz.py tests/test_gpu_fullsize.py tests/test_gpu_reload.py tests/test_gpu_interpod.py \
     -q -m gpu -p no:cacheprovider --maxfail=10 > "$out/pytest_subset.txt" 2>&1; echo "differential modules, both commit kernels rc=$? $(tail -1 "$out/pytest_subset.txt")" | tee -a "$out/summary.txt"

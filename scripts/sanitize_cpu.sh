@@ -19,7 +19,7 @@ KB_ORACLE_LIB="$out/libkboracle.so" KB_ORDER_HARNESS_LIB="$out/liborderharness.s
     tests/test_interpod_oracle_cpu.py tests/test_manifests_cpu.py \
     -x -q -p no:cacheprovider "$@"
 # the complete C ABI on the emulated device: kb_engine.cpp's round protocol, session load / reset, evict actions, kb_round_* (about 3 minutes)
-g++ -std=c++17 $san -Itests/host_harness/hip_mock -o "$out/libkbengine_emu.so" kube-batch_amd/csrc/kb_engine.cpp kube-batch_amd/csrc/kb_session.cpp \
+g++ -std=c++17 $san -Itests/host_harness/hip_mock -o "$out/libkbengine_emu.so" kube-batch_amd/csrc/kb_engine.cpp kube-batch_amd/csrc/kb_load.cpp kube-batch_amd/csrc/kb_rounds.cpp kube-batch_amd/csrc/kb_evict.cpp kube-batch_amd/csrc/kb_matrix.cpp kube-batch_amd/csrc/kb_session.cpp \
   kube-batch_amd/csrc/kb_order.cpp kube-batch_amd/csrc/kb_preempt.cpp tests/host_harness/device_emu.cpp tests/host_harness/hip_mock/hip_mock.cpp
 ASAN_OPTIONS=detect_leaks=0 LD_PRELOAD="$(gcc -print-file-name=libasan.so) $(g++ -print-file-name=libstdc++.so.6)" KB_EMU_LIB="$out/libkbengine_emu.so" \
   python -m pytest tests/test_emu_engine_cpu.py -x -q -p no:cacheprovider -k "not two_gloo" "$@"
@@ -41,7 +41,7 @@ KB_DEVICE_WATERFILL=0 python -m pytest tests/test_emu_engine_cpu.py -x -q -p no:
 # ThreadSanitizer over the host <-> device handshake: the emulated streams run asynchronously (KB_EMU_ASYNC=1: a worker thread per stream with
 # HIP's ordering rules, tests/host_harness/hip_mock), so a staging half, a mailbox word or a result the host touches before the device is done
 # with it is a reported race.  Chained / unchained rounds, pinned mailbox / synchronous rounds, direct window, both commit-kernel pins.
-emu_src="kube-batch_amd/csrc/kb_engine.cpp kube-batch_amd/csrc/kb_session.cpp kube-batch_amd/csrc/kb_order.cpp kube-batch_amd/csrc/kb_preempt.cpp tests/host_harness/hip_mock/hip_mock.cpp"
+emu_src="kube-batch_amd/csrc/kb_engine.cpp kube-batch_amd/csrc/kb_load.cpp kube-batch_amd/csrc/kb_rounds.cpp kube-batch_amd/csrc/kb_evict.cpp kube-batch_amd/csrc/kb_matrix.cpp kube-batch_amd/csrc/kb_session.cpp kube-batch_amd/csrc/kb_order.cpp kube-batch_amd/csrc/kb_preempt.cpp tests/host_harness/hip_mock/hip_mock.cpp"
 tsan="-std=c++17 -O1 -g -fPIC -shared -ffp-contract=off -fsanitize=thread -pthread -Itests/host_harness/hip_mock"
 g++ $tsan -o "$out/libkbengine_emu_tsan.so" $emu_src tests/host_harness/device_emu.cpp
 # KB_OVERLAP=0: an overlapped round's matrix launch (second stream) reads node state the predecessor's commit kernel (first stream) is writing
@@ -80,7 +80,7 @@ if [ -x "$CL" ]; then
     python -m pytest tests/test_host_order_cpu.py tests/test_host_evict_cpu.py -x -q -p no:cacheprovider
   # ... and the whole host side of the engine on the emulated device (the library's name is part of one test)
   mkdir -p "$out/clang"
-  $CL $fl -pthread -Itests/host_harness/hip_mock -o "$out/clang/libkbengine_emu.so" kube-batch_amd/csrc/kb_engine.cpp kube-batch_amd/csrc/kb_session.cpp \
+  $CL $fl -pthread -Itests/host_harness/hip_mock -o "$out/clang/libkbengine_emu.so" kube-batch_amd/csrc/kb_engine.cpp kube-batch_amd/csrc/kb_load.cpp kube-batch_amd/csrc/kb_rounds.cpp kube-batch_amd/csrc/kb_evict.cpp kube-batch_amd/csrc/kb_matrix.cpp kube-batch_amd/csrc/kb_session.cpp \
     kube-batch_amd/csrc/kb_order.cpp kube-batch_amd/csrc/kb_preempt.cpp tests/host_harness/device_emu.cpp tests/host_harness/hip_mock/hip_mock.cpp
   KB_EMU_LIB="$out/clang/libkbengine_emu.so" python -m pytest tests/test_emu_engine_cpu.py -x -q -p no:cacheprovider -n 8 -k "not two_gloo"
 fi

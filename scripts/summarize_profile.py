@@ -44,6 +44,11 @@ for sub in ("pmc_commit_a", "pmc_commit_b"):
     for (k, cname), v in sorted(acc.items()):
         crow.append((k, cname, len(v), sum(v) / len(v), max(v)))
 if crow:
+    # which launch the commit kernel's counters are of (bench.py quotes it beside them): scripts/gpu_r6.sh profile runs these two passes with the
+    # commit workgroup ALONE in its launch (KB_PROFILE_SOLO_COMMIT=1 KB_FUSE_REPAIR=0); round 5's passes summed ~30 workgroups per dispatch
+    shape = src / "pmc_commit_launch_shape.txt"
+    if shape.exists():
+        shutil.copy(shape, dst / "rocprofv3_pmc_k_commit.launch_shape.txt")
     with open(dst / "rocprofv3_pmc_k_commit.csv", "w", newline="") as f:
         w = csv.writer(f)
         w.writerow(["kernel", "counter", "dispatches", "mean_per_dispatch", "max_per_dispatch"])

@@ -1,4 +1,4 @@
-"""The engine's HOST side, whole, on a CPU: kb_engine.cpp + kb_session.cpp + kb_order.cpp + kb_preempt.cpp compiled unchanged with g++ against
+"""The engine's HOST side, whole, on a CPU: kb_engine.cpp + kb_load.cpp + kb_rounds.cpp + kb_evict.cpp + kb_matrix.cpp + kb_session.cpp + kb_order.cpp + kb_preempt.cpp compiled unchanged with g++ against
 tests/host_harness/hip_mock (a synchronous stand-in for the few HIP runtime calls they make) and linked with
 tests/host_harness/device_emu.cpp, a sequential restatement of what each kernel launch computes.  The result exports the complete C ABI
 of include/kb_engine.h, so the `-m gpu` suites themselves run here — same test functions, same oracle comparison — with the emulated
@@ -36,8 +36,8 @@ def build_emulated_library():
     out_dir = os.path.join(HH, "build")
     os.makedirs(out_dir, exist_ok=True)
     so = os.path.join(out_dir, "libkbengine_emu.so")
-    srcs = [os.path.join(CSRC, f) for f in ("kb_engine.cpp", "kb_session.cpp", "kb_order.cpp", "kb_preempt.cpp")] + [os.path.join(HH, "device_emu.cpp"), os.path.join(HH, "hip_mock", "hip_mock.cpp")]
-    deps = srcs + [os.path.join(CSRC, f) for f in ("kb_device.h", "kb_eval.hpp", "kb_host.hpp", "kb_res.hpp", "kb_waterfill.hpp", "kb_preempt.hpp")] + \
+    srcs = [os.path.join(CSRC, f) for f in ("kb_engine.cpp", "kb_load.cpp", "kb_rounds.cpp", "kb_evict.cpp", "kb_matrix.cpp", "kb_session.cpp", "kb_order.cpp", "kb_preempt.cpp")] + [os.path.join(HH, "device_emu.cpp"), os.path.join(HH, "hip_mock", "hip_mock.cpp")]
+    deps = srcs + [os.path.join(CSRC, f) for f in ("kb_engine_int.hpp", "kb_device.h", "kb_eval.hpp", "kb_host.hpp", "kb_res.hpp", "kb_waterfill.hpp", "kb_preempt.hpp")] + \
         [os.path.join(HH, "hip_mock", "hip", "hip_runtime.h"), os.path.join(HERE, "..", "include", "kb_engine.h")]
     if not os.path.exists(so) or any(os.path.getmtime(d) > os.path.getmtime(so) for d in deps):
         tmp = f"{so}.{os.getpid()}"                      # atomic: parallel pytest workers may build at the same time
