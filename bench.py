@@ -247,6 +247,7 @@ def main():
     for _ in range(args.warmup):
         step()
     s0 = eng.stats()
+    coll0 = dict(runner.collective_times(), replicated=runner.replicated_rounds, checks=runner.deferred_checks) if dist_mode == "sharded" else None
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -273,7 +274,8 @@ def main():
     if dist_mode == "sharded":
         # outside the timed region: one more cycle; every rank decided the SAME session, whose decisions + bind set are held to the committed digest of
         # rank 0's snapshot (the oracle's); the ranks' verdicts are reduced so that the line says what ALL of them found
-        coll = runner.collective_times()
+        coll1 = dict(runner.collective_times(), replicated=runner.replicated_rounds, checks=runner.deferred_checks)
+        coll = {k: (coll1[k] - coll0[k] if isinstance(coll1[k], (int, float)) else coll1[k]) for k in coll1}      # the timed region's own
         dec_last = runner.step()
         mine = distmod.ReplicatedCycle.digest(dec_last, eng.binds(), eng.journal() if args.preempt else None, eng.evictions() if args.preempt else None)
         want = golden_ranks.get("0")
@@ -290,10 +292,10 @@ def main():
                          "ms_per_step": elapsed * 1e3 / args.steps, "value": None if sharded_verified is False else value, "scaling": "strong",
                          "dist_backend": dist.get_backend(), "ranks_seen_by_rccl": dist.get_world_size() if dist.get_backend() == "nccl" else 0,
                          "ranks": dist.get_world_size(), "rounds_per_step": d["rounds"] / args.steps, "spec_breaks_per_step": d["spec_breaks"] / args.steps,
-                         "rounds_that_exchanged_lists": coll["gathers"], "rounds_every_rank_evaluated_alone": runner.replicated_rounds,
+                         "rounds_that_exchanged_lists_per_step": coll["gathers"] / args.steps, "rounds_every_rank_evaluated_alone_per_step": coll["replicated"] / args.steps,
                          "allgather_us_per_round": None if not coll["gathers"] else round(coll["gather_s"] * 1e6 / coll["gathers"], 1),
                          "allreduce_us_per_round": None if not coll["reduces"] else round(coll["reduce_s"] * 1e6 / coll["reduces"], 1),
-                         "collective_times_are": coll["clock"], "deferred_delta_checks": runner.deferred_checks,
+                         "collective_times_are": coll["clock"], "deferred_delta_checks_per_step": coll["checks"] / args.steps,
                          "verified": sharded_verified, "verified_with": "tests/golden/bench_rank_digests.json, rank 0's snapshot (the oracle's digest of decisions + bind set)"}
         if sharded_verified is False:
             value = None

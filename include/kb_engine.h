@@ -306,7 +306,7 @@ typedef struct kb_stats {
   uint64_t binds;             /* tasks dispatched to the Binder */
   uint64_t rounds;            /* device rounds (matrix -> arg-max -> commit) */
   uint64_t spec_breaks;       /* rounds cut short because the speculated order diverged */
-  uint64_t row_fallbacks;     /* rows the commit kernel committed in its row-at-a-time mode (dirty-winner chains) */
+  uint64_t row_fallbacks;     /* rows won by a node the round had already changed (a dirty slot): committed by shots, single rows one by one (the name is round 3's) */
   uint64_t matrix_launches;   /* launches of the mask+score matrix kernel */
   uint64_t matrix_evals;      /* (task,node) pairs those launches evaluated */
   double   matrix_ms;         /* HIP-event time of those launches on the engine stream */
@@ -402,9 +402,10 @@ int  kb_get_stats(kb_engine *e, kb_stats *out);
  *                          differs from the replica's own commit (replicas diverged)
  * The reduced deltas are a CROSS-CHECK (every replica commits the whole window itself): they need not sit between two rounds.  The
  * deferred form takes the all-reduce off the critical path: kb_round_apply with a NULL buffer only absorbs the round's result; the
- * caller reduces round k's buffer on a side stream while round k + 1 is planned and evaluated, and hands it to
+ * caller reduces round k's buffer on a side stream while round k + 1 is planned, evaluated and committed, and hands it to
  *   kb_round_check      -> queued, nothing waited for: (state at the start of round k) + reduced deltas == (state at the start of
- *                          round k + 1), called after kb_round_begin of round k + 1 has returned rows; with against_live != 0
+ *                          round k + 1), called after kb_round_begin of round k + 1 has returned rows and before the one of round
+ *                          k + 2 (kube-batch_amd/dist.py: behind kb_round_commit of round k + 1, in front of its kb_round_apply); with against_live != 0
  *                          after the kb_round_begin that returned n_rows == 0: == the live state (the action's last round)
  *   kb_round_check_result -> the number of values that differed in any check since the action began (one synchronisation);
  *                          non-zero: the replicas diverged

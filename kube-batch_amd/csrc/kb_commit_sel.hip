@@ -161,7 +161,18 @@ __global__ void __launch_bounds__(K9_THREADS) k_commit_select(const K9KernArgs k
 #endif
   // how long a waiting prep / evaluating wave sleeps between two polls: s_sleep 1 (64 clocks).  Measured 0 .. 1 alike, longer slower
   // (profiles/round4/call18_19_20_polls_and_fence); the KB_SEL_SLEEP switch that swept it is gone
-  constexpr uint32_t nap_prep = 1u, nap_dk = 1u;
+#ifndef KB_K9_NAP_PREP
+#define KB_K9_NAP_PREP 1u
+#endif
+  constexpr uint32_t nap_prep = KB_K9_NAP_PREP, nap_dk = 1u;
+  // issue priority (-DKB_K9_PRIO=1, an A/B build): waves that share a SIMD — wave w and wave w + 4 — and the CU's one scalar unit are arbitrated by
+  // priority, then age (MI355X_MICROARCH.md).  Wave 0 is the pipeline's critical path, the evaluating waves are what it waits for, the preparing waves
+  // work two runs ahead
+#if defined(KB_K9_PRIO) && KB_K9_PRIO
+#define K9S_SETPRIO(p) __builtin_amdgcn_s_setprio(p)
+#else
+#define K9S_SETPRIO(p) do { } while (0)
+#endif
   const unsigned long long lt = (1ull << lane) - 1ull;
   gptrd gi, gr;
   { const KbDev &d = *a.dev; gi = (gptrd)d.idle; gr = (gptrd)d.rel; }
@@ -186,6 +197,7 @@ __global__ void __launch_bounds__(K9_THREADS) k_commit_select(const K9KernArgs k
 
   //@@ w0_setup
   if (wave == 0) {
+    K9S_SETPRIO(3);
     // =================================================== wave 0: the selection ===================================================
     uint32_t nd = 0, n_dirty_rows = 0, n_runs = 0, n_slow = 0, i_end = 0, reason_end = KB_REASON_DONE;
     uint32_t prev_nd0 = 0, prev_pc = 0;   // the run in front: dirty slots when it started, clean candidates it consumed
@@ -648,6 +660,7 @@ __global__ void __launch_bounds__(K9_THREADS) k_commit_select(const K9KernArgs k
     }
   //@@ dk_waves
   } else if (wave <= 4u) {
+    K9S_SETPRIO(2);
     // =================================================== waves 1..4: the dirty slots ===================================================
     // Run q's dirty keys are evaluated EARLY, while run q - 1 is still being selected: against the slots as run q - 2 left them plus run
     // q - 1's candidates in their prepared state (one placement).  Most runs only consume clean candidates, once each: then the early

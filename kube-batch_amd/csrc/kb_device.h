@@ -244,7 +244,7 @@ void kb_launch_argmax(const KbDev &d, const KbRound &r, void *stream);
 void kb_launch_repair(const KbDev &d, const KbRound &r, void *stream);
 size_t kb_repair_smem_bytes(uint32_t NP);   // its dynamic LDS (<= 150 KiB or the engine does not overlap rounds)
 // per-task rows out of the per-shape rows (kb_eval_matrix / kb_bench_matrix: the materialised T x N matrix)
-// order: the rows sorted by shape slot (nullptr: row order).  chunks (with order): stretches of `order` that share a shape, at most KB_XCHUNK_ROWS rows
+// order: the rows sorted by shape slot (nullptr: row order).  chunks: stretches of `order` (of the rows themselves without it) that share a shape, at most KB_XCHUNK_ROWS rows
 // each — a workgroup then loads its tile of the shape row (up to 16 384 nodes) ONCE and stores it to every row of its chunk (round 6: the source is read
 // ~n_rows / KB_XCHUNK_ROWS times instead of n_rows times; k_expand re-fetched a few MB of shape rows through eight L2s 226 MB worth per launch)
 struct KbXChunk { uint32_t slot, first, count, pad; };

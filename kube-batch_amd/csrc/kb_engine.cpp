@@ -174,8 +174,7 @@ int kb_engine_create(const kb_config *cfg, kb_engine **out) {
         else if (ck[0] == 's') eng->commit_pin = KB_COMMIT_SELECT;
         if (eng->commit_pin >= 0) eng->commit_kernel = eng->commit_pin;
       }
-      const char *sr = getenv("KB_SYNC_ROUNDS");
-      eng->fast_rounds = !(eng->flags & KB_FLAG_SYNC_ROUNDS) && !(sr && sr[0] == '1');
+      eng->fast_rounds = !(eng->flags & KB_FLAG_SYNC_ROUNDS);   // (the environment form KB_SYNC_ROUNDS went in round 6: the flag is the switch, tests/test_gpu_parity.py runs it)
       const char *cr = getenv("KB_CHAIN_ROUNDS");   // 0: launch every round only after the previous one was collected (A/B, debugging)
       eng->chain_rounds = !(cr && cr[0] == '0');
       const char *pb = getenv("KB_PROBE");
@@ -186,8 +185,6 @@ int kb_engine_create(const kb_config *cfg, kb_engine **out) {
       eng->fuse_repair = !(fr && fr[0] == '0');
       const char *wf = getenv("KB_DEVICE_WATERFILL");
       eng->device_waterfill = !(wf && wf[0] == '0');
-      const char *dw = getenv("KB_DIRECT_WINDOW");
-      eng->direct_window = !(dw && dw[0] == '0');
     }
     e = eng.release();
   });

@@ -283,7 +283,6 @@ struct kb_engine {
   Pinned<uint32_t> h_win;             // per-round upload  [rows | slots | mrows] at fixed offsets of KB_K5_MAX_WINDOW
   Pinned<unsigned long long> h_out;   // per-round download: KB_OUT_HDR header words (kb_device.h) + decision records
   const uint32_t *d_hwin = nullptr;       // device view of h_win
-  bool direct_window = true;              // KB_DIRECT_WINDOW=0: always copy the window into b_win first
   unsigned long long *d_hout = nullptr;   // device view of h_out (fast rounds: the commit kernel writes it directly)
   bool fast_rounds = true;            // host spins on h_out[KB_OUT_SEQ] instead of synchronising the stream every round
   bool chain_rounds = true;           // queue the next speculated round behind the running one (KbRound::chain); KB_CHAIN_ROUNDS=0 disables

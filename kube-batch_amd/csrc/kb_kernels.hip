@@ -779,13 +779,8 @@ void kb_launch_affinity(const KbDev &d, const KbRound &r, void *stream) {
 // whole row at 10k nodes, so a row leaves as ONE contiguous 20 KB stream like k_expand's) and the tile's mask words — and streams them to every task row of
 // the chunk: the launch's HBM traffic is its stores (2.125 B per pair) plus one read of a shape tile per 64 rows
 #define KB_XTILE_NODES 16384u
-// the rows are written once and read by nobody in this launch: -DKB_XTILE_NT=1 stores them non-temporally (A/B build)
-typedef unsigned int kb_u32x4 __attribute__((ext_vector_type(4)));
-#if defined(KB_XTILE_NT) && KB_XTILE_NT
-#define KB_XSTORE(p, val) __builtin_nontemporal_store(kb_u32x4{(val).x, (val).y, (val).z, (val).w}, reinterpret_cast<kb_u32x4 *>(p))
-#else
-#define KB_XSTORE(p, val) (*(p) = (val))
-#endif
+// (non-temporal stores for the rows — written once, read by nobody in this launch — measured no consistent gain: 0.353 / 0.410 ms against 0.386 / 0.369 at
+//  100k x 10k on one box, profiles/round6/call8_expand_tiles_whole_row/summary.txt)
 __global__ void __launch_bounds__(256) k_expand_tiles(const uint16_t *__restrict__ s_score, const uint32_t *__restrict__ s_mask, const uint32_t *__restrict__ order,
                                                       const KbXChunk *__restrict__ chunks, uint32_t NP, uint16_t *__restrict__ score, uint32_t *__restrict__ maskw) {
   const KbXChunk c = chunks[blockIdx.y];
@@ -803,20 +798,20 @@ __global__ void __launch_bounds__(256) k_expand_tiles(const uint16_t *__restrict
   // load, and the wait for it, in every iteration; the stores then leave back to back
   static_assert(KB_XCHUNK_ROWS == 64u, "one lane per row of a chunk");
   const uint32_t lane = threadIdx.x & 63u;
-  const uint32_t myrow = lane < c.count ? order[c.first + lane] : 0u;
+  const uint32_t myrow = lane < c.count ? (order ? order[c.first + lane] : c.first + lane) : 0u;   // (no `order`: the chunk is rows first .. first + count - 1)
   for (uint32_t i = 0; i < c.count; i++) {
     const size_t row = (size_t)(uint32_t)__builtin_amdgcn_readlane((int)myrow, (int)i);
     uint4 *dst = reinterpret_cast<uint4 *>(score + row * NP + node0);
 #pragma unroll
-    for (uint32_t k = 0; k < 8u; k++) { const uint32_t p = threadIdx.x + 256u * k; if (p < n16) KB_XSTORE(&dst[p], v[k]); }
-    if (ml) KB_XSTORE(&reinterpret_cast<uint4 *>(maskw + row * mstride + node0 / 32u)[threadIdx.x], mv);
+    for (uint32_t k = 0; k < 8u; k++) { const uint32_t p = threadIdx.x + 256u * k; if (p < n16) dst[p] = v[k]; }
+    if (ml) reinterpret_cast<uint4 *>(maskw + row * mstride + node0 / 32u)[threadIdx.x] = mv;
   }
 }
 
 void kb_launch_expand(const KbDev &d, const uint16_t *s_score, const uint32_t *s_mask, const uint32_t *row_slot, const uint32_t *order, uint32_t n_rows,
                       uint16_t *score, uint32_t *maskw, void *stream, const KbXChunk *chunks, uint32_t n_chunks) {
   if (n_rows == 0) return;
-  if (chunks && order && n_chunks) {   // NP is a multiple of KB_NODE_PAD = 2048
+  if (chunks && n_chunks) {   // NP is a multiple of KB_NODE_PAD = 2048
     hipLaunchKernelGGL(k_expand_tiles, dim3((d.NP + KB_XTILE_NODES - 1u) / KB_XTILE_NODES, n_chunks), dim3(256), 0, (hipStream_t)stream, s_score, s_mask, order, chunks, d.NP, score, maskw);
     return;
   }

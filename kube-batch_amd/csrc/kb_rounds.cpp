@@ -78,7 +78,7 @@ RoundCtx round_prepare(kb_engine *e, uint32_t n, int fit_mode, bool backfill, bo
   std::memcpy(hw + 2 * KB_K5_MAX_WINDOW, e->h_mrows.data(), sizeof(uint32_t) * c.ns);
   // single-GPU fast rounds: the descriptor gather and the matrix kernel read the staged window straight from the pinned block
   // (a few hundred 4-byte reads over PCIe, overlapped with the matrix evaluation) instead of waiting for a 7 us copy command
-  const bool direct = gather_in_matrix && e->fast_rounds && e->direct_window;
+  const bool direct = gather_in_matrix && e->fast_rounds;   // (the copied window is what the round API and KB_FLAG_SYNC_ROUNDS take: both tested)
   if (!direct) HIP_OK(hipMemcpyAsync(e->b_win.p, hw, sizeof(uint32_t) * (2 * KB_K5_MAX_WINDOW + c.ns), hipMemcpyHostToDevice, e->stream));
   c.d = e->dev;
   if (backfill) {

@@ -168,9 +168,17 @@ void build_host_session(const kb_snapshot *sn, const Policy &pol, uint32_t NP, H
   // shots (the rows of a run then go one by one: one Sub per placement, in order, whatever the values)
   std::atomic<int> fractional{0};
   auto whole_run = [](const double *p, size_t n) {
-    bool ok = true;
-    for (size_t i = 0; i < n; i++) ok = ok && p[i] == std::floor(p[i]) && std::fabs(p[i]) < 140737488355328.0;
-    return ok;
+    // |x| < 2^47 and (|x| + 2^52) - 2^52 == |x|: below 2^52 the sum rounds to a whole number (round-to-nearest), so the difference gives |x| back iff
+    // it was one — no libm call (std::floor is one without SSE4.1), straight-line, vectorisable (the build never contracts or reassociates:
+    // -ffp-contract=off -fno-fast-math); NaN and infinities fail the first compare
+    int bad = 0;
+    for (size_t i = 0; i < n; i++) {
+      const double a = std::fabs(p[i]);
+      const double big = 4503599627370496.0;   // 2^52 (never folded: the build does not reassociate)
+      const double r = (a + big) - big;
+      bad |= !(a < 140737488355328.0) | (r != a);
+    }
+    return bad == 0;
   };
   for (int d = 0; d < R; d++)
     if (!whole_run(sn->node_idle + (size_t)d * N, N) || !whole_run(sn->node_releasing + (size_t)d * N, N)) fractional.store(1, std::memory_order_relaxed);

@@ -12,8 +12,8 @@ of the session.  Per round:
 
 Every replica commits the whole window itself, so the reduced deltas are a CROSS-CHECK, not data the next round waits for.  The default
 (`defer_check=True`) therefore takes that all-reduce off the critical path: round k's buffer (two alternate) is reduced asynchronously — on a
-side stream with RCCL — while round k + 1 is planned and evaluated, and compared one round late on the device (kb_round_check: start of round
-k + deltas == start of round k + 1; a counter read once per action).  `defer_check=False` is the lock-step form above.
+side stream with RCCL — while round k + 1 is planned, evaluated and committed, and compared one round late on the device (kb_round_check, queued
+behind round k + 1's commit: start of round k + deltas == start of round k + 1; a counter read once per action).  `defer_check=False` is the lock-step form above.
 
 preempt / reclaim (BASELINE configs[4] names allocate + backfill + preempt) in this mode: the evict actions are host machines around a few
 device lists (kb_preempt.cpp; 49 ms of host time at 1M x 50k, nothing in them shards), and every replica needs their result — the
@@ -270,12 +270,12 @@ class ShardedCycle:
         k = 0
         while True:
             n_rows, n_mrows, L = b.begin(action)
-            if pending is not None:     # round k - 1's reduced deltas: start of k - 1 + deltas == start of k (or, behind the last round, == the live state)
-                pending[0]()
-                b.check(pending[1], n_rows == 0)
-                self.deferred_checks += 1
-                pending = None
             if n_rows == 0:
+                if pending is not None:     # the last round's reduced deltas: its start + deltas == the live state (the begin that ended the action took no copy)
+                    pending[0]()
+                    b.check(pending[1], True)
+                    self.deferred_checks += 1
+                    pending = None
                 break
             # equal-sized shards of the matrix rows (padded so all_gather_into_tensor applies); the sorted candidate
             # lists are 0-terminated, padding rows stay 0
@@ -300,6 +300,13 @@ class ShardedCycle:
             if self.defer_check:
                 buf = self.delta if (k & 1) == 0 else self.delta2
                 b.commit(table, r0, r1, buf)
+                if pending is not None:
+                    # round k - 1's reduction had THIS round's plan, candidate lists and commit to hide behind (round 5's advisor: completed right
+                    # behind begin() it only overlapped the host's plan): start of k - 1 + deltas == start of k, queued before the next begin
+                    # rotates the two start copies; the other delta buffer is not written again before round k + 1's commit
+                    pending[0]()
+                    b.check(pending[1], False)
+                    self.deferred_checks += 1
                 pending = (self._all_reduce_delta_async(buf), buf)
                 b.apply(None)                   # absorb the round's result; the cross-check follows one round late
             else:

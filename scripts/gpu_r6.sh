@@ -119,21 +119,59 @@ expand)  # the tiled expansion: bench's own event timing (normal run) for the de
     timeout 300 env "${envs[@]}" python bench.py --steps 2 --warmup 1 --no-cpu-baseline "$@" > "$out/x_${name}.json" 2> "$out/x_${name}.err"
     python -c "import json; d=json.loads(open('$out/x_${name}.json').read().strip().splitlines()[-1]); r=d['roofline']; print('$name', r['kernel'], 'frac', r['frac'], 'ms', r['avg_launch_ms'])" | tee -a "$out/summary.txt"
   }
-  nt="KB_ENGINE_LIB=$PWD/kube-batch_amd/libkbengine_nt.so"
-  for rep in 1 2; do
+  base="KB_ENGINE_LIB=$PWD/kube-batch_amd/libkbengine_base.so"   # (here: an earlier build of the tiled kernel, if one is beside the default)
+  for rep in 1 2 3; do
     for cfg in 3 4; do
       one "c${cfg}_tiles_r${rep}" -- --config $cfg
-      one "c${cfg}_nt_r${rep}" $nt -- --config $cfg
+      [ -f kube-batch_amd/libkbengine_base.so ] && one "c${cfg}_base_r${rep}" $base -- --config $cfg
       one "c${cfg}_rowcopy_r${rep}" KB_EXPAND_TILES=0 -- --config $cfg
     done
   done
+  one "c5_tiles" -- --config 5
+  one "c5_rowcopy" KB_EXPAND_TILES=0 -- --config 5
   export TMPDIR=/tmp
   P="$PWD/$out"
-  for v in tiles nt; do
-    envs=(); [ "$v" = nt ] && envs=($nt)
+  for v in tiles; do
+    envs=()
     ( cd /tmp; env "${envs[@]}" rocprofv3 --kernel-trace --stats -f csv -d "$P/trace_$v" -o bench -- python /root/repo/bench.py --steps 2 --warmup 1 --no-cpu-baseline > "$P/trace_$v.log" 2>&1 ) || true
     grep -h "k_expand\|k_matrix<1, 16>" "$P/trace_$v/bench_kernel_stats.csv" 2>/dev/null | cut -c1-140 | tee -a "$out/summary.txt"
     grep -h '"metric"' "$P/trace_$v.log" | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('under rocprofv3 ($v):', d['roofline']['avg_launch_ms'], d['roofline']['frac'])" | tee -a "$out/summary.txt"
+  done
+  ;;
+final)   # the closing evidence on the tree as it stands: the whole -m gpu suite, the rocprofv3 passes summarised ON THE BOX into profiles/round6 (so that the bench
+         # line below quotes them), the default bench with its variants, the single-configuration lines, smoke, a fresh-seed hunt, two gloo ranks on the one GPU
+  timeout 1700 python -m pytest tests -q -m gpu -p no:cacheprovider > "$out/pytest_gpu.txt" 2>&1; echo "gpu suite rc=$? $(tail -1 "$out/pytest_gpu.txt")" | tee -a "$out/summary.txt"
+  grep -h "^FAILED\|^ERROR" "$out/pytest_gpu.txt" | head -20 | tee -a "$out/summary.txt"
+  bash scripts/gpu_r6.sh profile > "$out/profile_step.txt" 2>&1; tail -14 "$out/profile_step.txt" | tee -a "$out/summary.txt"
+  mkdir -p "$out/profiles_round6" && cp -r profiles/round6/. "$out/profiles_round6/"
+  timeout 900 python bench.py > "$out/bench_default.json" 2> "$out/bench_default.err"; echo "bench default rc=$? $(ms "$out/bench_default.json")" | tee -a "$out/summary.txt"
+  python - "$out/bench_default.json" <<'PY' | tee -a "$out/summary.txt"
+import json, sys
+d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+print("value", d["value"], "verified", d.get("verified_bind_set_equals_oracle"), d.get("verified_evals_equal_oracle"), "roofline", d["roofline"]["frac"], "traffic", d["roofline"].get("traffic"), d["roofline"].get("traffic_refused"))
+print("commit counters:", (d["roofline_commit"].get("counters_launch_shape") or d["roofline_commit"].get("counters_refused")))
+for k, v in d.get("variants", {}).items():
+    print(" variant", k, v["ms_per_step"], v["verified"], (v.get("roofline") or {}).get("frac"), v.get("evals_per_s"))
+print("loads", d.get("session_load_ms_samples"))
+PY
+  bench_ab survey_nodes -- --config 3 --survey-nodes --steps 5 --warmup 2 --verify
+  bench_ab config4 -- --config 4 --steps 5 --warmup 2 --verify
+  bench_ab config2 -- --config 2 --steps 10 --warmup 3 --verify
+  bench_ab config5 -- --config 5 --steps 3 --warmup 1 --verify
+  KB_EVICT_TRACE=1 bench_ab config5_preempt -- --config 5 --preempt --steps 2 --warmup 1 --verify
+  grep -h "kb evict" "$out/bench_config5_preempt.err" | tail -2 | tee -a "$out/summary.txt"
+  timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -1 | tee -a "$out/summary.txt"
+  KB_HUNT_OFFSET=${KB_HUNT_OFFSET:-80000} timeout 600 python scripts/gpu_hunt.py ${HUNT_ARGS:-200 600 300} > "$out/hunt.txt" 2>&1; echo "fresh-seed hunt (both kernels) rc=$? $(tail -1 "$out/hunt.txt")" | tee -a "$out/summary.txt"
+  KB_SCALE_GLOO=1 timeout 900 bash scripts/scale_curve.sh "$out/scale" 3 > "$out/scale_curve_log.txt" 2>&1; cat "$out/scale/scale_curve.txt" | tee -a "$out/summary.txt"
+  ;;
+variants)  # same-box A/B of builds of the selection kernel: kube-batch_amd/libkbengine_<tag>.so beside the default one, alternating, each verified:   variants tag,tag,... [configs...]
+  IFS=',' read -r -a tags <<< "${1:-prio}"; shift || true
+  if [ $# -eq 0 ]; then set -- 3 4 survey; fi
+  for rep in 1 2; do
+    for c in "$@"; do
+      bench_ab "c${c}_default_r${rep}" -- $(cfg_args $c) --verify
+      for t in "${tags[@]}"; do bench_ab "c${c}_${t}_r${rep}" KB_ENGINE_LIB=$PWD/kube-batch_amd/libkbengine_$t.so -- $(cfg_args $c) --verify; done
+    done
   done
   ;;
 subset)

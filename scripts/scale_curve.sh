@@ -48,7 +48,7 @@ else:
     ok = ok and d.get("dist_backend") == want and sh["dist_backend"] == want and sh["ranks"] == n and (gloo or sh["ranks_seen_by_rccl"] == n)
     ok = ok and sh["verified"] is True and se["verified"] is True and d["scaling"] == "strong" and d["value"] == sh["value"]
     print(f"N={n} sharded : value {sh['value']:.4g} evals/s, {sh['ms_per_step']:.2f} ms/step, rounds {sh['rounds_per_step']}, breaks {sh['spec_breaks_per_step']}, "
-          f"all-gather {sh['allgather_us_per_round']} us/round ({sh['rounds_that_exchanged_lists']} rounds), all-reduce {sh['allreduce_us_per_round']} us/round, backend {sh['dist_backend']}, verified {sh['verified']}")
+          f"all-gather {sh['allgather_us_per_round']} us/round ({sh['rounds_that_exchanged_lists_per_step']} rounds per step), all-reduce {sh['allreduce_us_per_round']} us/round, backend {sh['dist_backend']}, verified {sh['verified']}")
     print(f"N={n} sessions: value {se['value']:.4g} evals/s per session, {se['ms_per_step']:.2f} ms/step, aggregate {se['aggregate_evals_per_s']:.4g}, verified {se['verified']}, {'ok' if ok else 'CHECK FAILED'}")
 sys.exit(0 if ok else 1)
 PY

@@ -627,13 +627,13 @@ void kb_launch_repair(const KbDev &d, const KbRound &r, void *stream) {
 
 void kb_launch_expand(const KbDev &d, const uint16_t *s_score, const uint32_t *s_mask, const uint32_t *row_slot, const uint32_t *order, uint32_t n_rows,
                       uint16_t *score, uint32_t *maskw, void *stream, const KbXChunk *chunks, uint32_t n_chunks) {
-  if (chunks) {   // the chunk table's contract: the chunks tile `order` exactly, every row of a chunk has the chunk's shape (the kernel takes the shape from the chunk)
+  if (chunks) {   // the chunk table's contract: the chunks tile `order` (or, without it, the rows) exactly, every row of a chunk has the chunk's shape (the kernel takes the shape from the chunk)
     kbemu_enqueue((hipStream_t)stream, [row_slot, order, n_rows, chunks, n_chunks]() {
       uint32_t at = 0;
       for (uint32_t c = 0; c < n_chunks; c++) {
         if (chunks[c].first != at || chunks[c].count == 0 || chunks[c].count > KB_XCHUNK_ROWS) abort();
         for (uint32_t i = 0; i < chunks[c].count; i++)
-          if (row_slot[order[at + i]] != chunks[c].slot) abort();
+          if (row_slot[order ? order[at + i] : at + i] != chunks[c].slot) abort();   // (no `order`: the chunks tile the rows themselves)
         at += chunks[c].count;
       }
       if (at != n_rows) abort();

@@ -127,9 +127,9 @@ def test_two_ranks_under_torch_distributed_run_print_one_line(tmp_path):
     assert sh["verified"] is True and sh["scaling"] == "strong" and sh["dist_backend"] == "gloo" and sh["ranks"] == 2 and sh["ranks_seen_by_rccl"] == 0
     assert sh["value"] == d["value"] and abs(sh["ms_per_step"] - d["ms_per_step"]) < 1e-9 and sh["rounds_per_step"] > 0
     assert abs(d["value"] - d["evals_per_step"] / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"]       # the split's rate: ONE session's evaluations over the job's time
-    assert sh["allreduce_us_per_round"] > 0 and sh["deferred_delta_checks"] > 0
-    assert sh["rounds_that_exchanged_lists"] + sh["rounds_every_rank_evaluated_alone"] >= sh["rounds_per_step"]
-    assert (sh["allgather_us_per_round"] is None) == (sh["rounds_that_exchanged_lists"] == 0)
+    assert sh["allreduce_us_per_round"] > 0 and sh["deferred_delta_checks_per_step"] > 0
+    assert abs(sh["rounds_that_exchanged_lists_per_step"] + sh["rounds_every_rank_evaluated_alone_per_step"] - sh["rounds_per_step"]) < 1e-9      # a round either exchanges its lists or every rank builds them all
+    assert (sh["allgather_us_per_round"] is None) == (sh["rounds_that_exchanged_lists_per_step"] == 0)
     assert se["verified"] is True and se["scaling"] == "weak" and se["value"] > 0
     # sessions: one session's rate (the slowest rank's), never the ranks' sum; the sum is the aggregate
     assert se["aggregate_evals_per_s"] >= 1.5 * se["value"] and abs(se["sessions_per_s"] - 2 * 2 / (se["ms_per_step"] * 2e-3)) <= 1e-6 * se["sessions_per_s"]

@@ -23,8 +23,10 @@ pytestmark = [pytest.mark.gpu]
 
 
 # ---- every launch-path variant of the host protocol gives the same cycle ------------------------------------------------------
-_VARIANTS = [{}, {"KB_CHAIN_ROUNDS": "0"}, {"KB_SYNC_ROUNDS": "1"}, {"KB_PROBE": "0"}, {"KB_DIRECT_WINDOW": "0"},
-             {"KB_COMMIT_KERNEL": "run"}, {"KB_COMMIT_KERNEL": "select"}, {"KB_CHAIN_ROUNDS": "0", "KB_PROBE": "0", "KB_DIRECT_WINDOW": "0"},
+_VARIANTS = [{}, {"KB_CHAIN_ROUNDS": "0"}, {"KB_PROBE": "0"},
+             {"KB_COMMIT_KERNEL": "run"}, {"KB_COMMIT_KERNEL": "select"}, {"KB_CHAIN_ROUNDS": "0", "KB_PROBE": "0"},
+             # (round 6: the environment switches KB_SYNC_ROUNDS and KB_DIRECT_WINDOW are gone — kb_config.flags & KB_FLAG_SYNC_ROUNDS is the former,
+             #  run by tests/test_gpu_parity.py, and the copied window is what that flag and the round API of the task-row split take)
              # round 3: chained rounds build their candidate lists on a second stream beside the predecessor's commit and repair them
              # (the default, variant 0); KB_OVERLAP=0 keeps every round on one stream
              {"KB_OVERLAP": "0"}, {"KB_OVERLAP": "0", "KB_COMMIT_KERNEL": "run"},
