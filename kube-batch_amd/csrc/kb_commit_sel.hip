@@ -165,10 +165,12 @@ __global__ void __launch_bounds__(K9_THREADS) k_commit_select(const K9KernArgs k
 #define KB_K9_NAP_PREP 1u
 #endif
   constexpr uint32_t nap_prep = KB_K9_NAP_PREP, nap_dk = 1u;
-  // issue priority (-DKB_K9_PRIO=1, an A/B build): waves that share a SIMD — wave w and wave w + 4 — and the CU's one scalar unit are arbitrated by
-  // priority, then age (MI355X_MICROARCH.md).  Wave 0 is the pipeline's critical path, the evaluating waves are what it waits for, the preparing waves
-  // work two runs ahead
-#if defined(KB_K9_PRIO) && KB_K9_PRIO
+  // issue priority: waves that share a SIMD — wave w and wave w + 4 — and the CU's one scalar unit are arbitrated by priority, then age
+  // (MI355X_MICROARCH.md).  Wave 0 is the pipeline's critical path (3), the evaluating waves are what it waits for (2), the preparing waves work two
+  // runs ahead (0).  Measured on one box, two runs each (profiles/round6/call11_issue_priority/): 100k x 10k 39.36 / 39.40 ms against 39.82 / 39.73,
+  // survey nodes 54.66 / 55.00 against 55.11 / 55.49, R = 16 unchanged; a longer sleep of the preparing waves (KB_K9_NAP_PREP=2) gave nothing.
+  // -DKB_K9_PRIO=0 builds without it
+#if !defined(KB_K9_PRIO) || KB_K9_PRIO
 #define K9S_SETPRIO(p) __builtin_amdgcn_s_setprio(p)
 #else
 #define K9S_SETPRIO(p) do { } while (0)

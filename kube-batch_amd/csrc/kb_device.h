@@ -248,7 +248,9 @@ size_t kb_repair_smem_bytes(uint32_t NP);   // its dynamic LDS (<= 150 KiB or th
 // each — a workgroup then loads its tile of the shape row (up to 16 384 nodes) ONCE and stores it to every row of its chunk (round 6: the source is read
 // ~n_rows / KB_XCHUNK_ROWS times instead of n_rows times; k_expand re-fetched a few MB of shape rows through eight L2s 226 MB worth per launch)
 struct KbXChunk { uint32_t slot, first, count, pad; };
-#define KB_XCHUNK_ROWS 64u
+#ifndef KB_XCHUNK_ROWS
+#define KB_XCHUNK_ROWS 64u   // at most 64: one lane of a wave per row of a chunk
+#endif
 void kb_launch_expand(const KbDev &d, const uint16_t *s_score, const uint32_t *s_mask, const uint32_t *row_slot, const uint32_t *order, uint32_t n_rows,
                       uint16_t *score, uint32_t *maskw, void *stream, const KbXChunk *chunks = nullptr, uint32_t n_chunks = 0);
 void kb_launch_commit(const KbDev &d, const KbRound &r, void *stream);         // KB_COMMIT_RUN

@@ -796,7 +796,7 @@ __global__ void __launch_bounds__(256) k_expand_tiles(const uint16_t *__restrict
   if (ml) mv = reinterpret_cast<const uint4 *>(s_mask + (size_t)c.slot * mstride + node0 / 32u)[threadIdx.x];
   // the chunk's rows: lane i of every wave holds row i (KB_XCHUNK_ROWS = 64 = a wave) — one vector load in front of the loop instead of a scalar
   // load, and the wait for it, in every iteration; the stores then leave back to back
-  static_assert(KB_XCHUNK_ROWS == 64u, "one lane per row of a chunk");
+  static_assert(KB_XCHUNK_ROWS <= 64u, "one lane per row of a chunk");
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t myrow = lane < c.count ? (order ? order[c.first + lane] : c.first + lane) : 0u;   // (no `order`: the chunk is rows first .. first + count - 1)
   for (uint32_t i = 0; i < c.count; i++) {

@@ -174,6 +174,20 @@ variants)  # same-box A/B of builds of the selection kernel: kube-batch_amd/libk
     done
   done
   ;;
+xchunk)  # rows per chunk of the tiled expansion: the default build (64) against libkbengine_x8.so / _x16.so and the row copy, configs 3 and 4, three times each
+  one() { local name="$1"; shift; local envs=(); while [ "$1" != "--" ]; do envs+=("$1"); shift; done; shift
+    timeout 300 env "${envs[@]}" python bench.py --steps 2 --warmup 1 --no-cpu-baseline "$@" > "$out/x_${name}.json" 2> "$out/x_${name}.err"
+    python -c "import json; d=json.loads(open('$out/x_${name}.json').read().strip().splitlines()[-1]); r=d['roofline']; print('$name', 'frac', r['frac'], 'ms', r['avg_launch_ms'])" | tee -a "$out/summary.txt"; }
+  for rep in 1 2 3; do
+    for cfg in 3 4; do
+      one "c${cfg}_x64_r${rep}" -- --config $cfg
+      one "c${cfg}_x16_r${rep}" KB_ENGINE_LIB=$PWD/kube-batch_amd/libkbengine_x16.so -- --config $cfg
+      one "c${cfg}_x8_r${rep}" KB_ENGINE_LIB=$PWD/kube-batch_amd/libkbengine_x8.so -- --config $cfg
+      one "c${cfg}_rowcopy_r${rep}" KB_EXPAND_TILES=0 -- --config $cfg
+    done
+  done
+  trace_cfgs 3
+  ;;
 subset)
   timeout 1200 python -m pytest tests/test_gpu_parity.py tests/test_gpu_adversarial.py tests/test_gpu_regressions.py tests/test_gpu_fuzz.py tests/test_gpu_fullsize.py tests/test_gpu_reload.py tests/test_gpu_interpod.py \
     -q -m gpu -p no:cacheprovider --maxfail=10 > "$out/pytest_subset.txt" 2>&1; echo "differential modules, both commit kernels rc=$? $(tail -1 "$out/pytest_subset.txt")" | tee -a "$out/summary.txt"
