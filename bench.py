@@ -212,9 +212,23 @@ def main():
             snap = kbm.snapshot.synth(params)
         if dist_mode == "sessions":
             rank_digest_expected = golden_ranks.get(str(rank))
+        sharded_setup_error = None
         if dist_mode == "sharded":
-            runner = distmod.ShardedCycle(conf, snap, device=local_rank, window=args.window, commit_batch=args.commit_batch, actions=actions)
-        else:
+            # The split's set-up (its streams, the engine on torch's stream, one whole cycle with its collectives) has only ever run at world size
+            # <= 2 (no multi-GPU node was available to any round): if it fails HERE — symmetric failures: every rank runs the same code on the same
+            # session — the line still carries the sessions mode's figures as its value, and `sharded` says what went wrong
+            try:
+                runner = distmod.ShardedCycle(conf, snap, device=local_rank, window=args.window, commit_batch=args.commit_batch, actions=actions)
+                runner.step()
+            except Exception as err:     # noqa: BLE001 — whatever it is, it is reported in the line
+                sharded_setup_error = f"{type(err).__name__}: {err}"
+                print(f"bench.py: rank {rank}: the task-row split failed during set-up ({sharded_setup_error}); reporting the sessions mode", file=sys.stderr)
+                dist_mode = "sessions"
+                if rank > 0:
+                    import dataclasses
+                    snap = kbm.snapshot.synth(dataclasses.replace(params, seed=params.seed + RANK_SEED_STRIDE * rank))
+                rank_digest_expected = golden_ranks.get(str(rank))
+        if dist_mode != "sharded":
             runner = distmod.ReplicatedCycle(conf, snap, device=local_rank, window=args.window, commit_batch=args.commit_batch, actions=actions)
         step = (lambda: runner.step(verify=False)) if dist_mode != "sharded" else runner.step
         eng = runner.engine
@@ -494,7 +508,8 @@ def main():
                                                           "replicas": "the same session on every GPU (KB_DIST_MODE=replicas), digests compared; value = one session's rate",
                                                           "sharded": "north_star's task-row split of ONE session (value, ms_per_step, scaling are its figures)"
                                                                      + ("; the sessions mode of the same invocation under `sessions`" if sessions_block else "")}[dist_mode],
-        "sharded": sharded_block, "sessions": sessions_block,
+        "sharded": sharded_block if sharded_block is not None else ({"error": sharded_setup_error, "verified": None} if (world > 1 or force_sharded) and sharded_setup_error else None),
+        "sessions": sessions_block,
         "dist_backend": None if dist_mode is None else dist.get_backend(),   # "nccl" = RCCL: what carried the N ranks (scripts/scale_curve.sh asserts it)
         "replicas_agree": replicas_agree, "sessions_verified_against_golden_digests": sessions_verified,
         **(aggregate or {}),

@@ -12,7 +12,6 @@ struct ChunkPlan {
   KbRound rs{};       // the per-shape launch
   uint32_t ns = 0;
   uint32_t n_xchunks = 0;   // chunks of the tiled expansion (kb_device.h: KbXChunk)
-  bool x_by_shape = false;  // ... over the rows in shape order (else: over consecutive task rows)
   bool direct = false;   // evaluate every task row itself (no per-shape rows, no expansion)
 };
 static ChunkPlan matrix_plan(kb_engine *e, uint32_t t0, uint32_t n, uint32_t fit_flags, uint32_t k) {
@@ -58,23 +57,13 @@ static ChunkPlan matrix_plan(kb_engine *e, uint32_t t0, uint32_t n, uint32_t fit
     for (uint32_t sidx = 0; sidx < p.ns; sidx++) start[sidx + 1] += start[sidx];
     for (uint32_t i = 0; i < n; i++) e->h_xorder[start[e->h_slot[i]]++] = i;
     HIP_OK(hipMemcpyAsync(e->b_xorder.p, e->h_xorder.data(), sizeof(uint32_t) * n, hipMemcpyHostToDevice, e->stream));
-    // ... and the chunk table of the tiled expansion: stretches of one shape, KB_XCHUNK_ROWS rows at most.  While the shape rows fit the L2s (by_shape
-    // below is false) the chunks are stretches of CONSECUTIVE task rows — the tasks of a job are adjacent and share a shape —, so that the launch
-    // writes the matrix front to back like a plain copy and reads a shape row's tile once per stretch (out of the L2); when they do not, the chunks are
-    // stretches of `order` (start[s] is now the END of shape s's stretch there): a shape row comes from HBM once per 64 of its task rows
+    // ... and the chunk table of the tiled expansion: stretches of `order` that share a shape, KB_XCHUNK_ROWS rows at most (start[s] is now the END of
+    // shape s's stretch): a shape row's tile comes from memory once per 64 of its task rows.  (Chunks of CONSECUTIVE task rows — the tasks of a job are
+    // adjacent and share a shape, the matrix is then written front to back — measured no faster and read more: 0.447 - 0.451 ms and 1.11 x the algorithmic
+    // bytes against 0.438 - 0.446 and 1.04 x at 100k x 10k, profiles/round6/call10_expand_row_order_chunks/, call14_profile_final/.)
     e->h_xchunks.clear();
-    p.x_by_shape = (size_t)p.ns * NP * 2 > (16u << 20);
-    if (p.x_by_shape) {
-      for (uint32_t sidx = 0, at = 0; sidx < p.ns; sidx++)
-        while (at < start[sidx]) { const uint32_t cnt = std::min<uint32_t>(KB_XCHUNK_ROWS, start[sidx] - at); e->h_xchunks.push_back(KbXChunk{sidx, at, cnt, 0u}); at += cnt; }
-    } else {
-      for (uint32_t at = 0; at < n;) {
-        uint32_t cnt = 1;
-        while (cnt < KB_XCHUNK_ROWS && at + cnt < n && e->h_slot[at + cnt] == e->h_slot[at]) cnt++;
-        e->h_xchunks.push_back(KbXChunk{e->h_slot[at], at, cnt, 0u});
-        at += cnt;
-      }
-    }
+    for (uint32_t sidx = 0, at = 0; sidx < p.ns; sidx++)
+      while (at < start[sidx]) { const uint32_t cnt = std::min<uint32_t>(KB_XCHUNK_ROWS, start[sidx] - at); e->h_xchunks.push_back(KbXChunk{sidx, at, cnt, 0u}); at += cnt; }
     e->b_xchunks.alloc(sizeof(KbXChunk) * std::max<size_t>(e->h_xchunks.size(), 1));
     HIP_OK(hipMemcpyAsync(e->b_xchunks.p, e->h_xchunks.data(), sizeof(KbXChunk) * e->h_xchunks.size(), hipMemcpyHostToDevice, e->stream));
     p.n_xchunks = (uint32_t)e->h_xchunks.size();
@@ -108,7 +97,7 @@ static void matrix_launch(kb_engine *e, const ChunkPlan &p, uint32_t n, uint32_t
   // round 5's row-per-workgroup copy (the A/B switch of the traffic measurement)
   static const bool tiles = [] { const char *v = getenv("KB_EXPAND_TILES"); return !(v && v[0] == '0'); }();
   const bool by_shape = (size_t)p.ns * e->dev.NP * 2 > (16u << 20);
-  if (tiles) kb_launch_expand(e->dev, p.rs.score, p.rs.maskw, e->b_xslot.as<uint32_t>(), p.x_by_shape ? e->b_xorder.as<uint32_t>() : nullptr, n, p.r.score, p.r.maskw, e->stream, e->b_xchunks.as<KbXChunk>(), p.n_xchunks);
+  if (tiles) kb_launch_expand(e->dev, p.rs.score, p.rs.maskw, e->b_xslot.as<uint32_t>(), e->b_xorder.as<uint32_t>(), n, p.r.score, p.r.maskw, e->stream, e->b_xchunks.as<KbXChunk>(), p.n_xchunks);
   else kb_launch_expand(e->dev, p.rs.score, p.rs.maskw, e->b_xslot.as<uint32_t>(), by_shape ? e->b_xorder.as<uint32_t>() : nullptr, n, p.r.score, p.r.maskw, e->stream);
   if (k) kb_launch_argmax(e->dev, p.r, e->stream);
 }

@@ -142,7 +142,7 @@ final)   # the closing evidence on the tree as it stands: the whole -m gpu suite
          # line below quotes them), the default bench with its variants, the single-configuration lines, smoke, a fresh-seed hunt, two gloo ranks on the one GPU
   timeout 1700 python -m pytest tests -q -m gpu -p no:cacheprovider > "$out/pytest_gpu.txt" 2>&1; echo "gpu suite rc=$? $(tail -1 "$out/pytest_gpu.txt")" | tee -a "$out/summary.txt"
   grep -h "^FAILED\|^ERROR" "$out/pytest_gpu.txt" | head -20 | tee -a "$out/summary.txt"
-  bash scripts/gpu_r6.sh profile > "$out/profile_step.txt" 2>&1; tail -14 "$out/profile_step.txt" | tee -a "$out/summary.txt"
+  R6_TAG= bash scripts/gpu_r6.sh profile > "$out/profile_step.txt" 2>&1; tail -14 "$out/profile_step.txt" | tee -a "$out/summary.txt"
   mkdir -p "$out/profiles_round6" && cp -r profiles/round6/. "$out/profiles_round6/"
   timeout 900 python bench.py > "$out/bench_default.json" 2> "$out/bench_default.err"; echo "bench default rc=$? $(ms "$out/bench_default.json")" | tee -a "$out/summary.txt"
   python - "$out/bench_default.json" <<'PY' | tee -a "$out/summary.txt"
@@ -187,6 +187,20 @@ xchunk)  # rows per chunk of the tiled expansion: the default build (64) against
     done
   done
   trace_cfgs 3
+  ;;
+profile_bench)  # the profile passes (summarised on the box into profiles/round6), then the default bench line, which quotes them
+  R6_TAG= bash scripts/gpu_r6.sh profile > "$out/profile_step.txt" 2>&1; tail -14 "$out/profile_step.txt" | tee -a "$out/summary.txt"
+  mkdir -p "$out/profiles_round6" && cp -r profiles/round6/. "$out/profiles_round6/"
+  timeout 900 python bench.py > "$out/bench_default.json" 2> "$out/bench_default.err"; echo "bench default rc=$? $(ms "$out/bench_default.json")" | tee -a "$out/summary.txt"
+  python - "$out/bench_default.json" <<'PY' | tee -a "$out/summary.txt"
+import json, sys
+d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+print("value", d["value"], "verified", d.get("verified_bind_set_equals_oracle"), d.get("verified_evals_equal_oracle"), "roofline", d["roofline"]["frac"], "traffic", d["roofline"].get("traffic"), d["roofline"].get("traffic_refused"))
+print("commit counters:", (d["roofline_commit"].get("counters_launch_shape") or d["roofline_commit"].get("counters_refused")))
+for k, v in d.get("variants", {}).items():
+    print(" variant", k, v["ms_per_step"], v["verified"], (v.get("roofline") or {}).get("frac"), v.get("evals_per_s"))
+print("loads", d.get("session_load_ms_samples"))
+PY
   ;;
 subset)
   timeout 1200 python -m pytest tests/test_gpu_parity.py tests/test_gpu_adversarial.py tests/test_gpu_regressions.py tests/test_gpu_fuzz.py tests/test_gpu_fullsize.py tests/test_gpu_reload.py tests/test_gpu_interpod.py \

@@ -27,6 +27,8 @@ _ShardedCycle = distmod.ShardedCycle
 
 class _EmulatedShardedCycle(_ShardedCycle):
     def __init__(self, conf, snap, device=0, window=0, commit_batch=0, actions=("allocate", "backfill"), **kw):
+        if os.environ.get("KB_EMU_BREAK_SHARDED") == "1":      # tests/test_bench_cpu.py: what bench.py prints when the split cannot be set up
+            raise RuntimeError("the task-row split is broken on purpose")
         eng = engine.Engine(conf, device=device, window=window, commit_batch=commit_batch)
         eng.load(snap)
         cpu = torch.device("cpu")

@@ -175,3 +175,26 @@ def test_two_identical_replicas_still_agree(tmp_path):
     d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
     assert d["replicas_agree"] is True and d["multi_gpu_mode"].startswith("the same session on every GPU")
     assert abs(d["value"] - d["evals_per_step"] / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"]
+
+
+def test_two_ranks_when_the_split_cannot_be_set_up(tmp_path):
+    """The task-row split has never run on more than one GPU (no such node was available): if its set-up fails on the driver's 8-GPU box, the line still
+    carries the sessions mode — verified, "weak", its rate as `value` — and `sharded.error` says what went wrong; the exit code stays 0."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, KB_EMU_LIB=emu.build_emulated_library(), KB_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1", KB_EMU_BREAK_SHARDED="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "KB_DIST_MODE"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(HERE, "host_harness", "bench_emu_launcher.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--scale", "0.02"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=os.path.dirname(HERE))
+    assert r.returncode == 0, r.stdout + r.stderr
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0
+    assert "broken on purpose" in d["sharded"]["error"] and d["sharded"]["verified"] is None
+    assert d["sessions"]["verified"] is True and d["sessions_verified_against_golden_digests"] is True
+    assert d["multi_gpu_mode"].startswith("one independent session per GPU")
