@@ -202,6 +202,23 @@ for k, v in d.get("variants", {}).items():
 print("loads", d.get("session_load_ms_samples"))
 PY
   ;;
+pmc_matrix)  # the matrix launches' HBM bytes and the kernel stats again after a change that left the commit kernels' translation unit alone (host side of the
+             # expansion, kb_kernels.hip): FETCH_SIZE, WRITE_SIZE, kernel trace; summarised on the box (the commit kernel's lines of profiles/round6 stay)
+  export TMPDIR=/tmp
+  CMD="python $PWD/bench.py --steps 2 --warmup 1 --no-cpu-baseline"
+  P="$PWD/gpurun_out/r6_profile"; mkdir -p "$P"
+  python scripts/kernel_sources_sha.py > "$P/kernel_sources.sha256"; python scripts/kernel_sources_sha.py --tu > "$P/kernel_tu.sha256"
+  ( cd /tmp
+    rocprofv3 --pmc FETCH_SIZE -f csv --kernel-include-regex "k_matrix|k_expand" -d "$P/pmc_fetch" -o bench -- $CMD > "$P/bench_pmc_fetch.log" 2>&1
+    rocprofv3 --pmc WRITE_SIZE -f csv --kernel-include-regex "k_matrix|k_expand" -d "$P/pmc_write" -o bench -- $CMD > "$P/bench_pmc_write.log" 2>&1
+    rocprofv3 --kernel-trace --stats -f csv -d "$P/trace" -o bench -- $CMD > "$P/bench_trace.log" 2>&1
+  )
+  python scripts/summarize_profile.py r6_profile profiles/round6 2>&1 | tail -2 | tee -a "$out/summary.txt"
+  mkdir -p "$out/profiles_round6" && cp -r profiles/round6/rocprofv3_* profiles/round6/kernel_* profiles/round6/bench_under_rocprofv3_kernel_trace.json "$out/profiles_round6/"
+  cat profiles/round6/rocprofv3_pmc_k_matrix.csv | cut -c1-150 | tee -a "$out/summary.txt"
+  timeout 600 python bench.py --no-cpu-baseline --verify > "$out/bench_c3.json" 2> "$out/bench_c3.err"
+  python -c "import json; d=json.loads(open('$out/bench_c3.json').read().strip().splitlines()[-1]); r=d['roofline']; print('bench: ms', d['ms_per_step'], 'verified', d.get('verified_bind_set_equals_oracle'), 'roofline', r['frac'], r['avg_launch_ms'], 'traffic', r.get('traffic'), r.get('traffic_refused'), 'ratio', (r.get('traffic') or 0) / r['bytes_per_launch'])" | tee -a "$out/summary.txt"
+  ;;
 subset)
   timeout 1200 python -m pytest tests/test_gpu_parity.py tests/test_gpu_adversarial.py tests/test_gpu_regressions.py tests/test_gpu_fuzz.py tests/test_gpu_fullsize.py tests/test_gpu_reload.py tests/test_gpu_interpod.py \
     -q -m gpu -p no:cacheprovider --maxfail=10 > "$out/pytest_subset.txt" 2>&1; echo "differential modules, both commit kernels rc=$? $(tail -1 "$out/pytest_subset.txt")" | tee -a "$out/summary.txt"
