@@ -363,10 +363,23 @@ __global__ void __launch_bounds__(K9_THREADS) k_commit_select(const K9KernArgs k
               rk += (q0_.x > myk ? 1u : 0u) + (q0_.y > myk ? 1u : 0u) + (q0_.z > myk ? 1u : 0u) + (q0_.w > myk ? 1u : 0u);
               rk += (q1_.x > myk ? 1u : 0u) + (q1_.y > myk ? 1u : 0u) + (q1_.z > myk ? 1u : 0u) + (q1_.w > myk ? 1u : 0u);
             }
-            if (lane_i < nC && rk < rem) X.c_sorted[rk] = X.c_slot[lane_i];
-            if (nC > rem) {
-              thr = rl32(myk, (uint32_t)__ffsll((unsigned long long)__ballot(lane_i < nC && rk == rem - 1u)) - 1u);
-              nC = rem;
+            // A packing session (a.wM > a.wL) keeps ten at most: its winners are few and take many rows each, so ten contenders with deeper tables (the two
+            // best sixteen entries, the others four) resolve more rows per shot than rem contenders with two — BASELINE configs[3], shots per cycle: cap 6
+            // 8 715, 8 8 135, 10 7 790, 12 7 813, none 9 106; 58.0 - 60.1 ms against 62.4 - 64.8 on that box (profiles/round6/call18_19_contender_cap/).
+            // Every other session keeps sixteen at most (four entries each instead of two for seventeen and more): 100k x 10k 11 473 shots per five cycles against
+            // 12 887 (cap 12: 13 566, 20: 13 363), survey nodes 27 111 against 34 398 and 51.8 - 52.1 ms against 54.6 - 54.8 (call20_21_contender_cap_every_session/).
+            // -DKB_K9_PACK_CAP=n / -DKB_K9_SPREAD_CAP=n are the A/B builds
+#ifndef KB_K9_PACK_CAP
+#define KB_K9_PACK_CAP 10u
+#endif
+#ifndef KB_K9_SPREAD_CAP
+#define KB_K9_SPREAD_CAP 16u
+#endif
+            const uint32_t keep = min(rem, (a.wM > a.wL) ? (uint32_t)KB_K9_PACK_CAP : (uint32_t)KB_K9_SPREAD_CAP);
+            if (lane_i < nC && rk < keep) X.c_sorted[rk] = X.c_slot[lane_i];
+            if (nC > keep) {
+              thr = rl32(myk, (uint32_t)__ffsll((unsigned long long)__ballot(lane_i < nC && rk == keep - 1u)) - 1u);
+              nC = keep;
             }
             K9_WAVE_FENCE();
           }
@@ -374,20 +387,26 @@ __global__ void __launch_bounds__(K9_THREADS) k_commit_select(const K9KernArgs k
           //    entries: under MostRequested the node just used wins until it is full, most_requested.go:34-61), the others share lanes 16 .. 63 — wherever
           //    that costs them nothing (their D is what the uniform layout gives them) or the session packs (a.wM > a.wL)
           uint32_t lgD = nC <= 2u ? 5u : (nC <= 4u ? 4u : (nC <= 8u ? 3u : (nC <= 16u ? 2u : 1u)));
-          bool deep = false;
+          uint32_t ndeep = 0u;   // contenders 0 .. ndeep - 1 (the best ones: they are numbered by key) get sixteen entries each
           if (nC >= 5u && nC <= 25u) {
             const uint32_t o_ = nC - 1u, lgO = o_ <= 6u ? 3u : (o_ <= 12u ? 2u : 1u);   // 48 lanes for the others
-            if (lgO == lgD || a.wM > a.wL) { deep = true; lgD = lgO; }
+            if (lgO == lgD || a.wM > a.wL) { ndeep = 1u; lgD = lgO; }
           }
-          const uint32_t D = 1u << lgD;
+#if !defined(KB_K9_DEEP2) || KB_K9_DEEP2
+          if (a.wM > a.wL && ((nC >= 5u && nC <= 10u) || (nC >= 14u && nC <= 18u))) {   // a packing session: the best TWO (BASELINE configs[3]: 61.6 / 62.1 -> 60.3 / 60.8 ms,
+                                                                                          // 6 % fewer shots; profiles/round6/call17_last_row_and_two_deep_tables/; -DKB_K9_DEEP2=0 builds without)
+            const uint32_t o_ = nC - 2u;                                                  // 32 lanes for the others, never fewer entries each than with one deep table
+            ndeep = 2u; lgD = o_ <= 2u ? 4u : (o_ <= 4u ? 3u : (o_ <= 8u ? 2u : 1u));
+          }
+#endif
+          const uint32_t D = 1u << lgD, dl = 16u * ndeep;   // dl: the deep tables' lanes
           K9_STAMP(5);
           // -- the table: contender tg's entry tu (its key after tu further placements); gst: the first lane of my contender, Dg: its entries
           uint32_t tg, tu, gst, Dg;
-          if (deep && lane_i < 16u) { tg = 0u; tu = lane_i; gst = 0u; Dg = 16u; }
-          else if (deep) { const uint32_t l_ = lane_i - 16u; tg = 1u + (l_ >> lgD); tu = l_ & (D - 1u); gst = lane_i - tu; Dg = D; }
-          else { tg = lane_i >> lgD; tu = lane_i & (D - 1u); gst = lane_i - tu; Dg = D; }
+          if (lane_i < dl) { tg = lane_i >> 4; tu = lane_i & 15u; gst = lane_i & ~15u; Dg = 16u; }
+          else { const uint32_t l_ = lane_i - dl; tg = ndeep + (l_ >> lgD); tu = l_ & (D - 1u); gst = lane_i - tu; Dg = D; }
           const bool act = tg < nC;
-          const uint32_t n_e = deep ? 16u + ((nC - 1u) << lgD) : (nC << lgD);   // lanes in use
+          const uint32_t n_e = dl + ((nC - ndeep) << lgD);   // lanes in use
           uint32_t key = 0u, kind = 0u, tnode = 0u;
           if (act) {
             const uint32_t cs = X.c_sorted[tg], slot = cs & 0x7FFFFFFFu, b = cs >> 31;
@@ -446,7 +465,8 @@ __global__ void __launch_bounds__(K9_THREADS) k_commit_select(const K9KernArgs k
           uint32_t cutv = 0xFFFFu;
           if (valid) {
             if (eff < thr) cutv = rank;                          // somebody outside the table may come first
-            else if (tu == Dg - 1u && kind == 0u) cutv = rank;    // the table ends here, the sequence may not: the next shot
+            else if (tu == Dg - 1u && kind == 0u && rank + 1u < rem) cutv = rank;   // the table ends here, the sequence may not: the next shot — unless this
+                                                                                    // is the run's last row: nobody asks for the contender's key behind it
             else if (kind != 0u) cutv = rank + 1u;                // a Pipeline ends the round behind its row
           }
           const uint32_t cut_at = 0xFFFFu - wave_max_u32(0xFFFFu - cutv);
@@ -458,12 +478,12 @@ __global__ void __launch_bounds__(K9_THREADS) k_commit_select(const K9KernArgs k
           const unsigned long long pb = __ballot(picked), ppipe = __ballot(picked && kind != 0u);
           const bool pipe = ppipe != 0ull;
           uint32_t gp = 0xFFFFFFFFu;   // the contender whose last row is the Pipeline
-          if (pipe) { const uint32_t lp_ = (uint32_t)__ffsll((unsigned long long)ppipe) - 1u; gp = deep ? (lp_ < 16u ? 0u : 1u + ((lp_ - 16u) >> lgD)) : (lp_ >> lgD); }
+          if (pipe) { const uint32_t lp_ = (uint32_t)__ffsll((unsigned long long)ppipe) - 1u; gp = lp_ < dl ? (lp_ >> 4) : ndeep + ((lp_ - dl) >> lgD); }
           // -- NodeInfo.AddTask (api/node_info.go:172-212) on every contender that took rows: lane g = contender g
           uint32_t T = 0u, c_x = 0u, c_b = 0u;
-          const uint32_t cst = deep ? (lane_i == 0u ? 0u : 16u + ((lane_i - 1u) << lgD)) : (lane_i << lgD);   // lane g: the first lane of contender g's table
+          const uint32_t cst = lane_i < ndeep ? 16u * lane_i : dl + ((lane_i - ndeep) << lgD);   // lane g: the first lane of contender g's table
           if (lane_i < nC) {
-            T = (uint32_t)__popcll((pb >> cst) & ((1ull << ((deep && lane_i == 0u) ? 16u : D)) - 1ull));
+            T = (uint32_t)__popcll((pb >> cst) & ((1ull << (lane_i < ndeep ? 16u : D)) - 1ull));
             const uint32_t cs = X.c_sorted[lane_i];
             c_x = cs & 0x7FFFFFFFu; c_b = cs >> 31;
           }
