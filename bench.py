@@ -349,7 +349,7 @@ def main():
     # mask per evaluation written once, node and task vectors read once).  Two measurements, both with HIP events on the
     # engine's stream:
     #   "roofline"        the materialised T x N matrix of this workload (kb_bench_matrix, rows [0,T)): k_matrix over the
-    #                     distinct task shapes + k_expand streaming every task row out — the size north_star quotes the
+    #                     distinct task shapes + k_expand_tiles streaming every task row out — the size north_star quotes the
     #                     roofline target on; the time is for BOTH launches;
     #   "roofline_cycle"  k_matrix as the scheduling cycle launches it inside the timed region: one launch per round over the
     #                     DISTINCT task shapes of the window (a few dozen rows), i.e. latency-sized.

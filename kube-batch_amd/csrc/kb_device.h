@@ -246,7 +246,7 @@ size_t kb_repair_smem_bytes(uint32_t NP);   // its dynamic LDS (<= 150 KiB or th
 // per-task rows out of the per-shape rows (kb_eval_matrix / kb_bench_matrix: the materialised T x N matrix)
 // order: the rows sorted by shape slot (nullptr: row order).  chunks: stretches of `order` (of the rows themselves without it) that share a shape, at most KB_XCHUNK_ROWS rows
 // each — a workgroup then loads its tile of the shape row (up to 16 384 nodes) ONCE and stores it to every row of its chunk (round 6: the source is read
-// ~n_rows / KB_XCHUNK_ROWS times instead of n_rows times; k_expand re-fetched a few MB of shape rows through eight L2s 226 MB worth per launch)
+// ~n_rows / KB_XCHUNK_ROWS times instead of n_rows times; round 5's copy, a workgroup per task row, re-fetched a few MB of shape rows through eight L2s 226 MB worth per launch)
 struct KbXChunk { uint32_t slot, first, count, pad; };
 #ifndef KB_XCHUNK_ROWS
 #define KB_XCHUNK_ROWS 64u   // at most 64: one lane of a wave per row of a chunk

@@ -126,7 +126,7 @@ __global__ void __launch_bounds__(256) k_matrix(KbDev d, KbRound r) {
 // VALU work: the stores of a run are issued one by one between LDS reads and scalar branches, with nothing to overlap them.
 // Here a run is evaluated ONCE into LDS (2 KB of scores + 128 B of mask for the tile's 1 024 nodes) and then streamed out by the whole
 // workgroup with 16-byte stores, every thread holding its 16 bytes in registers and issuing run_len / 2 independent stores back to back:
-// k_expand's store pattern without its load.
+// the row expansion's store pattern without its load.
 __global__ void __launch_bounds__(256) k_matrix_runs(KbDev d, KbRound r) {
   constexpr int NPT = 4, TR = 32;
   __shared__ K1Task srow[TR];
@@ -195,34 +195,6 @@ __global__ void __launch_bounds__(256) k_matrix_runs(KbDev d, KbRound r) {
   }
 }
 
-// K1b: row expansion.  Tasks with the same shape (InitResreq, non-zero request, class) have identical matrix rows, so the
-// materialised T x N matrix is produced by evaluating each distinct shape once (k_matrix over the representative rows)
-// and streaming every task row out of its shape's row: 16-byte loads that hit L2 / Infinity Cache (S x N is a few MB),
-// 16-byte stores that are the launch's HBM traffic (2 B score + 1 mask bit per evaluation).  One workgroup per task row.
-// Rows are taken in SHAPE order (order[]: the host's counting sort by slot), an eighth of that order per XCD (workgroup b runs on XCD
-// b % 8): the workgroups that share an L2 copy out of the same few shape rows, so a shape row is fetched from HBM once per launch
-// however many shapes the session has (with rows in task order, 2 989 shapes = 61 MB of shape rows thrashed the 4 MB L2s and the
-// launch read as much as it wrote: 0.54 ms instead of 0.38, profiles/round3/k1_profile).
-__global__ void __launch_bounds__(256) k_expand(const uint16_t *__restrict__ s_score, const uint32_t *__restrict__ s_mask,
-                                                const uint32_t *__restrict__ row_slot, const uint32_t *__restrict__ order, uint32_t n_rows, uint32_t NP,
-                                                uint16_t *__restrict__ score, uint32_t *__restrict__ maskw) {
-  uint32_t row = blockIdx.x;
-  if (order) {
-    const uint32_t per = (n_rows + 7u) / 8u, at = (blockIdx.x & 7u) * per + (blockIdx.x >> 3);
-    if ((blockIdx.x >> 3) >= per || at >= n_rows) return;
-    row = order[at];
-  }
-  if (row >= n_rows) return;
-  const uint32_t slot = row_slot[row];
-  const uint4 *src = reinterpret_cast<const uint4 *>(s_score + (size_t)slot * NP);
-  uint4 *dst = reinterpret_cast<uint4 *>(score + (size_t)row * NP);
-  const uint32_t n16 = NP / 8;                 // 16-byte chunks per row (NP is a multiple of 2048)
-  for (uint32_t c = threadIdx.x; c < n16; c += 256) dst[c] = src[c];
-  const uint4 *msrc = reinterpret_cast<const uint4 *>(s_mask + (size_t)slot * (NP / 32));
-  uint4 *mdst = reinterpret_cast<uint4 *>(maskw + (size_t)row * (NP / 32));
-  const uint32_t m16 = NP / 128;               // NP/32 words = NP/128 16-byte chunks
-  for (uint32_t c = threadIdx.x; c < m16; c += 256) mdst[c] = msrc[c];
-}
 
 // ------------------------------------------------------------------------------------------------------------
 // wave64 helpers
@@ -775,8 +747,12 @@ void kb_launch_affinity(const KbDev &d, const KbRound &r, void *stream) {
   if (r.n_mrows == 0 || !d.aff || !d.score_enabled) return;
   hipLaunchKernelGGL(k_affinity, dim3(r.n_mrows), dim3(256), 0, (hipStream_t)stream, d, r);
 }
-// K1b, tiled: workgroup (tile, chunk) holds its tile of the chunk's shape row in registers — up to 16 384 u16 scores (eight 16-byte pieces per thread: a
-// whole row at 10k nodes, so a row leaves as ONE contiguous 20 KB stream like k_expand's) and the tile's mask words — and streams them to every task row of
+// K1b: row expansion.  Tasks with the same shape (InitResreq, non-zero request, class) have identical matrix rows, so the materialised T x N matrix is
+// produced by evaluating each distinct shape once (k_matrix over the representative rows) and streaming every task row out of its shape's row: the
+// stores are the launch's HBM traffic (2 B score + 1 mask bit per evaluation).  The rows come in SHAPE order (order[]: the host's counting sort by slot),
+// cut into chunks of at most 64 rows of one shape.
+// Tiled: workgroup (tile, chunk) holds its tile of the chunk's shape row in registers — up to 16 384 u16 scores (eight 16-byte pieces per thread: a
+// whole row at 10k nodes, so a row leaves as ONE contiguous 20 KB stream) and the tile's mask words — and streams them to every task row of
 // the chunk: the launch's HBM traffic is its stores (2.125 B per pair) plus one read of a shape tile per 64 rows
 #define KB_XTILE_NODES 16384u
 // (non-temporal stores for the rows — written once, read by nobody in this launch — measured no consistent gain: 0.353 / 0.410 ms against 0.386 / 0.369 at
@@ -811,12 +787,10 @@ __global__ void __launch_bounds__(256) k_expand_tiles(const uint16_t *__restrict
 void kb_launch_expand(const KbDev &d, const uint16_t *s_score, const uint32_t *s_mask, const uint32_t *row_slot, const uint32_t *order, uint32_t n_rows,
                       uint16_t *score, uint32_t *maskw, void *stream, const KbXChunk *chunks, uint32_t n_chunks) {
   if (n_rows == 0) return;
-  if (chunks && n_chunks) {   // NP is a multiple of KB_NODE_PAD = 2048
-    hipLaunchKernelGGL(k_expand_tiles, dim3((d.NP + KB_XTILE_NODES - 1u) / KB_XTILE_NODES, n_chunks), dim3(256), 0, (hipStream_t)stream, s_score, s_mask, order, chunks, d.NP, score, maskw);
-    return;
-  }
-  const uint32_t grid = order ? 8u * ((n_rows + 7u) / 8u) : n_rows;
-  hipLaunchKernelGGL(k_expand, dim3(grid), dim3(256), 0, (hipStream_t)stream, s_score, s_mask, row_slot, order, n_rows, d.NP, score, maskw);
+  (void)row_slot;   // (the chunks carry their shape; the row -> shape map is the emulated launch's cross-check)
+  if (!chunks || !n_chunks) return;
+  // NP is a multiple of KB_NODE_PAD = 2048
+  hipLaunchKernelGGL(k_expand_tiles, dim3((d.NP + KB_XTILE_NODES - 1u) / KB_XTILE_NODES, n_chunks), dim3(256), 0, (hipStream_t)stream, s_score, s_mask, order, chunks, d.NP, score, maskw);
 }
 template <bool WIDE, int THREADS, int NW> static void k3_launch(const KbDev &d, const KbRound &r, size_t sh, hipStream_t st) {
   static bool lds_set[64] = {};   // one per instantiation

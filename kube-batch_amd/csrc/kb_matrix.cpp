@@ -24,7 +24,7 @@ static ChunkPlan matrix_plan(kb_engine *e, uint32_t t0, uint32_t n, uint32_t fit
   for (uint32_t i = 0; i < n; i++) e->h_rows[i] = t0 + i;
   if (e->h_mrows.size() < n) e->h_mrows.resize(n);
   p.ns = assign_shapes(e, n);
-  // Expansion streams every task row out of its shape's row.  The rows are expanded in SHAPE order (k_expand's `order`), so a shape
+  // Expansion streams every task row out of its shape's row.  The rows are expanded in SHAPE order (`order`), so a shape
   // row is read from HBM once and copied to all its task rows out of the L2 however many shapes there are; what the per-shape pass
   // cannot avoid is evaluating and storing the shape rows themselves.  When (nearly) every job has its own request that is a second
   // matrix: then every row is evaluated by the matrix kernel itself, adjacent equal rows (the tasks of a job) sharing one evaluation
@@ -50,7 +50,7 @@ static ChunkPlan matrix_plan(kb_engine *e, uint32_t t0, uint32_t n, uint32_t fit
   }
   if (n > e->xslot_cap) { e->b_xslot.alloc(sizeof(uint32_t) * n); e->b_xorder.alloc(sizeof(uint32_t) * n); e->xslot_cap = n; }
   HIP_OK(hipMemcpyAsync(e->b_xslot.p, e->h_slot.data(), sizeof(uint32_t) * n, hipMemcpyHostToDevice, e->stream));
-  {   // the rows in shape order (stable counting sort by slot): consecutive workgroups of k_expand then copy out of the same shape row
+  {   // the rows in shape order (stable counting sort by slot): the chunks of k_expand_tiles are stretches of it
     e->h_xorder.resize(n);
     std::vector<uint32_t> start((size_t)p.ns + 1, 0u);
     for (uint32_t i = 0; i < n; i++) start[e->h_slot[i] + 1]++;
@@ -93,12 +93,10 @@ static void matrix_launch(kb_engine *e, const ChunkPlan &p, uint32_t n, uint32_t
   kb_launch_interpod(e->dev, p.rs, e->stream);
   // shape order pays when the shape rows do not fit the L2s (C5: 23.0 -> 18.8 ms, BASELINE configs[3]: 0.66 -> 0.64 ms); while they do,
   // task order writes consecutive rows and is the faster one (C3, 509 shapes = 10 MB: 0.41 ms against 0.52; profiles/round3/call6)
-  // round 6: the TILED expansion (a workgroup loads its tile of the shape row once for 64 task rows) takes the rows in shape order always; KB_EXPAND_TILES=0:
-  // round 5's row-per-workgroup copy (the A/B switch of the traffic measurement)
-  static const bool tiles = [] { const char *v = getenv("KB_EXPAND_TILES"); return !(v && v[0] == '0'); }();
-  const bool by_shape = (size_t)p.ns * e->dev.NP * 2 > (16u << 20);
-  if (tiles) kb_launch_expand(e->dev, p.rs.score, p.rs.maskw, e->b_xslot.as<uint32_t>(), e->b_xorder.as<uint32_t>(), n, p.r.score, p.r.maskw, e->stream, e->b_xchunks.as<KbXChunk>(), p.n_xchunks);
-  else kb_launch_expand(e->dev, p.rs.score, p.rs.maskw, e->b_xslot.as<uint32_t>(), by_shape ? e->b_xorder.as<uint32_t>() : nullptr, n, p.r.score, p.r.maskw, e->stream);
+  // round 6: the TILED expansion — a workgroup loads its tile of the shape row once for 64 task rows, the rows in shape order.  (Round 5's copy, one
+  // workgroup per task row, re-fetched the shape rows through eight L2s — 1.25 x the algorithmic bytes against 1.04 x — and was slower at R = 16 and at
+  // 1M x 50k on every box, within +- 6 % at 100k x 10k depending on the box: profiles/round6/call8..., call10..., call12...; retired with its switch.)
+  kb_launch_expand(e->dev, p.rs.score, p.rs.maskw, e->b_xslot.as<uint32_t>(), e->b_xorder.as<uint32_t>(), n, p.r.score, p.r.maskw, e->stream, e->b_xchunks.as<KbXChunk>(), p.n_xchunks);
   if (k) kb_launch_argmax(e->dev, p.r, e->stream);
 }
 static KbRound matrix_chunk(kb_engine *e, uint32_t t0, uint32_t n, uint32_t fit_mode, uint32_t k) {

@@ -6,6 +6,8 @@
 #   trace      the selection kernel's per-phase cycle trace (libkbengine_trace.so), configs 4 and 3
 #   subset     the differential modules under both commit kernels (parity, adversarial, fuzz, full size, regressions, reload)
 #   suite      the whole -m gpu suite
+# (Steps that set KB_EXPAND_TILES=0 — mix, mix2, expand, xchunk — compared the tiled row expansion with round 5's copy; that kernel and its switch were retired
+#  afterwards, the steps are kept as the record of how the numbers under profiles/round6/ were produced: they need the tree of commit b8bea44.)
 set -uo pipefail
 cd "$(dirname "$0")/.."
 step="${1:-suite}"; shift || true
