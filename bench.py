@@ -372,7 +372,7 @@ def main():
     if args.diverse:     # shapes > rows / 16: the engine evaluates every row directly instead of expanding shape rows (kb_engine.cpp)
         full_label, full_kernel = f"kb_bench_matrix rows [0,{T}) x {N} nodes: direct per-row evaluation, runs of adjacent equal rows evaluated once", "k_matrix_runs"
     else:
-        full_label, full_kernel = f"kb_bench_matrix rows [0,{T}) x {N} nodes: per-shape evaluation + row expansion", "k_matrix+k_expand"
+        full_label, full_kernel = f"kb_bench_matrix rows [0,{T}) x {N} nodes: per-shape evaluation + row expansion", "k_matrix+k_expand_tiles"
     roofline = roof(T, full_ms, full_reps, full_label, full_kernel) if full_ms > 0 else roofline_cycle
     # The launch above leans on the snapshot's shape redundancy (a few hundred distinct task shapes: evaluate once, copy out).  The same
     # T x N matrix through the matrix kernel's own evaluation, so that the driver's record shows the evaluator and not only the copy:
@@ -428,7 +428,7 @@ def main():
             import csv
             vals = {}
             for row in csv.DictReader(open(pmc)):
-                # the materialised-matrix launch: k_expand + the matrix kernel over the distinct shapes (any tile but the per-round <1, 4>)
+                # the materialised-matrix launch: k_expand_tiles + the matrix kernel over the distinct shapes (any tile but the per-round <1, 4>)
                 if "k_expand" in row["kernel"] or ("k_matrix<" in row["kernel"] and "k_matrix<1, 4>" not in row["kernel"]):
                     vals[row["counter"]] = vals.get(row["counter"], 0.0) + float(row["mean_KB_per_dispatch"])
             if "FETCH_SIZE" in vals and "WRITE_SIZE" in vals:
@@ -573,7 +573,7 @@ def main():
             configuration's roofline fraction in the driver's record — R = 16's sits below R = 2's, and was invisible in round 5's line"""
             vR, vN, vT = vsnap.n_res, vsnap.n_nodes, vsnap.n_tasks
             vms = ve.bench_matrix(0, vT, reps=3)
-            kn = "k_matrix_runs" if direct else "k_matrix+k_expand"
+            kn = "k_matrix_runs" if direct else "k_matrix+k_expand_tiles"
             rf = roof(vT, vms, 3, f"kb_bench_matrix rows [0,{vT}) x {vN} nodes, R={vR}", kn, N=vN, b_node=16 * vR + 44, b_task=8 * vR + 24)
             return {k: rf[k] for k in ("kernel", "achieved", "peak", "unit", "frac", "bytes_per_launch", "avg_launch_ms")}
 

@@ -57,6 +57,18 @@ trace)
   if [ $# -eq 0 ]; then set -- 4 3; fi
   trace_cfgs "$@"
   ;;
+gaps)   # where a cycle's time goes outside the commit kernels:   gaps [configs...]   (kernel trace of two timed sessions + one warm-up, the host's own timeline)
+  if [ $# -eq 0 ]; then set -- 5; fi
+  export TMPDIR=/tmp
+  for cfg in "$@"; do
+    ( cd /tmp; KB_K5_STATS=1 rocprofv3 --kernel-trace -f csv -d "$OLDPWD/$out/trace_c${cfg}" -o bench -- python "$OLDPWD/bench.py" --config ${cfg} --steps 2 --warmup 1 --no-cpu-baseline \
+        > "$OLDPWD/$out/gaps_c${cfg}.json" 2> "$OLDPWD/$out/gaps_c${cfg}.err" )
+    echo "== gaps c${cfg} $(ms "$out/gaps_c${cfg}.json")" | tee -a "$out/summary.txt"
+    grep -h "kb host\|kb probe\|kb overlap" "$out/gaps_c${cfg}.err" | tee -a "$out/summary.txt"
+    python scripts/trace_gaps.py "$(find "$out/trace_c${cfg}" -name '*kernel_trace.csv' | head -1)" 3 > "$out/gaps_config${cfg}.txt" 2>&1; head -14 "$out/gaps_config${cfg}.txt" | tee -a "$out/summary.txt"
+    find "$out/trace_c${cfg}" -name '*.csv' -size +8M -delete   # the trace itself is too large to bring back
+  done
+  ;;
 mix)   # one call: the differential modules under both commit kernels, the default bench line (variants, driver-style), then two A/Bs on the same box:
        # the tiled row expansion against round 5's copy (roofline of configs 3 and 4), the yielding wait against the pure spin
   timeout 1200 python -m pytest tests/test_gpu_parity.py tests/test_gpu_adversarial.py tests/test_gpu_regressions.py tests/test_gpu_fuzz.py tests/test_gpu_fullsize.py tests/test_gpu_interpod.py tests/test_gpu_waterfill.py \
