@@ -213,6 +213,42 @@ def main():
         if dist_mode == "sessions":
             rank_digest_expected = golden_ranks.get(str(rank))
         sharded_setup_error = None
+        sharded_watch = None
+        if dist_mode == "sharded" and sessions_block is not None and world > 1:
+            # A failure of the split that is NOT an exception — a collective that never completes — would cost the whole line, the sessions mode's
+            # finished answer with it.  The sessions phase above is done: if the split's phase (set-up, warm-up, timed cycles, the verifying cycle)
+            # is not through within a generous bound, rank 0 prints the line with the sessions mode's figures as its value and `sharded.error`
+            # saying so, and every rank leaves with exit code 0 (a thread stuck in a collective cannot be interrupted: os._exit).
+            # KB_SHARDED_LIMIT_S: the bound in seconds (default: 240 s + 400 x the time the sessions phase took per cycle, per cycle to run).
+            import threading
+            limit_s = float(os.environ.get("KB_SHARDED_LIMIT_S", "0")) or (240.0 + 0.4 * sessions_block["ms_per_step"] * (args.warmup + args.steps + 2))
+            sharded_watch = threading.Event()
+
+            def _abandon_the_split():
+                if sharded_watch.wait(limit_s):
+                    return
+                why = (f"no answer within {limit_s:.0f} s of the split's phase (set-up + {args.warmup} warm-up + {args.steps} timed cycles + the verifying one): "
+                       "abandoned by bench.py's watchdog; the line's value is the sessions mode's")
+                print(f"bench.py: rank {rank}: {why}", file=sys.stderr, flush=True)
+                if rank == 0:
+                    print(json.dumps({
+                        "metric": f"pod-node scoring evals/sec + binds/sec, {_k(snap.n_tasks)} tasks x {_k(snap.n_nodes)} nodes snapshot",
+                        "value": sessions_block["value"], "unit": "evals/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                        "ms_per_step": sessions_block["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                        "dtype": "f64+i64", "data": "synthetic",
+                        "config": {"workload": f"BASELINE configs[{args.config - 1}]: {snap.n_tasks} tasks x {snap.n_nodes} nodes, {snap.n_jobs} gang jobs, "
+                                               f"{snap.n_queues} queues, R={snap.n_res}, {'+'.join(actions)}, plugins priority,gang,drf,predicates,proportion,nodeorder ({weights})",
+                                   "window": args.window or 256, "scale": args.scale},
+                        "multi_gpu_mode": "one independent session per GPU (rank k: seed + k), no data-path collective; value = the slowest rank's per-session rate",
+                        "sharded": {"error": why, "verified": None}, "sessions": sessions_block,
+                        "sessions_verified_against_golden_digests": sessions_block["verified"],
+                        "aggregate_evals_per_s": sessions_block["aggregate_evals_per_s"], "sessions_per_s": sessions_block["sessions_per_s"],
+                        "dist_backend": dist.get_backend(), "roofline": None, "cpu_baseline": None,
+                        "roofline_note": "N > 1: the roofline and the CPU baseline are the N = 1 line's"}), flush=True)
+                sys.stdout.flush()
+                os._exit(0)
+
+            threading.Thread(target=_abandon_the_split, daemon=True, name="kb-sharded-watchdog").start()
         if dist_mode == "sharded":
             # The split's set-up (its streams, the engine on torch's stream, one whole cycle with its collectives) has only ever run at world size
             # <= 2 (no multi-GPU node was available to any round): if it fails HERE — symmetric failures: every rank runs the same code on the same
@@ -222,6 +258,8 @@ def main():
                 runner.step()
             except Exception as err:     # noqa: BLE001 — whatever it is, it is reported in the line
                 sharded_setup_error = f"{type(err).__name__}: {err}"
+                if sharded_watch is not None:
+                    sharded_watch.set()          # an exception is an answer: the sessions mode runs again below as the line's own
                 print(f"bench.py: rank {rank}: the task-row split failed during set-up ({sharded_setup_error}); reporting the sessions mode", file=sys.stderr)
                 dist_mode = "sessions"
                 if rank > 0:
@@ -313,6 +351,8 @@ def main():
                          "verified": sharded_verified, "verified_with": "tests/golden/bench_rank_digests.json, rank 0's snapshot (the oracle's digest of decisions + bind set)"}
         if sharded_verified is False:
             value = None
+        if sharded_watch is not None:
+            sharded_watch.set()                  # the split's phase is through (its last collective was the verdict's reduction above)
     if dist_mode == "replicas" and world > 1:
         dec_last = runner.step(verify=False)                 # outside the timed region: one more cycle, its digest compared across ranks
         try:

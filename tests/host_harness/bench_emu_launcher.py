@@ -34,6 +34,13 @@ class _EmulatedShardedCycle(_ShardedCycle):
         cpu = torch.device("cpu")
         super().__init__(conf, snap, backend=distmod.EngineBackend(eng, cpu), buffer_device=cpu, actions=actions, **kw)
 
+    def step(self, *a, **k):
+        if os.environ.get("KB_EMU_HANG_SHARDED") == "1":       # tests/test_bench_cpu.py: a collective of the split that never completes
+            import time
+            while True:
+                time.sleep(3600)
+        return super().step(*a, **k)
+
 
 distmod.ShardedCycle = _EmulatedShardedCycle
 

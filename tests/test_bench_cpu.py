@@ -198,3 +198,29 @@ def test_two_ranks_when_the_split_cannot_be_set_up(tmp_path):
     assert "broken on purpose" in d["sharded"]["error"] and d["sharded"]["verified"] is None
     assert d["sessions"]["verified"] is True and d["sessions_verified_against_golden_digests"] is True
     assert d["multi_gpu_mode"].startswith("one independent session per GPU")
+
+
+def test_two_ranks_when_the_split_never_answers(tmp_path):
+    """A collective of the split that never completes (the one failure an exception handler cannot see) must not cost the sessions mode's finished answer:
+    bench.py's watchdog prints the line with the sessions figures as its value and `sharded.error` saying that the phase was abandoned; every rank exits 0."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, KB_EMU_LIB=emu.build_emulated_library(), KB_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1", KB_EMU_HANG_SHARDED="1", KB_SHARDED_LIMIT_S="4")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "KB_DIST_MODE"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(HERE, "host_harness", "bench_emu_launcher.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--scale", "0.02"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=os.path.dirname(HERE))
+    assert r.returncode == 0, r.stdout + r.stderr
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0 and d["value"] == d["sessions"]["value"]
+    assert "abandoned by bench.py's watchdog" in d["sharded"]["error"] and d["sharded"]["verified"] is None
+    assert d["sessions"]["verified"] is True and d["sessions_verified_against_golden_digests"] is True
+    for k in ("metric", "unit", "steps", "warmup", "ms_per_step", "higher_is_better", "vs_baseline", "dtype", "data", "config"):
+        assert k in d, k
