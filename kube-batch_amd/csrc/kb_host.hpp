@@ -147,11 +147,21 @@ class OrderMachine {
   std::vector<double> jalloc, jshare, qalloc, qshare;
   std::vector<int32_t> ready;
   uint64_t steps = 0;
+  // how the roll-back points keep the two heap arrays (one slot per job each): -1 = by the session's size (journals from kJournalJobs jobs
+  // on, copies below), 0 / 1 = copies / journals (tests/host_harness/order_harness.cpp runs every case both ways)
+  int force_journal = -1;
+#ifndef KB_ORDER_JOURNAL_JOBS
+#define KB_ORDER_JOURNAL_JOBS 32768   // (make EXTRA=-DKB_ORDER_JOURNAL_JOBS=... for an A/B build)
+#endif
+  static constexpr uint32_t kJournalJobs = KB_ORDER_JOURNAL_JOBS;
 
  private:
   const HostSession *hs_ = nullptr;
   const Policy *pol_ = nullptr;
+  // the queue heap: a fixed array of one slot per job (allocate.go:50-52 pushes one entry per job, and nothing is pushed that was not popped) and
+  // its size.  Writes go through qset / jset: the FIRST write to a slot behind a roll-back point logs the slot's old value in that point's frame
   std::vector<uint32_t> qheap_;
+  uint32_t qn_ = 0;
   static constexpr uint32_t kNotBuilt = 0xFFFFFFFFu;   // jheap_n_: the queue has not been popped yet, its job heap is still to be built
   std::vector<uint32_t> jheap_items_, jheap_off_, jheap_n_, qjobs_;
   void build_jobs(uint32_t q);
@@ -162,9 +172,15 @@ class OrderMachine {
   int cur_q_ = -1, cur_j_ = -1;
   uint32_t cur_t_ = KB_NONE;
   bool inner_ = false;
-  // roll-back points: copies of the small state + first-touch journal of the per-job state, at most two deep
+  // roll-back points: copies of the small state (per queue) + first-touch journal of the per-job state, at most two deep.  The two heap arrays
+  // (one slot per job each) are COPIED into the frame in small sessions and JOURNALLED in large ones (journal_): at 100k jobs the copies were
+  // 0.8 MB per roll-back point, one point per round, in front of every round's launches — the next round's matrix went out ~25 us later and its
+  // lists were late for the commit launch (1M x 50k: 252 -> 242 ms); at 10k jobs the copy is 80 KB and cheaper than a stamp test on each of the
+  // ~8k heap writes of a round (100k x 10k, R = 16: 57.8 against 58.6 ms with journals).
   struct Frame {
-    std::vector<uint32_t> qheap, jheap_items, jheap_n;
+    std::vector<uint32_t> qheap, jheap_items, jheap_n;   // (qheap / jheap_items: copy mode)
+    std::vector<uint64_t> qlog, jlog;   // journal mode: (slot << 32) | the slot's value when the frame was armed
+    uint32_t qn = 0;
     std::vector<double> qalloc, qshare;
     int cur_q = -1, cur_j = -1;
     uint32_t cur_t = KB_NONE;
@@ -177,8 +193,23 @@ class OrderMachine {
   };
   Frame fr_[2];
   int depth_ = 0;
-  std::vector<uint32_t> stamp_;
+  std::vector<uint32_t> stamp_, qstamp_, jstamp_;   // per job / queue-heap slot / job-heap slot: the epoch of the frame that holds its old value
   uint32_t epoch_ = 0;
+  bool journal_ = false;
+  void qset(uint32_t i, uint32_t v) {
+    if (journal_) {
+      Frame &f = fr_[depth_ - 1];
+      if (qstamp_[i] != f.epoch) { qstamp_[i] = f.epoch; f.qlog.push_back(((uint64_t)i << 32) | qheap_[i]); }
+    }
+    qheap_[i] = v;
+  }
+  void jset(uint32_t i, uint32_t v) {   // i: index into jheap_items_ (the queue's offset included)
+    if (journal_) {
+      Frame &f = fr_[depth_ - 1];
+      if (jstamp_[i] != f.epoch) { jstamp_[i] = f.epoch; f.jlog.push_back(((uint64_t)i << 32) | jheap_items_[i]); }
+    }
+    jheap_items_[i] = v;
+  }
   void arm(Frame &f);
   void undo(Frame &f);
   void touch(uint32_t j) {

@@ -55,61 +55,67 @@ bool OrderMachine::overused(uint32_t q) const {
   return true;
 }
 
+// The sifts move a hole instead of swapping (the element on its way is compared by value, the others move one level): the same comparisons in
+// the same order as container/heap's up / down, the same final array, half the writes.
 void OrderMachine::qpush(uint32_t q) {
-  qheap_.push_back(q);
-  size_t j = qheap_.size() - 1;
-  for (;;) {
-    size_t i = j == 0 ? 0 : (j - 1) / 2;
-    if (i == j || !queue_less(qheap_[j], qheap_[i])) break;
-    std::swap(qheap_[i], qheap_[j]);
+  uint32_t j = qn_++;
+  while (j > 0) {
+    const uint32_t i = (j - 1) / 2;
+    if (!queue_less(q, qheap_[i])) break;
+    qset(j, qheap_[i]);
     j = i;
   }
+  qset(j, q);
 }
 uint32_t OrderMachine::qpop() {
-  size_t n = qheap_.size() - 1;
-  std::swap(qheap_[0], qheap_[n]);
-  size_t i = 0;
-  for (;;) {
-    size_t j1 = 2 * i + 1;
-    if (j1 >= n) break;
-    size_t j = j1;
-    if (j1 + 1 < n && queue_less(qheap_[j1 + 1], qheap_[j1])) j = j1 + 1;
-    if (!queue_less(qheap_[j], qheap_[i])) break;
-    std::swap(qheap_[i], qheap_[j]);
-    i = j;
-  }
-  uint32_t x = qheap_.back();
-  qheap_.pop_back();
-  return x;
-}
-void OrderMachine::jpush(uint32_t q, uint32_t job) {
-  uint32_t *h = &jheap_items_[jheap_off_[q]];
-  uint32_t n = jheap_n_[q]++;
-  h[n] = job;
-  uint32_t j = n;
-  for (;;) {
-    uint32_t i = j == 0 ? 0 : (j - 1) / 2;
-    if (i == j || !job_less(h[j], h[i])) break;
-    std::swap(h[i], h[j]);
-    j = i;
-  }
-}
-uint32_t OrderMachine::jpop(uint32_t q) {
-  uint32_t *h = &jheap_items_[jheap_off_[q]];
-  uint32_t n = jheap_n_[q] - 1;
-  std::swap(h[0], h[n]);
+  const uint32_t n = --qn_;          // Pop: swap(0, n), down(0, n), remove last — the old root leaves, the last element sinks from the root
+  const uint32_t top = qheap_[0];
+  if (n == 0) return top;
+  const uint32_t x = qheap_[n];
   uint32_t i = 0;
   for (;;) {
-    uint32_t j1 = 2 * i + 1;
+    const uint32_t j1 = 2 * i + 1;
+    if (j1 >= n) break;
+    uint32_t j = j1;
+    if (j1 + 1 < n && queue_less(qheap_[j1 + 1], qheap_[j1])) j = j1 + 1;
+    if (!queue_less(qheap_[j], x)) break;
+    qset(i, qheap_[j]);
+    i = j;
+  }
+  qset(i, x);
+  return top;
+}
+void OrderMachine::jpush(uint32_t q, uint32_t job) {
+  const uint32_t b = jheap_off_[q];
+  const uint32_t *h = &jheap_items_[b];
+  uint32_t j = jheap_n_[q]++;
+  while (j > 0) {
+    const uint32_t i = (j - 1) / 2;
+    if (!job_less(job, h[i])) break;
+    jset(b + j, h[i]);
+    j = i;
+  }
+  jset(b + j, job);
+}
+uint32_t OrderMachine::jpop(uint32_t q) {
+  const uint32_t b = jheap_off_[q];
+  const uint32_t *h = &jheap_items_[b];
+  const uint32_t n = --jheap_n_[q];
+  const uint32_t top = h[0];
+  if (n == 0) return top;
+  const uint32_t x = h[n];
+  uint32_t i = 0;
+  for (;;) {
+    const uint32_t j1 = 2 * i + 1;
     if (j1 >= n) break;
     uint32_t j = j1;
     if (j1 + 1 < n && job_less(h[j1 + 1], h[j1])) j = j1 + 1;
-    if (!job_less(h[j], h[i])) break;
-    std::swap(h[i], h[j]);
+    if (!job_less(h[j], x)) break;
+    jset(b + i, h[j]);
     i = j;
   }
-  jheap_n_[q] = n;
-  return h[n];
+  jset(b + i, x);
+  return top;
 }
 
 void OrderMachine::init_allocate(const HostSession *hs, const Policy *pol) {
@@ -138,8 +144,16 @@ void OrderMachine::init_allocate(const HostSession *hs, const Policy *pol) {
     for (uint32_t j = 0; j < J; j++)
       if (hs->job_queue[j] < Q) qjobs_[fill[hs->job_queue[j]]++] = j;
   }
-  qheap_.clear();
-  qheap_.reserve(J);
+  qheap_.assign(J ? J : 1, 0);
+  qn_ = 0;
+  // the heaps' journals (large sessions): every stamp equals frame 0's epoch (0) while the heap is filled below, so nothing is logged;
+  // checkpoint() starts epoch 1
+  journal_ = force_journal < 0 ? J >= kJournalJobs : force_journal != 0;
+  if (journal_) { qstamp_.assign(J ? J : 1, 0); jstamp_.assign(J ? J : 1, 0); }
+  stamp_.assign(J ? J : 1, 0);
+  epoch_ = 0;
+  depth_ = 1;
+  fr_[0].epoch = 0;
   // pendingTasks[job] (allocate.go:110-123): Pending tasks whose Resreq is not empty, in TaskOrderFn order.  A job's list is built the
   // first time the job is popped (build_pending): a job's tasks are adjacent in the snapshot, so its list lives in pend_ at the job's own
   // task range, and nothing about it depends on what the action has done so far (statuses only change when the action closes).  The host
@@ -158,8 +172,6 @@ void OrderMachine::init_allocate(const HostSession *hs, const Policy *pol) {
   inner_ = false;
   cur_q_ = cur_j_ = -1;
   cur_t_ = KB_NONE;
-  stamp_.assign(J ? J : 1, 0);
-  epoch_ = 0;
   checkpoint();
 }
 
@@ -190,8 +202,9 @@ void OrderMachine::build_pending(uint32_t j) {
 void OrderMachine::arm(Frame &f) {
   f.epoch = ++epoch_;
   f.jobs.clear(); f.cursor.clear(); f.ready.clear(); f.vals.clear();
-  f.qheap = qheap_;
-  f.jheap_items = jheap_items_;
+  f.qlog.clear(); f.jlog.clear();
+  if (!journal_) { f.qheap.assign(qheap_.begin(), qheap_.begin() + qn_); f.jheap_items = jheap_items_; }
+  f.qn = qn_;
   f.jheap_n = jheap_n_;
   f.qalloc = qalloc;
   f.qshare = qshare;
@@ -208,8 +221,14 @@ void OrderMachine::undo(Frame &f) {
     for (int d = 0; d < R; d++) jalloc[(size_t)j * R + d] = v[d];
     jshare[j] = v[R];
   }
-  qheap_ = f.qheap;
-  jheap_items_ = f.jheap_items;
+  if (journal_) {
+    for (const uint64_t w : f.qlog) qheap_[(uint32_t)(w >> 32)] = (uint32_t)w;        // (a frame holds a slot once: any order)
+    for (const uint64_t w : f.jlog) jheap_items_[(uint32_t)(w >> 32)] = (uint32_t)w;
+  } else {
+    std::copy(f.qheap.begin(), f.qheap.end(), qheap_.begin());   // (slots behind the size then: never read before they are written)
+    jheap_items_ = f.jheap_items;
+  }
+  qn_ = f.qn;
   jheap_n_ = f.jheap_n;
   qalloc = f.qalloc;
   qshare = f.qshare;
@@ -251,7 +270,7 @@ bool OrderMachine::next(uint32_t &task) {
       inner_ = false;
       qpush((uint32_t)cur_q_);               // allocate.go:192
     }
-    if (qheap_.empty()) return false;        // allocate.go:90-92
+    if (qn_ == 0) return false;              // allocate.go:90-92
     uint32_t q = qpop();
     if (overused(q)) continue;               // allocate.go:95-98
     if (jheap_n_[q] == kNotBuilt) build_jobs(q);

@@ -1,7 +1,9 @@
 #!/usr/bin/env python
 """sha256 over the DEVICE sources of the engine, two granularities:
 
-  kernel_sources_sha()      kube-batch_amd/csrc/*.hip, *.hpp, *.h and the Makefile's flags, in name order: the whole tree
+  kernel_sources_sha()      every file some translation unit below reaches (the four .hip files, the headers they include, the C ABI header, the
+                            Makefile), in name order: the device sources as a whole.  (Until round 6's call 29 it took every *.hpp of csrc/, the
+                            host-only ones too: a change to the host's order machine â€” kb_host.hpp â€” then voided a stamp no kernel depends on.)
   kernel_tu_sha(root, tu)   ONE translation unit: the .hip file, every header it reaches through `#include "..."` (transitively; the
                             C ABI header included) and the Makefile â€” what decides the ISA of the kernels that file defines
 
@@ -14,7 +16,6 @@ their counters, while it does void the matrix kernels' â€” they share its file â
   python scripts/kernel_sources_sha.py          the whole-tree value
   python scripts/kernel_sources_sha.py --tu     one line per translation unit: "<sha256>  <file>"
 """
-import glob
 import hashlib
 import os
 import re
@@ -26,11 +27,9 @@ TUS = ("kb_kernels.hip", "kb_commit_sel.hip", "kb_commit.hip", "kb_waterfill.hip
 
 def kernel_sources_sha(root=ROOT):
     h = hashlib.sha256()
-    src = os.path.join(root, "kube-batch_amd", "csrc")
-    files = sorted(f for pat in ("*.hip", "*.hpp", "*.h", "Makefile") for f in glob.glob(os.path.join(src, pat)))
-    for f in files:
-        h.update(os.path.basename(f).encode() + b"\0")
-        h.update(open(f, "rb").read())
+    for rel in sorted({rel for tu in TUS for rel in tu_files(root, tu)}):
+        h.update(rel.replace(os.sep, "/").encode() + b"\0")
+        h.update(open(os.path.join(root, rel), "rb").read())
     return h.hexdigest()
 
 

@@ -2,10 +2,12 @@
 // compiled unchanged with g++) through a tiny C interface, so that the CPU suite can drive its next()/report()/checkpoint()/
 // rollback() protocol against the restated reference loop without a GPU (tests/test_host_order_cpu.py).  The device's part
 // (which node a task gets) is played by tests/pyref.py.  Nothing here is linked into libkbengine.so.
+#include <time.h>
 #include "../../kube-batch_amd/csrc/kb_host.hpp"
 
 using namespace kb;
 
+static int g_force_journal = -1;
 struct HH {
   HostSession hs;
   Policy pol;
@@ -56,10 +58,29 @@ HH *hh_create(int R, uint32_t T, uint32_t J, uint32_t Q,
   p.task_order_priority = task_order_priority;
   p.gang_job_ready = gang_job_ready;
   p.has_gang = has_gang; p.has_drf = has_drf; p.has_proportion = has_proportion;
+  h->om.force_journal = g_force_journal;
   h->om.init_allocate(&h->hs, &h->pol);
   return h;
 }
 void hh_destroy(HH *h) { delete h; }
+// the allocate action's host loop with every round confirmed (ActionRun::plan / plan_ahead / promote, every row Allocated): seconds for the whole
+// action, rows handed out in *rows — what the order machine costs per round when nothing breaks (scripts/time_order_machine.py)
+double hh_bench(HH *h, uint32_t W, uint64_t *rows) {
+  struct timespec a, b;
+  clock_gettime(CLOCK_MONOTONIC, &a);
+  OrderMachine &om = h->om;
+  uint32_t t = 0;
+  uint64_t total = 0;
+  auto window = [&]() { uint32_t n = 0; while (n < W && om.next(t)) { om.report(Outcome::Allocated); n++; } total += n; return n; };
+  om.checkpoint();
+  uint32_t n = window();
+  while (n) { om.push_checkpoint(); n = window(); om.pop_commit(); }
+  clock_gettime(CLOCK_MONOTONIC, &b);
+  if (rows) *rows = total;
+  return (double)(b.tv_sec - a.tv_sec) + 1e-9 * (double)(b.tv_nsec - a.tv_nsec);
+}
+// how the machines created from now on keep their heap arrays across roll-back points: -1 by size, 0 copies, 1 journals (OrderMachine::force_journal)
+void hh_set_journal(int mode) { g_force_journal = mode; }
 int hh_next(HH *h, uint32_t *task) { return h->om.next(*task) ? 1 : 0; }
 void hh_report(HH *h, int outcome) { h->om.report(outcome == 0 ? Outcome::Allocated : outcome == 1 ? Outcome::Pipelined : Outcome::NoFeasibleNode); }
 void hh_checkpoint(HH *h) { h->om.checkpoint(); }

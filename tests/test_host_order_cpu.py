@@ -25,6 +25,10 @@ DONE, NO_FEASIBLE, PIPELINED, RENORM = 0, 1, 2, 4           # KB_REASON_* (kube-
 
 @pytest.fixture(scope="module")
 def harness():
+    return _build()
+
+
+def _build():
     if os.environ.get("KB_ORDER_HARNESS_LIB"):               # an instrumented build (scripts/sanitize_cpu.sh)
         return _bind(C.CDLL(os.environ["KB_ORDER_HARNESS_LIB"]))
     out_dir = os.path.join(HERE, "host_harness", "build")
@@ -257,14 +261,23 @@ def _check(L, cfg, snap, seed):
             assert qa[q].tolist() == [a["allocated"].get(d) for d in range(snap.n_res)], tag
 
 
+@pytest.fixture(params=[0, 1], ids=["heap-copies", "heap-journals"])
+def heap_mode(harness, request):
+    """The roll-back points keep the two heap arrays as copies (small sessions) or as first-write journals (from OrderMachine::kJournalJobs jobs on):
+    every case both ways — the sessions of this file are all small."""
+    harness.hh_set_journal(C.c_int(request.param))
+    yield request.param
+    harness.hh_set_journal(C.c_int(-1))
+
+
 @pytest.mark.parametrize("seed", range(40))
-def test_order_machine_on_synthetic_clusters(harness, seed):
+def test_order_machine_on_synthetic_clusters(harness, heap_mode, seed):
     cfg, snap = cases._case(seed)
     _check(harness, cfg, snap, seed)
 
 
 @pytest.mark.parametrize("seed", range(200))
-def test_order_machine_on_adversarial_snapshots(harness, seed):
+def test_order_machine_on_adversarial_snapshots(harness, heap_mode, seed):
     snap = rawgen.raw_snapshot(seed)
     rng = np.random.RandomState(seed)
     if seed % 4 == 3:
