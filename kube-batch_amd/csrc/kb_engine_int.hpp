@@ -376,8 +376,9 @@ struct ActionRun {
   std::vector<kb_decision> decs;
   std::vector<uint32_t> bf_list;
   size_t bf_pos = 0;
-  uint64_t popped = 0, spec_pops = 0, spec_pops_next = 0;
+  uint64_t popped = 0, spec_pops = 0, spec_pops_next = 0, spec_pops_next2 = 0;
   std::vector<uint32_t> rows_next;   // the window speculated behind the one in flight
+  std::vector<uint32_t> rows_next2;  // ... and the one behind that: planned while the first two are on the device, launched when the first one's answer is in
   std::vector<uint32_t> probe_list;  // feasibility shapes the probe looks at (the ones still alive)
   uint32_t probe_calls = 0;
   double host_ms = 0, t_start = 0;
@@ -497,31 +498,39 @@ struct ActionRun {
 
   // While the device works on the window just launched, speculate the one after it (assuming the one in flight completes,
   // which ~70 % do) behind a second roll-back point; promote() makes it the current window, a break rolls both back.
-  uint32_t plan_ahead(kb_engine *e) {
+  // `second`: the window behind the speculated one (rows_next2), behind a third roll-back point.  It is only PLANNED ahead — its matrix would be two
+  // rounds stale; run_action launches it when the round in flight has answered, and then has its rows ready: the order machine's ~30 us per
+  // window are no longer between a round's answer and the next launches (1M x 50k: the arg-max launch of the second stream was late for the
+  // commit launch by ~3 us per round, and by more on a slower host)
+  uint32_t plan_ahead(kb_engine *e, bool second = false) {
     HostSession &hs = e->hs;
     const uint32_t W = e->eff_window;
     double t0 = now_ms();
     om.push_checkpoint();
-    if (rows_next.size() < W) rows_next.resize(W);
+    std::vector<uint32_t> &rows = second ? rows_next2 : rows_next;
+    uint64_t &pops = second ? spec_pops_next2 : spec_pops_next;
+    if (rows.size() < W) rows.resize(W);
     uint32_t n = 0, t, nshapes = 0;
-    spec_pops_next = 0;
+    pops = 0;
     new_window(e);
     while (n < W && om.next(t)) {
-      spec_pops_next++;
+      pops++;
       if (dead[hs.t_feas_shape[t]]) { om.report(Outcome::NoFeasibleNode); continue; }
-      if (!admit_shape(e, hs.t_row_shape[t], nshapes) || (n > 0 && !hs.t_ip_subject.empty() && hs.t_ip_subject[t]) || (n > 0 && hs.wide(t))) { om.rollback_last_pop(); spec_pops_next--; break; }
-      rows_next[n++] = t;
+      if (!admit_shape(e, hs.t_row_shape[t], nshapes) || (n > 0 && !hs.t_ip_subject.empty() && hs.t_ip_subject[t]) || (n > 0 && hs.wide(t))) { om.rollback_last_pop(); pops--; break; }
+      rows[n++] = t;
       om.report(Outcome::Allocated);
       if (hs.wide(t)) break;
     }
     host_ms += now_ms() - t0;
     return n;
   }
-  void promote(kb_engine *e, uint32_t n_next) {
+  // the window in flight is confirmed: the speculated one becomes the current one; with `have_second` the one planned behind it moves up
+  void promote(kb_engine *e, uint32_t n_next, bool have_second = false) {
     om.pop_commit();
     if (n_next) std::memcpy(e->h_rows.data(), rows_next.data(), sizeof(uint32_t) * n_next);
     spec_pops = spec_pops_next;
     if (n_next == 0) popped += spec_pops;
+    if (have_second) { rows_next.swap(rows_next2); spec_pops_next = spec_pops_next2; }
   }
 
   // the plugin predicates of task t (predicates.go:127,181-190 and the static class table) against the pod counts / ports

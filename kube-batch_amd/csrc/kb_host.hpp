@@ -138,9 +138,10 @@ class OrderMachine {
   bool next(uint32_t &task);
   void report(Outcome o);
   void checkpoint();        // roll-back point = now (drops every earlier one)
-  void push_checkpoint();   // a second roll-back point on top (the window after the one in flight is speculated behind it)
-  void pop_commit();        // the older window is confirmed: the newer roll-back point becomes the only one
+  void push_checkpoint();   // another roll-back point on top (the windows behind the one in flight are speculated behind their own: at most kFrames in all)
+  void pop_commit();        // the oldest window is confirmed: its roll-back point goes, the newer ones stay
   void rollback();          // back to the OLDEST roll-back point, which stays armed
+  static constexpr int kFrames = 3;   // the window in flight, the one queued behind it, the one planned behind that (run_action)
   // undo the effect of the last next(): the task it returned is handed out again by the following next()
   void rollback_last_pop() { cursor_[(uint32_t)cur_j_]--; steps--; }
   // running aggregates, compared with the device reduction after the action
@@ -172,7 +173,7 @@ class OrderMachine {
   int cur_q_ = -1, cur_j_ = -1;
   uint32_t cur_t_ = KB_NONE;
   bool inner_ = false;
-  // roll-back points: copies of the small state (per queue) + first-touch journal of the per-job state, at most two deep.  The two heap arrays
+  // roll-back points: copies of the small state (per queue) + first-touch journal of the per-job state, at most kFrames deep.  The two heap arrays
   // (one slot per job each) are COPIED into the frame in small sessions and JOURNALLED in large ones (journal_): at 100k jobs the copies were
   // 0.8 MB per roll-back point, one point per round, in front of every round's launches — the next round's matrix went out ~25 us later and its
   // lists were late for the commit launch (1M x 50k: 252 -> 242 ms); at 10k jobs the copy is 80 KB and cheaper than a stamp test on each of the
@@ -191,7 +192,7 @@ class OrderMachine {
     std::vector<double> vals;   // per journalled job: allocated[R], share
     uint32_t epoch = 0;
   };
-  Frame fr_[2];
+  Frame fr_[kFrames];
   int depth_ = 0;
   std::vector<uint32_t> stamp_, qstamp_, jstamp_;   // per job / queue-heap slot / job-heap slot: the epoch of the frame that holds its old value
   uint32_t epoch_ = 0;

@@ -241,18 +241,20 @@ void OrderMachine::checkpoint() {
 }
 
 void OrderMachine::push_checkpoint() {
-  depth_ = 2;
-  arm(fr_[1]);
+  if (depth_ >= kFrames) throw std::logic_error("order machine: too many roll-back points");
+  depth_++;
+  arm(fr_[depth_ - 1]);
 }
 
 void OrderMachine::pop_commit() {
-  if (depth_ == 2) std::swap(fr_[0], fr_[1]);
-  depth_ = 1;
+  if (depth_ >= 2) {   // the oldest frame goes (its storage moves to the end for the next push), the others move down
+    std::rotate(fr_, fr_ + 1, fr_ + depth_);
+    depth_--;
+  }
 }
 
 void OrderMachine::rollback() {
-  if (depth_ == 2) undo(fr_[1]);
-  undo(fr_[0]);
+  for (int k = depth_; k-- > 0;) undo(fr_[k]);   // newest first
   checkpoint();   // the restored state is the new roll-back point (fresh journal)
 }
 

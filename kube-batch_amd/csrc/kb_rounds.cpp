@@ -417,12 +417,21 @@ static int run_action(kb_engine *e, uint32_t action, kb_decision *out, uint64_t 
     RoundCtx c{};
     if (n) c = launch(n, nullptr, buf, 0, 0);
     (action == 0 ? e->tl_begin : e->tl_backfill) += now_ms() - t_act0;
+    // n_next: the window speculated behind the one in flight (planned: have_next; launched behind it: queued, its round cn).  n_next2: the
+    // window behind THAT, planned while both are on the device (have_next2) and launched the moment the first one's answer is in — the
+    // order machine's work for a window is then never between an answer and the launches that wait for it (ActionRun::plan_ahead).
+    uint32_t n_next = 0, n_next2 = 0;
+    bool have_next = false, have_next2 = false, queued = false;
+    RoundCtx cn{};
     while (n) {
       uint32_t n_done = 0, reason = 0;
-      const uint32_t n_next = ahead ? run.plan_ahead(e) : 0;
-      RoundCtx cn{};
-      const bool queued = chained && n_next > 0;
-      if (queued) cn = launch(n_next, run.rows_next.data(), buf ^ 1u, c.r.chain_tag, n);
+      if (ahead && !have_next) {
+        n_next = run.plan_ahead(e);
+        have_next = true;
+        queued = chained && n_next > 0;
+        if (queued) cn = launch(n_next, run.rows_next.data(), buf ^ 1u, c.r.chain_tag, n);
+      }
+      if (queued && !have_next2) { n_next2 = run.plan_ahead(e, true); have_next2 = true; }
       const double t_w0 = now_ms();
       round_collect(e, c, true, n_done, reason);
       const double t_b0 = now_ms();
@@ -433,10 +442,21 @@ static int run_action(kb_engine *e, uint32_t action, kb_decision *out, uint64_t 
       try { run.absorb(e, n, n_done, reason); } catch (...) { run.probe_abandon(e); throw; }
       const double t_b1 = now_ms();
       if (ahead && reason == KB_REASON_DONE) {
-        run.promote(e, n_next);
+        run.promote(e, n_next, have_next2);
+        const uint32_t n_prev_rows = n;
+        (void)n_prev_rows;
         n = n_next;
         if (queued) { c = cn; buf ^= 1u; }
         else if (n) c = launch(n, nullptr, buf, 0, 0);
+        if (have_next2) {   // the window planned behind the queued one is the speculated one now: behind the round that has just become current
+          n_next = n_next2;
+          have_next2 = false;
+          queued = chained && n_next > 0 && n > 0;
+          if (queued) cn = launch(n_next, run.rows_next.data(), buf ^ 1u, c.r.chain_tag, n);
+        } else {
+          have_next = false;
+          queued = false;
+        }
       } else {
         if (probe_early) run.probe_collect(e);
         else if (reason != KB_REASON_RENORM) run.probe_dead_shapes(e);
@@ -453,6 +473,7 @@ static int run_action(kb_engine *e, uint32_t action, kb_decision *out, uint64_t 
           // halves the re-planned rounds are about to rewrite from the first stream: nothing else orders the two
           if (cn.overlapped && e->stream_b) HIP_OK(hipStreamSynchronize(e->stream_b));
         }
+        have_next = have_next2 = queued = false;   // (absorb rolled every window back)
         if (n) c = launch(n, nullptr, buf, 0, 0);
         if (action == 0) e->tl_break += now_ms() - t_b0;
       }

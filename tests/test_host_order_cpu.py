@@ -195,16 +195,19 @@ def _drive(L, cfg, snap, window, ahead, renorm_prob, rng):
     rows, spec_pops = speculate()
     if not rows:
         popped += spec_pops
+    ahead_windows = []                                       # the windows speculated behind the current one, each behind its own roll-back point
+    depth = 2 if ahead == 2 else (1 if ahead else 0)         # run_action: one queued behind the round in flight, one more only planned (ahead == 2)
     while rows:
-        if ahead:
+        while len(ahead_windows) < depth and (not ahead_windows or ahead_windows[-1][0]):
             L.hh_push_checkpoint(m.h)
-            rows_next, spec_next = speculate()
+            ahead_windows.append(speculate())
         n_done, reason, out = device(rows)
         if reason == DONE:
             popped += spec_pops
             decs += out
         else:
             L.hh_rollback(m.h)
+            ahead_windows = []
             i = 0
             while True:
                 t = m.next()
@@ -229,7 +232,7 @@ def _drive(L, cfg, snap, window, ahead, renorm_prob, rng):
                     break
         if ahead and reason == DONE:
             L.hh_pop_commit(m.h)
-            rows, spec_pops = rows_next, spec_next
+            rows, spec_pops = ahead_windows.pop(0)
             if not rows:
                 popped += spec_pops
         else:
@@ -245,8 +248,9 @@ def _drive(L, cfg, snap, window, ahead, renorm_prob, rng):
 def _check(L, cfg, snap, seed):
     ref = pyref.Session(cases._tiers(cfg), snap).run(["allocate"])
     rng = np.random.RandomState(seed)
-    for window, ahead, renorm in ((1, False, 0.0), (int(rng.choice([2, 3, 5, 8])), True, 0.0), (int(rng.choice([16, 64, 256])), True, 0.0),
-                                  (int(rng.choice([4, 7, 32])), bool(rng.randint(2)), 0.15)):
+    # ahead: 0 = one window at a time, 1 = the next window speculated behind the one in flight, 2 = two windows (run_action since round 6)
+    for window, ahead, renorm in ((1, 0, 0.0), (int(rng.choice([2, 3, 5, 8])), 1, 0.0), (int(rng.choice([16, 64, 256])), 2, 0.0),
+                                  (int(rng.choice([2, 3, 5, 8])), 2, 0.0), (int(rng.choice([4, 7, 32])), int(rng.randint(3)), 0.15)):
         p, decs, popped, (js, qs, rd, ja, qa) = _drive(L, cfg, snap, window, ahead, renorm, rng)
         tag = (seed, window, ahead, renorm)
         assert decs == ref.decisions, tag
