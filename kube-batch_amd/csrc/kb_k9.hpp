@@ -447,7 +447,9 @@ __device__ __forceinline__ void k9_epilogue(const KbCommitArgs &a, const K9Layou
   if (a.host_out)
     for (uint32_t i = tid; i < n_done; i += K9_THREADS) a.host_out[KB_OUT_HDR + i] = ldec[i];
   unsigned long long hpre = 0ull;
-  if (a.host_out && tid < KB_OUT_HDR) hpre = hdr[tid];
+  // (agent-scope loads: in a launch that carries its repair workgroups two of these words — the round's stamps — were stored through by repair row 0
+  //  on another CU a moment ago; a plain load may be served an earlier round's value by this CU's caches)
+  if (a.host_out && tid < KB_OUT_HDR) hpre = __hip_atomic_load(const_cast<unsigned long long *>(&hdr[tid]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   uint32_t my_job = job_of_my_row;
   if (!job_known && tid < n_done) my_job = a.dev->t_job[desc[tid].task];
   {   // the dirty nodes' live state back to HBM

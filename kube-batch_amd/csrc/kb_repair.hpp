@@ -64,8 +64,10 @@ __device__ __forceinline__ bool kb_repair_row(const KbDev &d, const KbRound &r, 
   uint32_t *bitmap = s_late + 4;                                                               // [NP / 32]
   const uint32_t lane = tid & 63u, wave = tid >> 6;
   if (row == 0 && tid == 0) {   // the round's matrix / arg-max stamps: the candidate launches ran beside the predecessor, this is what the round waits for
+    // (stored through, like the lists: inside a commit launch the reader is the commit workgroup's epilogue on another CU, which mirrors the result
+    //  block to the host — a plain store could sit in this XCD's L2 while that epilogue reads an earlier round's value; statistics only)
     unsigned long long *st = reinterpret_cast<unsigned long long *>(r.result);
-    st[KB_OUT_STAMP0] = wall_clock64();   // [+1] follows when row 0's tag has been seen
+    __hip_atomic_store(&st[KB_OUT_STAMP0], (unsigned long long)wall_clock64(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // [+1] follows when row 0's tag has been seen
   }
   // Latency is what this costs (it sits on the dependent chain of every round): every load that does not depend on another is issued before the
   // first wait.  The predecessor's decision records are final (kernel boundary), so its nodes are fetched while another thread still looks for the tag.
@@ -87,7 +89,7 @@ __device__ __forceinline__ bool kb_repair_row(const KbDev &d, const KbRound &r, 
     }
     s_late[0] = late;
     if (late && r.chain != nullptr) __hip_atomic_store(r.chain, 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-    if (row == 0) reinterpret_cast<unsigned long long *>(r.result)[KB_OUT_STAMP0 + 1] = wall_clock64();
+    if (row == 0) __hip_atomic_store(&reinterpret_cast<unsigned long long *>(r.result)[KB_OUT_STAMP0 + 1], (unsigned long long)wall_clock64(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   __syncthreads();
   if (s_late[0]) return false;
