@@ -124,11 +124,15 @@ class Engine:
 
     def _run(self, fn):
         cap = max(int(self.snap.n_tasks), 1)
-        arr = (abi.Decision * cap)()
+        # the caller's decision buffer, kept between calls and never cleared (the engine writes the records it reports): a fresh ctypes array of T
+        # records is zero-filled — 16 MB per action at 1M tasks, twice per cycle, charged to the actions by every timing of this wrapper; a Go caller
+        # allocates once (the journal buffer of run_preempt had the same artefact)
+        buf = getattr(self, "_dec_buf", None)
+        if buf is None or buf.shape[0] < cap:
+            buf = self._dec_buf = np.empty((cap, 4), np.uint32)
         n = C.c_uint64()
-        self._ck(fn(self.h, arr, cap, C.byref(n)))
-        a = np.frombuffer(arr, dtype=np.uint32).reshape(cap, 4)[: n.value]
-        return a[:, :3].copy()
+        self._ck(fn(self.h, C.cast(buf.ctypes.data, C.POINTER(abi.Decision)), cap, C.byref(n)))
+        return buf[: n.value, :3].copy()
 
     def run_allocate(self):
         """-> uint32[n,3] (task, node, kind) in the order the reference loop places them."""
@@ -256,8 +260,9 @@ class Engine:
 
     def round_decisions(self):
         cap = max(int(self.snap.n_tasks), 1)
-        arr = (abi.Decision * cap)()
+        buf = getattr(self, "_dec_buf", None)          # (the buffer of _run: kept between calls, never cleared)
+        if buf is None or buf.shape[0] < cap:
+            buf = self._dec_buf = np.empty((cap, 4), np.uint32)
         n = C.c_uint64()
-        self._ck(self.L.kb_round_decisions(self.h, arr, cap, C.byref(n)))
-        a = np.frombuffer(arr, dtype=np.uint32).reshape(cap, 4)[: n.value]
-        return a[:, :3].copy()
+        self._ck(self.L.kb_round_decisions(self.h, C.cast(buf.ctypes.data, C.POINTER(abi.Decision)), cap, C.byref(n)))
+        return buf[: n.value, :3].copy()
